@@ -1,0 +1,123 @@
+"""oracle/oracle.py -- TEST INFRASTRUCTURE ONLY.
+
+ctypes binding for oracle/_build/libcmixoracle.so (the plain-C restatement in
+oracle/*.c).  Importers allowed: tests/, __graft_entry__.smoke(), bench.py's
+cpu_baseline leg.  The product package cmix_amd/ must never import this.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_build", "libcmixoracle.so")
+
+N_IN0, N_MIX = 2078, 47
+
+
+def build(force=False):
+    srcs = [f for f in os.listdir(HERE) if f.endswith((".c", ".h"))]
+    newest = max(os.path.getmtime(os.path.join(HERE, f)) for f in srcs)
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest:
+        subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        L.orc_logistic.restype = C.c_float
+        L.orc_logistic.argtypes = [C.c_float]
+        L.orc_stretch.restype = C.c_float
+        L.orc_stretch.argtypes = [C.c_float]
+        L.orc_mixnet_create.restype = C.c_void_p
+        L.orc_mixnet_destroy.argtypes = [C.c_void_p]
+        L.orc_mixnet_step.restype = C.c_float
+        L.orc_mixnet_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_mixnet_aux_context.restype = C.c_uint64
+        L.orc_mixnet_aux_context.argtypes = [C.c_void_p]
+        L.orc_sse_create.restype = C.c_void_p
+        L.orc_sse_destroy.argtypes = [C.c_void_p]
+        L.orc_sse_predict.restype = C.c_float
+        L.orc_sse_predict.argtypes = [C.c_void_p, C.c_float]
+        L.orc_sse_perceive.argtypes = [C.c_void_p, C.c_int]
+        _lib = L
+    return _lib
+
+
+def logistic(x):
+    return np.float32(lib().orc_logistic(C.c_float(float(x))))
+
+
+def stretch(p):
+    return np.float32(lib().orc_stretch(C.c_float(float(p))))
+
+
+def logit_table():
+    out = np.empty(100001, np.float32)
+    lib().orc_logit_table(out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def sse_tables():
+    st = np.empty(32768, np.uint16)
+    sq = np.empty(32768, np.uint16)
+    lib().orc_sse_tables(st.ctypes.data_as(C.c_void_p), sq.ctypes.data_as(C.c_void_p))
+    return st, sq
+
+
+class MixNet:
+    """Layers 0-2 + SSE. step() = one Predict()+Perceive(bit)."""
+
+    def __init__(self):
+        self.h = lib().orc_mixnet_create()
+        self._mix = np.empty(N_MIX, np.float32)
+
+    def step(self, probs, sel, bit, want_mix=False):
+        probs = np.ascontiguousarray(probs, np.float32)
+        sel = np.ascontiguousarray(sel, np.uint64)
+        assert probs.shape == (N_IN0,) and sel.shape == (N_MIX,)
+        p = lib().orc_mixnet_step(self.h, probs.ctypes.data_as(C.c_void_p),
+                                  sel.ctypes.data_as(C.c_void_p), int(bit),
+                                  self._mix.ctypes.data_as(C.c_void_p) if want_mix else None)
+        return (np.float32(p), self._mix.copy()) if want_mix else np.float32(p)
+
+    def run(self, probs, sel, bits):
+        """probs [T,2078] f32, sel [T,47] u64, bits [T] -> p [T] f32"""
+        T = len(bits)
+        out = np.empty(T, np.float32)
+        for t in range(T):
+            out[t] = self.step(probs[t], sel[t], bits[t])
+        return out
+
+    def aux_context(self):
+        return int(lib().orc_mixnet_aux_context(self.h))
+
+    def close(self):
+        if self.h:
+            lib().orc_mixnet_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+class SSE:
+    def __init__(self):
+        self.h = lib().orc_sse_create()
+
+    def predict(self, p):
+        return np.float32(lib().orc_sse_predict(self.h, C.c_float(float(p))))
+
+    def perceive(self, bit):
+        lib().orc_sse_perceive(self.h, int(bit))
+
+    def __del__(self):
+        if self.h:
+            lib().orc_sse_destroy(self.h)
+            self.h = None

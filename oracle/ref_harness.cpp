@@ -1,0 +1,211 @@
+// oracle/ref_harness.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// Thin C-ABI window onto the *unmodified* reference Predictor compiled from
+// /root/reference (see oracle/Makefile, target _ref/libcmixref.so).  It drives
+// the real Predictor::Predict()/Perceive() (reference src/predictor.cpp:361,
+// :421) and copies out the state those calls leave behind, so that the CPU
+// restatement in oracle/*.c and the HIP engine can be compared stage by stage:
+//   raw model probabilities, layer-0/1/2 stretched inputs, every mixer's
+//   selector key and output, final probability, ContextManager registers,
+//   PPMd / LSTM byte distributions.
+// No reference logic is re-implemented here; only member access is widened.
+//
+// One Predictor per process: paq8/fxcm keep state in namespace globals
+// (SURVEY.md section 5), so ref_create() may be called once.
+
+#include <algorithm>
+#include <array>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <memory>
+#include <numeric>
+#include <set>
+#include <string>
+#include <unordered_map>
+#include <valarray>
+#include <vector>
+#include <math.h>
+
+#define private public
+#define protected public
+#include "predictor.h"
+#include "mixer/lstm.h"
+#include "mixer/byte-mixer.h"
+#include "models/byte-model.h"
+#undef private
+#undef protected
+
+// The reference defines this in runner.cpp (which is not linked into the .so);
+// fxcm reads it (reference src/models/fxcmv1.cpp:412-428).
+char* dictionary_path = NULL;
+
+namespace {
+Predictor* g_p = nullptr;
+std::vector<bool> g_vocab(256, true);
+}
+
+extern "C" {
+
+// Layout constants so the Python side can size its buffers.
+int ref_num_inputs(int layer) { return g_p ? (int)g_p->layers_[layer]->Inputs().size() : -1; }
+int ref_num_mixers(int layer) { return g_p ? (int)g_p->mixers_[layer].size() : -1; }
+int ref_num_models(void) { return g_p ? (int)g_p->models_.size() : -1; }
+int ref_num_contexts(void) { return g_p ? (int)g_p->manager_.contexts_.size() : -1; }
+int ref_num_bit_contexts(void) { return g_p ? (int)g_p->manager_.bit_contexts_.size() : -1; }
+int ref_auxiliary(int i) { return g_p ? (int)g_p->auxiliary_[i] : -1; }
+
+int ref_create(const uint8_t* vocab256, const char* dict_path) {
+  if (g_p) return -1;
+  for (int i = 0; i < 256; ++i) g_vocab[i] = vocab256[i] != 0;
+  if (dict_path && dict_path[0]) dictionary_path = strdup(dict_path);
+  g_p = new Predictor(g_vocab);
+  return 0;
+}
+
+float ref_predict(void) { return g_p->Predict(); }
+void ref_perceive(int bit) { g_p->Perceive(bit); }
+void ref_pretrain(int bit) { g_p->Pretrain(bit); }
+
+// ---- state readout, valid after ref_predict() and before ref_perceive() ----
+
+// Raw (pre-stretch) outputs of every model in layer-0 order (2078 floats).
+int ref_get_model_probs(float* out) {
+  int n = 0;
+  for (auto& m : g_p->models_) {
+    // PAQ8/FXCM override Predict() with a side-effect-free accessor; all other
+    // models keep the value produced by the last Predict() in outputs_.
+    const std::valarray<float>* o = &m->outputs_;
+    if (m->NumOutputs() != o->size()) o = &m->Predict();
+    for (size_t j = 0; j < o->size(); ++j) out[n++] = (*o)[j];
+  }
+  for (auto& m : g_p->byte_models_) out[n++] = m->outputs_[0];
+  for (auto& m : g_p->byte_mixers_) out[n++] = m->outputs_[0];
+  return n;
+}
+
+int ref_get_layer_inputs(int layer, float* out) {
+  const std::valarray<float>& in = g_p->layers_[layer]->Inputs();
+  for (size_t i = 0; i < in.size(); ++i) out[i] = in[i];
+  return (int)in.size();
+}
+
+// Selector key (as the Mixer sees it: the referenced 64-bit context) and the
+// mixer's own stretch-domain output p_ for every mixer of a layer.
+int ref_get_mixers(int layer, uint64_t* ctx, float* out) {
+  auto& v = g_p->mixers_[layer];
+  for (size_t k = 0; k < v.size(); ++k) {
+    ctx[k] = v[k]->context_;
+    out[k] = v[k]->p_;
+  }
+  return (int)v.size();
+}
+
+uint64_t ref_mixer_steps(int layer, int k) { return g_p->mixers_[layer][k]->steps_; }
+uint64_t ref_mixer_rows(int layer, int k) { return g_p->mixers_[layer][k]->context_map_.size(); }
+float ref_mixer_lr(int layer, int k) { return g_p->mixers_[layer][k]->learning_rate_; }
+
+// Weight row currently selected by mixer (layer,k): weights then extra weights.
+int ref_get_mixer_row(int layer, int k, float* w, float* ew, uint64_t* row_steps) {
+  Mixer* m = g_p->mixers_[layer][k].get();
+  unsigned int key = (unsigned int)m->context_;
+  auto it = m->context_map_.find(key);
+  if (it == m->context_map_.end() || !it->second) {
+    it = m->context_map_.find(0xDEADBEEF);
+    if (it == m->context_map_.end() || !it->second) return -1;
+  }
+  ContextData* d = it->second.get();
+  for (size_t i = 0; i < d->weights.size(); ++i) w[i] = d->weights[i];
+  for (size_t i = 0; i < d->extra_weights.size(); ++i) ew[i] = d->extra_weights[i];
+  *row_steps = d->steps;
+  return (int)d->weights.size();
+}
+
+// ContextManager registers (reference src/context-manager.h:21-27).
+// regs: bit_context, long_bit_context, zero, history_pos, line_break,
+//       longest_match, auxiliary_context, wrt_context, wrt_state,
+//       recent_bytes[0..7], words[0..7]            => 25 values
+int ref_get_manager(uint64_t* regs, uint64_t* ctx, uint64_t* bit_ctx) {
+  ContextManager& m = g_p->manager_;
+  int n = 0;
+  regs[n++] = m.bit_context_;
+  regs[n++] = m.long_bit_context_;
+  regs[n++] = m.zero_context_;
+  regs[n++] = m.history_pos_;
+  regs[n++] = m.line_break_;
+  regs[n++] = m.longest_match_;
+  regs[n++] = m.auxiliary_context_;
+  regs[n++] = m.wrt_context_;
+  regs[n++] = m.wrt_state_;
+  for (int i = 0; i < 8; ++i) regs[n++] = m.recent_bytes_[i];
+  for (int i = 0; i < 8; ++i) regs[n++] = m.words_[i];
+  for (size_t i = 0; i < m.contexts_.size(); ++i) ctx[i] = m.contexts_[i]->context_;
+  for (size_t i = 0; i < m.bit_contexts_.size(); ++i) bit_ctx[i] = m.bit_contexts_[i]->context_;
+  return n;
+}
+
+uint64_t ref_context_size(int i) { return g_p->manager_.contexts_[i]->size_; }
+
+// 256-way byte distributions: which = 0 -> PPMd (byte_models_[0]),
+// 1 -> LSTM byte mixer (byte_mixers_[0]), 2 -> Bracket (models_[0]).
+int ref_get_byte_probs(int which, float* out, int* top_bot_ex) {
+  ByteModel* b = nullptr;
+  if (which == 0) b = g_p->byte_models_[0].get();
+  else if (which == 1) b = g_p->byte_mixers_[0].get();
+  else b = dynamic_cast<ByteModel*>(g_p->models_[0].get());
+  if (!b) return -1;
+  for (int i = 0; i < 256; ++i) out[i] = b->probs_[i];
+  top_bot_ex[0] = b->top_;
+  top_bot_ex[1] = b->bot_;
+  top_bot_ex[2] = b->ex;
+  return 256;
+}
+
+// LSTM internals for stage-level parity (sizes: hidden = 2*cells+1).
+int ref_lstm_dims(int* dims) {
+  Lstm* l = g_p->byte_mixers_[0]->lstm_.get();
+  dims[0] = l->input_size_;
+  dims[1] = l->output_size_;
+  dims[2] = l->num_cells_;
+  dims[3] = (int)l->layers_.size();
+  dims[4] = l->horizon_;
+  dims[5] = l->epoch_;
+  return 6;
+}
+int ref_lstm_hidden(float* out) {
+  Lstm* l = g_p->byte_mixers_[0]->lstm_.get();
+  for (size_t i = 0; i < l->hidden_.size(); ++i) out[i] = l->hidden_[i];
+  return (int)l->hidden_.size();
+}
+// gate: 0 forget, 1 input node, 2 output gate. Copies weights_[cell][*].
+int ref_lstm_gate_weights(int layer, int gate, float* out) {
+  LstmLayer* L = g_p->byte_mixers_[0]->lstm_->layers_[layer].get();
+  NeuronLayer* n = gate == 0 ? &L->forget_gate_ : gate == 1 ? &L->input_node_ : &L->output_gate_;
+  size_t k = 0;
+  for (size_t i = 0; i < n->weights_.size(); ++i)
+    for (size_t j = 0; j < n->weights_[i].size(); ++j) out[k++] = n->weights_[i][j];
+  return (int)k;
+}
+int ref_lstm_gate_row_len(int layer) {
+  LstmLayer* L = g_p->byte_mixers_[0]->lstm_->layers_[layer].get();
+  return (int)L->forget_gate_.weights_[0].size();
+}
+// Output layer weights for time slot `epoch` (V x hidden).
+int ref_lstm_output_layer(int epoch, float* out) {
+  Lstm* l = g_p->byte_mixers_[0]->lstm_.get();
+  size_t k = 0;
+  for (size_t i = 0; i < l->output_layer_[epoch].size(); ++i)
+    for (size_t j = 0; j < l->output_layer_[epoch][i].size(); ++j) out[k++] = l->output_layer_[epoch][i][j];
+  return (int)k;
+}
+
+// libm probes: the exact host functions the reference's float path resolves to,
+// exported so tests can compare the device re-implementations against the very
+// same glibc variant (ifunc-selected) that the oracle process uses.
+float ref_logistic(float x) { return Sigmoid::Logistic(x); }
+float ref_logit(float p) { return g_p->sigmoid_.Logit(p); }
+
+}  // extern "C"

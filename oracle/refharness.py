@@ -1,0 +1,145 @@
+"""oracle/refharness.py -- TEST INFRASTRUCTURE ONLY.
+
+ctypes binding for oracle/_ref/libcmixref.so: the unmodified reference
+Predictor (reference src/predictor.cpp) plus oracle/ref_harness.cpp's state
+read-out.  Used to (a) generate the golden fixtures under tests/golden/ and
+(b) pin the C restatement in oracle/*.c.  Never imported by the product
+(cmix_amd/) -- see DESIGN.md "oracle".
+
+The reference keeps paq8/fxcm state in process globals, so one Predictor per
+process: callers that need several runs use `run_in_subprocess`.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_ref", "libcmixref.so")
+
+N_IN0, N_IN1, N_IN2 = 2078, 29, 49
+N_MIX = (26, 20, 1)
+
+
+def available():
+    return os.path.exists(LIB_PATH)
+
+
+class Ref:
+    def __init__(self, vocab=None, dict_path=None):
+        self.lib = C.CDLL(LIB_PATH)
+        L = self.lib
+        L.ref_predict.restype = C.c_float
+        L.ref_logistic.restype = C.c_float
+        L.ref_logistic.argtypes = [C.c_float]
+        L.ref_logit.restype = C.c_float
+        L.ref_logit.argtypes = [C.c_float]
+        L.ref_mixer_steps.restype = C.c_uint64
+        L.ref_mixer_rows.restype = C.c_uint64
+        L.ref_mixer_lr.restype = C.c_float
+        L.ref_context_size.restype = C.c_uint64
+        if vocab is None:
+            vocab = np.ones(256, np.uint8)
+        vocab = np.ascontiguousarray(vocab, np.uint8)
+        rc = L.ref_create(vocab.ctypes.data_as(C.c_void_p),
+                          (dict_path or "").encode())
+        if rc != 0:
+            raise RuntimeError("reference Predictor already created in this process")
+        self.n_in = [L.ref_num_inputs(i) for i in range(3)]
+        self.n_mix = [L.ref_num_mixers(i) for i in range(3)]
+        self.n_ctx = L.ref_num_contexts()
+        self.n_bitctx = L.ref_num_bit_contexts()
+        self.aux = [L.ref_auxiliary(i) for i in range(3)]
+
+    def predict(self):
+        return np.float32(self.lib.ref_predict())
+
+    def perceive(self, bit):
+        self.lib.ref_perceive(int(bit))
+
+    def pretrain(self, bit):
+        self.lib.ref_pretrain(int(bit))
+
+    def model_probs(self):
+        out = np.empty(self.n_in[0], np.float32)
+        n = self.lib.ref_get_model_probs(out.ctypes.data_as(C.c_void_p))
+        assert n == self.n_in[0]
+        return out
+
+    def layer_inputs(self, layer):
+        out = np.empty(self.n_in[layer], np.float32)
+        self.lib.ref_get_layer_inputs(layer, out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def mixers(self, layer):
+        ctx = np.empty(self.n_mix[layer], np.uint64)
+        out = np.empty(self.n_mix[layer], np.float32)
+        self.lib.ref_get_mixers(layer, ctx.ctypes.data_as(C.c_void_p),
+                                out.ctypes.data_as(C.c_void_p))
+        return ctx, out
+
+    def mixer_row(self, layer, k):
+        w = np.zeros(self.n_in[layer], np.float32)
+        ew = np.zeros(max(k, 1), np.float32)
+        steps = C.c_uint64(0)
+        n = self.lib.ref_get_mixer_row(layer, k, w.ctypes.data_as(C.c_void_p),
+                                       ew.ctypes.data_as(C.c_void_p), C.byref(steps))
+        return (w, ew[:k], steps.value) if n >= 0 else None
+
+    def manager(self):
+        regs = np.empty(25, np.uint64)
+        ctx = np.empty(self.n_ctx, np.uint64)
+        bctx = np.empty(self.n_bitctx, np.uint64)
+        self.lib.ref_get_manager(regs.ctypes.data_as(C.c_void_p),
+                                 ctx.ctypes.data_as(C.c_void_p),
+                                 bctx.ctypes.data_as(C.c_void_p))
+        return regs, ctx, bctx
+
+    def context_sizes(self):
+        return np.array([self.lib.ref_context_size(i) for i in range(self.n_ctx)], np.uint64)
+
+    def byte_probs(self, which):
+        out = np.empty(256, np.float32)
+        tbe = (C.c_int * 3)()
+        self.lib.ref_get_byte_probs(which, out.ctypes.data_as(C.c_void_p), tbe)
+        return out, tuple(tbe)
+
+    def lstm_dims(self):
+        d = (C.c_int * 6)()
+        self.lib.ref_lstm_dims(d)
+        return dict(input_size=d[0], output_size=d[1], cells=d[2], layers=d[3],
+                    horizon=d[4], epoch=d[5])
+
+    def lstm_hidden(self):
+        d = self.lstm_dims()
+        out = np.empty(d["cells"] * d["layers"] + 1, np.float32)
+        self.lib.ref_lstm_hidden(out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def lstm_gate_weights(self, layer, gate):
+        d = self.lstm_dims()
+        n = self.lib.ref_lstm_gate_row_len(layer)
+        out = np.empty((d["cells"], n), np.float32)
+        self.lib.ref_lstm_gate_weights(layer, gate, out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def lstm_output_layer(self, epoch):
+        d = self.lstm_dims()
+        out = np.empty((d["output_size"], d["cells"] * d["layers"] + 1), np.float32)
+        self.lib.ref_lstm_output_layer(epoch, out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def logistic(self, x):
+        return np.float32(self.lib.ref_logistic(C.c_float(float(x))))
+
+    def logit(self, p):
+        return np.float32(self.lib.ref_logit(C.c_float(float(p))))
+
+
+def vocab_of(data: bytes):
+    """Reference src/runner.cpp:88-94,196-202: all 256 below 10000 bytes."""
+    v = np.zeros(256, np.uint8)
+    if len(data) < 10000:
+        v[:] = 1
+    else:
+        v[np.unique(np.frombuffer(data, np.uint8))] = 1
+    return v
