@@ -1,0 +1,347 @@
+// cmx_api.hip -- host side of the C ABI declared in include/cmix_amd.h.
+//
+// Owns device memory, builds the read-only tables with the HOST libm (so they
+// are bit-identical to what the reference process computes at start-up:
+// logit LUT ref src/mixer/sigmoid.cpp:5-10, SSE stretch/squash tables ref
+// src/mixer/sse.cpp:80-135, mixer decay schedule ref src/mixer/mixer.cpp:58),
+// and launches the persistent kernels.  No CPU implementation of the per-bit
+// path exists in this library: every entry point needs a gfx950 device.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/cmix_amd.h"
+#include "mixnet_state.h"
+
+extern "C" __global__ void cmx_mixnet_kernel(MixState*, const float*, const uint32_t*,
+                                             const uint8_t*, const float*, int, float*, float*, int);
+extern "C" __global__ void cmx_sse_init_kernel(MixState*);
+extern "C" __global__ void cmx_probe_libm_kernel(int, const float*, float*, size_t);
+
+namespace {
+
+thread_local std::string g_err;
+void set_err(const std::string& s) { g_err = s; }
+
+#define HIP_OK(call)                                                                  \
+  do {                                                                                \
+    hipError_t e_ = (call);                                                           \
+    if (e_ != hipSuccess) {                                                           \
+      set_err(std::string(#call) + ": " + hipGetErrorString(e_));                     \
+      return fail_value;                                                              \
+    }                                                                                 \
+  } while (0)
+
+// learning rates in construction order, ref src/predictor.cpp:199-356
+const float kLr[CMX_MIXERS] = {
+    0.005f, 0.0005f, 0.005f, 0.0005f, 0.005f, 0.002f, 0.002f, 0.005f, 0.00005f, 0.0007f, 0.0005f,
+    0.002f, 0.0005f, 0.001f, 0.001f, 0.001f, 0.005f, 0.001f, 0.001f, 0.005f, 0.001f, 0.001f,
+    0.005f, 0.005f, 0.005f, 0.003f,
+    0.005f, 0.0005f, 0.005f, 0.0005f, 0.00001f, 0.005f, 0.005f, 0.005f, 0.0005f, 0.002f, 0.001f,
+    0.001f, 0.001f, 0.001f, 0.001f, 0.001f, 0.001f, 0.001f, 0.001f, 0.001f,
+    0.0003f};
+
+#define CMX_MIXNET_THREADS 512
+constexpr size_t kLdsBytes = (size_t)(17 * CMX_MIX0 * 68 + 2112 + 32 + 32 + 64 + 48 + 48 + 48) * 4;
+
+// ---- host-side table construction (host libm on purpose) -------------------
+void build_logit(std::vector<float>& t) {  // ref sigmoid.cpp:5-10,23-25
+  t.resize(100001);
+  for (int i = 0; i < 100001; ++i) {
+    float p = (i + 0.5f) / 100001;
+    t[i] = logf(p / (1 - p));
+  }
+}
+
+void build_sse_tables(std::vector<uint16_t>& t_st, std::vector<uint16_t>& t_sq) {
+  // ref sse.cpp:80-135. Note sse.cpp defines its own log2/exp2 via log/exp.
+  const double LOG2E = 1.44269504088896340736;
+  auto l2 = [&](double a) { return LOG2E * log(a); };
+  auto e2 = [&](double a) { return exp(a / LOG2E); };
+  auto st = [&](double p) { return l2((1 - p) / p); };
+  auto sq = [&](double p) { return 1.0 / (1.0 + e2(p)); };
+  const int SCALE = 32768, hSCALE = 16384;
+  const double st_coef = (hSCALE - 1) / l2(SCALE - 1);
+  const double sq_coef = 1.0 / st_coef;
+  t_st.assign(SCALE, 0);
+  t_sq.assign(SCALE, 0);
+  for (int i = 1; i < SCALE; i++)
+    t_sq[i] = (uint16_t)(unsigned)(sq((double)(i - hSCALE) * sq_coef) * SCALE);
+  unsigned x = 0;
+  for (unsigned i = 1; i < (unsigned)SCALE; i++) {
+    unsigned s = (unsigned)(st((double)i / SCALE) * st_coef + hSCALE);
+    t_st[i] = (uint16_t)s;
+    if ((uint16_t)s != t_st[x]) {
+      unsigned y = i - 1;
+      t_sq[t_st[x]] = (uint16_t)((x + y + 1) / 2);
+      x = i;
+    }
+  }
+}
+
+}  // namespace
+
+struct cmx_mixnet {
+  int device = 0;
+  MixState* d_state = nullptr;
+  MixState h_state;  // host copy of the pointer block
+  std::vector<void*> allocs;
+  float* d_decay = nullptr;
+  size_t decay_cap = 0;
+  float* h_decay = nullptr;  // pinned
+  uint64_t bits_done = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  // bit-synchronous staging
+  float* d_sync_probs = nullptr;
+  uint32_t* d_sync_sel = nullptr;
+  uint8_t* d_sync_bit = nullptr;
+  float* d_sync_p = nullptr;
+  float h_sync_decay = 0;
+  bool predicted = false;
+};
+
+extern "C" {
+
+const char* cmx_last_error(void) { return g_err.c_str(); }
+const char* cmx_version(void) { return "cmix_amd 0.1 (gfx950; cmix v21 predictor path)"; }
+
+int cmx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// --------------------------------------------------------------------------
+// whole-predictor surface: assembled from the device stages as they land.
+// Until the paq8 / fxcm / ppmd stages exist on the device a full Predictor
+// cannot be formed, and there is deliberately no host fallback.
+// --------------------------------------------------------------------------
+struct cmx_engine { int unused; };
+cmx_t* cmx_create(const uint8_t*, const char*, int) {
+  set_err("cmx_create: device stages paq8, fxcm and ppmd are not implemented yet; "
+          "use the stage-level entry points (cmx_mixnet_*, ...). No CPU fallback exists.");
+  return nullptr;
+}
+float cmx_predict(cmx_t*) { set_err("cmx_predict: no engine"); return -1.0f; }
+int cmx_perceive(cmx_t*, int) { set_err("cmx_perceive: no engine"); return 1; }
+int cmx_pretrain(cmx_t*, int) { set_err("cmx_pretrain: no engine"); return 1; }
+int cmx_stage_input(cmx_t*, const uint8_t*, size_t) { set_err("cmx_stage_input: no engine"); return 1; }
+void cmx_destroy(cmx_t*) {}
+
+// --------------------------------------------------------------------------
+// mixing-network stage
+// --------------------------------------------------------------------------
+void cmx_mixnet_destroy(cmx_mixnet_t* h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  hipDeviceSynchronize();
+  for (void* p : h->allocs) hipFree(p);
+  if (h->h_decay) hipHostFree(h->h_decay);
+  if (h->ev0) hipEventDestroy(h->ev0);
+  if (h->ev1) hipEventDestroy(h->ev1);
+  delete h;
+}
+
+cmx_mixnet_t* cmx_mixnet_create(int device) {
+  cmx_mixnet_t* const fail_value = nullptr;
+  int n = cmx_device_count();
+  if (n <= 0) { set_err("cmx_mixnet_create: no HIP device visible (a gfx950 GPU is required)"); return nullptr; }
+  if (device < 0 || device >= n) { set_err("cmx_mixnet_create: bad device index"); return nullptr; }
+  HIP_OK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_OK(hipGetDeviceProperties(&prop, device));
+  if (!strstr(prop.gcnArchName, "gfx950")) {
+    set_err(std::string("cmx_mixnet_create: device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    return nullptr;
+  }
+  cmx_mixnet_t* h = new cmx_mixnet();
+  h->device = device;
+  MixState& S = h->h_state;
+  memset(&S, 0, sizeof S);
+  auto dalloc = [&](size_t bytes, bool zero) -> void* {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    h->allocs.push_back(p);
+    if (zero) hipMemset(p, 0, bytes);
+    return p;
+  };
+#define ALLOC(field, type, count, zero)                                       \
+  do {                                                                        \
+    S.field = (type*)dalloc((size_t)(count) * sizeof(type), zero);            \
+    if (!S.field) { set_err("hipMalloc failed for " #field); cmx_mixnet_destroy(h); return nullptr; } \
+  } while (0)
+  std::vector<float> lut;
+  std::vector<uint16_t> t_st, t_sq;
+  build_logit(lut);
+  build_sse_tables(t_st, t_sq);
+  float* d_lut = (float*)dalloc(lut.size() * 4, false);
+  uint16_t* d_st = (uint16_t*)dalloc(32768 * 2, false);
+  uint16_t* d_sq = (uint16_t*)dalloc(32768 * 2, false);
+  if (!d_lut || !d_st || !d_sq) { set_err("hipMalloc failed for tables"); cmx_mixnet_destroy(h); return nullptr; }
+  hipMemcpy(d_lut, lut.data(), lut.size() * 4, hipMemcpyHostToDevice);
+  hipMemcpy(d_st, t_st.data(), 32768 * 2, hipMemcpyHostToDevice);
+  hipMemcpy(d_sq, t_sq.data(), 32768 * 2, hipMemcpyHostToDevice);
+  S.logit_lut = d_lut;
+  S.t_st = d_st;
+  S.t_sq = d_sq;
+  S.stretch_min = lut[0];        // Logit(0), ref mixer-input.cpp:5
+  S.stretch_max = lut[100000];   // Logit(1)
+  memcpy(S.lr, kLr, sizeof kLr);
+  ALLOC(rows0, float, (size_t)CMX_MIX0 * CMX_ROWS_PER_MIXER * CMX_ROW0_STRIDE, true);
+  ALLOC(rows1, float, (size_t)CMX_MIX1 * CMX_ROWS_PER_MIXER * CMX_ROW1_STRIDE, true);
+  ALLOC(rows2, float, (size_t)CMX_ROWS_PER_MIXER * CMX_ROW2_STRIDE, true);
+  ALLOC(row_steps, uint64_t, (size_t)CMX_MIXERS * CMX_ROWS_PER_MIXER, true);
+  ALLOC(map_keys, uint32_t, (size_t)CMX_MIXERS * CMX_MAP_SLOTS, true);
+  ALLOC(map_vals, uint32_t, (size_t)CMX_MIXERS * CMX_MAP_SLOTS, true);
+  ALLOC(s6, uint16_t, (size_t)CMX_SM6_VOL * 8, false);
+  ALLOC(s7, uint16_t, (size_t)CMX_SM7_VOL * 8, false);
+  ALLOC(x1, int, CMX_MIX1_VOL, false);
+  ALLOC(x2, int, CMX_MIX2_VOL, false);
+#undef ALLOC
+  for (int i = 0; i <= CMX_MIXERS; ++i) S.max_steps[i] = 1;  // ref mixer.cpp:13
+  S.steps = 0;
+  S.sse_j = 1;  // ref sse.cpp:226
+  S.sse_pc = 0;
+  S.sse_ffl = 0;
+  for (int i = 0; i <= CMX_MIXERS; ++i) S.fwd_p[i] = 0.5f;
+  h->d_state = (MixState*)dalloc(sizeof(MixState), false);
+  if (!h->d_state) { set_err("hipMalloc failed for state"); cmx_mixnet_destroy(h); return nullptr; }
+  hipMemcpy(h->d_state, &S, sizeof S, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(cmx_sse_init_kernel, dim3(2048), dim3(256), 0, 0, h->d_state);
+  h->d_sync_probs = (float*)dalloc(CMX_IN0 * 4, true);
+  h->d_sync_sel = (uint32_t*)dalloc(CMX_MIXERS * 4, true);
+  h->d_sync_bit = (uint8_t*)dalloc(16, true);
+  h->d_sync_p = (float*)dalloc(16, true);
+  if (hipFuncSetAttribute((const void*)cmx_mixnet_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)kLdsBytes) != hipSuccess) {
+    set_err("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    cmx_mixnet_destroy(h);
+    return nullptr;
+  }
+  hipEventCreate(&h->ev0);
+  hipEventCreate(&h->ev1);
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) { set_err(std::string("init: ") + hipGetErrorString(e)); cmx_mixnet_destroy(h); return nullptr; }
+  return h;
+}
+
+// Mixer::Perceive's global schedule, ref mixer.cpp:58: a pure function of the
+// mixer's step counter, evaluated with the host's double pow().
+static inline float decay_of(uint64_t steps) {
+  return (float)(0.9 / pow(0.0000001 * steps + 0.8, 0.8));
+}
+
+static int ensure_decay(cmx_mixnet_t* h, size_t nbits) {
+  const int fail_value = 1;
+  if (nbits <= h->decay_cap) return 0;
+  size_t cap = nbits < 4096 ? 4096 : nbits;
+  if (h->h_decay) hipHostFree(h->h_decay);
+  h->h_decay = nullptr;
+  HIP_OK(hipHostMalloc((void**)&h->h_decay, cap * 4, hipHostMallocDefault));
+  void* p = nullptr;
+  HIP_OK(hipMalloc(&p, cap * 4));
+  h->allocs.push_back(p);
+  h->d_decay = (float*)p;
+  h->decay_cap = cap;
+  return 0;
+}
+
+int cmx_mixnet_run(cmx_mixnet_t* h, const float* d_probs, const uint32_t* d_sel,
+                   const uint8_t* d_bits, size_t nbits, float* d_p_out, float* d_mix_out,
+                   void* stream) {
+  const int fail_value = 1;
+  if (!h) { set_err("cmx_mixnet_run: null handle"); return 1; }
+  if (h->predicted) { set_err("cmx_mixnet_run: a bit-synchronous predict() is pending"); return 1; }
+  if (nbits == 0) return 0;
+  if (nbits > 0x7fffffff) { set_err("cmx_mixnet_run: chunk too large"); return 1; }
+  HIP_OK(hipSetDevice(h->device));
+  hipStream_t st = (hipStream_t)stream;
+  // the pinned staging buffer is reused: wait for the previous chunk's copy
+  HIP_OK(hipStreamSynchronize(st));
+  if (ensure_decay(h, nbits)) return 1;
+  for (size_t t = 0; t < nbits; ++t) h->h_decay[t] = decay_of(h->bits_done + t);
+  HIP_OK(hipMemcpyAsync(h->d_decay, h->h_decay, nbits * 4, hipMemcpyHostToDevice, st));
+  HIP_OK(hipEventRecord(h->ev0, st));
+  hipLaunchKernelGGL(cmx_mixnet_kernel, dim3(1), dim3(CMX_MIXNET_THREADS), kLdsBytes, st, h->d_state, d_probs,
+                     d_sel, d_bits, h->d_decay, (int)nbits, d_p_out, d_mix_out, 3);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipEventRecord(h->ev1, st));
+  h->timed = true;
+  h->bits_done += nbits;
+  return 0;
+}
+
+float cmx_mixnet_predict(cmx_mixnet_t* h, const float* probs, const uint32_t* sel) {
+  const float fail_value = -1.0f;
+  if (!h) { set_err("cmx_mixnet_predict: null handle"); return -1.0f; }
+  if (h->predicted) { set_err("cmx_mixnet_predict: called twice without perceive()"); return -1.0f; }
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipMemcpy(h->d_sync_probs, probs, CMX_IN0 * 4, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(h->d_sync_sel, sel, CMX_MIXERS * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(cmx_mixnet_kernel, dim3(1), dim3(CMX_MIXNET_THREADS), kLdsBytes, 0, h->d_state,
+                     h->d_sync_probs, h->d_sync_sel, h->d_sync_bit, h->d_decay, 1, h->d_sync_p,
+                     (float*)nullptr, 1);
+  HIP_OK(hipGetLastError());
+  float p = -1.0f;
+  HIP_OK(hipMemcpy(&p, h->d_sync_p, 4, hipMemcpyDeviceToHost));
+  h->predicted = true;
+  return p;
+}
+
+int cmx_mixnet_perceive(cmx_mixnet_t* h, int bit) {
+  const int fail_value = 1;
+  if (!h) { set_err("cmx_mixnet_perceive: null handle"); return 1; }
+  if (!h->predicted) { set_err("cmx_mixnet_perceive: no pending predict()"); return 1; }
+  HIP_OK(hipSetDevice(h->device));
+  if (ensure_decay(h, 1)) return 1;
+  uint8_t b = bit ? 1 : 0;
+  float d = decay_of(h->bits_done);
+  HIP_OK(hipMemcpy(h->d_sync_bit, &b, 1, hipMemcpyHostToDevice));
+  HIP_OK(hipMemcpy(h->d_decay, &d, 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(cmx_mixnet_kernel, dim3(1), dim3(CMX_MIXNET_THREADS), kLdsBytes, 0, h->d_state,
+                     h->d_sync_probs, h->d_sync_sel, h->d_sync_bit, h->d_decay, 1, h->d_sync_p,
+                     (float*)nullptr, 2);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipDeviceSynchronize());
+  h->predicted = false;
+  h->bits_done += 1;
+  return 0;
+}
+
+int cmx_mixnet_bits_done(const cmx_mixnet_t* h, uint64_t* out) {
+  if (!h || !out) { set_err("cmx_mixnet_bits_done: null argument"); return 1; }
+  *out = h->bits_done;
+  return 0;
+}
+
+int cmx_mixnet_last_kernel_ms(cmx_mixnet_t* h, float* ms) {
+  const int fail_value = 1;
+  if (!h || !ms) { set_err("cmx_mixnet_last_kernel_ms: null argument"); return 1; }
+  if (!h->timed) { set_err("cmx_mixnet_last_kernel_ms: no chunk has been run"); return 1; }
+  HIP_OK(hipEventSynchronize(h->ev1));
+  HIP_OK(hipEventElapsedTime(ms, h->ev0, h->ev1));
+  return 0;
+}
+
+int cmx_probe_libm(int device, int which, const float* x, float* y, size_t n) {
+  const int fail_value = 1;
+  if (cmx_device_count() <= 0) { set_err("cmx_probe_libm: no HIP device"); return 1; }
+  HIP_OK(hipSetDevice(device));
+  float *dx = nullptr, *dy = nullptr;
+  HIP_OK(hipMalloc((void**)&dx, n * 4));
+  HIP_OK(hipMalloc((void**)&dy, n * 4));
+  HIP_OK(hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(cmx_probe_libm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, which,
+                     dx, dy, n);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipMemcpy(y, dy, n * 4, hipMemcpyDeviceToHost));
+  hipFree(dx);
+  hipFree(dy);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,69 @@
+// mixnet_state.h -- HBM-resident state of one stream's final mixing network.
+// Shared between the kernels (mixnet_kernels.hip) and the host C-ABI layer.
+#ifndef CMX_MIXNET_STATE_H
+#define CMX_MIXNET_STATE_H
+#include <stdint.h>
+
+#define CMX_IN0 2078
+#define CMX_IN1 29
+#define CMX_IN2 49
+#define CMX_MIX0 26
+#define CMX_MIX1 20
+#define CMX_MIXERS 47
+#define CMX_AUX 12
+
+// Mixer::GetContextData caps a mixer at 10000 rows + 1 shared overflow row
+// (reference src/mixer/mixer.cpp:16-36).
+#define CMX_ROW_LIMIT 10000u
+#define CMX_ROWS_PER_MIXER 10001u
+#define CMX_MAP_SLOTS 32768u  // open-addressing table per mixer (load <= 0.31)
+
+// Row layouts (floats). Layer 0: 2078 weights, pad to 2080, then 26 extra
+// weights (only the first k used by mixer k), padded to 33 * 64.
+#define CMX_ROW0_STRIDE 2112
+#define CMX_ROW0_EXTRA 2080
+// Layer 1: 29 weights, pad to 32, then 20 extra weights -> 64 floats (256 B).
+#define CMX_ROW1_STRIDE 64
+#define CMX_ROW1_EXTRA 32
+#define CMX_ROW2_STRIDE 64
+
+// SSE table volumes (reference src/mixer/sse.cpp:197-200); entries padded from
+// 7 to 8 u16 so that an entry never straddles a 16-byte boundary.
+#define CMX_SM6_VOL (3 * 128 * 256 * 256)
+#define CMX_MIX1_VOL (4 * 256 * 8 * 79)
+#define CMX_SM7_VOL (3 * 32 * 256 * 255)
+#define CMX_MIX2_VOL (3 * 2 * 256 * 256)
+
+struct MixState {
+  // read-only tables, built on the host with the host libm and uploaded
+  const float* logit_lut;   // [100001]  Sigmoid::Sigmoid, sigmoid.cpp:5-10
+  const uint16_t* t_st;     // [32768]   Init_ST_SQ, sse.cpp:112-135
+  const uint16_t* t_sq;     // [32768]
+  float stretch_min, stretch_max;  // Logit(0), Logit(1): mixer-input.cpp:3-5
+  float lr[CMX_MIXERS];     // learning rates in construction order, predictor.cpp:199-356
+
+  // mixer weight rows
+  float* rows0;             // [26][10001][2112]
+  float* rows1;             // [20][10001][64]
+  float* rows2;             // [1][64]
+  uint64_t* row_steps;      // [47][10001]   ContextData::steps
+  uint32_t* map_keys;       // [47][32768]
+  uint32_t* map_vals;       // [47][32768]   row index + 1, 0 = empty
+  uint32_t n_rows[CMX_MIXERS + 1];   // context_map_.size()
+  uint64_t max_steps[CMX_MIXERS + 1];  // Mixer::max_steps_ (starts at 1)
+  uint64_t steps;           // Mixer::steps_ (same value in all 47 mixers)
+
+  // SSE
+  uint16_t* s6;             // [SM6_VOL][8]
+  uint16_t* s7;             // [SM7_VOL][8]
+  int* x1;                  // [MIX1_VOL]
+  int* x2;                  // [MIX2_VOL]
+  uint32_t sse_j, sse_pc, sse_ffl;
+
+  // forward results kept for a separate Perceive launch (bit-synchronous mode)
+  float fwd_p[CMX_MIXERS + 1];
+  float fwd_out0[32];
+  float fwd_in2[64];
+};
+
+#endif

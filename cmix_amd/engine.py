@@ -1,0 +1,139 @@
+"""Host-side Python binding of the C ABI in include/cmix_amd.h (ctypes).
+
+This mirrors, for test and bench drivers, what the C++ shim in INTEGRATION.md
+does for the reference's `class Predictor` (reference src/predictor.h:17-22):
+it only forwards to libcmixamd.so.  There is no Python or CPU implementation of
+the per-bit path behind it -- if the HIP library is missing or no gfx950 device
+is visible, construction raises.
+
+torch is used purely as the device-memory allocator for chunk operands
+(`tensor.data_ptr()` is what crosses the ABI).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libcmixamd.so")
+
+N_INPUTS, N_MIXERS = 2078, 47
+
+
+class CmxError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CmxError(f"{LIB_PATH} is missing: run `python -m cmix_amd.build` "
+                           "(there is no non-HIP fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.cmx_last_error.restype = C.c_char_p
+        L.cmx_version.restype = C.c_char_p
+        L.cmx_create.restype = C.c_void_p
+        L.cmx_create.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.cmx_predict.restype = C.c_float
+        L.cmx_predict.argtypes = [C.c_void_p]
+        L.cmx_mixnet_create.restype = C.c_void_p
+        L.cmx_mixnet_create.argtypes = [C.c_int]
+        L.cmx_mixnet_destroy.argtypes = [C.c_void_p]
+        L.cmx_mixnet_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cmx_mixnet_predict.restype = C.c_float
+        L.cmx_mixnet_predict.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cmx_mixnet_perceive.argtypes = [C.c_void_p, C.c_int]
+        L.cmx_mixnet_bits_done.argtypes = [C.c_void_p, C.c_void_p]
+        L.cmx_mixnet_last_kernel_ms.argtypes = [C.c_void_p, C.c_void_p]
+        L.cmx_probe_libm.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().cmx_last_error().decode()
+
+
+def device_count():
+    return lib().cmx_device_count()
+
+
+def probe_libm(which, x, device=0):
+    """which: 0 expf, 1 tanhf, 2 logistic; x: float32 ndarray -> float32 ndarray (device-evaluated)."""
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.empty_like(x)
+    if lib().cmx_probe_libm(device, which, x.ctypes.data, y.ctypes.data, x.size):
+        raise CmxError(last_error())
+    return y
+
+
+class MixNet:
+    """Final mixing network stage (layers 0-2 + SSE) of one stream on one GPU."""
+
+    def __init__(self, device=0):
+        self.h = lib().cmx_mixnet_create(device)
+        if not self.h:
+            raise CmxError(last_error())
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().cmx_mixnet_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, probs, sel, bits, p_out=None, mix_out=None, stream=None):
+        """Chunk mode on HBM-resident torch tensors.
+        probs [T,2078] f32, sel [T,47] int32 (u32 keys), bits [T] u8 -> p_out [T] f32."""
+        import torch
+        T = int(bits.numel())
+        assert probs.is_cuda and sel.is_cuda and bits.is_cuda
+        assert probs.dtype == torch.float32 and probs.is_contiguous() and probs.numel() == T * N_INPUTS
+        assert sel.dtype == torch.int32 and sel.is_contiguous() and sel.numel() == T * N_MIXERS
+        assert bits.dtype == torch.uint8 and bits.is_contiguous()
+        if p_out is None:
+            p_out = torch.empty(T, dtype=torch.float32, device=probs.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(probs.device).cuda_stream
+        rc = lib().cmx_mixnet_run(self.h, probs.data_ptr(), sel.data_ptr(), bits.data_ptr(), T,
+                                  p_out.data_ptr(), mix_out.data_ptr() if mix_out is not None else None,
+                                  C.c_void_p(stream))
+        if rc:
+            raise CmxError(last_error())
+        return p_out
+
+    def predict(self, probs, sel):
+        """Bit-synchronous Predict(): host arrays in, float out."""
+        probs = np.ascontiguousarray(probs, np.float32)
+        sel = np.ascontiguousarray(sel, np.uint32)
+        assert probs.size == N_INPUTS and sel.size == N_MIXERS
+        p = lib().cmx_mixnet_predict(self.h, probs.ctypes.data, sel.ctypes.data)
+        if p < 0:
+            raise CmxError(last_error())
+        return np.float32(p)
+
+    def perceive(self, bit):
+        if lib().cmx_mixnet_perceive(self.h, int(bit)):
+            raise CmxError(last_error())
+
+    def bits_done(self):
+        v = C.c_uint64(0)
+        if lib().cmx_mixnet_bits_done(self.h, C.byref(v)):
+            raise CmxError(last_error())
+        return v.value
+
+    def last_kernel_ms(self):
+        v = C.c_float(0)
+        if lib().cmx_mixnet_last_kernel_ms(self.h, C.byref(v)):
+            raise CmxError(last_error())
+        return v.value

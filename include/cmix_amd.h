@@ -1,0 +1,114 @@
+/* cmix_amd.h -- C ABI of libcmixamd.so, the MI355X (gfx950) per-bit prediction
+ * engine for cmix v21.
+ *
+ * Drop-in boundary: the reference's `class Predictor`
+ *   Predictor(const std::vector<bool>& vocab); float Predict();
+ *   void Perceive(int bit); void Pretrain(int bit);
+ * (reference src/predictor.h:17-22), whose only callers are Encoder::Encode
+ * (src/coder/encoder.cpp:14-30), Decoder::Decode (src/coder/decoder.cpp:20-39),
+ * preprocessor::Pretrain (src/preprocess/preprocessor.cpp:37-69) and the two
+ * construction sites src/runner.cpp:205,246.  INTEGRATION.md shows the C++ shim
+ * a cmix maintainer adds to bind these entry points.
+ *
+ * Two granularities are exported:
+ *   1. the whole-predictor surface (cmx_create .. cmx_destroy), one handle per
+ *      input stream, any number of handles per process (one per GPU);
+ *   2. stage-level entry points (cmx_mixnet_*, cmx_lstm_*, ...) -- the device
+ *      pipeline stages the predictor is assembled from.  A stage consumes and
+ *      produces plain arrays, either one bit at a time (bit-synchronous: what a
+ *      decoder needs, and what a hybrid build uses while some model families
+ *      still run on the host) or a whole chunk of already-known bits at once
+ *      (compression look-ahead: every input bit is known in advance, SURVEY.md
+ *      7.1) with all operands resident in HBM.
+ *
+ * All functions return 0 / non-NULL on success; on failure they return
+ * nonzero / NULL and cmx_last_error() describes why.  Nothing here falls back
+ * to a CPU implementation: without a gfx950 device every create call fails.
+ *
+ * Plain C: no C++ or torch types cross this boundary.
+ */
+#ifndef CMIX_AMD_H
+#define CMIX_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CMX_N_INPUTS 2078 /* layer-0 width, SURVEY.md Appendix A.1 */
+#define CMX_N_MIXERS 47   /* 26 + 20 + 1, predictor.cpp:193-356 */
+#define CMX_N_MIX0 26
+#define CMX_N_MIX1 20
+#define CMX_AUX_MIXER 12 /* layer-0 mixer keyed by auxiliary_context_ */
+
+const char* cmx_last_error(void);
+/* Library / device identification: fills name (<=256 bytes) and returns the
+ * number of visible HIP devices (0 if none; never fails). */
+int cmx_device_count(void);
+const char* cmx_version(void);
+
+/* ------------------------------------------------------------------------
+ * 1. Whole-predictor surface (replaces class Predictor, predictor.h:17-22)
+ * ------------------------------------------------------------------------ */
+typedef struct cmx_engine cmx_t;
+/* vocab[i] != 0 iff byte value i occurs in the (preprocessed) input
+ * (runner.cpp:196-202). dict_path replaces the global `dictionary_path`
+ * (runner.cpp:17) read by fxcm; may be NULL. */
+cmx_t* cmx_create(const uint8_t vocab[256], const char* dict_path, int device);
+float cmx_predict(cmx_t*);             /* Predictor::Predict,  predictor.cpp:361 */
+int cmx_perceive(cmx_t*, int bit);     /* Predictor::Perceive, predictor.cpp:421 */
+int cmx_pretrain(cmx_t*, int bit);     /* Predictor::Pretrain, predictor.cpp:471 */
+/* Optional look-ahead for compression: the bytes the coder is about to code,
+ * so the device pipeline can run ahead of the host. */
+int cmx_stage_input(cmx_t*, const uint8_t* bytes, size_t n);
+void cmx_destroy(cmx_t*);
+
+/* ------------------------------------------------------------------------
+ * 2a. Stage: final mixing network = MixerInput stretch -> 26+20+1 gated
+ *     logistic mixers -> squash -> SSE  (predictor.cpp:388-418,432-437;
+ *     src/mixer/{mixer,mixer-input,sigmoid,sse}.cpp)
+ * ------------------------------------------------------------------------ */
+typedef struct cmx_mixnet cmx_mixnet_t;
+cmx_mixnet_t* cmx_mixnet_create(int device);
+void cmx_mixnet_destroy(cmx_mixnet_t*);
+
+/* Chunk mode. All pointers are DEVICE pointers (HBM-resident operands):
+ *   d_probs [nbits][2078] f32  raw model outputs (Model::Predict values)
+ *   d_sel   [nbits][47]   u32  each mixer's selector key (its 64-bit context
+ *                              truncated to 32 bits exactly as the reference's
+ *                              unordered_map<unsigned int,...> key does,
+ *                              mixer.h:33); entry 12 is ignored (derived on
+ *                              device from the inputs, predictor.cpp:388-393)
+ *   d_bits  [nbits]       u8   the coded bits
+ *   d_p_out [nbits]       f32  OUT: value Predictor::Predict() returns
+ *   d_mix_out [nbits][47] f32  OUT (may be NULL): every Mixer::p_
+ * Processes the bits strictly in order inside one persistent kernel launch on
+ * `stream` (a hipStream_t passed as void*, NULL = default stream) and returns
+ * without synchronising. */
+int cmx_mixnet_run(cmx_mixnet_t*, const float* d_probs, const uint32_t* d_sel,
+                   const uint8_t* d_bits, size_t nbits, float* d_p_out, float* d_mix_out,
+                   void* stream);
+
+/* Bit-synchronous mode. HOST pointers; synchronous. predict() may be followed
+ * only by perceive() (same protocol as the reference). */
+float cmx_mixnet_predict(cmx_mixnet_t*, const float* probs2078, const uint32_t* sel47);
+int cmx_mixnet_perceive(cmx_mixnet_t*, int bit);
+
+/* Introspection used by the parity tests. */
+int cmx_mixnet_bits_done(const cmx_mixnet_t*, uint64_t* out);
+/* Elapsed device time (ms, HIP events on the launch stream) of the last
+ * cmx_mixnet_run kernel; synchronises with it. */
+int cmx_mixnet_last_kernel_ms(cmx_mixnet_t*, float* ms);
+
+/* ------------------------------------------------------------------------
+ * Device libm probes (parity tests): evaluate the engine's expf / tanhf /
+ * logistic on the device for n host floats. which: 0 expf, 1 tanhf, 2 logistic
+ * ------------------------------------------------------------------------ */
+int cmx_probe_libm(int device, int which, const float* x, float* y, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CMIX_AMD_H */
