@@ -33,6 +33,12 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise CmxError(f"{LIB_PATH} is missing: run `python -m cmix_amd.build` "
                            "(there is no non-HIP fallback)")
+        # Load the HIP runtime that PyTorch-ROCm bundles first, so that libcmixamd.so binds to the
+        # same libamdhip64 instance (two HIP runtimes in one process cannot both own the GPU).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.cmx_last_error.restype = C.c_char_p
         L.cmx_version.restype = C.c_char_p
