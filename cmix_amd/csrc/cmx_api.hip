@@ -10,6 +10,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <stddef.h>
 #include <string>
 #include <vector>
 
@@ -102,6 +103,7 @@ struct cmx_mixnet {
   float* d_sync_p = nullptr;
   float h_sync_decay = 0;
   bool predicted = false;
+  int profile = 0;
 };
 
 extern "C" {
@@ -267,7 +269,7 @@ int cmx_mixnet_run(cmx_mixnet_t* h, const float* d_probs, const uint32_t* d_sel,
   HIP_OK(hipMemcpyAsync(h->d_decay, h->h_decay, nbits * 4, hipMemcpyHostToDevice, st));
   HIP_OK(hipEventRecord(h->ev0, st));
   hipLaunchKernelGGL(cmx_mixnet_kernel, dim3(1), dim3(CMX_MIXNET_THREADS), kLdsBytes, st, h->d_state, d_probs,
-                     d_sel, d_bits, h->d_decay, (int)nbits, d_p_out, d_mix_out, 3);
+                     d_sel, d_bits, h->d_decay, (int)nbits, d_p_out, d_mix_out, 3 | (h->profile ? 4 : 0));
   HIP_OK(hipGetLastError());
   HIP_OK(hipEventRecord(h->ev1, st));
   h->timed = true;
@@ -309,6 +311,20 @@ int cmx_mixnet_perceive(cmx_mixnet_t* h, int bit) {
   HIP_OK(hipDeviceSynchronize());
   h->predicted = false;
   h->bits_done += 1;
+  return 0;
+}
+
+int cmx_mixnet_profile(cmx_mixnet_t* h, int enable, uint64_t* out16) {
+  const int fail_value = 1;
+  if (!h) { set_err("cmx_mixnet_profile: null handle"); return 1; }
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipDeviceSynchronize());
+  MixState tmp;
+  HIP_OK(hipMemcpy(&tmp, h->d_state, sizeof tmp, hipMemcpyDeviceToHost));
+  if (out16) memcpy(out16, tmp.prof, sizeof tmp.prof);
+  memset(tmp.prof, 0, sizeof tmp.prof);
+  HIP_OK(hipMemcpy((char*)h->d_state + offsetof(MixState, prof), tmp.prof, sizeof tmp.prof, hipMemcpyHostToDevice));
+  h->profile = enable;
   return 0;
 }
 

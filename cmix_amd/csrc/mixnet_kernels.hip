@@ -304,17 +304,30 @@ __device__ __forceinline__ float perceive_scalar(MixState* S, const Smem& sm, in
   return u;
 }
 
+// Optional phase timers (mode bit 4): shader-clock ticks accumulated per phase by lane 0 of the
+// chain wave into S->prof[]; read back through cmx_mixnet_profile().
+#define PROF(k)                                                        \
+  do {                                                                 \
+    if (prof_on) {                                                     \
+      uint64_t now_ = __builtin_readcyclecounter();                    \
+      if (tid == 0) S->prof[k] += now_ - tprev;                        \
+      tprev = now_;                                                    \
+    }                                                                  \
+  } while (0)
+
 // ---------------------------------------------------------------- chain wave
 __device__ void chain_role(MixState* S, const Smem& sm, const float* probs, const uint32_t* sel,
                            const uint8_t* bits, const float* decay1, int nbits, float* p_out,
-                           float* mix_out, bool fwd, bool upd_on, int tid) {
-  const int m = tid;  // lane = mixer index within its layer
+                           float* mix_out, bool fwd, bool upd_on, bool prof_on, int tid) {
+  const int m = tid;
+  uint64_t tprev = __builtin_readcyclecounter();  // lane = mixer index within its layer
   const float smin = S->stretch_min, smax = S->stretch_max;
   const float cdec = 1.0f - 3.0e-6f;
   for (int t = 0; t < nbits; ++t) {
     const float* pr = probs + (size_t)t * CMX_IN0;
     stretch_inputs(S, pr, sm.xs, tid);
     __syncthreads();  // B1
+    PROF(0);
     // B. selectors -> weight rows
     if (m < CMX_MIXERS) {
       uint32_t key = sel[(size_t)t * CMX_MIXERS + m];
@@ -328,6 +341,7 @@ __device__ void chain_role(MixState* S, const Smem& sm, const float* probs, cons
       }
       sm.rowidx[m] = select_row(S, m, key);
     }
+    PROF(1);
     __syncthreads();  // B2
     const int bit = bits[t];
     float* row0 = nullptr;
@@ -341,13 +355,18 @@ __device__ void chain_role(MixState* S, const Smem& sm, const float* probs, cons
     float* row1 = S->rows1 + ((size_t)(m < CMX_MIX1 ? m : 0) * CMX_ROWS_PER_MIXER +
                               sm.rowidx[CMX_MIX0 + (m < CMX_MIX1 ? m : 0)]) * CMX_ROW1_STRIDE;
     float* row2 = S->rows2 + (size_t)sm.rowidx[CMX_MIXERS - 1] * CMX_ROW2_STRIDE;
+    PROF(2);
     if (fwd) {
       __syncthreads();  // B3
+      PROF(3);
       float p_main = 0.0f;
       if (m < CMX_MIX0) p_main = chain_half(sm.prod, m, H0_CHUNKS, 64, 0.0f);
+      PROF(4);
       __syncthreads();  // B4
       __syncthreads();  // B5
+      PROF(5);
       if (m < CMX_MIX0) p_main = chain_half(sm.prod, m, H1_CHUNKS, CMX_IN0 - 32 * 64, p_main);
+      PROF(6);
       // intra-layer chain: mixer k also sees the clamped outputs of mixers 0..k-1
       // (ref predictor.cpp:395-400, mixer.cpp:45-53)
       float e = 0.0f;
@@ -361,6 +380,7 @@ __device__ void chain_role(MixState* S, const Smem& sm, const float* probs, cons
         if (m > j && m < CMX_MIX0) e = fadd(e, fmul(oj, ew[j]));
       }
       if (m < CMX_MIX0) { S->fwd_p[m] = p_; S->fwd_out0[m] = sm.out0[m]; }
+      PROF(7);
     } else {
       __syncthreads();  // B5
       if (m < CMX_MIX0) { p_ = S->fwd_p[m]; sm.out0[m] = S->fwd_out0[m]; }
@@ -399,6 +419,7 @@ __device__ void chain_role(MixState* S, const Smem& sm, const float* probs, cons
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    PROF(8);
     // layer 2 (lane 0): 49 inputs; squash; SSE; LSTM override (ref predictor.cpp:413-418)
     if (m == 0) {
       if (fwd) {
@@ -421,6 +442,7 @@ __device__ void chain_role(MixState* S, const Smem& sm, const float* probs, cons
       if (m < CMX_MIX1) mo[CMX_MIX0 + m] = p1_;
       if (m == 0) mo[CMX_MIXERS - 1] = p2_;
     }
+    PROF(9);
     // Mixer::Perceive for the rows this wave owns (ref mixer.cpp:56-72)
     if (upd_on) {
       const double d1 = (double)decay1[t];  // (float)(0.9/pow(1e-7*steps_+0.8,0.8)), host libm
@@ -461,8 +483,10 @@ __device__ void chain_role(MixState* S, const Smem& sm, const float* probs, cons
         S->steps = S->steps + 1;
       }
     }
+    PROF(10);
     __syncthreads();  // B6
     __syncthreads();  // B7
+    PROF(11);
   }
 }
 
@@ -485,7 +509,7 @@ extern "C" __global__ __launch_bounds__(NTHREADS) void cmx_mixnet_kernel(
   const int tid = threadIdx.x;
   const bool fwd = mode & 1, upd_on = mode & 2;
   if (tid < 2112 - CMX_IN0) sm.xs[CMX_IN0 + tid] = 0.0f;  // padding read by the last chunk
-  if (tid < 64) chain_role(S, sm, probs, sel, bits, decay1, nbits, p_out, mix_out, fwd, upd_on, tid);
+  if (tid < 64) chain_role(S, sm, probs, sel, bits, decay1, nbits, p_out, mix_out, fwd, upd_on, (mode & 4) != 0, tid);
   else producer_role(S, sm, probs, nbits, fwd, upd_on, tid);
 }
 

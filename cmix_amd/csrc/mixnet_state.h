@@ -64,6 +64,8 @@ struct MixState {
   float fwd_p[CMX_MIXERS + 1];
   float fwd_out0[32];
   float fwd_in2[64];
+
+  uint64_t prof[16];        // phase timers (shader clocks), see PROF() in mixnet_kernels.hip
 };
 
 #endif

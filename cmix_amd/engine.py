@@ -55,6 +55,7 @@ def lib():
         L.cmx_mixnet_predict.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.cmx_mixnet_perceive.argtypes = [C.c_void_p, C.c_int]
         L.cmx_mixnet_bits_done.argtypes = [C.c_void_p, C.c_void_p]
+        L.cmx_mixnet_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.cmx_mixnet_last_kernel_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.cmx_probe_libm.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
         _lib = L
@@ -137,6 +138,12 @@ class MixNet:
         if lib().cmx_mixnet_bits_done(self.h, C.byref(v)):
             raise CmxError(last_error())
         return v.value
+
+    def profile(self, enable=True):
+        out = (C.c_uint64 * 16)()
+        if lib().cmx_mixnet_profile(self.h, int(enable), out):
+            raise CmxError(last_error())
+        return list(out)
 
     def last_kernel_ms(self):
         v = C.c_float(0)

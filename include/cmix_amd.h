@@ -98,6 +98,10 @@ int cmx_mixnet_perceive(cmx_mixnet_t*, int bit);
 
 /* Introspection used by the parity tests. */
 int cmx_mixnet_bits_done(const cmx_mixnet_t*, uint64_t* out);
+/* Phase timers: enable != 0 turns on in-kernel shader-clock accumulation for the
+ * following chunks; out16 (may be NULL) receives the 16 accumulators gathered
+ * since the previous call, which are then cleared. Synchronises the device. */
+int cmx_mixnet_profile(cmx_mixnet_t*, int enable, uint64_t* out16);
 /* Elapsed device time (ms, HIP events on the launch stream) of the last
  * cmx_mixnet_run kernel; synchronises with it. */
 int cmx_mixnet_last_kernel_ms(cmx_mixnet_t*, float* ms);

@@ -1,0 +1,25 @@
+"""Per-phase shader-clock breakdown of the mixnet kernel (debug aid; not the bench)."""
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+from conftest import synth_mixnet_inputs
+from cmix_amd import engine as E
+
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+probs, sel, bits = synth_mixnet_inputs(T, seed=1)
+net = E.MixNet(0)
+dp = torch.from_numpy(probs).cuda()
+ds = torch.from_numpy((sel & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.int32)).cuda()
+db = torch.from_numpy(bits).cuda()
+net.run(dp, ds, db); torch.cuda.synchronize()
+print('plain: kernel %.2f ms  %.2f us/bit' % (net.last_kernel_ms(), net.last_kernel_ms() * 1e3 / T))
+net.profile(True)
+net.run(dp, ds, db); torch.cuda.synchronize()
+ms = net.last_kernel_ms()
+pr = net.profile(False)
+names = ['stretch+B1', 'select_row', 'B2+ew load', 'B3 wait (row loads+prod h0)', 'chain h0', 'B4,B5 (prod h1)',
+         'chain h1', 'extras chain L0', 'L1', 'L2+SSE', 'perceive scalars+L1/L2 upd', 'B6,B7 (L0 row update)']
+tot = sum(pr[:12])
+print('profiled: kernel %.2f ms  %.2f us/bit; total ticks/bit %.0f' % (ms, ms * 1e3 / T, tot / T))
+for n, v in zip(names, pr):
+    print('  %-34s %9.0f ticks/bit  %5.1f%%' % (n, v / T, 100.0 * v / tot))
