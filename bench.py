@@ -60,18 +60,18 @@ def make_operands(nbytes, seed, device):
     probs[:, 2025:2078] = torch.rand((T, 53), generator=g, device=device)
     probs[:, 432:434] = 0.5
     # selector keys from the actual bytes: order-0/1/2 partial-byte contexts, byte classes ...
-    b = text.astype(np.uint64)
+    b = text.astype(np.int64)
     prev1 = np.concatenate([[0], b[:-1]])
     prev2 = np.concatenate([[0, 0], b[:-2]])
     prev3 = np.concatenate([[0, 0, 0], b[:-3]])
-    lbc = np.ones(T, np.uint64)
+    lbc = np.ones(T, np.int64)
     for j in range(1, 8):
         lbc[j::8] = lbc[j - 1::8] * 2 + bits_np[j - 1::8]
     rep = lambda a: np.repeat(a, 8)
-    sel = np.zeros((T, 47), np.uint64)
+    sel = np.zeros((T, 47), np.int64)
     percol = {0: lbc, 1: lbc, 2: (rep(prev1) << 8) + lbc, 3: (rep(prev1) << 8) + lbc,
               4: (rep(prev1 & 15) << 12) + (rep(prev2 & 15) << 8) + lbc, 5: (rep(prev1 & 3) << 8) + lbc,
-              6: rep(prev3), 7: rep(prev3), 8: 0 * lbc, 9: rep(np.arange(nbytes, dtype=np.uint64) % 100),
+              6: rep(prev3), 7: rep(prev3), 8: 0 * lbc, 9: rep(np.arange(nbytes, dtype=np.int64) % 100),
               10: rep(prev1 & 7), 11: rep((prev1 << 8) + prev2), 13: rep(prev1 >> 3), 14: rep(prev1 >> 2),
               15: rep(prev1 >> 5), 16: (rep(prev1 >> 5) << 8) + lbc, 17: rep((prev1 >> 6) + 4 * (prev2 >> 6)),
               18: rep((prev1 >> 6) + 4 * (prev2 >> 6) + 16 * (prev3 >> 6)), 19: (rep(prev1 >> 6) << 8) + lbc,
@@ -86,7 +86,7 @@ def make_operands(nbytes, seed, device):
           (rep(prev1 >> 5) << 8) + lbc, (rep(prev1 >> 5) << 8) + lbc]
     for j, v in enumerate(l1):
         sel[:, 26 + j] = v
-    sel32 = torch.from_numpy((sel & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.int32)).to(device)
+    sel32 = torch.from_numpy((sel & 0xFFFFFFFF).astype(np.uint32).view(np.int32)).to(device)
     return probs.contiguous(), sel32.contiguous(), bits.contiguous(), text
 
 

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <stddef.h>
 #include <string>
@@ -19,6 +20,8 @@
 
 extern "C" __global__ void cmx_mixnet_kernel(MixState*, const float*, const uint32_t*,
                                              const uint8_t*, const float*, int, float*, float*, int);
+extern "C" __global__ void cmx_mixnet_chunk_kernel(MixState*, const float*, const uint32_t*,
+                                                   const uint8_t*, const float*, int, float*, float*, int);
 extern "C" __global__ void cmx_sse_init_kernel(MixState*);
 extern "C" __global__ void cmx_probe_libm_kernel(int, const float*, float*, size_t);
 
@@ -104,6 +107,8 @@ struct cmx_mixnet {
   float h_sync_decay = 0;
   bool predicted = false;
   int profile = 0;
+  int dbg = 0;          // CMX_MIXNET_DBG: timing experiments (results invalid when nonzero)
+  bool use_v1 = false;  // CMX_MIXNET_V1=1: run chunks through the bit-synchronous kernel
 };
 
 extern "C" {
@@ -224,6 +229,14 @@ cmx_mixnet_t* cmx_mixnet_create(int device) {
     cmx_mixnet_destroy(h);
     return nullptr;
   }
+  if (hipFuncSetAttribute((const void*)cmx_mixnet_chunk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          CMX_CHUNK_LDS_BYTES) != hipSuccess) {
+    set_err("hipFuncSetAttribute(MaxDynamicSharedMemorySize, chunk kernel) failed");
+    cmx_mixnet_destroy(h);
+    return nullptr;
+  }
+  { const char* v = getenv("CMX_MIXNET_V1"); h->use_v1 = v && v[0] == '1'; }
+  { const char* v = getenv("CMX_MIXNET_DBG"); h->dbg = v ? atoi(v) : 0; }
   hipEventCreate(&h->ev0);
   hipEventCreate(&h->ev1);
   hipError_t e = hipDeviceSynchronize();
@@ -268,8 +281,14 @@ int cmx_mixnet_run(cmx_mixnet_t* h, const float* d_probs, const uint32_t* d_sel,
   for (size_t t = 0; t < nbits; ++t) h->h_decay[t] = decay_of(h->bits_done + t);
   HIP_OK(hipMemcpyAsync(h->d_decay, h->h_decay, nbits * 4, hipMemcpyHostToDevice, st));
   HIP_OK(hipEventRecord(h->ev0, st));
-  hipLaunchKernelGGL(cmx_mixnet_kernel, dim3(1), dim3(CMX_MIXNET_THREADS), kLdsBytes, st, h->d_state, d_probs,
-                     d_sel, d_bits, h->d_decay, (int)nbits, d_p_out, d_mix_out, 3 | (h->profile ? 4 : 0));
+  if (h->use_v1)
+    hipLaunchKernelGGL(cmx_mixnet_kernel, dim3(1), dim3(CMX_MIXNET_THREADS), kLdsBytes, st, h->d_state,
+                       d_probs, d_sel, d_bits, h->d_decay, (int)nbits, d_p_out, d_mix_out,
+                       3 | (h->profile ? 4 : 0));
+  else
+    hipLaunchKernelGGL(cmx_mixnet_chunk_kernel, dim3(1), dim3(CMX_CHUNK_THREADS), CMX_CHUNK_LDS_BYTES, st,
+                       h->d_state, d_probs, d_sel, d_bits, h->d_decay, (int)nbits, d_p_out, d_mix_out,
+                       3 | (h->profile ? 4 : 0) | (h->dbg << 4));
   HIP_OK(hipGetLastError());
   HIP_OK(hipEventRecord(h->ev1, st));
   h->timed = true;
@@ -331,6 +350,17 @@ int cmx_mixnet_profile(cmx_mixnet_t* h, int enable, uint64_t* out16) {
 int cmx_mixnet_bits_done(const cmx_mixnet_t* h, uint64_t* out) {
   if (!h || !out) { set_err("cmx_mixnet_bits_done: null argument"); return 1; }
   *out = h->bits_done;
+  return 0;
+}
+
+int cmx_mixnet_sync(cmx_mixnet_t* h) {
+  const int fail_value = 1;
+  if (!h) { set_err("cmx_mixnet_sync: null handle"); return 1; }
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipDeviceSynchronize());
+  int err = 0;
+  HIP_OK(hipMemcpy(&err, (char*)h->d_state + offsetof(MixState, error), 4, hipMemcpyDeviceToHost));
+  if (err) { set_err("cmx_mixnet: a device-side wait timed out (kernel aborted); state is invalid"); return 1; }
   return 0;
 }
 

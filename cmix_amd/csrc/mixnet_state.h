@@ -65,7 +65,13 @@ struct MixState {
   float fwd_out0[32];
   float fwd_in2[64];
 
+  int error;                // set by a kernel whose bounded spin timed out
+  int pad_;
   uint64_t prof[16];        // phase timers (shader clocks), see PROF() in mixnet_kernels.hip
 };
+
+// dynamic LDS of cmx_mixnet_chunk_kernel (see the carve-up in mixnet_chunk.hip)
+#define CMX_CHUNK_LDS_BYTES 142336
+#define CMX_CHUNK_THREADS 768
 
 #endif

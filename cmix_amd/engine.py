@@ -54,6 +54,7 @@ def lib():
         L.cmx_mixnet_predict.restype = C.c_float
         L.cmx_mixnet_predict.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.cmx_mixnet_perceive.argtypes = [C.c_void_p, C.c_int]
+        L.cmx_mixnet_sync.argtypes = [C.c_void_p]
         L.cmx_mixnet_bits_done.argtypes = [C.c_void_p, C.c_void_p]
         L.cmx_mixnet_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.cmx_mixnet_last_kernel_ms.argtypes = [C.c_void_p, C.c_void_p]
@@ -131,6 +132,10 @@ class MixNet:
 
     def perceive(self, bit):
         if lib().cmx_mixnet_perceive(self.h, int(bit)):
+            raise CmxError(last_error())
+
+    def sync(self):
+        if lib().cmx_mixnet_sync(self.h):
             raise CmxError(last_error())
 
     def bits_done(self):

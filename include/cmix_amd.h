@@ -96,6 +96,10 @@ int cmx_mixnet_run(cmx_mixnet_t*, const float* d_probs, const uint32_t* d_sel,
 float cmx_mixnet_predict(cmx_mixnet_t*, const float* probs2078, const uint32_t* sel47);
 int cmx_mixnet_perceive(cmx_mixnet_t*, int bit);
 
+/* Waits for all work of this handle and reports device-side failures (a bounded
+ * in-kernel wait that timed out). */
+int cmx_mixnet_sync(cmx_mixnet_t*);
+
 /* Introspection used by the parity tests. */
 int cmx_mixnet_bits_done(const cmx_mixnet_t*, uint64_t* out);
 /* Phase timers: enable != 0 turns on in-kernel shader-clock accumulation for the
