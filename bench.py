@@ -204,7 +204,7 @@ def main():
             "us_per_bit": dt / (a.steps * cb) * 1e6,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "cmx_mixnet_kernel", "avg_kernel_ms": avg_kernel_s * 1e3,
+                         "kernel": "cmx_mixnet_chunk_kernel", "avg_kernel_ms": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": algo},
         }
         if not a.no_cpu_baseline:
