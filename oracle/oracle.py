@@ -46,6 +46,20 @@ def lib():
         L.orc_sse_predict.restype = C.c_float
         L.orc_sse_predict.argtypes = [C.c_void_p, C.c_float]
         L.orc_sse_perceive.argtypes = [C.c_void_p, C.c_int]
+        L.orc_lstm_create.restype = C.c_void_p
+        L.orc_lstm_create.argtypes = [C.c_void_p, C.c_int]
+        L.orc_lstm_destroy.argtypes = [C.c_void_p]
+        L.orc_lstm_vocab_size.argtypes = [C.c_void_p]
+        L.orc_lstm_gate_rowlen.argtypes = [C.c_void_p, C.c_int]
+        L.orc_lstm_gate_weights.restype = C.POINTER(C.c_float)
+        L.orc_lstm_gate_weights.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_lstm_byte_update.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_lstm_bit_predict.restype = C.c_float
+        L.orc_lstm_bit_predict.argtypes = [C.c_void_p]
+        L.orc_lstm_bit_perceive.argtypes = [C.c_void_p, C.c_int]
+        L.orc_lstm_probs.restype = C.POINTER(C.c_float)
+        L.orc_lstm_probs.argtypes = [C.c_void_p]
+        L.orc_lstm_ex.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -120,4 +134,41 @@ class SSE:
     def __del__(self):
         if self.h:
             lib().orc_sse_destroy(self.h)
+            self.h = None
+
+
+class Lstm:
+    """Byte-level LSTM byte mixer + its ByteModel bit interface."""
+    SKIP_RAND = 31  # Indirect constructors before the LSTM in Predictor::Predictor
+
+    def __init__(self, vocab, skip_rand=SKIP_RAND):
+        vocab = np.ascontiguousarray(vocab, np.uint8)
+        self.h = lib().orc_lstm_create(vocab.ctypes.data, skip_rand)
+        self.V = lib().orc_lstm_vocab_size(self.h)
+
+    def gate_weights(self, layer, gate):
+        n = lib().orc_lstm_gate_rowlen(self.h, layer)
+        p = lib().orc_lstm_gate_weights(self.h, layer, gate)
+        return np.ctypeslib.as_array(p, shape=(200, n)).copy()
+
+    def byte_update(self, in256, byte):
+        in256 = np.ascontiguousarray(in256, np.float32)
+        lib().orc_lstm_byte_update(self.h, in256.ctypes.data, int(byte))
+        return self.probs()
+
+    def probs(self):
+        return np.ctypeslib.as_array(lib().orc_lstm_probs(self.h), shape=(256,)).copy()
+
+    def bit_predict(self):
+        return np.float32(lib().orc_lstm_bit_predict(self.h))
+
+    def bit_perceive(self, bit):
+        lib().orc_lstm_bit_perceive(self.h, int(bit))
+
+    def ex(self):
+        return lib().orc_lstm_ex(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_lstm_destroy(self.h)
             self.h = None

@@ -47,3 +47,34 @@ def test_sse_tables_shape():
     st, sq = O.sse_tables()
     assert st[0] == 0 and st[16384] in (16383, 16384) and sq[1] > 32000 and sq[32767] < 100
     assert np.all(np.diff(st[1:].astype(np.int32)) <= 0)  # stretch((1-p)/p) decreases with p
+
+
+def _check_lstm(name):
+    """LSTM byte mixer restatement vs the reference's byte_mixers_[0] (per byte: 256-way
+    distribution; per bit: ByteModel::Predict value = layer-0 input 2077)."""
+    g = load_golden(name)
+    l = O.Lstm(g["vocab"])
+    stream = g["stream"]
+    probs = mg.unpack_probs(g) if "probs_q" in g else None
+    t = 0
+    for n in range(len(stream)):
+        for j in range(7, -1, -1):
+            p = l.bit_predict()
+            if probs is not None:
+                assert bits_equal(p, probs[t, 2077]).all(), f"{name}: LSTM bit prediction differs at bit {t}"
+            l.bit_perceive((int(stream[n]) >> j) & 1)
+            t += 1
+        out = l.byte_update(g["ppmd_probs"][n + 1], stream[n])
+        assert bits_equal(out, g["lstm_probs"][n + 1]).all(), f"{name}: LSTM distribution differs after byte {n}"
+
+
+def test_lstm_text_golden():
+    _check_lstm("text_96")
+
+
+def test_lstm_binary_golden():
+    _check_lstm("binary_64")
+
+
+def test_lstm_2k_golden_20_bptt_rounds():
+    _check_lstm("text_2k_nofull")  # 2048 bytes: 21 BPTT + Adam rounds (every 100 bytes)
