@@ -88,6 +88,8 @@ void build_sse_tables(std::vector<uint16_t>& t_st, std::vector<uint16_t>& t_sq) 
 
 }  // namespace
 
+void cmx_set_err(const std::string& s) { set_err(s); }  // shared with the other stage files
+
 struct cmx_mixnet {
   int device = 0;
   MixState* d_state = nullptr;

@@ -1,0 +1,274 @@
+// lstm_api.hip -- host side of the LSTM byte-mixer stage (C ABI: cmx_lstm_* in include/cmix_amd.h).
+//
+// Initialisation follows the reference constructor chain exactly: glibc rand() after
+// srand(0xDEADBEEF) (predictor.cpp:26) -- re-implemented here (TYPE_3 additive-feedback generator,
+// glibc stdlib/random_r.c) so the library never touches the process-global rand() state -- with the
+// 31 draws of the Indirect models constructed before the LSTM skipped (indirect.cpp:10), then
+// lstm-layer.cpp:52-59. Adam's per-step scalars (lstm-layer.cpp:14-30: sqrtf / powf / double pow)
+// come from the HOST libm as a 3001-entry table.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/cmix_amd.h"
+#include "lstm_state.h"
+
+extern "C" __global__ void cmx_lstm_prep(LstmState*, const float*, const uint8_t*, size_t);
+extern "C" __global__ void cmx_lstm_sgd(LstmState*);
+extern "C" __global__ void cmx_lstm_gate_fwd(LstmState*, int);
+extern "C" __global__ void cmx_lstm_cell(LstmState*, int);
+extern "C" __global__ void cmx_lstm_out(LstmState*);
+extern "C" __global__ void cmx_lstm_softmax(LstmState*, float*);
+extern "C" __global__ void cmx_lstm_bptt_seq(LstmState*);
+extern "C" __global__ void cmx_lstm_bptt_acc(LstmState*);
+extern "C" __global__ void cmx_lstm_bptt_gb(LstmState*);
+extern "C" __global__ void cmx_bytemodel_bits(const float*, const float*, const uint8_t*, size_t, float*, int*);
+
+void cmx_set_err(const std::string& s);  // cmx_api.hip
+
+namespace {
+
+// glibc rand(): TYPE_3, r[i] = r[i-3] + r[i-31], 310 warm-up draws, result >> 1.
+struct GlibcRand {
+  std::vector<int32_t> r;
+  size_t k = 344;
+  explicit GlibcRand(uint32_t seed) : r(344) {
+    int32_t word = (int32_t)seed;
+    if (word == 0) word = 1;
+    r[0] = word;
+    for (int i = 1; i < 31; ++i) {
+      long hi = word / 127773, lo = word % 127773;
+      long w = 16807 * lo - 2836 * hi;
+      if (w < 0) w += 2147483647;
+      word = (int32_t)w;
+      r[i] = word;
+    }
+    for (int i = 31; i < 34; ++i) r[i] = r[i - 31];
+    for (int i = 34; i < 344; ++i) r[i] = (int32_t)((uint32_t)r[i - 31] + (uint32_t)r[i - 3]);
+  }
+  int next() {
+    int32_t v = (int32_t)((uint32_t)r[k - 31] + (uint32_t)r[k - 3]);
+    r.push_back(v);
+    ++k;
+    return (int)((uint32_t)v >> 1);
+  }
+};
+
+}  // namespace
+
+struct cmx_lstm {
+  int device = 0;
+  LstmState h_state;
+  LstmState* d_state = nullptr;
+  std::vector<void*> allocs;
+  float* d_prev_probs = nullptr;  // byte distribution at chunk start
+  uint64_t bytes_done = 0;
+};
+
+extern "C" {
+
+void cmx_lstm_destroy(cmx_lstm_t* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  for (void* p : h->allocs) (void)hipFree(p);
+  delete h;
+}
+
+int cmx_glibc_rand_selftest(uint32_t seed, int n, int* out) {  // test hook: first n draws
+  GlibcRand g(seed);
+  for (int i = 0; i < n; ++i) out[i] = g.next();
+  return 0;
+}
+
+cmx_lstm_t* cmx_lstm_create(const uint8_t vocab[256], int skip_rand, int device) {
+  int ndev = cmx_device_count();
+  if (ndev <= 0) { cmx_set_err("cmx_lstm_create: no HIP device visible (a gfx950 GPU is required)"); return nullptr; }
+  if (device < 0 || device >= ndev) { cmx_set_err("cmx_lstm_create: bad device index"); return nullptr; }
+  if (hipSetDevice(device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return nullptr; }
+  cmx_lstm_t* h = new cmx_lstm();
+  h->device = device;
+  LstmState& S = h->h_state;
+  memset(&S, 0, sizeof S);
+  int V = 0;
+  for (int i = 0; i < 256; ++i) {
+    S.vocab[i] = vocab[i] != 0;
+    S.byte_map[i] = V;
+    if (S.vocab[i]) ++V;
+  }
+  if (V == 0) { cmx_set_err("cmx_lstm_create: empty vocabulary"); delete h; return nullptr; }
+  S.V = V;
+  S.insz[0] = 1 + LSTM_C + V;
+  S.insz[1] = V + 1 + 2 * LSTM_C;
+  S.rowlen[0] = S.insz[0] + V;
+  S.rowlen[1] = S.insz[1] + V;
+  S.lr = 0.03f;
+  bool fail = false;
+  auto dallocf = [&](size_t count, const float* init) -> float* {
+    void* p = nullptr;
+    if (hipMalloc(&p, count * 4) != hipSuccess) { fail = true; return nullptr; }
+    h->allocs.push_back(p);
+    if (init) (void)hipMemcpy(p, init, count * 4, hipMemcpyHostToDevice);
+    else (void)hipMemset(p, 0, count * 4);
+    return (float*)p;
+  };
+  // weights, reference draw order: per cell i, per column j: forget, input node, output (lstm-layer.cpp:52-59)
+  GlibcRand rng(0xDEADBEEFu);
+  for (int i = 0; i < skip_rand; ++i) rng.next();
+  for (int l = 0; l < LSTM_L; ++l) {
+    const int rl = S.rowlen[l];
+    std::vector<float> w[3], wt[3];
+    for (int g = 0; g < 3; ++g) { w[g].resize((size_t)LSTM_C * rl); wt[g].resize((size_t)LSTM_C * rl); }
+    const float val = sqrtf(6.0f / (float)(V + V));
+    const float low = -val, range = 2 * val;
+    for (int i = 0; i < LSTM_C; ++i) {
+      for (int j = 0; j < rl; ++j)
+        for (int g = 0; g < 3; ++g) w[g][(size_t)i * rl + j] = low + ((float)rng.next() / (float)2147483647) * range;
+      w[0][(size_t)i * rl + rl - 1] = 1;
+    }
+    for (int g = 0; g < 3; ++g) {
+      for (int i = 0; i < LSTM_C; ++i)
+        for (int j = 0; j < rl; ++j) wt[g][(size_t)j * LSTM_C + i] = w[g][(size_t)i * rl + j];
+      S.W[l][g] = dallocf((size_t)LSTM_C * rl, w[g].data());
+      S.WT[l][g] = dallocf((size_t)LSTM_C * rl, wt[g].data());
+      S.M[l][g] = dallocf((size_t)LSTM_C * rl, nullptr);
+      S.Vv[l][g] = dallocf((size_t)LSTM_C * rl, nullptr);
+      std::vector<float> gb(8 * LSTM_C, 0.0f);
+      for (int i = 0; i < LSTM_C; ++i) gb[i] = 1.0f;  // gamma_ (lstm-layer.h:12)
+      S.gb[l][g] = dallocf(8 * LSTM_C, gb.data());
+      S.norm[l][g] = dallocf((size_t)LSTM_H * LSTM_C, nullptr);
+      S.gstate[l][g] = dallocf((size_t)LSTM_H * LSTM_C, nullptr);
+      S.ivar[l][g] = dallocf(LSTM_H, nullptr);
+      S.raw[l][g] = dallocf(LSTM_C, nullptr);
+      S.E[l][g] = dallocf((size_t)LSTM_H * LSTM_C, nullptr);
+    }
+    S.last_state[l] = dallocf((size_t)LSTM_H * LSTM_C, nullptr);
+    S.tanh_state[l] = dallocf((size_t)LSTM_H * LSTM_C, nullptr);
+    S.in_gate_state[l] = dallocf((size_t)LSTM_H * LSTM_C, nullptr);
+    S.state[l] = dallocf(LSTM_C, nullptr);
+    std::vector<float> li((size_t)LSTM_H * S.insz[l], 0.0f);
+    for (int e = 0; e < LSTM_H; ++e) li[(size_t)e * S.insz[l] + S.insz[l] - 1] = 1.0f;  // lstm.cpp:21-23
+    S.layer_input[l] = dallocf(li.size(), li.data());
+  }
+  S.OL = dallocf((size_t)LSTM_H * V * LSTM_NH, nullptr);
+  S.OLT = dallocf((size_t)LSTM_H * LSTM_NH * LSTM_VP, nullptr);
+  {
+    std::vector<float> out((size_t)LSTM_H * LSTM_VP, 0.0f);
+    for (int e = 0; e < LSTM_H; ++e)
+      for (int i = 0; i < V; ++i) out[(size_t)e * LSTM_VP + i] = (float)(1.0 / V);  // lstm.cpp:16
+    S.output = dallocf(out.size(), out.data());
+  }
+  {
+    std::vector<float> hid(LSTM_NH, 0.0f);
+    hid[LSTM_NH - 1] = 1.0f;  // lstm.cpp:18
+    S.hid[0] = dallocf(LSTM_NH, hid.data());
+    S.hid[1] = dallocf(LSTM_NH, hid.data());
+  }
+  S.input_history = (unsigned*)dallocf(LSTM_H, nullptr);
+  S.bp_symbol = (unsigned*)dallocf(LSTM_H, nullptr);
+  S.logits = dallocf(LSTM_VP, nullptr);
+  {
+    // Adam scalars per update step t (lstm-layer.cpp:14-30), host libm.
+    std::vector<float> tab(4 * (LSTM_UPDATE_LIMIT + 1), 0.0f);
+    const float beta1 = 0.025f, beta2 = 0.9999f, lr = S.lr;
+    const unsigned long long limit = LSTM_UPDATE_LIMIT;
+    for (unsigned long long s = 0; s <= limit; ++s) {
+      float t = (float)s, alpha, b1, b2;
+      if (t < limit) {
+        alpha = lr * 0.1f / sqrtf(5e-5f * t + 1.0f);
+        b1 = (float)(1.0f - powf(beta1, t));
+        b2 = (float)(1.0f - powf(beta2, t));
+      } else {
+        alpha = lr * 0.1f / sqrtf(5e-5f * limit + 1.0f);
+        b1 = (float)(1.0f - pow(beta1, limit));
+        b2 = (float)(1.0f - pow(beta2, limit));
+      }
+      tab[4 * s] = alpha;
+      tab[4 * s + 1] = b1;
+      tab[4 * s + 2] = b2;
+    }
+    S.adam_tab = dallocf(tab.size(), tab.data());
+  }
+  {
+    std::vector<float> bp(256, (float)(1.0 / 256));  // ByteModel ctor, byte-model.cpp:5-6
+    S.byte_probs = dallocf(256, bp.data());
+    h->d_prev_probs = dallocf(256, bp.data());
+  }
+  void* ds = nullptr;
+  if (fail || hipMalloc(&ds, sizeof(LstmState)) != hipSuccess) {
+    cmx_set_err("cmx_lstm_create: hipMalloc failed");
+    cmx_lstm_destroy(h);
+    return nullptr;
+  }
+  h->allocs.push_back(ds);
+  h->d_state = (LstmState*)ds;
+  (void)hipMemcpy(ds, &S, sizeof S, hipMemcpyHostToDevice);
+  if (hipDeviceSynchronize() != hipSuccess) { cmx_set_err("cmx_lstm_create: init failed"); cmx_lstm_destroy(h); return nullptr; }
+  return h;
+}
+
+int cmx_lstm_vocab_size(const cmx_lstm_t* h) { return h ? h->h_state.V : -1; }
+
+int cmx_lstm_run(cmx_lstm_t* h, const float* d_in_probs, const uint8_t* d_bytes, size_t nbytes,
+                 float* d_out_probs, float* d_bit_p, int* d_bit_ex, void* stream) {
+  if (!h) { cmx_set_err("cmx_lstm_run: null handle"); return 1; }
+  if (nbytes == 0) return 0;
+  if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
+  hipStream_t st = (hipStream_t)stream;
+  LstmState* S = h->d_state;
+  const int V = h->h_state.V;
+  (void)hipMemcpyAsync(h->d_prev_probs, h->h_state.byte_probs, 256 * 4, hipMemcpyDeviceToDevice, st);
+  for (size_t n = 0; n < nbytes; ++n) {
+    const bool bptt = (h->bytes_done % LSTM_H) == 0;  // Lstm::epoch_ == 0 (lstm.cpp:93)
+    hipLaunchKernelGGL(cmx_lstm_prep, dim3(1), dim3(256), 0, st, S, d_in_probs + n * 256, d_bytes, n);
+    if (bptt) {
+      hipLaunchKernelGGL(cmx_lstm_bptt_seq, dim3(1), dim3(1024), 0, st, S);
+      const int maxrl = h->h_state.rowlen[1];
+      hipLaunchKernelGGL(cmx_lstm_bptt_acc, dim3((maxrl + 63) / 64, LSTM_C / 4, 6), dim3(64, 4), 0, st, S);
+      hipLaunchKernelGGL(cmx_lstm_bptt_gb, dim3(6), dim3(256), 0, st, S);
+    }
+    hipLaunchKernelGGL(cmx_lstm_sgd, dim3((V * LSTM_NH + 255) / 256), dim3(256), 0, st, S);
+    hipLaunchKernelGGL(cmx_lstm_gate_fwd, dim3(4, 3), dim3(64), 0, st, S, 0);
+    hipLaunchKernelGGL(cmx_lstm_cell, dim3(1), dim3(256), 0, st, S, 0);
+    hipLaunchKernelGGL(cmx_lstm_gate_fwd, dim3(4, 3), dim3(64), 0, st, S, 1);
+    hipLaunchKernelGGL(cmx_lstm_cell, dim3(1), dim3(256), 0, st, S, 1);
+    hipLaunchKernelGGL(cmx_lstm_out, dim3((V + 63) / 64), dim3(64), 0, st, S);
+    hipLaunchKernelGGL(cmx_lstm_softmax, dim3(1), dim3(256), 0, st, S, d_out_probs ? d_out_probs + n * 256 : nullptr);
+    h->bytes_done += 1;
+  }
+  if (d_bit_p) {
+    if (!d_out_probs) { cmx_set_err("cmx_lstm_run: bit predictions need d_out_probs"); return 1; }
+    hipLaunchKernelGGL(cmx_bytemodel_bits, dim3((unsigned)nbytes), dim3(64), 0, st, h->d_prev_probs, d_out_probs,
+                       d_bytes, nbytes, d_bit_p, d_bit_ex);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { cmx_set_err(std::string("cmx_lstm_run: ") + hipGetErrorString(e)); return 1; }
+  return 0;
+}
+
+int cmx_bytemodel_bits_run(int device, const float* d_dist0, const float* d_dist_rest, const uint8_t* d_bytes,
+                           size_t nbytes, float* d_bit_p, int* d_bit_ex, void* stream) {
+  if (nbytes == 0) return 0;
+  if (hipSetDevice(device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
+  hipLaunchKernelGGL(cmx_bytemodel_bits, dim3((unsigned)nbytes), dim3(64), 0, (hipStream_t)stream, d_dist0,
+                     d_dist_rest, d_bytes, nbytes, d_bit_p, d_bit_ex);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { cmx_set_err(std::string("cmx_bytemodel_bits_run: ") + hipGetErrorString(e)); return 1; }
+  return 0;
+}
+
+// test hook: copy gate weights (reference layout [200][rowlen]) back to the host
+int cmx_lstm_get_gate_weights(cmx_lstm_t* h, int layer, int gate, float* out) {
+  if (!h) return 1;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  size_t n = (size_t)LSTM_C * h->h_state.rowlen[layer];
+  return hipMemcpy(out, h->h_state.W[layer][gate], n * 4, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+int cmx_lstm_gate_rowlen(const cmx_lstm_t* h, int layer) { return h ? h->h_state.rowlen[layer] : -1; }
+
+}  // extern "C"

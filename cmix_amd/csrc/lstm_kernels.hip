@@ -1,0 +1,435 @@
+// lstm_kernels.hip -- gfx950 kernels of the byte-level LSTM byte mixer stage.
+//
+// Reference: ByteMixer::ByteUpdate (src/mixer/byte-mixer.cpp:22-38), Lstm::Perceive/Predict
+// (src/mixer/lstm.cpp:87-150), LstmLayer::ForwardPass/BackwardPass and Adam
+// (src/mixer/lstm-layer.cpp:11-197), ByteModel::Predict (src/models/byte-model.cpp:8-24).
+//
+// Strict mode: every dot product is an ordered f32 chain (product rounded, then added, in the
+// reference's index order; `(expr).sum()` of libstdc++ runs BACKWARD, `valarray::sum()` forward),
+// libm through cmx_libm.h, no FMA contraction. The parallelism is ACROSS chains: 600 gate rows
+// per layer, V output rows, 200 hidden-error lanes, and every weight element in the BPTT
+// accumulation/Adam sweep. MFMA is not used: an MFMA step is a fused multiply-add with one
+// rounding and a blocked K order, which cannot reproduce the reference stream.
+//
+// Per byte (stream order): prep -> [bptt_seq -> bptt_acc every 100 bytes] -> sgd || (gate_fwd(0)
+// -> cell(0) -> gate_fwd(1) -> cell(1)) -> out -> softmax.  Bit-level predictions for a whole
+// chunk are produced by bytemodel_bits at the end (the coded bytes are known in compression).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "cmx_libm.h"
+#include "lstm_state.h"
+
+namespace {
+
+__device__ __forceinline__ float fmul(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float fadd(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float fsub(float a, float b) { return __fsub_rn(a, b); }
+__device__ __forceinline__ float fdiv(float a, float b) { return __fdiv_rn(a, b); }
+// NOT __fsqrt_rn: without OCML_BASIC_ROUNDED_OPERATIONS that maps to the approximate native sqrt.
+__device__ __forceinline__ float fsqrt(float a) { return __builtin_sqrtf(a); }  // IEEE-correct (hipcc default)
+
+constexpr int C = LSTM_C, H = LSTM_H, NH = LSTM_NH, VP = LSTM_VP;
+
+}  // namespace
+
+// ---- ByteMixer::SetInput/ByteUpdate head + Lstm::Perceive bookkeeping (byte-mixer.cpp:15-26,
+//      lstm.cpp:80-92). in256 = the byte model's distribution, byte = the byte just coded.
+extern "C" __global__ void cmx_lstm_prep(LstmState* S, const float* in256, const uint8_t* bytes, size_t n) {
+  const int tid = threadIdx.x, e = S->epoch, V = S->V;
+  if (S->vocab[tid]) {
+    float v = fmul(in256[tid], 2.0f);  // inputs_ (0 + val) *= 2 / num_models_  (unsigned division = 2)
+    int k = S->byte_map[tid];
+    S->layer_input[0][(size_t)e * S->insz[0] + k] = v;
+    S->layer_input[1][(size_t)e * S->insz[1] + k] = v;
+  }
+  if (tid == 0) {
+    int sym = S->byte_map[bytes[n]];
+    int last = e == 0 ? H - 1 : e - 1;
+    S->old_input = (int)S->input_history[last];
+    S->input_history[last] = (unsigned)sym;
+    S->cur_sym = sym;
+  }
+  (void)V;
+}
+
+// ---- output layer SGD (lstm.cpp:112-116): slot[e] = slot[last] - (lr*err_i)*hidden_, both layouts
+extern "C" __global__ void cmx_lstm_sgd(LstmState* S) {
+  const int V = S->V, e = S->epoch, last = e == 0 ? H - 1 : e - 1;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= V * NH) return;
+  const int i = idx / NH, j = idx - i * NH;
+  float o = S->output[(size_t)last * VP + i];
+  float err = (i == S->cur_sym) ? fsub(o, 1.0f) : o;
+  float le = fmul(S->lr, err);
+  const float* hid = S->hid[S->hid_cur];
+  float v = fsub(S->OL[((size_t)last * V + i) * NH + j], fmul(le, hid[j]));
+  S->OL[((size_t)e * V + i) * NH + j] = v;
+  S->OLT[((size_t)e * NH + j) * VP + i] = v;
+}
+
+// ---- LstmLayer::ForwardPass(NeuronLayer&) dot products (lstm-layer.cpp:85-92):
+//      grid (4, 3): blockIdx.y = gate, 64 cells per block; one ordered chain per lane.
+extern "C" __global__ void cmx_lstm_gate_fwd(LstmState* S, int layer) {
+  __shared__ float in[832];
+  const int V = S->V, e = S->epoch, insz = S->insz[layer], g = blockIdx.y;
+  const float* hold = S->hid[S->hid_cur];
+  const float* hnew = S->hid[S->hid_cur ^ 1];
+  float* li = S->layer_input[layer] + (size_t)e * insz;
+  for (int j = threadIdx.x; j < insz; j += blockDim.x) {
+    float v;
+    if (j < V) v = li[j];                                  // Lstm::SetInput
+    else if (j < V + C) v = hold[layer * C + (j - V)];     // own previous hidden (lstm.cpp:122-124)
+    else if (j < insz - 1) v = hnew[j - V - C];            // layer 1: layer 0's new hidden (lstm.cpp:127-131)
+    else v = 1.0f;                                         // bias
+    in[j] = v;
+    if (g == 0 && blockIdx.x == 0 && j >= V) li[j] = v;    // keep the assembled vector for BPTT
+  }
+  __syncthreads();
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= C) return;
+  const float* wt = S->WT[layer][g];
+  float f = wt[(size_t)S->cur_sym * C + i];
+  const float* wj = wt + (size_t)V * C + i;
+  int j = 0;
+  for (; j + 8 <= insz; j += 8) {
+    float w0 = wj[(size_t)(j + 0) * C], w1 = wj[(size_t)(j + 1) * C], w2 = wj[(size_t)(j + 2) * C],
+          w3 = wj[(size_t)(j + 3) * C], w4 = wj[(size_t)(j + 4) * C], w5 = wj[(size_t)(j + 5) * C],
+          w6 = wj[(size_t)(j + 6) * C], w7 = wj[(size_t)(j + 7) * C];
+    f = fadd(f, fmul(in[j + 0], w0));
+    f = fadd(f, fmul(in[j + 1], w1));
+    f = fadd(f, fmul(in[j + 2], w2));
+    f = fadd(f, fmul(in[j + 3], w3));
+    f = fadd(f, fmul(in[j + 4], w4));
+    f = fadd(f, fmul(in[j + 5], w5));
+    f = fadd(f, fmul(in[j + 6], w6));
+    f = fadd(f, fmul(in[j + 7], w7));
+  }
+  for (; j < insz; ++j) f = fadd(f, fmul(in[j], wj[(size_t)j * C]));
+  S->raw[layer][g][i] = f;
+}
+
+// ---- RMS norm, activations, cell update (lstm-layer.cpp:62-83, 93-98). One block of 256.
+extern "C" __global__ void cmx_lstm_cell(LstmState* S, int layer) {
+  __shared__ float raw[3][C];
+  __shared__ float ivar_s[3];
+  const int tid = threadIdx.x, e = S->epoch;
+  if (tid < C)
+    for (int g = 0; g < 3; ++g) raw[g][tid] = S->raw[layer][g][tid];
+  __syncthreads();
+  if (tid < 3) {  // (norm_*norm_).sum(): expression-template sum runs backward from the last element
+    float s = fmul(raw[tid][C - 1], raw[tid][C - 1]);
+    for (int i = C - 2; i >= 0; --i) s = fadd(s, fmul(raw[tid][i], raw[tid][i]));
+    float iv = fdiv(1.0f, fsqrt(fadd(fdiv(s, (float)C), 1e-5f)));
+    ivar_s[tid] = iv;
+    S->ivar[layer][tid][e] = iv;
+  }
+  __syncthreads();
+  if (tid >= C) return;
+  float st[3];
+  for (int g = 0; g < 3; ++g) {
+    const float* gb = S->gb[layer][g];
+    float nrm = fmul(raw[g][tid], ivar_s[g]);
+    S->norm[layer][g][(size_t)e * C + tid] = nrm;
+    st[g] = fadd(fmul(nrm, gb[tid]), gb[C + tid]);  // norm*gamma + beta
+  }
+  float fg = cmx_logistic(st[0]);
+  float in = cmx_tanhf(st[1]);
+  float og = cmx_logistic(st[2]);
+  S->gstate[layer][0][(size_t)e * C + tid] = fg;
+  S->gstate[layer][1][(size_t)e * C + tid] = in;
+  S->gstate[layer][2][(size_t)e * C + tid] = og;
+  float state = S->state[layer][tid];
+  S->last_state[layer][(size_t)e * C + tid] = state;
+  float igs = fsub(1.0f, fg);
+  S->in_gate_state[layer][(size_t)e * C + tid] = igs;
+  state = fmul(state, fg);
+  state = fadd(state, fmul(in, igs));
+  S->state[layer][tid] = state;
+  float th = cmx_tanhf(state);
+  S->tanh_state[layer][(size_t)e * C + tid] = th;
+  S->hid[S->hid_cur ^ 1][layer * C + tid] = fmul(og, th);
+}
+
+// ---- output layer matvec (lstm.cpp:132-140): one ordered 401-term chain per vocabulary symbol
+extern "C" __global__ void cmx_lstm_out(LstmState* S) {
+  __shared__ float hid[NH];
+  const int V = S->V, e = S->epoch;
+  const float* hnew = S->hid[S->hid_cur ^ 1];
+  for (int j = threadIdx.x; j < NH; j += blockDim.x) hid[j] = hnew[j];
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= V) return;
+  const float* ot = S->OLT + (size_t)e * NH * VP + i;
+  float sum = 0.0f;
+  int j = 0;
+  for (; j + 8 <= NH; j += 8) {
+    float w0 = ot[(size_t)(j + 0) * VP], w1 = ot[(size_t)(j + 1) * VP], w2 = ot[(size_t)(j + 2) * VP],
+          w3 = ot[(size_t)(j + 3) * VP], w4 = ot[(size_t)(j + 4) * VP], w5 = ot[(size_t)(j + 5) * VP],
+          w6 = ot[(size_t)(j + 6) * VP], w7 = ot[(size_t)(j + 7) * VP];
+    sum = fadd(sum, fmul(hid[j + 0], w0));
+    sum = fadd(sum, fmul(hid[j + 1], w1));
+    sum = fadd(sum, fmul(hid[j + 2], w2));
+    sum = fadd(sum, fmul(hid[j + 3], w3));
+    sum = fadd(sum, fmul(hid[j + 4], w4));
+    sum = fadd(sum, fmul(hid[j + 5], w5));
+    sum = fadd(sum, fmul(hid[j + 6], w6));
+    sum = fadd(sum, fmul(hid[j + 7], w7));
+  }
+  for (; j < NH; ++j) sum = fadd(sum, fmul(hid[j], ot[(size_t)j * VP]));
+  S->logits[i] = sum;
+}
+
+// ---- softmax (lstm.cpp:141-149), ByteMixer::ByteUpdate tail (byte-mixer.cpp:27-37), epoch advance
+extern "C" __global__ void cmx_lstm_softmax(LstmState* S, float* out_probs256) {
+  __shared__ float ex[VP];
+  __shared__ float red[256];
+  __shared__ float tot_s;
+  const int tid = threadIdx.x, V = S->V, e = S->epoch;
+  float lg = tid < V ? S->logits[tid] : 0.0f;
+  red[tid] = tid < V ? lg : 0.0f;  // max_out starts at 0 (lstm.cpp:132)
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
+    __syncthreads();
+  }
+  const float mx = red[0];
+  if (tid < V) ex[tid] = cmx_expf(fsub(lg, mx));
+  __syncthreads();
+  if (tid == 0) {  // valarray::sum(): forward from 0
+    float t = 0.0f;
+    for (int i = 0; i < V; ++i) t = fadd(t, ex[i]);
+    tot_s = t;
+  }
+  __syncthreads();
+  if (tid < V) {
+    float p = fdiv(ex[tid], tot_s);
+    S->output[(size_t)e * VP + tid] = p;
+    ex[tid] = p;
+  }
+  __syncthreads();
+  float pb = S->vocab[tid] ? ex[S->byte_map[tid]] : 0.0f;
+  S->byte_probs[tid] = pb;
+  if (out_probs256) out_probs256[tid] = pb;
+  __syncthreads();
+  if (tid == 0) {
+    S->epoch = e + 1 == H ? 0 : e + 1;
+    S->hid_cur ^= 1;
+    S->bytes_done += 1;
+  }
+}
+
+// ---- BPTT, sequential part (lstm.cpp:93-110; lstm-layer.cpp:108-183): one block of 1024 walks
+//      epoch 99..0 x layer 1..0, leaving the final gate errors E[l][g][epoch][.] for the sweep.
+extern "C" __global__ __launch_bounds__(1024) void cmx_lstm_bptt_seq(LstmState* S) {
+  __shared__ float errv[VP];        // softmax-CE error of the epoch
+  __shared__ float herr[C];         // Lstm::hidden_error_
+  __shared__ float gerr[3][C];      // NeuronLayer::error_
+  __shared__ float gprod[3][C];
+  __shared__ float gsm[3];
+  __shared__ float fres[2][3][C];   // matvec results: [stored|hidden][gate][i]
+  const int tid = threadIdx.x, V = S->V;
+  const int j = tid;                // cell index for the element-wise phases
+  float stored[LSTM_L] = {0, 0}, state_err[LSTM_L] = {0, 0};
+  if (tid < C) herr[tid] = 0.0f;    // hidden_error_ is zero on entry (cleared by the last BackwardPass)
+  __syncthreads();
+  for (int epoch = H - 1; epoch >= 0; --epoch) {
+    if (tid < V) {
+      float o = S->output[(size_t)epoch * VP + tid];
+      errv[tid] = ((unsigned)tid == S->input_history[epoch]) ? fsub(o, 1.0f) : o;
+    }
+    if (tid == 0) S->bp_symbol[epoch] = epoch == 0 ? (unsigned)S->old_input : S->input_history[epoch - 1];
+    __syncthreads();
+#pragma unroll
+    for (int layer = LSTM_L - 1; layer >= 0; --layer) {
+      // hidden_error_[j] += output_layer_[epoch][i][j+offset] * error_i, i ascending (lstm.cpp:98-103)
+      if (j < C) {
+        float h = herr[j];
+        const float* ol = S->OL + (size_t)epoch * V * NH + layer * C + j;
+        int i = 0;
+        for (; i + 4 <= V; i += 4) {
+          float a0 = ol[(size_t)(i + 0) * NH], a1 = ol[(size_t)(i + 1) * NH], a2 = ol[(size_t)(i + 2) * NH],
+                a3 = ol[(size_t)(i + 3) * NH];
+          h = fadd(h, fmul(a0, errv[i + 0]));
+          h = fadd(h, fmul(a1, errv[i + 1]));
+          h = fadd(h, fmul(a2, errv[i + 2]));
+          h = fadd(h, fmul(a3, errv[i + 3]));
+        }
+        for (; i < V; ++i) h = fadd(h, fmul(ol[(size_t)i * NH], errv[i]));
+        // LstmLayer::BackwardPass head (lstm-layer.cpp:110-132)
+        const size_t ec = (size_t)epoch * C + j;
+        if (epoch == H - 1) { stored[layer] = h; state_err[layer] = 0.0f; }
+        else stored[layer] = fadd(stored[layer], h);
+        const float th = S->tanh_state[layer][ec], os = S->gstate[layer][2][ec], fs = S->gstate[layer][0][ec],
+                    is = S->gstate[layer][1][ec], igs = S->in_gate_state[layer][ec], ls = S->last_state[layer][ec];
+        float og_e = fmul(fmul(fmul(th, stored[layer]), os), fsub(1.0f, os));
+        state_err[layer] = fadd(state_err[layer], fmul(fmul(stored[layer], os), fsub(1.0f, fmul(th, th))));
+        float in_e = fmul(fmul(state_err[layer], igs), fsub(1.0f, fmul(is, is)));
+        float fg_e = fmul(fmul(fmul(fsub(ls, is), state_err[layer]), fs), igs);
+        gerr[0][j] = fg_e;
+        gerr[1][j] = in_e;
+        gerr[2][j] = og_e;
+        if (epoch > 0) { state_err[layer] = fmul(state_err[layer], fs); stored[layer] = 0.0f; }
+      }
+      if (tid == 0 && epoch == 0 && S->update_steps[layer] < LSTM_UPDATE_LIMIT) S->update_steps[layer] += 1;
+      __syncthreads();
+      // per-gate normalisation backward (lstm-layer.cpp:158-163); thread = (gate, cell)
+      const int g = tid >> 8, c = tid & 255;
+      float myerr = 0.0f, mynorm = 0.0f;
+      if (g < 3 && c < C) {
+        float* gb = S->gb[layer][g];
+        float* gamma_u = gb + 6 * C;
+        float* beta_u = gb + 7 * C;
+        if (epoch == H - 1) { gamma_u[c] = 0.0f; beta_u[c] = 0.0f; }
+        myerr = gerr[g][c];
+        mynorm = S->norm[layer][g][(size_t)epoch * C + c];
+        beta_u[c] = fadd(beta_u[c], myerr);
+        gamma_u[c] = fadd(gamma_u[c], fmul(myerr, mynorm));
+        myerr = fmul(myerr, fmul(gb[c], S->ivar[layer][g][epoch]));
+        gprod[g][c] = fmul(myerr, mynorm);
+      }
+      __syncthreads();
+      if (g < 3 && c == 0) {  // (error_*norm_).sum(): backward
+        float s = gprod[g][C - 1];
+        for (int i = C - 2; i >= 0; --i) s = fadd(s, gprod[g][i]);
+        gsm[g] = fdiv(s, (float)C);
+      }
+      __syncthreads();
+      if (g < 3 && c < C) {
+        myerr = fsub(myerr, fmul(gsm[g], mynorm));
+        gerr[g][c] = myerr;
+        S->E[layer][g][(size_t)epoch * C + c] = myerr;
+      }
+      __syncthreads();
+      // W^T matvecs (lstm-layer.cpp:164-181): f_i = sum_j error_[j] * W[j][col+i], j ascending
+      for (int kind = 0; kind < 2; ++kind) {
+        const bool need = kind == 0 ? epoch > 0 : layer > 0;
+        if (need && g < 3 && c < C) {
+          const int rl = S->rowlen[layer];
+          const float* w = S->W[layer][g] + 2 * V + (kind == 1 ? C : 0) + c;
+          float f = 0.0f;
+          int jj = 0;
+          for (; jj + 4 <= C; jj += 4) {
+            float w0 = w[(size_t)(jj + 0) * rl], w1 = w[(size_t)(jj + 1) * rl], w2 = w[(size_t)(jj + 2) * rl],
+                  w3 = w[(size_t)(jj + 3) * rl];
+            f = fadd(f, fmul(gerr[g][jj + 0], w0));
+            f = fadd(f, fmul(gerr[g][jj + 1], w1));
+            f = fadd(f, fmul(gerr[g][jj + 2], w2));
+            f = fadd(f, fmul(gerr[g][jj + 3], w3));
+          }
+          fres[kind][g][c] = f;
+        }
+      }
+      __syncthreads();
+      if (j < C) {
+        // *hidden_error = 0, then += f per gate in order forget, input node, output (lstm-layer.cpp:126,137-139)
+        float he = 0.0f;
+        if (layer > 0) { he = fadd(he, fres[1][0][j]); he = fadd(he, fres[1][1][j]); he = fadd(he, fres[1][2][j]); }
+        if (epoch > 0) {
+          float se = stored[layer];
+          se = fadd(se, fres[0][0][j]); se = fadd(se, fres[0][1][j]); se = fadd(se, fres[0][2][j]);
+          stored[layer] = se;
+        }
+        // ClipGradients (lstm-layer.cpp:140-142)
+        state_err[layer] = fminf(fmaxf(state_err[layer], -10.0f), 10.0f);
+        stored[layer] = fminf(fmaxf(stored[layer], -10.0f), 10.0f);
+        herr[j] = fminf(fmaxf(he, -10.0f), 10.0f);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ---- BPTT sweep: update_[i][c] accumulated over epochs 99..0 (lstm-layer.cpp:182-186) held in a
+//      register, then Adam (lstm-layer.cpp:11-32) and both weight layouts rewritten.
+//      grid (ceil(rowlen/64), 50, 6): blockIdx.z = layer*3 + gate; block (64, 4) = 64 columns x 4 rows.
+extern "C" __global__ void cmx_lstm_bptt_acc(LstmState* S) {
+  __shared__ float es[H][4];
+  __shared__ float ins[H][64];
+  __shared__ unsigned sym[H];
+  const int layer = blockIdx.z / 3, g = blockIdx.z % 3;
+  const int V = S->V, rl = S->rowlen[layer], insz = S->insz[layer];
+  const int c = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
+  const int t = threadIdx.y * 64 + threadIdx.x;
+  for (int k = t; k < H * 4; k += 256) es[k >> 2][k & 3] = S->E[layer][g][(size_t)(k >> 2) * C + blockIdx.y * 4 + (k & 3)];
+  for (int k = t; k < H * 64; k += 256) {
+    int ee = k >> 6, cc = blockIdx.x * 64 + (k & 63);
+    ins[ee][k & 63] = (cc >= V && cc < rl) ? S->layer_input[layer][(size_t)ee * insz + (cc - V)] : 0.0f;
+  }
+  if (t < H) sym[t] = S->bp_symbol[t];
+  __syncthreads();
+  if (c >= rl) return;
+  float acc = 0.0f;
+  if (c < V) {
+    for (int e = H - 1; e >= 0; --e)
+      if (sym[e] == (unsigned)c) acc = fadd(acc, es[e][threadIdx.y]);
+  } else {
+    for (int e = H - 1; e >= 0; --e) acc = fadd(acc, fmul(es[e][threadIdx.y], ins[e][threadIdx.x]));
+  }
+  const float* tab = S->adam_tab + 4 * S->update_steps[layer];
+  const float alpha = tab[0], b1 = tab[1], b2 = tab[2];
+  const float beta1 = 0.025f, beta2 = 0.9999f, eps = 1e-6f;
+  const size_t ix = (size_t)i * rl + c;
+  float m = S->M[layer][g][ix], v = S->Vv[layer][g][ix], w = S->W[layer][g][ix];
+  m = fmul(m, beta1);
+  m = fadd(m, fmul(fsub(1.0f, beta1), acc));
+  v = fmul(v, beta2);
+  v = fadd(v, fmul(fmul(fsub(1.0f, beta2), acc), acc));
+  w = fsub(w, fmul(alpha, fdiv(fdiv(m, b1), fsqrt(fadd(fdiv(v, b2), eps)))));
+  S->M[layer][g][ix] = m;
+  S->Vv[layer][g][ix] = v;
+  S->W[layer][g][ix] = w;
+  S->WT[layer][g][(size_t)c * C + i] = w;
+}
+
+// ---- Adam for gamma / beta (lstm-layer.cpp:191-195); grid 6 blocks of 256
+extern "C" __global__ void cmx_lstm_bptt_gb(LstmState* S) {
+  const int layer = blockIdx.x / 3, g = blockIdx.x % 3, c = threadIdx.x;
+  if (c >= C) return;
+  float* gb = S->gb[layer][g];
+  const float* tab = S->adam_tab + 4 * S->update_steps[layer];
+  const float alpha = tab[0], b1 = tab[1], b2 = tab[2];
+  const float beta1 = 0.025f, beta2 = 0.9999f, eps = 1e-6f;
+  for (int which = 0; which < 2; ++which) {  // 0: gamma (w 0, m 2, v 3, u 6)   1: beta (w 1, m 4, v 5, u 7)
+    float* w = gb + (which ? 1 : 0) * C;
+    float* m = gb + (which ? 4 : 2) * C;
+    float* v = gb + (which ? 5 : 3) * C;
+    float gr = gb[(which ? 7 : 6) * C + c];
+    float mm = fmul(m[c], beta1);
+    mm = fadd(mm, fmul(fsub(1.0f, beta1), gr));
+    float vv = fmul(v[c], beta2);
+    vv = fadd(vv, fmul(fmul(fsub(1.0f, beta2), gr), gr));
+    w[c] = fsub(w[c], fmul(alpha, fdiv(fdiv(mm, b1), fsqrt(fadd(fdiv(vv, b2), eps)))));
+    m[c] = mm;
+    v[c] = vv;
+  }
+}
+
+// ---- ByteModel::Predict / Perceive along the known bits of a byte (byte-model.cpp:8-37).
+//      One block per byte: dist(n) is the distribution the byte model held while byte n was coded.
+//      Outputs p[n][8] (Model::Predict value per bit) and ex[n][8] (arg-max symbol, `ex`).
+extern "C" __global__ void cmx_bytemodel_bits(const float* dist0, const float* dist_rest, const uint8_t* bytes,
+                                              size_t nbytes, float* p_out, int* ex_out) {
+  __shared__ float pr[256];
+  const size_t n = blockIdx.x;
+  const float* d = n == 0 ? dist0 : dist_rest + (n - 1) * 256;
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) pr[i] = d[i];
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  int top = 255, bot = 0;
+  const int byte = bytes[n];
+  for (int k = 0; k < 8; ++k) {
+    int mid = bot + ((top - bot) / 2);
+    float num = 0.0f;
+    for (int i = mid + 1; i <= top; ++i) num = fadd(num, pr[i]);
+    float denom = num;
+    for (int i = bot; i <= mid; ++i) denom = fadd(denom, pr[i]);
+    int ex = bot;
+    float mx = pr[bot];
+    for (int i = bot + 1; i <= top; ++i)
+      if (pr[i] > mx) { mx = pr[i]; ex = i; }
+    p_out[n * 8 + k] = denom == 0.0f ? 0.5f : fdiv(num, denom);
+    if (ex_out) ex_out[n * 8 + k] = ex;
+    if ((byte >> (7 - k)) & 1) bot = mid + 1;
+    else top = mid;
+  }
+}

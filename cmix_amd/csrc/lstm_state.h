@@ -1,0 +1,56 @@
+// lstm_state.h -- HBM-resident state of one stream's byte-level LSTM byte mixer
+// (reference src/mixer/{lstm,lstm-layer,byte-mixer}.*, src/models/byte-model.*).
+#ifndef CMX_LSTM_STATE_H
+#define CMX_LSTM_STATE_H
+#include <stdint.h>
+
+#define LSTM_C 200     // cells per layer          (predictor.cpp:190)
+#define LSTM_L 2       // layers
+#define LSTM_H 100     // truncated-BPTT horizon
+#define LSTM_NH 401    // hidden_ size = C*L + 1 (bias)
+#define LSTM_VP 256    // padded vocabulary stride
+#define LSTM_UPDATE_LIMIT 3000
+
+struct LstmState {
+  int V;                         // vocabulary size (distinct bytes of the input)
+  int insz[LSTM_L];              // layer_input sizes: 1+C+V, V+1+2C   (lstm.cpp:13-24)
+  int rowlen[LSTM_L];            // gate weight row length = insz + V  (lstm.cpp:27)
+  int epoch;                     // Lstm::epoch_ == every LstmLayer::epoch_
+  int cur_sym, old_input;        // Lstm::Perceive locals for the byte being processed
+  int hid_cur;                   // which of hid[2] holds Lstm::hidden_
+  unsigned long long update_steps[LSTM_L];
+  unsigned long long bytes_done;
+  int byte_map[256];             // byte value -> vocabulary index (byte-mixer.cpp:9-12)
+  unsigned char vocab[256];
+  float lr;                      // 0.03
+
+  // gate parameters, g = 0 forget, 1 input node, 2 output gate
+  float* W[LSTM_L][3];           // [C][rowlen]   reference layout (coalesced for the BPTT matvecs)
+  float* WT[LSTM_L][3];          // [rowlen][C]   transposed copy  (coalesced for the forward chains)
+  float* M[LSTM_L][3];           // Adam first moment  [C][rowlen]
+  float* Vv[LSTM_L][3];          // Adam second moment [C][rowlen]
+  float* gb[LSTM_L][3];          // [8][C]: gamma, beta, gamma_m, gamma_v, beta_m, beta_v, gamma_u, beta_u
+  // per-time-step caches (ring of H)
+  float* norm[LSTM_L][3];        // [H][C]
+  float* gstate[LSTM_L][3];      // [H][C]  activated gate state
+  float* ivar[LSTM_L][3];        // [H]
+  float* last_state[LSTM_L];     // [H][C]
+  float* tanh_state[LSTM_L];     // [H][C]
+  float* in_gate_state[LSTM_L];  // [H][C]
+  float* state[LSTM_L];          // [C]   LstmLayer::state_
+  float* layer_input[LSTM_L];    // [H][insz]
+  float* OL;                     // [H][V][401]   output_layer_
+  float* OLT;                    // [H][401][VP]  transposed copy
+  float* output;                 // [H][VP]       output_
+  float* hid[2];                 // [401] double-buffered hidden_
+  unsigned* input_history;       // [H]
+  unsigned* bp_symbol;           // [H]  input_symbol seen by BackwardPass at each epoch
+  float* raw[LSTM_L][3];         // [C]  pre-normalisation gate sums of the current step
+  float* logits;                 // [VP]
+  float* E[LSTM_L][3];           // [H][C] final gate errors of the current BPTT round
+  const float* adam_tab;         // [3001][4] alpha, 1-beta1^t, 1-beta2^t (host libm)
+  float* byte_probs;             // [256] ByteModel::probs_ of the byte mixer
+  int error;
+};
+
+#endif

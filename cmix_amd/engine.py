@@ -58,6 +58,17 @@ def lib():
         L.cmx_mixnet_bits_done.argtypes = [C.c_void_p, C.c_void_p]
         L.cmx_mixnet_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.cmx_mixnet_last_kernel_ms.argtypes = [C.c_void_p, C.c_void_p]
+        L.cmx_lstm_create.restype = C.c_void_p
+        L.cmx_lstm_create.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.cmx_lstm_destroy.argtypes = [C.c_void_p]
+        L.cmx_lstm_vocab_size.argtypes = [C.c_void_p]
+        L.cmx_lstm_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]
+        L.cmx_bytemodel_bits_run.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                             C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cmx_lstm_get_gate_weights.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.cmx_lstm_gate_rowlen.argtypes = [C.c_void_p, C.c_int]
+        L.cmx_glibc_rand_selftest.argtypes = [C.c_uint32, C.c_int, C.c_void_p]
         L.cmx_probe_libm.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
         _lib = L
     return _lib
@@ -155,3 +166,58 @@ class MixNet:
         if lib().cmx_mixnet_last_kernel_ms(self.h, C.byref(v)):
             raise CmxError(last_error())
         return v.value
+
+
+class Lstm:
+    """Byte-level LSTM byte mixer stage of one stream on one GPU (chunk mode)."""
+    SKIP_RAND = 31
+
+    def __init__(self, vocab, device=0, skip_rand=SKIP_RAND):
+        vocab = np.ascontiguousarray(vocab, np.uint8)
+        assert vocab.size == 256
+        self.h = lib().cmx_lstm_create(vocab.ctypes.data, skip_rand, device)
+        if not self.h:
+            raise CmxError(last_error())
+        self.V = lib().cmx_lstm_vocab_size(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().cmx_lstm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, in_probs, data, want_bits=True, stream=None):
+        """in_probs [N,256] f32 cuda, data [N] u8 cuda -> (out_probs [N,256], bit_p [N,8], bit_ex [N,8])"""
+        import torch
+        N = int(data.numel())
+        assert in_probs.is_cuda and in_probs.dtype == torch.float32 and in_probs.is_contiguous()
+        assert in_probs.numel() == N * 256 and data.dtype == torch.uint8 and data.is_contiguous()
+        out = torch.empty((N, 256), dtype=torch.float32, device=in_probs.device)
+        bp = torch.empty((N, 8), dtype=torch.float32, device=in_probs.device) if want_bits else None
+        bx = torch.empty((N, 8), dtype=torch.int32, device=in_probs.device) if want_bits else None
+        if stream is None:
+            stream = torch.cuda.current_stream(in_probs.device).cuda_stream
+        rc = lib().cmx_lstm_run(self.h, in_probs.data_ptr(), data.data_ptr(), N, out.data_ptr(),
+                                bp.data_ptr() if want_bits else None, bx.data_ptr() if want_bits else None,
+                                C.c_void_p(stream))
+        if rc:
+            raise CmxError(last_error())
+        return out, bp, bx
+
+    def gate_weights(self, layer, gate):
+        n = lib().cmx_lstm_gate_rowlen(self.h, layer)
+        out = np.empty((200, n), np.float32)
+        if lib().cmx_lstm_get_gate_weights(self.h, layer, gate, out.ctypes.data):
+            raise CmxError("cmx_lstm_get_gate_weights failed")
+        return out
+
+
+def glibc_rand(seed, n):
+    out = np.empty(n, np.int32)
+    lib().cmx_glibc_rand_selftest(seed, n, out.ctypes.data)
+    return out

@@ -111,6 +111,39 @@ int cmx_mixnet_profile(cmx_mixnet_t*, int enable, uint64_t* out16);
 int cmx_mixnet_last_kernel_ms(cmx_mixnet_t*, float* ms);
 
 /* ------------------------------------------------------------------------
+ * 2b. Stage: byte-level LSTM byte mixer = ByteMixer + Lstm + LstmLayer + its ByteModel bit
+ *     interface (src/mixer/{byte-mixer,lstm,lstm-layer}.cpp, src/models/byte-model.cpp;
+ *     wired at predictor.cpp:189-191,378-387,450-467)
+ * ------------------------------------------------------------------------ */
+typedef struct cmx_lstm cmx_lstm_t;
+/* vocab as for cmx_create. skip_rand = number of rand() values the reference consumes after
+ * srand(0xDEADBEEF) before it constructs the LSTM (31 in Predictor::Predictor: one per Indirect
+ * model, indirect.cpp:10); the weights are then drawn exactly as lstm-layer.cpp:52-59 does. */
+cmx_lstm_t* cmx_lstm_create(const uint8_t vocab[256], int skip_rand, int device);
+void cmx_lstm_destroy(cmx_lstm_t*);
+int cmx_lstm_vocab_size(const cmx_lstm_t*);
+/* Chunk mode over nbytes already-known bytes. DEVICE pointers:
+ *   d_in_probs  [nbytes][256] f32  the byte model's (PPMd) distribution after each byte
+ *                                  (ByteModel::BytePredict, predictor.cpp:450-457)
+ *   d_bytes     [nbytes]      u8   the bytes coded
+ *   d_out_probs [nbytes][256] f32  OUT: the LSTM's distribution after each byte (ByteMixer::probs_)
+ *   d_bit_p     [nbytes][8]   f32  OUT (may be NULL): ByteModel::Predict value for each bit of byte n,
+ *                                  i.e. layer-0 input 2077 (for n = 0: from the state before this call)
+ *   d_bit_ex    [nbytes][8]   i32  OUT (may be NULL): ByteModel::ex per bit (-> lstmex, predictor.cpp:465)
+ * Asynchronous on `stream`. Truncated BPTT + Adam run every 100 bytes as in lstm.cpp:93-110. */
+int cmx_lstm_run(cmx_lstm_t*, const float* d_in_probs, const uint8_t* d_bytes, size_t nbytes,
+                 float* d_out_probs, float* d_bit_p, int* d_bit_ex, void* stream);
+/* ByteModel::Predict/Perceive for any byte model (PPMd, Bracket, LSTM): per-bit predictions along
+ * the known bytes. dist for byte 0 = d_dist0[256]; for byte n >= 1 = d_dist_rest[(n-1)*256 ...]. */
+int cmx_bytemodel_bits_run(int device, const float* d_dist0, const float* d_dist_rest,
+                           const uint8_t* d_bytes, size_t nbytes, float* d_bit_p, int* d_bit_ex,
+                           void* stream);
+/* Test hooks. */
+int cmx_lstm_get_gate_weights(cmx_lstm_t*, int layer, int gate, float* out_host);
+int cmx_lstm_gate_rowlen(const cmx_lstm_t*, int layer);
+int cmx_glibc_rand_selftest(uint32_t seed, int n, int* out);
+
+/* ------------------------------------------------------------------------
  * Device libm probes (parity tests): evaluate the engine's expf / tanhf /
  * logistic on the device for n host floats. which: 0 expf, 1 tanhf, 2 logistic
  * ------------------------------------------------------------------------ */

@@ -44,3 +44,14 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle" not in txt.replace("-- the oracle", "") or f == "__init__.py" or \
                     "import oracle" not in txt and "from oracle" not in txt and "oracle/" not in txt, f
+
+
+def test_glibc_rand_clone_matches_libc():
+    """The LSTM weight draw re-implements glibc rand() (TYPE_3) so the library never touches the
+    process-global generator; it must reproduce srand(0xDEADBEEF); rand()... exactly."""
+    from cmix_amd import engine as E
+    libc = C.CDLL("libc.so.6")
+    for seed in (0xDEADBEEF, 1, 12345):
+        libc.srand(seed)
+        ref = np.array([libc.rand() for _ in range(5000)], np.int32)
+        assert np.array_equal(ref, E.glibc_rand(seed, 5000))
