@@ -17,15 +17,15 @@
 #include "../../include/cmix_amd.h"
 #include "lstm_state.h"
 
-extern "C" __global__ void cmx_lstm_prep(LstmState*, const float*, const uint8_t*, size_t);
-extern "C" __global__ void cmx_lstm_sgd(LstmState*);
-extern "C" __global__ void cmx_lstm_gate_fwd(LstmState*, int);
-extern "C" __global__ void cmx_lstm_cell(LstmState*, int);
-extern "C" __global__ void cmx_lstm_out(LstmState*);
-extern "C" __global__ void cmx_lstm_softmax(LstmState*, float*);
-extern "C" __global__ void cmx_lstm_bptt_seq(LstmState*);
-extern "C" __global__ void cmx_lstm_bptt_acc(LstmState*);
-extern "C" __global__ void cmx_lstm_bptt_gb(LstmState*);
+extern "C" __global__ void cmx_lstm_prep(const LstmState, const float*, const uint8_t*, size_t, int);
+extern "C" __global__ void cmx_lstm_sgd(const LstmState, const uint8_t*, size_t, int, int);
+extern "C" __global__ void cmx_lstm_gate_fwd(const LstmState, int, const uint8_t*, size_t, int, int);
+extern "C" __global__ void cmx_lstm_cell(const LstmState, int, int, int);
+extern "C" __global__ void cmx_lstm_out(const LstmState, int, int);
+extern "C" __global__ void cmx_lstm_softmax(const LstmState, float*, int);
+extern "C" __global__ void cmx_lstm_bptt_seq(const LstmState);
+extern "C" __global__ void cmx_lstm_bptt_acc(const LstmState, int);
+extern "C" __global__ void cmx_lstm_bptt_gb(const LstmState, int);
 extern "C" __global__ void cmx_bytemodel_bits(const float*, const float*, const uint8_t*, size_t, float*, int*);
 
 void cmx_set_err(const std::string& s);  // cmx_api.hip
@@ -62,11 +62,11 @@ struct GlibcRand {
 
 struct cmx_lstm {
   int device = 0;
-  LstmState h_state;
-  LstmState* d_state = nullptr;
+  LstmState h_state;   // passed to every kernel by value
   std::vector<void*> allocs;
   float* d_prev_probs = nullptr;  // byte distribution at chunk start
   uint64_t bytes_done = 0;
+  uint64_t bptt_rounds = 0;  // LstmLayer::update_steps_ = min(rounds, 3000) (lstm-layer.cpp:131-133)
 };
 
 extern "C" {
@@ -198,15 +198,12 @@ cmx_lstm_t* cmx_lstm_create(const uint8_t vocab[256], int skip_rand, int device)
     S.byte_probs = dallocf(256, bp.data());
     h->d_prev_probs = dallocf(256, bp.data());
   }
-  void* ds = nullptr;
-  if (fail || hipMalloc(&ds, sizeof(LstmState)) != hipSuccess) {
+  S.dyn = (int*)dallocf(4, nullptr);
+  if (fail) {
     cmx_set_err("cmx_lstm_create: hipMalloc failed");
     cmx_lstm_destroy(h);
     return nullptr;
   }
-  h->allocs.push_back(ds);
-  h->d_state = (LstmState*)ds;
-  (void)hipMemcpy(ds, &S, sizeof S, hipMemcpyHostToDevice);
   if (hipDeviceSynchronize() != hipSuccess) { cmx_set_err("cmx_lstm_create: init failed"); cmx_lstm_destroy(h); return nullptr; }
   return h;
 }
@@ -219,25 +216,27 @@ int cmx_lstm_run(cmx_lstm_t* h, const float* d_in_probs, const uint8_t* d_bytes,
   if (nbytes == 0) return 0;
   if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
   hipStream_t st = (hipStream_t)stream;
-  LstmState* S = h->d_state;
-  const int V = h->h_state.V;
-  (void)hipMemcpyAsync(h->d_prev_probs, h->h_state.byte_probs, 256 * 4, hipMemcpyDeviceToDevice, st);
+  const LstmState& S = h->h_state;
+  const int V = S.V;
+  (void)hipMemcpyAsync(h->d_prev_probs, S.byte_probs, 256 * 4, hipMemcpyDeviceToDevice, st);
   for (size_t n = 0; n < nbytes; ++n) {
-    const bool bptt = (h->bytes_done % LSTM_H) == 0;  // Lstm::epoch_ == 0 (lstm.cpp:93)
-    hipLaunchKernelGGL(cmx_lstm_prep, dim3(1), dim3(256), 0, st, S, d_in_probs + n * 256, d_bytes, n);
-    if (bptt) {
+    const int e = (int)(h->bytes_done % LSTM_H);   // Lstm::epoch_
+    const int hc = (int)(h->bytes_done & 1);       // which hid[] buffer holds hidden_
+    hipLaunchKernelGGL(cmx_lstm_prep, dim3(1), dim3(256), 0, st, S, d_in_probs + n * 256, d_bytes, n, e);
+    if (e == 0) {                                  // lstm.cpp:93
+      h->bptt_rounds += 1;
+      const int us = (int)(h->bptt_rounds < LSTM_UPDATE_LIMIT ? h->bptt_rounds : LSTM_UPDATE_LIMIT);
       hipLaunchKernelGGL(cmx_lstm_bptt_seq, dim3(1), dim3(1024), 0, st, S);
-      const int maxrl = h->h_state.rowlen[1];
-      hipLaunchKernelGGL(cmx_lstm_bptt_acc, dim3((maxrl + 63) / 64, LSTM_C / 4, 6), dim3(64, 4), 0, st, S);
-      hipLaunchKernelGGL(cmx_lstm_bptt_gb, dim3(6), dim3(256), 0, st, S);
+      hipLaunchKernelGGL(cmx_lstm_bptt_acc, dim3((S.rowlen[1] + 63) / 64, LSTM_C / 4, 6), dim3(64, 4), 0, st, S, us);
+      hipLaunchKernelGGL(cmx_lstm_bptt_gb, dim3(6), dim3(256), 0, st, S, us);
     }
-    hipLaunchKernelGGL(cmx_lstm_sgd, dim3((V * LSTM_NH + 255) / 256), dim3(256), 0, st, S);
-    hipLaunchKernelGGL(cmx_lstm_gate_fwd, dim3(4, 3), dim3(64), 0, st, S, 0);
-    hipLaunchKernelGGL(cmx_lstm_cell, dim3(1), dim3(256), 0, st, S, 0);
-    hipLaunchKernelGGL(cmx_lstm_gate_fwd, dim3(4, 3), dim3(64), 0, st, S, 1);
-    hipLaunchKernelGGL(cmx_lstm_cell, dim3(1), dim3(256), 0, st, S, 1);
-    hipLaunchKernelGGL(cmx_lstm_out, dim3((V + 63) / 64), dim3(64), 0, st, S);
-    hipLaunchKernelGGL(cmx_lstm_softmax, dim3(1), dim3(256), 0, st, S, d_out_probs ? d_out_probs + n * 256 : nullptr);
+    hipLaunchKernelGGL(cmx_lstm_sgd, dim3((V * LSTM_NH + 255) / 256), dim3(256), 0, st, S, d_bytes, n, e, hc);
+    hipLaunchKernelGGL(cmx_lstm_gate_fwd, dim3(4, 3), dim3(64), 0, st, S, 0, d_bytes, n, e, hc);
+    hipLaunchKernelGGL(cmx_lstm_cell, dim3(1), dim3(256), 0, st, S, 0, e, hc);
+    hipLaunchKernelGGL(cmx_lstm_gate_fwd, dim3(4, 3), dim3(64), 0, st, S, 1, d_bytes, n, e, hc);
+    hipLaunchKernelGGL(cmx_lstm_cell, dim3(1), dim3(256), 0, st, S, 1, e, hc);
+    hipLaunchKernelGGL(cmx_lstm_out, dim3((V + 63) / 64), dim3(64), 0, st, S, e, hc);
+    hipLaunchKernelGGL(cmx_lstm_softmax, dim3(1), dim3(256), 0, st, S, d_out_probs ? d_out_probs + n * 256 : nullptr, e);
     h->bytes_done += 1;
   }
   if (d_bit_p) {

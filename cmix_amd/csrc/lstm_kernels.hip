@@ -34,8 +34,9 @@ constexpr int C = LSTM_C, H = LSTM_H, NH = LSTM_NH, VP = LSTM_VP;
 
 // ---- ByteMixer::SetInput/ByteUpdate head + Lstm::Perceive bookkeeping (byte-mixer.cpp:15-26,
 //      lstm.cpp:80-92). in256 = the byte model's distribution, byte = the byte just coded.
-extern "C" __global__ void cmx_lstm_prep(LstmState* S, const float* in256, const uint8_t* bytes, size_t n) {
-  const int tid = threadIdx.x, e = S->epoch, V = S->V;
+extern "C" __global__ void cmx_lstm_prep(const LstmState P, const float* in256, const uint8_t* bytes, size_t n, int e) {
+  const LstmState* S = &P;
+  const int tid = threadIdx.x, V = S->V;
   if (S->vocab[tid]) {
     float v = fmul(in256[tid], 2.0f);  // inputs_ (0 + val) *= 2 / num_models_  (unsigned division = 2)
     int k = S->byte_map[tid];
@@ -45,23 +46,24 @@ extern "C" __global__ void cmx_lstm_prep(LstmState* S, const float* in256, const
   if (tid == 0) {
     int sym = S->byte_map[bytes[n]];
     int last = e == 0 ? H - 1 : e - 1;
-    S->old_input = (int)S->input_history[last];
+    S->dyn[0] = (int)S->input_history[last];  // old_input (lstm.cpp:90)
     S->input_history[last] = (unsigned)sym;
-    S->cur_sym = sym;
   }
   (void)V;
 }
 
 // ---- output layer SGD (lstm.cpp:112-116): slot[e] = slot[last] - (lr*err_i)*hidden_, both layouts
-extern "C" __global__ void cmx_lstm_sgd(LstmState* S) {
-  const int V = S->V, e = S->epoch, last = e == 0 ? H - 1 : e - 1;
+extern "C" __global__ void cmx_lstm_sgd(const LstmState P, const uint8_t* bytes, size_t n, int e, int hid_cur) {
+  const LstmState* S = &P;
+  const int V = S->V, last = e == 0 ? H - 1 : e - 1;
+  const int cur_sym = S->byte_map[bytes[n]];
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= V * NH) return;
   const int i = idx / NH, j = idx - i * NH;
   float o = S->output[(size_t)last * VP + i];
-  float err = (i == S->cur_sym) ? fsub(o, 1.0f) : o;
+  float err = (i == cur_sym) ? fsub(o, 1.0f) : o;
   float le = fmul(S->lr, err);
-  const float* hid = S->hid[S->hid_cur];
+  const float* hid = S->hid[hid_cur];
   float v = fsub(S->OL[((size_t)last * V + i) * NH + j], fmul(le, hid[j]));
   S->OL[((size_t)e * V + i) * NH + j] = v;
   S->OLT[((size_t)e * NH + j) * VP + i] = v;
@@ -69,11 +71,13 @@ extern "C" __global__ void cmx_lstm_sgd(LstmState* S) {
 
 // ---- LstmLayer::ForwardPass(NeuronLayer&) dot products (lstm-layer.cpp:85-92):
 //      grid (4, 3): blockIdx.y = gate, 64 cells per block; one ordered chain per lane.
-extern "C" __global__ void cmx_lstm_gate_fwd(LstmState* S, int layer) {
+extern "C" __global__ void cmx_lstm_gate_fwd(const LstmState P, int layer, const uint8_t* bytes, size_t n, int e, int hid_cur) {
+  const LstmState* S = &P;
   __shared__ float in[832];
-  const int V = S->V, e = S->epoch, insz = S->insz[layer], g = blockIdx.y;
-  const float* hold = S->hid[S->hid_cur];
-  const float* hnew = S->hid[S->hid_cur ^ 1];
+  const int V = S->V, insz = S->insz[layer], g = blockIdx.y;
+  const int cur_sym = S->byte_map[bytes[n]];
+  const float* hold = S->hid[hid_cur];
+  const float* hnew = S->hid[hid_cur ^ 1];
   float* li = S->layer_input[layer] + (size_t)e * insz;
   for (int j = threadIdx.x; j < insz; j += blockDim.x) {
     float v;
@@ -88,31 +92,26 @@ extern "C" __global__ void cmx_lstm_gate_fwd(LstmState* S, int layer) {
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= C) return;
   const float* wt = S->WT[layer][g];
-  float f = wt[(size_t)S->cur_sym * C + i];
+  float f = wt[(size_t)cur_sym * C + i];
   const float* wj = wt + (size_t)V * C + i;
   int j = 0;
-  for (; j + 8 <= insz; j += 8) {
-    float w0 = wj[(size_t)(j + 0) * C], w1 = wj[(size_t)(j + 1) * C], w2 = wj[(size_t)(j + 2) * C],
-          w3 = wj[(size_t)(j + 3) * C], w4 = wj[(size_t)(j + 4) * C], w5 = wj[(size_t)(j + 5) * C],
-          w6 = wj[(size_t)(j + 6) * C], w7 = wj[(size_t)(j + 7) * C];
-    f = fadd(f, fmul(in[j + 0], w0));
-    f = fadd(f, fmul(in[j + 1], w1));
-    f = fadd(f, fmul(in[j + 2], w2));
-    f = fadd(f, fmul(in[j + 3], w3));
-    f = fadd(f, fmul(in[j + 4], w4));
-    f = fadd(f, fmul(in[j + 5], w5));
-    f = fadd(f, fmul(in[j + 6], w6));
-    f = fadd(f, fmul(in[j + 7], w7));
+  for (; j + 32 <= insz; j += 32) {   // 32 independent loads in flight per lane, then the ordered chain
+    float w[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) w[k] = wj[(size_t)(j + k) * C];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) f = fadd(f, fmul(in[j + k], w[k]));
   }
   for (; j < insz; ++j) f = fadd(f, fmul(in[j], wj[(size_t)j * C]));
   S->raw[layer][g][i] = f;
 }
 
 // ---- RMS norm, activations, cell update (lstm-layer.cpp:62-83, 93-98). One block of 256.
-extern "C" __global__ void cmx_lstm_cell(LstmState* S, int layer) {
+extern "C" __global__ void cmx_lstm_cell(const LstmState P, int layer, int e, int hid_cur) {
+  const LstmState* S = &P;
   __shared__ float raw[3][C];
   __shared__ float ivar_s[3];
-  const int tid = threadIdx.x, e = S->epoch;
+  const int tid = threadIdx.x;
   if (tid < C)
     for (int g = 0; g < 3; ++g) raw[g][tid] = S->raw[layer][g][tid];
   __syncthreads();
@@ -147,14 +146,15 @@ extern "C" __global__ void cmx_lstm_cell(LstmState* S, int layer) {
   S->state[layer][tid] = state;
   float th = cmx_tanhf(state);
   S->tanh_state[layer][(size_t)e * C + tid] = th;
-  S->hid[S->hid_cur ^ 1][layer * C + tid] = fmul(og, th);
+  S->hid[hid_cur ^ 1][layer * C + tid] = fmul(og, th);
 }
 
 // ---- output layer matvec (lstm.cpp:132-140): one ordered 401-term chain per vocabulary symbol
-extern "C" __global__ void cmx_lstm_out(LstmState* S) {
+extern "C" __global__ void cmx_lstm_out(const LstmState P, int e, int hid_cur) {
+  const LstmState* S = &P;
   __shared__ float hid[NH];
-  const int V = S->V, e = S->epoch;
-  const float* hnew = S->hid[S->hid_cur ^ 1];
+  const int V = S->V;
+  const float* hnew = S->hid[hid_cur ^ 1];
   for (int j = threadIdx.x; j < NH; j += blockDim.x) hid[j] = hnew[j];
   __syncthreads();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -162,29 +162,24 @@ extern "C" __global__ void cmx_lstm_out(LstmState* S) {
   const float* ot = S->OLT + (size_t)e * NH * VP + i;
   float sum = 0.0f;
   int j = 0;
-  for (; j + 8 <= NH; j += 8) {
-    float w0 = ot[(size_t)(j + 0) * VP], w1 = ot[(size_t)(j + 1) * VP], w2 = ot[(size_t)(j + 2) * VP],
-          w3 = ot[(size_t)(j + 3) * VP], w4 = ot[(size_t)(j + 4) * VP], w5 = ot[(size_t)(j + 5) * VP],
-          w6 = ot[(size_t)(j + 6) * VP], w7 = ot[(size_t)(j + 7) * VP];
-    sum = fadd(sum, fmul(hid[j + 0], w0));
-    sum = fadd(sum, fmul(hid[j + 1], w1));
-    sum = fadd(sum, fmul(hid[j + 2], w2));
-    sum = fadd(sum, fmul(hid[j + 3], w3));
-    sum = fadd(sum, fmul(hid[j + 4], w4));
-    sum = fadd(sum, fmul(hid[j + 5], w5));
-    sum = fadd(sum, fmul(hid[j + 6], w6));
-    sum = fadd(sum, fmul(hid[j + 7], w7));
+  for (; j + 32 <= NH; j += 32) {
+    float w[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) w[k] = ot[(size_t)(j + k) * VP];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) sum = fadd(sum, fmul(hid[j + k], w[k]));
   }
   for (; j < NH; ++j) sum = fadd(sum, fmul(hid[j], ot[(size_t)j * VP]));
   S->logits[i] = sum;
 }
 
 // ---- softmax (lstm.cpp:141-149), ByteMixer::ByteUpdate tail (byte-mixer.cpp:27-37), epoch advance
-extern "C" __global__ void cmx_lstm_softmax(LstmState* S, float* out_probs256) {
+extern "C" __global__ void cmx_lstm_softmax(const LstmState P, float* out_probs256, int e) {
+  const LstmState* S = &P;
   __shared__ float ex[VP];
   __shared__ float red[256];
   __shared__ float tot_s;
-  const int tid = threadIdx.x, V = S->V, e = S->epoch;
+  const int tid = threadIdx.x, V = S->V;
   float lg = tid < V ? S->logits[tid] : 0.0f;
   red[tid] = tid < V ? lg : 0.0f;  // max_out starts at 0 (lstm.cpp:132)
   __syncthreads();
@@ -210,17 +205,12 @@ extern "C" __global__ void cmx_lstm_softmax(LstmState* S, float* out_probs256) {
   float pb = S->vocab[tid] ? ex[S->byte_map[tid]] : 0.0f;
   S->byte_probs[tid] = pb;
   if (out_probs256) out_probs256[tid] = pb;
-  __syncthreads();
-  if (tid == 0) {
-    S->epoch = e + 1 == H ? 0 : e + 1;
-    S->hid_cur ^= 1;
-    S->bytes_done += 1;
-  }
 }
 
 // ---- BPTT, sequential part (lstm.cpp:93-110; lstm-layer.cpp:108-183): one block of 1024 walks
 //      epoch 99..0 x layer 1..0, leaving the final gate errors E[l][g][epoch][.] for the sweep.
-extern "C" __global__ __launch_bounds__(1024) void cmx_lstm_bptt_seq(LstmState* S) {
+extern "C" __global__ __launch_bounds__(1024) void cmx_lstm_bptt_seq(const LstmState P) {
+  const LstmState* S = &P;
   __shared__ float errv[VP];        // softmax-CE error of the epoch
   __shared__ float herr[C];         // Lstm::hidden_error_
   __shared__ float gerr[3][C];      // NeuronLayer::error_
@@ -237,7 +227,7 @@ extern "C" __global__ __launch_bounds__(1024) void cmx_lstm_bptt_seq(LstmState* 
       float o = S->output[(size_t)epoch * VP + tid];
       errv[tid] = ((unsigned)tid == S->input_history[epoch]) ? fsub(o, 1.0f) : o;
     }
-    if (tid == 0) S->bp_symbol[epoch] = epoch == 0 ? (unsigned)S->old_input : S->input_history[epoch - 1];
+    if (tid == 0) S->bp_symbol[epoch] = epoch == 0 ? (unsigned)S->dyn[0] : S->input_history[epoch - 1];
     __syncthreads();
 #pragma unroll
     for (int layer = LSTM_L - 1; layer >= 0; --layer) {
@@ -246,13 +236,12 @@ extern "C" __global__ __launch_bounds__(1024) void cmx_lstm_bptt_seq(LstmState* 
         float h = herr[j];
         const float* ol = S->OL + (size_t)epoch * V * NH + layer * C + j;
         int i = 0;
-        for (; i + 4 <= V; i += 4) {
-          float a0 = ol[(size_t)(i + 0) * NH], a1 = ol[(size_t)(i + 1) * NH], a2 = ol[(size_t)(i + 2) * NH],
-                a3 = ol[(size_t)(i + 3) * NH];
-          h = fadd(h, fmul(a0, errv[i + 0]));
-          h = fadd(h, fmul(a1, errv[i + 1]));
-          h = fadd(h, fmul(a2, errv[i + 2]));
-          h = fadd(h, fmul(a3, errv[i + 3]));
+        for (; i + 16 <= V; i += 16) {
+          float a[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) a[k] = ol[(size_t)(i + k) * NH];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) h = fadd(h, fmul(a[k], errv[i + k]));
         }
         for (; i < V; ++i) h = fadd(h, fmul(ol[(size_t)i * NH], errv[i]));
         // LstmLayer::BackwardPass head (lstm-layer.cpp:110-132)
@@ -270,7 +259,6 @@ extern "C" __global__ __launch_bounds__(1024) void cmx_lstm_bptt_seq(LstmState* 
         gerr[2][j] = og_e;
         if (epoch > 0) { state_err[layer] = fmul(state_err[layer], fs); stored[layer] = 0.0f; }
       }
-      if (tid == 0 && epoch == 0 && S->update_steps[layer] < LSTM_UPDATE_LIMIT) S->update_steps[layer] += 1;
       __syncthreads();
       // per-gate normalisation backward (lstm-layer.cpp:158-163); thread = (gate, cell)
       const int g = tid >> 8, c = tid & 255;
@@ -307,14 +295,12 @@ extern "C" __global__ __launch_bounds__(1024) void cmx_lstm_bptt_seq(LstmState* 
           const int rl = S->rowlen[layer];
           const float* w = S->W[layer][g] + 2 * V + (kind == 1 ? C : 0) + c;
           float f = 0.0f;
-          int jj = 0;
-          for (; jj + 4 <= C; jj += 4) {
-            float w0 = w[(size_t)(jj + 0) * rl], w1 = w[(size_t)(jj + 1) * rl], w2 = w[(size_t)(jj + 2) * rl],
-                  w3 = w[(size_t)(jj + 3) * rl];
-            f = fadd(f, fmul(gerr[g][jj + 0], w0));
-            f = fadd(f, fmul(gerr[g][jj + 1], w1));
-            f = fadd(f, fmul(gerr[g][jj + 2], w2));
-            f = fadd(f, fmul(gerr[g][jj + 3], w3));
+          for (int jj = 0; jj < C; jj += 20) {   // C = 200 = 10 x 20
+            float wv[20];
+#pragma unroll
+            for (int k = 0; k < 20; ++k) wv[k] = w[(size_t)(jj + k) * rl];
+#pragma unroll
+            for (int k = 0; k < 20; ++k) f = fadd(f, fmul(gerr[g][jj + k], wv[k]));
           }
           fres[kind][g][c] = f;
         }
@@ -342,7 +328,8 @@ extern "C" __global__ __launch_bounds__(1024) void cmx_lstm_bptt_seq(LstmState* 
 // ---- BPTT sweep: update_[i][c] accumulated over epochs 99..0 (lstm-layer.cpp:182-186) held in a
 //      register, then Adam (lstm-layer.cpp:11-32) and both weight layouts rewritten.
 //      grid (ceil(rowlen/64), 50, 6): blockIdx.z = layer*3 + gate; block (64, 4) = 64 columns x 4 rows.
-extern "C" __global__ void cmx_lstm_bptt_acc(LstmState* S) {
+extern "C" __global__ void cmx_lstm_bptt_acc(const LstmState P, int update_steps) {
+  const LstmState* S = &P;
   __shared__ float es[H][4];
   __shared__ float ins[H][64];
   __shared__ unsigned sym[H];
@@ -365,7 +352,7 @@ extern "C" __global__ void cmx_lstm_bptt_acc(LstmState* S) {
   } else {
     for (int e = H - 1; e >= 0; --e) acc = fadd(acc, fmul(es[e][threadIdx.y], ins[e][threadIdx.x]));
   }
-  const float* tab = S->adam_tab + 4 * S->update_steps[layer];
+  const float* tab = S->adam_tab + 4 * update_steps;
   const float alpha = tab[0], b1 = tab[1], b2 = tab[2];
   const float beta1 = 0.025f, beta2 = 0.9999f, eps = 1e-6f;
   const size_t ix = (size_t)i * rl + c;
@@ -382,11 +369,12 @@ extern "C" __global__ void cmx_lstm_bptt_acc(LstmState* S) {
 }
 
 // ---- Adam for gamma / beta (lstm-layer.cpp:191-195); grid 6 blocks of 256
-extern "C" __global__ void cmx_lstm_bptt_gb(LstmState* S) {
+extern "C" __global__ void cmx_lstm_bptt_gb(const LstmState P, int update_steps) {
+  const LstmState* S = &P;
   const int layer = blockIdx.x / 3, g = blockIdx.x % 3, c = threadIdx.x;
   if (c >= C) return;
   float* gb = S->gb[layer][g];
-  const float* tab = S->adam_tab + 4 * S->update_steps[layer];
+  const float* tab = S->adam_tab + 4 * update_steps;
   const float alpha = tab[0], b1 = tab[1], b2 = tab[2];
   const float beta1 = 0.025f, beta2 = 0.9999f, eps = 1e-6f;
   for (int which = 0; which < 2; ++which) {  // 0: gamma (w 0, m 2, v 3, u 6)   1: beta (w 1, m 4, v 5, u 7)

@@ -15,11 +15,10 @@ struct LstmState {
   int V;                         // vocabulary size (distinct bytes of the input)
   int insz[LSTM_L];              // layer_input sizes: 1+C+V, V+1+2C   (lstm.cpp:13-24)
   int rowlen[LSTM_L];            // gate weight row length = insz + V  (lstm.cpp:27)
-  int epoch;                     // Lstm::epoch_ == every LstmLayer::epoch_
-  int cur_sym, old_input;        // Lstm::Perceive locals for the byte being processed
-  int hid_cur;                   // which of hid[2] holds Lstm::hidden_
-  unsigned long long update_steps[LSTM_L];
-  unsigned long long bytes_done;
+  // Passed to the kernels BY VALUE (kernarg segment -> scalar loads); everything that changes per
+  // byte and is known to the host (epoch = bytes_done % 100, the hidden_ double-buffer index,
+  // LstmLayer::update_steps_) is a plain kernel argument instead of a device-memory field.
+  int* dyn;                      // [4] device scalars: [0] = old_input of the current Perceive
   int byte_map[256];             // byte value -> vocabulary index (byte-mixer.cpp:9-12)
   unsigned char vocab[256];
   float lr;                      // 0.03
@@ -50,7 +49,6 @@ struct LstmState {
   float* E[LSTM_L][3];           // [H][C] final gate errors of the current BPTT round
   const float* adam_tab;         // [3001][4] alpha, 1-beta1^t, 1-beta2^t (host libm)
   float* byte_probs;             // [256] ByteModel::probs_ of the byte mixer
-  int error;
 };
 
 #endif
