@@ -60,6 +60,17 @@ def lib():
         L.orc_lstm_probs.restype = C.POINTER(C.c_float)
         L.orc_lstm_probs.argtypes = [C.c_void_p]
         L.orc_lstm_ex.argtypes = [C.c_void_p]
+        L.orc_ctx_create.restype = C.c_void_p
+        L.orc_ctx_create.argtypes = [C.c_void_p]
+        L.orc_ctx_destroy.argtypes = [C.c_void_p]
+        L.orc_ctx_predict.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_ctx_perceive.argtypes = [C.c_void_p, C.c_int]
+        L.orc_ctx_get_manager.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_ctx_bracket_probs.restype = C.POINTER(C.c_float)
+        L.orc_ctx_bracket_probs.argtypes = [C.c_void_p]
+        L.orc_ctx_indirect_offset.restype = C.c_uint64
+        L.orc_ctx_indirect_offset.argtypes = [C.c_void_p, C.c_int]
+        L.orc_ctx_model_column.argtypes = [C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
@@ -172,3 +183,55 @@ class Lstm:
         if getattr(self, "h", None):
             lib().orc_lstm_destroy(self.h)
             self.h = None
+
+
+SMALL_COLS = np.array([0, 1, 2] + list(range(2025, 2076)))  # layer-0 columns of the 54 small models
+
+
+class CtxModels:
+    """ContextManager + contexts + the 54 small native models. run(bytes) walks Predict/Perceive."""
+
+    def __init__(self, vocab):
+        vocab = np.ascontiguousarray(vocab, np.uint8)
+        self.h = lib().orc_ctx_create(vocab.ctypes.data)
+
+    def predict(self, want_sel=True):
+        p = np.empty(54, np.float32)
+        s = np.empty(47, np.uint64)
+        lib().orc_ctx_predict(self.h, p.ctypes.data, s.ctypes.data if want_sel else None)
+        return p, s
+
+    def perceive(self, bit):
+        lib().orc_ctx_perceive(self.h, int(bit))
+
+    def manager(self):
+        regs = np.empty(25, np.uint64)
+        ctx = np.empty(54, np.uint64)
+        bctx = np.empty(8, np.uint64)
+        lib().orc_ctx_get_manager(self.h, regs.ctypes.data, ctx.ctypes.data, bctx.ctypes.data)
+        return regs, ctx, bctx
+
+    def bracket_probs(self):
+        return np.ctypeslib.as_array(lib().orc_ctx_bracket_probs(self.h), shape=(256,)).copy()
+
+    def run(self, data):
+        """data: bytes -> (probs [T,54] f32, sel [T,47] u64, bracket byte dists [N+1,256])"""
+        data = np.frombuffer(bytes(data), np.uint8)
+        T = 8 * len(data)
+        probs = np.empty((T, 54), np.float32)
+        sel = np.empty((T, 47), np.uint64)
+        t = 0
+        for byte in data:
+            for j in range(7, -1, -1):
+                probs[t], sel[t] = self.predict()
+                self.perceive((int(byte) >> j) & 1)
+                t += 1
+        return probs, sel
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().orc_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()

@@ -36,6 +36,9 @@
 #include "mixer/lstm.h"
 #include "mixer/byte-mixer.h"
 #include "models/byte-model.h"
+#include "contexts/interval.h"
+#include "contexts/interval-hash.h"
+#include "states/nonstationary.h"
 #undef private
 #undef protected
 
@@ -200,6 +203,24 @@ int ref_lstm_output_layer(int epoch, float* out) {
   for (size_t i = 0; i < l->output_layer_[epoch].size(); ++i)
     for (size_t j = 0; j < l->output_layer_[epoch][i].size(); ++j) out[k++] = l->output_layer_[epoch][i][j];
   return (int)k;
+}
+
+// Reference DATA tables (dumped by oracle/gen_ref_tables.py, never transcribed by hand):
+// the Nonstationary transition table (src/states/nonstationary.cpp:3) ...
+int ref_nonstationary_table(uint8_t* out512) {
+  for (int s = 0; s < 256; ++s)
+    for (int b = 0; b < 2; ++b) out512[2 * s + b] = (uint8_t)g_p->manager_.nonstationary_.Next(s, b);
+  return 512;
+}
+// ... and the byte-class map an Interval / IntervalHash context was built with (predictor.cpp:230-304).
+int ref_interval_map(int ctx_index, int* out256) {
+  Context* c = g_p->manager_.contexts_[ctx_index].get();
+  const std::vector<int>* m = nullptr;
+  if (Interval* i = dynamic_cast<Interval*>(c)) m = &i->map_;
+  else if (IntervalHash* h = dynamic_cast<IntervalHash*>(c)) m = &h->map_;
+  if (!m) return -1;
+  for (int i = 0; i < 256; ++i) out256[i] = (*m)[i];
+  return 256;
 }
 
 // libm probes: the exact host functions the reference's float path resolves to,

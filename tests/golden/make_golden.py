@@ -19,6 +19,9 @@ Each trace records, per coded bit, what Predictor::Predict() saw and produced
     bitctx      [T,8]     u64  bit-level contexts at Predict() time
     ppmd_probs  [N+1,256] f32  PPMd byte distribution after each byte
     lstm_probs  [N+1,256] f32  LSTM byte distribution after each byte
+    bracket_probs [N+1,256] f32 Bracket model byte distribution after each byte
+    small_probs [T,56]    f32  (traces without probs_q) layer-0 columns 0,1,2,2025..2077: the 54 small
+                               native models, the PPMd and the LSTM bit predictions
 The reference Predictor is one-per-process, so every trace is produced in a
 fresh subprocess.
 """
@@ -33,6 +36,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 GRID = np.float32(1.0 / 4095)
+SMALL_COLS = np.array([0, 1, 2] + list(range(2025, 2078)))
 
 
 def text_block(payload: bytes) -> bytes:
@@ -63,9 +67,12 @@ def trace(stream: bytes, full=True):
     ctx = np.empty((N + 1, r.n_ctx), np.uint64)
     ppmd = np.empty((N + 1, 256), np.float32)
     lstm = np.empty((N + 1, 256), np.float32)
+    brk = np.empty((N + 1, 256), np.float32)
+    small = None if full else np.empty((T, len(SMALL_COLS)), np.float32)
     regs[0], ctx[0], _ = r.manager()
     ppmd[0] = r.byte_probs(0)[0]
     lstm[0] = r.byte_probs(1)[0]
+    brk[0] = r.byte_probs(2)[0]
     t = 0
     for n, byte in enumerate(stream):
         for j in range(7, -1, -1):
@@ -73,6 +80,8 @@ def trace(stream: bytes, full=True):
             p_final[t] = r.predict()
             if full:
                 probs[t] = r.model_probs()
+            else:
+                small[t] = r.model_probs()[SMALL_COLS]
             c0, o0 = r.mixers(0)
             c1, o1 = r.mixers(1)
             c2, o2 = r.mixers(2)
@@ -85,9 +94,12 @@ def trace(stream: bytes, full=True):
         regs[n + 1], ctx[n + 1], _ = r.manager()
         ppmd[n + 1] = r.byte_probs(0)[0]
         lstm[n + 1] = r.byte_probs(1)[0]
+        brk[n + 1] = r.byte_probs(2)[0]
     out = dict(stream=np.frombuffer(stream, np.uint8), bits=bits, p_final=p_final, sel=sel,
                mix_out=mix_out, bitctx=bitctx, regs=regs, ctx=ctx, ppmd_probs=ppmd,
-               lstm_probs=lstm, vocab=R.vocab_of(stream), ctx_sizes=r.context_sizes())
+               lstm_probs=lstm, bracket_probs=brk, vocab=R.vocab_of(stream), ctx_sizes=r.context_sizes())
+    if not full:
+        out["small_probs"] = small
     if full:
         q = np.rint(probs / GRID).astype(np.int64)
         on = (q >= 0) & (q <= 4095) & ((q.astype(np.float32) * GRID) == probs)
@@ -111,6 +123,13 @@ def _child(kind, nbytes, seed, path, full):
     if kind == "text":
         payload = synth.enwik_like(nbytes + 4096, seed)[4096:4096 + nbytes]
         stream = text_block(payload)
+    elif kind == "random":  # incompressible bytes: fills the hashed tables fast (DirectHash evictions)
+        stream = default_block(np.random.default_rng(seed).integers(0, 256, nbytes, dtype=np.uint8).tobytes())
+    elif kind == "brackets":  # nested / unbalanced brackets and quotes, long repeats (Match length >= 32)
+        rng = np.random.default_rng(seed)
+        unit = bytes(rng.choice(np.frombuffer(b"(){}[]<>'\" ab\n", np.uint8), 97).tobytes())
+        body = (unit * 3 + b"((((((((((((" + unit[:40] + b"))))" + bytes(300) + unit * 2)
+        stream = text_block((body * (nbytes // len(body) + 1))[:nbytes])
     elif kind == "binary":
         rng = np.random.default_rng(seed)
         recs = rng.integers(0, 256, (nbytes // 16 + 1, 16), dtype=np.uint8)
@@ -127,10 +146,12 @@ FIXTURES = [  # (name, kind, payload bytes, seed, full probs?)
     ("text_96", "text", 90, 1000, True),
     ("binary_64", "binary", 59, 7, True),
     ("text_2k_nofull", "text", 2042, 1001, False),
+    ("brackets_1k", "brackets", 1018, 5, False),
 ]
 BIG = [
     ("text_4k", "text", 4090, 1000, True),
     ("text_32k", "text", 32762, 1002, True),
+    ("random_160k", "random", 160000, 11, False),
 ]
 
 if __name__ == "__main__":

@@ -78,3 +78,57 @@ def test_lstm_binary_golden():
 
 def test_lstm_2k_golden_20_bptt_rounds():
     _check_lstm("text_2k_nofull")  # 2048 bytes: 21 BPTT + Adam rounds (every 100 bytes)
+
+
+def _check_ctxmodels(name, big=False):
+    """ContextManager + contexts + 54 small models restatement vs the reference: per bit the 54 model
+    outputs (layer-0 columns 0,1,2,2025..2075) and all 47 mixer selectors; per byte the manager
+    registers, the 54 byte contexts; per bit the 8 bit contexts."""
+    g = load_golden(name, big)
+    c = O.CtxModels(g["vocab"])
+    stream = g["stream"]
+    probs = mg.unpack_probs(g)[:, O.SMALL_COLS] if "probs_q" in g else g["small_probs"][:, :54]
+    t = 0
+    for n in range(len(stream)):
+        for j in range(7, -1, -1):
+            p, sel = c.predict()
+            if probs is not None:
+                bad = np.nonzero(~bits_equal(p, probs[t]))[0]
+                assert len(bad) == 0, f"{name}: small model {bad[0]} (col {O.SMALL_COLS[bad[0]]}) differs at bit {t}"
+            want = g["sel"][t].copy()
+            want[12] = 0
+            bad = np.nonzero(sel != want)[0]
+            assert len(bad) == 0, f"{name}: selector {bad[0]} differs at bit {t}: {sel[bad[0]]} vs {want[bad[0]]}"
+            assert (c.manager()[2] == g["bitctx"][t]).all(), f"{name}: bit contexts differ at bit {t}"
+            c.perceive((int(stream[n]) >> j) & 1)
+            t += 1
+        regs, ctx, _ = c.manager()
+        want = g["regs"][n + 1].copy()
+        want[6] = 0  # auxiliary_context_ belongs to the mixing network
+        assert (regs == want).all(), f"{name}: manager registers differ after byte {n}: {regs} vs {want}"
+        bad = np.nonzero(ctx != g["ctx"][n + 1])[0]
+        assert len(bad) == 0, f"{name}: context {bad[0]} differs after byte {n}"
+        assert bits_equal(c.bracket_probs(), g["bracket_probs"][n + 1]).all(), f"{name}: Bracket dist after byte {n}"
+    c.close()
+
+
+def test_ctxmodels_text_golden():
+    _check_ctxmodels("text_96")
+
+
+def test_ctxmodels_binary_golden():
+    _check_ctxmodels("binary_64")
+
+
+def test_ctxmodels_2k_golden():
+    _check_ctxmodels("text_2k_nofull")
+
+
+def test_ctxmodels_brackets_golden():
+    g = load_golden("brackets_1k")
+    assert g["regs"][:, 5].max() >= 1  # longest_match_ reaches >= 1 (a Match model saw >= 32 matching bits)
+    _check_ctxmodels("brackets_1k")
+
+
+def test_ctxmodels_random_160k_local():
+    _check_ctxmodels("random_160k", big=True)  # DirectHash evictions (20-probe reset), full hashed tables
