@@ -16,6 +16,7 @@
 
 #include "../../include/cmix_amd.h"
 #include "lstm_state.h"
+#include "cmx_glibc_rand.h"
 
 extern "C" __global__ void cmx_lstm_prep(const LstmState, const float*, const uint8_t*, size_t, int);
 extern "C" __global__ void cmx_lstm_sgd(const LstmState, const uint8_t*, size_t, int, int);
@@ -26,39 +27,10 @@ extern "C" __global__ void cmx_lstm_softmax(const LstmState, float*, int);
 extern "C" __global__ void cmx_lstm_bptt_seq(const LstmState);
 extern "C" __global__ void cmx_lstm_bptt_acc(const LstmState, int);
 extern "C" __global__ void cmx_lstm_bptt_gb(const LstmState, int);
-extern "C" __global__ void cmx_bytemodel_bits(const float*, const float*, const uint8_t*, size_t, float*, int*);
+extern "C" __global__ void cmx_bytemodel_bits(const float*, const float*, const uint8_t*, size_t, float*, int*, size_t);
 
 void cmx_set_err(const std::string& s);  // cmx_api.hip
 
-namespace {
-
-// glibc rand(): TYPE_3, r[i] = r[i-3] + r[i-31], 310 warm-up draws, result >> 1.
-struct GlibcRand {
-  std::vector<int32_t> r;
-  size_t k = 344;
-  explicit GlibcRand(uint32_t seed) : r(344) {
-    int32_t word = (int32_t)seed;
-    if (word == 0) word = 1;
-    r[0] = word;
-    for (int i = 1; i < 31; ++i) {
-      long hi = word / 127773, lo = word % 127773;
-      long w = 16807 * lo - 2836 * hi;
-      if (w < 0) w += 2147483647;
-      word = (int32_t)w;
-      r[i] = word;
-    }
-    for (int i = 31; i < 34; ++i) r[i] = r[i - 31];
-    for (int i = 34; i < 344; ++i) r[i] = (int32_t)((uint32_t)r[i - 31] + (uint32_t)r[i - 3]);
-  }
-  int next() {
-    int32_t v = (int32_t)((uint32_t)r[k - 31] + (uint32_t)r[k - 3]);
-    r.push_back(v);
-    ++k;
-    return (int)((uint32_t)v >> 1);
-  }
-};
-
-}  // namespace
 
 struct cmx_lstm {
   int device = 0;
@@ -242,7 +214,7 @@ int cmx_lstm_run(cmx_lstm_t* h, const float* d_in_probs, const uint8_t* d_bytes,
   if (d_bit_p) {
     if (!d_out_probs) { cmx_set_err("cmx_lstm_run: bit predictions need d_out_probs"); return 1; }
     hipLaunchKernelGGL(cmx_bytemodel_bits, dim3((unsigned)nbytes), dim3(64), 0, st, h->d_prev_probs, d_out_probs,
-                       d_bytes, nbytes, d_bit_p, d_bit_ex);
+                       d_bytes, nbytes, d_bit_p, d_bit_ex, (size_t)1);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { cmx_set_err(std::string("cmx_lstm_run: ") + hipGetErrorString(e)); return 1; }
@@ -254,7 +226,7 @@ int cmx_bytemodel_bits_run(int device, const float* d_dist0, const float* d_dist
   if (nbytes == 0) return 0;
   if (hipSetDevice(device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
   hipLaunchKernelGGL(cmx_bytemodel_bits, dim3((unsigned)nbytes), dim3(64), 0, (hipStream_t)stream, d_dist0,
-                     d_dist_rest, d_bytes, nbytes, d_bit_p, d_bit_ex);
+                     d_dist_rest, d_bytes, nbytes, d_bit_p, d_bit_ex, (size_t)1);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { cmx_set_err(std::string("cmx_bytemodel_bits_run: ") + hipGetErrorString(e)); return 1; }
   return 0;

@@ -396,7 +396,7 @@ extern "C" __global__ void cmx_lstm_bptt_gb(const LstmState P, int update_steps)
 //      One block per byte: dist(n) is the distribution the byte model held while byte n was coded.
 //      Outputs p[n][8] (Model::Predict value per bit) and ex[n][8] (arg-max symbol, `ex`).
 extern "C" __global__ void cmx_bytemodel_bits(const float* dist0, const float* dist_rest, const uint8_t* bytes,
-                                              size_t nbytes, float* p_out, int* ex_out) {
+                                              size_t nbytes, float* p_out, int* ex_out, size_t pstride) {
   __shared__ float pr[256];
   const size_t n = blockIdx.x;
   const float* d = n == 0 ? dist0 : dist_rest + (n - 1) * 256;
@@ -415,7 +415,7 @@ extern "C" __global__ void cmx_bytemodel_bits(const float* dist0, const float* d
     float mx = pr[bot];
     for (int i = bot + 1; i <= top; ++i)
       if (pr[i] > mx) { mx = pr[i]; ex = i; }
-    p_out[n * 8 + k] = denom == 0.0f ? 0.5f : fdiv(num, denom);
+    p_out[(n * 8 + k) * pstride] = denom == 0.0f ? 0.5f : fdiv(num, denom);  // pstride 1, or a layer-0 row stride
     if (ex_out) ex_out[n * 8 + k] = ex;
     if ((byte >> (7 - k)) & 1) bot = mid + 1;
     else top = mid;

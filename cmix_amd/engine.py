@@ -69,6 +69,13 @@ def lib():
         L.cmx_lstm_get_gate_weights.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.cmx_lstm_gate_rowlen.argtypes = [C.c_void_p, C.c_int]
         L.cmx_glibc_rand_selftest.argtypes = [C.c_uint32, C.c_int, C.c_void_p]
+        L.cmx_ctxmodels_create.restype = C.c_void_p
+        L.cmx_ctxmodels_create.argtypes = [C.c_void_p, C.c_int]
+        L.cmx_ctxmodels_destroy.argtypes = [C.c_void_p]
+        L.cmx_ctxmodels_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                        C.c_void_p]
+        L.cmx_ctxmodels_sync.argtypes = [C.c_void_p]
+        L.cmx_ctxmodels_get_manager.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.cmx_probe_libm.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
         _lib = L
     return _lib
@@ -215,6 +222,62 @@ class Lstm:
         if lib().cmx_lstm_get_gate_weights(self.h, layer, gate, out.ctypes.data):
             raise CmxError("cmx_lstm_get_gate_weights failed")
         return out
+
+
+SMALL_COLS = [0, 1, 2] + list(range(2025, 2076))  # layer-0 columns the ctx/small-model stage writes
+
+
+class CtxModels:
+    """Context plumbing + the 54 small native models of one stream on one GPU (chunk mode)."""
+
+    def __init__(self, vocab, device=0):
+        vocab = np.ascontiguousarray(vocab, np.uint8)
+        assert vocab.size == 256
+        self.h = lib().cmx_ctxmodels_create(vocab.ctypes.data, device)
+        if not self.h:
+            raise CmxError(last_error())
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().cmx_ctxmodels_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, data, probs=None, sel=None, stream=None):
+        """data [N] u8 cuda -> writes columns SMALL_COLS of probs [8N,2078] f32 and sel [8N,47] i32 (u32 keys)."""
+        import torch
+        N = int(data.numel())
+        assert data.is_cuda and data.dtype == torch.uint8 and data.is_contiguous()
+        if probs is None:
+            probs = torch.full((8 * N, N_INPUTS), 0.5, dtype=torch.float32, device=data.device)
+        if sel is None:
+            sel = torch.zeros((8 * N, N_MIXERS), dtype=torch.int32, device=data.device)
+        assert probs.dtype == torch.float32 and probs.is_contiguous() and probs.shape[0] == 8 * N
+        assert sel.dtype == torch.int32 and sel.is_contiguous() and sel.numel() == 8 * N * N_MIXERS
+        if stream is None:
+            stream = torch.cuda.current_stream(data.device).cuda_stream
+        rc = lib().cmx_ctxmodels_run(self.h, data.data_ptr(), N, probs.data_ptr(), probs.shape[1], sel.data_ptr(),
+                                     C.c_void_p(stream))
+        if rc:
+            raise CmxError(last_error())
+        return probs, sel
+
+    def sync(self):
+        if lib().cmx_ctxmodels_sync(self.h):
+            raise CmxError(last_error())
+
+    def manager(self):
+        regs = np.empty(25, np.uint64)
+        ctx = np.empty(54, np.uint64)
+        bctx = np.empty(8, np.uint64)
+        if lib().cmx_ctxmodels_get_manager(self.h, regs.ctypes.data, ctx.ctypes.data, bctx.ctypes.data):
+            raise CmxError(last_error())
+        return regs, ctx, bctx
 
 
 def glibc_rand(seed, n):

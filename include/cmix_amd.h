@@ -144,6 +144,30 @@ int cmx_lstm_gate_rowlen(const cmx_lstm_t*, int layer);
 int cmx_glibc_rand_selftest(uint32_t seed, int n, int* out);
 
 /* ------------------------------------------------------------------------
+ * 2c. Stage: context plumbing + the 54 small native models = ContextManager, the 54 byte / 8 bit
+ *     contexts, Direct / DirectHash / Indirect / Match / Bracket (src/context-manager.cpp,
+ *     src/contexts/ *.cpp, src/states/ *.cpp, src/models/{direct,direct-hash,indirect,match,bracket,
+ *     byte-model}.cpp; wired at predictor.cpp:90-178,199-356,361-369,421-446)
+ * ------------------------------------------------------------------------ */
+typedef struct cmx_ctxmodels cmx_ctxmodels_t;
+cmx_ctxmodels_t* cmx_ctxmodels_create(const uint8_t vocab[256], int device);
+void cmx_ctxmodels_destroy(cmx_ctxmodels_t*);
+/* Chunk mode over nbytes already-known bytes. DEVICE pointers:
+ *   d_bytes [nbytes]            u8   the bytes coded
+ *   d_probs [8*nbytes][pstride] f32  the layer-0 matrix the mixing network reads (pstride >= 2078);
+ *                                    OUT: columns 0,1,2 and 2025..2075 of every row (Model::Predict of
+ *                                    the 54 models); other columns untouched
+ *   d_sel   [8*nbytes][47]      u32  OUT: every mixer's selector at each Predict() (entry 12 = 0: the
+ *                                    mixing-network stage derives auxiliary_context_ itself)
+ * Asynchronous on `stream`. */
+int cmx_ctxmodels_run(cmx_ctxmodels_t*, const uint8_t* d_bytes, size_t nbytes, float* d_probs, size_t pstride,
+                      uint32_t* d_sel, void* stream);
+/* Waits for the handle's work; reports device-side failures. */
+int cmx_ctxmodels_sync(cmx_ctxmodels_t*);
+/* Test hook: ContextManager registers (25), byte contexts (54), bit contexts (8) between bytes. */
+int cmx_ctxmodels_get_manager(cmx_ctxmodels_t*, uint64_t* regs25, uint64_t* ctx54, uint64_t* bitctx8);
+
+/* ------------------------------------------------------------------------
  * Device libm probes (parity tests): evaluate the engine's expf / tanhf /
  * logistic on the device for n host floats. which: 0 expf, 1 tanhf, 2 logistic
  * ------------------------------------------------------------------------ */

@@ -587,3 +587,15 @@ void orc_ctx_get_manager(const orc_ctx* o, uint64_t* regs25, uint64_t* ctx54, ui
 const float* orc_ctx_bracket_probs(const orc_ctx* o) { return o->br_probs; }
 uint64_t orc_ctx_indirect_offset(const orc_ctx* o, int model) { return o->m[model].map_offset; }
 int orc_ctx_model_column(const orc_ctx* o, int model) { return o->m[model].col; }
+
+/* Batch driver for the tests: walks Predict()/Perceive() over n bytes (MSB first).
+ * probs [8n][54] f32, sel [8n][47] u64 (either may be NULL). */
+void orc_ctx_run(orc_ctx* o, const uint8_t* bytes, size_t n, float* probs, uint64_t* sel) {
+  float p[N_MODELS];
+  size_t t = 0;
+  for (size_t i = 0; i < n; ++i)
+    for (int j = 7; j >= 0; --j, ++t) {
+      orc_ctx_predict(o, probs ? probs + t * N_MODELS : p, sel ? sel + t * 47 : NULL);
+      orc_ctx_perceive(o, (bytes[i] >> j) & 1);
+    }
+}

@@ -65,6 +65,7 @@ def lib():
         L.orc_ctx_destroy.argtypes = [C.c_void_p]
         L.orc_ctx_predict.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_ctx_perceive.argtypes = [C.c_void_p, C.c_int]
+        L.orc_ctx_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.orc_ctx_get_manager.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_ctx_bracket_probs.restype = C.POINTER(C.c_float)
         L.orc_ctx_bracket_probs.argtypes = [C.c_void_p]
@@ -215,17 +216,12 @@ class CtxModels:
         return np.ctypeslib.as_array(lib().orc_ctx_bracket_probs(self.h), shape=(256,)).copy()
 
     def run(self, data):
-        """data: bytes -> (probs [T,54] f32, sel [T,47] u64, bracket byte dists [N+1,256])"""
-        data = np.frombuffer(bytes(data), np.uint8)
+        """data: bytes -> (probs [T,54] f32, sel [T,47] u64)"""
+        data = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8))
         T = 8 * len(data)
         probs = np.empty((T, 54), np.float32)
         sel = np.empty((T, 47), np.uint64)
-        t = 0
-        for byte in data:
-            for j in range(7, -1, -1):
-                probs[t], sel[t] = self.predict()
-                self.perceive((int(byte) >> j) & 1)
-                t += 1
+        lib().orc_ctx_run(self.h, data.ctypes.data, len(data), probs.ctypes.data, sel.ctypes.data)
         return probs, sel
 
     def close(self):
