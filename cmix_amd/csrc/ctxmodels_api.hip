@@ -318,7 +318,7 @@ int cmx_ctxmodels_sync(cmx_ctxmodels_t* h) {
   return 0;
 }
 
-// ref_get_manager-compatible readout (oracle/ref_harness.cpp): regs25, ctx54, bitctx8
+// Test readout in the layout the parity tests use for ContextManager state: regs25, ctx54, bitctx8
 int cmx_ctxmodels_get_manager(cmx_ctxmodels_t* h, uint64_t* regs25, uint64_t* ctx54, uint64_t* bitctx8) {
   if (!h) return 1;
   if (cmx_ctxmodels_sync(h)) return 1;

@@ -183,7 +183,7 @@ cmx_lstm_t* cmx_lstm_create(const uint8_t vocab[256], int skip_rand, int device)
 int cmx_lstm_vocab_size(const cmx_lstm_t* h) { return h ? h->h_state.V : -1; }
 
 int cmx_lstm_run(cmx_lstm_t* h, const float* d_in_probs, const uint8_t* d_bytes, size_t nbytes,
-                 float* d_out_probs, float* d_bit_p, int* d_bit_ex, void* stream) {
+                 float* d_out_probs, float* d_bit_p, size_t bit_p_stride, int* d_bit_ex, void* stream) {
   if (!h) { cmx_set_err("cmx_lstm_run: null handle"); return 1; }
   if (nbytes == 0) return 0;
   if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
@@ -214,7 +214,7 @@ int cmx_lstm_run(cmx_lstm_t* h, const float* d_in_probs, const uint8_t* d_bytes,
   if (d_bit_p) {
     if (!d_out_probs) { cmx_set_err("cmx_lstm_run: bit predictions need d_out_probs"); return 1; }
     hipLaunchKernelGGL(cmx_bytemodel_bits, dim3((unsigned)nbytes), dim3(64), 0, st, h->d_prev_probs, d_out_probs,
-                       d_bytes, nbytes, d_bit_p, d_bit_ex, (size_t)1);
+                       d_bytes, nbytes, d_bit_p, d_bit_ex, bit_p_stride ? bit_p_stride : (size_t)1);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { cmx_set_err(std::string("cmx_lstm_run: ") + hipGetErrorString(e)); return 1; }
@@ -222,11 +222,11 @@ int cmx_lstm_run(cmx_lstm_t* h, const float* d_in_probs, const uint8_t* d_bytes,
 }
 
 int cmx_bytemodel_bits_run(int device, const float* d_dist0, const float* d_dist_rest, const uint8_t* d_bytes,
-                           size_t nbytes, float* d_bit_p, int* d_bit_ex, void* stream) {
+                           size_t nbytes, float* d_bit_p, size_t bit_p_stride, int* d_bit_ex, void* stream) {
   if (nbytes == 0) return 0;
   if (hipSetDevice(device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
   hipLaunchKernelGGL(cmx_bytemodel_bits, dim3((unsigned)nbytes), dim3(64), 0, (hipStream_t)stream, d_dist0,
-                     d_dist_rest, d_bytes, nbytes, d_bit_p, d_bit_ex, (size_t)1);
+                     d_dist_rest, d_bytes, nbytes, d_bit_p, d_bit_ex, bit_p_stride ? bit_p_stride : (size_t)1);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { cmx_set_err(std::string("cmx_bytemodel_bits_run: ") + hipGetErrorString(e)); return 1; }
   return 0;

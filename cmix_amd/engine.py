@@ -63,9 +63,9 @@ def lib():
         L.cmx_lstm_destroy.argtypes = [C.c_void_p]
         L.cmx_lstm_vocab_size.argtypes = [C.c_void_p]
         L.cmx_lstm_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
-                                   C.c_void_p, C.c_void_p]
+                                   C.c_size_t, C.c_void_p, C.c_void_p]
         L.cmx_bytemodel_bits_run.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
-                                             C.c_void_p, C.c_void_p, C.c_void_p]
+                                             C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.cmx_lstm_get_gate_weights.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.cmx_lstm_gate_rowlen.argtypes = [C.c_void_p, C.c_int]
         L.cmx_glibc_rand_selftest.argtypes = [C.c_uint32, C.c_int, C.c_void_p]
@@ -198,20 +198,28 @@ class Lstm:
         except Exception:
             pass
 
-    def run(self, in_probs, data, want_bits=True, stream=None):
-        """in_probs [N,256] f32 cuda, data [N] u8 cuda -> (out_probs [N,256], bit_p [N,8], bit_ex [N,8])"""
+    def run(self, in_probs, data, want_bits=True, stream=None, layer0=None, out=None):
+        """in_probs [N,256] f32 cuda, data [N] u8 cuda -> (out_probs [N,256], bit_p [N,8], bit_ex [N,8]).
+        With layer0 = the [8N,2078] layer-0 matrix, the bit predictions are written in place into its
+        column 2077 (and bit_p is None)."""
         import torch
         N = int(data.numel())
         assert in_probs.is_cuda and in_probs.dtype == torch.float32 and in_probs.is_contiguous()
         assert in_probs.numel() == N * 256 and data.dtype == torch.uint8 and data.is_contiguous()
-        out = torch.empty((N, 256), dtype=torch.float32, device=in_probs.device)
-        bp = torch.empty((N, 8), dtype=torch.float32, device=in_probs.device) if want_bits else None
-        bx = torch.empty((N, 8), dtype=torch.int32, device=in_probs.device) if want_bits else None
+        if out is None:
+            out = torch.empty((N, 256), dtype=torch.float32, device=in_probs.device)
+        bp, bp_ptr, stride = None, None, 1
+        if layer0 is not None:
+            assert layer0.dtype == torch.float32 and layer0.is_contiguous() and layer0.shape == (8 * N, N_INPUTS)
+            bp_ptr, stride = layer0.data_ptr() + 4 * (N_INPUTS - 1), N_INPUTS
+        elif want_bits:
+            bp = torch.empty((N, 8), dtype=torch.float32, device=in_probs.device)
+            bp_ptr = bp.data_ptr()
+        bx = torch.empty((N, 8), dtype=torch.int32, device=in_probs.device) if bp_ptr else None
         if stream is None:
             stream = torch.cuda.current_stream(in_probs.device).cuda_stream
         rc = lib().cmx_lstm_run(self.h, in_probs.data_ptr(), data.data_ptr(), N, out.data_ptr(),
-                                bp.data_ptr() if want_bits else None, bx.data_ptr() if want_bits else None,
-                                C.c_void_p(stream))
+                                bp_ptr, stride, bx.data_ptr() if bx is not None else None, C.c_void_p(stream))
         if rc:
             raise CmxError(last_error())
         return out, bp, bx
@@ -278,6 +286,21 @@ class CtxModels:
         if lib().cmx_ctxmodels_get_manager(self.h, regs.ctypes.data, ctx.ctypes.data, bctx.ctypes.data):
             raise CmxError(last_error())
         return regs, ctx, bctx
+
+
+def bytemodel_bits(dist0, dist_rest, data, layer0, col, device=0, stream=None):
+    """ByteModel::Predict/Perceive along known bytes for any byte model (PPMd: col 2076): dist0 [256] is the
+    distribution going into byte 0, dist_rest [N-1.., 256] the one after each byte; writes layer0[:, col]."""
+    import torch
+    N = int(data.numel())
+    assert layer0.dtype == torch.float32 and layer0.is_contiguous() and layer0.shape == (8 * N, N_INPUTS)
+    assert dist0.is_contiguous() and dist_rest.is_contiguous() and dist_rest.numel() >= (N - 1) * 256
+    if stream is None:
+        stream = torch.cuda.current_stream(data.device).cuda_stream
+    rc = lib().cmx_bytemodel_bits_run(device, dist0.data_ptr(), dist_rest.data_ptr(), data.data_ptr(), N,
+                                      layer0.data_ptr() + 4 * col, N_INPUTS, None, C.c_void_p(stream))
+    if rc:
+        raise CmxError(last_error())
 
 
 def glibc_rand(seed, n):

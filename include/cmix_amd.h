@@ -128,16 +128,18 @@ int cmx_lstm_vocab_size(const cmx_lstm_t*);
  *   d_bytes     [nbytes]      u8   the bytes coded
  *   d_out_probs [nbytes][256] f32  OUT: the LSTM's distribution after each byte (ByteMixer::probs_)
  *   d_bit_p     [nbytes][8]   f32  OUT (may be NULL): ByteModel::Predict value for each bit of byte n,
- *                                  i.e. layer-0 input 2077 (for n = 0: from the state before this call)
+ *                                  i.e. layer-0 input 2077 (for n = 0: from the state before this call);
+ *                                  bit k of byte n goes to d_bit_p[(8n+k)*bit_p_stride] -- stride 1 for a
+ *                                  dense array, 2078 to write column 2077 of the layer-0 matrix in place
  *   d_bit_ex    [nbytes][8]   i32  OUT (may be NULL): ByteModel::ex per bit (-> lstmex, predictor.cpp:465)
  * Asynchronous on `stream`. Truncated BPTT + Adam run every 100 bytes as in lstm.cpp:93-110. */
 int cmx_lstm_run(cmx_lstm_t*, const float* d_in_probs, const uint8_t* d_bytes, size_t nbytes,
-                 float* d_out_probs, float* d_bit_p, int* d_bit_ex, void* stream);
+                 float* d_out_probs, float* d_bit_p, size_t bit_p_stride, int* d_bit_ex, void* stream);
 /* ByteModel::Predict/Perceive for any byte model (PPMd, Bracket, LSTM): per-bit predictions along
  * the known bytes. dist for byte 0 = d_dist0[256]; for byte n >= 1 = d_dist_rest[(n-1)*256 ...]. */
 int cmx_bytemodel_bits_run(int device, const float* d_dist0, const float* d_dist_rest,
-                           const uint8_t* d_bytes, size_t nbytes, float* d_bit_p, int* d_bit_ex,
-                           void* stream);
+                           const uint8_t* d_bytes, size_t nbytes, float* d_bit_p, size_t bit_p_stride,
+                           int* d_bit_ex, void* stream);
 /* Test hooks. */
 int cmx_lstm_get_gate_weights(cmx_lstm_t*, int layer, int gate, float* out_host);
 int cmx_lstm_gate_rowlen(const cmx_lstm_t*, int layer);

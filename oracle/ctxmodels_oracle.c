@@ -15,7 +15,7 @@
  *
  * The 256x2 transition table of the Nonstationary state machine (nonstationary.cpp:3) and the two
  * literal byte-class maps of predictor.cpp:255-272,285-302 are DATA of the reference; they are not
- * transcribed by hand but dumped from the reference build by oracle/gen_ref_tables.py into
+ * transcribed by hand but dumped from the reference build by scripts/gen_ref_tables.py into
  * oracle/ref_tables.h.
  *
  * Compiled with -ffp-contract=off; every float expression below has the operand types of the

@@ -205,7 +205,7 @@ int ref_lstm_output_layer(int epoch, float* out) {
   return (int)k;
 }
 
-// Reference DATA tables (dumped by oracle/gen_ref_tables.py, never transcribed by hand):
+// Reference DATA tables (dumped by scripts/gen_ref_tables.py, never transcribed by hand):
 // the Nonstationary transition table (src/states/nonstationary.cpp:3) ...
 int ref_nonstationary_table(uint8_t* out512) {
   for (int s = 0; s < 256; ++s)

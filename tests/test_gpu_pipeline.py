@@ -1,0 +1,65 @@
+"""GPU integration parity: the three device stages chained through HBM exactly as the engine runs them.
+
+    bytes ──► ctx/small-model stage ──► layer-0 columns 0,1,2,2025..2075 + 47 selectors ─┐
+    PPMd byte distributions (trace) ──► ByteModel bits ──► column 2076                     ├─► mixing network ─► p
+    PPMd byte distributions (trace) ──► LSTM byte mixer ──► column 2077                    │
+    fxcm / paq8 columns 3..2024 (trace of the unmodified reference) ───────────────────────┘
+
+Only what has no device stage yet (fxcm, paq8, PPMd) is replayed from the golden trace of the reference; every
+other number is produced on the MI355X. The final probability must equal Predictor::Predict()'s float bit
+for bit, for every coded bit (predictor.cpp:361-419)."""
+import numpy as np
+import pytest
+
+from conftest import bits_equal, load_golden
+import make_golden as mg
+
+pytestmark = pytest.mark.gpu
+
+
+def _pipeline(name, chunks=None, big=False):
+    import torch
+    from cmix_amd import engine as E
+    g = load_golden(name, big)
+    stream = np.ascontiguousarray(g["stream"])
+    N = len(stream)
+    ref = mg.unpack_probs(g)
+    layer0 = torch.from_numpy(ref.copy()).cuda()
+    own = E.SMALL_COLS + [2076, 2077]
+    layer0[:, own] = float("nan")  # the device must produce these
+    sel = torch.full((8 * N, 47), -1, dtype=torch.int32, device="cuda")
+    d = torch.from_numpy(stream).cuda()
+    ppmd = torch.from_numpy(np.ascontiguousarray(g["ppmd_probs"])).cuda()  # [N+1,256]
+    bits = torch.from_numpy(np.ascontiguousarray(g["bits"])).cuda()
+    ctx, lstm, net = E.CtxModels(g["vocab"], 0), E.Lstm(g["vocab"], 0), E.MixNet(0)
+    p = torch.empty(8 * N, dtype=torch.float32, device="cuda")
+    edges = [0, N] if not chunks else sorted(set([0, N] + list(chunks)))
+    for a, b in zip(edges[:-1], edges[1:]):
+        rows = slice(8 * a, 8 * b)
+        ctx.run(d[a:b], layer0[rows], sel[rows])
+        E.bytemodel_bits(ppmd[a], ppmd[a + 1:b + 1], d[a:b], layer0[rows], 2076)
+        lstm.run(ppmd[a + 1:b + 1], d[a:b], layer0=layer0[rows])
+        net.run(layer0[rows], sel[rows], bits[rows], p[rows])
+    torch.cuda.synchronize()
+    ctx.sync()
+    net.sync()
+    got_l0 = layer0.cpu().numpy()
+    bad = np.argwhere(~bits_equal(got_l0, ref))
+    assert len(bad) == 0, f"{name}: layer-0 input {bad[0][1]} differs first at bit {bad[0][0]}"
+    got = p.cpu().numpy()
+    bad = np.nonzero(~bits_equal(got, g["p_final"]))[0]
+    assert len(bad) == 0, f"{name}: final probability differs first at bit {bad[0]} of {8 * N}"
+    for o in (ctx, lstm, net):
+        o.close()
+
+
+def test_pipeline_text_96():
+    _pipeline("text_96")
+
+
+def test_pipeline_binary_64_ragged():
+    _pipeline("binary_64", chunks=[1, 7, 40])
+
+
+def test_pipeline_text_4k_local():
+    _pipeline("text_4k", chunks=[1024, 3000], big=True)
