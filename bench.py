@@ -10,18 +10,22 @@ resident in HBM before the timed region. Streams are independent:
 processes its own shard (seed 1000+r) on its own GPU, no collective on the data path
 ("scaling": "weak"); value = bytes processed by all ranks / max-over-ranks time.
 
-Device stages covered this round: the final mixing network -- stretch, 26+20+1 gated
-logistic mixers with online update, squash, SSE (reference src/predictor.cpp:388-418,
-432-437). The model families that feed it (paq8, fxcm, ppmd, lstm, small models) are not
-on the device yet, so their 2078-wide per-bit prediction stream is a seeded synthetic
-stand-in with the reference's value grid (k/4095) and enwik8-like selector locality;
-`config.workload` says so. The number is therefore the throughput of this stage, not of a
-whole predictor.
+Device stages covered: (1) ContextManager + the 54 byte contexts + the 54 small native models
+(reference src/context-manager.cpp, src/contexts, src/models/{direct,direct-hash,indirect,match,
+bracket}.cpp) -> layer-0 columns 0-2, 2025-2075 and the 47 mixer selectors; (2) the byte-level
+LSTM byte mixer (src/mixer/{byte-mixer,lstm,lstm-layer}.cpp) -> column 2077; (3) the final mixing
+network -- stretch, 26+20+1 gated logistic mixers with online update, squash, SSE
+(src/predictor.cpp:388-418,432-437). Each stage runs on its own HIP stream; a chunk's mixing
+network starts when the chunk's other two stages have written their columns. paq8, fxcm (layer-0
+columns 3..2024) and PPMd (byte distribution feeding the LSTM and column 2076) have no device
+stage yet: seeded stand-ins of the same shape and value grid (k/4095) replace them, and
+`config.workload` says so. The number is the throughput of these device stages, not of a whole
+predictor.
 
 roofline: HBM-bound accounting per SURVEY.md 8(d)(i): 55 172 f32 weights x 8 B (read +
 write) per bit = 3.53 MB per input byte for the final mixers, + 4 SSE cache lines per bit.
-cpu_baseline: the plain-C oracle of the same stage (oracle/mixnet_oracle.c, "port") timed on
-one host core over a bounded prefix of the same operands; `cpu_reference_full` additionally
+cpu_baseline: the plain-C oracle of the same three stages (oracle/*.c, "port") timed on one host
+core over bounded prefixes of the same operands (us/bit of the stages add up on a CPU); `cpu_reference_full` additionally
 times the unmodified reference binary (whole predictor, oracle/_ref/cmix_O3) on a short
 prefix of the same shard for context.
 """
@@ -90,8 +94,9 @@ def make_operands(nbytes, seed, device):
     return probs.contiguous(), sel32.contiguous(), bits.contiguous(), text
 
 
-def cpu_baseline_port(probs, sel32, bits, budget_s=12.0):
-    """Time the plain-C oracle of the same stage on one host core over a bounded prefix."""
+def cpu_baseline_port(probs, sel32, bits, text, ppmd, vocab, budget_s=14.0):
+    """Time the plain-C oracle of the same three stages on one host core over a bounded prefix.
+    cmix is single-threaded, so the stages run back to back on the CPU: us/bit adds up."""
     from oracle import oracle as O
     n = min(len(bits), 4096)
     p = probs[:n].cpu().numpy()
@@ -100,13 +105,29 @@ def cpu_baseline_port(probs, sel32, bits, budget_s=12.0):
     net = O.MixNet()
     t0 = time.perf_counter()
     done = 0
-    while done < n and time.perf_counter() - t0 < budget_s:
+    while done < n and time.perf_counter() - t0 < budget_s / 2:
         net.step(p[done], s[done], b[done])
         done += 1
-    dt = time.perf_counter() - t0
-    return {"value": (done / 8.0) / dt, "unit": "input bytes/s", "cores": 1, "kind": "port",
-            "sample": f"first {done} bits of the same stage operands through oracle/mixnet_oracle.c "
-                      f"(includes ~{5e-6 * done / dt * 100:.0f}% ctypes call overhead)"}
+    us_mix = (time.perf_counter() - t0) / done * 1e6
+    nb = min(len(text), 256)
+    ctx = O.CtxModels(vocab)
+    t0 = time.perf_counter()
+    ctx.run(bytes(text[:nb]))
+    us_ctx = (time.perf_counter() - t0) / (8 * nb) * 1e6
+    lstm = O.Lstm(vocab)
+    pp = ppmd[1:nb + 1].cpu().numpy()
+    t0 = time.perf_counter()
+    k = 0
+    while k < nb and time.perf_counter() - t0 < budget_s / 2:
+        lstm.byte_update(pp[k], text[k])
+        k += 1
+    us_lstm = (time.perf_counter() - t0) / (8 * k) * 1e6
+    tot = us_mix + us_ctx + us_lstm
+    return {"value": 1e6 / (8 * tot), "unit": "input bytes/s", "cores": 1, "kind": "port",
+            "sample": f"oracle/*.c of the same three stages on one core: mixing network {done} bits "
+                      f"({us_mix:.1f} us/bit), contexts+small models {8 * nb} bits ({us_ctx:.1f} us/bit), "
+                      f"LSTM {k} bytes ({us_lstm:.1f} us/bit); stages run back to back on a CPU",
+            "us_per_bit": {"mixnet": us_mix, "ctxmodels": us_ctx, "lstm": us_lstm}}
 
 
 def cpu_reference_full(text, nbytes=4096):
@@ -132,7 +153,7 @@ def cpu_reference_full(text, nbytes=4096):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--chunk-bytes", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -154,15 +175,46 @@ def main():
     dev = torch.device("cuda", local)
 
     nsteps = a.warmup + a.steps
-    probs, sel, bits, text = make_operands(a.chunk_bytes * nsteps, 1000 + rank, dev)
+    nbytes = a.chunk_bytes * nsteps
+    probs, sel_standin, bits, text = make_operands(nbytes, 1000 + rank, dev)
+    del sel_standin  # selectors now come from the context stage
+    text = np.ascontiguousarray(text)
+    vocab = np.zeros(256, np.uint8)
+    vocab[np.unique(text)] = 1
+    d_bytes = torch.from_numpy(text.copy()).to(dev)
+    # PPMd stand-in: a peaked distribution over the vocabulary after every byte (PPMd itself is a host stage)
+    g = torch.Generator(device=dev)
+    g.manual_seed(77 + rank)
+    ppmd = torch.rand((nbytes + 1, 256), generator=g, device=dev) ** 8
+    ppmd[:, torch.from_numpy(vocab == 0).to(dev)] = 0
+    ppmd = (ppmd / ppmd.sum(1, keepdim=True)).contiguous()
+    sel = torch.zeros((nbytes * 8, 47), dtype=torch.int32, device=dev)
     cb = a.chunk_bytes * 8
-    net = E.MixNet(local)
-    stream = torch.cuda.current_stream(dev)
+    net, ctx, lstm = E.MixNet(local), E.CtxModels(vocab, local), E.Lstm(vocab, local)
+    st_mix = torch.cuda.current_stream(dev)
+    st_ctx, st_lstm = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
     p_out = torch.empty(cb * nsteps, dtype=torch.float32, device=dev)
+    lstm_out = torch.empty((a.chunk_bytes, 256), dtype=torch.float32, device=dev)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(nsteps)]
+    torch.cuda.synchronize()
 
     def step(i):
-        s = slice(i * cb, (i + 1) * cb)
-        net.run(probs[s], sel[s], bits[s], p_out[s])
+        """One chunk through the three device stages; the stages of a chunk overlap on their own HIP
+        streams, the mixing network consumes the chunk once the other two have produced their columns."""
+        r = slice(i * cb, (i + 1) * cb)
+        n0, n1 = i * a.chunk_bytes, (i + 1) * a.chunk_bytes
+        ev[i][0].record(st_ctx)
+        ctx.run(d_bytes[n0:n1], probs[r], sel[r], stream=st_ctx.cuda_stream)
+        E.bytemodel_bits(ppmd[n0], ppmd[n0 + 1:n1 + 1], d_bytes[n0:n1], probs[r], 2076, local, st_ctx.cuda_stream)
+        ev[i][1].record(st_ctx)
+        ev[i][2].record(st_lstm)
+        lstm.run(ppmd[n0 + 1:n1 + 1], d_bytes[n0:n1], layer0=probs[r], out=lstm_out, stream=st_lstm.cuda_stream)
+        ev[i][3].record(st_lstm)
+        st_mix.wait_event(ev[i][1])
+        st_mix.wait_event(ev[i][3])
+        ev[i][4].record(st_mix)  # HIP events on the stream the mixing-network kernel is launched on
+        net.run(probs[r], sel[r], bits[r], p_out[r])
+        ev[i][5].record(st_mix)
 
     for i in range(a.warmup):
         step(i)
@@ -170,20 +222,23 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    kernel_ms = []
     t0 = time.perf_counter()
     for i in range(a.warmup, nsteps):
-        step(i)
-        kernel_ms.append(net.last_kernel_ms())  # HIP events on the launch stream (syncs this chunk)
+        step(i)  # everything is enqueued asynchronously: chunk i+1's context/LSTM stages run under chunk i's mixing
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    ctx.sync()
+    net.sync()
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    kernel_ms = [ev[i][4].elapsed_time(ev[i][5]) for i in range(a.warmup, nsteps)]
+    ctx_ms = float(np.mean([ev[i][0].elapsed_time(ev[i][1]) for i in range(a.warmup, nsteps)]))
+    lstm_ms = float(np.mean([ev[i][2].elapsed_time(ev[i][3]) for i in range(a.warmup, nsteps)]))
 
     if rank == 0:
         total_bytes = a.chunk_bytes * a.steps * world
@@ -196,24 +251,30 @@ def main():
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "S-enwik8 shard (seed 1000+rank), %d-byte chunks; device stage = final mixing "
-                            "network (stretch + 26/20/1 mixers + SSE, strict bit-exact mode); model-prediction "
-                            "stream (paq8/fxcm/ppmd/lstm/small models) is a seeded synthetic stand-in: those "
-                            "stages are not on the device yet" % a.chunk_bytes,
+                "workload": "S-enwik8 shard (seed 1000+rank), %d-byte chunks through the three device stages: "
+                            "contexts + 54 small models (layer-0 columns 0-2, 2025-2075, all 47 selectors), "
+                            "byte-level LSTM (column 2077) and the final mixing network (stretch + 26/20/1 mixers + "
+                            "SSE), strict bit-exact mode. Not on the device yet, replaced by seeded stand-ins of the "
+                            "same shape: the paq8 and fxcm columns (3..2024) and the PPMd byte distribution "
+                            "(host stage)" % a.chunk_bytes,
                 "chunk_bytes": a.chunk_bytes, "streams_per_gpu": 1, "parallelism": "1 stream per GPU, no collective"},
             "us_per_bit": dt / (a.steps * cb) * 1e6,
+            "stage_us_per_bit": {"mixnet": avg_kernel_s / cb * 1e6, "ctxmodels": ctx_ms * 1e3 / cb,
+                                 "lstm": lstm_ms * 1e3 / cb,
+                                 "note": "HIP-event time of each stage over a chunk (stages overlap on separate streams)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "cmx_mixnet_chunk_kernel", "avg_kernel_ms": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": algo},
         }
         if not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_port(probs, sel, bits)
+            out["cpu_baseline"] = cpu_baseline_port(probs, sel, bits, text, ppmd, vocab)
             ref = cpu_reference_full(text)
             if ref:
                 out["cpu_reference_full"] = ref
         print(json.dumps(out))
-    net.close()
+    for o in (net, ctx, lstm):
+        o.close()
     if world > 1:
         dist.destroy_process_group()
 
