@@ -108,6 +108,12 @@ __device__ __forceinline__ bool wait_ge(Ctl* ctl, const int* p, int target, bool
   return true;
 }
 
+// Broadcast lane j (a compile-time constant in the unrolled extra-input chains) through an SGPR:
+// v_readlane_b32 costs a few clocks, ds_bpermute_b32 a full LDS round trip per step of the chain.
+__device__ __forceinline__ float bcast_lane(float v, int j) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
+}
+
 __device__ __forceinline__ float4 f4sub_mul(float4 w, float u, float4 x) {
   w.x = fsub(w.x, fmul(u, x.x));
   w.y = fsub(w.y, fmul(u, x.y));
@@ -171,6 +177,7 @@ __device__ void scout_role(MixState* S, const Lds& L, const float* probs, const 
   const gptr<const float> gprobs = as_global(probs);
   const gptr<const uint32_t> gsel = as_global(sel);
   const float smin = S->stretch_min, smax = S->stretch_max;
+  float pf_sink = 0.0f;  // destination of the row-prefetch loads (see below); never read
   for (int t = 0; t < nbits; ++t) {
     if (t >= 2 && !wait_ge(L.ctl, &L.ctl->consumed, 4 * t - 4, true)) return;
     float* xs = L.xs + (t % 3) * XS;
@@ -219,19 +226,22 @@ __device__ void scout_role(MixState* S, const Lds& L, const float* probs, const 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     // Pull the rows that change at this bit towards L2 (one dword per 128-byte line, 66 lines per
-    // row) so the producers' row swap two bits from now is an L2 hit. The values are discarded.
+    // row) so the producers' row swap two bits from now is an L2 hit. The values are discarded and
+    // nothing ever waits for them individually: the loads are issued from asm statements the compiler
+    // keeps no waitcnt bookkeeping for, all into one register that stays live (so it is never re-used
+    // while a load is in flight) and is drained once, at the top of the next bit's prefetch -- a
+    // whole bit later. (Consuming each value made the wave wait for every row's HBM miss in turn.)
     {
       const gptr<const float> r0 = as_global(S->rows0);
-      float sink = 0.0f;
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink) :: "memory");
 #pragma unroll 1
       for (int mm = 0; mm < CMX_MIX0; ++mm) {
         if (rec->changed[mm]) {
           const uint32_t base = (mm * CMX_ROWS_PER_MIXER + rec->rowidx[mm]) * CMX_ROW0_STRIDE;
-          sink += r0[base + 32 * lane];
-          if (lane < 2) sink += r0[base + 2048 + 32 * lane];
+          asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(r0 + base + 32 * lane) : "memory");
+          if (lane < 2) asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(r0 + base + 2048 + 32 * lane) : "memory");
         }
       }
-      asm volatile("" :: "v"(sink));
     }
     if (lane < 3) {
       float v = xs[lane == 0 ? 433 : lane == 1 ? 2024 : 2077];
@@ -245,6 +255,7 @@ __device__ void scout_role(MixState* S, const Lds& L, const float* probs, const 
     }
     st_rel(&L.ctl->scout_epoch, t + 1);
   }
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink) :: "memory");
 }
 
 // ------------------------------------------------------------------ producers (waves 3..11)
@@ -275,75 +286,113 @@ __device__ void producer_role(MixState* S, const Lds& L, int nbits, int p, int l
     const bool live = t < nbits;   // t == nbits: flush the last update and store every row
     if (live && !wait_ge(L.ctl, &L.ctl->scout_epoch, t + 1, true)) return;
     PPROF(6);
-    if (t > 0 && !wait_ge(L.ctl, &L.ctl->u_epoch, t, true)) return;
-    PPROF(7);
     const float* xs = L.xs + (t % 3) * XS;
     const float* xsp = L.xs + ((t + 2) % 3) * XS;
     const BitRec* rec = L.rec + (t % 3);
     const BitRec* prev = L.rec + ((t + 2) % 3);
-    float u[MPW];
-    bool df[MPW], chg[MPW];
+    // Everything that does not depend on bit t-1's error is fetched BEFORE waiting for it, so the
+    // window between "u published" and "segment 0 staged" (the serial part of the bit) is as short
+    // as possible: row indices, the previous and current inputs of chunks 0 and 1.
+    bool chg[MPW];
     uint32_t bold[MPW], bnew[MPW];
+#pragma unroll
+    for (int j = 0; j < MPW; ++j) {
+      chg[j] = ok[j] && (!live || (rec->changed[mj[j]] != 0 && !((dbg & 1) && t > 0)));  // dbg&1: timing experiment only
+      bold[j] = (mj[j] * CMX_ROWS_PER_MIXER + prev->rowidx[mj[j]]) * CMX_ROW0_STRIDE;
+      bnew[j] = (mj[j] * CMX_ROWS_PER_MIXER + rec->rowidx[mj[j]]) * CMX_ROW0_STRIDE;
+    }
+    const float4 xp0 = *reinterpret_cast<const float4*>(xsp + 4 * lane);
+    const float4 xp1 = *reinterpret_cast<const float4*>(xsp + 256 + 4 * lane);
+    const float4 xc0 = *reinterpret_cast<const float4*>(xs + 4 * lane);
+    const float4 xc1 = *reinterpret_cast<const float4*>(xs + 256 + 4 * lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (t > 0 && !wait_ge(L.ctl, &L.ctl->u_epoch, t, false)) return;
+    PPROF(7);
+    float u[MPW];
+    bool anydf = false;
+    bool df[MPW];
 #pragma unroll
     for (int j = 0; j < MPW; ++j) {
       u[j] = L.upd[mj[j]];
       df[j] = L.dflag[mj[j]] != 0;
-      chg[j] = !live || (rec->changed[mj[j]] != 0 && !((dbg & 1) && t > 0));  // dbg&1: timing experiment only
-      bold[j] = (mj[j] * CMX_ROWS_PER_MIXER + prev->rowidx[mj[j]]) * CMX_ROW0_STRIDE;
-      bnew[j] = (mj[j] * CMX_ROWS_PER_MIXER + rec->rowidx[mj[j]]) * CMX_ROW0_STRIDE;
+      anydf |= df[j];
     }
-    // phase A for chunk k: apply bit t-1's update (mixer.cpp:66-71), swap rows whose selector changed
-    auto phaseA = [&](int k) {
-      const int i = 256 * k + 4 * lane;
-      const bool valid = k < 8 || lane_ok8;
+    // Every row load of the previous bit has long landed; telling the compiler so here (a wait it can
+    // see, on every path) keeps it from draining vmcnt(0) in front of each conditional store/load below.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched (gfx9 encoding)
+    // upd: apply bit t-1's update (mixer.cpp:66-71). Pure VALU; the rare 1024-step weight decay is a
+    // separate pass so the common path has no per-element branch.
+    auto upd = [&](int k, float4 x) {
 #pragma unroll
-      for (int j = 0; j < MPW; ++j) {
-        if (ok[j] && valid) {
-          if (t > 0) {
-            float4 x = *reinterpret_cast<const float4*>(xsp + i);
-            W[k][j] = f4sub_mul(W[k][j], u[j], x);
-            if (df[j]) W[k][j] = f4scale(W[k][j], cdec);
-          }
-          if (chg[j]) {
-            if (t > 0) gstore4(rows0 + bold[j] + i, W[k][j]);
-            if (live) W[k][j] = gload4(rows0 + bnew[j] + i);
+      for (int j = 0; j < MPW; ++j) W[k][j] = f4sub_mul(W[k][j], u[j], x);
+      if (anydf) {
+#pragma unroll
+        for (int j = 0; j < MPW; ++j)
+          if (df[j]) W[k][j] = f4scale(W[k][j], cdec);
+      }
+    };
+    // swp: 16-byte store of the outgoing row / load of the incoming one, for mixers whose selector changed
+    auto swp = [&](int j, int k0, int k1) {
+      if (chg[j]) {
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+          if (k >= k0 && k < k1) {
+            const int i = 256 * k + 4 * lane;
+            if (k < 8 || lane_ok8) {
+              if (t > 0) gstore4_async(rows0 + bold[j] + i, W[k][j]);
+              if (live) W[k][j] = gload4(rows0 + bnew[j] + i);
+            }
           }
         }
       }
     };
     // stage the rounded products of chunk k into segment buffer (mixer.cpp:41: in[i]*w[i])
-    auto stageK = [&](int k, int q, float* buf) {
+    auto stageX = [&](int k, int q, float* buf, float4 x) {
       const int i = 256 * k + 4 * lane;
-      const bool valid = k < 8 || lane_ok8;
-      if (valid) {
-        float4 x = *reinterpret_cast<const float4*>(xs + i);
 #pragma unroll
-        for (int j = 0; j < MPW; ++j)
-          if (ok[j]) *reinterpret_cast<float4*>(buf + mj[j] * SEG + (i - 512 * q)) = f4mul(x, W[k][j]);
-      }
+      for (int j = 0; j < MPW; ++j)
+        if (ok[j]) *reinterpret_cast<float4*>(buf + mj[j] * SEG + (i - 512 * q)) = f4mul(x, W[k][j]);
     };
-    auto stage = [&](int q) -> bool {
-      const int g = 4 * t + q;
-      if (g >= 2 && !wait_ge(L.ctl, &L.ctl->consumed, g - 1, true)) return false;
-      float* buf = L.prod + (g & 1) * PBUF;
-      stageK(2 * q, q, buf);
-      stageK(2 * q + 1, q, buf);
-      if (q == 3) stageK(8, q, buf);
+    auto stageK = [&](int k, int q, float* buf) {
+      if (k < 8 || lane_ok8) stageX(k, q, buf, *reinterpret_cast<const float4*>(xs + 256 * k + 4 * lane));
+    };
+    auto publish = [&](int g) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (lane == 0) lds_publish_add1(&L.ctl->staged[g & 1]);
-      return true;
     };
-    phaseA(0);
-    phaseA(1);
-    if (live && !stage(0)) return;
-    PPROF(8);
+    // ---- serial window: chunks 0,1 -> segment 0 ----
+    if (t > 0) { upd(0, xp0); upd(1, xp1); }
 #pragma unroll
-    for (int k = 2; k < NCH; ++k) phaseA(k);
+    for (int j = 0; j < MPW; ++j) swp(j, 0, 2);
+    if (live) {
+      // buffer (4t)&1 was last read for segment 2 of bit t-1, which the chain finished before it
+      // published u: no need to poll `consumed` here (nor for segment 1)
+      float* buf = L.prod + ((4 * t) & 1) * PBUF;
+      stageX(0, 0, buf, xc0);
+      stageX(1, 0, buf, xc1);
+      publish(4 * t);
+    }
+    PPROF(8);
+    // ---- the rest runs underneath the chain wave's segment 0 ----
+    if (t > 0) {
+#pragma unroll
+      for (int k = 2; k < NCH; ++k)
+        if (k < 8 || lane_ok8) upd(k, *reinterpret_cast<const float4*>(xsp + 256 * k + 4 * lane));
+    }
+#pragma unroll
+    for (int j = 0; j < MPW; ++j) swp(j, 2, NCH);
     PPROF(9);
     if (live) {
-      if (!stage(1)) return;
-      if (!stage(2)) return;
-      if (!stage(3)) return;
+#pragma unroll
+      for (int q = 1; q < 4; ++q) {
+        const int g = 4 * t + q;
+        if (q >= 2 && !wait_ge(L.ctl, &L.ctl->consumed, g - 1, true)) return;
+        float* buf = L.prod + (g & 1) * PBUF;
+        stageK(2 * q, q, buf);
+        stageK(2 * q + 1, q, buf);
+        if (q == 3) stageK(8, q, buf);
+        publish(g);
+      }
     }
     PPROF(10);
   }
@@ -406,7 +455,7 @@ __device__ void chain_role(MixState* S, const Lds& L, const float* decay1, int n
 #pragma unroll
     for (int j = 0; j < CMX_MIX0; ++j) {
       float mine = fadd(pm, e);
-      float oj = __shfl(mine, j);
+      float oj = bcast_lane(mine, j);
       if (oj > smax) oj = smax;
       else if (oj < smin) oj = smin;
       if (m == j) { p_ = mine; myout = oj; }
@@ -440,7 +489,7 @@ __device__ void chain_role(MixState* S, const Lds& L, const float* decay1, int n
     // extra weights: ew[j] -= u * out_j (mixer.cpp:67,70)
 #pragma unroll
     for (int j = 0; j < CMX_MIX0; ++j) {
-      float oj = __shfl(myout, j);
+      float oj = bcast_lane(myout, j);
       if (j < m) {
         float v = fsub(ew[j], fmul(uu, oj));
         if (dfl) v = fmul(v, cdec);
@@ -498,7 +547,7 @@ __device__ void tail_role(MixState* S, const Lds& L, const float* decay1, int nb
 #pragma unroll
     for (int j = 0; j < CMX_MIX1; ++j) {
       float mine = fadd(pm, e);
-      float oj = __shfl(mine, j);
+      float oj = bcast_lane(mine, j);
       if (oj > smax) oj = smax;
       else if (oj < smin) oj = smin;
       if (k == j) { p1_ = mine; myout = oj; }

@@ -21,6 +21,16 @@ __device__ __forceinline__ float4 gload4(gptr<const float> p) {
   return make_float4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ float4 gload4(gptr<float> p) { return gload4((gptr<const float>)p); }
+// 16-byte global store issued from an asm statement. hipcc keeps no waitcnt bookkeeping for it, so
+// re-using the data registers afterwards (loading the next weight row into them) does not make
+// the compiler drain vmcnt(0) -- i.e. wait for the store's acknowledgement from L2 -- the way a
+// compiler-visible store does. The hardware has read the data registers once the trailing
+// s_nop 1 has passed. Vector memory operations of one wave are performed in issue order, so a later
+// load of the same address by this wave still observes the stored value.
+__device__ __forceinline__ void gstore4_async(gptr<float> p, float4 v) {
+  v4f o = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(p), "v"(o) : "memory");
+}
 __device__ __forceinline__ void gstore4(gptr<float> p, float4 v) {
   v4f o = {v.x, v.y, v.z, v.w};
   *(gptr<v4f>)p = o;
