@@ -71,6 +71,7 @@ struct Lds {
   uint32_t* dflag; // [32]
   float* in2;      // [64] (tail wave scratch)
   Ctl* ctl;
+  unsigned pfdump; // LDS byte offset of a 256-byte dump area for the row-prefetch LDS-DMA loads
 };
 
 // All inter-wave traffic of this kernel goes through LDS, so its synchronisation only has to
@@ -90,6 +91,14 @@ __device__ __forceinline__ void lds_publish_store(int* p, int v) {
 __device__ __forceinline__ void lds_publish_add1(int* p) {
   int one = 1;
   asm volatile("s_waitcnt lgkmcnt(0)\n\tds_add_u32 %0, %1" :: "v"((lds_int*)p), "v"(one) : "memory");
+}
+// Touch one cache line per lane without a register destination: LDS-DMA load of one dword per lane
+// into LDS[lds_dst + 4*lane] (M0 = LDS destination base, saved and restored in the same statement).
+__device__ __forceinline__ void touch_line(gptr<const float> g, unsigned lds_dst) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
 }
 __device__ __forceinline__ int ld_acq(const int* p) { return lds_poll(p); }
 __device__ __forceinline__ void st_rel(int* p, int v) { lds_publish_store(p, v); }
@@ -112,6 +121,13 @@ __device__ __forceinline__ bool wait_ge(Ctl* ctl, const int* p, int target, bool
 // v_readlane_b32 costs a few clocks, ds_bpermute_b32 a full LDS round trip per step of the chain.
 __device__ __forceinline__ float bcast_lane(float v, int j) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
+}
+
+// MixerInput::SetStretchedInput / SetExtraInput clamp (mixer-input.cpp:17-27): if (x > max) x = max;
+// else if (x < min) x = min;  -- as two selects, no branch.
+__device__ __forceinline__ float clamp_out(float x, float mn, float mx) {
+  const float lo = x < mn ? mn : x;
+  return x > mx ? mx : lo;
 }
 
 __device__ __forceinline__ float4 f4sub_mul(float4 w, float u, float4 x) {
@@ -172,14 +188,25 @@ __device__ __forceinline__ float chain_seg(const float* rowp, int n, float p) {
 
 // ------------------------------------------------------------------ scout (wave 2)
 __device__ void scout_role(MixState* S, const Lds& L, const float* probs, const uint32_t* sel,
-                           const uint8_t* bits, int nbits, int lane) {
+                           const uint8_t* bits, int nbits, int lane, bool prof_on) {
+  uint64_t tprev = __builtin_readcyclecounter();
+#define SPROF(k)                                                       \
+  do {                                                                 \
+    if (prof_on) {                                                     \
+      uint64_t now_ = __builtin_readcyclecounter();                    \
+      pacc[k - 6] += now_ - tprev;                                     \
+      tprev = now_;                                                    \
+    }                                                                  \
+  } while (0)
+  uint64_t pacc[6] = {0, 0, 0, 0, 0, 0};
   const gptr<const float> lut = as_global(S->logit_lut);
   const gptr<const float> gprobs = as_global(probs);
   const gptr<const uint32_t> gsel = as_global(sel);
   const float smin = S->stretch_min, smax = S->stretch_max;
-  float pf_sink = 0.0f;  // destination of the row-prefetch loads (see below); never read
   for (int t = 0; t < nbits; ++t) {
+    SPROF(11);
     if (t >= 2 && !wait_ge(L.ctl, &L.ctl->consumed, 4 * t - 4, true)) return;
+    SPROF(6);
     float* xs = L.xs + (t % 3) * XS;
     BitRec* rec = L.rec + (t % 3);
     const BitRec* prev = L.rec + ((t + 2) % 3);
@@ -210,6 +237,7 @@ __device__ void scout_role(MixState* S, const Lds& L, const float* probs, const 
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    SPROF(7);
     if (lane == CMX_AUX) {  // predictor.cpp:388-393
       float avg = 0;
       avg = fadd(avg, cmx_logistic(xs[433]));
@@ -225,24 +253,8 @@ __device__ void scout_role(MixState* S, const Lds& L, const float* probs, const 
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    // Pull the rows that change at this bit towards L2 (one dword per 128-byte line, 66 lines per
-    // row) so the producers' row swap two bits from now is an L2 hit. The values are discarded and
-    // nothing ever waits for them individually: the loads are issued from asm statements the compiler
-    // keeps no waitcnt bookkeeping for, all into one register that stays live (so it is never re-used
-    // while a load is in flight) and is drained once, at the top of the next bit's prefetch -- a
-    // whole bit later. (Consuming each value made the wave wait for every row's HBM miss in turn.)
-    {
-      const gptr<const float> r0 = as_global(S->rows0);
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink) :: "memory");
-#pragma unroll 1
-      for (int mm = 0; mm < CMX_MIX0; ++mm) {
-        if (rec->changed[mm]) {
-          const uint32_t base = (mm * CMX_ROWS_PER_MIXER + rec->rowidx[mm]) * CMX_ROW0_STRIDE;
-          asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(r0 + base + 32 * lane) : "memory");
-          if (lane < 2) asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(r0 + base + 2048 + 32 * lane) : "memory");
-        }
-      }
-    }
+    SPROF(8);
+    SPROF(9);
     if (lane < 3) {
       float v = xs[lane == 0 ? 433 : lane == 1 ? 2024 : 2077];
       if (v > smax) v = smax;
@@ -254,8 +266,13 @@ __device__ void scout_role(MixState* S, const Lds& L, const float* probs, const 
       rec->bit = bitv;
     }
     st_rel(&L.ctl->scout_epoch, t + 1);
+    SPROF(10);
   }
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink) :: "memory");
+  if (prof_on && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) S->prof[6 + i] += pacc[i];
+  }
+#undef SPROF
 }
 
 // ------------------------------------------------------------------ producers (waves 3..11)
@@ -272,12 +289,13 @@ __device__ void producer_role(MixState* S, const Lds& L, int nbits, int p, int l
   }
   const float cdec = 1.0f - 3.0e-6f;
   const bool lane_ok8 = lane < 8;  // chunk 8 = floats 2048..2079: 8 lanes
+  uint64_t pacc[6] = {0, 0, 0, 0, 0, 0};
   uint64_t tprev = __builtin_readcyclecounter();
 #define PPROF(k)                                                       \
   do {                                                                 \
-    if (prof_on && p == 0) {                                           \
+    if (prof_on && p == 0 && !(dbg & 2)) {                             \
       uint64_t now_ = __builtin_readcyclecounter();                    \
-      if (lane == 0) S->prof[k] += now_ - tprev;                       \
+      pacc[k - 6] += now_ - tprev;                                     \
       tprev = now_;                                                    \
     }                                                                  \
   } while (0)
@@ -394,7 +412,30 @@ __device__ void producer_role(MixState* S, const Lds& L, int nbits, int p, int l
         publish(g);
       }
     }
+    // Pull the rows this wave will swap in at the NEXT bit towards L2 while it would otherwise idle
+    // waiting for the error of this bit: one dword per 128-byte line, 66 lines per row. The values are
+    // discarded: the loads are LDS-DMA (global_load_lds_dword) into a 256-byte dump area, so they have
+    // NO register destination -- an ordinary load issued from asm and never waited for may land in its
+    // VGPR after the compiler has re-assigned that register. They are drained by the vmcnt(0) at the
+    // top of the next serial window, ~10k clocks later. Skipped when the scout has not published the
+    // next bit yet.
+    if (t + 1 < nbits && lds_poll(&L.ctl->scout_epoch) >= t + 2) {
+      const BitRec* nxt = L.rec + ((t + 1) % 3);
+#pragma unroll
+      for (int j = 0; j < MPW; ++j) {
+        if (ok[j] && nxt->changed[mj[j]]) {
+          const uint32_t base = (mj[j] * CMX_ROWS_PER_MIXER + nxt->rowidx[mj[j]]) * CMX_ROW0_STRIDE;
+          touch_line(rows0 + base + 32 * lane, L.pfdump);
+          if (lane < 2) touch_line(rows0 + base + 2048 + 32 * lane, L.pfdump);
+        }
+      }
+    }
     PPROF(10);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (prof_on && p == 0 && !(dbg & 2) && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) S->prof[6 + i] += pacc[i];
   }
 #undef PPROF
 }
@@ -408,63 +449,96 @@ __device__ void chain_role(MixState* S, const Lds& L, const float* decay1, int n
   const float cdec = 1.0f - 3.0e-6f;
   const float lr = is0 ? S->lr[m] : 0.0f;
   uint64_t tprev = __builtin_readcyclecounter();
+  // phase timers accumulate in scalar registers and are written once at the end: a global
+  // read-modify-write per timer would put an L2 round trip into every phase it measures
+  uint64_t pacc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) pacc[i] = 0;
 #define CPROF(k)                                                       \
   do {                                                                 \
     if (prof_on) {                                                     \
       uint64_t now_ = __builtin_readcyclecounter();                    \
-      if (lane == 0) S->prof[k] += now_ - tprev;                       \
+      pacc[k] += now_ - tprev;                                         \
       tprev = now_;                                                    \
     }                                                                  \
   } while (0)
   __builtin_amdgcn_s_setprio(3);
+  // Per-row state of lane m's current weight row stays in registers while the selector does not
+  // change (like the producers' weights): the 0..25 extra weights (mixer.cpp:45-53), the row's step
+  // counter (ContextData::steps) and the mixer's max_steps_. It is swapped only when the row changes.
+  const int mm = is0 ? m : 0;
+  float ew[28];
+#pragma unroll
+  for (int i = 0; i < 28; ++i) ew[i] = 0.0f;
+  uint64_t rsteps = 0;
+  uint64_t mx = S->max_steps[mm];
+  gptr<float> row0 = as_global(S->rows0);
+  gptr<uint64_t> rsp = as_global(S->row_steps);
+  auto store_row_state = [&]() {
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+      if (4 * i < m) gstore4_async(row0 + CMX_ROW0_EXTRA + 4 * i, make_float4(ew[4 * i], ew[4 * i + 1], ew[4 * i + 2], ew[4 * i + 3]));
+    asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 0" :: "v"(rsp), "v"(rsteps) : "memory");
+  };
   for (int t = 0; t < nbits; ++t) {
     if (!wait_ge(L.ctl, &L.ctl->scout_epoch, t + 1, false)) return;
     CPROF(0);
     const BitRec* rec = L.rec + (t % 3);
     const int bit = rec->bit;
-    // state needed after the chain: fetch now, latency hides behind the chain
-    const gptr<float> row0 = as_global(S->rows0) + ((size_t)(is0 ? m : 0) * CMX_ROWS_PER_MIXER + rec->rowidx[is0 ? m : 0]) * CMX_ROW0_STRIDE;
-    float ew[28];
-    {
+    if (is0 && rec->changed[mm]) {
+      // asm stores: re-using ew[] for the incoming row must not make the compiler wait for their acks
+      if (t > 0) store_row_state();
+      row0 = as_global(S->rows0) + ((size_t)mm * CMX_ROWS_PER_MIXER + rec->rowidx[mm]) * CMX_ROW0_STRIDE;
+      rsp = as_global(S->row_steps) + (size_t)mm * CMX_ROWS_PER_MIXER + rec->rowidx[mm];
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
         float4 v = gload4(row0 + CMX_ROW0_EXTRA + 4 * i);
         ew[4 * i] = v.x; ew[4 * i + 1] = v.y; ew[4 * i + 2] = v.z; ew[4 * i + 3] = v.w;
       }
+      rsteps = *rsp;
+#pragma unroll
+      for (int i = 0; i < 28; ++i)
+        if (i >= m) ew[i] = 0.0f;  // only j < m are weights of mixer m (mixer.cpp:45-53); the rest is padding
     }
-    const gptr<uint64_t> rsp = as_global(S->row_steps) + (size_t)(is0 ? m : 0) * CMX_ROWS_PER_MIXER + rec->rowidx[is0 ? m : 0];
-    uint64_t rsteps = *rsp;
-    uint64_t mx = S->max_steps[is0 ? m : 0];
     const double d1 = (double)as_global(decay1)[t];  // (float)(0.9/pow(1e-7*steps_+0.8,0.8)), host libm
 
-    float pm = 0.0f;
+    float pm = 0.0f, dlr = 0.0f;
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {
       const int g = 4 * t + q;
       if (!wait_ge(L.ctl, &L.ctl->staged[g & 1], NPROD * ((g >> 1) + 1), false)) return;
-      CPROF(1);
-      pm = chain_seg(L.prod + (g & 1) * PBUF + (is0 ? m : 0) * SEG, q == 3 ? CMX_IN0 - 1536 : 512, pm);
+      if (q == 0) CPROF(1); else if (q == 1) CPROF(13); else if (q == 2) CPROF(14); else CPROF(15);
+      pm = chain_seg(L.prod + (g & 1) * PBUF + mm * SEG, q == 3 ? CMX_IN0 - 1536 : 512, pm);
       st_rel(&L.ctl->consumed, g + 1);
+      if (q == 0) {
+        // decay * lr (mixer.cpp:58-60): double-precision, needs only state fetched above; done here,
+        // where the row loads have landed and the next segment is usually still being staged
+        float decay = (float)(d1 * (1.5 - ((1.0 * (double)rsteps) / (double)mx)));
+        dlr = fmul(decay, lr);
+      }
       CPROF(2);
     }
-    // decay * lr, ready before the error (mixer.cpp:58-60)
-    float decay = (float)(d1 * (1.5 - ((1.0 * (double)rsteps) / (double)mx)));
-    float dlr = fmul(decay, lr);
-    // intra-layer chain (predictor.cpp:395-400, mixer.cpp:45-53)
-    float e = 0.0f, p_ = 0.0f, myout = 0.0f;
+    // intra-layer chain (predictor.cpp:395-400, mixer.cpp:45-53): mixer j's clamped output is an
+    // extra input of every later mixer. Serial over j, so each step is kept to add -> clamp -> SGPR
+    // broadcast -> mul -> add with no branch and no per-step lane select:
+    //  * ew[j] is exactly 0 for j >= m (zeroed when the row is loaded), so every lane can add
+    //    oj*ew[j] unconditionally: e + (+-0) == e bit for bit (e is never -0: it starts at +0);
+    //  * lane m's own p_ is pm + e after the loop (only terms j < m ever changed its e);
+    //  * the clamp (mixer-input.cpp:23-27) is done per lane before the broadcast.
+    float e = 0.0f;
 #pragma unroll
     for (int j = 0; j < CMX_MIX0; ++j) {
-      float mine = fadd(pm, e);
-      float oj = bcast_lane(mine, j);
-      if (oj > smax) oj = smax;
-      else if (oj < smin) oj = smin;
-      if (m == j) { p_ = mine; myout = oj; }
-      if (m > j) e = fadd(e, fmul(oj, ew[j]));
+      const float mine = clamp_out(fadd(pm, e), smin, smax);
+      const float oj = bcast_lane(mine, j);
+      e = fadd(e, fmul(oj, ew[j]));
     }
+    const float p_ = fadd(pm, e);
+    const float myout = clamp_out(p_, smin, smax);
     CPROF(3);
     // Mixer::Perceive scalar (mixer.cpp:56-64)
     float uu = fmul(dlr, fsub(cmx_logistic(p_), (float)bit));
     ++rsteps;
+    if (rsteps > mx) mx = rsteps;
     const bool dfl = (rsteps & 1023) == 0;
     if (is0) {
       L.upd[m] = uu;
@@ -479,13 +553,8 @@ __device__ void chain_role(MixState* S, const Lds& L, const float* decay1, int n
     if (m >= CMX_MIX0 && m < CMX_MIXERS) tr->rowidx[m - CMX_MIX0] = rec->rowidx[m];
     if (m < 3) tr->aux3[m] = rec->aux3[m];
     if (m == 0) { tr->lstm_p = rec->lstm_p; tr->bit = bit; }
-    // out0 of all lanes is needed below for the extra-weight update: exchange via shuffles
     st_rel(&L.ctl->tail_in, t + 1);
-    if (is0) {
-      if (mix_out) as_global(mix_out)[(size_t)t * CMX_MIXERS + m] = p_;
-      *rsp = rsteps;
-      if (rsteps > mx) S->max_steps[m] = rsteps;
-    }
+    if (is0 && mix_out) as_global(mix_out)[(size_t)t * CMX_MIXERS + m] = p_;
     // extra weights: ew[j] -= u * out_j (mixer.cpp:67,70)
 #pragma unroll
     for (int j = 0; j < CMX_MIX0; ++j) {
@@ -496,12 +565,16 @@ __device__ void chain_role(MixState* S, const Lds& L, const float* decay1, int n
         ew[j] = v;
       }
     }
-    if (is0) {
-#pragma unroll
-      for (int i = 0; i < 7; ++i)
-        if (4 * i < m) gstore4(row0 + CMX_ROW0_EXTRA + 4 * i, make_float4(ew[4 * i], ew[4 * i + 1], ew[4 * i + 2], ew[4 * i + 3]));
-    }
     CPROF(5);
+  }
+  if (is0 && nbits > 0) {
+    store_row_state();
+    S->max_steps[m] = mx;
+  }
+  if (prof_on && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (i < 6 || i > 12) S->prof[i] += pacc[i];
   }
 #undef CPROF
 }
@@ -640,6 +713,7 @@ extern "C" __global__ __launch_bounds__(NTHREADS) void cmx_mixnet_chunk_kernel(
   L.dflag = reinterpret_cast<uint32_t*>(L.upd + 32);              // 32
   L.in2 = reinterpret_cast<float*>(L.dflag + 32);                 // 64
   L.ctl = reinterpret_cast<Ctl*>(L.in2 + 64);
+  L.pfdump = (unsigned)(size_t)(lds_int*)(reinterpret_cast<int*>(L.ctl) + 16);   // 256 B behind the control block
   const int tid = threadIdx.x;
   for (int i = tid; i < 3 * XS; i += NTHREADS) L.xs[i] = 0.0f;    // incl. the zero padding 2078..2111
   for (int i = tid; i < 2 * PBUF; i += NTHREADS) L.prod[i] = 0.0f;
@@ -655,7 +729,7 @@ extern "C" __global__ __launch_bounds__(NTHREADS) void cmx_mixnet_chunk_kernel(
   // mostly-sleeping roles, so nothing competes with its dependent add chain for issue slots.
   if (wave == 0) chain_role(S, L, decay1, nbits, mix_out, (mode & 4) != 0, lane);
   else if (wave == 4) tail_role(S, L, decay1, nbits, p_out, mix_out, lane);
-  else if (wave == 8) scout_role(S, L, probs, sel, bits, nbits, lane);
+  else if (wave == 8) scout_role(S, L, probs, sel, bits, nbits, lane, (mode & 4) != 0 && ((mode >> 4) & 2) != 0);
   else producer_role(S, L, nbits, wave - 1 - (wave > 4) - (wave > 8), lane, (mode & 4) != 0, mode >> 4);
   __syncthreads();
   if (tid == 0 && L.ctl->abort) S->error = 1;
