@@ -71,6 +71,8 @@ struct Lds {
   uint32_t* dflag; // [32]
   float* in2;      // [64] (tail wave scratch)
   Ctl* ctl;
+  float* w2;       // [64] layer-2 weight row
+  float* w1;       // [20][68] layer-1 weight rows
   unsigned pfdump; // LDS byte offset of a 256-byte dump area for the row-prefetch LDS-DMA loads
 };
 
@@ -206,6 +208,9 @@ __device__ void scout_role(MixState* S, const Lds& L, const float* probs, const 
   for (int t = 0; t < nbits; ++t) {
     SPROF(11);
     if (t >= 2 && !wait_ge(L.ctl, &L.ctl->consumed, 4 * t - 4, true)) return;
+    // rec slot t%3 still holds bit t-3, whose layer-1/2 row indices the tail wave reads at the start of
+    // its bit t-3: wait until it has finished that bit
+    if (t >= 3 && !wait_ge(L.ctl, &L.ctl->tail_done, t - 2, true)) return;
     SPROF(6);
     float* xs = L.xs + (t % 3) * XS;
     BitRec* rec = L.rec + (t % 3);
@@ -293,7 +298,7 @@ __device__ void producer_role(MixState* S, const Lds& L, int nbits, int p, int l
   uint64_t tprev = __builtin_readcyclecounter();
 #define PPROF(k)                                                       \
   do {                                                                 \
-    if (prof_on && p == 0 && !(dbg & 2)) {                             \
+    if (prof_on && p == 0 && !(dbg & 6)) {                             \
       uint64_t now_ = __builtin_readcyclecounter();                    \
       pacc[k - 6] += now_ - tprev;                                     \
       tprev = now_;                                                    \
@@ -433,7 +438,7 @@ __device__ void producer_role(MixState* S, const Lds& L, int nbits, int p, int l
     PPROF(10);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (prof_on && p == 0 && !(dbg & 2) && lane == 0) {
+  if (prof_on && p == 0 && !(dbg & 6) && lane == 0) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) S->prof[6 + i] += pacc[i];
   }
@@ -548,6 +553,7 @@ __device__ void chain_role(MixState* S, const Lds& L, const float* decay1, int n
     CPROF(4);
     // hand the layer-0 outputs to the tail wave
     if (t >= 2 && !wait_ge(L.ctl, &L.ctl->tail_done, t - 1, false)) return;
+    CPROF(12);
     TailRec* tr = L.trec + (t & 1);
     if (is0) tr->out0[m] = myout;
     if (m >= CMX_MIX0 && m < CMX_MIXERS) tr->rowidx[m - CMX_MIX0] = rec->rowidx[m];
@@ -574,126 +580,340 @@ __device__ void chain_role(MixState* S, const Lds& L, const float* decay1, int n
   if (prof_on && lane == 0) {
 #pragma unroll
     for (int i = 0; i < 16; ++i)
-      if (i < 6 || i > 12) S->prof[i] += pacc[i];
+      if (i < 6 || i >= 12) S->prof[i] += pacc[i];
   }
 #undef CPROF
 }
 
-// ------------------------------------------------------------------ tail (wave 1)
+// ------------------------------------------------------------------ tail (wave 4)
+// One bit behind the chain wave: layer 1, layer 2, squash, SSE, LSTM override, output, and the
+// Perceive of those 21 mixers and of the SSE (predictor.cpp:402-418,432-437).
+//
+// Everything whose ADDRESS is known before the layer-0 outputs arrive is fetched before waiting for
+// them: the layer-1 rows (kept in registers while a mixer's selector does not change, swapped with
+// asm stores otherwise), and every SSE cell the bit can possibly touch -- the four SSE contexts
+// depend on the final probability only through a 3-way / 4-way quantisation (sse.cpp:248-262), so the
+// 3+3 interpolation cells and 4+3 mixer weights are all loaded up front and selected afterwards.
+// The single layer-2 row lives in LDS for the whole chunk. The SSE context registers (sse.cpp:222-240)
+// stay in registers. What remains serial per bit is arithmetic plus the t_st/t_sq lookups (L1/L2 hits).
+struct U16x8 { unsigned w[4]; };
+__device__ __forceinline__ U16x8 load_cell(const uint16_t* p) {
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  v4u v = *(gptr<const v4u>)as_global(p);
+  U16x8 r; r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
+  return r;
+}
+__device__ __forceinline__ void store_cell_async(uint16_t* p, const U16x8& c) {
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  v4u o = {c.w[0], c.w[1], c.w[2], c.w[3]};
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(as_global(p)), "v"(o) : "memory");
+}
+__device__ __forceinline__ int cell_get(const U16x8& c, int i) {  // entry i of 8 u16
+  unsigned w = i < 2 ? c.w[0] : i < 4 ? c.w[1] : i < 6 ? c.w[2] : c.w[3];
+  return (int)((i & 1) ? (w >> 16) : (w & 0xffffu));
+}
+__device__ __forceinline__ void cell_set(U16x8& c, int i, int v) {
+  const unsigned m = (i & 1) ? 0x0000ffffu : 0xffff0000u, x = ((unsigned)v & 0xffffu) << ((i & 1) * 16);
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if ((i >> 1) == q) c.w[q] = (c.w[q] & m) | x;
+}
+__device__ __forceinline__ unsigned bcast_u(unsigned v) { return (unsigned)__builtin_amdgcn_readlane((int)v, 0); }
+template <class T> __device__ __forceinline__ T pick3(int a, T x0, T x1, T x2) { return a == 0 ? x0 : a == 1 ? x1 : x2; }
+
+struct SseInterp {  // SSEi<7>::SSE_Pred / SSE_Update on a cell held in registers (sse.cpp:37-62)
+  int freq, sw, P;
+  __device__ __forceinline__ int pred(const U16x8& c, int iP) {
+    freq = (6 * iP) >> 15;
+    sw = (6 * iP) & 32767;
+    int f = (((32768 - sw) * cell_get(c, freq) + sw * cell_get(c, freq + 1)) >> 15) - 8192;
+    if (f <= 0) f = 1;
+    if (f >= 32768) f = 32767;
+    P = f;
+    return f;
+  }
+  __device__ __forceinline__ void update(U16x8& c, int bit, int wr0) {
+    P = (P * (32768 - wr0)) >> 15;
+    if (bit == 0) P += wr0;
+    const int c0 = cell_get(c, freq), c1 = cell_get(c, freq + 1);
+    const int dC = c0 - c1;
+    const int sw_dC = (sw * dC + 32767) >> 15;
+    cell_set(c, freq, (uint16_t)(P + sw_dC + 8192));
+    cell_set(c, freq + 1, (uint16_t)(P - (dC - sw_dC) + 8192));
+  }
+};
+
 __device__ void tail_role(MixState* S, const Lds& L, const float* decay1, int nbits, float* p_out,
-                          float* mix_out, int lane) {
+                          float* mix_out, int lane, bool prof_on) {
+  uint64_t tprev = __builtin_readcyclecounter();
+  uint64_t pacc[6] = {0, 0, 0, 0, 0, 0};
+#define TPROF(k)                                                       \
+  do {                                                                 \
+    if (prof_on) {                                                     \
+      uint64_t now_ = __builtin_readcyclecounter();                    \
+      pacc[k - 6] += now_ - tprev;                                     \
+      tprev = now_;                                                    \
+    }                                                                  \
+  } while (0)
   const int k = lane;  // layer-1 mixer index
   const bool is1 = k < CMX_MIX1;
+  const int kk = is1 ? k : 0;
   const float smin = S->stretch_min, smax = S->stretch_max;
   const float cdec = 1.0f - 3.0e-6f;
+  const float lr1 = S->lr[CMX_MIX0 + kk], lr2 = S->lr[CMX_MIXERS - 1];
+  const uint16_t* const t_st = S->t_st;
+  const uint16_t* const t_sq = S->t_sq;
+  uint16_t* const s6 = S->s6;
+  uint16_t* const s7 = S->s7;
+  int* const x1 = S->x1;
+  int* const x2 = S->x2;
+  const gptr<float> rows1 = as_global(S->rows1);
+  const gptr<uint64_t> row_steps = as_global(S->row_steps);
+  float* const w2 = L.w2;  // layer-2 row (predictor.cpp:354-356: a single weight set), LDS-resident
+  const gptr<float> rows2 = as_global(S->rows2);
+  const gptr<uint64_t> rsteps2 = row_steps + (size_t)(CMX_MIXERS - 1) * CMX_ROWS_PER_MIXER;
+  // ---- chunk prologue ----
+  uint32_t cur_row2 = 0xffffffffu;
+  uint64_t rs2 = 0, mx2 = S->max_steps[CMX_MIXERS - 1];
+  uint64_t mx1 = S->max_steps[CMX_MIX0 + kk], rs1 = 0;
+  unsigned sj = S->sse_j, spc = S->sse_pc, sffl = S->sse_ffl;
+  uint64_t steps_done = 0;
+  // layer-1 row of mixer k: LDS-resident (the tail's register budget goes to the SSE arithmetic);
+  // 68-float pitch keeps the rows 16-byte aligned and spreads them over the banks
+  float* const w1 = L.w1 + kk * 68;
+  uint32_t cur_row = 0xffffffffu;
+  gptr<float> row1 = rows1;
+  gptr<uint64_t> rsp1 = row_steps;
+  auto store_row1 = [&]() {
+#pragma unroll
+    for (int i = 0; i < 13; ++i)
+      gstore4_async(row1 + 4 * i, *reinterpret_cast<const float4*>(w1 + 4 * i));
+    asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 0" :: "v"(rsp1), "v"(rs1) : "memory");
+  };
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   for (int t = 0; t < nbits; ++t) {
-    if (!wait_ge(L.ctl, &L.ctl->tail_in, t + 1, true)) return;
-    const TailRec* tr = L.trec + (t & 1);
-    const int bit = tr->bit;
+    // ---- before the layer-0 outputs exist: rows and SSE cells of bit t ----
+    TPROF(11);
+    if (!wait_ge(L.ctl, &L.ctl->scout_epoch, t + 1, true)) return;
+    const BitRec* rec = L.rec + (t % 3);
+    const uint32_t newrow = rec->rowidx[CMX_MIX0 + kk];
     const double d1 = (double)as_global(decay1)[t];
-    // layer-1 inputs: 26 clamped layer-0 outputs + 3 auxiliary stretches (predictor.cpp:397-406)
-    float in1[CMX_IN1];
+    if (is1 && newrow != cur_row) {
+      if (cur_row != 0xffffffffu) store_row1();
+      cur_row = newrow;
+      row1 = rows1 + ((size_t)kk * CMX_ROWS_PER_MIXER + newrow) * CMX_ROW1_STRIDE;
+      rsp1 = row_steps + (size_t)(CMX_MIX0 + kk) * CMX_ROWS_PER_MIXER + newrow;
 #pragma unroll
-    for (int i = 0; i < CMX_MIX0; ++i) in1[i] = tr->out0[i];
+      for (int i = 0; i < 13; ++i) *reinterpret_cast<float4*>(w1 + 4 * i) = gload4(row1 + 4 * i);
+      rs1 = *rsp1;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) in1[CMX_MIX0 + i] = tr->aux3[i];
-    // rows: 64 floats = 29 weights, pad, 20 extra weights
-    const int kk = is1 ? k : 0;
-    const gptr<float> row1 = as_global(S->rows1) + ((size_t)kk * CMX_ROWS_PER_MIXER + tr->rowidx[kk]) * CMX_ROW1_STRIDE;
-    float w1[64];
-    {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        float4 v = gload4(row1 + 4 * i);
-        w1[4 * i] = v.x; w1[4 * i + 1] = v.y; w1[4 * i + 2] = v.z; w1[4 * i + 3] = v.w;
+      for (int j = 0; j < CMX_MIX1; ++j)
+        if (j >= k) w1[CMX_ROW1_EXTRA + j] = 0.0f;  // only j < k are extra weights of mixer k
+    }
+    {  // layer 2 has one weight set in cmix (selector = zero_context_); a changing key is still honoured
+      const uint32_t newrow2 = rec->rowidx[CMX_MIXERS - 1];
+      if (newrow2 != cur_row2) {
+        if (cur_row2 != 0xffffffffu) {
+          if (k < 16) gstore4(rows2 + (size_t)cur_row2 * CMX_ROW2_STRIDE + 4 * k, *reinterpret_cast<const float4*>(w2 + 4 * k));
+          if (k == 0) rsteps2[cur_row2] = rs2;
+        }
+        cur_row2 = newrow2;
+        if (k < 16) *reinterpret_cast<float4*>(w2 + 4 * k) = gload4(rows2 + (size_t)newrow2 * CMX_ROW2_STRIDE + 4 * k);
+        rs2 = rsteps2[newrow2];
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
       }
     }
-    const gptr<uint64_t> rsp1 = as_global(S->row_steps) + (size_t)(CMX_MIX0 + kk) * CMX_ROWS_PER_MIXER + tr->rowidx[kk];
-    uint64_t rs1 = *rsp1, mx1 = S->max_steps[CMX_MIX0 + kk];
-    const gptr<float> row2 = as_global(S->rows2) + (size_t)tr->rowidx[CMX_MIX1] * CMX_ROW2_STRIDE;
-    const gptr<uint64_t> rsp2 = as_global(S->row_steps) + (size_t)(CMX_MIXERS - 1) * CMX_ROWS_PER_MIXER + tr->rowidx[CMX_MIX1];
-
-    float pm = 0.0f;
-#pragma unroll
-    for (int i = 0; i < CMX_IN1; ++i) pm = fadd(pm, fmul(in1[i], w1[i]));
-    float e = 0.0f, p1_ = 0.0f, myout = 0.0f;
-#pragma unroll
-    for (int j = 0; j < CMX_MIX1; ++j) {
-      float mine = fadd(pm, e);
-      float oj = bcast_lane(mine, j);
-      if (oj > smax) oj = smax;
-      else if (oj < smin) oj = smin;
-      if (k == j) { p1_ = mine; myout = oj; }
-      if (k > j) e = fadd(e, fmul(oj, w1[CMX_ROW1_EXTRA + j]));
+    // pull the layer-1 rows of the NEXT bit towards the caches (2 lines per row), if the scout is there yet
+    if (t + 1 < nbits && lds_poll(&L.ctl->scout_epoch) >= t + 2) {
+      const uint32_t nr = L.rec[(t + 1) % 3].rowidx[CMX_MIX0 + kk];
+      if (is1 && nr != cur_row) {
+        const gptr<const float> nrow = rows1 + ((size_t)kk * CMX_ROWS_PER_MIXER + nr) * CMX_ROW1_STRIDE;
+        touch_line(nrow, L.pfdump + 256 + 256 + 64);
+        touch_line(nrow + 32, L.pfdump + 256 + 256 + 64);
+      }
     }
-    // layer-2 inputs = 26 + 20 + 3 (predictor.cpp:397-411)
+    // SSE contexts for a = 0..2 / b = 0..3 (sse.cpp:248-262): lane i pulls candidate cell i towards the
+    // caches (no register destination: LDS-DMA into the dump area); lane 0 reloads the selected ones below
+    if (k < 13) {
+      const unsigned j_ = bcast_u(sj), pc_ = bcast_u(spc), ffl_ = bcast_u(sffl);
+      const int a = k % 3, b = k - 9;
+      const float* addr;
+      if (k < 3) addr = (const float*)(s6 + (size_t)(((((a << 7) + (int)(ffl_ & 127)) << 8) + (int)(pc_ & 255)) * 256 + (int)j_) * 8);
+      else if (k < 6) addr = (const float*)(s7 + (size_t)(((((a << 5) + (int)(ffl_ & 31)) << 8) + (int)(pc_ & 255)) * 255 + (j_ ? (int)j_ - 1 : 0)) * 8);
+      else if (k < 9) addr = (const float*)(x2 + (((((a << 1) + (int)(ffl_ & 1)) << 8) + (int)(pc_ & 255)) * 256 + (int)j_));
+      else addr = (const float*)(x1 + (((((b << 8) + (int)(ffl_ & 255)) << 3) + (int)((pc_ >> 5) & 7)) * 79 + sse_mx1mask((int)j_)));
+      touch_line(as_global(addr), L.pfdump + 256 + 256);  // own 64-byte dump slot behind w2 (not the producers' one)
+    }
+    // ---- layer-0 outputs of bit t ----
+    TPROF(6);
+    if (!wait_ge(L.ctl, &L.ctl->tail_in, t + 1, false)) return;
+    TPROF(7);
+    const TailRec* tr = L.trec + (t & 1);
+    const int bit = tr->bit;
+    // layer-2 inputs = 26 layer-0 outputs + 20 layer-1 outputs + 3 auxiliary stretches (predictor.cpp:
+    // 397-411); the first 26 and the last 3 are also the layer-1 inputs, in this order (:402-406). They
+    // are kept in LDS (in2) and read from there wherever they are needed, not held in registers.
     if (k < CMX_MIX0) L.in2[k] = tr->out0[k];
-    if (is1) L.in2[CMX_MIX0 + k] = myout;
     if (k < 3) L.in2[CMX_MIX0 + CMX_MIX1 + k] = tr->aux3[k];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    float p2_ = 0.0f;
-    if (k == 0) {
-      float w2[52];
+    float pm = 0.0f;
 #pragma unroll
-      for (int i = 0; i < 13; ++i) {
-        float4 v = gload4(row2 + 4 * i);
-        w2[4 * i] = v.x; w2[4 * i + 1] = v.y; w2[4 * i + 2] = v.z; w2[4 * i + 3] = v.w;
-      }
-      uint64_t rs2 = *rsp2, mx2 = S->max_steps[CMX_MIXERS - 1];
+    for (int i = 0; i < CMX_MIX0; ++i) pm = fadd(pm, fmul(L.in2[i], w1[i]));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pm = fadd(pm, fmul(L.in2[CMX_MIX0 + CMX_MIX1 + i], w1[CMX_MIX0 + i]));
+    // intra-layer chain, branch-free (see chain_role): extra weights j >= k are exactly 0
+    float e = 0.0f;
+#pragma unroll
+    for (int j = 0; j < CMX_MIX1; ++j) {
+      const float mine = clamp_out(fadd(pm, e), smin, smax);
+      const float oj = bcast_lane(mine, j);
+      e = fadd(e, fmul(oj, w1[CMX_ROW1_EXTRA + j]));
+    }
+    const float p1_ = fadd(pm, e);
+    const float myout = clamp_out(p1_, smin, smax);
+    if (is1) L.in2[CMX_MIX0 + k] = myout;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    float u2 = 0.0f;
+    int df2 = 0;
+    TPROF(8);
+    if (k == 0) {
       float acc = 0.0f;
 #pragma unroll
-      for (int i = 0; i < CMX_IN2; ++i) acc = fadd(acc, fmul(L.in2[i], w2[i]));
-      p2_ = acc;
-      float pf = sse_step(S, cmx_logistic(p2_), bit, true);  // predictor.cpp:413-414
-      float lp = tr->lstm_p;
-      if (lp == 0.0f || lp == 1.0f) pf = lp;                 // predictor.cpp:383,415-417
+      for (int i = 0; i < 12; ++i) {
+        const float4 xv = *reinterpret_cast<const float4*>(L.in2 + 4 * i);
+        const float4 wv = *reinterpret_cast<const float4*>(w2 + 4 * i);
+        acc = fadd(acc, fmul(xv.x, wv.x)); acc = fadd(acc, fmul(xv.y, wv.y));
+        acc = fadd(acc, fmul(xv.z, wv.z)); acc = fadd(acc, fmul(xv.w, wv.w));
+      }
+      acc = fadd(acc, fmul(L.in2[48], w2[48]));
+      const float p2_ = acc;
+      const float sq = cmx_logistic(p2_);                  // predictor.cpp:413
+      // ---- SSE::Predict (sse.cpp:243-290,320-324) on the pre-fetched cells ----
+      const int p = (int)(1 + (1 - sq) * 32766);
+      const unsigned prq = (unsigned)p >> 11;
+      const int a = (prq > 0) + (prq > 14);
+      const int b = (prq > 0) + (prq > 7) + (prq > 14);
+      const int i6 = ((((a << 7) + (int)(sffl & 127)) << 8) + (int)(spc & 255)) * 256 + (int)sj;
+      const int i7 = ((((a << 5) + (int)(sffl & 31)) << 8) + (int)(spc & 255)) * 255 + (sj ? (int)sj - 1 : 0);
+      const int im2 = ((((a << 1) + (int)(sffl & 1)) << 8) + (int)(spc & 255)) * 256 + (int)sj;
+      const int im1 = ((((b << 8) + (int)(sffl & 255)) << 3) + (int)((spc >> 5) & 7)) * 79 + sse_mx1mask((int)sj);
+      U16x8 c6 = load_cell(s6 + (size_t)i6 * 8);
+      U16x8 c7 = load_cell(s7 + (size_t)i7 * 8);
+      const int w1x = as_global(x1)[im1];
+      const int w2x = as_global(x2)[im2];
+      SseInterp e6, e7;
+      const int stp = as_global(t_st)[p];
+      const int q6 = as_global(t_sq)[sse_extrap(stp, 10240)], q7 = as_global(t_sq)[sse_extrap(stp, 8200)];
+      const int pp1 = e6.pred(c6, q6);
+      const int pp2 = e7.pred(c7, q7);
+      const int s0 = sse_extrap(stp, 7935);
+      const int s1 = sse_extrap(as_global(t_st)[pp1], 9592);
+      const int s4 = sse_extrap(as_global(t_st)[pp2], 7677);
+      const int s2 = sse_extrap(sse_mixup(w1x, s0, s1), 8092);
+      const int mix1_p = as_global(t_sq)[s2];
+      const int s5 = sse_extrap(sse_mixup(w2x, s2, s4), 8202);
+      const int mix2_p = as_global(t_sq)[s5];
+      float pf = (float)(1 - ((mix2_p - 1) / 32766.0));
+      const float lp = tr->lstm_p;
+      if (lp == 0.0f || lp == 1.0f) pf = lp;               // predictor.cpp:383,415-417
       as_global(p_out)[t] = pf;
-      // Mixer::Perceive, layer 2 (mixer.cpp:56-72)
-      float decay = (float)(d1 * (1.5 - ((1.0 * (double)rs2) / (double)mx2)));
-      float u = fmul(fmul(decay, S->lr[CMX_MIXERS - 1]), fsub(cmx_logistic(p2_), (float)bit));
+      // ---- SSE::Perceive (sse.cpp:291-306,326-328) ----
+      e6.update(c6, bit, 106);
+      e7.update(c7, bit, 127);
+      store_cell_async(s6 + (size_t)i6 * 8, c6);
+      store_cell_async(s7 + (size_t)i7 * 8, c7);
+      as_global(x1)[im1] = w1x + sse_wdelta(bit, s0, s1, 6202, mix1_p);
+      as_global(x2)[im2] = w2x + sse_wdelta(bit, s2, s4, 8320, mix2_p);
+      sj += sj + (unsigned)bit;
+      if (sj >= 256) {
+        sffl = (sffl * 2 + (spc >= 0x40)) & 255;
+        spc = sj & 255;
+        sj = 1;
+      }
+      // ---- Mixer::Perceive, layer 2 (mixer.cpp:56-72) ----
+      const float decay = (float)(d1 * (1.5 - ((1.0 * (double)rs2) / (double)mx2)));
+      u2 = fmul(fmul(decay, lr2), fsub(sq, (float)bit));
       ++rs2;
-      *rsp2 = rs2;
-      if (rs2 > mx2) S->max_steps[CMX_MIXERS - 1] = rs2;
-      const bool df = (rs2 & 1023) == 0;
-#pragma unroll
-      for (int i = 0; i < CMX_IN2; ++i) {
-        float v = fsub(w2[i], fmul(u, L.in2[i]));
-        if (df) v = fmul(v, cdec);
-        w2[i] = v;
-      }
-#pragma unroll
-      for (int i = 0; i < 13; ++i) gstore4(row2 + 4 * i, make_float4(w2[4 * i], w2[4 * i + 1], w2[4 * i + 2], w2[4 * i + 3]));
-      if (mix_out) mix_out[(size_t)t * CMX_MIXERS + CMX_MIXERS - 1] = p2_;
-      S->steps = S->steps + 1;
+      if (rs2 > mx2) mx2 = rs2;
+      df2 = (rs2 & 1023) == 0;
+      if (mix_out) as_global(mix_out)[(size_t)t * CMX_MIXERS + CMX_MIXERS - 1] = p2_;
+      ++steps_done;
     }
-    // Mixer::Perceive, layer 1
+    TPROF(9);
+    u2 = bcast_lane(u2, 0);
+    df2 = __builtin_amdgcn_readlane(df2, 0);
+    if (k < CMX_IN2) {  // layer-2 weights: one lane per weight
+      float v = fsub(w2[k], fmul(u2, L.in2[k]));
+      if (df2) v = fmul(v, cdec);
+      w2[k] = v;
+    }
+    // ---- Mixer::Perceive, layer 1 ----
     if (is1) {
-      float decay = (float)(d1 * (1.5 - ((1.0 * (double)rs1) / (double)mx1)));
-      float u = fmul(fmul(decay, S->lr[CMX_MIX0 + k]), fsub(cmx_logistic(p1_), (float)bit));
+      const float decay = (float)(d1 * (1.5 - ((1.0 * (double)rs1) / (double)mx1)));
+      const float u = fmul(fmul(decay, lr1), fsub(cmx_logistic(p1_), (float)bit));
       ++rs1;
-      *rsp1 = rs1;
-      if (rs1 > mx1) S->max_steps[CMX_MIX0 + k] = rs1;
+      if (rs1 > mx1) mx1 = rs1;
       const bool df = (rs1 & 1023) == 0;
+      // w -= u*x over the 29 weights and the k extra weights (mixer.cpp:66-71). All operands are read
+      // into registers first and written back at the end: w1 and in2 are both LDS, and element-wise
+      // read-modify-write through possibly aliasing pointers would serialise on an LDS round trip each.
+      float4 xv[13], wv[13];
 #pragma unroll
-      for (int i = 0; i < CMX_IN1; ++i) {
-        float v = fsub(w1[i], fmul(u, in1[i]));
-        if (df) v = fmul(v, cdec);
-        w1[i] = v;
+      for (int i = 0; i < 13; ++i) wv[i] = *reinterpret_cast<const float4*>(w1 + 4 * i);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) xv[i] = *reinterpret_cast<const float4*>(L.in2 + 4 * i);          // out0[0..23]
+      xv[6] = make_float4(L.in2[24], L.in2[25], L.in2[46], L.in2[47]);                               // out0[24,25], aux[0,1]
+      xv[7] = make_float4(L.in2[48], 0.0f, 0.0f, 0.0f);                                              // aux[2], pad
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {                                                                  // layer-1 outputs 0..19
+        xv[8 + i] = make_float4(L.in2[CMX_MIX0 + 4 * i], L.in2[CMX_MIX0 + 4 * i + 1], L.in2[CMX_MIX0 + 4 * i + 2],
+                                L.in2[CMX_MIX0 + 4 * i + 3]);
       }
+      const float c = df ? cdec : 1.0f;  // w * 1.0f == w exactly
 #pragma unroll
-      for (int j = 0; j < CMX_MIX1; ++j) {
-        if (j < k) {
-          float v = fsub(w1[CMX_ROW1_EXTRA + j], fmul(u, L.in2[CMX_MIX0 + j]));
-          if (df) v = fmul(v, cdec);
-          w1[CMX_ROW1_EXTRA + j] = v;
+      for (int i = 0; i < 13; ++i) {
+        float4 v = f4sub_mul(wv[i], u, xv[i]);
+        if (i >= 8) {  // extra weights: only j < k belong to mixer k, the rest stays exactly 0
+          const int j0 = 4 * (i - 8);
+          if (j0 + 0 >= k) v.x = 0.0f;
+          if (j0 + 1 >= k) v.y = 0.0f;
+          if (j0 + 2 >= k) v.z = 0.0f;
+          if (j0 + 3 >= k) v.w = 0.0f;
         }
+        wv[i] = f4scale(v, c);
       }
 #pragma unroll
-      for (int i = 0; i < 13; ++i) gstore4(row1 + 4 * i, make_float4(w1[4 * i], w1[4 * i + 1], w1[4 * i + 2], w1[4 * i + 3]));
-      if (mix_out) mix_out[(size_t)t * CMX_MIXERS + CMX_MIX0 + k] = p1_;
+      for (int i = 0; i < 13; ++i) *reinterpret_cast<float4*>(w1 + 4 * i) = wv[i];
+      if (mix_out) as_global(mix_out)[(size_t)t * CMX_MIXERS + CMX_MIX0 + k] = p1_;
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     st_rel(&L.ctl->tail_done, t + 1);
+    TPROF(10);
+  }
+  if (prof_on && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) S->prof[6 + i] += pacc[i];
+  }
+#undef TPROF
+  // ---- chunk epilogue: registers / LDS -> HBM ----
+  if (nbits > 0) {
+    if (is1 && cur_row != 0xffffffffu) {
+      store_row1();
+      S->max_steps[CMX_MIX0 + k] = mx1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (k < 16 && cur_row2 != 0xffffffffu)
+      gstore4(rows2 + (size_t)cur_row2 * CMX_ROW2_STRIDE + 4 * k, *reinterpret_cast<const float4*>(w2 + 4 * k));
+    if (k == 0) {
+      if (cur_row2 != 0xffffffffu) rsteps2[cur_row2] = rs2;
+      S->max_steps[CMX_MIXERS - 1] = mx2;
+      S->sse_j = sj; S->sse_pc = spc; S->sse_ffl = sffl;
+      S->steps = S->steps + steps_done;
+    }
   }
 }
 
@@ -714,6 +934,8 @@ extern "C" __global__ __launch_bounds__(NTHREADS) void cmx_mixnet_chunk_kernel(
   L.in2 = reinterpret_cast<float*>(L.dflag + 32);                 // 64
   L.ctl = reinterpret_cast<Ctl*>(L.in2 + 64);
   L.pfdump = (unsigned)(size_t)(lds_int*)(reinterpret_cast<int*>(L.ctl) + 16);   // 256 B behind the control block
+  L.w2 = reinterpret_cast<float*>(L.ctl) + 16 + 64;                               // 256 B behind the dump area
+  L.w1 = L.w2 + 64 + 16 + 64;                                                     // behind w2 and the tail's two dump slots
   const int tid = threadIdx.x;
   for (int i = tid; i < 3 * XS; i += NTHREADS) L.xs[i] = 0.0f;    // incl. the zero padding 2078..2111
   for (int i = tid; i < 2 * PBUF; i += NTHREADS) L.prod[i] = 0.0f;
@@ -721,14 +943,10 @@ extern "C" __global__ __launch_bounds__(NTHREADS) void cmx_mixnet_chunk_kernel(
   if (tid < (int)(sizeof(Ctl) / 4)) reinterpret_cast<int*>(L.ctl)[tid] = 0;
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  if ((mode & 4) && lane == 0) {  // profiling: which SIMD does each wave sit on (HW_ID[5:4])
-    unsigned hwid = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));
-    atomicOr((unsigned long long*)&S->prof[12], (unsigned long long)((hwid >> 4) & 3) << (4 * wave));
-  }
   // Waves w, w+4, w+8 share a SIMD. The chain wave's SIMD-mates are the two latency-tolerant,
   // mostly-sleeping roles, so nothing competes with its dependent add chain for issue slots.
   if (wave == 0) chain_role(S, L, decay1, nbits, mix_out, (mode & 4) != 0, lane);
-  else if (wave == 4) tail_role(S, L, decay1, nbits, p_out, mix_out, lane);
+  else if (wave == 4) tail_role(S, L, decay1, nbits, p_out, mix_out, lane, (mode & 4) != 0 && ((mode >> 4) & 4) != 0);
   else if (wave == 8) scout_role(S, L, probs, sel, bits, nbits, lane, (mode & 4) != 0 && ((mode >> 4) & 2) != 0);
   else producer_role(S, L, nbits, wave - 1 - (wave > 4) - (wave > 8), lane, (mode & 4) != 0, mode >> 4);
   __syncthreads();

@@ -71,7 +71,7 @@ struct MixState {
 };
 
 // dynamic LDS of cmx_mixnet_chunk_kernel (see the carve-up in mixnet_chunk.hip)
-#define CMX_CHUNK_LDS_BYTES 142336
+#define CMX_CHUNK_LDS_BYTES 163840   /* the whole 160 KB LDS of a gfx950 CU: one workgroup per CU */
 #define CMX_CHUNK_THREADS 768
 
 #endif

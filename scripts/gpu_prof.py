@@ -23,15 +23,17 @@ if os.environ.get('CMX_MIXNET_V1') == '1':
 else:
     names = ['wait scout', 'wait staged seg 0', 'chain (4 segs)', 'extras chain', 'u + publish',
              'tail handoff + extras upd', 'P0: wait scout', 'P0: wait u', 'P0: serial window (upd/swap 0,1 + stage 0)',
-             'P0: upd/swap chunks 2..8', 'P0: stage 1..3 (incl. waits)', 'P0: loop top', 'simd ids',
+             'P0: upd/swap chunks 2..8', 'P0: stage 1..3 (incl. waits)', 'P0: loop top', 'wait tail_done(t-1)',
              'wait staged seg 1', 'wait staged seg 2', 'wait staged seg 3']
 if int(os.environ.get('CMX_MIXNET_DBG', '0')) & 2:
     names[6:12] = ['SCOUT: wait consumed', 'SCOUT: probs load + stretch LUT + xs', 'SCOUT: aux + select_row', 'SCOUT: prefetch drain+issue', 'SCOUT: rest + publish', 'SCOUT: loop top']
-tot = sum(pr[:6]) + sum(pr[13:16]) if os.environ.get('CMX_MIXNET_V1') != '1' else sum(pr[:12])
+if int(os.environ.get('CMX_MIXNET_DBG', '0')) & 4:
+    names[6:12] = ['TAIL: prefetch rows + SSE cells', 'TAIL: wait tail_in', 'TAIL: layer 1 (dot + chain)', 'TAIL: layer 2 + SSE + L2 perceive scalars', 'TAIL: updates + publish', 'TAIL: loop top + wait scout']
+tot = sum(pr[:6]) + sum(pr[12:16]) if os.environ.get('CMX_MIXNET_V1') != '1' else sum(pr[:12])
 print('profiled: kernel %.2f ms  %.2f us/bit; total ticks/bit %.0f' % (ms, ms * 1e3 / T, tot / T))
 for n, v in zip(names, pr):
     if n == 'simd ids':
         continue
     print('  %-34s %9.0f ticks/bit  %5.1f%%' % (n, v / T, 100.0 * v / tot))
 
-print('simd id per wave 0..11:', [(pr[12] >> (4 * w)) & 15 for w in range(12)])
+
