@@ -19,11 +19,8 @@
 #include "cmx_glibc_rand.h"
 
 extern "C" __global__ void cmx_lstm_prep(const LstmState, const float*, const uint8_t*, size_t, int);
-extern "C" __global__ void cmx_lstm_sgd(const LstmState, const uint8_t*, size_t, int, int);
-extern "C" __global__ void cmx_lstm_gate_fwd(const LstmState, int, const uint8_t*, size_t, int, int);
-extern "C" __global__ void cmx_lstm_cell(const LstmState, int, int, int);
-extern "C" __global__ void cmx_lstm_out(const LstmState, int, int);
-extern "C" __global__ void cmx_lstm_softmax(const LstmState, float*, int);
+extern "C" __global__ void cmx_lstm_sgd(const LstmState, const float*, const uint8_t*, size_t, int, int);
+extern "C" __global__ void cmx_lstm_fwd(const LstmState, const uint8_t*, size_t, int, int, float*);
 extern "C" __global__ void cmx_lstm_bptt_seq(const LstmState);
 extern "C" __global__ void cmx_lstm_bptt_acc(const LstmState, int);
 extern "C" __global__ void cmx_lstm_bptt_gb(const LstmState, int);
@@ -104,7 +101,7 @@ cmx_lstm_t* cmx_lstm_create(const uint8_t vocab[256], int skip_rand, int device)
     }
     for (int g = 0; g < 3; ++g) {
       for (int i = 0; i < LSTM_C; ++i)
-        for (int j = 0; j < rl; ++j) wt[g][(size_t)j * LSTM_C + i] = w[g][(size_t)i * rl + j];
+        for (int j = 0; j < rl; ++j) wt[g][lstm_wt_index(V, S.insz[l], j, i)] = w[g][(size_t)i * rl + j];
       S.W[l][g] = dallocf((size_t)LSTM_C * rl, w[g].data());
       S.WT[l][g] = dallocf((size_t)LSTM_C * rl, wt[g].data());
       S.M[l][g] = dallocf((size_t)LSTM_C * rl, nullptr);
@@ -194,21 +191,18 @@ int cmx_lstm_run(cmx_lstm_t* h, const float* d_in_probs, const uint8_t* d_bytes,
   for (size_t n = 0; n < nbytes; ++n) {
     const int e = (int)(h->bytes_done % LSTM_H);   // Lstm::epoch_
     const int hc = (int)(h->bytes_done & 1);       // which hid[] buffer holds hidden_
-    hipLaunchKernelGGL(cmx_lstm_prep, dim3(1), dim3(256), 0, st, S, d_in_probs + n * 256, d_bytes, n, e);
     if (e == 0) {                                  // lstm.cpp:93
+      hipLaunchKernelGGL(cmx_lstm_prep, dim3(1), dim3(256), 0, st, S, d_in_probs + n * 256, d_bytes, n, e);
       h->bptt_rounds += 1;
       const int us = (int)(h->bptt_rounds < LSTM_UPDATE_LIMIT ? h->bptt_rounds : LSTM_UPDATE_LIMIT);
       hipLaunchKernelGGL(cmx_lstm_bptt_seq, dim3(1), dim3(1024), 0, st, S);
       hipLaunchKernelGGL(cmx_lstm_bptt_acc, dim3((S.rowlen[1] + 63) / 64, LSTM_C / 4, 6), dim3(64, 4), 0, st, S, us);
       hipLaunchKernelGGL(cmx_lstm_bptt_gb, dim3(6), dim3(256), 0, st, S, us);
     }
-    hipLaunchKernelGGL(cmx_lstm_sgd, dim3((V * LSTM_NH + 255) / 256), dim3(256), 0, st, S, d_bytes, n, e, hc);
-    hipLaunchKernelGGL(cmx_lstm_gate_fwd, dim3(4, 3), dim3(64), 0, st, S, 0, d_bytes, n, e, hc);
-    hipLaunchKernelGGL(cmx_lstm_cell, dim3(1), dim3(256), 0, st, S, 0, e, hc);
-    hipLaunchKernelGGL(cmx_lstm_gate_fwd, dim3(4, 3), dim3(64), 0, st, S, 1, d_bytes, n, e, hc);
-    hipLaunchKernelGGL(cmx_lstm_cell, dim3(1), dim3(256), 0, st, S, 1, e, hc);
-    hipLaunchKernelGGL(cmx_lstm_out, dim3((V + 63) / 64), dim3(64), 0, st, S, e, hc);
-    hipLaunchKernelGGL(cmx_lstm_softmax, dim3(1), dim3(256), 0, st, S, d_out_probs ? d_out_probs + n * 256 : nullptr, e);
+    hipLaunchKernelGGL(cmx_lstm_sgd, dim3((V * LSTM_NH + 255) / 256 + 1), dim3(256), 0, st, S,
+                       e == 0 ? (const float*)nullptr : d_in_probs + n * 256, d_bytes, n, e, hc);
+    hipLaunchKernelGGL(cmx_lstm_fwd, dim3(1), dim3(640), 0, st, S, d_bytes, n, e, hc,
+                       d_out_probs ? d_out_probs + n * 256 : nullptr);
     h->bytes_done += 1;
   }
   if (d_bit_p) {

@@ -11,8 +11,8 @@
 // accumulation/Adam sweep. MFMA is not used: an MFMA step is a fused multiply-add with one
 // rounding and a blocked K order, which cannot reproduce the reference stream.
 //
-// Per byte (stream order): prep -> [bptt_seq -> bptt_acc every 100 bytes] -> sgd || (gate_fwd(0)
-// -> cell(0) -> gate_fwd(1) -> cell(1)) -> out -> softmax.  Bit-level predictions for a whole
+// Per byte (stream order): prep -> [bptt_seq -> bptt_acc -> bptt_gb every 100 bytes] -> sgd -> fwd
+// (both layers, output layer and softmax fused in one workgroup).  Bit-level predictions for a whole
 // chunk are produced by bytemodel_bits at the end (the coded bytes are known in compression).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -34,8 +34,7 @@ constexpr int C = LSTM_C, H = LSTM_H, NH = LSTM_NH, VP = LSTM_VP;
 
 // ---- ByteMixer::SetInput/ByteUpdate head + Lstm::Perceive bookkeeping (byte-mixer.cpp:15-26,
 //      lstm.cpp:80-92). in256 = the byte model's distribution, byte = the byte just coded.
-extern "C" __global__ void cmx_lstm_prep(const LstmState P, const float* in256, const uint8_t* bytes, size_t n, int e) {
-  const LstmState* S = &P;
+__device__ __forceinline__ void lstm_prep(const LstmState* S, const float* in256, const uint8_t* bytes, size_t n, int e) {
   const int tid = threadIdx.x, V = S->V;
   if (S->vocab[tid]) {
     float v = fmul(in256[tid], 2.0f);  // inputs_ (0 + val) *= 2 / num_models_  (unsigned division = 2)
@@ -53,8 +52,17 @@ extern "C" __global__ void cmx_lstm_prep(const LstmState P, const float* in256, 
 }
 
 // ---- output layer SGD (lstm.cpp:112-116): slot[e] = slot[last] - (lr*err_i)*hidden_, both layouts
-extern "C" __global__ void cmx_lstm_sgd(const LstmState P, const uint8_t* bytes, size_t n, int e, int hid_cur) {
+// stand-alone form: on BPTT bytes (epoch 0) the bookkeeping must precede the backward pass (lstm.cpp:88-93)
+extern "C" __global__ void cmx_lstm_prep(const LstmState P, const float* in256, const uint8_t* bytes, size_t n, int e) {
+  lstm_prep(&P, in256, bytes, n, e);
+}
+
+extern "C" __global__ void cmx_lstm_sgd(const LstmState P, const float* in256, const uint8_t* bytes, size_t n, int e, int hid_cur) {
   const LstmState* S = &P;
+  if (blockIdx.x == gridDim.x - 1) {  // the extra block does ByteMixer::SetInput / Lstm::Perceive bookkeeping
+    if (in256) lstm_prep(S, in256, bytes, n, e);   // NULL: already done by cmx_lstm_prep
+    return;
+  }
   const int V = S->V, last = e == 0 ? H - 1 : e - 1;
   const int cur_sym = S->byte_map[bytes[n]];
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -69,119 +77,138 @@ extern "C" __global__ void cmx_lstm_sgd(const LstmState P, const uint8_t* bytes,
   S->OLT[((size_t)e * NH + j) * VP + i] = v;
 }
 
-// ---- LstmLayer::ForwardPass(NeuronLayer&) dot products (lstm-layer.cpp:85-92):
-//      grid (4, 3): blockIdx.y = gate, 64 cells per block; one ordered chain per lane.
-extern "C" __global__ void cmx_lstm_gate_fwd(const LstmState P, int layer, const uint8_t* bytes, size_t n, int e, int hid_cur) {
+// ---- Fused forward pass of one byte: both layers' gate dot products, RMS norm + activations + cell
+//      update, the output-layer matvec and the softmax (lstm.cpp:120-150; lstm-layer.cpp:62-99;
+//      byte-mixer.cpp:27-37) in ONE workgroup of 640 lanes. The byte-rate recurrence is a chain of
+//      six dependent steps; as six launches it was bound by launch latency (4-10 us each), not by
+//      work. Here the steps are separated by workgroup barriers. The 600 gate rows of a layer are
+//      600 ordered chains, one per lane; the transposed weight layout makes a wave's loads of one term
+//      a contiguous 256-byte run, so the CU streams the layer's weights from L2 at its L1 fill rate.
+extern "C" __global__ __launch_bounds__(640) void cmx_lstm_fwd(const LstmState P, const uint8_t* bytes, size_t n, int e,
+                                                               int hid_cur, float* out_probs256) {
   const LstmState* S = &P;
   __shared__ float in[832];
-  const int V = S->V, insz = S->insz[layer], g = blockIdx.y;
-  const int cur_sym = S->byte_map[bytes[n]];
-  const float* hold = S->hid[hid_cur];
-  const float* hnew = S->hid[hid_cur ^ 1];
-  float* li = S->layer_input[layer] + (size_t)e * insz;
-  for (int j = threadIdx.x; j < insz; j += blockDim.x) {
-    float v;
-    if (j < V) v = li[j];                                  // Lstm::SetInput
-    else if (j < V + C) v = hold[layer * C + (j - V)];     // own previous hidden (lstm.cpp:122-124)
-    else if (j < insz - 1) v = hnew[j - V - C];            // layer 1: layer 0's new hidden (lstm.cpp:127-131)
-    else v = 1.0f;                                         // bias
-    in[j] = v;
-    if (g == 0 && blockIdx.x == 0 && j >= V) li[j] = v;    // keep the assembled vector for BPTT
-  }
-  __syncthreads();
-  const int i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= C) return;
-  const float* wt = S->WT[layer][g];
-  float f = wt[(size_t)cur_sym * C + i];
-  const float* wj = wt + (size_t)V * C + i;
-  int j = 0;
-  for (; j + 32 <= insz; j += 32) {   // 32 independent loads in flight per lane, then the ordered chain
-    float w[32];
-#pragma unroll
-    for (int k = 0; k < 32; ++k) w[k] = wj[(size_t)(j + k) * C];
-#pragma unroll
-    for (int k = 0; k < 32; ++k) f = fadd(f, fmul(in[j + k], w[k]));
-  }
-  for (; j < insz; ++j) f = fadd(f, fmul(in[j], wj[(size_t)j * C]));
-  S->raw[layer][g][i] = f;
-}
-
-// ---- RMS norm, activations, cell update (lstm-layer.cpp:62-83, 93-98). One block of 256.
-extern "C" __global__ void cmx_lstm_cell(const LstmState P, int layer, int e, int hid_cur) {
-  const LstmState* S = &P;
   __shared__ float raw[3][C];
   __shared__ float ivar_s[3];
-  const int tid = threadIdx.x;
-  if (tid < C)
-    for (int g = 0; g < 3; ++g) raw[g][tid] = S->raw[layer][g][tid];
-  __syncthreads();
-  if (tid < 3) {  // (norm_*norm_).sum(): expression-template sum runs backward from the last element
-    float s = fmul(raw[tid][C - 1], raw[tid][C - 1]);
-    for (int i = C - 2; i >= 0; --i) s = fadd(s, fmul(raw[tid][i], raw[tid][i]));
-    float iv = fdiv(1.0f, fsqrt(fadd(fdiv(s, (float)C), 1e-5f)));
-    ivar_s[tid] = iv;
-    S->ivar[layer][tid][e] = iv;
-  }
-  __syncthreads();
-  if (tid >= C) return;
-  float st[3];
-  for (int g = 0; g < 3; ++g) {
-    const float* gb = S->gb[layer][g];
-    float nrm = fmul(raw[g][tid], ivar_s[g]);
-    S->norm[layer][g][(size_t)e * C + tid] = nrm;
-    st[g] = fadd(fmul(nrm, gb[tid]), gb[C + tid]);  // norm*gamma + beta
-  }
-  float fg = cmx_logistic(st[0]);
-  float in = cmx_tanhf(st[1]);
-  float og = cmx_logistic(st[2]);
-  S->gstate[layer][0][(size_t)e * C + tid] = fg;
-  S->gstate[layer][1][(size_t)e * C + tid] = in;
-  S->gstate[layer][2][(size_t)e * C + tid] = og;
-  float state = S->state[layer][tid];
-  S->last_state[layer][(size_t)e * C + tid] = state;
-  float igs = fsub(1.0f, fg);
-  S->in_gate_state[layer][(size_t)e * C + tid] = igs;
-  state = fmul(state, fg);
-  state = fadd(state, fmul(in, igs));
-  S->state[layer][tid] = state;
-  float th = cmx_tanhf(state);
-  S->tanh_state[layer][(size_t)e * C + tid] = th;
-  S->hid[hid_cur ^ 1][layer * C + tid] = fmul(og, th);
-}
-
-// ---- output layer matvec (lstm.cpp:132-140): one ordered 401-term chain per vocabulary symbol
-extern "C" __global__ void cmx_lstm_out(const LstmState P, int e, int hid_cur) {
-  const LstmState* S = &P;
   __shared__ float hid[NH];
-  const int V = S->V;
-  const float* hnew = S->hid[hid_cur ^ 1];
-  for (int j = threadIdx.x; j < NH; j += blockDim.x) hid[j] = hnew[j];
-  __syncthreads();
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= V) return;
-  const float* ot = S->OLT + (size_t)e * NH * VP + i;
-  float sum = 0.0f;
-  int j = 0;
-  for (; j + 32 <= NH; j += 32) {
-    float w[32];
-#pragma unroll
-    for (int k = 0; k < 32; ++k) w[k] = ot[(size_t)(j + k) * VP];
-#pragma unroll
-    for (int k = 0; k < 32; ++k) sum = fadd(sum, fmul(hid[j + k], w[k]));
-  }
-  for (; j < NH; ++j) sum = fadd(sum, fmul(hid[j], ot[(size_t)j * VP]));
-  S->logits[i] = sum;
-}
-
-// ---- softmax (lstm.cpp:141-149), ByteMixer::ByteUpdate tail (byte-mixer.cpp:27-37), epoch advance
-extern "C" __global__ void cmx_lstm_softmax(const LstmState P, float* out_probs256, int e) {
-  const LstmState* S = &P;
   __shared__ float ex[VP];
   __shared__ float red[256];
   __shared__ float tot_s;
   const int tid = threadIdx.x, V = S->V;
-  float lg = tid < V ? S->logits[tid] : 0.0f;
-  red[tid] = tid < V ? lg : 0.0f;  // max_out starts at 0 (lstm.cpp:132)
+  const int cur_sym = S->byte_map[bytes[n]];
+  const float* hold = S->hid[hid_cur];
+  float* hnew = S->hid[hid_cur ^ 1];
+  if (tid == 0) hid[NH - 1] = 1.0f;  // bias element of hidden_ (lstm.cpp:18)
+#pragma unroll 1
+  for (int layer = 0; layer < LSTM_L; ++layer) {
+    const int insz = S->insz[layer];
+    float* li = S->layer_input[layer] + (size_t)e * insz;
+    __syncthreads();
+    for (int j = tid; j < insz; j += 640) {
+      float v;
+      if (j < V) v = li[j];                                  // Lstm::SetInput (written by cmx_lstm_prep)
+      else if (j < V + C) v = hold[layer * C + (j - V)];     // own previous hidden (lstm.cpp:122-124)
+      else if (j < insz - 1) v = hid[j - V - C];             // layer 1: layer 0's new hidden (lstm.cpp:127-131)
+      else v = 1.0f;                                         // bias
+      in[j] = v;
+      if (j >= V) li[j] = v;                                 // keep the assembled vector for BPTT
+    }
+    __syncthreads();
+    if (tid < 3 * C) {  // LstmLayer::ForwardPass(NeuronLayer&) dot products (lstm-layer.cpp:85-92)
+      const int g = tid / C, i = tid - g * C;
+      const float* wt = S->WT[layer][g];
+      float f = wt[(size_t)cur_sym * C + i];
+      // dense part: 16-byte loads of four consecutive terms (layout: lstm_wt_index), 8 loads = 32 terms
+      // in flight per lane, then the ordered chain over them
+      const float4* w4 = reinterpret_cast<const float4*>(wt + (size_t)V * C) + i;
+      const int full = insz & ~3, nq = full >> 2;
+      // (A single CU sustains ~50 GB/s from L2/HBM whatever the load width or depth -- measured with dword,
+      // 16-byte and 16-deep ring variants -- so this workgroup is bandwidth-bound at ~45 us per byte; the
+      // next step is to spread the rows over several workgroups with in-launch hand-offs.)
+      int q0 = 0;
+      for (; q0 + 8 <= nq; q0 += 8) {  // 8 x 16-byte loads (32 terms) in flight per lane, then the ordered chain
+        float4 w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w[k] = w4[(size_t)(q0 + k) * C];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float* x = in + 4 * (q0 + k);
+          f = fadd(f, fmul(x[0], w[k].x));
+          f = fadd(f, fmul(x[1], w[k].y));
+          f = fadd(f, fmul(x[2], w[k].z));
+          f = fadd(f, fmul(x[3], w[k].w));
+        }
+      }
+      for (; q0 < nq; ++q0) {
+        const float4 v = w4[(size_t)q0 * C];
+        const float* x = in + 4 * q0;
+        f = fadd(f, fmul(x[0], v.x));
+        f = fadd(f, fmul(x[1], v.y));
+        f = fadd(f, fmul(x[2], v.z));
+        f = fadd(f, fmul(x[3], v.w));
+      }
+      int j = full;
+      const float* wr = wt + (size_t)V * C + (size_t)full * C + i;
+      for (; j < insz; ++j) f = fadd(f, fmul(in[j], wr[(size_t)(j - full) * C]));
+      raw[g][i] = f;
+    }
+    __syncthreads();
+    // RMS norm, activations, cell update (lstm-layer.cpp:62-83, 93-98)
+    if (tid < 3) {  // (norm_*norm_).sum(): expression-template sum runs backward from the last element
+      float s = fmul(raw[tid][C - 1], raw[tid][C - 1]);
+      for (int i = C - 2; i >= 0; --i) s = fadd(s, fmul(raw[tid][i], raw[tid][i]));
+      float iv = fdiv(1.0f, fsqrt(fadd(fdiv(s, (float)C), 1e-5f)));
+      ivar_s[tid] = iv;
+      S->ivar[layer][tid][e] = iv;
+    }
+    __syncthreads();
+    if (tid < C) {
+      float st[3];
+      for (int g = 0; g < 3; ++g) {
+        const float* gb = S->gb[layer][g];
+        float nrm = fmul(raw[g][tid], ivar_s[g]);
+        S->norm[layer][g][(size_t)e * C + tid] = nrm;
+        st[g] = fadd(fmul(nrm, gb[tid]), gb[C + tid]);  // norm*gamma + beta
+      }
+      float fg = cmx_logistic(st[0]);
+      float inn = cmx_tanhf(st[1]);
+      float og = cmx_logistic(st[2]);
+      S->gstate[layer][0][(size_t)e * C + tid] = fg;
+      S->gstate[layer][1][(size_t)e * C + tid] = inn;
+      S->gstate[layer][2][(size_t)e * C + tid] = og;
+      float state = S->state[layer][tid];
+      S->last_state[layer][(size_t)e * C + tid] = state;
+      float igs = fsub(1.0f, fg);
+      S->in_gate_state[layer][(size_t)e * C + tid] = igs;
+      state = fmul(state, fg);
+      state = fadd(state, fmul(inn, igs));
+      S->state[layer][tid] = state;
+      float th = cmx_tanhf(state);
+      S->tanh_state[layer][(size_t)e * C + tid] = th;
+      const float h = fmul(og, th);
+      hid[layer * C + tid] = h;
+      hnew[layer * C + tid] = h;
+    }
+  }
+  __syncthreads();
+  // output layer matvec (lstm.cpp:132-140): one ordered 401-term chain per vocabulary symbol
+  float lg = 0.0f;
+  if (tid < V) {
+    const float* ot = S->OLT + (size_t)e * NH * VP + tid;
+    float sum = 0.0f;
+    int j = 0;
+    for (; j + 32 <= NH; j += 32) {
+      float w[32];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) w[k] = ot[(size_t)(j + k) * VP];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) sum = fadd(sum, fmul(hid[j + k], w[k]));
+    }
+    for (; j < NH; ++j) sum = fadd(sum, fmul(hid[j], ot[(size_t)j * VP]));
+    lg = sum;
+  }
+  // softmax (lstm.cpp:141-149), ByteMixer::ByteUpdate tail (byte-mixer.cpp:27-37)
+  if (tid < 256) red[tid] = tid < V ? lg : 0.0f;  // max_out starts at 0 (lstm.cpp:132)
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
     if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
@@ -202,9 +229,11 @@ extern "C" __global__ void cmx_lstm_softmax(const LstmState P, float* out_probs2
     ex[tid] = p;
   }
   __syncthreads();
-  float pb = S->vocab[tid] ? ex[S->byte_map[tid]] : 0.0f;
-  S->byte_probs[tid] = pb;
-  if (out_probs256) out_probs256[tid] = pb;
+  if (tid < 256) {
+    float pb = S->vocab[tid] ? ex[S->byte_map[tid]] : 0.0f;
+    S->byte_probs[tid] = pb;
+    if (out_probs256) out_probs256[tid] = pb;
+  }
 }
 
 // ---- BPTT, sequential part (lstm.cpp:93-110; lstm-layer.cpp:108-183): one block of 1024 walks
@@ -365,7 +394,7 @@ extern "C" __global__ void cmx_lstm_bptt_acc(const LstmState P, int update_steps
   S->M[layer][g][ix] = m;
   S->Vv[layer][g][ix] = v;
   S->W[layer][g][ix] = w;
-  S->WT[layer][g][(size_t)c * C + i] = w;
+  S->WT[layer][g][lstm_wt_index(V, insz, c, i)] = w;
 }
 
 // ---- Adam for gamma / beta (lstm-layer.cpp:191-195); grid 6 blocks of 256

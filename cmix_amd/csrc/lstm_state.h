@@ -25,7 +25,7 @@ struct LstmState {
 
   // gate parameters, g = 0 forget, 1 input node, 2 output gate
   float* W[LSTM_L][3];           // [C][rowlen]   reference layout (coalesced for the BPTT matvecs)
-  float* WT[LSTM_L][3];          // [rowlen][C]   transposed copy  (coalesced for the forward chains)
+  float* WT[LSTM_L][3];          // transposed copy for the forward chains, see lstm_wt_index()
   float* M[LSTM_L][3];           // Adam first moment  [C][rowlen]
   float* Vv[LSTM_L][3];          // Adam second moment [C][rowlen]
   float* gb[LSTM_L][3];          // [8][C]: gamma, beta, gamma_m, gamma_v, beta_m, beta_v, gamma_u, beta_u
@@ -50,5 +50,22 @@ struct LstmState {
   const float* adam_tab;         // [3001][4] alpha, 1-beta1^t, 1-beta2^t (host libm)
   float* byte_probs;             // [256] ByteModel::probs_ of the byte mixer
 };
+
+// Position of weight (cell i, column c) in the transposed copy WT[l][g]. The V one-hot columns come
+// first, [c][i]. The dense columns (d = c - V, insz of them) are grouped four at a time so that a
+// lane's four consecutive terms are one 16-byte load: [d/4][i][4]; the insz%4 trailing columns are
+// stored [d][i] again. (dword loads left the CU's L2->L1 path at ~1/3 of its rate.)
+#if defined(__HIPCC__) || defined(__cplusplus)
+static inline
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+size_t lstm_wt_index(int V, int insz, int c, int i) {
+  if (c < V) return (size_t)c * LSTM_C + i;
+  const int d = c - V, full = insz & ~3;
+  if (d < full) return (size_t)V * LSTM_C + ((size_t)(d >> 2) * LSTM_C + i) * 4 + (d & 3);
+  return (size_t)V * LSTM_C + (size_t)full * LSTM_C + (size_t)(d - full) * LSTM_C + i;
+}
+#endif
 
 #endif
