@@ -162,6 +162,7 @@ def main():
     import torch
     import torch.distributed as dist
     from cmix_amd import engine as E
+    from cmix_amd import shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -176,7 +177,7 @@ def main():
 
     nsteps = a.warmup + a.steps
     nbytes = a.chunk_bytes * nsteps
-    probs, sel_standin, bits, text = make_operands(nbytes, 1000 + rank, dev)
+    probs, sel_standin, bits, text = make_operands(nbytes, shard.shard_seed(rank), dev)
     del sel_standin  # selectors now come from the context stage
     text = np.ascontiguousarray(text)
     vocab = np.zeros(256, np.uint8)
@@ -232,16 +233,12 @@ def main():
     dt = time.perf_counter() - t0
     ctx.sync()
     net.sync()
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    total_bytes, dt, _ = shard.aggregate_throughput(a.chunk_bytes * a.steps, dt, dev)  # sum of bytes / max of times
     kernel_ms = [ev[i][4].elapsed_time(ev[i][5]) for i in range(a.warmup, nsteps)]
     ctx_ms = float(np.mean([ev[i][0].elapsed_time(ev[i][1]) for i in range(a.warmup, nsteps)]))
     lstm_ms = float(np.mean([ev[i][2].elapsed_time(ev[i][3]) for i in range(a.warmup, nsteps)]))
 
     if rank == 0:
-        total_bytes = a.chunk_bytes * a.steps * world
         avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
         algo = ALGO_BYTES_PER_INPUT_BYTE * a.chunk_bytes
         achieved = algo / avg_kernel_s / 1e9
