@@ -130,6 +130,23 @@ def cpu_baseline_port(probs, sel32, bits, text, ppmd, vocab, budget_s=14.0):
             "us_per_bit": {"mixnet": us_mix, "ctxmodels": us_ctx, "lstm": us_lstm}}
 
 
+def measured_traffic(chunk_bytes):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command
+    (profiles/r01_pmc_bench.json: `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate runs,
+    scripts/gpu_pmc_bench.sh). FETCH_SIZE is doubled: on gfx950 it reports half of the bytes of 16 B/lane
+    reads (MI355X_MICROARCH.md, HBM section); WRITE_SIZE matched a known 503 MB fill to 1.5 %. Counters cannot
+    be collected inside a timed run, so this is a recorded measurement, valid for 1024-byte chunks."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_bench.json")
+    if chunk_bytes != 1024 or not os.path.exists(path):
+        return None
+    k = json.load(open(path)).get("cmx_mixnet_chunk_kernel")
+    if not k:
+        return None
+    rd = 2.0 * k["FETCH_SIZE"]["sum_kb"] * 1024 / k["FETCH_SIZE"]["launches"]
+    wr = k["WRITE_SIZE"]["sum_kb"] * 1024 / k["WRITE_SIZE"]["launches"]
+    return rd + wr
+
+
 def cpu_reference_full(text, nbytes=4096):
     exe = os.path.join(ROOT, "oracle", "_ref", "cmix_O3")
     if not os.path.exists(exe):
@@ -260,7 +277,7 @@ def main():
                                  "lstm": lstm_ms * 1e3 / cb,
                                  "note": "HIP-event time of each stage over a chunk (stages overlap on separate streams)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(a.chunk_bytes),
                          "kernel": "cmx_mixnet_chunk_kernel", "avg_kernel_ms": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": algo},
         }

@@ -282,11 +282,29 @@ cmx_ctxmodels_t* cmx_ctxmodels_create(const uint8_t vocab[256], int device) {
   return h;
 }
 
+static int ctxmodels_launch(cmx_ctxmodels_t* h, const uint8_t* d_bytes, size_t nbytes, float* d_probs, size_t pstride,
+                            uint32_t* d_sel, void* stream);
+
 int cmx_ctxmodels_run(cmx_ctxmodels_t* h, const uint8_t* d_bytes, size_t nbytes, float* d_probs, size_t pstride,
                       uint32_t* d_sel, void* stream) {
   if (!h) { cmx_set_err("cmx_ctxmodels_run: null handle"); return 1; }
   if (nbytes == 0) return 0;
   if (!d_bytes || !d_probs || !d_sel || pstride < CMX_N_INPUTS) { cmx_set_err("cmx_ctxmodels_run: bad argument"); return 1; }
+  return ctxmodels_launch(h, d_bytes, nbytes, d_probs, pstride, d_sel, stream);
+}
+
+// Predictor::Pretrain (predictor.cpp:471-487) for the models this stage owns: Predict, Perceive,
+// UpdateContexts and ByteUpdate exactly as in normal coding -- only nothing downstream (mixers, SSE,
+// LSTM, PPMd) is trained, so no outputs are produced.
+int cmx_ctxmodels_pretrain(cmx_ctxmodels_t* h, const uint8_t* d_bytes, size_t nbytes, void* stream) {
+  if (!h) { cmx_set_err("cmx_ctxmodels_pretrain: null handle"); return 1; }
+  if (nbytes == 0) return 0;
+  if (!d_bytes) { cmx_set_err("cmx_ctxmodels_pretrain: bad argument"); return 1; }
+  return ctxmodels_launch(h, d_bytes, nbytes, nullptr, CMX_N_INPUTS, nullptr, stream);
+}
+
+static int ctxmodels_launch(cmx_ctxmodels_t* h, const uint8_t* d_bytes, size_t nbytes, float* d_probs, size_t pstride,
+                            uint32_t* d_sel, void* stream) {
   if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
   hipStream_t st = (hipStream_t)stream;
   if (h->dist_cap < nbytes) {
@@ -301,8 +319,9 @@ int cmx_ctxmodels_run(cmx_ctxmodels_t* h, const uint8_t* d_bytes, size_t nbytes,
   hipLaunchKernelGGL(cmx_ctxmodels_kernel, dim3(1), dim3(64), cmx_ctxmodels_lds_bytes(), st, h->dev, d_bytes, nbytes,
                      d_probs, pstride, d_sel, h->d_bracket_dist);
   // column 0: ByteModel::Predict of the Bracket model along the known bytes (byte-model.cpp:8-37)
-  hipLaunchKernelGGL(cmx_bytemodel_bits, dim3((unsigned)nbytes), dim3(64), 0, st, h->d_prev_dist, h->d_bracket_dist,
-                     d_bytes, nbytes, d_probs, (int*)nullptr, pstride);
+  if (d_probs)
+    hipLaunchKernelGGL(cmx_bytemodel_bits, dim3((unsigned)nbytes), dim3(64), 0, st, h->d_prev_dist, h->d_bracket_dist,
+                       d_bytes, nbytes, d_probs, (int*)nullptr, pstride);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { cmx_set_err(std::string("cmx_ctxmodels_run: ") + hipGetErrorString(e)); return 1; }
   return 0;

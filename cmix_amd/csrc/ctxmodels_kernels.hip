@@ -145,7 +145,7 @@ cmx_ctxmodels_kernel(const CtxDev D, const uint8_t* __restrict__ bytes, size_t n
     const size_t t0 = 8 * n;
 
     // ---- the 47 selectors Mixer::Mix reads at each of the 8 Predict() calls ----
-    if (lane < CTX_NSEL) {
+    if (sel && lane < CTX_NSEL) {
       const u64 base = L.sel_kind == SEL_ZERO ? 0 : regs[L.sel_src];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -259,7 +259,7 @@ cmx_ctxmodels_kernel(const CtxDev D, const uint8_t* __restrict__ bytes, size_t n
         }
       }
     }
-    if (lane >= 1 && lane < CTX_NM) {
+    if (probs && lane >= 1 && lane < CTX_NM) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) probs[(t0 + j) * pstride + L.col] = out[j];
     }

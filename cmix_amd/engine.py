@@ -74,6 +74,7 @@ def lib():
         L.cmx_ctxmodels_destroy.argtypes = [C.c_void_p]
         L.cmx_ctxmodels_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
                                         C.c_void_p]
+        L.cmx_ctxmodels_pretrain.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.cmx_ctxmodels_sync.argtypes = [C.c_void_p]
         L.cmx_ctxmodels_get_manager.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.cmx_probe_libm.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
@@ -274,6 +275,15 @@ class CtxModels:
         if rc:
             raise CmxError(last_error())
         return probs, sel
+
+    def pretrain(self, data, stream=None):
+        """Predictor::Pretrain over data [N] u8 cuda (dictionary warm-up): state only, no outputs."""
+        import torch
+        assert data.is_cuda and data.dtype == torch.uint8 and data.is_contiguous()
+        if stream is None:
+            stream = torch.cuda.current_stream(data.device).cuda_stream
+        if lib().cmx_ctxmodels_pretrain(self.h, data.data_ptr(), int(data.numel()), C.c_void_p(stream)):
+            raise CmxError(last_error())
 
     def sync(self):
         if lib().cmx_ctxmodels_sync(self.h):

@@ -164,6 +164,10 @@ void cmx_ctxmodels_destroy(cmx_ctxmodels_t*);
  * Asynchronous on `stream`. */
 int cmx_ctxmodels_run(cmx_ctxmodels_t*, const uint8_t* d_bytes, size_t nbytes, float* d_probs, size_t pstride,
                       uint32_t* d_sel, void* stream);
+/* Predictor::Pretrain (predictor.cpp:471-487) over nbytes dictionary bytes for the models of this
+ * stage: same state transitions as cmx_ctxmodels_run, no outputs (mixers/SSE/LSTM/PPMd are not
+ * trained during pretraining). */
+int cmx_ctxmodels_pretrain(cmx_ctxmodels_t*, const uint8_t* d_bytes, size_t nbytes, void* stream);
 /* Waits for the handle's work; reports device-side failures. */
 int cmx_ctxmodels_sync(cmx_ctxmodels_t*);
 /* Test hook: ContextManager registers (25), byte contexts (54), bit contexts (8) between bytes. */

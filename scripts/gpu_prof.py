@@ -1,7 +1,7 @@
 """Per-phase shader-clock breakdown of the mixnet kernel (debug aid; not the bench)."""
 import sys, time, os
 import numpy as np, torch
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [R, os.path.join(R, 'tests')]
 from conftest import synth_mixnet_inputs
 from cmix_amd import engine as E
 

@@ -52,9 +52,12 @@ def default_block(payload: bytes) -> bytes:
     return bytes([0]) + len(payload).to_bytes(4, "big") + payload
 
 
-def trace(stream: bytes, full=True):
+def trace(stream: bytes, full=True, pretrain: bytes = b""):
     from oracle import refharness as R
     r = R.Ref(R.vocab_of(stream))
+    for byte in pretrain:  # preprocessor::Pretrain (preprocessor.cpp:37-69): Predictor::Pretrain per bit, MSB first
+        for j in range(7, -1, -1):
+            r.pretrain((byte >> j) & 1)
     N = len(stream)
     T = 8 * N
     bits = np.empty(T, np.uint8)
@@ -100,6 +103,8 @@ def trace(stream: bytes, full=True):
                lstm_probs=lstm, bracket_probs=brk, vocab=R.vocab_of(stream), ctx_sizes=r.context_sizes())
     if not full:
         out["small_probs"] = small
+    if pretrain:
+        out["pretrain"] = np.frombuffer(pretrain, np.uint8)
     if full:
         q = np.rint(probs / GRID).astype(np.int64)
         on = (q >= 0) & (q <= 4095) & ((q.astype(np.float32) * GRID) == probs)
@@ -120,6 +125,11 @@ def unpack_probs(g):
 
 def _child(kind, nbytes, seed, path, full):
     from cmix_amd import synth
+    pre = b""
+    if kind == "pretrained":  # a dictionary-like word list is pretrained, then text is coded
+        words = synth.enwik_like(6000, seed + 1).split()
+        pre = (b"\n".join(sorted(set(words))[:60]) + b"\n")[:300]
+        kind = "text"
     if kind == "text":
         payload = synth.enwik_like(nbytes + 4096, seed)[4096:4096 + nbytes]
         stream = text_block(payload)
@@ -137,7 +147,7 @@ def _child(kind, nbytes, seed, path, full):
         stream = default_block(recs.tobytes()[:nbytes])
     else:
         raise ValueError(kind)
-    g = trace(stream, full)
+    g = trace(stream, full, pre)
     np.savez_compressed(path, **g)
     print("wrote", path, {k: v.shape for k, v in g.items()})
 
@@ -147,6 +157,7 @@ FIXTURES = [  # (name, kind, payload bytes, seed, full probs?)
     ("binary_64", "binary", 59, 7, True),
     ("text_2k_nofull", "text", 2042, 1001, False),
     ("brackets_1k", "brackets", 1018, 5, False),
+    ("pretrained_128", "pretrained", 122, 21, False),
 ]
 BIG = [
     ("text_4k", "text", 4090, 1000, True),

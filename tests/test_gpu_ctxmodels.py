@@ -13,10 +13,12 @@ pytestmark = pytest.mark.gpu
 COLS = np.array([0, 1, 2] + list(range(2025, 2076)))
 
 
-def _run_gpu(vocab, data, chunks=None, want_mgr=False):
+def _run_gpu(vocab, data, chunks=None, want_mgr=False, pretrain=None):
     import torch
     from cmix_amd import engine as E
     c = E.CtxModels(vocab, 0)
+    if pretrain is not None:
+        c.pretrain(torch.from_numpy(np.ascontiguousarray(pretrain)).cuda())
     data = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8))
     N = len(data)
     d = torch.from_numpy(data.copy()).cuda()
@@ -40,7 +42,7 @@ def _check_golden(name, chunks=None, big=False):
     g = load_golden(name, big)
     stream = g["stream"]
     want_p = mg.unpack_probs(g)[:, COLS] if "probs_q" in g else g["small_probs"][:, :54]
-    p, s, mgr = _run_gpu(g["vocab"], stream, chunks, want_mgr=True)
+    p, s, mgr = _run_gpu(g["vocab"], stream, chunks, want_mgr=True, pretrain=g.get("pretrain"))
     bad = np.argwhere(~bits_equal(p, want_p))
     assert len(bad) == 0, f"{name}: model {bad[0][1]} (col {COLS[bad[0][1]]}) differs first at bit {bad[0][0]}"
     want_s = (g["sel"] & np.uint64(0xFFFFFFFF)).astype(np.uint32)
@@ -66,6 +68,10 @@ def test_golden_binary_64():
 
 def test_golden_brackets_1k_ragged_chunks():
     _check_golden("brackets_1k", chunks=[1, 2, 9, 100, 101, 640])
+
+
+def test_golden_pretrained_128():
+    _check_golden("pretrained_128", chunks=[50])  # Predictor::Pretrain over 300 dictionary bytes first
 
 
 def test_golden_text_2k():

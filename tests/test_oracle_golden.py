@@ -86,6 +86,8 @@ def _check_ctxmodels(name, big=False):
     registers, the 54 byte contexts; per bit the 8 bit contexts."""
     g = load_golden(name, big)
     c = O.CtxModels(g["vocab"])
+    if "pretrain" in g:  # Predictor::Pretrain = the same transitions for these models, outputs unused
+        c.run(g["pretrain"].tobytes())
     stream = g["stream"]
     probs = mg.unpack_probs(g)[:, O.SMALL_COLS] if "probs_q" in g else g["small_probs"][:, :54]
     t = 0
@@ -132,3 +134,7 @@ def test_ctxmodels_brackets_golden():
 
 def test_ctxmodels_random_160k_local():
     _check_ctxmodels("random_160k", big=True)  # DirectHash evictions (20-probe reset), full hashed tables
+
+
+def test_ctxmodels_pretrained_golden():
+    _check_ctxmodels("pretrained_128")  # 300 dictionary bytes through Predictor::Pretrain first
