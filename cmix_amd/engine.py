@@ -77,6 +77,10 @@ def lib():
         L.cmx_ctxmodels_pretrain.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.cmx_ctxmodels_sync.argtypes = [C.c_void_p]
         L.cmx_ctxmodels_get_manager.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cmx_ppmd_create.restype = C.c_void_p
+        L.cmx_ppmd_create.argtypes = [C.c_void_p]
+        L.cmx_ppmd_destroy.argtypes = [C.c_void_p]
+        L.cmx_ppmd_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.cmx_probe_libm.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
         _lib = L
     return _lib
@@ -311,6 +315,36 @@ def bytemodel_bits(dist0, dist_rest, data, layer0, col, device=0, stream=None):
                                       layer0.data_ptr() + 4 * col, N_INPUTS, None, C.c_void_p(stream))
     if rc:
         raise CmxError(last_error())
+
+
+class Ppmd:
+    """HOST stage: PPMd order-25 byte model (runs on a host core ahead of the device pipeline)."""
+
+    def __init__(self, vocab):
+        vocab = np.ascontiguousarray(vocab, np.uint8)
+        assert vocab.size == 256
+        self.h = lib().cmx_ppmd_create(vocab.ctypes.data)
+        if not self.h:
+            raise CmxError(last_error())
+
+    def run(self, data):
+        """data: bytes / u8 array -> [N,256] f32: the byte distribution after each byte."""
+        data = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8))
+        out = np.empty((len(data), 256), np.float32)
+        if lib().cmx_ppmd_run(self.h, data.ctypes.data, len(data), out.ctypes.data):
+            raise CmxError(last_error())
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().cmx_ppmd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def glibc_rand(seed, n):

@@ -174,6 +174,20 @@ int cmx_ctxmodels_sync(cmx_ctxmodels_t*);
 int cmx_ctxmodels_get_manager(cmx_ctxmodels_t*, uint64_t* regs25, uint64_t* ctx54, uint64_t* bitctx8);
 
 /* ------------------------------------------------------------------------
+ * 2d. HOST stage: PPMd order-25 byte model = PPMD::PPMD / PPMD::ByteUpdate (src/models/ppmd.cpp:
+ *     1322-1338 and everything below it; constructed with (25, 14000 MB) at predictor.cpp:101).
+ *     A pure function of the byte stream, 0.4 % of the reference's CPU time: it runs ahead of the device
+ *     pipeline on one host core (SURVEY.md 8 note 2). HOST pointers.
+ * ------------------------------------------------------------------------ */
+typedef struct cmx_ppmd cmx_ppmd_t;
+cmx_ppmd_t* cmx_ppmd_create(const uint8_t vocab[256]);
+void cmx_ppmd_destroy(cmx_ppmd_t*);
+/* Feeds nbytes bytes; out_probs [nbytes][256] f32 receives ByteModel::probs_ after each byte (what
+ * predictor.cpp:450-457 hands to the byte mixer and what column 2076 is formed from). Fails (nonzero) if the
+ * model would need the reference's memory-exhaustion path (ppmd.cpp:686-727), which is not implemented. */
+int cmx_ppmd_run(cmx_ppmd_t*, const uint8_t* bytes, size_t nbytes, float* out_probs);
+
+/* ------------------------------------------------------------------------
  * Device libm probes (parity tests): evaluate the engine's expf / tanhf /
  * logistic on the device for n host floats. which: 0 expf, 1 tanhf, 2 logistic
  * ------------------------------------------------------------------------ */
