@@ -16,10 +16,10 @@ bracket}.cpp) -> layer-0 columns 0-2, 2025-2075 and the 47 mixer selectors; (2) 
 LSTM byte mixer (src/mixer/{byte-mixer,lstm,lstm-layer}.cpp) -> column 2077; (3) the final mixing
 network -- stretch, 26+20+1 gated logistic mixers with online update, squash, SSE
 (src/predictor.cpp:388-418,432-437). Each stage runs on its own HIP stream; a chunk's mixing
-network starts when the chunk's other two stages have written their columns. paq8, fxcm (layer-0
-columns 3..2024) and PPMd (byte distribution feeding the LSTM and column 2076) have no device
-stage yet: seeded stand-ins of the same shape and value grid (k/4095) replace them, and
-`config.workload` says so. The number is the throughput of these device stages, not of a whole
+network starts when the chunk's other two stages have written their columns. PPMd (byte distribution
+feeding the LSTM and column 2076) is the engine's host stage (cmix_amd/csrc/ppmd_host.cpp): it runs
+on one host core inside the timed loop. paq8 and fxcm (layer-0 columns 3..2024) have no stage yet: a
+seeded stand-in of the same shape and value grid (k/4095) replaces them, and `config.workload` says so. The number is the throughput of these device stages, not of a whole
 predictor.
 
 roofline: HBM-bound accounting per SURVEY.md 8(d)(i): 55 172 f32 weights x 8 B (read +
@@ -95,6 +95,7 @@ def make_operands(nbytes, seed, device):
 
 
 def cpu_baseline_port(probs, sel32, bits, text, ppmd, vocab, budget_s=14.0):
+    ppmd = ppmd.clone()
     """Time the plain-C oracle of the same three stages on one host core over a bounded prefix.
     cmix is single-threaded, so the stages run back to back on the CPU: us/bit adds up."""
     from oracle import oracle as O
@@ -200,12 +201,12 @@ def main():
     vocab = np.zeros(256, np.uint8)
     vocab[np.unique(text)] = 1
     d_bytes = torch.from_numpy(text.copy()).to(dev)
-    # PPMd stand-in: a peaked distribution over the vocabulary after every byte (PPMd itself is a host stage)
-    g = torch.Generator(device=dev)
-    g.manual_seed(77 + rank)
-    ppmd = torch.rand((nbytes + 1, 256), generator=g, device=dev) ** 8
-    ppmd[:, torch.from_numpy(vocab == 0).to(dev)] = 0
-    ppmd = (ppmd / ppmd.sum(1, keepdim=True)).contiguous()
+    # PPMd = host stage: runs on a host core inside the timed loop, one chunk ahead of the device stages,
+    # and ships its 1 KB-per-byte distributions to HBM
+    host_ppmd = E.Ppmd(vocab)
+    ppmd = torch.empty((nbytes + 1, 256), dtype=torch.float32, device=dev)
+    ppmd[0] = 1.0 / 256  # ByteModel constructor (byte-model.cpp:5-6)
+    pp_host = torch.empty((nbytes, 256), dtype=torch.float32).pin_memory()
     sel = torch.zeros((nbytes * 8, 47), dtype=torch.int32, device=dev)
     cb = a.chunk_bytes * 8
     net, ctx, lstm = E.MixNet(local), E.CtxModels(vocab, local), E.Lstm(vocab, local)
@@ -221,6 +222,12 @@ def main():
         streams, the mixing network consumes the chunk once the other two have produced their columns."""
         r = slice(i * cb, (i + 1) * cb)
         n0, n1 = i * a.chunk_bytes, (i + 1) * a.chunk_bytes
+        pp_host[n0:n1] = torch.from_numpy(host_ppmd.run(text[n0:n1]))
+        with torch.cuda.stream(st_lstm):
+            ppmd[n0 + 1:n1 + 1].copy_(pp_host[n0:n1], non_blocking=True)
+            ev_pp = torch.cuda.Event()
+            ev_pp.record(st_lstm)
+        st_ctx.wait_event(ev_pp)
         ev[i][0].record(st_ctx)
         ctx.run(d_bytes[n0:n1], probs[r], sel[r], stream=st_ctx.cuda_stream)
         E.bytemodel_bits(ppmd[n0], ppmd[n0 + 1:n1 + 1], d_bytes[n0:n1], probs[r], 2076, local, st_ctx.cuda_stream)
@@ -260,7 +267,7 @@ def main():
         algo = ALGO_BYTES_PER_INPUT_BYTE * a.chunk_bytes
         achieved = algo / avg_kernel_s / 1e9
         out = {
-            "metric": "input bytes/s on enwik8-shaped text (device stages only, see config.workload)",
+            "metric": "input bytes/s on enwik8-shaped text (engine stages built so far, see config.workload)",
             "value": total_bytes / dt, "unit": "input bytes/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -268,9 +275,9 @@ def main():
                 "workload": "S-enwik8 shard (seed 1000+rank), %d-byte chunks through the three device stages: "
                             "contexts + 54 small models (layer-0 columns 0-2, 2025-2075, all 47 selectors), "
                             "byte-level LSTM (column 2077) and the final mixing network (stretch + 26/20/1 mixers + "
-                            "SSE), strict bit-exact mode. Not on the device yet, replaced by seeded stand-ins of the "
-                            "same shape: the paq8 and fxcm columns (3..2024) and the PPMd byte distribution "
-                            "(host stage)" % a.chunk_bytes,
+                            "SSE), strict bit-exact mode, fed by the PPMd host stage (one host core, inside the timed loop). "
+                            "No stage yet, replaced by a seeded stand-in of the same shape: the paq8 and fxcm "
+                            "columns (3..2024)" % a.chunk_bytes,
                 "chunk_bytes": a.chunk_bytes, "streams_per_gpu": 1, "parallelism": "1 stream per GPU, no collective"},
             "us_per_bit": dt / (a.steps * cb) * 1e6,
             "stage_us_per_bit": {"mixnet": avg_kernel_s / cb * 1e6, "ctxmodels": ctx_ms * 1e3 / cb,
@@ -287,7 +294,7 @@ def main():
             if ref:
                 out["cpu_reference_full"] = ref
         print(json.dumps(out))
-    for o in (net, ctx, lstm):
+    for o in (net, ctx, lstm, host_ppmd):
         o.close()
     if world > 1:
         dist.destroy_process_group()

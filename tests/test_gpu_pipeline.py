@@ -1,12 +1,12 @@
 """GPU integration parity: the three device stages chained through HBM exactly as the engine runs them.
 
     bytes ──► ctx/small-model stage ──► layer-0 columns 0,1,2,2025..2075 + 47 selectors ─┐
-    PPMd byte distributions (trace) ──► ByteModel bits ──► column 2076                     ├─► mixing network ─► p
-    PPMd byte distributions (trace) ──► LSTM byte mixer ──► column 2077                    │
+    bytes ──► PPMd (host stage) ──► byte distributions ──► ByteModel bits ──► column 2076   ├─► mixing network ─► p
+                                                      └──► LSTM byte mixer ──► column 2077  │
     fxcm / paq8 columns 3..2024 (trace of the unmodified reference) ───────────────────────┘
 
-Only what has no device stage yet (fxcm, paq8, PPMd) is replayed from the golden trace of the reference; every
-other number is produced on the MI355X. The final probability must equal Predictor::Predict()'s float bit
+Only what has no stage yet (fxcm, paq8) is replayed from the golden trace of the reference; every other number
+is produced by the engine (PPMd on a host core, the rest on the MI355X). The final probability must equal Predictor::Predict()'s float bit
 for bit, for every coded bit (predictor.cpp:361-419)."""
 import numpy as np
 import pytest
@@ -29,7 +29,13 @@ def _pipeline(name, chunks=None, big=False):
     layer0[:, own] = float("nan")  # the device must produce these
     sel = torch.full((8 * N, 47), -1, dtype=torch.int32, device="cuda")
     d = torch.from_numpy(stream).cuda()
-    ppmd = torch.from_numpy(np.ascontiguousarray(g["ppmd_probs"])).cuda()  # [N+1,256]
+    host_ppmd = E.Ppmd(g["vocab"])
+    pp = np.empty((N + 1, 256), np.float32)
+    pp[0] = np.float32(1.0 / 256)  # ByteModel constructor (byte-model.cpp:5-6)
+    pp[1:] = host_ppmd.run(stream.tobytes())
+    host_ppmd.close()
+    assert bits_equal(pp, g["ppmd_probs"]).all(), "host PPMd stage != reference"
+    ppmd = torch.from_numpy(pp).cuda()  # [N+1,256]
     bits = torch.from_numpy(np.ascontiguousarray(g["bits"])).cuda()
     ctx, lstm, net = E.CtxModels(g["vocab"], 0), E.Lstm(g["vocab"], 0), E.MixNet(0)
     p = torch.empty(8 * N, dtype=torch.float32, device="cuda")
