@@ -46,54 +46,6 @@ ALGO_BYTES_PER_INPUT_BYTE = 55172 * 8 * 8 + 4 * 64 * 8  # SURVEY.md 8(d)(i) + SS
 HBM_PEAK_GBS = 8000.0
 
 
-def make_operands(nbytes, seed, device):
-    """Seeded stand-in for the upstream model stages, generated on the device."""
-    import torch
-    from cmix_amd import synth
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    T = nbytes * 8
-    text = np.frombuffer(synth.enwik_like(nbytes + 8, seed), np.uint8)[:nbytes]
-    bits_np = np.unpackbits(text)  # MSB first, as runner.cpp:106-108 feeds the coder
-    bits = torch.from_numpy(bits_np).to(device)
-    k = torch.randint(0, 4096, (T, 2078), generator=g, device=device, dtype=torch.int32)
-    conf = torch.rand((T, 2078), generator=g, device=device) < 0.5
-    side = torch.rand((T, 2078), generator=g, device=device) < 0.5
-    k = torch.where(conf, torch.where(side, k % 200, 4095 - (k % 200)), k)
-    probs = k.to(torch.float32) * np.float32(1.0 / 4095)
-    probs[:, 2025:2078] = torch.rand((T, 53), generator=g, device=device)
-    probs[:, 432:434] = 0.5
-    # selector keys from the actual bytes: order-0/1/2 partial-byte contexts, byte classes ...
-    b = text.astype(np.int64)
-    prev1 = np.concatenate([[0], b[:-1]])
-    prev2 = np.concatenate([[0, 0], b[:-2]])
-    prev3 = np.concatenate([[0, 0, 0], b[:-3]])
-    lbc = np.ones(T, np.int64)
-    for j in range(1, 8):
-        lbc[j::8] = lbc[j - 1::8] * 2 + bits_np[j - 1::8]
-    rep = lambda a: np.repeat(a, 8)
-    sel = np.zeros((T, 47), np.int64)
-    percol = {0: lbc, 1: lbc, 2: (rep(prev1) << 8) + lbc, 3: (rep(prev1) << 8) + lbc,
-              4: (rep(prev1 & 15) << 12) + (rep(prev2 & 15) << 8) + lbc, 5: (rep(prev1 & 3) << 8) + lbc,
-              6: rep(prev3), 7: rep(prev3), 8: 0 * lbc, 9: rep(np.arange(nbytes, dtype=np.int64) % 100),
-              10: rep(prev1 & 7), 11: rep((prev1 << 8) + prev2), 13: rep(prev1 >> 3), 14: rep(prev1 >> 2),
-              15: rep(prev1 >> 5), 16: (rep(prev1 >> 5) << 8) + lbc, 17: rep((prev1 >> 6) + 4 * (prev2 >> 6)),
-              18: rep((prev1 >> 6) + 4 * (prev2 >> 6) + 16 * (prev3 >> 6)), 19: (rep(prev1 >> 6) << 8) + lbc,
-              20: rep(prev1 >> 5), 21: rep((prev1 >> 5) + 8 * (prev2 >> 5)), 22: (rep(prev1 >> 5) << 8) + lbc,
-              23: (rep(prev2) << 8) + lbc, 24: rep(prev1 + 256 * prev2), 25: rep(prev2 + 256 * prev3)}
-    for m, v in percol.items():
-        sel[:, m] = v
-    l1 = [0 * lbc, 0 * lbc, lbc, lbc, lbc, rep(prev1), rep(prev2), rep(prev3), rep(prev1 & 7),
-          rep((prev1 << 8) + prev2), rep(prev1 >> 3), rep(prev1 >> 2), rep(prev1 >> 5),
-          rep((prev1 >> 6) + 4 * (prev2 >> 6)), rep((prev1 >> 6) + 4 * (prev2 >> 6) + 16 * (prev3 >> 6)),
-          rep(prev1 >> 5), rep((prev1 >> 5) + 8 * (prev2 >> 5)), (rep(prev1 >> 6) << 8) + lbc,
-          (rep(prev1 >> 5) << 8) + lbc, (rep(prev1 >> 5) << 8) + lbc]
-    for j, v in enumerate(l1):
-        sel[:, 26 + j] = v
-    sel32 = torch.from_numpy((sel & 0xFFFFFFFF).astype(np.uint32).view(np.int32)).to(device)
-    return probs.contiguous(), sel32.contiguous(), bits.contiguous(), text
-
-
 def cpu_baseline_port(probs, sel32, bits, text, ppmd, vocab, budget_s=14.0):
     ppmd = ppmd.clone()
     """Time the plain-C oracle of the same three stages on one host core over a bounded prefix.
@@ -194,52 +146,11 @@ def main():
     dev = torch.device("cuda", local)
 
     nsteps = a.warmup + a.steps
-    nbytes = a.chunk_bytes * nsteps
-    probs, sel_standin, bits, text = make_operands(nbytes, shard.shard_seed(rank), dev)
-    del sel_standin  # selectors now come from the context stage
-    text = np.ascontiguousarray(text)
-    vocab = np.zeros(256, np.uint8)
-    vocab[np.unique(text)] = 1
-    d_bytes = torch.from_numpy(text.copy()).to(dev)
-    # PPMd = host stage: runs on a host core inside the timed loop, one chunk ahead of the device stages,
-    # and ships its 1 KB-per-byte distributions to HBM
-    host_ppmd = E.Ppmd(vocab)
-    ppmd = torch.empty((nbytes + 1, 256), dtype=torch.float32, device=dev)
-    ppmd[0] = 1.0 / 256  # ByteModel constructor (byte-model.cpp:5-6)
-    pp_host = torch.empty((nbytes, 256), dtype=torch.float32).pin_memory()
-    sel = torch.zeros((nbytes * 8, 47), dtype=torch.int32, device=dev)
     cb = a.chunk_bytes * 8
-    net, ctx, lstm = E.MixNet(local), E.CtxModels(vocab, local), E.Lstm(vocab, local)
-    st_mix = torch.cuda.current_stream(dev)
-    st_ctx, st_lstm = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-    p_out = torch.empty(cb * nsteps, dtype=torch.float32, device=dev)
-    lstm_out = torch.empty((a.chunk_bytes, 256), dtype=torch.float32, device=dev)
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(nsteps)]
+    from cmix_amd.pipeline import StreamPipeline
+    pipe = StreamPipeline(local, shard.shard_seed(rank), a.chunk_bytes, nsteps)  # rank r = GPU r = stream r
+    step = pipe.step
     torch.cuda.synchronize()
-
-    def step(i):
-        """One chunk through the three device stages; the stages of a chunk overlap on their own HIP
-        streams, the mixing network consumes the chunk once the other two have produced their columns."""
-        r = slice(i * cb, (i + 1) * cb)
-        n0, n1 = i * a.chunk_bytes, (i + 1) * a.chunk_bytes
-        pp_host[n0:n1] = torch.from_numpy(host_ppmd.run(text[n0:n1]))
-        with torch.cuda.stream(st_lstm):
-            ppmd[n0 + 1:n1 + 1].copy_(pp_host[n0:n1], non_blocking=True)
-            ev_pp = torch.cuda.Event()
-            ev_pp.record(st_lstm)
-        st_ctx.wait_event(ev_pp)
-        ev[i][0].record(st_ctx)
-        ctx.run(d_bytes[n0:n1], probs[r], sel[r], stream=st_ctx.cuda_stream)
-        E.bytemodel_bits(ppmd[n0], ppmd[n0 + 1:n1 + 1], d_bytes[n0:n1], probs[r], 2076, local, st_ctx.cuda_stream)
-        ev[i][1].record(st_ctx)
-        ev[i][2].record(st_lstm)
-        lstm.run(ppmd[n0 + 1:n1 + 1], d_bytes[n0:n1], layer0=probs[r], out=lstm_out, stream=st_lstm.cuda_stream)
-        ev[i][3].record(st_lstm)
-        st_mix.wait_event(ev[i][1])
-        st_mix.wait_event(ev[i][3])
-        ev[i][4].record(st_mix)  # HIP events on the stream the mixing-network kernel is launched on
-        net.run(probs[r], sel[r], bits[r], p_out[r])
-        ev[i][5].record(st_mix)
 
     for i in range(a.warmup):
         step(i)
@@ -255,15 +166,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    ctx.sync()
-    net.sync()
+    pipe.sync()
     total_bytes, dt, _ = shard.aggregate_throughput(a.chunk_bytes * a.steps, dt, dev)  # sum of bytes / max of times
-    kernel_ms = [ev[i][4].elapsed_time(ev[i][5]) for i in range(a.warmup, nsteps)]
-    ctx_ms = float(np.mean([ev[i][0].elapsed_time(ev[i][1]) for i in range(a.warmup, nsteps)]))
-    lstm_ms = float(np.mean([ev[i][2].elapsed_time(ev[i][3]) for i in range(a.warmup, nsteps)]))
+    mix_ms, ctx_ms, lstm_ms = pipe.stage_ms(a.warmup, nsteps)
 
     if rank == 0:
-        avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
+        avg_kernel_s = mix_ms / 1e3
         algo = ALGO_BYTES_PER_INPUT_BYTE * a.chunk_bytes
         achieved = algo / avg_kernel_s / 1e9
         out = {
@@ -289,13 +197,12 @@ def main():
                          "algorithmic_bytes_per_launch": algo},
         }
         if not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_port(probs, sel, bits, text, ppmd, vocab)
-            ref = cpu_reference_full(text)
+            out["cpu_baseline"] = cpu_baseline_port(pipe.probs, pipe.sel, pipe.bits, pipe.text, pipe.ppmd, pipe.vocab)
+            ref = cpu_reference_full(pipe.text)
             if ref:
                 out["cpu_reference_full"] = ref
         print(json.dumps(out))
-    for o in (net, ctx, lstm, host_ppmd):
-        o.close()
+    pipe.close()
     if world > 1:
         dist.destroy_process_group()
 
