@@ -46,29 +46,28 @@ ALGO_BYTES_PER_INPUT_BYTE = 55172 * 8 * 8 + 4 * 64 * 8  # SURVEY.md 8(d)(i) + SS
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline_port(probs, sel32, bits, text, ppmd, vocab, budget_s=14.0):
-    ppmd = ppmd.clone()
-    """Time the plain-C oracle of the same three stages on one host core over a bounded prefix.
+def cpu_baseline_port(probs, bits, text, vocab, budget_s=14.0):
+    """Time the plain-C oracle of the same three device stages on one host core over a bounded prefix.
     cmix is single-threaded, so the stages run back to back on the CPU: us/bit adds up."""
     from oracle import oracle as O
-    n = min(len(bits), 4096)
+    from cmix_amd import engine as E
+    nb = min(len(text), 512)
+    ctx = O.CtxModels(vocab)
+    t0 = time.perf_counter()
+    _, sel = ctx.run(bytes(text[:nb]))
+    us_ctx = (time.perf_counter() - t0) / (8 * nb) * 1e6
+    n = 8 * nb
     p = probs[:n].cpu().numpy()
-    s = sel32[:n].cpu().numpy().view(np.uint32).astype(np.uint64)
     b = bits[:n].cpu().numpy()
     net = O.MixNet()
     t0 = time.perf_counter()
     done = 0
     while done < n and time.perf_counter() - t0 < budget_s / 2:
-        net.step(p[done], s[done], b[done])
+        net.step(p[done], sel[done], b[done])
         done += 1
     us_mix = (time.perf_counter() - t0) / done * 1e6
-    nb = min(len(text), 256)
-    ctx = O.CtxModels(vocab)
-    t0 = time.perf_counter()
-    ctx.run(bytes(text[:nb]))
-    us_ctx = (time.perf_counter() - t0) / (8 * nb) * 1e6
+    pp = E.Ppmd(vocab).run(bytes(text[:nb]))  # the engine's own host stage supplies the LSTM's input
     lstm = O.Lstm(vocab)
-    pp = ppmd[1:nb + 1].cpu().numpy()
     t0 = time.perf_counter()
     k = 0
     while k < nb and time.perf_counter() - t0 < budget_s / 2:
@@ -77,7 +76,7 @@ def cpu_baseline_port(probs, sel32, bits, text, ppmd, vocab, budget_s=14.0):
     us_lstm = (time.perf_counter() - t0) / (8 * k) * 1e6
     tot = us_mix + us_ctx + us_lstm
     return {"value": 1e6 / (8 * tot), "unit": "input bytes/s", "cores": 1, "kind": "port",
-            "sample": f"oracle/*.c of the same three stages on one core: mixing network {done} bits "
+            "sample": f"oracle/*.c of the same three device stages on one core: mixing network {done} bits "
                       f"({us_mix:.1f} us/bit), contexts+small models {8 * nb} bits ({us_ctx:.1f} us/bit), "
                       f"LSTM {k} bytes ({us_lstm:.1f} us/bit); stages run back to back on a CPU",
             "us_per_bit": {"mixnet": us_mix, "ctxmodels": us_ctx, "lstm": us_lstm}}
@@ -168,7 +167,8 @@ def main():
     dt = time.perf_counter() - t0
     pipe.sync()
     total_bytes, dt, _ = shard.aggregate_throughput(a.chunk_bytes * a.steps, dt, dev)  # sum of bytes / max of times
-    mix_ms, ctx_ms, lstm_ms = pipe.stage_ms(a.warmup, nsteps)
+    st = pipe.last_stage_ms()  # HIP events around each stage of the last timed chunk, on the stage's own stream
+    mix_ms, ctx_ms, lstm_ms = st["mixnet"], st["ctxmodels"], st["lstm"]
 
     if rank == 0:
         avg_kernel_s = mix_ms / 1e3
@@ -190,14 +190,14 @@ def main():
             "us_per_bit": dt / (a.steps * cb) * 1e6,
             "stage_us_per_bit": {"mixnet": avg_kernel_s / cb * 1e6, "ctxmodels": ctx_ms * 1e3 / cb,
                                  "lstm": lstm_ms * 1e3 / cb,
-                                 "note": "HIP-event time of each stage over a chunk (stages overlap on separate streams)"},
+                                 "note": "HIP-event time of each stage over the last timed chunk (stages overlap on separate streams)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(a.chunk_bytes),
                          "kernel": "cmx_mixnet_chunk_kernel", "avg_kernel_ms": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": algo},
         }
         if not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_port(pipe.probs, pipe.sel, pipe.bits, pipe.text, pipe.ppmd, pipe.vocab)
+            out["cpu_baseline"] = cpu_baseline_port(pipe.probs, pipe.bits, pipe.text, pipe.vocab)
             ref = cpu_reference_full(pipe.text)
             if ref:
                 out["cpu_reference_full"] = ref

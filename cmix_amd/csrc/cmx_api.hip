@@ -97,7 +97,10 @@ struct cmx_mixnet {
   std::vector<void*> allocs;
   float* d_decay = nullptr;
   size_t decay_cap = 0;
-  float* h_decay = nullptr;  // pinned
+  float* h_decay = nullptr;  // pinned, DECAY_SLOTS x decay_cap: a slot is rewritten only after its copy ran
+  hipEvent_t ev_decay[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool decay_used[4] = {false, false, false, false};
+  uint64_t runs = 0;
   uint64_t bits_done = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
@@ -152,6 +155,7 @@ void cmx_mixnet_destroy(cmx_mixnet_t* h) {
   if (h->h_decay) hipHostFree(h->h_decay);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
+  for (int i = 0; i < 4; ++i) if (h->ev_decay[i]) hipEventDestroy(h->ev_decay[i]);
   delete h;
 }
 
@@ -241,6 +245,7 @@ cmx_mixnet_t* cmx_mixnet_create(int device) {
   { const char* v = getenv("CMX_MIXNET_DBG"); h->dbg = v ? atoi(v) : 0; }
   hipEventCreate(&h->ev0);
   hipEventCreate(&h->ev1);
+  for (int i = 0; i < 4; ++i) hipEventCreateWithFlags(&h->ev_decay[i], hipEventDisableTiming);
   hipError_t e = hipDeviceSynchronize();
   if (e != hipSuccess) { set_err(std::string("init: ") + hipGetErrorString(e)); cmx_mixnet_destroy(h); return nullptr; }
   return h;
@@ -258,7 +263,11 @@ static int ensure_decay(cmx_mixnet_t* h, size_t nbits) {
   size_t cap = nbits < 4096 ? 4096 : nbits;
   if (h->h_decay) hipHostFree(h->h_decay);
   h->h_decay = nullptr;
-  HIP_OK(hipHostMalloc((void**)&h->h_decay, cap * 4, hipHostMallocDefault));
+  for (int i = 0; i < 4; ++i) {  // nothing of the old buffer may still be waiting to be copied
+    if (h->decay_used[i]) (void)hipEventSynchronize(h->ev_decay[i]);
+    h->decay_used[i] = false;
+  }
+  HIP_OK(hipHostMalloc((void**)&h->h_decay, 4 * cap * 4, hipHostMallocDefault));
   void* p = nullptr;
   HIP_OK(hipMalloc(&p, cap * 4));
   h->allocs.push_back(p);
@@ -277,11 +286,16 @@ int cmx_mixnet_run(cmx_mixnet_t* h, const float* d_probs, const uint32_t* d_sel,
   if (nbits > 0x7fffffff) { set_err("cmx_mixnet_run: chunk too large"); return 1; }
   HIP_OK(hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
-  // the pinned staging buffer is reused: wait for the previous chunk's copy
-  HIP_OK(hipStreamSynchronize(st));
+  // The decay schedule is staged through one of four pinned slots; a slot is rewritten only once the copy
+  // that read it has executed, so up to four chunks can be enqueued without the host waiting for the GPU.
   if (ensure_decay(h, nbits)) return 1;
-  for (size_t t = 0; t < nbits; ++t) h->h_decay[t] = decay_of(h->bits_done + t);
-  HIP_OK(hipMemcpyAsync(h->d_decay, h->h_decay, nbits * 4, hipMemcpyHostToDevice, st));
+  const int slot = (int)(h->runs++ & 3);
+  if (h->decay_used[slot]) HIP_OK(hipEventSynchronize(h->ev_decay[slot]));
+  float* hd = h->h_decay + (size_t)slot * h->decay_cap;
+  for (size_t t = 0; t < nbits; ++t) hd[t] = decay_of(h->bits_done + t);
+  HIP_OK(hipMemcpyAsync(h->d_decay, hd, nbits * 4, hipMemcpyHostToDevice, st));
+  HIP_OK(hipEventRecord(h->ev_decay[slot], st));
+  h->decay_used[slot] = true;
   HIP_OK(hipEventRecord(h->ev0, st));
   if (h->use_v1)
     hipLaunchKernelGGL(cmx_mixnet_kernel, dim3(1), dim3(CMX_MIXNET_THREADS), kLdsBytes, st, h->d_state,

@@ -295,7 +295,6 @@ __device__ void producer_role(MixState* S, const Lds& L, int nbits, int p, int l
   const float cdec = 1.0f - 3.0e-6f;
   const bool lane_ok8 = lane < 8;  // chunk 8 = floats 2048..2079: 8 lanes
   uint64_t pacc[6] = {0, 0, 0, 0, 0, 0};
-  uint64_t win_acc = 0;
   uint64_t tprev = __builtin_readcyclecounter();
 #define PPROF(k)                                                       \
   do {                                                                 \
@@ -332,7 +331,6 @@ __device__ void producer_role(MixState* S, const Lds& L, int nbits, int p, int l
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (t > 0 && !wait_ge(L.ctl, &L.ctl->u_epoch, t, false)) return;
     PPROF(7);
-    const uint64_t win_t0 = (prof_on && (dbg & 8)) ? __builtin_readcyclecounter() : 0;
     float u[MPW];
     bool anydf = false;
     bool df[MPW];
@@ -398,7 +396,6 @@ __device__ void producer_role(MixState* S, const Lds& L, int nbits, int p, int l
       publish(4 * t);
     }
     PPROF(8);
-    if (prof_on && (dbg & 8)) win_acc += __builtin_readcyclecounter() - win_t0;
     // ---- the rest runs underneath the chain wave's segment 0 ----
     if (t > 0) {
 #pragma unroll
@@ -441,8 +438,7 @@ __device__ void producer_role(MixState* S, const Lds& L, int nbits, int p, int l
     PPROF(10);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (prof_on && (dbg & 8) && lane == 0) S->prof[6 + p] += win_acc;  // per-producer serial window (slots 6..14)
-  if (prof_on && p == 0 && !(dbg & 14) && lane == 0) {
+  if (prof_on && p == 0 && !(dbg & 6) && lane == 0) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) S->prof[6 + i] += pacc[i];
   }
@@ -451,7 +447,7 @@ __device__ void producer_role(MixState* S, const Lds& L, int nbits, int p, int l
 
 // ------------------------------------------------------------------ chain (wave 0)
 __device__ void chain_role(MixState* S, const Lds& L, const float* decay1, int nbits,
-                           float* mix_out, bool prof_on, int lane, bool dbg8) {
+                           float* mix_out, bool prof_on, int lane) {
   const int m = lane;
   const bool is0 = m < CMX_MIX0;
   const float smin = S->stretch_min, smax = S->stretch_max;
@@ -584,7 +580,7 @@ __device__ void chain_role(MixState* S, const Lds& L, const float* decay1, int n
   if (prof_on && lane == 0) {
 #pragma unroll
     for (int i = 0; i < 16; ++i)
-      if (i < 6 || (i >= 12 && !dbg8)) S->prof[i] += pacc[i];
+      if (i < 6 || i >= 12) S->prof[i] += pacc[i];
   }
 #undef CPROF
 }
@@ -949,7 +945,7 @@ extern "C" __global__ __launch_bounds__(NTHREADS) void cmx_mixnet_chunk_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   // Waves w, w+4, w+8 share a SIMD. The chain wave's SIMD-mates are the two latency-tolerant,
   // mostly-sleeping roles, so nothing competes with its dependent add chain for issue slots.
-  if (wave == 0) chain_role(S, L, decay1, nbits, mix_out, (mode & 4) != 0, lane, ((mode >> 4) & 8) != 0);
+  if (wave == 0) chain_role(S, L, decay1, nbits, mix_out, (mode & 4) != 0, lane);
   else if (wave == 4) tail_role(S, L, decay1, nbits, p_out, mix_out, lane, (mode & 4) != 0 && ((mode >> 4) & 4) != 0);
   else if (wave == 8) scout_role(S, L, probs, sel, bits, nbits, lane, (mode & 4) != 0 && ((mode >> 4) & 2) != 0);
   else producer_role(S, L, nbits, wave - 1 - (wave > 4) - (wave > 8), lane, (mode & 4) != 0, mode >> 4);

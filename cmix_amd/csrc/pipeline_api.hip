@@ -1,0 +1,187 @@
+// pipeline_api.hip -- one input stream through every stage the engine has: the native host-side
+// orchestration behind the Predictor surface (C ABI: cmx_pipeline_* in include/cmix_amd.h).
+//
+// What Predictor::Predict/Perceive do bit by bit (src/predictor.cpp:361-469) is done here a chunk of
+// already-known bytes at a time (compression look-ahead):
+//
+//   host:   PPMd byte model (ppmd_host.cpp) over the chunk            predictor.cpp:447-449
+//   s_lstm: H2D of its distributions; LSTM byte mixer -> column 2077   predictor.cpp:378-387,450-467
+//   s_ctx:  contexts + 54 small models -> columns 0-2, 2025-2075, 47 selectors; PPMd bits -> column 2076
+//                                                                       predictor.cpp:362-377,421-446
+//   s_mix:  (after both) final mixing network + SSE -> p per bit       predictor.cpp:388-418,432-437
+//
+// The three device stages of a chunk run on their own HIP streams and the stages of consecutive chunks
+// overlap (two chunks in flight). Columns 3..2024 (fxcm, paq8) have no stage yet: the caller supplies
+// them inside d_layer0. No CPU fallback exists for any device stage.
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+#include <string>
+
+#include "../../include/cmix_amd.h"
+
+void cmx_set_err(const std::string& s);  // cmx_api.hip
+
+namespace {
+constexpr int kSlots = 2;
+struct Slot {
+  uint8_t* d_bytes = nullptr;
+  uint8_t* d_bits = nullptr;
+  uint32_t* d_sel = nullptr;
+  float* d_ppmd = nullptr;      // [max+1][256]: row 0 = distribution going into the chunk
+  float* d_lstm_out = nullptr;  // [max][256]
+  uint8_t* h_bytes = nullptr;   // pinned: bytes, then the 8n unpacked bits
+  float* h_ppmd = nullptr;      // pinned [max+1][256]
+  hipEvent_t ev_in = nullptr, ev_ctx0 = nullptr, ev_ctx1 = nullptr, ev_lstm0 = nullptr, ev_lstm1 = nullptr,
+             ev_mix0 = nullptr, ev_mix1 = nullptr;
+  bool used = false;
+};
+}  // namespace
+
+struct cmx_pipeline {
+  int device = 0;
+  size_t max_chunk = 0;
+  cmx_ppmd_t* ppmd = nullptr;
+  cmx_ctxmodels_t* ctx = nullptr;
+  cmx_lstm_t* lstm = nullptr;
+  cmx_mixnet_t* mix = nullptr;
+  hipStream_t s_ctx = nullptr, s_lstm = nullptr, s_mix = nullptr;
+  Slot slot[kSlots];
+  uint64_t chunks = 0;
+  float last_dist[256];
+  float stage_ms[3] = {0, 0, 0};
+  int last_slot = -1;
+};
+
+extern "C" {
+
+void cmx_pipeline_destroy(cmx_pipeline_t* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  for (Slot& s : h->slot) {
+    if (s.d_bytes) (void)hipFree(s.d_bytes);
+    if (s.d_bits) (void)hipFree(s.d_bits);
+    if (s.d_sel) (void)hipFree(s.d_sel);
+    if (s.d_ppmd) (void)hipFree(s.d_ppmd);
+    if (s.d_lstm_out) (void)hipFree(s.d_lstm_out);
+    if (s.h_bytes) (void)hipHostFree(s.h_bytes);
+    if (s.h_ppmd) (void)hipHostFree(s.h_ppmd);
+    for (hipEvent_t e : {s.ev_in, s.ev_ctx0, s.ev_ctx1, s.ev_lstm0, s.ev_lstm1, s.ev_mix0, s.ev_mix1})
+      if (e) (void)hipEventDestroy(e);
+  }
+  if (h->s_ctx) (void)hipStreamDestroy(h->s_ctx);
+  if (h->s_lstm) (void)hipStreamDestroy(h->s_lstm);
+  if (h->s_mix) (void)hipStreamDestroy(h->s_mix);
+  cmx_mixnet_destroy(h->mix);
+  cmx_lstm_destroy(h->lstm);
+  cmx_ctxmodels_destroy(h->ctx);
+  cmx_ppmd_destroy(h->ppmd);
+  delete h;
+}
+
+cmx_pipeline_t* cmx_pipeline_create(const uint8_t vocab[256], int device, size_t max_chunk_bytes) {
+  if (max_chunk_bytes == 0 || max_chunk_bytes > (1u << 24)) { cmx_set_err("cmx_pipeline_create: bad max_chunk_bytes"); return nullptr; }
+  cmx_pipeline_t* h = new cmx_pipeline();
+  h->device = device;
+  h->max_chunk = max_chunk_bytes;
+  // every stage reports its own failure (no device, out of memory) through cmx_last_error()
+  h->ctx = cmx_ctxmodels_create(vocab, device);
+  h->lstm = h->ctx ? cmx_lstm_create(vocab, 31, device) : nullptr;  // 31 rand() draws precede the LSTM (indirect.cpp:10)
+  h->mix = h->lstm ? cmx_mixnet_create(device) : nullptr;
+  h->ppmd = h->mix ? cmx_ppmd_create(vocab) : nullptr;
+  if (!h->ppmd) { cmx_pipeline_destroy(h); return nullptr; }
+  bool ok = hipSetDevice(device) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&h->s_ctx, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&h->s_lstm, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&h->s_mix, hipStreamNonBlocking) == hipSuccess;
+  const size_t n = max_chunk_bytes;
+  for (Slot& s : h->slot) {
+    ok = ok && hipMalloc((void**)&s.d_bytes, n) == hipSuccess;
+    ok = ok && hipMalloc((void**)&s.d_bits, 8 * n) == hipSuccess;
+    ok = ok && hipMalloc((void**)&s.d_sel, 8 * n * CMX_N_MIXERS * 4) == hipSuccess;
+    ok = ok && hipMalloc((void**)&s.d_ppmd, (n + 1) * 256 * 4) == hipSuccess;
+    ok = ok && hipMalloc((void**)&s.d_lstm_out, n * 256 * 4) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&s.h_bytes, 9 * n, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&s.h_ppmd, (n + 1) * 256 * 4, hipHostMallocDefault) == hipSuccess;
+    for (hipEvent_t* e : {&s.ev_in, &s.ev_ctx0, &s.ev_ctx1, &s.ev_lstm0, &s.ev_lstm1, &s.ev_mix0, &s.ev_mix1})
+      ok = ok && hipEventCreate(e) == hipSuccess;
+  }
+  if (!ok) { cmx_set_err("cmx_pipeline_create: stream / buffer allocation failed"); cmx_pipeline_destroy(h); return nullptr; }
+  for (int i = 0; i < 256; ++i) h->last_dist[i] = (float)(1.0 / 256);  // ByteModel constructor (byte-model.cpp:5-6)
+  return h;
+}
+
+int cmx_pipeline_submit(cmx_pipeline_t* h, const uint8_t* bytes, size_t n, float* d_layer0, float* d_p_out) {
+  if (!h) { cmx_set_err("cmx_pipeline_submit: null handle"); return 1; }
+  if (n == 0) return 0;
+  if (!bytes || !d_layer0 || !d_p_out || n > h->max_chunk) { cmx_set_err("cmx_pipeline_submit: bad argument"); return 1; }
+  if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
+  Slot& s = h->slot[h->chunks % kSlots];
+  if (s.used && hipEventSynchronize(s.ev_mix1) != hipSuccess) {  // the chunk that used these buffers two submits ago
+    cmx_set_err("cmx_pipeline_submit: device error in an earlier chunk");
+    return 1;
+  }
+  // ---- host stage: PPMd runs ahead of the device on this thread ----
+  memcpy(s.h_ppmd, h->last_dist, 256 * 4);
+  if (cmx_ppmd_run(h->ppmd, bytes, n, s.h_ppmd + 256)) return 1;
+  memcpy(h->last_dist, s.h_ppmd + n * 256, 256 * 4);
+  memcpy(s.h_bytes, bytes, n);
+  uint8_t* hb = s.h_bytes + n;
+  for (size_t i = 0; i < n; ++i)
+    for (int j = 0; j < 8; ++j) hb[8 * i + j] = (bytes[i] >> (7 - j)) & 1;  // MSB first (runner.cpp:106-108)
+  // ---- inputs ----
+  bool ok = hipMemcpyAsync(s.d_ppmd, s.h_ppmd, (n + 1) * 256 * 4, hipMemcpyHostToDevice, h->s_lstm) == hipSuccess;
+  ok = ok && hipMemcpyAsync(s.d_bytes, s.h_bytes, n, hipMemcpyHostToDevice, h->s_lstm) == hipSuccess;
+  ok = ok && hipMemcpyAsync(s.d_bits, hb, 8 * n, hipMemcpyHostToDevice, h->s_lstm) == hipSuccess;
+  ok = ok && hipEventRecord(s.ev_in, h->s_lstm) == hipSuccess;
+  ok = ok && hipStreamWaitEvent(h->s_ctx, s.ev_in, 0) == hipSuccess;
+  if (!ok) { cmx_set_err("cmx_pipeline_submit: input upload failed"); return 1; }
+  // ---- context / small-model stage + PPMd's bit predictions ----
+  (void)hipEventRecord(s.ev_ctx0, h->s_ctx);
+  if (cmx_ctxmodels_run(h->ctx, s.d_bytes, n, d_layer0, CMX_N_INPUTS, s.d_sel, h->s_ctx)) return 1;
+  if (cmx_bytemodel_bits_run(h->device, s.d_ppmd, s.d_ppmd + 256, s.d_bytes, n, d_layer0 + 2076, CMX_N_INPUTS, nullptr,
+                             h->s_ctx)) return 1;
+  (void)hipEventRecord(s.ev_ctx1, h->s_ctx);
+  // ---- LSTM byte mixer ----
+  (void)hipEventRecord(s.ev_lstm0, h->s_lstm);
+  if (cmx_lstm_run(h->lstm, s.d_ppmd + 256, s.d_bytes, n, s.d_lstm_out, d_layer0 + 2077, CMX_N_INPUTS, nullptr, h->s_lstm))
+    return 1;
+  (void)hipEventRecord(s.ev_lstm1, h->s_lstm);
+  // ---- final mixing network, once both producers have written their columns ----
+  (void)hipStreamWaitEvent(h->s_mix, s.ev_ctx1, 0);
+  (void)hipStreamWaitEvent(h->s_mix, s.ev_lstm1, 0);
+  (void)hipEventRecord(s.ev_mix0, h->s_mix);
+  if (cmx_mixnet_run(h->mix, d_layer0, s.d_sel, s.d_bits, 8 * n, d_p_out, nullptr, h->s_mix)) return 1;
+  (void)hipEventRecord(s.ev_mix1, h->s_mix);
+  s.used = true;
+  h->last_slot = (int)(h->chunks % kSlots);
+  h->chunks++;
+  return 0;
+}
+
+int cmx_pipeline_sync(cmx_pipeline_t* h) {
+  if (!h) return 1;
+  (void)hipSetDevice(h->device);
+  bool ok = hipStreamSynchronize(h->s_ctx) == hipSuccess;
+  ok = hipStreamSynchronize(h->s_lstm) == hipSuccess && ok;
+  ok = hipStreamSynchronize(h->s_mix) == hipSuccess && ok;
+  if (!ok) { cmx_set_err("cmx_pipeline_sync: device error"); return 1; }
+  if (cmx_ctxmodels_sync(h->ctx) || cmx_mixnet_sync(h->mix)) return 1;
+  if (h->last_slot >= 0) {
+    Slot& s = h->slot[h->last_slot];
+    (void)hipEventElapsedTime(&h->stage_ms[0], s.ev_ctx0, s.ev_ctx1);
+    (void)hipEventElapsedTime(&h->stage_ms[1], s.ev_lstm0, s.ev_lstm1);
+    (void)hipEventElapsedTime(&h->stage_ms[2], s.ev_mix0, s.ev_mix1);
+  }
+  return 0;
+}
+
+int cmx_pipeline_last_stage_ms(cmx_pipeline_t* h, float ms[3]) {
+  if (!h || !ms) return 1;
+  memcpy(ms, h->stage_ms, sizeof h->stage_ms);
+  return 0;
+}
+
+}  // extern "C"

@@ -81,6 +81,12 @@ def lib():
         L.cmx_ppmd_create.argtypes = [C.c_void_p]
         L.cmx_ppmd_destroy.argtypes = [C.c_void_p]
         L.cmx_ppmd_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.cmx_pipeline_create.restype = C.c_void_p
+        L.cmx_pipeline_create.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        L.cmx_pipeline_destroy.argtypes = [C.c_void_p]
+        L.cmx_pipeline_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.cmx_pipeline_sync.argtypes = [C.c_void_p]
+        L.cmx_pipeline_last_stage_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.cmx_probe_libm.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
         _lib = L
     return _lib
@@ -315,6 +321,48 @@ def bytemodel_bits(dist0, dist_rest, data, layer0, col, device=0, stream=None):
                                       layer0.data_ptr() + 4 * col, N_INPUTS, None, C.c_void_p(stream))
     if rc:
         raise CmxError(last_error())
+
+
+class Pipeline:
+    """One stream through every stage built so far (native orchestration in libcmixamd.so)."""
+
+    def __init__(self, vocab, device=0, max_chunk_bytes=4096):
+        vocab = np.ascontiguousarray(vocab, np.uint8)
+        assert vocab.size == 256
+        self.h = lib().cmx_pipeline_create(vocab.ctypes.data, device, max_chunk_bytes)
+        if not self.h:
+            raise CmxError(last_error())
+
+    def submit(self, data, layer0, p_out):
+        """data: bytes / u8 array (host); layer0 [8n,2078] f32 cuda with columns 3..2024 filled and synchronised;
+        p_out [8n] f32 cuda. Asynchronous."""
+        import torch
+        data = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8))
+        n = len(data)
+        assert layer0.is_cuda and layer0.dtype == torch.float32 and layer0.is_contiguous() and layer0.shape == (8 * n, N_INPUTS)
+        assert p_out.is_cuda and p_out.dtype == torch.float32 and p_out.is_contiguous() and p_out.numel() == 8 * n
+        if lib().cmx_pipeline_submit(self.h, data.ctypes.data, n, layer0.data_ptr(), p_out.data_ptr()):
+            raise CmxError(last_error())
+
+    def sync(self):
+        if lib().cmx_pipeline_sync(self.h):
+            raise CmxError(last_error())
+
+    def last_stage_ms(self):
+        ms = (C.c_float * 3)()
+        lib().cmx_pipeline_last_stage_ms(self.h, ms)
+        return {"ctxmodels": ms[0], "lstm": ms[1], "mixnet": ms[2]}
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().cmx_pipeline_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Ppmd:

@@ -32,69 +32,36 @@ def standin_columns(nbytes, seed, device):
 
 
 class StreamPipeline:
-    """One input stream on one GPU: buffers for `nchunks` chunks, three HIP streams, step(i) enqueues chunk i."""
+    """One input stream on one GPU: operand buffers for `nchunks` chunks; step(i) hands chunk i to the native
+    orchestration (cmx_pipeline_submit: PPMd host stage + three device stages on their own HIP streams)."""
 
     def __init__(self, device_index, seed, chunk_bytes, nchunks):
         import torch
         self.torch = torch
         self.dev = torch.device("cuda", device_index)
-        self.local = device_index
         self.chunk_bytes, self.cb, self.nchunks = chunk_bytes, chunk_bytes * 8, nchunks
         nbytes = chunk_bytes * nchunks
         self.probs, self.bits, text = standin_columns(nbytes, seed, self.dev)
         self.text = np.ascontiguousarray(text)
         self.vocab = np.zeros(256, np.uint8)
         self.vocab[np.unique(self.text)] = 1
-        self.d_bytes = torch.from_numpy(self.text.copy()).to(self.dev)
-        # PPMd = host stage: runs on a host core inside the timed loop and ships 1 KB per byte to HBM
-        self.host_ppmd = E.Ppmd(self.vocab)
-        self.ppmd = torch.empty((nbytes + 1, 256), dtype=torch.float32, device=self.dev)
-        self.ppmd[0] = 1.0 / 256  # ByteModel constructor (byte-model.cpp:5-6)
-        self.pp_host = torch.empty((nbytes, 256), dtype=torch.float32).pin_memory()
-        self.sel = torch.zeros((nbytes * 8, 47), dtype=torch.int32, device=self.dev)
-        self.net, self.ctx, self.lstm = E.MixNet(device_index), E.CtxModels(self.vocab, device_index), E.Lstm(self.vocab, device_index)
-        self.st_mix, self.st_ctx, self.st_lstm = (torch.cuda.Stream(self.dev) for _ in range(3))
         self.p_out = torch.empty(self.cb * nchunks, dtype=torch.float32, device=self.dev)
-        self.lstm_out = torch.empty((chunk_bytes, 256), dtype=torch.float32, device=self.dev)
-        self.ev = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(nchunks)]
+        torch.cuda.synchronize(self.dev)  # the stand-in columns are complete before any submit
+        self.pipe = E.Pipeline(self.vocab, device_index, chunk_bytes)
+        self.stage_log = []
 
     def step(self, i):
-        """Chunk i through all stages, asynchronously: chunk i+1's context/LSTM stages run under chunk i's
-        mixing network; the mixing network consumes a chunk once the other stages have written their columns."""
-        torch, cb = self.torch, self.cb
+        """Chunk i through all stages, asynchronously (two chunks in flight): chunk i+1's PPMd / context / LSTM
+        stages run under chunk i's mixing network."""
+        cb = self.cb
         r = slice(i * cb, (i + 1) * cb)
-        n0, n1 = i * self.chunk_bytes, (i + 1) * self.chunk_bytes
-        ev = self.ev[i]
-        self.pp_host[n0:n1] = torch.from_numpy(self.host_ppmd.run(self.text[n0:n1]))
-        with torch.cuda.stream(self.st_lstm):
-            self.ppmd[n0 + 1:n1 + 1].copy_(self.pp_host[n0:n1], non_blocking=True)
-            ev_pp = torch.cuda.Event()
-            ev_pp.record(self.st_lstm)
-        self.st_ctx.wait_event(ev_pp)
-        ev[0].record(self.st_ctx)
-        self.ctx.run(self.d_bytes[n0:n1], self.probs[r], self.sel[r], stream=self.st_ctx.cuda_stream)
-        E.bytemodel_bits(self.ppmd[n0], self.ppmd[n0 + 1:n1 + 1], self.d_bytes[n0:n1], self.probs[r], 2076, self.local,
-                         self.st_ctx.cuda_stream)
-        ev[1].record(self.st_ctx)
-        ev[2].record(self.st_lstm)
-        self.lstm.run(self.ppmd[n0 + 1:n1 + 1], self.d_bytes[n0:n1], layer0=self.probs[r], out=self.lstm_out,
-                      stream=self.st_lstm.cuda_stream)
-        ev[3].record(self.st_lstm)
-        self.st_mix.wait_event(ev[1])
-        self.st_mix.wait_event(ev[3])
-        ev[4].record(self.st_mix)  # HIP events on the stream the mixing-network kernel is launched on
-        self.net.run(self.probs[r], self.sel[r], self.bits[r], self.p_out[r], stream=self.st_mix.cuda_stream)
-        ev[5].record(self.st_mix)
-
-    def stage_ms(self, first, last):
-        """Mean HIP-event time per chunk of (mixnet, ctxmodels, lstm) over chunks [first, last)."""
-        m = lambda a, b: float(np.mean([self.ev[i][a].elapsed_time(self.ev[i][b]) for i in range(first, last)]))
-        return m(4, 5), m(0, 1), m(2, 3)
+        self.pipe.submit(self.text[i * self.chunk_bytes:(i + 1) * self.chunk_bytes], self.probs[r], self.p_out[r])
 
     def sync(self):
-        self.ctx.sync()
-        self.net.sync()
+        self.pipe.sync()
+
+    def last_stage_ms(self):
+        return self.pipe.last_stage_ms()
 
     def close(self):
-        for o in (self.net, self.ctx, self.lstm, self.host_ppmd):
-            o.close()
+        self.pipe.close()

@@ -188,6 +188,29 @@ void cmx_ppmd_destroy(cmx_ppmd_t*);
 int cmx_ppmd_run(cmx_ppmd_t*, const uint8_t* bytes, size_t nbytes, float* out_probs);
 
 /* ------------------------------------------------------------------------
+ * 3. One stream through every stage built so far: the native orchestration behind the Predictor
+ *    surface, a chunk of already-known bytes at a time (Predictor::Predict/Perceive, predictor.cpp:
+ *    361-469, in compression look-ahead form). PPMd runs on the calling host thread; the context /
+ *    small-model stage, the LSTM and the mixing network run on three internal HIP streams; two chunks
+ *    may be in flight. cmx_create will sit on top of this once the fxcm and paq8 stages exist.
+ * ------------------------------------------------------------------------ */
+typedef struct cmx_pipeline cmx_pipeline_t;
+cmx_pipeline_t* cmx_pipeline_create(const uint8_t vocab[256], int device, size_t max_chunk_bytes);
+void cmx_pipeline_destroy(cmx_pipeline_t*);
+/* Code the next n <= max_chunk_bytes bytes of the stream.
+ *   bytes    HOST   [n]
+ *   d_layer0 DEVICE [8n][2078] f32: columns 3..2024 (fxcm, paq8 -- no stage yet) must already hold the
+ *                   Model::Predict values of every bit and be complete on the device; all other columns
+ *                   are written by the engine
+ *   d_p_out  DEVICE [8n] f32 OUT: the value Predictor::Predict() returns for each bit
+ * Returns after enqueueing (it only waits for the chunk before the previous one); d_layer0 / d_p_out must
+ * stay valid until cmx_pipeline_sync() or until two further submits have returned. */
+int cmx_pipeline_submit(cmx_pipeline_t*, const uint8_t* bytes, size_t n, float* d_layer0, float* d_p_out);
+int cmx_pipeline_sync(cmx_pipeline_t*);
+/* HIP-event time (ms) the last submitted chunk spent in [0] contexts+small models, [1] LSTM, [2] mixing network. */
+int cmx_pipeline_last_stage_ms(cmx_pipeline_t*, float ms[3]);
+
+/* ------------------------------------------------------------------------
  * Device libm probes (parity tests): evaluate the engine's expf / tanhf /
  * logistic on the device for n host floats. which: 0 expf, 1 tanhf, 2 logistic
  * ------------------------------------------------------------------------ */

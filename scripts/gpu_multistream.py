@@ -27,7 +27,7 @@ for S in counts:
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     for p in pipes: p.sync()
-    mix = float(np.mean([p.stage_ms(warm, warm + steps)[0] for p in pipes]))
+    mix = float(np.mean([p.last_stage_ms()['mixnet'] for p in pipes]))
     r = {"streams": S, "bytes_per_s": S * steps * chunk / dt, "per_stream_bytes_per_s": steps * chunk / dt,
          "host_enqueue_s": t_host, "wall_s": dt, "mixnet_ms_per_chunk": mix,
          "algorithmic_GBps_mixnet": S * 3617849344 / (mix / 1e3) / 1e9}

@@ -29,8 +29,6 @@ if int(os.environ.get('CMX_MIXNET_DBG', '0')) & 2:
     names[6:12] = ['SCOUT: wait consumed', 'SCOUT: probs load + stretch LUT + xs', 'SCOUT: aux + select_row', 'SCOUT: prefetch drain+issue', 'SCOUT: rest + publish', 'SCOUT: loop top']
 if int(os.environ.get('CMX_MIXNET_DBG', '0')) & 4:
     names[6:12] = ['TAIL: prefetch rows + SSE cells', 'TAIL: wait tail_in', 'TAIL: layer 1 (dot + chain)', 'TAIL: layer 2 + SSE + L2 perceive scalars', 'TAIL: updates + publish', 'TAIL: loop top + wait scout']
-if int(os.environ.get('CMX_MIXNET_DBG', '0')) & 8:
-    names[6:15] = ['producer %d: serial window (u seen -> segment 0 staged)' % k for k in range(9)]
 tot = sum(pr[:6]) + sum(pr[12:16]) if os.environ.get('CMX_MIXNET_V1') != '1' else sum(pr[:12])
 print('profiled: kernel %.2f ms  %.2f us/bit; total ticks/bit %.0f' % (ms, ms * 1e3 / T, tot / T))
 for n, v in zip(names, pr):

@@ -69,3 +69,48 @@ def test_pipeline_binary_64_ragged():
 
 def test_pipeline_text_4k_local():
     _pipeline("text_4k", chunks=[1024, 3000], big=True)
+
+
+def _native(name, chunks=None, big=False):
+    """Same check through cmx_pipeline_* (the native C++ orchestration: PPMd host stage, three HIP streams, two
+    chunks in flight): only the fxcm/paq8 columns come from the trace."""
+    import torch
+    from cmix_amd import engine as E
+    g = load_golden(name, big)
+    stream = np.ascontiguousarray(g["stream"])
+    N = len(stream)
+    ref = mg.unpack_probs(g)
+    layer0 = torch.from_numpy(ref.copy()).cuda()
+    layer0[:, E.SMALL_COLS + [2076, 2077]] = float("nan")
+    p = torch.full((8 * N,), -1.0, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    pipe = E.Pipeline(g["vocab"], 0, max_chunk_bytes=max(N, 1))
+    edges = [0, N] if not chunks else sorted(set([0, N] + list(chunks)))
+    for a, b in zip(edges[:-1], edges[1:]):
+        pipe.submit(stream[a:b].tobytes(), layer0[8 * a:8 * b], p[8 * a:8 * b])
+    pipe.sync()
+    assert all(v > 0 for v in pipe.last_stage_ms().values())
+    bad = np.argwhere(~bits_equal(layer0.cpu().numpy(), ref))
+    assert len(bad) == 0, f"{name}: layer-0 input {bad[0][1]} differs first at bit {bad[0][0]}"
+    bad = np.nonzero(~bits_equal(p.cpu().numpy(), g["p_final"]))[0]
+    assert len(bad) == 0, f"{name}: final probability differs first at bit {bad[0]} of {8 * N}"
+    pipe.close()
+
+
+def test_native_pipeline_text_96_ragged():
+    _native("text_96", chunks=[1, 2, 3, 50, 51])  # more chunks than slots: buffer recycling
+
+
+def test_native_pipeline_binary_64():
+    _native("binary_64")
+
+
+def test_native_pipeline_text_4k_local():
+    _native("text_4k", chunks=[1000, 2000, 3000], big=True)
+
+
+def test_native_pipeline_bad_args():
+    from cmix_amd import engine as E
+    pipe = E.Pipeline(np.ones(256, np.uint8), 0, max_chunk_bytes=16)
+    assert E.lib().cmx_pipeline_submit(pipe.h, None, 4, None, None) != 0 and "bad argument" in E.last_error()
+    pipe.close()
