@@ -126,7 +126,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--chunk-bytes", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams-per-gpu", type=int, default=1,
+                    help="independent input streams per GPU (throughput mode for multi-file jobs); the headline "
+                         "metric is 1 stream per GPU")
     a = ap.parse_args()
+    if a.streams_per_gpu > 1:  # persistent stage kernels pin hardware queues: give every stream's stages their own
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
     import torch
     import torch.distributed as dist
@@ -147,8 +152,20 @@ def main():
     nsteps = a.warmup + a.steps
     cb = a.chunk_bytes * 8
     from cmix_amd.pipeline import StreamPipeline
-    pipe = StreamPipeline(local, shard.shard_seed(rank), a.chunk_bytes, nsteps)  # rank r = GPU r = stream r
-    step = pipe.step
+    S = a.streams_per_gpu
+    pipes = [StreamPipeline(local, shard.shard_seed(rank, s, S), a.chunk_bytes, nsteps) for s in range(S)]
+    pipe = pipes[0]  # rank r = GPU r owns streams r*S .. r*S+S-1
+
+    def step(i):
+        if S == 1:
+            pipe.step(i)
+            return
+        import threading  # one host thread per stream: PPMd and the launches of different streams overlap
+        th = [threading.Thread(target=p.step, args=(i,)) for p in pipes]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
     torch.cuda.synchronize()
 
     for i in range(a.warmup):
@@ -165,8 +182,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    pipe.sync()
-    total_bytes, dt, _ = shard.aggregate_throughput(a.chunk_bytes * a.steps, dt, dev)  # sum of bytes / max of times
+    for p in pipes:
+        p.sync()
+    total_bytes, dt, _ = shard.aggregate_throughput(S * a.chunk_bytes * a.steps, dt, dev)  # sum of bytes / max of times
     st = pipe.last_stage_ms()  # HIP events around each stage of the last timed chunk, on the stage's own stream
     mix_ms, ctx_ms, lstm_ms = st["mixnet"], st["ctxmodels"], st["lstm"]
 
@@ -186,8 +204,9 @@ def main():
                             "SSE), strict bit-exact mode, fed by the PPMd host stage (one host core, inside the timed loop). "
                             "No stage yet, replaced by a seeded stand-in of the same shape: the paq8 and fxcm "
                             "columns (3..2024)" % a.chunk_bytes,
-                "chunk_bytes": a.chunk_bytes, "streams_per_gpu": 1, "parallelism": "1 stream per GPU, no collective"},
-            "us_per_bit": dt / (a.steps * cb) * 1e6,
+                "chunk_bytes": a.chunk_bytes, "streams_per_gpu": S,
+                "parallelism": "%d stream%s per GPU, no collective" % (S, "" if S == 1 else "s")},
+            "us_per_bit": dt / (a.steps * cb) * 1e6,  # wall per bit of ONE stream
             "stage_us_per_bit": {"mixnet": avg_kernel_s / cb * 1e6, "ctxmodels": ctx_ms * 1e3 / cb,
                                  "lstm": lstm_ms * 1e3 / cb,
                                  "note": "HIP-event time of each stage over the last timed chunk (stages overlap on separate streams)"},
@@ -202,7 +221,8 @@ def main():
             if ref:
                 out["cpu_reference_full"] = ref
         print(json.dumps(out))
-    pipe.close()
+    for p in pipes:
+        p.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -53,12 +53,25 @@ __device__ __forceinline__ void lstm_prep(const LstmState* S, const float* in256
 
 // ---- output layer SGD (lstm.cpp:112-116): slot[e] = slot[last] - (lr*err_i)*hidden_, both layouts
 // stand-alone form: on BPTT bytes (epoch 0) the bookkeeping must precede the backward pass (lstm.cpp:88-93)
-extern "C" __global__ void cmx_lstm_prep(const LstmState P, const float* in256, const uint8_t* bytes, size_t n, int e) {
+// Every per-byte kernel takes a trailing `k`: k < 0 = direct launch, the explicit arguments hold; k >= 0 = node
+// k of a captured 100-byte block, the arguments come from the device-resident LstmBlockArgs (epoch = k).
+extern "C" __global__ void cmx_lstm_setblk(LstmBlockArgs* dst, const LstmBlockArgs v) {
+  if (threadIdx.x == 0) *dst = v;
+}
+
+extern "C" __global__ void cmx_lstm_prep(const LstmState P, const float* in256, const uint8_t* bytes, size_t n, int e, int k) {
+  if (k >= 0) { const LstmBlockArgs a = *P.blk; in256 = a.in_probs + a.n0 * 256; bytes = a.bytes; n = a.n0; e = 0; }
   lstm_prep(&P, in256, bytes, n, e);
 }
 
-extern "C" __global__ void cmx_lstm_sgd(const LstmState P, const float* in256, const uint8_t* bytes, size_t n, int e, int hid_cur) {
+extern "C" __global__ void cmx_lstm_sgd(const LstmState P, const float* in256, const uint8_t* bytes, size_t n, int e, int hid_cur,
+                                        int k) {
   const LstmState* S = &P;
+  if (k >= 0) {
+    const LstmBlockArgs a = *P.blk;
+    n = a.n0 + k; e = k; hid_cur = (a.hc0 + k) & 1; bytes = a.bytes;
+    in256 = k == 0 ? nullptr : a.in_probs + n * 256;  // node 0 follows the stand-alone bookkeeping kernel
+  }
   if (blockIdx.x == gridDim.x - 1) {  // the extra block does ByteMixer::SetInput / Lstm::Perceive bookkeeping
     if (in256) lstm_prep(S, in256, bytes, n, e);   // NULL: already done by cmx_lstm_prep
     return;
@@ -85,8 +98,13 @@ extern "C" __global__ void cmx_lstm_sgd(const LstmState P, const float* in256, c
 //      600 ordered chains, one per lane; the transposed weight layout makes a wave's loads of one term
 //      a contiguous 256-byte run, so the CU streams the layer's weights from L2 at its L1 fill rate.
 extern "C" __global__ __launch_bounds__(640) void cmx_lstm_fwd(const LstmState P, const uint8_t* bytes, size_t n, int e,
-                                                               int hid_cur, float* out_probs256) {
+                                                               int hid_cur, float* out_probs256, int k) {
   const LstmState* S = &P;
+  if (k >= 0) {
+    const LstmBlockArgs a = *P.blk;
+    n = a.n0 + k; e = k; hid_cur = (a.hc0 + k) & 1; bytes = a.bytes;
+    out_probs256 = a.out_probs ? a.out_probs + n * 256 : nullptr;
+  }
   __shared__ float in[832];
   __shared__ float raw[3][C];
   __shared__ float ivar_s[3];
@@ -357,8 +375,9 @@ extern "C" __global__ __launch_bounds__(1024) void cmx_lstm_bptt_seq(const LstmS
 // ---- BPTT sweep: update_[i][c] accumulated over epochs 99..0 (lstm-layer.cpp:182-186) held in a
 //      register, then Adam (lstm-layer.cpp:11-32) and both weight layouts rewritten.
 //      grid (ceil(rowlen/64), 50, 6): blockIdx.z = layer*3 + gate; block (64, 4) = 64 columns x 4 rows.
-extern "C" __global__ void cmx_lstm_bptt_acc(const LstmState P, int update_steps) {
+extern "C" __global__ void cmx_lstm_bptt_acc(const LstmState P, int update_steps, int k) {
   const LstmState* S = &P;
+  if (k >= 0) update_steps = P.blk->us;
   __shared__ float es[H][4];
   __shared__ float ins[H][64];
   __shared__ unsigned sym[H];
@@ -398,8 +417,9 @@ extern "C" __global__ void cmx_lstm_bptt_acc(const LstmState P, int update_steps
 }
 
 // ---- Adam for gamma / beta (lstm-layer.cpp:191-195); grid 6 blocks of 256
-extern "C" __global__ void cmx_lstm_bptt_gb(const LstmState P, int update_steps) {
+extern "C" __global__ void cmx_lstm_bptt_gb(const LstmState P, int update_steps, int k) {
   const LstmState* S = &P;
+  if (k >= 0) update_steps = P.blk->us;
   const int layer = blockIdx.x / 3, g = blockIdx.x % 3, c = threadIdx.x;
   if (c >= C) return;
   float* gb = S->gb[layer][g];

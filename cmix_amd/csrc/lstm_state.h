@@ -11,6 +11,18 @@
 #define LSTM_VP 256    // padded vocabulary stride
 #define LSTM_UPDATE_LIMIT 3000
 
+// Arguments of one epoch-aligned block of 100 bytes (one BPTT round + 100 x (SGD, forward)) replayed as a
+// HIP graph: the graph's kernel parameters are frozen at capture, so everything that changes per block is
+// read from this device-resident record, written by a 1-lane kernel ahead of each replay.
+struct LstmBlockArgs {
+  const float* in_probs;         // byte model distributions of the chunk
+  const unsigned char* bytes;    // the chunk's bytes
+  float* out_probs;              // LSTM distributions out (may be NULL)
+  unsigned long long n0;         // index in the chunk of the block's first byte
+  int hc0;                       // hidden_ double-buffer index at the block's first byte
+  int us;                        // LstmLayer::update_steps_ of this block's BPTT round
+};
+
 struct LstmState {
   int V;                         // vocabulary size (distinct bytes of the input)
   int insz[LSTM_L];              // layer_input sizes: 1+C+V, V+1+2C   (lstm.cpp:13-24)
@@ -19,6 +31,7 @@ struct LstmState {
   // byte and is known to the host (epoch = bytes_done % 100, the hidden_ double-buffer index,
   // LstmLayer::update_steps_) is a plain kernel argument instead of a device-memory field.
   int* dyn;                      // [4] device scalars: [0] = old_input of the current Perceive
+  struct LstmBlockArgs* blk;     // device copy of the arguments of the 100-byte block a captured graph is replaying
   int byte_map[256];             // byte value -> vocabulary index (byte-mixer.cpp:9-12)
   unsigned char vocab[256];
   float lr;                      // 0.03

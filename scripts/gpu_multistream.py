@@ -3,6 +3,9 @@ stage + three device stages, one CU per persistent stage kernel). Streams are in
 is what a GPU does when it is given several files (config 4: 12 Silesia files on 8 GPUs) -- not the single-stream
 `value` bench.py reports. One host thread per stream (the C ABI calls release the GIL)."""
 import json, os, sys, threading, time
+# every stage kernel is persistent for a whole chunk and pins a hardware queue: with the default 4 queues the
+# streams of different pipelines queue up behind each other's 90 ms kernels
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 import numpy as np, torch
 from cmix_amd.pipeline import StreamPipeline
