@@ -16,7 +16,8 @@
 // area (a successor that has not been turned into a context yet), anything above is a unit number.
 // Unit bookkeeping mirrors the reference's size classes and free-list discipline so that the arena
 // fills up at exactly the same moment; what happens after that moment (the reference's cut-off /
-// restore path, ppmd.cpp:562-640,686-727) is NOT implemented: the model reports the condition and
+// restore path, ppmd.cpp:562-640,686-727 -- in which the reference build itself segfaults, checked with a
+// 1 MB arena) is NOT implemented: the model reports the condition and
 // stops (cmx_ppmd_run fails loudly) instead of drifting away from the reference. With the reference's
 // 14000 MB arena this is beyond ~1.7 GB of input text.
 #include <stddef.h>
@@ -149,8 +150,9 @@ struct Ppmd {
     return old;
   }
 
-  bool init() {
-    heap_bytes = (u64)14000 << 20;  // predictor.cpp:101
+  bool init(int order, u64 memory_mb) {
+    max_order = order;
+    heap_bytes = memory_mb << 20;   // 14000 MB at predictor.cpp:101
     void* m = mmap(nullptr, heap_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
     if (m == MAP_FAILED) return false;
     heap = (u8*)m;
@@ -607,11 +609,15 @@ struct cmx_ppmd {
 
 extern "C" {
 
-cmx_ppmd_t* cmx_ppmd_create(const uint8_t vocab[256]) {
+cmx_ppmd_t* cmx_ppmd_create(const uint8_t vocab[256]) { return cmx_ppmd_create_ex(vocab, 25, 14000); }
+
+// Test hook: other order / arena size (the reference's own constructor arguments, ppmd.cpp:1322-1326).
+cmx_ppmd_t* cmx_ppmd_create_ex(const uint8_t vocab[256], int order, int memory_mb) {
+  if (order < 2 || order > 64 || memory_mb < 1) { cmx_set_err("cmx_ppmd_create_ex: bad argument"); return nullptr; }
   cmx_ppmd_t* h = new cmx_ppmd();
   memcpy(h->m.vocab, vocab, 256);
-  if (!h->m.init()) {
-    cmx_set_err("cmx_ppmd_create: cannot reserve the 14000 MB PPMd arena (mmap failed)");
+  if (!h->m.init(order, (uint64_t)memory_mb)) {
+    cmx_set_err("cmx_ppmd_create: cannot reserve the PPMd arena (mmap failed)");
     delete h;
     return nullptr;
   }
@@ -630,8 +636,8 @@ int cmx_ppmd_run(cmx_ppmd_t* h, const uint8_t* bytes, size_t nbytes, float* out_
   for (size_t n = 0; n < nbytes; ++n) {
     if (m.exhausted || !m.update_byte(bytes[n])) {
       m.exhausted = true;
-      cmx_set_err("cmx_ppmd_run: the 14000 MB PPMd arena is exhausted; the reference's cut-off/restore path "
-                  "(ppmd.cpp:686-727) is not implemented");
+      cmx_set_err("cmx_ppmd_run: the PPMd arena is exhausted; the reference's cut-off/restore path "
+                  "(ppmd.cpp:686-727) is not implemented (the reference build itself crashes there)");
       return 1;
     }
     m.prepare_byte();

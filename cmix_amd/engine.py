@@ -79,6 +79,8 @@ def lib():
         L.cmx_ctxmodels_get_manager.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.cmx_ppmd_create.restype = C.c_void_p
         L.cmx_ppmd_create.argtypes = [C.c_void_p]
+        L.cmx_ppmd_create_ex.restype = C.c_void_p
+        L.cmx_ppmd_create_ex.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.cmx_ppmd_destroy.argtypes = [C.c_void_p]
         L.cmx_ppmd_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.cmx_pipeline_create.restype = C.c_void_p
@@ -368,10 +370,10 @@ class Pipeline:
 class Ppmd:
     """HOST stage: PPMd order-25 byte model (runs on a host core ahead of the device pipeline)."""
 
-    def __init__(self, vocab):
+    def __init__(self, vocab, order=25, memory_mb=14000):
         vocab = np.ascontiguousarray(vocab, np.uint8)
         assert vocab.size == 256
-        self.h = lib().cmx_ppmd_create(vocab.ctypes.data)
+        self.h = lib().cmx_ppmd_create_ex(vocab.ctypes.data, order, memory_mb)
         if not self.h:
             raise CmxError(last_error())
 

@@ -181,6 +181,7 @@ int cmx_ctxmodels_get_manager(cmx_ctxmodels_t*, uint64_t* regs25, uint64_t* ctx5
  * ------------------------------------------------------------------------ */
 typedef struct cmx_ppmd cmx_ppmd_t;
 cmx_ppmd_t* cmx_ppmd_create(const uint8_t vocab[256]);
+cmx_ppmd_t* cmx_ppmd_create_ex(const uint8_t vocab[256], int order, int memory_mb); /* test hook: other (order, MB) */
 void cmx_ppmd_destroy(cmx_ppmd_t*);
 /* Feeds nbytes bytes; out_probs [nbytes][256] f32 receives ByteModel::probs_ after each byte (what
  * predictor.cpp:450-457 hands to the byte mixer and what column 2076 is formed from). Fails (nonzero) if the

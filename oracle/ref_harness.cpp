@@ -36,6 +36,7 @@
 #include "mixer/lstm.h"
 #include "mixer/byte-mixer.h"
 #include "models/byte-model.h"
+#include "models/ppmd.h"
 #include "contexts/interval.h"
 #include "contexts/interval-hash.h"
 #include "states/nonstationary.h"
@@ -221,6 +222,27 @@ int ref_interval_map(int ctx_index, int* out256) {
   if (!m) return -1;
   for (int i = 0; i < 256; ++i) out256[i] = (*m)[i];
   return 256;
+}
+
+// A stand-alone instance of the reference's PPMd byte model with an arbitrary arena size (the Predictor's own
+// is fixed at 14000 MB, predictor.cpp:101): a small arena makes the memory-exhaustion path -- cut-off and
+// restore, ppmd.cpp:562-640,686-727 -- run every few tens of KB, so it can be pinned by short traces.
+namespace {
+PPMD::PPMD* g_ppmd = nullptr;
+unsigned int g_ppmd_byte = 0;
+std::vector<bool> g_ppmd_vocab(256, true);
+}
+int ref_ppmd_create(int order, int memory_mb, const uint8_t* vocab256) {
+  if (g_ppmd) return -1;
+  for (int i = 0; i < 256; ++i) g_ppmd_vocab[i] = vocab256[i] != 0;
+  g_ppmd = new PPMD::PPMD(order, memory_mb, g_ppmd_byte, g_ppmd_vocab);
+  return 0;
+}
+int ref_ppmd_update(int byte, float* out256) {
+  g_ppmd_byte = (unsigned int)byte;
+  g_ppmd->ByteUpdate();
+  for (int i = 0; i < 256; ++i) out256[i] = g_ppmd->probs_[i];
+  return 0;
 }
 
 // libm probes: the exact host functions the reference's float path resolves to,

@@ -54,3 +54,24 @@ def test_vocab_mask_and_errors():
     assert np.allclose(out.sum(1), 1, atol=1e-5) and out[-1, 97] > 0.5  # 'a' follows "abc" repeats
     assert E.lib().cmx_ppmd_run(p.h, None, 3, None) != 0 and "bad argument" in E.last_error()
     p.close()
+
+
+def test_small_arena_fills_up_then_fails_loudly():
+    """1 MB arena (reference PPMD(25, 1) stand-alone): bit-exact while the reference works (50 000 bytes, arena
+    full to the brim), then -- where the reference build segfaults in its restore path -- a clean error."""
+    from cmix_amd import engine as E
+    g = load_golden("ppmd_1mb_50k")
+    data = g["stream"]
+    N = len(g["p_next"])
+    p = E.Ppmd(np.ones(256, np.uint8), 25, 1)
+    out = p.run(data[:N].tobytes())
+    nxt = out[np.arange(N), data[1:N + 1]]
+    bad = np.nonzero(~bits_equal(nxt, g["p_next"]))[0]
+    assert len(bad) == 0, f"p(next byte) differs first after byte {bad[0]}"
+    chk = (out.astype(np.float64) * np.arange(1, 257, dtype=np.float64)).sum(1)
+    assert np.array_equal(chk, g["chk"]), "distribution checksum differs"
+    with pytest.raises(E.CmxError, match="exhausted"):
+        p.run(data[N:N + 10000].tobytes())
+    with pytest.raises(E.CmxError, match="exhausted"):  # stays failed
+        p.run(b"abc")
+    p.close()
