@@ -161,6 +161,24 @@ int cmx_pipeline_submit(cmx_pipeline_t* h, const uint8_t* bytes, size_t n, float
   return 0;
 }
 
+// Predictor::Pretrain (predictor.cpp:471-487) over dictionary bytes: only `models_` learn -- here the context /
+// small-model stage; PPMd, the LSTM, the mixers and the SSE are untouched, exactly as in the reference.
+int cmx_pipeline_pretrain(cmx_pipeline_t* h, const uint8_t* bytes, size_t n) {
+  if (!h) { cmx_set_err("cmx_pipeline_pretrain: null handle"); return 1; }
+  if (n == 0) return 0;
+  if (!bytes) { cmx_set_err("cmx_pipeline_pretrain: bad argument"); return 1; }
+  if (h->chunks) { cmx_set_err("cmx_pipeline_pretrain: only before the first submit (preprocessor.cpp:37-69)"); return 1; }
+  if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
+  uint8_t* d = nullptr;
+  if (hipMalloc((void**)&d, n) != hipSuccess) { cmx_set_err("cmx_pipeline_pretrain: hipMalloc failed"); return 1; }
+  bool ok = hipMemcpyAsync(d, bytes, n, hipMemcpyHostToDevice, h->s_ctx) == hipSuccess;
+  ok = ok && cmx_ctxmodels_pretrain(h->ctx, d, n, h->s_ctx) == 0;
+  ok = hipStreamSynchronize(h->s_ctx) == hipSuccess && ok;
+  (void)hipFree(d);
+  if (!ok) { cmx_set_err("cmx_pipeline_pretrain: device error"); return 1; }
+  return 0;
+}
+
 int cmx_pipeline_sync(cmx_pipeline_t* h) {
   if (!h) return 1;
   (void)hipSetDevice(h->device);

@@ -87,6 +87,7 @@ def lib():
         L.cmx_pipeline_create.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
         L.cmx_pipeline_destroy.argtypes = [C.c_void_p]
         L.cmx_pipeline_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.cmx_pipeline_pretrain.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.cmx_pipeline_sync.argtypes = [C.c_void_p]
         L.cmx_pipeline_last_stage_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.cmx_probe_libm.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
@@ -344,6 +345,11 @@ class Pipeline:
         assert layer0.is_cuda and layer0.dtype == torch.float32 and layer0.is_contiguous() and layer0.shape == (8 * n, N_INPUTS)
         assert p_out.is_cuda and p_out.dtype == torch.float32 and p_out.is_contiguous() and p_out.numel() == 8 * n
         if lib().cmx_pipeline_submit(self.h, data.ctypes.data, n, layer0.data_ptr(), p_out.data_ptr()):
+            raise CmxError(last_error())
+
+    def pretrain(self, data):
+        data = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8))
+        if lib().cmx_pipeline_pretrain(self.h, data.ctypes.data, len(data)):
             raise CmxError(last_error())
 
     def sync(self):

@@ -207,6 +207,9 @@ void cmx_pipeline_destroy(cmx_pipeline_t*);
  * Returns after enqueueing (it only waits for the chunk before the previous one); d_layer0 / d_p_out must
  * stay valid until cmx_pipeline_sync() or until two further submits have returned. */
 int cmx_pipeline_submit(cmx_pipeline_t*, const uint8_t* bytes, size_t n, float* d_layer0, float* d_p_out);
+/* Predictor::Pretrain over n dictionary bytes (HOST pointer), before the first submit: only the stages holding
+ * `models_` learn (today: contexts + small models); mixers, SSE, LSTM and PPMd are not trained (predictor.cpp:471-487). */
+int cmx_pipeline_pretrain(cmx_pipeline_t*, const uint8_t* bytes, size_t n);
 int cmx_pipeline_sync(cmx_pipeline_t*);
 /* HIP-event time (ms) the last submitted chunk spent in [0] contexts+small models, [1] LSTM, [2] mixing network. */
 int cmx_pipeline_last_stage_ms(cmx_pipeline_t*, float ms[3]);
