@@ -87,6 +87,24 @@ def lib():
         L.cmx_pipeline_create.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
         L.cmx_pipeline_destroy.argtypes = [C.c_void_p]
         L.cmx_pipeline_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.cmx_encoder_create.restype = C.c_void_p
+        L.cmx_encoder_destroy.argtypes = [C.c_void_p]
+        L.cmx_encoder_encode_bits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.cmx_encoder_encode_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.cmx_encoder_flush.argtypes = [C.c_void_p]
+        L.cmx_encoder_size.restype = C.c_size_t
+        L.cmx_encoder_size.argtypes = [C.c_void_p]
+        L.cmx_encoder_data.restype = C.c_void_p
+        L.cmx_encoder_data.argtypes = [C.c_void_p]
+        L.cmx_decoder_create.restype = C.c_void_p
+        L.cmx_decoder_create.argtypes = [C.c_void_p, C.c_size_t]
+        L.cmx_decoder_destroy.argtypes = [C.c_void_p]
+        L.cmx_decoder_decode.argtypes = [C.c_void_p, C.c_float]
+        L.cmx_decoder_decode_bits.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.cmx_header_write.restype = C.c_size_t
+        L.cmx_header_write.argtypes = [C.c_uint64, C.c_void_p, C.c_int, C.c_void_p]
+        L.cmx_header_read.restype = C.c_size_t
+        L.cmx_header_read.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         L.cmx_pipeline_pretrain.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.cmx_pipeline_sync.argtypes = [C.c_void_p]
         L.cmx_pipeline_last_stage_ms.argtypes = [C.c_void_p, C.c_void_p]
@@ -407,3 +425,91 @@ def glibc_rand(seed, n):
     out = np.empty(n, np.int32)
     lib().cmx_glibc_rand_selftest(seed, n, out.ctypes.data)
     return out
+
+
+class Encoder:
+    """Encoder::Encode / Flush (src/coder/encoder.cpp) over probabilities a pipeline chunk produced (host arrays)."""
+
+    def __init__(self):
+        self.h = lib().cmx_encoder_create()
+
+    def encode_bits(self, p, bits):
+        p = np.ascontiguousarray(p, np.float32)
+        bits = np.ascontiguousarray(bits, np.uint8)
+        if p.shape != bits.shape:
+            raise CmxError("Encoder.encode_bits: p and bits differ in length")
+        if lib().cmx_encoder_encode_bits(self.h, p.ctypes.data, bits.ctypes.data, len(p)):
+            raise CmxError(last_error())
+
+    def encode_bytes(self, p, data):
+        p = np.ascontiguousarray(p, np.float32)
+        data = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8))
+        if len(p) != 8 * len(data):
+            raise CmxError("Encoder.encode_bytes: need 8 probabilities per byte")
+        if lib().cmx_encoder_encode_bytes(self.h, p.ctypes.data, data.ctypes.data, len(data)):
+            raise CmxError(last_error())
+
+    def flush(self):
+        if lib().cmx_encoder_flush(self.h):
+            raise CmxError(last_error())
+
+    def data(self):
+        n = lib().cmx_encoder_size(self.h)
+        return C.string_at(lib().cmx_encoder_data(self.h), n) if n else b""
+
+    def close(self):
+        if self.h:
+            lib().cmx_encoder_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+
+class Decoder:
+    """Decoder::Decode (src/coder/decoder.cpp)."""
+
+    def __init__(self, code):
+        self._code = np.ascontiguousarray(np.frombuffer(bytes(code), np.uint8))  # kept alive: the decoder reads it
+        self.h = lib().cmx_decoder_create(self._code.ctypes.data if len(self._code) else None, len(self._code))
+        if not self.h:
+            raise CmxError(last_error())
+
+    def decode(self, p):
+        b = lib().cmx_decoder_decode(self.h, float(p))
+        if b < 0:
+            raise CmxError(last_error())
+        return b
+
+    def decode_bits(self, p):
+        p = np.ascontiguousarray(p, np.float32)
+        bits = np.empty(len(p), np.uint8)
+        if lib().cmx_decoder_decode_bits(self.h, p.ctypes.data, len(p), bits.ctypes.data):
+            raise CmxError(last_error())
+        return bits
+
+    def close(self):
+        if self.h:
+            lib().cmx_decoder_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+
+def header_write(length, vocab, dictionary_used=False):
+    """WriteHeader (src/runner.cpp:34-52)."""
+    out = np.zeros(37, np.uint8)
+    vocab = np.ascontiguousarray(vocab, np.uint8)
+    n = lib().cmx_header_write(int(length), vocab.ctypes.data, int(bool(dictionary_used)), out.ctypes.data)
+    if n == 0:
+        raise CmxError(last_error())
+    return out[:n].tobytes()
+
+
+def header_read(buf):
+    """ReadHeader (src/runner.cpp:62-84) -> (length, dictionary_used, vocab[256], header bytes consumed)."""
+    b = np.ascontiguousarray(np.frombuffer(bytes(buf[:37]), np.uint8))
+    length, dic, vocab = C.c_uint64(0), C.c_int(0), np.zeros(256, np.uint8)
+    n = lib().cmx_header_read(b.ctypes.data if len(b) else None, len(b), C.byref(length), C.byref(dic), vocab.ctypes.data)
+    if n == 0:
+        raise CmxError(last_error())
+    return length.value, bool(dic.value), vocab, n

@@ -65,3 +65,36 @@ class StreamPipeline:
 
     def close(self):
         self.pipe.close()
+
+
+def compress_stream(stream, vocab, layer0, device_index=0, chunk_bytes=4096, pretrain=None, dictionary_used=False):
+    """What runner.cpp's RunCompression does after preprocessing (runner.cpp:196-208): header, then every byte of
+    the (already preprocessed) stream through the predictor and the arithmetic coder. The prediction runs a chunk
+    at a time on the device; p[] then comes back to the host, where the coder (a few ns per bit against the
+    predictor's microseconds) consumes it. `layer0` is the stream's [8n, 2078] device matrix holding the columns no stage produces yet
+    (fxcm, paq8); the stages fill in theirs. Returns the container bytes (header + code)."""
+    import torch
+    stream = np.ascontiguousarray(np.frombuffer(bytes(stream), np.uint8))
+    n = len(stream)
+    if tuple(layer0.shape) != (8 * n, 2078) or layer0.dtype != torch.float32 or not layer0.is_cuda:
+        raise E.CmxError("compress_stream: layer0 must be a float32 [8n, 2078] device matrix")
+    dev = layer0.device
+    pipe = E.Pipeline(vocab, device_index, max(1, min(chunk_bytes, n)))
+    enc = E.Encoder()
+    try:
+        if pretrain:
+            pipe.pretrain(pretrain)
+        p_dev = torch.empty(8 * n, dtype=torch.float32, device=dev)
+        p_host = torch.empty(8 * n, dtype=torch.float32).pin_memory()
+        edges = list(range(0, n, chunk_bytes)) + [n]
+        torch.cuda.synchronize(dev)
+        for a, b in zip(edges[:-1], edges[1:]):
+            pipe.submit(stream[a:b], layer0[8 * a:8 * b], p_dev[8 * a:8 * b])
+        pipe.sync()
+        p_host.copy_(p_dev)
+        enc.encode_bytes(p_host.numpy(), stream)
+        enc.flush()
+        return E.header_write(n, vocab, dictionary_used) + enc.data()
+    finally:
+        enc.close()
+        pipe.close()

@@ -173,6 +173,31 @@ int cmx_ctxmodels_sync(cmx_ctxmodels_t*);
 /* Test hook: ContextManager registers (25), byte contexts (54), bit contexts (8) between bytes. */
 int cmx_ctxmodels_get_manager(cmx_ctxmodels_t*, uint64_t* regs25, uint64_t* ctx54, uint64_t* bitctx8);
 
+/* ---- callers of the path: arithmetic coder + container header (HOST code) -------------------------------------
+ * Replaces Encoder::Encode/Flush (src/coder/encoder.cpp:10-39), Decoder::Decoder/Decode (src/coder/decoder.cpp:3-39)
+ * and WriteHeader/ReadHeader (src/runner.cpp:34-84). The probabilities are the p[] a pipeline chunk produced
+ * (copied to the host by the caller); p[t] = P(bit t = 1). Bytes are coded MSB first (runner.cpp:106-108). */
+typedef struct cmx_encoder cmx_encoder_t;
+typedef struct cmx_decoder cmx_decoder_t;
+cmx_encoder_t* cmx_encoder_create(void);
+void cmx_encoder_destroy(cmx_encoder_t*);
+int cmx_encoder_encode_bits(cmx_encoder_t*, const float* p, const uint8_t* bits, size_t nbits);
+int cmx_encoder_encode_bytes(cmx_encoder_t*, const float* p /* [8*nbytes] */, const uint8_t* bytes, size_t nbytes);
+int cmx_encoder_flush(cmx_encoder_t*);                 /* Encoder::Flush; further encode calls fail */
+size_t cmx_encoder_size(const cmx_encoder_t*);          /* code bytes produced so far */
+const uint8_t* cmx_encoder_data(const cmx_encoder_t*);  /* valid until the next encode/flush/destroy */
+/* `code` must stay valid for the decoder's lifetime; reads past its end return zeros like the reference. */
+cmx_decoder_t* cmx_decoder_create(const uint8_t* code, size_t len);
+void cmx_decoder_destroy(cmx_decoder_t*);
+int cmx_decoder_decode(cmx_decoder_t*, float p);        /* the next bit (0/1), -1 on a bad argument */
+int cmx_decoder_decode_bits(cmx_decoder_t*, const float* p, size_t nbits, uint8_t* bits_out); /* replay of known p[] */
+#define CMX_HEADER_MAX 37
+#define CMX_MIN_VOCAB_FILE_SIZE 10000                   /* runner.cpp:14 */
+/* 5 bytes of length (bit 39 = dictionary flag) + the 32-byte vocabulary bitmap when length >= 10000. Return the
+ * number of header bytes written / consumed, 0 on error. */
+size_t cmx_header_write(uint64_t length, const uint8_t vocab[256], int dictionary_used, uint8_t out[CMX_HEADER_MAX]);
+size_t cmx_header_read(const uint8_t* in, size_t len, uint64_t* length, int* dictionary_used, uint8_t vocab[256]);
+
 /* ------------------------------------------------------------------------
  * 2d. HOST stage: PPMd order-25 byte model = PPMD::PPMD / PPMD::ByteUpdate (src/models/ppmd.cpp:
  *     1322-1338 and everything below it; constructed with (25, 14000 MB) at predictor.cpp:101).

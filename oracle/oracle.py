@@ -46,6 +46,11 @@ def lib():
         L.orc_sse_predict.restype = C.c_float
         L.orc_sse_predict.argtypes = [C.c_void_p, C.c_float]
         L.orc_sse_perceive.argtypes = [C.c_void_p, C.c_int]
+        L.orc_coder_encode.restype = C.c_size_t
+        L.orc_coder_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.orc_coder_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.orc_header_write.restype = C.c_size_t
+        L.orc_header_write.argtypes = [C.c_uint64, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_lstm_create.restype = C.c_void_p
         L.orc_lstm_create.argtypes = [C.c_void_p, C.c_int]
         L.orc_lstm_destroy.argtypes = [C.c_void_p]
@@ -231,3 +236,30 @@ class CtxModels:
 
     def __del__(self):
         self.close()
+
+
+def coder_encode(p, bits):
+    """Encoder::Encode over (p[t], bits[t]) then Flush (encoder.cpp) -> code bytes."""
+    p = np.ascontiguousarray(p, np.float32)
+    bits = np.ascontiguousarray(bits, np.uint8)
+    assert p.shape == bits.shape
+    out = np.empty(len(p) * 2 + 16, np.uint8)
+    n = lib().orc_coder_encode(p.ctypes.data, bits.ctypes.data, len(p), out.ctypes.data, len(out))
+    assert n != C.c_size_t(-1).value
+    return out[:n].tobytes()
+
+
+def coder_decode(p, code):
+    """Decoder::Decode replaying p[] (decoder.cpp) -> bits."""
+    p = np.ascontiguousarray(p, np.float32)
+    code = np.ascontiguousarray(np.frombuffer(bytes(code), np.uint8))
+    bits = np.empty(len(p), np.uint8)
+    lib().orc_coder_decode(p.ctypes.data, len(p), code.ctypes.data, len(code), bits.ctypes.data)
+    return bits
+
+
+def header_write(length, vocab, dictionary_used=False):
+    out = np.zeros(37, np.uint8)
+    vocab = np.ascontiguousarray(vocab, np.uint8)
+    n = lib().orc_header_write(int(length), vocab.ctypes.data, int(bool(dictionary_used)), out.ctypes.data)
+    return out[:n].tobytes()

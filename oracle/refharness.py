@@ -143,3 +143,39 @@ def vocab_of(data: bytes):
     else:
         v[np.unique(np.frombuffer(data, np.uint8))] = 1
     return v
+
+
+CODER_LIB_PATH = os.path.join(HERE, "_ref", "libcmixrefcoder.so")
+
+
+def coder_available():
+    return os.path.exists(CODER_LIB_PATH)
+
+
+def _coder_lib():
+    L = C.CDLL(CODER_LIB_PATH)
+    L.refcoder_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p]
+    L.refcoder_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_void_p]
+    return L
+
+
+def ref_encode(p, bits):
+    """The reference's own Encoder (compiled by oracle/ref_coder.cpp) over a recorded p[] -> code bytes."""
+    import tempfile
+    p = np.ascontiguousarray(p, np.float32)
+    bits = np.ascontiguousarray(bits, np.uint8)
+    with tempfile.NamedTemporaryFile(suffix=".cmix") as f:
+        assert _coder_lib().refcoder_encode(p.ctypes.data, bits.ctypes.data, len(p), f.name.encode()) == 0
+        with open(f.name, "rb") as g:
+            return g.read()
+
+
+def ref_decode(p, code):
+    import tempfile
+    p = np.ascontiguousarray(p, np.float32)
+    bits = np.empty(len(p), np.uint8)
+    with tempfile.NamedTemporaryFile(suffix=".cmix") as f:
+        f.write(bytes(code))
+        f.flush()
+        assert _coder_lib().refcoder_decode(p.ctypes.data, len(p), f.name.encode(), bits.ctypes.data) == 0
+    return bits

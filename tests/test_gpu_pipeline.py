@@ -8,10 +8,12 @@
 Only what has no stage yet (fxcm, paq8) is replayed from the golden trace of the reference; every other number
 is produced by the engine (PPMd on a host core, the rest on the MI355X). The final probability must equal Predictor::Predict()'s float bit
 for bit, for every coded bit (predictor.cpp:361-419)."""
+import os
+
 import numpy as np
 import pytest
 
-from conftest import bits_equal, load_golden
+from conftest import GOLDEN, bits_equal, load_golden
 import make_golden as mg
 
 pytestmark = pytest.mark.gpu
@@ -107,6 +109,53 @@ def test_native_pipeline_binary_64():
 
 def test_native_pipeline_text_4k_local():
     _native("text_4k", chunks=[1000, 2000, 3000], big=True)
+
+
+def test_native_pipeline_pretrained_128():
+    """Predictor::Pretrain over 300 dictionary bytes, then 128 coded bytes: every column a stage owns (0-2,
+    2025-2077) against the reference trace; pretraining after the first submit is refused."""
+    import torch
+    from cmix_amd import engine as E
+    g = load_golden("pretrained_128")
+    stream = np.ascontiguousarray(g["stream"])
+    N = len(stream)
+    cols = E.SMALL_COLS + [2076, 2077]
+    layer0 = torch.full((8 * N, 2078), 0.5, dtype=torch.float32, device="cuda")
+    p = torch.full((8 * N,), -1.0, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    pipe = E.Pipeline(g["vocab"], 0, max_chunk_bytes=N)
+    pipe.pretrain(g["pretrain"].tobytes())
+    pipe.submit(stream[:50].tobytes(), layer0[:400], p[:400])
+    with pytest.raises(E.CmxError, match="before the first submit"):
+        pipe.pretrain(b"abc")
+    pipe.submit(stream[50:].tobytes(), layer0[400:], p[400:])
+    pipe.sync()
+    got = layer0.cpu().numpy()
+    bad = np.argwhere(~bits_equal(got[:, cols], g["small_probs"]))
+    assert len(bad) == 0, f"column {cols[bad[0][1]]} differs first at bit {bad[0][0]}"
+    assert (np.delete(got, cols, axis=1) == 0.5).all()
+    pv = p.cpu().numpy()
+    assert ((pv > 0) & (pv < 1)).all()
+    pipe.close()
+
+
+def test_compress_stream_reproduces_the_reference_file():
+    """Device pipeline + host coder + header = the file `cmix -n` writes for the same payload, byte for byte (the
+    fxcm/paq8 columns come from the trace of that very run); then decoded back with the same probabilities."""
+    import torch
+    from cmix_amd import engine as E
+    from cmix_amd.pipeline import compress_stream
+    g = load_golden("binary_64")
+    with np.load(os.path.join(GOLDEN, "coder_vectors.npz")) as v:
+        want = v["binary_64_file"].tobytes()
+    stream = np.ascontiguousarray(g["stream"])
+    layer0 = torch.from_numpy(mg.unpack_probs(g).copy()).cuda()
+    layer0[:, E.SMALL_COLS + [2076, 2077]] = float("nan")
+    got = compress_stream(stream, g["vocab"], layer0, chunk_bytes=24)
+    assert got == want
+    length, _, _, used = E.header_read(got)
+    bits = E.Decoder(got[used:]).decode_bits(g["p_final"])
+    assert length == len(stream) and (np.packbits(bits) == stream).all()
 
 
 def test_native_pipeline_bad_args():

@@ -1,6 +1,9 @@
 """CPU: the C restatement (oracle/) against the committed golden traces of the
 unmodified reference (tests/golden/*.npz, produced by tests/golden/make_golden.py)."""
+import os
+
 import numpy as np
+import pytest
 
 from conftest import bits_equal, load_golden
 import make_golden as mg
@@ -66,6 +69,19 @@ def _check_lstm(name):
             t += 1
         out = l.byte_update(g["ppmd_probs"][n + 1], stream[n])
         assert bits_equal(out, g["lstm_probs"][n + 1]).all(), f"{name}: LSTM distribution differs after byte {n}"
+
+
+@pytest.mark.skipif(os.environ.get("CMX_LONG") != "1", reason="~5 min; set CMX_LONG=1")
+def test_lstm_330k_golden_past_3000_adam_rounds():
+    """330 000 bytes = 3300 BPTT rounds: LstmLayer::update_steps_ saturates at 3000 and Adam's bias terms switch
+    to the double-precision pow() path (lstm-layer.cpp:26-30). Fixture: tests/golden/make_long_trace.py (local)."""
+    g = load_golden("text_330k_bytes", big=True)
+    l = O.Lstm(g["vocab"])
+    stream = g["stream"]
+    for n in range(len(stream)):
+        out = l.byte_update(g["ppmd_probs"][n + 1], stream[n])
+        if n % 997 == 0 or n >= len(stream) - 300:
+            assert bits_equal(out, g["lstm_probs"][n + 1]).all(), f"LSTM distribution differs after byte {n}"
 
 
 def test_lstm_text_golden():

@@ -44,6 +44,10 @@ def test_random_160k_local():
     _check("random_160k", big=True)  # incompressible: widest contexts, constant escapes
 
 
+def test_text_330k_local():
+    _check("text_330k_bytes", big=True, chunks=[100000, 200001])  # tests/golden/make_long_trace.py
+
+
 def test_vocab_mask_and_errors():
     from cmix_amd import engine as E
     v = np.zeros(256, np.uint8)
