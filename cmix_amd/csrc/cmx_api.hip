@@ -127,22 +127,7 @@ int cmx_device_count(void) {
   return n;
 }
 
-// --------------------------------------------------------------------------
-// whole-predictor surface: assembled from the device stages as they land.
-// Until the paq8 / fxcm / ppmd stages exist on the device a full Predictor
-// cannot be formed, and there is deliberately no host fallback.
-// --------------------------------------------------------------------------
-struct cmx_engine { int unused; };
-cmx_t* cmx_create(const uint8_t*, const char*, int) {
-  set_err("cmx_create: device stages paq8, fxcm and ppmd are not implemented yet; "
-          "use the stage-level entry points (cmx_mixnet_*, ...). No CPU fallback exists.");
-  return nullptr;
-}
-float cmx_predict(cmx_t*) { set_err("cmx_predict: no engine"); return -1.0f; }
-int cmx_perceive(cmx_t*, int) { set_err("cmx_perceive: no engine"); return 1; }
-int cmx_pretrain(cmx_t*, int) { set_err("cmx_pretrain: no engine"); return 1; }
-int cmx_stage_input(cmx_t*, const uint8_t*, size_t) { set_err("cmx_stage_input: no engine"); return 1; }
-void cmx_destroy(cmx_t*) {}
+// whole-predictor surface (cmx_create .. cmx_destroy): engine_api.hip
 
 // --------------------------------------------------------------------------
 // mixing-network stage

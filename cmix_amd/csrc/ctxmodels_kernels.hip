@@ -74,7 +74,11 @@ extern "C" unsigned cmx_ctxmodels_lds_bytes() { return LdsMap::total; }
 
 extern "C" __global__ void __launch_bounds__(64)
 cmx_ctxmodels_kernel(const CtxDev D, const uint8_t* __restrict__ bytes, size_t nbytes, float* probs, size_t pstride,
-                     uint32_t* sel, float* bracket_dist) {
+                     uint32_t* sel, float* bracket_dist, int dry) {
+  // dry != 0 (bit-synchronous mode, one byte): the 8 Predict/Perceive steps run on a byte whose low bits are
+  // still unknown (zeros); outputs and selectors of bit j depend only on bits < j, so row j is exact once j bits
+  // are known. Nothing of the pass survives: HBM writes are suppressed (or rolled back, overlapping Indirect
+  // maps), the LDS-resident tables are never stored, and the kernel returns before the byte boundary.
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u64* regs = (u64*)(smem + LdsMap::regs);
   float* ipred = (float*)(smem + LdsMap::ipred);
@@ -192,6 +196,7 @@ cmx_ctxmodels_kernel(const CtxDev D, const uint8_t* __restrict__ bytes, size_t n
         const int bit = (B >> (7 - j)) & 1;
         out[j] = pv[j];
         float div = L.divisor;
+        if (dry) continue;
         if ((int)cv[j] < L.limit) {
           const unsigned c = cv[j] + 1;
           cn[bc] = (uint8_t)c;
@@ -212,7 +217,7 @@ cmx_ctxmodels_kernel(const CtxDev D, const uint8_t* __restrict__ bytes, size_t n
           const float p = ip[s];
           out[j] = p;
           ip[s] = p + ((float)bit - p) * L.divisor;
-          mp8[(1u << j) | (B >> (8 - j))] = trans[s * 2 + bit];
+          if (!dry) mp8[(1u << j) | (B >> (8 - j))] = trans[s * 2 + bit];
         }
       }
     } else if (is_match) {  // match.cpp:17-46
@@ -234,9 +239,10 @@ cmx_ctxmodels_kernel(const CtxDev D, const uint8_t* __restrict__ bytes, size_t n
         m = match ? (m < 255 ? m + 1 : m) : 0;
       }
       ml = m;
-      L.map[mbase] = (uint32_t)mhp;  // map_[byte_context_ % map_.size()] = history_pos_
+      if (!dry) L.map[mbase] = (uint32_t)mhp;  // map_[byte_context_ % map_.size()] = history_pos_
       ++mhp;
     }
+    unsigned undo[8];  // dry pass over overlapping maps: the states this lane replaced, restored below
     if (slow) {  // reference order, bit by bit and model by model
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -254,8 +260,22 @@ cmx_ctxmodels_kernel(const CtxDev D, const uint8_t* __restrict__ bytes, size_t n
             const float p = ip[s];
             ip[s] = p + ((float)bit - p) * L.divisor;
             D.shared_map[mbase + bc] = trans[s * 2 + bit];
+            undo[j] = s;
           }
           wave_mem_sync();
+        }
+      }
+      if (dry) {  // exact rollback: newest write first (bits 7..0, lanes high..low)
+#pragma unroll
+        for (int j = 7; j >= 0; --j) {
+          const unsigned bc = (1u << j) | (B >> (8 - j));
+          u64 m = __ballot(is_ind);
+          while (m) {
+            const int k = 63 - __clzll((long long)m);
+            m &= ~(1ull << k);
+            if (lane == k) D.shared_map[mbase + bc] = (uint8_t)undo[j];
+            wave_mem_sync();
+          }
         }
       }
     }
@@ -263,6 +283,7 @@ cmx_ctxmodels_kernel(const CtxDev D, const uint8_t* __restrict__ bytes, size_t n
 #pragma unroll
       for (int j = 0; j < 8; ++j) probs[(t0 + j) * pstride + L.col] = out[j];
     }
+    if (dry) return;  // uniform: the whole wave leaves before the byte boundary and the epilogue
 
     // ---- ContextManager::UpdateContexts at the byte boundary (context-manager.cpp:69-94) ----
     __syncthreads();

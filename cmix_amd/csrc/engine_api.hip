@@ -1,0 +1,253 @@
+// engine_api.hip -- the whole-predictor surface (cmx_create .. cmx_destroy): `class Predictor`'s four members
+// (src/predictor.h:17-22) in their strict per-bit protocol, the form a Decoder needs (src/coder/decoder.cpp:20-39:
+// bit t is unknown until Predict() of bit t has returned).
+//
+// Per Predict() (predictor.cpp:361-419):
+//   device  contexts + 54 small models, "dry" pass over the partially known byte -> columns 0-2, 2025-2075 and the
+//           47 selectors of this bit (ctxmodels_kernels.hip, dry mode: no state survives the pass)
+//   device  ByteModel::Predict of PPMd and of the LSTM byte mixer over the same partial byte -> columns 2076, 2077
+//   caller  columns 3..2024 (fxcm, paq8) -- no device stage yet; the shim that owns the reference's two vendored
+//           models hands their outputs in through cmx_set_model_outputs()
+//   device  mixing network + SSE, bit-synchronous (cmx_mixnet_predict)
+// Per Perceive(bit) (predictor.cpp:421-469): the mixing network learns; on the 8th bit the byte is committed to the
+// context stage (the same kernel, now for real), to PPMd (host stage) and to the LSTM; then lstmpr / lstmex
+// (predictor.cpp:462-466), which fxcm reads in its own Perceive, are refreshed for the caller.
+// Pretrain(bit) (predictor.cpp:471-487) collects bytes and trains the context stage in batches.
+//
+// Launch-latency bound by construction (a handful of small launches and two host round trips per bit): this is the
+// decode path and the parity anchor; compression uses the chunk pipeline (pipeline_api.hip). No CPU fallback.
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/cmix_amd.h"
+
+void cmx_set_err(const std::string& s);  // cmx_api.hip
+
+struct cmx_engine {
+  int device = 0;
+  cmx_ctxmodels_t* ctx = nullptr;
+  cmx_lstm_t* lstm = nullptr;
+  cmx_mixnet_t* mix = nullptr;
+  cmx_ppmd_t* ppmd = nullptr;
+  uint8_t* d_byte = nullptr;
+  float* d_rows = nullptr;        // [8][2078]: the dry pass writes all 8 rows, row j is the valid one
+  uint32_t* d_sel = nullptr;      // [8][47]
+  float* d_ppmd = nullptr;        // [256]: PPMd's distribution while the current byte is coded
+  float* d_lstm = nullptr;        // [256]: the LSTM byte mixer's
+  float* d_lstm_next = nullptr;   // [256]
+  int* d_ex = nullptr;            // [8]
+  float* d_scratch = nullptr;     // [8][2078] outputs of the committing pass (unused)
+  uint32_t* d_scratch_sel = nullptr;
+  float h_row[CMX_N_INPUTS];
+  uint32_t h_sel[CMX_N_MIXERS];
+  float h_ppmd[256];
+  float staged[2022];
+  bool have_staged = false, predicted = false, started = false;
+  int j = 0;                      // bits of the current byte already coded
+  unsigned partial = 0;           // those bits
+  int lstmpr = 0, lstmex = 0;
+  std::vector<uint8_t> pre;       // Pretrain bytes not yet trained
+  int pre_j = 0;
+  unsigned pre_partial = 0;
+};
+
+#define E_HIP(x)                                                                          \
+  do {                                                                                    \
+    hipError_t e_ = (x);                                                                  \
+    if (e_ != hipSuccess) {                                                               \
+      cmx_set_err(std::string(where) + ": " #x ": " + hipGetErrorString(e_));             \
+      return fail;                                                                        \
+    }                                                                                     \
+  } while (0)
+
+namespace {
+
+int flush_pretrain(cmx_engine* h) {
+  const char* where = "cmx_pretrain";
+  const int fail = 1;
+  if (h->pre.empty()) return 0;
+  uint8_t* d = nullptr;
+  E_HIP(hipMalloc((void**)&d, h->pre.size()));
+  bool ok = hipMemcpy(d, h->pre.data(), h->pre.size(), hipMemcpyHostToDevice) == hipSuccess;
+  ok = ok && cmx_ctxmodels_pretrain(h->ctx, d, h->pre.size(), nullptr) == 0;
+  ok = hipDeviceSynchronize() == hipSuccess && ok;
+  (void)hipFree(d);
+  h->pre.clear();
+  if (!ok) { cmx_set_err("cmx_pretrain: device error"); return 1; }
+  return 0;
+}
+
+// lstmpr / lstmex for the next bit: Discretize(byte_mixer->Predict()[0]) and byte_mixer->ex (predictor.cpp:180-182,
+// 462-465) = ByteModel::Predict of the LSTM's distribution over the bits coded so far in this byte.
+int refresh_lstm_hint(cmx_engine* h) {
+  const char* where = "cmx_perceive";
+  const int fail = 1;
+  const uint8_t b = (uint8_t)(h->partial << (8 - h->j));
+  E_HIP(hipMemcpy(h->d_byte, &b, 1, hipMemcpyHostToDevice));
+  if (cmx_bytemodel_bits_run(h->device, h->d_lstm, h->d_lstm, h->d_byte, 1, h->d_rows + 2077, CMX_N_INPUTS, h->d_ex,
+                             nullptr)) return 1;
+  float p;
+  int ex;
+  E_HIP(hipMemcpy(&p, h->d_rows + (size_t)h->j * CMX_N_INPUTS + 2077, 4, hipMemcpyDeviceToHost));
+  E_HIP(hipMemcpy(&ex, h->d_ex + h->j, 4, hipMemcpyDeviceToHost));
+  volatile float prod = 4094.0f * p;
+  const float s = 1.0f + prod;
+  h->lstmpr = (int)(unsigned)s;
+  h->lstmex = ex;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+void cmx_destroy(cmx_t* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  for (void* p : {(void*)h->d_byte, (void*)h->d_rows, (void*)h->d_sel, (void*)h->d_ppmd, (void*)h->d_lstm,
+                  (void*)h->d_lstm_next, (void*)h->d_ex, (void*)h->d_scratch, (void*)h->d_scratch_sel})
+    if (p) (void)hipFree(p);
+  cmx_mixnet_destroy(h->mix);
+  cmx_lstm_destroy(h->lstm);
+  cmx_ctxmodels_destroy(h->ctx);
+  cmx_ppmd_destroy(h->ppmd);
+  delete h;
+}
+
+cmx_t* cmx_create(const uint8_t vocab[256], const char* dict_path, int device) {
+  (void)dict_path;  // read by fxcm only (fxcmv1.cpp:412-428), which still lives with the caller
+  const char* where = "cmx_create";
+  cmx_t* const fail = nullptr;
+  if (!vocab) { cmx_set_err("cmx_create: null vocab"); return nullptr; }
+  cmx_engine* h = new cmx_engine();
+  h->device = device;
+  h->ctx = cmx_ctxmodels_create(vocab, device);
+  h->lstm = h->ctx ? cmx_lstm_create(vocab, 31, device) : nullptr;  // 31 rand() draws precede the LSTM (indirect.cpp:10)
+  h->mix = h->lstm ? cmx_mixnet_create(device) : nullptr;
+  h->ppmd = h->mix ? cmx_ppmd_create(vocab) : nullptr;
+  if (!h->ppmd) { cmx_destroy(h); return nullptr; }  // the failing stage has set the error
+  bool ok = hipSetDevice(device) == hipSuccess;
+  ok = ok && hipMalloc((void**)&h->d_byte, 16) == hipSuccess;
+  ok = ok && hipMalloc((void**)&h->d_rows, 8 * CMX_N_INPUTS * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&h->d_sel, 8 * CMX_N_MIXERS * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&h->d_ppmd, 256 * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&h->d_lstm, 256 * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&h->d_lstm_next, 256 * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&h->d_ex, 8 * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&h->d_scratch, 8 * CMX_N_INPUTS * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&h->d_scratch_sel, 8 * CMX_N_MIXERS * 4) == hipSuccess;
+  if (!ok) { cmx_set_err("cmx_create: buffer allocation failed"); cmx_destroy(h); return nullptr; }
+  float u[256];
+  for (int i = 0; i < 256; ++i) u[i] = (float)(1.0 / 256);  // ByteModel constructor (byte-model.cpp:5-6)
+  if (hipMemcpy(h->d_ppmd, u, sizeof u, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(h->d_lstm, u, sizeof u, hipMemcpyHostToDevice) != hipSuccess) {
+    cmx_set_err("cmx_create: upload failed");
+    cmx_destroy(h);
+    return nullptr;
+  }
+  (void)where; (void)fail;
+  return h;
+}
+
+int cmx_set_model_outputs(cmx_t* h, const float* cols) {
+  if (!h || !cols) { cmx_set_err("cmx_set_model_outputs: bad argument"); return 1; }
+  if (h->predicted) { cmx_set_err("cmx_set_model_outputs: between predict() and perceive()"); return 1; }
+  memcpy(h->staged, cols, sizeof h->staged);
+  h->have_staged = true;
+  return 0;
+}
+
+float cmx_predict(cmx_t* h) {
+  const char* where = "cmx_predict";
+  const float fail = -1.0f;
+  if (!h) { cmx_set_err("cmx_predict: null handle"); return fail; }
+  if (h->predicted) { cmx_set_err("cmx_predict: called twice without perceive()"); return fail; }
+  if (!h->have_staged) {
+    cmx_set_err("cmx_predict: the fxcm/paq8 columns of this bit were not supplied (cmx_set_model_outputs); those "
+                "two model families have no device stage yet and there is no CPU fallback");
+    return fail;
+  }
+  E_HIP(hipSetDevice(h->device));
+  if (h->pre_j) { cmx_set_err("cmx_predict: Pretrain() stopped inside a byte"); return fail; }
+  if (flush_pretrain(h)) return fail;
+  h->started = true;
+  const int j = h->j;
+  const uint8_t b = (uint8_t)(h->partial << (8 - j));  // coded bits on top, zeros below
+  E_HIP(hipMemcpy(h->d_byte, &b, 1, hipMemcpyHostToDevice));
+  if (cmx_ctxmodels_peek(h->ctx, h->d_byte, h->d_rows, CMX_N_INPUTS, h->d_sel, nullptr)) return fail;
+  if (cmx_bytemodel_bits_run(h->device, h->d_ppmd, h->d_ppmd, h->d_byte, 1, h->d_rows + 2076, CMX_N_INPUTS, nullptr,
+                             nullptr)) return fail;
+  if (cmx_bytemodel_bits_run(h->device, h->d_lstm, h->d_lstm, h->d_byte, 1, h->d_rows + 2077, CMX_N_INPUTS, h->d_ex,
+                             nullptr)) return fail;
+  E_HIP(hipMemcpy(h->h_row, h->d_rows + (size_t)j * CMX_N_INPUTS, sizeof h->h_row, hipMemcpyDeviceToHost));
+  E_HIP(hipMemcpy(h->h_sel, h->d_sel + (size_t)j * CMX_N_MIXERS, sizeof h->h_sel, hipMemcpyDeviceToHost));
+  memcpy(h->h_row + 3, h->staged, sizeof h->staged);
+  const float p = cmx_mixnet_predict(h->mix, h->h_row, h->h_sel);
+  if (p < 0.0f) return fail;
+  h->predicted = true;
+  h->have_staged = false;
+  return p;
+}
+
+int cmx_perceive(cmx_t* h, int bit) {
+  const char* where = "cmx_perceive";
+  const int fail = 1;
+  if (!h) { cmx_set_err("cmx_perceive: null handle"); return 1; }
+  if (!h->predicted) { cmx_set_err("cmx_perceive: no pending predict()"); return 1; }
+  E_HIP(hipSetDevice(h->device));
+  if (cmx_mixnet_perceive(h->mix, bit)) return 1;
+  h->predicted = false;
+  h->partial = (h->partial << 1) | (bit ? 1u : 0u);
+  if (++h->j == 8) {  // byte boundary (predictor.cpp:439-461)
+    const uint8_t B = (uint8_t)h->partial;
+    E_HIP(hipMemcpy(h->d_byte, &B, 1, hipMemcpyHostToDevice));
+    if (cmx_ctxmodels_run(h->ctx, h->d_byte, 1, h->d_scratch, CMX_N_INPUTS, h->d_scratch_sel, nullptr)) return 1;
+    if (cmx_ppmd_run(h->ppmd, &B, 1, h->h_ppmd)) return 1;
+    E_HIP(hipMemcpy(h->d_ppmd, h->h_ppmd, sizeof h->h_ppmd, hipMemcpyHostToDevice));
+    if (cmx_lstm_run(h->lstm, h->d_ppmd, h->d_byte, 1, h->d_lstm_next, nullptr, 0, nullptr, nullptr)) return 1;
+    E_HIP(hipDeviceSynchronize());
+    float* t = h->d_lstm; h->d_lstm = h->d_lstm_next; h->d_lstm_next = t;
+    h->j = 0;
+    h->partial = 0;
+  }
+  return refresh_lstm_hint(h);
+}
+
+int cmx_get_lstm_hint(cmx_t* h, int* lstmpr, int* lstmex) {
+  if (!h || !lstmpr || !lstmex) { cmx_set_err("cmx_get_lstm_hint: bad argument"); return 1; }
+  *lstmpr = h->lstmpr;
+  *lstmex = h->lstmex;
+  return 0;
+}
+
+const float* cmx_debug_last_row(const cmx_t* h) { return h ? h->h_row : nullptr; }
+
+int cmx_pretrain(cmx_t* h, int bit) {
+  if (!h) { cmx_set_err("cmx_pretrain: null handle"); return 1; }
+  if (h->started) { cmx_set_err("cmx_pretrain: only before the first predict() (preprocessor.cpp:37-69)"); return 1; }
+  h->pre_partial = (h->pre_partial << 1) | (bit ? 1u : 0u);
+  if (++h->pre_j == 8) {
+    h->pre.push_back((uint8_t)h->pre_partial);
+    h->pre_j = 0;
+    h->pre_partial = 0;
+    if (h->pre.size() >= (1u << 16)) {
+      if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
+      return flush_pretrain(h);
+    }
+  }
+  return 0;
+}
+
+int cmx_stage_input(cmx_t* h, const uint8_t*, size_t) {
+  (void)h;
+  cmx_set_err("cmx_stage_input: look-ahead coding goes through cmx_pipeline_* (whole chunks of known bytes); the "
+              "per-bit surface has no use for it while fxcm/paq8 outputs arrive one bit at a time from the caller");
+  return 1;
+}
+
+}  // extern "C"

@@ -42,10 +42,6 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.cmx_last_error.restype = C.c_char_p
         L.cmx_version.restype = C.c_char_p
-        L.cmx_create.restype = C.c_void_p
-        L.cmx_create.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
-        L.cmx_predict.restype = C.c_float
-        L.cmx_predict.argtypes = [C.c_void_p]
         L.cmx_mixnet_create.restype = C.c_void_p
         L.cmx_mixnet_create.argtypes = [C.c_int]
         L.cmx_mixnet_destroy.argtypes = [C.c_void_p]
@@ -87,6 +83,19 @@ def lib():
         L.cmx_pipeline_create.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
         L.cmx_pipeline_destroy.argtypes = [C.c_void_p]
         L.cmx_pipeline_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.cmx_create.restype = C.c_void_p
+        L.cmx_create.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.cmx_destroy.argtypes = [C.c_void_p]
+        L.cmx_predict.restype = C.c_float
+        L.cmx_predict.argtypes = [C.c_void_p]
+        L.cmx_perceive.argtypes = [C.c_void_p, C.c_int]
+        L.cmx_pretrain.argtypes = [C.c_void_p, C.c_int]
+        L.cmx_set_model_outputs.argtypes = [C.c_void_p, C.c_void_p]
+        L.cmx_get_lstm_hint.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cmx_stage_input.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.cmx_debug_last_row.restype = C.c_void_p
+        L.cmx_debug_last_row.argtypes = [C.c_void_p]
+        L.cmx_ctxmodels_peek.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.cmx_encoder_create.restype = C.c_void_p
         L.cmx_encoder_destroy.argtypes = [C.c_void_p]
         L.cmx_encoder_encode_bits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
@@ -513,3 +522,50 @@ def header_read(buf):
     if n == 0:
         raise CmxError(last_error())
     return length.value, bool(dic.value), vocab, n
+
+
+class Predictor:
+    """`class Predictor` (src/predictor.h:17-22) over cmx_create .. cmx_destroy: Predict / Perceive / Pretrain in the
+    reference's strict per-bit protocol (what a Decoder needs). The fxcm and paq8 columns of each bit come from
+    the caller (`set_model_outputs`) until those model families have device stages."""
+
+    def __init__(self, vocab, device=0, dict_path=None):
+        vocab = np.ascontiguousarray(vocab, np.uint8)
+        assert vocab.size == 256
+        self.h = lib().cmx_create(vocab.ctypes.data, dict_path.encode() if dict_path else None, device)
+        if not self.h:
+            raise CmxError(last_error())
+
+    def set_model_outputs(self, cols):
+        cols = np.ascontiguousarray(cols, np.float32)
+        if cols.shape != (2022,):
+            raise CmxError("Predictor.set_model_outputs: need the 2022 layer-0 columns 3..2024")
+        if lib().cmx_set_model_outputs(self.h, cols.ctypes.data):
+            raise CmxError(last_error())
+
+    def Predict(self):
+        p = lib().cmx_predict(self.h)
+        if p < 0:
+            raise CmxError(last_error())
+        return np.float32(p)
+
+    def Perceive(self, bit):
+        if lib().cmx_perceive(self.h, int(bit)):
+            raise CmxError(last_error())
+
+    def Pretrain(self, bit):
+        if lib().cmx_pretrain(self.h, int(bit)):
+            raise CmxError(last_error())
+
+    def lstm_hint(self):
+        a, b = C.c_int(0), C.c_int(0)
+        if lib().cmx_get_lstm_hint(self.h, C.byref(a), C.byref(b)):
+            raise CmxError(last_error())
+        return a.value, b.value
+
+    def close(self):
+        if self.h:
+            lib().cmx_destroy(self.h)
+            self.h = None
+
+    __del__ = close

@@ -57,11 +57,21 @@ typedef struct cmx_engine cmx_t;
  * (runner.cpp:196-202). dict_path replaces the global `dictionary_path`
  * (runner.cpp:17) read by fxcm; may be NULL. */
 cmx_t* cmx_create(const uint8_t vocab[256], const char* dict_path, int device);
-float cmx_predict(cmx_t*);             /* Predictor::Predict,  predictor.cpp:361 */
+float cmx_predict(cmx_t*);             /* Predictor::Predict,  predictor.cpp:361; < 0 on error */
 int cmx_perceive(cmx_t*, int bit);     /* Predictor::Perceive, predictor.cpp:421 */
 int cmx_pretrain(cmx_t*, int bit);     /* Predictor::Pretrain, predictor.cpp:471 */
-/* Optional look-ahead for compression: the bytes the coder is about to code,
- * so the device pipeline can run ahead of the host. */
+/* The two vendored model families without a device stage yet (fxcm, paq8) stay with the caller, which owns the
+ * reference's objects: before every cmx_predict() it hands in their outputs for that bit -- layer-0 columns
+ * 3..2024 in the reference's order (431 fxcm values, then 1591 paq8 values; predictor.cpp:363-369). cmx_predict()
+ * fails loudly when they are missing: nothing is computed on the CPU in their place. */
+int cmx_set_model_outputs(cmx_t*, const float cols_3_to_2024[2022]);
+/* The hidden globals `lstmpr`, `lstmex` (predictor.cpp:359,462-465) as they stand after the last cmx_perceive():
+ * what the caller's fxcm reads in its own Perceive. */
+int cmx_get_lstm_hint(cmx_t*, int* lstmpr, int* lstmex);
+/* Introspection used by the parity tests: the 2078 layer-0 inputs of the last cmx_predict() (valid until the next). */
+const float* cmx_debug_last_row(const cmx_t*);
+/* Optional look-ahead for compression. On the per-bit surface it is refused: look-ahead coding is
+ * cmx_pipeline_* below. */
 int cmx_stage_input(cmx_t*, const uint8_t* bytes, size_t n);
 void cmx_destroy(cmx_t*);
 
@@ -167,6 +177,11 @@ int cmx_ctxmodels_run(cmx_ctxmodels_t*, const uint8_t* d_bytes, size_t nbytes, f
 /* Predictor::Pretrain (predictor.cpp:471-487) over nbytes dictionary bytes for the models of this
  * stage: same state transitions as cmx_ctxmodels_run, no outputs (mixers/SSE/LSTM/PPMd are not
  * trained during pretraining). */
+/* Bit-synchronous mode: the 8 rows (outputs + selectors) the stage would produce if the next byte were *d_byte,
+ * without changing any state. Row j depends only on the top j bits of *d_byte: with j bits of the byte coded, row j
+ * is what Predict() uses for the next bit. */
+int cmx_ctxmodels_peek(cmx_ctxmodels_t*, const uint8_t* d_byte, float* d_probs8, size_t probs_stride, uint32_t* d_sel8,
+                       void* stream);
 int cmx_ctxmodels_pretrain(cmx_ctxmodels_t*, const uint8_t* d_bytes, size_t nbytes, void* stream);
 /* Waits for the handle's work; reports device-side failures. */
 int cmx_ctxmodels_sync(cmx_ctxmodels_t*);

@@ -33,7 +33,9 @@ def test_no_cpu_fallback():
     with pytest.raises(E.CmxError, match="no HIP device"):
         E.MixNet(0)
     assert not E.lib().cmx_create(np.ones(256, np.uint8).ctypes.data, None, 0)
-    assert "No CPU fallback" in E.last_error()
+    assert "no HIP device" in E.last_error()
+    with pytest.raises(E.CmxError, match="no HIP device"):
+        E.Pipeline(np.ones(256, np.uint8), 0, 64)
 
 
 def test_product_never_imports_oracle():
