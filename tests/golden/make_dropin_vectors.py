@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Whole-file fixtures for the drop-in test (tests/golden/dropin_vectors.npz): seeded payloads and the `.cmix`
+files the UNMODIFIED reference binary (oracle/_ref/cmix_O3, built by oracle/Makefile) writes for them.
+
+    case      command                         what it exercises
+    raw_n     cmix -n in out                  no preprocessing (DEFAULT block), all-true vocabulary
+    text_c    cmix -c in out                  preprocessor::Encode (type detection), no dictionary
+    dict_c    cmix -c dict in out             WRT dictionary transform + Predictor::Pretrain over the dictionary
+
+    python tests/golden/make_dropin_vectors.py
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+HERE = os.path.dirname(os.path.abspath(__file__))
+EXE = os.path.join(ROOT, "oracle", "_ref", "cmix_O3")
+
+
+def run(args, files):
+    with tempfile.TemporaryDirectory() as d:
+        paths = []
+        for name, data in files:
+            p = os.path.join(d, name)
+            with open(p, "wb") as f:
+                f.write(data)
+            paths.append(p)
+        out = os.path.join(d, "out")
+        subprocess.run([EXE, args] + paths + [out], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        with open(out, "rb") as f:
+            return f.read()
+
+
+def payloads():
+    from cmix_amd import synth
+    rng = np.random.default_rng(4242)
+    text = synth.enwik_like(6000, 31)
+    raw = text[:500] + bytes(rng.integers(0, 256, 300, dtype=np.uint8)) + b"\x00" * 40 + text[500:860]
+    words = sorted({w for w in text.replace(b"\n", b" ").split(b" ") if w.isalpha() and w.islower() and len(w) > 2})
+    dic = b"\n".join(words[:400]) + b"\n"
+    return {"raw_n": raw, "text_c": text[1000:3000], "dict_c": text[3000:4500], "dict": dic}
+
+
+if __name__ == "__main__":
+    p = payloads()
+    out = {k + "_payload": np.frombuffer(v, np.uint8) for k, v in p.items()}
+    out["raw_n_file"] = np.frombuffer(run("-n", [("in", p["raw_n"])]), np.uint8)
+    out["text_c_file"] = np.frombuffer(run("-c", [("in", p["text_c"])]), np.uint8)
+    out["dict_c_file"] = np.frombuffer(run("-c", [("dict", p["dict"]), ("in", p["dict_c"])]), np.uint8)
+    for k in ("raw_n", "text_c", "dict_c"):
+        print(k, len(p[k]), "->", len(out[k + "_file"]), "bytes; header", out[k + "_file"][:5])
+    np.savez_compressed(os.path.join(HERE, "dropin_vectors.npz"), **out)

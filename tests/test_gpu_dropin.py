@@ -1,0 +1,59 @@
+"""GPU: the drop-in, end to end. oracle/_ref/cmix_hybrid is the reference's own CLI, container, preprocessor,
+arithmetic coder, paq8 and fxcm -- unmodified, compiled from where they lie -- built against the Predictor shim of
+integration/predictor.h and linked with libcmixamd.so (recipe: oracle/Makefile, target `hybrid`). Everything else
+behind Predict()/Perceive()/Pretrain() runs in the library on the MI355X. Its `.cmix` files must equal, byte for
+byte, the ones the unmodified reference binary wrote for the same payloads (tests/golden/dropin_vectors.npz,
+tests/golden/make_dropin_vectors.py), and it must decompress them back."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+
+EXE = os.path.join(ROOT, "oracle", "_ref", "cmix_hybrid")
+
+
+def _run(mode, files, timeout=600):
+    with tempfile.TemporaryDirectory() as d:
+        paths = []
+        for name, data in files:
+            p = os.path.join(d, name)
+            with open(p, "wb") as f:
+                f.write(data)
+            paths.append(p)
+        out = os.path.join(d, "out")
+        r = subprocess.run([EXE, mode] + paths + [out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+        assert r.returncode == 0, f"cmix_hybrid {mode} failed: {r.stderr.decode(errors='replace')[-400:]}"
+        with open(out, "rb") as f:
+            return f.read()
+
+
+def _vectors():
+    if not os.path.exists(EXE):
+        pytest.skip("oracle/_ref/cmix_hybrid not built (make -C oracle hybrid)")
+    with np.load(os.path.join(GOLDEN, "dropin_vectors.npz")) as z:
+        return {k: z[k].tobytes() for k in z.files}
+
+
+def test_no_preprocessing_file_is_byte_identical_and_round_trips():
+    v = _vectors()
+    got = _run("-n", [("in", v["raw_n_payload"])])
+    assert got == v["raw_n_file"]
+    assert _run("-d", [("in", v["raw_n_file"])]) == v["raw_n_payload"]
+
+
+def test_preprocessed_text_file_is_byte_identical_and_round_trips():
+    v = _vectors()
+    assert _run("-c", [("in", v["text_c_payload"])]) == v["text_c_file"]
+    assert _run("-d", [("in", v["text_c_file"])]) == v["text_c_payload"]
+
+
+def test_dictionary_mode_pretrain_file_is_byte_identical_and_round_trips():
+    v = _vectors()
+    assert _run("-c", [("dict", v["dict_payload"]), ("in", v["dict_c_payload"])]) == v["dict_c_file"]
+    assert _run("-d", [("dict", v["dict_payload"]), ("in", v["dict_c_file"])]) == v["dict_c_payload"]
