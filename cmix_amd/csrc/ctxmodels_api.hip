@@ -347,6 +347,14 @@ int cmx_ctxmodels_sync(cmx_ctxmodels_t* h) {
   return 0;
 }
 
+// Test readout: how many bytes took the serial (overlapping Indirect maps) path, committed / in dry passes
+int cmx_ctxmodels_debug_slow_bytes(cmx_ctxmodels_t* h, uint64_t out2[2]) {
+  if (!h || !out2) return 1;
+  if (cmx_ctxmodels_sync(h)) return 1;
+  return hipMemcpy(out2, (const char*)h->dev.persist + offsetof(CtxPersist, slow_bytes), 16, hipMemcpyDeviceToHost) ==
+                 hipSuccess ? 0 : 1;
+}
+
 // Test readout in the layout the parity tests use for ContextManager state: regs25, ctx54, bitctx8
 int cmx_ctxmodels_get_manager(cmx_ctxmodels_t* h, uint64_t* regs25, uint64_t* ctx54, uint64_t* bitctx8) {
   if (!h) return 1;

@@ -173,6 +173,7 @@ cmx_ctxmodels_kernel(const CtxDev D, const uint8_t* __restrict__ bytes, size_t n
       }
     }
     const bool slow = __any(conf);
+    if (slow && lane == 0) ++P->slow_bytes[dry ? 1 : 0];
 
     // ---- 8 x (Predict, Perceive) of the table models ----
     float out[8];

@@ -79,6 +79,8 @@ struct CtxPersist {
   unsigned long long map_index[64];    // Indirect::map_index_ (byte base) / DirectHash::index_ / Match map slot
   unsigned long long m_history_pos[64], cur_match[64];
   unsigned cur_byte[64], match_length[64];
+  // statistics (test introspection): bytes that took the serial path [0] committed, [1] in dry passes
+  unsigned long long slow_bytes[2];
 };
 
 struct CtxDev {                        // passed to the kernel by value

@@ -95,6 +95,7 @@ def lib():
         L.cmx_stage_input.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.cmx_debug_last_row.restype = C.c_void_p
         L.cmx_debug_last_row.argtypes = [C.c_void_p]
+        L.cmx_ctxmodels_debug_slow_bytes.argtypes = [C.c_void_p, C.c_void_p]
         L.cmx_ctxmodels_peek.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.cmx_encoder_create.restype = C.c_void_p
         L.cmx_encoder_destroy.argtypes = [C.c_void_p]
@@ -324,6 +325,23 @@ class CtxModels:
             stream = torch.cuda.current_stream(data.device).cuda_stream
         if lib().cmx_ctxmodels_pretrain(self.h, data.data_ptr(), int(data.numel()), C.c_void_p(stream)):
             raise CmxError(last_error())
+
+    def peek(self, byte, probs8, sel8, stream=None):
+        """Bit-synchronous mode: the 8 rows the stage would write if the next byte were byte[0] (u8 cuda), leaving
+        all state untouched; row j is exact when the top j bits of byte[0] are the coded ones."""
+        import torch
+        assert byte.is_cuda and byte.dtype == torch.uint8 and probs8.shape == (8, N_INPUTS) and sel8.numel() == 8 * N_MIXERS
+        if stream is None:
+            stream = torch.cuda.current_stream(byte.device).cuda_stream
+        if lib().cmx_ctxmodels_peek(self.h, byte.data_ptr(), probs8.data_ptr(), N_INPUTS, sel8.data_ptr(),
+                                    C.c_void_p(stream)):
+            raise CmxError(last_error())
+
+    def slow_bytes(self):
+        out = np.zeros(2, np.uint64)
+        if lib().cmx_ctxmodels_debug_slow_bytes(self.h, out.ctypes.data):
+            raise CmxError(last_error())
+        return int(out[0]), int(out[1])
 
     def sync(self):
         if lib().cmx_ctxmodels_sync(self.h):

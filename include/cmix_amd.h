@@ -183,6 +183,9 @@ int cmx_ctxmodels_run(cmx_ctxmodels_t*, const uint8_t* d_bytes, size_t nbytes, f
 int cmx_ctxmodels_peek(cmx_ctxmodels_t*, const uint8_t* d_byte, float* d_probs8, size_t probs_stride, uint32_t* d_sel8,
                        void* stream);
 int cmx_ctxmodels_pretrain(cmx_ctxmodels_t*, const uint8_t* d_bytes, size_t nbytes, void* stream);
+/* Test introspection: bytes that went through the serial path taken when two Indirect models' 256-byte windows of
+ * the shared map overlap (indirect.cpp:16-31) -- [0] committed, [1] in dry (peek) passes. Synchronises. */
+int cmx_ctxmodels_debug_slow_bytes(cmx_ctxmodels_t*, uint64_t out2[2]);
 /* Waits for the handle's work; reports device-side failures. */
 int cmx_ctxmodels_sync(cmx_ctxmodels_t*);
 /* Test hook: ContextManager registers (25), byte contexts (54), bit contexts (8) between bytes. */

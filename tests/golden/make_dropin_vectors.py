@@ -6,6 +6,8 @@ files the UNMODIFIED reference binary (oracle/_ref/cmix_O3, built by oracle/Make
     raw_n     cmix -n in out                  no preprocessing (DEFAULT block), all-true vocabulary
     text_c    cmix -c in out                  preprocessor::Encode (type detection), no dictionary
     dict_c    cmix -c dict in out             WRT dictionary transform + Predictor::Pretrain over the dictionary
+    text12k_c cmix -c in out                  >= 10 000 bytes: vocabulary bitmap in the header, LSTM sized by the
+                                              real vocabulary (V < 256), 120 BPTT/Adam rounds
 
     python tests/golden/make_dropin_vectors.py
 """
@@ -43,7 +45,8 @@ def payloads():
     raw = text[:500] + bytes(rng.integers(0, 256, 300, dtype=np.uint8)) + b"\x00" * 40 + text[500:860]
     words = sorted({w for w in text.replace(b"\n", b" ").split(b" ") if w.isalpha() and w.islower() and len(w) > 2})
     dic = b"\n".join(words[:400]) + b"\n"
-    return {"raw_n": raw, "text_c": text[1000:3000], "dict_c": text[3000:4500], "dict": dic}
+    big = synth.enwik_like(12000, 77)
+    return {"raw_n": raw, "text_c": text[1000:3000], "dict_c": text[3000:4500], "dict": dic, "text12k_c": big}
 
 
 if __name__ == "__main__":
@@ -52,6 +55,7 @@ if __name__ == "__main__":
     out["raw_n_file"] = np.frombuffer(run("-n", [("in", p["raw_n"])]), np.uint8)
     out["text_c_file"] = np.frombuffer(run("-c", [("in", p["text_c"])]), np.uint8)
     out["dict_c_file"] = np.frombuffer(run("-c", [("dict", p["dict"]), ("in", p["dict_c"])]), np.uint8)
-    for k in ("raw_n", "text_c", "dict_c"):
+    out["text12k_c_file"] = np.frombuffer(run("-c", [("in", p["text12k_c"])]), np.uint8)
+    for k in ("raw_n", "text_c", "dict_c", "text12k_c"):
         print(k, len(p[k]), "->", len(out[k + "_file"]), "bytes; header", out[k + "_file"][:5])
     np.savez_compressed(os.path.join(HERE, "dropin_vectors.npz"), **out)

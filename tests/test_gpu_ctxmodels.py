@@ -135,3 +135,38 @@ def test_empty_chunk_and_bad_args():
     rc = E.lib().cmx_ctxmodels_run(c.h, d8.data_ptr(), 8, None, 2078, None, None)  # null output pointers
     assert rc != 0 and "bad argument" in E.last_error()
     c.close()
+
+
+def test_peek_is_exact_and_leaves_no_trace():
+    """Bit-synchronous mode: a dry pass over byte n (cmx_ctxmodels_peek) followed by the committing run of byte n,
+    for 96 000 random bytes, against a second instance that only ever ran in chunk mode. Random bytes make two
+    Indirect models' windows of the shared map overlap now and then (about once per 12 000 bytes), which is the one place where a dry
+    pass has to write to HBM and roll back -- the test requires that path to have been taken."""
+    import torch
+    from cmix_amd import engine as E
+    rng = np.random.default_rng(2024)
+    N, BLK = 96000, 4000
+    data = rng.integers(0, 256, N, dtype=np.uint8)
+    vocab = np.ones(256, np.uint8)
+    a, b = E.CtxModels(vocab, 0), E.CtxModels(vocab, 0)
+    d = torch.from_numpy(data).cuda()
+    cols = torch.tensor(list(COLS), device="cuda")
+    peek_p = torch.empty((8 * BLK, 2078), dtype=torch.float32, device="cuda")
+    peek_s = torch.empty((8 * BLK, 47), dtype=torch.int32, device="cuda")
+    run_p, run_s = torch.empty_like(peek_p), torch.empty_like(peek_s)
+    for blk in range(0, N, BLK):
+        want_p, want_s = b.run(d[blk:blk + BLK])
+        for i in range(BLK):
+            n = blk + i
+            a.peek(d[n:n + 1], peek_p[8 * i:8 * i + 8], peek_s[8 * i:8 * i + 8])
+            a.run(d[n:n + 1], run_p[8 * i:8 * i + 8], run_s[8 * i:8 * i + 8])
+        torch.cuda.synchronize()
+        for name, got_p, got_s in (("peek", peek_p, peek_s), ("run after peek", run_p, run_s)):
+            assert torch.equal(got_p[:, cols].view(torch.int32), want_p[:, cols].view(torch.int32)), f"{name}: outputs, block {blk}"
+            assert torch.equal(got_s, want_s), f"{name}: selectors, block {blk}"
+    ra, rb = a.manager(), b.manager()
+    assert all((x == y).all() for x, y in zip(ra, rb))
+    committed, dry = a.slow_bytes()
+    assert committed == b.slow_bytes()[0] and dry == committed and committed >= 3, (committed, dry)
+    a.close()
+    b.close()

@@ -57,3 +57,10 @@ def test_dictionary_mode_pretrain_file_is_byte_identical_and_round_trips():
     v = _vectors()
     assert _run("-c", [("dict", v["dict_payload"]), ("in", v["dict_c_payload"])]) == v["dict_c_file"]
     assert _run("-d", [("dict", v["dict_payload"]), ("in", v["dict_c_file"])]) == v["dict_c_payload"]
+
+
+def test_12k_text_with_vocabulary_header_is_byte_identical_and_round_trips():
+    """>= 10 000 bytes: the header carries the vocabulary bitmap and the LSTM is sized by the real vocabulary."""
+    v = _vectors()
+    assert _run("-c", [("in", v["text12k_c_payload"])]) == v["text12k_c_file"]
+    assert _run("-d", [("in", v["text12k_c_file"])]) == v["text12k_c_payload"]
