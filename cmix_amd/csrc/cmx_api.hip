@@ -111,6 +111,11 @@ struct cmx_mixnet {
   float* d_sync_p = nullptr;
   float h_sync_decay = 0;
   bool predicted = false;
+  // asynchronous bit-synchronous mode (device operands): the pending predict's operands, pinned (bit, decay) ring
+  const float* pend_probs = nullptr;
+  const uint32_t* pend_sel = nullptr;
+  unsigned char* h_sync_pin = nullptr;  // 16 slots x 8 bytes
+  unsigned sync_slot = 0;
   int profile = 0;
   int dbg = 0;          // CMX_MIXNET_DBG: timing experiments (results invalid when nonzero)
   bool use_v1 = false;  // CMX_MIXNET_V1=1: run chunks through the bit-synchronous kernel
@@ -138,6 +143,7 @@ void cmx_mixnet_destroy(cmx_mixnet_t* h) {
   hipDeviceSynchronize();
   for (void* p : h->allocs) hipFree(p);
   if (h->h_decay) hipHostFree(h->h_decay);
+  if (h->h_sync_pin) hipHostFree(h->h_sync_pin);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
   for (int i = 0; i < 4; ++i) if (h->ev_decay[i]) hipEventDestroy(h->ev_decay[i]);
@@ -330,6 +336,44 @@ int cmx_mixnet_perceive(cmx_mixnet_t* h, int bit) {
   HIP_OK(hipGetLastError());
   HIP_OK(hipDeviceSynchronize());
   h->predicted = false;
+  h->bits_done += 1;
+  return 0;
+}
+
+// Bit-synchronous mode with DEVICE operands, asynchronous on `stream` (engine_api.hip drives these): same kernel,
+// same protocol; the operands must stay untouched until the matching perceive has run.
+int cmx_mixnet_predict_async(cmx_mixnet_t* h, const float* d_probs, const uint32_t* d_sel, float* d_p, void* stream) {
+  const int fail_value = 1;
+  if (!h || !d_probs || !d_sel || !d_p) { set_err("cmx_mixnet_predict_async: bad argument"); return 1; }
+  if (h->predicted) { set_err("cmx_mixnet_predict_async: called twice without perceive()"); return 1; }
+  HIP_OK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(cmx_mixnet_kernel, dim3(1), dim3(CMX_MIXNET_THREADS), kLdsBytes, (hipStream_t)stream, h->d_state,
+                     d_probs, d_sel, h->d_sync_bit, (const float*)(h->d_sync_bit + 4), 1, d_p, (float*)nullptr, 1);
+  HIP_OK(hipGetLastError());
+  h->pend_probs = d_probs;
+  h->pend_sel = d_sel;
+  h->predicted = true;
+  return 0;
+}
+
+int cmx_mixnet_perceive_async(cmx_mixnet_t* h, int bit, void* stream) {
+  const int fail_value = 1;
+  if (!h) { set_err("cmx_mixnet_perceive_async: null handle"); return 1; }
+  if (!h->predicted || !h->pend_probs) { set_err("cmx_mixnet_perceive_async: no pending predict_async()"); return 1; }
+  HIP_OK(hipSetDevice(h->device));
+  if (!h->h_sync_pin) HIP_OK(hipHostMalloc((void**)&h->h_sync_pin, 16 * 8, hipHostMallocDefault));
+  // the caller synchronises at least once per bit (it needs p), so 16 slots can never wrap onto a pending copy
+  unsigned char* slot = h->h_sync_pin + 8 * (h->sync_slot++ & 15);
+  slot[0] = bit ? 1 : 0;
+  const float d = decay_of(h->bits_done);
+  memcpy(slot + 4, &d, 4);
+  hipStream_t st = (hipStream_t)stream;
+  HIP_OK(hipMemcpyAsync(h->d_sync_bit, slot, 8, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(cmx_mixnet_kernel, dim3(1), dim3(CMX_MIXNET_THREADS), kLdsBytes, st, h->d_state, h->pend_probs,
+                     h->pend_sel, h->d_sync_bit, (const float*)(h->d_sync_bit + 4), 1, h->d_sync_p, (float*)nullptr, 2);
+  HIP_OK(hipGetLastError());
+  h->predicted = false;
+  h->pend_probs = nullptr;
   h->bits_done += 1;
   return 0;
 }

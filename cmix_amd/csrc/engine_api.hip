@@ -14,8 +14,11 @@
 // (predictor.cpp:462-466), which fxcm reads in its own Perceive, are refreshed for the caller.
 // Pretrain(bit) (predictor.cpp:471-487) collects bytes and trains the context stage in batches.
 //
-// Launch-latency bound by construction (a handful of small launches and two host round trips per bit): this is the
-// decode path and the parity anchor; compression uses the chunk pipeline (pipeline_api.hip). No CPU fallback.
+// Everything of a handle goes through one HIP stream in order, host buffers are page-locked, and the host waits
+// exactly twice per bit: for p at the end of cmx_predict(), and for lstmpr/lstmex in cmx_get_lstm_hint() -- not in
+// cmx_perceive(), so the caller's own work (the shim runs paq8's Perceive there) overlaps the device's. Still
+// launch-latency bound by construction (about ten small launches/copies per bit): this is the decode path and the
+// parity anchor; compression throughput comes from the chunk pipeline (pipeline_api.hip). No CPU fallback.
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -27,27 +30,40 @@
 
 void cmx_set_err(const std::string& s);  // cmx_api.hip
 
+namespace {
+struct Pinned {               // one page-locked block: everything the host hands to / takes from the stream
+  float staged[2022];         // fxcm / paq8 columns of the pending bit
+  float ppmd[256];            // PPMd's distribution after the byte just committed
+  float p;                    // Predict() value
+  float hint_p[8];            // LSTM bit predictions of the current byte position (refresh_hint)
+  int hint_ex[8];
+  float row[CMX_N_INPUTS];    // cmx_debug_last_row
+  uint8_t byte[16];           // ring: partial / committed bytes on their way to the device
+};
+}  // namespace
+
 struct cmx_engine {
   int device = 0;
   cmx_ctxmodels_t* ctx = nullptr;
   cmx_lstm_t* lstm = nullptr;
   cmx_mixnet_t* mix = nullptr;
   cmx_ppmd_t* ppmd = nullptr;
-  uint8_t* d_byte = nullptr;
+  hipStream_t st = nullptr;       // every launch and copy of this handle, in order
+  Pinned* pin = nullptr;
+  uint8_t* d_byte = nullptr;      // [16] ring, mirrors pin->byte
   float* d_rows = nullptr;        // [8][2078]: the dry pass writes all 8 rows, row j is the valid one
   uint32_t* d_sel = nullptr;      // [8][47]
   float* d_ppmd = nullptr;        // [256]: PPMd's distribution while the current byte is coded
   float* d_lstm = nullptr;        // [256]: the LSTM byte mixer's
   float* d_lstm_next = nullptr;   // [256]
-  int* d_ex = nullptr;            // [8]
+  float* d_hint = nullptr;        // [8] f32 bit predictions + [8] i32 arg-max symbols
+  float* d_p = nullptr;
   float* d_scratch = nullptr;     // [8][2078] outputs of the committing pass (unused)
   uint32_t* d_scratch_sel = nullptr;
-  float h_row[CMX_N_INPUTS];
-  uint32_t h_sel[CMX_N_MIXERS];
-  float h_ppmd[256];
-  float staged[2022];
-  bool have_staged = false, predicted = false, started = false;
+  unsigned byte_slot = 0;
+  bool have_staged = false, predicted = false, started = false, hint_pending = false;
   int j = 0;                      // bits of the current byte already coded
+  int row_j = 0;                  // row of d_rows the last predict used
   unsigned partial = 0;           // those bits
   int lstmpr = 0, lstmex = 0;
   std::vector<uint8_t> pre;       // Pretrain bytes not yet trained
@@ -73,31 +89,47 @@ int flush_pretrain(cmx_engine* h) {
   uint8_t* d = nullptr;
   E_HIP(hipMalloc((void**)&d, h->pre.size()));
   bool ok = hipMemcpy(d, h->pre.data(), h->pre.size(), hipMemcpyHostToDevice) == hipSuccess;
-  ok = ok && cmx_ctxmodels_pretrain(h->ctx, d, h->pre.size(), nullptr) == 0;
-  ok = hipDeviceSynchronize() == hipSuccess && ok;
+  ok = ok && cmx_ctxmodels_pretrain(h->ctx, d, h->pre.size(), h->st) == 0;
+  ok = hipStreamSynchronize(h->st) == hipSuccess && ok;
   (void)hipFree(d);
   h->pre.clear();
   if (!ok) { cmx_set_err("cmx_pretrain: device error"); return 1; }
   return 0;
 }
 
+// A byte value on its way to the device: a ring of 16 page-locked slots, each mirrored by its own device byte. The
+// caller synchronises at least once per coded bit, far more often than the ring wraps.
+const uint8_t* send_byte(cmx_engine* h, uint8_t v) {
+  const unsigned s = h->byte_slot++ & 15;
+  h->pin->byte[s] = v;
+  if (hipMemcpyAsync(h->d_byte + s, &h->pin->byte[s], 1, hipMemcpyHostToDevice, h->st) != hipSuccess) return nullptr;
+  return h->d_byte + s;
+}
+
 // lstmpr / lstmex for the next bit: Discretize(byte_mixer->Predict()[0]) and byte_mixer->ex (predictor.cpp:180-182,
-// 462-465) = ByteModel::Predict of the LSTM's distribution over the bits coded so far in this byte.
-int refresh_lstm_hint(cmx_engine* h) {
+// 462-465) = ByteModel::Predict of the LSTM's distribution over the bits coded so far in this byte. Enqueued
+// here, collected by finish_hint() -- the host is free in between (the shim runs paq8's Perceive there).
+int enqueue_hint(cmx_engine* h) {
   const char* where = "cmx_perceive";
   const int fail = 1;
-  const uint8_t b = (uint8_t)(h->partial << (8 - h->j));
-  E_HIP(hipMemcpy(h->d_byte, &b, 1, hipMemcpyHostToDevice));
-  if (cmx_bytemodel_bits_run(h->device, h->d_lstm, h->d_lstm, h->d_byte, 1, h->d_rows + 2077, CMX_N_INPUTS, h->d_ex,
-                             nullptr)) return 1;
-  float p;
-  int ex;
-  E_HIP(hipMemcpy(&p, h->d_rows + (size_t)h->j * CMX_N_INPUTS + 2077, 4, hipMemcpyDeviceToHost));
-  E_HIP(hipMemcpy(&ex, h->d_ex + h->j, 4, hipMemcpyDeviceToHost));
-  volatile float prod = 4094.0f * p;
+  const uint8_t* db = send_byte(h, (uint8_t)(h->partial << (8 - h->j)));
+  if (!db) { cmx_set_err("cmx_perceive: upload failed"); return 1; }
+  if (cmx_bytemodel_bits_run(h->device, h->d_lstm, h->d_lstm, db, 1, h->d_hint, 1, (int*)(h->d_hint + 8), h->st)) return 1;
+  E_HIP(hipMemcpyAsync(h->pin->hint_p, h->d_hint, 16 * 4, hipMemcpyDeviceToHost, h->st));  // hint_p[8] + hint_ex[8]
+  h->hint_pending = true;
+  return 0;
+}
+
+int finish_hint(cmx_engine* h) {
+  const char* where = "cmx_get_lstm_hint";
+  const int fail = 1;
+  if (!h->hint_pending) return 0;
+  E_HIP(hipStreamSynchronize(h->st));
+  volatile float prod = 4094.0f * h->pin->hint_p[h->j];
   const float s = 1.0f + prod;
   h->lstmpr = (int)(unsigned)s;
-  h->lstmex = ex;
+  h->lstmex = h->pin->hint_ex[h->j];
+  h->hint_pending = false;
   return 0;
 }
 
@@ -110,8 +142,10 @@ void cmx_destroy(cmx_t* h) {
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
   for (void* p : {(void*)h->d_byte, (void*)h->d_rows, (void*)h->d_sel, (void*)h->d_ppmd, (void*)h->d_lstm,
-                  (void*)h->d_lstm_next, (void*)h->d_ex, (void*)h->d_scratch, (void*)h->d_scratch_sel})
+                  (void*)h->d_lstm_next, (void*)h->d_hint, (void*)h->d_p, (void*)h->d_scratch, (void*)h->d_scratch_sel})
     if (p) (void)hipFree(p);
+  if (h->pin) (void)hipHostFree(h->pin);
+  if (h->st) (void)hipStreamDestroy(h->st);
   cmx_mixnet_destroy(h->mix);
   cmx_lstm_destroy(h->lstm);
   cmx_ctxmodels_destroy(h->ctx);
@@ -121,8 +155,6 @@ void cmx_destroy(cmx_t* h) {
 
 cmx_t* cmx_create(const uint8_t vocab[256], const char* dict_path, int device) {
   (void)dict_path;  // read by fxcm only (fxcmv1.cpp:412-428), which still lives with the caller
-  const char* where = "cmx_create";
-  cmx_t* const fail = nullptr;
   if (!vocab) { cmx_set_err("cmx_create: null vocab"); return nullptr; }
   cmx_engine* h = new cmx_engine();
   h->device = device;
@@ -132,32 +164,36 @@ cmx_t* cmx_create(const uint8_t vocab[256], const char* dict_path, int device) {
   h->ppmd = h->mix ? cmx_ppmd_create(vocab) : nullptr;
   if (!h->ppmd) { cmx_destroy(h); return nullptr; }  // the failing stage has set the error
   bool ok = hipSetDevice(device) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&h->pin, sizeof(Pinned), hipHostMallocDefault) == hipSuccess;
   ok = ok && hipMalloc((void**)&h->d_byte, 16) == hipSuccess;
   ok = ok && hipMalloc((void**)&h->d_rows, 8 * CMX_N_INPUTS * 4) == hipSuccess;
   ok = ok && hipMalloc((void**)&h->d_sel, 8 * CMX_N_MIXERS * 4) == hipSuccess;
   ok = ok && hipMalloc((void**)&h->d_ppmd, 256 * 4) == hipSuccess;
   ok = ok && hipMalloc((void**)&h->d_lstm, 256 * 4) == hipSuccess;
   ok = ok && hipMalloc((void**)&h->d_lstm_next, 256 * 4) == hipSuccess;
-  ok = ok && hipMalloc((void**)&h->d_ex, 8 * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&h->d_hint, 16 * 4) == hipSuccess;
+  ok = ok && hipMalloc((void**)&h->d_p, 16) == hipSuccess;
   ok = ok && hipMalloc((void**)&h->d_scratch, 8 * CMX_N_INPUTS * 4) == hipSuccess;
   ok = ok && hipMalloc((void**)&h->d_scratch_sel, 8 * CMX_N_MIXERS * 4) == hipSuccess;
-  if (!ok) { cmx_set_err("cmx_create: buffer allocation failed"); cmx_destroy(h); return nullptr; }
+  if (!ok) { cmx_set_err("cmx_create: stream / buffer allocation failed"); cmx_destroy(h); return nullptr; }
+  memset(h->pin, 0, sizeof(Pinned));
   float u[256];
   for (int i = 0; i < 256; ++i) u[i] = (float)(1.0 / 256);  // ByteModel constructor (byte-model.cpp:5-6)
   if (hipMemcpy(h->d_ppmd, u, sizeof u, hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(h->d_lstm, u, sizeof u, hipMemcpyHostToDevice) != hipSuccess) {
+      hipMemcpy(h->d_lstm, u, sizeof u, hipMemcpyHostToDevice) != hipSuccess ||
+      hipDeviceSynchronize() != hipSuccess) {
     cmx_set_err("cmx_create: upload failed");
     cmx_destroy(h);
     return nullptr;
   }
-  (void)where; (void)fail;
   return h;
 }
 
 int cmx_set_model_outputs(cmx_t* h, const float* cols) {
   if (!h || !cols) { cmx_set_err("cmx_set_model_outputs: bad argument"); return 1; }
   if (h->predicted) { cmx_set_err("cmx_set_model_outputs: between predict() and perceive()"); return 1; }
-  memcpy(h->staged, cols, sizeof h->staged);
+  memcpy(h->pin->staged, cols, sizeof h->pin->staged);  // the previous bit's upload finished before its p came back
   h->have_staged = true;
   return 0;
 }
@@ -177,21 +213,22 @@ float cmx_predict(cmx_t* h) {
   if (flush_pretrain(h)) return fail;
   h->started = true;
   const int j = h->j;
-  const uint8_t b = (uint8_t)(h->partial << (8 - j));  // coded bits on top, zeros below
-  E_HIP(hipMemcpy(h->d_byte, &b, 1, hipMemcpyHostToDevice));
-  if (cmx_ctxmodels_peek(h->ctx, h->d_byte, h->d_rows, CMX_N_INPUTS, h->d_sel, nullptr)) return fail;
-  if (cmx_bytemodel_bits_run(h->device, h->d_ppmd, h->d_ppmd, h->d_byte, 1, h->d_rows + 2076, CMX_N_INPUTS, nullptr,
-                             nullptr)) return fail;
-  if (cmx_bytemodel_bits_run(h->device, h->d_lstm, h->d_lstm, h->d_byte, 1, h->d_rows + 2077, CMX_N_INPUTS, h->d_ex,
-                             nullptr)) return fail;
-  E_HIP(hipMemcpy(h->h_row, h->d_rows + (size_t)j * CMX_N_INPUTS, sizeof h->h_row, hipMemcpyDeviceToHost));
-  E_HIP(hipMemcpy(h->h_sel, h->d_sel + (size_t)j * CMX_N_MIXERS, sizeof h->h_sel, hipMemcpyDeviceToHost));
-  memcpy(h->h_row + 3, h->staged, sizeof h->staged);
-  const float p = cmx_mixnet_predict(h->mix, h->h_row, h->h_sel);
-  if (p < 0.0f) return fail;
+  float* const row = h->d_rows + (size_t)j * CMX_N_INPUTS;
+  const uint8_t* db = send_byte(h, (uint8_t)(h->partial << (8 - j)));  // coded bits on top, zeros below
+  if (!db) { cmx_set_err("cmx_predict: upload failed"); return fail; }
+  if (cmx_ctxmodels_peek(h->ctx, db, h->d_rows, CMX_N_INPUTS, h->d_sel, h->st)) return fail;
+  if (cmx_bytemodel_bits_run(h->device, h->d_ppmd, h->d_ppmd, db, 1, h->d_rows + 2076, CMX_N_INPUTS, nullptr, h->st))
+    return fail;
+  if (cmx_bytemodel_bits_run(h->device, h->d_lstm, h->d_lstm, db, 1, h->d_rows + 2077, CMX_N_INPUTS, nullptr, h->st))
+    return fail;
+  E_HIP(hipMemcpyAsync(row + 3, h->pin->staged, sizeof h->pin->staged, hipMemcpyHostToDevice, h->st));
+  if (cmx_mixnet_predict_async(h->mix, row, h->d_sel + (size_t)j * CMX_N_MIXERS, h->d_p, h->st)) return fail;
+  E_HIP(hipMemcpyAsync(&h->pin->p, h->d_p, 4, hipMemcpyDeviceToHost, h->st));
+  E_HIP(hipStreamSynchronize(h->st));
+  h->row_j = j;
   h->predicted = true;
   h->have_staged = false;
-  return p;
+  return h->pin->p;
 }
 
 int cmx_perceive(cmx_t* h, int bit) {
@@ -200,32 +237,39 @@ int cmx_perceive(cmx_t* h, int bit) {
   if (!h) { cmx_set_err("cmx_perceive: null handle"); return 1; }
   if (!h->predicted) { cmx_set_err("cmx_perceive: no pending predict()"); return 1; }
   E_HIP(hipSetDevice(h->device));
-  if (cmx_mixnet_perceive(h->mix, bit)) return 1;
+  if (cmx_mixnet_perceive_async(h->mix, bit, h->st)) return 1;
   h->predicted = false;
   h->partial = (h->partial << 1) | (bit ? 1u : 0u);
   if (++h->j == 8) {  // byte boundary (predictor.cpp:439-461)
     const uint8_t B = (uint8_t)h->partial;
-    E_HIP(hipMemcpy(h->d_byte, &B, 1, hipMemcpyHostToDevice));
-    if (cmx_ctxmodels_run(h->ctx, h->d_byte, 1, h->d_scratch, CMX_N_INPUTS, h->d_scratch_sel, nullptr)) return 1;
-    if (cmx_ppmd_run(h->ppmd, &B, 1, h->h_ppmd)) return 1;
-    E_HIP(hipMemcpy(h->d_ppmd, h->h_ppmd, sizeof h->h_ppmd, hipMemcpyHostToDevice));
-    if (cmx_lstm_run(h->lstm, h->d_ppmd, h->d_byte, 1, h->d_lstm_next, nullptr, 0, nullptr, nullptr)) return 1;
-    E_HIP(hipDeviceSynchronize());
+    const uint8_t* db = send_byte(h, B);
+    if (!db) { cmx_set_err("cmx_perceive: upload failed"); return 1; }
+    if (cmx_ctxmodels_run(h->ctx, db, 1, h->d_scratch, CMX_N_INPUTS, h->d_scratch_sel, h->st)) return 1;
+    if (cmx_ppmd_run(h->ppmd, &B, 1, h->pin->ppmd)) return 1;  // host stage, while the device commits the byte
+    E_HIP(hipMemcpyAsync(h->d_ppmd, h->pin->ppmd, sizeof h->pin->ppmd, hipMemcpyHostToDevice, h->st));
+    if (cmx_lstm_run(h->lstm, h->d_ppmd, db, 1, h->d_lstm_next, nullptr, 0, nullptr, h->st)) return 1;
     float* t = h->d_lstm; h->d_lstm = h->d_lstm_next; h->d_lstm_next = t;
     h->j = 0;
     h->partial = 0;
   }
-  return refresh_lstm_hint(h);
+  return enqueue_hint(h);  // nothing waits here: cmx_get_lstm_hint() / the next cmx_predict() synchronise
 }
 
 int cmx_get_lstm_hint(cmx_t* h, int* lstmpr, int* lstmex) {
   if (!h || !lstmpr || !lstmex) { cmx_set_err("cmx_get_lstm_hint: bad argument"); return 1; }
+  if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
+  if (finish_hint(h)) return 1;
   *lstmpr = h->lstmpr;
   *lstmex = h->lstmex;
   return 0;
 }
 
-const float* cmx_debug_last_row(const cmx_t* h) { return h ? h->h_row : nullptr; }
+const float* cmx_debug_last_row(cmx_t* h) {
+  if (!h || hipSetDevice(h->device) != hipSuccess) return nullptr;
+  if (hipMemcpyAsync(h->pin->row, h->d_rows + (size_t)h->row_j * CMX_N_INPUTS, sizeof h->pin->row, hipMemcpyDeviceToHost,
+                     h->st) != hipSuccess || hipStreamSynchronize(h->st) != hipSuccess) return nullptr;
+  return h->pin->row;
+}
 
 int cmx_pretrain(cmx_t* h, int bit) {
   if (!h) { cmx_set_err("cmx_pretrain: null handle"); return 1; }

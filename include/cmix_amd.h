@@ -66,10 +66,11 @@ int cmx_pretrain(cmx_t*, int bit);     /* Predictor::Pretrain, predictor.cpp:471
  * fails loudly when they are missing: nothing is computed on the CPU in their place. */
 int cmx_set_model_outputs(cmx_t*, const float cols_3_to_2024[2022]);
 /* The hidden globals `lstmpr`, `lstmex` (predictor.cpp:359,462-465) as they stand after the last cmx_perceive():
- * what the caller's fxcm reads in its own Perceive. */
+ * what the caller's fxcm reads in its own Perceive. cmx_perceive() only enqueues the device work; this call (or the
+ * next cmx_predict()) waits for it, so host work placed between the two overlaps the device. */
 int cmx_get_lstm_hint(cmx_t*, int* lstmpr, int* lstmex);
 /* Introspection used by the parity tests: the 2078 layer-0 inputs of the last cmx_predict() (valid until the next). */
-const float* cmx_debug_last_row(const cmx_t*);
+const float* cmx_debug_last_row(cmx_t*);
 /* Optional look-ahead for compression. On the per-bit surface it is refused: look-ahead coding is
  * cmx_pipeline_* below. */
 int cmx_stage_input(cmx_t*, const uint8_t* bytes, size_t n);
@@ -105,6 +106,12 @@ int cmx_mixnet_run(cmx_mixnet_t*, const float* d_probs, const uint32_t* d_sel,
  * only by perceive() (same protocol as the reference). */
 float cmx_mixnet_predict(cmx_mixnet_t*, const float* probs2078, const uint32_t* sel47);
 int cmx_mixnet_perceive(cmx_mixnet_t*, int bit);
+
+/* Bit-synchronous mode with DEVICE operands, asynchronous on `stream`: the same kernel and protocol without the
+ * host round trips. The operands must stay untouched until the matching perceive has run; *d_p receives the
+ * probability. */
+int cmx_mixnet_predict_async(cmx_mixnet_t*, const float* d_probs2078, const uint32_t* d_sel47, float* d_p, void* stream);
+int cmx_mixnet_perceive_async(cmx_mixnet_t*, int bit, void* stream);
 
 /* Waits for all work of this handle and reports device-side failures (a bounded
  * in-kernel wait that timed out). */

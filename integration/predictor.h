@@ -50,9 +50,9 @@ class Predictor {
   }
 
   void Perceive(int bit) {  // predictor.cpp:421-469
-    paq8_->Perceive(bit);   // every model but fxcm first (:422-425)
-    if (cmx_perceive(h_, bit)) Die();
-    if (cmx_get_lstm_hint(h_, &lstmpr, &lstmex)) Die();  // :462-465
+    if (cmx_perceive(h_, bit)) Die();  // enqueues the device side of :422-461 and returns
+    paq8_->Perceive(bit);              // host model, overlapped with it (the models are independent of each other)
+    if (cmx_get_lstm_hint(h_, &lstmpr, &lstmex)) Die();  // :462-465 -- waits for the device
     fxcm_->Perceive(bit);   // fxcm last (:466)
   }
 
