@@ -18,7 +18,8 @@
 #include "ctxmodels_state.h"
 
 extern "C" __global__ void cmx_ctxmodels_kernel(const CtxDev, const uint8_t*, size_t, float*, size_t, uint32_t*, float*, int);
-extern "C" __global__ void cmx_bytemodel_bits(const float*, const float*, const uint8_t*, size_t, float*, int*, size_t);
+extern "C" __global__ void cmx_bytemodel_bits(const float*, const float*, const uint8_t*, size_t, float*, int*, size_t, int,
+                                              float*);
 extern "C" unsigned cmx_ctxmodels_lds_bytes();
 
 void cmx_set_err(const std::string& s);  // cmx_api.hip
@@ -283,7 +284,7 @@ cmx_ctxmodels_t* cmx_ctxmodels_create(const uint8_t vocab[256], int device) {
 }
 
 static int ctxmodels_launch(cmx_ctxmodels_t* h, const uint8_t* d_bytes, size_t nbytes, float* d_probs, size_t pstride,
-                            uint32_t* d_sel, void* stream, int dry = 0);
+                            uint32_t* d_sel, void* stream, int dry = 0, int only_k = -1);
 
 int cmx_ctxmodels_run(cmx_ctxmodels_t* h, const uint8_t* d_bytes, size_t nbytes, float* d_probs, size_t pstride,
                       uint32_t* d_sel, void* stream) {
@@ -306,15 +307,18 @@ int cmx_ctxmodels_pretrain(cmx_ctxmodels_t* h, const uint8_t* d_bytes, size_t nb
 // Bit-synchronous mode (what a decoder needs): the 8 rows the stage would write if the next byte were *d_byte,
 // leaving every piece of state untouched. Row j only depends on the top j bits of *d_byte, so with j bits coded
 // (and anything below) row j is what Predict() sees for the next bit (predictor.cpp:362-369).
-int cmx_ctxmodels_peek(cmx_ctxmodels_t* h, const uint8_t* d_byte, float* d_probs, size_t pstride, uint32_t* d_sel,
-                       void* stream) {
+int cmx_ctxmodels_peek(cmx_ctxmodels_t* h, const uint8_t* d_byte, int bit_index, float* d_probs, size_t pstride,
+                       uint32_t* d_sel, void* stream) {
   if (!h) { cmx_set_err("cmx_ctxmodels_peek: null handle"); return 1; }
-  if (!d_byte || !d_probs || !d_sel || pstride < CMX_N_INPUTS) { cmx_set_err("cmx_ctxmodels_peek: bad argument"); return 1; }
-  return ctxmodels_launch(h, d_byte, 1, d_probs, pstride, d_sel, stream, 1);
+  if (!d_byte || !d_probs || !d_sel || pstride < CMX_N_INPUTS || bit_index < -1 || bit_index > 7) {
+    cmx_set_err("cmx_ctxmodels_peek: bad argument");
+    return 1;
+  }
+  return ctxmodels_launch(h, d_byte, 1, d_probs, pstride, d_sel, stream, 1, bit_index);
 }
 
 static int ctxmodels_launch(cmx_ctxmodels_t* h, const uint8_t* d_bytes, size_t nbytes, float* d_probs, size_t pstride,
-                            uint32_t* d_sel, void* stream, int dry) {
+                            uint32_t* d_sel, void* stream, int dry, int only_k) {
   if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
   hipStream_t st = (hipStream_t)stream;
   if (h->dist_cap < nbytes) {
@@ -323,15 +327,18 @@ static int ctxmodels_launch(cmx_ctxmodels_t* h, const uint8_t* d_bytes, size_t n
     if (hipMalloc((void**)&h->d_bracket_dist, cap * 256 * 4) != hipSuccess) { cmx_set_err("cmx_ctxmodels_run: hipMalloc failed"); return 1; }
     h->dist_cap = cap;
   }
-  // the Bracket model's distribution going into the first byte of this chunk
-  (void)hipMemcpyAsync(h->d_prev_dist, (const char*)h->dev.persist + offsetof(CtxPersist, br_probs), 256 * 4,
-                       hipMemcpyDeviceToDevice, st);
+  // the Bracket model's distribution going into the first byte of this chunk (a dry pass leaves it where it is)
+  const float* prev_dist = (const float*)((const char*)h->dev.persist + offsetof(CtxPersist, br_probs));
+  if (!dry) {
+    (void)hipMemcpyAsync(h->d_prev_dist, prev_dist, 256 * 4, hipMemcpyDeviceToDevice, st);
+    prev_dist = h->d_prev_dist;
+  }
   hipLaunchKernelGGL(cmx_ctxmodels_kernel, dim3(1), dim3(64), cmx_ctxmodels_lds_bytes(), st, h->dev, d_bytes, nbytes,
                      d_probs, pstride, d_sel, h->d_bracket_dist, dry);
   // column 0: ByteModel::Predict of the Bracket model along the known bytes (byte-model.cpp:8-37)
   if (d_probs)
-    hipLaunchKernelGGL(cmx_bytemodel_bits, dim3((unsigned)nbytes), dim3(64), 0, st, h->d_prev_dist, h->d_bracket_dist,
-                       d_bytes, nbytes, d_probs, (int*)nullptr, pstride);
+    hipLaunchKernelGGL(cmx_bytemodel_bits, dim3((unsigned)nbytes), dim3(64), 0, st, prev_dist, h->d_bracket_dist,
+                       d_bytes, nbytes, d_probs, (int*)nullptr, pstride, only_k, (float*)nullptr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { cmx_set_err(std::string("cmx_ctxmodels_run: ") + hipGetErrorString(e)); return 1; }
   return 0;

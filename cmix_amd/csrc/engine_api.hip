@@ -114,7 +114,9 @@ int enqueue_hint(cmx_engine* h) {
   const int fail = 1;
   const uint8_t* db = send_byte(h, (uint8_t)(h->partial << (8 - h->j)));
   if (!db) { cmx_set_err("cmx_perceive: upload failed"); return 1; }
-  if (cmx_bytemodel_bits_run(h->device, h->d_lstm, h->d_lstm, db, 1, h->d_hint, 1, (int*)(h->d_hint + 8), h->st)) return 1;
+  // the value is also the LSTM column (2077) of the row the next Predict() assembles
+  if (cmx_bytemodel_bit_run(h->device, h->d_lstm, db, h->j, h->d_hint, 1, (int*)(h->d_hint + 8),
+                            h->d_rows + (size_t)h->j * CMX_N_INPUTS + 2077, h->st)) return 1;
   E_HIP(hipMemcpyAsync(h->pin->hint_p, h->d_hint, 16 * 4, hipMemcpyDeviceToHost, h->st));  // hint_p[8] + hint_ex[8]
   h->hint_pending = true;
   return 0;
@@ -187,6 +189,7 @@ cmx_t* cmx_create(const uint8_t vocab[256], const char* dict_path, int device) {
     cmx_destroy(h);
     return nullptr;
   }
+  if (enqueue_hint(h) || finish_hint(h)) { cmx_destroy(h); return nullptr; }  // lstmpr/lstmex + column 2077 of bit 0
   return h;
 }
 
@@ -216,11 +219,10 @@ float cmx_predict(cmx_t* h) {
   float* const row = h->d_rows + (size_t)j * CMX_N_INPUTS;
   const uint8_t* db = send_byte(h, (uint8_t)(h->partial << (8 - j)));  // coded bits on top, zeros below
   if (!db) { cmx_set_err("cmx_predict: upload failed"); return fail; }
-  if (cmx_ctxmodels_peek(h->ctx, db, h->d_rows, CMX_N_INPUTS, h->d_sel, h->st)) return fail;
-  if (cmx_bytemodel_bits_run(h->device, h->d_ppmd, h->d_ppmd, db, 1, h->d_rows + 2076, CMX_N_INPUTS, nullptr, h->st))
+  if (cmx_ctxmodels_peek(h->ctx, db, j, h->d_rows, CMX_N_INPUTS, h->d_sel, h->st)) return fail;
+  if (cmx_bytemodel_bit_run(h->device, h->d_ppmd, db, j, h->d_rows + 2076, CMX_N_INPUTS, nullptr, nullptr, h->st))
     return fail;
-  if (cmx_bytemodel_bits_run(h->device, h->d_lstm, h->d_lstm, db, 1, h->d_rows + 2077, CMX_N_INPUTS, nullptr, h->st))
-    return fail;
+  // column 2077 of this row was written when the LSTM hint of this bit position was formed (enqueue_hint)
   E_HIP(hipMemcpyAsync(row + 3, h->pin->staged, sizeof h->pin->staged, hipMemcpyHostToDevice, h->st));
   if (cmx_mixnet_predict_async(h->mix, row, h->d_sel + (size_t)j * CMX_N_MIXERS, h->d_p, h->st)) return fail;
   E_HIP(hipMemcpyAsync(&h->pin->p, h->d_p, 4, hipMemcpyDeviceToHost, h->st));

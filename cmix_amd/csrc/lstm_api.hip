@@ -26,7 +26,8 @@ extern "C" __global__ void cmx_lstm_fwd(const LstmState, const uint8_t*, size_t,
 extern "C" __global__ void cmx_lstm_bptt_seq(const LstmState);
 extern "C" __global__ void cmx_lstm_bptt_acc(const LstmState, int, int);
 extern "C" __global__ void cmx_lstm_bptt_gb(const LstmState, int, int);
-extern "C" __global__ void cmx_bytemodel_bits(const float*, const float*, const uint8_t*, size_t, float*, int*, size_t);
+extern "C" __global__ void cmx_bytemodel_bits(const float*, const float*, const uint8_t*, size_t, float*, int*, size_t, int,
+                                              float*);
 
 void cmx_set_err(const std::string& s);  // cmx_api.hip
 
@@ -259,7 +260,7 @@ int cmx_lstm_run(cmx_lstm_t* h, const float* d_in_probs, const uint8_t* d_bytes,
   if (d_bit_p) {
     if (!d_out_probs) { cmx_set_err("cmx_lstm_run: bit predictions need d_out_probs"); return 1; }
     hipLaunchKernelGGL(cmx_bytemodel_bits, dim3((unsigned)nbytes), dim3(64), 0, st, h->d_prev_probs, d_out_probs,
-                       d_bytes, nbytes, d_bit_p, d_bit_ex, bit_p_stride ? bit_p_stride : (size_t)1);
+                       d_bytes, nbytes, d_bit_p, d_bit_ex, bit_p_stride ? bit_p_stride : (size_t)1, -1, (float*)nullptr);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { cmx_set_err(std::string("cmx_lstm_run: ") + hipGetErrorString(e)); return 1; }
@@ -271,9 +272,23 @@ int cmx_bytemodel_bits_run(int device, const float* d_dist0, const float* d_dist
   if (nbytes == 0) return 0;
   if (hipSetDevice(device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
   hipLaunchKernelGGL(cmx_bytemodel_bits, dim3((unsigned)nbytes), dim3(64), 0, (hipStream_t)stream, d_dist0,
-                     d_dist_rest, d_bytes, nbytes, d_bit_p, d_bit_ex, bit_p_stride ? bit_p_stride : (size_t)1);
+                     d_dist_rest, d_bytes, nbytes, d_bit_p, d_bit_ex, bit_p_stride ? bit_p_stride : (size_t)1, -1,
+                     (float*)nullptr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { cmx_set_err(std::string("cmx_bytemodel_bits_run: ") + hipGetErrorString(e)); return 1; }
+  return 0;
+}
+
+// Bit-synchronous mode: ByteModel::Predict for bit `k` (0..7) of the byte whose top k bits are the coded ones:
+// d_bit_p[k * stride] (and *d_p_copy, may be NULL) <- the value, d_bit_ex[k] <- `ex` when given.
+int cmx_bytemodel_bit_run(int device, const float* d_dist, const uint8_t* d_byte, int k, float* d_bit_p,
+                          size_t bit_p_stride, int* d_bit_ex, float* d_p_copy, void* stream) {
+  if (!d_dist || !d_byte || !d_bit_p || k < 0 || k > 7) { cmx_set_err("cmx_bytemodel_bit_run: bad argument"); return 1; }
+  if (hipSetDevice(device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
+  hipLaunchKernelGGL(cmx_bytemodel_bits, dim3(1), dim3(64), 0, (hipStream_t)stream, d_dist, d_dist, d_byte, (size_t)1,
+                     d_bit_p, d_bit_ex, bit_p_stride ? bit_p_stride : (size_t)1, k, d_p_copy);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { cmx_set_err(std::string("cmx_bytemodel_bit_run: ") + hipGetErrorString(e)); return 1; }
   return 0;
 }
 

@@ -445,7 +445,11 @@ extern "C" __global__ void cmx_lstm_bptt_gb(const LstmState P, int update_steps,
 //      One block per byte: dist(n) is the distribution the byte model held while byte n was coded.
 //      Outputs p[n][8] (Model::Predict value per bit) and ex[n][8] (arg-max symbol, `ex`).
 extern "C" __global__ void cmx_bytemodel_bits(const float* dist0, const float* dist_rest, const uint8_t* bytes,
-                                              size_t nbytes, float* p_out, int* ex_out, size_t pstride) {
+                                              size_t nbytes, float* p_out, int* ex_out, size_t pstride, int only_k,
+                                              float* p_out2) {
+  // only_k >= 0 (bit-synchronous mode): just bit only_k of the byte -- the interval after only_k halvings needs no
+  // sums -- and p_out2 (may be NULL) receives a second copy of that one value. The arg-max scan runs only when
+  // ex_out is given.
   __shared__ float pr[256];
   const size_t n = blockIdx.x;
   const float* d = n == 0 ? dist0 : dist_rest + (n - 1) * 256;
@@ -456,16 +460,23 @@ extern "C" __global__ void cmx_bytemodel_bits(const float* dist0, const float* d
   const int byte = bytes[n];
   for (int k = 0; k < 8; ++k) {
     int mid = bot + ((top - bot) / 2);
-    float num = 0.0f;
-    for (int i = mid + 1; i <= top; ++i) num = fadd(num, pr[i]);
-    float denom = num;
-    for (int i = bot; i <= mid; ++i) denom = fadd(denom, pr[i]);
-    int ex = bot;
-    float mx = pr[bot];
-    for (int i = bot + 1; i <= top; ++i)
-      if (pr[i] > mx) { mx = pr[i]; ex = i; }
-    p_out[(n * 8 + k) * pstride] = denom == 0.0f ? 0.5f : fdiv(num, denom);  // pstride 1, or a layer-0 row stride
-    if (ex_out) ex_out[n * 8 + k] = ex;
+    if (only_k < 0 || k == only_k) {
+      float num = 0.0f;
+      for (int i = mid + 1; i <= top; ++i) num = fadd(num, pr[i]);
+      float denom = num;
+      for (int i = bot; i <= mid; ++i) denom = fadd(denom, pr[i]);
+      const float p = denom == 0.0f ? 0.5f : fdiv(num, denom);
+      p_out[(n * 8 + k) * pstride] = p;  // pstride 1, or a layer-0 row stride
+      if (p_out2) *p_out2 = p;
+      if (ex_out) {
+        int ex = bot;
+        float mx = pr[bot];
+        for (int i = bot + 1; i <= top; ++i)
+          if (pr[i] > mx) { mx = pr[i]; ex = i; }
+        ex_out[n * 8 + k] = ex;
+      }
+      if (k == only_k) return;
+    }
     if ((byte >> (7 - k)) & 1) bot = mid + 1;
     else top = mid;
   }

@@ -96,7 +96,7 @@ def lib():
         L.cmx_debug_last_row.restype = C.c_void_p
         L.cmx_debug_last_row.argtypes = [C.c_void_p]
         L.cmx_ctxmodels_debug_slow_bytes.argtypes = [C.c_void_p, C.c_void_p]
-        L.cmx_ctxmodels_peek.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.cmx_ctxmodels_peek.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.cmx_encoder_create.restype = C.c_void_p
         L.cmx_encoder_destroy.argtypes = [C.c_void_p]
         L.cmx_encoder_encode_bits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
@@ -333,7 +333,7 @@ class CtxModels:
         assert byte.is_cuda and byte.dtype == torch.uint8 and probs8.shape == (8, N_INPUTS) and sel8.numel() == 8 * N_MIXERS
         if stream is None:
             stream = torch.cuda.current_stream(byte.device).cuda_stream
-        if lib().cmx_ctxmodels_peek(self.h, byte.data_ptr(), probs8.data_ptr(), N_INPUTS, sel8.data_ptr(),
+        if lib().cmx_ctxmodels_peek(self.h, byte.data_ptr(), -1, probs8.data_ptr(), N_INPUTS, sel8.data_ptr(),
                                     C.c_void_p(stream)):
             raise CmxError(last_error())
 

@@ -157,6 +157,10 @@ int cmx_lstm_run(cmx_lstm_t*, const float* d_in_probs, const uint8_t* d_bytes, s
 int cmx_bytemodel_bits_run(int device, const float* d_dist0, const float* d_dist_rest,
                            const uint8_t* d_bytes, size_t nbytes, float* d_bit_p, size_t bit_p_stride,
                            int* d_bit_ex, void* stream);
+/* Bit-synchronous mode: ByteModel::Predict for bit k (0..7) of the byte whose top k bits (in *d_byte) are the coded
+ * ones: d_bit_p[k * stride] and *d_p_copy (may be NULL) receive the value, d_bit_ex[k] (may be NULL) `ex`. */
+int cmx_bytemodel_bit_run(int device, const float* d_dist, const uint8_t* d_byte, int k, float* d_bit_p,
+                          size_t bit_p_stride, int* d_bit_ex, float* d_p_copy, void* stream);
 /* Test hooks. */
 int cmx_lstm_get_gate_weights(cmx_lstm_t*, int layer, int gate, float* out_host);
 int cmx_lstm_gate_rowlen(const cmx_lstm_t*, int layer);
@@ -187,8 +191,8 @@ int cmx_ctxmodels_run(cmx_ctxmodels_t*, const uint8_t* d_bytes, size_t nbytes, f
 /* Bit-synchronous mode: the 8 rows (outputs + selectors) the stage would produce if the next byte were *d_byte,
  * without changing any state. Row j depends only on the top j bits of *d_byte: with j bits of the byte coded, row j
  * is what Predict() uses for the next bit. */
-int cmx_ctxmodels_peek(cmx_ctxmodels_t*, const uint8_t* d_byte, float* d_probs8, size_t probs_stride, uint32_t* d_sel8,
-                       void* stream);
+int cmx_ctxmodels_peek(cmx_ctxmodels_t*, const uint8_t* d_byte, int bit_index /* 0..7: the row needed; -1: all */,
+                       float* d_probs8, size_t probs_stride, uint32_t* d_sel8, void* stream);
 int cmx_ctxmodels_pretrain(cmx_ctxmodels_t*, const uint8_t* d_bytes, size_t nbytes, void* stream);
 /* Test introspection: bytes that went through the serial path taken when two Indirect models' 256-byte windows of
  * the shared map overlap (indirect.cpp:16-31) -- [0] committed, [1] in dry (peek) passes. Synchronises. */
