@@ -118,6 +118,7 @@ struct cmx_mixnet {
   unsigned sync_slot = 0;
   int profile = 0;
   int dbg = 0;          // CMX_MIXNET_DBG: timing experiments (results invalid when nonzero)
+  int xcd = -1;         // CMX_MIXNET_XCD=k: place the persistent kernel on XCD k (speed only; -1 = wherever block 0 lands)
   bool use_v1 = false;  // CMX_MIXNET_V1=1: run chunks through the bit-synchronous kernel
 };
 
@@ -234,6 +235,7 @@ cmx_mixnet_t* cmx_mixnet_create(int device) {
   }
   { const char* v = getenv("CMX_MIXNET_V1"); h->use_v1 = v && v[0] == '1'; }
   { const char* v = getenv("CMX_MIXNET_DBG"); h->dbg = v ? atoi(v) : 0; }
+  { const char* v = getenv("CMX_MIXNET_XCD"); h->xcd = v ? atoi(v) : -1; }
   hipEventCreate(&h->ev0);
   hipEventCreate(&h->ev1);
   for (int i = 0; i < 4; ++i) hipEventCreateWithFlags(&h->ev_decay[i], hipEventDisableTiming);
@@ -293,9 +295,10 @@ int cmx_mixnet_run(cmx_mixnet_t* h, const float* d_probs, const uint32_t* d_sel,
                        d_probs, d_sel, d_bits, h->d_decay, (int)nbits, d_p_out, d_mix_out,
                        3 | (h->profile ? 4 : 0));
   else
-    hipLaunchKernelGGL(cmx_mixnet_chunk_kernel, dim3(1), dim3(CMX_CHUNK_THREADS), CMX_CHUNK_LDS_BYTES, st,
+    // XCD placement (observed: block b runs on XCD b % 8): 8 blocks, all but block `xcd` leave at once
+    hipLaunchKernelGGL(cmx_mixnet_chunk_kernel, dim3(h->xcd >= 0 ? 8 : 1), dim3(CMX_CHUNK_THREADS), CMX_CHUNK_LDS_BYTES, st,
                        h->d_state, d_probs, d_sel, d_bits, h->d_decay, (int)nbits, d_p_out, d_mix_out,
-                       3 | (h->profile ? 4 : 0) | (h->dbg << 4));
+                       3 | (h->profile ? 4 : 0) | ((h->dbg & 15) << 4) | (h->xcd >= 0 ? ((h->xcd & 7) + 1) << 8 : 0));
   HIP_OK(hipGetLastError());
   HIP_OK(hipEventRecord(h->ev1, st));
   h->timed = true;

@@ -17,7 +17,8 @@
 #include "cmx_glibc_rand.h"
 #include "ctxmodels_state.h"
 
-extern "C" __global__ void cmx_ctxmodels_kernel(const CtxDev, const uint8_t*, size_t, float*, size_t, uint32_t*, float*, int);
+extern "C" __global__ void cmx_ctxmodels_kernel(const CtxDev, const uint8_t*, size_t, float*, size_t, uint32_t*, float*);
+extern "C" __global__ void cmx_ctxmodels_peek_kernel(const CtxDev, const uint8_t*, float*, size_t, uint32_t*);
 extern "C" __global__ void cmx_bytemodel_bits(const float*, const float*, const uint8_t*, size_t, float*, int*, size_t, int,
                                               float*);
 extern "C" unsigned cmx_ctxmodels_lds_bytes();
@@ -275,6 +276,8 @@ cmx_ctxmodels_t* cmx_ctxmodels_create(const uint8_t vocab[256], int device) {
   }
   (void)hipFuncSetAttribute((const void*)cmx_ctxmodels_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)cmx_ctxmodels_lds_bytes());
+  (void)hipFuncSetAttribute((const void*)cmx_ctxmodels_peek_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)cmx_ctxmodels_lds_bytes());
   if (hipDeviceSynchronize() != hipSuccess) {
     cmx_set_err("cmx_ctxmodels_create: init failed");
     cmx_ctxmodels_destroy(h);
@@ -333,8 +336,12 @@ static int ctxmodels_launch(cmx_ctxmodels_t* h, const uint8_t* d_bytes, size_t n
     (void)hipMemcpyAsync(h->d_prev_dist, prev_dist, 256 * 4, hipMemcpyDeviceToDevice, st);
     prev_dist = h->d_prev_dist;
   }
-  hipLaunchKernelGGL(cmx_ctxmodels_kernel, dim3(1), dim3(64), cmx_ctxmodels_lds_bytes(), st, h->dev, d_bytes, nbytes,
-                     d_probs, pstride, d_sel, h->d_bracket_dist, dry);
+  if (dry)
+    hipLaunchKernelGGL(cmx_ctxmodels_peek_kernel, dim3(1), dim3(64), cmx_ctxmodels_lds_bytes(), st, h->dev, d_bytes,
+                       d_probs, pstride, d_sel);
+  else
+    hipLaunchKernelGGL(cmx_ctxmodels_kernel, dim3(1), dim3(64), cmx_ctxmodels_lds_bytes(), st, h->dev, d_bytes, nbytes,
+                       d_probs, pstride, d_sel, h->d_bracket_dist);
   // column 0: ByteModel::Predict of the Bracket model along the known bytes (byte-model.cpp:8-37)
   if (d_probs)
     hipLaunchKernelGGL(cmx_bytemodel_bits, dim3((unsigned)nbytes), dim3(64), 0, st, prev_dist, h->d_bracket_dist,

@@ -72,9 +72,10 @@ struct LdsMap {  // carve of the dynamic LDS region (byte offsets, all multiples
 
 extern "C" unsigned cmx_ctxmodels_lds_bytes() { return LdsMap::total; }
 
-extern "C" __global__ void __launch_bounds__(64)
-cmx_ctxmodels_kernel(const CtxDev D, const uint8_t* __restrict__ bytes, size_t nbytes, float* probs, size_t pstride,
-                     uint32_t* sel, float* bracket_dist, int dry) {
+namespace {
+template <bool dry>
+__device__ __forceinline__ void ctxmodels_body(const CtxDev& D, const uint8_t* __restrict__ bytes, size_t nbytes,
+                                               float* probs, size_t pstride, uint32_t* sel, float* bracket_dist) {
   // dry != 0 (bit-synchronous mode, one byte): the 8 Predict/Perceive steps run on a byte whose low bits are
   // still unknown (zeros); outputs and selectors of bit j depend only on bits < j, so row j is exact once j bits
   // are known. Nothing of the pass survives: HBM writes are suppressed (or rolled back, overlapping Indirect
@@ -516,4 +517,19 @@ cmx_ctxmodels_kernel(const CtxDev D, const uint8_t* __restrict__ bytes, size_t n
     P->bc_n = bc_n; P->bc_top_active = bc_top_active; P->bc_top_dist = bc_top_dist;
     P->br_n = br_n;
   }
+}
+}  // namespace
+
+// chunk mode (and Pretrain): committing passes over known bytes
+extern "C" __global__ void __launch_bounds__(64)
+cmx_ctxmodels_kernel(const CtxDev D, const uint8_t* __restrict__ bytes, size_t nbytes, float* probs, size_t pstride,
+                     uint32_t* sel, float* bracket_dist) {
+  ctxmodels_body<false>(D, bytes, nbytes, probs, pstride, sel, bracket_dist);
+}
+
+// bit-synchronous mode: one dry pass over a partially known byte (see the comment at the top of the body)
+extern "C" __global__ void __launch_bounds__(64)
+cmx_ctxmodels_peek_kernel(const CtxDev D, const uint8_t* __restrict__ bytes, float* probs, size_t pstride,
+                          uint32_t* sel) {
+  ctxmodels_body<true>(D, bytes, 1, probs, pstride, sel, nullptr);
 }

@@ -53,13 +53,13 @@ static void lstm_launch_byte(cmx_lstm_t* h, hipStream_t st, const float* d_in_pr
   const int V = S.V;
   if (e == 0) {                                  // lstm.cpp:93
     hipLaunchKernelGGL(cmx_lstm_prep, dim3(1), dim3(256), 0, st, S, d_in_probs ? d_in_probs + n * 256 : nullptr, d_bytes, n, e, k);
-    hipLaunchKernelGGL(cmx_lstm_bptt_seq, dim3(1), dim3(1024), 0, st, S);
+    hipLaunchKernelGGL(cmx_lstm_bptt_seq, dim3(S.xcd >= 0 ? 8 : 1), dim3(1024), 0, st, S);
     hipLaunchKernelGGL(cmx_lstm_bptt_acc, dim3((S.rowlen[1] + 63) / 64, LSTM_C / 4, 6), dim3(64, 4), 0, st, S, us, k);
     hipLaunchKernelGGL(cmx_lstm_bptt_gb, dim3(6), dim3(256), 0, st, S, us, k);
   }
   hipLaunchKernelGGL(cmx_lstm_sgd, dim3((V * LSTM_NH + 255) / 256 + 1), dim3(256), 0, st, S,
                      (e == 0 || !d_in_probs) ? (const float*)nullptr : d_in_probs + n * 256, d_bytes, n, e, hc, k);
-  hipLaunchKernelGGL(cmx_lstm_fwd, dim3(1), dim3(640), 0, st, S, d_bytes, n, e, hc,
+  hipLaunchKernelGGL(cmx_lstm_fwd, dim3(S.xcd >= 0 ? 8 : 1), dim3(640), 0, st, S, d_bytes, n, e, hc,
                      d_out_probs ? d_out_probs + n * 256 : nullptr, k);
 }
 
@@ -122,6 +122,7 @@ cmx_lstm_t* cmx_lstm_create(const uint8_t vocab[256], int skip_rand, int device)
   S.rowlen[0] = S.insz[0] + V;
   S.rowlen[1] = S.insz[1] + V;
   S.lr = 0.03f;
+  { const char* v = getenv("CMX_LSTM_XCD"); S.xcd = v ? atoi(v) : -1; }
   bool fail = false;
   auto dallocf = [&](size_t count, const float* init) -> float* {
     void* p = nullptr;

@@ -99,6 +99,7 @@ extern "C" __global__ void cmx_lstm_sgd(const LstmState P, const float* in256, c
 //      a contiguous 256-byte run, so the CU streams the layer's weights from L2 at its L1 fill rate.
 extern "C" __global__ __launch_bounds__(640) void cmx_lstm_fwd(const LstmState P, const uint8_t* bytes, size_t n, int e,
                                                                int hid_cur, float* out_probs256, int k) {
+  if (P.xcd >= 0 && (int)blockIdx.x != (P.xcd & 7)) return;
   const LstmState* S = &P;
   if (k >= 0) {
     const LstmBlockArgs a = *P.blk;
@@ -257,6 +258,7 @@ extern "C" __global__ __launch_bounds__(640) void cmx_lstm_fwd(const LstmState P
 // ---- BPTT, sequential part (lstm.cpp:93-110; lstm-layer.cpp:108-183): one block of 1024 walks
 //      epoch 99..0 x layer 1..0, leaving the final gate errors E[l][g][epoch][.] for the sweep.
 extern "C" __global__ __launch_bounds__(1024) void cmx_lstm_bptt_seq(const LstmState P) {
+  if (P.xcd >= 0 && (int)blockIdx.x != (P.xcd & 7)) return;
   const LstmState* S = &P;
   __shared__ float errv[VP];        // softmax-CE error of the epoch
   __shared__ float herr[C];         // Lstm::hidden_error_

@@ -35,6 +35,7 @@ struct LstmState {
   int byte_map[256];             // byte value -> vocabulary index (byte-mixer.cpp:9-12)
   unsigned char vocab[256];
   float lr;                      // 0.03
+  int xcd;                       // >= 0: the single-workgroup kernels run as block `xcd` of 8 (XCD placement, speed only)
 
   // gate parameters, g = 0 forget, 1 input node, 2 output gate
   float* W[LSTM_L][3];           // [C][rowlen]   reference layout (coalesced for the BPTT matvecs)

@@ -924,6 +924,11 @@ extern "C" __global__ __launch_bounds__(NTHREADS) void cmx_mixnet_chunk_kernel(
     const uint8_t* __restrict__ bits, const float* __restrict__ decay1, int nbits,
     float* __restrict__ p_out, float* __restrict__ mix_out, int mode) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  {  // optional XCD placement: mode bits 8..11 = 1 + the block that does the work (the others only occupy a slot)
+    const int want = (mode >> 8) & 15;
+    if (want && (int)blockIdx.x != want - 1) return;
+    mode &= 0xff;
+  }
   Lds L;
   L.prod = smem;                                                  // 2 * PBUF
   L.xs = L.prod + 2 * PBUF;                                       // 3 * XS

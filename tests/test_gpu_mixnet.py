@@ -125,5 +125,5 @@ def test_protocol_errors():
         net.predict(np.full(2078, 0.5, np.float32), np.zeros(47, np.uint32))
     net.perceive(1)
     net.close()
-    assert E.lib().cmx_create(None, None, 0) is None  # whole-predictor surface not assembled yet
-    assert "not implemented" in E.last_error()
+    assert E.lib().cmx_create(None, None, 0) is None  # the whole-predictor surface: tests/test_gpu_predictor.py
+    assert "null vocab" in E.last_error()
