@@ -122,8 +122,8 @@ def cpu_reference_full(text, nbytes=4096):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=48)   # 48 KB per stream, ~5 s timed: the ~95 ms pipeline fill
+    ap.add_argument("--warmup", type=int, default=2)   # (PPMd + LSTM of the first timed chunk) weighs 2 %
     ap.add_argument("--chunk-bytes", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams-per-gpu", type=int, default=1,
@@ -171,6 +171,9 @@ def main():
     for i in range(a.warmup):
         step(i)
     torch.cuda.synchronize()
+    for p in pipes:
+        p.sync()
+        p.stage_totals(reset=True)  # the stage timers below cover exactly the timed chunks
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -185,8 +188,9 @@ def main():
     for p in pipes:
         p.sync()
     total_bytes, dt, _ = shard.aggregate_throughput(S * a.chunk_bytes * a.steps, dt, dev)  # sum of bytes / max of times
-    st = pipe.last_stage_ms()  # HIP events around each stage of the last timed chunk, on the stage's own stream
+    st = pipe.stage_totals()  # HIP events around each stage of every timed chunk, on the stage's own stream: means
     mix_ms, ctx_ms, lstm_ms = st["mixnet"], st["ctxmodels"], st["lstm"]
+    assert st["chunks"] == a.steps, st
 
     if rank == 0:
         avg_kernel_s = mix_ms / 1e3
@@ -209,7 +213,7 @@ def main():
             "us_per_bit": dt / (a.steps * cb) * 1e6,  # wall per bit of ONE stream
             "stage_us_per_bit": {"mixnet": avg_kernel_s / cb * 1e6, "ctxmodels": ctx_ms * 1e3 / cb,
                                  "lstm": lstm_ms * 1e3 / cb,
-                                 "note": "HIP-event time of each stage over the last timed chunk (stages overlap on separate streams)"},
+                                 "note": "mean HIP-event time of each stage over the timed chunks (stages overlap on separate streams)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(a.chunk_bytes),
                          "kernel": "cmx_mixnet_chunk_kernel", "avg_kernel_ms": avg_kernel_s * 1e3,

@@ -11,7 +11,7 @@
 //   s_mix:  (after both) final mixing network + SSE -> p per bit       predictor.cpp:388-418,432-437
 //
 // The three device stages of a chunk run on their own HIP streams and the stages of consecutive chunks
-// overlap (two chunks in flight). Columns 3..2024 (fxcm, paq8) have no stage yet: the caller supplies
+// overlap (up to four chunks in flight). Columns 3..2024 (fxcm, paq8) have no stage yet: the caller supplies
 // them inside d_layer0. No CPU fallback exists for any device stage.
 #include <hip/hip_runtime.h>
 #include <stddef.h>
@@ -24,7 +24,7 @@
 void cmx_set_err(const std::string& s);  // cmx_api.hip
 
 namespace {
-constexpr int kSlots = 2;
+constexpr int kSlots = 4;  // chunks in flight: the LSTM of chunk i+2 must be able to start while chunk i is still in the mixing network
 struct Slot {
   uint8_t* d_bytes = nullptr;
   uint8_t* d_bits = nullptr;
@@ -36,6 +36,7 @@ struct Slot {
   hipEvent_t ev_in = nullptr, ev_ctx0 = nullptr, ev_ctx1 = nullptr, ev_lstm0 = nullptr, ev_lstm1 = nullptr,
              ev_mix0 = nullptr, ev_mix1 = nullptr;
   bool used = false;
+  bool untimed = false;  // the chunk in this slot has not been added to the stage totals yet
 };
 }  // namespace
 
@@ -52,7 +53,22 @@ struct cmx_pipeline {
   float last_dist[256];
   float stage_ms[3] = {0, 0, 0};
   int last_slot = -1;
+  double tot_ms[3] = {0, 0, 0};  // HIP-event time of every finished chunk's stages since the last reset
+  uint64_t tot_chunks = 0;
 };
+
+namespace {
+void collect(cmx_pipeline* h, Slot& s) {  // the slot's chunk has finished (its ev_mix1 was waited for)
+  if (!s.untimed) return;
+  float ms[3] = {0, 0, 0};
+  (void)hipEventElapsedTime(&ms[0], s.ev_ctx0, s.ev_ctx1);
+  (void)hipEventElapsedTime(&ms[1], s.ev_lstm0, s.ev_lstm1);
+  (void)hipEventElapsedTime(&ms[2], s.ev_mix0, s.ev_mix1);
+  for (int i = 0; i < 3; ++i) h->tot_ms[i] += ms[i];
+  h->tot_chunks++;
+  s.untimed = false;
+}
+}  // namespace
 
 extern "C" {
 
@@ -123,6 +139,7 @@ int cmx_pipeline_submit(cmx_pipeline_t* h, const uint8_t* bytes, size_t n, float
     cmx_set_err("cmx_pipeline_submit: device error in an earlier chunk");
     return 1;
   }
+  collect(h, s);
   // ---- host stage: PPMd runs ahead of the device on this thread ----
   memcpy(s.h_ppmd, h->last_dist, 256 * 4);
   if (cmx_ppmd_run(h->ppmd, bytes, n, s.h_ppmd + 256)) return 1;
@@ -156,6 +173,7 @@ int cmx_pipeline_submit(cmx_pipeline_t* h, const uint8_t* bytes, size_t n, float
   if (cmx_mixnet_run(h->mix, d_layer0, s.d_sel, s.d_bits, 8 * n, d_p_out, nullptr, h->s_mix)) return 1;
   (void)hipEventRecord(s.ev_mix1, h->s_mix);
   s.used = true;
+  s.untimed = true;
   h->last_slot = (int)(h->chunks % kSlots);
   h->chunks++;
   return 0;
@@ -187,12 +205,21 @@ int cmx_pipeline_sync(cmx_pipeline_t* h) {
   ok = hipStreamSynchronize(h->s_mix) == hipSuccess && ok;
   if (!ok) { cmx_set_err("cmx_pipeline_sync: device error"); return 1; }
   if (cmx_ctxmodels_sync(h->ctx) || cmx_mixnet_sync(h->mix)) return 1;
+  for (Slot& s : h->slot) collect(h, s);
   if (h->last_slot >= 0) {
     Slot& s = h->slot[h->last_slot];
     (void)hipEventElapsedTime(&h->stage_ms[0], s.ev_ctx0, s.ev_ctx1);
     (void)hipEventElapsedTime(&h->stage_ms[1], s.ev_lstm0, s.ev_lstm1);
     (void)hipEventElapsedTime(&h->stage_ms[2], s.ev_mix0, s.ev_mix1);
   }
+  return 0;
+}
+
+int cmx_pipeline_stage_totals(cmx_pipeline_t* h, double ms[3], uint64_t* chunks, int reset) {
+  if (!h || !ms || !chunks) return 1;
+  for (int i = 0; i < 3; ++i) ms[i] = h->tot_ms[i];
+  *chunks = h->tot_chunks;
+  if (reset) { h->tot_ms[0] = h->tot_ms[1] = h->tot_ms[2] = 0; h->tot_chunks = 0; }
   return 0;
 }
 

@@ -115,6 +115,7 @@ def lib():
         L.cmx_header_write.argtypes = [C.c_uint64, C.c_void_p, C.c_int, C.c_void_p]
         L.cmx_header_read.restype = C.c_size_t
         L.cmx_header_read.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cmx_pipeline_stage_totals.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.cmx_pipeline_pretrain.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.cmx_pipeline_sync.argtypes = [C.c_void_p]
         L.cmx_pipeline_last_stage_ms.argtypes = [C.c_void_p, C.c_void_p]
@@ -405,6 +406,14 @@ class Pipeline:
         ms = (C.c_float * 3)()
         lib().cmx_pipeline_last_stage_ms(self.h, ms)
         return {"ctxmodels": ms[0], "lstm": ms[1], "mixnet": ms[2]}
+
+    def stage_totals(self, reset=False):
+        """Mean HIP-event ms per chunk of each stage over the chunks finished since the last reset (call after sync)."""
+        ms = (C.c_double * 3)()
+        n = C.c_uint64(0)
+        lib().cmx_pipeline_stage_totals(self.h, ms, C.byref(n), int(reset))
+        k = max(n.value, 1)
+        return {"ctxmodels": ms[0] / k, "lstm": ms[1] / k, "mixnet": ms[2] / k, "chunks": n.value}
 
     def close(self):
         if getattr(self, "h", None):

@@ -51,7 +51,7 @@ class StreamPipeline:
         self.stage_log = []
 
     def step(self, i):
-        """Chunk i through all stages, asynchronously (two chunks in flight): chunk i+1's PPMd / context / LSTM
+        """Chunk i through all stages, asynchronously (up to four chunks in flight): chunk i+1's PPMd / context / LSTM
         stages run under chunk i's mixing network."""
         cb = self.cb
         r = slice(i * cb, (i + 1) * cb)
@@ -62,6 +62,9 @@ class StreamPipeline:
 
     def last_stage_ms(self):
         return self.pipe.last_stage_ms()
+
+    def stage_totals(self, reset=False):
+        return self.pipe.stage_totals(reset)
 
     def close(self):
         self.pipe.close()

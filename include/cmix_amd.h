@@ -246,8 +246,8 @@ int cmx_ppmd_run(cmx_ppmd_t*, const uint8_t* bytes, size_t nbytes, float* out_pr
  * 3. One stream through every stage built so far: the native orchestration behind the Predictor
  *    surface, a chunk of already-known bytes at a time (Predictor::Predict/Perceive, predictor.cpp:
  *    361-469, in compression look-ahead form). PPMd runs on the calling host thread; the context /
- *    small-model stage, the LSTM and the mixing network run on three internal HIP streams; two chunks
- *    may be in flight. cmx_create will sit on top of this once the fxcm and paq8 stages exist.
+ *    small-model stage, the LSTM and the mixing network run on three internal HIP streams; up to four
+ *    chunks may be in flight (a submit blocks while the chunk four submits back is still running).
  * ------------------------------------------------------------------------ */
 typedef struct cmx_pipeline cmx_pipeline_t;
 cmx_pipeline_t* cmx_pipeline_create(const uint8_t vocab[256], int device, size_t max_chunk_bytes);
@@ -267,6 +267,9 @@ int cmx_pipeline_pretrain(cmx_pipeline_t*, const uint8_t* bytes, size_t n);
 int cmx_pipeline_sync(cmx_pipeline_t*);
 /* HIP-event time (ms) the last submitted chunk spent in [0] contexts+small models, [1] LSTM, [2] mixing network. */
 int cmx_pipeline_last_stage_ms(cmx_pipeline_t*, float ms[3]);
+/* HIP-event time of each stage (contexts, LSTM, mixing network; ms) summed over every chunk that has finished since
+ * the last reset, and the number of those chunks: call after cmx_pipeline_sync(). */
+int cmx_pipeline_stage_totals(cmx_pipeline_t*, double ms[3], uint64_t* chunks, int reset);
 
 /* ------------------------------------------------------------------------
  * Device libm probes (parity tests): evaluate the engine's expf / tanhf /

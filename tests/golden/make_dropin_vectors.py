@@ -8,6 +8,8 @@ files the UNMODIFIED reference binary (oracle/_ref/cmix_O3, built by oracle/Make
     dict_c    cmix -c dict in out             WRT dictionary transform + Predictor::Pretrain over the dictionary
     text12k_c cmix -c in out                  >= 10 000 bytes: vocabulary bitmap in the header, LSTM sized by the
                                               real vocabulary (V < 256), 120 BPTT/Adam rounds
+    text50k_c cmix -c in out                  50 000 bytes (only the SHA-256 and the size of the reference's file are
+                                              kept): 500 BPTT rounds, mixer rows past their first weight decay
 
     python tests/golden/make_dropin_vectors.py
 """
@@ -46,7 +48,8 @@ def payloads():
     words = sorted({w for w in text.replace(b"\n", b" ").split(b" ") if w.isalpha() and w.islower() and len(w) > 2})
     dic = b"\n".join(words[:400]) + b"\n"
     big = synth.enwik_like(12000, 77)
-    return {"raw_n": raw, "text_c": text[1000:3000], "dict_c": text[3000:4500], "dict": dic, "text12k_c": big}
+    return {"raw_n": raw, "text_c": text[1000:3000], "dict_c": text[3000:4500], "dict": dic, "text12k_c": big,
+            "text50k_c": synth.enwik_like(50000, 91)}
 
 
 if __name__ == "__main__":
@@ -56,6 +59,13 @@ if __name__ == "__main__":
     out["text_c_file"] = np.frombuffer(run("-c", [("in", p["text_c"])]), np.uint8)
     out["dict_c_file"] = np.frombuffer(run("-c", [("dict", p["dict"]), ("in", p["dict_c"])]), np.uint8)
     out["text12k_c_file"] = np.frombuffer(run("-c", [("in", p["text12k_c"])]), np.uint8)
+    import hashlib
+    big50 = run("-c", [("in", p["text50k_c"])])
+    out["text50k_c_sha256"] = np.frombuffer(hashlib.sha256(big50).digest(), np.uint8)
+    out["text50k_c_size"] = np.array([len(big50)], np.int64)
+    out["text50k_c_seed"] = np.array([50000, 91], np.int64)  # synth.enwik_like(50000, 91): not stored, regenerated
+    del out["text50k_c_payload"]
+    print("text50k_c", len(p["text50k_c"]), "->", len(big50), "bytes")
     for k in ("raw_n", "text_c", "dict_c", "text12k_c"):
         print(k, len(p[k]), "->", len(out[k + "_file"]), "bytes; header", out[k + "_file"][:5])
     np.savez_compressed(os.path.join(HERE, "dropin_vectors.npz"), **out)

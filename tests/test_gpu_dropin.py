@@ -64,3 +64,19 @@ def test_12k_text_with_vocabulary_header_is_byte_identical_and_round_trips():
     v = _vectors()
     assert _run("-c", [("in", v["text12k_c_payload"])]) == v["text12k_c_file"]
     assert _run("-d", [("in", v["text12k_c_file"])]) == v["text12k_c_payload"]
+
+
+def test_50k_text_compresses_to_the_reference_binarys_file():
+    """50 000 bytes (500 BPTT rounds, mixer rows past their first weight decay, PPMd well into its tree): size and
+    SHA-256 of the reference binary's output are the fixture; the payload is regenerated from its seed."""
+    import hashlib
+    from cmix_amd import synth
+    if not os.path.exists(EXE):
+        pytest.skip("oracle/_ref/cmix_hybrid not built (make -C oracle hybrid)")
+    with np.load(os.path.join(GOLDEN, "dropin_vectors.npz")) as z:
+        if "text50k_c_sha256" not in z.files:
+            pytest.skip("fixture without the 50 KB case")
+        want_sha, want_size, (n, seed) = z["text50k_c_sha256"].tobytes(), int(z["text50k_c_size"][0]), z["text50k_c_seed"]
+    got = _run("-c", [("in", synth.enwik_like(int(n), int(seed)))], timeout=900)
+    assert len(got) == want_size
+    assert hashlib.sha256(got).digest() == want_sha

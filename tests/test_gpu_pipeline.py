@@ -74,7 +74,7 @@ def test_pipeline_text_4k_local():
 
 
 def _native(name, chunks=None, big=False):
-    """Same check through cmx_pipeline_* (the native C++ orchestration: PPMd host stage, three HIP streams, two
+    """Same check through cmx_pipeline_* (the native C++ orchestration: PPMd host stage, three HIP streams, up to four
     chunks in flight): only the fxcm/paq8 columns come from the trace."""
     import torch
     from cmix_amd import engine as E
@@ -100,7 +100,7 @@ def _native(name, chunks=None, big=False):
 
 
 def test_native_pipeline_text_96_ragged():
-    _native("text_96", chunks=[1, 2, 3, 50, 51])  # more chunks than slots: buffer recycling
+    _native("text_96", chunks=[1, 2, 3, 10, 11, 50, 51])  # more chunks (8) than slots (4): buffer recycling
 
 
 def test_native_pipeline_binary_64():
