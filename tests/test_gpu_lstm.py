@@ -102,3 +102,36 @@ def test_bytemodel_bits_matches_oracle_ex():
             assert orc.ex() == bx[n, j], (n, j)
             orc.bit_perceive((int(g["stream"][n]) >> (7 - j)) & 1)
         orc.byte_update(g["ppmd_probs"][n + 1], g["stream"][n])
+
+
+def test_330k_bytes_past_the_adam_step_limit():
+    """330 000 bytes = 3300 BPTT/Adam rounds on the device: LstmLayer::update_steps_ saturates at 3000 (byte 300 000)
+    and the bias terms take the double-precision pow() path (lstm-layer.cpp:26-30). The stream is regenerated from
+    its seed, the host PPMd stage supplies the input distributions (and is itself checked at the same bytes), and
+    the LSTM's output distribution is compared, bit for bit, with checkpoints of the reference trace on both sides
+    of the switch (tests/golden/make_lstm_long_checkpoints.py)."""
+    import torch
+    from cmix_amd import engine as E
+    import make_lstm_long_checkpoints as mk
+    g = load_golden("lstm_330k_checkpoints")
+    stream = mk.stream_330k()
+    N = len(stream)
+    ppmd = E.Ppmd(g["vocab"])
+    lstm = E.Lstm(g["vocab"], 0)
+    want = {int(n): i for i, n in enumerate(g["at"])}
+    BLK = 30000
+    for a in range(0, N, BLK):
+        b = min(N, a + BLK)
+        pp = ppmd.run(stream[a:b].tobytes())
+        for n in range(a, b):
+            if n in want:
+                assert bits_equal(pp[n - a], g["ppmd_probs"][want[n]]).all(), f"PPMd distribution after byte {n}"
+        out, _, _ = lstm.run(torch.from_numpy(pp).cuda(), torch.from_numpy(stream[a:b].copy()).cuda(), want_bits=False)
+        torch.cuda.synchronize()
+        rows = [n for n in want if a <= n < b]
+        if rows:
+            got = out[torch.tensor([n - a for n in rows], device="cuda")].cpu().numpy()
+            for k, n in enumerate(rows):
+                assert bits_equal(got[k], g["lstm_probs"][want[n]]).all(), f"LSTM distribution after byte {n}"
+    ppmd.close()
+    lstm.close()
