@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 
@@ -87,7 +88,7 @@ void cmx_pipeline_destroy(cmx_pipeline_t* h) {
     for (hipEvent_t e : {s.ev_in, s.ev_ctx0, s.ev_ctx1, s.ev_lstm0, s.ev_lstm1, s.ev_mix0, s.ev_mix1})
       if (e) (void)hipEventDestroy(e);
   }
-  if (h->s_ctx) (void)hipStreamDestroy(h->s_ctx);
+  if (h->s_ctx && h->s_ctx != h->s_lstm) (void)hipStreamDestroy(h->s_ctx);
   if (h->s_lstm) (void)hipStreamDestroy(h->s_lstm);
   if (h->s_mix) (void)hipStreamDestroy(h->s_mix);
   cmx_mixnet_destroy(h->mix);
@@ -109,8 +110,14 @@ cmx_pipeline_t* cmx_pipeline_create(const uint8_t vocab[256], int device, size_t
   h->ppmd = h->mix ? cmx_ppmd_create(vocab) : nullptr;
   if (!h->ppmd) { cmx_pipeline_destroy(h); return nullptr; }
   bool ok = hipSetDevice(device) == hipSuccess;
-  ok = ok && hipStreamCreateWithFlags(&h->s_ctx, hipStreamNonBlocking) == hipSuccess;
+  // CMX_PIPELINE_STREAMS=2 (throughput mode, many streams per GPU): the context stage shares the LSTM's HIP stream.
+  // Every HIP stream is a hardware queue; past ~24 active queues the hardware scheduler starts time-slicing them
+  // (profiles/r01_multiproc.txt: microsecond kernels then show 13 ms durations), so 8+ streams per GPU want 2 each.
+  const char* ns = getenv("CMX_PIPELINE_STREAMS");
+  const bool two = ns && ns[0] == '2';
   ok = ok && hipStreamCreateWithFlags(&h->s_lstm, hipStreamNonBlocking) == hipSuccess;
+  if (two) h->s_ctx = h->s_lstm;
+  else ok = ok && hipStreamCreateWithFlags(&h->s_ctx, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipStreamCreateWithFlags(&h->s_mix, hipStreamNonBlocking) == hipSuccess;
   const size_t n = max_chunk_bytes;
   for (Slot& s : h->slot) {

@@ -1,4 +1,3 @@
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
-timeout 300 python -m pytest tests/test_gpu_lstm.py -m gpu -q -x -k "not 330k" 2>&1 | tail -2
-timeout 120 python scripts/gpu_lstm_time.py 2000 2>&1 | tail -2
-CMX_LSTM_PERBYTE=1 timeout 120 python scripts/gpu_lstm_time.py 2000 2>&1 | tail -1
+echo "== threads, 2 HIP streams per pipeline"; CMX_PIPELINE_STREAMS=2 timeout 300 python scripts/gpu_multistream.py 1,8,11 2>/dev/null | cut -c1-200
+echo "== processes, 2 HIP streams per pipeline, GPU_MAX_HW_QUEUES=2"; CMX_PIPELINE_STREAMS=2 GPU_MAX_HW_QUEUES=2 timeout 300 python scripts/gpu_multiproc.py 8,12 2>/dev/null | cut -c1-230
