@@ -135,6 +135,33 @@ int cmx_device_count(void) {
 
 // whole-predictor surface (cmx_create .. cmx_destroy): engine_api.hip
 
+// Plain-C memory helpers so that a host program written against this header needs no HIP headers of its own.
+void* cmx_device_alloc(int device, size_t bytes) {
+  void* p = nullptr;
+  if (hipSetDevice(device) != hipSuccess || hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+    set_err("cmx_device_alloc: hipMalloc failed");
+    return nullptr;
+  }
+  return p;
+}
+void cmx_device_free(int device, void* p) {
+  if (p && hipSetDevice(device) == hipSuccess) (void)hipFree(p);
+}
+void* cmx_host_alloc(size_t bytes) {  // page-locked
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { set_err("cmx_host_alloc: hipHostMalloc failed"); return nullptr; }
+  return p;
+}
+void cmx_host_free(void* p) { if (p) (void)hipHostFree(p); }
+int cmx_copy_to_host(int device, void* dst, const void* d_src, size_t bytes) {  // synchronous, after all prior work of the device
+  if (hipSetDevice(device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+      hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+    set_err("cmx_copy_to_host: device error");
+    return 1;
+  }
+  return 0;
+}
+
 // --------------------------------------------------------------------------
 // mixing-network stage
 // --------------------------------------------------------------------------

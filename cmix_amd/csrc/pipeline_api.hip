@@ -34,8 +34,12 @@ struct Slot {
   float* d_lstm_out = nullptr;  // [max][256]
   uint8_t* h_bytes = nullptr;   // pinned: bytes, then the 8n unpacked bits
   float* h_ppmd = nullptr;      // pinned [max+1][256]
+  float* d_hint = nullptr;      // [8 max + 1] f32 LSTM bit predictions, then [8 max + 1] i32 `ex` (look-ahead hybrid)
+  float* h_hint = nullptr;      // pinned mirror
+  size_t n = 0;                 // bytes of the chunk in this slot
+  float* d_layer0 = nullptr;    // the caller's layer-0 rows of that chunk
   hipEvent_t ev_in = nullptr, ev_ctx0 = nullptr, ev_ctx1 = nullptr, ev_lstm0 = nullptr, ev_lstm1 = nullptr,
-             ev_mix0 = nullptr, ev_mix1 = nullptr;
+             ev_mix0 = nullptr, ev_mix1 = nullptr, ev_cols = nullptr;
   bool used = false;
   bool untimed = false;  // the chunk in this slot has not been added to the stage totals yet
 };
@@ -50,7 +54,9 @@ struct cmx_pipeline {
   cmx_mixnet_t* mix = nullptr;
   hipStream_t s_ctx = nullptr, s_lstm = nullptr, s_mix = nullptr;
   Slot slot[kSlots];
-  uint64_t chunks = 0;
+  uint64_t chunks = 0;    // chunks begun
+  uint64_t hinted = 0;    // chunks whose LSTM hints were handed out (<= chunks)
+  uint64_t finished = 0;  // chunks whose mixing network was enqueued (<= chunks)
   float last_dist[256];
   float stage_ms[3] = {0, 0, 0};
   int last_slot = -1;
@@ -85,7 +91,9 @@ void cmx_pipeline_destroy(cmx_pipeline_t* h) {
     if (s.d_lstm_out) (void)hipFree(s.d_lstm_out);
     if (s.h_bytes) (void)hipHostFree(s.h_bytes);
     if (s.h_ppmd) (void)hipHostFree(s.h_ppmd);
-    for (hipEvent_t e : {s.ev_in, s.ev_ctx0, s.ev_ctx1, s.ev_lstm0, s.ev_lstm1, s.ev_mix0, s.ev_mix1})
+    if (s.d_hint) (void)hipFree(s.d_hint);
+    if (s.h_hint) (void)hipHostFree(s.h_hint);
+    for (hipEvent_t e : {s.ev_in, s.ev_ctx0, s.ev_ctx1, s.ev_lstm0, s.ev_lstm1, s.ev_mix0, s.ev_mix1, s.ev_cols})
       if (e) (void)hipEventDestroy(e);
   }
   if (h->s_ctx && h->s_ctx != h->s_lstm) (void)hipStreamDestroy(h->s_ctx);
@@ -128,7 +136,9 @@ cmx_pipeline_t* cmx_pipeline_create(const uint8_t vocab[256], int device, size_t
     ok = ok && hipMalloc((void**)&s.d_lstm_out, n * 256 * 4) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&s.h_bytes, 9 * n, hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&s.h_ppmd, (n + 1) * 256 * 4, hipHostMallocDefault) == hipSuccess;
-    for (hipEvent_t* e : {&s.ev_in, &s.ev_ctx0, &s.ev_ctx1, &s.ev_lstm0, &s.ev_lstm1, &s.ev_mix0, &s.ev_mix1})
+    ok = ok && hipMalloc((void**)&s.d_hint, 2 * (8 * n + 1) * 4) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&s.h_hint, 2 * (8 * n + 1) * 4, hipHostMallocDefault) == hipSuccess;
+    for (hipEvent_t* e : {&s.ev_in, &s.ev_ctx0, &s.ev_ctx1, &s.ev_lstm0, &s.ev_lstm1, &s.ev_mix0, &s.ev_mix1, &s.ev_cols})
       ok = ok && hipEventCreate(e) == hipSuccess;
   }
   if (!ok) { cmx_set_err("cmx_pipeline_create: stream / buffer allocation failed"); cmx_pipeline_destroy(h); return nullptr; }
@@ -136,17 +146,21 @@ cmx_pipeline_t* cmx_pipeline_create(const uint8_t vocab[256], int device, size_t
   return h;
 }
 
-int cmx_pipeline_submit(cmx_pipeline_t* h, const uint8_t* bytes, size_t n, float* d_layer0, float* d_p_out) {
-  if (!h) { cmx_set_err("cmx_pipeline_submit: null handle"); return 1; }
-  if (n == 0) return 0;
-  if (!bytes || !d_layer0 || !d_p_out || n > h->max_chunk) { cmx_set_err("cmx_pipeline_submit: bad argument"); return 1; }
+// ---- a chunk in two steps -------------------------------------------------------------------------------------
+// begin: everything that does not need the fxcm/paq8 columns -- PPMd on this thread, upload, context stage, LSTM.
+int cmx_pipeline_begin(cmx_pipeline_t* h, const uint8_t* bytes, size_t n, float* d_layer0) {
+  if (!h) { cmx_set_err("cmx_pipeline_begin: null handle"); return 1; }
+  if (!bytes || !d_layer0 || n == 0 || n > h->max_chunk) { cmx_set_err("cmx_pipeline_begin: bad argument"); return 1; }
+  if (h->chunks - h->finished >= (uint64_t)kSlots) { cmx_set_err("cmx_pipeline_begin: too many chunks begun and not finished"); return 1; }
   if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
   Slot& s = h->slot[h->chunks % kSlots];
-  if (s.used && hipEventSynchronize(s.ev_mix1) != hipSuccess) {  // the chunk that used these buffers two submits ago
-    cmx_set_err("cmx_pipeline_submit: device error in an earlier chunk");
+  if (s.used && hipEventSynchronize(s.ev_mix1) != hipSuccess) {  // the chunk that used these buffers kSlots submits ago
+    cmx_set_err("cmx_pipeline_begin: device error in an earlier chunk");
     return 1;
   }
   collect(h, s);
+  s.n = n;
+  s.d_layer0 = d_layer0;
   // ---- host stage: PPMd runs ahead of the device on this thread ----
   memcpy(s.h_ppmd, h->last_dist, 256 * 4);
   if (cmx_ppmd_run(h->ppmd, bytes, n, s.h_ppmd + 256)) return 1;
@@ -161,7 +175,7 @@ int cmx_pipeline_submit(cmx_pipeline_t* h, const uint8_t* bytes, size_t n, float
   ok = ok && hipMemcpyAsync(s.d_bits, hb, 8 * n, hipMemcpyHostToDevice, h->s_lstm) == hipSuccess;
   ok = ok && hipEventRecord(s.ev_in, h->s_lstm) == hipSuccess;
   ok = ok && hipStreamWaitEvent(h->s_ctx, s.ev_in, 0) == hipSuccess;
-  if (!ok) { cmx_set_err("cmx_pipeline_submit: input upload failed"); return 1; }
+  if (!ok) { cmx_set_err("cmx_pipeline_begin: input upload failed"); return 1; }
   // ---- context / small-model stage + PPMd's bit predictions ----
   (void)hipEventRecord(s.ev_ctx0, h->s_ctx);
   if (cmx_ctxmodels_run(h->ctx, s.d_bytes, n, d_layer0, CMX_N_INPUTS, s.d_sel, h->s_ctx)) return 1;
@@ -170,20 +184,80 @@ int cmx_pipeline_submit(cmx_pipeline_t* h, const uint8_t* bytes, size_t n, float
   (void)hipEventRecord(s.ev_ctx1, h->s_ctx);
   // ---- LSTM byte mixer ----
   (void)hipEventRecord(s.ev_lstm0, h->s_lstm);
-  if (cmx_lstm_run(h->lstm, s.d_ppmd + 256, s.d_bytes, n, s.d_lstm_out, d_layer0 + 2077, CMX_N_INPUTS, nullptr, h->s_lstm))
+  if (cmx_lstm_run(h->lstm, s.d_ppmd + 256, s.d_bytes, n, s.d_lstm_out, d_layer0 + 2077, CMX_N_INPUTS,
+                   (int*)(s.d_hint + (8 * h->max_chunk + 1)), h->s_lstm))
     return 1;
   (void)hipEventRecord(s.ev_lstm1, h->s_lstm);
+  s.used = true;
+  s.untimed = false;  // becomes true once its mixing network is enqueued
+  h->chunks++;
+  return 0;
+}
+
+// hints: what Predictor::Perceive leaves in `lstmpr` / `lstmex` (predictor.cpp:462-465) along the oldest begun chunk
+// that has not handed them out: lstm_p[t] / lstm_ex[t] = ByteModel::Predict value and `ex` of the LSTM byte mixer for
+// bit t of the chunk, t = 0 .. 8n (entry 8n = the first bit after the chunk, known from the last distribution alone).
+// After coding bit t the reference holds lstmpr = 1 + 4094 * lstm_p[t + 1] (float arithmetic), lstmex = lstm_ex[t + 1].
+// Waits for that chunk's LSTM stage.
+int cmx_pipeline_hints(cmx_pipeline_t* h, float* lstm_p, int* lstm_ex) {
+  if (!h || !lstm_p || !lstm_ex) { cmx_set_err("cmx_pipeline_hints: bad argument"); return 1; }
+  if (h->hinted >= h->chunks) { cmx_set_err("cmx_pipeline_hints: no begun chunk is waiting for them"); return 1; }
+  if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
+  Slot& s = h->slot[h->hinted % kSlots];
+  const size_t n = s.n, T = 8 * n;
+  float* dp = s.d_hint;
+  int* dx = (int*)(s.d_hint + (8 * h->max_chunk + 1));  // bits 0 .. 8n-1 were written by the LSTM stage (begin)
+  float* hp = s.h_hint;
+  int* hx = (int*)(s.h_hint + (8 * h->max_chunk + 1));
+  // entry 8n: bit 0 of whatever byte follows, from the distribution after the chunk's last byte
+  if (cmx_bytemodel_bit_run(h->device, s.d_lstm_out + (n - 1) * 256, s.d_bytes, 0, dp + T, 1, dx + T, nullptr, h->s_lstm))
+    return 1;
+  // bits 0 .. 8n-1: column 2077 of the chunk's layer-0 rows, gathered
+  bool ok = hipMemcpy2DAsync(hp, 4, s.d_layer0 + 2077, CMX_N_INPUTS * 4, 4, T, hipMemcpyDeviceToHost, h->s_lstm) == hipSuccess;
+  ok = ok && hipMemcpyAsync(hp + T, dp + T, 4, hipMemcpyDeviceToHost, h->s_lstm) == hipSuccess;
+  ok = ok && hipMemcpyAsync(hx, dx, (T + 1) * 4, hipMemcpyDeviceToHost, h->s_lstm) == hipSuccess;
+  ok = ok && hipStreamSynchronize(h->s_lstm) == hipSuccess;
+  if (!ok) { cmx_set_err("cmx_pipeline_hints: device error"); return 1; }
+  memcpy(lstm_p, hp, (T + 1) * 4);
+  memcpy(lstm_ex, hx, (T + 1) * 4);
+  h->hinted++;
+  return 0;
+}
+
+// finish: the oldest begun chunk gets its fxcm/paq8 columns (HOST rows of 2022 floats = layer-0 columns 3..2024; NULL
+// = the caller has already written them into d_layer0) and its mixing network. Asynchronous.
+int cmx_pipeline_finish(cmx_pipeline_t* h, const float* cols, float* d_p_out) {
+  if (!h || !d_p_out) { cmx_set_err("cmx_pipeline_finish: bad argument"); return 1; }
+  if (h->finished >= h->chunks) { cmx_set_err("cmx_pipeline_finish: no begun chunk"); return 1; }
+  if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
+  Slot& s = h->slot[h->finished % kSlots];
+  const size_t n = s.n;
+  if (cols) {  // returns once the rows have been read: the caller may reuse `cols` right away
+    bool ok = hipMemcpy2DAsync(s.d_layer0 + 3, CMX_N_INPUTS * 4, cols, 2022 * 4, 2022 * 4, 8 * n, hipMemcpyHostToDevice,
+                               h->s_mix) == hipSuccess;
+    ok = ok && hipEventRecord(s.ev_cols, h->s_mix) == hipSuccess && hipEventSynchronize(s.ev_cols) == hipSuccess;
+    if (!ok) { cmx_set_err("cmx_pipeline_finish: column upload failed"); return 1; }
+  }
   // ---- final mixing network, once both producers have written their columns ----
   (void)hipStreamWaitEvent(h->s_mix, s.ev_ctx1, 0);
   (void)hipStreamWaitEvent(h->s_mix, s.ev_lstm1, 0);
   (void)hipEventRecord(s.ev_mix0, h->s_mix);
-  if (cmx_mixnet_run(h->mix, d_layer0, s.d_sel, s.d_bits, 8 * n, d_p_out, nullptr, h->s_mix)) return 1;
+  if (cmx_mixnet_run(h->mix, s.d_layer0, s.d_sel, s.d_bits, 8 * n, d_p_out, nullptr, h->s_mix)) return 1;
   (void)hipEventRecord(s.ev_mix1, h->s_mix);
-  s.used = true;
   s.untimed = true;
-  h->last_slot = (int)(h->chunks % kSlots);
-  h->chunks++;
+  h->last_slot = (int)(h->finished % kSlots);
+  h->finished++;
+  if (h->hinted < h->finished) h->hinted = h->finished;  // hints nobody asked for are skipped
   return 0;
+}
+
+int cmx_pipeline_submit(cmx_pipeline_t* h, const uint8_t* bytes, size_t n, float* d_layer0, float* d_p_out) {
+  if (!h) { cmx_set_err("cmx_pipeline_submit: null handle"); return 1; }
+  if (n == 0) return 0;
+  if (!bytes || !d_layer0 || !d_p_out || n > h->max_chunk) { cmx_set_err("cmx_pipeline_submit: bad argument"); return 1; }
+  if (h->finished != h->chunks) { cmx_set_err("cmx_pipeline_submit: a begun chunk is waiting for cmx_pipeline_finish"); return 1; }
+  if (cmx_pipeline_begin(h, bytes, n, d_layer0)) return 1;
+  return cmx_pipeline_finish(h, nullptr, d_p_out);
 }
 
 // Predictor::Pretrain (predictor.cpp:471-487) over dictionary bytes: only `models_` learn -- here the context /

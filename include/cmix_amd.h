@@ -48,6 +48,13 @@ const char* cmx_last_error(void);
  * number of visible HIP devices (0 if none; never fails). */
 int cmx_device_count(void);
 const char* cmx_version(void);
+/* Memory helpers, so that a host program written against this header needs no HIP headers: device memory,
+ * page-locked host memory, and a synchronous device-to-host copy ordered after all prior work of the device. */
+void* cmx_device_alloc(int device, size_t bytes);
+void cmx_device_free(int device, void* p);
+void* cmx_host_alloc(size_t bytes);
+void cmx_host_free(void* p);
+int cmx_copy_to_host(int device, void* dst, const void* d_src, size_t bytes);
 
 /* ------------------------------------------------------------------------
  * 1. Whole-predictor surface (replaces class Predictor, predictor.h:17-22)
@@ -261,6 +268,20 @@ void cmx_pipeline_destroy(cmx_pipeline_t*);
  * Returns after enqueueing (it only waits for the chunk before the previous one); d_layer0 / d_p_out must
  * stay valid until cmx_pipeline_sync() or until two further submits have returned. */
 int cmx_pipeline_submit(cmx_pipeline_t*, const uint8_t* bytes, size_t n, float* d_layer0, float* d_p_out);
+/* The same chunk in steps, for look-ahead coding while some model families still run on the host:
+ *   _begin   PPMd (this thread), upload, context stage and LSTM are enqueued; up to 4 chunks may be begun and not
+ *            finished;
+ *   _hints   (optional) for the oldest begun chunk that has not handed them out: lstm_p[t], lstm_ex[t], t = 0 .. 8n,
+ *            = the LSTM byte mixer's ByteModel::Predict value and `ex` for bit t of the chunk (t = 8n: the first bit
+ *            after it). After coding bit t the reference's globals hold lstmpr = 1 + 4094 * lstm_p[t+1] (float
+ *            arithmetic, truncated) and lstmex = lstm_ex[t+1] (predictor.cpp:180-182,462-465): what a host fxcm
+ *            needs to run ahead. HOST arrays of 8n+1 entries; waits for that chunk's LSTM stage;
+ *   _finish  the oldest begun chunk: its layer-0 columns 3..2024 from HOST rows cols[8n][2022] (NULL = already in
+ *            d_layer0), then the mixing network -> d_p_out[8n]. Asynchronous.
+ * cmx_pipeline_submit = _begin + _finish(NULL). */
+int cmx_pipeline_begin(cmx_pipeline_t*, const uint8_t* bytes, size_t nbytes, float* d_layer0);
+int cmx_pipeline_hints(cmx_pipeline_t*, float* lstm_p, int* lstm_ex);
+int cmx_pipeline_finish(cmx_pipeline_t*, const float* cols, float* d_p_out);
 /* Predictor::Pretrain over n dictionary bytes (HOST pointer), before the first submit: only the stages holding
  * `models_` learn (today: contexts + small models); mixers, SSE, LSTM and PPMd are not trained (predictor.cpp:471-487). */
 int cmx_pipeline_pretrain(cmx_pipeline_t*, const uint8_t* bytes, size_t n);

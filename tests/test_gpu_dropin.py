@@ -18,7 +18,10 @@ pytestmark = pytest.mark.gpu
 EXE = os.path.join(ROOT, "oracle", "_ref", "cmix_hybrid")
 
 
-def _run(mode, files, timeout=600):
+LOOKAHEAD = os.path.join(ROOT, "oracle", "_ref", "cmix_lookahead")
+
+
+def _run(mode, files, timeout=600, exe=None):
     with tempfile.TemporaryDirectory() as d:
         paths = []
         for name, data in files:
@@ -27,8 +30,9 @@ def _run(mode, files, timeout=600):
                 f.write(data)
             paths.append(p)
         out = os.path.join(d, "out")
-        r = subprocess.run([EXE, mode] + paths + [out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
-        assert r.returncode == 0, f"cmix_hybrid {mode} failed: {r.stderr.decode(errors='replace')[-400:]}"
+        exe = exe or EXE
+        r = subprocess.run([exe, mode] + paths + [out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+        assert r.returncode == 0, f"{os.path.basename(exe)} {mode} failed: {r.stderr.decode(errors='replace')[-400:]}"
         with open(out, "rb") as f:
             return f.read()
 
@@ -80,3 +84,36 @@ def test_50k_text_compresses_to_the_reference_binarys_file():
     got = _run("-c", [("in", synth.enwik_like(int(n), int(seed)))], timeout=900)
     assert len(got) == want_size
     assert hashlib.sha256(got).digest() == want_sha
+
+
+# ---- the look-ahead compressor: same files through the CHUNK pipeline (the path bench.py times) -----------------
+# oracle/_ref/cmix_lookahead = integration/compress_lookahead.cpp + the reference's unmodified preprocessor, paq8 and
+# fxcm objects: per 1 KB chunk cmx_pipeline_begin / _hints / _finish, the two host model families running ahead on
+# two threads with the LSTM's per-bit hints, the mixing network one chunk behind, cmx_encoder_* at the end.
+
+def _lookahead_vectors():
+    if not os.path.exists(LOOKAHEAD):
+        pytest.skip("oracle/_ref/cmix_lookahead not built (make -C oracle lookahead)")
+    return _vectors()
+
+
+def test_lookahead_no_preprocessing_file_is_byte_identical():
+    v = _lookahead_vectors()
+    assert _run("-n", [("in", v["raw_n_payload"])], exe=LOOKAHEAD) == v["raw_n_file"]  # 1205 bytes: a ragged 2nd chunk
+
+
+def test_lookahead_text_and_dictionary_files_are_byte_identical():
+    v = _lookahead_vectors()
+    assert _run("-c", [("in", v["text_c_payload"])], exe=LOOKAHEAD) == v["text_c_file"]
+    assert _run("-c", [("dict", v["dict_payload"]), ("in", v["dict_c_payload"])], exe=LOOKAHEAD) == v["dict_c_file"]
+
+
+def test_lookahead_12k_and_50k_files_are_byte_identical():
+    import hashlib
+    from cmix_amd import synth
+    v = _lookahead_vectors()
+    assert _run("-c", [("in", v["text12k_c_payload"])], exe=LOOKAHEAD) == v["text12k_c_file"]
+    with np.load(os.path.join(GOLDEN, "dropin_vectors.npz")) as z:
+        want_sha, want_size, (n, seed) = z["text50k_c_sha256"].tobytes(), int(z["text50k_c_size"][0]), z["text50k_c_seed"]
+    got = _run("-c", [("in", synth.enwik_like(int(n), int(seed)))], exe=LOOKAHEAD, timeout=900)
+    assert len(got) == want_size and hashlib.sha256(got).digest() == want_sha
