@@ -115,6 +115,9 @@ def lib():
         L.cmx_header_write.argtypes = [C.c_uint64, C.c_void_p, C.c_int, C.c_void_p]
         L.cmx_header_read.restype = C.c_size_t
         L.cmx_header_read.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cmx_pipeline_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.cmx_pipeline_hints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cmx_pipeline_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.cmx_pipeline_stage_totals.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.cmx_pipeline_pretrain.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.cmx_pipeline_sync.argtypes = [C.c_void_p]
@@ -406,6 +409,30 @@ class Pipeline:
         ms = (C.c_float * 3)()
         lib().cmx_pipeline_last_stage_ms(self.h, ms)
         return {"ctxmodels": ms[0], "lstm": ms[1], "mixnet": ms[2]}
+
+    def begin(self, data, layer0):
+        """First step of a chunk (PPMd, contexts, LSTM); up to 4 chunks may be begun and not finished."""
+        data = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8))
+        self._n_begun = getattr(self, "_n_begun", [])
+        self._n_begun.append(len(data))
+        if lib().cmx_pipeline_begin(self.h, data.ctypes.data, len(data), layer0.data_ptr()):
+            raise CmxError(last_error())
+
+    def hints(self, nbytes):
+        """The LSTM byte mixer's per-bit ByteModel::Predict value and `ex` for the oldest begun chunk (8n+1 entries)."""
+        p = np.empty(8 * nbytes + 1, np.float32)
+        ex = np.empty(8 * nbytes + 1, np.int32)
+        if lib().cmx_pipeline_hints(self.h, p.ctypes.data, ex.ctypes.data):
+            raise CmxError(last_error())
+        return p, ex
+
+    def finish(self, cols, p_out):
+        """Last step of the oldest begun chunk: host rows cols [8n, 2022] (or None) + the mixing network."""
+        if cols is not None:
+            cols = np.ascontiguousarray(cols, np.float32)
+            assert cols.shape[1] == 2022
+        if lib().cmx_pipeline_finish(self.h, cols.ctypes.data if cols is not None else None, p_out.data_ptr()):
+            raise CmxError(last_error())
 
     def stage_totals(self, reset=False):
         """Mean HIP-event ms per chunk of each stage over the chunks finished since the last reset (call after sync)."""

@@ -58,7 +58,6 @@ void CompressLookahead(Predictor* P, const std::vector<uint8_t>& data, cmx_encod
   for (size_t c = 0; c < nchunks; ++c) {
     const size_t n = len(c);
     const uint8_t* bytes = data.data() + c * C;
-    if (c + 1 < nchunks && cmx_pipeline_begin(P->pipe(), bytes + C, len(c + 1), d_layer0[(c + 1) & 3])) Predictor::Die();
     if (cmx_pipeline_hints(P->pipe(), hint_p.data(), hint_ex.data())) Predictor::Die();
     // the host model families over the chunk: Predict() then Perceive(bit) per bit, as Predictor::Predict / Perceive
     // order them (predictor.cpp:363-369,422-425,462-467); each only touches its own state and its own columns
@@ -82,6 +81,9 @@ void CompressLookahead(Predictor* P, const std::vector<uint8_t>& data, cmx_encod
         m->Perceive((bytes[t >> 3] >> (7 - (t & 7))) & 1);
       }
     }
+    // fxcm is the lighter family: while paq8 is still at it, this thread runs PPMd for the next chunk and enqueues
+    // its context stage and LSTM, whose hints are ready long before the next iteration asks for them
+    if (c + 1 < nchunks && cmx_pipeline_begin(P->pipe(), bytes + C, len(c + 1), d_layer0[(c + 1) & 3])) Predictor::Die();
     tp.join();
     if (cmx_pipeline_finish(P->pipe(), cols, d_p + 8 * c * C)) Predictor::Die();
     fprintf(stderr, "\rprogress: %.2f%%", 100.0 * (c + 1) / nchunks);

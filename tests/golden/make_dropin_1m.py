@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""SHA-256 and size of the file the unmodified reference binary writes for the first 1 MiB of the bench shard
+(synth.enwik_like(1 << 20, 1000), `cmix -c`): tests/golden/dropin_1m.npz. The parity check SURVEY.md 8d prescribes
+for 100 MB shards ("the separately compressed 1 MiB prefix file"). About 50 minutes on one core.
+
+    python tests/golden/make_dropin_1m.py [nbytes]
+"""
+import hashlib
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+if __name__ == "__main__":
+    from cmix_amd import synth
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
+    payload = synth.enwik_like(n, 1000)
+    with tempfile.TemporaryDirectory() as d:
+        a, b = os.path.join(d, "in"), os.path.join(d, "out")
+        open(a, "wb").write(payload)
+        t0 = time.time()
+        subprocess.run([os.path.join(ROOT, "oracle", "_ref", "cmix_O3"), "-c", a, b], check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        dt = time.time() - t0
+        blob = open(b, "rb").read()
+    np.savez(os.path.join(ROOT, "tests", "golden", "dropin_1m.npz"), sha256=np.frombuffer(hashlib.sha256(blob).digest(), np.uint8),
+             size=np.array([len(blob)], np.int64), seed=np.array([n, 1000], np.int64), ref_seconds=np.array([dt]))
+    print(n, "->", len(blob), "bytes in", round(dt), "s")

@@ -117,3 +117,19 @@ def test_lookahead_12k_and_50k_files_are_byte_identical():
         want_sha, want_size, (n, seed) = z["text50k_c_sha256"].tobytes(), int(z["text50k_c_size"][0]), z["text50k_c_seed"]
     got = _run("-c", [("in", synth.enwik_like(int(n), int(seed)))], exe=LOOKAHEAD, timeout=900)
     assert len(got) == want_size and hashlib.sha256(got).digest() == want_sha
+
+
+@pytest.mark.skipif(os.environ.get("CMX_LONG") != "1", reason="~6 GPU-minutes; set CMX_LONG=1")
+def test_lookahead_1mib_shard_prefix_is_byte_identical():
+    """The parity check SURVEY.md 8d prescribes for 100 MB shards: the first 1 MiB of the bench shard
+    (synth.enwik_like(1 << 20, 1000)) compressed on its own; size and SHA-256 of the reference binary's file are the
+    fixture (tests/golden/make_dropin_1m.py, ~50 CPU-minutes)."""
+    import hashlib
+    from cmix_amd import synth
+    path = os.path.join(GOLDEN, "dropin_1m.npz")
+    if not os.path.exists(path) or not os.path.exists(LOOKAHEAD):
+        pytest.skip("fixture or oracle/_ref/cmix_lookahead missing")
+    with np.load(path) as z:
+        want_sha, want_size, (n, seed) = z["sha256"].tobytes(), int(z["size"][0]), z["seed"]
+    got = _run("-c", [("in", synth.enwik_like(int(n), int(seed)))], exe=LOOKAHEAD, timeout=1500)
+    assert len(got) == want_size and hashlib.sha256(got).digest() == want_sha

@@ -158,6 +158,40 @@ def test_compress_stream_reproduces_the_reference_file():
     assert length == len(stream) and (np.packbits(bits) == stream).all()
 
 
+def test_native_pipeline_in_steps_with_host_columns():
+    """cmx_pipeline_begin / _hints / _finish (look-ahead coding with fxcm/paq8 on the host): two chunks begun before
+    the first is finished; the hints are the LSTM column of the trace (plus the first bit after the chunk), the
+    fxcm/paq8 columns go in from HOST memory, and p equals Predictor::Predict() bit for bit."""
+    import torch
+    from cmix_amd import engine as E
+    g = load_golden("text_96")
+    stream = np.ascontiguousarray(g["stream"])
+    N, A = len(stream), 40
+    ref = mg.unpack_probs(g)
+    layer0 = torch.full((8 * N, 2078), float("nan"), dtype=torch.float32, device="cuda")
+    p = torch.full((8 * N,), -1.0, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    pipe = E.Pipeline(g["vocab"], 0, max_chunk_bytes=64)
+    pipe.begin(stream[:A].tobytes(), layer0[:8 * A])
+    pipe.begin(stream[A:].tobytes(), layer0[8 * A:])
+    hp, hx = pipe.hints(A)
+    assert bits_equal(hp, ref[:8 * A + 1, 2077]).all()  # entry 8A = first bit of the next chunk
+    pipe.finish(ref[:8 * A, 3:2025], p[:8 * A])
+    hp2, hx2 = pipe.hints(N - A)
+    assert bits_equal(hp2[:-1], ref[8 * A:, 2077]).all()
+    assert ((hx >= 0) & (hx < 256)).all() and ((hx2 >= 0) & (hx2 < 256)).all()
+    pipe.finish(ref[8 * A:, 3:2025], p[8 * A:])
+    pipe.sync()
+    got = layer0.cpu().numpy()
+    assert bits_equal(got, ref).all()
+    assert bits_equal(p.cpu().numpy(), g["p_final"]).all()
+    with pytest.raises(E.CmxError, match="no begun chunk"):
+        pipe.finish(None, p[:8])
+    with pytest.raises(E.CmxError, match="no begun chunk is waiting"):
+        pipe.hints(1)
+    pipe.close()
+
+
 def test_native_pipeline_bad_args():
     from cmix_amd import engine as E
     pipe = E.Pipeline(np.ones(256, np.uint8), 0, max_chunk_bytes=16)
