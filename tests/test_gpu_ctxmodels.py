@@ -170,3 +170,22 @@ def test_peek_is_exact_and_leaves_no_trace():
     assert committed == b.slow_bytes()[0] and dry == committed and committed >= 3, (committed, dry)
     a.close()
     b.close()
+
+
+def test_vs_oracle_fuzz_flavours():
+    """The 8 adversarial stream flavours of tests/golden/fuzz_vs_reference.py (high bytes, 99+ character lines, bracket
+    stacks past every limit, long exact repeats, byte runs, random, tiny alphabet, text) x 2 seeds, ragged chunks,
+    against the C oracle -- which that script pins against the reference on the very same streams."""
+    from oracle import oracle as O
+    import fuzz_vs_reference as fz
+    for seed in range(16):
+        data, name = fz.make_stream(seed)
+        vocab = np.ones(256, np.uint8)
+        orc = O.CtxModels(vocab)
+        want_p, want_s = orc.run(data)
+        p, s, _ = _run_gpu(vocab, data, chunks=[1, 7, 300, 301])
+        bad = np.argwhere(~bits_equal(p, want_p))
+        assert len(bad) == 0, f"seed {seed} ({name}): model {bad[0][1]} (col {COLS[bad[0][1]]}) differs first at bit {bad[0][0]}"
+        ws = (want_s & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        bad = np.argwhere(s != ws)
+        assert len(bad) == 0, f"seed {seed} ({name}): selector {bad[0][1]} differs first at bit {bad[0][0]}"
