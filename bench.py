@@ -132,6 +132,8 @@ def main():
     a = ap.parse_args()
     if a.streams_per_gpu > 1:  # persistent stage kernels pin hardware queues: give every stream's stages their own
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+        if a.streams_per_gpu > 5:  # ~16 queues run unsliced (profiles/r01_multiproc.txt): two HIP streams per pipeline
+            os.environ.setdefault("CMX_PIPELINE_STREAMS", "2")
 
     import torch
     import torch.distributed as dist
