@@ -29,6 +29,7 @@ if __name__ == "__main__":
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         dt = time.time() - t0
         blob = open(b, "rb").read()
-    np.savez(os.path.join(ROOT, "tests", "golden", "dropin_1m.npz"), sha256=np.frombuffer(hashlib.sha256(blob).digest(), np.uint8),
+    name = "dropin_1m.npz" if n == 1 << 20 else "dropin_%dk.npz" % (n >> 10)
+    np.savez(os.path.join(ROOT, "tests", "golden", name), sha256=np.frombuffer(hashlib.sha256(blob).digest(), np.uint8),
              size=np.array([len(blob)], np.int64), seed=np.array([n, 1000], np.int64), ref_seconds=np.array([dt]))
     print(n, "->", len(blob), "bytes in", round(dt), "s")
