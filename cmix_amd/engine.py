@@ -97,6 +97,11 @@ def lib():
         L.cmx_debug_last_row.argtypes = [C.c_void_p]
         L.cmx_ctxmodels_debug_slow_bytes.argtypes = [C.c_void_p, C.c_void_p]
         L.cmx_ctxmodels_peek.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.cmx_p8mixer_create.restype = C.c_void_p
+        L.cmx_p8mixer_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.cmx_p8mixer_destroy.argtypes = [C.c_void_p]
+        L.cmx_p8mixer_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]
         L.cmx_encoder_create.restype = C.c_void_p
         L.cmx_encoder_destroy.argtypes = [C.c_void_p]
         L.cmx_encoder_encode_bits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
@@ -620,6 +625,40 @@ class Predictor:
     def close(self):
         if self.h:
             lib().cmx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+
+class P8Mixer:
+    """paq8's two-layer int16 mixer over a chunk of known bits (building block of the paq8 stage, SURVEY.md 8a')."""
+
+    def __init__(self, total_rows, squash4096, stretch4096, device=0):
+        sq = np.ascontiguousarray(squash4096, np.int16)
+        st = np.ascontiguousarray(stretch4096, np.int16)
+        assert sq.shape == (4096,) and st.shape == (4096,)
+        self.h = lib().cmx_p8mixer_create(device, int(total_rows), sq.ctypes.data, st.ctypes.data)
+        if not self.h:
+            raise CmxError(last_error())
+
+    def run(self, x, rows, bits, want_pr=False, stream=None):
+        """x [T,1552] i16, rows [T,28] i32, bits [T] u8 (cuda) -> p [T] i32 (and pr [T,28])."""
+        import torch
+        T = int(bits.numel())
+        assert x.dtype == torch.int16 and tuple(x.shape) == (T, 1552) and x.is_contiguous()
+        assert rows.dtype == torch.int32 and tuple(rows.shape) == (T, 28) and rows.is_contiguous()
+        p = torch.empty(T, dtype=torch.int32, device=x.device)
+        pr = torch.empty((T, 28), dtype=torch.int32, device=x.device) if want_pr else None
+        if stream is None:
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+        if lib().cmx_p8mixer_run(self.h, x.data_ptr(), rows.data_ptr(), bits.data_ptr(), T, p.data_ptr(),
+                                 pr.data_ptr() if want_pr else None, C.c_void_p(stream)):
+            raise CmxError(last_error())
+        return p, pr
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().cmx_p8mixer_destroy(self.h)
             self.h = None
 
     __del__ = close

@@ -209,6 +209,22 @@ int cmx_ctxmodels_sync(cmx_ctxmodels_t*);
 /* Test hook: ContextManager registers (25), byte contexts (54), bit contexts (8) between bytes. */
 int cmx_ctxmodels_get_manager(cmx_ctxmodels_t*, uint64_t* regs25, uint64_t* ctx54, uint64_t* bitctx8);
 
+/* ------------------------------------------------------------------------
+ * 2e. Building block of the paq8 / fxcm stages (not yet wired into a stage): paq8's two-layer int16 mixer
+ *     (src/models/paq8.cpp:513-598, dot_product / train :403-432) over a chunk of known bits. DEVICE pointers:
+ *       d_x    [nbits][1552] i16  the values Mixer::add() receives for the bit (stretch domain), in call order
+ *       d_rows [nbits][28]   i32  weight-set selectors as Mixer::set() leaves them (cumulative base + cx)
+ *       d_bits [nbits]       u8
+ *       d_p    [nbits]       i32  OUT Mixer::p() (12-bit probability)
+ *       d_pr   [nbits][28]   i32  OUT (may be NULL) the first layer's squashed outputs
+ *     squash4096[d + 2048] = squash(d), stretch4096[p] = stretch(p): paq8's two tables (HOST, copied once).
+ * ------------------------------------------------------------------------ */
+typedef struct cmx_p8mixer cmx_p8mixer_t;
+cmx_p8mixer_t* cmx_p8mixer_create(int device, int total_rows, const int16_t squash4096[4096], const int16_t stretch4096[4096]);
+void cmx_p8mixer_destroy(cmx_p8mixer_t*);
+int cmx_p8mixer_run(cmx_p8mixer_t*, const int16_t* d_x, const int* d_rows, const uint8_t* d_bits, size_t nbits, int* d_p,
+                    int* d_pr, void* stream);
+
 /* ---- callers of the path: arithmetic coder + container header (HOST code) -------------------------------------
  * Replaces Encoder::Encode/Flush (src/coder/encoder.cpp:10-39), Decoder::Decoder/Decode (src/coder/decoder.cpp:3-39)
  * and WriteHeader/ReadHeader (src/runner.cpp:34-84). The probabilities are the p[] a pipeline chunk produced

@@ -51,6 +51,19 @@ def lib():
         L.orc_coder_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
         L.orc_header_write.restype = C.c_size_t
         L.orc_header_write.argtypes = [C.c_uint64, C.c_void_p, C.c_int, C.c_void_p]
+        for name in ("orc_p8_mixer_new", "orc_p8_apm1_new", "orc_p8_statemap_new", "orc_p8_statemap32_new", "orc_p8_apm_new"):
+            getattr(L, name).restype = C.c_void_p
+        L.orc_p8_mixer_new.argtypes = [C.c_int] * 4
+        L.orc_p8_mixer_free.argtypes = [C.c_void_p]
+        L.orc_p8_mixer_step.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_void_p, C.c_void_p]
+        L.orc_p8_apm1_new.argtypes = [C.c_int]
+        L.orc_p8_apm1_p.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_p8_statemap_p.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_p8_statemap32_new.argtypes = [C.c_int]
+        L.orc_p8_statemap32_p.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.orc_p8_apm_new.argtypes = [C.c_int]
+        L.orc_p8_apm_p.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_lstm_create.restype = C.c_void_p
         L.orc_lstm_create.argtypes = [C.c_void_p, C.c_int]
         L.orc_lstm_destroy.argtypes = [C.c_void_p]

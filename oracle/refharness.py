@@ -179,3 +179,31 @@ def ref_decode(p, code):
         f.flush()
         assert _coder_lib().refcoder_decode(p.ctypes.data, len(p), f.name.encode(), bits.ctypes.data) == 0
     return bits
+
+
+PAQ8_LIB_PATH = os.path.join(HERE, "_ref", "libcmixrefpaq8.so")
+
+
+def paq8core_available():
+    return os.path.exists(PAQ8_LIB_PATH)
+
+
+def paq8core_lib():
+    """The reference's own paq8 building blocks (oracle/ref_paq8core.cpp)."""
+    L = C.CDLL(PAQ8_LIB_PATH)
+    for name in ("refp8_mixer_new", "refp8_apm1_new", "refp8_statemap_new", "refp8_statemap32_new", "refp8_apm_new"):
+        getattr(L, name).restype = C.c_void_p
+    L.refp8_tables.argtypes = [C.c_void_p] * 4
+    L.refp8_mixer_new.argtypes = [C.c_int] * 4
+    L.refp8_mixer_free.argtypes = [C.c_void_p]
+    L.refp8_mixer_step.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                   C.c_void_p, C.c_void_p]
+    L.refp8_apm1_new.argtypes = [C.c_int]
+    L.refp8_apm1_p.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.refp8_statemap_p.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.refp8_statemap32_new.argtypes = [C.c_int]
+    L.refp8_statemap32_p.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.refp8_apm_new.argtypes = [C.c_int]
+    L.refp8_apm_p.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.refp8_init_dt()
+    return L

@@ -1,0 +1,136 @@
+"""CPU: the restated numeric building blocks of the vendored paq8 model (oracle/paq8_core.c: two-layer int16 mixer with
+dot_product/train, APM1, StateMap, StateMap32, APM; SURVEY.md 8a') against the reference's own classes compiled from
+paq8.cpp (oracle/ref_paq8core.cpp -> oracle/_ref/libcmixrefpaq8.so) and against committed vectors produced from them
+(tests/golden/paq8core_vectors.npz, tests/golden/make_paq8core_vectors.py). Integer work: bit-exact."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import oracle as O
+from oracle import refharness as R
+
+needs_ref = pytest.mark.skipif(not R.paq8core_available(), reason="oracle/_ref/libcmixrefpaq8.so not built")
+
+
+def mixer_case(seed, n, m, s, steps):
+    """Seeded drive of a mixer: stretch-domain inputs, selectors with locality, bits correlated with the prediction."""
+    rng = np.random.default_rng(seed)
+    ranges = rng.integers(1, max(2, m // s), s).astype(np.int32)
+    ranges[-1] = max(1, m - int(ranges[:-1].sum()) - 1) if ranges[:-1].sum() < m - 1 else 1
+    while ranges.sum() > m:
+        ranges[np.argmax(ranges)] //= 2
+    ranges = np.maximum(ranges, 1)
+    xs = np.clip(rng.normal(0, 600, (steps, n)), -2047, 2047).astype(np.int16)
+    xs[rng.random((steps, n)) < 0.02] = 32767          # saturation paths of train (2t overflows 16 bits)
+    xs[rng.random((steps, n)) < 0.02] = -32768
+    cx = np.zeros((steps, s), np.int32)
+    cur = rng.integers(0, ranges)
+    for t in range(steps):
+        move = rng.random(s) < 0.3
+        cur = np.where(move, rng.integers(0, ranges), cur)
+        cx[t] = cur
+    return ranges, xs, cx, rng
+
+
+def run_mixer(step_fn, handle, ranges, xs, cx, rng_bits):
+    steps, n = xs.shape
+    s = len(ranges)
+    out_p = np.zeros(steps, np.int32)
+    exported = np.zeros((steps, n + s + 8), np.float32)
+    nexp = C.c_int(0)
+    y = 0
+    for t in range(steps):
+        p = step_fn(handle, y, xs[t].ctypes.data, n, cx[t].ctypes.data, ranges.ctypes.data, s,
+                    exported[t].ctypes.data, C.byref(nexp))
+        out_p[t] = p
+        y = int(rng_bits[t] < p / 4096.0)
+    return out_p, exported[:, :nexp.value], nexp.value
+
+
+@needs_ref
+def test_tables_match_the_reference():
+    L = R.paq8core_lib()
+    sq, st = np.zeros(4096, np.int16), np.zeros(4096, np.int16)
+    dt, stt = np.zeros(1024, np.int32), np.zeros(1024, np.uint8)
+    L.refp8_tables(sq.ctypes.data, st.ctypes.data, dt.ctypes.data, stt.ctypes.data)
+    lib = O.lib()
+    assert [lib.orc_p8_squash(d) for d in range(-2300, 2300)] == [int(sq[min(max(d, -2048), 2047) + 2048]) if -2047 <= d <= 2047
+                                                                   else (4095 if d > 2047 else 0) for d in range(-2300, 2300)]
+    assert [lib.orc_p8_stretch(p) for p in range(4096)] == [int(v) for v in st]
+
+
+@needs_ref
+@pytest.mark.parametrize("n,m,s,w,steps", [(1552, 77472, 28, 32, 400), (64, 300, 5, 32, 3000), (8, 1, 1, 0x7fff, 2000)])
+def test_mixer_vs_reference(n, m, s, w, steps):
+    L, lib = R.paq8core_lib(), O.lib()
+    ranges, xs, cx, rng = mixer_case(11 + n, n, m, s, steps)
+    bits = rng.random(steps)
+    ref = L.refp8_mixer_new(n, m, s, w)
+    got = lib.orc_p8_mixer_new(n, m, s, w)
+    p_ref, e_ref, k_ref = run_mixer(L.refp8_mixer_step, ref, ranges, xs, cx, bits)
+    p_got, e_got, k_got = run_mixer(lib.orc_p8_mixer_step, got, ranges, xs, cx, bits)
+    assert k_ref == k_got == n + (s + 0 if s > 1 else 0)
+    bad = np.nonzero(p_ref != p_got)[0]
+    assert len(bad) == 0, f"mixer output differs first at step {bad[0]}: {p_ref[bad[0]]} vs {p_got[bad[0]]}"
+    assert (e_ref.view(np.uint32) == e_got.view(np.uint32)).all()
+    assert len(np.unique(p_ref)) > steps // 20  # the drive exercises the mixer
+    L.refp8_mixer_free(ref)
+    lib.orc_p8_mixer_free(got)
+
+
+def _adaptive_case(seed, steps, ncx):
+    rng = np.random.default_rng(seed)
+    pr = rng.integers(0, 4096, steps).astype(np.int32)
+    cx = rng.integers(0, ncx, steps).astype(np.int32)
+    cx[rng.random(steps) < 0.7] = 3                     # one hot context so that counts climb to their limits
+    y = (rng.random(steps) < pr / 4096.0).astype(np.int32)
+    return pr, cx, y
+
+
+@needs_ref
+def test_apm1_statemap_statemap32_apm_vs_reference():
+    L, lib = R.paq8core_lib(), O.lib()
+    steps = 20000
+    pr, cx, y = _adaptive_case(5, steps, 1 << 10)
+    a_ref, a_got = L.refp8_apm1_new(1 << 10), lib.orc_p8_apm1_new(1 << 10)
+    for rate in (7, 6):
+        r = [L.refp8_apm1_p(a_ref, int(y[t]), int(pr[t]), int(cx[t]), rate) for t in range(steps)]
+        g = [lib.orc_p8_apm1_p(a_got, int(y[t]), int(pr[t]), int(cx[t]), rate) for t in range(steps)]
+        assert r == g
+    s_ref, s_got = L.refp8_statemap_new(), lib.orc_p8_statemap_new()
+    assert [L.refp8_statemap_p(s_ref, int(y[t]), int(cx[t]) & 255) for t in range(steps)] == \
+           [lib.orc_p8_statemap_p(s_got, int(y[t]), int(cx[t]) & 255) for t in range(steps)]
+    for n, limit in ((256, 1023), (1 << 16, 1023), (1 << 10, 127)):
+        q_ref, q_got = L.refp8_statemap32_new(n), lib.orc_p8_statemap32_new(n)
+        assert [L.refp8_statemap32_p(q_ref, int(y[t]), int(cx[t]) % n, limit) for t in range(steps)] == \
+               [lib.orc_p8_statemap32_p(q_got, int(y[t]), int(cx[t]) % n, limit) for t in range(steps)]
+    for limit in (0xFF, 0x3FF >> 2, 0x3FF):
+        p_ref, p_got = L.refp8_apm_new(1 << 10), lib.orc_p8_apm_new(1 << 10)
+        assert [L.refp8_apm_p(p_ref, int(y[t]), int(pr[t]), int(cx[t]), limit) for t in range(steps)] == \
+               [lib.orc_p8_apm_p(p_got, int(y[t]), int(pr[t]), int(cx[t]), limit) for t in range(steps)]
+
+
+def test_golden_vectors():
+    """The same drives, recorded from the reference (runs wherever the fixture is, oracle/_ref not needed)."""
+    path = os.path.join(GOLDEN, "paq8core_vectors.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/paq8core_vectors.npz not generated yet")
+    lib = O.lib()
+    with np.load(path) as z:
+        v = {k: z[k] for k in z.files}
+    n, m, s, w, steps = (int(x) for x in v["mixer_shape"])
+    ranges, xs, cx, rng = mixer_case(int(v["mixer_seed"][0]), n, m, s, steps)
+    bits = rng.random(steps)
+    got = lib.orc_p8_mixer_new(n, m, s, w)
+    p_got, e_got, _ = run_mixer(lib.orc_p8_mixer_step, got, ranges, xs, cx, bits)
+    assert (p_got == v["mixer_p"]).all() and (e_got[-1].view(np.uint32) == v["mixer_exported_last"].view(np.uint32)).all()
+    pr, cx1, y = _adaptive_case(5, len(v["apm1_p"]), 1 << 10)
+    a = lib.orc_p8_apm1_new(1 << 10)
+    assert [lib.orc_p8_apm1_p(a, int(y[t]), int(pr[t]), int(cx1[t]), 7) for t in range(len(pr))] == list(v["apm1_p"])
+    q = lib.orc_p8_apm_new(1 << 10)
+    assert [lib.orc_p8_apm_p(q, int(y[t]), int(pr[t]), int(cx1[t]), 0xFF) for t in range(len(pr))] == list(v["apm_p"])
+    sm = lib.orc_p8_statemap32_new(256)
+    assert [lib.orc_p8_statemap32_p(sm, int(y[t]), int(cx1[t]) & 255, 1023) for t in range(len(pr))] == list(v["sm32_p"])
