@@ -64,6 +64,23 @@ def lib():
         L.orc_p8_statemap32_p.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.orc_p8_apm_new.argtypes = [C.c_int]
         L.orc_p8_apm_p.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_p8_cm2_new.restype = C.c_void_p
+        L.orc_p8_cm2_new.argtypes = [C.c_uint64, C.c_uint32]
+        L.orc_p8_cm2_free.argtypes = [C.c_void_p]
+        L.orc_p8_cm2_step.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_p8_dmap_new.restype = C.c_void_p
+        L.orc_p8_dmap_new.argtypes = [C.c_int] * 4
+        L.orc_p8_dmap_set_direct.argtypes = [C.c_void_p, C.c_uint32]
+        L.orc_p8_dmap_set.argtypes = [C.c_void_p, C.c_uint64]
+        L.orc_p8_dmap_mix.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_p8_hash2.restype = C.c_uint64
+        L.orc_p8_hash2.argtypes = [C.c_uint64, C.c_uint64]
+        L.orc_p8_combine64.restype = C.c_uint64
+        L.orc_p8_combine64.argtypes = [C.c_uint64, C.c_uint64]
+        L.orc_p8_finalize64.restype = C.c_uint32
+        L.orc_p8_finalize64.argtypes = [C.c_uint64, C.c_int]
+        L.orc_p8_checksum64.restype = C.c_uint64
+        L.orc_p8_checksum64.argtypes = [C.c_uint64, C.c_int, C.c_int]
         L.orc_lstm_create.restype = C.c_void_p
         L.orc_lstm_create.argtypes = [C.c_void_p, C.c_int]
         L.orc_lstm_destroy.argtypes = [C.c_void_p]

@@ -37,7 +37,21 @@
 
 char* dictionary_path = NULL;  // referenced by other reference objects' externs; unused here
 
+// Mixer's members are private by default (no access keyword to widen): pointers to them are taken through explicit
+// template instantiation, which is exempt from access checking.
+namespace {
+template <typename Tag, typename Tag::type M> struct Rob { friend typename Tag::type get(Tag) { return M; } };
+struct MixerNx { typedef int paq8::Mixer::*type; friend type get(MixerNx); };
+struct MixerTx { typedef paq8::Array<short, 16> paq8::Mixer::*type; friend type get(MixerTx); };
+template struct Rob<MixerNx, &paq8::Mixer::nx>;
+template struct Rob<MixerTx, &paq8::Mixer::tx>;
+}  // namespace
+
 extern "C" {
+
+void refp8_ilog_table(uint8_t* out65536) {
+  for (int i = 0; i < 65536; ++i) out65536[i] = (uint8_t)paq8::ilog((paq8::U16)i);
+}
 
 void refp8_tables(int16_t* squash4096, int16_t* stretch4096, int32_t* dt1024, uint8_t* state_table_256x4) {
   for (int i = 0; i < 4096; ++i) squash4096[i] = (int16_t)paq8::squash(i - 2048);
@@ -78,5 +92,64 @@ void* refp8_statemap32_new(int n) { return new paq8::StateMap32(n); }
 int refp8_statemap32_p(void* h, int y_prev, int cx, int limit) { paq8::y = y_prev; return ((paq8::StateMap32*)h)->p(cx, limit); }
 void* refp8_apm_new(int n) { return new paq8::APM(n); }
 int refp8_apm_p(void* h, int y_prev, int pr, int cx, int limit) { paq8::y = y_prev; return ((paq8::APM*)h)->p(pr, cx, limit); }
+
+
+// ---- the models below hand their outputs to a Mixer through add(): a recording mixer collects them ----
+static paq8::Mixer* sink() {
+  static paq8::Mixer* m = new paq8::Mixer(4096, 1, 1, 0);
+  return m;
+}
+static int drain(int16_t* out) {
+  paq8::Mixer* m = sink();
+  int& nx = m->*get(MixerNx());
+  paq8::Array<short, 16>& tx = m->*get(MixerTx());
+  const int n = nx;
+  for (int i = 0; i < n; ++i) out[i] = tx[i];
+  nx = 0;
+  paq8::ResetPredictions();
+  return n;
+}
+
+// ContextMap2 (:1164-1358): one coded bit. At bpos == 0 the nset byte contexts are handed to set() first.
+void* refp8_cm2_new(uint64_t size_bytes, uint32_t count) { return new paq8::ContextMap2(size_bytes, count); }
+void refp8_cm2_free(void* h) { delete (paq8::ContextMap2*)h; }
+int refp8_cm2_step(void* h, int y_prev, int bpos, const uint64_t* ctx, int nset, int16_t* out, int* nout) {
+  paq8::y = y_prev;
+  paq8::bpos = bpos;
+  paq8::ContextMap2& cm = *(paq8::ContextMap2*)h;
+  if (bpos == 0) for (int i = 0; i < nset; ++i) cm.set(ctx[i]);
+  const int r = cm.mix(*sink());
+  *nout = drain(out);
+  return r;
+}
+
+// SmallStationaryContextMap (:891-933), StationaryMap (:935-974), IndirectMap (:976-1008)
+void* refp8_sscm_new(int boc, int bpc) { return new paq8::SmallStationaryContextMap(boc, bpc); }
+void refp8_sscm_set(void* h, uint32_t ctx) { ((paq8::SmallStationaryContextMap*)h)->set(ctx); }
+int refp8_sscm_mix(void* h, int y_prev, int rate, int mul, int div, int16_t* out) {
+  paq8::y = y_prev;
+  ((paq8::SmallStationaryContextMap*)h)->mix(*sink(), rate, mul, div);
+  return drain(out);
+}
+void* refp8_smap_new(int boc, int bpc, int rate) { return new paq8::StationaryMap(boc, bpc, rate); }
+void refp8_smap_set_direct(void* h, uint32_t ctx) { ((paq8::StationaryMap*)h)->set_direct(ctx); }
+void refp8_smap_set(void* h, uint64_t ctx) { ((paq8::StationaryMap*)h)->set(ctx); }
+int refp8_smap_mix(void* h, int y_prev, int mul, int div, int limit, int16_t* out) {
+  paq8::y = y_prev;
+  ((paq8::StationaryMap*)h)->mix(*sink(), mul, div, (paq8::U16)limit);
+  return drain(out);
+}
+void* refp8_imap_new(int boc, int bpc) { return new paq8::IndirectMap(boc, bpc); }
+void refp8_imap_set_direct(void* h, uint32_t ctx) { ((paq8::IndirectMap*)h)->set_direct(ctx); }
+void refp8_imap_set(void* h, uint64_t ctx) { ((paq8::IndirectMap*)h)->set(ctx); }
+int refp8_imap_mix(void* h, int y_prev, int mul, int div, int limit, int16_t* out) {
+  paq8::y = y_prev;
+  ((paq8::IndirectMap*)h)->mix(*sink(), mul, div, (paq8::U16)limit);
+  return drain(out);
+}
+uint64_t refp8_hash2(uint64_t a, uint64_t b) { return paq8::hash(a, b); }
+uint64_t refp8_combine64(uint64_t seed, uint64_t x) { return paq8::combine64(seed, x); }
+uint32_t refp8_finalize64(uint64_t h, int bits) { return paq8::finalize64(h, bits); }
+uint64_t refp8_checksum64(uint64_t h, int hashbits, int checksumbits) { return paq8::checksum64(h, hashbits, checksumbits); }
 
 }  // extern "C"

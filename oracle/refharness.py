@@ -205,5 +205,27 @@ def paq8core_lib():
     L.refp8_statemap32_p.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.refp8_apm_new.argtypes = [C.c_int]
     L.refp8_apm_p.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.refp8_ilog_table.argtypes = [C.c_void_p]
+    L.refp8_cm2_new.restype = C.c_void_p
+    L.refp8_cm2_new.argtypes = [C.c_uint64, C.c_uint32]
+    L.refp8_cm2_free.argtypes = [C.c_void_p]
+    L.refp8_cm2_step.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    for name in ("refp8_sscm_new", "refp8_smap_new", "refp8_imap_new"):
+        getattr(L, name).restype = C.c_void_p
+    L.refp8_sscm_new.argtypes = [C.c_int, C.c_int]
+    L.refp8_sscm_set.argtypes = [C.c_void_p, C.c_uint32]
+    L.refp8_sscm_mix.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.refp8_smap_new.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.refp8_smap_set_direct.argtypes = [C.c_void_p, C.c_uint32]
+    L.refp8_smap_set.argtypes = [C.c_void_p, C.c_uint64]
+    L.refp8_smap_mix.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.refp8_imap_new.argtypes = [C.c_int, C.c_int]
+    L.refp8_imap_set_direct.argtypes = [C.c_void_p, C.c_uint32]
+    L.refp8_imap_set.argtypes = [C.c_void_p, C.c_uint64]
+    L.refp8_imap_mix.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    for name, rt, at in (("refp8_hash2", C.c_uint64, [C.c_uint64, C.c_uint64]), ("refp8_combine64", C.c_uint64, [C.c_uint64, C.c_uint64]),
+                         ("refp8_finalize64", C.c_uint32, [C.c_uint64, C.c_int]), ("refp8_checksum64", C.c_uint64, [C.c_uint64, C.c_int, C.c_int])):
+        getattr(L, name).restype = rt
+        getattr(L, name).argtypes = at
     L.refp8_init_dt()
     return L

@@ -134,3 +134,102 @@ def test_golden_vectors():
     assert [lib.orc_p8_apm_p(q, int(y[t]), int(pr[t]), int(cx1[t]), 0xFF) for t in range(len(pr))] == list(v["apm_p"])
     sm = lib.orc_p8_statemap32_new(256)
     assert [lib.orc_p8_statemap32_p(sm, int(y[t]), int(cx1[t]) & 255, 1023) for t in range(len(pr))] == list(v["sm32_p"])
+
+
+# ---- context-to-prediction structures (oracle/paq8_maps.c) -----------------------------------------------------
+
+def _byte_contexts(data, n, count):
+    """contextModel2's order-N hashes of the bytes before position n (paq8.cpp:8139-8153): combine64 chains."""
+    lib = O.lib()
+    cx = [0] * count
+    h = 0
+    for k in range(count):
+        b = data[n - 1 - k] if n - 1 - k >= 0 else 0
+        h = lib.orc_p8_combine64(h, int(b))
+        cx[k] = h
+    return np.array(cx, np.uint64)
+
+
+@needs_ref
+def test_hash_helpers_and_ilog_vs_reference():
+    L, lib = R.paq8core_lib(), O.lib()
+    rng = np.random.default_rng(3)
+    for _ in range(2000):
+        a, b = (int(v) for v in rng.integers(0, 1 << 63, 2, dtype=np.uint64))
+        assert lib.orc_p8_hash2(a, b) == L.refp8_hash2(a, b) and lib.orc_p8_combine64(a, b) == L.refp8_combine64(a, b)
+        for bits in (12, 16, 22):
+            assert lib.orc_p8_finalize64(a, bits) == L.refp8_finalize64(a, bits)
+            assert lib.orc_p8_checksum64(a, bits, 16) == L.refp8_checksum64(a, bits, 16)
+    t = np.zeros(65536, np.uint8)
+    L.refp8_ilog_table(t.ctypes.data)
+    lib.orc_p8_ilog.argtypes = [C.c_int]
+    assert [lib.orc_p8_ilog(i) for i in range(65536)] == [int(v) for v in t]
+
+
+@needs_ref
+@pytest.mark.parametrize("size_bytes,count,nbytes", [(1 << 16, 10, 6000), (1 << 22, 6, 6000)])
+def test_contextmap2_vs_reference(size_bytes, count, nbytes):
+    """Order-1..N contexts over text-like bytes; the small table forces bucket replacement (Find's priority rule, the
+    MRU pair) all the time, the large one lets byte histories and run statistics mature."""
+    from cmix_amd import synth
+    L, lib = R.paq8core_lib(), O.lib()
+    data = np.frombuffer(synth.enwik_like(nbytes, 13), np.uint8)
+    ref, got = L.refp8_cm2_new(size_bytes, count), lib.orc_p8_cm2_new(size_bytes, count)
+    o_ref, o_got = np.zeros(256, np.int16), np.zeros(256, np.int16)
+    n_ref, n_got = C.c_int(0), C.c_int(0)
+    y = 0
+    for n in range(nbytes):
+        cx = _byte_contexts(data, n, count)
+        for bpos in range(8):
+            r = L.refp8_cm2_step(ref, y, bpos, cx.ctypes.data, count, o_ref.ctypes.data, C.byref(n_ref))
+            g = lib.orc_p8_cm2_step(got, y, bpos, cx.ctypes.data, count, o_got.ctypes.data, C.byref(n_got))
+            assert r == g and n_ref.value == n_got.value == 7 * count, (n, bpos, r, g, n_ref.value, n_got.value)
+            assert (o_ref[:n_ref.value] == o_got[:n_got.value]).all(), f"byte {n} bit {bpos}: {o_ref[:70]} vs {o_got[:70]}"
+            y = (int(data[n]) >> (7 - bpos)) & 1
+    L.refp8_cm2_free(ref)
+    lib.orc_p8_cm2_free(got)
+
+
+@needs_ref
+def test_direct_lookup_maps_vs_reference():
+    L, lib = R.paq8core_lib(), O.lib()
+    rng = np.random.default_rng(8)
+    nbytes = 4000
+    data = rng.integers(0, 4, nbytes) * 37 % 256
+    o_ref, o_got = np.zeros(8, np.int16), np.zeros(8, np.int16)
+    cases = [("sscm", 0, (11, 8, 0), (7, 1, 4)), ("sscm", 0, (8, 1, 0), (6, 3, 2)),
+             ("smap", 1, (16, 8, 0), (1023, 1, 4)), ("smap", 1, (10, 3, 200), (255, 2, 1)),
+             ("imap", 2, (12, 8, 0), (1023, 1, 4)), ("imap", 2, (9, 2, 0), (127, 3, 2))]
+    for name, kind, (boc, bpc, rate), (a, mul, div) in cases:
+        if name == "sscm":
+            ref = L.refp8_sscm_new(boc, bpc)
+        elif name == "smap":
+            ref = L.refp8_smap_new(boc, bpc, rate)
+        else:
+            ref = L.refp8_imap_new(boc, bpc)
+        got = lib.orc_p8_dmap_new(kind, boc, bpc, rate)
+        y, bit_in_ctx = 0, 0
+        for n in range(nbytes):
+            for bpos in range(8):
+                if bit_in_ctx == 0:  # a new context every bpc bits
+                    ctx = int(rng.integers(0, 1 << 20)) if n % 3 else 5
+                    if name == "sscm":
+                        L.refp8_sscm_set(ref, ctx)
+                    elif name == "smap":
+                        L.refp8_smap_set_direct(ref, ctx) if n % 2 else L.refp8_smap_set(ref, ctx * 0x9E3779B97F4A7C15 % (1 << 64))
+                    else:
+                        L.refp8_imap_set_direct(ref, ctx) if n % 2 else L.refp8_imap_set(ref, ctx * 0x9E3779B97F4A7C15 % (1 << 64))
+                    if name == "sscm" or n % 2:
+                        lib.orc_p8_dmap_set_direct(got, ctx)
+                    else:
+                        lib.orc_p8_dmap_set(got, ctx * 0x9E3779B97F4A7C15 % (1 << 64))
+                if name == "sscm":
+                    k = L.refp8_sscm_mix(ref, y, a, mul, div, o_ref.ctypes.data)
+                elif name == "smap":
+                    k = L.refp8_smap_mix(ref, y, mul, div, a, o_ref.ctypes.data)
+                else:
+                    k = L.refp8_imap_mix(ref, y, mul, div, a, o_ref.ctypes.data)
+                assert lib.orc_p8_dmap_mix(got, y, a, mul, div, o_got.ctypes.data) == k == 2
+                assert (o_ref[:2] == o_got[:2]).all(), (name, boc, bpc, n, bpos, o_ref[:2], o_got[:2])
+                y = (int(data[n]) >> (7 - bpos)) & 1
+                bit_in_ctx = (bit_in_ctx + 1) % bpc
