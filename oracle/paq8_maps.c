@@ -297,3 +297,140 @@ int orc_p8_dmap_mix(DMap* m, int y, int a, int mul, int div, int16_t* out) {
   if (m->bcount == m->btotal) m->bcount = m->B = 0;
   return s.n;
 }
+
+/* ---- paq8's process-global pseudo-random generator (reference :152-165), used by ContextMap's state decay. Every
+ * ContextMap of every sub-model draws from the ONE sequence, and only when a state >= 204 comes up: the order of
+ * draws is data-dependent and global. A device stage has to walk those contexts in the reference's order. ---- */
+typedef struct { uint32_t table[64]; int i; } P8Rnd;
+static P8Rnd g_rnd;
+void orc_p8_rnd_reset(void) {
+  g_rnd.table[0] = 123456789;
+  g_rnd.table[1] = 987654321;
+  for (int j = 0; j < 62; ++j) g_rnd.table[j + 2] = g_rnd.table[j + 1] * 11 + g_rnd.table[j] * 23 / 16;
+  g_rnd.i = 0;
+}
+uint32_t orc_p8_rnd_next(void) {
+  ++g_rnd.i;
+  return g_rnd.table[g_rnd.i & 63] = g_rnd.table[(g_rnd.i - 24) & 63] ^ g_rnd.table[(g_rnd.i - 55) & 63];
+}
+
+/* ---- StateMap (u16, :623-645) local copy ---- */
+typedef struct { int cxt; uint16_t t[256]; } SM16;
+static void sm16_init(SM16* s) {
+  s->cxt = 0;
+  for (int i = 0; i < 256; ++i) {
+    int n0 = NEX(i, 2), n1 = NEX(i, 3);
+    if (n0 == 0) n1 *= 64;
+    if (n1 == 0) n0 *= 64;
+    s->t[i] = (uint16_t)(65536 * (n1 + 1) / (n0 + n1 + 2));
+  }
+}
+static int sm16_p(SM16* s, int y, int cx) {
+  s->t[s->cxt] += ((y << 16) - s->t[s->cxt] + 128) >> 8;
+  return s->t[s->cxt = cx] >> 4;
+}
+
+/* ---- ContextMap (:1010-1145): same 64-byte bucket as ContextMap2 (chk[7], last, bh[7][7]) ---- */
+typedef struct {
+  int C, cn, hashbits;
+  uint32_t mask;
+  uint8_t* table;
+  uint32_t *cp, *cp0, *runp, *cxt;
+  uint16_t* chk;
+  SM16* sm;
+  CM2 find_view;  /* bucket_find() only needs table; reuse it through a view */
+} CM1;
+CM1* orc_p8_cm_new(uint64_t size_bytes, int count) {
+  ilog_init();
+  CM1* c = (CM1*)calloc(1, sizeof *c);
+  c->C = count;
+  const uint64_t nb = size_bytes >> 6;
+  c->mask = (uint32_t)(nb - 1);
+  c->hashbits = (int)ilog2u(c->mask + 1);
+  c->table = (uint8_t*)calloc(nb, B_SIZE);
+  c->find_view.table = c->table;
+  c->cp = (uint32_t*)malloc(count * 4); c->cp0 = (uint32_t*)malloc(count * 4); c->runp = (uint32_t*)malloc(count * 4);
+  c->cxt = (uint32_t*)calloc(count, 4); c->chk = (uint16_t*)calloc(count, 2);
+  c->sm = (SM16*)malloc(count * sizeof(SM16));
+  for (int i = 0; i < count; ++i) {
+    sm16_init(&c->sm[i]);
+    c->cp0[i] = c->cp[i] = B_STATE;  /* &t[0].bh[0][0] */
+    c->runp[i] = c->cp[i] + 3;
+  }
+  return c;
+}
+void orc_p8_cm_free(CM1* c) {
+  if (!c) return;
+  free(c->table); free(c->cp); free(c->cp0); free(c->runp); free(c->cxt); free(c->chk); free(c->sm); free(c);
+}
+/* One coded bit: set() at bpos == 0 (the callers' pattern), then mix1(m, c0, bpos, buf(1), y) :1072-1145 */
+int orc_p8_cm_step(CM1* c, int y1, int bp, int c0, int c1, const uint64_t* ctx, int nset, int16_t* out, int* nout) {
+  Sink s = {out, 0};
+  if (bp == 0)
+    for (int i = 0; i < nset; ++i) {  /* ContextMap::set :1064-1069 */
+      const uint64_t h = orc_p8_hash2(ctx[i], (uint64_t)c->cn);
+      c->cxt[c->cn] = orc_p8_finalize64(h, c->hashbits);
+      c->chk[c->cn] = (uint16_t)(orc_p8_checksum64(h, c->hashbits, 16) & 0xffff);
+      c->cn++;
+    }
+  uint8_t* T = c->table;
+  int result = 0;
+  for (int i = 0; i < c->cn; ++i) {
+    if (c->cp[i] != NIL) {
+      int ns = NEX(T[c->cp[i]], y1);
+      if (ns >= 204 && (uint32_t)(orc_p8_rnd_next() << ((452 - ns) >> 3))) ns -= 4;  /* the draw happens only for ns >= 204 */
+      T[c->cp[i]] = (uint8_t)ns;
+    }
+    if (bp > 1 && T[c->runp[i]] == 0) c->cp[i] = NIL;
+    else {
+      switch (bp) {
+        case 1: case 3: case 6: c->cp[i] = c->cp0[i] + 1 + (c0 & 1); break;
+        case 4: case 7: c->cp[i] = c->cp0[i] + 3 + (c0 & 3); break;
+        case 2: case 5: c->cp0[i] = c->cp[i] = bucket_find(&c->find_view, (c->cxt[i] + (uint32_t)c0) & c->mask, c->chk[i]); break;
+        default: {
+          const uint16_t checksum = c->chk[i];
+          const uint32_t cx = c->cxt[i];
+          c->cp0[i] = c->cp[i] = bucket_find(&c->find_view, (cx + (uint32_t)c0) & c->mask, checksum);
+          uint8_t* s0 = T + c->cp0[i];
+          if (s0[3] == 2) {
+            const int cc = s0[4] + 256;
+            uint8_t* p = T + bucket_find(&c->find_view, (cx + (cc >> 6)) & c->mask, checksum);
+            p[0] = (uint8_t)(1 + ((cc >> 5) & 1));
+            p[1 + ((cc >> 5) & 1)] = (uint8_t)(1 + ((cc >> 4) & 1));
+            p[3 + ((cc >> 4) & 3)] = (uint8_t)(1 + ((cc >> 3) & 1));
+            p = T + bucket_find(&c->find_view, (cx + (cc >> 3)) & c->mask, checksum);
+            p[0] = (uint8_t)(1 + ((cc >> 2) & 1));
+            p[1 + ((cc >> 2) & 1)] = (uint8_t)(1 + ((cc >> 1) & 1));
+            p[3 + ((cc >> 1) & 3)] = (uint8_t)(1 + (cc & 1));
+            s0[6] = 0;
+          }
+          uint8_t* rp = T + c->runp[i];  /* run count of the previous context */
+          if (rp[0] == 0) { rp[0] = 2; rp[1] = (uint8_t)c1; }
+          else if (rp[1] != c1) { rp[0] = 1; rp[1] = (uint8_t)c1; }
+          else if (rp[0] < 254) rp[0] += 2;
+          else if (rp[0] == 255) rp[0] = 128;
+          c->runp[i] = c->cp0[i] + 3;
+        } break;
+      }
+    }
+    const uint8_t* rp = T + c->runp[i];
+    const int rc = rp[0];
+    if ((rp[1] + 256) >> (8 - bp) == c0) {
+      const int b = ((rp[1] >> (7 - bp)) & 1) * 2 - 1;
+      sink_add(&s, b * (g_ilog[rc + 1] << (2 + (~rc & 1))));
+    } else sink_add(&s, 0);
+    const int st8 = c->cp[i] != NIL ? T[c->cp[i]] : 0;
+    const int p1 = sm16_p(&c->sm[i], y1, st8);
+    const int st = (orc_p8_stretch(p1) + (1 << 1)) >> 2;
+    sink_add(&s, st);
+    sink_add(&s, (p1 - 2047 + (1 << 2)) >> 3);
+    const int n0 = -!NEX(st8, 2), n1 = -!NEX(st8, 3);
+    sink_add(&s, st * abs(n1 - n0));
+    const int p0 = 4095 - p1;
+    sink_add(&s, ((p1 & n0) - (p0 & n1) + (1 << 3)) >> 4);
+    result += st8 > 0;
+  }
+  if (bp == 7) c->cn = 0;
+  *nout = s.n;
+  return result;
+}

@@ -45,6 +45,10 @@ struct MixerNx { typedef int paq8::Mixer::*type; friend type get(MixerNx); };
 struct MixerTx { typedef paq8::Array<short, 16> paq8::Mixer::*type; friend type get(MixerTx); };
 template struct Rob<MixerNx, &paq8::Mixer::nx>;
 template struct Rob<MixerTx, &paq8::Mixer::tx>;
+struct RndTable { typedef paq8::Array<paq8::U32> paq8::Random::*type; friend type get(RndTable); };
+struct RndI { typedef int paq8::Random::*type; friend type get(RndI); };
+template struct Rob<RndTable, &paq8::Random::table>;
+template struct Rob<RndI, &paq8::Random::i>;
 }  // namespace
 
 extern "C" {
@@ -147,6 +151,37 @@ int refp8_imap_mix(void* h, int y_prev, int mul, int div, int limit, int16_t* ou
   ((paq8::IndirectMap*)h)->mix(*sink(), mul, div, (paq8::U16)limit);
   return drain(out);
 }
+// ContextMap (:1010-1145): one coded bit; globals c0 / buf(1) / y / bpos are what mix() reads. The process-global rnd
+// (:152-165) advances inside -- the harness exposes a reset so that a test starts from the constructor's state.
+void* refp8_cm_new(uint64_t size_bytes, int count) { return new paq8::ContextMap(size_bytes, count); }
+void refp8_cm_free(void* h) { delete (paq8::ContextMap*)h; }
+// back to the state Random::Random() left: a snapshot of the live object taken when this library was loaded (paq8's
+// globals are constructed first: they come earlier in this translation unit), before anything could draw from it
+static std::vector<paq8::U32> rnd_pristine = [] {
+  paq8::Array<paq8::U32>& t = paq8::rnd.*get(RndTable());
+  std::vector<paq8::U32> v(64);
+  for (int j = 0; j < 64; ++j) v[j] = t[j];
+  return v;
+}();
+void refp8_rnd_reset() {
+  paq8::Array<paq8::U32>& t = paq8::rnd.*get(RndTable());
+  for (int j = 0; j < 64; ++j) t[j] = rnd_pristine[j];
+  paq8::rnd.*get(RndI()) = 0;
+}
+uint32_t refp8_rnd_next() { return paq8::rnd(); }
+int refp8_cm_step(void* h, int y_prev, int bpos, int c0, int c1, const uint64_t* ctx, int nset, int16_t* out, int* nout) {
+  paq8::y = y_prev;
+  paq8::bpos = bpos;
+  paq8::c0 = c0;
+  if (paq8::buf.size() == 0) paq8::buf.setsize(1 << 16);
+  paq8::buf[paq8::pos - 1] = (paq8::U8)c1;  // buf(1)
+  paq8::ContextMap& cm = *(paq8::ContextMap*)h;
+  if (bpos == 0) for (int i = 0; i < nset; ++i) cm.set(ctx[i]);
+  const int r = cm.mix(*sink());
+  *nout = drain(out);
+  return r;
+}
+
 uint64_t refp8_hash2(uint64_t a, uint64_t b) { return paq8::hash(a, b); }
 uint64_t refp8_combine64(uint64_t seed, uint64_t x) { return paq8::combine64(seed, x); }
 uint32_t refp8_finalize64(uint64_t h, int bits) { return paq8::finalize64(h, bits); }

@@ -206,6 +206,11 @@ def paq8core_lib():
     L.refp8_apm_new.argtypes = [C.c_int]
     L.refp8_apm_p.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
     L.refp8_ilog_table.argtypes = [C.c_void_p]
+    L.refp8_cm_new.restype = C.c_void_p
+    L.refp8_cm_new.argtypes = [C.c_uint64, C.c_int]
+    L.refp8_cm_free.argtypes = [C.c_void_p]
+    L.refp8_cm_step.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.refp8_rnd_next.restype = C.c_uint32
     L.refp8_cm2_new.restype = C.c_void_p
     L.refp8_cm2_new.argtypes = [C.c_uint64, C.c_uint32]
     L.refp8_cm2_free.argtypes = [C.c_void_p]

@@ -233,3 +233,42 @@ def test_direct_lookup_maps_vs_reference():
                 assert (o_ref[:2] == o_got[:2]).all(), (name, boc, bpc, n, bpos, o_ref[:2], o_got[:2])
                 y = (int(data[n]) >> (7 - bpos)) & 1
                 bit_in_ctx = (bit_in_ctx + 1) % bpc
+
+
+@needs_ref
+def test_global_rnd_vs_reference():
+    L, lib = R.paq8core_lib(), O.lib()
+    L.refp8_rnd_reset()
+    lib.orc_p8_rnd_reset()
+    assert [L.refp8_rnd_next() for _ in range(500)] == [lib.orc_p8_rnd_next() for _ in range(500)]
+
+
+@needs_ref
+@pytest.mark.parametrize("size_bytes,count,nbytes", [(1 << 16, 12, 5000), (1 << 22, 5, 12000)])
+def test_contextmap_vs_reference(size_bytes, count, nbytes):
+    """The older ContextMap (wordModel, sparseModel, indirectModel, ...): same bucket, u16 StateMap, and the
+    process-global rnd() drawn only when a bit-history state >= 204 comes up (long deterministic runs reach them:
+    the second case is a repetitive stream)."""
+    from cmix_amd import synth
+    L, lib = R.paq8core_lib(), O.lib()
+    text = synth.enwik_like(nbytes, 17)
+    data = np.frombuffer(text if count > 5 else (text[:40] * (nbytes // 40 + 1))[:nbytes], np.uint8)
+    L.refp8_rnd_reset()
+    lib.orc_p8_rnd_reset()
+    ref, got = L.refp8_cm_new(size_bytes, count), lib.orc_p8_cm_new(size_bytes, count)
+    o_ref, o_got = np.zeros(256, np.int16), np.zeros(256, np.int16)
+    n_ref, n_got = C.c_int(0), C.c_int(0)
+    y, c0 = 0, 1
+    for n in range(nbytes):
+        cx = _byte_contexts(data, n, count)
+        c1 = int(data[n - 1]) if n else 0
+        for bpos in range(8):
+            r = L.refp8_cm_step(ref, y, bpos, c0, c1, cx.ctypes.data, count, o_ref.ctypes.data, C.byref(n_ref))
+            g = lib.orc_p8_cm_step(got, y, bpos, c0, c1, cx.ctypes.data, count, o_got.ctypes.data, C.byref(n_got))
+            assert r == g and n_ref.value == n_got.value == 5 * count, (n, bpos, r, g)
+            assert (o_ref[:n_ref.value] == o_got[:n_got.value]).all(), f"byte {n} bit {bpos}"
+            y = (int(data[n]) >> (7 - bpos)) & 1
+            c0 = (c0 << 1 | y) if bpos < 7 else 1
+    assert L.refp8_rnd_next() == lib.orc_p8_rnd_next()  # the same number of draws happened on both sides
+    L.refp8_cm_free(ref)
+    lib.orc_p8_cm_free(got)
