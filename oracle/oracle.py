@@ -73,6 +73,10 @@ def lib():
         L.orc_p8_cm_free.argtypes = [C.c_void_p]
         L.orc_p8_cm_step.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_p8_rnd_next.restype = C.c_uint32
+        L.orc_p8_rcm_new.restype = C.c_void_p
+        L.orc_p8_rcm_new.argtypes = [C.c_int]
+        L.orc_p8_rcm_set.argtypes = [C.c_void_p, C.c_uint64, C.c_int]
+        L.orc_p8_rcm_mix.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orc_p8_dmap_new.restype = C.c_void_p
         L.orc_p8_dmap_new.argtypes = [C.c_int] * 4
         L.orc_p8_dmap_set_direct.argtypes = [C.c_void_p, C.c_uint32]

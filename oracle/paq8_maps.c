@@ -434,3 +434,53 @@ int orc_p8_cm_step(CM1* c, int y1, int bp, int c0, int c1, const uint64_t* ctx, 
   *nout = s.n;
   return result;
 }
+
+/* ---- BH<4> (:778-813) and RunContextMap (:857-889) ---- */
+typedef struct { uint8_t* t; uint32_t mask; int hashbits; uint32_t cp; } RCM;  /* cp: byte offset of the current element + 1 */
+static uint32_t bh4_get(RCM* r, uint64_t ctx) {  /* BH<4>::operator[] -> offset of element byte 1 */
+  enum { Bsz = 4, Mlim = 8 };
+  const uint16_t chk = (uint16_t)(orc_p8_checksum64(ctx, r->hashbits, 16) & 0xffff);
+  const uint32_t i = (orc_p8_finalize64(ctx, r->hashbits) * Mlim) & r->mask;
+  uint8_t* t = r->t;
+  int j;
+  uint32_t p = 0;
+  for (j = 0; j < Mlim; ++j) {
+    p = (i + j) * Bsz;
+    uint16_t cur;
+    memcpy(&cur, t + p, 2);
+    if (t[p + 2] == 0) { memcpy(t + p, &chk, 2); break; }  /* empty slot */
+    if (cur == chk) break;                                    /* found */
+  }
+  if (j == 0) return p + 1;  /* front */
+  uint8_t tmp[Bsz];
+  if (j == Mlim) {
+    --j;
+    memset(tmp, 0, Bsz);
+    memcpy(tmp, &chk, 2);
+    if (Mlim > 2 && t[(i + j) * Bsz + 2] > t[(i + j - 1) * Bsz + 2]) --j;
+  } else memcpy(tmp, t + p, Bsz);
+  memmove(t + (i + 1) * Bsz, t + i * Bsz, (size_t)j * Bsz);
+  memcpy(t + i * Bsz, tmp, Bsz);
+  return i * Bsz + 1;
+}
+RCM* orc_p8_rcm_new(int m) {
+  ilog_init();
+  RCM* r = (RCM*)calloc(1, sizeof *r);
+  const int n = m / 4;             /* BH<4> t(m/4): i elements of B bytes */
+  r->t = (uint8_t*)calloc((size_t)n * 4 + 64, 1);
+  r->mask = (uint32_t)(n - 1);
+  r->hashbits = (int)ilog2u(r->mask + 1);
+  r->cp = bh4_get(r, 0) + 1;       /* cp = t[0] + 1 */
+  return r;
+}
+void orc_p8_rcm_set(RCM* r, uint64_t cx, int c1) {
+  uint8_t* cp = r->t + r->cp;
+  if (cp[0] == 0 || cp[1] != c1) { cp[0] = 1; cp[1] = (uint8_t)c1; }
+  else if (cp[0] < 255) ++cp[0];
+  r->cp = bh4_get(r, cx) + 1;
+}
+int orc_p8_rcm_mix(RCM* r, int bpos, int c0, int16_t* out) {
+  const uint8_t* cp = r->t + r->cp;
+  out[0] = (int16_t)(((cp[1] + 256) >> (8 - bpos)) == c0 ? (((cp[1] >> (7 - bpos)) & 1) * 2 - 1) * g_ilog[cp[0] + 1] * 8 : 0);
+  return cp[0] != 0;
+}

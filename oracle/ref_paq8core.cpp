@@ -182,6 +182,22 @@ int refp8_cm_step(void* h, int y_prev, int bpos, int c0, int c1, const uint64_t*
   return r;
 }
 
+// RunContextMap over BH<4> (:778-813, :857-889): set() at byte boundaries (reads buf(1)), mix() every bit (reads c0,
+// bpos). c1 = the byte just coded.
+void* refp8_rcm_new(int m) { return new paq8::RunContextMap(m); }
+void refp8_rcm_set(void* h, uint64_t cx, int c1) {
+  if (paq8::buf.size() == 0) paq8::buf.setsize(1 << 16);
+  paq8::buf[paq8::pos - 1] = (paq8::U8)c1;
+  ((paq8::RunContextMap*)h)->set(cx);
+}
+int refp8_rcm_mix(void* h, int bpos, int c0, int16_t* out) {
+  paq8::bpos = bpos;
+  paq8::c0 = c0;
+  const int r = ((paq8::RunContextMap*)h)->mix(*sink());
+  drain(out);
+  return r;
+}
+
 uint64_t refp8_hash2(uint64_t a, uint64_t b) { return paq8::hash(a, b); }
 uint64_t refp8_combine64(uint64_t seed, uint64_t x) { return paq8::combine64(seed, x); }
 uint32_t refp8_finalize64(uint64_t h, int bits) { return paq8::finalize64(h, bits); }

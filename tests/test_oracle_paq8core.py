@@ -272,3 +272,25 @@ def test_contextmap_vs_reference(size_bytes, count, nbytes):
     assert L.refp8_rnd_next() == lib.orc_p8_rnd_next()  # the same number of draws happened on both sides
     L.refp8_cm_free(ref)
     lib.orc_p8_cm_free(got)
+
+
+@needs_ref
+def test_runcontextmap_vs_reference():
+    """RunContextMap over BH<4>: 8-way probe, move-to-front, replacement of the lower-priority of the last two."""
+    from cmix_amd import synth
+    L, lib = R.paq8core_lib(), O.lib()
+    for m, nbytes, order in ((1 << 10, 6000, 2), (1 << 16, 6000, 4)):  # the tiny table overflows its probe windows
+        data = np.frombuffer(synth.enwik_like(nbytes, 23), np.uint8)
+        ref, got = L.refp8_rcm_new(m), lib.orc_p8_rcm_new(m)
+        o_ref, o_got = np.zeros(4, np.int16), np.zeros(4, np.int16)
+        c0 = 1
+        for n in range(nbytes):
+            cx = int(_byte_contexts(data, n, order)[-1])
+            c1 = int(data[n - 1]) if n else 0
+            L.refp8_rcm_set(ref, cx, c1)
+            lib.orc_p8_rcm_set(got, cx, c1)
+            for bpos in range(8):
+                assert L.refp8_rcm_mix(ref, bpos, c0, o_ref.ctypes.data) == lib.orc_p8_rcm_mix(got, bpos, c0, o_got.ctypes.data)
+                assert o_ref[0] == o_got[0], (n, bpos, o_ref[0], o_got[0])
+                y = (int(data[n]) >> (7 - bpos)) & 1
+                c0 = (c0 << 1 | y) if bpos < 7 else 1
