@@ -198,6 +198,16 @@ int refp8_rcm_mix(void* h, int bpos, int c0, int16_t* out) {
   return r;
 }
 
+// dmcForest (:7637-7822): ten DMC state graphs; only y and bpos go in. `level` sets MEM() and with it the graph sizes.
+void* refp8_dmc_new(int level) { paq8::level = level; return new paq8::dmcForest(); }
+void refp8_dmc_free(void* h) { delete (paq8::dmcForest*)h; }
+int refp8_dmc_mix(void* h, int y_prev, int bpos, int16_t* out) {
+  paq8::y = y_prev;
+  paq8::bpos = bpos;
+  ((paq8::dmcForest*)h)->mix(*sink());
+  return drain(out);
+}
+
 uint64_t refp8_hash2(uint64_t a, uint64_t b) { return paq8::hash(a, b); }
 uint64_t refp8_combine64(uint64_t seed, uint64_t x) { return paq8::combine64(seed, x); }
 uint32_t refp8_finalize64(uint64_t h, int bits) { return paq8::finalize64(h, bits); }

@@ -206,6 +206,10 @@ def paq8core_lib():
     L.refp8_apm_new.argtypes = [C.c_int]
     L.refp8_apm_p.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
     L.refp8_ilog_table.argtypes = [C.c_void_p]
+    L.refp8_dmc_new.restype = C.c_void_p
+    L.refp8_dmc_new.argtypes = [C.c_int]
+    L.refp8_dmc_free.argtypes = [C.c_void_p]
+    L.refp8_dmc_mix.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.refp8_rcm_new.restype = C.c_void_p
     L.refp8_rcm_new.argtypes = [C.c_int]
     L.refp8_rcm_set.argtypes = [C.c_void_p, C.c_uint64, C.c_int]

@@ -294,3 +294,23 @@ def test_runcontextmap_vs_reference():
                 assert o_ref[0] == o_got[0], (n, bpos, o_ref[0], o_got[0])
                 y = (int(data[n]) >> (7 - bpos)) & 1
                 c0 = (c0 << 1 | y) if bpos < 7 else 1
+
+
+@needs_ref
+@pytest.mark.parametrize("level,nbytes", [(0, 40000), (5, 20000)])
+def test_dmc_forest_vs_reference(level, nbytes):
+    """Ten DMC state graphs: cloning, threshold growth, and -- at level 0, where the graphs fill within a few KB --
+    the `isfull` resets of the eight fast models."""
+    from cmix_amd import synth
+    L, lib = R.paq8core_lib(), O.lib()
+    data = np.frombuffer(synth.enwik_like(nbytes, 29), np.uint8)
+    ref, got = L.refp8_dmc_new(level), lib.orc_p8_dmc_new(level)
+    o_ref, o_got = np.zeros(8, np.int16), np.zeros(8, np.int16)
+    y = 0
+    for n in range(nbytes):
+        for bpos in range(8):
+            assert L.refp8_dmc_mix(ref, y, bpos, o_ref.ctypes.data) == lib.orc_p8_dmc_mix(got, y, bpos, o_got.ctypes.data) == 6
+            assert (o_ref[:6] == o_got[:6]).all(), (n, bpos, o_ref[:6], o_got[:6])
+            y = (int(data[n]) >> (7 - bpos)) & 1
+    L.refp8_dmc_free(ref)
+    lib.orc_p8_dmc_free(got)
