@@ -81,6 +81,8 @@ def lib():
         L.orc_p8_dmc_new.argtypes = [C.c_int]
         L.orc_p8_dmc_free.argtypes = [C.c_void_p]
         L.orc_p8_dmc_mix.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_p8_lpm_new.restype = C.c_void_p
+        L.orc_p8_lpm_step.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_p8_dmap_new.restype = C.c_void_p
         L.orc_p8_dmap_new.argtypes = [C.c_int] * 4
         L.orc_p8_dmap_set_direct.argtypes = [C.c_void_p, C.c_uint32]

@@ -208,6 +208,18 @@ int refp8_dmc_mix(void* h, int y_prev, int bpos, int16_t* out) {
   return drain(out);
 }
 
+// linearPredictionModel (:4476-4502): three OLS<double,U8> predictors (:1364-1466) + two fixed ones over the last
+// 64 bytes, each read through a SmallStationaryContextMap. last[i-1] = buf(i). One instance per process (statics).
+int refp8_lpm_step(int y_prev, int bpos, int c0, const uint8_t* last, int nlast, int16_t* out) {
+  paq8::y = y_prev;
+  paq8::bpos = bpos;
+  paq8::c0 = c0;
+  if (paq8::buf.size() == 0) paq8::buf.setsize(1 << 16);
+  for (int i = 1; i <= nlast; ++i) paq8::buf[paq8::pos - i] = last[i - 1];
+  paq8::linearPredictionModel(*sink());
+  return drain(out);
+}
+
 uint64_t refp8_hash2(uint64_t a, uint64_t b) { return paq8::hash(a, b); }
 uint64_t refp8_combine64(uint64_t seed, uint64_t x) { return paq8::combine64(seed, x); }
 uint32_t refp8_finalize64(uint64_t h, int bits) { return paq8::finalize64(h, bits); }

@@ -206,6 +206,7 @@ def paq8core_lib():
     L.refp8_apm_new.argtypes = [C.c_int]
     L.refp8_apm_p.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
     L.refp8_ilog_table.argtypes = [C.c_void_p]
+    L.refp8_lpm_step.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     L.refp8_dmc_new.restype = C.c_void_p
     L.refp8_dmc_new.argtypes = [C.c_int]
     L.refp8_dmc_free.argtypes = [C.c_void_p]

@@ -314,3 +314,31 @@ def test_dmc_forest_vs_reference(level, nbytes):
             y = (int(data[n]) >> (7 - bpos)) & 1
     L.refp8_dmc_free(ref)
     lib.orc_p8_dmc_free(got)
+
+
+@needs_ref
+def test_linear_prediction_model_vs_reference():
+    """Three OLS<double> recursive least-squares predictors + two fixed extrapolations, read through SSCMs: the only
+    double-precision arithmetic on paq8's text path. Text, then a smooth ramp (where the predictors lock on), then
+    noise. One reference instance per process (function-local statics)."""
+    from cmix_amd import synth
+    L, lib = R.paq8core_lib(), O.lib()
+    rng = np.random.default_rng(31)
+    text = np.frombuffer(synth.enwik_like(3000, 41), np.uint8)
+    ramp = ((np.arange(3000) * 3 + (np.sin(np.arange(3000) / 9.0) * 20).astype(int)) & 255).astype(np.uint8)
+    data = np.concatenate([text, ramp, rng.integers(0, 256, 2000, dtype=np.uint8)])
+    got = lib.orc_p8_lpm_new()
+    o_ref, o_got = np.zeros(16, np.int16), np.zeros(16, np.int16)
+    hist = np.zeros(64, np.uint8)  # hist[i-1] = buf(i)
+    y, c0 = 0, 1
+    seen = set()
+    for n in range(len(data)):
+        for bpos in range(8):
+            k = L.refp8_lpm_step(y, bpos, c0, hist.ctypes.data, 64, o_ref.ctypes.data)
+            assert lib.orc_p8_lpm_step(got, y, bpos, c0, hist.ctypes.data, o_got.ctypes.data) == k == 10
+            assert (o_ref[:10] == o_got[:10]).all(), (n, bpos, o_ref[:10], o_got[:10])
+            seen.add(int(o_ref[0]))
+            y = (int(data[n]) >> (7 - bpos)) & 1
+            c0 = (c0 << 1 | y) if bpos < 7 else 1
+        hist = np.concatenate([[data[n]], hist[:-1]]).astype(np.uint8)
+    assert len(seen) > 50
