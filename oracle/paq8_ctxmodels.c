@@ -1,0 +1,187 @@
+/* oracle/paq8_ctxmodels.c -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+ *
+ * CPU restatement of three of paq8's context models that read only the byte history and plain globals -- nestModel
+ * (reference src/models/paq8.cpp:4107-4181: bracket / quote / vowel-class nesting state), distanceModel (:4598-4612:
+ * distance to the last 0x00 / space / line end) and indirectModel (:7548-7599: byte-history-indexed second-order
+ * contexts) -- each feeding a ContextMap (oracle/paq8_maps.c). They show the shape of the rest of paq8's front end: a
+ * few dozen integer state updates per byte ending in ContextMap::set(hash(...)) calls, then ContextMap::mix() per bit.
+ * Pinned against the reference's own functions in tests/test_oracle_paq8core.py.
+ *
+ * Inputs per bit: the coded bit, bpos, c0 and -- used at bpos == 0 only -- c4 (last four bytes), f4, pos, and
+ * last[i-1] = buf(i) for i = 1..8. */
+#include <ctype.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct CM1 CM1;
+CM1* orc_p8_cm_new(uint64_t size_bytes, int count);
+int orc_p8_cm_step(CM1* c, int y1, int bp, int c0, int c1, const uint64_t* ctx, int nset, int16_t* out, int* nout);
+
+#define PHI64 0x9E3779B97F4A7C15ull
+static const uint64_t MUL[8] = {PHI64, 0x993DDEFFB1462949ull, 0xE9C91DC159AB0D2Dull, 0x83D6A14F1B0CED73ull,
+                                0xA14F1B0CED5A841Full, 0xC0E51314A614F4EFull, 0xDA9CC2600AE45A27ull, 0x826797AA04A65737ull};
+static uint64_t hashn(int n, const uint64_t* x) {  /* hash(x0 .. x(n-1)) :742-773 */
+  uint64_t h = 0;
+  for (int i = 0; i < n; ++i) h += (x[i] + 1) * MUL[i];
+  return h;
+}
+#define H2(a, b) hashn(2, (const uint64_t[]){(uint64_t)(a), (uint64_t)(b)})
+#define H3(a, b, c) hashn(3, (const uint64_t[]){(uint64_t)(a), (uint64_t)(b), (uint64_t)(c)})
+#define H4(a, b, c, d) hashn(4, (const uint64_t[]){(uint64_t)(a), (uint64_t)(b), (uint64_t)(c), (uint64_t)(d)})
+#define H6(a, b, c, d, e, f) hashn(6, (const uint64_t[]){(uint64_t)(a), (uint64_t)(b), (uint64_t)(c), (uint64_t)(d), (uint64_t)(e), (uint64_t)(f)})
+uint64_t orc_p8_hash3(uint64_t a, uint64_t b, uint64_t c) { return H3(a, b, c); }
+uint64_t orc_p8_hash6(uint64_t a, uint64_t b, uint64_t c, uint64_t d, uint64_t e, uint64_t f) { return H6(a, b, c, d, e, f); }
+
+static unsigned ilog2u(unsigned x) { unsigned n = 0; while (x > 1) { x >>= 1; ++n; } return n; }
+static uint64_t mem_of(int level) { return 0x10000ull << level; }
+
+typedef struct {
+  int which, level;
+  CM1* cm;
+  /* nestModel :4109-4110 */
+  int ic, bc, pc, qc, lvc, ac, ec, uc, sense1, sense2, w;
+  unsigned vc, wc;
+  /* distanceModel :4601 */
+  int pos00, pos20, posnl;
+  /* indirectModel :7550-7554 */
+  uint32_t t1[256];
+  uint16_t t2[0x10000], t3[0x8000], t4[0x8000];
+  uint32_t ictx_data[1 << 16];
+  uint32_t ictx_cur;  /* index into ictx_data */
+} P8CtxModel;
+
+P8CtxModel* orc_p8_ctxmodel_new(int which, int level) {
+  P8CtxModel* m = (P8CtxModel*)calloc(1, sizeof *m);
+  m->which = which; m->level = level;
+  m->cm = which == 0 ? orc_p8_cm_new(mem_of(level) / 2, 12) : which == 1 ? orc_p8_cm_new(mem_of(level), 3)
+                                                                         : orc_p8_cm_new(mem_of(level), 15);
+  return m;
+}
+
+static int nest_contexts(P8CtxModel* m, uint32_t c4, uint32_t f4, const uint8_t* last, uint64_t* cx) {
+  int c = c4 & 255, matched = 1, vv;
+  m->w *= ((m->vc & 7) > 0 && (m->vc & 7) < 3);
+  if (c & 0x80) m->w = m->w * 11 * 32 + c;
+  const int lc = (c >= 'A' && c <= 'Z' ? c + 'a' - 'A' : c);
+  if (lc == 'a' || lc == 'e' || lc == 'i' || lc == 'o' || lc == 'u') { vv = 1; m->w = m->w * 997 * 8 + (lc / 4 - 22); }
+  else if (lc >= 'a' && lc <= 'z') { vv = 2; m->w = m->w * 271 * 32 + lc - 97; }
+  else if (lc == ' ' || lc == '.' || lc == ',' || lc == '!' || lc == '?' || lc == '\n') vv = 3;
+  else if (lc >= '0' && lc <= '9') vv = 4;
+  else if (lc == 'y') vv = 5;
+  else if (lc == '\'') vv = 6;
+  else vv = (c & 32) ? 7 : 0;
+  m->vc = (m->vc << 3) | (unsigned)vv;
+  if (vv != m->lvc) { m->wc = (m->wc << 3) | (unsigned)vv; m->lvc = vv; }
+  switch (c) {
+    case ' ': m->qc = 0; break;
+    case '(': m->ic += 31; break;
+    case ')': m->ic -= 31; break;
+    case '[': m->ic += 11; break;
+    case ']': m->ic -= 11; break;
+    case '<': m->ic += 23; m->qc += 34; break;
+    case '>': m->ic -= 23; m->qc /= 5; break;
+    case ':': m->pc = 20; break;
+    case '{': m->ic += 17; break;
+    case '}': m->ic -= 17; break;
+    case '|': m->pc += 223; break;
+    case '"': m->pc += 0x40; break;
+    case '\'': m->pc += 0x42; if (c != (uint8_t)(c4 >> 8)) m->sense2 ^= 1; else m->ac += (2 * m->sense2 - 1); break;
+    case '\n': m->pc = m->qc = 0; break;
+    case '.': case '!': case '?': m->pc = 0; break;
+    case '#': m->pc += 0x08; break;
+    case '%': m->pc += 0x76; break;
+    case '$': m->pc += 0x45; break;
+    case '*': m->pc += 0x35; break;
+    case '-': m->pc += 0x3; break;
+    case '@': m->pc += 0x72; break;
+    case '&': m->qc += 0x12; break;
+    case ';': m->qc /= 3; break;
+    case '\\': m->pc += 0x29; break;
+    case '/': m->pc += 0x11; if (last[0] == '<') m->qc += 74; break;  /* buf(1) is the byte itself here: never '<' */
+    case '=': m->pc += 87; if (c != (uint8_t)(c4 >> 8)) m->sense1 ^= 1; else m->ec += (2 * m->sense1 - 1); break;
+    default: matched = 0;
+  }
+  if (c4 == 0x266C743B) m->uc = m->uc + 1 < 7 ? m->uc + 1 : 7;
+  else if (c4 == 0x2667743B) m->uc -= (m->uc > 0);
+  if (matched) m->bc = 0; else m->bc += 1;
+  if (m->bc > 300) m->bc = m->ic = m->pc = m->qc = m->uc = 0;
+  uint64_t i = 0;
+  const unsigned vc = m->vc, wc = m->wc;
+  const int ic = m->ic, pc = m->pc, qc = m->qc, bc = m->bc;
+  ++i; cx[0] = H6(i, (vv > 0 && vv < 3) ? 0 : (lc | 0x100), ic & 0x3FF, m->ec & 0x7, m->ac & 0x7, m->uc);
+  ++i; cx[1] = H4(i, ic, m->w, ilog2u((unsigned)(bc + 1)));
+  ++i; cx[2] = H2(i, (3 * vc + 77 * pc + 373 * ic + qc) & 0xffff);
+  ++i; cx[3] = H2(i, (31 * vc + 27 * pc + 281 * qc) & 0xffff);
+  ++i; cx[4] = H2(i, (13 * vc + 271 * ic + qc + bc) & 0xffff);
+  ++i; cx[5] = H2(i, (17 * pc + 7 * ic) & 0xffff);
+  ++i; cx[6] = H2(i, (13 * vc + ic) & 0xffff);
+  ++i; cx[7] = H2(i, (vc / 3 + pc) & 0xffff);
+  ++i; cx[8] = H2(i, (7 * wc + qc) & 0xffff);
+  ++i; cx[9] = H3(i, vc & 0xffff, f4 & 0xf);
+  ++i; cx[10] = H3(i, (3 * pc) & 0xffff, f4 & 0xf);
+  ++i; cx[11] = H3(i, ic & 0xffff, f4 & 0xf);
+  return 12;
+}
+
+static int distance_contexts(P8CtxModel* m, uint32_t c4, int pos, uint64_t* cx) {
+  const int c = c4 & 0xff;
+  if (c == 0x00) m->pos00 = pos;
+  if (c == 0x20) m->pos20 = pos;
+  if (c == 0xff || c == '\r' || c == '\n') m->posnl = pos;
+  const int a = pos - m->pos00 < 255 ? pos - m->pos00 : 255, b = pos - m->pos20 < 255 ? pos - m->pos20 : 255,
+            d = pos - m->posnl < 255 ? pos - m->posnl : 255;
+  cx[0] = H2(1, a | c << 8);
+  cx[1] = H2(2, b | c << 8);
+  cx[2] = H2(3, d | c << 8);
+  return 3;
+}
+
+static int indirect_contexts(P8CtxModel* m, uint32_t c4, const uint8_t* last, uint64_t* cx) {
+  uint32_t d = c4 & 0xffff, c = d & 255;
+  const uint32_t d2 = (last[0] & 31) + 32 * (last[1] & 31) + 1024 * (last[2] & 31);
+  const uint32_t d3 = (last[0] >> 3 & 31) + 32 * (last[2] >> 3 & 31) + 1024 * (last[3] >> 3 & 31);
+  uint32_t* r1 = &m->t1[d >> 8]; *r1 = *r1 << 8 | c;
+  uint16_t* r2 = &m->t2[c4 >> 8 & 0xffff]; *r2 = (uint16_t)(*r2 << 8 | c);
+  uint16_t* r3 = &m->t3[(last[1] & 31) + 32 * (last[2] & 31) + 1024 * (last[3] & 31)]; *r3 = (uint16_t)(*r3 << 8 | c);
+  uint16_t* r4 = &m->t4[(last[1] >> 3 & 31) + 32 * (last[3] >> 3 & 31) + 1024 * (last[4] >> 3 & 31)]; *r4 = (uint16_t)(*r4 << 8 | c);
+  const uint32_t t = c | m->t1[c] << 8;
+  const uint32_t t0 = d | (uint32_t)m->t2[d] << 16;
+  const uint32_t ta = d2 | (uint32_t)m->t3[d2] << 16;
+  const uint32_t tc = d3 | (uint32_t)m->t4[d3] << 16;
+  const uint8_t pc = (uint8_t)tolower((uint8_t)(c4 >> 8));
+  c = (uint32_t)tolower((int)c);
+  m->ictx_data[m->ictx_cur] = (m->ictx_data[m->ictx_cur] << 8) | (c & 0xff);   /* iCtx += c  (:1484-1487) */
+  m->ictx_cur = (((uint32_t)pc << 8) | c) & 0xffff;                              /* iCtx = (pc << 8) | c */
+  const uint32_t ctx0 = m->ictx_data[m->ictx_cur];
+  const uint32_t mask = ((uint8_t)m->t1[c] == (uint8_t)m->t2[d]) | (((uint8_t)m->t1[c] == (uint8_t)m->t3[d2]) << 1) |
+                        (((uint8_t)m->t1[c] == (uint8_t)m->t4[d3]) << 2) | (((uint8_t)m->t1[c] == (uint8_t)ctx0) << 3);
+  uint64_t i = 0;
+  ++i; cx[0] = H2(i, t);
+  ++i; cx[1] = H2(i, t0);
+  ++i; cx[2] = H2(i, ta);
+  ++i; cx[3] = H2(i, tc);
+  ++i; cx[4] = H3(i, t & 0xff00, mask);
+  ++i; cx[5] = H2(i, t0 & 0xff0000);
+  ++i; cx[6] = H2(i, ta & 0xff0000);
+  ++i; cx[7] = H2(i, tc & 0xff0000);
+  ++i; cx[8] = H2(i, t & 0xffff);
+  ++i; cx[9] = H2(i, t0 & 0xffffff);
+  ++i; cx[10] = H2(i, ta & 0xffffff);
+  ++i; cx[11] = H2(i, tc & 0xffffff);
+  ++i; cx[12] = H3(i, ctx0 & 0xff, c);
+  ++i; cx[13] = H2(i, ctx0 & 0xffff);
+  ++i; cx[14] = H2(i, ctx0 & 0x7f7fff);
+  return 15;
+}
+
+int orc_p8_ctxmodel_step(P8CtxModel* m, int y, int bpos, int c0, uint32_t c4, uint32_t f4, int pos, const uint8_t* last,
+                         int16_t* out) {
+  uint64_t cx[16];
+  int nset = 0, nout = 0;
+  if (bpos == 0)
+    nset = m->which == 0 ? nest_contexts(m, c4, f4, last, cx) : m->which == 1 ? distance_contexts(m, c4, pos, cx)
+                                                                              : indirect_contexts(m, c4, last, cx);
+  orc_p8_cm_step(m->cm, y, bpos, c0, last[0], cx, nset, out, &nout);
+  return nout;
+}

@@ -220,7 +220,29 @@ int refp8_lpm_step(int y_prev, int bpos, int c0, const uint8_t* last, int nlast,
   return drain(out);
 }
 
+// Context models that read only the byte history and a few plain globals: nestModel (:4107-4181), distanceModel
+// (:4598-4612), indirectModel (:7548-7599). The caller marshals the globals they read: c4, f4, pos, buf(1..8); `level`
+// sizes their ContextMaps. One instance of each per process (function-local statics).
+int refp8_ctxmodel_step(int which, int level, int y_prev, int bpos, int c0, uint32_t c4, uint32_t f4, int pos,
+                        const uint8_t* last, int nlast, int16_t* out) {
+  paq8::level = level;
+  paq8::y = y_prev;
+  paq8::bpos = bpos;
+  paq8::c0 = c0;
+  paq8::c4 = c4;
+  paq8::f4 = f4;
+  paq8::pos = pos;
+  if (paq8::buf.size() == 0) paq8::buf.setsize(1 << 16);
+  for (int i = 1; i <= nlast; ++i) paq8::buf[paq8::pos - i] = last[i - 1];
+  if (which == 0) paq8::nestModel(*sink());
+  else if (which == 1) paq8::distanceModel(*sink());
+  else paq8::indirectModel(*sink());
+  return drain(out);
+}
+
 uint64_t refp8_hash2(uint64_t a, uint64_t b) { return paq8::hash(a, b); }
+uint64_t refp8_hash3(uint64_t a, uint64_t b, uint64_t c) { return paq8::hash(a, b, c); }
+uint64_t refp8_hash6(uint64_t a, uint64_t b, uint64_t c, uint64_t d, uint64_t e, uint64_t f) { return paq8::hash(a, b, c, d, e, f); }
 uint64_t refp8_combine64(uint64_t seed, uint64_t x) { return paq8::combine64(seed, x); }
 uint32_t refp8_finalize64(uint64_t h, int bits) { return paq8::finalize64(h, bits); }
 uint64_t refp8_checksum64(uint64_t h, int hashbits, int checksumbits) { return paq8::checksum64(h, hashbits, checksumbits); }

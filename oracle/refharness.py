@@ -206,6 +206,12 @@ def paq8core_lib():
     L.refp8_apm_new.argtypes = [C.c_int]
     L.refp8_apm_p.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
     L.refp8_ilog_table.argtypes = [C.c_void_p]
+    L.refp8_ctxmodel_step.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p,
+                                      C.c_int, C.c_void_p]
+    L.refp8_hash3.restype = C.c_uint64
+    L.refp8_hash3.argtypes = [C.c_uint64] * 3
+    L.refp8_hash6.restype = C.c_uint64
+    L.refp8_hash6.argtypes = [C.c_uint64] * 6
     L.refp8_lpm_step.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     L.refp8_dmc_new.restype = C.c_void_p
     L.refp8_dmc_new.argtypes = [C.c_int]

@@ -342,3 +342,34 @@ def test_linear_prediction_model_vs_reference():
             c0 = (c0 << 1 | y) if bpos < 7 else 1
         hist = np.concatenate([[data[n]], hist[:-1]]).astype(np.uint8)
     assert len(seen) > 50
+
+
+@needs_ref
+def test_nest_distance_indirect_models_vs_reference():
+    """Three of paq8's context models end to end (state machines -> hashed contexts -> ContextMap -> mixer inputs), each
+    against the reference's own function. Markup-heavy text (brackets, quotes, entities) for the nesting state."""
+    from cmix_amd import synth
+    L, lib = R.paq8core_lib(), O.lib()
+    rng = np.random.default_rng(37)
+    for a, b in ((1, 2), (3, 4), (1 << 40, 7)):
+        assert lib.orc_p8_hash3(a, b, 9) == L.refp8_hash3(a, b, 9) and lib.orc_p8_hash6(a, b, 3, 4, 5, 6) == L.refp8_hash6(a, b, 3, 4, 5, 6)
+    text = synth.enwik_like(5000, 43) + b"&lt;&gt; (a [b {c} 'd' \"e\"]) = == 'x' / | \\ # % $ * - @ ; : \xc3\xa9\xc3\xa8 " * 20
+    data = np.frombuffer(text, np.uint8)
+    level = 6
+    L.refp8_rnd_reset()
+    lib.orc_p8_rnd_reset()
+    for which, nout in ((0, 60), (1, 15), (2, 75)):
+        got = lib.orc_p8_ctxmodel_new(which, level)
+        o_ref, o_got = np.zeros(128, np.int16), np.zeros(128, np.int16)
+        hist = np.zeros(8, np.uint8)
+        y, c0, c4, f4 = 0, 1, 0, 0
+        for n in range(len(data)):
+            for bpos in range(8):
+                k = L.refp8_ctxmodel_step(which, level, y, bpos, c0, c4, f4, n, hist.ctypes.data, 8, o_ref.ctypes.data)
+                assert lib.orc_p8_ctxmodel_step(got, y, bpos, c0, c4, f4, n, hist.ctypes.data, o_got.ctypes.data) == k == nout
+                assert (o_ref[:k] == o_got[:k]).all(), (which, n, bpos, o_ref[:k], o_got[:k])
+                y = (int(data[n]) >> (7 - bpos)) & 1
+                c0 = (c0 << 1 | y) if bpos < 7 else 1
+            c4 = ((c4 << 8) | int(data[n])) & 0xffffffff
+            f4 = ((f4 << 4) | (int(data[n]) >> 4)) & 0xffffffff
+            hist = np.concatenate([[data[n]], hist[:-1]]).astype(np.uint8)
