@@ -185,3 +185,101 @@ int orc_p8_ctxmodel_step(P8CtxModel* m, int y, int bpos, int c0, uint32_t c4, ui
   orc_p8_cm_step(m->cm, y, bpos, c0, last[0], cx, nset, out, &nout);
   return nout;
 }
+
+/* ---- sparseModel (:4504-4535): 42 skip / masked contexts of the last bytes; sparseModel1 (:4539-4596): 31 contexts
+ * mixing byte history with the word-level globals, plus seven SmallStationaryContextMaps. g[] = c4, f4, x4, w4, tt,
+ * words, spaces, frstchar, spafdo (plain globals maintained elsewhere in paq8); last[i-1] = buf(i), i = 1..10. ---- */
+typedef struct DMap DMap;
+DMap* orc_p8_dmap_new(int kind, int bits_of_context, int bits_per_context, int rate);
+void orc_p8_dmap_set_direct(DMap* m, uint32_t ctx);
+int orc_p8_dmap_mix(DMap* m, int y, int a, int mul, int div, int16_t* out);
+
+typedef struct { int which; CM1* cm; DMap* scm[7]; } P8Sparse;
+P8Sparse* orc_p8_sparse_new(int which, int level) {
+  P8Sparse* m = (P8Sparse*)calloc(1, sizeof *m);
+  m->which = which;
+  if (which == 0) m->cm = orc_p8_cm_new(mem_of(level) * 2, 40 + 2);
+  else {
+    m->cm = orc_p8_cm_new(mem_of(level) * 4, 31);
+    static const int bits[7] = {7, 8, 4, 6, 4, 4, 7};  /* scm1 .. scm6, scma */
+    for (int i = 0; i < 7; ++i) m->scm[i] = orc_p8_dmap_new(0, bits[i], 8, 0);
+  }
+  return m;
+}
+#define BUF(i) ((uint32_t)last[(i) - 1])
+int orc_p8_sparse_step(P8Sparse* m, int y, int bpos, int c0, const uint32_t* g, int seenbefore, int howmany,
+                       const uint8_t* last, int16_t* out) {
+  const uint32_t c4 = g[0], f4 = g[1], x4 = g[2], w4 = g[3], tt = g[4], words = g[5], spaces = g[6], frstchar = g[7],
+                 spafdo = g[8];
+  uint64_t cx[48];
+  int n = 0, nout = 0;
+  if (bpos == 0 && m->which == 0) {
+    uint64_t i = 0;
+    ++i; cx[n++] = H2(i, seenbefore);
+    ++i; cx[n++] = H2(i, howmany);
+    ++i; cx[n++] = H2(i, BUF(1) | BUF(5) << 8);
+    ++i; cx[n++] = H2(i, BUF(1) | BUF(6) << 8);
+    ++i; cx[n++] = H2(i, BUF(3) | BUF(6) << 8);
+    ++i; cx[n++] = H2(i, BUF(4) | BUF(8) << 8);
+    ++i; cx[n++] = H2(i, BUF(1) | BUF(3) << 8 | BUF(5) << 16);
+    ++i; cx[n++] = H2(i, BUF(2) | BUF(4) << 8 | BUF(6) << 16);
+    static const uint32_t masks1[5] = {0x00f0f0ff, 0x00ff00ff, 0xff0000ff, 0x00f8f8f8, 0xf8f8f8f8};
+    for (int k = 0; k < 5; ++k) { ++i; cx[n++] = H2(i, c4 & masks1[k]); }
+    ++i; cx[n++] = H2(i, f4 & 0x00000fff);
+    ++i; cx[n++] = H2(i, f4);
+    static const uint32_t masks2[6] = {0x00e0e0e0, 0xe0e0e0e0, 0x810000c1, 0xC3CCC38C, 0x0081CC81, 0x00c10081};
+    for (int k = 0; k < 6; ++k) { ++i; cx[n++] = H2(i, c4 & masks2[k]); }
+    for (int j = 1; j < 8; ++j) {
+      ++i; cx[n++] = H2(i, (uint32_t)seenbefore | BUF(j) << 8);
+      ++i; cx[n++] = H2(i, (BUF(j + 2) << 8) | BUF(j + 1));
+      ++i; cx[n++] = H2(i, (BUF(j + 3) << 8) | BUF(j + 1));
+    }
+  } else if (bpos == 0) {
+    orc_p8_dmap_set_direct(m->scm[4], (uint32_t)seenbefore);  /* scm5 */
+    orc_p8_dmap_set_direct(m->scm[5], (uint32_t)howmany);     /* scm6 */
+    uint32_t h = x4 << 6;
+    cx[n++] = BUF(1) + (h & 0xffffff00);
+    cx[n++] = BUF(1) + (h & 0x00ffff00);
+    cx[n++] = BUF(1) + (h & 0x0000ff00);
+    uint32_t d = c4 & 0xffff;
+    h <<= 6;
+    cx[n++] = d + (h & 0xffff0000);
+    cx[n++] = d + (h & 0x00ff0000);
+    h <<= 6; d = c4 & 0xffffff;
+    cx[n++] = d + (h & 0xff000000);
+    for (int i = 1; i < 5; ++i) {
+      cx[n++] = (uint32_t)seenbefore | BUF(i) << 8;
+      cx[n++] = (BUF(i + 3) << 8) | BUF(i + 1);
+    }
+    cx[n++] = spaces & 0x7fff;
+    cx[n++] = spaces & 0xff;
+    cx[n++] = words & 0x1ffff;
+    cx[n++] = f4 & 0x000fffff;
+    cx[n++] = tt & 0x00000fff;
+    h = w4 << 6;
+    cx[n++] = BUF(1) + (h & 0xffffff00);
+    cx[n++] = BUF(1) + (h & 0x00ffff00);
+    cx[n++] = BUF(1) + (h & 0x0000ff00);
+    d = c4 & 0xffff;
+    h <<= 6;
+    cx[n++] = d + (h & 0xffff0000);
+    cx[n++] = d + (h & 0x00ff0000);
+    h <<= 6; d = c4 & 0xffffff;
+    cx[n++] = d + (h & 0xff000000);
+    cx[n++] = w4 & 0xf0f0f0ff;
+    cx[n++] = (w4 & 63) * 128 + (5 << 17);
+    cx[n++] = (f4 & 0xffff) << 11 | frstchar;
+    cx[n++] = spafdo * 8 * ((w4 & 3) == 1);
+    orc_p8_dmap_set_direct(m->scm[0], words & 127);
+    orc_p8_dmap_set_direct(m->scm[1], (words & 12) * 16 + (w4 & 12) * 4 + (BUF(1) >> 4));
+    orc_p8_dmap_set_direct(m->scm[2], w4 & 15);
+    orc_p8_dmap_set_direct(m->scm[3], spafdo * ((w4 & 3) == 1));
+    orc_p8_dmap_set_direct(m->scm[6], frstchar);
+  }
+  orc_p8_cm_step(m->cm, y, bpos, c0, last[0], cx, n, out, &nout);
+  if (m->which == 1) {
+    static const int order[7] = {0, 1, 2, 3, 4, 5, 6};  /* scm1, scm2, scm3, scm4, scm5, scm6, scma */
+    for (int k = 0; k < 7; ++k) nout += orc_p8_dmap_mix(m->scm[order[k]], y, 7, 1, 4, out + nout);
+  }
+  return nout;
+}

@@ -240,6 +240,23 @@ int refp8_ctxmodel_step(int which, int level, int y_prev, int bpos, int c0, uint
   return drain(out);
 }
 
+// sparseModel (:4504-4535) and sparseModel1 (:4539-4596). g[] = the plain globals they read, in this order:
+// c4, f4, x4, w4, tt, words, spaces, frstchar, spafdo; seenbefore / howmany are their arguments.
+int refp8_sparse_step(int which, int level, int y_prev, int bpos, int c0, const uint32_t* g, int seenbefore, int howmany,
+                      const uint8_t* last, int nlast, int16_t* out) {
+  paq8::level = level;
+  paq8::y = y_prev;
+  paq8::bpos = bpos;
+  paq8::c0 = c0;
+  paq8::c4 = g[0]; paq8::f4 = g[1]; paq8::x4 = g[2]; paq8::w4 = g[3]; paq8::tt = g[4];
+  paq8::words = g[5]; paq8::spaces = g[6]; paq8::frstchar = g[7]; paq8::spafdo = g[8];
+  if (paq8::buf.size() == 0) paq8::buf.setsize(1 << 16);
+  for (int i = 1; i <= nlast; ++i) paq8::buf[paq8::pos - i] = last[i - 1];
+  if (which == 0) paq8::sparseModel(*sink(), seenbefore, howmany);
+  else paq8::sparseModel1(*sink(), seenbefore, howmany);
+  return drain(out);
+}
+
 uint64_t refp8_hash2(uint64_t a, uint64_t b) { return paq8::hash(a, b); }
 uint64_t refp8_hash3(uint64_t a, uint64_t b, uint64_t c) { return paq8::hash(a, b, c); }
 uint64_t refp8_hash6(uint64_t a, uint64_t b, uint64_t c, uint64_t d, uint64_t e, uint64_t f) { return paq8::hash(a, b, c, d, e, f); }

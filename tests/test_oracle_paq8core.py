@@ -373,3 +373,40 @@ def test_nest_distance_indirect_models_vs_reference():
             c4 = ((c4 << 8) | int(data[n])) & 0xffffffff
             f4 = ((f4 << 4) | (int(data[n]) >> 4)) & 0xffffffff
             hist = np.concatenate([[data[n]], hist[:-1]]).astype(np.uint8)
+
+
+@needs_ref
+def test_sparse_models_vs_reference():
+    """sparseModel (42 skip contexts) and sparseModel1 (31 contexts + 7 SSCMs) against the reference's own functions;
+    the word-level globals they read are inputs here (arbitrary but history-derived values)."""
+    from cmix_amd import synth
+    L, lib = R.paq8core_lib(), O.lib()
+    data = np.frombuffer(synth.enwik_like(4000, 47), np.uint8)
+    level = 5
+    L.refp8_rnd_reset()
+    lib.orc_p8_rnd_reset()
+    for which, nout in ((0, 42 * 5), (1, 29 * 5 + 14)):  # sparseModel1 sets 29 of its 31 slots
+        got = lib.orc_p8_sparse_new(which, level)
+        o_ref, o_got = np.zeros(512, np.int16), np.zeros(512, np.int16)
+        hist = np.zeros(10, np.uint8)
+        g = np.zeros(9, np.uint32)
+        y, c0 = 0, 1
+        for n in range(len(data)):
+            seen, many = int(g[2] % 7), int(g[3] % 11)
+            for bpos in range(8):
+                k = L.refp8_sparse_step(which, level, y, bpos, c0, g.ctypes.data, seen, many, hist.ctypes.data, 10, o_ref.ctypes.data)
+                assert lib.orc_p8_sparse_step(got, y, bpos, c0, g.ctypes.data, seen, many, hist.ctypes.data, o_got.ctypes.data) == k == nout
+                assert (o_ref[:k] == o_got[:k]).all(), (which, n, bpos)
+                y = (int(data[n]) >> (7 - bpos)) & 1
+                c0 = (c0 << 1 | y) if bpos < 7 else 1
+            b = int(data[n])
+            g[0] = ((int(g[0]) << 8) | b) & 0xffffffff                      # c4
+            g[1] = ((int(g[1]) << 4) | (b >> 4)) & 0xffffffff               # f4
+            g[2] = (int(g[2]) * 256 + b) & 0xffffffff                       # x4
+            g[3] = (int(g[3]) * 4 + (b >> 6)) & 0xffffffff                  # w4
+            g[4] = (int(g[4]) * 8 + (b & 7)) & 0xffffffff                   # tt
+            g[5] = (int(g[5]) * 2 + (1 if chr(b).isalpha() else 0)) & 0xffffffff   # words
+            g[6] = (int(g[6]) * 2 + (1 if b == 32 else 0)) & 0xffffffff     # spaces
+            g[7] = b if b in (32, 61, 91) else int(g[7])                    # frstchar
+            g[8] = 0 if b == 46 else min(63, int(g[8]) + 1)                 # spafdo
+            hist = np.concatenate([[data[n]], hist[:-1]]).astype(np.uint8)
