@@ -283,3 +283,7 @@ int orc_p8_sparse_step(P8Sparse* m, int y, int bpos, int c0, const uint32_t* g, 
   }
   return nout;
 }
+
+uint64_t orc_p8_hash5(uint64_t a, uint64_t b, uint64_t c, uint64_t d, uint64_t e) {
+  return hashn(5, (const uint64_t[]){a, b, c, d, e});
+}

@@ -1,0 +1,146 @@
+/* oracle/paq8_match.c -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+ *
+ * CPU restatement of paq8's MatchModel (reference src/models/paq8.cpp:3520-3692): the longest-match predictor over the
+ * whole byte history -- three hashes of the last 9 / 7 / 5 bytes into a position table, match verification and
+ * extension, "delta" mode after a miss, and its read-out through three StateMap32s, three SmallStationaryContextMaps
+ * and three StationaryMaps plus an IndirectContext<U8>(19, 1). Pinned against the reference's own class in
+ * tests/test_oracle_paq8core.py. hist[] is the reference's Buf: a ring of bmask + 1 bytes, hist[(pos-1) & bmask] = the
+ * last byte. */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+int orc_p8_stretch(int p);
+int orc_p8_ilog(int x);
+uint64_t orc_p8_combine64(uint64_t seed, uint64_t x);
+uint32_t orc_p8_finalize64(uint64_t h, int bits);
+uint64_t orc_p8_hash5(uint64_t a, uint64_t b, uint64_t c, uint64_t d, uint64_t e);
+typedef struct DMap DMap;
+DMap* orc_p8_dmap_new(int kind, int bits_of_context, int bits_per_context, int rate);
+void orc_p8_dmap_set_direct(DMap* m, uint32_t ctx);
+void orc_p8_dmap_set(DMap* m, uint64_t ctx);
+int orc_p8_dmap_mix(DMap* m, int y, int a, int mul, int div, int16_t* out);
+typedef struct OrcP8StateMap32 OrcP8StateMap32;
+OrcP8StateMap32* orc_p8_statemap32_new(int n);
+int orc_p8_statemap32_p(OrcP8StateMap32* s, int y, int cx, int limit);
+
+enum { MaxLen = 0xFFFF, MinLen = 5, StepSize = 2, DeltaLen = 5, NumCtxs = 3, NumHashes = 3 };
+static unsigned ilog2u(unsigned x) { unsigned n = 0; while (x > 1) { x >>= 1; ++n; } return n; }
+
+typedef struct {
+  uint32_t* table;
+  uint32_t mask, hashes[NumHashes], length, index;
+  int hashbits;
+  uint8_t expected, delta;
+  OrcP8StateMap32* sm[NumCtxs];
+  DMap *scm[3], *maps[3];
+  uint8_t* ictx;       /* IndirectContext<U8>(19, 1): 1 << 19 cells, 1 input bit */
+  uint32_t ictx_cur;
+} Match;
+
+Match* orc_p8_match_new(uint32_t size) {
+  Match* m = (Match*)calloc(1, sizeof *m);
+  m->table = (uint32_t*)calloc(size / 4, 4);
+  m->mask = size / 4 - 1;
+  m->hashbits = (int)ilog2u(m->mask + 1);
+  m->sm[0] = orc_p8_statemap32_new(56 * 256);
+  m->sm[1] = orc_p8_statemap32_new(8 * 256 * 256 + 1);
+  m->sm[2] = orc_p8_statemap32_new(256 * 256);
+  m->scm[0] = orc_p8_dmap_new(0, 8, 8, 0);
+  m->scm[1] = orc_p8_dmap_new(0, 11, 1, 0);
+  m->scm[2] = orc_p8_dmap_new(0, 8, 8, 0);
+  m->maps[0] = orc_p8_dmap_new(1, 16, 8, 0);
+  m->maps[1] = orc_p8_dmap_new(1, 22, 1, 0);
+  m->maps[2] = orc_p8_dmap_new(1, 4, 1, 0);
+  m->ictx = (uint8_t*)calloc(1 << 19, 1);
+  return m;
+}
+/* Buf (:169-187): a ring of 2^k bytes; buffer(i) = i-th last byte, buffer[i] = absolute position, both wrapped */
+#define BUFB(i) ((uint32_t)hist[((uint32_t)pos - (uint32_t)(i)) & bmask])
+#define BUFA(i) ((uint32_t)hist[(uint32_t)(i) & bmask])
+static void ictx_add_set(Match* m, int y, uint32_t next) {  /* iCtx += y, iCtx = next  (:1484-1490) */
+  m->ictx[m->ictx_cur] = (uint8_t)((m->ictx[m->ictx_cur] << 1) | (y & 1));
+  m->ictx_cur = next & ((1u << 19) - 1);
+}
+static uint64_t maps1_ctx(Match* m, int c0, const uint8_t* hist, int pos, uint32_t bmask) {
+  const unsigned lg = ilog2u(m->length + 1);
+  return orc_p8_hash5(m->expected, (uint64_t)c0, BUFB(1), BUFB(2), lg < 3 ? lg : 3);
+}
+static void match_update(Match* m, int y, int c0, const uint8_t* hist, int pos, uint32_t bmask) {  /* Update() :3544-3596 */
+  m->delta = 0;
+  unsigned minLen = MinLen + (NumHashes - 1) * StepSize;
+  for (unsigned i = 0; i < NumHashes; i++, minLen -= StepSize) {
+    uint64_t h = 0;
+    for (unsigned j = minLen; j > 0; j--) h = orc_p8_combine64(h, BUFB(j));
+    m->hashes[i] = orc_p8_finalize64(h, m->hashbits);
+  }
+  if (m->length) {
+    m->index++;
+    if (m->length < MaxLen) m->length++;
+  } else {
+    unsigned bestLen = 0, bestIndex = 0;
+    minLen = MinLen + (NumHashes - 1) * StepSize;
+    for (unsigned i = 0; i < NumHashes && m->length < minLen; i++, minLen -= StepSize) {
+      m->index = m->table[m->hashes[i]];
+      if (m->index > 0) {
+        m->length = 0;
+        while (m->length < minLen && BUFB(m->length + 1) == BUFA(m->index - m->length - 1)) m->length++;
+        if (m->length > bestLen) { bestLen = m->length; bestIndex = m->index; }
+      }
+    }
+    if (bestLen >= MinLen) { m->length = bestLen - (MinLen - 1); m->index = bestIndex; }
+    else m->length = m->index = 0;
+  }
+  for (unsigned i = 0; i < NumHashes; i++) m->table[m->hashes[i]] = (uint32_t)pos;
+  m->expected = (uint8_t)BUFA(m->index);
+  ictx_add_set(m, y, (BUFB(1) << 8) | m->expected);
+  orc_p8_dmap_set_direct(m->scm[0], m->expected);
+  orc_p8_dmap_set_direct(m->scm[1], m->expected);
+  orc_p8_dmap_set_direct(m->scm[2], (uint32_t)pos);
+  orc_p8_dmap_set_direct(m->maps[0], ((uint32_t)m->expected << 8) | BUFB(1));
+  orc_p8_dmap_set(m->maps[1], maps1_ctx(m, c0, hist, pos, bmask));
+  orc_p8_dmap_set_direct(m->maps[2], m->ictx[m->ictx_cur]);
+}
+/* Predict() :3630-3691. Returns the match length; *expected_out = Stats->Match.expectedByte. */
+int orc_p8_match_step(Match* m, int y, int bpos, int c0, const uint8_t* hist, uint32_t bmask, int pos, int16_t* out,
+                      int* nout, int* expected_out) {
+  int n = 0;
+  if (bpos == 0) match_update(m, y, c0, hist, pos, bmask);
+  else {
+    const uint8_t B = (uint8_t)(c0 << (8 - bpos));
+    orc_p8_dmap_set_direct(m->scm[1], ((uint32_t)bpos << 8) | (uint32_t)(m->expected ^ B));
+    orc_p8_dmap_set(m->maps[1], maps1_ctx(m, c0, hist, pos, bmask));
+    ictx_add_set(m, y, ((uint32_t)bpos << 16) | (BUFB(1) << 8) | (uint32_t)(m->expected ^ B));
+    orc_p8_dmap_set_direct(m->maps[2], m->ictx[m->ictx_cur]);
+  }
+  if (bpos == 0) *expected_out = m->length > 0 ? m->expected : 0;
+  const int expectedBit = (m->expected >> (7 - bpos)) & 1;
+  if (m->length > 0) {
+    const int isMatch = bpos == 0 ? (BUFB(1) == BUFA(m->index - 1)) : (((m->expected + 256) >> (8 - bpos)) == c0);
+    if (!isMatch) { m->delta = (m->length + MinLen) > DeltaLen; m->length = 0; }
+  }
+  uint32_t ctx[NumCtxs] = {0, 0, 0};
+  if (m->length > 0) {
+    if (m->length <= 16) ctx[0] = (m->length - 1) * 2 + (uint32_t)expectedBit;
+    else ctx[0] = 24 + (((m->length - 1) < 63 ? (m->length - 1) : 63) >> 2) * 2 + (uint32_t)expectedBit;
+    ctx[0] = (ctx[0] << 8) | (uint32_t)c0;
+    ctx[1] = (((uint32_t)m->expected << 11) | ((uint32_t)bpos << 8) | BUFB(1)) + 1;
+    const int sign = 2 * expectedBit - 1;
+    out[n++] = (int16_t)(sign * (int)((m->length < 32 ? m->length : 32) << 5));
+    out[n++] = (int16_t)(sign * (orc_p8_ilog((int)(m->length & 0xffff)) << 2));
+  } else { out[n++] = 0; out[n++] = 0; }
+  if (m->delta) ctx[2] = ((uint32_t)m->expected << 8) | (uint32_t)c0;
+  for (int i = 0; i < NumCtxs; i++) {
+    const int p = orc_p8_statemap32_p(m->sm[i], y, (int)ctx[i], 1023);
+    out[n++] = (int16_t)(ctx[i] != 0 ? (orc_p8_stretch(p) + 1) >> 1 : 0);
+  }
+  n += orc_p8_dmap_mix(m->scm[0], y, 7, 1, 4, out + n);
+  n += orc_p8_dmap_mix(m->scm[1], y, 6, 1, 4, out + n);
+  n += orc_p8_dmap_mix(m->scm[2], y, 5, 1, 4, out + n);
+  n += orc_p8_dmap_mix(m->maps[0], y, 255, 1, 4, out + n);
+  n += orc_p8_dmap_mix(m->maps[1], y, 1023, 1, 4, out + n);
+  n += orc_p8_dmap_mix(m->maps[2], y, 1023, 1, 4, out + n);
+  if (bpos != 0) *expected_out = -1;
+  *nout = n;
+  return (int)m->length;
+}

@@ -257,8 +257,30 @@ int refp8_sparse_step(int which, int level, int y_prev, int bpos, int c0, const 
   return drain(out);
 }
 
+// MatchModel (:3520-3692): needs random access to the whole history. refp8_buf_reset / refp8_buf_push keep the
+// reference's own buffer and `pos` the way Predictor::update does (buf[pos++] = byte, :8254).
+void refp8_buf_reset(int log2size) {
+  paq8::buf.setsize(1u << log2size);
+  for (uint32_t i = 0; i < paq8::buf.size(); ++i) paq8::buf[i] = 0;
+  paq8::pos = 0;
+}
+void refp8_buf_push(int byte) { paq8::buf[paq8::pos++] = (paq8::U8)byte; }
+void* refp8_match_new(uint32_t size) { return new paq8::MatchModel(size); }
+int refp8_match_step(void* h, int y_prev, int bpos, int c0, int16_t* out, int* nout, int* expected_byte) {
+  paq8::y = y_prev;
+  paq8::bpos = bpos;
+  paq8::c0 = c0;
+  paq8::ModelStats st;
+  memset(&st, 0, sizeof st);
+  const int len = ((paq8::MatchModel*)h)->Predict(*sink(), paq8::buf, &st);
+  *nout = drain(out);
+  *expected_byte = st.Match.expectedByte;
+  return len;
+}
+
 uint64_t refp8_hash2(uint64_t a, uint64_t b) { return paq8::hash(a, b); }
 uint64_t refp8_hash3(uint64_t a, uint64_t b, uint64_t c) { return paq8::hash(a, b, c); }
+uint64_t refp8_hash5(uint64_t a, uint64_t b, uint64_t c, uint64_t d, uint64_t e) { return paq8::hash(a, b, c, d, e); }
 uint64_t refp8_hash6(uint64_t a, uint64_t b, uint64_t c, uint64_t d, uint64_t e, uint64_t f) { return paq8::hash(a, b, c, d, e, f); }
 uint64_t refp8_combine64(uint64_t seed, uint64_t x) { return paq8::combine64(seed, x); }
 uint32_t refp8_finalize64(uint64_t h, int bits) { return paq8::finalize64(h, bits); }

@@ -410,3 +410,35 @@ def test_sparse_models_vs_reference():
             g[7] = b if b in (32, 61, 91) else int(g[7])                    # frstchar
             g[8] = 0 if b == 46 else min(63, int(g[8]) + 1)                 # spafdo
             hist = np.concatenate([[data[n]], hist[:-1]]).astype(np.uint8)
+
+
+@needs_ref
+def test_match_model_vs_reference():
+    """MatchModel: repeated passages (long matches, extension, recovery after a miss -> delta mode), against the
+    reference's own class over its own ring buffer."""
+    from cmix_amd import synth
+    L, lib = R.paq8core_lib(), O.lib()
+    a = synth.enwik_like(1500, 53)
+    data = np.frombuffer(a + a[200:900] + b"XY" + a[300:1200] + a[:700] + bytes(50) + a[100:600], np.uint8)
+    LOG = 16
+    L.refp8_buf_reset(LOG)
+    ring = np.zeros(1 << LOG, np.uint8)
+    ref, got = L.refp8_match_new(1 << 18), lib.orc_p8_match_new(1 << 18)
+    o_ref, o_got = np.zeros(32, np.int16), np.zeros(32, np.int16)
+    n_ref, n_got, e_ref, e_got = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+    y, c0, longest = 0, 1, 0
+    for n in range(len(data)):
+        for bpos in range(8):
+            r = L.refp8_match_step(ref, y, bpos, c0, o_ref.ctypes.data, C.byref(n_ref), C.byref(e_ref))
+            g = lib.orc_p8_match_step(got, y, bpos, c0, ring.ctypes.data, (1 << LOG) - 1, n, o_got.ctypes.data, C.byref(n_got),
+                                      C.byref(e_got))
+            assert r == g and n_ref.value == n_got.value == 17, (n, bpos, r, g, n_ref.value, n_got.value)
+            assert (o_ref[:17] == o_got[:17]).all(), (n, bpos, o_ref[:17], o_got[:17])
+            if bpos == 0:
+                assert e_ref.value == e_got.value
+            longest = max(longest, r)
+            y = (int(data[n]) >> (7 - bpos)) & 1
+            c0 = (c0 << 1 | y) if bpos < 7 else 1
+        L.refp8_buf_push(int(data[n]))
+        ring[n] = data[n]
+    assert longest > 400
