@@ -144,3 +144,134 @@ int orc_p8_match_step(Match* m, int y, int bpos, int c0, const uint8_t* hist, ui
   *nout = n;
   return (int)m->length;
 }
+
+/* ---- SparseMatchModel (:3694-3843): four "sparse" match finders (byte masks, skipped bytes, strides) tried in
+ * move-to-front order (MTFList :1498-1528), read out through four StationaryMaps and two indirect contexts, plus two
+ * mixer weight-set selectors. ---- */
+typedef struct { uint32_t offset, stride, deletions, minLen, bitMask; } SparseCfg;
+typedef struct {
+  uint32_t* table;
+  uint32_t mask, hashes[4], hashIndex, length, index;
+  int hashbits;
+  uint8_t expected, valid;
+  DMap* maps[4];
+  uint8_t* ictx8; uint32_t ictx8_cur;     /* IndirectContext<U8>(19, 1) */
+  uint16_t* ictx16; uint32_t ictx16_cur;  /* IndirectContext<U16>(16) */
+  int root, idx, prev[4], next[4];        /* MTFList(4) */
+  SparseCfg sparse[4];
+} SMatch;
+
+SMatch* orc_p8_sparsematch_new(uint64_t size) {
+  SMatch* m = (SMatch*)calloc(1, sizeof *m);
+  m->table = (uint32_t*)calloc(size / 4, 4);
+  m->mask = (uint32_t)(size / 4 - 1);
+  m->hashbits = (int)ilog2u(m->mask + 1);
+  m->maps[0] = orc_p8_dmap_new(1, 22, 1, 0);
+  m->maps[1] = orc_p8_dmap_new(1, 14, 4, 0);
+  m->maps[2] = orc_p8_dmap_new(1, 8, 1, 0);
+  m->maps[3] = orc_p8_dmap_new(1, 19, 1, 0);
+  m->ictx8 = (uint8_t*)calloc(1 << 19, 1);
+  m->ictx16 = (uint16_t*)calloc(1 << 16, 2);
+  for (int i = 0; i < 4; ++i) {
+    m->prev[i] = i - 1; m->next[i] = i + 1;
+    m->sparse[i] = (SparseCfg){0, 1, 0, 3, 0xFF};
+  }
+  m->next[3] = -1;
+  m->sparse[0].minLen = 5; m->sparse[0].bitMask = 0xDF;
+  m->sparse[1].offset = 1; m->sparse[1].minLen = 4;
+  m->sparse[2].stride = 2; m->sparse[2].minLen = 4; m->sparse[2].bitMask = 0xDF;
+  m->sparse[3].minLen = 5; m->sparse[3].bitMask = 0xF;
+  return m;
+}
+static void mtf_front(SMatch* m, int i) {  /* MTFList::MoveToFront */
+  m->idx = i;
+  if (i == m->root) return;
+  const int p = m->prev[i], n = m->next[i];
+  if (p >= 0) m->next[p] = m->next[i];
+  if (n >= 0) m->prev[n] = m->prev[i];
+  m->prev[m->root] = i;
+  m->next[i] = m->root;
+  m->root = i;
+  m->prev[m->root] = -1;
+}
+static uint64_t smaps0_ctx(SMatch* m, int c0, const uint8_t* hist, int pos, uint32_t bmask) {
+  return orc_p8_hash5(m->expected, (uint64_t)c0, BUFB(1), BUFB(2), ilog2u(m->length + 1) * 4 + m->hashIndex);
+}
+static void smatch_update(SMatch* m, int y, int c0, const uint8_t* hist, int pos, uint32_t bmask) {
+  for (unsigned i = 0; i < 4; i++) {
+    uint64_t h = 0;
+    for (unsigned j = 0, k = m->sparse[i].offset + 1; j < m->sparse[i].minLen; j++, k += m->sparse[i].stride)
+      h = orc_p8_combine64(h, BUFB(k) & m->sparse[i].bitMask);
+    m->hashes[i] = orc_p8_finalize64(h, m->hashbits);
+  }
+  if (m->length) {
+    m->index++;
+    if (m->length < 0xFFFF) m->length++;
+  } else {
+    for (int i = (m->idx = m->root); i >= 0; i = (m->idx >= 0 ? (m->idx = m->next[m->idx]) : m->idx)) {
+      m->index = m->table[m->hashes[i]];
+      if (m->index > 0) {
+        uint32_t offset = m->sparse[i].offset + 1;
+        while (m->length < m->sparse[i].minLen && ((BUFB(offset) ^ BUFA(m->index - offset)) & m->sparse[i].bitMask) == 0) {
+          m->length++;
+          offset += m->sparse[i].stride;
+        }
+        if (m->length >= m->sparse[i].minLen) {
+          m->length -= (m->sparse[i].minLen - 1);
+          m->index += m->sparse[i].deletions;
+          m->hashIndex = (uint32_t)i;
+          mtf_front(m, i);
+          break;
+        }
+      }
+      m->length = m->index = 0;
+    }
+  }
+  for (unsigned i = 0; i < 4; i++) m->table[m->hashes[i]] = (uint32_t)pos;
+  m->expected = (uint8_t)BUFA(m->index);
+  if (m->valid) {
+    m->ictx8[m->ictx8_cur] = (uint8_t)((m->ictx8[m->ictx8_cur] << 1) | (y & 1));
+    m->ictx16[m->ictx16_cur] = (uint16_t)((m->ictx16[m->ictx16_cur] << 8) | (BUFB(1) & 0xff));
+  }
+  m->valid = m->length > 1;
+  if (m->valid) {
+    orc_p8_dmap_set(m->maps[0], smaps0_ctx(m, c0, hist, pos, bmask));
+    orc_p8_dmap_set_direct(m->maps[1], ((uint32_t)m->expected << 8) | BUFB(1));
+    m->ictx8_cur = ((BUFB(1) << 8) | m->expected) & ((1u << 19) - 1);
+    m->ictx16_cur = ((BUFB(1) << 8) | m->expected) & 0xffff;
+    orc_p8_dmap_set_direct(m->maps[2], m->ictx8[m->ictx8_cur]);
+    orc_p8_dmap_set_direct(m->maps[3], m->ictx16[m->ictx16_cur]);
+  }
+}
+int orc_p8_sparsematch_step(SMatch* m, int y, int bpos, int c0, const uint8_t* hist, uint32_t bmask, int pos, int16_t* out,
+                            int* nout, int* sets) {
+  const uint8_t B = (uint8_t)(c0 << (8 - bpos));
+  int n = 0;
+  if (bpos == 0) smatch_update(m, y, c0, hist, pos, bmask);
+  else if (m->valid) {
+    orc_p8_dmap_set(m->maps[0], smaps0_ctx(m, c0, hist, pos, bmask));
+    if (bpos == 4) orc_p8_dmap_set_direct(m->maps[1], 0x10000u | ((uint32_t)(m->expected ^ (uint8_t)(c0 << 4)) << 8) | BUFB(1));
+    m->ictx8[m->ictx8_cur] = (uint8_t)((m->ictx8[m->ictx8_cur] << 1) | (y & 1));
+    m->ictx8_cur = (((uint32_t)bpos << 16) | (BUFB(1) << 8) | (uint32_t)(m->expected ^ B)) & ((1u << 19) - 1);
+    orc_p8_dmap_set_direct(m->maps[2], m->ictx8[m->ictx8_cur]);
+    orc_p8_dmap_set_direct(m->maps[3], ((uint32_t)bpos << 16) | (m->ictx16[m->ictx16_cur] ^ (uint32_t)(B | (B << 8))));
+  }
+  if (m->length > 0 && (((m->expected ^ B) & m->sparse[m->hashIndex].bitMask) >> (8 - bpos)) != 0) m->length = 0;
+  if (m->valid) {
+    if (m->length > 1 && ((m->sparse[m->hashIndex].bitMask >> (7 - bpos)) & 1) > 0) {
+      const int expectedBit = (m->expected >> (7 - bpos)) & 1, sign = 2 * expectedBit - 1;
+      const uint32_t l1 = m->length - 1, l2 = m->length - 2;
+      out[n++] = (int16_t)(sign * (int)((l1 < 64 ? l1 : 64) << 4));
+      out[n++] = (int16_t)((sign * (1 << (l2 < 3 ? l2 : 3)) * (int)(l1 < 8 ? l1 : 8)) << 4);
+      out[n++] = (int16_t)(sign * 512);
+    } else { out[n++] = 0; out[n++] = 0; out[n++] = 0; }
+    for (int i = 0; i < 4; i++) n += orc_p8_dmap_mix(m->maps[i], y, 1023, 1, 2, out + n);
+  } else {
+    for (int i = 0; i < 11; i++) out[n++] = 0;
+  }
+  const uint32_t l7 = m->length < 7 ? m->length : 7, lg = ilog2u(m->length + 1);
+  sets[0] = (int)((m->hashIndex << 6) | ((uint32_t)bpos << 3) | l7);
+  sets[1] = 4 * 64 + (int)((m->hashIndex << 11) | ((lg < 7 ? lg : 7) << 8) | ((uint32_t)c0 ^ (uint32_t)(m->expected >> (8 - bpos))));
+  *nout = n;
+  return (int)m->length;
+}

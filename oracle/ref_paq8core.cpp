@@ -45,6 +45,12 @@ struct MixerNx { typedef int paq8::Mixer::*type; friend type get(MixerNx); };
 struct MixerTx { typedef paq8::Array<short, 16> paq8::Mixer::*type; friend type get(MixerTx); };
 template struct Rob<MixerNx, &paq8::Mixer::nx>;
 template struct Rob<MixerTx, &paq8::Mixer::tx>;
+struct MixerCxt { typedef paq8::Array<int> paq8::Mixer::*type; friend type get(MixerCxt); };
+struct MixerNcxt { typedef int paq8::Mixer::*type; friend type get(MixerNcxt); };
+struct MixerBase { typedef int paq8::Mixer::*type; friend type get(MixerBase); };
+template struct Rob<MixerCxt, &paq8::Mixer::cxt>;
+template struct Rob<MixerNcxt, &paq8::Mixer::ncxt>;
+template struct Rob<MixerBase, &paq8::Mixer::base>;
 struct RndTable { typedef paq8::Array<paq8::U32> paq8::Random::*type; friend type get(RndTable); };
 struct RndI { typedef int paq8::Random::*type; friend type get(RndI); };
 template struct Rob<RndTable, &paq8::Random::table>;
@@ -100,8 +106,19 @@ int refp8_apm_p(void* h, int y_prev, int pr, int cx, int limit) { paq8::y = y_pr
 
 // ---- the models below hand their outputs to a Mixer through add(): a recording mixer collects them ----
 static paq8::Mixer* sink() {
-  static paq8::Mixer* m = new paq8::Mixer(4096, 1, 1, 0);
+  static paq8::Mixer* m = new paq8::Mixer(4096, 1, 64, 0);  // room for 64 set() calls per step
   return m;
+}
+// the weight-set selectors a model handed to Mixer::set(): the cumulative values the mixer stored (base + cx)
+static int drain_sets(int* out) {
+  paq8::Mixer* m = sink();
+  int& ncxt = m->*get(MixerNcxt());
+  paq8::Array<int>& cxt = m->*get(MixerCxt());
+  const int n = ncxt;
+  for (int i = 0; i < n; ++i) out[i] = cxt[i];
+  ncxt = 0;
+  m->*get(MixerBase()) = 0;
+  return n;
 }
 static int drain(int16_t* out) {
   paq8::Mixer* m = sink();
@@ -275,6 +292,19 @@ int refp8_match_step(void* h, int y_prev, int bpos, int c0, int16_t* out, int* n
   const int len = ((paq8::MatchModel*)h)->Predict(*sink(), paq8::buf, &st);
   *nout = drain(out);
   *expected_byte = st.Match.expectedByte;
+  return len;
+}
+
+// SparseMatchModel (:3694-3843): over the same buffer as MatchModel (refp8_buf_reset / _push). sets[] receives the
+// two mixer weight-set selectors (cumulative, as Mixer::set stores them).
+void* refp8_sparsematch_new(uint64_t size) { return new paq8::SparseMatchModel(size); }
+int refp8_sparsematch_step(void* h, int y_prev, int bpos, int c0, int16_t* out, int* nout, int* sets, int* nsets) {
+  paq8::y = y_prev;
+  paq8::bpos = bpos;
+  paq8::c0 = c0;
+  const int len = ((paq8::SparseMatchModel*)h)->Predict(*sink(), paq8::buf, nullptr);
+  *nout = drain(out);
+  *nsets = drain_sets(sets);
   return len;
 }
 

@@ -442,3 +442,40 @@ def test_match_model_vs_reference():
         L.refp8_buf_push(int(data[n]))
         ring[n] = data[n]
     assert longest > 400
+
+
+@needs_ref
+def test_sparse_match_model_vs_reference():
+    """SparseMatchModel: repeats with case flips (mask 0xDF), a skipped byte, every-other-byte repeats and nibble-only
+    repeats, so that each of the four finders wins at some point (move-to-front order changes)."""
+    from cmix_amd import synth
+    L, lib = R.paq8core_lib(), O.lib()
+    a = synth.enwik_like(1200, 59)
+    up = bytes(c ^ 0x20 if 97 <= c <= 122 else c for c in a[100:500])
+    inter = bytes(b for pair in zip(a[200:500], bytes(i % 251 for i in range(300))) for b in pair)
+    nib = bytes((c & 0x0F) | 0x40 for c in a[300:700])
+    data = np.frombuffer(a + up + b"#" + a[101:600] + inter + inter + nib + a[:400] + nib, np.uint8)
+    LOG = 16
+    L.refp8_buf_reset(LOG)
+    ring = np.zeros(1 << LOG, np.uint8)
+    ref, got = L.refp8_sparsematch_new(1 << 18), lib.orc_p8_sparsematch_new(1 << 18)
+    o_ref, o_got = np.zeros(32, np.int16), np.zeros(32, np.int16)
+    s_ref, s_got = np.zeros(8, np.int32), np.zeros(8, np.int32)
+    n_ref, n_got, k_ref = C.c_int(0), C.c_int(0), C.c_int(0)
+    y, c0 = 0, 1
+    winners = set()
+    for n in range(len(data)):
+        for bpos in range(8):
+            r = L.refp8_sparsematch_step(ref, y, bpos, c0, o_ref.ctypes.data, C.byref(n_ref), s_ref.ctypes.data, C.byref(k_ref))
+            g = lib.orc_p8_sparsematch_step(got, y, bpos, c0, ring.ctypes.data, (1 << LOG) - 1, n, o_got.ctypes.data,
+                                            C.byref(n_got), s_got.ctypes.data)
+            assert r == g and n_ref.value == n_got.value == 11 and k_ref.value == 2, (n, bpos, r, g, n_ref.value, n_got.value)
+            assert (o_ref[:11] == o_got[:11]).all(), (n, bpos, o_ref[:11], o_got[:11])
+            assert (s_ref[:2] == s_got[:2]).all(), (n, bpos, s_ref[:2], s_got[:2])
+            if r > 1:
+                winners.add(int(s_ref[0]) >> 6)
+            y = (int(data[n]) >> (7 - bpos)) & 1
+            c0 = (c0 << 1 | y) if bpos < 7 else 1
+        L.refp8_buf_push(int(data[n]))
+        ring[n] = data[n]
+    assert len(winners) >= 3, winners
