@@ -287,3 +287,89 @@ int orc_p8_sparse_step(P8Sparse* m, int y, int bpos, int c0, const uint32_t* g, 
 uint64_t orc_p8_hash5(uint64_t a, uint64_t b, uint64_t c, uint64_t d, uint64_t e) {
   return hashn(5, (const uint64_t[]){a, b, c, d, e});
 }
+
+/* ---- picModel (:3844-3864): three bit-history contexts over the bits 215 / 431 / 647 bytes back (it runs on every
+ * file type); recordModel1 (:4435-4474): five small ContextMaps over byte / word distances. hist[] = the reference's
+ * ring buffer (bmask + 1 bytes), pos = bytes so far. ---- */
+#include "paq8_tables.h"
+int orc_p8_stretch(int p);
+typedef struct { int cxt; uint16_t t[256]; } Sm16;
+static void sm16i(Sm16* s) {
+  s->cxt = 0;
+  for (int i = 0; i < 256; ++i) {
+    int n0 = P8_STATE[4 * i + 2], n1 = P8_STATE[4 * i + 3];
+    if (n0 == 0) n1 *= 64;
+    if (n1 == 0) n0 *= 64;
+    s->t[i] = (uint16_t)(65536 * (n1 + 1) / (n0 + n1 + 2));
+  }
+}
+static int sm16p(Sm16* s, int y, int cx) {
+  s->t[s->cxt] += ((y << 16) - s->t[s->cxt] + 128) >> 8;
+  return s->t[s->cxt = cx] >> 4;
+}
+typedef struct {
+  int which;
+  uint32_t r0, r1, r2, r3;
+  uint8_t t[0x10200];
+  int cxt[3];
+  Sm16 sm[3];
+  int cpos1[256], wpos1[0x10000];
+  CM1 *cm, *cn, *co, *cp, *cq;
+} P8Small;
+P8Small* orc_p8_small_new(int which) {
+  P8Small* m = (P8Small*)calloc(1, sizeof *m);
+  m->which = which;
+  if (which == 0) for (int i = 0; i < 3; ++i) sm16i(&m->sm[i]);
+  else {
+    m->cm = orc_p8_cm_new(32768, 2); m->cn = orc_p8_cm_new(32768 / 2, 4 + 1); m->co = orc_p8_cm_new(32768 * 4, 4);
+    m->cp = orc_p8_cm_new(32768 * 2, 3); m->cq = orc_p8_cm_new(32768 * 2, 3);
+  }
+  return m;
+}
+static int llog_u(uint32_t x) {  /* llog :268-275 */
+  int orc_p8_ilog(int);
+  if (x >= 0x1000000) return 256 + orc_p8_ilog((int)(x >> 16));
+  if (x >= 0x10000) return 128 + orc_p8_ilog((int)(x >> 8));
+  return orc_p8_ilog((int)x);
+}
+int orc_p8_small_step(P8Small* m, int y, int bpos, int c0, uint32_t c4, uint32_t f4, uint32_t w5, const uint8_t* hist,
+                      uint32_t bmask, int pos, int16_t* out) {
+#define RB(i) ((uint32_t)hist[((uint32_t)pos - (uint32_t)(i)) & bmask])
+  int n = 0;
+  if (m->which == 0) {
+    for (int i = 0; i < 3; ++i) m->t[m->cxt[i]] = P8_STATE[4 * m->t[m->cxt[i]] + y];
+    m->r0 += m->r0 + (uint32_t)y;
+    m->r1 += m->r1 + ((RB(215) >> (7 - bpos)) & 1);
+    m->r2 += m->r2 + ((RB(431) >> (7 - bpos)) & 1);
+    m->r3 += m->r3 + ((RB(647) >> (7 - bpos)) & 1);
+    m->cxt[0] = (int)((m->r0 & 0x7) | ((m->r1 >> 4) & 0x38) | ((m->r2 >> 3) & 0xc0));
+    m->cxt[1] = (int)(0x100 + ((m->r0 & 1) | ((m->r1 >> 4) & 0x3e) | ((m->r2 >> 2) & 0x40) | ((m->r3 >> 1) & 0x80)));
+    m->cxt[2] = (int)(0x200 + ((m->r0 & 0x3f) ^ (m->r1 & 0x3ffe) ^ ((m->r2 << 2) & 0x7f00) ^ ((m->r3 << 5) & 0xf800)));
+    for (int i = 0; i < 3; ++i) out[n++] = (int16_t)orc_p8_stretch(sm16p(&m->sm[i], y, m->t[m->cxt[i]]));
+    return n;
+  }
+  uint64_t a[2], b[5], c3[4], d3[3], e3[3];
+  int na = 0, nb = 0, nc = 0, nd = 0, ne = 0;
+  if (bpos == 0) {
+    const int w = c4 & 0xffff, c = w & 255, d = w & 0xf0ff, e = c4 & 0xffffff;
+    const int dist = pos - m->cpos1[c];
+    a[na++] = (uint64_t)(c << 8 | ((dist < 255 ? dist : 255) / 4));
+    a[na++] = (uint64_t)(int64_t)(w << 9 | llog_u((uint32_t)(pos - m->wpos1[w])) >> 2);
+    b[nb++] = (uint64_t)w; b[nb++] = (uint64_t)(d << 8); b[nb++] = (uint64_t)(c << 16); b[nb++] = f4 & 0xfffff;
+    b[nb++] = (uint64_t)((pos & 3) | 2 << 12);
+    c3[nc++] = (uint64_t)c; c3[nc++] = (uint64_t)(w << 8); c3[nc++] = w5 & 0x3ffff; c3[nc++] = (uint64_t)(int64_t)(e << 3);
+    d3[nd++] = (uint64_t)d; d3[nd++] = (uint64_t)(c << 8); d3[nd++] = (uint64_t)(int64_t)(w << 16);
+    e3[ne++] = (uint64_t)(w << 3); e3[ne++] = (uint64_t)(c << 19); e3[ne++] = (uint64_t)e;
+    m->cpos1[c] = pos;
+    m->wpos1[w] = pos;
+  }
+  int k = 0;
+  const int c1 = (int)RB(1);
+  orc_p8_cm_step(m->cm, y, bpos, c0, c1, a, na, out + n, &k); n += k;
+  orc_p8_cm_step(m->cn, y, bpos, c0, c1, b, nb, out + n, &k); n += k;
+  orc_p8_cm_step(m->co, y, bpos, c0, c1, c3, nc, out + n, &k); n += k;
+  orc_p8_cm_step(m->cq, y, bpos, c0, c1, e3, ne, out + n, &k); n += k;
+  orc_p8_cm_step(m->cp, y, bpos, c0, c1, d3, nd, out + n, &k); n += k;
+  return n;
+#undef RB
+}

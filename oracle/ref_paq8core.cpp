@@ -308,6 +308,19 @@ int refp8_sparsematch_step(void* h, int y_prev, int bpos, int c0, int16_t* out, 
   return len;
 }
 
+// picModel (:3844-3864) and recordModel1 (:4435-4474) over the reference's buffer (refp8_buf_reset / _push).
+int refp8_small_step(int which, int y_prev, int bpos, int c0, uint32_t c4, uint32_t f4, uint32_t w5, int16_t* out) {
+  paq8::y = y_prev;
+  paq8::bpos = bpos;
+  paq8::c0 = c0;
+  paq8::c4 = c4;
+  paq8::f4 = f4;
+  paq8::w5 = w5;
+  if (which == 0) paq8::picModel(*sink());
+  else paq8::recordModel1(*sink());
+  return drain(out);
+}
+
 uint64_t refp8_hash2(uint64_t a, uint64_t b) { return paq8::hash(a, b); }
 uint64_t refp8_hash3(uint64_t a, uint64_t b, uint64_t c) { return paq8::hash(a, b, c); }
 uint64_t refp8_hash5(uint64_t a, uint64_t b, uint64_t c, uint64_t d, uint64_t e) { return paq8::hash(a, b, c, d, e); }

@@ -479,3 +479,32 @@ def test_sparse_match_model_vs_reference():
         L.refp8_buf_push(int(data[n]))
         ring[n] = data[n]
     assert len(winners) >= 3, winners
+
+
+@needs_ref
+def test_pic_and_record1_models_vs_reference():
+    from cmix_amd import synth
+    L, lib = R.paq8core_lib(), O.lib()
+    data = np.frombuffer(synth.enwik_like(3000, 61), np.uint8)
+    LOG = 16
+    L.refp8_rnd_reset()
+    lib.orc_p8_rnd_reset()
+    for which, nout in ((0, 3), (1, (2 + 5 + 4 + 3 + 3) * 5)):
+        L.refp8_buf_reset(LOG)
+        ring = np.zeros(1 << LOG, np.uint8)
+        got = lib.orc_p8_small_new(which)
+        o_ref, o_got = np.zeros(128, np.int16), np.zeros(128, np.int16)
+        y, c0, c4, f4, w5 = 0, 1, 0, 0, 0
+        for n in range(len(data)):
+            for bpos in range(8):
+                k = L.refp8_small_step(which, y, bpos, c0, c4, f4, w5, o_ref.ctypes.data)
+                assert lib.orc_p8_small_step(got, y, bpos, c0, c4, f4, w5, ring.ctypes.data, (1 << LOG) - 1, n, o_got.ctypes.data) == k == nout
+                assert (o_ref[:k] == o_got[:k]).all(), (which, n, bpos, o_ref[:k], o_got[:k])
+                y = (int(data[n]) >> (7 - bpos)) & 1
+                c0 = (c0 << 1 | y) if bpos < 7 else 1
+            b = int(data[n])
+            L.refp8_buf_push(b)
+            ring[n] = b
+            c4 = ((c4 << 8) | b) & 0xffffffff
+            f4 = ((f4 << 4) | (b >> 4)) & 0xffffffff
+            w5 = (w5 * 4 + (b >> 6)) & 0xffffffff
