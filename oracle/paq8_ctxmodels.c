@@ -373,3 +373,5 @@ int orc_p8_small_step(P8Small* m, int y, int bpos, int c0, uint32_t c4, uint32_t
   return n;
 #undef RB
 }
+
+uint64_t orc_p8_hash4(uint64_t a, uint64_t b, uint64_t c, uint64_t d) { return hashn(4, (const uint64_t[]){a, b, c, d}); }

@@ -321,8 +321,31 @@ int refp8_small_step(int which, int y_prev, int bpos, int c0, uint32_t c4, uint3
   return drain(out);
 }
 
+// recordModel (:4204-4433) over the reference's buffer. io[] in: blpos, grp0, filetype, Stats.Record,
+// Stats.Match.length, Stats.Match.expectedByte; out: io[3] = Stats.Record as the model leaves it.
+int refp8_record_step(int level, int y_prev, int bpos, int c0, uint32_t c4, uint32_t* io, int16_t* out, int* sets, int* nsets) {
+  paq8::level = level;
+  paq8::y = y_prev;
+  paq8::bpos = bpos;
+  paq8::c0 = c0;
+  paq8::c4 = c4;
+  paq8::blpos = (int)io[0];
+  paq8::grp0 = (paq8::U8)io[1];
+  paq8::ModelStats st;
+  memset(&st, 0, sizeof st);
+  st.Record = io[3];
+  st.Match.length = io[4];
+  st.Match.expectedByte = (paq8::U8)io[5];
+  paq8::recordModel(*sink(), (paq8::Filetype)io[2], &st);
+  io[3] = st.Record;
+  const int n = drain(out);
+  *nsets = drain_sets(sets);
+  return n;
+}
+
 uint64_t refp8_hash2(uint64_t a, uint64_t b) { return paq8::hash(a, b); }
 uint64_t refp8_hash3(uint64_t a, uint64_t b, uint64_t c) { return paq8::hash(a, b, c); }
+uint64_t refp8_hash4(uint64_t a, uint64_t b, uint64_t c, uint64_t d) { return paq8::hash(a, b, c, d); }
 uint64_t refp8_hash5(uint64_t a, uint64_t b, uint64_t c, uint64_t d, uint64_t e) { return paq8::hash(a, b, c, d, e); }
 uint64_t refp8_hash6(uint64_t a, uint64_t b, uint64_t c, uint64_t d, uint64_t e, uint64_t f) { return paq8::hash(a, b, c, d, e, f); }
 uint64_t refp8_combine64(uint64_t seed, uint64_t x) { return paq8::combine64(seed, x); }

@@ -508,3 +508,51 @@ def test_pic_and_record1_models_vs_reference():
             c4 = ((c4 << 8) | b) & 0xffffffff
             f4 = ((f4 << 4) | (b >> 4)) & 0xffffffff
             w5 = (w5 * 4 + (b >> 6)) & 0xffffffff
+
+
+@needs_ref
+def test_record_model_vs_reference():
+    """recordModel: fixed-length records with space / zero padding (length detection, the two candidates, padding
+    transitions), a length change, a multiple-of-3 length (the 24-bit-image guess), then text."""
+    from cmix_amd import synth
+    L, lib = R.paq8core_lib(), O.lib()
+    rng = np.random.default_rng(67)
+
+    def records(n, length, pad):
+        out = bytearray()
+        for k in range(n):
+            name = bytes(rng.integers(97, 123, int(rng.integers(3, length - 6))).astype(np.uint8))
+            out += (name + bytes([pad]) * length)[:length - 4] + int(k * 37).to_bytes(4, "little")
+        return bytes(out)
+    data = np.frombuffer(records(120, 24, 32) + records(80, 40, 0) + records(60, 33, 32) + synth.enwik_like(1500, 71), np.uint8)
+    LOG, level = 16, 4
+    L.refp8_rnd_reset()
+    lib.orc_p8_rnd_reset()
+    L.refp8_buf_reset(LOG)
+    ring = np.zeros(1 << LOG, np.uint8)
+    got = lib.orc_p8_record_new(level)
+    o_ref, o_got = np.zeros(256, np.int16), np.zeros(256, np.int16)
+    s_ref, s_got = np.zeros(8, np.int32), np.zeros(8, np.int32)
+    io_ref, io_got = np.zeros(6, np.uint32), np.zeros(6, np.uint32)
+    k_ref = C.c_int(0)
+    y, c0, c4 = 0, 1, 0
+    lens = set()
+    for n in range(len(data)):
+        for bpos in range(8):
+            for io in (io_ref, io_got):
+                io[0], io[1], io[2] = n, (c0 * 7) & 31, 4 if n > 7000 else 0
+                io[4], io[5] = (n // 50) % 3, int(data[n - 3]) if n > 3 else 0
+            k = L.refp8_record_step(level, y, bpos, c0, c4, io_ref.ctypes.data, o_ref.ctypes.data, s_ref.ctypes.data, C.byref(k_ref))
+            g = lib.orc_p8_record_step(got, y, bpos, c0, c4, io_got.ctypes.data, ring.ctypes.data, (1 << LOG) - 1, n, o_got.ctypes.data,
+                                       s_got.ctypes.data)
+            assert k == g == 149 and k_ref.value == 3, (n, bpos, k, g)
+            assert (o_ref[:k] == o_got[:k]).all(), (n, bpos, np.nonzero(o_ref[:k] != o_got[:k])[0][:5])
+            assert (s_ref[:3] == s_got[:3]).all() and io_ref[3] == io_got[3], (n, bpos, s_ref[:3], s_got[:3], io_ref[3], io_got[3])
+            lens.add(int(io_ref[3]) >> 16)
+            y = (int(data[n]) >> (7 - bpos)) & 1
+            c0 = (c0 << 1 | y) if bpos < 7 else 1
+        b = int(data[n])
+        L.refp8_buf_push(b)
+        ring[n] = b
+        c4 = ((c4 << 8) | b) & 0xffffffff
+    assert {24, 40, 33} <= lens, lens
