@@ -343,6 +343,20 @@ int refp8_record_step(int level, int y_prev, int bpos, int c0, uint32_t c4, uint
   return n;
 }
 
+// XMLModel (:7823-8096) over the reference's buffer; returns Stats.XML in *xml.
+int refp8_xml_step(int level, int y_prev, int bpos, int c0, uint32_t c4, int16_t* out, uint32_t* xml) {
+  paq8::level = level;
+  paq8::y = y_prev;
+  paq8::bpos = bpos;
+  paq8::c0 = c0;
+  paq8::c4 = c4;
+  paq8::ModelStats st;
+  memset(&st, 0, sizeof st);
+  paq8::XMLModel(*sink(), &st);
+  *xml = st.XML;
+  return drain(out);
+}
+
 uint64_t refp8_hash2(uint64_t a, uint64_t b) { return paq8::hash(a, b); }
 uint64_t refp8_hash3(uint64_t a, uint64_t b, uint64_t c) { return paq8::hash(a, b, c); }
 uint64_t refp8_hash4(uint64_t a, uint64_t b, uint64_t c, uint64_t d) { return paq8::hash(a, b, c, d); }

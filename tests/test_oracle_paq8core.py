@@ -556,3 +556,41 @@ def test_record_model_vs_reference():
         ring[n] = b
         c4 = ((c4 << 8) | b) & 0xffffffff
     assert {24, 40, 33} <= lens, lens
+
+
+@needs_ref
+def test_xml_model_vs_reference():
+    """XMLModel: nested tags with attributes (href / http links), empty tags, comments, CDATA, indentation with spaces
+    and tabs, CRLF and LF line ends, dates, times, numbers, coordinates, temperatures, ISBN -- plus enwik-like text."""
+    from cmix_amd import synth
+    L, lib = R.paq8core_lib(), O.lib()
+    doc = (b'<?xml version="1.0"?>\r\n<root a="1" href="http://example.org/x" b=\'two\'>\r\n  <item id="7">\r\n    <date>2006-03-14</date>\n'
+           b'    <time>12:34:56</time> <t2>9:05:01</t2>\n\t<empty/>\n\t\t<deep x="https://a.b/c"><!-- a comment --></deep>\n'
+           b'    <![CDATA[ raw <stuff> ]]]]>\n    <coord>12\xc2\xb034\'56</coord><temp>21 \xc2\xb0C</temp><temp>7\xc2\xb0F</temp>\n'
+           b'    <isbn>ISBN 0-306-40615-2</isbn><n>1234567890 text of more than eight letters</n>\n  </item>\n</root>\n'
+           b'<a><b><c>31-12-1999</c></b></a><!x><1bad> < notatag >\n') * 3
+    data = np.frombuffer(doc + synth.enwik_like(5000, 73), np.uint8)
+    LOG, level = 16, 4
+    L.refp8_rnd_reset()
+    lib.orc_p8_rnd_reset()
+    L.refp8_buf_reset(LOG)
+    ring = np.zeros(1 << LOG, np.uint8)
+    got = lib.orc_p8_xml_new(level)
+    o_ref, o_got = np.zeros(64, np.int16), np.zeros(64, np.int16)
+    x_ref, x_got = C.c_uint32(0), C.c_uint32(0)
+    y, c0, c4 = 0, 1, 0
+    states = set()
+    for n in range(len(data)):
+        for bpos in range(8):
+            k = L.refp8_xml_step(level, y, bpos, c0, c4, o_ref.ctypes.data, C.byref(x_ref))
+            g = lib.orc_p8_xml_step(got, y, bpos, c0, c4, ring.ctypes.data, (1 << LOG) - 1, n, o_got.ctypes.data, C.byref(x_got))
+            assert k == g == 20 and x_ref.value == x_got.value, (n, bpos, k, g, x_ref.value, x_got.value)
+            assert (o_ref[:k] == o_got[:k]).all(), (n, bpos, o_ref[:k], o_got[:k])
+            states.add(x_ref.value & 7)
+            y = (int(data[n]) >> (7 - bpos)) & 1
+            c0 = (c0 << 1 | y) if bpos < 7 else 1
+        b = int(data[n])
+        L.refp8_buf_push(b)
+        ring[n] = b
+        c4 = ((c4 << 8) | b) & 0xffffffff
+    assert states == set(range(8)), states
