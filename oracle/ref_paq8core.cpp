@@ -357,6 +357,40 @@ int refp8_xml_step(int level, int y_prev, int bpos, int c0, uint32_t c4, int16_t
   return drain(out);
 }
 
+// exeModel (:6560-7546): the x86 decoder's opcode tables as data, and the model itself (forced on, as contextModel2
+// calls it) over the reference's buffer.
+void refp8_exe_tables(uint8_t* out /* 4*256 + 32 + 4*256 + 32 + 19 + 8 + 1 */) {
+  int n = 0;
+  for (int i = 0; i < 256; ++i) out[n++] = paq8::Table1[i];
+  for (int i = 0; i < 256; ++i) out[n++] = paq8::Table2[i];
+  for (int i = 0; i < 256; ++i) out[n++] = paq8::Table3_38[i];
+  for (int i = 0; i < 256; ++i) out[n++] = paq8::Table3_3A[i];
+  for (int i = 0; i < 32; ++i) out[n++] = paq8::TableX[i];
+  for (int i = 0; i < 256; ++i) out[n++] = paq8::TypeOp1[i];
+  for (int i = 0; i < 256; ++i) out[n++] = paq8::TypeOp2[i];
+  for (int i = 0; i < 256; ++i) out[n++] = paq8::TypeOp3_38[i];
+  for (int i = 0; i < 256; ++i) out[n++] = paq8::TypeOp3_3A[i];
+  for (int i = 0; i < 32; ++i) out[n++] = paq8::TypeOpX[i];
+  for (int i = 0; i < 19; ++i) out[n++] = paq8::InvalidX64Ops[i];
+  for (int i = 0; i < 8; ++i) out[n++] = paq8::X64Prefixes[i];
+  out[n++] = (uint8_t)paq8::OP_GEN_BRANCH;
+}
+int refp8_exe_step(int level, int y_prev, int bpos, int c0, uint32_t c4, int blpos, int16_t* out, int* sets, int* nsets, uint32_t* x86) {
+  paq8::level = level;
+  paq8::y = y_prev;
+  paq8::bpos = bpos;
+  paq8::c0 = c0;
+  paq8::c4 = c4;
+  paq8::blpos = blpos;
+  paq8::ModelStats st;
+  memset(&st, 0, sizeof st);
+  paq8::exeModel(*sink(), true, &st);
+  *x86 = st.x86_64;
+  const int n = drain(out);
+  *nsets = drain_sets(sets);
+  return n;
+}
+
 uint64_t refp8_hash2(uint64_t a, uint64_t b) { return paq8::hash(a, b); }
 uint64_t refp8_hash3(uint64_t a, uint64_t b, uint64_t c) { return paq8::hash(a, b, c); }
 uint64_t refp8_hash4(uint64_t a, uint64_t b, uint64_t c, uint64_t d) { return paq8::hash(a, b, c, d); }

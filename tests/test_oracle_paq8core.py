@@ -594,3 +594,44 @@ def test_xml_model_vs_reference():
         ring[n] = b
         c4 = ((c4 << 8) | b) & 0xffffffff
     assert states == set(range(8)), states
+
+
+@needs_ref
+def test_exe_model_vs_reference():
+    """exeModel (forced on, as contextModel2 runs it): x86-like opcode soup with prefixes, REX, 0F / 0F38 / 0F3A
+    escapes, ModRM + SIB forms and immediates, random bytes (decoder errors), and text."""
+    from cmix_amd import synth
+    L, lib = R.paq8core_lib(), O.lib()
+    rng = np.random.default_rng(79)
+    ops = [b"\x55\x8b\xec", b"\x83\xec\x10", b"\x8b\x45\x08", b"\x89\x44\x24\x04", b"\xe8\x10\x00\x00\x00", b"\x0f\x84\x20\x01\x00\x00",
+           b"\x66\x89\x06", b"\x48\x8b\x05\x10\x20\x00\x00", b"\x48\xb8\x01\x02\x03\x04\x05\x06\x07\x08", b"\xf3\xa4", b"\xc3", b"\x90",
+           b"\x0f\x38\x00\xc1", b"\x0f\x3a\x0f\xc1\x04", b"\xff\x15\x00\x10\x40\x00", b"\x8d\x04\x8d\x00\x00\x00\x00", b"\xc8\x10\x00\x01",
+           b"\x9a\x01\x02\x03\x04\x05\x06", b"\xf7\xd8", b"\xfe\xc0", b"\x64\x67\x8b\x00", b"\x0f\x0b", b"\xd9\xee", b"\xeb\xfe"]
+    soup = b"".join(ops[int(k)] for k in rng.integers(0, len(ops), 600))
+    data = np.frombuffer(soup + bytes(rng.integers(0, 256, 1500, dtype=np.uint8)) + synth.enwik_like(2500, 83) + soup[:800], np.uint8)
+    LOG, level = 16, 3
+    L.refp8_buf_reset(LOG)
+    ring = np.zeros(1 << LOG, np.uint8)
+    got = lib.orc_p8_exe_new(level)
+    o_ref, o_got = np.zeros(256, np.int16), np.zeros(256, np.int16)
+    s_ref, s_got = np.zeros(8, np.int32), np.zeros(8, np.int32)
+    k_ref, x_ref, x_got = C.c_int(0), C.c_uint32(0), C.c_uint32(0)
+    y, c0, c4 = 0, 1, 0
+    valid_seen = False
+    for n in range(len(data)):
+        for bpos in range(8):
+            k = L.refp8_exe_step(level, y, bpos, c0, c4, n, o_ref.ctypes.data, s_ref.ctypes.data, C.byref(k_ref), C.byref(x_ref))
+            g = lib.orc_p8_exe_step(got, y, bpos, c0, c4, n, ring.ctypes.data, (1 << LOG) - 1, n, o_got.ctypes.data, s_got.ctypes.data,
+                                    C.byref(x_got))
+            assert k == g == 140 and k_ref.value == 6, (n, bpos, k, g, k_ref.value)
+            assert x_ref.value == x_got.value, (n, bpos, hex(x_ref.value), hex(x_got.value))
+            assert (s_ref[:6] == s_got[:6]).all(), (n, bpos, s_ref[:6], s_got[:6])
+            assert (o_ref[:k] == o_got[:k]).all(), (n, bpos, np.nonzero(o_ref[:k] != o_got[:k])[0][:5])
+            valid_seen |= bool(x_ref.value & 1)
+            y = (int(data[n]) >> (7 - bpos)) & 1
+            c0 = (c0 << 1 | y) if bpos < 7 else 1
+        b = int(data[n])
+        L.refp8_buf_push(b)
+        ring[n] = b
+        c4 = ((c4 << 8) | b) & 0xffffffff
+    assert valid_seen
