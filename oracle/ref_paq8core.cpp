@@ -391,6 +391,23 @@ int refp8_exe_step(int level, int y_prev, int bpos, int c0, uint32_t c4, int blp
   return n;
 }
 
+// EnglishStemmer (:1764-2431) on one word, letters added the way wordModel adds them (Word::operator+=).
+int refp8_en_stem_word(const char* s, uint8_t* letters64, int* start_end, uint64_t* type_lang, uint64_t* hash4_after_stem,
+                       uint64_t* hash4_gethashes) {
+  static paq8::EnglishStemmer stemmer;
+  paq8::Word w;
+  w.Language = 0;  // not initialised by Word::Word()
+  for (const char* p = s; *p; ++p) w += *p;
+  const int r = stemmer.Stem(&w);
+  memcpy(letters64, w.Letters, 64);
+  start_end[0] = w.Start; start_end[1] = w.End;
+  type_lang[0] = w.Type; type_lang[1] = w.Language;
+  memcpy(hash4_after_stem, w.Hash, 32);
+  w.GetHashes();
+  memcpy(hash4_gethashes, w.Hash, 32);
+  return r;
+}
+
 uint64_t refp8_hash2(uint64_t a, uint64_t b) { return paq8::hash(a, b); }
 uint64_t refp8_hash3(uint64_t a, uint64_t b, uint64_t c) { return paq8::hash(a, b, c); }
 uint64_t refp8_hash4(uint64_t a, uint64_t b, uint64_t c, uint64_t d) { return paq8::hash(a, b, c, d); }

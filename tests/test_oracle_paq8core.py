@@ -635,3 +635,36 @@ def test_exe_model_vs_reference():
         ring[n] = b
         c4 = ((c4 << 8) | b) & 0xffffffff
     assert valid_seen
+
+
+@needs_ref
+def test_english_stemmer_vs_reference():
+    """EnglishStemmer on every word of a 6 000-word vocabulary drawn from the synthetic corpus generator's word list
+    plus inflected / prefixed / possessive forms of each: stem letters, Start / End, type flags, language, both hash
+    sets. (The reference's own dictionary is the natural list, but it is not available on every box; the generator's
+    list is derived from it.)"""
+    from cmix_amd import synth
+    L, lib = R.paq8core_lib(), O.lib()
+    sig = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.refp8_en_stem_word.argtypes = sig
+    lib.orc_p8_en_stem_word.argtypes = sig
+    text = synth.enwik_like(400000, 3)
+    base = sorted({w.lower() for w in text.replace(b"\n", b" ").split(b" ") if w.isalpha() and len(w) < 40})[:6000]
+    extra = [b"skis", b"skies", b"dying", b"idly", b"news", b"atlas", b"inning", b"proceed", b"zinc", b"here", b"he", b"she", b"the",
+             b"can't", b"won't", b"ain't", b"isn't", b"o'clock", b"'tis", b"non-linear", b"nonsense", b"overestimate", b"underground",
+             b"irregular", b"unnatural", b"biggest", b"suggest", b"fullest", b"congest", b"happiest", b"smallest", b"finest", b"nearest",
+             b"slowest", b"highest", b"childhood", b"neighbourhood", b"quizzing", b"squeaking", b"generously", b"communal", b"arsenic",
+             b"y", b"yy", b"a", b"by", b"say", b"yellowy", b"x" * 70]
+    suffixes = [b"", b"s", b"es", b"ed", b"ing", b"ly", b"ness", b"est", b"'s", b"ation", b"ational", b"fully", b"less", b"ize", b"ied", b"ies",
+                b"edly", b"ingly", b"ative", b"ement", b"n't"]
+    words = extra + [w + sfx for w in base for sfx in suffixes[: 1 + (len(w) % 7) * 3]]
+    bufs = [(np.zeros(64, np.uint8), np.zeros(2, np.int32), np.zeros(2, np.uint64), np.zeros(4, np.uint64), np.zeros(4, np.uint64)) for _ in range(2)]
+    changed = 0
+    for w in words:
+        out = []
+        for fn, (let, se, tl, h1, h2) in ((L.refp8_en_stem_word, bufs[0]), (lib.orc_p8_en_stem_word, bufs[1])):
+            r = fn(w, let.ctypes.data, se.ctypes.data, tl.ctypes.data, h1.ctypes.data, h2.ctypes.data)
+            out.append((r, let.tobytes(), tuple(se), int(tl[0]), int(tl[1]) if r else -1, tuple(h1), tuple(h2)))
+        assert out[0] == out[1], (w, out[0][:5], out[1][:5])
+        changed += out[0][0]
+    assert changed > len(words) // 4
