@@ -118,6 +118,10 @@ def lib():
         L.orc_p8_exe_new.argtypes = [C.c_int]
         L.orc_p8_exe_step.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_void_p, C.c_uint32, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_p8_word_new.restype = C.c_void_p
+        L.orc_p8_word_new.argtypes = [C.c_int]
+        L.orc_p8_word_step.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p,
+                                       C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_p8_dmap_new.restype = C.c_void_p
         L.orc_p8_dmap_new.argtypes = [C.c_int] * 4
         L.orc_p8_dmap_set_direct.argtypes = [C.c_void_p, C.c_uint32]

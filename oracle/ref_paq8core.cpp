@@ -408,6 +408,24 @@ int refp8_en_stem_word(const char* s, uint8_t* letters64, int* start_end, uint64
   return r;
 }
 
+// wordModel (:3873-4105) over the reference's buffer. g_out receives the word-level globals it maintains for other
+// models: spaces, spacecount, words, wordcount, wordlen, wordlen1, frstchar, spafdo, col.
+int refp8_word_step(int level, int y_prev, int bpos, int c0, uint32_t c4, uint32_t f4, uint32_t b3, int blpos, int16_t* out,
+                    uint32_t* g_out) {
+  paq8::level = level;
+  paq8::y = y_prev;
+  paq8::bpos = bpos;
+  paq8::c0 = c0;
+  paq8::c4 = c4;
+  paq8::f4 = f4;
+  paq8::b3 = b3;
+  paq8::blpos = blpos;
+  paq8::wordModel(*sink());
+  g_out[0] = paq8::spaces; g_out[1] = paq8::spacecount; g_out[2] = paq8::words; g_out[3] = paq8::wordcount; g_out[4] = paq8::wordlen;
+  g_out[5] = paq8::wordlen1; g_out[6] = paq8::frstchar; g_out[7] = paq8::spafdo; g_out[8] = paq8::col;
+  return drain(out);
+}
+
 uint64_t refp8_hash2(uint64_t a, uint64_t b) { return paq8::hash(a, b); }
 uint64_t refp8_hash3(uint64_t a, uint64_t b, uint64_t c) { return paq8::hash(a, b, c); }
 uint64_t refp8_hash4(uint64_t a, uint64_t b, uint64_t c, uint64_t d) { return paq8::hash(a, b, c, d); }

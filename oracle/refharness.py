@@ -206,6 +206,7 @@ def paq8core_lib():
     L.refp8_apm_new.argtypes = [C.c_int]
     L.refp8_apm_p.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
     L.refp8_ilog_table.argtypes = [C.c_void_p]
+    L.refp8_word_step.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
     L.refp8_exe_step.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.refp8_xml_step.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
     L.refp8_record_step.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -668,3 +668,39 @@ def test_english_stemmer_vs_reference():
         assert out[0] == out[1], (w, out[0][:5], out[1][:5])
         changed += out[0][0]
     assert changed > len(words) // 4
+
+
+@needs_ref
+def test_word_model_vs_reference():
+    """wordModel: enwik-like text plus hyphenated line breaks ("+\\n", "-\\r\\n"), numbers with decimal points, wiki
+    markup ("==", "''", "[[..]]"), upper-case words, high bytes, long lines. 57 contexts and the nine word-level
+    globals other models read."""
+    from cmix_amd import synth
+    L, lib = R.paq8core_lib(), O.lib()
+    extra = (b"The quick-\nbrown fox+\njumps over-\r\nthe lazy+\r\ndog. 3.1415 and 12.5% of 1,000 items; == Heading ==\n''italic'' [[link]] "
+             b"[[ spaced ]] : definition = value\n\nUPPER lower MiXed don't o'clock well-known \xc3\xa9t\xc3\xa9 na\xc3\xafve\n" + b"x" * 300 + b"\n") * 4
+    data = np.frombuffer(synth.enwik_like(6000, 89) + extra + synth.enwik_like(2000, 97), np.uint8)
+    LOG, level = 16, 2
+    L.refp8_rnd_reset()
+    lib.orc_p8_rnd_reset()
+    L.refp8_buf_reset(LOG)
+    ring = np.zeros(1 << LOG, np.uint8)
+    got = lib.orc_p8_word_new(level)
+    o_ref, o_got = np.zeros(512, np.int16), np.zeros(512, np.int16)
+    g_ref, g_got = np.zeros(9, np.uint32), np.zeros(9, np.uint32)
+    y, c0, c4, f4, b2, b3 = 0, 1, 0, 0, 0, 0
+    for n in range(len(data)):
+        for bpos in range(8):
+            k = L.refp8_word_step(level, y, bpos, c0, c4, f4, b3, n, o_ref.ctypes.data, g_ref.ctypes.data)
+            g = lib.orc_p8_word_step(got, y, bpos, c0, c4, f4, b3, n, ring.ctypes.data, (1 << LOG) - 1, n, o_got.ctypes.data, g_got.ctypes.data)
+            assert k == g == 285, (n, bpos, k, g)  # 57 of the 61 slots are set
+            assert (g_ref == g_got).all(), (n, bpos, g_ref, g_got)
+            assert (o_ref[:k] == o_got[:k]).all(), (n, bpos, np.nonzero(o_ref[:k] != o_got[:k])[0][:6] // 5)
+            y = (int(data[n]) >> (7 - bpos)) & 1
+            c0 = (c0 << 1 | y) if bpos < 7 else 1
+        b = int(data[n])
+        L.refp8_buf_push(b)
+        ring[n] = b
+        c4 = ((c4 << 8) | b) & 0xffffffff
+        f4 = ((f4 << 4) | (b >> 4)) & 0xffffffff
+        b3, b2 = b2, b
