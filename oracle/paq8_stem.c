@@ -369,13 +369,320 @@ int p8_en_stem(P8Word* w) {  /* Stem :2363-2429 */
   return res;
 }
 
+/* ---- FrenchStemmer :2433-2822 (a Snowball-French derivative working on Latin-1 letters) ---- */
+#undef V
+#undef CONS
+int p8_fr_is_vowel(int c) { return in_set(c, FR_Vowels, COUNT(FR_Vowels)); }
+#define V(c) p8_fr_is_vowel(c)
+#define CONS(c) (!p8_fr_is_vowel(c))
+#define SLEN(s) ((uint8_t)strlen(s))
+#define ENDS_IN(s, rn) (p8w_ends(w, s) && suffix_in_rn(w, rn, s))
+static void fr_utf8(P8Word* w) {  /* ConvertUTF8 :2487-2497: 0xC3 xx pairs folded to one Latin-1 letter, in place */
+  for (int i = w->Start; i < w->End; i++) {
+    const uint8_t n = w->Letters[i + 1], c = (uint8_t)(n + (n < 0xA0 ? 0x60 : 0x40));
+    if (w->Letters[i] == 0xC3 && (V(c) || (n & 0xDF) == 0x87)) {
+      w->Letters[i] = c;
+      if (i + 1 < w->End) memmove(&w->Letters[i + 1], &w->Letters[i + 2], (size_t)(w->End - i - 1));
+      w->End--;
+    }
+  }
+}
+static void fr_mark(P8Word* w) {  /* MarkVowelsAsConsonants :2498-2513 */
+  uint8_t* L = w->Letters;
+  for (int i = w->Start; i <= w->End; i++) {
+    if (L[i] == 'i' || L[i] == 'u') {
+      if (i > w->Start && i < w->End && (V(L[i - 1]) || (L[i - 1] == 'q' && L[i] == 'u')) && V(L[i + 1])) L[i] = (uint8_t)toupper(L[i]);
+    } else if (L[i] == 'y') {
+      if ((i > w->Start && V(L[i - 1])) || (i < w->End && V(L[i + 1]))) L[i] = 'Y';
+    }
+  }
+}
+static uint32_t fr_rv(const P8Word* w) {  /* GetRV :2514-2526 */
+  const uint32_t len = p8w_len(w);
+  if (len >= 3 && ((V(w->Letters[w->Start]) && V(w->Letters[w->Start + 1])) || p8w_starts(w, "par") || p8w_starts(w, "col") || p8w_starts(w, "tap")))
+    return (uint32_t)w->Start + 3;
+  for (int i = w->Start + 1; i <= w->End; i++)
+    if (V(w->Letters[i])) return (uint32_t)i + 1;
+  return w->Start + len;
+}
+static void fr_ic(P8Word* w, uint32_t R2) {  /* "ic": dropped inside R2, respelt "iqU" outside */
+  if (suffix_in_rn(w, R2, "ic")) w->End -= 2;
+  else p8w_change_suffix(w, "c", "qU");
+}
+static int fr_step1(P8Word* w, uint32_t RV, uint32_t R1, uint32_t R2, int* force2a) {  /* :2527-2664; the suffix list is scanned in groups */
+  const char* const* S = FR_SuffixesStep1;
+  int i = 0;
+  for (; i < 11; i++)
+    if (ENDS_IN(S[i], R2)) { w->End -= SLEN(S[i]); if (i == 3) w->Type |= FR_Adjective; return 1; }
+  for (; i < 17; i++)
+    if (ENDS_IN(S[i], R2)) { w->End -= SLEN(S[i]); if (p8w_ends(w, "ic")) p8w_change_suffix(w, "c", "qU"); return 1; }
+  for (; i < 25; i++)
+    if (ENDS_IN(S[i], R2)) {
+      w->End -= (uint8_t)(SLEN(S[i]) - 1 - (i < 19) * 2);
+      if (i > 22) { w->End += 2; w->Letters[w->End] = 't'; }
+      return 1;
+    }
+  for (; i < 27; i++)
+    if (ENDS_IN(S[i], R1) && CONS(p8w_back(w, SLEN(S[i])))) { w->End -= SLEN(S[i]); return 1; }
+  for (; i < 29; i++)
+    if (ENDS_IN(S[i], RV)) {
+      w->End -= SLEN(S[i]);
+      if (ENDS_IN("iv", R2)) {
+        w->End -= 2;
+        if (ENDS_IN("at", R2)) w->End -= 2;
+      } else if (p8w_ends(w, "eus")) {
+        if (suffix_in_rn(w, R2, "eus")) w->End -= 3;
+        else if (suffix_in_rn(w, R1, "eus")) w->Letters[w->End] = 'x';
+      } else if (ENDS_IN("abl", R2) || ENDS_IN("iqU", R2)) w->End -= 3;
+      else if (ENDS_IN("i\xE8r", RV) || ENDS_IN("I\xE8r", RV)) { w->End -= 2; w->Letters[w->End] = 'i'; }
+      return 1;
+    }
+  for (; i < 31; i++)
+    if (ENDS_IN(S[i], R2)) {
+      w->End -= SLEN(S[i]);
+      if (p8w_ends(w, "abil")) {
+        if (suffix_in_rn(w, R2, "abil")) w->End -= 4;
+        else { w->End--; w->Letters[w->End] = 'l'; }
+      } else if (p8w_ends(w, "ic")) fr_ic(w, R2);
+      else if (ENDS_IN("iv", R2)) w->End -= 2;
+      return 1;
+    }
+  for (; i < 35; i++)
+    if (ENDS_IN(S[i], R2)) {
+      w->End -= SLEN(S[i]);
+      if (ENDS_IN("at", R2)) {
+        w->End -= 2;
+        if (p8w_ends(w, "ic")) fr_ic(w, R2);
+      }
+      return 1;
+    }
+  for (; i < 37; i++)
+    if (p8w_ends(w, S[i])) {
+      if (suffix_in_rn(w, R2, S[i])) { w->End -= SLEN(S[i]); return 1; }
+      if (suffix_in_rn(w, R1, S[i])) { p8w_change_suffix(w, S[i], "eux"); return 1; }
+    }
+  for (; i < COUNT(FR_SuffixesStep1); i++)
+    if (ENDS_IN(S[i], RV + 1) && V(p8w_back(w, SLEN(S[i])))) { w->End -= SLEN(S[i]); *force2a = 1; return 1; }
+  if (p8w_ends(w, "eaux") || p8w_eq(w, "eaux")) { w->End--; w->Type |= FR_Plural; return 1; }
+  if (ENDS_IN("aux", R1)) { w->End--; w->Letters[w->End] = 'l'; w->Type |= FR_Plural; return 1; }
+  if (ENDS_IN("amment", RV)) { p8w_change_suffix(w, "amment", "ant"); *force2a = 1; return 1; }
+  if (ENDS_IN("emment", RV)) { p8w_change_suffix(w, "emment", "ent"); *force2a = 1; return 1; }
+  return 0;
+}
+static int fr_step2a(P8Word* w, uint32_t RV) {
+  for (int i = 0; i < COUNT(FR_SuffixesStep2a); i++) {
+    const char* s = FR_SuffixesStep2a[i];
+    if (ENDS_IN(s, RV + 1) && CONS(p8w_back(w, SLEN(s)))) { w->End -= SLEN(s); if (i == 31) w->Type |= FR_Verb; return 1; }
+  }
+  return 0;
+}
+static int fr_step2b(P8Word* w, uint32_t RV, uint32_t R2) {
+  for (int i = 0; i < COUNT(FR_SuffixesStep2b); i++) {
+    const char* s = FR_SuffixesStep2b[i];
+    if (!ENDS_IN(s, RV)) continue;
+    if (s[0] == 'a' || s[0] == '\xE2') {
+      w->End -= SLEN(s);
+      if (ENDS_IN("e", RV)) w->End--;
+      return 1;
+    }
+    if (i != 14 || suffix_in_rn(w, R2, s)) { w->End -= SLEN(s); return 1; }
+  }
+  return 0;
+}
+static int fr_step4(P8Word* w, uint32_t RV, uint32_t R2) {
+  int res = 0;
+  if (p8w_len(w) >= 2 && w->Letters[w->End] == 's' && !in_set(p8w_back(w, 1), FR_SetStep4, COUNT(FR_SetStep4))) { w->End--; res = 1; }
+  for (int i = 0; i < COUNT(FR_SuffixesStep4); i++) {
+    const char* s = FR_SuffixesStep4[i];
+    if (!ENDS_IN(s, RV)) continue;
+    if (i == 2) {          /* ion: only after s / t, inside R2 */
+      const uint8_t prec = p8w_back(w, 3);
+      if (suffix_in_rn(w, R2, s) && suffix_in_rn(w, RV + 1, s) && (prec == 's' || prec == 't')) { w->End -= 3; return 1; }
+    } else if (i == 5) { w->End--; return 1; }
+    else if (i == 6) { if (p8w_ends(w, "gu\xEB")) { w->End--; return 1; } }
+    else { p8w_change_suffix(w, s, "i"); return 1; }
+  }
+  return res;
+}
+static void fr_hash(P8Word* w) {  /* :2766-2778; the seed is ~0xeff1cace as a 32-bit value */
+  w->Hash[2] = w->Hash[3] = 0x100e3531u;
+  for (int i = w->Start; i <= w->End; i++) {
+    const uint8_t l = w->Letters[i];
+    w->Hash[2] = w->Hash[2] * 251 * 32 + l;
+    if (V(l)) w->Hash[3] = w->Hash[3] * 997 * 16 + l;
+    else if (l >= 'b' && l <= 'z') w->Hash[3] = w->Hash[3] * 271 * 32 + (uint64_t)(l - 97);
+    else w->Hash[3] = w->Hash[3] * 11 * 32 + l;
+  }
+}
+int p8_fr_stem(P8Word* w) {  /* Stem :2779-2821 */
+  fr_utf8(w);
+  if (p8w_len(w) < 2) { fr_hash(w); return 0; }
+  for (int i = 0; i < COUNT(FR_Exceptions); i++)
+    if (p8w_eq(w, FR_Exceptions[i][0])) {
+      const size_t len = strlen(FR_Exceptions[i][1]);
+      memcpy(&w->Letters[w->Start], FR_Exceptions[i][1], len);
+      w->End = (uint8_t)(w->Start + (uint8_t)(len - 1));
+      fr_hash(w);
+      w->Type |= FR_TypesExceptions[i];
+      w->Language = LANG_French;
+      return 1;
+    }
+  fr_mark(w);
+  const uint32_t RV = fr_rv(w), R1 = region(w, 0, p8_fr_is_vowel), R2 = region(w, R1, p8_fr_is_vowel);
+  int next = 0, res = fr_step1(w, RV, R1, R2, &next);
+  next |= !res;
+  if (next) {
+    next = !fr_step2a(w, RV);
+    res |= !next;
+    if (next) res |= fr_step2b(w, RV, R2);
+  }
+  if (res) {  /* Step3 */
+    uint8_t* last = &w->Letters[w->End];
+    if (*last == 'Y') *last = 'i';
+    else if (*last == 0xE7) *last = 'c';
+  } else res |= fr_step4(w, RV, R2);
+  { int s5 = 0;  /* Step5: undouble */
+    for (int i = 0; i < COUNT(FR_SuffixesStep5) && !s5; i++) if (p8w_ends(w, FR_SuffixesStep5[i])) { w->End--; s5 = 1; }
+    res |= s5; }
+  for (int i = w->End; i >= w->Start; i--)  /* Step6: unaccent the last vowel when consonants follow it */
+    if (V(w->Letters[i])) {
+      if (i < w->End && (w->Letters[i] & 0xFE) == 0xE8) { w->Letters[i] = 'e'; res |= 1; }
+      break;
+    }
+  for (int i = w->Start; i <= w->End; i++) w->Letters[i] = (uint8_t)tolower(w->Letters[i]);
+  if (!res) res = p8w_matches_any(w, FR_CommonWords, COUNT(FR_CommonWords));
+  fr_hash(w);
+  if (res) w->Language = LANG_French;
+  return res;
+}
+
+/* ---- GermanStemmer :2831-3004 ---- */
+#undef V
+#undef CONS
+int p8_de_is_vowel(int c) { return in_set(c, DE_Vowels, COUNT(DE_Vowels)); }
+#define V(c) p8_de_is_vowel(c)
+static int de_valid_ending(int c, int include_r) { return in_set(c, DE_Endings, COUNT(DE_Endings)) || (include_r && (char)c == 'r'); }
+static void de_hash(P8Word* w) {  /* :2958-2970; the seed is ~0xbea7ab1e as a 32-bit value */
+  w->Hash[2] = w->Hash[3] = 0x415854e1u;
+  for (int i = w->Start; i <= w->End; i++) {
+    const uint8_t l = w->Letters[i];
+    w->Hash[2] = w->Hash[2] * 263 * 32 + l;
+    if (V(l)) w->Hash[3] = w->Hash[3] * 997 * 16 + l;
+    else if (l >= 'b' && l <= 'z') w->Hash[3] = w->Hash[3] * 251 * 32 + (uint64_t)(l - 97);
+    else w->Hash[3] = w->Hash[3] * 11 * 32 + l;
+  }
+}
+static int de_step1(P8Word* w, uint32_t R1) {
+  for (int i = 0; i < COUNT(DE_SuffixesStep1); i++)
+    if (ENDS_IN(DE_SuffixesStep1[i], R1)) {
+      w->End -= SLEN(DE_SuffixesStep1[i]);
+      if (i >= 3) w->End -= (uint8_t)p8w_ends(w, "niss");
+      return 1;
+    }
+  if (ENDS_IN("s", R1) && de_valid_ending(p8w_back(w, 1), 1)) { w->End--; return 1; }
+  return 0;
+}
+static int de_step2(P8Word* w, uint32_t R1) {
+  for (int i = 0; i < COUNT(DE_SuffixesStep2); i++)
+    if (ENDS_IN(DE_SuffixesStep2[i], R1)) { w->End -= SLEN(DE_SuffixesStep2[i]); return 1; }
+  if (ENDS_IN("st", R1) && p8w_len(w) > 5 && de_valid_ending(p8w_back(w, 2), 0)) { w->End -= 2; return 1; }
+  return 0;
+}
+static int de_step3(P8Word* w, uint32_t R1, uint32_t R2) {  /* :2912-2953 */
+  const char* const* S = DE_SuffixesStep3;
+  int i = 0;
+  for (; i < 2; i++)
+    if (ENDS_IN(S[i], R2)) {
+      w->End -= SLEN(S[i]);
+      if (p8w_ends(w, "ig") && p8w_back(w, 2) != 'e' && suffix_in_rn(w, R2, "ig")) w->End -= 2;
+      if (i) w->Type |= DE_Noun;
+      return 1;
+    }
+  for (; i < 5; i++)
+    if (ENDS_IN(S[i], R2) && p8w_back(w, SLEN(S[i])) != 'e') { w->End -= SLEN(S[i]); if (i > 2) w->Type |= DE_Adjective; return 1; }
+  for (; i < COUNT(DE_SuffixesStep3); i++)
+    if (ENDS_IN(S[i], R2)) {
+      w->End -= SLEN(S[i]);
+      if ((p8w_ends(w, "er") || p8w_ends(w, "en")) && suffix_in_rn(w, R1, "e?")) w->End -= 2;
+      if (i > 5) w->Type |= DE_Noun | DE_Female;
+      return 1;
+    }
+  if (ENDS_IN("keit", R2)) {
+    w->End -= 4;
+    if (ENDS_IN("lich", R2)) w->End -= 4;
+    else if (ENDS_IN("ig", R2)) w->End -= 2;
+    w->Type |= DE_Noun | DE_Female;
+    return 1;
+  }
+  return 0;
+}
+/* The reference closes the gap left by a folded UTF-8 pair with memcpy() on OVERLAPPING ranges (:2852, source one byte
+ * above the destination) -- undefined behaviour whose outcome depends on how the compiler expands the call. The
+ * reference as built here (g++ 11 -O3, oracle/Makefile) expands it inline: head block, then tail block, then the
+ * 8-byte-aligned middle, loads and stores interleaved -- so letters after an umlaut come out doubled / dropped when 5
+ * or more follow it. This reproduces that expansion (Letters is 8-byte aligned in Word, as in the reference's
+ * calloc'ed caches); pinned by the stemmer test against the reference build. */
+static void de_close_gap(uint8_t* L, int d, int n) {
+  uint8_t t[8];
+  const int s = d + 1;
+#define BLOCK(off, len) do { memcpy(t, L + s + (off), (len)); memcpy(L + d + (off), t, (len)); } while (0)
+  if (n >= 8) {
+    BLOCK(0, 8);
+    BLOCK(n - 8, 8);
+    const int k = 8 - (d & 7);
+    for (int j = 0; j < (n - k) >> 3; j++) BLOCK(k + 8 * j, 8);
+  } else if (n & 4) { BLOCK(0, 4); BLOCK(n - 4, 4); }
+  else if (n) { L[d] = L[s]; if (n & 2) BLOCK(n - 2, 2); }
+#undef BLOCK
+}
+int p8_de_stem(P8Word* w) {  /* Stem :2971-3002 */
+  for (int i = w->Start; i < w->End; i++) {  /* ConvertUTF8 :2846-2856 */
+    const uint8_t n = w->Letters[i + 1], c = (uint8_t)(n + (n < 0x9F ? 0x60 : 0x40));
+    if (w->Letters[i] == 0xC3 && (V(c) || c == 0xDF)) {
+      w->Letters[i] = c;
+      if (i + 1 < w->End) de_close_gap(w->Letters, i + 1, w->End - i - 1);
+      w->End--;
+    }
+  }
+  if (p8w_len(w) < 2) { de_hash(w); return 0; }
+  for (int i = w->Start; i <= w->End; i++)  /* ReplaceSharpS */
+    if (w->Letters[i] == 0xDF) {
+      w->Letters[i] = 's';
+      if (i + 1 < P8_MAX_WORD) {
+        memmove(&w->Letters[i + 2], &w->Letters[i + 1], (size_t)(P8_MAX_WORD - i - 2));
+        w->Letters[i + 1] = 's';
+        w->End += (w->End < P8_MAX_WORD - 1);
+      }
+    }
+  for (int i = w->Start + 1; i < w->End; i++) {  /* MarkVowelsAsConsonants */
+    const uint8_t c = w->Letters[i];
+    if ((c == 'u' || c == 'y') && V(w->Letters[i - 1]) && V(w->Letters[i + 1])) w->Letters[i] = (uint8_t)toupper(c);
+  }
+  uint32_t R1 = region(w, 0, p8_de_is_vowel);
+  const uint32_t R2 = region(w, R1, p8_de_is_vowel);
+  if ((int)R1 > 3) R1 = 3;  /* min(3, R1) on ints */
+  int res = de_step1(w, R1);
+  res |= de_step2(w, R1);
+  res |= de_step3(w, R1, R2);
+  for (int i = w->Start; i <= w->End; i++) {
+    uint8_t* l = &w->Letters[i];
+    if (*l == 0xE4) *l = 'a';
+    else if (*l == 0xF6 || *l == 0xFC) *l -= 0x87;
+    else *l = (uint8_t)tolower(*l);
+  }
+  if (!res) res = p8w_matches_any(w, DE_CommonWords, COUNT(DE_CommonWords));
+  de_hash(w);
+  if (res) w->Language = LANG_German;
+  return res;
+}
+
 /* test entry: stem one word given as a C string (letters are added the way wordModel adds them) */
-int orc_p8_en_stem_word(const char* s, uint8_t* letters64, int* start_end, uint64_t* type_lang, uint64_t* hash4_after_stem,
-                        uint64_t* hash4_gethashes) {
+int orc_p8_stem_word(int lang, const char* s, uint8_t* letters64, int* start_end, uint64_t* type_lang, uint64_t* hash4_after_stem,
+                     uint64_t* hash4_gethashes) {
   P8Word w;
   p8w_init(&w);
   for (const char* p = s; *p; ++p) p8w_add(&w, *p);
-  const int r = p8_en_stem(&w);
+  const int r = lang == LANG_French ? p8_fr_stem(&w) : lang == LANG_German ? p8_de_stem(&w) : p8_en_stem(&w);
   memcpy(letters64, w.Letters, 64);
   start_end[0] = w.Start; start_end[1] = w.End;
   type_lang[0] = w.Type; type_lang[1] = w.Language;
@@ -383,4 +690,8 @@ int orc_p8_en_stem_word(const char* s, uint8_t* letters64, int* start_end, uint6
   p8w_hashes(&w);
   memcpy(hash4_gethashes, w.Hash, 32);
   return r;
+}
+int orc_p8_en_stem_word(const char* s, uint8_t* letters64, int* start_end, uint64_t* type_lang, uint64_t* hash4_after_stem,
+                        uint64_t* hash4_gethashes) {
+  return orc_p8_stem_word(LANG_English, s, letters64, start_end, type_lang, hash4_after_stem, hash4_gethashes);
 }

@@ -28,4 +28,8 @@ int p8w_change_suffix(P8Word* w, const char* old_suffix, const char* new_suffix)
 int p8w_matches_any(const P8Word* w, const char* const* a, int count);
 int p8_en_stem(P8Word* w);                      /* EnglishStemmer::Stem */
 int p8_en_is_vowel(int c);
+int p8_fr_stem(P8Word* w);                      /* FrenchStemmer::Stem */
+int p8_fr_is_vowel(int c);
+int p8_de_stem(P8Word* w);                      /* GermanStemmer::Stem */
+int p8_de_is_vowel(int c);
 #endif

@@ -391,14 +391,18 @@ int refp8_exe_step(int level, int y_prev, int bpos, int c0, uint32_t c4, int blp
   return n;
 }
 
-// EnglishStemmer (:1764-2431) on one word, letters added the way wordModel adds them (Word::operator+=).
-int refp8_en_stem_word(const char* s, uint8_t* letters64, int* start_end, uint64_t* type_lang, uint64_t* hash4_after_stem,
-                       uint64_t* hash4_gethashes) {
-  static paq8::EnglishStemmer stemmer;
+// EnglishStemmer (:1764-2431) / FrenchStemmer (:2433-2822) / GermanStemmer (:2831-3004) on one word, letters added the
+// way wordModel and TextModel add them (Word::operator+=). lang: 1 English, 2 French, 3 German.
+int refp8_stem_word(int lang, const char* s, uint8_t* letters64, int* start_end, uint64_t* type_lang, uint64_t* hash4_after_stem,
+                    uint64_t* hash4_gethashes) {
+  static paq8::EnglishStemmer en;
+  static paq8::FrenchStemmer fr;
+  static paq8::GermanStemmer de;
+  paq8::Stemmer* stemmer = lang == 2 ? (paq8::Stemmer*)&fr : lang == 3 ? (paq8::Stemmer*)&de : (paq8::Stemmer*)&en;
   paq8::Word w;
   w.Language = 0;  // not initialised by Word::Word()
   for (const char* p = s; *p; ++p) w += *p;
-  const int r = stemmer.Stem(&w);
+  const int r = stemmer->Stem(&w);
   memcpy(letters64, w.Letters, 64);
   start_end[0] = w.Start; start_end[1] = w.End;
   type_lang[0] = w.Type; type_lang[1] = w.Language;
@@ -406,6 +410,10 @@ int refp8_en_stem_word(const char* s, uint8_t* letters64, int* start_end, uint64
   w.GetHashes();
   memcpy(hash4_gethashes, w.Hash, 32);
   return r;
+}
+int refp8_en_stem_word(const char* s, uint8_t* letters64, int* start_end, uint64_t* type_lang, uint64_t* hash4_after_stem,
+                       uint64_t* hash4_gethashes) {
+  return refp8_stem_word(1, s, letters64, start_end, type_lang, hash4_after_stem, hash4_gethashes);
 }
 
 // wordModel (:3873-4105) over the reference's buffer. g_out receives the word-level globals it maintains for other

@@ -671,6 +671,71 @@ def test_english_stemmer_vs_reference():
 
 
 @needs_ref
+def test_french_and_german_stemmers_vs_reference():
+    """FrenchStemmer and GermanStemmer (TextModel stems every completed word in all three languages): synthetic stems
+    (consonant / vowel syllables with accented letters, both as Latin-1 bytes and as UTF-8 pairs, q-u / y / i vowel
+    marking, sharp s) crossed with every suffix the step tables know, the exception and common words, and the
+    synthetic corpus' English vocabulary. Stem letters, Start / End, type flags, language, both hash sets."""
+    from cmix_amd import synth
+    L, lib = R.paq8core_lib(), O.lib()
+    sig = [C.c_int, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.refp8_stem_word.argtypes = sig
+    lib.orc_p8_stem_word.argtypes = sig
+    rng = np.random.default_rng(2024)
+    fr_sfx = ("ance iqUe isme able iste eux ances iques ismes ables istes atrice ateur ation atrices ateurs ations logie logies usion ution "
+              "usions utions ence ences issement issements ement ements it\xe9 it\xe9s if ive ifs ives euse euses ment ments issaient issantes "
+              "iraient issante issants issions irions issais issait issant issent issiez issons irais irait irent iriez irons iront isses issez "
+              "\xeemes \xeetes irai iras irez isse ies ira \xeet ie ir is it i eraient assions erions assent assiez \xe8rent erais erait eriez "
+              "erons eront aient antes asses ions erai eras erez \xe2mes \xe2tes ante ants asse \xe9es era iez ais ait ant \xe9e \xe9s er ez "
+              "\xe2t ai as \xe9 a i\xe8re ion ier e \xeb gu\xeb enn onn ett ell eill eaux aux amment emment s ivement ativement eusement "
+              "ablement iquement i\xe8rement abilit\xe9 icit\xe9 ivit\xe9 icatif atif icateur y \xe7").split()
+    de_sfx = ("em ern er e en es s nisse nissen st est end ung igung ik ig isch lich heit keit lichkeit igkeit erheit enheit ungen "
+              "\xdf \xdfe \xdfen").split()
+    cons, vow = list("bcdfghjklmnpqrstvwxz") + ["qu", "ch", "ss", "ll", "gu", "\xe7", "\xdf"], list("aeiouy") + ["\xe9", "\xe8", "\xea", "\xe2", "\xee", "\xf4", "\xfb", "\xe4", "\xf6", "\xfc", "ou", "ai", "ie", "ue", "uy", "ay"]
+
+    def lat(t):
+        return t.encode("latin-1").decode("unicode_escape").encode("latin-1")
+
+    def utf(b):
+        return b"".join(bytes([0xC3, c - 0x40]) if c >= 0xC0 else bytes([c]) for c in b)
+
+    stems = [b"par", b"col", b"tap", b"", b"a", b"ou", b"monument", b"yeux", b"travaux", b"de", b"pas", b"une", b"der", b"nicht", b"sich",
+             b"parl", b"fin", b"chant", b"gross", b"klein", b"freund", b"sch\xf6n".decode("unicode_escape").encode("latin-1")]
+    for _ in range(900):
+        k = int(rng.integers(1, 5))
+        parts = []
+        if rng.random() < 0.3:
+            parts.append(vow[int(rng.integers(len(vow)))])
+        for _ in range(k):
+            parts.append(cons[int(rng.integers(len(cons)))])
+            parts.append(vow[int(rng.integers(len(vow)))])
+        if rng.random() < 0.6:
+            parts.append(cons[int(rng.integers(len(cons)))])
+        stems.append(lat("".join(parts)))
+    english = sorted({w.lower() for w in synth.enwik_like(200000, 5).replace(b"\n", b" ").split(b" ") if w.isalpha() and len(w) < 40})[:3000]
+    bufs = [(np.zeros(64, np.uint8), np.zeros(2, np.int32), np.zeros(2, np.uint64), np.zeros(4, np.uint64), np.zeros(4, np.uint64)) for _ in range(2)]
+    for lang, sfxs in ((2, fr_sfx), (3, de_sfx)):
+        words = list(english) + [b"x" * 70, b"\xc3".decode("unicode_escape").encode("latin-1") * 5]
+        for st in stems:
+            for j in rng.choice(len(sfxs), 12 if lang == 2 else 10, replace=False):
+                w = st + lat(sfxs[int(j)])
+                words.append(w)
+                if any(c >= 0xC0 for c in w):
+                    words.append(utf(w))
+        changed = 0
+        for w in words:
+            if not w or 0 in w:
+                continue
+            out = []
+            for fn, (let, se, tl, h1, h2) in ((L.refp8_stem_word, bufs[0]), (lib.orc_p8_stem_word, bufs[1])):
+                r = fn(lang, w, let.ctypes.data, se.ctypes.data, tl.ctypes.data, h1.ctypes.data, h2.ctypes.data)
+                out.append((r, let.tobytes(), tuple(se), int(tl[0]), int(tl[1]) if r else -1, tuple(h1), tuple(h2)))
+            assert out[0] == out[1], (lang, w, out[0][:5], out[1][:5])
+            changed += out[0][0]
+        assert changed > len(words) // 4, (lang, changed, len(words))
+
+
+@needs_ref
 def test_word_model_vs_reference():
     """wordModel: enwik-like text plus hyphenated line breaks ("+\\n", "-\\r\\n"), numbers with decimal points, wiki
     markup ("==", "''", "[[..]]"), upper-case words, high bytes, long lines. 57 contexts and the nine word-level
