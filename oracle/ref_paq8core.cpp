@@ -434,6 +434,27 @@ int refp8_word_step(int level, int y_prev, int bpos, int c0, uint32_t c4, uint32
   return drain(out);
 }
 
+// TextModel (:3006-3518) over the reference's buffer. sets: the eight mixer selectors; stats: ModelStats::Text.
+void refp8_text_tables(uint8_t* out /* 254 + 128 */) {
+  memcpy(out, paq8::AsciiGroupC0, 254);
+  memcpy(out + 254, paq8::AsciiGroup, 128);
+}
+void* refp8_text_new(uint32_t size) { return new paq8::TextModel(size); }
+int refp8_text_step(void* h, int y_prev, int bpos, int c0, int16_t* out, int* sets, int* nsets, uint32_t* stats) {
+  paq8::y = y_prev;
+  paq8::bpos = bpos;
+  paq8::c0 = c0;
+  paq8::grp0 = (bpos > 0) ? paq8::AsciiGroupC0[(1 << bpos) - 2 + (c0 & ((1 << bpos) - 1))] : 0;  // Predictor::update :8274
+  paq8::ModelStats st;
+  memset(&st, 0, sizeof st);
+  ((paq8::TextModel*)h)->Predict(*sink(), paq8::buf, &st);
+  stats[0] = st.Text.state; stats[1] = st.Text.lastPunct; stats[2] = st.Text.wordLength; stats[3] = st.Text.boolmask;
+  stats[4] = st.Text.firstLetter; stats[5] = st.Text.mask;
+  const int n = drain(out);
+  *nsets = drain_sets(sets);
+  return n;
+}
+
 uint64_t refp8_hash2(uint64_t a, uint64_t b) { return paq8::hash(a, b); }
 uint64_t refp8_hash3(uint64_t a, uint64_t b, uint64_t c) { return paq8::hash(a, b, c); }
 uint64_t refp8_hash4(uint64_t a, uint64_t b, uint64_t c, uint64_t d) { return paq8::hash(a, b, c, d); }

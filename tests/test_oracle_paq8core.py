@@ -769,3 +769,59 @@ def test_word_model_vs_reference():
         c4 = ((c4 << 8) | b) & 0xffffffff
         f4 = ((f4 << 4) | (b >> 4)) & 0xffffffff
         b3, b2 = b2, b
+
+
+def _text_corpus():
+    from cmix_amd import synth
+    fr = ("Les enfants \xc3\xa9taient heureusement arriv\xc3\xa9s; ils parlaient doucement, finissaient leurs travaux et regardaient les "
+          "monuments. M. Dupont (le directeur) disait: \xab la nation fran\xc3\xa7aise est une grande nation \xbb ! Que faites-vous? "
+          "Nous chanterons demain, et vous danserez apr\xc3\xa8s. ").encode("latin-1")
+    de = ("Die Kinder spielten fr\xc3\xb6hlich auf der Stra\xc3\x9fe und sangen sch\xc3\xb6ne Lieder. Hr. M\xc3\xbcller sagte: "
+          "die Freundlichkeit der Menschen ist nicht selbstverst\xc3\xa4ndlich! Wir haben sich mit den Nachbarn getroffen, "
+          "und das Wetter war herrlich. ").encode("latin-1")
+    en = (b"Mr. Smith said, \"the running dogs were happily jumping over 1,234 fences\"; Dr. Jones disagreed! Why? Because 10, 11, 12, 13 "
+          b"and 100 - 99 = 1 {see [note (3)]} <tag> 'quoted words' aren't it's. St. Paul's; U.S.A. e.g. the+\nbroken+\r\nword\n\nNew "
+          b"paragraph: Topic: details follow\twith\ttabs | and \\ slashes @ & ^ _ 50% 3*4/2=6\r\n\r\n")
+    return np.frombuffer(synth.enwik_like(5000, 41) + en * 3 + fr * 6 + en + de * 6 + synth.enwik_like(2500, 43) + bytes(range(256)) * 2 + fr + en,
+                         np.uint8)
+
+
+@needs_ref
+def test_text_model_vs_reference():
+    """TextModel: enwik-like text, English with abbreviations / quotes / number sequences / nesting / "+\\n" hyphenation,
+    French and German paragraphs long enough to flip the detected language (UTF-8 accents, guillemets, sharp s), all 256
+    byte values. The 33-context map's 231 inputs, the eight mixer selectors and ModelStats::Text, bit for bit."""
+    L, lib = R.paq8core_lib(), O.lib()
+    data = _text_corpus()
+    LOG, level = 16, 2
+    L.refp8_buf_reset(LOG)
+    L.refp8_text_new.restype = C.c_void_p
+    lib.orc_p8_text_new.restype = C.c_void_p
+    L.refp8_text_step.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.orc_p8_text_step.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    size = (0x10000 << level) * 16
+    ref, got = L.refp8_text_new(size), lib.orc_p8_text_new(size)
+    ring = np.zeros(1 << LOG, np.uint8)
+    o_ref, o_got = np.zeros(512, np.int16), np.zeros(512, np.int16)
+    s_ref, s_got = np.zeros(64, np.int32), np.zeros(8, np.int32)
+    t_ref, t_got = np.zeros(6, np.uint32), np.zeros(6, np.uint32)
+    k_ref = C.c_int(0)
+    y, c0 = 0, 1
+    states = set()
+    bases = np.concatenate([[0], np.cumsum([2048, 2048, 4096, 4096, 2048, 2048, 4096])]).astype(np.int32)  # the recording mixer stores base + selector
+    for n in range(len(data)):
+        for bpos in range(8):
+            k = L.refp8_text_step(ref, y, bpos, c0, o_ref.ctypes.data, s_ref.ctypes.data, C.byref(k_ref), t_ref.ctypes.data)
+            g = lib.orc_p8_text_step(got, y, bpos, c0, ring.ctypes.data, (1 << LOG) - 1, n, o_got.ctypes.data, s_got.ctypes.data, t_got.ctypes.data)
+            assert k == g == 231 and k_ref.value == 8, (n, bpos, k, g, k_ref.value)
+            if bpos == 0:
+                assert (t_ref == t_got).all(), (n, bytes(data[max(0, n - 30):n]), t_ref, t_got)
+                states.add(int(t_ref[0]))
+            assert (s_ref[:8] - bases == s_got).all(), (n, bpos, bytes(data[max(0, n - 30):n]), s_ref[:8] - bases, s_got)
+            assert (o_ref[:k] == o_got[:k]).all(), (n, bpos, bytes(data[max(0, n - 30):n]), np.nonzero(o_ref[:k] != o_got[:k])[0][:6] // 5)
+            y = (int(data[n]) >> (7 - bpos)) & 1
+            c0 = (c0 << 1 | y) if bpos < 7 else 1
+        b = int(data[n])
+        L.refp8_buf_push(b)
+        ring[n] = b
+    assert states == set(range(8)), states
