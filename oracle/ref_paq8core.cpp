@@ -455,6 +455,21 @@ int refp8_text_step(void* h, int y_prev, int bpos, int c0, int16_t* out, int* se
   return n;
 }
 
+// The whole model as cmix drives it: paq8::Predictor (:8208-8362) behind PAQ8::Perceive / PAQ8::Predict (:8366-8385).
+// contextModel2 keeps its sub-models in function-local statics sized by the level at the first call: ONE predictor per
+// loaded copy of this library, and none of the single-model entries above may be used in the same copy.
+void* refp8_predictor_new(int level) {
+  paq8::level = level;
+  paq8::buf.setsize(paq8::MEM() * 8);
+  return new paq8::Predictor();
+}
+int refp8_predictor_update(void* h, int bit, float* out1591) {
+  paq8::y = bit;
+  ((paq8::Predictor*)h)->update();
+  for (int i = 0; i < 1591; ++i) out1591[i] = paq8::model_predictions[i];
+  return ((paq8::Predictor*)h)->p();
+}
+
 uint64_t refp8_hash2(uint64_t a, uint64_t b) { return paq8::hash(a, b); }
 uint64_t refp8_hash3(uint64_t a, uint64_t b, uint64_t c) { return paq8::hash(a, b, c); }
 uint64_t refp8_hash4(uint64_t a, uint64_t b, uint64_t c, uint64_t d) { return paq8::hash(a, b, c, d); }

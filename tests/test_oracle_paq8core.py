@@ -825,3 +825,92 @@ def test_text_model_vs_reference():
         L.refp8_buf_push(b)
         ring[n] = b
     assert states == set(range(8)), states
+
+
+def _private_ref_copy(tmp_path):
+    """contextModel2 keeps its sub-models in function-local statics: the whole-predictor runs use their own loaded
+    copy of the reference library so that the single-model tests of this file do not share state with them."""
+    import shutil
+    dst = tmp_path / "libcmixrefpaq8_private.so"
+    shutil.copy(R.PAQ8_LIB_PATH, dst)
+    L = C.CDLL(str(dst))
+    L.refp8_predictor_new.restype = C.c_void_p
+    L.refp8_predictor_new.argtypes = [C.c_int]
+    L.refp8_predictor_update.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    return L
+
+
+def _block(ftype, payload, info=None):
+    """A block as cmix's preprocessor frames it for paq8 (contextModel2 :8117-8134): type, big-endian size[, info]."""
+    hdr = bytes([ftype]) + len(payload).to_bytes(4, "big")
+    if info is not None:
+        hdr += info.to_bytes(4, "big")
+    return hdr + payload
+
+
+def _predictor_streams():
+    from cmix_amd import synth
+    rng = np.random.default_rng(311)
+    ops = [b"\x55\x8b\xec", b"\x83\xec\x10", b"\x8b\x45\x08", b"\xe8\x10\x00\x00\x00", b"\x0f\x84\x20\x01\x00\x00", b"\x48\x8b\x05\x10\x20\x00\x00",
+           b"\xc3", b"\x90", b"\xff\x15\x00\x10\x40\x00", b"\xeb\xfe", b"\x89\x44\x24\x04"]
+    exe = b"".join(ops[int(k)] for k in rng.integers(0, len(ops), 500))
+    recs = b"".join(int(i).to_bytes(4, "little") + bytes([i % 7, 0, 0, 0]) + b"name%04d" % (i % 50) + b"\x00\x00\x28\x00" for i in range(150))
+    text = bytes(_text_corpus()[:9000])
+    framed = (_block(4, text[:5000], 0) + _block(0, recs + bytes(rng.integers(0, 256, 600, dtype=np.uint8))) + _block(3, exe[:1500]) +
+              _block(4, text[5000:8000], 0) + _block(1, b"hdr-ish \x00\x01\x02" * 20))
+    raw = synth.enwik_like(3000, 71) + recs[:1200] + bytes(range(256))
+    return {"framed": framed, "raw": raw}
+
+
+@needs_ref
+@pytest.mark.parametrize("name", ["framed", "raw"])
+def test_whole_paq8_predictor_vs_reference(name, tmp_path):
+    """The assembled oracle (oracle/paq8_predictor.c) against the reference's own paq8::Predictor, all 1591 values
+    PAQ8::Predict() hands to cmix after every bit plus the final probability: a stream framed the way cmix's
+    preprocessor frames blocks (TEXT with English / French / German, DEFAULT with records and noise, EXE, HDR) and a
+    raw stream whose first bytes get read as a block header. Floats are int * (1/4095.f): compared bit for bit."""
+    L, lib = _private_ref_copy(tmp_path), O.lib()
+    lib.orc_p8_predictor_new.restype = C.c_void_p
+    lib.orc_p8_predictor_new.argtypes = [C.c_int]
+    lib.orc_p8_predictor_update.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    level = 2
+    data = _predictor_streams()[name]
+    lib.orc_p8_rnd_reset()
+    ref, got = L.refp8_predictor_new(level), lib.orc_p8_predictor_new(level)
+    o_ref, o_got = np.zeros(1591, np.float32), np.zeros(1591, np.float32)
+    for n, byte in enumerate(data):
+        for bpos in range(8):
+            y = (byte >> (7 - bpos)) & 1
+            pr = L.refp8_predictor_update(ref, y, o_ref.ctypes.data)
+            pg = lib.orc_p8_predictor_update(got, y, o_got.ctypes.data)
+            assert pg >= 0, (n, bpos, pg)
+            bad = np.nonzero(o_ref.view(np.uint32) != o_got.view(np.uint32))[0]
+            assert bad.size == 0, (name, n, bpos, bad[:8], o_ref[bad[:4]] * 4095, o_got[bad[:4]] * 4095)
+            assert pr == pg, (n, bpos, pr, pg)
+
+
+def test_paq8_predictor_refuses_streams_it_does_not_model():
+    """JPEG / BMP / WAV payloads and image-typed blocks switch on sub-models the oracle does not restate: it must
+    return an error code, never a number."""
+    lib = O.lib()
+    lib.orc_p8_predictor_new.restype = C.c_void_p
+    lib.orc_p8_predictor_new.argtypes = [C.c_int]
+    lib.orc_p8_predictor_update.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    bmp = b"\x28\x00\x00\x00" + (16).to_bytes(4, "little") + (16).to_bytes(4, "little") + b"\x01\x00\x18\x00" + bytes(24)
+    wav = (b"RIFF" + (1000).to_bytes(4, "little") + b"WAVEfmt " + (16).to_bytes(4, "little") + b"\x01\x00\x02\x00" + (44100).to_bytes(4, "little") +
+           (176400).to_bytes(4, "little") + b"\x04\x00\x10\x00" + b"data" + (800).to_bytes(4, "little") + bytes(16))
+    cases = {-2: _block(0, b"abc\xff\xd8\xff\xe0 more"), -3: _block(0, b"x" * 10 + bmp + b"y" * 20), -5: _block(0, b"zz" + wav),
+             -1: _block(7, bytes(64), 8)}
+    for code, stream in cases.items():
+        lib.orc_p8_rnd_reset()
+        h = lib.orc_p8_predictor_new(0)
+        seen = None
+        for byte in stream:
+            for bpos in range(8):
+                r = lib.orc_p8_predictor_update(h, (byte >> (7 - bpos)) & 1, None)
+                if r < 0:
+                    seen = r
+                    break
+            if seen is not None:
+                break
+        assert seen == code, (code, seen)
