@@ -34,6 +34,29 @@ def test_mixnet_text_4k_local():
     _check("text_4k", big=True)
 
 
+@pytest.mark.parametrize("name", ["text_96", "binary_64"])
+def test_paq8_oracle_reproduces_golden_columns(name):
+    """The assembled paq8 restatement (oracle/paq8_predictor.c) at cmix's own setting (level 11, reference
+    src/predictor.cpp:85) against layer-0 columns 434..2024 of the traces recorded from the unmodified reference
+    predictor: all 1591 values after every coded bit, bit for bit. Needs nothing but the committed fixtures."""
+    import ctypes as C
+    lib = O.lib()
+    lib.orc_p8_predictor_new.restype = C.c_void_p
+    lib.orc_p8_predictor_new.argtypes = [C.c_int]
+    lib.orc_p8_predictor_update.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    g = load_golden(name)
+    probs, bits = mg.unpack_probs(g), g["bits"]
+    lib.orc_p8_rnd_reset()
+    h = lib.orc_p8_predictor_new(11)
+    out = np.zeros(1591, np.float32)
+    assert (probs[0, 434:2025] == 0.5).all()          # PAQ8::Predict() before the first Perceive
+    for t in range(len(bits) - 1):
+        assert lib.orc_p8_predictor_update(h, int(bits[t]), out.ctypes.data) >= 0
+        want = np.ascontiguousarray(probs[t + 1, 434:2025])
+        bad = np.nonzero(want.view(np.uint32) != out.view(np.uint32))[0]
+        assert bad.size == 0, (name, t, bad[:8], want[bad[:4]] * 4095, out[bad[:4]] * 4095)
+
+
 def test_stretch_matches_reference_layer0():
     """MixerInput::SetInput: raw probs -> stretch; aux selector derived from them."""
     g = load_golden("text_96")
