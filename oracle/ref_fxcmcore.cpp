@@ -1,0 +1,159 @@
+// oracle/ref_fxcmcore.cpp -- TEST INFRASTRUCTURE ONLY. Compiled by oracle/Makefile into oracle/_ref/libcmixreffxcm.so
+// together with the UNMODIFIED reference source src/models/fxcmv1.cpp (included below from where it lies under
+// /root/reference; nothing is copied). Exposes the vendored fxcm model's own building blocks -- the tables its
+// constructor computes, Mixer1, StateMap, StateMap1, APM, RunContextMap, SmallStationaryContextMap, DirectStateMap --
+// so that the C restatement in oracle/fxcm_core.c can be pinned against the reference's objects, bit for bit.
+#include <stdint.h>
+#include <string.h>
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <time.h>
+#include <math.h>
+#include <ctype.h>
+#include <assert.h>
+#include <algorithm>
+#include <unordered_map>
+#include <memory>
+#include <valarray>
+#include <vector>
+
+// The reference's alloc1() (fxcmv1.cpp:146-150) aligns the pointer it got from calloc() upwards WITHOUT having asked
+// for the extra bytes: harmless for the model's huge, mmap-backed tables, but the small instances the tests build
+// would write past their allocation into their neighbours. The harness pads every allocation the reference makes;
+// the reference source itself is untouched.
+static void* reffx_padded_calloc(size_t count, size_t size) { return calloc(count * size + 128, 1); }
+#define calloc(count, size) reffx_padded_calloc(count, size)
+#define private public
+#define protected public
+#include "models/fxcmv1.cpp"
+#undef private
+#undef protected
+#undef calloc
+
+char* dictionary_path = NULL;  // hidden inputs of the model (predictor.cpp:359, runner.cpp:17)
+int lstmpr = 0, lstmex = 0;
+
+namespace fx = fxcmv1;
+
+static int drain(int16_t* inputs, float* exported, int* nexported) {
+  const int n = fx::x.mxInputs1.ncount;
+  for (int i = 0; i < n; ++i) inputs[i] = fx::x.mxInputs1.n[i];
+  if (exported) {
+    *nexported = (int)fx::prediction_index;
+    for (unsigned i = 0; i < fx::prediction_index; ++i) exported[i] = fx::model_predictions[i];
+  }
+  fx::x.mxInputs1.ncount = 0;
+  fx::prediction_index = 0;
+  return n;
+}
+static void set_bit_state(int y, int bpos, int c0) {  // update1 :4776-4779
+  fx::x.y = y; fx::x.bpos = bpos; fx::x.c0 = c0;
+  fx::x.bposshift = 7 - bpos;
+  fx::x.c0shift_bpos = (c0 << 1) ^ (256 >> fx::x.bposshift);
+}
+
+extern "C" {
+
+// what Predictor::Predictor() precomputes (:4846-4875), without building the 3.7 GB of model tables
+void reffx_init() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  int o = 2;
+  for (int i = 0; i < 1024; ++i) fx::dt[i] = 4096 / (o), o++;
+  fx::dt[1023] = 1;
+  for (int i = 0; i <= 4095; i++) fx::strt[i] = fx::stretchc(i);
+  for (int i = -2047; i <= 2047; i++) fx::sqt[i + 2047] = fx::squashc(i);
+  fx::InitIlog();
+  fx::x.Init();
+  for (int i = 0; i < 4096; i++) { fx::st2_p1[i] = fx::clp(fx::sc(12 * (i - 2048))); fx::st2_p2[i] = fx::clp(fx::sc(14 * (i - 2048))); }
+  fx::StateTable st;
+  st.Init(28, 28, 31, 29, 23, 4, 17, &fx::STA1[0][0]);
+  st.Init(32, 28, 31, 28, 21, 5, 6, &fx::STA2[0][0]);
+  st.Init(31, 27, 30, 27, 24, 4, 27, &fx::STA4[0][0]);
+  st.Init(33, 31, 31, 24, 20, 4, 33, &fx::STA5[0][0]);
+  st.Init(28, 29, 30, 30, 23, 3, 22, &fx::STA6[0][0]);
+  st.Init(28, 29, 33, 23, 23, 6, 14, &fx::STA7[0][0]);
+  fx::pre2(&fx::STA7[0][0]);
+}
+void reffx_tables(int16_t* squash4095, int16_t* stretch4096, uint8_t* ilog256, int32_t* dt1024, uint8_t* sta6x1024, int16_t* pre1_256,
+                  int16_t* st2_p1_4096, int16_t* st2_p2_4096) {
+  reffx_init();
+  memcpy(squash4095, fx::sqt, 4095 * 2);
+  memcpy(stretch4096, fx::strt, 4096 * 2);
+  memcpy(ilog256, fx::ilog, 256);
+  memcpy(dt1024, fx::dt, 1024 * 4);
+  const uint8_t* tabs[6] = {&fx::STA1[0][0], &fx::STA2[0][0], &fx::STA4[0][0], &fx::STA5[0][0], &fx::STA6[0][0], &fx::STA7[0][0]};
+  for (int k = 0; k < 6; ++k) memcpy(sta6x1024 + 1024 * k, tabs[k], 1024);
+  memcpy(pre1_256, fx::pre1, 256 * 2);
+  memcpy(st2_p1_4096, fx::st2_p1, 4096 * 2);
+  memcpy(st2_p2_4096, fx::st2_p2, 4096 * 2);
+}
+static const uint8_t* sta(int which) {
+  const uint8_t* tabs[6] = {&fx::STA1[0][0], &fx::STA2[0][0], &fx::STA4[0][0], &fx::STA5[0][0], &fx::STA6[0][0], &fx::STA7[0][0]};
+  return tabs[which];
+}
+
+// Mixer1 (:472-660): one coded bit = update(y) on the previous inputs, new inputs, context, p() or p1()
+struct MixerBox { fx::Mixer1 m; short* tx; };
+void* reffx_mixer_new(int n, int m, int shift, int elim, int uperr) {
+  reffx_init();
+  MixerBox* b = new MixerBox();
+  b->tx = (short*)aligned_alloc(64, (size_t)n * 2 + 64);
+  memset(b->tx, 0, (size_t)n * 2 + 64);
+  b->m.Init(m, shift, elim, uperr);
+  b->m.setTxWx(n, b->tx);
+  return b;
+}
+int reffx_mixer_step(void* h, int y, const int16_t* in, int cxt, int elim, int use_p1, int* pr_out) {
+  MixerBox* b = (MixerBox*)h;
+  b->m.elim = elim;  // adapted per byte by the caller (:4766-4771)
+  b->m.update(y);
+  memcpy(b->tx, in, (size_t)b->m.N * 2);
+  b->m.cxt = cxt;
+  const int r = use_p1 ? b->m.p1() : b->m.p();
+  *pr_out = b->m.pr;
+  return r;
+}
+
+// StateMap (:672-705), StateMap1 (:707-736)
+void* reffx_statemap_new(int n, int which_sta) { reffx_init(); fx::StateMap* s = new fx::StateMap(); s->Init(n, sta(which_sta)); return s; }
+int reffx_statemap_set(void* h, int y, int c) { fx::x.y = y; fx::StateMap* s = (fx::StateMap*)h; s->set(c); return s->pr; }
+void* reffx_statemap1_new(int n, int limit) { reffx_init(); fx::StateMap1* s = new fx::StateMap1(); s->Init(n, limit); return s; }
+int reffx_statemap1_set(void* h, int y, int c) { fx::x.y = y; fx::StateMap1* s = (fx::StateMap1*)h; s->set(c); return s->pr; }
+
+// APM<S> (:1622-1643); the model uses S = 0x10000 ... see :3287-3292; one size is enough to pin the arithmetic
+void* reffx_apm_new() { reffx_init(); fx::APM<1024>* a = new fx::APM<1024>(); a->Init(); return a; }
+int reffx_apm_p(void* h, int pr, int cxt, int rate, int y) { return ((fx::APM<1024>*)h)->p(pr, cxt, rate, y); }
+
+// RunContextMap (:756-829)
+void* reffx_rcm_new(int m, int ml) { reffx_init(); fx::RunContextMap* r = new fx::RunContextMap(); r->Init(m, ml); return r; }
+void reffx_rcm_set(void* h, uint32_t cx, int c1) { ((fx::RunContextMap*)h)->set(cx, (fx::U8)c1); }
+int reffx_rcm_mix(void* h, int y, int bpos, int c0, int16_t* out) {
+  set_bit_state(y, bpos, c0);
+  const int r = ((fx::RunContextMap*)h)->mix();
+  drain(out, nullptr, nullptr);
+  return r;
+}
+
+// SmallStationaryContextMap (:831-863): note the second add() re-uses the exported slot (prediction_index--)
+void* reffx_sscm_new(int bits_of_context, int input_bits) { reffx_init(); fx::SmallStationaryContextMap* s = new fx::SmallStationaryContextMap(); s->Init(bits_of_context, input_bits); return s; }
+void reffx_sscm_set(void* h, uint32_t ctx) { ((fx::SmallStationaryContextMap*)h)->set(ctx); }
+int reffx_sscm_mix(void* h, int y, int rate, int16_t* out, float* exported, int* nexported) {
+  fx::x.y = y;
+  ((fx::SmallStationaryContextMap*)h)->mix(rate);
+  return drain(out, exported, nexported);
+}
+
+// DirectStateMap (:1646-1683)
+void* reffx_dsm_new(int m, int c, int which_sta) { reffx_init(); fx::DirectStateMap* d = new fx::DirectStateMap(); d->Init(m, c, sta(which_sta)); return d; }
+int reffx_dsm_step(void* h, int y, const uint32_t* cx, int n, int16_t* out, float* exported, int* nexported) {
+  fx::x.y = y;
+  fx::DirectStateMap* d = (fx::DirectStateMap*)h;
+  for (int i = 0; i < n; ++i) d->set(cx[i], y);
+  d->mix();
+  return drain(out, exported, nexported);
+}
+
+}  // extern "C"

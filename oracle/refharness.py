@@ -262,3 +262,17 @@ def paq8core_lib():
         getattr(L, name).argtypes = at
     L.refp8_init_dt()
     return L
+
+
+FXCM_LIB_PATH = os.path.join(HERE, "_ref", "libcmixreffxcm.so")
+
+
+def fxcmcore_available():
+    return os.path.exists(FXCM_LIB_PATH)
+
+
+def fxcmcore_lib():
+    """The reference's own fxcm building blocks (oracle/ref_fxcmcore.cpp)."""
+    L = C.CDLL(FXCM_LIB_PATH)
+    L.reffx_init()
+    return L

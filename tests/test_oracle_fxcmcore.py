@@ -1,0 +1,157 @@
+"""CPU: the restated numeric building blocks of the vendored fxcm model (oracle/fxcm_core.c; SURVEY.md 8a') against the
+reference's own structs compiled from fxcmv1.cpp (oracle/ref_fxcmcore.cpp -> oracle/_ref/libcmixreffxcm.so). Integer
+work: bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from oracle import refharness as R
+
+needs_ref = pytest.mark.skipif(not R.fxcmcore_available(), reason="oracle/_ref/libcmixreffxcm.so not built")
+P = C.c_void_p
+
+
+def _libs():
+    return R.fxcmcore_lib(), O.lib()
+
+
+def _bits(rng, n, p1=0.5):
+    return (rng.random(n) < p1).astype(np.int32)
+
+
+@needs_ref
+def test_tables_match_the_reference():
+    """squash / stretch (float exp / log + round in the reference's constructor), ilog, dt, the six generated state
+    tables and the tables derived from them: the committed numbers (oracle/fxcm_tables.h) and the oracle's formulas
+    against what the reference computes at start-up."""
+    L, lib = _libs()
+    outs = []
+    for fn in (L.reffx_tables, lib.orc_fx_tables):
+        a = [np.zeros(4095, np.int16), np.zeros(4096, np.int16), np.zeros(256, np.uint8), np.zeros(1024, np.int32), np.zeros(6144, np.uint8),
+             np.zeros(256, np.int16), np.zeros(4096, np.int16), np.zeros(4096, np.int16)]
+        fn.argtypes = [P] * 8
+        fn(*[x.ctypes.data for x in a])
+        outs.append(a)
+    for x, y in zip(*outs):
+        assert (x == y).all()
+    assert outs[0][4].reshape(6, 256, 4)[:, :, :2].max() > 200          # real state tables, not zeros
+    assert [lib.orc_fx_squash(d) for d in (-3000, -2047, 0, 2047, 3000)] == [1, int(outs[0][0][0]), int(outs[0][0][2047]), int(outs[0][0][4094]), 4095]
+
+
+@needs_ref
+@pytest.mark.parametrize("n,m,shift,elim0,uperr,use_p1", [(512, 64, 14, 0, 24, 1), (512, 2048, 40, 27, 28, 1), (16, 8, 16, 0, 14, 0), (16, 256, 80, 3, 20, 0)])
+def test_mixer1_vs_reference(n, m, shift, elim0, uperr, use_p1):
+    """Mixer1: stretch-domain inputs with saturating outliers, contexts with locality, bits correlated with the
+    prediction, the dead zone `elim` changing over time (the model adapts it per byte)."""
+    L, lib = _libs()
+    L.reffx_mixer_new.restype = P
+    lib.orc_fx_mixer_new.restype = P
+    sig = [P, C.c_int, P, C.c_int, C.c_int, C.c_int, P]
+    L.reffx_mixer_step.argtypes = sig
+    lib.orc_fx_mixer_step.argtypes = sig
+    rng = np.random.default_rng(n * 31 + m)
+    ref, got = L.reffx_mixer_new(n, m, shift, elim0, uperr), lib.orc_fx_mixer_new(n, m, shift, elim0, uperr)
+    steps = 3000
+    xs = np.clip(rng.normal(0, 500, (steps, n)), -2047, 2047).astype(np.int16)
+    xs[rng.random((steps, n)) < 0.01] = 32767
+    xs[rng.random((steps, n)) < 0.01] = -32768
+    xs[:, n // 2:] *= (rng.random((steps, n - n // 2)) < 0.3)
+    cur, y = 0, 0
+    pr_r, pr_g = C.c_int(0), C.c_int(0)
+    for t in range(steps):
+        if rng.random() < 0.3:
+            cur = int(rng.integers(0, m))
+        elim = elim0 + (t // 500) % 3 * 9
+        a = L.reffx_mixer_step(ref, y, xs[t].ctypes.data, cur, elim, use_p1, C.byref(pr_r))
+        b = lib.orc_fx_mixer_step(got, y, xs[t].ctypes.data, cur, elim, use_p1, C.byref(pr_g))
+        assert (a, pr_r.value) == (b, pr_g.value), (t, a, b, pr_r.value, pr_g.value)
+        y = int(rng.random() < pr_r.value / 4096.0)
+
+
+@needs_ref
+def test_statemaps_and_apm_vs_reference():
+    L, lib = _libs()
+    rng = np.random.default_rng(5)
+    for name in ("statemap_new", "statemap1_new", "apm_new"):
+        getattr(L, "reffx_" + name).restype = P
+        getattr(lib, "orc_fx_" + name).restype = P
+    for fn in (L.reffx_statemap_set, lib.orc_fx_statemap_set, L.reffx_statemap1_set, lib.orc_fx_statemap1_set):
+        fn.argtypes = [P, C.c_int, C.c_int]
+    for fn in (L.reffx_apm_p, lib.orc_fx_apm_p):
+        fn.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_int]
+    for which in range(6):                      # StateMap over each state table
+        ref, got = L.reffx_statemap_new(256, which), lib.orc_fx_statemap_new(256, which)
+        cx = rng.integers(0, 256, 20000) * (rng.random(20000) < 0.7)
+        for t, y in enumerate(_bits(rng, 20000, 0.3 + 0.1 * which)):
+            assert L.reffx_statemap_set(ref, int(y), int(cx[t])) == lib.orc_fx_statemap_set(got, int(y), int(cx[t])), (which, t)
+    for n, limit in ((1 << 16, 1023), (1 << 10, 127), (1 << 8, 1)):   # StateMap1: few contexts so that counts reach the limit
+        ref, got = L.reffx_statemap1_new(n, limit), lib.orc_fx_statemap1_new(n, limit)
+        cx = rng.integers(0, 1 << 20, 40000) % rng.choice([7, 64, n * 4])
+        for t, y in enumerate(_bits(rng, 40000, 0.9)):
+            assert L.reffx_statemap1_set(ref, int(y), int(cx[t])) == lib.orc_fx_statemap1_set(got, int(y), int(cx[t])), (n, limit, t)
+    ref, got = L.reffx_apm_new(), lib.orc_fx_apm_new(1024)
+    for t in range(30000):
+        pr, cx, rate, y = int(rng.integers(0, 4096)), int(rng.integers(0, 1024) % (1 + t % 37)), int(rng.integers(5, 9)), int(rng.random() < 0.6)
+        assert L.reffx_apm_p(ref, pr, cx, rate, y) == lib.orc_fx_apm_p(got, pr, cx, rate, y), t
+
+
+@needs_ref
+def test_run_map_sscm_and_direct_state_map_vs_reference():
+    L, lib = _libs()
+    rng = np.random.default_rng(17)
+    for name in ("rcm_new", "sscm_new", "dsm_new"):
+        getattr(L, "reffx_" + name).restype = P
+        getattr(lib, "orc_fx_" + name).restype = P
+    # RunContextMap: a small table (constant replacement in the 4-way sets), bytes with runs
+    for fn in (L.reffx_rcm_set, lib.orc_fx_rcm_set):
+        fn.argtypes = [P, C.c_uint32, C.c_int]
+    for fn in (L.reffx_rcm_mix, lib.orc_fx_rcm_mix):
+        fn.argtypes = [P, C.c_int, C.c_int, C.c_int, P]
+    for m, ml in ((1 << 10, 8), (1 << 16, 5)):
+        ref, got = L.reffx_rcm_new(m, ml), lib.orc_fx_rcm_new(m, ml)
+        data = (rng.integers(0, 4, 6000) * 40 + 30).astype(np.uint8)
+        data[1000:1400] = 65
+        o_r, o_g = np.zeros(4, np.int16), np.zeros(4, np.int16)
+        h, y, c0 = 0, 0, 1
+        for n, b in enumerate(data):
+            for bpos in range(8):
+                a = L.reffx_rcm_mix(ref, y, bpos, c0, o_r.ctypes.data)
+                g = lib.orc_fx_rcm_mix(got, y, bpos, c0, o_g.ctypes.data)
+                assert (a, int(o_r[0])) == (g, int(o_g[0])), (m, n, bpos)
+                y = (int(b) >> (7 - bpos)) & 1
+                c0 = (c0 << 1 | y) if bpos < 7 else 1
+            h = (h * 773 + int(b) + 1) & 0xffffffff if n % 5 else int(b)
+            L.reffx_rcm_set(ref, h, int(b))
+            lib.orc_fx_rcm_set(got, h, int(b))
+    # SmallStationaryContextMap: 8 and 1 input bits, the exported slot of the second input is given back
+    for fn in (L.reffx_sscm_set, lib.orc_fx_sscm_set):
+        fn.argtypes = [P, C.c_uint32]
+    for fn in (L.reffx_sscm_mix, lib.orc_fx_sscm_mix):
+        fn.argtypes = [P, C.c_int, C.c_int, P, P, P]
+    for boc, ib in ((11, 8), (8, 1), (16, 8)):
+        ref, got = L.reffx_sscm_new(boc, ib), lib.orc_fx_sscm_new(boc, ib)
+        o_r, o_g, e_r, e_g = np.zeros(4, np.int16), np.zeros(4, np.int16), np.zeros(4, np.float32), np.zeros(4, np.float32)
+        k_r, k_g = C.c_int(0), C.c_int(0)
+        for t, y in enumerate(_bits(rng, 24000, 0.4)):
+            if t % ib == 0:
+                cx = int(rng.integers(0, 1 << 20) % 300)
+                L.reffx_sscm_set(ref, cx)
+                lib.orc_fx_sscm_set(got, cx)
+            rate = t // 8000
+            a = L.reffx_sscm_mix(ref, int(y), rate, o_r.ctypes.data, e_r.ctypes.data, C.byref(k_r))
+            g = lib.orc_fx_sscm_mix(got, int(y), rate, o_g.ctypes.data, e_g.ctypes.data, C.byref(k_g))
+            assert a == g == 2 and k_r.value == k_g.value == 1 and (o_r[:2] == o_g[:2]).all() and e_r[0] == e_g[0], (boc, ib, t)
+    # DirectStateMap: 3 contexts per bit over a 2^m table of states
+    for fn in (L.reffx_dsm_step, lib.orc_fx_dsm_step):
+        fn.argtypes = [P, C.c_int, P, C.c_int, P, P, P]
+    for which in (5, 0):
+        ref, got = L.reffx_dsm_new(12, 3, which), lib.orc_fx_dsm_new(12, 3, which)
+        o_r, o_g, e_r, e_g = np.zeros(8, np.int16), np.zeros(8, np.int16), np.zeros(8, np.float32), np.zeros(8, np.float32)
+        k_r, k_g = C.c_int(0), C.c_int(0)
+        for t, y in enumerate(_bits(rng, 20000, 0.35)):
+            cx = (rng.integers(0, 1 << 16, 3) % np.array([50, 700, 5000])).astype(np.uint32)
+            a = L.reffx_dsm_step(ref, int(y), cx.ctypes.data, 3, o_r.ctypes.data, e_r.ctypes.data, C.byref(k_r))
+            g = lib.orc_fx_dsm_step(got, int(y), cx.ctypes.data, 3, o_g.ctypes.data, e_g.ctypes.data, C.byref(k_g))
+            assert a == g == 6 and k_r.value == k_g.value == 0 and (o_r[:6] == o_g[:6]).all(), (which, t, o_r[:6], o_g[:6])
