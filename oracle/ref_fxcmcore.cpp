@@ -156,4 +156,38 @@ int reffx_dsm_step(void* h, int y, const uint32_t* cx, int n, int16_t* out, floa
   return drain(out, exported, nexported);
 }
 
+// ContextMap (:971-1174, 64-byte buckets of 7), ContextMap1 (:1176-1379, 32-byte buckets of 3), ContextMap2 (:1408-1612,
+// 128-byte buckets of 14). One coded bit: at bpos == 0 the byte's contexts first (set(), or sets() = "skip this slot").
+}  // extern "C"
+template <class CM> static void* cm_new(uint32_t m, int c, int s3, int which_sta, int cs4, int k, int u, int which_st2) {
+  reffx_init();
+  CM* cm = new CM();
+  memset(cm, 0, sizeof(CM));
+  cm->Init(m, c, s3, sta(which_sta), cs4, k, u, which_st2 == 0 ? fx::st2_p0 : which_st2 == 1 ? fx::st2_p1 : fx::st2_p2);
+  return cm;
+}
+template <class CM> static int cm_step(void* h, int y, int bpos, int c0, uint32_t c4, const uint32_t* cx, const uint8_t* skip, int n, int16_t* out,
+                                       float* exported, int* nexported, int* ninputs) {
+  set_bit_state(y, bpos, c0);
+  fx::x.c4 = c4;
+  CM* cm = (CM*)h;
+  if (bpos == 0)
+    for (int i = 0; i < n; ++i) { if (skip[i]) cm->sets(); else cm->set(cx[i]); }
+  const int r = cm->mix();
+  *ninputs = drain(out, exported, nexported);
+  return r;
+}
+extern "C" {
+void* reffx_cm_new(int kind, uint32_t m, int c, int s3, int which_sta, int cs4, int k, int u, int which_st2) {
+  return kind == 0 ? cm_new<fx::ContextMap>(m, c, s3, which_sta, cs4, k, u, which_st2)
+       : kind == 1 ? cm_new<fx::ContextMap1>(m, c, s3, which_sta, cs4, k, u, which_st2)
+                   : cm_new<fx::ContextMap2>(m, c, s3, which_sta, cs4, k, u, which_st2);
+}
+int reffx_cm_step(int kind, void* h, int y, int bpos, int c0, uint32_t c4, const uint32_t* cx, const uint8_t* skip, int n, int16_t* out,
+                  float* exported, int* nexported, int* ninputs) {
+  return kind == 0 ? cm_step<fx::ContextMap>(h, y, bpos, c0, c4, cx, skip, n, out, exported, nexported, ninputs)
+       : kind == 1 ? cm_step<fx::ContextMap1>(h, y, bpos, c0, c4, cx, skip, n, out, exported, nexported, ninputs)
+                   : cm_step<fx::ContextMap2>(h, y, bpos, c0, c4, cx, skip, n, out, exported, nexported, ninputs);
+}
+
 }  // extern "C"

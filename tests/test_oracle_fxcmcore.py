@@ -155,3 +155,62 @@ def test_run_map_sscm_and_direct_state_map_vs_reference():
             a = L.reffx_dsm_step(ref, int(y), cx.ctypes.data, 3, o_r.ctypes.data, e_r.ctypes.data, C.byref(k_r))
             g = lib.orc_fx_dsm_step(got, int(y), cx.ctypes.data, 3, o_g.ctypes.data, e_g.ctypes.data, C.byref(k_g))
             assert a == g == 6 and k_r.value == k_g.value == 0 and (o_r[:6] == o_g[:6]).all(), (which, t, o_r[:6], o_g[:6])
+
+
+@needs_ref
+@pytest.mark.parametrize("kind,m,ncx,cr,cs,s3,sta,s4,keep,u,st2", [
+    (0, 16 * 4096, 7, 4, 34, 35, 1, 8, 0, 1, 1),          # cmC[0]: 7 contexts, STA2, st2_p1
+    (0, 2 * 4096, 2, 6, 36, 30, 1, 13, 0xf0, 0, 0),       # cmC[2]: tiny table (constant replacement), keep flag, no st2 input
+    (0, 32 * 4096, 2, 4, 33, 32, 1, 12, 0, 1, 2),         # cmC[3]: st2_p2
+    (1, 32 * 4096, 2, 3, 35, 35, 4, 12, 0, 0, 0),         # cmC1[0]: 32-byte buckets of 3
+    (1, 16 * 4096, 5, 3, 33, 31, 5, 7, 0, 1, 1),          # cmC1[4]: 5 contexts, STA7
+    (2, 64 * 4096, 3, 3, 28, 43, 4, 9, 0xf0, 1, 1),       # cmC2[0] shape at a small size: 128-byte buckets of 14
+    (2, 8 * 4096, 6, 6, 31, 29, 4, 12, 0xf0, 1, 1),       # cmC2[5] shape, heavy replacement
+    (2, 16 * 4096, 1, 2, 33, 32, 0, 15, 0, 1, 1),         # cmC2[6]: a single context (the `1<C` initial mask quirk), STA1
+])
+def test_context_maps_vs_reference(kind, m, ncx, cr, cs, s3, sta, s4, keep, u, st2):
+    """ContextMap / ContextMap1 / ContextMap2 with the parameter sets the model uses, at table sizes small enough that
+    buckets fill and get replaced: order-1..n byte-history contexts over text with long repeats (run model, deferred
+    creation of the bits 2-7 histories on the second visit), some slots skipped the way the model skips them. Every
+    input, every exported probability and the confidence count, per bit."""
+    from cmix_amd import synth
+    L, lib = _libs()
+    L.reffx_cm_new.restype = P
+    lib.orc_fx_cm_new.restype = P
+    new_sig = [C.c_int, C.c_uint32] + [C.c_int] * 7
+    L.reffx_cm_new.argtypes = new_sig
+    lib.orc_fx_cm_new.argtypes = new_sig
+    L.reffx_cm_step.argtypes = [C.c_int, P, C.c_int, C.c_int, C.c_int, C.c_uint32, P, P, C.c_int, P, P, P, P]
+    lib.orc_fx_cm_step.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_uint32, P, P, C.c_int, P, P, P, P]
+    c = ncx | (cr << 8) | (cs << 16)
+    ref, got = L.reffx_cm_new(kind, m, c, s3, sta, s4, keep, u, st2), lib.orc_fx_cm_new(kind, m, c, s3, sta, s4, keep, u, st2)
+    rng = np.random.default_rng(kind * 100 + ncx)
+    text = synth.enwik_like(3000, 7 + kind)
+    data = np.frombuffer(text[:1500] + text[200:900] + bytes(rng.integers(0, 256, 500, dtype=np.uint8)) + text[:1200] + b"a" * 300 + text[1500:], np.uint8)
+    o_r, o_g, e_r, e_g = np.zeros(64, np.int16), np.zeros(64, np.int16), np.zeros(64, np.float32), np.zeros(64, np.float32)
+    k_r, k_g, n_r, n_g = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+    cx, skip = np.zeros(8, np.uint32), np.zeros(8, np.uint8)
+    y, c0, c4, hist = 0, 1, 0, [0] * 8
+    per = 6 if u == 1 else 5
+    for n in range(len(data)):
+        for bpos in range(8):
+            if bpos == 0:
+                for i in range(ncx):
+                    h = 0
+                    for j in range(i + 1):
+                        h = (h * 0x2F0B4A47 + hist[j] + 1) & 0xffffffff
+                    cx[i] = h
+                    skip[i] = 1 if (i >= 2 and (n // 97 + i) % 5 == 0) else 0
+            a = L.reffx_cm_step(kind, ref, y, bpos, c0, c4, cx.ctypes.data, skip.ctypes.data, ncx, o_r.ctypes.data, e_r.ctypes.data, C.byref(k_r), C.byref(n_r))
+            g = lib.orc_fx_cm_step(got, y, bpos, c0, c4, cx.ctypes.data, skip.ctypes.data, ncx, o_g.ctypes.data, e_g.ctypes.data, C.byref(k_g), C.byref(n_g))
+            cn = ncx if n > 0 or bpos == 0 else ncx
+            assert a == g and n_r.value == n_g.value and k_r.value == k_g.value, (n, bpos, a, g, n_r.value, n_g.value, k_r.value, k_g.value)
+            if n > 0:
+                assert n_r.value == per * cn and k_r.value == (per - 1) * cn, (n, bpos, n_r.value, k_r.value)
+            assert (o_r[:n_r.value] == o_g[:n_r.value]).all(), (n, bpos, o_r[:n_r.value], o_g[:n_r.value])
+            assert (e_r[:k_r.value].view(np.uint32) == e_g[:k_r.value].view(np.uint32)).all(), (n, bpos)
+            y = (int(data[n]) >> (7 - bpos)) & 1
+            c0 = (c0 << 1 | y) if bpos < 7 else 1
+        b = int(data[n])
+        c4 = ((c4 << 8) | b) & 0xffffffff
+        hist = [b] + hist[:7]
