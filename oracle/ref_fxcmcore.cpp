@@ -190,4 +190,19 @@ int reffx_cm_step(int kind, void* h, int y, int bpos, int c0, uint32_t c4, const
                    : cm_step<fx::ContextMap2>(h, y, bpos, c0, c4, cx, skip, n, out, exported, nexported, ninputs);
 }
 
+// the byte history the match models read through buf() / bufr() (:3251-3253, :3411-3416)
+void reffx_buf_reset() { memset(fx::buffer, 0, sizeof fx::buffer); fx::pos = 0; }
+void reffx_buf_push(int byte) { fx::buffer[fx::pos & fx::BMASK] = (fx::U8)byte; fx::pos++; }
+
+// SparseMatchModel (:1742-1829)
+void* reffx_sparsematch_new() { reffx_init(); fx::SparseMatchModel* m = new fx::SparseMatchModel(); m->Init(); return m; }
+int reffx_sparsematch_p(void* h, int y, int bpos, int c0, int16_t* out, int* state4) {
+  set_bit_state(y, bpos, c0);
+  fx::SparseMatchModel* m = (fx::SparseMatchModel*)h;
+  const int r = m->p();
+  drain(out, nullptr, nullptr);
+  state4[0] = (int)m->hashIndex; state4[1] = (int)m->index; state4[2] = m->expectedByte; state4[3] = m->valid;
+  return r;
+}
+
 }  // extern "C"

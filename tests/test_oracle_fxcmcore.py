@@ -214,3 +214,40 @@ def test_context_maps_vs_reference(kind, m, ncx, cr, cs, s3, sta, s4, keep, u, s
         b = int(data[n])
         c4 = ((c4 << 8) | b) & 0xffffffff
         hist = [b] + hist[:7]
+
+
+@needs_ref
+def test_sparse_match_model_vs_reference():
+    """fxcm's SparseMatchModel: text with long repeats, repeats with every other byte changed (the stride-2 finder),
+    random bytes. Match length, the finder that won, the match position, the expected byte and both inputs."""
+    from cmix_amd import synth
+    L, lib = _libs()
+    L.reffx_sparsematch_new.restype = P
+    lib.orc_fx_sparsematch_new.restype = P
+    L.reffx_sparsematch_p.argtypes = [P, C.c_int, C.c_int, C.c_int, P, P]
+    lib.orc_fx_sparsematch_p.argtypes = [P, C.c_int, C.c_int, P, C.c_uint32, C.c_int, P, P]
+    rng = np.random.default_rng(23)
+    text = synth.enwik_like(4000, 29)
+    alt = bytearray(text[300:1300])
+    alt[1::2] = bytes(rng.integers(97, 123, len(alt[1::2]), dtype=np.uint8))
+    data = np.frombuffer(text[:2000] + text[300:1300] + bytes(alt) + bytes(rng.integers(0, 256, 400, dtype=np.uint8)) + text[100:1500] + bytes(alt[:600]), np.uint8)
+    LOG = 16
+    ring = np.zeros(1 << LOG, np.uint8)
+    L.reffx_buf_reset()
+    ref, got = L.reffx_sparsematch_new(), lib.orc_fx_sparsematch_new()
+    o_r, o_g, s_r, s_g = np.zeros(4, np.int16), np.zeros(4, np.int16), np.zeros(4, np.int32), np.zeros(4, np.int32)
+    y, c0 = 0, 1
+    winners, longest = set(), 0
+    for n in range(len(data)):
+        for bpos in range(8):
+            a = L.reffx_sparsematch_p(ref, y, bpos, c0, o_r.ctypes.data, s_r.ctypes.data)
+            g = lib.orc_fx_sparsematch_p(got, bpos, c0, ring.ctypes.data, (1 << LOG) - 1, n, o_g.ctypes.data, s_g.ctypes.data)
+            assert a == g and (s_r == s_g).all() and (o_r[:2] == o_g[:2]).all(), (n, bpos, a, g, s_r, s_g, o_r[:2], o_g[:2])
+            if a:
+                winners.add(int(s_r[0]))
+                longest = max(longest, a)
+            y = (int(data[n]) >> (7 - bpos)) & 1
+            c0 = (c0 << 1 | y) if bpos < 7 else 1
+        L.reffx_buf_push(int(data[n]))
+        ring[n] = data[n]
+    assert longest == 64 and winners >= {0, 2}, (longest, winners)   # the stride-1 and the stride-2 finder both win
