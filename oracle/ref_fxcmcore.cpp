@@ -205,4 +205,55 @@ int reffx_sparsematch_p(void* h, int y, int bpos, int c0, int16_t* out, int* sta
   return r;
 }
 
+// The stemmer's DATA tables (:2417-2653: suffix lists, word lists, per-suffix flag words) written out as C arrays --
+// numbers and strings only -- for scripts/gen_fxcm_tables.py.
+static int emit_strs(char* o, const char* name, const char** a, int n) {
+  int k = sprintf(o, "static const char* const FXW_%s[] = {", name);
+  for (int i = 0; i < n; ++i) k += sprintf(o + k, "%s\"%s\"", i ? "," : "", a[i]);
+  return k + sprintf(o + k, "};\n");
+}
+static int emit_pairs(char* o, const char* name, const char* (*a)[2], int n) {
+  int k = sprintf(o, "static const char* const FXW_%s[][2] = {", name);
+  for (int i = 0; i < n; ++i) k += sprintf(o + k, "%s{\"%s\",\"%s\"}", i ? "," : "", a[i][0], a[i][1]);
+  return k + sprintf(o + k, "};\n");
+}
+static int emit_u32(char* o, const char* name, const fx::U32* a, int n) {
+  int k = sprintf(o, "static const uint32_t FXW_%s[] = {", name);
+  for (int i = 0; i < n; ++i) k += sprintf(o + k, "%s%u", i ? "," : "", a[i]);
+  return k + sprintf(o + k, "};\n");
+}
+int reffx_dump_stem_tables(char* o) {
+  int k = 0;
+#define STRS(x, n) k += emit_strs(o + k, #x, fx::x, n)
+#define U32S(x, n) k += emit_u32(o + k, #x, fx::x, n)
+  STRS(VerbWords1, NUM_VERB); STRS(Numbers, NUM_NUM); STRS(ConjWords, NUM_CONJ_WORDS); STRS(ApoWords, NUM_APO_WORDS); STRS(PrepWords, NUM_PREP_WORDS);
+  STRS(ConAdVerPrepWords, NUM_CAVER_WORDS); STRS(VerbWords, NUM_VERB_WORDS); STRS(MaleWords, NUM_MALE_WORDS); STRS(FemaleWords, NUM_FEMALE_WORDS);
+  STRS(ArticleWords, NUM_ARTICLE_WORDS); STRS(SuffixesStep0, NUM_SUFFIXES_STEP0); STRS(SuffixesStep1b, NUM_SUFFIXES_STEP1b);
+  U32S(TypesStep1b, NUM_SUFFIXES_STEP1b);
+  k += emit_pairs(o + k, "SuffixesStep2", fx::SuffixesStep2, NUM_SUFFIXES_STEP2);
+  U32S(TypesStep2, NUM_SUFFIXES_STEP2); U32S(TypesStep2Suffix, NUM_SUFFIXES_STEP2);
+  k += emit_pairs(o + k, "SuffixesStep3", fx::SuffixesStep3, NUM_SUFFIXES_STEP3);
+  U32S(TypesStep3, NUM_SUFFIXES_STEP3); U32S(TypesStep3Suffix, NUM_SUFFIXES_STEP3);
+  STRS(SuffixesStep4, NUM_SUFFIXES_STEP4); U32S(TypesStep4, NUM_SUFFIXES_STEP4); U32S(TypesStep4Suffix, NUM_SUFFIXES_STEP4);
+  STRS(ExceptionsRegion1, NUM_EXCEPTION_REGION1);
+  k += emit_pairs(o + k, "Exceptions1", fx::Exceptions1, NUM_EXCEPTIONS1);
+  U32S(TypesExceptions1, NUM_EXCEPTIONS1); STRS(Exceptions2, NUM_EXCEPTIONS2); U32S(TypesExceptions2, NUM_EXCEPTIONS2);
+#undef STRS
+#undef U32S
+  return k;
+}
+
+// fxcm's Word + EnglishStemmer (:2302-3216) on one word; letters added the way the model adds them (Word::operator+=)
+int reffx_stem_word(const char* s, int blpos, uint8_t* letters64, int* start_end, uint32_t* hash_type_suffix_prefix) {
+  static fx::EnglishStemmer stemmer;
+  fx::x.blpos = blpos;
+  fx::Word w;
+  for (const char* p = s; *p; ++p) w += *p;
+  const int r = stemmer.Stem(&w);
+  memcpy(letters64, w.Letters, 64);
+  start_end[0] = w.Start; start_end[1] = w.End;
+  hash_type_suffix_prefix[0] = w.Hash; hash_type_suffix_prefix[1] = w.Type; hash_type_suffix_prefix[2] = w.Suffix; hash_type_suffix_prefix[3] = w.Preffix;
+  return r;
+}
+
 }  // extern "C"

@@ -251,3 +251,37 @@ def test_sparse_match_model_vs_reference():
         L.reffx_buf_push(int(data[n]))
         ring[n] = data[n]
     assert longest == 64 and winners >= {0, 2}, (longest, winners)   # the stride-1 and the stride-2 finder both win
+
+
+@needs_ref
+def test_fxcm_english_stemmer_vs_reference():
+    """fxcm's EnglishStemmer: the synthetic corpus' vocabulary crossed with inflection suffixes, prefixes (incl. the
+    "anti-" / "dis-" forms this variant adds), apostrophes on both ends, trailing hyphens, the closed word classes,
+    both sides of the block-position switch of the auxiliary-verb list. Stem letters, Start / End, the stem hash and
+    the three flag words."""
+    from cmix_amd import synth
+    L, lib = _libs()
+    sig = [C.c_char_p, C.c_int, P, P, P]
+    L.reffx_stem_word.argtypes = sig
+    lib.orc_fx_stem_word.argtypes = sig
+    text = synth.enwik_like(400000, 3)
+    base = sorted({w.lower() for w in text.replace(b"\n", b" ").split(b" ") if w.isalpha() and len(w) < 40})[:5000]
+    extra = [b"skis", b"skies", b"dying", b"idly", b"news", b"atlas", b"texas", b"inning", b"proceed", b"zinc", b"here", b"he", b"she", b"the", b"an",
+             b"can't", b"won't", b"ain't", b"isn't", b"o'clock", b"'tis", b"''quoted''", b"'word'", b"non-linear", b"nonsense", b"overestimate",
+             b"underground", b"irregular", b"unnatural", b"anti-hero", b"antimatter", b"dis-agree", b"disagree", b"biggest", b"suggest", b"fullest",
+             b"happiest", b"smallest", b"childhood", b"neighbourhood", b"quizzing", b"generously", b"communal", b"y", b"yy", b"a", b"by", b"say",
+             b"yellowy", b"well-", b"co-", b"because", b"between", b"also", b"thus", b"would", b"been", b"seven", b"million", b"x" * 70]
+    suffixes = [b"", b"s", b"es", b"ed", b"ing", b"ly", b"ness", b"est", b"'s", b"ation", b"ational", b"fully", b"less", b"ize", b"ied", b"ies",
+                b"edly", b"ingly", b"ative", b"ement", b"n't", b"-"]
+    words = extra + [w + sfx for w in base for sfx in suffixes[: 1 + (len(w) % 7) * 3]] + [b"anti-" + w for w in base[:300]] + [b"'" + w + b"'" for w in base[:300]]
+    bufs = [(np.zeros(64, np.uint8), np.zeros(2, np.int32), np.zeros(4, np.uint32)) for _ in range(2)]
+    changed = 0
+    for k, w in enumerate(words):
+        blpos = 451531986 + 5 if k % 11 == 0 else 1000
+        out = []
+        for fn, (let, se, h) in ((L.reffx_stem_word, bufs[0]), (lib.orc_fx_stem_word, bufs[1])):
+            r = fn(w, blpos, let.ctypes.data, se.ctypes.data, h.ctypes.data)
+            out.append((r, let.tobytes(), tuple(se), tuple(h)))
+        assert out[0] == out[1], (w, out[0][0], out[0][2:], out[1][0], out[1][2:])
+        changed += out[0][0]
+    assert changed > len(words) // 4
