@@ -104,6 +104,8 @@ void fx_cm_set(FxCm* x, uint32_t cx) {  /* :1057-1065 */
   x->cxt[i] = cx * 123456791u + i;
   x->cxtMask = (uint16_t)(x->cxtMask * 2);
 }
+uint32_t fx_cm_context(const FxCm* x, int i) { return x->cxt[i]; }
+int fx_cm_skipmask(const FxCm* x) { return x->cxtMask; }
 void fx_cm_skip(FxCm* x) { x->cn++; x->cxtMask = (uint16_t)((x->cxtMask + 1) * 2); }  /* sets() :1066-1070 */
 
 static void skipped(const FxCm* x, FxSink* s) {  /* mix4 :1099-1107 */

@@ -256,4 +256,36 @@ int reffx_stem_word(const char* s, int blpos, uint8_t* letters64, int* start_end
   return r;
 }
 
+void reffx_wrt_tables(uint8_t* out768) { memcpy(out768, wrt_2b, 256); memcpy(out768 + 256, wrt_3b, 256); memcpy(out768 + 512, fx::wrt_4b, 256); }
+
+// The whole model as cmix drives it: fxcmv1::Predictor (:4837-4890) behind FXCM::Perceive / FXCM::Predict (:4893-4911).
+// All of its state is in namespace-level globals: ONE model per loaded copy of this library, and none of the
+// single-block entries above may be used in the same copy.
+void* reffx_model_new() { return new fx::Predictor(); }
+int reffx_model_update(void* h, int bit, int hint_pr, int hint_ex, float* out431) {
+  lstmpr = hint_pr; lstmex = hint_ex;
+  fx::x.y = bit;
+  ((fx::Predictor*)h)->update();
+  for (int i = 0; i < 431; ++i) out431[i] = fx::model_predictions[i];
+  return fx::pr;
+}
+int reffx_model_debug(uint32_t* out) {
+  int n = 0;
+  for (int i = 0; i < 12; i++) out[n++] = (uint32_t)fx::mxA[i].cxt;
+  out[n++] = fx::stream2b; out[n++] = fx::stream3b; out[n++] = fx::stream2bR; out[n++] = fx::stream3bR; out[n++] = fx::word0; out[n++] = (uint32_t)fx::fc;
+  out[n++] = fx::BrFcIdx; out[n++] = fx::FcIdx; out[n++] = (uint32_t)fx::isParagraph; out[n++] = fx::fccxt.context; out[n++] = fx::brcxt.context;
+  out[n++] = fx::qocxt.context; out[n++] = fx::worcxt.fword; out[n++] = fx::worcxt.Word(1); out[n++] = fx::worcxt.Type(1); out[n++] = (uint32_t)fx::ordX;
+  out[n++] = (uint32_t)fx::ordW; out[n++] = fx::isMatch; out[n++] = fx::fails; out[n++] = (uint32_t)fx::col;
+  out[n++] = fx::colcxt.colb(1, 0); out[n++] = fx::colcxt.colb(1, 1); out[n++] = fx::colcxt.nlChar; out[n++] = (uint32_t)fx::colcxt.rows; out[n++] = (uint32_t)fx::colcxt.collen(1);
+  out[n++] = (uint32_t)fx::nl1; out[n++] = (uint32_t)fx::colcxt.abovecellpos; out[n++] = (uint32_t)fx::numlen0;
+  return n;
+}
+// the byte contexts the maps currently hold: cmC[0..5] x 8, cmC1[0..7] x 8, cmC2[0..17] x 8 (unused slots as they are)
+void reffx_model_contexts(uint32_t* out) {
+  int n = 0;
+  for (int k = 0; k < 6; k++) for (int i = 0; i < 8; i++) out[n++] = fx::cmC[k].cxt[i];
+  for (int k = 0; k < 8; k++) for (int i = 0; i < 8; i++) out[n++] = fx::cmC1[k].cxt[i];
+  for (int k = 0; k < 18; k++) for (int i = 0; i < 8; i++) out[n++] = fx::cmC2[k].cxt[i];
+}
+
 }  // extern "C"

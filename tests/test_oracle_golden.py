@@ -57,6 +57,43 @@ def test_paq8_oracle_reproduces_golden_columns(name):
         assert bad.size == 0, (name, t, bad[:8], want[bad[:4]] * 4095, out[bad[:4]] * 4095)
 
 
+@pytest.mark.parametrize("name", ["text_96", "binary_64"])
+def test_fxcm_oracle_reproduces_golden_columns(name):
+    """The assembled fxcm restatement (oracle/fxcm_model.c) against layer-0 columns 3..433 of the traces recorded from
+    the unmodified reference predictor: all 431 values after every coded bit, bit for bit. fxcm reads two hints from
+    the LSTM before every update (reference predictor.cpp:462-465: lstmpr = 1 + 4094 * p of the NEXT bit, lstmex = the
+    likeliest byte of the current interval); they come from the LSTM restatement stepped over the same trace. Needs
+    nothing but the committed fixtures."""
+    import ctypes as C
+    lib = O.lib()
+    lib.orc_fx_model_new.restype = C.c_void_p
+    lib.orc_fx_model_update.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    g = load_golden(name)
+    probs, bits, stream = mg.unpack_probs(g), g["bits"], g["stream"]
+    assert (probs[0, 3:434] == 0.5).all()              # FXCM::Predict() before the first Perceive
+    l = O.Lstm(g["vocab"])
+    h = lib.orc_fx_model_new()
+    out = np.zeros(431, np.float32)
+    t = 0
+    for n in range(len(stream)):
+        for j in range(7, -1, -1):
+            bit = (int(stream[n]) >> j) & 1
+            assert bit == int(bits[t])
+            l.bit_perceive(bit)
+            if j == 0:
+                l.byte_update(g["ppmd_probs"][n + 1], stream[n])
+            if t + 1 == len(bits):
+                break
+            p_next = np.float32(l.bit_predict())
+            assert bits_equal(p_next, probs[t + 1, 2077]).all()
+            lstmpr = int(np.float32(1) + np.float32(4094) * p_next)
+            assert lib.orc_fx_model_update(h, bit, lstmpr, int(l.ex()), out.ctypes.data) >= 0
+            want = np.ascontiguousarray(probs[t + 1, 3:434])
+            bad = np.nonzero(want.view(np.uint32) != out.view(np.uint32))[0]
+            assert bad.size == 0, (name, t, bad[:8], want[bad[:4]] * 4095, out[bad[:4]] * 4095)
+            t += 1
+
+
 def test_stretch_matches_reference_layer0():
     """MixerInput::SetInput: raw probs -> stretch; aux selector derived from them."""
     g = load_golden("text_96")
