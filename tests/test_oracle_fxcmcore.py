@@ -285,3 +285,57 @@ def test_fxcm_english_stemmer_vs_reference():
         assert out[0] == out[1], (w, out[0][0], out[0][2:], out[1][0], out[1][2:])
         changed += out[0][0]
     assert changed > len(words) // 4
+
+
+def _private_fx_copy(tmp_path):
+    """All of fxcm's state is in namespace-level globals: the whole-model runs use their own loaded copy of the
+    reference library so that the single-block tests of this file do not share state with them."""
+    import shutil
+    dst = tmp_path / "libcmixreffxcm_private.so"
+    shutil.copy(R.FXCM_LIB_PATH, dst)
+    L = C.CDLL(str(dst))
+    L.reffx_model_new.restype = P
+    L.reffx_model_update.argtypes = [P, C.c_int, C.c_int, C.c_int, P]
+    L.reffx_model_debug.argtypes = [P]
+    L.reffx_model_contexts.argtypes = [P]
+    return L
+
+
+@needs_ref
+@pytest.mark.parametrize("name", ["wiki", "mixed", "binary"])
+def test_whole_fxcm_model_vs_reference(name, tmp_path):
+    """The assembled oracle (oracle/fxcm_model.c) against the reference's own fxcmv1::Predictor after every bit: all 431
+    values FXCM::Predict() hands to cmix, the model's final probability, the ten mixer selectors and a set of parser
+    registers, and the 256 context-slot hashes the 32 maps hold. Streams: wiki-like text (markup, links, tables,
+    numbers), prose in three languages with abbreviations / quotes / nesting / all 256 byte values, and binary records.
+    The LSTM hints the model reads before each update are seeded random numbers (same on both sides)."""
+    from cmix_amd import synth
+    import test_oracle_paq8core as T
+    L, lib = _private_fx_copy(tmp_path), O.lib()
+    lib.orc_fx_model_new.restype = P
+    lib.orc_fx_model_update.argtypes = [P, C.c_int, C.c_int, C.c_int, P]
+    lib.orc_fx_model_debug.argtypes = [P, P]
+    lib.orc_fx_model_contexts.argtypes = [P, P]
+    rng = np.random.default_rng(77)
+    wiki = (b"{{Infobox|name=Test|value=12}}\n{|\n|-\n| cell one || cell two\n|-\n| 3.14 || [[link|text]]\n|}\n* item one\n* item [[two]], three\n"
+            b"== Heading ==\n'''Bold''' and ''italic'' text. See [http://example.org/page link] &amp; more; x &lt; y.\n\n")
+    data = {"wiki": synth.enwik_like(2500, 51) + wiki * 3 + synth.enwik_like(800, 52),
+            "mixed": bytes(T._text_corpus()[:3500]),
+            "binary": b"".join(int(i).to_bytes(4, "little") + bytes([i % 7, 0, 255, 12]) + b"rec%03d" % (i % 40) for i in range(150)) +
+                      bytes(rng.integers(0, 256, 800, dtype=np.uint8))}[name]
+    ref, got = L.reffx_model_new(), lib.orc_fx_model_new()
+    a, b = np.zeros(431, np.float32), np.zeros(431, np.float32)
+    da, db, ca, cb = np.zeros(48, np.uint32), np.zeros(48, np.uint32), np.zeros(256, np.uint32), np.zeros(256, np.uint32)
+    for n, byte in enumerate(data):
+        for bpos in range(8):
+            y = (byte >> (7 - bpos)) & 1
+            hp, hx = int(rng.integers(1, 4095)), int(rng.integers(0, 256))
+            pr, pg = L.reffx_model_update(ref, y, hp, hx, a.ctypes.data), lib.orc_fx_model_update(got, y, hp, hx, b.ctypes.data)
+            bad = np.nonzero(a.view(np.uint32) != b.view(np.uint32))[0]
+            assert bad.size == 0 and pr == pg, (name, n, bpos, bytes(data[max(0, n - 20):n]), bad[:8], pr, pg)
+            if bpos == 7:
+                k = L.reffx_model_debug(da.ctypes.data)
+                assert k == lib.orc_fx_model_debug(got, db.ctypes.data) and (da == db).all(), (name, n, np.nonzero(da != db)[0])
+                L.reffx_model_contexts(ca.ctypes.data)
+                lib.orc_fx_model_contexts(got, cb.ctypes.data)
+                assert (ca == cb).all(), (name, n, np.nonzero(ca != cb)[0])
