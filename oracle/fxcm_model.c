@@ -9,10 +9,11 @@
  * models and a run map; ten 512-input mixers selected by hand-written contexts, two final mixers). What
  * FXCM::Predict() hands to cmix is every value passed to AddPrediction in call order: 431 columns (layer-0 columns
  * 3..433 of the cmix predictor). Inputs besides the coded bits: the LSTM's per-bit hints lstmpr / lstmex
- * (predictor.cpp:462-465). SCOPE: no WRT dictionary (cmix without a dictionary argument); with one, decoded words
- * enter the parser -- not restated, orc_fx_model_new() takes no dictionary.
+ * (predictor.cpp:462-465) and, optionally, cmix's WRT dictionary: codeword bytes (128..255) are decoded to words that
+ * feed the stemmer and switch the <text> / <math> / <pre> / <nowiki> states.
  * Pinned against the reference's own fxcmv1::Predictor in tests/test_oracle_fxcmcore.py. */
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -230,6 +231,8 @@ typedef struct FxModel {
   int lastArt, isNowiki, isText, isMath, isPre, isParagraph, utf8left, deccode;
   int pr, rate, sscmrate;
   int lstmpr, lstmex;
+  /* WRT dictionary (:352-437): the decoded word of the last codeword and the one before the last ':' */
+  char** dictW; int sizeDict, lastCW; const char *so, *colonstr;
   /* model components :3281-3311 */
   FxStateMap1 smA[3]; FxSscm scmA[7]; FxMixer* mxA[12];
   FxCm *cmC[6], *cmC1[8], *cmC2[18];
@@ -312,10 +315,33 @@ static void set_buf(FxModel* m, int ch) {
     wc_update(&m->worcxt2, m->word0, m->c1, pw->Type, whash);
 }
 
-static void proc_word(FxModel* m) {  /* procWord :3782-3795 without a dictionary: the codeword is dropped, nothing is decoded */
+static const char kEmpty[1] = {0};
+static int decode_codeword(int cw) {  /* decodeCodeWord :389-411: 1 to 3 codeword bytes (128..255) -> dictionary index */
+  enum { d1 = 80, d2 = 32 };
+#define SYM(c) ((c) >= 128 ? (c) - 128 : 0)   /* codeword2sym after dosym() :424-431 */
+  int c = cw & 255, i;
+  if (SYM(c) < d1) return SYM(c);
+  i = d1 * (SYM(c) - d1);
+  c = (cw >> 8) & 255;
+  if (SYM(c) < d1) return i + SYM(c) + d1;
+  i = (i - d1 * d2) * d2;
+  i += d1 * (SYM(c) - d1);
+  c = (cw >> 16) & 255;
+  return i + SYM(c) + 80 * 49;
+#undef SYM
+}
+static void set_buf(FxModel* m, int ch);
+static void proc_word(FxModel* m) {  /* procWord :3782-3795: a finished codeword is decoded and its letters go through the word parser */
   if (m->dcwl > 0) {
+    if (m->dcwl == 2) m->dcw = (m->dcw / 256) + (m->dcw & 255) * 256;
+    if (m->dcwl == 3) m->dcw = ((m->dcw / 256) / 256) + (m->dcw & 0xff00) + (m->dcw & 255) * 256 * 256;
     if (m->dcwl > 3) return;
+    if (m->dictW) {
+      const int j = decode_codeword(m->dcw);
+      if (j > 0 && j < m->sizeDict) { m->lastCW = j; m->so = m->dictW[j]; }
+    }
     m->dcw = m->dcwl = 0;
+    for (const char* p = m->so; *p; ++p) set_buf(m, *p);   /* an undecodable codeword replays the previous word (:3790-3794) */
   }
 }
 #define CM(k) fx_cm_set(m->cmC[k],
@@ -392,11 +418,19 @@ static void byte_update(FxModel* m) {
     const int word3bit = m->words & 7;
     if ((word3bit == 5 && c2 == APOSTROPHE) || (word3bit == 1 && c3 == SQUARECLOSE && c2 == APOSTROPHE) || (word3bit == 1 && (m->numbers & 4) && c2 == APOSTROPHE))
       br_update(&m->qocxt, (int)m->qocxt.cxt);
-    if (c1 > 127) { m->dcw = m->dcw * 256 + c1; m->dcwl++; }   /* no dictionary: decodeCodeWord finds nothing (sizeDict == 0) */
-    else if (m->dcw) { proc_word(m); if (m->blpos < 448131719) m->deccode = 0; }
+    if (c1 > 127) {   /* a codeword byte: try to decode what there is of it */
+      m->dcw = (int)((uint32_t)m->dcw * 256 + (uint32_t)c1); m->dcwl++;
+      if (m->blpos > 6) {
+        int dcw2 = 0;
+        if (m->dcwl == 2) dcw2 = (m->dcw / 256) + (m->dcw & 255) * 256;
+        else if (m->dcwl == 3) dcw2 = ((m->dcw / 256) / 256) + (m->dcw & 0xff00) + (m->dcw & 255) * 256 * 256;
+        const int k = m->dictW ? decode_codeword(dcw2) : 0;
+        if (k > 0 && k < m->sizeDict) m->deccode = k;
+      }
+    } else if (m->dcw) { proc_word(m); if (m->blpos < 448131719) m->deccode = m->lastCW; }
     if (c1 == 10 || c1 == 9 || (c1 > 31 && c1 < 128)) set_buf(m, char_swap(c1));
   } else {
-    if (m->word0) { proc_word(m); if (m->blpos < 448131719) m->deccode = 0; }
+    if (m->word0) { proc_word(m); if (m->blpos < 448131719) m->deccode = m->lastCW; }
     else m->deccode = (int)(0x10000 + (m->stream2b & 0xffff));
     if (c1 == 10 || c1 == 9 || (c1 > 31 && c1 < 128)) set_buf(m, char_swap(c1));
     if (c1 >= '0' && c1 <= '9') {   /* numbers: (number), (number.number), (number,number) */
@@ -446,9 +480,20 @@ static void byte_update(FxModel* m) {
       wc_set(wc, (int)(sb >> 8), (int)ca);
       wc_update(wc, w, c1, t, w);
     }
-    /* <text>, <nowiki>, <math>, <pre>, </page> boundaries are recognised through the decoded dictionary word `so`; without
-     * a dictionary it is always the empty string, so only the comparisons that do not involve it survive (:4028-4045) */
-    if (m->isMath && c1 == '/' && c2 == LESSTHAN && c3 == GREATERTHAN && BUFFER1(4) == 'h') m->isMath = 0;
+    /* <text>, <nowiki>, <math>, <pre>, </page> boundaries, recognised through the last decoded dictionary word (:4028-4045) */
+#define SO_IS(str) (strcmp(m->so, str) == 0)
+    const int lt = char_swap(LESSTHAN);
+    if (BUFFER1(6) == lt && BUFFER1(5) == 't' && !m->isText && c1 == SPACE && SO_IS("text")) { m->isText = 1; m->so = kEmpty; }
+    if (BUFFER1(8) == lt && !m->isNowiki && SO_IS("nowiki")) m->isNowiki = 1;
+    else if (BUFFER1(9) == '/' && c1 == GREATERTHAN && m->isNowiki && SO_IS("nowiki")) { m->isNowiki = m->isPre = 0; m->so = kEmpty; }
+    if (m->isMath && ((c1 == SPACE && col_lastfc(&m->colcxt, 0) != COLON) || c1 == ',') && c2 == GREATERTHAN && SO_IS("math")) { m->isMath = 0; m->so = kEmpty; }
+    if (m->isMath && c1 == '/' && c2 == LESSTHAN && c3 == GREATERTHAN && BUFFER1(4) == 'h') { m->isMath = 0; m->so = kEmpty; }
+    if (!m->isNowiki && BUFFER1(6) == lt && BUFFER1(5) == 'm' && !m->isMath && c1 != '.' && BUFFER1(7) != '&' && BUFFER1(8) != '&' && SO_IS("math")) m->isMath = 1;
+    else if (BUFFER1(6) == '/' && (c1 == GREATERTHAN || c1 == '&') && m->isMath && SO_IS("math")) { m->isMath = 0; m->so = kEmpty; }
+    if (BUFFER1(5) == lt && c1 == GREATERTHAN && BUFFER1(4) == 'p' && !m->isPre && SO_IS("pre")) { m->isPre = 1; m->so = kEmpty; }
+    else if (BUFFER1(5) == '/' && c1 == GREATERTHAN && BUFFER1(4) == 'p' && SO_IS("pre")) { m->isPre = 0; m->so = kEmpty; }
+    if (BUFFER1(6) == '/' && c1 == GREATERTHAN && BUFFER1(5) == 'p' && SO_IS("page")) m->isPre = m->isMath = m->isNowiki = 0;
+#undef SO_IS
 
     m->wp[m->word0 & 0xffff] = m->pos;
     m->word0 = h = 0;
@@ -543,8 +588,10 @@ static void byte_update(FxModel* m) {
     if ((m->fccxt.cxt == COLON || m->fccxt.cxt == HTLINK) && c1 == SQUARECLOSE) while (m->fccxt.cxt == COLON || m->fccxt.cxt == HTLINK) br_update(&m->fccxt, LF);
     if (c1 < 128) br_update(&m->fccxt, c1);
   }
-  /* colonstr is the decoded dictionary word before ':' -- empty without a dictionary, so never "image" / "category" / "wikipedia" */
-  if (c1 == SPACE && m->fccxt.cxt == COLON && col_lastfc(cc, 0) != COLON && cc->nlChar != WIKITABLE) while (m->fccxt.cxt == COLON) br_update(&m->fccxt, LF);
+  if (c1 == COLON && (m->words & 2) == 2) m->colonstr = m->so;   /* the decoded dictionary word before ':' */
+  if (c1 == SPACE && m->fccxt.cxt == COLON && col_lastfc(cc, 0) != COLON && cc->nlChar != WIKITABLE && strcmp(m->colonstr, "image") != 0)
+    while (m->fccxt.cxt == COLON) br_update(&m->fccxt, LF);
+  if (c1 == COLON && (strcmp(m->colonstr, "category") == 0 || strcmp(m->colonstr, "wikipedia") == 0)) { br_update(&m->fccxt, LF); wc_remove(&m->worcxt); }
   if (c1 == SPACE && c2 == LESSTHAN) br_update(&m->fccxt, GREATERTHAN);
   if (m->fccxt.cxt == COLON && c2 == '/' && c1 == '/') { br_update(&m->fccxt, LF); br_update(&m->fccxt, HTLINK); }
   if (col_lastfc(cc, 0) == SQUAREOPEN && c1 == SPACE && m->isParagraph == 0 && (c2 == SQUARECLOSE || c3 == SQUARECLOSE)) {
@@ -961,7 +1008,28 @@ int orc_fx_model_update(FxModel* m, int y, int lstmpr, int lstmex, float* out431
   return nexp <= FX_OUTPUTS ? pr : -1;
 }
 
-FxModel* orc_fx_model_new(void) {   /* Predictor::Predictor + PredictorInit :4845-4876, :3313-3405 */
+static void load_dictionary(FxModel* m, const char* path) {  /* dosym + loaddict + wfgets :352-381, :413-433: one word per line, index = line number */
+  FILE* f = fopen(path, "rb");
+  if (!f) return;
+  m->dictW = (char**)calloc(44516, sizeof(char*));
+  char* line = (char*)malloc(8192 * 8);
+  int n = 0, c;
+  for (;;) {
+    int i = 0;
+    while (i < 8192 * 8 - 1 && (c = getc(f)) != EOF) { line[i++] = (char)c; if (c == '\n') { line[i - 1] = 0; break; } }
+    line[i] = 0;
+    if (i == 0 || n >= 44516) break;
+    m->dictW[n] = (char*)calloc((size_t)i + 1, 1);
+    memcpy(m->dictW[n], line, (size_t)i);
+    n++;
+  }
+  free(line);
+  fclose(f);
+  m->sizeDict = n;
+}
+FxModel* orc_fx_model_new_dict(const char* dictionary_path);
+FxModel* orc_fx_model_new(void) { return orc_fx_model_new_dict(NULL); }
+FxModel* orc_fx_model_new_dict(const char* dictionary_path) {   /* Predictor::Predictor + PredictorInit :4845-4876, :3313-3405 */
   static const uint32_t c_r[27] = {3, 4, 6, 4, 6, 6, 2, 3, 3, 3, 6, 4, 3, 4, 5, 6, 2, 6, 4, 4, 4, 4, 4, 4, 4, 4, 4};
   static const uint32_t c_s[27] = {28, 26, 28, 31, 34, 31, 33, 33, 35, 35, 29, 32, 33, 34, 30, 36, 31, 32, 32, 32, 32, 32, 33, 32, 32, 32, 32};
   static const uint32_t c_s3[27] = {43, 33, 34, 28, 34, 29, 32, 33, 37, 35, 33, 28, 31, 35, 28, 30, 33, 34, 32, 32, 32, 32, 32, 32, 32, 32, 32};
@@ -1024,6 +1092,8 @@ FxModel* orc_fx_model_new(void) {   /* Predictor::Predictor + PredictorInit :484
   m->colcxt.nlChar = LF; m->colcxt.limit = 31;
   m->smatch = orc_fx_sparsematch_new();
   m->cWord = 0; m->pWord = 3;
+  m->so = m->colonstr = kEmpty;
+  if (dictionary_path) load_dictionary(m, dictionary_path);
   for (int i = 0; i < FX_OUTPUTS; i++) m->in1.exported[i] = 0.5f;   /* model_predictions(0.5f, num_models) :94 */
   return m;
 }
@@ -1037,6 +1107,7 @@ int orc_fx_model_debug(const FxModel* m, uint32_t* out) {
   out[n++] = (uint32_t)m->ordW; out[n++] = m->isMatch; out[n++] = m->fails; out[n++] = (uint32_t)m->col;
   out[n++] = (uint32_t)col_b(&m->colcxt, 1, 0); out[n++] = (uint32_t)col_b(&m->colcxt, 1, 1); out[n++] = m->colcxt.nlChar; out[n++] = (uint32_t)m->colcxt.rows;
   out[n++] = (uint32_t)col_len(&m->colcxt, 1, 0); out[n++] = (uint32_t)m->nl1; out[n++] = (uint32_t)m->colcxt.abovecellpos; out[n++] = m->numlen0;
+  out[n++] = (uint32_t)(m->isText | m->isMath << 1 | m->isPre << 2 | m->isNowiki << 3); out[n++] = (uint32_t)m->deccode; out[n++] = (uint32_t)m->lastCW;
   return n;
 }
 uint32_t fx_cm_context(const FxCm* x, int i);

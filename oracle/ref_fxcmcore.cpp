@@ -262,6 +262,7 @@ void reffx_wrt_tables(uint8_t* out768) { memcpy(out768, wrt_2b, 256); memcpy(out
 // All of its state is in namespace-level globals: ONE model per loaded copy of this library, and none of the
 // single-block entries above may be used in the same copy.
 void* reffx_model_new() { return new fx::Predictor(); }
+void* reffx_model_new_dict(const char* path) { dictionary_path = strdup(path); return new fx::Predictor(); }  // cmix's WRT dictionary (runner.cpp:290)
 int reffx_model_update(void* h, int bit, int hint_pr, int hint_ex, float* out431) {
   lstmpr = hint_pr; lstmex = hint_ex;
   fx::x.y = bit;
@@ -278,6 +279,7 @@ int reffx_model_debug(uint32_t* out) {
   out[n++] = (uint32_t)fx::ordW; out[n++] = fx::isMatch; out[n++] = fx::fails; out[n++] = (uint32_t)fx::col;
   out[n++] = fx::colcxt.colb(1, 0); out[n++] = fx::colcxt.colb(1, 1); out[n++] = fx::colcxt.nlChar; out[n++] = (uint32_t)fx::colcxt.rows; out[n++] = (uint32_t)fx::colcxt.collen(1);
   out[n++] = (uint32_t)fx::nl1; out[n++] = (uint32_t)fx::colcxt.abovecellpos; out[n++] = (uint32_t)fx::numlen0;
+  out[n++] = (uint32_t)(fx::isText | fx::isMath << 1 | fx::isPre << 2 | fx::isNowiki << 3); out[n++] = (uint32_t)fx::deccode; out[n++] = (uint32_t)fx::lastCW;
   return n;
 }
 // the byte contexts the maps currently hold: cmC[0..5] x 8, cmC1[0..7] x 8, cmC2[0..17] x 8 (unused slots as they are)

@@ -339,3 +339,90 @@ def test_whole_fxcm_model_vs_reference(name, tmp_path):
                 L.reffx_model_contexts(ca.ctypes.data)
                 lib.orc_fx_model_contexts(got, cb.ctypes.data)
                 assert (ca == cb).all(), (name, n, np.nonzero(ca != cb)[0])
+
+
+DICTIONARY = "/root/reference/dictionary/english.dic"
+
+
+def _wrt_codewords():
+    """Inverse of fxcm's decodeCodeWord (reference src/models/fxcmv1.cpp:389-411): dictionary index -> the 1..3 codeword
+    bytes (128..255) cmix's WRT preprocessor writes for it."""
+    inv = {}
+    for s0 in range(128):
+        if s0 < 80:
+            inv[s0] = bytes([128 + s0])
+            continue
+        for s1 in range(128):
+            i = 80 * (s0 - 80)
+            if s1 < 80:
+                inv.setdefault(i + s1 + 80, bytes([128 + s0, 128 + s1]))
+                continue
+            j = (i - 80 * 32) * 32 + 80 * (s1 - 80)
+            for s2 in range(128):
+                if j + s2 + 80 * 49 > 0:
+                    inv.setdefault(j + s2 + 80 * 49, bytes([128 + s0, 128 + s1, 128 + s2]))
+    return inv
+
+
+@needs_ref
+@pytest.mark.skipif(not __import__("os").path.exists(DICTIONARY), reason="the reference's dictionary is not on this box")
+def test_whole_fxcm_model_with_wrt_dictionary_vs_reference(tmp_path):
+    """cmix -c <dictionary>: the stream carries WRT codewords (bytes 128..255) that fxcm decodes through the
+    dictionary; the decoded words feed the stemmer and the <text> / <math> / <pre> / <nowiki> / </page> detectors, the
+    dictionary index selects a mixer weight set. A wiki page written the way the preprocessor writes it (swapped
+    punctuation, codewords for dictionary words, literal letters otherwise), plus undecodable and over-long codewords."""
+    L, lib = _private_fx_copy(tmp_path), O.lib()
+    L.reffx_model_new_dict.restype = P
+    L.reffx_model_new_dict.argtypes = [C.c_char_p]
+    lib.orc_fx_model_new_dict.restype = P
+    lib.orc_fx_model_new_dict.argtypes = [C.c_char_p]
+    lib.orc_fx_model_update.argtypes = [P, C.c_int, C.c_int, C.c_int, P]
+    lib.orc_fx_model_debug.argtypes = [P, P]
+    lib.orc_fx_model_contexts.argtypes = [P, P]
+    words = [w.rstrip(b"\n") for w in open(DICTIONARY, "rb").read().split(b"\n")]
+    index = {w: i for i, w in enumerate(words) if w}
+    inv = _wrt_codewords()
+    rng = np.random.default_rng(5)
+
+    def enc(text):
+        """lower-case letters runs -> codeword when in the dictionary; punctuation swapped the way cmix swaps it"""
+        import re
+        out = bytearray()
+        for tok in re.findall(rb"[a-z]+|[^a-z]", text):
+            if tok.isalpha() and tok in index and index[tok] in inv and rng.random() < 0.85:
+                out += inv[index[tok]]
+            else:
+                for c in tok:
+                    if ord("{") <= c < 127:
+                        c += ord("P") - ord("{")
+                    elif ord(":") <= c <= ord("?"):
+                        c ^= 0x70
+                    out.append(c)
+        return bytes(out)
+
+    page = (b"<page> <title>the first page</title> <text xml:space=\"preserve\">'''the page''' is about the history of science and the people.\n"
+            b"it has <math>a + b</math> and <nowiki>some [[raw]] text</nowiki> and <pre>fixed\n  text</pre> here. see [[category:history]] "
+            b"[[image:people.png|the caption]] [[wikipedia:about]] and: more words, seven hundred million times.\n\n* one item\n* another item\n"
+            b"</text> </page>\n")
+    data = enc(page) * 4 + bytes([0xff, 0xfe, 0xfd, 0xfc, 0xfb]) + enc(b" after a long codeword ") + bytes([200, 255]) + enc(b" end of the text.\n" * 20)
+    assert max(data) > 127
+    ref, got = L.reffx_model_new_dict(DICTIONARY.encode()), lib.orc_fx_model_new_dict(DICTIONARY.encode())
+    a, b = np.zeros(431, np.float32), np.zeros(431, np.float32)
+    da, db, ca, cb = np.zeros(48, np.uint32), np.zeros(48, np.uint32), np.zeros(256, np.uint32), np.zeros(256, np.uint32)
+    flags, decoded = 0, set()
+    for n, byte in enumerate(data):
+        for bpos in range(8):
+            y = (byte >> (7 - bpos)) & 1
+            hp, hx = int(rng.integers(1, 4095)), int(rng.integers(0, 256))
+            pr, pg = L.reffx_model_update(ref, y, hp, hx, a.ctypes.data), lib.orc_fx_model_update(got, y, hp, hx, b.ctypes.data)
+            bad = np.nonzero(a.view(np.uint32) != b.view(np.uint32))[0]
+            assert bad.size == 0 and pr == pg, (n, bpos, bytes(data[max(0, n - 20):n]), bad[:8], pr, pg)
+        k = L.reffx_model_debug(da.ctypes.data)
+        flags |= int(da[k - 3])
+        decoded.add(int(da[k - 1]))
+        lib.orc_fx_model_debug(got, db.ctypes.data)
+        assert (da == db).all(), (n, bytes(data[max(0, n - 20):n + 1]), np.nonzero(da != db)[0], da[np.nonzero(da != db)[0]], db[np.nonzero(da != db)[0]])
+        L.reffx_model_contexts(ca.ctypes.data)
+        lib.orc_fx_model_contexts(got, cb.ctypes.data)
+        assert (ca == cb).all(), (n, bytes(data[max(0, n - 20):n + 1]), np.nonzero(ca != cb)[0])
+    assert flags & 7 == 7 and len(decoded) > 20, (flags, len(decoded))   # <text>, <math>, <pre> states entered ("nowiki" is not a dictionary word); many words decoded
