@@ -416,6 +416,11 @@ int refp8_en_stem_word(const char* s, uint8_t* letters64, int* start_end, uint64
   return refp8_stem_word(1, s, letters64, start_end, type_lang, hash4_after_stem, hash4_gethashes);
 }
 
+// the word-level globals are process-wide and other harness entries (refp8_sparse_step) set them as inputs
+void refp8_word_globals_reset() {
+  paq8::spaces = paq8::spacecount = paq8::words = paq8::wordcount = paq8::wordlen = paq8::wordlen1 = 0;
+  paq8::frstchar = 0; paq8::spafdo = 0; paq8::col = 0;
+}
 // wordModel (:3873-4105) over the reference's buffer. g_out receives the word-level globals it maintains for other
 // models: spaces, spacecount, words, wordcount, wordlen, wordlen1, frstchar, spafdo, col.
 int refp8_word_step(int level, int y_prev, int bpos, int c0, uint32_t c4, uint32_t f4, uint32_t b3, int blpos, int16_t* out,

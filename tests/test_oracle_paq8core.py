@@ -749,6 +749,7 @@ def test_word_model_vs_reference():
     L.refp8_rnd_reset()
     lib.orc_p8_rnd_reset()
     L.refp8_buf_reset(LOG)
+    L.refp8_word_globals_reset()  # process-wide; test_sparse_models_vs_reference leaves its inputs in them
     ring = np.zeros(1 << LOG, np.uint8)
     got = lib.orc_p8_word_new(level)
     o_ref, o_got = np.zeros(512, np.int16), np.zeros(512, np.int16)
