@@ -29,7 +29,8 @@
 #define FX_HD inline
 #endif
 
-enum { FX_THREADS = 256, FX_BMASK = 0xffffff, FX_NONE = 0xffffffffu,
+#define FX_NONE 0xffffffffu
+enum { FX_THREADS = 256, FX_BMASK = 0xffffff,
        FX_U_SSCM = 31, FX_U_MATCH = 38, FX_U_RCM = 39, FX_U_LSTM = 40, FX_U_MIX10 = 41, FX_U_MIX11 = 42, FX_U_APM = 43, FX_UNITS = 49,
        FX_TAB_RC1 = 0, FX_TAB_ST1 = 512, FX_TAB_ST2 = 512 + 4096, FX_TAB_ST32 = 512 + 8192, FX_TAB_ST8 = 512 + 8192 + 256, FX_TAB_LEN = 512 + 8192 + 512 };
 
@@ -49,6 +50,7 @@ struct FxMtf { int root, index, prev[4], next[4]; };
 struct FxDev {                         // everything a stream owns on the device (global memory)
   FxMapDev maps[FX_NMAPS];
   const int16_t *squash, *stretch;     // squash[d + 2047], stretch[p]
+  const uint8_t* wrt;                  // byte -> 2-bit class [256], 3-bit class [256] of cmix's WRT-swapped alphabet
   uint16_t* sscm_data[FX_NSSCM]; int sscm_mask[FX_NSSCM], sscm_ctx[FX_NSSCM], sscm_B[FX_NSSCM], sscm_bcount[FX_NSSCM], sscm_cp[FX_NSSCM];
   uint32_t* sm1_t[3]; int sm1_mask[3], sm1_cxt[3];
   uint8_t* rcm_t; uint32_t rcm_n, rcm_cp; int16_t rcm_rc[512];
@@ -541,7 +543,7 @@ FX_HD void fxd_phase2(FxDev* d, FxShared* sh, const FxBit& u, int tid) {
   }
   const uint32_t s2 = r->s2, s3 = r->s3, s3R = r->s3R, BrFc = r->BrFc, words = r->words, FcIdx = r->FcIdx, isPar = r->isPar;
   const uint32_t isMatch = (uint32_t)sh->isMatch;
-  const uint8_t* w2b = FX_WRT_2B_DEV(d);
+  const uint8_t* w2b = d->wrt;
   const uint8_t* w3b = w2b + 256;
   int* cx = sh->mx_cxt;
   int c;
@@ -641,6 +643,7 @@ FX_HD void fxd_phase5(FxDev* d, FxShared* sh, const FxBit& u, int tid) {
   else pr = (pt * 4 + pu * 5 + pv * 12 + pz * 11 + 31) >> 5;
   EXPV(pr);
 #undef EXPV
+  while (ex < u.orow + FX_OUTPUTS) *ex++ = 0.5f;   // slots no AddPrediction reaches keep the constructor's 0.5 (:94)
   sh->pr = pr;
   sh->parity ^= 1;
 }

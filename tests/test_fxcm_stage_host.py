@@ -1,0 +1,160 @@
+"""The fxcm stage without a GPU: the product's host text parser (cmix_amd/csrc/fxcm_parser_host.cpp) and the BODY of
+cmx_fxcm_chunk_kernel (cmix_amd/csrc/fxcm_dev.h: five barrier-separated phases per bit) run through
+tests/host/fxcm_emul.cpp -- a loop over thread ids per phase, in shuffled order -- against the oracle's monolithic
+restatement of the model (oracle/fxcm_model.c, itself pinned against the reference's fxcmv1::Predictor) and against
+layer-0 columns 3..433 of the golden traces recorded from the unmodified reference predictor. All 431 values per bit,
+bit for bit. The same comparison runs on the device in tests/test_zgpu_fxcm_stage.py."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "tests", "host", "libfxcmemul.so")
+SRC = [os.path.join(ROOT, "tests", "host", "fxcm_emul.cpp"), os.path.join(ROOT, "cmix_amd", "csrc", "fxcm_parser_host.cpp")]
+DEPS = SRC + [os.path.join(ROOT, "cmix_amd", "csrc", f) for f in ("fxcm_dev.h", "fxcm_build.h", "fxcm_rec.h")]
+
+
+def emul():
+    if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in DEPS):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-o", SO] + SRC)
+    L = C.CDLL(SO)
+    L.fxe_create.restype = C.c_void_p
+    L.fxe_create.argtypes = [C.c_char_p, C.c_uint32]
+    L.fxe_destroy.argtypes = [C.c_void_p]
+    L.fxe_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long]
+    return L
+
+
+def oracle_rows(data, lstmpr, lstmex, dictionary=None):
+    """rows[q] = FXCM::Predict() before bit q is coded (row 0 = the constructor's 0.5)."""
+    lib = O.lib()
+    lib.orc_fx_model_new.restype = C.c_void_p
+    lib.orc_fx_model_new_dict.restype = C.c_void_p
+    lib.orc_fx_model_new_dict.argtypes = [C.c_char_p]
+    lib.orc_fx_model_update.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    h = lib.orc_fx_model_new_dict(dictionary) if dictionary else lib.orc_fx_model_new()
+    rows = np.full((8 * len(data), 431), 0.5, np.float32)
+    out = np.zeros(431, np.float32)
+    q = 0
+    for b in data:
+        for j in range(7, -1, -1):
+            assert lib.orc_fx_model_update(h, (int(b) >> j) & 1, int(lstmpr[q]), int(lstmex[q]), out.ctypes.data) >= 0
+            if q + 1 < len(rows):
+                rows[q + 1] = out
+            q += 1
+    return rows
+
+
+def run_emul(L, data, lstmpr, lstmex, chunks, seed=12345, dictionary=None):
+    h = L.fxe_create(dictionary, seed)
+    data = np.ascontiguousarray(data, np.uint8)
+    out = np.zeros((8 * len(data), 431), np.float32)
+    pos = 0
+    for n in chunks:
+        n = min(n, len(data) - pos)
+        if n <= 0:
+            break
+        pr = np.ascontiguousarray(lstmpr[8 * pos:8 * (pos + n)], np.int16)
+        ex = np.ascontiguousarray(lstmex[8 * pos:8 * (pos + n)], np.uint8)
+        o = out[8 * pos:8 * (pos + n)]
+        assert L.fxe_run(h, data[pos:pos + n].ctypes.data, n, pr.ctypes.data, ex.ctypes.data, o.ctypes.data, 431) == 0
+        pos += n
+    L.fxe_destroy(h)
+    return out[:8 * pos]
+
+
+def hints(nbits, seed):
+    r = np.random.default_rng(seed)
+    return r.integers(1, 4096, nbits).astype(np.int16), r.integers(0, 256, nbits).astype(np.uint8)
+
+
+def compare(got, want, what):
+    bad = np.argwhere(got.view(np.uint32) != want[:len(got)].view(np.uint32))
+    assert bad.size == 0, (what, "first mismatch (bit, column):", bad[0], got[tuple(bad[0])] * 4095, want[tuple(bad[0])] * 4095, "columns:", sorted(set(bad[:, 1]))[:12])
+
+
+def test_text_vs_oracle_ragged_chunks():
+    from cmix_amd import synth
+    L = emul()
+    data = np.frombuffer(synth.enwik_like(6000, 31), np.uint8)
+    pr, ex = hints(8 * len(data), 7)
+    want = oracle_rows(data, pr, ex)
+    got = run_emul(L, data, pr, ex, [1, 1, 7, 100, 1000, 3, 2000, 4000])
+    compare(got, want, "enwik-like text")
+
+
+@pytest.mark.parametrize("flavour", ["binary", "runs", "markup"])
+def test_other_data_vs_oracle(flavour):
+    L = emul()
+    r = np.random.default_rng(5)
+    if flavour == "binary":
+        data = r.integers(0, 256, 3000).astype(np.uint8)
+    elif flavour == "runs":
+        data = np.concatenate([np.full(int(n), int(v), np.uint8) for n, v in zip(r.integers(1, 40, 150), r.integers(0, 256, 150))])[:3000]
+    else:   # cmix's WRT-swapped wiki markup: tables, links, headers, entities, escaped UTF-8, numbers
+        parts = [b"PPQ class=wikitable\nQ-\nQ cell one QQ cell two\nQ-\nQ 12.5 QQ 1,000\nQR\n", b"NN Heading NN\n@the quick [[brown fox]] jumps over the (lazy) dog. ",
+                 b"''italic'' and &Lref&N http://example.org/x J y\n", b"* item one\n* item two\n\n", b"\x0c\xc3\xa9t\x0c\xc3\xa9 1999 2001, 3.14 ", b"@she said 'hello' to him; it was theirs.\n"]
+        data = np.frombuffer(b"".join(parts[int(i)] for i in r.integers(0, len(parts), 80)), np.uint8)[:3500]
+    pr, ex = hints(8 * len(data), 11)
+    want = oracle_rows(data, pr, ex)
+    got = run_emul(L, data, pr, ex, [512] * 8, seed=99)
+    compare(got, want, flavour)
+
+
+def test_dictionary_mode_vs_oracle():
+    """WRT codewords (bytes >= 128) decoded through cmix's dictionary feed the stemmer; the dictionary travels with the
+    fixtures as a small stand-in (one word per line)."""
+    L = emul()
+    import tempfile
+    words = ["the", "of", "and", "text", "math", "page", "category", "image", "running", "houses", "quickly", "nowiki", "pre", "wikipedia"] + ["w%dx" % i for i in range(200)]
+    with tempfile.NamedTemporaryFile("w", suffix=".dic", delete=False) as f:
+        f.write("\n".join(words) + "\n")
+        path = f.name.encode()
+    r = np.random.default_rng(3)
+    toks = []
+    for _ in range(700):
+        k = int(r.integers(0, 3))
+        if k == 0:
+            toks.append(bytes([128 + int(r.integers(0, 80))]))
+        elif k == 1:
+            toks.append(bytes([128 + 80 + int(r.integers(0, 2)), 128 + int(r.integers(0, 80))]))
+        else:
+            toks.append([b"the", b"Ltext N", b"J", b".", b",", b"dog", b"@"][int(r.integers(0, 7))])
+        toks.append(b" " if r.random() < 0.8 else b"\n")
+    data = np.frombuffer(b"".join(toks), np.uint8)[:2500]
+    pr, ex = hints(8 * len(data), 13)
+    want = oracle_rows(data, pr, ex, dictionary=path)
+    got = run_emul(L, data, pr, ex, [300] * 10, dictionary=path)
+    os.unlink(path.decode())
+    compare(got, want, "dictionary mode")
+
+
+@pytest.mark.parametrize("name", ["text_96"])
+def test_golden_columns(name):
+    """Columns 3..433 of a trace of the unmodified reference predictor, with the hints the reference's LSTM produced
+    (recomputed by the LSTM restatement): fixtures only."""
+    import make_golden as mg
+    g = load_golden(name)
+    probs, bits, stream = mg.unpack_probs(g), g["bits"], g["stream"]
+    l = O.Lstm(g["vocab"])
+    pr, ex = np.zeros(len(bits), np.int16), np.zeros(len(bits), np.uint8)
+    t = 0
+    for n in range(len(stream)):
+        for j in range(7, -1, -1):
+            l.bit_perceive((int(stream[n]) >> j) & 1)
+            if j == 0:
+                l.byte_update(g["ppmd_probs"][n + 1], stream[n])
+            if t + 1 < len(bits):
+                pr[t] = int(np.float32(1) + np.float32(4094) * np.float32(l.bit_predict()))
+                ex[t] = int(l.ex())
+            else:
+                pr[t] = 2048
+            t += 1
+    got = run_emul(emul(), np.asarray(stream, np.uint8), pr, ex, [len(stream)])
+    compare(got, np.ascontiguousarray(probs[:, 3:434]), name)
