@@ -1,0 +1,165 @@
+// fxcm_stage.hip -- the fxcm stage of the pipeline: layer-0 columns 3..433 of the cmix predictor, i.e. the 431 values
+// FXCM::Predict() returns per bit (reference src/models/fxcm.cpp, src/models/fxcmv1.cpp; wired at predictor.cpp:98-99,
+// :462-468). Two halves:
+//   * host:   the text parser (fxcm_parser_host.cpp) turns the chunk's bytes into one FxByteRec per byte on the calling
+//             thread, written to page-locked memory and copied to the device on the stage's stream;
+//   * device: cmx_fxcm_chunk_kernel, ONE persistent workgroup per stream, walks the chunk's bits through the learned
+//             tables (fxcm_dev.h: the phases, argued there). State: ~4.4 GB of HBM per stream (3.7 GB context-map
+//             buckets, 0.3 GB mixer rows, 60 MB APM cells, 70 MB match / run tables).
+// Bound: latency (a map lane walks up to 7 dependent bucket probes per bit); the kernel's HBM traffic is ~0.2 MB per
+// input byte algorithmic (SURVEY.md 8d iii + iv). Parity: tests/test_fxcm_stage_host.py runs this kernel's body on the
+// host against the oracle; tests/test_zgpu_fxcm_stage.py runs the kernel.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/cmix_amd.h"
+#include "fxcm_build.h"
+
+void cmx_set_err(const std::string& s);  // cmx_api.hip
+extern "C" int cmx_device_count(void);
+
+__global__ __launch_bounds__(FX_THREADS) void cmx_fxcm_chunk_kernel(FxDev* d, const uint8_t* bytes, const FxByteRec* recs, const int16_t* lstmpr,
+                                                                    const uint8_t* lstmex, float* out, long ostride, int n) {
+  __shared__ FxShared sh;
+  const int tid = threadIdx.x;
+  const int nbits = 8 * n, blpos0 = d->blpos, lastbyte0 = d->lastbyte, have0 = d->have_rec;
+  fxd_load_shared(d, &sh, tid);
+  for (int i = tid; i < FX_OUTPUTS; i += FX_THREADS) out[i] = d->pending[i];   // row 0: what the previous chunk's last update left
+  __syncthreads();
+  for (int q = 0; q < nbits; q++) {
+    const FxBit u = fxd_bit(d, bytes, recs, lstmpr, lstmex, out, ostride, nbits, q, blpos0, lastbyte0, have0);
+    fxd_phase1(d, &sh, u, tid);
+    __syncthreads();
+    fxd_phase2(d, &sh, u, tid);
+    __syncthreads();
+    fxd_phase3(d, &sh, u, tid);
+    __syncthreads();
+    fxd_phase4(d, &sh, u, tid);
+    __syncthreads();
+    fxd_phase5(d, &sh, u, tid);
+    __syncthreads();
+  }
+  fxd_store_shared(d, &sh, tid);
+  if (tid == 0) { d->blpos = blpos0 + n; d->lastbyte = bytes[n - 1]; d->have_rec = 1; d->rec = recs[n - 1]; }
+}
+
+__global__ void cmx_fxcm_pattern16_kernel(uint16_t* p, size_t n, const uint16_t* pat, int plen) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = pat[i % (size_t)plen];
+}
+
+namespace {
+struct DevPolicy {
+  std::vector<void*> blocks;
+  bool ok = true;
+  void* zalloc(size_t bytes) {
+    void* p = nullptr;
+    if (!ok || hipMalloc(&p, bytes + 64) != hipSuccess || hipMemset(p, 0, bytes + 64) != hipSuccess) { ok = false; return nullptr; }
+    blocks.push_back(p);
+    return p;
+  }
+  void fill16(void* p, size_t n, uint16_t v) { if (p && hipMemsetD16((hipDeviceptr_t)p, v, n) != hipSuccess) ok = false; }
+  void fill32(void* p, size_t n, uint32_t v) { if (p && hipMemsetD32((hipDeviceptr_t)p, (int)v, n) != hipSuccess) ok = false; }
+  void pattern16(void* p, size_t n, const uint16_t* pat, int plen) {
+    if (!p) return;
+    uint16_t* dp = (uint16_t*)zalloc((size_t)plen * 2);
+    if (!dp) return;
+    upload(dp, pat, (size_t)plen * 2);
+    hipLaunchKernelGGL(cmx_fxcm_pattern16_kernel, dim3(1024), dim3(256), 0, 0, (uint16_t*)p, n, dp, plen);
+    if (hipDeviceSynchronize() != hipSuccess) ok = false;
+  }
+  void upload(void* dst, const void* src, size_t bytes) { if (dst && hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess) ok = false; }
+};
+enum { FX_STAGE_BUFS = 4 };
+}  // namespace
+
+struct cmx_fxcm {
+  int device = 0;
+  FxParser* parser = nullptr;
+  DevPolicy pol;
+  FxDev* d_dev = nullptr;
+  // record staging: page-locked host buffers and their device twins, recycled once the copy that read them is done
+  FxByteRec* h_recs[FX_STAGE_BUFS] = {};
+  FxByteRec* d_recs[FX_STAGE_BUFS] = {};
+  hipEvent_t done[FX_STAGE_BUFS] = {};
+  size_t cap[FX_STAGE_BUFS] = {};
+  bool used[FX_STAGE_BUFS] = {};
+  int next = 0;
+  uint64_t bytes_done = 0;
+};
+
+extern "C" {
+
+void cmx_fxcm_destroy(cmx_fxcm_t* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  for (void* p : h->pol.blocks) (void)hipFree(p);
+  if (h->d_dev) (void)hipFree(h->d_dev);
+  for (int i = 0; i < FX_STAGE_BUFS; i++) {
+    if (h->h_recs[i]) (void)hipHostFree(h->h_recs[i]);
+    if (h->d_recs[i]) (void)hipFree(h->d_recs[i]);
+    if (h->done[i]) (void)hipEventDestroy(h->done[i]);
+  }
+  if (h->parser) fxp_destroy(h->parser);
+  delete h;
+}
+
+cmx_fxcm_t* cmx_fxcm_create(const char* dictionary_path, int device) {
+  if (cmx_device_count() <= 0) { cmx_set_err("cmx_fxcm_create: no HIP device visible (a gfx950 GPU is required)"); return nullptr; }
+  if (hipSetDevice(device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return nullptr; }
+  cmx_fxcm_t* h = new cmx_fxcm();
+  h->device = device;
+  FxDev host;
+  fxb::build(host, h->pol);
+  bool ok = h->pol.ok;
+  ok = ok && hipMalloc((void**)&h->d_dev, sizeof(FxDev)) == hipSuccess;
+  ok = ok && hipMemcpy(h->d_dev, &host, sizeof(FxDev), hipMemcpyHostToDevice) == hipSuccess;
+  for (int i = 0; ok && i < FX_STAGE_BUFS; i++) ok = hipEventCreateWithFlags(&h->done[i], hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipDeviceSynchronize() == hipSuccess;
+  if (!ok) { cmx_set_err("cmx_fxcm_create: allocation / init failed (the stage needs ~4.4 GB of HBM)"); cmx_fxcm_destroy(h); return nullptr; }
+  h->parser = fxp_create(dictionary_path);
+  return h;
+}
+
+int cmx_fxcm_run(cmx_fxcm_t* h, const uint8_t* bytes, const uint8_t* d_bytes, size_t nbytes, const int16_t* d_lstmpr, const uint8_t* d_lstmex,
+                 float* d_probs, size_t pstride, void* stream) {
+  if (!h) { cmx_set_err("cmx_fxcm_run: null handle"); return 1; }
+  if (nbytes == 0) return 0;
+  if (!bytes || !d_bytes || !d_lstmpr || !d_lstmex || !d_probs || pstride < 3 + FX_OUTPUTS || nbytes > (1u << 24)) { cmx_set_err("cmx_fxcm_run: bad argument"); return 1; }
+  if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
+  const int b = h->next;
+  h->next = (h->next + 1) % FX_STAGE_BUFS;
+  if (h->used[b] && hipEventSynchronize(h->done[b]) != hipSuccess) { cmx_set_err("cmx_fxcm_run: staging buffer wait failed"); return 1; }
+  if (h->cap[b] < nbytes) {
+    if (h->h_recs[b]) (void)hipHostFree(h->h_recs[b]);
+    if (h->d_recs[b]) (void)hipFree(h->d_recs[b]);
+    h->h_recs[b] = nullptr; h->d_recs[b] = nullptr; h->cap[b] = 0;
+    if (hipHostMalloc((void**)&h->h_recs[b], nbytes * sizeof(FxByteRec), hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void**)&h->d_recs[b], nbytes * sizeof(FxByteRec)) != hipSuccess) { cmx_set_err("cmx_fxcm_run: staging allocation failed"); return 1; }
+    h->cap[b] = nbytes;
+  }
+  if (fxp_run(h->parser, bytes, (int)nbytes, h->h_recs[b]) != 0) { cmx_set_err("cmx_fxcm_run: parser emitted a context count a map does not expect"); return 1; }
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemcpyAsync(h->d_recs[b], h->h_recs[b], nbytes * sizeof(FxByteRec), hipMemcpyHostToDevice, s) != hipSuccess) { cmx_set_err("cmx_fxcm_run: record upload failed"); return 1; }
+  hipLaunchKernelGGL(cmx_fxcm_chunk_kernel, dim3(1), dim3(FX_THREADS), 0, s, h->d_dev, d_bytes, h->d_recs[b], d_lstmpr, d_lstmex, d_probs + 3, (long)pstride,
+                     (int)nbytes);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { cmx_set_err(std::string("cmx_fxcm_run: ") + hipGetErrorString(e)); return 1; }
+  if (hipEventRecord(h->done[b], s) != hipSuccess) { cmx_set_err("cmx_fxcm_run: event record failed"); return 1; }
+  h->used[b] = true;
+  h->bytes_done += nbytes;
+  return 0;
+}
+
+int cmx_fxcm_sync(cmx_fxcm_t* h) {
+  if (!h) { cmx_set_err("cmx_fxcm_sync: null handle"); return 1; }
+  if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) { cmx_set_err(std::string("cmx_fxcm_sync: ") + hipGetErrorString(e)); return 1; }
+  return 0;
+}
+
+}  // extern "C"

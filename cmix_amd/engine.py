@@ -42,6 +42,11 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.cmx_last_error.restype = C.c_char_p
         L.cmx_version.restype = C.c_char_p
+        L.cmx_fxcm_create.restype = C.c_void_p
+        L.cmx_fxcm_create.argtypes = [C.c_char_p, C.c_int]
+        L.cmx_fxcm_destroy.argtypes = [C.c_void_p]
+        L.cmx_fxcm_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.cmx_fxcm_sync.argtypes = [C.c_void_p]
         L.cmx_mixnet_create.restype = C.c_void_p
         L.cmx_mixnet_create.argtypes = [C.c_int]
         L.cmx_mixnet_destroy.argtypes = [C.c_void_p]
@@ -662,3 +667,52 @@ class P8Mixer:
             self.h = None
 
     __del__ = close
+
+
+FXCM_COLS = slice(3, 434)
+
+
+class Fxcm:
+    """The fxcm stage of one stream on one GPU (chunk mode): layer-0 columns 3..433. The text parser half runs on the
+    calling thread inside run(); the learned tables live on the device (include/cmix_amd.h section 2f)."""
+
+    def __init__(self, dictionary_path=None, device=0):
+        self.h = lib().cmx_fxcm_create(dictionary_path.encode() if isinstance(dictionary_path, str) else dictionary_path, device)
+        if not self.h:
+            raise CmxError(last_error())
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().cmx_fxcm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, data_host, lstmpr, lstmex, probs=None, stream=None):
+        """data_host [N] u8 numpy; lstmpr [8N] i16 cuda, lstmex [8N] u8 cuda -> writes columns 3..433 of probs [8N, >=434] f32."""
+        import torch
+        data_host = np.ascontiguousarray(data_host, np.uint8)
+        N = int(data_host.size)
+        dev = lstmpr.device
+        assert lstmpr.is_cuda and lstmpr.dtype == torch.int16 and lstmpr.is_contiguous() and lstmpr.numel() == 8 * N
+        assert lstmex.is_cuda and lstmex.dtype == torch.uint8 and lstmex.is_contiguous() and lstmex.numel() == 8 * N
+        d_bytes = torch.from_numpy(data_host.copy()).to(dev)
+        if probs is None:
+            probs = torch.full((8 * N, N_INPUTS), 0.5, dtype=torch.float32, device=dev)
+        assert probs.dtype == torch.float32 and probs.is_contiguous() and probs.shape[0] == 8 * N and probs.shape[1] >= 434
+        if stream is None:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = lib().cmx_fxcm_run(self.h, data_host.ctypes.data, d_bytes.data_ptr(), N, lstmpr.data_ptr(), lstmex.data_ptr(), probs.data_ptr(),
+                                probs.shape[1], C.c_void_p(stream))
+        if rc:
+            raise CmxError(last_error())
+        self._keep = d_bytes   # the kernel reads it asynchronously
+        return probs
+
+    def sync(self):
+        if lib().cmx_fxcm_sync(self.h):
+            raise CmxError(last_error())

@@ -225,6 +225,31 @@ void cmx_p8mixer_destroy(cmx_p8mixer_t*);
 int cmx_p8mixer_run(cmx_p8mixer_t*, const int16_t* d_x, const int* d_rows, const uint8_t* d_bits, size_t nbits, int* d_p,
                     int* d_pr, void* stream);
 
+/* ------------------------------------------------------------------------
+ * 2f. Stage: the vendored fxcm model = FXCM::Predict / FXCM::Perceive (src/models/fxcm.cpp:14-33) around
+ *     fxcmv1::Predictor::update1 + modelPrediction (src/models/fxcmv1.cpp:4758-4833, :3798-4757); cmix wires it at
+ *     predictor.cpp:98-99 (construction, dictionary path), :462-468 (lstmpr / lstmex set, then Perceive last).
+ *     431 values per bit = layer-0 columns 3..433. The text parser half (everything the model computes at a byte
+ *     boundary from the bytes alone) runs on the calling host thread, the learned tables on the device.
+ * ------------------------------------------------------------------------ */
+typedef struct cmx_fxcm cmx_fxcm_t;
+/* dictionary_path: cmix's WRT dictionary (the reference's global `dictionary_path`, runner.cpp:17; fxcmv1.cpp:412-428),
+ * NULL or "" without one. */
+cmx_fxcm_t* cmx_fxcm_create(const char* dictionary_path, int device);
+void cmx_fxcm_destroy(cmx_fxcm_t*);
+/* Chunk mode over nbytes already-known bytes (whole bytes; chunks of one stream in order).
+ *   bytes    [nbytes]            u8  HOST   the bytes coded (parsed on the calling thread before the call returns)
+ *   d_bytes  [nbytes]            u8  DEVICE the same bytes
+ *   d_lstmpr [8*nbytes]          i16 DEVICE lstmpr as cmix sets it before FXCM::Perceive of each bit (1 + 4094 * p, predictor.cpp:463)
+ *   d_lstmex [8*nbytes]          u8  DEVICE lstmex, same (the LSTM's likeliest byte, predictor.cpp:464)
+ *   d_probs  [8*nbytes][pstride] f32 DEVICE OUT columns 3..433 of every row: row q = FXCM::Predict() before bit q of the
+ *                                    chunk is coded (row 0 of a stream's first chunk = the constructor's 0.5); other
+ *                                    columns untouched; pstride >= 434
+ * Asynchronous on `stream`. */
+int cmx_fxcm_run(cmx_fxcm_t*, const uint8_t* bytes, const uint8_t* d_bytes, size_t nbytes, const int16_t* d_lstmpr, const uint8_t* d_lstmex,
+                 float* d_probs, size_t pstride, void* stream);
+int cmx_fxcm_sync(cmx_fxcm_t*);
+
 /* ---- callers of the path: arithmetic coder + container header (HOST code) -------------------------------------
  * Replaces Encoder::Encode/Flush (src/coder/encoder.cpp:10-39), Decoder::Decoder/Decode (src/coder/decoder.cpp:3-39)
  * and WriteHeader/ReadHeader (src/runner.cpp:34-84). The probabilities are the p[] a pipeline chunk produced
