@@ -40,6 +40,9 @@ struct Slot {
   float* d_layer0 = nullptr;    // the caller's layer-0 rows of that chunk
   hipEvent_t ev_in = nullptr, ev_ctx0 = nullptr, ev_ctx1 = nullptr, ev_lstm0 = nullptr, ev_lstm1 = nullptr,
              ev_mix0 = nullptr, ev_mix1 = nullptr, ev_cols = nullptr;
+  int16_t* d_fx_pr = nullptr;   // [8 max] fxcm stage (opt-in): lstmpr per update
+  uint8_t* d_fx_ex = nullptr;   // [8 max] lstmex per update
+  hipEvent_t ev_fxin = nullptr, ev_fx0 = nullptr, ev_fx1 = nullptr;
   bool used = false;
   bool untimed = false;  // the chunk in this slot has not been added to the stage totals yet
 };
@@ -53,6 +56,10 @@ struct cmx_pipeline {
   cmx_lstm_t* lstm = nullptr;
   cmx_mixnet_t* mix = nullptr;
   hipStream_t s_ctx = nullptr, s_lstm = nullptr, s_mix = nullptr;
+  cmx_fxcm_t* fxcm = nullptr;    // device fxcm stage (cmx_pipeline_enable_fxcm); NULL: the caller supplies columns 3..433
+  hipStream_t s_fx = nullptr;
+  float* d_fx_scratch = nullptr; // pretraining writes its (discarded) rows here
+  double fx_ms = 0;
   Slot slot[kSlots];
   uint64_t chunks = 0;    // chunks begun
   uint64_t hinted = 0;    // chunks whose LSTM hints were handed out (<= chunks)
@@ -72,10 +79,20 @@ void collect(cmx_pipeline* h, Slot& s) {  // the slot's chunk has finished (its 
   (void)hipEventElapsedTime(&ms[1], s.ev_lstm0, s.ev_lstm1);
   (void)hipEventElapsedTime(&ms[2], s.ev_mix0, s.ev_mix1);
   for (int i = 0; i < 3; ++i) h->tot_ms[i] += ms[i];
+  if (h->fxcm) { float f = 0; (void)hipEventElapsedTime(&f, s.ev_fx0, s.ev_fx1); h->fx_ms += f; }
   h->tot_chunks++;
   s.untimed = false;
 }
 }  // namespace
+
+__global__ void cmx_fxcm_hints_kernel(const float* layer0, long stride, const float* p_after, const int* ex, int T, int16_t* lstmpr, uint8_t* lstmex) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const float p = t + 1 < T ? layer0[(long)(t + 1) * stride + 2077] : *p_after;
+  const float prod = 4094.0f * p;                 // Discretize (predictor.cpp:180-182): the product is rounded to float, then 1 is added
+  lstmpr[t] = (int16_t)(unsigned)(1.0f + prod);
+  lstmex[t] = (uint8_t)ex[t + 1];
+}
 
 extern "C" {
 
@@ -93,12 +110,19 @@ void cmx_pipeline_destroy(cmx_pipeline_t* h) {
     if (s.h_ppmd) (void)hipHostFree(s.h_ppmd);
     if (s.d_hint) (void)hipFree(s.d_hint);
     if (s.h_hint) (void)hipHostFree(s.h_hint);
+    if (s.d_fx_pr) (void)hipFree(s.d_fx_pr);
+    if (s.d_fx_ex) (void)hipFree(s.d_fx_ex);
+    for (hipEvent_t e : {s.ev_fxin, s.ev_fx0, s.ev_fx1})
+      if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : {s.ev_in, s.ev_ctx0, s.ev_ctx1, s.ev_lstm0, s.ev_lstm1, s.ev_mix0, s.ev_mix1, s.ev_cols})
       if (e) (void)hipEventDestroy(e);
   }
   if (h->s_ctx && h->s_ctx != h->s_lstm) (void)hipStreamDestroy(h->s_ctx);
   if (h->s_lstm) (void)hipStreamDestroy(h->s_lstm);
   if (h->s_mix) (void)hipStreamDestroy(h->s_mix);
+  if (h->s_fx) (void)hipStreamDestroy(h->s_fx);
+  if (h->d_fx_scratch) (void)hipFree(h->d_fx_scratch);
+  cmx_fxcm_destroy(h->fxcm);
   cmx_mixnet_destroy(h->mix);
   cmx_lstm_destroy(h->lstm);
   cmx_ctxmodels_destroy(h->ctx);
@@ -146,6 +170,33 @@ cmx_pipeline_t* cmx_pipeline_create(const uint8_t vocab[256], int device, size_t
   return h;
 }
 
+// ---- the fxcm stage on the device (opt-in) ----------------------------------------------------------------------
+// After coding bit t the reference holds lstmpr = Discretize(p of bit t + 1) = 1 + 4094 * p in float arithmetic,
+// truncated (predictor.cpp:180-182,463), and lstmex = the LSTM byte mixer's `ex` at that moment (:464); fxcm reads both
+// in the Perceive of bit t (:465). p of bit t + 1 is column 2077 of row t + 1; the entry after the chunk's last bit
+// comes from the distribution after the chunk's last byte (hint arrays, entry 8n).
+int cmx_pipeline_enable_fxcm(cmx_pipeline_t* h, const char* dictionary_path) {
+  if (!h) { cmx_set_err("cmx_pipeline_enable_fxcm: null handle"); return 1; }
+  if (h->fxcm) return 0;
+  if (h->chunks) { cmx_set_err("cmx_pipeline_enable_fxcm: only before the first chunk"); return 1; }
+  if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
+  h->fxcm = cmx_fxcm_create(dictionary_path, h->device);
+  if (!h->fxcm) return 1;
+  const size_t n = h->max_chunk;
+  bool ok = hipStreamCreateWithFlags(&h->s_fx, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipMalloc((void**)&h->d_fx_scratch, 8 * n * 434 * sizeof(float)) == hipSuccess;
+  for (Slot& s : h->slot) {
+    ok = ok && hipMalloc((void**)&s.d_fx_pr, 8 * n * 2) == hipSuccess;
+    ok = ok && hipMalloc((void**)&s.d_fx_ex, 8 * n) == hipSuccess;
+    for (hipEvent_t* e : {&s.ev_fxin, &s.ev_fx0, &s.ev_fx1}) ok = ok && hipEventCreate(e) == hipSuccess;
+  }
+  if (!ok) { cmx_set_err("cmx_pipeline_enable_fxcm: stream / buffer allocation failed"); return 1; }
+  return 0;
+}
+int cmx_pipeline_fxcm_enabled(cmx_pipeline_t* h) { return h && h->fxcm ? 1 : 0; }
+// HIP-event time of the fxcm kernel over the chunks counted by cmx_pipeline_stage_totals (same reset)
+int cmx_pipeline_fxcm_total_ms(cmx_pipeline_t* h, double* ms) { if (!h || !ms) return 1; *ms = h->fx_ms; return 0; }
+
 // ---- a chunk in two steps -------------------------------------------------------------------------------------
 // begin: everything that does not need the fxcm/paq8 columns -- PPMd on this thread, upload, context stage, LSTM.
 int cmx_pipeline_begin(cmx_pipeline_t* h, const uint8_t* bytes, size_t n, float* d_layer0) {
@@ -188,6 +239,19 @@ int cmx_pipeline_begin(cmx_pipeline_t* h, const uint8_t* bytes, size_t n, float*
                    (int*)(s.d_hint + (8 * h->max_chunk + 1)), h->s_lstm))
     return 1;
   (void)hipEventRecord(s.ev_lstm1, h->s_lstm);
+  if (h->fxcm) {  // ---- fxcm stage: hints from the LSTM's columns, then the parser (this thread) and the kernel on its own stream ----
+    const size_t T = 8 * n;
+    float* dp = s.d_hint;
+    int* dx = (int*)(s.d_hint + (8 * h->max_chunk + 1));
+    if (cmx_bytemodel_bit_run(h->device, s.d_lstm_out + (n - 1) * 256, s.d_bytes, 0, dp + T, 1, dx + T, nullptr, h->s_lstm)) return 1;
+    hipLaunchKernelGGL(cmx_fxcm_hints_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, h->s_lstm, d_layer0, (long)CMX_N_INPUTS, dp + T, dx, (int)T,
+                       s.d_fx_pr, s.d_fx_ex);
+    (void)hipEventRecord(s.ev_fxin, h->s_lstm);
+    (void)hipStreamWaitEvent(h->s_fx, s.ev_fxin, 0);
+    (void)hipEventRecord(s.ev_fx0, h->s_fx);
+    if (cmx_fxcm_run(h->fxcm, bytes, s.d_bytes, n, s.d_fx_pr, s.d_fx_ex, d_layer0, CMX_N_INPUTS, h->s_fx)) return 1;
+    (void)hipEventRecord(s.ev_fx1, h->s_fx);
+  }
   s.used = true;
   s.untimed = false;  // becomes true once its mixing network is enqueued
   h->chunks++;
@@ -226,14 +290,24 @@ int cmx_pipeline_hints(cmx_pipeline_t* h, float* lstm_p, int* lstm_ex) {
 
 // finish: the oldest begun chunk gets its fxcm/paq8 columns (HOST rows of 2022 floats = layer-0 columns 3..2024; NULL
 // = the caller has already written them into d_layer0) and its mixing network. Asynchronous.
+static int finish_impl(cmx_pipeline_t* h, const float* cols, int first_col, int ncols, float* d_p_out);
 int cmx_pipeline_finish(cmx_pipeline_t* h, const float* cols, float* d_p_out) {
+  if (h && h->fxcm && cols) { cmx_set_err("cmx_pipeline_finish: the fxcm stage is on the device; hand in columns 434..2024 with cmx_pipeline_finish_cols"); return 1; }
+  return finish_impl(h, cols, 3, 2022, d_p_out);
+}
+// the same with the caller's rows covering layer-0 columns first_col .. first_col + ncols - 1 only (HOST rows of ncols floats)
+int cmx_pipeline_finish_cols(cmx_pipeline_t* h, const float* cols, int first_col, int ncols, float* d_p_out) {
+  if (!cols || first_col < 3 || ncols <= 0 || first_col + ncols > 2025 || (h && h->fxcm && first_col < 434)) { cmx_set_err("cmx_pipeline_finish_cols: bad column range"); return 1; }
+  return finish_impl(h, cols, first_col, ncols, d_p_out);
+}
+static int finish_impl(cmx_pipeline_t* h, const float* cols, int first_col, int ncols, float* d_p_out) {
   if (!h || !d_p_out) { cmx_set_err("cmx_pipeline_finish: bad argument"); return 1; }
   if (h->finished >= h->chunks) { cmx_set_err("cmx_pipeline_finish: no begun chunk"); return 1; }
   if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
   Slot& s = h->slot[h->finished % kSlots];
   const size_t n = s.n;
   if (cols) {  // returns once the rows have been read: the caller may reuse `cols` right away
-    bool ok = hipMemcpy2DAsync(s.d_layer0 + 3, CMX_N_INPUTS * 4, cols, 2022 * 4, 2022 * 4, 8 * n, hipMemcpyHostToDevice,
+    bool ok = hipMemcpy2DAsync(s.d_layer0 + first_col, CMX_N_INPUTS * 4, cols, (size_t)ncols * 4, (size_t)ncols * 4, 8 * n, hipMemcpyHostToDevice,
                                h->s_mix) == hipSuccess;
     ok = ok && hipEventRecord(s.ev_cols, h->s_mix) == hipSuccess && hipEventSynchronize(s.ev_cols) == hipSuccess;
     if (!ok) { cmx_set_err("cmx_pipeline_finish: column upload failed"); return 1; }
@@ -241,6 +315,7 @@ int cmx_pipeline_finish(cmx_pipeline_t* h, const float* cols, float* d_p_out) {
   // ---- final mixing network, once both producers have written their columns ----
   (void)hipStreamWaitEvent(h->s_mix, s.ev_ctx1, 0);
   (void)hipStreamWaitEvent(h->s_mix, s.ev_lstm1, 0);
+  if (h->fxcm) (void)hipStreamWaitEvent(h->s_mix, s.ev_fx1, 0);
   (void)hipEventRecord(s.ev_mix0, h->s_mix);
   if (cmx_mixnet_run(h->mix, s.d_layer0, s.d_sel, s.d_bits, 8 * n, d_p_out, nullptr, h->s_mix)) return 1;
   (void)hipEventRecord(s.ev_mix1, h->s_mix);
@@ -273,6 +348,19 @@ int cmx_pipeline_pretrain(cmx_pipeline_t* h, const uint8_t* bytes, size_t n) {
   bool ok = hipMemcpyAsync(d, bytes, n, hipMemcpyHostToDevice, h->s_ctx) == hipSuccess;
   ok = ok && cmx_ctxmodels_pretrain(h->ctx, d, n, h->s_ctx) == 0;
   ok = hipStreamSynchronize(h->s_ctx) == hipSuccess && ok;
+  if (ok && h->fxcm) {  // fxcm is one of models_: Predict + Perceive per dictionary bit with the hints at their start-up value 0 (predictor.cpp:359,471-476)
+    const size_t C = h->max_chunk;
+    int16_t* zpr = nullptr; uint8_t* zex = nullptr;
+    ok = hipMalloc((void**)&zpr, 8 * C * 2) == hipSuccess && hipMalloc((void**)&zex, 8 * C) == hipSuccess;
+    ok = ok && hipMemsetAsync(zpr, 0, 8 * C * 2, h->s_fx) == hipSuccess && hipMemsetAsync(zex, 0, 8 * C, h->s_fx) == hipSuccess;
+    for (size_t off = 0; ok && off < n; off += C) {
+      const size_t m = n - off < C ? n - off : C;
+      ok = cmx_fxcm_run(h->fxcm, bytes + off, d + off, m, zpr, zex, h->d_fx_scratch, 434, h->s_fx) == 0;
+    }
+    ok = hipStreamSynchronize(h->s_fx) == hipSuccess && ok;
+    if (zpr) (void)hipFree(zpr);
+    if (zex) (void)hipFree(zex);
+  }
   (void)hipFree(d);
   if (!ok) { cmx_set_err("cmx_pipeline_pretrain: device error"); return 1; }
   return 0;
@@ -284,6 +372,7 @@ int cmx_pipeline_sync(cmx_pipeline_t* h) {
   bool ok = hipStreamSynchronize(h->s_ctx) == hipSuccess;
   ok = hipStreamSynchronize(h->s_lstm) == hipSuccess && ok;
   ok = hipStreamSynchronize(h->s_mix) == hipSuccess && ok;
+  if (h->s_fx) ok = hipStreamSynchronize(h->s_fx) == hipSuccess && ok;
   if (!ok) { cmx_set_err("cmx_pipeline_sync: device error"); return 1; }
   if (cmx_ctxmodels_sync(h->ctx) || cmx_mixnet_sync(h->mix)) return 1;
   for (Slot& s : h->slot) collect(h, s);
@@ -300,7 +389,7 @@ int cmx_pipeline_stage_totals(cmx_pipeline_t* h, double ms[3], uint64_t* chunks,
   if (!h || !ms || !chunks) return 1;
   for (int i = 0; i < 3; ++i) ms[i] = h->tot_ms[i];
   *chunks = h->tot_chunks;
-  if (reset) { h->tot_ms[0] = h->tot_ms[1] = h->tot_ms[2] = 0; h->tot_chunks = 0; }
+  if (reset) { h->tot_ms[0] = h->tot_ms[1] = h->tot_ms[2] = 0; h->tot_chunks = 0; h->fx_ms = 0; }
   return 0;
 }
 

@@ -323,6 +323,16 @@ int cmx_pipeline_submit(cmx_pipeline_t*, const uint8_t* bytes, size_t n, float* 
 int cmx_pipeline_begin(cmx_pipeline_t*, const uint8_t* bytes, size_t nbytes, float* d_layer0);
 int cmx_pipeline_hints(cmx_pipeline_t*, float* lstm_p, int* lstm_ex);
 int cmx_pipeline_finish(cmx_pipeline_t*, const float* cols, float* d_p_out);
+/* The fxcm stage on the device (section 2f), opt-in, before the first chunk: cmx_pipeline_begin then also derives the
+ * per-bit lstmpr / lstmex from the LSTM stage's output on the device and runs the fxcm stage (text parser on the calling
+ * thread, kernel on a fourth HIP stream) into columns 3..433; cmx_pipeline_pretrain covers it; the caller hands in only
+ * the remaining columns with cmx_pipeline_finish_cols (HOST rows of ncols floats = layer-0 columns first_col ..
+ * first_col + ncols - 1; with the fxcm stage enabled first_col >= 434) -- cmx_pipeline_finish with rows then fails.
+ * dictionary_path: as cmx_fxcm_create. */
+int cmx_pipeline_enable_fxcm(cmx_pipeline_t*, const char* dictionary_path);
+int cmx_pipeline_fxcm_enabled(cmx_pipeline_t*);
+int cmx_pipeline_finish_cols(cmx_pipeline_t*, const float* cols, int first_col, int ncols, float* d_p_out);
+int cmx_pipeline_fxcm_total_ms(cmx_pipeline_t*, double* ms);
 /* Predictor::Pretrain over n dictionary bytes (HOST pointer), before the first submit: only the stages holding
  * `models_` learn (today: contexts + small models); mixers, SSE, LSTM and PPMd are not trained (predictor.cpp:471-487). */
 int cmx_pipeline_pretrain(cmx_pipeline_t*, const uint8_t* bytes, size_t n);

@@ -9,6 +9,8 @@
 // the chunk on two threads -- they only depend on the bits and on those hints, never on the mixer -- writing their
 // 2022 columns per bit, and cmx_pipeline_finish uploads the columns and runs the mixing network while the host is
 // already in the next chunk. The probabilities come back once and feed the arithmetic coder (cmx_encoder_*).
+// With CMX_FXCM_DEVICE=1 in the environment the fxcm family runs as a device stage instead (cmx_pipeline_enable_fxcm):
+// no hints come back, only paq8 runs on a host thread and only its 1591 columns are uploaded.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -58,7 +60,8 @@ void CompressLookahead(Predictor* P, const std::vector<uint8_t>& data, cmx_encod
   for (size_t c = 0; c < nchunks; ++c) {
     const size_t n = len(c);
     const uint8_t* bytes = data.data() + c * C;
-    if (cmx_pipeline_hints(P->pipe(), hint_p.data(), hint_ex.data())) Predictor::Die();
+    // CMX_FXCM_DEVICE=1: fxcm runs as a device stage behind cmx_pipeline_begin (its hints never leave the device)
+    if (!P->fxcm_on_device() && cmx_pipeline_hints(P->pipe(), hint_p.data(), hint_ex.data())) Predictor::Die();
     // the host model families over the chunk: Predict() then Perceive(bit) per bit, as Predictor::Predict / Perceive
     // order them (predictor.cpp:363-369,422-425,462-467); each only touches its own state and its own columns
     std::thread tp([&] {
@@ -70,7 +73,7 @@ void CompressLookahead(Predictor* P, const std::vector<uint8_t>& data, cmx_encod
         m->Perceive((bytes[t >> 3] >> (7 - (t & 7))) & 1);
       }
     });
-    {
+    if (!P->fxcm_on_device()) {
       Model* m = P->fxcm();
       for (size_t t = 0; t < 8 * n; ++t) {
         const std::valarray<float>& o = m->Predict();
@@ -85,7 +88,11 @@ void CompressLookahead(Predictor* P, const std::vector<uint8_t>& data, cmx_encod
     // its context stage and LSTM, whose hints are ready long before the next iteration asks for them
     if (c + 1 < nchunks && cmx_pipeline_begin(P->pipe(), bytes + C, len(c + 1), d_layer0[(c + 1) & 3])) Predictor::Die();
     tp.join();
-    if (cmx_pipeline_finish(P->pipe(), cols, d_p + 8 * c * C)) Predictor::Die();
+    if (P->fxcm_on_device()) {   // only paq8's 1591 columns (434..2024) go up; rows stay 2022 floats apart
+      std::vector<float> pq(8 * n * 1591);
+      for (size_t t = 0; t < 8 * n; ++t) memcpy(&pq[t * 1591], cols + t * 2022 + 431, 1591 * sizeof(float));
+      if (cmx_pipeline_finish_cols(P->pipe(), pq.data(), 434, 1591, d_p + 8 * c * C)) Predictor::Die();
+    } else if (cmx_pipeline_finish(P->pipe(), cols, d_p + 8 * c * C)) Predictor::Die();
     fprintf(stderr, "\rprogress: %.2f%%", 100.0 * (c + 1) / nchunks);
   }
   if (cmx_pipeline_sync(P->pipe())) Predictor::Die();

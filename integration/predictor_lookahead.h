@@ -2,7 +2,8 @@
 // every byte is known before it is coded (runner.cpp:101-119): `class Predictor` here only has to serve
 // preprocessor::Pretrain (the one caller besides the coder, preprocessor.cpp:37-69); the coding itself goes a chunk
 // at a time through cmx_pipeline_begin / _hints / _finish (integration/compress_lookahead.cpp). The two vendored
-// model families without a device stage yet (fxcm, paq8) are owned here and run on host threads.
+// model families are owned here and run on host threads: paq8 always (no device stage yet); fxcm unless
+// CMX_FXCM_DEVICE=1 asks for the device stage (cmx_pipeline_enable_fxcm), in which case no host fxcm object exists.
 #ifndef PREDICTOR_H
 #define PREDICTOR_H
 
@@ -28,7 +29,10 @@ class Predictor {
     device_ = dev ? atoi(dev) : 0;
     pipe_ = cmx_pipeline_create(vocab_, device_, chunk_);
     if (!pipe_) Die();
-    fxcm_.reset(new FXCM());    // predictor.cpp:77-82
+    const char* fxd = getenv("CMX_FXCM_DEVICE");
+    fxcm_on_device_ = fxd && fxd[0] == '1';
+    if (fxcm_on_device_) { if (cmx_pipeline_enable_fxcm(pipe_, dictionary_path)) Die(); }
+    else fxcm_.reset(new FXCM());    // predictor.cpp:77-82
     paq8_.reset(new PAQ8(11));  // predictor.cpp:84-88
   }
   ~Predictor() { cmx_pipeline_destroy(pipe_); }
@@ -38,9 +42,9 @@ class Predictor {
   // predictor.cpp:471-487: the host models learn bit by bit; the device's share is trained in one batch before the
   // first chunk (FlushPretrain), which is equivalent because nothing downstream is trained during pretraining.
   void Pretrain(int bit) {
-    fxcm_->Predict();
+    if (fxcm_) fxcm_->Predict();
     paq8_->Predict();
-    fxcm_->Perceive(bit);
+    if (fxcm_) fxcm_->Perceive(bit);   // on the device: cmx_pipeline_pretrain (FlushPretrain) covers it
     paq8_->Perceive(bit);
     pre_partial_ = (pre_partial_ << 1) | (bit ? 1u : 0u);
     if (++pre_j_ == 8) { pre_.push_back((uint8_t)pre_partial_); pre_j_ = 0; pre_partial_ = 0; }
@@ -54,6 +58,7 @@ class Predictor {
 
   cmx_pipeline_t* pipe() { return pipe_; }
   Model* fxcm() { return fxcm_.get(); }
+  bool fxcm_on_device() const { return fxcm_on_device_; }
   Model* paq8() { return paq8_.get(); }
   int device() const { return device_; }
   size_t chunk() const { return chunk_; }
@@ -65,6 +70,7 @@ class Predictor {
  private:
   size_t chunk_;
   int device_ = 0;
+  bool fxcm_on_device_ = false;
   unsigned char vocab_[256];
   cmx_pipeline_t* pipe_ = nullptr;
   std::unique_ptr<Model> fxcm_, paq8_;

@@ -81,9 +81,50 @@ def test_long_text_properties():
     a = run_device(data, pr, ex, [4096] * 16)
     b = run_device(data, pr, ex, [65536])
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
-    k = a[:, :429] * np.float32(4095)
-    assert np.abs(k - np.round(k)).max() < 1e-3 and k.min() >= 0.999 and k.max() <= 4095.001
+    k = a[8:, :429] * np.float32(4095)                   # rows 0..7: the first byte's layout, 0.5 where no map has a context yet
+    assert np.abs(k - np.round(k)).max() < 1e-3 and k.min() >= 0 and k.max() <= 4095.001 and (a[:, 429:] == 0.5).all()
     bits = np.unpackbits(data)
-    p1 = a[:, 428].astype(np.float64)                    # the model's own final probability (last AddPrediction)
+    p1 = np.clip(a[:, 428].astype(np.float64), 1 / 4096, 1 - 1 / 4096)   # the model's own final probability (last AddPrediction); an APM may return 0
     cost = -np.log2(np.where(bits == 1, p1, 1 - p1)).sum() / len(data)
     assert cost < 4.0, cost
+
+
+# ---- the stage inside the chunk pipeline: cmx_pipeline_enable_fxcm --------------------------------------------------
+# oracle/_ref/cmix_lookahead with CMX_FXCM_DEVICE=1: the reference's preprocessor and paq8 objects on the host, fxcm as a
+# device stage fed by the LSTM stage's hints on the device (pretraining over the dictionary included). The files must
+# equal the reference binary's byte for byte (tests/golden/dropin_vectors.npz).
+
+def _lookahead(mode, files, timeout=900):
+    import os
+    import subprocess
+    import tempfile
+    from test_gpu_dropin import LOOKAHEAD
+    if not os.path.exists(LOOKAHEAD):
+        pytest.skip("oracle/_ref/cmix_lookahead not built (make -C oracle lookahead)")
+    with tempfile.TemporaryDirectory() as d:
+        paths = []
+        for name, data in files:
+            p = os.path.join(d, name)
+            with open(p, "wb") as f:
+                f.write(data)
+            paths.append(p)
+        out = os.path.join(d, "out")
+        r = subprocess.run([LOOKAHEAD, mode] + paths + [out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout,
+                           env=dict(os.environ, CMX_FXCM_DEVICE="1"))
+        assert r.returncode == 0, f"cmix_lookahead {mode} (fxcm on the device) failed: {r.stderr.decode(errors='replace')[-400:]}"
+        with open(out, "rb") as f:
+            return f.read()
+
+
+def test_pipeline_with_device_fxcm_files_are_byte_identical():
+    from test_gpu_dropin import _lookahead_vectors
+    v = _lookahead_vectors()
+    assert _lookahead("-n", [("in", v["raw_n_payload"])]) == v["raw_n_file"]
+    assert _lookahead("-c", [("in", v["text_c_payload"])]) == v["text_c_file"]
+    assert _lookahead("-c", [("in", v["text12k_c_payload"])]) == v["text12k_c_file"]
+
+
+def test_pipeline_with_device_fxcm_dictionary_pretraining():
+    from test_gpu_dropin import _lookahead_vectors
+    v = _lookahead_vectors()
+    assert _lookahead("-c", [("dict", v["dict_payload"]), ("in", v["dict_c_payload"])]) == v["dict_c_file"]
