@@ -1178,6 +1178,7 @@ extern "C" void fxp_destroy(FxParser* p) {
   if (m->dictW) { for (int i = 0; i < m->sizeDict; i++) free(m->dictW[i]); free(m->dictW); }
   free(m->buffer); free(m->ind3); free(p);
 }
+extern "C" void fxp_set_blpos(FxParser* p, int blpos) { p->s.blpos = blpos; }
 extern "C" int fxp_run(FxParser* p, const uint8_t* bytes, int n, FxByteRec* out) {
   FxModel* m = &p->s;
   int bad = 0;

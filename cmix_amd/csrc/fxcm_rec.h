@@ -55,6 +55,8 @@ struct FxParser* fxp_create(const char* dictionary_path);
 void fxp_destroy(struct FxParser* p);
 // consume n bytes, write n records; returns 0, or -1 if a map received a number of contexts other than its C
 int fxp_run(struct FxParser* p, const uint8_t* bytes, int n, struct FxByteRec* out);
+// test hook: the position in the block (several thresholds of the model depend on it, up to 463 139 793)
+void fxp_set_blpos(struct FxParser* p, int blpos);
 #ifdef __cplusplus
 }
 #endif

@@ -1097,6 +1097,12 @@ FxModel* orc_fx_model_new_dict(const char* dictionary_path) {   /* Predictor::Pr
   for (int i = 0; i < FX_OUTPUTS; i++) m->in1.exported[i] = 0.5f;   /* model_predictions(0.5f, num_models) :94 */
   return m;
 }
+/* test hook: continue as if blpos bytes of the block had been coded (the rates follow the position, update1 :4772-4774) */
+void orc_fx_model_set_blpos(FxModel* m, int blpos) {
+  m->blpos = blpos;
+  m->sscmrate = (blpos > 14 * 256 * 1024);
+  m->rate = 6 + (blpos > 14 * 256 * 1024) + (blpos > 28 * 512 * 1024);
+}
 /* diagnostics for the tests: the byte contexts the maps hold, the ten mixer selectors, a few parser registers */
 int orc_fx_model_debug(const FxModel* m, uint32_t* out) {
   int n = 0;

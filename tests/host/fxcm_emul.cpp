@@ -68,6 +68,7 @@ int fxe_run(void* h, const uint8_t* bytes, int n, const int16_t* lstmpr, const u
   d->blpos = blpos0 + n; d->lastbyte = bytes[n - 1]; d->have_rec = 1; d->rec = recs[(size_t)n - 1];
   return 0;
 }
+void fxe_set_blpos(void* h, int blpos) { Emul* e = (Emul*)h; e->dev.blpos = blpos; fxp_set_blpos(e->parser, blpos); }
 int fxe_debug(void* h, uint32_t* out) {   // the twelve mixer selectors + a few registers
   Emul* e = (Emul*)h;
   int n = 0;

@@ -31,14 +31,18 @@ def emul():
     return L
 
 
-def oracle_rows(data, lstmpr, lstmex, dictionary=None):
-    """rows[q] = FXCM::Predict() before bit q is coded (row 0 = the constructor's 0.5)."""
+def oracle_rows(data, lstmpr, lstmex, dictionary=None, blpos=0):
+    """rows[q] = FXCM::Predict() before bit q is coded (row 0 = the constructor's 0.5). blpos: start the model at that
+    position in the block (orc_fx_model_set_blpos) to reach the thresholds that depend on it."""
     lib = O.lib()
     lib.orc_fx_model_new.restype = C.c_void_p
     lib.orc_fx_model_new_dict.restype = C.c_void_p
     lib.orc_fx_model_new_dict.argtypes = [C.c_char_p]
     lib.orc_fx_model_update.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     h = lib.orc_fx_model_new_dict(dictionary) if dictionary else lib.orc_fx_model_new()
+    if blpos:
+        lib.orc_fx_model_set_blpos.argtypes = [C.c_void_p, C.c_int]
+        lib.orc_fx_model_set_blpos(h, blpos)
     rows = np.full((8 * len(data), 431), 0.5, np.float32)
     out = np.zeros(431, np.float32)
     q = 0
@@ -51,8 +55,11 @@ def oracle_rows(data, lstmpr, lstmex, dictionary=None):
     return rows
 
 
-def run_emul(L, data, lstmpr, lstmex, chunks, seed=12345, dictionary=None):
+def run_emul(L, data, lstmpr, lstmex, chunks, seed=12345, dictionary=None, blpos=0):
     h = L.fxe_create(dictionary, seed)
+    if blpos:
+        L.fxe_set_blpos.argtypes = [C.c_void_p, C.c_int]
+        L.fxe_set_blpos(h, blpos)
     data = np.ascontiguousarray(data, np.uint8)
     out = np.zeros((8 * len(data), 431), np.float32)
     pos = 0
@@ -158,3 +165,27 @@ def test_golden_columns(name):
             t += 1
     got = run_emul(emul(), np.asarray(stream, np.uint8), pr, ex, [len(stream)])
     compare(got, np.ascontiguousarray(probs[:, 3:434]), name)
+
+
+def test_pretraining_then_data_vs_oracle():
+    """Predictor::Pretrain drives fxcm over the dictionary with the hints at their start-up value 0 (predictor.cpp:359,
+    471-476); the coded data follows in the same model."""
+    from cmix_amd import synth
+    L = emul()
+    data = np.frombuffer(b"aardvark\nabacus\nabandon\nability\nzebra\n" * 20 + synth.enwik_like(1500, 8), np.uint8)
+    npre = 8 * 41 * 20
+    pr, ex = hints(8 * len(data), 21)
+    pr[:npre] = 0
+    ex[:npre] = 0
+    compare(run_emul(L, data, pr, ex, [41 * 20, 700, 800]), oracle_rows(data, pr, ex), "pretraining + data")
+
+
+@pytest.mark.parametrize("blpos", [14 * 256 * 1024 - 900, 28 * 512 * 1024 - 900, 448131719 - 700, 463139793 - 700])
+def test_block_position_thresholds_vs_oracle(blpos):
+    """The SSCM / APM rates change 3.67 MB and 14.7 MB into the block, two parser rules 448 MB and 463 MB in (update1
+    :4772-4774, modelPrediction :3866, :3932): the stream starts just before each threshold."""
+    from cmix_amd import synth
+    L = emul()
+    data = np.frombuffer(synth.enwik_like(1800, 4), np.uint8)
+    pr, ex = hints(8 * len(data), 17)
+    compare(run_emul(L, data, pr, ex, [600] * 3, blpos=blpos), oracle_rows(data, pr, ex, blpos=blpos), "blpos %d" % blpos)
