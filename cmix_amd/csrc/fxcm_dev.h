@@ -68,13 +68,17 @@ struct FxDev {                         // everything a stream owns on the device
   FxByteRec rec;                       // the record of the last completed byte (or the start-up values)
 };
 
-struct FxShared {                      // LDS on the device
+struct FxShared {                      // LDS on the device (~100 KB: dynamic shared memory)
   int16_t tx[2][FX_TX], in2[16];
   int32_t part[FX_NMIX1][FX_THREADS], part2[FX_NMIX1][16];
   int mx_elim[12], mx_cxt[12], mx_pr[12], apm_index[6];
   int pr, parity;
   uint32_t fails, failz, failcount;
   int map_result[FX_NMAPS], isMatch;
+  // per-slot registers of the context maps and their StateMaps, resident for the chunk (home: FxMapDev / FxMapDev::sm)
+  uint32_t mcp[FX_NMAPS][8], mcp0[FX_NMAPS][8], mrunp[FX_NMAPS][8], mcxt[FX_NMAPS][8];
+  int msmc[FX_NMAPS][8];
+  uint32_t sm[FX_NSLOTS][256];
 };
 
 struct FxBit {                         // uniform per-bit values every thread derives from the byte stream
@@ -129,8 +133,10 @@ FX_HD uint32_t fxd_bucket_get(uint8_t* b, int A, uint16_t ch, int keep) {
   return (uint32_t)(2 * A + 1 + 7 * bi);
 }
 FX_HD void fxd_map_unit(FxDev* d, FxShared* sh, const FxBit& u, int k) {
-  FxMapDev* x = &d->maps[k];
+  const FxMapDev* x = &d->maps[k];
   if (!u.normal) { sh->map_result[k] = 0; return; }
+  uint32_t *cp = sh->mcp[k], *cp0 = sh->mcp0[k], *runp = sh->mrunp[k], *cxt = sh->mcxt[k];
+  int* sm_cxt = sh->msmc[k];
   int16_t* tx = sh->tx[sh->parity ^ 1] + x->tx_off;
   float* ex = u.orow + x->exp_off;
   uint8_t* t = x->t;
@@ -139,56 +145,56 @@ FX_HD void fxd_map_unit(FxDev* d, FxShared* sh, const FxBit& u, int k) {
   int result = 0;
   for (int i = 0; i < x->C; ++i) {
     const int s = x->slot_base + i;
-    if (u.boundary) x->cxt[i] = u.rec->cx[s];
+    if (u.boundary) cxt[i] = u.rec->cx[s];
     int n = 0, e = 0;
 #define ADD(v) do { const int v_ = (v); tx[n++] = (int16_t)v_; ex[e++] = fxd_export(d, v_); } while (0)
 #define ADDQ(v) do { tx[n++] = (int16_t)(v); } while (0)
     if ((u.rec->skip[s >> 5] >> (s & 31)) & 1) {   // mix4 :1099-1107
       ADD(0); if (x->u) ADD(0); ADD(0); ADD(0); ADDQ(64); ADD(0);
     } else {
-      if (x->cp[i] != FX_NONE) t[x->cp[i]] = x->nn[t[x->cp[i]] * 4 + y];
+      if (cp[i] != FX_NONE) t[cp[i]] = x->nn[t[cp[i]] * 4 + y];
       int state = 0;
-      if (bpos > 1 && t[x->runp[i]] == 0) x->cp[i] = FX_NONE;
+      if (bpos > 1 && t[runp[i]] == 0) cp[i] = FX_NONE;
       else {
-        const uint16_t chk = (uint16_t)((x->cxt[i] >> 16) ^ (uint32_t)i);
+        const uint16_t chk = (uint16_t)((cxt[i] >> 16) ^ (uint32_t)i);
         if (bpos == 2 || bpos == 5) {
-          const size_t b = (size_t)((x->cxt[i] + (uint32_t)c0) & x->tmask) * (size_t)x->B;
-          x->cp0[i] = x->cp[i] = (uint32_t)(b + fxd_bucket_get(t + b, x->A, chk, x->kep));
+          const size_t b = (size_t)((cxt[i] + (uint32_t)c0) & x->tmask) * (size_t)x->B;
+          cp0[i] = cp[i] = (uint32_t)(b + fxd_bucket_get(t + b, x->A, chk, x->kep));
         } else if (bpos) {
           const uint32_t smask = (0x31031010u >> (bpos << 2)) & 0x0F;   // getStateByteLocation :959-964
-          x->cp[i] = x->cp0[i] + smask + ((uint32_t)c0 & smask);
+          cp[i] = cp0[i] + smask + ((uint32_t)c0 & smask);
         } else {
-          size_t b = (size_t)((x->cxt[i] + (uint32_t)c0) & x->tmask) * (size_t)x->B;
-          x->cp0[i] = x->cp[i] = (uint32_t)(b + fxd_bucket_get(t + b, x->A, chk, x->kep));
-          if (t[x->cp0[i] + 3] == 2) {  // second visit: create the histories for bits 2-7 of the byte seen the first time
-            const int c = t[x->cp0[i] + 4] + 256;
-            b = (size_t)((x->cxt[i] + (uint32_t)(c >> 6)) & x->tmask) * (size_t)x->B;
+          size_t b = (size_t)((cxt[i] + (uint32_t)c0) & x->tmask) * (size_t)x->B;
+          cp0[i] = cp[i] = (uint32_t)(b + fxd_bucket_get(t + b, x->A, chk, x->kep));
+          if (t[cp0[i] + 3] == 2) {  // second visit: create the histories for bits 2-7 of the byte seen the first time
+            const int c = t[cp0[i] + 4] + 256;
+            b = (size_t)((cxt[i] + (uint32_t)(c >> 6)) & x->tmask) * (size_t)x->B;
             uint8_t* p = t + b + fxd_bucket_get(t + b, x->A, chk, x->kep);
             p[0] = (uint8_t)(1 + ((c >> 5) & 1));
             p[1 + ((c >> 5) & 1)] = (uint8_t)(1 + ((c >> 4) & 1));
             p[3 + ((c >> 4) & 3)] = (uint8_t)(1 + ((c >> 3) & 1));
-            b = (size_t)((x->cxt[i] + (uint32_t)(c >> 3)) & x->tmask) * (size_t)x->B;
+            b = (size_t)((cxt[i] + (uint32_t)(c >> 3)) & x->tmask) * (size_t)x->B;
             p = t + b + fxd_bucket_get(t + b, x->A, chk, x->kep);
             p[0] = (uint8_t)(1 + ((c >> 2) & 1));
             p[1 + ((c >> 2) & 1)] = (uint8_t)(1 + ((c >> 1) & 1));
             p[3 + ((c >> 1) & 3)] = (uint8_t)(1 + (c & 1));
-            t[x->cp0[i] + 6] = 0;
+            t[cp0[i] + 6] = 0;
           }
-          uint8_t* run = t + x->runp[i];  // run count of the previous context
+          uint8_t* run = t + runp[i];  // run count of the previous context
           if (run[0] == 0) { run[0] = 2; run[1] = (uint8_t)c1; }
           else if (run[1] != c1) { run[0] = 1; run[1] = (uint8_t)c1; }
           else if (run[0] < 254) run[0] = (uint8_t)(run[0] + 2);
-          x->runp[i] = x->cp0[i] + 3;
+          runp[i] = cp0[i] + 3;
         }
-        state = t[x->cp[i]];
+        state = t[cp[i]];
       }
       if (state == 0) {  // mix3 :1077-1097
         ADD(0); if (x->u) ADD(0); ADD(0); ADD(0); ADDQ(64);
       } else {
-        uint32_t* smt = x->sm + 256 * i;   // StateMap::set :693-700
-        uint32_t* p = &smt[x->sm_cxt[i]];
+        uint32_t* smt = sh->sm[x->slot_base + i];   // StateMap::set :693-700
+        uint32_t* p = &smt[sm_cxt[i]];
         *p += (uint32_t)(y << 19) - (*p >> 13);
-        x->sm_cxt[i] = state;
+        sm_cxt[i] = state;
         const int p1 = (int)(smt[state] >> 20);
         ADD(tab[FX_TAB_ST1 + p1]);
         if (x->u) ADD(tab[FX_TAB_ST2 + p1]);
@@ -197,7 +203,7 @@ FX_HD void fxd_map_unit(FxDev* d, FxShared* sh, const FxBit& u, int k) {
         ADDQ(0);
         result++;
       }
-      const uint8_t* run = t + x->runp[i];
+      const uint8_t* run = t + runp[i];
       const int bposshift = 7 - bpos, c0shift_bpos = (c0 << 1) ^ (256 >> bposshift);
       const int b = c0shift_bpos ^ (run[1] >> bposshift);
       ADD(b <= 1 ? tab[FX_TAB_RC1 + run[0] + b * 256] : 0);
@@ -655,6 +661,15 @@ FX_HD void fxd_load_shared(const FxDev* d, FxShared* sh, int tid) {
   if (tid < 12) { sh->mx_elim[tid] = d->mx_elim[tid]; sh->mx_cxt[tid] = d->mx_cxt[tid]; sh->mx_pr[tid] = d->mx_pr[tid]; }
   if (tid < 6) sh->apm_index[tid] = d->apm_index[tid];
   if (tid == 0) { sh->pr = d->pr; sh->parity = d->parity; sh->fails = d->fails; sh->failz = d->failz; sh->failcount = d->failcount; sh->isMatch = 0; }
+  for (int i = tid; i < FX_NMAPS * 8; i += FX_THREADS) {
+    const FxMapDev* x = &d->maps[i >> 3];
+    const int j = i & 7;
+    sh->mcp[i >> 3][j] = x->cp[j]; sh->mcp0[i >> 3][j] = x->cp0[j]; sh->mrunp[i >> 3][j] = x->runp[j]; sh->mcxt[i >> 3][j] = x->cxt[j]; sh->msmc[i >> 3][j] = x->sm_cxt[j];
+  }
+  for (int k = 0; k < FX_NMAPS; k++) {
+    const FxMapDev* x = &d->maps[k];
+    for (int i = tid; i < x->C * 256; i += FX_THREADS) (&sh->sm[x->slot_base][0])[i] = x->sm[i];
+  }
 }
 FX_HD void fxd_store_shared(FxDev* d, const FxShared* sh, int tid) {
   for (int i = tid; i < 2 * FX_TX; i += FX_THREADS) (&d->tx[0][0])[i] = (&sh->tx[0][0])[i];
@@ -662,6 +677,15 @@ FX_HD void fxd_store_shared(FxDev* d, const FxShared* sh, int tid) {
   if (tid < 12) { d->mx_elim[tid] = sh->mx_elim[tid]; d->mx_cxt[tid] = sh->mx_cxt[tid]; d->mx_pr[tid] = sh->mx_pr[tid]; }
   if (tid < 6) d->apm_index[tid] = sh->apm_index[tid];
   if (tid == 0) { d->pr = sh->pr; d->parity = sh->parity; d->fails = sh->fails; d->failz = sh->failz; d->failcount = sh->failcount; }
+  for (int i = tid; i < FX_NMAPS * 8; i += FX_THREADS) {
+    FxMapDev* x = &d->maps[i >> 3];
+    const int j = i & 7;
+    x->cp[j] = sh->mcp[i >> 3][j]; x->cp0[j] = sh->mcp0[i >> 3][j]; x->runp[j] = sh->mrunp[i >> 3][j]; x->cxt[j] = sh->mcxt[i >> 3][j]; x->sm_cxt[j] = sh->msmc[i >> 3][j];
+  }
+  for (int k = 0; k < FX_NMAPS; k++) {
+    FxMapDev* x = &d->maps[k];
+    for (int i = tid; i < x->C * 256; i += FX_THREADS) x->sm[i] = (&sh->sm[x->slot_base][0])[i];
+  }
 }
 
 // The uniform values of the update of bit q (0..8n-1) of a chunk of n bytes. Row q + 1 of the output receives the

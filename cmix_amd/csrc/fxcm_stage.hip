@@ -23,7 +23,8 @@ extern "C" int cmx_device_count(void);
 
 __global__ __launch_bounds__(FX_THREADS) void cmx_fxcm_chunk_kernel(FxDev* d, const uint8_t* bytes, const FxByteRec* recs, const int16_t* lstmpr,
                                                                     const uint8_t* lstmex, float* out, long ostride, int n) {
-  __shared__ FxShared sh;
+  extern __shared__ __attribute__((aligned(16))) unsigned char fx_smem[];   // sizeof(FxShared) > 64 KB: dynamic
+  FxShared& sh = *(FxShared*)fx_smem;
   const int tid = threadIdx.x;
   const int nbits = 8 * n, blpos0 = d->blpos, lastbyte0 = d->lastbyte, have0 = d->have_rec;
   fxd_load_shared(d, &sh, tid);
@@ -118,6 +119,7 @@ cmx_fxcm_t* cmx_fxcm_create(const char* dictionary_path, int device) {
   ok = ok && hipMalloc((void**)&h->d_dev, sizeof(FxDev)) == hipSuccess;
   ok = ok && hipMemcpy(h->d_dev, &host, sizeof(FxDev), hipMemcpyHostToDevice) == hipSuccess;
   for (int i = 0; ok && i < FX_STAGE_BUFS; i++) ok = hipEventCreateWithFlags(&h->done[i], hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipFuncSetAttribute((const void*)cmx_fxcm_chunk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(FxShared)) == hipSuccess;
   ok = ok && hipDeviceSynchronize() == hipSuccess;
   if (!ok) { cmx_set_err("cmx_fxcm_create: allocation / init failed (the stage needs ~4.4 GB of HBM)"); cmx_fxcm_destroy(h); return nullptr; }
   h->parser = fxp_create(dictionary_path);
@@ -144,7 +146,7 @@ int cmx_fxcm_run(cmx_fxcm_t* h, const uint8_t* bytes, const uint8_t* d_bytes, si
   if (fxp_run(h->parser, bytes, (int)nbytes, h->h_recs[b]) != 0) { cmx_set_err("cmx_fxcm_run: parser emitted a context count a map does not expect"); return 1; }
   hipStream_t s = (hipStream_t)stream;
   if (hipMemcpyAsync(h->d_recs[b], h->h_recs[b], nbytes * sizeof(FxByteRec), hipMemcpyHostToDevice, s) != hipSuccess) { cmx_set_err("cmx_fxcm_run: record upload failed"); return 1; }
-  hipLaunchKernelGGL(cmx_fxcm_chunk_kernel, dim3(1), dim3(FX_THREADS), 0, s, h->d_dev, d_bytes, h->d_recs[b], d_lstmpr, d_lstmex, d_probs + 3, (long)pstride,
+  hipLaunchKernelGGL(cmx_fxcm_chunk_kernel, dim3(1), dim3(FX_THREADS), sizeof(FxShared), s, h->d_dev, d_bytes, h->d_recs[b], d_lstmpr, d_lstmex, d_probs + 3, (long)pstride,
                      (int)nbytes);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { cmx_set_err(std::string("cmx_fxcm_run: ") + hipGetErrorString(e)); return 1; }
