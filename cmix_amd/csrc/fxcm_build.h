@@ -54,6 +54,7 @@ void build(FxDev& h, Policy& P) {
     else { x.tmask = (df.size >> 6) - 1; buckets = (size_t)(df.size >> 6) + 64; }
     x.t = (uint8_t*)P.zalloc(buckets * (size_t)x.B);
     x.slot_base = slot; x.tx_off = tx; x.exp_off = ex;
+    for (int i = 0; i < x.C; i++) { h.slot_map[slot + i] = (uint8_t)k; h.slot_idx[slot + i] = (uint8_t)i; }
     slot += x.C; tx += x.C * (5 + x.u); ex += x.C * (4 + x.u);
     const uint8_t* nn = sta(df.sta);
     x.nn = sta_dev[df.sta];
@@ -138,6 +139,7 @@ void build(FxDev& h, Policy& P) {
     P.pattern16(h.apm_t[j], n, pat, 33);
   }
   h.pr = 2048;
+  h.slot_parallel = 1;
   for (int i = 0; i < FX_OUTPUTS; i++) h.pending[i] = 0.5f;   // model_predictions(0.5f, num_models) :94
   h.rec.AH2 = 0x765BA55C;                                      // :3262
 }

@@ -31,7 +31,7 @@
 
 #define FX_NONE 0xffffffffu
 enum { FX_THREADS = 256, FX_BMASK = 0xffffff,
-       FX_U_SSCM = 31, FX_U_MATCH = 38, FX_U_RCM = 39, FX_U_LSTM = 40, FX_U_MIX10 = 41, FX_U_MIX11 = 42, FX_U_APM = 43, FX_UNITS = 49,
+       FX_U_SSCM = 81, FX_U_MATCH = 88, FX_U_RCM = 89, FX_U_LSTM = 90, FX_U_MIX10 = 91, FX_U_MIX11 = 92, FX_U_APM = 93, FX_UNITS = 99, FX_TRAIN0 = 128,
        FX_TAB_RC1 = 0, FX_TAB_ST1 = 512, FX_TAB_ST2 = 512 + 4096, FX_TAB_ST32 = 512 + 8192, FX_TAB_ST8 = 512 + 8192 + 256, FX_TAB_LEN = 512 + 8192 + 512 };
 
 struct FxMapDev {
@@ -49,6 +49,8 @@ struct FxMtf { int root, index, prev[4], next[4]; };
 
 struct FxDev {                         // everything a stream owns on the device (global memory)
   FxMapDev maps[FX_NMAPS];
+  uint8_t slot_map[FX_NSLOTS], slot_idx[FX_NSLOTS];   // slot -> map (mixing order), context index within the map
+  int slot_parallel;                   // 1: one lane per context slot with a per-map serial fallback; 0: one lane per map
   const int16_t *squash, *stretch;     // squash[d + 2047], stretch[p]
   const uint8_t* wrt;                  // byte -> 2-bit class [256], 3-bit class [256] of cmix's WRT-swapped alphabet
   uint16_t* sscm_data[FX_NSSCM]; int sscm_mask[FX_NSSCM], sscm_ctx[FX_NSSCM], sscm_B[FX_NSSCM], sscm_bcount[FX_NSSCM], sscm_cp[FX_NSSCM];
@@ -74,7 +76,9 @@ struct FxShared {                      // LDS on the device (~100 KB: dynamic sh
   int mx_elim[12], mx_cxt[12], mx_pr[12], apm_index[6];
   int pr, parity;
   uint32_t fails, failz, failcount;
-  int map_result[FX_NMAPS], isMatch;
+  int slot_res[FX_NSLOTS], isMatch;
+  int32_t touched[FX_NSLOTS][5];       // buckets a context will touch this bit (-1: none), for the conflict check
+  int mconf[FX_NMAPS];                 // two contexts of the map touch the same bucket this bit: the map runs serially
   // per-slot registers of the context maps and their StateMaps, resident for the chunk (home: FxMapDev / FxMapDev::sm)
   uint32_t mcp[FX_NMAPS][8], mcp0[FX_NMAPS][8], mrunp[FX_NMAPS][8], mcxt[FX_NMAPS][8];
   int msmc[FX_NMAPS][8];
@@ -132,20 +136,19 @@ FX_HD uint32_t fxd_bucket_get(uint8_t* b, int A, uint16_t ch, int keep) {
   for (int k = 0; k < 7; k++) h[k] = 0;
   return (uint32_t)(2 * A + 1 + 7 * bi);
 }
-FX_HD void fxd_map_unit(FxDev* d, FxShared* sh, const FxBit& u, int k) {
+// one context of one map for one bit: ContextMap::mix's loop body (mix1 / mix :1110-1173)
+FX_HD void fxd_map_ctx(FxDev* d, FxShared* sh, const FxBit& u, int k, int i) {
   const FxMapDev* x = &d->maps[k];
-  if (!u.normal) { sh->map_result[k] = 0; return; }
   uint32_t *cp = sh->mcp[k], *cp0 = sh->mcp0[k], *runp = sh->mrunp[k], *cxt = sh->mcxt[k];
   int* sm_cxt = sh->msmc[k];
-  int16_t* tx = sh->tx[sh->parity ^ 1] + x->tx_off;
-  float* ex = u.orow + x->exp_off;
+  int16_t* tx = sh->tx[sh->parity ^ 1] + x->tx_off + i * (5 + x->u);
+  float* ex = u.orow + x->exp_off + i * (4 + x->u);
   uint8_t* t = x->t;
   const int16_t* tab = x->tab;
   const int y = u.y, bpos = u.bpos, c0 = u.c0, c1 = u.lastbyte;
   int result = 0;
-  for (int i = 0; i < x->C; ++i) {
+  {
     const int s = x->slot_base + i;
-    if (u.boundary) cxt[i] = u.rec->cx[s];
     int n = 0, e = 0;
 #define ADD(v) do { const int v_ = (v); tx[n++] = (int16_t)v_; ex[e++] = fxd_export(d, v_); } while (0)
 #define ADDQ(v) do { tx[n++] = (int16_t)(v); } while (0)
@@ -208,9 +211,71 @@ FX_HD void fxd_map_unit(FxDev* d, FxShared* sh, const FxBit& u, int k) {
       const int b = c0shift_bpos ^ (run[1] >> bposshift);
       ADD(b <= 1 ? tab[FX_TAB_RC1 + run[0] + b * 256] : 0);
     }
-    tx += n; ex += e;
+    sh->slot_res[s] = result;
   }
-  sh->map_result[k] = result;
+}
+
+
+// Which buckets will context i of map k touch in this bit? Read-only. Serial order inside a map only matters when two of
+// its contexts touch the same bucket (checksum replacement, the last-used byte, shared state bytes), so: every context
+// lane lists its buckets (fxd_map_touch), lanes compare lists within their map (fxd_map_conflict), and a map with an
+// overlap is walked by its first lane in context order while all other maps run one lane per context (fxd_map_run).
+// The list: the bucket of the state byte being updated, the bucket holding the run bytes, at bits 0 / 2 / 5 the bucket
+// about to be looked up, and at bit 0 the two buckets a second visit creates histories in -- known from a read-only
+// look at the slot the lookup will return, which is exact unless an earlier context writes that bucket first, i.e.
+// unless there is an overlap.
+FX_HD void fxd_map_touch(FxDev* d, FxShared* sh, const FxBit& u, int s) {
+  const int k = d->slot_map[s], i = d->slot_idx[s];
+  const FxMapDev* x = &d->maps[k];
+  int32_t* T = sh->touched[s];
+  for (int j = 0; j < 5; j++) T[j] = -1;
+  if (i == 0) sh->mconf[k] = 0;
+  if (!u.normal) return;
+  if (u.boundary) sh->mcxt[k][i] = u.rec->cx[s];
+  if ((u.rec->skip[s >> 5] >> (s & 31)) & 1) return;
+  const int sh_b = x->B == 32 ? 5 : x->B == 64 ? 6 : 7;
+  const uint32_t cp = sh->mcp[k][i], runp = sh->mrunp[k][i], cxt = sh->mcxt[k][i];
+  if (cp != FX_NONE) T[0] = (int32_t)(cp >> sh_b);
+  T[1] = (int32_t)(runp >> sh_b);
+  const int bpos = u.bpos;
+  if (bpos > 1 && x->t[runp] == 0) return;
+  if (bpos == 0 || bpos == 2 || bpos == 5) {
+    const uint32_t nb = (cxt + (uint32_t)u.c0) & x->tmask;
+    T[2] = (int32_t)nb;
+    if (bpos == 0) {
+      const uint8_t* b = x->t + (size_t)nb * (size_t)x->B;
+      const uint16_t* chk = (const uint16_t*)b;
+      const uint16_t ch = (uint16_t)((cxt >> 16) ^ (uint32_t)i);
+      const int A = x->A, last = b[2 * A];
+      int slot = -1;
+      if (chk[last & 15] == ch) slot = last & 15;
+      else for (int j = 0; j < A; ++j) if (chk[j] == ch) { slot = j; break; }
+      if (slot >= 0 && b[2 * A + 1 + 7 * slot + 3] == 2) {
+        const int c = b[2 * A + 1 + 7 * slot + 4] + 256;
+        T[3] = (int32_t)((cxt + (uint32_t)(c >> 6)) & x->tmask);
+        T[4] = (int32_t)((cxt + (uint32_t)(c >> 3)) & x->tmask);
+      }
+    }
+  }
+}
+FX_HD void fxd_map_conflict(FxDev* d, FxShared* sh, const FxBit& u, int s) {
+  if (!u.normal) return;
+  const int k = d->slot_map[s];
+  const FxMapDev* x = &d->maps[k];
+  const int32_t* T = sh->touched[s];
+  for (int o = x->slot_base; o < x->slot_base + x->C; o++) {
+    if (o == s) continue;
+    const int32_t* O = sh->touched[o];
+    for (int a = 0; a < 5; a++)
+      if (T[a] >= 0)
+        for (int b = 0; b < 5; b++) if (T[a] == O[b]) { sh->mconf[k] = 1; return; }
+  }
+}
+FX_HD void fxd_map_run(FxDev* d, FxShared* sh, const FxBit& u, int s) {
+  const int k = d->slot_map[s], i = d->slot_idx[s];
+  if (!u.normal) { sh->slot_res[s] = 0; return; }
+  if (!sh->mconf[k] && d->slot_parallel) fxd_map_ctx(d, sh, u, k, i);
+  else if (i == 0) for (int j = 0; j < d->maps[k].C; j++) fxd_map_ctx(d, sh, u, k, j);
 }
 
 // ---------------------------------------------------------------- SmallStationaryContextMap :831-863
@@ -507,16 +572,19 @@ FX_HD int fxd_apm_p(FxDev* d, FxShared* sh, int j, int pr, int cxt) {
 }
 
 // ---------------------------------------------------------------- the phases
-FX_HD void fxd_phase1(FxDev* d, FxShared* sh, const FxBit& u, int tid) {
-  if (tid < FX_NMAPS) fxd_map_unit(d, sh, u, tid);
+// phase 1 in three barrier-separated steps: a = bucket lists + everything that is not a context map, b = overlap check, c = the maps
+FX_HD void fxd_phase1a(FxDev* d, FxShared* sh, const FxBit& u, int tid) {
+  if (tid < FX_NSLOTS) fxd_map_touch(d, sh, u, tid);
   else if (tid < FX_U_MATCH) fxd_sscm_unit(d, sh, u, tid - FX_U_SSCM);
   else if (tid == FX_U_MATCH) fxd_match_unit(d, sh, u);
   else if (tid == FX_U_RCM) fxd_rcm_unit(d, sh, u);
   else if (tid == FX_U_LSTM) { const FxLayout l = fxd_layout(d, u.normal); sh->tx[sh->parity ^ 1][l.tx_lstm] = d->stretch[u.lstmpr]; }
   else if (tid == FX_U_MIX10 || tid == FX_U_MIX11) fxd_train_small(d, sh, u, 10 + tid - FX_U_MIX10);
   else if (tid < FX_UNITS) fxd_apm_update(d, sh, u, tid - FX_U_APM);
-  else if (tid >= 64) fxd_train_rows(d, sh, u, tid - 64, FX_THREADS - 64);
+  else if (tid >= FX_TRAIN0) fxd_train_rows(d, sh, u, tid - FX_TRAIN0, FX_THREADS - FX_TRAIN0);
 }
+FX_HD void fxd_phase1b(FxDev* d, FxShared* sh, const FxBit& u, int tid) { if (tid < FX_NSLOTS) fxd_map_conflict(d, sh, u, tid); }
+FX_HD void fxd_phase1c(FxDev* d, FxShared* sh, const FxBit& u, int tid) { if (tid < FX_NSLOTS) fxd_map_run(d, sh, u, tid); }
 FX_HD void fxd_phase2(FxDev* d, FxShared* sh, const FxBit& u, int tid) {
   if (tid != 0) return;
   const int e_l[8] = {1830, 1997, 1973, 1851, 1897, 1690, 1998, 1842};   // :3222
@@ -540,12 +608,22 @@ FX_HD void fxd_phase2(FxDev* d, FxShared* sh, const FxBit& u, int tid) {
     int skipped = 0;
     for (int i = 0; i < 3; i++) skipped |= (int)((r->skip[(b0 + i) >> 5] >> ((b0 + i) & 31)) & 1);
     if (skipped) ordX = 2;
-    ordX += sh->map_result[0];
+    int mr[6];   // ContextMap::mix's return value (contexts with a known state) of cmC2[0..5], cmC2[13], cmC2[14]
+    const int which[8] = {0, 1, 2, 3, 4, 5, 21, 23};
+    int res8[8];
+    for (int q = 0; q < 8; q++) {
+      const FxMapDev* x = &d->maps[which[q]];
+      int v = 0;
+      for (int i = 0; i < x->C; i++) v += sh->slot_res[x->slot_base + i];
+      res8[q] = v;
+    }
+    for (int q = 0; q < 6; q++) mr[q] = res8[q];
+    ordX += mr[0];
     if (ordX == 3) ordX = 2;
-    ordX += sh->map_result[1] + sh->map_result[2] + sh->map_result[3];
-    ordW = sh->map_result[4] + sh->map_result[5];
+    ordX += mr[1] + mr[2] + mr[3];
+    ordW = mr[4] + mr[5];
     if (ordW > 3) ordW = 3;
-    ordW += sh->map_result[21] + sh->map_result[23];   // cmC2[13], cmC2[14]
+    ordW += res8[6] + res8[7];
   }
   const uint32_t s2 = r->s2, s3 = r->s3, s3R = r->s3R, BrFc = r->BrFc, words = r->words, FcIdx = r->FcIdx, isPar = r->isPar;
   const uint32_t isMatch = (uint32_t)sh->isMatch;

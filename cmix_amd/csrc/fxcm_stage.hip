@@ -11,6 +11,7 @@
 // host against the oracle; tests/test_zgpu_fxcm_stage.py runs the kernel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <string>
 #include <vector>
@@ -32,7 +33,11 @@ __global__ __launch_bounds__(FX_THREADS) void cmx_fxcm_chunk_kernel(FxDev* d, co
   __syncthreads();
   for (int q = 0; q < nbits; q++) {
     const FxBit u = fxd_bit(d, bytes, recs, lstmpr, lstmex, out, ostride, nbits, q, blpos0, lastbyte0, have0);
-    fxd_phase1(d, &sh, u, tid);
+    fxd_phase1a(d, &sh, u, tid);
+    __syncthreads();
+    fxd_phase1b(d, &sh, u, tid);
+    __syncthreads();
+    fxd_phase1c(d, &sh, u, tid);
     __syncthreads();
     fxd_phase2(d, &sh, u, tid);
     __syncthreads();
@@ -115,6 +120,8 @@ cmx_fxcm_t* cmx_fxcm_create(const char* dictionary_path, int device) {
   h->device = device;
   FxDev host;
   fxb::build(host, h->pol);
+  const char* serial = getenv("CMX_FXCM_SERIAL_MAPS");   // A/B switch: one lane per map instead of one per context slot
+  if (serial && serial[0] == '1') host.slot_parallel = 0;
   bool ok = h->pol.ok;
   ok = ok && hipMalloc((void**)&h->d_dev, sizeof(FxDev)) == hipSuccess;
   ok = ok && hipMemcpy(h->d_dev, &host, sizeof(FxDev), hipMemcpyHostToDevice) == hipSuccess;

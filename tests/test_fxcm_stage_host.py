@@ -55,8 +55,11 @@ def oracle_rows(data, lstmpr, lstmex, dictionary=None, blpos=0):
     return rows
 
 
-def run_emul(L, data, lstmpr, lstmex, chunks, seed=12345, dictionary=None, blpos=0):
+def run_emul(L, data, lstmpr, lstmex, chunks, seed=12345, dictionary=None, blpos=0, serial_maps=False, stats=None):
     h = L.fxe_create(dictionary, seed)
+    if serial_maps:
+        L.fxe_set_serial_maps.argtypes = [C.c_void_p, C.c_int]
+        L.fxe_set_serial_maps(h, 1)
     if blpos:
         L.fxe_set_blpos.argtypes = [C.c_void_p, C.c_int]
         L.fxe_set_blpos(h, blpos)
@@ -72,6 +75,11 @@ def run_emul(L, data, lstmpr, lstmex, chunks, seed=12345, dictionary=None, blpos
         o = out[8 * pos:8 * (pos + n)]
         assert L.fxe_run(h, data[pos:pos + n].ctypes.data, n, pr.ctypes.data, ex.ctypes.data, o.ctypes.data, 431) == 0
         pos += n
+    if stats is not None:
+        st = np.zeros(2, np.uint64)
+        L.fxe_conflict_stats.argtypes = [C.c_void_p, C.c_void_p]
+        L.fxe_conflict_stats(h, st.ctypes.data)
+        stats.extend(int(v) for v in st)
     L.fxe_destroy(h)
     return out[:8 * pos]
 
@@ -92,8 +100,12 @@ def test_text_vs_oracle_ragged_chunks():
     data = np.frombuffer(synth.enwik_like(6000, 31), np.uint8)
     pr, ex = hints(8 * len(data), 7)
     want = oracle_rows(data, pr, ex)
-    got = run_emul(L, data, pr, ex, [1, 1, 7, 100, 1000, 3, 2000, 4000])
+    stats = []
+    got = run_emul(L, data, pr, ex, [1, 1, 7, 100, 1000, 3, 2000, 4000], stats=stats)
     compare(got, want, "enwik-like text")
+    # the slot-parallel path is the one exercised, and its serial fallback (two contexts of a map in one bucket) occurs
+    assert 0 < stats[1] < stats[0] // 4, stats
+    compare(run_emul(L, data[:2500], pr, ex, [2500], serial_maps=True), want, "one lane per map")
 
 
 @pytest.mark.parametrize("flavour", ["binary", "runs", "markup"])
