@@ -126,6 +126,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)   # (PPMd + LSTM of the first timed chunk) weighs 2 %
     ap.add_argument("--chunk-bytes", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fxcm-device", action="store_true",
+                    help="also run the fxcm family as a device stage (columns 3..433) instead of its stand-in; off by default until the stage has been timed on a GPU")
     ap.add_argument("--streams-per-gpu", type=int, default=1,
                     help="independent input streams per GPU (throughput mode for multi-file jobs); the headline "
                          "metric is 1 stream per GPU")
@@ -155,7 +157,7 @@ def main():
     cb = a.chunk_bytes * 8
     from cmix_amd.pipeline import StreamPipeline
     S = a.streams_per_gpu
-    pipes = [StreamPipeline(local, shard.shard_seed(rank, s, S), a.chunk_bytes, nsteps) for s in range(S)]
+    pipes = [StreamPipeline(local, shard.shard_seed(rank, s, S), a.chunk_bytes, nsteps, fxcm_device=a.fxcm_device) for s in range(S)]
     pipe = pipes[0]  # rank r = GPU r owns streams r*S .. r*S+S-1
 
     def step(i):
@@ -221,6 +223,9 @@ def main():
                          "kernel": "cmx_mixnet_chunk_kernel", "avg_kernel_ms": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": algo},
         }
+        if a.fxcm_device:
+            out["stage_us_per_bit"]["fxcm"] = pipe.pipe.fxcm_total_ms() / a.steps * 1e3 / cb
+            out["config"]["workload"] += "; --fxcm-device: fxcm's columns (3..433) come from the fxcm device stage (host text parser + cmx_fxcm_chunk_kernel), only paq8's are a stand-in"
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_port(pipe.probs, pipe.bits, pipe.text, pipe.vocab)
             ref = cpu_reference_full(pipe.text)

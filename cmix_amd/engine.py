@@ -131,6 +131,10 @@ def lib():
         L.cmx_pipeline_stage_totals.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.cmx_pipeline_pretrain.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.cmx_pipeline_sync.argtypes = [C.c_void_p]
+        L.cmx_pipeline_enable_fxcm.argtypes = [C.c_void_p, C.c_char_p]
+        L.cmx_pipeline_fxcm_enabled.argtypes = [C.c_void_p]
+        L.cmx_pipeline_finish_cols.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.cmx_pipeline_fxcm_total_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.cmx_pipeline_last_stage_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.cmx_probe_libm.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
         _lib = L
@@ -405,6 +409,22 @@ class Pipeline:
         assert p_out.is_cuda and p_out.dtype == torch.float32 and p_out.is_contiguous() and p_out.numel() == 8 * n
         if lib().cmx_pipeline_submit(self.h, data.ctypes.data, n, layer0.data_ptr(), p_out.data_ptr()):
             raise CmxError(last_error())
+
+    def enable_fxcm(self, dictionary_path=None):
+        """Run the fxcm family as a device stage (columns 3..433) instead of taking its columns from the caller; before the first chunk."""
+        if lib().cmx_pipeline_enable_fxcm(self.h, dictionary_path.encode() if isinstance(dictionary_path, str) else dictionary_path):
+            raise CmxError(last_error())
+
+    def finish_cols(self, cols, first_col, p_out):
+        """finish() with host rows covering layer-0 columns first_col .. first_col + cols.shape[1] - 1 only."""
+        cols = np.ascontiguousarray(cols, np.float32)
+        if lib().cmx_pipeline_finish_cols(self.h, cols.ctypes.data, first_col, cols.shape[1], p_out.data_ptr()):
+            raise CmxError(last_error())
+
+    def fxcm_total_ms(self):
+        ms = C.c_double(0)
+        lib().cmx_pipeline_fxcm_total_ms(self.h, C.byref(ms))
+        return ms.value
 
     def pretrain(self, data):
         data = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8))

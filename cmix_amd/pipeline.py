@@ -3,8 +3,9 @@ PPMd on a host core, then per chunk the context/small-model stage, the LSTM byte
 mixing network on their own HIP streams, each writing its columns of the chunk's layer-0 matrix in place.
 Used by bench.py, scripts/gpu_multistream.py; tests/test_gpu_pipeline.py does the same by hand.
 
-Until the fxcm and paq8 stages exist their columns (3..2024) are a seeded stand-in with the
-reference's value grid (k/4095), generated on the device (`standin_columns`)."""
+Model columns without a stage behind them are a seeded stand-in with the reference's value grid (k/4095), generated on
+the device (`standin_columns`): paq8's (434..2024) always, fxcm's (3..433) unless the fxcm device stage is enabled
+(`fxcm_device=True`, cmx_pipeline_enable_fxcm)."""
 import numpy as np
 
 from . import engine as E
@@ -35,7 +36,7 @@ class StreamPipeline:
     """One input stream on one GPU: operand buffers for `nchunks` chunks; step(i) hands chunk i to the native
     orchestration (cmx_pipeline_submit: PPMd host stage + three device stages on their own HIP streams)."""
 
-    def __init__(self, device_index, seed, chunk_bytes, nchunks):
+    def __init__(self, device_index, seed, chunk_bytes, nchunks, fxcm_device=False):
         import torch
         self.torch = torch
         self.dev = torch.device("cuda", device_index)
@@ -48,6 +49,8 @@ class StreamPipeline:
         self.p_out = torch.empty(self.cb * nchunks, dtype=torch.float32, device=self.dev)
         torch.cuda.synchronize(self.dev)  # the stand-in columns are complete before any submit
         self.pipe = E.Pipeline(self.vocab, device_index, chunk_bytes)
+        if fxcm_device:  # the fxcm stage writes columns 3..433 itself (the stand-in there is overwritten)
+            self.pipe.enable_fxcm(None)
         self.stage_log = []
 
     def step(self, i):
