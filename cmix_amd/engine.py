@@ -42,6 +42,11 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.cmx_last_error.restype = C.c_char_p
         L.cmx_version.restype = C.c_char_p
+        L.cmx_p8cm2_create.restype = C.c_void_p
+        L.cmx_p8cm2_create.argtypes = [C.c_int, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cmx_p8cm2_destroy.argtypes = [C.c_void_p]
+        L.cmx_p8cm2_hash.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.cmx_p8cm2_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.cmx_fxcm_create.restype = C.c_void_p
         L.cmx_fxcm_create.argtypes = [C.c_char_p, C.c_int]
         L.cmx_fxcm_destroy.argtypes = [C.c_void_p]
@@ -736,3 +741,51 @@ class Fxcm:
     def sync(self):
         if lib().cmx_fxcm_sync(self.h):
             raise CmxError(last_error())
+
+
+class P8ContextMap2:
+    """One instance of paq8's ContextMap2 on one GPU (building block of the paq8 stage, include/cmix_amd.h section 2e')."""
+
+    def __init__(self, size_bytes, count, nex, stretch, ilog, device=0):
+        nex, stretch, ilog = np.ascontiguousarray(nex, np.uint8), np.ascontiguousarray(stretch, np.int16), np.ascontiguousarray(ilog, np.uint8)
+        assert nex.size == 1024 and stretch.size == 4096 and ilog.size == 257
+        self.size_bytes, self.count = size_bytes, count
+        self.h = lib().cmx_p8cm2_create(device, size_bytes, count, nex.ctypes.data, stretch.ctypes.data, ilog.ctypes.data)
+        if not self.h:
+            raise CmxError(last_error())
+
+    def hash(self, cx):
+        """cx [n, count] u64 (the contexts of each byte, in set() order) -> (ctx32 [n, count] u32, chk16 [n, count] u16)."""
+        cx = np.ascontiguousarray(cx, np.uint64)
+        c32, k16 = np.zeros(cx.shape, np.uint32), np.zeros(cx.shape, np.uint16)
+        a, b = C.c_uint32(0), C.c_uint16(0)
+        for n in range(cx.shape[0]):
+            for i in range(cx.shape[1]):
+                lib().cmx_p8cm2_hash(int(cx[n, i]), i, self.size_bytes, C.byref(a), C.byref(b))
+                c32[n, i], k16[n, i] = a.value, b.value
+        return c32, k16
+
+    def run(self, ctx32, chk16, bits, stream=None):
+        """ctx32 [n, count] i32-viewed u32 cuda, chk16 [n, count] i16-viewed u16 cuda, bits [8n] u8 cuda -> [8n, 7 count] i16."""
+        import torch
+        n = int(ctx32.shape[0])
+        assert ctx32.is_cuda and ctx32.is_contiguous() and ctx32.numel() == n * self.count and ctx32.element_size() == 4
+        assert chk16.is_cuda and chk16.is_contiguous() and chk16.numel() == n * self.count and chk16.element_size() == 2
+        assert bits.is_cuda and bits.dtype == torch.uint8 and bits.is_contiguous() and bits.numel() == 8 * n
+        out = torch.zeros((8 * n, 7 * self.count), dtype=torch.int16, device=bits.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(bits.device).cuda_stream
+        if lib().cmx_p8cm2_run(self.h, ctx32.data_ptr(), chk16.data_ptr(), bits.data_ptr(), n, out.data_ptr(), C.c_void_p(stream)):
+            raise CmxError(last_error())
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().cmx_p8cm2_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -226,6 +226,24 @@ int cmx_p8mixer_run(cmx_p8mixer_t*, const int16_t* d_x, const int* d_rows, const
                     int* d_pr, void* stream);
 
 /* ------------------------------------------------------------------------
+ * 2e'. Building block of the paq8 stage (not yet wired into a stage): paq8's ContextMap2 (src/models/paq8.cpp:1164-1358;
+ *      instances: contextModel2's order-N map :8102, TextModel's :3137, exeModel's :7275) for ONE instance of `count`
+ *      contexts over a chunk of known bits; seven mixer inputs per context and bit, in ContextMap2::mix's order.
+ *        d_ctx  [nbytes][count] u32  bucket-index hashes   } what ContextMap2::set (:1305-1310) derives from the 64-bit
+ *        d_chk  [nbytes][count] u16  bucket checksums      } context of call `index`: cmx_p8cm2_hash (HOST helper)
+ *        d_bits [8*nbytes]      u8   the coded bits; step t uses bit t-1 as "last bit" (the previous chunk's last bit for t = 0)
+ *        d_out  [8*nbytes][7*count] i16 OUT
+ *      size_bytes: the table size the reference passes (a power of two >= 64 KB); nex1024[4 s + k] = nex(s, k),
+ *      stretch4096[p] = stretch(p), ilog257[x] = ilog(x): paq8's tables (HOST, copied once).
+ * ------------------------------------------------------------------------ */
+typedef struct cmx_p8cm2 cmx_p8cm2_t;
+cmx_p8cm2_t* cmx_p8cm2_create(int device, uint64_t size_bytes, int count, const uint8_t nex1024[1024], const int16_t stretch4096[4096],
+                              const uint8_t ilog257[257]);
+void cmx_p8cm2_destroy(cmx_p8cm2_t*);
+void cmx_p8cm2_hash(uint64_t ctx, uint32_t index, uint64_t size_bytes, uint32_t* ctx32, uint16_t* chk16);
+int cmx_p8cm2_run(cmx_p8cm2_t*, const uint32_t* d_ctx, const uint16_t* d_chk, const uint8_t* d_bits, size_t nbytes, int16_t* d_out, void* stream);
+
+/* ------------------------------------------------------------------------
  * 2f. Stage: the vendored fxcm model = FXCM::Predict / FXCM::Perceive (src/models/fxcm.cpp:14-33) around
  *     fxcmv1::Predictor::update1 + modelPrediction (src/models/fxcmv1.cpp:4758-4833, :3798-4757); cmix wires it at
  *     predictor.cpp:98-99 (construction, dictionary path), :462-468 (lstmpr / lstmex set, then Perceive last).

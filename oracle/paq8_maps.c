@@ -484,3 +484,6 @@ int orc_p8_rcm_mix(RCM* r, int bpos, int c0, int16_t* out) {
   out[0] = (int16_t)(((cp[1] + 256) >> (8 - bpos)) == c0 ? (((cp[1] >> (7 - bpos)) & 1) * 2 - 1) * g_ilog[cp[0] + 1] * 8 : 0);
   return cp[0] != 0;
 }
+
+/* the nex() state table as data, for tests that hand it to the device building blocks (cmx_p8cm2_create) */
+void orc_p8_state_table(uint8_t* out1024) { memcpy(out1024, P8_STATE, 1024); }
