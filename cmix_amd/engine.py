@@ -42,6 +42,11 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.cmx_last_error.restype = C.c_char_p
         L.cmx_version.restype = C.c_char_p
+        L.cmx_p8cm_create.restype = C.c_void_p
+        L.cmx_p8cm_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cmx_p8cm_destroy.argtypes = [C.c_void_p]
+        L.cmx_p8cm_slots.argtypes = [C.c_void_p]
+        L.cmx_p8cm_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.cmx_p8cm2_create.restype = C.c_void_p
         L.cmx_p8cm2_create.argtypes = [C.c_int, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.cmx_p8cm2_destroy.argtypes = [C.c_void_p]
@@ -782,6 +787,42 @@ class P8ContextMap2:
     def close(self):
         if getattr(self, "h", None):
             lib().cmx_p8cm2_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class P8ContextMapFamily:
+    """All instances of paq8's older ContextMap of one predictor on one GPU (include/cmix_amd.h section 2e")."""
+
+    def __init__(self, sizes, counts, nex, stretch, ilog, device=0):
+        nex, stretch, ilog = np.ascontiguousarray(nex, np.uint8), np.ascontiguousarray(stretch, np.int16), np.ascontiguousarray(ilog, np.uint8)
+        sz, ct = np.array(sizes, np.uint64), np.array(counts, np.int32)
+        self.total = int(ct.sum())
+        self.h = lib().cmx_p8cm_create(device, len(sz), sz.ctypes.data, ct.ctypes.data, nex.ctypes.data, stretch.ctypes.data, ilog.ctypes.data)
+        if not self.h:
+            raise CmxError(last_error())
+
+    def run(self, ctx32, chk16, bits, stream=None):
+        import torch
+        n = int(ctx32.shape[0])
+        assert ctx32.is_cuda and ctx32.is_contiguous() and ctx32.numel() == n * self.total and ctx32.element_size() == 4
+        assert chk16.is_cuda and chk16.is_contiguous() and chk16.numel() == n * self.total and chk16.element_size() == 2
+        assert bits.is_cuda and bits.dtype == torch.uint8 and bits.is_contiguous() and bits.numel() == 8 * n
+        out = torch.zeros((8 * n, 5 * self.total), dtype=torch.int16, device=bits.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(bits.device).cuda_stream
+        if lib().cmx_p8cm_run(self.h, ctx32.data_ptr(), chk16.data_ptr(), bits.data_ptr(), n, out.data_ptr(), C.c_void_p(stream)):
+            raise CmxError(last_error())
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().cmx_p8cm_destroy(self.h)
             self.h = None
 
     def __del__(self):

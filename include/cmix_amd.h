@@ -244,6 +244,24 @@ void cmx_p8cm2_hash(uint64_t ctx, uint32_t index, uint64_t size_bytes, uint32_t*
 int cmx_p8cm2_run(cmx_p8cm2_t*, const uint32_t* d_ctx, const uint16_t* d_chk, const uint8_t* d_bits, size_t nbytes, int16_t* d_out, void* stream);
 
 /* ------------------------------------------------------------------------
+ * 2e". Building block of the paq8 stage (not yet wired into a stage): the FAMILY of paq8's older ContextMap instances
+ *      (src/models/paq8.cpp:1010-1145; wordModel :3880, sparseModel :4505, sparseModel1 :4540, indirectModel :7549,
+ *      nestModel :4111, recordModel :4213, distanceModel :4599, XMLModel :7915) over a chunk of known bits. One handle
+ *      = all instances, listed in the order the reference calls their mix(): they share the process-global rnd()
+ *      (:152-165, drawn at :1075 when a bit history reaches state >= 204) and its draws are handed out in that order.
+ *      Five mixer inputs per context and bit. total = sum of counts:
+ *        d_ctx [nbytes][total] u32, d_chk [nbytes][total] u16: cmx_p8cm2_hash(ctx, index within the instance, that
+ *        instance's size_bytes, ...) -- ContextMap::set (:1064-1069) hashes like ContextMap2::set
+ *        d_bits [8*nbytes] u8; d_out [8*nbytes][5*total] i16 OUT.  Tables as for cmx_p8cm2_create.
+ * ------------------------------------------------------------------------ */
+typedef struct cmx_p8cm cmx_p8cm_t;
+cmx_p8cm_t* cmx_p8cm_create(int device, int ninst, const uint64_t* size_bytes, const int* counts, const uint8_t nex1024[1024],
+                            const int16_t stretch4096[4096], const uint8_t ilog257[257]);
+void cmx_p8cm_destroy(cmx_p8cm_t*);
+int cmx_p8cm_slots(cmx_p8cm_t*);
+int cmx_p8cm_run(cmx_p8cm_t*, const uint32_t* d_ctx, const uint16_t* d_chk, const uint8_t* d_bits, size_t nbytes, int16_t* d_out, void* stream);
+
+/* ------------------------------------------------------------------------
  * 2f. Stage: the vendored fxcm model = FXCM::Predict / FXCM::Perceive (src/models/fxcm.cpp:14-33) around
  *     fxcmv1::Predictor::update1 + modelPrediction (src/models/fxcmv1.cpp:4758-4833, :3798-4757); cmix wires it at
  *     predictor.cpp:98-99 (construction, dictionary path), :462-468 (lstmpr / lstmex set, then Perceive last).
