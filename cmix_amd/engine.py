@@ -42,6 +42,10 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.cmx_last_error.restype = C.c_char_p
         L.cmx_version.restype = C.c_char_p
+        L.cmx_p8dmc_create.restype = C.c_void_p
+        L.cmx_p8dmc_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.cmx_p8dmc_destroy.argtypes = [C.c_void_p]
+        L.cmx_p8dmc_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.cmx_p8cm_create.restype = C.c_void_p
         L.cmx_p8cm_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.cmx_p8cm_destroy.argtypes = [C.c_void_p]
@@ -823,6 +827,37 @@ class P8ContextMapFamily:
     def close(self):
         if getattr(self, "h", None):
             lib().cmx_p8cm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class P8DmcForest:
+    """paq8's DMC forest on one GPU (include/cmix_amd.h section 2e"'): bits in, six mixer inputs per bit out."""
+
+    def __init__(self, level, nex, stretch, device=0):
+        nex, stretch = np.ascontiguousarray(nex, np.uint8), np.ascontiguousarray(stretch, np.int16)
+        self.h = lib().cmx_p8dmc_create(device, level, nex.ctypes.data, stretch.ctypes.data)
+        if not self.h:
+            raise CmxError(last_error())
+
+    def run(self, bits, stream=None):
+        import torch
+        assert bits.is_cuda and bits.dtype == torch.uint8 and bits.is_contiguous()
+        out = torch.zeros((bits.numel(), 6), dtype=torch.int16, device=bits.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(bits.device).cuda_stream
+        if lib().cmx_p8dmc_run(self.h, bits.data_ptr(), bits.numel(), out.data_ptr(), C.c_void_p(stream)):
+            raise CmxError(last_error())
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().cmx_p8dmc_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -262,6 +262,17 @@ int cmx_p8cm_slots(cmx_p8cm_t*);
 int cmx_p8cm_run(cmx_p8cm_t*, const uint32_t* d_ctx, const uint16_t* d_chk, const uint8_t* d_bits, size_t nbytes, int16_t* d_out, void* stream);
 
 /* ------------------------------------------------------------------------
+ * 2e"'. Building block of the paq8 stage (not yet wired into a stage): the DMC forest (src/models/paq8.cpp:7637-7822:
+ *       ten dmcModel state graphs + dmcForest::mix). Needs the coded bits only. level: paq8's memory level (cmix: 11,
+ *       predictor.cpp:85; ~0.7 GB of nodes). d_bits [nbits] u8 (any number of bits per call, in stream order),
+ *       d_out [nbits][6] i16 OUT: the six mixer inputs before each bit. nex1024 / stretch4096 as for cmx_p8cm2_create.
+ * ------------------------------------------------------------------------ */
+typedef struct cmx_p8dmc cmx_p8dmc_t;
+cmx_p8dmc_t* cmx_p8dmc_create(int device, int level, const uint8_t nex1024[1024], const int16_t stretch4096[4096]);
+void cmx_p8dmc_destroy(cmx_p8dmc_t*);
+int cmx_p8dmc_run(cmx_p8dmc_t*, const uint8_t* d_bits, size_t nbits, int16_t* d_out, void* stream);
+
+/* ------------------------------------------------------------------------
  * 2f. Stage: the vendored fxcm model = FXCM::Predict / FXCM::Perceive (src/models/fxcm.cpp:14-33) around
  *     fxcmv1::Predictor::update1 + modelPrediction (src/models/fxcmv1.cpp:4758-4833, :3798-4757); cmix wires it at
  *     predictor.cpp:98-99 (construction, dictionary path), :462-468 (lstmpr / lstmex set, then Perceive last).

@@ -1,0 +1,78 @@
+"""paq8's DMC forest as a device building block, without a GPU: the BODY of cmx_p8dmc_kernel (cmix_amd/csrc/p8dmc_dev.h:
+one lane per state graph, cooperative reset) run on the host by tests/host/p8dmc_emul.cpp against the oracle's restatement
+(oracle/paq8_dmc.c, pinned against the reference's own classes): the 6 mixer inputs of every bit, at level 0 (the graphs
+fill within a few KB and the eight fast models are reset again and again) and at level 5. The same comparison runs on the
+device in tests/test_zgpu_p8dmc.py."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from test_p8cm2_host import tables
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "tests", "host", "libp8dmcemul.so")
+SRC = os.path.join(ROOT, "tests", "host", "p8dmc_emul.cpp")
+DEPS = [SRC] + [os.path.join(ROOT, "cmix_amd", "csrc", f) for f in ("p8dmc_dev.h", "p8dmc_build.h", "p8cm2_dev.h")]
+
+
+def emul():
+    if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in DEPS):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-o", SO, SRC])
+    L = C.CDLL(SO)
+    L.p8x_create.restype = C.c_void_p
+    L.p8x_create.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+    L.p8x_destroy.argtypes = [C.c_void_p]
+    L.p8x_resets.restype = C.c_uint64
+    L.p8x_resets.argtypes = [C.c_void_p]
+    L.p8x_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    return L
+
+
+def oracle_rows(level, data):
+    lib = O.lib()
+    lib.orc_p8_dmc_new.restype = C.c_void_p
+    lib.orc_p8_dmc_new.argtypes = [C.c_int]
+    lib.orc_p8_dmc_mix.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.orc_p8_dmc_free.argtypes = [C.c_void_p]
+    f = lib.orc_p8_dmc_new(level)
+    rows = np.zeros((8 * len(data), 6), np.int16)
+    o, y = np.zeros(8, np.int16), 0
+    for n in range(len(data)):
+        for bpos in range(8):
+            assert lib.orc_p8_dmc_mix(f, y, bpos, o.ctypes.data) == 6
+            rows[8 * n + bpos] = o[:6]
+            y = (int(data[n]) >> (7 - bpos)) & 1
+    lib.orc_p8_dmc_free(f)
+    return rows
+
+
+CASES = [(0, 40000), (5, 12000)]
+
+
+@pytest.mark.parametrize("level,nbytes", CASES)
+def test_vs_oracle(level, nbytes):
+    from cmix_amd import synth
+    L = emul()
+    data = np.frombuffer(synth.enwik_like(nbytes, 29), np.uint8)
+    want = oracle_rows(level, data)
+    nex, stretch, _ = tables()
+    h = L.p8x_create(level, nex.ctypes.data, stretch.ctypes.data)
+    bits = np.unpackbits(np.ascontiguousarray(data))
+    got = np.zeros((len(bits), 6), np.int16)
+    pos = 0
+    for n in [3, 13, 8000, 1 << 30]:        # chunks need not be whole bytes here
+        n = min(n, len(bits) - pos)
+        if n <= 0:
+            break
+        b, o = np.ascontiguousarray(bits[pos:pos + n]), got[pos:pos + n]
+        L.p8x_run(h, b.ctypes.data, n, o.ctypes.data)
+        pos += n
+    resets = L.p8x_resets(h)
+    L.p8x_destroy(h)
+    bad = np.argwhere(got != want)
+    assert bad.size == 0, ("first mismatch (bit, input):", bad[0], got[tuple(bad[0])], want[tuple(bad[0])])
+    assert (resets > 0) == (level == 0), resets
