@@ -8,7 +8,7 @@
 //             buckets, 0.3 GB mixer rows, 60 MB APM cells, 70 MB match / run tables).
 // Bound: latency (a map lane walks up to 7 dependent bucket probes per bit); the kernel's HBM traffic is ~0.2 MB per
 // input byte algorithmic (SURVEY.md 8d iii + iv). Parity: tests/test_fxcm_stage_host.py runs this kernel's body on the
-// host against the oracle; tests/test_zgpu_fxcm_stage.py runs the kernel.
+// host against the oracle; tests/test_zgpu_stage_fxcm.py runs the kernel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>

@@ -3,7 +3,7 @@ cmx_fxcm_chunk_kernel (cmix_amd/csrc/fxcm_dev.h: five barrier-separated phases p
 tests/host/fxcm_emul.cpp -- a loop over thread ids per phase, in shuffled order -- against the oracle's monolithic
 restatement of the model (oracle/fxcm_model.c, itself pinned against the reference's fxcmv1::Predictor) and against
 layer-0 columns 3..433 of the golden traces recorded from the unmodified reference predictor. All 431 values per bit,
-bit for bit. The same comparison runs on the device in tests/test_zgpu_fxcm_stage.py."""
+bit for bit. The same comparison runs on the device in tests/test_zgpu_stage_fxcm.py."""
 import ctypes as C
 import os
 import subprocess
