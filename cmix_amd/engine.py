@@ -42,6 +42,10 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.cmx_last_error.restype = C.c_char_p
         L.cmx_version.restype = C.c_char_p
+        L.cmx_p8match_create.restype = C.c_void_p
+        L.cmx_p8match_create.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cmx_p8match_destroy.argtypes = [C.c_void_p]
+        L.cmx_p8match_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.cmx_p8dmc_create.restype = C.c_void_p
         L.cmx_p8dmc_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.cmx_p8dmc_destroy.argtypes = [C.c_void_p]
@@ -858,6 +862,41 @@ class P8DmcForest:
     def close(self):
         if getattr(self, "h", None):
             lib().cmx_p8dmc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class P8MatchModels:
+    """paq8's MatchModel + SparseMatchModel on one GPU (include/cmix_amd.h section 2e""): bytes in; 28 inputs, 3 statistics, 2 selectors per bit out."""
+
+    def __init__(self, match_bytes, sparse_bytes, hist_log2, nex, stretch, ilog65536, device=0):
+        nex, stretch, ilog = np.ascontiguousarray(nex, np.uint8), np.ascontiguousarray(stretch, np.int16), np.ascontiguousarray(ilog65536, np.uint8)
+        assert ilog.size == 65536
+        self.h = lib().cmx_p8match_create(device, match_bytes, sparse_bytes, hist_log2, nex.ctypes.data, stretch.ctypes.data, ilog.ctypes.data)
+        if not self.h:
+            raise CmxError(last_error())
+
+    def run(self, data, stream=None):
+        import torch
+        assert data.is_cuda and data.dtype == torch.uint8 and data.is_contiguous()
+        T = 8 * data.numel()
+        out = torch.zeros((T, 28), dtype=torch.int16, device=data.device)
+        stats = torch.zeros((T, 3), dtype=torch.int32, device=data.device)
+        sets = torch.zeros((T, 2), dtype=torch.int32, device=data.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(data.device).cuda_stream
+        if lib().cmx_p8match_run(self.h, data.data_ptr(), data.numel(), out.data_ptr(), stats.data_ptr(), sets.data_ptr(), C.c_void_p(stream)):
+            raise CmxError(last_error())
+        return out, stats, sets
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().cmx_p8match_destroy(self.h)
             self.h = None
 
     def __del__(self):

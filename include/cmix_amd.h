@@ -273,6 +273,21 @@ void cmx_p8dmc_destroy(cmx_p8dmc_t*);
 int cmx_p8dmc_run(cmx_p8dmc_t*, const uint8_t* d_bits, size_t nbits, int16_t* d_out, void* stream);
 
 /* ------------------------------------------------------------------------
+ * 2e"". Building block of the paq8 stage (not yet wired into a stage): MatchModel (src/models/paq8.cpp:3520-3692) and
+ *       SparseMatchModel (:3694-3843) with their SmallStationaryContextMap / StationaryMap / IndirectMap read-outs
+ *       (:891-1008). Needs the bytes only. match_bytes / sparse_bytes: the two position tables (powers of two);
+ *       hist_log2: the byte-history ring (Buf :169-187). d_bytes [nbytes] u8 (whole bytes, stream order);
+ *       d_out [8*nbytes][28] i16 OUT: 17 MatchModel inputs then 11 SparseMatchModel inputs before each bit;
+ *       d_stats [8*nbytes][3] i32 OUT: match length, expected byte at bit 0 (else -1), sparse match length;
+ *       d_sets [8*nbytes][2] i32 OUT: the sparse model's two mixer weight-set selectors. ilog65536[x] = ilog(x).
+ * ------------------------------------------------------------------------ */
+typedef struct cmx_p8match cmx_p8match_t;
+cmx_p8match_t* cmx_p8match_create(int device, uint64_t match_bytes, uint64_t sparse_bytes, int hist_log2, const uint8_t nex1024[1024],
+                                  const int16_t stretch4096[4096], const uint8_t ilog65536[65536]);
+void cmx_p8match_destroy(cmx_p8match_t*);
+int cmx_p8match_run(cmx_p8match_t*, const uint8_t* d_bytes, size_t nbytes, int16_t* d_out, int* d_stats, int* d_sets, void* stream);
+
+/* ------------------------------------------------------------------------
  * 2f. Stage: the vendored fxcm model = FXCM::Predict / FXCM::Perceive (src/models/fxcm.cpp:14-33) around
  *     fxcmv1::Predictor::update1 + modelPrediction (src/models/fxcmv1.cpp:4758-4833, :3798-4757); cmix wires it at
  *     predictor.cpp:98-99 (construction, dictionary path), :462-468 (lstmpr / lstmex set, then Perceive last).
