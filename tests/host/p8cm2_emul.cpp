@@ -28,6 +28,8 @@ void* p8e_create(uint64_t size_bytes, int count, const uint8_t* nex, const int16
 }
 void p8e_destroy(void* h) { Emul* e = (Emul*)h; for (void* p : e->pol.blocks) free(p); delete e; }
 void p8e_hash(uint64_t ctx, uint32_t index, uint64_t size_bytes, uint32_t* ctx32, uint16_t* chk16) { p8b::hash(ctx, index, p8b::hashbits(size_bytes), ctx32, chk16); }
+// start in the middle of a stream: the partial-byte register and the last coded bit as ContextMap2 would hold them
+void p8e_seed(void* h, uint32_t bits, int last_y) { ((Emul*)h)->dev.bits = bits; ((Emul*)h)->dev.last_y = last_y; }
 void p8e_stats(void* h, uint64_t* out2) { out2[0] = ((Emul*)h)->steps; out2[1] = ((Emul*)h)->serial; }
 int p8e_run(void* h, const uint32_t* ctx, const uint16_t* chk, const uint8_t* bits, int nbytes, int16_t* out) {
   Emul* e = (Emul*)h;

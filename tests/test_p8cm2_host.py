@@ -137,3 +137,43 @@ def test_vs_oracle(size_bytes, count, nbytes, flavour):
         assert stats[1] < stats[0] // 2, stats       # and the lane-per-context path is the common one otherwise
     got = run_emul(L, size_bytes, count, data[:600], cx[:600], [600], serial=1)
     assert np.array_equal(got, want[:8 * 600])
+
+
+def test_order_n_map_vs_golden_columns():
+    """contextModel2's order-N ContextMap2 (10 contexts, 2 GB at cmix's level 11; reference paq8.cpp:8102, :8139-8153) is
+    the first map paq8 mixes: its 70 inputs are paq8's mixer inputs 3..72, and cmix sees every mixer input as
+    squash(x) / 4095 (paq8.cpp:542-545) -- layer-0 columns 437..506 of the golden traces recorded from the unmodified
+    reference predictor. The kernel body, fed with contexts computed here from the trace's bytes, must reproduce those
+    columns from the second byte on (during the first byte the map holds no context and emits nothing). Fixtures only."""
+    import make_golden as mg
+    from conftest import load_golden
+    lib = O.lib()
+    lib.orc_p8_combine64.restype = C.c_uint64
+    lib.orc_p8_combine64.argtypes = [C.c_uint64, C.c_uint64]
+    lib.orc_p8_squash.argtypes = [C.c_int]
+    g = load_golden("text_96")
+    probs, stream = mg.unpack_probs(g), np.asarray(g["stream"], np.uint8)
+    size_bytes, count = 1 << 31, 10
+    cxt = [0] * 16
+    cx = np.zeros((len(stream) - 1, count), np.uint64)
+    for n in range(1, len(stream)):          # the contexts set when byte n-1 is complete, in set() order (:8141-8152)
+        B = int(stream[n - 1])
+        cxt[15] = (lib.orc_p8_combine64(cxt[15], ord(chr(B).lower())) & 0xffffffff) if chr(B).isalpha() and B < 128 else 0
+        for i in range(14, 0, -1):
+            cxt[i] = lib.orc_p8_combine64(cxt[i - 1], B) & 0xffffffff
+        cx[n - 1] = [cxt[15]] + cxt[0:7] + [cxt[8], cxt[14]]
+    L = emul()
+    nex, stretch, ilog = tables()
+    h = L.p8e_create(size_bytes, count, nex.ctypes.data, stretch.ctypes.data, ilog.ctypes.data, 99, 0)
+    L.p8e_seed.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
+    L.p8e_seed(h, 128 | (int(stream[0]) >> 1), int(stream[0]) & 1)
+    c32, k16 = hashed(L, cx, size_bytes)
+    bits = np.unpackbits(stream[1:])
+    out = np.zeros((len(bits), 7 * count), np.int16)
+    assert L.p8e_run(h, c32.ctypes.data, k16.ctypes.data, bits.ctypes.data, len(stream) - 1, out.ctypes.data) == 0
+    L.p8e_destroy(h)
+    sq = np.array([lib.orc_p8_squash(int(v)) for v in range(-2048, 2048)], np.int32)
+    got = sq[np.clip(out.astype(np.int32), -2047, 2047) + 2048].astype(np.float32) * np.float32(1.0 / 4095)
+    want = np.ascontiguousarray(probs[8:8 + len(bits), 437:507])
+    bad = np.argwhere(got.view(np.uint32) != want.view(np.uint32))
+    assert bad.size == 0, ("first mismatch (bit after the first byte, input):", bad[0], got[tuple(bad[0])] * 4095, want[tuple(bad[0])] * 4095)
