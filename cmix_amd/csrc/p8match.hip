@@ -14,10 +14,11 @@
 void cmx_set_err(const std::string& s);  // cmx_api.hip
 extern "C" int cmx_device_count(void);
 
-__global__ __launch_bounds__(64) void cmx_p8match_kernel(P8MatchDev* d, const uint8_t* bytes, int n, int16_t* out, int* stats, int* sets) {
+__global__ __launch_bounds__(64) void cmx_p8match_kernel(P8MatchDev* d, const uint8_t* bytes, int n, int t0, int16_t* out, int* stats, int* sets) {
   const int tid = threadIdx.x;
   int y = d->last_y;
-  for (int t = 0; t < 8 * n; t++) {
+  for (int t = 0; t < t0; t++) y = (bytes[t >> 3] >> (7 - (t & 7))) & 1;
+  for (int t = t0; t < 8 * n; t++) {
     const int bpos = t & 7, cur = bytes[t >> 3];
     const int c0 = (1 << bpos) | (cur >> (8 - bpos));
     p8d_match_step2(d, tid, y, bpos, c0, out + (size_t)t * 28, stats + (size_t)t * 3, sets + (size_t)t * 2);
@@ -68,12 +69,17 @@ cmx_p8match_t* cmx_p8match_create(int device, uint64_t match_bytes, uint64_t spa
   if (!ok) { cmx_set_err("cmx_p8match_create: bad sizes (powers of two, ring 2^12..2^30) or allocation failed"); cmx_p8match_destroy(h); return nullptr; }
   return h;
 }
+int cmx_p8match_run_from(cmx_p8match_t* h, const uint8_t* d_bytes, size_t nbytes, int first_bit, int16_t* d_out, int* d_stats, int* d_sets, void* stream);
 int cmx_p8match_run(cmx_p8match_t* h, const uint8_t* d_bytes, size_t nbytes, int16_t* d_out, int* d_stats, int* d_sets, void* stream) {
+  return cmx_p8match_run_from(h, d_bytes, nbytes, 0, d_out, d_stats, d_sets, stream);
+}
+int cmx_p8match_run_from(cmx_p8match_t* h, const uint8_t* d_bytes, size_t nbytes, int first_bit, int16_t* d_out, int* d_stats, int* d_sets, void* stream) {
   if (!h) { cmx_set_err("cmx_p8match_run: null handle"); return 1; }
+  if (first_bit < 0 || first_bit > 7) { cmx_set_err("cmx_p8match_run_from: first_bit must be 0..7"); return 1; }
   if (nbytes == 0) return 0;
   if (!d_bytes || !d_out || !d_stats || !d_sets || nbytes > (1u << 24)) { cmx_set_err("cmx_p8match_run: bad argument"); return 1; }
   if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
-  hipLaunchKernelGGL(cmx_p8match_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, h->d_dev, d_bytes, (int)nbytes, d_out, d_stats, d_sets);
+  hipLaunchKernelGGL(cmx_p8match_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, h->d_dev, d_bytes, (int)nbytes, first_bit, d_out, d_stats, d_sets);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { cmx_set_err(std::string("cmx_p8match_run: ") + hipGetErrorString(e)); return 1; }
   return 0;

@@ -286,6 +286,9 @@ cmx_p8match_t* cmx_p8match_create(int device, uint64_t match_bytes, uint64_t spa
                                   const int16_t stretch4096[4096], const uint8_t ilog65536[65536]);
 void cmx_p8match_destroy(cmx_p8match_t*);
 int cmx_p8match_run(cmx_p8match_t*, const uint8_t* d_bytes, size_t nbytes, int16_t* d_out, int* d_stats, int* d_sets, void* stream);
+/* The same, skipping the steps before bit `first_bit` of the chunk's first byte (rows before it untouched). first_bit = 1 on a
+ * stream's first chunk starts the models the way paq8's Predictor does: its first contextModel2 call comes after one coded bit. */
+int cmx_p8match_run_from(cmx_p8match_t*, const uint8_t* d_bytes, size_t nbytes, int first_bit, int16_t* d_out, int* d_stats, int* d_sets, void* stream);
 
 /* ------------------------------------------------------------------------
  * 2f. Stage: the vendored fxcm model = FXCM::Predict / FXCM::Perceive (src/models/fxcm.cpp:14-33) around

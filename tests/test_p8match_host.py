@@ -100,3 +100,34 @@ def test_vs_oracle():
         bad = np.argwhere(g != w)
         assert bad.size == 0, (name, "first mismatch (bit, column):", bad[0], g[tuple(bad[0])], w[tuple(bad[0])])
     assert want[1][:, 0].max() > 400 and want[1][:, 2].max() > 20      # long matches and sparse matches occurred
+
+
+def test_vs_golden_columns():
+    """In paq8's input order MatchModel's 17 inputs are mixer inputs 76..92 and SparseMatchModel's 11 are 93..103
+    (contextModel2, reference paq8.cpp:8155-8165), which cmix sees as squash(x) / 4095 in layer-0 columns 510..537. The
+    kernel body at cmix's sizes (level 11: 256 MB / 64 MB position tables, 1 GB history ring), started the way paq8's
+    Predictor starts (first call at bit position 1), must reproduce those columns of the golden trace recorded from the
+    unmodified reference predictor from the second byte on (during the first byte the context maps ahead of it emit
+    nothing, so the columns sit elsewhere). Fixtures only."""
+    import make_golden as mg
+    from conftest import load_golden
+    lib = O.lib()
+    lib.orc_p8_squash.argtypes = [C.c_int]
+    g = load_golden("text_96")
+    probs, data = mg.unpack_probs(g), np.ascontiguousarray(g["stream"], np.uint8)
+    L = emul()
+    L.p8m_run_from.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    nex, stretch, _ = tables()
+    ilog = ilog_table()
+    mem = 0x10000 << 11
+    h = L.p8m_create(mem * 2, mem // 2, 30, nex.ctypes.data, stretch.ctypes.data, ilog.ctypes.data)
+    assert h
+    T = 8 * len(data)
+    out, stats, sets = np.zeros((T, 28), np.int16), np.zeros((T, 3), np.int32), np.zeros((T, 2), np.int32)
+    L.p8m_run_from(h, data.ctypes.data, len(data), 1, out.ctypes.data, stats.ctypes.data, sets.ctypes.data)
+    L.p8m_destroy(h)
+    sq = np.array([lib.orc_p8_squash(int(v)) for v in range(-2048, 2048)], np.int32)
+    got = sq[np.clip(out[8:].astype(np.int32), -2047, 2047) + 2048].astype(np.float32) * np.float32(1.0 / 4095)
+    want = np.ascontiguousarray(probs[8:T, 510:538])
+    bad = np.argwhere(got.view(np.uint32) != want.view(np.uint32))
+    assert bad.size == 0, ("first mismatch (bit after the first byte, input):", bad[0], got[tuple(bad[0])] * 4095, want[tuple(bad[0])] * 4095)
