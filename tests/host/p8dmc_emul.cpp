@@ -20,6 +20,8 @@ struct Emul { P8DmcDev dev; P8DmcShared sh; HostPolicy pol; uint64_t resets = 0;
 extern "C" {
 void* p8x_create(int level, const uint8_t* nex, const int16_t* stretch) { Emul* e = new Emul(); p8b::build_dmc(e->dev, e->pol, level, nex, stretch); return e; }
 void p8x_destroy(void* h) { Emul* e = (Emul*)h; for (void* p : e->pol.blocks) free(p); delete e; }
+// start mid-stream: the last coded bit and the number of bits coded so far
+void p8x_seed(void* h, int last_y, uint32_t bits_done) { ((Emul*)h)->dev.last_y = last_y; ((Emul*)h)->dev.bits_done = bits_done; }
 uint64_t p8x_resets(void* h) { return ((Emul*)h)->resets; }
 void p8x_run(void* h, const uint8_t* bits, int nbits, int16_t* out) {
   Emul* e = (Emul*)h;

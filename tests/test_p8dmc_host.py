@@ -76,3 +76,32 @@ def test_vs_oracle(level, nbytes):
     bad = np.argwhere(got != want)
     assert bad.size == 0, ("first mismatch (bit, input):", bad[0], got[tuple(bad[0])], want[tuple(bad[0])])
     assert (resets > 0) == (level == 0), resets
+
+
+def test_vs_golden_columns():
+    """cmix sees paq8's mixer inputs as squash(x) / 4095 (paq8.cpp:542-545). The forest's six inputs at cmix's level 11,
+    started the way paq8's Predictor starts (first call after one coded bit), must appear as six consecutive layer-0
+    columns of the golden trace recorded from the unmodified reference predictor, from the second byte on (during the
+    first byte the context maps ahead of it emit nothing and the columns sit elsewhere). Fixtures only; the test finds
+    the columns rather than assuming them and requires the match to be unique."""
+    import make_golden as mg
+    from conftest import load_golden
+    lib = O.lib()
+    lib.orc_p8_squash.argtypes = [C.c_int]
+    g = load_golden("text_96")
+    probs, data = mg.unpack_probs(g), np.ascontiguousarray(g["stream"], np.uint8)
+    bits = np.unpackbits(data)
+    L = emul()
+    L.p8x_seed.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
+    nex, stretch, _ = tables()
+    h = L.p8x_create(11, nex.ctypes.data, stretch.ctypes.data)
+    L.p8x_seed(h, int(bits[0]), 1)
+    rest = np.ascontiguousarray(bits[1:])
+    out = np.zeros((len(rest), 6), np.int16)          # row j = the inputs before bit j + 1
+    L.p8x_run(h, rest.ctypes.data, len(rest), out.ctypes.data)
+    L.p8x_destroy(h)
+    sq = np.array([lib.orc_p8_squash(int(v)) for v in range(-2048, 2048)], np.int32)
+    got = sq[np.clip(out[7:].astype(np.int32), -2047, 2047) + 2048].astype(np.float32) * np.float32(1.0 / 4095)
+    rows = probs[8:8 + len(got)]
+    hits = [k for k in range(434, 2025 - 5) if np.array_equal(rows[:, k:k + 6].view(np.uint32), got.view(np.uint32))]
+    assert len(hits) == 1, hits
