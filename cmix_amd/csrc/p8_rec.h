@@ -1,0 +1,91 @@
+/* p8_rec.h -- records that connect the paq8 stage's HOST front end (cmix_amd/csrc/p8front: everything
+ * contextModel2 and its sub-models compute from the byte stream alone, reference src/models/paq8.cpp:8101-8207) with
+ * its DEVICE kernels (p8stage.hip: every table that learns, the 1552-input mixer, the APM chains). Plain C, included
+ * from both sides.
+ *
+ * Step t of a stream is PAQ8::Perceive(bit t-1) = Predictor::update (:8248-8362); its 1591 exported values are what
+ * PAQ8::Predict() returns before bit t is coded (layer-0 columns 434..2024 of the cmix predictor). Step 0 does not
+ * exist (the first prediction is the constructor's 0.5 in every slot); steps 1..7 run with no byte context yet, so the
+ * ContextMaps add nothing and the mixer's input vector is shorter (P8Layout.first_map). */
+#ifndef CMX_P8_REC_H
+#define CMX_P8_REC_H
+#include <stdint.h>
+
+enum {
+  P8_NX = 1552,            /* mixer inputs (:8109) */
+  P8_NSEL = 28,            /* weight sets selected per bit */
+  P8_NROWS = 77472,        /* total selector range */
+  P8_NOUT = P8_NX + P8_NSEL + 11,   /* 1591 exported values */
+  P8_FAM_MAXI = 24,        /* ContextMap instances of the family */
+  P8_FAM_MAXS = 256,       /* contexts of the family */
+  P8_NCM2 = 3,             /* ContextMap2 instances: contextModel2's order-N map, TextModel's, exeModel's */
+  P8_NLANE = 64,           /* small learners + host-computed inputs, one lane each */
+  P8_ORDER_MAX = 10        /* ContextMap2::mix's return value for the 10-context order-N map */
+};
+
+/* small lanes (one wavefront): kinds */
+enum {
+  P8L_NONE = 0,
+  P8L_SSCM,      /* SmallStationaryContextMap :891-933   (u16 cells; a = rate) */
+  P8L_STAT,      /* StationaryMap :935-974               (u32 cells; a = limit) */
+  P8L_IND,       /* IndirectMap :976-1008                (u8 bit histories + StateMap32(256); a = limit) */
+  P8L_SM32,      /* StateMap32 :645-690 read out as (stretch(p) + 1) >> 1 (contextModel2 :8155-8156, MatchModel :3672-3679) */
+  P8L_PIC,       /* picModel :3844-3864: a bit-history byte + a u16 StateMap */
+  P8L_DIRECT     /* an input the host front end computes itself (run maps, match lengths, constants): op = the value */
+};
+/* per step and lane one op word */
+#define P8OP_MIX   0x80000000u   /* the map's mix() / p() is called this step (else: untouched, its inputs are 0) */
+#define P8OP_SET   0x40000000u   /* preceded by set(): low 30 bits = cell index of the context (masked, times stride) */
+#define P8OP_ORDER 0x20000000u   /* the context is the order-N map's return value of this step (sparseModel1's scm6 :4566) */
+#define P8OP_ZERO  0x10000000u   /* StateMap32: update, but the input is 0 (MatchModel with ctx == 0 :3675) */
+#define P8OP_CTX   0x0FFFFFFFu
+
+typedef struct {
+  uint8_t kind, a, mul, div;   /* kind, rate or limit selector, output scale mul / div (:909-919) */
+  uint16_t limit;              /* STAT / IND / SM32: count limit */
+  uint16_t bits_per_ctx;       /* dmaps: bits consumed before the context restarts (BitsPerContext) */
+  int16_t off;                 /* first input position in the 1552-vector */
+  int16_t nout;                /* inputs produced (2 for the maps, 1 for SM32 / PIC / DIRECT) */
+  uint32_t cells;              /* table size in cells */
+  uint32_t init;               /* cell initial value (SM32 with 256 cells: the state-table prior instead) */
+} P8Lane;
+
+typedef struct {
+  int fam_ninst, fam_slots;
+  uint64_t fam_size[P8_FAM_MAXI];      /* bytes, in the order contextModel2 walks the instances (= rnd() draw order) */
+  int fam_count[P8_FAM_MAXI];
+  int16_t fam_off[P8_FAM_MAXS];        /* input position of a context's five inputs */
+  uint64_t cm2_size[P8_NCM2];
+  int cm2_count[P8_NCM2];
+  int16_t cm2_off[P8_NCM2];            /* seven inputs per context, contiguous */
+  int nlanes;
+  P8Lane lane[P8_NLANE];
+  int16_t dmc_off;                     /* six inputs */
+  int order_slot;                      /* family context whose value is hash(2, order) (sparseModel :4513) */
+  uint32_t order_ctx[P8_ORDER_MAX + 1];
+  uint16_t order_chk[P8_ORDER_MAX + 1];
+  int nx_first;                        /* inputs during the first byte */
+  int16_t first_map[P8_NX];            /* compact position -> position in the full vector */
+} P8Layout;
+
+/* selectors whose value depends on device state: the host part is in sel[], the device adds
+ *   sel[P8_SEL_ORDER3] += max(order - 3, 0) << 3;  sel[P8_SEL_ORDER5_a/b/c] += max(order - 5, 0) * 256   (:8171-8190)
+ *   sel[P8_SEL_LASTPR] += last prediction / 16 (:8193) */
+enum { P8_SEL_ORDER3 = 19, P8_SEL_ORDER5_A = 20, P8_SEL_ORDER5_B = 21, P8_SEL_ORDER5_C = 24, P8_SEL_LASTPR = 26 };
+
+/* per step: contexts of the final APM stages (Predictor::update :8281-8358) as far as the host knows them.
+ * TEXT block:  c[0] = c0 << 8 | mask & 15 (device ORs (misses & 15) << 4), c[1..4] = second APM's context for
+ *              misses & 3 = 0..3, c[5], c[6] = third, fourth; c[7..9] = the three APM1 contexts
+ * other:       c[0] = mlen << 11 | c0 << 3 (device ORs misses & 7), c[1..3] = ctx1..3, c[4] = expected byte << 8 | c1 */
+typedef struct { uint16_t c[10]; uint16_t limit; uint8_t text, pad; } P8ApmRec;
+
+/* one chunk of nbytes input bytes = 8 nbytes steps */
+typedef struct {
+  uint32_t* fam_ctx; uint16_t* fam_chk;                   /* [nbytes][fam_slots]: set at the step with bpos == 0 */
+  uint32_t* cm2_ctx[P8_NCM2]; uint16_t* cm2_chk[P8_NCM2]; /* [nbytes][cm2_count[k]] */
+  uint32_t* ops;                                          /* [8 nbytes][P8_NLANE] */
+  int32_t* sel;                                           /* [8 nbytes][P8_NSEL] absolute rows */
+  P8ApmRec* apm;                                          /* [8 nbytes] */
+} P8Chunk;
+
+#endif

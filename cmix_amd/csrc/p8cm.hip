@@ -23,7 +23,7 @@ __global__ __launch_bounds__(P8CM_MAXS) void cmx_p8cm_kernel(P8CmDev* d, const u
   int last_y = d->last_y, c1 = d->c1;
   __syncthreads();
   for (int t = 0; t < nbits; t++) {
-    const P8CmBit u = p8d_cm_bit(ctx, chk, bits, out, S, t, &last_y, &c1);
+    const P8CmBit u = p8d_cm_bit(d, ctx, chk, bits, out, nullptr, t, &last_y, &c1);
     if (s < S) p8d_cm_touch(d, &sh, u, s);
     __syncthreads();
     if (s < S) p8d_cm_check(d, &sh, s);

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(P8CM2_MAXC) void cmx_p8cm2_kernel(P8Cm2Dev* d, cons
   int last_y = d->last_y;
   __syncthreads();
   for (int t = 0; t < nbits; t++) {
-    const P8Cm2Bit u = p8d_bit(ctx, chk, bits, out, C, t, &run_bits, &last_y);
+    const P8Cm2Bit u = p8d_bit(d, ctx, chk, bits, out, t, &run_bits, &last_y);
     if (i < C) p8d_touch(d, &sh, u, i);
     __syncthreads();
     if (i < C) p8d_conflict(d, &sh, i);

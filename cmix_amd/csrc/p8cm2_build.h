@@ -43,6 +43,7 @@ bool build(P8Cm2Dev& h, Policy& P, uint64_t size_bytes, int count, const uint8_t
     h.regs.byte_hist[i] = h.regs.bit_state[i] + 3;
   }
   h.bits = 1;
+  h.row_stride = 7 * count; h.out_off = 0;
   return true;
 }
 }  // namespace p8b

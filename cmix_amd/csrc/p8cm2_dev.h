@@ -38,8 +38,9 @@ struct P8Cm2Dev {
   uint32_t *m6, *m8, *m12;              // StateMap32 cells: [C][72], [C][256], [C][4608]
   P8Cm2Regs regs;                       // home between chunks
   uint32_t bits; int last_y;            // c0-style partial byte (:1196-1200) and the last coded bit, carried between chunks
+  int row_stride, out_off;              // output placement: stand-alone 7 C per row at 0; in the paq8 stage the 1552-vector
 };
-struct P8Cm2Shared { P8Cm2Regs r; int32_t touched[P8CM2_MAXC][5]; int conflict; };
+struct P8Cm2Shared { P8Cm2Regs r; int32_t touched[P8CM2_MAXC][5]; int conflict; uint8_t nz[P8CM2_MAXC]; };   // nz: state > 0 (mix()'s return value counts them)
 struct P8Cm2Bit { int y, bpos; uint32_t bits; uint8_t last_byte; const uint32_t* ctx; const uint16_t* chk; int16_t* out; };
 
 P8_HD int p8d_sm32(uint32_t* t, int* cxt, int y, int cx) {   // StateMap32::p with limit 1023 (:660-672)
@@ -106,8 +107,9 @@ P8_HD void p8d_update(P8Cm2Dev* d, P8Cm2Shared* sh, const P8Cm2Bit& u, int i) { 
 P8_HD void p8d_mix(P8Cm2Dev* d, P8Cm2Shared* sh, const P8Cm2Bit& u, int i) {   // ContextMap2::mix, one context (:1321-1357)
   const uint8_t* T = d->table;
   P8Cm2Regs* r = &sh->r;
-  int16_t* o = u.out + 7 * i;
+  int16_t* o = u.out + d->out_off + 7 * i;
   int state = r->bit_state[i] != P8_NIL ? T[r->bit_state[i]] : 0;
+  sh->nz[i] = (uint8_t)(state > 0);
   int p1 = p8d_sm32(d->m8 + (size_t)i * P8_M8, &r->m8_cxt[i], u.y, state);
   int n0 = d->nex[4 * state + 2], n1 = d->nex[4 * state + 3], k = n1 + 1;
   k = (k * 64) / (k + n0 + 1);
@@ -186,7 +188,8 @@ P8_HD void p8d_run(P8Cm2Dev* d, P8Cm2Shared* sh, const P8Cm2Bit& u, int i) {   /
   }
 }
 // uniform values of step t of a chunk: y = the bit coded before it, bits / last_byte as ContextMap2::Update leaves them
-P8_HD P8Cm2Bit p8d_bit(const uint32_t* ctx, const uint16_t* chk, const uint8_t* bits_in, int16_t* out, int C, int t, uint32_t* run_bits, int* last_y) {
+P8_HD P8Cm2Bit p8d_bit(const P8Cm2Dev* d, const uint32_t* ctx, const uint16_t* chk, const uint8_t* bits_in, int16_t* out, int t, uint32_t* run_bits, int* last_y) {
+  const int C = d->C;
   P8Cm2Bit u;
   u.y = *last_y;
   u.bpos = t & 7;
@@ -196,7 +199,7 @@ P8_HD P8Cm2Bit p8d_bit(const uint32_t* ctx, const uint16_t* chk, const uint8_t* 
   u.bits = *run_bits;
   u.ctx = ctx + (size_t)(t >> 3) * (size_t)C;
   u.chk = chk + (size_t)(t >> 3) * (size_t)C;
-  u.out = out + (size_t)t * (size_t)(7 * C);
+  u.out = out + (size_t)t * (size_t)d->row_stride;
   *last_y = bits_in[t];
   return u;
 }

@@ -17,7 +17,7 @@ bool build_family(P8CmDev& h, Policy& P, int ninst, const uint64_t* size_bytes, 
   int s = 0;
   for (int k = 0; k < ninst; k++) {
     const uint64_t sz = size_bytes[k];
-    if (counts[k] <= 0 || s + counts[k] > P8CM_MAXS || sz < 64 * 1024 || (sz & (sz - 1)) || (sz >> 6) > 0x4000000ull) return false;
+    if (counts[k] <= 0 || s + counts[k] > P8CM_MAXS || sz < 4096 || (sz & (sz - 1)) || (sz >> 6) > 0x4000000ull) return false;
     h.inst[k].table = (uint8_t*)P.zalloc((size_t)sz);
     h.inst[k].mask = (uint32_t)((sz >> 6) - 1);
     h.inst[k].first = s; h.inst[k].count = counts[k];
@@ -28,6 +28,8 @@ bool build_family(P8CmDev& h, Policy& P, int ninst, const uint64_t* size_bytes, 
     }
   }
   h.nslots = s;
+  h.row_stride = 5 * s; h.order_slot = -1;
+  for (int i = 0; i < s; i++) h.slot_off[i] = (int16_t)(5 * i);
   h.nex = (const uint8_t*)up(nex1024, 1024);
   h.stretch = (const int16_t*)up(stretch4096, 4096 * 2);
   h.ilog = (const uint8_t*)up(ilog257, 257);

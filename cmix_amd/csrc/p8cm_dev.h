@@ -33,6 +33,12 @@ struct P8CmDev {
   P8CmRegs regs;
   P8Rnd rnd;
   int last_y, c1;                        // carried between chunks: the last coded bit, the last whole byte
+  // placement of the outputs (a stand-alone family: row = 5 * nslots inputs, context s at 5 s; inside the paq8 stage:
+  // the 1552-vector, contexts where contextModel2's walk puts them) and the one context whose VALUE is device state:
+  // sparseModel's hash(2, order) (reference :4513), looked up from the order-N map's return value of the byte
+  int row_stride, order_slot;
+  int16_t slot_off[P8CM_MAXS];
+  uint32_t order_ctx[16]; uint16_t order_chk[16];
 };
 struct P8CmShared {
   P8CmRegs r;
@@ -43,8 +49,11 @@ struct P8CmShared {
   int conflict, ndraws;
   P8Rnd rnd;
 };
-struct P8CmBit { int y, bp, c0, c1; const uint32_t* ctx; const uint16_t* chk; int16_t* out; };
+struct P8CmBit { int y, bp, c0, c1, order; const uint32_t* ctx; const uint16_t* chk; int16_t* out; };
 
+
+P8_HD uint32_t p8d_cm_ctxof(const P8CmDev* d, const P8CmBit& u, int s) { return s == d->order_slot ? d->order_ctx[u.order] : u.ctx[s]; }
+P8_HD uint16_t p8d_cm_chkof(const P8CmDev* d, const P8CmBit& u, int s) { return s == d->order_slot ? d->order_chk[u.order] : u.chk[s]; }
 P8_HD uint32_t p8d_rnd_next(P8Rnd* g) {   // Random::operator() :158-161
   ++g->i;
   return g->table[g->i & 63] = g->table[(g->i - 24) & 63] ^ g->table[(g->i - 55) & 63];
@@ -67,10 +76,10 @@ P8_HD void p8d_cm_ctx(P8CmDev* d, P8CmShared* sh, const P8CmBit& u, int s, const
   if (bp > 1 && T[r->runp[s]] == 0) r->cp[s] = P8_NIL;
   else if (bp == 1 || bp == 3 || bp == 6) r->cp[s] = r->cp0[s] + 1 + (uint32_t)(c0 & 1);
   else if (bp == 4 || bp == 7) r->cp[s] = r->cp0[s] + 3 + (uint32_t)(c0 & 3);
-  else if (bp == 2 || bp == 5) r->cp0[s] = r->cp[s] = p8d_bucket_find(T, (u.ctx[s] + (uint32_t)c0) & x->mask, u.chk[s]);
+  else if (bp == 2 || bp == 5) r->cp0[s] = r->cp[s] = p8d_bucket_find(T, (p8d_cm_ctxof(d, u, s) + (uint32_t)c0) & x->mask, p8d_cm_chkof(d, u, s));
   else {
-    const uint16_t checksum = u.chk[s];
-    const uint32_t cx = u.ctx[s];
+    const uint16_t checksum = p8d_cm_chkof(d, u, s);
+    const uint32_t cx = p8d_cm_ctxof(d, u, s);
     r->cp0[s] = r->cp[s] = p8d_bucket_find(T, (cx + (uint32_t)c0) & x->mask, checksum);
     uint8_t* s0 = T + r->cp0[s];
     if (s0[3] == 2) {
@@ -92,7 +101,7 @@ P8_HD void p8d_cm_ctx(P8CmDev* d, P8CmShared* sh, const P8CmBit& u, int s, const
     else if (rp[0] == 255) rp[0] = 128;
     r->runp[s] = r->cp0[s] + 3;
   }
-  int16_t* o = u.out + 5 * s;
+  int16_t* o = u.out + d->slot_off[s];
   const uint8_t* rp = T + r->runp[s];
   const int rc = rp[0];
   if ((rp[1] + 256) >> (8 - bp) == c0) {
@@ -128,19 +137,19 @@ P8_HD void p8d_cm_touch(P8CmDev* d, P8CmShared* sh, const P8CmBit& u, int s) {  
   L[1] = (int32_t)(r->runp[s] >> 6);
   if (u.bp > 1 && T[r->runp[s]] == 0) return;
   if (u.bp == 0 || u.bp == 2 || u.bp == 5) {
-    const uint32_t nb = (u.ctx[s] + (uint32_t)u.c0) & x->mask;
+    const uint32_t nb = (p8d_cm_ctxof(d, u, s) + (uint32_t)u.c0) & x->mask;
     L[2] = (int32_t)nb;
     if (u.bp == 0) {
       const uint8_t* p = T + (size_t)nb * P8_B_SIZE;
       const uint16_t* cs = (const uint16_t*)p;
       const int mru = p[P8_B_MRU];
       int slot = -1;
-      if (cs[mru & 15] == u.chk[s]) slot = mru & 15;
-      else for (int j = 0; j < 7; ++j) if (cs[j] == u.chk[s]) { slot = j; break; }
+      if (cs[mru & 15] == p8d_cm_chkof(d, u, s)) slot = mru & 15;
+      else for (int j = 0; j < 7; ++j) if (cs[j] == p8d_cm_chkof(d, u, s)) { slot = j; break; }
       if (slot >= 0 && p[P8_B_STATE + 7 * slot + 3] == 2) {
         const int cc = p[P8_B_STATE + 7 * slot + 4] + 256;
-        L[3] = (int32_t)((u.ctx[s] + (uint32_t)(cc >> 6)) & x->mask);
-        L[4] = (int32_t)((u.ctx[s] + (uint32_t)(cc >> 3)) & x->mask);
+        L[3] = (int32_t)((p8d_cm_ctxof(d, u, s) + (uint32_t)(cc >> 6)) & x->mask);
+        L[4] = (int32_t)((p8d_cm_ctxof(d, u, s) + (uint32_t)(cc >> 3)) & x->mask);
       }
     }
   }
@@ -170,15 +179,17 @@ P8_HD void p8d_cm_run(P8CmDev* d, P8CmShared* sh, const P8CmBit& u, int s) {   /
   if (!sh->conflict && d->slot_parallel) p8d_cm_ctx(d, sh, u, s, &sh->draw_val[sh->rank[s]]);
   else if (s == 0) for (int j = 0; j < d->nslots; j++) p8d_cm_ctx(d, sh, u, j, nullptr);
 }
-P8_HD P8CmBit p8d_cm_bit(const uint32_t* ctx, const uint16_t* chk, const uint8_t* bits_in, int16_t* out, int nslots, int t, int* last_y, int* c1) {
+// uniform values of step t of a chunk. order: the order-N map's return values per step (NULL: no order context)
+P8_HD P8CmBit p8d_cm_bit(const P8CmDev* d, const uint32_t* ctx, const uint16_t* chk, const uint8_t* bits_in, int16_t* out, const uint8_t* order, int t, int* last_y, int* c1) {
   P8CmBit u;
-  const int bp = t & 7;
+  const int bp = t & 7, nslots = d->nslots;
   int c0 = 1;
   for (int j = 0; j < bp; j++) c0 = c0 * 2 + bits_in[t - bp + j];
   u.y = *last_y; u.bp = bp; u.c0 = c0; u.c1 = *c1;
+  u.order = order ? order[t - bp] : 0;
   u.ctx = ctx + (size_t)(t >> 3) * (size_t)nslots;
   u.chk = chk + (size_t)(t >> 3) * (size_t)nslots;
-  u.out = out + (size_t)t * (size_t)(5 * nslots);
+  u.out = out + (size_t)t * (size_t)d->row_stride;
   *last_y = bits_in[t];
   if (bp == 7) *c1 = (c0 * 2 + bits_in[t]) & 0xff;
   return u;

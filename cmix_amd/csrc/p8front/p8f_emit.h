@@ -1,0 +1,36 @@
+/* p8f_emit.h -- the table interface the paq8 front end's sub-models are written against. On the reference's CPU path
+ * these calls ARE the tables (ContextMap::set/mix, ContextMap2::set/mix, StationaryMap::set/mix ..., reference
+ * src/models/paq8.cpp:891-1358); here they only RECORD what the tables are asked -- hashed contexts per byte, one op
+ * word per small map and step -- into the chunk records of ../p8_rec.h, which the device kernels (../p8stage.hip)
+ * consume. The sub-models themselves (p8f_word.c, p8f_text.c, ...) compute everything that depends on the byte stream
+ * alone; nothing in this directory holds a learned table except the three RunContextMaps (byte-run bookkeeping, no
+ * dependence on coded predictions). */
+#ifndef CMX_P8F_EMIT_H
+#define CMX_P8F_EMIT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../p8_rec.h"
+
+typedef struct {
+  P8Layout L;
+  int discovering;        /* layout pass: objects register themselves, offsets are learned */
+  int16_t* in_base;       /* the step's mixer-input array (models write host-computed inputs into it) */
+  P8Chunk* chunk;         /* where the step's records go (NULL: discard) */
+  size_t byte_row, step_row;
+  int full;               /* a byte boundary has been passed: every object produces its inputs */
+  int fam_calls, cm2_calls, lane_objs;   /* per-step walk counters (calling-order checks) */
+  int err;
+  int16_t lane_off0[P8_NLANE];           /* discovery: input positions during the first byte */
+  int16_t dmc_off0;
+  uint8_t claimed[P8_NX], claimed0[P8_NX];
+} P8Emit;
+
+extern __thread P8Emit* p8f_cur;
+
+void p8f_emit_begin_step(P8Emit* e, int16_t* in_base, P8Chunk* chunk, size_t byte_row, size_t step_row, int full);
+int p8f_emit_finish_discovery(P8Emit* e, int nx_first, int nx_full);
+/* after a step: copy the host-computed inputs into their DIRECT lanes' op words */
+void p8f_emit_directs(P8Emit* e);
+
+#endif

@@ -1,0 +1,147 @@
+// p8stage_build.h -- host-side construction of the paq8 stage's device state from the front end's P8Layout (p8_rec.h):
+// the ContextMap family and the three ContextMap2 instances at the places contextModel2's walk gives them in the
+// 1552-vector (reference src/models/paq8.cpp:8101-8207), the small lanes (constructors :893-898, :937-942, :978-983,
+// :651-658, :3846-3850), the DMC forest, the mixer (Mixer m(NUM_INPUTS, 77472, NUM_SETS, 32) :8109) and the APM chains
+// (Predictor :8216-8240). Memory comes from a policy object (hipMalloc in p8stage.hip, calloc in tests/host/p8stage_emul.cpp).
+#ifndef CMX_P8STAGE_BUILD_H
+#define CMX_P8STAGE_BUILD_H
+#include <cstring>
+#include <vector>
+
+#include "p8cm_build.h"
+#include "p8dmc_build.h"
+#include "p8stage_dev.h"
+
+struct P8MixDev {
+  int16_t* wx;             // [P8_NROWS][P8_NX]
+  int16_t* wx2;            // [32]: the second layer's one row
+  const int16_t* squash; const int16_t* stretch;
+  int nx_first;
+  int16_t first_map[P8_NX];
+};
+// host-side description of one stream's state; every pointer inside the members is policy memory
+struct P8StageState {
+  P8CmDev fam;
+  P8Cm2Dev cm2[P8_NCM2];
+  P8LanesDev lanes;
+  P8DmcDev dmc;
+  P8TailDev tail;
+  P8MixDev mix;
+};
+
+namespace p8b {
+inline uint32_t sm32_prior(const uint8_t* nex1024, int i) {   // StateMap32(256) :651-656
+  uint32_t n0 = nex1024[4 * i + 2], n1 = nex1024[4 * i + 3];
+  if (n0 == 0) n1 *= 64;
+  if (n1 == 0) n0 *= 64;
+  return ((n1 << 16) / (n0 + n1 + 1)) << 16;
+}
+template <class Policy>
+bool build_stage(P8StageState& S, Policy& P, const P8Layout& L, int level, const uint8_t* nex1024, const int16_t* stretch4096, const int16_t* squash4096,
+                 const uint8_t* ilog65536) {
+  auto up = [&](const void* src, size_t bytes) { void* p = P.zalloc(bytes); P.upload(p, src, bytes); return p; };
+  // ---- ContextMap family ----
+  if (!build_family(S.fam, P, L.fam_ninst, L.fam_size, L.fam_count, nex1024, stretch4096, ilog65536)) return false;
+  S.fam.row_stride = P8_NX; S.fam.order_slot = L.order_slot;
+  for (int s = 0; s < L.fam_slots; s++) S.fam.slot_off[s] = L.fam_off[s];
+  for (int o = 0; o <= P8_ORDER_MAX; o++) { S.fam.order_ctx[o] = L.order_ctx[o]; S.fam.order_chk[o] = L.order_chk[o]; }
+  // ---- ContextMap2 x 3 ----
+  for (int k = 0; k < P8_NCM2; k++) {
+    if (!build(S.cm2[k], P, L.cm2_size[k], L.cm2_count[k], nex1024, stretch4096, ilog65536)) return false;
+    S.cm2[k].row_stride = P8_NX; S.cm2[k].out_off = L.cm2_off[k];
+  }
+  // ---- small lanes ----
+  P8LanesDev& D = S.lanes;
+  memset(&D, 0, sizeof D);
+  D.nlanes = L.nlanes;
+  D.nex = (const uint8_t*)up(nex1024, 1024);
+  D.stretch = (const int16_t*)up(stretch4096, 4096 * 2);
+  uint32_t prior[256];
+  for (int i = 0; i < 256; i++) prior[i] = sm32_prior(nex1024, i);
+  for (int l = 0; l < L.nlanes; l++) {
+    P8LaneDev& q = D.lane[l];
+    q.q = L.lane[l];
+    const size_t n = q.q.cells;
+    switch (q.q.kind) {
+      case P8L_SSCM: {
+        std::vector<uint16_t> v(n, (uint16_t)q.q.init);
+        q.c16 = (uint16_t*)up(v.data(), n * 2);
+        break;
+      }
+      case P8L_STAT: {
+        std::vector<uint32_t> v(n, q.q.init);
+        q.c32 = (uint32_t*)up(v.data(), n * 4);
+        break;
+      }
+      case P8L_IND:
+        q.c8 = (uint8_t*)P.zalloc(n);
+        q.sm = (uint32_t*)up(prior, sizeof prior);
+        break;
+      case P8L_SM32: {
+        std::vector<uint32_t> v(n, q.q.init);
+        if (n == 256) for (int i = 0; i < 256; i++) v[i] = prior[i];
+        q.c32 = (uint32_t*)up(v.data(), n * 4);
+        break;
+      }
+      case P8L_PIC: {
+        q.c8 = (uint8_t*)P.zalloc(n);
+        uint16_t sm[256];
+        for (int i = 0; i < 256; i++) {   // StateMap :626-635
+          int n0 = nex1024[4 * i + 2], n1 = nex1024[4 * i + 3];
+          if (n0 == 0) n1 *= 64;
+          if (n1 == 0) n0 *= 64;
+          sm[i] = (uint16_t)(65536 * (n1 + 1) / (n0 + n1 + 2));
+        }
+        q.sm16 = (uint16_t*)up(sm, sizeof sm);
+        break;
+      }
+      default: break;
+    }
+    if (q.q.kind == P8L_SSCM || q.q.kind == P8L_STAT || q.q.kind == P8L_IND) {
+      q.stride = (1u << q.q.bits_per_ctx) - 1;
+      q.mask = q.stride ? (uint32_t)(n / q.stride) - 1 : 0;
+    }
+  }
+  // ---- DMC forest ----
+  build_dmc(S.dmc, P, level, nex1024, stretch4096);
+  // ---- mixer ----
+  P8MixDev& M = S.mix;
+  memset(&M, 0, sizeof M);
+  {
+    const size_t n = (size_t)P8_NROWS * P8_NX;
+    M.wx = (int16_t*)P.zalloc(n * 2);
+    P.fill16(M.wx, 32, n);                 // rows are created lazily with init_w = 32 (:530-537)
+    int16_t w2[32];
+    for (int i = 0; i < 32; i++) w2[i] = 0x7fff;   // :589
+    M.wx2 = (int16_t*)up(w2, sizeof w2);
+    M.squash = (const int16_t*)up(squash4096, 4096 * 2);
+    M.stretch = D.stretch;
+    M.nx_first = L.nx_first;
+    for (int i = 0; i < P8_NX; i++) M.first_map[i] = L.first_map[i];
+  }
+  // ---- APM chains ----
+  P8TailDev& T = S.tail;
+  memset(&T, 0, sizeof T);
+  T.stretch = D.stretch; T.squash = M.squash;
+  T.pr = 2048;
+  for (int i = 0; i < P8_NOUT; i++) T.out[i] = 0.5f;   // model_predictions(0.5, ...) :500
+  auto sq = [&](int d) { return d > 2047 ? 4095 : d < -2047 ? 0 : (int)squash4096[d + 2048]; };
+  {
+    std::vector<uint32_t> v((size_t)0x10000 * 24);
+    for (size_t i = 0; i < v.size(); i++) {   // APM :693-698
+      const int p = (((int)(i % 24) * 2 + 1) * 4096) / 48 - 2048;
+      v[i] = ((uint32_t)sq(p) << 20) + 6;
+    }
+    for (int k = 0; k < 4; k++) T.apm[k] = (uint32_t*)up(v.data(), v.size() * 4);
+  }
+  {
+    std::vector<uint16_t> v((size_t)0x10000 * 33);
+    for (size_t i = 0; i < v.size(); i++) v[i] = (uint16_t)(sq(((int)(i % 33) - 16) * 128) * 16);   // APM1 :603-607
+    for (int k = 0; k < 3; k++) T.apm1[k] = (uint16_t*)up(v.data(), v.size() * 2);
+    T.gen[0] = (uint16_t*)up(v.data(), (size_t)0x2000 * 33 * 2);
+    for (int k = 1; k < 7; k++) T.gen[k] = (uint16_t*)up(v.data(), v.size() * 2);
+  }
+  return true;
+}
+}  // namespace p8b
+#endif

@@ -1,0 +1,182 @@
+// p8stage_dev.h -- device bodies of the paq8 stage that are not one of the table families (p8cm_dev.h, p8cm2_dev.h,
+// p8dmc_dev.h): (1) the SMALL LANES -- every small learner of contextModel2 and its sub-models, one lane each, driven by
+// the op words of the host front end (p8_rec.h): SmallStationaryContextMap, StationaryMap, IndirectMap (reference
+// src/models/paq8.cpp:891-1008), StateMap32 read-outs (:645-690), picModel's maps (:3844-3864), plus the inputs the host
+// computes itself; (2) the tail of Predictor::update (:8281-8358): selector completion, the APM / APM1 chains, the
+// exported values. Single source: tests/host/p8stage_emul.cpp runs these bodies on the host.
+#ifndef CMX_P8STAGE_DEV_H
+#define CMX_P8STAGE_DEV_H
+#include <stdint.h>
+
+#include "p8_rec.h"
+#include "p8cm2_dev.h"   // P8_HD
+
+// ---------------------------------------------------------------- small lanes
+struct P8LaneDev {
+  P8Lane q;
+  uint32_t mask, stride;     // context mask and cells per context (dmaps)
+  uint8_t* c8; uint16_t* c16; uint32_t* c32;   // the lane's cells, by kind
+  uint32_t* sm;              // IND: StateMap32(256); PIC: unused
+  uint16_t* sm16;            // PIC: u16 StateMap(256)
+};
+struct P8LaneRegs { uint32_t cp, context, B, bcount; int sm_cxt; };
+struct P8LanesDev {
+  int nlanes;
+  P8LaneDev lane[P8_NLANE];
+  P8LaneRegs regs[P8_NLANE];   // home between chunks
+  const uint8_t* nex; const int16_t* stretch;
+  int last_y;
+};
+
+P8_HD int p8s_sm32(uint32_t* t, int* cxt, int y, int cx, int limit) {   // StateMap32::p :660-672
+  uint32_t p0 = t[*cxt];
+  const int n = p0 & 1023, pr = p0 >> 10;
+  if (n < limit) ++p0; else p0 = (p0 & 0xfffffc00u) | (uint32_t)limit;
+  const int delta = (((y << 22) - pr) >> 3) * (16384 / (n + n + 3));
+  p0 += (uint32_t)delta & 0xfffffc00u;
+  t[*cxt] = p0;
+  *cxt = cx;
+  return (int)(t[cx] >> 20);
+}
+
+// one lane, one step. x: the step's 1552-vector; order: the order-N map's return value of this step.
+P8_HD void p8s_lane_step(const P8LanesDev* d, P8LaneRegs* r, int l, uint32_t op, int y, int order, int16_t* x) {
+  const P8LaneDev* L = &d->lane[l];
+  const int kind = L->q.kind;
+  int16_t* o = x + L->q.off;
+  if (kind == P8L_DIRECT) { if (op & P8OP_MIX) o[0] = (int16_t)(op & 0xffffu); return; }
+  if (kind == P8L_NONE) return;
+  if (!(op & P8OP_MIX)) { for (int j = 0; j < L->q.nout; j++) o[j] = 0; return; }
+  if (kind == P8L_SM32) {
+    const int p = p8s_sm32(L->c32, &r->sm_cxt, y, (int)(op & P8OP_CTX), L->q.limit);
+    o[0] = (op & P8OP_ZERO) ? (int16_t)0 : (int16_t)((d->stretch[p] + 1) >> 1);
+    return;
+  }
+  if (kind == P8L_PIC) {   // t[old] = nex(t[old], y); stretch(sm.p(t[new]))
+    uint8_t* t = L->c8;
+    int s = d->nex[4 * t[r->cp] + y];
+    if ((op & P8OP_ZERO) && L->q.a == 0) { s = d->nex[4 * s + y]; s = d->nex[4 * s + y]; }   // stream start: all three maps sit on cell 0
+    t[r->cp] = (uint8_t)s;
+    r->cp = op & P8OP_CTX;
+    const int st = t[r->cp];
+    uint16_t* m = L->sm16;
+    m[r->sm_cxt] = (uint16_t)(m[r->sm_cxt] + (((y << 16) - m[r->sm_cxt] + 128) >> 8));
+    r->sm_cxt = st;
+    o[0] = d->stretch[m[st] >> 4];
+    return;
+  }
+  // the three direct-lookup maps: set() :900-907 / :944-951 / :985-992, then mix()
+  if (op & P8OP_SET) {
+    r->context = (op & P8OP_ORDER) ? ((uint32_t)order & L->mask) * L->stride : (op & P8OP_CTX);
+    r->B = r->bcount = 0;
+  }
+  int pred;
+  if (kind == P8L_SSCM) {
+    uint16_t* c = L->c16;
+    const int a = L->q.a;
+    c[r->cp] = (uint16_t)(c[r->cp] + (((y << 16) - c[r->cp] + (1 << (a - 1))) >> a));
+    r->B += (uint32_t)(y && r->B > 0);
+    r->cp = r->context + r->B;
+    pred = c[r->cp] >> 4;
+  } else if (kind == P8L_STAT) {
+    uint32_t* c = L->c32;
+    const uint32_t v = c[r->cp];
+    const int lim = L->q.limit;
+    const uint32_t count = (uint32_t)lim < (v & 0x3FF) + 1 ? (uint32_t)lim : (v & 0x3FF) + 1;
+    int p = (int)(v >> 10), err = (y << 22) - p;
+    err = ((err / 8) * (16384 / (int)(count + count + 3))) / 1024;
+    p = p + err; p = p < 0 ? 0 : p > 0x3FFFFF ? 0x3FFFFF : p;
+    c[r->cp] = ((uint32_t)p << 10) | count;
+    r->B += (uint32_t)(y && r->B > 0);
+    r->cp = r->context + r->B;
+    pred = (int)(c[r->cp] >> 20);
+  } else {   // P8L_IND
+    uint8_t* c = L->c8;
+    c[r->cp] = d->nex[4 * c[r->cp] + y];
+    r->B += (uint32_t)(y && r->B > 0);
+    r->cp = r->context + r->B;
+    pred = p8s_sm32(L->sm, &r->sm_cxt, y, c[r->cp], L->q.limit);
+  }
+  const int mul = L->q.mul, div = L->q.div;
+  o[0] = (int16_t)((d->stretch[pred] * mul) / div);
+  o[1] = (int16_t)(((pred - 2048) * mul) / (div * 2));
+  r->bcount++; r->B += r->B + 1;
+  if (r->bcount == L->q.bits_per_ctx) r->bcount = r->B = 0;
+}
+
+// ---------------------------------------------------------------- tail of Predictor::update
+struct P8TailDev {
+  uint32_t* apm[4]; int apm_cxt[4];      // TEXT: four APM (StateMap32 of 0x10000 * 24 cells) :691-712
+  uint16_t* apm1[3]; int apm1_idx[3];    // TEXT: three APM1 (0x10000 * 33 cells) :600-621
+  uint16_t* gen[7]; int gen_idx[7];      // other blocks: seven APM1 (0x2000 and 6 x 0x10000 contexts)
+  uint64_t misses;
+  int pr;                                 // the last final prediction (12 bits)
+  const int16_t* stretch; const int16_t* squash;   // squash: index d + 2048
+  float out[P8_NOUT];                     // PAQ8::Predict()'s vector, as the reference keeps it between bits
+};
+
+P8_HD int p8s_squash(const int16_t* t, int d) { return d > 2047 ? 4095 : d < -2047 ? 0 : t[d + 2048]; }
+P8_HD int p8s_apm(uint32_t* t, int* cxt, const int16_t* stretch, int y, int pr, int cx, int limit) {   // APM::p :699-711
+  uint32_t p0 = t[*cxt];
+  const int n = p0 & 1023, q = p0 >> 10;
+  if (n < limit) ++p0; else p0 = (p0 & 0xfffffc00u) | (uint32_t)limit;
+  p0 += (uint32_t)((((y << 22) - q) >> 3) * (16384 / (n + n + 3))) & 0xfffffc00u;
+  t[*cxt] = p0;
+  pr = (stretch[pr] + 2048) * 23;
+  const int wt = pr & 0xfff;
+  cx = cx * 24 + (pr >> 12);
+  *cxt = cx + (wt >> 11);
+  return (int)(((t[cx] >> 13) * (uint32_t)(4096 - wt) + (t[cx + 1] >> 13) * (uint32_t)wt) >> 19);
+}
+P8_HD int p8s_apm1(uint16_t* t, int* index, const int16_t* stretch, int y, int pr, int cxt, int rate) {   // APM1::pp :609-620
+  pr = stretch[pr];
+  const int g = (y << 16) + (y << rate) - y - y;
+  t[*index] = (uint16_t)(t[*index] + ((g - t[*index]) >> rate));
+  t[*index + 1] = (uint16_t)(t[*index + 1] + ((g - t[*index + 1]) >> rate));
+  const int w = pr & 127;
+  *index = ((pr + 2048) >> 7) + cxt * 33;
+  return (t[*index] * (128 - w) + t[*index + 1] * w) >> 11;
+}
+// selectors: the device terms (p8_rec.h)
+P8_HD int p8s_sel(int i, int host, int order, int last_pr) {
+  const int o3 = order > 3 ? order - 3 : 0, o5 = order > 5 ? order - 5 : 0;
+  if (i == P8_SEL_ORDER3) return host + (o3 << 3);
+  if (i == P8_SEL_ORDER5_A || i == P8_SEL_ORDER5_B || i == P8_SEL_ORDER5_C) return host + o5 * 256;
+  if (i == P8_SEL_LASTPR) return host + last_pr / 16;
+  return host;
+}
+// the chain after the mixer (:8281-8358): y = the bit coded before this step, pr0 = the mixer's output.
+// Writes the 10 or 11 exported stage values at o[] and returns the final prediction.
+P8_HD int p8s_tail(P8TailDev* d, const P8ApmRec* a, int y, int pr0, float* o) {
+  const float cf = (float)(1.0 / 4095);
+  const int16_t* st = d->stretch;
+  int k = 0;
+  o[k++] = (float)pr0 * cf;
+  int pr, pr1, pr2, pr3;
+  if (a->text) {
+    const int limit = a->limit;
+    pr = p8s_apm(d->apm[0], &d->apm_cxt[0], st, y, pr0, a->c[0] | (int)((d->misses & 0xF) << 4), limit); o[k++] = (float)pr * cf;
+    pr1 = p8s_apm(d->apm[1], &d->apm_cxt[1], st, y, pr0, a->c[1 + (int)(d->misses & 3)], limit); o[k++] = (float)pr1 * cf;
+    pr2 = p8s_apm(d->apm[2], &d->apm_cxt[2], st, y, pr0, a->c[5], limit); o[k++] = (float)pr2 * cf;
+    pr3 = p8s_apm(d->apm[3], &d->apm_cxt[3], st, y, pr0, a->c[6], limit); o[k++] = (float)pr3 * cf;
+    pr0 = (pr0 + pr1 + pr2 + pr3 + 2) >> 2; o[k++] = (float)pr0 * cf;
+    pr1 = p8s_apm1(d->apm1[0], &d->apm1_idx[0], st, y, pr0, a->c[7], 7); o[k++] = (float)pr1 * cf;
+    pr2 = p8s_apm1(d->apm1[1], &d->apm1_idx[1], st, y, pr, a->c[8], 6); o[k++] = (float)pr2 * cf;
+    pr3 = p8s_apm1(d->apm1[2], &d->apm1_idx[2], st, y, pr, a->c[9], 6); o[k++] = (float)pr3 * cf;
+    pr = (pr + pr1 + pr2 + pr3 + 2) >> 2; o[k++] = (float)pr * cf;
+    pr = (pr + pr0 + 1) >> 1; o[k++] = (float)pr * cf;
+  } else {
+    pr = p8s_apm1(d->gen[0], &d->gen_idx[0], st, y, pr0, a->c[0] | (int)(d->misses & 7), 7); o[k++] = (float)pr * cf;
+    pr1 = p8s_apm1(d->gen[1], &d->gen_idx[1], st, y, pr0, a->c[1], 7); o[k++] = (float)pr1 * cf;
+    pr2 = p8s_apm1(d->gen[2], &d->gen_idx[2], st, y, pr0, a->c[2], 7); o[k++] = (float)pr2 * cf;
+    pr3 = p8s_apm1(d->gen[3], &d->gen_idx[3], st, y, pr0, a->c[3], 7); o[k++] = (float)pr3 * cf;
+    pr0 = (pr0 + pr1 + pr2 + pr3 + 2) >> 2;
+    pr1 = p8s_apm1(d->gen[4], &d->gen_idx[4], st, y, pr, a->c[4], 7); o[k++] = (float)pr1 * cf;
+    pr2 = p8s_apm1(d->gen[5], &d->gen_idx[5], st, y, pr, a->c[2], 7); o[k++] = (float)pr2 * cf;
+    pr3 = p8s_apm1(d->gen[6], &d->gen_idx[6], st, y, pr, a->c[3], 7); o[k++] = (float)pr3 * cf;
+    pr = (pr + pr1 + pr2 + pr3 + 2) >> 2; o[k++] = (float)pr * cf;
+    pr = (pr + pr0 + 1) >> 1; o[k++] = (float)pr * cf;
+  }
+  return pr;
+}
+#endif

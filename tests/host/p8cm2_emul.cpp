@@ -40,7 +40,7 @@ int p8e_run(void* h, const uint32_t* ctx, const uint16_t* chk, const uint8_t* bi
   int last_y = d->last_y;
   const int C = d->C;
   for (int t = 0; t < 8 * nbytes; t++) {
-    const P8Cm2Bit u = p8d_bit(ctx, chk, bits, out, C, t, &run_bits, &last_y);
+    const P8Cm2Bit u = p8d_bit(d, ctx, chk, bits, out, t, &run_bits, &last_y);
     if (e->rng)
       for (int i = C - 1; i > 0; i--) {
         e->rng = e->rng * 1664525u + 1013904223u;

@@ -36,7 +36,7 @@ int p8f_run(void* h, const uint32_t* ctx, const uint16_t* chk, const uint8_t* bi
   int last_y = d->last_y, c1 = d->c1;
   const int S = d->nslots;
   for (int t = 0; t < 8 * nbytes; t++) {
-    const P8CmBit u = p8d_cm_bit(ctx, chk, bits, out, S, t, &last_y, &c1);
+    const P8CmBit u = p8d_cm_bit(d, ctx, chk, bits, out, nullptr, t, &last_y, &c1);
     if (e->rng)
       for (int i = S - 1; i > 0; i--) {
         e->rng = e->rng * 1664525u + 1013904223u;

@@ -1,0 +1,167 @@
+// tests/host/p8stage_emul.cpp -- TEST INFRASTRUCTURE ONLY. The whole paq8 stage on the host: the PRODUCT's front end
+// (cmix_amd/csrc/p8front/*.c, linked in) and the PRODUCT's device bodies (p8cm_dev.h, p8cm2_dev.h, p8dmc_dev.h,
+// p8stage_dev.h: the same step functions the kernels of p8stage.hip call), lanes looped per barrier step, state built
+// by the same p8stage_build.h with a calloc policy. Only the mixer's dot products / training are plain loops here (on
+// the device they are wave-parallel code, p8stage.hip). tests/test_p8stage_host.py compares its 1591 values per step
+// with columns 434..2024 of traces of the unmodified reference. Nothing in cmix_amd/ loads it.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../cmix_amd/csrc/p8front/p8f_front.h"
+#include "../../cmix_amd/csrc/p8stage_build.h"
+
+namespace {
+struct HostPolicy {
+  std::vector<void*> blocks;
+  void* zalloc(size_t bytes) { void* p = calloc(bytes + 64, 1); blocks.push_back(p); return p; }
+  void upload(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); }
+  void fill16(int16_t* dst, int16_t v, size_t n) { for (size_t i = 0; i < n; i++) dst[i] = v; }
+};
+struct Emul {
+  P8Front* front = nullptr;
+  P8StageState S;
+  HostPolicy pol;
+  P8CmShared fsh;
+  P8Cm2Shared csh[P8_NCM2];
+  P8DmcShared dsh;
+  uint64_t steps = 0;
+  int last_bit = 0;
+  uint64_t fam_serial = 0, cm2_serial = 0;
+};
+int16_t sat16(int v) { return (int16_t)(v > 32767 ? 32767 : v < -32768 ? -32768 : v); }
+int dot(const int16_t* t, const int16_t* w, int n) {
+  uint32_t sum = 0;
+  for (int i = 0; i + 1 < n; i += 2) {
+    const uint32_t pair = (uint32_t)((int32_t)t[i] * w[i]) + (uint32_t)((int32_t)t[i + 1] * w[i + 1]);
+    sum += (uint32_t)((int32_t)pair >> 8);
+  }
+  return (int32_t)sum;
+}
+void train(const int16_t* t, int16_t* w, int n, int e) {
+  if (!e) return;
+  const int16_t err = (int16_t)e;
+  for (int i = 0; i < n; ++i) {
+    int v = sat16(2 * (int)t[i]);
+    v = (v * (int)err) >> 16;
+    v = sat16(v + 1) >> 1;
+    w[i] = sat16(v + (int)w[i]);
+  }
+}
+}  // namespace
+
+extern "C" {
+void* p8s_create(int level) {
+  Emul* e = new Emul();
+  e->front = p8f_front_new(level);
+  if (!e->front) { delete e; return nullptr; }
+  if (!p8b::build_stage(e->S, e->pol, *p8f_front_layout(e->front), level, p8f_state_table(), p8f_stretch_table(), p8f_squash_table(), p8f_ilog_table())) {
+    p8f_front_free(e->front); delete e; return nullptr;
+  }
+  e->fsh.r = e->S.fam.regs; e->fsh.rnd = e->S.fam.rnd;
+  for (int k = 0; k < P8_NCM2; k++) e->csh[k].r = e->S.cm2[k].regs;
+  return e;
+}
+void p8s_destroy(void* h) {
+  Emul* e = (Emul*)h;
+  if (!e) return;
+  p8f_front_free(e->front);
+  for (void* p : e->pol.blocks) free(p);
+  delete e;
+}
+void p8s_stats(void* h, uint64_t* out3) { Emul* e = (Emul*)h; out3[0] = e->steps; out3[1] = e->fam_serial; out3[2] = e->cm2_serial; }
+// nbytes more bytes of the stream; out [8 nbytes][1591] f32 = PAQ8::Predict() before each of their bits. 0 or a negative front-end code.
+int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
+  Emul* e = (Emul*)h;
+  const P8Layout& L = *p8f_front_layout(e->front);
+  const size_t n = (size_t)nbytes, T = 8 * n;
+  std::vector<uint32_t> fctx(n * L.fam_slots), c2ctx[P8_NCM2], ops(T * P8_NLANE);
+  std::vector<uint16_t> fchk(n * L.fam_slots), c2chk[P8_NCM2];
+  std::vector<int32_t> sel(T * P8_NSEL);
+  std::vector<P8ApmRec> apm(T);
+  P8Chunk c;
+  c.fam_ctx = fctx.data(); c.fam_chk = fchk.data();
+  for (int k = 0; k < P8_NCM2; k++) { c2ctx[k].resize(n * L.cm2_count[k]); c2chk[k].resize(n * L.cm2_count[k]); c.cm2_ctx[k] = c2ctx[k].data(); c.cm2_chk[k] = c2chk[k].data(); }
+  c.ops = ops.data(); c.sel = sel.data(); c.apm = apm.data();
+  const int rc = p8f_front_run(e->front, bytes, n, &c);
+  if (rc) return rc;
+  std::vector<uint8_t> bits(T), order(T, 0);
+  for (size_t i = 0; i < T; i++) bits[i] = (bytes[i >> 3] >> (7 - (i & 7))) & 1;
+  std::vector<int16_t> x(T * P8_NX, 0);
+  P8StageState& S = e->S;
+  // per-family uniform registers, carried between calls
+  int f_last_y = S.fam.last_y, f_c1 = S.fam.c1;
+  uint32_t run_bits[P8_NCM2]; int c_last_y[P8_NCM2];
+  for (int k = 0; k < P8_NCM2; k++) { run_bits[k] = S.cm2[k].bits; c_last_y[k] = S.cm2[k].last_y; }
+  for (size_t t = 0; t < T; t++) {
+    const uint64_t g = e->steps + t;
+    const int y = t ? bits[t - 1] : e->last_bit;
+    int16_t* xr = x.data() + t * P8_NX;
+    float* orow = out + t * P8_NOUT;
+    // the uniform registers advance on every step, the lanes run once a byte boundary has been passed
+    P8Cm2Bit cu[P8_NCM2];
+    for (int k = 0; k < P8_NCM2; k++) cu[k] = p8d_bit(&S.cm2[k], c.cm2_ctx[k], c.cm2_chk[k], bits.data(), x.data(), (int)t, &run_bits[k], &c_last_y[k]);
+    const P8CmBit fu_pre = P8CmBit();
+    (void)fu_pre;
+    if (g >= 8) {
+      for (int k = 0; k < P8_NCM2; k++) {   // instance 0 first: the family needs its return value
+        P8Cm2Dev* d = &S.cm2[k];
+        for (int i = d->C - 1; i >= 0; i--) p8d_touch(d, &e->csh[k], cu[k], i);
+        for (int i = d->C - 1; i >= 0; i--) p8d_conflict(d, &e->csh[k], i);
+        e->cm2_serial += e->csh[k].conflict != 0;
+        for (int i = d->C - 1; i >= 0; i--) p8d_run(d, &e->csh[k], cu[k], i);
+        if (k == 0) { int o = 0; for (int i = 0; i < d->C; i++) o += e->csh[0].nz[i]; order[t] = (uint8_t)o; }
+      }
+    }
+    const P8CmBit fu = p8d_cm_bit(&S.fam, c.fam_ctx, c.fam_chk, bits.data(), x.data(), order.data(), (int)t, &f_last_y, &f_c1);
+    if (g >= 8) {
+      P8CmDev* d = &S.fam;
+      for (int s = d->nslots - 1; s >= 0; s--) p8d_cm_touch(d, &e->fsh, fu, s);
+      for (int s = d->nslots - 1; s >= 0; s--) p8d_cm_check(d, &e->fsh, s);
+      for (int s = d->nslots - 1; s >= 0; s--) p8d_cm_draw(d, &e->fsh, s);
+      e->fam_serial += e->fsh.conflict != 0;
+      for (int s = d->nslots - 1; s >= 0; s--) p8d_cm_run(d, &e->fsh, fu, s);
+    }
+    if (g == 0) { memcpy(orow, S.tail.out, sizeof S.tail.out); continue; }   // no step 0: the constructor's 0.5
+    for (int l = S.lanes.nlanes - 1; l >= 0; l--) p8s_lane_step(&S.lanes, &S.lanes.regs[l], l, c.ops[t * P8_NLANE + l], y, order[t], xr);
+    for (int tid = P8DMC_THREADS - 1; tid >= 0; tid--) p8d_dmc_step1(&S.dmc, &e->dsh, tid, y);
+    for (int tid = P8DMC_THREADS - 1; tid >= 0; tid--) p8d_dmc_step2(&S.dmc, &e->dsh, tid, (int)(g & 7), xr + L.dmc_off);
+    for (int tid = P8DMC_THREADS - 1; tid >= 0; tid--) p8d_dmc_step3(&S.dmc, &e->dsh, tid);
+    // ---- mixer + tail (Mixer::p :553-581, Predictor::update :8281-8358) ----
+    P8TailDev& Tl = S.tail;
+    Tl.misses += Tl.misses + (uint64_t)((Tl.pr >> 11) != y);
+    int16_t xs[P8_NX + 8];
+    memset(xs, 0, sizeof xs);
+    int nx = P8_NX;
+    if (g < 8) { nx = S.mix.nx_first; for (int i = 0; i < nx; i++) xs[i] = xr[S.mix.first_map[i]]; }
+    else memcpy(xs, xr, P8_NX * 2);
+    const float cf = (float)(1.0 / 4095);
+    for (int i = 0; i < nx; i++) Tl.out[i] = (float)p8s_squash(Tl.squash, xs[i]) * cf;
+    const int npad = (nx + 7) & ~7;
+    int row[P8_NSEL], pr[P8_NSEL];
+    int16_t st[32];
+    memset(st, 0, sizeof st);
+    for (int i = 0; i < P8_NSEL; i++) {
+      row[i] = p8s_sel(i, c.sel[t * P8_NSEL + i], order[t], Tl.pr);
+      const int dsum = dot(xs, S.mix.wx + (size_t)row[i] * P8_NX, npad);
+      pr[i] = p8s_squash(Tl.squash, (int32_t)((uint32_t)dsum * 9u) >> 9);
+      st[i] = Tl.stretch[pr[i]];
+      Tl.out[nx + i] = (float)p8s_squash(Tl.squash, st[i]) * cf;
+    }
+    const int p2 = p8s_squash(Tl.squash, dot(st, S.mix.wx2, 32) >> 9);
+    const int fin = p8s_tail(&Tl, &c.apm[t], y, p2, Tl.out + nx + P8_NSEL);
+    Tl.pr = fin;
+    memcpy(orow, Tl.out, sizeof Tl.out);
+    // training with this step's bit (the reference does it at the start of the next step: nothing reads the rows in between)
+    const int yb = bits[t];
+    for (int i = 0; i < P8_NSEL; i++) train(xs, S.mix.wx + (size_t)row[i] * P8_NX, npad, ((yb << 12) - pr[i]) * 7);
+    train(st, S.mix.wx2, 32, ((yb << 12) - p2) * 7);
+  }
+  S.fam.last_y = f_last_y; S.fam.c1 = f_c1;
+  for (int k = 0; k < P8_NCM2; k++) { S.cm2[k].bits = run_bits[k]; S.cm2[k].last_y = c_last_y[k]; }
+  e->steps += T; e->last_bit = T ? bits[T - 1] : e->last_bit;
+  return 0;
+}
+}

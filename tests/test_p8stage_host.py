@@ -1,0 +1,77 @@
+"""The paq8 stage without a GPU: the product's host front end (cmix_amd/csrc/p8front/) + the product's device bodies
+(p8cm_dev.h, p8cm2_dev.h, p8dmc_dev.h, p8stage_dev.h) run on the host by tests/host/p8stage_emul.cpp, against
+  * columns 434..2024 of the committed traces of the UNMODIFIED reference predictor (tests/golden/*.npz,
+    tests/golden/make_golden.py): all 1591 values PAQ8::Predict() hands to cmix before every bit, bit for bit;
+  * per-step hashes of the same columns over longer reference traces (tests/golden/paq8_cols_*.npz,
+    tests/golden/make_paq8_hashes.py);
+  * the oracle's restatement (oracle/paq8_predictor.c, itself pinned to the reference's paq8::Predictor) on streams
+    the fixtures do not hold.
+The same comparisons run on the device in tests/test_zgpu_p8stage.py."""
+import ctypes as C
+import glob
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+import make_golden as mg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "tests", "host", "libp8stageemul.so")
+SRC = os.path.join(ROOT, "tests", "host", "p8stage_emul.cpp")
+CSRC = os.path.join(ROOT, "cmix_amd", "csrc")
+FRONT = sorted(glob.glob(os.path.join(CSRC, "p8front", "*.c")))
+DEPS = [SRC] + FRONT + glob.glob(os.path.join(CSRC, "p8front", "*.h")) + [os.path.join(CSRC, f) for f in (
+    "p8_rec.h", "p8stage_dev.h", "p8stage_build.h", "p8cm_dev.h", "p8cm_build.h", "p8cm2_dev.h", "p8cm2_build.h", "p8dmc_dev.h", "p8dmc_build.h")]
+
+
+def emul():
+    if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in DEPS):
+        obj = os.path.join(ROOT, "tests", "host", "_p8obj")
+        os.makedirs(obj, exist_ok=True)
+        objs = []
+        for f in FRONT:
+            o = os.path.join(obj, os.path.basename(f)[:-2] + ".o")
+            subprocess.check_call(["gcc", "-std=gnu11", "-O2", "-fPIC", "-ffp-contract=off", "-w", "-include", os.path.join(CSRC, "p8front", "p8f_alloc.h"), "-c", f, "-o", o])
+            objs.append(o)
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-o", SO, SRC] + objs + ["-lm"])
+    L = C.CDLL(SO)
+    L.p8s_create.restype = C.c_void_p
+    L.p8s_create.argtypes = [C.c_int]
+    L.p8s_destroy.argtypes = [C.c_void_p]
+    L.p8s_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.p8s_stats.argtypes = [C.c_void_p, C.c_void_p]
+    return L
+
+
+def run_stage(data, chunks=None):
+    """PAQ8::Predict()'s 1591 values before every bit of data, through the emulated stage in the given chunk sizes."""
+    L = emul()
+    data = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8))
+    h = L.p8s_create(11)
+    assert h
+    out = np.zeros((8 * len(data), 1591), np.float32)
+    pos, k = 0, 0
+    chunks = chunks or [len(data)]
+    while pos < len(data):
+        n = min(chunks[k % len(chunks)], len(data) - pos)
+        k += 1
+        part = out[8 * pos:8 * (pos + n)]
+        assert L.p8s_run(h, data[pos:].ctypes.data, n, part.ctypes.data) == 0
+        pos += n
+    st = np.zeros(3, np.uint64)
+    L.p8s_stats(h, st.ctypes.data)
+    L.p8s_destroy(h)
+    return out, st
+
+
+@pytest.mark.parametrize("name", ["text_96", "binary_64"])
+def test_stage_reproduces_golden_columns(name):
+    g = load_golden(name)
+    probs = mg.unpack_probs(g)
+    got, _ = run_stage(g["stream"], chunks=[1, 1, 7, 30])
+    want = np.ascontiguousarray(probs[:, 434:2025])
+    bad = np.argwhere(got.view(np.uint32) != want.view(np.uint32))
+    assert bad.size == 0, (name, "first mismatch (step, column):", bad[0], got[tuple(bad[0])] * 4095, want[tuple(bad[0])] * 4095)
