@@ -1,0 +1,436 @@
+// p8stage.hip -- the paq8 stage of the pipeline: layer-0 columns 434..2024 of the cmix predictor, i.e. the 1591 values
+// PAQ8::Predict() returns per bit (reference src/models/paq8.cpp: Predictor::update :8248-8362 around contextModel2
+// :8101-8207; wired at src/predictor.cpp:85-97). Two halves:
+//   * host:   the front end (p8front/: the 15 sub-models' parsers and contexts, everything that is a function of the
+//             byte stream alone) runs on the calling thread and leaves, per chunk, hashed contexts per byte and one op
+//             word per small map and step in page-locked memory (p8_rec.h);
+//   * device: every table that learns, as role kernels over the chunk's known bits, all writing one int16 row of 1552
+//             mixer inputs per step into HBM:
+//               cm2     3 x ContextMap2 (p8cm2_dev.h): contextModel2's order-N map (whose return value, the "order",
+//                       feeds the family and the mixer selectors), TextModel's, exeModel's
+//               fam     the ContextMap family, 204 contexts of 16 instances with the shared rnd() stream (p8cm_dev.h)
+//               lanes   one wavefront: every small learner, one lane each (p8stage_dev.h)
+//               dmc     the DMC forest (p8dmc_dev.h)
+//               mix     the 1552 x 28 int16 mixer (rows in registers from dot product to training), the second layer,
+//                       the APM / APM1 chains, squash(x)/4095 export of all 1591 values into the layer-0 matrix
+//             Streams: s_a = cm2[0] -> fam, s_b = cm2[1] -> cm2[2], s_c = lanes -> dmc (after cm2[0]); mix after all.
+// Integer work, latency-bound by construction (dependent table accesses per bit); algorithmic HBM traffic per input
+// byte: mixer 28 rows x 1552 x 2 B x 2 (read + write) x 8 = 1.39 MB, buckets ~270 contexts x 3 probes x 64 B x 2 = 0.1 MB.
+// Parity: tests/test_p8stage_host.py runs the bodies on the host, tests/test_zgpu_p8stage.py the kernels, both against
+// columns 434..2024 of traces of the unmodified reference.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/cmix_amd.h"
+#include "p8front/p8f_front.h"
+#include "p8stage_build.h"
+
+void cmx_set_err(const std::string& s);  // cmx_api.hip
+extern "C" int cmx_device_count(void);
+
+// ---------------------------------------------------------------- role kernels
+// skip: chunk-local steps before the stream's first byte boundary (the maps have no contexts yet, reference :1072 loop over cn == 0)
+__global__ __launch_bounds__(P8CM2_MAXC) void cmx_p8s_cm2_kernel(P8Cm2Dev* d, const uint32_t* ctx, const uint16_t* chk, const uint8_t* bits, int16_t* x,
+                                                                uint8_t* order_out, int nbits, int skip) {
+  __shared__ P8Cm2Shared sh;
+  const int i = threadIdx.x, C = d->C;
+  if (i == 0) sh.r = d->regs;
+  uint32_t run_bits = d->bits;
+  int last_y = d->last_y;
+  __syncthreads();
+  for (int t = 0; t < nbits; t++) {
+    const P8Cm2Bit u = p8d_bit(d, ctx, chk, bits, x, t, &run_bits, &last_y);
+    if (t < skip) { if (order_out && i == 0) order_out[t] = 0; continue; }
+    if (i < C) p8d_touch(d, &sh, u, i);
+    __syncthreads();
+    if (i < C) p8d_conflict(d, &sh, i);
+    __syncthreads();
+    if (i < C) p8d_run(d, &sh, u, i);
+    __syncthreads();
+    if (order_out && i == 0) { int o = 0; for (int k = 0; k < C; k++) o += sh.nz[k]; order_out[t] = (uint8_t)o; }
+  }
+  if (i == 0) { d->regs = sh.r; d->bits = run_bits; d->last_y = last_y; }
+}
+
+__global__ __launch_bounds__(P8CM_MAXS) void cmx_p8s_fam_kernel(P8CmDev* d, const uint32_t* ctx, const uint16_t* chk, const uint8_t* bits, int16_t* x,
+                                                               const uint8_t* order, int nbits, int skip) {
+  __shared__ P8CmShared sh;
+  const int s = threadIdx.x, S = d->nslots;
+  if (s == 0) { sh.r = d->regs; sh.rnd = d->rnd; }
+  int last_y = d->last_y, c1 = d->c1;
+  __syncthreads();
+  for (int t = 0; t < nbits; t++) {
+    const P8CmBit u = p8d_cm_bit(d, ctx, chk, bits, x, order, t, &last_y, &c1);
+    if (t < skip) continue;
+    if (s < S) p8d_cm_touch(d, &sh, u, s);
+    __syncthreads();
+    if (s < S) p8d_cm_check(d, &sh, s);
+    __syncthreads();
+    if (s < S) p8d_cm_draw(d, &sh, s);
+    __syncthreads();
+    if (s < S) p8d_cm_run(d, &sh, u, s);
+    __syncthreads();
+  }
+  if (s == 0) { d->regs = sh.r; d->rnd = sh.rnd; d->last_y = last_y; d->c1 = c1; }
+}
+
+// t0: 1 for the chunk that starts the stream (there is no step 0), else 0
+__global__ __launch_bounds__(P8_NLANE) void cmx_p8s_lanes_kernel(P8LanesDev* d, const uint32_t* ops, const uint8_t* bits, const uint8_t* order, int16_t* x,
+                                                                int nbits, int t0) {
+  const int l = threadIdx.x;
+  P8LaneRegs r = d->regs[l];
+  const int last_y = d->last_y;
+  for (int t = t0; t < nbits; t++) {
+    const int y = t ? bits[t - 1] : last_y;
+    if (l < d->nlanes) p8s_lane_step(d, &r, l, ops[(size_t)t * P8_NLANE + l], y, order[t], x + (size_t)t * P8_NX);
+  }
+  d->regs[l] = r;
+  if (l == 0) d->last_y = bits[nbits - 1];
+}
+
+__global__ __launch_bounds__(P8DMC_THREADS) void cmx_p8s_dmc_kernel(P8DmcDev* d, const uint8_t* bits, int16_t* x, int off, int nbits, int t0) {
+  __shared__ P8DmcShared sh;
+  const int tid = threadIdx.x;
+  const uint32_t done = d->bits_done;
+  const int last_y = d->last_y;
+  for (int t = t0; t < nbits; t++) {
+    const int y = t ? bits[t - 1] : last_y;
+    p8d_dmc_step1(d, &sh, tid, y);
+    __syncthreads();
+    p8d_dmc_step2(d, &sh, tid, (int)((done + (uint32_t)t) & 7), x + (size_t)t * P8_NX + off);
+    __syncthreads();
+    p8d_dmc_step3(d, &sh, tid);
+    __syncthreads();
+  }
+  if (tid == 0) { d->last_y = bits[nbits - 1]; d->bits_done = done + (uint32_t)nbits; }
+}
+
+// ---------------------------------------------------------------- mixer + APM chains + export
+namespace {
+constexpr int MX_THREADS = 448, MX_GROUPS = P8_NX / 8;   // 7 waves x 4 sets; 194 groups of 8 int16
+__device__ __forceinline__ int sat16(int v) { return v > 32767 ? 32767 : v < -32768 ? -32768 : v; }
+__device__ __forceinline__ int lo16(uint32_t v) { return (int)(int16_t)(v & 0xffffu); }
+__device__ __forceinline__ int hi16(uint32_t v) { return (int)(int16_t)(v >> 16); }
+__device__ __forceinline__ uint32_t pair_dot(uint32_t t, uint32_t w) {   // one dword = one pair: ((t0*w0 + t1*w1) >> 8), wrapping (:403-413)
+  const uint32_t s = (uint32_t)(lo16(t) * lo16(w)) + (uint32_t)(hi16(t) * hi16(w));
+  return (uint32_t)((int32_t)s >> 8);
+}
+__device__ __forceinline__ int train1(int t, int w, int err) {   // :415-430
+  int v = sat16(2 * t);
+  v = (v * err) >> 16;
+  v = sat16(v + 1) >> 1;
+  return sat16(v + w);
+}
+__device__ __forceinline__ uint32_t pair_train(uint32_t t, uint32_t w, int err) {
+  const int a = train1(lo16(t), lo16(w), err), b = train1(hi16(t), hi16(w), err);
+  return ((uint32_t)a & 0xffffu) | ((uint32_t)b << 16);
+}
+}  // namespace
+
+// out: row t of the caller's matrix (ld floats per row) receives the 1591 values before bit t. first: chunk-local steps
+// that belong to the stream's first byte (compacted input vector, P8Layout.first_map).
+__global__ __launch_bounds__(MX_THREADS) void cmx_p8s_mix_kernel(const P8MixDev* M, P8TailDev* T, const int16_t* __restrict__ x, const int32_t* __restrict__ sel,
+                                                                const P8ApmRec* __restrict__ apm, const uint8_t* __restrict__ order,
+                                                                const uint8_t* __restrict__ bits, float* __restrict__ out, size_t ld, int nbits, int t0, int first,
+                                                                int last_y) {
+  __shared__ __attribute__((aligned(16))) uint32_t xs[P8_NX / 2];   // the step's inputs, as pairs
+  __shared__ float outs[P8_NOUT];                                   // PAQ8::Predict()'s vector, kept between steps as the reference does
+  __shared__ int pr_s[32], res_s[8];
+  __shared__ uint32_t st_s[16];
+  __shared__ int p_s, fin_s;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int16_t* squash = M->squash; const int16_t* stretch = M->stretch;
+  const float cf = (float)(1.0 / 4095);
+  for (int i = tid; i < P8_NOUT; i += MX_THREADS) outs[i] = T->out[i];
+  if (tid == 0) fin_s = T->pr;
+  __syncthreads();
+  if (t0) for (int i = tid; i < P8_NOUT; i += MX_THREADS) out[i] = outs[i];   // no step 0: the constructor's values
+  for (int t = t0; t < nbits; ++t) {
+    const int y = t ? bits[t - 1] : last_y;
+    const int nx = t < first ? M->nx_first : P8_NX;
+    const int16_t* xr = x + (size_t)t * P8_NX;
+    // ---- inputs -> LDS (compacted during the first byte), their exported values ----
+    if (t < first) {
+      int16_t* xh = reinterpret_cast<int16_t*>(xs);
+      for (int i = tid; i < P8_NX; i += MX_THREADS) xh[i] = i < nx ? xr[M->first_map[i]] : (int16_t)0;
+    } else if (tid < MX_GROUPS) reinterpret_cast<uint4*>(xs)[tid] = reinterpret_cast<const uint4*>(xr)[tid];
+    if (tid < 32) pr_s[tid] = 0;
+    if (tid == 0) T->misses += T->misses + (uint64_t)((fin_s >> 11) != y);
+    __syncthreads();
+    for (int i = tid; i < nx; i += MX_THREADS) outs[i] = (float)p8s_squash(squash, reinterpret_cast<const int16_t*>(xs)[i]) * cf;
+    // ---- first layer: 4 sets per wave, the rows stay in registers until they are trained ----
+    uint4 w[4][4];
+    int row[4];
+    const int ord = order[t], lastpr = fin_s;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int si = 4 * wave + q;
+      row[q] = p8s_sel(si, sel[(size_t)t * P8_NSEL + si], ord, lastpr);
+      const uint4* wr = reinterpret_cast<const uint4*>(M->wx + (size_t)row[q] * P8_NX);
+      uint32_t acc = 0;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int grp = lane + 64 * g;
+        w[q][g] = grp < MX_GROUPS ? wr[grp] : make_uint4(0, 0, 0, 0);
+        const uint4 xv = grp < MX_GROUPS ? reinterpret_cast<const uint4*>(xs)[grp] : make_uint4(0, 0, 0, 0);
+        acc += pair_dot(xv.x, w[q][g].x) + pair_dot(xv.y, w[q][g].y) + pair_dot(xv.z, w[q][g].z) + pair_dot(xv.w, w[q][g].w);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+      if (lane == 0) pr_s[si] = p8s_squash(squash, (int32_t)(acc * 9u) >> 9);   // :566
+    }
+    __syncthreads();
+    // ---- second layer, APM chains (wave 0) ----
+    if (wave == 0) {
+      const int a = lane < P8_NSEL ? stretch[pr_s[lane]] : 0;
+      if (lane < P8_NSEL) outs[nx + lane] = (float)p8s_squash(squash, a) * cf;   // mp->add(stretch(pr[i])) exports too (:568)
+      const int b = __shfl_down(a, 1);
+      if ((lane & 1) == 0 && lane < 32) st_s[lane >> 1] = ((uint32_t)a & 0xffffu) | ((uint32_t)b << 16);
+      __builtin_amdgcn_s_waitcnt(0);
+      __builtin_amdgcn_wave_barrier();
+      uint32_t acc = 0;
+      if (lane < 16) acc = pair_dot(st_s[lane], reinterpret_cast<const uint32_t*>(M->wx2)[lane]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+      const int p2 = p8s_squash(squash, (int32_t)acc >> 9);   // :578
+      if (lane == 0) p_s = p2;
+      const P8ApmRec* a_rec = &apm[t];
+      if (lane < 4) p8s_tail_a(T, a_rec, y, p2, lane, res_s);
+      __builtin_amdgcn_s_waitcnt(0);
+      __builtin_amdgcn_wave_barrier();
+      if (lane < 3) p8s_tail_b(T, a_rec, y, p2, lane, res_s);
+      __builtin_amdgcn_s_waitcnt(0);
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) fin_s = p8s_tail_c(a_rec, p2, res_s, outs + nx + P8_NSEL);
+    }
+    __syncthreads();
+    // ---- the row of the layer-0 matrix; training with the step's own bit (the reference trains at the start of the
+    //      next step, :528-541: nothing reads the rows in between) ----
+    float* orow = out + (size_t)t * ld;
+    for (int i = tid; i < P8_NOUT; i += MX_THREADS) orow[i] = outs[i];
+    const int yb = bits[t];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int err = (int)(int16_t)(((yb << 12) - pr_s[4 * wave + q]) * 7);
+      uint4* wr = reinterpret_cast<uint4*>(M->wx + (size_t)row[q] * P8_NX);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int grp = lane + 64 * g;
+        if (grp < MX_GROUPS && err) {
+          const uint4 xv = reinterpret_cast<const uint4*>(xs)[grp];
+          uint4 v = w[q][g];
+          v.x = pair_train(xv.x, v.x, err); v.y = pair_train(xv.y, v.y, err);
+          v.z = pair_train(xv.z, v.z, err); v.w = pair_train(xv.w, v.w, err);
+          wr[grp] = v;
+        }
+      }
+    }
+    if (wave == 0 && lane < 16) {
+      const int err2 = (int)(int16_t)(((yb << 12) - p_s) * 7);
+      uint32_t* w2 = reinterpret_cast<uint32_t*>(M->wx2);
+      if (err2) w2[lane] = pair_train(st_s[lane], w2[lane], err2);
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < P8_NOUT; i += MX_THREADS) T->out[i] = outs[i];
+  if (tid == 0) T->pr = fin_s;
+}
+
+// ---------------------------------------------------------------- host side
+namespace {
+struct DevPolicy {
+  std::vector<void*> blocks;
+  bool ok = true;
+  void* zalloc(size_t bytes) {
+    void* p = nullptr;
+    if (!ok || hipMalloc(&p, bytes + 64) != hipSuccess || hipMemset(p, 0, bytes + 64) != hipSuccess) { ok = false; return nullptr; }
+    blocks.push_back(p);
+    return p;
+  }
+  void upload(void* dst, const void* src, size_t bytes) { if (dst && hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess) ok = false; }
+  void fill16(int16_t* dst, int16_t v, size_t n) { if (dst && hipMemsetD16((hipDeviceptr_t)dst, (unsigned short)v, n) != hipSuccess) ok = false; }
+};
+enum { P8S_BUFS = 4 };
+struct Staging {   // one chunk's records: page-locked host arrays and their device twins
+  size_t cap = 0;  // bytes of input
+  char* h = nullptr; char* d = nullptr;
+  size_t o_fctx, o_fchk, o_cctx[P8_NCM2], o_cchk[P8_NCM2], o_ops, o_sel, o_apm, o_bits, total;
+  hipEvent_t done = nullptr;
+  bool used = false;
+};
+template <class Tp> Tp* dev_copy(const Tp& host, DevPolicy& pol) {
+  Tp* p = (Tp*)pol.zalloc(sizeof(Tp));
+  pol.upload(p, &host, sizeof(Tp));
+  return p;
+}
+}  // namespace
+
+struct cmx_p8stage {
+  int device = 0;
+  P8Front* front = nullptr;
+  P8Layout L;
+  DevPolicy pol;
+  P8CmDev* d_fam = nullptr; P8Cm2Dev* d_cm2[P8_NCM2] = {}; P8LanesDev* d_lanes = nullptr; P8DmcDev* d_dmc = nullptr;
+  P8TailDev* d_tail = nullptr; P8MixDev* d_mix = nullptr;
+  Staging st[P8S_BUFS];
+  int next = 0;
+  int16_t* d_x = nullptr; uint8_t* d_order = nullptr; size_t x_cap = 0;   // one chunk's input rows / order values
+  hipStream_t s_b = nullptr, s_c = nullptr;
+  hipEvent_t ev_up = nullptr, ev_ord = nullptr, ev_b = nullptr, ev_c = nullptr, ev_mix = nullptr;
+  uint64_t steps = 0;
+  int last_bit = 0;
+  bool failed = false;
+  float ms_front = 0;   // host time of the last front-end pass
+};
+
+extern "C" {
+
+void cmx_p8stage_destroy(cmx_p8stage_t* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  for (void* p : h->pol.blocks) (void)hipFree(p);
+  for (auto& s : h->st) {
+    if (s.h) (void)hipHostFree(s.h);
+    if (s.d) (void)hipFree(s.d);
+    if (s.done) (void)hipEventDestroy(s.done);
+  }
+  if (h->d_x) (void)hipFree(h->d_x);
+  if (h->d_order) (void)hipFree(h->d_order);
+  if (h->s_b) (void)hipStreamDestroy(h->s_b);
+  if (h->s_c) (void)hipStreamDestroy(h->s_c);
+  for (hipEvent_t e : {h->ev_up, h->ev_ord, h->ev_b, h->ev_c, h->ev_mix}) if (e) (void)hipEventDestroy(e);
+  if (h->front) p8f_front_free(h->front);
+  delete h;
+}
+
+cmx_p8stage_t* cmx_p8stage_create(int device) {
+  if (cmx_device_count() <= 0) { cmx_set_err("cmx_p8stage_create: no HIP device visible (a gfx950 GPU is required)"); return nullptr; }
+  if (hipSetDevice(device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return nullptr; }
+  cmx_p8stage_t* h = new cmx_p8stage();
+  h->device = device;
+  h->front = p8f_front_new(11);   // cmix runs paq8 at level 11 (reference src/predictor.cpp:85)
+  if (!h->front) { cmx_set_err("cmx_p8stage_create: front end construction failed"); delete h; return nullptr; }
+  h->L = *p8f_front_layout(h->front);
+  P8StageState* S = new P8StageState();
+  bool ok = p8b::build_stage(*S, h->pol, h->L, 11, p8f_state_table(), p8f_stretch_table(), p8f_squash_table(), p8f_ilog_table()) && h->pol.ok;
+  if (ok) {
+    const char* serial = getenv("CMX_P8CM_SERIAL");   // A/B switch: the reference's serial walk on lane 0
+    if (serial && serial[0] == '1') { S->fam.slot_parallel = 0; for (auto& c : S->cm2) c.slot_parallel = 0; }
+    h->d_fam = dev_copy(S->fam, h->pol);
+    for (int k = 0; k < P8_NCM2; k++) h->d_cm2[k] = dev_copy(S->cm2[k], h->pol);
+    h->d_lanes = dev_copy(S->lanes, h->pol);
+    h->d_dmc = dev_copy(S->dmc, h->pol);
+    h->d_tail = dev_copy(S->tail, h->pol);
+    h->d_mix = dev_copy(S->mix, h->pol);
+    ok = h->pol.ok;
+  }
+  delete S;
+  ok = ok && hipStreamCreateWithFlags(&h->s_b, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&h->s_c, hipStreamNonBlocking) == hipSuccess;
+  for (hipEvent_t* e : {&h->ev_up, &h->ev_ord, &h->ev_b, &h->ev_c, &h->ev_mix}) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+  for (auto& s : h->st) ok = ok && hipEventCreateWithFlags(&s.done, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipDeviceSynchronize() == hipSuccess;
+  if (!ok) { cmx_set_err("cmx_p8stage_create: allocation / init failed (the stage needs ~9 GB of HBM)"); cmx_p8stage_destroy(h); return nullptr; }
+  return h;
+}
+
+// The next nbytes bytes of the stream (host memory): front end on the calling thread, then the role kernels, ordered
+// behind `stream`. d_out: device matrix, row t (ld floats apart) receives the 1591 values before bit t of this chunk.
+int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float* d_out, size_t ld, void* stream) {
+  if (!h) { cmx_set_err("cmx_p8stage_run: null handle"); return 1; }
+  if (h->failed) { cmx_set_err("cmx_p8stage_run: the stage failed earlier on this stream"); return 1; }
+  if (nbytes == 0) return 0;
+  if (!bytes || !d_out || ld < P8_NOUT || nbytes > (1u << 22)) { cmx_set_err("cmx_p8stage_run: bad argument"); return 1; }
+  if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
+  const P8Layout& L = h->L;
+  Staging& b = h->st[h->next];
+  h->next = (h->next + 1) % P8S_BUFS;
+  if (b.used && hipEventSynchronize(b.done) != hipSuccess) { cmx_set_err("cmx_p8stage_run: staging buffer wait failed"); h->failed = true; return 1; }
+  const size_t n = nbytes, T = 8 * n;
+  if (b.cap < n) {
+    if (b.h) (void)hipHostFree(b.h);
+    if (b.d) (void)hipFree(b.d);
+    b.h = b.d = nullptr; b.cap = 0;
+    size_t o = 0;
+    auto take = [&](size_t bytes_) { const size_t at = o; o += (bytes_ + 255) & ~(size_t)255; return at; };
+    b.o_fctx = take(n * L.fam_slots * 4); b.o_fchk = take(n * L.fam_slots * 2);
+    for (int k = 0; k < P8_NCM2; k++) { b.o_cctx[k] = take(n * L.cm2_count[k] * 4); b.o_cchk[k] = take(n * L.cm2_count[k] * 2); }
+    b.o_ops = take(T * P8_NLANE * 4); b.o_sel = take(T * P8_NSEL * 4); b.o_apm = take(T * sizeof(P8ApmRec)); b.o_bits = take(T);
+    b.total = o;
+    if (hipHostMalloc((void**)&b.h, o, hipHostMallocDefault) != hipSuccess || hipMalloc((void**)&b.d, o) != hipSuccess) { cmx_set_err("cmx_p8stage_run: staging allocation failed"); h->failed = true; return 1; }
+    b.cap = n;
+  }
+  P8Chunk c;
+  c.fam_ctx = (uint32_t*)(b.h + b.o_fctx); c.fam_chk = (uint16_t*)(b.h + b.o_fchk);
+  for (int k = 0; k < P8_NCM2; k++) { c.cm2_ctx[k] = (uint32_t*)(b.h + b.o_cctx[k]); c.cm2_chk[k] = (uint16_t*)(b.h + b.o_cchk[k]); }
+  c.ops = (uint32_t*)(b.h + b.o_ops); c.sel = (int32_t*)(b.h + b.o_sel); c.apm = (P8ApmRec*)(b.h + b.o_apm);
+  const int rc = p8f_front_run(h->front, bytes, n, &c);
+  if (rc) { cmx_set_err(std::string("cmx_p8stage_run: ") + p8f_strerror(rc)); h->failed = true; return 1; }
+  uint8_t* hb = (uint8_t*)(b.h + b.o_bits);
+  for (size_t i = 0; i < T; i++) hb[i] = (bytes[i >> 3] >> (7 - (i & 7))) & 1;
+  hipStream_t s = (hipStream_t)stream;
+  bool ok = true;
+  if (h->x_cap < n) {   // grown between chunks only when nothing is in flight on it
+    ok = hipDeviceSynchronize() == hipSuccess;
+    if (h->d_x) (void)hipFree(h->d_x);
+    if (h->d_order) (void)hipFree(h->d_order);
+    h->d_x = nullptr; h->d_order = nullptr; h->x_cap = 0;
+    ok = ok && hipMalloc((void**)&h->d_x, T * P8_NX * 2) == hipSuccess && hipMalloc((void**)&h->d_order, T) == hipSuccess;
+    if (ok) h->x_cap = n;
+  }
+  ok = ok && hipMemcpyAsync(b.d, b.h, b.total, hipMemcpyHostToDevice, s) == hipSuccess;
+  ok = ok && hipEventRecord(h->ev_up, s) == hipSuccess;
+  const int nbits = (int)T;
+  const int skip = h->steps >= 8 ? 0 : (int)(8 - h->steps), t0 = h->steps == 0 ? 1 : 0;
+  const uint8_t* d_bits = (const uint8_t*)(b.d + b.o_bits);
+  auto cm2 = [&](int k, hipStream_t q, uint8_t* ord) {
+    hipLaunchKernelGGL(cmx_p8s_cm2_kernel, dim3(1), dim3(P8CM2_MAXC), 0, q, h->d_cm2[k], (const uint32_t*)(b.d + b.o_cctx[k]), (const uint16_t*)(b.d + b.o_cchk[k]), d_bits,
+                       h->d_x, ord, nbits, skip);
+  };
+  if (ok) {
+    // stream a (the caller's): order-N map, then the family
+    cm2(0, s, h->d_order);
+    ok = hipEventRecord(h->ev_ord, s) == hipSuccess;
+    hipLaunchKernelGGL(cmx_p8s_fam_kernel, dim3(1), dim3(P8CM_MAXS), 0, s, h->d_fam, (const uint32_t*)(b.d + b.o_fctx), (const uint16_t*)(b.d + b.o_fchk), d_bits, h->d_x,
+                       (const uint8_t*)h->d_order, nbits, skip);
+    // stream b: TextModel's and exeModel's maps
+    ok = ok && hipStreamWaitEvent(h->s_b, h->ev_up, 0) == hipSuccess;
+    cm2(1, h->s_b, nullptr);
+    cm2(2, h->s_b, nullptr);
+    ok = ok && hipEventRecord(h->ev_b, h->s_b) == hipSuccess;
+    // stream c: small lanes (one needs the order), DMC
+    ok = ok && hipStreamWaitEvent(h->s_c, h->ev_ord, 0) == hipSuccess;
+    hipLaunchKernelGGL(cmx_p8s_lanes_kernel, dim3(1), dim3(P8_NLANE), 0, h->s_c, h->d_lanes, (const uint32_t*)(b.d + b.o_ops), d_bits, (const uint8_t*)h->d_order, h->d_x,
+                       nbits, t0);
+    hipLaunchKernelGGL(cmx_p8s_dmc_kernel, dim3(1), dim3(P8DMC_THREADS), 0, h->s_c, h->d_dmc, d_bits, h->d_x, (int)L.dmc_off, nbits, t0);
+    ok = ok && hipEventRecord(h->ev_c, h->s_c) == hipSuccess;
+    // back on the caller's stream: the mixer consumes the rows
+    ok = ok && hipStreamWaitEvent(s, h->ev_b, 0) == hipSuccess && hipStreamWaitEvent(s, h->ev_c, 0) == hipSuccess;
+    hipLaunchKernelGGL(cmx_p8s_mix_kernel, dim3(1), dim3(MX_THREADS), 0, s, (const P8MixDev*)h->d_mix, h->d_tail, (const int16_t*)h->d_x, (const int32_t*)(b.d + b.o_sel),
+                       (const P8ApmRec*)(b.d + b.o_apm), (const uint8_t*)h->d_order, d_bits, d_out, ld, nbits, t0, skip, h->last_bit);
+    ok = ok && hipGetLastError() == hipSuccess;
+    ok = ok && hipEventRecord(b.done, s) == hipSuccess;
+    // the next chunk's role kernels reuse d_x / d_order: streams b and c wait for this mixer through ev_up's successor
+    ok = ok && hipEventRecord(h->ev_mix, s) == hipSuccess;
+    ok = ok && hipStreamWaitEvent(h->s_b, h->ev_mix, 0) == hipSuccess && hipStreamWaitEvent(h->s_c, h->ev_mix, 0) == hipSuccess;
+  }
+  if (!ok) { cmx_set_err(std::string("cmx_p8stage_run: launch failed: ") + hipGetErrorString(hipGetLastError())); h->failed = true; return 1; }
+  b.used = true;
+  h->steps += T;
+  h->last_bit = hb[T - 1];
+  return 0;
+}
+
+int cmx_p8stage_sync(cmx_p8stage_t* h) {
+  if (!h) { cmx_set_err("cmx_p8stage_sync: null handle"); return 1; }
+  if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) { cmx_set_err(std::string("cmx_p8stage_sync: ") + hipGetErrorString(e)); h->failed = true; return 1; }
+  return 0;
+}
+
+}  // extern "C"

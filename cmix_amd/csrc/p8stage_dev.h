@@ -145,38 +145,40 @@ P8_HD int p8s_sel(int i, int host, int order, int last_pr) {
   if (i == P8_SEL_LASTPR) return host + last_pr / 16;
   return host;
 }
-// the chain after the mixer (:8281-8358): y = the bit coded before this step, pr0 = the mixer's output.
-// Writes the 10 or 11 exported stage values at o[] and returns the final prediction.
-P8_HD int p8s_tail(P8TailDev* d, const P8ApmRec* a, int y, int pr0, float* o) {
-  const float cf = (float)(1.0 / 4095);
+// the chain after the mixer (:8281-8358) in three lane-parallel phases; y = the bit coded before this step, pr0 = the
+// mixer's output. res[0..3]: first group's outputs, res[4..6]: second group's. Each lane owns one table.
+//   phase A  lanes 0..3:  TEXT: the four APMs on pr0           other: gen[0..3] on pr0
+//   phase B  lanes 0..2:  TEXT: APM1[0] on the average, APM1[1,2] on res[0]     other: gen[4..6] on res[0]
+//   phase C  one lane:    the exported values and the final prediction
+P8_HD void p8s_tail_a(P8TailDev* d, const P8ApmRec* a, int y, int pr0, int j, int* res) {
   const int16_t* st = d->stretch;
+  if (a->text) {
+    const int cx = j == 0 ? (a->c[0] | (int)((d->misses & 0xF) << 4)) : j == 1 ? a->c[1 + (int)(d->misses & 3)] : a->c[3 + j];
+    res[j] = p8s_apm(d->apm[j], &d->apm_cxt[j], st, y, pr0, cx, a->limit);
+  } else {
+    const int cx = j == 0 ? (a->c[0] | (int)(d->misses & 7)) : a->c[j];
+    res[j] = p8s_apm1(d->gen[j], &d->gen_idx[j], st, y, pr0, cx, 7);
+  }
+}
+P8_HD void p8s_tail_b(P8TailDev* d, const P8ApmRec* a, int y, int pr0, int j, int* res) {
+  const int16_t* st = d->stretch;
+  const int avg = (pr0 + res[1] + res[2] + res[3] + 2) >> 2;
+  if (a->text) res[4 + j] = p8s_apm1(d->apm1[j], &d->apm1_idx[j], st, y, j == 0 ? avg : res[0], a->c[7 + j], j == 0 ? 7 : 6);
+  else res[4 + j] = p8s_apm1(d->gen[4 + j], &d->gen_idx[4 + j], st, y, res[0], j == 0 ? a->c[4] : a->c[1 + j], 7);
+}
+// writes the 10 or 11 exported stage values at o[] and returns the final prediction
+P8_HD int p8s_tail_c(const P8ApmRec* a, int pr0, const int* res, float* o) {
+  const float cf = (float)(1.0 / 4095);
   int k = 0;
   o[k++] = (float)pr0 * cf;
-  int pr, pr1, pr2, pr3;
-  if (a->text) {
-    const int limit = a->limit;
-    pr = p8s_apm(d->apm[0], &d->apm_cxt[0], st, y, pr0, a->c[0] | (int)((d->misses & 0xF) << 4), limit); o[k++] = (float)pr * cf;
-    pr1 = p8s_apm(d->apm[1], &d->apm_cxt[1], st, y, pr0, a->c[1 + (int)(d->misses & 3)], limit); o[k++] = (float)pr1 * cf;
-    pr2 = p8s_apm(d->apm[2], &d->apm_cxt[2], st, y, pr0, a->c[5], limit); o[k++] = (float)pr2 * cf;
-    pr3 = p8s_apm(d->apm[3], &d->apm_cxt[3], st, y, pr0, a->c[6], limit); o[k++] = (float)pr3 * cf;
-    pr0 = (pr0 + pr1 + pr2 + pr3 + 2) >> 2; o[k++] = (float)pr0 * cf;
-    pr1 = p8s_apm1(d->apm1[0], &d->apm1_idx[0], st, y, pr0, a->c[7], 7); o[k++] = (float)pr1 * cf;
-    pr2 = p8s_apm1(d->apm1[1], &d->apm1_idx[1], st, y, pr, a->c[8], 6); o[k++] = (float)pr2 * cf;
-    pr3 = p8s_apm1(d->apm1[2], &d->apm1_idx[2], st, y, pr, a->c[9], 6); o[k++] = (float)pr3 * cf;
-    pr = (pr + pr1 + pr2 + pr3 + 2) >> 2; o[k++] = (float)pr * cf;
-    pr = (pr + pr0 + 1) >> 1; o[k++] = (float)pr * cf;
-  } else {
-    pr = p8s_apm1(d->gen[0], &d->gen_idx[0], st, y, pr0, a->c[0] | (int)(d->misses & 7), 7); o[k++] = (float)pr * cf;
-    pr1 = p8s_apm1(d->gen[1], &d->gen_idx[1], st, y, pr0, a->c[1], 7); o[k++] = (float)pr1 * cf;
-    pr2 = p8s_apm1(d->gen[2], &d->gen_idx[2], st, y, pr0, a->c[2], 7); o[k++] = (float)pr2 * cf;
-    pr3 = p8s_apm1(d->gen[3], &d->gen_idx[3], st, y, pr0, a->c[3], 7); o[k++] = (float)pr3 * cf;
-    pr0 = (pr0 + pr1 + pr2 + pr3 + 2) >> 2;
-    pr1 = p8s_apm1(d->gen[4], &d->gen_idx[4], st, y, pr, a->c[4], 7); o[k++] = (float)pr1 * cf;
-    pr2 = p8s_apm1(d->gen[5], &d->gen_idx[5], st, y, pr, a->c[2], 7); o[k++] = (float)pr2 * cf;
-    pr3 = p8s_apm1(d->gen[6], &d->gen_idx[6], st, y, pr, a->c[3], 7); o[k++] = (float)pr3 * cf;
-    pr = (pr + pr1 + pr2 + pr3 + 2) >> 2; o[k++] = (float)pr * cf;
-    pr = (pr + pr0 + 1) >> 1; o[k++] = (float)pr * cf;
-  }
+  const int avg = (pr0 + res[1] + res[2] + res[3] + 2) >> 2;
+  for (int j = 0; j < 4; j++) o[k++] = (float)res[j] * cf;
+  if (a->text) o[k++] = (float)avg * cf;   // the general path does not export this one (:8345)
+  for (int j = 4; j < 7; j++) o[k++] = (float)res[j] * cf;
+  int pr = (res[0] + res[4] + res[5] + res[6] + 2) >> 2;
+  o[k++] = (float)pr * cf;
+  pr = (pr + avg + 1) >> 1;
+  o[k++] = (float)pr * cf;
   return pr;
 }
 #endif

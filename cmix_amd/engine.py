@@ -42,6 +42,11 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.cmx_last_error.restype = C.c_char_p
         L.cmx_version.restype = C.c_char_p
+        L.cmx_p8stage_create.restype = C.c_void_p
+        L.cmx_p8stage_create.argtypes = [C.c_int]
+        L.cmx_p8stage_destroy.argtypes = [C.c_void_p]
+        L.cmx_p8stage_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.cmx_p8stage_sync.argtypes = [C.c_void_p]
         L.cmx_p8match_create.restype = C.c_void_p
         L.cmx_p8match_create.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.cmx_p8match_destroy.argtypes = [C.c_void_p]
@@ -754,6 +759,47 @@ class Fxcm:
     def sync(self):
         if lib().cmx_fxcm_sync(self.h):
             raise CmxError(last_error())
+
+
+class P8Stage:
+    """The paq8 stage of one stream on one GPU (include/cmix_amd.h section 2f): bytes in (host), per bit the 1591 values
+    PAQ8::Predict() returns out (device)."""
+
+    def __init__(self, device=0):
+        self.device = device
+        self.h = lib().cmx_p8stage_create(device)
+        if not self.h:
+            raise CmxError(last_error())
+
+    def run(self, data, out=None, col0=0, stream=None):
+        """data: bytes-like (host). out: cuda f32 [8 n, >= col0 + 1591] (default: a fresh [8 n, 1591]); the values go to
+        columns col0 .. col0 + 1590 of row t."""
+        import torch
+        data = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8))
+        n = len(data)
+        if out is None:
+            out = torch.empty((8 * n, 1591), dtype=torch.float32, device="cuda:%d" % self.device)
+        assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.shape[0] == 8 * n and out.shape[1] >= col0 + 1591
+        if stream is None:
+            stream = torch.cuda.current_stream(out.device).cuda_stream
+        if lib().cmx_p8stage_run(self.h, data.ctypes.data, n, out.data_ptr() + 4 * col0, out.shape[1], C.c_void_p(stream)):
+            raise CmxError(last_error())
+        return out
+
+    def sync(self):
+        if lib().cmx_p8stage_sync(self.h):
+            raise CmxError(last_error())
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().cmx_p8stage_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class P8ContextMap2:

@@ -414,6 +414,22 @@ int cmx_pipeline_stage_totals(cmx_pipeline_t*, double ms[3], uint64_t* chunks, i
  * ------------------------------------------------------------------------ */
 int cmx_probe_libm(int device, int which, const float* x, float* y, size_t n);
 
+/* ---- 2f. The paq8 stage: layer-0 columns 434..2024 = the 1591 values PAQ8::Predict() returns per bit (replaces
+ *        src/models/paq8.{h,cpp} as wired at src/predictor.cpp:85-97: PAQ8::Predict / Perceive around
+ *        paq8::Predictor::update, reference src/models/paq8.cpp:8248-8362, and contextModel2 :8101-8207).
+ *        One handle per stream. cmx_p8stage_run takes the NEXT nbytes bytes of the stream in HOST memory: the front end
+ *        (word / text / record / XML / x86 / match parsers, cmix_amd/csrc/p8front/) runs on the calling thread, the
+ *        tables, the 1552 x 28 mixer and the APM chains run as kernels ordered behind `stream`.
+ *        d_out: device matrix of f32, row t (ld floats apart, ld >= 1591) receives the 1591 values valid BEFORE bit t of
+ *        this chunk is coded (pass layer0 + 434 with ld = 2078 to fill the predictor's columns in place).
+ *        Scope: general data and text blocks; a stream that would switch on paq8's image / audio / JPEG sub-models makes
+ *        the call fail (cmx_last_error names the detector) -- never a silently different number. ~9 GB of HBM. ---- */
+typedef struct cmx_p8stage cmx_p8stage_t;
+cmx_p8stage_t* cmx_p8stage_create(int device);
+void cmx_p8stage_destroy(cmx_p8stage_t*);
+int cmx_p8stage_run(cmx_p8stage_t*, const uint8_t* bytes_host, size_t nbytes, float* d_out, size_t ld, void* stream);
+int cmx_p8stage_sync(cmx_p8stage_t*);
+
 #ifdef __cplusplus
 }
 #endif

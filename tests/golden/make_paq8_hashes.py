@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Reference-derived fixtures for the paq8 stage on streams longer than the full traces can hold: per step a 32-bit
+hash of the 1591 values PAQ8::Predict() returns (layer-0 columns 434..2024), from the UNMODIFIED reference's
+paq8::Predictor compiled from /root/reference/src/models/paq8.cpp (oracle/_ref/libcmixrefpaq8.so, oracle/Makefile)
+at cmix's level 11.   python tests/golden/make_paq8_hashes.py   ->  tests/golden/paq8_cols_*.npz
+    stream [N] u8 (what cmix's preprocessor hands the predictor: block header + payload), hash [8 N] u32."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def multipliers():
+    return np.random.default_rng(20260925).integers(1, 2**63, 1591, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+
+
+def row_hash(rows):
+    """rows [T, 1591] f32 -> [T] u32: sum over columns of (bit pattern + 1) * odd multiplier, top 32 bits."""
+    v = np.ascontiguousarray(rows, np.float32).view(np.uint32).astype(np.uint64) + np.uint64(1)
+    with np.errstate(over="ignore"):
+        h = (v * multipliers()[None, :]).sum(axis=1, dtype=np.uint64)
+    return (h >> np.uint64(32)).astype(np.uint32)
+
+
+def streams():
+    from cmix_amd import synth
+    from make_golden import default_block, text_block
+    wiki = (b"== History ==\nThe '''town''' of [[Example, Ohio|Example]] was founded in [[1820]].<ref name=\"c\">{{cite web|url=http://x.org|title=T}}</ref>\n"
+            b"{| class=\"wikitable\"\n|-\n! Year !! Pop.\n|-\n| 1900 || 1,204\n|-\n| 1910 || 1,377\n|}\n* [[Category:Towns]]\n&lt;br&gt; &amp; caf\xc3\xa9 na\xc3\xafve\n")
+    r = np.random.default_rng(5)
+    rec = b"".join(bytes([i & 255, (i >> 8) & 255, 0, 0]) + bytes(r.integers(32, 48, 12, dtype=np.uint8)) for i in range(512))
+    return {
+        "text_32k": text_block(synth.enwik_like(32768 - 6, 4242)),
+        "wiki_12k": text_block((wiki * 60)[:12288 - 6]),
+        "records_8k": default_block(rec[:8192 - 5]),
+    }
+
+
+def reference_hashes(stream):
+    L = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libcmixrefpaq8.so"))
+    L.refp8_predictor_new.restype = C.c_void_p
+    L.refp8_predictor_new.argtypes = [C.c_int]
+    L.refp8_predictor_update.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    h = L.refp8_predictor_new(11)
+    bits = np.unpackbits(np.frombuffer(stream, np.uint8))
+    out = np.full((len(bits), 1591), 0.5, np.float32)   # PAQ8::Predict() before the first Perceive: 0.5 everywhere
+    for t in range(len(bits) - 1):
+        L.refp8_predictor_update(h, int(bits[t]), out[t + 1].ctypes.data)
+    return row_hash(out)
+
+
+if __name__ == "__main__":
+    for name, s in streams().items():
+        # one reference predictor per process (it keeps state in globals)
+        if len(sys.argv) > 1 and sys.argv[1] == name:
+            np.savez_compressed(os.path.join(HERE, "paq8_cols_%s.npz" % name), stream=np.frombuffer(s, np.uint8), hash=reference_hashes(s))
+            print(name, len(s), "bytes")
+        elif len(sys.argv) == 1:
+            import subprocess
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), name])

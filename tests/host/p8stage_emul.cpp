@@ -151,7 +151,10 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
       Tl.out[nx + i] = (float)p8s_squash(Tl.squash, st[i]) * cf;
     }
     const int p2 = p8s_squash(Tl.squash, dot(st, S.mix.wx2, 32) >> 9);
-    const int fin = p8s_tail(&Tl, &c.apm[t], y, p2, Tl.out + nx + P8_NSEL);
+    int res[8];
+    for (int j = 3; j >= 0; j--) p8s_tail_a(&Tl, &c.apm[t], y, p2, j, res);
+    for (int j = 2; j >= 0; j--) p8s_tail_b(&Tl, &c.apm[t], y, p2, j, res);
+    const int fin = p8s_tail_c(&c.apm[t], p2, res, Tl.out + nx + P8_NSEL);
     Tl.pr = fin;
     memcpy(orow, Tl.out, sizeof Tl.out);
     // training with this step's bit (the reference does it at the start of the next step: nothing reads the rows in between)

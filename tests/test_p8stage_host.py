@@ -75,3 +75,54 @@ def test_stage_reproduces_golden_columns(name):
     want = np.ascontiguousarray(probs[:, 434:2025])
     bad = np.argwhere(got.view(np.uint32) != want.view(np.uint32))
     assert bad.size == 0, (name, "first mismatch (step, column):", bad[0], got[tuple(bad[0])] * 4095, want[tuple(bad[0])] * 4095)
+
+
+def oracle_columns(data):
+    from oracle import oracle as O
+    lib = O.lib()
+    lib.orc_p8_predictor_new.restype = C.c_void_p
+    lib.orc_p8_predictor_new.argtypes = [C.c_int]
+    lib.orc_p8_predictor_update.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.orc_p8_rnd_reset()
+    h = lib.orc_p8_predictor_new(11)
+    bits = np.unpackbits(np.frombuffer(bytes(data), np.uint8))
+    out = np.full((len(bits), 1591), 0.5, np.float32)
+    for t in range(len(bits) - 1):
+        assert lib.orc_p8_predictor_update(h, int(bits[t]), out[t + 1].ctypes.data) >= 0
+    return out
+
+
+@pytest.mark.parametrize("kind", ["text", "wiki", "binary", "runs"])
+def test_stage_vs_oracle(kind):
+    """Streams the fixtures do not hold, against the oracle's monolithic restatement (pinned to paq8::Predictor)."""
+    from cmix_amd import synth
+    r = np.random.default_rng(7)
+    if kind == "text":
+        data = synth.enwik_like(6000, 11)
+    elif kind == "wiki":
+        data = (b"== Heading ==\n[[Link|text]] and ''italic'' {{template|a=1}}\n* item one\n* item two\n<ref name=\"x\">cite</ref>\n" * 40)[:4000]
+    elif kind == "binary":
+        data = bytes(r.integers(0, 256, 3000, dtype=np.uint8))
+    else:
+        data = b"\x00" * 700 + b"abcabcabc" * 100 + b"\xff" * 300 + bytes(r.integers(0, 4, 1000, dtype=np.uint8))
+    got, st = run_stage(data, chunks=[1, 100, 1000])
+    want = oracle_columns(data)
+    bad = np.argwhere(got.view(np.uint32) != want.view(np.uint32))
+    assert bad.size == 0, (kind, "first mismatch (step, column):", bad[0], got[tuple(bad[0])] * 4095, want[tuple(bad[0])] * 4095, st)
+
+
+def load_hashes(name):
+    path = os.path.join(ROOT, "tests", "golden", "paq8_cols_%s.npz" % name)
+    with np.load(path) as z:
+        return z["stream"].copy(), z["hash"].copy()
+
+
+@pytest.mark.parametrize("name,nbytes", [("text_32k", 6144), ("wiki_12k", 4096), ("records_8k", 4096)])
+def test_stage_vs_reference_hashes(name, nbytes):
+    """Prefixes of the reference-derived fixtures of tests/golden/make_paq8_hashes.py (the device test runs them whole)."""
+    from make_paq8_hashes import row_hash
+    stream, want = load_hashes(name)
+    got, _ = run_stage(stream[:nbytes], chunks=[1000, 333])
+    h = row_hash(got)
+    bad = np.nonzero(h != want[:8 * nbytes])[0]
+    assert bad.size == 0, (name, "first differing step:", bad[0], "of", 8 * nbytes)

@@ -1,0 +1,68 @@
+"""The paq8 stage on the MI355X through the C ABI (cmx_p8stage_create / _run): host front end + role kernels, against
+columns 434..2024 of the committed traces of the UNMODIFIED reference predictor and against the reference-derived
+per-step hashes of tests/golden/make_paq8_hashes.py (32 KB of text, wiki markup, binary records), in ragged chunks.
+The same bodies run on the host in tests/test_p8stage_host.py."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+import make_golden as mg
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
+
+
+def run_device(data, chunks):
+    import torch
+    from cmix_amd import engine as E
+    st = E.P8Stage(0)
+    outs, pos, k = [], 0, 0
+    data = bytes(data)
+    while pos < len(data):
+        n = min(chunks[k % len(chunks)], len(data) - pos)
+        k += 1
+        o = st.run(data[pos:pos + n])
+        outs.append(o)
+        pos += n
+    st.sync()
+    got = torch.cat(outs).cpu().numpy()
+    st.close()
+    return got
+
+
+@pytest.mark.parametrize("name", ["text_96", "binary_64"])
+def test_stage_reproduces_golden_columns(name):
+    g = load_golden(name)
+    probs = mg.unpack_probs(g)
+    got = run_device(g["stream"], [1, 1, 7, 30])
+    want = np.ascontiguousarray(probs[:, 434:2025])
+    bad = np.argwhere(got.view(np.uint32) != want.view(np.uint32))
+    assert bad.size == 0, (name, "first mismatch (step, column):", bad[0], got[tuple(bad[0])] * 4095, want[tuple(bad[0])] * 4095)
+
+
+@pytest.mark.parametrize("name", ["text_32k", "wiki_12k", "records_8k"])
+def test_stage_vs_reference_hashes(name):
+    from make_paq8_hashes import row_hash
+    from test_p8stage_host import load_hashes
+    stream, want = load_hashes(name)
+    got = run_device(stream, [1024, 1, 4096, 333])
+    h = row_hash(got)
+    bad = np.nonzero(h != want)[0]
+    assert bad.size == 0, (name, "first differing step:", bad[0], "of", len(want))
+
+
+def test_layer0_columns_in_place():
+    """Writing straight into columns 434..2024 of a [T, 2078] layer-0 matrix leaves the other columns alone."""
+    import torch
+    from cmix_amd import engine as E
+    g = load_golden("text_96")
+    probs = mg.unpack_probs(g)
+    st = E.P8Stage(0)
+    l0 = torch.full((8 * len(g["stream"]), 2078), -1.0, dtype=torch.float32, device="cuda")
+    st.run(bytes(g["stream"]), out=l0, col0=434)
+    st.sync()
+    got = l0.cpu().numpy()
+    st.close()
+    assert (got[:, :434] == -1).all() and (got[:, 2025:] == -1).all()
+    assert np.array_equal(got[:, 434:2025].view(np.uint32), np.ascontiguousarray(probs[:, 434:2025]).view(np.uint32))
