@@ -43,6 +43,7 @@ struct Slot {
   int16_t* d_fx_pr = nullptr;   // [8 max] fxcm stage (opt-in): lstmpr per update
   uint8_t* d_fx_ex = nullptr;   // [8 max] lstmex per update
   hipEvent_t ev_fxin = nullptr, ev_fx0 = nullptr, ev_fx1 = nullptr;
+  hipEvent_t ev_p80 = nullptr, ev_p81 = nullptr;   // paq8 stage (opt-in)
   bool used = false;
   bool untimed = false;  // the chunk in this slot has not been added to the stage totals yet
 };
@@ -60,6 +61,10 @@ struct cmx_pipeline {
   hipStream_t s_fx = nullptr;
   float* d_fx_scratch = nullptr; // pretraining writes its (discarded) rows here
   double fx_ms = 0;
+  cmx_p8stage_t* p8 = nullptr;   // device paq8 stage (cmx_pipeline_enable_paq8); NULL: the caller supplies columns 434..2024
+  hipStream_t s_p8 = nullptr;
+  float* d_p8_scratch = nullptr; // pretraining writes its (discarded) rows here
+  double p8_ms = 0;
   Slot slot[kSlots];
   uint64_t chunks = 0;    // chunks begun
   uint64_t hinted = 0;    // chunks whose LSTM hints were handed out (<= chunks)
@@ -80,6 +85,7 @@ void collect(cmx_pipeline* h, Slot& s) {  // the slot's chunk has finished (its 
   (void)hipEventElapsedTime(&ms[2], s.ev_mix0, s.ev_mix1);
   for (int i = 0; i < 3; ++i) h->tot_ms[i] += ms[i];
   if (h->fxcm) { float f = 0; (void)hipEventElapsedTime(&f, s.ev_fx0, s.ev_fx1); h->fx_ms += f; }
+  if (h->p8) { float f = 0; (void)hipEventElapsedTime(&f, s.ev_p80, s.ev_p81); h->p8_ms += f; }
   h->tot_chunks++;
   s.untimed = false;
 }
@@ -112,7 +118,7 @@ void cmx_pipeline_destroy(cmx_pipeline_t* h) {
     if (s.h_hint) (void)hipHostFree(s.h_hint);
     if (s.d_fx_pr) (void)hipFree(s.d_fx_pr);
     if (s.d_fx_ex) (void)hipFree(s.d_fx_ex);
-    for (hipEvent_t e : {s.ev_fxin, s.ev_fx0, s.ev_fx1})
+    for (hipEvent_t e : {s.ev_fxin, s.ev_fx0, s.ev_fx1, s.ev_p80, s.ev_p81})
       if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : {s.ev_in, s.ev_ctx0, s.ev_ctx1, s.ev_lstm0, s.ev_lstm1, s.ev_mix0, s.ev_mix1, s.ev_cols})
       if (e) (void)hipEventDestroy(e);
@@ -122,6 +128,9 @@ void cmx_pipeline_destroy(cmx_pipeline_t* h) {
   if (h->s_mix) (void)hipStreamDestroy(h->s_mix);
   if (h->s_fx) (void)hipStreamDestroy(h->s_fx);
   if (h->d_fx_scratch) (void)hipFree(h->d_fx_scratch);
+  if (h->s_p8) (void)hipStreamDestroy(h->s_p8);
+  if (h->d_p8_scratch) (void)hipFree(h->d_p8_scratch);
+  cmx_p8stage_destroy(h->p8);
   cmx_fxcm_destroy(h->fxcm);
   cmx_mixnet_destroy(h->mix);
   cmx_lstm_destroy(h->lstm);
@@ -180,8 +189,8 @@ int cmx_pipeline_enable_fxcm(cmx_pipeline_t* h, const char* dictionary_path) {
   if (h->fxcm) return 0;
   if (h->chunks) { cmx_set_err("cmx_pipeline_enable_fxcm: only before the first chunk"); return 1; }
   if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
-  h->fxcm = cmx_fxcm_create(dictionary_path, h->device);
-  if (!h->fxcm) return 1;
+  cmx_fxcm_t* fx = cmx_fxcm_create(dictionary_path, h->device);
+  if (!fx) return 1;
   const size_t n = h->max_chunk;
   bool ok = hipStreamCreateWithFlags(&h->s_fx, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipMalloc((void**)&h->d_fx_scratch, 8 * n * 434 * sizeof(float)) == hipSuccess;
@@ -190,9 +199,51 @@ int cmx_pipeline_enable_fxcm(cmx_pipeline_t* h, const char* dictionary_path) {
     ok = ok && hipMalloc((void**)&s.d_fx_ex, 8 * n) == hipSuccess;
     for (hipEvent_t* e : {&s.ev_fxin, &s.ev_fx0, &s.ev_fx1}) ok = ok && hipEventCreate(e) == hipSuccess;
   }
-  if (!ok) { cmx_set_err("cmx_pipeline_enable_fxcm: stream / buffer allocation failed"); return 1; }
+  if (!ok) {   // leave the handle as it was: no half-enabled stage (a retry starts from scratch)
+    for (Slot& s : h->slot) {
+      if (s.d_fx_pr) (void)hipFree(s.d_fx_pr);
+      if (s.d_fx_ex) (void)hipFree(s.d_fx_ex);
+      s.d_fx_pr = nullptr; s.d_fx_ex = nullptr;
+      for (hipEvent_t* e : {&s.ev_fxin, &s.ev_fx0, &s.ev_fx1}) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
+    }
+    if (h->s_fx) (void)hipStreamDestroy(h->s_fx);
+    if (h->d_fx_scratch) (void)hipFree(h->d_fx_scratch);
+    h->s_fx = nullptr; h->d_fx_scratch = nullptr;
+    cmx_fxcm_destroy(fx);
+    cmx_set_err("cmx_pipeline_enable_fxcm: stream / buffer allocation failed");
+    return 1;
+  }
+  h->fxcm = fx;
   return 0;
 }
+
+// ---- the paq8 stage on the device (opt-in): layer-0 columns 434..2024 (include/cmix_amd.h section 2f) ------------
+int cmx_pipeline_enable_paq8(cmx_pipeline_t* h) {
+  if (!h) { cmx_set_err("cmx_pipeline_enable_paq8: null handle"); return 1; }
+  if (h->p8) return 0;
+  if (h->chunks) { cmx_set_err("cmx_pipeline_enable_paq8: only before the first chunk"); return 1; }
+  if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
+  cmx_p8stage_t* p8 = cmx_p8stage_create(h->device);
+  if (!p8) return 1;
+  bool ok = hipStreamCreateWithFlags(&h->s_p8, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipMalloc((void**)&h->d_p8_scratch, 8 * h->max_chunk * 1591 * sizeof(float)) == hipSuccess;
+  for (Slot& s : h->slot)
+    for (hipEvent_t* e : {&s.ev_p80, &s.ev_p81}) ok = ok && hipEventCreate(e) == hipSuccess;
+  if (!ok) {
+    for (Slot& s : h->slot)
+      for (hipEvent_t* e : {&s.ev_p80, &s.ev_p81}) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
+    if (h->s_p8) (void)hipStreamDestroy(h->s_p8);
+    if (h->d_p8_scratch) (void)hipFree(h->d_p8_scratch);
+    h->s_p8 = nullptr; h->d_p8_scratch = nullptr;
+    cmx_p8stage_destroy(p8);
+    cmx_set_err("cmx_pipeline_enable_paq8: stream / buffer allocation failed");
+    return 1;
+  }
+  h->p8 = p8;
+  return 0;
+}
+int cmx_pipeline_paq8_enabled(cmx_pipeline_t* h) { return h && h->p8 ? 1 : 0; }
+int cmx_pipeline_paq8_total_ms(cmx_pipeline_t* h, double* ms) { if (!h || !ms) return 1; *ms = h->p8_ms; return 0; }
 int cmx_pipeline_fxcm_enabled(cmx_pipeline_t* h) { return h && h->fxcm ? 1 : 0; }
 // HIP-event time of the fxcm kernel over the chunks counted by cmx_pipeline_stage_totals (same reset)
 int cmx_pipeline_fxcm_total_ms(cmx_pipeline_t* h, double* ms) { if (!h || !ms) return 1; *ms = h->fx_ms; return 0; }
@@ -252,6 +303,11 @@ int cmx_pipeline_begin(cmx_pipeline_t* h, const uint8_t* bytes, size_t n, float*
     if (cmx_fxcm_run(h->fxcm, bytes, s.d_bytes, n, s.d_fx_pr, s.d_fx_ex, d_layer0, CMX_N_INPUTS, h->s_fx)) return 1;
     (void)hipEventRecord(s.ev_fx1, h->s_fx);
   }
+  if (h->p8) {  // ---- paq8 stage: front end on this thread, role kernels on its own streams; needs nothing from the other stages ----
+    (void)hipEventRecord(s.ev_p80, h->s_p8);
+    if (cmx_p8stage_run(h->p8, bytes, n, d_layer0 + 434, CMX_N_INPUTS, h->s_p8)) return 1;
+    (void)hipEventRecord(s.ev_p81, h->s_p8);
+  }
   s.used = true;
   s.untimed = false;  // becomes true once its mixing network is enqueued
   h->chunks++;
@@ -292,12 +348,13 @@ int cmx_pipeline_hints(cmx_pipeline_t* h, float* lstm_p, int* lstm_ex) {
 // = the caller has already written them into d_layer0) and its mixing network. Asynchronous.
 static int finish_impl(cmx_pipeline_t* h, const float* cols, int first_col, int ncols, float* d_p_out);
 int cmx_pipeline_finish(cmx_pipeline_t* h, const float* cols, float* d_p_out) {
+  if (h && h->fxcm && h->p8 && cols) { cmx_set_err("cmx_pipeline_finish: the fxcm and paq8 stages are on the device: there are no columns to hand in"); return 1; }
   if (h && h->fxcm && cols) { cmx_set_err("cmx_pipeline_finish: the fxcm stage is on the device; hand in columns 434..2024 with cmx_pipeline_finish_cols"); return 1; }
   return finish_impl(h, cols, 3, 2022, d_p_out);
 }
 // the same with the caller's rows covering layer-0 columns first_col .. first_col + ncols - 1 only (HOST rows of ncols floats)
 int cmx_pipeline_finish_cols(cmx_pipeline_t* h, const float* cols, int first_col, int ncols, float* d_p_out) {
-  if (!cols || first_col < 3 || ncols <= 0 || first_col + ncols > 2025 || (h && h->fxcm && first_col < 434)) { cmx_set_err("cmx_pipeline_finish_cols: bad column range"); return 1; }
+  if (!cols || first_col < 3 || ncols <= 0 || first_col + ncols > 2025 || (h && h->fxcm && first_col < 434) || (h && h->p8 && first_col + ncols > 434)) { cmx_set_err("cmx_pipeline_finish_cols: bad column range"); return 1; }
   return finish_impl(h, cols, first_col, ncols, d_p_out);
 }
 static int finish_impl(cmx_pipeline_t* h, const float* cols, int first_col, int ncols, float* d_p_out) {
@@ -316,6 +373,7 @@ static int finish_impl(cmx_pipeline_t* h, const float* cols, int first_col, int 
   (void)hipStreamWaitEvent(h->s_mix, s.ev_ctx1, 0);
   (void)hipStreamWaitEvent(h->s_mix, s.ev_lstm1, 0);
   if (h->fxcm) (void)hipStreamWaitEvent(h->s_mix, s.ev_fx1, 0);
+  if (h->p8) (void)hipStreamWaitEvent(h->s_mix, s.ev_p81, 0);
   (void)hipEventRecord(s.ev_mix0, h->s_mix);
   if (cmx_mixnet_run(h->mix, s.d_layer0, s.d_sel, s.d_bits, 8 * n, d_p_out, nullptr, h->s_mix)) return 1;
   (void)hipEventRecord(s.ev_mix1, h->s_mix);
@@ -361,8 +419,26 @@ int cmx_pipeline_pretrain(cmx_pipeline_t* h, const uint8_t* bytes, size_t n) {
     if (zpr) (void)hipFree(zpr);
     if (zex) (void)hipFree(zex);
   }
+  if (ok && h->p8) {  // paq8 is one of models_ too: its Perceive per dictionary bit (predictor.cpp:471-476), the rows are discarded
+    const size_t C = h->max_chunk;
+    for (size_t off = 0; ok && off < n; off += C) {
+      const size_t m = n - off < C ? n - off : C;
+      ok = cmx_p8stage_run(h->p8, bytes + off, m, h->d_p8_scratch, 1591, h->s_p8) == 0;
+    }
+    ok = hipStreamSynchronize(h->s_p8) == hipSuccess && ok;
+  }
   (void)hipFree(d);
   if (!ok) { cmx_set_err("cmx_pipeline_pretrain: device error"); return 1; }
+  return 0;
+}
+
+// Wait until chunk number `index` (0 = the first chunk submitted) has left the mixing network: its p[] is complete.
+// Only the last four chunks can be waited for (their slots still hold the events).
+int cmx_pipeline_wait(cmx_pipeline_t* h, uint64_t index) {
+  if (!h) { cmx_set_err("cmx_pipeline_wait: null handle"); return 1; }
+  if (index >= h->finished || index + kSlots < h->finished) { cmx_set_err("cmx_pipeline_wait: that chunk is not in flight"); return 1; }
+  if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
+  if (hipEventSynchronize(h->slot[index % kSlots].ev_mix1) != hipSuccess) { cmx_set_err("cmx_pipeline_wait: device error"); return 1; }
   return 0;
 }
 
@@ -373,6 +449,7 @@ int cmx_pipeline_sync(cmx_pipeline_t* h) {
   ok = hipStreamSynchronize(h->s_lstm) == hipSuccess && ok;
   ok = hipStreamSynchronize(h->s_mix) == hipSuccess && ok;
   if (h->s_fx) ok = hipStreamSynchronize(h->s_fx) == hipSuccess && ok;
+  if (h->p8) ok = cmx_p8stage_sync(h->p8) == 0 && ok;
   if (!ok) { cmx_set_err("cmx_pipeline_sync: device error"); return 1; }
   if (cmx_ctxmodels_sync(h->ctx) || cmx_mixnet_sync(h->mix)) return 1;
   for (Slot& s : h->slot) collect(h, s);
@@ -389,7 +466,7 @@ int cmx_pipeline_stage_totals(cmx_pipeline_t* h, double ms[3], uint64_t* chunks,
   if (!h || !ms || !chunks) return 1;
   for (int i = 0; i < 3; ++i) ms[i] = h->tot_ms[i];
   *chunks = h->tot_chunks;
-  if (reset) { h->tot_ms[0] = h->tot_ms[1] = h->tot_ms[2] = 0; h->tot_chunks = 0; h->fx_ms = 0; }
+  if (reset) { h->tot_ms[0] = h->tot_ms[1] = h->tot_ms[2] = 0; h->tot_chunks = 0; h->fx_ms = 0; h->p8_ms = 0; }
   return 0;
 }
 

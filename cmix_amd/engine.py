@@ -158,6 +158,9 @@ def lib():
         L.cmx_pipeline_fxcm_enabled.argtypes = [C.c_void_p]
         L.cmx_pipeline_finish_cols.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.cmx_pipeline_fxcm_total_ms.argtypes = [C.c_void_p, C.c_void_p]
+        L.cmx_pipeline_enable_paq8.argtypes = [C.c_void_p]
+        L.cmx_pipeline_wait.argtypes = [C.c_void_p, C.c_uint64]
+        L.cmx_pipeline_paq8_total_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.cmx_pipeline_last_stage_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.cmx_probe_libm.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
         _lib = L
@@ -437,6 +440,20 @@ class Pipeline:
         """Run the fxcm family as a device stage (columns 3..433) instead of taking its columns from the caller; before the first chunk."""
         if lib().cmx_pipeline_enable_fxcm(self.h, dictionary_path.encode() if isinstance(dictionary_path, str) else dictionary_path):
             raise CmxError(last_error())
+
+    def wait(self, index):
+        if lib().cmx_pipeline_wait(self.h, index):
+            raise CmxError(last_error())
+
+    def enable_paq8(self):
+        """Run the paq8 family as a device stage (columns 434..2024); before the first chunk."""
+        if lib().cmx_pipeline_enable_paq8(self.h):
+            raise CmxError(last_error())
+
+    def paq8_total_ms(self):
+        ms = C.c_double(0)
+        lib().cmx_pipeline_paq8_total_ms(self.h, C.byref(ms))
+        return ms.value
 
     def finish_cols(self, cols, first_col, p_out):
         """finish() with host rows covering layer-0 columns first_col .. first_col + cols.shape[1] - 1 only."""

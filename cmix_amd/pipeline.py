@@ -104,3 +104,65 @@ def compress_stream(stream, vocab, layer0, device_index=0, chunk_bytes=4096, pre
     finally:
         enc.close()
         pipe.close()
+
+
+def text_block(payload):
+    """What `cmix -c` without a dictionary hands the predictor for a plain-text file: preprocessor::Encode detects one
+    TEXT block and writes type byte 4, the big-endian block length, the WRT flag 0, then the bytes (reference
+    src/preprocess/preprocessor.cpp:443-449,536-537). bench.py checks the resulting .cmix file against the reference
+    binary's (tests/golden/dropin_*.npz), which pins this framing."""
+    n = len(payload) + 1
+    return bytes([4]) + n.to_bytes(4, "big") + b"\x00" + bytes(payload)
+
+
+class EngineStream:
+    """One input stream through the WHOLE engine on one GPU: every model family has a stage (contexts + small models,
+    PPMd host stage, LSTM, fxcm, paq8) and the final mixing network consumes their 2078 columns -- what `Predictor`
+    is for a compressor (reference src/predictor.cpp:361-469), a sub-chunk of known bytes at a time. feed() enqueues;
+    finish() returns the container bytes (header + arithmetic code), identical to the reference binary's file."""
+
+    def __init__(self, device_index, stream, sub_chunk=4096, dictionary_used=False):
+        import torch
+        self.torch = torch
+        self.dev = torch.device("cuda", device_index)
+        self.stream = np.ascontiguousarray(np.frombuffer(bytes(stream), np.uint8))
+        n = len(self.stream)
+        self.sub = max(1, min(sub_chunk, n))
+        self.vocab = np.ones(256, np.uint8)
+        if n >= 10000:  # kMinVocabFileSize (runner.cpp:14,196-199)
+            self.vocab = np.zeros(256, np.uint8)
+            self.vocab[np.unique(self.stream)] = 1
+        self.header = E.header_write(n, self.vocab, dictionary_used)
+        self.layer0 = [torch.empty((8 * self.sub, E.N_INPUTS), dtype=torch.float32, device=self.dev) for _ in range(4)]
+        self.p_dev = torch.empty(8 * n, dtype=torch.float32, device=self.dev)
+        self.pipe = E.Pipeline(self.vocab, device_index, self.sub)
+        self.pipe.enable_fxcm(None)
+        self.pipe.enable_paq8()
+        self.pos = 0
+        self.nsub = 0
+        torch.cuda.synchronize(self.dev)
+
+    def feed(self, nbytes):
+        """The next nbytes bytes of the stream, in sub-chunks (asynchronous; up to four sub-chunks in flight)."""
+        end = min(self.pos + nbytes, len(self.stream))
+        while self.pos < end:
+            m = min(self.sub, end - self.pos)
+            l0 = self.layer0[self.nsub % 4][:8 * m]
+            self.pipe.submit(self.stream[self.pos:self.pos + m], l0, self.p_dev[8 * self.pos:8 * (self.pos + m)])
+            self.pos += m
+            self.nsub += 1
+
+    def finish(self):
+        """Wait for the device, bring p[] back, run the arithmetic coder (host: a multiply-add and a compare per bit)."""
+        self.pipe.sync()
+        p = self.p_dev[:8 * self.pos].cpu().numpy()
+        enc = E.Encoder()
+        try:
+            enc.encode_bytes(p, self.stream[:self.pos])
+            enc.flush()
+            return self.header + enc.data()
+        finally:
+            enc.close()
+
+    def close(self):
+        self.pipe.close()

@@ -395,6 +395,15 @@ int cmx_pipeline_finish(cmx_pipeline_t*, const float* cols, float* d_p_out);
  * first_col + ncols - 1; with the fxcm stage enabled first_col >= 434) -- cmx_pipeline_finish with rows then fails.
  * dictionary_path: as cmx_fxcm_create. */
 int cmx_pipeline_enable_fxcm(cmx_pipeline_t*, const char* dictionary_path);
+/* The paq8 stage on the device (section 2f at the end of this file), opt-in, before the first chunk: cmx_pipeline_begin then
+ * also runs it (front end on the calling thread, kernels on the stage's own streams) into columns 434..2024 of d_layer0;
+ * cmx_pipeline_pretrain feeds it the dictionary. With both vendored families on the device cmx_pipeline_finish takes no
+ * columns (cmx_pipeline_submit does everything) and the Predictor shim needs no cmx_set_model_outputs. */
+int cmx_pipeline_enable_paq8(cmx_pipeline_t*);
+/* Wait until chunk number `index` (0 = the first submitted) has left the mixing network; only the last four can be waited for. */
+int cmx_pipeline_wait(cmx_pipeline_t*, uint64_t index);
+int cmx_pipeline_paq8_enabled(cmx_pipeline_t*);
+int cmx_pipeline_paq8_total_ms(cmx_pipeline_t*, double* ms);
 int cmx_pipeline_fxcm_enabled(cmx_pipeline_t*);
 int cmx_pipeline_finish_cols(cmx_pipeline_t*, const float* cols, int first_col, int ncols, float* d_p_out);
 int cmx_pipeline_fxcm_total_ms(cmx_pipeline_t*, double* ms);

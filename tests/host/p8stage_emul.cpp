@@ -30,6 +30,8 @@ struct Emul {
   uint64_t steps = 0;
   int last_bit = 0;
   uint64_t fam_serial = 0, cm2_serial = 0;
+  // diagnostics: per family instance, lookup bits with an overlap / with an overlap AND a pending rnd() draw in the instance
+  uint64_t inst_conf[P8CM_MAXI] = {}, inst_risky[P8CM_MAXI] = {}, lookups = 0, bits_with_conf = 0, bits_with_risky = 0, draws_total = 0, multi_conf = 0;
 };
 int16_t sat16(int v) { return (int16_t)(v > 32767 ? 32767 : v < -32768 ? -32768 : v); }
 int dot(const int16_t* t, const int16_t* w, int n) {
@@ -70,6 +72,14 @@ void p8s_destroy(void* h) {
   p8f_front_free(e->front);
   for (void* p : e->pol.blocks) free(p);
   delete e;
+}
+void p8s_conflict_report(void* h) {
+  Emul* e = (Emul*)h;
+  printf("lookup bits %llu: with an overlap %llu (two or more instances %llu), with overlap + pending draw %llu; draws %llu\n", (unsigned long long)e->lookups,
+         (unsigned long long)e->bits_with_conf, (unsigned long long)e->multi_conf, (unsigned long long)e->bits_with_risky, (unsigned long long)e->draws_total);
+  for (int k = 0; k < e->S.fam.ninst; k++)
+    printf("  inst %2d (%3d ctx, %8u buckets): overlap %llu, + draw %llu\n", k, e->S.fam.inst[k].count, e->S.fam.inst[k].mask + 1, (unsigned long long)e->inst_conf[k],
+           (unsigned long long)e->inst_risky[k]);
 }
 void p8s_stats(void* h, uint64_t* out3) { Emul* e = (Emul*)h; out3[0] = e->steps; out3[1] = e->fam_serial; out3[2] = e->cm2_serial; }
 // nbytes more bytes of the stream; out [8 nbytes][1591] f32 = PAQ8::Predict() before each of their bits. 0 or a negative front-end code.
@@ -122,6 +132,24 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
       for (int s = d->nslots - 1; s >= 0; s--) p8d_cm_check(d, &e->fsh, s);
       for (int s = d->nslots - 1; s >= 0; s--) p8d_cm_draw(d, &e->fsh, s);
       e->fam_serial += e->fsh.conflict != 0;
+      e->draws_total += (uint64_t)e->fsh.ndraws;
+      if (fu.bp == 0 || fu.bp == 2 || fu.bp == 5) {
+        e->lookups++;
+        int nconf = 0, nrisky = 0;
+        for (int k = 0; k < d->ninst; k++) {
+          const P8CmInst* x = &d->inst[k];
+          int hit = 0, draw = 0;
+          for (int a = x->first; a < x->first + x->count; a++) {
+            draw |= e->fsh.draws[a];
+            for (int b = a + 1; b < x->first + x->count && !hit; b++)
+              for (int i = 0; i < 5 && !hit; i++)
+                if (e->fsh.touched[a][i] >= 0)
+                  for (int j = 0; j < 5; j++) if (e->fsh.touched[a][i] == e->fsh.touched[b][j]) { hit = 1; break; }
+          }
+          if (hit) { e->inst_conf[k]++; nconf++; if (draw) { e->inst_risky[k]++; nrisky++; } }
+        }
+        e->bits_with_conf += nconf > 0; e->bits_with_risky += nrisky > 0; e->multi_conf += nconf > 1;
+      }
       for (int s = d->nslots - 1; s >= 0; s--) p8d_cm_run(d, &e->fsh, fu, s);
     }
     if (g == 0) { memcpy(orow, S.tail.out, sizeof S.tail.out); continue; }   // no step 0: the constructor's 0.5

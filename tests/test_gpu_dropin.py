@@ -133,3 +133,44 @@ def test_lookahead_1mib_shard_prefix_is_byte_identical():
         want_sha, want_size, (n, seed) = z["sha256"].tobytes(), int(z["size"][0]), z["seed"]
     got = _run("-c", [("in", synth.enwik_like(int(n), int(seed)))], exe=LOOKAHEAD, timeout=1500)
     assert len(got) == want_size and hashlib.sha256(got).digest() == want_sha
+
+
+# ---- the whole predictor on the device ---------------------------------------------------------------------------
+# oracle/_ref/cmix_engine = integration/compress_engine.cpp + the reference's unmodified preprocessor + libcmixamd.so and
+# NOTHING else: no reference model object is linked (fxcm and paq8 are engine stages, cmx_pipeline_enable_fxcm / _paq8).
+ENGINE = os.path.join(ROOT, "oracle", "_ref", "cmix_engine")
+
+
+def _engine_vectors():
+    if not os.path.exists(ENGINE):
+        pytest.skip("oracle/_ref/cmix_engine not built (make -C oracle engine)")
+    return _vectors()
+
+
+def test_engine_links_no_reference_model():
+    if not os.path.exists(ENGINE):
+        pytest.skip("oracle/_ref/cmix_engine not built")
+    syms = subprocess.run(["nm", "-C", ENGINE], capture_output=True, text=True).stdout
+    assert "paq8" not in syms.replace("cmx_pipeline_enable_paq8", "") and "fxcmv1" not in syms and "PPMD" not in syms
+
+
+def test_engine_no_preprocessing_file_is_byte_identical():
+    v = _engine_vectors()
+    assert _run("-n", [("in", v["raw_n_payload"])], exe=ENGINE) == v["raw_n_file"]
+
+
+def test_engine_text_and_dictionary_files_are_byte_identical():
+    v = _engine_vectors()
+    assert _run("-c", [("in", v["text_c_payload"])], exe=ENGINE) == v["text_c_file"]
+    assert _run("-c", [("dict", v["dict_payload"]), ("in", v["dict_c_payload"])], exe=ENGINE) == v["dict_c_file"]
+
+
+def test_engine_12k_and_50k_files_are_byte_identical():
+    import hashlib
+    from cmix_amd import synth
+    v = _engine_vectors()
+    assert _run("-c", [("in", v["text12k_c_payload"])], exe=ENGINE) == v["text12k_c_file"]
+    with np.load(os.path.join(GOLDEN, "dropin_vectors.npz")) as z:
+        want_sha, want_size, (n, seed) = z["text50k_c_sha256"].tobytes(), int(z["text50k_c_size"][0]), z["text50k_c_seed"]
+    got = _run("-c", [("in", synth.enwik_like(int(n), int(seed)))], exe=ENGINE, timeout=900)
+    assert len(got) == want_size and hashlib.sha256(got).digest() == want_sha
