@@ -92,7 +92,7 @@ def main():
     import torch
     import torch.distributed as dist
     from cmix_amd import shard, synth
-    from cmix_amd.pipeline import EngineStream, text_block
+    from cmix_amd.pipeline import EngineStream, text_file_stream
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -105,7 +105,7 @@ def main():
     torch.cuda.set_device(local)
 
     payload = synth.enwik_like(a.payload_bytes, shard.shard_seed(rank))
-    stream = text_block(payload)
+    stream = text_file_stream(payload)
     n = len(stream)
     step_bytes = -(-n // a.steps)
 

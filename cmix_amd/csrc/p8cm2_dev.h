@@ -47,8 +47,7 @@ P8_HD int p8d_sm32(uint32_t* t, int* cxt, int y, int cx) {   // StateMap32::p wi
   uint32_t p0 = t[*cxt];
   const int n = p0 & 1023, pr = p0 >> 10;
   if (n < 1023) ++p0; else p0 = (p0 & 0xfffffc00u) | 1023u;
-  const int delta = (((y << 22) - pr) >> 3) * (16384 / (n + n + 3));
-  p0 += (uint32_t)delta & 0xfffffc00u;
+  p0 += ((uint32_t)(((y << 22) - pr) >> 3) * (uint32_t)(16384 / (n + n + 3))) & 0xfffffc00u;   // the product wraps (as the reference's compiled code does)
   t[*cxt] = p0;
   *cxt = cx;
   return (int)(t[cx] >> 20);

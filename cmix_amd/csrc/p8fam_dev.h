@@ -1,0 +1,410 @@
+// p8fam_dev.h -- the ContextMap family of the paq8 stage, second design (the first, p8cm_dev.h, is kept as the stand-alone
+// building block): the same 204 contexts of 16 instances with the shared rnd() stream (reference src/models/paq8.cpp:
+// 1010-1145, :152-165), one lane per context, but
+//   * the 7 state bytes of a context's current bucket slot, its run bytes and its StateMap live in LDS (160 KB per CU:
+//     204 x 512 B of StateMaps + tables + staging); HBM/L2 is touched only at the three bucket lookups per byte
+//     (bit positions 0, 2, 5), whose 64-byte buckets are fetched by all lanes at once before a barrier; every
+//     modification is also stored through to the table at once (fire and forget), so the table is always current;
+//   * overlap detection (two contexts of one instance touching the same bucket in the same bit, the only way contexts
+//     interact) runs at lookup bits only, through an LDS hash set with compare-and-swap: O(1) per lane;
+//   * the rnd() draws: a bit history reaching state >= 204 decays with a value of the ONE process-wide generator,
+//     consumed in the reference's walk order. Lanes publish a draw bit, ranks are prefix popcounts, the values come from
+//     an LDS ring that always holds the next 256 values of the sequence;
+//   * a bit with an overlap runs in ROUNDS over the instance order: runs of overlap-free instances lane-parallel, an
+//     instance with an overlap walked by its first lane on the table itself in the reference's order -- exact whatever
+//     the overlap does to replacement decisions or draws -- then its lanes reload their cached bytes.
+// One barrier per bit on the common path. Single source: tests/host/p8stage_emul.cpp runs these steps on the host.
+#ifndef CMX_P8FAM_DEV_H
+#define CMX_P8FAM_DEV_H
+#include <stdint.h>
+
+#include "p8cm_dev.h"
+
+enum { P8F_HASH = 2048, P8F_RV = 512, P8F_NIL = 0xFF, P8F_LOOK = 256 };
+
+#ifdef __HIPCC__
+#define P8F_CAS(p, c, v) atomicCAS((p), (c), (v))
+#define P8F_OR(p, v) atomicOr((p), (v))
+#define P8F_POPC(x) __popc(x)
+#else
+static inline uint32_t p8f_cas_host(uint32_t* p, uint32_t c, uint32_t v) { const uint32_t o = *p; if (o == c) *p = v; return o; }
+#define P8F_CAS(p, c, v) p8f_cas_host((p), (c), (v))
+#define P8F_OR(p, v) (*(p) |= (v))
+#define P8F_POPC(x) __builtin_popcount(x)
+#endif
+
+// per-context state between chunks (HBM); during a chunk the copy in P8FamShared is the live one
+struct P8FamHome {
+  uint32_t cp0[P8CM_MAXS], runp[P8CM_MAXS];          // byte offsets into the instance's table: slot base, run bytes
+  uint8_t cpo[P8CM_MAXS], rc[P8CM_MAXS], rb[P8CM_MAXS], smc[P8CM_MAXS];   // cp - cp0 (P8F_NIL: none), run count / byte, StateMap context
+  uint8_t slot[P8CM_MAXS][8];                         // the slot's 7 state bytes
+};
+struct P8FamShared {
+  P8FamHome r;
+  uint8_t bk[P8CM_MAXS][64];        // the bucket each lane is about to search (fetched before the barrier of a lookup bit)
+  uint8_t nex[1024];
+  int16_t stretch[4096];
+  uint8_t ilog[260];
+  uint32_t hash[2][P8F_HASH];       // touched (instance, bucket) pairs of a lookup bit
+  uint32_t db[3][8];                // draw bits of the bit, one per slot
+  uint8_t conflict[2][P8CM_MAXI + 8];
+  uint32_t anyconf[2];
+  uint8_t shared[P8CM_MAXI + 8];   // the instance has two contexts on one bucket slot (established by an overlap; lasts until they look up again)
+  uint32_t anyshared;
+  uint32_t rv[P8F_RV];              // rv[idx & 511] = value number idx of the generator, idx in (i - 64, i + 256]
+  uint32_t walk_cnt;
+  uint16_t sm[1];                   // [nslots][256] u16 StateMaps follow (dynamic LDS)
+};
+// per lane, per bit scratch: registers on the device, an array on the host
+struct P8FamTmp { int ns, draw, look; uint32_t nb; };
+struct P8FamUni { int y, bp, c0, c1, order, lk; uint32_t rnd_i; const uint32_t* ctx; const uint16_t* chk; int16_t* out; int t; };
+
+P8_HD uint16_t* p8f_smrow(P8FamShared* sh, int s) { return sh->sm + (size_t)s * 256; }
+P8_HD uint32_t p8f_ctx(const P8CmDev* d, const P8FamUni& u, int s) { return s == d->order_slot ? d->order_ctx[u.order] : u.ctx[s]; }
+P8_HD uint16_t p8f_chk(const P8CmDev* d, const P8FamUni& u, int s) { return s == d->order_slot ? d->order_chk[u.order] : u.chk[s]; }
+
+// ---- chunk start / end -------------------------------------------------------------------------------------------
+P8_HD void p8f_load(const P8CmDev* d, const P8FamHome* home, const uint16_t* sm_home, P8FamShared* sh, int tid, int nthreads) {
+  const int S = d->nslots;
+  for (int s = tid; s < S; s += nthreads) {
+    sh->r.cp0[s] = home->cp0[s]; sh->r.runp[s] = home->runp[s]; sh->r.cpo[s] = home->cpo[s]; sh->r.rc[s] = home->rc[s]; sh->r.rb[s] = home->rb[s];
+    sh->r.smc[s] = home->smc[s];
+    for (int j = 0; j < 8; j++) sh->r.slot[s][j] = home->slot[s][j];
+  }
+  for (int i = tid; i < S * 256; i += nthreads) sh->sm[i] = sm_home[i];
+  for (int i = tid; i < 1024; i += nthreads) sh->nex[i] = d->nex[i];
+  for (int i = tid; i < 4096; i += nthreads) sh->stretch[i] = d->stretch[i];
+  for (int i = tid; i < 257; i += nthreads) sh->ilog[i] = d->ilog[i];
+  { uint32_t* p = &sh->hash[0][0]; for (int i = tid; i < 2 * P8F_HASH; i += nthreads) p[i] = 0; }
+  { uint32_t* p = &sh->db[0][0]; for (int i = tid; i < 24; i += nthreads) p[i] = 0; }
+  { uint8_t* p = &sh->conflict[0][0]; for (int i = tid; i < 2 * (P8CM_MAXI + 8); i += nthreads) p[i] = 0; }
+  if (tid == 0) {
+    sh->anyconf[0] = sh->anyconf[1] = 0; sh->walk_cnt = 0; sh->anyshared = 0;
+    for (int k = 0; k < P8CM_MAXI + 8; k++) sh->shared[k] = 0;
+    const int i0 = d->rnd.i;   // V(idx) for idx in (i0 - 64, i0] is the generator's table; then the next 256
+    for (int k = 0; k < 64; k++) { const int idx = i0 - k; sh->rv[(uint32_t)idx & (P8F_RV - 1)] = d->rnd.table[idx & 63]; }
+    for (int idx = i0 + 1; idx <= i0 + P8F_LOOK; idx++) sh->rv[(uint32_t)idx & (P8F_RV - 1)] = sh->rv[(uint32_t)(idx - 24) & (P8F_RV - 1)] ^ sh->rv[(uint32_t)(idx - 55) & (P8F_RV - 1)];
+  }
+}
+P8_HD void p8f_store(P8CmDev* d, P8FamHome* home, uint16_t* sm_home, const P8FamShared* sh, uint32_t rnd_i, int tid, int nthreads) {
+  const int S = d->nslots;
+  for (int s = tid; s < S; s += nthreads) {
+    home->cp0[s] = sh->r.cp0[s]; home->runp[s] = sh->r.runp[s]; home->cpo[s] = sh->r.cpo[s]; home->rc[s] = sh->r.rc[s]; home->rb[s] = sh->r.rb[s];
+    home->smc[s] = sh->r.smc[s];
+    for (int j = 0; j < 8; j++) home->slot[s][j] = sh->r.slot[s][j];
+  }
+  for (int i = tid; i < S * 256; i += nthreads) sm_home[i] = sh->sm[i];
+  if (tid == 0) {
+    for (int k = 0; k < 64; k++) { const uint32_t idx = rnd_i - (uint32_t)k; d->rnd.table[idx & 63] = sh->rv[idx & (P8F_RV - 1)]; }
+    d->rnd.i = (int)rnd_i;
+  }
+}
+// keep the ring 256 values ahead of i: values (old_i + 256, new_i + 256], 24 at a time (a value depends on those 24 and 55
+// back, so 24 consecutive new ones are independent of each other). One call = one group of 24; callers loop over the
+// groups with all 24 lanes per group (one wavefront in lockstep on the device).
+P8_HD void p8f_refill_group(P8FamShared* sh, uint32_t base, uint32_t hi, int lane24) {
+  const uint32_t idx = base + (uint32_t)lane24;
+  if (idx <= hi) sh->rv[idx & (P8F_RV - 1)] = sh->rv[(idx - 24) & (P8F_RV - 1)] ^ sh->rv[(idx - 55) & (P8F_RV - 1)];
+}
+
+// ---- phase 1 (every bit): the state update's outcome and whether it draws; at a lookup bit also the touched buckets into
+//      the hash set and the bucket about to be searched into LDS ----
+P8_HD void p8f_insert(P8FamShared* sh, int lk, int inst, uint32_t bucket) {
+  const uint32_t key = ((uint32_t)(inst + 1) << 26) | bucket;
+  uint32_t h = (key * 2654435761u) >> 21;
+  uint32_t* tab = sh->hash[lk & 1];
+  for (;;) {
+    const uint32_t old = P8F_CAS(&tab[h], 0u, key);
+    if (old == 0) return;
+    if (old == key) { sh->conflict[lk & 1][inst] = 1; sh->anyconf[lk & 1] = 1; return; }
+    h = (h + 1) & (P8F_HASH - 1);
+  }
+}
+P8_HD void p8f_phase1(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int s, P8FamTmp* t) {
+  P8FamHome* r = &sh->r;
+  const int inst = d->slot_inst[s];
+  const P8CmInst* x = &d->inst[inst];
+  t->ns = 0; t->draw = 0; t->look = 0; t->nb = 0;
+  if (r->cpo[s] != P8F_NIL) {
+    t->ns = sh->nex[4 * r->slot[s][r->cpo[s]] + u.y];
+    t->draw = t->ns >= 204;
+  }
+  if (t->draw) P8F_OR(&sh->db[u.t % 3][s >> 5], 1u << (s & 31));
+  if (s < 8) sh->db[(u.t + 1) % 3][s] = 0;
+  const int bp = u.bp;
+  if (!(bp == 0 || bp == 2 || bp == 5)) return;
+  // touched buckets: the old slot's, the run bytes', the one about to be searched, and at a byte boundary the two a second visit creates histories in
+  uint32_t L[5]; int n = 0;
+  if (r->cpo[s] != P8F_NIL) L[n++] = r->cp0[s] >> 6;
+  L[n++] = r->runp[s] >> 6;
+  if (!(bp > 1 && r->rc[s] == 0)) {
+    t->look = 1;
+    t->nb = (p8f_ctx(d, u, s) + (uint32_t)u.c0) & x->mask;
+    L[n++] = t->nb;
+    const uint8_t* g = x->table + (size_t)t->nb * 64;
+    uint8_t* b = sh->bk[s];
+#ifdef __HIPCC__
+    const uint4* g4 = reinterpret_cast<const uint4*>(g);
+    uint4* b4 = reinterpret_cast<uint4*>(b);
+    const uint4 v0 = g4[0], v1 = g4[1], v2 = g4[2], v3 = g4[3];
+    b4[0] = v0; b4[1] = v1; b4[2] = v2; b4[3] = v3;
+#else
+    for (int j = 0; j < 64; j++) b[j] = g[j];
+#endif
+    if (bp == 0) {
+      const uint16_t* cs = (const uint16_t*)b;
+      const uint16_t chk = p8f_chk(d, u, s);
+      const int mru = b[P8_B_MRU];
+      int slot = -1;
+      if (cs[mru & 15] == chk) slot = mru & 15;
+      else for (int j = 0; j < 7; ++j) if (cs[j] == chk) { slot = j; break; }
+      if (slot >= 0 && b[P8_B_STATE + 7 * slot + 3] == 2) {
+        const int cc = b[P8_B_STATE + 7 * slot + 4] + 256;
+        L[n++] = (p8f_ctx(d, u, s) + (uint32_t)(cc >> 6)) & x->mask;
+        L[n++] = (p8f_ctx(d, u, s) + (uint32_t)(cc >> 3)) & x->mask;
+      }
+    }
+  }
+  for (int a = 0; a < n; a++) {
+    int dup = 0;
+    for (int c = 0; c < a; c++) dup |= L[c] == L[a];
+    if (!dup) p8f_insert(sh, u.lk, inst, L[a]);
+  }
+}
+// housekeeping of a lookup bit's run phase: the OTHER parity's hash set and flags are cleared for the next lookup bit
+P8_HD void p8f_clear_next(P8FamShared* sh, int lk, int tid, int nthreads) {
+  uint32_t* tab = sh->hash[(lk + 1) & 1];
+  for (int i = tid; i < P8F_HASH; i += nthreads) tab[i] = 0;
+  if (tid < P8CM_MAXI + 8) sh->conflict[(lk + 1) & 1][tid] = 0;
+  if (tid == 0) sh->anyconf[(lk + 1) & 1] = 0;
+}
+
+// draws among slots [a, b) of this bit
+P8_HD int p8f_count(const P8FamShared* sh, int t, int a, int b) {
+  const uint32_t* w = sh->db[t % 3];
+  int n = 0;
+  for (int k = a >> 5; k <= (b - 1) >> 5 && a < b; k++) {
+    uint32_t m = w[k];
+    if (k == a >> 5) m &= ~0u << (a & 31);
+    if (k == (b - 1) >> 5 && ((b & 31) != 0)) m &= (1u << (b & 31)) - 1u;
+    n += P8F_POPC(m);
+  }
+  return n;
+}
+
+// the five inputs of a context (ContextMap::mix1's tail :1119-1143) from the cached bytes; the StateMap learns in LDS
+P8_HD void p8f_outputs(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int s) {
+  P8FamHome* r = &sh->r;
+  int16_t* o = u.out + d->slot_off[s];
+  const int bp = u.bp, c0 = u.c0, rc = r->rc[s], rb = r->rb[s];
+  if ((rb + 256) >> (8 - bp) == c0) {
+    const int b = ((rb >> (7 - bp)) & 1) * 2 - 1;
+    o[0] = (int16_t)(b * (sh->ilog[rc + 1] << (2 + (~rc & 1))));
+  } else o[0] = 0;
+  const int st8 = r->cpo[s] != P8F_NIL ? r->slot[s][r->cpo[s]] : 0;
+  uint16_t* smt = p8f_smrow(sh, s);
+  const int sc = r->smc[s];
+  smt[sc] = (uint16_t)(smt[sc] + (((u.y << 16) - smt[sc] + 128) >> 8));
+  r->smc[s] = (uint8_t)st8;
+  const int p1 = smt[st8] >> 4;
+  const int st = (sh->stretch[p1] + (1 << 1)) >> 2;
+  o[1] = (int16_t)st;
+  o[2] = (int16_t)((p1 - 2047 + (1 << 2)) >> 3);
+  const int n0 = -!sh->nex[4 * st8 + 2], n1 = -!sh->nex[4 * st8 + 3];
+  const int dn = n1 - n0;
+  o[3] = (int16_t)(st * (dn < 0 ? -dn : dn));
+  const int p0 = 4095 - p1;
+  o[4] = (int16_t)(((p1 & n0) - (p0 & n1) + (1 << 3)) >> 4);
+}
+
+// a store to the table that also keeps the lane's cached bytes right when the address falls inside them
+P8_HD void p8f_wr(uint8_t* T, P8FamHome* r, int s, uint32_t addr, uint8_t v) {
+  T[addr] = v;
+  if (addr - r->cp0[s] < 7u) r->slot[s][addr - r->cp0[s]] = v;
+  if (addr == r->runp[s]) r->rc[s] = v;
+  if (addr == r->runp[s] + 1) r->rb[s] = v;
+}
+// Bucket::Find on the staged copy; header changes go to the table. Returns the slot index.
+P8_HD int p8f_find_staged(uint8_t* T, uint32_t nb, uint8_t* b, uint16_t checksum) {
+  uint16_t* cs = (uint16_t*)b;
+  uint8_t* g = T + (size_t)nb * 64;
+  const int mru = b[P8_B_MRU];
+  if (cs[mru & 15] == checksum) return mru & 15;
+  int worst = 0xFFFF, index = 0;
+  for (int i = 0; i < 7; ++i) {
+    if (cs[i] == checksum) { b[P8_B_MRU] = (uint8_t)(mru << 4 | i); g[P8_B_MRU] = b[P8_B_MRU]; return i; }
+    if (b[P8_B_STATE + 7 * i] < worst && (mru & 15) != i && mru >> 4 != i) { worst = b[P8_B_STATE + 7 * i]; index = i; }
+  }
+  b[P8_B_MRU] = (uint8_t)(0xF0 | index); g[P8_B_MRU] = b[P8_B_MRU];
+  cs[index] = checksum; ((uint16_t*)g)[index] = checksum;
+  for (int k = 0; k < 7; k++) { b[P8_B_STATE + 7 * index + k] = 0; g[P8_B_STATE + 7 * index + k] = 0; }
+  return index;
+}
+
+// ---- run phase, lane-parallel: ContextMap::mix1's loop body for context s (:1072-1145) on the cached bytes.
+//      rank: number of draws of this bit before this context. ----
+P8_HD void p8f_run(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int s, const P8FamTmp* t, int rank) {
+  P8FamHome* r = &sh->r;
+  const P8CmInst* x = &d->inst[d->slot_inst[s]];
+  uint8_t* T = x->table;
+  const int bp = u.bp, c0 = u.c0;
+  if (r->cpo[s] != P8F_NIL) {
+    int ns = t->ns;
+    if (t->draw) {
+      const uint32_t v = sh->rv[(u.rnd_i + 1u + (uint32_t)rank) & (P8F_RV - 1)];
+      if ((uint32_t)(v << ((452 - ns) >> 3))) ns -= 4;
+    }
+    r->slot[s][r->cpo[s]] = (uint8_t)ns;
+    T[r->cp0[s] + r->cpo[s]] = (uint8_t)ns;
+    if (r->cp0[s] + r->cpo[s] == r->runp[s]) r->rc[s] = (uint8_t)ns;           // the state byte doubles as this context's run count / byte
+    if (r->cp0[s] + r->cpo[s] == r->runp[s] + 1) r->rb[s] = (uint8_t)ns;
+  }
+  if (bp > 1 && r->rc[s] == 0) r->cpo[s] = P8F_NIL;
+  else if (bp == 1 || bp == 3 || bp == 6) r->cpo[s] = (uint8_t)(1 + (c0 & 1));
+  else if (bp == 4 || bp == 7) r->cpo[s] = (uint8_t)(3 + (c0 & 3));
+  else {
+    const uint16_t checksum = p8f_chk(d, u, s);
+    const uint32_t cx = p8f_ctx(d, u, s), nb = t->nb;
+    uint8_t* b = sh->bk[s];
+    // the staged bucket predates this lane's own state store above: same bucket -> same byte in the copy
+    {
+      const uint32_t old = r->cp0[s] + (uint32_t)(r->cpo[s] != P8F_NIL ? r->cpo[s] : 0);
+      if (r->cpo[s] != P8F_NIL && (old >> 6) == nb) b[old & 63] = r->slot[s][r->cpo[s]];
+    }
+    const int idx = p8f_find_staged(T, nb, b, checksum);
+    const uint32_t ncp0 = nb * 64 + P8_B_STATE + 7 * (uint32_t)idx;
+    const uint32_t old_runp = r->runp[s];
+    r->cp0[s] = ncp0; r->cpo[s] = 0;
+    for (int k = 0; k < 7; k++) r->slot[s][k] = b[P8_B_STATE + 7 * idx + k];
+    if (bp == 0) {
+      int refresh = 0;
+      if (r->slot[s][3] == 2) {   // second visit: create the bit histories of bits 2-7 from the one byte seen (:1096-1106)
+        const int cc = r->slot[s][4] + 256;
+        uint32_t p = p8d_bucket_find(T, (cx + (uint32_t)(cc >> 6)) & x->mask, checksum);
+        T[p] = (uint8_t)(1 + ((cc >> 5) & 1));
+        T[p + 1 + ((cc >> 5) & 1)] = (uint8_t)(1 + ((cc >> 4) & 1));
+        T[p + 3 + ((cc >> 4) & 3)] = (uint8_t)(1 + ((cc >> 3) & 1));
+        p = p8d_bucket_find(T, (cx + (uint32_t)(cc >> 3)) & x->mask, checksum);
+        T[p] = (uint8_t)(1 + ((cc >> 2) & 1));
+        T[p + 1 + ((cc >> 2) & 1)] = (uint8_t)(1 + ((cc >> 1) & 1));
+        T[p + 3 + ((cc >> 1) & 3)] = (uint8_t)(1 + (cc & 1));
+        T[ncp0 + 6] = 0; r->slot[s][6] = 0;
+        refresh = 1;   // those stores may have landed on the old run bytes (same checksum in a coinciding bucket): read them back
+      }
+      // run count of the PREVIOUS context (:1107-1112)
+      int rc = r->rc[s], rb = r->rb[s];
+      if ((old_runp >> 6) == nb) { rc = b[old_runp & 63]; rb = b[(old_runp + 1) & 63]; }   // the search above may have replaced the very slot that holds them
+      if (refresh) { rc = T[old_runp]; rb = T[old_runp + 1]; }
+      const int c1 = u.c1;
+      if (rc == 0) { rc = 2; rb = c1; }
+      else if (rb != c1) { rc = 1; rb = c1; }
+      else if (rc < 254) rc += 2;
+      else if (rc == 255) rc = 128;
+      T[old_runp] = (uint8_t)rc; T[old_runp + 1] = (uint8_t)rb;
+      if (old_runp - ncp0 < 7u) r->slot[s][old_runp - ncp0] = (uint8_t)rc;           // the same context again: its run bytes are in the new slot
+      if (old_runp + 1 - ncp0 < 7u) r->slot[s][old_runp + 1 - ncp0] = (uint8_t)rb;
+      if (refresh) for (int k = 0; k < 7; k++) r->slot[s][k] = T[ncp0 + k];
+      r->runp[s] = ncp0 + 3;
+      r->rc[s] = r->slot[s][3]; r->rb[s] = r->slot[s][4];
+    }
+  }
+  p8f_outputs(d, sh, u, s);
+}
+
+// ---- an instance with an overlap: its first lane walks it on the table, in the reference's order. draws0: draws of this bit
+//      before the instance; returns its own. Afterwards every lane of the instance reloads (p8f_reload). ----
+P8_HD int p8f_walk(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int inst, int draws0) {
+  P8FamHome* r = &sh->r;
+  const P8CmInst* x = &d->inst[inst];
+  uint8_t* T = x->table;
+  const int bp = u.bp, c0 = u.c0, c1 = u.c1;
+  int cnt = 0;
+  for (int s = x->first; s < x->first + x->count; s++) {
+    uint32_t cp = r->cpo[s] != P8F_NIL ? r->cp0[s] + r->cpo[s] : P8_NIL;
+    uint32_t cp0 = r->cp0[s], runp = r->runp[s];
+    if (cp != P8_NIL) {
+      int ns = sh->nex[4 * T[cp] + u.y];
+      if (ns >= 204) {
+        const uint32_t v = sh->rv[(u.rnd_i + 1u + (uint32_t)(draws0 + cnt)) & (P8F_RV - 1)];
+        cnt++;
+        if ((uint32_t)(v << ((452 - ns) >> 3))) ns -= 4;
+      }
+      T[cp] = (uint8_t)ns;
+    }
+    if (bp > 1 && T[runp] == 0) cp = P8_NIL;
+    else if (bp == 1 || bp == 3 || bp == 6) cp = cp0 + 1 + (uint32_t)(c0 & 1);
+    else if (bp == 4 || bp == 7) cp = cp0 + 3 + (uint32_t)(c0 & 3);
+    else if (bp == 2 || bp == 5) cp0 = cp = p8d_bucket_find(T, (p8f_ctx(d, u, s) + (uint32_t)c0) & x->mask, p8f_chk(d, u, s));
+    else {
+      const uint16_t checksum = p8f_chk(d, u, s);
+      const uint32_t cx = p8f_ctx(d, u, s);
+      cp0 = cp = p8d_bucket_find(T, (cx + (uint32_t)c0) & x->mask, checksum);
+      uint8_t* s0 = T + cp0;
+      if (s0[3] == 2) {
+        const int cc = s0[4] + 256;
+        uint8_t* p = T + p8d_bucket_find(T, (cx + (uint32_t)(cc >> 6)) & x->mask, checksum);
+        p[0] = (uint8_t)(1 + ((cc >> 5) & 1));
+        p[1 + ((cc >> 5) & 1)] = (uint8_t)(1 + ((cc >> 4) & 1));
+        p[3 + ((cc >> 4) & 3)] = (uint8_t)(1 + ((cc >> 3) & 1));
+        p = T + p8d_bucket_find(T, (cx + (uint32_t)(cc >> 3)) & x->mask, checksum);
+        p[0] = (uint8_t)(1 + ((cc >> 2) & 1));
+        p[1 + ((cc >> 2) & 1)] = (uint8_t)(1 + ((cc >> 1) & 1));
+        p[3 + ((cc >> 1) & 3)] = (uint8_t)(1 + (cc & 1));
+        s0[6] = 0;
+      }
+      uint8_t* rp = T + runp;
+      if (rp[0] == 0) { rp[0] = 2; rp[1] = (uint8_t)c1; }
+      else if (rp[1] != c1) { rp[0] = 1; rp[1] = (uint8_t)c1; }
+      else if (rp[0] < 254) rp[0] = (uint8_t)(rp[0] + 2);
+      else if (rp[0] == 255) rp[0] = 128;
+      runp = cp0 + 3;
+    }
+    r->cp0[s] = cp0; r->runp[s] = runp; r->cpo[s] = cp == P8_NIL ? (uint8_t)P8F_NIL : (uint8_t)(cp - cp0);
+    // outputs need this context's bytes as they are NOW (a later context of the walk may change them again)
+    for (int k = 0; k < 7; k++) r->slot[s][k] = T[cp0 + k];
+    r->rc[s] = T[runp]; r->rb[s] = T[runp + 1];
+    p8f_outputs(d, sh, u, s);
+  }
+  return cnt;
+}
+// After a walk (the only way two contexts can come to sit on one slot: the later one's search replaced or found the
+// slot the earlier one had just taken): do two contexts of the instance share a slot -- as state bytes, or one's state
+// bytes under the other's run bytes? While they do, the instance is walked every bit (p8f_walk), lookup bit or not.
+P8_HD int p8f_shares(const P8CmDev* d, const P8FamShared* sh, int inst) {
+  const P8FamHome* r = &sh->r;
+  const P8CmInst* x = &d->inst[inst];
+  for (int a = x->first; a < x->first + x->count; a++) {
+    const uint32_t cur_a = r->cpo[a] != P8F_NIL ? r->cp0[a] : 0xFFFFFFF0u, run_a = r->runp[a] - 3;
+    for (int b = a + 1; b < x->first + x->count; b++) {
+      const uint32_t cur_b = r->cpo[b] != P8F_NIL ? r->cp0[b] : 0xFFFFFFF1u, run_b = r->runp[b] - 3;
+      if (cur_a == cur_b || cur_a == run_b || run_a == cur_b) return 1;
+    }
+  }
+  return 0;
+}
+P8_HD void p8f_reload(const P8CmDev* d, P8FamShared* sh, int s) {
+  P8FamHome* r = &sh->r;
+  const uint8_t* T = d->inst[d->slot_inst[s]].table;
+  for (int k = 0; k < 7; k++) r->slot[s][k] = T[r->cp0[s] + k];
+  r->rc[s] = T[r->runp[s]]; r->rb[s] = T[r->runp[s] + 1];
+}
+
+// uniform values of step t of a chunk
+P8_HD P8FamUni p8f_uni(const P8CmDev* d, const uint32_t* ctx, const uint16_t* chk, const uint8_t* bits_in, int16_t* out, const uint8_t* order, int t, int* last_y, int* c1,
+                       int* lk, uint32_t rnd_i) {
+  P8FamUni u;
+  const int bp = t & 7, nslots = d->nslots;
+  int c0 = 1;
+  for (int j = 0; j < bp; j++) c0 = c0 * 2 + bits_in[t - bp + j];
+  u.y = *last_y; u.bp = bp; u.c0 = c0; u.c1 = *c1; u.t = t; u.rnd_i = rnd_i;
+  u.order = order ? order[t - bp] : 0;
+  u.ctx = ctx + (size_t)(t >> 3) * (size_t)nslots;
+  u.chk = chk + (size_t)(t >> 3) * (size_t)nslots;
+  u.out = out + (size_t)t * (size_t)d->row_stride;
+  if (bp == 0 || bp == 2 || bp == 5) ++*lk;
+  u.lk = *lk;
+  *last_y = bits_in[t];
+  if (bp == 7) *c1 = (c0 * 2 + bits_in[t]) & 0xff;
+  return u;
+}
+#endif

@@ -78,6 +78,67 @@ __global__ __launch_bounds__(P8CM_MAXS) void cmx_p8s_fam_kernel(P8CmDev* d, cons
   if (s == 0) { d->regs = sh.r; d->rnd = sh.rnd; d->last_y = last_y; d->c1 = c1; }
 }
 
+// Second design of the family kernel (p8fam_dev.h): per-context bytes and StateMaps in LDS, one barrier per bit on the
+// common path, overlaps resolved in rounds over the instance order. 256 threads: lanes 0..S-1 own a context each,
+// the last 24 lanes keep the rnd() ring filled.
+__global__ __launch_bounds__(P8CM_MAXS) void cmx_p8s_fam2_kernel(P8CmDev* d, P8FamHome* home, const uint32_t* ctx, const uint16_t* chk, const uint8_t* bits, int16_t* x,
+                                                                const uint8_t* order, int nbits, int skip) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char p8f_smem[];
+  P8FamShared& sh = *(P8FamShared*)p8f_smem;
+  const int tid = threadIdx.x, S = d->nslots, ninst = d->ninst;
+  p8f_load(d, home, d->sm, &sh, tid, P8CM_MAXS);
+  int last_y = d->last_y, c1 = d->c1, lk = 0;
+  uint32_t rnd_i = (uint32_t)d->rnd.i, prev_i = rnd_i;
+  __syncthreads();
+  for (int t = 0; t < nbits; t++) {
+    const P8FamUni u = p8f_uni(d, ctx, chk, bits, x, order, t, &last_y, &c1, &lk, rnd_i);
+    if (t < skip) continue;
+    P8FamTmp tmp;
+    if (tid < S) p8f_phase1(d, &sh, u, tid, &tmp);
+    if (tid >= P8CM_MAXS - 24)   // one wavefront's tail: 24 lanes in lockstep, a group of 24 values per iteration
+      for (uint32_t base = prev_i + P8F_LOOK + 1; base <= rnd_i + P8F_LOOK; base += 24) p8f_refill_group(&sh, base, rnd_i + P8F_LOOK, tid - (P8CM_MAXS - 24));
+    __syncthreads();
+    const bool look = u.bp == 0 || u.bp == 2 || u.bp == 5;
+    int total;
+    if (!(look && sh.anyconf[lk & 1]) && !sh.anyshared) {
+      if (tid < S) p8f_run(d, &sh, u, tid, &tmp, p8f_count(&sh, t, 0, tid));
+      total = p8f_count(&sh, t, 0, S);
+    } else {
+      int base = 0, k = 0;
+      while (k < ninst) {
+        const bool walked = (look && sh.conflict[lk & 1][k]) || sh.shared[k];
+        if (!walked) {
+          int k2 = k;
+          while (k2 < ninst && !((look && sh.conflict[lk & 1][k2]) || sh.shared[k2])) k2++;
+          const int a = d->inst[k].first, b = k2 < ninst ? d->inst[k2].first : S;
+          if (tid >= a && tid < b) p8f_run(d, &sh, u, tid, &tmp, base + p8f_count(&sh, t, a, tid));
+          base += p8f_count(&sh, t, a, b);
+          k = k2;
+        } else {
+          const int first = d->inst[k].first, cnt = d->inst[k].count;
+          if (tid == first) {
+            sh.walk_cnt = (uint32_t)p8f_walk(d, &sh, u, k, base);
+            if (look) sh.shared[k] = (uint8_t)p8f_shares(d, &sh, k);
+          }
+          __syncthreads();
+          base += (int)sh.walk_cnt;
+          if (tid >= first && tid < first + cnt) p8f_reload(d, &sh, tid);
+          __syncthreads();   // walk_cnt may be rewritten by the next walker
+          k++;
+        }
+      }
+      if (tid == 0) { int anys = 0; for (int q = 0; q < ninst; q++) anys |= sh.shared[q]; sh.anyshared = (uint32_t)anys; }
+      total = base;
+      __syncthreads();
+    }
+    if (look) p8f_clear_next(&sh, lk, tid, P8CM_MAXS);
+    prev_i = rnd_i; rnd_i += (uint32_t)total;
+  }
+  __syncthreads();
+  p8f_store(d, home, d->sm, &sh, rnd_i, tid, P8CM_MAXS);
+  if (tid == 0) { d->last_y = last_y; d->c1 = c1; }
+}
+
 // t0: 1 for the chunk that starts the stream (there is no step 0), else 0
 __global__ __launch_bounds__(P8_NLANE) void cmx_p8s_lanes_kernel(P8LanesDev* d, const uint32_t* ops, const uint8_t* bits, const uint8_t* order, int16_t* x,
                                                                 int nbits, int t0) {
@@ -274,7 +335,7 @@ struct cmx_p8stage {
   P8Front* front = nullptr;
   P8Layout L;
   DevPolicy pol;
-  P8CmDev* d_fam = nullptr; P8Cm2Dev* d_cm2[P8_NCM2] = {}; P8LanesDev* d_lanes = nullptr; P8DmcDev* d_dmc = nullptr;
+  P8CmDev* d_fam = nullptr; P8FamHome* d_fam_home = nullptr; size_t fam_lds = 0; bool fam_v1 = false; P8Cm2Dev* d_cm2[P8_NCM2] = {}; P8LanesDev* d_lanes = nullptr; P8DmcDev* d_dmc = nullptr;
   P8TailDev* d_tail = nullptr; P8MixDev* d_mix = nullptr;
   Staging st[P8S_BUFS];
   int next = 0;
@@ -322,6 +383,9 @@ cmx_p8stage_t* cmx_p8stage_create(int device) {
     const char* serial = getenv("CMX_P8CM_SERIAL");   // A/B switch: the reference's serial walk on lane 0
     if (serial && serial[0] == '1') { S->fam.slot_parallel = 0; for (auto& c : S->cm2) c.slot_parallel = 0; }
     h->d_fam = dev_copy(S->fam, h->pol);
+    h->d_fam_home = S->fam_home;
+    h->fam_lds = sizeof(P8FamShared) + (size_t)S->fam.nslots * 512;
+    h->fam_v1 = getenv("CMX_P8FAM_V1") != nullptr;   // A/B switch: the first design (p8cm_dev.h) instead of p8fam_dev.h
     for (int k = 0; k < P8_NCM2; k++) h->d_cm2[k] = dev_copy(S->cm2[k], h->pol);
     h->d_lanes = dev_copy(S->lanes, h->pol);
     h->d_dmc = dev_copy(S->dmc, h->pol);
@@ -330,6 +394,7 @@ cmx_p8stage_t* cmx_p8stage_create(int device) {
     ok = h->pol.ok;
   }
   delete S;
+  ok = ok && hipFuncSetAttribute((const void*)cmx_p8s_fam2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->fam_lds) == hipSuccess;
   ok = ok && hipStreamCreateWithFlags(&h->s_b, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&h->s_c, hipStreamNonBlocking) == hipSuccess;
   for (hipEvent_t* e : {&h->ev_up, &h->ev_ord, &h->ev_b, &h->ev_c, &h->ev_mix}) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
   for (auto& s : h->st) ok = ok && hipEventCreateWithFlags(&s.done, hipEventDisableTiming) == hipSuccess;
@@ -395,8 +460,12 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
     // stream a (the caller's): order-N map, then the family
     cm2(0, s, h->d_order);
     ok = hipEventRecord(h->ev_ord, s) == hipSuccess;
-    hipLaunchKernelGGL(cmx_p8s_fam_kernel, dim3(1), dim3(P8CM_MAXS), 0, s, h->d_fam, (const uint32_t*)(b.d + b.o_fctx), (const uint16_t*)(b.d + b.o_fchk), d_bits, h->d_x,
-                       (const uint8_t*)h->d_order, nbits, skip);
+    if (h->fam_v1)
+      hipLaunchKernelGGL(cmx_p8s_fam_kernel, dim3(1), dim3(P8CM_MAXS), 0, s, h->d_fam, (const uint32_t*)(b.d + b.o_fctx), (const uint16_t*)(b.d + b.o_fchk), d_bits, h->d_x,
+                         (const uint8_t*)h->d_order, nbits, skip);
+    else
+      hipLaunchKernelGGL(cmx_p8s_fam2_kernel, dim3(1), dim3(P8CM_MAXS), h->fam_lds, s, h->d_fam, h->d_fam_home, (const uint32_t*)(b.d + b.o_fctx),
+                         (const uint16_t*)(b.d + b.o_fchk), d_bits, h->d_x, (const uint8_t*)h->d_order, nbits, skip);
     // stream b: TextModel's and exeModel's maps
     ok = ok && hipStreamWaitEvent(h->s_b, h->ev_up, 0) == hipSuccess;
     cm2(1, h->s_b, nullptr);

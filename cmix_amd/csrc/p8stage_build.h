@@ -10,6 +10,7 @@
 
 #include "p8cm_build.h"
 #include "p8dmc_build.h"
+#include "p8fam_dev.h"
 #include "p8stage_dev.h"
 
 struct P8MixDev {
@@ -22,6 +23,7 @@ struct P8MixDev {
 // host-side description of one stream's state; every pointer inside the members is policy memory
 struct P8StageState {
   P8CmDev fam;
+  P8FamHome* fam_home;     // policy memory: the family's per-context registers between chunks (p8fam_dev.h)
   P8Cm2Dev cm2[P8_NCM2];
   P8LanesDev lanes;
   P8DmcDev dmc;
@@ -45,6 +47,13 @@ bool build_stage(P8StageState& S, Policy& P, const P8Layout& L, int level, const
   S.fam.row_stride = P8_NX; S.fam.order_slot = L.order_slot;
   for (int s = 0; s < L.fam_slots; s++) S.fam.slot_off[s] = L.fam_off[s];
   for (int o = 0; o <= P8_ORDER_MAX; o++) { S.fam.order_ctx[o] = L.order_ctx[o]; S.fam.order_chk[o] = L.order_chk[o]; }
+  {   // the second-design kernel's home state: ContextMap's constructor (:1049-1062) in cached form
+    P8FamHome* hh = new P8FamHome();
+    memset(hh, 0, sizeof *hh);
+    for (int s = 0; s < S.fam.nslots; s++) { hh->cp0[s] = P8_B_STATE; hh->cpo[s] = 0; hh->runp[s] = P8_B_STATE + 3; }
+    S.fam_home = (P8FamHome*)up(hh, sizeof *hh);
+    delete hh;
+  }
   // ---- ContextMap2 x 3 ----
   for (int k = 0; k < P8_NCM2; k++) {
     if (!build(S.cm2[k], P, L.cm2_size[k], L.cm2_count[k], nex1024, stretch4096, ilog65536)) return false;

@@ -32,8 +32,7 @@ P8_HD int p8s_sm32(uint32_t* t, int* cxt, int y, int cx, int limit) {   // State
   uint32_t p0 = t[*cxt];
   const int n = p0 & 1023, pr = p0 >> 10;
   if (n < limit) ++p0; else p0 = (p0 & 0xfffffc00u) | (uint32_t)limit;
-  const int delta = (((y << 22) - pr) >> 3) * (16384 / (n + n + 3));
-  p0 += (uint32_t)delta & 0xfffffc00u;
+  p0 += ((uint32_t)(((y << 22) - pr) >> 3) * (uint32_t)(16384 / (n + n + 3))) & 0xfffffc00u;   // the product wraps (as the reference's compiled code does)
   t[*cxt] = p0;
   *cxt = cx;
   return (int)(t[cx] >> 20);
@@ -84,7 +83,7 @@ P8_HD void p8s_lane_step(const P8LanesDev* d, P8LaneRegs* r, int l, uint32_t op,
     const int lim = L->q.limit;
     const uint32_t count = (uint32_t)lim < (v & 0x3FF) + 1 ? (uint32_t)lim : (v & 0x3FF) + 1;
     int p = (int)(v >> 10), err = (y << 22) - p;
-    err = ((err / 8) * (16384 / (int)(count + count + 3))) / 1024;
+    err = (int)((uint32_t)(err / 8) * (uint32_t)(16384 / (int)(count + count + 3))) / 1024;   // the product wraps
     p = p + err; p = p < 0 ? 0 : p > 0x3FFFFF ? 0x3FFFFF : p;
     c[r->cp] = ((uint32_t)p << 10) | count;
     r->B += (uint32_t)(y && r->B > 0);
@@ -120,7 +119,7 @@ P8_HD int p8s_apm(uint32_t* t, int* cxt, const int16_t* stretch, int y, int pr, 
   uint32_t p0 = t[*cxt];
   const int n = p0 & 1023, q = p0 >> 10;
   if (n < limit) ++p0; else p0 = (p0 & 0xfffffc00u) | (uint32_t)limit;
-  p0 += (uint32_t)((((y << 22) - q) >> 3) * (16384 / (n + n + 3))) & 0xfffffc00u;
+  p0 += ((uint32_t)(((y << 22) - q) >> 3) * (uint32_t)(16384 / (n + n + 3))) & 0xfffffc00u;
   t[*cxt] = p0;
   pr = (stretch[pr] + 2048) * 23;
   const int wt = pr & 0xfff;

@@ -106,12 +106,14 @@ def compress_stream(stream, vocab, layer0, device_index=0, chunk_bytes=4096, pre
         pipe.close()
 
 
-def text_block(payload):
-    """What `cmix -c` without a dictionary hands the predictor for a plain-text file: preprocessor::Encode detects one
-    TEXT block and writes type byte 4, the big-endian block length, the WRT flag 0, then the bytes (reference
-    src/preprocess/preprocessor.cpp:443-449,536-537). bench.py checks the resulting .cmix file against the reference
-    binary's (tests/golden/dropin_*.npz), which pins this framing."""
-    n = len(payload) + 1
+def text_file_stream(payload):
+    """What `cmix -c` without a dictionary hands the predictor for a file its detector classifies as (>= 95 %) text:
+    preprocessor::Encode writes ONE block -- type byte TEXT = 4, the file length big-endian -- and encode_text a WRT flag 0
+    followed by the bytes (reference src/preprocess/preprocessor.cpp:533-540, 443-449). The enwik8-shaped bench shards
+    are such files from 64 KB on; bench.py checks the resulting .cmix file against the reference binary's
+    (tests/golden/dropin_*.npz), which pins this framing. (Mixed files are split into typed blocks by the reference's
+    detector; the engine compressor integration/compress_engine.cpp runs the reference's own preprocessor.)"""
+    n = len(payload)
     return bytes([4]) + n.to_bytes(4, "big") + b"\x00" + bytes(payload)
 
 

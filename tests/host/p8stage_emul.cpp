@@ -25,6 +25,10 @@ struct Emul {
   P8StageState S;
   HostPolicy pol;
   P8CmShared fsh;
+  std::vector<unsigned char> f2mem;   // P8FamShared + StateMaps (second-design family body)
+  P8FamShared* f2 = nullptr;
+  int f2_lk = 0; uint32_t f2_prev_i = 0, f2_i = 0;
+  int use_v1 = 0;
   P8Cm2Shared csh[P8_NCM2];
   P8DmcShared dsh;
   uint64_t steps = 0;
@@ -63,6 +67,9 @@ void* p8s_create(int level) {
     p8f_front_free(e->front); delete e; return nullptr;
   }
   e->fsh.r = e->S.fam.regs; e->fsh.rnd = e->S.fam.rnd;
+  e->use_v1 = getenv("CMX_P8FAM_V1") != nullptr;
+  e->f2mem.resize(sizeof(P8FamShared) + (size_t)e->S.fam.nslots * 512 + 64);
+  e->f2 = (P8FamShared*)e->f2mem.data();
   for (int k = 0; k < P8_NCM2; k++) e->csh[k].r = e->S.cm2[k].regs;
   return e;
 }
@@ -81,6 +88,19 @@ void p8s_conflict_report(void* h) {
     printf("  inst %2d (%3d ctx, %8u buckets): overlap %llu, + draw %llu\n", k, e->S.fam.inst[k].count, e->S.fam.inst[k].mask + 1, (unsigned long long)e->inst_conf[k],
            (unsigned long long)e->inst_risky[k]);
 }
+// diagnostics: per family context cp, cp0, runp (byte offsets; cp = 0xFFFFFFFF: none), state byte at cp, StateMap context
+void p8s_dump_fam(void* h, uint32_t* out /* [nslots][5] */) {
+  Emul* e = (Emul*)h;
+  const P8CmDev* d = &e->S.fam;
+  for (int s = 0; s < d->nslots; s++) {
+    const uint8_t* T = d->inst[d->slot_inst[s]].table;
+    uint32_t cp, cp0, runp, smc;
+    if (e->use_v1) { cp = e->fsh.r.cp[s]; cp0 = e->fsh.r.cp0[s]; runp = e->fsh.r.runp[s]; smc = (uint32_t)e->fsh.r.sm_cxt[s]; }
+    else { const P8FamHome* r = &e->f2->r; cp0 = r->cp0[s]; cp = r->cpo[s] == P8F_NIL ? 0xFFFFFFFFu : cp0 + r->cpo[s]; runp = r->runp[s]; smc = r->smc[s]; }
+    out[5 * s] = cp; out[5 * s + 1] = cp0; out[5 * s + 2] = runp; out[5 * s + 3] = cp == 0xFFFFFFFFu ? 0 : T[cp]; out[5 * s + 4] = smc;
+  }
+}
+void p8s_dump_table(void* h, int inst, uint8_t* out) { Emul* e = (Emul*)h; memcpy(out, e->S.fam.inst[inst].table, ((size_t)e->S.fam.inst[inst].mask + 1) * 64); }
 void p8s_stats(void* h, uint64_t* out3) { Emul* e = (Emul*)h; out3[0] = e->steps; out3[1] = e->fam_serial; out3[2] = e->cm2_serial; }
 // nbytes more bytes of the stream; out [8 nbytes][1591] f32 = PAQ8::Predict() before each of their bits. 0 or a negative front-end code.
 int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
@@ -105,6 +125,10 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
   int f_last_y = S.fam.last_y, f_c1 = S.fam.c1;
   uint32_t run_bits[P8_NCM2]; int c_last_y[P8_NCM2];
   for (int k = 0; k < P8_NCM2; k++) { run_bits[k] = S.cm2[k].bits; c_last_y[k] = S.cm2[k].last_y; }
+  if (!e->use_v1) {
+    for (int tid = 0; tid < 256; tid++) p8f_load(&S.fam, S.fam_home, S.fam.sm, e->f2, tid, 256);
+    e->f2_lk = 0; e->f2_i = e->f2_prev_i = (uint32_t)S.fam.rnd.i;
+  }
   for (size_t t = 0; t < T; t++) {
     const uint64_t g = e->steps + t;
     const int y = t ? bits[t - 1] : e->last_bit;
@@ -125,6 +149,7 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
         if (k == 0) { int o = 0; for (int i = 0; i < d->C; i++) o += e->csh[0].nz[i]; order[t] = (uint8_t)o; }
       }
     }
+    if (e->use_v1) {
     const P8CmBit fu = p8d_cm_bit(&S.fam, c.fam_ctx, c.fam_chk, bits.data(), x.data(), order.data(), (int)t, &f_last_y, &f_c1);
     if (g >= 8) {
       P8CmDev* d = &S.fam;
@@ -132,25 +157,87 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
       for (int s = d->nslots - 1; s >= 0; s--) p8d_cm_check(d, &e->fsh, s);
       for (int s = d->nslots - 1; s >= 0; s--) p8d_cm_draw(d, &e->fsh, s);
       e->fam_serial += e->fsh.conflict != 0;
-      e->draws_total += (uint64_t)e->fsh.ndraws;
-      if (fu.bp == 0 || fu.bp == 2 || fu.bp == 5) {
-        e->lookups++;
-        int nconf = 0, nrisky = 0;
-        for (int k = 0; k < d->ninst; k++) {
-          const P8CmInst* x = &d->inst[k];
-          int hit = 0, draw = 0;
-          for (int a = x->first; a < x->first + x->count; a++) {
-            draw |= e->fsh.draws[a];
-            for (int b = a + 1; b < x->first + x->count && !hit; b++)
-              for (int i = 0; i < 5 && !hit; i++)
-                if (e->fsh.touched[a][i] >= 0)
-                  for (int j = 0; j < 5; j++) if (e->fsh.touched[a][i] == e->fsh.touched[b][j]) { hit = 1; break; }
-          }
-          if (hit) { e->inst_conf[k]++; nconf++; if (draw) { e->inst_risky[k]++; nrisky++; } }
-        }
-        e->bits_with_conf += nconf > 0; e->bits_with_risky += nrisky > 0; e->multi_conf += nconf > 1;
-      }
       for (int s = d->nslots - 1; s >= 0; s--) p8d_cm_run(d, &e->fsh, fu, s);
+    }
+    } else {   // second design (p8fam_dev.h): the control flow of cmx_p8s_fam2_kernel, lanes looped per phase
+      P8CmDev* d = &S.fam;
+      P8FamShared* sh = e->f2;
+      const int SS = d->nslots;
+      const P8FamUni fu = p8f_uni(d, c.fam_ctx, c.fam_chk, bits.data(), x.data(), order.data(), (int)t, &f_last_y, &f_c1, &e->f2_lk, e->f2_i);
+      if (g >= 8) {
+        static P8FamTmp tmp[P8CM_MAXS];
+        for (int s = SS - 1; s >= 0; s--) p8f_phase1(d, sh, fu, s, &tmp[s]);
+        for (uint32_t base = e->f2_prev_i + P8F_LOOK + 1; base <= e->f2_i + P8F_LOOK; base += 24)
+          for (int l = 23; l >= 0; l--) p8f_refill_group(sh, base, e->f2_i + P8F_LOOK, l);
+        const bool look = fu.bp == 0 || fu.bp == 2 || fu.bp == 5;
+        int total = 0;
+        if (getenv("CMX_P8_TRACE_G") && g == (uint64_t)atoi(getenv("CMX_P8_TRACE_G"))) {
+          const int k = d->slot_inst[atoi(getenv("CMX_P8_TRACE_SLOT"))];
+          printf("g %llu: anyconf %u conflict[inst %d] %d\n", (unsigned long long)g, sh->anyconf[fu.lk & 1], k, sh->conflict[fu.lk & 1][k]);
+          for (int s = d->inst[k].first; s < d->inst[k].first + d->inst[k].count; s++)
+            printf("  slot %d: look %d nb %u | old cp0 %u (bucket %u) cpo %d runp %u (bucket %u) ctx %u chk %u\n", s, tmp[s].look, tmp[s].nb, sh->r.cp0[s], sh->r.cp0[s] >> 6, sh->r.cpo[s], sh->r.runp[s],
+                   sh->r.runp[s] >> 6, p8f_ctx(d, fu, s), p8f_chk(d, fu, s));
+        }
+        if (!(look && sh->anyconf[fu.lk & 1]) && !sh->anyshared) {
+          for (int s = SS - 1; s >= 0; s--) p8f_run(d, sh, fu, s, &tmp[s], p8f_count(sh, (int)t, 0, s));
+          total = p8f_count(sh, (int)t, 0, SS);
+        } else {
+          e->fam_serial++;
+          int base = 0, k = 0, anys = 0;
+          auto walked = [&](int q) { return (look && sh->conflict[fu.lk & 1][q]) || sh->shared[q]; };
+          while (k < d->ninst) {
+            if (!walked(k)) {
+              int k2 = k;
+              while (k2 < d->ninst && !walked(k2)) k2++;
+              const int a = d->inst[k].first, b = k2 < d->ninst ? d->inst[k2].first : SS;
+              for (int s = b - 1; s >= a; s--) p8f_run(d, sh, fu, s, &tmp[s], base + p8f_count(sh, (int)t, a, s));
+              base += p8f_count(sh, (int)t, a, b);
+              k = k2;
+            } else {
+              base += p8f_walk(d, sh, fu, k, base);
+              if (look) sh->shared[k] = (uint8_t)p8f_shares(d, sh, k);   // slots change hands at lookup bits only
+              for (int s = d->inst[k].first; s < d->inst[k].first + d->inst[k].count; s++) p8f_reload(d, sh, s);
+              k++;
+            }
+          }
+          for (int q = 0; q < d->ninst; q++) anys |= sh->shared[q];
+          sh->anyshared = (uint32_t)anys;
+          total = base;
+          e->multi_conf += anys != 0;
+        }
+        if (look) for (int tid = 255; tid >= 0; tid--) p8f_clear_next(sh, fu.lk, tid, 256);
+        e->f2_prev_i = e->f2_i; e->f2_i += (uint32_t)total;
+        if (getenv("CMX_P8FAM_CHECK")) {   // invariant: the cached bytes equal the table
+          for (int s = 0; s < SS; s++) {
+            const uint8_t* T = d->inst[d->slot_inst[s]].table;
+            const P8FamHome* r = &sh->r;
+            int bad = r->rc[s] != T[r->runp[s]] || r->rb[s] != T[r->runp[s] + 1];
+            for (int k = 0; k < 7; k++) bad |= r->slot[s][k] != T[r->cp0[s] + k];
+            if (bad) {
+              printf("step %llu (bp %d) slot %d inst %d: cache != table: cp0 %u cpo %d runp %u rc %d/%d rb %d/%d slot", (unsigned long long)g, fu.bp, s, d->slot_inst[s], r->cp0[s], r->cpo[s],
+                     r->runp[s], r->rc[s], T[r->runp[s]], r->rb[s], T[r->runp[s] + 1]);
+              for (int k = 0; k < 7; k++) printf(" %d/%d", r->slot[s][k], T[r->cp0[s] + k]);
+              printf("  conflict-bit %d\n", (int)(look && sh->anyconf[fu.lk & 1]));
+              fflush(stdout);
+              setenv("CMX_P8FAM_CHECK_HIT", "1", 1);
+            }
+          }
+          if (getenv("CMX_P8FAM_CHECK_HIT")) { unsetenv("CMX_P8FAM_CHECK"); }
+        }
+      }
+    }
+    if (const char* ts = getenv("CMX_P8_TRACE_SLOT")) {
+      const int s = atoi(ts);
+      const P8CmDev* d = &S.fam;
+      const uint8_t* T = d->inst[d->slot_inst[s]].table;
+      uint32_t cp, cp0, runp, smc;
+      if (e->use_v1) { cp = e->fsh.r.cp[s]; cp0 = e->fsh.r.cp0[s]; runp = e->fsh.r.runp[s]; smc = (uint32_t)e->fsh.r.sm_cxt[s]; }
+      else { const P8FamHome* r = &e->f2->r; cp0 = r->cp0[s]; cp = r->cpo[s] == P8F_NIL ? 0xFFFFFFFFu : cp0 + r->cpo[s]; runp = r->runp[s]; smc = r->smc[s]; }
+      if (g >= (uint64_t)atoi(getenv("CMX_P8_TRACE_FROM")) && g < (uint64_t)atoi(getenv("CMX_P8_TRACE_FROM")) + 24) {
+        if (getenv("CMX_P8_TRACE_ADDR")) printf("[T[%d]=%d] ", atoi(getenv("CMX_P8_TRACE_ADDR")), T[atoi(getenv("CMX_P8_TRACE_ADDR"))]);
+        printf("g %llu bp %d: cp %d cp0 %u runp %u T[cp] %d rc %d rb %d smc %u | x %d %d %d %d %d\n", (unsigned long long)g, (int)(g & 7), (int)cp, cp0, runp, cp == 0xFFFFFFFFu ? -1 : T[cp], T[runp], T[runp + 1], smc,
+               xr[d->slot_off[s]], xr[d->slot_off[s] + 1], xr[d->slot_off[s] + 2], xr[d->slot_off[s] + 3], xr[d->slot_off[s] + 4]);
+      }
     }
     if (g == 0) { memcpy(orow, S.tail.out, sizeof S.tail.out); continue; }   // no step 0: the constructor's 0.5
     for (int l = S.lanes.nlanes - 1; l >= 0; l--) p8s_lane_step(&S.lanes, &S.lanes.regs[l], l, c.ops[t * P8_NLANE + l], y, order[t], xr);
@@ -191,6 +278,7 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
     train(st, S.mix.wx2, 32, ((yb << 12) - p2) * 7);
   }
   S.fam.last_y = f_last_y; S.fam.c1 = f_c1;
+  if (!e->use_v1) for (int tid = 0; tid < 256; tid++) p8f_store(&S.fam, S.fam_home, S.fam.sm, e->f2, e->f2_i, tid, 256);
   for (int k = 0; k < P8_NCM2; k++) { S.cm2[k].bits = run_bits[k]; S.cm2[k].last_y = c_last_y[k]; }
   e->steps += T; e->last_bit = T ? bits[T - 1] : e->last_bit;
   return 0;

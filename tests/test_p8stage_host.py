@@ -24,7 +24,7 @@ SRC = os.path.join(ROOT, "tests", "host", "p8stage_emul.cpp")
 CSRC = os.path.join(ROOT, "cmix_amd", "csrc")
 FRONT = sorted(glob.glob(os.path.join(CSRC, "p8front", "*.c")))
 DEPS = [SRC] + FRONT + glob.glob(os.path.join(CSRC, "p8front", "*.h")) + [os.path.join(CSRC, f) for f in (
-    "p8_rec.h", "p8stage_dev.h", "p8stage_build.h", "p8cm_dev.h", "p8cm_build.h", "p8cm2_dev.h", "p8cm2_build.h", "p8dmc_dev.h", "p8dmc_build.h")]
+    "p8_rec.h", "p8stage_dev.h", "p8stage_build.h", "p8fam_dev.h", "p8cm_dev.h", "p8cm_build.h", "p8cm2_dev.h", "p8cm2_build.h", "p8dmc_dev.h", "p8dmc_build.h")]
 
 
 def emul():
@@ -36,7 +36,7 @@ def emul():
             o = os.path.join(obj, os.path.basename(f)[:-2] + ".o")
             subprocess.check_call(["gcc", "-std=gnu11", "-O2", "-fPIC", "-ffp-contract=off", "-w", "-include", os.path.join(CSRC, "p8front", "p8f_alloc.h"), "-c", f, "-o", o])
             objs.append(o)
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-o", SO, SRC] + objs + ["-lm"])
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared"] + os.environ.get("CMX_EMUL_FLAGS", "").split() + ["-o", SO, SRC] + objs + ["-lm"])
     L = C.CDLL(SO)
     L.p8s_create.restype = C.c_void_p
     L.p8s_create.argtypes = [C.c_int]
