@@ -27,6 +27,7 @@
 
 #include "../../include/cmix_amd.h"
 #include "p8front/p8f_front.h"
+#include "p8cm2v2_dev.h"
 #include "p8stage_build.h"
 
 void cmx_set_err(const std::string& s);  // cmx_api.hip
@@ -54,6 +55,41 @@ __global__ __launch_bounds__(P8CM2_MAXC) void cmx_p8s_cm2_kernel(P8Cm2Dev* d, co
     if (order_out && i == 0) { int o = 0; for (int k = 0; k < C; k++) o += sh.nz[k]; order_out[t] = (uint8_t)o; }
   }
   if (i == 0) { d->regs = sh.r; d->bits = run_bits; d->last_y = last_y; }
+}
+
+// Second design (p8cm2v2_dev.h): cached slot / byte-history bytes, bucket fetch before the bit's barrier, hash-set overlap
+// detection at lookup bits; overlap or shared slots -> lane 0 walks the instance with the first design's code.
+__global__ __launch_bounds__(P8CM2_MAXC) void cmx_p8s_cm2v2_kernel(P8Cm2Dev* d, const uint32_t* ctx, const uint16_t* chk, const uint8_t* bits, int16_t* x,
+                                                                  uint8_t* order_out, int nbits, int skip) {
+  __shared__ __attribute__((aligned(16))) P8Cm2V2Shared sh;
+  const int i = threadIdx.x, C = d->C;
+  p8c2_load(d, &sh, i, P8CM2_MAXC);
+  uint32_t run_bits = d->bits;
+  int last_y = d->last_y, lk = 0;
+  __syncthreads();
+  if (i < C) p8c2_reload(d, &sh, i);
+  __syncthreads();
+  for (int t = 0; t < nbits; t++) {
+    const P8Cm2Bit u = p8d_bit(d, ctx, chk, bits, x, t, &run_bits, &last_y);
+    if (t < skip) { if (order_out && i == 0) order_out[t] = 0; continue; }
+    const bool look = u.bpos == 0 || u.bpos == 2 || u.bpos == 5;
+    P8Cm2Tmp tmp;
+    if (look) {
+      ++lk;
+      if (i < C) p8c2_phase1(d, &sh, u, lk, i, &tmp);
+      __syncthreads();
+    }
+    if ((look && sh.conf[lk & 1]) || sh.shared || !d->slot_parallel) {   // slot_parallel == 0: A/B switch, always the serial walk
+      if (i == 0) p8c2_walk(d, &sh, u, look);
+      __syncthreads();
+      if (i < C) p8c2_reload(d, &sh, i);
+    } else if (i < C) p8c2_run(d, &sh, u, i, &tmp);
+    __syncthreads();
+    if (order_out && i == 0) { int o = 0; for (int k = 0; k < C; k++) o += sh.base.nz[k]; order_out[t] = (uint8_t)o; }
+    if (look) p8c2_clear_next(&sh, lk, i, P8CM2_MAXC);
+  }
+  __syncthreads();
+  if (i == 0) { d->regs = sh.base.r; d->bits = run_bits; d->last_y = last_y; }
 }
 
 __global__ __launch_bounds__(P8CM_MAXS) void cmx_p8s_fam_kernel(P8CmDev* d, const uint32_t* ctx, const uint16_t* chk, const uint8_t* bits, int16_t* x,
@@ -100,16 +136,17 @@ __global__ __launch_bounds__(P8CM_MAXS) void cmx_p8s_fam2_kernel(P8CmDev* d, P8F
     __syncthreads();
     const bool look = u.bp == 0 || u.bp == 2 || u.bp == 5;
     int total;
-    if (!(look && sh.anyconf[lk & 1]) && !sh.anyshared) {
+    const bool all_serial = !d->slot_parallel;   // A/B switch (CMX_P8CM_SERIAL=1): every instance walked by its first lane
+    if (!(look && sh.anyconf[lk & 1]) && !sh.anyshared && !all_serial) {
       if (tid < S) p8f_run(d, &sh, u, tid, &tmp, p8f_count(&sh, t, 0, tid));
       total = p8f_count(&sh, t, 0, S);
     } else {
       int base = 0, k = 0;
       while (k < ninst) {
-        const bool walked = (look && sh.conflict[lk & 1][k]) || sh.shared[k];
+        const bool walked = (look && sh.conflict[lk & 1][k]) || sh.shared[k] || all_serial;
         if (!walked) {
           int k2 = k;
-          while (k2 < ninst && !((look && sh.conflict[lk & 1][k2]) || sh.shared[k2])) k2++;
+          while (k2 < ninst && !((look && sh.conflict[lk & 1][k2]) || sh.shared[k2] || all_serial)) k2++;
           const int a = d->inst[k].first, b = k2 < ninst ? d->inst[k2].first : S;
           if (tid >= a && tid < b) p8f_run(d, &sh, u, tid, &tmp, base + p8f_count(&sh, t, a, tid));
           base += p8f_count(&sh, t, a, b);
@@ -453,7 +490,7 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
   const int skip = h->steps >= 8 ? 0 : (int)(8 - h->steps), t0 = h->steps == 0 ? 1 : 0;
   const uint8_t* d_bits = (const uint8_t*)(b.d + b.o_bits);
   auto cm2 = [&](int k, hipStream_t q, uint8_t* ord) {
-    hipLaunchKernelGGL(cmx_p8s_cm2_kernel, dim3(1), dim3(P8CM2_MAXC), 0, q, h->d_cm2[k], (const uint32_t*)(b.d + b.o_cctx[k]), (const uint16_t*)(b.d + b.o_cchk[k]), d_bits,
+    hipLaunchKernelGGL(h->fam_v1 ? cmx_p8s_cm2_kernel : cmx_p8s_cm2v2_kernel, dim3(1), dim3(P8CM2_MAXC), 0, q, h->d_cm2[k], (const uint32_t*)(b.d + b.o_cctx[k]), (const uint16_t*)(b.d + b.o_cchk[k]), d_bits,
                        h->d_x, ord, nbits, skip);
   };
   if (ok) {

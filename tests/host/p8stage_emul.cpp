@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../cmix_amd/csrc/p8front/p8f_front.h"
+#include "../../cmix_amd/csrc/p8cm2v2_dev.h"
 #include "../../cmix_amd/csrc/p8stage_build.h"
 
 namespace {
@@ -30,6 +31,8 @@ struct Emul {
   int f2_lk = 0; uint32_t f2_prev_i = 0, f2_i = 0;
   int use_v1 = 0;
   P8Cm2Shared csh[P8_NCM2];
+  P8Cm2V2Shared* c2[P8_NCM2] = {};   // second-design ContextMap2 body
+  int c2_lk[P8_NCM2] = {};
   P8DmcShared dsh;
   uint64_t steps = 0;
   int last_bit = 0;
@@ -68,6 +71,7 @@ void* p8s_create(int level) {
   }
   e->fsh.r = e->S.fam.regs; e->fsh.rnd = e->S.fam.rnd;
   e->use_v1 = getenv("CMX_P8FAM_V1") != nullptr;
+  for (int k = 0; k < P8_NCM2; k++) e->c2[k] = new P8Cm2V2Shared();
   e->f2mem.resize(sizeof(P8FamShared) + (size_t)e->S.fam.nslots * 512 + 64);
   e->f2 = (P8FamShared*)e->f2mem.data();
   for (int k = 0; k < P8_NCM2; k++) e->csh[k].r = e->S.cm2[k].regs;
@@ -125,6 +129,12 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
   int f_last_y = S.fam.last_y, f_c1 = S.fam.c1;
   uint32_t run_bits[P8_NCM2]; int c_last_y[P8_NCM2];
   for (int k = 0; k < P8_NCM2; k++) { run_bits[k] = S.cm2[k].bits; c_last_y[k] = S.cm2[k].last_y; }
+  if (!e->use_v1)
+    for (int k = 0; k < P8_NCM2; k++) {
+      for (int tid = 0; tid < P8CM2_MAXC; tid++) p8c2_load(&S.cm2[k], e->c2[k], tid, P8CM2_MAXC);
+      for (int i = 0; i < S.cm2[k].C; i++) p8c2_reload(&S.cm2[k], e->c2[k], i);
+      e->c2_lk[k] = 0;
+    }
   if (!e->use_v1) {
     for (int tid = 0; tid < 256; tid++) p8f_load(&S.fam, S.fam_home, S.fam.sm, e->f2, tid, 256);
     e->f2_lk = 0; e->f2_i = e->f2_prev_i = (uint32_t)S.fam.rnd.i;
@@ -139,7 +149,7 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
     for (int k = 0; k < P8_NCM2; k++) cu[k] = p8d_bit(&S.cm2[k], c.cm2_ctx[k], c.cm2_chk[k], bits.data(), x.data(), (int)t, &run_bits[k], &c_last_y[k]);
     const P8CmBit fu_pre = P8CmBit();
     (void)fu_pre;
-    if (g >= 8) {
+    if (g >= 8 && e->use_v1) {
       for (int k = 0; k < P8_NCM2; k++) {   // instance 0 first: the family needs its return value
         P8Cm2Dev* d = &S.cm2[k];
         for (int i = d->C - 1; i >= 0; i--) p8d_touch(d, &e->csh[k], cu[k], i);
@@ -147,6 +157,22 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
         e->cm2_serial += e->csh[k].conflict != 0;
         for (int i = d->C - 1; i >= 0; i--) p8d_run(d, &e->csh[k], cu[k], i);
         if (k == 0) { int o = 0; for (int i = 0; i < d->C; i++) o += e->csh[0].nz[i]; order[t] = (uint8_t)o; }
+      }
+    } else if (g >= 8) {   // second design: the control flow of cmx_p8s_cm2v2_kernel
+      for (int k = 0; k < P8_NCM2; k++) {
+        P8Cm2Dev* d = &S.cm2[k];
+        P8Cm2V2Shared* sh = e->c2[k];
+        const bool look = cu[k].bpos == 0 || cu[k].bpos == 2 || cu[k].bpos == 5;
+        static P8Cm2Tmp tmp[P8CM2_MAXC];
+        if (look) { ++e->c2_lk[k]; for (int i = d->C - 1; i >= 0; i--) p8c2_phase1(d, sh, cu[k], e->c2_lk[k], i, &tmp[i]); }
+        const bool force = getenv("CMX_P8C2_FORCE_WALK") && (g % 5) == 2;   // test hook: exercise walk + reload
+        if ((look && sh->conf[e->c2_lk[k] & 1]) || sh->shared || force) {
+          e->cm2_serial++;
+          p8c2_walk(d, sh, cu[k], look);
+          for (int i = d->C - 1; i >= 0; i--) p8c2_reload(d, sh, i);
+        } else for (int i = d->C - 1; i >= 0; i--) p8c2_run(d, sh, cu[k], i, &tmp[i]);
+        if (k == 0) { int o = 0; for (int i = 0; i < d->C; i++) o += sh->base.nz[i]; order[t] = (uint8_t)o; }
+        if (look) for (int tid = P8CM2_MAXC - 1; tid >= 0; tid--) p8c2_clear_next(sh, e->c2_lk[k], tid, P8CM2_MAXC);
       }
     }
     if (e->use_v1) {
@@ -279,7 +305,7 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
   }
   S.fam.last_y = f_last_y; S.fam.c1 = f_c1;
   if (!e->use_v1) for (int tid = 0; tid < 256; tid++) p8f_store(&S.fam, S.fam_home, S.fam.sm, e->f2, e->f2_i, tid, 256);
-  for (int k = 0; k < P8_NCM2; k++) { S.cm2[k].bits = run_bits[k]; S.cm2[k].last_y = c_last_y[k]; }
+  for (int k = 0; k < P8_NCM2; k++) { S.cm2[k].bits = run_bits[k]; S.cm2[k].last_y = c_last_y[k]; if (!e->use_v1) S.cm2[k].regs = e->c2[k]->base.r; }
   e->steps += T; e->last_bit = T ? bits[T - 1] : e->last_bit;
   return 0;
 }

@@ -24,7 +24,7 @@ SRC = os.path.join(ROOT, "tests", "host", "p8stage_emul.cpp")
 CSRC = os.path.join(ROOT, "cmix_amd", "csrc")
 FRONT = sorted(glob.glob(os.path.join(CSRC, "p8front", "*.c")))
 DEPS = [SRC] + FRONT + glob.glob(os.path.join(CSRC, "p8front", "*.h")) + [os.path.join(CSRC, f) for f in (
-    "p8_rec.h", "p8stage_dev.h", "p8stage_build.h", "p8fam_dev.h", "p8cm_dev.h", "p8cm_build.h", "p8cm2_dev.h", "p8cm2_build.h", "p8dmc_dev.h", "p8dmc_build.h")]
+    "p8_rec.h", "p8stage_dev.h", "p8stage_build.h", "p8fam_dev.h", "p8cm2v2_dev.h", "p8cm_dev.h", "p8cm_build.h", "p8cm2_dev.h", "p8cm2_build.h", "p8dmc_dev.h", "p8dmc_build.h")]
 
 
 def emul():
@@ -126,3 +126,15 @@ def test_stage_vs_reference_hashes(name, nbytes):
     h = row_hash(got)
     bad = np.nonzero(h != want[:8 * nbytes])[0]
     assert bad.size == 0, (name, "first differing step:", bad[0], "of", 8 * nbytes)
+
+
+def test_cm2_walk_and_reload_path(monkeypatch):
+    """ContextMap2's second design falls back to a serial walk of the instance on overlaps, which the 2 GB tables almost
+    never produce: force the walk on two bits out of five and check that walk -> reload -> lane-parallel stays exact."""
+    monkeypatch.setenv("CMX_P8C2_FORCE_WALK", "1")
+    g = load_golden("text_96")
+    probs = mg.unpack_probs(g)
+    got, st = run_stage(g["stream"], chunks=[5, 40])
+    assert st[2] > 100
+    want = np.ascontiguousarray(probs[:, 434:2025])
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))

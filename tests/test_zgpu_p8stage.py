@@ -66,3 +66,14 @@ def test_layer0_columns_in_place():
     st.close()
     assert (got[:, :434] == -1).all() and (got[:, 2025:] == -1).all()
     assert np.array_equal(got[:, 434:2025].view(np.uint32), np.ascontiguousarray(probs[:, 434:2025]).view(np.uint32))
+
+
+def test_serial_walk_paths_on_device(monkeypatch):
+    """CMX_P8CM_SERIAL=1: every ContextMap / ContextMap2 instance is walked serially by one lane each bit (the fallback
+    the lane-parallel kernels take on overlaps), then the lanes reload their cached bytes: same values."""
+    monkeypatch.setenv("CMX_P8CM_SERIAL", "1")
+    g = load_golden("text_96")
+    probs = mg.unpack_probs(g)
+    got = run_device(g["stream"], [9, 50])
+    want = np.ascontiguousarray(probs[:, 434:2025])
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
