@@ -22,8 +22,10 @@
 void cmx_set_err(const std::string& s);  // cmx_api.hip
 extern "C" int cmx_device_count(void);
 
-__global__ __launch_bounds__(FX_THREADS) void cmx_fxcm_chunk_kernel(FxDev* d, const uint8_t* bytes, const FxByteRec* recs, const int16_t* lstmpr,
-                                                                    const uint8_t* lstmex, float* out, long ostride, int n) {
+// PROF: per-phase clocks of thread 0 (s_memtime) accumulated into prof[0..7] (CMX_FXCM_PROFILE=1, scripts/gpu_fxcm_time.py)
+template <bool PROF>
+__global__ __launch_bounds__(FX_THREADS) void cmx_fxcm_chunk_kernel_t(FxDev* d, const uint8_t* bytes, const FxByteRec* recs, const int16_t* lstmpr,
+                                                                      const uint8_t* lstmex, float* out, long ostride, int n, unsigned long long* prof) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fx_smem[];   // sizeof(FxShared) > 64 KB: dynamic
   FxShared& sh = *(FxShared*)fx_smem;
   const int tid = threadIdx.x;
@@ -31,25 +33,30 @@ __global__ __launch_bounds__(FX_THREADS) void cmx_fxcm_chunk_kernel(FxDev* d, co
   fxd_load_shared(d, &sh, tid);
   for (int i = tid; i < FX_OUTPUTS; i += FX_THREADS) out[i] = d->pending[i];   // row 0: what the previous chunk's last update left
   __syncthreads();
+  unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c0 = 0;
+#define FX_TICK(k) do { if (PROF && tid == 0) { const unsigned long long c1 = __builtin_readcyclecounter(); acc[k] += c1 - c0; c0 = c1; } } while (0)
+  if (PROF && tid == 0) c0 = __builtin_readcyclecounter();
   for (int q = 0; q < nbits; q++) {
     const FxBit u = fxd_bit(d, bytes, recs, lstmpr, lstmex, out, ostride, nbits, q, blpos0, lastbyte0, have0);
     fxd_phase1a(d, &sh, u, tid);
-    __syncthreads();
+    __syncthreads(); FX_TICK(0);
     fxd_phase1b(d, &sh, u, tid);
-    __syncthreads();
+    __syncthreads(); FX_TICK(1);
     fxd_phase1c(d, &sh, u, tid);
-    __syncthreads();
+    __syncthreads(); FX_TICK(2);
     fxd_phase2(d, &sh, u, tid);
-    __syncthreads();
+    __syncthreads(); FX_TICK(3);
     fxd_phase3(d, &sh, u, tid);
-    __syncthreads();
+    __syncthreads(); FX_TICK(4);
     fxd_phase4(d, &sh, u, tid);
-    __syncthreads();
+    __syncthreads(); FX_TICK(5);
     fxd_phase5(d, &sh, u, tid);
-    __syncthreads();
+    __syncthreads(); FX_TICK(6);
   }
+#undef FX_TICK
   fxd_store_shared(d, &sh, tid);
   if (tid == 0) { d->blpos = blpos0 + n; d->lastbyte = bytes[n - 1]; d->have_rec = 1; d->rec = recs[n - 1]; }
+  if (PROF && tid == 0) for (int k = 0; k < 8; k++) prof[k] += acc[k];
 }
 
 __global__ void cmx_fxcm_pattern16_kernel(uint16_t* p, size_t n, const uint16_t* pat, int plen) {
@@ -94,6 +101,7 @@ struct cmx_fxcm {
   bool used[FX_STAGE_BUFS] = {};
   int next = 0;
   uint64_t bytes_done = 0;
+  unsigned long long* d_prof = nullptr;   // CMX_FXCM_PROFILE=1: per-phase clocks
 };
 
 extern "C" {
@@ -109,6 +117,7 @@ void cmx_fxcm_destroy(cmx_fxcm_t* h) {
     if (h->d_recs[i]) (void)hipFree(h->d_recs[i]);
     if (h->done[i]) (void)hipEventDestroy(h->done[i]);
   }
+  if (h->d_prof) (void)hipFree(h->d_prof);
   if (h->parser) fxp_destroy(h->parser);
   delete h;
 }
@@ -126,7 +135,10 @@ cmx_fxcm_t* cmx_fxcm_create(const char* dictionary_path, int device) {
   ok = ok && hipMalloc((void**)&h->d_dev, sizeof(FxDev)) == hipSuccess;
   ok = ok && hipMemcpy(h->d_dev, &host, sizeof(FxDev), hipMemcpyHostToDevice) == hipSuccess;
   for (int i = 0; ok && i < FX_STAGE_BUFS; i++) ok = hipEventCreateWithFlags(&h->done[i], hipEventDisableTiming) == hipSuccess;
-  ok = ok && hipFuncSetAttribute((const void*)cmx_fxcm_chunk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(FxShared)) == hipSuccess;
+  ok = ok && hipFuncSetAttribute((const void*)cmx_fxcm_chunk_kernel_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(FxShared)) == hipSuccess;
+  ok = ok && hipFuncSetAttribute((const void*)cmx_fxcm_chunk_kernel_t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(FxShared)) == hipSuccess;
+  const char* prof = getenv("CMX_FXCM_PROFILE");
+  if (ok && prof && prof[0] == '1') ok = hipMalloc((void**)&h->d_prof, 64) == hipSuccess && hipMemset(h->d_prof, 0, 64) == hipSuccess;
   ok = ok && hipDeviceSynchronize() == hipSuccess;
   if (!ok) { cmx_set_err("cmx_fxcm_create: allocation / init failed (the stage needs ~4.4 GB of HBM)"); cmx_fxcm_destroy(h); return nullptr; }
   h->parser = fxp_create(dictionary_path);
@@ -153,14 +165,24 @@ int cmx_fxcm_run(cmx_fxcm_t* h, const uint8_t* bytes, const uint8_t* d_bytes, si
   if (fxp_run(h->parser, bytes, (int)nbytes, h->h_recs[b]) != 0) { cmx_set_err("cmx_fxcm_run: parser emitted a context count a map does not expect"); return 1; }
   hipStream_t s = (hipStream_t)stream;
   if (hipMemcpyAsync(h->d_recs[b], h->h_recs[b], nbytes * sizeof(FxByteRec), hipMemcpyHostToDevice, s) != hipSuccess) { cmx_set_err("cmx_fxcm_run: record upload failed"); return 1; }
-  hipLaunchKernelGGL(cmx_fxcm_chunk_kernel, dim3(1), dim3(FX_THREADS), sizeof(FxShared), s, h->d_dev, d_bytes, h->d_recs[b], d_lstmpr, d_lstmex, d_probs + 3, (long)pstride,
-                     (int)nbytes);
+  if (h->d_prof)
+    hipLaunchKernelGGL(cmx_fxcm_chunk_kernel_t<true>, dim3(1), dim3(FX_THREADS), sizeof(FxShared), s, h->d_dev, d_bytes, h->d_recs[b], d_lstmpr, d_lstmex, d_probs + 3,
+                       (long)pstride, (int)nbytes, h->d_prof);
+  else
+    hipLaunchKernelGGL(cmx_fxcm_chunk_kernel_t<false>, dim3(1), dim3(FX_THREADS), sizeof(FxShared), s, h->d_dev, d_bytes, h->d_recs[b], d_lstmpr, d_lstmex, d_probs + 3,
+                       (long)pstride, (int)nbytes, (unsigned long long*)nullptr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { cmx_set_err(std::string("cmx_fxcm_run: ") + hipGetErrorString(e)); return 1; }
   if (hipEventRecord(h->done[b], s) != hipSuccess) { cmx_set_err("cmx_fxcm_run: event record failed"); return 1; }
   h->used[b] = true;
   h->bytes_done += nbytes;
   return 0;
+}
+
+// CMX_FXCM_PROFILE=1: thread 0's clocks per barrier phase (1a, 1b, 1c, 2, 3, 4, 5) since creation
+int cmx_fxcm_profile(cmx_fxcm_t* h, unsigned long long out8[8]) {
+  if (!h || !h->d_prof) return 1;
+  return hipMemcpy(out8, h->d_prof, 64, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
 }
 
 int cmx_fxcm_sync(cmx_fxcm_t* h) {

@@ -35,3 +35,12 @@ fx.sync()
 ms = [a.elapsed_time(b) for a, b in ev]
 print("fxcm stage, %d x %d-byte chunks, serial_maps=%s: kernel+copy %.2f us/bit (min %.2f, max %.2f); host parse+launch %.2f us/byte" % (
     nchunks, C, os.environ.get("CMX_FXCM_SERIAL_MAPS", "0"), np.mean(ms) * 1e3 / (8 * C), np.min(ms) * 1e3 / (8 * C), np.max(ms) * 1e3 / (8 * C), host / (nchunks * C) * 1e6))
+
+if os.environ.get("CMX_FXCM_PROFILE") == "1":
+    import ctypes as C
+    acc = (C.c_ulonglong * 8)()
+    E.lib().cmx_fxcm_profile.argtypes = [C.c_void_p, C.c_void_p]
+    if E.lib().cmx_fxcm_profile(fx.h, acc) == 0:
+        tot = sum(acc) or 1
+        nb = 8.0 * C_BYTES * (nchunks + 4) if False else 8.0 * 1024 * (nchunks + 4)
+        print("thread-0 clocks per bit by phase (1a, 1b, 1c, 2, 3, 4, 5):", " ".join("%.0f" % (a / nb) for a in list(acc)[:7]), "| total %.0f" % (tot / nb))
