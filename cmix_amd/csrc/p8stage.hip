@@ -338,6 +338,225 @@ __global__ __launch_bounds__(MX_THREADS) void cmx_p8s_mix_kernel(const P8MixDev*
   if (tid == 0) T->pr = fin_s;
 }
 
+// Second design of the mixer kernel: everything a bit needs from HBM / L2 is requested one bit ahead.
+//   * weight rows: the 28 selectors of bit t+1 are known while bit t is being mixed (host part + the order-N map's
+//     value; only set 26 needs this bit's final probability): the rows of t+1 are loaded into a second register set
+//     right after the dot products of t were issued; a row that bit t trains and bit t+1 selects again is taken from the
+//     trained registers instead (rows of different sets never coincide: cumulative bases, :548-551);
+//   * the input row of t+1 (3104 B) the same way, LDS double-buffered;
+//   * the APM / APM1 chains (:8281-8358): the 24 / 33 cells of each table's context row are fetched into LDS at the top
+//     of the bit by the lane that owns the table (the contexts are the host's, plus the miss history); the cell(s) a
+//     table has to update were read one bit earlier and are kept in registers, so the update is a store, not a
+//     load-modify-store; the chain itself then runs on LDS.
+namespace {
+struct MxApmLane {       // one lane per table: j = 0..3 first group, 4..6 second group
+  int idx;               // cell index chosen by the previous lookup (APM: cxt; APM1: index)
+  uint32_t v0, v1;       // its value(s) as of the last lookup (APM uses v0 only)
+};
+__device__ __forceinline__ uint32_t apm_upd(uint32_t p0, int y, int limit) {   // StateMap32 cell update (APM::p :699-703)
+  const int n = p0 & 1023, q = p0 >> 10;
+  if (n < limit) ++p0; else p0 = (p0 & 0xfffffc00u) | (uint32_t)limit;
+  p0 += ((uint32_t)(((y << 22) - q) >> 3) * (uint32_t)(16384 / (n + n + 3))) & 0xfffffc00u;
+  return p0;
+}
+__device__ __forceinline__ uint32_t apm1_upd(uint32_t v, int y, int rate) {   // APM1 cell update :611-613
+  const int g = (y << 16) + (y << rate) - y - y;
+  return (uint16_t)(v + ((g - (int)v) >> rate));
+}
+}  // namespace
+
+__global__ __launch_bounds__(MX_THREADS) void cmx_p8s_mix2_kernel(const P8MixDev* M, P8TailDev* T, const int16_t* __restrict__ x, const int32_t* __restrict__ sel,
+                                                                 const P8ApmRec* __restrict__ apm, const uint8_t* __restrict__ order,
+                                                                 const uint8_t* __restrict__ bits, float* __restrict__ out, size_t ld, int nbits, int t0, int first,
+                                                                 int last_y) {
+  __shared__ __attribute__((aligned(16))) uint32_t xs[2][P8_NX / 2];   // the step's inputs as pairs, double-buffered
+  __shared__ float outs[P8_NOUT];
+  __shared__ int pr_s[32], res_s[8];
+  __shared__ uint32_t st_s[16];
+  __shared__ uint32_t arow[7][36];    // the context rows of the seven chain tables (24 u32 or 33 u16 cells, widened)
+  __shared__ int p_s, fin_s;
+  __shared__ unsigned long long misses_s;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int16_t* squash = M->squash; const int16_t* stretch = M->stretch;
+  const float cf = (float)(1.0 / 4095);
+  for (int i = tid; i < P8_NOUT; i += MX_THREADS) outs[i] = T->out[i];
+  if (tid == 0) { fin_s = T->pr; misses_s = T->misses; }
+  // the chain lanes: wave 1, lanes 0..6 (wave 0 does the second layer)
+  const bool chain = wave == 1 && lane < 7;
+  MxApmLane al_txt = {0, 0, 0}, al_gen = {0, 0, 0};   // the TEXT tables' and the other blocks' tables' pending cells
+  if (chain) {   // home form (P8TailDev): the index of the cell(s) the next call updates; their values are read once per chunk
+    const int j = lane;
+    if (j < 4) { al_txt.idx = T->apm_cxt[j]; al_txt.v0 = T->apm[j][al_txt.idx]; }
+    else { al_txt.idx = T->apm1_idx[j - 4]; al_txt.v0 = T->apm1[j - 4][al_txt.idx]; al_txt.v1 = T->apm1[j - 4][al_txt.idx + 1]; }
+    al_gen.idx = T->gen_idx[j]; al_gen.v0 = T->gen[j][al_gen.idx]; al_gen.v1 = T->gen[j][al_gen.idx + 1];
+  }
+  __syncthreads();
+  if (t0) for (int i = tid; i < P8_NOUT; i += MX_THREADS) out[i] = outs[i];   // no step 0: the constructor's values
+  // ---- prologue: rows and inputs of the first step ----
+  uint4 w[4][4], wn[4][4];
+  int row[4], rown[4];
+  uint4 xn = make_uint4(0, 0, 0, 0);
+  auto load_rows = [&](int t, int lastpr, uint4 (&dst)[4][4], int (&r)[4], bool only_lastpr) {
+    const int ord = order[t];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int si = 4 * wave + q;
+      if (only_lastpr != (si == P8_SEL_LASTPR)) continue;
+      r[q] = p8s_sel(si, sel[(size_t)t * P8_NSEL + si], ord, lastpr);
+      const uint4* wr = reinterpret_cast<const uint4*>(M->wx + (size_t)r[q] * P8_NX);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) { const int grp = lane + 64 * g; dst[q][g] = grp < MX_GROUPS ? wr[grp] : make_uint4(0, 0, 0, 0); }
+    }
+  };
+  auto stage_x = [&](int t, int buf) {   // the input row of step t -> LDS (compacted during the first byte)
+    const int16_t* xr = x + (size_t)t * P8_NX;
+    if (t < first) {
+      int16_t* xh = reinterpret_cast<int16_t*>(xs[buf]);
+      for (int i = tid; i < P8_NX; i += MX_THREADS) xh[i] = i < M->nx_first ? xr[M->first_map[i]] : (int16_t)0;
+    } else if (tid < MX_GROUPS) reinterpret_cast<uint4*>(xs[buf])[tid] = reinterpret_cast<const uint4*>(xr)[tid];
+  };
+  if (t0 < nbits) {
+    load_rows(t0, T->pr, w, row, false);
+    load_rows(t0, T->pr, w, row, true);
+    stage_x(t0, t0 & 1);
+  }
+  for (int t = t0; t < nbits; ++t) {
+    const int y = t ? bits[t - 1] : last_y;
+    const int nx = t < first ? M->nx_first : P8_NX;
+    const int buf = t & 1;
+    if (tid < 32) pr_s[tid] = 0;
+    if (tid == 0) misses_s += misses_s + (unsigned long long)((fin_s >> 11) != y);
+    __syncthreads();   // B1: xs[buf], misses, fin_s of the previous step
+    const P8ApmRec arec = apm[t];
+    // ---- chain lanes: update the cell(s) chosen one step ago, fetch this step's context row ----
+    int a_ctx = 0, a_base = 0;
+    if (chain) {
+      const int j = lane;
+      const unsigned long long ms = misses_s;
+      // the tables of THIS step's block type learn from y at the cell(s) their last lookup chose (p() = update, then lookup)
+      if (arec.text) {
+        if (j < 4) T->apm[j][al_txt.idx] = apm_upd(al_txt.v0, y, (int)arec.limit);
+        else { T->apm1[j - 4][al_txt.idx] = (uint16_t)apm1_upd(al_txt.v0, y, j == 4 ? 7 : 6); T->apm1[j - 4][al_txt.idx + 1] = (uint16_t)apm1_upd(al_txt.v1, y, j == 4 ? 7 : 6); }
+      } else { T->gen[j][al_gen.idx] = (uint16_t)apm1_upd(al_gen.v0, y, 7); T->gen[j][al_gen.idx + 1] = (uint16_t)apm1_upd(al_gen.v1, y, 7); }
+      if (arec.text) {
+        a_ctx = j == 0 ? (arec.c[0] | (int)((ms & 0xF) << 4)) : j == 1 ? arec.c[1 + (int)(ms & 3)] : j < 4 ? arec.c[3 + j] : arec.c[3 + j];   // c[5], c[6]; c[7..9]
+        if (j < 4) { a_base = a_ctx * 24; for (int k = 0; k < 24; k++) arow[j][k] = T->apm[j][a_base + k]; }
+        else { a_base = a_ctx * 33; for (int k = 0; k < 33; k++) arow[j][k] = T->apm1[j - 4][a_base + k]; }
+      } else {
+        a_ctx = j == 0 ? (arec.c[0] | (int)(ms & 7)) : j < 4 ? arec.c[j] : j == 4 ? arec.c[4] : arec.c[j - 3];   // gen[5], gen[6] reuse ctx2, ctx3
+        a_base = a_ctx * 33;
+        for (int k = 0; k < 33; k++) arow[j][k] = T->gen[j][a_base + k];
+      }
+    }
+    for (int i = tid; i < nx; i += MX_THREADS) outs[i] = (float)p8s_squash(squash, reinterpret_cast<const int16_t*>(xs[buf])[i]) * cf;
+    // ---- first layer on the rows in registers ----
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uint32_t acc = 0;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int grp = lane + 64 * g;
+        const uint4 xv = grp < MX_GROUPS ? reinterpret_cast<const uint4*>(xs[buf])[grp] : make_uint4(0, 0, 0, 0);
+        acc += pair_dot(xv.x, w[q][g].x) + pair_dot(xv.y, w[q][g].y) + pair_dot(xv.z, w[q][g].z) + pair_dot(xv.w, w[q][g].w);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+      if (lane == 0) pr_s[4 * wave + q] = p8s_squash(squash, (int32_t)(acc * 9u) >> 9);
+    }
+    // ---- one step ahead: rows (all but the one that needs this step's final probability) and the input row ----
+    const bool more = t + 1 < nbits;
+    if (more) {
+      load_rows(t + 1, 0, wn, rown, false);
+      if (t + 1 >= first && tid < MX_GROUPS) xn = reinterpret_cast<const uint4*>(x + (size_t)(t + 1) * P8_NX)[tid];
+    }
+    __syncthreads();   // B2: pr_s, arow
+    if (wave == 0) {   // second layer
+      const int a = lane < P8_NSEL ? stretch[pr_s[lane]] : 0;
+      if (lane < P8_NSEL) outs[nx + lane] = (float)p8s_squash(squash, a) * cf;
+      const int b = __shfl_down(a, 1);
+      if ((lane & 1) == 0 && lane < 32) st_s[lane >> 1] = ((uint32_t)a & 0xffffu) | ((uint32_t)b << 16);
+      __builtin_amdgcn_s_waitcnt(0);
+      __builtin_amdgcn_wave_barrier();
+      uint32_t acc = 0;
+      if (lane < 16) acc = pair_dot(st_s[lane], reinterpret_cast<const uint32_t*>(M->wx2)[lane]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+      if (lane == 0) p_s = p8s_squash(squash, (int32_t)acc >> 9);
+    }
+    __syncthreads();   // B3: p_s
+    if (wave == 1) {   // the chains on the fetched rows: group A (lanes 0..3), then group B (lanes 4..6), then the read-out
+      const int p2 = p_s;
+      auto look_apm = [&](int j, int pr) {   // APM::p's interpolation :704-710 on arow[j]
+        const int s = (stretch[pr] + 2048) * 23;
+        const int wt = s & 0xfff, lo = s >> 12;
+        al_txt.idx = a_base + lo + (wt >> 11); al_txt.v0 = arow[j][lo + (wt >> 11)];
+        return (int)(((arow[j][lo] >> 13) * (uint32_t)(4096 - wt) + (arow[j][lo + 1] >> 13) * (uint32_t)wt) >> 19);
+      };
+      auto look_apm1 = [&](int j, int pr) {   // APM1::pp's interpolation :614-619
+        const int s = stretch[pr];
+        const int wgt = s & 127, lo = (s + 2048) >> 7;
+        MxApmLane& al = arec.text ? al_txt : al_gen;
+        al.idx = a_base + lo; al.v0 = arow[j][lo]; al.v1 = arow[j][lo + 1];
+        return (int)((arow[j][lo] * (uint32_t)(128 - wgt) + arow[j][lo + 1] * (uint32_t)wgt) >> 11);
+      };
+      if (lane < 4) res_s[lane] = arec.text ? look_apm(lane, p2) : look_apm1(lane, p2);
+      __builtin_amdgcn_s_waitcnt(0);
+      __builtin_amdgcn_wave_barrier();
+      if (lane >= 4 && lane < 7) {
+        const int avg = (p2 + res_s[1] + res_s[2] + res_s[3] + 2) >> 2;
+        res_s[lane] = look_apm1(lane, arec.text ? (lane == 4 ? avg : res_s[0]) : res_s[0]);
+      }
+      __builtin_amdgcn_s_waitcnt(0);
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) fin_s = p8s_tail_c(&arec, p2, res_s, outs + nx + P8_NSEL);
+    }
+    __syncthreads();   // B4: outs complete, fin_s
+    float* orow = out + (size_t)t * ld;
+    for (int i = tid; i < P8_NOUT; i += MX_THREADS) orow[i] = outs[i];
+    // ---- training with the step's own bit; the rows go back to HBM, the next step's rows become current ----
+    const int yb = bits[t];
+    if (more) load_rows(t + 1, fin_s, wn, rown, true);   // the one row that needed this step's final probability
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const int q = qq == 2 ? 3 : qq == 3 ? 2 : qq;   // set 26 (q == 2 of wave 6) last: its next row was requested a moment ago
+      const int err = (int)(int16_t)(((yb << 12) - pr_s[4 * wave + q]) * 7);
+      uint4* wr = reinterpret_cast<uint4*>(M->wx + (size_t)row[q] * P8_NX);
+      const bool again = more && rown[q] == row[q];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int grp = lane + 64 * g;
+        uint4 v = w[q][g];
+        if (grp < MX_GROUPS && err) {
+          const uint4 xv = reinterpret_cast<const uint4*>(xs[buf])[grp];
+          v.x = pair_train(xv.x, v.x, err); v.y = pair_train(xv.y, v.y, err);
+          v.z = pair_train(xv.z, v.z, err); v.w = pair_train(xv.w, v.w, err);
+          wr[grp] = v;
+        }
+        w[q][g] = again ? v : wn[q][g];
+      }
+      row[q] = more ? rown[q] : row[q];
+    }
+    if (wave == 0 && lane < 16) {
+      const int err2 = (int)(int16_t)(((yb << 12) - p_s) * 7);
+      uint32_t* w2 = reinterpret_cast<uint32_t*>(M->wx2);
+      if (err2) w2[lane] = pair_train(st_s[lane], w2[lane], err2);
+    }
+    if (more) {   // the next step's inputs into the other LDS buffer
+      if (t + 1 < first) stage_x(t + 1, buf ^ 1);
+      else if (tid < MX_GROUPS) reinterpret_cast<uint4*>(xs[buf ^ 1])[tid] = xn;
+    }
+  }
+  __syncthreads();
+  // the cells the chain tables chose last are updated at the top of the next step (update, then lookup): their indices go home
+  if (chain) {
+    const int j = lane;
+    if (j < 4) T->apm_cxt[j] = al_txt.idx; else T->apm1_idx[j - 4] = al_txt.idx;
+    T->gen_idx[j] = al_gen.idx;
+  }
+  for (int i = tid; i < P8_NOUT; i += MX_THREADS) T->out[i] = outs[i];
+  if (tid == 0) { T->pr = fin_s; T->misses = misses_s; }
+}
+
 // ---------------------------------------------------------------- host side
 namespace {
 struct DevPolicy {
@@ -376,9 +595,11 @@ struct cmx_p8stage {
   P8TailDev* d_tail = nullptr; P8MixDev* d_mix = nullptr;
   Staging st[P8S_BUFS];
   int next = 0;
-  int16_t* d_x = nullptr; uint8_t* d_order = nullptr; size_t x_cap = 0;   // one chunk's input rows / order values
-  hipStream_t s_b = nullptr, s_c = nullptr;
-  hipEvent_t ev_up = nullptr, ev_ord = nullptr, ev_b = nullptr, ev_c = nullptr, ev_mix = nullptr;
+  int16_t* d_x[2] = {}; uint8_t* d_order[2] = {}; size_t x_cap = 0;   // two chunks' input rows / order values: the mixer of chunk c runs under the tables of chunk c + 1
+  hipStream_t s_a = nullptr, s_b = nullptr, s_c = nullptr, s_m = nullptr;
+  hipEvent_t ev_up = nullptr, ev_ord = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_mix[2] = {};
+  bool mix_used[2] = {false, false};
+  uint64_t chunks = 0;
   uint64_t steps = 0;
   int last_bit = 0;
   bool failed = false;
@@ -397,11 +618,9 @@ void cmx_p8stage_destroy(cmx_p8stage_t* h) {
     if (s.d) (void)hipFree(s.d);
     if (s.done) (void)hipEventDestroy(s.done);
   }
-  if (h->d_x) (void)hipFree(h->d_x);
-  if (h->d_order) (void)hipFree(h->d_order);
-  if (h->s_b) (void)hipStreamDestroy(h->s_b);
-  if (h->s_c) (void)hipStreamDestroy(h->s_c);
-  for (hipEvent_t e : {h->ev_up, h->ev_ord, h->ev_b, h->ev_c, h->ev_mix}) if (e) (void)hipEventDestroy(e);
+  for (int i = 0; i < 2; i++) { if (h->d_x[i]) (void)hipFree(h->d_x[i]); if (h->d_order[i]) (void)hipFree(h->d_order[i]); }
+  for (hipStream_t q : {h->s_a, h->s_b, h->s_c, h->s_m}) if (q) (void)hipStreamDestroy(q);
+  for (hipEvent_t e : {h->ev_up, h->ev_ord, h->ev_a, h->ev_b, h->ev_c, h->ev_mix[0], h->ev_mix[1]}) if (e) (void)hipEventDestroy(e);
   if (h->front) p8f_front_free(h->front);
   delete h;
 }
@@ -432,8 +651,8 @@ cmx_p8stage_t* cmx_p8stage_create(int device) {
   }
   delete S;
   ok = ok && hipFuncSetAttribute((const void*)cmx_p8s_fam2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->fam_lds) == hipSuccess;
-  ok = ok && hipStreamCreateWithFlags(&h->s_b, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&h->s_c, hipStreamNonBlocking) == hipSuccess;
-  for (hipEvent_t* e : {&h->ev_up, &h->ev_ord, &h->ev_b, &h->ev_c, &h->ev_mix}) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+  for (hipStream_t* q : {&h->s_a, &h->s_b, &h->s_c, &h->s_m}) ok = ok && hipStreamCreateWithFlags(q, hipStreamNonBlocking) == hipSuccess;
+  for (hipEvent_t* e : {&h->ev_up, &h->ev_ord, &h->ev_a, &h->ev_b, &h->ev_c, &h->ev_mix[0], &h->ev_mix[1]}) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
   for (auto& s : h->st) ok = ok && hipEventCreateWithFlags(&s.done, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipDeviceSynchronize() == hipSuccess;
   if (!ok) { cmx_set_err("cmx_p8stage_create: allocation / init failed (the stage needs ~9 GB of HBM)"); cmx_p8stage_destroy(h); return nullptr; }
@@ -476,53 +695,59 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
   for (size_t i = 0; i < T; i++) hb[i] = (bytes[i >> 3] >> (7 - (i & 7))) & 1;
   hipStream_t s = (hipStream_t)stream;
   bool ok = true;
-  if (h->x_cap < n) {   // grown between chunks only when nothing is in flight on it
+  if (h->x_cap < n) {   // grown between chunks only when nothing is in flight on them
     ok = hipDeviceSynchronize() == hipSuccess;
-    if (h->d_x) (void)hipFree(h->d_x);
-    if (h->d_order) (void)hipFree(h->d_order);
-    h->d_x = nullptr; h->d_order = nullptr; h->x_cap = 0;
-    ok = ok && hipMalloc((void**)&h->d_x, T * P8_NX * 2) == hipSuccess && hipMalloc((void**)&h->d_order, T) == hipSuccess;
-    if (ok) h->x_cap = n;
+    for (int i = 0; i < 2; i++) {
+      if (h->d_x[i]) (void)hipFree(h->d_x[i]);
+      if (h->d_order[i]) (void)hipFree(h->d_order[i]);
+      h->d_x[i] = nullptr; h->d_order[i] = nullptr;
+      ok = ok && hipMalloc((void**)&h->d_x[i], T * P8_NX * 2) == hipSuccess && hipMalloc((void**)&h->d_order[i], T) == hipSuccess;
+    }
+    h->x_cap = ok ? n : 0;
   }
-  ok = ok && hipMemcpyAsync(b.d, b.h, b.total, hipMemcpyHostToDevice, s) == hipSuccess;
-  ok = ok && hipEventRecord(h->ev_up, s) == hipSuccess;
+  // The stage's own streams: a = order-N map -> family, b = TextModel's and exeModel's maps, c = small lanes -> DMC,
+  // m = mixer + chains. Input rows are double-buffered by chunk parity, so the mixer of chunk c runs under the tables of
+  // chunk c + 1; the caller's stream only waits for this chunk's mixer at the end (the input is host memory: nothing of
+  // the caller's earlier work is needed, d_out must simply not be in use).
+  const int par = (int)(h->chunks & 1);
+  int16_t* dx = h->d_x[par]; uint8_t* dord = h->d_order[par];
+  if (h->mix_used[par]) for (hipStream_t q : {h->s_a, h->s_b, h->s_c}) ok = ok && hipStreamWaitEvent(q, h->ev_mix[par], 0) == hipSuccess;   // the mixer that last read these rows
+  ok = ok && hipMemcpyAsync(b.d, b.h, b.total, hipMemcpyHostToDevice, h->s_a) == hipSuccess;
+  ok = ok && hipEventRecord(h->ev_up, h->s_a) == hipSuccess;
   const int nbits = (int)T;
   const int skip = h->steps >= 8 ? 0 : (int)(8 - h->steps), t0 = h->steps == 0 ? 1 : 0;
   const uint8_t* d_bits = (const uint8_t*)(b.d + b.o_bits);
   auto cm2 = [&](int k, hipStream_t q, uint8_t* ord) {
-    hipLaunchKernelGGL(h->fam_v1 ? cmx_p8s_cm2_kernel : cmx_p8s_cm2v2_kernel, dim3(1), dim3(P8CM2_MAXC), 0, q, h->d_cm2[k], (const uint32_t*)(b.d + b.o_cctx[k]), (const uint16_t*)(b.d + b.o_cchk[k]), d_bits,
-                       h->d_x, ord, nbits, skip);
+    hipLaunchKernelGGL(h->fam_v1 ? cmx_p8s_cm2_kernel : cmx_p8s_cm2v2_kernel, dim3(1), dim3(P8CM2_MAXC), 0, q, h->d_cm2[k], (const uint32_t*)(b.d + b.o_cctx[k]),
+                       (const uint16_t*)(b.d + b.o_cchk[k]), d_bits, dx, ord, nbits, skip);
   };
   if (ok) {
-    // stream a (the caller's): order-N map, then the family
-    cm2(0, s, h->d_order);
-    ok = hipEventRecord(h->ev_ord, s) == hipSuccess;
+    cm2(0, h->s_a, dord);
+    ok = hipEventRecord(h->ev_ord, h->s_a) == hipSuccess;
     if (h->fam_v1)
-      hipLaunchKernelGGL(cmx_p8s_fam_kernel, dim3(1), dim3(P8CM_MAXS), 0, s, h->d_fam, (const uint32_t*)(b.d + b.o_fctx), (const uint16_t*)(b.d + b.o_fchk), d_bits, h->d_x,
-                         (const uint8_t*)h->d_order, nbits, skip);
+      hipLaunchKernelGGL(cmx_p8s_fam_kernel, dim3(1), dim3(P8CM_MAXS), 0, h->s_a, h->d_fam, (const uint32_t*)(b.d + b.o_fctx), (const uint16_t*)(b.d + b.o_fchk), d_bits, dx,
+                         (const uint8_t*)dord, nbits, skip);
     else
-      hipLaunchKernelGGL(cmx_p8s_fam2_kernel, dim3(1), dim3(P8CM_MAXS), h->fam_lds, s, h->d_fam, h->d_fam_home, (const uint32_t*)(b.d + b.o_fctx),
-                         (const uint16_t*)(b.d + b.o_fchk), d_bits, h->d_x, (const uint8_t*)h->d_order, nbits, skip);
-    // stream b: TextModel's and exeModel's maps
+      hipLaunchKernelGGL(cmx_p8s_fam2_kernel, dim3(1), dim3(P8CM_MAXS), h->fam_lds, h->s_a, h->d_fam, h->d_fam_home, (const uint32_t*)(b.d + b.o_fctx),
+                         (const uint16_t*)(b.d + b.o_fchk), d_bits, dx, (const uint8_t*)dord, nbits, skip);
+    ok = ok && hipEventRecord(h->ev_a, h->s_a) == hipSuccess;
     ok = ok && hipStreamWaitEvent(h->s_b, h->ev_up, 0) == hipSuccess;
     cm2(1, h->s_b, nullptr);
     cm2(2, h->s_b, nullptr);
     ok = ok && hipEventRecord(h->ev_b, h->s_b) == hipSuccess;
-    // stream c: small lanes (one needs the order), DMC
     ok = ok && hipStreamWaitEvent(h->s_c, h->ev_ord, 0) == hipSuccess;
-    hipLaunchKernelGGL(cmx_p8s_lanes_kernel, dim3(1), dim3(P8_NLANE), 0, h->s_c, h->d_lanes, (const uint32_t*)(b.d + b.o_ops), d_bits, (const uint8_t*)h->d_order, h->d_x,
-                       nbits, t0);
-    hipLaunchKernelGGL(cmx_p8s_dmc_kernel, dim3(1), dim3(P8DMC_THREADS), 0, h->s_c, h->d_dmc, d_bits, h->d_x, (int)L.dmc_off, nbits, t0);
+    hipLaunchKernelGGL(cmx_p8s_lanes_kernel, dim3(1), dim3(P8_NLANE), 0, h->s_c, h->d_lanes, (const uint32_t*)(b.d + b.o_ops), d_bits, (const uint8_t*)dord, dx, nbits, t0);
+    hipLaunchKernelGGL(cmx_p8s_dmc_kernel, dim3(1), dim3(P8DMC_THREADS), 0, h->s_c, h->d_dmc, d_bits, dx, (int)L.dmc_off, nbits, t0);
     ok = ok && hipEventRecord(h->ev_c, h->s_c) == hipSuccess;
-    // back on the caller's stream: the mixer consumes the rows
-    ok = ok && hipStreamWaitEvent(s, h->ev_b, 0) == hipSuccess && hipStreamWaitEvent(s, h->ev_c, 0) == hipSuccess;
-    hipLaunchKernelGGL(cmx_p8s_mix_kernel, dim3(1), dim3(MX_THREADS), 0, s, (const P8MixDev*)h->d_mix, h->d_tail, (const int16_t*)h->d_x, (const int32_t*)(b.d + b.o_sel),
-                       (const P8ApmRec*)(b.d + b.o_apm), (const uint8_t*)h->d_order, d_bits, d_out, ld, nbits, t0, skip, h->last_bit);
+    for (hipEvent_t e : {h->ev_a, h->ev_b, h->ev_c}) ok = ok && hipStreamWaitEvent(h->s_m, e, 0) == hipSuccess;
+    hipLaunchKernelGGL(h->fam_v1 ? cmx_p8s_mix_kernel : cmx_p8s_mix2_kernel, dim3(1), dim3(MX_THREADS), 0, h->s_m, (const P8MixDev*)h->d_mix, h->d_tail, (const int16_t*)dx,
+                       (const int32_t*)(b.d + b.o_sel), (const P8ApmRec*)(b.d + b.o_apm), (const uint8_t*)dord, d_bits, d_out, ld, nbits, t0, skip, h->last_bit);
     ok = ok && hipGetLastError() == hipSuccess;
-    ok = ok && hipEventRecord(b.done, s) == hipSuccess;
-    // the next chunk's role kernels reuse d_x / d_order: streams b and c wait for this mixer through ev_up's successor
-    ok = ok && hipEventRecord(h->ev_mix, s) == hipSuccess;
-    ok = ok && hipStreamWaitEvent(h->s_b, h->ev_mix, 0) == hipSuccess && hipStreamWaitEvent(h->s_c, h->ev_mix, 0) == hipSuccess;
+    ok = ok && hipEventRecord(h->ev_mix[par], h->s_m) == hipSuccess;
+    ok = ok && hipEventRecord(b.done, h->s_m) == hipSuccess;
+    ok = ok && hipStreamWaitEvent(s, h->ev_mix[par], 0) == hipSuccess;   // what the caller enqueues next sees this chunk's rows of d_out
+    h->mix_used[par] = true;
+    h->chunks++;
   }
   if (!ok) { cmx_set_err(std::string("cmx_p8stage_run: launch failed: ") + hipGetErrorString(hipGetLastError())); h->failed = true; return 1; }
   b.used = true;
