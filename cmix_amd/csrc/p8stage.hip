@@ -213,19 +213,24 @@ constexpr int MX_THREADS = 448, MX_GROUPS = P8_NX / 8;   // 7 waves x 4 sets; 19
 __device__ __forceinline__ int sat16(int v) { return v > 32767 ? 32767 : v < -32768 ? -32768 : v; }
 __device__ __forceinline__ int lo16(uint32_t v) { return (int)(int16_t)(v & 0xffffu); }
 __device__ __forceinline__ int hi16(uint32_t v) { return (int)(int16_t)(v >> 16); }
-__device__ __forceinline__ uint32_t pair_dot(uint32_t t, uint32_t w) {   // one dword = one pair: ((t0*w0 + t1*w1) >> 8), wrapping (:403-413)
-  const uint32_t s = (uint32_t)(lo16(t) * lo16(w)) + (uint32_t)(hi16(t) * hi16(w));
-  return (uint32_t)((int32_t)s >> 8);
+typedef short mx_s2 __attribute__((ext_vector_type(2)));
+// one dword = one pair of int16: ((t0*w0 + t1*w1) >> 8), the sum wrapping as pmaddwd's does (:403-413): v_dot2_i32_i16 + a shift
+__device__ __forceinline__ uint32_t pair_dot(uint32_t t, uint32_t w) {
+  const int s = __builtin_amdgcn_sdot2(__builtin_bit_cast(mx_s2, t), __builtin_bit_cast(mx_s2, w), 0, false);
+  return (uint32_t)(s >> 8);
 }
-__device__ __forceinline__ int train1(int t, int w, int err) {   // :415-430
-  int v = sat16(2 * t);
-  v = (v * err) >> 16;
-  v = sat16(v + 1) >> 1;
-  return sat16(v + w);
-}
+// train (:415-430) on a pair, in packed 16-bit math: w += ((sat(2 t) * err >> 16) + 1 sat >> 1), saturating -- paddsw /
+// pmulhw / psraw map onto v_pk_add_i16 clamp, two 24-bit multiplies + v_perm, v_pk_ashrrev_i16 (7 instructions per pair)
 __device__ __forceinline__ uint32_t pair_train(uint32_t t, uint32_t w, int err) {
-  const int a = train1(lo16(t), lo16(w), err), b = train1(hi16(t), hi16(w), err);
-  return ((uint32_t)a & 0xffffu) | ((uint32_t)b << 16);
+  const mx_s2 tv = __builtin_bit_cast(mx_s2, t), wv = __builtin_bit_cast(mx_s2, w);
+  const mx_s2 v = __builtin_elementwise_add_sat(tv, tv);
+  mx_s2 r;
+  r.x = (short)(__mul24((int)v.x, err) >> 16);
+  r.y = (short)(__mul24((int)v.y, err) >> 16);
+  const mx_s2 one = {1, 1};
+  r = __builtin_elementwise_add_sat(r, one) >> 1;
+  r = __builtin_elementwise_add_sat(r, wv);
+  return __builtin_bit_cast(uint32_t, r);
 }
 }  // namespace
 
@@ -338,6 +343,11 @@ __global__ __launch_bounds__(MX_THREADS) void cmx_p8s_mix_kernel(const P8MixDev*
   if (tid == 0) T->pr = fin_s;
 }
 
+// A workgroup barrier that orders LDS traffic only. __syncthreads() also waits for every outstanding global load and
+// store of the wave (s_waitcnt vmcnt(0)), which would serialise the one-bit-ahead requests below with the barriers of
+// the bit; the kernel's cross-lane traffic through global memory is handled where it occurs.
+__device__ __forceinline__ void mx_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Second design of the mixer kernel: everything a bit needs from HBM / L2 is requested one bit ahead.
 //   * weight rows: the 28 selectors of bit t+1 are known while bit t is being mixed (host part + the order-N map's
 //     value; only set 26 needs this bit's final probability): the rows of t+1 are loaded into a second register set
@@ -368,27 +378,60 @@ __device__ __forceinline__ uint32_t apm1_upd(uint32_t v, int y, int rate) {   //
 __global__ __launch_bounds__(MX_THREADS) void cmx_p8s_mix2_kernel(const P8MixDev* M, P8TailDev* T, const int16_t* __restrict__ x, const int32_t* __restrict__ sel,
                                                                  const P8ApmRec* __restrict__ apm, const uint8_t* __restrict__ order,
                                                                  const uint8_t* __restrict__ bits, float* __restrict__ out, size_t ld, int nbits, int t0, int first,
-                                                                 int last_y) {
+                                                                 int last_y, unsigned long long* prof) {
   __shared__ __attribute__((aligned(16))) uint32_t xs[2][P8_NX / 2];   // the step's inputs as pairs, double-buffered
   __shared__ float outs[P8_NOUT];
   __shared__ int pr_s[32], res_s[8];
   __shared__ uint32_t st_s[16];
   __shared__ uint32_t arow[7][36];    // the context rows of the seven chain tables (24 u32 or 33 u16 cells, widened)
   __shared__ int p_s, fin_s;
-  __shared__ unsigned long long misses_s;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int16_t* squash = M->squash; const int16_t* stretch = M->stretch;
+  __shared__ int16_t squash[4096], stretch[4096];   // the two tables every stage of the bit reads through: LDS, not L2
+  for (int i = threadIdx.x; i < 4096; i += MX_THREADS) { squash[i] = M->squash[i]; stretch[i] = M->stretch[i]; }
   const float cf = (float)(1.0 / 4095);
   for (int i = tid; i < P8_NOUT; i += MX_THREADS) outs[i] = T->out[i];
-  if (tid == 0) { fin_s = T->pr; misses_s = T->misses; }
+  if (tid == 0) fin_s = T->pr;
+  unsigned long long misses = T->misses;   // every thread keeps the miss history itself (uniform)
+  // Nothing inside the step loop may chase a pointer through M / T / sel / apm in global memory: every such load is a
+  // full L2 round trip on the bit's critical path (and the compiler must redo it after each global store). Base pointers
+  // go to registers here; the per-step records (28 selectors, the order, the APM contexts, the coded bit) travel through
+  // an LDS ring, loaded two steps ahead by a few lanes of wave 5 and written at the end of the step.
+  int16_t* const wx = M->wx; int16_t* const wx2 = M->wx2;
+  const int nx_first = M->nx_first;
+  __shared__ int32_t ring_sel[4][P8_NSEL];
+  __shared__ uint32_t ring_apm[4][6];     // P8ApmRec = 24 bytes
+  __shared__ int ring_ord[4], ring_bit[4];
   // the chain lanes: wave 1, lanes 0..6 (wave 0 does the second layer)
   const bool chain = wave == 1 && lane < 7;
+  // the table this lane fetches one cell of (waves 1..4) / updates (chain lanes), for either block type
+  const int fl = tid - 64, fj = fl >= 0 && fl < 7 * 36 ? fl / 36 : (chain ? lane : 0), fk = fl >= 0 ? fl % 36 : 0;
+  uint32_t* const tb_apm = fj < 4 ? T->apm[fj] : nullptr;
+  uint16_t* const tb_apm1 = fj >= 4 ? T->apm1[fj - 4] : nullptr;
+  uint16_t* const tb_gen = T->gen[fj];
+  uint32_t* const my_apm = chain && lane < 4 ? T->apm[lane] : nullptr;
+  uint16_t* const my_apm1 = chain && lane >= 4 ? T->apm1[lane - 4] : nullptr;
+  uint16_t* const my_gen = chain ? T->gen[lane] : nullptr;
+  auto ring_load = [&](int ts, uint32_t& v) {   // wave 5: lanes 0..27 selectors, 28 order, 29 bit, 32..37 APM record
+    if (wave != 5 || ts >= nbits) return;
+    if (lane < P8_NSEL) v = (uint32_t)sel[(size_t)ts * P8_NSEL + lane];
+    else if (lane == 28) v = order[ts];
+    else if (lane == 29) v = bits[ts];
+    else if (lane >= 32 && lane < 38) v = reinterpret_cast<const uint32_t*>(apm + ts)[lane - 32];
+  };
+  auto ring_store = [&](int ts, uint32_t v) {
+    if (wave != 5 || ts >= nbits) return;
+    const int slot = ts & 3;
+    if (lane < P8_NSEL) ring_sel[slot][lane] = (int32_t)v;
+    else if (lane == 28) ring_ord[slot] = (int)v;
+    else if (lane == 29) ring_bit[slot] = (int)v;
+    else if (lane >= 32 && lane < 38) ring_apm[slot][lane - 32] = v;
+  };
   MxApmLane al_txt = {0, 0, 0}, al_gen = {0, 0, 0};   // the TEXT tables' and the other blocks' tables' pending cells
   if (chain) {   // home form (P8TailDev): the index of the cell(s) the next call updates; their values are read once per chunk
     const int j = lane;
-    if (j < 4) { al_txt.idx = T->apm_cxt[j]; al_txt.v0 = T->apm[j][al_txt.idx]; }
-    else { al_txt.idx = T->apm1_idx[j - 4]; al_txt.v0 = T->apm1[j - 4][al_txt.idx]; al_txt.v1 = T->apm1[j - 4][al_txt.idx + 1]; }
-    al_gen.idx = T->gen_idx[j]; al_gen.v0 = T->gen[j][al_gen.idx]; al_gen.v1 = T->gen[j][al_gen.idx + 1];
+    if (j < 4) { al_txt.idx = T->apm_cxt[j]; al_txt.v0 = my_apm[al_txt.idx]; }
+    else { al_txt.idx = T->apm1_idx[j - 4]; al_txt.v0 = my_apm1[al_txt.idx]; al_txt.v1 = my_apm1[al_txt.idx + 1]; }
+    al_gen.idx = T->gen_idx[j]; al_gen.v0 = my_gen[al_gen.idx]; al_gen.v1 = my_gen[al_gen.idx + 1];
   }
   __syncthreads();
   if (t0) for (int i = tid; i < P8_NOUT; i += MX_THREADS) out[i] = outs[i];   // no step 0: the constructor's values
@@ -396,57 +439,98 @@ __global__ __launch_bounds__(MX_THREADS) void cmx_p8s_mix2_kernel(const P8MixDev
   uint4 w[4][4], wn[4][4];
   int row[4], rown[4];
   uint4 xn = make_uint4(0, 0, 0, 0);
-  auto load_rows = [&](int t, int lastpr, uint4 (&dst)[4][4], int (&r)[4], bool only_lastpr) {
-    const int ord = order[t];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int si = 4 * wave + q;
-      if (only_lastpr != (si == P8_SEL_LASTPR)) continue;
-      r[q] = p8s_sel(si, sel[(size_t)t * P8_NSEL + si], ord, lastpr);
-      const uint4* wr = reinterpret_cast<const uint4*>(M->wx + (size_t)r[q] * P8_NX);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) { const int grp = lane + 64 * g; dst[q][g] = grp < MX_GROUPS ? wr[grp] : make_uint4(0, 0, 0, 0); }
-    }
-  };
+#define MX_LOAD_G(dst, q, g, wr_) { const int grp_ = lane + 64 * (g); dst[q][g] = grp_ < MX_GROUPS ? (wr_)[grp_] : make_uint4(0, 0, 0, 0); }
+#define MX_LOAD_ROW(dst, q, rowid)                                                               \
+  {                                                                                               \
+    const uint4* wr_ = reinterpret_cast<const uint4*>(wx + (size_t)(rowid) * P8_NX);            \
+    MX_LOAD_G(dst, q, 0, wr_) MX_LOAD_G(dst, q, 1, wr_) MX_LOAD_G(dst, q, 2, wr_) MX_LOAD_G(dst, q, 3, wr_) \
+  }
+#define MX_LOAD_SET(dst, r, ts, q, ord_)                                                         \
+  {                                                                                               \
+    const int si_ = 4 * wave + (q);                                                               \
+    if (si_ != P8_SEL_LASTPR) { r[q] = p8s_sel(si_, ring_sel[(ts) & 3][si_], ord_, 0); MX_LOAD_ROW(dst, q, r[q]) } \
+  }
+  // every set of step ts except set 26 (whose row needs the previous step's final probability)
+#define MX_LOAD_EARLY(dst, r, ts) { const int ord_ = ring_ord[(ts) & 3]; MX_LOAD_SET(dst, r, ts, 0, ord_) MX_LOAD_SET(dst, r, ts, 1, ord_) MX_LOAD_SET(dst, r, ts, 2, ord_) MX_LOAD_SET(dst, r, ts, 3, ord_) }
+#define MX_LOAD_LATE(dst, r, ts, lastpr)                                                         \
+  if (wave == 6) { r[2] = p8s_sel(P8_SEL_LASTPR, ring_sel[(ts) & 3][P8_SEL_LASTPR], 0, lastpr); MX_LOAD_ROW(dst, 2, r[2]) }
   auto stage_x = [&](int t, int buf) {   // the input row of step t -> LDS (compacted during the first byte)
     const int16_t* xr = x + (size_t)t * P8_NX;
     if (t < first) {
       int16_t* xh = reinterpret_cast<int16_t*>(xs[buf]);
-      for (int i = tid; i < P8_NX; i += MX_THREADS) xh[i] = i < M->nx_first ? xr[M->first_map[i]] : (int16_t)0;
+      for (int i = tid; i < P8_NX; i += MX_THREADS) xh[i] = i < nx_first ? xr[M->first_map[i]] : (int16_t)0;
     } else if (tid < MX_GROUPS) reinterpret_cast<uint4*>(xs[buf])[tid] = reinterpret_cast<const uint4*>(xr)[tid];
   };
-  if (t0 < nbits) {
-    load_rows(t0, T->pr, w, row, false);
-    load_rows(t0, T->pr, w, row, true);
-    stage_x(t0, t0 & 1);
-  }
-  for (int t = t0; t < nbits; ++t) {
-    const int y = t ? bits[t - 1] : last_y;
-    const int nx = t < first ? M->nx_first : P8_NX;
-    const int buf = t & 1;
-    if (tid < 32) pr_s[tid] = 0;
-    if (tid == 0) misses_s += misses_s + (unsigned long long)((fin_s >> 11) != y);
-    __syncthreads();   // B1: xs[buf], misses, fin_s of the previous step
-    const P8ApmRec arec = apm[t];
-    // ---- chain lanes: update the cell(s) chosen one step ago, fetch this step's context row ----
-    int a_ctx = 0, a_base = 0;
+  int a_base = 0, upd_idx = -1; uint32_t upd_v0 = 0, upd_v1 = 0;
+  // For the step `ts` about to come (y = the bit coded before it, ms = its miss history):
+  //  * the chain lanes let the tables of that step's block type learn at the cell(s) their last lookup chose (p() =
+  //    update, then lookup) -- a store of a value they kept, not a load-modify-store;
+  //  * waves 1..4 fetch the step's context rows, ONE cell per lane (7 tables x up to 33 cells), into LDS;
+  //  * after the next barrier the chain lanes write their just-updated cells over the fetched copy (chain_patch): the
+  //    fetch may or may not have seen the store.
+  auto row_ctx = [&](const P8ApmRec* a, int j, unsigned long long ms) {
+    if (a->text) return j == 0 ? (a->c[0] | (int)((ms & 0xF) << 4)) : j == 1 ? (int)a->c[1 + (int)(ms & 3)] : (int)a->c[3 + j];   // c[5], c[6]; c[7..9]
+    return j == 0 ? (a->c[0] | (int)(ms & 7)) : j < 4 ? (int)a->c[j] : j == 4 ? (int)a->c[4] : (int)a->c[j - 3];                  // gen[5], gen[6] reuse ctx2, ctx3
+  };
+  auto chain_fetch = [&](int ts, int y, unsigned long long ms) {
+    const P8ApmRec* ap = reinterpret_cast<const P8ApmRec*>(ring_apm[ts & 3]);
+    const int a_text = ap->text, a_limit = ap->limit;
+    if (fl >= 0 && fl < 7 * 36) {
+      const int ncell = (a_text && fj < 4) ? 24 : 33;
+      if (fk < ncell) {
+        const int base = row_ctx(ap, fj, ms) * ncell;
+        arow[fj][fk] = a_text ? (fj < 4 ? tb_apm[base + fk] : (uint32_t)tb_apm1[base + fk]) : (uint32_t)tb_gen[base + fk];
+      }
+    }
     if (chain) {
       const int j = lane;
-      const unsigned long long ms = misses_s;
-      // the tables of THIS step's block type learn from y at the cell(s) their last lookup chose (p() = update, then lookup)
-      if (arec.text) {
-        if (j < 4) T->apm[j][al_txt.idx] = apm_upd(al_txt.v0, y, (int)arec.limit);
-        else { T->apm1[j - 4][al_txt.idx] = (uint16_t)apm1_upd(al_txt.v0, y, j == 4 ? 7 : 6); T->apm1[j - 4][al_txt.idx + 1] = (uint16_t)apm1_upd(al_txt.v1, y, j == 4 ? 7 : 6); }
-      } else { T->gen[j][al_gen.idx] = (uint16_t)apm1_upd(al_gen.v0, y, 7); T->gen[j][al_gen.idx + 1] = (uint16_t)apm1_upd(al_gen.v1, y, 7); }
-      if (arec.text) {
-        a_ctx = j == 0 ? (arec.c[0] | (int)((ms & 0xF) << 4)) : j == 1 ? arec.c[1 + (int)(ms & 3)] : j < 4 ? arec.c[3 + j] : arec.c[3 + j];   // c[5], c[6]; c[7..9]
-        if (j < 4) { a_base = a_ctx * 24; for (int k = 0; k < 24; k++) arow[j][k] = T->apm[j][a_base + k]; }
-        else { a_base = a_ctx * 33; for (int k = 0; k < 33; k++) arow[j][k] = T->apm1[j - 4][a_base + k]; }
+      if (a_text) {
+        upd_idx = al_txt.idx;
+        if (j < 4) { upd_v0 = apm_upd(al_txt.v0, y, a_limit); my_apm[upd_idx] = upd_v0; }
+        else { upd_v0 = apm1_upd(al_txt.v0, y, j == 4 ? 7 : 6); upd_v1 = apm1_upd(al_txt.v1, y, j == 4 ? 7 : 6); my_apm1[upd_idx] = (uint16_t)upd_v0; my_apm1[upd_idx + 1] = (uint16_t)upd_v1; }
+        a_base = row_ctx(ap, j, ms) * (j < 4 ? 24 : 33);
       } else {
-        a_ctx = j == 0 ? (arec.c[0] | (int)(ms & 7)) : j < 4 ? arec.c[j] : j == 4 ? arec.c[4] : arec.c[j - 3];   // gen[5], gen[6] reuse ctx2, ctx3
-        a_base = a_ctx * 33;
-        for (int k = 0; k < 33; k++) arow[j][k] = T->gen[j][a_base + k];
+        upd_idx = al_gen.idx;
+        upd_v0 = apm1_upd(al_gen.v0, y, 7); upd_v1 = apm1_upd(al_gen.v1, y, 7);
+        my_gen[upd_idx] = (uint16_t)upd_v0; my_gen[upd_idx + 1] = (uint16_t)upd_v1;
+        a_base = row_ctx(ap, j, ms) * 33;
       }
+    }
+  };
+  auto chain_patch = [&](int a_text) {   // chain lanes, after the barrier that follows chain_fetch
+    const int j = lane;
+    const bool one = a_text && j < 4;            // APM: one cell; APM1: two
+    const int ncell = one ? 24 : 33, off = upd_idx - a_base;
+    if (off >= 0 && off < ncell) arow[j][off] = upd_v0;
+    if (!one && off + 1 >= 0 && off + 1 < ncell) arow[j][off + 1] = upd_v1;
+  };
+  bool pend26 = false, again26 = false;
+  { uint32_t v0_ = 0, v1_ = 0; ring_load(t0, v0_); ring_load(t0 + 1, v1_); ring_store(t0, v0_); ring_store(t0 + 1, v1_); }
+  __syncthreads();
+  if (t0 < nbits) {
+    const int y0 = t0 ? (int)bits[t0 - 1] : last_y;
+    misses += misses + (unsigned long long)((T->pr >> 11) != y0);   // Predictor::update's first line (:8250), for the first step
+    chain_fetch(t0, y0, misses);
+    MX_LOAD_EARLY(w, row, t0)
+    MX_LOAD_LATE(w, row, t0, T->pr)
+    stage_x(t0, t0 & 1);
+  }
+  unsigned long long pacc[6] = {0, 0, 0, 0, 0, 0}, pc0 = __builtin_readcyclecounter();
+#define MX_TICK(i) do { if (prof && (tid & 63) == 0) { const unsigned long long c_ = __builtin_readcyclecounter(); pacc[i] += c_ - pc0; pc0 = c_; } } while (0)
+  for (int t = t0; t < nbits; ++t) {
+    const int y = t > t0 ? ring_bit[(t - 1) & 3] : (t ? (int)bits[t - 1] : last_y);
+    const int nx = t < first ? nx_first : P8_NX;
+    uint32_t ring_v = 0;
+    ring_load(t + 2, ring_v);   // two steps ahead; lands in LDS at the end of this step
+    const int buf = t & 1;
+    MX_TICK(0);
+    mx_lds_barrier();   // B1: xs[buf], arow, fin_s of the previous step
+    const P8ApmRec* arp = reinterpret_cast<const P8ApmRec*>(ring_apm[t & 3]);
+    const int a_text = arp->text;
+    if (chain) chain_patch(a_text);
+    if (wave == 6 && pend26 && !again26) {   // set 26's row was requested after the previous step's chain: take it now (same row again: the trained registers stay)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) w[2][g] = wn[2][g];
     }
     for (int i = tid; i < nx; i += MX_THREADS) outs[i] = (float)p8s_squash(squash, reinterpret_cast<const int16_t*>(xs[buf])[i]) * cf;
     // ---- first layer on the rows in registers ----
@@ -466,10 +550,12 @@ __global__ __launch_bounds__(MX_THREADS) void cmx_p8s_mix2_kernel(const P8MixDev
     // ---- one step ahead: rows (all but the one that needs this step's final probability) and the input row ----
     const bool more = t + 1 < nbits;
     if (more) {
-      load_rows(t + 1, 0, wn, rown, false);
+      MX_LOAD_EARLY(wn, rown, t + 1)
       if (t + 1 >= first && tid < MX_GROUPS) xn = reinterpret_cast<const uint4*>(x + (size_t)(t + 1) * P8_NX)[tid];
     }
-    __syncthreads();   // B2: pr_s, arow
+    MX_TICK(1);
+    mx_lds_barrier();   // B2: pr_s, arow
+    if (chain) __builtin_amdgcn_s_waitcnt(0);   // this lane's table updates have reached L2 before other lanes fetch rows again (after B4)
     if (wave == 0) {   // second layer
       const int a = lane < P8_NSEL ? stretch[pr_s[lane]] : 0;
       if (lane < P8_NSEL) outs[nx + lane] = (float)p8s_squash(squash, a) * cf;
@@ -478,12 +564,13 @@ __global__ __launch_bounds__(MX_THREADS) void cmx_p8s_mix2_kernel(const P8MixDev
       __builtin_amdgcn_s_waitcnt(0);
       __builtin_amdgcn_wave_barrier();
       uint32_t acc = 0;
-      if (lane < 16) acc = pair_dot(st_s[lane], reinterpret_cast<const uint32_t*>(M->wx2)[lane]);
+      if (lane < 16) acc = pair_dot(st_s[lane], reinterpret_cast<const uint32_t*>(wx2)[lane]);
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
       if (lane == 0) p_s = p8s_squash(squash, (int32_t)acc >> 9);
     }
-    __syncthreads();   // B3: p_s
+    MX_TICK(2);
+    mx_lds_barrier();   // B3: p_s
     if (wave == 1) {   // the chains on the fetched rows: group A (lanes 0..3), then group B (lanes 4..6), then the read-out
       const int p2 = p_s;
       auto look_apm = [&](int j, int pr) {   // APM::p's interpolation :704-710 on arow[j]
@@ -495,32 +582,35 @@ __global__ __launch_bounds__(MX_THREADS) void cmx_p8s_mix2_kernel(const P8MixDev
       auto look_apm1 = [&](int j, int pr) {   // APM1::pp's interpolation :614-619
         const int s = stretch[pr];
         const int wgt = s & 127, lo = (s + 2048) >> 7;
-        MxApmLane& al = arec.text ? al_txt : al_gen;
+        MxApmLane& al = a_text ? al_txt : al_gen;
         al.idx = a_base + lo; al.v0 = arow[j][lo]; al.v1 = arow[j][lo + 1];
         return (int)((arow[j][lo] * (uint32_t)(128 - wgt) + arow[j][lo + 1] * (uint32_t)wgt) >> 11);
       };
-      if (lane < 4) res_s[lane] = arec.text ? look_apm(lane, p2) : look_apm1(lane, p2);
+      if (lane < 4) res_s[lane] = a_text ? look_apm(lane, p2) : look_apm1(lane, p2);
       __builtin_amdgcn_s_waitcnt(0);
       __builtin_amdgcn_wave_barrier();
       if (lane >= 4 && lane < 7) {
         const int avg = (p2 + res_s[1] + res_s[2] + res_s[3] + 2) >> 2;
-        res_s[lane] = look_apm1(lane, arec.text ? (lane == 4 ? avg : res_s[0]) : res_s[0]);
+        res_s[lane] = look_apm1(lane, a_text ? (lane == 4 ? avg : res_s[0]) : res_s[0]);
       }
       __builtin_amdgcn_s_waitcnt(0);
       __builtin_amdgcn_wave_barrier();
-      if (lane == 0) fin_s = p8s_tail_c(&arec, p2, res_s, outs + nx + P8_NSEL);
+      if (lane == 0) fin_s = p8s_tail_c(arp, p2, res_s, outs + nx + P8_NSEL);
     }
-    __syncthreads();   // B4: outs complete, fin_s
+    MX_TICK(3);
+    mx_lds_barrier();   // B4: outs complete, fin_s
     float* orow = out + (size_t)t * ld;
     for (int i = tid; i < P8_NOUT; i += MX_THREADS) orow[i] = outs[i];
     // ---- training with the step's own bit; the rows go back to HBM, the next step's rows become current ----
-    const int yb = bits[t];
-    if (more) load_rows(t + 1, fin_s, wn, rown, true);   // the one row that needed this step's final probability
+    const int yb = ring_bit[t & 3];
+    if (more) MX_LOAD_LATE(wn, rown, t + 1, fin_s)   // the one row that needed this step's final probability
+    if (more) misses += misses + (unsigned long long)((fin_s >> 11) != yb);   // the next step's
+    if (more) chain_fetch(t + 1, yb, misses);
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
       const int q = qq == 2 ? 3 : qq == 3 ? 2 : qq;   // set 26 (q == 2 of wave 6) last: its next row was requested a moment ago
       const int err = (int)(int16_t)(((yb << 12) - pr_s[4 * wave + q]) * 7);
-      uint4* wr = reinterpret_cast<uint4*>(M->wx + (size_t)row[q] * P8_NX);
+      uint4* wr = reinterpret_cast<uint4*>(wx + (size_t)row[q] * P8_NX);
       const bool again = more && rown[q] == row[q];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -532,20 +622,27 @@ __global__ __launch_bounds__(MX_THREADS) void cmx_p8s_mix2_kernel(const P8MixDev
           v.z = pair_train(xv.z, v.z, err); v.w = pair_train(xv.w, v.w, err);
           wr[grp] = v;
         }
-        w[q][g] = again ? v : wn[q][g];
+        if (wave == 6 && q == 2) w[q][g] = v;   // resolved at the top of the next step, when the late request has arrived
+        else w[q][g] = again ? v : wn[q][g];
       }
+      if (wave == 6 && q == 2) { pend26 = more; again26 = again; }
       row[q] = more ? rown[q] : row[q];
     }
+
     if (wave == 0 && lane < 16) {
       const int err2 = (int)(int16_t)(((yb << 12) - p_s) * 7);
-      uint32_t* w2 = reinterpret_cast<uint32_t*>(M->wx2);
+      uint32_t* w2 = reinterpret_cast<uint32_t*>(wx2);
       if (err2) w2[lane] = pair_train(st_s[lane], w2[lane], err2);
     }
+    ring_store(t + 2, ring_v);
+    MX_TICK(4);
     if (more) {   // the next step's inputs into the other LDS buffer
       if (t + 1 < first) stage_x(t + 1, buf ^ 1);
       else if (tid < MX_GROUPS) reinterpret_cast<uint4*>(xs[buf ^ 1])[tid] = xn;
     }
   }
+  if (prof && (tid & 63) == 0) for (int i = 0; i < 6; i++) prof[(tid >> 6) * 8 + i] += pacc[i];
+#undef MX_TICK
   __syncthreads();
   // the cells the chain tables chose last are updated at the top of the next step (update, then lookup): their indices go home
   if (chain) {
@@ -554,7 +651,7 @@ __global__ __launch_bounds__(MX_THREADS) void cmx_p8s_mix2_kernel(const P8MixDev
     T->gen_idx[j] = al_gen.idx;
   }
   for (int i = tid; i < P8_NOUT; i += MX_THREADS) T->out[i] = outs[i];
-  if (tid == 0) { T->pr = fin_s; T->misses = misses_s; }
+  if (tid == 0) { T->pr = fin_s; T->misses = misses; }
 }
 
 // ---------------------------------------------------------------- host side
@@ -599,6 +696,7 @@ struct cmx_p8stage {
   hipStream_t s_a = nullptr, s_b = nullptr, s_c = nullptr, s_m = nullptr;
   hipEvent_t ev_up = nullptr, ev_ord = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_mix[2] = {};
   bool mix_used[2] = {false, false};
+  unsigned long long* d_prof = nullptr;   // CMX_P8MIX_PROFILE=1: per-wave clocks by phase of the mixer kernel
   uint64_t chunks = 0;
   uint64_t steps = 0;
   int last_bit = 0;
@@ -654,6 +752,7 @@ cmx_p8stage_t* cmx_p8stage_create(int device) {
   for (hipStream_t* q : {&h->s_a, &h->s_b, &h->s_c, &h->s_m}) ok = ok && hipStreamCreateWithFlags(q, hipStreamNonBlocking) == hipSuccess;
   for (hipEvent_t* e : {&h->ev_up, &h->ev_ord, &h->ev_a, &h->ev_b, &h->ev_c, &h->ev_mix[0], &h->ev_mix[1]}) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
   for (auto& s : h->st) ok = ok && hipEventCreateWithFlags(&s.done, hipEventDisableTiming) == hipSuccess;
+  if (ok && getenv("CMX_P8MIX_PROFILE")) ok = hipMalloc((void**)&h->d_prof, 7 * 8 * 8) == hipSuccess && hipMemset(h->d_prof, 0, 7 * 8 * 8) == hipSuccess;
   ok = ok && hipDeviceSynchronize() == hipSuccess;
   if (!ok) { cmx_set_err("cmx_p8stage_create: allocation / init failed (the stage needs ~9 GB of HBM)"); cmx_p8stage_destroy(h); return nullptr; }
   return h;
@@ -740,8 +839,12 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
     hipLaunchKernelGGL(cmx_p8s_dmc_kernel, dim3(1), dim3(P8DMC_THREADS), 0, h->s_c, h->d_dmc, d_bits, dx, (int)L.dmc_off, nbits, t0);
     ok = ok && hipEventRecord(h->ev_c, h->s_c) == hipSuccess;
     for (hipEvent_t e : {h->ev_a, h->ev_b, h->ev_c}) ok = ok && hipStreamWaitEvent(h->s_m, e, 0) == hipSuccess;
-    hipLaunchKernelGGL(h->fam_v1 ? cmx_p8s_mix_kernel : cmx_p8s_mix2_kernel, dim3(1), dim3(MX_THREADS), 0, h->s_m, (const P8MixDev*)h->d_mix, h->d_tail, (const int16_t*)dx,
-                       (const int32_t*)(b.d + b.o_sel), (const P8ApmRec*)(b.d + b.o_apm), (const uint8_t*)dord, d_bits, d_out, ld, nbits, t0, skip, h->last_bit);
+    if (h->fam_v1 || getenv("CMX_P8MIX_V1"))
+      hipLaunchKernelGGL(cmx_p8s_mix_kernel, dim3(1), dim3(MX_THREADS), 0, h->s_m, (const P8MixDev*)h->d_mix, h->d_tail, (const int16_t*)dx, (const int32_t*)(b.d + b.o_sel),
+                         (const P8ApmRec*)(b.d + b.o_apm), (const uint8_t*)dord, d_bits, d_out, ld, nbits, t0, skip, h->last_bit);
+    else
+      hipLaunchKernelGGL(cmx_p8s_mix2_kernel, dim3(1), dim3(MX_THREADS), 0, h->s_m, (const P8MixDev*)h->d_mix, h->d_tail, (const int16_t*)dx, (const int32_t*)(b.d + b.o_sel),
+                         (const P8ApmRec*)(b.d + b.o_apm), (const uint8_t*)dord, d_bits, d_out, ld, nbits, t0, skip, h->last_bit, h->d_prof);
     ok = ok && hipGetLastError() == hipSuccess;
     ok = ok && hipEventRecord(h->ev_mix[par], h->s_m) == hipSuccess;
     ok = ok && hipEventRecord(b.done, h->s_m) == hipSuccess;
@@ -754,6 +857,13 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
   h->steps += T;
   h->last_bit = hb[T - 1];
   return 0;
+}
+
+// diagnostics (CMX_P8MIX_PROFILE=1 at create time): clocks of lane 0 of each of the mixer kernel's 7 waves, by phase
+// (to B1, to B2, to B3, to B4, orow + training, -), summed over all steps so far
+int cmx_p8stage_mix_profile(cmx_p8stage_t* h, unsigned long long out56[56]) {
+  if (!h || !h->d_prof) return 1;
+  return hipMemcpy(out56, h->d_prof, 56 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
 }
 
 int cmx_p8stage_sync(cmx_p8stage_t* h) {

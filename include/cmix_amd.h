@@ -440,6 +440,8 @@ cmx_p8stage_t* cmx_p8stage_create(int device);
 void cmx_p8stage_destroy(cmx_p8stage_t*);
 int cmx_p8stage_run(cmx_p8stage_t*, const uint8_t* bytes_host, size_t nbytes, float* d_out, size_t ld, void* stream);
 int cmx_p8stage_sync(cmx_p8stage_t*);
+/* diagnostics (CMX_P8MIX_PROFILE=1 at create time): the mixer kernel's clocks per wave (7) and phase (8 slots, 5 used) */
+int cmx_p8stage_mix_profile(cmx_p8stage_t*, unsigned long long out56[56]);
 
 #ifdef __cplusplus
 }

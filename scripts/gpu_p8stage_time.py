@@ -23,3 +23,12 @@ for i in range(2, N + 2):
 b.record()
 st.sync()
 print("paq8 stage %d x 1 KB: %.2f us/bit device span, %.2f us/bit wall" % (N, a.elapsed_time(b) * 1e3 / (8192 * N), (time.perf_counter() - t0) * 1e6 / (8192 * N)))
+
+if os.environ.get("CMX_P8MIX_PROFILE"):
+    import ctypes as C
+    acc = (C.c_ulonglong * 56)()
+    E.lib().cmx_p8stage_mix_profile.argtypes = [C.c_void_p, C.c_void_p]
+    if E.lib().cmx_p8stage_mix_profile(st.h, acc) == 0:
+        nb = 8192.0 * (N + 2)
+        for w in range(7):
+            print("mixer wave %d clocks/bit by phase (->B1 ->B2 ->B3 ->B4 tail):" % w, " ".join("%6.0f" % (acc[8 * w + i] / nb) for i in range(5)), "| total %.0f" % (sum(acc[8 * w + i] for i in range(5)) / nb))
