@@ -40,7 +40,7 @@ void build(FxDev& h, Policy& P) {
   memcpy(wrt, FX_WRT_2B, 256); memcpy(wrt + 256, FX_WRT_3B, 256);
   h.wrt = (const uint8_t*)up(wrt, 512);
   const uint8_t* sta_dev[6];
-  for (int k = 0; k < 6; k++) sta_dev[k] = (const uint8_t*)up(sta(k), 1024);
+  for (int k = 0; k < 6; k++) h.sta[k] = sta_dev[k] = (const uint8_t*)up(sta(k), 1024);
 
   int slot = 0, tx = 2 * FX_NSSCM + 7 + 2, ex = FX_NSSCM + 7 + 2;
   for (int k = 0; k < FX_NMAPS; k++) {

@@ -30,6 +30,12 @@
 #endif
 
 #define FX_NONE 0xffffffffu
+#ifdef __HIPCC__
+#define FX_CAS(p, c, v) atomicCAS((p), (c), (v))
+#else
+static inline uint32_t fx_cas_host(uint32_t* p, uint32_t c, uint32_t v) { const uint32_t o = *p; if (o == c) *p = v; return o; }
+#define FX_CAS(p, c, v) fx_cas_host((p), (c), (v))
+#endif
 enum { FX_THREADS = 256, FX_BMASK = 0xffffff,
        FX_U_SSCM = 81, FX_U_MATCH = 88, FX_U_RCM = 89, FX_U_LSTM = 90, FX_U_MIX10 = 91, FX_U_MIX11 = 92, FX_U_APM = 93, FX_UNITS = 99, FX_TRAIN0 = 128,
        FX_TAB_RC1 = 0, FX_TAB_ST1 = 512, FX_TAB_ST2 = 512 + 4096, FX_TAB_ST32 = 512 + 8192, FX_TAB_ST8 = 512 + 8192 + 256, FX_TAB_LEN = 512 + 8192 + 512 };
@@ -53,6 +59,7 @@ struct FxDev {                         // everything a stream owns on the device
   int slot_parallel;                   // 1: one lane per context slot with a per-map serial fallback; 0: one lane per map
   const int16_t *squash, *stretch;     // squash[d + 2047], stretch[p]
   const uint8_t* wrt;                  // byte -> 2-bit class [256], 3-bit class [256] of cmix's WRT-swapped alphabet
+  const uint8_t* sta[6];               // the six state tables the maps' nn pointers refer to (the kernel keeps copies in LDS)
   uint16_t* sscm_data[FX_NSSCM]; int sscm_mask[FX_NSSCM], sscm_ctx[FX_NSSCM], sscm_B[FX_NSSCM], sscm_bcount[FX_NSSCM], sscm_cp[FX_NSSCM];
   uint32_t* sm1_t[3]; int sm1_mask[3], sm1_cxt[3];
   uint8_t* rcm_t; uint32_t rcm_n, rcm_cp; int16_t rcm_rc[512];
@@ -77,8 +84,9 @@ struct FxShared {                      // LDS on the device (~100 KB: dynamic sh
   int pr, parity;
   uint32_t fails, failz, failcount;
   int slot_res[FX_NSLOTS], isMatch;
-  int32_t touched[FX_NSLOTS][5];       // buckets a context will touch this bit (-1: none), for the conflict check
-  int mconf[FX_NMAPS];                 // two contexts of the map touch the same bucket this bit: the map runs serially
+  uint32_t m_ctx[3];                   // MatchModel2's StateMap1 contexts of the bit (0: none)
+  uint32_t ohash[2][1024];             // (map, bucket) pairs the contexts touch this bit: a compare-and-swap hash set, two parities
+  int mconf[2][FX_NMAPS];              // two contexts of the map touch the same bucket this bit: the map runs serially
   // per-slot registers of the context maps and their StateMaps, resident for the chunk (home: FxMapDev / FxMapDev::sm)
   uint32_t mcp[FX_NMAPS][8], mcp0[FX_NMAPS][8], mrunp[FX_NMAPS][8], mcxt[FX_NMAPS][8];
   int msmc[FX_NMAPS][8];
@@ -86,6 +94,7 @@ struct FxShared {                      // LDS on the device (~100 KB: dynamic sh
 };
 
 struct FxBit {                         // uniform per-bit values every thread derives from the byte stream
+  int q;                               // the update's number within the stream's chunk (parity of the overlap hash set)
   int y, bpos, c0, lastbyte, blpos, rate, sscmrate, boundary, lstmpr, lstmex, normal;
   const FxByteRec* rec;                // the record in force for this bit
   float* orow;                         // where the 431 exported values of this bit go
@@ -218,7 +227,7 @@ FX_HD void fxd_map_ctx(FxDev* d, FxShared* sh, const FxBit& u, int k, int i) {
 
 // Which buckets will context i of map k touch in this bit? Read-only. Serial order inside a map only matters when two of
 // its contexts touch the same bucket (checksum replacement, the last-used byte, shared state bytes), so: every context
-// lane lists its buckets (fxd_map_touch), lanes compare lists within their map (fxd_map_conflict), and a map with an
+// lane puts its buckets into an LDS hash set (fxd_map_touch: a pair that is already there = an overlap), and a map with an
 // overlap is walked by its first lane in context order while all other maps run one lane per context (fxd_map_run).
 // The list: the bucket of the state byte being updated, the bucket holding the run bytes, at bits 0 / 2 / 5 the bucket
 // about to be looked up, and at bit 0 the two buckets a second visit creates histories in -- known from a read-only
@@ -227,21 +236,19 @@ FX_HD void fxd_map_ctx(FxDev* d, FxShared* sh, const FxBit& u, int k, int i) {
 FX_HD void fxd_map_touch(FxDev* d, FxShared* sh, const FxBit& u, int s) {
   const int k = d->slot_map[s], i = d->slot_idx[s];
   const FxMapDev* x = &d->maps[k];
-  int32_t* T = sh->touched[s];
-  for (int j = 0; j < 5; j++) T[j] = -1;
-  if (i == 0) sh->mconf[k] = 0;
+  const int par = u.q & 1;
+  uint32_t T[5]; int n = 0;
   if (!u.normal) return;
   if (u.boundary) sh->mcxt[k][i] = u.rec->cx[s];
   if ((u.rec->skip[s >> 5] >> (s & 31)) & 1) return;
   const int sh_b = x->B == 32 ? 5 : x->B == 64 ? 6 : 7;
   const uint32_t cp = sh->mcp[k][i], runp = sh->mrunp[k][i], cxt = sh->mcxt[k][i];
-  if (cp != FX_NONE) T[0] = (int32_t)(cp >> sh_b);
-  T[1] = (int32_t)(runp >> sh_b);
+  if (cp != FX_NONE) T[n++] = cp >> sh_b;
+  T[n++] = runp >> sh_b;
   const int bpos = u.bpos;
-  if (bpos > 1 && x->t[runp] == 0) return;
-  if (bpos == 0 || bpos == 2 || bpos == 5) {
+  if (!(bpos > 1 && x->t[runp] == 0) && (bpos == 0 || bpos == 2 || bpos == 5)) {
     const uint32_t nb = (cxt + (uint32_t)u.c0) & x->tmask;
-    T[2] = (int32_t)nb;
+    T[n++] = nb;
     if (bpos == 0) {
       const uint8_t* b = x->t + (size_t)nb * (size_t)x->B;
       const uint16_t* chk = (const uint16_t*)b;
@@ -252,29 +259,37 @@ FX_HD void fxd_map_touch(FxDev* d, FxShared* sh, const FxBit& u, int s) {
       else for (int j = 0; j < A; ++j) if (chk[j] == ch) { slot = j; break; }
       if (slot >= 0 && b[2 * A + 1 + 7 * slot + 3] == 2) {
         const int c = b[2 * A + 1 + 7 * slot + 4] + 256;
-        T[3] = (int32_t)((cxt + (uint32_t)(c >> 6)) & x->tmask);
-        T[4] = (int32_t)((cxt + (uint32_t)(c >> 3)) & x->tmask);
+        T[n++] = (cxt + (uint32_t)(c >> 6)) & x->tmask;
+        T[n++] = (cxt + (uint32_t)(c >> 3)) & x->tmask;
       }
     }
   }
-}
-FX_HD void fxd_map_conflict(FxDev* d, FxShared* sh, const FxBit& u, int s) {
-  if (!u.normal) return;
-  const int k = d->slot_map[s];
-  const FxMapDev* x = &d->maps[k];
-  const int32_t* T = sh->touched[s];
-  for (int o = x->slot_base; o < x->slot_base + x->C; o++) {
-    if (o == s) continue;
-    const int32_t* O = sh->touched[o];
-    for (int a = 0; a < 5; a++)
-      if (T[a] >= 0)
-        for (int b = 0; b < 5; b++) if (T[a] == O[b]) { sh->mconf[k] = 1; return; }
+  // into the hash set: a pair another context of the map has put there = an overlap (this lane's own repeats are dropped first)
+  uint32_t* tab = sh->ohash[par];
+  for (int a = 0; a < n; a++) {
+    int dup = 0;
+    for (int c = 0; c < a; c++) dup |= T[c] == T[a];
+    if (dup) continue;
+    const uint32_t key = ((uint32_t)(k + 1) << 26) | T[a];
+    uint32_t h = (key * 2654435761u) >> 22;
+    for (;;) {
+      const uint32_t old = FX_CAS(&tab[h], 0u, key);
+      if (old == 0) break;
+      if (old == key) { sh->mconf[par][k] = 1; break; }
+      h = (h + 1) & 1023;
+    }
   }
+}
+// the other parity's hash set and flags are cleared for the next bit (any phase after the maps have run)
+FX_HD void fxd_map_clear_next(FxShared* sh, const FxBit& u, int tid) {
+  uint32_t* tab = sh->ohash[(u.q + 1) & 1];
+  for (int i = tid; i < 1024; i += FX_THREADS) tab[i] = 0;
+  if (tid < FX_NMAPS) sh->mconf[(u.q + 1) & 1][tid] = 0;
 }
 FX_HD void fxd_map_run(FxDev* d, FxShared* sh, const FxBit& u, int s) {
   const int k = d->slot_map[s], i = d->slot_idx[s];
   if (!u.normal) { sh->slot_res[s] = 0; return; }
-  if (!sh->mconf[k] && d->slot_parallel) fxd_map_ctx(d, sh, u, k, i);
+  if (!sh->mconf[u.q & 1][k] && d->slot_parallel) fxd_map_ctx(d, sh, u, k, i);
   else if (i == 0) for (int j = 0; j < d->maps[k].C; j++) fxd_map_ctx(d, sh, u, k, j);
 }
 
@@ -357,7 +372,8 @@ FX_HD int fxd_statemap1(FxDev* d, int j, int y, int c) {
 FX_HD uint32_t fxd_mi_prio(const FxMatchInfo* c) {
   return (uint32_t)(c->length != 0) << 31 | (uint32_t)c->delta << 30 | (c->delta ? (c->lengthBak >> 1) : (c->length >> 1)) << 24 | (c->index & 0x00ffffff);
 }
-FX_HD void fxd_match2(FxDev* d, const FxBit& u, int16_t* tx, float* ex, int* isMatch) {
+// part A: the candidates (:3447-3566) and the three StateMap1 contexts; part B (fxd_match2_sm): one StateMap1 read-out each
+FX_HD void fxd_match2(FxDev* d, FxShared* sh, const FxBit& u, int16_t* tx, float* ex, int* isMatch) {
   enum { MAXLEN = 62, MINLEN_RM = 3, LEN1 = 5, LEN2 = 7, LEN3 = 9 };
   const int pc1 = u.rec->pc1;
   const uint32_t n = (uint32_t)fxd_max((int)d->nActive, 1);
@@ -432,16 +448,19 @@ FX_HD void fxd_match2(FxDev* d, const FxBit& u, int16_t* tx, float* ex, int* isM
   }
   tx[0] = (int16_t)v; ex[0] = fxd_export(d, v);
   if (delta) ctx[2] = (expectedByte << 8) | (uint32_t)u.c0;
-  for (int i = 0; i < 3; i++) {
-    int a = 0, b = 0;
-    if (ctx[i] != 0) {
-      const int p1 = fxd_statemap1(d, i, u.y, (int)ctx[i]);
-      a = d->stretch[p1] >> 2; b = (p1 - 2048) >> 3;
-    }
-    tx[1 + 2 * i] = (int16_t)a; ex[1 + 2 * i] = fxd_export(d, a);
-    tx[2 + 2 * i] = (int16_t)b; ex[2 + 2 * i] = fxd_export(d, b);
-  }
+  for (int i = 0; i < 3; i++) sh->m_ctx[i] = ctx[i];
   *isMatch = (int)length;
+}
+FX_HD void fxd_match2_sm(FxDev* d, FxShared* sh, const FxBit& u, int i) {   // i = 0..2 (:3620-3640)
+  int16_t* tx = sh->tx[sh->parity ^ 1] + 2 * FX_NSSCM;
+  float* ex = u.orow + FX_NSSCM;
+  int a = 0, b = 0;
+  if (sh->m_ctx[i] != 0) {
+    const int p1 = fxd_statemap1(d, i, u.y, (int)sh->m_ctx[i]);
+    a = d->stretch[p1] >> 2; b = (p1 - 2048) >> 3;
+  }
+  tx[1 + 2 * i] = (int16_t)a; ex[1 + 2 * i] = fxd_export(d, a);
+  tx[2 + 2 * i] = (int16_t)b; ex[2 + 2 * i] = fxd_export(d, b);
 }
 FX_HD void fxd_mtf_front(FxMtf* l, int i) {  // MTFList::MoveToFront :1715-1731
   if ((l->index = i) == l->root) return;
@@ -502,7 +521,7 @@ FX_HD void fxd_match_unit(FxDev* d, FxShared* sh, const FxBit& u) {
   if (u.boundary) { d->buffer[(uint32_t)d->pos & FX_BMASK] = (uint8_t)u.lastbyte; d->pos++; }   // :3806-3807
   int16_t* tx = sh->tx[sh->parity ^ 1] + 2 * FX_NSSCM;
   float* ex = u.orow + FX_NSSCM;
-  fxd_match2(d, u, tx, ex, &sh->isMatch);
+  fxd_match2(d, sh, u, tx, ex, &sh->isMatch);
   fxd_sparse(d, u, tx + 7, ex + 7);
 }
 #undef FXB
@@ -576,14 +595,13 @@ FX_HD int fxd_apm_p(FxDev* d, FxShared* sh, int j, int pr, int cxt) {
 FX_HD void fxd_phase1a(FxDev* d, FxShared* sh, const FxBit& u, int tid) {
   if (tid < FX_NSLOTS) fxd_map_touch(d, sh, u, tid);
   else if (tid < FX_U_MATCH) fxd_sscm_unit(d, sh, u, tid - FX_U_SSCM);
-  else if (tid == FX_U_MATCH) fxd_match_unit(d, sh, u);
+  else if (tid == FX_U_MATCH) { fxd_match_unit(d, sh, u); for (int i = 0; i < 3; i++) fxd_match2_sm(d, sh, u, i); }
   else if (tid == FX_U_RCM) fxd_rcm_unit(d, sh, u);
   else if (tid == FX_U_LSTM) { const FxLayout l = fxd_layout(d, u.normal); sh->tx[sh->parity ^ 1][l.tx_lstm] = d->stretch[u.lstmpr]; }
   else if (tid == FX_U_MIX10 || tid == FX_U_MIX11) fxd_train_small(d, sh, u, 10 + tid - FX_U_MIX10);
   else if (tid < FX_UNITS) fxd_apm_update(d, sh, u, tid - FX_U_APM);
   else if (tid >= FX_TRAIN0) fxd_train_rows(d, sh, u, tid - FX_TRAIN0, FX_THREADS - FX_TRAIN0);
 }
-FX_HD void fxd_phase1b(FxDev* d, FxShared* sh, const FxBit& u, int tid) { if (tid < FX_NSLOTS) fxd_map_conflict(d, sh, u, tid); }
 FX_HD void fxd_phase1c(FxDev* d, FxShared* sh, const FxBit& u, int tid) { if (tid < FX_NSLOTS) fxd_map_run(d, sh, u, tid); }
 FX_HD void fxd_phase2(FxDev* d, FxShared* sh, const FxBit& u, int tid) {
   if (tid != 0) return;
@@ -664,7 +682,8 @@ FX_HD void fxd_phase2(FxDev* d, FxShared* sh, const FxBit& u, int tid) {
   cx[9] = (bpos << 8) * 4 + (int)(sh->fails & 3) * 256 + u.lstmex;
   cx[11] = 0;
 }
-FX_HD void fxd_phase3(FxDev* d, FxShared* sh, const FxBit&, int tid) {   // dot_product, SSE2 form :522-541: one pair per thread
+FX_HD void fxd_phase3(FxDev* d, FxShared* sh, const FxBit& u, int tid) {   // dot_product, SSE2 form :522-541: one pair per thread
+  fxd_map_clear_next(sh, u, tid);
   const int16_t* tx = sh->tx[sh->parity ^ 1] + 2 * tid;
   const int t0 = tx[0], t1 = tx[1];
   for (int k = 0; k < FX_NMIX1; k++) {
@@ -738,6 +757,8 @@ FX_HD void fxd_load_shared(const FxDev* d, FxShared* sh, int tid) {
   if (tid < 16) sh->in2[tid] = d->in2[tid];
   if (tid < 12) { sh->mx_elim[tid] = d->mx_elim[tid]; sh->mx_cxt[tid] = d->mx_cxt[tid]; sh->mx_pr[tid] = d->mx_pr[tid]; }
   if (tid < 6) sh->apm_index[tid] = d->apm_index[tid];
+  for (int i = tid; i < 2048; i += FX_THREADS) (&sh->ohash[0][0])[i] = 0;
+  for (int i = tid; i < 2 * FX_NMAPS; i += FX_THREADS) (&sh->mconf[0][0])[i] = 0;
   if (tid == 0) { sh->pr = d->pr; sh->parity = d->parity; sh->fails = d->fails; sh->failz = d->failz; sh->failcount = d->failcount; sh->isMatch = 0; }
   for (int i = tid; i < FX_NMAPS * 8; i += FX_THREADS) {
     const FxMapDev* x = &d->maps[i >> 3];
@@ -772,6 +793,7 @@ FX_HD void fxd_store_shared(FxDev* d, const FxShared* sh, int tid) {
 FX_HD FxBit fxd_bit(FxDev* d, const uint8_t* bytes, const FxByteRec* recs, const int16_t* lstmpr, const uint8_t* lstmex, float* out, long ostride, int nbits,
                     int q, int blpos0, int lastbyte0, int have_rec0) {
   FxBit u;
+  u.q = q;
   const int b = q >> 3, k = q & 7, cur = bytes[b];
   u.y = (cur >> (7 - k)) & 1;
   u.bpos = (k + 1) & 7;

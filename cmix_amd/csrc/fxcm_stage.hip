@@ -22,46 +22,150 @@
 void cmx_set_err(const std::string& s);  // cmx_api.hip
 extern "C" int cmx_device_count(void);
 
-// PROF: per-phase clocks of thread 0 (s_memtime) accumulated into prof[0..7] (CMX_FXCM_PROFILE=1, scripts/gpu_fxcm_time.py)
+typedef short fx_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t fx_pair_train(uint32_t t, uint32_t w, int err) {   // train, SSE2 form (:543-557) in packed 16-bit math
+  const fx_s2 tv = __builtin_bit_cast(fx_s2, t), wv = __builtin_bit_cast(fx_s2, w);
+  const fx_s2 v = __builtin_elementwise_add_sat(tv, tv);
+  fx_s2 r;
+  r.x = (short)(__mul24((int)v.x, err) >> 16);
+  r.y = (short)(__mul24((int)v.y, err) >> 16);
+  const fx_s2 one = {1, 1};
+  r = __builtin_elementwise_add_sat(r, one) >> 1;
+  r = __builtin_elementwise_add_sat(r, wv);
+  return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ int fx_pair_dot(uint32_t t, uint32_t w) {   // one pmaddwd lane >> 8 (:522-541)
+  return __builtin_amdgcn_sdot2(__builtin_bit_cast(fx_s2, t), __builtin_bit_cast(fx_s2, w), 0, false) >> 8;
+}
+// The trainer lanes' share of fxd_train_rows (same values): trainer j of 128 owns 16-byte groups j, j + 128, ... of the
+// 10 x 64 groups of the selected first-layer rows, on the previous inputs -- five vector loads up front, packed math, five
+// vector stores, instead of 40 dependent load / store pairs.
+__device__ __forceinline__ void fx_train_rows_fast(FxDev* d, FxShared* sh, const FxBit& u, int j) {
+  const uint4* tx = reinterpret_cast<const uint4*>(sh->tx[sh->parity]);
+  uint4 w[5]; uint4* wp[5]; int err[5];
+#pragma unroll
+  for (int r = 0; r < 5; r++) {
+    const int g = j + 128 * r, k = g >> 6;   // 64 groups of 8 weights per row
+    err[r] = (int)(int16_t)fxd_mixer_err(sh, d, u, k);
+    wp[r] = reinterpret_cast<uint4*>(d->wx[k] + (size_t)sh->mx_cxt[k] * FX_TX) + (g & 63);
+    w[r] = *wp[r];
+  }
+#pragma unroll
+  for (int r = 0; r < 5; r++) {
+    if (!err[r]) continue;
+    const uint4 t = tx[(j + 128 * r) & 63];
+    uint4 v = w[r];
+    v.x = fx_pair_train(t.x, v.x, err[r]); v.y = fx_pair_train(t.y, v.y, err[r]);
+    v.z = fx_pair_train(t.z, v.z, err[r]); v.w = fx_pair_train(t.w, v.w, err[r]);
+    *wp[r] = v;
+  }
+}
+
+// Phase 1a on the device. The step functions are the ones fxd_phase1a calls (tests/host/fxcm_emul.cpp runs that), but the
+// units get wavefronts of their own: lanes of one wavefront that take different branches run one branch after the other,
+// so 81 context lanes + 7 SSCMs + the match lane + the run map + 6 APMs in two wavefronts cost the SUM of their chains.
+//   waves 0-1  lanes 0..80: context slots (bucket lists + overlap hash)
+//   waves 2-3  the 128 trainer lanes (vector loads, packed math)
+//   wave 4     MatchModel2: lane 0 the candidates, then lanes 0..2 one StateMap1 each; lane 0 the sparse model
+//   wave 5     lanes 0..6 the SmallStationaryContextMaps
+//   wave 6     lane 0 run map, lane 1 LSTM input, lanes 2-3 training of mixers 10 / 11
+//   wave 7     lanes 0..5 APM cell updates
+enum { FX_DEV_THREADS = 512 };
+__device__ __forceinline__ void fx_phase1a_dev(FxDev* d, FxShared* sh, const FxBit& u, int tid) {
+  const int wave = tid >> 6, lane = tid & 63;
+  if (wave < 2) { if (tid < FX_NSLOTS) fxd_map_touch(d, sh, u, tid); }
+  else if (wave < 4) fx_train_rows_fast(d, sh, u, tid - 128);
+  else if (wave == 4) {
+    if (lane == 0) {
+      if (u.boundary) { d->buffer[(uint32_t)d->pos & FX_BMASK] = (uint8_t)u.lastbyte; d->pos++; }   // fxd_match_unit's first line (:3806-3807)
+      fxd_match2(d, sh, u, sh->tx[sh->parity ^ 1] + 2 * FX_NSSCM, u.orow + FX_NSSCM, &sh->isMatch);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the contexts are in LDS
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 3) fxd_match2_sm(d, sh, u, lane);
+    if (lane == 0) fxd_sparse(d, u, sh->tx[sh->parity ^ 1] + 2 * FX_NSSCM + 7, u.orow + FX_NSSCM + 7);
+  } else if (wave == 5) { if (lane < FX_NSSCM) fxd_sscm_unit(d, sh, u, lane); }
+  else if (wave == 6) {
+    if (lane == 0) fxd_rcm_unit(d, sh, u);
+    else if (lane == 1) { const FxLayout l = fxd_layout(d, u.normal); sh->tx[sh->parity ^ 1][l.tx_lstm] = d->stretch[u.lstmpr]; }
+    else if (lane == 2 || lane == 3) fxd_train_small(d, sh, u, 10 + lane - 2);
+  } else if (lane < 6) fxd_apm_update(d, sh, u, lane);
+}
+
+// Everything the bit loop reads lives in LDS: FxShared (inputs, StateMaps, per-context registers), a working COPY of the
+// stream's FxDev (map descriptors, unit registers, scalars: the step functions read them through `d` many times per bit,
+// and from global memory every such read is an L2 round trip the compiler must redo after each store), the squash /
+// stretch / state tables, and the record of the byte in force (copied one update ahead). Only the learned tables and the
+// per-map output tables stay in HBM / L2.
+struct FxLocal {
+  FxDev dev;
+  int16_t squash[4096], stretch[4096];
+  uint8_t wrt[512];
+  uint8_t sta[6][1024];
+  FxByteRec rec[2];
+};
+// PROF: per-phase clocks of thread 0 accumulated into prof[0..7] (CMX_FXCM_PROFILE=1, scripts/gpu_fxcm_time.py)
 template <bool PROF>
-__global__ __launch_bounds__(FX_THREADS) void cmx_fxcm_chunk_kernel_t(FxDev* d, const uint8_t* bytes, const FxByteRec* recs, const int16_t* lstmpr,
+__global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_chunk_kernel_t(FxDev* gd, const uint8_t* bytes, const FxByteRec* recs, const int16_t* lstmpr,
                                                                       const uint8_t* lstmex, float* out, long ostride, int n, unsigned long long* prof) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char fx_smem[];   // sizeof(FxShared) > 64 KB: dynamic
+  extern __shared__ __attribute__((aligned(16))) unsigned char fx_smem[];   // sizeof(FxShared) + sizeof(FxLocal) > 64 KB: dynamic
   FxShared& sh = *(FxShared*)fx_smem;
+  FxLocal& loc = *(FxLocal*)(fx_smem + ((sizeof(FxShared) + 15) & ~(size_t)15));
+  FxDev* d = &loc.dev;
   const int tid = threadIdx.x;
+  for (int i = tid; i < (int)(sizeof(FxDev) / 4); i += FX_DEV_THREADS) ((uint32_t*)d)[i] = ((const uint32_t*)gd)[i];
+  for (int i = tid; i < 4095; i += FX_DEV_THREADS) loc.squash[i] = gd->squash[i];
+  for (int i = tid; i < 4096; i += FX_DEV_THREADS) loc.stretch[i] = gd->stretch[i];
+  for (int i = tid; i < 512; i += FX_DEV_THREADS) loc.wrt[i] = gd->wrt[i];
+  for (int i = tid; i < 6 * 1024; i += FX_DEV_THREADS) loc.sta[i >> 10][i & 1023] = gd->sta[i >> 10][i & 1023];
+  __syncthreads();
+  if (tid == 0) { d->squash = loc.squash; d->stretch = loc.stretch; d->wrt = loc.wrt; }
+  if (tid < FX_NMAPS) for (int q = 0; q < 6; q++) if (gd->maps[tid].nn == gd->sta[q]) d->maps[tid].nn = loc.sta[q];
   const int nbits = 8 * n, blpos0 = d->blpos, lastbyte0 = d->lastbyte, have0 = d->have_rec;
-  fxd_load_shared(d, &sh, tid);
-  for (int i = tid; i < FX_OUTPUTS; i += FX_THREADS) out[i] = d->pending[i];   // row 0: what the previous chunk's last update left
+  if (tid < FX_THREADS) fxd_load_shared(d, &sh, tid);
+  for (int i = tid; i < FX_OUTPUTS; i += FX_DEV_THREADS) out[i] = d->pending[i];   // row 0: what the previous chunk's last update left
   __syncthreads();
   unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c0 = 0;
-#define FX_TICK(k) do { if (PROF && tid == 0) { const unsigned long long c1 = __builtin_readcyclecounter(); acc[k] += c1 - c0; c0 = c1; } } while (0)
-  if (PROF && tid == 0) c0 = __builtin_readcyclecounter();
+#define FX_TICK(k) do { if (PROF && (tid & 63) == 0) { const unsigned long long c1 = __builtin_readcyclecounter(); acc[k] += c1 - c0; c0 = c1; } } while (0)
+  if (PROF && (tid & 63) == 0) c0 = __builtin_readcyclecounter();
   for (int q = 0; q < nbits; q++) {
-    const FxBit u = fxd_bit(d, bytes, recs, lstmpr, lstmex, out, ostride, nbits, q, blpos0, lastbyte0, have0);
-    fxd_phase1a(d, &sh, u, tid);
-    __syncthreads(); FX_TICK(0);
-    fxd_phase1b(d, &sh, u, tid);
+    FxBit u = fxd_bit(d, bytes, recs, lstmpr, lstmex, out, ostride, nbits, q, blpos0, lastbyte0, have0);
+    {   // the record in force: the LDS copy (made during the previous update), and the next one on its way
+      const int b = q >> 3, ri = u.boundary ? b : b - 1;
+      if (ri >= 0) u.rec = &loc.rec[ri & 1];
+      if ((q & 7) == 6 && tid >= 128 && tid - 128 < (int)(sizeof(FxByteRec) / 4)) ((uint32_t*)&loc.rec[b & 1])[tid - 128] = ((const uint32_t*)&recs[b])[tid - 128];
+    }
+    fx_phase1a_dev(d, &sh, u, tid);
+    FX_TICK(0);
     __syncthreads(); FX_TICK(1);
-    fxd_phase1c(d, &sh, u, tid);
+    if (tid < FX_THREADS) fxd_phase1c(d, &sh, u, tid);
     __syncthreads(); FX_TICK(2);
-    fxd_phase2(d, &sh, u, tid);
+    if (tid < FX_THREADS) fxd_phase2(d, &sh, u, tid);
     __syncthreads(); FX_TICK(3);
-    fxd_phase3(d, &sh, u, tid);
+    if (tid < FX_THREADS) fxd_phase3(d, &sh, u, tid);
     __syncthreads(); FX_TICK(4);
-    fxd_phase4(d, &sh, u, tid);
+    if (tid < FX_THREADS) fxd_phase4(d, &sh, u, tid);
     __syncthreads(); FX_TICK(5);
-    fxd_phase5(d, &sh, u, tid);
+    if (tid < FX_THREADS) fxd_phase5(d, &sh, u, tid);
     __syncthreads(); FX_TICK(6);
   }
 #undef FX_TICK
-  fxd_store_shared(d, &sh, tid);
-  if (tid == 0) { d->blpos = blpos0 + n; d->lastbyte = bytes[n - 1]; d->have_rec = 1; d->rec = recs[n - 1]; }
-  if (PROF && tid == 0) for (int k = 0; k < 8; k++) prof[k] += acc[k];
+  if (tid < FX_THREADS) fxd_store_shared(d, &sh, tid);
+  if (tid == 0) {
+    d->blpos = blpos0 + n; d->lastbyte = bytes[n - 1]; d->have_rec = 1; d->rec = n >= 1 ? loc.rec[(n - 1) & 1] : d->rec;
+    d->squash = gd->squash; d->stretch = gd->stretch; d->wrt = gd->wrt;   // home pointers
+  }
+  if (tid < FX_NMAPS) d->maps[tid].nn = gd->maps[tid].nn;
+  __syncthreads();
+  for (int i = tid; i < (int)(sizeof(FxDev) / 4); i += FX_DEV_THREADS) ((uint32_t*)gd)[i] = ((const uint32_t*)d)[i];
+  if (PROF && (tid & 63) == 0) for (int k = 0; k < 8; k++) prof[(tid >> 6) * 8 + k] += acc[k];
 }
 
 __global__ void cmx_fxcm_pattern16_kernel(uint16_t* p, size_t n, const uint16_t* pat, int plen) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = pat[i % (size_t)plen];
 }
+
+static const size_t FX_LDS_BYTES = ((sizeof(FxShared) + 15) & ~(size_t)15) + sizeof(FxLocal);
 
 namespace {
 struct DevPolicy {
@@ -135,10 +239,10 @@ cmx_fxcm_t* cmx_fxcm_create(const char* dictionary_path, int device) {
   ok = ok && hipMalloc((void**)&h->d_dev, sizeof(FxDev)) == hipSuccess;
   ok = ok && hipMemcpy(h->d_dev, &host, sizeof(FxDev), hipMemcpyHostToDevice) == hipSuccess;
   for (int i = 0; ok && i < FX_STAGE_BUFS; i++) ok = hipEventCreateWithFlags(&h->done[i], hipEventDisableTiming) == hipSuccess;
-  ok = ok && hipFuncSetAttribute((const void*)cmx_fxcm_chunk_kernel_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(FxShared)) == hipSuccess;
-  ok = ok && hipFuncSetAttribute((const void*)cmx_fxcm_chunk_kernel_t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(FxShared)) == hipSuccess;
+  ok = ok && hipFuncSetAttribute((const void*)cmx_fxcm_chunk_kernel_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FX_LDS_BYTES) == hipSuccess;
+  ok = ok && hipFuncSetAttribute((const void*)cmx_fxcm_chunk_kernel_t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FX_LDS_BYTES) == hipSuccess;
   const char* prof = getenv("CMX_FXCM_PROFILE");
-  if (ok && prof && prof[0] == '1') ok = hipMalloc((void**)&h->d_prof, 64) == hipSuccess && hipMemset(h->d_prof, 0, 64) == hipSuccess;
+  if (ok && prof && prof[0] == '1') ok = hipMalloc((void**)&h->d_prof, 512) == hipSuccess && hipMemset(h->d_prof, 0, 512) == hipSuccess;
   ok = ok && hipDeviceSynchronize() == hipSuccess;
   if (!ok) { cmx_set_err("cmx_fxcm_create: allocation / init failed (the stage needs ~4.4 GB of HBM)"); cmx_fxcm_destroy(h); return nullptr; }
   h->parser = fxp_create(dictionary_path);
@@ -166,10 +270,10 @@ int cmx_fxcm_run(cmx_fxcm_t* h, const uint8_t* bytes, const uint8_t* d_bytes, si
   hipStream_t s = (hipStream_t)stream;
   if (hipMemcpyAsync(h->d_recs[b], h->h_recs[b], nbytes * sizeof(FxByteRec), hipMemcpyHostToDevice, s) != hipSuccess) { cmx_set_err("cmx_fxcm_run: record upload failed"); return 1; }
   if (h->d_prof)
-    hipLaunchKernelGGL(cmx_fxcm_chunk_kernel_t<true>, dim3(1), dim3(FX_THREADS), sizeof(FxShared), s, h->d_dev, d_bytes, h->d_recs[b], d_lstmpr, d_lstmex, d_probs + 3,
+    hipLaunchKernelGGL(cmx_fxcm_chunk_kernel_t<true>, dim3(1), dim3(FX_DEV_THREADS), FX_LDS_BYTES, s, h->d_dev, d_bytes, h->d_recs[b], d_lstmpr, d_lstmex, d_probs + 3,
                        (long)pstride, (int)nbytes, h->d_prof);
   else
-    hipLaunchKernelGGL(cmx_fxcm_chunk_kernel_t<false>, dim3(1), dim3(FX_THREADS), sizeof(FxShared), s, h->d_dev, d_bytes, h->d_recs[b], d_lstmpr, d_lstmex, d_probs + 3,
+    hipLaunchKernelGGL(cmx_fxcm_chunk_kernel_t<false>, dim3(1), dim3(FX_DEV_THREADS), FX_LDS_BYTES, s, h->d_dev, d_bytes, h->d_recs[b], d_lstmpr, d_lstmex, d_probs + 3,
                        (long)pstride, (int)nbytes, (unsigned long long*)nullptr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { cmx_set_err(std::string("cmx_fxcm_run: ") + hipGetErrorString(e)); return 1; }
@@ -180,9 +284,9 @@ int cmx_fxcm_run(cmx_fxcm_t* h, const uint8_t* bytes, const uint8_t* d_bytes, si
 }
 
 // CMX_FXCM_PROFILE=1: thread 0's clocks per barrier phase (1a, 1b, 1c, 2, 3, 4, 5) since creation
-int cmx_fxcm_profile(cmx_fxcm_t* h, unsigned long long out8[8]) {
+int cmx_fxcm_profile(cmx_fxcm_t* h, unsigned long long out64[64]) {
   if (!h || !h->d_prof) return 1;
-  return hipMemcpy(out8, h->d_prof, 64, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+  return hipMemcpy(out64, h->d_prof, 512, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
 }
 
 int cmx_fxcm_sync(cmx_fxcm_t* h) {

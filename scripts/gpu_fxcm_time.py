@@ -38,9 +38,9 @@ print("fxcm stage, %d x %d-byte chunks, serial_maps=%s: kernel+copy %.2f us/bit 
 
 if os.environ.get("CMX_FXCM_PROFILE") == "1":
     import ctypes as C
-    acc = (C.c_ulonglong * 8)()
+    acc = (C.c_ulonglong * 64)()
     E.lib().cmx_fxcm_profile.argtypes = [C.c_void_p, C.c_void_p]
     if E.lib().cmx_fxcm_profile(fx.h, acc) == 0:
-        tot = sum(acc) or 1
-        nb = 8.0 * C_BYTES * (nchunks + 4) if False else 8.0 * 1024 * (nchunks + 4)
-        print("thread-0 clocks per bit by phase (1a, 1b, 1c, 2, 3, 4, 5):", " ".join("%.0f" % (a / nb) for a in list(acc)[:7]), "| total %.0f" % (tot / nb))
+        nb = 8.0 * 1024 * (nchunks + 4)
+        for w in range(8):
+            print("wave %d clocks per bit by phase (1a work, 1a barrier, 1c, 2, 3, 4, 5):" % w, " ".join("%6.0f" % (acc[8 * w + i] / nb) for i in range(7)), "| total %.0f" % (sum(acc[8 * w + i] for i in range(7)) / nb))

@@ -59,8 +59,7 @@ int fxe_run(void* h, const uint8_t* bytes, int n, const int16_t* lstmpr, const u
     const FxBit u = fxd_bit(d, bytes, recs.data(), lstmpr, lstmex, out, ostride, nbits, q, blpos0, lastbyte0, have0);
     if (e->rng) shuffle(e);
     for (int t = 0; t < FX_THREADS; t++) fxd_phase1a(d, sh, u, e->order[t]);
-    for (int t = 0; t < FX_THREADS; t++) fxd_phase1b(d, sh, u, e->order[t]);
-    if (d->slot_parallel) for (int k = 0; k < FX_NMAPS; k++) { e->bits_maps++; e->bits_serial += sh->mconf[k] != 0; }
+    if (d->slot_parallel) for (int k = 0; k < FX_NMAPS; k++) { e->bits_maps++; e->bits_serial += sh->mconf[u.q & 1][k] != 0; }
     for (int t = 0; t < FX_THREADS; t++) fxd_phase1c(d, sh, u, e->order[t]);
     for (int t = 0; t < FX_THREADS; t++) fxd_phase2(d, sh, u, e->order[t]);
     for (int t = 0; t < FX_THREADS; t++) fxd_phase3(d, sh, u, e->order[t]);
