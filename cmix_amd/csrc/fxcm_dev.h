@@ -85,6 +85,11 @@ struct FxShared {                      // LDS on the device (~100 KB: dynamic sh
   uint32_t fails, failz, failcount;
   int slot_res[FX_NSLOTS], isMatch;
   uint32_t m_ctx[3];                   // MatchModel2's StateMap1 contexts of the bit (0: none)
+  // cached bytes of every context (write-through: the table is always current): the 7 state bytes at cp0, the 2 run bytes at
+  // runp, and -- at bits 0 / 2 / 5 -- the bucket about to be searched, fetched by the touch step before the barrier
+  uint8_t mslot[FX_NSLOTS][8], mrun[FX_NSLOTS][2];
+  alignas(16) uint8_t mbk[FX_NSLOTS][128];
+  uint8_t mlook[FX_NSLOTS];            // the touch step staged a bucket for this context
   uint32_t ohash[2][1024];             // (map, bucket) pairs the contexts touch this bit: a compare-and-swap hash set, two parities
   int mconf[2][FX_NMAPS];              // two contexts of the map touch the same bucket this bit: the map runs serially
   // per-slot registers of the context maps and their StateMaps, resident for the chunk (home: FxMapDev / FxMapDev::sm)
@@ -145,6 +150,126 @@ FX_HD uint32_t fxd_bucket_get(uint8_t* b, int A, uint16_t ch, int keep) {
   for (int k = 0; k < 7; k++) h[k] = 0;
   return (uint32_t)(2 * A + 1 + 7 * bi);
 }
+// the same search on a staged copy b of the bucket; every change also goes to the table g
+FX_HD uint32_t fxd_bucket_get_staged(uint8_t* b, uint8_t* g, int A, uint16_t ch, int keep) {
+  uint16_t* chk = (uint16_t*)b;
+  const uint8_t last = b[2 * A];
+  if (chk[last & 15] == ch) return (uint32_t)(2 * A + 1 + 7 * (last & 15));
+  int lowest = 0xffff, bi = 0;
+  for (int i = 0; i < A; ++i) {
+    if (chk[i] == ch) { b[2 * A] = (uint8_t)(last << 4 | i); g[2 * A] = b[2 * A]; return (uint32_t)(2 * A + 1 + 7 * i); }
+    const int pri = b[2 * A + 1 + 7 * i];
+    if (pri < lowest && (last & 15) != i && (last >> 4) != i) { lowest = pri; bi = i; }
+  }
+  b[2 * A] = (uint8_t)(last << 4 | bi | keep); g[2 * A] = b[2 * A];
+  chk[bi] = ch; ((uint16_t*)g)[bi] = ch;
+  for (int k = 0; k < 7; k++) { b[2 * A + 1 + 7 * bi + k] = 0; g[2 * A + 1 + 7 * bi + k] = 0; }
+  return (uint32_t)(2 * A + 1 + 7 * bi);
+}
+FX_HD void fxd_map_reload(FxDev* d, FxShared* sh, int k, int i) {   // the cached bytes of context i of map k from the table
+  const FxMapDev* x = &d->maps[k];
+  const int s = x->slot_base + i;
+  for (int q = 0; q < 7; q++) sh->mslot[s][q] = x->t[sh->mcp0[k][i] + q];
+  sh->mrun[s][0] = x->t[sh->mrunp[k][i]]; sh->mrun[s][1] = x->t[sh->mrunp[k][i] + 1];
+}
+// one context of one map for one bit on the cached bytes: same values as fxd_map_ctx below (which stays as the serial walk
+// for maps with an overlap), HBM touched only through the staged bucket, write-through stores and the output tables
+FX_HD void fxd_map_ctx_fast(FxDev* d, FxShared* sh, const FxBit& u, int k, int i) {
+  const FxMapDev* x = &d->maps[k];
+  uint32_t *cp = sh->mcp[k], *cp0 = sh->mcp0[k], *runp = sh->mrunp[k], *cxt = sh->mcxt[k];
+  int* sm_cxt = sh->msmc[k];
+  int16_t* tx = sh->tx[sh->parity ^ 1] + x->tx_off + i * (5 + x->u);
+  float* ex = u.orow + x->exp_off + i * (4 + x->u);
+  uint8_t* t = x->t;
+  const int16_t* tab = x->tab;
+  const int y = u.y, bpos = u.bpos, c0 = u.c0, c1 = u.lastbyte;
+  const int s = x->slot_base + i;
+  uint8_t* sl = sh->mslot[s];
+  uint8_t* rn = sh->mrun[s];
+  int result = 0, n = 0, e = 0;
+#define ADD(v) do { const int v_ = (v); tx[n++] = (int16_t)v_; ex[e++] = fxd_export(d, v_); } while (0)
+#define ADDQ(v) do { tx[n++] = (int16_t)(v); } while (0)
+  if ((u.rec->skip[s >> 5] >> (s & 31)) & 1) {
+    ADD(0); if (x->u) ADD(0); ADD(0); ADD(0); ADDQ(64); ADD(0);
+  } else {
+    if (cp[i] != FX_NONE) {
+      const uint8_t ns = x->nn[sl[cp[i] - cp0[i]] * 4 + y];
+      sl[cp[i] - cp0[i]] = ns; t[cp[i]] = ns;
+      if (cp[i] - runp[i] < 2u) rn[cp[i] - runp[i]] = ns;
+    }
+    int state = 0;
+    if (bpos > 1 && rn[0] == 0) cp[i] = FX_NONE;
+    else {
+      const uint16_t chk = (uint16_t)((cxt[i] >> 16) ^ (uint32_t)i);
+      if (bpos && bpos != 2 && bpos != 5) {
+        const uint32_t smask = (0x31031010u >> (bpos << 2)) & 0x0F;
+        cp[i] = cp0[i] + smask + ((uint32_t)c0 & smask);
+      } else {
+        const uint32_t nb = (cxt[i] + (uint32_t)c0) & x->tmask;
+        const size_t b = (size_t)nb * (size_t)x->B;
+        uint8_t* bk = sh->mbk[s];
+        if (cp[i] != FX_NONE && cp[i] - (uint32_t)b < (uint32_t)x->B) bk[cp[i] - (uint32_t)b] = sl[cp[i] - cp0[i]];   // own store above, same bucket
+        const uint32_t off = fxd_bucket_get_staged(bk, t + b, x->A, chk, x->kep);
+        const uint32_t old_runp = runp[i];
+        cp0[i] = cp[i] = (uint32_t)b + off;
+        for (int q = 0; q < 7; q++) sl[q] = bk[off + q];
+        if (bpos == 0) {
+          int refresh = 0;
+          if (sl[3] == 2) {  // second visit: create the histories for bits 2-7 of the byte seen the first time
+            const int c = sl[4] + 256;
+            size_t b2 = (size_t)((cxt[i] + (uint32_t)(c >> 6)) & x->tmask) * (size_t)x->B;
+            uint8_t* p = t + b2 + fxd_bucket_get(t + b2, x->A, chk, x->kep);
+            p[0] = (uint8_t)(1 + ((c >> 5) & 1));
+            p[1 + ((c >> 5) & 1)] = (uint8_t)(1 + ((c >> 4) & 1));
+            p[3 + ((c >> 4) & 3)] = (uint8_t)(1 + ((c >> 3) & 1));
+            b2 = (size_t)((cxt[i] + (uint32_t)(c >> 3)) & x->tmask) * (size_t)x->B;
+            p = t + b2 + fxd_bucket_get(t + b2, x->A, chk, x->kep);
+            p[0] = (uint8_t)(1 + ((c >> 2) & 1));
+            p[1 + ((c >> 2) & 1)] = (uint8_t)(1 + ((c >> 1) & 1));
+            p[3 + ((c >> 1) & 3)] = (uint8_t)(1 + (c & 1));
+            t[cp0[i] + 6] = 0; sl[6] = 0;
+            refresh = 1;
+          }
+          int r0 = rn[0], r1 = rn[1];   // run count of the previous context
+          if (old_runp - (uint32_t)b < (uint32_t)x->B) { r0 = bk[old_runp - (uint32_t)b]; r1 = bk[old_runp + 1 - (uint32_t)b]; }   // the search may have replaced the slot that holds them
+          if (refresh) { r0 = t[old_runp]; r1 = t[old_runp + 1]; }
+          if (r0 == 0) { r0 = 2; r1 = c1; }
+          else if (r1 != c1) { r0 = 1; r1 = c1; }
+          else if (r0 < 254) r0 += 2;
+          t[old_runp] = (uint8_t)r0; t[old_runp + 1] = (uint8_t)r1;
+          if (old_runp - cp0[i] < 7u) sl[old_runp - cp0[i]] = (uint8_t)r0;
+          if (old_runp + 1 - cp0[i] < 7u) sl[old_runp + 1 - cp0[i]] = (uint8_t)r1;
+          if (refresh) for (int q = 0; q < 7; q++) sl[q] = t[cp0[i] + q];
+          runp[i] = cp0[i] + 3;
+          rn[0] = sl[3]; rn[1] = sl[4];
+        }
+      }
+      state = sl[cp[i] - cp0[i]];
+    }
+    if (state == 0) {
+      ADD(0); if (x->u) ADD(0); ADD(0); ADD(0); ADDQ(64);
+    } else {
+      uint32_t* smt = sh->sm[x->slot_base + i];
+      uint32_t* p = &smt[sm_cxt[i]];
+      *p += (uint32_t)(y << 19) - (*p >> 13);
+      sm_cxt[i] = state;
+      const int p1 = (int)(smt[state] >> 20);
+      ADD(tab[FX_TAB_ST1 + p1]);
+      if (x->u) ADD(tab[FX_TAB_ST2 + p1]);
+      ADD(tab[FX_TAB_ST8 + state]);
+      ADD(tab[FX_TAB_ST32 + state]);
+      ADDQ(0);
+      result++;
+    }
+    const int bposshift = 7 - bpos, c0shift_bpos = (c0 << 1) ^ (256 >> bposshift);
+    const int bb = c0shift_bpos ^ (rn[1] >> bposshift);
+    ADD(bb <= 1 ? tab[FX_TAB_RC1 + rn[0] + bb * 256] : 0);
+  }
+#undef ADD
+#undef ADDQ
+  sh->slot_res[s] = result;
+}
+
 // one context of one map for one bit: ContextMap::mix's loop body (mix1 / mix :1110-1173)
 FX_HD void fxd_map_ctx(FxDev* d, FxShared* sh, const FxBit& u, int k, int i) {
   const FxMapDev* x = &d->maps[k];
@@ -246,11 +371,29 @@ FX_HD void fxd_map_touch(FxDev* d, FxShared* sh, const FxBit& u, int s) {
   if (cp != FX_NONE) T[n++] = cp >> sh_b;
   T[n++] = runp >> sh_b;
   const int bpos = u.bpos;
-  if (!(bpos > 1 && x->t[runp] == 0) && (bpos == 0 || bpos == 2 || bpos == 5)) {
+  sh->mlook[s] = 0;
+  if (!(bpos > 1 && sh->mrun[s][0] == 0) && (bpos == 0 || bpos == 2 || bpos == 5)) {
     const uint32_t nb = (cxt + (uint32_t)u.c0) & x->tmask;
     T[n++] = nb;
+    sh->mlook[s] = 1;
+    {   // the bucket about to be searched -> LDS
+      const uint8_t* g = x->t + (size_t)nb * (size_t)x->B;
+      uint8_t* bk = sh->mbk[s];
+#ifdef __HIPCC__
+      const uint4* g4 = reinterpret_cast<const uint4*>(g);
+      uint4* b4 = reinterpret_cast<uint4*>(bk);
+      const int nv = x->B >> 4;
+      uint4 v[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) if (q < nv) v[q] = g4[q];
+#pragma unroll
+      for (int q = 0; q < 8; q++) if (q < nv) b4[q] = v[q];
+#else
+      for (int q = 0; q < x->B; q++) bk[q] = g[q];
+#endif
+    }
     if (bpos == 0) {
-      const uint8_t* b = x->t + (size_t)nb * (size_t)x->B;
+      const uint8_t* b = sh->mbk[s];
       const uint16_t* chk = (const uint16_t*)b;
       const uint16_t ch = (uint16_t)((cxt >> 16) ^ (uint32_t)i);
       const int A = x->A, last = b[2 * A];
@@ -289,8 +432,11 @@ FX_HD void fxd_map_clear_next(FxShared* sh, const FxBit& u, int tid) {
 FX_HD void fxd_map_run(FxDev* d, FxShared* sh, const FxBit& u, int s) {
   const int k = d->slot_map[s], i = d->slot_idx[s];
   if (!u.normal) { sh->slot_res[s] = 0; return; }
-  if (!sh->mconf[u.q & 1][k] && d->slot_parallel) fxd_map_ctx(d, sh, u, k, i);
-  else if (i == 0) for (int j = 0; j < d->maps[k].C; j++) fxd_map_ctx(d, sh, u, k, j);
+  if (!sh->mconf[u.q & 1][k] && d->slot_parallel) fxd_map_ctx_fast(d, sh, u, k, i);
+  else if (i == 0) {   // overlap: the map's first lane walks it on the table in the reference's order, then the cached bytes are read back
+    for (int j = 0; j < d->maps[k].C; j++) fxd_map_ctx(d, sh, u, k, j);
+    for (int j = 0; j < d->maps[k].C; j++) fxd_map_reload(d, sh, k, j);
+  }
 }
 
 // ---------------------------------------------------------------- SmallStationaryContextMap :831-863
@@ -768,6 +914,13 @@ FX_HD void fxd_load_shared(const FxDev* d, FxShared* sh, int tid) {
   for (int k = 0; k < FX_NMAPS; k++) {
     const FxMapDev* x = &d->maps[k];
     for (int i = tid; i < x->C * 256; i += FX_THREADS) (&sh->sm[x->slot_base][0])[i] = x->sm[i];
+  }
+  if (tid < FX_NSLOTS) {   // cached bytes: straight from the table (the per-context registers above are this thread's own writes)
+    const int k = d->slot_map[tid], i = d->slot_idx[tid];
+    const FxMapDev* x = &d->maps[k];
+    for (int q = 0; q < 7; q++) sh->mslot[tid][q] = x->t[x->cp0[i] + q];
+    sh->mrun[tid][0] = x->t[x->runp[i]]; sh->mrun[tid][1] = x->t[x->runp[i] + 1];
+    sh->mlook[tid] = 0;
   }
 }
 FX_HD void fxd_store_shared(FxDev* d, const FxShared* sh, int tid) {

@@ -71,6 +71,8 @@ __device__ __forceinline__ void fx_train_rows_fast(FxDev* d, FxShared* sh, const
 //   wave 6     lane 0 run map, lane 1 LSTM input, lanes 2-3 training of mixers 10 / 11
 //   wave 7     lanes 0..5 APM cell updates
 enum { FX_DEV_THREADS = 512 };
+// a workgroup barrier that orders LDS traffic only (no wait for outstanding global loads / stores, which __syncthreads adds)
+__device__ __forceinline__ void fx_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void fx_phase1a_dev(FxDev* d, FxShared* sh, const FxBit& u, int tid) {
   const int wave = tid >> 6, lane = tid & 63;
   if (wave < 2) { if (tid < FX_NSLOTS) fxd_map_touch(d, sh, u, tid); }
@@ -103,6 +105,7 @@ struct FxLocal {
   uint8_t wrt[512];
   uint8_t sta[6][1024];
   FxByteRec rec[2];
+  float ex[2][FX_OUTPUTS + 1];   // the bit's 431 exported values (two parities: the copy-out of bit q runs under bit q + 1): the units write here, one coalesced copy per bit goes to the output row
 };
 // PROF: per-phase clocks of thread 0 accumulated into prof[0..7] (CMX_FXCM_PROFILE=1, scripts/gpu_fxcm_time.py)
 template <bool PROF>
@@ -135,19 +138,24 @@ __global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_chunk_kernel_t(FxDev*
       if (ri >= 0) u.rec = &loc.rec[ri & 1];
       if ((q & 7) == 6 && tid >= 128 && tid - 128 < (int)(sizeof(FxByteRec) / 4)) ((uint32_t*)&loc.rec[b & 1])[tid - 128] = ((const uint32_t*)&recs[b])[tid - 128];
     }
+    float* const real_row = u.orow;
+    u.orow = loc.ex[q & 1];
     fx_phase1a_dev(d, &sh, u, tid);
     FX_TICK(0);
+    // the one full barrier of the bit: every wave's table stores (write-through state bytes, trained rows, APM cells) are
+    // complete before another lane may read them (serial walks in 1c, rows in 3, APM cells in 5)
     __syncthreads(); FX_TICK(1);
     if (tid < FX_THREADS) fxd_phase1c(d, &sh, u, tid);
-    __syncthreads(); FX_TICK(2);
+    fx_lds_barrier(); FX_TICK(2);
     if (tid < FX_THREADS) fxd_phase2(d, &sh, u, tid);
-    __syncthreads(); FX_TICK(3);
+    fx_lds_barrier(); FX_TICK(3);
     if (tid < FX_THREADS) fxd_phase3(d, &sh, u, tid);
-    __syncthreads(); FX_TICK(4);
+    fx_lds_barrier(); FX_TICK(4);
     if (tid < FX_THREADS) fxd_phase4(d, &sh, u, tid);
-    __syncthreads(); FX_TICK(5);
+    fx_lds_barrier(); FX_TICK(5);
     if (tid < FX_THREADS) fxd_phase5(d, &sh, u, tid);
-    __syncthreads(); FX_TICK(6);
+    fx_lds_barrier(); FX_TICK(6);
+    for (int i = tid; i < FX_OUTPUTS; i += FX_DEV_THREADS) real_row[i] = loc.ex[q & 1][i];
   }
 #undef FX_TICK
   if (tid < FX_THREADS) fxd_store_shared(d, &sh, tid);
