@@ -246,24 +246,32 @@ FX_HD void fxd_map_ctx_fast(FxDev* d, FxShared* sh, const FxBit& u, int k, int i
       }
       state = sl[cp[i] - cp0[i]];
     }
-    if (state == 0) {
-      ADD(0); if (x->u) ADD(0); ADD(0); ADD(0); ADDQ(64);
-    } else {
+    // every table value of the bit is requested before the first output is stored: the tables are reached through generic
+    // pointers, so a load that follows an LDS store would have to wait for it, one L2 round trip per value
+    const int bposshift = 7 - bpos, c0shift_bpos = (c0 << 1) ^ (256 >> bposshift);
+    const int bb = c0shift_bpos ^ (rn[1] >> bposshift);
+    int p1 = 0;
+    if (state != 0) {
       uint32_t* smt = sh->sm[x->slot_base + i];
       uint32_t* p = &smt[sm_cxt[i]];
       *p += (uint32_t)(y << 19) - (*p >> 13);
       sm_cxt[i] = state;
-      const int p1 = (int)(smt[state] >> 20);
-      ADD(tab[FX_TAB_ST1 + p1]);
-      if (x->u) ADD(tab[FX_TAB_ST2 + p1]);
-      ADD(tab[FX_TAB_ST8 + state]);
-      ADD(tab[FX_TAB_ST32 + state]);
+      p1 = (int)(smt[state] >> 20);
+    }
+    const int v_st1 = state ? tab[FX_TAB_ST1 + p1] : 0, v_st2 = (state && x->u) ? tab[FX_TAB_ST2 + p1] : 0;
+    const int v_st8 = state ? tab[FX_TAB_ST8 + state] : 0, v_st32 = state ? tab[FX_TAB_ST32 + state] : 0;
+    const int v_rc = bb <= 1 ? tab[FX_TAB_RC1 + rn[0] + bb * 256] : 0;
+    if (state == 0) {
+      ADD(0); if (x->u) ADD(0); ADD(0); ADD(0); ADDQ(64);
+    } else {
+      ADD(v_st1);
+      if (x->u) ADD(v_st2);
+      ADD(v_st8);
+      ADD(v_st32);
       ADDQ(0);
       result++;
     }
-    const int bposshift = 7 - bpos, c0shift_bpos = (c0 << 1) ^ (256 >> bposshift);
-    const int bb = c0shift_bpos ^ (rn[1] >> bposshift);
-    ADD(bb <= 1 ? tab[FX_TAB_RC1 + rn[0] + bb * 256] : 0);
+    ADD(v_rc);
   }
 #undef ADD
 #undef ADDQ
@@ -325,25 +333,33 @@ FX_HD void fxd_map_ctx(FxDev* d, FxShared* sh, const FxBit& u, int k, int i) {
         }
         state = t[cp[i]];
       }
-      if (state == 0) {  // mix3 :1077-1097
-        ADD(0); if (x->u) ADD(0); ADD(0); ADD(0); ADDQ(64);
-      } else {
+      // (the table values are requested together, before the first output is stored: see fxd_map_ctx_fast)
+      const uint8_t* run = t + runp[i];
+      const int run0 = run[0], run1 = run[1];
+      const int bposshift = 7 - bpos, c0shift_bpos = (c0 << 1) ^ (256 >> bposshift);
+      const int b = c0shift_bpos ^ (run1 >> bposshift);
+      int p1 = 0;
+      if (state != 0) {
         uint32_t* smt = sh->sm[x->slot_base + i];   // StateMap::set :693-700
         uint32_t* p = &smt[sm_cxt[i]];
         *p += (uint32_t)(y << 19) - (*p >> 13);
         sm_cxt[i] = state;
-        const int p1 = (int)(smt[state] >> 20);
-        ADD(tab[FX_TAB_ST1 + p1]);
-        if (x->u) ADD(tab[FX_TAB_ST2 + p1]);
-        ADD(tab[FX_TAB_ST8 + state]);
-        ADD(tab[FX_TAB_ST32 + state]);
+        p1 = (int)(smt[state] >> 20);
+      }
+      const int v_st1 = state ? tab[FX_TAB_ST1 + p1] : 0, v_st2 = (state && x->u) ? tab[FX_TAB_ST2 + p1] : 0;
+      const int v_st8 = state ? tab[FX_TAB_ST8 + state] : 0, v_st32 = state ? tab[FX_TAB_ST32 + state] : 0;
+      const int v_rc = b <= 1 ? tab[FX_TAB_RC1 + run0 + b * 256] : 0;
+      if (state == 0) {  // mix3 :1077-1097
+        ADD(0); if (x->u) ADD(0); ADD(0); ADD(0); ADDQ(64);
+      } else {
+        ADD(v_st1);
+        if (x->u) ADD(v_st2);
+        ADD(v_st8);
+        ADD(v_st32);
         ADDQ(0);
         result++;
       }
-      const uint8_t* run = t + runp[i];
-      const int bposshift = 7 - bpos, c0shift_bpos = (c0 << 1) ^ (256 >> bposshift);
-      const int b = c0shift_bpos ^ (run[1] >> bposshift);
-      ADD(b <= 1 ? tab[FX_TAB_RC1 + run[0] + b * 256] : 0);
+      ADD(v_rc);
     }
     sh->slot_res[s] = result;
   }
@@ -368,11 +384,18 @@ FX_HD void fxd_map_touch(FxDev* d, FxShared* sh, const FxBit& u, int s) {
   if ((u.rec->skip[s >> 5] >> (s & 31)) & 1) return;
   const int sh_b = x->B == 32 ? 5 : x->B == 64 ? 6 : 7;
   const uint32_t cp = sh->mcp[k][i], runp = sh->mrunp[k][i], cxt = sh->mcxt[k][i];
-  if (cp != FX_NONE) T[n++] = cp >> sh_b;
-  T[n++] = runp >> sh_b;
   const int bpos = u.bpos;
+  const int lookbit = bpos == 0 || bpos == 2 || bpos == 5;
+  if (lookbit) {   // searches read and rewrite bucket headers: contexts interact through a shared BUCKET
+    if (cp != FX_NONE) T[n++] = cp >> sh_b;
+    T[n++] = runp >> sh_b;
+  } else {         // between searches a context only touches its own slot's bytes: they interact through a shared SLOT only
+    const uint32_t first = (uint32_t)(2 * x->A + 1), bm = (uint32_t)x->B - 1, cur0 = sh->mcp0[k][i], run0 = runp - 3;
+    if (cp != FX_NONE) T[n++] = ((cur0 >> sh_b) << 4) | (((cur0 & bm) - first) / 7);
+    T[n++] = ((run0 >> sh_b) << 4) | (((run0 & bm) - first) / 7);
+  }
   sh->mlook[s] = 0;
-  if (!(bpos > 1 && sh->mrun[s][0] == 0) && (bpos == 0 || bpos == 2 || bpos == 5)) {
+  if (!(bpos > 1 && sh->mrun[s][0] == 0) && lookbit) {
     const uint32_t nb = (cxt + (uint32_t)u.c0) & x->tmask;
     T[n++] = nb;
     sh->mlook[s] = 1;
@@ -407,7 +430,7 @@ FX_HD void fxd_map_touch(FxDev* d, FxShared* sh, const FxBit& u, int s) {
       }
     }
   }
-  // into the hash set: a pair another context of the map has put there = an overlap (this lane's own repeats are dropped first)
+  // into the hash set: a key another context of the map has put there = an overlap (this lane's own repeats are dropped first)
   uint32_t* tab = sh->ohash[par];
   for (int a = 0; a < n; a++) {
     int dup = 0;

@@ -73,7 +73,9 @@ __device__ __forceinline__ void fx_train_rows_fast(FxDev* d, FxShared* sh, const
 enum { FX_DEV_THREADS = 512 };
 // a workgroup barrier that orders LDS traffic only (no wait for outstanding global loads / stores, which __syncthreads adds)
 __device__ __forceinline__ void fx_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-__device__ __forceinline__ void fx_phase1a_dev(FxDev* d, FxShared* sh, const FxBit& u, int tid) {
+struct FxApmRows;
+__device__ __forceinline__ void fx_apm_prefetch(FxDev* d, const FxShared* sh, const FxBit& u, FxApmRows* A, int j);
+__device__ __forceinline__ void fx_phase1a_dev(FxDev* d, FxShared* sh, const FxBit& u, FxApmRows* A, int tid) {
   const int wave = tid >> 6, lane = tid & 63;
   if (wave < 2) { if (tid < FX_NSLOTS) fxd_map_touch(d, sh, u, tid); }
   else if (wave < 4) fx_train_rows_fast(d, sh, u, tid - 128);
@@ -91,7 +93,204 @@ __device__ __forceinline__ void fx_phase1a_dev(FxDev* d, FxShared* sh, const FxB
     if (lane == 0) fxd_rcm_unit(d, sh, u);
     else if (lane == 1) { const FxLayout l = fxd_layout(d, u.normal); sh->tx[sh->parity ^ 1][l.tx_lstm] = d->stretch[u.lstmpr]; }
     else if (lane == 2 || lane == 3) fxd_train_small(d, sh, u, 10 + lane - 2);
-  } else if (lane < 6) fxd_apm_update(d, sh, u, lane);
+  } else if (lane < 6) { fxd_apm_update(d, sh, u, lane); fx_apm_prefetch(d, sh, u, A, lane); }
+}
+
+// ---- phase 2 on the device, split (same values as fxd_phase2): part A needs nothing from the context maps -- the failure
+// history (update1 :4784-4790), the dead zones and the selectors without an order term -- and runs on one lane of wave 4
+// UNDER the maps' run phase; part B (after the barrier) sums the maps' return values on 8 lanes and finishes the four
+// selectors that carry ordX / ordW (:4601-4640).
+__device__ __forceinline__ void fx_fail_next(const FxShared* sh, const FxBit& u, uint32_t* fails, uint32_t* failz, uint32_t* failcount) {
+  const int e_l[8] = {1830, 1997, 1973, 1851, 1897, 1690, 1998, 1842};   // :3222
+  uint32_t f = sh->fails, z = sh->failz, c = sh->failcount;
+  if (f & 0x00000080) --c;
+  f *= 2; z *= 2;
+  int pr = sh->pr;
+  if (u.y) pr = 4095 - pr;
+  if (pr >= e_l[u.bpos]) { ++f; ++c; }
+  if (pr >= 848) ++z;
+  *fails = f; *failz = z; *failcount = c;
+}
+__device__ __forceinline__ void fx_phase2a_dev(FxDev* d, FxShared* sh, const FxBit& u) {
+  if (u.boundary)
+    for (int i = 0; i < FX_NMIX1; i++)
+      sh->mx_elim[i] = (sh->fails & 255) == 0 ? fxd_max(256, sh->mx_elim[i] + 1) : fxd_max(0, fxd_min(16, sh->mx_elim[i] - 1));
+  uint32_t f, z, c_;
+  fx_fail_next(sh, u, &f, &z, &c_);
+  sh->fails = f; sh->failz = z; sh->failcount = c_;
+  const FxByteRec* r = u.rec;
+  const int bpos = u.bpos, c0b = u.c0 << (8 - bpos);
+  const uint32_t s2 = r->s2, s3 = r->s3, s3R = r->s3R, BrFc = r->BrFc, words = r->words, FcIdx = r->FcIdx, isPar = r->isPar;
+  const uint32_t isMatch = (uint32_t)sh->isMatch;
+  const uint8_t* w2b = d->wrt;
+  const uint8_t* w3b = w2b + 256;
+  int* cx = sh->mx_cxt;
+  int c;
+  if (bpos == 0) cx[0] = (int)((s2 & 255) * 8 + (s3 & 7));
+  else if (bpos > 3) cx[0] = (int)((((s2 << 2) & 255) + w2b[c0b & 255]) * 8 + BrFc);
+  else cx[0] = (int)((s2 & 255) * 8 + BrFc);
+  if (bpos) {
+    c = c0b;
+    if (bpos == 1) c = c + 16 * (int)(words * 2 & 4);
+    else if (bpos > 3) c = w2b[c0b & 255] * 64;
+    c = fxd_min(bpos, 5) * 256 + (int)(s3R & 7) + (int)FcIdx * 8 + (c & 192);
+  } else c = (int)((words & 12) * 16 + (s3R & 7) + BrFc * 8);
+  cx[1] = c;
+  cx[6] = (int)((s3R & 0xff8) * 4 + ((2 * words) & 0x1c) + (s2 & 3));
+  c = c0b;
+  cx[3] = bpos * 256 + (int)((((((uint32_t)r->numbers | words) << bpos) & 255) >> bpos) | ((uint32_t)c & 255));
+  if (bpos > 2) cx[7] = (int)(((s3 & 7) * 8 + w3b[c0b & 255]) * 256 + BrFc * 32 + (words & 7) * 4 + isPar + (isMatch ? 2u : 0u));
+  else cx[7] = (int)(((s3 & 63) * 256 + BrFc * 16 + (words & 7) * 2 + isPar) | (isMatch ? 128u : 0u));
+  cx[8] = (int)r->deccode;
+  cx[9] = (bpos << 8) * 4 + (int)(f & 3) * 256 + u.lstmex;
+  cx[11] = 0;
+}
+__device__ __forceinline__ void fx_phase2b_dev(FxDev* d, FxShared* sh, const FxBit& u, int lane, int* res8_s) {   // wave 0
+  const int which[8] = {0, 1, 2, 3, 4, 5, 21, 23};
+  if (lane < 8) {
+    int v = 0;
+    if (u.normal) { const FxMapDev* x = &d->maps[which[lane]]; for (int i = 0; i < x->C; i++) v += sh->slot_res[x->slot_base + i]; }
+    res8_s[lane] = v;
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
+  if (lane != 0) return;
+  const FxByteRec* r = u.rec;
+  const int bpos = u.bpos, c0b = u.c0 << (8 - bpos);
+  int ordX = 0, ordW = 0;
+  if (u.normal) {
+    const int b0 = d->maps[0].slot_base;
+    int skipped = 0;
+    for (int i = 0; i < 3; i++) skipped |= (int)((r->skip[(b0 + i) >> 5] >> ((b0 + i) & 31)) & 1);
+    if (skipped) ordX = 2;
+    ordX += res8_s[0];
+    if (ordX == 3) ordX = 2;
+    ordX += res8_s[1] + res8_s[2] + res8_s[3];
+    ordW = res8_s[4] + res8_s[5];
+    if (ordW > 3) ordW = 3;
+    ordW += res8_s[6] + res8_s[7];
+  }
+  const uint32_t s2 = r->s2, s3 = r->s3, BrFc = r->BrFc, words = r->words, FcIdx = r->FcIdx, isPar = r->isPar;
+  const uint32_t isMatch = (uint32_t)sh->isMatch;
+  int* cx = sh->mx_cxt;
+  cx[2] = (int)(((4 * words) & 0xf0) * 4 + (uint32_t)ordX * 256 * 4 + (s2 & 63));
+  cx[10] = (int)(((uint32_t)ordX * 8 + (BrFc ? 1u : 0u) * 4 + (s2 & 3)) * 2 + (words & 1));
+  int c = c0b;
+  if (bpos) {
+    if (bpos == 1) c = c + 16 * (int)(s3 & 7);
+    else if (bpos == 2) c = c + 16 * (int)(s2 & 3);
+    else if (bpos == 3) c = c + 16 * (int)(words & 1);
+    else c = bpos + (c & 0xf0);
+    if (bpos < 5) c = bpos + (c & 0xf0);
+  } else c = 16 * (int)(s2 & 0xf);
+  ordX = ordX - 1;
+  if (ordX < 0) ordX = 0;
+  if (isMatch) ordX = ordX + 1;
+  cx[4] = c + ordX * 256 + 8 * (int)isPar;
+  cx[5] = (int)(((uint32_t)ordW * 256 + (s2 & 0xf0) + ((s3 & 0x38) >> 2)) * 4 + FcIdx);
+}
+
+// ---- phase 3 on the device (same values as fxd_phase3): the ten weight pairs are requested together, then multiplied
+__device__ __forceinline__ void fx_phase3_dev(FxDev* d, FxShared* sh, const FxBit& u, int tid) {
+  fxd_map_clear_next(sh, u, tid);
+  const uint32_t t = reinterpret_cast<const uint32_t*>(sh->tx[sh->parity ^ 1])[tid];
+  uint32_t w[FX_NMIX1];
+#pragma unroll
+  for (int k = 0; k < FX_NMIX1; k++) w[k] = reinterpret_cast<const uint32_t*>(d->wx[k] + (size_t)sh->mx_cxt[k] * FX_TX)[tid];
+#pragma unroll
+  for (int k = 0; k < FX_NMIX1; k++) sh->part[k][tid] = fx_pair_dot(t, w[k]);
+}
+
+// ---- phase 5 on the device (same values as fxd_phase5): the ten first-layer finals on ten lanes, the two final mixers on
+// two, the six APMs as a three-level tree (0, 1, 2 | 3, 4 | 5) reading the context rows a lane of wave 7 fetched into LDS
+// during phase 1a -- every APM context is known when the bit starts (c0, the parser's hashes, the failure history).
+struct FxApmRows { uint32_t cx[6]; uint16_t row[6][34]; };
+__device__ __forceinline__ void fx_apm_ctx(const FxShared* sh, const FxBit& u, uint32_t cx[6]) {   // update1 :4792-4826
+  uint32_t fails, failz, failcount;
+  fx_fail_next(sh, u, &fails, &failz, &failcount);
+  const uint32_t tri[4] = {0, 4, 3, 7}, trj[4] = {0, 6, 6, 12};
+  const FxByteRec* r = u.rec;
+  const uint32_t c0 = (uint32_t)u.c0;
+  int pz = (int)failcount + 1;
+  pz += (int)tri[(fails >> 5) & 3];
+  pz += (int)trj[(fails >> 3) & 3];
+  pz += (int)trj[(fails >> 1) & 3];
+  if (fails & 1) pz += 8;
+  pz = pz / 2;
+  cx[0] = c0;
+  cx[3] = ((c0 * 2) ^ r->AH1) & 0x3ffff;
+  cx[1] = ((c0 * 8) ^ fxd_hash3(29, failz & 2047, 0xffffffffu)) & 0xffff;
+  cx[4] = ((fails & 255) ? fxd_hash3(c0, r->s2 & 0xfffc, r->s3R & 0x1ff) : fxd_hash3(c0, (r->s2R & 0xfffc) + 0x10000, r->s3R & 0x1ff)) & 0x3ffff;
+  cx[2] = ((c0 * 32) ^ r->AH2) & 0xffff;
+  cx[5] = ((c0 * 4) ^ fxd_hash3((uint32_t)fxd_min(9, pz), r->x5 & 0x80ff, 0xffffffffu)) & 0x3ffff;
+}
+__device__ __forceinline__ void fx_apm_prefetch(FxDev* d, const FxShared* sh, const FxBit& u, FxApmRows* A, int j) {   // after this lane's fxd_apm_update
+  uint32_t cx[6];
+  fx_apm_ctx(sh, u, cx);
+  const uint16_t* p = d->apm_t[j] + (size_t)cx[j] * 33;
+  uint16_t v[33];
+#pragma unroll
+  for (int q = 0; q < 33; q++) v[q] = p[q];
+#pragma unroll
+  for (int q = 0; q < 33; q++) A->row[j][q] = v[q];
+  A->cx[j] = cx[j];
+}
+__device__ __forceinline__ int fx_apm_row_p(const FxDev* d, FxShared* sh, const FxApmRows* A, int j, int pr) {   // fxd_apm_p on the fetched row
+  pr = d->stretch[pr];
+  const int w = pr & 127, i = (pr + 2048) >> 7;
+  sh->apm_index[j] = i + (int)A->cx[j] * 33;
+  return (A->row[j][i] * (128 - w) + A->row[j][i + 1] * w) >> 11;
+}
+__device__ __forceinline__ void fx_phase5_dev(FxDev* d, FxShared* sh, const FxBit& u, const FxApmRows* A, int lane, int* scr) {   // wave 0; scr: 16 ints of LDS
+  const FxLayout l = fxd_layout(d, u.normal);
+  float* ex = u.orow + l.exp_mix;
+  if (lane < FX_NMIX1) {   // p1 :641-651, mxInputs2.add
+    const int k = lane;
+    uint32_t s = 0;
+    for (int g = 0; g < 16; g++) s += (uint32_t)sh->part2[k][g];
+    int dp = (int32_t)(s * (uint32_t)d->mx_shift[k]) >> 11;
+    dp = fxd_clp(dp);
+    sh->mx_pr[k] = fxd_squash(d, dp);
+    sh->in2[k] = (int16_t)dp;
+    ex[k] = fxd_export(d, dp);
+  }
+  if (lane == 10) sh->in2[10] = (int16_t)(d->stretch[u.lstmpr] / 2);
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
+  if (lane < 2) {
+    const int k = 10 + lane;
+    int dp = (int32_t)((uint32_t)fxd_dot16(sh->in2, d->wx[k] + (size_t)sh->mx_cxt[k] * 16) * (uint32_t)d->mx_shift[k]) >> 11;
+    dp = fxd_clp(dp);
+    sh->mx_pr[k] = fxd_squash(d, dp);
+    scr[lane] = dp;
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
+  const int pr = fxd_squash(d, (scr[0] * 7 + scr[1] + 4) >> 3);
+  // level 1: APM 0, 1, 2 on pr
+  if (lane < 3) scr[4 + lane] = fx_apm_row_p(d, sh, A, lane, pr);
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
+  const int pu1 = (scr[4] + 7 * pr + 4) >> 3, pv1 = scr[5], pt = scr[6];
+  // level 2: APM 3 on pu, APM 4 on pv
+  if (lane == 0) scr[8] = fx_apm_row_p(d, sh, A, 3, pu1);
+  if (lane == 1) scr[9] = fx_apm_row_p(d, sh, A, 4, pv1);
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
+  if (lane != 0) return;
+  const int pu = scr[8], pv = scr[9];
+  const int pz = fx_apm_row_p(d, sh, A, 5, pu);
+  ex += FX_NMIX1;
+#define EXPV(v) (*ex++ = (float)(v) * (float)(1.0 / 4095))
+  EXPV(pr); EXPV(pu); EXPV(pv1); EXPV(pv); EXPV(pt); EXPV(pz);
+  int fin;
+  if (sh->fails & 255) fin = (pt * 6 + pu + pv * 11 + pz * 14 + 31) >> 5;
+  else fin = (pt * 4 + pu * 5 + pv * 12 + pz * 11 + 31) >> 5;
+  EXPV(fin);
+#undef EXPV
+  while (ex < u.orow + FX_OUTPUTS) *ex++ = 0.5f;   // slots no AddPrediction reaches keep the constructor's 0.5 (:94)
+  sh->pr = fin;
+  sh->parity ^= 1;
 }
 
 // Everything the bit loop reads lives in LDS: FxShared (inputs, StateMaps, per-context registers), a working COPY of the
@@ -105,6 +304,7 @@ struct FxLocal {
   uint8_t wrt[512];
   uint8_t sta[6][1024];
   FxByteRec rec[2];
+  FxApmRows apm;
   float ex[2][FX_OUTPUTS + 1];   // the bit's 431 exported values (two parities: the copy-out of bit q runs under bit q + 1): the units write here, one coalesced copy per bit goes to the output row
 };
 // PROF: per-phase clocks of thread 0 accumulated into prof[0..7] (CMX_FXCM_PROFILE=1, scripts/gpu_fxcm_time.py)
@@ -115,6 +315,7 @@ __global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_chunk_kernel_t(FxDev*
   FxShared& sh = *(FxShared*)fx_smem;
   FxLocal& loc = *(FxLocal*)(fx_smem + ((sizeof(FxShared) + 15) & ~(size_t)15));
   FxDev* d = &loc.dev;
+  __shared__ int res8_s[8], scr_s[16];
   const int tid = threadIdx.x;
   for (int i = tid; i < (int)(sizeof(FxDev) / 4); i += FX_DEV_THREADS) ((uint32_t*)d)[i] = ((const uint32_t*)gd)[i];
   for (int i = tid; i < 4095; i += FX_DEV_THREADS) loc.squash[i] = gd->squash[i];
@@ -140,20 +341,22 @@ __global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_chunk_kernel_t(FxDev*
     }
     float* const real_row = u.orow;
     u.orow = loc.ex[q & 1];
-    fx_phase1a_dev(d, &sh, u, tid);
+    fx_phase1a_dev(d, &sh, u, &loc.apm, tid);
     FX_TICK(0);
     // the one full barrier of the bit: every wave's table stores (write-through state bytes, trained rows, APM cells) are
     // complete before another lane may read them (serial walks in 1c, rows in 3, APM cells in 5)
     __syncthreads(); FX_TICK(1);
     if (tid < FX_THREADS) fxd_phase1c(d, &sh, u, tid);
+    else if (tid == 256) fx_phase2a_dev(d, &sh, u);   // wave 4, under the maps
+    FX_TICK(7);
     fx_lds_barrier(); FX_TICK(2);
-    if (tid < FX_THREADS) fxd_phase2(d, &sh, u, tid);
+    if (tid < 64) fx_phase2b_dev(d, &sh, u, tid, res8_s);
     fx_lds_barrier(); FX_TICK(3);
-    if (tid < FX_THREADS) fxd_phase3(d, &sh, u, tid);
+    if (tid < FX_THREADS) fx_phase3_dev(d, &sh, u, tid);
     fx_lds_barrier(); FX_TICK(4);
     if (tid < FX_THREADS) fxd_phase4(d, &sh, u, tid);
     fx_lds_barrier(); FX_TICK(5);
-    if (tid < FX_THREADS) fxd_phase5(d, &sh, u, tid);
+    if (tid < 64) fx_phase5_dev(d, &sh, u, &loc.apm, tid, scr_s);
     fx_lds_barrier(); FX_TICK(6);
     for (int i = tid; i < FX_OUTPUTS; i += FX_DEV_THREADS) real_row[i] = loc.ex[q & 1][i];
   }

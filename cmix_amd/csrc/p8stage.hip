@@ -343,6 +343,20 @@ __global__ __launch_bounds__(MX_THREADS) void cmx_p8s_mix_kernel(const P8MixDev*
   if (tid == 0) T->pr = fin_s;
 }
 
+// Pointers read out of structures are "generic" to the compiler: it has to use flat_load / flat_store for them, which count
+// on BOTH memory counters (they might address LDS), so an LDS-only barrier would still wait for every outstanding table
+// access. Everything the kernels below reach through such pointers is HBM: say so.
+#define MX_GLOBAL __attribute__((address_space(1)))
+typedef uint32_t mx_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 mx_gload4(const MX_GLOBAL int16_t* row, int grp) {   // 16-byte group grp of a weight row
+  const mx_u4 v = reinterpret_cast<const MX_GLOBAL mx_u4*>(row)[grp];
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void mx_gstore4(MX_GLOBAL int16_t* row, int grp, uint4 v) {
+  mx_u4 o; o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w;
+  reinterpret_cast<MX_GLOBAL mx_u4*>(row)[grp] = o;
+}
+
 // A workgroup barrier that orders LDS traffic only. __syncthreads() also waits for every outstanding global load and
 // store of the wave (s_waitcnt vmcnt(0)), which would serialise the one-bit-ahead requests below with the barriers of
 // the bit; the kernel's cross-lane traffic through global memory is handled where it occurs.
@@ -396,7 +410,7 @@ __global__ __launch_bounds__(MX_THREADS) void cmx_p8s_mix2_kernel(const P8MixDev
   // full L2 round trip on the bit's critical path (and the compiler must redo it after each global store). Base pointers
   // go to registers here; the per-step records (28 selectors, the order, the APM contexts, the coded bit) travel through
   // an LDS ring, loaded two steps ahead by a few lanes of wave 5 and written at the end of the step.
-  int16_t* const wx = M->wx; int16_t* const wx2 = M->wx2;
+  MX_GLOBAL int16_t* const wx = (MX_GLOBAL int16_t*)M->wx; MX_GLOBAL int16_t* const wx2 = (MX_GLOBAL int16_t*)M->wx2;
   const int nx_first = M->nx_first;
   __shared__ int32_t ring_sel[4][P8_NSEL];
   __shared__ uint32_t ring_apm[4][6];     // P8ApmRec = 24 bytes
@@ -405,12 +419,12 @@ __global__ __launch_bounds__(MX_THREADS) void cmx_p8s_mix2_kernel(const P8MixDev
   const bool chain = wave == 1 && lane < 7;
   // the table this lane fetches one cell of (waves 1..4) / updates (chain lanes), for either block type
   const int fl = tid - 64, fj = fl >= 0 && fl < 7 * 36 ? fl / 36 : (chain ? lane : 0), fk = fl >= 0 ? fl % 36 : 0;
-  uint32_t* const tb_apm = fj < 4 ? T->apm[fj] : nullptr;
-  uint16_t* const tb_apm1 = fj >= 4 ? T->apm1[fj - 4] : nullptr;
-  uint16_t* const tb_gen = T->gen[fj];
-  uint32_t* const my_apm = chain && lane < 4 ? T->apm[lane] : nullptr;
-  uint16_t* const my_apm1 = chain && lane >= 4 ? T->apm1[lane - 4] : nullptr;
-  uint16_t* const my_gen = chain ? T->gen[lane] : nullptr;
+  MX_GLOBAL uint32_t* const tb_apm = (MX_GLOBAL uint32_t*)(fj < 4 ? T->apm[fj] : nullptr);
+  MX_GLOBAL uint16_t* const tb_apm1 = (MX_GLOBAL uint16_t*)(fj >= 4 ? T->apm1[fj - 4] : nullptr);
+  MX_GLOBAL uint16_t* const tb_gen = (MX_GLOBAL uint16_t*)T->gen[fj];
+  MX_GLOBAL uint32_t* const my_apm = (MX_GLOBAL uint32_t*)(chain && lane < 4 ? T->apm[lane] : nullptr);
+  MX_GLOBAL uint16_t* const my_apm1 = (MX_GLOBAL uint16_t*)(chain && lane >= 4 ? T->apm1[lane - 4] : nullptr);
+  MX_GLOBAL uint16_t* const my_gen = (MX_GLOBAL uint16_t*)(chain ? T->gen[lane] : nullptr);
   auto ring_load = [&](int ts, uint32_t& v) {   // wave 5: lanes 0..27 selectors, 28 order, 29 bit, 32..37 APM record
     if (wave != 5 || ts >= nbits) return;
     if (lane < P8_NSEL) v = (uint32_t)sel[(size_t)ts * P8_NSEL + lane];
@@ -439,10 +453,10 @@ __global__ __launch_bounds__(MX_THREADS) void cmx_p8s_mix2_kernel(const P8MixDev
   uint4 w[4][4], wn[4][4];
   int row[4], rown[4];
   uint4 xn = make_uint4(0, 0, 0, 0);
-#define MX_LOAD_G(dst, q, g, wr_) { const int grp_ = lane + 64 * (g); dst[q][g] = grp_ < MX_GROUPS ? (wr_)[grp_] : make_uint4(0, 0, 0, 0); }
+#define MX_LOAD_G(dst, q, g, wr_) { const int grp_ = lane + 64 * (g); if (grp_ < MX_GROUPS) dst[q][g] = mx_gload4(wr_, grp_); else dst[q][g] = make_uint4(0, 0, 0, 0); }
 #define MX_LOAD_ROW(dst, q, rowid)                                                               \
   {                                                                                               \
-    const uint4* wr_ = reinterpret_cast<const uint4*>(wx + (size_t)(rowid) * P8_NX);            \
+    const MX_GLOBAL int16_t* wr_ = wx + (size_t)(rowid) * P8_NX;                                \
     MX_LOAD_G(dst, q, 0, wr_) MX_LOAD_G(dst, q, 1, wr_) MX_LOAD_G(dst, q, 2, wr_) MX_LOAD_G(dst, q, 3, wr_) \
   }
 #define MX_LOAD_SET(dst, r, ts, q, ord_)                                                         \
@@ -564,7 +578,7 @@ __global__ __launch_bounds__(MX_THREADS) void cmx_p8s_mix2_kernel(const P8MixDev
       __builtin_amdgcn_s_waitcnt(0);
       __builtin_amdgcn_wave_barrier();
       uint32_t acc = 0;
-      if (lane < 16) acc = pair_dot(st_s[lane], reinterpret_cast<const uint32_t*>(wx2)[lane]);
+      if (lane < 16) acc = pair_dot(st_s[lane], reinterpret_cast<const MX_GLOBAL uint32_t*>(wx2)[lane]);
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
       if (lane == 0) p_s = p8s_squash(squash, (int32_t)acc >> 9);
@@ -610,7 +624,7 @@ __global__ __launch_bounds__(MX_THREADS) void cmx_p8s_mix2_kernel(const P8MixDev
     for (int qq = 0; qq < 4; ++qq) {
       const int q = qq == 2 ? 3 : qq == 3 ? 2 : qq;   // set 26 (q == 2 of wave 6) last: its next row was requested a moment ago
       const int err = (int)(int16_t)(((yb << 12) - pr_s[4 * wave + q]) * 7);
-      uint4* wr = reinterpret_cast<uint4*>(wx + (size_t)row[q] * P8_NX);
+      MX_GLOBAL int16_t* wr = wx + (size_t)row[q] * P8_NX;
       const bool again = more && rown[q] == row[q];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -620,7 +634,7 @@ __global__ __launch_bounds__(MX_THREADS) void cmx_p8s_mix2_kernel(const P8MixDev
           const uint4 xv = reinterpret_cast<const uint4*>(xs[buf])[grp];
           v.x = pair_train(xv.x, v.x, err); v.y = pair_train(xv.y, v.y, err);
           v.z = pair_train(xv.z, v.z, err); v.w = pair_train(xv.w, v.w, err);
-          wr[grp] = v;
+          mx_gstore4(wr, grp, v);
         }
         if (wave == 6 && q == 2) w[q][g] = v;   // resolved at the top of the next step, when the late request has arrived
         else w[q][g] = again ? v : wn[q][g];
@@ -631,7 +645,7 @@ __global__ __launch_bounds__(MX_THREADS) void cmx_p8s_mix2_kernel(const P8MixDev
 
     if (wave == 0 && lane < 16) {
       const int err2 = (int)(int16_t)(((yb << 12) - p_s) * 7);
-      uint32_t* w2 = reinterpret_cast<uint32_t*>(wx2);
+      MX_GLOBAL uint32_t* w2 = reinterpret_cast<MX_GLOBAL uint32_t*>(wx2);
       if (err2) w2[lane] = pair_train(st_s[lane], w2[lane], err2);
     }
     ring_store(t + 2, ring_v);

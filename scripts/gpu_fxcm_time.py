@@ -43,4 +43,4 @@ if os.environ.get("CMX_FXCM_PROFILE") == "1":
     if E.lib().cmx_fxcm_profile(fx.h, acc) == 0:
         nb = 8.0 * 1024 * (nchunks + 4)
         for w in range(8):
-            print("wave %d clocks per bit by phase (1a work, 1a barrier, 1c, 2, 3, 4, 5):" % w, " ".join("%6.0f" % (acc[8 * w + i] / nb) for i in range(7)), "| total %.0f" % (sum(acc[8 * w + i] for i in range(7)) / nb))
+            print("wave %d clocks per bit by phase (1a work, 1a barrier, 1c, 2, 3, 4, 5):" % w, " ".join("%6.0f" % (acc[8 * w + i] / nb) for i in range(7)), "| 1c work %.0f | total %.0f" % (acc[8 * w + 7] / nb, sum(acc[8 * w + i] for i in range(8)) / nb))
