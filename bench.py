@@ -37,6 +37,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# every stage of a stream runs on its own HIP stream (9 per stream); HIP multiplexes streams onto 4 hardware queues by
+# default, which would serialise stage kernels that are meant to overlap: ask for one queue per stream before HIP starts
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBS = 8000.0
 # algorithmic HBM bytes per input byte: weights touched per bit x 8 B (read + write) x 8 bits

@@ -64,6 +64,7 @@ void CompressEngine(Predictor* P, const std::vector<uint8_t>& data, cmx_encoder_
 }  // namespace
 
 int main(int argc, char* argv[]) {
+  setenv("GPU_MAX_HW_QUEUES", "16", 0);   // one hardware queue per stage stream (HIP's default of 4 would serialise the stages)
   if (argc < 4 || argc > 5 || strlen(argv[1]) != 2 || argv[1][0] != '-' || (argv[1][1] != 'c' && argv[1][1] != 'n'))
     return Help();
   const bool enable_preprocess = argv[1][1] == 'c';
