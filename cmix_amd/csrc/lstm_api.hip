@@ -26,6 +26,8 @@ extern "C" __global__ void cmx_lstm_fwd(const LstmState, const uint8_t*, size_t,
 extern "C" __global__ void cmx_lstm_bptt_seq(const LstmState);
 extern "C" __global__ void cmx_lstm_bptt_acc(const LstmState, int, int);
 extern "C" __global__ void cmx_lstm_bptt_gb(const LstmState, int, int);
+extern "C" __global__ void cmx_lstm_fwdblk(const LstmState, const uint8_t*, const float*, float*, size_t, int, int, int);
+extern "C" __global__ void cmx_lstm_bpttblk(const LstmState);
 extern "C" __global__ void cmx_bytemodel_bits(const float*, const float*, const uint8_t*, size_t, float*, int*, size_t, int,
                                               float*);
 
@@ -38,6 +40,8 @@ struct cmx_lstm {
   std::vector<void*> allocs;
   float* d_prev_probs = nullptr;  // byte distribution at chunk start
   uint64_t bytes_done = 0;
+  int hc = 0;                // which hid[] / stateb[] buffer holds the current hidden_ / state_
+  size_t fb_lds = 0, bp_lds = 0;   // dynamic LDS of the block kernels (lstm_block.hip)
   uint64_t bptt_rounds = 0;  // LstmLayer::update_steps_ = min(rounds, 3000) (lstm-layer.cpp:131-133)
   // one epoch-aligned block of 100 bytes (BPTT round + 100 x (SGD, forward) = 204 launches) captured once and
   // replayed with one hipGraphLaunch: the per-byte launch rate, not the GPU, limits how many streams one host
@@ -166,6 +170,8 @@ cmx_lstm_t* cmx_lstm_create(const uint8_t vocab[256], int skip_rand, int device)
     S.tanh_state[l] = dallocf((size_t)LSTM_H * LSTM_C, nullptr);
     S.in_gate_state[l] = dallocf((size_t)LSTM_H * LSTM_C, nullptr);
     S.state[l] = dallocf(LSTM_C, nullptr);
+    S.stateb[0][l] = S.state[l];
+    S.stateb[1][l] = dallocf(LSTM_C, nullptr);
     std::vector<float> li((size_t)LSTM_H * S.insz[l], 0.0f);
     for (int e = 0; e < LSTM_H; ++e) li[(size_t)e * S.insz[l] + S.insz[l] - 1] = 1.0f;  // lstm.cpp:21-23
     S.layer_input[l] = dallocf(li.size(), li.data());
@@ -215,6 +221,24 @@ cmx_lstm_t* cmx_lstm_create(const uint8_t vocab[256], int skip_rand, int device)
     h->d_prev_probs = dallocf(256, bp.data());
   }
   S.dyn = (int*)dallocf(4, nullptr);
+  S.sync = (LstmSync*)dallocf((sizeof(LstmSync) + 3) / 4, nullptr);
+  S.raw_ring = dallocf((size_t)LSTM_L * LSTM_H * 3 * LSTM_C, nullptr);
+  S.h_ring = dallocf((size_t)LSTM_H * LSTM_NH, nullptr);
+  S.logit_ring = dallocf((size_t)LSTM_H * LSTM_VP, nullptr);
+  S.bp_pub = dallocf((size_t)2 * LSTM_H * 2 * LSTM_C, nullptr);
+  {
+    // dynamic LDS of the block kernels (the carve-up is in lstm_block.hip)
+    const size_t nq1 = (size_t)(S.insz[1] + 3) / 4;
+    const size_t gate = nq1 * LSTM_FB_R * 16 + (836 + 3 * LSTM_C + 4 + 256) * 4;
+    const size_t ro = (size_t)(V + LSTM_FB_GO - 1) / LSTM_FB_GO, rp = ro | 1;
+    const size_t outl = (size_t)((LSTM_NH + 3) / 4) * rp * 16 + (2 * 404 + 256 + 256 + 36 + 36 + 4) * 4;
+    h->fb_lds = gate > outl ? gate : outl;
+    h->bp_lds = (size_t)9 * 50 * LSTM_BP_J * 16 +
+                ((size_t)3 * 256 * LSTM_BP_J + 3 * 256 + 3 * LSTM_C + 3 * LSTM_C + 4 + 6 * LSTM_BP_J) * 4;
+    if (hipFuncSetAttribute((const void*)cmx_lstm_fwdblk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->fb_lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cmx_lstm_bpttblk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bp_lds) != hipSuccess)
+      fail = true;
+  }
   S.blk = (LstmBlockArgs*)dallocf((sizeof(LstmBlockArgs) + 3) / 4 + 4, nullptr);
   if (fail) {
     cmx_set_err("cmx_lstm_create: hipMalloc failed");
@@ -237,13 +261,43 @@ int cmx_lstm_run(cmx_lstm_t* h, const float* d_in_probs, const uint8_t* d_bytes,
   const int V = S.V;
   (void)hipMemcpyAsync(h->d_prev_probs, S.byte_probs, 256 * 4, hipMemcpyDeviceToDevice, st);
   static const bool use_graph = !(getenv("CMX_LSTM_NOGRAPH") && getenv("CMX_LSTM_NOGRAPH")[0] == '1');
+  static const bool v1 = getenv("CMX_LSTM_V1") && getenv("CMX_LSTM_V1")[0] == '1';            // one-workgroup kernels
+  static const bool bptt_v1 = getenv("CMX_LSTM_BPTT_V1") && getenv("CMX_LSTM_BPTT_V1")[0] == '1';
+  if (!v1 && !d_in_probs) { cmx_set_err("cmx_lstm_run: d_in_probs is required"); return 1; }
+  auto sync_reset = [&]() {
+    return hipMemsetAsync((char*)S.sync + 16, 0, sizeof(LstmSync) - 16, st) == hipSuccess;
+  };
   for (size_t n = 0; n < nbytes;) {
     const int e = (int)(h->bytes_done % LSTM_H);   // Lstm::epoch_
-    const int hc = (int)(h->bytes_done & 1);       // which hid[] buffer holds hidden_
+    const int hc = h->hc;                          // which hid[] buffer holds hidden_
     int us = 0;
     if (e == 0) {
       h->bptt_rounds += 1;
       us = (int)(h->bptt_rounds < LSTM_UPDATE_LIMIT ? h->bptt_rounds : LSTM_UPDATE_LIMIT);
+    }
+    if (!v1) {
+      // multi-workgroup path (lstm_block.hip): [bookkeeping, BPTT round] at an epoch-0 byte, then ONE launch for the
+      // bytes up to the end of the block
+      if (e == 0) {                                // lstm.cpp:93
+        hipLaunchKernelGGL(cmx_lstm_prep, dim3(1), dim3(256), 0, st, S, d_in_probs + n * 256, d_bytes, n, e, -1);
+        if (bptt_v1) {
+          hipLaunchKernelGGL(cmx_lstm_bptt_seq, dim3(S.xcd >= 0 ? 8 : 1), dim3(1024), 0, st, S);
+        } else {
+          if (!sync_reset()) { cmx_set_err("cmx_lstm_run: hipMemsetAsync failed"); return 1; }
+          hipLaunchKernelGGL(cmx_lstm_bpttblk, dim3(LSTM_BP_G), dim3(LSTM_BP_THREADS), h->bp_lds, st, S);
+        }
+        hipLaunchKernelGGL(cmx_lstm_bptt_acc, dim3((S.rowlen[1] + 63) / 64, LSTM_C / 4, 6), dim3(64, 4), 0, st, S, us, -1);
+        hipLaunchKernelGGL(cmx_lstm_bptt_gb, dim3(6), dim3(256), 0, st, S, us, -1);
+      }
+      const size_t left = nbytes - n;
+      const int cnt = (int)(left < (size_t)(LSTM_H - e) ? left : (size_t)(LSTM_H - e));
+      if (!sync_reset()) { cmx_set_err("cmx_lstm_run: hipMemsetAsync failed"); return 1; }
+      hipLaunchKernelGGL(cmx_lstm_fwdblk, dim3(2 * LSTM_FB_GL + LSTM_FB_GO), dim3(LSTM_FB_THREADS), h->fb_lds, st, S, d_bytes,
+                         d_in_probs, d_out_probs, n, cnt, e, hc);
+      h->hc ^= 1;
+      h->bytes_done += cnt;
+      n += cnt;
+      continue;
     }
     if (e == 0 && nbytes - n >= LSTM_H && use_graph && lstm_build_graph(h)) {
       LstmBlockArgs a;
@@ -255,6 +309,7 @@ int cmx_lstm_run(cmx_lstm_t* h, const float* d_in_probs, const uint8_t* d_bytes,
       continue;
     }
     lstm_launch_byte(h, st, d_in_probs, d_bytes, n, d_out_probs, e, hc, us, -1);
+    h->hc ^= 1;
     h->bytes_done += 1;
     ++n;
   }
@@ -266,6 +321,16 @@ int cmx_lstm_run(cmx_lstm_t* h, const float* d_in_probs, const uint8_t* d_bytes,
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { cmx_set_err(std::string("cmx_lstm_run: ") + hipGetErrorString(e)); return 1; }
   return 0;
+}
+
+// 1 = a bounded in-launch wait of a block kernel ran out (the stream's LSTM results are void); synchronises the device
+int cmx_lstm_failed(cmx_lstm_t* h) {
+  if (!h) return 1;
+  (void)hipSetDevice(h->device);
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  unsigned f = 0;
+  if (hipMemcpy(&f, &h->h_state.sync->fail, 4, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+  return f ? 1 : 0;
 }
 
 int cmx_bytemodel_bits_run(int device, const float* d_dist0, const float* d_dist_rest, const uint8_t* d_bytes,

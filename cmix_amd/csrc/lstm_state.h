@@ -10,6 +10,24 @@
 #define LSTM_NH 401    // hidden_ size = C*L + 1 (bias)
 #define LSTM_VP 256    // padded vocabulary stride
 #define LSTM_UPDATE_LIMIT 3000
+// workgroup geometry of the block kernels (lstm_block.hip)
+#define LSTM_FB_GL 12       // workgroups per gate layer in the forward block
+#define LSTM_FB_R 50        //   gate rows per workgroup (12 x 50 = 3 gates x 200 cells)
+#define LSTM_FB_GO 8        // workgroups of the output layer
+#define LSTM_FB_THREADS 256
+#define LSTM_BP_G 20        // workgroups of the sequential BPTT part
+#define LSTM_BP_J 10        //   cells per workgroup
+#define LSTM_BP_THREADS 512
+
+// In-launch hand-off counters of the block kernels; everything after `fail` is zeroed ahead of every launch.
+struct LstmSync {
+  unsigned fail;                           // sticky: a bounded wait ran out (cmx_lstm_failed)
+  unsigned pad[3];
+  unsigned raw_cnt[LSTM_L][LSTM_H];        // workgroups of a gate layer that delivered their raw sums of epoch e
+  unsigned h_flag[LSTM_L][LSTM_H];         // the layer's hidden vector of epoch e is in h_ring
+  unsigned logit_cnt[LSTM_H];              // output-layer workgroups that delivered their logits of epoch e
+  unsigned bp_cnt[2 * LSTM_H];             // BPTT workgroups that delivered step s
+};
 
 // Arguments of one epoch-aligned block of 100 bytes (one BPTT round + 100 x (SGD, forward)) replayed as a
 // HIP graph: the graph's kernel parameters are frozen at capture, so everything that changes per block is
@@ -50,7 +68,8 @@ struct LstmState {
   float* last_state[LSTM_L];     // [H][C]
   float* tanh_state[LSTM_L];     // [H][C]
   float* in_gate_state[LSTM_L];  // [H][C]
-  float* state[LSTM_L];          // [C]   LstmLayer::state_
+  float* state[LSTM_L];          // [C]   LstmLayer::state_ (= stateb[0])
+  float* stateb[2][LSTM_L];      // state_ double-buffered like hid[]: a block launch reads [hc], leaves [hc ^ 1]
   float* layer_input[LSTM_L];    // [H][insz]
   float* OL;                     // [H][V][401]   output_layer_
   float* OLT;                    // [H][401][VP]  transposed copy
@@ -63,6 +82,12 @@ struct LstmState {
   float* E[LSTM_L][3];           // [H][C] final gate errors of the current BPTT round
   const float* adam_tab;         // [3001][4] alpha, 1-beta1^t, 1-beta2^t (host libm)
   float* byte_probs;             // [256] ByteModel::probs_ of the byte mixer
+  // block kernels (lstm_block.hip): values that cross workgroups inside a launch
+  struct LstmSync* sync;
+  float* raw_ring;               // [L][H][3*C]  pre-normalisation gate sums of epoch e
+  float* h_ring;                 // [H][401]     hidden_ after epoch e
+  float* logit_ring;             // [H][VP]
+  float* bp_pub;                 // [2*H][2][C]  BPTT step s: hidden error after the output-layer chain | stored error
 };
 
 // Position of weight (cell i, column c) in the transposed copy WT[l][g]. The V one-hot columns come

@@ -92,6 +92,7 @@ def lib():
                                              C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.cmx_lstm_get_gate_weights.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.cmx_lstm_gate_rowlen.argtypes = [C.c_void_p, C.c_int]
+        L.cmx_lstm_failed.argtypes = [C.c_void_p]
         L.cmx_glibc_rand_selftest.argtypes = [C.c_uint32, C.c_int, C.c_void_p]
         L.cmx_ctxmodels_create.restype = C.c_void_p
         L.cmx_ctxmodels_create.argtypes = [C.c_void_p, C.c_int]

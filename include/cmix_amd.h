@@ -171,6 +171,9 @@ int cmx_bytemodel_bit_run(int device, const float* d_dist, const uint8_t* d_byte
 /* Test hooks. */
 int cmx_lstm_get_gate_weights(cmx_lstm_t*, int layer, int gate, float* out_host);
 int cmx_lstm_gate_rowlen(const cmx_lstm_t*, int layer);
+/* 1 if a bounded in-launch wait of the multi-workgroup kernels (lstm_block.hip) ran out -- the stream's LSTM output
+ * is void from that point --, 0 otherwise. Synchronises the device. */
+int cmx_lstm_failed(cmx_lstm_t*);
 int cmx_glibc_rand_selftest(uint32_t seed, int n, int* out);
 
 /* ------------------------------------------------------------------------
