@@ -145,16 +145,14 @@ __device__ __forceinline__ void fx_phase2a_dev(FxDev* d, FxShared* sh, const FxB
   cx[9] = (bpos << 8) * 4 + (int)(f & 3) * 256 + u.lstmex;
   cx[11] = 0;
 }
-__device__ __forceinline__ void fx_phase2b_dev(FxDev* d, FxShared* sh, const FxBit& u, int lane, int* res8_s) {   // wave 0
+// the eight sums of the maps' return values the selectors use (lanes 0..7)
+__device__ __forceinline__ int fx_res8(const FxDev* d, const FxShared* sh, const FxBit& u, int lane) {
   const int which[8] = {0, 1, 2, 3, 4, 5, 21, 23};
-  if (lane < 8) {
-    int v = 0;
-    if (u.normal) { const FxMapDev* x = &d->maps[which[lane]]; for (int i = 0; i < x->C; i++) v += sh->slot_res[x->slot_base + i]; }
-    res8_s[lane] = v;
-  }
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-  __builtin_amdgcn_wave_barrier();
-  if (lane != 0) return;
+  int v = 0;
+  if (u.normal) { const FxMapDev* x = &d->maps[which[lane]]; for (int i = 0; i < x->C; i++) v += sh->slot_res[x->slot_base + i]; }
+  return v;
+}
+__device__ __forceinline__ void fx_phase2b_tail(FxDev* d, FxShared* sh, const FxBit& u, const int* res8_s) {   // one lane
   const FxByteRec* r = u.rec;
   const int bpos = u.bpos, c0b = u.c0 << (8 - bpos);
   int ordX = 0, ordW = 0;
@@ -190,9 +188,15 @@ __device__ __forceinline__ void fx_phase2b_dev(FxDev* d, FxShared* sh, const FxB
   cx[5] = (int)(((uint32_t)ordW * 256 + (s2 & 0xf0) + ((s3 & 0x38) >> 2)) * 4 + FcIdx);
 }
 
+__device__ __forceinline__ void fx_phase2b_dev(FxDev* d, FxShared* sh, const FxBit& u, int lane, int* res8_s) {   // wave 0
+  if (lane < 8) res8_s[lane] = fx_res8(d, sh, u, lane);
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) fx_phase2b_tail(d, sh, u, res8_s);
+}
+
 // ---- phase 3 on the device (same values as fxd_phase3): the ten weight pairs are requested together, then multiplied
-__device__ __forceinline__ void fx_phase3_dev(FxDev* d, FxShared* sh, const FxBit& u, int tid) {
-  fxd_map_clear_next(sh, u, tid);
+__device__ __forceinline__ void fx_phase3_dots(FxDev* d, FxShared* sh, const FxBit& u, int tid) {
   const uint32_t t = reinterpret_cast<const uint32_t*>(sh->tx[sh->parity ^ 1])[tid];
   uint32_t w[FX_NMIX1];
 #pragma unroll
@@ -293,6 +297,11 @@ __device__ __forceinline__ void fx_phase5_dev(FxDev* d, FxShared* sh, const FxBi
   sh->parity ^= 1;
 }
 
+__device__ __forceinline__ void fx_phase3_dev(FxDev* d, FxShared* sh, const FxBit& u, int tid) {
+  fxd_map_clear_next(sh, u, tid);
+  fx_phase3_dots(d, sh, u, tid);
+}
+
 // Everything the bit loop reads lives in LDS: FxShared (inputs, StateMaps, per-context registers), a working COPY of the
 // stream's FxDev (map descriptors, unit registers, scalars: the step functions read them through `d` many times per bit,
 // and from global memory every such read is an L2 round trip the compiler must redo after each store), the squash /
@@ -372,6 +381,228 @@ __global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_chunk_kernel_t(FxDev*
   if (PROF && (tid & 63) == 0) for (int k = 0; k < 8; k++) prof[(tid >> 6) * 8 + k] += acc[k];
 }
 
+// =====================================================================================================================
+// The same stage on THREE workgroups (the default). Nothing the context maps, the match models, the SSCMs or the run map
+// learn depends on the mixers or on the final probability -- only on the byte stream -- so the bit's work splits into
+// three roles that run on three compute units, each with its own LDS state, coupled only by the rows they hand over:
+//   role M  (block 0) the 31 context maps: touch -> run; publishes its 5..6 inputs per context, the eight return-value
+//           sums the selectors use, and its exported values
+//   role U  (block 1) MatchModel2 + SparseMatchModel, the SSCMs, the run map, the LSTM input; publishes 25 inputs, isMatch
+//   role X  (block 2) everything that learns from the coded probability: trainers, selectors, dot products, final
+//           mixers, APM chain. Takes row q when both M and U have published it.
+// M and U run ahead of X as far as the data lets them (they never wait for X); the per-bit cost of the stage is the
+// slowest role instead of the sum of the phases. Rows travel through global memory: agent-scope stores, a workgroup-wide
+// wait for them, then the role's row counter; X polls the counters (bounded) and loads the row with agent-scope loads.
+struct FxXfer {
+  unsigned fail; unsigned pad[3];   // sticky: a bounded wait ran out
+  unsigned started;                 // zeroed ahead of every launch from here on: workgroups that hold the stream state
+  unsigned m_done, u_done;          // rows published by the roles
+  unsigned pad2;
+};
+enum { FX_ROW_WORDS = 288,          // one row: 1152 bytes
+       FX_ROW_RES = 256,            //   [0, 256) role M: its copy of the 512 inputs (its own range is taken); then the 8 sums
+       FX_ROW_UTX = 264,            //   role U: inputs 0..23 as 12 words, word 12 = run map | LSTM input
+       FX_ROW_MATCH = 280,          //   isMatch
+       FX_ROLE_SPIN = 1 << 24 };
+struct FxAhead { uint8_t byte[4]; int16_t pr[4][8]; uint8_t ex[4][8]; };   // the stream values of the byte in force and the next one
+
+__device__ __forceinline__ unsigned fx_ld_u(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void fx_st_u(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool fx_wait_ge(unsigned* p, unsigned want, unsigned* fail) {   // one lane
+  unsigned it = 0;
+  while (fx_ld_u(p) < want)
+    if ((++it & 4095u) == 0 && (it > (unsigned)FX_ROLE_SPIN || fx_ld_u(fail))) { fx_st_u(fail, 1u); return false; }
+  return true;
+}
+// fxd_bit from LDS: the chunk's bytes and LSTM hints of the byte in force are staged a byte ahead (FxAhead), the records
+// one update ahead (FxLocal::rec)
+__device__ __forceinline__ FxBit fx_bit_dev(const FxDev* d, const FxAhead* ah, const FxLocal* loc, int q, int blpos0, int lastbyte0, int have0) {
+  FxBit u;
+  u.q = q;
+  const int b = q >> 3, k = q & 7, cur = ah->byte[b & 3];
+  u.y = (cur >> (7 - k)) & 1;
+  u.bpos = (k + 1) & 7;
+  u.boundary = (k == 7);
+  u.c0 = u.boundary ? 1 : ((1 << (k + 1)) | (cur >> (7 - k)));
+  u.blpos = blpos0 + b + (u.boundary ? 1 : 0);
+  u.lastbyte = u.boundary ? cur : (b > 0 ? ah->byte[(b - 1) & 3] : lastbyte0);
+  u.sscmrate = (u.blpos > 14 * 256 * 1024);
+  u.rate = 6 + (u.blpos > 14 * 256 * 1024) + (u.blpos > 28 * 512 * 1024);
+  u.lstmpr = ah->pr[b & 3][k]; u.lstmex = ah->ex[b & 3][k];
+  const int ri = u.boundary ? b : b - 1;
+  u.normal = ri >= 0 ? 1 : have0;
+  u.rec = ri >= 0 ? &loc->rec[ri & 1] : &d->rec;
+  u.orow = nullptr;
+  return u;
+}
+// the helper wave of a role, at the top of update q: next byte's stream values (at bit 0) and the next record (at bit 6)
+__device__ __forceinline__ void fx_stage_ahead(FxAhead* ah, FxLocal* loc, const uint8_t* bytes, const FxByteRec* recs, const int16_t* lstmpr, const uint8_t* lstmex,
+                                               int n, int q, int lane) {
+  const int b = q >> 3, k = q & 7;
+  if (k == 0 && b + 1 < n) {
+    if (lane < 8) { ah->pr[(b + 1) & 3][lane] = lstmpr[8 * (b + 1) + lane]; ah->ex[(b + 1) & 3][lane] = lstmex[8 * (b + 1) + lane]; }
+    else if (lane == 8) ah->byte[(b + 1) & 3] = bytes[b + 1];
+  }
+  if (k == 6) for (int i = lane; i < (int)(sizeof(FxByteRec) / 4); i += 64) ((uint32_t*)&loc->rec[b & 1])[i] = ((const uint32_t*)&recs[b])[i];
+}
+
+__global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_roles_kernel(FxDev* gd, FxXfer* X, unsigned* rows, const uint8_t* bytes, const FxByteRec* recs,
+                                                                         const int16_t* lstmpr, const uint8_t* lstmex, float* out, long ostride, int n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fx_smem[];
+  FxShared& sh = *(FxShared*)fx_smem;
+  FxLocal& loc = *(FxLocal*)(fx_smem + ((sizeof(FxShared) + 15) & ~(size_t)15));
+  FxDev* d = &loc.dev;
+  __shared__ int res8_s[8], scr_s[16];
+  __shared__ FxAhead ah;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, role = blockIdx.x;   // 0 = M, 1 = U, 2 = X
+  // ---- every role starts from the stream's state (it uses its own part of it) ----
+  for (int i = tid; i < (int)(sizeof(FxDev) / 4); i += FX_DEV_THREADS) ((uint32_t*)d)[i] = ((const uint32_t*)gd)[i];
+  for (int i = tid; i < 4095; i += FX_DEV_THREADS) loc.squash[i] = gd->squash[i];
+  for (int i = tid; i < 4096; i += FX_DEV_THREADS) loc.stretch[i] = gd->stretch[i];
+  for (int i = tid; i < 512; i += FX_DEV_THREADS) loc.wrt[i] = gd->wrt[i];
+  for (int i = tid; i < 6 * 1024; i += FX_DEV_THREADS) loc.sta[i >> 10][i & 1023] = gd->sta[i >> 10][i & 1023];
+  __syncthreads();
+  if (tid == 0) { d->squash = loc.squash; d->stretch = loc.stretch; d->wrt = loc.wrt; }
+  if (tid < FX_NMAPS) for (int q = 0; q < 6; q++) if (gd->maps[tid].nn == gd->sta[q]) d->maps[tid].nn = loc.sta[q];
+  const int nbits = 8 * n, blpos0 = d->blpos, lastbyte0 = d->lastbyte, have0 = d->have_rec;
+  if (tid < FX_THREADS) fxd_load_shared(d, &sh, tid);
+  if (role == 2) for (int i = tid; i < FX_OUTPUTS; i += FX_DEV_THREADS) out[i] = gd->pending[i];   // row 0: what the previous chunk's last update left
+  if (tid < 8) { ah.pr[0][tid] = lstmpr[tid]; ah.ex[0][tid] = lstmex[tid]; }
+  if (tid == 8) ah.byte[0] = bytes[0];
+  __syncthreads();
+  if (role != 2 && tid == 0) sh.parity = 0;   // M and U build the bit's inputs in tx[1]
+  // all three workgroups hold the state before any of them may write a part of it back (or the pending row)
+  if (tid == 0) { __hip_atomic_fetch_add(&X->started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); fx_wait_ge(&X->started, 3u, &X->fail); }
+  __syncthreads();
+  const FxLayout ln = fxd_layout(d, 1);   // the normal layout's offsets
+  unsigned have_m = 0, have_u = 0;
+  for (int q = 0; q < nbits; q++) {
+    FxBit u = fx_bit_dev(d, &ah, &loc, q, blpos0, lastbyte0, have0);
+    float* const real_row = q + 1 < nbits ? out + (long)(q + 1) * ostride : gd->pending;
+    unsigned* const row = rows + (size_t)q * FX_ROW_WORDS;
+    const FxLayout l = fxd_layout(d, u.normal);
+    if (role == 0) {
+      // ================= role M: the context maps =================
+      u.orow = loc.ex[0];
+      if (tid < FX_NSLOTS) fxd_map_touch(d, &sh, u, tid);
+      else if (wave == 3) fx_stage_ahead(&ah, &loc, bytes, recs, lstmpr, lstmex, n, q, lane);
+      // the full barrier of the bit: the previous run's table stores are complete before a serial walk may read them
+      __syncthreads();
+      if (tid < FX_THREADS) fxd_phase1c(d, &sh, u, tid);
+      fx_lds_barrier();
+      if (tid < FX_THREADS) {
+        fxd_map_clear_next(&sh, u, tid);
+        if (u.normal) fx_st_u(row + tid, reinterpret_cast<const uint32_t*>(sh.tx[1])[tid]);
+      } else if (tid < FX_THREADS + 8) fx_st_u(row + FX_ROW_RES + (tid - FX_THREADS), (unsigned)fx_res8(d, &sh, u, tid - FX_THREADS));
+      if (u.normal) for (int i = FX_NSSCM + 9 + tid; i < ln.exp_rcm; i += FX_DEV_THREADS) real_row[i] = loc.ex[0][i];
+      __syncthreads();   // every store of the row is complete
+      if (tid == 0) fx_st_u(&X->m_done, (unsigned)(q + 1));
+    } else if (role == 1) {
+      // ================= role U: match models, SSCMs, run map, LSTM input =================
+      u.orow = loc.ex[0];
+      int16_t* txn = sh.tx[1];
+      if (wave == 0) {
+        if (lane == 0) {
+          if (u.boundary) { d->buffer[(uint32_t)d->pos & FX_BMASK] = (uint8_t)u.lastbyte; d->pos++; }   // fxd_match_unit's first line (:3806-3807)
+          fxd_match2(d, &sh, u, txn + 2 * FX_NSSCM, u.orow + FX_NSSCM, &sh.isMatch);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the contexts are in LDS
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 3) fxd_match2_sm(d, &sh, u, lane);
+        if (lane == 0) fxd_sparse(d, u, txn + 2 * FX_NSSCM + 7, u.orow + FX_NSSCM + 7);
+      } else if (wave == 1) { if (lane < FX_NSSCM) fxd_sscm_unit(d, &sh, u, lane); }
+      else if (wave == 2) {
+        if (lane == 0) fxd_rcm_unit(d, &sh, u);
+        else if (lane == 1) txn[l.tx_lstm] = d->stretch[u.lstmpr];
+      } else if (wave == 3) fx_stage_ahead(&ah, &loc, bytes, recs, lstmpr, lstmex, n, q, lane);
+      fx_lds_barrier();
+      if (tid < 12) fx_st_u(row + FX_ROW_UTX + tid, reinterpret_cast<const uint32_t*>(txn)[tid]);
+      else if (tid == 12) fx_st_u(row + FX_ROW_UTX + 12, (uint32_t)(uint16_t)txn[l.tx_rcm] | ((uint32_t)(uint16_t)txn[l.tx_lstm] << 16));
+      else if (tid == 13) fx_st_u(row + FX_ROW_MATCH, (unsigned)sh.isMatch);
+      else if (tid >= 64 && tid < 64 + FX_NSSCM + 9) real_row[tid - 64] = loc.ex[0][tid - 64];
+      else if (tid >= 128 && tid < 130) real_row[l.exp_rcm + (tid - 128)] = loc.ex[0][l.exp_rcm + (tid - 128)];
+      __syncthreads();
+      if (tid == 0) fx_st_u(&X->u_done, (unsigned)(q + 1));
+    } else {
+      // ================= role X: trainers, selectors, mixers, APM chain =================
+      u.orow = loc.ex[q & 1];
+      if (tid == 0) {
+        if (have_m < (unsigned)(q + 1)) { fx_wait_ge(&X->m_done, (unsigned)(q + 1), &X->fail); have_m = fx_ld_u(&X->m_done); }
+        if (have_u < (unsigned)(q + 1)) { fx_wait_ge(&X->u_done, (unsigned)(q + 1), &X->fail); have_u = fx_ld_u(&X->u_done); }
+      }
+      fx_lds_barrier();
+      {   // the bit's inputs: the maps' range from M's row, the units' from U's
+        int16_t* txn = sh.tx[sh.parity ^ 1];
+        if (tid < FX_THREADS) {
+          if (u.normal) {
+            const uint32_t w = fx_ld_u(row + tid);
+            const int i0 = 2 * tid, lo = FX_NSSCM * 2 + 9;
+            if (i0 >= lo && i0 < l.tx_rcm) txn[i0] = (int16_t)(w & 0xffff);
+            if (i0 + 1 >= lo && i0 + 1 < l.tx_rcm) txn[i0 + 1] = (int16_t)(w >> 16);
+          }
+        } else if (tid < FX_THREADS + 12) {
+          const int i = tid - FX_THREADS;
+          const uint32_t w = fx_ld_u(row + FX_ROW_UTX + i);
+          txn[2 * i] = (int16_t)(w & 0xffff);
+          if (2 * i + 1 < FX_NSSCM * 2 + 9) txn[2 * i + 1] = (int16_t)(w >> 16);
+        } else if (tid == FX_THREADS + 12) {
+          const uint32_t w = fx_ld_u(row + FX_ROW_UTX + 12);
+          txn[l.tx_rcm] = (int16_t)(w & 0xffff); txn[l.tx_lstm] = (int16_t)(w >> 16);
+        } else if (tid == FX_THREADS + 13) sh.isMatch = (int)fx_ld_u(row + FX_ROW_MATCH);
+        else if (tid >= FX_THREADS + 16 && tid < FX_THREADS + 24) res8_s[tid - FX_THREADS - 16] = (int)fx_ld_u(row + FX_ROW_RES + (tid - FX_THREADS - 16));
+      }
+      if (wave == 2 || wave == 3) fx_train_rows_fast(d, &sh, u, tid - 128);
+      else if (wave == 6) { if (lane == 2 || lane == 3) fxd_train_small(d, &sh, u, 10 + lane - 2); }
+      else if (wave == 7) { if (lane < 6) { fxd_apm_update(d, &sh, u, lane); fx_apm_prefetch(d, &sh, u, &loc.apm, lane); } }
+      else if (wave == 5) fx_stage_ahead(&ah, &loc, bytes, recs, lstmpr, lstmex, n, q, lane);
+      // the full barrier of the bit: the trained rows and APM cells are stored before phase 3 / 5 read them
+      __syncthreads();
+      if (tid == 0) fx_phase2b_tail(d, &sh, u, res8_s);
+      else if (tid == 256) fx_phase2a_dev(d, &sh, u);
+      fx_lds_barrier();
+      if (tid < FX_THREADS) fx_phase3_dots(d, &sh, u, tid);
+      fx_lds_barrier();
+      if (tid < FX_THREADS) fxd_phase4(d, &sh, u, tid);
+      fx_lds_barrier();
+      if (tid < 64) fx_phase5_dev(d, &sh, u, &loc.apm, tid, scr_s);
+      fx_lds_barrier();
+      for (int i = l.exp_mix + tid; i < FX_OUTPUTS; i += FX_DEV_THREADS) real_row[i] = loc.ex[q & 1][i];
+    }
+  }
+  __syncthreads();
+  // ---- every role writes its own part of the stream's state back ----
+  if (role == 0) {
+    for (int i = tid; i < FX_NMAPS * 8; i += FX_DEV_THREADS) {
+      FxMapDev* x = &gd->maps[i >> 3];
+      const int j = i & 7;
+      x->cp[j] = sh.mcp[i >> 3][j]; x->cp0[j] = sh.mcp0[i >> 3][j]; x->runp[j] = sh.mrunp[i >> 3][j]; x->cxt[j] = sh.mcxt[i >> 3][j]; x->sm_cxt[j] = sh.msmc[i >> 3][j];
+    }
+    for (int k = 0; k < FX_NMAPS; k++) {
+      const FxMapDev* x = &d->maps[k];
+      for (int i = tid; i < x->C * 256; i += FX_DEV_THREADS) x->sm[i] = (&sh.sm[x->slot_base][0])[i];
+    }
+  } else if (role == 1) {
+    const int w0 = (int)(offsetof(FxDev, sscm_data) / 4), w1 = (int)(offsetof(FxDev, wx) / 4);
+    for (int i = w0 + tid; i < w1; i += FX_DEV_THREADS) ((uint32_t*)gd)[i] = ((const uint32_t*)d)[i];
+  } else {
+    if (tid < FX_THREADS) {   // the mixer / APM part of fxd_store_shared, into the LDS copy first
+      for (int i = tid; i < 2 * FX_TX; i += FX_THREADS) (&d->tx[0][0])[i] = (&sh.tx[0][0])[i];
+      if (tid < 16) d->in2[tid] = sh.in2[tid];
+      if (tid < 12) { d->mx_elim[tid] = sh.mx_elim[tid]; d->mx_cxt[tid] = sh.mx_cxt[tid]; d->mx_pr[tid] = sh.mx_pr[tid]; }
+      if (tid < 6) d->apm_index[tid] = sh.apm_index[tid];
+      if (tid == 0) {
+        d->pr = sh.pr; d->parity = sh.parity; d->fails = sh.fails; d->failz = sh.failz; d->failcount = sh.failcount;
+        d->blpos = blpos0 + n; d->lastbyte = ah.byte[(n - 1) & 3]; d->have_rec = 1; d->rec = loc.rec[(n - 1) & 1];
+      }
+    }
+    __syncthreads();
+    const int w0 = (int)(offsetof(FxDev, mx_elim) / 4), w1 = (int)(offsetof(FxDev, pending) / 4);
+    for (int i = w0 + tid; i < w1; i += FX_DEV_THREADS) ((uint32_t*)gd)[i] = ((const uint32_t*)d)[i];
+    const int r0 = (int)(offsetof(FxDev, rec) / 4), r1 = r0 + (int)(sizeof(FxByteRec) / 4);
+    for (int i = r0 + tid; i < r1; i += FX_DEV_THREADS) ((uint32_t*)gd)[i] = ((const uint32_t*)d)[i];
+  }
+}
+
 __global__ void cmx_fxcm_pattern16_kernel(uint16_t* p, size_t n, const uint16_t* pat, int plen) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = pat[i % (size_t)plen];
 }
@@ -416,7 +647,10 @@ struct cmx_fxcm {
   bool used[FX_STAGE_BUFS] = {};
   int next = 0;
   uint64_t bytes_done = 0;
-  unsigned long long* d_prof = nullptr;   // CMX_FXCM_PROFILE=1: per-phase clocks
+  unsigned long long* d_prof = nullptr;   // CMX_FXCM_PROFILE=1: per-phase clocks (one-workgroup kernel)
+  bool v1 = false;                        // CMX_FXCM_V1=1: the one-workgroup kernel
+  FxXfer* d_xfer = nullptr;               // three-role kernel: hand-off counters and the rows M / U publish for X
+  unsigned* d_rows = nullptr; size_t rows_cap = 0;
 };
 
 extern "C" {
@@ -433,6 +667,8 @@ void cmx_fxcm_destroy(cmx_fxcm_t* h) {
     if (h->done[i]) (void)hipEventDestroy(h->done[i]);
   }
   if (h->d_prof) (void)hipFree(h->d_prof);
+  if (h->d_xfer) (void)hipFree(h->d_xfer);
+  if (h->d_rows) (void)hipFree(h->d_rows);
   if (h->parser) fxp_destroy(h->parser);
   delete h;
 }
@@ -452,7 +688,10 @@ cmx_fxcm_t* cmx_fxcm_create(const char* dictionary_path, int device) {
   for (int i = 0; ok && i < FX_STAGE_BUFS; i++) ok = hipEventCreateWithFlags(&h->done[i], hipEventDisableTiming) == hipSuccess;
   ok = ok && hipFuncSetAttribute((const void*)cmx_fxcm_chunk_kernel_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FX_LDS_BYTES) == hipSuccess;
   ok = ok && hipFuncSetAttribute((const void*)cmx_fxcm_chunk_kernel_t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FX_LDS_BYTES) == hipSuccess;
+  ok = ok && hipFuncSetAttribute((const void*)cmx_fxcm_roles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FX_LDS_BYTES) == hipSuccess;
+  ok = ok && hipMalloc((void**)&h->d_xfer, sizeof(FxXfer)) == hipSuccess && hipMemset(h->d_xfer, 0, sizeof(FxXfer)) == hipSuccess;
   const char* prof = getenv("CMX_FXCM_PROFILE");
+  { const char* v = getenv("CMX_FXCM_V1"); h->v1 = (v && v[0] == '1') || (prof && prof[0] == '1'); }
   if (ok && prof && prof[0] == '1') ok = hipMalloc((void**)&h->d_prof, 512) == hipSuccess && hipMemset(h->d_prof, 0, 512) == hipSuccess;
   ok = ok && hipDeviceSynchronize() == hipSuccess;
   if (!ok) { cmx_set_err("cmx_fxcm_create: allocation / init failed (the stage needs ~4.4 GB of HBM)"); cmx_fxcm_destroy(h); return nullptr; }
@@ -480,7 +719,18 @@ int cmx_fxcm_run(cmx_fxcm_t* h, const uint8_t* bytes, const uint8_t* d_bytes, si
   if (fxp_run(h->parser, bytes, (int)nbytes, h->h_recs[b]) != 0) { cmx_set_err("cmx_fxcm_run: parser emitted a context count a map does not expect"); return 1; }
   hipStream_t s = (hipStream_t)stream;
   if (hipMemcpyAsync(h->d_recs[b], h->h_recs[b], nbytes * sizeof(FxByteRec), hipMemcpyHostToDevice, s) != hipSuccess) { cmx_set_err("cmx_fxcm_run: record upload failed"); return 1; }
-  if (h->d_prof)
+  if (!h->v1) {
+    if (h->rows_cap < nbytes) {   // grown between chunks: nothing of this stream may be in flight on the old buffer
+      if (hipDeviceSynchronize() != hipSuccess) { cmx_set_err("cmx_fxcm_run: device error"); return 1; }
+      if (h->d_rows) (void)hipFree(h->d_rows);
+      h->d_rows = nullptr; h->rows_cap = 0;
+      if (hipMalloc((void**)&h->d_rows, nbytes * 8 * FX_ROW_WORDS * 4) != hipSuccess) { cmx_set_err("cmx_fxcm_run: row buffer allocation failed"); return 1; }
+      h->rows_cap = nbytes;
+    }
+    if (hipMemsetAsync((char*)h->d_xfer + 16, 0, sizeof(FxXfer) - 16, s) != hipSuccess) { cmx_set_err("cmx_fxcm_run: hipMemsetAsync failed"); return 1; }
+    hipLaunchKernelGGL(cmx_fxcm_roles_kernel, dim3(3), dim3(FX_DEV_THREADS), FX_LDS_BYTES, s, h->d_dev, h->d_xfer, h->d_rows, d_bytes, h->d_recs[b], d_lstmpr, d_lstmex,
+                       d_probs + 3, (long)pstride, (int)nbytes);
+  } else if (h->d_prof)
     hipLaunchKernelGGL(cmx_fxcm_chunk_kernel_t<true>, dim3(1), dim3(FX_DEV_THREADS), FX_LDS_BYTES, s, h->d_dev, d_bytes, h->d_recs[b], d_lstmpr, d_lstmex, d_probs + 3,
                        (long)pstride, (int)nbytes, h->d_prof);
   else
@@ -498,6 +748,16 @@ int cmx_fxcm_run(cmx_fxcm_t* h, const uint8_t* bytes, const uint8_t* d_bytes, si
 int cmx_fxcm_profile(cmx_fxcm_t* h, unsigned long long out64[64]) {
   if (!h || !h->d_prof) return 1;
   return hipMemcpy(out64, h->d_prof, 512, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+
+// 1 = a bounded in-launch wait of the three-role kernel ran out (the stream's fxcm columns are void); synchronises the device
+int cmx_fxcm_failed(cmx_fxcm_t* h) {
+  if (!h) return 1;
+  (void)hipSetDevice(h->device);
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  unsigned f = 0;
+  if (hipMemcpy(&f, &h->d_xfer->fail, 4, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+  return f ? 1 : 0;
 }
 
 int cmx_fxcm_sync(cmx_fxcm_t* h) {

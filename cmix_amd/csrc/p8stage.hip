@@ -13,7 +13,8 @@
 //               dmc     the DMC forest (p8dmc_dev.h)
 //               mix     the 1552 x 28 int16 mixer (rows in registers from dot product to training), the second layer,
 //                       the APM / APM1 chains, squash(x)/4095 export of all 1591 values into the layer-0 matrix
-//             Streams: s_a = cm2[0] -> fam, s_b = cm2[1] -> cm2[2], s_c = lanes -> dmc (after cm2[0]); mix after all.
+//             Streams: s_d = upload, cm2[0]; s_a = fam (after cm2[0] of the same chunk, beside cm2[0] of the next); s_b = cm2[1];
+//             s_e = cm2[2]; s_c = lanes -> dmc (after cm2[0]); s_m = mix after all.
 // Integer work, latency-bound by construction (dependent table accesses per bit); algorithmic HBM traffic per input
 // byte: mixer 28 rows x 1552 x 2 B x 2 (read + write) x 8 = 1.39 MB, buckets ~270 contexts x 3 probes x 64 B x 2 = 0.1 MB.
 // Parity: tests/test_p8stage_host.py runs the bodies on the host, tests/test_zgpu_p8stage.py the kernels, both against
@@ -707,8 +708,8 @@ struct cmx_p8stage {
   Staging st[P8S_BUFS];
   int next = 0;
   int16_t* d_x[2] = {}; uint8_t* d_order[2] = {}; size_t x_cap = 0;   // two chunks' input rows / order values: the mixer of chunk c runs under the tables of chunk c + 1
-  hipStream_t s_a = nullptr, s_b = nullptr, s_c = nullptr, s_m = nullptr;
-  hipEvent_t ev_up = nullptr, ev_ord = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_mix[2] = {};
+  hipStream_t s_a = nullptr, s_b = nullptr, s_c = nullptr, s_d = nullptr, s_e = nullptr, s_m = nullptr;
+  hipEvent_t ev_up = nullptr, ev_ord = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_e = nullptr, ev_mix[2] = {};
   bool mix_used[2] = {false, false};
   unsigned long long* d_prof = nullptr;   // CMX_P8MIX_PROFILE=1: per-wave clocks by phase of the mixer kernel
   uint64_t chunks = 0;
@@ -731,8 +732,8 @@ void cmx_p8stage_destroy(cmx_p8stage_t* h) {
     if (s.done) (void)hipEventDestroy(s.done);
   }
   for (int i = 0; i < 2; i++) { if (h->d_x[i]) (void)hipFree(h->d_x[i]); if (h->d_order[i]) (void)hipFree(h->d_order[i]); }
-  for (hipStream_t q : {h->s_a, h->s_b, h->s_c, h->s_m}) if (q) (void)hipStreamDestroy(q);
-  for (hipEvent_t e : {h->ev_up, h->ev_ord, h->ev_a, h->ev_b, h->ev_c, h->ev_mix[0], h->ev_mix[1]}) if (e) (void)hipEventDestroy(e);
+  for (hipStream_t q : {h->s_a, h->s_b, h->s_c, h->s_d, h->s_e, h->s_m}) if (q) (void)hipStreamDestroy(q);
+  for (hipEvent_t e : {h->ev_up, h->ev_ord, h->ev_a, h->ev_b, h->ev_c, h->ev_e, h->ev_mix[0], h->ev_mix[1]}) if (e) (void)hipEventDestroy(e);
   if (h->front) p8f_front_free(h->front);
   delete h;
 }
@@ -763,8 +764,8 @@ cmx_p8stage_t* cmx_p8stage_create(int device) {
   }
   delete S;
   ok = ok && hipFuncSetAttribute((const void*)cmx_p8s_fam2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->fam_lds) == hipSuccess;
-  for (hipStream_t* q : {&h->s_a, &h->s_b, &h->s_c, &h->s_m}) ok = ok && hipStreamCreateWithFlags(q, hipStreamNonBlocking) == hipSuccess;
-  for (hipEvent_t* e : {&h->ev_up, &h->ev_ord, &h->ev_a, &h->ev_b, &h->ev_c, &h->ev_mix[0], &h->ev_mix[1]}) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+  for (hipStream_t* q : {&h->s_a, &h->s_b, &h->s_c, &h->s_d, &h->s_e, &h->s_m}) ok = ok && hipStreamCreateWithFlags(q, hipStreamNonBlocking) == hipSuccess;
+  for (hipEvent_t* e : {&h->ev_up, &h->ev_ord, &h->ev_a, &h->ev_b, &h->ev_c, &h->ev_e, &h->ev_mix[0], &h->ev_mix[1]}) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
   for (auto& s : h->st) ok = ok && hipEventCreateWithFlags(&s.done, hipEventDisableTiming) == hipSuccess;
   if (ok && getenv("CMX_P8MIX_PROFILE")) ok = hipMalloc((void**)&h->d_prof, 7 * 8 * 8) == hipSuccess && hipMemset(h->d_prof, 0, 7 * 8 * 8) == hipSuccess;
   ok = ok && hipDeviceSynchronize() == hipSuccess;
@@ -818,15 +819,16 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
     }
     h->x_cap = ok ? n : 0;
   }
-  // The stage's own streams: a = order-N map -> family, b = TextModel's and exeModel's maps, c = small lanes -> DMC,
-  // m = mixer + chains. Input rows are double-buffered by chunk parity, so the mixer of chunk c runs under the tables of
+  // The stage's own streams: d = upload, order-N map; a = family (needs the order-N map's `order` of the same chunk, so it
+  // runs one kernel behind it -- on its own stream the family of chunk c overlaps the order-N map of chunk c + 1);
+  // b = TextModel's and exeModel's maps, c = small lanes -> DMC, m = mixer + chains. Input rows are double-buffered by chunk parity, so the mixer of chunk c runs under the tables of
   // chunk c + 1; the caller's stream only waits for this chunk's mixer at the end (the input is host memory: nothing of
   // the caller's earlier work is needed, d_out must simply not be in use).
   const int par = (int)(h->chunks & 1);
   int16_t* dx = h->d_x[par]; uint8_t* dord = h->d_order[par];
-  if (h->mix_used[par]) for (hipStream_t q : {h->s_a, h->s_b, h->s_c}) ok = ok && hipStreamWaitEvent(q, h->ev_mix[par], 0) == hipSuccess;   // the mixer that last read these rows
-  ok = ok && hipMemcpyAsync(b.d, b.h, b.total, hipMemcpyHostToDevice, h->s_a) == hipSuccess;
-  ok = ok && hipEventRecord(h->ev_up, h->s_a) == hipSuccess;
+  if (h->mix_used[par]) for (hipStream_t q : {h->s_a, h->s_b, h->s_c, h->s_d, h->s_e}) ok = ok && hipStreamWaitEvent(q, h->ev_mix[par], 0) == hipSuccess;   // the mixer that last read these rows
+  ok = ok && hipMemcpyAsync(b.d, b.h, b.total, hipMemcpyHostToDevice, h->s_d) == hipSuccess;
+  ok = ok && hipEventRecord(h->ev_up, h->s_d) == hipSuccess;
   const int nbits = (int)T;
   const int skip = h->steps >= 8 ? 0 : (int)(8 - h->steps), t0 = h->steps == 0 ? 1 : 0;
   const uint8_t* d_bits = (const uint8_t*)(b.d + b.o_bits);
@@ -835,8 +837,9 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
                        (const uint16_t*)(b.d + b.o_cchk[k]), d_bits, dx, ord, nbits, skip);
   };
   if (ok) {
-    cm2(0, h->s_a, dord);
-    ok = hipEventRecord(h->ev_ord, h->s_a) == hipSuccess;
+    cm2(0, h->s_d, dord);
+    ok = hipEventRecord(h->ev_ord, h->s_d) == hipSuccess;
+    ok = ok && hipStreamWaitEvent(h->s_a, h->ev_ord, 0) == hipSuccess;   // (implies the upload)
     if (h->fam_v1)
       hipLaunchKernelGGL(cmx_p8s_fam_kernel, dim3(1), dim3(P8CM_MAXS), 0, h->s_a, h->d_fam, (const uint32_t*)(b.d + b.o_fctx), (const uint16_t*)(b.d + b.o_fchk), d_bits, dx,
                          (const uint8_t*)dord, nbits, skip);
@@ -846,13 +849,15 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
     ok = ok && hipEventRecord(h->ev_a, h->s_a) == hipSuccess;
     ok = ok && hipStreamWaitEvent(h->s_b, h->ev_up, 0) == hipSuccess;
     cm2(1, h->s_b, nullptr);
-    cm2(2, h->s_b, nullptr);
     ok = ok && hipEventRecord(h->ev_b, h->s_b) == hipSuccess;
+    ok = ok && hipStreamWaitEvent(h->s_e, h->ev_up, 0) == hipSuccess;
+    cm2(2, h->s_e, nullptr);
+    ok = ok && hipEventRecord(h->ev_e, h->s_e) == hipSuccess;
     ok = ok && hipStreamWaitEvent(h->s_c, h->ev_ord, 0) == hipSuccess;
     hipLaunchKernelGGL(cmx_p8s_lanes_kernel, dim3(1), dim3(P8_NLANE), 0, h->s_c, h->d_lanes, (const uint32_t*)(b.d + b.o_ops), d_bits, (const uint8_t*)dord, dx, nbits, t0);
     hipLaunchKernelGGL(cmx_p8s_dmc_kernel, dim3(1), dim3(P8DMC_THREADS), 0, h->s_c, h->d_dmc, d_bits, dx, (int)L.dmc_off, nbits, t0);
     ok = ok && hipEventRecord(h->ev_c, h->s_c) == hipSuccess;
-    for (hipEvent_t e : {h->ev_a, h->ev_b, h->ev_c}) ok = ok && hipStreamWaitEvent(h->s_m, e, 0) == hipSuccess;
+    for (hipEvent_t e : {h->ev_a, h->ev_b, h->ev_c, h->ev_e}) ok = ok && hipStreamWaitEvent(h->s_m, e, 0) == hipSuccess;
     if (h->fam_v1 || getenv("CMX_P8MIX_V1"))
       hipLaunchKernelGGL(cmx_p8s_mix_kernel, dim3(1), dim3(MX_THREADS), 0, h->s_m, (const P8MixDev*)h->d_mix, h->d_tail, (const int16_t*)dx, (const int32_t*)(b.d + b.o_sel),
                          (const P8ApmRec*)(b.d + b.o_apm), (const uint8_t*)dord, d_bits, d_out, ld, nbits, t0, skip, h->last_bit);

@@ -70,6 +70,7 @@ def lib():
         L.cmx_fxcm_destroy.argtypes = [C.c_void_p]
         L.cmx_fxcm_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.cmx_fxcm_sync.argtypes = [C.c_void_p]
+        L.cmx_fxcm_failed.argtypes = [C.c_void_p]
         L.cmx_mixnet_create.restype = C.c_void_p
         L.cmx_mixnet_create.argtypes = [C.c_int]
         L.cmx_mixnet_destroy.argtypes = [C.c_void_p]

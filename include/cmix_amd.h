@@ -317,6 +317,8 @@ void cmx_fxcm_destroy(cmx_fxcm_t*);
 int cmx_fxcm_run(cmx_fxcm_t*, const uint8_t* bytes, const uint8_t* d_bytes, size_t nbytes, const int16_t* d_lstmpr, const uint8_t* d_lstmex,
                  float* d_probs, size_t pstride, void* stream);
 int cmx_fxcm_sync(cmx_fxcm_t*);
+/* 1 if a bounded in-launch wait of the three-role kernel ran out (the stream's fxcm columns are void from there); syncs. */
+int cmx_fxcm_failed(cmx_fxcm_t*);
 /* diagnostics (CMX_FXCM_PROFILE=1 at create time): clocks of lane 0 of each of the kernel's 8 wavefronts per phase
  * (1a work, 1a barrier wait, 1c, 2, 3, 4, 5, -) */
 int cmx_fxcm_profile(cmx_fxcm_t*, unsigned long long out64[64]);
