@@ -98,8 +98,8 @@ struct cmx_mixnet {
   float* d_decay = nullptr;
   size_t decay_cap = 0;
   float* h_decay = nullptr;  // pinned, DECAY_SLOTS x decay_cap: a slot is rewritten only after its copy ran
-  hipEvent_t ev_decay[4] = {nullptr, nullptr, nullptr, nullptr};
-  bool decay_used[4] = {false, false, false, false};
+  hipEvent_t ev_decay[CMX_PIPELINE_SLOTS] = {};
+  bool decay_used[CMX_PIPELINE_SLOTS] = {};
   uint64_t runs = 0;
   uint64_t bits_done = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -174,7 +174,7 @@ void cmx_mixnet_destroy(cmx_mixnet_t* h) {
   if (h->h_sync_pin) hipHostFree(h->h_sync_pin);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
-  for (int i = 0; i < 4; ++i) if (h->ev_decay[i]) hipEventDestroy(h->ev_decay[i]);
+  for (int i = 0; i < CMX_PIPELINE_SLOTS; ++i) if (h->ev_decay[i]) hipEventDestroy(h->ev_decay[i]);
   delete h;
 }
 
@@ -265,7 +265,7 @@ cmx_mixnet_t* cmx_mixnet_create(int device) {
   { const char* v = getenv("CMX_MIXNET_XCD"); h->xcd = v ? atoi(v) : -1; }
   hipEventCreate(&h->ev0);
   hipEventCreate(&h->ev1);
-  for (int i = 0; i < 4; ++i) hipEventCreateWithFlags(&h->ev_decay[i], hipEventDisableTiming);
+  for (int i = 0; i < CMX_PIPELINE_SLOTS; ++i) hipEventCreateWithFlags(&h->ev_decay[i], hipEventDisableTiming);
   hipError_t e = hipDeviceSynchronize();
   if (e != hipSuccess) { set_err(std::string("init: ") + hipGetErrorString(e)); cmx_mixnet_destroy(h); return nullptr; }
   return h;
@@ -283,11 +283,11 @@ static int ensure_decay(cmx_mixnet_t* h, size_t nbits) {
   size_t cap = nbits < 4096 ? 4096 : nbits;
   if (h->h_decay) hipHostFree(h->h_decay);
   h->h_decay = nullptr;
-  for (int i = 0; i < 4; ++i) {  // nothing of the old buffer may still be waiting to be copied
+  for (int i = 0; i < CMX_PIPELINE_SLOTS; ++i) {  // nothing of the old buffer may still be waiting to be copied
     if (h->decay_used[i]) (void)hipEventSynchronize(h->ev_decay[i]);
     h->decay_used[i] = false;
   }
-  HIP_OK(hipHostMalloc((void**)&h->h_decay, 4 * cap * 4, hipHostMallocDefault));
+  HIP_OK(hipHostMalloc((void**)&h->h_decay, (size_t)CMX_PIPELINE_SLOTS * cap * 4, hipHostMallocDefault));
   void* p = nullptr;
   HIP_OK(hipMalloc(&p, cap * 4));
   h->allocs.push_back(p);
@@ -306,10 +306,10 @@ int cmx_mixnet_run(cmx_mixnet_t* h, const float* d_probs, const uint32_t* d_sel,
   if (nbits > 0x7fffffff) { set_err("cmx_mixnet_run: chunk too large"); return 1; }
   HIP_OK(hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
-  // The decay schedule is staged through one of four pinned slots; a slot is rewritten only once the copy
-  // that read it has executed, so up to four chunks can be enqueued without the host waiting for the GPU.
+  // The decay schedule is staged through one of CMX_PIPELINE_SLOTS pinned slots; a slot is rewritten only once the copy
+  // that read it has executed, so that many chunks can be enqueued without the host waiting for the GPU.
   if (ensure_decay(h, nbits)) return 1;
-  const int slot = (int)(h->runs++ & 3);
+  const int slot = (int)(h->runs++ % CMX_PIPELINE_SLOTS);
   if (h->decay_used[slot]) HIP_OK(hipEventSynchronize(h->ev_decay[slot]));
   float* hd = h->h_decay + (size_t)slot * h->decay_cap;
   for (size_t t = 0; t < nbits; ++t) hd[t] = decay_of(h->bits_done + t);

@@ -631,7 +631,7 @@ struct DevPolicy {
   }
   void upload(void* dst, const void* src, size_t bytes) { if (dst && hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess) ok = false; }
 };
-enum { FX_STAGE_BUFS = 4 };
+enum { FX_STAGE_BUFS = CMX_PIPELINE_SLOTS };
 }  // namespace
 
 struct cmx_fxcm {

@@ -683,7 +683,7 @@ struct DevPolicy {
   void upload(void* dst, const void* src, size_t bytes) { if (dst && hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess) ok = false; }
   void fill16(int16_t* dst, int16_t v, size_t n) { if (dst && hipMemsetD16((hipDeviceptr_t)dst, (unsigned short)v, n) != hipSuccess) ok = false; }
 };
-enum { P8S_BUFS = 4 };
+enum { P8S_BUFS = CMX_PIPELINE_SLOTS, P8S_XBUFS = 3 };   // staging buffers; input-row buffers (maps -> family -> mixer: three chunks deep)
 struct Staging {   // one chunk's records: page-locked host arrays and their device twins
   size_t cap = 0;  // bytes of input
   char* h = nullptr; char* d = nullptr;
@@ -707,10 +707,10 @@ struct cmx_p8stage {
   P8TailDev* d_tail = nullptr; P8MixDev* d_mix = nullptr;
   Staging st[P8S_BUFS];
   int next = 0;
-  int16_t* d_x[2] = {}; uint8_t* d_order[2] = {}; size_t x_cap = 0;   // two chunks' input rows / order values: the mixer of chunk c runs under the tables of chunk c + 1
+  int16_t* d_x[P8S_XBUFS] = {}; uint8_t* d_order[P8S_XBUFS] = {}; size_t x_cap = 0;   // two chunks' input rows / order values: the mixer of chunk c runs under the tables of chunk c + 1
   hipStream_t s_a = nullptr, s_b = nullptr, s_c = nullptr, s_d = nullptr, s_e = nullptr, s_m = nullptr;
-  hipEvent_t ev_up = nullptr, ev_ord = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_e = nullptr, ev_mix[2] = {};
-  bool mix_used[2] = {false, false};
+  hipEvent_t ev_up = nullptr, ev_ord = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_e = nullptr, ev_mix[P8S_XBUFS] = {};
+  bool mix_used[P8S_XBUFS] = {};
   unsigned long long* d_prof = nullptr;   // CMX_P8MIX_PROFILE=1: per-wave clocks by phase of the mixer kernel
   uint64_t chunks = 0;
   uint64_t steps = 0;
@@ -731,9 +731,10 @@ void cmx_p8stage_destroy(cmx_p8stage_t* h) {
     if (s.d) (void)hipFree(s.d);
     if (s.done) (void)hipEventDestroy(s.done);
   }
-  for (int i = 0; i < 2; i++) { if (h->d_x[i]) (void)hipFree(h->d_x[i]); if (h->d_order[i]) (void)hipFree(h->d_order[i]); }
+  for (int i = 0; i < P8S_XBUFS; i++) { if (h->d_x[i]) (void)hipFree(h->d_x[i]); if (h->d_order[i]) (void)hipFree(h->d_order[i]); }
   for (hipStream_t q : {h->s_a, h->s_b, h->s_c, h->s_d, h->s_e, h->s_m}) if (q) (void)hipStreamDestroy(q);
-  for (hipEvent_t e : {h->ev_up, h->ev_ord, h->ev_a, h->ev_b, h->ev_c, h->ev_e, h->ev_mix[0], h->ev_mix[1]}) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {h->ev_up, h->ev_ord, h->ev_a, h->ev_b, h->ev_c, h->ev_e}) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->ev_mix) if (e) (void)hipEventDestroy(e);
   if (h->front) p8f_front_free(h->front);
   delete h;
 }
@@ -765,7 +766,8 @@ cmx_p8stage_t* cmx_p8stage_create(int device) {
   delete S;
   ok = ok && hipFuncSetAttribute((const void*)cmx_p8s_fam2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->fam_lds) == hipSuccess;
   for (hipStream_t* q : {&h->s_a, &h->s_b, &h->s_c, &h->s_d, &h->s_e, &h->s_m}) ok = ok && hipStreamCreateWithFlags(q, hipStreamNonBlocking) == hipSuccess;
-  for (hipEvent_t* e : {&h->ev_up, &h->ev_ord, &h->ev_a, &h->ev_b, &h->ev_c, &h->ev_e, &h->ev_mix[0], &h->ev_mix[1]}) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+  for (hipEvent_t* e : {&h->ev_up, &h->ev_ord, &h->ev_a, &h->ev_b, &h->ev_c, &h->ev_e}) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+  for (hipEvent_t& e : h->ev_mix) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
   for (auto& s : h->st) ok = ok && hipEventCreateWithFlags(&s.done, hipEventDisableTiming) == hipSuccess;
   if (ok && getenv("CMX_P8MIX_PROFILE")) ok = hipMalloc((void**)&h->d_prof, 7 * 8 * 8) == hipSuccess && hipMemset(h->d_prof, 0, 7 * 8 * 8) == hipSuccess;
   ok = ok && hipDeviceSynchronize() == hipSuccess;
@@ -811,7 +813,7 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
   bool ok = true;
   if (h->x_cap < n) {   // grown between chunks only when nothing is in flight on them
     ok = hipDeviceSynchronize() == hipSuccess;
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < P8S_XBUFS; i++) {
       if (h->d_x[i]) (void)hipFree(h->d_x[i]);
       if (h->d_order[i]) (void)hipFree(h->d_order[i]);
       h->d_x[i] = nullptr; h->d_order[i] = nullptr;
@@ -824,7 +826,7 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
   // b = TextModel's and exeModel's maps, c = small lanes -> DMC, m = mixer + chains. Input rows are double-buffered by chunk parity, so the mixer of chunk c runs under the tables of
   // chunk c + 1; the caller's stream only waits for this chunk's mixer at the end (the input is host memory: nothing of
   // the caller's earlier work is needed, d_out must simply not be in use).
-  const int par = (int)(h->chunks & 1);
+  const int par = (int)(h->chunks % P8S_XBUFS);
   int16_t* dx = h->d_x[par]; uint8_t* dord = h->d_order[par];
   if (h->mix_used[par]) for (hipStream_t q : {h->s_a, h->s_b, h->s_c, h->s_d, h->s_e}) ok = ok && hipStreamWaitEvent(q, h->ev_mix[par], 0) == hipSuccess;   // the mixer that last read these rows
   ok = ok && hipMemcpyAsync(b.d, b.h, b.total, hipMemcpyHostToDevice, h->s_d) == hipSuccess;

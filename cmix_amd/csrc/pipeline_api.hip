@@ -14,6 +14,7 @@
 // overlap (up to four chunks in flight). Columns 3..2024 (fxcm, paq8) have no stage yet: the caller supplies
 // them inside d_layer0. No CPU fallback exists for any device stage.
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -25,7 +26,7 @@
 void cmx_set_err(const std::string& s);  // cmx_api.hip
 
 namespace {
-constexpr int kSlots = 4;  // chunks in flight: the LSTM of chunk i+2 must be able to start while chunk i is still in the mixing network
+constexpr int kSlots = CMX_PIPELINE_SLOTS;  // chunks in flight: a chunk's latency (paq8 maps -> family -> paq8 mixer -> mixing network) is ~3 chunk periods
 struct Slot {
   uint8_t* d_bytes = nullptr;
   uint8_t* d_bits = nullptr;
@@ -65,6 +66,7 @@ struct cmx_pipeline {
   hipStream_t s_p8 = nullptr;
   float* d_p8_scratch = nullptr; // pretraining writes its (discarded) rows here
   double p8_ms = 0;
+  double host_ms[6] = {0, 0, 0, 0, 0, 0};   // calling thread, since the last reset: slot wait, PPMd, ctx + LSTM enqueue, fxcm (parser + enqueue), paq8 (front end + enqueue), mixing network enqueue
   Slot slot[kSlots];
   uint64_t chunks = 0;    // chunks begun
   uint64_t hinted = 0;    // chunks whose LSTM hints were handed out (<= chunks)
@@ -244,6 +246,10 @@ int cmx_pipeline_enable_paq8(cmx_pipeline_t* h) {
 }
 int cmx_pipeline_paq8_enabled(cmx_pipeline_t* h) { return h && h->p8 ? 1 : 0; }
 int cmx_pipeline_paq8_total_ms(cmx_pipeline_t* h, double* ms) { if (!h || !ms) return 1; *ms = h->p8_ms; return 0; }
+// wall time of the CALLING thread inside cmx_pipeline_begin / _finish since the last reset of the stage totals, in ms:
+// [0] waiting for a slot (the device is behind), [1] PPMd, [2] uploads + context stage + LSTM enqueue, [3] fxcm (text parser,
+// staging wait, enqueue), [4] paq8 (front end, staging wait, enqueue), [5] mixing network enqueue
+int cmx_pipeline_host_ms(cmx_pipeline_t* h, double ms[6]) { if (!h || !ms) return 1; for (int i = 0; i < 6; i++) ms[i] = h->host_ms[i]; return 0; }
 int cmx_pipeline_fxcm_enabled(cmx_pipeline_t* h) { return h && h->fxcm ? 1 : 0; }
 // HIP-event time of the fxcm kernel over the chunks counted by cmx_pipeline_stage_totals (same reset)
 int cmx_pipeline_fxcm_total_ms(cmx_pipeline_t* h, double* ms) { if (!h || !ms) return 1; *ms = h->fx_ms; return 0; }
@@ -256,17 +262,22 @@ int cmx_pipeline_begin(cmx_pipeline_t* h, const uint8_t* bytes, size_t n, float*
   if (h->chunks - h->finished >= (uint64_t)kSlots) { cmx_set_err("cmx_pipeline_begin: too many chunks begun and not finished"); return 1; }
   if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
   Slot& s = h->slot[h->chunks % kSlots];
+  auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_mark = now();
+  auto lap = [&](int k) { const double t = now(); h->host_ms[k] += t - t_mark; t_mark = t; };
   if (s.used && hipEventSynchronize(s.ev_mix1) != hipSuccess) {  // the chunk that used these buffers kSlots submits ago
     cmx_set_err("cmx_pipeline_begin: device error in an earlier chunk");
     return 1;
   }
   collect(h, s);
+  lap(0);
   s.n = n;
   s.d_layer0 = d_layer0;
   // ---- host stage: PPMd runs ahead of the device on this thread ----
   memcpy(s.h_ppmd, h->last_dist, 256 * 4);
   if (cmx_ppmd_run(h->ppmd, bytes, n, s.h_ppmd + 256)) return 1;
   memcpy(h->last_dist, s.h_ppmd + n * 256, 256 * 4);
+  lap(1);
   memcpy(s.h_bytes, bytes, n);
   uint8_t* hb = s.h_bytes + n;
   for (size_t i = 0; i < n; ++i)
@@ -290,6 +301,7 @@ int cmx_pipeline_begin(cmx_pipeline_t* h, const uint8_t* bytes, size_t n, float*
                    (int*)(s.d_hint + (8 * h->max_chunk + 1)), h->s_lstm))
     return 1;
   (void)hipEventRecord(s.ev_lstm1, h->s_lstm);
+  lap(2);
   if (h->fxcm) {  // ---- fxcm stage: hints from the LSTM's columns, then the parser (this thread) and the kernel on its own stream ----
     const size_t T = 8 * n;
     float* dp = s.d_hint;
@@ -303,11 +315,13 @@ int cmx_pipeline_begin(cmx_pipeline_t* h, const uint8_t* bytes, size_t n, float*
     if (cmx_fxcm_run(h->fxcm, bytes, s.d_bytes, n, s.d_fx_pr, s.d_fx_ex, d_layer0, CMX_N_INPUTS, h->s_fx)) return 1;
     (void)hipEventRecord(s.ev_fx1, h->s_fx);
   }
+  lap(3);
   if (h->p8) {  // ---- paq8 stage: front end on this thread, role kernels on its own streams; needs nothing from the other stages ----
     (void)hipEventRecord(s.ev_p80, h->s_p8);
     if (cmx_p8stage_run(h->p8, bytes, n, d_layer0 + 434, CMX_N_INPUTS, h->s_p8)) return 1;
     (void)hipEventRecord(s.ev_p81, h->s_p8);
   }
+  lap(4);
   s.used = true;
   s.untimed = false;  // becomes true once its mixing network is enqueued
   h->chunks++;
@@ -370,6 +384,7 @@ static int finish_impl(cmx_pipeline_t* h, const float* cols, int first_col, int 
     if (!ok) { cmx_set_err("cmx_pipeline_finish: column upload failed"); return 1; }
   }
   // ---- final mixing network, once both producers have written their columns ----
+  const auto t_fin = std::chrono::steady_clock::now();
   (void)hipStreamWaitEvent(h->s_mix, s.ev_ctx1, 0);
   (void)hipStreamWaitEvent(h->s_mix, s.ev_lstm1, 0);
   if (h->fxcm) (void)hipStreamWaitEvent(h->s_mix, s.ev_fx1, 0);
@@ -377,6 +392,7 @@ static int finish_impl(cmx_pipeline_t* h, const float* cols, int first_col, int 
   (void)hipEventRecord(s.ev_mix0, h->s_mix);
   if (cmx_mixnet_run(h->mix, s.d_layer0, s.d_sel, s.d_bits, 8 * n, d_p_out, nullptr, h->s_mix)) return 1;
   (void)hipEventRecord(s.ev_mix1, h->s_mix);
+  h->host_ms[5] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fin).count();
   s.untimed = true;
   h->last_slot = (int)(h->finished % kSlots);
   h->finished++;
@@ -466,7 +482,7 @@ int cmx_pipeline_stage_totals(cmx_pipeline_t* h, double ms[3], uint64_t* chunks,
   if (!h || !ms || !chunks) return 1;
   for (int i = 0; i < 3; ++i) ms[i] = h->tot_ms[i];
   *chunks = h->tot_chunks;
-  if (reset) { h->tot_ms[0] = h->tot_ms[1] = h->tot_ms[2] = 0; h->tot_chunks = 0; h->fx_ms = 0; h->p8_ms = 0; }
+  if (reset) { h->tot_ms[0] = h->tot_ms[1] = h->tot_ms[2] = 0; h->tot_chunks = 0; h->fx_ms = 0; h->p8_ms = 0; for (double& v : h->host_ms) v = 0; }
   return 0;
 }
 

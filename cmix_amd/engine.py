@@ -18,6 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libcmixamd.so")
 
 N_INPUTS, N_MIXERS = 2078, 47
+PIPELINE_SLOTS = 8   # CMX_PIPELINE_SLOTS (include/cmix_amd.h): chunks in flight per stream
 
 
 class CmxError(RuntimeError):
@@ -163,6 +164,7 @@ def lib():
         L.cmx_pipeline_enable_paq8.argtypes = [C.c_void_p]
         L.cmx_pipeline_wait.argtypes = [C.c_void_p, C.c_uint64]
         L.cmx_pipeline_paq8_total_ms.argtypes = [C.c_void_p, C.c_void_p]
+        L.cmx_pipeline_host_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.cmx_pipeline_last_stage_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.cmx_probe_libm.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
         _lib = L
@@ -457,6 +459,12 @@ class Pipeline:
         lib().cmx_pipeline_paq8_total_ms(self.h, C.byref(ms))
         return ms.value
 
+    def host_ms(self):
+        """Calling-thread wall time inside begin / finish since the last totals reset: dict of ms."""
+        v = (C.c_double * 6)()
+        lib().cmx_pipeline_host_ms(self.h, v)
+        return dict(zip(("slot_wait", "ppmd", "ctx_lstm_enqueue", "fxcm_parser_enqueue", "paq8_front_enqueue", "mixnet_enqueue"), [float(x) for x in v]))
+
     def finish_cols(self, cols, first_col, p_out):
         """finish() with host rows covering layer-0 columns first_col .. first_col + cols.shape[1] - 1 only."""
         cols = np.ascontiguousarray(cols, np.float32)
@@ -483,7 +491,7 @@ class Pipeline:
         return {"ctxmodels": ms[0], "lstm": ms[1], "mixnet": ms[2]}
 
     def begin(self, data, layer0):
-        """First step of a chunk (PPMd, contexts, LSTM); up to 4 chunks may be begun and not finished."""
+        """First step of a chunk (PPMd, contexts, LSTM); up to PIPELINE_SLOTS chunks may be begun and not finished."""
         data = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8))
         self._n_begun = getattr(self, "_n_begun", [])
         self._n_begun.append(len(data))

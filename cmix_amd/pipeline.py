@@ -135,7 +135,7 @@ class EngineStream:
             self.vocab = np.zeros(256, np.uint8)
             self.vocab[np.unique(self.stream)] = 1
         self.header = E.header_write(n, self.vocab, dictionary_used)
-        self.layer0 = [torch.empty((8 * self.sub, E.N_INPUTS), dtype=torch.float32, device=self.dev) for _ in range(4)]
+        self.layer0 = [torch.empty((8 * self.sub, E.N_INPUTS), dtype=torch.float32, device=self.dev) for _ in range(E.PIPELINE_SLOTS)]
         self.p_dev = torch.empty(8 * n, dtype=torch.float32, device=self.dev)
         self.pipe = E.Pipeline(self.vocab, device_index, self.sub)
         self.pipe.enable_fxcm(None)
@@ -145,11 +145,11 @@ class EngineStream:
         torch.cuda.synchronize(self.dev)
 
     def feed(self, nbytes):
-        """The next nbytes bytes of the stream, in sub-chunks (asynchronous; up to four sub-chunks in flight)."""
+        """The next nbytes bytes of the stream, in sub-chunks (asynchronous; up to E.PIPELINE_SLOTS sub-chunks in flight)."""
         end = min(self.pos + nbytes, len(self.stream))
         while self.pos < end:
             m = min(self.sub, end - self.pos)
-            l0 = self.layer0[self.nsub % 4][:8 * m]
+            l0 = self.layer0[self.nsub % E.PIPELINE_SLOTS][:8 * m]
             self.pipe.submit(self.stream[self.pos:self.pos + m], l0, self.p_dev[8 * self.pos:8 * (self.pos + m)])
             self.pos += m
             self.nsub += 1

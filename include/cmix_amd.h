@@ -367,9 +367,11 @@ int cmx_ppmd_run(cmx_ppmd_t*, const uint8_t* bytes, size_t nbytes, float* out_pr
  * 3. One stream through every stage built so far: the native orchestration behind the Predictor
  *    surface, a chunk of already-known bytes at a time (Predictor::Predict/Perceive, predictor.cpp:
  *    361-469, in compression look-ahead form). PPMd runs on the calling host thread; the context /
- *    small-model stage, the LSTM and the mixing network run on three internal HIP streams; up to four
- *    chunks may be in flight (a submit blocks while the chunk four submits back is still running).
+ *    small-model stage, the LSTM and the mixing network run on three internal HIP streams; up to
+ *    CMX_PIPELINE_SLOTS chunks may be in flight (a submit blocks while the chunk that many submits back is still running:
+ *    a chunk's latency through the stages is several chunk periods, the depth keeps every stage busy).
  * ------------------------------------------------------------------------ */
+#define CMX_PIPELINE_SLOTS 8   /* chunks in flight per stream (layer-0 matrices the caller cycles through) */
 typedef struct cmx_pipeline cmx_pipeline_t;
 cmx_pipeline_t* cmx_pipeline_create(const uint8_t vocab[256], int device, size_t max_chunk_bytes);
 void cmx_pipeline_destroy(cmx_pipeline_t*);
@@ -383,7 +385,7 @@ void cmx_pipeline_destroy(cmx_pipeline_t*);
  * stay valid until cmx_pipeline_sync() or until two further submits have returned. */
 int cmx_pipeline_submit(cmx_pipeline_t*, const uint8_t* bytes, size_t n, float* d_layer0, float* d_p_out);
 /* The same chunk in steps, for look-ahead coding while some model families still run on the host:
- *   _begin   PPMd (this thread), upload, context stage and LSTM are enqueued; up to 4 chunks may be begun and not
+ *   _begin   PPMd (this thread), upload, context stage and LSTM are enqueued; up to CMX_PIPELINE_SLOTS chunks may be begun and not
  *            finished;
  *   _hints   (optional) for the oldest begun chunk that has not handed them out: lstm_p[t], lstm_ex[t], t = 0 .. 8n,
  *            = the LSTM byte mixer's ByteModel::Predict value and `ex` for bit t of the chunk (t = 8n: the first bit
@@ -408,10 +410,14 @@ int cmx_pipeline_enable_fxcm(cmx_pipeline_t*, const char* dictionary_path);
  * cmx_pipeline_pretrain feeds it the dictionary. With both vendored families on the device cmx_pipeline_finish takes no
  * columns (cmx_pipeline_submit does everything) and the Predictor shim needs no cmx_set_model_outputs. */
 int cmx_pipeline_enable_paq8(cmx_pipeline_t*);
-/* Wait until chunk number `index` (0 = the first submitted) has left the mixing network; only the last four can be waited for. */
+/* Wait until chunk number `index` (0 = the first submitted) has left the mixing network; only the last CMX_PIPELINE_SLOTS can be waited for. */
 int cmx_pipeline_wait(cmx_pipeline_t*, uint64_t index);
 int cmx_pipeline_paq8_enabled(cmx_pipeline_t*);
 int cmx_pipeline_paq8_total_ms(cmx_pipeline_t*, double* ms);
+/* wall time of the calling thread inside begin / finish since the last reset of the stage totals, ms: [0] waiting for a
+ * slot, [1] PPMd, [2] uploads + context stage + LSTM enqueue, [3] fxcm (parser + enqueue), [4] paq8 (front end + enqueue),
+ * [5] mixing network enqueue */
+int cmx_pipeline_host_ms(cmx_pipeline_t*, double ms[6]);
 int cmx_pipeline_fxcm_enabled(cmx_pipeline_t*);
 int cmx_pipeline_finish_cols(cmx_pipeline_t*, const float* cols, int first_col, int ncols, float* d_p_out);
 int cmx_pipeline_fxcm_total_ms(cmx_pipeline_t*, double* ms);

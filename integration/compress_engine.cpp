@@ -36,10 +36,11 @@ void CompressEngine(Predictor* P, const std::vector<uint8_t>& data, cmx_encoder_
   if (N == 0) return;
   const int dev = P->device();
   const size_t C = P->chunk(), T = 8 * C;
-  // four chunks in flight: each owns a layer-0 matrix and a p[] buffer on the device; p[] comes back and is coded as
+  // CMX_PIPELINE_SLOTS chunks in flight: each owns a layer-0 matrix and a p[] buffer on the device; p[] comes back and is coded as
   // soon as the chunk has left the mixing network, so memory does not grow with the input and output appears as it goes
-  float* d_layer0[4]; float* d_p[4];
-  for (int i = 0; i < 4; ++i) {
+  constexpr size_t R = CMX_PIPELINE_SLOTS;
+  float* d_layer0[R]; float* d_p[R];
+  for (size_t i = 0; i < R; ++i) {
     d_layer0[i] = (float*)cmx_device_alloc(dev, T * CMX_N_INPUTS * sizeof(float));
     d_p[i] = (float*)cmx_device_alloc(dev, T * sizeof(float));
     if (!d_layer0[i] || !d_p[i]) Predictor::Die();
@@ -49,17 +50,17 @@ void CompressEngine(Predictor* P, const std::vector<uint8_t>& data, cmx_encoder_
   auto len = [&](size_t c) { return c + 1 < nchunks ? C : N - c * C; };
   auto drain = [&](size_t c) {   // chunk c: wait, copy its probabilities back, code its bytes
     if (cmx_pipeline_wait(P->pipe(), c)) Predictor::Die();
-    if (cmx_copy_to_host(dev, p.data(), d_p[c & 3], 8 * len(c) * sizeof(float))) Predictor::Die();
+    if (cmx_copy_to_host(dev, p.data(), d_p[c % R], 8 * len(c) * sizeof(float))) Predictor::Die();
     if (cmx_encoder_encode_bytes(enc, p.data(), data.data() + c * C, len(c))) Predictor::Die();
   };
   for (size_t c = 0; c < nchunks; ++c) {
-    if (c >= 4) drain(c - 4);   // frees slot c & 3
-    if (cmx_pipeline_submit(P->pipe(), data.data() + c * C, len(c), d_layer0[c & 3], d_p[c & 3])) Predictor::Die();
+    if (c >= R) drain(c - R);   // frees slot c % R
+    if (cmx_pipeline_submit(P->pipe(), data.data() + c * C, len(c), d_layer0[c % R], d_p[c % R])) Predictor::Die();
     fprintf(stderr, "\rprogress: %.2f%%", 100.0 * (c + 1) / nchunks);
   }
-  for (size_t c = nchunks > 4 ? nchunks - 4 : 0; c < nchunks; ++c) drain(c);
+  for (size_t c = nchunks > R ? nchunks - R : 0; c < nchunks; ++c) drain(c);
   if (cmx_pipeline_sync(P->pipe())) Predictor::Die();
-  for (int i = 0; i < 4; ++i) { cmx_device_free(dev, d_layer0[i]); cmx_device_free(dev, d_p[i]); }
+  for (size_t i = 0; i < R; ++i) { cmx_device_free(dev, d_layer0[i]); cmx_device_free(dev, d_p[i]); }
 }
 }  // namespace
 
