@@ -62,6 +62,41 @@ __device__ __forceinline__ float seg_v1(const float* rowp, float p) {
   }
   return p;
 }
+// variant 2: two lanes per chain -- lane L (L & 8 == 0) owns the chain, lane L + 8 of the same row of 16 fetches the
+// other half of every 8 consecutive terms; the owner adds its partner's four values with DPP (row_shl:8) adds, so one
+// ds_read_b128 of the wave feeds EIGHT terms of every chain instead of four.
+__device__ __forceinline__ float dpp_add(float p, float x) {
+  asm volatile("v_add_f32_dpp %0, %1, %0 row_shl:8 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(p) : "v"(x));
+  return p;
+}
+__device__ __forceinline__ float add8(float p, float4 v) {
+  p = add4(p, v);
+  p = dpp_add(p, v.x); p = dpp_add(p, v.y); p = dpp_add(p, v.z); p = dpp_add(p, v.w);
+  return p;
+}
+// rowp: the lane's own view (owner: row, partner: row + 4 floats); 512 terms = 64 reads of 8 terms
+__device__ __forceinline__ float seg_v2(const float* rowp, float p) {
+  const float4* row = reinterpret_cast<const float4*>(__builtin_assume_aligned(rowp, 16));
+  float4 a[8], b[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = row[2 * i];
+#pragma unroll 1
+  for (int bi = 0; bi < 8; bi += 2) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b[i] = row[2 * ((bi + 1) * 8 + i)];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) p = add8(p, a[i]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = row[2 * ((bi + 2) * 8 + i)];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) p = add8(p, b[i]);
+  }
+  return p;
+}
 template <int V, int ACTIVE, int EXTRA_WAVES>
 __global__ void k(float* out, uint64_t* t) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -73,12 +108,13 @@ __global__ void k(float* out, uint64_t* t) {
     return;
   }
   int m = threadIdx.x < 26 ? threadIdx.x : 0;
+  const int L = threadIdx.x, m2 = (L >> 4) * 8 + (L & 7), part = (L >> 3) & 1;
   float p = 0;
   __builtin_amdgcn_s_setprio(3);
   uint64_t c0 = __builtin_readcyclecounter();
   if ((int)threadIdx.x < ACTIVE) {
 #pragma unroll 1
-    for (int r = 0; r < 64; ++r) p = V == 0 ? seg_v0(sm + m * SEG, p) : seg_v1(sm + m * SEG, p);
+    for (int r = 0; r < 64; ++r) p = V == 0 ? seg_v0(sm + m * SEG, p) : V == 1 ? seg_v1(sm + m * SEG, p) : seg_v2(sm + (m2 < 26 ? m2 : 0) * SEG + 4 * part, p);
   }
   uint64_t c1 = __builtin_readcyclecounter();
   out[threadIdx.x] = p;
@@ -103,5 +139,7 @@ int main() {
   run<1, 26, 0>("v1 asm one-wait, 26 lanes, alone", out, t);
   run<1, 26, 11>("v1 asm one-wait, 26 lanes, +11 sleeping waves", out, t);
   run<0, 26, 11>("v0 ladder, 26 lanes, +11 sleeping waves", out, t);
+  run<2, 64, 0>("v2 owner+partner DPP, 64 lanes, alone", out, t);
+  run<2, 64, 11>("v2 owner+partner DPP, +11 sleeping waves", out, t);
   return 0;
 }

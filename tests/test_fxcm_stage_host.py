@@ -201,3 +201,37 @@ def test_block_position_thresholds_vs_oracle(blpos):
     data = np.frombuffer(synth.enwik_like(1800, 4), np.uint8)
     pr, ex = hints(8 * len(data), 17)
     compare(run_emul(L, data, pr, ex, [600] * 3, blpos=blpos), oracle_rows(data, pr, ex, blpos=blpos), "blpos %d" % blpos)
+
+
+def _reference_fixture(name):
+    """tests/golden/fxcm_cols_*.npz (tests/golden/make_fxcm_hashes.py): per-bit hashes of the 431 values the UNMODIFIED
+    reference's fxcmv1::Predictor returned for a 16 KB stream, with the seeded hints it was driven with."""
+    import make_fxcm_hashes as mk
+    g = load_golden(name)
+    data = g["stream"]
+    pr, ex = mk.hints(8 * len(data), int(g["hint_seed"][0]))
+    dic = None
+    if "dictionary" in g:
+        import tempfile
+        with tempfile.NamedTemporaryFile("wb", suffix=".dic", delete=False) as f:
+            f.write(g["dictionary"].tobytes())
+            dic = f.name.encode()
+    return data, pr, ex, dic, g["hash"], mk.row_hash
+
+
+@pytest.mark.parametrize("name", ["fxcm_cols_wiki_16k", "fxcm_cols_dict_16k"])
+def test_reference_hashes_16k(name):
+    """The product's text parser + the kernel body (host run) and the oracle against the reference itself on 16 KB of
+    wiki markup and of dictionary-mode (WRT-coded) text: 131072 bits x 431 values each, compared through row hashes."""
+    L = emul()
+    data, pr, ex, dic, want, row_hash = _reference_fixture(name)
+    try:
+        got = row_hash(run_emul(L, data, pr, ex, [4096, 1, 4095, 8192], dictionary=dic))
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (name, "kernel body: first differing bit", int(bad[0]))
+        orc = row_hash(oracle_rows(data, pr, ex, dictionary=dic))
+        bad = np.nonzero(orc != want)[0]
+        assert bad.size == 0, (name, "oracle: first differing bit", int(bad[0]))
+    finally:
+        if dic:
+            os.unlink(dic.decode())

@@ -52,10 +52,6 @@ def test_golden_text_96_ragged_chunks():
     _check_golden("text_96", chunks=[1, 2, 9, 64, 65, 300, 511])
 
 
-def test_golden_text_4k_reference_trace():
-    _check_golden("text_4k", big=True)
-
-
 def test_vs_oracle_synthetic_long():
     """3000 bits with few distinct contexts so rows pass 1024 steps (periodic weight decay)."""
     from oracle import oracle as O

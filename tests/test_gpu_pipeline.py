@@ -69,10 +69,6 @@ def test_pipeline_binary_64_ragged():
     _pipeline("binary_64", chunks=[1, 7, 40])
 
 
-def test_pipeline_text_4k_local():
-    _pipeline("text_4k", chunks=[1024, 3000], big=True)
-
-
 def _native(name, chunks=None, big=False):
     """Same check through cmx_pipeline_* (the native C++ orchestration: PPMd host stage, three HIP streams, up to four
     chunks in flight): only the fxcm/paq8 columns come from the trace."""
@@ -105,10 +101,6 @@ def test_native_pipeline_text_96_ragged():
 
 def test_native_pipeline_binary_64():
     _native("binary_64")
-
-
-def test_native_pipeline_text_4k_local():
-    _native("text_4k", chunks=[1000, 2000, 3000], big=True)
 
 
 def test_native_pipeline_pretrained_128():

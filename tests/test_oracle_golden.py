@@ -30,10 +30,6 @@ def test_mixnet_binary_golden():
     _check("binary_64")
 
 
-def test_mixnet_text_4k_local():
-    _check("text_4k", big=True)
-
-
 @pytest.mark.parametrize("name", ["text_96", "binary_64"])
 def test_paq8_oracle_reproduces_golden_columns(name):
     """The assembled paq8 restatement (oracle/paq8_predictor.c) at cmix's own setting (level 11, reference
