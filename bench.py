@@ -50,7 +50,20 @@ ALGO = {
     "lstm": 8.86e6,                                       # gate weights forward + BPTT share per byte
     "ctxmodels": 54 * 8 * 64,
 }
-KERNEL = {"mixnet": "cmx_mixnet_chunk_kernel", "paq8": "cmx_p8s_* role kernels (span)", "fxcm": "cmx_fxcm_chunk_kernel",
+# HBM traffic per input byte of each stage's kernels, from the PMC passes of this bench command (profiles/r02_pmc_bench_64k.json:
+# rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, KB summed over the launches; FETCH_SIZE doubled as
+# /opt/skills/guides/MI355X_MICROARCH.md prescribes for 16-byte-per-lane loads on gfx950); that run processed 81 926 stream bytes
+# (65 542 timed + 16 384 warm-up) in 22 launches per stage
+PMC_KB = {"mixnet": (28218.2e3, 54742.7e3, 22), "fxcm": (1442.8e3, 2832.8e3, 22), "lstm": (46764.0e3 + 7836.3e3 + 4565.0e3, 904.9e3 + 10470.9e3 + 21056.7e3, 22),
+          "paq8": (9444.5e3, 26357.6e3, 22), "ctxmodels": (379.5e3, 679.1e3, 22)}   # paq8: its mixer kernel (the role that sets the stage's period)
+
+
+def pmc_traffic_per_byte(stage):
+    f, w, _launches = PMC_KB[stage]
+    return (2.0 * f + w) * 1024.0 / 81926.0
+
+
+KERNEL = {"mixnet": "cmx_mixnet_chunk_kernel", "paq8": "cmx_p8s_mix2_kernel / cmx_p8s_fam2_kernel (slowest role)", "fxcm": "cmx_fxcm_chunk_kernel",
           "lstm": "cmx_lstm_fwd / cmx_lstm_bptt_*", "ctxmodels": "cmx_ctxmodels_kernel"}
 
 
@@ -143,8 +156,12 @@ def main():
     st = eng.pipe.stage_totals()
     nsub = max(st["chunks"], 1)
     bits_per_sub = 8.0 * n / nsub
+    roles, rchunks = eng.pipe.paq8_role_ms()
+    p8_roles = {k: v / max(rchunks, 1) * 1e3 / bits_per_sub for k, v in roles.items()}
+    # the paq8 stage's role kernels run on streams of their own: its period is the slowest role, its latency their chain
     us = {"mixnet": st["mixnet"] * 1e3 / bits_per_sub, "ctxmodels": st["ctxmodels"] * 1e3 / bits_per_sub, "lstm": st["lstm"] * 1e3 / bits_per_sub,
-          "fxcm": eng.pipe.fxcm_total_ms() / nsub * 1e3 / bits_per_sub, "paq8": eng.pipe.paq8_total_ms() / nsub * 1e3 / bits_per_sub}
+          "fxcm": eng.pipe.fxcm_total_ms() / nsub * 1e3 / bits_per_sub, "paq8": max(p8_roles.values())}
+    p8_span = eng.pipe.paq8_total_ms() / nsub * 1e3 / bits_per_sub
 
     if rank == 0:
         sha = hashlib.sha256(blob).hexdigest()
@@ -173,11 +190,16 @@ def main():
                 "payload_bytes": a.payload_bytes, "stream_bytes": n, "sub_chunk_bytes": a.sub_chunk,
                 "parallelism": "1 stream per GPU, no collective"},
             "us_per_bit": dt / (8.0 * n) * 1e6,
-            "stage_us_per_bit": dict(us, note="mean HIP-event time per bit of each stage over the timed run (stages overlap on their own streams; paq8 = span of its role kernels + mixer)"),
+            "stage_us_per_bit": dict(us, note="mean HIP-event time per bit of each stage's kernel(s) over the timed run; the stages overlap on their own streams, "
+                                              "so the stream's period is the slowest one (paq8 = its slowest role kernel)"),
+            "paq8_role_us_per_bit": dict(p8_roles, span=p8_span, note="role kernels of the paq8 stage on their own streams; span = first launch to end of its mixer, per chunk"),
             "host_us_per_byte": dict({k: v * 1e3 / n for k, v in host.items()}, note="wall time of the submitting thread per stream byte (slot_wait = blocked on the device)"),
             "verified": verified,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": KERNEL[dom], "stage": dom, "avg_launch_ms": kernel_s * 1e3,
+                         "traffic": pmc_traffic_per_byte(dom) * n / nsub,
+                         "traffic_source": "profiles/r02_pmc_bench_64k.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at 64 KB; 2 x FETCH_SIZE + WRITE_SIZE, "
+                                           "scaled to this launch size)",
+                         "kernel": KERNEL[dom], "stage": dom, "avg_launch_ms": kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": algo_launch,
                          "note": "every stage is a latency-bound dependent chain per stream (DESIGN.md 4); strict-mode ceiling of the final mixing network: "
                                  "2078 dependent f32 adds per bit"},

@@ -689,7 +689,8 @@ struct Staging {   // one chunk's records: page-locked host arrays and their dev
   char* h = nullptr; char* d = nullptr;
   size_t o_fctx, o_fchk, o_cctx[P8_NCM2], o_cchk[P8_NCM2], o_ops, o_sel, o_apm, o_bits, total;
   hipEvent_t done = nullptr;
-  bool used = false;
+  hipEvent_t t0[6] = {}, t1[6] = {};   // HIP-event brackets of the role kernels of the chunk: family, mixer, cm2[0..2], lanes + DMC
+  bool used = false, timed = false;
 };
 template <class Tp> Tp* dev_copy(const Tp& host, DevPolicy& pol) {
   Tp* p = (Tp*)pol.zalloc(sizeof(Tp));
@@ -717,7 +718,14 @@ struct cmx_p8stage {
   int last_bit = 0;
   bool failed = false;
   float ms_front = 0;   // host time of the last front-end pass
+  double role_ms[6] = {0, 0, 0, 0, 0, 0}; uint64_t role_chunks = 0;   // summed over the chunks collected so far
 };
+static void p8s_collect(cmx_p8stage* h, Staging& b) {   // the chunk that used b is complete
+  if (!b.timed) return;
+  for (int i = 0; i < 6; i++) { float f = 0; if (hipEventElapsedTime(&f, b.t0[i], b.t1[i]) == hipSuccess) h->role_ms[i] += f; }
+  h->role_chunks++;
+  b.timed = false;
+}
 
 extern "C" {
 
@@ -730,6 +738,8 @@ void cmx_p8stage_destroy(cmx_p8stage_t* h) {
     if (s.h) (void)hipHostFree(s.h);
     if (s.d) (void)hipFree(s.d);
     if (s.done) (void)hipEventDestroy(s.done);
+    for (hipEvent_t e : s.t0) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : s.t1) if (e) (void)hipEventDestroy(e);
   }
   for (int i = 0; i < P8S_XBUFS; i++) { if (h->d_x[i]) (void)hipFree(h->d_x[i]); if (h->d_order[i]) (void)hipFree(h->d_order[i]); }
   for (hipStream_t q : {h->s_a, h->s_b, h->s_c, h->s_d, h->s_e, h->s_m}) if (q) (void)hipStreamDestroy(q);
@@ -768,7 +778,10 @@ cmx_p8stage_t* cmx_p8stage_create(int device) {
   for (hipStream_t* q : {&h->s_a, &h->s_b, &h->s_c, &h->s_d, &h->s_e, &h->s_m}) ok = ok && hipStreamCreateWithFlags(q, hipStreamNonBlocking) == hipSuccess;
   for (hipEvent_t* e : {&h->ev_up, &h->ev_ord, &h->ev_a, &h->ev_b, &h->ev_c, &h->ev_e}) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
   for (hipEvent_t& e : h->ev_mix) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
-  for (auto& s : h->st) ok = ok && hipEventCreateWithFlags(&s.done, hipEventDisableTiming) == hipSuccess;
+  for (auto& s : h->st) {
+    ok = ok && hipEventCreateWithFlags(&s.done, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 6; i++) ok = ok && hipEventCreate(&s.t0[i]) == hipSuccess && hipEventCreate(&s.t1[i]) == hipSuccess;
+  }
   if (ok && getenv("CMX_P8MIX_PROFILE")) ok = hipMalloc((void**)&h->d_prof, 7 * 8 * 8) == hipSuccess && hipMemset(h->d_prof, 0, 7 * 8 * 8) == hipSuccess;
   ok = ok && hipDeviceSynchronize() == hipSuccess;
   if (!ok) { cmx_set_err("cmx_p8stage_create: allocation / init failed (the stage needs ~9 GB of HBM)"); cmx_p8stage_destroy(h); return nullptr; }
@@ -787,6 +800,7 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
   Staging& b = h->st[h->next];
   h->next = (h->next + 1) % P8S_BUFS;
   if (b.used && hipEventSynchronize(b.done) != hipSuccess) { cmx_set_err("cmx_p8stage_run: staging buffer wait failed"); h->failed = true; return 1; }
+  p8s_collect(h, b);
   const size_t n = nbytes, T = 8 * n;
   if (b.cap < n) {
     if (b.h) (void)hipHostFree(b.h);
@@ -835,19 +849,23 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
   const int skip = h->steps >= 8 ? 0 : (int)(8 - h->steps), t0 = h->steps == 0 ? 1 : 0;
   const uint8_t* d_bits = (const uint8_t*)(b.d + b.o_bits);
   auto cm2 = [&](int k, hipStream_t q, uint8_t* ord) {
+    (void)hipEventRecord(b.t0[2 + k], q);
     hipLaunchKernelGGL(h->fam_v1 ? cmx_p8s_cm2_kernel : cmx_p8s_cm2v2_kernel, dim3(1), dim3(P8CM2_MAXC), 0, q, h->d_cm2[k], (const uint32_t*)(b.d + b.o_cctx[k]),
                        (const uint16_t*)(b.d + b.o_cchk[k]), d_bits, dx, ord, nbits, skip);
+    (void)hipEventRecord(b.t1[2 + k], q);
   };
   if (ok) {
     cm2(0, h->s_d, dord);
     ok = hipEventRecord(h->ev_ord, h->s_d) == hipSuccess;
     ok = ok && hipStreamWaitEvent(h->s_a, h->ev_ord, 0) == hipSuccess;   // (implies the upload)
+    (void)hipEventRecord(b.t0[0], h->s_a);
     if (h->fam_v1)
       hipLaunchKernelGGL(cmx_p8s_fam_kernel, dim3(1), dim3(P8CM_MAXS), 0, h->s_a, h->d_fam, (const uint32_t*)(b.d + b.o_fctx), (const uint16_t*)(b.d + b.o_fchk), d_bits, dx,
                          (const uint8_t*)dord, nbits, skip);
     else
       hipLaunchKernelGGL(cmx_p8s_fam2_kernel, dim3(1), dim3(P8CM_MAXS), h->fam_lds, h->s_a, h->d_fam, h->d_fam_home, (const uint32_t*)(b.d + b.o_fctx),
                          (const uint16_t*)(b.d + b.o_fchk), d_bits, dx, (const uint8_t*)dord, nbits, skip);
+    (void)hipEventRecord(b.t1[0], h->s_a);
     ok = ok && hipEventRecord(h->ev_a, h->s_a) == hipSuccess;
     ok = ok && hipStreamWaitEvent(h->s_b, h->ev_up, 0) == hipSuccess;
     cm2(1, h->s_b, nullptr);
@@ -856,10 +874,13 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
     cm2(2, h->s_e, nullptr);
     ok = ok && hipEventRecord(h->ev_e, h->s_e) == hipSuccess;
     ok = ok && hipStreamWaitEvent(h->s_c, h->ev_ord, 0) == hipSuccess;
+    (void)hipEventRecord(b.t0[5], h->s_c);
     hipLaunchKernelGGL(cmx_p8s_lanes_kernel, dim3(1), dim3(P8_NLANE), 0, h->s_c, h->d_lanes, (const uint32_t*)(b.d + b.o_ops), d_bits, (const uint8_t*)dord, dx, nbits, t0);
     hipLaunchKernelGGL(cmx_p8s_dmc_kernel, dim3(1), dim3(P8DMC_THREADS), 0, h->s_c, h->d_dmc, d_bits, dx, (int)L.dmc_off, nbits, t0);
+    (void)hipEventRecord(b.t1[5], h->s_c);
     ok = ok && hipEventRecord(h->ev_c, h->s_c) == hipSuccess;
     for (hipEvent_t e : {h->ev_a, h->ev_b, h->ev_c, h->ev_e}) ok = ok && hipStreamWaitEvent(h->s_m, e, 0) == hipSuccess;
+    (void)hipEventRecord(b.t0[1], h->s_m);
     if (h->fam_v1 || getenv("CMX_P8MIX_V1"))
       hipLaunchKernelGGL(cmx_p8s_mix_kernel, dim3(1), dim3(MX_THREADS), 0, h->s_m, (const P8MixDev*)h->d_mix, h->d_tail, (const int16_t*)dx, (const int32_t*)(b.d + b.o_sel),
                          (const P8ApmRec*)(b.d + b.o_apm), (const uint8_t*)dord, d_bits, d_out, ld, nbits, t0, skip, h->last_bit);
@@ -867,6 +888,8 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
       hipLaunchKernelGGL(cmx_p8s_mix2_kernel, dim3(1), dim3(MX_THREADS), 0, h->s_m, (const P8MixDev*)h->d_mix, h->d_tail, (const int16_t*)dx, (const int32_t*)(b.d + b.o_sel),
                          (const P8ApmRec*)(b.d + b.o_apm), (const uint8_t*)dord, d_bits, d_out, ld, nbits, t0, skip, h->last_bit, h->d_prof);
     ok = ok && hipGetLastError() == hipSuccess;
+    (void)hipEventRecord(b.t1[1], h->s_m);
+    b.timed = true;
     ok = ok && hipEventRecord(h->ev_mix[par], h->s_m) == hipSuccess;
     ok = ok && hipEventRecord(b.done, h->s_m) == hipSuccess;
     ok = ok && hipStreamWaitEvent(s, h->ev_mix[par], 0) == hipSuccess;   // what the caller enqueues next sees this chunk's rows of d_out
@@ -892,6 +915,19 @@ int cmx_p8stage_sync(cmx_p8stage_t* h) {
   if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
   hipError_t e = hipDeviceSynchronize();
   if (e != hipSuccess) { cmx_set_err(std::string("cmx_p8stage_sync: ") + hipGetErrorString(e)); h->failed = true; return 1; }
+  for (auto& b : h->st) p8s_collect(h, b);
+  return 0;
+}
+
+// HIP-event time of the role kernels, summed over the chunks completed and collected so far (a chunk is collected when its
+// staging buffer comes round again, or by cmx_p8stage_sync): ms[0] family, [1] mixer + APM chains, [2..4] the three
+// ContextMap2 instances, [5] small lanes + DMC. They run on streams of their own: the stage's period per chunk is the
+// largest of them (the family after the order-N map of the same chunk, the mixer after all), not their sum.
+int cmx_p8stage_role_ms(cmx_p8stage_t* h, double ms[6], uint64_t* chunks, int reset) {
+  if (!h || !ms || !chunks) return 1;
+  for (int i = 0; i < 6; i++) ms[i] = h->role_ms[i];
+  *chunks = h->role_chunks;
+  if (reset) { for (double& v : h->role_ms) v = 0; h->role_chunks = 0; }
   return 0;
 }
 

@@ -165,6 +165,7 @@ def lib():
         L.cmx_pipeline_wait.argtypes = [C.c_void_p, C.c_uint64]
         L.cmx_pipeline_paq8_total_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.cmx_pipeline_host_ms.argtypes = [C.c_void_p, C.c_void_p]
+        L.cmx_pipeline_paq8_role_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.cmx_pipeline_last_stage_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.cmx_probe_libm.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
         _lib = L
@@ -458,6 +459,12 @@ class Pipeline:
         ms = C.c_double(0)
         lib().cmx_pipeline_paq8_total_ms(self.h, C.byref(ms))
         return ms.value
+
+    def paq8_role_ms(self):
+        """(dict of the paq8 role kernels' summed HIP-event ms, chunks collected) since the last totals reset."""
+        v, c = (C.c_double * 6)(), C.c_uint64(0)
+        lib().cmx_pipeline_paq8_role_ms(self.h, v, C.byref(c))
+        return dict(zip(("family", "mixer", "cm2_order_n", "cm2_text", "cm2_exe", "lanes_dmc"), [float(x) for x in v])), int(c.value)
 
     def host_ms(self):
         """Calling-thread wall time inside begin / finish since the last totals reset: dict of ms."""
