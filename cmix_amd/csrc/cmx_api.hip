@@ -96,6 +96,7 @@ struct cmx_mixnet {
   MixState h_state;  // host copy of the pointer block
   std::vector<void*> allocs;
   float* d_decay = nullptr;
+  hipStream_t run_stream = nullptr; bool run_stream_set = false;   // the stream cmx_mixnet_run was first called with
   size_t decay_cap = 0;
   float* h_decay = nullptr;  // pinned, DECAY_SLOTS x decay_cap: a slot is rewritten only after its copy ran
   hipEvent_t ev_decay[CMX_PIPELINE_SLOTS] = {};
@@ -306,6 +307,10 @@ int cmx_mixnet_run(cmx_mixnet_t* h, const float* d_probs, const uint32_t* d_sel,
   if (nbits > 0x7fffffff) { set_err("cmx_mixnet_run: chunk too large"); return 1; }
   HIP_OK(hipSetDevice(h->device));
   hipStream_t st = (hipStream_t)stream;
+  // One in-order stream per handle: the decay schedule goes through ONE device buffer and the kernel trains the handle's
+  // state, so chunks enqueued on different streams would race on both.
+  if (h->run_stream_set && st != h->run_stream) { set_err("cmx_mixnet_run: every chunk of a handle must be enqueued on the same stream"); return 1; }
+  h->run_stream = st; h->run_stream_set = true;
   // The decay schedule is staged through one of CMX_PIPELINE_SLOTS pinned slots; a slot is rewritten only once the copy
   // that read it has executed, so that many chunks can be enqueued without the host waiting for the GPU.
   if (ensure_decay(h, nbits)) return 1;

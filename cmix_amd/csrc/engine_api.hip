@@ -66,6 +66,7 @@ struct cmx_engine {
   int row_j = 0;                  // row of d_rows the last predict used
   unsigned partial = 0;           // those bits
   int lstmpr = 0, lstmex = 0;
+  bool failed = false;            // sticky: a step failed after the handle's state had begun to change (every later call is refused)
   std::vector<uint8_t> pre;       // Pretrain bytes not yet trained
   int pre_j = 0;
   unsigned pre_partial = 0;
@@ -81,6 +82,19 @@ struct cmx_engine {
   } while (0)
 
 namespace {
+
+// A call that fails after it has begun to change the handle's state (mixers trained, a stage half-enqueued) leaves the
+// stream in no state the reference ever is in: the handle is poisoned instead of silently diverging on a retry.
+struct Txn {
+  cmx_engine* h; bool ok = false;
+  explicit Txn(cmx_engine* e) : h(e) {}
+  ~Txn() { if (!ok) h->failed = true; }
+};
+bool refused(cmx_engine* h, const char* where) {
+  if (!h->failed) return false;
+  cmx_set_err(std::string(where) + ": an earlier call on this handle failed part-way; its state is void (destroy it)");
+  return true;
+}
 
 int flush_pretrain(cmx_engine* h) {
   const char* where = "cmx_pretrain";
@@ -211,8 +225,10 @@ float cmx_predict(cmx_t* h) {
                 "two model families have no device stage yet and there is no CPU fallback");
     return fail;
   }
+  if (refused(h, where)) return fail;
   E_HIP(hipSetDevice(h->device));
   if (h->pre_j) { cmx_set_err("cmx_predict: Pretrain() stopped inside a byte"); return fail; }
+  Txn txn(h);
   if (flush_pretrain(h)) return fail;
   h->started = true;
   const int j = h->j;
@@ -230,6 +246,7 @@ float cmx_predict(cmx_t* h) {
   h->row_j = j;
   h->predicted = true;
   h->have_staged = false;
+  txn.ok = true;
   return h->pin->p;
 }
 
@@ -238,7 +255,9 @@ int cmx_perceive(cmx_t* h, int bit) {
   const int fail = 1;
   if (!h) { cmx_set_err("cmx_perceive: null handle"); return 1; }
   if (!h->predicted) { cmx_set_err("cmx_perceive: no pending predict()"); return 1; }
+  if (refused(h, where)) return 1;
   E_HIP(hipSetDevice(h->device));
+  Txn txn(h);
   if (cmx_mixnet_perceive_async(h->mix, bit, h->st)) return 1;
   h->predicted = false;
   h->partial = (h->partial << 1) | (bit ? 1u : 0u);
@@ -254,7 +273,9 @@ int cmx_perceive(cmx_t* h, int bit) {
     h->j = 0;
     h->partial = 0;
   }
-  return enqueue_hint(h);  // nothing waits here: cmx_get_lstm_hint() / the next cmx_predict() synchronise
+  const int rc = enqueue_hint(h);  // nothing waits here: cmx_get_lstm_hint() / the next cmx_predict() synchronise
+  txn.ok = rc == 0;
+  return rc;
 }
 
 int cmx_get_lstm_hint(cmx_t* h, int* lstmpr, int* lstmex) {
@@ -282,8 +303,12 @@ int cmx_pretrain(cmx_t* h, int bit) {
     h->pre_j = 0;
     h->pre_partial = 0;
     if (h->pre.size() >= (1u << 16)) {
+      if (refused(h, "cmx_pretrain")) return 1;
       if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
-      return flush_pretrain(h);
+      Txn txn(h);
+      const int rc = flush_pretrain(h);
+      txn.ok = rc == 0;
+      return rc;
     }
   }
   return 0;

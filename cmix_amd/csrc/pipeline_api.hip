@@ -66,6 +66,7 @@ struct cmx_pipeline {
   hipStream_t s_p8 = nullptr;
   float* d_p8_scratch = nullptr; // pretraining writes its (discarded) rows here
   double p8_ms = 0;
+  bool failed = false;   // sticky: a chunk failed after its stages had begun to be enqueued (the stream's state is void)
   double host_ms[6] = {0, 0, 0, 0, 0, 0};   // calling thread, since the last reset: slot wait, PPMd, ctx + LSTM enqueue, fxcm (parser + enqueue), paq8 (front end + enqueue), mixing network enqueue
   Slot slot[kSlots];
   uint64_t chunks = 0;    // chunks begun
@@ -261,7 +262,9 @@ int cmx_pipeline_begin(cmx_pipeline_t* h, const uint8_t* bytes, size_t n, float*
   if (!h) { cmx_set_err("cmx_pipeline_begin: null handle"); return 1; }
   if (!bytes || !d_layer0 || n == 0 || n > h->max_chunk) { cmx_set_err("cmx_pipeline_begin: bad argument"); return 1; }
   if (h->chunks - h->finished >= (uint64_t)kSlots) { cmx_set_err("cmx_pipeline_begin: too many chunks begun and not finished"); return 1; }
+  if (h->failed) { cmx_set_err("cmx_pipeline_begin: an earlier chunk of this handle failed part-way; its state is void (destroy it)"); return 1; }
   if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
+  struct Txn { cmx_pipeline* h; bool ok = false; ~Txn() { if (!ok) h->failed = true; } } txn{h};   // from here on a failure leaves stages half-enqueued
   Slot& s = h->slot[h->chunks % kSlots];
   auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_mark = now();
@@ -326,6 +329,7 @@ int cmx_pipeline_begin(cmx_pipeline_t* h, const uint8_t* bytes, size_t n, float*
   s.used = true;
   s.untimed = false;  // becomes true once its mixing network is enqueued
   h->chunks++;
+  txn.ok = true;
   return 0;
 }
 
@@ -375,7 +379,9 @@ int cmx_pipeline_finish_cols(cmx_pipeline_t* h, const float* cols, int first_col
 static int finish_impl(cmx_pipeline_t* h, const float* cols, int first_col, int ncols, float* d_p_out) {
   if (!h || !d_p_out) { cmx_set_err("cmx_pipeline_finish: bad argument"); return 1; }
   if (h->finished >= h->chunks) { cmx_set_err("cmx_pipeline_finish: no begun chunk"); return 1; }
+  if (h->failed) { cmx_set_err("cmx_pipeline_finish: an earlier chunk of this handle failed part-way; its state is void (destroy it)"); return 1; }
   if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
+  struct Txn { cmx_pipeline* h; bool ok = false; ~Txn() { if (!ok) h->failed = true; } } txn{h};
   Slot& s = h->slot[h->finished % kSlots];
   const size_t n = s.n;
   if (cols) {  // returns once the rows have been read: the caller may reuse `cols` right away
@@ -398,6 +404,7 @@ static int finish_impl(cmx_pipeline_t* h, const float* cols, int first_col, int 
   h->last_slot = (int)(h->finished % kSlots);
   h->finished++;
   if (h->hinted < h->finished) h->hinted = h->finished;  // hints nobody asked for are skipped
+  txn.ok = true;
   return 0;
 }
 

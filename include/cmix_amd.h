@@ -104,7 +104,8 @@ void cmx_mixnet_destroy(cmx_mixnet_t*);
  *   d_mix_out [nbits][47] f32  OUT (may be NULL): every Mixer::p_
  * Processes the bits strictly in order inside one persistent kernel launch on
  * `stream` (a hipStream_t passed as void*, NULL = default stream) and returns
- * without synchronising. */
+ * without synchronising. Every chunk of a handle must be enqueued on the SAME stream (the chunks train one state in order
+ * and share one staging buffer); a call with a different stream is refused. */
 int cmx_mixnet_run(cmx_mixnet_t*, const float* d_probs, const uint32_t* d_sel,
                    const uint8_t* d_bits, size_t nbits, float* d_p_out, float* d_mix_out,
                    void* stream);

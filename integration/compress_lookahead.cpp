@@ -46,16 +46,27 @@ void CompressLookahead(Predictor* P, const std::vector<uint8_t>& data, cmx_encod
   if (N == 0) return;
   const int dev = P->device();
   const size_t C = P->chunk(), T = 8 * C;
-  float* d_layer0[4];
-  for (int i = 0; i < 4; ++i)
-    if (!(d_layer0[i] = (float*)cmx_device_alloc(dev, T * CMX_N_INPUTS * sizeof(float)))) Predictor::Die();
-  float* d_p = (float*)cmx_device_alloc(dev, 8 * N * sizeof(float));
+  // CMX_PIPELINE_SLOTS chunks in flight: each owns a layer-0 matrix and a p[] buffer on the device; p[] comes back and is coded
+  // as soon as the chunk has left the mixing network, so memory does not grow with the input and output appears as it goes
+  constexpr size_t R = CMX_PIPELINE_SLOTS;
+  float* d_layer0[R]; float* d_p[R];
+  for (size_t i = 0; i < R; ++i) {
+    d_layer0[i] = (float*)cmx_device_alloc(dev, T * CMX_N_INPUTS * sizeof(float));
+    d_p[i] = (float*)cmx_device_alloc(dev, T * sizeof(float));
+    if (!d_layer0[i] || !d_p[i]) Predictor::Die();
+  }
   float* cols = (float*)cmx_host_alloc(T * 2022 * sizeof(float));
-  if (!d_p || !cols) Predictor::Die();
+  if (!cols) Predictor::Die();
+  std::vector<float> p(T);
   std::vector<float> hint_p(T + 1);
   std::vector<int> hint_ex(T + 1);
   const size_t nchunks = (N + C - 1) / C;
   auto len = [&](size_t c) { return c + 1 < nchunks ? C : N - c * C; };
+  auto drain = [&](size_t c) {   // chunk c: wait, copy its probabilities back, code its bytes
+    if (cmx_pipeline_wait(P->pipe(), c)) Predictor::Die();
+    if (cmx_copy_to_host(dev, p.data(), d_p[c % R], 8 * len(c) * sizeof(float))) Predictor::Die();
+    if (cmx_encoder_encode_bytes(enc, p.data(), data.data() + c * C, len(c))) Predictor::Die();
+  };
   if (cmx_pipeline_begin(P->pipe(), data.data(), len(0), d_layer0[0])) Predictor::Die();
   for (size_t c = 0; c < nchunks; ++c) {
     const size_t n = len(c);
@@ -86,21 +97,19 @@ void CompressLookahead(Predictor* P, const std::vector<uint8_t>& data, cmx_encod
     }
     // fxcm is the lighter family: while paq8 is still at it, this thread runs PPMd for the next chunk and enqueues
     // its context stage and LSTM, whose hints are ready long before the next iteration asks for them
-    if (c + 1 < nchunks && cmx_pipeline_begin(P->pipe(), bytes + C, len(c + 1), d_layer0[(c + 1) & 3])) Predictor::Die();
+    if (c + 1 >= R) drain(c + 1 - R);   // frees slot (c + 1) % R: its layer-0 matrix and p[] buffer
+    if (c + 1 < nchunks && cmx_pipeline_begin(P->pipe(), bytes + C, len(c + 1), d_layer0[(c + 1) % R])) Predictor::Die();
     tp.join();
     if (P->fxcm_on_device()) {   // only paq8's 1591 columns (434..2024) go up; rows stay 2022 floats apart
       std::vector<float> pq(8 * n * 1591);
       for (size_t t = 0; t < 8 * n; ++t) memcpy(&pq[t * 1591], cols + t * 2022 + 431, 1591 * sizeof(float));
-      if (cmx_pipeline_finish_cols(P->pipe(), pq.data(), 434, 1591, d_p + 8 * c * C)) Predictor::Die();
-    } else if (cmx_pipeline_finish(P->pipe(), cols, d_p + 8 * c * C)) Predictor::Die();
+      if (cmx_pipeline_finish_cols(P->pipe(), pq.data(), 434, 1591, d_p[c % R])) Predictor::Die();
+    } else if (cmx_pipeline_finish(P->pipe(), cols, d_p[c % R])) Predictor::Die();
     fprintf(stderr, "\rprogress: %.2f%%", 100.0 * (c + 1) / nchunks);
   }
+  for (size_t c = nchunks + 1 > R ? nchunks + 1 - R : 0; c < nchunks; ++c) drain(c);
   if (cmx_pipeline_sync(P->pipe())) Predictor::Die();
-  std::vector<float> p(8 * N);
-  if (cmx_copy_to_host(dev, p.data(), d_p, 8 * N * sizeof(float))) Predictor::Die();
-  if (cmx_encoder_encode_bytes(enc, p.data(), data.data(), N)) Predictor::Die();
-  for (int i = 0; i < 4; ++i) cmx_device_free(dev, d_layer0[i]);
-  cmx_device_free(dev, d_p);
+  for (size_t i = 0; i < R; ++i) { cmx_device_free(dev, d_layer0[i]); cmx_device_free(dev, d_p[i]); }
   cmx_host_free(cols);
 }
 }  // namespace
