@@ -447,7 +447,7 @@ __device__ void producer_role(MixState* S, const Lds& L, int nbits, int p, int l
 
 // ------------------------------------------------------------------ chain (wave 0)
 __device__ void chain_role(MixState* S, const Lds& L, const float* decay1, int nbits,
-                           float* mix_out, bool prof_on, int lane) {
+                           float* mix_out, bool prof_on, int lane, int dbg) {
   const int m = lane;
   const bool is0 = m < CMX_MIX0;
   const float smin = S->stretch_min, smax = S->stretch_max;
@@ -490,7 +490,7 @@ __device__ void chain_role(MixState* S, const Lds& L, const float* decay1, int n
     CPROF(0);
     const BitRec* rec = L.rec + (t % 3);
     const int bit = rec->bit;
-    if (is0 && rec->changed[mm]) {
+    if (is0 && rec->changed[mm] && !((dbg & 8) && t > 0)) {  // dbg&8: timing experiment only (the chain wave keeps its first row state)
       // asm stores: re-using ew[] for the incoming row must not make the compiler wait for their acks
       if (t > 0) store_row_state();
       row0 = as_global(S->rows0) + ((size_t)mm * CMX_ROWS_PER_MIXER + rec->rowidx[mm]) * CMX_ROW0_STRIDE;
@@ -950,7 +950,7 @@ extern "C" __global__ __launch_bounds__(NTHREADS) void cmx_mixnet_chunk_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   // Waves w, w+4, w+8 share a SIMD. The chain wave's SIMD-mates are the two latency-tolerant,
   // mostly-sleeping roles, so nothing competes with its dependent add chain for issue slots.
-  if (wave == 0) chain_role(S, L, decay1, nbits, mix_out, (mode & 4) != 0, lane);
+  if (wave == 0) chain_role(S, L, decay1, nbits, mix_out, (mode & 4) != 0, lane, mode >> 4);
   else if (wave == 4) tail_role(S, L, decay1, nbits, p_out, mix_out, lane, (mode & 4) != 0 && ((mode >> 4) & 4) != 0);
   else if (wave == 8) scout_role(S, L, probs, sel, bits, nbits, lane, (mode & 4) != 0 && ((mode >> 4) & 2) != 0);
   else producer_role(S, L, nbits, wave - 1 - (wave > 4) - (wave > 8), lane, (mode & 4) != 0, mode >> 4);
