@@ -7,11 +7,11 @@
 //   wave 0  chain    lane m = layer-0 mixer m: the 26 ordered 2078-term add chains
 //                    (mixer.cpp:40-43) in four LDS-staged segments, the intra-layer
 //                    extra-input chain (predictor.cpp:395-400), Mixer::Perceive scalars.
-//   wave 4  tail     one bit behind: layer 1, layer 2, squash, SSE, override, output
+//   wave 1  tail     one bit behind: layer 1, layer 2, squash, SSE, override, output
 //                    (predictor.cpp:402-418) and the updates of those rows.
-//   wave 8  scout    up to two bits ahead: MixerInput stretch of the 2078 inputs, aux
+//   wave 2  scout    up to two bits ahead: MixerInput stretch of the 2078 inputs, aux
 //                    context, Mixer::GetContextData row selection for all 47 mixers.
-//   other 9 waves    producers p=0..8: own the selected layer-0 rows of mixers p, p+9,
+//   waves 3..11      producers p=0..8: own the selected layer-0 rows of mixers p, p+9,
 //                    p+18 in registers as float4 (9 chunks x 3 mixers), apply the previous
 //                    bit's update lazily (w -= u*x), swap rows whose selector changed
 //                    (16-byte global stores / loads, issued a segment ahead), and stage
@@ -585,7 +585,7 @@ __device__ void chain_role(MixState* S, const Lds& L, const float* decay1, int n
 #undef CPROF
 }
 
-// ------------------------------------------------------------------ tail (wave 4)
+// ------------------------------------------------------------------ tail (wave 1)
 // One bit behind the chain wave: layer 1, layer 2, squash, SSE, LSTM override, output, and the
 // Perceive of those 21 mixers and of the SSE (predictor.cpp:402-418,432-437).
 //
@@ -948,12 +948,14 @@ extern "C" __global__ __launch_bounds__(NTHREADS) void cmx_mixnet_chunk_kernel(
   if (tid < (int)(sizeof(Ctl) / 4)) reinterpret_cast<int*>(L.ctl)[tid] = 0;
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  // Waves w, w+4, w+8 share a SIMD. The chain wave's SIMD-mates are the two latency-tolerant,
-  // mostly-sleeping roles, so nothing competes with its dependent add chain for issue slots.
+  // Waves w, w+4, w+8 share a SIMD. The chain wave's SIMD-mates are two producers: they are busy mainly in the u -> segment-0
+  // window, when the chain wave waits anyway, and idle (sleeping polls) for most of the chain; the scout and the tail do
+  // 10-14 k clocks of VALU / memory work per bit spread over the whole bit and would compete with the dependent add chain
+  // for issue slots (ubench: 6.7 clk/add alone, 7.5 with busy SIMD-mates).
   if (wave == 0) chain_role(S, L, decay1, nbits, mix_out, (mode & 4) != 0, lane, mode >> 4);
-  else if (wave == 4) tail_role(S, L, decay1, nbits, p_out, mix_out, lane, (mode & 4) != 0 && ((mode >> 4) & 4) != 0);
-  else if (wave == 8) scout_role(S, L, probs, sel, bits, nbits, lane, (mode & 4) != 0 && ((mode >> 4) & 2) != 0);
-  else producer_role(S, L, nbits, wave - 1 - (wave > 4) - (wave > 8), lane, (mode & 4) != 0, mode >> 4);
+  else if (wave == 1) tail_role(S, L, decay1, nbits, p_out, mix_out, lane, (mode & 4) != 0 && ((mode >> 4) & 4) != 0);
+  else if (wave == 2) scout_role(S, L, probs, sel, bits, nbits, lane, (mode & 4) != 0 && ((mode >> 4) & 2) != 0);
+  else producer_role(S, L, nbits, wave - 3, lane, (mode & 4) != 0, mode >> 4);
   __syncthreads();
   if (tid == 0 && L.ctl->abort) S->error = 1;
 }
