@@ -96,7 +96,9 @@ struct cmx_mixnet {
   MixState h_state;  // host copy of the pointer block
   std::vector<void*> allocs;
   float* d_decay = nullptr;
-  hipStream_t run_stream = nullptr; bool run_stream_set = false;   // the stream cmx_mixnet_run was first called with
+  hipStream_t run_stream = nullptr; bool run_stream_set = false;
+  hipStream_t s_up = nullptr; bool own_up = false;                   // uploads go on a stream that never has a kernel in front of them (cmx_mixnet_set_upload_stream)
+  hipEvent_t ev_kdone[CMX_PIPELINE_SLOTS] = {};                       // the kernel that read decay slot i has run   // the stream cmx_mixnet_run was first called with
   size_t decay_cap = 0;
   float* h_decay = nullptr;  // pinned, DECAY_SLOTS x decay_cap: a slot is rewritten only after its copy ran
   hipEvent_t ev_decay[CMX_PIPELINE_SLOTS] = {};
@@ -175,7 +177,8 @@ void cmx_mixnet_destroy(cmx_mixnet_t* h) {
   if (h->h_sync_pin) hipHostFree(h->h_sync_pin);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
-  for (int i = 0; i < CMX_PIPELINE_SLOTS; ++i) if (h->ev_decay[i]) hipEventDestroy(h->ev_decay[i]);
+  for (int i = 0; i < CMX_PIPELINE_SLOTS; ++i) { if (h->ev_decay[i]) hipEventDestroy(h->ev_decay[i]); if (h->ev_kdone[i]) hipEventDestroy(h->ev_kdone[i]); }
+  if (h->own_up && h->s_up) hipStreamDestroy(h->s_up);
   delete h;
 }
 
@@ -266,7 +269,7 @@ cmx_mixnet_t* cmx_mixnet_create(int device) {
   { const char* v = getenv("CMX_MIXNET_XCD"); h->xcd = v ? atoi(v) : -1; }
   hipEventCreate(&h->ev0);
   hipEventCreate(&h->ev1);
-  for (int i = 0; i < CMX_PIPELINE_SLOTS; ++i) hipEventCreateWithFlags(&h->ev_decay[i], hipEventDisableTiming);
+  for (int i = 0; i < CMX_PIPELINE_SLOTS; ++i) { hipEventCreateWithFlags(&h->ev_decay[i], hipEventDisableTiming); hipEventCreateWithFlags(&h->ev_kdone[i], hipEventDisableTiming); }
   hipError_t e = hipDeviceSynchronize();
   if (e != hipSuccess) { set_err(std::string("init: ") + hipGetErrorString(e)); cmx_mixnet_destroy(h); return nullptr; }
   return h;
@@ -284,16 +287,25 @@ static int ensure_decay(cmx_mixnet_t* h, size_t nbits) {
   size_t cap = nbits < 4096 ? 4096 : nbits;
   if (h->h_decay) hipHostFree(h->h_decay);
   h->h_decay = nullptr;
-  for (int i = 0; i < CMX_PIPELINE_SLOTS; ++i) {  // nothing of the old buffer may still be waiting to be copied
-    if (h->decay_used[i]) (void)hipEventSynchronize(h->ev_decay[i]);
+  for (int i = 0; i < CMX_PIPELINE_SLOTS; ++i) {  // nothing of the old buffers may still be waiting to be copied or read
+    if (h->decay_used[i]) { (void)hipEventSynchronize(h->ev_decay[i]); (void)hipEventSynchronize(h->ev_kdone[i]); }
     h->decay_used[i] = false;
   }
   HIP_OK(hipHostMalloc((void**)&h->h_decay, (size_t)CMX_PIPELINE_SLOTS * cap * 4, hipHostMallocDefault));
   void* p = nullptr;
-  HIP_OK(hipMalloc(&p, cap * 4));
+  HIP_OK(hipMalloc(&p, (size_t)CMX_PIPELINE_SLOTS * cap * 4));   // one device slot per host slot (slot 0 doubles as the bit-synchronous scalar)
   h->allocs.push_back(p);
   h->d_decay = (float*)p;
   h->decay_cap = cap;
+  return 0;
+}
+
+// The stream the handle's host-to-device copies go on (the pipeline gives all its stages ONE upload stream that never has
+// a kernel in front of a copy); without it the handle creates its own on first use.
+int cmx_mixnet_set_upload_stream(cmx_mixnet_t* h, void* stream) {
+  if (!h) { set_err("cmx_mixnet_set_upload_stream: null handle"); return 1; }
+  if (h->own_up && h->s_up) hipStreamDestroy(h->s_up);
+  h->s_up = (hipStream_t)stream; h->own_up = false;
   return 0;
 }
 
@@ -311,27 +323,33 @@ int cmx_mixnet_run(cmx_mixnet_t* h, const float* d_probs, const uint32_t* d_sel,
   // state, so chunks enqueued on different streams would race on both.
   if (h->run_stream_set && st != h->run_stream) { set_err("cmx_mixnet_run: every chunk of a handle must be enqueued on the same stream"); return 1; }
   h->run_stream = st; h->run_stream_set = true;
-  // The decay schedule is staged through one of CMX_PIPELINE_SLOTS pinned slots; a slot is rewritten only once the copy
-  // that read it has executed, so that many chunks can be enqueued without the host waiting for the GPU.
+  // The decay schedule is staged through one of CMX_PIPELINE_SLOTS pinned host slots, each with its own device slot, and
+  // copied on the UPLOAD stream: a copy enqueued on the kernel's stream sits behind the previous chunk's persistent kernel,
+  // and on this hardware a host-to-device copy that waits in stream order holds up every later copy of the process (the
+  // other stages' uploads of chunks further ahead: their kernels then start a mixing-network period late).
   if (ensure_decay(h, nbits)) return 1;
+  if (!h->s_up) { HIP_OK(hipStreamCreateWithFlags(&h->s_up, hipStreamNonBlocking)); h->own_up = true; }
   const int slot = (int)(h->runs++ % CMX_PIPELINE_SLOTS);
-  if (h->decay_used[slot]) HIP_OK(hipEventSynchronize(h->ev_decay[slot]));
+  if (h->decay_used[slot]) HIP_OK(hipEventSynchronize(h->ev_kdone[slot]));   // the kernel that read this slot (implies its copy)
   float* hd = h->h_decay + (size_t)slot * h->decay_cap;
+  float* dd = h->d_decay + (size_t)slot * h->decay_cap;
   for (size_t t = 0; t < nbits; ++t) hd[t] = decay_of(h->bits_done + t);
-  HIP_OK(hipMemcpyAsync(h->d_decay, hd, nbits * 4, hipMemcpyHostToDevice, st));
-  HIP_OK(hipEventRecord(h->ev_decay[slot], st));
+  HIP_OK(hipMemcpyAsync(dd, hd, nbits * 4, hipMemcpyHostToDevice, h->s_up));
+  HIP_OK(hipEventRecord(h->ev_decay[slot], h->s_up));
+  HIP_OK(hipStreamWaitEvent(st, h->ev_decay[slot], 0));
   h->decay_used[slot] = true;
   HIP_OK(hipEventRecord(h->ev0, st));
   if (h->use_v1)
     hipLaunchKernelGGL(cmx_mixnet_kernel, dim3(1), dim3(CMX_MIXNET_THREADS), kLdsBytes, st, h->d_state,
-                       d_probs, d_sel, d_bits, h->d_decay, (int)nbits, d_p_out, d_mix_out,
+                       d_probs, d_sel, d_bits, dd, (int)nbits, d_p_out, d_mix_out,
                        3 | (h->profile ? 4 : 0));
   else
     // XCD placement (observed: block b runs on XCD b % 8): 8 blocks, all but block `xcd` leave at once
     hipLaunchKernelGGL(cmx_mixnet_chunk_kernel, dim3(h->xcd >= 0 ? 8 : 1), dim3(CMX_CHUNK_THREADS), CMX_CHUNK_LDS_BYTES, st,
-                       h->d_state, d_probs, d_sel, d_bits, h->d_decay, (int)nbits, d_p_out, d_mix_out,
+                       h->d_state, d_probs, d_sel, d_bits, dd, (int)nbits, d_p_out, d_mix_out,
                        3 | (h->profile ? 4 : 0) | ((h->dbg & 15) << 4) | (h->xcd >= 0 ? ((h->xcd & 7) + 1) << 8 : 0));
   HIP_OK(hipGetLastError());
+  HIP_OK(hipEventRecord(h->ev_kdone[slot], st));
   HIP_OK(hipEventRecord(h->ev1, st));
   h->timed = true;
   h->bits_done += nbits;

@@ -651,6 +651,8 @@ struct cmx_fxcm {
   bool v1 = false;                        // CMX_FXCM_V1=1: the one-workgroup kernel
   FxXfer* d_xfer = nullptr;               // three-role kernel: hand-off counters and the rows M / U publish for X
   unsigned* d_rows = nullptr; size_t rows_cap = 0;
+  hipStream_t s_up = nullptr; bool own_up = false;   // record uploads: a stream that never has a kernel in front of a copy (cmx_fxcm_set_upload_stream)
+  hipEvent_t ev_up[FX_STAGE_BUFS] = {};
 };
 
 extern "C" {
@@ -668,6 +670,8 @@ void cmx_fxcm_destroy(cmx_fxcm_t* h) {
   }
   if (h->d_prof) (void)hipFree(h->d_prof);
   if (h->d_xfer) (void)hipFree(h->d_xfer);
+  for (hipEvent_t e : h->ev_up) if (e) (void)hipEventDestroy(e);
+  if (h->own_up && h->s_up) (void)hipStreamDestroy(h->s_up);
   if (h->d_rows) (void)hipFree(h->d_rows);
   if (h->parser) fxp_destroy(h->parser);
   delete h;
@@ -685,7 +689,7 @@ cmx_fxcm_t* cmx_fxcm_create(const char* dictionary_path, int device) {
   bool ok = h->pol.ok;
   ok = ok && hipMalloc((void**)&h->d_dev, sizeof(FxDev)) == hipSuccess;
   ok = ok && hipMemcpy(h->d_dev, &host, sizeof(FxDev), hipMemcpyHostToDevice) == hipSuccess;
-  for (int i = 0; ok && i < FX_STAGE_BUFS; i++) ok = hipEventCreateWithFlags(&h->done[i], hipEventDisableTiming) == hipSuccess;
+  for (int i = 0; ok && i < FX_STAGE_BUFS; i++) ok = hipEventCreateWithFlags(&h->done[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&h->ev_up[i], hipEventDisableTiming) == hipSuccess;
   ok = ok && hipFuncSetAttribute((const void*)cmx_fxcm_chunk_kernel_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FX_LDS_BYTES) == hipSuccess;
   ok = ok && hipFuncSetAttribute((const void*)cmx_fxcm_chunk_kernel_t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FX_LDS_BYTES) == hipSuccess;
   ok = ok && hipFuncSetAttribute((const void*)cmx_fxcm_roles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FX_LDS_BYTES) == hipSuccess;
@@ -718,7 +722,12 @@ int cmx_fxcm_run(cmx_fxcm_t* h, const uint8_t* bytes, const uint8_t* d_bytes, si
   }
   if (fxp_run(h->parser, bytes, (int)nbytes, h->h_recs[b]) != 0) { cmx_set_err("cmx_fxcm_run: parser emitted a context count a map does not expect"); return 1; }
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemcpyAsync(h->d_recs[b], h->h_recs[b], nbytes * sizeof(FxByteRec), hipMemcpyHostToDevice, s) != hipSuccess) { cmx_set_err("cmx_fxcm_run: record upload failed"); return 1; }
+  // the records go up on the upload stream (nothing in front of them), the kernel's stream waits for the copy: enqueued on
+  // `s` the copy would sit behind the previous chunk's kernel, and a host-to-device copy that waits in stream order holds up
+  // every later copy of the process
+  if (!h->s_up) { if (hipStreamCreateWithFlags(&h->s_up, hipStreamNonBlocking) != hipSuccess) { cmx_set_err("cmx_fxcm_run: stream creation failed"); return 1; } h->own_up = true; }
+  if (hipMemcpyAsync(h->d_recs[b], h->h_recs[b], nbytes * sizeof(FxByteRec), hipMemcpyHostToDevice, h->s_up) != hipSuccess ||
+      hipEventRecord(h->ev_up[b], h->s_up) != hipSuccess || hipStreamWaitEvent(s, h->ev_up[b], 0) != hipSuccess) { cmx_set_err("cmx_fxcm_run: record upload failed"); return 1; }
   if (!h->v1) {
     if (h->rows_cap < nbytes) {   // grown between chunks: nothing of this stream may be in flight on the old buffer
       if (hipDeviceSynchronize() != hipSuccess) { cmx_set_err("cmx_fxcm_run: device error"); return 1; }
@@ -748,6 +757,13 @@ int cmx_fxcm_run(cmx_fxcm_t* h, const uint8_t* bytes, const uint8_t* d_bytes, si
 int cmx_fxcm_profile(cmx_fxcm_t* h, unsigned long long out64[64]) {
   if (!h || !h->d_prof) return 1;
   return hipMemcpy(out64, h->d_prof, 512, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+
+int cmx_fxcm_set_upload_stream(cmx_fxcm_t* h, void* stream) {
+  if (!h) { cmx_set_err("cmx_fxcm_set_upload_stream: null handle"); return 1; }
+  if (h->own_up && h->s_up) (void)hipStreamDestroy(h->s_up);
+  h->s_up = (hipStream_t)stream; h->own_up = false;
+  return 0;
 }
 
 // 1 = a bounded in-launch wait of the three-role kernel ran out (the stream's fxcm columns are void); synchronises the device

@@ -710,6 +710,7 @@ struct cmx_p8stage {
   int next = 0;
   int16_t* d_x[P8S_XBUFS] = {}; uint8_t* d_order[P8S_XBUFS] = {}; size_t x_cap = 0;   // two chunks' input rows / order values: the mixer of chunk c runs under the tables of chunk c + 1
   hipStream_t s_a = nullptr, s_b = nullptr, s_c = nullptr, s_d = nullptr, s_e = nullptr, s_m = nullptr;
+  hipStream_t s_up = nullptr; bool own_up = false;   // the chunk's records go up on a stream that never has a kernel in front of a copy (cmx_p8stage_set_upload_stream)
   hipEvent_t ev_up = nullptr, ev_ord = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_e = nullptr, ev_mix[P8S_XBUFS] = {};
   bool mix_used[P8S_XBUFS] = {};
   unsigned long long* d_prof = nullptr;   // CMX_P8MIX_PROFILE=1: per-wave clocks by phase of the mixer kernel
@@ -743,6 +744,7 @@ void cmx_p8stage_destroy(cmx_p8stage_t* h) {
   }
   for (int i = 0; i < P8S_XBUFS; i++) { if (h->d_x[i]) (void)hipFree(h->d_x[i]); if (h->d_order[i]) (void)hipFree(h->d_order[i]); }
   for (hipStream_t q : {h->s_a, h->s_b, h->s_c, h->s_d, h->s_e, h->s_m}) if (q) (void)hipStreamDestroy(q);
+  if (h->own_up && h->s_up) (void)hipStreamDestroy(h->s_up);
   for (hipEvent_t e : {h->ev_up, h->ev_ord, h->ev_a, h->ev_b, h->ev_c, h->ev_e}) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->ev_mix) if (e) (void)hipEventDestroy(e);
   if (h->front) p8f_front_free(h->front);
@@ -843,8 +845,12 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
   const int par = (int)(h->chunks % P8S_XBUFS);
   int16_t* dx = h->d_x[par]; uint8_t* dord = h->d_order[par];
   if (h->mix_used[par]) for (hipStream_t q : {h->s_a, h->s_b, h->s_c, h->s_d, h->s_e}) ok = ok && hipStreamWaitEvent(q, h->ev_mix[par], 0) == hipSuccess;   // the mixer that last read these rows
-  ok = ok && hipMemcpyAsync(b.d, b.h, b.total, hipMemcpyHostToDevice, h->s_d) == hipSuccess;
-  ok = ok && hipEventRecord(h->ev_up, h->s_d) == hipSuccess;
+  // upload on the upload stream: on s_d the copy would sit behind the previous chunk's order-N kernel, and a host-to-device
+  // copy that waits in stream order holds up every later copy of the process
+  if (!h->s_up) { ok = ok && hipStreamCreateWithFlags(&h->s_up, hipStreamNonBlocking) == hipSuccess; h->own_up = true; }
+  ok = ok && hipMemcpyAsync(b.d, b.h, b.total, hipMemcpyHostToDevice, h->s_up) == hipSuccess;
+  ok = ok && hipEventRecord(h->ev_up, h->s_up) == hipSuccess;
+  ok = ok && hipStreamWaitEvent(h->s_d, h->ev_up, 0) == hipSuccess;
   const int nbits = (int)T;
   const int skip = h->steps >= 8 ? 0 : (int)(8 - h->steps), t0 = h->steps == 0 ? 1 : 0;
   const uint8_t* d_bits = (const uint8_t*)(b.d + b.o_bits);
@@ -900,6 +906,13 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
   b.used = true;
   h->steps += T;
   h->last_bit = hb[T - 1];
+  return 0;
+}
+
+int cmx_p8stage_set_upload_stream(cmx_p8stage_t* h, void* stream) {
+  if (!h) { cmx_set_err("cmx_p8stage_set_upload_stream: null handle"); return 1; }
+  if (h->own_up && h->s_up) (void)hipStreamDestroy(h->s_up);
+  h->s_up = (hipStream_t)stream; h->own_up = false;
   return 0;
 }
 

@@ -58,6 +58,7 @@ struct cmx_pipeline {
   cmx_lstm_t* lstm = nullptr;
   cmx_mixnet_t* mix = nullptr;
   hipStream_t s_ctx = nullptr, s_lstm = nullptr, s_mix = nullptr;
+  hipStream_t s_up = nullptr;   // every host-to-device copy of the stream's chunks (inputs, fxcm records, paq8 records, decay schedule): never a kernel in front of a copy
   cmx_fxcm_t* fxcm = nullptr;    // device fxcm stage (cmx_pipeline_enable_fxcm); NULL: the caller supplies columns 3..433
   hipStream_t s_fx = nullptr;
   float* d_fx_scratch = nullptr; // pretraining writes its (discarded) rows here
@@ -129,6 +130,7 @@ void cmx_pipeline_destroy(cmx_pipeline_t* h) {
   if (h->s_ctx && h->s_ctx != h->s_lstm) (void)hipStreamDestroy(h->s_ctx);
   if (h->s_lstm) (void)hipStreamDestroy(h->s_lstm);
   if (h->s_mix) (void)hipStreamDestroy(h->s_mix);
+  if (h->s_up) (void)hipStreamDestroy(h->s_up);
   if (h->s_fx) (void)hipStreamDestroy(h->s_fx);
   if (h->d_fx_scratch) (void)hipFree(h->d_fx_scratch);
   if (h->s_p8) (void)hipStreamDestroy(h->s_p8);
@@ -163,6 +165,8 @@ cmx_pipeline_t* cmx_pipeline_create(const uint8_t vocab[256], int device, size_t
   if (two) h->s_ctx = h->s_lstm;
   else ok = ok && hipStreamCreateWithFlags(&h->s_ctx, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipStreamCreateWithFlags(&h->s_mix, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&h->s_up, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && cmx_mixnet_set_upload_stream(h->mix, h->s_up) == 0;
   const size_t n = max_chunk_bytes;
   for (Slot& s : h->slot) {
     ok = ok && hipMalloc((void**)&s.d_bytes, n) == hipSuccess;
@@ -216,6 +220,7 @@ int cmx_pipeline_enable_fxcm(cmx_pipeline_t* h, const char* dictionary_path) {
     cmx_set_err("cmx_pipeline_enable_fxcm: stream / buffer allocation failed");
     return 1;
   }
+  (void)cmx_fxcm_set_upload_stream(fx, h->s_up);
   h->fxcm = fx;
   return 0;
 }
@@ -242,6 +247,7 @@ int cmx_pipeline_enable_paq8(cmx_pipeline_t* h) {
     cmx_set_err("cmx_pipeline_enable_paq8: stream / buffer allocation failed");
     return 1;
   }
+  (void)cmx_p8stage_set_upload_stream(p8, h->s_up);
   h->p8 = p8;
   return 0;
 }
@@ -287,11 +293,14 @@ int cmx_pipeline_begin(cmx_pipeline_t* h, const uint8_t* bytes, size_t n, float*
   for (size_t i = 0; i < n; ++i)
     for (int j = 0; j < 8; ++j) hb[8 * i + j] = (bytes[i] >> (7 - j)) & 1;  // MSB first (runner.cpp:106-108)
   // ---- inputs ----
-  bool ok = hipMemcpyAsync(s.d_ppmd, s.h_ppmd, (n + 1) * 256 * 4, hipMemcpyHostToDevice, h->s_lstm) == hipSuccess;
-  ok = ok && hipMemcpyAsync(s.d_bytes, s.h_bytes, n, hipMemcpyHostToDevice, h->s_lstm) == hipSuccess;
-  ok = ok && hipMemcpyAsync(s.d_bits, hb, 8 * n, hipMemcpyHostToDevice, h->s_lstm) == hipSuccess;
-  ok = ok && hipEventRecord(s.ev_in, h->s_lstm) == hipSuccess;
-  ok = ok && hipStreamWaitEvent(h->s_ctx, s.ev_in, 0) == hipSuccess;
+  // on the upload stream: behind the previous chunk's kernels in a stage's own stream the copies would wait in stream order, and
+  // a waiting host-to-device copy holds up every later copy of the process (kernels of chunks further ahead start late)
+  bool ok = hipMemcpyAsync(s.d_ppmd, s.h_ppmd, (n + 1) * 256 * 4, hipMemcpyHostToDevice, h->s_up) == hipSuccess;
+  ok = ok && hipMemcpyAsync(s.d_bytes, s.h_bytes, n, hipMemcpyHostToDevice, h->s_up) == hipSuccess;
+  ok = ok && hipMemcpyAsync(s.d_bits, hb, 8 * n, hipMemcpyHostToDevice, h->s_up) == hipSuccess;
+  ok = ok && hipEventRecord(s.ev_in, h->s_up) == hipSuccess;
+  ok = ok && hipStreamWaitEvent(h->s_lstm, s.ev_in, 0) == hipSuccess;
+  if (h->s_ctx != h->s_lstm) ok = ok && hipStreamWaitEvent(h->s_ctx, s.ev_in, 0) == hipSuccess;
   if (!ok) { cmx_set_err("cmx_pipeline_begin: input upload failed"); return 1; }
   // ---- context / small-model stage + PPMd's bit predictions ----
   (void)hipEventRecord(s.ev_ctx0, h->s_ctx);
@@ -474,8 +483,11 @@ int cmx_pipeline_sync(cmx_pipeline_t* h) {
   ok = hipStreamSynchronize(h->s_mix) == hipSuccess && ok;
   if (h->s_fx) ok = hipStreamSynchronize(h->s_fx) == hipSuccess && ok;
   if (h->p8) ok = cmx_p8stage_sync(h->p8) == 0 && ok;
-  if (!ok) { cmx_set_err("cmx_pipeline_sync: device error"); return 1; }
-  if (cmx_ctxmodels_sync(h->ctx) || cmx_mixnet_sync(h->mix)) return 1;
+  if (!ok) { cmx_set_err("cmx_pipeline_sync: device error"); h->failed = true; return 1; }
+  if (cmx_ctxmodels_sync(h->ctx) || cmx_mixnet_sync(h->mix)) { h->failed = true; return 1; }
+  // the multi-workgroup kernels bound every in-launch wait: one that ran out left garbage behind, not a hang
+  if (cmx_lstm_failed(h->lstm)) { cmx_set_err("cmx_pipeline_sync: an in-launch hand-off of the LSTM kernels timed out (workgroups not co-resident?): the stream's output is void"); h->failed = true; return 1; }
+  if (h->fxcm && cmx_fxcm_failed(h->fxcm)) { cmx_set_err("cmx_pipeline_sync: an in-launch hand-off of the fxcm kernel timed out (workgroups not co-resident?): the stream's output is void"); h->failed = true; return 1; }
   for (Slot& s : h->slot) collect(h, s);
   if (h->last_slot >= 0) {
     Slot& s = h->slot[h->last_slot];

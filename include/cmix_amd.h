@@ -92,6 +92,10 @@ typedef struct cmx_mixnet cmx_mixnet_t;
 cmx_mixnet_t* cmx_mixnet_create(int device);
 void cmx_mixnet_destroy(cmx_mixnet_t*);
 
+/* The stream the handle's host-to-device copies (the decay schedule of a chunk) go on; NULL-less default: a stream the handle
+ * creates. A copy must never sit behind a long kernel in stream order: on this hardware it then holds up later copies of the
+ * whole process. cmx_pipeline_* hands ONE upload stream to all its stages. Same for cmx_fxcm_* (records) and cmx_p8stage_*. */
+int cmx_mixnet_set_upload_stream(cmx_mixnet_t*, void* stream);
 /* Chunk mode. All pointers are DEVICE pointers (HBM-resident operands):
  *   d_probs [nbits][2078] f32  raw model outputs (Model::Predict values)
  *   d_sel   [nbits][47]   u32  each mixer's selector key (its 64-bit context
@@ -320,6 +324,7 @@ int cmx_fxcm_run(cmx_fxcm_t*, const uint8_t* bytes, const uint8_t* d_bytes, size
 int cmx_fxcm_sync(cmx_fxcm_t*);
 /* 1 if a bounded in-launch wait of the three-role kernel ran out (the stream's fxcm columns are void from there); syncs. */
 int cmx_fxcm_failed(cmx_fxcm_t*);
+int cmx_fxcm_set_upload_stream(cmx_fxcm_t*, void* stream);   /* see cmx_mixnet_set_upload_stream */
 /* diagnostics (CMX_FXCM_PROFILE=1 at create time): clocks of lane 0 of each of the kernel's 8 wavefronts per phase
  * (1a work, 1a barrier wait, 1c, 2, 3, 4, 5, -) */
 int cmx_fxcm_profile(cmx_fxcm_t*, unsigned long long out64[64]);
@@ -458,6 +463,7 @@ int cmx_p8stage_sync(cmx_p8stage_t*);
 /* HIP-event time of the role kernels summed over the chunks collected so far (a chunk is collected when its staging
  * buffer comes round again, or by _sync): ms[0] family, [1] mixer + APM chains, [2..4] ContextMap2 x 3, [5] lanes + DMC. */
 int cmx_p8stage_role_ms(cmx_p8stage_t*, double ms[6], uint64_t* chunks, int reset);
+int cmx_p8stage_set_upload_stream(cmx_p8stage_t*, void* stream);   /* see cmx_mixnet_set_upload_stream */
 /* diagnostics (CMX_P8MIX_PROFILE=1 at create time): the mixer kernel's clocks per wave (7) and phase (8 slots, 5 used) */
 int cmx_p8stage_mix_profile(cmx_p8stage_t*, unsigned long long out56[56]);
 
