@@ -13,7 +13,7 @@ fi
 ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -o pipe -- python $GRAFT_REPO_ROOT/bench.py --payload-bytes 262144 --steps 8 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/prof_bench_256k.json 2> $GRAFT_REPO_ROOT/$O/prof.err )
 for f in $(find $O/prof -name '*kernel_stats*.csv'); do grep -v "at::native\|rocclr" $f | head -24 > $O/bench_256k_kernel_stats.csv; done
 cat $O/bench_256k_kernel_stats.csv | cut -c1-150
-for c in FETCH_SIZE WRITE_SIZE; do
+for c in $( [ "$CMX_SKIP_PMC" = 1 ] || echo FETCH_SIZE WRITE_SIZE ); do
 ( cd /tmp && timeout -k 5 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/pmc -o pmc_$c -- python $GRAFT_REPO_ROOT/bench.py --payload-bytes 65536 --steps 4 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/pmc_$c.out 2> $GRAFT_REPO_ROOT/$O/pmc_$c.err ; echo "rocprofv3 $c rc=$?" )
 done
 python - <<'PY'
