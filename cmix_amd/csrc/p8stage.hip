@@ -743,7 +743,14 @@ void cmx_p8stage_destroy(cmx_p8stage_t* h) {
     for (hipEvent_t e : s.t1) if (e) (void)hipEventDestroy(e);
   }
   for (int i = 0; i < P8S_XBUFS; i++) { if (h->d_x[i]) (void)hipFree(h->d_x[i]); if (h->d_order[i]) (void)hipFree(h->d_order[i]); }
-  for (hipStream_t q : {h->s_a, h->s_b, h->s_c, h->s_d, h->s_e, h->s_m}) if (q) (void)hipStreamDestroy(q);
+  {
+    hipStream_t seen[6] = {}; int ns = 0;   // in compact modes several roles share a stream
+    for (hipStream_t q : {h->s_a, h->s_b, h->s_c, h->s_d, h->s_e, h->s_m}) {
+      bool dup = !q;
+      for (int i = 0; i < ns; i++) dup = dup || seen[i] == q;
+      if (!dup) { seen[ns++] = q; (void)hipStreamDestroy(q); }
+    }
+  }
   if (h->own_up && h->s_up) (void)hipStreamDestroy(h->s_up);
   for (hipEvent_t e : {h->ev_up, h->ev_ord, h->ev_a, h->ev_b, h->ev_c, h->ev_e}) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->ev_mix) if (e) (void)hipEventDestroy(e);
@@ -777,7 +784,19 @@ cmx_p8stage_t* cmx_p8stage_create(int device) {
   }
   delete S;
   ok = ok && hipFuncSetAttribute((const void*)cmx_p8s_fam2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->fam_lds) == hipSuccess;
-  for (hipStream_t* q : {&h->s_a, &h->s_b, &h->s_c, &h->s_d, &h->s_e, &h->s_m}) ok = ok && hipStreamCreateWithFlags(q, hipStreamNonBlocking) == hipSuccess;
+  {
+    // CMX_PIPELINE_STREAMS (throughput mode, several streams per GPU; every HIP stream is a hardware queue and the scheduler
+    // time-slices queues past ~16-24): unset = one stream per role (6); 2 = the three ContextMap2 instances share one (4);
+    // 1 = they also share it with the small lanes / DMC (3). The roles of a chunk then run one after the other on the shared
+    // stream: the stage's period grows to their sum, the stream count is what many engines per GPU need.
+    const char* ns = getenv("CMX_PIPELINE_STREAMS");
+    const int mode = ns && ns[0] == '2' ? 2 : ns && ns[0] == '1' ? 1 : 0;
+    for (hipStream_t* q : {&h->s_a, &h->s_d, &h->s_m}) ok = ok && hipStreamCreateWithFlags(q, hipStreamNonBlocking) == hipSuccess;
+    if (mode == 0) for (hipStream_t* q : {&h->s_b, &h->s_e}) ok = ok && hipStreamCreateWithFlags(q, hipStreamNonBlocking) == hipSuccess;
+    else { h->s_b = h->s_d; h->s_e = h->s_d; }
+    if (mode == 1) h->s_c = h->s_d;
+    else ok = ok && hipStreamCreateWithFlags(&h->s_c, hipStreamNonBlocking) == hipSuccess;
+  }
   for (hipEvent_t* e : {&h->ev_up, &h->ev_ord, &h->ev_a, &h->ev_b, &h->ev_c, &h->ev_e}) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
   for (hipEvent_t& e : h->ev_mix) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
   for (auto& s : h->st) {

@@ -67,6 +67,7 @@ struct cmx_pipeline {
   hipStream_t s_p8 = nullptr;
   float* d_p8_scratch = nullptr; // pretraining writes its (discarded) rows here
   double p8_ms = 0;
+  int compact = 0;       // CMX_PIPELINE_STREAMS: 0 = one stream per stage / role, 2 and 1 = throughput modes with fewer hardware queues per engine
   bool failed = false;   // sticky: a chunk failed after its stages had begun to be enqueued (the stream's state is void)
   double host_ms[6] = {0, 0, 0, 0, 0, 0};   // calling thread, since the last reset: slot wait, PPMd, ctx + LSTM enqueue, fxcm (parser + enqueue), paq8 (front end + enqueue), mixing network enqueue
   Slot slot[kSlots];
@@ -131,9 +132,9 @@ void cmx_pipeline_destroy(cmx_pipeline_t* h) {
   if (h->s_lstm) (void)hipStreamDestroy(h->s_lstm);
   if (h->s_mix) (void)hipStreamDestroy(h->s_mix);
   if (h->s_up) (void)hipStreamDestroy(h->s_up);
-  if (h->s_fx) (void)hipStreamDestroy(h->s_fx);
+  if (h->s_fx && h->s_fx != h->s_lstm) (void)hipStreamDestroy(h->s_fx);
   if (h->d_fx_scratch) (void)hipFree(h->d_fx_scratch);
-  if (h->s_p8) (void)hipStreamDestroy(h->s_p8);
+  if (h->s_p8 && h->s_p8 != h->s_mix) (void)hipStreamDestroy(h->s_p8);
   if (h->d_p8_scratch) (void)hipFree(h->d_p8_scratch);
   cmx_p8stage_destroy(h->p8);
   cmx_fxcm_destroy(h->fxcm);
@@ -160,7 +161,8 @@ cmx_pipeline_t* cmx_pipeline_create(const uint8_t vocab[256], int device, size_t
   // Every HIP stream is a hardware queue; past ~24 active queues the hardware scheduler starts time-slicing them
   // (profiles/r01_multiproc.txt: microsecond kernels then show 13 ms durations), so 8+ streams per GPU want 2 each.
   const char* ns = getenv("CMX_PIPELINE_STREAMS");
-  const bool two = ns && ns[0] == '2';
+  const bool two = ns && (ns[0] == '2' || ns[0] == '1');   // 2: contexts on the LSTM's stream, paq8 on 4 streams; 1: fxcm there too, paq8 on 3
+  h->compact = ns && ns[0] == '1' ? 1 : two ? 2 : 0;
   ok = ok && hipStreamCreateWithFlags(&h->s_lstm, hipStreamNonBlocking) == hipSuccess;
   if (two) h->s_ctx = h->s_lstm;
   else ok = ok && hipStreamCreateWithFlags(&h->s_ctx, hipStreamNonBlocking) == hipSuccess;
@@ -199,7 +201,9 @@ int cmx_pipeline_enable_fxcm(cmx_pipeline_t* h, const char* dictionary_path) {
   cmx_fxcm_t* fx = cmx_fxcm_create(dictionary_path, h->device);
   if (!fx) return 1;
   const size_t n = h->max_chunk;
-  bool ok = hipStreamCreateWithFlags(&h->s_fx, hipStreamNonBlocking) == hipSuccess;
+  bool ok = true;
+  if (h->compact == 1) h->s_fx = h->s_lstm;   // throughput mode: LSTM, contexts and fxcm take turns on one stream
+  else ok = hipStreamCreateWithFlags(&h->s_fx, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipMalloc((void**)&h->d_fx_scratch, 8 * n * 434 * sizeof(float)) == hipSuccess;
   for (Slot& s : h->slot) {
     ok = ok && hipMalloc((void**)&s.d_fx_pr, 8 * n * 2) == hipSuccess;
@@ -213,7 +217,7 @@ int cmx_pipeline_enable_fxcm(cmx_pipeline_t* h, const char* dictionary_path) {
       s.d_fx_pr = nullptr; s.d_fx_ex = nullptr;
       for (hipEvent_t* e : {&s.ev_fxin, &s.ev_fx0, &s.ev_fx1}) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
     }
-    if (h->s_fx) (void)hipStreamDestroy(h->s_fx);
+    if (h->s_fx && h->s_fx != h->s_lstm) (void)hipStreamDestroy(h->s_fx);
     if (h->d_fx_scratch) (void)hipFree(h->d_fx_scratch);
     h->s_fx = nullptr; h->d_fx_scratch = nullptr;
     cmx_fxcm_destroy(fx);
@@ -233,14 +237,16 @@ int cmx_pipeline_enable_paq8(cmx_pipeline_t* h) {
   if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
   cmx_p8stage_t* p8 = cmx_p8stage_create(h->device);
   if (!p8) return 1;
-  bool ok = hipStreamCreateWithFlags(&h->s_p8, hipStreamNonBlocking) == hipSuccess;
+  bool ok = true;
+  if (h->compact) h->s_p8 = h->s_mix;   // throughput mode: the mixing network's stream itself waits for the stage's mixer
+  else ok = hipStreamCreateWithFlags(&h->s_p8, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipMalloc((void**)&h->d_p8_scratch, 8 * h->max_chunk * 1591 * sizeof(float)) == hipSuccess;
   for (Slot& s : h->slot)
     for (hipEvent_t* e : {&s.ev_p80, &s.ev_p81}) ok = ok && hipEventCreate(e) == hipSuccess;
   if (!ok) {
     for (Slot& s : h->slot)
       for (hipEvent_t* e : {&s.ev_p80, &s.ev_p81}) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
-    if (h->s_p8) (void)hipStreamDestroy(h->s_p8);
+    if (h->s_p8 && h->s_p8 != h->s_mix) (void)hipStreamDestroy(h->s_p8);
     if (h->d_p8_scratch) (void)hipFree(h->d_p8_scratch);
     h->s_p8 = nullptr; h->d_p8_scratch = nullptr;
     cmx_p8stage_destroy(p8);
