@@ -377,6 +377,14 @@ int cmx_ppmd_run(cmx_ppmd_t*, const uint8_t* bytes, size_t nbytes, float* out_pr
  *    CMX_PIPELINE_SLOTS chunks may be in flight (a submit blocks while the chunk that many submits back is still running:
  *    a chunk's latency through the stages is several chunk periods, the depth keeps every stage busy).
  * ------------------------------------------------------------------------ */
+/* Environment read by the engine (all optional):
+ *   GPU_MAX_HW_QUEUES      (HIP's own) must be >= 13 before the first HIP call for the stages of one stream to overlap: an
+ *                          engine uses 13 HIP streams (5 stages, upload, 6 paq8 roles, paq8 hand-over) and HIP maps streams
+ *                          onto 4 hardware queues by default. bench.py and cmix_engine set 16.
+ *   CMX_PIPELINE_STREAMS   2 or 1: throughput mode for several streams per GPU -- fewer hardware queues per engine (8 or 6;
+ *                          roles take turns on shared streams, the per-stream period grows)
+ *   CMX_LSTM_V1, CMX_FXCM_V1, CMX_P8FAM_V1, CMX_P8MIX_V1   the one-workgroup / first-design kernels (A/B reference)
+ *   CMX_FXCM_PROFILE, CMX_P8MIX_PROFILE, CMX_MIXNET_DBG     in-kernel phase timers / timing experiments (scripts/gpu_*prof*) */
 #define CMX_PIPELINE_SLOTS 8   /* chunks in flight per stream (layer-0 matrices the caller cycles through) */
 typedef struct cmx_pipeline cmx_pipeline_t;
 cmx_pipeline_t* cmx_pipeline_create(const uint8_t vocab[256], int device, size_t max_chunk_bytes);
