@@ -46,8 +46,9 @@ static const uint64_t cmx_exp2f_tab[32] = {
     0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
     0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
 
-// glibc __expf (FMA build). T[] = asuint64(2^(i/32)) - (i << 47).
-CMX_HD float cmx_expf(float x) {
+// glibc __expf (FMA build). T[] = asuint64(2^(i/32)) - (i << 47). `tab`: where the caller keeps the 32 table words (a kernel
+// on a latency-critical path keeps a copy in LDS: from device-global memory the lookup is an L2 round trip).
+CMX_HD float cmx_expf_t(float x, const uint64_t* tab) {
   const double InvLn2N = 0x1.71547652b82fep+5;  // 32/ln2
   const double Shift = 0x1.8p+52;
   const double C0 = 0x1.c6af84b912394p-20, C1 = 0x1.ebfce50fac4f3p-13, C2 = 0x1.62e42ff0c52d6p-6;
@@ -64,7 +65,7 @@ CMX_HD float cmx_expf(float x) {
   uint64_t ki = cmx_d2u(kd);
   kd = kd - Shift;
   double r = __builtin_fma(InvLn2N, xd, -kd);
-  uint64_t t = cmx_exp2f_tab[ki & 31] + (ki << 47);
+  uint64_t t = tab[ki & 31] + (ki << 47);
   double s = cmx_u2d(t);
   double z = __builtin_fma(C0, r, C1);
   double r2 = r * r;
@@ -73,6 +74,8 @@ CMX_HD float cmx_expf(float x) {
   y = y * s;
   return (float)y;
 }
+
+CMX_HD float cmx_expf(float x) { return cmx_expf_t(x, cmx_exp2f_tab); }
 
 // glibc __expm1f (s_expm1f.c)
 CMX_HD float cmx_expm1f(float x) {
@@ -175,5 +178,6 @@ CMX_HD float cmx_tanhf(float x) {
 
 // Sigmoid::Logistic, reference src/mixer/sigmoid.cpp:19-21
 CMX_HD float cmx_logistic(float x) { return 1.0f / (1.0f + cmx_expf(-x)); }
+CMX_HD float cmx_logistic_t(float x, const uint64_t* tab) { return 1.0f / (1.0f + cmx_expf_t(-x, tab)); }
 
 #endif  // CMX_LIBM_H

@@ -74,6 +74,7 @@ struct Lds {
   float* w2;       // [64] layer-2 weight row
   float* w1;       // [20][68] layer-1 weight rows
   unsigned pfdump; // LDS byte offset of a 256-byte dump area for the row-prefetch LDS-DMA loads
+  uint64_t* exptab; // [32] expf's table (cmx_libm.h): the chain wave's error needs it on the serial path
 };
 
 // All inter-wave traffic of this kernel goes through LDS, so its synchronisation only has to
@@ -127,6 +128,10 @@ __device__ __forceinline__ float bcast_lane(float v, int j) {
 
 // MixerInput::SetStretchedInput / SetExtraInput clamp (mixer-input.cpp:17-27): if (x > max) x = max;
 // else if (x < min) x = min;  -- as two selects, no branch.
+// The same clamp as ONE instruction on the serial extra-input chain: v_med3_f32(x, min, max) is the median of the three, i.e.
+// the reference's two-sided clamp for every non-NaN x (min < max always; a NaN never reaches a mixer output: its weights
+// would have been NaN for every later bit in the reference as well). 1.9 k -> 1.2 k clocks per bit for the 26 steps.
+__device__ __forceinline__ float clamp_med3(float x, float mn, float mx) { return __builtin_amdgcn_fmed3f(x, mn, mx); }
 __device__ __forceinline__ float clamp_out(float x, float mn, float mx) {
   const float lo = x < mn ? mn : x;
   return x > mx ? mx : lo;
@@ -533,7 +538,7 @@ __device__ void chain_role(MixState* S, const Lds& L, const float* decay1, int n
     float e = 0.0f;
 #pragma unroll
     for (int j = 0; j < CMX_MIX0; ++j) {
-      const float mine = clamp_out(fadd(pm, e), smin, smax);
+      const float mine = clamp_med3(fadd(pm, e), smin, smax);
       const float oj = bcast_lane(mine, j);
       e = fadd(e, fmul(oj, ew[j]));
     }
@@ -541,7 +546,7 @@ __device__ void chain_role(MixState* S, const Lds& L, const float* decay1, int n
     const float myout = clamp_out(p_, smin, smax);
     CPROF(3);
     // Mixer::Perceive scalar (mixer.cpp:56-64)
-    float uu = fmul(dlr, fsub(cmx_logistic(p_), (float)bit));
+    float uu = fmul(dlr, fsub(cmx_logistic_t(p_, L.exptab), (float)bit));
     ++rsteps;
     if (rsteps > mx) mx = rsteps;
     const bool dfl = (rsteps & 1023) == 0;
@@ -941,10 +946,11 @@ extern "C" __global__ __launch_bounds__(NTHREADS) void cmx_mixnet_chunk_kernel(
   L.pfdump = (unsigned)(size_t)(lds_int*)(reinterpret_cast<int*>(L.ctl) + 16);   // 256 B behind the control block
   L.w2 = reinterpret_cast<float*>(L.ctl) + 16 + 64;                               // 256 B behind the dump area
   L.w1 = L.w2 + 64 + 16 + 64;                                                     // behind w2 and the tail's two dump slots
+  L.exptab = reinterpret_cast<uint64_t*>(L.w1 + 20 * 68);                         // 256 B
   const int tid = threadIdx.x;
   for (int i = tid; i < 3 * XS; i += NTHREADS) L.xs[i] = 0.0f;    // incl. the zero padding 2078..2111
   for (int i = tid; i < 2 * PBUF; i += NTHREADS) L.prod[i] = 0.0f;
-  if (tid < 32) { L.upd[tid] = 0.0f; L.dflag[tid] = 0; }
+  if (tid < 32) { L.upd[tid] = 0.0f; L.dflag[tid] = 0; L.exptab[tid] = cmx_exp2f_tab[tid]; }
   if (tid < (int)(sizeof(Ctl) / 4)) reinterpret_cast<int*>(L.ctl)[tid] = 0;
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
