@@ -41,6 +41,7 @@ struct cmx_lstm {
   float* d_prev_probs = nullptr;  // byte distribution at chunk start
   uint64_t bytes_done = 0;
   int hc = 0;                // which hid[] / stateb[] buffer holds the current hidden_ / state_
+  bool v1 = false;           // CMX_LSTM_V1=1 at creation: the one-workgroup kernels (and their transposed output-layer copy)
   size_t fb_lds = 0, bp_lds = 0;   // dynamic LDS of the block kernels (lstm_block.hip)
   uint64_t bptt_rounds = 0;  // LstmLayer::update_steps_ = min(rounds, 3000) (lstm-layer.cpp:131-133)
   // one epoch-aligned block of 100 bytes (BPTT round + 100 x (SGD, forward) = 204 launches) captured once and
@@ -177,7 +178,8 @@ cmx_lstm_t* cmx_lstm_create(const uint8_t vocab[256], int skip_rand, int device)
     S.layer_input[l] = dallocf(li.size(), li.data());
   }
   S.OL = dallocf((size_t)LSTM_H * V * LSTM_NH, nullptr);
-  S.OLT = dallocf((size_t)LSTM_H * LSTM_NH * LSTM_VP, nullptr);
+  { const char* v = getenv("CMX_LSTM_V1"); h->v1 = v && v[0] == '1'; }
+  S.OLT = h->v1 ? dallocf((size_t)LSTM_H * LSTM_NH * LSTM_VP, nullptr) : nullptr;   // 41 MB only the one-workgroup forward kernel reads
   {
     std::vector<float> out((size_t)LSTM_H * LSTM_VP, 0.0f);
     for (int e = 0; e < LSTM_H; ++e)
@@ -261,7 +263,7 @@ int cmx_lstm_run(cmx_lstm_t* h, const float* d_in_probs, const uint8_t* d_bytes,
   const int V = S.V;
   (void)hipMemcpyAsync(h->d_prev_probs, S.byte_probs, 256 * 4, hipMemcpyDeviceToDevice, st);
   static const bool use_graph = !(getenv("CMX_LSTM_NOGRAPH") && getenv("CMX_LSTM_NOGRAPH")[0] == '1');
-  static const bool v1 = getenv("CMX_LSTM_V1") && getenv("CMX_LSTM_V1")[0] == '1';            // one-workgroup kernels
+  const bool v1 = h->v1;   // one-workgroup kernels
   static const bool bptt_v1 = getenv("CMX_LSTM_BPTT_V1") && getenv("CMX_LSTM_BPTT_V1")[0] == '1';
   if (!v1 && !d_in_probs) { cmx_set_err("cmx_lstm_run: d_in_probs is required"); return 1; }
   auto sync_reset = [&]() {
