@@ -46,6 +46,10 @@ __device__ __forceinline__ unsigned ld_u(const unsigned* p) { return __hip_atomi
 __device__ __forceinline__ float ld_f(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_f(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// a workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt(0), i.e. waits for every global load the
+// wave has in flight -- the prefetches issued at the top of a step would be awaited at its first barrier instead of at their use
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // lane 0 polls the counter, the workgroup waits at the barrier
 __device__ __forceinline__ void wg_wait(const unsigned* p, unsigned want, unsigned* fail) {
   if (threadIdx.x == 0) {
@@ -57,7 +61,7 @@ __device__ __forceinline__ void wg_wait(const unsigned* p, unsigned want, unsign
       }
     }
   }
-  __syncthreads();
+  lds_barrier();
 }
 // the calling wave's agent-scope stores are complete, then the counter moves (callers: lanes of wave 0 only)
 __device__ __forceinline__ void wave_signal(unsigned* p) {
@@ -127,7 +131,7 @@ __device__ __forceinline__ void fb_finish_layer(const LstmState* S, int layer, i
   wg_wait(&Y->raw_cnt[layer][e], GL, &Y->fail);
   const float* rr = S->raw_ring + ((size_t)layer * H + e) * (3 * C);
   for (int idx = tid; idx < 3 * C; idx += FT) rawl[idx] = ld_f(rr + idx);
-  __syncthreads();
+  lds_barrier();
   if (tid < 3) {  // (norm_*norm_).sum(): expression-template sum runs backward from the last element
     const float* rw = rawl + tid * C;
     float s = fmul(rw[C - 1], rw[C - 1]);
@@ -137,7 +141,7 @@ __device__ __forceinline__ void fb_finish_layer(const LstmState* S, int layer, i
     ivar_s[tid] = iv;
     if (lead) S->ivar[layer][tid][e] = iv;
   }
-  __syncthreads();
+  lds_barrier();
   if (tid < C) {
     float stg[3];
 #pragma unroll
@@ -168,7 +172,7 @@ __device__ __forceinline__ void fb_finish_layer(const LstmState* S, int layer, i
     }
   }
   if (lead) wg_signal(&Y->h_flag[layer][e]);
-  else __syncthreads();
+  else lds_barrier();
 }
 
 __device__ void fb_gate_wg(const LstmState* S, const FbArgs& A, int layer, int w, float* lds) {
@@ -206,7 +210,7 @@ __device__ void fb_gate_wg(const LstmState* S, const FbArgs& A, int layer, int w
     const size_t n = A.n0 + k;
     const int cur_sym = S->byte_map[A.bytes[n]];
     float* li = S->layer_input[layer] + (size_t)e * insz;
-    __syncthreads();
+    lds_barrier();
     if (tid < V) {  // ByteMixer::SetInput / Lstm::SetInput (byte-mixer.cpp:15-20): inputs_ *= 2 / num_models_
       const float v = fmul(A.in_probs[n * 256 + sym2byte[tid]], 2.0f);
       xv[tid] = v;
@@ -216,7 +220,7 @@ __device__ void fb_gate_wg(const LstmState* S, const FbArgs& A, int layer, int w
       S->dyn[0] = (int)S->input_history[e - 1];
       S->input_history[e - 1] = (unsigned)cur_sym;
     }
-    __syncthreads();
+    lds_barrier();
     float f = 0.0f;
     if (tid < 64) {  // LstmLayer::ForwardPass dot products (lstm-layer.cpp:85-92): one-hot column, then the symbol inputs
       f = wt[(size_t)cur_sym * C + i0 + r];
@@ -232,7 +236,7 @@ __device__ void fb_gate_wg(const LstmState* S, const FbArgs& A, int layer, int w
         xv[V + C + tid] = h;
         if (lead) li[V + C + tid] = h;
       }
-      __syncthreads();
+      lds_barrier();
     }
     if (tid < 64) {
       f = lds_chain(f, Wl, R, r, xv, V + C, insz);   // layer 1: layer 0's new hidden; then the bias
@@ -240,7 +244,7 @@ __device__ void fb_gate_wg(const LstmState* S, const FbArgs& A, int layer, int w
       wave_signal(&Y->raw_cnt[layer][e]);
     }
   }
-  __syncthreads();
+  lds_barrier();
   const int el = A.e0 + A.cnt - 1;
   fb_finish_layer(S, layer, el, lead, rawl, ivar_s, xv + V, st);
   if (lead && tid < C) {
@@ -288,13 +292,13 @@ __device__ void fb_out_wg(const LstmState* S, const FbArgs& A, int w, float* lds
     const int cur_sym = S->byte_map[A.bytes[n]];
     float* hprev = hbuf + pb * 404;
     float* hcur = hbuf + (pb ^ 1) * 404;
-    __syncthreads();
+    lds_barrier();
     if (tid < nr) {
       const float o = outp[tid];
       const float err = (i0 + tid == cur_sym) ? fsub(o, 1.0f) : o;
       le_s[tid] = fmul(S->lr, err);
     }
-    __syncthreads();
+    lds_barrier();
     for (int idx = tid; idx < nr * NQ; idx += FT) {   // slot[e] = slot[last] - (lr*err_i) * hidden_
       const int rr = idx / NQ, q = idx - rr * NQ, j = q * 4;
       const float le = le_s[rr];
@@ -312,13 +316,13 @@ __device__ void fb_out_wg(const LstmState* S, const FbArgs& A, int w, float* lds
     }
     wg_wait(&Y->h_flag[0][e], 1, &Y->fail);
     if (tid < C) hcur[tid] = ld_f(&S->h_ring[(size_t)e * NH + tid]);
-    __syncthreads();
+    lds_barrier();
     float sum = 0.0f;
     if (tid < 64) sum = lds_chain(sum, OLs, RP, r, hcur, 0, C);
     wg_wait(&Y->h_flag[1][e], 1, &Y->fail);
     if (tid < C) hcur[C + tid] = ld_f(&S->h_ring[(size_t)e * NH + C + tid]);
     if (tid == 0) hcur[2 * C] = 1.0f;   // bias element of hidden_ (lstm.cpp:18)
-    __syncthreads();
+    lds_barrier();
     if (tid < 64) {
       sum = lds_chain(sum, OLs, RP, r, hcur, C, NH);
       if (tid < nr) st_f(&S->logit_ring[(size_t)e * VP + i0 + tid], sum);
@@ -328,29 +332,29 @@ __device__ void fb_out_wg(const LstmState* S, const FbArgs& A, int w, float* lds
     float lg = 0.0f;
     if (tid < V) lg = ld_f(&S->logit_ring[(size_t)e * VP + tid]);
     red[tid] = tid < V ? lg : 0.0f;   // max_out starts at 0 (lstm.cpp:132)
-    __syncthreads();
+    lds_barrier();
     for (int s = 128; s > 0; s >>= 1) {
       if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
-      __syncthreads();
+      lds_barrier();
     }
     const float mx = red[0];
     if (tid < V) lgs[tid] = cmx_expf(fsub(lg, mx));
-    __syncthreads();
+    lds_barrier();
     if (tid == 0) {  // valarray::sum(): forward from 0
       float t = 0.0f;
 #pragma unroll 16
       for (int i = 0; i < V; ++i) t = fadd(t, lgs[i]);
       tot_s[0] = t;
     }
-    __syncthreads();
+    lds_barrier();
     float p = 0.0f;
     if (tid < V) p = fdiv(lgs[tid], tot_s[0]);
-    __syncthreads();
+    lds_barrier();
     if (tid < V) {
       lgs[tid] = p;
       if (lead) S->output[(size_t)e * VP + tid] = p;
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < nr) outp[tid] = lgs[i0 + tid];
     if (lead) {
       const float pbv = S->vocab[tid] ? lgs[S->byte_map[tid]] : 0.0f;
@@ -473,7 +477,7 @@ extern "C" __global__ __launch_bounds__(LSTM_BP_THREADS) void cmx_lstm_bpttblk(c
   slice_load(0); slice_store(0);
   slice_load(1); slice_store(1);
   slice_load(2);
-  __syncthreads();
+  lds_barrier();
   float* pub = S->bp_pub;   // [200 steps][2][C]
   if (tid < 64) {  // step 0's hidden error: hidden_error_ is zero on entry
     const float h = p1_chain(0, 0.0f);
@@ -497,7 +501,7 @@ extern "C" __global__ __launch_bounds__(LSTM_BP_THREADS) void cmx_lstm_bpttblk(c
     ia.norm = S->norm[layer][ia.g][(size_t)epoch * C + ia.c]; ia.iv = S->ivar[layer][ia.g][epoch];
     if (ib.on) { ib.norm = S->norm[layer][ib.g][(size_t)epoch * C + ib.c]; ib.iv = S->ivar[layer][ib.g][epoch]; }
     if (lead && tid == 0 && layer == 1) S->bp_symbol[epoch] = epoch == 0 ? (unsigned)S->dyn[0] : S->input_history[epoch - 1];
-    __syncthreads();   // slice s+2 is in LDS
+    lds_barrier();   // slice s+2 is in LDS
     // the next step's chain does not depend on this step when it starts from zero (layer 0 leaves hidden_error_ = 0)
     if (layer == 0 && s + 1 < 2 * H && tid < 64) hpre = p1_chain(s + 1, 0.0f);
     wg_wait(&Y->bp_cnt[s], GB, &Y->fail);
@@ -516,7 +520,7 @@ extern "C" __global__ __launch_bounds__(LSTM_BP_THREADS) void cmx_lstm_bpttblk(c
       gerr[2 * C + tid] = og_e;
       if (epoch > 0) { serr_c = fmul(serr_c, fs); stored_c = 0.0f; }
     }
-    __syncthreads();
+    lds_barrier();
     // per-gate normalisation backward (lstm-layer.cpp:158-163); item = (gate, cell)
     auto norm_a = [&](BpItem& it) {
       if (epoch == H - 1) { it.gu_c = 0.0f; it.bu_c = 0.0f; }
@@ -529,7 +533,7 @@ extern "C" __global__ __launch_bounds__(LSTM_BP_THREADS) void cmx_lstm_bpttblk(c
     };
     norm_a(ia);
     if (ib.on) norm_a(ib);
-    __syncthreads();
+    lds_barrier();
     if (tid < 3) {  // (error_*norm_).sum(): backward
       const float* gp = gprod + tid * C;
       float sm = gp[C - 1];
@@ -537,7 +541,7 @@ extern "C" __global__ __launch_bounds__(LSTM_BP_THREADS) void cmx_lstm_bpttblk(c
       for (int i = C - 2; i >= 0; --i) sm = fadd(sm, gp[i]);
       gsm[tid] = fdiv(sm, (float)C);
     }
-    __syncthreads();
+    lds_barrier();
     auto norm_b = [&](BpItem& it) {
       const float e = fsub(it.err, fmul(gsm[it.g], it.norm));
       gerr[it.g * C + it.c] = e;
@@ -545,7 +549,7 @@ extern "C" __global__ __launch_bounds__(LSTM_BP_THREADS) void cmx_lstm_bpttblk(c
     };
     norm_b(ia);
     if (ib.on) norm_b(ib);
-    __syncthreads();
+    lds_barrier();
     // W^T chains into the own cells (lstm-layer.cpp:164-181): f = sum_j error_[j] * W[j][col + c], j ascending
     if (tid < 64) {
       const int nl = layer == 0 ? 3 * J : 6 * J;
@@ -560,7 +564,7 @@ extern "C" __global__ __launch_bounds__(LSTM_BP_THREADS) void cmx_lstm_bpttblk(c
         if (tid < nl) fres[(kind * 3 + gg) * J + cl] = f;
       }
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < C) serr_c = fminf(fmaxf(serr_c, -10.0f), 10.0f);   // ClipGradients (lstm-layer.cpp:140-142), replicated part
     if (tid < 64) {
       float h = 0.0f, sn = 0.0f;
