@@ -1,4 +1,4 @@
-"""Host stages of one stream (the calling thread's work per chunk): PPMd, fxcm's text parser, paq8's front end -- us/byte."""
+"""Host stages of one stream (the calling thread's work per chunk): PPMd, fxcm's text parser -- us/byte."""
 import ctypes as C, os, sys, time
 import numpy as np
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
@@ -15,5 +15,4 @@ L.fxp_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
 fp = L.fxp_create(None)
 out = np.zeros(n * 424, np.uint8)
 t = time.time(); L.fxp_run(fp, data.ctypes.data, n, out.ctypes.data); print("fxcm parser %.2f us/byte" % ((time.time() - t) / n * 1e6))
-L.p8f_front_time.restype = C.c_double; L.p8f_front_time.argtypes = [C.c_void_p, C.c_size_t]
-print("paq8 front  %.2f us/byte" % (L.p8f_front_time(data.ctypes.data, n) * 1e6 / n))
+# paq8's front end: see host_us_per_byte.paq8_front_enqueue in the bench line (cmx_pipeline_host_ms)
