@@ -39,6 +39,9 @@ def streams():
         "text_32k": text_block(synth.enwik_like(32768 - 6, 4242)),
         "wiki_12k": text_block((wiki * 60)[:12288 - 6]),
         "records_8k": default_block(rec[:8192 - 5]),
+        # what the reference's preprocessor made of a mixed file (tests/golden/make_dropin_mixed.py): a TEXT block, then an EXE
+        # block (x86-like calls with rewritten addresses, records, text) -- block headers, type switches, exeModel on real targets
+        "mixed_24k": bytes(np.load(os.path.join(HERE, "dropin_mixed.npz"))["stream"]),
     }
 
 

@@ -219,14 +219,14 @@ def _reference_fixture(name):
     return data, pr, ex, dic, g["hash"], mk.row_hash
 
 
-@pytest.mark.parametrize("name", ["fxcm_cols_wiki_16k", "fxcm_cols_dict_16k"])
+@pytest.mark.parametrize("name", ["fxcm_cols_wiki_16k", "fxcm_cols_dict_16k", "fxcm_cols_mixed_24k"])
 def test_reference_hashes_16k(name):
     """The product's text parser + the kernel body (host run) and the oracle against the reference itself on 16 KB of
     wiki markup and of dictionary-mode (WRT-coded) text: 131072 bits x 431 values each, compared through row hashes."""
     L = emul()
     data, pr, ex, dic, want, row_hash = _reference_fixture(name)
     try:
-        got = row_hash(run_emul(L, data, pr, ex, [4096, 1, 4095, 8192], dictionary=dic))
+        got = row_hash(run_emul(L, data, pr, ex, [4096, 1, 4095, 8192, 8192], dictionary=dic))
         bad = np.nonzero(got != want)[0]
         assert bad.size == 0, (name, "kernel body: first differing bit", int(bad[0]))
         orc = row_hash(oracle_rows(data, pr, ex, dictionary=dic))

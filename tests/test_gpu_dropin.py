@@ -199,3 +199,15 @@ def test_engine_256k_shard_prefix_is_byte_identical():
 @pytest.mark.skipif(os.environ.get("CMX_LONG") != "1", reason="~2.5 GPU-minutes (bench.py checks the same file on every default run); set CMX_LONG=1")
 def test_engine_1mib_shard_prefix_is_byte_identical():
     _shard_prefix("dropin_1m.npz", 1500)
+
+
+def test_engine_mixed_text_and_exe_blocks_file_is_byte_identical():
+    """A file the reference's detector splits into a TEXT block and an EXE block (x86-like calls whose addresses its
+    preprocessor rewrites, then records and text inside the EXE block): block headers and type switches inside one stream
+    through every stage (tests/golden/make_dropin_mixed.py; the same stream pins the paq8 and fxcm stages per bit through
+    tests/golden/{paq8,fxcm}_cols_mixed_24k.npz)."""
+    if not os.path.exists(ENGINE):
+        pytest.skip("oracle/_ref/cmix_engine not built")
+    with np.load(os.path.join(GOLDEN, "dropin_mixed.npz")) as z:
+        payload, want = z["payload"].tobytes(), z["cmix_file"].tobytes()
+    assert _run("-c", [("in", payload)], exe=ENGINE, timeout=600) == want

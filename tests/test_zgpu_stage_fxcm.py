@@ -130,7 +130,7 @@ def test_pipeline_with_device_fxcm_dictionary_pretraining():
     assert _lookahead("-c", [("dict", v["dict_payload"]), ("in", v["dict_c_payload"])]) == v["dict_c_file"]
 
 
-@pytest.mark.parametrize("name", ["fxcm_cols_wiki_16k", "fxcm_cols_dict_16k"])
+@pytest.mark.parametrize("name", ["fxcm_cols_wiki_16k", "fxcm_cols_dict_16k", "fxcm_cols_mixed_24k"])
 def test_reference_hashes_16k(name):
     """The device stage against the reference itself (not against its twin, the oracle): 16 KB of wiki markup and of
     dictionary-mode text, per-bit hashes of all 431 values recorded from the unmodified fxcmv1::Predictor
@@ -139,7 +139,7 @@ def test_reference_hashes_16k(name):
     from test_fxcm_stage_host import _reference_fixture
     data, pr, ex, dic, want, row_hash = _reference_fixture(name)
     try:
-        got = row_hash(run_device(data, pr, ex, [4096, 1, 4095, 8192], dictionary=dic))
+        got = row_hash(run_device(data, pr, ex, [4096, 1, 4095, 8192, 8192], dictionary=dic))
         bad = np.nonzero(got != want)[0]
         assert bad.size == 0, (name, "first differing bit", int(bad[0]))
     finally:
