@@ -211,3 +211,13 @@ def test_engine_mixed_text_and_exe_blocks_file_is_byte_identical():
     with np.load(os.path.join(GOLDEN, "dropin_mixed.npz")) as z:
         payload, want = z["payload"].tobytes(), z["cmix_file"].tobytes()
     assert _run("-c", [("in", payload)], exe=ENGINE, timeout=600) == want
+
+
+def test_engine_binary_file_with_default_blocks_is_byte_identical():
+    """Random bytes, 24-byte records, zero / 0xFF runs, a ramp: `cmix -c` on data its detector leaves as DEFAULT blocks
+    (tests/golden/make_dropin_binary.py) -- the record / sparse / match / DMC models on their home ground."""
+    if not os.path.exists(ENGINE):
+        pytest.skip("oracle/_ref/cmix_engine not built")
+    with np.load(os.path.join(GOLDEN, "dropin_binary.npz")) as z:
+        payload, want = z["payload"].tobytes(), z["cmix_file"].tobytes()
+    assert _run("-c", [("in", payload)], exe=ENGINE, timeout=600) == want
