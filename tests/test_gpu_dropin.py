@@ -221,3 +221,15 @@ def test_engine_binary_file_with_default_blocks_is_byte_identical():
     with np.load(os.path.join(GOLDEN, "dropin_binary.npz")) as z:
         payload, want = z["payload"].tobytes(), z["cmix_file"].tobytes()
     assert _run("-c", [("in", payload)], exe=ENGINE, timeout=600) == want
+
+
+def test_engine_tiny_files_are_byte_identical():
+    """1, 2, 17 and 100 bytes (`-c`) and 1 byte (`-n`): inputs shorter than a block header, than one BPTT block, than a
+    sub-chunk (tests/golden/make_dropin_tiny.py)."""
+    if not os.path.exists(ENGINE):
+        pytest.skip("oracle/_ref/cmix_engine not built")
+    import make_dropin_tiny as mk
+    with np.load(os.path.join(GOLDEN, "dropin_tiny.npz")) as z:
+        v = {k: z[k].tobytes() for k in z.files}
+    for name, mode, _ in mk.CASES:
+        assert _run(mode, [("in", v[name + "_payload"])], exe=ENGINE, timeout=300) == v[name + "_file"], name
