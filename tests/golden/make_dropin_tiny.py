@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Tiny files for the drop-in test (tests/golden/dropin_tiny.npz): 1, 2, 17 and 100 bytes through `cmix -c` and 1 byte through
+"""Tiny files for the drop-in test (tests/golden/dropin_tiny.npz): 0, 1, 2, 17 and 100 bytes through `cmix -c` and 0 and 1 byte through
 `cmix -n` -- shorter than a block header, than a byte of LSTM history, than one BPTT block -- with the files the UNMODIFIED
 reference binary writes.    python tests/golden/make_dropin_tiny.py"""
 import os
@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 HERE = os.path.dirname(os.path.abspath(__file__))
-CASES = [("c1", "-c", b"A"), ("c2", "-c", b"ab"), ("c17", "-c", b"hello, hello, wor"), ("c100", "-c", (b"the quick brown fox. " * 5)[:100]), ("n1", "-n", b"\x00")]
+CASES = [("c0", "-c", b""), ("n0", "-n", b""), ("c1", "-c", b"A"), ("c2", "-c", b"ab"), ("c17", "-c", b"hello, hello, wor"), ("c100", "-c", (b"the quick brown fox. " * 5)[:100]), ("n1", "-n", b"\x00")]
 
 if __name__ == "__main__":
     from make_dropin_vectors import run

@@ -224,7 +224,7 @@ def test_engine_binary_file_with_default_blocks_is_byte_identical():
 
 
 def test_engine_tiny_files_are_byte_identical():
-    """1, 2, 17 and 100 bytes (`-c`) and 1 byte (`-n`): inputs shorter than a block header, than one BPTT block, than a
+    """0, 1, 2, 17 and 100 bytes (`-c`), 0 and 1 byte (`-n`): the empty file, inputs shorter than a block header, one BPTT block, a
     sub-chunk (tests/golden/make_dropin_tiny.py)."""
     if not os.path.exists(ENGINE):
         pytest.skip("oracle/_ref/cmix_engine not built")
