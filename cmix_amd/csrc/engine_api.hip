@@ -6,8 +6,9 @@
 //   device  contexts + 54 small models, "dry" pass over the partially known byte -> columns 0-2, 2025-2075 and the
 //           47 selectors of this bit (ctxmodels_kernels.hip, dry mode: no state survives the pass)
 //   device  ByteModel::Predict of PPMd and of the LSTM byte mixer over the same partial byte -> columns 2076, 2077
-//   caller  columns 3..2024 (fxcm, paq8) -- no device stage yet; the shim that owns the reference's two vendored
-//           models hands their outputs in through cmx_set_model_outputs()
+//   caller  columns 3..2024 (fxcm, paq8) -- their device stages walk whole chunks of known bytes (cmx_pipeline_*), there is
+//           no bit-synchronous form of them yet; on this surface the shim that owns the reference's two vendored models
+//           hands their outputs in through cmx_set_model_outputs()
 //   device  mixing network + SSE, bit-synchronous (cmx_mixnet_predict)
 // Per Perceive(bit) (predictor.cpp:421-469): the mixing network learns; on the 8th bit the byte is committed to the
 // context stage (the same kernel, now for real), to PPMd (host stage) and to the LSTM; then lstmpr / lstmex
@@ -221,8 +222,8 @@ float cmx_predict(cmx_t* h) {
   if (!h) { cmx_set_err("cmx_predict: null handle"); return fail; }
   if (h->predicted) { cmx_set_err("cmx_predict: called twice without perceive()"); return fail; }
   if (!h->have_staged) {
-    cmx_set_err("cmx_predict: the fxcm/paq8 columns of this bit were not supplied (cmx_set_model_outputs); those "
-                "two model families have no device stage yet and there is no CPU fallback");
+    cmx_set_err("cmx_predict: the fxcm/paq8 columns of this bit were not supplied (cmx_set_model_outputs); on the per-bit "
+                "surface those two families come from the caller (their device stages are chunk-mode) and there is no CPU fallback");
     return fail;
   }
   if (refused(h, where)) return fail;

@@ -2,7 +2,8 @@
 // exactly the reference's four public members (src/predictor.h:17-22) that forwards to the C ABI of libcmixamd.so.
 // src/coder/*, src/preprocess/* and src/runner.cpp compile against it unmodified (build: see integration/README).
 //
-// The two vendored model families that have no device stage yet (fxcm, paq8) are owned here, constructed in the
+// The two vendored model families whose device stages only exist in chunk (look-ahead) form (fxcm, paq8) are owned here -- this
+// is the strict per-bit surface a DEcoder needs; a compressor uses integration/predictor_engine.h instead --, constructed in the
 // reference's order (predictor.cpp:28-36: Bracket, FXCM, PAQ8, ...), and their outputs are handed to the library
 // per bit; everything else behind Predict()/Perceive() runs in the library (MI355X + the PPMd host stage).
 #ifndef PREDICTOR_H

@@ -2,7 +2,8 @@
 // every byte is known before it is coded (runner.cpp:101-119): `class Predictor` here only has to serve
 // preprocessor::Pretrain (the one caller besides the coder, preprocessor.cpp:37-69); the coding itself goes a chunk
 // at a time through cmx_pipeline_begin / _hints / _finish (integration/compress_lookahead.cpp). The two vendored
-// model families are owned here and run on host threads: paq8 always (no device stage yet); fxcm unless
+// model families are owned here and run on host threads (the hybrid path that preceded the whole-engine compressor,
+// integration/predictor_engine.h): paq8 always; fxcm unless
 // CMX_FXCM_DEVICE=1 asks for the device stage (cmx_pipeline_enable_fxcm), in which case no host fxcm object exists.
 #ifndef PREDICTOR_H
 #define PREDICTOR_H
