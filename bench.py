@@ -6,7 +6,7 @@ torch.distributed.run, one rank per GPU. Prints ONE JSON line on rank 0.
 
 Workload (BASELINE.json configs[1], "enwik8 full model ensemble on 1 MI355X", at the size the parity fixture holds):
 rank r compresses the first --payload-bytes (default 1 MiB) of its own S-enwik8 shard (cmix_amd.synth.enwik_like,
-seed 1000 + r) exactly as `cmix -c` would: the stream the reference's preprocessor hands the predictor (one TEXT
+seed 1000 + r, rich alphabet: V = 205 distinct bytes as in enwik8) exactly as `cmix -c` would: the stream the reference's preprocessor hands the predictor (one TEXT
 block), every bit through the FULL ensemble -- all 2078 layer-0 inputs come from engine stages on the GPU (contexts + 54
 small models, LSTM, fxcm's 431 and paq8's 1591 outputs; PPMd and the two text parsers are the engine's host stages,
 inside the timed loop) -- and the final mixing network + SSE, strict bit-exact mode; then the arithmetic coder. A
@@ -20,9 +20,13 @@ verified: the timed run's OUTPUT FILE (header + code) is compared with the SHA-2
 reference binary wrote for the same payload (tests/golden/dropin_*.npz, tests/golden/make_dropin_1m.py) -- compressed
 -size parity in its strongest form -- on rank 0; a payload size without a fixture reports the size only.
 
-roofline: per SURVEY.md 8(d): algorithmic HBM bytes of the slowest stage's dominant kernel / its HIP-event time.
-cpu_baseline (kind "reference"): the unmodified reference binary (oracle/_ref/cmix_O3 -c) on a bounded prefix of the
-same shard, construction excluded by differencing two runs, on one pinned host core.
+roofline: per SURVEY.md 8(d): algorithmic HBM bytes of the slowest stage's dominant kernel / its HIP-event time;
+`traffic` from the PMC passes committed under profiles/ (read at run time, null when the file is missing).
+end_to_end: the second figure SURVEY.md 8d asks for -- payload bytes / (engine construction + framing + the timed run).
+cpu_baseline (kind "reference"): the unmodified reference binary (oracle/_ref/cmix_O3) on the first --cpu-baseline-bytes
+(default 128 KB) of the SAME payload, `-c` (the GPU run's mode, end to end) and `-n` (no preprocessing: predictor only),
+each minus a 256-byte run (construction), each on its own pinned host core, running WHILE the GPU run is timed (the bench
+thread is kept off those cores), so the driver's wall time does not grow by the CPU leg.
 """
 import argparse
 import hashlib
@@ -47,51 +51,116 @@ ALGO = {
     "mixnet": 55172 * 8 * 8 + 4 * 64 * 8,                 # final mixers (f32) + 4 SSE lines per bit
     "paq8": (28 * 1552 + 32) * 2 * 2 * 8 + 267 * 3 * 64 * 2,  # paq8 mixer rows (i16, read + write) + bucket probes
     "fxcm": (10 * 512 + 2 * 16) * 2 * 2 * 8 + 81 * 3 * 64 * 2,  # fxcm mixers + bucket probes
-    "lstm": 8.86e6,                                       # gate weights forward + BPTT share per byte
     "ctxmodels": 54 * 8 * 64,
 }
-# HBM traffic per input byte of each stage's kernels, from the PMC passes of this bench command (profiles/r02_pmc_bench_64k.json:
-# rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, KB summed over the launches; FETCH_SIZE doubled as
-# /opt/skills/guides/MI355X_MICROARCH.md prescribes for 16-byte-per-lane loads on gfx950); that run processed 81 926 stream bytes
-# (65 542 timed + 16 384 warm-up) in 22 launches per stage
-PMC_KB = {"mixnet": (28218.2e3, 54742.7e3, 22), "fxcm": (1442.8e3, 2832.8e3, 22), "lstm": (46764.0e3 + 7836.3e3 + 4565.0e3, 904.9e3 + 10470.9e3 + 21056.7e3, 22),
-          "paq8": (9444.5e3, 26357.6e3, 22), "ctxmodels": (379.5e3, 679.1e3, 22)}   # paq8: its mixer kernel (the role that sets the stage's period)
+
+
+def lstm_algo_bytes(V, C=200, H=100):
+    """forward + output layer + BPTT accumulators + output-layer BPTT read + Adam share, per input byte."""
+    g = 3 * C * (2 * V + 3 * C + 4)
+    return 4 * g + 3 * 4 * V * (2 * C + 1) + 8 * g + 4 * V * 2 * C + 28 * 3 * C * (4 * V + 3 * C + 2) / H
+
+
+# Strict-mode floor of the final mixing network (DESIGN.md 4.1): the 2078-term ordered f32 add chain of a layer-0 mixer is
+# 2078 dependent v_add_f32 at >= 4.5 clocks (register-chain microbenchmark, profiles/r01_ubench.txt) = 3.9 us at 2.4 GHz, plus the
+# serial hand-offs a bit cannot avoid (error -> first products 3.4 k clocks, extra-input chain 1.2 k, error 0.7 k): 5.7 us/bit.
+STRICT_FLOOR_US_PER_BIT = 5.7
+
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_bench.json")
+PMC_KERNELS = {"mixnet": ["cmx_mixnet_chunk_kernel"], "fxcm": ["cmx_fxcm_roles_kernel"], "ctxmodels": ["cmx_ctxmodels_kernel"],
+               "lstm": ["cmx_lstm_fwdblk", "cmx_lstm_bpttblk", "cmx_lstm_bptt_acc", "cmx_lstm_bptt_gb"], "paq8": ["cmx_p8s_mix2_kernel"]}
 
 
 def pmc_traffic_per_byte(stage):
-    f, w, _launches = PMC_KB[stage]
-    return (2.0 * f + w) * 1024.0 / 81926.0
-
-
-KERNEL = {"mixnet": "cmx_mixnet_chunk_kernel", "paq8": "cmx_p8s_mix2_kernel / cmx_p8s_fam2_kernel (slowest role)", "fxcm": "cmx_fxcm_chunk_kernel",
-          "lstm": "cmx_lstm_fwd / cmx_lstm_bptt_*", "ctxmodels": "cmx_ctxmodels_kernel"}
-
-
-def cpu_reference(payload, nbytes, core):
-    """The unmodified reference binary on the first nbytes of the shard, minus a 256-byte run (construction: ~4 s)."""
-    exe = os.path.join(ROOT, "oracle", "_ref", "cmix_O3")
-    if not os.path.exists(exe):
-        return None
-    pin = ["taskset", "-c", str(core)] if subprocess.call(["which", "taskset"], stdout=subprocess.DEVNULL) == 0 else []
-
-    def run(n):
-        with tempfile.TemporaryDirectory() as d:
-            src, dst = os.path.join(d, "in"), os.path.join(d, "out")
-            with open(src, "wb") as f:
-                f.write(bytes(payload[:n]))
-            t0 = time.perf_counter()
-            subprocess.run(pin + [exe, "-c", src, dst], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600, check=True)
-            return time.perf_counter() - t0, os.path.getsize(dst)
+    """HBM bytes per stream byte of the stage's kernels from the committed PMC passes of this command (scripts/gpu_r3_measure.sh:
+    rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs with --kernel-trace only; the counters are KB summed over the
+    launches; FETCH_SIZE doubled as /opt/skills/guides/MI355X_MICROARCH.md prescribes for 16-byte-per-lane loads on gfx950).
+    None when the file is missing or does not list the kernel: a stale constant is worse than no number."""
     try:
-        t_small, _ = run(256)
-        t_big, size = run(256 + nbytes)
-    except Exception as e:  # noqa: BLE001
-        return {"error": str(e)}
-    dt = max(t_big - t_small, 1e-9)
-    return {"value": nbytes / dt, "unit": "input bytes/s", "cores": 1, "kind": "reference",
-            "sample": f"oracle/_ref/cmix_O3 -c (unmodified reference, g++ -O3) on the first {256 + nbytes} bytes of the same shard "
-                      f"minus a 256-byte run ({t_small:.1f} s: construction), whole predictor + coder, "
-                      f"{'taskset -c %d' % core if pin else 'unpinned'}; {dt:.1f} s for {nbytes} bytes; file {size} bytes"}
+        with open(PMC_FILE) as f:
+            z = json.load(f)
+        nbytes = float(z["_meta"]["stream_bytes_processed"])
+        tot = 0.0
+        for k in PMC_KERNELS[stage]:
+            match = [v for name, v in z.items() if name.startswith(k)]
+            if not match:
+                return None
+            for v in match:
+                tot += (2.0 * v["FETCH_SIZE"]["sum"] + v["WRITE_SIZE"]["sum"]) * 1024.0
+        return tot / nbytes
+    except Exception:  # noqa: BLE001
+        return None
+
+
+KERNEL = {"mixnet": "cmx_mixnet_chunk_kernel", "paq8": "cmx_p8s_mix2_kernel / cmx_p8s_fam2_kernel (slowest role)", "fxcm": "cmx_fxcm_roles_kernel",
+          "lstm": "cmx_lstm_fwdblk / cmx_lstm_bpttblk / cmx_lstm_bptt_*", "ctxmodels": "cmx_ctxmodels_kernel"}
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+class CpuReference:
+    """The unmodified reference binary on the first nbytes of the SAME payload, in the background: `-c` (end to end, the GPU run's
+    mode) and `-n` (predictor only: no preprocessing), each as (run on 256 + nbytes bytes) - (run on 256 bytes:
+    construction, ~4 s), each on its own pinned core. start() before the GPU work, result() after it."""
+
+    def __init__(self, payload, nbytes, cores):
+        self.payload, self.nbytes, self.cores = payload, nbytes, cores
+        self.exe = os.path.join(ROOT, "oracle", "_ref", "cmix_O3")
+        self.pin = subprocess.call(["which", "taskset"], stdout=subprocess.DEVNULL) == 0
+        self.res, self.threads = {}, []
+
+    def _one(self, mode, core):
+        pin = ["taskset", "-c", str(core)] if self.pin else []
+
+        def run(n):
+            with tempfile.TemporaryDirectory() as d:
+                src, dst = os.path.join(d, "in"), os.path.join(d, "out")
+                with open(src, "wb") as f:
+                    f.write(bytes(self.payload[:n]))
+                t0 = time.perf_counter()
+                subprocess.run(pin + [self.exe, mode, src, dst], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=1500, check=True)
+                return time.perf_counter() - t0, os.path.getsize(dst)
+        try:
+            t_small, _ = run(256)
+            t_big, size = run(256 + self.nbytes)
+            self.res[mode] = {"seconds": max(t_big - t_small, 1e-9), "construct_s": t_small, "wall_s": t_big, "file_bytes": size, "core": core}
+        except Exception as e:  # noqa: BLE001
+            self.res[mode] = {"error": str(e)}
+
+    def start(self):
+        if not os.path.exists(self.exe):
+            return False
+        import threading
+        for mode, core in zip(("-c", "-n"), self.cores):
+            t = threading.Thread(target=self._one, args=(mode, core), daemon=True)
+            t.start()
+            self.threads.append(t)
+        return True
+
+    def result(self):
+        for t in self.threads:
+            t.join()
+        c, n = self.res.get("-c", {}), self.res.get("-n", {})
+        if "seconds" not in c:
+            return {"error": c.get("error", "reference binary missing")}
+        out = {"value": self.nbytes / c["seconds"], "unit": "input bytes/s", "cores": 1, "kind": "reference", "cpu_model": cpu_model(),
+               "host_cores": os.cpu_count(),
+               "end_to_end": (256 + self.nbytes) / c["wall_s"],
+               "sample": f"oracle/_ref/cmix_O3 -c (unmodified reference, g++ -O3) on the first {256 + self.nbytes} bytes of the same payload minus a 256-byte "
+                         f"run ({c['construct_s']:.1f} s: construction), whole predictor + coder, {'taskset -c %d' % c['core'] if self.pin else 'unpinned'}, concurrent "
+                         f"with the GPU run; {c['seconds']:.1f} s for {self.nbytes} bytes; file {c['file_bytes']} bytes; end_to_end = bytes / wall of main() incl. construction"}
+        if "seconds" in n:
+            out["predictor_only"] = self.nbytes / n["seconds"]
+            out["sample"] += f"; predictor_only = the same with -n (no preprocessing) on core {n['core']}: {n['seconds']:.1f} s"
+        return out
 
 
 def main():
@@ -102,7 +171,7 @@ def main():
     ap.add_argument("--payload-bytes", type=int, default=1 << 20, help="bytes of the shard each rank compresses (fixtures: 65536, 262144, 1048576)")
     ap.add_argument("--sub-chunk", type=int, default=4096, help="bytes per pipeline submit (stages of consecutive sub-chunks overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-bytes", type=int, default=16384)
+    ap.add_argument("--cpu-baseline-bytes", type=int, default=131072)
     a = ap.parse_args()
 
     import torch
@@ -120,7 +189,19 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
     torch.cuda.set_device(local)
 
-    payload = synth.enwik_like(a.payload_bytes, shard.shard_seed(rank))
+    payload = synth.enwik_like(a.payload_bytes, shard.shard_seed(rank), rich=True)
+    ncpu = os.cpu_count() or 2
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and ncpu >= 4:
+        cpu = CpuReference(payload, min(a.cpu_baseline_bytes, a.payload_bytes), (ncpu - 1, ncpu - 2))
+        if cpu.start():
+            try:
+                os.sched_setaffinity(0, set(range(ncpu - 2)))   # the bench thread (PPMd, text parsers, submits) stays off the two cores
+            except (AttributeError, OSError):
+                pass
+        else:
+            cpu = None
+    t_c0 = time.perf_counter()
     stream = text_file_stream(payload)
     n = len(stream)
     # a step = 1/K of the stream's sub-chunks (whole sub-chunks: a ragged step would put a few-byte chunk into the pipeline)
@@ -138,8 +219,11 @@ def main():
         w.finish()
         w.close()
         del w
+    t_c0 = time.perf_counter() - t_c0   # framing (+ step plan); the engine's construction is timed next
+    t_c1 = time.perf_counter()
     eng = EngineStream(local, stream, a.sub_chunk)
     torch.cuda.synchronize()
+    t_construct = t_c0 + time.perf_counter() - t_c1
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -174,7 +258,11 @@ def main():
             if int(seed[0]) == a.payload_bytes and int(seed[1]) == shard.shard_seed(0):
                 verified.update(fixture="tests/golden/" + name, reference_bytes=want_size, identical_to_reference_file=bool(sha == want_sha and len(blob) == want_size))
         dom = max(us, key=us.get)
+        V = int(eng.vocab.sum())
+        ALGO["lstm"] = lstm_algo_bytes(V)
         algo_launch = ALGO[dom] * n / nsub
+        traffic_pb = pmc_traffic_per_byte(dom)
+        ceiling = 1e6 / (8.0 * STRICT_FLOOR_US_PER_BIT)
         kernel_s = us[dom] * bits_per_sub / 1e6
         achieved = algo_launch / kernel_s / 1e9
         out = {
@@ -183,33 +271,42 @@ def main():
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "enwik8-shaped shard (cmix_amd.synth.enwik_like, seed 1000 + rank), first %d bytes, compressed as `cmix -c` does: "
+                "workload": "enwik8-shaped shard (cmix_amd.synth.enwik_like, seed 1000 + rank, rich alphabet), first %d bytes, compressed as `cmix -c` does: "
                             "TEXT-block stream through the FULL model ensemble (2078 layer-0 inputs: contexts + 54 small models, PPMd host stage, "
                             "LSTM, fxcm 431, paq8 1591 -- every column produced by an engine stage, no stand-ins) + final mixing network + SSE, "
                             "strict bit-exact mode, + arithmetic coder; output file checked against the reference binary's" % a.payload_bytes,
-                "payload_bytes": a.payload_bytes, "stream_bytes": n, "sub_chunk_bytes": a.sub_chunk,
+                "payload_bytes": a.payload_bytes, "stream_bytes": n, "sub_chunk_bytes": a.sub_chunk, "vocab": V,
                 "parallelism": "1 stream per GPU, no collective"},
             "us_per_bit": dt / (8.0 * n) * 1e6,
+            "end_to_end": {"value": a.payload_bytes * world / (dt + t_construct), "unit": "input bytes/s", "construct_s": t_construct,
+                           "note": "payload bytes / (framing + engine construction: ~20 GB of tables allocated and initialised + the timed run incl. the coder); "
+                                   "`value` above is the predictor-only figure of SURVEY.md 8d (stream bytes / the Compress() loop)"},
+            "strict_mode_ceiling": {"floor_us_per_bit": STRICT_FLOOR_US_PER_BIT, "ceiling_bytes_per_s": ceiling,
+                                    "note": "one stream in strict (bit-exact) mode cannot go below the ordered 2078-term f32 add chain of the final mixers + the serial "
+                                            "hand-offs of a bit (DESIGN.md 4.1); ceiling_speedup_vs_cpu_reference is filled in below"},
             "stage_us_per_bit": dict(us, note="mean HIP-event time per bit of each stage's kernel(s) over the timed run; the stages overlap on their own streams, "
                                               "so the stream's period is the slowest one (paq8 = its slowest role kernel)"),
             "paq8_role_us_per_bit": dict(p8_roles, span=p8_span, note="role kernels of the paq8 stage on their own streams; span = first launch to end of its mixer, per chunk"),
             "host_us_per_byte": dict({k: v * 1e3 / n for k, v in host.items()}, note="wall time of the submitting thread per stream byte (slot_wait = blocked on the device)"),
             "verified": verified,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic_per_byte(dom) * n / nsub,
-                         "traffic_source": "profiles/r02_pmc_bench_64k.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at 64 KB; 2 x FETCH_SIZE + WRITE_SIZE, "
-                                           "scaled to this launch size)",
+                         "traffic": None if traffic_pb is None else traffic_pb * n / nsub,
+                         "traffic_source": "profiles/r03_pmc_bench.json read at run time (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, kernel-trace only; "
+                                           "2 x FETCH_SIZE + WRITE_SIZE per stream byte, scaled to this launch size); null if the file is missing",
                          "kernel": KERNEL[dom], "stage": dom, "avg_launch_ms": kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": algo_launch,
-                         "note": "every stage is a latency-bound dependent chain per stream (DESIGN.md 4); strict-mode ceiling of the final mixing network: "
-                                 "2078 dependent f32 adds per bit"},
+                         "note": "every stage is a latency-bound dependent chain per stream (DESIGN.md 4): the HBM roof is the wrong roof by construction; see "
+                                 "strict_mode_ceiling for the latency floor (%.1f us/bit -> %.0f B/s)" % (STRICT_FLOOR_US_PER_BIT, ceiling)},
         }
-        if not a.no_cpu_baseline:
-            ref = cpu_reference(payload, a.cpu_baseline_bytes, core=max((os.cpu_count() or 2) - 1, 0))
-            if ref:
-                out["cpu_baseline"] = ref
-                if "value" in ref:
-                    out["speedup_vs_cpu_reference"] = out["value"] / ref["value"]
+        if cpu is not None:
+            ref = cpu.result()
+            out["cpu_baseline"] = ref
+            if "value" in ref:
+                out["speedup_vs_cpu_reference"] = out["value"] / ref["value"]
+                out["strict_mode_ceiling"]["ceiling_speedup_vs_cpu_reference"] = ceiling / ref["value"]
+                if "predictor_only" in ref:
+                    out["speedup_vs_cpu_reference_predictor_only"] = out["value"] / ref["predictor_only"]
+                out["end_to_end"]["speedup_vs_cpu_reference_end_to_end"] = out["end_to_end"]["value"] / ref["end_to_end"]
         print(json.dumps(out))
     eng.close()
     if world > 1:

@@ -90,6 +90,12 @@ void build_sse_tables(std::vector<uint16_t>& t_st, std::vector<uint16_t>& t_sq) 
 
 void cmx_set_err(const std::string& s) { set_err(s); }  // shared with the other stage files
 
+// HIP maps a process's streams onto 4 hardware queues unless told otherwise, which serialises the stage kernels of one input
+// stream that are meant to overlap (3.3 -> 6.2 KB/s when it was found). The runtime reads the variable at its
+// first API call, so setting it when the library is loaded covers every host program (the reference's own main() included);
+// a value the user has set is left alone.
+__attribute__((constructor)) static void cmx_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 struct cmx_mixnet {
   int device = 0;
   MixState* d_state = nullptr;

@@ -776,6 +776,9 @@ int cmx_fxcm_failed(cmx_fxcm_t* h) {
   return f ? 1 : 0;
 }
 
+// DEVICE address of that flag (see cmx_lstm_fail_flag)
+const unsigned* cmx_fxcm_fail_flag(cmx_fxcm_t* h) { return h ? &h->d_xfer->fail : nullptr; }
+
 int cmx_fxcm_sync(cmx_fxcm_t* h) {
   if (!h) { cmx_set_err("cmx_fxcm_sync: null handle"); return 1; }
   if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }

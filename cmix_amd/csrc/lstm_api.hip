@@ -335,6 +335,10 @@ int cmx_lstm_failed(cmx_lstm_t* h) {
   return f ? 1 : 0;
 }
 
+// DEVICE address of the sticky flag above, for callers that copy it back in stream order behind the stage's kernels
+// (4 bytes, asynchronously) instead of synchronising the device: the per-bit surface and cmx_pipeline_wait
+const unsigned* cmx_lstm_fail_flag(cmx_lstm_t* h) { return h ? &h->h_state.sync->fail : nullptr; }
+
 int cmx_bytemodel_bits_run(int device, const float* d_dist0, const float* d_dist_rest, const uint8_t* d_bytes,
                            size_t nbytes, float* d_bit_p, size_t bit_p_stride, int* d_bit_ex, void* stream) {
   if (nbytes == 0) return 0;

@@ -6,6 +6,7 @@
 
 #include <stdio.h>
 #include <stdlib.h>
+#include <pthread.h>
 #include <string.h>
 
 #include "p8f_tables.h"
@@ -17,16 +18,15 @@ int p8f_squash(int d) { return d > 2047 ? 4095 : d < -2047 ? 0 : P8_SQUASH[d + 2
 int p8f_stretch(int p) { return P8_STRETCH[p]; }
 
 static uint8_t g_ilog[65536];
-static int g_ilog_ready;
-static void ilog_init(void) {  /* Ilog::Ilog :260-266 */
-  if (g_ilog_ready) return;
+static pthread_once_t g_ilog_once = PTHREAD_ONCE_INIT;   /* several streams are created concurrently (one thread per GPU) */
+static void ilog_fill(void) {  /* Ilog::Ilog :260-266 */
   uint32_t x = 14155776;
   for (int i = 2; i < 65536; ++i) {
     x += 774541002 / (i * 2 - 1);
     g_ilog[i] = (uint8_t)(x >> 24);
   }
-  g_ilog_ready = 1;
 }
+static void ilog_init(void) { pthread_once(&g_ilog_once, ilog_fill); }
 int p8f_ilog(int x) { ilog_init(); return g_ilog[x & 0xffff]; }
 const uint8_t* p8f_ilog_table(void) { ilog_init(); return g_ilog; }
 static unsigned ilog2u(unsigned x) { unsigned n = 0; while (x > 1) { x >>= 1; ++n; } return n; }
@@ -364,6 +364,6 @@ void p8f_rcm_set(RCM* r, uint64_t cx, int c1) {
 }
 int p8f_rcm_mix(RCM* r, int bpos, int c0, int16_t* out) {
   const uint8_t* cp = r->t + r->cp;
-  out[0] = (int16_t)(((cp[1] + 256) >> (8 - bpos)) == c0 ? (((cp[1] >> (7 - bpos)) & 1) * 2 - 1) * g_ilog[cp[0] + 1] * 8 : 0);
+  out[0] = (int16_t)(((cp[1] + 256) >> (8 - bpos)) == c0 ? (((cp[1] >> (7 - bpos)) & 1) * 2 - 1) * p8f_ilog(cp[0] + 1) * 8 : 0);
   return cp[0] != 0;
 }

@@ -37,6 +37,7 @@ struct Slot {
   float* h_ppmd = nullptr;      // pinned [max+1][256]
   float* d_hint = nullptr;      // [8 max + 1] f32 LSTM bit predictions, then [8 max + 1] i32 `ex` (look-ahead hybrid)
   float* h_hint = nullptr;      // pinned mirror
+  unsigned* h_fail = nullptr;   // pinned [2]: the LSTM's / fxcm's sticky hand-off flags as they stood behind this chunk's kernels
   size_t n = 0;                 // bytes of the chunk in this slot
   float* d_layer0 = nullptr;    // the caller's layer-0 rows of that chunk
   hipEvent_t ev_in = nullptr, ev_ctx0 = nullptr, ev_ctx1 = nullptr, ev_lstm0 = nullptr, ev_lstm1 = nullptr,
@@ -121,6 +122,7 @@ void cmx_pipeline_destroy(cmx_pipeline_t* h) {
     if (s.h_ppmd) (void)hipHostFree(s.h_ppmd);
     if (s.d_hint) (void)hipFree(s.d_hint);
     if (s.h_hint) (void)hipHostFree(s.h_hint);
+    if (s.h_fail) (void)hipHostFree(s.h_fail);
     if (s.d_fx_pr) (void)hipFree(s.d_fx_pr);
     if (s.d_fx_ex) (void)hipFree(s.d_fx_ex);
     for (hipEvent_t e : {s.ev_fxin, s.ev_fx0, s.ev_fx1, s.ev_p80, s.ev_p81})
@@ -180,6 +182,8 @@ cmx_pipeline_t* cmx_pipeline_create(const uint8_t vocab[256], int device, size_t
     ok = ok && hipHostMalloc((void**)&s.h_ppmd, (n + 1) * 256 * 4, hipHostMallocDefault) == hipSuccess;
     ok = ok && hipMalloc((void**)&s.d_hint, 2 * (8 * n + 1) * 4) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&s.h_hint, 2 * (8 * n + 1) * 4, hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&s.h_fail, 8, hipHostMallocDefault) == hipSuccess;
+    if (ok) s.h_fail[0] = s.h_fail[1] = 0;
     for (hipEvent_t* e : {&s.ev_in, &s.ev_ctx0, &s.ev_ctx1, &s.ev_lstm0, &s.ev_lstm1, &s.ev_mix0, &s.ev_mix1, &s.ev_cols})
       ok = ok && hipEventCreate(e) == hipSuccess;
   }
@@ -319,6 +323,8 @@ int cmx_pipeline_begin(cmx_pipeline_t* h, const uint8_t* bytes, size_t n, float*
   if (cmx_lstm_run(h->lstm, s.d_ppmd + 256, s.d_bytes, n, s.d_lstm_out, d_layer0 + 2077, CMX_N_INPUTS,
                    (int*)(s.d_hint + (8 * h->max_chunk + 1)), h->s_lstm))
     return 1;
+  // the stage's sticky time-out flag, in stream order behind its kernels: cmx_pipeline_wait looks at it per chunk
+  (void)hipMemcpyAsync(&s.h_fail[0], cmx_lstm_fail_flag(h->lstm), 4, hipMemcpyDeviceToHost, h->s_lstm);
   (void)hipEventRecord(s.ev_lstm1, h->s_lstm);
   lap(2);
   if (h->fxcm) {  // ---- fxcm stage: hints from the LSTM's columns, then the parser (this thread) and the kernel on its own stream ----
@@ -332,6 +338,7 @@ int cmx_pipeline_begin(cmx_pipeline_t* h, const uint8_t* bytes, size_t n, float*
     (void)hipStreamWaitEvent(h->s_fx, s.ev_fxin, 0);
     (void)hipEventRecord(s.ev_fx0, h->s_fx);
     if (cmx_fxcm_run(h->fxcm, bytes, s.d_bytes, n, s.d_fx_pr, s.d_fx_ex, d_layer0, CMX_N_INPUTS, h->s_fx)) return 1;
+    (void)hipMemcpyAsync(&s.h_fail[1], cmx_fxcm_fail_flag(h->fxcm), 4, hipMemcpyDeviceToHost, h->s_fx);
     (void)hipEventRecord(s.ev_fx1, h->s_fx);
   }
   lap(3);
@@ -472,12 +479,22 @@ int cmx_pipeline_pretrain(cmx_pipeline_t* h, const uint8_t* bytes, size_t n) {
 }
 
 // Wait until chunk number `index` (0 = the first chunk submitted) has left the mixing network: its p[] is complete.
-// Only the last four chunks can be waited for (their slots still hold the events).
+// Only the last CMX_PIPELINE_SLOTS chunks can be waited for (their slots still hold the events). Also reports a timed-out
+// in-launch hand-off of the multi-workgroup LSTM / fxcm kernels as of this chunk (their sticky flags were copied back in
+// stream order behind the chunk's kernels, which the mixing network waited for): a caller that codes chunk by chunk
+// learns of a void stream at the chunk where it happened, not at the end of the file.
 int cmx_pipeline_wait(cmx_pipeline_t* h, uint64_t index) {
   if (!h) { cmx_set_err("cmx_pipeline_wait: null handle"); return 1; }
   if (index >= h->finished || index + kSlots < h->finished) { cmx_set_err("cmx_pipeline_wait: that chunk is not in flight"); return 1; }
   if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
-  if (hipEventSynchronize(h->slot[index % kSlots].ev_mix1) != hipSuccess) { cmx_set_err("cmx_pipeline_wait: device error"); return 1; }
+  Slot& s = h->slot[index % kSlots];
+  if (hipEventSynchronize(s.ev_mix1) != hipSuccess) { cmx_set_err("cmx_pipeline_wait: device error"); return 1; }
+  if (s.h_fail[0] || s.h_fail[1]) {
+    cmx_set_err(std::string("cmx_pipeline_wait: an in-launch hand-off of the ") + (s.h_fail[0] ? "LSTM" : "fxcm") +
+                " kernels timed out (workgroups not co-resident?): the stream's output is void from chunk " + std::to_string(index) + " on");
+    h->failed = true;
+    return 1;
+  }
   return 0;
 }
 

@@ -124,6 +124,7 @@ def lib():
         L.cmx_set_model_outputs.argtypes = [C.c_void_p, C.c_void_p]
         L.cmx_get_lstm_hint.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.cmx_stage_input.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.cmx_mode.argtypes = [C.c_void_p, C.c_void_p]
         L.cmx_debug_last_row.restype = C.c_void_p
         L.cmx_debug_last_row.argtypes = [C.c_void_p]
         L.cmx_ctxmodels_debug_slow_bytes.argtypes = [C.c_void_p, C.c_void_p]
@@ -667,8 +668,10 @@ def header_read(buf):
 
 class Predictor:
     """`class Predictor` (src/predictor.h:17-22) over cmx_create .. cmx_destroy: Predict / Perceive / Pretrain in the
-    reference's strict per-bit protocol (what a Decoder needs). The fxcm and paq8 columns of each bit come from
-    the caller (`set_model_outputs`) until those model families have device stages."""
+    reference's strict per-bit protocol. Two modes, decided by the first call that needs device state: after
+    `stage_input` (a compressor knows its bytes) the handle runs the chunk pipeline with every model family on the device and
+    Predict / Perceive pop and check; without it the per-bit stages are built (what a Decoder needs) and the fxcm / paq8
+    columns of each bit come from the caller (`set_model_outputs`)."""
 
     def __init__(self, vocab, device=0, dict_path=None):
         vocab = np.ascontiguousarray(vocab, np.uint8)
@@ -697,6 +700,18 @@ class Predictor:
     def Pretrain(self, bit):
         if lib().cmx_pretrain(self.h, int(bit)):
             raise CmxError(last_error())
+
+    def stage_input(self, data, end=True):
+        """Look-ahead: the bytes about to be coded (appended to what is already staged); end=True marks the end of the input."""
+        b = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8))
+        if len(b) and lib().cmx_stage_input(self.h, b.ctypes.data, len(b)):
+            raise CmxError(last_error())
+        if end and lib().cmx_stage_input(self.h, None, 0):
+            raise CmxError(last_error())
+
+    def mode(self):
+        n = C.c_int(0)
+        return lib().cmx_mode(self.h, C.byref(n)), n.value
 
     def lstm_hint(self):
         a, b = C.c_int(0), C.c_int(0)

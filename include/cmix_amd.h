@@ -63,7 +63,7 @@ typedef struct cmx_engine cmx_t;
 /* vocab[i] != 0 iff byte value i occurs in the (preprocessed) input
  * (runner.cpp:196-202). dict_path replaces the global `dictionary_path`
  * (runner.cpp:17) read by fxcm; may be NULL. */
-cmx_t* cmx_create(const uint8_t vocab[256], const char* dict_path, int device);
+cmx_t* cmx_create(const uint8_t vocab[256], const char* dict_path, int device);   /* checks the device; stages are built on first use */
 float cmx_predict(cmx_t*);             /* Predictor::Predict,  predictor.cpp:361; < 0 on error */
 int cmx_perceive(cmx_t*, int bit);     /* Predictor::Perceive, predictor.cpp:421 */
 int cmx_pretrain(cmx_t*, int bit);     /* Predictor::Pretrain, predictor.cpp:471 */
@@ -78,9 +78,19 @@ int cmx_set_model_outputs(cmx_t*, const float cols_3_to_2024[2022]);
 int cmx_get_lstm_hint(cmx_t*, int* lstmpr, int* lstmex);
 /* Introspection used by the parity tests: the 2078 layer-0 inputs of the last cmx_predict() (valid until the next). */
 const float* cmx_debug_last_row(cmx_t*);
-/* Optional look-ahead for compression. On the per-bit surface it is refused: look-ahead coding is
- * cmx_pipeline_* below. */
+/* Look-ahead for compression: the next n bytes the caller is going to code, in order; may be called
+ * repeatedly (bytes are appended); n == 0 marks the end of the input (the ragged last chunk is then submitted at once).
+ * The first call must precede the first cmx_predict() and puts the handle in LOOK-AHEAD MODE: it builds the chunk
+ * pipeline (cmx_pipeline_*: every model family a device stage, fxcm and paq8 included -- no cmx_set_model_outputs),
+ * trains it on the bytes cmx_pretrain() has collected, and keeps CMX_PIPELINE_SLOTS chunks of 4 KB in flight.
+ * cmx_predict() then pops the next probability of the chunk that has left the mixing network (same float the per-bit
+ * surface would return) and cmx_perceive(bit) checks the bit against the staged one -- a mismatch is an error, the
+ * device has already learnt the staged bit. With it the reference's unmodified Encoder (encoder.cpp:14-30) and
+ * Compress loop (runner.cpp:101-119) run at the pipeline's speed: integration/predictor_dropin.h.
+ * Without it the handle builds the per-bit stages on first use (what a Decoder needs). */
 int cmx_stage_input(cmx_t*, const uint8_t* bytes, size_t n);
+/* 0 = undecided (nothing built yet), 1 = per-bit stages, 2 = look-ahead pipeline; *chunks_in_flight (may be NULL). */
+int cmx_mode(cmx_t*, int* chunks_in_flight);
 void cmx_destroy(cmx_t*);
 
 /* ------------------------------------------------------------------------
@@ -179,6 +189,9 @@ int cmx_lstm_gate_rowlen(const cmx_lstm_t*, int layer);
 /* 1 if a bounded in-launch wait of the multi-workgroup kernels (lstm_block.hip) ran out -- the stream's LSTM output
  * is void from that point --, 0 otherwise. Synchronises the device. */
 int cmx_lstm_failed(cmx_lstm_t*);
+/* DEVICE address of the sticky flag cmx_lstm_failed reads (4 bytes): copy it back in stream order behind the stage's
+ * kernels to learn of a timed-out hand-off without synchronising the device. */
+const unsigned* cmx_lstm_fail_flag(cmx_lstm_t*);
 int cmx_glibc_rand_selftest(uint32_t seed, int n, int* out);
 
 /* ------------------------------------------------------------------------
@@ -324,6 +337,7 @@ int cmx_fxcm_run(cmx_fxcm_t*, const uint8_t* bytes, const uint8_t* d_bytes, size
 int cmx_fxcm_sync(cmx_fxcm_t*);
 /* 1 if a bounded in-launch wait of the three-role kernel ran out (the stream's fxcm columns are void from there); syncs. */
 int cmx_fxcm_failed(cmx_fxcm_t*);
+const unsigned* cmx_fxcm_fail_flag(cmx_fxcm_t*);   /* as cmx_lstm_fail_flag */
 int cmx_fxcm_set_upload_stream(cmx_fxcm_t*, void* stream);   /* see cmx_mixnet_set_upload_stream */
 /* diagnostics (CMX_FXCM_PROFILE=1 at create time): clocks of lane 0 of each of the kernel's 8 wavefronts per phase
  * (1a work, 1a barrier wait, 1c, 2, 3, 4, 5, -) */

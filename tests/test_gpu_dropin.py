@@ -233,3 +233,112 @@ def test_engine_tiny_files_are_byte_identical():
         v = {k: z[k].tobytes() for k in z.files}
     for name, mode, _ in mk.CASES:
         assert _run(mode, [("in", v[name + "_payload"])], exe=ENGINE, timeout=300) == v[name + "_file"], name
+
+
+# ---- the drop-in with the whole engine behind Predict() / Perceive() ---------------------------------------------
+# oracle/_ref/cmix_dropin = the reference's runner.cpp (+ the ONE look-ahead line, applied to a scratch copy by oracle/Makefile),
+# encoder.cpp, decoder.cpp, preprocessor.cpp, dictionary.cpp -- compiled where they lie -- against integration/predictor_dropin.h
+# and libcmixamd.so. No reference model object, none of the builder's own main(): the reference's Compress loop and Encoder
+# call Predict() / Perceive() per bit and the library serves them from the chunk pipeline (cmx_stage_input).
+DROPIN = os.path.join(ROOT, "oracle", "_ref", "cmix_dropin")
+
+
+def _dropin_vectors():
+    if not os.path.exists(DROPIN):
+        pytest.skip("oracle/_ref/cmix_dropin not built (make -C oracle dropin_engine)")
+    return _vectors()
+
+
+def test_dropin_engine_links_no_reference_model():
+    if not os.path.exists(DROPIN):
+        pytest.skip("oracle/_ref/cmix_dropin not built")
+    syms = subprocess.run(["nm", "-C", DROPIN], capture_output=True, text=True).stdout
+    assert "paq8" not in syms and "fxcmv1" not in syms and "PPMD" not in syms and "Lstm" not in syms
+    assert "Encoder::Encode" in syms and "cmx_stage_input" in syms   # the reference's coder, the library's look-ahead
+
+
+def test_dropin_engine_small_files_are_byte_identical():
+    v = _dropin_vectors()
+    assert _run("-n", [("in", v["raw_n_payload"])], exe=DROPIN) == v["raw_n_file"]
+    assert _run("-c", [("in", v["text_c_payload"])], exe=DROPIN) == v["text_c_file"]
+    assert _run("-c", [("dict", v["dict_payload"]), ("in", v["dict_c_payload"])], exe=DROPIN) == v["dict_c_file"]
+
+
+def test_dropin_engine_12k_and_50k_files_are_byte_identical():
+    import hashlib
+    from cmix_amd import synth
+    v = _dropin_vectors()
+    assert _run("-c", [("in", v["text12k_c_payload"])], exe=DROPIN) == v["text12k_c_file"]
+    with np.load(os.path.join(GOLDEN, "dropin_vectors.npz")) as z:
+        want_sha, want_size, (n, seed) = z["text50k_c_sha256"].tobytes(), int(z["text50k_c_size"][0]), z["text50k_c_seed"]
+    got = _run("-c", [("in", synth.enwik_like(int(n), int(seed)))], exe=DROPIN, timeout=900)
+    assert len(got) == want_size and hashlib.sha256(got).digest() == want_sha
+
+
+def test_dropin_engine_empty_and_tiny_files():
+    if not os.path.exists(DROPIN):
+        pytest.skip("oracle/_ref/cmix_dropin not built")
+    import make_dropin_tiny as mk
+    with np.load(os.path.join(GOLDEN, "dropin_tiny.npz")) as z:
+        v = {k: z[k].tobytes() for k in z.files}
+    for name, mode, _ in mk.CASES[:3]:
+        assert _run(mode, [("in", v[name + "_payload"])], exe=DROPIN, timeout=300) == v[name + "_file"], name
+
+
+# ---- BASELINE config 3: the reference's own dictionary (44 515 words, 412 KB of Pretrain) ------------------------------
+def test_dropin_engine_english_dic_pretrain_and_wrt_text_is_byte_identical():
+    """`cmix -c english.dic in out` on 64 KB of rich enwik-like text whose words come from that dictionary (tests/golden/
+    make_dropin_dict.py): the reference's WRT transform (2- and 3-byte codewords), Predictor::Pretrain over the 412 KB dictionary
+    through the device paq8 / fxcm / context stages in one batch, fxcm's dictionary-mode parser, then the coded stream -- through
+    the reference's unmodified runner + coder and the library's look-ahead mode. Size and SHA-256 of the reference binary's file."""
+    import hashlib
+    import time
+    dic = os.path.join(ROOT, "oracle", "_ref", "english.dic")
+    fx = os.path.join(GOLDEN, "dropin_dict.npz")
+    if not (os.path.exists(DROPIN) and os.path.exists(dic) and os.path.exists(fx)):
+        pytest.skip("cmix_dropin, oracle/_ref/english.dic or the fixture missing")
+    with np.load(fx) as z:
+        payload, want_sha, want_size, dic_sha = z["payload"].tobytes(), z["sha256"].tobytes(), int(z["size"][0]), z["dict_sha256"].tobytes()
+    blob = open(dic, "rb").read()
+    assert hashlib.sha256(blob).digest() == dic_sha
+    t0 = time.time()
+    got = _run("-c", [("english.dic", blob), ("in", payload)], exe=DROPIN, timeout=900)
+    dt = time.time() - t0
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "config3_dict_time.txt"), "w") as f:
+        f.write("cmix_dropin -c english.dic (412 KB pretraining + %d bytes coded): %.1f s wall, file %d bytes (reference: %d)\n" % (len(payload), dt, len(got), want_size))
+    assert len(got) == want_size and hashlib.sha256(got).digest() == want_sha
+
+
+# ---- BASELINE config 4: twelve files of mixed types through the reference's own framing, one process per file ----------
+def test_silesia_like_members_through_the_multifile_driver_are_byte_identical(tmp_path):
+    """synth.silesia_like at reduced size (prose, wiki text, XML, text + record tables, x86-like code + data, 16-bit samples,
+    uniform bytes; tests/golden/make_dropin_silesia.py): cmix_amd.multifile.compress_paths gives every member to the engine
+    command line (the reference's detector / block framing / e8e9 transform inside it, every model family on the device) on this
+    box's GPU(s); every output file must be the file the reference binary wrote for that member."""
+    import hashlib
+    from cmix_amd import multifile, synth
+    fx = os.path.join(GOLDEN, "dropin_silesia.npz")
+    if not (os.path.exists(ENGINE) and os.path.exists(fx)):
+        pytest.skip("cmix_engine or the fixture missing")
+    import torch
+    with np.load(fx) as z:
+        g = {k: z[k] for k in z.files}
+    scale, seed = (int(v) for v in g["scale_seed"])
+    files = synth.silesia_like(scale, seed)
+    jobs = []
+    for name, data in files.items():
+        assert len(data) == int(g[name + "_size"][0])
+        (tmp_path / name).write_bytes(data)
+        jobs.append((str(tmp_path / name), str(tmp_path / (name + ".cmix"))))
+    rep = multifile.compress_paths(jobs, devices=range(max(1, torch.cuda.device_count())), exe=ENGINE, timeout=1200)
+    assert sum(len(r["files"]) for r in rep.values()) == 12
+    bad = []
+    for name in files:
+        got = (tmp_path / (name + ".cmix")).read_bytes()
+        if len(got) != int(g[name + "_size"][1]) or hashlib.sha256(got).digest() != g[name + "_sha256"].tobytes():
+            bad.append((name, len(got), int(g[name + "_size"][1])))
+    with open(os.path.join(ROOT, "gpurun_out", "config4_silesia_time.txt"), "w") as f:
+        for dev, r in sorted(rep.items()):
+            f.write("GPU %d: %d files, %d bytes, %.1f s\n" % (dev, len(r["files"]), r["bytes"], r["seconds"]))
+    assert not bad, "members whose file differs from the reference binary's (name, got, want): %s" % bad

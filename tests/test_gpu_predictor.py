@@ -109,7 +109,8 @@ def test_pretrain_then_code():
 def test_protocol_errors():
     from cmix_amd import engine as E
     pr = E.Predictor(np.ones(256, np.uint8), 0)
-    with pytest.raises(E.CmxError, match="not supplied"):
+    assert pr.mode() == (0, 0)   # nothing is built before the first call that needs device state
+    with pytest.raises(E.CmxError, match="neither staged input"):
         pr.Predict()
     pr.set_model_outputs(np.full(2022, 0.5, np.float32))
     pr.Predict()
@@ -118,5 +119,69 @@ def test_protocol_errors():
     pr.Perceive(1)
     with pytest.raises(E.CmxError, match="no pending"):
         pr.Perceive(0)
-    assert E.lib().cmx_stage_input(pr.h, None, 0) != 0 and "cmx_pipeline" in E.last_error()
+    assert pr.mode()[0] == 1
+    with pytest.raises(E.CmxError, match="per-bit stages of this handle already exist"):
+        pr.stage_input(b"abc")
+    pr.close()
+
+
+# ---- look-ahead mode of the same surface (cmx_stage_input): the chunk pipeline behind Predict() / Perceive() ----------
+
+def _lookahead_walk(name, pretrain=False, split=None):
+    """Stage the trace's bytes, then drive Predict / Perceive bit by bit as Encoder::Encode does (encoder.cpp:14-30): every
+    returned float must equal the reference trace's final probability, with NO column handed in by the caller."""
+    from cmix_amd import engine as E
+    g = load_golden(name)
+    pr = E.Predictor(g["vocab"], 0)
+    if pretrain:
+        for byte in g["pretrain"]:
+            for j in range(7, -1, -1):
+                pr.Pretrain((int(byte) >> j) & 1)
+    data = g["stream"].tobytes()
+    if split:   # staged in pieces, as a streaming caller would
+        pr.stage_input(data[:split], end=False)
+        pr.stage_input(data[split:], end=True)
+    else:
+        pr.stage_input(data)
+    assert pr.mode()[0] == 2
+    t = 0
+    for byte in data:
+        for j in range(7, -1, -1):
+            p = pr.Predict()
+            assert np.float32(p).view(np.uint32) == g["p_final"][t].view(np.uint32), f"{name}: p differs at bit {t}"
+            pr.Perceive((byte >> j) & 1)
+            t += 1
+    return pr, g
+
+
+def test_lookahead_mode_reproduces_the_reference_trace():
+    from cmix_amd import engine as E
+    pr, _ = _lookahead_walk("text_96", split=50)
+    with pytest.raises(E.CmxError, match="no staged input is left"):
+        pr.Predict()
+    pr.close()
+
+
+def test_lookahead_mode_after_pretrain():
+    pr, _ = _lookahead_walk("pretrained_128", pretrain=True)
+    pr.close()
+
+
+def test_lookahead_mode_protocol_errors():
+    from cmix_amd import engine as E
+    g = load_golden("text_96")
+    pr = E.Predictor(g["vocab"], 0)
+    pr.stage_input(g["stream"].tobytes()[:8])
+    with pytest.raises(E.CmxError, match="takes no columns"):
+        pr.set_model_outputs(np.full(2022, 0.5, np.float32))
+    with pytest.raises(E.CmxError, match="after the end-of-input mark"):
+        pr.stage_input(b"x")
+    pr.Predict()
+    with pytest.raises(E.CmxError, match="twice"):
+        pr.Predict()
+    first = int(g["stream"][0]) >> 7
+    with pytest.raises(E.CmxError, match="differs from the staged input"):
+        pr.Perceive(1 - first)
+    with pytest.raises(E.CmxError, match="failed part-way"):   # the device has learnt the staged bit: the handle is void
+        pr.Predict()
     pr.close()

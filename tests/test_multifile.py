@@ -64,3 +64,34 @@ def test_a_failing_file_is_reported_and_the_other_gpu_finishes():
         multifile.compress_files(files, devices=[0, 1], open_stream=open_stream, step_bytes=4096)
     closes = [e for e in FakeStream.log if e[0] == "close"]
     assert len(closes) == 3   # a, the failed b, and c after it on the same GPU
+
+
+def test_compress_paths_runs_one_process_per_file_bound_to_its_gpu(tmp_path):
+    """The process-per-file driver with a FAKE engine command line (a shell script that records CMIX_DEVICE and its arguments):
+    longest-first assignment, the device binding through the environment, the optional dictionary argument, failure reporting."""
+    import os
+    import stat
+    exe = tmp_path / "fake_engine.sh"
+    exe.write_text('#!/bin/sh\n'
+                   'eval "out=\\${$#}"\n'
+                   'echo "$CMIX_DEVICE $*" > "$out"\n'
+                   'case "$*" in *poison*) exit 3;; esac\n')
+    exe.chmod(exe.stat().st_mode | stat.S_IEXEC)
+    jobs = []
+    for name, n in (("a", 5000), ("b", 3000), ("c", 2500), ("d", 100)):
+        src = tmp_path / name
+        src.write_bytes(b"x" * n)
+        jobs.append((str(src), str(tmp_path / (name + ".cmix"))))
+    rep = multifile.compress_paths(jobs, devices=[0, 1], exe=str(exe), dictionary=str(tmp_path / "dic"))
+    assert [os.path.basename(f) for f in rep[0]["files"]] == ["a", "d"] and [os.path.basename(f) for f in rep[1]["files"]] == ["b", "c"]
+    got = {os.path.basename(dst)[0]: open(dst).read().split() for _, dst in jobs}
+    assert got["a"][0] == "0" and got["d"][0] == "0" and got["b"][0] == "1" and got["c"][0] == "1"
+    assert got["b"][1:] == ["-c", str(tmp_path / "dic"), jobs[1][0], jobs[1][1]]
+    bad = tmp_path / "poison"
+    bad.write_bytes(b"y" * 4000)
+    with pytest.raises(RuntimeError, match="poison.*failed on GPU 1"):
+        multifile.compress_paths(jobs + [(str(bad), str(tmp_path / "poison.cmix"))], devices=[0, 1], exe=str(exe))
+    with pytest.raises(FileNotFoundError):
+        multifile.compress_paths(jobs, devices=[0], exe=str(tmp_path / "missing"))
+    with pytest.raises(ValueError, match="open_stream is required"):
+        multifile.compress_files({"a": b"x"}, devices=[0], open_stream=None)
