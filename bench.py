@@ -250,12 +250,12 @@ def main():
     if rank == 0:
         sha = hashlib.sha256(blob).hexdigest()
         verified = {"output_bytes": len(blob), "sha256": sha, "fixture": None, "identical_to_reference_file": None}
-        name = "dropin_1m.npz" if a.payload_bytes == 1 << 20 else "dropin_%dk.npz" % (a.payload_bytes >> 10)
+        name = "dropin_1m.npz" if a.payload_bytes == 1 << 20 else "dropin_rich_%dk.npz" % (a.payload_bytes >> 10)
         fx = os.path.join(ROOT, "tests", "golden", name)
         if os.path.exists(fx):
             with np.load(fx) as z:
-                want_sha, want_size, seed = z["sha256"].tobytes().hex(), int(z["size"][0]), z["seed"]
-            if int(seed[0]) == a.payload_bytes and int(seed[1]) == shard.shard_seed(0):
+                want_sha, want_size, seed, fx_rich = z["sha256"].tobytes().hex(), int(z["size"][0]), z["seed"], "rich" in z.files
+            if int(seed[0]) == a.payload_bytes and int(seed[1]) == shard.shard_seed(0) and fx_rich:
                 verified.update(fixture="tests/golden/" + name, reference_bytes=want_size, identical_to_reference_file=bool(sha == want_sha and len(blob) == want_size))
         dom = max(us, key=us.get)
         V = int(eng.vocab.sum())

@@ -104,6 +104,9 @@ typedef struct {
   uint32_t gword[9];                /* wordModel's globals: spaces, spacecount, words, wordcount, wordlen, wordlen1, frstchar, spafdo, col */
   /* detectors (imgModel :5386-5504, audioModel :5810-5865) */
   struct { uint32_t Header, Offset, Bpp, Size, Palette, HdrLess, Width, Height, BitMask; } bmp;
+  int img_gray, img_pltorder;                      /* imgModel's statics `gray`, `pltorder` while a palette is being skipped */
+  struct { int offset, jpeg, app; } jimg[4];       /* jpegModel's images[0..3] as far as the header phase goes (:5898-5908) */
+  int jidx, jlast_pos, jdqt_state, jdqt_end, jqnum;
   struct { uint32_t Header, IdLength, Bpp, ImgType, MapSize, Width, Height; } tga;
   struct { uint32_t Header, Size, Channels, BitsPerSample, Chunk, Data; } wav;
   uint32_t wav_length;
@@ -126,6 +129,7 @@ static P8Predictor* predictor_new(int level) {
   p->level = level;
   p->buf = (uint8_t*)p8f_tracked_calloc(mem * 8, 1); p->bmask = (uint32_t)(mem * 8 - 1);
   p->c0 = 1;
+  p->jdqt_state = -1;
   p->cm = p8f_cm2_new(mem * 16, 10);
   p->text = p8f_text_new((uint32_t)(mem * 16));
   p->match = p8f_match_new((uint32_t)(mem * 2));
@@ -149,12 +153,73 @@ static int m2(const P8Predictor* p, int i) { return (int)(RB(i) * 256 + RB(i - 1
 static unsigned ilog2u(unsigned x) { unsigned n = 0; while (x > 1) { x >>= 1; ++n; } return n; }
 static uint64_t hash1(uint64_t a) { return (a + 1) * 0x9E3779B97F4A7C15ull; }
 
-/* The detectors of the sub-models that are not restated, at a byte boundary. 0: ordinary data, go on. */
-static int jpeg_detect(const P8Predictor* p) {  /* jpegModel :6098 -- SOI followed by a valid marker */
-  const uint32_t b1 = RB(1);
-  return (RB(4) == 0xFF && RB(3) == 0xD8 && RB(2) == 0xFF && ((b1 & 0xFE) == 0xC0 || b1 == 0xC4 || (b1 >= 0xDB && b1 <= 0xFE))) ? P8F_ERR_JPEG : 0;
+/* The detectors of the sub-models that are not restated, at a byte boundary. 0: ordinary data, go on. Each one follows the
+ * reference up to the byte at which the sub-model would switch on (its return value turns non-zero and contextModel2 :8161-8167
+ * takes the short path): only there is the stream refused. A header-like pattern that the reference itself drops (a DIB header
+ * with no plausible pixel area, an SOI that is not followed by a valid scan header) is ordinary data here too. */
+
+/* jpegModel :5911-6133, header phase. images[idx].jpeg: 1 after SOI + marker, 2 once a valid SOS has been seen -- from that byte on
+ * the model codes Huffman data and returns 1. Before that, everything it does (APPx skipping with embedded thumbnails, DQT tables,
+ * pointers to SOF / DHT) is private state; what matters is which bytes reset it. bpos == 0 here, so `jassert` failures reset. */
+#define JFINISH() do { const int length_ = p->pos - p->jimg[p->jidx].offset; memset(&p->jimg[p->jidx], 0, sizeof p->jimg[0]); \
+    p->jdqt_state = -1; p->jidx -= (p->jidx > 0); p->jimg[p->jidx].app -= length_; if (p->jimg[p->jidx].app < 0) p->jimg[p->jidx].app = 0; } while (0)
+#define JASSERT(x) do { if (!(x)) { if (p->jidx > 0) JFINISH(); else p->jimg[p->jidx].jpeg = 0; return 0; } } while (0)
+static int jpeg_detect(P8Predictor* p) {
+  const uint32_t b1 = RB(1), b2 = RB(2), b3 = RB(3), b4 = RB(4);
+  const int soi_marker = b4 == 0xFF && b3 == 0xD8 && b2 == 0xFF && ((b1 & 0xFE) == 0xC0 || b1 == 0xC4 || (b1 >= 0xDB && b1 <= 0xFE));
+  if (p->jimg[p->jidx].app > 0) {   /* inside an APPx / COM segment: only an embedded image is looked for (:6058-6063) */
+    --p->jimg[p->jidx].app;
+    if (p->jidx < 3 && soi_marker) { ++p->jidx; memset(&p->jimg[p->jidx], 0, sizeof p->jimg[0]); }
+  }
+  if (p->jimg[p->jidx].app > 0) return 0;
+  if (!p->jimg[p->jidx].jpeg && soi_marker) {   /* :6098-6107 */
+    p->jimg[p->jidx].jpeg = 1;
+    p->jimg[p->jidx].offset = p->pos - 4;
+    p->jimg[p->jidx].app = ((b1 >> 4) == 0xE) * 2;
+  }
+  /* the end-of-image test (:6111-6114) needs images[idx].data, which only a valid SOS sets: never true before the refusal below */
+  p->jlast_pos = p->pos;
+  if (!p->jimg[p->jidx].jpeg) return 0;
+  if (!p->jimg[p->jidx].app && b4 == 0xFF && ((b3 > 0xC1 && b3 <= 0xCF && b3 != 0xC4) || (b3 >= 0xDC && b3 <= 0xFE))) {   /* :6119-6123 */
+    p->jimg[p->jidx].app = (int)(b2 * 256 + b1 + 2);
+    if (p->jidx > 0) JASSERT(p->pos + p->jimg[p->jidx].app < p->jimg[p->jidx].offset + p->jimg[p->jidx - 1].app);
+  }
+  if (RB(5) == 0xFF && b4 == 0xDA) {   /* SOS with a consistent length: Huffman-coded data follows, the model switches on (:6126-6130) */
+    const int len = (int)(b3 * 256 + b2);
+    if (len == 6 + 2 * (int)b1 && b1 && b1 <= 4) return P8F_ERR_JPEG;
+  }
+  if (b4 == 0xFF && b3 == 0xDB) { p->jdqt_end = p->pos + (int)(b2 * 256 + b1) - 1; p->jdqt_state = 0; }   /* DQT :6136-6151 */
+  else if (p->jdqt_state >= 0) {
+    if (p->pos >= p->jdqt_end) p->jdqt_state = -1;
+    else {
+      if (p->jdqt_state % 65 == 0) p->jqnum = (int)b1;
+      else { JASSERT(b1 > 0); JASSERT(p->jqnum >= 0 && p->jqnum < 4); }
+      p->jdqt_state++;
+    }
+  }
+  return 0;
 }
-static int img_detect(P8Predictor* p) {  /* imgModel :5393-5483 with w == 0, eoi == 0 */
+
+/* imgModel :5386-5483 with w == 0, eoi == 0. *record = Stats.Record, which the palette walk of an 8-bit header rewrites (:5363) and
+ * recordModel reads (:4225). */
+static void img_check_gray(P8Predictor* p, uint32_t x, int a, uint32_t* record) {   /* CheckIfGrayscale(x, a) :5355-5377 with w == 0 */
+  if (!p->img_gray || (x % (uint32_t)(3 + a)) != 0) return;
+  for (int i = 0; i < 3 + a && p->img_gray; i++) {
+    const uint8_t B = (uint8_t)RB(4 - i);
+    if (p->img_gray >> 9) {
+      p->img_gray = 0x100 | B;
+      p->img_pltorder = 1 - 2 * (B > 0);
+      *record = (*record & 0xFFFF) | ((uint32_t)(3 + a) << 16);
+      continue;
+    }
+    if (!i) {
+      p->img_gray = p->img_gray & ((((int)B - (p->img_gray & 0xFF)) == p->img_pltorder) << 8);
+      p->img_gray |= p->img_gray ? B : 0;
+    } else if (i == 3) p->img_gray &= ((!B || B == 0xFF) * 0x1FF);
+    else p->img_gray &= ((B == (p->img_gray & 0xFF)) * 0x1FF);
+  }
+}
+static int img_detect(P8Predictor* p, uint32_t* record) {
   const int pos = p->pos;
   if (pos >= 40 && !p->bmp.Header &&
       ((RB(54) == 'B' && RB(53) == 'M' && ((p->bmp.Offset = i4(p, 44)) & 0xFFFFFBF7) == 0x36 && i4(p, 40) == 0x28) ||
@@ -164,11 +229,32 @@ static int img_detect(P8Predictor* p) {  /* imgModel :5393-5483 with w == 0, eoi
     p->bmp.Bpp = (uint32_t)i2(p, 26);
     p->bmp.Size = i4(p, 20);
     p->bmp.Palette = i4(p, 4);
-    const uint32_t bpp = p->bmp.Bpp;
+    const uint32_t bpp = p->bmp.Bpp, W = p->bmp.Width;
     p->bmp.Header = (i4(p, 24) == 0) && (i2(p, 28) == 1) && (bpp == 1 || bpp == 4 || bpp == 8 || bpp == 24 || bpp == 32) && p->bmp.Width < 30000 &&
                     p->bmp.Height < 10000 && (!p->bmp.Palette || (1u << (bpp & 31)) >= p->bmp.Palette);
-    if (p->bmp.Header) return P8F_ERR_BMP;
-  } else p->bmp.Offset -= (p->bmp.Offset > 0);
+    if (p->bmp.Header) {   /* a plausible header: skip the palette (Offset bytes), then look at the pixel area (:5405-5425) */
+      p->bmp.Offset = p->bmp.HdrLess ? ((bpp < 24) ? (p->bmp.Palette ? p->bmp.Palette * 4 : (uint32_t)(4 << bpp)) : 0) : p->bmp.Offset - 54;
+      p->img_gray = (bpp == 8) ? 0x300 : 0;
+      if (p->bmp.HdrLess && (W * 2 == p->bmp.Height) && bpp > 1 &&
+          ((p->bmp.Size > 0 && p->bmp.Size == ((W * p->bmp.Height * (bpp + 1)) >> 4)) ||
+           ((!p->bmp.Size || p->bmp.Size < ((W * p->bmp.Height * bpp) >> 3)) &&
+            (W == 8 || W == 10 || W == 14 || W == 16 || W == 20 || W == 22 || W == 24 || W == 32 || W == 40 || W == 48 || W == 60 || W == 64 || W == 72 ||
+             W == 80 || W == 96 || W == 128 || W == 256))))
+        p->bmp.Height = p->bmp.BitMask = W;   /* icon / cursor: colour image and 1-bit AND mask of equal size */
+    }
+  } else {
+    p->bmp.Offset -= (p->bmp.Offset > 0);
+    img_check_gray(p, p->bmp.Offset, 1, record);
+  }
+  if (!p->bmp.Offset && (p->bmp.Header > 0 || p->bmp.BitMask > 0)) {   /* :5427-5438, pos >= eoi always */
+    if (!p->bmp.Header && p->bmp.BitMask) { p->bmp.Header = p->bmp.Bpp = 1; p->bmp.Width = p->bmp.BitMask; p->bmp.BitMask = 0; }
+    const int bpp = (int)p->bmp.Bpp;
+    const int w = (bpp > 4) ? (int)((p->bmp.Width * (uint32_t)(bpp >> 3) + 3) & (uint32_t)(-4)) : (bpp == 1) ? (int)((((p->bmp.Width - 1) >> 5) + 1) * 4)
+                                                                                                           : (int)(((p->bmp.Width * 4 + 31) >> 5) * 4);
+    const int eoi = (int)((uint32_t)w * p->bmp.Height);
+    if (eoi > 64) return P8F_ERR_BMP;   /* the image model switches on for eoi bytes */
+    p->bmp.Header = 0;                  /* too small to be an image: dropped, as the reference drops it */
+  }
   if (pos >= 8 && !p->tga.Header) {
     if ((m4(p, 8) & 0xFFFFFF) == 0x010100 && (m4(p, 4) & 0xFFFFFFC7) == 0x00000100 && (RB(1) == 16 || RB(1) == 24 || RB(1) == 32)) {
       p->tga.Header = (uint32_t)pos; p->tga.IdLength = RB(8); p->tga.MapSize = RB(1) / 8; p->tga.Bpp = 8; p->tga.ImgType = 1;
@@ -274,7 +360,7 @@ static int context_model2(P8Predictor* p, int y, int32_t* sel) {
   if (bpos == 0) {
     int e;
     if (p->filetype != FT_EXE && (e = jpeg_detect(p)) != 0) return e;
-    if (p->size > 0 && (e = img_detect(p)) != 0) return e;
+    if (p->size > 0 && (e = img_detect(p, &p->stat_record)) != 0) return e;
     if ((e = wav_detect(p)) != 0) return e;
   }
 

@@ -131,9 +131,13 @@ static row_t* get_row(mixer_t* m, uint64_t context) {
   return *slot;
 }
 
+/* Study hook (scripts/spec_chain_study.py): called with the inputs and the selected weight row of every Mix. NULL in the tests. */
+void (*orc_mix_probe)(const void* mixer, const float* in, const float* w, int n_in) = 0;
+
 /* Mixer::Mix, mixer.cpp:38-54 */
 static float mix(mixer_t* m, const float* in, const float* extra_vec, uint64_t ctx) {
   row_t* r = get_row(m, ctx);
+  if (orc_mix_probe) orc_mix_probe(m, in, r->w, m->n_in);
   float p = 0;
   for (int i = 0; i < m->n_in; ++i) p += in[i] * r->w[i];
   m->p = p;

@@ -28,6 +28,33 @@ def row_hash(rows):
     return (h >> np.uint64(32)).astype(np.uint32)
 
 
+def header_lookalikes():
+    """Binary data sprinkled with byte patterns paq8's image / JPEG detectors look at but do NOT accept -- the reference goes on
+    as for ordinary data, after private state changes that must be followed exactly (imgModel :5393-5438, jpegModel :6058-6151):
+    header-less DIB headers whose pixel area is <= 64 bytes (8 bpp with a 1 KB grayscale palette walked entry by entry, which rewrites
+    Stats.Record for recordModel; 24 bpp; an icon-shaped 4 bpp one that comes back as a 1-bit mask), a 'BM' file header, SOI + APP0
+    with a DQT holding a zero (parser reset), SOI + DQT + SOF without a scan header, an APP1 with an embedded SOI."""
+    r = np.random.default_rng(31)
+
+    def noise(n):
+        return bytes(r.integers(0, 6, n, dtype=np.uint8) * 17)
+
+    def dib(w, h, bpp, size=0, clr=0):
+        return (40).to_bytes(4, "little") + w.to_bytes(4, "little") + h.to_bytes(4, "little") + (1).to_bytes(2, "little") + \
+            bpp.to_bytes(2, "little") + bytes(4) + size.to_bytes(4, "little") + bytes(8) + bytes(4) + clr.to_bytes(4, "little")
+    gray_palette = b"".join(bytes([i, i, i, 0]) for i in range(256))
+    dqt_bad = b"\xff\xdb\x00\x43\x00" + bytes([3] * 20) + b"\x00" + bytes([5] * 43)
+    dqt_ok = b"\xff\xdb\x00\x43\x00" + bytes(r.integers(1, 40, 64, dtype=np.uint8))
+    sof = b"\xff\xc0\x00\x11\x08\x00\x10\x00\x10\x03\x01\x22\x00\x02\x11\x01\x03\x11\x01"
+    parts = [noise(300), dib(4, 4, 8), gray_palette, noise(200), dib(3, 2, 24), noise(150),
+             b"BM" + (1000).to_bytes(4, "little") + bytes(4) + (0x36).to_bytes(4, "little") + dib(2, 2, 24), noise(120),
+             dib(8, 16, 4), bytes(r.integers(0, 256, 64, dtype=np.uint8)), noise(200),
+             b"\xff\xd8\xff\xe0\x00\x10JFIF\x00\x01\x01\x00\x00\x01\x00\x01\x00\x00" + dqt_bad + noise(100),
+             b"\xff\xd8" + dqt_ok + sof + noise(300),
+             b"\xff\xd8\xff\xe1\x00\x40Exif\x00\x00" + b"\xff\xd8" + dqt_ok[:30] + noise(200), noise(500)]
+    return b"".join(parts)
+
+
 def streams():
     from cmix_amd import synth
     from make_golden import default_block, text_block
@@ -42,6 +69,9 @@ def streams():
         # what the reference's preprocessor made of a mixed file (tests/golden/make_dropin_mixed.py): a TEXT block, then an EXE
         # block (x86-like calls with rewritten addresses, records, text) -- block headers, type switches, exeModel on real targets
         "mixed_24k": bytes(np.load(os.path.join(HERE, "dropin_mixed.npz"))["stream"]),
+        # the head of the bench shard (round 3: rich alphabet, V = 205): multi-byte UTF-8 from 46 script blocks, all of ASCII
+        "rich_16k": text_block(synth.enwik_like(16384 - 6, 1000, rich=True)),
+        "hdrs_4k": default_block(header_lookalikes()),
     }
 
 

@@ -219,7 +219,7 @@ def _reference_fixture(name):
     return data, pr, ex, dic, g["hash"], mk.row_hash
 
 
-@pytest.mark.parametrize("name", ["fxcm_cols_wiki_16k", "fxcm_cols_dict_16k", "fxcm_cols_mixed_24k"])
+@pytest.mark.parametrize("name", ["fxcm_cols_wiki_16k", "fxcm_cols_dict_16k", "fxcm_cols_mixed_24k", "fxcm_cols_rich_16k"])
 def test_reference_hashes_16k(name):
     """The product's text parser + the kernel body (host run) and the oracle against the reference itself on 16 KB of
     wiki markup and of dictionary-mode (WRT-coded) text: 131072 bits x 431 values each, compared through row hashes."""

@@ -117,7 +117,7 @@ def load_hashes(name):
         return z["stream"].copy(), z["hash"].copy()
 
 
-@pytest.mark.parametrize("name,nbytes", [("text_32k", 6144), ("wiki_12k", 4096), ("records_8k", 4096), ("mixed_24k", 6400)])
+@pytest.mark.parametrize("name,nbytes", [("text_32k", 6144), ("wiki_12k", 4096), ("records_8k", 4096), ("mixed_24k", 6400), ("rich_16k", 16384), ("hdrs_4k", 3560)])
 def test_stage_vs_reference_hashes(name, nbytes):
     """Prefixes of the reference-derived fixtures of tests/golden/make_paq8_hashes.py (the device test runs them whole)."""
     from make_paq8_hashes import row_hash

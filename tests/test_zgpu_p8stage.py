@@ -41,7 +41,7 @@ def test_stage_reproduces_golden_columns(name):
     assert bad.size == 0, (name, "first mismatch (step, column):", bad[0], got[tuple(bad[0])] * 4095, want[tuple(bad[0])] * 4095)
 
 
-@pytest.mark.parametrize("name", ["text_32k", "wiki_12k", "records_8k", "mixed_24k"])
+@pytest.mark.parametrize("name", ["text_32k", "wiki_12k", "records_8k", "mixed_24k", "rich_16k", "hdrs_4k"])
 def test_stage_vs_reference_hashes(name):
     from make_paq8_hashes import row_hash
     from test_p8stage_host import load_hashes

@@ -130,7 +130,7 @@ def test_pipeline_with_device_fxcm_dictionary_pretraining():
     assert _lookahead("-c", [("dict", v["dict_payload"]), ("in", v["dict_c_payload"])]) == v["dict_c_file"]
 
 
-@pytest.mark.parametrize("name", ["fxcm_cols_wiki_16k", "fxcm_cols_dict_16k", "fxcm_cols_mixed_24k"])
+@pytest.mark.parametrize("name", ["fxcm_cols_wiki_16k", "fxcm_cols_dict_16k", "fxcm_cols_mixed_24k", "fxcm_cols_rich_16k"])
 def test_reference_hashes_16k(name):
     """The device stage against the reference itself (not against its twin, the oracle): 16 KB of wiki markup and of
     dictionary-mode text, per-bit hashes of all 431 values recorded from the unmodified fxcmv1::Predictor
