@@ -22,6 +22,8 @@ extern "C" __global__ void cmx_mixnet_kernel(MixState*, const float*, const uint
                                              const uint8_t*, const float*, int, float*, float*, int);
 extern "C" __global__ void cmx_mixnet_chunk_kernel(MixState*, const float*, const uint32_t*,
                                                    const uint8_t*, const float*, int, float*, float*, int);
+extern "C" __global__ void cmx_mixnet_spec_kernel(MixState*, SpecXfer*, const float*, const uint32_t*, const uint8_t*, const float*, int, float*,
+                                                  float*, int);
 extern "C" __global__ void cmx_sse_init_kernel(MixState*);
 extern "C" __global__ void cmx_probe_libm_kernel(int, const float*, float*, size_t);
 
@@ -129,6 +131,8 @@ struct cmx_mixnet {
   int dbg = 0;          // CMX_MIXNET_DBG: timing experiments (results invalid when nonzero)
   int xcd = -1;         // CMX_MIXNET_XCD=k: place the persistent kernel on XCD k (speed only; -1 = wherever block 0 lands)
   bool use_v1 = false;  // CMX_MIXNET_V1=1: run chunks through the bit-synchronous kernel
+  bool use_spec = true; // cmx_mixnet_spec_kernel (26 helper workgroups, speculative segment-parallel chains); CMX_MIXNET_SPEC=0: the one-workgroup kernel
+  SpecXfer* d_xfer = nullptr;
 };
 
 extern "C" {
@@ -271,6 +275,13 @@ cmx_mixnet_t* cmx_mixnet_create(int device) {
     return nullptr;
   }
   { const char* v = getenv("CMX_MIXNET_V1"); h->use_v1 = v && v[0] == '1'; }
+  { const char* v = getenv("CMX_MIXNET_SPEC"); h->use_spec = !(v && v[0] == '0'); }
+  h->d_xfer = (SpecXfer*)dalloc(sizeof(SpecXfer), true);   // incl. the zero padding of the input ring
+  if (!h->d_xfer || hipFuncSetAttribute((const void*)cmx_mixnet_spec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CMX_SPEC_LDS_BYTES) != hipSuccess) {
+    set_err("cmx_mixnet_create: hand-off area / kernel attribute (spec kernel) failed");
+    cmx_mixnet_destroy(h);
+    return nullptr;
+  }
   { const char* v = getenv("CMX_MIXNET_DBG"); h->dbg = v ? atoi(v) : 0; }
   { const char* v = getenv("CMX_MIXNET_XCD"); h->xcd = v ? atoi(v) : -1; }
   hipEventCreate(&h->ev0);
@@ -303,6 +314,19 @@ static int ensure_decay(cmx_mixnet_t* h, size_t nbits) {
   h->allocs.push_back(p);
   h->d_decay = (float*)p;
   h->decay_cap = cap;
+  return 0;
+}
+
+// Speculation statistics of cmx_mixnet_spec_kernel since the handle was created: out[0] speculative segments run, [1] resolved from a
+// candidate lane, [2..4] re-runs (misses) of segment 1, 2, 3. Synchronises the device.
+int cmx_mixnet_spec_stats(cmx_mixnet_t* h, uint64_t out[5]) {
+  const int fail_value = 1;
+  if (!h || !out) { set_err("cmx_mixnet_spec_stats: bad argument"); return 1; }
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipDeviceSynchronize());
+  unsigned long long st[8];
+  HIP_OK(hipMemcpy(st, (char*)h->d_xfer + offsetof(SpecXfer, stat), sizeof st, hipMemcpyDeviceToHost));
+  for (int i = 0; i < 5; ++i) out[i] = st[i];
   return 0;
 }
 
@@ -349,7 +373,13 @@ int cmx_mixnet_run(cmx_mixnet_t* h, const float* d_probs, const uint32_t* d_sel,
     hipLaunchKernelGGL(cmx_mixnet_kernel, dim3(1), dim3(CMX_MIXNET_THREADS), kLdsBytes, st, h->d_state,
                        d_probs, d_sel, d_bits, dd, (int)nbits, d_p_out, d_mix_out,
                        3 | (h->profile ? 4 : 0));
-  else
+  else if (h->use_spec) {
+    // epochs and value|tag words restart at 0 with every launch; 1 main + 26 helper workgroups, co-resident (27 of 256 CUs)
+    HIP_OK(hipMemsetAsync(h->d_xfer, 0, CMX_SPEC_HEADER_BYTES, st));
+    hipLaunchKernelGGL(cmx_mixnet_spec_kernel, dim3(1 + CMX_SPEC_HELPERS), dim3(CMX_SPEC_THREADS), CMX_SPEC_LDS_BYTES, st,
+                       h->d_state, h->d_xfer, d_probs, d_sel, d_bits, dd, (int)nbits, d_p_out, d_mix_out,
+                       3 | (h->profile ? 4 : 0) | ((h->dbg & 15) << 4));
+  } else
     // XCD placement (observed: block b runs on XCD b % 8): 8 blocks, all but block `xcd` leave at once
     hipLaunchKernelGGL(cmx_mixnet_chunk_kernel, dim3(h->xcd >= 0 ? 8 : 1), dim3(CMX_CHUNK_THREADS), CMX_CHUNK_LDS_BYTES, st,
                        h->d_state, d_probs, d_sel, d_bits, dd, (int)nbits, d_p_out, d_mix_out,

@@ -401,8 +401,8 @@ float cmx_predict(cmx_t* h) {
   const char* where = "cmx_predict";
   const float fail = -1.0f;
   if (!h) { cmx_set_err("cmx_predict: null handle"); return fail; }
-  if (h->predicted) { cmx_set_err("cmx_predict: called twice without perceive()"); return fail; }
   if (refused(h, where)) return fail;
+  if (h->predicted) { cmx_set_err("cmx_predict: called twice without perceive()"); return fail; }
   if (h->mode == 2) {
     Txn txn(h);
     const float p = la_predict(h);
@@ -446,8 +446,8 @@ int cmx_perceive(cmx_t* h, int bit) {
   const char* where = "cmx_perceive";
   const int fail = 1;
   if (!h) { cmx_set_err("cmx_perceive: null handle"); return 1; }
-  if (!h->predicted) { cmx_set_err("cmx_perceive: no pending predict()"); return 1; }
   if (refused(h, where)) return 1;
+  if (!h->predicted) { cmx_set_err("cmx_perceive: no pending predict()"); return 1; }
   if (h->mode == 2) {
     Txn txn(h);
     if (la_perceive(h, bit)) return 1;

@@ -194,8 +194,10 @@ __device__ __forceinline__ float chain_seg(const float* rowp, int n, float p) {
 }
 
 // ------------------------------------------------------------------ scout (wave 2)
+// X != nullptr (cmx_mixnet_spec_kernel): the stretched inputs and the layer-0 rows of the bit are also published to the helper
+// workgroups through the global ring (agent-scope stores, then the epoch).
 __device__ void scout_role(MixState* S, const Lds& L, const float* probs, const uint32_t* sel,
-                           const uint8_t* bits, int nbits, int lane, bool prof_on) {
+                           const uint8_t* bits, int nbits, int lane, bool prof_on, SpecXfer* X = nullptr) {
   uint64_t tprev = __builtin_readcyclecounter();
 #define SPROF(k)                                                       \
   do {                                                                 \
@@ -259,7 +261,23 @@ __device__ void scout_role(MixState* S, const Lds& L, const float* probs, const 
     if (lane < CMX_MIXERS) {
       uint32_t r = select_row(S, lane, key);
       rec->rowidx[lane] = r;
-      if (lane < CMX_MIX0) rec->changed[lane] = (t == 0) || (r != prev->rowidx[lane]);
+      const uint32_t chg = (t == 0) || (r != prev->rowidx[lane]);
+      if (lane < CMX_MIX0) rec->changed[lane] = chg;
+      if (X && lane < CMX_MIX0) {
+        __hip_atomic_store(&X->rowidx[t % CMX_SPEC_RING][lane], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&X->changed[t % CMX_SPEC_RING][lane], chg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (X) {
+      float* gx = X->xs[t % CMX_SPEC_RING];
+#pragma unroll
+      for (int r = 0; r < 33; ++r) {
+        int i = r * 64 + lane;
+        if (i < CMX_IN0) __hip_atomic_store(gx + i, pv[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring slot is complete before the epoch moves
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) __hip_atomic_store(&X->scout_epoch, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
@@ -922,6 +940,301 @@ __device__ void tail_role(MixState* S, const Lds& L, const float* decay1, int nb
   }
 }
 
+
+// ==================================================================================================================================
+// cmx_mixnet_spec_kernel: the layer-0 dot products on 26 helper workgroups, each cutting its 2078-term ordered chain into four
+// segments that run AT THE SAME TIME -- segment 0 exactly, segments 1..3 speculatively from 64 candidate start values.
+//
+// s -> RN(s + x) is the only operation of the chain, so a segment is a function of its start value alone. The start of segment k
+// is the f32 running sum after the preceding terms; an estimate of it (the f64 sum of those products, rounded) is available as soon
+// as the products are, and the true value lies within a few dozen ulps of it (profiles/r03_spec_chain_study.txt: within +-32 ulp
+// for 96-97 % of the segments on the bench text). Wave k of a helper therefore runs segment k from the 64 consecutive floats around
+// the estimate, one per lane; when wave k-1 delivers the true start, the lane whose candidate has the same bit pattern holds the
+// exact result (same operations on the same operands), otherwise the wave re-runs the segment from the true start (the serial
+// path). Either way the value handed on is exactly the reference's (mixer.cpp:40-43), and the chain's latency drops from 2078
+// dependent adds to ~520 plus the re-runs.
+//
+//   block 0 (main)        wave 0 gather: waits for the 26 sums, intra-layer extra-input chain, Mixer::Perceive scalars, publishes u
+//                         wave 1 tail, wave 2 scout: as in cmx_mixnet_chunk_kernel (the scout also feeds the global ring)
+//   block 1 + m (helper)  owns the selected row of layer-0 mixer m in registers (wave w: elements 512 w .. 512 w + 511 / 541):
+//                         u of bit t-1 arrives -> w -= u x (mixer.cpp:66-71), row swap if the selector changed (the incoming row is
+//                         already in registers: it was requested a bit ahead) -> products -> LDS -> four segment chains -> resolve
+//                         -> the sum of bit t goes back to the gather wave.
+// Two global hand-offs per bit (sum, u), 8-byte value|tag words, agent scope.
+struct HelperLds {
+  float prod[4][SEG];          // rounded products of the four segments (each read back as broadcast float4s by its own wave)
+  double segsum[4];            // f64 sum of a segment's products
+  float res[4];                // exact running sum after segment w
+  int sum_epoch[4];            // bit + 1 for which segsum[w] is valid
+  int res_epoch[4];            // bit + 1 for which res[w] is valid
+  int abort;
+};
+
+__device__ __forceinline__ unsigned long long ld_u64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_u64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned ld_u32(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_f32(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+constexpr unsigned SPEC_SPIN = 1u << 24;
+
+// float <-> integer with the same order (consecutive floats = consecutive integers, across zero too)
+__device__ __forceinline__ int f2ord(float f) { int b = __float_as_int(f); return b ^ ((b >> 31) & 0x7fffffff); }
+__device__ __forceinline__ float ord2f(int o) { return __int_as_float(o ^ ((o >> 31) & 0x7fffffff)); }
+
+__device__ void helper_role(MixState* S, SpecXfer* X, HelperLds* H, int nbits, int m, int w, int lane) {
+  const gptr<float> rows0 = as_global(S->rows0);
+  const int base = 512 * w;                 // first element of this wave's segment
+  const int nseg = w == 3 ? CMX_IN0 - 1536 : 512;
+  const bool tailk = w == 3 && lane < 30;   // k == 8: elements 2048 + lane (lane < 30)
+  const float cdec = 1.0f - 3.0e-6f;
+  float W[9], Wn[9], xc[9], xp[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { W[k] = 0.0f; Wn[k] = 0.0f; xc[k] = 0.0f; xp[k] = 0.0f; }
+  unsigned long long n_spec = 0, n_hit = 0, n_miss = 0;
+  uint32_t cur_base = 0;
+  auto failed = [&]() { return lds_poll(&H->abort) != 0; };
+  auto give_up = [&]() { lds_publish_store(&H->abort, 1); __hip_atomic_store(&X->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  // fetch the inputs of bit t (this wave's slice) and, if its selector changes, the incoming row
+  auto fetch = [&](int t) -> bool {
+    unsigned spins = 0;
+    while (ld_u32(&X->scout_epoch) < (unsigned)(t + 1)) {
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 1023u) == 0 && (spins > SPEC_SPIN || failed() || ld_u32(&X->fail))) { give_up(); return false; }
+    }
+    const int slot = t % CMX_SPEC_RING;
+    const float* gx = X->xs[slot] + base;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) xc[k] = ld_f32(gx + 64 * k + lane);
+    xc[8] = tailk ? ld_f32(gx + 512 + lane) : 0.0f;
+    if (ld_u32(&X->changed[slot][m])) {
+      const uint32_t nb = ((uint32_t)m * CMX_ROWS_PER_MIXER + ld_u32(&X->rowidx[slot][m])) * CMX_ROW0_STRIDE + (uint32_t)base;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) Wn[k] = rows0[nb + 64 * k + lane];
+      Wn[8] = tailk ? rows0[nb + 512 + lane] : 0.0f;
+    }
+    return true;
+  };
+  if (nbits > 0 && !fetch(0)) return;
+  for (int t = 0; t <= nbits; ++t) {
+    const bool live = t < nbits;             // t == nbits: apply the last update and store the row
+    // ---- u of bit t-1 (the serial hand-off of the bit) ----
+    if (t > 0) {
+      unsigned long long v;
+      unsigned spins = 0;
+      while ((unsigned)((v = ld_u64(&X->u[m])) >> 33) != (unsigned)t) {
+        if ((++spins & 1023u) == 0 && (spins > SPEC_SPIN || failed() || ld_u32(&X->fail))) { give_up(); return; }
+      }
+      const float u = __int_as_float((int)(unsigned)v);
+      const bool df = ((v >> 32) & 1ull) != 0;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {          // mixer.cpp:66-71; xp = the inputs of bit t-1
+        W[k] = fsub(W[k], fmul(u, xp[k]));
+        if (df) W[k] = fmul(W[k], cdec);
+      }
+    }
+    const int slot = t % CMX_SPEC_RING;
+    const bool chg = !live || ld_u32(&X->changed[slot][m]) != 0;
+    if (chg) {                               // outgoing row to HBM (16 B per 4 lanes: 64 consecutive floats per k), incoming row is in Wn
+      if (t > 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) rows0[cur_base + 64 * k + lane] = W[k];
+        if (tailk) rows0[cur_base + 512 + lane] = W[8];
+      }
+      if (live) {
+        cur_base = ((uint32_t)m * CMX_ROWS_PER_MIXER + ld_u32(&X->rowidx[slot][m])) * CMX_ROW0_STRIDE + (uint32_t)base;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) W[k] = Wn[k];
+      }
+    }
+    if (!live) break;
+    // ---- products of bit t (mixer.cpp:41: in[i] * w[i], rounded) -> LDS, f64 sum of the segment ----
+    float* pr = H->prod[w];
+    double ds = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const float p = fmul(xc[k], W[k]); pr[64 * k + lane] = p; ds += (double)p; }
+    if (w == 3) { const float p = tailk ? fmul(xc[8], W[8]) : 0.0f; if (lane < 36) pr[512 + lane] = p; ds += (double)p; }   // 542..547: zero pad read by chain_seg
+#pragma unroll
+    for (int k = 0; k < 9; ++k) xp[k] = xc[k];
+    if (w < 3) {                             // the later waves centre their candidates on the sum of what precedes them
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) ds += __shfl_xor(ds, o, 64);
+      if (lane == 0) H->segsum[w] = ds;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) lds_publish_store(&H->sum_epoch[w], t + 1);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // ---- the segment's chain ----
+    float start = 0.0f;
+    if (w > 0) {
+      double est = 0.0;
+      for (int q = 0; q < w; ++q) {
+        unsigned spins = 0;
+        while (lds_poll(&H->sum_epoch[q]) < t + 1)
+          if ((++spins & 1023u) == 0 && (spins > SPEC_SPIN || failed())) { give_up(); return; }
+        est += H->segsum[q];
+      }
+      start = ord2f(f2ord((float)est) + lane - 32);
+    }
+    float r = chain_seg(pr, nseg, start);
+    // ---- resolve against the true start ----
+    if (w > 0) {
+      unsigned spins = 0;
+      while (lds_poll(&H->res_epoch[w - 1]) < t + 1)
+        if ((++spins & 1023u) == 0 && (spins > SPEC_SPIN || failed())) { give_up(); return; }
+      const float s = H->res[w - 1];
+      const unsigned long long hit = __ballot(__float_as_int(start) == __float_as_int(s));
+      ++n_spec;
+      if (hit) {
+        r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), (int)__builtin_amdgcn_readfirstlane(__ffsll((long long)hit) - 1)));
+        ++n_hit;
+      } else {
+        r = chain_seg(pr, nseg, s);          // outside the candidates: the serial path
+        ++n_miss;
+      }
+    }
+    if (w < 3) {
+      if (lane == 0) H->res[w] = r;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) lds_publish_store(&H->res_epoch[w], t + 1);
+    } else if (lane == 0) {
+      st_u64(&X->sum[m], ((unsigned long long)(unsigned)(t + 1) << 32) | (unsigned)__float_as_int(r));
+    }
+    // ---- while the gather wave works: the inputs / incoming row of bit t+1 ----
+    if (t + 1 < nbits && !fetch(t + 1)) return;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0 && w > 0) {
+    atomicAdd(&X->stat[0], n_spec); atomicAdd(&X->stat[1], n_hit); atomicAdd(&X->stat[1 + w], n_miss);
+  }
+}
+
+// ------------------------------------------------------------------ gather (main workgroup, wave 0)
+// chain_role with the 26 ordered sums arriving from the helpers instead of being added up here.
+__device__ void gather_role(MixState* S, const Lds& L, SpecXfer* X, const float* decay1, int nbits,
+                            float* mix_out, bool prof_on, int lane) {
+  const int m = lane;
+  const bool is0 = m < CMX_MIX0;
+  const float smin = S->stretch_min, smax = S->stretch_max;
+  const float cdec = 1.0f - 3.0e-6f;
+  const float lr = is0 ? S->lr[m] : 0.0f;
+  uint64_t tprev = __builtin_readcyclecounter();
+  uint64_t pacc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) pacc[i] = 0;
+#define GPROF(k)                                                       \
+  do {                                                                 \
+    if (prof_on) {                                                     \
+      uint64_t now_ = __builtin_readcyclecounter();                    \
+      pacc[k] += now_ - tprev;                                         \
+      tprev = now_;                                                    \
+    }                                                                  \
+  } while (0)
+  __builtin_amdgcn_s_setprio(3);
+  const int mm = is0 ? m : 0;
+  float ew[28];
+#pragma unroll
+  for (int i = 0; i < 28; ++i) ew[i] = 0.0f;
+  uint64_t rsteps = 0;
+  uint64_t mx = S->max_steps[mm];
+  gptr<float> row0 = as_global(S->rows0);
+  gptr<uint64_t> rsp = as_global(S->row_steps);
+  auto store_row_state = [&]() {
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+      if (4 * i < m) gstore4_async(row0 + CMX_ROW0_EXTRA + 4 * i, make_float4(ew[4 * i], ew[4 * i + 1], ew[4 * i + 2], ew[4 * i + 3]));
+    asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 0" :: "v"(rsp), "v"(rsteps) : "memory");
+  };
+  for (int t = 0; t < nbits; ++t) {
+    if (!wait_ge(L.ctl, &L.ctl->scout_epoch, t + 1, false)) return;
+    st_rel(&L.ctl->consumed, 4 * t + 1);      // the scout may go on to bit t + 1 (it waits for consumed >= 4 t)
+    GPROF(0);
+    const BitRec* rec = L.rec + (t % 3);
+    const int bit = rec->bit;
+    if (is0 && rec->changed[mm]) {
+      if (t > 0) store_row_state();
+      row0 = as_global(S->rows0) + ((size_t)mm * CMX_ROWS_PER_MIXER + rec->rowidx[mm]) * CMX_ROW0_STRIDE;
+      rsp = as_global(S->row_steps) + (size_t)mm * CMX_ROWS_PER_MIXER + rec->rowidx[mm];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        float4 v = gload4(row0 + CMX_ROW0_EXTRA + 4 * i);
+        ew[4 * i] = v.x; ew[4 * i + 1] = v.y; ew[4 * i + 2] = v.z; ew[4 * i + 3] = v.w;
+      }
+      rsteps = *rsp;
+#pragma unroll
+      for (int i = 0; i < 28; ++i)
+        if (i >= m) ew[i] = 0.0f;
+    }
+    const double d1 = (double)as_global(decay1)[t];
+    const float decay = (float)(d1 * (1.5 - ((1.0 * (double)rsteps) / (double)mx)));   // mixer.cpp:58-60
+    const float dlr = fmul(decay, lr);
+    GPROF(1);
+    // ---- the 26 ordered sums of bit t ----
+    float pm = 0.0f;
+    {
+      bool have = !is0;
+      unsigned spins = 0;
+      while (true) {
+        if (!have) {
+          const unsigned long long v = ld_u64(&X->sum[mm]);
+          if ((unsigned)(v >> 32) == (unsigned)(t + 1)) { pm = __int_as_float((int)(unsigned)v); have = true; }
+        }
+        if (__ballot(!have) == 0) break;
+        if ((++spins & 1023u) == 0 && (spins > SPEC_SPIN || lds_poll(&L.ctl->abort) || ld_u32(&X->fail))) {
+          lds_publish_store(&L.ctl->abort, 1);
+          __hip_atomic_store(&X->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          return;
+        }
+      }
+    }
+    GPROF(2);
+    float e = 0.0f;
+#pragma unroll
+    for (int j = 0; j < CMX_MIX0; ++j) {      // intra-layer chain (predictor.cpp:395-400), see chain_role
+      const float mine = clamp_med3(fadd(pm, e), smin, smax);
+      const float oj = bcast_lane(mine, j);
+      e = fadd(e, fmul(oj, ew[j]));
+    }
+    const float p_ = fadd(pm, e);
+    const float myout = clamp_out(p_, smin, smax);
+    GPROF(3);
+    float uu = fmul(dlr, fsub(cmx_logistic_t(p_, L.exptab), (float)bit));   // Mixer::Perceive scalar (mixer.cpp:56-64)
+    ++rsteps;
+    if (rsteps > mx) mx = rsteps;
+    const bool dfl = (rsteps & 1023) == 0;
+    if (is0) st_u64(&X->u[m], ((unsigned long long)(2u * (unsigned)(t + 1) + (dfl ? 1u : 0u)) << 32) | (unsigned)__float_as_int(uu));
+    GPROF(4);
+    if (t >= 2 && !wait_ge(L.ctl, &L.ctl->tail_done, t - 1, false)) return;
+    GPROF(12);
+    TailRec* tr = L.trec + (t & 1);
+    if (is0) tr->out0[m] = myout;
+    if (m >= CMX_MIX0 && m < CMX_MIXERS) tr->rowidx[m - CMX_MIX0] = rec->rowidx[m];
+    if (m < 3) tr->aux3[m] = rec->aux3[m];
+    if (m == 0) { tr->lstm_p = rec->lstm_p; tr->bit = bit; }
+    st_rel(&L.ctl->tail_in, t + 1);
+    if (is0 && mix_out) as_global(mix_out)[(size_t)t * CMX_MIXERS + m] = p_;
+#pragma unroll
+    for (int j = 0; j < CMX_MIX0; ++j) {      // extra weights: ew[j] -= u * out_j (mixer.cpp:67,70)
+      float oj = bcast_lane(myout, j);
+      if (j < m) {
+        float v = fsub(ew[j], fmul(uu, oj));
+        if (dfl) v = fmul(v, cdec);
+        ew[j] = v;
+      }
+    }
+    GPROF(5);
+  }
+  if (is0 && nbits > 0) {
+    store_row_state();
+    S->max_steps[m] = mx;
+  }
+  if (prof_on && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (i < 6 || i >= 12) S->prof[i] += pacc[i];
+  }
+#undef GPROF
+}
+
 }  // namespace
 
 extern "C" __global__ __launch_bounds__(NTHREADS) void cmx_mixnet_chunk_kernel(
@@ -964,4 +1277,45 @@ extern "C" __global__ __launch_bounds__(NTHREADS) void cmx_mixnet_chunk_kernel(
   else producer_role(S, L, nbits, wave - 3, lane, (mode & 4) != 0, mode >> 4);
   __syncthreads();
   if (tid == 0 && L.ctl->abort) S->error = 1;
+}
+
+// Grid: 1 + 26 workgroups of 256 threads; all of them must be resident at once (they hand values to each other inside the launch;
+// every wait is bounded and a time-out sets SpecXfer::fail / MixState::error instead of hanging).
+extern "C" __global__ __launch_bounds__(CMX_SPEC_THREADS) void cmx_mixnet_spec_kernel(
+    MixState* __restrict__ S, SpecXfer* __restrict__ X, const float* __restrict__ probs, const uint32_t* __restrict__ sel,
+    const uint8_t* __restrict__ bits, const float* __restrict__ decay1, int nbits,
+    float* __restrict__ p_out, float* __restrict__ mix_out, int mode) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  if (blockIdx.x > 0) {
+    HelperLds* H = reinterpret_cast<HelperLds*>(smem);
+    for (int i = tid; i < (int)(sizeof(HelperLds) / 4); i += CMX_SPEC_THREADS) reinterpret_cast<int*>(H)[i] = 0;
+    __syncthreads();
+    helper_role(S, X, H, nbits, (int)blockIdx.x - 1, wave, lane);
+    return;
+  }
+  Lds L;
+  L.prod = smem;                                                  // unused here (no producers): 16 floats
+  L.xs = L.prod + 16;                                             // 3 * XS
+  L.rec = reinterpret_cast<BitRec*>(L.xs + 3 * XS);               // 3
+  L.trec = reinterpret_cast<TailRec*>(L.rec + 3);                 // 2
+  L.upd = reinterpret_cast<float*>(L.trec + 2);                   // 32
+  L.dflag = reinterpret_cast<uint32_t*>(L.upd + 32);              // 32
+  L.in2 = reinterpret_cast<float*>(L.dflag + 32);                 // 64
+  L.ctl = reinterpret_cast<Ctl*>(L.in2 + 64);
+  L.pfdump = (unsigned)(size_t)(lds_int*)(reinterpret_cast<int*>(L.ctl) + 16);
+  L.w2 = reinterpret_cast<float*>(L.ctl) + 16 + 64;
+  L.w1 = L.w2 + 64 + 16 + 64;
+  L.exptab = reinterpret_cast<uint64_t*>(L.w1 + 20 * 68);
+  for (int i = tid; i < 3 * XS; i += CMX_SPEC_THREADS) L.xs[i] = 0.0f;
+  if (tid < 32) { L.upd[tid] = 0.0f; L.dflag[tid] = 0; L.exptab[tid] = cmx_exp2f_tab[tid]; }
+  if (tid < (int)(sizeof(Ctl) / 4)) reinterpret_cast<int*>(L.ctl)[tid] = 0;
+  __syncthreads();
+  const bool prof = (mode & 4) != 0;
+  if (wave == 0) gather_role(S, L, X, decay1, nbits, mix_out, prof, lane);
+  else if (wave == 1) tail_role(S, L, decay1, nbits, p_out, mix_out, lane, prof && ((mode >> 4) & 4) != 0);
+  else if (wave == 2) scout_role(S, L, probs, sel, bits, nbits, lane, prof && ((mode >> 4) & 2) != 0, X);
+  __syncthreads();
+  if (tid == 0 && (L.ctl->abort || ld_u32(&X->fail))) S->error = 1;
 }

@@ -70,6 +70,27 @@ struct MixState {
   uint64_t prof[16];        // phase timers (shader clocks), see PROF() in mixnet_kernels.hip
 };
 
+// ---- cmx_mixnet_spec_kernel (mixnet_chunk.hip): the layer-0 dot products on 26 helper workgroups -----------------------------
+// Global hand-off area between the main workgroup (scout / gather / tail) and the helpers, one per handle. Everything in it is
+// written and read with agent-scope atomics (the workgroups sit on different compute units, possibly different XCDs / L2s).
+#define CMX_SPEC_RING 8        /* bits the scout may publish ahead (it is held to 2 ahead of the gather wave) */
+#define CMX_SPEC_XS 2112       /* stretched inputs of a bit, zero padded (2078 used) */
+#define CMX_SPEC_HELPERS CMX_MIX0
+#define CMX_SPEC_THREADS 256
+struct SpecXfer {
+  unsigned scout_epoch;        // bits whose inputs / rows the scout has published
+  unsigned fail;               // sticky: a bounded in-launch wait ran out
+  unsigned pad0[14];
+  unsigned long long u[32];    // by the gather wave after bit t: ((2 (t + 1) + decay flag) << 32) | bits of u = decay * lr * err   (mixer.cpp:56-64)
+  unsigned long long sum[32];  // by helper m after bit t: ((t + 1) << 32) | bits of the 2078-term ordered sum                     (mixer.cpp:40-43)
+  unsigned rowidx[CMX_SPEC_RING][32];
+  unsigned changed[CMX_SPEC_RING][32];
+  float xs[CMX_SPEC_RING][CMX_SPEC_XS];
+  unsigned long long stat[8];  // [0] speculative segments run, [1] of them resolved from a candidate lane, [2..4] misses of segment 1..3
+};
+#define CMX_SPEC_HEADER_BYTES (64 + 2 * 32 * 8)   /* what the host clears ahead of every launch (epochs and tags restart at 0) */
+#define CMX_SPEC_LDS_BYTES 49152
+
 // dynamic LDS of cmx_mixnet_chunk_kernel (see the carve-up in mixnet_chunk.hip)
 #define CMX_CHUNK_LDS_BYTES 163840   /* the whole 160 KB LDS of a gfx950 CU: one workgroup per CU */
 #define CMX_CHUNK_THREADS 768

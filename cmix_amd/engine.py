@@ -84,6 +84,7 @@ def lib():
         L.cmx_mixnet_bits_done.argtypes = [C.c_void_p, C.c_void_p]
         L.cmx_mixnet_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.cmx_mixnet_last_kernel_ms.argtypes = [C.c_void_p, C.c_void_p]
+        L.cmx_mixnet_spec_stats.argtypes = [C.c_void_p, C.c_void_p]
         L.cmx_lstm_create.restype = C.c_void_p
         L.cmx_lstm_create.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.cmx_lstm_destroy.argtypes = [C.c_void_p]
@@ -265,6 +266,14 @@ class MixNet:
         if lib().cmx_mixnet_last_kernel_ms(self.h, C.byref(v)):
             raise CmxError(last_error())
         return v.value
+
+    def spec_stats(self):
+        """Speculative segment-parallel chain (cmx_mixnet_spec_kernel): segments run, resolved from a candidate, re-runs of segment 1..3."""
+        out = (C.c_uint64 * 5)()
+        if lib().cmx_mixnet_spec_stats(self.h, out):
+            raise CmxError(last_error())
+        v = list(out)
+        return {"segments": v[0], "hits": v[1], "reruns": v[2:5], "hit_rate": (v[1] / v[0]) if v[0] else None}
 
 
 class Lstm:

@@ -148,6 +148,11 @@ int cmx_mixnet_profile(cmx_mixnet_t*, int enable, uint64_t* out16);
 /* Elapsed device time (ms, HIP events on the launch stream) of the last
  * cmx_mixnet_run kernel; synchronises with it. */
 int cmx_mixnet_last_kernel_ms(cmx_mixnet_t*, float* ms);
+/* Chunk mode runs cmx_mixnet_spec_kernel: 26 helper workgroups cut each layer-0 mixer's ordered 2078-term sum into four segments
+ * that run at once, segments 1..3 speculatively from 64 candidate start values (exact: the lane whose candidate equals the true
+ * start holds the reference's result, otherwise the segment is re-run). Statistics since creation: out[0] speculative segments,
+ * [1] resolved from a candidate, [2..4] re-runs of segment 1 / 2 / 3. Synchronises the device. */
+int cmx_mixnet_spec_stats(cmx_mixnet_t*, uint64_t out[5]);
 
 /* ------------------------------------------------------------------------
  * 2b. Stage: byte-level LSTM byte mixer = ByteMixer + Lstm + LstmLayer + its ByteModel bit

@@ -25,6 +25,10 @@ else:
              'tail handoff + extras upd', 'P0: wait scout', 'P0: wait u', 'P0: serial window (upd/swap 0,1 + stage 0)',
              'P0: upd/swap chunks 2..8', 'P0: stage 1..3 (incl. waits)', 'P0: loop top', 'wait tail_done(t-1)',
              'wait staged seg 1', 'wait staged seg 2', 'wait staged seg 3']
+if os.environ.get('CMX_MIXNET_V1') != '1' and os.environ.get('CMX_MIXNET_SPEC', '1') != '0':   # cmx_mixnet_spec_kernel: the gather wave's phases
+    names = ['wait scout', 'row state + decay', 'wait the 26 sums (helpers)', 'extras chain', 'u + publish (global)',
+             'tail handoff + extras upd', 'P0: -', 'P0: -', 'P0: -', 'P0: -', 'P0: -', 'P0: -', 'wait tail_done(t-1)', '-', '-', '-']
+    print('speculation:', net.spec_stats())
 if int(os.environ.get('CMX_MIXNET_DBG', '0')) & 2:
     names[6:12] = ['SCOUT: wait consumed', 'SCOUT: probs load + stretch LUT + xs', 'SCOUT: aux + select_row', 'SCOUT: prefetch drain+issue', 'SCOUT: rest + publish', 'SCOUT: loop top']
 if int(os.environ.get('CMX_MIXNET_DBG', '0')) & 4:
