@@ -65,7 +65,9 @@ struct TailRec {           // written by the chain wave for bit t (slot t & 1)
 struct Lds {
   float* prod;     // [2][PBUF]
   float* xs;       // [3][XS]
-  BitRec* rec;     // [3]
+  BitRec* rec;     // [rr]
+  int rr;          // depth of the rec ring: 3 (one-workgroup kernel), 8 (cmx_mixnet_spec_kernel)
+  int lead;        // bits the scout may run ahead of the chain / gather wave: 2 resp. 4
   TailRec* trec;   // [2]
   float* upd;      // [32]
   uint32_t* dflag; // [32]
@@ -214,14 +216,15 @@ __device__ void scout_role(MixState* S, const Lds& L, const float* probs, const 
   const float smin = S->stretch_min, smax = S->stretch_max;
   for (int t = 0; t < nbits; ++t) {
     SPROF(11);
-    if (t >= 2 && !wait_ge(L.ctl, &L.ctl->consumed, 4 * t - 4, true)) return;
-    // rec slot t%3 still holds bit t-3, whose layer-1/2 row indices the tail wave reads at the start of
-    // its bit t-3: wait until it has finished that bit
-    if (t >= 3 && !wait_ge(L.ctl, &L.ctl->tail_done, t - 2, true)) return;
+    if (!X) { if (t >= 2 && !wait_ge(L.ctl, &L.ctl->consumed, 4 * t - 4, true)) return; }
+    else if (t >= L.lead && !wait_ge(L.ctl, &L.ctl->consumed, 4 * (t - L.lead) + 1, true)) return;   // the gather wave has begun bit t - lead
+    // rec slot t % rr still holds bit t-rr, whose layer-1/2 row indices the tail wave reads at the start of
+    // its bit t-rr: wait until it has finished that bit
+    if (t >= L.rr && !wait_ge(L.ctl, &L.ctl->tail_done, t - L.rr + 1, true)) return;
     SPROF(6);
     float* xs = L.xs + (t % 3) * XS;
-    BitRec* rec = L.rec + (t % 3);
-    const BitRec* prev = L.rec + ((t + 2) % 3);
+    BitRec* rec = L.rec + (t % L.rr);
+    const BitRec* prev = L.rec + ((t + L.rr - 1) % L.rr);
     const gptr<const float> pr = gprobs + (size_t)t * CMX_IN0;
     // MixerInput::SetInput (mixer-input.cpp:11-15) + Sigmoid::Logit (sigmoid.cpp:12-17)
     float pv[33];
@@ -242,19 +245,23 @@ __device__ void scout_role(MixState* S, const Lds& L, const float* probs, const 
       else if (idx < 0) idx = 0;
       pv[r] = lut[idx];
     }
+    // the three auxiliary inputs (columns 433, 2024, 2077) sit in lanes 49, 40, 29 of rows 6, 31, 32
+    const float ax0 = bcast_lane(pv[6], 49), ax1 = bcast_lane(pv[31], 40), ax2 = bcast_lane(pv[32], 29);
+    if (!X) {   // the producers of the one-workgroup kernel read the inputs from LDS; the helpers get them through the global ring
 #pragma unroll
-    for (int r = 0; r < 33; ++r) {
-      int i = r * 64 + lane;
-      if (i < CMX_IN0) xs[i] = pv[r];
+      for (int r = 0; r < 33; ++r) {
+        int i = r * 64 + lane;
+        if (i < CMX_IN0) xs[i] = pv[r];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
     SPROF(7);
     if (lane == CMX_AUX) {  // predictor.cpp:388-393
       float avg = 0;
-      avg = fadd(avg, cmx_logistic(xs[433]));
-      avg = fadd(avg, cmx_logistic(xs[2024]));
-      avg = fadd(avg, cmx_logistic(xs[2077]));
+      avg = fadd(avg, cmx_logistic(ax0));
+      avg = fadd(avg, cmx_logistic(ax1));
+      avg = fadd(avg, cmx_logistic(ax2));
       avg = avg / 3.0f;
       key = (uint32_t)(unsigned long long)(avg * 15);
     }
@@ -284,7 +291,7 @@ __device__ void scout_role(MixState* S, const Lds& L, const float* probs, const 
     SPROF(8);
     SPROF(9);
     if (lane < 3) {
-      float v = xs[lane == 0 ? 433 : lane == 1 ? 2024 : 2077];
+      float v = lane == 0 ? ax0 : lane == 1 ? ax1 : ax2;
       if (v > smax) v = smax;
       else if (v < smin) v = smin;
       rec->aux3[lane] = v;
@@ -334,8 +341,8 @@ __device__ void producer_role(MixState* S, const Lds& L, int nbits, int p, int l
     PPROF(6);
     const float* xs = L.xs + (t % 3) * XS;
     const float* xsp = L.xs + ((t + 2) % 3) * XS;
-    const BitRec* rec = L.rec + (t % 3);
-    const BitRec* prev = L.rec + ((t + 2) % 3);
+    const BitRec* rec = L.rec + (t % L.rr);
+    const BitRec* prev = L.rec + ((t + L.rr - 1) % L.rr);
     // Everything that does not depend on bit t-1's error is fetched BEFORE waiting for it, so the
     // window between "u published" and "segment 0 staged" (the serial part of the bit) is as short
     // as possible: row indices, the previous and current inputs of chunks 0 and 1.
@@ -448,7 +455,7 @@ __device__ void producer_role(MixState* S, const Lds& L, int nbits, int p, int l
     // top of the next serial window, ~10k clocks later. Skipped when the scout has not published the
     // next bit yet.
     if (t + 1 < nbits && lds_poll(&L.ctl->scout_epoch) >= t + 2) {
-      const BitRec* nxt = L.rec + ((t + 1) % 3);
+      const BitRec* nxt = L.rec + ((t + 1) % L.rr);
 #pragma unroll
       for (int j = 0; j < MPW; ++j) {
         if (ok[j] && nxt->changed[mj[j]]) {
@@ -511,7 +518,7 @@ __device__ void chain_role(MixState* S, const Lds& L, const float* decay1, int n
   for (int t = 0; t < nbits; ++t) {
     if (!wait_ge(L.ctl, &L.ctl->scout_epoch, t + 1, false)) return;
     CPROF(0);
-    const BitRec* rec = L.rec + (t % 3);
+    const BitRec* rec = L.rec + (t % L.rr);
     const int bit = rec->bit;
     if (is0 && rec->changed[mm] && !((dbg & 8) && t > 0)) {  // dbg&8: timing experiment only (the chain wave keeps its first row state)
       // asm stores: re-using ew[] for the incoming row must not make the compiler wait for their acks
@@ -718,7 +725,7 @@ __device__ void tail_role(MixState* S, const Lds& L, const float* decay1, int nb
     // ---- before the layer-0 outputs exist: rows and SSE cells of bit t ----
     TPROF(11);
     if (!wait_ge(L.ctl, &L.ctl->scout_epoch, t + 1, true)) return;
-    const BitRec* rec = L.rec + (t % 3);
+    const BitRec* rec = L.rec + (t % L.rr);
     const uint32_t newrow = rec->rowidx[CMX_MIX0 + kk];
     const double d1 = (double)as_global(decay1)[t];
     if (is1 && newrow != cur_row) {
@@ -749,7 +756,7 @@ __device__ void tail_role(MixState* S, const Lds& L, const float* decay1, int nb
     }
     // pull the layer-1 rows of the NEXT bit towards the caches (2 lines per row), if the scout is there yet
     if (t + 1 < nbits && lds_poll(&L.ctl->scout_epoch) >= t + 2) {
-      const uint32_t nr = L.rec[(t + 1) % 3].rowidx[CMX_MIX0 + kk];
+      const uint32_t nr = L.rec[(t + 1) % L.rr].rowidx[CMX_MIX0 + kk];
       if (is1 && nr != cur_row) {
         const gptr<const float> nrow = rows1 + ((size_t)kk * CMX_ROWS_PER_MIXER + nr) * CMX_ROW1_STRIDE;
         touch_line(nrow, L.pfdump + 256 + 256 + 64);
@@ -1144,22 +1151,35 @@ __device__ void gather_role(MixState* S, const Lds& L, SpecXfer* X, const float*
       if (4 * i < m) gstore4_async(row0 + CMX_ROW0_EXTRA + 4 * i, make_float4(ew[4 * i], ew[4 * i + 1], ew[4 * i + 2], ew[4 * i + 3]));
     asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 0" :: "v"(rsp), "v"(rsteps) : "memory");
   };
+  // row state of the NEXT bit, requested at the end of a bit (the scout is ahead) so that the loads run under the helpers' work:
+  // a row that changes comes from a different row than the current one, whose last stores this wave issued earlier (in order)
+  float4 ewn[7];
+  uint64_t rsn = 0;
+  int pf_t = -1;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) ewn[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   for (int t = 0; t < nbits; ++t) {
     if (!wait_ge(L.ctl, &L.ctl->scout_epoch, t + 1, false)) return;
     st_rel(&L.ctl->consumed, 4 * t + 1);      // the scout may go on to bit t + 1 (it waits for consumed >= 4 t)
     GPROF(0);
-    const BitRec* rec = L.rec + (t % 3);
+    const BitRec* rec = L.rec + (t % L.rr);
     const int bit = rec->bit;
     if (is0 && rec->changed[mm]) {
       if (t > 0) store_row_state();
       row0 = as_global(S->rows0) + ((size_t)mm * CMX_ROWS_PER_MIXER + rec->rowidx[mm]) * CMX_ROW0_STRIDE;
       rsp = as_global(S->row_steps) + (size_t)mm * CMX_ROWS_PER_MIXER + rec->rowidx[mm];
+      if (pf_t == t) {          // requested while the helpers worked on the previous bit
 #pragma unroll
-      for (int i = 0; i < 7; ++i) {
-        float4 v = gload4(row0 + CMX_ROW0_EXTRA + 4 * i);
-        ew[4 * i] = v.x; ew[4 * i + 1] = v.y; ew[4 * i + 2] = v.z; ew[4 * i + 3] = v.w;
+        for (int i = 0; i < 7; ++i) { ew[4 * i] = ewn[i].x; ew[4 * i + 1] = ewn[i].y; ew[4 * i + 2] = ewn[i].z; ew[4 * i + 3] = ewn[i].w; }
+        rsteps = rsn;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+          float4 v = gload4(row0 + CMX_ROW0_EXTRA + 4 * i);
+          ew[4 * i] = v.x; ew[4 * i + 1] = v.y; ew[4 * i + 2] = v.z; ew[4 * i + 3] = v.w;
+        }
+        rsteps = *rsp;
       }
-      rsteps = *rsp;
 #pragma unroll
       for (int i = 0; i < 28; ++i)
         if (i >= m) ew[i] = 0.0f;
@@ -1221,6 +1241,16 @@ __device__ void gather_role(MixState* S, const Lds& L, SpecXfer* X, const float*
         ew[j] = v;
       }
     }
+    if (t + 1 < nbits && lds_poll(&L.ctl->scout_epoch) >= t + 2) {
+      const BitRec* nx = L.rec + ((t + 1) % L.rr);
+      if (is0 && nx->changed[mm]) {
+        const gptr<float> r1 = as_global(S->rows0) + ((size_t)mm * CMX_ROWS_PER_MIXER + nx->rowidx[mm]) * CMX_ROW0_STRIDE;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) ewn[i] = gload4(r1 + CMX_ROW0_EXTRA + 4 * i);
+        rsn = (as_global(S->row_steps) + (size_t)mm * CMX_ROWS_PER_MIXER + nx->rowidx[mm])[0];
+      }
+      pf_t = t + 1;
+    }
     GPROF(5);
   }
   if (is0 && nbits > 0) {
@@ -1251,6 +1281,7 @@ extern "C" __global__ __launch_bounds__(NTHREADS) void cmx_mixnet_chunk_kernel(
   L.prod = smem;                                                  // 2 * PBUF
   L.xs = L.prod + 2 * PBUF;                                       // 3 * XS
   L.rec = reinterpret_cast<BitRec*>(L.xs + 3 * XS);               // 3
+  L.rr = 3; L.lead = 2;
   L.trec = reinterpret_cast<TailRec*>(L.rec + 3);                 // 2
   L.upd = reinterpret_cast<float*>(L.trec + 2);                   // 32
   L.dflag = reinterpret_cast<uint32_t*>(L.upd + 32);              // 32
@@ -1298,8 +1329,9 @@ extern "C" __global__ __launch_bounds__(CMX_SPEC_THREADS) void cmx_mixnet_spec_k
   Lds L;
   L.prod = smem;                                                  // unused here (no producers): 16 floats
   L.xs = L.prod + 16;                                             // 3 * XS
-  L.rec = reinterpret_cast<BitRec*>(L.xs + 3 * XS);               // 3
-  L.trec = reinterpret_cast<TailRec*>(L.rec + 3);                 // 2
+  L.rec = reinterpret_cast<BitRec*>(L.xs + 3 * XS);               // 8: the scout runs up to 4 bits ahead of the gather wave
+  L.rr = 8; L.lead = 4;
+  L.trec = reinterpret_cast<TailRec*>(L.rec + 8);                 // 2
   L.upd = reinterpret_cast<float*>(L.trec + 2);                   // 32
   L.dflag = reinterpret_cast<uint32_t*>(L.upd + 32);              // 32
   L.in2 = reinterpret_cast<float*>(L.dflag + 32);                 // 64

@@ -14,7 +14,7 @@
 //               mix     the 1552 x 28 int16 mixer (rows in registers from dot product to training), the second layer,
 //                       the APM / APM1 chains, squash(x)/4095 export of all 1591 values into the layer-0 matrix
 //             Streams: s_d = upload, cm2[0]; s_a = fam (after cm2[0] of the same chunk, beside cm2[0] of the next); s_b = cm2[1];
-//             s_e = cm2[2]; s_c = lanes -> dmc (after cm2[0]); s_m = mix after all.
+//             s_e = cm2[2]; s_c = lanes (after cm2[0]); s_f = dmc (bits only); s_m = mix after all.
 // Integer work, latency-bound by construction (dependent table accesses per bit); algorithmic HBM traffic per input
 // byte: mixer 28 rows x 1552 x 2 B x 2 (read + write) x 8 = 1.39 MB, buckets ~270 contexts x 3 probes x 64 B x 2 = 0.1 MB.
 // Parity: tests/test_p8stage_host.py runs the bodies on the host, tests/test_zgpu_p8stage.py the kernels, both against
@@ -689,7 +689,7 @@ struct Staging {   // one chunk's records: page-locked host arrays and their dev
   char* h = nullptr; char* d = nullptr;
   size_t o_fctx, o_fchk, o_cctx[P8_NCM2], o_cchk[P8_NCM2], o_ops, o_sel, o_apm, o_bits, total;
   hipEvent_t done = nullptr;
-  hipEvent_t t0[6] = {}, t1[6] = {};   // HIP-event brackets of the role kernels of the chunk: family, mixer, cm2[0..2], lanes + DMC
+  hipEvent_t t0[7] = {}, t1[7] = {};   // HIP-event brackets of the role kernels of the chunk: family, mixer, cm2[0..2], lanes, DMC
   bool used = false, timed = false;
 };
 template <class Tp> Tp* dev_copy(const Tp& host, DevPolicy& pol) {
@@ -709,9 +709,9 @@ struct cmx_p8stage {
   Staging st[P8S_BUFS];
   int next = 0;
   int16_t* d_x[P8S_XBUFS] = {}; uint8_t* d_order[P8S_XBUFS] = {}; size_t x_cap = 0;   // two chunks' input rows / order values: the mixer of chunk c runs under the tables of chunk c + 1
-  hipStream_t s_a = nullptr, s_b = nullptr, s_c = nullptr, s_d = nullptr, s_e = nullptr, s_m = nullptr;
+  hipStream_t s_a = nullptr, s_b = nullptr, s_c = nullptr, s_d = nullptr, s_e = nullptr, s_m = nullptr, s_f = nullptr;   // s_f: the DMC forest (needs the bits only)
   hipStream_t s_up = nullptr; bool own_up = false;   // the chunk's records go up on a stream that never has a kernel in front of a copy (cmx_p8stage_set_upload_stream)
-  hipEvent_t ev_up = nullptr, ev_ord = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_e = nullptr, ev_mix[P8S_XBUFS] = {};
+  hipEvent_t ev_up = nullptr, ev_ord = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_e = nullptr, ev_f = nullptr, ev_mix[P8S_XBUFS] = {};
   bool mix_used[P8S_XBUFS] = {};
   unsigned long long* d_prof = nullptr;   // CMX_P8MIX_PROFILE=1: per-wave clocks by phase of the mixer kernel
   uint64_t chunks = 0;
@@ -719,11 +719,11 @@ struct cmx_p8stage {
   int last_bit = 0;
   bool failed = false;
   float ms_front = 0;   // host time of the last front-end pass
-  double role_ms[6] = {0, 0, 0, 0, 0, 0}; uint64_t role_chunks = 0;   // summed over the chunks collected so far
+  double role_ms[7] = {0, 0, 0, 0, 0, 0, 0}; uint64_t role_chunks = 0;   // summed over the chunks collected so far
 };
 static void p8s_collect(cmx_p8stage* h, Staging& b) {   // the chunk that used b is complete
   if (!b.timed) return;
-  for (int i = 0; i < 6; i++) { float f = 0; if (hipEventElapsedTime(&f, b.t0[i], b.t1[i]) == hipSuccess) h->role_ms[i] += f; }
+  for (int i = 0; i < 7; i++) { float f = 0; if (hipEventElapsedTime(&f, b.t0[i], b.t1[i]) == hipSuccess) h->role_ms[i] += f; }
   h->role_chunks++;
   b.timed = false;
 }
@@ -744,15 +744,15 @@ void cmx_p8stage_destroy(cmx_p8stage_t* h) {
   }
   for (int i = 0; i < P8S_XBUFS; i++) { if (h->d_x[i]) (void)hipFree(h->d_x[i]); if (h->d_order[i]) (void)hipFree(h->d_order[i]); }
   {
-    hipStream_t seen[6] = {}; int ns = 0;   // in compact modes several roles share a stream
-    for (hipStream_t q : {h->s_a, h->s_b, h->s_c, h->s_d, h->s_e, h->s_m}) {
+    hipStream_t seen[7] = {}; int ns = 0;   // in compact modes several roles share a stream
+    for (hipStream_t q : {h->s_a, h->s_b, h->s_c, h->s_d, h->s_e, h->s_m, h->s_f}) {
       bool dup = !q;
       for (int i = 0; i < ns; i++) dup = dup || seen[i] == q;
       if (!dup) { seen[ns++] = q; (void)hipStreamDestroy(q); }
     }
   }
   if (h->own_up && h->s_up) (void)hipStreamDestroy(h->s_up);
-  for (hipEvent_t e : {h->ev_up, h->ev_ord, h->ev_a, h->ev_b, h->ev_c, h->ev_e}) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {h->ev_up, h->ev_ord, h->ev_a, h->ev_b, h->ev_c, h->ev_e, h->ev_f}) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->ev_mix) if (e) (void)hipEventDestroy(e);
   if (h->front) p8f_front_free(h->front);
   delete h;
@@ -796,12 +796,14 @@ cmx_p8stage_t* cmx_p8stage_create(int device) {
     else { h->s_b = h->s_d; h->s_e = h->s_d; }
     if (mode == 1) h->s_c = h->s_d;
     else ok = ok && hipStreamCreateWithFlags(&h->s_c, hipStreamNonBlocking) == hipSuccess;
+    if (mode == 0) ok = ok && hipStreamCreateWithFlags(&h->s_f, hipStreamNonBlocking) == hipSuccess;   // the DMC forest beside the small learners
+    else h->s_f = h->s_c;
   }
-  for (hipEvent_t* e : {&h->ev_up, &h->ev_ord, &h->ev_a, &h->ev_b, &h->ev_c, &h->ev_e}) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
+  for (hipEvent_t* e : {&h->ev_up, &h->ev_ord, &h->ev_a, &h->ev_b, &h->ev_c, &h->ev_e, &h->ev_f}) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
   for (hipEvent_t& e : h->ev_mix) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
   for (auto& s : h->st) {
     ok = ok && hipEventCreateWithFlags(&s.done, hipEventDisableTiming) == hipSuccess;
-    for (int i = 0; i < 6; i++) ok = ok && hipEventCreate(&s.t0[i]) == hipSuccess && hipEventCreate(&s.t1[i]) == hipSuccess;
+    for (int i = 0; i < 7; i++) ok = ok && hipEventCreate(&s.t0[i]) == hipSuccess && hipEventCreate(&s.t1[i]) == hipSuccess;
   }
   if (ok && getenv("CMX_P8MIX_PROFILE")) ok = hipMalloc((void**)&h->d_prof, 7 * 8 * 8) == hipSuccess && hipMemset(h->d_prof, 0, 7 * 8 * 8) == hipSuccess;
   ok = ok && hipDeviceSynchronize() == hipSuccess;
@@ -863,7 +865,7 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
   // the caller's earlier work is needed, d_out must simply not be in use).
   const int par = (int)(h->chunks % P8S_XBUFS);
   int16_t* dx = h->d_x[par]; uint8_t* dord = h->d_order[par];
-  if (h->mix_used[par]) for (hipStream_t q : {h->s_a, h->s_b, h->s_c, h->s_d, h->s_e}) ok = ok && hipStreamWaitEvent(q, h->ev_mix[par], 0) == hipSuccess;   // the mixer that last read these rows
+  if (h->mix_used[par]) for (hipStream_t q : {h->s_a, h->s_b, h->s_c, h->s_d, h->s_e, h->s_f}) ok = ok && hipStreamWaitEvent(q, h->ev_mix[par], 0) == hipSuccess;   // the mixer that last read these rows
   // upload on the upload stream: on s_d the copy would sit behind the previous chunk's order-N kernel, and a host-to-device
   // copy that waits in stream order holds up every later copy of the process
   if (!h->s_up) { ok = ok && hipStreamCreateWithFlags(&h->s_up, hipStreamNonBlocking) == hipSuccess; h->own_up = true; }
@@ -901,10 +903,15 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
     ok = ok && hipStreamWaitEvent(h->s_c, h->ev_ord, 0) == hipSuccess;
     (void)hipEventRecord(b.t0[5], h->s_c);
     hipLaunchKernelGGL(cmx_p8s_lanes_kernel, dim3(1), dim3(P8_NLANE), 0, h->s_c, h->d_lanes, (const uint32_t*)(b.d + b.o_ops), d_bits, (const uint8_t*)dord, dx, nbits, t0);
-    hipLaunchKernelGGL(cmx_p8s_dmc_kernel, dim3(1), dim3(P8DMC_THREADS), 0, h->s_c, h->d_dmc, d_bits, dx, (int)L.dmc_off, nbits, t0);
     (void)hipEventRecord(b.t1[5], h->s_c);
     ok = ok && hipEventRecord(h->ev_c, h->s_c) == hipSuccess;
-    for (hipEvent_t e : {h->ev_a, h->ev_b, h->ev_c, h->ev_e}) ok = ok && hipStreamWaitEvent(h->s_m, e, 0) == hipSuccess;
+    // the DMC forest reads the coded bits only: on a stream of its own it runs beside the small learners (4.0 + 2.8 us/bit in a row before)
+    if (h->s_f != h->s_c) ok = ok && hipStreamWaitEvent(h->s_f, h->ev_up, 0) == hipSuccess;
+    (void)hipEventRecord(b.t0[6], h->s_f);
+    hipLaunchKernelGGL(cmx_p8s_dmc_kernel, dim3(1), dim3(P8DMC_THREADS), 0, h->s_f, h->d_dmc, d_bits, dx, (int)L.dmc_off, nbits, t0);
+    (void)hipEventRecord(b.t1[6], h->s_f);
+    ok = ok && hipEventRecord(h->ev_f, h->s_f) == hipSuccess;
+    for (hipEvent_t e : {h->ev_a, h->ev_b, h->ev_c, h->ev_e, h->ev_f}) ok = ok && hipStreamWaitEvent(h->s_m, e, 0) == hipSuccess;
     (void)hipEventRecord(b.t0[1], h->s_m);
     if (h->fam_v1 || getenv("CMX_P8MIX_V1"))
       hipLaunchKernelGGL(cmx_p8s_mix_kernel, dim3(1), dim3(MX_THREADS), 0, h->s_m, (const P8MixDev*)h->d_mix, h->d_tail, (const int16_t*)dx, (const int32_t*)(b.d + b.o_sel),
@@ -955,9 +962,9 @@ int cmx_p8stage_sync(cmx_p8stage_t* h) {
 // staging buffer comes round again, or by cmx_p8stage_sync): ms[0] family, [1] mixer + APM chains, [2..4] the three
 // ContextMap2 instances, [5] small lanes + DMC. They run on streams of their own: the stage's period per chunk is the
 // largest of them (the family after the order-N map of the same chunk, the mixer after all), not their sum.
-int cmx_p8stage_role_ms(cmx_p8stage_t* h, double ms[6], uint64_t* chunks, int reset) {
+int cmx_p8stage_role_ms(cmx_p8stage_t* h, double ms[7], uint64_t* chunks, int reset) {
   if (!h || !ms || !chunks) return 1;
-  for (int i = 0; i < 6; i++) ms[i] = h->role_ms[i];
+  for (int i = 0; i < 7; i++) ms[i] = h->role_ms[i];
   *chunks = h->role_chunks;
   if (reset) { for (double& v : h->role_ms) v = 0; h->role_chunks = 0; }
   return 0;

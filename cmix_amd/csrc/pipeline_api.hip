@@ -267,7 +267,7 @@ int cmx_pipeline_paq8_total_ms(cmx_pipeline_t* h, double* ms) { if (!h || !ms) r
 // [0] waiting for a slot (the device is behind), [1] PPMd, [2] uploads + context stage + LSTM enqueue, [3] fxcm (text parser,
 // staging wait, enqueue), [4] paq8 (front end, staging wait, enqueue), [5] mixing network enqueue
 int cmx_pipeline_host_ms(cmx_pipeline_t* h, double ms[6]) { if (!h || !ms) return 1; for (int i = 0; i < 6; i++) ms[i] = h->host_ms[i]; return 0; }
-int cmx_pipeline_paq8_role_ms(cmx_pipeline_t* h, double ms[6], uint64_t* chunks) { return h && h->p8 ? cmx_p8stage_role_ms(h->p8, ms, chunks, 0) : 1; }
+int cmx_pipeline_paq8_role_ms(cmx_pipeline_t* h, double ms[7], uint64_t* chunks) { return h && h->p8 ? cmx_p8stage_role_ms(h->p8, ms, chunks, 0) : 1; }
 int cmx_pipeline_fxcm_enabled(cmx_pipeline_t* h) { return h && h->fxcm ? 1 : 0; }
 // HIP-event time of the fxcm kernel over the chunks counted by cmx_pipeline_stage_totals (same reset)
 int cmx_pipeline_fxcm_total_ms(cmx_pipeline_t* h, double* ms) { if (!h || !ms) return 1; *ms = h->fx_ms; return 0; }
@@ -525,7 +525,7 @@ int cmx_pipeline_stage_totals(cmx_pipeline_t* h, double ms[3], uint64_t* chunks,
   if (!h || !ms || !chunks) return 1;
   for (int i = 0; i < 3; ++i) ms[i] = h->tot_ms[i];
   *chunks = h->tot_chunks;
-  if (reset) { h->tot_ms[0] = h->tot_ms[1] = h->tot_ms[2] = 0; h->tot_chunks = 0; h->fx_ms = 0; h->p8_ms = 0; for (double& v : h->host_ms) v = 0; if (h->p8) { double t[6]; uint64_t c; (void)cmx_p8stage_role_ms(h->p8, t, &c, 1); } }
+  if (reset) { h->tot_ms[0] = h->tot_ms[1] = h->tot_ms[2] = 0; h->tot_chunks = 0; h->fx_ms = 0; h->p8_ms = 0; for (double& v : h->host_ms) v = 0; if (h->p8) { double t[7]; uint64_t c; (void)cmx_p8stage_role_ms(h->p8, t, &c, 1); } }
   return 0;
 }
 

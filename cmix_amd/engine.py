@@ -472,9 +472,9 @@ class Pipeline:
 
     def paq8_role_ms(self):
         """(dict of the paq8 role kernels' summed HIP-event ms, chunks collected) since the last totals reset."""
-        v, c = (C.c_double * 6)(), C.c_uint64(0)
+        v, c = (C.c_double * 7)(), C.c_uint64(0)
         lib().cmx_pipeline_paq8_role_ms(self.h, v, C.byref(c))
-        return dict(zip(("family", "mixer", "cm2_order_n", "cm2_text", "cm2_exe", "lanes_dmc"), [float(x) for x in v])), int(c.value)
+        return dict(zip(("family", "mixer", "cm2_order_n", "cm2_text", "cm2_exe", "lanes", "dmc"), [float(x) for x in v])), int(c.value)
 
     def host_ms(self):
         """Calling-thread wall time inside begin / finish since the last totals reset: dict of ms."""

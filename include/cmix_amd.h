@@ -448,7 +448,7 @@ int cmx_pipeline_wait(cmx_pipeline_t*, uint64_t index);
 int cmx_pipeline_paq8_enabled(cmx_pipeline_t*);
 int cmx_pipeline_paq8_total_ms(cmx_pipeline_t*, double* ms);
 /* the paq8 stage's role-kernel times (cmx_p8stage_role_ms) since the last reset of the stage totals */
-int cmx_pipeline_paq8_role_ms(cmx_pipeline_t*, double ms[6], uint64_t* chunks);
+int cmx_pipeline_paq8_role_ms(cmx_pipeline_t*, double ms[7], uint64_t* chunks);
 /* wall time of the calling thread inside begin / finish since the last reset of the stage totals, ms: [0] waiting for a
  * slot, [1] PPMd, [2] uploads + context stage + LSTM enqueue, [3] fxcm (parser + enqueue), [4] paq8 (front end + enqueue),
  * [5] mixing network enqueue */
@@ -488,8 +488,8 @@ void cmx_p8stage_destroy(cmx_p8stage_t*);
 int cmx_p8stage_run(cmx_p8stage_t*, const uint8_t* bytes_host, size_t nbytes, float* d_out, size_t ld, void* stream);
 int cmx_p8stage_sync(cmx_p8stage_t*);
 /* HIP-event time of the role kernels summed over the chunks collected so far (a chunk is collected when its staging
- * buffer comes round again, or by _sync): ms[0] family, [1] mixer + APM chains, [2..4] ContextMap2 x 3, [5] lanes + DMC. */
-int cmx_p8stage_role_ms(cmx_p8stage_t*, double ms[6], uint64_t* chunks, int reset);
+ * buffer comes round again, or by _sync): ms[0] family, [1] mixer + APM chains, [2..4] ContextMap2 x 3, [5] small learners (lanes), [6] DMC forest. */
+int cmx_p8stage_role_ms(cmx_p8stage_t*, double ms[7], uint64_t* chunks, int reset);
 int cmx_p8stage_set_upload_stream(cmx_p8stage_t*, void* stream);   /* see cmx_mixnet_set_upload_stream */
 /* diagnostics (CMX_P8MIX_PROFILE=1 at create time): the mixer kernel's clocks per wave (7) and phase (8 slots, 5 used) */
 int cmx_p8stage_mix_profile(cmx_p8stage_t*, unsigned long long out56[56]);
