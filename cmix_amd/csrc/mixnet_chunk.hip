@@ -50,7 +50,8 @@ struct BitRec {            // written by the scout for bit t (slot t % 3)
   float aux3[4];           // clamped stretch of the three auxiliary inputs
   float lstm_p;            // raw probs[t][2077] (override test)
   int bit;
-  int pad[2];
+  uint32_t auxkey;         // cmx_mixnet_spec_kernel: auxiliary_context_ of the bit (predictor.cpp:388-393), from the stretch wave
+  int pad;
 };
 
 struct TailRec {           // written by the chain wave for bit t (slot t & 1)
@@ -77,6 +78,9 @@ struct Lds {
   float* w1;       // [20][68] layer-1 weight rows
   unsigned pfdump; // LDS byte offset of a 256-byte dump area for the row-prefetch LDS-DMA loads
   uint64_t* exptab; // [32] expf's table (cmx_libm.h): the chain wave's error needs it on the serial path
+  const uint16_t* lst;  // cmx_mixnet_spec_kernel: LDS copies of the SSE's t_st / t_sq (64 KB each: five dependent look-ups per bit
+  const uint16_t* lsq;  //   sit on the tail wave's path); nullptr: read them from global memory
+  int* sdone;       // [rr] cmx_mixnet_spec_kernel: bit + 1 whose stretched inputs a stretch wave has published
 };
 
 // All inter-wave traffic of this kernel goes through LDS, so its synchronisation only has to
@@ -835,17 +839,19 @@ __device__ void tail_role(MixState* S, const Lds& L, const float* decay1, int nb
       const int w1x = as_global(x1)[im1];
       const int w2x = as_global(x2)[im2];
       SseInterp e6, e7;
-      const int stp = as_global(t_st)[p];
-      const int q6 = as_global(t_sq)[sse_extrap(stp, 10240)], q7 = as_global(t_sq)[sse_extrap(stp, 8200)];
+      auto ST = [&](int i) -> int { return L.lst ? (int)L.lst[i] : (int)as_global(t_st)[i]; };
+      auto SQ = [&](int i) -> int { return L.lsq ? (int)L.lsq[i] : (int)as_global(t_sq)[i]; };
+      const int stp = ST(p);
+      const int q6 = SQ(sse_extrap(stp, 10240)), q7 = SQ(sse_extrap(stp, 8200));
       const int pp1 = e6.pred(c6, q6);
       const int pp2 = e7.pred(c7, q7);
       const int s0 = sse_extrap(stp, 7935);
-      const int s1 = sse_extrap(as_global(t_st)[pp1], 9592);
-      const int s4 = sse_extrap(as_global(t_st)[pp2], 7677);
+      const int s1 = sse_extrap(ST(pp1), 9592);
+      const int s4 = sse_extrap(ST(pp2), 7677);
       const int s2 = sse_extrap(sse_mixup(w1x, s0, s1), 8092);
-      const int mix1_p = as_global(t_sq)[s2];
+      const int mix1_p = SQ(s2);
       const int s5 = sse_extrap(sse_mixup(w2x, s2, s4), 8202);
-      const int mix2_p = as_global(t_sq)[s5];
+      const int mix2_p = SQ(s5);
       float pf = (float)(1 - ((mix2_p - 1) / 32766.0));
       const float lp = tr->lstm_p;
       if (lp == 0.0f || lp == 1.0f) pf = lp;               // predictor.cpp:383,415-417
@@ -1115,6 +1121,91 @@ __device__ void helper_role(MixState* S, SpecXfer* X, HelperLds* H, int nbits, i
   }
 }
 
+// ------------------------------------------------------------------ scout, split (main workgroup of cmx_mixnet_spec_kernel)
+// The one-wave scout needs ~18 k clocks per bit (three memory round trips for the 2078 inputs -- load, logit table, publish -- and
+// two more for the row selection), more than a whole bit of the helpers. Only Mixer::GetContextData is stateful; the stretch of a
+// bit's inputs depends on nothing, so four stretch waves take the bits round robin (each bit still costs its ~12 k clocks, four
+// are in flight) and one select wave follows them in order.
+__device__ void stretch_role(MixState* S, const Lds& L, SpecXfer* X, const float* probs, const uint8_t* bits, int nbits, int sw, int lane) {
+  const gptr<const float> lut = as_global(S->logit_lut);
+  const gptr<const float> gprobs = as_global(probs);
+  const float smin = S->stretch_min, smax = S->stretch_max;
+  for (int t = sw; t < nbits; t += 4) {
+    if (t >= L.lead && !wait_ge(L.ctl, &L.ctl->consumed, 4 * (t - L.lead) + 1, true)) return;   // the gather wave has begun bit t - lead
+    if (t >= L.rr && !wait_ge(L.ctl, &L.ctl->tail_done, t - L.rr + 1, true)) return;             // rec slot t % rr is free (see scout_role)
+    BitRec* rec = L.rec + (t % L.rr);
+    const gptr<const float> pr = gprobs + (size_t)t * CMX_IN0;
+    float pv[33];
+#pragma unroll
+    for (int r = 0; r < 33; ++r) {
+      int i = r * 64 + lane;
+      pv[r] = i < CMX_IN0 ? pr[i] : 0.5f;
+    }
+    const int bitv = bits[t];
+    const float lstm_raw = bcast_lane(pv[32], 29);   // probs[t][2077]
+#pragma unroll
+    for (int r = 0; r < 33; ++r) {   // MixerInput::SetInput (mixer-input.cpp:11-15) + Sigmoid::Logit (sigmoid.cpp:12-17)
+      float p = pv[r];
+      if (p < 1.0e-4f) p = 1.0e-4f;
+      else if (p > 1 - 1.0e-4f) p = 1 - 1.0e-4f;
+      int idx = (int)(p * 100001.0f);
+      if (idx >= 100001) idx = 100000;
+      else if (idx < 0) idx = 0;
+      pv[r] = lut[idx];
+    }
+    float* gx = X->xs[t % CMX_SPEC_RING];
+#pragma unroll
+    for (int r = 0; r < 33; ++r) {
+      int i = r * 64 + lane;
+      if (i < CMX_IN0) __hip_atomic_store(gx + i, pv[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const float ax0 = bcast_lane(pv[6], 49), ax1 = bcast_lane(pv[31], 40), ax2 = bcast_lane(pv[32], 29);   // columns 433, 2024, 2077
+    if (lane < 3) {
+      float v = lane == 0 ? ax0 : lane == 1 ? ax1 : ax2;
+      if (v > smax) v = smax;
+      else if (v < smin) v = smin;
+      rec->aux3[lane] = v;
+    } else if (lane == 3) {  // predictor.cpp:388-393
+      float avg = 0;
+      avg = fadd(avg, cmx_logistic(ax0));
+      avg = fadd(avg, cmx_logistic(ax1));
+      avg = fadd(avg, cmx_logistic(ax2));
+      avg = avg / 3.0f;
+      rec->auxkey = (uint32_t)(unsigned long long)(avg * 15);
+      rec->lstm_p = lstm_raw;
+      rec->bit = bitv;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the ring slot and the record are complete
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) st_rel(&L.sdone[t % L.rr], t + 1);
+  }
+}
+
+__device__ void select_role(MixState* S, const Lds& L, SpecXfer* X, const uint32_t* sel, int nbits, int lane) {
+  const gptr<const uint32_t> gsel = as_global(sel);
+  for (int t = 0; t < nbits; ++t) {
+    uint32_t key = lane < CMX_MIXERS ? gsel[(size_t)t * CMX_MIXERS + lane] : 0;
+    if (!wait_ge(L.ctl, &L.sdone[t % L.rr], t + 1, true)) return;
+    BitRec* rec = L.rec + (t % L.rr);
+    const BitRec* prev = L.rec + ((t + L.rr - 1) % L.rr);
+    if (lane == CMX_AUX) key = rec->auxkey;
+    if (lane < CMX_MIXERS) {
+      uint32_t r = select_row(S, lane, key);
+      rec->rowidx[lane] = r;
+      const uint32_t chg = (t == 0) || (r != prev->rowidx[lane]);
+      if (lane < CMX_MIX0) {
+        rec->changed[lane] = chg;
+        __hip_atomic_store(&X->rowidx[t % CMX_SPEC_RING][lane], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&X->changed[t % CMX_SPEC_RING][lane], chg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) __hip_atomic_store(&X->scout_epoch, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    st_rel(&L.ctl->scout_epoch, t + 1);
+  }
+}
+
 // ------------------------------------------------------------------ gather (main workgroup, wave 0)
 // chain_role with the 26 ordered sums arriving from the helpers instead of being added up here.
 __device__ void gather_role(MixState* S, const Lds& L, SpecXfer* X, const float* decay1, int nbits,
@@ -1155,7 +1246,8 @@ __device__ void gather_role(MixState* S, const Lds& L, SpecXfer* X, const float*
   // a row that changes comes from a different row than the current one, whose last stores this wave issued earlier (in order)
   float4 ewn[7];
   uint64_t rsn = 0;
-  int pf_t = -1;
+  int pf_t = -1, d1_t = -1;
+  float d1n = 0.0f;
 #pragma unroll
   for (int i = 0; i < 7; ++i) ewn[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   for (int t = 0; t < nbits; ++t) {
@@ -1184,7 +1276,7 @@ __device__ void gather_role(MixState* S, const Lds& L, SpecXfer* X, const float*
       for (int i = 0; i < 28; ++i)
         if (i >= m) ew[i] = 0.0f;
     }
-    const double d1 = (double)as_global(decay1)[t];
+    const double d1 = (double)(d1_t == t ? d1n : as_global(decay1)[t]);  // (float)(0.9/pow(1e-7*steps_+0.8,0.8)), host libm; fetched a bit ahead
     const float decay = (float)(d1 * (1.5 - ((1.0 * (double)rsteps) / (double)mx)));   // mixer.cpp:58-60
     const float dlr = fmul(decay, lr);
     GPROF(1);
@@ -1241,6 +1333,7 @@ __device__ void gather_role(MixState* S, const Lds& L, SpecXfer* X, const float*
         ew[j] = v;
       }
     }
+    if (t + 1 < nbits) { d1n = as_global(decay1)[t + 1]; d1_t = t + 1; }
     if (t + 1 < nbits && lds_poll(&L.ctl->scout_epoch) >= t + 2) {
       const BitRec* nx = L.rec + ((t + 1) % L.rr);
       if (is0 && nx->changed[mm]) {
@@ -1281,7 +1374,7 @@ extern "C" __global__ __launch_bounds__(NTHREADS) void cmx_mixnet_chunk_kernel(
   L.prod = smem;                                                  // 2 * PBUF
   L.xs = L.prod + 2 * PBUF;                                       // 3 * XS
   L.rec = reinterpret_cast<BitRec*>(L.xs + 3 * XS);               // 3
-  L.rr = 3; L.lead = 2;
+  L.rr = 3; L.lead = 2; L.lst = nullptr; L.lsq = nullptr; L.sdone = nullptr;
   L.trec = reinterpret_cast<TailRec*>(L.rec + 3);                 // 2
   L.upd = reinterpret_cast<float*>(L.trec + 2);                   // 32
   L.dflag = reinterpret_cast<uint32_t*>(L.upd + 32);              // 32
@@ -1323,14 +1416,14 @@ extern "C" __global__ __launch_bounds__(CMX_SPEC_THREADS) void cmx_mixnet_spec_k
     HelperLds* H = reinterpret_cast<HelperLds*>(smem);
     for (int i = tid; i < (int)(sizeof(HelperLds) / 4); i += CMX_SPEC_THREADS) reinterpret_cast<int*>(H)[i] = 0;
     __syncthreads();
-    helper_role(S, X, H, nbits, (int)blockIdx.x - 1, wave, lane);
+    if (wave < 4) helper_role(S, X, H, nbits, (int)blockIdx.x - 1, wave, lane);
     return;
   }
   Lds L;
   L.prod = smem;                                                  // unused here (no producers): 16 floats
-  L.xs = L.prod + 16;                                             // 3 * XS
-  L.rec = reinterpret_cast<BitRec*>(L.xs + 3 * XS);               // 8: the scout runs up to 4 bits ahead of the gather wave
-  L.rr = 8; L.lead = 4;
+  L.xs = L.prod;                                                  // unused (the inputs go to the helpers through the global ring)
+  L.rec = reinterpret_cast<BitRec*>(L.prod + 16);                 // 8: the scout waves run up to 5 bits ahead of the gather wave
+  L.rr = 8; L.lead = 5;
   L.trec = reinterpret_cast<TailRec*>(L.rec + 8);                 // 2
   L.upd = reinterpret_cast<float*>(L.trec + 2);                   // 32
   L.dflag = reinterpret_cast<uint32_t*>(L.upd + 32);              // 32
@@ -1340,14 +1433,19 @@ extern "C" __global__ __launch_bounds__(CMX_SPEC_THREADS) void cmx_mixnet_spec_k
   L.w2 = reinterpret_cast<float*>(L.ctl) + 16 + 64;
   L.w1 = L.w2 + 64 + 16 + 64;
   L.exptab = reinterpret_cast<uint64_t*>(L.w1 + 20 * 68);
-  for (int i = tid; i < 3 * XS; i += CMX_SPEC_THREADS) L.xs[i] = 0.0f;
+  L.sdone = reinterpret_cast<int*>(L.exptab + 32);                // 8
+  uint16_t* lst = reinterpret_cast<uint16_t*>(L.sdone + 8);       // 2 x 32768 u16: the SSE's t_st / t_sq on chip
+  L.lst = lst; L.lsq = lst + 32768;
+  for (int i = tid; i < 32768; i += CMX_SPEC_THREADS) reinterpret_cast<uint32_t*>(lst)[i] = i < 16384 ? reinterpret_cast<const uint32_t*>(S->t_st)[i] : reinterpret_cast<const uint32_t*>(S->t_sq)[i - 16384];
   if (tid < 32) { L.upd[tid] = 0.0f; L.dflag[tid] = 0; L.exptab[tid] = cmx_exp2f_tab[tid]; }
+  if (tid < 8) L.sdone[tid] = 0;
   if (tid < (int)(sizeof(Ctl) / 4)) reinterpret_cast<int*>(L.ctl)[tid] = 0;
   __syncthreads();
   const bool prof = (mode & 4) != 0;
   if (wave == 0) gather_role(S, L, X, decay1, nbits, mix_out, prof, lane);
   else if (wave == 1) tail_role(S, L, decay1, nbits, p_out, mix_out, lane, prof && ((mode >> 4) & 4) != 0);
-  else if (wave == 2) scout_role(S, L, probs, sel, bits, nbits, lane, prof && ((mode >> 4) & 2) != 0, X);
+  else if (wave == 2) select_role(S, L, X, sel, nbits, lane);
+  else if (wave >= 4) stretch_role(S, L, X, probs, bits, nbits, wave - 4, lane);
   __syncthreads();
   if (tid == 0 && (L.ctl->abort || ld_u32(&X->fail))) S->error = 1;
 }

@@ -76,7 +76,7 @@ struct MixState {
 #define CMX_SPEC_RING 8        /* bits the scout may publish ahead (it is held to 2 ahead of the gather wave) */
 #define CMX_SPEC_XS 2112       /* stretched inputs of a bit, zero padded (2078 used) */
 #define CMX_SPEC_HELPERS CMX_MIX0
-#define CMX_SPEC_THREADS 256
+#define CMX_SPEC_THREADS 512      /* main: gather, tail, select, -, 4 stretch waves; helpers use the first four */
 struct SpecXfer {
   unsigned scout_epoch;        // bits whose inputs / rows the scout has published
   unsigned fail;               // sticky: a bounded in-launch wait ran out
@@ -89,7 +89,7 @@ struct SpecXfer {
   unsigned long long stat[8];  // [0] speculative segments run, [1] of them resolved from a candidate lane, [2..4] misses of segment 1..3
 };
 #define CMX_SPEC_HEADER_BYTES (64 + 2 * 32 * 8)   /* what the host clears ahead of every launch (epochs and tags restart at 0) */
-#define CMX_SPEC_LDS_BYTES 49152
+#define CMX_SPEC_LDS_BYTES 147456  /* main workgroup: 128 KB of SSE tables + records; a helper uses 9 KB of it */
 
 // dynamic LDS of cmx_mixnet_chunk_kernel (see the carve-up in mixnet_chunk.hip)
 #define CMX_CHUNK_LDS_BYTES 163840   /* the whole 160 KB LDS of a gfx950 CU: one workgroup per CU */
