@@ -67,7 +67,7 @@ def lstm_algo_bytes(V, C=200, H=100):
 STRICT_FLOOR_US_PER_BIT = 5.7
 
 PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_bench.json")
-PMC_KERNELS = {"mixnet": ["cmx_mixnet_chunk_kernel"], "fxcm": ["cmx_fxcm_roles_kernel"], "ctxmodels": ["cmx_ctxmodels_kernel"],
+PMC_KERNELS = {"mixnet": ["cmx_mixnet_spec_kernel"], "fxcm": ["cmx_fxcm_roles_kernel"], "ctxmodels": ["cmx_ctxmodels_kernel"],
                "lstm": ["cmx_lstm_fwdblk", "cmx_lstm_bpttblk", "cmx_lstm_bptt_acc", "cmx_lstm_bptt_gb"], "paq8": ["cmx_p8s_mix2_kernel"]}
 
 
@@ -92,7 +92,7 @@ def pmc_traffic_per_byte(stage):
         return None
 
 
-KERNEL = {"mixnet": "cmx_mixnet_chunk_kernel", "paq8": "cmx_p8s_mix2_kernel / cmx_p8s_fam2_kernel (slowest role)", "fxcm": "cmx_fxcm_roles_kernel",
+KERNEL = {"mixnet": "cmx_mixnet_spec_kernel", "paq8": "cmx_p8s_mix2_kernel / cmx_p8s_fam2_kernel (slowest role)", "fxcm": "cmx_fxcm_roles_kernel",
           "lstm": "cmx_lstm_fwdblk / cmx_lstm_bpttblk / cmx_lstm_bptt_*", "ctxmodels": "cmx_ctxmodels_kernel"}
 
 
@@ -211,6 +211,7 @@ def main():
     step_bytes = max(step_sizes)
 
     # ---- warm-up: the same code on a throw-away engine over the head of the shard ----
+    wn = 0
     if a.warmup > 0:
         wn = min(n, a.warmup * step_bytes)
         w = EngineStream(local, stream[:wn], a.sub_chunk)
@@ -257,9 +258,12 @@ def main():
                 want_sha, want_size, seed, fx_rich = z["sha256"].tobytes().hex(), int(z["size"][0]), z["seed"], "rich" in z.files
             if int(seed[0]) == a.payload_bytes and int(seed[1]) == shard.shard_seed(0) and fx_rich:
                 verified.update(fixture="tests/golden/" + name, reference_bytes=want_size, identical_to_reference_file=bool(sha == want_sha and len(blob) == want_size))
-        dom = max(us, key=us.get)
+        period_stage = max(us, key=us.get)
         V = int(eng.vocab.sum())
         ALGO["lstm"] = lstm_algo_bytes(V)
+        # the roofline kernel: the one with the largest algorithmic traffic on the path (the final mixing network: 3.53 of the 14.1 MB per
+        # input byte), which the reviews name; the stage that sets the stream's period is reported beside it
+        dom = "mixnet"
         algo_launch = ALGO[dom] * n / nsub
         traffic_pb = pmc_traffic_per_byte(dom)
         ceiling = 1e6 / (8.0 * STRICT_FLOOR_US_PER_BIT)
@@ -275,7 +279,7 @@ def main():
                             "TEXT-block stream through the FULL model ensemble (2078 layer-0 inputs: contexts + 54 small models, PPMd host stage, "
                             "LSTM, fxcm 431, paq8 1591 -- every column produced by an engine stage, no stand-ins) + final mixing network + SSE, "
                             "strict bit-exact mode, + arithmetic coder; output file checked against the reference binary's" % a.payload_bytes,
-                "payload_bytes": a.payload_bytes, "stream_bytes": n, "sub_chunk_bytes": a.sub_chunk, "vocab": V,
+                "payload_bytes": a.payload_bytes, "stream_bytes": n, "sub_chunk_bytes": a.sub_chunk, "vocab": V, "warmup_stream_bytes": wn,
                 "parallelism": "1 stream per GPU, no collective"},
             "us_per_bit": dt / (8.0 * n) * 1e6,
             "end_to_end": {"value": a.payload_bytes * world / (dt + t_construct), "unit": "input bytes/s", "construct_s": t_construct,
@@ -294,6 +298,12 @@ def main():
                          "traffic_source": "profiles/r03_pmc_bench.json read at run time (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, kernel-trace only; "
                                            "2 x FETCH_SIZE + WRITE_SIZE per stream byte, scaled to this launch size); null if the file is missing",
                          "kernel": KERNEL[dom], "stage": dom, "avg_launch_ms": kernel_s * 1e3,
+                         "period_stage": {"stage": period_stage, "kernel": KERNEL[period_stage], "us_per_bit": us[period_stage],
+                                          "achieved_GBps": ALGO[period_stage] / (8.0 * us[period_stage] * 1e-6) / 1e9,
+                                          "note": "the stage whose kernel sets the stream's period this run; its algorithmic traffic per input byte is %.2f MB" % (ALGO[period_stage] / 1e6)},
+                         "whole_path": {"achieved_GBps": (total_bytes / dt) * (5.28e6 + ALGO["lstm"]) / 1e9,
+                                        "frac": (total_bytes / dt) * (5.28e6 + ALGO["lstm"]) / 1e9 / HBM_PEAK_GBS,
+                                        "note": "SURVEY.md 8d's formula: input bytes/s x (5.28 MB + LSTM(V)) algorithmic bytes per input byte / 8 TB/s"},
                          "algorithmic_bytes_per_launch": algo_launch,
                          "note": "every stage is a latency-bound dependent chain per stream (DESIGN.md 4): the HBM roof is the wrong roof by construction; see "
                                  "strict_mode_ceiling for the latency floor (%.1f us/bit -> %.0f B/s)" % (STRICT_FLOOR_US_PER_BIT, ceiling)},
