@@ -13,8 +13,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libcmixamd.so")
 OBJ = os.path.join(HERE, "lib", "obj")
 SOURCES = ["cmx_api.hip", "mixnet_kernels.hip", "mixnet_chunk.hip", "lstm_api.hip", "lstm_kernels.hip", "lstm_block.hip",
-           "ctxmodels_api.hip", "ctxmodels_kernels.hip", "ppmd_host.cpp", "pipeline_api.hip", "coder_host.cpp", "engine_api.hip", "p8mixer.hip",
-           "fxcm_stage.hip", "fxcm_parser_host.cpp", "p8cm2.hip", "p8cm.hip", "p8dmc.hip", "p8match.hip", "p8stage.hip"]
+           "ctxmodels_api.hip", "ctxmodels_kernels.hip", "ppmd_host.cpp", "pipeline_api.hip", "coder_host.cpp", "engine_api.hip",
+           "fxcm_stage.hip", "fxcm_parser_host.cpp", "p8stage.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wno-unused-value"]
 # the paq8 stage's host front end: plain C (gcc), every allocation tracked through the force-included p8f_alloc.h
 FRONT_DIR = os.path.join(CSRC, "p8front")

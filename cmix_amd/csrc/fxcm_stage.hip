@@ -3,8 +3,8 @@
 // :462-468). Two halves:
 //   * host:   the text parser (fxcm_parser_host.cpp) turns the chunk's bytes into one FxByteRec per byte on the calling
 //             thread, written to page-locked memory and copied to the device on the stage's stream;
-//   * device: cmx_fxcm_chunk_kernel, ONE persistent workgroup per stream, walks the chunk's bits through the learned
-//             tables (fxcm_dev.h: the phases, argued there). State: ~4.4 GB of HBM per stream (3.7 GB context-map
+//   * device: cmx_fxcm_roles_kernel, THREE persistent workgroups per stream (context maps / units / mixers + APM chain), walks
+//             the chunk's bits through the learned tables (fxcm_dev.h: the phases, argued there). State: ~4.4 GB of HBM per stream (3.7 GB context-map
 //             buckets, 0.3 GB mixer rows, 60 MB APM cells, 70 MB match / run tables).
 // Bound: latency (a map lane walks up to 7 dependent bucket probes per bit); the kernel's HBM traffic is ~0.2 MB per
 // input byte algorithmic (SURVEY.md 8d iii + iv). Parity: tests/test_fxcm_stage_host.py runs this kernel's body on the
@@ -61,40 +61,14 @@ __device__ __forceinline__ void fx_train_rows_fast(FxDev* d, FxShared* sh, const
   }
 }
 
-// Phase 1a on the device. The step functions are the ones fxd_phase1a calls (tests/host/fxcm_emul.cpp runs that), but the
-// units get wavefronts of their own: lanes of one wavefront that take different branches run one branch after the other,
-// so 81 context lanes + 7 SSCMs + the match lane + the run map + 6 APMs in two wavefronts cost the SUM of their chains.
-//   waves 0-1  lanes 0..80: context slots (bucket lists + overlap hash)
-//   waves 2-3  the 128 trainer lanes (vector loads, packed math)
-//   wave 4     MatchModel2: lane 0 the candidates, then lanes 0..2 one StateMap1 each; lane 0 the sparse model
-//   wave 5     lanes 0..6 the SmallStationaryContextMaps
-//   wave 6     lane 0 run map, lane 1 LSTM input, lanes 2-3 training of mixers 10 / 11
-//   wave 7     lanes 0..5 APM cell updates
+// The step functions are the ones fxd_phase1a .. fxd_phase5 call (tests/host/fxcm_emul.cpp runs those), but the units get wavefronts
+// of their own: lanes of one wavefront that take different branches run one branch after the other, so context lanes, SSCMs, the
+// match lane, the run map, trainers and APMs sharing wavefronts would cost the SUM of their chains (role assignment: cmx_fxcm_roles_kernel).
 enum { FX_DEV_THREADS = 512 };
 // a workgroup barrier that orders LDS traffic only (no wait for outstanding global loads / stores, which __syncthreads adds)
 __device__ __forceinline__ void fx_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 struct FxApmRows;
 __device__ __forceinline__ void fx_apm_prefetch(FxDev* d, const FxShared* sh, const FxBit& u, FxApmRows* A, int j);
-__device__ __forceinline__ void fx_phase1a_dev(FxDev* d, FxShared* sh, const FxBit& u, FxApmRows* A, int tid) {
-  const int wave = tid >> 6, lane = tid & 63;
-  if (wave < 2) { if (tid < FX_NSLOTS) fxd_map_touch(d, sh, u, tid); }
-  else if (wave < 4) fx_train_rows_fast(d, sh, u, tid - 128);
-  else if (wave == 4) {
-    if (lane == 0) {
-      if (u.boundary) { d->buffer[(uint32_t)d->pos & FX_BMASK] = (uint8_t)u.lastbyte; d->pos++; }   // fxd_match_unit's first line (:3806-3807)
-      fxd_match2(d, sh, u, sh->tx[sh->parity ^ 1] + 2 * FX_NSSCM, u.orow + FX_NSSCM, &sh->isMatch);
-    }
-    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the contexts are in LDS
-    __builtin_amdgcn_wave_barrier();
-    if (lane < 3) fxd_match2_sm(d, sh, u, lane);
-    if (lane == 0) fxd_sparse(d, u, sh->tx[sh->parity ^ 1] + 2 * FX_NSSCM + 7, u.orow + FX_NSSCM + 7);
-  } else if (wave == 5) { if (lane < FX_NSSCM) fxd_sscm_unit(d, sh, u, lane); }
-  else if (wave == 6) {
-    if (lane == 0) fxd_rcm_unit(d, sh, u);
-    else if (lane == 1) { const FxLayout l = fxd_layout(d, u.normal); sh->tx[sh->parity ^ 1][l.tx_lstm] = d->stretch[u.lstmpr]; }
-    else if (lane == 2 || lane == 3) fxd_train_small(d, sh, u, 10 + lane - 2);
-  } else if (lane < 6) { fxd_apm_update(d, sh, u, lane); fx_apm_prefetch(d, sh, u, A, lane); }
-}
 
 // ---- phase 2 on the device, split (same values as fxd_phase2): part A needs nothing from the context maps -- the failure
 // history (update1 :4784-4790), the dead zones and the selectors without an order term -- and runs on one lane of wave 4
@@ -297,10 +271,6 @@ __device__ __forceinline__ void fx_phase5_dev(FxDev* d, FxShared* sh, const FxBi
   sh->parity ^= 1;
 }
 
-__device__ __forceinline__ void fx_phase3_dev(FxDev* d, FxShared* sh, const FxBit& u, int tid) {
-  fxd_map_clear_next(sh, u, tid);
-  fx_phase3_dots(d, sh, u, tid);
-}
 
 // Everything the bit loop reads lives in LDS: FxShared (inputs, StateMaps, per-context registers), a working COPY of the
 // stream's FxDev (map descriptors, unit registers, scalars: the step functions read them through `d` many times per bit,
@@ -316,73 +286,8 @@ struct FxLocal {
   FxApmRows apm;
   float ex[2][FX_OUTPUTS + 1];   // the bit's 431 exported values (two parities: the copy-out of bit q runs under bit q + 1): the units write here, one coalesced copy per bit goes to the output row
 };
-// PROF: per-phase clocks of thread 0 accumulated into prof[0..7] (CMX_FXCM_PROFILE=1, scripts/gpu_fxcm_time.py)
-template <bool PROF>
-__global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_chunk_kernel_t(FxDev* gd, const uint8_t* bytes, const FxByteRec* recs, const int16_t* lstmpr,
-                                                                      const uint8_t* lstmex, float* out, long ostride, int n, unsigned long long* prof) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char fx_smem[];   // sizeof(FxShared) + sizeof(FxLocal) > 64 KB: dynamic
-  FxShared& sh = *(FxShared*)fx_smem;
-  FxLocal& loc = *(FxLocal*)(fx_smem + ((sizeof(FxShared) + 15) & ~(size_t)15));
-  FxDev* d = &loc.dev;
-  __shared__ int res8_s[8], scr_s[16];
-  const int tid = threadIdx.x;
-  for (int i = tid; i < (int)(sizeof(FxDev) / 4); i += FX_DEV_THREADS) ((uint32_t*)d)[i] = ((const uint32_t*)gd)[i];
-  for (int i = tid; i < 4095; i += FX_DEV_THREADS) loc.squash[i] = gd->squash[i];
-  for (int i = tid; i < 4096; i += FX_DEV_THREADS) loc.stretch[i] = gd->stretch[i];
-  for (int i = tid; i < 512; i += FX_DEV_THREADS) loc.wrt[i] = gd->wrt[i];
-  for (int i = tid; i < 6 * 1024; i += FX_DEV_THREADS) loc.sta[i >> 10][i & 1023] = gd->sta[i >> 10][i & 1023];
-  __syncthreads();
-  if (tid == 0) { d->squash = loc.squash; d->stretch = loc.stretch; d->wrt = loc.wrt; }
-  if (tid < FX_NMAPS) for (int q = 0; q < 6; q++) if (gd->maps[tid].nn == gd->sta[q]) d->maps[tid].nn = loc.sta[q];
-  const int nbits = 8 * n, blpos0 = d->blpos, lastbyte0 = d->lastbyte, have0 = d->have_rec;
-  if (tid < FX_THREADS) fxd_load_shared(d, &sh, tid);
-  for (int i = tid; i < FX_OUTPUTS; i += FX_DEV_THREADS) out[i] = d->pending[i];   // row 0: what the previous chunk's last update left
-  __syncthreads();
-  unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c0 = 0;
-#define FX_TICK(k) do { if (PROF && (tid & 63) == 0) { const unsigned long long c1 = __builtin_readcyclecounter(); acc[k] += c1 - c0; c0 = c1; } } while (0)
-  if (PROF && (tid & 63) == 0) c0 = __builtin_readcyclecounter();
-  for (int q = 0; q < nbits; q++) {
-    FxBit u = fxd_bit(d, bytes, recs, lstmpr, lstmex, out, ostride, nbits, q, blpos0, lastbyte0, have0);
-    {   // the record in force: the LDS copy (made during the previous update), and the next one on its way
-      const int b = q >> 3, ri = u.boundary ? b : b - 1;
-      if (ri >= 0) u.rec = &loc.rec[ri & 1];
-      if ((q & 7) == 6 && tid >= 128 && tid - 128 < (int)(sizeof(FxByteRec) / 4)) ((uint32_t*)&loc.rec[b & 1])[tid - 128] = ((const uint32_t*)&recs[b])[tid - 128];
-    }
-    float* const real_row = u.orow;
-    u.orow = loc.ex[q & 1];
-    fx_phase1a_dev(d, &sh, u, &loc.apm, tid);
-    FX_TICK(0);
-    // the one full barrier of the bit: every wave's table stores (write-through state bytes, trained rows, APM cells) are
-    // complete before another lane may read them (serial walks in 1c, rows in 3, APM cells in 5)
-    __syncthreads(); FX_TICK(1);
-    if (tid < FX_THREADS) fxd_phase1c(d, &sh, u, tid);
-    else if (tid == 256) fx_phase2a_dev(d, &sh, u);   // wave 4, under the maps
-    FX_TICK(7);
-    fx_lds_barrier(); FX_TICK(2);
-    if (tid < 64) fx_phase2b_dev(d, &sh, u, tid, res8_s);
-    fx_lds_barrier(); FX_TICK(3);
-    if (tid < FX_THREADS) fx_phase3_dev(d, &sh, u, tid);
-    fx_lds_barrier(); FX_TICK(4);
-    if (tid < FX_THREADS) fxd_phase4(d, &sh, u, tid);
-    fx_lds_barrier(); FX_TICK(5);
-    if (tid < 64) fx_phase5_dev(d, &sh, u, &loc.apm, tid, scr_s);
-    fx_lds_barrier(); FX_TICK(6);
-    for (int i = tid; i < FX_OUTPUTS; i += FX_DEV_THREADS) real_row[i] = loc.ex[q & 1][i];
-  }
-#undef FX_TICK
-  if (tid < FX_THREADS) fxd_store_shared(d, &sh, tid);
-  if (tid == 0) {
-    d->blpos = blpos0 + n; d->lastbyte = bytes[n - 1]; d->have_rec = 1; d->rec = n >= 1 ? loc.rec[(n - 1) & 1] : d->rec;
-    d->squash = gd->squash; d->stretch = gd->stretch; d->wrt = gd->wrt;   // home pointers
-  }
-  if (tid < FX_NMAPS) d->maps[tid].nn = gd->maps[tid].nn;
-  __syncthreads();
-  for (int i = tid; i < (int)(sizeof(FxDev) / 4); i += FX_DEV_THREADS) ((uint32_t*)gd)[i] = ((const uint32_t*)d)[i];
-  if (PROF && (tid & 63) == 0) for (int k = 0; k < 8; k++) prof[(tid >> 6) * 8 + k] += acc[k];
-}
-
 // =====================================================================================================================
-// The same stage on THREE workgroups (the default). Nothing the context maps, the match models, the SSCMs or the run map
+// The stage on THREE workgroups. Nothing the context maps, the match models, the SSCMs or the run map
 // learn depends on the mixers or on the final probability -- only on the byte stream -- so the bit's work splits into
 // three roles that run on three compute units, each with its own LDS state, coupled only by the rows they hand over:
 //   role M  (block 0) the 31 context maps: touch -> run; publishes its 5..6 inputs per context, the eight return-value
@@ -447,9 +352,13 @@ __device__ __forceinline__ void fx_stage_ahead(FxAhead* ah, FxLocal* loc, const 
 }
 
 __global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_roles_kernel(FxDev* gd, FxXfer* X, unsigned* rows, const uint8_t* bytes, const FxByteRec* recs,
-                                                                         const int16_t* lstmpr, const uint8_t* lstmex, float* out, long ostride, int n) {
+                                                                         const int16_t* lstmpr, const uint8_t* lstmex, float* out, long ostride, int n,
+                                                                         unsigned long long* prof) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fx_smem[];
   FxShared& sh = *(FxShared*)fx_smem;
+  // CMX_FXCM_PROFILE=1: thread 0 of each role accumulates its clocks per phase: prof[16 role + k] (scripts/gpu_fxcm_time.py)
+  unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pc0 = __builtin_readcyclecounter();
+#define FX_TICK(k) do { if (prof && threadIdx.x == 0) { const unsigned long long c_ = __builtin_readcyclecounter(); pacc[k] += c_ - pc0; pc0 = c_; } } while (0)
   FxLocal& loc = *(FxLocal*)(fx_smem + ((sizeof(FxShared) + 15) & ~(size_t)15));
   FxDev* d = &loc.dev;
   __shared__ int res8_s[8], scr_s[16];
@@ -486,17 +395,23 @@ __global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_roles_kernel(FxDev* g
       u.orow = loc.ex[0];
       if (tid < FX_NSLOTS) fxd_map_touch(d, &sh, u, tid);
       else if (wave == 3) fx_stage_ahead(&ah, &loc, bytes, recs, lstmpr, lstmex, n, q, lane);
+      FX_TICK(0);
       // the full barrier of the bit: the previous run's table stores are complete before a serial walk may read them
       __syncthreads();
+      FX_TICK(1);
       if (tid < FX_THREADS) fxd_phase1c(d, &sh, u, tid);
+      FX_TICK(2);
       fx_lds_barrier();
+      FX_TICK(3);
       if (tid < FX_THREADS) {
         fxd_map_clear_next(&sh, u, tid);
         if (u.normal) fx_st_u(row + tid, reinterpret_cast<const uint32_t*>(sh.tx[1])[tid]);
       } else if (tid < FX_THREADS + 8) fx_st_u(row + FX_ROW_RES + (tid - FX_THREADS), (unsigned)fx_res8(d, &sh, u, tid - FX_THREADS));
       if (u.normal) for (int i = FX_NSSCM + 9 + tid; i < ln.exp_rcm; i += FX_DEV_THREADS) real_row[i] = loc.ex[0][i];
+      FX_TICK(4);
       __syncthreads();   // every store of the row is complete
       if (tid == 0) fx_st_u(&X->m_done, (unsigned)(q + 1));
+      FX_TICK(5);
     } else if (role == 1) {
       // ================= role U: match models, SSCMs, run map, LSTM input =================
       u.orow = loc.ex[0];
@@ -515,14 +430,18 @@ __global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_roles_kernel(FxDev* g
         if (lane == 0) fxd_rcm_unit(d, &sh, u);
         else if (lane == 1) txn[l.tx_lstm] = d->stretch[u.lstmpr];
       } else if (wave == 3) fx_stage_ahead(&ah, &loc, bytes, recs, lstmpr, lstmex, n, q, lane);
+      FX_TICK(0);
       fx_lds_barrier();
+      FX_TICK(1);
       if (tid < 12) fx_st_u(row + FX_ROW_UTX + tid, reinterpret_cast<const uint32_t*>(txn)[tid]);
       else if (tid == 12) fx_st_u(row + FX_ROW_UTX + 12, (uint32_t)(uint16_t)txn[l.tx_rcm] | ((uint32_t)(uint16_t)txn[l.tx_lstm] << 16));
       else if (tid == 13) fx_st_u(row + FX_ROW_MATCH, (unsigned)sh.isMatch);
       else if (tid >= 64 && tid < 64 + FX_NSSCM + 9) real_row[tid - 64] = loc.ex[0][tid - 64];
       else if (tid >= 128 && tid < 130) real_row[l.exp_rcm + (tid - 128)] = loc.ex[0][l.exp_rcm + (tid - 128)];
+      FX_TICK(2);
       __syncthreads();
       if (tid == 0) fx_st_u(&X->u_done, (unsigned)(q + 1));
+      FX_TICK(3);
     } else {
       // ================= role X: trainers, selectors, mixers, APM chain =================
       u.orow = loc.ex[q & 1];
@@ -530,7 +449,9 @@ __global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_roles_kernel(FxDev* g
         if (have_m < (unsigned)(q + 1)) { fx_wait_ge(&X->m_done, (unsigned)(q + 1), &X->fail); have_m = fx_ld_u(&X->m_done); }
         if (have_u < (unsigned)(q + 1)) { fx_wait_ge(&X->u_done, (unsigned)(q + 1), &X->fail); have_u = fx_ld_u(&X->u_done); }
       }
+      FX_TICK(0);
       fx_lds_barrier();
+      FX_TICK(1);
       {   // the bit's inputs: the maps' range from M's row, the units' from U's
         int16_t* txn = sh.tx[sh.parity ^ 1];
         if (tid < FX_THREADS) {
@@ -555,21 +476,29 @@ __global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_roles_kernel(FxDev* g
       else if (wave == 6) { if (lane == 2 || lane == 3) fxd_train_small(d, &sh, u, 10 + lane - 2); }
       else if (wave == 7) { if (lane < 6) { fxd_apm_update(d, &sh, u, lane); fx_apm_prefetch(d, &sh, u, &loc.apm, lane); } }
       else if (wave == 5) fx_stage_ahead(&ah, &loc, bytes, recs, lstmpr, lstmex, n, q, lane);
+      FX_TICK(2);
       // the full barrier of the bit: the trained rows and APM cells are stored before phase 3 / 5 read them
       __syncthreads();
+      FX_TICK(3);
       if (tid == 0) fx_phase2b_tail(d, &sh, u, res8_s);
       else if (tid == 256) fx_phase2a_dev(d, &sh, u);
       fx_lds_barrier();
+      FX_TICK(4);
       if (tid < FX_THREADS) fx_phase3_dots(d, &sh, u, tid);
       fx_lds_barrier();
       if (tid < FX_THREADS) fxd_phase4(d, &sh, u, tid);
       fx_lds_barrier();
+      FX_TICK(5);
       if (tid < 64) fx_phase5_dev(d, &sh, u, &loc.apm, tid, scr_s);
       fx_lds_barrier();
+      FX_TICK(6);
       for (int i = l.exp_mix + tid; i < FX_OUTPUTS; i += FX_DEV_THREADS) real_row[i] = loc.ex[q & 1][i];
+      FX_TICK(7);
     }
   }
   __syncthreads();
+  if (prof && tid == 0) for (int k = 0; k < 8; k++) prof[16 * role + k] += pacc[k];
+#undef FX_TICK
   // ---- every role writes its own part of the stream's state back ----
   if (role == 0) {
     for (int i = tid; i < FX_NMAPS * 8; i += FX_DEV_THREADS) {
@@ -647,8 +576,7 @@ struct cmx_fxcm {
   bool used[FX_STAGE_BUFS] = {};
   int next = 0;
   uint64_t bytes_done = 0;
-  unsigned long long* d_prof = nullptr;   // CMX_FXCM_PROFILE=1: per-phase clocks (one-workgroup kernel)
-  bool v1 = false;                        // CMX_FXCM_V1=1: the one-workgroup kernel
+  unsigned long long* d_prof = nullptr;   // CMX_FXCM_PROFILE=1: thread 0's clocks per phase of each role (prof[16 role + k])
   FxXfer* d_xfer = nullptr;               // three-role kernel: hand-off counters and the rows M / U publish for X
   unsigned* d_rows = nullptr; size_t rows_cap = 0;
   hipStream_t s_up = nullptr; bool own_up = false;   // record uploads: a stream that never has a kernel in front of a copy (cmx_fxcm_set_upload_stream)
@@ -690,12 +618,9 @@ cmx_fxcm_t* cmx_fxcm_create(const char* dictionary_path, int device) {
   ok = ok && hipMalloc((void**)&h->d_dev, sizeof(FxDev)) == hipSuccess;
   ok = ok && hipMemcpy(h->d_dev, &host, sizeof(FxDev), hipMemcpyHostToDevice) == hipSuccess;
   for (int i = 0; ok && i < FX_STAGE_BUFS; i++) ok = hipEventCreateWithFlags(&h->done[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&h->ev_up[i], hipEventDisableTiming) == hipSuccess;
-  ok = ok && hipFuncSetAttribute((const void*)cmx_fxcm_chunk_kernel_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FX_LDS_BYTES) == hipSuccess;
-  ok = ok && hipFuncSetAttribute((const void*)cmx_fxcm_chunk_kernel_t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FX_LDS_BYTES) == hipSuccess;
   ok = ok && hipFuncSetAttribute((const void*)cmx_fxcm_roles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FX_LDS_BYTES) == hipSuccess;
   ok = ok && hipMalloc((void**)&h->d_xfer, sizeof(FxXfer)) == hipSuccess && hipMemset(h->d_xfer, 0, sizeof(FxXfer)) == hipSuccess;
   const char* prof = getenv("CMX_FXCM_PROFILE");
-  { const char* v = getenv("CMX_FXCM_V1"); h->v1 = (v && v[0] == '1') || (prof && prof[0] == '1'); }
   if (ok && prof && prof[0] == '1') ok = hipMalloc((void**)&h->d_prof, 512) == hipSuccess && hipMemset(h->d_prof, 0, 512) == hipSuccess;
   ok = ok && hipDeviceSynchronize() == hipSuccess;
   if (!ok) { cmx_set_err("cmx_fxcm_create: allocation / init failed (the stage needs ~4.4 GB of HBM)"); cmx_fxcm_destroy(h); return nullptr; }
@@ -728,23 +653,16 @@ int cmx_fxcm_run(cmx_fxcm_t* h, const uint8_t* bytes, const uint8_t* d_bytes, si
   if (!h->s_up) { if (hipStreamCreateWithFlags(&h->s_up, hipStreamNonBlocking) != hipSuccess) { cmx_set_err("cmx_fxcm_run: stream creation failed"); return 1; } h->own_up = true; }
   if (hipMemcpyAsync(h->d_recs[b], h->h_recs[b], nbytes * sizeof(FxByteRec), hipMemcpyHostToDevice, h->s_up) != hipSuccess ||
       hipEventRecord(h->ev_up[b], h->s_up) != hipSuccess || hipStreamWaitEvent(s, h->ev_up[b], 0) != hipSuccess) { cmx_set_err("cmx_fxcm_run: record upload failed"); return 1; }
-  if (!h->v1) {
-    if (h->rows_cap < nbytes) {   // grown between chunks: nothing of this stream may be in flight on the old buffer
-      if (hipDeviceSynchronize() != hipSuccess) { cmx_set_err("cmx_fxcm_run: device error"); return 1; }
-      if (h->d_rows) (void)hipFree(h->d_rows);
-      h->d_rows = nullptr; h->rows_cap = 0;
-      if (hipMalloc((void**)&h->d_rows, nbytes * 8 * FX_ROW_WORDS * 4) != hipSuccess) { cmx_set_err("cmx_fxcm_run: row buffer allocation failed"); return 1; }
-      h->rows_cap = nbytes;
-    }
-    if (hipMemsetAsync((char*)h->d_xfer + 16, 0, sizeof(FxXfer) - 16, s) != hipSuccess) { cmx_set_err("cmx_fxcm_run: hipMemsetAsync failed"); return 1; }
-    hipLaunchKernelGGL(cmx_fxcm_roles_kernel, dim3(3), dim3(FX_DEV_THREADS), FX_LDS_BYTES, s, h->d_dev, h->d_xfer, h->d_rows, d_bytes, h->d_recs[b], d_lstmpr, d_lstmex,
-                       d_probs + 3, (long)pstride, (int)nbytes);
-  } else if (h->d_prof)
-    hipLaunchKernelGGL(cmx_fxcm_chunk_kernel_t<true>, dim3(1), dim3(FX_DEV_THREADS), FX_LDS_BYTES, s, h->d_dev, d_bytes, h->d_recs[b], d_lstmpr, d_lstmex, d_probs + 3,
-                       (long)pstride, (int)nbytes, h->d_prof);
-  else
-    hipLaunchKernelGGL(cmx_fxcm_chunk_kernel_t<false>, dim3(1), dim3(FX_DEV_THREADS), FX_LDS_BYTES, s, h->d_dev, d_bytes, h->d_recs[b], d_lstmpr, d_lstmex, d_probs + 3,
-                       (long)pstride, (int)nbytes, (unsigned long long*)nullptr);
+  if (h->rows_cap < nbytes) {   // grown between chunks: nothing of this stream may be in flight on the old buffer
+    if (hipDeviceSynchronize() != hipSuccess) { cmx_set_err("cmx_fxcm_run: device error"); return 1; }
+    if (h->d_rows) (void)hipFree(h->d_rows);
+    h->d_rows = nullptr; h->rows_cap = 0;
+    if (hipMalloc((void**)&h->d_rows, nbytes * 8 * FX_ROW_WORDS * 4) != hipSuccess) { cmx_set_err("cmx_fxcm_run: row buffer allocation failed"); return 1; }
+    h->rows_cap = nbytes;
+  }
+  if (hipMemsetAsync((char*)h->d_xfer + 16, 0, sizeof(FxXfer) - 16, s) != hipSuccess) { cmx_set_err("cmx_fxcm_run: hipMemsetAsync failed"); return 1; }
+  hipLaunchKernelGGL(cmx_fxcm_roles_kernel, dim3(3), dim3(FX_DEV_THREADS), FX_LDS_BYTES, s, h->d_dev, h->d_xfer, h->d_rows, d_bytes, h->d_recs[b], d_lstmpr, d_lstmex,
+                     d_probs + 3, (long)pstride, (int)nbytes, h->d_prof);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { cmx_set_err(std::string("cmx_fxcm_run: ") + hipGetErrorString(e)); return 1; }
   if (hipEventRecord(h->done[b], s) != hipSuccess) { cmx_set_err("cmx_fxcm_run: event record failed"); return 1; }
@@ -753,7 +671,7 @@ int cmx_fxcm_run(cmx_fxcm_t* h, const uint8_t* bytes, const uint8_t* d_bytes, si
   return 0;
 }
 
-// CMX_FXCM_PROFILE=1: thread 0's clocks per barrier phase (1a, 1b, 1c, 2, 3, 4, 5) since creation
+// CMX_FXCM_PROFILE=1: thread 0's clocks per phase of each role since creation: out64[16 role + k], role 0 = M, 1 = U, 2 = X
 int cmx_fxcm_profile(cmx_fxcm_t* h, unsigned long long out64[64]) {
   if (!h || !h->d_prof) return 1;
   return hipMemcpy(out64, h->d_prof, 512, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;

@@ -19,11 +19,7 @@
 #include "lstm_state.h"
 #include "cmx_glibc_rand.h"
 
-extern "C" __global__ void cmx_lstm_setblk(LstmBlockArgs*, const LstmBlockArgs);
 extern "C" __global__ void cmx_lstm_prep(const LstmState, const float*, const uint8_t*, size_t, int, int);
-extern "C" __global__ void cmx_lstm_sgd(const LstmState, const float*, const uint8_t*, size_t, int, int, int);
-extern "C" __global__ void cmx_lstm_fwd(const LstmState, const uint8_t*, size_t, int, int, float*, int);
-extern "C" __global__ void cmx_lstm_bptt_seq(const LstmState);
 extern "C" __global__ void cmx_lstm_bptt_acc(const LstmState, int, int);
 extern "C" __global__ void cmx_lstm_bptt_gb(const LstmState, int, int);
 extern "C" __global__ void cmx_lstm_fwdblk(const LstmState, const uint8_t*, const float*, float*, size_t, int, int, int);
@@ -41,50 +37,9 @@ struct cmx_lstm {
   float* d_prev_probs = nullptr;  // byte distribution at chunk start
   uint64_t bytes_done = 0;
   int hc = 0;                // which hid[] / stateb[] buffer holds the current hidden_ / state_
-  bool v1 = false;           // CMX_LSTM_V1=1 at creation: the one-workgroup kernels (and their transposed output-layer copy)
   size_t fb_lds = 0, bp_lds = 0;   // dynamic LDS of the block kernels (lstm_block.hip)
   uint64_t bptt_rounds = 0;  // LstmLayer::update_steps_ = min(rounds, 3000) (lstm-layer.cpp:131-133)
-  // one epoch-aligned block of 100 bytes (BPTT round + 100 x (SGD, forward) = 204 launches) captured once and
-  // replayed with one hipGraphLaunch: the per-byte launch rate, not the GPU, limits how many streams one host
-  // thread can feed
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t graph_exec = nullptr;
-  bool graph_failed = false;
 };
-
-static void lstm_launch_byte(cmx_lstm_t* h, hipStream_t st, const float* d_in_probs, const uint8_t* d_bytes, size_t n,
-                             float* d_out_probs, int e, int hc, int us, int k) {
-  const LstmState& S = h->h_state;
-  const int V = S.V;
-  if (e == 0) {                                  // lstm.cpp:93
-    hipLaunchKernelGGL(cmx_lstm_prep, dim3(1), dim3(256), 0, st, S, d_in_probs ? d_in_probs + n * 256 : nullptr, d_bytes, n, e, k);
-    hipLaunchKernelGGL(cmx_lstm_bptt_seq, dim3(S.xcd >= 0 ? 8 : 1), dim3(1024), 0, st, S);
-    hipLaunchKernelGGL(cmx_lstm_bptt_acc, dim3((S.rowlen[1] + 63) / 64, LSTM_C / 4, 6), dim3(64, 4), 0, st, S, us, k);
-    hipLaunchKernelGGL(cmx_lstm_bptt_gb, dim3(6), dim3(256), 0, st, S, us, k);
-  }
-  hipLaunchKernelGGL(cmx_lstm_sgd, dim3((V * LSTM_NH + 255) / 256 + 1), dim3(256), 0, st, S,
-                     (e == 0 || !d_in_probs) ? (const float*)nullptr : d_in_probs + n * 256, d_bytes, n, e, hc, k);
-  hipLaunchKernelGGL(cmx_lstm_fwd, dim3(S.xcd >= 0 ? 8 : 1), dim3(640), 0, st, S, d_bytes, n, e, hc,
-                     d_out_probs ? d_out_probs + n * 256 : nullptr, k);
-}
-
-// Capture the 204 launches of one aligned block (arguments read from S.blk at run time). Returns false if
-// capture is not possible; the caller then keeps launching directly.
-static bool lstm_build_graph(cmx_lstm_t* h) {
-  if (h->graph_exec) return true;
-  if (h->graph_failed) return false;
-  hipStream_t cap = nullptr;
-  bool ok = hipStreamCreateWithFlags(&cap, hipStreamNonBlocking) == hipSuccess;
-  ok = ok && hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal) == hipSuccess;
-  if (ok) {
-    for (int k = 0; k < LSTM_H; ++k) lstm_launch_byte(h, cap, nullptr, nullptr, 0, nullptr, k, 0, 0, k);
-    ok = hipStreamEndCapture(cap, &h->graph) == hipSuccess && h->graph;
-  }
-  ok = ok && hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0) == hipSuccess;
-  if (cap) (void)hipStreamDestroy(cap);
-  if (!ok) { (void)hipGetLastError(); h->graph_failed = true; h->graph_exec = nullptr; }
-  return ok;
-}
 
 
 extern "C" {
@@ -94,8 +49,6 @@ void cmx_lstm_destroy(cmx_lstm_t* h) {
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
   for (void* p : h->allocs) (void)hipFree(p);
-  if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
-  if (h->graph) (void)hipGraphDestroy(h->graph);
   delete h;
 }
 
@@ -178,8 +131,7 @@ cmx_lstm_t* cmx_lstm_create(const uint8_t vocab[256], int skip_rand, int device)
     S.layer_input[l] = dallocf(li.size(), li.data());
   }
   S.OL = dallocf((size_t)LSTM_H * V * LSTM_NH, nullptr);
-  { const char* v = getenv("CMX_LSTM_V1"); h->v1 = v && v[0] == '1'; }
-  S.OLT = h->v1 ? dallocf((size_t)LSTM_H * LSTM_NH * LSTM_VP, nullptr) : nullptr;   // 41 MB only the one-workgroup forward kernel reads
+  S.OLT = nullptr;   // (the transposed output-layer copy of the retired one-workgroup forward kernel)
   {
     std::vector<float> out((size_t)LSTM_H * LSTM_VP, 0.0f);
     for (int e = 0; e < LSTM_H; ++e)
@@ -262,10 +214,7 @@ int cmx_lstm_run(cmx_lstm_t* h, const float* d_in_probs, const uint8_t* d_bytes,
   const LstmState& S = h->h_state;
   const int V = S.V;
   (void)hipMemcpyAsync(h->d_prev_probs, S.byte_probs, 256 * 4, hipMemcpyDeviceToDevice, st);
-  static const bool use_graph = !(getenv("CMX_LSTM_NOGRAPH") && getenv("CMX_LSTM_NOGRAPH")[0] == '1');
-  const bool v1 = h->v1;   // one-workgroup kernels
-  static const bool bptt_v1 = getenv("CMX_LSTM_BPTT_V1") && getenv("CMX_LSTM_BPTT_V1")[0] == '1';
-  if (!v1 && !d_in_probs) { cmx_set_err("cmx_lstm_run: d_in_probs is required"); return 1; }
+  if (!d_in_probs) { cmx_set_err("cmx_lstm_run: d_in_probs is required"); return 1; }
   auto sync_reset = [&]() {
     return hipMemsetAsync((char*)S.sync + 16, 0, sizeof(LstmSync) - 16, st) == hipSuccess;
   };
@@ -277,43 +226,23 @@ int cmx_lstm_run(cmx_lstm_t* h, const float* d_in_probs, const uint8_t* d_bytes,
       h->bptt_rounds += 1;
       us = (int)(h->bptt_rounds < LSTM_UPDATE_LIMIT ? h->bptt_rounds : LSTM_UPDATE_LIMIT);
     }
-    if (!v1) {
-      // multi-workgroup path (lstm_block.hip): [bookkeeping, BPTT round] at an epoch-0 byte, then ONE launch for the
-      // bytes up to the end of the block
-      if (e == 0) {                                // lstm.cpp:93
-        hipLaunchKernelGGL(cmx_lstm_prep, dim3(1), dim3(256), 0, st, S, d_in_probs + n * 256, d_bytes, n, e, -1);
-        if (bptt_v1) {
-          hipLaunchKernelGGL(cmx_lstm_bptt_seq, dim3(S.xcd >= 0 ? 8 : 1), dim3(1024), 0, st, S);
-        } else {
-          if (!sync_reset()) { cmx_set_err("cmx_lstm_run: hipMemsetAsync failed"); return 1; }
-          hipLaunchKernelGGL(cmx_lstm_bpttblk, dim3(LSTM_BP_G), dim3(LSTM_BP_THREADS), h->bp_lds, st, S);
-        }
-        hipLaunchKernelGGL(cmx_lstm_bptt_acc, dim3((S.rowlen[1] + 63) / 64, LSTM_C / 4, 6), dim3(64, 4), 0, st, S, us, -1);
-        hipLaunchKernelGGL(cmx_lstm_bptt_gb, dim3(6), dim3(256), 0, st, S, us, -1);
-      }
-      const size_t left = nbytes - n;
-      const int cnt = (int)(left < (size_t)(LSTM_H - e) ? left : (size_t)(LSTM_H - e));
+    // multi-workgroup kernels (lstm_block.hip): [bookkeeping, BPTT round] at an epoch-0 byte, then ONE launch for the
+    // bytes up to the end of the block
+    if (e == 0) {                                // lstm.cpp:93
+      hipLaunchKernelGGL(cmx_lstm_prep, dim3(1), dim3(256), 0, st, S, d_in_probs + n * 256, d_bytes, n, e, -1);
       if (!sync_reset()) { cmx_set_err("cmx_lstm_run: hipMemsetAsync failed"); return 1; }
-      hipLaunchKernelGGL(cmx_lstm_fwdblk, dim3(2 * LSTM_FB_GL + LSTM_FB_GO), dim3(LSTM_FB_THREADS), h->fb_lds, st, S, d_bytes,
-                         d_in_probs, d_out_probs, n, cnt, e, hc);
-      h->hc ^= 1;
-      h->bytes_done += cnt;
-      n += cnt;
-      continue;
+      hipLaunchKernelGGL(cmx_lstm_bpttblk, dim3(LSTM_BP_G), dim3(LSTM_BP_THREADS), h->bp_lds, st, S);
+      hipLaunchKernelGGL(cmx_lstm_bptt_acc, dim3((S.rowlen[1] + 63) / 64, LSTM_C / 4, 6), dim3(64, 4), 0, st, S, us, -1);
+      hipLaunchKernelGGL(cmx_lstm_bptt_gb, dim3(6), dim3(256), 0, st, S, us, -1);
     }
-    if (e == 0 && nbytes - n >= LSTM_H && use_graph && lstm_build_graph(h)) {
-      LstmBlockArgs a;
-      a.in_probs = d_in_probs; a.bytes = d_bytes; a.out_probs = d_out_probs; a.n0 = n; a.hc0 = hc; a.us = us;
-      hipLaunchKernelGGL(cmx_lstm_setblk, dim3(1), dim3(1), 0, st, S.blk, a);
-      if (hipGraphLaunch(h->graph_exec, st) != hipSuccess) { cmx_set_err("cmx_lstm_run: hipGraphLaunch failed"); return 1; }
-      h->bytes_done += LSTM_H;
-      n += LSTM_H;
-      continue;
-    }
-    lstm_launch_byte(h, st, d_in_probs, d_bytes, n, d_out_probs, e, hc, us, -1);
+    const size_t left = nbytes - n;
+    const int cnt = (int)(left < (size_t)(LSTM_H - e) ? left : (size_t)(LSTM_H - e));
+    if (!sync_reset()) { cmx_set_err("cmx_lstm_run: hipMemsetAsync failed"); return 1; }
+    hipLaunchKernelGGL(cmx_lstm_fwdblk, dim3(2 * LSTM_FB_GL + LSTM_FB_GO), dim3(LSTM_FB_THREADS), h->fb_lds, st, S, d_bytes,
+                       d_in_probs, d_out_probs, n, cnt, e, hc);
     h->hc ^= 1;
-    h->bytes_done += 1;
-    ++n;
+    h->bytes_done += cnt;
+    n += cnt;
   }
   if (d_bit_p) {
     if (!d_out_probs) { cmx_set_err("cmx_lstm_run: bit predictions need d_out_probs"); return 1; }

@@ -11,9 +11,9 @@
 // accumulation/Adam sweep. MFMA is not used: an MFMA step is a fused multiply-add with one
 // rounding and a blocked K order, which cannot reproduce the reference stream.
 //
-// Per byte (stream order): prep -> [bptt_seq -> bptt_acc -> bptt_gb every 100 bytes] -> sgd -> fwd
-// (both layers, output layer and softmax fused in one workgroup).  Bit-level predictions for a whole
-// chunk are produced by bytemodel_bits at the end (the coded bytes are known in compression).
+// This file: the per-block bookkeeping (prep), the element-parallel half of BPTT (update accumulation, Adam: one lane per
+// weight) and ByteModel's bit predictions. The sequential halves -- the forward pass of a block of up to 100 bytes and the
+// BPTT walk -- are the multi-workgroup kernels of lstm_block.hip (cmx_lstm_fwdblk, cmx_lstm_bpttblk).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "cmx_libm.h"
@@ -51,327 +51,11 @@ __device__ __forceinline__ void lstm_prep(const LstmState* S, const float* in256
   (void)V;
 }
 
-// ---- output layer SGD (lstm.cpp:112-116): slot[e] = slot[last] - (lr*err_i)*hidden_, both layouts
-// stand-alone form: on BPTT bytes (epoch 0) the bookkeeping must precede the backward pass (lstm.cpp:88-93)
-// Every per-byte kernel takes a trailing `k`: k < 0 = direct launch, the explicit arguments hold; k >= 0 = node
-// k of a captured 100-byte block, the arguments come from the device-resident LstmBlockArgs (epoch = k).
-extern "C" __global__ void cmx_lstm_setblk(LstmBlockArgs* dst, const LstmBlockArgs v) {
-  if (threadIdx.x == 0) *dst = v;
-}
-
+// on BPTT bytes (epoch 0) the bookkeeping must precede the backward pass (lstm.cpp:88-93). The trailing `k` of these kernels
+// is always -1 (explicit arguments); k >= 0 read them from the device-resident LstmBlockArgs of a replayed block.
 extern "C" __global__ void cmx_lstm_prep(const LstmState P, const float* in256, const uint8_t* bytes, size_t n, int e, int k) {
   if (k >= 0) { const LstmBlockArgs a = *P.blk; in256 = a.in_probs + a.n0 * 256; bytes = a.bytes; n = a.n0; e = 0; }
   lstm_prep(&P, in256, bytes, n, e);
-}
-
-extern "C" __global__ void cmx_lstm_sgd(const LstmState P, const float* in256, const uint8_t* bytes, size_t n, int e, int hid_cur,
-                                        int k) {
-  const LstmState* S = &P;
-  if (k >= 0) {
-    const LstmBlockArgs a = *P.blk;
-    n = a.n0 + k; e = k; hid_cur = (a.hc0 + k) & 1; bytes = a.bytes;
-    in256 = k == 0 ? nullptr : a.in_probs + n * 256;  // node 0 follows the stand-alone bookkeeping kernel
-  }
-  if (blockIdx.x == gridDim.x - 1) {  // the extra block does ByteMixer::SetInput / Lstm::Perceive bookkeeping
-    if (in256) lstm_prep(S, in256, bytes, n, e);   // NULL: already done by cmx_lstm_prep
-    return;
-  }
-  const int V = S->V, last = e == 0 ? H - 1 : e - 1;
-  const int cur_sym = S->byte_map[bytes[n]];
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= V * NH) return;
-  const int i = idx / NH, j = idx - i * NH;
-  float o = S->output[(size_t)last * VP + i];
-  float err = (i == cur_sym) ? fsub(o, 1.0f) : o;
-  float le = fmul(S->lr, err);
-  const float* hid = S->hid[hid_cur];
-  float v = fsub(S->OL[((size_t)last * V + i) * NH + j], fmul(le, hid[j]));
-  S->OL[((size_t)e * V + i) * NH + j] = v;
-  S->OLT[((size_t)e * NH + j) * VP + i] = v;
-}
-
-// ---- Fused forward pass of one byte: both layers' gate dot products, RMS norm + activations + cell
-//      update, the output-layer matvec and the softmax (lstm.cpp:120-150; lstm-layer.cpp:62-99;
-//      byte-mixer.cpp:27-37) in ONE workgroup of 640 lanes. The byte-rate recurrence is a chain of
-//      six dependent steps; as six launches it was bound by launch latency (4-10 us each), not by
-//      work. Here the steps are separated by workgroup barriers. The 600 gate rows of a layer are
-//      600 ordered chains, one per lane; the transposed weight layout makes a wave's loads of one term
-//      a contiguous 256-byte run, so the CU streams the layer's weights from L2 at its L1 fill rate.
-extern "C" __global__ __launch_bounds__(640) void cmx_lstm_fwd(const LstmState P, const uint8_t* bytes, size_t n, int e,
-                                                               int hid_cur, float* out_probs256, int k) {
-  if (P.xcd >= 0 && (int)blockIdx.x != (P.xcd & 7)) return;
-  const LstmState* S = &P;
-  if (k >= 0) {
-    const LstmBlockArgs a = *P.blk;
-    n = a.n0 + k; e = k; hid_cur = (a.hc0 + k) & 1; bytes = a.bytes;
-    out_probs256 = a.out_probs ? a.out_probs + n * 256 : nullptr;
-  }
-  __shared__ float in[832];
-  __shared__ float raw[3][C];
-  __shared__ float ivar_s[3];
-  __shared__ float hid[NH];
-  __shared__ float ex[VP];
-  __shared__ float red[256];
-  __shared__ float tot_s;
-  const int tid = threadIdx.x, V = S->V;
-  const int cur_sym = S->byte_map[bytes[n]];
-  const float* hold = S->hid[hid_cur];
-  float* hnew = S->hid[hid_cur ^ 1];
-  if (tid == 0) hid[NH - 1] = 1.0f;  // bias element of hidden_ (lstm.cpp:18)
-#pragma unroll 1
-  for (int layer = 0; layer < LSTM_L; ++layer) {
-    const int insz = S->insz[layer];
-    float* li = S->layer_input[layer] + (size_t)e * insz;
-    __syncthreads();
-    for (int j = tid; j < insz; j += 640) {
-      float v;
-      if (j < V) v = li[j];                                  // Lstm::SetInput (written by cmx_lstm_prep)
-      else if (j < V + C) v = hold[layer * C + (j - V)];     // own previous hidden (lstm.cpp:122-124)
-      else if (j < insz - 1) v = hid[j - V - C];             // layer 1: layer 0's new hidden (lstm.cpp:127-131)
-      else v = 1.0f;                                         // bias
-      in[j] = v;
-      if (j >= V) li[j] = v;                                 // keep the assembled vector for BPTT
-    }
-    __syncthreads();
-    if (tid < 3 * C) {  // LstmLayer::ForwardPass(NeuronLayer&) dot products (lstm-layer.cpp:85-92)
-      const int g = tid / C, i = tid - g * C;
-      const float* wt = S->WT[layer][g];
-      float f = wt[(size_t)cur_sym * C + i];
-      // dense part: 16-byte loads of four consecutive terms (layout: lstm_wt_index), 8 loads = 32 terms
-      // in flight per lane, then the ordered chain over them
-      const float4* w4 = reinterpret_cast<const float4*>(wt + (size_t)V * C) + i;
-      const int full = insz & ~3, nq = full >> 2;
-      // (A single CU sustains ~50 GB/s from L2/HBM whatever the load width or depth -- measured with dword,
-      // 16-byte and 16-deep ring variants -- so this workgroup is bandwidth-bound at ~45 us per byte; the
-      // next step is to spread the rows over several workgroups with in-launch hand-offs.)
-      int q0 = 0;
-      for (; q0 + 8 <= nq; q0 += 8) {  // 8 x 16-byte loads (32 terms) in flight per lane, then the ordered chain
-        float4 w[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) w[k] = w4[(size_t)(q0 + k) * C];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const float* x = in + 4 * (q0 + k);
-          f = fadd(f, fmul(x[0], w[k].x));
-          f = fadd(f, fmul(x[1], w[k].y));
-          f = fadd(f, fmul(x[2], w[k].z));
-          f = fadd(f, fmul(x[3], w[k].w));
-        }
-      }
-      for (; q0 < nq; ++q0) {
-        const float4 v = w4[(size_t)q0 * C];
-        const float* x = in + 4 * q0;
-        f = fadd(f, fmul(x[0], v.x));
-        f = fadd(f, fmul(x[1], v.y));
-        f = fadd(f, fmul(x[2], v.z));
-        f = fadd(f, fmul(x[3], v.w));
-      }
-      int j = full;
-      const float* wr = wt + (size_t)V * C + (size_t)full * C + i;
-      for (; j < insz; ++j) f = fadd(f, fmul(in[j], wr[(size_t)(j - full) * C]));
-      raw[g][i] = f;
-    }
-    __syncthreads();
-    // RMS norm, activations, cell update (lstm-layer.cpp:62-83, 93-98)
-    if (tid < 3) {  // (norm_*norm_).sum(): expression-template sum runs backward from the last element
-      float s = fmul(raw[tid][C - 1], raw[tid][C - 1]);
-      for (int i = C - 2; i >= 0; --i) s = fadd(s, fmul(raw[tid][i], raw[tid][i]));
-      float iv = fdiv(1.0f, fsqrt(fadd(fdiv(s, (float)C), 1e-5f)));
-      ivar_s[tid] = iv;
-      S->ivar[layer][tid][e] = iv;
-    }
-    __syncthreads();
-    if (tid < C) {
-      float st[3];
-      for (int g = 0; g < 3; ++g) {
-        const float* gb = S->gb[layer][g];
-        float nrm = fmul(raw[g][tid], ivar_s[g]);
-        S->norm[layer][g][(size_t)e * C + tid] = nrm;
-        st[g] = fadd(fmul(nrm, gb[tid]), gb[C + tid]);  // norm*gamma + beta
-      }
-      float fg = cmx_logistic(st[0]);
-      float inn = cmx_tanhf(st[1]);
-      float og = cmx_logistic(st[2]);
-      S->gstate[layer][0][(size_t)e * C + tid] = fg;
-      S->gstate[layer][1][(size_t)e * C + tid] = inn;
-      S->gstate[layer][2][(size_t)e * C + tid] = og;
-      float state = S->state[layer][tid];
-      S->last_state[layer][(size_t)e * C + tid] = state;
-      float igs = fsub(1.0f, fg);
-      S->in_gate_state[layer][(size_t)e * C + tid] = igs;
-      state = fmul(state, fg);
-      state = fadd(state, fmul(inn, igs));
-      S->state[layer][tid] = state;
-      float th = cmx_tanhf(state);
-      S->tanh_state[layer][(size_t)e * C + tid] = th;
-      const float h = fmul(og, th);
-      hid[layer * C + tid] = h;
-      hnew[layer * C + tid] = h;
-    }
-  }
-  __syncthreads();
-  // output layer matvec (lstm.cpp:132-140): one ordered 401-term chain per vocabulary symbol
-  float lg = 0.0f;
-  if (tid < V) {
-    const float* ot = S->OLT + (size_t)e * NH * VP + tid;
-    float sum = 0.0f;
-    int j = 0;
-    for (; j + 32 <= NH; j += 32) {
-      float w[32];
-#pragma unroll
-      for (int k = 0; k < 32; ++k) w[k] = ot[(size_t)(j + k) * VP];
-#pragma unroll
-      for (int k = 0; k < 32; ++k) sum = fadd(sum, fmul(hid[j + k], w[k]));
-    }
-    for (; j < NH; ++j) sum = fadd(sum, fmul(hid[j], ot[(size_t)j * VP]));
-    lg = sum;
-  }
-  // softmax (lstm.cpp:141-149), ByteMixer::ByteUpdate tail (byte-mixer.cpp:27-37)
-  if (tid < 256) red[tid] = tid < V ? lg : 0.0f;  // max_out starts at 0 (lstm.cpp:132)
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
-    __syncthreads();
-  }
-  const float mx = red[0];
-  if (tid < V) ex[tid] = cmx_expf(fsub(lg, mx));
-  __syncthreads();
-  if (tid == 0) {  // valarray::sum(): forward from 0
-    float t = 0.0f;
-    for (int i = 0; i < V; ++i) t = fadd(t, ex[i]);
-    tot_s = t;
-  }
-  __syncthreads();
-  if (tid < V) {
-    float p = fdiv(ex[tid], tot_s);
-    S->output[(size_t)e * VP + tid] = p;
-    ex[tid] = p;
-  }
-  __syncthreads();
-  if (tid < 256) {
-    float pb = S->vocab[tid] ? ex[S->byte_map[tid]] : 0.0f;
-    S->byte_probs[tid] = pb;
-    if (out_probs256) out_probs256[tid] = pb;
-  }
-}
-
-// ---- BPTT, sequential part (lstm.cpp:93-110; lstm-layer.cpp:108-183): one block of 1024 walks
-//      epoch 99..0 x layer 1..0, leaving the final gate errors E[l][g][epoch][.] for the sweep.
-extern "C" __global__ __launch_bounds__(1024) void cmx_lstm_bptt_seq(const LstmState P) {
-  if (P.xcd >= 0 && (int)blockIdx.x != (P.xcd & 7)) return;
-  const LstmState* S = &P;
-  __shared__ float errv[VP];        // softmax-CE error of the epoch
-  __shared__ float herr[C];         // Lstm::hidden_error_
-  __shared__ float gerr[3][C];      // NeuronLayer::error_
-  __shared__ float gprod[3][C];
-  __shared__ float gsm[3];
-  __shared__ float fres[2][3][C];   // matvec results: [stored|hidden][gate][i]
-  const int tid = threadIdx.x, V = S->V;
-  const int j = tid;                // cell index for the element-wise phases
-  float stored[LSTM_L] = {0, 0}, state_err[LSTM_L] = {0, 0};
-  if (tid < C) herr[tid] = 0.0f;    // hidden_error_ is zero on entry (cleared by the last BackwardPass)
-  __syncthreads();
-  for (int epoch = H - 1; epoch >= 0; --epoch) {
-    if (tid < V) {
-      float o = S->output[(size_t)epoch * VP + tid];
-      errv[tid] = ((unsigned)tid == S->input_history[epoch]) ? fsub(o, 1.0f) : o;
-    }
-    if (tid == 0) S->bp_symbol[epoch] = epoch == 0 ? (unsigned)S->dyn[0] : S->input_history[epoch - 1];
-    __syncthreads();
-#pragma unroll
-    for (int layer = LSTM_L - 1; layer >= 0; --layer) {
-      // hidden_error_[j] += output_layer_[epoch][i][j+offset] * error_i, i ascending (lstm.cpp:98-103)
-      if (j < C) {
-        float h = herr[j];
-        const float* ol = S->OL + (size_t)epoch * V * NH + layer * C + j;
-        int i = 0;
-        for (; i + 16 <= V; i += 16) {
-          float a[16];
-#pragma unroll
-          for (int k = 0; k < 16; ++k) a[k] = ol[(size_t)(i + k) * NH];
-#pragma unroll
-          for (int k = 0; k < 16; ++k) h = fadd(h, fmul(a[k], errv[i + k]));
-        }
-        for (; i < V; ++i) h = fadd(h, fmul(ol[(size_t)i * NH], errv[i]));
-        // LstmLayer::BackwardPass head (lstm-layer.cpp:110-132)
-        const size_t ec = (size_t)epoch * C + j;
-        if (epoch == H - 1) { stored[layer] = h; state_err[layer] = 0.0f; }
-        else stored[layer] = fadd(stored[layer], h);
-        const float th = S->tanh_state[layer][ec], os = S->gstate[layer][2][ec], fs = S->gstate[layer][0][ec],
-                    is = S->gstate[layer][1][ec], igs = S->in_gate_state[layer][ec], ls = S->last_state[layer][ec];
-        float og_e = fmul(fmul(fmul(th, stored[layer]), os), fsub(1.0f, os));
-        state_err[layer] = fadd(state_err[layer], fmul(fmul(stored[layer], os), fsub(1.0f, fmul(th, th))));
-        float in_e = fmul(fmul(state_err[layer], igs), fsub(1.0f, fmul(is, is)));
-        float fg_e = fmul(fmul(fmul(fsub(ls, is), state_err[layer]), fs), igs);
-        gerr[0][j] = fg_e;
-        gerr[1][j] = in_e;
-        gerr[2][j] = og_e;
-        if (epoch > 0) { state_err[layer] = fmul(state_err[layer], fs); stored[layer] = 0.0f; }
-      }
-      __syncthreads();
-      // per-gate normalisation backward (lstm-layer.cpp:158-163); thread = (gate, cell)
-      const int g = tid >> 8, c = tid & 255;
-      float myerr = 0.0f, mynorm = 0.0f;
-      if (g < 3 && c < C) {
-        float* gb = S->gb[layer][g];
-        float* gamma_u = gb + 6 * C;
-        float* beta_u = gb + 7 * C;
-        if (epoch == H - 1) { gamma_u[c] = 0.0f; beta_u[c] = 0.0f; }
-        myerr = gerr[g][c];
-        mynorm = S->norm[layer][g][(size_t)epoch * C + c];
-        beta_u[c] = fadd(beta_u[c], myerr);
-        gamma_u[c] = fadd(gamma_u[c], fmul(myerr, mynorm));
-        myerr = fmul(myerr, fmul(gb[c], S->ivar[layer][g][epoch]));
-        gprod[g][c] = fmul(myerr, mynorm);
-      }
-      __syncthreads();
-      if (g < 3 && c == 0) {  // (error_*norm_).sum(): backward
-        float s = gprod[g][C - 1];
-        for (int i = C - 2; i >= 0; --i) s = fadd(s, gprod[g][i]);
-        gsm[g] = fdiv(s, (float)C);
-      }
-      __syncthreads();
-      if (g < 3 && c < C) {
-        myerr = fsub(myerr, fmul(gsm[g], mynorm));
-        gerr[g][c] = myerr;
-        S->E[layer][g][(size_t)epoch * C + c] = myerr;
-      }
-      __syncthreads();
-      // W^T matvecs (lstm-layer.cpp:164-181): f_i = sum_j error_[j] * W[j][col+i], j ascending
-      for (int kind = 0; kind < 2; ++kind) {
-        const bool need = kind == 0 ? epoch > 0 : layer > 0;
-        if (need && g < 3 && c < C) {
-          const int rl = S->rowlen[layer];
-          const float* w = S->W[layer][g] + 2 * V + (kind == 1 ? C : 0) + c;
-          float f = 0.0f;
-          for (int jj = 0; jj < C; jj += 20) {   // C = 200 = 10 x 20
-            float wv[20];
-#pragma unroll
-            for (int k = 0; k < 20; ++k) wv[k] = w[(size_t)(jj + k) * rl];
-#pragma unroll
-            for (int k = 0; k < 20; ++k) f = fadd(f, fmul(gerr[g][jj + k], wv[k]));
-          }
-          fres[kind][g][c] = f;
-        }
-      }
-      __syncthreads();
-      if (j < C) {
-        // *hidden_error = 0, then += f per gate in order forget, input node, output (lstm-layer.cpp:126,137-139)
-        float he = 0.0f;
-        if (layer > 0) { he = fadd(he, fres[1][0][j]); he = fadd(he, fres[1][1][j]); he = fadd(he, fres[1][2][j]); }
-        if (epoch > 0) {
-          float se = stored[layer];
-          se = fadd(se, fres[0][0][j]); se = fadd(se, fres[0][1][j]); se = fadd(se, fres[0][2][j]);
-          stored[layer] = se;
-        }
-        // ClipGradients (lstm-layer.cpp:140-142)
-        state_err[layer] = fminf(fmaxf(state_err[layer], -10.0f), 10.0f);
-        stored[layer] = fminf(fmaxf(stored[layer], -10.0f), 10.0f);
-        herr[j] = fminf(fmaxf(he, -10.0f), 10.0f);
-      }
-      __syncthreads();
-    }
-  }
 }
 
 // ---- BPTT sweep: update_[i][c] accumulated over epochs 99..0 (lstm-layer.cpp:182-186) held in a

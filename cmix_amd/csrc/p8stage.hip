@@ -36,30 +36,6 @@ extern "C" int cmx_device_count(void);
 
 // ---------------------------------------------------------------- role kernels
 // skip: chunk-local steps before the stream's first byte boundary (the maps have no contexts yet, reference :1072 loop over cn == 0)
-__global__ __launch_bounds__(P8CM2_MAXC) void cmx_p8s_cm2_kernel(P8Cm2Dev* d, const uint32_t* ctx, const uint16_t* chk, const uint8_t* bits, int16_t* x,
-                                                                uint8_t* order_out, int nbits, int skip) {
-  __shared__ P8Cm2Shared sh;
-  const int i = threadIdx.x, C = d->C;
-  if (i == 0) sh.r = d->regs;
-  uint32_t run_bits = d->bits;
-  int last_y = d->last_y;
-  __syncthreads();
-  for (int t = 0; t < nbits; t++) {
-    const P8Cm2Bit u = p8d_bit(d, ctx, chk, bits, x, t, &run_bits, &last_y);
-    if (t < skip) { if (order_out && i == 0) order_out[t] = 0; continue; }
-    if (i < C) p8d_touch(d, &sh, u, i);
-    __syncthreads();
-    if (i < C) p8d_conflict(d, &sh, i);
-    __syncthreads();
-    if (i < C) p8d_run(d, &sh, u, i);
-    __syncthreads();
-    if (order_out && i == 0) { int o = 0; for (int k = 0; k < C; k++) o += sh.nz[k]; order_out[t] = (uint8_t)o; }
-  }
-  if (i == 0) { d->regs = sh.r; d->bits = run_bits; d->last_y = last_y; }
-}
-
-// Second design (p8cm2v2_dev.h): cached slot / byte-history bytes, bucket fetch before the bit's barrier, hash-set overlap
-// detection at lookup bits; overlap or shared slots -> lane 0 walks the instance with the first design's code.
 __global__ __launch_bounds__(P8CM2_MAXC) void cmx_p8s_cm2v2_kernel(P8Cm2Dev* d, const uint32_t* ctx, const uint16_t* chk, const uint8_t* bits, int16_t* x,
                                                                   uint8_t* order_out, int nbits, int skip) {
   __shared__ __attribute__((aligned(16))) P8Cm2V2Shared sh;
@@ -91,28 +67,6 @@ __global__ __launch_bounds__(P8CM2_MAXC) void cmx_p8s_cm2v2_kernel(P8Cm2Dev* d, 
   }
   __syncthreads();
   if (i == 0) { d->regs = sh.base.r; d->bits = run_bits; d->last_y = last_y; }
-}
-
-__global__ __launch_bounds__(P8CM_MAXS) void cmx_p8s_fam_kernel(P8CmDev* d, const uint32_t* ctx, const uint16_t* chk, const uint8_t* bits, int16_t* x,
-                                                               const uint8_t* order, int nbits, int skip) {
-  __shared__ P8CmShared sh;
-  const int s = threadIdx.x, S = d->nslots;
-  if (s == 0) { sh.r = d->regs; sh.rnd = d->rnd; }
-  int last_y = d->last_y, c1 = d->c1;
-  __syncthreads();
-  for (int t = 0; t < nbits; t++) {
-    const P8CmBit u = p8d_cm_bit(d, ctx, chk, bits, x, order, t, &last_y, &c1);
-    if (t < skip) continue;
-    if (s < S) p8d_cm_touch(d, &sh, u, s);
-    __syncthreads();
-    if (s < S) p8d_cm_check(d, &sh, s);
-    __syncthreads();
-    if (s < S) p8d_cm_draw(d, &sh, s);
-    __syncthreads();
-    if (s < S) p8d_cm_run(d, &sh, u, s);
-    __syncthreads();
-  }
-  if (s == 0) { d->regs = sh.r; d->rnd = sh.rnd; d->last_y = last_y; d->c1 = c1; }
 }
 
 // Second design of the family kernel (p8fam_dev.h): per-context bytes and StateMaps in LDS, one barrier per bit on the
@@ -235,115 +189,6 @@ __device__ __forceinline__ uint32_t pair_train(uint32_t t, uint32_t w, int err) 
 }
 }  // namespace
 
-// out: row t of the caller's matrix (ld floats per row) receives the 1591 values before bit t. first: chunk-local steps
-// that belong to the stream's first byte (compacted input vector, P8Layout.first_map).
-__global__ __launch_bounds__(MX_THREADS) void cmx_p8s_mix_kernel(const P8MixDev* M, P8TailDev* T, const int16_t* __restrict__ x, const int32_t* __restrict__ sel,
-                                                                const P8ApmRec* __restrict__ apm, const uint8_t* __restrict__ order,
-                                                                const uint8_t* __restrict__ bits, float* __restrict__ out, size_t ld, int nbits, int t0, int first,
-                                                                int last_y) {
-  __shared__ __attribute__((aligned(16))) uint32_t xs[P8_NX / 2];   // the step's inputs, as pairs
-  __shared__ float outs[P8_NOUT];                                   // PAQ8::Predict()'s vector, kept between steps as the reference does
-  __shared__ int pr_s[32], res_s[8];
-  __shared__ uint32_t st_s[16];
-  __shared__ int p_s, fin_s;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int16_t* squash = M->squash; const int16_t* stretch = M->stretch;
-  const float cf = (float)(1.0 / 4095);
-  for (int i = tid; i < P8_NOUT; i += MX_THREADS) outs[i] = T->out[i];
-  if (tid == 0) fin_s = T->pr;
-  __syncthreads();
-  if (t0) for (int i = tid; i < P8_NOUT; i += MX_THREADS) out[i] = outs[i];   // no step 0: the constructor's values
-  for (int t = t0; t < nbits; ++t) {
-    const int y = t ? bits[t - 1] : last_y;
-    const int nx = t < first ? M->nx_first : P8_NX;
-    const int16_t* xr = x + (size_t)t * P8_NX;
-    // ---- inputs -> LDS (compacted during the first byte), their exported values ----
-    if (t < first) {
-      int16_t* xh = reinterpret_cast<int16_t*>(xs);
-      for (int i = tid; i < P8_NX; i += MX_THREADS) xh[i] = i < nx ? xr[M->first_map[i]] : (int16_t)0;
-    } else if (tid < MX_GROUPS) reinterpret_cast<uint4*>(xs)[tid] = reinterpret_cast<const uint4*>(xr)[tid];
-    if (tid < 32) pr_s[tid] = 0;
-    if (tid == 0) T->misses += T->misses + (uint64_t)((fin_s >> 11) != y);
-    __syncthreads();
-    for (int i = tid; i < nx; i += MX_THREADS) outs[i] = (float)p8s_squash(squash, reinterpret_cast<const int16_t*>(xs)[i]) * cf;
-    // ---- first layer: 4 sets per wave, the rows stay in registers until they are trained ----
-    uint4 w[4][4];
-    int row[4];
-    const int ord = order[t], lastpr = fin_s;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int si = 4 * wave + q;
-      row[q] = p8s_sel(si, sel[(size_t)t * P8_NSEL + si], ord, lastpr);
-      const uint4* wr = reinterpret_cast<const uint4*>(M->wx + (size_t)row[q] * P8_NX);
-      uint32_t acc = 0;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int grp = lane + 64 * g;
-        w[q][g] = grp < MX_GROUPS ? wr[grp] : make_uint4(0, 0, 0, 0);
-        const uint4 xv = grp < MX_GROUPS ? reinterpret_cast<const uint4*>(xs)[grp] : make_uint4(0, 0, 0, 0);
-        acc += pair_dot(xv.x, w[q][g].x) + pair_dot(xv.y, w[q][g].y) + pair_dot(xv.z, w[q][g].z) + pair_dot(xv.w, w[q][g].w);
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-      if (lane == 0) pr_s[si] = p8s_squash(squash, (int32_t)(acc * 9u) >> 9);   // :566
-    }
-    __syncthreads();
-    // ---- second layer, APM chains (wave 0) ----
-    if (wave == 0) {
-      const int a = lane < P8_NSEL ? stretch[pr_s[lane]] : 0;
-      if (lane < P8_NSEL) outs[nx + lane] = (float)p8s_squash(squash, a) * cf;   // mp->add(stretch(pr[i])) exports too (:568)
-      const int b = __shfl_down(a, 1);
-      if ((lane & 1) == 0 && lane < 32) st_s[lane >> 1] = ((uint32_t)a & 0xffffu) | ((uint32_t)b << 16);
-      __builtin_amdgcn_s_waitcnt(0);
-      __builtin_amdgcn_wave_barrier();
-      uint32_t acc = 0;
-      if (lane < 16) acc = pair_dot(st_s[lane], reinterpret_cast<const uint32_t*>(M->wx2)[lane]);
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-      const int p2 = p8s_squash(squash, (int32_t)acc >> 9);   // :578
-      if (lane == 0) p_s = p2;
-      const P8ApmRec* a_rec = &apm[t];
-      if (lane < 4) p8s_tail_a(T, a_rec, y, p2, lane, res_s);
-      __builtin_amdgcn_s_waitcnt(0);
-      __builtin_amdgcn_wave_barrier();
-      if (lane < 3) p8s_tail_b(T, a_rec, y, p2, lane, res_s);
-      __builtin_amdgcn_s_waitcnt(0);
-      __builtin_amdgcn_wave_barrier();
-      if (lane == 0) fin_s = p8s_tail_c(a_rec, p2, res_s, outs + nx + P8_NSEL);
-    }
-    __syncthreads();
-    // ---- the row of the layer-0 matrix; training with the step's own bit (the reference trains at the start of the
-    //      next step, :528-541: nothing reads the rows in between) ----
-    float* orow = out + (size_t)t * ld;
-    for (int i = tid; i < P8_NOUT; i += MX_THREADS) orow[i] = outs[i];
-    const int yb = bits[t];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int err = (int)(int16_t)(((yb << 12) - pr_s[4 * wave + q]) * 7);
-      uint4* wr = reinterpret_cast<uint4*>(M->wx + (size_t)row[q] * P8_NX);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int grp = lane + 64 * g;
-        if (grp < MX_GROUPS && err) {
-          const uint4 xv = reinterpret_cast<const uint4*>(xs)[grp];
-          uint4 v = w[q][g];
-          v.x = pair_train(xv.x, v.x, err); v.y = pair_train(xv.y, v.y, err);
-          v.z = pair_train(xv.z, v.z, err); v.w = pair_train(xv.w, v.w, err);
-          wr[grp] = v;
-        }
-      }
-    }
-    if (wave == 0 && lane < 16) {
-      const int err2 = (int)(int16_t)(((yb << 12) - p_s) * 7);
-      uint32_t* w2 = reinterpret_cast<uint32_t*>(M->wx2);
-      if (err2) w2[lane] = pair_train(st_s[lane], w2[lane], err2);
-    }
-    __syncthreads();
-  }
-  for (int i = tid; i < P8_NOUT; i += MX_THREADS) T->out[i] = outs[i];
-  if (tid == 0) T->pr = fin_s;
-}
-
 // Pointers read out of structures are "generic" to the compiler: it has to use flat_load / flat_store for them, which count
 // on BOTH memory counters (they might address LDS), so an LDS-only barrier would still wait for every outstanding table
 // access. Everything the kernels below reach through such pointers is HBM: say so.
@@ -363,7 +208,9 @@ __device__ __forceinline__ void mx_gstore4(MX_GLOBAL int16_t* row, int grp, uint
 // the bit; the kernel's cross-lane traffic through global memory is handled where it occurs.
 __device__ __forceinline__ void mx_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// Second design of the mixer kernel: everything a bit needs from HBM / L2 is requested one bit ahead.
+// The mixer kernel. out: row t of the caller's matrix (ld floats per row) receives the 1591 values before bit t; first: chunk-local steps
+// that belong to the stream's first byte (compacted input vector, P8Layout.first_map). Everything a bit needs from HBM / L2 is requested
+// one bit ahead:
 //   * weight rows: the 28 selectors of bit t+1 are known while bit t is being mixed (host part + the order-N map's
 //     value; only set 26 needs this bit's final probability): the rows of t+1 are loaded into a second register set
 //     right after the dot products of t were issued; a row that bit t trains and bit t+1 selects again is taken from the
@@ -704,7 +551,7 @@ struct cmx_p8stage {
   P8Front* front = nullptr;
   P8Layout L;
   DevPolicy pol;
-  P8CmDev* d_fam = nullptr; P8FamHome* d_fam_home = nullptr; size_t fam_lds = 0; bool fam_v1 = false; P8Cm2Dev* d_cm2[P8_NCM2] = {}; P8LanesDev* d_lanes = nullptr; P8DmcDev* d_dmc = nullptr;
+  P8CmDev* d_fam = nullptr; P8FamHome* d_fam_home = nullptr; size_t fam_lds = 0; P8Cm2Dev* d_cm2[P8_NCM2] = {}; P8LanesDev* d_lanes = nullptr; P8DmcDev* d_dmc = nullptr;
   P8TailDev* d_tail = nullptr; P8MixDev* d_mix = nullptr;
   Staging st[P8S_BUFS];
   int next = 0;
@@ -774,7 +621,6 @@ cmx_p8stage_t* cmx_p8stage_create(int device) {
     h->d_fam = dev_copy(S->fam, h->pol);
     h->d_fam_home = S->fam_home;
     h->fam_lds = sizeof(P8FamShared) + (size_t)S->fam.nslots * 512;
-    h->fam_v1 = getenv("CMX_P8FAM_V1") != nullptr;   // A/B switch: the first design (p8cm_dev.h) instead of p8fam_dev.h
     for (int k = 0; k < P8_NCM2; k++) h->d_cm2[k] = dev_copy(S->cm2[k], h->pol);
     h->d_lanes = dev_copy(S->lanes, h->pol);
     h->d_dmc = dev_copy(S->dmc, h->pol);
@@ -877,7 +723,7 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
   const uint8_t* d_bits = (const uint8_t*)(b.d + b.o_bits);
   auto cm2 = [&](int k, hipStream_t q, uint8_t* ord) {
     (void)hipEventRecord(b.t0[2 + k], q);
-    hipLaunchKernelGGL(h->fam_v1 ? cmx_p8s_cm2_kernel : cmx_p8s_cm2v2_kernel, dim3(1), dim3(P8CM2_MAXC), 0, q, h->d_cm2[k], (const uint32_t*)(b.d + b.o_cctx[k]),
+    hipLaunchKernelGGL(cmx_p8s_cm2v2_kernel, dim3(1), dim3(P8CM2_MAXC), 0, q, h->d_cm2[k], (const uint32_t*)(b.d + b.o_cctx[k]),
                        (const uint16_t*)(b.d + b.o_cchk[k]), d_bits, dx, ord, nbits, skip);
     (void)hipEventRecord(b.t1[2 + k], q);
   };
@@ -886,12 +732,8 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
     ok = hipEventRecord(h->ev_ord, h->s_d) == hipSuccess;
     ok = ok && hipStreamWaitEvent(h->s_a, h->ev_ord, 0) == hipSuccess;   // (implies the upload)
     (void)hipEventRecord(b.t0[0], h->s_a);
-    if (h->fam_v1)
-      hipLaunchKernelGGL(cmx_p8s_fam_kernel, dim3(1), dim3(P8CM_MAXS), 0, h->s_a, h->d_fam, (const uint32_t*)(b.d + b.o_fctx), (const uint16_t*)(b.d + b.o_fchk), d_bits, dx,
-                         (const uint8_t*)dord, nbits, skip);
-    else
-      hipLaunchKernelGGL(cmx_p8s_fam2_kernel, dim3(1), dim3(P8CM_MAXS), h->fam_lds, h->s_a, h->d_fam, h->d_fam_home, (const uint32_t*)(b.d + b.o_fctx),
-                         (const uint16_t*)(b.d + b.o_fchk), d_bits, dx, (const uint8_t*)dord, nbits, skip);
+    hipLaunchKernelGGL(cmx_p8s_fam2_kernel, dim3(1), dim3(P8CM_MAXS), h->fam_lds, h->s_a, h->d_fam, h->d_fam_home, (const uint32_t*)(b.d + b.o_fctx),
+                       (const uint16_t*)(b.d + b.o_fchk), d_bits, dx, (const uint8_t*)dord, nbits, skip);
     (void)hipEventRecord(b.t1[0], h->s_a);
     ok = ok && hipEventRecord(h->ev_a, h->s_a) == hipSuccess;
     ok = ok && hipStreamWaitEvent(h->s_b, h->ev_up, 0) == hipSuccess;
@@ -913,12 +755,8 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
     ok = ok && hipEventRecord(h->ev_f, h->s_f) == hipSuccess;
     for (hipEvent_t e : {h->ev_a, h->ev_b, h->ev_c, h->ev_e, h->ev_f}) ok = ok && hipStreamWaitEvent(h->s_m, e, 0) == hipSuccess;
     (void)hipEventRecord(b.t0[1], h->s_m);
-    if (h->fam_v1 || getenv("CMX_P8MIX_V1"))
-      hipLaunchKernelGGL(cmx_p8s_mix_kernel, dim3(1), dim3(MX_THREADS), 0, h->s_m, (const P8MixDev*)h->d_mix, h->d_tail, (const int16_t*)dx, (const int32_t*)(b.d + b.o_sel),
-                         (const P8ApmRec*)(b.d + b.o_apm), (const uint8_t*)dord, d_bits, d_out, ld, nbits, t0, skip, h->last_bit);
-    else
-      hipLaunchKernelGGL(cmx_p8s_mix2_kernel, dim3(1), dim3(MX_THREADS), 0, h->s_m, (const P8MixDev*)h->d_mix, h->d_tail, (const int16_t*)dx, (const int32_t*)(b.d + b.o_sel),
-                         (const P8ApmRec*)(b.d + b.o_apm), (const uint8_t*)dord, d_bits, d_out, ld, nbits, t0, skip, h->last_bit, h->d_prof);
+    hipLaunchKernelGGL(cmx_p8s_mix2_kernel, dim3(1), dim3(MX_THREADS), 0, h->s_m, (const P8MixDev*)h->d_mix, h->d_tail, (const int16_t*)dx, (const int32_t*)(b.d + b.o_sel),
+                       (const P8ApmRec*)(b.d + b.o_apm), (const uint8_t*)dord, d_bits, d_out, ld, nbits, t0, skip, h->last_bit, h->d_prof);
     ok = ok && hipGetLastError() == hipSuccess;
     (void)hipEventRecord(b.t1[1], h->s_m);
     b.timed = true;

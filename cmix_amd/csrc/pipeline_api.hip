@@ -19,11 +19,63 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include <string>
+#include <thread>
 
 #include "../../include/cmix_amd.h"
 
 void cmx_set_err(const std::string& s);  // cmx_api.hip
+
+// ---- construction ahead of time ------------------------------------------------------------------------------
+// Most of an engine's construction does not depend on the input: the mixing network's 2.8 GB of weight rows and SSE tables, the
+// paq8 stage's 9 GB and the fxcm stage's 4.4 GB of tables are allocated and initialised the same way for every stream (only the
+// context stage, the LSTM and PPMd are sized by the vocabulary, which the preprocessed stream defines). cmx_prewarm() builds those
+// three stages on a thread of its own while the caller still preprocesses its input (runner.cpp:166-186: type detection, dictionary
+// transform, temp file) and scans the vocabulary; cmx_pipeline_create / _enable_fxcm / _enable_paq8 then adopt them.
+namespace {
+struct Prewarm {
+  std::thread th;
+  int device = 0;
+  bool want_fxcm = false, has_dict = false;
+  std::string dict;
+  cmx_mixnet_t* mix = nullptr;
+  cmx_fxcm_t* fx = nullptr;
+  cmx_p8stage_t* p8 = nullptr;
+  ~Prewarm() {   // never adopted (or only in part): finish and release
+    if (th.joinable()) th.join();
+    cmx_mixnet_destroy(mix); cmx_fxcm_destroy(fx); cmx_p8stage_destroy(p8);
+  }
+};
+std::mutex g_pw_mu;
+Prewarm* g_pw = nullptr;
+struct PrewarmAtExit { ~PrewarmAtExit() { std::lock_guard<std::mutex> l(g_pw_mu); delete g_pw; g_pw = nullptr; } } g_pw_at_exit;
+// the prewarmed set for `device`, its thread joined; nullptr if there is none
+Prewarm* prewarmed(int device) {
+  std::lock_guard<std::mutex> l(g_pw_mu);
+  if (!g_pw || g_pw->device != device) return nullptr;
+  if (g_pw->th.joinable()) g_pw->th.join();
+  return g_pw;
+}
+}  // namespace
+
+extern "C" int cmx_prewarm(int device, const char* dictionary_path, int with_fxcm) {
+  std::lock_guard<std::mutex> l(g_pw_mu);
+  if (g_pw) { cmx_set_err("cmx_prewarm: already called in this process"); return 1; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { cmx_set_err("cmx_prewarm: no HIP device " + std::to_string(device)); return 1; }
+  Prewarm* p = new Prewarm();
+  p->device = device; p->want_fxcm = with_fxcm != 0;
+  if (dictionary_path) { p->dict = dictionary_path; p->has_dict = true; }
+  p->th = std::thread([p]() {   // a stage that fails here is simply built (and its error reported) by the normal path later
+    (void)hipSetDevice(p->device);
+    p->mix = cmx_mixnet_create(p->device);
+    p->p8 = cmx_p8stage_create(p->device);
+    if (p->want_fxcm) p->fx = cmx_fxcm_create(p->has_dict ? p->dict.c_str() : nullptr, p->device);
+  });
+  g_pw = p;
+  return 0;
+}
 
 namespace {
 constexpr int kSlots = CMX_PIPELINE_SLOTS;  // chunks in flight: a chunk's latency (paq8 maps -> family -> paq8 mixer -> mixing network) is ~3 chunk periods
@@ -155,9 +207,12 @@ cmx_pipeline_t* cmx_pipeline_create(const uint8_t vocab[256], int device, size_t
   // every stage reports its own failure (no device, out of memory) through cmx_last_error()
   h->ctx = cmx_ctxmodels_create(vocab, device);
   h->lstm = h->ctx ? cmx_lstm_create(vocab, 31, device) : nullptr;  // 31 rand() draws precede the LSTM (indirect.cpp:10)
-  h->mix = h->lstm ? cmx_mixnet_create(device) : nullptr;
-  h->ppmd = h->mix ? cmx_ppmd_create(vocab) : nullptr;
-  if (!h->ppmd) { cmx_pipeline_destroy(h); return nullptr; }
+  h->ppmd = h->lstm ? cmx_ppmd_create(vocab) : nullptr;
+  if (h->ppmd) {   // the vocabulary-independent mixing network may have been built ahead of time (cmx_prewarm), beside the three above
+    if (Prewarm* pw = prewarmed(device)) { h->mix = pw->mix; pw->mix = nullptr; }
+    if (!h->mix) h->mix = cmx_mixnet_create(device);
+  }
+  if (!h->mix) { cmx_pipeline_destroy(h); return nullptr; }
   bool ok = hipSetDevice(device) == hipSuccess;
   // CMX_PIPELINE_STREAMS=2 (throughput mode, many streams per GPU): the context stage shares the LSTM's HIP stream.
   // Every HIP stream is a hardware queue; past ~24 active queues the hardware scheduler starts time-slicing them
@@ -202,7 +257,10 @@ int cmx_pipeline_enable_fxcm(cmx_pipeline_t* h, const char* dictionary_path) {
   if (h->fxcm) return 0;
   if (h->chunks) { cmx_set_err("cmx_pipeline_enable_fxcm: only before the first chunk"); return 1; }
   if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
-  cmx_fxcm_t* fx = cmx_fxcm_create(dictionary_path, h->device);
+  cmx_fxcm_t* fx = nullptr;
+  if (Prewarm* pw = prewarmed(h->device))   // built ahead of time for the same dictionary?
+    if (pw->fx && pw->has_dict == (dictionary_path != nullptr) && (!dictionary_path || pw->dict == dictionary_path)) { fx = pw->fx; pw->fx = nullptr; }
+  if (!fx) fx = cmx_fxcm_create(dictionary_path, h->device);
   if (!fx) return 1;
   const size_t n = h->max_chunk;
   bool ok = true;
@@ -239,7 +297,9 @@ int cmx_pipeline_enable_paq8(cmx_pipeline_t* h) {
   if (h->p8) return 0;
   if (h->chunks) { cmx_set_err("cmx_pipeline_enable_paq8: only before the first chunk"); return 1; }
   if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
-  cmx_p8stage_t* p8 = cmx_p8stage_create(h->device);
+  cmx_p8stage_t* p8 = nullptr;
+  if (Prewarm* pw = prewarmed(h->device)) { p8 = pw->p8; pw->p8 = nullptr; }
+  if (!p8) p8 = cmx_p8stage_create(h->device);
   if (!p8) return 1;
   bool ok = true;
   if (h->compact) h->s_p8 = h->s_mix;   // throughput mode: the mixing network's stream itself waits for the stage's mixer

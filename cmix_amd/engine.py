@@ -48,24 +48,6 @@ def lib():
         L.cmx_p8stage_destroy.argtypes = [C.c_void_p]
         L.cmx_p8stage_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
         L.cmx_p8stage_sync.argtypes = [C.c_void_p]
-        L.cmx_p8match_create.restype = C.c_void_p
-        L.cmx_p8match_create.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.cmx_p8match_destroy.argtypes = [C.c_void_p]
-        L.cmx_p8match_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.cmx_p8dmc_create.restype = C.c_void_p
-        L.cmx_p8dmc_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-        L.cmx_p8dmc_destroy.argtypes = [C.c_void_p]
-        L.cmx_p8dmc_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
-        L.cmx_p8cm_create.restype = C.c_void_p
-        L.cmx_p8cm_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.cmx_p8cm_destroy.argtypes = [C.c_void_p]
-        L.cmx_p8cm_slots.argtypes = [C.c_void_p]
-        L.cmx_p8cm_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
-        L.cmx_p8cm2_create.restype = C.c_void_p
-        L.cmx_p8cm2_create.argtypes = [C.c_int, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.cmx_p8cm2_destroy.argtypes = [C.c_void_p]
-        L.cmx_p8cm2_hash.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]
-        L.cmx_p8cm2_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.cmx_fxcm_create.restype = C.c_void_p
         L.cmx_fxcm_create.argtypes = [C.c_char_p, C.c_int]
         L.cmx_fxcm_destroy.argtypes = [C.c_void_p]
@@ -130,11 +112,6 @@ def lib():
         L.cmx_debug_last_row.argtypes = [C.c_void_p]
         L.cmx_ctxmodels_debug_slow_bytes.argtypes = [C.c_void_p, C.c_void_p]
         L.cmx_ctxmodels_peek.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
-        L.cmx_p8mixer_create.restype = C.c_void_p
-        L.cmx_p8mixer_create.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-        L.cmx_p8mixer_destroy.argtypes = [C.c_void_p]
-        L.cmx_p8mixer_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
-                                      C.c_void_p]
         L.cmx_encoder_create.restype = C.c_void_p
         L.cmx_encoder_destroy.argtypes = [C.c_void_p]
         L.cmx_encoder_encode_bits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
@@ -736,42 +713,6 @@ class Predictor:
     __del__ = close
 
 
-class P8Mixer:
-    """paq8's two-layer int16 mixer over a chunk of known bits (building block of the paq8 stage, SURVEY.md 8a')."""
-
-    def __init__(self, total_rows, squash4096, stretch4096, device=0):
-        sq = np.ascontiguousarray(squash4096, np.int16)
-        st = np.ascontiguousarray(stretch4096, np.int16)
-        assert sq.shape == (4096,) and st.shape == (4096,)
-        self.h = lib().cmx_p8mixer_create(device, int(total_rows), sq.ctypes.data, st.ctypes.data)
-        if not self.h:
-            raise CmxError(last_error())
-
-    def run(self, x, rows, bits, want_pr=False, stream=None):
-        """x [T,1552] i16, rows [T,28] i32, bits [T] u8 (cuda) -> p [T] i32 (and pr [T,28])."""
-        import torch
-        T = int(bits.numel())
-        assert x.dtype == torch.int16 and tuple(x.shape) == (T, 1552) and x.is_contiguous()
-        assert rows.dtype == torch.int32 and tuple(rows.shape) == (T, 28) and rows.is_contiguous()
-        p = torch.empty(T, dtype=torch.int32, device=x.device)
-        pr = torch.empty((T, 28), dtype=torch.int32, device=x.device) if want_pr else None
-        if stream is None:
-            stream = torch.cuda.current_stream(x.device).cuda_stream
-        if lib().cmx_p8mixer_run(self.h, x.data_ptr(), rows.data_ptr(), bits.data_ptr(), T, p.data_ptr(),
-                                 pr.data_ptr() if want_pr else None, C.c_void_p(stream)):
-            raise CmxError(last_error())
-        return p, pr
-
-    def close(self):
-        if getattr(self, "h", None):
-            lib().cmx_p8mixer_destroy(self.h)
-            self.h = None
-
-    __del__ = close
-
-
-FXCM_COLS = slice(3, 434)
-
 
 class Fxcm:
     """The fxcm stage of one stream on one GPU (chunk mode): layer-0 columns 3..433. The text parser half runs on the
@@ -860,151 +801,5 @@ class P8Stage:
             pass
 
 
-class P8ContextMap2:
-    """One instance of paq8's ContextMap2 on one GPU (building block of the paq8 stage, include/cmix_amd.h section 2e')."""
-
-    def __init__(self, size_bytes, count, nex, stretch, ilog, device=0):
-        nex, stretch, ilog = np.ascontiguousarray(nex, np.uint8), np.ascontiguousarray(stretch, np.int16), np.ascontiguousarray(ilog, np.uint8)
-        assert nex.size == 1024 and stretch.size == 4096 and ilog.size == 257
-        self.size_bytes, self.count = size_bytes, count
-        self.h = lib().cmx_p8cm2_create(device, size_bytes, count, nex.ctypes.data, stretch.ctypes.data, ilog.ctypes.data)
-        if not self.h:
-            raise CmxError(last_error())
-
-    def hash(self, cx):
-        """cx [n, count] u64 (the contexts of each byte, in set() order) -> (ctx32 [n, count] u32, chk16 [n, count] u16)."""
-        cx = np.ascontiguousarray(cx, np.uint64)
-        c32, k16 = np.zeros(cx.shape, np.uint32), np.zeros(cx.shape, np.uint16)
-        a, b = C.c_uint32(0), C.c_uint16(0)
-        for n in range(cx.shape[0]):
-            for i in range(cx.shape[1]):
-                lib().cmx_p8cm2_hash(int(cx[n, i]), i, self.size_bytes, C.byref(a), C.byref(b))
-                c32[n, i], k16[n, i] = a.value, b.value
-        return c32, k16
-
-    def run(self, ctx32, chk16, bits, stream=None):
-        """ctx32 [n, count] i32-viewed u32 cuda, chk16 [n, count] i16-viewed u16 cuda, bits [8n] u8 cuda -> [8n, 7 count] i16."""
-        import torch
-        n = int(ctx32.shape[0])
-        assert ctx32.is_cuda and ctx32.is_contiguous() and ctx32.numel() == n * self.count and ctx32.element_size() == 4
-        assert chk16.is_cuda and chk16.is_contiguous() and chk16.numel() == n * self.count and chk16.element_size() == 2
-        assert bits.is_cuda and bits.dtype == torch.uint8 and bits.is_contiguous() and bits.numel() == 8 * n
-        out = torch.zeros((8 * n, 7 * self.count), dtype=torch.int16, device=bits.device)
-        if stream is None:
-            stream = torch.cuda.current_stream(bits.device).cuda_stream
-        if lib().cmx_p8cm2_run(self.h, ctx32.data_ptr(), chk16.data_ptr(), bits.data_ptr(), n, out.data_ptr(), C.c_void_p(stream)):
-            raise CmxError(last_error())
-        return out
-
-    def close(self):
-        if getattr(self, "h", None):
-            lib().cmx_p8cm2_destroy(self.h)
-            self.h = None
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
 
 
-class P8ContextMapFamily:
-    """All instances of paq8's older ContextMap of one predictor on one GPU (include/cmix_amd.h section 2e")."""
-
-    def __init__(self, sizes, counts, nex, stretch, ilog, device=0):
-        nex, stretch, ilog = np.ascontiguousarray(nex, np.uint8), np.ascontiguousarray(stretch, np.int16), np.ascontiguousarray(ilog, np.uint8)
-        sz, ct = np.array(sizes, np.uint64), np.array(counts, np.int32)
-        self.total = int(ct.sum())
-        self.h = lib().cmx_p8cm_create(device, len(sz), sz.ctypes.data, ct.ctypes.data, nex.ctypes.data, stretch.ctypes.data, ilog.ctypes.data)
-        if not self.h:
-            raise CmxError(last_error())
-
-    def run(self, ctx32, chk16, bits, stream=None):
-        import torch
-        n = int(ctx32.shape[0])
-        assert ctx32.is_cuda and ctx32.is_contiguous() and ctx32.numel() == n * self.total and ctx32.element_size() == 4
-        assert chk16.is_cuda and chk16.is_contiguous() and chk16.numel() == n * self.total and chk16.element_size() == 2
-        assert bits.is_cuda and bits.dtype == torch.uint8 and bits.is_contiguous() and bits.numel() == 8 * n
-        out = torch.zeros((8 * n, 5 * self.total), dtype=torch.int16, device=bits.device)
-        if stream is None:
-            stream = torch.cuda.current_stream(bits.device).cuda_stream
-        if lib().cmx_p8cm_run(self.h, ctx32.data_ptr(), chk16.data_ptr(), bits.data_ptr(), n, out.data_ptr(), C.c_void_p(stream)):
-            raise CmxError(last_error())
-        return out
-
-    def close(self):
-        if getattr(self, "h", None):
-            lib().cmx_p8cm_destroy(self.h)
-            self.h = None
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
-
-
-class P8DmcForest:
-    """paq8's DMC forest on one GPU (include/cmix_amd.h section 2e"'): bits in, six mixer inputs per bit out."""
-
-    def __init__(self, level, nex, stretch, device=0):
-        nex, stretch = np.ascontiguousarray(nex, np.uint8), np.ascontiguousarray(stretch, np.int16)
-        self.h = lib().cmx_p8dmc_create(device, level, nex.ctypes.data, stretch.ctypes.data)
-        if not self.h:
-            raise CmxError(last_error())
-
-    def run(self, bits, stream=None):
-        import torch
-        assert bits.is_cuda and bits.dtype == torch.uint8 and bits.is_contiguous()
-        out = torch.zeros((bits.numel(), 6), dtype=torch.int16, device=bits.device)
-        if stream is None:
-            stream = torch.cuda.current_stream(bits.device).cuda_stream
-        if lib().cmx_p8dmc_run(self.h, bits.data_ptr(), bits.numel(), out.data_ptr(), C.c_void_p(stream)):
-            raise CmxError(last_error())
-        return out
-
-    def close(self):
-        if getattr(self, "h", None):
-            lib().cmx_p8dmc_destroy(self.h)
-            self.h = None
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
-
-
-class P8MatchModels:
-    """paq8's MatchModel + SparseMatchModel on one GPU (include/cmix_amd.h section 2e""): bytes in; 28 inputs, 3 statistics, 2 selectors per bit out."""
-
-    def __init__(self, match_bytes, sparse_bytes, hist_log2, nex, stretch, ilog65536, device=0):
-        nex, stretch, ilog = np.ascontiguousarray(nex, np.uint8), np.ascontiguousarray(stretch, np.int16), np.ascontiguousarray(ilog65536, np.uint8)
-        assert ilog.size == 65536
-        self.h = lib().cmx_p8match_create(device, match_bytes, sparse_bytes, hist_log2, nex.ctypes.data, stretch.ctypes.data, ilog.ctypes.data)
-        if not self.h:
-            raise CmxError(last_error())
-
-    def run(self, data, stream=None):
-        import torch
-        assert data.is_cuda and data.dtype == torch.uint8 and data.is_contiguous()
-        T = 8 * data.numel()
-        out = torch.zeros((T, 28), dtype=torch.int16, device=data.device)
-        stats = torch.zeros((T, 3), dtype=torch.int32, device=data.device)
-        sets = torch.zeros((T, 2), dtype=torch.int32, device=data.device)
-        if stream is None:
-            stream = torch.cuda.current_stream(data.device).cuda_stream
-        if lib().cmx_p8match_run(self.h, data.data_ptr(), data.numel(), out.data_ptr(), stats.data_ptr(), sets.data_ptr(), C.c_void_p(stream)):
-            raise CmxError(last_error())
-        return out, stats, sets
-
-    def close(self):
-        if getattr(self, "h", None):
-            lib().cmx_p8match_destroy(self.h)
-            self.h = None
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass

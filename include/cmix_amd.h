@@ -236,87 +236,6 @@ int cmx_ctxmodels_sync(cmx_ctxmodels_t*);
 int cmx_ctxmodels_get_manager(cmx_ctxmodels_t*, uint64_t* regs25, uint64_t* ctx54, uint64_t* bitctx8);
 
 /* ------------------------------------------------------------------------
- * 2e. Building block of the paq8 / fxcm stages (not yet wired into a stage): paq8's two-layer int16 mixer
- *     (src/models/paq8.cpp:513-598, dot_product / train :403-432) over a chunk of known bits. DEVICE pointers:
- *       d_x    [nbits][1552] i16  the values Mixer::add() receives for the bit (stretch domain), in call order
- *       d_rows [nbits][28]   i32  weight-set selectors as Mixer::set() leaves them (cumulative base + cx)
- *       d_bits [nbits]       u8
- *       d_p    [nbits]       i32  OUT Mixer::p() (12-bit probability)
- *       d_pr   [nbits][28]   i32  OUT (may be NULL) the first layer's squashed outputs
- *     squash4096[d + 2048] = squash(d), stretch4096[p] = stretch(p): paq8's two tables (HOST, copied once).
- * ------------------------------------------------------------------------ */
-typedef struct cmx_p8mixer cmx_p8mixer_t;
-cmx_p8mixer_t* cmx_p8mixer_create(int device, int total_rows, const int16_t squash4096[4096], const int16_t stretch4096[4096]);
-void cmx_p8mixer_destroy(cmx_p8mixer_t*);
-int cmx_p8mixer_run(cmx_p8mixer_t*, const int16_t* d_x, const int* d_rows, const uint8_t* d_bits, size_t nbits, int* d_p,
-                    int* d_pr, void* stream);
-
-/* ------------------------------------------------------------------------
- * 2e'. Building block of the paq8 stage (not yet wired into a stage): paq8's ContextMap2 (src/models/paq8.cpp:1164-1358;
- *      instances: contextModel2's order-N map :8102, TextModel's :3137, exeModel's :7275) for ONE instance of `count`
- *      contexts over a chunk of known bits; seven mixer inputs per context and bit, in ContextMap2::mix's order.
- *        d_ctx  [nbytes][count] u32  bucket-index hashes   } what ContextMap2::set (:1305-1310) derives from the 64-bit
- *        d_chk  [nbytes][count] u16  bucket checksums      } context of call `index`: cmx_p8cm2_hash (HOST helper)
- *        d_bits [8*nbytes]      u8   the coded bits; step t uses bit t-1 as "last bit" (the previous chunk's last bit for t = 0)
- *        d_out  [8*nbytes][7*count] i16 OUT
- *      size_bytes: the table size the reference passes (a power of two >= 64 KB); nex1024[4 s + k] = nex(s, k),
- *      stretch4096[p] = stretch(p), ilog257[x] = ilog(x): paq8's tables (HOST, copied once).
- * ------------------------------------------------------------------------ */
-typedef struct cmx_p8cm2 cmx_p8cm2_t;
-cmx_p8cm2_t* cmx_p8cm2_create(int device, uint64_t size_bytes, int count, const uint8_t nex1024[1024], const int16_t stretch4096[4096],
-                              const uint8_t ilog257[257]);
-void cmx_p8cm2_destroy(cmx_p8cm2_t*);
-void cmx_p8cm2_hash(uint64_t ctx, uint32_t index, uint64_t size_bytes, uint32_t* ctx32, uint16_t* chk16);
-int cmx_p8cm2_run(cmx_p8cm2_t*, const uint32_t* d_ctx, const uint16_t* d_chk, const uint8_t* d_bits, size_t nbytes, int16_t* d_out, void* stream);
-
-/* ------------------------------------------------------------------------
- * 2e". Building block of the paq8 stage (not yet wired into a stage): the FAMILY of paq8's older ContextMap instances
- *      (src/models/paq8.cpp:1010-1145; wordModel :3880, sparseModel :4505, sparseModel1 :4540, indirectModel :7549,
- *      nestModel :4111, recordModel :4213, distanceModel :4599, XMLModel :7915) over a chunk of known bits. One handle
- *      = all instances, listed in the order the reference calls their mix(): they share the process-global rnd()
- *      (:152-165, drawn at :1075 when a bit history reaches state >= 204) and its draws are handed out in that order.
- *      Five mixer inputs per context and bit. total = sum of counts:
- *        d_ctx [nbytes][total] u32, d_chk [nbytes][total] u16: cmx_p8cm2_hash(ctx, index within the instance, that
- *        instance's size_bytes, ...) -- ContextMap::set (:1064-1069) hashes like ContextMap2::set
- *        d_bits [8*nbytes] u8; d_out [8*nbytes][5*total] i16 OUT.  Tables as for cmx_p8cm2_create.
- * ------------------------------------------------------------------------ */
-typedef struct cmx_p8cm cmx_p8cm_t;
-cmx_p8cm_t* cmx_p8cm_create(int device, int ninst, const uint64_t* size_bytes, const int* counts, const uint8_t nex1024[1024],
-                            const int16_t stretch4096[4096], const uint8_t ilog257[257]);
-void cmx_p8cm_destroy(cmx_p8cm_t*);
-int cmx_p8cm_slots(cmx_p8cm_t*);
-int cmx_p8cm_run(cmx_p8cm_t*, const uint32_t* d_ctx, const uint16_t* d_chk, const uint8_t* d_bits, size_t nbytes, int16_t* d_out, void* stream);
-
-/* ------------------------------------------------------------------------
- * 2e"'. Building block of the paq8 stage (not yet wired into a stage): the DMC forest (src/models/paq8.cpp:7637-7822:
- *       ten dmcModel state graphs + dmcForest::mix). Needs the coded bits only. level: paq8's memory level (cmix: 11,
- *       predictor.cpp:85; ~0.7 GB of nodes). d_bits [nbits] u8 (any number of bits per call, in stream order),
- *       d_out [nbits][6] i16 OUT: the six mixer inputs before each bit. nex1024 / stretch4096 as for cmx_p8cm2_create.
- * ------------------------------------------------------------------------ */
-typedef struct cmx_p8dmc cmx_p8dmc_t;
-cmx_p8dmc_t* cmx_p8dmc_create(int device, int level, const uint8_t nex1024[1024], const int16_t stretch4096[4096]);
-void cmx_p8dmc_destroy(cmx_p8dmc_t*);
-int cmx_p8dmc_run(cmx_p8dmc_t*, const uint8_t* d_bits, size_t nbits, int16_t* d_out, void* stream);
-
-/* ------------------------------------------------------------------------
- * 2e"". Building block of the paq8 stage (not yet wired into a stage): MatchModel (src/models/paq8.cpp:3520-3692) and
- *       SparseMatchModel (:3694-3843) with their SmallStationaryContextMap / StationaryMap / IndirectMap read-outs
- *       (:891-1008). Needs the bytes only. match_bytes / sparse_bytes: the two position tables (powers of two);
- *       hist_log2: the byte-history ring (Buf :169-187). d_bytes [nbytes] u8 (whole bytes, stream order);
- *       d_out [8*nbytes][28] i16 OUT: 17 MatchModel inputs then 11 SparseMatchModel inputs before each bit;
- *       d_stats [8*nbytes][3] i32 OUT: match length, expected byte at bit 0 (else -1), sparse match length;
- *       d_sets [8*nbytes][2] i32 OUT: the sparse model's two mixer weight-set selectors. ilog65536[x] = ilog(x).
- * ------------------------------------------------------------------------ */
-typedef struct cmx_p8match cmx_p8match_t;
-cmx_p8match_t* cmx_p8match_create(int device, uint64_t match_bytes, uint64_t sparse_bytes, int hist_log2, const uint8_t nex1024[1024],
-                                  const int16_t stretch4096[4096], const uint8_t ilog65536[65536]);
-void cmx_p8match_destroy(cmx_p8match_t*);
-int cmx_p8match_run(cmx_p8match_t*, const uint8_t* d_bytes, size_t nbytes, int16_t* d_out, int* d_stats, int* d_sets, void* stream);
-/* The same, skipping the steps before bit `first_bit` of the chunk's first byte (rows before it untouched). first_bit = 1 on a
- * stream's first chunk starts the models the way paq8's Predictor does: its first contextModel2 call comes after one coded bit. */
-int cmx_p8match_run_from(cmx_p8match_t*, const uint8_t* d_bytes, size_t nbytes, int first_bit, int16_t* d_out, int* d_stats, int* d_sets, void* stream);
-
-/* ------------------------------------------------------------------------
  * 2f. Stage: the vendored fxcm model = FXCM::Predict / FXCM::Perceive (src/models/fxcm.cpp:14-33) around
  *     fxcmv1::Predictor::update1 + modelPrediction (src/models/fxcmv1.cpp:4758-4833, :3798-4757); cmix wires it at
  *     predictor.cpp:98-99 (construction, dictionary path), :462-468 (lstmpr / lstmex set, then Perceive last).
@@ -397,14 +316,22 @@ int cmx_ppmd_run(cmx_ppmd_t*, const uint8_t* bytes, size_t nbytes, float* out_pr
  *    a chunk's latency through the stages is several chunk periods, the depth keeps every stage busy).
  * ------------------------------------------------------------------------ */
 /* Environment read by the engine (all optional):
- *   GPU_MAX_HW_QUEUES      (HIP's own) must be >= 13 before the first HIP call for the stages of one stream to overlap: an
- *                          engine uses 13 HIP streams (5 stages, upload, 6 paq8 roles, paq8 hand-over) and HIP maps streams
- *                          onto 4 hardware queues by default. bench.py and cmix_engine set 16.
+ *   GPU_MAX_HW_QUEUES      (HIP's own) must be >= 14 before the first HIP call for the stages of one stream to overlap: an
+ *                          engine uses 14 HIP streams (5 stages, upload, 7 paq8 roles, paq8 hand-over) and HIP maps streams
+ *                          onto 4 hardware queues by default. The library sets 16 when it is loaded unless the variable is set.
  *   CMX_PIPELINE_STREAMS   2 or 1: throughput mode for several streams per GPU -- fewer hardware queues per engine (8 or 6;
  *                          roles take turns on shared streams, the per-stream period grows)
- *   CMX_LSTM_V1, CMX_FXCM_V1, CMX_P8FAM_V1, CMX_P8MIX_V1   the one-workgroup / first-design kernels (A/B reference)
+ *   CMX_MIXNET_SPEC=0      the one-workgroup mixing-network kernel (1 compute unit per stream instead of 27: many streams per GPU)
  *   CMX_FXCM_PROFILE, CMX_P8MIX_PROFILE, CMX_MIXNET_DBG     in-kernel phase timers / timing experiments (scripts/gpu_*prof*) */
 #define CMX_PIPELINE_SLOTS 8   /* chunks in flight per stream (layer-0 matrices the caller cycles through) */
+/* Construction ahead of time: start building the vocabulary-independent stages of an engine for `device` -- mixing
+ * network, paq8 stage and (with_fxcm != 0; dictionary_path as for cmx_pipeline_enable_fxcm) the fxcm stage, ~16 GB of tables -- on a
+ * thread of the library, and return at once. The caller goes on with what has to precede the predictor (runner.cpp:166-202:
+ * preprocessing into the temp file, the vocabulary scan); the next cmx_pipeline_create / _enable_fxcm / _enable_paq8 on that device
+ * (also behind cmx_stage_input) adopts whatever is ready and waits for what is not. Once per process; purely an optimisation: every
+ * stage that was not prewarmed (or failed to) is built by the normal path. */
+int cmx_prewarm(int device, const char* dictionary_path, int with_fxcm);
+
 typedef struct cmx_pipeline cmx_pipeline_t;
 cmx_pipeline_t* cmx_pipeline_create(const uint8_t vocab[256], int device, size_t max_chunk_bytes);
 void cmx_pipeline_destroy(cmx_pipeline_t*);

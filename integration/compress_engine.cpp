@@ -8,6 +8,7 @@
 // Per chunk: cmx_pipeline_submit = PPMd + the fxcm / paq8 text parsers on this thread, every learning stage and the final
 // mixing network on the MI355X; the probabilities come back a chunk at a time and feed the arithmetic coder
 // (cmx_encoder_*). tests/test_gpu_dropin.py compares its files with the reference binary's, byte for byte.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -80,6 +81,15 @@ int main(int argc, char* argv[]) {
     output_path = argv[4];
   }
   const std::string temp_path = output_path + ".cmix.temp";
+  // ---- the vocabulary-independent stages of the engine (mixing network, paq8 and fxcm stages: ~16 GB of tables to
+  // allocate and initialise) are built on a library thread WHILE this thread preprocesses the input and scans the vocabulary ----
+  const auto t_start = std::chrono::steady_clock::now();
+  auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
+  const bool timing = getenv("CMIX_TIMING") != NULL;
+  {
+    const char* dev = getenv("CMIX_DEVICE");
+    if (!getenv("CMIX_NO_PREWARM") && cmx_prewarm(dev ? atoi(dev) : 0, dictionary_path, 1)) Predictor::Die();
+  }
   // ---- runner.cpp:166-186: the reference's preprocessor into a temp file ----
   FILE* data_in = fopen(input_path.c_str(), "rb");
   FILE* temp_out = data_in ? fopen(temp_path.c_str(), "wb") : NULL;
@@ -110,9 +120,12 @@ int main(int argc, char* argv[]) {
   for (int i = 0; i < 256; ++i) v8[i] = vocab[i];
   const size_t hn = cmx_header_write(data.size(), v8, dictionary != NULL, hdr);
   if (!hn) Predictor::Die();
+  const double t_pre = since();
   Predictor p(vocab, kChunk);
+  const double t_ready = since();
   if (enable_preprocess) preprocessor::Pretrain(&p, dictionary);
   p.FlushPretrain();
+  const double t_trained = since();
   // ---- runner.cpp:101-119: the coding loop, a chunk at a time ----
   cmx_encoder_t* enc = cmx_encoder_create();
   CompressEngine(&p, data, enc);
@@ -124,6 +137,10 @@ int main(int argc, char* argv[]) {
   const unsigned long long output_bytes = hn + cmx_encoder_size(enc);
   fclose(out);
   cmx_encoder_destroy(enc);
+  if (timing)
+    fprintf(stderr, "\ncmix_engine timing: preprocessing + vocabulary %.2f s | engine ready +%.2f s (%s) | pretraining +%.2f s | coding +%.2f s | total %.2f s\n", t_pre,
+            t_ready - t_pre, getenv("CMIX_NO_PREWARM") ? "built after preprocessing" : "vocabulary-independent stages built during preprocessing", t_trained - t_ready,
+            since() - t_trained, since());
   printf("\r%llu bytes -> %llu bytes (engine: all model families on the device).\n", input_bytes, output_bytes);
   return 0;
 }

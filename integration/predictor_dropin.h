@@ -25,6 +25,20 @@
 
 extern char* dictionary_path;  // runner.cpp:17
 
+// SURVEY.md 8f-3 without touching main(): the vocabulary-independent stages the engine needs whatever the input is (mixing network,
+// paq8 stage: ~12 GB of tables) start being built on a library thread when the program starts, i.e. while runner.cpp parses its
+// arguments and preprocesses the input into the temp file; the Predictor constructed afterwards adopts them (cmx_prewarm). The fxcm
+// stage waits for the dictionary path, which only main() knows. CMIX_NO_PREWARM=1 switches this off (decompression does not use
+// the chunk pipeline's stages).
+inline void cmx_dropin_prewarm_once() {
+  static const int once = []() {
+    if (!getenv("CMIX_NO_PREWARM")) { const char* dev = getenv("CMIX_DEVICE"); (void)cmx_prewarm(dev ? atoi(dev) : 0, NULL, 0); }
+    return 0;
+  }();
+  (void)once;
+}
+namespace { struct CmxAtStart { CmxAtStart() { cmx_dropin_prewarm_once(); } } cmx_at_start; }
+
 class Predictor {
  public:
   explicit Predictor(const std::vector<bool>& vocab) {

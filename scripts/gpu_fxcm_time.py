@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Time the fxcm stage on one GPU: us per bit of cmx_fxcm_chunk_kernel (HIP events around cmx_fxcm_run, host parser time
+"""Time the fxcm stage on one GPU: us per bit of cmx_fxcm_roles_kernel (HIP events around cmx_fxcm_run, host parser time
 reported separately), 1 KB chunks of enwik-like text after a warm-up. CMX_FXCM_SERIAL_MAPS=1 times the one-lane-per-map
-variant.     python scripts/gpu_fxcm_time.py [nchunks]"""
+variant; CMX_FXCM_PROFILE=1 prints thread 0's clocks per phase of each of the three roles.     python scripts/gpu_fxcm_time.py [nchunks]"""
 import os
 import sys
 import time
@@ -42,5 +42,11 @@ if os.environ.get("CMX_FXCM_PROFILE") == "1":
     E.lib().cmx_fxcm_profile.argtypes = [C.c_void_p, C.c_void_p]
     if E.lib().cmx_fxcm_profile(fx.h, acc) == 0:
         nb = 8.0 * 1024 * (nchunks + 4)
-        for w in range(8):
-            print("wave %d clocks per bit by phase (1a work, 1a barrier, 1c, 2, 3, 4, 5):" % w, " ".join("%6.0f" % (acc[8 * w + i] / nb) for i in range(7)), "| 1c work %.0f | total %.0f" % (acc[8 * w + 7] / nb, sum(acc[8 * w + i] for i in range(8)) / nb))
+        names = {0: ("M", ["touch (bucket lists, fetches)", "full barrier (load / store drain)", "phase 1c (maps run)", "lds barrier", "row stores", "store drain + publish"]),
+                 1: ("U", ["units (match models, SSCMs, run map)", "lds barrier", "row stores", "store drain + publish"]),
+                 2: ("X", ["wait M/U rows", "lds barrier", "gather inputs + trainers + APM updates", "full barrier (store drain)", "phase 2 (selectors)", "phases 3-4 (dots)",
+                           "phase 5 (final mixers + APM chain)", "row stores"])}
+        for r in range(3):
+            nm, ph = names[r]
+            vals = [acc[16 * r + k] / nb for k in range(len(ph))]
+            print("role %s: %6.0f clk/bit |" % (nm, sum(vals)), "  ".join("%s %.0f" % (a_, b_) for a_, b_ in zip(ph, vals)))
