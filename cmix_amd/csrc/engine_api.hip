@@ -327,9 +327,7 @@ float la_predict(cmx_engine* h) {
     }
   }
   if (!la->loaded) {
-    const size_t k = la->n_done % kLaSlots;
-    if (cmx_pipeline_wait(la->pipe, la->n_done)) return -1.0f;
-    if (cmx_copy_to_host(h->device, la->h_p, la->d_p[k], 8 * la->ring[k].n * sizeof(float))) return -1.0f;
+    if (cmx_pipeline_fetch(la->pipe, la->n_done, la->h_p)) return -1.0f;   // this chunk only: the seven behind it stay in flight
     la->loaded = true;
     la->bit = 0;
   }

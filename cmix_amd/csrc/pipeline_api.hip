@@ -92,6 +92,7 @@ struct Slot {
   unsigned* h_fail = nullptr;   // pinned [2]: the LSTM's / fxcm's sticky hand-off flags as they stood behind this chunk's kernels
   size_t n = 0;                 // bytes of the chunk in this slot
   float* d_layer0 = nullptr;    // the caller's layer-0 rows of that chunk
+  float* d_p = nullptr;         // the caller's p[] buffer of that chunk (cmx_pipeline_fetch)
   hipEvent_t ev_in = nullptr, ev_ctx0 = nullptr, ev_ctx1 = nullptr, ev_lstm0 = nullptr, ev_lstm1 = nullptr,
              ev_mix0 = nullptr, ev_mix1 = nullptr, ev_cols = nullptr;
   int16_t* d_fx_pr = nullptr;   // [8 max] fxcm stage (opt-in): lstmpr per update
@@ -481,6 +482,7 @@ static int finish_impl(cmx_pipeline_t* h, const float* cols, int first_col, int 
   (void)hipEventRecord(s.ev_mix0, h->s_mix);
   if (cmx_mixnet_run(h->mix, s.d_layer0, s.d_sel, s.d_bits, 8 * n, d_p_out, nullptr, h->s_mix)) return 1;
   (void)hipEventRecord(s.ev_mix1, h->s_mix);
+  s.d_p = d_p_out;
   h->host_ms[5] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fin).count();
   s.untimed = true;
   h->last_slot = (int)(h->finished % kSlots);
@@ -510,29 +512,30 @@ int cmx_pipeline_pretrain(cmx_pipeline_t* h, const uint8_t* bytes, size_t n) {
   uint8_t* d = nullptr;
   if (hipMalloc((void**)&d, n) != hipSuccess) { cmx_set_err("cmx_pipeline_pretrain: hipMalloc failed"); return 1; }
   bool ok = hipMemcpyAsync(d, bytes, n, hipMemcpyHostToDevice, h->s_ctx) == hipSuccess;
+  hipEvent_t ev_d = nullptr;   // the dictionary bytes are on the device before the fxcm kernels read them
+  ok = ok && hipEventCreateWithFlags(&ev_d, hipEventDisableTiming) == hipSuccess && hipEventRecord(ev_d, h->s_ctx) == hipSuccess;
   ok = ok && cmx_ctxmodels_pretrain(h->ctx, d, n, h->s_ctx) == 0;
-  ok = hipStreamSynchronize(h->s_ctx) == hipSuccess && ok;
-  if (ok && h->fxcm) {  // fxcm is one of models_: Predict + Perceive per dictionary bit with the hints at their start-up value 0 (predictor.cpp:359,471-476)
-    const size_t C = h->max_chunk;
-    int16_t* zpr = nullptr; uint8_t* zex = nullptr;
+  // fxcm and paq8 are two of models_: Predict + Perceive per dictionary bit (predictor.cpp:471-476), fxcm with the hints at their start-up
+  // value 0 (:359); the rows are discarded. The three stages learn independently, so their chunks are enqueued side by side (context
+  // stage on its stream, fxcm and paq8 chunk by chunk on theirs) and waited for once: the dictionary costs the slowest stage, not the sum.
+  const size_t C = h->max_chunk;
+  int16_t* zpr = nullptr; uint8_t* zex = nullptr;
+  if (ok && h->fxcm) {
     ok = hipMalloc((void**)&zpr, 8 * C * 2) == hipSuccess && hipMalloc((void**)&zex, 8 * C) == hipSuccess;
     ok = ok && hipMemsetAsync(zpr, 0, 8 * C * 2, h->s_fx) == hipSuccess && hipMemsetAsync(zex, 0, 8 * C, h->s_fx) == hipSuccess;
-    for (size_t off = 0; ok && off < n; off += C) {
-      const size_t m = n - off < C ? n - off : C;
-      ok = cmx_fxcm_run(h->fxcm, bytes + off, d + off, m, zpr, zex, h->d_fx_scratch, 434, h->s_fx) == 0;
-    }
-    ok = hipStreamSynchronize(h->s_fx) == hipSuccess && ok;
-    if (zpr) (void)hipFree(zpr);
-    if (zex) (void)hipFree(zex);
+    ok = ok && hipStreamWaitEvent(h->s_fx, ev_d, 0) == hipSuccess;
   }
-  if (ok && h->p8) {  // paq8 is one of models_ too: its Perceive per dictionary bit (predictor.cpp:471-476), the rows are discarded
-    const size_t C = h->max_chunk;
-    for (size_t off = 0; ok && off < n; off += C) {
-      const size_t m = n - off < C ? n - off : C;
-      ok = cmx_p8stage_run(h->p8, bytes + off, m, h->d_p8_scratch, 1591, h->s_p8) == 0;
-    }
-    ok = hipStreamSynchronize(h->s_p8) == hipSuccess && ok;
+  for (size_t off = 0; ok && off < n; off += C) {
+    const size_t m = n - off < C ? n - off : C;
+    if (h->fxcm) ok = cmx_fxcm_run(h->fxcm, bytes + off, d + off, m, zpr, zex, h->d_fx_scratch, 434, h->s_fx) == 0;
+    if (ok && h->p8) ok = cmx_p8stage_run(h->p8, bytes + off, m, h->d_p8_scratch, 1591, h->s_p8) == 0;
   }
+  ok = hipStreamSynchronize(h->s_ctx) == hipSuccess && ok;
+  if (h->fxcm) ok = hipStreamSynchronize(h->s_fx) == hipSuccess && ok;
+  if (h->p8) ok = hipStreamSynchronize(h->s_p8) == hipSuccess && ok;
+  if (zpr) (void)hipFree(zpr);
+  if (zex) (void)hipFree(zex);
+  if (ev_d) (void)hipEventDestroy(ev_d);
   (void)hipFree(d);
   if (!ok) { cmx_set_err("cmx_pipeline_pretrain: device error"); return 1; }
   return 0;
@@ -553,6 +556,21 @@ int cmx_pipeline_wait(cmx_pipeline_t* h, uint64_t index) {
     cmx_set_err(std::string("cmx_pipeline_wait: an in-launch hand-off of the ") + (s.h_fail[0] ? "LSTM" : "fxcm") +
                 " kernels timed out (workgroups not co-resident?): the stream's output is void from chunk " + std::to_string(index) + " on");
     h->failed = true;
+    return 1;
+  }
+  return 0;
+}
+
+// cmx_pipeline_wait(index), then the chunk's probabilities (8 x its byte count floats) into p_host. Only this chunk is waited for:
+// the chunks behind it stay in flight (a device-wide synchronisation here -- what cmx_copy_to_host does -- would drain the whole
+// pipeline once per chunk and cost two thirds of the throughput: a chunk's latency is three chunk periods).
+int cmx_pipeline_fetch(cmx_pipeline_t* h, uint64_t index, float* p_host) {
+  if (!p_host) { cmx_set_err("cmx_pipeline_fetch: bad argument"); return 1; }
+  if (cmx_pipeline_wait(h, index)) return 1;
+  const Slot& s = h->slot[index % kSlots];
+  // the upload stream is idle between submits (its copies were waited for by the stages long ago) and non-blocking: the copy runs at once
+  if (hipMemcpyAsync(p_host, s.d_p, 8 * s.n * sizeof(float), hipMemcpyDeviceToHost, h->s_up) != hipSuccess || hipStreamSynchronize(h->s_up) != hipSuccess) {
+    cmx_set_err("cmx_pipeline_fetch: device-to-host copy failed");
     return 1;
   }
   return 0;

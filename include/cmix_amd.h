@@ -372,6 +372,9 @@ int cmx_pipeline_enable_fxcm(cmx_pipeline_t*, const char* dictionary_path);
 int cmx_pipeline_enable_paq8(cmx_pipeline_t*);
 /* Wait until chunk number `index` (0 = the first submitted) has left the mixing network; only the last CMX_PIPELINE_SLOTS can be waited for. */
 int cmx_pipeline_wait(cmx_pipeline_t*, uint64_t index);
+/* cmx_pipeline_wait(index), then that chunk's probabilities (8 x its byte count floats, from the d_p_out it was submitted with) into
+ * the HOST buffer p_host (page-locked for speed). Waits for this chunk only; the chunks behind it stay in flight. */
+int cmx_pipeline_fetch(cmx_pipeline_t*, uint64_t index, float* p_host);
 int cmx_pipeline_paq8_enabled(cmx_pipeline_t*);
 int cmx_pipeline_paq8_total_ms(cmx_pipeline_t*, double* ms);
 /* the paq8 stage's role-kernel times (cmx_p8stage_role_ms) since the last reset of the stage totals */

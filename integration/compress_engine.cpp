@@ -46,13 +46,13 @@ void CompressEngine(Predictor* P, const std::vector<uint8_t>& data, cmx_encoder_
     d_p[i] = (float*)cmx_device_alloc(dev, T * sizeof(float));
     if (!d_layer0[i] || !d_p[i]) Predictor::Die();
   }
-  std::vector<float> p(T);
+  float* const p = (float*)cmx_host_alloc(T * sizeof(float));   // page-locked
+  if (!p) Predictor::Die();
   const size_t nchunks = (N + C - 1) / C;
   auto len = [&](size_t c) { return c + 1 < nchunks ? C : N - c * C; };
   auto drain = [&](size_t c) {   // chunk c: wait, copy its probabilities back, code its bytes
-    if (cmx_pipeline_wait(P->pipe(), c)) Predictor::Die();
-    if (cmx_copy_to_host(dev, p.data(), d_p[c % R], 8 * len(c) * sizeof(float))) Predictor::Die();
-    if (cmx_encoder_encode_bytes(enc, p.data(), data.data() + c * C, len(c))) Predictor::Die();
+    if (cmx_pipeline_fetch(P->pipe(), c, p)) Predictor::Die();   // waits for this chunk only
+    if (cmx_encoder_encode_bytes(enc, p, data.data() + c * C, len(c))) Predictor::Die();
   };
   for (size_t c = 0; c < nchunks; ++c) {
     if (c >= R) drain(c - R);   // frees slot c % R
@@ -62,6 +62,7 @@ void CompressEngine(Predictor* P, const std::vector<uint8_t>& data, cmx_encoder_
   for (size_t c = nchunks > R ? nchunks - R : 0; c < nchunks; ++c) drain(c);
   if (cmx_pipeline_sync(P->pipe())) Predictor::Die();
   for (size_t i = 0; i < R; ++i) { cmx_device_free(dev, d_layer0[i]); cmx_device_free(dev, d_p[i]); }
+  cmx_host_free(p);
 }
 }  // namespace
 

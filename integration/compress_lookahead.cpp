@@ -63,8 +63,7 @@ void CompressLookahead(Predictor* P, const std::vector<uint8_t>& data, cmx_encod
   const size_t nchunks = (N + C - 1) / C;
   auto len = [&](size_t c) { return c + 1 < nchunks ? C : N - c * C; };
   auto drain = [&](size_t c) {   // chunk c: wait, copy its probabilities back, code its bytes
-    if (cmx_pipeline_wait(P->pipe(), c)) Predictor::Die();
-    if (cmx_copy_to_host(dev, p.data(), d_p[c % R], 8 * len(c) * sizeof(float))) Predictor::Die();
+    if (cmx_pipeline_fetch(P->pipe(), c, p.data())) Predictor::Die();   // waits for this chunk only
     if (cmx_encoder_encode_bytes(enc, p.data(), data.data() + c * C, len(c))) Predictor::Die();
   };
   if (cmx_pipeline_begin(P->pipe(), data.data(), len(0), d_layer0[0])) Predictor::Die();
