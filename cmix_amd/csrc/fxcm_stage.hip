@@ -393,13 +393,17 @@ __global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_roles_kernel(FxDev* g
     if (role == 0) {
       // ================= role M: the context maps =================
       u.orow = loc.ex[0];
-      if (tid < FX_NSLOTS) fxd_map_touch(d, &sh, u, tid);
-      else if (wave == 3) fx_stage_ahead(&ah, &loc, bytes, recs, lstmpr, lstmex, n, q, lane);
+      // The 81 context slots on 7 wavefronts of 12 lanes, not on two of 64 + 17: a lane's walk through touch / run is a chain of
+      // data-dependent branches (lookup bit or not, hit / replace, second visit, run model), and lanes of one wavefront that take
+      // different branches run them one after the other -- a wavefront costs the SUM of its lanes' distinct paths.
+      const int msl = (wave < 7 && lane < 12) ? 12 * wave + lane : FX_NSLOTS;
+      if (msl < FX_NSLOTS) fxd_map_touch(d, &sh, u, msl);
+      else if (wave == 7) fx_stage_ahead(&ah, &loc, bytes, recs, lstmpr, lstmex, n, q, lane);
       FX_TICK(0);
       // the full barrier of the bit: the previous run's table stores are complete before a serial walk may read them
       __syncthreads();
       FX_TICK(1);
-      if (tid < FX_THREADS) fxd_phase1c(d, &sh, u, tid);
+      if (msl < FX_NSLOTS) fxd_phase1c(d, &sh, u, msl);
       FX_TICK(2);
       fx_lds_barrier();
       FX_TICK(3);

@@ -69,15 +69,22 @@ __global__ __launch_bounds__(P8CM2_MAXC) void cmx_p8s_cm2v2_kernel(P8Cm2Dev* d, 
   if (i == 0) { d->regs = sh.base.r; d->bits = run_bits; d->last_y = last_y; }
 }
 
-// Second design of the family kernel (p8fam_dev.h): per-context bytes and StateMaps in LDS, one barrier per bit on the
-// common path, overlaps resolved in rounds over the instance order. 256 threads: lanes 0..S-1 own a context each,
-// the last 24 lanes keep the rnd() ring filled.
-__global__ __launch_bounds__(P8CM_MAXS) void cmx_p8s_fam2_kernel(P8CmDev* d, P8FamHome* home, const uint32_t* ctx, const uint16_t* chk, const uint8_t* bits, int16_t* x,
-                                                                const uint8_t* order, int nbits, int skip) {
+// The family kernel (p8fam_dev.h): per-context bytes and StateMaps in LDS, one barrier per bit on the common path, overlaps resolved
+// in rounds over the instance order. 512 threads: the (up to 256) contexts on 8 wavefronts of 32 lanes -- a context's walk through
+// phase 1 / run is a chain of data-dependent branches (lookup bit or not, hit / replace, second visit, draw), and lanes of one
+// wavefront that take different branches run them one after the other, so fewer lanes per wavefront cost less --; 24 more lanes of the
+// last wavefront keep the rnd() ring filled.
+constexpr int P8FAM_THREADS = 512;
+__global__ __launch_bounds__(P8FAM_THREADS) void cmx_p8s_fam2_kernel(P8CmDev* d, P8FamHome* home, const uint32_t* ctx, const uint16_t* chk, const uint8_t* bits, int16_t* x,
+                                                                    const uint8_t* order, int nbits, int skip, unsigned long long* prof) {
   extern __shared__ __attribute__((aligned(16))) unsigned char p8f_smem[];
   P8FamShared& sh = *(P8FamShared*)p8f_smem;
   const int tid = threadIdx.x, S = d->nslots, ninst = d->ninst;
-  p8f_load(d, home, d->sm, &sh, tid, P8CM_MAXS);
+  const int wv = tid >> 6, ln = tid & 63;
+  const int sl = ln < 32 ? 32 * wv + ln : P8CM_MAXS;          // this thread's context slot (>= S: none)
+  const int rl = (wv == 7 && ln >= 32 && ln < 56) ? ln - 32 : -1;   // refill lane 0..23
+  (void)prof;
+  p8f_load(d, home, d->sm, &sh, tid, P8FAM_THREADS);
   int last_y = d->last_y, c1 = d->c1, lk = 0;
   uint32_t rnd_i = (uint32_t)d->rnd.i, prev_i = rnd_i;
   __syncthreads();
@@ -85,15 +92,15 @@ __global__ __launch_bounds__(P8CM_MAXS) void cmx_p8s_fam2_kernel(P8CmDev* d, P8F
     const P8FamUni u = p8f_uni(d, ctx, chk, bits, x, order, t, &last_y, &c1, &lk, rnd_i);
     if (t < skip) continue;
     P8FamTmp tmp;
-    if (tid < S) p8f_phase1(d, &sh, u, tid, &tmp);
-    if (tid >= P8CM_MAXS - 24)   // one wavefront's tail: 24 lanes in lockstep, a group of 24 values per iteration
-      for (uint32_t base = prev_i + P8F_LOOK + 1; base <= rnd_i + P8F_LOOK; base += 24) p8f_refill_group(&sh, base, rnd_i + P8F_LOOK, tid - (P8CM_MAXS - 24));
+    if (sl < S) p8f_phase1(d, &sh, u, sl, &tmp);
+    if (rl >= 0)   // 24 lanes of one wavefront in lockstep, a group of 24 values per iteration
+      for (uint32_t base = prev_i + P8F_LOOK + 1; base <= rnd_i + P8F_LOOK; base += 24) p8f_refill_group(&sh, base, rnd_i + P8F_LOOK, rl);
     __syncthreads();
     const bool look = u.bp == 0 || u.bp == 2 || u.bp == 5;
     int total;
     const bool all_serial = !d->slot_parallel;   // A/B switch (CMX_P8CM_SERIAL=1): every instance walked by its first lane
     if (!(look && sh.anyconf[lk & 1]) && !sh.anyshared && !all_serial) {
-      if (tid < S) p8f_run(d, &sh, u, tid, &tmp, p8f_count(&sh, t, 0, tid));
+      if (sl < S) p8f_run(d, &sh, u, sl, &tmp, p8f_count(&sh, t, 0, sl));
       total = p8f_count(&sh, t, 0, S);
     } else {
       int base = 0, k = 0;
@@ -103,18 +110,18 @@ __global__ __launch_bounds__(P8CM_MAXS) void cmx_p8s_fam2_kernel(P8CmDev* d, P8F
           int k2 = k;
           while (k2 < ninst && !((look && sh.conflict[lk & 1][k2]) || sh.shared[k2] || all_serial)) k2++;
           const int a = d->inst[k].first, b = k2 < ninst ? d->inst[k2].first : S;
-          if (tid >= a && tid < b) p8f_run(d, &sh, u, tid, &tmp, base + p8f_count(&sh, t, a, tid));
+          if (sl >= a && sl < b) p8f_run(d, &sh, u, sl, &tmp, base + p8f_count(&sh, t, a, sl));
           base += p8f_count(&sh, t, a, b);
           k = k2;
         } else {
           const int first = d->inst[k].first, cnt = d->inst[k].count;
-          if (tid == first) {
+          if (sl == first) {
             sh.walk_cnt = (uint32_t)p8f_walk(d, &sh, u, k, base);
             if (look) sh.shared[k] = (uint8_t)p8f_shares(d, &sh, k);
           }
           __syncthreads();
           base += (int)sh.walk_cnt;
-          if (tid >= first && tid < first + cnt) p8f_reload(d, &sh, tid);
+          if (sl >= first && sl < first + cnt) p8f_reload(d, &sh, sl);
           __syncthreads();   // walk_cnt may be rewritten by the next walker
           k++;
         }
@@ -123,18 +130,22 @@ __global__ __launch_bounds__(P8CM_MAXS) void cmx_p8s_fam2_kernel(P8CmDev* d, P8F
       total = base;
       __syncthreads();
     }
-    if (look) p8f_clear_next(&sh, lk, tid, P8CM_MAXS);
+    if (look) p8f_clear_next(&sh, lk, tid, P8FAM_THREADS);
     prev_i = rnd_i; rnd_i += (uint32_t)total;
   }
   __syncthreads();
-  p8f_store(d, home, d->sm, &sh, rnd_i, tid, P8CM_MAXS);
+  p8f_store(d, home, d->sm, &sh, rnd_i, tid, P8FAM_THREADS);
   if (tid == 0) { d->last_y = last_y; d->c1 = c1; }
 }
 
 // t0: 1 for the chunk that starts the stream (there is no step 0), else 0
-__global__ __launch_bounds__(P8_NLANE) void cmx_p8s_lanes_kernel(P8LanesDev* d, const uint32_t* ops, const uint8_t* bits, const uint8_t* order, int16_t* x,
-                                                                int nbits, int t0) {
-  const int l = threadIdx.x;
+// The (up to 64) learners are independent of each other and of six different kinds (p8s_lane_step switches on the lane's kind): on one
+// wavefront the kinds run one after the other every step. 8 wavefronts of 8 learners each keep most kinds in wavefronts of their own.
+constexpr int P8LANES_THREADS = 512;
+__global__ __launch_bounds__(P8LANES_THREADS) void cmx_p8s_lanes_kernel(P8LanesDev* d, const uint32_t* ops, const uint8_t* bits, const uint8_t* order, int16_t* x,
+                                                                       int nbits, int t0) {
+  const int ln = threadIdx.x & 63, l = ln < 8 ? 8 * (int)(threadIdx.x >> 6) + ln : P8_NLANE;
+  if (l >= P8_NLANE) return;
   P8LaneRegs r = d->regs[l];
   const int last_y = d->last_y;
   for (int t = t0; t < nbits; t++) {
@@ -732,8 +743,8 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
     ok = hipEventRecord(h->ev_ord, h->s_d) == hipSuccess;
     ok = ok && hipStreamWaitEvent(h->s_a, h->ev_ord, 0) == hipSuccess;   // (implies the upload)
     (void)hipEventRecord(b.t0[0], h->s_a);
-    hipLaunchKernelGGL(cmx_p8s_fam2_kernel, dim3(1), dim3(P8CM_MAXS), h->fam_lds, h->s_a, h->d_fam, h->d_fam_home, (const uint32_t*)(b.d + b.o_fctx),
-                       (const uint16_t*)(b.d + b.o_fchk), d_bits, dx, (const uint8_t*)dord, nbits, skip);
+    hipLaunchKernelGGL(cmx_p8s_fam2_kernel, dim3(1), dim3(P8FAM_THREADS), h->fam_lds, h->s_a, h->d_fam, h->d_fam_home, (const uint32_t*)(b.d + b.o_fctx),
+                       (const uint16_t*)(b.d + b.o_fchk), d_bits, dx, (const uint8_t*)dord, nbits, skip, h->d_prof);
     (void)hipEventRecord(b.t1[0], h->s_a);
     ok = ok && hipEventRecord(h->ev_a, h->s_a) == hipSuccess;
     ok = ok && hipStreamWaitEvent(h->s_b, h->ev_up, 0) == hipSuccess;
@@ -744,7 +755,7 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
     ok = ok && hipEventRecord(h->ev_e, h->s_e) == hipSuccess;
     ok = ok && hipStreamWaitEvent(h->s_c, h->ev_ord, 0) == hipSuccess;
     (void)hipEventRecord(b.t0[5], h->s_c);
-    hipLaunchKernelGGL(cmx_p8s_lanes_kernel, dim3(1), dim3(P8_NLANE), 0, h->s_c, h->d_lanes, (const uint32_t*)(b.d + b.o_ops), d_bits, (const uint8_t*)dord, dx, nbits, t0);
+    hipLaunchKernelGGL(cmx_p8s_lanes_kernel, dim3(1), dim3(P8LANES_THREADS), 0, h->s_c, h->d_lanes, (const uint32_t*)(b.d + b.o_ops), d_bits, (const uint8_t*)dord, dx, nbits, t0);
     (void)hipEventRecord(b.t1[5], h->s_c);
     ok = ok && hipEventRecord(h->ev_c, h->s_c) == hipSuccess;
     // the DMC forest reads the coded bits only: on a stream of its own it runs beside the small learners (4.0 + 2.8 us/bit in a row before)
