@@ -413,7 +413,8 @@ __global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_roles_kernel(FxDev* g
       } else if (tid < FX_THREADS + 8) fx_st_u(row + FX_ROW_RES + (tid - FX_THREADS), (unsigned)fx_res8(d, &sh, u, tid - FX_THREADS));
       if (u.normal) for (int i = FX_NSSCM + 9 + tid; i < ln.exp_rcm; i += FX_DEV_THREADS) real_row[i] = loc.ex[0][i];
       FX_TICK(4);
-      __syncthreads();   // every store of the row is complete
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's row stores have reached the coherence point (explicit: not left to what __syncthreads happens to emit)
+      __syncthreads();   // every wave's have
       if (tid == 0) fx_st_u(&X->m_done, (unsigned)(q + 1));
       FX_TICK(5);
     } else if (role == 1) {
@@ -443,6 +444,7 @@ __global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_roles_kernel(FxDev* g
       else if (tid >= 64 && tid < 64 + FX_NSSCM + 9) real_row[tid - 64] = loc.ex[0][tid - 64];
       else if (tid >= 128 && tid < 130) real_row[l.exp_rcm + (tid - 128)] = loc.ex[0][l.exp_rcm + (tid - 128)];
       FX_TICK(2);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // as in role M: the row is complete before its counter moves
       __syncthreads();
       if (tid == 0) fx_st_u(&X->u_done, (unsigned)(q + 1));
       FX_TICK(3);

@@ -527,6 +527,312 @@ __global__ __launch_bounds__(MX_THREADS) void cmx_p8s_mix2_kernel(const P8MixDev
   if (tid == 0) { T->pr = fin_s; T->misses = misses; }
 }
 
+// ---- the mixer on FOUR workgroups ------------------------------------------------------------------------------------------------
+// The 28 first-layer weight sets are independent of each other: a set needs the step's inputs, its selector and -- to train -- the coded
+// bit and its OWN output. Only set 26 (selected by the previous step's final probability) and everything behind the first layer
+// (second layer, APM chains, export) need the chain's result. So workgroup 0 keeps one set per wavefront (sets 2, 6, .., 26), the second
+// layer, the chains and the export, and workgroups 1..3 run the other 21 sets -- one per wavefront, its row in registers from the dot
+// product to the training step as in the one-workgroup kernel -- and hand their 12-bit outputs over through a per-step exchange row
+// (value | tag words, agent scope). They need nothing back, so they run ahead of workgroup 0 as far as the input rows let them: no
+// hand-off on anybody's serial path, and the VALU work of a step (28 x 1552 int16 MACs + as many training operations, which bound the
+// one-workgroup kernel: 8 k + 7.5 k of its 19.1 k clocks per bit) is spread over four compute units.
+// BLK = workgroup; it owns set 4 wave + QSEL of every wavefront, QSEL = (BLK + 2) & 3 (so that set 26 = 4 * 6 + 2 stays with workgroup 0).
+constexpr unsigned MX4_SPIN = 1u << 24;
+template <int BLK>
+__device__ __forceinline__ void mx4_body(const P8MixDev* M, P8TailDev* T, const int16_t* __restrict__ x, const int32_t* __restrict__ sel,
+                                         const P8ApmRec* __restrict__ apm, const uint8_t* __restrict__ order, const uint8_t* __restrict__ bits,
+                                         float* __restrict__ out, size_t ld, int nbits, int t0, int first, int last_y, unsigned long long* prx,
+                                         unsigned epoch, unsigned* fail) {
+  constexpr int QSEL = (BLK + 2) & 3;
+  constexpr bool MAIN = BLK == 0;
+  __shared__ __attribute__((aligned(16))) uint32_t xs[2][P8_NX / 2];   // the step's inputs as pairs, double-buffered
+  __shared__ float outs[MAIN ? P8_NOUT : 1];
+  __shared__ int pr_s[32], res_s[8];
+  __shared__ uint32_t st_s[16];
+  __shared__ uint32_t arow[MAIN ? 7 : 1][36];    // the context rows of the seven chain tables (24 u32 or 33 u16 cells, widened)
+  __shared__ int p_s, fin_s;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int si = 4 * wave + QSEL;                  // this wavefront's weight set
+  __shared__ int16_t squash[4096], stretch[MAIN ? 4096 : 1];
+  for (int i = threadIdx.x; i < 4096; i += MX_THREADS) { squash[i] = M->squash[i]; if (MAIN) stretch[i] = M->stretch[i]; }
+  const float cf = (float)(1.0 / 4095);
+  if (MAIN) for (int i = tid; i < P8_NOUT; i += MX_THREADS) outs[i] = T->out[i];
+  if (MAIN && tid == 0) fin_s = T->pr;
+  unsigned long long misses = MAIN ? T->misses : 0;   // every thread keeps the miss history itself (uniform)
+  MX_GLOBAL int16_t* const wx = (MX_GLOBAL int16_t*)M->wx; MX_GLOBAL int16_t* const wx2 = (MX_GLOBAL int16_t*)M->wx2;
+  const int nx_first = M->nx_first;
+  __shared__ int32_t ring_sel[4][P8_NSEL];
+  __shared__ uint32_t ring_apm[4][6];     // P8ApmRec = 24 bytes
+  __shared__ int ring_ord[4], ring_bit[4];
+  const bool chain = MAIN && wave == 1 && lane < 7;
+  const int fl = tid - 64, fj = fl >= 0 && fl < 7 * 36 ? fl / 36 : (chain ? lane : 0), fk = fl >= 0 ? fl % 36 : 0;
+  MX_GLOBAL uint32_t* const tb_apm = (MX_GLOBAL uint32_t*)(MAIN && fj < 4 ? T->apm[fj] : nullptr);
+  MX_GLOBAL uint16_t* const tb_apm1 = (MX_GLOBAL uint16_t*)(MAIN && fj >= 4 ? T->apm1[fj - 4] : nullptr);
+  MX_GLOBAL uint16_t* const tb_gen = (MX_GLOBAL uint16_t*)(MAIN ? T->gen[fj] : nullptr);
+  MX_GLOBAL uint32_t* const my_apm = (MX_GLOBAL uint32_t*)(chain && lane < 4 ? T->apm[lane] : nullptr);
+  MX_GLOBAL uint16_t* const my_apm1 = (MX_GLOBAL uint16_t*)(chain && lane >= 4 ? T->apm1[lane - 4] : nullptr);
+  MX_GLOBAL uint16_t* const my_gen = (MX_GLOBAL uint16_t*)(chain ? T->gen[lane] : nullptr);
+  auto ring_load = [&](int ts, uint32_t& v) {   // wave 5: lanes 0..27 selectors, 28 order, 29 bit, 32..37 APM record (workgroup 0)
+    if (wave != 5 || ts >= nbits) return;
+    if (lane < P8_NSEL) v = (uint32_t)sel[(size_t)ts * P8_NSEL + lane];
+    else if (lane == 28) v = order[ts];
+    else if (lane == 29) v = bits[ts];
+    else if (MAIN && lane >= 32 && lane < 38) v = reinterpret_cast<const uint32_t*>(apm + ts)[lane - 32];
+  };
+  auto ring_store = [&](int ts, uint32_t v) {
+    if (wave != 5 || ts >= nbits) return;
+    const int slot = ts & 3;
+    if (lane < P8_NSEL) ring_sel[slot][lane] = (int32_t)v;
+    else if (lane == 28) ring_ord[slot] = (int)v;
+    else if (lane == 29) ring_bit[slot] = (int)v;
+    else if (MAIN && lane >= 32 && lane < 38) ring_apm[slot][lane - 32] = v;
+  };
+  MxApmLane al_txt = {0, 0, 0}, al_gen = {0, 0, 0};
+  if (chain) {
+    const int j = lane;
+    if (j < 4) { al_txt.idx = T->apm_cxt[j]; al_txt.v0 = my_apm[al_txt.idx]; }
+    else { al_txt.idx = T->apm1_idx[j - 4]; al_txt.v0 = my_apm1[al_txt.idx]; al_txt.v1 = my_apm1[al_txt.idx + 1]; }
+    al_gen.idx = T->gen_idx[j]; al_gen.v0 = my_gen[al_gen.idx]; al_gen.v1 = my_gen[al_gen.idx + 1];
+  }
+  __syncthreads();
+  if (MAIN && t0) for (int i = tid; i < P8_NOUT; i += MX_THREADS) out[i] = outs[i];   // no step 0: the constructor's values
+  // ---- this wavefront's one set: its row now and at the next step ----
+  uint4 w[4], wn[4];
+  int row = 0, rown = 0;
+  uint4 xn = make_uint4(0, 0, 0, 0);
+#define MX4_LOAD_ROW(dst, rowid)                                                                  \
+  {                                                                                               \
+    const MX_GLOBAL int16_t* wr_ = wx + (size_t)(rowid) * P8_NX;                                \
+    _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) { const int grp_ = lane + 64 * g_; dst[g_] = grp_ < MX_GROUPS ? mx_gload4(wr_, grp_) : make_uint4(0, 0, 0, 0); } \
+  }
+  // the set's row of step ts -- unless it is set 26, whose row needs the previous step's final probability (load_late)
+  auto load_early = [&](uint4* dst, int& r, int ts) {
+    if (si != P8_SEL_LASTPR) { r = p8s_sel(si, ring_sel[ts & 3][si], ring_ord[ts & 3], 0); MX4_LOAD_ROW(dst, r) }
+  };
+  auto load_late = [&](uint4* dst, int& r, int ts, int lastpr) {
+    if (MAIN && si == P8_SEL_LASTPR) { r = p8s_sel(P8_SEL_LASTPR, ring_sel[ts & 3][P8_SEL_LASTPR], 0, lastpr); MX4_LOAD_ROW(dst, r) }
+  };
+  auto stage_x = [&](int t, int buf) {   // the input row of step t -> LDS (compacted during the first byte)
+    const int16_t* xr = x + (size_t)t * P8_NX;
+    if (t < first) {
+      int16_t* xh = reinterpret_cast<int16_t*>(xs[buf]);
+      for (int i = tid; i < P8_NX; i += MX_THREADS) xh[i] = i < nx_first ? xr[M->first_map[i]] : (int16_t)0;
+    } else if (tid < MX_GROUPS) reinterpret_cast<uint4*>(xs[buf])[tid] = reinterpret_cast<const uint4*>(xr)[tid];
+  };
+  int a_base = 0, upd_idx = -1; uint32_t upd_v0 = 0, upd_v1 = 0;
+  auto row_ctx = [&](const P8ApmRec* a, int j, unsigned long long ms) {
+    if (a->text) return j == 0 ? (a->c[0] | (int)((ms & 0xF) << 4)) : j == 1 ? (int)a->c[1 + (int)(ms & 3)] : (int)a->c[3 + j];
+    return j == 0 ? (a->c[0] | (int)(ms & 7)) : j < 4 ? (int)a->c[j] : j == 4 ? (int)a->c[4] : (int)a->c[j - 3];
+  };
+  auto chain_fetch = [&](int ts, int y, unsigned long long ms) {   // see cmx_p8s_mix2_kernel's notes: update of the chosen cells, fetch of the step's rows
+    const P8ApmRec* ap = reinterpret_cast<const P8ApmRec*>(ring_apm[ts & 3]);
+    const int a_text = ap->text, a_limit = ap->limit;
+    if (fl >= 0 && fl < 7 * 36) {
+      const int ncell = (a_text && fj < 4) ? 24 : 33;
+      if (fk < ncell) {
+        const int base = row_ctx(ap, fj, ms) * ncell;
+        arow[fj][fk] = a_text ? (fj < 4 ? tb_apm[base + fk] : (uint32_t)tb_apm1[base + fk]) : (uint32_t)tb_gen[base + fk];
+      }
+    }
+    if (chain) {
+      const int j = lane;
+      if (a_text) {
+        upd_idx = al_txt.idx;
+        if (j < 4) { upd_v0 = apm_upd(al_txt.v0, y, a_limit); my_apm[upd_idx] = upd_v0; }
+        else { upd_v0 = apm1_upd(al_txt.v0, y, j == 4 ? 7 : 6); upd_v1 = apm1_upd(al_txt.v1, y, j == 4 ? 7 : 6); my_apm1[upd_idx] = (uint16_t)upd_v0; my_apm1[upd_idx + 1] = (uint16_t)upd_v1; }
+        a_base = row_ctx(ap, j, ms) * (j < 4 ? 24 : 33);
+      } else {
+        upd_idx = al_gen.idx;
+        upd_v0 = apm1_upd(al_gen.v0, y, 7); upd_v1 = apm1_upd(al_gen.v1, y, 7);
+        my_gen[upd_idx] = (uint16_t)upd_v0; my_gen[upd_idx + 1] = (uint16_t)upd_v1;
+        a_base = row_ctx(ap, j, ms) * 33;
+      }
+    }
+  };
+  auto chain_patch = [&](int a_text) {
+    const int j = lane;
+    const bool one = a_text && j < 4;
+    const int ncell = one ? 24 : 33, off = upd_idx - a_base;
+    if (off >= 0 && off < ncell) arow[j][off] = upd_v0;
+    if (!one && off + 1 >= 0 && off + 1 < ncell) arow[j][off + 1] = upd_v1;
+  };
+  bool pend26 = false, again26 = false;
+  { uint32_t v0_ = 0, v1_ = 0; ring_load(t0, v0_); ring_load(t0 + 1, v1_); ring_store(t0, v0_); ring_store(t0 + 1, v1_); }
+  __syncthreads();
+  if (t0 < nbits) {
+    if (MAIN) {
+      const int y0 = t0 ? (int)bits[t0 - 1] : last_y;
+      misses += misses + (unsigned long long)((T->pr >> 11) != y0);   // Predictor::update's first line (:8250), for the first step
+      chain_fetch(t0, y0, misses);
+    }
+    load_early(w, row, t0);
+    if (MAIN) load_late(w, row, t0, T->pr);
+    stage_x(t0, t0 & 1);
+  }
+  for (int t = t0; t < nbits; ++t) {
+    const int nx = t < first ? nx_first : P8_NX;
+    uint32_t ring_v = 0;
+    ring_load(t + 2, ring_v);   // two steps ahead; lands in LDS at the end of this step
+    const int buf = t & 1;
+    mx_lds_barrier();   // B1: xs[buf], the ring entries of this step (and, workgroup 0, arow / fin_s of the previous step)
+    int a_text = 0;
+    const P8ApmRec* arp = reinterpret_cast<const P8ApmRec*>(ring_apm[t & 3]);
+    if (MAIN) {
+      a_text = arp->text;
+      if (chain) chain_patch(a_text);
+      if (wave == 6 && pend26 && !again26) {   // set 26's row was requested after the previous step's chain: take it now
+#pragma unroll
+        for (int g = 0; g < 4; ++g) w[g] = wn[g];
+      }
+      for (int i = tid; i < nx; i += MX_THREADS) outs[i] = (float)p8s_squash(squash, reinterpret_cast<const int16_t*>(xs[buf])[i]) * cf;
+    }
+    // ---- first layer: this wavefront's set on the row in registers ----
+    int my_pr;
+    {
+      uint32_t acc = 0;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int grp = lane + 64 * g;
+        const uint4 xv = grp < MX_GROUPS ? reinterpret_cast<const uint4*>(xs[buf])[grp] : make_uint4(0, 0, 0, 0);
+        acc += pair_dot(xv.x, w[g].x) + pair_dot(xv.y, w[g].y) + pair_dot(xv.z, w[g].z) + pair_dot(xv.w, w[g].w);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+      my_pr = p8s_squash(squash, (int32_t)(acc * 9u) >> 9);   // uniform in the wavefront
+      if (lane == 0) {
+        if (MAIN) pr_s[si] = my_pr;
+        else __hip_atomic_store(&prx[(size_t)t * P8_NSEL + si], (((unsigned long long)epoch << 32 | (unsigned)(t + 1)) << 12) | (unsigned)my_pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (MAIN && wave == 4 && lane < P8_NSEL && (lane & 3) != QSEL) {   // the 21 outputs of the other workgroups (they run ahead: normally there already)
+      unsigned spins = 0;
+      for (;;) {
+        const unsigned long long v = __hip_atomic_load(&prx[(size_t)t * P8_NSEL + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((v >> 12) == ((unsigned long long)epoch << 32 | (unsigned)(t + 1))) { pr_s[lane] = (int)(v & 4095u); break; }
+        if ((++spins & 1023u) == 0 && (spins > MX4_SPIN || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+          __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pr_s[lane] = 2048; break;
+        }
+      }
+    }
+    // ---- one step ahead: the row (unless it needs this step's final probability) and the input row ----
+    const bool more = t + 1 < nbits;
+    if (more) {
+      load_early(wn, rown, t + 1);
+      if (t + 1 >= first && tid < MX_GROUPS) xn = reinterpret_cast<const uint4*>(x + (size_t)(t + 1) * P8_NX)[tid];
+    }
+    if (MAIN) {
+      mx_lds_barrier();   // B2: pr_s, arow
+      if (chain) __builtin_amdgcn_s_waitcnt(0);   // this lane's table updates have reached L2 before other lanes fetch rows again (after B4)
+      if (wave == 0) {   // second layer
+        const int a = lane < P8_NSEL ? stretch[pr_s[lane]] : 0;
+        if (lane < P8_NSEL) outs[nx + lane] = (float)p8s_squash(squash, a) * cf;
+        const int b = __shfl_down(a, 1);
+        if ((lane & 1) == 0 && lane < 32) st_s[lane >> 1] = ((uint32_t)a & 0xffffu) | ((uint32_t)b << 16);
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        uint32_t acc = 0;
+        if (lane < 16) acc = pair_dot(st_s[lane], reinterpret_cast<const MX_GLOBAL uint32_t*>(wx2)[lane]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) p_s = p8s_squash(squash, (int32_t)acc >> 9);
+      }
+      mx_lds_barrier();   // B3: p_s
+      if (wave == 1) {   // the chains on the fetched rows: group A (lanes 0..3), then group B (lanes 4..6), then the read-out
+        const int p2 = p_s;
+        auto look_apm = [&](int j, int pr) {   // APM::p's interpolation :704-710 on arow[j]
+          const int s = (stretch[pr] + 2048) * 23;
+          const int wt = s & 0xfff, lo = s >> 12;
+          al_txt.idx = a_base + lo + (wt >> 11); al_txt.v0 = arow[j][lo + (wt >> 11)];
+          return (int)(((arow[j][lo] >> 13) * (uint32_t)(4096 - wt) + (arow[j][lo + 1] >> 13) * (uint32_t)wt) >> 19);
+        };
+        auto look_apm1 = [&](int j, int pr) {   // APM1::pp's interpolation :614-619
+          const int s = stretch[pr];
+          const int wgt = s & 127, lo = (s + 2048) >> 7;
+          MxApmLane& al = a_text ? al_txt : al_gen;
+          al.idx = a_base + lo; al.v0 = arow[j][lo]; al.v1 = arow[j][lo + 1];
+          return (int)((arow[j][lo] * (uint32_t)(128 - wgt) + arow[j][lo + 1] * (uint32_t)wgt) >> 11);
+        };
+        if (lane < 4) res_s[lane] = a_text ? look_apm(lane, p2) : look_apm1(lane, p2);
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        if (lane >= 4 && lane < 7) {
+          const int avg = (p2 + res_s[1] + res_s[2] + res_s[3] + 2) >> 2;
+          res_s[lane] = look_apm1(lane, a_text ? (lane == 4 ? avg : res_s[0]) : res_s[0]);
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) fin_s = p8s_tail_c(arp, p2, res_s, outs + nx + P8_NSEL);
+      }
+      mx_lds_barrier();   // B4: outs complete, fin_s
+      float* orow = out + (size_t)t * ld;
+      for (int i = tid; i < P8_NOUT; i += MX_THREADS) orow[i] = outs[i];
+    }
+    // ---- training with the step's own bit; the row goes back to HBM, the next step's row becomes current ----
+    const int yb = ring_bit[t & 3];
+    if (MAIN) {
+      if (more) load_late(wn, rown, t + 1, fin_s);   // the one row that needed this step's final probability
+      if (more) misses += misses + (unsigned long long)((fin_s >> 11) != yb);   // the next step's
+      if (more) chain_fetch(t + 1, yb, misses);
+    }
+    {
+      const int err = (int)(int16_t)(((yb << 12) - my_pr) * 7);
+      MX_GLOBAL int16_t* wr = wx + (size_t)row * P8_NX;
+      const bool again = more && rown == row;
+      const bool is26 = MAIN && si == P8_SEL_LASTPR;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int grp = lane + 64 * g;
+        uint4 v = w[g];
+        if (grp < MX_GROUPS && err) {
+          const uint4 xv = reinterpret_cast<const uint4*>(xs[buf])[grp];
+          v.x = pair_train(xv.x, v.x, err); v.y = pair_train(xv.y, v.y, err);
+          v.z = pair_train(xv.z, v.z, err); v.w = pair_train(xv.w, v.w, err);
+          mx_gstore4(wr, grp, v);
+        }
+        if (is26) w[g] = v;   // resolved at the top of the next step, when the late request has arrived
+        else w[g] = again ? v : wn[g];
+      }
+      if (is26) { pend26 = more; again26 = again; }
+      row = more ? rown : row;
+    }
+    if (MAIN && wave == 0 && lane < 16) {
+      const int err2 = (int)(int16_t)(((yb << 12) - p_s) * 7);
+      MX_GLOBAL uint32_t* w2 = reinterpret_cast<MX_GLOBAL uint32_t*>(wx2);
+      if (err2) w2[lane] = pair_train(st_s[lane], w2[lane], err2);
+    }
+    ring_store(t + 2, ring_v);
+    if (more) {   // the next step's inputs into the other LDS buffer
+      if (t + 1 < first) stage_x(t + 1, buf ^ 1);
+      else if (tid < MX_GROUPS) reinterpret_cast<uint4*>(xs[buf ^ 1])[tid] = xn;
+    }
+  }
+#undef MX4_LOAD_ROW
+  if (MAIN) {
+    __syncthreads();
+    if (chain) {
+      const int j = lane;
+      if (j < 4) T->apm_cxt[j] = al_txt.idx; else T->apm1_idx[j - 4] = al_txt.idx;
+      T->gen_idx[j] = al_gen.idx;
+    }
+    for (int i = tid; i < P8_NOUT; i += MX_THREADS) T->out[i] = outs[i];
+    if (tid == 0) { T->pr = fin_s; T->misses = misses; }
+  }
+}
+
+// prx: [>= nbits][28] exchange words, (launch number, step + 1) | 12-bit output: never cleared, a word of an earlier launch does not
+// match; fail: sticky time-out flag of workgroup 0's wait (host-mapped)
+__global__ __launch_bounds__(MX_THREADS) void cmx_p8s_mix4_kernel(const P8MixDev* M, P8TailDev* T, const int16_t* __restrict__ x, const int32_t* __restrict__ sel,
+                                                                 const P8ApmRec* __restrict__ apm, const uint8_t* __restrict__ order,
+                                                                 const uint8_t* __restrict__ bits, float* __restrict__ out, size_t ld, int nbits, int t0, int first,
+                                                                 int last_y, unsigned long long* prx, unsigned epoch, unsigned* fail) {
+  switch (blockIdx.x) {
+    case 0: mx4_body<0>(M, T, x, sel, apm, order, bits, out, ld, nbits, t0, first, last_y, prx, epoch, fail); break;
+    case 1: mx4_body<1>(M, T, x, sel, apm, order, bits, out, ld, nbits, t0, first, last_y, prx, epoch, fail); break;
+    case 2: mx4_body<2>(M, T, x, sel, apm, order, bits, out, ld, nbits, t0, first, last_y, prx, epoch, fail); break;
+    default: mx4_body<3>(M, T, x, sel, apm, order, bits, out, ld, nbits, t0, first, last_y, prx, epoch, fail); break;
+  }
+}
+
 // ---------------------------------------------------------------- host side
 namespace {
 struct DevPolicy {
@@ -572,6 +878,9 @@ struct cmx_p8stage {
   hipEvent_t ev_up = nullptr, ev_ord = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_e = nullptr, ev_f = nullptr, ev_mix[P8S_XBUFS] = {};
   bool mix_used[P8S_XBUFS] = {};
   unsigned long long* d_prof = nullptr;   // CMX_P8MIX_PROFILE=1: per-wave clocks by phase of the mixer kernel
+  unsigned long long* d_prx = nullptr; size_t prx_steps = 0; unsigned mix_epoch = 0;   // the mixer's exchange rows (cmx_p8s_mix4_kernel)
+  unsigned* h_mixfail = nullptr;         // host-mapped: the mixer's workgroup 0 gave up waiting for another workgroup
+  bool mix1 = false;                     // CMX_P8MIX_ONE_WG=1: the one-workgroup mixer
   uint64_t chunks = 0;
   uint64_t steps = 0;
   int last_bit = 0;
@@ -609,6 +918,8 @@ void cmx_p8stage_destroy(cmx_p8stage_t* h) {
       if (!dup) { seen[ns++] = q; (void)hipStreamDestroy(q); }
     }
   }
+  if (h->d_prx) (void)hipFree(h->d_prx);
+  if (h->h_mixfail) (void)hipHostFree(h->h_mixfail);
   if (h->own_up && h->s_up) (void)hipStreamDestroy(h->s_up);
   for (hipEvent_t e : {h->ev_up, h->ev_ord, h->ev_a, h->ev_b, h->ev_c, h->ev_e, h->ev_f}) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->ev_mix) if (e) (void)hipEventDestroy(e);
@@ -662,6 +973,9 @@ cmx_p8stage_t* cmx_p8stage_create(int device) {
     ok = ok && hipEventCreateWithFlags(&s.done, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < 7; i++) ok = ok && hipEventCreate(&s.t0[i]) == hipSuccess && hipEventCreate(&s.t1[i]) == hipSuccess;
   }
+  { const char* e = getenv("CMX_P8MIX_ONE_WG"); h->mix1 = (e && *e == '1') || getenv("CMX_P8MIX_PROFILE"); }
+  ok = ok && hipHostMalloc((void**)&h->h_mixfail, 64, hipHostMallocMapped) == hipSuccess;
+  if (ok) *h->h_mixfail = 0;
   if (ok && getenv("CMX_P8MIX_PROFILE")) ok = hipMalloc((void**)&h->d_prof, 7 * 8 * 8) == hipSuccess && hipMemset(h->d_prof, 0, 7 * 8 * 8) == hipSuccess;
   ok = ok && hipDeviceSynchronize() == hipSuccess;
   if (!ok) { cmx_set_err("cmx_p8stage_create: allocation / init failed (the stage needs ~9 GB of HBM)"); cmx_p8stage_destroy(h); return nullptr; }
@@ -713,8 +1027,12 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
       h->d_x[i] = nullptr; h->d_order[i] = nullptr;
       ok = ok && hipMalloc((void**)&h->d_x[i], T * P8_NX * 2) == hipSuccess && hipMalloc((void**)&h->d_order[i], T) == hipSuccess;
     }
+    if (h->d_prx) (void)hipFree(h->d_prx);
+    h->d_prx = nullptr;
+    ok = ok && hipMalloc((void**)&h->d_prx, T * P8_NSEL * 8) == hipSuccess && hipMemset(h->d_prx, 0, T * P8_NSEL * 8) == hipSuccess;
     h->x_cap = ok ? n : 0;
   }
+  if (h->h_mixfail && *h->h_mixfail) { cmx_set_err("cmx_p8stage_run: the mixer kernel's workgroup 0 timed out waiting for another workgroup's outputs (are four workgroups co-resident?)"); h->failed = true; return 1; }
   // The stage's own streams: d = upload, order-N map; a = family (needs the order-N map's `order` of the same chunk, so it
   // runs one kernel behind it -- on its own stream the family of chunk c overlaps the order-N map of chunk c + 1);
   // b = TextModel's and exeModel's maps, c = small lanes -> DMC, m = mixer + chains. Input rows are double-buffered by chunk parity, so the mixer of chunk c runs under the tables of
@@ -766,8 +1084,14 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
     ok = ok && hipEventRecord(h->ev_f, h->s_f) == hipSuccess;
     for (hipEvent_t e : {h->ev_a, h->ev_b, h->ev_c, h->ev_e, h->ev_f}) ok = ok && hipStreamWaitEvent(h->s_m, e, 0) == hipSuccess;
     (void)hipEventRecord(b.t0[1], h->s_m);
-    hipLaunchKernelGGL(cmx_p8s_mix2_kernel, dim3(1), dim3(MX_THREADS), 0, h->s_m, (const P8MixDev*)h->d_mix, h->d_tail, (const int16_t*)dx, (const int32_t*)(b.d + b.o_sel),
-                       (const P8ApmRec*)(b.d + b.o_apm), (const uint8_t*)dord, d_bits, d_out, ld, nbits, t0, skip, h->last_bit, h->d_prof);
+    if (h->mix1) {
+      hipLaunchKernelGGL(cmx_p8s_mix2_kernel, dim3(1), dim3(MX_THREADS), 0, h->s_m, (const P8MixDev*)h->d_mix, h->d_tail, (const int16_t*)dx, (const int32_t*)(b.d + b.o_sel),
+                         (const P8ApmRec*)(b.d + b.o_apm), (const uint8_t*)dord, d_bits, d_out, ld, nbits, t0, skip, h->last_bit, h->d_prof);
+    } else {
+      ++h->mix_epoch;
+      hipLaunchKernelGGL(cmx_p8s_mix4_kernel, dim3(4), dim3(MX_THREADS), 0, h->s_m, (const P8MixDev*)h->d_mix, h->d_tail, (const int16_t*)dx, (const int32_t*)(b.d + b.o_sel),
+                         (const P8ApmRec*)(b.d + b.o_apm), (const uint8_t*)dord, d_bits, d_out, ld, nbits, t0, skip, h->last_bit, h->d_prx, h->mix_epoch, h->h_mixfail);
+    }
     ok = ok && hipGetLastError() == hipSuccess;
     (void)hipEventRecord(b.t1[1], h->s_m);
     b.timed = true;
@@ -804,6 +1128,7 @@ int cmx_p8stage_sync(cmx_p8stage_t* h) {
   hipError_t e = hipDeviceSynchronize();
   if (e != hipSuccess) { cmx_set_err(std::string("cmx_p8stage_sync: ") + hipGetErrorString(e)); h->failed = true; return 1; }
   for (auto& b : h->st) p8s_collect(h, b);
+  if (h->h_mixfail && *h->h_mixfail) { cmx_set_err("cmx_p8stage_sync: the mixer kernel's workgroup 0 timed out waiting for another workgroup's outputs"); h->failed = true; return 1; }
   return 0;
 }
 
