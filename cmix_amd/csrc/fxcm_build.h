@@ -140,6 +140,19 @@ void build(FxDev& h, Policy& P) {
   }
   h.pr = 2048;
   h.slot_parallel = 1;
+  // role M's wavefronts: consecutive whole maps, as few slots per wavefront as FX_M_WAVES groups allow
+  for (int cap = 1;; cap++) {
+    int w = 0, cnt = 0;
+    h.mw_slot[0] = 0; h.mw_map[0] = 0;
+    bool fits = true;
+    for (int k = 0; k < FX_NMAPS && fits; k++) {
+      if (cnt && cnt + h.maps[k].C > cap) { ++w; if (w >= FX_M_WAVES) { fits = false; break; } h.mw_slot[w] = (uint8_t)h.maps[k].slot_base; h.mw_map[w] = (uint8_t)k; cnt = 0; }
+      cnt += h.maps[k].C;
+    }
+    if (!fits) continue;
+    for (int v = w + 1; v <= FX_M_WAVES; v++) { h.mw_slot[v] = FX_NSLOTS; h.mw_map[v] = FX_NMAPS; }
+    break;
+  }
   for (int i = 0; i < FX_OUTPUTS; i++) h.pending[i] = 0.5f;   // model_predictions(0.5f, num_models) :94
   h.rec.AH2 = 0x765BA55C;                                      // :3262
 }

@@ -38,6 +38,7 @@ static inline uint32_t fx_cas_host(uint32_t* p, uint32_t c, uint32_t v) { const 
 #endif
 enum { FX_THREADS = 256, FX_BMASK = 0xffffff,
        FX_U_SSCM = 81, FX_U_MATCH = 88, FX_U_RCM = 89, FX_U_LSTM = 90, FX_U_MIX10 = 91, FX_U_MIX11 = 92, FX_U_APM = 93, FX_UNITS = 99, FX_TRAIN0 = 128,
+       FX_M_WGS = 2, FX_M_WAVES = 16,   // role M of the device stage: workgroups x 8 wavefronts, each wavefront owns whole maps
        FX_TAB_RC1 = 0, FX_TAB_ST1 = 512, FX_TAB_ST2 = 512 + 4096, FX_TAB_ST32 = 512 + 8192, FX_TAB_ST8 = 512 + 8192 + 256, FX_TAB_LEN = 512 + 8192 + 512 };
 
 struct FxMapDev {
@@ -57,6 +58,7 @@ struct FxDev {                         // everything a stream owns on the device
   FxMapDev maps[FX_NMAPS];
   uint8_t slot_map[FX_NSLOTS], slot_idx[FX_NSLOTS];   // slot -> map (mixing order), context index within the map
   int slot_parallel;                   // 1: one lane per context slot with a per-map serial fallback; 0: one lane per map
+  uint8_t mw_slot[FX_M_WAVES + 1], mw_map[FX_M_WAVES + 1];   // role M's wavefront w owns slots [mw_slot[w], mw_slot[w + 1]) = maps [mw_map[w], mw_map[w + 1])
   const int16_t *squash, *stretch;     // squash[d + 2047], stretch[p]
   const uint8_t* wrt;                  // byte -> 2-bit class [256], 3-bit class [256] of cmix's WRT-swapped alphabet
   const uint8_t* sta[6];               // the six state tables the maps' nn pointers refer to (the kernel keeps copies in LDS)
@@ -150,21 +152,49 @@ FX_HD uint32_t fxd_bucket_get(uint8_t* b, int A, uint16_t ch, int keep) {
   for (int k = 0; k < 7; k++) h[k] = 0;
   return (uint32_t)(2 * A + 1 + 7 * bi);
 }
-// the same search on a staged copy b of the bucket; every change also goes to the table g
+// the same search on a staged copy b of the bucket; every change also goes to the table g. All checksums and priorities are read
+// before the first comparison (loads that do not depend on each other: one LDS latency, not one per slot looked at).
 FX_HD uint32_t fxd_bucket_get_staged(uint8_t* b, uint8_t* g, int A, uint16_t ch, int keep) {
-  uint16_t* chk = (uint16_t*)b;
+  const uint16_t* chk = (const uint16_t*)b;
   const uint8_t last = b[2 * A];
-  if (chk[last & 15] == ch) return (uint32_t)(2 * A + 1 + 7 * (last & 15));
-  int lowest = 0xffff, bi = 0;
-  for (int i = 0; i < A; ++i) {
-    if (chk[i] == ch) { b[2 * A] = (uint8_t)(last << 4 | i); g[2 * A] = b[2 * A]; return (uint32_t)(2 * A + 1 + 7 * i); }
-    const int pri = b[2 * A + 1 + 7 * i];
-    if (pri < lowest && (last & 15) != i && (last >> 4) != i) { lowest = pri; bi = i; }
+  const int l0 = last & 15, l1 = last >> 4;
+  const uint16_t clast = chk[l0];
+  uint16_t c[14]; uint8_t pr[14];
+#ifdef __HIPCC__
+#pragma unroll
+#endif
+  for (int i = 0; i < 14; ++i) { const int j = i < A ? i : A - 1; c[i] = chk[j]; pr[i] = b[2 * A + 1 + 7 * j]; }
+  if (clast == ch) return (uint32_t)(2 * A + 1 + 7 * l0);
+  int found = -1, lowest = 0xffff, bi = 0;
+#ifdef __HIPCC__
+#pragma unroll
+#endif
+  for (int i = 0; i < 14; ++i) {
+    if (i < A && found < 0) {
+      if (c[i] == ch) found = i;
+      else if (pr[i] < lowest && l0 != i && l1 != i) { lowest = pr[i]; bi = i; }
+    }
   }
+  if (found >= 0) { b[2 * A] = (uint8_t)(last << 4 | found); g[2 * A] = b[2 * A]; return (uint32_t)(2 * A + 1 + 7 * found); }
   b[2 * A] = (uint8_t)(last << 4 | bi | keep); g[2 * A] = b[2 * A];
-  chk[bi] = ch; ((uint16_t*)g)[bi] = ch;
+  ((uint16_t*)b)[bi] = ch; ((uint16_t*)g)[bi] = ch;
   for (int k = 0; k < 7; k++) { b[2 * A + 1 + 7 * bi + k] = 0; g[2 * A + 1 + 7 * bi + k] = 0; }
   return (uint32_t)(2 * A + 1 + 7 * bi);
+}
+// a bucket of the table -> its staged copy (vector loads: one round trip)
+FX_HD void fxd_stage_bucket(uint8_t* bk, const uint8_t* g, int B) {
+#ifdef __HIPCC__
+  const uint4* g4 = reinterpret_cast<const uint4*>(g);
+  uint4* b4 = reinterpret_cast<uint4*>(bk);
+  const int nv = B >> 4;
+  uint4 v[8];
+#pragma unroll
+  for (int q = 0; q < 8; q++) if (q < nv) v[q] = g4[q];
+#pragma unroll
+  for (int q = 0; q < 8; q++) if (q < nv) b4[q] = v[q];
+#else
+  for (int q = 0; q < B; q++) bk[q] = g[q];
+#endif
 }
 FX_HD void fxd_map_reload(FxDev* d, FxShared* sh, int k, int i) {   // the cached bytes of context i of map k from the table
   const FxMapDev* x = &d->maps[k];
@@ -215,23 +245,29 @@ FX_HD void fxd_map_ctx_fast(FxDev* d, FxShared* sh, const FxBit& u, int k, int i
         for (int q = 0; q < 7; q++) sl[q] = bk[off + q];
         if (bpos == 0) {
           int refresh = 0;
+          int r0 = rn[0], r1 = rn[1];   // run count of the previous context
+          if (old_runp - (uint32_t)b < (uint32_t)x->B) { r0 = bk[old_runp - (uint32_t)b]; r1 = bk[old_runp + 1 - (uint32_t)b]; }   // the search may have replaced the slot that holds them
           if (sl[3] == 2) {  // second visit: create the histories for bits 2-7 of the byte seen the first time
+            // the two buckets go through the staging area of the lookup above (done with: its slot is in sl, the run bytes in r0 / r1):
+            // one vector fetch and a search on LDS each, instead of a walk over table bytes one dependent load at a time
             const int c = sl[4] + 256;
-            size_t b2 = (size_t)((cxt[i] + (uint32_t)(c >> 6)) & x->tmask) * (size_t)x->B;
-            uint8_t* p = t + b2 + fxd_bucket_get(t + b2, x->A, chk, x->kep);
-            p[0] = (uint8_t)(1 + ((c >> 5) & 1));
-            p[1 + ((c >> 5) & 1)] = (uint8_t)(1 + ((c >> 4) & 1));
-            p[3 + ((c >> 4) & 3)] = (uint8_t)(1 + ((c >> 3) & 1));
-            b2 = (size_t)((cxt[i] + (uint32_t)(c >> 3)) & x->tmask) * (size_t)x->B;
-            p = t + b2 + fxd_bucket_get(t + b2, x->A, chk, x->kep);
-            p[0] = (uint8_t)(1 + ((c >> 2) & 1));
-            p[1 + ((c >> 2) & 1)] = (uint8_t)(1 + ((c >> 1) & 1));
-            p[3 + ((c >> 1) & 3)] = (uint8_t)(1 + (c & 1));
+            uint32_t held = nb;
+            for (int v = 0; v < 2; v++) {
+              const int cc = v ? c >> 3 : c >> 6, sh3 = v ? 0 : 3;
+              const uint32_t nb2 = (cxt[i] + (uint32_t)cc) & x->tmask;
+              uint8_t* g2 = t + (size_t)nb2 * (size_t)x->B;
+              if (nb2 != held) { fxd_stage_bucket(bk, g2, x->B); held = nb2; }
+              const uint32_t o2 = fxd_bucket_get_staged(bk, g2, x->A, chk, x->kep);
+              const int cs = c >> sh3;   // v = 0: bits 5, 4, 3 of c;  v = 1: bits 2, 1, 0
+              const uint32_t i1 = o2 + 1 + ((cs >> 2) & 1), i2 = o2 + 3 + ((cs >> 1) & 3);
+              const uint8_t v0 = (uint8_t)(1 + ((cs >> 2) & 1)), v1 = (uint8_t)(1 + ((cs >> 1) & 1)), v2 = (uint8_t)(1 + (cs & 1));
+              bk[o2] = v0; g2[o2] = v0;
+              bk[i1] = v1; g2[i1] = v1;
+              bk[i2] = v2; g2[i2] = v2;
+            }
             t[cp0[i] + 6] = 0; sl[6] = 0;
             refresh = 1;
           }
-          int r0 = rn[0], r1 = rn[1];   // run count of the previous context
-          if (old_runp - (uint32_t)b < (uint32_t)x->B) { r0 = bk[old_runp - (uint32_t)b]; r1 = bk[old_runp + 1 - (uint32_t)b]; }   // the search may have replaced the slot that holds them
           if (refresh) { r0 = t[old_runp]; r1 = t[old_runp + 1]; }
           if (r0 == 0) { r0 = 2; r1 = c1; }
           else if (r1 != c1) { r0 = 1; r1 = c1; }
@@ -374,7 +410,7 @@ FX_HD void fxd_map_ctx(FxDev* d, FxShared* sh, const FxBit& u, int k, int i) {
 // about to be looked up, and at bit 0 the two buckets a second visit creates histories in -- known from a read-only
 // look at the slot the lookup will return, which is exact unless an earlier context writes that bucket first, i.e.
 // unless there is an overlap.
-FX_HD void fxd_map_touch(FxDev* d, FxShared* sh, const FxBit& u, int s) {
+FX_HD void fxd_map_touch(FxDev* d, FxShared* sh, const FxBit& u, int s, uint32_t* tab, uint32_t hmask) {   // tab / hmask: the bit's hash set (cleared)
   const int k = d->slot_map[s], i = d->slot_idx[s];
   const FxMapDev* x = &d->maps[k];
   const int par = u.q & 1;
@@ -421,8 +457,19 @@ FX_HD void fxd_map_touch(FxDev* d, FxShared* sh, const FxBit& u, int s) {
       const uint16_t ch = (uint16_t)((cxt >> 16) ^ (uint32_t)i);
       const int A = x->A, last = b[2 * A];
       int slot = -1;
-      if (chk[last & 15] == ch) slot = last & 15;
-      else for (int j = 0; j < A; ++j) if (chk[j] == ch) { slot = j; break; }
+      {   // every checksum is read before the first comparison (independent loads)
+        uint16_t cj[14];
+        const uint16_t clast = chk[last & 15];
+#ifdef __HIPCC__
+#pragma unroll
+#endif
+        for (int j = 0; j < 14; ++j) cj[j] = chk[j < A ? j : A - 1];
+#ifdef __HIPCC__
+#pragma unroll
+#endif
+        for (int j = 13; j >= 0; --j) if (j < A && cj[j] == ch) slot = j;
+        if (clast == ch) slot = last & 15;
+      }
       if (slot >= 0 && b[2 * A + 1 + 7 * slot + 3] == 2) {
         const int c = b[2 * A + 1 + 7 * slot + 4] + 256;
         T[n++] = (cxt + (uint32_t)(c >> 6)) & x->tmask;
@@ -431,18 +478,17 @@ FX_HD void fxd_map_touch(FxDev* d, FxShared* sh, const FxBit& u, int s) {
     }
   }
   // into the hash set: a key another context of the map has put there = an overlap (this lane's own repeats are dropped first)
-  uint32_t* tab = sh->ohash[par];
   for (int a = 0; a < n; a++) {
     int dup = 0;
     for (int c = 0; c < a; c++) dup |= T[c] == T[a];
     if (dup) continue;
     const uint32_t key = ((uint32_t)(k + 1) << 26) | T[a];
-    uint32_t h = (key * 2654435761u) >> 22;
+    uint32_t h = ((key * 2654435761u) >> 22) & hmask;
     for (;;) {
       const uint32_t old = FX_CAS(&tab[h], 0u, key);
       if (old == 0) break;
       if (old == key) { sh->mconf[par][k] = 1; break; }
-      h = (h + 1) & 1023;
+      h = (h + 1) & hmask;
     }
   }
 }
@@ -762,7 +808,7 @@ FX_HD int fxd_apm_p(FxDev* d, FxShared* sh, int j, int pr, int cxt) {
 // ---------------------------------------------------------------- the phases
 // phase 1 in three barrier-separated steps: a = bucket lists + everything that is not a context map, b = overlap check, c = the maps
 FX_HD void fxd_phase1a(FxDev* d, FxShared* sh, const FxBit& u, int tid) {
-  if (tid < FX_NSLOTS) fxd_map_touch(d, sh, u, tid);
+  if (tid < FX_NSLOTS) fxd_map_touch(d, sh, u, tid, sh->ohash[u.q & 1], 1023u);
   else if (tid < FX_U_MATCH) fxd_sscm_unit(d, sh, u, tid - FX_U_SSCM);
   else if (tid == FX_U_MATCH) { fxd_match_unit(d, sh, u); for (int i = 0; i < 3; i++) fxd_match2_sm(d, sh, u, i); }
   else if (tid == FX_U_RCM) fxd_rcm_unit(d, sh, u);

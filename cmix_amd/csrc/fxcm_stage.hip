@@ -301,8 +301,9 @@ struct FxLocal {
 struct FxXfer {
   unsigned fail; unsigned pad[3];   // sticky: a bounded wait ran out
   unsigned started;                 // zeroed ahead of every launch from here on: workgroups that hold the stream state
-  unsigned m_done, u_done;          // rows published by the roles
+  unsigned m_done, u_done;          // rows published by role U (m_done: unused since role M publishes per wavefront)
   unsigned pad2;
+  unsigned mw_done[FX_M_WAVES];     // rows published by each of role M's wavefronts
 };
 enum { FX_ROW_WORDS = 288,          // one row: 1152 bytes
        FX_ROW_RES = 256,            //   [0, 256) role M: its copy of the 512 inputs (its own range is taken); then the 8 sums
@@ -358,12 +359,15 @@ __global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_roles_kernel(FxDev* g
   FxShared& sh = *(FxShared*)fx_smem;
   // CMX_FXCM_PROFILE=1: thread 0 of each role accumulates its clocks per phase: prof[16 role + k] (scripts/gpu_fxcm_time.py)
   unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pc0 = __builtin_readcyclecounter();
-#define FX_TICK(k) do { if (prof && threadIdx.x == 0) { const unsigned long long c_ = __builtin_readcyclecounter(); pacc[k] += c_ - pc0; pc0 = c_; } } while (0)
+  __shared__ unsigned long long pbp[8][8];   // role M's clocks by bit position as well (prof[64 + 8 bpos + k])
+  if (threadIdx.x < 64) pbp[threadIdx.x >> 3][threadIdx.x & 7] = 0;
+#define FX_TICK(k) do { if (prof && threadIdx.x == 0 && blockIdx.x != 1) { const unsigned long long c_ = __builtin_readcyclecounter(); pacc[k] += c_ - pc0; if (blockIdx.x == 0) pbp[u.bpos][k] += c_ - pc0; pc0 = c_; } } while (0)
   FxLocal& loc = *(FxLocal*)(fx_smem + ((sizeof(FxShared) + 15) & ~(size_t)15));
   FxDev* d = &loc.dev;
   __shared__ int res8_s[8], scr_s[16];
   __shared__ FxAhead ah;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, role = blockIdx.x;   // 0 = M, 1 = U, 2 = X
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int role = (int)blockIdx.x < FX_M_WGS ? 0 : (int)blockIdx.x - FX_M_WGS + 1, mwg = blockIdx.x;   // 0 = M (FX_M_WGS workgroups), 1 = U, 2 = X
   // ---- every role starts from the stream's state (it uses its own part of it) ----
   for (int i = tid; i < (int)(sizeof(FxDev) / 4); i += FX_DEV_THREADS) ((uint32_t*)d)[i] = ((const uint32_t*)gd)[i];
   for (int i = tid; i < 4095; i += FX_DEV_THREADS) loc.squash[i] = gd->squash[i];
@@ -381,43 +385,89 @@ __global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_roles_kernel(FxDev* g
   __syncthreads();
   if (role != 2 && tid == 0) sh.parity = 0;   // M and U build the bit's inputs in tx[1]
   // all three workgroups hold the state before any of them may write a part of it back (or the pending row)
-  if (tid == 0) { __hip_atomic_fetch_add(&X->started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); fx_wait_ge(&X->started, 3u, &X->fail); }
+  if (tid == 0) { __hip_atomic_fetch_add(&X->started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); fx_wait_ge(&X->started, (unsigned)(FX_M_WGS + 2), &X->fail); }
   __syncthreads();
   const FxLayout ln = fxd_layout(d, 1);   // the normal layout's offsets
-  unsigned have_m = 0, have_u = 0;
+  unsigned have_row = 0;
+  if (role == 0) {
+    // ================= role M: the context maps, one free-running wavefront per group of maps =================
+    // Nothing a map learns depends on another map or on role X, and the coded bits are the chunk's bytes: every wavefront owns whole maps
+    // (FxDev::mw_map; their contexts are its lanes), walks the chunk's bits at its own pace -- touch -> run per bit, synchronised inside the
+    // wavefront only -- and publishes its part of row q and its own row counter. A slow bit of one map (a table miss, a second visit, a serial
+    // walk after an overlap) delays that wavefront's counter, not the other maps: role X sees the slowest wavefront's AVERAGE, not the sum of
+    // every bit's slowest lane. The overlap hash set is per wavefront (128 of the 1024 entries, both parities); the byte records travel
+    // through a per-wavefront LDS copy (in FxShared::part, which only role X uses).
+    const int mw = 8 * mwg + wave;
+    const int s0 = d->mw_slot[mw], s1 = d->mw_slot[mw + 1], k0 = d->mw_map[mw], k1 = d->mw_map[mw + 1];
+    const int msl = s0 + lane < s1 ? s0 + lane : FX_NSLOTS;
+    if (k0 >= k1) { if (lane == 0) fx_st_u(&X->mw_done[mw], (unsigned)nbits); }
+    else {
+      const FxMapDev* xa = &d->maps[k0]; const FxMapDev* xb = &d->maps[k1 - 1];
+      const int txlo = xa->tx_off, txhi = xb->tx_off + xb->C * (5 + xb->u), exlo = xa->exp_off, exhi = xb->exp_off + xb->C * (4 + xb->u);
+      uint32_t* const ht[2] = {sh.ohash[0] + 128 * wave, sh.ohash[1] + 128 * wave};
+      FxByteRec* const wrec = reinterpret_cast<FxByteRec*>(&sh.part[0][0]) + 2 * wave;   // [2]: the record in force and the next one
+      static_assert(sizeof(FxByteRec) * 16 <= sizeof(sh.part), "per-wavefront record copies do not fit");
+      const int which8[8] = {0, 1, 2, 3, 4, 5, 21, 23};
+      const bool res_lane = lane < 8 && which8[lane & 7] >= k0 && which8[lane & 7] < k1;
+      uint32_t bv = 0;
+      int prev_byte = lastbyte0;
+      for (int q = 0; q < nbits; q++) {
+        const int b = q >> 3, k = q & 7;
+        if (k == 0 && (b & 63) == 0) bv = b + lane < n ? (uint32_t)bytes[b + lane] : 0u;
+        const int cur = (int)__builtin_amdgcn_readlane((int)bv, b & 63);
+        FxBit u;
+        u.q = q;
+        u.y = (cur >> (7 - k)) & 1;
+        u.bpos = (k + 1) & 7;
+        u.boundary = (k == 7);
+        u.c0 = u.boundary ? 1 : ((1 << (k + 1)) | (cur >> (7 - k)));
+        u.blpos = blpos0 + b + (u.boundary ? 1 : 0);
+        u.lastbyte = u.boundary ? cur : prev_byte;
+        u.sscmrate = 0; u.rate = 0; u.lstmpr = 0; u.lstmex = 0;   // (not read by the maps)
+        const int ri = u.boundary ? b : b - 1;
+        u.normal = ri >= 0 ? 1 : have0;
+        u.rec = ri >= 0 ? &wrec[ri & 1] : &d->rec;
+        u.orow = loc.ex[0];
+        float* const real_row = q + 1 < nbits ? out + (long)(q + 1) * ostride : gd->pending;
+        unsigned* const row = rows + (size_t)q * FX_ROW_WORDS;
+        const int par = q & 1;
+        const bool carry = u.bpos == 4 || u.bpos == 7;   // the keys of a bit between two lookups are those of the bit before it (or fewer): its flags carry over
+        if (k == 6) for (int i = lane; i < (int)(sizeof(FxByteRec) / 4); i += 64) ((uint32_t*)&wrec[b & 1])[i] = ((const uint32_t*)&recs[b])[i];
+        if (carry) { if (k0 + lane < k1) sh.mconf[par][k0 + lane] = sh.mconf[par ^ 1][k0 + lane]; }
+        else if (msl < FX_NSLOTS) fxd_map_touch(d, &sh, u, msl, ht[par], 127u);
+        FX_TICK(0);
+        // the wavefront's barrier of the bit: the previous run's table stores are complete before a serial walk may read them
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        FX_TICK(1);
+        if (msl < FX_NSLOTS) fxd_map_run(d, &sh, u, msl);
+        FX_TICK(2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        FX_TICK(3);
+        ht[par ^ 1][lane] = 0; ht[par ^ 1][lane + 64] = 0;
+        if (k0 + lane < k1) sh.mconf[par ^ 1][k0 + lane] = 0;
+        if (u.normal) {
+          for (int i = txlo + lane; i < txhi; i += 64)
+            __hip_atomic_store(reinterpret_cast<unsigned short*>(row) + i, (unsigned short)sh.tx[1][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int i = exlo + lane; i < exhi; i += 64) real_row[i] = loc.ex[0][i];
+        }
+        if (res_lane) fx_st_u(row + FX_ROW_RES + lane, (unsigned)fx_res8(d, &sh, u, lane));
+        FX_TICK(4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's row stores have reached the coherence point before its counter moves
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) fx_st_u(&X->mw_done[mw], (unsigned)(q + 1));
+        FX_TICK(5);
+        if (k == 7) prev_byte = cur;
+      }
+    }
+  } else
   for (int q = 0; q < nbits; q++) {
     FxBit u = fx_bit_dev(d, &ah, &loc, q, blpos0, lastbyte0, have0);
     float* const real_row = q + 1 < nbits ? out + (long)(q + 1) * ostride : gd->pending;
     unsigned* const row = rows + (size_t)q * FX_ROW_WORDS;
     const FxLayout l = fxd_layout(d, u.normal);
-    if (role == 0) {
-      // ================= role M: the context maps =================
-      u.orow = loc.ex[0];
-      // The 81 context slots on 7 wavefronts of 12 lanes, not on two of 64 + 17: a lane's walk through touch / run is a chain of
-      // data-dependent branches (lookup bit or not, hit / replace, second visit, run model), and lanes of one wavefront that take
-      // different branches run them one after the other -- a wavefront costs the SUM of its lanes' distinct paths.
-      const int msl = (wave < 7 && lane < 12) ? 12 * wave + lane : FX_NSLOTS;
-      if (msl < FX_NSLOTS) fxd_map_touch(d, &sh, u, msl);
-      else if (wave == 7) fx_stage_ahead(&ah, &loc, bytes, recs, lstmpr, lstmex, n, q, lane);
-      FX_TICK(0);
-      // the full barrier of the bit: the previous run's table stores are complete before a serial walk may read them
-      __syncthreads();
-      FX_TICK(1);
-      if (msl < FX_NSLOTS) fxd_phase1c(d, &sh, u, msl);
-      FX_TICK(2);
-      fx_lds_barrier();
-      FX_TICK(3);
-      if (tid < FX_THREADS) {
-        fxd_map_clear_next(&sh, u, tid);
-        if (u.normal) fx_st_u(row + tid, reinterpret_cast<const uint32_t*>(sh.tx[1])[tid]);
-      } else if (tid < FX_THREADS + 8) fx_st_u(row + FX_ROW_RES + (tid - FX_THREADS), (unsigned)fx_res8(d, &sh, u, tid - FX_THREADS));
-      if (u.normal) for (int i = FX_NSSCM + 9 + tid; i < ln.exp_rcm; i += FX_DEV_THREADS) real_row[i] = loc.ex[0][i];
-      FX_TICK(4);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's row stores have reached the coherence point (explicit: not left to what __syncthreads happens to emit)
-      __syncthreads();   // every wave's have
-      if (tid == 0) fx_st_u(&X->m_done, (unsigned)(q + 1));
-      FX_TICK(5);
-    } else if (role == 1) {
+    if (role == 1) {
       // ================= role U: match models, SSCMs, run map, LSTM input =================
       u.orow = loc.ex[0];
       int16_t* txn = sh.tx[1];
@@ -451,9 +501,10 @@ __global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_roles_kernel(FxDev* g
     } else {
       // ================= role X: trainers, selectors, mixers, APM chain =================
       u.orow = loc.ex[q & 1];
-      if (tid == 0) {
-        if (have_m < (unsigned)(q + 1)) { fx_wait_ge(&X->m_done, (unsigned)(q + 1), &X->fail); have_m = fx_ld_u(&X->m_done); }
-        if (have_u < (unsigned)(q + 1)) { fx_wait_ge(&X->u_done, (unsigned)(q + 1), &X->fail); have_u = fx_ld_u(&X->u_done); }
+      if (tid <= FX_M_WAVES && have_row < (unsigned)(q + 1)) {   // one lane per row counter: role M's wavefronts, role U
+        unsigned* const c = tid < FX_M_WAVES ? &X->mw_done[tid] : &X->u_done;
+        fx_wait_ge(c, (unsigned)(q + 1), &X->fail);
+        have_row = fx_ld_u(c);
       }
       FX_TICK(0);
       fx_lds_barrier();
@@ -503,16 +554,18 @@ __global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_roles_kernel(FxDev* g
     }
   }
   __syncthreads();
-  if (prof && tid == 0) for (int k = 0; k < 8; k++) prof[16 * role + k] += pacc[k];
+  if (prof && tid == 0 && blockIdx.x != 1) for (int k = 0; k < 8; k++) prof[16 * role + k] += pacc[k];
+  if (prof && blockIdx.x == 0 && tid < 64) prof[64 + tid] += pbp[tid >> 3][tid & 7];
 #undef FX_TICK
   // ---- every role writes its own part of the stream's state back ----
-  if (role == 0) {
-    for (int i = tid; i < FX_NMAPS * 8; i += FX_DEV_THREADS) {
+  if (role == 0) {   // (the maps of this workgroup's wavefronts)
+    const int ka = d->mw_map[8 * mwg], kb = d->mw_map[8 * mwg + 8];
+    for (int i = 8 * ka + tid; i < 8 * kb; i += FX_DEV_THREADS) {
       FxMapDev* x = &gd->maps[i >> 3];
       const int j = i & 7;
       x->cp[j] = sh.mcp[i >> 3][j]; x->cp0[j] = sh.mcp0[i >> 3][j]; x->runp[j] = sh.mrunp[i >> 3][j]; x->cxt[j] = sh.mcxt[i >> 3][j]; x->sm_cxt[j] = sh.msmc[i >> 3][j];
     }
-    for (int k = 0; k < FX_NMAPS; k++) {
+    for (int k = ka; k < kb; k++) {
       const FxMapDev* x = &d->maps[k];
       for (int i = tid; i < x->C * 256; i += FX_DEV_THREADS) x->sm[i] = (&sh.sm[x->slot_base][0])[i];
     }
@@ -627,7 +680,7 @@ cmx_fxcm_t* cmx_fxcm_create(const char* dictionary_path, int device) {
   ok = ok && hipFuncSetAttribute((const void*)cmx_fxcm_roles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FX_LDS_BYTES) == hipSuccess;
   ok = ok && hipMalloc((void**)&h->d_xfer, sizeof(FxXfer)) == hipSuccess && hipMemset(h->d_xfer, 0, sizeof(FxXfer)) == hipSuccess;
   const char* prof = getenv("CMX_FXCM_PROFILE");
-  if (ok && prof && prof[0] == '1') ok = hipMalloc((void**)&h->d_prof, 512) == hipSuccess && hipMemset(h->d_prof, 0, 512) == hipSuccess;
+  if (ok && prof && prof[0] == '1') ok = hipMalloc((void**)&h->d_prof, 1024) == hipSuccess && hipMemset(h->d_prof, 0, 1024) == hipSuccess;
   ok = ok && hipDeviceSynchronize() == hipSuccess;
   if (!ok) { cmx_set_err("cmx_fxcm_create: allocation / init failed (the stage needs ~4.4 GB of HBM)"); cmx_fxcm_destroy(h); return nullptr; }
   h->parser = fxp_create(dictionary_path);
@@ -667,7 +720,7 @@ int cmx_fxcm_run(cmx_fxcm_t* h, const uint8_t* bytes, const uint8_t* d_bytes, si
     h->rows_cap = nbytes;
   }
   if (hipMemsetAsync((char*)h->d_xfer + 16, 0, sizeof(FxXfer) - 16, s) != hipSuccess) { cmx_set_err("cmx_fxcm_run: hipMemsetAsync failed"); return 1; }
-  hipLaunchKernelGGL(cmx_fxcm_roles_kernel, dim3(3), dim3(FX_DEV_THREADS), FX_LDS_BYTES, s, h->d_dev, h->d_xfer, h->d_rows, d_bytes, h->d_recs[b], d_lstmpr, d_lstmex,
+  hipLaunchKernelGGL(cmx_fxcm_roles_kernel, dim3(FX_M_WGS + 2), dim3(FX_DEV_THREADS), FX_LDS_BYTES, s, h->d_dev, h->d_xfer, h->d_rows, d_bytes, h->d_recs[b], d_lstmpr, d_lstmex,
                      d_probs + 3, (long)pstride, (int)nbytes, h->d_prof);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { cmx_set_err(std::string("cmx_fxcm_run: ") + hipGetErrorString(e)); return 1; }
@@ -678,9 +731,9 @@ int cmx_fxcm_run(cmx_fxcm_t* h, const uint8_t* bytes, const uint8_t* d_bytes, si
 }
 
 // CMX_FXCM_PROFILE=1: thread 0's clocks per phase of each role since creation: out64[16 role + k], role 0 = M, 1 = U, 2 = X
-int cmx_fxcm_profile(cmx_fxcm_t* h, unsigned long long out64[64]) {
+int cmx_fxcm_profile(cmx_fxcm_t* h, unsigned long long out64[128]) {
   if (!h || !h->d_prof) return 1;
-  return hipMemcpy(out64, h->d_prof, 512, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+  return hipMemcpy(out64, h->d_prof, 1024, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
 }
 
 int cmx_fxcm_set_upload_stream(cmx_fxcm_t* h, void* stream) {

@@ -265,7 +265,7 @@ const unsigned* cmx_fxcm_fail_flag(cmx_fxcm_t*);   /* as cmx_lstm_fail_flag */
 int cmx_fxcm_set_upload_stream(cmx_fxcm_t*, void* stream);   /* see cmx_mixnet_set_upload_stream */
 /* diagnostics (CMX_FXCM_PROFILE=1 at create time): clocks of lane 0 of each of the kernel's 8 wavefronts per phase
  * (1a work, 1a barrier wait, 1c, 2, 3, 4, 5, -) */
-int cmx_fxcm_profile(cmx_fxcm_t*, unsigned long long out64[64]);
+int cmx_fxcm_profile(cmx_fxcm_t*, unsigned long long out128[128]);   /* [64 + 8 bpos + k]: role M by bit position */
 
 /* ---- callers of the path: arithmetic coder + container header (HOST code) -------------------------------------
  * Replaces Encoder::Encode/Flush (src/coder/encoder.cpp:10-39), Decoder::Decoder/Decode (src/coder/decoder.cpp:3-39)

@@ -38,11 +38,11 @@ print("fxcm stage, %d x %d-byte chunks, serial_maps=%s: kernel+copy %.2f us/bit 
 
 if os.environ.get("CMX_FXCM_PROFILE") == "1":
     import ctypes as C
-    acc = (C.c_ulonglong * 64)()
+    acc = (C.c_ulonglong * 128)()
     E.lib().cmx_fxcm_profile.argtypes = [C.c_void_p, C.c_void_p]
     if E.lib().cmx_fxcm_profile(fx.h, acc) == 0:
         nb = 8.0 * 1024 * (nchunks + 4)
-        names = {0: ("M", ["touch (bucket lists, fetches)", "full barrier (load / store drain)", "phase 1c (maps run)", "lds barrier", "row stores", "store drain + publish"]),
+        names = {0: ("M", ["touch (bucket lists, fetches)", "wave sync (load / store drain)", "maps run", "wave sync", "row stores", "store drain + publish"]),
                  1: ("U", ["units (match models, SSCMs, run map)", "lds barrier", "row stores", "store drain + publish"]),
                  2: ("X", ["wait M/U rows", "lds barrier", "gather inputs + trainers + APM updates", "full barrier (store drain)", "phase 2 (selectors)", "phases 3-4 (dots)",
                            "phase 5 (final mixers + APM chain)", "row stores"])}
@@ -50,3 +50,7 @@ if os.environ.get("CMX_FXCM_PROFILE") == "1":
             nm, ph = names[r]
             vals = [acc[16 * r + k] / nb for k in range(len(ph))]
             print("role %s: %6.0f clk/bit |" % (nm, sum(vals)), "  ".join("%s %.0f" % (a_, b_) for a_, b_ in zip(ph, vals)))
+        print("role M by bit position (bpos of the update = position of the NEXT bit; lookups at 0, 2, 5), clk per bit of that position:")
+        for bp in range(8):
+            vals = [acc[64 + 8 * bp + k] / (nb / 8) for k in range(6)]
+            print("  bpos %d: %6.0f |" % (bp, sum(vals)), "  ".join("%.0f" % v for v in vals))

@@ -19,7 +19,7 @@ struct HostPolicy {
   void pattern16(void* p, size_t n, const uint16_t* pat, int plen) { uint16_t* q = (uint16_t*)p; for (size_t i = 0; i < n; i++) q[i] = pat[i % (size_t)plen]; }
   void upload(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); }
 };
-struct Emul { FxDev dev; FxShared sh; HostPolicy pol; FxParser* parser; uint32_t rng; int order[FX_THREADS]; uint64_t bits_maps = 0, bits_serial = 0; };
+struct Emul { FxDev dev; FxShared sh; HostPolicy pol; FxParser* parser; uint32_t rng; int order[FX_THREADS]; uint64_t bits_maps = 0, bits_serial = 0; uint64_t serial_by[FX_NMAPS][8] = {}; };
 void shuffle(Emul* e) {
   for (int i = FX_THREADS - 1; i > 0; i--) {
     e->rng = e->rng * 1664525u + 1013904223u;
@@ -59,7 +59,7 @@ int fxe_run(void* h, const uint8_t* bytes, int n, const int16_t* lstmpr, const u
     const FxBit u = fxd_bit(d, bytes, recs.data(), lstmpr, lstmex, out, ostride, nbits, q, blpos0, lastbyte0, have0);
     if (e->rng) shuffle(e);
     for (int t = 0; t < FX_THREADS; t++) fxd_phase1a(d, sh, u, e->order[t]);
-    if (d->slot_parallel) for (int k = 0; k < FX_NMAPS; k++) { e->bits_maps++; e->bits_serial += sh->mconf[u.q & 1][k] != 0; }
+    if (d->slot_parallel) for (int k = 0; k < FX_NMAPS; k++) { e->bits_maps++; e->bits_serial += sh->mconf[u.q & 1][k] != 0; e->serial_by[k][u.bpos] += sh->mconf[u.q & 1][k] != 0; }
     for (int t = 0; t < FX_THREADS; t++) fxd_phase1c(d, sh, u, e->order[t]);
     for (int t = 0; t < FX_THREADS; t++) fxd_phase2(d, sh, u, e->order[t]);
     for (int t = 0; t < FX_THREADS; t++) fxd_phase3(d, sh, u, e->order[t]);
@@ -73,6 +73,8 @@ int fxe_run(void* h, const uint8_t* bytes, int n, const int16_t* lstmpr, const u
 void fxe_set_serial_maps(void* h, int serial) { ((Emul*)h)->dev.slot_parallel = !serial; }
 // how often a map fell back to its serial walk: [0] map-bits in total, [1] serial ones
 void fxe_conflict_stats(void* h, uint64_t* out2) { out2[0] = ((Emul*)h)->bits_maps; out2[1] = ((Emul*)h)->bits_serial; }
+// ... by map and bit position: out[31][8]
+void fxe_conflict_by(void* h, uint64_t* out) { for (int k = 0; k < FX_NMAPS; k++) for (int b = 0; b < 8; b++) out[8 * k + b] = ((Emul*)h)->serial_by[k][b]; }
 void fxe_set_blpos(void* h, int blpos) { Emul* e = (Emul*)h; e->dev.blpos = blpos; fxp_set_blpos(e->parser, blpos); }
 int fxe_debug(void* h, uint32_t* out) {   // the twelve mixer selectors + a few registers
   Emul* e = (Emul*)h;
