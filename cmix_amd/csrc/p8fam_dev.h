@@ -156,8 +156,19 @@ P8_HD void p8f_phase1(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int 
       const uint16_t chk = p8f_chk(d, u, s);
       const int mru = b[P8_B_MRU];
       int slot = -1;
-      if (cs[mru & 15] == chk) slot = mru & 15;
-      else for (int j = 0; j < 7; ++j) if (cs[j] == chk) { slot = j; break; }
+      {   // (independent loads first)
+        uint16_t cj[7];
+        const uint16_t cm = cs[mru & 15];
+#ifdef __HIPCC__
+#pragma unroll
+#endif
+        for (int j = 0; j < 7; ++j) cj[j] = cs[j];
+#ifdef __HIPCC__
+#pragma unroll
+#endif
+        for (int j = 6; j >= 0; --j) if (cj[j] == chk) slot = j;
+        if (cm == chk) slot = mru & 15;
+      }
       if (slot >= 0 && b[P8_B_STATE + 7 * slot + 3] == 2) {
         const int cc = b[P8_B_STATE + 7 * slot + 4] + 256;
         L[n++] = (p8f_ctx(d, u, s) + (uint32_t)(cc >> 6)) & x->mask;
@@ -224,21 +235,45 @@ P8_HD void p8f_wr(uint8_t* T, P8FamHome* r, int s, uint32_t addr, uint8_t v) {
   if (addr == r->runp[s]) r->rc[s] = v;
   if (addr == r->runp[s] + 1) r->rb[s] = v;
 }
-// Bucket::Find on the staged copy; header changes go to the table. Returns the slot index.
+// Bucket::Find on the staged copy; header changes go to the table. Returns the slot index. The seven checksums and priorities are read
+// before the first comparison: loads that do not depend on each other cost one LDS latency, not one per slot looked at.
 P8_HD int p8f_find_staged(uint8_t* T, uint32_t nb, uint8_t* b, uint16_t checksum) {
   uint16_t* cs = (uint16_t*)b;
   uint8_t* g = T + (size_t)nb * 64;
-  const int mru = b[P8_B_MRU];
-  if (cs[mru & 15] == checksum) return mru & 15;
-  int worst = 0xFFFF, index = 0;
+  const int mru = b[P8_B_MRU], m0 = mru & 15, m1 = mru >> 4;
+  const uint16_t cm = cs[m0];
+  uint16_t c[7]; uint8_t pr[7];
+#ifdef __HIPCC__
+#pragma unroll
+#endif
+  for (int i = 0; i < 7; ++i) { c[i] = cs[i]; pr[i] = b[P8_B_STATE + 7 * i]; }
+  if (cm == checksum) return m0;
+  int found = -1, worst = 0xFFFF, index = 0;
+#ifdef __HIPCC__
+#pragma unroll
+#endif
   for (int i = 0; i < 7; ++i) {
-    if (cs[i] == checksum) { b[P8_B_MRU] = (uint8_t)(mru << 4 | i); g[P8_B_MRU] = b[P8_B_MRU]; return i; }
-    if (b[P8_B_STATE + 7 * i] < worst && (mru & 15) != i && mru >> 4 != i) { worst = b[P8_B_STATE + 7 * i]; index = i; }
+    if (found < 0) {
+      if (c[i] == checksum) found = i;
+      else if (pr[i] < worst && m0 != i && m1 != i) { worst = pr[i]; index = i; }
+    }
   }
+  if (found >= 0) { b[P8_B_MRU] = (uint8_t)(mru << 4 | found); g[P8_B_MRU] = b[P8_B_MRU]; return found; }
   b[P8_B_MRU] = (uint8_t)(0xF0 | index); g[P8_B_MRU] = b[P8_B_MRU];
   cs[index] = checksum; ((uint16_t*)g)[index] = checksum;
   for (int k = 0; k < 7; k++) { b[P8_B_STATE + 7 * index + k] = 0; g[P8_B_STATE + 7 * index + k] = 0; }
   return index;
+}
+// a bucket of the table -> a lane's staging area (vector loads: one round trip)
+P8_HD void p8f_stage_bucket(uint8_t* b, const uint8_t* g) {
+#ifdef __HIPCC__
+  const uint4* g4 = reinterpret_cast<const uint4*>(g);
+  uint4* b4 = reinterpret_cast<uint4*>(b);
+  const uint4 v0 = g4[0], v1 = g4[1], v2 = g4[2], v3 = g4[3];
+  b4[0] = v0; b4[1] = v1; b4[2] = v2; b4[3] = v3;
+#else
+  for (int j = 0; j < 64; j++) b[j] = g[j];
+#endif
 }
 
 // ---- run phase, lane-parallel: ContextMap::mix1's loop body for context s (:1072-1145) on the cached bytes.
@@ -278,22 +313,29 @@ P8_HD void p8f_run(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int s, 
     for (int k = 0; k < 7; k++) r->slot[s][k] = b[P8_B_STATE + 7 * idx + k];
     if (bp == 0) {
       int refresh = 0;
-      if (r->slot[s][3] == 2) {   // second visit: create the bit histories of bits 2-7 from the one byte seen (:1096-1106)
-        const int cc = r->slot[s][4] + 256;
-        uint32_t p = p8d_bucket_find(T, (cx + (uint32_t)(cc >> 6)) & x->mask, checksum);
-        T[p] = (uint8_t)(1 + ((cc >> 5) & 1));
-        T[p + 1 + ((cc >> 5) & 1)] = (uint8_t)(1 + ((cc >> 4) & 1));
-        T[p + 3 + ((cc >> 4) & 3)] = (uint8_t)(1 + ((cc >> 3) & 1));
-        p = p8d_bucket_find(T, (cx + (uint32_t)(cc >> 3)) & x->mask, checksum);
-        T[p] = (uint8_t)(1 + ((cc >> 2) & 1));
-        T[p + 1 + ((cc >> 2) & 1)] = (uint8_t)(1 + ((cc >> 1) & 1));
-        T[p + 3 + ((cc >> 1) & 3)] = (uint8_t)(1 + (cc & 1));
-        T[ncp0 + 6] = 0; r->slot[s][6] = 0;
-        refresh = 1;   // those stores may have landed on the old run bytes (same checksum in a coinciding bucket): read them back
-      }
       // run count of the PREVIOUS context (:1107-1112)
       int rc = r->rc[s], rb = r->rb[s];
       if ((old_runp >> 6) == nb) { rc = b[old_runp & 63]; rb = b[(old_runp + 1) & 63]; }   // the search above may have replaced the very slot that holds them
+      if (r->slot[s][3] == 2) {   // second visit: create the bit histories of bits 2-7 from the one byte seen (:1096-1106)
+        // the two buckets go through the lane's staging area (done with: the slot is in r->slot, the run bytes in rc / rb): one vector
+        // fetch and a search on LDS each, instead of a walk over table bytes one dependent load at a time
+        const int cc = r->slot[s][4] + 256;
+        uint32_t held = nb;
+        for (int v = 0; v < 2; v++) {
+          const uint32_t nb2 = (cx + (uint32_t)(v ? cc >> 3 : cc >> 6)) & x->mask;
+          if (nb2 != held) { p8f_stage_bucket(b, T + (size_t)nb2 * 64); held = nb2; }
+          const uint32_t o = (uint32_t)(P8_B_STATE + 7 * p8f_find_staged(T, nb2, b, checksum));
+          uint8_t* g2 = T + (size_t)nb2 * 64;
+          const int cs3 = v ? cc : cc >> 3;   // v = 0: bits 5, 4, 3 of cc;  v = 1: bits 2, 1, 0
+          const uint32_t i1 = o + 1 + ((cs3 >> 2) & 1), i2 = o + 3 + ((cs3 >> 1) & 3);
+          const uint8_t v0 = (uint8_t)(1 + ((cs3 >> 2) & 1)), v1 = (uint8_t)(1 + ((cs3 >> 1) & 1)), v2 = (uint8_t)(1 + (cs3 & 1));
+          b[o] = v0; g2[o] = v0;
+          b[i1] = v1; g2[i1] = v1;
+          b[i2] = v2; g2[i2] = v2;
+        }
+        T[ncp0 + 6] = 0; r->slot[s][6] = 0;
+        refresh = 1;   // those stores may have landed on the old run bytes (same checksum in a coinciding bucket): read them back
+      }
       if (refresh) { rc = T[old_runp]; rb = T[old_runp + 1]; }
       const int c1 = u.c1;
       if (rc == 0) { rc = 2; rb = c1; }
