@@ -42,6 +42,7 @@ struct Ctl {
   int tail_in;
   int tail_done;
   int abort;
+  int b_in, b_done;   // cmx_mixnet_spec_kernel: bit + 1 handed from the layer-1 wave to the layer-2 / SSE wave, and finished by it
 };
 
 struct BitRec {            // written by the scout for bit t (slot t % 3)
@@ -81,6 +82,7 @@ struct Lds {
   const uint16_t* lst;  // cmx_mixnet_spec_kernel: LDS copies of the SSE's t_st / t_sq (64 KB each: five dependent look-ups per bit
   const uint16_t* lsq;  //   sit on the tail wave's path); nullptr: read them from global memory
   int* sdone;       // [rr] cmx_mixnet_spec_kernel: bit + 1 whose stretched inputs a stretch wave has published
+  float* h2;        // [2][64] cmx_mixnet_spec_kernel: the layer-2 inputs of a bit (49) + bit, lstm_p, layer-2 row, from tail_a_role to tail_b_role
 };
 
 // All inter-wave traffic of this kernel goes through LDS, so its synchronisation only has to
@@ -954,6 +956,295 @@ __device__ void tail_role(MixState* S, const Lds& L, const float* decay1, int nb
 }
 
 
+// ------------------------------------------------------------------ the tail on two waves (cmx_mixnet_spec_kernel)
+// tail_role's bit is layer 1 (dot products, intra-layer chain, its 20 updates) followed by layer 2 + SSE + output on one lane: 17 k clocks
+// in a row, the longest role of the kernel once the layer-0 chains moved to the helper workgroups. Layer 1's learning needs nothing from
+// layer 2 (every mixer learns from its own output, mixer.cpp:56-72), so the two halves are a pipeline: tail_a_role (wave 1) does layer 1 of
+// bit t and hands the 49 layer-2 inputs over through LDS (Lds::h2, two slots); tail_b_role (wave 3) does layer 2, the SSE and the output of
+// bit t while wave 1 is on bit t + 1. Same arithmetic, same order, per half as in tail_role.
+__device__ void tail_a_role(MixState* S, const Lds& L, const float* decay1, int nbits, float* mix_out, int lane, bool prof_on) {
+  uint64_t tprev = __builtin_readcyclecounter();
+  uint64_t pacc[6] = {0, 0, 0, 0, 0, 0};
+#define TPROF(k) do { if (prof_on) { uint64_t now_ = __builtin_readcyclecounter(); pacc[k - 6] += now_ - tprev; tprev = now_; } } while (0)
+  const int k = lane;  // layer-1 mixer index
+  const bool is1 = k < CMX_MIX1;
+  const int kk = is1 ? k : 0;
+  const float smin = S->stretch_min, smax = S->stretch_max;
+  const float cdec = 1.0f - 3.0e-6f;
+  const float lr1 = S->lr[CMX_MIX0 + kk];
+  const gptr<float> rows1 = as_global(S->rows1);
+  const gptr<uint64_t> row_steps = as_global(S->row_steps);
+  uint64_t mx1 = S->max_steps[CMX_MIX0 + kk], rs1 = 0;
+  float* const w1 = L.w1 + kk * 68;
+  uint32_t cur_row = 0xffffffffu;
+  gptr<float> row1 = rows1;
+  gptr<uint64_t> rsp1 = row_steps;
+  auto store_row1 = [&]() {
+#pragma unroll
+    for (int i = 0; i < 13; ++i) gstore4_async(row1 + 4 * i, *reinterpret_cast<const float4*>(w1 + 4 * i));
+    asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 0" :: "v"(rsp1), "v"(rs1) : "memory");
+  };
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  for (int t = 0; t < nbits; ++t) {
+    TPROF(11);
+    if (!wait_ge(L.ctl, &L.ctl->scout_epoch, t + 1, true)) return;
+    const BitRec* rec = L.rec + (t % L.rr);
+    const uint32_t newrow = rec->rowidx[CMX_MIX0 + kk];
+    const uint32_t row2 = rec->rowidx[CMX_MIXERS - 1];
+    const double d1 = (double)as_global(decay1)[t];
+    if (is1 && newrow != cur_row) {
+      if (cur_row != 0xffffffffu) store_row1();
+      cur_row = newrow;
+      row1 = rows1 + ((size_t)kk * CMX_ROWS_PER_MIXER + newrow) * CMX_ROW1_STRIDE;
+      rsp1 = row_steps + (size_t)(CMX_MIX0 + kk) * CMX_ROWS_PER_MIXER + newrow;
+#pragma unroll
+      for (int i = 0; i < 13; ++i) *reinterpret_cast<float4*>(w1 + 4 * i) = gload4(row1 + 4 * i);
+      rs1 = *rsp1;
+#pragma unroll
+      for (int j = 0; j < CMX_MIX1; ++j)
+        if (j >= k) w1[CMX_ROW1_EXTRA + j] = 0.0f;  // only j < k are extra weights of mixer k
+    }
+    if (t + 1 < nbits && lds_poll(&L.ctl->scout_epoch) >= t + 2) {   // the layer-1 rows of the NEXT bit towards the caches
+      const uint32_t nr = L.rec[(t + 1) % L.rr].rowidx[CMX_MIX0 + kk];
+      if (is1 && nr != cur_row) {
+        const gptr<const float> nrow = rows1 + ((size_t)kk * CMX_ROWS_PER_MIXER + nr) * CMX_ROW1_STRIDE;
+        touch_line(nrow, L.pfdump + 256 + 256 + 64);
+        touch_line(nrow + 32, L.pfdump + 256 + 256 + 64);
+      }
+    }
+    TPROF(6);
+    if (t >= 2 && !wait_ge(L.ctl, &L.ctl->b_done, t - 1, false)) return;   // the hand-over slot t & 1 is free
+    if (!wait_ge(L.ctl, &L.ctl->tail_in, t + 1, false)) return;
+    TPROF(7);
+    const TailRec* tr = L.trec + (t & 1);
+    const int bit = tr->bit;
+    float* const in2 = L.h2 + 64 * (t & 1);   // this bit's layer-2 inputs: built here, read by tail_b_role
+    if (k < CMX_MIX0) in2[k] = tr->out0[k];
+    if (k < 3) in2[CMX_MIX0 + CMX_MIX1 + k] = tr->aux3[k];
+    if (k == 49) in2[49] = __int_as_float(bit);
+    if (k == 50) in2[50] = tr->lstm_p;
+    if (k == 51) in2[51] = __int_as_float((int)row2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    st_rel(&L.ctl->tail_done, t + 1);   // the gather wave's record of this bit and the scout's are read: their slots may be rewritten
+    float pm = 0.0f;
+#pragma unroll
+    for (int i = 0; i < CMX_MIX0; ++i) pm = fadd(pm, fmul(in2[i], w1[i]));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pm = fadd(pm, fmul(in2[CMX_MIX0 + CMX_MIX1 + i], w1[CMX_MIX0 + i]));
+    float e = 0.0f;
+#pragma unroll
+    for (int j = 0; j < CMX_MIX1; ++j) {
+      const float mine = clamp_out(fadd(pm, e), smin, smax);
+      const float oj = bcast_lane(mine, j);
+      e = fadd(e, fmul(oj, w1[CMX_ROW1_EXTRA + j]));
+    }
+    const float p1_ = fadd(pm, e);
+    const float myout = clamp_out(p1_, smin, smax);
+    if (is1) in2[CMX_MIX0 + k] = myout;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    st_rel(&L.ctl->b_in, t + 1);
+    TPROF(8);
+    // ---- Mixer::Perceive, layer 1 ----
+    if (is1) {
+      const float decay = (float)(d1 * (1.5 - ((1.0 * (double)rs1) / (double)mx1)));
+      const float u = fmul(fmul(decay, lr1), fsub(cmx_logistic(p1_), (float)bit));
+      ++rs1;
+      if (rs1 > mx1) mx1 = rs1;
+      const bool df = (rs1 & 1023) == 0;
+      float4 xv[13], wv[13];
+#pragma unroll
+      for (int i = 0; i < 13; ++i) wv[i] = *reinterpret_cast<const float4*>(w1 + 4 * i);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) xv[i] = *reinterpret_cast<const float4*>(in2 + 4 * i);          // out0[0..23]
+      xv[6] = make_float4(in2[24], in2[25], in2[46], in2[47]);                                     // out0[24,25], aux[0,1]
+      xv[7] = make_float4(in2[48], 0.0f, 0.0f, 0.0f);                                              // aux[2], pad
+#pragma unroll
+      for (int i = 0; i < 5; ++i) xv[8 + i] = make_float4(in2[CMX_MIX0 + 4 * i], in2[CMX_MIX0 + 4 * i + 1], in2[CMX_MIX0 + 4 * i + 2], in2[CMX_MIX0 + 4 * i + 3]);
+      const float c = df ? cdec : 1.0f;  // w * 1.0f == w exactly
+#pragma unroll
+      for (int i = 0; i < 13; ++i) {
+        float4 v = f4sub_mul(wv[i], u, xv[i]);
+        if (i >= 8) {  // extra weights: only j < k belong to mixer k, the rest stays exactly 0
+          const int j0 = 4 * (i - 8);
+          if (j0 + 0 >= k) v.x = 0.0f;
+          if (j0 + 1 >= k) v.y = 0.0f;
+          if (j0 + 2 >= k) v.z = 0.0f;
+          if (j0 + 3 >= k) v.w = 0.0f;
+        }
+        wv[i] = f4scale(v, c);
+      }
+#pragma unroll
+      for (int i = 0; i < 13; ++i) *reinterpret_cast<float4*>(w1 + 4 * i) = wv[i];
+      if (mix_out) as_global(mix_out)[(size_t)t * CMX_MIXERS + CMX_MIX0 + k] = p1_;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    TPROF(10);
+  }
+  if (prof_on && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) S->prof[6 + i] += pacc[i];
+  }
+#undef TPROF
+  if (nbits > 0 && is1 && cur_row != 0xffffffffu) {
+    store_row1();
+    S->max_steps[CMX_MIX0 + k] = mx1;
+  }
+}
+
+__device__ void tail_b_role(MixState* S, const Lds& L, const float* decay1, int nbits, float* p_out, float* mix_out, int lane, bool prof_on) {
+  uint64_t tprev = __builtin_readcyclecounter();
+  uint64_t pacc[3] = {0, 0, 0};
+#define TPROF(k) do { if (prof_on) { uint64_t now_ = __builtin_readcyclecounter(); pacc[k] += now_ - tprev; tprev = now_; } } while (0)
+  const int k = lane;
+  const float cdec = 1.0f - 3.0e-6f;
+  const float lr2 = S->lr[CMX_MIXERS - 1];
+  const uint16_t* const t_st = S->t_st;
+  const uint16_t* const t_sq = S->t_sq;
+  uint16_t* const s6 = S->s6;
+  uint16_t* const s7 = S->s7;
+  int* const x1 = S->x1;
+  int* const x2 = S->x2;
+  const gptr<uint64_t> row_steps = as_global(S->row_steps);
+  float* const w2 = L.w2;  // layer-2 row (predictor.cpp:354-356: a single weight set), LDS-resident
+  const gptr<float> rows2 = as_global(S->rows2);
+  const gptr<uint64_t> rsteps2 = row_steps + (size_t)(CMX_MIXERS - 1) * CMX_ROWS_PER_MIXER;
+  uint32_t cur_row2 = 0xffffffffu;
+  uint64_t rs2 = 0, mx2 = S->max_steps[CMX_MIXERS - 1];
+  unsigned sj = S->sse_j, spc = S->sse_pc, sffl = S->sse_ffl;
+  uint64_t steps_done = 0;
+  for (int t = 0; t < nbits; ++t) {
+    const double d1 = (double)as_global(decay1)[t];
+    // SSE contexts for a = 0..2 / b = 0..3 (sse.cpp:248-262): lane i pulls candidate cell i towards the caches (see tail_role)
+    if (k < 13) {
+      const unsigned j_ = bcast_u(sj), pc_ = bcast_u(spc), ffl_ = bcast_u(sffl);
+      const int a = k % 3, b = k - 9;
+      const float* addr;
+      if (k < 3) addr = (const float*)(s6 + (size_t)(((((a << 7) + (int)(ffl_ & 127)) << 8) + (int)(pc_ & 255)) * 256 + (int)j_) * 8);
+      else if (k < 6) addr = (const float*)(s7 + (size_t)(((((a << 5) + (int)(ffl_ & 31)) << 8) + (int)(pc_ & 255)) * 255 + (j_ ? (int)j_ - 1 : 0)) * 8);
+      else if (k < 9) addr = (const float*)(x2 + (((((a << 1) + (int)(ffl_ & 1)) << 8) + (int)(pc_ & 255)) * 256 + (int)j_));
+      else addr = (const float*)(x1 + (((((b << 8) + (int)(ffl_ & 255)) << 3) + (int)((pc_ >> 5) & 7)) * 79 + sse_mx1mask((int)j_)));
+      touch_line(as_global(addr), L.pfdump + 256 + 256);
+    }
+    if (!wait_ge(L.ctl, &L.ctl->b_in, t + 1, false)) return;
+    TPROF(0);
+    const float* const in2 = L.h2 + 64 * (t & 1);
+    const int bit = __float_as_int(in2[49]);
+    {  // layer 2 has one weight set in cmix (selector = zero_context_); a changing key is still honoured
+      const uint32_t newrow2 = (uint32_t)__float_as_int(in2[51]);
+      if (newrow2 != cur_row2) {
+        if (cur_row2 != 0xffffffffu) {
+          if (k < 16) gstore4(rows2 + (size_t)cur_row2 * CMX_ROW2_STRIDE + 4 * k, *reinterpret_cast<const float4*>(w2 + 4 * k));
+          if (k == 0) rsteps2[cur_row2] = rs2;
+        }
+        cur_row2 = newrow2;
+        if (k < 16) *reinterpret_cast<float4*>(w2 + 4 * k) = gload4(rows2 + (size_t)newrow2 * CMX_ROW2_STRIDE + 4 * k);
+        rs2 = rsteps2[newrow2];
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    float u2 = 0.0f;
+    int df2 = 0;
+    if (k == 0) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        const float4 xv = *reinterpret_cast<const float4*>(in2 + 4 * i);
+        const float4 wv = *reinterpret_cast<const float4*>(w2 + 4 * i);
+        acc = fadd(acc, fmul(xv.x, wv.x)); acc = fadd(acc, fmul(xv.y, wv.y));
+        acc = fadd(acc, fmul(xv.z, wv.z)); acc = fadd(acc, fmul(xv.w, wv.w));
+      }
+      acc = fadd(acc, fmul(in2[48], w2[48]));
+      const float p2_ = acc;
+      const float sq = cmx_logistic(p2_);                  // predictor.cpp:413
+      // ---- SSE::Predict (sse.cpp:243-290,320-324) on the pre-fetched cells ----
+      const int p = (int)(1 + (1 - sq) * 32766);
+      const unsigned prq = (unsigned)p >> 11;
+      const int a = (prq > 0) + (prq > 14);
+      const int b = (prq > 0) + (prq > 7) + (prq > 14);
+      const int i6 = ((((a << 7) + (int)(sffl & 127)) << 8) + (int)(spc & 255)) * 256 + (int)sj;
+      const int i7 = ((((a << 5) + (int)(sffl & 31)) << 8) + (int)(spc & 255)) * 255 + (sj ? (int)sj - 1 : 0);
+      const int im2 = ((((a << 1) + (int)(sffl & 1)) << 8) + (int)(spc & 255)) * 256 + (int)sj;
+      const int im1 = ((((b << 8) + (int)(sffl & 255)) << 3) + (int)((spc >> 5) & 7)) * 79 + sse_mx1mask((int)sj);
+      U16x8 c6 = load_cell(s6 + (size_t)i6 * 8);
+      U16x8 c7 = load_cell(s7 + (size_t)i7 * 8);
+      const int w1x = as_global(x1)[im1];
+      const int w2x = as_global(x2)[im2];
+      SseInterp e6, e7;
+      auto ST = [&](int i) -> int { return L.lst ? (int)L.lst[i] : (int)as_global(t_st)[i]; };
+      auto SQ = [&](int i) -> int { return L.lsq ? (int)L.lsq[i] : (int)as_global(t_sq)[i]; };
+      const int stp = ST(p);
+      const int q6 = SQ(sse_extrap(stp, 10240)), q7 = SQ(sse_extrap(stp, 8200));
+      const int pp1 = e6.pred(c6, q6);
+      const int pp2 = e7.pred(c7, q7);
+      const int s0 = sse_extrap(stp, 7935);
+      const int s1 = sse_extrap(ST(pp1), 9592);
+      const int s4 = sse_extrap(ST(pp2), 7677);
+      const int s2 = sse_extrap(sse_mixup(w1x, s0, s1), 8092);
+      const int mix1_p = SQ(s2);
+      const int s5 = sse_extrap(sse_mixup(w2x, s2, s4), 8202);
+      const int mix2_p = SQ(s5);
+      float pf = (float)(1 - ((mix2_p - 1) / 32766.0));
+      const float lp = in2[50];
+      if (lp == 0.0f || lp == 1.0f) pf = lp;               // predictor.cpp:383,415-417
+      as_global(p_out)[t] = pf;
+      // ---- SSE::Perceive (sse.cpp:291-306,326-328) ----
+      e6.update(c6, bit, 106);
+      e7.update(c7, bit, 127);
+      store_cell_async(s6 + (size_t)i6 * 8, c6);
+      store_cell_async(s7 + (size_t)i7 * 8, c7);
+      as_global(x1)[im1] = w1x + sse_wdelta(bit, s0, s1, 6202, mix1_p);
+      as_global(x2)[im2] = w2x + sse_wdelta(bit, s2, s4, 8320, mix2_p);
+      sj += sj + (unsigned)bit;
+      if (sj >= 256) {
+        sffl = (sffl * 2 + (spc >= 0x40)) & 255;
+        spc = sj & 255;
+        sj = 1;
+      }
+      // ---- Mixer::Perceive, layer 2 (mixer.cpp:56-72) ----
+      const float decay = (float)(d1 * (1.5 - ((1.0 * (double)rs2) / (double)mx2)));
+      u2 = fmul(fmul(decay, lr2), fsub(sq, (float)bit));
+      ++rs2;
+      if (rs2 > mx2) mx2 = rs2;
+      df2 = (rs2 & 1023) == 0;
+      if (mix_out) as_global(mix_out)[(size_t)t * CMX_MIXERS + CMX_MIXERS - 1] = p2_;
+      ++steps_done;
+    }
+    TPROF(1);
+    u2 = bcast_lane(u2, 0);
+    df2 = __builtin_amdgcn_readlane(df2, 0);
+    if (k < CMX_IN2) {  // layer-2 weights: one lane per weight
+      float v = fsub(w2[k], fmul(u2, in2[k]));
+      if (df2) v = fmul(v, cdec);
+      w2[k] = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    st_rel(&L.ctl->b_done, t + 1);
+    TPROF(2);
+  }
+  if (prof_on && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) S->prof[13 + i] += pacc[i];
+  }
+#undef TPROF
+  if (nbits > 0) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (k < 16 && cur_row2 != 0xffffffffu)
+      gstore4(rows2 + (size_t)cur_row2 * CMX_ROW2_STRIDE + 4 * k, *reinterpret_cast<const float4*>(w2 + 4 * k));
+    if (k == 0) {
+      if (cur_row2 != 0xffffffffu) rsteps2[cur_row2] = rs2;
+      S->max_steps[CMX_MIXERS - 1] = mx2;
+      S->sse_j = sj; S->sse_pc = spc; S->sse_ffl = sffl;
+      S->steps = S->steps + steps_done;
+    }
+  }
+}
+
+
 // ==================================================================================================================================
 // cmx_mixnet_spec_kernel: the layer-0 dot products on 26 helper workgroups, each cutting its 2078-term ordered chain into four
 // segments that run AT THE SAME TIME -- segment 0 exactly, segments 1..3 speculatively from 64 candidate start values.
@@ -993,6 +1284,24 @@ constexpr unsigned SPEC_SPIN = 1u << 24;
 __device__ __forceinline__ int f2ord(float f) { int b = __float_as_int(f); return b ^ ((b >> 31) & 0x7fffffff); }
 __device__ __forceinline__ float ord2f(int o) { return __int_as_float(o ^ ((o >> 31) & 0x7fffffff)); }
 
+// sum of a double over the wavefront, in every lane (any order will do: it only centres the candidates). Cross-lane moves as DPP modifiers
+// (quad permutes, rotations inside the rows of 16) and four readlanes instead of six LDS-crossbar round trips of two dwords each.
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+  v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]: every lane holds its quad's sum
+  v += dpp_f64<0x124>(v);   // row_ror:4
+  v += dpp_f64<0x128>(v);   // row_ror:8: every lane holds its row's sum
+  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+
 __device__ void helper_role(MixState* S, SpecXfer* X, HelperLds* H, int nbits, int m, int w, int lane) {
   const gptr<float> rows0 = as_global(S->rows0);
   const int base = 512 * w;                 // first element of this wave's segment
@@ -1004,6 +1313,7 @@ __device__ void helper_role(MixState* S, SpecXfer* X, HelperLds* H, int nbits, i
   for (int k = 0; k < 9; ++k) { W[k] = 0.0f; Wn[k] = 0.0f; xc[k] = 0.0f; xp[k] = 0.0f; }
   unsigned long long n_spec = 0, n_hit = 0, n_miss = 0;
   uint32_t cur_base = 0;
+  bool f_chg = false; uint32_t f_base = 0;   // of the bit fetched last: its selector changes, and to which row (read off the serial path)
   auto failed = [&]() { return lds_poll(&H->abort) != 0; };
   auto give_up = [&]() { lds_publish_store(&H->abort, 1); __hip_atomic_store(&X->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   // fetch the inputs of bit t (this wave's slice) and, if its selector changes, the incoming row
@@ -1018,8 +1328,10 @@ __device__ void helper_role(MixState* S, SpecXfer* X, HelperLds* H, int nbits, i
 #pragma unroll
     for (int k = 0; k < 8; ++k) xc[k] = ld_f32(gx + 64 * k + lane);
     xc[8] = tailk ? ld_f32(gx + 512 + lane) : 0.0f;
-    if (ld_u32(&X->changed[slot][m])) {
+    f_chg = ld_u32(&X->changed[slot][m]) != 0;
+    if (f_chg) {
       const uint32_t nb = ((uint32_t)m * CMX_ROWS_PER_MIXER + ld_u32(&X->rowidx[slot][m])) * CMX_ROW0_STRIDE + (uint32_t)base;
+      f_base = nb;
 #pragma unroll
       for (int k = 0; k < 8; ++k) Wn[k] = rows0[nb + 64 * k + lane];
       Wn[8] = tailk ? rows0[nb + 512 + lane] : 0.0f;
@@ -1044,8 +1356,7 @@ __device__ void helper_role(MixState* S, SpecXfer* X, HelperLds* H, int nbits, i
         if (df) W[k] = fmul(W[k], cdec);
       }
     }
-    const int slot = t % CMX_SPEC_RING;
-    const bool chg = !live || ld_u32(&X->changed[slot][m]) != 0;
+    const bool chg = !live || f_chg;
     if (chg) {                               // outgoing row to HBM (16 B per 4 lanes: 64 consecutive floats per k), incoming row is in Wn
       if (t > 0) {
 #pragma unroll
@@ -1053,7 +1364,7 @@ __device__ void helper_role(MixState* S, SpecXfer* X, HelperLds* H, int nbits, i
         if (tailk) rows0[cur_base + 512 + lane] = W[8];
       }
       if (live) {
-        cur_base = ((uint32_t)m * CMX_ROWS_PER_MIXER + ld_u32(&X->rowidx[slot][m])) * CMX_ROW0_STRIDE + (uint32_t)base;
+        cur_base = f_base;
 #pragma unroll
         for (int k = 0; k < 9; ++k) W[k] = Wn[k];
       }
@@ -1068,8 +1379,7 @@ __device__ void helper_role(MixState* S, SpecXfer* X, HelperLds* H, int nbits, i
 #pragma unroll
     for (int k = 0; k < 9; ++k) xp[k] = xc[k];
     if (w < 3) {                             // the later waves centre their candidates on the sum of what precedes them
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) ds += __shfl_xor(ds, o, 64);
+      ds = wave_sum_f64(ds);
       if (lane == 0) H->segsum[w] = ds;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (lane == 0) lds_publish_store(&H->sum_epoch[w], t + 1);
@@ -1374,7 +1684,7 @@ extern "C" __global__ __launch_bounds__(NTHREADS) void cmx_mixnet_chunk_kernel(
   L.prod = smem;                                                  // 2 * PBUF
   L.xs = L.prod + 2 * PBUF;                                       // 3 * XS
   L.rec = reinterpret_cast<BitRec*>(L.xs + 3 * XS);               // 3
-  L.rr = 3; L.lead = 2; L.lst = nullptr; L.lsq = nullptr; L.sdone = nullptr;
+  L.rr = 3; L.lead = 2; L.lst = nullptr; L.lsq = nullptr; L.sdone = nullptr; L.h2 = nullptr;
   L.trec = reinterpret_cast<TailRec*>(L.rec + 3);                 // 2
   L.upd = reinterpret_cast<float*>(L.trec + 2);                   // 32
   L.dflag = reinterpret_cast<uint32_t*>(L.upd + 32);              // 32
@@ -1436,6 +1746,7 @@ extern "C" __global__ __launch_bounds__(CMX_SPEC_THREADS) void cmx_mixnet_spec_k
   L.sdone = reinterpret_cast<int*>(L.exptab + 32);                // 8
   uint16_t* lst = reinterpret_cast<uint16_t*>(L.sdone + 8);       // 2 x 32768 u16: the SSE's t_st / t_sq on chip
   L.lst = lst; L.lsq = lst + 32768;
+  L.h2 = reinterpret_cast<float*>(lst + 65536);                   // 2 x 64
   for (int i = tid; i < 32768; i += CMX_SPEC_THREADS) reinterpret_cast<uint32_t*>(lst)[i] = i < 16384 ? reinterpret_cast<const uint32_t*>(S->t_st)[i] : reinterpret_cast<const uint32_t*>(S->t_sq)[i - 16384];
   if (tid < 32) { L.upd[tid] = 0.0f; L.dflag[tid] = 0; L.exptab[tid] = cmx_exp2f_tab[tid]; }
   if (tid < 8) L.sdone[tid] = 0;
@@ -1443,7 +1754,8 @@ extern "C" __global__ __launch_bounds__(CMX_SPEC_THREADS) void cmx_mixnet_spec_k
   __syncthreads();
   const bool prof = (mode & 4) != 0;
   if (wave == 0) gather_role(S, L, X, decay1, nbits, mix_out, prof, lane);
-  else if (wave == 1) tail_role(S, L, decay1, nbits, p_out, mix_out, lane, prof && ((mode >> 4) & 4) != 0);
+  else if (wave == 1) tail_a_role(S, L, decay1, nbits, mix_out, lane, prof && ((mode >> 4) & 4) != 0);
+  else if (wave == 3) tail_b_role(S, L, decay1, nbits, p_out, mix_out, lane, prof && ((mode >> 4) & 4) != 0);
   else if (wave == 2) select_role(S, L, X, sel, nbits, lane);
   else if (wave >= 4) stretch_role(S, L, X, probs, bits, nbits, wave - 4, lane);
   __syncthreads();

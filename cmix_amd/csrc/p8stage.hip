@@ -83,7 +83,9 @@ __global__ __launch_bounds__(P8FAM_THREADS) void cmx_p8s_fam2_kernel(P8CmDev* d,
   const int wv = tid >> 6, ln = tid & 63;
   const int sl = ln < 32 ? 32 * wv + ln : P8CM_MAXS;          // this thread's context slot (>= S: none)
   const int rl = (wv == 7 && ln >= 32 && ln < 56) ? ln - 32 : -1;   // refill lane 0..23
-  (void)prof;
+  unsigned long long pc0 = __builtin_readcyclecounter();
+#define P8F_TICK(k) do { if (prof && tid == 0) { const unsigned long long c_ = __builtin_readcyclecounter(); __hip_atomic_fetch_add(&prof[8 * u.bp + (k)], c_ - pc0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pc0 = c_; } } while (0)
+#define P8F_COUNT(i, v) do { if (prof && tid == 0) __hip_atomic_fetch_add(&prof[(i)], (unsigned long long)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
   p8f_load(d, home, d->sm, &sh, tid, P8FAM_THREADS);
   int last_y = d->last_y, c1 = d->c1, lk = 0;
   uint32_t rnd_i = (uint32_t)d->rnd.i, prev_i = rnd_i;
@@ -91,11 +93,14 @@ __global__ __launch_bounds__(P8FAM_THREADS) void cmx_p8s_fam2_kernel(P8CmDev* d,
   for (int t = 0; t < nbits; t++) {
     const P8FamUni u = p8f_uni(d, ctx, chk, bits, x, order, t, &last_y, &c1, &lk, rnd_i);
     if (t < skip) continue;
+    P8F_TICK(0);
     P8FamTmp tmp;
     if (sl < S) p8f_phase1(d, &sh, u, sl, &tmp);
     if (rl >= 0)   // 24 lanes of one wavefront in lockstep, a group of 24 values per iteration
       for (uint32_t base = prev_i + P8F_LOOK + 1; base <= rnd_i + P8F_LOOK; base += 24) p8f_refill_group(&sh, base, rnd_i + P8F_LOOK, rl);
+    P8F_TICK(1);
     __syncthreads();
+    P8F_TICK(2);
     const bool look = u.bp == 0 || u.bp == 2 || u.bp == 5;
     int total;
     const bool all_serial = !d->slot_parallel;   // A/B switch (CMX_P8CM_SERIAL=1): every instance walked by its first lane
@@ -103,6 +108,7 @@ __global__ __launch_bounds__(P8FAM_THREADS) void cmx_p8s_fam2_kernel(P8CmDev* d,
       if (sl < S) p8f_run(d, &sh, u, sl, &tmp, p8f_count(&sh, t, 0, sl));
       total = p8f_count(&sh, t, 0, S);
     } else {
+      P8F_COUNT(64 + u.bp, 1);
       int base = 0, k = 0;
       while (k < ninst) {
         const bool walked = (look && sh.conflict[lk & 1][k]) || sh.shared[k] || all_serial;
@@ -115,6 +121,7 @@ __global__ __launch_bounds__(P8FAM_THREADS) void cmx_p8s_fam2_kernel(P8CmDev* d,
           k = k2;
         } else {
           const int first = d->inst[k].first, cnt = d->inst[k].count;
+          P8F_COUNT(72 + u.bp, 1);
           if (sl == first) {
             sh.walk_cnt = (uint32_t)p8f_walk(d, &sh, u, k, base);
             if (look) sh.shared[k] = (uint8_t)p8f_shares(d, &sh, k);
@@ -130,9 +137,14 @@ __global__ __launch_bounds__(P8FAM_THREADS) void cmx_p8s_fam2_kernel(P8CmDev* d,
       total = base;
       __syncthreads();
     }
+    P8F_TICK(3);
     if (look) p8f_clear_next(&sh, lk, tid, P8FAM_THREADS);
     prev_i = rnd_i; rnd_i += (uint32_t)total;
+    P8F_COUNT(80 + u.bp, 1);
+    P8F_TICK(4);
   }
+#undef P8F_TICK
+#undef P8F_COUNT
   __syncthreads();
   p8f_store(d, home, d->sm, &sh, rnd_i, tid, P8FAM_THREADS);
   if (tid == 0) { d->last_y = last_y; d->c1 = c1; }
@@ -247,285 +259,6 @@ __device__ __forceinline__ uint32_t apm1_upd(uint32_t v, int y, int rate) {   //
   return (uint16_t)(v + ((g - (int)v) >> rate));
 }
 }  // namespace
-
-__global__ __launch_bounds__(MX_THREADS) void cmx_p8s_mix2_kernel(const P8MixDev* M, P8TailDev* T, const int16_t* __restrict__ x, const int32_t* __restrict__ sel,
-                                                                 const P8ApmRec* __restrict__ apm, const uint8_t* __restrict__ order,
-                                                                 const uint8_t* __restrict__ bits, float* __restrict__ out, size_t ld, int nbits, int t0, int first,
-                                                                 int last_y, unsigned long long* prof) {
-  __shared__ __attribute__((aligned(16))) uint32_t xs[2][P8_NX / 2];   // the step's inputs as pairs, double-buffered
-  __shared__ float outs[P8_NOUT];
-  __shared__ int pr_s[32], res_s[8];
-  __shared__ uint32_t st_s[16];
-  __shared__ uint32_t arow[7][36];    // the context rows of the seven chain tables (24 u32 or 33 u16 cells, widened)
-  __shared__ int p_s, fin_s;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  __shared__ int16_t squash[4096], stretch[4096];   // the two tables every stage of the bit reads through: LDS, not L2
-  for (int i = threadIdx.x; i < 4096; i += MX_THREADS) { squash[i] = M->squash[i]; stretch[i] = M->stretch[i]; }
-  const float cf = (float)(1.0 / 4095);
-  for (int i = tid; i < P8_NOUT; i += MX_THREADS) outs[i] = T->out[i];
-  if (tid == 0) fin_s = T->pr;
-  unsigned long long misses = T->misses;   // every thread keeps the miss history itself (uniform)
-  // Nothing inside the step loop may chase a pointer through M / T / sel / apm in global memory: every such load is a
-  // full L2 round trip on the bit's critical path (and the compiler must redo it after each global store). Base pointers
-  // go to registers here; the per-step records (28 selectors, the order, the APM contexts, the coded bit) travel through
-  // an LDS ring, loaded two steps ahead by a few lanes of wave 5 and written at the end of the step.
-  MX_GLOBAL int16_t* const wx = (MX_GLOBAL int16_t*)M->wx; MX_GLOBAL int16_t* const wx2 = (MX_GLOBAL int16_t*)M->wx2;
-  const int nx_first = M->nx_first;
-  __shared__ int32_t ring_sel[4][P8_NSEL];
-  __shared__ uint32_t ring_apm[4][6];     // P8ApmRec = 24 bytes
-  __shared__ int ring_ord[4], ring_bit[4];
-  // the chain lanes: wave 1, lanes 0..6 (wave 0 does the second layer)
-  const bool chain = wave == 1 && lane < 7;
-  // the table this lane fetches one cell of (waves 1..4) / updates (chain lanes), for either block type
-  const int fl = tid - 64, fj = fl >= 0 && fl < 7 * 36 ? fl / 36 : (chain ? lane : 0), fk = fl >= 0 ? fl % 36 : 0;
-  MX_GLOBAL uint32_t* const tb_apm = (MX_GLOBAL uint32_t*)(fj < 4 ? T->apm[fj] : nullptr);
-  MX_GLOBAL uint16_t* const tb_apm1 = (MX_GLOBAL uint16_t*)(fj >= 4 ? T->apm1[fj - 4] : nullptr);
-  MX_GLOBAL uint16_t* const tb_gen = (MX_GLOBAL uint16_t*)T->gen[fj];
-  MX_GLOBAL uint32_t* const my_apm = (MX_GLOBAL uint32_t*)(chain && lane < 4 ? T->apm[lane] : nullptr);
-  MX_GLOBAL uint16_t* const my_apm1 = (MX_GLOBAL uint16_t*)(chain && lane >= 4 ? T->apm1[lane - 4] : nullptr);
-  MX_GLOBAL uint16_t* const my_gen = (MX_GLOBAL uint16_t*)(chain ? T->gen[lane] : nullptr);
-  auto ring_load = [&](int ts, uint32_t& v) {   // wave 5: lanes 0..27 selectors, 28 order, 29 bit, 32..37 APM record
-    if (wave != 5 || ts >= nbits) return;
-    if (lane < P8_NSEL) v = (uint32_t)sel[(size_t)ts * P8_NSEL + lane];
-    else if (lane == 28) v = order[ts];
-    else if (lane == 29) v = bits[ts];
-    else if (lane >= 32 && lane < 38) v = reinterpret_cast<const uint32_t*>(apm + ts)[lane - 32];
-  };
-  auto ring_store = [&](int ts, uint32_t v) {
-    if (wave != 5 || ts >= nbits) return;
-    const int slot = ts & 3;
-    if (lane < P8_NSEL) ring_sel[slot][lane] = (int32_t)v;
-    else if (lane == 28) ring_ord[slot] = (int)v;
-    else if (lane == 29) ring_bit[slot] = (int)v;
-    else if (lane >= 32 && lane < 38) ring_apm[slot][lane - 32] = v;
-  };
-  MxApmLane al_txt = {0, 0, 0}, al_gen = {0, 0, 0};   // the TEXT tables' and the other blocks' tables' pending cells
-  if (chain) {   // home form (P8TailDev): the index of the cell(s) the next call updates; their values are read once per chunk
-    const int j = lane;
-    if (j < 4) { al_txt.idx = T->apm_cxt[j]; al_txt.v0 = my_apm[al_txt.idx]; }
-    else { al_txt.idx = T->apm1_idx[j - 4]; al_txt.v0 = my_apm1[al_txt.idx]; al_txt.v1 = my_apm1[al_txt.idx + 1]; }
-    al_gen.idx = T->gen_idx[j]; al_gen.v0 = my_gen[al_gen.idx]; al_gen.v1 = my_gen[al_gen.idx + 1];
-  }
-  __syncthreads();
-  if (t0) for (int i = tid; i < P8_NOUT; i += MX_THREADS) out[i] = outs[i];   // no step 0: the constructor's values
-  // ---- prologue: rows and inputs of the first step ----
-  uint4 w[4][4], wn[4][4];
-  int row[4], rown[4];
-  uint4 xn = make_uint4(0, 0, 0, 0);
-#define MX_LOAD_G(dst, q, g, wr_) { const int grp_ = lane + 64 * (g); if (grp_ < MX_GROUPS) dst[q][g] = mx_gload4(wr_, grp_); else dst[q][g] = make_uint4(0, 0, 0, 0); }
-#define MX_LOAD_ROW(dst, q, rowid)                                                               \
-  {                                                                                               \
-    const MX_GLOBAL int16_t* wr_ = wx + (size_t)(rowid) * P8_NX;                                \
-    MX_LOAD_G(dst, q, 0, wr_) MX_LOAD_G(dst, q, 1, wr_) MX_LOAD_G(dst, q, 2, wr_) MX_LOAD_G(dst, q, 3, wr_) \
-  }
-#define MX_LOAD_SET(dst, r, ts, q, ord_)                                                         \
-  {                                                                                               \
-    const int si_ = 4 * wave + (q);                                                               \
-    if (si_ != P8_SEL_LASTPR) { r[q] = p8s_sel(si_, ring_sel[(ts) & 3][si_], ord_, 0); MX_LOAD_ROW(dst, q, r[q]) } \
-  }
-  // every set of step ts except set 26 (whose row needs the previous step's final probability)
-#define MX_LOAD_EARLY(dst, r, ts) { const int ord_ = ring_ord[(ts) & 3]; MX_LOAD_SET(dst, r, ts, 0, ord_) MX_LOAD_SET(dst, r, ts, 1, ord_) MX_LOAD_SET(dst, r, ts, 2, ord_) MX_LOAD_SET(dst, r, ts, 3, ord_) }
-#define MX_LOAD_LATE(dst, r, ts, lastpr)                                                         \
-  if (wave == 6) { r[2] = p8s_sel(P8_SEL_LASTPR, ring_sel[(ts) & 3][P8_SEL_LASTPR], 0, lastpr); MX_LOAD_ROW(dst, 2, r[2]) }
-  auto stage_x = [&](int t, int buf) {   // the input row of step t -> LDS (compacted during the first byte)
-    const int16_t* xr = x + (size_t)t * P8_NX;
-    if (t < first) {
-      int16_t* xh = reinterpret_cast<int16_t*>(xs[buf]);
-      for (int i = tid; i < P8_NX; i += MX_THREADS) xh[i] = i < nx_first ? xr[M->first_map[i]] : (int16_t)0;
-    } else if (tid < MX_GROUPS) reinterpret_cast<uint4*>(xs[buf])[tid] = reinterpret_cast<const uint4*>(xr)[tid];
-  };
-  int a_base = 0, upd_idx = -1; uint32_t upd_v0 = 0, upd_v1 = 0;
-  // For the step `ts` about to come (y = the bit coded before it, ms = its miss history):
-  //  * the chain lanes let the tables of that step's block type learn at the cell(s) their last lookup chose (p() =
-  //    update, then lookup) -- a store of a value they kept, not a load-modify-store;
-  //  * waves 1..4 fetch the step's context rows, ONE cell per lane (7 tables x up to 33 cells), into LDS;
-  //  * after the next barrier the chain lanes write their just-updated cells over the fetched copy (chain_patch): the
-  //    fetch may or may not have seen the store.
-  auto row_ctx = [&](const P8ApmRec* a, int j, unsigned long long ms) {
-    if (a->text) return j == 0 ? (a->c[0] | (int)((ms & 0xF) << 4)) : j == 1 ? (int)a->c[1 + (int)(ms & 3)] : (int)a->c[3 + j];   // c[5], c[6]; c[7..9]
-    return j == 0 ? (a->c[0] | (int)(ms & 7)) : j < 4 ? (int)a->c[j] : j == 4 ? (int)a->c[4] : (int)a->c[j - 3];                  // gen[5], gen[6] reuse ctx2, ctx3
-  };
-  auto chain_fetch = [&](int ts, int y, unsigned long long ms) {
-    const P8ApmRec* ap = reinterpret_cast<const P8ApmRec*>(ring_apm[ts & 3]);
-    const int a_text = ap->text, a_limit = ap->limit;
-    if (fl >= 0 && fl < 7 * 36) {
-      const int ncell = (a_text && fj < 4) ? 24 : 33;
-      if (fk < ncell) {
-        const int base = row_ctx(ap, fj, ms) * ncell;
-        arow[fj][fk] = a_text ? (fj < 4 ? tb_apm[base + fk] : (uint32_t)tb_apm1[base + fk]) : (uint32_t)tb_gen[base + fk];
-      }
-    }
-    if (chain) {
-      const int j = lane;
-      if (a_text) {
-        upd_idx = al_txt.idx;
-        if (j < 4) { upd_v0 = apm_upd(al_txt.v0, y, a_limit); my_apm[upd_idx] = upd_v0; }
-        else { upd_v0 = apm1_upd(al_txt.v0, y, j == 4 ? 7 : 6); upd_v1 = apm1_upd(al_txt.v1, y, j == 4 ? 7 : 6); my_apm1[upd_idx] = (uint16_t)upd_v0; my_apm1[upd_idx + 1] = (uint16_t)upd_v1; }
-        a_base = row_ctx(ap, j, ms) * (j < 4 ? 24 : 33);
-      } else {
-        upd_idx = al_gen.idx;
-        upd_v0 = apm1_upd(al_gen.v0, y, 7); upd_v1 = apm1_upd(al_gen.v1, y, 7);
-        my_gen[upd_idx] = (uint16_t)upd_v0; my_gen[upd_idx + 1] = (uint16_t)upd_v1;
-        a_base = row_ctx(ap, j, ms) * 33;
-      }
-    }
-  };
-  auto chain_patch = [&](int a_text) {   // chain lanes, after the barrier that follows chain_fetch
-    const int j = lane;
-    const bool one = a_text && j < 4;            // APM: one cell; APM1: two
-    const int ncell = one ? 24 : 33, off = upd_idx - a_base;
-    if (off >= 0 && off < ncell) arow[j][off] = upd_v0;
-    if (!one && off + 1 >= 0 && off + 1 < ncell) arow[j][off + 1] = upd_v1;
-  };
-  bool pend26 = false, again26 = false;
-  { uint32_t v0_ = 0, v1_ = 0; ring_load(t0, v0_); ring_load(t0 + 1, v1_); ring_store(t0, v0_); ring_store(t0 + 1, v1_); }
-  __syncthreads();
-  if (t0 < nbits) {
-    const int y0 = t0 ? (int)bits[t0 - 1] : last_y;
-    misses += misses + (unsigned long long)((T->pr >> 11) != y0);   // Predictor::update's first line (:8250), for the first step
-    chain_fetch(t0, y0, misses);
-    MX_LOAD_EARLY(w, row, t0)
-    MX_LOAD_LATE(w, row, t0, T->pr)
-    stage_x(t0, t0 & 1);
-  }
-  unsigned long long pacc[6] = {0, 0, 0, 0, 0, 0}, pc0 = __builtin_readcyclecounter();
-#define MX_TICK(i) do { if (prof && (tid & 63) == 0) { const unsigned long long c_ = __builtin_readcyclecounter(); pacc[i] += c_ - pc0; pc0 = c_; } } while (0)
-  for (int t = t0; t < nbits; ++t) {
-    const int y = t > t0 ? ring_bit[(t - 1) & 3] : (t ? (int)bits[t - 1] : last_y);
-    const int nx = t < first ? nx_first : P8_NX;
-    uint32_t ring_v = 0;
-    ring_load(t + 2, ring_v);   // two steps ahead; lands in LDS at the end of this step
-    const int buf = t & 1;
-    MX_TICK(0);
-    mx_lds_barrier();   // B1: xs[buf], arow, fin_s of the previous step
-    const P8ApmRec* arp = reinterpret_cast<const P8ApmRec*>(ring_apm[t & 3]);
-    const int a_text = arp->text;
-    if (chain) chain_patch(a_text);
-    if (wave == 6 && pend26 && !again26) {   // set 26's row was requested after the previous step's chain: take it now (same row again: the trained registers stay)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) w[2][g] = wn[2][g];
-    }
-    for (int i = tid; i < nx; i += MX_THREADS) outs[i] = (float)p8s_squash(squash, reinterpret_cast<const int16_t*>(xs[buf])[i]) * cf;
-    // ---- first layer on the rows in registers ----
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      uint32_t acc = 0;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int grp = lane + 64 * g;
-        const uint4 xv = grp < MX_GROUPS ? reinterpret_cast<const uint4*>(xs[buf])[grp] : make_uint4(0, 0, 0, 0);
-        acc += pair_dot(xv.x, w[q][g].x) + pair_dot(xv.y, w[q][g].y) + pair_dot(xv.z, w[q][g].z) + pair_dot(xv.w, w[q][g].w);
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-      if (lane == 0) pr_s[4 * wave + q] = p8s_squash(squash, (int32_t)(acc * 9u) >> 9);
-    }
-    // ---- one step ahead: rows (all but the one that needs this step's final probability) and the input row ----
-    const bool more = t + 1 < nbits;
-    if (more) {
-      MX_LOAD_EARLY(wn, rown, t + 1)
-      if (t + 1 >= first && tid < MX_GROUPS) xn = reinterpret_cast<const uint4*>(x + (size_t)(t + 1) * P8_NX)[tid];
-    }
-    MX_TICK(1);
-    mx_lds_barrier();   // B2: pr_s, arow
-    if (chain) __builtin_amdgcn_s_waitcnt(0);   // this lane's table updates have reached L2 before other lanes fetch rows again (after B4)
-    if (wave == 0) {   // second layer
-      const int a = lane < P8_NSEL ? stretch[pr_s[lane]] : 0;
-      if (lane < P8_NSEL) outs[nx + lane] = (float)p8s_squash(squash, a) * cf;
-      const int b = __shfl_down(a, 1);
-      if ((lane & 1) == 0 && lane < 32) st_s[lane >> 1] = ((uint32_t)a & 0xffffu) | ((uint32_t)b << 16);
-      __builtin_amdgcn_s_waitcnt(0);
-      __builtin_amdgcn_wave_barrier();
-      uint32_t acc = 0;
-      if (lane < 16) acc = pair_dot(st_s[lane], reinterpret_cast<const MX_GLOBAL uint32_t*>(wx2)[lane]);
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-      if (lane == 0) p_s = p8s_squash(squash, (int32_t)acc >> 9);
-    }
-    MX_TICK(2);
-    mx_lds_barrier();   // B3: p_s
-    if (wave == 1) {   // the chains on the fetched rows: group A (lanes 0..3), then group B (lanes 4..6), then the read-out
-      const int p2 = p_s;
-      auto look_apm = [&](int j, int pr) {   // APM::p's interpolation :704-710 on arow[j]
-        const int s = (stretch[pr] + 2048) * 23;
-        const int wt = s & 0xfff, lo = s >> 12;
-        al_txt.idx = a_base + lo + (wt >> 11); al_txt.v0 = arow[j][lo + (wt >> 11)];
-        return (int)(((arow[j][lo] >> 13) * (uint32_t)(4096 - wt) + (arow[j][lo + 1] >> 13) * (uint32_t)wt) >> 19);
-      };
-      auto look_apm1 = [&](int j, int pr) {   // APM1::pp's interpolation :614-619
-        const int s = stretch[pr];
-        const int wgt = s & 127, lo = (s + 2048) >> 7;
-        MxApmLane& al = a_text ? al_txt : al_gen;
-        al.idx = a_base + lo; al.v0 = arow[j][lo]; al.v1 = arow[j][lo + 1];
-        return (int)((arow[j][lo] * (uint32_t)(128 - wgt) + arow[j][lo + 1] * (uint32_t)wgt) >> 11);
-      };
-      if (lane < 4) res_s[lane] = a_text ? look_apm(lane, p2) : look_apm1(lane, p2);
-      __builtin_amdgcn_s_waitcnt(0);
-      __builtin_amdgcn_wave_barrier();
-      if (lane >= 4 && lane < 7) {
-        const int avg = (p2 + res_s[1] + res_s[2] + res_s[3] + 2) >> 2;
-        res_s[lane] = look_apm1(lane, a_text ? (lane == 4 ? avg : res_s[0]) : res_s[0]);
-      }
-      __builtin_amdgcn_s_waitcnt(0);
-      __builtin_amdgcn_wave_barrier();
-      if (lane == 0) fin_s = p8s_tail_c(arp, p2, res_s, outs + nx + P8_NSEL);
-    }
-    MX_TICK(3);
-    mx_lds_barrier();   // B4: outs complete, fin_s
-    float* orow = out + (size_t)t * ld;
-    for (int i = tid; i < P8_NOUT; i += MX_THREADS) orow[i] = outs[i];
-    // ---- training with the step's own bit; the rows go back to HBM, the next step's rows become current ----
-    const int yb = ring_bit[t & 3];
-    if (more) MX_LOAD_LATE(wn, rown, t + 1, fin_s)   // the one row that needed this step's final probability
-    if (more) misses += misses + (unsigned long long)((fin_s >> 11) != yb);   // the next step's
-    if (more) chain_fetch(t + 1, yb, misses);
-#pragma unroll
-    for (int qq = 0; qq < 4; ++qq) {
-      const int q = qq == 2 ? 3 : qq == 3 ? 2 : qq;   // set 26 (q == 2 of wave 6) last: its next row was requested a moment ago
-      const int err = (int)(int16_t)(((yb << 12) - pr_s[4 * wave + q]) * 7);
-      MX_GLOBAL int16_t* wr = wx + (size_t)row[q] * P8_NX;
-      const bool again = more && rown[q] == row[q];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int grp = lane + 64 * g;
-        uint4 v = w[q][g];
-        if (grp < MX_GROUPS && err) {
-          const uint4 xv = reinterpret_cast<const uint4*>(xs[buf])[grp];
-          v.x = pair_train(xv.x, v.x, err); v.y = pair_train(xv.y, v.y, err);
-          v.z = pair_train(xv.z, v.z, err); v.w = pair_train(xv.w, v.w, err);
-          mx_gstore4(wr, grp, v);
-        }
-        if (wave == 6 && q == 2) w[q][g] = v;   // resolved at the top of the next step, when the late request has arrived
-        else w[q][g] = again ? v : wn[q][g];
-      }
-      if (wave == 6 && q == 2) { pend26 = more; again26 = again; }
-      row[q] = more ? rown[q] : row[q];
-    }
-
-    if (wave == 0 && lane < 16) {
-      const int err2 = (int)(int16_t)(((yb << 12) - p_s) * 7);
-      MX_GLOBAL uint32_t* w2 = reinterpret_cast<MX_GLOBAL uint32_t*>(wx2);
-      if (err2) w2[lane] = pair_train(st_s[lane], w2[lane], err2);
-    }
-    ring_store(t + 2, ring_v);
-    MX_TICK(4);
-    if (more) {   // the next step's inputs into the other LDS buffer
-      if (t + 1 < first) stage_x(t + 1, buf ^ 1);
-      else if (tid < MX_GROUPS) reinterpret_cast<uint4*>(xs[buf ^ 1])[tid] = xn;
-    }
-  }
-  if (prof && (tid & 63) == 0) for (int i = 0; i < 6; i++) prof[(tid >> 6) * 8 + i] += pacc[i];
-#undef MX_TICK
-  __syncthreads();
-  // the cells the chain tables chose last are updated at the top of the next step (update, then lookup): their indices go home
-  if (chain) {
-    const int j = lane;
-    if (j < 4) T->apm_cxt[j] = al_txt.idx; else T->apm1_idx[j - 4] = al_txt.idx;
-    T->gen_idx[j] = al_gen.idx;
-  }
-  for (int i = tid; i < P8_NOUT; i += MX_THREADS) T->out[i] = outs[i];
-  if (tid == 0) { T->pr = fin_s; T->misses = misses; }
-}
 
 // ---- the mixer on FOUR workgroups ------------------------------------------------------------------------------------------------
 // The 28 first-layer weight sets are independent of each other: a set needs the step's inputs, its selector and -- to train -- the coded
@@ -877,10 +610,9 @@ struct cmx_p8stage {
   hipStream_t s_up = nullptr; bool own_up = false;   // the chunk's records go up on a stream that never has a kernel in front of a copy (cmx_p8stage_set_upload_stream)
   hipEvent_t ev_up = nullptr, ev_ord = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_e = nullptr, ev_f = nullptr, ev_mix[P8S_XBUFS] = {};
   bool mix_used[P8S_XBUFS] = {};
-  unsigned long long* d_prof = nullptr;   // CMX_P8MIX_PROFILE=1: per-wave clocks by phase of the mixer kernel
+  unsigned long long* d_prof = nullptr;   // CMX_P8FAM_PROFILE=1: the family kernel's clocks by bit position and phase (cmx_p8stage_profile)
   unsigned long long* d_prx = nullptr; size_t prx_steps = 0; unsigned mix_epoch = 0;   // the mixer's exchange rows (cmx_p8s_mix4_kernel)
   unsigned* h_mixfail = nullptr;         // host-mapped: the mixer's workgroup 0 gave up waiting for another workgroup
-  bool mix1 = false;                     // CMX_P8MIX_ONE_WG=1: the one-workgroup mixer
   uint64_t chunks = 0;
   uint64_t steps = 0;
   int last_bit = 0;
@@ -973,10 +705,9 @@ cmx_p8stage_t* cmx_p8stage_create(int device) {
     ok = ok && hipEventCreateWithFlags(&s.done, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < 7; i++) ok = ok && hipEventCreate(&s.t0[i]) == hipSuccess && hipEventCreate(&s.t1[i]) == hipSuccess;
   }
-  { const char* e = getenv("CMX_P8MIX_ONE_WG"); h->mix1 = (e && *e == '1') || getenv("CMX_P8MIX_PROFILE"); }
   ok = ok && hipHostMalloc((void**)&h->h_mixfail, 64, hipHostMallocMapped) == hipSuccess;
   if (ok) *h->h_mixfail = 0;
-  if (ok && getenv("CMX_P8MIX_PROFILE")) ok = hipMalloc((void**)&h->d_prof, 7 * 8 * 8) == hipSuccess && hipMemset(h->d_prof, 0, 7 * 8 * 8) == hipSuccess;
+  if (ok && getenv("CMX_P8FAM_PROFILE")) ok = hipMalloc((void**)&h->d_prof, 128 * 8) == hipSuccess && hipMemset(h->d_prof, 0, 128 * 8) == hipSuccess;
   ok = ok && hipDeviceSynchronize() == hipSuccess;
   if (!ok) { cmx_set_err("cmx_p8stage_create: allocation / init failed (the stage needs ~9 GB of HBM)"); cmx_p8stage_destroy(h); return nullptr; }
   return h;
@@ -1084,10 +815,7 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
     ok = ok && hipEventRecord(h->ev_f, h->s_f) == hipSuccess;
     for (hipEvent_t e : {h->ev_a, h->ev_b, h->ev_c, h->ev_e, h->ev_f}) ok = ok && hipStreamWaitEvent(h->s_m, e, 0) == hipSuccess;
     (void)hipEventRecord(b.t0[1], h->s_m);
-    if (h->mix1) {
-      hipLaunchKernelGGL(cmx_p8s_mix2_kernel, dim3(1), dim3(MX_THREADS), 0, h->s_m, (const P8MixDev*)h->d_mix, h->d_tail, (const int16_t*)dx, (const int32_t*)(b.d + b.o_sel),
-                         (const P8ApmRec*)(b.d + b.o_apm), (const uint8_t*)dord, d_bits, d_out, ld, nbits, t0, skip, h->last_bit, h->d_prof);
-    } else {
+    {
       ++h->mix_epoch;
       hipLaunchKernelGGL(cmx_p8s_mix4_kernel, dim3(4), dim3(MX_THREADS), 0, h->s_m, (const P8MixDev*)h->d_mix, h->d_tail, (const int16_t*)dx, (const int32_t*)(b.d + b.o_sel),
                          (const P8ApmRec*)(b.d + b.o_apm), (const uint8_t*)dord, d_bits, d_out, ld, nbits, t0, skip, h->last_bit, h->d_prx, h->mix_epoch, h->h_mixfail);
@@ -1115,11 +843,12 @@ int cmx_p8stage_set_upload_stream(cmx_p8stage_t* h, void* stream) {
   return 0;
 }
 
-// diagnostics (CMX_P8MIX_PROFILE=1 at create time): clocks of lane 0 of each of the mixer kernel's 7 waves, by phase
-// (to B1, to B2, to B3, to B4, orow + training, -), summed over all steps so far
-int cmx_p8stage_mix_profile(cmx_p8stage_t* h, unsigned long long out56[56]) {
+// diagnostics (CMX_P8FAM_PROFILE=1 at create time): thread 0 of the family kernel, clocks summed over all steps so far: out[8 bp + k], k = 0 per-step
+// values, 1 phase 1, 2 barrier, 3 run (common path) or rounds, 4 rest; out[64 + bp] steps that took the rounds path, out[72 + bp] instances walked,
+// out[80 + bp] steps
+int cmx_p8stage_profile(cmx_p8stage_t* h, unsigned long long out128[128]) {
   if (!h || !h->d_prof) return 1;
-  return hipMemcpy(out56, h->d_prof, 56 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+  return hipMemcpy(out128, h->d_prof, 128 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
 }
 
 int cmx_p8stage_sync(cmx_p8stage_t* h) {

@@ -322,7 +322,7 @@ int cmx_ppmd_run(cmx_ppmd_t*, const uint8_t* bytes, size_t nbytes, float* out_pr
  *   CMX_PIPELINE_STREAMS   2 or 1: throughput mode for several streams per GPU -- fewer hardware queues per engine (8 or 6;
  *                          roles take turns on shared streams, the per-stream period grows)
  *   CMX_MIXNET_SPEC=0      the one-workgroup mixing-network kernel (1 compute unit per stream instead of 27: many streams per GPU)
- *   CMX_FXCM_PROFILE, CMX_P8MIX_PROFILE, CMX_MIXNET_DBG     in-kernel phase timers / timing experiments (scripts/gpu_*prof*) */
+ *   CMX_FXCM_PROFILE, CMX_P8FAM_PROFILE, CMX_MIXNET_DBG     in-kernel phase timers / timing experiments (scripts/gpu_*prof*) */
 #define CMX_PIPELINE_SLOTS 8   /* chunks in flight per stream (layer-0 matrices the caller cycles through) */
 /* Construction ahead of time: start building the vocabulary-independent stages of an engine for `device` -- mixing
  * network, paq8 stage and (with_fxcm != 0; dictionary_path as for cmx_pipeline_enable_fxcm) the fxcm stage, ~16 GB of tables -- on a
@@ -421,8 +421,10 @@ int cmx_p8stage_sync(cmx_p8stage_t*);
  * buffer comes round again, or by _sync): ms[0] family, [1] mixer + APM chains, [2..4] ContextMap2 x 3, [5] small learners (lanes), [6] DMC forest. */
 int cmx_p8stage_role_ms(cmx_p8stage_t*, double ms[7], uint64_t* chunks, int reset);
 int cmx_p8stage_set_upload_stream(cmx_p8stage_t*, void* stream);   /* see cmx_mixnet_set_upload_stream */
-/* diagnostics (CMX_P8MIX_PROFILE=1 at create time): the mixer kernel's clocks per wave (7) and phase (8 slots, 5 used) */
-int cmx_p8stage_mix_profile(cmx_p8stage_t*, unsigned long long out56[56]);
+/* diagnostics (CMX_P8FAM_PROFILE=1 at create time): the family kernel's clocks by bit position and phase, and how often it left the
+ * common path: out[8 bp + k] (k = 0 per-step values, 1 phase 1, 2 barrier, 3 run / rounds, 4 rest), out[64 + bp] steps in rounds,
+ * out[72 + bp] instances walked, out[80 + bp] steps */
+int cmx_p8stage_profile(cmx_p8stage_t*, unsigned long long out128[128]);
 
 #ifdef __cplusplus
 }

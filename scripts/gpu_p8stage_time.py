@@ -25,11 +25,16 @@ b.record()
 st.sync()
 print("paq8 stage %d x 1 KB: %.2f us/bit device span, %.2f us/bit wall" % (N, a.elapsed_time(b) * 1e3 / (8192 * N), (time.perf_counter() - t0) * 1e6 / (8192 * N)))
 
-if os.environ.get("CMX_P8MIX_PROFILE"):
+if os.environ.get("CMX_P8FAM_PROFILE"):
     import ctypes as C
-    acc = (C.c_ulonglong * 56)()
-    E.lib().cmx_p8stage_mix_profile.argtypes = [C.c_void_p, C.c_void_p]
-    if E.lib().cmx_p8stage_mix_profile(st.h, acc) == 0:
-        nb = 8192.0 * (N + 2)
-        for w in range(7):
-            print("mixer wave %d clocks/bit by phase (->B1 ->B2 ->B3 ->B4 tail):" % w, " ".join("%6.0f" % (acc[8 * w + i] / nb) for i in range(5)), "| total %.0f" % (sum(acc[8 * w + i] for i in range(5)) / nb))
+    acc = (C.c_ulonglong * 128)()
+    E.lib().cmx_p8stage_profile.argtypes = [C.c_void_p, C.c_void_p]
+    if E.lib().cmx_p8stage_profile(st.h, acc) == 0:
+        print("family kernel, thread 0, clocks per step of each bit position: per-step values | phase 1 | barrier | run or rounds | rest ; share of steps in rounds ; instances walked per step")
+        tot = 0.0
+        for bp in range(8):
+            n = max(1, acc[80 + bp])
+            v = [acc[8 * bp + k] / n for k in range(5)]
+            tot += sum(v)
+            print("  bp %d: %6.0f |" % (bp, sum(v)), " ".join("%6.0f" % x for x in v), "; rounds %.3f ; walks %.3f" % (acc[64 + bp] / n, acc[72 + bp] / n))
+        print("  mean %.0f clk/bit" % (tot / 8))

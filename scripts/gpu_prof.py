@@ -33,7 +33,10 @@ if int(os.environ.get('CMX_MIXNET_DBG', '0')) & 2:
     names[6:12] = ['SCOUT: wait consumed', 'SCOUT: probs load + stretch LUT + xs', 'SCOUT: aux + select_row', 'SCOUT: prefetch drain+issue', 'SCOUT: rest + publish', 'SCOUT: loop top']
 if int(os.environ.get('CMX_MIXNET_DBG', '0')) & 4:
     names[6:12] = ['TAIL: prefetch rows + SSE cells', 'TAIL: wait tail_in', 'TAIL: layer 1 (dot + chain)', 'TAIL: layer 2 + SSE + L2 perceive scalars', 'TAIL: updates + publish', 'TAIL: loop top + wait scout']
-tot = sum(pr[:6]) + sum(pr[12:16]) if os.environ.get('CMX_MIXNET_V1') != '1' else sum(pr[:12])
+    if os.environ.get('CMX_MIXNET_SPEC', '1') != '0':   # the tail on two waves
+        names[6:12] = ['TAIL A: row switch + prefetch', 'TAIL A: wait slot + tail_in', 'TAIL A: layer 1 (dot + chain) + hand-over', '-', 'TAIL A: layer-1 updates', 'TAIL A: loop top + wait scout']
+        names[13:16] = ['TAIL B: SSE touches + wait hand-over', 'TAIL B: layer 2 + SSE + output', 'TAIL B: layer-2 update + publish']
+tot = sum(pr[:6]) + pr[12] + (sum(pr[13:16]) if os.environ.get('CMX_MIXNET_SPEC', '1') == '0' else 0) if os.environ.get('CMX_MIXNET_V1') != '1' else sum(pr[:12])
 print('profiled: kernel %.2f ms  %.2f us/bit; total ticks/bit %.0f' % (ms, ms * 1e3 / T, tot / T))
 for n, v in zip(names, pr):
     if n == 'simd ids':

@@ -1,15 +1,6 @@
 #!/bin/bash
-# Round-3 session N: paq8 family -- branch-free bucket search, second-visit buckets through the staging area
+# Round-3 session N: paq8 family -- clocks by bit position and phase, how often it leaves the common path
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 O=gpurun_out/r3n; mkdir -p $O
 export TMPDIR=/tmp
-( timeout 900 python -m pytest tests/test_zgpu_p8stage.py -m gpu -q -x 2>&1 | tail -6 ) | tee $O/pytest.txt
-timeout 300 python scripts/gpu_p8stage_time.py 16 2>&1 | grep -v amdgpu.ids | tee $O/p8_time.txt
-timeout 300 python bench.py --payload-bytes 131072 --steps 8 --warmup 1 --no-cpu-baseline > $O/bench_128k.json 2> $O/bench_128k.err
-python - <<PY
-import json
-d = json.load(open("$O/bench_128k.json"))
-print(round(d["value"]), "B/s", d["verified"]["sha256"][:16], d["verified"]["output_bytes"], {k: round(x, 2) for k, x in d["stage_us_per_bit"].items() if k != "note"})
-print({k: round(x, 2) for k, x in d["paq8_role_us_per_bit"].items() if k != "note"})
-PY
-tail -2 $O/bench_128k.err
+CMX_P8FAM_PROFILE=1 timeout 300 python scripts/gpu_p8stage_time.py 16 2>&1 | grep -v amdgpu.ids | tee $O/p8_fam_phases.txt
