@@ -20,17 +20,20 @@
 
 #include "p8cm_dev.h"
 
-enum { P8F_HASH = 2048, P8F_RV = 512, P8F_NIL = 0xFF, P8F_LOOK = 256 };
+enum { P8F_HASH = 2048, P8F_RV = 512, P8F_NIL = 0xFF, P8F_LOOK = 256, P8F_KMAX = 16 };
 
 #ifdef __HIPCC__
 #define P8F_CAS(p, c, v) atomicCAS((p), (c), (v))
 #define P8F_OR(p, v) atomicOr((p), (v))
 #define P8F_POPC(x) __popc(x)
+#define P8F_INC(p) atomicAdd((p), 1u)
 #else
 static inline uint32_t p8f_cas_host(uint32_t* p, uint32_t c, uint32_t v) { const uint32_t o = *p; if (o == c) *p = v; return o; }
 #define P8F_CAS(p, c, v) p8f_cas_host((p), (c), (v))
 #define P8F_OR(p, v) (*(p) |= (v))
 #define P8F_POPC(x) __builtin_popcount(x)
+static inline uint32_t p8f_inc_host(uint32_t* p) { return (*p)++; }
+#define P8F_INC(p) p8f_inc_host((p))
 #endif
 
 // per-context state between chunks (HBM); during a chunk the copy in P8FamShared is the live one
@@ -53,10 +56,16 @@ struct P8FamShared {
   uint32_t anyshared;
   uint32_t rv[P8F_RV];              // rv[idx & 511] = value number idx of the generator, idx in (i - 64, i + 256]
   uint32_t walk_cnt;
+  uint8_t wfull[P8CM_MAXI + 8];     // the instance was walked whole this bit: its lanes reload
+  // a lookup bit's overlap, narrowed down (p8f_miniwalk): the contexts whose keys another context of the instance also holds
+  uint8_t ink[P8CM_MAXS];           // 1: such a context, 2: already walked this bit
+  uint32_t kcount;                  // how many have registered their keys
+  uint32_t kkeys[P8F_KMAX][5];
+  uint8_t kslot[P8F_KMAX], knk[P8F_KMAX];
   uint16_t sm[1];                   // [nslots][256] u16 StateMaps follow (dynamic LDS)
 };
 // per lane, per bit scratch: registers on the device, an array on the host
-struct P8FamTmp { int ns, draw, look; uint32_t nb; };
+struct P8FamTmp { int ns, draw, look; uint32_t nb; uint32_t L[5]; int nk; };   // L / nk: the buckets the context touches at a lookup bit
 struct P8FamUni { int y, bp, c0, c1, order, lk; uint32_t rnd_i; const uint32_t* ctx; const uint16_t* chk; int16_t* out; int t; };
 
 P8_HD uint16_t* p8f_smrow(P8FamShared* sh, int s) { return sh->sm + (size_t)s * 256; }
@@ -79,7 +88,7 @@ P8_HD void p8f_load(const P8CmDev* d, const P8FamHome* home, const uint16_t* sm_
   { uint32_t* p = &sh->db[0][0]; for (int i = tid; i < 24; i += nthreads) p[i] = 0; }
   { uint8_t* p = &sh->conflict[0][0]; for (int i = tid; i < 2 * (P8CM_MAXI + 8); i += nthreads) p[i] = 0; }
   if (tid == 0) {
-    sh->anyconf[0] = sh->anyconf[1] = 0; sh->walk_cnt = 0; sh->anyshared = 0;
+    sh->anyconf[0] = sh->anyconf[1] = 0; sh->walk_cnt = 0; sh->kcount = 0; sh->anyshared = 0;
     for (int k = 0; k < P8CM_MAXI + 8; k++) sh->shared[k] = 0;
     const int i0 = d->rnd.i;   // V(idx) for idx in (i0 - 64, i0] is the generator's table; then the next 256
     for (int k = 0; k < 64; k++) { const int idx = i0 - k; sh->rv[(uint32_t)idx & (P8F_RV - 1)] = d->rnd.table[idx & 63]; }
@@ -116,7 +125,11 @@ P8_HD void p8f_insert(P8FamShared* sh, int lk, int inst, uint32_t bucket) {
   for (;;) {
     const uint32_t old = P8F_CAS(&tab[h], 0u, key);
     if (old == 0) return;
-    if (old == key) { sh->conflict[lk & 1][inst] = 1; sh->anyconf[lk & 1] = 1; return; }
+    if ((old & 0x7fffffffu) == key) {   // another context of the instance holds it: the entry is marked (bit 31) for p8f_marked
+      sh->conflict[lk & 1][inst] = 1; sh->anyconf[lk & 1] = 1;
+      P8F_OR(&tab[h], 0x80000000u);
+      return;
+    }
     h = (h + 1) & (P8F_HASH - 1);
   }
 }
@@ -124,7 +137,7 @@ P8_HD void p8f_phase1(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int 
   P8FamHome* r = &sh->r;
   const int inst = d->slot_inst[s];
   const P8CmInst* x = &d->inst[inst];
-  t->ns = 0; t->draw = 0; t->look = 0; t->nb = 0;
+  t->ns = 0; t->draw = 0; t->look = 0; t->nb = 0; t->nk = 0;
   if (r->cpo[s] != P8F_NIL) {
     t->ns = sh->nex[4 * r->slot[s][r->cpo[s]] + u.y];
     t->draw = t->ns >= 204;
@@ -181,6 +194,23 @@ P8_HD void p8f_phase1(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int 
     for (int c = 0; c < a; c++) dup |= L[c] == L[a];
     if (!dup) p8f_insert(sh, u.lk, inst, L[a]);
   }
+  t->nk = n;
+  for (int a = 0; a < 5; a++) t->L[a] = a < n ? L[a] : 0;
+}
+// after the barrier of a lookup bit: does another context of the instance hold one of this context's keys?
+P8_HD int p8f_marked(const P8FamShared* sh, int lk, int inst, const P8FamTmp* t) {
+  const uint32_t* tab = sh->hash[lk & 1];
+  for (int a = 0; a < t->nk; a++) {
+    const uint32_t key = ((uint32_t)(inst + 1) << 26) | t->L[a];
+    uint32_t h = (key * 2654435761u) >> 21;
+    for (int guard = 0; guard < P8F_HASH; guard++) {
+      const uint32_t v = tab[h];
+      if ((v & 0x7fffffffu) == key) { if (v >> 31) return 1; break; }
+      if (v == 0) break;
+      h = (h + 1) & (P8F_HASH - 1);
+    }
+  }
+  return 0;
 }
 // housekeeping of a lookup bit's run phase: the OTHER parity's hash set and flags are cleared for the next lookup bit
 P8_HD void p8f_clear_next(P8FamShared* sh, int lk, int tid, int nthreads) {
@@ -353,61 +383,154 @@ P8_HD void p8f_run(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int s, 
   p8f_outputs(d, sh, u, s);
 }
 
-// ---- an instance with an overlap: its first lane walks it on the table, in the reference's order. draws0: draws of this bit
-//      before the instance; returns its own. Afterwards every lane of the instance reloads (p8f_reload). ----
-P8_HD int p8f_walk(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int inst, int draws0) {
+// ---- an instance with an overlap: its first lane walks it on the table, in the reference's order. One context of the walk = p8f_walk_a
+//      (its state update with the draw, the bucket search) + p8f_walk_b (second visit, run bytes, registers, outputs); rank: draws of this
+//      bit before the context. ----
+struct P8FamWalk { uint32_t cp, cp0, runp, cx, nb2[2]; uint16_t checksum; int need2, cc, drew; };
+P8_HD void p8f_walk_a(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int inst, int s, int rank, P8FamWalk* w) {
   P8FamHome* r = &sh->r;
   const P8CmInst* x = &d->inst[inst];
   uint8_t* T = x->table;
-  const int bp = u.bp, c0 = u.c0, c1 = u.c1;
+  const int bp = u.bp, c0 = u.c0;
+  uint32_t cp = r->cpo[s] != P8F_NIL ? r->cp0[s] + r->cpo[s] : P8_NIL;
+  uint32_t cp0 = r->cp0[s];
+  const uint32_t runp = r->runp[s];
+  w->drew = 0; w->need2 = 0; w->cc = 0; w->cx = 0; w->checksum = 0; w->nb2[0] = w->nb2[1] = 0;
+  if (cp != P8_NIL) {
+    int ns = sh->nex[4 * T[cp] + u.y];
+    if (ns >= 204) {
+      const uint32_t v = sh->rv[(u.rnd_i + 1u + (uint32_t)rank) & (P8F_RV - 1)];
+      w->drew = 1;
+      if ((uint32_t)(v << ((452 - ns) >> 3))) ns -= 4;
+    }
+    T[cp] = (uint8_t)ns;
+  }
+  if (bp > 1 && T[runp] == 0) cp = P8_NIL;
+  else if (bp == 1 || bp == 3 || bp == 6) cp = cp0 + 1 + (uint32_t)(c0 & 1);
+  else if (bp == 4 || bp == 7) cp = cp0 + 3 + (uint32_t)(c0 & 3);
+  else if (bp == 2 || bp == 5) cp0 = cp = p8d_bucket_find(T, (p8f_ctx(d, u, s) + (uint32_t)c0) & x->mask, p8f_chk(d, u, s));
+  else {
+    w->checksum = p8f_chk(d, u, s);
+    w->cx = p8f_ctx(d, u, s);
+    cp0 = cp = p8d_bucket_find(T, (w->cx + (uint32_t)c0) & x->mask, w->checksum);
+    const uint8_t* s0 = T + cp0;
+    if (s0[3] == 2) {
+      w->need2 = 1;
+      w->cc = s0[4] + 256;
+      w->nb2[0] = (w->cx + (uint32_t)(w->cc >> 6)) & x->mask;
+      w->nb2[1] = (w->cx + (uint32_t)(w->cc >> 3)) & x->mask;
+    }
+  }
+  w->cp = cp; w->cp0 = cp0; w->runp = runp;
+}
+P8_HD void p8f_walk_b(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int inst, int s, const P8FamWalk* w) {
+  P8FamHome* r = &sh->r;
+  const P8CmInst* x = &d->inst[inst];
+  uint8_t* T = x->table;
+  const int c1 = u.c1;
+  const uint32_t cp = w->cp, cp0 = w->cp0;
+  uint32_t runp = w->runp;
+  if (u.bp == 0) {
+    if (w->need2) {
+      const int cc = w->cc;
+      uint8_t* p = T + p8d_bucket_find(T, w->nb2[0], w->checksum);
+      p[0] = (uint8_t)(1 + ((cc >> 5) & 1));
+      p[1 + ((cc >> 5) & 1)] = (uint8_t)(1 + ((cc >> 4) & 1));
+      p[3 + ((cc >> 4) & 3)] = (uint8_t)(1 + ((cc >> 3) & 1));
+      p = T + p8d_bucket_find(T, w->nb2[1], w->checksum);
+      p[0] = (uint8_t)(1 + ((cc >> 2) & 1));
+      p[1 + ((cc >> 2) & 1)] = (uint8_t)(1 + ((cc >> 1) & 1));
+      p[3 + ((cc >> 1) & 3)] = (uint8_t)(1 + (cc & 1));
+      T[cp0 + 6] = 0;
+    }
+    uint8_t* rp = T + runp;
+    if (rp[0] == 0) { rp[0] = 2; rp[1] = (uint8_t)c1; }
+    else if (rp[1] != c1) { rp[0] = 1; rp[1] = (uint8_t)c1; }
+    else if (rp[0] < 254) rp[0] = (uint8_t)(rp[0] + 2);
+    else if (rp[0] == 255) rp[0] = 128;
+    runp = cp0 + 3;
+  }
+  r->cp0[s] = cp0; r->runp[s] = runp; r->cpo[s] = cp == P8_NIL ? (uint8_t)P8F_NIL : (uint8_t)(cp - cp0);
+  // outputs need this context's bytes as they are NOW (a later context of the walk may change them again)
+  for (int k = 0; k < 7; k++) r->slot[s][k] = T[cp0 + k];
+  r->rc[s] = T[runp]; r->rb[s] = T[runp + 1];
+  p8f_outputs(d, sh, u, s);
+}
+// the whole instance. draws0: draws of this bit before the instance; returns its own. Afterwards every lane of the instance reloads (p8f_reload).
+P8_HD int p8f_walk(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int inst, int draws0) {
+  const P8CmInst* x = &d->inst[inst];
   int cnt = 0;
   for (int s = x->first; s < x->first + x->count; s++) {
-    uint32_t cp = r->cpo[s] != P8F_NIL ? r->cp0[s] + r->cpo[s] : P8_NIL;
-    uint32_t cp0 = r->cp0[s], runp = r->runp[s];
-    if (cp != P8_NIL) {
-      int ns = sh->nex[4 * T[cp] + u.y];
-      if (ns >= 204) {
-        const uint32_t v = sh->rv[(u.rnd_i + 1u + (uint32_t)(draws0 + cnt)) & (P8F_RV - 1)];
-        cnt++;
-        if ((uint32_t)(v << ((452 - ns) >> 3))) ns -= 4;
-      }
-      T[cp] = (uint8_t)ns;
-    }
-    if (bp > 1 && T[runp] == 0) cp = P8_NIL;
-    else if (bp == 1 || bp == 3 || bp == 6) cp = cp0 + 1 + (uint32_t)(c0 & 1);
-    else if (bp == 4 || bp == 7) cp = cp0 + 3 + (uint32_t)(c0 & 3);
-    else if (bp == 2 || bp == 5) cp0 = cp = p8d_bucket_find(T, (p8f_ctx(d, u, s) + (uint32_t)c0) & x->mask, p8f_chk(d, u, s));
-    else {
-      const uint16_t checksum = p8f_chk(d, u, s);
-      const uint32_t cx = p8f_ctx(d, u, s);
-      cp0 = cp = p8d_bucket_find(T, (cx + (uint32_t)c0) & x->mask, checksum);
-      uint8_t* s0 = T + cp0;
-      if (s0[3] == 2) {
-        const int cc = s0[4] + 256;
-        uint8_t* p = T + p8d_bucket_find(T, (cx + (uint32_t)(cc >> 6)) & x->mask, checksum);
-        p[0] = (uint8_t)(1 + ((cc >> 5) & 1));
-        p[1 + ((cc >> 5) & 1)] = (uint8_t)(1 + ((cc >> 4) & 1));
-        p[3 + ((cc >> 4) & 3)] = (uint8_t)(1 + ((cc >> 3) & 1));
-        p = T + p8d_bucket_find(T, (cx + (uint32_t)(cc >> 3)) & x->mask, checksum);
-        p[0] = (uint8_t)(1 + ((cc >> 2) & 1));
-        p[1 + ((cc >> 2) & 1)] = (uint8_t)(1 + ((cc >> 1) & 1));
-        p[3 + ((cc >> 1) & 3)] = (uint8_t)(1 + (cc & 1));
-        s0[6] = 0;
-      }
-      uint8_t* rp = T + runp;
-      if (rp[0] == 0) { rp[0] = 2; rp[1] = (uint8_t)c1; }
-      else if (rp[1] != c1) { rp[0] = 1; rp[1] = (uint8_t)c1; }
-      else if (rp[0] < 254) rp[0] = (uint8_t)(rp[0] + 2);
-      else if (rp[0] == 255) rp[0] = 128;
-      runp = cp0 + 3;
-    }
-    r->cp0[s] = cp0; r->runp[s] = runp; r->cpo[s] = cp == P8_NIL ? (uint8_t)P8F_NIL : (uint8_t)(cp - cp0);
-    // outputs need this context's bytes as they are NOW (a later context of the walk may change them again)
-    for (int k = 0; k < 7; k++) r->slot[s][k] = T[cp0 + k];
-    r->rc[s] = T[runp]; r->rb[s] = T[runp + 1];
-    p8f_outputs(d, sh, u, s);
+    P8FamWalk w;
+    p8f_walk_a(d, sh, u, inst, s, draws0 + cnt, &w);
+    cnt += w.drew;
+    p8f_walk_b(d, sh, u, inst, s, &w);
   }
   return cnt;
+}
+// ---- the same, narrowed down (lookup bits). Contexts interact through shared buckets only, and phase 1 has listed every bucket a context
+//      touches: a context none of whose keys another context of the instance also holds (sh->ink[s] == 0) is independent of all the others and
+//      runs on its own lane afterwards; only the ones that do share a key (ink == 1; their keys in kkeys) are walked here, in order. What makes
+//      this exact:
+//        * ranks: a context's rank is the number of draws before it. Phase 1's draw bits (sh->db) are exact for independent contexts; a walked
+//          context's bit is corrected here as soon as its real state byte has been seen, before any later context's rank is taken from db;
+//        * a walked context may find, after an earlier one changed its bucket, a second visit that phase 1 did not list (buckets outside its
+//          keys, possibly an independent context's). Then the reference's order matters for everything not yet processed: the walk falls back
+//          to the whole instance -- the unprocessed contexts below it first (independent of all that was done so far), then the rest of this
+//          context, then everything above it -- and *full tells the lanes to reload instead of running.
+//      base: draws of this bit before the instance (db is exact below it). whole: walk every context (sh->db is corrected all the same).
+//      force: test switch, every second visit counts as unlisted. Returns the instance's draws.
+P8_HD int p8f_miniwalk(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int inst, int base, int whole, int force, uint32_t* full) {
+  const P8CmInst* x = &d->inst[inst];
+  const int first = x->first, end = x->first + x->count;
+  uint32_t* db = sh->db[u.t % 3];
+  *full = 0;
+  const int nK = (int)sh->kcount;
+  // one context of the walk; its draw bit is made exact before anybody above it looks at db
+#define P8F_WALK_A(q, w_)                                                                          \
+  {                                                                                                \
+    p8f_walk_a(d, sh, u, inst, (q), base + p8f_count(sh, u.t, first, (q)), &(w_));                 \
+    const uint32_t bit_ = 1u << ((q) & 31);                                                        \
+    if ((((db[(q) >> 5] & bit_) != 0) ? 1 : 0) != (w_).drew) db[(q) >> 5] ^= bit_;                 \
+  }
+  if (whole || nK > P8F_KMAX) {   // asked for (no key list: not a lookup bit, or contexts sitting on one slot), or more than the key list holds: the whole instance
+    *full = 1;
+    for (int q = first; q < end; q++) { P8FamWalk w; P8F_WALK_A(q, w) p8f_walk_b(d, sh, u, inst, q, &w); sh->ink[q] = 2; }
+  } else {
+    for (int s = first; s < end; s++) {
+      if (sh->ink[s] != 1) continue;
+      P8FamWalk w;
+      P8F_WALK_A(s, w)
+      int listed = 1;
+      if (w.need2) {
+        int j = 0;
+        while (j < nK && sh->kslot[j] != s) j++;
+        int in0 = 0, in1 = 0;
+        if (j < nK) for (int a = 0; a < sh->knk[j]; a++) { in0 |= sh->kkeys[j][a] == w.nb2[0]; in1 |= sh->kkeys[j][a] == w.nb2[1]; }
+        listed = in0 && in1 && !force;
+      }
+      if (!listed) {
+        *full = 1;
+        for (int q = first; q < s; q++) if (sh->ink[q] != 2) { P8FamWalk v; P8F_WALK_A(q, v) p8f_walk_b(d, sh, u, inst, q, &v); sh->ink[q] = 2; }
+        p8f_walk_b(d, sh, u, inst, s, &w); sh->ink[s] = 2;
+        for (int q = s + 1; q < end; q++) { P8FamWalk v; P8F_WALK_A(q, v) p8f_walk_b(d, sh, u, inst, q, &v); sh->ink[q] = 2; }
+        break;
+      }
+      p8f_walk_b(d, sh, u, inst, s, &w); sh->ink[s] = 2;
+    }
+  }
+#undef P8F_WALK_A
+  sh->kcount = 0;
+  return p8f_count(sh, u.t, first, end);
+}
+// a lane of an instance that is about to be mini-walked: is this context one of those that share a key? If so its keys go on the list.
+P8_HD void p8f_register(P8FamShared* sh, const P8FamUni& u, int inst, int s, const P8FamTmp* t) {
+  const int mine = p8f_marked(sh, u.lk, inst, t);
+  sh->ink[s] = (uint8_t)mine;
+  if (mine) {
+    const uint32_t j = P8F_INC(&sh->kcount);
+    if (j < P8F_KMAX) { sh->kslot[j] = (uint8_t)s; sh->knk[j] = (uint8_t)t->nk; for (int a = 0; a < 5; a++) sh->kkeys[j][a] = t->L[a]; }
+  }
 }
 // After a walk (the only way two contexts can come to sit on one slot: the later one's search replaced or found the
 // slot the earlier one had just taken): do two contexts of the instance share a slot -- as state bytes, or one's state

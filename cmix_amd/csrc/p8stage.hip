@@ -108,33 +108,34 @@ __global__ __launch_bounds__(P8FAM_THREADS) void cmx_p8s_fam2_kernel(P8CmDev* d,
       if (sl < S) p8f_run(d, &sh, u, sl, &tmp, p8f_count(&sh, t, 0, sl));
       total = p8f_count(&sh, t, 0, S);
     } else {
+      // An overlap (or two contexts sitting on one slot). The walked instances first, in order -- at a lookup bit only their contexts that
+      // share a key (p8f_miniwalk), which leaves sh.db exact -- then every other context on its lane in ONE pass, its rank a prefix count of db.
       P8F_COUNT(64 + u.bp, 1);
-      int base = 0, k = 0;
-      while (k < ninst) {
+      for (int k = 0; k < ninst; k++) {
         const bool walked = (look && sh.conflict[lk & 1][k]) || sh.shared[k] || all_serial;
-        if (!walked) {
-          int k2 = k;
-          while (k2 < ninst && !((look && sh.conflict[lk & 1][k2]) || sh.shared[k2] || all_serial)) k2++;
-          const int a = d->inst[k].first, b = k2 < ninst ? d->inst[k2].first : S;
-          if (sl >= a && sl < b) p8f_run(d, &sh, u, sl, &tmp, base + p8f_count(&sh, t, a, sl));
-          base += p8f_count(&sh, t, a, b);
-          k = k2;
-        } else {
-          const int first = d->inst[k].first, cnt = d->inst[k].count;
-          P8F_COUNT(72 + u.bp, 1);
-          if (sl == first) {
-            sh.walk_cnt = (uint32_t)p8f_walk(d, &sh, u, k, base);
-            if (look) sh.shared[k] = (uint8_t)p8f_shares(d, &sh, k);
-          }
-          __syncthreads();
-          base += (int)sh.walk_cnt;
-          if (sl >= first && sl < first + cnt) p8f_reload(d, &sh, sl);
-          __syncthreads();   // walk_cnt may be rewritten by the next walker
-          k++;
-        }
+        if (!walked) continue;
+        const int first = d->inst[k].first, cnt = d->inst[k].count;
+        const bool whole = !look || sh.shared[k] || all_serial;
+        P8F_COUNT(72 + u.bp, 1);
+        if (!whole && sl >= first && sl < first + cnt) p8f_register(&sh, u, k, sl, &tmp);
+        __syncthreads();
+        if (sl == first) { uint32_t full; (void)p8f_miniwalk(d, &sh, u, k, p8f_count(&sh, t, 0, first), whole, d->slot_parallel == 2, &full); sh.wfull[k] = (uint8_t)full; }
+        __syncthreads();
       }
+      if (sl < S) {
+        const int k = d->slot_inst[sl];
+        const bool walked = (look && sh.conflict[lk & 1][k]) || sh.shared[k] || all_serial;
+        if (walked && (sh.wfull[k] || sh.ink[sl] == 2)) p8f_reload(d, &sh, sl);
+        else p8f_run(d, &sh, u, sl, &tmp, p8f_count(&sh, t, 0, sl));
+      }
+      total = p8f_count(&sh, t, 0, S);
+      __syncthreads();   // every context has its new registers
+      if (look && sl < S && sl == d->inst[d->slot_inst[sl]].first) {   // slots change hands at lookup bits only
+        const int k = d->slot_inst[sl];
+        if (sh.conflict[lk & 1][k] || sh.shared[k] || all_serial) sh.shared[k] = (uint8_t)p8f_shares(d, &sh, k);
+      }
+      __syncthreads();
       if (tid == 0) { int anys = 0; for (int q = 0; q < ninst; q++) anys |= sh.shared[q]; sh.anyshared = (uint32_t)anys; }
-      total = base;
       __syncthreads();
     }
     P8F_TICK(3);
@@ -672,6 +673,7 @@ cmx_p8stage_t* cmx_p8stage_create(int device) {
   if (ok) {
     const char* serial = getenv("CMX_P8CM_SERIAL");   // A/B switch: the reference's serial walk on lane 0
     if (serial && serial[0] == '1') { S->fam.slot_parallel = 0; for (auto& c : S->cm2) c.slot_parallel = 0; }
+    if (serial && serial[0] == '2') S->fam.slot_parallel = 2;   // test switch: the family's narrowed walk treats every second visit as unlisted (its fall-back path)
     h->d_fam = dev_copy(S->fam, h->pol);
     h->d_fam_home = S->fam_home;
     h->fam_lds = sizeof(P8FamShared) + (size_t)S->fam.nslots * 512;

@@ -37,6 +37,8 @@ struct Emul {
   uint64_t steps = 0;
   int last_bit = 0;
   uint64_t fam_serial = 0, cm2_serial = 0;
+  int fam_miniwalk = 1;   // 0: whole-instance walks only; 1: the kernel's narrowed walk; 2: with every second visit treated as unlisted (the fall-back path)
+  uint64_t fam_mini = 0, fam_mini_full = 0;
   // diagnostics: per family instance, lookup bits with an overlap / with an overlap AND a pending rnd() draw in the instance
   uint64_t inst_conf[P8CM_MAXI] = {}, inst_risky[P8CM_MAXI] = {}, lookups = 0, bits_with_conf = 0, bits_with_risky = 0, draws_total = 0, multi_conf = 0;
 };
@@ -105,6 +107,8 @@ void p8s_dump_fam(void* h, uint32_t* out /* [nslots][5] */) {
   }
 }
 void p8s_dump_table(void* h, int inst, uint8_t* out) { Emul* e = (Emul*)h; memcpy(out, e->S.fam.inst[inst].table, ((size_t)e->S.fam.inst[inst].mask + 1) * 64); }
+void p8s_set_miniwalk(void* h, int mode) { ((Emul*)h)->fam_miniwalk = mode; }
+void p8s_miniwalk_stats(void* h, uint64_t* out2) { out2[0] = ((Emul*)h)->fam_mini; out2[1] = ((Emul*)h)->fam_mini_full; }
 void p8s_stats(void* h, uint64_t* out3) { Emul* e = (Emul*)h; out3[0] = e->steps; out3[1] = e->fam_serial; out3[2] = e->cm2_serial; }
 // nbytes more bytes of the stream; out [8 nbytes][1591] f32 = PAQ8::Predict() before each of their bits. 0 or a negative front-end code.
 int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
@@ -209,23 +213,27 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
           total = p8f_count(sh, (int)t, 0, SS);
         } else {
           e->fam_serial++;
-          int base = 0, k = 0, anys = 0;
+          int anys = 0;
           auto walked = [&](int q) { return (look && sh->conflict[fu.lk & 1][q]) || sh->shared[q]; };
-          while (k < d->ninst) {
-            if (!walked(k)) {
-              int k2 = k;
-              while (k2 < d->ninst && !walked(k2)) k2++;
-              const int a = d->inst[k].first, b = k2 < d->ninst ? d->inst[k2].first : SS;
-              for (int s = b - 1; s >= a; s--) p8f_run(d, sh, fu, s, &tmp[s], base + p8f_count(sh, (int)t, a, s));
-              base += p8f_count(sh, (int)t, a, b);
-              k = k2;
-            } else {
-              base += p8f_walk(d, sh, fu, k, base);
-              if (look) sh->shared[k] = (uint8_t)p8f_shares(d, sh, k);   // slots change hands at lookup bits only
-              for (int s = d->inst[k].first; s < d->inst[k].first + d->inst[k].count; s++) p8f_reload(d, sh, s);
-              k++;
-            }
+          // as in the kernel: the walked instances first, in order (narrowed at a lookup bit: p8f_miniwalk; sh->db is exact afterwards), then every
+          // other context in one pass with its rank taken from db
+          for (int k = 0; k < d->ninst; k++) {
+            if (!walked(k)) continue;
+            const int first = d->inst[k].first, end = first + d->inst[k].count;
+            const int whole = !look || sh->shared[k] || !e->fam_miniwalk;
+            if (!whole) for (int s = end - 1; s >= first; s--) p8f_register(sh, fu, k, s, &tmp[s]);
+            uint32_t full = 0;
+            (void)p8f_miniwalk(d, sh, fu, k, p8f_count(sh, (int)t, 0, first), whole, e->fam_miniwalk == 2, &full);
+            sh->wfull[k] = (uint8_t)full;
+            if (!whole) { e->fam_mini++; e->fam_mini_full += full; }
           }
+          for (int s = SS - 1; s >= 0; s--) {
+            const int k = d->slot_inst[s];
+            if (walked(k) && (sh->wfull[k] || sh->ink[s] == 2)) p8f_reload(d, sh, s);
+            else p8f_run(d, sh, fu, s, &tmp[s], p8f_count(sh, (int)t, 0, s));
+          }
+          const int base = p8f_count(sh, (int)t, 0, SS);
+          if (look) for (int k = 0; k < d->ninst; k++) if (walked(k)) sh->shared[k] = (uint8_t)p8f_shares(d, sh, k);   // slots change hands at lookup bits only
           for (int q = 0; q < d->ninst; q++) anys |= sh->shared[q];
           sh->anyshared = (uint32_t)anys;
           total = base;

@@ -46,12 +46,16 @@ def emul():
     return L
 
 
-def run_stage(data, chunks=None):
-    """PAQ8::Predict()'s 1591 values before every bit of data, through the emulated stage in the given chunk sizes."""
+def run_stage(data, chunks=None, miniwalk=None, mini_stats=None):
+    """PAQ8::Predict()'s 1591 values before every bit of data, through the emulated stage in the given chunk sizes. miniwalk: how the
+    ContextMap family resolves an overlap at a lookup bit (None / 1: as the kernel, 0: whole-instance walks, 2: the fall-back path forced)."""
     L = emul()
     data = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8))
     h = L.p8s_create(11)
     assert h
+    if miniwalk is not None:
+        L.p8s_set_miniwalk.argtypes = [C.c_void_p, C.c_int]
+        L.p8s_set_miniwalk(h, miniwalk)
     out = np.zeros((8 * len(data), 1591), np.float32)
     pos, k = 0, 0
     chunks = chunks or [len(data)]
@@ -63,6 +67,9 @@ def run_stage(data, chunks=None):
         pos += n
     st = np.zeros(3, np.uint64)
     L.p8s_stats(h, st.ctypes.data)
+    if mini_stats is not None:
+        L.p8s_miniwalk_stats.argtypes = [C.c_void_p, C.c_void_p]
+        L.p8s_miniwalk_stats(h, mini_stats.ctypes.data)
     L.p8s_destroy(h)
     return out, st
 
@@ -126,6 +133,22 @@ def test_stage_vs_reference_hashes(name, nbytes):
     h = row_hash(got)
     bad = np.nonzero(h != want[:8 * nbytes])[0]
     assert bad.size == 0, (name, "first differing step:", bad[0], "of", 8 * nbytes)
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_family_overlap_paths(mode):
+    """An overlap of the ContextMap family at a lookup bit walks only the contexts that share a key (p8f_miniwalk); the whole-instance walk
+    (mode 0) and the narrowed walk's fall-back for a second visit phase 1 did not list (mode 2: forced at every second visit) must give the
+    same columns -- the reference's."""
+    from make_paq8_hashes import row_hash
+    stream, want = load_hashes("rich_16k")
+    nbytes = 5000
+    ms = np.zeros(2, np.uint64)
+    got, _ = run_stage(stream[:nbytes], chunks=[1000, 333], miniwalk=mode, mini_stats=ms)
+    bad = np.nonzero(row_hash(got) != want[:8 * nbytes])[0]
+    assert bad.size == 0, (mode, "first differing step:", bad[0])
+    if mode == 2:
+        assert ms[0] > 500 and ms[1] > 50, ms   # narrowed walks happened, and a good part of them took the fall-back
 
 
 def test_cm2_walk_and_reload_path(monkeypatch):
