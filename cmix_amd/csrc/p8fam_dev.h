@@ -383,6 +383,12 @@ P8_HD void p8f_run(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int s, 
   p8f_outputs(d, sh, u, s);
 }
 
+// Bucket::Find for the walks: the bucket as it is in the table NOW -> the context's staging area (one vector fetch), the search on the copy
+// (p8f_find_staged: changes go to both). Returns the byte offset of the slot's first state byte, like p8d_bucket_find.
+P8_HD uint32_t p8f_find_fetch(uint8_t* T, uint32_t nb, uint8_t* b, uint16_t checksum) {
+  p8f_stage_bucket(b, T + (size_t)nb * 64);
+  return nb * 64 + P8_B_STATE + 7 * (uint32_t)p8f_find_staged(T, nb, b, checksum);
+}
 // ---- an instance with an overlap: its first lane walks it on the table, in the reference's order. One context of the walk = p8f_walk_a
 //      (its state update with the draw, the bucket search) + p8f_walk_b (second visit, run bytes, registers, outputs); rank: draws of this
 //      bit before the context. ----
@@ -408,12 +414,12 @@ P8_HD void p8f_walk_a(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int 
   if (bp > 1 && T[runp] == 0) cp = P8_NIL;
   else if (bp == 1 || bp == 3 || bp == 6) cp = cp0 + 1 + (uint32_t)(c0 & 1);
   else if (bp == 4 || bp == 7) cp = cp0 + 3 + (uint32_t)(c0 & 3);
-  else if (bp == 2 || bp == 5) cp0 = cp = p8d_bucket_find(T, (p8f_ctx(d, u, s) + (uint32_t)c0) & x->mask, p8f_chk(d, u, s));
+  else if (bp == 2 || bp == 5) cp0 = cp = p8f_find_fetch(T, (p8f_ctx(d, u, s) + (uint32_t)c0) & x->mask, sh->bk[s], p8f_chk(d, u, s));
   else {
     w->checksum = p8f_chk(d, u, s);
     w->cx = p8f_ctx(d, u, s);
-    cp0 = cp = p8d_bucket_find(T, (w->cx + (uint32_t)c0) & x->mask, w->checksum);
-    const uint8_t* s0 = T + cp0;
+    cp0 = cp = p8f_find_fetch(T, (w->cx + (uint32_t)c0) & x->mask, sh->bk[s], w->checksum);
+    const uint8_t* s0 = sh->bk[s] + (cp0 & 63);   // (the fetched copy is current: every change of the search went to both)
     if (s0[3] == 2) {
       w->need2 = 1;
       w->cc = s0[4] + 256;
@@ -433,11 +439,11 @@ P8_HD void p8f_walk_b(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int 
   if (u.bp == 0) {
     if (w->need2) {
       const int cc = w->cc;
-      uint8_t* p = T + p8d_bucket_find(T, w->nb2[0], w->checksum);
+      uint8_t* p = T + p8f_find_fetch(T, w->nb2[0], sh->bk[s], w->checksum);
       p[0] = (uint8_t)(1 + ((cc >> 5) & 1));
       p[1 + ((cc >> 5) & 1)] = (uint8_t)(1 + ((cc >> 4) & 1));
       p[3 + ((cc >> 4) & 3)] = (uint8_t)(1 + ((cc >> 3) & 1));
-      p = T + p8d_bucket_find(T, w->nb2[1], w->checksum);
+      p = T + p8f_find_fetch(T, w->nb2[1], sh->bk[s], w->checksum);
       p[0] = (uint8_t)(1 + ((cc >> 2) & 1));
       p[1 + ((cc >> 2) & 1)] = (uint8_t)(1 + ((cc >> 1) & 1));
       p[3 + ((cc >> 1) & 3)] = (uint8_t)(1 + (cc & 1));
@@ -535,12 +541,16 @@ P8_HD void p8f_register(P8FamShared* sh, const P8FamUni& u, int inst, int s, con
 // After a walk (the only way two contexts can come to sit on one slot: the later one's search replaced or found the
 // slot the earlier one had just taken): do two contexts of the instance share a slot -- as state bytes, or one's state
 // bytes under the other's run bytes? While they do, the instance is walked every bit (p8f_walk), lookup bit or not.
-P8_HD int p8f_shares(const P8CmDev* d, const P8FamShared* sh, int inst) {
+// walked_only: after a narrowed walk only the walked contexts (sh->ink == 2) can have come to share a slot -- sharing takes a common bucket, i.e. a
+// common key, and the contexts with a common key are the walked ones.
+P8_HD int p8f_shares(const P8CmDev* d, const P8FamShared* sh, int inst, int walked_only) {
   const P8FamHome* r = &sh->r;
   const P8CmInst* x = &d->inst[inst];
   for (int a = x->first; a < x->first + x->count; a++) {
+    if (walked_only && sh->ink[a] != 2) continue;
     const uint32_t cur_a = r->cpo[a] != P8F_NIL ? r->cp0[a] : 0xFFFFFFF0u, run_a = r->runp[a] - 3;
     for (int b = a + 1; b < x->first + x->count; b++) {
+      if (walked_only && sh->ink[b] != 2) continue;
       const uint32_t cur_b = r->cpo[b] != P8F_NIL ? r->cp0[b] : 0xFFFFFFF1u, run_b = r->runp[b] - 3;
       if (cur_a == cur_b || cur_a == run_b || run_a == cur_b) return 1;
     }

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(P8FAM_THREADS) void cmx_p8s_fam2_kernel(P8CmDev* d,
       __syncthreads();   // every context has its new registers
       if (look && sl < S && sl == d->inst[d->slot_inst[sl]].first) {   // slots change hands at lookup bits only
         const int k = d->slot_inst[sl];
-        if (sh.conflict[lk & 1][k] || sh.shared[k] || all_serial) sh.shared[k] = (uint8_t)p8f_shares(d, &sh, k);
+        if (sh.conflict[lk & 1][k] || sh.shared[k] || all_serial) sh.shared[k] = (uint8_t)p8f_shares(d, &sh, k, !(sh.shared[k] || all_serial));
       }
       __syncthreads();
       if (tid == 0) { int anys = 0; for (int q = 0; q < ninst; q++) anys |= sh.shared[q]; sh.anyshared = (uint32_t)anys; }

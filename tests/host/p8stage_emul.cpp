@@ -233,7 +233,7 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
             else p8f_run(d, sh, fu, s, &tmp[s], p8f_count(sh, (int)t, 0, s));
           }
           const int base = p8f_count(sh, (int)t, 0, SS);
-          if (look) for (int k = 0; k < d->ninst; k++) if (walked(k)) sh->shared[k] = (uint8_t)p8f_shares(d, sh, k);   // slots change hands at lookup bits only
+          if (look) for (int k = 0; k < d->ninst; k++) if (walked(k)) sh->shared[k] = (uint8_t)p8f_shares(d, sh, k, !(sh->shared[k] || !e->fam_miniwalk));   // slots change hands at lookup bits only
           for (int q = 0; q < d->ninst; q++) anys |= sh->shared[q];
           sh->anyshared = (uint32_t)anys;
           total = base;
