@@ -61,14 +61,15 @@ def lstm_algo_bytes(V, C=200, H=100):
     return 4 * g + 3 * 4 * V * (2 * C + 1) + 8 * g + 4 * V * 2 * C + 28 * 3 * C * (4 * V + 3 * C + 2) / H
 
 
-# Strict-mode floor of the final mixing network: the 2078-term ordered f32 add chain of a layer-0 mixer is
-# 2078 dependent v_add_f32 at >= 4.5 clocks (register-chain microbenchmark, profiles/r01_ubench.txt) = 3.9 us at 2.4 GHz, plus the
-# serial hand-offs a bit cannot avoid (error -> first products 3.4 k clocks, extra-input chain 1.2 k, error 0.7 k): 5.7 us/bit.
-STRICT_FLOOR_US_PER_BIT = 5.7
+# Strict-mode floor of the final mixing network: the ordered f32 add chain of a layer-0 mixer cannot be reassociated; cut
+# into four speculative segments it is 520 dependent v_add_f32 at >= 4.5 clocks (register-chain microbenchmark, profiles/r01_ubench.txt)
+# = 2.3 k clocks, between two cross-workgroup hand-offs a bit cannot avoid (error out, sum back: ~1.5 k clocks each as the poller sees them),
+# plus update + products 0.5 k, in-order resolve 0.6 k, extra-input chain 0.9 k, error 0.8 k: 9.1 k clocks = 3.8 us/bit at 2.4 GHz.
+STRICT_FLOOR_US_PER_BIT = 3.8
 
 PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_bench.json")
 PMC_KERNELS = {"mixnet": ["cmx_mixnet_spec_kernel"], "fxcm": ["cmx_fxcm_roles_kernel"], "ctxmodels": ["cmx_ctxmodels_kernel"],
-               "lstm": ["cmx_lstm_fwdblk", "cmx_lstm_bpttblk", "cmx_lstm_bptt_acc", "cmx_lstm_bptt_gb"], "paq8": ["cmx_p8s_mix2_kernel"]}
+               "lstm": ["cmx_lstm_fwdblk", "cmx_lstm_bpttblk", "cmx_lstm_bptt_acc", "cmx_lstm_bptt_gb"], "paq8": ["cmx_p8s_fam2_kernel", "cmx_p8s_mix4_kernel"]}
 
 
 def pmc_traffic_per_byte(stage):
@@ -92,7 +93,7 @@ def pmc_traffic_per_byte(stage):
         return None
 
 
-KERNEL = {"mixnet": "cmx_mixnet_spec_kernel", "paq8": "cmx_p8s_mix2_kernel / cmx_p8s_fam2_kernel (slowest role)", "fxcm": "cmx_fxcm_roles_kernel",
+KERNEL = {"mixnet": "cmx_mixnet_spec_kernel", "paq8": "cmx_p8s_fam2_kernel / cmx_p8s_mix4_kernel (slowest role)", "fxcm": "cmx_fxcm_roles_kernel",
           "lstm": "cmx_lstm_fwdblk / cmx_lstm_bpttblk / cmx_lstm_bptt_*", "ctxmodels": "cmx_ctxmodels_kernel"}
 
 
