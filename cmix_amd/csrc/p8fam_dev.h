@@ -17,6 +17,7 @@
 #ifndef CMX_P8FAM_DEV_H
 #define CMX_P8FAM_DEV_H
 #include <stdint.h>
+#include <string.h>
 
 #include "p8cm_dev.h"
 
@@ -40,7 +41,7 @@ static inline uint32_t p8f_inc_host(uint32_t* p) { return (*p)++; }
 struct P8FamHome {
   uint32_t cp0[P8CM_MAXS], runp[P8CM_MAXS];          // byte offsets into the instance's table: slot base, run bytes
   uint8_t cpo[P8CM_MAXS], rc[P8CM_MAXS], rb[P8CM_MAXS], smc[P8CM_MAXS];   // cp - cp0 (P8F_NIL: none), run count / byte, StateMap context
-  uint8_t slot[P8CM_MAXS][8];                         // the slot's 7 state bytes
+  alignas(8) uint8_t slot[P8CM_MAXS][8];              // the slot's 7 state bytes
 };
 struct P8FamShared {
   P8FamHome r;
@@ -65,7 +66,7 @@ struct P8FamShared {
   uint16_t sm[1];                   // [nslots][256] u16 StateMaps follow (dynamic LDS)
 };
 // per lane, per bit scratch: registers on the device, an array on the host
-struct P8FamTmp { int ns, draw, look; uint32_t nb; uint32_t L[5]; int nk; };   // L / nk: the buckets the context touches at a lookup bit
+struct P8FamTmp { int ns, draw, look; uint32_t nb; uint32_t L[5]; int nk; uint32_t cx; uint16_t ck; };   // cx / ck: the context's hash and checksum of this byte (filled in by the caller: p8f_ctx / p8f_chk, read once per byte)   // L / nk: the buckets the context touches at a lookup bit
 struct P8FamUni { int y, bp, c0, c1, order, lk; uint32_t rnd_i; const uint32_t* ctx; const uint16_t* chk; int16_t* out; int t; };
 
 P8_HD uint16_t* p8f_smrow(P8FamShared* sh, int s) { return sh->sm + (size_t)s * 256; }
@@ -152,7 +153,7 @@ P8_HD void p8f_phase1(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int 
   L[n++] = r->runp[s] >> 6;
   if (!(bp > 1 && r->rc[s] == 0)) {
     t->look = 1;
-    t->nb = (p8f_ctx(d, u, s) + (uint32_t)u.c0) & x->mask;
+    t->nb = (t->cx + (uint32_t)u.c0) & x->mask;
     L[n++] = t->nb;
     const uint8_t* g = x->table + (size_t)t->nb * 64;
     uint8_t* b = sh->bk[s];
@@ -166,7 +167,7 @@ P8_HD void p8f_phase1(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int 
 #endif
     if (bp == 0) {
       const uint16_t* cs = (const uint16_t*)b;
-      const uint16_t chk = p8f_chk(d, u, s);
+      const uint16_t chk = t->ck;
       const int mru = b[P8_B_MRU];
       int slot = -1;
       {   // (independent loads first)
@@ -184,8 +185,8 @@ P8_HD void p8f_phase1(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int 
       }
       if (slot >= 0 && b[P8_B_STATE + 7 * slot + 3] == 2) {
         const int cc = b[P8_B_STATE + 7 * slot + 4] + 256;
-        L[n++] = (p8f_ctx(d, u, s) + (uint32_t)(cc >> 6)) & x->mask;
-        L[n++] = (p8f_ctx(d, u, s) + (uint32_t)(cc >> 3)) & x->mask;
+        L[n++] = (t->cx + (uint32_t)(cc >> 6)) & x->mask;
+        L[n++] = (t->cx + (uint32_t)(cc >> 3)) & x->mask;
       }
     }
   }
@@ -234,28 +235,35 @@ P8_HD int p8f_count(const P8FamShared* sh, int t, int a, int b) {
 }
 
 // the five inputs of a context (ContextMap::mix1's tail :1119-1143) from the cached bytes; the StateMap learns in LDS
-P8_HD void p8f_outputs(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int s) {
+P8_HD void p8f_outputs_v(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int s, int rc, int rb, int st8) {   // rc / rb: run count / byte, st8: the state in force (0: none)
   P8FamHome* r = &sh->r;
   int16_t* o = u.out + d->slot_off[s];
-  const int bp = u.bp, c0 = u.c0, rc = r->rc[s], rb = r->rb[s];
+  const int bp = u.bp, c0 = u.c0;
+  int o0 = 0;
   if ((rb + 256) >> (8 - bp) == c0) {
     const int b = ((rb >> (7 - bp)) & 1) * 2 - 1;
-    o[0] = (int16_t)(b * (sh->ilog[rc + 1] << (2 + (~rc & 1))));
-  } else o[0] = 0;
-  const int st8 = r->cpo[s] != P8F_NIL ? r->slot[s][r->cpo[s]] : 0;
+    o0 = b * (sh->ilog[rc + 1] << (2 + (~rc & 1)));
+  }
   uint16_t* smt = p8f_smrow(sh, s);
   const int sc = r->smc[s];
-  smt[sc] = (uint16_t)(smt[sc] + (((u.y << 16) - smt[sc] + 128) >> 8));
+  const int n0 = -!sh->nex[4 * st8 + 2], n1 = -!sh->nex[4 * st8 + 3];
+  const int old = smt[sc];
+  const int upd = (uint16_t)(old + (((u.y << 16) - old + 128) >> 8));
+  smt[sc] = (uint16_t)upd;
   r->smc[s] = (uint8_t)st8;
-  const int p1 = smt[st8] >> 4;
+  const int p1 = (st8 == sc ? upd : (int)smt[st8]) >> 4;
   const int st = (sh->stretch[p1] + (1 << 1)) >> 2;
+  const int dn = n1 - n0;
+  const int p0 = 4095 - p1;
+  o[0] = (int16_t)o0;
   o[1] = (int16_t)st;
   o[2] = (int16_t)((p1 - 2047 + (1 << 2)) >> 3);
-  const int n0 = -!sh->nex[4 * st8 + 2], n1 = -!sh->nex[4 * st8 + 3];
-  const int dn = n1 - n0;
   o[3] = (int16_t)(st * (dn < 0 ? -dn : dn));
-  const int p0 = 4095 - p1;
   o[4] = (int16_t)(((p1 & n0) - (p0 & n1) + (1 << 3)) >> 4);
+}
+P8_HD void p8f_outputs(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int s) {
+  const P8FamHome* r = &sh->r;
+  p8f_outputs_v(d, sh, u, s, r->rc[s], r->rb[s], r->cpo[s] != P8F_NIL ? r->slot[s][r->cpo[s]] : 0);
 }
 
 // a store to the table that also keeps the lane's cached bytes right when the address falls inside them
@@ -308,48 +316,58 @@ P8_HD void p8f_stage_bucket(uint8_t* b, const uint8_t* g) {
 
 // ---- run phase, lane-parallel: ContextMap::mix1's loop body for context s (:1072-1145) on the cached bytes.
 //      rank: number of draws of this bit before this context. ----
+// The context's registers (slot base, run bytes' address, position in the slot, run count / byte, the slot's seven bytes) are read from LDS once
+// at the top -- loads that do not depend on each other --, live in locals (the slot's bytes packed in one 64-bit value) and are written back once at
+// the end: as byte arrays in LDS every access was a round trip the compiler had to wait for before the next one (any byte store may alias).
+P8_HD int p8f_sv_get(uint64_t sv, int k) { return (int)((sv >> (8 * k)) & 0xff); }
+P8_HD uint64_t p8f_sv_set(uint64_t sv, int k, int v) { return (sv & ~((uint64_t)0xff << (8 * k))) | ((uint64_t)(v & 0xff) << (8 * k)); }
 P8_HD void p8f_run(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int s, const P8FamTmp* t, int rank) {
   P8FamHome* r = &sh->r;
   const P8CmInst* x = &d->inst[d->slot_inst[s]];
   uint8_t* T = x->table;
   const int bp = u.bp, c0 = u.c0;
-  if (r->cpo[s] != P8F_NIL) {
+  uint32_t cp0 = r->cp0[s], runp = r->runp[s];
+  int cpo = r->cpo[s], rc = r->rc[s], rb = r->rb[s];
+  uint64_t sv;
+  memcpy(&sv, __builtin_assume_aligned(r->slot[s], 8), 8);
+  if (cpo != P8F_NIL) {
     int ns = t->ns;
     if (t->draw) {
       const uint32_t v = sh->rv[(u.rnd_i + 1u + (uint32_t)rank) & (P8F_RV - 1)];
       if ((uint32_t)(v << ((452 - ns) >> 3))) ns -= 4;
     }
-    r->slot[s][r->cpo[s]] = (uint8_t)ns;
-    T[r->cp0[s] + r->cpo[s]] = (uint8_t)ns;
-    if (r->cp0[s] + r->cpo[s] == r->runp[s]) r->rc[s] = (uint8_t)ns;           // the state byte doubles as this context's run count / byte
-    if (r->cp0[s] + r->cpo[s] == r->runp[s] + 1) r->rb[s] = (uint8_t)ns;
+    sv = p8f_sv_set(sv, cpo, ns);
+    T[cp0 + (uint32_t)cpo] = (uint8_t)ns;
+    if (cp0 + (uint32_t)cpo == runp) rc = ns & 0xff;           // the state byte doubles as this context's run count / byte
+    if (cp0 + (uint32_t)cpo == runp + 1) rb = ns & 0xff;
   }
-  if (bp > 1 && r->rc[s] == 0) r->cpo[s] = P8F_NIL;
-  else if (bp == 1 || bp == 3 || bp == 6) r->cpo[s] = (uint8_t)(1 + (c0 & 1));
-  else if (bp == 4 || bp == 7) r->cpo[s] = (uint8_t)(3 + (c0 & 3));
+  if (bp > 1 && rc == 0) cpo = P8F_NIL;
+  else if (bp == 1 || bp == 3 || bp == 6) cpo = 1 + (c0 & 1);
+  else if (bp == 4 || bp == 7) cpo = 3 + (c0 & 3);
   else {
-    const uint16_t checksum = p8f_chk(d, u, s);
-    const uint32_t cx = p8f_ctx(d, u, s), nb = t->nb;
+    const uint16_t checksum = t->ck;
+    const uint32_t cx = t->cx, nb = t->nb;
     uint8_t* b = sh->bk[s];
     // the staged bucket predates this lane's own state store above: same bucket -> same byte in the copy
-    {
-      const uint32_t old = r->cp0[s] + (uint32_t)(r->cpo[s] != P8F_NIL ? r->cpo[s] : 0);
-      if (r->cpo[s] != P8F_NIL && (old >> 6) == nb) b[old & 63] = r->slot[s][r->cpo[s]];
-    }
+    if (cpo != P8F_NIL && ((cp0 + (uint32_t)cpo) >> 6) == nb) b[(cp0 + (uint32_t)cpo) & 63] = (uint8_t)p8f_sv_get(sv, cpo);
     const int idx = p8f_find_staged(T, nb, b, checksum);
     const uint32_t ncp0 = nb * 64 + P8_B_STATE + 7 * (uint32_t)idx;
-    const uint32_t old_runp = r->runp[s];
-    r->cp0[s] = ncp0; r->cpo[s] = 0;
-    for (int k = 0; k < 7; k++) r->slot[s][k] = b[P8_B_STATE + 7 * idx + k];
+    const uint32_t old_runp = runp;
+    cp0 = ncp0; cpo = 0;
+    {
+      const uint8_t* q = b + P8_B_STATE + 7 * idx;
+      const uint32_t q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6];
+      sv = (uint64_t)(q0 | q1 << 8 | q2 << 16 | q3 << 24) | ((uint64_t)(q4 | q5 << 8 | q6 << 16) << 32);
+    }
     if (bp == 0) {
       int refresh = 0;
       // run count of the PREVIOUS context (:1107-1112)
-      int rc = r->rc[s], rb = r->rb[s];
-      if ((old_runp >> 6) == nb) { rc = b[old_runp & 63]; rb = b[(old_runp + 1) & 63]; }   // the search above may have replaced the very slot that holds them
-      if (r->slot[s][3] == 2) {   // second visit: create the bit histories of bits 2-7 from the one byte seen (:1096-1106)
-        // the two buckets go through the lane's staging area (done with: the slot is in r->slot, the run bytes in rc / rb): one vector
+      int prc = rc, prb = rb;
+      if ((old_runp >> 6) == nb) { prc = b[old_runp & 63]; prb = b[(old_runp + 1) & 63]; }   // the search above may have replaced the very slot that holds them
+      if (p8f_sv_get(sv, 3) == 2) {   // second visit: create the bit histories of bits 2-7 from the one byte seen (:1096-1106)
+        // the two buckets go through the lane's staging area (done with: the slot is in sv, the run bytes in prc / prb): one vector
         // fetch and a search on LDS each, instead of a walk over table bytes one dependent load at a time
-        const int cc = r->slot[s][4] + 256;
+        const int cc = p8f_sv_get(sv, 4) + 256;
         uint32_t held = nb;
         for (int v = 0; v < 2; v++) {
           const uint32_t nb2 = (cx + (uint32_t)(v ? cc >> 3 : cc >> 6)) & x->mask;
@@ -363,24 +381,29 @@ P8_HD void p8f_run(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int s, 
           b[i1] = v1; g2[i1] = v1;
           b[i2] = v2; g2[i2] = v2;
         }
-        T[ncp0 + 6] = 0; r->slot[s][6] = 0;
+        T[ncp0 + 6] = 0; sv = p8f_sv_set(sv, 6, 0);
         refresh = 1;   // those stores may have landed on the old run bytes (same checksum in a coinciding bucket): read them back
       }
-      if (refresh) { rc = T[old_runp]; rb = T[old_runp + 1]; }
+      if (refresh) { prc = T[old_runp]; prb = T[old_runp + 1]; }
       const int c1 = u.c1;
-      if (rc == 0) { rc = 2; rb = c1; }
-      else if (rb != c1) { rc = 1; rb = c1; }
-      else if (rc < 254) rc += 2;
-      else if (rc == 255) rc = 128;
-      T[old_runp] = (uint8_t)rc; T[old_runp + 1] = (uint8_t)rb;
-      if (old_runp - ncp0 < 7u) r->slot[s][old_runp - ncp0] = (uint8_t)rc;           // the same context again: its run bytes are in the new slot
-      if (old_runp + 1 - ncp0 < 7u) r->slot[s][old_runp + 1 - ncp0] = (uint8_t)rb;
-      if (refresh) for (int k = 0; k < 7; k++) r->slot[s][k] = T[ncp0 + k];
-      r->runp[s] = ncp0 + 3;
-      r->rc[s] = r->slot[s][3]; r->rb[s] = r->slot[s][4];
+      if (prc == 0) { prc = 2; prb = c1; }
+      else if (prb != c1) { prc = 1; prb = c1; }
+      else if (prc < 254) prc += 2;
+      else if (prc == 255) prc = 128;
+      T[old_runp] = (uint8_t)prc; T[old_runp + 1] = (uint8_t)prb;
+      if (old_runp - ncp0 < 7u) sv = p8f_sv_set(sv, (int)(old_runp - ncp0), prc);           // the same context again: its run bytes are in the new slot
+      if (old_runp + 1 - ncp0 < 7u) sv = p8f_sv_set(sv, (int)(old_runp + 1 - ncp0), prb);
+      if (refresh) {
+        const uint32_t q0 = T[ncp0], q1 = T[ncp0 + 1], q2 = T[ncp0 + 2], q3 = T[ncp0 + 3], q4 = T[ncp0 + 4], q5 = T[ncp0 + 5], q6 = T[ncp0 + 6];
+        sv = (uint64_t)(q0 | q1 << 8 | q2 << 16 | q3 << 24) | ((uint64_t)(q4 | q5 << 8 | q6 << 16) << 32);
+      }
+      runp = ncp0 + 3;
+      rc = p8f_sv_get(sv, 3); rb = p8f_sv_get(sv, 4);
     }
   }
-  p8f_outputs(d, sh, u, s);
+  r->cp0[s] = cp0; r->runp[s] = runp; r->cpo[s] = (uint8_t)cpo; r->rc[s] = (uint8_t)rc; r->rb[s] = (uint8_t)rb;
+  memcpy(__builtin_assume_aligned(r->slot[s], 8), &sv, 8);
+  p8f_outputs_v(d, sh, u, s, rc, rb, cpo != P8F_NIL ? p8f_sv_get(sv, cpo) : 0);
 }
 
 // Bucket::Find for the walks: the bucket as it is in the table NOW -> the context's staging area (one vector fetch), the search on the copy

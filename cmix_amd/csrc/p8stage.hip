@@ -89,12 +89,29 @@ __global__ __launch_bounds__(P8FAM_THREADS) void cmx_p8s_fam2_kernel(P8CmDev* d,
   p8f_load(d, home, d->sm, &sh, tid, P8FAM_THREADS);
   int last_y = d->last_y, c1 = d->c1, lk = 0;
   uint32_t rnd_i = (uint32_t)d->rnd.i, prev_i = rnd_i;
+  uint32_t my_cx = 0, nx_cx = 0; uint16_t my_ck = 0, nx_ck = 0; bool have_nx = false, have_cur = false;
   __syncthreads();
   for (int t = 0; t < nbits; t++) {
     const P8FamUni u = p8f_uni(d, ctx, chk, bits, x, order, t, &last_y, &c1, &lk, rnd_i);
     if (t < skip) continue;
     P8F_TICK(0);
     P8FamTmp tmp;
+    // the context's hash / checksum of the byte: read once per byte -- the next byte's during bit 6, an ordinary bit, so that no lookup bit
+    // starts with a global round trip before it can even compute its bucket's address
+    if (sl < S) {
+      if (u.bp == 0 && have_nx) { my_cx = nx_cx; my_ck = nx_ck; }
+      else if (u.bp == 0 || !have_cur) { my_cx = p8f_ctx(d, u, sl); my_ck = p8f_chk(d, u, sl); }   // (a chunk's first byte; a stream's first step is bit 1)
+      have_cur = true;
+      if (u.bp == 0) have_nx = false;
+      tmp.cx = my_cx; tmp.ck = my_ck;
+      if (u.bp == 6 && t + 2 < nbits) {
+        const size_t nb_ = (size_t)((t >> 3) + 1) * (size_t)S;
+        const int ord_ = order ? order[t + 2] : 0;
+        nx_cx = sl == d->order_slot ? d->order_ctx[ord_] : ctx[nb_ + sl];
+        nx_ck = sl == d->order_slot ? d->order_chk[ord_] : chk[nb_ + sl];
+        have_nx = true;
+      }
+    }
     if (sl < S) p8f_phase1(d, &sh, u, sl, &tmp);
     if (rl >= 0)   // 24 lanes of one wavefront in lockstep, a group of 24 values per iteration
       for (uint32_t base = prev_i + P8F_LOOK + 1; base <= rnd_i + P8F_LOOK; base += 24) p8f_refill_group(&sh, base, rnd_i + P8F_LOOK, rl);

@@ -196,7 +196,7 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
       const P8FamUni fu = p8f_uni(d, c.fam_ctx, c.fam_chk, bits.data(), x.data(), order.data(), (int)t, &f_last_y, &f_c1, &e->f2_lk, e->f2_i);
       if (g >= 8) {
         static P8FamTmp tmp[P8CM_MAXS];
-        for (int s = SS - 1; s >= 0; s--) p8f_phase1(d, sh, fu, s, &tmp[s]);
+        for (int s = SS - 1; s >= 0; s--) { tmp[s].cx = p8f_ctx(d, fu, s); tmp[s].ck = p8f_chk(d, fu, s); p8f_phase1(d, sh, fu, s, &tmp[s]); }
         for (uint32_t base = e->f2_prev_i + P8F_LOOK + 1; base <= e->f2_i + P8F_LOOK; base += 24)
           for (int l = 23; l >= 0; l--) p8f_refill_group(sh, base, e->f2_i + P8F_LOOK, l);
         const bool look = fu.bp == 0 || fu.bp == 2 || fu.bp == 5;
