@@ -123,6 +123,7 @@ struct cmx_pipeline {
   double p8_ms = 0;
   int compact = 0;       // CMX_PIPELINE_STREAMS: 0 = one stream per stage / role, 2 and 1 = throughput modes with fewer hardware queues per engine
   bool failed = false;   // sticky: a chunk failed after its stages had begun to be enqueued (the stream's state is void)
+  int wgs = 0;           // workgroups this engine's persistent kernels keep resident (wg_claim)
   double host_ms[6] = {0, 0, 0, 0, 0, 0};   // calling thread, since the last reset: slot wait, PPMd, ctx + LSTM enqueue, fxcm (parser + enqueue), paq8 (front end + enqueue), mixing network enqueue
   Slot slot[kSlots];
   uint64_t chunks = 0;    // chunks begun
@@ -161,8 +162,34 @@ __global__ void cmx_fxcm_hints_kernel(const float* layer0, long stride, const fl
 
 extern "C" {
 
+// Co-residency: the stage kernels of a stream run for a whole chunk and hand values to each other inside the launch (bounded waits), so
+// all of their workgroups must be resident at once -- mixing network 27 (1 with CMX_MIXNET_SPEC=0), LSTM 52, contexts 1, fxcm 4, paq8 10 --
+// and most of them own a compute unit (130-160 KB of LDS). An engine that would take the device past its compute-unit count is refused at
+// construction (with the reason) instead of timing out in the middle of a stream. Process-wide per device.
+static std::mutex g_wg_mu;
+static int g_wg_used[64];
+static bool wg_claim(cmx_pipeline* h, int n, const char* what) {
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || cus <= 0) return true;   // unknown: do not guess
+  std::lock_guard<std::mutex> g(g_wg_mu);
+  int& used = g_wg_used[h->device & 63];
+  if (used + n > cus) {
+    cmx_set_err(std::string(what) + ": " + std::to_string(used) + " workgroups of persistent stage kernels are already resident on device " + std::to_string(h->device) + " and this stage needs " +
+                std::to_string(n) + " more, the device has " + std::to_string(cus) + " compute units (fewer streams per GPU, or CMX_MIXNET_SPEC=0 for the one-workgroup mixing network)");
+    return false;
+  }
+  used += n; h->wgs += n;
+  return true;
+}
+static void wg_release(cmx_pipeline* h) {
+  std::lock_guard<std::mutex> g(g_wg_mu);
+  g_wg_used[h->device & 63] -= h->wgs;
+  h->wgs = 0;
+}
+
 void cmx_pipeline_destroy(cmx_pipeline_t* h) {
   if (!h) return;
+  wg_release(h);
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
   for (Slot& s : h->slot) {
@@ -205,6 +232,10 @@ cmx_pipeline_t* cmx_pipeline_create(const uint8_t vocab[256], int device, size_t
   cmx_pipeline_t* h = new cmx_pipeline();
   h->device = device;
   h->max_chunk = max_chunk_bytes;
+  {
+    const char* sp = getenv("CMX_MIXNET_SPEC");
+    if (cmx_device_count() > 0 && !wg_claim(h, ((sp && sp[0] == '0') ? 1 : 27) + 52 + 1, "cmx_pipeline_create")) { delete h; return nullptr; }
+  }
   // every stage reports its own failure (no device, out of memory) through cmx_last_error()
   h->ctx = cmx_ctxmodels_create(vocab, device);
   h->lstm = h->ctx ? cmx_lstm_create(vocab, 31, device) : nullptr;  // 31 rand() draws precede the LSTM (indirect.cpp:10)
@@ -258,6 +289,7 @@ int cmx_pipeline_enable_fxcm(cmx_pipeline_t* h, const char* dictionary_path) {
   if (h->fxcm) return 0;
   if (h->chunks) { cmx_set_err("cmx_pipeline_enable_fxcm: only before the first chunk"); return 1; }
   if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
+  if (!wg_claim(h, 4, "cmx_pipeline_enable_fxcm")) return 1;
   cmx_fxcm_t* fx = nullptr;
   if (Prewarm* pw = prewarmed(h->device))   // built ahead of time for the same dictionary?
     if (pw->fx && pw->has_dict == (dictionary_path != nullptr) && (!dictionary_path || pw->dict == dictionary_path)) { fx = pw->fx; pw->fx = nullptr; }
@@ -298,6 +330,7 @@ int cmx_pipeline_enable_paq8(cmx_pipeline_t* h) {
   if (h->p8) return 0;
   if (h->chunks) { cmx_set_err("cmx_pipeline_enable_paq8: only before the first chunk"); return 1; }
   if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
+  if (!wg_claim(h, 10, "cmx_pipeline_enable_paq8")) return 1;
   cmx_p8stage_t* p8 = nullptr;
   if (Prewarm* pw = prewarmed(h->device)) { p8 = pw->p8; pw->p8 = nullptr; }
   if (!p8) p8 = cmx_p8stage_create(h->device);

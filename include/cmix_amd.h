@@ -259,12 +259,13 @@ void cmx_fxcm_destroy(cmx_fxcm_t*);
 int cmx_fxcm_run(cmx_fxcm_t*, const uint8_t* bytes, const uint8_t* d_bytes, size_t nbytes, const int16_t* d_lstmpr, const uint8_t* d_lstmex,
                  float* d_probs, size_t pstride, void* stream);
 int cmx_fxcm_sync(cmx_fxcm_t*);
-/* 1 if a bounded in-launch wait of the three-role kernel ran out (the stream's fxcm columns are void from there); syncs. */
+/* 1 if a bounded in-launch wait of the roles kernel (context maps on two workgroups, units, mixers: four workgroups) ran out (the stream's
+ * fxcm columns are void from there); syncs. */
 int cmx_fxcm_failed(cmx_fxcm_t*);
 const unsigned* cmx_fxcm_fail_flag(cmx_fxcm_t*);   /* as cmx_lstm_fail_flag */
 int cmx_fxcm_set_upload_stream(cmx_fxcm_t*, void* stream);   /* see cmx_mixnet_set_upload_stream */
-/* diagnostics (CMX_FXCM_PROFILE=1 at create time): clocks of lane 0 of each of the kernel's 8 wavefronts per phase
- * (1a work, 1a barrier wait, 1c, 2, 3, 4, 5, -) */
+/* diagnostics (CMX_FXCM_PROFILE=1 at create time): thread 0's clocks per phase of each role since creation, out[16 role + k] (role 0 = the
+ * context maps' first wavefront, 1 = units, 2 = mixers; scripts/gpu_fxcm_time.py names the phases) */
 int cmx_fxcm_profile(cmx_fxcm_t*, unsigned long long out128[128]);   /* [64 + 8 bpos + k]: role M by bit position */
 
 /* ---- callers of the path: arithmetic coder + container header (HOST code) -------------------------------------
@@ -322,6 +323,11 @@ int cmx_ppmd_run(cmx_ppmd_t*, const uint8_t* bytes, size_t nbytes, float* out_pr
  *   CMX_PIPELINE_STREAMS   2 or 1: throughput mode for several streams per GPU -- fewer hardware queues per engine (8 or 6;
  *                          roles take turns on shared streams, the per-stream period grows)
  *   CMX_MIXNET_SPEC=0      the one-workgroup mixing-network kernel (1 compute unit per stream instead of 27: many streams per GPU)
+ *   CMX_P8CM_SERIAL        1: paq8's table families walk every instance serially (A/B timing); 2: the ContextMap family's narrowed walk takes
+ *                          its whole-instance fall-back at every second visit (test switch)
+ * Co-residency: a stream's stage kernels run for a whole chunk and wait for each other inside the launch, so their workgroups -- 94 per
+ * stream (68 with CMX_MIXNET_SPEC=0), most of them a compute unit each -- must all be resident. cmx_pipeline_create / _enable_fxcm /
+ * _enable_paq8 keep count per device and refuse (cmx_last_error says why) an engine that would exceed the device's compute units.
  *   CMX_FXCM_PROFILE, CMX_P8FAM_PROFILE, CMX_MIXNET_DBG     in-kernel phase timers / timing experiments (scripts/gpu_*prof*) */
 #define CMX_PIPELINE_SLOTS 8   /* chunks in flight per stream (layer-0 matrices the caller cycles through) */
 /* Construction ahead of time: start building the vocabulary-independent stages of an engine for `device` -- mixing
