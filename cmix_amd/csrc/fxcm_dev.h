@@ -30,6 +30,7 @@
 #endif
 
 #define FX_NONE 0xffffffffu
+#define FX_NOKEY 0xffffffffu
 #ifdef __HIPCC__
 #define FX_CAS(p, c, v) atomicCAS((p), (c), (v))
 #else
@@ -184,14 +185,19 @@ FX_HD uint32_t fxd_bucket_get_staged(uint8_t* b, uint8_t* g, int A, uint16_t ch,
 // a bucket of the table -> its staged copy (vector loads: one round trip)
 FX_HD void fxd_stage_bucket(uint8_t* bk, const uint8_t* g, int B) {
 #ifdef __HIPCC__
+  // (one branch per bucket size, every vector a named value: an array filled under a run-time bound stays in scratch memory)
   const uint4* g4 = reinterpret_cast<const uint4*>(g);
   uint4* b4 = reinterpret_cast<uint4*>(bk);
-  const int nv = B >> 4;
-  uint4 v[8];
-#pragma unroll
-  for (int q = 0; q < 8; q++) if (q < nv) v[q] = g4[q];
-#pragma unroll
-  for (int q = 0; q < 8; q++) if (q < nv) b4[q] = v[q];
+  if (B == 128) {
+    const uint4 v0 = g4[0], v1 = g4[1], v2 = g4[2], v3 = g4[3], v4 = g4[4], v5 = g4[5], v6 = g4[6], v7 = g4[7];
+    b4[0] = v0; b4[1] = v1; b4[2] = v2; b4[3] = v3; b4[4] = v4; b4[5] = v5; b4[6] = v6; b4[7] = v7;
+  } else if (B == 64) {
+    const uint4 v0 = g4[0], v1 = g4[1], v2 = g4[2], v3 = g4[3];
+    b4[0] = v0; b4[1] = v1; b4[2] = v2; b4[3] = v3;
+  } else {
+    const uint4 v0 = g4[0], v1 = g4[1];
+    b4[0] = v0; b4[1] = v1;
+  }
 #else
   for (int q = 0; q < B; q++) bk[q] = g[q];
 #endif
@@ -414,7 +420,9 @@ FX_HD void fxd_map_touch(FxDev* d, FxShared* sh, const FxBit& u, int s, uint32_t
   const int k = d->slot_map[s], i = d->slot_idx[s];
   const FxMapDev* x = &d->maps[k];
   const int par = u.q & 1;
-  uint32_t T[5]; int n = 0;
+  // (fixed positions, FX_NOKEY = unused, loops with constant bounds: a list filled through a running index is an array in scratch memory on
+  // the device, every access a global-memory round trip)
+  uint32_t K0 = FX_NOKEY, K1 = FX_NOKEY, K2 = FX_NOKEY, K3 = FX_NOKEY, K4 = FX_NOKEY;
   if (!u.normal) return;
   if (u.boundary) sh->mcxt[k][i] = u.rec->cx[s];
   if ((u.rec->skip[s >> 5] >> (s & 31)) & 1) return;
@@ -423,34 +431,19 @@ FX_HD void fxd_map_touch(FxDev* d, FxShared* sh, const FxBit& u, int s, uint32_t
   const int bpos = u.bpos;
   const int lookbit = bpos == 0 || bpos == 2 || bpos == 5;
   if (lookbit) {   // searches read and rewrite bucket headers: contexts interact through a shared BUCKET
-    if (cp != FX_NONE) T[n++] = cp >> sh_b;
-    T[n++] = runp >> sh_b;
+    if (cp != FX_NONE) K0 = cp >> sh_b;
+    K1 = runp >> sh_b;
   } else {         // between searches a context only touches its own slot's bytes: they interact through a shared SLOT only
     const uint32_t first = (uint32_t)(2 * x->A + 1), bm = (uint32_t)x->B - 1, cur0 = sh->mcp0[k][i], run0 = runp - 3;
-    if (cp != FX_NONE) T[n++] = ((cur0 >> sh_b) << 4) | (((cur0 & bm) - first) / 7);
-    T[n++] = ((run0 >> sh_b) << 4) | (((run0 & bm) - first) / 7);
+    if (cp != FX_NONE) K0 = ((cur0 >> sh_b) << 4) | (((cur0 & bm) - first) / 7);
+    K1 = ((run0 >> sh_b) << 4) | (((run0 & bm) - first) / 7);
   }
   sh->mlook[s] = 0;
   if (!(bpos > 1 && sh->mrun[s][0] == 0) && lookbit) {
     const uint32_t nb = (cxt + (uint32_t)u.c0) & x->tmask;
-    T[n++] = nb;
+    K2 = nb;
     sh->mlook[s] = 1;
-    {   // the bucket about to be searched -> LDS
-      const uint8_t* g = x->t + (size_t)nb * (size_t)x->B;
-      uint8_t* bk = sh->mbk[s];
-#ifdef __HIPCC__
-      const uint4* g4 = reinterpret_cast<const uint4*>(g);
-      uint4* b4 = reinterpret_cast<uint4*>(bk);
-      const int nv = x->B >> 4;
-      uint4 v[8];
-#pragma unroll
-      for (int q = 0; q < 8; q++) if (q < nv) v[q] = g4[q];
-#pragma unroll
-      for (int q = 0; q < 8; q++) if (q < nv) b4[q] = v[q];
-#else
-      for (int q = 0; q < x->B; q++) bk[q] = g[q];
-#endif
-    }
+    fxd_stage_bucket(sh->mbk[s], x->t + (size_t)nb * (size_t)x->B, x->B);   // the bucket about to be searched -> LDS
     if (bpos == 0) {
       const uint8_t* b = sh->mbk[s];
       const uint16_t* chk = (const uint16_t*)b;
@@ -472,25 +465,29 @@ FX_HD void fxd_map_touch(FxDev* d, FxShared* sh, const FxBit& u, int s, uint32_t
       }
       if (slot >= 0 && b[2 * A + 1 + 7 * slot + 3] == 2) {
         const int c = b[2 * A + 1 + 7 * slot + 4] + 256;
-        T[n++] = (cxt + (uint32_t)(c >> 6)) & x->tmask;
-        T[n++] = (cxt + (uint32_t)(c >> 3)) & x->tmask;
+        K3 = (cxt + (uint32_t)(c >> 6)) & x->tmask;
+        K4 = (cxt + (uint32_t)(c >> 3)) & x->tmask;
       }
     }
   }
   // into the hash set: a key another context of the map has put there = an overlap (this lane's own repeats are dropped first)
-  for (int a = 0; a < n; a++) {
-    int dup = 0;
-    for (int c = 0; c < a; c++) dup |= T[c] == T[a];
-    if (dup) continue;
-    const uint32_t key = ((uint32_t)(k + 1) << 26) | T[a];
-    uint32_t h = ((key * 2654435761u) >> 22) & hmask;
-    for (;;) {
-      const uint32_t old = FX_CAS(&tab[h], 0u, key);
-      if (old == 0) break;
-      if (old == key) { sh->mconf[par][k] = 1; break; }
-      h = (h + 1) & hmask;
-    }
+  if (K1 == K0) K1 = FX_NOKEY;
+  if (K2 == K0 || K2 == K1) K2 = FX_NOKEY;
+  if (K3 == K0 || K3 == K1 || K3 == K2) K3 = FX_NOKEY;
+  if (K4 == K0 || K4 == K1 || K4 == K2 || K4 == K3) K4 = FX_NOKEY;
+#define FX_PUT(K)                                                                   \
+  if ((K) != FX_NOKEY) {                                                            \
+    const uint32_t key = ((uint32_t)(k + 1) << 26) | (K);                           \
+    uint32_t h = ((key * 2654435761u) >> 22) & hmask;                               \
+    for (;;) {                                                                      \
+      const uint32_t old = FX_CAS(&tab[h], 0u, key);                                \
+      if (old == 0) break;                                                          \
+      if (old == key) { sh->mconf[par][k] = 1; break; }                             \
+      h = (h + 1) & hmask;                                                          \
+    }                                                                               \
   }
+  FX_PUT(K0) FX_PUT(K1) FX_PUT(K2) FX_PUT(K3) FX_PUT(K4)
+#undef FX_PUT
 }
 // the other parity's hash set and flags are cleared for the next bit (any phase after the maps have run)
 FX_HD void fxd_map_clear_next(FxShared* sh, const FxBit& u, int tid) {

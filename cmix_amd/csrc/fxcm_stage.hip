@@ -75,13 +75,16 @@ __device__ __forceinline__ void fx_apm_prefetch(FxDev* d, const FxShared* sh, co
 // UNDER the maps' run phase; part B (after the barrier) sums the maps' return values on 8 lanes and finishes the four
 // selectors that carry ordX / ordW (:4601-4640).
 __device__ __forceinline__ void fx_fail_next(const FxShared* sh, const FxBit& u, uint32_t* fails, uint32_t* failz, uint32_t* failcount) {
-  const int e_l[8] = {1830, 1997, 1973, 1851, 1897, 1690, 1998, 1842};   // :3222
+  // e_l[bpos] (:3222) = {1830, 1997, 1973, 1851, 1897, 1690, 1998, 1842} as selects: a table indexed at run time is a load from constant memory
+  const int bp_ = u.bpos;
+  const int e_lo = bp_ & 2 ? (bp_ & 1 ? 1851 : 1973) : (bp_ & 1 ? 1997 : 1830), e_hi = bp_ & 2 ? (bp_ & 1 ? 1842 : 1998) : (bp_ & 1 ? 1690 : 1897);
+  const int e_l_bpos = bp_ & 4 ? e_hi : e_lo;
   uint32_t f = sh->fails, z = sh->failz, c = sh->failcount;
   if (f & 0x00000080) --c;
   f *= 2; z *= 2;
   int pr = sh->pr;
   if (u.y) pr = 4095 - pr;
-  if (pr >= e_l[u.bpos]) { ++f; ++c; }
+  if (pr >= e_l_bpos) { ++f; ++c; }
   if (pr >= 848) ++z;
   *fails = f; *failz = z; *failcount = c;
 }
@@ -121,9 +124,9 @@ __device__ __forceinline__ void fx_phase2a_dev(FxDev* d, FxShared* sh, const FxB
 }
 // the eight sums of the maps' return values the selectors use (lanes 0..7)
 __device__ __forceinline__ int fx_res8(const FxDev* d, const FxShared* sh, const FxBit& u, int lane) {
-  const int which[8] = {0, 1, 2, 3, 4, 5, 21, 23};
+  const int which = lane < 6 ? lane : lane == 6 ? 21 : 23;   // (arithmetic, not a table: a table indexed by the lane is a load from constant memory)
   int v = 0;
-  if (u.normal) { const FxMapDev* x = &d->maps[which[lane]]; for (int i = 0; i < x->C; i++) v += sh->slot_res[x->slot_base + i]; }
+  if (u.normal) { const FxMapDev* x = &d->maps[which]; for (int i = 0; i < x->C; i++) v += sh->slot_res[x->slot_base + i]; }
   return v;
 }
 __device__ __forceinline__ void fx_phase2b_tail(FxDev* d, FxShared* sh, const FxBit& u, const int* res8_s) {   // one lane
@@ -186,13 +189,13 @@ struct FxApmRows { uint32_t cx[6]; uint16_t row[6][34]; };
 __device__ __forceinline__ void fx_apm_ctx(const FxShared* sh, const FxBit& u, uint32_t cx[6]) {   // update1 :4792-4826
   uint32_t fails, failz, failcount;
   fx_fail_next(sh, u, &fails, &failz, &failcount);
-  const uint32_t tri[4] = {0, 4, 3, 7}, trj[4] = {0, 6, 6, 12};
+  // tri[4] = {0, 4, 3, 7}, trj[4] = {0, 6, 6, 12} as arithmetic (no table in constant memory)
   const FxByteRec* r = u.rec;
   const uint32_t c0 = (uint32_t)u.c0;
   int pz = (int)failcount + 1;
-  pz += (int)tri[(fails >> 5) & 3];
-  pz += (int)trj[(fails >> 3) & 3];
-  pz += (int)trj[(fails >> 1) & 3];
+  { const uint32_t a = (fails >> 5) & 3; pz += (int)((a & 1) * 4 + (a >> 1) * 3); }
+  { const uint32_t a = (fails >> 3) & 3; pz += (int)(((a & 1) + (a >> 1)) * 6); }
+  { const uint32_t a = (fails >> 1) & 3; pz += (int)(((a & 1) + (a >> 1)) * 6); }
   if (fails & 1) pz += 8;
   pz = pz / 2;
   cx[0] = c0;
@@ -205,13 +208,14 @@ __device__ __forceinline__ void fx_apm_ctx(const FxShared* sh, const FxBit& u, u
 __device__ __forceinline__ void fx_apm_prefetch(FxDev* d, const FxShared* sh, const FxBit& u, FxApmRows* A, int j) {   // after this lane's fxd_apm_update
   uint32_t cx[6];
   fx_apm_ctx(sh, u, cx);
-  const uint16_t* p = d->apm_t[j] + (size_t)cx[j] * 33;
+  const uint32_t cxj = j == 0 ? cx[0] : j == 1 ? cx[1] : j == 2 ? cx[2] : j == 3 ? cx[3] : j == 4 ? cx[4] : cx[5];   // (selects: cx[j] would put the array in scratch memory)
+  const uint16_t* p = d->apm_t[j] + (size_t)cxj * 33;
   uint16_t v[33];
 #pragma unroll
   for (int q = 0; q < 33; q++) v[q] = p[q];
 #pragma unroll
   for (int q = 0; q < 33; q++) A->row[j][q] = v[q];
-  A->cx[j] = cx[j];
+  A->cx[j] = cxj;
 }
 __device__ __forceinline__ int fx_apm_row_p(const FxDev* d, FxShared* sh, const FxApmRows* A, int j, int pr) {   // fxd_apm_p on the fetched row
   pr = d->stretch[pr];
@@ -407,8 +411,8 @@ __global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_roles_kernel(FxDev* g
       uint32_t* const ht[2] = {sh.ohash[0] + 128 * wave, sh.ohash[1] + 128 * wave};
       FxByteRec* const wrec = reinterpret_cast<FxByteRec*>(&sh.part[0][0]) + 2 * wave;   // [2]: the record in force and the next one
       static_assert(sizeof(FxByteRec) * 16 <= sizeof(sh.part), "per-wavefront record copies do not fit");
-      const int which8[8] = {0, 1, 2, 3, 4, 5, 21, 23};
-      const bool res_lane = lane < 8 && which8[lane & 7] >= k0 && which8[lane & 7] < k1;
+      const int which8 = (lane & 7) < 6 ? (lane & 7) : (lane & 7) == 6 ? 21 : 23;
+      const bool res_lane = lane < 8 && which8 >= k0 && which8 < k1;
       uint32_t bv = 0;
       int prev_byte = lastbyte0;
       for (int q = 0; q < nbits; q++) {

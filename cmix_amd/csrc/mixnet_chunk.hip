@@ -632,27 +632,29 @@ __device__ void chain_role(MixState* S, const Lds& L, const float* decay1, int n
 // 3+3 interpolation cells and 4+3 mixer weights are all loaded up front and selected afterwards.
 // The single layer-2 row lives in LDS for the whole chunk. The SSE context registers (sse.cpp:222-240)
 // stay in registers. What remains serial per bit is arithmetic plus the t_st/t_sq lookups (L1/L2 hits).
-struct U16x8 { unsigned w[4]; };
+struct U16x8 { unsigned w0, w1, w2, w3; };   // (named words: as an array the cell went through scratch memory)
 __device__ __forceinline__ U16x8 load_cell(const uint16_t* p) {
   typedef unsigned v4u __attribute__((ext_vector_type(4)));
   v4u v = *(gptr<const v4u>)as_global(p);
-  U16x8 r; r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
+  U16x8 r; r.w0 = v.x; r.w1 = v.y; r.w2 = v.z; r.w3 = v.w;
   return r;
 }
 __device__ __forceinline__ void store_cell_async(uint16_t* p, const U16x8& c) {
   typedef unsigned v4u __attribute__((ext_vector_type(4)));
-  v4u o = {c.w[0], c.w[1], c.w[2], c.w[3]};
+  v4u o = {c.w0, c.w1, c.w2, c.w3};
   asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(as_global(p)), "v"(o) : "memory");
 }
 __device__ __forceinline__ int cell_get(const U16x8& c, int i) {  // entry i of 8 u16
-  unsigned w = i < 2 ? c.w[0] : i < 4 ? c.w[1] : i < 6 ? c.w[2] : c.w[3];
+  unsigned w = i < 2 ? c.w0 : i < 4 ? c.w1 : i < 6 ? c.w2 : c.w3;
   return (int)((i & 1) ? (w >> 16) : (w & 0xffffu));
 }
 __device__ __forceinline__ void cell_set(U16x8& c, int i, int v) {
   const unsigned m = (i & 1) ? 0x0000ffffu : 0xffff0000u, x = ((unsigned)v & 0xffffu) << ((i & 1) * 16);
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-    if ((i >> 1) == q) c.w[q] = (c.w[q] & m) | x;
+  const int q = i >> 1;
+  c.w0 = q == 0 ? (c.w0 & m) | x : c.w0;
+  c.w1 = q == 1 ? (c.w1 & m) | x : c.w1;
+  c.w2 = q == 2 ? (c.w2 & m) | x : c.w2;
+  c.w3 = q == 3 ? (c.w3 & m) | x : c.w3;
 }
 __device__ __forceinline__ unsigned bcast_u(unsigned v) { return (unsigned)__builtin_amdgcn_readlane((int)v, 0); }
 template <class T> __device__ __forceinline__ T pick3(int a, T x0, T x1, T x2) { return a == 0 ? x0 : a == 1 ? x1 : x2; }

@@ -22,6 +22,7 @@
 #include "p8cm_dev.h"
 
 enum { P8F_HASH = 2048, P8F_RV = 512, P8F_NIL = 0xFF, P8F_LOOK = 256, P8F_KMAX = 16 };
+#define P8F_NOKEY 0xFFFFFFFFu
 
 #ifdef __HIPCC__
 #define P8F_CAS(p, c, v) atomicCAS((p), (c), (v))
@@ -147,14 +148,16 @@ P8_HD void p8f_phase1(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int 
   if (s < 8) sh->db[(u.t + 1) % 3][s] = 0;
   const int bp = u.bp;
   if (!(bp == 0 || bp == 2 || bp == 5)) return;
-  // touched buckets: the old slot's, the run bytes', the one about to be searched, and at a byte boundary the two a second visit creates histories in
-  uint32_t L[5]; int n = 0;
-  if (r->cpo[s] != P8F_NIL) L[n++] = r->cp0[s] >> 6;
-  L[n++] = r->runp[s] >> 6;
+  // touched buckets: the old slot's, the run bytes', the one about to be searched, and at a byte boundary the two a second visit creates histories in.
+  // Fixed positions (P8F_NOKEY = unused), every loop over them with constant bounds: a list filled through a running index is an array in
+  // scratch memory on the device, and every access to it a global-memory round trip.
+  uint32_t K0 = P8F_NOKEY, K1, K2 = P8F_NOKEY, K3 = P8F_NOKEY, K4 = P8F_NOKEY;
+  if (r->cpo[s] != P8F_NIL) K0 = r->cp0[s] >> 6;
+  K1 = r->runp[s] >> 6;
   if (!(bp > 1 && r->rc[s] == 0)) {
     t->look = 1;
     t->nb = (t->cx + (uint32_t)u.c0) & x->mask;
-    L[n++] = t->nb;
+    K2 = t->nb;
     const uint8_t* g = x->table + (size_t)t->nb * 64;
     uint8_t* b = sh->bk[s];
 #ifdef __HIPCC__
@@ -185,23 +188,31 @@ P8_HD void p8f_phase1(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int 
       }
       if (slot >= 0 && b[P8_B_STATE + 7 * slot + 3] == 2) {
         const int cc = b[P8_B_STATE + 7 * slot + 4] + 256;
-        L[n++] = (t->cx + (uint32_t)(cc >> 6)) & x->mask;
-        L[n++] = (t->cx + (uint32_t)(cc >> 3)) & x->mask;
+        K3 = (t->cx + (uint32_t)(cc >> 6)) & x->mask;
+        K4 = (t->cx + (uint32_t)(cc >> 3)) & x->mask;
       }
     }
   }
-  for (int a = 0; a < n; a++) {
-    int dup = 0;
-    for (int c = 0; c < a; c++) dup |= L[c] == L[a];
-    if (!dup) p8f_insert(sh, u.lk, inst, L[a]);
-  }
-  t->nk = n;
-  for (int a = 0; a < 5; a++) t->L[a] = a < n ? L[a] : 0;
+  if (K1 == K0) K1 = P8F_NOKEY;                                   // a context's own repeats are dropped
+  if (K2 == K0 || K2 == K1) K2 = P8F_NOKEY;
+  if (K3 == K0 || K3 == K1 || K3 == K2) K3 = P8F_NOKEY;
+  if (K4 == K0 || K4 == K1 || K4 == K2 || K4 == K3) K4 = P8F_NOKEY;
+  if (K0 != P8F_NOKEY) p8f_insert(sh, u.lk, inst, K0);
+  if (K1 != P8F_NOKEY) p8f_insert(sh, u.lk, inst, K1);
+  if (K2 != P8F_NOKEY) p8f_insert(sh, u.lk, inst, K2);
+  if (K3 != P8F_NOKEY) p8f_insert(sh, u.lk, inst, K3);
+  if (K4 != P8F_NOKEY) p8f_insert(sh, u.lk, inst, K4);
+  t->nk = 5;
+  t->L[0] = K0; t->L[1] = K1; t->L[2] = K2; t->L[3] = K3; t->L[4] = K4;
 }
 // after the barrier of a lookup bit: does another context of the instance hold one of this context's keys?
 P8_HD int p8f_marked(const P8FamShared* sh, int lk, int inst, const P8FamTmp* t) {
   const uint32_t* tab = sh->hash[lk & 1];
-  for (int a = 0; a < t->nk; a++) {
+#ifdef __HIPCC__
+#pragma unroll
+#endif
+  for (int a = 0; a < 5; a++) {
+    if (a >= t->nk || t->L[a] == P8F_NOKEY) continue;
     const uint32_t key = ((uint32_t)(inst + 1) << 26) | t->L[a];
     uint32_t h = (key * 2654435761u) >> 21;
     for (int guard = 0; guard < P8F_HASH; guard++) {
