@@ -616,4 +616,31 @@ P8_HD P8FamUni p8f_uni(const P8CmDev* d, const uint32_t* ctx, const uint16_t* ch
   if (bp == 7) *c1 = (c0 * 2 + bits_in[t]) & 0xff;
   return u;
 }
+// The same values with the running state kept by the caller: the partial byte c0 grows by one bit per step and the byte's eight coded bits and its
+// order value are read once, at its first step (nine loads that do not depend on each other) -- p8f_uni re-reads up to seven bits and the order
+// value from global memory at EVERY step, ~2 k clocks of the family kernel's 17 k per bit. Chunks are whole bytes: bits_in[t .. t + 7] exist.
+struct P8FamRun { int last_y, c1, lk, c0; uint32_t bits8; int order; };
+P8_HD P8FamUni p8f_uni_inc(const P8CmDev* d, const uint32_t* ctx, const uint16_t* chk, const uint8_t* bits_in, int16_t* out, const uint8_t* order, int t, P8FamRun* st,
+                           uint32_t rnd_i) {
+  P8FamUni u;
+  const int bp = t & 7, nslots = d->nslots;
+  if (bp == 0) {
+    const uint32_t b0 = bits_in[t], b1 = bits_in[t + 1], b2 = bits_in[t + 2], b3 = bits_in[t + 3], b4 = bits_in[t + 4], b5 = bits_in[t + 5], b6 = bits_in[t + 6], b7 = bits_in[t + 7];
+    st->order = order ? order[t] : 0;
+    st->bits8 = (b0 & 1) | (b1 & 1) << 1 | (b2 & 1) << 2 | (b3 & 1) << 3 | (b4 & 1) << 4 | (b5 & 1) << 5 | (b6 & 1) << 6 | (b7 & 1) << 7;
+    st->c0 = 1;
+  }
+  u.y = st->last_y; u.bp = bp; u.c0 = st->c0; u.c1 = st->c1; u.t = t; u.rnd_i = rnd_i;
+  u.order = st->order;
+  u.ctx = ctx + (size_t)(t >> 3) * (size_t)nslots;
+  u.chk = chk + (size_t)(t >> 3) * (size_t)nslots;
+  u.out = out + (size_t)t * (size_t)d->row_stride;
+  if (bp == 0 || bp == 2 || bp == 5) ++st->lk;
+  u.lk = st->lk;
+  const int bit = (int)((st->bits8 >> bp) & 1u);
+  st->last_y = bit;
+  if (bp == 7) st->c1 = (st->c0 * 2 + bit) & 0xff;
+  st->c0 = st->c0 * 2 + bit;
+  return u;
+}
 #endif

@@ -87,12 +87,13 @@ __global__ __launch_bounds__(P8FAM_THREADS) void cmx_p8s_fam2_kernel(P8CmDev* d,
 #define P8F_TICK(k) do { if (prof && tid == 0) { const unsigned long long c_ = __builtin_readcyclecounter(); __hip_atomic_fetch_add(&prof[8 * u.bp + (k)], c_ - pc0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pc0 = c_; } } while (0)
 #define P8F_COUNT(i, v) do { if (prof && tid == 0) __hip_atomic_fetch_add(&prof[(i)], (unsigned long long)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
   p8f_load(d, home, d->sm, &sh, tid, P8FAM_THREADS);
-  int last_y = d->last_y, c1 = d->c1, lk = 0;
+  P8FamRun frun; frun.last_y = d->last_y; frun.c1 = d->c1; frun.lk = 0; frun.c0 = 1; frun.bits8 = 0; frun.order = 0;
   uint32_t rnd_i = (uint32_t)d->rnd.i, prev_i = rnd_i;
   uint32_t my_cx = 0, nx_cx = 0; uint16_t my_ck = 0, nx_ck = 0; bool have_nx = false, have_cur = false;
   __syncthreads();
   for (int t = 0; t < nbits; t++) {
-    const P8FamUni u = p8f_uni(d, ctx, chk, bits, x, order, t, &last_y, &c1, &lk, rnd_i);
+    const P8FamUni u = p8f_uni_inc(d, ctx, chk, bits, x, order, t, &frun, rnd_i);
+    const int lk = frun.lk;
     if (t < skip) continue;
     P8F_TICK(0);
     P8FamTmp tmp;
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(P8FAM_THREADS) void cmx_p8s_fam2_kernel(P8CmDev* d,
 #undef P8F_COUNT
   __syncthreads();
   p8f_store(d, home, d->sm, &sh, rnd_i, tid, P8FAM_THREADS);
-  if (tid == 0) { d->last_y = last_y; d->c1 = c1; }
+  if (tid == 0) { d->last_y = frun.last_y; d->c1 = frun.c1; }
 }
 
 // t0: 1 for the chunk that starts the stream (there is no step 0), else 0

@@ -131,6 +131,7 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
   P8StageState& S = e->S;
   // per-family uniform registers, carried between calls
   int f_last_y = S.fam.last_y, f_c1 = S.fam.c1;
+  P8FamRun f_run; f_run.last_y = S.fam.last_y; f_run.c1 = S.fam.c1; f_run.lk = 0; f_run.c0 = 1; f_run.bits8 = 0; f_run.order = 0;   // as cmx_p8s_fam2_kernel starts a chunk
   uint32_t run_bits[P8_NCM2]; int c_last_y[P8_NCM2];
   for (int k = 0; k < P8_NCM2; k++) { run_bits[k] = S.cm2[k].bits; c_last_y[k] = S.cm2[k].last_y; }
   if (!e->use_v1)
@@ -193,7 +194,7 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
       P8CmDev* d = &S.fam;
       P8FamShared* sh = e->f2;
       const int SS = d->nslots;
-      const P8FamUni fu = p8f_uni(d, c.fam_ctx, c.fam_chk, bits.data(), x.data(), order.data(), (int)t, &f_last_y, &f_c1, &e->f2_lk, e->f2_i);
+      const P8FamUni fu = p8f_uni_inc(d, c.fam_ctx, c.fam_chk, bits.data(), x.data(), order.data(), (int)t, &f_run, e->f2_i);
       if (g >= 8) {
         static P8FamTmp tmp[P8CM_MAXS];
         for (int s = SS - 1; s >= 0; s--) { tmp[s].cx = p8f_ctx(d, fu, s); tmp[s].ck = p8f_chk(d, fu, s); p8f_phase1(d, sh, fu, s, &tmp[s]); }
@@ -311,6 +312,7 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
     for (int i = 0; i < P8_NSEL; i++) train(xs, S.mix.wx + (size_t)row[i] * P8_NX, npad, ((yb << 12) - pr[i]) * 7);
     train(st, S.mix.wx2, 32, ((yb << 12) - p2) * 7);
   }
+  if (!e->use_v1) { f_last_y = f_run.last_y; f_c1 = f_run.c1; }
   S.fam.last_y = f_last_y; S.fam.c1 = f_c1;
   if (!e->use_v1) for (int tid = 0; tid < 256; tid++) p8f_store(&S.fam, S.fam_home, S.fam.sm, e->f2, e->f2_i, tid, 256);
   for (int k = 0; k < P8_NCM2; k++) { S.cm2[k].bits = run_bits[k]; S.cm2[k].last_y = c_last_y[k]; if (!e->use_v1) S.cm2[k].regs = e->c2[k]->base.r; }
