@@ -67,7 +67,8 @@ struct P8FamShared {
   uint16_t sm[1];                   // [nslots][256] u16 StateMaps follow (dynamic LDS)
 };
 // per lane, per bit scratch: registers on the device, an array on the host
-struct P8FamTmp { int ns, draw, look; uint32_t nb; uint32_t L[5]; int nk; uint32_t cx; uint16_t ck; };   // cx / ck: the context's hash and checksum of this byte (filled in by the caller: p8f_ctx / p8f_chk, read once per byte)   // L / nk: the buckets the context touches at a lookup bit
+struct P8FamTmp { int ns, draw, look; uint32_t nb; uint32_t L[5]; int nk; uint32_t cx; uint16_t ck;
+                  uint8_t* tab; uint32_t mask; int inst, off; };   // tab / mask / inst / off: the context's table, bucket mask, instance and output offset (p8f_lane: once per chunk -- P8CmDev is global memory)   // cx / ck: the context's hash and checksum of this byte (filled in by the caller: p8f_ctx / p8f_chk, read once per byte)   // L / nk: the buckets the context touches at a lookup bit
 struct P8FamUni { int y, bp, c0, c1, order, lk; uint32_t rnd_i; const uint32_t* ctx; const uint16_t* chk; int16_t* out; int t; };
 
 P8_HD uint16_t* p8f_smrow(P8FamShared* sh, int s) { return sh->sm + (size_t)s * 256; }
@@ -118,6 +119,11 @@ P8_HD void p8f_refill_group(P8FamShared* sh, uint32_t base, uint32_t hi, int lan
   if (idx <= hi) sh->rv[idx & (P8F_RV - 1)] = sh->rv[(idx - 24) & (P8F_RV - 1)] ^ sh->rv[(idx - 55) & (P8F_RV - 1)];
 }
 
+P8_HD void p8f_lane(const P8CmDev* d, int s, P8FamTmp* t) {
+  t->inst = d->slot_inst[s];
+  t->tab = d->inst[t->inst].table; t->mask = d->inst[t->inst].mask;
+  t->off = d->slot_off[s];
+}
 // ---- phase 1 (every bit): the state update's outcome and whether it draws; at a lookup bit also the touched buckets into
 //      the hash set and the bucket about to be searched into LDS ----
 P8_HD void p8f_insert(P8FamShared* sh, int lk, int inst, uint32_t bucket) {
@@ -137,8 +143,8 @@ P8_HD void p8f_insert(P8FamShared* sh, int lk, int inst, uint32_t bucket) {
 }
 P8_HD void p8f_phase1(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int s, P8FamTmp* t) {
   P8FamHome* r = &sh->r;
-  const int inst = d->slot_inst[s];
-  const P8CmInst* x = &d->inst[inst];
+  const int inst = t->inst;
+  const uint32_t xmask = t->mask;
   t->ns = 0; t->draw = 0; t->look = 0; t->nb = 0; t->nk = 0;
   if (r->cpo[s] != P8F_NIL) {
     t->ns = sh->nex[4 * r->slot[s][r->cpo[s]] + u.y];
@@ -156,9 +162,9 @@ P8_HD void p8f_phase1(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int 
   K1 = r->runp[s] >> 6;
   if (!(bp > 1 && r->rc[s] == 0)) {
     t->look = 1;
-    t->nb = (t->cx + (uint32_t)u.c0) & x->mask;
+    t->nb = (t->cx + (uint32_t)u.c0) & xmask;
     K2 = t->nb;
-    const uint8_t* g = x->table + (size_t)t->nb * 64;
+    const uint8_t* g = t->tab + (size_t)t->nb * 64;
     uint8_t* b = sh->bk[s];
 #ifdef __HIPCC__
     const uint4* g4 = reinterpret_cast<const uint4*>(g);
@@ -188,8 +194,8 @@ P8_HD void p8f_phase1(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int 
       }
       if (slot >= 0 && b[P8_B_STATE + 7 * slot + 3] == 2) {
         const int cc = b[P8_B_STATE + 7 * slot + 4] + 256;
-        K3 = (t->cx + (uint32_t)(cc >> 6)) & x->mask;
-        K4 = (t->cx + (uint32_t)(cc >> 3)) & x->mask;
+        K3 = (t->cx + (uint32_t)(cc >> 6)) & xmask;
+        K4 = (t->cx + (uint32_t)(cc >> 3)) & xmask;
       }
     }
   }
@@ -246,9 +252,9 @@ P8_HD int p8f_count(const P8FamShared* sh, int t, int a, int b) {
 }
 
 // the five inputs of a context (ContextMap::mix1's tail :1119-1143) from the cached bytes; the StateMap learns in LDS
-P8_HD void p8f_outputs_v(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int s, int rc, int rb, int st8) {   // rc / rb: run count / byte, st8: the state in force (0: none)
+P8_HD void p8f_outputs_v(P8FamShared* sh, const P8FamUni& u, int s, int off, int rc, int rb, int st8) {   // off: the context's place in the row; rc / rb: run count / byte, st8: the state in force (0: none)
   P8FamHome* r = &sh->r;
-  int16_t* o = u.out + d->slot_off[s];
+  int16_t* o = u.out + off;
   const int bp = u.bp, c0 = u.c0;
   int o0 = 0;
   if ((rb + 256) >> (8 - bp) == c0) {
@@ -274,7 +280,7 @@ P8_HD void p8f_outputs_v(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, i
 }
 P8_HD void p8f_outputs(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int s) {
   const P8FamHome* r = &sh->r;
-  p8f_outputs_v(d, sh, u, s, r->rc[s], r->rb[s], r->cpo[s] != P8F_NIL ? r->slot[s][r->cpo[s]] : 0);
+  p8f_outputs_v(sh, u, s, d->slot_off[s], r->rc[s], r->rb[s], r->cpo[s] != P8F_NIL ? r->slot[s][r->cpo[s]] : 0);
 }
 
 // a store to the table that also keeps the lane's cached bytes right when the address falls inside them
@@ -334,8 +340,8 @@ P8_HD int p8f_sv_get(uint64_t sv, int k) { return (int)((sv >> (8 * k)) & 0xff);
 P8_HD uint64_t p8f_sv_set(uint64_t sv, int k, int v) { return (sv & ~((uint64_t)0xff << (8 * k))) | ((uint64_t)(v & 0xff) << (8 * k)); }
 P8_HD void p8f_run(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int s, const P8FamTmp* t, int rank) {
   P8FamHome* r = &sh->r;
-  const P8CmInst* x = &d->inst[d->slot_inst[s]];
-  uint8_t* T = x->table;
+  uint8_t* T = t->tab;
+  const uint32_t xmask = t->mask;
   const int bp = u.bp, c0 = u.c0;
   uint32_t cp0 = r->cp0[s], runp = r->runp[s];
   int cpo = r->cpo[s], rc = r->rc[s], rb = r->rb[s];
@@ -381,7 +387,7 @@ P8_HD void p8f_run(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int s, 
         const int cc = p8f_sv_get(sv, 4) + 256;
         uint32_t held = nb;
         for (int v = 0; v < 2; v++) {
-          const uint32_t nb2 = (cx + (uint32_t)(v ? cc >> 3 : cc >> 6)) & x->mask;
+          const uint32_t nb2 = (cx + (uint32_t)(v ? cc >> 3 : cc >> 6)) & xmask;
           if (nb2 != held) { p8f_stage_bucket(b, T + (size_t)nb2 * 64); held = nb2; }
           const uint32_t o = (uint32_t)(P8_B_STATE + 7 * p8f_find_staged(T, nb2, b, checksum));
           uint8_t* g2 = T + (size_t)nb2 * 64;
@@ -414,7 +420,7 @@ P8_HD void p8f_run(const P8CmDev* d, P8FamShared* sh, const P8FamUni& u, int s, 
   }
   r->cp0[s] = cp0; r->runp[s] = runp; r->cpo[s] = (uint8_t)cpo; r->rc[s] = (uint8_t)rc; r->rb[s] = (uint8_t)rb;
   memcpy(__builtin_assume_aligned(r->slot[s], 8), &sv, 8);
-  p8f_outputs_v(d, sh, u, s, rc, rb, cpo != P8F_NIL ? p8f_sv_get(sv, cpo) : 0);
+  p8f_outputs_v(sh, u, s, t->off, rc, rb, cpo != P8F_NIL ? p8f_sv_get(sv, cpo) : 0);
 }
 
 // Bucket::Find for the walks: the bucket as it is in the table NOW -> the context's staging area (one vector fetch), the search on the copy
@@ -619,11 +625,12 @@ P8_HD P8FamUni p8f_uni(const P8CmDev* d, const uint32_t* ctx, const uint16_t* ch
 // The same values with the running state kept by the caller: the partial byte c0 grows by one bit per step and the byte's eight coded bits and its
 // order value are read once, at its first step (nine loads that do not depend on each other) -- p8f_uni re-reads up to seven bits and the order
 // value from global memory at EVERY step, ~2 k clocks of the family kernel's 17 k per bit. Chunks are whole bytes: bits_in[t .. t + 7] exist.
-struct P8FamRun { int last_y, c1, lk, c0; uint32_t bits8; int order; };
+struct P8FamRun { int last_y, c1, lk, c0; uint32_t bits8; int order, nslots, row_stride; };   // nslots / row_stride: d's, read once
 P8_HD P8FamUni p8f_uni_inc(const P8CmDev* d, const uint32_t* ctx, const uint16_t* chk, const uint8_t* bits_in, int16_t* out, const uint8_t* order, int t, P8FamRun* st,
                            uint32_t rnd_i) {
   P8FamUni u;
-  const int bp = t & 7, nslots = d->nslots;
+  const int bp = t & 7, nslots = st->nslots;
+  (void)d;
   if (bp == 0) {
     const uint32_t b0 = bits_in[t], b1 = bits_in[t + 1], b2 = bits_in[t + 2], b3 = bits_in[t + 3], b4 = bits_in[t + 4], b5 = bits_in[t + 5], b6 = bits_in[t + 6], b7 = bits_in[t + 7];
     st->order = order ? order[t] : 0;
@@ -634,7 +641,7 @@ P8_HD P8FamUni p8f_uni_inc(const P8CmDev* d, const uint32_t* ctx, const uint16_t
   u.order = st->order;
   u.ctx = ctx + (size_t)(t >> 3) * (size_t)nslots;
   u.chk = chk + (size_t)(t >> 3) * (size_t)nslots;
-  u.out = out + (size_t)t * (size_t)d->row_stride;
+  u.out = out + (size_t)t * (size_t)st->row_stride;
   if (bp == 0 || bp == 2 || bp == 5) ++st->lk;
   u.lk = st->lk;
   const int bit = (int)((st->bits8 >> bp) & 1u);

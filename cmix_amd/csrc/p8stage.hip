@@ -87,7 +87,11 @@ __global__ __launch_bounds__(P8FAM_THREADS) void cmx_p8s_fam2_kernel(P8CmDev* d,
 #define P8F_TICK(k) do { if (prof && tid == 0) { const unsigned long long c_ = __builtin_readcyclecounter(); __hip_atomic_fetch_add(&prof[8 * u.bp + (k)], c_ - pc0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pc0 = c_; } } while (0)
 #define P8F_COUNT(i, v) do { if (prof && tid == 0) __hip_atomic_fetch_add(&prof[(i)], (unsigned long long)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
   p8f_load(d, home, d->sm, &sh, tid, P8FAM_THREADS);
-  P8FamRun frun; frun.last_y = d->last_y; frun.c1 = d->c1; frun.lk = 0; frun.c0 = 1; frun.bits8 = 0; frun.order = 0;
+  P8FamRun frun; frun.last_y = d->last_y; frun.c1 = d->c1; frun.lk = 0; frun.c0 = 1; frun.bits8 = 0; frun.order = 0; frun.nslots = d->nslots; frun.row_stride = d->row_stride;
+  P8FamTmp tmp;   // (its per-context constants are filled once)
+  tmp.tab = nullptr; tmp.mask = 0; tmp.inst = 0; tmp.off = 0;
+  if (sl < S) p8f_lane(d, sl, &tmp);
+  const int order_slot = d->order_slot;
   uint32_t rnd_i = (uint32_t)d->rnd.i, prev_i = rnd_i;
   uint32_t my_cx = 0, nx_cx = 0; uint16_t my_ck = 0, nx_ck = 0; bool have_nx = false, have_cur = false;
   __syncthreads();
@@ -96,7 +100,6 @@ __global__ __launch_bounds__(P8FAM_THREADS) void cmx_p8s_fam2_kernel(P8CmDev* d,
     const int lk = frun.lk;
     if (t < skip) continue;
     P8F_TICK(0);
-    P8FamTmp tmp;
     // the context's hash / checksum of the byte: read once per byte -- the next byte's during bit 6, an ordinary bit, so that no lookup bit
     // starts with a global round trip before it can even compute its bucket's address
     if (sl < S) {
@@ -108,8 +111,8 @@ __global__ __launch_bounds__(P8FAM_THREADS) void cmx_p8s_fam2_kernel(P8CmDev* d,
       if (u.bp == 6 && t + 2 < nbits) {
         const size_t nb_ = (size_t)((t >> 3) + 1) * (size_t)S;
         const int ord_ = order ? order[t + 2] : 0;
-        nx_cx = sl == d->order_slot ? d->order_ctx[ord_] : ctx[nb_ + sl];
-        nx_ck = sl == d->order_slot ? d->order_chk[ord_] : chk[nb_ + sl];
+        nx_cx = sl == order_slot ? d->order_ctx[ord_] : ctx[nb_ + sl];
+        nx_ck = sl == order_slot ? d->order_chk[ord_] : chk[nb_ + sl];
         have_nx = true;
       }
     }
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(P8FAM_THREADS) void cmx_p8s_fam2_kernel(P8CmDev* d,
         __syncthreads();
       }
       if (sl < S) {
-        const int k = d->slot_inst[sl];
+        const int k = tmp.inst;
         const bool walked = (look && sh.conflict[lk & 1][k]) || sh.shared[k] || all_serial;
         if (walked && (sh.wfull[k] || sh.ink[sl] == 2)) p8f_reload(d, &sh, sl);
         else p8f_run(d, &sh, u, sl, &tmp, p8f_count(&sh, t, 0, sl));

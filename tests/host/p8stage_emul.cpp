@@ -131,7 +131,7 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
   P8StageState& S = e->S;
   // per-family uniform registers, carried between calls
   int f_last_y = S.fam.last_y, f_c1 = S.fam.c1;
-  P8FamRun f_run; f_run.last_y = S.fam.last_y; f_run.c1 = S.fam.c1; f_run.lk = 0; f_run.c0 = 1; f_run.bits8 = 0; f_run.order = 0;   // as cmx_p8s_fam2_kernel starts a chunk
+  P8FamRun f_run; f_run.last_y = S.fam.last_y; f_run.c1 = S.fam.c1; f_run.lk = 0; f_run.c0 = 1; f_run.bits8 = 0; f_run.order = 0; f_run.nslots = S.fam.nslots; f_run.row_stride = S.fam.row_stride;   // as cmx_p8s_fam2_kernel starts a chunk
   uint32_t run_bits[P8_NCM2]; int c_last_y[P8_NCM2];
   for (int k = 0; k < P8_NCM2; k++) { run_bits[k] = S.cm2[k].bits; c_last_y[k] = S.cm2[k].last_y; }
   if (!e->use_v1)
@@ -197,7 +197,7 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
       const P8FamUni fu = p8f_uni_inc(d, c.fam_ctx, c.fam_chk, bits.data(), x.data(), order.data(), (int)t, &f_run, e->f2_i);
       if (g >= 8) {
         static P8FamTmp tmp[P8CM_MAXS];
-        for (int s = SS - 1; s >= 0; s--) { tmp[s].cx = p8f_ctx(d, fu, s); tmp[s].ck = p8f_chk(d, fu, s); p8f_phase1(d, sh, fu, s, &tmp[s]); }
+        for (int s = SS - 1; s >= 0; s--) { p8f_lane(d, s, &tmp[s]); tmp[s].cx = p8f_ctx(d, fu, s); tmp[s].ck = p8f_chk(d, fu, s); p8f_phase1(d, sh, fu, s, &tmp[s]); }
         for (uint32_t base = e->f2_prev_i + P8F_LOOK + 1; base <= e->f2_i + P8F_LOOK; base += 24)
           for (int l = 23; l >= 0; l--) p8f_refill_group(sh, base, e->f2_i + P8F_LOOK, l);
         const bool look = fu.bp == 0 || fu.bp == 2 || fu.bp == 5;
