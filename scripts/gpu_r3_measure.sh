@@ -38,4 +38,7 @@ for k, v in out.items():
         print(k, {c: (round(x["sum"] / 1e3, 1), x["launches"]) for c, x in v.items()})
 PY
 python scripts/gpu_prof.py 4096 2>&1 | grep -v amdgpu.ids > $O/mixnet_phases.txt; head -12 $O/mixnet_phases.txt
+CMX_MIXNET_DBG=4 python scripts/gpu_prof.py 4096 2>&1 | grep -v amdgpu.ids > $O/mixnet_phases_tail.txt
+CMX_FXCM_PROFILE=1 timeout 300 python scripts/gpu_fxcm_time.py 16 2>&1 | grep -v amdgpu.ids | tee $O/fxcm_roles_phases.txt
+CMX_P8FAM_PROFILE=1 timeout 300 python scripts/gpu_p8stage_time.py 16 2>&1 | grep -v amdgpu.ids | tee $O/p8_fam_phases.txt
 timeout 200 python scripts/gpu_create_time.py 2>&1 | grep -v amdgpu.ids | tee $O/create_time.txt
