@@ -604,27 +604,9 @@ P8_HD void p8f_reload(const P8CmDev* d, P8FamShared* sh, int s) {
   r->rc[s] = T[r->runp[s]]; r->rb[s] = T[r->runp[s] + 1];
 }
 
-// uniform values of step t of a chunk
-P8_HD P8FamUni p8f_uni(const P8CmDev* d, const uint32_t* ctx, const uint16_t* chk, const uint8_t* bits_in, int16_t* out, const uint8_t* order, int t, int* last_y, int* c1,
-                       int* lk, uint32_t rnd_i) {
-  P8FamUni u;
-  const int bp = t & 7, nslots = d->nslots;
-  int c0 = 1;
-  for (int j = 0; j < bp; j++) c0 = c0 * 2 + bits_in[t - bp + j];
-  u.y = *last_y; u.bp = bp; u.c0 = c0; u.c1 = *c1; u.t = t; u.rnd_i = rnd_i;
-  u.order = order ? order[t - bp] : 0;
-  u.ctx = ctx + (size_t)(t >> 3) * (size_t)nslots;
-  u.chk = chk + (size_t)(t >> 3) * (size_t)nslots;
-  u.out = out + (size_t)t * (size_t)d->row_stride;
-  if (bp == 0 || bp == 2 || bp == 5) ++*lk;
-  u.lk = *lk;
-  *last_y = bits_in[t];
-  if (bp == 7) *c1 = (c0 * 2 + bits_in[t]) & 0xff;
-  return u;
-}
-// The same values with the running state kept by the caller: the partial byte c0 grows by one bit per step and the byte's eight coded bits and its
-// order value are read once, at its first step (nine loads that do not depend on each other) -- p8f_uni re-reads up to seven bits and the order
-// value from global memory at EVERY step, ~2 k clocks of the family kernel's 17 k per bit. Chunks are whole bytes: bits_in[t .. t + 7] exist.
+// uniform values of step t of a chunk, the running state kept by the caller: the partial byte c0 grows by one bit per step and the byte's eight coded bits and its
+// order value are read once, at its first step (nine loads that do not depend on each other) -- rebuilding c0 from up to seven already-coded bits and
+// re-reading the order value from global memory at EVERY step cost ~2 k clocks of the family kernel's 17 k per bit. Chunks are whole bytes: bits_in[t .. t + 7] exist.
 struct P8FamRun { int last_y, c1, lk, c0; uint32_t bits8; int order, nslots, row_stride; };   // nslots / row_stride: d's, read once
 P8_HD P8FamUni p8f_uni_inc(const P8CmDev* d, const uint32_t* ctx, const uint16_t* chk, const uint8_t* bits_in, int16_t* out, const uint8_t* order, int t, P8FamRun* st,
                            uint32_t rnd_i) {

@@ -75,6 +75,12 @@ void fxe_set_serial_maps(void* h, int serial) { ((Emul*)h)->dev.slot_parallel = 
 void fxe_conflict_stats(void* h, uint64_t* out2) { out2[0] = ((Emul*)h)->bits_maps; out2[1] = ((Emul*)h)->bits_serial; }
 // ... by map and bit position: out[31][8]
 void fxe_conflict_by(void* h, uint64_t* out) { for (int k = 0; k < FX_NMAPS; k++) for (int b = 0; b < 8; b++) out[8 * k + b] = ((Emul*)h)->serial_by[k][b]; }
+// role M's wavefront ownership (FxDev::mw_slot / mw_map), for the layout test: out[0..16] slots, out[17..33] maps, then C of every map
+void fxe_wave_layout(void* h, int* out) {
+  Emul* e = (Emul*)h;
+  for (int i = 0; i <= FX_M_WAVES; i++) { out[i] = e->dev.mw_slot[i]; out[FX_M_WAVES + 1 + i] = e->dev.mw_map[i]; }
+  for (int k = 0; k < FX_NMAPS; k++) out[2 * (FX_M_WAVES + 1) + k] = e->dev.maps[k].C;
+}
 void fxe_set_blpos(void* h, int blpos) { Emul* e = (Emul*)h; e->dev.blpos = blpos; fxp_set_blpos(e->parser, blpos); }
 int fxe_debug(void* h, uint32_t* out) {   // the twelve mixer selectors + a few registers
   Emul* e = (Emul*)h;

@@ -235,3 +235,23 @@ def test_reference_hashes_16k(name):
     finally:
         if dic:
             os.unlink(dic.decode())
+
+
+def test_role_m_wavefront_layout():
+    """Role M of the device stage runs as free-running wavefronts that own whole maps (fxcm_build.h): the groups must cover every
+    slot and map exactly once, in order, cut at map boundaries, fit the 16 wavefronts and leave every wavefront a handful of lanes."""
+    L = emul()
+    h = L.fxe_create(None, 0)
+    out = (C.c_int * (2 * 17 + 31))()
+    L.fxe_wave_layout.argtypes = [C.c_void_p, C.c_void_p]
+    L.fxe_wave_layout(h, out)
+    L.fxe_destroy(h)
+    slots, maps, cs = list(out[0:17]), list(out[17:34]), list(out[34:65])
+    assert sum(cs) == 81 and len(cs) == 31
+    assert slots[0] == 0 and maps[0] == 0 and slots[16] == 81 and maps[16] == 31
+    first_slot = [sum(cs[:k]) for k in range(32)]
+    for w in range(16):
+        assert maps[w] <= maps[w + 1] and slots[w] <= slots[w + 1]
+        assert slots[w] == first_slot[maps[w]], "a wavefront starts at a map boundary"
+        assert slots[w + 1] - slots[w] <= 12, "few lanes per wavefront"
+    assert sum(1 for w in range(16) if slots[w + 1] > slots[w]) >= 12, "the maps are spread over the wavefronts"
