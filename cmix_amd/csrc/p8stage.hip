@@ -293,6 +293,8 @@ __device__ __forceinline__ uint32_t apm1_upd(uint32_t v, int y, int rate) {   //
 // one-workgroup kernel: 8 k + 7.5 k of its 19.1 k clocks per bit) is spread over four compute units.
 // BLK = workgroup; it owns set 4 wave + QSEL of every wavefront, QSEL = (BLK + 2) & 3 (so that set 26 = 4 * 6 + 2 stays with workgroup 0).
 constexpr unsigned MX4_SPIN = 1u << 24;
+// an exchange word = tag << 12 | the 12-bit output; tag = launch number (24 bits, of this stage) << 28 | step + 1 (a chunk is at most 2^27 steps)
+__device__ __forceinline__ unsigned long long mx4_tag(unsigned epoch, int t) { return ((unsigned long long)(epoch & 0xFFFFFFu) << 28) | (unsigned long long)(unsigned)(t + 1); }
 template <int BLK>
 __device__ __forceinline__ void mx4_body(const P8MixDev* M, P8TailDev* T, const int16_t* __restrict__ x, const int32_t* __restrict__ sel,
                                          const P8ApmRec* __restrict__ apm, const uint8_t* __restrict__ order, const uint8_t* __restrict__ bits,
@@ -456,14 +458,14 @@ __device__ __forceinline__ void mx4_body(const P8MixDev* M, P8TailDev* T, const 
       my_pr = p8s_squash(squash, (int32_t)(acc * 9u) >> 9);   // uniform in the wavefront
       if (lane == 0) {
         if (MAIN) pr_s[si] = my_pr;
-        else __hip_atomic_store(&prx[(size_t)t * P8_NSEL + si], (((unsigned long long)epoch << 32 | (unsigned)(t + 1)) << 12) | (unsigned)my_pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_store(&prx[(size_t)t * P8_NSEL + si], (mx4_tag(epoch, t) << 12) | (unsigned)my_pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     if (MAIN && wave == 4 && lane < P8_NSEL && (lane & 3) != QSEL) {   // the 21 outputs of the other workgroups (they run ahead: normally there already)
       unsigned spins = 0;
       for (;;) {
         const unsigned long long v = __hip_atomic_load(&prx[(size_t)t * P8_NSEL + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((v >> 12) == ((unsigned long long)epoch << 32 | (unsigned)(t + 1))) { pr_s[lane] = (int)(v & 4095u); break; }
+        if ((v >> 12) == mx4_tag(epoch, t)) { pr_s[lane] = (int)(v & 4095u); break; }
         if ((++spins & 1023u) == 0 && (spins > MX4_SPIN || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
           __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pr_s[lane] = 2048; break;
         }
@@ -575,7 +577,7 @@ __device__ __forceinline__ void mx4_body(const P8MixDev* M, P8TailDev* T, const 
 }
 
 // prx: [>= nbits][28] exchange words, (launch number, step + 1) | 12-bit output: never cleared, a word of an earlier launch does not
-// match; fail: sticky time-out flag of workgroup 0's wait (host-mapped)
+// match (the launch number wraps after 2^24 launches, 64 GB of input in 4 KB chunks; every launch rewrites the words of its own steps); fail: sticky time-out flag of workgroup 0's wait (host-mapped)
 __global__ __launch_bounds__(MX_THREADS) void cmx_p8s_mix4_kernel(const P8MixDev* M, P8TailDev* T, const int16_t* __restrict__ x, const int32_t* __restrict__ sel,
                                                                  const P8ApmRec* __restrict__ apm, const uint8_t* __restrict__ order,
                                                                  const uint8_t* __restrict__ bits, float* __restrict__ out, size_t ld, int nbits, int t0, int first,
