@@ -189,3 +189,27 @@ def test_native_pipeline_bad_args():
     pipe = E.Pipeline(np.ones(256, np.uint8), 0, max_chunk_bytes=16)
     assert E.lib().cmx_pipeline_submit(pipe.h, None, 4, None, None) != 0 and "bad argument" in E.last_error()
     pipe.close()
+
+
+@pytest.mark.gpu
+def test_engines_beyond_the_compute_units_are_refused():
+    """A stream's stage kernels run for a whole chunk and wait for each other inside the launch, so their workgroups must be co-resident.
+    The library keeps count per device (80 workgroups for the stages cmx_pipeline_create builds) and refuses, with the reason, the engine
+    that would take the device past its compute units -- instead of a time-out in the middle of a stream. Destroying an engine gives its
+    share back."""
+    import torch
+    from cmix_amd import engine as E
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    room = cus // 80
+    pipes = []
+    try:
+        for _ in range(room):
+            pipes.append(E.Pipeline(np.ones(256, np.uint8), 0, max_chunk_bytes=16))
+        with pytest.raises(E.CmxError) as ei:
+            E.Pipeline(np.ones(256, np.uint8), 0, max_chunk_bytes=16)
+        assert "compute units" in str(ei.value) and "workgroups" in str(ei.value)
+        pipes.pop().close()
+        pipes.append(E.Pipeline(np.ones(256, np.uint8), 0, max_chunk_bytes=16))   # the released share is available again
+    finally:
+        for p in pipes:
+            p.close()
