@@ -291,7 +291,7 @@ struct FxLocal {
   float ex[2][FX_OUTPUTS + 1];   // the bit's 431 exported values (two parities: the copy-out of bit q runs under bit q + 1): the units write here, one coalesced copy per bit goes to the output row
 };
 // =====================================================================================================================
-// The stage on THREE workgroups. Nothing the context maps, the match models, the SSCMs or the run map
+// The stage in THREE roles (role M on FX_M_WGS workgroups since round 3). Nothing the context maps, the match models, the SSCMs or the run map
 // learn depends on the mixers or on the final probability -- only on the byte stream -- so the bit's work splits into
 // three roles that run on three compute units, each with its own LDS state, coupled only by the rows they hand over:
 //   role M  (block 0) the 31 context maps: touch -> run; publishes its 5..6 inputs per context, the eight return-value
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_roles_kernel(FxDev* g
   if (tid == 8) ah.byte[0] = bytes[0];
   __syncthreads();
   if (role != 2 && tid == 0) sh.parity = 0;   // M and U build the bit's inputs in tx[1]
-  // all three workgroups hold the state before any of them may write a part of it back (or the pending row)
+  // all workgroups hold the state before any of them may write a part of it back (or the pending row)
   if (tid == 0) { __hip_atomic_fetch_add(&X->started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); fx_wait_ge(&X->started, (unsigned)(FX_M_WGS + 2), &X->fail); }
   __syncthreads();
   const FxLayout ln = fxd_layout(d, 1);   // the normal layout's offsets
