@@ -281,7 +281,9 @@ def main():
                             "LSTM, fxcm 431, paq8 1591 -- every column produced by an engine stage, no stand-ins) + final mixing network + SSE, "
                             "strict bit-exact mode, + arithmetic coder; output file checked against the reference binary's" % a.payload_bytes,
                 "payload_bytes": a.payload_bytes, "stream_bytes": n, "sub_chunk_bytes": a.sub_chunk, "vocab": V, "warmup_stream_bytes": wn,
-                "parallelism": "1 stream per GPU, no collective"},
+                "parallelism": "1 stream per GPU, no collective",
+                "mode": ("tolerance (CMX_MIXNET_TOLERANCE=1: tree-sum dot products in the final mixing network; NOT bit-exact, the output is not the "
+                         "reference's file and `verified` says so)") if os.environ.get("CMX_MIXNET_TOLERANCE") == "1" else "strict (bit-exact; the default and the only mode that claims stream parity)"},
             "us_per_bit": dt / (8.0 * n) * 1e6,
             "end_to_end": {"value": a.payload_bytes * world / (dt + t_construct), "unit": "input bytes/s", "construct_s": t_construct,
                            "note": "payload bytes / (framing + engine construction: ~20 GB of tables allocated and initialised + the timed run incl. the coder); "

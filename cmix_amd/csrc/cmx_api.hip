@@ -131,6 +131,7 @@ struct cmx_mixnet {
   int dbg = 0;          // CMX_MIXNET_DBG: timing experiments (results invalid when nonzero)
   int xcd = -1;         // CMX_MIXNET_XCD=k: place the persistent kernel on XCD k (speed only; -1 = wherever block 0 lands)
   bool use_v1 = false;  // CMX_MIXNET_V1=1: run chunks through the bit-synchronous kernel
+  bool tolerance = false;   // CMX_MIXNET_TOLERANCE=1 (opt-in, NOT bit-exact): layer-0 dot products as f64 tree sums rounded once (cmx_mixnet_spec_kernel only)
   bool use_spec = true; // cmx_mixnet_spec_kernel (26 helper workgroups, speculative segment-parallel chains); CMX_MIXNET_SPEC=0: the one-workgroup kernel
   SpecXfer* d_xfer = nullptr;
 };
@@ -276,6 +277,7 @@ cmx_mixnet_t* cmx_mixnet_create(int device) {
   }
   { const char* v = getenv("CMX_MIXNET_V1"); h->use_v1 = v && v[0] == '1'; }
   { const char* v = getenv("CMX_MIXNET_SPEC"); h->use_spec = !(v && v[0] == '0'); }
+  { const char* v = getenv("CMX_MIXNET_TOLERANCE"); h->tolerance = v && v[0] == '1' && h->use_spec; }
   h->d_xfer = (SpecXfer*)dalloc(sizeof(SpecXfer), true);   // incl. the zero padding of the input ring
   if (!h->d_xfer || hipFuncSetAttribute((const void*)cmx_mixnet_spec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CMX_SPEC_LDS_BYTES) != hipSuccess) {
     set_err("cmx_mixnet_create: hand-off area / kernel attribute (spec kernel) failed");
@@ -378,7 +380,7 @@ int cmx_mixnet_run(cmx_mixnet_t* h, const float* d_probs, const uint32_t* d_sel,
     HIP_OK(hipMemsetAsync(h->d_xfer, 0, CMX_SPEC_HEADER_BYTES, st));
     hipLaunchKernelGGL(cmx_mixnet_spec_kernel, dim3(1 + CMX_SPEC_HELPERS), dim3(CMX_SPEC_THREADS), CMX_SPEC_LDS_BYTES, st,
                        h->d_state, h->d_xfer, d_probs, d_sel, d_bits, dd, (int)nbits, d_p_out, d_mix_out,
-                       3 | (h->profile ? 4 : 0) | ((h->dbg & 15) << 4));
+                       3 | (h->profile ? 4 : 0) | ((h->dbg & 15) << 4) | (h->tolerance ? 0x1000 : 0));
   } else
     // XCD placement (observed: block b runs on XCD b % 8): 8 blocks, all but block `xcd` leave at once
     hipLaunchKernelGGL(cmx_mixnet_chunk_kernel, dim3(h->xcd >= 0 ? 8 : 1), dim3(CMX_CHUNK_THREADS), CMX_CHUNK_LDS_BYTES, st,

@@ -1304,7 +1304,7 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
-__device__ void helper_role(MixState* S, SpecXfer* X, HelperLds* H, int nbits, int m, int w, int lane) {
+__device__ void helper_role(MixState* S, SpecXfer* X, HelperLds* H, int nbits, int m, int w, int lane, bool tol) {
   const gptr<float> rows0 = as_global(S->rows0);
   const int base = 512 * w;                 // first element of this wave's segment
   const int nseg = w == 3 ? CMX_IN0 - 1536 : 512;
@@ -1380,6 +1380,29 @@ __device__ void helper_role(MixState* S, SpecXfer* X, HelperLds* H, int nbits, i
     if (w == 3) { const float p = tailk ? fmul(xc[8], W[8]) : 0.0f; if (lane < 36) pr[512 + lane] = p; ds += (double)p; }   // 542..547: zero pad read by chain_seg
 #pragma unroll
     for (int k = 0; k < 9; ++k) xp[k] = xc[k];
+    if (tol) {
+      // TOLERANCE MODE (opt-in, CMX_MIXNET_TOLERANCE=1; NOT bit-exact): the dot product as a tree sum -- every wave reduces its segment's products in
+      // f64 across its lanes, the last wave adds the four segment sums and rounds once. No ordered chain, no speculation. The value differs from the
+      // reference's sequentially rounded f32 sum in the last bits (it is the more accurate one); streams coded with it are not the reference's.
+      ds = wave_sum_f64(ds);
+      if (w < 3) {
+        if (lane == 0) H->segsum[w] = ds;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) lds_publish_store(&H->sum_epoch[w], t + 1);
+      } else {
+        double tot = 0.0;
+        for (int q = 0; q < 3; ++q) {
+          unsigned spins = 0;
+          while (lds_poll(&H->sum_epoch[q]) < t + 1)
+            if ((++spins & 1023u) == 0 && (spins > SPEC_SPIN || failed())) { give_up(); return; }
+          tot += H->segsum[q];
+        }
+        tot += ds;
+        if (lane == 0) st_u64(&X->sum[m], ((unsigned long long)(unsigned)(t + 1) << 32) | (unsigned)__float_as_int((float)tot));
+      }
+      if (t + 1 < nbits && !fetch(t + 1)) return;
+      continue;
+    }
     if (w < 3) {                             // the later waves centre their candidates on the sum of what precedes them
       ds = wave_sum_f64(ds);
       if (lane == 0) H->segsum[w] = ds;
@@ -1728,7 +1751,7 @@ extern "C" __global__ __launch_bounds__(CMX_SPEC_THREADS) void cmx_mixnet_spec_k
     HelperLds* H = reinterpret_cast<HelperLds*>(smem);
     for (int i = tid; i < (int)(sizeof(HelperLds) / 4); i += CMX_SPEC_THREADS) reinterpret_cast<int*>(H)[i] = 0;
     __syncthreads();
-    if (wave < 4) helper_role(S, X, H, nbits, (int)blockIdx.x - 1, wave, lane);
+    if (wave < 4) helper_role(S, X, H, nbits, (int)blockIdx.x - 1, wave, lane, (mode & 0x1000) != 0);
     return;
   }
   Lds L;
