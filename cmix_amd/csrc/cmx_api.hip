@@ -22,8 +22,9 @@ extern "C" __global__ void cmx_mixnet_kernel(MixState*, const float*, const uint
                                              const uint8_t*, const float*, int, float*, float*, int);
 extern "C" __global__ void cmx_mixnet_chunk_kernel(MixState*, const float*, const uint32_t*,
                                                    const uint8_t*, const float*, int, float*, float*, int);
+struct CmxLateBox;
 extern "C" __global__ void cmx_mixnet_spec_kernel(MixState*, SpecXfer*, const float*, const uint32_t*, const uint8_t*, const float*, int, float*,
-                                                  float*, int);
+                                                  float*, int, CmxLateBox*);
 extern "C" __global__ void cmx_sse_init_kernel(MixState*);
 extern "C" __global__ void cmx_probe_libm_kernel(int, const float*, float*, size_t);
 
@@ -134,6 +135,7 @@ struct cmx_mixnet {
   bool tolerance = false;   // CMX_MIXNET_TOLERANCE=1 (opt-in, NOT bit-exact): layer-0 dot products as f64 tree sums rounded once (cmx_mixnet_spec_kernel only)
   bool use_spec = true; // cmx_mixnet_spec_kernel (26 helper workgroups, speculative segment-parallel chains); CMX_MIXNET_SPEC=0: the one-workgroup kernel
   SpecXfer* d_xfer = nullptr;
+  float* d_late_p = nullptr; size_t late_p_cap = 0;   // the decoder's form: the kernel's p[] array (the host reads p from the box)
 };
 
 extern "C" {
@@ -167,6 +169,15 @@ void* cmx_host_alloc(size_t bytes) {  // page-locked
   return p;
 }
 void cmx_host_free(void* p) { if (p) (void)hipHostFree(p); }
+// Memory that kernels of DIFFERENT launches read and write while all of them run, and that the host writes while they run (the
+// decoder's late-bit protocol, cmx_late.h): page-locked host memory mapped coherent (uncached on the device), zeroed.
+void* cmx_late_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { set_err("cmx_late_alloc: hipHostMalloc failed"); return nullptr; }
+  memset(p, 0, bytes);
+  return p;
+}
+void cmx_late_free(void* p) { if (p) (void)hipHostFree(p); }
 int cmx_copy_to_host(int device, void* dst, const void* d_src, size_t bytes) {  // synchronous, after all prior work of the device
   if (hipSetDevice(device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
       hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
@@ -341,9 +352,29 @@ int cmx_mixnet_set_upload_stream(cmx_mixnet_t* h, void* stream) {
   return 0;
 }
 
+static int mixnet_run_impl(cmx_mixnet_t* h, const float* d_probs, const uint32_t* d_sel, const uint8_t* d_bits, size_t nbits, float* d_p_out, float* d_mix_out,
+                           void* stream, CmxLateBox* box);
 int cmx_mixnet_run(cmx_mixnet_t* h, const float* d_probs, const uint32_t* d_sel,
                    const uint8_t* d_bits, size_t nbits, float* d_p_out, float* d_mix_out,
                    void* stream) {
+  return mixnet_run_impl(h, d_probs, d_sel, d_bits, nbits, d_p_out, d_mix_out, stream, nullptr);
+}
+// The decoder's form of a chunk (cmx_late.h): rows and selectors (memory the producing kernels and this one see coherently) are
+// consumed as their stages count them in `box`; p(t) goes to the box, bit t comes back through it. Only the 27-workgroup kernel.
+int cmx_mixnet_run_late(cmx_mixnet_t* h, void* box, const float* probs, const uint32_t* sel, size_t nbits, void* stream) {
+  if (!h || !box) { set_err("cmx_mixnet_run_late: bad argument"); return 1; }
+  if (!h->use_spec || h->use_v1 || h->tolerance) { set_err("cmx_mixnet_run_late: a decoder needs the strict 27-workgroup kernel (CMX_MIXNET_SPEC=0 / CMX_MIXNET_V1 / CMX_MIXNET_TOLERANCE are set)"); return 1; }
+  if (hipSetDevice(h->device) != hipSuccess) { set_err("hipSetDevice failed"); return 1; }
+  if (h->late_p_cap < nbits) {
+    void* p = nullptr;
+    if (hipMalloc(&p, nbits * 4) != hipSuccess) { set_err("cmx_mixnet_run_late: hipMalloc failed"); return 1; }
+    h->allocs.push_back(p);
+    h->d_late_p = (float*)p; h->late_p_cap = nbits;
+  }
+  return mixnet_run_impl(h, probs, sel, nullptr, nbits, h->d_late_p, nullptr, stream, (CmxLateBox*)box);
+}
+static int mixnet_run_impl(cmx_mixnet_t* h, const float* d_probs, const uint32_t* d_sel, const uint8_t* d_bits, size_t nbits, float* d_p_out, float* d_mix_out,
+                           void* stream, CmxLateBox* box) {
   const int fail_value = 1;
   if (!h) { set_err("cmx_mixnet_run: null handle"); return 1; }
   if (h->predicted) { set_err("cmx_mixnet_run: a bit-synchronous predict() is pending"); return 1; }
@@ -380,7 +411,7 @@ int cmx_mixnet_run(cmx_mixnet_t* h, const float* d_probs, const uint32_t* d_sel,
     HIP_OK(hipMemsetAsync(h->d_xfer, 0, CMX_SPEC_HEADER_BYTES, st));
     hipLaunchKernelGGL(cmx_mixnet_spec_kernel, dim3(1 + CMX_SPEC_HELPERS), dim3(CMX_SPEC_THREADS), CMX_SPEC_LDS_BYTES, st,
                        h->d_state, h->d_xfer, d_probs, d_sel, d_bits, dd, (int)nbits, d_p_out, d_mix_out,
-                       3 | (h->profile ? 4 : 0) | ((h->dbg & 15) << 4) | (h->tolerance ? 0x1000 : 0));
+                       3 | (h->profile ? 4 : 0) | ((h->dbg & 15) << 4) | (h->tolerance ? 0x1000 : 0), box);
   } else
     // XCD placement (observed: block b runs on XCD b % 8): 8 blocks, all but block `xcd` leave at once
     hipLaunchKernelGGL(cmx_mixnet_chunk_kernel, dim3(h->xcd >= 0 ? 8 : 1), dim3(CMX_CHUNK_THREADS), CMX_CHUNK_LDS_BYTES, st,

@@ -1,0 +1,99 @@
+// cmx_late.h -- the LATE-BIT protocol: the stage kernels of the chunk pipeline driven by a decoder.
+//
+// Decoder::Decode (reference src/coder/decoder.cpp:20-39) calls Predictor::Predict() and only then learns the bit it hands to
+// Perceive(): bit t of the stream is an OUTPUT of the arithmetic decoder that needs p(t). The stage kernels are the same persistent
+// per-chunk kernels a compressor runs, but every place where they read a coded bit, a host-stage record or another
+// stage's row now WAITS for it:
+//
+//   host (decoder thread)                               device (every stage kernel of the chunk, all co-resident)
+//   ---------------------------------------------       -----------------------------------------------------------
+//   poll p_word until its tag is bit t        <-------   mixing network: row t complete (all producers' counters) -> p(t)
+//   bit = Decoder::Decode(p)
+//   front ends for the step after the bit
+//   (paq8 per step; PPMd, fxcm parser, LSTM
+//   launch per byte) into host-mapped records
+//   bit[t] = bit; nknown = t + 1              ------->   every kernel: learns bit t, produces row t + 1, bumps its row counter
+//
+// ONE counter carries both facts: nknown > t means "bit t is known AND every host record of step t + 1 is in place" (the host
+// writes the records first). The box and every buffer that one kernel writes and another reads WHILE BOTH RUN live in
+// host-coherent pinned memory (uncached on the device: no stale line in an XCD's L2), written with plain stores followed by
+// `s_waitcnt vmcnt(0)` and the producer's counter (system-scope atomic), read after the consumer has seen the counter.
+// Every wait is bounded by wall-clock time (CMX_LATE_TIMEOUT_S without progress) and by the box's abort word: a decoder that
+// stops mid-chunk (cmx_destroy) unwinds the kernels instead of leaving them spinning.
+#ifndef CMX_LATE_H
+#define CMX_LATE_H
+#include <stdint.h>
+
+enum {
+  LC_CTX = 0,     // rows whose columns 1, 2, 2025..2075 and 47 selectors the context stage has written
+  LC_BM0,         // rows with column 0 (Bracket's ByteModel::Predict)
+  LC_BM1,         // rows with column 2076 (PPMd's)
+  LC_BM2,         // rows with column 2077 (the LSTM byte mixer's) and the fxcm hints of the update before them
+  LC_FX,          // rows with columns 3..433 (fxcm stage, role X)
+  LC_P8,          // rows with columns 434..2024 (paq8 stage, mixer workgroup 0)
+  LC_CM2_0,       // paq8: mixer-input rows (and `order`) of the order-N ContextMap2
+  LC_CM2_1, LC_CM2_2,
+  LC_FAM, LC_LANES, LC_DMC,
+  LC_BRK,         // bytes whose Bracket distribution (after the byte) the context stage has written
+  LC_LSTM,        // bytes whose LSTM distribution (after the byte) is in place (bumped behind the per-byte LSTM launch)
+  LC_N = 16
+};
+#define CMX_LATE_P_RING 8
+
+struct CmxLateBox {
+  uint32_t nknown;   // host -> device
+  uint32_t start;    // host -> device: 1 = the chunk before this one is complete (last_y, the step-0 records and row-0 carry-overs are valid)
+  uint32_t last_y;   // the bit before the chunk's first
+  uint32_t abort;    // host -> device: leave
+  uint32_t fail;     // device -> host, sticky: a wait ran out of time
+  uint32_t nbits;    // bits of this chunk (information only)
+  uint32_t pad0[10];
+  struct { uint32_t v; uint32_t pad[15]; } cnt[LC_N];   // device -> device, one 64-byte line each
+  unsigned long long p_word[CMX_LATE_P_RING];           // device -> host: ((t + 1) << 32) | bits of p(t), slot t % ring
+  uint8_t bit[8];    // [nbits] follows (allocated behind the struct)
+};
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#ifndef CMX_LATE_TIMEOUT_TICKS
+#define CMX_LATE_TIMEOUT_TICKS (30ull * 100000000ull)   // 30 s of the 100 MHz constant clock without the awaited value
+#endif
+__device__ __forceinline__ uint32_t late_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void late_st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// Bounded wait until *p >= want (callable by one lane or by a whole wavefront on a uniform address). false: aborted / timed out.
+__device__ __forceinline__ bool late_wait_ge(CmxLateBox* B, const uint32_t* p, uint32_t want) {
+  if (late_ld(p) >= want) return true;
+  unsigned spins = 0;
+  unsigned long long t0 = 0;
+  for (;;) {
+    __builtin_amdgcn_s_sleep(1);
+    if (late_ld(p) >= want) return true;
+    if ((++spins & 255u) == 0) {
+      if (late_ld(&B->abort) || late_ld(&B->fail)) return false;
+      const unsigned long long now = wall_clock64();
+      if (!t0) t0 = now;
+      else if (now - t0 > CMX_LATE_TIMEOUT_TICKS) { late_st(&B->fail, 1u); return false; }
+    }
+  }
+}
+// the bit before step t of the chunk (t == 0: the previous chunk's last), once it is known; -1: aborted
+__device__ __forceinline__ int late_y(CmxLateBox* B, int t) {
+  if (t == 0) { if (!late_wait_ge(B, &B->start, 1u)) return -1; return (int)late_ld(&B->last_y); }
+  if (!late_wait_ge(B, &B->nknown, (uint32_t)t)) return -1;
+  asm volatile("" ::: "memory");
+  return (int)*(volatile const uint8_t*)(B->bit + (t - 1));
+}
+// publish: every store of this wavefront issued so far has left before the counter moves (call with one lane; the others' stores
+// are covered when the caller puts a wave / workgroup barrier with s_waitcnt vmcnt(0) in front)
+__device__ __forceinline__ void late_publish(CmxLateBox* B, int which, uint32_t v) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  late_st(&B->cnt[which].v, v);
+}
+__device__ __forceinline__ bool late_wait_cnt(CmxLateBox* B, int which, uint32_t want) {
+  const bool ok = late_wait_ge(B, &B->cnt[which].v, want);
+  asm volatile("" ::: "memory");
+  return ok;
+}
+#endif
+
+#endif

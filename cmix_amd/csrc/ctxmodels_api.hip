@@ -19,6 +19,8 @@
 
 extern "C" __global__ void cmx_ctxmodels_kernel(const CtxDev, const uint8_t*, size_t, float*, size_t, uint32_t*, float*);
 extern "C" __global__ void cmx_ctxmodels_peek_kernel(const CtxDev, const uint8_t*, float*, size_t, uint32_t*);
+struct CmxLateBox;
+extern "C" __global__ void cmx_ctxmodels_late_kernel(const CtxDev, CmxLateBox*, size_t, float*, size_t, uint32_t*, float*);
 extern "C" __global__ void cmx_bytemodel_bits(const float*, const float*, const uint8_t*, size_t, float*, int*, size_t, int,
                                               float*);
 extern "C" unsigned cmx_ctxmodels_lds_bytes();
@@ -348,6 +350,24 @@ static int ctxmodels_launch(cmx_ctxmodels_t* h, const uint8_t* d_bytes, size_t n
                        d_bytes, nbytes, d_probs, (int*)nullptr, pstride, only_k, (float*)nullptr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { cmx_set_err(std::string("cmx_ctxmodels_run: ") + hipGetErrorString(e)); return 1; }
+  return 0;
+}
+
+// The decoder's form of a chunk (cmx_late.h): the kernel is launched for the next nbytes bytes; their bits arrive through `box`.
+// probs / sel / brk_dist ([nbytes][256]: the Bracket model's distribution after each byte) are memory that the kernels reading them
+// (mixing network, ByteModel kernel) see coherently while this one runs. *brk_dist0_out: where the distribution going into the
+// chunk's first byte is (valid when every earlier kernel of this stage has ended).
+int cmx_ctxmodels_run_late(cmx_ctxmodels_t* h, void* box, size_t nbytes, float* probs, size_t pstride, uint32_t* sel, float* brk_dist,
+                           const float** brk_dist0_out, void* stream) {
+  if (!h || !box || !probs || !sel || !brk_dist || nbytes == 0 || pstride < CMX_N_INPUTS) { cmx_set_err("cmx_ctxmodels_run_late: bad argument"); return 1; }
+  if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
+  hipStream_t st = (hipStream_t)stream;
+  // (the stage's own copy in its persistent state: the kernel rewrites it only in its epilogue, long after the first byte's reader has it)
+  if (brk_dist0_out) *brk_dist0_out = (const float*)((const char*)h->dev.persist + offsetof(CtxPersist, br_probs));
+  (void)hipFuncSetAttribute((const void*)cmx_ctxmodels_late_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cmx_ctxmodels_lds_bytes());
+  hipLaunchKernelGGL(cmx_ctxmodels_late_kernel, dim3(1), dim3(64), cmx_ctxmodels_lds_bytes(), st, h->dev, (CmxLateBox*)box, nbytes, probs, pstride, sel, brk_dist);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { cmx_set_err(std::string("cmx_ctxmodels_run_late: ") + hipGetErrorString(e)); return 1; }
   return 0;
 }
 

@@ -26,6 +26,7 @@
 #include <stdint.h>
 #include "cmx_ref_tables.h"
 #include "ctxmodels_state.h"
+#include "cmx_late.h"
 
 namespace {
 
@@ -73,9 +74,13 @@ struct LdsMap {  // carve of the dynamic LDS region (byte offsets, all multiples
 extern "C" unsigned cmx_ctxmodels_lds_bytes() { return LdsMap::total; }
 
 namespace {
-template <bool dry>
+template <bool dry, bool late = false>
 __device__ __forceinline__ void ctxmodels_body(const CtxDev& D, const uint8_t* __restrict__ bytes, size_t nbytes,
-                                               float* probs, size_t pstride, uint32_t* sel, float* bracket_dist) {
+                                               float* probs, size_t pstride, uint32_t* sel, float* bracket_dist, CmxLateBox* LB = nullptr) {
+  // late (the decoder's form, cmx_late.h): the byte is not known when its first bit is predicted. The wave walks BITS: Predict of
+  // bit j from the bits decoded so far (one probe per table model), row t and the selectors published (counter LC_CTX), then it
+  // waits for the decoder's bit and runs the Perceive of every model -- the reference's own order (predictor.cpp:361-369, 421-446).
+  // The byte-boundary part below is the chunk kernel's, on the byte the 8 bits spell.
   // dry != 0 (bit-synchronous mode, one byte): the 8 Predict/Perceive steps run on a byte whose low bits are
   // still unknown (zeros); outputs and selectors of bit j depend only on bits < j, so row j is exact once j bits
   // are known. Nothing of the pass survives: HBM writes are suppressed (or rolled back, overlapping Indirect
@@ -146,11 +151,11 @@ __device__ __forceinline__ void ctxmodels_body(const CtxDev& D, const uint8_t* _
   const uint8_t* const trans = L.run_map ? runmap : nonstat;
 
   for (size_t n = 0; n < nbytes; ++n) {
-    const unsigned B = bytes[n];
+    unsigned B = late ? 0u : (unsigned)bytes[n];
     const size_t t0 = 8 * n;
 
     // ---- the 47 selectors Mixer::Mix reads at each of the 8 Predict() calls ----
-    if (sel && lane < CTX_NSEL) {
+    if (!late && sel && lane < CTX_NSEL) {
       const u64 base = L.sel_kind == SEL_ZERO ? 0 : regs[L.sel_src];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -176,11 +181,94 @@ __device__ __forceinline__ void ctxmodels_body(const CtxDev& D, const uint8_t* _
     const bool slow = __any(conf);
     if (slow && lane == 0) ++P->slow_bytes[dry ? 1 : 0];
 
+    if (late) {
+      // ---- 8 x (Predict -> row out -> wait for the bit -> Perceive), bit by bit ----
+      float* const pr = is_dir ? L.pred + (L.mtype == MT_DIRECT ? regs[R_CTX + L.mctx] : mbase) * 256 : nullptr;
+      uint8_t* const cn = is_dir ? L.cnt + (L.mtype == MT_DIRECT ? regs[R_CTX + L.mctx] : mbase) * 256 : nullptr;
+      uint8_t* const mp8 = D.shared_map + mbase;
+      const u64 selbase = (lane < CTX_NSEL && L.sel_kind != SEL_ZERO) ? regs[L.sel_src] : 0;
+      unsigned part = 0, m = ml;
+#pragma unroll 1
+      for (int j = 0; j < 8; ++j) {
+        const size_t t = t0 + j;
+        const unsigned bc = (1u << j) | part;
+        if (sel && lane < CTX_NSEL) {
+          const unsigned lbc = j == 0 ? 1u : bc;  // long_bit_context_
+          u64 v = L.sel_kind == SEL_BITCTX ? (selbase << 8) + lbc : L.sel_kind == SEL_LBC ? (u64)lbc : selbase;
+          if (L.sel_kind == SEL_BITCTX && j == 0 && n == 0 && bytes_done0 == 0) v = 0;  // BitContext ctor: context_ = 0
+          sel[t * CTX_NSEL + lane] = (uint32_t)v;
+        }
+        float o = 0.5f, pv = 0.5f;
+        unsigned cv = 0, s = 0;
+        if (is_dir) { pv = pr[bc]; cv = cn[bc]; o = pv; }
+        else if (is_ind) {
+          if (slow) wave_mem_sync();
+          s = mp8[bc];
+          o = ip[s];
+        } else if (is_match) {
+          const int expected = (cur_byte >> (7 - j)) & 1;
+          const float p = mp[m];
+          o = expected ? p : 1.0f - p;
+        }
+        if (probs && lane >= 1 && lane < CTX_NM) probs[t * pstride + L.col] = o;
+        wave_mem_sync();   // the row's stores (and, on the serial path, every Predict() probe) are complete
+        if (lane == 0) late_st(&LB->cnt[LC_CTX].v, (uint32_t)(t + 1));
+        const int bit = late_y(LB, (int)t + 1);   // uniform: the whole wave leaves on abort
+        if (bit < 0) return;
+        if (is_dir) {  // direct.cpp:22-28
+          float div = L.divisor;
+          if ((int)cv < L.limit) {
+            const unsigned c = cv + 1;
+            cn[bc] = (uint8_t)c;
+            div = divtab[L.divtab + c];
+          }
+          pr[bc] = pv + ((float)bit - pv) * div;
+        } else if (is_ind && !slow) {  // indirect.cpp:22-27
+          const float p = ip[s];
+          ip[s] = p + ((float)bit - p) * L.divisor;
+          mp8[bc] = trans[s * 2 + bit];
+        } else if (is_match) {  // match.cpp:25-46
+          const int expected = (cur_byte >> (7 - j)) & 1;
+          const float p = mp[m];
+          const int match = bit == expected;
+          float div = L.divisor;
+          const unsigned c = mc[m];
+          if ((int)c < L.limit) {
+            mc[m] = (uint8_t)(c + 1);
+            div = divtab[L.divtab + c + 1];
+          }
+          mp[m] = p + ((float)match - p) * div;
+          m = match ? (m < 255 ? m + 1 : m) : 0;
+        }
+        if (slow) {  // overlapping Indirect maps: Perceive model by model, in the reference's order
+          u64 mk = __ballot(is_ind);
+          while (mk) {
+            const int k = __ffsll((long long)mk) - 1;
+            mk &= mk - 1;
+            if (lane == k) {
+              const unsigned s2 = D.shared_map[mbase + bc];
+              const float p = ip[s2];
+              ip[s2] = p + ((float)bit - p) * L.divisor;
+              D.shared_map[mbase + bc] = trans[s2 * 2 + bit];
+            }
+            wave_mem_sync();
+          }
+        }
+        part = (part << 1) | (unsigned)bit;
+      }
+      B = part;
+      if (is_match) {
+        ml = m;
+        L.map[mbase] = (uint32_t)mhp;  // map_[byte_context_ % map_.size()] = history_pos_
+        ++mhp;
+      }
+    }
     // ---- 8 x (Predict, Perceive) of the table models ----
     float out[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) out[j] = 0.5f;
-    if (is_dir) {  // direct.cpp:15-28, direct-hash.cpp:16-29
+    if (late) {
+    } else if (is_dir) {  // direct.cpp:15-28, direct-hash.cpp:16-29
       const u64 row = L.mtype == MT_DIRECT ? regs[R_CTX + L.mctx] : mbase;
       float* const pr = L.pred + row * 256;
       uint8_t* const cn = L.cnt + row * 256;
@@ -245,7 +333,7 @@ __device__ __forceinline__ void ctxmodels_body(const CtxDev& D, const uint8_t* _
       ++mhp;
     }
     unsigned undo[8];  // dry pass over overlapping maps: the states this lane replaced, restored below
-    if (slow) {  // reference order, bit by bit and model by model
+    if (slow && !late) {  // reference order, bit by bit and model by model
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const unsigned bc = (1u << j) | (B >> (8 - j));
@@ -281,7 +369,7 @@ __device__ __forceinline__ void ctxmodels_body(const CtxDev& D, const uint8_t* _
         }
       }
     }
-    if (probs && lane >= 1 && lane < CTX_NM) {
+    if (!late && probs && lane >= 1 && lane < CTX_NM) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) probs[(t0 + j) * pstride + L.col] = out[j];
     }
@@ -488,6 +576,10 @@ __device__ __forceinline__ void ctxmodels_body(const CtxDev& D, const uint8_t* _
       *(float4*)(bracket_dist + n * 256 + 4 * lane) = make_float4(v[0], v[1], v[2], v[3]);
     }
     __syncthreads();
+    if (late) {   // the Bracket model's distribution after byte n is in place (the ByteModel kernel of the late pipeline reads it)
+      wave_mem_sync();
+      if (lane == 0) late_st(&LB->cnt[LC_BRK].v, (uint32_t)(n + 1));
+    }
   }
 
   // ---- chunk epilogue: LDS / registers -> HBM ----
@@ -525,6 +617,13 @@ extern "C" __global__ void __launch_bounds__(64)
 cmx_ctxmodels_kernel(const CtxDev D, const uint8_t* __restrict__ bytes, size_t nbytes, float* probs, size_t pstride,
                      uint32_t* sel, float* bracket_dist) {
   ctxmodels_body<false>(D, bytes, nbytes, probs, pstride, sel, bracket_dist);
+}
+
+// the decoder's form (cmx_late.h): bits arrive through the box as the arithmetic decoder produces them
+extern "C" __global__ void __launch_bounds__(64)
+cmx_ctxmodels_late_kernel(const CtxDev D, CmxLateBox* box, size_t nbytes, float* probs, size_t pstride, uint32_t* sel,
+                          float* bracket_dist) {
+  ctxmodels_body<false, true>(D, nullptr, nbytes, probs, pstride, sel, bracket_dist, box);
 }
 
 // bit-synchronous mode: one dry pass over a partially known byte (see the comment at the top of the body)

@@ -77,8 +77,9 @@ struct cmx_engine {
   uint8_t vocab[256];
   std::string dict;               // the hidden global `dictionary_path` (runner.cpp:17), read by the fxcm stage
   bool has_dict = false;
-  int mode = 0;                   // 0 undecided, 1 per-bit stages built, 2 look-ahead pipeline built
+  int mode = 0;                   // 0 undecided, 1 per-bit stages built (columns from the caller), 2 look-ahead pipeline built, 3 the decoder's pipeline (late-bit protocol)
   LookAhead* la = nullptr;
+  cmx_pipeline_t* late = nullptr; // mode 3: every model family on the device, bits arriving one at a time (cmx_pipeline_late_*)
   cmx_ctxmodels_t* ctx = nullptr;
   cmx_lstm_t* lstm = nullptr;
   cmx_mixnet_t* mix = nullptr;
@@ -201,6 +202,7 @@ void free_perbit(cmx_engine* h) {
 int ensure_perbit(cmx_engine* h, const char* where) {
   if (h->mode == 1) return 0;
   if (h->mode == 2) { cmx_set_err(std::string(where) + ": the handle is in look-ahead mode (cmx_stage_input was called)"); return 1; }
+  if (h->mode == 3) { cmx_set_err(std::string(where) + ": the handle is decoding with every model family on the device (no columns are taken from the caller)"); return 1; }
   h->ctx = cmx_ctxmodels_create(h->vocab, h->device);
   h->lstm = h->ctx ? cmx_lstm_create(h->vocab, 31, h->device) : nullptr;  // 31 rand() draws precede the LSTM (indirect.cpp:10)
   h->mix = h->lstm ? cmx_mixnet_create(h->device) : nullptr;
@@ -252,6 +254,27 @@ int flush_pretrain(cmx_engine* h) {
   return 0;
 }
 
+// ---- the decoder's mode (3): the chunk pipeline under the late-bit protocol (cmx_late.h) -------------------------------
+// What a Decoder gets (decoder.cpp:20-39) when it has staged nothing and hands in no columns: the same stage kernels as the
+// look-ahead compressor -- fxcm and paq8 included --, launched for chunks of bytes that do not exist yet; cmx_perceive(bit)
+// publishes the bit (and the host stages' records of the step after it), cmx_predict() waits for the mixing network's p.
+int ensure_late(cmx_engine* h, const char* where) {
+  if (h->mode == 3) return 0;
+  if (h->mode != 0) { cmx_set_err(std::string(where) + ": the handle is already in another mode"); return 1; }
+  if (h->pre_j) { cmx_set_err(std::string(where) + ": Pretrain() stopped inside a byte"); return 1; }
+  h->late = cmx_pipeline_create(h->vocab, h->device, kLaChunk);
+  bool ok = h->late && cmx_pipeline_enable_fxcm(h->late, h->has_dict ? h->dict.c_str() : nullptr) == 0 && cmx_pipeline_enable_paq8(h->late) == 0;
+  // Predictor::Pretrain's bytes (predictor.cpp:471-487), collected since cmx_create, in one batch through the stages
+  ok = ok && (h->pre.empty() || cmx_pipeline_pretrain(h->late, h->pre.data(), h->pre.size()) == 0);
+  ok = ok && cmx_pipeline_late_start(h->late, h->pre.empty() ? 0 : (int)(h->pre.back() & 1)) == 0;
+  if (!ok) { cmx_pipeline_destroy(h->late); h->late = nullptr; return 1; }   // the failing stage has set the error
+  h->pre.clear();
+  h->pre.shrink_to_fit();
+  h->mode = 3;
+  h->started = true;
+  return 0;
+}
+
 // ---- look-ahead mode --------------------------------------------------------------------------------------------
 void free_lookahead(cmx_engine* h) {
   LookAhead* la = h->la;
@@ -268,7 +291,7 @@ void free_lookahead(cmx_engine* h) {
 
 int ensure_lookahead(cmx_engine* h) {
   if (h->mode == 2) return 0;
-  if (h->mode == 1) {
+  if (h->mode == 1 || h->mode == 3) {
     cmx_set_err("cmx_stage_input: the per-bit stages of this handle already exist (a predict / pretrain flush came first): "
                 "stage the input before the first cmx_predict()");
     return 1;
@@ -368,6 +391,7 @@ void cmx_destroy(cmx_t* h) {
   (void)hipDeviceSynchronize();
   free_lookahead(h);
   free_perbit(h);
+  if (h->late) cmx_pipeline_destroy(h->late);   // unwinds the kernels of the chunk in progress first
   delete h;
 }
 
@@ -387,7 +411,7 @@ cmx_t* cmx_create(const uint8_t vocab[256], const char* dict_path, int device) {
 
 int cmx_set_model_outputs(cmx_t* h, const float* cols) {
   if (!h || !cols) { cmx_set_err("cmx_set_model_outputs: bad argument"); return 1; }
-  if (h->mode == 2) { cmx_set_err("cmx_set_model_outputs: look-ahead mode takes no columns from the caller (fxcm and paq8 are device stages)"); return 1; }
+  if (h->mode == 2 || h->mode == 3) { cmx_set_err("cmx_set_model_outputs: this handle takes no columns from the caller (fxcm and paq8 are device stages)"); return 1; }
   if (h->predicted) { cmx_set_err("cmx_set_model_outputs: between predict() and perceive()"); return 1; }
   if (refused(h, "cmx_set_model_outputs") || ensure_perbit(h, "cmx_set_model_outputs")) return 1;
   memcpy(h->pin->staged, cols, sizeof h->pin->staged);  // the previous bit's upload finished before its p came back
@@ -409,10 +433,19 @@ float cmx_predict(cmx_t* h) {
     txn.ok = true;
     return p;
   }
+  if (h->mode == 3 || (h->mode == 0 && !h->have_staged)) {   // a decoder: nothing staged, no columns handed in -- the whole engine, bit by bit
+    E_HIP(hipSetDevice(h->device));
+    Txn txn(h);
+    if (ensure_late(h, where)) return fail;
+    const float p = cmx_pipeline_late_predict(h->late);
+    if (p < 0) return fail;
+    h->predicted = true;
+    txn.ok = true;
+    return p;
+  }
   if (!h->have_staged) {
-    cmx_set_err("cmx_predict: neither staged input (cmx_stage_input: look-ahead compression, every model family on the device) "
-                "nor the fxcm/paq8 columns of this bit (cmx_set_model_outputs: the per-bit surface a decoder uses takes those two "
-                "families from the caller); there is no CPU fallback");
+    cmx_set_err("cmx_predict: this handle takes the fxcm / paq8 columns from the caller (cmx_set_model_outputs was used): hand in the "
+                "columns of this bit as well");
     return fail;
   }
   E_HIP(hipSetDevice(h->device));
@@ -454,6 +487,13 @@ int cmx_perceive(cmx_t* h, int bit) {
     return 0;
   }
   E_HIP(hipSetDevice(h->device));
+  if (h->mode == 3) {
+    Txn txn(h);
+    if (cmx_pipeline_late_perceive(h->late, bit)) return 1;
+    h->predicted = false;
+    txn.ok = true;
+    return 0;
+  }
   Txn txn(h);
   if (cmx_mixnet_perceive_async(h->mix, bit, h->st)) return 1;
   h->predicted = false;
@@ -478,7 +518,7 @@ int cmx_perceive(cmx_t* h, int bit) {
 
 int cmx_get_lstm_hint(cmx_t* h, int* lstmpr, int* lstmex) {
   if (!h || !lstmpr || !lstmex) { cmx_set_err("cmx_get_lstm_hint: bad argument"); return 1; }
-  if (h->mode == 2) { cmx_set_err("cmx_get_lstm_hint: look-ahead mode keeps the LSTM hints on the device (the fxcm stage reads them there)"); return 1; }
+  if (h->mode == 2 || h->mode == 3) { cmx_set_err("cmx_get_lstm_hint: this handle keeps the LSTM hints on the device (the fxcm stage reads them there)"); return 1; }
   if (refused(h, "cmx_get_lstm_hint") || ensure_perbit(h, "cmx_get_lstm_hint")) return 1;
   if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
   if (finish_hint(h)) return 1;
@@ -504,7 +544,7 @@ int cmx_pretrain(cmx_t* h, int bit) {
     h->pre.push_back((uint8_t)h->pre_partial);
     h->pre_j = 0;
     h->pre_partial = 0;
-    if (h->mode == 1 && h->pre.size() >= (1u << 16)) {
+    if (h->mode == 1 && h->pre.size() >= (1u << 16)) {   // (modes 2 and 3 take the whole batch when they are built)
       if (refused(h, "cmx_pretrain")) return 1;
       if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
       Txn txn(h);

@@ -18,6 +18,7 @@
 
 #include "../../include/cmix_amd.h"
 #include "fxcm_build.h"
+#include "cmx_late.h"
 
 void cmx_set_err(const std::string& s);  // cmx_api.hip
 extern "C" int cmx_device_count(void);
@@ -356,10 +357,15 @@ __device__ __forceinline__ void fx_stage_ahead(FxAhead* ah, FxLocal* loc, const 
   if (k == 6) for (int i = lane; i < (int)(sizeof(FxByteRec) / 4); i += 64) ((uint32_t*)&loc->rec[b & 1])[i] = ((const uint32_t*)&recs[b])[i];
 }
 
-__global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_roles_kernel(FxDev* gd, FxXfer* X, unsigned* rows, const uint8_t* bytes, const FxByteRec* recs,
-                                                                         const int16_t* lstmpr, const uint8_t* lstmex, float* out, long ostride, int n,
-                                                                         unsigned long long* prof) {
+// LATE (a decoder, cmx_late.h): the chunk's bytes are not known -- bit q arrives through the box LB (with it the host records of
+// the step after it: at a byte's last bit the parser's record of that byte), the LSTM hints of update q through the ByteModel kernel's
+// counter LC_BM2, and role X counts the rows it has completed (LC_FX) for the mixing network. `bytes` is unused; recs is host-mapped.
+template <bool LATE>
+__device__ __forceinline__ void fx_roles_body(FxDev* gd, FxXfer* X, unsigned* rows, const uint8_t* bytes, const FxByteRec* recs,
+                                              const int16_t* lstmpr, const uint8_t* lstmex, float* out, long ostride, int n,
+                                              unsigned long long* prof, CmxLateBox* LB) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fx_smem[];
+  __shared__ int late_go;
   FxShared& sh = *(FxShared*)fx_smem;
   // CMX_FXCM_PROFILE=1: thread 0 of each role accumulates its clocks per phase: prof[16 role + k] (scripts/gpu_fxcm_time.py)
   unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pc0 = __builtin_readcyclecounter();
@@ -384,8 +390,10 @@ __global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_roles_kernel(FxDev* g
   const int nbits = 8 * n, blpos0 = d->blpos, lastbyte0 = d->lastbyte, have0 = d->have_rec;
   if (tid < FX_THREADS) fxd_load_shared(d, &sh, tid);
   if (role == 2) for (int i = tid; i < FX_OUTPUTS; i += FX_DEV_THREADS) out[i] = gd->pending[i];   // row 0: what the previous chunk's last update left
-  if (tid < 8) { ah.pr[0][tid] = lstmpr[tid]; ah.ex[0][tid] = lstmex[tid]; }
-  if (tid == 8) ah.byte[0] = bytes[0];
+  if (!LATE) {
+    if (tid < 8) { ah.pr[0][tid] = lstmpr[tid]; ah.ex[0][tid] = lstmex[tid]; }
+    if (tid == 8) ah.byte[0] = bytes[0];
+  }
   __syncthreads();
   if (role != 2 && tid == 0) sh.parity = 0;   // M and U build the bit's inputs in tx[1]
   // all workgroups hold the state before any of them may write a part of it back (or the pending row)
@@ -393,6 +401,8 @@ __global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_roles_kernel(FxDev* g
   __syncthreads();
   const FxLayout ln = fxd_layout(d, 1);   // the normal layout's offsets
   unsigned have_row = 0;
+  if (LATE && role == 2 && tid == 0) late_publish(LB, LC_FX, 1u);   // row 0 (above) is in place
+  unsigned late_part = 0;   // LATE: the bits of the byte in force decoded so far (kept by the wavefront that stages them)
   if (role == 0) {
     // ================= role M: the context maps, one free-running wavefront per group of maps =================
     // Nothing a map learns depends on another map or on role X, and the coded bits are the chunk's bytes: every wavefront owns whole maps
@@ -417,8 +427,21 @@ __global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_roles_kernel(FxDev* g
       int prev_byte = lastbyte0;
       for (int q = 0; q < nbits; q++) {
         const int b = q >> 3, k = q & 7;
-        if (k == 0 && (b & 63) == 0) bv = b + lane < n ? (uint32_t)bytes[b + lane] : 0u;
-        const int cur = (int)__builtin_amdgcn_readlane((int)bv, b & 63);
+        int cur;
+        if (LATE) {   // the byte as far as it is known: the decoded bits on top (only those are used), zeros below
+          const int y = late_y(LB, q + 1);
+          if (y < 0) return;
+          late_part = (k == 0 ? 0u : late_part) * 2u + (unsigned)y;
+          cur = (int)(late_part << (7 - k));
+          if (k == 7) {   // the byte is complete: the parser's record of it is in place (it came with this bit)
+            for (int i = lane; i < (int)(sizeof(FxByteRec) / 4); i += 64) ((uint32_t*)&wrec[b & 1])[i] = ((const volatile uint32_t*)&recs[b])[i];
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+          }
+        } else {
+          if (k == 0 && (b & 63) == 0) bv = b + lane < n ? (uint32_t)bytes[b + lane] : 0u;
+          cur = (int)__builtin_amdgcn_readlane((int)bv, b & 63);
+        }
         FxBit u;
         u.q = q;
         u.y = (cur >> (7 - k)) & 1;
@@ -436,7 +459,7 @@ __global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_roles_kernel(FxDev* g
         unsigned* const row = rows + (size_t)q * FX_ROW_WORDS;
         const int par = q & 1;
         const bool carry = u.bpos == 4 || u.bpos == 7;   // the keys of a bit between two lookups are those of the bit before it (or fewer): its flags carry over
-        if (k == 6) for (int i = lane; i < (int)(sizeof(FxByteRec) / 4); i += 64) ((uint32_t*)&wrec[b & 1])[i] = ((const uint32_t*)&recs[b])[i];
+        if (!LATE && k == 6) for (int i = lane; i < (int)(sizeof(FxByteRec) / 4); i += 64) ((uint32_t*)&wrec[b & 1])[i] = ((const uint32_t*)&recs[b])[i];
         if (carry) { if (k0 + lane < k1) sh.mconf[par][k0 + lane] = sh.mconf[par ^ 1][k0 + lane]; }
         else if (msl < FX_NSLOTS) fxd_map_touch(d, &sh, u, msl, ht[par], 127u);
         FX_TICK(0);
@@ -467,6 +490,22 @@ __global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_roles_kernel(FxDev* g
     }
   } else
   for (int q = 0; q < nbits; q++) {
+    if (LATE) {   // the role's helper wavefront stages what the update needs as it arrives: bit q, the LSTM hints of update q, at a byte's last bit its record
+      if (wave == (role == 1 ? 3 : 5)) {
+        const int b = q >> 3, k = q & 7;
+        const int y = late_y(LB, q + 1);
+        const bool ok = y >= 0 && late_wait_cnt(LB, LC_BM2, (unsigned)(q + 2));
+        if (ok) {
+          late_part = (k == 0 ? 0u : late_part) * 2u + (unsigned)y;
+          if (lane == 8) ah.byte[b & 3] = (uint8_t)(late_part << (7 - k));
+          else if (lane == 0) { ah.pr[b & 3][k] = *(const volatile int16_t*)&lstmpr[q]; ah.ex[b & 3][k] = *(const volatile uint8_t*)&lstmex[q]; }
+          if (k == 7) for (int i = lane; i < (int)(sizeof(FxByteRec) / 4); i += 64) ((uint32_t*)&loc.rec[b & 1])[i] = ((const volatile uint32_t*)&recs[b])[i];
+        }
+        if (lane == 0) late_go = ok ? 1 : 0;
+      }
+      __syncthreads();
+      if (!late_go) return;
+    }
     FxBit u = fx_bit_dev(d, &ah, &loc, q, blpos0, lastbyte0, have0);
     float* const real_row = q + 1 < nbits ? out + (long)(q + 1) * ostride : gd->pending;
     unsigned* const row = rows + (size_t)q * FX_ROW_WORDS;
@@ -536,7 +575,7 @@ __global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_roles_kernel(FxDev* g
       if (wave == 2 || wave == 3) fx_train_rows_fast(d, &sh, u, tid - 128);
       else if (wave == 6) { if (lane == 2 || lane == 3) fxd_train_small(d, &sh, u, 10 + lane - 2); }
       else if (wave == 7) { if (lane < 6) { fxd_apm_update(d, &sh, u, lane); fx_apm_prefetch(d, &sh, u, &loc.apm, lane); } }
-      else if (wave == 5) fx_stage_ahead(&ah, &loc, bytes, recs, lstmpr, lstmex, n, q, lane);
+      else if (!LATE && wave == 5) fx_stage_ahead(&ah, &loc, bytes, recs, lstmpr, lstmex, n, q, lane);
       FX_TICK(2);
       // the full barrier of the bit: the trained rows and APM cells are stored before phase 3 / 5 read them
       __syncthreads();
@@ -555,6 +594,10 @@ __global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_roles_kernel(FxDev* g
       FX_TICK(6);
       for (int i = l.exp_mix + tid; i < FX_OUTPUTS; i += FX_DEV_THREADS) real_row[i] = loc.ex[q & 1][i];
       FX_TICK(7);
+      if (LATE && q + 1 < nbits) {   // row q + 1 is complete (roles M and U finished theirs before this update began)
+        __syncthreads();
+        if (tid == 0) late_publish(LB, LC_FX, (unsigned)(q + 2));
+      }
     }
   }
   __syncthreads();
@@ -593,6 +636,16 @@ __global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_roles_kernel(FxDev* g
     const int r0 = (int)(offsetof(FxDev, rec) / 4), r1 = r0 + (int)(sizeof(FxByteRec) / 4);
     for (int i = r0 + tid; i < r1; i += FX_DEV_THREADS) ((uint32_t*)gd)[i] = ((const uint32_t*)d)[i];
   }
+}
+
+__global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_roles_kernel(FxDev* gd, FxXfer* X, unsigned* rows, const uint8_t* bytes, const FxByteRec* recs,
+                                                                         const int16_t* lstmpr, const uint8_t* lstmex, float* out, long ostride, int n,
+                                                                         unsigned long long* prof) {
+  fx_roles_body<false>(gd, X, rows, bytes, recs, lstmpr, lstmex, out, ostride, n, prof, nullptr);
+}
+__global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_roles_late_kernel(FxDev* gd, FxXfer* X, unsigned* rows, CmxLateBox* box, const FxByteRec* recs,
+                                                                              const int16_t* lstmpr, const uint8_t* lstmex, float* out, long ostride, int n) {
+  fx_roles_body<true>(gd, X, rows, nullptr, recs, lstmpr, lstmex, out, ostride, n, nullptr, box);
 }
 
 __global__ void cmx_fxcm_pattern16_kernel(uint16_t* p, size_t n, const uint16_t* pat, int plen) {
@@ -644,6 +697,7 @@ struct cmx_fxcm {
   unsigned* d_rows = nullptr; size_t rows_cap = 0;
   hipStream_t s_up = nullptr; bool own_up = false;   // record uploads: a stream that never has a kernel in front of a copy (cmx_fxcm_set_upload_stream)
   hipEvent_t ev_up[FX_STAGE_BUFS] = {};
+  FxByteRec* late_recs[3] = {}; size_t late_cap[3] = {};   // the decoder's form (cmx_late.h): host-coherent records, three chunk slots
 };
 
 extern "C" {
@@ -664,6 +718,7 @@ void cmx_fxcm_destroy(cmx_fxcm_t* h) {
   for (hipEvent_t e : h->ev_up) if (e) (void)hipEventDestroy(e);
   if (h->own_up && h->s_up) (void)hipStreamDestroy(h->s_up);
   if (h->d_rows) (void)hipFree(h->d_rows);
+  for (FxByteRec* r : h->late_recs) cmx_late_free(r);
   if (h->parser) fxp_destroy(h->parser);
   delete h;
 }
@@ -682,6 +737,7 @@ cmx_fxcm_t* cmx_fxcm_create(const char* dictionary_path, int device) {
   ok = ok && hipMemcpy(h->d_dev, &host, sizeof(FxDev), hipMemcpyHostToDevice) == hipSuccess;
   for (int i = 0; ok && i < FX_STAGE_BUFS; i++) ok = hipEventCreateWithFlags(&h->done[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&h->ev_up[i], hipEventDisableTiming) == hipSuccess;
   ok = ok && hipFuncSetAttribute((const void*)cmx_fxcm_roles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FX_LDS_BYTES) == hipSuccess;
+  ok = ok && hipFuncSetAttribute((const void*)cmx_fxcm_roles_late_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FX_LDS_BYTES) == hipSuccess;
   ok = ok && hipMalloc((void**)&h->d_xfer, sizeof(FxXfer)) == hipSuccess && hipMemset(h->d_xfer, 0, sizeof(FxXfer)) == hipSuccess;
   const char* prof = getenv("CMX_FXCM_PROFILE");
   if (ok && prof && prof[0] == '1') ok = hipMalloc((void**)&h->d_prof, 1024) == hipSuccess && hipMemset(h->d_prof, 0, 1024) == hipSuccess;
@@ -731,6 +787,42 @@ int cmx_fxcm_run(cmx_fxcm_t* h, const uint8_t* bytes, const uint8_t* d_bytes, si
   if (hipEventRecord(h->done[b], s) != hipSuccess) { cmx_set_err("cmx_fxcm_run: event record failed"); return 1; }
   h->used[b] = true;
   h->bytes_done += nbytes;
+  return 0;
+}
+
+// ---- the decoder's form of a chunk (cmx_late.h): the kernel is launched for the next nbytes bytes, which arrive bit by bit through
+// `box`; the parser's record of a byte is written by cmx_fxcm_late_byte() when the decoder has completed it (before the byte's last
+// bit is published). hint_pr / hint_ex: the ByteModel kernel's per-update LSTM hints (host-coherent, counter LC_BM2); d_probs: rows
+// in memory the mixing network's kernel sees while both run. slot 0..2: the stage's set of record buffers for this chunk.
+int cmx_fxcm_run_late(cmx_fxcm_t* h, void* box, size_t nbytes, const int16_t* hint_pr, const uint8_t* hint_ex, float* d_probs, size_t pstride, int slot, void* stream) {
+  if (!h || !box || !hint_pr || !hint_ex || !d_probs || nbytes == 0 || nbytes > (1u << 16) || pstride < 3 + FX_OUTPUTS || slot < 0 || slot > 2) { cmx_set_err("cmx_fxcm_run_late: bad argument"); return 1; }
+  if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
+  if (h->late_cap[slot] < nbytes) {
+    if (h->late_cap[slot]) { cmx_set_err("cmx_fxcm_run_late: the chunk size may not grow"); return 1; }
+    h->late_recs[slot] = (FxByteRec*)cmx_late_alloc(nbytes * sizeof(FxByteRec));
+    if (!h->late_recs[slot]) { cmx_set_err("cmx_fxcm_run_late: record buffer allocation failed"); return 1; }
+    h->late_cap[slot] = nbytes;
+  }
+  if (h->rows_cap < nbytes) {   // grown between chunks: nothing of this stream may be in flight on the old buffer
+    if (hipDeviceSynchronize() != hipSuccess) { cmx_set_err("cmx_fxcm_run_late: device error"); return 1; }
+    if (h->d_rows) (void)hipFree(h->d_rows);
+    h->d_rows = nullptr; h->rows_cap = 0;
+    if (hipMalloc((void**)&h->d_rows, nbytes * 8 * FX_ROW_WORDS * 4) != hipSuccess) { cmx_set_err("cmx_fxcm_run_late: row buffer allocation failed"); return 1; }
+    h->rows_cap = nbytes;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync((char*)h->d_xfer + 16, 0, sizeof(FxXfer) - 16, s) != hipSuccess) { cmx_set_err("cmx_fxcm_run_late: hipMemsetAsync failed"); return 1; }
+  hipLaunchKernelGGL(cmx_fxcm_roles_late_kernel, dim3(FX_M_WGS + 2), dim3(FX_DEV_THREADS), FX_LDS_BYTES, s, h->d_dev, h->d_xfer, h->d_rows, (CmxLateBox*)box,
+                     (const FxByteRec*)h->late_recs[slot], hint_pr, hint_ex, d_probs + 3, (long)pstride, (int)nbytes);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { cmx_set_err(std::string("cmx_fxcm_run_late: ") + hipGetErrorString(e)); return 1; }
+  h->bytes_done += nbytes;
+  return 0;
+}
+// byte number b of the chunk in `slot` is complete: the parser's record of it
+int cmx_fxcm_late_byte(cmx_fxcm_t* h, int slot, size_t b, uint8_t byte) {
+  if (!h || slot < 0 || slot > 2 || b >= h->late_cap[slot]) { cmx_set_err("cmx_fxcm_late_byte: bad argument"); return 1; }
+  if (fxp_run(h->parser, &byte, 1, h->late_recs[slot] + b) != 0) { cmx_set_err("cmx_fxcm_late_byte: parser emitted a context count a map does not expect"); return 1; }
   return 0;
 }
 

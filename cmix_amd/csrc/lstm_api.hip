@@ -26,6 +26,10 @@ extern "C" __global__ void cmx_lstm_fwdblk(const LstmState, const uint8_t*, cons
 extern "C" __global__ void cmx_lstm_bpttblk(const LstmState);
 extern "C" __global__ void cmx_bytemodel_bits(const float*, const float*, const uint8_t*, size_t, float*, int*, size_t, int,
                                               float*);
+struct CmxLateBox;
+extern "C" __global__ void cmx_bytemodel_late_kernel(CmxLateBox*, size_t, const float*, const float*, const float*, const float*, const float*, const uint32_t*, uint32_t,
+                                                     const uint32_t*, uint32_t, float*, size_t, int16_t*, uint8_t*);
+extern "C" __global__ void cmx_late_bump_kernel(uint32_t*, uint32_t, uint32_t*, uint32_t);
 
 void cmx_set_err(const std::string& s);  // cmx_api.hip
 
@@ -279,6 +283,29 @@ int cmx_bytemodel_bits_run(int device, const float* d_dist0, const float* d_dist
   if (e != hipSuccess) { cmx_set_err(std::string("cmx_bytemodel_bits_run: ") + hipGetErrorString(e)); return 1; }
   return 0;
 }
+
+// The decoder's form (cmx_late.h): ByteModel::Predict / Perceive of the stream's three byte-level distributions bit by bit as the
+// bits arrive through `box` -> layer-0 columns 0, 2076, 2077 and the fxcm stage's LSTM hints (see cmx_bytemodel_late_kernel).
+int cmx_bytemodel_late_run(int device, void* box, size_t nbytes, const float* brk0, const float* brk, const float* ppmd, const float* lstm0, const float* lstm,
+                           const uint32_t* c0_brk, uint32_t c0_brk_want, const uint32_t* c0_lstm, uint32_t c0_lstm_want, float* layer0, size_t pstride,
+                           int16_t* hint_pr, uint8_t* hint_ex, void* stream) {
+  if (!box || !nbytes || !brk0 || !brk || !ppmd || !lstm0 || !lstm || !layer0 || !hint_pr || !hint_ex) { cmx_set_err("cmx_bytemodel_late_run: bad argument"); return 1; }
+  if (hipSetDevice(device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
+  hipLaunchKernelGGL(cmx_bytemodel_late_kernel, dim3(1), dim3(192), 0, (hipStream_t)stream, (CmxLateBox*)box, nbytes, brk0, brk, ppmd, lstm0, lstm, c0_brk, c0_brk_want,
+                     c0_lstm, c0_lstm_want, layer0, pstride, hint_pr, hint_ex);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { cmx_set_err(std::string("cmx_bytemodel_late_run: ") + hipGetErrorString(e)); return 1; }
+  return 0;
+}
+// one system-scope store behind everything already in `stream`: *counter = value (and *counter2 = value2 when given)
+int cmx_late_bump(int device, uint32_t* counter, uint32_t value, uint32_t* counter2, uint32_t value2, void* stream) {
+  if (!counter) { cmx_set_err("cmx_late_bump: bad argument"); return 1; }
+  if (hipSetDevice(device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
+  hipLaunchKernelGGL(cmx_late_bump_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, value, counter2, value2);
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+// the distribution the LSTM byte mixer holds between bytes (DEVICE memory, [256]; uniform until the first byte)
+const float* cmx_lstm_byte_probs(cmx_lstm_t* h) { return h ? h->h_state.byte_probs : nullptr; }
 
 // Bit-synchronous mode: ByteModel::Predict for bit `k` (0..7) of the byte whose top k bits are the coded ones:
 // d_bit_p[k * stride] (and *d_p_copy, may be NULL) <- the value, d_bit_ex[k] <- `ex` when given.

@@ -18,6 +18,7 @@
 #include <stdint.h>
 #include "cmx_libm.h"
 #include "lstm_state.h"
+#include "cmx_late.h"
 
 namespace {
 
@@ -165,5 +166,81 @@ extern "C" __global__ void cmx_bytemodel_bits(const float* dist0, const float* d
     }
     if ((byte >> (7 - k)) & 1) bot = mid + 1;
     else top = mid;
+  }
+}
+
+// ---- ByteModel::Predict / Perceive for a DECODER (cmx_late.h): the three byte-level distributions of the stream -- Bracket's
+//      (layer-0 column 0), PPMd's (2076), the LSTM byte mixer's (2077) -- one wavefront each, bit by bit as the bits arrive.
+//      Wave 2 also forms what Predictor::Perceive leaves in lstmpr / lstmex (predictor.cpp:180-182,462-465) for the fxcm stage:
+//      hint[q] = Discretize(p of bit q + 1), `ex` at that moment, q = chunk-local update; entry 8 nbytes - 1 comes from the
+//      distribution after the chunk's last byte. Counters: LC_BM0/1/2 = rows whose column is written (LC_BM2 = r also means
+//      hint[r - 2] is there). A distribution after byte n - 1 is awaited on its producer's counter (Bracket: LC_BRK of the context
+//      kernel; LSTM: LC_LSTM, bumped behind the byte's LSTM launch; PPMd: a host record, in place once the byte's last bit is
+//      published); the one going into the chunk on the previous chunk's counters (c0_*: may be null).
+extern "C" __global__ void __launch_bounds__(192)
+cmx_bytemodel_late_kernel(CmxLateBox* B, size_t nbytes, const float* brk0, const float* brk, const float* ppmd, const float* lstm0,
+                          const float* lstm, const uint32_t* c0_brk, uint32_t c0_brk_want, const uint32_t* c0_lstm, uint32_t c0_lstm_want,
+                          float* layer0, size_t pstride, int16_t* hint_pr, uint8_t* hint_ex) {
+  __shared__ float prs[3][256];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* const pr = prs[w];
+  const int col = w == 0 ? 0 : w == 1 ? 2076 : 2077;
+  const int which = w == 0 ? LC_BM0 : w == 1 ? LC_BM1 : LC_BM2;
+  const size_t T = 8 * nbytes;
+  for (size_t n = 0; n <= nbytes; ++n) {
+    if (n == nbytes && w != 2) break;   // the entry after the chunk's last bit: the LSTM hint only
+    const float* d;
+    bool ok = true;
+    if (n == 0) {
+      ok = late_wait_ge(B, &B->start, 1u);
+      if (ok && w == 0 && c0_brk) ok = late_wait_ge(B, c0_brk, c0_brk_want);
+      if (ok && w == 2 && c0_lstm) ok = late_wait_ge(B, c0_lstm, c0_lstm_want);
+      d = w == 0 ? brk0 : w == 1 ? ppmd : lstm0;
+    } else {
+      if (w == 0) { ok = late_wait_cnt(B, LC_BRK, (uint32_t)n); d = brk + (n - 1) * 256; }
+      else if (w == 1) { ok = late_wait_ge(B, &B->nknown, (uint32_t)(8 * n)); d = ppmd + n * 256; }
+      else { ok = late_wait_cnt(B, LC_LSTM, (uint32_t)n); d = lstm + (n - 1) * 256; }
+    }
+    if (!ok) return;
+    asm volatile("" ::: "memory");
+    for (int i = lane; i < 256; i += 64) pr[i] = *(volatile const float*)(d + i);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    int top = 255, bot = 0;
+    for (int k = 0; k < 8; ++k) {
+      const size_t t = 8 * n + k;
+      const int mid = bot + ((top - bot) / 2);
+      if (lane == 0) {   // byte-model.cpp:8-24
+        float num = 0.0f;
+        for (int i = mid + 1; i <= top; ++i) num = fadd(num, pr[i]);
+        float denom = num;
+        for (int i = bot; i <= mid; ++i) denom = fadd(denom, pr[i]);
+        const float p = denom == 0.0f ? 0.5f : fdiv(num, denom);
+        if (n < nbytes) layer0[t * pstride + col] = p;
+        if (w == 2 && t > 0) {
+          int ex = bot;
+          float mx = pr[bot];
+          for (int i = bot + 1; i <= top; ++i)
+            if (pr[i] > mx) { mx = pr[i]; ex = i; }
+          const float prod = fmul(4094.0f, p);     // Discretize (predictor.cpp:180-182): the product is rounded to float, then 1 is added
+          hint_pr[t - 1] = (int16_t)(unsigned)fadd(1.0f, prod);
+          hint_ex[t - 1] = (uint8_t)ex;
+        }
+        late_publish(B, which, (uint32_t)(t + 1));
+      }
+      if (n == nbytes) break;
+      const int bit = late_y(B, (int)t + 1);
+      if (bit < 0) return;
+      if (bit) bot = mid + 1; else top = mid;   // ByteModel::Perceive (byte-model.cpp:30-37)
+    }
+  }
+  (void)T;
+}
+
+// one store behind whatever is in front of it in the stream: the late pipeline's "the LSTM distribution of byte n is there"
+extern "C" __global__ void cmx_late_bump_kernel(uint32_t* counter, uint32_t value, uint32_t* counter2, uint32_t value2) {
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(counter, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (counter2) __hip_atomic_store(counter2, value2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }

@@ -22,6 +22,7 @@
 // critical recurrence per bit is  chain -> extras -> u -> first product segment.
 // Every spin is bounded; a timeout sets S->error and unwinds all roles.
 #include "mixnet_dev.h"
+#include "cmx_late.h"
 
 namespace {
 
@@ -43,6 +44,8 @@ struct Ctl {
   int tail_done;
   int abort;
   int b_in, b_done;   // cmx_mixnet_spec_kernel: bit + 1 handed from the layer-1 wave to the layer-2 / SSE wave, and finished by it
+  int bit_epoch;      // late mode (a decoder, cmx_late.h): bit + 1 whose value the output wave has received from the host and put into Lds::bitring
+  unsigned late_lo, late_hi;   // late mode: the box's address (0: a compressor's chunk) -- waits that depend on the decoder are bounded by wall-clock time, not by a spin count
 };
 
 struct BitRec {            // written by the scout for bit t (slot t % 3)
@@ -83,6 +86,8 @@ struct Lds {
   const uint16_t* lsq;  //   sit on the tail wave's path); nullptr: read them from global memory
   int* sdone;       // [rr] cmx_mixnet_spec_kernel: bit + 1 whose stretched inputs a stretch wave has published
   float* h2;        // [2][64] cmx_mixnet_spec_kernel: the layer-2 inputs of a bit (49) + bit, lstm_p, layer-2 row, from tail_a_role to tail_b_role
+  int* bitring;     // [8] late mode: the decoded bits, slot bit % 8 (Ctl::bit_epoch)
+  CmxLateBox* late; // late mode: the decoder's box; nullptr: every bit of the chunk is known (compression)
 };
 
 // All inter-wave traffic of this kernel goes through LDS, so its synchronisation only has to
@@ -114,12 +119,26 @@ __device__ __forceinline__ void touch_line(gptr<const float> g, unsigned lds_dst
 __device__ __forceinline__ int ld_acq(const int* p) { return lds_poll(p); }
 __device__ __forceinline__ void st_rel(int* p, int v) { lds_publish_store(p, v); }
 // Wave-uniform bounded spin until *p >= target. Returns false on abort/timeout.
+// late mode: what the wave waits for may depend on the decoder (host); then only the box's abort / fail words and 30 s of wall-clock time end the wait
+__device__ __forceinline__ CmxLateBox* ctl_box(Ctl* ctl) {
+  const unsigned lo = (unsigned)lds_poll((const int*)&ctl->late_lo), hi = (unsigned)lds_poll((const int*)&ctl->late_hi);
+  return reinterpret_cast<CmxLateBox*>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ bool late_expired(CmxLateBox* B, unsigned long long& t0) {
+  if (late_ld(&B->abort) || late_ld(&B->fail)) return true;
+  const unsigned long long now = wall_clock64();
+  if (!t0) { t0 = now; return false; }
+  if (now - t0 > CMX_LATE_TIMEOUT_TICKS) { late_st(&B->fail, 1u); return true; }
+  return false;
+}
 __device__ __forceinline__ bool wait_ge(Ctl* ctl, const int* p, int target, bool sleepy) {
   unsigned spins = 0;
+  unsigned long long t0 = 0;
   while (lds_poll(p) < target) {
     if (sleepy) __builtin_amdgcn_s_sleep(2);
     if ((++spins & 1023u) == 0) {
-      if (lds_poll(&ctl->abort) || spins > SPIN_LIMIT) {
+      CmxLateBox* const B = ctl_box(ctl);
+      if (lds_poll(&ctl->abort) || (B ? late_expired(B, t0) : spins > SPIN_LIMIT)) {
         lds_publish_store(&ctl->abort, 1);
         return false;
       }
@@ -1019,7 +1038,7 @@ __device__ void tail_a_role(MixState* S, const Lds& L, const float* decay1, int 
     if (!wait_ge(L.ctl, &L.ctl->tail_in, t + 1, false)) return;
     TPROF(7);
     const TailRec* tr = L.trec + (t & 1);
-    const int bit = tr->bit;
+    int bit = tr->bit;   // (late mode: not known yet -- awaited below, where layer 1 learns)
     float* const in2 = L.h2 + 64 * (t & 1);   // this bit's layer-2 inputs: built here, read by tail_b_role
     if (k < CMX_MIX0) in2[k] = tr->out0[k];
     if (k < 3) in2[CMX_MIX0 + CMX_MIX1 + k] = tr->aux3[k];
@@ -1048,6 +1067,10 @@ __device__ void tail_a_role(MixState* S, const Lds& L, const float* decay1, int 
     __builtin_amdgcn_wave_barrier();
     st_rel(&L.ctl->b_in, t + 1);
     TPROF(8);
+    if (L.late) {   // the decoder's bit: the output wave (tail_b_role) receives it after p has gone out
+      if (!wait_ge(L.ctl, &L.ctl->bit_epoch, t + 1, false)) return;
+      bit = L.bitring[t & 7];
+    }
     // ---- Mixer::Perceive, layer 1 ----
     if (is1) {
       const float decay = (float)(d1 * (1.5 - ((1.0 * (double)rs1) / (double)mx1)));
@@ -1132,7 +1155,7 @@ __device__ void tail_b_role(MixState* S, const Lds& L, const float* decay1, int 
     if (!wait_ge(L.ctl, &L.ctl->b_in, t + 1, false)) return;
     TPROF(0);
     const float* const in2 = L.h2 + 64 * (t & 1);
-    const int bit = __float_as_int(in2[49]);
+    int bit = __float_as_int(in2[49]);
     {  // layer 2 has one weight set in cmix (selector = zero_context_); a changing key is still honoured
       const uint32_t newrow2 = (uint32_t)__float_as_int(in2[51]);
       if (newrow2 != cur_row2) {
@@ -1192,6 +1215,16 @@ __device__ void tail_b_role(MixState* S, const Lds& L, const float* decay1, int 
       const float lp = in2[50];
       if (lp == 0.0f || lp == 1.0f) pf = lp;               // predictor.cpp:383,415-417
       as_global(p_out)[t] = pf;
+      if (L.late) {
+        // Decoder::Decode (decoder.cpp:20-39): p goes to the host (value | tag, one 8-byte store into its mapped memory); the arithmetic
+        // decoder turns it into the bit, which comes back through the box and is handed to the waves that learn from it
+        __hip_atomic_store(&L.late->p_word[t % CMX_LATE_P_RING], ((unsigned long long)(unsigned)(t + 1) << 32) | (unsigned)__float_as_int(pf), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+        bit = late_y(L.late, t + 1);
+        if (bit < 0) { lds_publish_store(&L.ctl->abort, 1); bit = 0; }
+        L.bitring[t & 7] = bit;
+        st_rel(&L.ctl->bit_epoch, t + 1);
+      }
       // ---- SSE::Perceive (sse.cpp:291-306,326-328) ----
       e6.update(c6, bit, 106);
       e7.update(c7, bit, 127);
@@ -1214,6 +1247,7 @@ __device__ void tail_b_role(MixState* S, const Lds& L, const float* decay1, int 
       if (mix_out) as_global(mix_out)[(size_t)t * CMX_MIXERS + CMX_MIXERS - 1] = p2_;
       ++steps_done;
     }
+    if (L.late && lds_poll(&L.ctl->abort)) return;   // (uniform: the decoder has left)
     TPROF(1);
     u2 = bcast_lane(u2, 0);
     df2 = __builtin_amdgcn_readlane(df2, 0);
@@ -1304,7 +1338,7 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
-__device__ void helper_role(MixState* S, SpecXfer* X, HelperLds* H, int nbits, int m, int w, int lane, bool tol) {
+__device__ void helper_role(MixState* S, SpecXfer* X, HelperLds* H, int nbits, int m, int w, int lane, bool tol, CmxLateBox* LB) {
   const gptr<float> rows0 = as_global(S->rows0);
   const int base = 512 * w;                 // first element of this wave's segment
   const int nseg = w == 3 ? CMX_IN0 - 1536 : 512;
@@ -1317,14 +1351,18 @@ __device__ void helper_role(MixState* S, SpecXfer* X, HelperLds* H, int nbits, i
   uint32_t cur_base = 0;
   bool f_chg = false; uint32_t f_base = 0;   // of the bit fetched last: its selector changes, and to which row (read off the serial path)
   auto failed = [&]() { return lds_poll(&H->abort) != 0; };
+  unsigned long long late_t0 = 0;
+  // has a wait for the main workgroup run out? a compressor's: by spin count; a decoder's (the wait then includes the host): by its box
+  auto spun_out = [&](unsigned spins) { return LB ? late_expired(LB, late_t0) : spins > SPEC_SPIN; };
   auto give_up = [&]() { lds_publish_store(&H->abort, 1); __hip_atomic_store(&X->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   // fetch the inputs of bit t (this wave's slice) and, if its selector changes, the incoming row
   auto fetch = [&](int t) -> bool {
     unsigned spins = 0;
     while (ld_u32(&X->scout_epoch) < (unsigned)(t + 1)) {
       __builtin_amdgcn_s_sleep(1);
-      if ((++spins & 1023u) == 0 && (spins > SPEC_SPIN || failed() || ld_u32(&X->fail))) { give_up(); return false; }
+      if ((++spins & 1023u) == 0 && (spun_out(spins) || failed() || ld_u32(&X->fail))) { give_up(); return false; }
     }
+    late_t0 = 0;
     const int slot = t % CMX_SPEC_RING;
     const float* gx = X->xs[slot] + base;
 #pragma unroll
@@ -1348,8 +1386,9 @@ __device__ void helper_role(MixState* S, SpecXfer* X, HelperLds* H, int nbits, i
       unsigned long long v;
       unsigned spins = 0;
       while ((unsigned)((v = ld_u64(&X->u[m])) >> 33) != (unsigned)t) {
-        if ((++spins & 1023u) == 0 && (spins > SPEC_SPIN || failed() || ld_u32(&X->fail))) { give_up(); return; }
+        if ((++spins & 1023u) == 0 && (spun_out(spins) || failed() || ld_u32(&X->fail))) { give_up(); return; }
       }
+      late_t0 = 0;
       const float u = __int_as_float((int)(unsigned)v);
       const bool df = ((v >> 32) & 1ull) != 0;
 #pragma unroll
@@ -1470,13 +1509,18 @@ __device__ void stretch_role(MixState* S, const Lds& L, SpecXfer* X, const float
     if (t >= L.rr && !wait_ge(L.ctl, &L.ctl->tail_done, t - L.rr + 1, true)) return;             // rec slot t % rr is free (see scout_role)
     BitRec* rec = L.rec + (t % L.rr);
     const gptr<const float> pr = gprobs + (size_t)t * CMX_IN0;
+    if (L.late) {   // a decoder: row t exists once every producing stage has counted it (cmx_late.h), one lane per counter
+      bool ok = true;
+      if (lane <= LC_P8) ok = late_wait_cnt(L.late, lane, (uint32_t)(t + 1));
+      if (__ballot(!ok)) { lds_publish_store(&L.ctl->abort, 1); return; }
+    }
     float pv[33];
 #pragma unroll
     for (int r = 0; r < 33; ++r) {
       int i = r * 64 + lane;
       pv[r] = i < CMX_IN0 ? pr[i] : 0.5f;
     }
-    const int bitv = bits[t];
+    const int bitv = L.late ? 0 : (int)bits[t];   // (late: not known yet; the waves that learn wait for it)
     const float lstm_raw = bcast_lane(pv[32], 29);   // probs[t][2077]
 #pragma unroll
     for (int r = 0; r < 33; ++r) {   // MixerInput::SetInput (mixer-input.cpp:11-15) + Sigmoid::Logit (sigmoid.cpp:12-17)
@@ -1521,6 +1565,7 @@ __device__ void select_role(MixState* S, const Lds& L, SpecXfer* X, const uint32
   for (int t = 0; t < nbits; ++t) {
     uint32_t key = lane < CMX_MIXERS ? gsel[(size_t)t * CMX_MIXERS + lane] : 0;
     if (!wait_ge(L.ctl, &L.sdone[t % L.rr], t + 1, true)) return;
+    if (L.late && lane < CMX_MIXERS) key = gsel[(size_t)t * CMX_MIXERS + lane];   // a decoder: the row's selectors exist only now
     BitRec* rec = L.rec + (t % L.rr);
     const BitRec* prev = L.rec + ((t + L.rr - 1) % L.rr);
     if (lane == CMX_AUX) key = rec->auxkey;
@@ -1620,13 +1665,14 @@ __device__ void gather_role(MixState* S, const Lds& L, SpecXfer* X, const float*
     {
       bool have = !is0;
       unsigned spins = 0;
+      unsigned long long gt0 = 0;
       while (true) {
         if (!have) {
           const unsigned long long v = ld_u64(&X->sum[mm]);
           if ((unsigned)(v >> 32) == (unsigned)(t + 1)) { pm = __int_as_float((int)(unsigned)v); have = true; }
         }
         if (__ballot(!have) == 0) break;
-        if ((++spins & 1023u) == 0 && (spins > SPEC_SPIN || lds_poll(&L.ctl->abort) || ld_u32(&X->fail))) {
+        if ((++spins & 1023u) == 0 && ((L.late ? late_expired(L.late, gt0) : spins > SPEC_SPIN) || lds_poll(&L.ctl->abort) || ld_u32(&X->fail))) {
           lds_publish_store(&L.ctl->abort, 1);
           __hip_atomic_store(&X->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           return;
@@ -1644,20 +1690,30 @@ __device__ void gather_role(MixState* S, const Lds& L, SpecXfer* X, const float*
     const float p_ = fadd(pm, e);
     const float myout = clamp_out(p_, smin, smax);
     GPROF(3);
-    float uu = fmul(dlr, fsub(cmx_logistic_t(p_, L.exptab), (float)bit));   // Mixer::Perceive scalar (mixer.cpp:56-64)
+    int bitv = bit;
+    auto hand_to_tail = [&]() -> bool {
+      if (t >= 2 && !wait_ge(L.ctl, &L.ctl->tail_done, t - 1, false)) return false;
+      TailRec* tr = L.trec + (t & 1);
+      if (is0) tr->out0[m] = myout;
+      if (m >= CMX_MIX0 && m < CMX_MIXERS) tr->rowidx[m - CMX_MIX0] = rec->rowidx[m];
+      if (m < 3) tr->aux3[m] = rec->aux3[m];
+      if (m == 0) { tr->lstm_p = rec->lstm_p; tr->bit = bit; }
+      st_rel(&L.ctl->tail_in, t + 1);
+      return true;
+    };
+    if (L.late) {   // a decoder: the bit is an output of the arithmetic decoder, which needs p -- the tail waves first, then the wait
+      if (!hand_to_tail()) return;
+      if (!wait_ge(L.ctl, &L.ctl->bit_epoch, t + 1, false)) return;
+      bitv = L.bitring[t & 7];
+    }
+    float uu = fmul(dlr, fsub(cmx_logistic_t(p_, L.exptab), (float)bitv));   // Mixer::Perceive scalar (mixer.cpp:56-64)
     ++rsteps;
     if (rsteps > mx) mx = rsteps;
     const bool dfl = (rsteps & 1023) == 0;
     if (is0) st_u64(&X->u[m], ((unsigned long long)(2u * (unsigned)(t + 1) + (dfl ? 1u : 0u)) << 32) | (unsigned)__float_as_int(uu));
     GPROF(4);
-    if (t >= 2 && !wait_ge(L.ctl, &L.ctl->tail_done, t - 1, false)) return;
+    if (!L.late && !hand_to_tail()) return;
     GPROF(12);
-    TailRec* tr = L.trec + (t & 1);
-    if (is0) tr->out0[m] = myout;
-    if (m >= CMX_MIX0 && m < CMX_MIXERS) tr->rowidx[m - CMX_MIX0] = rec->rowidx[m];
-    if (m < 3) tr->aux3[m] = rec->aux3[m];
-    if (m == 0) { tr->lstm_p = rec->lstm_p; tr->bit = bit; }
-    st_rel(&L.ctl->tail_in, t + 1);
     if (is0 && mix_out) as_global(mix_out)[(size_t)t * CMX_MIXERS + m] = p_;
 #pragma unroll
     for (int j = 0; j < CMX_MIX0; ++j) {      // extra weights: ew[j] -= u * out_j (mixer.cpp:67,70)
@@ -1709,7 +1765,7 @@ extern "C" __global__ __launch_bounds__(NTHREADS) void cmx_mixnet_chunk_kernel(
   L.prod = smem;                                                  // 2 * PBUF
   L.xs = L.prod + 2 * PBUF;                                       // 3 * XS
   L.rec = reinterpret_cast<BitRec*>(L.xs + 3 * XS);               // 3
-  L.rr = 3; L.lead = 2; L.lst = nullptr; L.lsq = nullptr; L.sdone = nullptr; L.h2 = nullptr;
+  L.rr = 3; L.lead = 2; L.lst = nullptr; L.lsq = nullptr; L.sdone = nullptr; L.h2 = nullptr; L.bitring = nullptr; L.late = nullptr;
   L.trec = reinterpret_cast<TailRec*>(L.rec + 3);                 // 2
   L.upd = reinterpret_cast<float*>(L.trec + 2);                   // 32
   L.dflag = reinterpret_cast<uint32_t*>(L.upd + 32);              // 32
@@ -1743,7 +1799,8 @@ extern "C" __global__ __launch_bounds__(NTHREADS) void cmx_mixnet_chunk_kernel(
 extern "C" __global__ __launch_bounds__(CMX_SPEC_THREADS) void cmx_mixnet_spec_kernel(
     MixState* __restrict__ S, SpecXfer* __restrict__ X, const float* __restrict__ probs, const uint32_t* __restrict__ sel,
     const uint8_t* __restrict__ bits, const float* __restrict__ decay1, int nbits,
-    float* __restrict__ p_out, float* __restrict__ mix_out, int mode) {
+    float* __restrict__ p_out, float* __restrict__ mix_out, int mode, CmxLateBox* box) {
+  // box != nullptr: a decoder's chunk (cmx_late.h) -- `bits` is unused, rows / selectors arrive as their stages count them, p goes to the box
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -1751,7 +1808,7 @@ extern "C" __global__ __launch_bounds__(CMX_SPEC_THREADS) void cmx_mixnet_spec_k
     HelperLds* H = reinterpret_cast<HelperLds*>(smem);
     for (int i = tid; i < (int)(sizeof(HelperLds) / 4); i += CMX_SPEC_THREADS) reinterpret_cast<int*>(H)[i] = 0;
     __syncthreads();
-    if (wave < 4) helper_role(S, X, H, nbits, (int)blockIdx.x - 1, wave, lane, (mode & 0x1000) != 0);
+    if (wave < 4) helper_role(S, X, H, nbits, (int)blockIdx.x - 1, wave, lane, (mode & 0x1000) != 0, box);
     return;
   }
   Lds L;
@@ -1772,10 +1829,14 @@ extern "C" __global__ __launch_bounds__(CMX_SPEC_THREADS) void cmx_mixnet_spec_k
   uint16_t* lst = reinterpret_cast<uint16_t*>(L.sdone + 8);       // 2 x 32768 u16: the SSE's t_st / t_sq on chip
   L.lst = lst; L.lsq = lst + 32768;
   L.h2 = reinterpret_cast<float*>(lst + 65536);                   // 2 x 64
+  L.bitring = reinterpret_cast<int*>(L.h2 + 128);                 // 8
+  L.late = box;
   for (int i = tid; i < 32768; i += CMX_SPEC_THREADS) reinterpret_cast<uint32_t*>(lst)[i] = i < 16384 ? reinterpret_cast<const uint32_t*>(S->t_st)[i] : reinterpret_cast<const uint32_t*>(S->t_sq)[i - 16384];
   if (tid < 32) { L.upd[tid] = 0.0f; L.dflag[tid] = 0; L.exptab[tid] = cmx_exp2f_tab[tid]; }
   if (tid < 8) L.sdone[tid] = 0;
   if (tid < (int)(sizeof(Ctl) / 4)) reinterpret_cast<int*>(L.ctl)[tid] = 0;
+  __syncthreads();
+  if (tid == 0) { L.ctl->late_lo = (unsigned)(unsigned long long)box; L.ctl->late_hi = (unsigned)((unsigned long long)box >> 32); }
   __syncthreads();
   const bool prof = (mode & 4) != 0;
   if (wave == 0) gather_role(S, L, X, decay1, nbits, mix_out, prof, lane);

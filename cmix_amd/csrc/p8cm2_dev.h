@@ -187,10 +187,11 @@ P8_HD void p8d_run(P8Cm2Dev* d, P8Cm2Shared* sh, const P8Cm2Bit& u, int i) {   /
   }
 }
 // uniform values of step t of a chunk: y = the bit coded before it, bits / last_byte as ContextMap2::Update leaves them
-P8_HD P8Cm2Bit p8d_bit(const P8Cm2Dev* d, const uint32_t* ctx, const uint16_t* chk, const uint8_t* bits_in, int16_t* out, int t, uint32_t* run_bits, int* last_y) {
+// y: the bit before step t (a compressor reads it from the chunk's bits, a decoder from its box: cmx_late.h)
+P8_HD P8Cm2Bit p8d_bit_y(const P8Cm2Dev* d, const uint32_t* ctx, const uint16_t* chk, int y, int16_t* out, int t, uint32_t* run_bits) {
   const int C = d->C;
   P8Cm2Bit u;
-  u.y = *last_y;
+  u.y = y;
   u.bpos = t & 7;
   *run_bits += *run_bits + (uint32_t)u.y;
   u.last_byte = (uint8_t)(*run_bits & 0xFF);
@@ -199,6 +200,10 @@ P8_HD P8Cm2Bit p8d_bit(const P8Cm2Dev* d, const uint32_t* ctx, const uint16_t* c
   u.ctx = ctx + (size_t)(t >> 3) * (size_t)C;
   u.chk = chk + (size_t)(t >> 3) * (size_t)C;
   u.out = out + (size_t)t * (size_t)d->row_stride;
+  return u;
+}
+P8_HD P8Cm2Bit p8d_bit(const P8Cm2Dev* d, const uint32_t* ctx, const uint16_t* chk, const uint8_t* bits_in, int16_t* out, int t, uint32_t* run_bits, int* last_y) {
+  const P8Cm2Bit u = p8d_bit_y(d, ctx, chk, *last_y, out, t, run_bits);
   *last_y = bits_in[t];
   return u;
 }

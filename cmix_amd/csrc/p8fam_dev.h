@@ -608,15 +608,14 @@ P8_HD void p8f_reload(const P8CmDev* d, P8FamShared* sh, int s) {
 // order value are read once, at its first step (nine loads that do not depend on each other) -- rebuilding c0 from up to seven already-coded bits and
 // re-reading the order value from global memory at EVERY step cost ~2 k clocks of the family kernel's 17 k per bit. Chunks are whole bytes: bits_in[t .. t + 7] exist.
 struct P8FamRun { int last_y, c1, lk, c0; uint32_t bits8; int order, nslots, row_stride; };   // nslots / row_stride: d's, read once
-P8_HD P8FamUni p8f_uni_inc(const P8CmDev* d, const uint32_t* ctx, const uint16_t* chk, const uint8_t* bits_in, int16_t* out, const uint8_t* order, int t, P8FamRun* st,
-                           uint32_t rnd_i) {
+// head: the step's uniform values from the run registers (at a byte's first step the order-N map's value of the step, c0 = 1);
+// tail: the step's own bit shifted into them. A compressor runs both per step (p8f_uni_inc: the byte's bits are read once per
+// byte); a decoder runs the tail of step t - 1 when bit t - 1 arrives, just before the head of step t (cmx_p8s_fam2_kernel<true>).
+P8_HD P8FamUni p8f_uni_head(const uint32_t* ctx, const uint16_t* chk, int16_t* out, const uint8_t* order, int t, P8FamRun* st, uint32_t rnd_i) {
   P8FamUni u;
   const int bp = t & 7, nslots = st->nslots;
-  (void)d;
   if (bp == 0) {
-    const uint32_t b0 = bits_in[t], b1 = bits_in[t + 1], b2 = bits_in[t + 2], b3 = bits_in[t + 3], b4 = bits_in[t + 4], b5 = bits_in[t + 5], b6 = bits_in[t + 6], b7 = bits_in[t + 7];
     st->order = order ? order[t] : 0;
-    st->bits8 = (b0 & 1) | (b1 & 1) << 1 | (b2 & 1) << 2 | (b3 & 1) << 3 | (b4 & 1) << 4 | (b5 & 1) << 5 | (b6 & 1) << 6 | (b7 & 1) << 7;
     st->c0 = 1;
   }
   u.y = st->last_y; u.bp = bp; u.c0 = st->c0; u.c1 = st->c1; u.t = t; u.rnd_i = rnd_i;
@@ -626,10 +625,23 @@ P8_HD P8FamUni p8f_uni_inc(const P8CmDev* d, const uint32_t* ctx, const uint16_t
   u.out = out + (size_t)t * (size_t)st->row_stride;
   if (bp == 0 || bp == 2 || bp == 5) ++st->lk;
   u.lk = st->lk;
-  const int bit = (int)((st->bits8 >> bp) & 1u);
+  return u;
+}
+P8_HD void p8f_uni_tail(P8FamRun* st, int bp, int bit) {
   st->last_y = bit;
   if (bp == 7) st->c1 = (st->c0 * 2 + bit) & 0xff;
   st->c0 = st->c0 * 2 + bit;
+}
+P8_HD P8FamUni p8f_uni_inc(const P8CmDev* d, const uint32_t* ctx, const uint16_t* chk, const uint8_t* bits_in, int16_t* out, const uint8_t* order, int t, P8FamRun* st,
+                           uint32_t rnd_i) {
+  const int bp = t & 7;
+  (void)d;
+  if (bp == 0) {
+    const uint32_t b0 = bits_in[t], b1 = bits_in[t + 1], b2 = bits_in[t + 2], b3 = bits_in[t + 3], b4 = bits_in[t + 4], b5 = bits_in[t + 5], b6 = bits_in[t + 6], b7 = bits_in[t + 7];
+    st->bits8 = (b0 & 1) | (b1 & 1) << 1 | (b2 & 1) << 2 | (b3 & 1) << 3 | (b4 & 1) << 4 | (b5 & 1) << 5 | (b6 & 1) << 6 | (b7 & 1) << 7;
+  }
+  const P8FamUni u = p8f_uni_head(ctx, chk, out, order, t, st, rnd_i);
+  p8f_uni_tail(st, bp, (int)((st->bits8 >> bp) & 1u));
   return u;
 }
 #endif

@@ -515,21 +515,32 @@ void p8f_front_free(P8Front* f) {
 }
 const P8Layout* p8f_front_layout(const P8Front* f) { return &f->emit.L; }
 
-int p8f_front_run(P8Front* f, const uint8_t* bytes, size_t nbytes, P8Chunk* out) {
+/* One step: the records of the stream's next step (Predictor::update after the bit handed in last) into row `step_row` of `out`
+ * (its byte-level arrays: row step_row >> 3). A compressor's chunk is a loop of these over known bits (p8f_front_run); a decoder
+ * calls p8f_front_emit_step() for step t + 1 as soon as it has decoded bit t and told the front end (p8f_front_set_bit). */
+int p8f_front_emit_step(P8Front* f, P8Chunk* out, size_t step_row) {
   if (f->err) return f->err;
   bind(f);
-  for (size_t i = 0; i < 8 * nbytes; ++i, ++f->steps) {
-    const int bit = (bytes[i >> 3] >> (7 - (i & 7))) & 1;
-    p8f_emit_begin_step(&f->emit, f->p->in, out, i >> 3, i, f->steps >= 8);
-    if (f->steps == 0) {   /* no step 0: the first prediction is the constructor's */
-      memset(out->sel + i * P8_NSEL, 0, P8_NSEL * sizeof(int32_t));
-      memset(&out->apm[i], 0, sizeof(P8ApmRec));
-    } else {
-      const int rc = front_step(f, f->last_bit, out->sel + i * P8_NSEL, &out->apm[i]);
-      if (rc < 0 || f->emit.err) { f->err = rc < 0 ? rc : P8F_ERR_INTERNAL; return f->err; }
-      p8f_emit_directs(&f->emit);
-    }
-    f->last_bit = bit;
+  p8f_emit_begin_step(&f->emit, f->p->in, out, step_row >> 3, step_row, f->steps >= 8);
+  if (f->steps == 0) {   /* no step 0: the first prediction is the constructor's */
+    memset(out->sel + step_row * P8_NSEL, 0, P8_NSEL * sizeof(int32_t));
+    memset(&out->apm[step_row], 0, sizeof(P8ApmRec));
+  } else {
+    const int rc = front_step(f, f->last_bit, out->sel + step_row * P8_NSEL, &out->apm[step_row]);
+    if (rc < 0 || f->emit.err) { f->err = rc < 0 ? rc : P8F_ERR_INTERNAL; return f->err; }
+    p8f_emit_directs(&f->emit);
+  }
+  ++f->steps;
+  return 0;
+}
+void p8f_front_set_bit(P8Front* f, int bit) { f->last_bit = bit ? 1 : 0; }
+
+int p8f_front_run(P8Front* f, const uint8_t* bytes, size_t nbytes, P8Chunk* out) {
+  if (f->err) return f->err;
+  for (size_t i = 0; i < 8 * nbytes; ++i) {
+    const int rc = p8f_front_emit_step(f, out, i);
+    if (rc) return rc;
+    p8f_front_set_bit(f, (bytes[i >> 3] >> (7 - (i & 7))) & 1);
   }
   return 0;
 }

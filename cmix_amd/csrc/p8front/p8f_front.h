@@ -18,6 +18,10 @@ const P8Layout* p8f_front_layout(const P8Front* f);
 /* the next nbytes bytes of the stream = the next 8 nbytes steps; fills every array of `out` (sized for nbytes).
  * 0, or a negative P8F_ERR_* (a block type outside the stage's scope, or an internal inconsistency). */
 int p8f_front_run(P8Front* f, const uint8_t* bytes, size_t nbytes, P8Chunk* out);
+/* the same one step at a time (a decoder): emit the records of the next step into row step_row of `out`, then tell the front end
+ * the bit that was coded with them. p8f_front_run() is a loop of the two. */
+int p8f_front_emit_step(P8Front* f, P8Chunk* out, size_t step_row);
+void p8f_front_set_bit(P8Front* f, int bit);
 const char* p8f_strerror(int code);
 /* data tables the device side is built from (the reference's nex() state table, stretch, squash, ilog) */
 const uint8_t* p8f_state_table(void);     /* [1024]  nex(s, k) = t[4 s + k] */

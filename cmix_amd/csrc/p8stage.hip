@@ -30,6 +30,7 @@
 #include "p8front/p8f_front.h"
 #include "p8cm2v2_dev.h"
 #include "p8stage_build.h"
+#include "cmx_late.h"
 
 void cmx_set_err(const std::string& s);  // cmx_api.hip
 extern "C" int cmx_device_count(void);
@@ -69,14 +70,64 @@ __global__ __launch_bounds__(P8CM2_MAXC) void cmx_p8s_cm2v2_kernel(P8Cm2Dev* d, 
   if (i == 0) { d->regs = sh.base.r; d->bits = run_bits; d->last_y = last_y; }
 }
 
+// ---- the role kernels for a DECODER (cmx_late.h): the same step functions, but the bit before a step arrives through the box
+// (thread 0 waits for it, one barrier hands it to the workgroup), the host records are read from host-mapped memory, the input rows
+// go to memory every kernel of the stream sees, and every role counts the rows it has completed.
+#define P8_LATE_Y(t_)                                             \
+  if (threadIdx.x == 0) late_y_s = late_y(B, (t_));               \
+  __syncthreads();                                                \
+  const int y_ = late_y_s;                                        \
+  if (y_ < 0) return;                                             \
+  __syncthreads()
+__global__ __launch_bounds__(P8CM2_MAXC) void cmx_p8s_cm2v2_late_kernel(P8Cm2Dev* d, CmxLateBox* B, int counter, const uint32_t* ctx, const uint16_t* chk, int16_t* x,
+                                                                       uint8_t* order_out, int nbits, int skip) {
+  __shared__ __attribute__((aligned(16))) P8Cm2V2Shared sh;
+  __shared__ int late_y_s;
+  const int i = threadIdx.x, C = d->C;
+  p8c2_load(d, &sh, i, P8CM2_MAXC);
+  uint32_t run_bits = d->bits;
+  int lk = 0;
+  __syncthreads();
+  if (i < C) p8c2_reload(d, &sh, i);
+  __syncthreads();
+  for (int t = 0; t < nbits; t++) {
+    P8_LATE_Y(t);
+    const P8Cm2Bit u = p8d_bit_y(d, ctx, chk, y_, x, t, &run_bits);
+    if (t < skip) { if (i == 0) { if (order_out) order_out[t] = 0; late_publish(B, counter, (uint32_t)(t + 1)); } continue; }
+    const bool look = u.bpos == 0 || u.bpos == 2 || u.bpos == 5;
+    P8Cm2Tmp tmp;
+    if (look) {
+      ++lk;
+      if (i < C) p8c2_phase1(d, &sh, u, lk, i, &tmp);
+      __syncthreads();
+    }
+    if ((look && sh.conf[lk & 1]) || sh.shared || !d->slot_parallel) {
+      if (i == 0) p8c2_walk(d, &sh, u, look);
+      __syncthreads();
+      if (i < C) p8c2_reload(d, &sh, i);
+    } else if (i < C) p8c2_run(d, &sh, u, i, &tmp);
+    __syncthreads();   // (drains every thread's stores: the step's inputs are in the row)
+    if (i == 0) {
+      if (order_out) { int o = 0; for (int k = 0; k < C; k++) o += sh.base.nz[k]; order_out[t] = (uint8_t)o; }
+      late_publish(B, counter, (uint32_t)(t + 1));
+    }
+    if (look) p8c2_clear_next(&sh, lk, i, P8CM2_MAXC);
+  }
+  P8_LATE_Y(nbits);   // the chunk's last bit: the state a later chunk starts from
+  if (i == 0) { d->regs = sh.base.r; d->bits = run_bits; d->last_y = y_; }
+}
+
 // The family kernel (p8fam_dev.h): per-context bytes and StateMaps in LDS, one barrier per bit on the common path, overlaps resolved
 // in rounds over the instance order. 512 threads: the (up to 256) contexts on 8 wavefronts of 32 lanes -- a context's walk through
 // phase 1 / run is a chain of data-dependent branches (lookup bit or not, hit / replace, second visit, draw), and lanes of one
 // wavefront that take different branches run them one after the other, so fewer lanes per wavefront cost less --; 24 more lanes of the
 // last wavefront keep the rnd() ring filled.
 constexpr int P8FAM_THREADS = 512;
-__global__ __launch_bounds__(P8FAM_THREADS) void cmx_p8s_fam2_kernel(P8CmDev* d, P8FamHome* home, const uint32_t* ctx, const uint16_t* chk, const uint8_t* bits, int16_t* x,
-                                                                    const uint8_t* order, int nbits, int skip, unsigned long long* prof) {
+// LATE (a decoder): B is the box, `bits` is unused; the order-N map's value of a byte's first step is awaited on its counter.
+template <bool LATE>
+__device__ __forceinline__ void p8s_fam2_body(P8CmDev* d, P8FamHome* home, const uint32_t* ctx, const uint16_t* chk, const uint8_t* bits, int16_t* x,
+                                              const uint8_t* order, int nbits, int skip, unsigned long long* prof, CmxLateBox* B) {
+  __shared__ int late_y_s;
   extern __shared__ __attribute__((aligned(16))) unsigned char p8f_smem[];
   P8FamShared& sh = *(P8FamShared*)p8f_smem;
   const int tid = threadIdx.x, S = d->nslots, ninst = d->ninst;
@@ -96,9 +147,17 @@ __global__ __launch_bounds__(P8FAM_THREADS) void cmx_p8s_fam2_kernel(P8CmDev* d,
   uint32_t my_cx = 0, nx_cx = 0; uint16_t my_ck = 0, nx_ck = 0; bool have_nx = false, have_cur = false;
   __syncthreads();
   for (int t = 0; t < nbits; t++) {
-    const P8FamUni u = p8f_uni_inc(d, ctx, chk, bits, x, order, t, &frun, rnd_i);
+    if (LATE) {
+      if (tid == 0) { int y = late_y(B, t); if (y >= 0 && (t & 7) == 0 && order && !late_wait_cnt(B, LC_CM2_0, (uint32_t)(t + 1))) y = -1; late_y_s = y; }
+      __syncthreads();
+      const int y = late_y_s;
+      if (y < 0) return;
+      __syncthreads();
+      if (t > 0) p8f_uni_tail(&frun, (t - 1) & 7, y); else frun.last_y = y;
+    }
+    const P8FamUni u = LATE ? p8f_uni_head(ctx, chk, x, order, t, &frun, rnd_i) : p8f_uni_inc(d, ctx, chk, bits, x, order, t, &frun, rnd_i);
     const int lk = frun.lk;
-    if (t < skip) continue;
+    if (t < skip) { if (LATE && tid == 0) late_publish(B, LC_FAM, (uint32_t)(t + 1)); continue; }
     P8F_TICK(0);
     // the context's hash / checksum of the byte: read once per byte -- the next byte's during bit 6, an ordinary bit, so that no lookup bit
     // starts with a global round trip before it can even compute its bucket's address
@@ -108,7 +167,7 @@ __global__ __launch_bounds__(P8FAM_THREADS) void cmx_p8s_fam2_kernel(P8CmDev* d,
       have_cur = true;
       if (u.bp == 0) have_nx = false;
       tmp.cx = my_cx; tmp.ck = my_ck;
-      if (u.bp == 6 && t + 2 < nbits) {
+      if (!LATE && u.bp == 6 && t + 2 < nbits) {
         const size_t nb_ = (size_t)((t >> 3) + 1) * (size_t)S;
         const int ord_ = order ? order[t + 2] : 0;
         nx_cx = sl == order_slot ? d->order_ctx[ord_] : ctx[nb_ + sl];
@@ -164,12 +223,30 @@ __global__ __launch_bounds__(P8FAM_THREADS) void cmx_p8s_fam2_kernel(P8CmDev* d,
     prev_i = rnd_i; rnd_i += (uint32_t)total;
     P8F_COUNT(80 + u.bp, 1);
     P8F_TICK(4);
+    if (LATE) {
+      __syncthreads();   // every context's inputs of the step are in the row
+      if (tid == 0) late_publish(B, LC_FAM, (uint32_t)(t + 1));
+    }
   }
 #undef P8F_TICK
 #undef P8F_COUNT
+  if (LATE && nbits > 0) {   // the chunk's last bit goes into the run registers a later chunk starts from
+    if (tid == 0) late_y_s = late_y(B, nbits);
+    __syncthreads();
+    if (late_y_s < 0) return;
+    p8f_uni_tail(&frun, (nbits - 1) & 7, late_y_s);
+  }
   __syncthreads();
   p8f_store(d, home, d->sm, &sh, rnd_i, tid, P8FAM_THREADS);
   if (tid == 0) { d->last_y = frun.last_y; d->c1 = frun.c1; }
+}
+__global__ __launch_bounds__(P8FAM_THREADS) void cmx_p8s_fam2_kernel(P8CmDev* d, P8FamHome* home, const uint32_t* ctx, const uint16_t* chk, const uint8_t* bits, int16_t* x,
+                                                                    const uint8_t* order, int nbits, int skip, unsigned long long* prof) {
+  p8s_fam2_body<false>(d, home, ctx, chk, bits, x, order, nbits, skip, prof, nullptr);
+}
+__global__ __launch_bounds__(P8FAM_THREADS) void cmx_p8s_fam2_late_kernel(P8CmDev* d, P8FamHome* home, CmxLateBox* B, const uint32_t* ctx, const uint16_t* chk, int16_t* x,
+                                                                         const uint8_t* order, int nbits, int skip) {
+  p8s_fam2_body<true>(d, home, ctx, chk, nullptr, x, order, nbits, skip, nullptr, B);
 }
 
 // t0: 1 for the chunk that starts the stream (there is no step 0), else 0
@@ -205,6 +282,49 @@ __global__ __launch_bounds__(P8DMC_THREADS) void cmx_p8s_dmc_kernel(P8DmcDev* d,
     __syncthreads();
   }
   if (tid == 0) { d->last_y = bits[nbits - 1]; d->bits_done = done + (uint32_t)nbits; }
+}
+
+__global__ __launch_bounds__(P8LANES_THREADS) void cmx_p8s_lanes_late_kernel(P8LanesDev* d, CmxLateBox* B, const uint32_t* ops, const uint8_t* order, int16_t* x, int nbits, int t0) {
+  __shared__ int late_y_s;
+  const int ln = threadIdx.x & 63, l = ln < 8 ? 8 * (int)(threadIdx.x >> 6) + ln : P8_NLANE;
+  const bool act = l < P8_NLANE;
+  P8LaneRegs r = d->regs[act ? l : 0];
+  for (int t = 0; t < nbits; t++) {
+    if (threadIdx.x == 0) { int y = late_y(B, t); if (y >= 0 && !late_wait_cnt(B, LC_CM2_0, (uint32_t)(t + 1))) y = -1; late_y_s = y; }   // the step's `order` is the order-N map's of the same step
+    __syncthreads();
+    const int y = late_y_s;
+    if (y < 0) return;
+    __syncthreads();
+    if (t >= t0 && act && l < d->nlanes) p8s_lane_step(d, &r, l, ops[(size_t)t * P8_NLANE + l], y, order[t], x + (size_t)t * P8_NX);
+    __syncthreads();
+    if (threadIdx.x == 0) late_publish(B, LC_LANES, (uint32_t)(t + 1));
+  }
+  if (threadIdx.x == 0) late_y_s = late_y(B, nbits);
+  __syncthreads();
+  if (late_y_s < 0) return;
+  if (act) d->regs[l] = r;
+  if (l == 0) d->last_y = late_y_s;
+}
+
+__global__ __launch_bounds__(P8DMC_THREADS) void cmx_p8s_dmc_late_kernel(P8DmcDev* d, CmxLateBox* B, int16_t* x, int off, int nbits, int t0) {
+  __shared__ P8DmcShared sh;
+  __shared__ int late_y_s;
+  const int tid = threadIdx.x;
+  const uint32_t done = d->bits_done;
+  for (int t = 0; t < nbits; t++) {
+    P8_LATE_Y(t);
+    if (t >= t0) {
+      p8d_dmc_step1(d, &sh, tid, y_);
+      __syncthreads();
+      p8d_dmc_step2(d, &sh, tid, (int)((done + (uint32_t)t) & 7), x + (size_t)t * P8_NX + off);
+      __syncthreads();
+      p8d_dmc_step3(d, &sh, tid);
+      __syncthreads();
+    }
+    if (tid == 0) late_publish(B, LC_DMC, (uint32_t)(t + 1));
+  }
+  P8_LATE_Y(nbits);
+  if (tid == 0) { d->last_y = y_; d->bits_done = done + (uint32_t)nbits; }
 }
 
 // ---------------------------------------------------------------- mixer + APM chains + export
@@ -576,6 +696,269 @@ __device__ __forceinline__ void mx4_body(const P8MixDev* M, P8TailDev* T, const 
   }
 }
 
+// ---- the mixer for a DECODER (cmx_late.h) --------------------------------------------------------------------------------------
+// The same four workgroups, the same arithmetic per step, nothing fetched ahead: a step's input row exists only when the six
+// producing roles have counted it (they wait for the bit before the step themselves), its selectors / APM contexts are host records
+// that arrive with that bit, and the step's own bit -- which trains the rows -- arrives after the row of outputs has gone out
+// (counter LC_P8) and the mixing network and the arithmetic decoder have used it. Per step: wait (bit before the step, producers)
+// -> records and inputs into LDS -> chains' cell updates + row fetch, weight rows (kept in registers when the selector repeats)
+// -> dot products, second layer, chains, export, LC_P8 -> wait for the step's bit -> training.
+template <int BLK>
+__device__ __forceinline__ void mx4_late_body(const P8MixDev* M, P8TailDev* T, CmxLateBox* B, const int16_t* x, const int32_t* sel, const P8ApmRec* apm,
+                                              const uint8_t* order, float* out, size_t ld, int nbits, int t0, int first, unsigned long long* prx,
+                                              unsigned epoch, unsigned* fail) {
+  constexpr int QSEL = (BLK + 2) & 3;
+  constexpr bool MAIN = BLK == 0;
+  __shared__ __attribute__((aligned(16))) uint32_t xs[P8_NX / 2];
+  __shared__ float outs[MAIN ? P8_NOUT : 1];
+  __shared__ int pr_s[32], res_s[8];
+  __shared__ uint32_t st_s[16];
+  __shared__ uint32_t arow[MAIN ? 7 : 1][36];
+  __shared__ int p_s, fin_s, late_y_s;
+  __shared__ int32_t sel_s[P8_NSEL];
+  __shared__ uint32_t apm_s[6];
+  __shared__ int ord_s;
+  __shared__ int16_t squash[4096], stretch[MAIN ? 4096 : 1];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int si = 4 * wave + QSEL;
+  for (int i = threadIdx.x; i < 4096; i += MX_THREADS) { squash[i] = M->squash[i]; if (MAIN) stretch[i] = M->stretch[i]; }
+  const float cf = (float)(1.0 / 4095);
+  if (MAIN) for (int i = tid; i < P8_NOUT; i += MX_THREADS) outs[i] = T->out[i];
+  if (MAIN && tid == 0) fin_s = T->pr;
+  unsigned long long misses = MAIN ? T->misses : 0;
+  MX_GLOBAL int16_t* const wx = (MX_GLOBAL int16_t*)M->wx; MX_GLOBAL int16_t* const wx2 = (MX_GLOBAL int16_t*)M->wx2;
+  const int nx_first = M->nx_first;
+  const bool chain = MAIN && wave == 1 && lane < 7;
+  const int fl = tid - 64, fj = fl >= 0 && fl < 7 * 36 ? fl / 36 : (chain ? lane : 0), fk = fl >= 0 ? fl % 36 : 0;
+  MX_GLOBAL uint32_t* const tb_apm = (MX_GLOBAL uint32_t*)(MAIN && fj < 4 ? T->apm[fj] : nullptr);
+  MX_GLOBAL uint16_t* const tb_apm1 = (MX_GLOBAL uint16_t*)(MAIN && fj >= 4 ? T->apm1[fj - 4] : nullptr);
+  MX_GLOBAL uint16_t* const tb_gen = (MX_GLOBAL uint16_t*)(MAIN ? T->gen[fj] : nullptr);
+  MX_GLOBAL uint32_t* const my_apm = (MX_GLOBAL uint32_t*)(chain && lane < 4 ? T->apm[lane] : nullptr);
+  MX_GLOBAL uint16_t* const my_apm1 = (MX_GLOBAL uint16_t*)(chain && lane >= 4 ? T->apm1[lane - 4] : nullptr);
+  MX_GLOBAL uint16_t* const my_gen = (MX_GLOBAL uint16_t*)(chain ? T->gen[lane] : nullptr);
+  MxApmLane al_txt = {0, 0, 0}, al_gen = {0, 0, 0};
+  if (chain) {
+    const int j = lane;
+    if (j < 4) { al_txt.idx = T->apm_cxt[j]; al_txt.v0 = my_apm[al_txt.idx]; }
+    else { al_txt.idx = T->apm1_idx[j - 4]; al_txt.v0 = my_apm1[al_txt.idx]; al_txt.v1 = my_apm1[al_txt.idx + 1]; }
+    al_gen.idx = T->gen_idx[j]; al_gen.v0 = my_gen[al_gen.idx]; al_gen.v1 = my_gen[al_gen.idx + 1];
+  }
+  __syncthreads();
+  if (MAIN && t0) {   // no step 0: the constructor's values are row 0
+    for (int i = tid; i < P8_NOUT; i += MX_THREADS) out[i] = outs[i];
+    __syncthreads();
+    if (tid == 0) late_publish(B, LC_P8, 1u);
+  }
+  uint4 w[4];
+  int row = -1;
+  int a_base = 0, upd_idx = -1; uint32_t upd_v0 = 0, upd_v1 = 0;
+  auto row_ctx = [&](const P8ApmRec* a, int j, unsigned long long ms) {
+    if (a->text) return j == 0 ? (a->c[0] | (int)((ms & 0xF) << 4)) : j == 1 ? (int)a->c[1 + (int)(ms & 3)] : (int)a->c[3 + j];
+    return j == 0 ? (a->c[0] | (int)(ms & 7)) : j < 4 ? (int)a->c[j] : j == 4 ? (int)a->c[4] : (int)a->c[j - 3];
+  };
+  for (int t = t0; t < nbits; ++t) {
+    const int nx = t < first ? nx_first : P8_NX;
+    // ---- the bit before the step (with it: the step's host records), the six producers' rows ----
+    if (tid == 0) {
+      int y = late_y(B, t);
+      for (int c = LC_CM2_0; y >= 0 && c <= LC_DMC; ++c) if (!late_wait_cnt(B, c, (uint32_t)(t + 1))) y = -1;
+      late_y_s = y;
+    }
+    __syncthreads();
+    const int y = late_y_s;
+    if (y < 0) return;
+    if (wave == 5) {
+      if (lane < P8_NSEL) sel_s[lane] = *(volatile const int32_t*)&sel[(size_t)t * P8_NSEL + lane];
+      else if (lane == 28) ord_s = *(volatile const uint8_t*)&order[t];
+      else if (MAIN && lane >= 32 && lane < 38) apm_s[lane - 32] = reinterpret_cast<volatile const uint32_t*>(apm + t)[lane - 32];
+    }
+    {
+      const int16_t* xr = x + (size_t)t * P8_NX;
+      if (t < first) {
+        int16_t* xh = reinterpret_cast<int16_t*>(xs);
+        for (int i = tid; i < P8_NX; i += MX_THREADS) xh[i] = i < nx_first ? *(volatile const int16_t*)&xr[M->first_map[i]] : (int16_t)0;
+      } else if (tid < MX_GROUPS) {
+        const volatile uint32_t* xq = reinterpret_cast<const volatile uint32_t*>(xr) + 4 * tid;
+        reinterpret_cast<uint4*>(xs)[tid] = make_uint4(xq[0], xq[1], xq[2], xq[3]);
+      }
+    }
+    __syncthreads();
+    const P8ApmRec* arp = reinterpret_cast<const P8ApmRec*>(apm_s);
+    int a_text = 0;
+    if (MAIN) {
+      // Predictor::update's first line (:8250), then the chains' cell updates with the bit and the fetch of the step's rows
+      misses += misses + (unsigned long long)((fin_s >> 11) != y);
+      a_text = arp->text;
+      const int a_limit = arp->limit;
+      if (fl >= 0 && fl < 7 * 36) {
+        const int ncell = (a_text && fj < 4) ? 24 : 33;
+        if (fk < ncell) {
+          const int base = row_ctx(arp, fj, misses) * ncell;
+          arow[fj][fk] = a_text ? (fj < 4 ? tb_apm[base + fk] : (uint32_t)tb_apm1[base + fk]) : (uint32_t)tb_gen[base + fk];
+        }
+      }
+      if (chain) {
+        const int j = lane;
+        if (a_text) {
+          upd_idx = al_txt.idx;
+          if (j < 4) { upd_v0 = apm_upd(al_txt.v0, y, a_limit); my_apm[upd_idx] = upd_v0; }
+          else { upd_v0 = apm1_upd(al_txt.v0, y, j == 4 ? 7 : 6); upd_v1 = apm1_upd(al_txt.v1, y, j == 4 ? 7 : 6); my_apm1[upd_idx] = (uint16_t)upd_v0; my_apm1[upd_idx + 1] = (uint16_t)upd_v1; }
+          a_base = row_ctx(arp, j, misses) * (j < 4 ? 24 : 33);
+        } else {
+          upd_idx = al_gen.idx;
+          upd_v0 = apm1_upd(al_gen.v0, y, 7); upd_v1 = apm1_upd(al_gen.v1, y, 7);
+          my_gen[upd_idx] = (uint16_t)upd_v0; my_gen[upd_idx + 1] = (uint16_t)upd_v1;
+          a_base = row_ctx(arp, j, misses) * 33;
+        }
+      }
+    }
+    {   // this wavefront's weight row of the step: a row the previous step trained and this one selects again stays in the registers
+      const int r = p8s_sel(si, sel_s[si], ord_s, MAIN ? fin_s : 0);
+      if (r != row) {
+        row = r;
+        const MX_GLOBAL int16_t* wr_ = wx + (size_t)r * P8_NX;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { const int grp = lane + 64 * g; w[g] = grp < MX_GROUPS ? mx_gload4(wr_, grp) : make_uint4(0, 0, 0, 0); }
+      }
+    }
+    mx_lds_barrier();   // arow
+    if (MAIN) {
+      if (chain) {
+        const int j = lane;
+        const bool one = a_text && j < 4;
+        const int ncell = one ? 24 : 33, off = upd_idx - a_base;
+        if (off >= 0 && off < ncell) arow[j][off] = upd_v0;
+        if (!one && off + 1 >= 0 && off + 1 < ncell) arow[j][off + 1] = upd_v1;
+      }
+      for (int i = tid; i < nx; i += MX_THREADS) outs[i] = (float)p8s_squash(squash, reinterpret_cast<const int16_t*>(xs)[i]) * cf;
+    }
+    // ---- first layer ----
+    int my_pr;
+    {
+      uint32_t acc = 0;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int grp = lane + 64 * g;
+        const uint4 xv = grp < MX_GROUPS ? reinterpret_cast<const uint4*>(xs)[grp] : make_uint4(0, 0, 0, 0);
+        acc += pair_dot(xv.x, w[g].x) + pair_dot(xv.y, w[g].y) + pair_dot(xv.z, w[g].z) + pair_dot(xv.w, w[g].w);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+      my_pr = p8s_squash(squash, (int32_t)(acc * 9u) >> 9);
+      if (lane == 0) {
+        if (MAIN) pr_s[si] = my_pr;
+        else __hip_atomic_store(&prx[(size_t)t * P8_NSEL + si], (mx4_tag(epoch, t) << 12) | (unsigned)my_pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (MAIN && wave == 4 && lane < P8_NSEL && (lane & 3) != QSEL) {
+      unsigned spins = 0;
+      for (;;) {
+        const unsigned long long v = __hip_atomic_load(&prx[(size_t)t * P8_NSEL + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((v >> 12) == mx4_tag(epoch, t)) { pr_s[lane] = (int)(v & 4095u); break; }
+        if ((++spins & 1023u) == 0 && (spins > MX4_SPIN || late_ld(&B->abort) || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+          __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pr_s[lane] = 2048; break;
+        }
+      }
+    }
+    if (MAIN) {
+      mx_lds_barrier();   // pr_s, arow
+      if (chain) __builtin_amdgcn_s_waitcnt(0);   // this lane's table updates have reached L2 before other lanes fetch rows again (next step)
+      if (wave == 0) {   // second layer
+        const int a = lane < P8_NSEL ? stretch[pr_s[lane]] : 0;
+        if (lane < P8_NSEL) outs[nx + lane] = (float)p8s_squash(squash, a) * cf;
+        const int b = __shfl_down(a, 1);
+        if ((lane & 1) == 0 && lane < 32) st_s[lane >> 1] = ((uint32_t)a & 0xffffu) | ((uint32_t)b << 16);
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        uint32_t acc = 0;
+        if (lane < 16) acc = pair_dot(st_s[lane], reinterpret_cast<const MX_GLOBAL uint32_t*>(wx2)[lane]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) p_s = p8s_squash(squash, (int32_t)acc >> 9);
+      }
+      mx_lds_barrier();   // p_s
+      if (wave == 1) {
+        const int p2 = p_s;
+        auto look_apm = [&](int j, int pr) {   // APM::p's interpolation :704-710 on arow[j]
+          const int s_ = (stretch[pr] + 2048) * 23;
+          const int wt = s_ & 0xfff, lo = s_ >> 12;
+          al_txt.idx = a_base + lo + (wt >> 11); al_txt.v0 = arow[j][lo + (wt >> 11)];
+          return (int)(((arow[j][lo] >> 13) * (uint32_t)(4096 - wt) + (arow[j][lo + 1] >> 13) * (uint32_t)wt) >> 19);
+        };
+        auto look_apm1 = [&](int j, int pr) {   // APM1::pp's interpolation :614-619
+          const int s_ = stretch[pr];
+          const int wgt = s_ & 127, lo = (s_ + 2048) >> 7;
+          MxApmLane& al = a_text ? al_txt : al_gen;
+          al.idx = a_base + lo; al.v0 = arow[j][lo]; al.v1 = arow[j][lo + 1];
+          return (int)((arow[j][lo] * (uint32_t)(128 - wgt) + arow[j][lo + 1] * (uint32_t)wgt) >> 11);
+        };
+        if (lane < 4) res_s[lane] = a_text ? look_apm(lane, p2) : look_apm1(lane, p2);
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        if (lane >= 4 && lane < 7) {
+          const int avg = (p2 + res_s[1] + res_s[2] + res_s[3] + 2) >> 2;
+          res_s[lane] = look_apm1(lane, a_text ? (lane == 4 ? avg : res_s[0]) : res_s[0]);
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) fin_s = p8s_tail_c(arp, p2, res_s, outs + nx + P8_NSEL);
+      }
+      mx_lds_barrier();   // outs complete, fin_s
+      float* orow = out + (size_t)t * ld;
+      for (int i = tid; i < P8_NOUT; i += MX_THREADS) orow[i] = outs[i];
+      __syncthreads();   // (drains every thread's stores)
+      if (tid == 0) late_publish(B, LC_P8, (uint32_t)(t + 1));
+    }
+    // ---- the step's own bit, then training ----
+    if (tid == 0) late_y_s = late_y(B, t + 1);
+    __syncthreads();
+    const int yb = late_y_s;
+    if (yb < 0) return;
+    {
+      const int err = (int)(int16_t)(((yb << 12) - my_pr) * 7);
+      MX_GLOBAL int16_t* wr = wx + (size_t)row * P8_NX;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int grp = lane + 64 * g;
+        if (grp < MX_GROUPS && err) {
+          const uint4 xv = reinterpret_cast<const uint4*>(xs)[grp];
+          uint4 v = w[g];
+          v.x = pair_train(xv.x, v.x, err); v.y = pair_train(xv.y, v.y, err);
+          v.z = pair_train(xv.z, v.z, err); v.w = pair_train(xv.w, v.w, err);
+          mx_gstore4(wr, grp, v);
+          w[g] = v;
+        }
+      }
+    }
+    if (MAIN && wave == 0 && lane < 16) {
+      const int err2 = (int)(int16_t)(((yb << 12) - p_s) * 7);
+      MX_GLOBAL uint32_t* w2 = reinterpret_cast<MX_GLOBAL uint32_t*>(wx2);
+      if (err2) w2[lane] = pair_train(st_s[lane], w2[lane], err2);
+    }
+    __syncthreads();   // xs, late_y_s and the second-layer weights are free for the next step
+  }
+  if (MAIN) {
+    __syncthreads();
+    if (chain) {
+      const int j = lane;
+      if (j < 4) T->apm_cxt[j] = al_txt.idx; else T->apm1_idx[j - 4] = al_txt.idx;
+      T->gen_idx[j] = al_gen.idx;
+    }
+    for (int i = tid; i < P8_NOUT; i += MX_THREADS) T->out[i] = outs[i];
+    if (tid == 0) { T->pr = fin_s; T->misses = misses; }
+  }
+}
+__global__ __launch_bounds__(MX_THREADS) void cmx_p8s_mix4_late_kernel(const P8MixDev* M, P8TailDev* T, CmxLateBox* B, const int16_t* x, const int32_t* sel, const P8ApmRec* apm,
+                                                                      const uint8_t* order, float* out, size_t ld, int nbits, int t0, int first, unsigned long long* prx,
+                                                                      unsigned epoch, unsigned* fail) {
+  switch (blockIdx.x) {
+    case 0: mx4_late_body<0>(M, T, B, x, sel, apm, order, out, ld, nbits, t0, first, prx, epoch, fail); break;
+    case 1: mx4_late_body<1>(M, T, B, x, sel, apm, order, out, ld, nbits, t0, first, prx, epoch, fail); break;
+    case 2: mx4_late_body<2>(M, T, B, x, sel, apm, order, out, ld, nbits, t0, first, prx, epoch, fail); break;
+    default: mx4_late_body<3>(M, T, B, x, sel, apm, order, out, ld, nbits, t0, first, prx, epoch, fail); break;
+  }
+}
+
 // prx: [>= nbits][28] exchange words, (launch number, step + 1) | 12-bit output: never cleared, a word of an earlier launch does not
 // match (the launch number wraps after 2^24 launches, 64 GB of input in 4 KB chunks; every launch rewrites the words of its own steps); fail: sticky time-out flag of workgroup 0's wait (host-mapped)
 __global__ __launch_bounds__(MX_THREADS) void cmx_p8s_mix4_kernel(const P8MixDev* M, P8TailDev* T, const int16_t* __restrict__ x, const int32_t* __restrict__ sel,
@@ -642,6 +1025,8 @@ struct cmx_p8stage {
   int last_bit = 0;
   bool failed = false;
   float ms_front = 0;   // host time of the last front-end pass
+  // the decoder's form (cmx_late.h): three chunk slots of host-coherent records and rows
+  struct Late { size_t cap = 0; char* rec = nullptr; size_t o_fctx, o_fchk, o_cctx[P8_NCM2], o_cchk[P8_NCM2], o_ops, o_sel, o_apm, total; int16_t* x = nullptr; uint8_t* order = nullptr; P8Chunk c; } late[3];
   double role_ms[7] = {0, 0, 0, 0, 0, 0, 0}; uint64_t role_chunks = 0;   // summed over the chunks collected so far
 };
 static void p8s_collect(cmx_p8stage* h, Staging& b) {   // the chunk that used b is complete
@@ -675,6 +1060,7 @@ void cmx_p8stage_destroy(cmx_p8stage_t* h) {
     }
   }
   if (h->d_prx) (void)hipFree(h->d_prx);
+  for (auto& b : h->late) { cmx_late_free(b.rec); cmx_late_free(b.x); cmx_late_free(b.order); }
   if (h->h_mixfail) (void)hipHostFree(h->h_mixfail);
   if (h->own_up && h->s_up) (void)hipStreamDestroy(h->s_up);
   for (hipEvent_t e : {h->ev_up, h->ev_ord, h->ev_a, h->ev_b, h->ev_c, h->ev_e, h->ev_f}) if (e) (void)hipEventDestroy(e);
@@ -786,6 +1172,7 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
     if (h->d_prx) (void)hipFree(h->d_prx);
     h->d_prx = nullptr;
     ok = ok && hipMalloc((void**)&h->d_prx, T * P8_NSEL * 8) == hipSuccess && hipMemset(h->d_prx, 0, T * P8_NSEL * 8) == hipSuccess;
+    h->prx_steps = ok ? T : 0;
     h->x_cap = ok ? n : 0;
   }
   if (h->h_mixfail && *h->h_mixfail) { cmx_set_err("cmx_p8stage_run: the mixer kernel's workgroup 0 timed out waiting for another workgroup's outputs (are four workgroups co-resident?)"); h->failed = true; return 1; }
@@ -860,6 +1247,83 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
   h->last_bit = hb[T - 1];
   return 0;
 }
+
+// ---- the decoder's form of a chunk (cmx_late.h) -------------------------------------------------------------------------------
+// Launches the role kernels of the next nbytes bytes; their bits, and with each bit the host records of the step after it, arrive
+// through `box` while they run. slot 0..2: which of the stage's three sets of host-coherent buffers the chunk uses (a chunk is
+// launched while its predecessor is still being decoded, and its predecessor's buffers are still read when it starts).
+int cmx_p8stage_run_late(cmx_p8stage_t* h, void* box_, size_t nbytes, float* d_out, size_t ld, int slot) {
+  if (!h || !box_ || !d_out || nbytes == 0 || nbytes > (1u << 16) || ld < P8_NOUT || slot < 0 || slot > 2) { cmx_set_err("cmx_p8stage_run_late: bad argument"); return 1; }
+  if (h->failed) { cmx_set_err("cmx_p8stage_run_late: the stage failed earlier on this stream"); return 1; }
+  if (h->s_b == h->s_d || h->s_c == h->s_d || h->s_f == h->s_c) { cmx_set_err("cmx_p8stage_run_late: the roles share HIP streams (CMX_PIPELINE_STREAMS): a decoder needs every role kernel running at once"); return 1; }
+  if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
+  CmxLateBox* B = (CmxLateBox*)box_;
+  const P8Layout& L = h->L;
+  const size_t n = nbytes, T = 8 * n;
+  cmx_p8stage::Late& b = h->late[slot];
+  if (b.cap < n) {
+    if (b.cap) { cmx_set_err("cmx_p8stage_run_late: the chunk size may not grow"); return 1; }
+    size_t o = 0;
+    auto take = [&](size_t bytes_) { const size_t at = o; o += (bytes_ + 255) & ~(size_t)255; return at; };
+    b.o_fctx = take(n * L.fam_slots * 4); b.o_fchk = take(n * L.fam_slots * 2);
+    for (int k = 0; k < P8_NCM2; k++) { b.o_cctx[k] = take(n * L.cm2_count[k] * 4); b.o_cchk[k] = take(n * L.cm2_count[k] * 2); }
+    b.o_ops = take(T * P8_NLANE * 4); b.o_sel = take(T * P8_NSEL * 4); b.o_apm = take(T * sizeof(P8ApmRec));
+    b.total = o;
+    b.rec = (char*)cmx_late_alloc(o);
+    b.x = (int16_t*)cmx_late_alloc(T * P8_NX * 2);
+    b.order = (uint8_t*)cmx_late_alloc(T);
+    if (!b.rec || !b.x || !b.order) { cmx_set_err("cmx_p8stage_run_late: buffer allocation failed"); h->failed = true; return 1; }
+    b.cap = n;
+    b.c.fam_ctx = (uint32_t*)(b.rec + b.o_fctx); b.c.fam_chk = (uint16_t*)(b.rec + b.o_fchk);
+    for (int k = 0; k < P8_NCM2; k++) { b.c.cm2_ctx[k] = (uint32_t*)(b.rec + b.o_cctx[k]); b.c.cm2_chk[k] = (uint16_t*)(b.rec + b.o_cchk[k]); }
+    b.c.ops = (uint32_t*)(b.rec + b.o_ops); b.c.sel = (int32_t*)(b.rec + b.o_sel); b.c.apm = (P8ApmRec*)(b.rec + b.o_apm);
+  }
+  bool ok = true;
+  if (h->prx_steps < T) {
+    ok = hipDeviceSynchronize() == hipSuccess;
+    if (h->d_prx) (void)hipFree(h->d_prx);
+    h->d_prx = nullptr;
+    ok = ok && hipMalloc((void**)&h->d_prx, T * P8_NSEL * 8) == hipSuccess && hipMemset(h->d_prx, 0, T * P8_NSEL * 8) == hipSuccess;
+    h->prx_steps = ok ? T : 0;
+  }
+  const int nbits = (int)T;
+  const int skip = h->steps >= 8 ? 0 : (int)(8 - h->steps), t0 = h->steps == 0 ? 1 : 0;
+  if (ok) {
+    // every role on its own stream (all of them run at the same time, for the whole chunk)
+    for (int k = 0; k < P8_NCM2; k++) {
+      hipStream_t q = k == 0 ? h->s_d : k == 1 ? h->s_b : h->s_e;
+      hipLaunchKernelGGL(cmx_p8s_cm2v2_late_kernel, dim3(1), dim3(P8CM2_MAXC), 0, q, h->d_cm2[k], B, (int)(LC_CM2_0 + k), (const uint32_t*)b.c.cm2_ctx[k], (const uint16_t*)b.c.cm2_chk[k],
+                         b.x, k == 0 ? b.order : (uint8_t*)nullptr, nbits, skip);
+    }
+    hipLaunchKernelGGL(cmx_p8s_fam2_late_kernel, dim3(1), dim3(P8FAM_THREADS), h->fam_lds, h->s_a, h->d_fam, h->d_fam_home, B, (const uint32_t*)b.c.fam_ctx, (const uint16_t*)b.c.fam_chk,
+                       b.x, (const uint8_t*)b.order, nbits, skip);
+    hipLaunchKernelGGL(cmx_p8s_lanes_late_kernel, dim3(1), dim3(P8LANES_THREADS), 0, h->s_c, h->d_lanes, B, (const uint32_t*)b.c.ops, (const uint8_t*)b.order, b.x, nbits, t0);
+    hipLaunchKernelGGL(cmx_p8s_dmc_late_kernel, dim3(1), dim3(P8DMC_THREADS), 0, h->s_f, h->d_dmc, B, b.x, (int)L.dmc_off, nbits, t0);
+    ++h->mix_epoch;
+    hipLaunchKernelGGL(cmx_p8s_mix4_late_kernel, dim3(4), dim3(MX_THREADS), 0, h->s_m, (const P8MixDev*)h->d_mix, h->d_tail, B, (const int16_t*)b.x, (const int32_t*)b.c.sel,
+                       (const P8ApmRec*)b.c.apm, (const uint8_t*)b.order, d_out, ld, nbits, t0, skip, h->d_prx, h->mix_epoch, h->h_mixfail);
+    ok = hipGetLastError() == hipSuccess;
+  }
+  if (!ok) { cmx_set_err(std::string("cmx_p8stage_run_late: launch failed: ") + hipGetErrorString(hipGetLastError())); h->failed = true; return 1; }
+  h->chunks++;
+  h->steps += T;
+  return 0;
+}
+// the host half of the decoder's form: the records of chunk-local step `step` of the chunk in `slot` (every bit before that step has
+// been handed to cmx_p8stage_late_bit), then the bit that was decoded with them
+int cmx_p8stage_late_emit(cmx_p8stage_t* h, int slot, size_t step) {
+  if (!h || slot < 0 || slot > 2 || !h->late[slot].cap || step >= 8 * h->late[slot].cap) { cmx_set_err("cmx_p8stage_late_emit: bad argument"); return 1; }
+  const int rc = p8f_front_emit_step(h->front, &h->late[slot].c, step);
+  if (rc) { cmx_set_err(std::string("cmx_p8stage_late_emit: ") + p8f_strerror(rc)); h->failed = true; return 1; }
+  return 0;
+}
+int cmx_p8stage_late_bit(cmx_p8stage_t* h, int bit) {
+  if (!h) { cmx_set_err("cmx_p8stage_late_bit: null handle"); return 1; }
+  p8f_front_set_bit(h->front, bit);
+  h->last_bit = bit ? 1 : 0;
+  return 0;
+}
+int cmx_p8stage_mixfail(cmx_p8stage_t* h) { return h && h->h_mixfail && *h->h_mixfail ? 1 : 0; }
 
 int cmx_p8stage_set_upload_stream(cmx_p8stage_t* h, void* stream) {
   if (!h) { cmx_set_err("cmx_p8stage_set_upload_stream: null handle"); return 1; }

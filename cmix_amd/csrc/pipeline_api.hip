@@ -24,6 +24,7 @@
 #include <thread>
 
 #include "../../include/cmix_amd.h"
+#include "cmx_late.h"
 
 void cmx_set_err(const std::string& s);  // cmx_api.hip
 
@@ -104,8 +105,39 @@ struct Slot {
 };
 }  // namespace
 
+namespace {
+// ---- the decoder's form (cmx_late.h): chunks of kLateChunk bytes, three sets of host-coherent buffers --------------------------
+// A chunk's kernels are launched while its predecessor is still being decoded (they queue behind it on every stage's stream), and a
+// chunk's first byte still reads its predecessor's last distributions: three sets, so that the one being launched is never one that
+// is still read.
+constexpr size_t kLateChunk = 512;
+struct LateSet {
+  CmxLateBox* box = nullptr;
+  float* layer0 = nullptr;       // [8 n][2078]
+  uint32_t* sel = nullptr;       // [8 n][47]
+  float* brk = nullptr;          // [n][256]   Bracket model's distribution after each byte (context stage)
+  float* lstm = nullptr;         // [n][256]   the LSTM byte mixer's
+  float* ppmd = nullptr;         // [n + 1][256]  PPMd's; row 0 = going into the chunk
+  uint8_t* bytes = nullptr;      // [n]
+  int16_t* hint_pr = nullptr; uint8_t* hint_ex = nullptr;   // [8 n] fxcm's LSTM hints per update
+};
+struct Late {
+  LateSet set[3];
+  bool active = false, failed = false, predicted = false;
+  uint64_t launched = 0;   // chunks whose kernels are enqueued
+  uint64_t cur = 0;        // chunk being decoded
+  size_t t = 0;            // its next bit
+  unsigned partial = 0;
+  hipStream_t s_bm = nullptr;
+  const float* lstm0 = nullptr;
+  double ms[6] = {0, 0, 0, 0, 0, 0};
+  uint64_t bits = 0;
+};
+}  // namespace
+
 struct cmx_pipeline {
   int device = 0;
+  Late* late = nullptr;
   size_t max_chunk = 0;
   cmx_ppmd_t* ppmd = nullptr;
   cmx_ctxmodels_t* ctx = nullptr;
@@ -189,6 +221,18 @@ static void wg_release(cmx_pipeline* h) {
 
 void cmx_pipeline_destroy(cmx_pipeline_t* h) {
   if (!h) return;
+  if (h->late) {
+    (void)cmx_pipeline_late_stop(h);
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    for (LateSet& q : h->late->set) {
+      cmx_late_free(q.box); cmx_late_free(q.layer0); cmx_late_free(q.sel); cmx_late_free(q.brk); cmx_late_free(q.lstm); cmx_late_free(q.ppmd);
+      cmx_late_free(q.bytes); cmx_late_free(q.hint_pr); cmx_late_free(q.hint_ex);
+    }
+    if (h->late->s_bm) (void)hipStreamDestroy(h->late->s_bm);
+    delete h->late;
+    h->late = nullptr;
+  }
   wg_release(h);
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
@@ -643,6 +687,202 @@ int cmx_pipeline_stage_totals(cmx_pipeline_t* h, double ms[3], uint64_t* chunks,
 int cmx_pipeline_last_stage_ms(cmx_pipeline_t* h, float ms[3]) {
   if (!h || !ms) return 1;
   memcpy(ms, h->stage_ms, sizeof h->stage_ms);
+  return 0;
+}
+
+// ================================================================================================================================
+// The decoder's form of the pipeline: the late-bit protocol (cmx_late.h; include/cmix_amd.h section 4)
+// ================================================================================================================================
+size_t cmx_late_box_bytes(size_t nbits) { return sizeof(CmxLateBox) + nbits + 64; }
+
+static double late_now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// enqueue every stage kernel of chunk number c (its bits arrive later)
+static int late_launch(cmx_pipeline* h, uint64_t c) {
+  Late* L = h->late;
+  const int s = (int)(c % 3);
+  LateSet& q = L->set[s];
+  const size_t n = kLateChunk;
+  CmxLateBox* B = q.box;
+  // the box of the chunk three back: nothing reads it any more (its kernels ended before those of chunk c - 2 began)
+  memset(B, 0, sizeof(CmxLateBox));
+  B->nbits = (uint32_t)(8 * n);
+  __sync_synchronize();
+  const float* brk0 = nullptr;
+  if (cmx_ctxmodels_run_late(h->ctx, B, n, q.layer0, CMX_N_INPUTS, q.sel, q.brk, &brk0, h->s_ctx)) return 1;
+  const uint32_t *c0_brk = nullptr, *c0_lstm = nullptr;
+  const float* lstm0 = L->lstm0;
+  if (c > 0) {   // the distributions going into the chunk are the previous chunk's last rows, valid when ITS stages have counted them
+    LateSet& pq = L->set[(int)((c - 1) % 3)];
+    brk0 = pq.brk + (n - 1) * 256; c0_brk = &pq.box->cnt[LC_BRK].v;
+    lstm0 = pq.lstm + (n - 1) * 256; c0_lstm = &pq.box->cnt[LC_LSTM].v;
+  }
+  if (cmx_bytemodel_late_run(h->device, B, n, brk0, q.brk, q.ppmd, lstm0, q.lstm, c0_brk, (uint32_t)n, c0_lstm, (uint32_t)n, q.layer0, CMX_N_INPUTS, q.hint_pr, q.hint_ex,
+                             L->s_bm)) return 1;
+  if (cmx_fxcm_run_late(h->fxcm, B, n, q.hint_pr, q.hint_ex, q.layer0, CMX_N_INPUTS, s, h->s_fx)) return 1;
+  if (cmx_p8stage_run_late(h->p8, B, n, q.layer0 + 434, CMX_N_INPUTS, s)) return 1;
+  if (cmx_mixnet_run_late(h->mix, B, q.layer0, q.sel, 8 * n, h->s_mix)) return 1;
+  L->launched = c + 1;
+  return 0;
+}
+
+int cmx_pipeline_late_start(cmx_pipeline_t* h, int last_bit) {
+  if (!h) { cmx_set_err("cmx_pipeline_late_start: null handle"); return 1; }
+  if (h->late) { cmx_set_err("cmx_pipeline_late_start: already started"); return 1; }
+  if (!h->fxcm || !h->p8) { cmx_set_err("cmx_pipeline_late_start: enable the fxcm and paq8 stages first (a decoder takes no columns from the caller)"); return 1; }
+  if (h->chunks) { cmx_set_err("cmx_pipeline_late_start: the handle has coded chunks of known bytes (a stream is decoded from its first bit)"); return 1; }
+  if (h->compact) { cmx_set_err("cmx_pipeline_late_start: the stages share HIP streams (CMX_PIPELINE_STREAMS); a decoder needs every stage kernel running at once"); return 1; }
+  if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
+  if (hipDeviceSynchronize() != hipSuccess) { cmx_set_err("cmx_pipeline_late_start: device error"); return 1; }   // pretraining is complete
+  Late* L = new Late();
+  h->late = L;
+  const size_t n = kLateChunk, T = 8 * n;
+  bool ok = hipStreamCreateWithFlags(&L->s_bm, hipStreamNonBlocking) == hipSuccess;
+  for (LateSet& q : L->set) {
+    q.box = (CmxLateBox*)cmx_late_alloc(cmx_late_box_bytes(T));
+    q.layer0 = (float*)cmx_late_alloc(T * CMX_N_INPUTS * 4);
+    q.sel = (uint32_t*)cmx_late_alloc(T * CMX_N_MIXERS * 4);
+    q.brk = (float*)cmx_late_alloc(n * 256 * 4);
+    q.lstm = (float*)cmx_late_alloc(n * 256 * 4);
+    q.ppmd = (float*)cmx_late_alloc((n + 1) * 256 * 4);
+    q.bytes = (uint8_t*)cmx_late_alloc(n);
+    q.hint_pr = (int16_t*)cmx_late_alloc(T * 2);
+    q.hint_ex = (uint8_t*)cmx_late_alloc(T);
+    ok = ok && q.box && q.layer0 && q.sel && q.brk && q.lstm && q.ppmd && q.bytes && q.hint_pr && q.hint_ex;
+  }
+  if (!ok) { cmx_set_err("cmx_pipeline_late_start: buffer allocation failed"); L->failed = true; return 1; }
+  L->lstm0 = cmx_lstm_byte_probs(h->lstm);
+  // chunk 0 and, queued behind it, chunk 1
+  if (late_launch(h, 0)) { L->failed = true; return 1; }
+  LateSet& q0 = L->set[0];
+  memcpy(q0.ppmd, h->last_dist, 256 * 4);                       // PPMd's distribution going into the stream
+  if (cmx_p8stage_late_emit(h->p8, 0, 0)) { L->failed = true; return 1; }   // the records of step 0
+  q0.box->last_y = last_bit ? 1u : 0u;
+  __sync_synchronize();
+  q0.box->start = 1;
+  if (late_launch(h, 1)) { L->failed = true; return 1; }
+  L->active = true;
+  return 0;
+}
+
+int cmx_pipeline_late_stop(cmx_pipeline_t* h) {
+  if (!h || !h->late) return 0;
+  Late* L = h->late;
+  if (!L->active) return 0;
+  for (LateSet& q : L->set) if (q.box) { q.box->abort = 1; }
+  __sync_synchronize();
+  (void)hipSetDevice(h->device);
+  const bool ok = hipDeviceSynchronize() == hipSuccess;
+  L->active = false;
+  if (!ok) { cmx_set_err("cmx_pipeline_late_stop: device error"); return 1; }
+  return 0;
+}
+
+float cmx_pipeline_late_predict(cmx_pipeline_t* h) {
+  if (!h || !h->late || !h->late->active) { cmx_set_err("cmx_pipeline_late_predict: not started"); return -1.0f; }
+  Late* L = h->late;
+  if (L->failed) { cmx_set_err("cmx_pipeline_late_predict: the stream failed earlier"); return -1.0f; }
+  if (L->predicted) { cmx_set_err("cmx_pipeline_late_predict: called twice without perceive()"); return -1.0f; }
+  LateSet& q = L->set[(int)(L->cur % 3)];
+  volatile unsigned long long* w = (volatile unsigned long long*)&q.box->p_word[L->t % CMX_LATE_P_RING];
+  const double t0 = late_now();
+  unsigned long long v;
+  unsigned spins = 0;
+  while ((unsigned)((v = *w) >> 32) != (unsigned)(L->t + 1)) {
+    if ((++spins & 0xfffu) == 0) {
+      const double el = late_now() - t0;
+      const char* why = nullptr;
+      if (*(volatile uint32_t*)&q.box->fail) why = "a stage kernel's wait ran out of time (are all stage kernels co-resident?)";
+      else if (cmx_p8stage_mixfail(h->p8)) why = "the paq8 mixer's workgroup 0 timed out waiting for another workgroup";
+      else if (el > 60000.0) why = "no prediction from the device for 60 s";
+      if (why) {
+        cmx_set_err(std::string("cmx_pipeline_late_predict: ") + why + " at bit " + std::to_string(L->bits));
+        L->failed = true;
+        for (LateSet& z : L->set) if (z.box) z.box->abort = 1;
+        return -1.0f;
+      }
+    }
+  }
+  L->ms[0] += late_now() - t0;
+  L->predicted = true;
+  float p;
+  const unsigned pb = (unsigned)v;
+  memcpy(&p, &pb, 4);
+  return p;
+}
+
+int cmx_pipeline_late_perceive(cmx_pipeline_t* h, int bit) {
+  if (!h || !h->late || !h->late->active) { cmx_set_err("cmx_pipeline_late_perceive: not started"); return 1; }
+  Late* L = h->late;
+  if (L->failed) { cmx_set_err("cmx_pipeline_late_perceive: the stream failed earlier"); return 1; }
+  if (!L->predicted) { cmx_set_err("cmx_pipeline_late_perceive: no pending predict()"); return 1; }
+  struct Txn { Late* L; bool ok = false; ~Txn() { if (!ok) L->failed = true; } } txn{L};
+  const int s = (int)(L->cur % 3);
+  LateSet& q = L->set[s];
+  const size_t n = kLateChunk, T = 8 * n, t = L->t;
+  bit = bit ? 1 : 0;
+  q.box->bit[t] = (uint8_t)bit;
+  L->partial = (L->partial << 1) | (unsigned)bit;
+  double t0 = late_now();
+  auto lap = [&](int k) { const double now = late_now(); L->ms[k] += now - t0; t0 = now; };
+  // ---- host stages for the step after this bit: their records are in place before the bit is published ----
+  (void)cmx_p8stage_late_bit(h->p8, bit);
+  const bool byte_done = (t & 7) == 7, chunk_done = t + 1 == T;
+  const size_t b = t >> 3;
+  uint8_t byte = 0;
+  if (byte_done) {   // predictor.cpp:439-461
+    byte = (uint8_t)L->partial;
+    L->partial = 0;
+    q.bytes[b] = byte;
+    if (cmx_ppmd_run(h->ppmd, &byte, 1, q.ppmd + (b + 1) * 256)) return 1;
+    memcpy(h->last_dist, q.ppmd + (b + 1) * 256, 256 * 4);
+    lap(1);
+    if (cmx_fxcm_late_byte(h->fxcm, s, b, byte)) return 1;
+    lap(3);
+  }
+  LateSet* nq = nullptr;
+  if (!chunk_done) { if (cmx_p8stage_late_emit(h->p8, s, t + 1)) return 1; }
+  else {
+    nq = &L->set[(int)((L->cur + 1) % 3)];
+    if (cmx_p8stage_late_emit(h->p8, (int)((L->cur + 1) % 3), 0)) return 1;
+    memcpy(nq->ppmd, q.ppmd + n * 256, 256 * 4);
+    nq->box->last_y = (uint32_t)bit;
+  }
+  lap(2);
+  __sync_synchronize();   // the records are written before the counter moves
+  *(volatile uint32_t*)&q.box->nknown = (uint32_t)(t + 1);
+  if (nq) *(volatile uint32_t*)&nq->box->start = 1;
+  // ---- the LSTM byte mixer's step for the completed byte (predictor.cpp:450-461), then "its distribution is there" ----
+  if (byte_done) {
+    if (cmx_lstm_run(h->lstm, q.ppmd + (b + 1) * 256, q.bytes + b, 1, q.lstm + b * 256, nullptr, 0, nullptr, h->s_lstm)) return 1;
+    if (cmx_late_bump(h->device, &q.box->cnt[LC_LSTM].v, (uint32_t)(b + 1), nullptr, 0, h->s_lstm)) { cmx_set_err("cmx_pipeline_late_perceive: launch failed"); return 1; }
+    lap(4);
+  }
+  L->predicted = false;
+  L->bits++;
+  if (chunk_done) {
+    L->cur++;
+    L->t = 0;
+    if (late_launch(h, L->cur + 1)) return 1;   // the chunk after the next, queued behind it
+    lap(5);
+  } else L->t = t + 1;
+  txn.ok = true;
+  return 0;
+}
+
+// test hook: the layer-0 row (2078 f32, host-coherent memory) and the 47 selectors of the bit whose p was predicted last -- valid
+// between cmx_pipeline_late_predict() and cmx_pipeline_late_perceive()
+const float* cmx_pipeline_late_debug_row(cmx_pipeline_t* h, const uint32_t** sel) {
+  if (!h || !h->late || !h->late->active || !h->late->predicted) return nullptr;
+  const LateSet& q = h->late->set[(int)(h->late->cur % 3)];
+  if (sel) *sel = q.sel + h->late->t * CMX_N_MIXERS;
+  return q.layer0 + h->late->t * CMX_N_INPUTS;
+}
+
+int cmx_pipeline_late_host_ms(cmx_pipeline_t* h, double ms[6], uint64_t* bits) {
+  if (!h || !h->late || !ms || !bits) return 1;
+  for (int i = 0; i < 6; ++i) ms[i] = h->late->ms[i];
+  *bits = h->late->bits;
   return 0;
 }
 

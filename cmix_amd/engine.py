@@ -147,6 +147,14 @@ def lib():
         L.cmx_pipeline_paq8_role_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.cmx_pipeline_last_stage_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.cmx_probe_libm.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.cmx_pipeline_late_start.argtypes = [C.c_void_p, C.c_int]
+        L.cmx_pipeline_late_predict.restype = C.c_float
+        L.cmx_pipeline_late_predict.argtypes = [C.c_void_p]
+        L.cmx_pipeline_late_perceive.argtypes = [C.c_void_p, C.c_int]
+        L.cmx_pipeline_late_stop.argtypes = [C.c_void_p]
+        L.cmx_pipeline_late_host_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cmx_pipeline_late_debug_row.restype = C.c_void_p
+        L.cmx_pipeline_late_debug_row.argtypes = [C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -515,6 +523,40 @@ class Pipeline:
         lib().cmx_pipeline_stage_totals(self.h, ms, C.byref(n), int(reset))
         k = max(n.value, 1)
         return {"ctxmodels": ms[0] / k, "lstm": ms[1] / k, "mixnet": ms[2] / k, "chunks": n.value}
+
+    # ---- the decoder's form (late-bit protocol, include/cmix_amd.h section 4): fxcm and paq8 must be enabled ----
+    def late_start(self, last_bit=0):
+        if lib().cmx_pipeline_late_start(self.h, int(last_bit)):
+            raise CmxError(last_error())
+
+    def late_predict(self):
+        p = lib().cmx_pipeline_late_predict(self.h)
+        if p < 0:
+            raise CmxError(last_error())
+        return p
+
+    def late_perceive(self, bit):
+        if lib().cmx_pipeline_late_perceive(self.h, int(bit)):
+            raise CmxError(last_error())
+
+    def late_stop(self):
+        if lib().cmx_pipeline_late_stop(self.h):
+            raise CmxError(last_error())
+
+    def late_row(self):
+        """(layer-0 row [2078] f32, selectors [47] u32) of the bit predicted last, copied out of the host-coherent chunk buffers."""
+        sel = C.c_void_p(0)
+        r = lib().cmx_pipeline_late_debug_row(self.h, C.byref(sel))
+        if not r:
+            raise CmxError("no pending late predict")
+        row = np.ctypeslib.as_array(C.cast(r, C.POINTER(C.c_float)), (N_INPUTS,)).copy()
+        s = np.ctypeslib.as_array(C.cast(sel.value, C.POINTER(C.c_uint32)), (47,)).copy()
+        return row, s
+
+    def late_host_ms(self):
+        v, n = (C.c_double * 6)(), C.c_uint64(0)
+        lib().cmx_pipeline_late_host_ms(self.h, v, C.byref(n))
+        return dict(zip(("wait_p", "ppmd", "paq8_front", "fxcm_parser", "lstm_launch", "chunk_launch"), [float(x) for x in v])), int(n.value)
 
     def close(self):
         if getattr(self, "h", None):

@@ -434,6 +434,47 @@ int cmx_p8stage_set_upload_stream(cmx_p8stage_t*, void* stream);   /* see cmx_mi
  * out[72 + bp] instances walked, out[80 + bp] steps */
 int cmx_p8stage_profile(cmx_p8stage_t*, unsigned long long out128[128]);
 
+
+/* ------------------------------------------------------------------------
+ * 4. The DECODER's form of the stages: the late-bit protocol (cmix_amd/csrc/cmx_late.h)
+ *
+ * Decoder::Decode (src/coder/decoder.cpp:20-39) learns bit t only after Predictor::Predict() has returned p(t): nothing can be
+ * looked ahead. The stage kernels are the chunk kernels of section 3, but each waits where it reads a coded bit, a host record or
+ * another stage's row: they are launched for a chunk of bytes that do not exist yet, and a BOX in host-coherent memory carries the
+ * bits in (with each bit: the host records of the step after it) and p out. cmx_pipeline_late_* below drive one stream this way --
+ * every model family on the device, no column from the caller, no reference object; cmx_predict()/cmx_perceive() of section 1 sit
+ * on top of them when no input was staged. The per-stage entry points are what the pipeline (and the stage-level tests) call.
+ * ------------------------------------------------------------------------ */
+void* cmx_late_alloc(size_t bytes);   /* zeroed host-coherent pinned memory: boxes, rows, records */
+void cmx_late_free(void* p);
+size_t cmx_late_box_bytes(size_t nbits);   /* allocation size of a box for a chunk of nbits */
+int cmx_late_bump(int device, uint32_t* counter, uint32_t value, uint32_t* counter2, uint32_t value2, void* stream);
+int cmx_ctxmodels_run_late(cmx_ctxmodels_t*, void* box, size_t nbytes, float* probs, size_t pstride, uint32_t* sel, float* brk_dist,
+                           const float** brk_dist0_out, void* stream);
+int cmx_bytemodel_late_run(int device, void* box, size_t nbytes, const float* brk0, const float* brk, const float* ppmd, const float* lstm0, const float* lstm,
+                           const uint32_t* c0_brk, uint32_t c0_brk_want, const uint32_t* c0_lstm, uint32_t c0_lstm_want, float* layer0, size_t pstride,
+                           int16_t* hint_pr, uint8_t* hint_ex, void* stream);
+const float* cmx_lstm_byte_probs(cmx_lstm_t*);
+int cmx_fxcm_run_late(cmx_fxcm_t*, void* box, size_t nbytes, const int16_t* hint_pr, const uint8_t* hint_ex, float* probs, size_t pstride, int slot, void* stream);
+int cmx_fxcm_late_byte(cmx_fxcm_t*, int slot, size_t b, uint8_t byte);
+int cmx_p8stage_run_late(cmx_p8stage_t*, void* box, size_t nbytes, float* out, size_t ld, int slot);
+int cmx_p8stage_late_emit(cmx_p8stage_t*, int slot, size_t step);
+int cmx_p8stage_late_bit(cmx_p8stage_t*, int bit);
+int cmx_p8stage_mixfail(cmx_p8stage_t*);
+int cmx_mixnet_run_late(cmx_mixnet_t*, void* box, const float* probs, const uint32_t* sel, size_t nbits, void* stream);
+/* One stream, bit by bit. The handle is a pipeline of section 3 with the fxcm and paq8 stages enabled (and, if there is a
+ * dictionary, pretrained): cmx_pipeline_late_start() launches the first chunks' kernels (last_bit: the bit coded before the first
+ * one -- the last Pretrain bit, else 0); then strictly alternating cmx_pipeline_late_predict() -> p, cmx_pipeline_late_perceive(bit).
+ * cmx_pipeline_late_stop() (also called by cmx_pipeline_destroy) unwinds the kernels of the chunk in progress. */
+int cmx_pipeline_late_start(cmx_pipeline_t*, int last_bit);
+float cmx_pipeline_late_predict(cmx_pipeline_t*);
+int cmx_pipeline_late_perceive(cmx_pipeline_t*, int bit);
+int cmx_pipeline_late_stop(cmx_pipeline_t*);
+/* diagnostics: the calling thread's wall time since start, in ms: [0] waiting for p, [1] PPMd, [2] paq8 front end, [3] fxcm parser, [4] LSTM launches, [5] chunk launches */
+int cmx_pipeline_late_host_ms(cmx_pipeline_t*, double ms[6], uint64_t* bits);
+/* test hook: the layer-0 row (2078 f32, host memory) and 47 selectors of the bit predicted last; valid until the matching perceive */
+const float* cmx_pipeline_late_debug_row(cmx_pipeline_t*, const uint32_t** sel);
+
 #ifdef __cplusplus
 }
 #endif

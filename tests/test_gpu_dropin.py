@@ -285,6 +285,85 @@ def test_dropin_engine_empty_and_tiny_files():
         assert _run(mode, [("in", v[name + "_payload"])], exe=DROPIN, timeout=300) == v[name + "_file"], name
 
 
+# ---- DECOMPRESSION with the whole engine: `cmix_dropin -d` = the reference's runner.cpp + decoder.cpp + preprocessor, no model ----
+# Decoder::Decode (decoder.cpp:20-39) calls Predict() and only then knows the bit it hands to Perceive(): the library's late-bit
+# protocol (cmix_amd/csrc/cmx_late.h) -- every stage kernel of the chunk pipeline, fxcm and paq8 included, waiting for the bits
+# as the arithmetic decoder produces them. The files decoded here were written by the UNMODIFIED reference binary.
+def test_dropin_decodes_the_reference_binarys_files():
+    v = _dropin_vectors()
+    syms = subprocess.run(["nm", "-C", DROPIN], capture_output=True, text=True).stdout
+    assert "Decoder::Decode" in syms and "paq8" not in syms and "fxcmv1" not in syms and "PPMD" not in syms and "Lstm" not in syms
+    assert _run("-d", [("in", v["raw_n_file"])], exe=DROPIN) == v["raw_n_payload"]
+    assert _run("-d", [("in", v["text_c_file"])], exe=DROPIN) == v["text_c_payload"]
+    assert _run("-d", [("dict", v["dict_payload"]), ("in", v["dict_c_file"])], exe=DROPIN) == v["dict_c_payload"]   # Pretrain, then the WRT inverse
+
+
+def test_dropin_decodes_empty_and_tiny_files():
+    if not os.path.exists(DROPIN):
+        pytest.fail("oracle/_ref/cmix_dropin not built")
+    import make_dropin_tiny as mk
+    with np.load(os.path.join(GOLDEN, "dropin_tiny.npz")) as z:
+        v = {k: z[k].tobytes() for k in z.files}
+    for name, mode, _ in mk.CASES:
+        assert _run("-d", [("in", v[name + "_file"])], exe=DROPIN, timeout=300) == v[name + "_payload"], name
+
+
+def test_dropin_decodes_mixed_and_binary_files():
+    """a TEXT block followed by an EXE block (e8e9 inverse), and DEFAULT blocks of random bytes / records / runs"""
+    if not os.path.exists(DROPIN):
+        pytest.fail("oracle/_ref/cmix_dropin not built")
+    for fx in ("dropin_mixed.npz", "dropin_binary.npz"):
+        with np.load(os.path.join(GOLDEN, fx)) as z:
+            payload, blob = z["payload"].tobytes(), z["cmix_file"].tobytes()
+        assert _run("-d", [("in", blob)], exe=DROPIN, timeout=600) == payload, fx
+
+
+def test_dropin_decodes_12k_and_times_it_against_the_reference_binary():
+    """12 000 bytes written by the reference binary, decoded by the engine and by the reference binary on the same box: the time of
+    both goes to gpurun_out/decode_time.txt (the engine's includes ~8 s of process start and engine construction)."""
+    import time
+    v = _dropin_vectors()
+    t0 = time.time()
+    assert _run("-d", [("in", v["text12k_c_file"])], exe=DROPIN, timeout=600) == v["text12k_c_payload"]
+    t_eng = time.time() - t0
+    ref = os.path.join(ROOT, "oracle", "_ref", "cmix_O3")
+    t_ref = None
+    if os.path.exists(ref):
+        t0 = time.time()
+        assert _run("-d", [("in", v["text12k_c_file"])], exe=ref, timeout=600) == v["text12k_c_payload"]
+        t_ref = time.time() - t0
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "decode_time.txt"), "a") as f:
+        f.write("12000 bytes: cmix_dropin -d %.1f s wall (%.0f us/byte incl. start-up)" % (t_eng, 1e6 * t_eng / 12000))
+        if t_ref:
+            f.write("; cmix_O3 -d %.1f s wall (%.0f us/byte)" % (t_ref, 1e6 * t_ref / 12000))
+        f.write("\n")
+
+
+def test_dropin_round_trips_50k_and_256k():
+    """compress (look-ahead mode; the file equals the reference binary's, checked above by SHA-256) and decompress again; the
+    decoder's time per byte without start-up follows from the two sizes"""
+    import time
+    from cmix_amd import synth
+    if not os.path.exists(DROPIN):
+        pytest.fail("oracle/_ref/cmix_dropin not built")
+    times = []
+    for n, seed, rich in ((50000, None, False), (262144, 1000, False)):
+        if seed is None:
+            with np.load(os.path.join(GOLDEN, "dropin_vectors.npz")) as z:
+                n, seed = (int(x) for x in z["text50k_c_seed"])
+        payload = synth.enwik_like(n, seed)
+        blob = _run("-c", [("in", payload)], exe=DROPIN, timeout=900)
+        t0 = time.time()
+        assert _run("-d", [("in", blob)], exe=DROPIN, timeout=1500) == payload
+        times.append((n, time.time() - t0))
+    (n0, t0_), (n1, t1_) = times
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "decode_time.txt"), "a") as f:
+        f.write("cmix_dropin -d: %d bytes %.1f s, %d bytes %.1f s -> %.0f us/byte marginal (start-up %.1f s)\n" %
+                (n0, t0_, n1, t1_, 1e6 * (t1_ - t0_) / (n1 - n0), t0_ - n0 * (t1_ - t0_) / (n1 - n0)))
+
+
 # ---- BASELINE config 3: the reference's own dictionary (44 515 words, 412 KB of Pretrain) ------------------------------
 def test_dropin_engine_english_dic_pretrain_and_wrt_text_is_byte_identical():
     """`cmix -c english.dic in out` on 64 KB of rich enwik-like text whose words come from that dictionary (tests/golden/
