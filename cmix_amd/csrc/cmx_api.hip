@@ -132,7 +132,7 @@ struct cmx_mixnet {
   int dbg = 0;          // CMX_MIXNET_DBG: timing experiments (results invalid when nonzero)
   int xcd = -1;         // CMX_MIXNET_XCD=k: place the persistent kernel on XCD k (speed only; -1 = wherever block 0 lands)
   bool use_v1 = false;  // CMX_MIXNET_V1=1: run chunks through the bit-synchronous kernel
-  bool tolerance = false;   // CMX_MIXNET_TOLERANCE=1 (opt-in, NOT bit-exact): layer-0 dot products as f64 tree sums rounded once (cmx_mixnet_spec_kernel only)
+  bool tolerance = false;   // cmx_mixnet_set_tolerance (opt-in through the API, NOT bit-exact): layer-0 dot products as f64 tree sums rounded once (cmx_mixnet_spec_kernel only)
   bool use_spec = true; // cmx_mixnet_spec_kernel (26 helper workgroups, speculative segment-parallel chains); CMX_MIXNET_SPEC=0: the one-workgroup kernel
   SpecXfer* d_xfer = nullptr;
   float* d_late_p = nullptr; size_t late_p_cap = 0;   // the decoder's form: the kernel's p[] array (the host reads p from the box)
@@ -288,7 +288,6 @@ cmx_mixnet_t* cmx_mixnet_create(int device) {
   }
   { const char* v = getenv("CMX_MIXNET_V1"); h->use_v1 = v && v[0] == '1'; }
   { const char* v = getenv("CMX_MIXNET_SPEC"); h->use_spec = !(v && v[0] == '0'); }
-  { const char* v = getenv("CMX_MIXNET_TOLERANCE"); h->tolerance = v && v[0] == '1' && h->use_spec; }
   h->d_xfer = (SpecXfer*)dalloc(sizeof(SpecXfer), true);   // incl. the zero padding of the input ring
   if (!h->d_xfer || hipFuncSetAttribute((const void*)cmx_mixnet_spec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CMX_SPEC_LDS_BYTES) != hipSuccess) {
     set_err("cmx_mixnet_create: hand-off area / kernel attribute (spec kernel) failed");
@@ -345,6 +344,22 @@ int cmx_mixnet_spec_stats(cmx_mixnet_t* h, uint64_t out[5]) {
 
 // The stream the handle's host-to-device copies go on (the pipeline gives all its stages ONE upload stream that never has
 // a kernel in front of a copy); without it the handle creates its own on first use.
+// Tolerance mode (NOT bit-exact; north_star's "per-bit probabilities within a tolerance"): the layer-0 dot products as f64 tree sums
+// rounded once. An explicit switch of the handle, never an environment variable: a file coded with it has the reference's header
+// but cannot be decoded by the reference or by this library's decoder (which is strict), so no file-writing program sets it.
+int cmx_mixnet_set_tolerance(cmx_mixnet_t* h, int on) {
+  if (!h) { set_err("cmx_mixnet_set_tolerance: null handle"); return 1; }
+  if (on && (!h->use_spec || h->use_v1)) { set_err("cmx_mixnet_set_tolerance: only the 27-workgroup kernel has the mode (CMX_MIXNET_SPEC=0 / CMX_MIXNET_V1 are set)"); return 1; }
+  if (h->runs || h->bits_done) { set_err("cmx_mixnet_set_tolerance: only before the first bit of the stream"); return 1; }
+  h->tolerance = on != 0;
+  return 0;
+}
+// DEVICE address of MixState::error (set by a chunk kernel whose bounded in-launch wait ran out), for callers that copy it back in
+// stream order behind the chunk's kernel (cmx_pipeline_finish) instead of synchronising the device
+const int* cmx_mixnet_error_flag(cmx_mixnet_t* h) { return h ? &h->d_state->error : nullptr; }
+// 0 strict (bit-exact, the default), 1 tolerance
+int cmx_mixnet_mode(cmx_mixnet_t* h) { return h && h->tolerance ? 1 : 0; }
+
 int cmx_mixnet_set_upload_stream(cmx_mixnet_t* h, void* stream) {
   if (!h) { set_err("cmx_mixnet_set_upload_stream: null handle"); return 1; }
   if (h->own_up && h->s_up) hipStreamDestroy(h->s_up);
@@ -363,15 +378,23 @@ int cmx_mixnet_run(cmx_mixnet_t* h, const float* d_probs, const uint32_t* d_sel,
 // consumed as their stages count them in `box`; p(t) goes to the box, bit t comes back through it. Only the 27-workgroup kernel.
 int cmx_mixnet_run_late(cmx_mixnet_t* h, void* box, const float* probs, const uint32_t* sel, size_t nbits, void* stream) {
   if (!h || !box) { set_err("cmx_mixnet_run_late: bad argument"); return 1; }
-  if (!h->use_spec || h->use_v1 || h->tolerance) { set_err("cmx_mixnet_run_late: a decoder needs the strict 27-workgroup kernel (CMX_MIXNET_SPEC=0 / CMX_MIXNET_V1 / CMX_MIXNET_TOLERANCE are set)"); return 1; }
+  if (!h->use_spec || h->use_v1 || h->tolerance) { set_err("cmx_mixnet_run_late: a decoder needs the strict 27-workgroup kernel (CMX_MIXNET_SPEC=0, CMX_MIXNET_V1 or the tolerance switch is set)"); return 1; }
+  if (hipSetDevice(h->device) != hipSuccess) { set_err("hipSetDevice failed"); return 1; }
+  if (h->late_p_cap < nbits || h->decay_cap < nbits) { set_err("cmx_mixnet_run_late: call cmx_mixnet_late_prepare first (nothing may be allocated while the stream's kernels run)"); return 1; }
+  return mixnet_run_impl(h, probs, sel, nullptr, nbits, h->d_late_p, nullptr, stream, (CmxLateBox*)box);
+}
+// everything the decoder's form allocates, for chunks of up to nbits bits: before the first chunk's kernels are launched
+int cmx_mixnet_late_prepare(cmx_mixnet_t* h, size_t nbits) {
+  if (!h || !nbits) { set_err("cmx_mixnet_late_prepare: bad argument"); return 1; }
   if (hipSetDevice(h->device) != hipSuccess) { set_err("hipSetDevice failed"); return 1; }
   if (h->late_p_cap < nbits) {
     void* p = nullptr;
-    if (hipMalloc(&p, nbits * 4) != hipSuccess) { set_err("cmx_mixnet_run_late: hipMalloc failed"); return 1; }
+    if (hipMalloc(&p, nbits * 4) != hipSuccess) { set_err("cmx_mixnet_late_prepare: hipMalloc failed"); return 1; }
     h->allocs.push_back(p);
     h->d_late_p = (float*)p; h->late_p_cap = nbits;
   }
-  return mixnet_run_impl(h, probs, sel, nullptr, nbits, h->d_late_p, nullptr, stream, (CmxLateBox*)box);
+  if (!h->s_up) { if (hipStreamCreateWithFlags(&h->s_up, hipStreamNonBlocking) != hipSuccess) { set_err("cmx_mixnet_late_prepare: stream creation failed"); return 1; } h->own_up = true; }
+  return ensure_decay(h, nbits);
 }
 static int mixnet_run_impl(cmx_mixnet_t* h, const float* d_probs, const uint32_t* d_sel, const uint8_t* d_bits, size_t nbits, float* d_p_out, float* d_mix_out,
                            void* stream, CmxLateBox* box) {

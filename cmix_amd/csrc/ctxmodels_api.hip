@@ -280,6 +280,8 @@ cmx_ctxmodels_t* cmx_ctxmodels_create(const uint8_t vocab[256], int device) {
                             (int)cmx_ctxmodels_lds_bytes());
   (void)hipFuncSetAttribute((const void*)cmx_ctxmodels_peek_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)cmx_ctxmodels_lds_bytes());
+  (void)hipFuncSetAttribute((const void*)cmx_ctxmodels_late_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)cmx_ctxmodels_lds_bytes());
   if (hipDeviceSynchronize() != hipSuccess) {
     cmx_set_err("cmx_ctxmodels_create: init failed");
     cmx_ctxmodels_destroy(h);
@@ -364,7 +366,6 @@ int cmx_ctxmodels_run_late(cmx_ctxmodels_t* h, void* box, size_t nbytes, float* 
   hipStream_t st = (hipStream_t)stream;
   // (the stage's own copy in its persistent state: the kernel rewrites it only in its epilogue, long after the first byte's reader has it)
   if (brk_dist0_out) *brk_dist0_out = (const float*)((const char*)h->dev.persist + offsetof(CtxPersist, br_probs));
-  (void)hipFuncSetAttribute((const void*)cmx_ctxmodels_late_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cmx_ctxmodels_lds_bytes());
   hipLaunchKernelGGL(cmx_ctxmodels_late_kernel, dim3(1), dim3(64), cmx_ctxmodels_lds_bytes(), st, h->dev, (CmxLateBox*)box, nbytes, probs, pstride, sel, brk_dist);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { cmx_set_err(std::string("cmx_ctxmodels_run_late: ") + hipGetErrorString(e)); return 1; }

@@ -794,22 +794,30 @@ int cmx_fxcm_run(cmx_fxcm_t* h, const uint8_t* bytes, const uint8_t* d_bytes, si
 // `box`; the parser's record of a byte is written by cmx_fxcm_late_byte() when the decoder has completed it (before the byte's last
 // bit is published). hint_pr / hint_ex: the ByteModel kernel's per-update LSTM hints (host-coherent, counter LC_BM2); d_probs: rows
 // in memory the mixing network's kernel sees while both run. slot 0..2: the stage's set of record buffers for this chunk.
+// everything the decoder's form allocates, for chunks of up to nbytes bytes: before the first chunk's kernels are launched
+int cmx_fxcm_late_prepare(cmx_fxcm_t* h, size_t nbytes) {
+  if (!h || nbytes == 0 || nbytes > (1u << 16)) { cmx_set_err("cmx_fxcm_late_prepare: bad argument"); return 1; }
+  if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
+  for (int slot = 0; slot < 3; slot++) {
+    if (h->late_cap[slot] >= nbytes) continue;
+    if (h->late_cap[slot]) { cmx_set_err("cmx_fxcm_late_prepare: the chunk size may not grow"); return 1; }
+    h->late_recs[slot] = (FxByteRec*)cmx_late_alloc(nbytes * sizeof(FxByteRec));
+    if (!h->late_recs[slot]) { cmx_set_err("cmx_fxcm_late_prepare: record buffer allocation failed"); return 1; }
+    h->late_cap[slot] = nbytes;
+  }
+  if (h->rows_cap < nbytes) {
+    if (hipDeviceSynchronize() != hipSuccess) { cmx_set_err("cmx_fxcm_late_prepare: device error"); return 1; }
+    if (h->d_rows) (void)hipFree(h->d_rows);
+    h->d_rows = nullptr; h->rows_cap = 0;
+    if (hipMalloc((void**)&h->d_rows, nbytes * 8 * FX_ROW_WORDS * 4) != hipSuccess) { cmx_set_err("cmx_fxcm_late_prepare: row buffer allocation failed"); return 1; }
+    h->rows_cap = nbytes;
+  }
+  return 0;
+}
 int cmx_fxcm_run_late(cmx_fxcm_t* h, void* box, size_t nbytes, const int16_t* hint_pr, const uint8_t* hint_ex, float* d_probs, size_t pstride, int slot, void* stream) {
   if (!h || !box || !hint_pr || !hint_ex || !d_probs || nbytes == 0 || nbytes > (1u << 16) || pstride < 3 + FX_OUTPUTS || slot < 0 || slot > 2) { cmx_set_err("cmx_fxcm_run_late: bad argument"); return 1; }
   if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
-  if (h->late_cap[slot] < nbytes) {
-    if (h->late_cap[slot]) { cmx_set_err("cmx_fxcm_run_late: the chunk size may not grow"); return 1; }
-    h->late_recs[slot] = (FxByteRec*)cmx_late_alloc(nbytes * sizeof(FxByteRec));
-    if (!h->late_recs[slot]) { cmx_set_err("cmx_fxcm_run_late: record buffer allocation failed"); return 1; }
-    h->late_cap[slot] = nbytes;
-  }
-  if (h->rows_cap < nbytes) {   // grown between chunks: nothing of this stream may be in flight on the old buffer
-    if (hipDeviceSynchronize() != hipSuccess) { cmx_set_err("cmx_fxcm_run_late: device error"); return 1; }
-    if (h->d_rows) (void)hipFree(h->d_rows);
-    h->d_rows = nullptr; h->rows_cap = 0;
-    if (hipMalloc((void**)&h->d_rows, nbytes * 8 * FX_ROW_WORDS * 4) != hipSuccess) { cmx_set_err("cmx_fxcm_run_late: row buffer allocation failed"); return 1; }
-    h->rows_cap = nbytes;
-  }
+  if (h->late_cap[slot] < nbytes || h->rows_cap < nbytes) { cmx_set_err("cmx_fxcm_run_late: call cmx_fxcm_late_prepare first (nothing may be allocated while the stream's kernels run)"); return 1; }
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync((char*)h->d_xfer + 16, 0, sizeof(FxXfer) - 16, s) != hipSuccess) { cmx_set_err("cmx_fxcm_run_late: hipMemsetAsync failed"); return 1; }
   hipLaunchKernelGGL(cmx_fxcm_roles_late_kernel, dim3(FX_M_WGS + 2), dim3(FX_DEV_THREADS), FX_LDS_BYTES, s, h->d_dev, h->d_xfer, h->d_rows, (CmxLateBox*)box,

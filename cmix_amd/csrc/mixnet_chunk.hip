@@ -1420,7 +1420,7 @@ __device__ void helper_role(MixState* S, SpecXfer* X, HelperLds* H, int nbits, i
 #pragma unroll
     for (int k = 0; k < 9; ++k) xp[k] = xc[k];
     if (tol) {
-      // TOLERANCE MODE (opt-in, CMX_MIXNET_TOLERANCE=1; NOT bit-exact): the dot product as a tree sum -- every wave reduces its segment's products in
+      // TOLERANCE MODE (opt-in, cmx_mixnet_set_tolerance; NOT bit-exact): the dot product as a tree sum -- every wave reduces its segment's products in
       // f64 across its lanes, the last wave adds the four segment sums and rounds once. No ordered chain, no speculation. The value differs from the
       // reference's sequentially rounded f32 sum in the last bits (it is the more accurate one); streams coded with it are not the reference's.
       ds = wave_sum_f64(ds);

@@ -1252,17 +1252,16 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
 // Launches the role kernels of the next nbytes bytes; their bits, and with each bit the host records of the step after it, arrive
 // through `box` while they run. slot 0..2: which of the stage's three sets of host-coherent buffers the chunk uses (a chunk is
 // launched while its predecessor is still being decoded, and its predecessor's buffers are still read when it starts).
-int cmx_p8stage_run_late(cmx_p8stage_t* h, void* box_, size_t nbytes, float* d_out, size_t ld, int slot) {
-  if (!h || !box_ || !d_out || nbytes == 0 || nbytes > (1u << 16) || ld < P8_NOUT || slot < 0 || slot > 2) { cmx_set_err("cmx_p8stage_run_late: bad argument"); return 1; }
-  if (h->failed) { cmx_set_err("cmx_p8stage_run_late: the stage failed earlier on this stream"); return 1; }
-  if (h->s_b == h->s_d || h->s_c == h->s_d || h->s_f == h->s_c) { cmx_set_err("cmx_p8stage_run_late: the roles share HIP streams (CMX_PIPELINE_STREAMS): a decoder needs every role kernel running at once"); return 1; }
+// Everything the decoder's form allocates, for chunks of up to nbytes bytes: before the first chunk's kernels are launched (an
+// allocation that maps memory into the device while persistent kernels wait for the host would wait for them).
+int cmx_p8stage_late_prepare(cmx_p8stage_t* h, size_t nbytes) {
+  if (!h || nbytes == 0 || nbytes > (1u << 16)) { cmx_set_err("cmx_p8stage_late_prepare: bad argument"); return 1; }
   if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
-  CmxLateBox* B = (CmxLateBox*)box_;
   const P8Layout& L = h->L;
   const size_t n = nbytes, T = 8 * n;
-  cmx_p8stage::Late& b = h->late[slot];
-  if (b.cap < n) {
-    if (b.cap) { cmx_set_err("cmx_p8stage_run_late: the chunk size may not grow"); return 1; }
+  for (cmx_p8stage::Late& b : h->late) {
+    if (b.cap >= n) continue;
+    if (b.cap) { cmx_set_err("cmx_p8stage_late_prepare: the chunk size may not grow"); return 1; }
     size_t o = 0;
     auto take = [&](size_t bytes_) { const size_t at = o; o += (bytes_ + 255) & ~(size_t)255; return at; };
     b.o_fctx = take(n * L.fam_slots * 4); b.o_fchk = take(n * L.fam_slots * 2);
@@ -1272,20 +1271,34 @@ int cmx_p8stage_run_late(cmx_p8stage_t* h, void* box_, size_t nbytes, float* d_o
     b.rec = (char*)cmx_late_alloc(o);
     b.x = (int16_t*)cmx_late_alloc(T * P8_NX * 2);
     b.order = (uint8_t*)cmx_late_alloc(T);
-    if (!b.rec || !b.x || !b.order) { cmx_set_err("cmx_p8stage_run_late: buffer allocation failed"); h->failed = true; return 1; }
+    if (!b.rec || !b.x || !b.order) { cmx_set_err("cmx_p8stage_late_prepare: buffer allocation failed"); h->failed = true; return 1; }
     b.cap = n;
     b.c.fam_ctx = (uint32_t*)(b.rec + b.o_fctx); b.c.fam_chk = (uint16_t*)(b.rec + b.o_fchk);
     for (int k = 0; k < P8_NCM2; k++) { b.c.cm2_ctx[k] = (uint32_t*)(b.rec + b.o_cctx[k]); b.c.cm2_chk[k] = (uint16_t*)(b.rec + b.o_cchk[k]); }
     b.c.ops = (uint32_t*)(b.rec + b.o_ops); b.c.sel = (int32_t*)(b.rec + b.o_sel); b.c.apm = (P8ApmRec*)(b.rec + b.o_apm);
   }
-  bool ok = true;
   if (h->prx_steps < T) {
-    ok = hipDeviceSynchronize() == hipSuccess;
+    bool ok = hipDeviceSynchronize() == hipSuccess;
     if (h->d_prx) (void)hipFree(h->d_prx);
     h->d_prx = nullptr;
     ok = ok && hipMalloc((void**)&h->d_prx, T * P8_NSEL * 8) == hipSuccess && hipMemset(h->d_prx, 0, T * P8_NSEL * 8) == hipSuccess;
     h->prx_steps = ok ? T : 0;
+    if (!ok) { cmx_set_err("cmx_p8stage_late_prepare: exchange rows allocation failed"); return 1; }
   }
+  if (hipFuncSetAttribute((const void*)cmx_p8s_fam2_late_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->fam_lds) != hipSuccess) { cmx_set_err("cmx_p8stage_late_prepare: kernel attribute failed"); return 1; }
+  return 0;
+}
+int cmx_p8stage_run_late(cmx_p8stage_t* h, void* box_, size_t nbytes, float* d_out, size_t ld, int slot) {
+  if (!h || !box_ || !d_out || nbytes == 0 || nbytes > (1u << 16) || ld < P8_NOUT || slot < 0 || slot > 2) { cmx_set_err("cmx_p8stage_run_late: bad argument"); return 1; }
+  if (h->failed) { cmx_set_err("cmx_p8stage_run_late: the stage failed earlier on this stream"); return 1; }
+  if (h->s_b == h->s_d || h->s_c == h->s_d || h->s_f == h->s_c) { cmx_set_err("cmx_p8stage_run_late: the roles share HIP streams (CMX_PIPELINE_STREAMS): a decoder needs every role kernel running at once"); return 1; }
+  if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
+  CmxLateBox* B = (CmxLateBox*)box_;
+  const P8Layout& L = h->L;
+  const size_t n = nbytes, T = 8 * n;
+  cmx_p8stage::Late& b = h->late[slot];
+  if (b.cap < n || h->prx_steps < T) { cmx_set_err("cmx_p8stage_run_late: call cmx_p8stage_late_prepare first (nothing may be allocated while the stream's kernels run)"); return 1; }
+  bool ok = true;
   const int nbits = (int)T;
   const int skip = h->steps >= 8 ? 0 : (int)(8 - h->steps), t0 = h->steps == 0 ? 1 : 0;
   if (ok) {

@@ -90,7 +90,7 @@ struct Slot {
   float* h_ppmd = nullptr;      // pinned [max+1][256]
   float* d_hint = nullptr;      // [8 max + 1] f32 LSTM bit predictions, then [8 max + 1] i32 `ex` (look-ahead hybrid)
   float* h_hint = nullptr;      // pinned mirror
-  unsigned* h_fail = nullptr;   // pinned [2]: the LSTM's / fxcm's sticky hand-off flags as they stood behind this chunk's kernels
+  unsigned* h_fail = nullptr;   // pinned [4]: the LSTM's / fxcm's / mixing network's sticky hand-off flags as they stood behind this chunk's kernels
   size_t n = 0;                 // bytes of the chunk in this slot
   float* d_layer0 = nullptr;    // the caller's layer-0 rows of that chunk
   float* d_p = nullptr;         // the caller's p[] buffer of that chunk (cmx_pipeline_fetch)
@@ -313,8 +313,8 @@ cmx_pipeline_t* cmx_pipeline_create(const uint8_t vocab[256], int device, size_t
     ok = ok && hipHostMalloc((void**)&s.h_ppmd, (n + 1) * 256 * 4, hipHostMallocDefault) == hipSuccess;
     ok = ok && hipMalloc((void**)&s.d_hint, 2 * (8 * n + 1) * 4) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&s.h_hint, 2 * (8 * n + 1) * 4, hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipHostMalloc((void**)&s.h_fail, 8, hipHostMallocDefault) == hipSuccess;
-    if (ok) s.h_fail[0] = s.h_fail[1] = 0;
+    ok = ok && hipHostMalloc((void**)&s.h_fail, 16, hipHostMallocDefault) == hipSuccess;
+    if (ok) s.h_fail[0] = s.h_fail[1] = s.h_fail[2] = s.h_fail[3] = 0;
     for (hipEvent_t* e : {&s.ev_in, &s.ev_ctx0, &s.ev_ctx1, &s.ev_lstm0, &s.ev_lstm1, &s.ev_mix0, &s.ev_mix1, &s.ev_cols})
       ok = ok && hipEventCreate(e) == hipSuccess;
   }
@@ -399,6 +399,13 @@ int cmx_pipeline_enable_paq8(cmx_pipeline_t* h) {
   h->p8 = p8;
   return 0;
 }
+// the mixing network's tolerance mode (cmx_mixnet_set_tolerance: NOT bit-exact, bench / measurement only); before the first chunk
+int cmx_pipeline_set_tolerance(cmx_pipeline_t* h, int on) {
+  if (!h) { cmx_set_err("cmx_pipeline_set_tolerance: null handle"); return 1; }
+  if (h->chunks || h->late) { cmx_set_err("cmx_pipeline_set_tolerance: only before the first chunk"); return 1; }
+  return cmx_mixnet_set_tolerance(h->mix, on);
+}
+int cmx_pipeline_mixnet_mode(cmx_pipeline_t* h) { return h ? cmx_mixnet_mode(h->mix) : -1; }
 int cmx_pipeline_paq8_enabled(cmx_pipeline_t* h) { return h && h->p8 ? 1 : 0; }
 int cmx_pipeline_paq8_total_ms(cmx_pipeline_t* h, double* ms) { if (!h || !ms) return 1; *ms = h->p8_ms; return 0; }
 // wall time of the CALLING thread inside cmx_pipeline_begin / _finish since the last reset of the stage totals, in ms:
@@ -558,6 +565,9 @@ static int finish_impl(cmx_pipeline_t* h, const float* cols, int first_col, int 
   if (h->p8) (void)hipStreamWaitEvent(h->s_mix, s.ev_p81, 0);
   (void)hipEventRecord(s.ev_mix0, h->s_mix);
   if (cmx_mixnet_run(h->mix, s.d_layer0, s.d_sel, s.d_bits, 8 * n, d_p_out, nullptr, h->s_mix)) return 1;
+  // the kernel's sticky time-out word, in stream order behind it: cmx_pipeline_wait looks at it per chunk (a look-ahead coder never
+  // calls cmx_pipeline_sync, the only other place where it is read)
+  (void)hipMemcpyAsync(&s.h_fail[2], cmx_mixnet_error_flag(h->mix), 4, hipMemcpyDeviceToHost, h->s_mix);
   (void)hipEventRecord(s.ev_mix1, h->s_mix);
   s.d_p = d_p_out;
   h->host_ms[5] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fin).count();
@@ -629,8 +639,9 @@ int cmx_pipeline_wait(cmx_pipeline_t* h, uint64_t index) {
   if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
   Slot& s = h->slot[index % kSlots];
   if (hipEventSynchronize(s.ev_mix1) != hipSuccess) { cmx_set_err("cmx_pipeline_wait: device error"); return 1; }
-  if (s.h_fail[0] || s.h_fail[1]) {
-    cmx_set_err(std::string("cmx_pipeline_wait: an in-launch hand-off of the ") + (s.h_fail[0] ? "LSTM" : "fxcm") +
+  const bool p8fail = h->p8 && cmx_p8stage_mixfail(h->p8);   // (host-mapped: the paq8 mixer's workgroup 0 gave up waiting for another workgroup)
+  if (s.h_fail[0] || s.h_fail[1] || s.h_fail[2] || p8fail) {
+    cmx_set_err(std::string("cmx_pipeline_wait: an in-launch hand-off of the ") + (s.h_fail[0] ? "LSTM" : s.h_fail[1] ? "fxcm" : s.h_fail[2] ? "mixing network" : "paq8 mixer") +
                 " kernels timed out (workgroups not co-resident?): the stream's output is void from chunk " + std::to_string(index) + " on");
     h->failed = true;
     return 1;
@@ -751,6 +762,10 @@ int cmx_pipeline_late_start(cmx_pipeline_t* h, int last_bit) {
     ok = ok && q.box && q.layer0 && q.sel && q.brk && q.lstm && q.ppmd && q.bytes && q.hint_pr && q.hint_ex;
   }
   if (!ok) { cmx_set_err("cmx_pipeline_late_start: buffer allocation failed"); L->failed = true; return 1; }
+  // every stage allocates what it needs NOW: once the first chunk's kernels run they wait for this thread, and an allocation that maps
+  // memory into the device may wait for them
+  if (cmx_fxcm_late_prepare(h->fxcm, n) || cmx_p8stage_late_prepare(h->p8, n) || cmx_mixnet_late_prepare(h->mix, T)) { L->failed = true; return 1; }
+  if (hipDeviceSynchronize() != hipSuccess) { cmx_set_err("cmx_pipeline_late_start: device error"); L->failed = true; return 1; }
   L->lstm0 = cmx_lstm_byte_probs(h->lstm);
   // chunk 0 and, queued behind it, chunk 1
   if (late_launch(h, 0)) { L->failed = true; return 1; }
@@ -796,7 +811,11 @@ float cmx_pipeline_late_predict(cmx_pipeline_t* h) {
       else if (cmx_p8stage_mixfail(h->p8)) why = "the paq8 mixer's workgroup 0 timed out waiting for another workgroup";
       else if (el > 60000.0) why = "no prediction from the device for 60 s";
       if (why) {
-        cmx_set_err(std::string("cmx_pipeline_late_predict: ") + why + " at bit " + std::to_string(L->bits));
+        std::string st = " [box: nknown " + std::to_string(q.box->nknown) + " start " + std::to_string(q.box->start) + " rows";
+        static const char* const nm[] = {"ctx", "bm0", "bm1", "bm2", "fx", "p8", "cm2a", "cm2b", "cm2c", "fam", "lanes", "dmc", "brk", "lstm"};
+        for (int i = 0; i < 14; ++i) st += std::string(" ") + nm[i] + "=" + std::to_string(*(volatile uint32_t*)&q.box->cnt[i].v);
+        st += "]";
+        cmx_set_err(std::string("cmx_pipeline_late_predict: ") + why + " at bit " + std::to_string(L->bits) + " (bit " + std::to_string(L->t) + " of its chunk)" + st);
         L->failed = true;
         for (LateSet& z : L->set) if (z.box) z.box->abort = 1;
         return -1.0f;

@@ -147,6 +147,10 @@ def lib():
         L.cmx_pipeline_paq8_role_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.cmx_pipeline_last_stage_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.cmx_probe_libm.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.cmx_pipeline_set_tolerance.argtypes = [C.c_void_p, C.c_int]
+        L.cmx_pipeline_mixnet_mode.argtypes = [C.c_void_p]
+        L.cmx_mixnet_set_tolerance.argtypes = [C.c_void_p, C.c_int]
+        L.cmx_mixnet_mode.argtypes = [C.c_void_p]
         L.cmx_pipeline_late_start.argtypes = [C.c_void_p, C.c_int]
         L.cmx_pipeline_late_predict.restype = C.c_float
         L.cmx_pipeline_late_predict.argtypes = [C.c_void_p]
@@ -184,6 +188,11 @@ class MixNet:
         if not self.h:
             raise CmxError(last_error())
         self.device = device
+
+    def set_tolerance(self, on=True):
+        """Tolerance mode (NOT bit-exact: layer-0 dot products as f64 tree sums): explicit, before the handle's first bit."""
+        if lib().cmx_mixnet_set_tolerance(self.h, int(bool(on))):
+            raise CmxError(last_error())
 
     def close(self):
         if getattr(self, "h", None):
@@ -523,6 +532,15 @@ class Pipeline:
         lib().cmx_pipeline_stage_totals(self.h, ms, C.byref(n), int(reset))
         k = max(n.value, 1)
         return {"ctxmodels": ms[0] / k, "lstm": ms[1] / k, "mixnet": ms[2] / k, "chunks": n.value}
+
+    def set_tolerance(self, on=True):
+        """The mixing network's tolerance mode (NOT bit-exact): an explicit switch, before the first chunk."""
+        if lib().cmx_pipeline_set_tolerance(self.h, int(bool(on))):
+            raise CmxError(last_error())
+
+    def mixnet_mode(self):
+        """0 strict (bit-exact, the default), 1 tolerance -- as the library reports it"""
+        return lib().cmx_pipeline_mixnet_mode(self.h)
 
     # ---- the decoder's form (late-bit protocol, include/cmix_amd.h section 4): fxcm and paq8 must be enabled ----
     def late_start(self, last_bit=0):

@@ -105,6 +105,12 @@ void cmx_mixnet_destroy(cmx_mixnet_t*);
 /* The stream the handle's host-to-device copies (the decay schedule of a chunk) go on; NULL-less default: a stream the handle
  * creates. A copy must never sit behind a long kernel in stream order: on this hardware it then holds up later copies of the
  * whole process. cmx_pipeline_* hands ONE upload stream to all its stages. Same for cmx_fxcm_* (records) and cmx_p8stage_*. */
+/* Tolerance mode of the 27-workgroup kernel (NOT bit-exact: layer-0 dot products as f64 tree sums rounded once). An explicit
+ * switch of the handle, before its first bit -- never an environment variable: a stream coded with it is not the reference's
+ * and cannot be decoded by this library's (strict) decoder. cmx_mixnet_mode: 0 strict (default), 1 tolerance. */
+int cmx_mixnet_set_tolerance(cmx_mixnet_t*, int on);
+const int* cmx_mixnet_error_flag(cmx_mixnet_t*);   /* DEVICE address of the sticky "an in-launch wait ran out" word (see cmx_lstm_fail_flag) */
+int cmx_mixnet_mode(cmx_mixnet_t*);
 int cmx_mixnet_set_upload_stream(cmx_mixnet_t*, void* stream);
 /* Chunk mode. All pointers are DEVICE pointers (HBM-resident operands):
  *   d_probs [nbits][2078] f32  raw model outputs (Model::Predict values)
@@ -394,6 +400,9 @@ int cmx_pipeline_host_ms(cmx_pipeline_t*, double ms[6]);
 int cmx_pipeline_fxcm_enabled(cmx_pipeline_t*);
 int cmx_pipeline_finish_cols(cmx_pipeline_t*, const float* cols, int first_col, int ncols, float* d_p_out);
 int cmx_pipeline_fxcm_total_ms(cmx_pipeline_t*, double* ms);
+/* the mixing network's tolerance mode for this stream (cmx_mixnet_set_tolerance), before the first chunk; _mixnet_mode: 0 strict, 1 tolerance */
+int cmx_pipeline_set_tolerance(cmx_pipeline_t*, int on);
+int cmx_pipeline_mixnet_mode(cmx_pipeline_t*);
 /* Predictor::Pretrain over n dictionary bytes (HOST pointer), before the first submit: only the stages holding
  * `models_` learn (today: contexts + small models); mixers, SSE, LSTM and PPMd are not trained (predictor.cpp:471-487). */
 int cmx_pipeline_pretrain(cmx_pipeline_t*, const uint8_t* bytes, size_t n);
@@ -455,6 +464,11 @@ int cmx_bytemodel_late_run(int device, void* box, size_t nbytes, const float* br
                            const uint32_t* c0_brk, uint32_t c0_brk_want, const uint32_t* c0_lstm, uint32_t c0_lstm_want, float* layer0, size_t pstride,
                            int16_t* hint_pr, uint8_t* hint_ex, void* stream);
 const float* cmx_lstm_byte_probs(cmx_lstm_t*);
+/* _late_prepare: everything a stage allocates for chunks of that size, BEFORE the stream's first kernels are launched (an allocation
+ * that maps memory into the device can wait for running kernels -- which, here, wait for the host) */
+int cmx_fxcm_late_prepare(cmx_fxcm_t*, size_t nbytes);
+int cmx_p8stage_late_prepare(cmx_p8stage_t*, size_t nbytes);
+int cmx_mixnet_late_prepare(cmx_mixnet_t*, size_t nbits);
 int cmx_fxcm_run_late(cmx_fxcm_t*, void* box, size_t nbytes, const int16_t* hint_pr, const uint8_t* hint_ex, float* probs, size_t pstride, int slot, void* stream);
 int cmx_fxcm_late_byte(cmx_fxcm_t*, int slot, size_t b, uint8_t byte);
 int cmx_p8stage_run_late(cmx_p8stage_t*, void* box, size_t nbytes, float* out, size_t ld, int slot);

@@ -21,6 +21,15 @@ EXE = os.path.join(ROOT, "oracle", "_ref", "cmix_hybrid")
 LOOKAHEAD = os.path.join(ROOT, "oracle", "_ref", "cmix_lookahead")
 
 
+def _missing(what):
+    """A reference-built test binary / fixture that should have travelled with the snapshot is absent: on the GPU box that is a FAILURE
+    (a green run with a third of the suite skipped proves nothing); in the GPU-less dev container the test has nothing to run on."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.fail(what + " (build oracle/_ref with `make -C oracle` before taking the snapshot to the GPU box)")
+    pytest.skip(what)
+
+
 def _run(mode, files, timeout=600, exe=None):
     with tempfile.TemporaryDirectory() as d:
         paths = []
@@ -39,7 +48,7 @@ def _run(mode, files, timeout=600, exe=None):
 
 def _vectors():
     if not os.path.exists(EXE):
-        pytest.skip("oracle/_ref/cmix_hybrid not built (make -C oracle hybrid)")
+        _missing("oracle/_ref/cmix_hybrid not built (make -C oracle hybrid)")
     with np.load(os.path.join(GOLDEN, "dropin_vectors.npz")) as z:
         return {k: z[k].tobytes() for k in z.files}
 
@@ -76,7 +85,7 @@ def test_50k_text_compresses_to_the_reference_binarys_file():
     import hashlib
     from cmix_amd import synth
     if not os.path.exists(EXE):
-        pytest.skip("oracle/_ref/cmix_hybrid not built (make -C oracle hybrid)")
+        _missing("oracle/_ref/cmix_hybrid not built (make -C oracle hybrid)")
     with np.load(os.path.join(GOLDEN, "dropin_vectors.npz")) as z:
         if "text50k_c_sha256" not in z.files:
             pytest.skip("fixture without the 50 KB case")
@@ -93,7 +102,7 @@ def test_50k_text_compresses_to_the_reference_binarys_file():
 
 def _lookahead_vectors():
     if not os.path.exists(LOOKAHEAD):
-        pytest.skip("oracle/_ref/cmix_lookahead not built (make -C oracle lookahead)")
+        _missing("oracle/_ref/cmix_lookahead not built (make -C oracle lookahead)")
     return _vectors()
 
 
@@ -128,7 +137,7 @@ def test_lookahead_1mib_shard_prefix_is_byte_identical():
     from cmix_amd import synth
     path = os.path.join(GOLDEN, "dropin_1m.npz")
     if not os.path.exists(path) or not os.path.exists(LOOKAHEAD):
-        pytest.skip("fixture or oracle/_ref/cmix_lookahead missing")
+        _missing("fixture or oracle/_ref/cmix_lookahead missing")
     with np.load(path) as z:
         want_sha, want_size, (n, seed) = z["sha256"].tobytes(), int(z["size"][0]), z["seed"]
     got = _run("-c", [("in", synth.enwik_like(int(n), int(seed)))], exe=LOOKAHEAD, timeout=1500)
@@ -143,13 +152,13 @@ ENGINE = os.path.join(ROOT, "oracle", "_ref", "cmix_engine")
 
 def _engine_vectors():
     if not os.path.exists(ENGINE):
-        pytest.skip("oracle/_ref/cmix_engine not built (make -C oracle engine)")
+        _missing("oracle/_ref/cmix_engine not built (make -C oracle engine)")
     return _vectors()
 
 
 def test_engine_links_no_reference_model():
     if not os.path.exists(ENGINE):
-        pytest.skip("oracle/_ref/cmix_engine not built")
+        _missing("oracle/_ref/cmix_engine not built")
     syms = subprocess.run(["nm", "-C", ENGINE], capture_output=True, text=True).stdout
     assert "paq8" not in syms.replace("cmx_pipeline_enable_paq8", "") and "fxcmv1" not in syms and "PPMD" not in syms
 
@@ -181,7 +190,7 @@ def _shard_prefix(fixture, timeout):
     from cmix_amd import synth
     path = os.path.join(GOLDEN, fixture)
     if not os.path.exists(path) or not os.path.exists(ENGINE):
-        pytest.skip("fixture or oracle/_ref/cmix_engine missing")
+        _missing("fixture or oracle/_ref/cmix_engine missing")
     with np.load(path) as z:
         want_sha, want_size, (n, seed) = z["sha256"].tobytes(), int(z["size"][0]), z["seed"]
     got = _run("-c", [("in", synth.enwik_like(int(n), int(seed)))], exe=ENGINE, timeout=timeout)
@@ -207,7 +216,7 @@ def test_engine_mixed_text_and_exe_blocks_file_is_byte_identical():
     through every stage (tests/golden/make_dropin_mixed.py; the same stream pins the paq8 and fxcm stages per bit through
     tests/golden/{paq8,fxcm}_cols_mixed_24k.npz)."""
     if not os.path.exists(ENGINE):
-        pytest.skip("oracle/_ref/cmix_engine not built")
+        _missing("oracle/_ref/cmix_engine not built")
     with np.load(os.path.join(GOLDEN, "dropin_mixed.npz")) as z:
         payload, want = z["payload"].tobytes(), z["cmix_file"].tobytes()
     assert _run("-c", [("in", payload)], exe=ENGINE, timeout=600) == want
@@ -217,7 +226,7 @@ def test_engine_binary_file_with_default_blocks_is_byte_identical():
     """Random bytes, 24-byte records, zero / 0xFF runs, a ramp: `cmix -c` on data its detector leaves as DEFAULT blocks
     (tests/golden/make_dropin_binary.py) -- the record / sparse / match / DMC models on their home ground."""
     if not os.path.exists(ENGINE):
-        pytest.skip("oracle/_ref/cmix_engine not built")
+        _missing("oracle/_ref/cmix_engine not built")
     with np.load(os.path.join(GOLDEN, "dropin_binary.npz")) as z:
         payload, want = z["payload"].tobytes(), z["cmix_file"].tobytes()
     assert _run("-c", [("in", payload)], exe=ENGINE, timeout=600) == want
@@ -227,7 +236,7 @@ def test_engine_tiny_files_are_byte_identical():
     """0, 1, 2, 17 and 100 bytes (`-c`), 0 and 1 byte (`-n`): the empty file, inputs shorter than a block header, one BPTT block, a
     sub-chunk (tests/golden/make_dropin_tiny.py)."""
     if not os.path.exists(ENGINE):
-        pytest.skip("oracle/_ref/cmix_engine not built")
+        _missing("oracle/_ref/cmix_engine not built")
     import make_dropin_tiny as mk
     with np.load(os.path.join(GOLDEN, "dropin_tiny.npz")) as z:
         v = {k: z[k].tobytes() for k in z.files}
@@ -245,13 +254,13 @@ DROPIN = os.path.join(ROOT, "oracle", "_ref", "cmix_dropin")
 
 def _dropin_vectors():
     if not os.path.exists(DROPIN):
-        pytest.skip("oracle/_ref/cmix_dropin not built (make -C oracle dropin_engine)")
+        _missing("oracle/_ref/cmix_dropin not built (make -C oracle dropin_engine)")
     return _vectors()
 
 
 def test_dropin_engine_links_no_reference_model():
     if not os.path.exists(DROPIN):
-        pytest.skip("oracle/_ref/cmix_dropin not built")
+        _missing("oracle/_ref/cmix_dropin not built")
     syms = subprocess.run(["nm", "-C", DROPIN], capture_output=True, text=True).stdout
     assert "paq8" not in syms and "fxcmv1" not in syms and "PPMD" not in syms and "Lstm" not in syms
     assert "Encoder::Encode" in syms and "cmx_stage_input" in syms   # the reference's coder, the library's look-ahead
@@ -277,7 +286,7 @@ def test_dropin_engine_12k_and_50k_files_are_byte_identical():
 
 def test_dropin_engine_empty_and_tiny_files():
     if not os.path.exists(DROPIN):
-        pytest.skip("oracle/_ref/cmix_dropin not built")
+        _missing("oracle/_ref/cmix_dropin not built")
     import make_dropin_tiny as mk
     with np.load(os.path.join(GOLDEN, "dropin_tiny.npz")) as z:
         v = {k: z[k].tobytes() for k in z.files}
@@ -300,7 +309,7 @@ def test_dropin_decodes_the_reference_binarys_files():
 
 def test_dropin_decodes_empty_and_tiny_files():
     if not os.path.exists(DROPIN):
-        pytest.fail("oracle/_ref/cmix_dropin not built")
+        _missing("oracle/_ref/cmix_dropin not built")
     import make_dropin_tiny as mk
     with np.load(os.path.join(GOLDEN, "dropin_tiny.npz")) as z:
         v = {k: z[k].tobytes() for k in z.files}
@@ -311,7 +320,7 @@ def test_dropin_decodes_empty_and_tiny_files():
 def test_dropin_decodes_mixed_and_binary_files():
     """a TEXT block followed by an EXE block (e8e9 inverse), and DEFAULT blocks of random bytes / records / runs"""
     if not os.path.exists(DROPIN):
-        pytest.fail("oracle/_ref/cmix_dropin not built")
+        _missing("oracle/_ref/cmix_dropin not built")
     for fx in ("dropin_mixed.npz", "dropin_binary.npz"):
         with np.load(os.path.join(GOLDEN, fx)) as z:
             payload, blob = z["payload"].tobytes(), z["cmix_file"].tobytes()
@@ -346,7 +355,7 @@ def test_dropin_round_trips_50k_and_256k():
     import time
     from cmix_amd import synth
     if not os.path.exists(DROPIN):
-        pytest.fail("oracle/_ref/cmix_dropin not built")
+        _missing("oracle/_ref/cmix_dropin not built")
     times = []
     for n, seed, rich in ((50000, None, False), (262144, 1000, False)):
         if seed is None:
@@ -375,7 +384,7 @@ def test_dropin_engine_english_dic_pretrain_and_wrt_text_is_byte_identical():
     dic = os.path.join(ROOT, "oracle", "_ref", "english.dic")
     fx = os.path.join(GOLDEN, "dropin_dict.npz")
     if not (os.path.exists(DROPIN) and os.path.exists(dic) and os.path.exists(fx)):
-        pytest.skip("cmix_dropin, oracle/_ref/english.dic or the fixture missing")
+        _missing("cmix_dropin, oracle/_ref/english.dic or the fixture missing")
     with np.load(fx) as z:
         payload, want_sha, want_size, dic_sha = z["payload"].tobytes(), z["sha256"].tobytes(), int(z["size"][0]), z["dict_sha256"].tobytes()
     blob = open(dic, "rb").read()
@@ -399,7 +408,7 @@ def test_silesia_like_members_through_the_multifile_driver_are_byte_identical(tm
     from cmix_amd import multifile, synth
     fx = os.path.join(GOLDEN, "dropin_silesia.npz")
     if not (os.path.exists(ENGINE) and os.path.exists(fx)):
-        pytest.skip("cmix_engine or the fixture missing")
+        _missing("cmix_engine or the fixture missing")
     import torch
     with np.load(fx) as z:
         g = {k: z[k] for k in z.files}
@@ -417,6 +426,7 @@ def test_silesia_like_members_through_the_multifile_driver_are_byte_identical(tm
         got = (tmp_path / (name + ".cmix")).read_bytes()
         if len(got) != int(g[name + "_size"][1]) or hashlib.sha256(got).digest() != g[name + "_sha256"].tobytes():
             bad.append((name, len(got), int(g[name + "_size"][1])))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "config4_silesia_time.txt"), "w") as f:
         for dev, r in sorted(rep.items()):
             f.write("GPU %d: %d files, %d bytes, %.1f s\n" % (dev, len(r["files"]), r["bytes"], r["seconds"]))

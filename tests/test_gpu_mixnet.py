@@ -9,10 +9,12 @@ import make_golden as mg
 pytestmark = pytest.mark.gpu
 
 
-def _gpu_run(probs, sel, bits, chunks=None):
+def _gpu_run(probs, sel, bits, chunks=None, tolerance=False):
     import torch
     from cmix_amd import engine as E
     net = E.MixNet(0)
+    if tolerance:
+        net.set_tolerance(True)
     T = len(bits)
     d_probs = torch.from_numpy(probs).cuda()
     d_sel = torch.from_numpy((sel & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.int32)).cuda()
@@ -126,24 +128,31 @@ def test_protocol_errors():
 
 
 def test_tolerance_mode_stays_within_its_tolerance(monkeypatch):
-    """CMX_MIXNET_TOLERANCE=1 (opt-in, not bit-exact): the layer-0 dot products as f64 tree sums rounded once instead of the reference's
-    2078 sequentially rounded f32 adds. The final probability comes out of integer SSE tables (steps of 1/32766 = 3.05e-5), so a
-    last-bit difference of a sum either vanishes or shows as whole steps: on the reference's own trace every bit is identical, on a
-    3000-bit synthetic trace with rows past 1024 steps 99.6 % are and the largest difference is ten steps (measured on the MI355X:
-    profiles/r03_mixnet_tolerance_mode.txt). The bound below is that picture with room -- the difference may appear, it must not
-    build up or run away -- and strict mode must be untouched by the switch's existence."""
+    """Tolerance mode (opt-in through cmx_mixnet_set_tolerance -- an API switch, never an environment variable; not bit-exact): the
+    layer-0 dot products as f64 tree sums rounded once instead of the reference's 2078 sequentially rounded f32 adds.
+    north_star's 1e-6 is a statement about what the mode changes -- the 26 layer-0 sums: over the first 64 bits of a stream (before
+    the two weight histories have had time to drift apart through the learning feedback) every sum agrees with strict mode's to
+    1e-6 of the sum's scale. The final probability comes out of integer SSE tables (steps of 1/32766 = 3.05e-5), so a last-bit
+    difference of a sum either vanishes or shows as whole steps: its deviation is REPORTED, with a loose guard that it neither builds
+    up nor runs away (measured on the MI355X, profiles/r03_mixnet_tolerance_mode.txt: identical on the reference's own trace, 99.6 %
+    identical and at most ten steps on a 3000-bit synthetic trace with rows past 1024 steps). The environment variable of round 3
+    must no longer switch anything."""
     g = load_golden("text_96")
     probs = mg.unpack_probs(g)
-    monkeypatch.setenv("CMX_MIXNET_TOLERANCE", "1")
-    p_tol, _ = _gpu_run(probs, g["sel"], g["bits"])
+    p_tol, m_tol = _gpu_run(probs, g["sel"], g["bits"], tolerance=True)
     T = 3000
     sp, ss, sb = synth_mixnet_inputs(T, seed=11, n_ctx_bits=1)
-    q_tol, _ = _gpu_run(sp, ss, sb)
+    q_tol, n_tol = _gpu_run(sp, ss, sb, tolerance=True)
+    monkeypatch.setenv("CMX_MIXNET_TOLERANCE", "1")   # ignored since round 4
+    p_strict, m_strict = _gpu_run(probs, g["sel"], g["bits"])
     monkeypatch.delenv("CMX_MIXNET_TOLERANCE")
-    p_strict, _ = _gpu_run(probs, g["sel"], g["bits"])
-    q_strict, _ = _gpu_run(sp, ss, sb)
+    q_strict, n_strict = _gpu_run(sp, ss, sb)
     assert bits_equal(p_strict, g["p_final"]).all()
-    for name, a, b in (("text_96", p_tol, p_strict), ("synthetic 3000 bits, rows past 1024 steps", q_tol, q_strict)):
+    for name, a, b, ma, mb in (("text_96", p_tol, p_strict, m_tol, m_strict), ("synthetic 3000 bits, rows past 1024 steps", q_tol, q_strict, n_tol, n_strict)):
         d = np.abs(a.astype(np.float64) - b.astype(np.float64))
-        print("tolerance mode, %s: max |dp| = %.3g, mean %.3g over %d bits; %d of them bit-identical" % (name, d.max(), d.mean(), len(d), int(bits_equal(a, b).sum())))
+        s0 = np.abs(ma[:64, :26].astype(np.float64) - mb[:64, :26].astype(np.float64)) / np.maximum(1.0, np.abs(mb[:64, :26].astype(np.float64)))
+        sall = np.abs(ma[:, :26].astype(np.float64) - mb[:, :26].astype(np.float64)) / np.maximum(1.0, np.abs(mb[:, :26].astype(np.float64)))
+        print("tolerance mode, %s: layer-0 sums, first 64 bits: max rel dev %.3g; all %d bits: max %.3g; final p: max |dp| = %.3g, mean %.3g; %d of %d bit-identical"
+              % (name, s0.max(), len(d), sall.max(), d.max(), d.mean(), int(bits_equal(a, b).sum()), len(d)))
+        assert s0.max() <= 1e-6, (name, s0.max())
         assert d.max() < 1e-3 and bits_equal(a, b).mean() > 0.99, (name, d.max(), bits_equal(a, b).mean())
