@@ -17,14 +17,14 @@
 
 #include "../../include/cmix_amd.h"
 #include "mixnet_state.h"
+#include "cmx_late.h"
 
 extern "C" __global__ void cmx_mixnet_kernel(MixState*, const float*, const uint32_t*,
                                              const uint8_t*, const float*, int, float*, float*, int);
 extern "C" __global__ void cmx_mixnet_chunk_kernel(MixState*, const float*, const uint32_t*,
                                                    const uint8_t*, const float*, int, float*, float*, int);
-struct CmxLateBox;
 extern "C" __global__ void cmx_mixnet_spec_kernel(MixState*, SpecXfer*, const float*, const uint32_t*, const uint8_t*, const float*, int, float*,
-                                                  float*, int, CmxLateBox*);
+                                                  float*, int, CmxLate);
 extern "C" __global__ void cmx_sse_init_kernel(MixState*);
 extern "C" __global__ void cmx_probe_libm_kernel(int, const float*, float*, size_t);
 
@@ -178,6 +178,20 @@ void* cmx_late_alloc(size_t bytes) {
   return p;
 }
 void cmx_late_free(void* p) { if (p) (void)hipHostFree(p); }
+// Memory that kernels of different launches hand rows to each other through WHILE THEY RUN (and the row counters): device memory with
+// the uncached attribute -- a store followed by s_waitcnt vmcnt(0) has reached the device's memory, a load never hits a stale line of
+// another XCD's L2 --, zeroed.
+void* cmx_late_alloc_dev(int device, size_t bytes) {
+  void* p = nullptr;
+  if (hipSetDevice(device) != hipSuccess) { set_err("cmx_late_alloc_dev: hipSetDevice failed"); return nullptr; }
+  if (hipExtMallocWithFlags(&p, bytes ? bytes : 1, hipDeviceMallocUncached) != hipSuccess) {
+    (void)hipGetLastError();
+    if (hipExtMallocWithFlags(&p, bytes ? bytes : 1, hipDeviceMallocFinegrained) != hipSuccess) { set_err("cmx_late_alloc_dev: hipExtMallocWithFlags failed"); return nullptr; }
+  }
+  if (hipMemset(p, 0, bytes) != hipSuccess) { (void)hipFree(p); set_err("cmx_late_alloc_dev: hipMemset failed"); return nullptr; }
+  return p;
+}
+void cmx_late_free_dev(void* p) { if (p) (void)hipFree(p); }
 int cmx_copy_to_host(int device, void* dst, const void* d_src, size_t bytes) {  // synchronous, after all prior work of the device
   if (hipSetDevice(device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
       hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
@@ -368,7 +382,7 @@ int cmx_mixnet_set_upload_stream(cmx_mixnet_t* h, void* stream) {
 }
 
 static int mixnet_run_impl(cmx_mixnet_t* h, const float* d_probs, const uint32_t* d_sel, const uint8_t* d_bits, size_t nbits, float* d_p_out, float* d_mix_out,
-                           void* stream, CmxLateBox* box);
+                           void* stream, const CmxLate* box);
 int cmx_mixnet_run(cmx_mixnet_t* h, const float* d_probs, const uint32_t* d_sel,
                    const uint8_t* d_bits, size_t nbits, float* d_p_out, float* d_mix_out,
                    void* stream) {
@@ -381,7 +395,7 @@ int cmx_mixnet_run_late(cmx_mixnet_t* h, void* box, const float* probs, const ui
   if (!h->use_spec || h->use_v1 || h->tolerance) { set_err("cmx_mixnet_run_late: a decoder needs the strict 27-workgroup kernel (CMX_MIXNET_SPEC=0, CMX_MIXNET_V1 or the tolerance switch is set)"); return 1; }
   if (hipSetDevice(h->device) != hipSuccess) { set_err("hipSetDevice failed"); return 1; }
   if (h->late_p_cap < nbits || h->decay_cap < nbits) { set_err("cmx_mixnet_run_late: call cmx_mixnet_late_prepare first (nothing may be allocated while the stream's kernels run)"); return 1; }
-  return mixnet_run_impl(h, probs, sel, nullptr, nbits, h->d_late_p, nullptr, stream, (CmxLateBox*)box);
+  return mixnet_run_impl(h, probs, sel, nullptr, nbits, h->d_late_p, nullptr, stream, (const CmxLate*)box);
 }
 // everything the decoder's form allocates, for chunks of up to nbits bits: before the first chunk's kernels are launched
 int cmx_mixnet_late_prepare(cmx_mixnet_t* h, size_t nbits) {
@@ -397,7 +411,7 @@ int cmx_mixnet_late_prepare(cmx_mixnet_t* h, size_t nbits) {
   return ensure_decay(h, nbits);
 }
 static int mixnet_run_impl(cmx_mixnet_t* h, const float* d_probs, const uint32_t* d_sel, const uint8_t* d_bits, size_t nbits, float* d_p_out, float* d_mix_out,
-                           void* stream, CmxLateBox* box) {
+                           void* stream, const CmxLate* box) {
   const int fail_value = 1;
   if (!h) { set_err("cmx_mixnet_run: null handle"); return 1; }
   if (h->predicted) { set_err("cmx_mixnet_run: a bit-synchronous predict() is pending"); return 1; }
@@ -434,7 +448,7 @@ static int mixnet_run_impl(cmx_mixnet_t* h, const float* d_probs, const uint32_t
     HIP_OK(hipMemsetAsync(h->d_xfer, 0, CMX_SPEC_HEADER_BYTES, st));
     hipLaunchKernelGGL(cmx_mixnet_spec_kernel, dim3(1 + CMX_SPEC_HELPERS), dim3(CMX_SPEC_THREADS), CMX_SPEC_LDS_BYTES, st,
                        h->d_state, h->d_xfer, d_probs, d_sel, d_bits, dd, (int)nbits, d_p_out, d_mix_out,
-                       3 | (h->profile ? 4 : 0) | ((h->dbg & 15) << 4) | (h->tolerance ? 0x1000 : 0), box);
+                       3 | (h->profile ? 4 : 0) | ((h->dbg & 15) << 4) | (h->tolerance ? 0x1000 : 0), box ? *box : CmxLate());
   } else
     // XCD placement (observed: block b runs on XCD b % 8): 8 blocks, all but block `xcd` leave at once
     hipLaunchKernelGGL(cmx_mixnet_chunk_kernel, dim3(h->xcd >= 0 ? 8 : 1), dim3(CMX_CHUNK_THREADS), CMX_CHUNK_LDS_BYTES, st,

@@ -15,9 +15,10 @@
 //   bit[t] = bit; nknown = t + 1              ------->   every kernel: learns bit t, produces row t + 1, bumps its row counter
 //
 // ONE counter carries both facts: nknown > t means "bit t is known AND every host record of step t + 1 is in place" (the host
-// writes the records first). The box and every buffer that one kernel writes and another reads WHILE BOTH RUN live in
-// host-coherent pinned memory (uncached on the device: no stale line in an XCD's L2), written with plain stores followed by
-// `s_waitcnt vmcnt(0)` and the producer's counter (system-scope atomic), read after the consumer has seen the counter.
+// writes the records first). The box and the host stages' records live in host-coherent pinned memory; every buffer that one kernel
+// writes and another reads WHILE BOTH RUN (rows, selectors, distributions, hints) and the producers' row counters live in UNCACHED
+// DEVICE memory (no stale line in an XCD's L2), written with plain stores followed by `s_waitcnt vmcnt(0)` and the producer's counter,
+// read after the consumer has seen the counter.
 // Every wait is bounded by wall-clock time (CMX_LATE_TIMEOUT_S without progress) and by the box's abort word: a decoder that
 // stops mid-chunk (cmx_destroy) unwinds the kernels instead of leaving them spinning.
 #ifndef CMX_LATE_H
@@ -40,7 +41,7 @@ enum {
 };
 #define CMX_LATE_P_RING 8
 
-struct CmxLateBox {
+struct CmxLateBox {   // HOST-coherent pinned memory: what the decoder thread and the kernels exchange
   uint32_t nknown;   // host -> device
   uint32_t start;    // host -> device: 1 = the chunk before this one is complete (last_y, the step-0 records and row-0 carry-overs are valid)
   uint32_t last_y;   // the bit before the chunk's first
@@ -48,9 +49,20 @@ struct CmxLateBox {
   uint32_t fail;     // device -> host, sticky: a wait ran out of time
   uint32_t nbits;    // bits of this chunk (information only)
   uint32_t pad0[10];
-  struct { uint32_t v; uint32_t pad[15]; } cnt[LC_N];   // device -> device, one 64-byte line each
-  unsigned long long p_word[CMX_LATE_P_RING];           // device -> host: ((t + 1) << 32) | bits of p(t), slot t % ring
+  unsigned long long p_word[CMX_LATE_P_RING];           // device -> host: ((t + 1) << 32) | bits of p(t), slot t % ring -- ONE self-validating word
   uint8_t bit[8];    // [nbits] follows (allocated behind the struct)
+};
+// What a late kernel is launched with (BY VALUE: the fields come out of the kernel-argument segment, not over PCIe). The row counters
+// that kernels hand to each other live in UNCACHED DEVICE memory, like every buffer one kernel writes and another reads while both
+// run: a producer's `data stores; s_waitcnt vmcnt(0); counter store` is only an ordering once the stores have reached the device's
+// memory -- through host memory the counter was seen before the data (measured: MI355X, round 4). A counter holds base | rows, base =
+// chunk number << 16: the three sets of buffers are reused every third chunk and never cleared, comparisons are wrap-safe differences.
+#define CMX_LATE_CNT_STRIDE 16   /* u32 per counter: one 64-byte line each */
+struct CmxLate {
+  CmxLateBox* box;
+  uint32_t* cnt;     // [LC_N][CMX_LATE_CNT_STRIDE]
+  uint32_t base;     // (chunk number & 0xFFFF) << 16
+  uint32_t pad;
 };
 
 #if defined(__HIPCC__)
@@ -60,14 +72,15 @@ struct CmxLateBox {
 #endif
 __device__ __forceinline__ uint32_t late_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void late_st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-// Bounded wait until *p >= want (callable by one lane or by a whole wavefront on a uniform address). false: aborted / timed out.
+// Bounded wait until *p has reached `want` (wrap-safe: a counter is base | rows). Callable by one lane or by a whole wavefront on a
+// uniform address. false: aborted / timed out.
 __device__ __forceinline__ bool late_wait_ge(CmxLateBox* B, const uint32_t* p, uint32_t want) {
-  if (late_ld(p) >= want) return true;
+  if ((int32_t)(late_ld(p) - want) >= 0) return true;
   unsigned spins = 0;
   unsigned long long t0 = 0;
   for (;;) {
     __builtin_amdgcn_s_sleep(1);
-    if (late_ld(p) >= want) return true;
+    if ((int32_t)(late_ld(p) - want) >= 0) return true;
     if ((++spins & 255u) == 0) {
       if (late_ld(&B->abort) || late_ld(&B->fail)) return false;
       const unsigned long long now = wall_clock64();
@@ -77,20 +90,21 @@ __device__ __forceinline__ bool late_wait_ge(CmxLateBox* B, const uint32_t* p, u
   }
 }
 // the bit before step t of the chunk (t == 0: the previous chunk's last), once it is known; -1: aborted
-__device__ __forceinline__ int late_y(CmxLateBox* B, int t) {
+__device__ __forceinline__ int late_y(const CmxLate& L, int t) {
+  CmxLateBox* const B = L.box;
   if (t == 0) { if (!late_wait_ge(B, &B->start, 1u)) return -1; return (int)late_ld(&B->last_y); }
   if (!late_wait_ge(B, &B->nknown, (uint32_t)t)) return -1;
   asm volatile("" ::: "memory");
   return (int)*(volatile const uint8_t*)(B->bit + (t - 1));
 }
-// publish: every store of this wavefront issued so far has left before the counter moves (call with one lane; the others' stores
-// are covered when the caller puts a wave / workgroup barrier with s_waitcnt vmcnt(0) in front)
-__device__ __forceinline__ void late_publish(CmxLateBox* B, int which, uint32_t v) {
+// publish: every store of this wavefront issued so far has reached the device's memory before the counter moves (call with one lane;
+// the others' stores are covered when the caller puts a wave / workgroup barrier with s_waitcnt vmcnt(0) in front)
+__device__ __forceinline__ void late_publish(const CmxLate& L, int which, uint32_t v) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  late_st(&B->cnt[which].v, v);
+  late_st(L.cnt + which * CMX_LATE_CNT_STRIDE, L.base | v);
 }
-__device__ __forceinline__ bool late_wait_cnt(CmxLateBox* B, int which, uint32_t want) {
-  const bool ok = late_wait_ge(B, &B->cnt[which].v, want);
+__device__ __forceinline__ bool late_wait_cnt(const CmxLate& L, int which, uint32_t want) {
+  const bool ok = late_wait_ge(L.box, L.cnt + which * CMX_LATE_CNT_STRIDE, L.base | want);
   asm volatile("" ::: "memory");
   return ok;
 }

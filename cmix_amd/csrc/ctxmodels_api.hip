@@ -16,11 +16,11 @@
 #include "../../include/cmix_amd.h"
 #include "cmx_glibc_rand.h"
 #include "ctxmodels_state.h"
+#include "cmx_late.h"
 
 extern "C" __global__ void cmx_ctxmodels_kernel(const CtxDev, const uint8_t*, size_t, float*, size_t, uint32_t*, float*);
 extern "C" __global__ void cmx_ctxmodels_peek_kernel(const CtxDev, const uint8_t*, float*, size_t, uint32_t*);
-struct CmxLateBox;
-extern "C" __global__ void cmx_ctxmodels_late_kernel(const CtxDev, CmxLateBox*, size_t, float*, size_t, uint32_t*, float*);
+extern "C" __global__ void cmx_ctxmodels_late_kernel(const CtxDev, CmxLate, size_t, float*, size_t, uint32_t*, float*);
 extern "C" __global__ void cmx_bytemodel_bits(const float*, const float*, const uint8_t*, size_t, float*, int*, size_t, int,
                                               float*);
 extern "C" unsigned cmx_ctxmodels_lds_bytes();
@@ -366,7 +366,7 @@ int cmx_ctxmodels_run_late(cmx_ctxmodels_t* h, void* box, size_t nbytes, float* 
   hipStream_t st = (hipStream_t)stream;
   // (the stage's own copy in its persistent state: the kernel rewrites it only in its epilogue, long after the first byte's reader has it)
   if (brk_dist0_out) *brk_dist0_out = (const float*)((const char*)h->dev.persist + offsetof(CtxPersist, br_probs));
-  hipLaunchKernelGGL(cmx_ctxmodels_late_kernel, dim3(1), dim3(64), cmx_ctxmodels_lds_bytes(), st, h->dev, (CmxLateBox*)box, nbytes, probs, pstride, sel, brk_dist);
+  hipLaunchKernelGGL(cmx_ctxmodels_late_kernel, dim3(1), dim3(64), cmx_ctxmodels_lds_bytes(), st, h->dev, *(const CmxLate*)box, nbytes, probs, pstride, sel, brk_dist);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { cmx_set_err(std::string("cmx_ctxmodels_run_late: ") + hipGetErrorString(e)); return 1; }
   return 0;

@@ -76,7 +76,7 @@ extern "C" unsigned cmx_ctxmodels_lds_bytes() { return LdsMap::total; }
 namespace {
 template <bool dry, bool late = false>
 __device__ __forceinline__ void ctxmodels_body(const CtxDev& D, const uint8_t* __restrict__ bytes, size_t nbytes,
-                                               float* probs, size_t pstride, uint32_t* sel, float* bracket_dist, CmxLateBox* LB = nullptr) {
+                                               float* probs, size_t pstride, uint32_t* sel, float* bracket_dist, CmxLate LB = CmxLate()) {
   // late (the decoder's form, cmx_late.h): the byte is not known when its first bit is predicted. The wave walks BITS: Predict of
   // bit j from the bits decoded so far (one probe per table model), row t and the selectors published (counter LC_CTX), then it
   // waits for the decoder's bit and runs the Perceive of every model -- the reference's own order (predictor.cpp:361-369, 421-446).
@@ -212,7 +212,7 @@ __device__ __forceinline__ void ctxmodels_body(const CtxDev& D, const uint8_t* _
         }
         if (probs && lane >= 1 && lane < CTX_NM) probs[t * pstride + L.col] = o;
         wave_mem_sync();   // the row's stores (and, on the serial path, every Predict() probe) are complete
-        if (lane == 0) late_st(&LB->cnt[LC_CTX].v, (uint32_t)(t + 1));
+        if (lane == 0) late_publish(LB, LC_CTX, (uint32_t)(t + 1));
         const int bit = late_y(LB, (int)t + 1);   // uniform: the whole wave leaves on abort
         if (bit < 0) return;
         if (is_dir) {  // direct.cpp:22-28
@@ -578,7 +578,7 @@ __device__ __forceinline__ void ctxmodels_body(const CtxDev& D, const uint8_t* _
     __syncthreads();
     if (late) {   // the Bracket model's distribution after byte n is in place (the ByteModel kernel of the late pipeline reads it)
       wave_mem_sync();
-      if (lane == 0) late_st(&LB->cnt[LC_BRK].v, (uint32_t)(n + 1));
+      if (lane == 0) late_publish(LB, LC_BRK, (uint32_t)(n + 1));
     }
   }
 
@@ -621,7 +621,7 @@ cmx_ctxmodels_kernel(const CtxDev D, const uint8_t* __restrict__ bytes, size_t n
 
 // the decoder's form (cmx_late.h): bits arrive through the box as the arithmetic decoder produces them
 extern "C" __global__ void __launch_bounds__(64)
-cmx_ctxmodels_late_kernel(const CtxDev D, CmxLateBox* box, size_t nbytes, float* probs, size_t pstride, uint32_t* sel,
+cmx_ctxmodels_late_kernel(const CtxDev D, CmxLate box, size_t nbytes, float* probs, size_t pstride, uint32_t* sel,
                           float* bracket_dist) {
   ctxmodels_body<false, true>(D, nullptr, nbytes, probs, pstride, sel, bracket_dist, box);
 }

@@ -363,7 +363,7 @@ __device__ __forceinline__ void fx_stage_ahead(FxAhead* ah, FxLocal* loc, const 
 template <bool LATE>
 __device__ __forceinline__ void fx_roles_body(FxDev* gd, FxXfer* X, unsigned* rows, const uint8_t* bytes, const FxByteRec* recs,
                                               const int16_t* lstmpr, const uint8_t* lstmex, float* out, long ostride, int n,
-                                              unsigned long long* prof, CmxLateBox* LB) {
+                                              unsigned long long* prof, CmxLate LB) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fx_smem[];
   __shared__ int late_go;
   FxShared& sh = *(FxShared*)fx_smem;
@@ -641,9 +641,9 @@ __device__ __forceinline__ void fx_roles_body(FxDev* gd, FxXfer* X, unsigned* ro
 __global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_roles_kernel(FxDev* gd, FxXfer* X, unsigned* rows, const uint8_t* bytes, const FxByteRec* recs,
                                                                          const int16_t* lstmpr, const uint8_t* lstmex, float* out, long ostride, int n,
                                                                          unsigned long long* prof) {
-  fx_roles_body<false>(gd, X, rows, bytes, recs, lstmpr, lstmex, out, ostride, n, prof, nullptr);
+  fx_roles_body<false>(gd, X, rows, bytes, recs, lstmpr, lstmex, out, ostride, n, prof, CmxLate());
 }
-__global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_roles_late_kernel(FxDev* gd, FxXfer* X, unsigned* rows, CmxLateBox* box, const FxByteRec* recs,
+__global__ __launch_bounds__(FX_DEV_THREADS) void cmx_fxcm_roles_late_kernel(FxDev* gd, FxXfer* X, unsigned* rows, CmxLate box, const FxByteRec* recs,
                                                                               const int16_t* lstmpr, const uint8_t* lstmex, float* out, long ostride, int n) {
   fx_roles_body<true>(gd, X, rows, nullptr, recs, lstmpr, lstmex, out, ostride, n, nullptr, box);
 }
@@ -820,7 +820,7 @@ int cmx_fxcm_run_late(cmx_fxcm_t* h, void* box, size_t nbytes, const int16_t* hi
   if (h->late_cap[slot] < nbytes || h->rows_cap < nbytes) { cmx_set_err("cmx_fxcm_run_late: call cmx_fxcm_late_prepare first (nothing may be allocated while the stream's kernels run)"); return 1; }
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync((char*)h->d_xfer + 16, 0, sizeof(FxXfer) - 16, s) != hipSuccess) { cmx_set_err("cmx_fxcm_run_late: hipMemsetAsync failed"); return 1; }
-  hipLaunchKernelGGL(cmx_fxcm_roles_late_kernel, dim3(FX_M_WGS + 2), dim3(FX_DEV_THREADS), FX_LDS_BYTES, s, h->d_dev, h->d_xfer, h->d_rows, (CmxLateBox*)box,
+  hipLaunchKernelGGL(cmx_fxcm_roles_late_kernel, dim3(FX_M_WGS + 2), dim3(FX_DEV_THREADS), FX_LDS_BYTES, s, h->d_dev, h->d_xfer, h->d_rows, *(const CmxLate*)box,
                      (const FxByteRec*)h->late_recs[slot], hint_pr, hint_ex, d_probs + 3, (long)pstride, (int)nbytes);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { cmx_set_err(std::string("cmx_fxcm_run_late: ") + hipGetErrorString(e)); return 1; }

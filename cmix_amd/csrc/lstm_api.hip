@@ -17,6 +17,8 @@
 
 #include "../../include/cmix_amd.h"
 #include "lstm_state.h"
+#include "cmx_late.h"
+#include "cmx_late.h"
 #include "cmx_glibc_rand.h"
 
 extern "C" __global__ void cmx_lstm_prep(const LstmState, const float*, const uint8_t*, size_t, int, int);
@@ -26,8 +28,7 @@ extern "C" __global__ void cmx_lstm_fwdblk(const LstmState, const uint8_t*, cons
 extern "C" __global__ void cmx_lstm_bpttblk(const LstmState);
 extern "C" __global__ void cmx_bytemodel_bits(const float*, const float*, const uint8_t*, size_t, float*, int*, size_t, int,
                                               float*);
-struct CmxLateBox;
-extern "C" __global__ void cmx_bytemodel_late_kernel(CmxLateBox*, size_t, const float*, const float*, const float*, const float*, const float*, const uint32_t*, uint32_t,
+extern "C" __global__ void cmx_bytemodel_late_kernel(CmxLate, size_t, const float*, const float*, const float*, const float*, const float*, const uint32_t*, uint32_t,
                                                      const uint32_t*, uint32_t, float*, size_t, int16_t*, uint8_t*);
 extern "C" __global__ void cmx_late_bump_kernel(uint32_t*, uint32_t, uint32_t*, uint32_t);
 
@@ -291,7 +292,7 @@ int cmx_bytemodel_late_run(int device, void* box, size_t nbytes, const float* br
                            int16_t* hint_pr, uint8_t* hint_ex, void* stream) {
   if (!box || !nbytes || !brk0 || !brk || !ppmd || !lstm0 || !lstm || !layer0 || !hint_pr || !hint_ex) { cmx_set_err("cmx_bytemodel_late_run: bad argument"); return 1; }
   if (hipSetDevice(device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
-  hipLaunchKernelGGL(cmx_bytemodel_late_kernel, dim3(1), dim3(192), 0, (hipStream_t)stream, (CmxLateBox*)box, nbytes, brk0, brk, ppmd, lstm0, lstm, c0_brk, c0_brk_want,
+  hipLaunchKernelGGL(cmx_bytemodel_late_kernel, dim3(1), dim3(192), 0, (hipStream_t)stream, *(const CmxLate*)box, nbytes, brk0, brk, ppmd, lstm0, lstm, c0_brk, c0_brk_want,
                      c0_lstm, c0_lstm_want, layer0, pstride, hint_pr, hint_ex);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { cmx_set_err(std::string("cmx_bytemodel_late_run: ") + hipGetErrorString(e)); return 1; }

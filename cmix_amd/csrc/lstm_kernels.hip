@@ -178,7 +178,7 @@ extern "C" __global__ void cmx_bytemodel_bits(const float* dist0, const float* d
 //      kernel; LSTM: LC_LSTM, bumped behind the byte's LSTM launch; PPMd: a host record, in place once the byte's last bit is
 //      published); the one going into the chunk on the previous chunk's counters (c0_*: may be null).
 extern "C" __global__ void __launch_bounds__(192)
-cmx_bytemodel_late_kernel(CmxLateBox* B, size_t nbytes, const float* brk0, const float* brk, const float* ppmd, const float* lstm0,
+cmx_bytemodel_late_kernel(CmxLate B, size_t nbytes, const float* brk0, const float* brk, const float* ppmd, const float* lstm0,
                           const float* lstm, const uint32_t* c0_brk, uint32_t c0_brk_want, const uint32_t* c0_lstm, uint32_t c0_lstm_want,
                           float* layer0, size_t pstride, int16_t* hint_pr, uint8_t* hint_ex) {
   __shared__ float prs[3][256];
@@ -192,13 +192,13 @@ cmx_bytemodel_late_kernel(CmxLateBox* B, size_t nbytes, const float* brk0, const
     const float* d;
     bool ok = true;
     if (n == 0) {
-      ok = late_wait_ge(B, &B->start, 1u);
-      if (ok && w == 0 && c0_brk) ok = late_wait_ge(B, c0_brk, c0_brk_want);
-      if (ok && w == 2 && c0_lstm) ok = late_wait_ge(B, c0_lstm, c0_lstm_want);
+      ok = late_wait_ge(B.box, &B.box->start, 1u);
+      if (ok && w == 0 && c0_brk) ok = late_wait_ge(B.box, c0_brk, c0_brk_want);
+      if (ok && w == 2 && c0_lstm) ok = late_wait_ge(B.box, c0_lstm, c0_lstm_want);
       d = w == 0 ? brk0 : w == 1 ? ppmd : lstm0;
     } else {
       if (w == 0) { ok = late_wait_cnt(B, LC_BRK, (uint32_t)n); d = brk + (n - 1) * 256; }
-      else if (w == 1) { ok = late_wait_ge(B, &B->nknown, (uint32_t)(8 * n)); d = ppmd + n * 256; }
+      else if (w == 1) { ok = late_wait_ge(B.box, &B.box->nknown, (uint32_t)(8 * n)); d = ppmd + n * 256; }
       else { ok = late_wait_cnt(B, LC_LSTM, (uint32_t)n); d = lstm + (n - 1) * 256; }
     }
     if (!ok) return;

@@ -87,7 +87,7 @@ struct Lds {
   int* sdone;       // [rr] cmx_mixnet_spec_kernel: bit + 1 whose stretched inputs a stretch wave has published
   float* h2;        // [2][64] cmx_mixnet_spec_kernel: the layer-2 inputs of a bit (49) + bit, lstm_p, layer-2 row, from tail_a_role to tail_b_role
   int* bitring;     // [8] late mode: the decoded bits, slot bit % 8 (Ctl::bit_epoch)
-  CmxLateBox* late; // late mode: the decoder's box; nullptr: every bit of the chunk is known (compression)
+  CmxLate late;     // late mode: the decoder's box + row counters; late.box == nullptr: every bit of the chunk is known (compression)
 };
 
 // All inter-wave traffic of this kernel goes through LDS, so its synchronisation only has to
@@ -1067,7 +1067,7 @@ __device__ void tail_a_role(MixState* S, const Lds& L, const float* decay1, int 
     __builtin_amdgcn_wave_barrier();
     st_rel(&L.ctl->b_in, t + 1);
     TPROF(8);
-    if (L.late) {   // the decoder's bit: the output wave (tail_b_role) receives it after p has gone out
+    if (L.late.box) {   // the decoder's bit: the output wave (tail_b_role) receives it after p has gone out
       if (!wait_ge(L.ctl, &L.ctl->bit_epoch, t + 1, false)) return;
       bit = L.bitring[t & 7];
     }
@@ -1215,10 +1215,10 @@ __device__ void tail_b_role(MixState* S, const Lds& L, const float* decay1, int 
       const float lp = in2[50];
       if (lp == 0.0f || lp == 1.0f) pf = lp;               // predictor.cpp:383,415-417
       as_global(p_out)[t] = pf;
-      if (L.late) {
+      if (L.late.box) {
         // Decoder::Decode (decoder.cpp:20-39): p goes to the host (value | tag, one 8-byte store into its mapped memory); the arithmetic
         // decoder turns it into the bit, which comes back through the box and is handed to the waves that learn from it
-        __hip_atomic_store(&L.late->p_word[t % CMX_LATE_P_RING], ((unsigned long long)(unsigned)(t + 1) << 32) | (unsigned)__float_as_int(pf), __ATOMIC_RELAXED,
+        __hip_atomic_store(&L.late.box->p_word[t % CMX_LATE_P_RING], ((unsigned long long)(unsigned)(t + 1) << 32) | (unsigned)__float_as_int(pf), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_SYSTEM);
         bit = late_y(L.late, t + 1);
         if (bit < 0) { lds_publish_store(&L.ctl->abort, 1); bit = 0; }
@@ -1247,7 +1247,7 @@ __device__ void tail_b_role(MixState* S, const Lds& L, const float* decay1, int 
       if (mix_out) as_global(mix_out)[(size_t)t * CMX_MIXERS + CMX_MIXERS - 1] = p2_;
       ++steps_done;
     }
-    if (L.late && lds_poll(&L.ctl->abort)) return;   // (uniform: the decoder has left)
+    if (L.late.box && lds_poll(&L.ctl->abort)) return;   // (uniform: the decoder has left)
     TPROF(1);
     u2 = bcast_lane(u2, 0);
     df2 = __builtin_amdgcn_readlane(df2, 0);
@@ -1509,7 +1509,7 @@ __device__ void stretch_role(MixState* S, const Lds& L, SpecXfer* X, const float
     if (t >= L.rr && !wait_ge(L.ctl, &L.ctl->tail_done, t - L.rr + 1, true)) return;             // rec slot t % rr is free (see scout_role)
     BitRec* rec = L.rec + (t % L.rr);
     const gptr<const float> pr = gprobs + (size_t)t * CMX_IN0;
-    if (L.late) {   // a decoder: row t exists once every producing stage has counted it (cmx_late.h), one lane per counter
+    if (L.late.box) {   // a decoder: row t exists once every producing stage has counted it (cmx_late.h), one lane per counter
       bool ok = true;
       if (lane <= LC_P8) ok = late_wait_cnt(L.late, lane, (uint32_t)(t + 1));
       if (__ballot(!ok)) { lds_publish_store(&L.ctl->abort, 1); return; }
@@ -1520,7 +1520,7 @@ __device__ void stretch_role(MixState* S, const Lds& L, SpecXfer* X, const float
       int i = r * 64 + lane;
       pv[r] = i < CMX_IN0 ? pr[i] : 0.5f;
     }
-    const int bitv = L.late ? 0 : (int)bits[t];   // (late: not known yet; the waves that learn wait for it)
+    const int bitv = L.late.box ? 0 : (int)bits[t];   // (late: not known yet; the waves that learn wait for it)
     const float lstm_raw = bcast_lane(pv[32], 29);   // probs[t][2077]
 #pragma unroll
     for (int r = 0; r < 33; ++r) {   // MixerInput::SetInput (mixer-input.cpp:11-15) + Sigmoid::Logit (sigmoid.cpp:12-17)
@@ -1565,7 +1565,7 @@ __device__ void select_role(MixState* S, const Lds& L, SpecXfer* X, const uint32
   for (int t = 0; t < nbits; ++t) {
     uint32_t key = lane < CMX_MIXERS ? gsel[(size_t)t * CMX_MIXERS + lane] : 0;
     if (!wait_ge(L.ctl, &L.sdone[t % L.rr], t + 1, true)) return;
-    if (L.late && lane < CMX_MIXERS) key = gsel[(size_t)t * CMX_MIXERS + lane];   // a decoder: the row's selectors exist only now
+    if (L.late.box && lane < CMX_MIXERS) key = gsel[(size_t)t * CMX_MIXERS + lane];   // a decoder: the row's selectors exist only now
     BitRec* rec = L.rec + (t % L.rr);
     const BitRec* prev = L.rec + ((t + L.rr - 1) % L.rr);
     if (lane == CMX_AUX) key = rec->auxkey;
@@ -1672,7 +1672,7 @@ __device__ void gather_role(MixState* S, const Lds& L, SpecXfer* X, const float*
           if ((unsigned)(v >> 32) == (unsigned)(t + 1)) { pm = __int_as_float((int)(unsigned)v); have = true; }
         }
         if (__ballot(!have) == 0) break;
-        if ((++spins & 1023u) == 0 && ((L.late ? late_expired(L.late, gt0) : spins > SPEC_SPIN) || lds_poll(&L.ctl->abort) || ld_u32(&X->fail))) {
+        if ((++spins & 1023u) == 0 && ((L.late.box ? late_expired(L.late.box, gt0) : spins > SPEC_SPIN) || lds_poll(&L.ctl->abort) || ld_u32(&X->fail))) {
           lds_publish_store(&L.ctl->abort, 1);
           __hip_atomic_store(&X->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           return;
@@ -1701,7 +1701,7 @@ __device__ void gather_role(MixState* S, const Lds& L, SpecXfer* X, const float*
       st_rel(&L.ctl->tail_in, t + 1);
       return true;
     };
-    if (L.late) {   // a decoder: the bit is an output of the arithmetic decoder, which needs p -- the tail waves first, then the wait
+    if (L.late.box) {   // a decoder: the bit is an output of the arithmetic decoder, which needs p -- the tail waves first, then the wait
       if (!hand_to_tail()) return;
       if (!wait_ge(L.ctl, &L.ctl->bit_epoch, t + 1, false)) return;
       bitv = L.bitring[t & 7];
@@ -1712,7 +1712,7 @@ __device__ void gather_role(MixState* S, const Lds& L, SpecXfer* X, const float*
     const bool dfl = (rsteps & 1023) == 0;
     if (is0) st_u64(&X->u[m], ((unsigned long long)(2u * (unsigned)(t + 1) + (dfl ? 1u : 0u)) << 32) | (unsigned)__float_as_int(uu));
     GPROF(4);
-    if (!L.late && !hand_to_tail()) return;
+    if (!L.late.box && !hand_to_tail()) return;
     GPROF(12);
     if (is0 && mix_out) as_global(mix_out)[(size_t)t * CMX_MIXERS + m] = p_;
 #pragma unroll
@@ -1765,7 +1765,7 @@ extern "C" __global__ __launch_bounds__(NTHREADS) void cmx_mixnet_chunk_kernel(
   L.prod = smem;                                                  // 2 * PBUF
   L.xs = L.prod + 2 * PBUF;                                       // 3 * XS
   L.rec = reinterpret_cast<BitRec*>(L.xs + 3 * XS);               // 3
-  L.rr = 3; L.lead = 2; L.lst = nullptr; L.lsq = nullptr; L.sdone = nullptr; L.h2 = nullptr; L.bitring = nullptr; L.late = nullptr;
+  L.rr = 3; L.lead = 2; L.lst = nullptr; L.lsq = nullptr; L.sdone = nullptr; L.h2 = nullptr; L.bitring = nullptr; L.late = CmxLate();
   L.trec = reinterpret_cast<TailRec*>(L.rec + 3);                 // 2
   L.upd = reinterpret_cast<float*>(L.trec + 2);                   // 32
   L.dflag = reinterpret_cast<uint32_t*>(L.upd + 32);              // 32
@@ -1799,7 +1799,7 @@ extern "C" __global__ __launch_bounds__(NTHREADS) void cmx_mixnet_chunk_kernel(
 extern "C" __global__ __launch_bounds__(CMX_SPEC_THREADS) void cmx_mixnet_spec_kernel(
     MixState* __restrict__ S, SpecXfer* __restrict__ X, const float* __restrict__ probs, const uint32_t* __restrict__ sel,
     const uint8_t* __restrict__ bits, const float* __restrict__ decay1, int nbits,
-    float* __restrict__ p_out, float* __restrict__ mix_out, int mode, CmxLateBox* box) {
+    float* __restrict__ p_out, float* __restrict__ mix_out, int mode, CmxLate box) {
   // box != nullptr: a decoder's chunk (cmx_late.h) -- `bits` is unused, rows / selectors arrive as their stages count them, p goes to the box
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
@@ -1808,7 +1808,7 @@ extern "C" __global__ __launch_bounds__(CMX_SPEC_THREADS) void cmx_mixnet_spec_k
     HelperLds* H = reinterpret_cast<HelperLds*>(smem);
     for (int i = tid; i < (int)(sizeof(HelperLds) / 4); i += CMX_SPEC_THREADS) reinterpret_cast<int*>(H)[i] = 0;
     __syncthreads();
-    if (wave < 4) helper_role(S, X, H, nbits, (int)blockIdx.x - 1, wave, lane, (mode & 0x1000) != 0, box);
+    if (wave < 4) helper_role(S, X, H, nbits, (int)blockIdx.x - 1, wave, lane, (mode & 0x1000) != 0, box.box);
     return;
   }
   Lds L;
@@ -1836,7 +1836,7 @@ extern "C" __global__ __launch_bounds__(CMX_SPEC_THREADS) void cmx_mixnet_spec_k
   if (tid < 8) L.sdone[tid] = 0;
   if (tid < (int)(sizeof(Ctl) / 4)) reinterpret_cast<int*>(L.ctl)[tid] = 0;
   __syncthreads();
-  if (tid == 0) { L.ctl->late_lo = (unsigned)(unsigned long long)box; L.ctl->late_hi = (unsigned)((unsigned long long)box >> 32); }
+  if (tid == 0) { L.ctl->late_lo = (unsigned)(unsigned long long)box.box; L.ctl->late_hi = (unsigned)((unsigned long long)box.box >> 32); }
   __syncthreads();
   const bool prof = (mode & 4) != 0;
   if (wave == 0) gather_role(S, L, X, decay1, nbits, mix_out, prof, lane);

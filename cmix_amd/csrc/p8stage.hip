@@ -79,7 +79,7 @@ __global__ __launch_bounds__(P8CM2_MAXC) void cmx_p8s_cm2v2_kernel(P8Cm2Dev* d, 
   const int y_ = late_y_s;                                        \
   if (y_ < 0) return;                                             \
   __syncthreads()
-__global__ __launch_bounds__(P8CM2_MAXC) void cmx_p8s_cm2v2_late_kernel(P8Cm2Dev* d, CmxLateBox* B, int counter, const uint32_t* ctx, const uint16_t* chk, int16_t* x,
+__global__ __launch_bounds__(P8CM2_MAXC) void cmx_p8s_cm2v2_late_kernel(P8Cm2Dev* d, CmxLate B, int counter, const uint32_t* ctx, const uint16_t* chk, int16_t* x,
                                                                        uint8_t* order_out, int nbits, int skip) {
   __shared__ __attribute__((aligned(16))) P8Cm2V2Shared sh;
   __shared__ int late_y_s;
@@ -126,7 +126,7 @@ constexpr int P8FAM_THREADS = 512;
 // LATE (a decoder): B is the box, `bits` is unused; the order-N map's value of a byte's first step is awaited on its counter.
 template <bool LATE>
 __device__ __forceinline__ void p8s_fam2_body(P8CmDev* d, P8FamHome* home, const uint32_t* ctx, const uint16_t* chk, const uint8_t* bits, int16_t* x,
-                                              const uint8_t* order, int nbits, int skip, unsigned long long* prof, CmxLateBox* B) {
+                                              const uint8_t* order, int nbits, int skip, unsigned long long* prof, CmxLate B) {
   __shared__ int late_y_s;
   extern __shared__ __attribute__((aligned(16))) unsigned char p8f_smem[];
   P8FamShared& sh = *(P8FamShared*)p8f_smem;
@@ -242,9 +242,9 @@ __device__ __forceinline__ void p8s_fam2_body(P8CmDev* d, P8FamHome* home, const
 }
 __global__ __launch_bounds__(P8FAM_THREADS) void cmx_p8s_fam2_kernel(P8CmDev* d, P8FamHome* home, const uint32_t* ctx, const uint16_t* chk, const uint8_t* bits, int16_t* x,
                                                                     const uint8_t* order, int nbits, int skip, unsigned long long* prof) {
-  p8s_fam2_body<false>(d, home, ctx, chk, bits, x, order, nbits, skip, prof, nullptr);
+  p8s_fam2_body<false>(d, home, ctx, chk, bits, x, order, nbits, skip, prof, CmxLate());
 }
-__global__ __launch_bounds__(P8FAM_THREADS) void cmx_p8s_fam2_late_kernel(P8CmDev* d, P8FamHome* home, CmxLateBox* B, const uint32_t* ctx, const uint16_t* chk, int16_t* x,
+__global__ __launch_bounds__(P8FAM_THREADS) void cmx_p8s_fam2_late_kernel(P8CmDev* d, P8FamHome* home, CmxLate B, const uint32_t* ctx, const uint16_t* chk, int16_t* x,
                                                                          const uint8_t* order, int nbits, int skip) {
   p8s_fam2_body<true>(d, home, ctx, chk, nullptr, x, order, nbits, skip, nullptr, B);
 }
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(P8DMC_THREADS) void cmx_p8s_dmc_kernel(P8DmcDev* d,
   if (tid == 0) { d->last_y = bits[nbits - 1]; d->bits_done = done + (uint32_t)nbits; }
 }
 
-__global__ __launch_bounds__(P8LANES_THREADS) void cmx_p8s_lanes_late_kernel(P8LanesDev* d, CmxLateBox* B, const uint32_t* ops, const uint8_t* order, int16_t* x, int nbits, int t0) {
+__global__ __launch_bounds__(P8LANES_THREADS) void cmx_p8s_lanes_late_kernel(P8LanesDev* d, CmxLate B, const uint32_t* ops, const uint8_t* order, int16_t* x, int nbits, int t0) {
   __shared__ int late_y_s;
   const int ln = threadIdx.x & 63, l = ln < 8 ? 8 * (int)(threadIdx.x >> 6) + ln : P8_NLANE;
   const bool act = l < P8_NLANE;
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(P8LANES_THREADS) void cmx_p8s_lanes_late_kernel(P8L
   if (l == 0) d->last_y = late_y_s;
 }
 
-__global__ __launch_bounds__(P8DMC_THREADS) void cmx_p8s_dmc_late_kernel(P8DmcDev* d, CmxLateBox* B, int16_t* x, int off, int nbits, int t0) {
+__global__ __launch_bounds__(P8DMC_THREADS) void cmx_p8s_dmc_late_kernel(P8DmcDev* d, CmxLate B, int16_t* x, int off, int nbits, int t0) {
   __shared__ P8DmcShared sh;
   __shared__ int late_y_s;
   const int tid = threadIdx.x;
@@ -704,7 +704,7 @@ __device__ __forceinline__ void mx4_body(const P8MixDev* M, P8TailDev* T, const 
 // -> records and inputs into LDS -> chains' cell updates + row fetch, weight rows (kept in registers when the selector repeats)
 // -> dot products, second layer, chains, export, LC_P8 -> wait for the step's bit -> training.
 template <int BLK>
-__device__ __forceinline__ void mx4_late_body(const P8MixDev* M, P8TailDev* T, CmxLateBox* B, const int16_t* x, const int32_t* sel, const P8ApmRec* apm,
+__device__ __forceinline__ void mx4_late_body(const P8MixDev* M, P8TailDev* T, CmxLate B, const int16_t* x, const int32_t* sel, const P8ApmRec* apm,
                                               const uint8_t* order, float* out, size_t ld, int nbits, int t0, int first, unsigned long long* prx,
                                               unsigned epoch, unsigned* fail) {
   constexpr int QSEL = (BLK + 2) & 3;
@@ -855,7 +855,7 @@ __device__ __forceinline__ void mx4_late_body(const P8MixDev* M, P8TailDev* T, C
       for (;;) {
         const unsigned long long v = __hip_atomic_load(&prx[(size_t)t * P8_NSEL + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((v >> 12) == mx4_tag(epoch, t)) { pr_s[lane] = (int)(v & 4095u); break; }
-        if ((++spins & 1023u) == 0 && (spins > MX4_SPIN || late_ld(&B->abort) || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        if ((++spins & 1023u) == 0 && (spins > MX4_SPIN || late_ld(&B.box->abort) || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
           __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pr_s[lane] = 2048; break;
         }
       }
@@ -948,7 +948,7 @@ __device__ __forceinline__ void mx4_late_body(const P8MixDev* M, P8TailDev* T, C
     if (tid == 0) { T->pr = fin_s; T->misses = misses; }
   }
 }
-__global__ __launch_bounds__(MX_THREADS) void cmx_p8s_mix4_late_kernel(const P8MixDev* M, P8TailDev* T, CmxLateBox* B, const int16_t* x, const int32_t* sel, const P8ApmRec* apm,
+__global__ __launch_bounds__(MX_THREADS) void cmx_p8s_mix4_late_kernel(const P8MixDev* M, P8TailDev* T, CmxLate B, const int16_t* x, const int32_t* sel, const P8ApmRec* apm,
                                                                       const uint8_t* order, float* out, size_t ld, int nbits, int t0, int first, unsigned long long* prx,
                                                                       unsigned epoch, unsigned* fail) {
   switch (blockIdx.x) {
@@ -1060,7 +1060,7 @@ void cmx_p8stage_destroy(cmx_p8stage_t* h) {
     }
   }
   if (h->d_prx) (void)hipFree(h->d_prx);
-  for (auto& b : h->late) { cmx_late_free(b.rec); cmx_late_free(b.x); cmx_late_free(b.order); }
+  for (auto& b : h->late) { cmx_late_free(b.rec); cmx_late_free_dev(b.x); cmx_late_free_dev(b.order); }
   if (h->h_mixfail) (void)hipHostFree(h->h_mixfail);
   if (h->own_up && h->s_up) (void)hipStreamDestroy(h->s_up);
   for (hipEvent_t e : {h->ev_up, h->ev_ord, h->ev_a, h->ev_b, h->ev_c, h->ev_e, h->ev_f}) if (e) (void)hipEventDestroy(e);
@@ -1269,8 +1269,8 @@ int cmx_p8stage_late_prepare(cmx_p8stage_t* h, size_t nbytes) {
     b.o_ops = take(T * P8_NLANE * 4); b.o_sel = take(T * P8_NSEL * 4); b.o_apm = take(T * sizeof(P8ApmRec));
     b.total = o;
     b.rec = (char*)cmx_late_alloc(o);
-    b.x = (int16_t*)cmx_late_alloc(T * P8_NX * 2);
-    b.order = (uint8_t*)cmx_late_alloc(T);
+    b.x = (int16_t*)cmx_late_alloc_dev(h->device, T * P8_NX * 2);   // rows the role kernels hand to the mixer while all of them run
+    b.order = (uint8_t*)cmx_late_alloc_dev(h->device, T);
     if (!b.rec || !b.x || !b.order) { cmx_set_err("cmx_p8stage_late_prepare: buffer allocation failed"); h->failed = true; return 1; }
     b.cap = n;
     b.c.fam_ctx = (uint32_t*)(b.rec + b.o_fctx); b.c.fam_chk = (uint16_t*)(b.rec + b.o_fchk);
@@ -1293,7 +1293,7 @@ int cmx_p8stage_run_late(cmx_p8stage_t* h, void* box_, size_t nbytes, float* d_o
   if (h->failed) { cmx_set_err("cmx_p8stage_run_late: the stage failed earlier on this stream"); return 1; }
   if (h->s_b == h->s_d || h->s_c == h->s_d || h->s_f == h->s_c) { cmx_set_err("cmx_p8stage_run_late: the roles share HIP streams (CMX_PIPELINE_STREAMS): a decoder needs every role kernel running at once"); return 1; }
   if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
-  CmxLateBox* B = (CmxLateBox*)box_;
+  const CmxLate B = *(const CmxLate*)box_;
   const P8Layout& L = h->L;
   const size_t n = nbytes, T = 8 * n;
   cmx_p8stage::Late& b = h->late[slot];

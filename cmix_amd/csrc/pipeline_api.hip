@@ -112,14 +112,18 @@ namespace {
 // is still read.
 constexpr size_t kLateChunk = 512;
 struct LateSet {
+  // host-coherent pinned memory: what the decoder thread writes / reads while the kernels run
   CmxLateBox* box = nullptr;
+  float* ppmd = nullptr;         // [n + 1][256]  PPMd's distributions; row 0 = going into the chunk
+  uint8_t* bytes = nullptr;      // [n]
+  // uncached device memory: what one stage kernel writes and another reads while both run
+  uint32_t* cnt = nullptr;       // [LC_N][CMX_LATE_CNT_STRIDE] row counters (base | rows, never cleared)
   float* layer0 = nullptr;       // [8 n][2078]
   uint32_t* sel = nullptr;       // [8 n][47]
   float* brk = nullptr;          // [n][256]   Bracket model's distribution after each byte (context stage)
   float* lstm = nullptr;         // [n][256]   the LSTM byte mixer's
-  float* ppmd = nullptr;         // [n + 1][256]  PPMd's; row 0 = going into the chunk
-  uint8_t* bytes = nullptr;      // [n]
   int16_t* hint_pr = nullptr; uint8_t* hint_ex = nullptr;   // [8 n] fxcm's LSTM hints per update
+  CmxLate lt;                    // what the chunk's kernels are launched with
 };
 struct Late {
   LateSet set[3];
@@ -132,6 +136,7 @@ struct Late {
   const float* lstm0 = nullptr;
   double ms[6] = {0, 0, 0, 0, 0, 0};
   uint64_t bits = 0;
+  float* dbg_row = nullptr; uint32_t* dbg_sel = nullptr;   // pinned: cmx_pipeline_late_debug_row
 };
 }  // namespace
 
@@ -226,10 +231,13 @@ void cmx_pipeline_destroy(cmx_pipeline_t* h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     for (LateSet& q : h->late->set) {
-      cmx_late_free(q.box); cmx_late_free(q.layer0); cmx_late_free(q.sel); cmx_late_free(q.brk); cmx_late_free(q.lstm); cmx_late_free(q.ppmd);
-      cmx_late_free(q.bytes); cmx_late_free(q.hint_pr); cmx_late_free(q.hint_ex);
+      cmx_late_free(q.box); cmx_late_free(q.ppmd); cmx_late_free(q.bytes);
+      cmx_late_free_dev(q.cnt); cmx_late_free_dev(q.layer0); cmx_late_free_dev(q.sel); cmx_late_free_dev(q.brk); cmx_late_free_dev(q.lstm);
+      cmx_late_free_dev(q.hint_pr); cmx_late_free_dev(q.hint_ex);
     }
     if (h->late->s_bm) (void)hipStreamDestroy(h->late->s_bm);
+    if (h->late->dbg_row) (void)hipHostFree(h->late->dbg_row);
+    if (h->late->dbg_sel) (void)hipHostFree(h->late->dbg_sel);
     delete h->late;
     h->late = nullptr;
   }
@@ -708,6 +716,8 @@ size_t cmx_late_box_bytes(size_t nbits) { return sizeof(CmxLateBox) + nbits + 64
 
 static double late_now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// the previous chunk's counter value that says "all n of its bytes' distributions are in place"
+static uint32_t pq_want(uint64_t c, size_t n) { return c ? ((uint32_t)((c - 1) & 0xFFFFu) << 16) | (uint32_t)n : 0u; }
 // enqueue every stage kernel of chunk number c (its bits arrive later)
 static int late_launch(cmx_pipeline* h, uint64_t c) {
   Late* L = h->late;
@@ -719,20 +729,23 @@ static int late_launch(cmx_pipeline* h, uint64_t c) {
   memset(B, 0, sizeof(CmxLateBox));
   B->nbits = (uint32_t)(8 * n);
   __sync_synchronize();
+  q.lt.box = B; q.lt.cnt = q.cnt; q.lt.base = (uint32_t)(c & 0xFFFFu) << 16; q.lt.pad = 0;   // the counters are never cleared: a value of the chunk three back is below this base
+  void* const LT = &q.lt;
   const float* brk0 = nullptr;
-  if (cmx_ctxmodels_run_late(h->ctx, B, n, q.layer0, CMX_N_INPUTS, q.sel, q.brk, &brk0, h->s_ctx)) return 1;
+  if (cmx_ctxmodels_run_late(h->ctx, LT, n, q.layer0, CMX_N_INPUTS, q.sel, q.brk, &brk0, h->s_ctx)) return 1;
   const uint32_t *c0_brk = nullptr, *c0_lstm = nullptr;
   const float* lstm0 = L->lstm0;
   if (c > 0) {   // the distributions going into the chunk are the previous chunk's last rows, valid when ITS stages have counted them
     LateSet& pq = L->set[(int)((c - 1) % 3)];
-    brk0 = pq.brk + (n - 1) * 256; c0_brk = &pq.box->cnt[LC_BRK].v;
-    lstm0 = pq.lstm + (n - 1) * 256; c0_lstm = &pq.box->cnt[LC_LSTM].v;
+    brk0 = pq.brk + (n - 1) * 256; c0_brk = pq.cnt + LC_BRK * CMX_LATE_CNT_STRIDE;
+    lstm0 = pq.lstm + (n - 1) * 256; c0_lstm = pq.cnt + LC_LSTM * CMX_LATE_CNT_STRIDE;
   }
-  if (cmx_bytemodel_late_run(h->device, B, n, brk0, q.brk, q.ppmd, lstm0, q.lstm, c0_brk, (uint32_t)n, c0_lstm, (uint32_t)n, q.layer0, CMX_N_INPUTS, q.hint_pr, q.hint_ex,
+  const uint32_t pwant = pq_want(c, n);
+  if (cmx_bytemodel_late_run(h->device, LT, n, brk0, q.brk, q.ppmd, lstm0, q.lstm, c0_brk, pwant, c0_lstm, pwant, q.layer0, CMX_N_INPUTS, q.hint_pr, q.hint_ex,
                              L->s_bm)) return 1;
-  if (cmx_fxcm_run_late(h->fxcm, B, n, q.hint_pr, q.hint_ex, q.layer0, CMX_N_INPUTS, s, h->s_fx)) return 1;
-  if (cmx_p8stage_run_late(h->p8, B, n, q.layer0 + 434, CMX_N_INPUTS, s)) return 1;
-  if (cmx_mixnet_run_late(h->mix, B, q.layer0, q.sel, 8 * n, h->s_mix)) return 1;
+  if (cmx_fxcm_run_late(h->fxcm, LT, n, q.hint_pr, q.hint_ex, q.layer0, CMX_N_INPUTS, s, h->s_fx)) return 1;
+  if (cmx_p8stage_run_late(h->p8, LT, n, q.layer0 + 434, CMX_N_INPUTS, s)) return 1;
+  if (cmx_mixnet_run_late(h->mix, LT, q.layer0, q.sel, 8 * n, h->s_mix)) return 1;
   L->launched = c + 1;
   return 0;
 }
@@ -749,17 +762,19 @@ int cmx_pipeline_late_start(cmx_pipeline_t* h, int last_bit) {
   h->late = L;
   const size_t n = kLateChunk, T = 8 * n;
   bool ok = hipStreamCreateWithFlags(&L->s_bm, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&L->dbg_row, CMX_N_INPUTS * 4, hipHostMallocDefault) == hipSuccess && hipHostMalloc((void**)&L->dbg_sel, CMX_N_MIXERS * 4, hipHostMallocDefault) == hipSuccess;
   for (LateSet& q : L->set) {
     q.box = (CmxLateBox*)cmx_late_alloc(cmx_late_box_bytes(T));
-    q.layer0 = (float*)cmx_late_alloc(T * CMX_N_INPUTS * 4);
-    q.sel = (uint32_t*)cmx_late_alloc(T * CMX_N_MIXERS * 4);
-    q.brk = (float*)cmx_late_alloc(n * 256 * 4);
-    q.lstm = (float*)cmx_late_alloc(n * 256 * 4);
     q.ppmd = (float*)cmx_late_alloc((n + 1) * 256 * 4);
     q.bytes = (uint8_t*)cmx_late_alloc(n);
-    q.hint_pr = (int16_t*)cmx_late_alloc(T * 2);
-    q.hint_ex = (uint8_t*)cmx_late_alloc(T);
-    ok = ok && q.box && q.layer0 && q.sel && q.brk && q.lstm && q.ppmd && q.bytes && q.hint_pr && q.hint_ex;
+    q.cnt = (uint32_t*)cmx_late_alloc_dev(h->device, LC_N * CMX_LATE_CNT_STRIDE * 4);
+    q.layer0 = (float*)cmx_late_alloc_dev(h->device, T * CMX_N_INPUTS * 4);
+    q.sel = (uint32_t*)cmx_late_alloc_dev(h->device, T * CMX_N_MIXERS * 4);
+    q.brk = (float*)cmx_late_alloc_dev(h->device, n * 256 * 4);
+    q.lstm = (float*)cmx_late_alloc_dev(h->device, n * 256 * 4);
+    q.hint_pr = (int16_t*)cmx_late_alloc_dev(h->device, T * 2);
+    q.hint_ex = (uint8_t*)cmx_late_alloc_dev(h->device, T);
+    ok = ok && q.box && q.cnt && q.layer0 && q.sel && q.brk && q.lstm && q.ppmd && q.bytes && q.hint_pr && q.hint_ex;
   }
   if (!ok) { cmx_set_err("cmx_pipeline_late_start: buffer allocation failed"); L->failed = true; return 1; }
   // every stage allocates what it needs NOW: once the first chunk's kernels run they wait for this thread, and an allocation that maps
@@ -813,7 +828,10 @@ float cmx_pipeline_late_predict(cmx_pipeline_t* h) {
       if (why) {
         std::string st = " [box: nknown " + std::to_string(q.box->nknown) + " start " + std::to_string(q.box->start) + " rows";
         static const char* const nm[] = {"ctx", "bm0", "bm1", "bm2", "fx", "p8", "cm2a", "cm2b", "cm2c", "fam", "lanes", "dmc", "brk", "lstm"};
-        for (int i = 0; i < 14; ++i) st += std::string(" ") + nm[i] + "=" + std::to_string(*(volatile uint32_t*)&q.box->cnt[i].v);
+        uint32_t cv[LC_N * CMX_LATE_CNT_STRIDE] = {0};
+        for (LateSet& z : L->set) if (z.box) z.box->abort = 1;   // the kernels leave, the copy below can run
+        if (hipMemcpy(cv, q.cnt, sizeof cv, hipMemcpyDeviceToHost) == hipSuccess)
+          for (int i = 0; i < 14; ++i) st += std::string(" ") + nm[i] + "=" + std::to_string(cv[i * CMX_LATE_CNT_STRIDE] & 0xFFFFu);
         st += "]";
         cmx_set_err(std::string("cmx_pipeline_late_predict: ") + why + " at bit " + std::to_string(L->bits) + " (bit " + std::to_string(L->t) + " of its chunk)" + st);
         L->failed = true;
@@ -874,7 +892,7 @@ int cmx_pipeline_late_perceive(cmx_pipeline_t* h, int bit) {
   // ---- the LSTM byte mixer's step for the completed byte (predictor.cpp:450-461), then "its distribution is there" ----
   if (byte_done) {
     if (cmx_lstm_run(h->lstm, q.ppmd + (b + 1) * 256, q.bytes + b, 1, q.lstm + b * 256, nullptr, 0, nullptr, h->s_lstm)) return 1;
-    if (cmx_late_bump(h->device, &q.box->cnt[LC_LSTM].v, (uint32_t)(b + 1), nullptr, 0, h->s_lstm)) { cmx_set_err("cmx_pipeline_late_perceive: launch failed"); return 1; }
+    if (cmx_late_bump(h->device, q.cnt + LC_LSTM * CMX_LATE_CNT_STRIDE, q.lt.base | (uint32_t)(b + 1), nullptr, 0, h->s_lstm)) { cmx_set_err("cmx_pipeline_late_perceive: launch failed"); return 1; }
     lap(4);
   }
   L->predicted = false;
@@ -893,9 +911,14 @@ int cmx_pipeline_late_perceive(cmx_pipeline_t* h, int bit) {
 // between cmx_pipeline_late_predict() and cmx_pipeline_late_perceive()
 const float* cmx_pipeline_late_debug_row(cmx_pipeline_t* h, const uint32_t** sel) {
   if (!h || !h->late || !h->late->active || !h->late->predicted) return nullptr;
-  const LateSet& q = h->late->set[(int)(h->late->cur % 3)];
-  if (sel) *sel = q.sel + h->late->t * CMX_N_MIXERS;
-  return q.layer0 + h->late->t * CMX_N_INPUTS;
+  Late* L = h->late;
+  const LateSet& q = L->set[(int)(L->cur % 3)];
+  // the rows live in (uncached) device memory: copied out on the upload stream, which is idle while a stream is decoded
+  if (hipMemcpyAsync(L->dbg_row, q.layer0 + L->t * CMX_N_INPUTS, CMX_N_INPUTS * 4, hipMemcpyDeviceToHost, h->s_up) != hipSuccess ||
+      hipMemcpyAsync(L->dbg_sel, q.sel + L->t * CMX_N_MIXERS, CMX_N_MIXERS * 4, hipMemcpyDeviceToHost, h->s_up) != hipSuccess ||
+      hipStreamSynchronize(h->s_up) != hipSuccess) return nullptr;
+  if (sel) *sel = L->dbg_sel;
+  return L->dbg_row;
 }
 
 int cmx_pipeline_late_host_ms(cmx_pipeline_t* h, double ms[6], uint64_t* bits) {

@@ -456,7 +456,10 @@ int cmx_p8stage_profile(cmx_p8stage_t*, unsigned long long out128[128]);
  * ------------------------------------------------------------------------ */
 void* cmx_late_alloc(size_t bytes);   /* zeroed host-coherent pinned memory: boxes, rows, records */
 void cmx_late_free(void* p);
+void* cmx_late_alloc_dev(int device, size_t bytes);   /* zeroed UNCACHED device memory: rows / row counters kernels hand to each other while they run */
+void cmx_late_free_dev(void* p);
 size_t cmx_late_box_bytes(size_t nbits);   /* allocation size of a box for a chunk of nbits */
+/* `box` of the per-stage entry points below: a `const CmxLate*` (cmx_late.h) = the host box, the chunk's row counters and their base */
 int cmx_late_bump(int device, uint32_t* counter, uint32_t value, uint32_t* counter2, uint32_t value2, void* stream);
 int cmx_ctxmodels_run_late(cmx_ctxmodels_t*, void* box, size_t nbytes, float* probs, size_t pstride, uint32_t* sel, float* brk_dist,
                            const float** brk_dist0_out, void* stream);

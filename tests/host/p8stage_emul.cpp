@@ -37,6 +37,8 @@ struct Emul {
   uint64_t steps = 0;
   int last_bit = 0;
   uint64_t fam_serial = 0, cm2_serial = 0;
+  int late = 0;           // 1: the DECODER's order of operations (cmx_late.h): the front end emits a step's records only after the bit before it has been
+                          // handed in, and the maps' uniform registers take that bit at the top of the step (p8d_bit_y, p8f_uni_tail + p8f_uni_head)
   int fam_miniwalk = 1;   // 0: whole-instance walks only; 1: the kernel's narrowed walk; 2: with every second visit treated as unlisted (the fall-back path)
   uint64_t fam_mini = 0, fam_mini_full = 0;
   // diagnostics: per family instance, lookup bits with an overlap / with an overlap AND a pending rnd() draw in the instance
@@ -108,6 +110,7 @@ void p8s_dump_fam(void* h, uint32_t* out /* [nslots][5] */) {
 }
 void p8s_dump_table(void* h, int inst, uint8_t* out) { Emul* e = (Emul*)h; memcpy(out, e->S.fam.inst[inst].table, ((size_t)e->S.fam.inst[inst].mask + 1) * 64); }
 void p8s_set_miniwalk(void* h, int mode) { ((Emul*)h)->fam_miniwalk = mode; }
+void p8s_set_late(void* h, int on) { ((Emul*)h)->late = on; }
 void p8s_miniwalk_stats(void* h, uint64_t* out2) { out2[0] = ((Emul*)h)->fam_mini; out2[1] = ((Emul*)h)->fam_mini_full; }
 void p8s_stats(void* h, uint64_t* out3) { Emul* e = (Emul*)h; out3[0] = e->steps; out3[1] = e->fam_serial; out3[2] = e->cm2_serial; }
 // nbytes more bytes of the stream; out [8 nbytes][1591] f32 = PAQ8::Predict() before each of their bits. 0 or a negative front-end code.
@@ -123,10 +126,12 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
   c.fam_ctx = fctx.data(); c.fam_chk = fchk.data();
   for (int k = 0; k < P8_NCM2; k++) { c2ctx[k].resize(n * L.cm2_count[k]); c2chk[k].resize(n * L.cm2_count[k]); c.cm2_ctx[k] = c2ctx[k].data(); c.cm2_chk[k] = c2chk[k].data(); }
   c.ops = ops.data(); c.sel = sel.data(); c.apm = apm.data();
-  const int rc = p8f_front_run(e->front, bytes, n, &c);
-  if (rc) return rc;
   std::vector<uint8_t> bits(T), order(T, 0);
   for (size_t i = 0; i < T; i++) bits[i] = (bytes[i >> 3] >> (7 - (i & 7))) & 1;
+  if (!e->late) {
+    const int rc = p8f_front_run(e->front, bytes, n, &c);
+    if (rc) return rc;
+  }
   std::vector<int16_t> x(T * P8_NX, 0);
   P8StageState& S = e->S;
   // per-family uniform registers, carried between calls
@@ -147,11 +152,19 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
   for (size_t t = 0; t < T; t++) {
     const uint64_t g = e->steps + t;
     const int y = t ? bits[t - 1] : e->last_bit;
+    if (e->late) {   // the records of step t exist only now: every bit before the step has been decoded and handed in
+      if (t) p8f_front_set_bit(e->front, bits[t - 1]);
+      const int rc = p8f_front_emit_step(e->front, &c, t);
+      if (rc) return rc;
+    }
     int16_t* xr = x.data() + t * P8_NX;
     float* orow = out + t * P8_NOUT;
     // the uniform registers advance on every step, the lanes run once a byte boundary has been passed
     P8Cm2Bit cu[P8_NCM2];
-    for (int k = 0; k < P8_NCM2; k++) cu[k] = p8d_bit(&S.cm2[k], c.cm2_ctx[k], c.cm2_chk[k], bits.data(), x.data(), (int)t, &run_bits[k], &c_last_y[k]);
+    for (int k = 0; k < P8_NCM2; k++) {
+      if (e->late) { cu[k] = p8d_bit_y(&S.cm2[k], c.cm2_ctx[k], c.cm2_chk[k], t ? y : c_last_y[k], x.data(), (int)t, &run_bits[k]); if (t + 1 == T) c_last_y[k] = bits[t]; }
+      else cu[k] = p8d_bit(&S.cm2[k], c.cm2_ctx[k], c.cm2_chk[k], bits.data(), x.data(), (int)t, &run_bits[k], &c_last_y[k]);
+    }
     const P8CmBit fu_pre = P8CmBit();
     (void)fu_pre;
     if (g >= 8 && e->use_v1) {
@@ -194,7 +207,9 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
       P8CmDev* d = &S.fam;
       P8FamShared* sh = e->f2;
       const int SS = d->nslots;
-      const P8FamUni fu = p8f_uni_inc(d, c.fam_ctx, c.fam_chk, bits.data(), x.data(), order.data(), (int)t, &f_run, e->f2_i);
+      if (e->late && t > 0) p8f_uni_tail(&f_run, (int)((t - 1) & 7), y);   // (t == 0: f_run.last_y is the carried bit, as the kernel takes it from the box)
+      const P8FamUni fu = e->late ? p8f_uni_head(c.fam_ctx, c.fam_chk, x.data(), order.data(), (int)t, &f_run, e->f2_i)
+                                  : p8f_uni_inc(d, c.fam_ctx, c.fam_chk, bits.data(), x.data(), order.data(), (int)t, &f_run, e->f2_i);
       if (g >= 8) {
         static P8FamTmp tmp[P8CM_MAXS];
         for (int s = SS - 1; s >= 0; s--) { p8f_lane(d, s, &tmp[s]); tmp[s].cx = p8f_ctx(d, fu, s); tmp[s].ck = p8f_chk(d, fu, s); p8f_phase1(d, sh, fu, s, &tmp[s]); }
@@ -311,6 +326,10 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
     const int yb = bits[t];
     for (int i = 0; i < P8_NSEL; i++) train(xs, S.mix.wx + (size_t)row[i] * P8_NX, npad, ((yb << 12) - pr[i]) * 7);
     train(st, S.mix.wx2, 32, ((yb << 12) - p2) * 7);
+  }
+  if (e->late && T) {   // the chunk's last bit: into the run registers a later chunk starts from, and to the front end
+    p8f_uni_tail(&f_run, (int)((T - 1) & 7), bits[T - 1]);
+    p8f_front_set_bit(e->front, bits[T - 1]);
   }
   if (!e->use_v1) { f_last_y = f_run.last_y; f_c1 = f_run.c1; }
   S.fam.last_y = f_last_y; S.fam.c1 = f_c1;

@@ -46,7 +46,7 @@ def emul():
     return L
 
 
-def run_stage(data, chunks=None, miniwalk=None, mini_stats=None):
+def run_stage(data, chunks=None, miniwalk=None, mini_stats=None, late=False):
     """PAQ8::Predict()'s 1591 values before every bit of data, through the emulated stage in the given chunk sizes. miniwalk: how the
     ContextMap family resolves an overlap at a lookup bit (None / 1: as the kernel, 0: whole-instance walks, 2: the fall-back path forced)."""
     L = emul()
@@ -56,6 +56,9 @@ def run_stage(data, chunks=None, miniwalk=None, mini_stats=None):
     if miniwalk is not None:
         L.p8s_set_miniwalk.argtypes = [C.c_void_p, C.c_int]
         L.p8s_set_miniwalk(h, miniwalk)
+    if late:
+        L.p8s_set_late.argtypes = [C.c_void_p, C.c_int]
+        L.p8s_set_late(h, 1)
     out = np.zeros((8 * len(data), 1591), np.float32)
     pos, k = 0, 0
     chunks = chunks or [len(data)]
@@ -161,3 +164,21 @@ def test_cm2_walk_and_reload_path(monkeypatch):
     assert st[2] > 100
     want = np.ascontiguousarray(probs[:, 434:2025])
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_decoders_order_of_operations_gives_the_same_columns():
+    """The late-bit protocol (cmix_amd/csrc/cmx_late.h): a decoder's front end emits the records of a step only after the bit before it
+    has been decoded (p8f_front_emit_step / p8f_front_set_bit instead of p8f_front_run over known bytes), and the maps' uniform
+    registers take that bit at the top of the step (p8d_bit_y; p8f_uni_tail of step t - 1, then p8f_uni_head of step t) instead of
+    reading the chunk's bytes ahead. Same values, bit for bit, in ragged chunks -- against the reference's own columns."""
+    g = load_golden("text_96")
+    probs = mg.unpack_probs(g)
+    out, _ = run_stage(g["stream"], chunks=[1, 7, 40, 13], late=True)
+    a, b = out.view(np.uint32), np.ascontiguousarray(probs[:, 434:2025]).view(np.uint32)
+    bad = np.argwhere(a != b)
+    assert len(bad) == 0, f"late order: column {434 + bad[0][1]} differs first at bit {bad[0][0]}"
+    rng = np.random.default_rng(3)
+    data = bytes(rng.integers(0, 256, 1500, dtype=np.uint8)) + b"the quick brown fox jumps over the lazy dog. " * 40
+    x, _ = run_stage(data, chunks=[512])
+    y, _ = run_stage(data, chunks=[512, 1, 300], late=True)
+    assert (x.view(np.uint32) == y.view(np.uint32)).all()
