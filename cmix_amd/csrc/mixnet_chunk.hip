@@ -1515,10 +1515,21 @@ __device__ void stretch_role(MixState* S, const Lds& L, SpecXfer* X, const float
       if (__ballot(!ok)) { lds_publish_store(&L.ctl->abort, 1); return; }
     }
     float pv[33];
+    if (L.late.box) {
+      // `probs` is a const __restrict__ kernel argument: the compiler may treat its contents as invariant for the whole launch (merge a
+      // load with an earlier one, move it above the wait). A decoder's rows are written WHILE this kernel runs: atomic loads, which
+      // it has to perform where they stand.
 #pragma unroll
-    for (int r = 0; r < 33; ++r) {
-      int i = r * 64 + lane;
-      pv[r] = i < CMX_IN0 ? pr[i] : 0.5f;
+      for (int r = 0; r < 33; ++r) {
+        int i = r * 64 + lane;
+        pv[r] = i < CMX_IN0 ? __hip_atomic_load(probs + (size_t)t * CMX_IN0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.5f;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 33; ++r) {
+        int i = r * 64 + lane;
+        pv[r] = i < CMX_IN0 ? pr[i] : 0.5f;
+      }
     }
     const int bitv = L.late.box ? 0 : (int)bits[t];   // (late: not known yet; the waves that learn wait for it)
     const float lstm_raw = bcast_lane(pv[32], 29);   // probs[t][2077]
@@ -1563,9 +1574,11 @@ __device__ void stretch_role(MixState* S, const Lds& L, SpecXfer* X, const float
 __device__ void select_role(MixState* S, const Lds& L, SpecXfer* X, const uint32_t* sel, int nbits, int lane) {
   const gptr<const uint32_t> gsel = as_global(sel);
   for (int t = 0; t < nbits; ++t) {
-    uint32_t key = lane < CMX_MIXERS ? gsel[(size_t)t * CMX_MIXERS + lane] : 0;
+    uint32_t key = (!L.late.box && lane < CMX_MIXERS) ? gsel[(size_t)t * CMX_MIXERS + lane] : 0;
     if (!wait_ge(L.ctl, &L.sdone[t % L.rr], t + 1, true)) return;
-    if (L.late.box && lane < CMX_MIXERS) key = gsel[(size_t)t * CMX_MIXERS + lane];   // a decoder: the row's selectors exist only now
+    // a decoder: the row's selectors exist only now -- and `sel` is a const __restrict__ kernel argument (see stretch_role): an atomic
+    // load, which the compiler cannot merge with an earlier one or hoist
+    if (L.late.box && lane < CMX_MIXERS) key = __hip_atomic_load(sel + (size_t)t * CMX_MIXERS + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     BitRec* rec = L.rec + (t % L.rr);
     const BitRec* prev = L.rec + ((t + L.rr - 1) % L.rr);
     if (lane == CMX_AUX) key = rec->auxkey;
