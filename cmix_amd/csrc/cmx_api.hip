@@ -136,6 +136,8 @@ struct cmx_mixnet {
   bool use_spec = true; // cmx_mixnet_spec_kernel (26 helper workgroups, speculative segment-parallel chains); CMX_MIXNET_SPEC=0: the one-workgroup kernel
   SpecXfer* d_xfer = nullptr;
   float* d_late_p = nullptr; size_t late_p_cap = 0;   // the decoder's form: the kernel's p[] array (the host reads p from the box)
+  float* late_mix_cur[3] = {nullptr, nullptr, nullptr};
+  float* d_late_mix = nullptr;                         // CMX_LATE_DEBUG=1: the 47 mixer outputs per bit of the chunk launched last (test hook)
 };
 
 extern "C" {
@@ -371,6 +373,19 @@ int cmx_mixnet_set_tolerance(cmx_mixnet_t* h, int on) {
 // DEVICE address of MixState::error (set by a chunk kernel whose bounded in-launch wait ran out), for callers that copy it back in
 // stream order behind the chunk's kernel (cmx_pipeline_finish) instead of synchronising the device
 const int* cmx_mixnet_error_flag(cmx_mixnet_t* h) { return h ? &h->d_state->error : nullptr; }
+// diagnostics: rows allocated so far by each of the 47 mixers (Mixer::GetContextData's context_map_.size(); the cap is 10 000 + the
+// shared overflow row, mixer.cpp:16-36). Synchronises the device.
+int cmx_mixnet_rows(cmx_mixnet_t* h, uint32_t rows[47]) {
+  if (!h || !rows) { set_err("cmx_mixnet_rows: bad argument"); return 1; }
+  if (hipSetDevice(h->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { set_err("cmx_mixnet_rows: device error"); return 1; }
+  return hipMemcpy(rows, (const char*)h->d_state + offsetof(MixState, n_rows), 47 * 4, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+uint64_t cmx_mixnet_runs(cmx_mixnet_t* h) { return h ? h->runs : 0; }   // chunks launched so far
+// test hook (CMX_LATE_DEBUG=1): DEVICE address of the 47 mixer outputs of bit `bit` of the late chunk launched as number `chunk` of this handle
+const float* cmx_mixnet_late_debug_mix(cmx_mixnet_t* h, uint64_t chunk, size_t bit) {
+  if (!h || !h->d_late_mix) return nullptr;
+  return h->d_late_mix + (size_t)(chunk % 3) * h->late_p_cap * CMX_MIXERS + bit * CMX_MIXERS;
+}
 // 0 strict (bit-exact, the default), 1 tolerance
 int cmx_mixnet_mode(cmx_mixnet_t* h) { return h && h->tolerance ? 1 : 0; }
 
@@ -395,7 +410,10 @@ int cmx_mixnet_run_late(cmx_mixnet_t* h, void* box, const float* probs, const ui
   if (!h->use_spec || h->use_v1 || h->tolerance) { set_err("cmx_mixnet_run_late: a decoder needs the strict 27-workgroup kernel (CMX_MIXNET_SPEC=0, CMX_MIXNET_V1 or the tolerance switch is set)"); return 1; }
   if (hipSetDevice(h->device) != hipSuccess) { set_err("hipSetDevice failed"); return 1; }
   if (h->late_p_cap < nbits || h->decay_cap < nbits) { set_err("cmx_mixnet_run_late: call cmx_mixnet_late_prepare first (nothing may be allocated while the stream's kernels run)"); return 1; }
-  return mixnet_run_impl(h, probs, sel, nullptr, nbits, h->d_late_p, nullptr, stream, (const CmxLate*)box);
+  // (debug: three chunk-sized areas of mixer outputs in rotation, like the pipeline's buffer sets)
+  float* mix = h->d_late_mix ? h->d_late_mix + (size_t)(h->runs % 3) * h->late_p_cap * CMX_MIXERS : nullptr;
+  h->late_mix_cur[h->runs % 3] = mix;
+  return mixnet_run_impl(h, probs, sel, nullptr, nbits, h->d_late_p, mix, stream, (const CmxLate*)box);
 }
 // everything the decoder's form allocates, for chunks of up to nbits bits: before the first chunk's kernels are launched
 int cmx_mixnet_late_prepare(cmx_mixnet_t* h, size_t nbits) {
@@ -406,6 +424,12 @@ int cmx_mixnet_late_prepare(cmx_mixnet_t* h, size_t nbits) {
     if (hipMalloc(&p, nbits * 4) != hipSuccess) { set_err("cmx_mixnet_late_prepare: hipMalloc failed"); return 1; }
     h->allocs.push_back(p);
     h->d_late_p = (float*)p; h->late_p_cap = nbits;
+    const char* dbg = getenv("CMX_LATE_DEBUG");
+    if (dbg && dbg[0] == '1') {
+      if (hipMalloc(&p, 3 * nbits * CMX_MIXERS * 4) != hipSuccess) { set_err("cmx_mixnet_late_prepare: hipMalloc failed"); return 1; }
+      h->allocs.push_back(p);
+      h->d_late_mix = (float*)p;
+    }
   }
   if (!h->s_up) { if (hipStreamCreateWithFlags(&h->s_up, hipStreamNonBlocking) != hipSuccess) { set_err("cmx_mixnet_late_prepare: stream creation failed"); return 1; } h->own_up = true; }
   return ensure_decay(h, nbits);

@@ -83,6 +83,8 @@ __global__ __launch_bounds__(P8CM2_MAXC) void cmx_p8s_cm2v2_late_kernel(P8Cm2Dev
                                                                        uint8_t* order_out, int nbits, int skip) {
   __shared__ __attribute__((aligned(16))) P8Cm2V2Shared sh;
   __shared__ int late_y_s;
+  __shared__ uint32_t ctx_s[P8CM2_MAXC];   // the byte's hashed contexts / checksums: host records that arrive while the kernel runs, read ONCE with
+  __shared__ uint16_t chk_s[P8CM2_MAXC];   // loads the compiler cannot merge, hoist or turn into cached scalar loads (volatile), kept here for the byte
   const int i = threadIdx.x, C = d->C;
   p8c2_load(d, &sh, i, P8CM2_MAXC);
   uint32_t run_bits = d->bits;
@@ -92,7 +94,12 @@ __global__ __launch_bounds__(P8CM2_MAXC) void cmx_p8s_cm2v2_late_kernel(P8Cm2Dev
   __syncthreads();
   for (int t = 0; t < nbits; t++) {
     P8_LATE_Y(t);
-    const P8Cm2Bit u = p8d_bit_y(d, ctx, chk, y_, x, t, &run_bits);
+    if ((t & 7) == 0) {
+      if (i < C) { ctx_s[i] = *(volatile const uint32_t*)(ctx + (size_t)(t >> 3) * C + i); chk_s[i] = *(volatile const uint16_t*)(chk + (size_t)(t >> 3) * C + i); }
+      __syncthreads();
+    }
+    P8Cm2Bit u = p8d_bit_y(d, ctx, chk, y_, x, t, &run_bits);
+    u.ctx = ctx_s; u.chk = chk_s;
     if (t < skip) { if (i == 0) { if (order_out) order_out[t] = 0; late_publish(B, counter, (uint32_t)(t + 1)); } continue; }
     const bool look = u.bpos == 0 || u.bpos == 2 || u.bpos == 5;
     P8Cm2Tmp tmp;
@@ -128,6 +135,8 @@ template <bool LATE>
 __device__ __forceinline__ void p8s_fam2_body(P8CmDev* d, P8FamHome* home, const uint32_t* ctx, const uint16_t* chk, const uint8_t* bits, int16_t* x,
                                               const uint8_t* order, int nbits, int skip, unsigned long long* prof, CmxLate B) {
   __shared__ int late_y_s;
+  __shared__ uint32_t fctx_s[LATE ? P8CM_MAXS : 1];
+  __shared__ uint16_t fchk_s[LATE ? P8CM_MAXS : 1];
   extern __shared__ __attribute__((aligned(16))) unsigned char p8f_smem[];
   P8FamShared& sh = *(P8FamShared*)p8f_smem;
   const int tid = threadIdx.x, S = d->nslots, ninst = d->ninst;
@@ -155,7 +164,17 @@ __device__ __forceinline__ void p8s_fam2_body(P8CmDev* d, P8FamHome* home, const
       __syncthreads();
       if (t > 0) p8f_uni_tail(&frun, (t - 1) & 7, y); else frun.last_y = y;
     }
-    const P8FamUni u = LATE ? p8f_uni_head(ctx, chk, x, order, t, &frun, rnd_i) : p8f_uni_inc(d, ctx, chk, bits, x, order, t, &frun, rnd_i);
+    P8FamUni u = LATE ? p8f_uni_head(ctx, chk, x, nullptr, t, &frun, rnd_i) : p8f_uni_inc(d, ctx, chk, bits, x, order, t, &frun, rnd_i);
+    if (LATE) {
+      // a decoder: the byte's hashed contexts / checksums (host records that arrived with the last bit) and the order-N map's value of the step (written by
+      // its kernel a moment ago) are read ONCE, with loads the compiler cannot merge, hoist or turn into cached scalar loads, and kept in LDS for the byte
+      if ((t & 7) == 0) {
+        for (int q = tid; q < S; q += P8FAM_THREADS) { fctx_s[q] = *(volatile const uint32_t*)(ctx + (size_t)(t >> 3) * S + q); fchk_s[q] = *(volatile const uint16_t*)(chk + (size_t)(t >> 3) * S + q); }
+        if (order) frun.order = (int)*(volatile const uint8_t*)(order + t);
+        __syncthreads();
+      }
+      u.order = frun.order; u.ctx = fctx_s; u.chk = fchk_s;
+    }
     const int lk = frun.lk;
     if (t < skip) { if (LATE && tid == 0) late_publish(B, LC_FAM, (uint32_t)(t + 1)); continue; }
     P8F_TICK(0);
@@ -163,7 +182,9 @@ __device__ __forceinline__ void p8s_fam2_body(P8CmDev* d, P8FamHome* home, const
     // starts with a global round trip before it can even compute its bucket's address
     if (sl < S) {
       if (u.bp == 0 && have_nx) { my_cx = nx_cx; my_ck = nx_ck; }
-      else if (u.bp == 0 || !have_cur) { my_cx = p8f_ctx(d, u, sl); my_ck = p8f_chk(d, u, sl); }   // (a chunk's first byte; a stream's first step is bit 1)
+      else if (u.bp == 0 || !have_cur) {   // (a chunk's first byte; a stream's first step is bit 1; a decoder: every byte)
+        my_cx = p8f_ctx(d, u, sl); my_ck = p8f_chk(d, u, sl);
+      }
       have_cur = true;
       if (u.bp == 0) have_nx = false;
       tmp.cx = my_cx; tmp.ck = my_ck;
@@ -295,7 +316,8 @@ __global__ __launch_bounds__(P8LANES_THREADS) void cmx_p8s_lanes_late_kernel(P8L
     const int y = late_y_s;
     if (y < 0) return;
     __syncthreads();
-    if (t >= t0 && act && l < d->nlanes) p8s_lane_step(d, &r, l, ops[(size_t)t * P8_NLANE + l], y, order[t], x + (size_t)t * P8_NX);
+    if (t >= t0 && act && l < d->nlanes)
+      p8s_lane_step(d, &r, l, *(volatile const uint32_t*)(ops + (size_t)t * P8_NLANE + l), y, (int)*(volatile const uint8_t*)(order + t), x + (size_t)t * P8_NX);
     __syncthreads();
     if (threadIdx.x == 0) late_publish(B, LC_LANES, (uint32_t)(t + 1));
   }

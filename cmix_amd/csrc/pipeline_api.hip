@@ -137,6 +137,7 @@ struct Late {
   double ms[6] = {0, 0, 0, 0, 0, 0};
   uint64_t bits = 0;
   float* dbg_row = nullptr; uint32_t* dbg_sel = nullptr;   // pinned: cmx_pipeline_late_debug_row
+  uint64_t mix_chunk0 = 0;                                  // the mixing-network handle's launch count when the stream started (debug hook)
 };
 }  // namespace
 
@@ -414,6 +415,11 @@ int cmx_pipeline_set_tolerance(cmx_pipeline_t* h, int on) {
   return cmx_mixnet_set_tolerance(h->mix, on);
 }
 int cmx_pipeline_mixnet_mode(cmx_pipeline_t* h) { return h ? cmx_mixnet_mode(h->mix) : -1; }
+// ---- diagnostics of a long run (scripts/gpu_long_run.py): all of them synchronise the device ----
+int cmx_pipeline_mixnet_rows(cmx_pipeline_t* h, uint32_t rows[47]) { return h ? cmx_mixnet_rows(h->mix, rows) : 1; }
+int cmx_pipeline_spec_stats(cmx_pipeline_t* h, uint64_t out[5]) { return h ? cmx_mixnet_spec_stats(h->mix, out) : 1; }
+int cmx_pipeline_paq8_profile(cmx_pipeline_t* h, unsigned long long out128[128]) { return h && h->p8 ? cmx_p8stage_profile(h->p8, out128) : 1; }
+int cmx_pipeline_ppmd_arena(cmx_pipeline_t* h, uint64_t out3[3]) { return h ? cmx_ppmd_arena(h->ppmd, out3) : 1; }
 int cmx_pipeline_paq8_enabled(cmx_pipeline_t* h) { return h && h->p8 ? 1 : 0; }
 int cmx_pipeline_paq8_total_ms(cmx_pipeline_t* h, double* ms) { if (!h || !ms) return 1; *ms = h->p8_ms; return 0; }
 // wall time of the CALLING thread inside cmx_pipeline_begin / _finish since the last reset of the stage totals, in ms:
@@ -782,6 +788,7 @@ int cmx_pipeline_late_start(cmx_pipeline_t* h, int last_bit) {
   if (cmx_fxcm_late_prepare(h->fxcm, n) || cmx_p8stage_late_prepare(h->p8, n) || cmx_mixnet_late_prepare(h->mix, T)) { L->failed = true; return 1; }
   if (hipDeviceSynchronize() != hipSuccess) { cmx_set_err("cmx_pipeline_late_start: device error"); L->failed = true; return 1; }
   L->lstm0 = cmx_lstm_byte_probs(h->lstm);
+  L->mix_chunk0 = cmx_mixnet_runs(h->mix);
   // chunk 0 and, queued behind it, chunk 1
   if (late_launch(h, 0)) { L->failed = true; return 1; }
   LateSet& q0 = L->set[0];
@@ -919,6 +926,20 @@ const float* cmx_pipeline_late_debug_row(cmx_pipeline_t* h, const uint32_t** sel
       hipStreamSynchronize(h->s_up) != hipSuccess) return nullptr;
   if (sel) *sel = L->dbg_sel;
   return L->dbg_row;
+}
+// test hook (CMX_LATE_DEBUG=1 when the handle was built): the 47 mixer outputs (Mixer::Mix values: 26 layer-0, 20 layer-1, the final one) of
+// the bit BEFORE the one predicted last (the waves write them when they learn, i.e. after the bit has arrived), copied to `out47`; 1 if the
+// hook is off or no bit has been coded yet
+int cmx_pipeline_late_debug_mix(cmx_pipeline_t* h, float out47[47]) {
+  if (!h || !h->late || !h->late->active || !h->late->predicted || !out47 || !h->late->bits) return 1;
+  Late* L = h->late;
+  const uint64_t chunk = L->t ? L->cur : L->cur - 1;
+  const size_t bit = L->t ? L->t - 1 : 8 * kLateChunk - 1;
+  const float* d = cmx_mixnet_late_debug_mix(h->mix, L->mix_chunk0 + chunk, bit);
+  if (!d) return 1;
+  if (hipMemcpyAsync(L->dbg_row, d, CMX_N_MIXERS * 4, hipMemcpyDeviceToHost, h->s_up) != hipSuccess || hipStreamSynchronize(h->s_up) != hipSuccess) return 1;
+  memcpy(out47, L->dbg_row, CMX_N_MIXERS * 4);
+  return 0;
 }
 
 int cmx_pipeline_late_host_ms(cmx_pipeline_t* h, double ms[6], uint64_t* bits) {

@@ -630,6 +630,17 @@ void cmx_ppmd_destroy(cmx_ppmd_t* h) {
   delete h;
 }
 
+// diagnostics: bytes of the arena in use -- raw text from the bottom, units from the top; the model restarts (not implemented: the call
+// above fails) when the untouched gap [lo, hi) between them is used up
+int cmx_ppmd_arena(cmx_ppmd_t* h, uint64_t out3[3]) {
+  if (!h || !out3) return 1;
+  const Ppmd& m = h->m;
+  out3[0] = m.heap_bytes;
+  out3[1] = (uint64_t)(m.hi - m.lo);                 // untouched
+  out3[2] = m.heap_bytes - (uint64_t)(m.hi - m.lo);  // in use (text + units, incl. free-listed units)
+  return 0;
+}
+
 int cmx_ppmd_run(cmx_ppmd_t* h, const uint8_t* bytes, size_t nbytes, float* out_probs) {
   if (!h || (nbytes && (!bytes || !out_probs))) { cmx_set_err("cmx_ppmd_run: bad argument"); return 1; }
   Ppmd& m = h->m;

@@ -571,6 +571,12 @@ class Pipeline:
         s = np.ctypeslib.as_array(C.cast(sel.value, C.POINTER(C.c_uint32)), (47,)).copy()
         return row, s
 
+    def late_mix(self):
+        """the 47 Mixer::Mix values of the bit BEFORE the one predicted last (CMX_LATE_DEBUG=1 when the handle was built), or None"""
+        out = np.zeros(47, np.float32)
+        lib().cmx_pipeline_late_debug_mix.argtypes = [C.c_void_p, C.c_void_p]
+        return None if lib().cmx_pipeline_late_debug_mix(self.h, out.ctypes.data) else out
+
     def late_host_ms(self):
         v, n = (C.c_double * 6)(), C.c_uint64(0)
         lib().cmx_pipeline_late_host_ms(self.h, v, C.byref(n))

@@ -401,6 +401,15 @@ int cmx_pipeline_fxcm_enabled(cmx_pipeline_t*);
 int cmx_pipeline_finish_cols(cmx_pipeline_t*, const float* cols, int first_col, int ncols, float* d_p_out);
 int cmx_pipeline_fxcm_total_ms(cmx_pipeline_t*, double* ms);
 /* the mixing network's tolerance mode for this stream (cmx_mixnet_set_tolerance), before the first chunk; _mixnet_mode: 0 strict, 1 tolerance */
+/* diagnostics of a long run (all synchronise the device): rows allocated by each of the 47 final mixers (cap 10 000 + the shared
+ * overflow row, mixer.cpp:16-36); speculation statistics of the mixing network (cmx_mixnet_spec_stats); the paq8 family kernel's
+ * phase / path counters (CMX_P8FAM_PROFILE=1 at create time; cmx_p8stage_profile); PPMd's arena: {bytes reserved, untouched, in use} */
+int cmx_mixnet_rows(cmx_mixnet_t*, uint32_t rows[47]);
+int cmx_ppmd_arena(cmx_ppmd_t*, uint64_t out3[3]);
+int cmx_pipeline_mixnet_rows(cmx_pipeline_t*, uint32_t rows[47]);
+int cmx_pipeline_spec_stats(cmx_pipeline_t*, uint64_t out[5]);
+int cmx_pipeline_paq8_profile(cmx_pipeline_t*, unsigned long long out128[128]);
+int cmx_pipeline_ppmd_arena(cmx_pipeline_t*, uint64_t out3[3]);
 int cmx_pipeline_set_tolerance(cmx_pipeline_t*, int on);
 int cmx_pipeline_mixnet_mode(cmx_pipeline_t*);
 /* Predictor::Pretrain over n dictionary bytes (HOST pointer), before the first submit: only the stages holding
@@ -491,6 +500,10 @@ int cmx_pipeline_late_stop(cmx_pipeline_t*);
 int cmx_pipeline_late_host_ms(cmx_pipeline_t*, double ms[6], uint64_t* bits);
 /* test hook: the layer-0 row (2078 f32, host memory) and 47 selectors of the bit predicted last; valid until the matching perceive */
 const float* cmx_pipeline_late_debug_row(cmx_pipeline_t*, const uint32_t** sel);
+/* test hooks (CMX_LATE_DEBUG=1 in the environment when the handle is built): the 47 Mixer::Mix values of the bit BEFORE the one predicted last */
+int cmx_pipeline_late_debug_mix(cmx_pipeline_t*, float out47[47]);
+const float* cmx_mixnet_late_debug_mix(cmx_mixnet_t*, uint64_t chunk, size_t bit);
+uint64_t cmx_mixnet_runs(cmx_mixnet_t*);
 
 #ifdef __cplusplus
 }

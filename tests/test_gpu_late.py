@@ -23,6 +23,7 @@ pytestmark = pytest.mark.gpu
 
 _CHILD = r'''
 import sys, os
+os.environ["CMX_LATE_DEBUG"] = "1"   # the mixing network also writes its 47 Mixer::Mix values per bit (test hook)
 import numpy as np
 sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests")); sys.path.insert(0, os.path.join({root!r}, "tests", "golden"))
 from conftest import bits_equal
@@ -42,6 +43,8 @@ if "pretrain" in g:
 pipe.late_start(last)
 bits = np.ascontiguousarray(g["bits"], np.uint8)
 ref_rows = mg.unpack_probs(g) if rows and "probs_q" in g else None
+ref_sel = (g["sel"] & np.uint64(0xFFFFFFFF)).astype(np.uint32) if "sel" in g else None
+ref_mix = np.ascontiguousarray(g["mix_out"], np.float32) if "mix_out" in g else None
 pf = np.ascontiguousarray(g["p_final"], np.float32)
 bad = None
 for t in range(len(bits)):
@@ -51,6 +54,17 @@ for t in range(len(bits)):
         d = np.nonzero(~bits_equal(row, ref_rows[t]))[0]
         if len(d):
             bad = "layer-0 input %d differs at bit %d: %r vs reference %r (%d inputs differ)" % (d[0], t, row[d[0]], ref_rows[t][d[0]], len(d))
+            break
+        if ref_sel is not None:
+            d = np.nonzero((sel != ref_sel[t]) & (np.arange(47) != 12))[0]   # (12: auxiliary_context_, formed inside the mixing network from three of the inputs)
+            if len(d):
+                bad = "selector %d differs at bit %d: %r vs reference %r (%d differ)" % (d[0], t, sel[d[0]], ref_sel[t][d[0]], len(d))
+                break
+    mix = pipe.late_mix() if ref_mix is not None and t > 0 else None   # (of bit t - 1: the waves write them when they learn)
+    if mix is not None:
+        d = np.nonzero(~bits_equal(mix, ref_mix[t - 1]))[0]
+        if len(d):
+            bad = "Mixer::Mix value of mixer %d differs at bit %d: %r vs reference %r (mixers that differ: %s)" % (d[0], t - 1, mix[d[0]], ref_mix[t - 1][d[0]], list(d[:12]))
             break
     if np.float32(p).view(np.uint32) != pf[t].view(np.uint32):
         bad = "p differs at bit %d: %r vs reference %r" % (t, p, pf[t])
