@@ -37,6 +37,7 @@ enum {
   LC_FAM, LC_LANES, LC_DMC,
   LC_BRK,         // bytes whose Bracket distribution (after the byte) the context stage has written
   LC_LSTM,        // bytes whose LSTM distribution (after the byte) is in place (bumped behind the per-byte LSTM launch)
+  LC_KNOWN,       // steps whose inputs are in DEVICE memory: the bit before the step and the host stages' records of the step (the relay wave)
   LC_N = 16
 };
 #define CMX_LATE_P_RING 8
@@ -63,7 +64,16 @@ struct CmxLate {
   uint32_t* cnt;     // [LC_N][CMX_LATE_CNT_STRIDE]
   uint32_t base;     // (chunk number & 0xFFFF) << 16
   uint32_t pad;
+  const uint8_t* dbit0;   // DEVICE mirror of the bits: dbit0[t] = bit t of the chunk, dbit0[-1] = the bit before it (the relay wave fills it)
 };
+// ONE wavefront per stream talks to the host (the relay, wave 3 of cmx_bytemodel_late_kernel): it polls the box, copies every newly
+// published bit and the host records that came with it into uncached device memory, and counts the step (LC_KNOWN). Every stage kernel
+// waits on that device counter and reads device memory only: forty wavefronts polling host memory across PCIe -- and then fetching
+// their records across it line by line -- cost 140 us per bit (measured), most of it queueing.
+// kind 0: one row per step (row s, s < T); 1: one row per byte, written with the byte's first step (row s / 8 at s % 8 == 0, s < T);
+// 2: one row per COMPLETED byte (row s / 8 - 1 at s % 8 == 0, 8 <= s <= T). src: host-coherent memory; dst: its device mirror (same layout).
+typedef struct { const void* src; void* dst; uint32_t stride; int32_t kind; } cmx_late_relay_t;
+#define CMX_LATE_RELAY_MAX 24
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -89,13 +99,17 @@ __device__ __forceinline__ bool late_wait_ge(CmxLateBox* B, const uint32_t* p, u
     }
   }
 }
-// the bit before step t of the chunk (t == 0: the previous chunk's last), once it is known; -1: aborted
+// the bit before step t of the chunk (t == 0: the previous chunk's last), once the relay has brought it (and the step's records) over; -1: aborted
 __device__ __forceinline__ int late_y(const CmxLate& L, int t) {
-  CmxLateBox* const B = L.box;
-  if (t == 0) { if (!late_wait_ge(B, &B->start, 1u)) return -1; return (int)late_ld(&B->last_y); }
-  if (!late_wait_ge(B, &B->nknown, (uint32_t)t)) return -1;
+  if (!late_wait_ge(L.box, L.cnt + LC_KNOWN * CMX_LATE_CNT_STRIDE, L.base | (uint32_t)(t + 1))) return -1;
   asm volatile("" ::: "memory");
-  return (int)*(volatile const uint8_t*)(B->bit + (t - 1));
+  return (int)*(volatile const uint8_t*)(L.dbit0 + (t - 1));
+}
+// have the inputs of step t arrived? (for waits that are not followed by a bit read)
+__device__ __forceinline__ bool late_wait_step(const CmxLate& L, int t) {
+  const bool ok = late_wait_ge(L.box, L.cnt + LC_KNOWN * CMX_LATE_CNT_STRIDE, L.base | (uint32_t)(t + 1));
+  asm volatile("" ::: "memory");
+  return ok;
 }
 // publish: every store of this wavefront issued so far has reached the device's memory before the counter moves (call with one lane;
 // the others' stores are covered when the caller puts a wave / workgroup barrier with s_waitcnt vmcnt(0) in front)
@@ -107,6 +121,39 @@ __device__ __forceinline__ bool late_wait_cnt(const CmxLate& L, int which, uint3
   const bool ok = late_wait_ge(L.box, L.cnt + which * CMX_LATE_CNT_STRIDE, L.base | want);
   asm volatile("" ::: "memory");
   return ok;
+}
+// The relay (one wavefront): for s = 0 .. nbits -- wait until the host has published step s (s == 0: `start`; else nknown >= s), copy
+// bit s - 1 and the records of step s from host memory to their device mirrors, count the step. Loads from host memory are atomic loads
+// (performed where they stand, not cached); the stores end in uncached device memory.
+__device__ __forceinline__ void late_relay(const CmxLate& L, uint8_t* dbit0, const cmx_late_relay_t* ent, int nent, int nbits, int lane) {
+  CmxLateBox* const B = L.box;
+  for (int s = 0; s <= nbits; ++s) {
+    if (s == 0) { if (!late_wait_ge(B, &B->start, 1u)) return; }
+    else if (!late_wait_ge(B, &B->nknown, (uint32_t)s)) return;
+    asm volatile("" ::: "memory");
+    if (lane == 0) dbit0[s - 1] = s ? *(volatile const uint8_t*)(B->bit + (s - 1)) : (uint8_t)late_ld(&B->last_y);
+    for (int e = 0; e < nent; ++e) {
+      const int kind = ent[e].kind;
+      long r;
+      if (kind == 0) { if (s >= nbits) continue; r = s; }
+      else if (kind == 1) { if ((s & 7) || s >= nbits) continue; r = s >> 3; }
+      else { if ((s & 7) || s < 8) continue; r = (s >> 3) - 1; }
+      const size_t off = (size_t)r * ent[e].stride;
+      const unsigned n = ent[e].stride;
+      if (((off | n) & 3) == 0) {
+        const uint32_t* sp = reinterpret_cast<const uint32_t*>(static_cast<const char*>(ent[e].src) + off);
+        uint32_t* dp = reinterpret_cast<uint32_t*>(static_cast<char*>(ent[e].dst) + off);
+        for (unsigned i = lane; i < n / 4; i += 64) dp[i] = __hip_atomic_load(sp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      } else {
+        const uint16_t* sp = reinterpret_cast<const uint16_t*>(static_cast<const char*>(ent[e].src) + off);
+        uint16_t* dp = reinterpret_cast<uint16_t*>(static_cast<char*>(ent[e].dst) + off);
+        for (unsigned i = lane; i < n / 2; i += 64) dp[i] = __hip_atomic_load(sp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) late_st(L.cnt + LC_KNOWN * CMX_LATE_CNT_STRIDE, L.base | (uint32_t)(s + 1));
+  }
 }
 #endif
 

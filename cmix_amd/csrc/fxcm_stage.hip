@@ -697,7 +697,7 @@ struct cmx_fxcm {
   unsigned* d_rows = nullptr; size_t rows_cap = 0;
   hipStream_t s_up = nullptr; bool own_up = false;   // record uploads: a stream that never has a kernel in front of a copy (cmx_fxcm_set_upload_stream)
   hipEvent_t ev_up[FX_STAGE_BUFS] = {};
-  FxByteRec* late_recs[3] = {}; size_t late_cap[3] = {};   // the decoder's form (cmx_late.h): host-coherent records, three chunk slots
+  FxByteRec* late_recs[3] = {}; FxByteRec* late_drecs[3] = {}; size_t late_cap[3] = {};   // the decoder's form (cmx_late.h): host-coherent records and their device mirrors (the relay wave copies a byte's record over when the byte is complete), three chunk slots
 };
 
 extern "C" {
@@ -719,6 +719,7 @@ void cmx_fxcm_destroy(cmx_fxcm_t* h) {
   if (h->own_up && h->s_up) (void)hipStreamDestroy(h->s_up);
   if (h->d_rows) (void)hipFree(h->d_rows);
   for (FxByteRec* r : h->late_recs) cmx_late_free(r);
+  for (FxByteRec* r : h->late_drecs) cmx_late_free_dev(r);
   if (h->parser) fxp_destroy(h->parser);
   delete h;
 }
@@ -802,7 +803,8 @@ int cmx_fxcm_late_prepare(cmx_fxcm_t* h, size_t nbytes) {
     if (h->late_cap[slot] >= nbytes) continue;
     if (h->late_cap[slot]) { cmx_set_err("cmx_fxcm_late_prepare: the chunk size may not grow"); return 1; }
     h->late_recs[slot] = (FxByteRec*)cmx_late_alloc(nbytes * sizeof(FxByteRec));
-    if (!h->late_recs[slot]) { cmx_set_err("cmx_fxcm_late_prepare: record buffer allocation failed"); return 1; }
+    h->late_drecs[slot] = (FxByteRec*)cmx_late_alloc_dev(h->device, nbytes * sizeof(FxByteRec));
+    if (!h->late_recs[slot] || !h->late_drecs[slot]) { cmx_set_err("cmx_fxcm_late_prepare: record buffer allocation failed"); return 1; }
     h->late_cap[slot] = nbytes;
   }
   if (h->rows_cap < nbytes) {
@@ -821,11 +823,19 @@ int cmx_fxcm_run_late(cmx_fxcm_t* h, void* box, size_t nbytes, const int16_t* hi
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync((char*)h->d_xfer + 16, 0, sizeof(FxXfer) - 16, s) != hipSuccess) { cmx_set_err("cmx_fxcm_run_late: hipMemsetAsync failed"); return 1; }
   hipLaunchKernelGGL(cmx_fxcm_roles_late_kernel, dim3(FX_M_WGS + 2), dim3(FX_DEV_THREADS), FX_LDS_BYTES, s, h->d_dev, h->d_xfer, h->d_rows, *(const CmxLate*)box,
-                     (const FxByteRec*)h->late_recs[slot], hint_pr, hint_ex, d_probs + 3, (long)pstride, (int)nbytes);
+                     (const FxByteRec*)h->late_drecs[slot], hint_pr, hint_ex, d_probs + 3, (long)pstride, (int)nbytes);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { cmx_set_err(std::string("cmx_fxcm_run_late: ") + hipGetErrorString(e)); return 1; }
   h->bytes_done += nbytes;
   return 0;
+}
+static_assert(sizeof(FxByteRec) % 4 == 0, "the relay copies whole words");
+// what the stream's relay wave has to bring over for this stage (cmx_late.h): the parser's record of every completed byte
+int cmx_fxcm_late_relay(cmx_fxcm_t* h, int slot, void* out_, int max) {
+  if (!h || slot < 0 || slot > 2 || !h->late_cap[slot] || !out_ || max < 1) { cmx_set_err("cmx_fxcm_late_relay: bad argument (prepare first)"); return -1; }
+  cmx_late_relay_t* out = (cmx_late_relay_t*)out_;
+  out[0].src = h->late_recs[slot]; out[0].dst = h->late_drecs[slot]; out[0].stride = (uint32_t)sizeof(FxByteRec); out[0].kind = 2;
+  return 1;
 }
 // byte number b of the chunk in `slot` is complete: the parser's record of it
 int cmx_fxcm_late_byte(cmx_fxcm_t* h, int slot, size_t b, uint8_t byte) {

@@ -29,7 +29,7 @@ extern "C" __global__ void cmx_lstm_bpttblk(const LstmState);
 extern "C" __global__ void cmx_bytemodel_bits(const float*, const float*, const uint8_t*, size_t, float*, int*, size_t, int,
                                               float*);
 extern "C" __global__ void cmx_bytemodel_late_kernel(CmxLate, size_t, const float*, const float*, const float*, const float*, const float*, const uint32_t*, uint32_t,
-                                                     const uint32_t*, uint32_t, float*, size_t, int16_t*, uint8_t*);
+                                                     const uint32_t*, uint32_t, float*, size_t, int16_t*, uint8_t*, uint8_t*, const cmx_late_relay_t*, int);
 extern "C" __global__ void cmx_late_bump_kernel(uint32_t*, uint32_t, uint32_t*, uint32_t);
 
 void cmx_set_err(const std::string& s);  // cmx_api.hip
@@ -289,11 +289,14 @@ int cmx_bytemodel_bits_run(int device, const float* d_dist0, const float* d_dist
 // bits arrive through `box` -> layer-0 columns 0, 2076, 2077 and the fxcm stage's LSTM hints (see cmx_bytemodel_late_kernel).
 int cmx_bytemodel_late_run(int device, void* box, size_t nbytes, const float* brk0, const float* brk, const float* ppmd, const float* lstm0, const float* lstm,
                            const uint32_t* c0_brk, uint32_t c0_brk_want, const uint32_t* c0_lstm, uint32_t c0_lstm_want, float* layer0, size_t pstride,
-                           int16_t* hint_pr, uint8_t* hint_ex, void* stream) {
-  if (!box || !nbytes || !brk0 || !brk || !ppmd || !lstm0 || !lstm || !layer0 || !hint_pr || !hint_ex) { cmx_set_err("cmx_bytemodel_late_run: bad argument"); return 1; }
+                           int16_t* hint_pr, uint8_t* hint_ex, uint8_t* dbit0, const void* relay_dev, int nrelay, void* stream) {
+  if (!box || !nbytes || !brk0 || !brk || !ppmd || !lstm0 || !lstm || !layer0 || !hint_pr || !hint_ex || !dbit0 || nrelay < 0 || nrelay > CMX_LATE_RELAY_MAX || (nrelay && !relay_dev)) {
+    cmx_set_err("cmx_bytemodel_late_run: bad argument");
+    return 1;
+  }
   if (hipSetDevice(device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
-  hipLaunchKernelGGL(cmx_bytemodel_late_kernel, dim3(1), dim3(192), 0, (hipStream_t)stream, *(const CmxLate*)box, nbytes, brk0, brk, ppmd, lstm0, lstm, c0_brk, c0_brk_want,
-                     c0_lstm, c0_lstm_want, layer0, pstride, hint_pr, hint_ex);
+  hipLaunchKernelGGL(cmx_bytemodel_late_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *(const CmxLate*)box, nbytes, brk0, brk, ppmd, lstm0, lstm, c0_brk, c0_brk_want,
+                     c0_lstm, c0_lstm_want, layer0, pstride, hint_pr, hint_ex, dbit0, (const cmx_late_relay_t*)relay_dev, nrelay);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { cmx_set_err(std::string("cmx_bytemodel_late_run: ") + hipGetErrorString(e)); return 1; }
   return 0;

@@ -1048,7 +1048,7 @@ struct cmx_p8stage {
   bool failed = false;
   float ms_front = 0;   // host time of the last front-end pass
   // the decoder's form (cmx_late.h): three chunk slots of host-coherent records and rows
-  struct Late { size_t cap = 0; char* rec = nullptr; size_t o_fctx, o_fchk, o_cctx[P8_NCM2], o_cchk[P8_NCM2], o_ops, o_sel, o_apm, total; int16_t* x = nullptr; uint8_t* order = nullptr; P8Chunk c; } late[3];
+  struct Late { size_t cap = 0; char* rec = nullptr; char* d_rec = nullptr; size_t o_fctx, o_fchk, o_cctx[P8_NCM2], o_cchk[P8_NCM2], o_ops, o_sel, o_apm, total; int16_t* x = nullptr; uint8_t* order = nullptr; P8Chunk c; } late[3];   // rec: the front end's records (host-coherent), d_rec: their device mirror (the relay copies them over step by step), same layout
   double role_ms[7] = {0, 0, 0, 0, 0, 0, 0}; uint64_t role_chunks = 0;   // summed over the chunks collected so far
 };
 static void p8s_collect(cmx_p8stage* h, Staging& b) {   // the chunk that used b is complete
@@ -1082,7 +1082,7 @@ void cmx_p8stage_destroy(cmx_p8stage_t* h) {
     }
   }
   if (h->d_prx) (void)hipFree(h->d_prx);
-  for (auto& b : h->late) { cmx_late_free(b.rec); cmx_late_free_dev(b.x); cmx_late_free_dev(b.order); }
+  for (auto& b : h->late) { cmx_late_free(b.rec); cmx_late_free_dev(b.d_rec); cmx_late_free_dev(b.x); cmx_late_free_dev(b.order); }
   if (h->h_mixfail) (void)hipHostFree(h->h_mixfail);
   if (h->own_up && h->s_up) (void)hipStreamDestroy(h->s_up);
   for (hipEvent_t e : {h->ev_up, h->ev_ord, h->ev_a, h->ev_b, h->ev_c, h->ev_e, h->ev_f}) if (e) (void)hipEventDestroy(e);
@@ -1291,9 +1291,10 @@ int cmx_p8stage_late_prepare(cmx_p8stage_t* h, size_t nbytes) {
     b.o_ops = take(T * P8_NLANE * 4); b.o_sel = take(T * P8_NSEL * 4); b.o_apm = take(T * sizeof(P8ApmRec));
     b.total = o;
     b.rec = (char*)cmx_late_alloc(o);
+    b.d_rec = (char*)cmx_late_alloc_dev(h->device, o);
     b.x = (int16_t*)cmx_late_alloc_dev(h->device, T * P8_NX * 2);   // rows the role kernels hand to the mixer while all of them run
     b.order = (uint8_t*)cmx_late_alloc_dev(h->device, T);
-    if (!b.rec || !b.x || !b.order) { cmx_set_err("cmx_p8stage_late_prepare: buffer allocation failed"); h->failed = true; return 1; }
+    if (!b.rec || !b.d_rec || !b.x || !b.order) { cmx_set_err("cmx_p8stage_late_prepare: buffer allocation failed"); h->failed = true; return 1; }
     b.cap = n;
     b.c.fam_ctx = (uint32_t*)(b.rec + b.o_fctx); b.c.fam_chk = (uint16_t*)(b.rec + b.o_fchk);
     for (int k = 0; k < P8_NCM2; k++) { b.c.cm2_ctx[k] = (uint32_t*)(b.rec + b.o_cctx[k]); b.c.cm2_chk[k] = (uint16_t*)(b.rec + b.o_cchk[k]); }
@@ -1327,22 +1328,38 @@ int cmx_p8stage_run_late(cmx_p8stage_t* h, void* box_, size_t nbytes, float* d_o
     // every role on its own stream (all of them run at the same time, for the whole chunk)
     for (int k = 0; k < P8_NCM2; k++) {
       hipStream_t q = k == 0 ? h->s_d : k == 1 ? h->s_b : h->s_e;
-      hipLaunchKernelGGL(cmx_p8s_cm2v2_late_kernel, dim3(1), dim3(P8CM2_MAXC), 0, q, h->d_cm2[k], B, (int)(LC_CM2_0 + k), (const uint32_t*)b.c.cm2_ctx[k], (const uint16_t*)b.c.cm2_chk[k],
+      hipLaunchKernelGGL(cmx_p8s_cm2v2_late_kernel, dim3(1), dim3(P8CM2_MAXC), 0, q, h->d_cm2[k], B, (int)(LC_CM2_0 + k), (const uint32_t*)(b.d_rec + b.o_cctx[k]), (const uint16_t*)(b.d_rec + b.o_cchk[k]),
                          b.x, k == 0 ? b.order : (uint8_t*)nullptr, nbits, skip);
     }
-    hipLaunchKernelGGL(cmx_p8s_fam2_late_kernel, dim3(1), dim3(P8FAM_THREADS), h->fam_lds, h->s_a, h->d_fam, h->d_fam_home, B, (const uint32_t*)b.c.fam_ctx, (const uint16_t*)b.c.fam_chk,
+    // (every record pointer below is the DEVICE mirror: the relay wave fills it step by step, cmx_p8stage_late_relay)
+    hipLaunchKernelGGL(cmx_p8s_fam2_late_kernel, dim3(1), dim3(P8FAM_THREADS), h->fam_lds, h->s_a, h->d_fam, h->d_fam_home, B, (const uint32_t*)(b.d_rec + b.o_fctx), (const uint16_t*)(b.d_rec + b.o_fchk),
                        b.x, (const uint8_t*)b.order, nbits, skip);
-    hipLaunchKernelGGL(cmx_p8s_lanes_late_kernel, dim3(1), dim3(P8LANES_THREADS), 0, h->s_c, h->d_lanes, B, (const uint32_t*)b.c.ops, (const uint8_t*)b.order, b.x, nbits, t0);
+    hipLaunchKernelGGL(cmx_p8s_lanes_late_kernel, dim3(1), dim3(P8LANES_THREADS), 0, h->s_c, h->d_lanes, B, (const uint32_t*)(b.d_rec + b.o_ops), (const uint8_t*)b.order, b.x, nbits, t0);
     hipLaunchKernelGGL(cmx_p8s_dmc_late_kernel, dim3(1), dim3(P8DMC_THREADS), 0, h->s_f, h->d_dmc, B, b.x, (int)L.dmc_off, nbits, t0);
     ++h->mix_epoch;
-    hipLaunchKernelGGL(cmx_p8s_mix4_late_kernel, dim3(4), dim3(MX_THREADS), 0, h->s_m, (const P8MixDev*)h->d_mix, h->d_tail, B, (const int16_t*)b.x, (const int32_t*)b.c.sel,
-                       (const P8ApmRec*)b.c.apm, (const uint8_t*)b.order, d_out, ld, nbits, t0, skip, h->d_prx, h->mix_epoch, h->h_mixfail);
+    hipLaunchKernelGGL(cmx_p8s_mix4_late_kernel, dim3(4), dim3(MX_THREADS), 0, h->s_m, (const P8MixDev*)h->d_mix, h->d_tail, B, (const int16_t*)b.x, (const int32_t*)(b.d_rec + b.o_sel),
+                       (const P8ApmRec*)(b.d_rec + b.o_apm), (const uint8_t*)b.order, d_out, ld, nbits, t0, skip, h->d_prx, h->mix_epoch, h->h_mixfail);
     ok = hipGetLastError() == hipSuccess;
   }
   if (!ok) { cmx_set_err(std::string("cmx_p8stage_run_late: launch failed: ") + hipGetErrorString(hipGetLastError())); h->failed = true; return 1; }
   h->chunks++;
   h->steps += T;
   return 0;
+}
+// What the stream's relay wave has to bring over for this stage (cmx_late.h): every record array of the chunk slot -- host source, device
+// mirror, bytes per row, when a row is written. Returns the number of entries (<= max), -1 on error.
+int cmx_p8stage_late_relay(cmx_p8stage_t* h, int slot, void* out_, int max) {
+  if (!h || slot < 0 || slot > 2 || !h->late[slot].cap || !out_) { cmx_set_err("cmx_p8stage_late_relay: bad argument (prepare first)"); return -1; }
+  cmx_late_relay_t* out = (cmx_late_relay_t*)out_;
+  const cmx_p8stage::Late& b = h->late[slot];
+  const P8Layout& L = h->L;
+  int n = 0;
+  auto add = [&](size_t off, size_t stride, int kind) { if (n < max) { out[n].src = b.rec + off; out[n].dst = b.d_rec + off; out[n].stride = (uint32_t)stride; out[n].kind = kind; } ++n; };
+  add(b.o_ops, P8_NLANE * 4, 0); add(b.o_sel, P8_NSEL * 4, 0); add(b.o_apm, sizeof(P8ApmRec), 0);
+  add(b.o_fctx, (size_t)L.fam_slots * 4, 1); add(b.o_fchk, (size_t)L.fam_slots * 2, 1);
+  for (int k = 0; k < P8_NCM2; k++) { add(b.o_cctx[k], (size_t)L.cm2_count[k] * 4, 1); add(b.o_cchk[k], (size_t)L.cm2_count[k] * 2, 1); }
+  if (n > max) { cmx_set_err("cmx_p8stage_late_relay: table too small"); return -1; }
+  return n;
 }
 // the host half of the decoder's form: the records of chunk-local step `step` of the chunk in `slot` (every bit before that step has
 // been handed to cmx_p8stage_late_bit), then the bit that was decoded with them

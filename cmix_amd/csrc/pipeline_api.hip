@@ -116,6 +116,9 @@ struct LateSet {
   CmxLateBox* box = nullptr;
   float* ppmd = nullptr;         // [n + 1][256]  PPMd's distributions; row 0 = going into the chunk
   uint8_t* bytes = nullptr;      // [n]
+  float* d_ppmd = nullptr;       // device mirror of ppmd (the relay wave copies row b over with byte b's first step)
+  uint8_t* d_bits = nullptr;     // device mirror of the bits: [8] prefix (byte 7 = the bit before the chunk), then [8 n]
+  cmx_late_relay_t* d_relay = nullptr; int nrelay = 0;   // what the relay wave copies, per step / per byte (device copy of the table)
   // uncached device memory: what one stage kernel writes and another reads while both run
   uint32_t* cnt = nullptr;       // [LC_N][CMX_LATE_CNT_STRIDE] row counters (base | rows, never cleared)
   float* layer0 = nullptr;       // [8 n][2078]
@@ -233,6 +236,7 @@ void cmx_pipeline_destroy(cmx_pipeline_t* h) {
     (void)hipDeviceSynchronize();
     for (LateSet& q : h->late->set) {
       cmx_late_free(q.box); cmx_late_free(q.ppmd); cmx_late_free(q.bytes);
+      cmx_late_free_dev(q.d_ppmd); cmx_late_free_dev(q.d_bits); cmx_late_free_dev(q.d_relay);
       cmx_late_free_dev(q.cnt); cmx_late_free_dev(q.layer0); cmx_late_free_dev(q.sel); cmx_late_free_dev(q.brk); cmx_late_free_dev(q.lstm);
       cmx_late_free_dev(q.hint_pr); cmx_late_free_dev(q.hint_ex);
     }
@@ -735,7 +739,7 @@ static int late_launch(cmx_pipeline* h, uint64_t c) {
   memset(B, 0, sizeof(CmxLateBox));
   B->nbits = (uint32_t)(8 * n);
   __sync_synchronize();
-  q.lt.box = B; q.lt.cnt = q.cnt; q.lt.base = (uint32_t)(c & 0xFFFFu) << 16; q.lt.pad = 0;   // the counters are never cleared: a value of the chunk three back is below this base
+  q.lt.box = B; q.lt.cnt = q.cnt; q.lt.base = (uint32_t)(c & 0xFFFFu) << 16; q.lt.pad = 0; q.lt.dbit0 = q.d_bits + 8;   // the counters are never cleared: a value of the chunk three back is below this base
   void* const LT = &q.lt;
   const float* brk0 = nullptr;
   if (cmx_ctxmodels_run_late(h->ctx, LT, n, q.layer0, CMX_N_INPUTS, q.sel, q.brk, &brk0, h->s_ctx)) return 1;
@@ -747,8 +751,8 @@ static int late_launch(cmx_pipeline* h, uint64_t c) {
     lstm0 = pq.lstm + (n - 1) * 256; c0_lstm = pq.cnt + LC_LSTM * CMX_LATE_CNT_STRIDE;
   }
   const uint32_t pwant = pq_want(c, n);
-  if (cmx_bytemodel_late_run(h->device, LT, n, brk0, q.brk, q.ppmd, lstm0, q.lstm, c0_brk, pwant, c0_lstm, pwant, q.layer0, CMX_N_INPUTS, q.hint_pr, q.hint_ex,
-                             L->s_bm)) return 1;
+  if (cmx_bytemodel_late_run(h->device, LT, n, brk0, q.brk, q.d_ppmd, lstm0, q.lstm, c0_brk, pwant, c0_lstm, pwant, q.layer0, CMX_N_INPUTS, q.hint_pr, q.hint_ex,
+                             q.d_bits + 8, q.d_relay, q.nrelay, L->s_bm)) return 1;
   if (cmx_fxcm_run_late(h->fxcm, LT, n, q.hint_pr, q.hint_ex, q.layer0, CMX_N_INPUTS, s, h->s_fx)) return 1;
   if (cmx_p8stage_run_late(h->p8, LT, n, q.layer0 + 434, CMX_N_INPUTS, s)) return 1;
   if (cmx_mixnet_run_late(h->mix, LT, q.layer0, q.sel, 8 * n, h->s_mix)) return 1;
@@ -774,6 +778,10 @@ int cmx_pipeline_late_start(cmx_pipeline_t* h, int last_bit) {
     q.ppmd = (float*)cmx_late_alloc((n + 1) * 256 * 4);
     q.bytes = (uint8_t*)cmx_late_alloc(n);
     q.cnt = (uint32_t*)cmx_late_alloc_dev(h->device, LC_N * CMX_LATE_CNT_STRIDE * 4);
+    q.d_ppmd = (float*)cmx_late_alloc_dev(h->device, (n + 1) * 256 * 4);
+    q.d_bits = (uint8_t*)cmx_late_alloc_dev(h->device, T + 16);
+    q.d_relay = (cmx_late_relay_t*)cmx_late_alloc_dev(h->device, CMX_LATE_RELAY_MAX * sizeof(cmx_late_relay_t));
+    ok = ok && q.d_ppmd && q.d_bits && q.d_relay;
     q.layer0 = (float*)cmx_late_alloc_dev(h->device, T * CMX_N_INPUTS * 4);
     q.sel = (uint32_t*)cmx_late_alloc_dev(h->device, T * CMX_N_MIXERS * 4);
     q.brk = (float*)cmx_late_alloc_dev(h->device, n * 256 * 4);
@@ -786,6 +794,17 @@ int cmx_pipeline_late_start(cmx_pipeline_t* h, int last_bit) {
   // every stage allocates what it needs NOW: once the first chunk's kernels run they wait for this thread, and an allocation that maps
   // memory into the device may wait for them
   if (cmx_fxcm_late_prepare(h->fxcm, n) || cmx_p8stage_late_prepare(h->p8, n) || cmx_mixnet_late_prepare(h->mix, T)) { L->failed = true; return 1; }
+  for (int s = 0; s < 3; ++s) {   // the relay wave's table of each buffer set: the stages' record arrays + PPMd's distributions
+    LateSet& q = L->set[s];
+    cmx_late_relay_t tab[CMX_LATE_RELAY_MAX];
+    int k = cmx_p8stage_late_relay(h->p8, s, tab, CMX_LATE_RELAY_MAX - 2);
+    const int kf = k < 0 ? -1 : cmx_fxcm_late_relay(h->fxcm, s, tab + k, 1);
+    if (k < 0 || kf < 0) { L->failed = true; return 1; }
+    k += kf;
+    tab[k].src = q.ppmd; tab[k].dst = q.d_ppmd; tab[k].stride = 1024; tab[k].kind = 1; ++k;
+    q.nrelay = k;
+    if (hipMemcpy(q.d_relay, tab, (size_t)k * sizeof(cmx_late_relay_t), hipMemcpyHostToDevice) != hipSuccess) { cmx_set_err("cmx_pipeline_late_start: table upload failed"); L->failed = true; return 1; }
+  }
   if (hipDeviceSynchronize() != hipSuccess) { cmx_set_err("cmx_pipeline_late_start: device error"); L->failed = true; return 1; }
   L->lstm0 = cmx_lstm_byte_probs(h->lstm);
   L->mix_chunk0 = cmx_mixnet_runs(h->mix);
@@ -834,11 +853,11 @@ float cmx_pipeline_late_predict(cmx_pipeline_t* h) {
       else if (el > 60000.0) why = "no prediction from the device for 60 s";
       if (why) {
         std::string st = " [box: nknown " + std::to_string(q.box->nknown) + " start " + std::to_string(q.box->start) + " rows";
-        static const char* const nm[] = {"ctx", "bm0", "bm1", "bm2", "fx", "p8", "cm2a", "cm2b", "cm2c", "fam", "lanes", "dmc", "brk", "lstm"};
+        static const char* const nm[] = {"ctx", "bm0", "bm1", "bm2", "fx", "p8", "cm2a", "cm2b", "cm2c", "fam", "lanes", "dmc", "brk", "lstm", "known"};
         uint32_t cv[LC_N * CMX_LATE_CNT_STRIDE] = {0};
         for (LateSet& z : L->set) if (z.box) z.box->abort = 1;   // the kernels leave, the copy below can run
         if (hipMemcpy(cv, q.cnt, sizeof cv, hipMemcpyDeviceToHost) == hipSuccess)
-          for (int i = 0; i < 14; ++i) st += std::string(" ") + nm[i] + "=" + std::to_string(cv[i * CMX_LATE_CNT_STRIDE] & 0xFFFFu);
+          for (int i = 0; i < 15; ++i) st += std::string(" ") + nm[i] + "=" + std::to_string(cv[i * CMX_LATE_CNT_STRIDE] & 0xFFFFu);
         st += "]";
         cmx_set_err(std::string("cmx_pipeline_late_predict: ") + why + " at bit " + std::to_string(L->bits) + " (bit " + std::to_string(L->t) + " of its chunk)" + st);
         L->failed = true;

@@ -474,7 +474,10 @@ int cmx_ctxmodels_run_late(cmx_ctxmodels_t*, void* box, size_t nbytes, float* pr
                            const float** brk_dist0_out, void* stream);
 int cmx_bytemodel_late_run(int device, void* box, size_t nbytes, const float* brk0, const float* brk, const float* ppmd, const float* lstm0, const float* lstm,
                            const uint32_t* c0_brk, uint32_t c0_brk_want, const uint32_t* c0_lstm, uint32_t c0_lstm_want, float* layer0, size_t pstride,
-                           int16_t* hint_pr, uint8_t* hint_ex, void* stream);
+                           int16_t* hint_pr, uint8_t* hint_ex, uint8_t* dbit0, const void* relay_dev, int nrelay, void* stream);
+/* what a stage's records need from the stream's relay wave (an array of cmx_late_relay_t, cmx_late.h); returns the number of entries, -1 on error */
+int cmx_p8stage_late_relay(cmx_p8stage_t*, int slot, void* out, int max);
+int cmx_fxcm_late_relay(cmx_fxcm_t*, int slot, void* out, int max);
 const float* cmx_lstm_byte_probs(cmx_lstm_t*);
 /* _late_prepare: everything a stage allocates for chunks of that size, BEFORE the stream's first kernels are launched (an allocation
  * that maps memory into the device can wait for running kernels -- which, here, wait for the host) */

@@ -60,14 +60,12 @@ for t in range(len(bits)):
             if len(d):
                 bad = "selector %d differs at bit %d: %r vs reference %r (%d differ)" % (d[0], t, sel[d[0]], ref_sel[t][d[0]], len(d))
                 break
-    mix = pipe.late_mix() if ref_mix is not None and t > 0 else None   # (of bit t - 1: the waves write them when they learn)
-    if mix is not None:
-        d = np.nonzero(~bits_equal(mix, ref_mix[t - 1]))[0]
-        if len(d):
-            bad = "Mixer::Mix value of mixer %d differs at bit %d: %r vs reference %r (mixers that differ: %s)" % (d[0], t - 1, mix[d[0]], ref_mix[t - 1][d[0]], list(d[:12]))
-            break
     if np.float32(p).view(np.uint32) != pf[t].view(np.uint32):
         bad = "p differs at bit %d: %r vs reference %r" % (t, p, pf[t])
+        mix = pipe.late_mix() if ref_mix is not None and t > 0 else None   # diagnostic (of bit t - 1: the waves write them when they learn; read while they run)
+        if mix is not None:
+            d = np.nonzero(~bits_equal(mix, ref_mix[t - 1]))[0]
+            bad += "; Mixer::Mix values of bit %d that differ from the reference's: mixers %s" % (t - 1, list(d[:16]))
         break
     pipe.late_perceive(int(bits[t]))
 ms, n = pipe.late_host_ms()
