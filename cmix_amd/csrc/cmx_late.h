@@ -49,7 +49,9 @@ struct CmxLateBox {   // HOST-coherent pinned memory: what the decoder thread an
   uint32_t abort;    // host -> device: leave
   uint32_t fail;     // device -> host, sticky: a wait ran out of time
   uint32_t nbits;    // bits of this chunk (information only)
-  uint32_t pad0[10];
+  uint32_t pad0[2];
+  unsigned long long kb;   // host -> device, ONE 8-byte store: (bit t << 32) | (t + 1) -- what nknown and bit[t] say, in one PCIe read for the relay
+  uint32_t pad1[6];
   unsigned long long p_word[CMX_LATE_P_RING];           // device -> host: ((t + 1) << 32) | bits of p(t), slot t % ring -- ONE self-validating word
   uint8_t bit[8];    // [nbits] follows (allocated behind the struct)
 };
@@ -116,7 +118,10 @@ __device__ __forceinline__ bool late_wait_step(const CmxLate& L, int t) {
 __device__ __forceinline__ void late_publish(const CmxLate& L, int which, uint32_t v) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   late_st(L.cnt + which * CMX_LATE_CNT_STRIDE, L.base | v);
+  L.cnt[which * CMX_LATE_CNT_STRIDE + 1] = (uint32_t)wall_clock64();   // diagnostics: when (100 MHz clock), cmx_pipeline_late_debug_times
 }
+// diagnostics: a time stamp of the mixing network's progress on the current bit (slots 1.. of the spare counter line 15)
+__device__ __forceinline__ void late_stamp(const CmxLate& L, int slot) { L.cnt[15 * CMX_LATE_CNT_STRIDE + slot] = (uint32_t)wall_clock64(); }
 __device__ __forceinline__ bool late_wait_cnt(const CmxLate& L, int which, uint32_t want) {
   const bool ok = late_wait_ge(L.box, L.cnt + which * CMX_LATE_CNT_STRIDE, L.base | want);
   asm volatile("" ::: "memory");
@@ -125,14 +130,42 @@ __device__ __forceinline__ bool late_wait_cnt(const CmxLate& L, int which, uint3
 // The relay (one wavefront): for s = 0 .. nbits -- wait until the host has published step s (s == 0: `start`; else nknown >= s), copy
 // bit s - 1 and the records of step s from host memory to their device mirrors, count the step. Loads from host memory are atomic loads
 // (performed where they stand, not cached); the stores end in uncached device memory.
-__device__ __forceinline__ void late_relay(const CmxLate& L, uint8_t* dbit0, const cmx_late_relay_t* ent, int nent, int nbits, int lane) {
+// rw / nrw: this wavefront's number among the relay's wavefronts (the entries are dealt out round robin: a copy is one PCIe round trip, and
+// the round trips of different wavefronts overlap); done: LDS word the relay's wavefronts count their finished steps in (rw 0 publishes)
+// (only wavefront 0 polls the host; the others follow its LDS word `seen` = steps the host has published, 0xFFFFFFFF = leave)
+__device__ __forceinline__ void late_relay(const CmxLate& L, uint8_t* dbit0, const cmx_late_relay_t* ent, int nent, int nbits, int lane, int rw, int nrw, unsigned* done, unsigned* seen) {
   CmxLateBox* const B = L.box;
   for (int s = 0; s <= nbits; ++s) {
-    if (s == 0) { if (!late_wait_ge(B, &B->start, 1u)) return; }
-    else if (!late_wait_ge(B, &B->nknown, (uint32_t)s)) return;
+    int ybit = -1;   // wavefront 0: the bit before step s when it came with the count (-1: read it from the array)
+    if (rw == 0) {
+      bool ok;
+      if (s == 0) ok = late_wait_ge(B, &B->start, 1u);
+      else {   // poll the 8-byte word: count and bit in one read
+        unsigned spins = 0;
+        unsigned long long t0 = 0, v;
+        ok = true;
+        while ((uint32_t)(v = __hip_atomic_load(&B->kb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) < (uint32_t)s) {
+          __builtin_amdgcn_s_sleep(1);
+          if ((++spins & 255u) == 0) {
+            if (late_ld(&B->abort) || late_ld(&B->fail)) { ok = false; break; }
+            const unsigned long long now = wall_clock64();
+            if (!t0) t0 = now;
+            else if (now - t0 > CMX_LATE_TIMEOUT_TICKS) { late_st(&B->fail, 1u); ok = false; break; }
+          }
+        }
+        if (ok && (uint32_t)v == (uint32_t)s) ybit = (int)(v >> 32) & 1;
+      }
+      if (lane == 0) __hip_atomic_store(seen, ok ? (unsigned)(s + 1) : 0xFFFFFFFFu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (!ok) return;
+    } else {
+      unsigned v;
+      while ((v = __hip_atomic_load(seen, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < (unsigned)(s + 1)) __builtin_amdgcn_s_sleep(1);
+      if (v == 0xFFFFFFFFu) return;
+    }
     asm volatile("" ::: "memory");
-    if (lane == 0) dbit0[s - 1] = s ? *(volatile const uint8_t*)(B->bit + (s - 1)) : (uint8_t)late_ld(&B->last_y);
-    for (int e = 0; e < nent; ++e) {
+    if (rw == 0 && lane == 0) dbit0[s - 1] = s == 0 ? (uint8_t)late_ld(&B->last_y) : ybit >= 0 ? (uint8_t)ybit : *(volatile const uint8_t*)(B->bit + (s - 1));
+    // wavefront 0 only watches the host and publishes; the copies are the others' (nrw > 1)
+    for (int e = (nrw > 1 ? rw - 1 : 0); e >= 0 && e < nent; e += (nrw > 1 ? nrw - 1 : 1)) {
       const int kind = ent[e].kind;
       long r;
       if (kind == 0) { if (s >= nbits) continue; r = s; }
@@ -152,7 +185,16 @@ __device__ __forceinline__ void late_relay(const CmxLate& L, uint8_t* dbit0, con
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) late_st(L.cnt + LC_KNOWN * CMX_LATE_CNT_STRIDE, L.base | (uint32_t)(s + 1));
+    if (rw != 0) { if (lane == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); continue; }
+    if (lane == 0) {
+      // the other wavefronts' copies of this step have landed: `done` counts (step, wavefront) pairs
+      unsigned spins = 0;
+      while (__hip_atomic_load(done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)(s + 1) * (unsigned)(nrw - 1))
+        if ((++spins & 1023u) == 0 && (late_ld(&B->abort) || late_ld(&B->fail))) break;
+      late_st(L.cnt + LC_KNOWN * CMX_LATE_CNT_STRIDE, L.base | (uint32_t)(s + 1));
+      L.cnt[LC_KNOWN * CMX_LATE_CNT_STRIDE + 1] = (uint32_t)wall_clock64();
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 #endif

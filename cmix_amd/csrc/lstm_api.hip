@@ -218,7 +218,7 @@ int cmx_lstm_run(cmx_lstm_t* h, const float* d_in_probs, const uint8_t* d_bytes,
   hipStream_t st = (hipStream_t)stream;
   const LstmState& S = h->h_state;
   const int V = S.V;
-  (void)hipMemcpyAsync(h->d_prev_probs, S.byte_probs, 256 * 4, hipMemcpyDeviceToDevice, st);
+  if (d_bit_p) (void)hipMemcpyAsync(h->d_prev_probs, S.byte_probs, 256 * 4, hipMemcpyDeviceToDevice, st);   // (the distribution going into the run: only ByteModel's bit predictions below read it)
   if (!d_in_probs) { cmx_set_err("cmx_lstm_run: d_in_probs is required"); return 1; }
   auto sync_reset = [&]() {
     return hipMemsetAsync((char*)S.sync + 16, 0, sizeof(LstmSync) - 16, st) == hipSuccess;
@@ -295,7 +295,7 @@ int cmx_bytemodel_late_run(int device, void* box, size_t nbytes, const float* br
     return 1;
   }
   if (hipSetDevice(device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return 1; }
-  hipLaunchKernelGGL(cmx_bytemodel_late_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *(const CmxLate*)box, nbytes, brk0, brk, ppmd, lstm0, lstm, c0_brk, c0_brk_want,
+  hipLaunchKernelGGL(cmx_bytemodel_late_kernel, dim3(1), dim3(192 + 64 * 6), 0, (hipStream_t)stream, *(const CmxLate*)box, nbytes, brk0, brk, ppmd, lstm0, lstm, c0_brk, c0_brk_want,
                      c0_lstm, c0_lstm_want, layer0, pstride, hint_pr, hint_ex, dbit0, (const cmx_late_relay_t*)relay_dev, nrelay);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { cmx_set_err(std::string("cmx_bytemodel_late_run: ") + hipGetErrorString(e)); return 1; }

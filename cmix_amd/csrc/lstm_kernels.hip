@@ -177,15 +177,19 @@ extern "C" __global__ void cmx_bytemodel_bits(const float* dist0, const float* d
 //      hint[r - 2] is there). A distribution after byte n - 1 is awaited on its producer's counter (Bracket: LC_BRK of the context
 //      kernel; LSTM: LC_LSTM, bumped behind the byte's LSTM launch; PPMd: a host record, in place once the byte's last bit is
 //      published); the one going into the chunk on the previous chunk's counters (c0_*: may be null).
-//      Wave 3 is the stream's RELAY (cmx_late.h): the one wavefront that talks to the host -- it brings every published bit and the host
+//      Waves 3.. are the stream's RELAY (cmx_late.h): the one wavefront that talks to the host -- it brings every published bit and the host
 //      stages' records of the step over into device memory and counts the step (LC_KNOWN), which is what every kernel waits on.
-extern "C" __global__ void __launch_bounds__(256)
+#define CMX_RELAY_WAVES 6
+extern "C" __global__ void __launch_bounds__(192 + 64 * CMX_RELAY_WAVES)
 cmx_bytemodel_late_kernel(CmxLate B, size_t nbytes, const float* brk0, const float* brk, const float* ppmd, const float* lstm0,
                           const float* lstm, const uint32_t* c0_brk, uint32_t c0_brk_want, const uint32_t* c0_lstm, uint32_t c0_lstm_want,
                           float* layer0, size_t pstride, int16_t* hint_pr, uint8_t* hint_ex, uint8_t* dbit0, const cmx_late_relay_t* relay, int nrelay) {
   __shared__ float prs[3][256];
+  __shared__ unsigned relay_done, relay_seen;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (w == 3) { late_relay(B, dbit0, relay, nrelay, (int)(8 * nbytes), lane); return; }
+  if (threadIdx.x == 0) { relay_done = 0; relay_seen = 0; }
+  __syncthreads();
+  if (w >= 3) { late_relay(B, dbit0, relay, nrelay, (int)(8 * nbytes), lane, w - 3, CMX_RELAY_WAVES, &relay_done, &relay_seen); return; }
   float* const pr = prs[w];
   const int col = w == 0 ? 0 : w == 1 ? 2076 : 2077;
   const int which = w == 0 ? LC_BM0 : w == 1 ? LC_BM1 : LC_BM2;

@@ -1154,6 +1154,7 @@ __device__ void tail_b_role(MixState* S, const Lds& L, const float* decay1, int 
     }
     if (!wait_ge(L.ctl, &L.ctl->b_in, t + 1, false)) return;
     TPROF(0);
+    if (L.late.box && lane == 0) late_stamp(L.late, 4);   // layer 1 done
     const float* const in2 = L.h2 + 64 * (t & 1);
     int bit = __float_as_int(in2[49]);
     {  // layer 2 has one weight set in cmix (selector = zero_context_); a changing key is still honoured
@@ -1220,6 +1221,7 @@ __device__ void tail_b_role(MixState* S, const Lds& L, const float* decay1, int 
         // decoder turns it into the bit, which comes back through the box and is handed to the waves that learn from it
         __hip_atomic_store(&L.late.box->p_word[t % CMX_LATE_P_RING], ((unsigned long long)(unsigned)(t + 1) << 32) | (unsigned)__float_as_int(pf), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_SYSTEM);
+        late_stamp(L.late, 1);   // p has gone out
         bit = late_y(L.late, t + 1);
         if (bit < 0) { lds_publish_store(&L.ctl->abort, 1); bit = 0; }
         L.bitring[t & 7] = bit;
@@ -1513,6 +1515,7 @@ __device__ void stretch_role(MixState* S, const Lds& L, SpecXfer* X, const float
       bool ok = true;
       if (lane <= LC_P8) ok = late_wait_cnt(L.late, lane, (uint32_t)(t + 1));
       if (__ballot(!ok)) { lds_publish_store(&L.ctl->abort, 1); return; }
+      if (lane == 0) late_stamp(L.late, 2);   // row t complete
     }
     float pv[33];
     if (L.late.box) {
@@ -1575,14 +1578,31 @@ __device__ void select_role(MixState* S, const Lds& L, SpecXfer* X, const uint32
   const gptr<const uint32_t> gsel = as_global(sel);
   for (int t = 0; t < nbits; ++t) {
     uint32_t key = (!L.late.box && lane < CMX_MIXERS) ? gsel[(size_t)t * CMX_MIXERS + lane] : 0;
-    if (!wait_ge(L.ctl, &L.sdone[t % L.rr], t + 1, true)) return;
-    // a decoder: the row's selectors exist only now -- and `sel` is a const __restrict__ kernel argument (see stretch_role): an atomic
-    // load, which the compiler cannot merge with an earlier one or hoist
-    if (L.late.box && lane < CMX_MIXERS) key = __hip_atomic_load(sel + (size_t)t * CMX_MIXERS + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     BitRec* rec = L.rec + (t % L.rr);
     const BitRec* prev = L.rec + ((t + L.rr - 1) % L.rr);
+    if (L.late.box) {
+      // A decoder: the context stage counts row t (LC_CTX) ~13 us before the slowest producer does, and 46 of the 47 selections need
+      // nothing else -- they are done while the stretch wave still waits for the row; only the auxiliary-context mixer (its key comes out
+      // of three of the inputs) follows the stretch wave. `sel` is a const __restrict__ kernel argument (see stretch_role): atomic loads.
+      if (t >= L.rr && !wait_ge(L.ctl, &L.ctl->tail_done, t - L.rr + 1, true)) return;   // rec slot t % rr is free (as the stretch wave checks)
+      bool ok = true;
+      if (lane == 0) ok = late_wait_cnt(L.late, LC_CTX, (uint32_t)(t + 1));
+      if (__ballot(!ok)) { lds_publish_store(&L.ctl->abort, 1); return; }
+      if (lane < CMX_MIXERS && lane != CMX_AUX) {
+        key = __hip_atomic_load(sel + (size_t)t * CMX_MIXERS + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t r = select_row(S, lane, key);
+        rec->rowidx[lane] = r;
+        const uint32_t chg = (t == 0) || (r != prev->rowidx[lane]);
+        if (lane < CMX_MIX0) {
+          rec->changed[lane] = chg;
+          __hip_atomic_store(&X->rowidx[t % CMX_SPEC_RING][lane], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&X->changed[t % CMX_SPEC_RING][lane], chg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+    if (!wait_ge(L.ctl, &L.sdone[t % L.rr], t + 1, true)) return;
     if (lane == CMX_AUX) key = rec->auxkey;
-    if (lane < CMX_MIXERS) {
+    if (lane < CMX_MIXERS && (!L.late.box || lane == CMX_AUX)) {
       uint32_t r = select_row(S, lane, key);
       rec->rowidx[lane] = r;
       const uint32_t chg = (t == 0) || (r != prev->rowidx[lane]);
@@ -1596,6 +1616,7 @@ __device__ void select_role(MixState* S, const Lds& L, SpecXfer* X, const uint32
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) __hip_atomic_store(&X->scout_epoch, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     st_rel(&L.ctl->scout_epoch, t + 1);
+    if (L.late.box && lane == 0) late_stamp(L.late, 5);   // inputs and rows published to the helpers
   }
 }
 
@@ -1693,6 +1714,7 @@ __device__ void gather_role(MixState* S, const Lds& L, SpecXfer* X, const float*
       }
     }
     GPROF(2);
+    if (L.late.box && lane == 0) late_stamp(L.late, 3);   // the 26 sums are there
     float e = 0.0f;
 #pragma unroll
     for (int j = 0; j < CMX_MIX0; ++j) {      // intra-layer chain (predictor.cpp:395-400), see chain_role

@@ -311,13 +311,20 @@ __global__ __launch_bounds__(P8LANES_THREADS) void cmx_p8s_lanes_late_kernel(P8L
   const bool act = l < P8_NLANE;
   P8LaneRegs r = d->regs[act ? l : 0];
   for (int t = 0; t < nbits; t++) {
-    if (threadIdx.x == 0) { int y = late_y(B, t); if (y >= 0 && !late_wait_cnt(B, LC_CM2_0, (uint32_t)(t + 1))) y = -1; late_y_s = y; }   // the step's `order` is the order-N map's of the same step
+    if (threadIdx.x == 0) late_y_s = late_y(B, t);
     __syncthreads();
     const int y = late_y_s;
     if (y < 0) return;
     __syncthreads();
-    if (t >= t0 && act && l < d->nlanes)
-      p8s_lane_step(d, &r, l, *(volatile const uint32_t*)(ops + (size_t)t * P8_NLANE + l), y, (int)*(volatile const uint8_t*)(order + t), x + (size_t)t * P8_NX);
+    if (t >= t0 && act && l < d->nlanes) {
+      const uint32_t op = *(volatile const uint32_t*)(ops + (size_t)t * P8_NLANE + l);
+      int ord = 0;
+      if ((op & P8OP_SET) && (op & P8OP_ORDER)) {   // the one kind of op that reads the order-N map's value of the SAME step: only that lane waits for its kernel
+        if (!late_wait_cnt(B, LC_CM2_0, (uint32_t)(t + 1))) ord = 0;
+        else ord = (int)*(volatile const uint8_t*)(order + t);
+      }
+      p8s_lane_step(d, &r, l, op, y, ord, x + (size_t)t * P8_NX);
+    }
     __syncthreads();
     if (threadIdx.x == 0) late_publish(B, LC_LANES, (uint32_t)(t + 1));
   }
@@ -781,10 +788,14 @@ __device__ __forceinline__ void mx4_late_body(const P8MixDev* M, P8TailDev* T, C
   for (int t = t0; t < nbits; ++t) {
     const int nx = t < first ? nx_first : P8_NX;
     // ---- the bit before the step (with it: the step's host records), the six producers' rows ----
-    if (tid == 0) {
-      int y = late_y(B, t);
-      for (int c = LC_CM2_0; y >= 0 && c <= LC_DMC; ++c) if (!late_wait_cnt(B, c, (uint32_t)(t + 1))) y = -1;
-      late_y_s = y;
+    if (wave == 0) {   // lane j < 6: producer j's counter; lane 6: the bit (one memory round trip for all seven, not seven in a row)
+      int yv = 0;
+      bool ok = true;
+      if (lane < 6) ok = late_wait_cnt(B, LC_CM2_0 + lane, (uint32_t)(t + 1));
+      else if (lane == 6) { yv = late_y(B, t); ok = yv >= 0; }
+      const bool all_ok = __ballot(!ok) == 0;
+      yv = __shfl(yv, 6);
+      if (lane == 0) late_y_s = all_ok ? yv : -1;
     }
     __syncthreads();
     const int y = late_y_s;

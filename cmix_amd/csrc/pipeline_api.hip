@@ -914,6 +914,7 @@ int cmx_pipeline_late_perceive(cmx_pipeline_t* h, int bit) {
   lap(2);
   __sync_synchronize();   // the records are written before the counter moves
   *(volatile uint32_t*)&q.box->nknown = (uint32_t)(t + 1);
+  *(volatile unsigned long long*)&q.box->kb = ((unsigned long long)(unsigned)bit << 32) | (unsigned long long)(t + 1);
   if (nq) *(volatile uint32_t*)&nq->box->start = 1;
   // ---- the LSTM byte mixer's step for the completed byte (predictor.cpp:450-461), then "its distribution is there" ----
   if (byte_done) {
@@ -958,6 +959,34 @@ int cmx_pipeline_late_debug_mix(cmx_pipeline_t* h, float out47[47]) {
   if (!d) return 1;
   if (hipMemcpyAsync(L->dbg_row, d, CMX_N_MIXERS * 4, hipMemcpyDeviceToHost, h->s_up) != hipSuccess || hipStreamSynchronize(h->s_up) != hipSuccess) return 1;
   memcpy(out47, L->dbg_row, CMX_N_MIXERS * 4);
+  return 0;
+}
+
+// Replay: predict / perceive for n known bits in one call (what a decoder does, minus the arithmetic decoder): p_out[i] = p before bits[i].
+// For tests against reference traces and for timing the protocol without a caller's per-call overhead.
+int cmx_pipeline_late_replay(cmx_pipeline_t* h, const uint8_t* bits, size_t n, float* p_out) {
+  if (!h || !bits || !p_out) { cmx_set_err("cmx_pipeline_late_replay: bad argument"); return 1; }
+  for (size_t i = 0; i < n; ++i) {
+    const float p = cmx_pipeline_late_predict(h);
+    if (p < 0) return 1;
+    p_out[i] = p;
+    if (cmx_pipeline_late_perceive(h, bits[i])) return 1;
+  }
+  return 0;
+}
+
+// diagnostics: the row counters of the chunk being decoded and when each was last moved (device clock, 100 MHz): out[2 i] = rows of
+// counter i (cmx_late.h: LC_*; 14 = steps the relay has brought over), out[2 i + 1] = its time stamp; out[30..39]: the mixing network's
+// stamps of the current bit (p out, row complete, sums there, layer 1 done, helpers fed). Taken between predict() and perceive() every
+// counter stands at the same bit. Copies 1 KB from the device on the upload stream.
+int cmx_pipeline_late_debug_times(cmx_pipeline_t* h, uint32_t out[48]) {
+  if (!h || !h->late || !h->late->active || !out) return 1;
+  Late* L = h->late;
+  const LateSet& q = L->set[(int)(L->cur % 3)];
+  uint32_t cv[LC_N * CMX_LATE_CNT_STRIDE];
+  if (hipMemcpyAsync(cv, q.cnt, sizeof cv, hipMemcpyDeviceToHost, h->s_up) != hipSuccess || hipStreamSynchronize(h->s_up) != hipSuccess) return 1;
+  for (int i = 0; i < 15; ++i) { out[2 * i] = cv[i * CMX_LATE_CNT_STRIDE] & 0xFFFFu; out[2 * i + 1] = cv[i * CMX_LATE_CNT_STRIDE + 1]; }
+  for (int k = 0; k < 10; ++k) out[30 + k] = cv[15 * CMX_LATE_CNT_STRIDE + k];
   return 0;
 }
 

@@ -557,6 +557,15 @@ class Pipeline:
         if lib().cmx_pipeline_late_perceive(self.h, int(bit)):
             raise CmxError(last_error())
 
+    def late_replay(self, bits):
+        """predict / perceive over known bits in one native call -> p before each bit"""
+        bits = np.ascontiguousarray(bits, np.uint8)
+        p = np.empty(len(bits), np.float32)
+        lib().cmx_pipeline_late_replay.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        if lib().cmx_pipeline_late_replay(self.h, bits.ctypes.data, len(bits), p.ctypes.data):
+            raise CmxError(last_error())
+        return p
+
     def late_stop(self):
         if lib().cmx_pipeline_late_stop(self.h):
             raise CmxError(last_error())

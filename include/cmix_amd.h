@@ -499,8 +499,13 @@ int cmx_pipeline_late_start(cmx_pipeline_t*, int last_bit);
 float cmx_pipeline_late_predict(cmx_pipeline_t*);
 int cmx_pipeline_late_perceive(cmx_pipeline_t*, int bit);
 int cmx_pipeline_late_stop(cmx_pipeline_t*);
+/* predict / perceive for n known bits in one call (a decoder minus the arithmetic decoder): p_out[i] = p before bits[i] */
+int cmx_pipeline_late_replay(cmx_pipeline_t*, const uint8_t* bits, size_t n, float* p_out);
 /* diagnostics: the calling thread's wall time since start, in ms: [0] waiting for p, [1] PPMd, [2] paq8 front end, [3] fxcm parser, [4] LSTM launches, [5] chunk launches */
 int cmx_pipeline_late_host_ms(cmx_pipeline_t*, double ms[6], uint64_t* bits);
+/* diagnostics: every row counter of the chunk being decoded and the device time (100 MHz) it was last moved at: out[2 i], out[2 i + 1] for
+ * counter i of cmx_late.h (14 = the relay's); out[30..39] the mixing network's stamps of the current bit. Call between predict() and perceive(). */
+int cmx_pipeline_late_debug_times(cmx_pipeline_t*, uint32_t out[48]);
 /* test hook: the layer-0 row (2078 f32, host memory) and 47 selectors of the bit predicted last; valid until the matching perceive */
 const float* cmx_pipeline_late_debug_row(cmx_pipeline_t*, const uint32_t** sel);
 /* test hooks (CMX_LATE_DEBUG=1 in the environment when the handle is built): the 47 Mixer::Mix values of the bit BEFORE the one predicted last */

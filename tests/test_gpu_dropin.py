@@ -396,6 +396,13 @@ def test_dropin_engine_english_dic_pretrain_and_wrt_text_is_byte_identical():
     with open(os.path.join(ROOT, "gpurun_out", "config3_dict_time.txt"), "w") as f:
         f.write("cmix_dropin -c english.dic (412 KB pretraining + %d bytes coded): %.1f s wall, file %d bytes (reference: %d)\n" % (len(payload), dt, len(got), want_size))
     assert len(got) == want_size and hashlib.sha256(got).digest() == want_sha
+    # ... and back: `cmix_dropin -d english.dic` -- Pretrain over the dictionary through the device stages, the stream bit by bit under the
+    # late-bit protocol, the WRT inverse by the reference's own preprocessor
+    t0 = time.time()
+    back = _run("-d", [("english.dic", blob), ("in", got)], exe=DROPIN, timeout=900)
+    with open(os.path.join(ROOT, "gpurun_out", "config3_dict_time.txt"), "a") as f:
+        f.write("cmix_dropin -d english.dic: %.1f s wall\n" % (time.time() - t0))
+    assert back == payload
 
 
 # ---- BASELINE config 4: twelve files of mixed types through the reference's own framing, one process per file ----------
