@@ -33,7 +33,10 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <string>
 #include <vector>
 
@@ -103,6 +106,7 @@ struct cmx_engine {
   unsigned partial = 0;           // those bits
   int lstmpr = 0, lstmex = 0;
   bool failed = false;            // sticky: a step failed after the handle's state had begun to change (every later call is refused)
+  double t_predict = 0, t_perceive = 0, t_outside = 0, t_last = 0; unsigned long long n_calls = 0;   // CMX_TIMING=1: wall time inside cmx_predict / cmx_perceive and between them
   std::vector<uint8_t> pre;       // Pretrain bytes not yet trained
   int pre_j = 0;
   unsigned pre_partial = 0;
@@ -258,15 +262,26 @@ int flush_pretrain(cmx_engine* h) {
 // What a Decoder gets (decoder.cpp:20-39) when it has staged nothing and hands in no columns: the same stage kernels as the
 // look-ahead compressor -- fxcm and paq8 included --, launched for chunks of bytes that do not exist yet; cmx_perceive(bit)
 // publishes the bit (and the host stages' records of the step after it), cmx_predict() waits for the mixing network's p.
+double cmx_timing_now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+bool cmx_timing_on() { static const bool on = getenv("CMX_TIMING") != nullptr; return on; }
+#define CMX_TIMING(what, t0) do { if (cmx_timing_on()) fprintf(stderr, "[cmx timing] %-28s %.3f s\n", what, cmx_timing_now() - (t0)); } while (0)
 int ensure_late(cmx_engine* h, const char* where) {
   if (h->mode == 3) return 0;
   if (h->mode != 0) { cmx_set_err(std::string(where) + ": the handle is already in another mode"); return 1; }
   if (h->pre_j) { cmx_set_err(std::string(where) + ": Pretrain() stopped inside a byte"); return 1; }
+  double t0 = cmx_timing_now();
+  if (cmx_timing_on()) fprintf(stderr, "[cmx timing] first predict (decoder) at    %.3f s (process clock)\n", t0);
   h->late = cmx_pipeline_create(h->vocab, h->device, kLaChunk);
-  bool ok = h->late && cmx_pipeline_enable_fxcm(h->late, h->has_dict ? h->dict.c_str() : nullptr) == 0 && cmx_pipeline_enable_paq8(h->late) == 0;
+  CMX_TIMING("pipeline_create", t0); t0 = cmx_timing_now();
+  bool ok = h->late && cmx_pipeline_enable_fxcm(h->late, h->has_dict ? h->dict.c_str() : nullptr) == 0;
+  CMX_TIMING("enable_fxcm", t0); t0 = cmx_timing_now();
+  ok = ok && cmx_pipeline_enable_paq8(h->late) == 0;
+  CMX_TIMING("enable_paq8", t0); t0 = cmx_timing_now();
   // Predictor::Pretrain's bytes (predictor.cpp:471-487), collected since cmx_create, in one batch through the stages
   ok = ok && (h->pre.empty() || cmx_pipeline_pretrain(h->late, h->pre.data(), h->pre.size()) == 0);
+  CMX_TIMING("pretrain", t0); t0 = cmx_timing_now();
   ok = ok && cmx_pipeline_late_start(h->late, h->pre.empty() ? 0 : (int)(h->pre.back() & 1)) == 0;
+  CMX_TIMING("late_start", t0);
   if (!ok) { cmx_pipeline_destroy(h->late); h->late = nullptr; return 1; }   // the failing stage has set the error
   h->pre.clear();
   h->pre.shrink_to_fit();
@@ -388,10 +403,16 @@ extern "C" {
 void cmx_destroy(cmx_t* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
+  if (h->late) (void)cmx_pipeline_late_stop(h->late);   // FIRST: a decoder's stage kernels wait for bits that will not come -- without the abort word a
+                                                        // device-wide synchronisation waits for their wall-clock time-outs (30 s per chunk in flight)
   (void)hipDeviceSynchronize();
   free_lookahead(h);
   free_perbit(h);
+  const double t0 = cmx_timing_now();
+  if (cmx_timing_on()) fprintf(stderr, "[cmx timing] cmx_destroy at                %.3f s (process clock); %llu bits: %.3f s inside cmx_predict, %.3f s inside cmx_perceive, %.3f s in the caller between them\n", t0,
+                               h->n_calls, h->t_predict, h->t_perceive, h->t_outside);
   if (h->late) cmx_pipeline_destroy(h->late);   // unwinds the kernels of the chunk in progress first
+  CMX_TIMING("pipeline_destroy", t0);
   delete h;
 }
 
@@ -434,13 +455,15 @@ float cmx_predict(cmx_t* h) {
     return p;
   }
   if (h->mode == 3 || (h->mode == 0 && !h->have_staged)) {   // a decoder: nothing staged, no columns handed in -- the whole engine, bit by bit
-    E_HIP(hipSetDevice(h->device));
+    const double tq = cmx_timing_on() ? cmx_timing_now() : 0;
+    if (h->mode != 3) E_HIP(hipSetDevice(h->device));
     Txn txn(h);
     if (ensure_late(h, where)) return fail;
     const float p = cmx_pipeline_late_predict(h->late);
     if (p < 0) return fail;
     h->predicted = true;
     txn.ok = true;
+    if (cmx_timing_on()) { h->t_predict += cmx_timing_now() - tq; h->n_calls++; if (h->t_last) h->t_outside += tq - h->t_last; }
     return p;
   }
   if (!h->have_staged) {
@@ -486,14 +509,16 @@ int cmx_perceive(cmx_t* h, int bit) {
     txn.ok = true;
     return 0;
   }
-  E_HIP(hipSetDevice(h->device));
   if (h->mode == 3) {
+    const double tq = cmx_timing_on() ? cmx_timing_now() : 0;
     Txn txn(h);
     if (cmx_pipeline_late_perceive(h->late, bit)) return 1;
     h->predicted = false;
     txn.ok = true;
+    if (cmx_timing_on()) { h->t_last = cmx_timing_now(); h->t_perceive += h->t_last - tq; }
     return 0;
   }
+  E_HIP(hipSetDevice(h->device));
   Txn txn(h);
   if (cmx_mixnet_perceive_async(h->mix, bit, h->st)) return 1;
   h->predicted = false;

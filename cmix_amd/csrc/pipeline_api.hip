@@ -15,6 +15,7 @@
 // them inside d_layer0. No CPU fallback exists for any device stage.
 #include <hip/hip_runtime.h>
 #include <chrono>
+#include <stdio.h>
 #include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -27,6 +28,7 @@
 #include "cmx_late.h"
 
 void cmx_set_err(const std::string& s);  // cmx_api.hip
+static double late_now();   // ms on the steady clock (defined with the late-bit pipeline below)
 
 // ---- construction ahead of time ------------------------------------------------------------------------------
 // Most of an engine's construction does not depend on the input: the mixing network's 2.8 GB of weight rows and SSE tables, the
@@ -43,14 +45,25 @@ struct Prewarm {
   cmx_mixnet_t* mix = nullptr;
   cmx_fxcm_t* fx = nullptr;
   cmx_p8stage_t* p8 = nullptr;
-  ~Prewarm() {   // never adopted (or only in part): finish and release
+  ~Prewarm() {
+    // Never adopted (or only in part), and the process is ending (the only caller is the static destructor below): wait for the builder
+    // thread -- it must not be inside the HIP runtime while the process tears down -- and leave what it built to the operating system.
+    // Destroying the stages here (hipFree, hipStreamDestroy from a static destructor of a shared library, next to the HIP runtime's own
+    // teardown) corrupted the heap of `cmix_dropin -d` on an empty file, the one program run that never builds an engine.
     if (th.joinable()) th.join();
-    cmx_mixnet_destroy(mix); cmx_fxcm_destroy(fx); cmx_p8stage_destroy(p8);
   }
 };
 std::mutex g_pw_mu;
 Prewarm* g_pw = nullptr;
 struct PrewarmAtExit { ~PrewarmAtExit() { std::lock_guard<std::mutex> l(g_pw_mu); delete g_pw; g_pw = nullptr; } } g_pw_at_exit;
+// exit(): handlers run in reverse order of registration, and the HIP runtime registered its own when cmx_prewarm() made the first HIP call --
+// this one is registered right after it, so it runs BEFORE the runtime goes away and waits for the builder thread (a thread inside
+// hipMalloc while the runtime is torn down under it crashed `cmix_dropin -d` on an empty file, which exits 0.1 s after it started)
+void prewarm_join_at_exit() {
+  std::lock_guard<std::mutex> l(g_pw_mu);
+  if (getenv("CMX_TIMING")) fprintf(stderr, "[cmx timing] exit handler at               %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count());
+  if (g_pw && g_pw->th.joinable()) g_pw->th.join();
+}
 // the prewarmed set for `device`, its thread joined; nullptr if there is none
 Prewarm* prewarmed(int device) {
   std::lock_guard<std::mutex> l(g_pw_mu);
@@ -68,13 +81,19 @@ extern "C" int cmx_prewarm(int device, const char* dictionary_path, int with_fxc
   Prewarm* p = new Prewarm();
   p->device = device; p->want_fxcm = with_fxcm != 0;
   if (dictionary_path) { p->dict = dictionary_path; p->has_dict = true; }
-  p->th = std::thread([p]() {   // a stage that fails here is simply built (and its error reported) by the normal path later
+  const bool timing = getenv("CMX_TIMING") != nullptr;
+  if (timing) fprintf(stderr, "[cmx timing] cmx_prewarm called at        %.3f s (process clock)\n", late_now() / 1e3);
+  p->th = std::thread([p, timing]() {   // a stage that fails here is simply built (and its error reported) by the normal path later
     (void)hipSetDevice(p->device);
     p->mix = cmx_mixnet_create(p->device);
+    if (timing) fprintf(stderr, "[cmx timing] prewarm: mixnet built at       %.3f s\n", late_now() / 1e3);
     p->p8 = cmx_p8stage_create(p->device);
+    if (timing) fprintf(stderr, "[cmx timing] prewarm: paq8 stage built at   %.3f s\n", late_now() / 1e3);
     if (p->want_fxcm) p->fx = cmx_fxcm_create(p->has_dict ? p->dict.c_str() : nullptr, p->device);
   });
   g_pw = p;
+  static const int registered = atexit(prewarm_join_at_exit);
+  (void)registered;
   return 0;
 }
 
@@ -828,7 +847,9 @@ int cmx_pipeline_late_stop(cmx_pipeline_t* h) {
   for (LateSet& q : L->set) if (q.box) { q.box->abort = 1; }
   __sync_synchronize();
   (void)hipSetDevice(h->device);
+  const double t0 = late_now();
   const bool ok = hipDeviceSynchronize() == hipSuccess;
+  if (getenv("CMX_TIMING")) fprintf(stderr, "[cmx timing] %-28s %.3f s\n", "late_stop: kernels unwound", (late_now() - t0) / 1e3);
   L->active = false;
   if (!ok) { cmx_set_err("cmx_pipeline_late_stop: device error"); return 1; }
   return 0;
@@ -848,6 +869,17 @@ float cmx_pipeline_late_predict(cmx_pipeline_t* h) {
     if ((++spins & 0xfffu) == 0) {
       const double el = late_now() - t0;
       const char* why = nullptr;
+      static int slow_reports = 0;
+      if (el > 1000.0 && slow_reports < 4 && getenv("CMX_TIMING")) {   // diagnostics: a wait of more than a second -- which stage is the stream waiting for?
+        ++slow_reports;
+        uint32_t cv[LC_N * CMX_LATE_CNT_STRIDE] = {0};
+        (void)hipMemcpyAsync(cv, q.cnt, sizeof cv, hipMemcpyDeviceToHost, h->s_up);
+        (void)hipStreamSynchronize(h->s_up);
+        fprintf(stderr, "\n[cmx timing] waiting > 1 s for p of bit %llu (bit %zu of chunk %llu); rows:", (unsigned long long)L->bits, L->t, (unsigned long long)L->cur);
+        static const char* const nm2[] = {"ctx", "bm0", "bm1", "bm2", "fx", "p8", "cm2a", "cm2b", "cm2c", "fam", "lanes", "dmc", "brk", "lstm", "known"};
+        for (int i = 0; i < 15; ++i) fprintf(stderr, " %s=%u", nm2[i], cv[i * CMX_LATE_CNT_STRIDE] & 0xFFFFu);
+        fprintf(stderr, " | box nknown %u start %u fail %u\n", q.box->nknown, q.box->start, q.box->fail);
+      }
       if (*(volatile uint32_t*)&q.box->fail) why = "a stage kernel's wait ran out of time (are all stage kernels co-resident?)";
       else if (cmx_p8stage_mixfail(h->p8)) why = "the paq8 mixer's workgroup 0 timed out waiting for another workgroup";
       else if (el > 60000.0) why = "no prediction from the device for 60 s";
