@@ -81,7 +81,7 @@ PMC_KERNELS = {"mixnet": ["cmx_mixnet_spec_kernel"], "fxcm": ["cmx_fxcm_roles_ke
 
 
 def pmc_traffic_per_byte(stage):
-    """HBM bytes per stream byte of the stage's kernels from the committed PMC passes of this command (scripts/gpu_r3_measure.sh:
+    """HBM bytes per stream byte of the stage's kernels from the committed PMC passes of this command (scripts/gpu_measure.sh:
     rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs with --kernel-trace only; the counters are KB summed over the
     launches; FETCH_SIZE doubled as /opt/skills/guides/MI355X_MICROARCH.md prescribes for 16-byte-per-lane loads on gfx950).
     None when the file is missing or does not list the kernel: a stale constant is worse than no number."""
@@ -272,8 +272,9 @@ def main():
     rank_checks = None
     if world > 1:
         mine = {"rank": rank, "seed": shard.shard_seed(rank), "fixture": None, "identical_to_reference_file": None}
-        fxr = os.path.join(ROOT, "tests", "golden", "dropin_rich_128k_s%d.npz" % shard.shard_seed(rank)) if rank else os.path.join(ROOT, "tests", "golden", "dropin_rich_128k.npz")
-        if os.path.exists(fxr) and a.payload_bytes >= 131072 and mode_name == "strict":
+        # (rank 0's WHOLE file is compared below; its entry is filled from that)
+        fxr = os.path.join(ROOT, "tests", "golden", "dropin_rich_128k_s%d.npz" % shard.shard_seed(rank))
+        if rank and os.path.exists(fxr) and a.payload_bytes >= 131072 and mode_name == "strict":
             with np.load(fxr) as z:
                 w_sha, w_size = z["sha256"].tobytes().hex(), int(z["size"][0])
             eng.close()
@@ -333,7 +334,7 @@ def main():
             "verified": verified,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if traffic_pb is None else traffic_pb * n / nsub,
-                         "traffic_source": "profiles/r03_pmc_bench.json read at run time (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, kernel-trace only; "
+                         "traffic_source": os.path.relpath(PMC_FILE, ROOT) + " read at run time (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, kernel-trace only; "
                                            "2 x FETCH_SIZE + WRITE_SIZE per stream byte, scaled to this launch size); null if the file is missing",
                          "kernel": KERNEL[dom], "stage": dom, "avg_launch_ms": kernel_s * 1e3,
                          "period_stage": {"stage": period_stage, "kernel": KERNEL[period_stage], "us_per_bit": us[period_stage],
@@ -346,6 +347,7 @@ def main():
                          "note": "every stage is a latency-bound dependent chain per stream (DESIGN.md 4): the HBM roof is the wrong roof by construction"},
         }
         if rank_checks is not None:
+            rank_checks[0].update(fixture=verified["fixture"], identical_to_reference_file=verified["identical_to_reference_file"], whole_file=True)
             out["verified"]["ranks"] = rank_checks
         if cpu is not None:
             if a.cpu_baseline_serial:

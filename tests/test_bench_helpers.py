@@ -1,6 +1,6 @@
 """bench.py's bookkeeping that needs no GPU: the algorithmic-traffic table, the PMC file it reads `roofline.traffic`
 from (the kernels it sums must be the ones the committed profile lists -- a renamed kernel must not silently turn the figure into
-None), the strict-mode floor, and the shape of the committed bench line."""
+None), and the shape of the committed bench line."""
 import json
 import os
 
@@ -12,7 +12,7 @@ def test_algorithmic_traffic_table():
     assert bench.ALGO["mixnet"] == 55172 * 8 * 8 + 4 * 64 * 8          # 3.53 MB per input byte
     assert 8.5e6 < bench.lstm_algo_bytes(205) < 9.2e6                    # 8.86 MB per byte at enwik8's alphabet
     assert bench.lstm_algo_bytes(145) < bench.lstm_algo_bytes(205)
-    assert bench.HBM_PEAK_GBS == 8000.0 and 3.0 < bench.STRICT_FLOOR_US_PER_BIT < 6.0
+    assert bench.HBM_PEAK_GBS == 8000.0
 
 
 def test_pmc_file_lists_every_kernel_the_bench_sums():
@@ -30,7 +30,8 @@ def test_pmc_file_lists_every_kernel_the_bench_sums():
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    with open(os.path.join(ROOT, "profiles", "r03_bench_1m.json")) as f:
+    import glob
+    with open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_1m.json")))[-1]) as f:   # the newest round's
         d = json.load(f)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
