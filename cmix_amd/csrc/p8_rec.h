@@ -20,8 +20,13 @@ enum {
   P8_FAM_MAXS = 256,       /* contexts of the family */
   P8_NCM2 = 3,             /* ContextMap2 instances: contextModel2's order-N map, TextModel's, exeModel's */
   P8_NLANE = 64,           /* small learners + host-computed inputs, one lane each */
-  P8_ORDER_MAX = 10        /* ContextMap2::mix's return value for the 10-context order-N map */
+  P8_ORDER_MAX = 10,       /* ContextMap2::mix's return value for the 10-context order-N map */
+  /* the image models (im24bitModel :5001-5353, im8bitModel :4743-4999): a model id per byte, 0 = everything above */
+  P8_NMODEL = 3,           /* 0 generic (text / default / exe ...), 1 im24 (IMAGE24 / IMAGE32 blocks, 24 / 32-bit BMP / TGA payloads), 2 im8 */
+  P8_XL_NLANE = 192,       /* small maps of one image model (im24: 100 StationaryMap + 59 SmallStationaryContextMap) */
+  P8_XL_MAXS = 64          /* contexts of an image model's ContextMap (im24: 47, im8: 52) */
 };
+enum { P8_MODEL_GENERIC = 0, P8_MODEL_IM24 = 1, P8_MODEL_IM8 = 2 };
 
 /* small lanes (one wavefront): kinds */
 enum {
@@ -50,6 +55,20 @@ typedef struct {
   uint32_t init;               /* cell initial value (SM32 with 256 cells: the state-table prior instead) */
 } P8Lane;
 
+/* An image model's part of the layout. Its steps run contextModel2's common prefix (:8133-8160: the constant, two StateMap32, the
+ * order-N ContextMap2, three run maps, MatchModel -- the same objects at the same input positions as in the generic layout), then the
+ * model's own maps instead of everything else (:8161-8167): inputs [0, prefix_nx) + [prefix_nx, nx), fewer weight sets (sel = -1
+ * for the unused ones), their own final APM stages (P8ApmRec.kind). AddPrediction() counts on: the exported values of such a step are
+ * its nx inputs, nsel second-layer inputs and the chain's values back to back; the rest of the 1591 keep their last values (:504-510). */
+typedef struct {
+  int prefix_nx, nx;
+  int nlanes;
+  P8Lane lane[P8_XL_NLANE];
+  uint64_t fam_size;                   /* the model's one ContextMap */
+  int fam_count;
+  int16_t fam_off[P8_XL_MAXS];
+} P8XLayout;
+
 typedef struct {
   int fam_ninst, fam_slots;
   uint64_t fam_size[P8_FAM_MAXI];      /* bytes, in the order contextModel2 walks the instances (= rnd() draw order) */
@@ -66,6 +85,7 @@ typedef struct {
   uint16_t order_chk[P8_ORDER_MAX + 1];
   int nx_first;                        /* inputs during the first byte */
   int16_t first_map[P8_NX];            /* compact position -> position in the full vector */
+  P8XLayout xl[P8_NMODEL - 1];         /* the image models (xl[model - 1]) */
 } P8Layout;
 
 /* selectors whose value depends on device state: the host part is in sel[], the device adds
@@ -77,15 +97,23 @@ enum { P8_SEL_ORDER3 = 19, P8_SEL_ORDER5_A = 20, P8_SEL_ORDER5_B = 21, P8_SEL_OR
  * TEXT block:  c[0] = c0 << 8 | mask & 15 (device ORs (misses & 15) << 4), c[1..4] = second APM's context for
  *              misses & 3 = 0..3, c[5], c[6] = third, fourth; c[7..9] = the three APM1 contexts
  * other:       c[0] = mlen << 11 | c0 << 3 (device ORs misses & 7), c[1..3] = ctx1..3, c[4] = expected byte << 8 | c1 */
-typedef struct { uint16_t c[10]; uint16_t limit; uint8_t text, pad; } P8ApmRec;
+/* IMAGE24/32 (kind 2, Image.Color :8299-8314): c[0] = c0 << 4 (device ORs misses & 15), c[1..3] = the other three APMs' contexts,
+ *              c[4], c[5] = the two APM1 contexts; c[8] = the step's input count nx, c[9] = its weight-set count
+ * IMAGE8GRAY (kind 3, Image.Gray :8315-8324): c[0] as above, c[1], c[2]; IMAGE8 (kind 4, Image.Palette :8325-8340): c[0..3], c[4], c[5] */
+enum { P8_APM_GENERIC = 0, P8_APM_TEXT = 1, P8_APM_COLOR = 2, P8_APM_GRAY = 3, P8_APM_PALETTE = 4 };
+typedef struct { uint16_t c[10]; uint16_t limit; uint8_t text /* = kind: P8_APM_* */, model /* P8_MODEL_* of the step */; } P8ApmRec;
 
 /* one chunk of nbytes input bytes = 8 nbytes steps */
 typedef struct {
   uint32_t* fam_ctx; uint16_t* fam_chk;                   /* [nbytes][fam_slots]: set at the step with bpos == 0 */
   uint32_t* cm2_ctx[P8_NCM2]; uint16_t* cm2_chk[P8_NCM2]; /* [nbytes][cm2_count[k]] */
   uint32_t* ops;                                          /* [8 nbytes][P8_NLANE] */
-  int32_t* sel;                                           /* [8 nbytes][P8_NSEL] absolute rows */
+  int32_t* sel;                                           /* [8 nbytes][P8_NSEL] absolute rows (-1: no such set at this step) */
   P8ApmRec* apm;                                          /* [8 nbytes] */
+  /* image models (NULL while a stream has met none: the stage allocates them at the first such byte) */
+  uint8_t* model;                                         /* [nbytes] P8_MODEL_* */
+  uint32_t* xops;                                         /* [8 nbytes][P8_XL_NLANE]: the model's small maps (the table of that byte's model) */
+  uint32_t* xfam_ctx; uint16_t* xfam_chk;                 /* [nbytes][P8_XL_MAXS] */
 } P8Chunk;
 
 #endif

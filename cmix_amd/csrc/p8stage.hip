@@ -527,12 +527,12 @@ __device__ __forceinline__ void mx4_body(const P8MixDev* M, P8TailDev* T, const 
   };
   int a_base = 0, upd_idx = -1; uint32_t upd_v0 = 0, upd_v1 = 0;
   auto row_ctx = [&](const P8ApmRec* a, int j, unsigned long long ms) {
-    if (a->text) return j == 0 ? (a->c[0] | (int)((ms & 0xF) << 4)) : j == 1 ? (int)a->c[1 + (int)(ms & 3)] : (int)a->c[3 + j];
+    if (a->text == P8_APM_TEXT) return j == 0 ? (a->c[0] | (int)((ms & 0xF) << 4)) : j == 1 ? (int)a->c[1 + (int)(ms & 3)] : (int)a->c[3 + j];
     return j == 0 ? (a->c[0] | (int)(ms & 7)) : j < 4 ? (int)a->c[j] : j == 4 ? (int)a->c[4] : (int)a->c[j - 3];
   };
   auto chain_fetch = [&](int ts, int y, unsigned long long ms) {   // see cmx_p8s_mix2_kernel's notes: update of the chosen cells, fetch of the step's rows
     const P8ApmRec* ap = reinterpret_cast<const P8ApmRec*>(ring_apm[ts & 3]);
-    const int a_text = ap->text, a_limit = ap->limit;
+    const int a_text = ap->text == P8_APM_TEXT, a_limit = ap->limit;
     if (fl >= 0 && fl < 7 * 36) {
       const int ncell = (a_text && fj < 4) ? 24 : 33;
       if (fk < ncell) {
@@ -584,7 +584,7 @@ __device__ __forceinline__ void mx4_body(const P8MixDev* M, P8TailDev* T, const 
     int a_text = 0;
     const P8ApmRec* arp = reinterpret_cast<const P8ApmRec*>(ring_apm[t & 3]);
     if (MAIN) {
-      a_text = arp->text;
+      a_text = arp->text == P8_APM_TEXT;
       if (chain) chain_patch(a_text);
       if (wave == 6 && pend26 && !again26) {   // set 26's row was requested after the previous step's chain: take it now
 #pragma unroll
@@ -782,7 +782,7 @@ __device__ __forceinline__ void mx4_late_body(const P8MixDev* M, P8TailDev* T, C
   int row = -1;
   int a_base = 0, upd_idx = -1; uint32_t upd_v0 = 0, upd_v1 = 0;
   auto row_ctx = [&](const P8ApmRec* a, int j, unsigned long long ms) {
-    if (a->text) return j == 0 ? (a->c[0] | (int)((ms & 0xF) << 4)) : j == 1 ? (int)a->c[1 + (int)(ms & 3)] : (int)a->c[3 + j];
+    if (a->text == P8_APM_TEXT) return j == 0 ? (a->c[0] | (int)((ms & 0xF) << 4)) : j == 1 ? (int)a->c[1 + (int)(ms & 3)] : (int)a->c[3 + j];
     return j == 0 ? (a->c[0] | (int)(ms & 7)) : j < 4 ? (int)a->c[j] : j == 4 ? (int)a->c[4] : (int)a->c[j - 3];
   };
   for (int t = t0; t < nbits; ++t) {
@@ -821,7 +821,7 @@ __device__ __forceinline__ void mx4_late_body(const P8MixDev* M, P8TailDev* T, C
     if (MAIN) {
       // Predictor::update's first line (:8250), then the chains' cell updates with the bit and the fetch of the step's rows
       misses += misses + (unsigned long long)((fin_s >> 11) != y);
-      a_text = arp->text;
+      a_text = arp->text == P8_APM_TEXT;
       const int a_limit = arp->limit;
       if (fl >= 0 && fl < 7 * 36) {
         const int ncell = (a_text && fj < 4) ? 24 : 33;

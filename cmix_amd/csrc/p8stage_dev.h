@@ -151,7 +151,7 @@ P8_HD int p8s_sel(int i, int host, int order, int last_pr) {
 //   phase C  one lane:    the exported values and the final prediction
 P8_HD void p8s_tail_a(P8TailDev* d, const P8ApmRec* a, int y, int pr0, int j, int* res) {
   const int16_t* st = d->stretch;
-  if (a->text) {
+  if (a->text == P8_APM_TEXT) {
     const int cx = j == 0 ? (a->c[0] | (int)((d->misses & 0xF) << 4)) : j == 1 ? a->c[1 + (int)(d->misses & 3)] : a->c[3 + j];
     res[j] = p8s_apm(d->apm[j], &d->apm_cxt[j], st, y, pr0, cx, a->limit);
   } else {
@@ -162,7 +162,7 @@ P8_HD void p8s_tail_a(P8TailDev* d, const P8ApmRec* a, int y, int pr0, int j, in
 P8_HD void p8s_tail_b(P8TailDev* d, const P8ApmRec* a, int y, int pr0, int j, int* res) {
   const int16_t* st = d->stretch;
   const int avg = (pr0 + res[1] + res[2] + res[3] + 2) >> 2;
-  if (a->text) res[4 + j] = p8s_apm1(d->apm1[j], &d->apm1_idx[j], st, y, j == 0 ? avg : res[0], a->c[7 + j], j == 0 ? 7 : 6);
+  if (a->text == P8_APM_TEXT) res[4 + j] = p8s_apm1(d->apm1[j], &d->apm1_idx[j], st, y, j == 0 ? avg : res[0], a->c[7 + j], j == 0 ? 7 : 6);
   else res[4 + j] = p8s_apm1(d->gen[4 + j], &d->gen_idx[4 + j], st, y, res[0], j == 0 ? a->c[4] : a->c[1 + j], 7);
 }
 // writes the 10 or 11 exported stage values at o[] and returns the final prediction
@@ -172,7 +172,7 @@ P8_HD int p8s_tail_c(const P8ApmRec* a, int pr0, const int* res, float* o) {
   o[k++] = (float)pr0 * cf;
   const int avg = (pr0 + res[1] + res[2] + res[3] + 2) >> 2;
   for (int j = 0; j < 4; j++) o[k++] = (float)res[j] * cf;
-  if (a->text) o[k++] = (float)avg * cf;   // the general path does not export this one (:8345)
+  if (a->text == P8_APM_TEXT) o[k++] = (float)avg * cf;   // the general path does not export this one (:8345)
   for (int j = 4; j < 7; j++) o[k++] = (float)res[j] * cf;
   int pr = (res[0] + res[4] + res[5] + res[6] + 2) >> 2;
   o[k++] = (float)pr * cf;

@@ -40,6 +40,7 @@
 #include "contexts/interval.h"
 #include "contexts/interval-hash.h"
 #include "states/nonstationary.h"
+#include "preprocess/preprocessor.h"
 #undef private
 #undef protected
 
@@ -250,5 +251,21 @@ int ref_ppmd_update(int byte, float* out256) {
 // same glibc variant (ifunc-selected) that the oracle process uses.
 float ref_logistic(float x) { return Sigmoid::Logistic(x); }
 float ref_logit(float p) { return g_p->sigmoid_.Logit(p); }
+
+// The reference's preprocessor (src/preprocess/preprocessor.cpp:568 Encode) on a file: the block-framed stream the predictor codes
+// (what runner.cpp writes to <out>.cmix.temp), for fixtures whose block types only the detector can produce (IMAGE*, AUDIO, JPEG).
+int ref_preprocess_encode(const char* in_path, const char* out_path, const char* temp_path) {
+  FILE* in = fopen(in_path, "rb");
+  if (!in) return -1;
+  fseek(in, 0, SEEK_END);
+  const unsigned long long n = (unsigned long long)ftell(in);
+  fseek(in, 0, SEEK_SET);
+  FILE* out = fopen(out_path, "wb");
+  if (!out) { fclose(in); return -2; }
+  preprocessor::Encode(in, out, false, n, std::string(temp_path), NULL);
+  fclose(in);
+  fclose(out);
+  return 0;
+}
 
 }  // extern "C"
