@@ -61,21 +61,27 @@ static void fail(const char* what) {
 void p8f_emit_begin_step(P8Emit* e, int16_t* in_base, P8Chunk* chunk, size_t byte_row, size_t step_row, int full) {
   e->in_base = in_base; e->chunk = chunk; e->byte_row = byte_row; e->step_row = step_row; e->full = full;
   e->fam_calls = e->cm2_calls = 0;
+  e->model = 0;
   if (chunk) memset(chunk->ops + step_row * P8_NLANE, 0, P8_NLANE * sizeof(uint32_t));
+}
+void p8f_emit_model(P8Emit* e, int m) {
+  e->model = m;
+  if (m && e->chunk && e->chunk->xops) memset(e->chunk->xops + e->step_row * P8_XL_NLANE, 0, P8_XL_NLANE * sizeof(uint32_t));
 }
 
 static int claim(P8Emit* e, const int16_t* out, int n) {  /* discovery: remember who produces which input positions */
   const int off = (int)(out - e->in_base);
   if (off < 0 || off + n > P8_NX) { fail("input position out of range"); return 0; }
-  if (e->discovering) memset((e->full ? e->claimed : e->claimed0) + off, 1, (size_t)n);
+  if (e->discovering && !e->model) memset((e->full ? e->claimed : e->claimed0) + off, 1, (size_t)n);
   return off;
 }
 
 /* ---- ContextMap family (:1010-1145): set() hashes, mix() is the device's ---- */
-typedef struct CM1 { int inst, first, count, cn, hashbits; uint64_t size; int order_idx; } CM1;
+typedef struct CM1 { int inst, first, count, cn, hashbits; uint64_t size; int order_idx; int model; } CM1;
 CM1* p8f_cm_new(uint64_t size_bytes, int count) {
   CM1* c = (CM1*)calloc(1, sizeof *c);
   c->inst = -1; c->count = count; c->size = size_bytes; c->order_idx = -1;
+  c->model = p8f_cur ? p8f_cur->model : 0;
   c->hashbits = (int)ilog2u((unsigned)(size_bytes >> 6));
   return c;
 }
@@ -91,9 +97,41 @@ void p8f_cm_order_slot(CM1* c, int idx, uint64_t seed) {
     e->L.order_chk[o] = (uint16_t)(p8f_checksum64(h, c->hashbits, 16) & 0xffff);
   }
 }
+/* an image model's one ContextMap: its contexts go to the chunk's xfam_* arrays, its offsets to the model's P8XLayout */
+static int xcm_step(CM1* c, int bp, const uint64_t* ctx, int nset, int16_t* out, int* nout) {
+  P8Emit* e = p8f_cur;
+  P8XLayout* X = &e->L.xl[c->model - 1];
+  if (e->model != c->model) { fail("an image model's ContextMap called outside its model"); return 0; }
+  if (c->inst < 0) {
+    c->inst = 0;
+    if (e->xdiscovering) { X->fam_size = c->size; X->fam_count = 0; }
+    else if (X->fam_size != c->size) { fail("an image model's ContextMap changed"); return 0; }
+  }
+  if (bp == 0) {
+    if (c->cn + nset > c->count || c->cn + nset > P8_XL_MAXS) { fail("too many contexts set (image model)"); return 0; }
+    if (e->xdiscovering) { if (c->cn + nset > X->fam_count) X->fam_count = c->cn + nset; }
+    else if (c->cn + nset > X->fam_count) { fail("an image model's ContextMap got more contexts than in the layout pass"); return 0; }
+    for (int i = 0; i < nset; ++i, ++c->cn) {
+      const uint64_t h = p8f_hash2(ctx[i], (uint64_t)c->cn);
+      if (e->chunk && e->chunk->xfam_ctx) {
+        e->chunk->xfam_ctx[e->byte_row * (size_t)P8_XL_MAXS + (size_t)c->cn] = p8f_finalize64(h, c->hashbits);
+        e->chunk->xfam_chk[e->byte_row * (size_t)P8_XL_MAXS + (size_t)c->cn] = (uint16_t)(p8f_checksum64(h, c->hashbits, 16) & 0xffff);
+      }
+    }
+  }
+  const int n = 5 * c->cn;
+  if (n) {
+    const int off = claim(e, out, n);
+    if (e->xdiscovering) for (int i = 0; i < c->cn; ++i) X->fam_off[i] = (int16_t)(off + 5 * i);
+  }
+  if (bp == 7) c->cn = 0;
+  *nout = n;
+  return 0;
+}
 int p8f_cm_step(CM1* c, int y1, int bp, int c0, int c1, const uint64_t* ctx, int nset, int16_t* out, int* nout) {
   P8Emit* e = p8f_cur;
   (void)y1; (void)c0; (void)c1;
+  if (c->model) return xcm_step(c, bp, ctx, nset, out, nout);
   P8Layout* L = &e->L;
   const int k = e->fam_calls++;
   if (c->inst < 0) {  /* first call: the instance takes the next place in the walk */
@@ -182,6 +220,18 @@ int p8f_cm2_step(CM2* c, int y_prev, int bpos, const uint64_t* ctx, int nset, in
 /* ---- small maps: one lane each ---- */
 static int new_lane(int kind, uint32_t cells, uint32_t init) {
   P8Emit* e = p8f_cur;
+  if (e->model) {   /* a map of an image model: the model's own table */
+    const int m = e->model - 1, l = e->xlane_objs[m]++;
+    if (l >= P8_XL_NLANE) { fail("too many small maps in an image model"); return 0; }
+    P8XLayout* X = &e->L.xl[m];
+    if (e->xdiscovering) {
+      P8Lane* q = &X->lane[l];
+      memset(q, 0, sizeof *q);
+      q->kind = (uint8_t)kind; q->cells = cells; q->init = init; q->off = -1;
+      X->nlanes = l + 1;
+    } else if (X->lane[l].kind != kind || X->lane[l].cells != cells) fail("small maps of an image model changed");
+    return l;
+  }
   const int l = e->lane_objs++;
   if (l >= P8_NLANE) { fail("too many small maps"); return 0; }
   if (e->discovering) {
@@ -192,22 +242,32 @@ static int new_lane(int kind, uint32_t cells, uint32_t init) {
   } else if (e->L.lane[l].kind != kind || e->L.lane[l].cells != cells) fail("small maps changed");
   return l;
 }
-static void lane_out(int l, const int16_t* out, int nout, int a, int mul, int div, int limit, int bpc) {
+static void lane_out(int model, int l, const int16_t* out, int nout, int a, int mul, int div, int limit, int bpc) {
   P8Emit* e = p8f_cur;
   const int off = claim(e, out, nout);
+  if (model) {
+    if (e->model != model) { fail("a map of an image model called outside its model"); return; }
+    if (!e->xdiscovering) return;
+    P8Lane* q = &e->L.xl[model - 1].lane[l];
+    q->off = (int16_t)off; q->nout = (int16_t)nout; q->a = (uint8_t)a; q->mul = (uint8_t)mul; q->div = (uint8_t)div; q->limit = (uint16_t)limit; q->bits_per_ctx = (uint16_t)bpc;
+    return;
+  }
   if (!e->discovering) return;
   P8Lane* q = &e->L.lane[l];
   if (e->full) { q->off = (int16_t)off; q->nout = (int16_t)nout; q->a = (uint8_t)a; q->mul = (uint8_t)mul; q->div = (uint8_t)div; q->limit = (uint16_t)limit; q->bits_per_ctx = (uint16_t)bpc; }
   else e->lane_off0[l] = (int16_t)off;
 }
-static void put_op(int l, uint32_t op) {
+static void put_op(int model, int l, uint32_t op) {
   P8Emit* e = p8f_cur;
-  if (e->chunk) e->chunk->ops[e->step_row * P8_NLANE + (size_t)l] = op;
+  if (!e->chunk) return;
+  if (model) { if (e->chunk->xops) e->chunk->xops[e->step_row * P8_XL_NLANE + (size_t)l] = op; }
+  else e->chunk->ops[e->step_row * P8_NLANE + (size_t)l] = op;
 }
 
-typedef struct DMap { int lane, kind, mask, maskbits, stride, btotal, pending, order; uint32_t ctx; } DMap;
+typedef struct DMap { int lane, kind, mask, maskbits, stride, btotal, pending, order, model; uint32_t ctx; } DMap;
 DMap* p8f_dmap_new(int kind, int bits_of_context, int bits_per_context, int rate) {
   DMap* m = (DMap*)calloc(1, sizeof *m);
+  m->model = p8f_cur ? p8f_cur->model : 0;
   m->kind = kind; m->mask = (1 << bits_of_context) - 1; m->maskbits = bits_of_context;
   m->stride = (1 << bits_per_context) - 1; m->btotal = bits_per_context;
   const uint32_t cells = ((uint32_t)1 << bits_of_context) * (uint32_t)m->stride;
@@ -221,17 +281,17 @@ void p8f_dmap_set(DMap* m, uint64_t ctx) { m->ctx = (p8f_finalize64(ctx, m->mask
 void p8f_dmap_set_order(DMap* m) { m->ctx = 0; m->pending = 1; m->order = 1; }   /* set(order-N map's return value) */
 int p8f_dmap_mix(DMap* m, int y, int a, int mul, int div, int16_t* out) {
   (void)y;
-  lane_out(m->lane, out, 2, a > 255 ? 255 : a, mul, div, a < 0x3FF ? a : 0x3FF, m->btotal);
+  lane_out(m->model, m->lane, out, 2, a > 255 ? 255 : a, mul, div, a < 0x3FF ? a : 0x3FF, m->btotal);
   uint32_t op = P8OP_MIX;
   if (m->pending) op |= P8OP_SET | (m->order ? P8OP_ORDER : 0) | (m->ctx & P8OP_CTX);
   m->pending = 0;
-  put_op(m->lane, op);
+  put_op(m->model, m->lane, op);
   return 2;
 }
 /* a step in which the model does not call mix(): the map is untouched, its two inputs are 0 (SparseMatchModel :3817-3822) */
 int p8f_dmap_skip(DMap* m, int a, int mul, int div, int16_t* out) {
-  lane_out(m->lane, out, 2, a > 255 ? 255 : a, mul, div, a < 0x3FF ? a : 0x3FF, m->btotal);
-  put_op(m->lane, 0);
+  lane_out(m->model, m->lane, out, 2, a > 255 ? 255 : a, mul, div, a < 0x3FF ? a : 0x3FF, m->btotal);
+  put_op(m->model, m->lane, 0);
   return 2;
 }
 
@@ -243,8 +303,8 @@ P8fStateMap32* p8f_statemap32_new(int n) {
 }
 /* StateMap32::p(cx, 1023) read out as one input (stretch(p) + 1) >> 1, or 0 when zero is set */
 void p8f_statemap32_emit(P8fStateMap32* s, int cx, int zero, int16_t* out) {
-  lane_out(s->lane, out, 1, 0, 1, 1, 1023, 0);
-  put_op(s->lane, P8OP_MIX | P8OP_SET | (zero ? P8OP_ZERO : 0) | ((uint32_t)cx & P8OP_CTX));
+  lane_out(0, s->lane, out, 1, 0, 1, 1, 1023, 0);
+  put_op(0, s->lane, P8OP_MIX | P8OP_SET | (zero ? P8OP_ZERO : 0) | ((uint32_t)cx & P8OP_CTX));
 }
 
 /* picModel's three maps (:3844-3864): a bit-history byte per context in one shared array + a u16 StateMap each */
@@ -255,8 +315,8 @@ P8fPic* p8f_pic_new(void) {
   return p;
 }
 void p8f_pic_emit(P8fPic* p, int i, int cxt, int first, int16_t* out) {
-  lane_out(p->lane[i], out, 1, i, 1, 1, 0, 0);   /* a = which of the three */
-  put_op(p->lane[i], P8OP_MIX | P8OP_SET | (first ? P8OP_ZERO : 0) | ((uint32_t)cxt & P8OP_CTX));
+  lane_out(0, p->lane[i], out, 1, i, 1, 1, 0, 0);   /* a = which of the three */
+  put_op(0, p->lane[i], P8OP_MIX | P8OP_SET | (first ? P8OP_ZERO : 0) | ((uint32_t)cxt & P8OP_CTX));
 }
 
 /* dmcForest (:7777-7822): bits only, lives on the device */
@@ -301,13 +361,13 @@ int p8f_emit_finish_discovery(P8Emit* e, int nx_first, int nx_full) {
   return e->err;
 }
 
-void p8f_emit_directs(P8Emit* e) {
+void p8f_emit_directs(P8Emit* e, int lim_off) {
   if (!e->chunk) return;
   const P8Layout* L = &e->L;
   uint32_t* ops = e->chunk->ops + e->step_row * P8_NLANE;
   if (e->full) {
     for (int l = 0; l < L->nlanes; ++l)
-      if (L->lane[l].kind == P8L_DIRECT) ops[l] = P8OP_MIX | (uint32_t)(uint16_t)e->in_base[L->lane[l].off];
+      if (L->lane[l].kind == P8L_DIRECT && L->lane[l].off < lim_off) ops[l] = P8OP_MIX | (uint32_t)(uint16_t)e->in_base[L->lane[l].off];
   } else {  /* first byte: the models wrote the compact vector */
     for (int i = 0; i < L->nx_first; ++i) {
       const int full = L->first_map[i];

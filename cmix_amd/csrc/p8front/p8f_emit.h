@@ -21,6 +21,11 @@ typedef struct {
   int full;               /* a byte boundary has been passed: every object produces its inputs */
   int fam_calls, cm2_calls, lane_objs;   /* per-step walk counters (calling-order checks) */
   int err;
+  /* image models (p8_rec.h P8XLayout): while `model` is non-zero, maps and the ContextMap that are created / called belong to
+   * that model's own tables (xops / xfam_* of the chunk) */
+  int model;
+  int xdiscovering;                      /* layout pass of the image models (the generic objects are already fixed) */
+  int xlane_objs[P8_NMODEL - 1];
   int16_t lane_off0[P8_NLANE];           /* discovery: input positions during the first byte */
   int16_t dmc_off0;
   uint8_t claimed[P8_NX], claimed0[P8_NX];
@@ -30,7 +35,10 @@ extern __thread P8Emit* p8f_cur;
 
 void p8f_emit_begin_step(P8Emit* e, int16_t* in_base, P8Chunk* chunk, size_t byte_row, size_t step_row, int full);
 int p8f_emit_finish_discovery(P8Emit* e, int nx_first, int nx_full);
-/* after a step: copy the host-computed inputs into their DIRECT lanes' op words */
-void p8f_emit_directs(P8Emit* e);
+/* after a step: copy the host-computed inputs into their DIRECT lanes' op words (positions below lim_off only: an image model's
+ * step ends the generic layout at its common prefix) */
+void p8f_emit_directs(P8Emit* e, int lim_off);
+/* the models of image model m (1 ..) are being constructed / stepped from here on (0: back to the generic tables) */
+void p8f_emit_model(P8Emit* e, int m);
 
 #endif

@@ -66,6 +66,9 @@ int p8f_exe_step(Exe* e, int y, int bpos, int c0, uint32_t c4, int blpos, const 
                  uint32_t* x86_out);
 Lpm* p8f_lpm_new(void);
 int p8f_lpm_step(Lpm* m, int y, int bpos, int c0, const uint8_t* last, int16_t* out);
+typedef struct Im24 Im24;
+Im24* p8f_im24_new(int level);
+int p8f_im24_step(Im24* m, int y, int bpos, int c0, const uint8_t* hist, uint32_t bmask, int pos, int w, int alpha, int16_t* out, int* sets, int* ranges, uint32_t* stats);
 P8fStateMap32* p8f_statemap32_new(int n);
 void p8f_statemap32_emit(P8fStateMap32* s, int cx, int zero, int16_t* out);
 int p8f_ilog(int x);
@@ -105,6 +108,11 @@ typedef struct {
   /* detectors (imgModel :5386-5504, audioModel :5810-5865) */
   struct { uint32_t Header, Offset, Bpp, Size, Palette, HdrLess, Width, Height, BitMask; } bmp;
   int img_gray, img_pltorder;                      /* imgModel's statics `gray`, `pltorder` while a palette is being skipped */
+  int img_w, img_bpp, img_eoi, img_alpha;          /* imgModel's statics w, bpp, eoi, alpha: an image payload is being modelled while w != 0 */
+  Im24* im24;
+  uint32_t img_stats[8];                           /* ModelStats.Image of the byte: W, N, NN, WW, Wp1, Np1, plane, ctx */
+  int model;                                       /* P8_MODEL_* of the current step */
+  int nsel;                                        /* weight sets of the current step */
   struct { int offset, jpeg, app; } jimg[4];       /* jpegModel's images[0..3] as far as the header phase goes (:5898-5908) */
   int jidx, jlast_pos, jdqt_state, jdqt_end, jqnum;
   struct { uint32_t Header, IdLength, Bpp, ImgType, MapSize, Width, Height; } tga;
@@ -142,6 +150,9 @@ static P8Predictor* predictor_new(int level) {
   p->pic = p8f_small_new(0); p->rec1 = p8f_small_new(1);
   p->rec = p8f_record_new(level); p->word = p8f_word_new(level); p->xml = p8f_xml_new(level); p->exe = p8f_exe_new(level);
   p->lpm = p8f_lpm_new();
+  p8f_emit_model(p8f_cur, P8_MODEL_IM24);   /* its maps and ContextMap go to the model's own tables (p8_rec.h P8XLayout) */
+  p->im24 = p8f_im24_new(level);
+  p8f_emit_model(p8f_cur, 0);
   return p;
 }
 
@@ -219,9 +230,12 @@ static void img_check_gray(P8Predictor* p, uint32_t x, int a, uint32_t* record) 
     else p->img_gray &= ((B == (p->img_gray & 0xFF)) * 0x1FF);
   }
 }
+/* imgModel's byte-boundary part :5393-5483: header detection; when a payload of more than 64 bytes follows, w / bpp / eoi / alpha are
+ * set and the image model runs until pos reaches eoi (img_model below). 0, or P8F_ERR_BMP / P8F_ERR_TGA for the pixel formats whose
+ * models are not built (1, 4, 8 bits). */
 static int img_detect(P8Predictor* p, uint32_t* record) {
-  const int pos = p->pos;
-  if (pos >= 40 && !p->bmp.Header &&
+  const int pos = p->pos, eoi = p->img_eoi;
+  if (pos >= eoi + 40 && !p->bmp.Header &&
       ((RB(54) == 'B' && RB(53) == 'M' && ((p->bmp.Offset = i4(p, 44)) & 0xFFFFFBF7) == 0x36 && i4(p, 40) == 0x28) ||
        (p->bmp.HdrLess = (i4(p, 40) == 0x28)))) {
     p->bmp.Width = i4(p, 36);
@@ -244,24 +258,28 @@ static int img_detect(P8Predictor* p, uint32_t* record) {
     }
   } else {
     p->bmp.Offset -= (p->bmp.Offset > 0);
-    img_check_gray(p, p->bmp.Offset, 1, record);
+    if (!p->img_w) img_check_gray(p, p->bmp.Offset, 1, record);   /* CheckIfGrayscale tests !w itself (:5356) */
   }
-  if (!p->bmp.Offset && (p->bmp.Header > 0 || p->bmp.BitMask > 0)) {   /* :5427-5438, pos >= eoi always */
+  if (!p->bmp.Offset && (p->bmp.Header > 0 || p->bmp.BitMask > 0) && pos >= eoi) {   /* :5427-5438 */
     if (!p->bmp.Header && p->bmp.BitMask) { p->bmp.Header = p->bmp.Bpp = 1; p->bmp.Width = p->bmp.BitMask; p->bmp.BitMask = 0; }
     const int bpp = (int)p->bmp.Bpp;
-    const int w = (bpp > 4) ? (int)((p->bmp.Width * (uint32_t)(bpp >> 3) + 3) & (uint32_t)(-4)) : (bpp == 1) ? (int)((((p->bmp.Width - 1) >> 5) + 1) * 4)
-                                                                                                           : (int)(((p->bmp.Width * 4 + 31) >> 5) * 4);
-    const int eoi = (int)((uint32_t)w * p->bmp.Height);
-    if (eoi > 64) return P8F_ERR_BMP;   /* the image model switches on for eoi bytes */
-    p->bmp.Header = 0;                  /* too small to be an image: dropped, as the reference drops it */
+    p->img_bpp = bpp;
+    p->img_w = (bpp > 4) ? (int)((p->bmp.Width * (uint32_t)(bpp >> 3) + 3) & (uint32_t)(-4)) : (bpp == 1) ? (int)((((p->bmp.Width - 1) >> 5) + 1) * 4)
+                                                                                                       : (int)(((p->bmp.Width * 4 + 31) >> 5) * 4);
+    p->img_alpha = (bpp == 32);
+    const int n = (int)((uint32_t)p->img_w * p->bmp.Height);
+    if (n > 64) {
+      p->img_eoi = n + pos;
+      if (bpp < 24) return P8F_ERR_BMP;   /* the 1 / 4 / 8-bit image models are not built */
+    } else { p->img_eoi = 0; p->bmp.Header = 0; p->img_w = 0; }   /* too small to be an image: dropped, as the reference drops it */
   }
-  if (pos >= 8 && !p->tga.Header) {
+  if (pos >= p->img_eoi + 8 && !p->tga.Header) {
     if ((m4(p, 8) & 0xFFFFFF) == 0x010100 && (m4(p, 4) & 0xFFFFFFC7) == 0x00000100 && (RB(1) == 16 || RB(1) == 24 || RB(1) == 32)) {
       p->tga.Header = (uint32_t)pos; p->tga.IdLength = RB(8); p->tga.MapSize = RB(1) / 8; p->tga.Bpp = 8; p->tga.ImgType = 1;
     } else if ((m4(p, 8) & 0xFFFEFF) == 0x000200 && !m4(p, 4)) {
       p->tga.Header = (uint32_t)pos; p->tga.IdLength = RB(8); p->tga.ImgType = RB(6); p->tga.Bpp = (p->tga.ImgType == 2) ? 24 : 8;
     }
-  } else if (p->tga.Header) {
+  } else if (!p->img_w && p->tga.Header) {
     const uint32_t q = (uint32_t)pos - p->tga.Header;
     if (q == 8) {
       p->tga.Width = (uint32_t)i2(p, 4); p->tga.Height = (uint32_t)i2(p, 2);
@@ -272,9 +290,15 @@ static int img_detect(P8Predictor* p, uint32_t* record) {
       if ((uint32_t)(i & 0xFFD7) != (p->tga.Bpp << 8)) memset(&p->tga, 0, sizeof p->tga);
     }
     if (p->tga.Header && q == 10 + p->tga.IdLength + p->tga.MapSize * 256) {
-      const int w = (int)((p->tga.Width * p->tga.Bpp) >> 3);
-      if (w * (int)p->tga.Height > 64) return P8F_ERR_TGA;
-      p->tga.Header = 0;
+      p->img_w = (int)((p->tga.Width * p->tga.Bpp) >> 3);
+      p->img_gray = (p->tga.ImgType == 3);
+      p->img_bpp = (int)p->tga.Bpp;
+      p->img_alpha = (p->tga.Bpp == 32);
+      const int n = p->img_w * (int)p->tga.Height;
+      if (n > 64) {
+        p->img_eoi = n + pos;
+        if (p->img_bpp < 24) return P8F_ERR_TGA;
+      } else { p->img_eoi = 0; p->tga.Header = 0; p->img_w = 0; }
     }
   }
   return 0;
@@ -356,14 +380,42 @@ static int context_model2(P8Predictor* p, int y, int32_t* sel) {
   p->match_length = (uint32_t)p8f_match_step(p->match, y, bpos, c0, p->buf, p->bmask, p->pos, in + nx, &k, &expected); nx += k;
   if (bpos == 0) p->match_expected = (uint32_t)expected;  /* Stats->Match.expectedByte changes at byte boundaries only (:3593) */
   const int ismatch = p8f_ilog((int)(p->match_length & 0xffff));
-  if (p->filetype >= FT_IMAGE1 && p->filetype <= FT_IMAGE32) return P8F_ERR_IMAGE_BLOCK;
-  if (bpos == 0) {
+  /* :8161-8167: an image block, or an image / audio / JPEG payload found inside another block, is modelled by its own sub-model
+   * INSTEAD of everything below */
+  p->model = P8_MODEL_GENERIC; p->nsel = P8_NSEL;
+  int img_w = 0, img_alpha = 0, by_block = 0;
+  if (p->filetype == FT_IMAGE24 || p->filetype == FT_IMAGE32) { img_w = p->info; img_alpha = p->filetype == FT_IMAGE32; by_block = 1; }
+  else if (p->filetype >= FT_IMAGE1 && p->filetype <= FT_IMAGE8GRAY) return P8F_ERR_IMAGE_BLOCK;
+  else {
     int e;
-    if (p->filetype != FT_EXE && (e = jpeg_detect(p)) != 0) return e;
-    if (p->size > 0 && (e = img_detect(p, &p->stat_record)) != 0) return e;
-    if ((e = wav_detect(p)) != 0) return e;
+    if (bpos == 0 && p->filetype != FT_EXE && (e = jpeg_detect(p)) != 0) return e;
+    if (p->size > 0) {   /* imgModel :5386-5504 */
+      if (bpos == 0 && (e = img_detect(p, &p->stat_record)) != 0) return e;
+      if (p->pos > p->img_eoi) p->img_w = 0;
+      img_w = p->img_w; img_alpha = p->img_alpha;
+    }
+    if (!img_w && bpos == 0 && (e = wav_detect(p)) != 0) return e;
   }
-
+  if (img_w) {   /* im24bitModel :5001-5353 through the model's own tables; 13 weight sets */
+    P8Emit* const em = p8f_cur;
+    if (em->chunk && !em->chunk->xops) return P8F_ERR_IMAGE_LATE;
+    int sets[16], ranges[16];
+    const int prefix = nx;
+    p8f_emit_model(em, P8_MODEL_IM24);
+    const int n = p8f_im24_step(p->im24, y, bpos, c0, p->buf, p->bmask, p->pos, img_w, img_alpha, in + nx, sets, ranges, bpos == 0 ? p->img_stats : NULL);
+    p8f_emit_model(em, 0);
+    if (n < 0) return P8F_ERR_IMAGE_PADDING;
+    nx += n;
+    if (em->xdiscovering) { em->L.xl[P8_MODEL_IM24 - 1].prefix_nx = prefix; em->L.xl[P8_MODEL_IM24 - 1].nx = nx; }
+    else if (em->L.xl[P8_MODEL_IM24 - 1].prefix_nx != prefix || em->L.xl[P8_MODEL_IM24 - 1].nx != nx) { fprintf(stderr, "paq8 front end: image step with %d + %d inputs\n", prefix, n); return P8F_ERR_INTERNAL; }
+    p->nx = nx; p->model = P8_MODEL_IM24; p->nsel = 13;
+    if (!by_block) p->type = img_alpha ? FT_IMAGE32 : FT_IMAGE24;   /* Stats->Type :5495 */
+    int base = 0;
+    for (int i = 0; i < 13; i++) { sel[ns++] = base + sets[i]; base += ranges[i]; }
+    for (; ns < P8_NSEL; ns++) sel[ns] = -1;
+    if (!by_block && bpos == 7 && p->pos + 1 == p->img_eoi) { memset(&p->tga, 0, sizeof p->tga); p->bmp.Header = 0; p->img_gray = p->img_alpha = 0; }   /* :5498-5501 */
+    return 0;
+  }
   uint8_t last[64];
   for (int i = 0; i < 64; i++) last[i] = (uint8_t)RB(i + 1);
   int sm_sets[2], rec_sets[3], text_sets[8], exe_sets[6];
@@ -456,8 +508,10 @@ static int front_step(P8Front* f, int y, int32_t* sel, P8ApmRec* apm) {
   const uint32_t lg = ilog2u(p->match_length + 1);
   const uint32_t c4 = p->c4, mlen = lg < 3 ? lg : 3, eb = p->match_expected;
   memset(apm, 0, sizeof *apm);
+  apm->model = (uint8_t)p->model;
+  if (p->model) { apm->c[8] = (uint16_t)p->nx; apm->c[9] = (uint16_t)p->nsel; }
   if (p->type == FT_TEXT) {
-    apm->text = 1;
+    apm->text = P8_APM_TEXT;
     apm->limit = (uint16_t)(0x3FF >> ((p->blpos < 0xFFF) * 2));
     apm->c[0] = (uint16_t)((c0 << 8) | (int)(p->text_mask & 0xF));
     for (uint64_t m = 0; m < 4; ++m) apm->c[1 + m] = (uint16_t)p8f_finalize64(p8f_hash4((uint64_t)bpos, m, c4 & 0xffff, p->text_mask >> 4), 16);
@@ -466,7 +520,17 @@ static int front_step(P8Front* f, int y, int32_t* sel, P8ApmRec* apm) {
     apm->c[7] = (uint16_t)p8f_finalize64(p8f_hash3(eb, mlen, c4 & 0xff), 16);
     apm->c[8] = (uint16_t)p8f_finalize64(p8f_hash2((uint64_t)c0, c4 & 0x00ffffff), 16);
     apm->c[9] = (uint16_t)p8f_finalize64(p8f_hash2((uint64_t)c0, c4 & 0xffffff00), 16);
-  } else {   /* the image types never get here (refused above) */
+  } else if (p->type == FT_IMAGE24 || p->type == FT_IMAGE32) {   /* Image.Color :8299-8314 */
+    const uint32_t* st = p->img_stats;   /* W, N, NN, WW, Wp1, Np1, plane, ctx */
+    apm->text = P8_APM_COLOR;
+    apm->limit = (uint16_t)(0x3FF >> ((p->blpos < 0xFFF) * 4));
+    apm->c[0] = (uint16_t)(c0 << 4);
+    apm->c[1] = (uint16_t)p8f_finalize64(p8f_hash3((uint64_t)c0, st[0], st[3]), 16);
+    apm->c[2] = (uint16_t)p8f_finalize64(p8f_hash3((uint64_t)c0, st[1], st[2]), 16);
+    apm->c[3] = (uint16_t)((c0 << 8) | (int)(st[7] & 0xff));
+    apm->c[4] = (uint16_t)p8f_finalize64(p8f_hash4((uint64_t)c0, st[0], (uint64_t)(uint32_t)((c4 & 0xff) - st[4]), st[6]), 16);   /* (c4 & 0xff) - Wp1 in 32-bit unsigned arithmetic */
+    apm->c[5] = (uint16_t)p8f_finalize64(p8f_hash4((uint64_t)c0, st[1], (uint64_t)(uint32_t)((c4 & 0xff) - st[5]), st[6]), 16);
+  } else {   /* the other image types never get here (refused above) */
     apm->c[0] = (uint16_t)((mlen << 11) | ((uint32_t)c0 << 3));
     apm->c[1] = (uint16_t)((uint32_t)c0 | RB(1) << 8);
     apm->c[2] = (uint16_t)((uint32_t)c0 ^ p8f_finalize64(hash1(c4 & 0xffff), 16));
@@ -489,7 +553,7 @@ P8Front* p8f_front_new(int level) {
   bind(f);
   /* layout pass: two bytes through a throw-away set of models -- which tables exist, in which order contextModel2 walks
    * them, where their inputs sit in the 1552-vector, during the first byte and after it (data-independent) */
-  f->emit.discovering = 1;
+  f->emit.discovering = 1; f->emit.xdiscovering = 1;   /* (the image models' maps register themselves when they are constructed) */
   f->emit.L.order_slot = -1; f->emit.L.dmc_off = -1;
   f->p = predictor_new(level);
   int32_t sel[P8_NSEL];
@@ -504,7 +568,25 @@ P8Front* p8f_front_new(int level) {
   if (rc == 0 && f->emit.L.order_slot < 0) rc = 1;
   release_models(f);
   if (rc != 0 || f->emit.err) { fprintf(stderr, "paq8 front end: layout pass failed\n"); free(f); return NULL; }
-  f->emit.discovering = 0; f->emit.lane_objs = 0;
+  f->emit.discovering = 0;
+  /* layout pass of the image models: a second throw-away set of models through an IMAGE24 block of two rows (header: type, size,
+   * width -- preprocessor.cpp:303-304) -- where their inputs start (the common prefix), how many there are, which maps exist */
+  {
+    static const uint8_t img[] = {FT_IMAGE24, 0, 0, 0, 24, 0, 0, 0, 12,   1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12,   1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12};
+    f->emit.xdiscovering = 1; f->emit.lane_objs = 0; memset(f->emit.xlane_objs, 0, sizeof f->emit.xlane_objs);
+    f->p = predictor_new(level);
+    int bit = 0;
+    for (size_t t = 1; t < 8 * sizeof img && rc == 0; ++t) {
+      p8f_emit_begin_step(&f->emit, f->p->in, NULL, 0, 0, t >= 8);
+      rc = front_step(f, bit, sel, &apm);
+      bit = (img[t >> 3] >> (7 - (t & 7))) & 1;
+    }
+    if (rc == 0 && f->emit.L.xl[P8_MODEL_IM24 - 1].nx == 0) rc = 1;
+    release_models(f);
+    f->emit.xdiscovering = 0;
+    if (rc != 0 || f->emit.err) { fprintf(stderr, "paq8 front end: layout pass of the image models failed (%d)\n", rc); free(f); return NULL; }
+  }
+  f->emit.lane_objs = 0; memset(f->emit.xlane_objs, 0, sizeof f->emit.xlane_objs);
   f->p = predictor_new(level);
   return f;
 }
@@ -525,10 +607,13 @@ int p8f_front_emit_step(P8Front* f, P8Chunk* out, size_t step_row) {
   if (f->steps == 0) {   /* no step 0: the first prediction is the constructor's */
     memset(out->sel + step_row * P8_NSEL, 0, P8_NSEL * sizeof(int32_t));
     memset(&out->apm[step_row], 0, sizeof(P8ApmRec));
+    if (out->model) out->model[0] = 0;
   } else {
     const int rc = front_step(f, f->last_bit, out->sel + step_row * P8_NSEL, &out->apm[step_row]);
     if (rc < 0 || f->emit.err) { f->err = rc < 0 ? rc : P8F_ERR_INTERNAL; return f->err; }
-    p8f_emit_directs(&f->emit);
+    const int model = f->p->model;
+    p8f_emit_directs(&f->emit, model ? f->emit.L.xl[model - 1].prefix_nx : P8_NX);
+    if (out->model && (step_row & 7) == 0) out->model[step_row >> 3] = (uint8_t)model;   /* a byte's eight steps share their model */
   }
   ++f->steps;
   return 0;
@@ -548,11 +633,13 @@ int p8f_front_run(P8Front* f, const uint8_t* bytes, size_t nbytes, P8Chunk* out)
 const char* p8f_strerror(int code) {
   switch (code) {
     case 0: return "ok";
-    case P8F_ERR_IMAGE_BLOCK: return "paq8 stage: image block type (the image sub-models are outside the stage's scope)";
+    case P8F_ERR_IMAGE_BLOCK: return "paq8 stage: 1 / 4 / 8-bit image block (only the 24 / 32-bit image model is built)";
     case P8F_ERR_JPEG: return "paq8 stage: JPEG stream detected (jpegModel is outside the stage's scope)";
-    case P8F_ERR_BMP: return "paq8 stage: BMP header detected (the image sub-models are outside the stage's scope)";
-    case P8F_ERR_TGA: return "paq8 stage: TGA header detected (the image sub-models are outside the stage's scope)";
+    case P8F_ERR_BMP: return "paq8 stage: 1 / 4 / 8-bit BMP payload detected (only the 24 / 32-bit image model is built)";
+    case P8F_ERR_TGA: return "paq8 stage: 8-bit TGA payload detected (only the 24 / 32-bit image model is built)";
     case P8F_ERR_WAV: return "paq8 stage: WAV header detected (audioModel is outside the stage's scope)";
+    case P8F_ERR_IMAGE_PADDING: return "paq8 stage: image rows whose byte width is not a multiple of the pixel size (the reference indexes past its OLS array there, paq8.cpp:5043,5226: undefined)";
+    case P8F_ERR_IMAGE_LATE: return "paq8 stage: an image model in a decoder's chunk (the late-bit form of the image models is not built)";
     default: return "paq8 stage: internal inconsistency in the front end";
   }
 }

@@ -1059,7 +1059,7 @@ struct cmx_p8stage {
   bool failed = false;
   float ms_front = 0;   // host time of the last front-end pass
   // the decoder's form (cmx_late.h): three chunk slots of host-coherent records and rows
-  struct Late { size_t cap = 0; char* rec = nullptr; char* d_rec = nullptr; size_t o_fctx, o_fchk, o_cctx[P8_NCM2], o_cchk[P8_NCM2], o_ops, o_sel, o_apm, total; int16_t* x = nullptr; uint8_t* order = nullptr; P8Chunk c; } late[3];   // rec: the front end's records (host-coherent), d_rec: their device mirror (the relay copies them over step by step), same layout
+  struct Late { size_t cap = 0; char* rec = nullptr; char* d_rec = nullptr; size_t o_fctx, o_fchk, o_cctx[P8_NCM2], o_cchk[P8_NCM2], o_ops, o_sel, o_apm, total; int16_t* x = nullptr; uint8_t* order = nullptr; P8Chunk c = P8Chunk(); } late[3];   // rec: the front end's records (host-coherent), d_rec: their device mirror (the relay copies them over step by step), same layout
   double role_ms[7] = {0, 0, 0, 0, 0, 0, 0}; uint64_t role_chunks = 0;   // summed over the chunks collected so far
 };
 static void p8s_collect(cmx_p8stage* h, Staging& b) {   // the chunk that used b is complete
@@ -1184,7 +1184,7 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
     if (hipHostMalloc((void**)&b.h, o, hipHostMallocDefault) != hipSuccess || hipMalloc((void**)&b.d, o) != hipSuccess) { cmx_set_err("cmx_p8stage_run: staging allocation failed"); h->failed = true; return 1; }
     b.cap = n;
   }
-  P8Chunk c;
+  P8Chunk c = P8Chunk();
   c.fam_ctx = (uint32_t*)(b.h + b.o_fctx); c.fam_chk = (uint16_t*)(b.h + b.o_fchk);
   for (int k = 0; k < P8_NCM2; k++) { c.cm2_ctx[k] = (uint32_t*)(b.h + b.o_cctx[k]); c.cm2_chk[k] = (uint16_t*)(b.h + b.o_cchk[k]); }
   c.ops = (uint32_t*)(b.h + b.o_ops); c.sel = (int32_t*)(b.h + b.o_sel); c.apm = (P8ApmRec*)(b.h + b.o_apm);

@@ -29,6 +29,11 @@ struct P8StageState {
   P8DmcDev dmc;
   P8TailDev tail;
   P8MixDev mix;
+  // the image models (p8_rec.h P8XLayout): one ContextMap each -- a one-instance family of the first design (p8cm_dev.h: the reference's
+  // loop body per context, the shared rnd() stream handed over at every switch between the generic family and this one) -- and
+  // their own lane tables
+  P8CmDev xfam[P8_NMODEL - 1];
+  P8XLanesDev xlanes[P8_NMODEL - 1];
 };
 
 namespace p8b {
@@ -111,6 +116,29 @@ bool build_stage(P8StageState& S, Policy& P, const P8Layout& L, int level, const
       q.mask = q.stride ? (uint32_t)(n / q.stride) - 1 : 0;
     }
   }
+  // ---- the image models ----
+  for (int m = 0; m < P8_NMODEL - 1; m++) {
+    const P8XLayout& X = L.xl[m];
+    memset(&S.xfam[m], 0, sizeof S.xfam[m]);
+    memset(&S.xlanes[m], 0, sizeof S.xlanes[m]);
+    if (X.nx == 0) continue;   // (a model the front end has not got)
+    if (!build_family(S.xfam[m], P, 1, &X.fam_size, &X.fam_count, nex1024, stretch4096, ilog65536)) return false;
+    S.xfam[m].row_stride = P8_NX;
+    for (int s = 0; s < X.fam_count; s++) S.xfam[m].slot_off[s] = X.fam_off[s];
+    P8XLanesDev& XD = S.xlanes[m];
+    XD.nlanes = X.nlanes; XD.model = m + 1;
+    XD.nex = D.nex; XD.stretch = D.stretch;
+    for (int l = 0; l < X.nlanes; l++) {
+      P8LaneDev& q = XD.lane[l];
+      q.q = X.lane[l];
+      const size_t n = q.q.cells;
+      if (q.q.kind == P8L_SSCM) { std::vector<uint16_t> v(n, (uint16_t)q.q.init); q.c16 = (uint16_t*)up(v.data(), n * 2); }
+      else if (q.q.kind == P8L_STAT) { std::vector<uint32_t> v(n, q.q.init); q.c32 = (uint32_t*)up(v.data(), n * 4); }
+      else return false;   // the image models hold no other kind
+      q.stride = (1u << q.q.bits_per_ctx) - 1;
+      q.mask = q.stride ? (uint32_t)(n / q.stride) - 1 : 0;
+    }
+  }
   // ---- DMC forest ----
   build_dmc(S.dmc, P, level, nex1024, stretch4096);
   // ---- mixer ----
@@ -149,6 +177,13 @@ bool build_stage(P8StageState& S, Policy& P, const P8Layout& L, int level, const
     for (int k = 0; k < 3; k++) T.apm1[k] = (uint16_t*)up(v.data(), v.size() * 2);
     T.gen[0] = (uint16_t*)up(v.data(), (size_t)0x2000 * 33 * 2);
     for (int k = 1; k < 7; k++) T.gen[k] = (uint16_t*)up(v.data(), v.size() * 2);
+    for (int k = 0; k < 2; k++) T.col_apm1[k] = (uint16_t*)up(v.data(), v.size() * 2);   // Image.Color's APM1s :8224
+  }
+  {
+    std::vector<uint32_t> v((size_t)0x10000 * 24);
+    for (size_t i = 0; i < v.size(); i++) { const int p = (((int)(i % 24) * 2 + 1) * 4096) / 48 - 2048; v[i] = ((uint32_t)sq(p) << 20) + 6; }
+    T.col_apm[0] = (uint32_t*)up(v.data(), (size_t)0x1000 * 24 * 4);                      // Image.Color's APMs {0x1000}, 3 x {0x10000} :8223
+    for (int k = 1; k < 4; k++) T.col_apm[k] = (uint32_t*)up(v.data(), v.size() * 4);
   }
   return true;
 }

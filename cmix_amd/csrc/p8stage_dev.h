@@ -38,10 +38,21 @@ P8_HD int p8s_sm32(uint32_t* t, int* cxt, int y, int cx, int limit) {   // State
   return (int)(t[cx] >> 20);
 }
 
-// one lane, one step. x: the step's 1552-vector; order: the order-N map's return value of this step.
-P8_HD void p8s_lane_step(const P8LanesDev* d, P8LaneRegs* r, int l, uint32_t op, int y, int order, int16_t* x) {
-  const P8LaneDev* L = &d->lane[l];
+// the small maps of one image model (p8_rec.h P8XLayout): the same lanes, a table of their own, op words from the chunk's xops rows
+struct P8XLanesDev {
+  int nlanes, model;
+  P8LaneDev lane[P8_XL_NLANE];
+  P8LaneRegs regs[P8_XL_NLANE];   // home between chunks
+  const uint8_t* nex; const int16_t* stretch;
+};
+
+// one lane, one step. x: the step's 1552-vector; order: the order-N map's return value of this step; lim_off: the first input
+// position that is NOT this table's at this step (a step of an image model ends the generic layout at the common prefix: a generic
+// lane behind it neither runs nor writes; P8_NX otherwise).
+struct P8LaneTabs { const uint8_t* nex; const int16_t* stretch; };
+P8_HD void p8s_lane_step_t(const P8LaneDev* L, const P8LaneTabs* d, P8LaneRegs* r, uint32_t op, int y, int order, int16_t* x, int lim_off) {
   const int kind = L->q.kind;
+  if (L->q.off >= lim_off) return;
   int16_t* o = x + L->q.off;
   if (kind == P8L_DIRECT) { if (op & P8OP_MIX) o[0] = (int16_t)(op & 0xffffu); return; }
   if (kind == P8L_NONE) return;
@@ -102,12 +113,18 @@ P8_HD void p8s_lane_step(const P8LanesDev* d, P8LaneRegs* r, int l, uint32_t op,
   r->bcount++; r->B += r->B + 1;
   if (r->bcount == L->q.bits_per_ctx) r->bcount = r->B = 0;
 }
+P8_HD void p8s_lane_step(const P8LanesDev* d, P8LaneRegs* r, int l, uint32_t op, int y, int order, int16_t* x, int lim_off = P8_NX) {
+  const P8LaneTabs tb = {d->nex, d->stretch};
+  p8s_lane_step_t(&d->lane[l], &tb, r, op, y, order, x, lim_off);
+}
 
 // ---------------------------------------------------------------- tail of Predictor::update
 struct P8TailDev {
   uint32_t* apm[4]; int apm_cxt[4];      // TEXT: four APM (StateMap32 of 0x10000 * 24 cells) :691-712
   uint16_t* apm1[3]; int apm1_idx[3];    // TEXT: three APM1 (0x10000 * 33 cells) :600-621
   uint16_t* gen[7]; int gen_idx[7];      // other blocks: seven APM1 (0x2000 and 6 x 0x10000 contexts)
+  uint32_t* col_apm[4]; int col_cxt[4];  // IMAGE24 / IMAGE32 (Image.Color :8222-8225): four APM (0x1000, 3 x 0x10000 contexts) ...
+  uint16_t* col_apm1[2]; int col_idx[2]; // ... and two APM1 (0x10000)
   uint64_t misses;
   int pr;                                 // the last final prediction (12 bits)
   const int16_t* stretch; const int16_t* squash;   // squash: index d + 2048
@@ -178,6 +195,28 @@ P8_HD int p8s_tail_c(const P8ApmRec* a, int pr0, const int* res, float* o) {
   o[k++] = (float)pr * cf;
   pr = (pr + avg + 1) >> 1;
   o[k++] = (float)pr * cf;
+  return pr;
+}
+// Image.Color (:8299-8314), the chain behind the mixer for IMAGE24 / IMAGE32 steps: writes the 10 exported values at o[] and returns
+// the final prediction. A serial chain (one lane): image steps are rare and their mixer is a plain one (p8stage.hip).
+P8_HD int p8s_tail_color(P8TailDev* d, const P8ApmRec* a, int y, int pr0, float* o) {
+  const int16_t* st = d->stretch;
+  const float cf = (float)(1.0 / 4095);
+  const int lim = a->limit;
+  int pr = p8s_apm(d->col_apm[0], &d->col_cxt[0], st, y, pr0, a->c[0] | (int)(d->misses & 0xF), lim);
+  int pr1 = p8s_apm(d->col_apm[1], &d->col_cxt[1], st, y, pr0, a->c[1], lim);
+  int pr2 = p8s_apm(d->col_apm[2], &d->col_cxt[2], st, y, pr0, a->c[2], lim);
+  const int pr3 = p8s_apm(d->col_apm[3], &d->col_cxt[3], st, y, pr0, a->c[3], lim);
+  o[0] = (float)pr0 * cf; o[1] = (float)pr * cf; o[2] = (float)pr1 * cf; o[3] = (float)pr2 * cf; o[4] = (float)pr3 * cf;
+  const int avg = (pr0 + pr1 + pr2 + pr3 + 2) >> 2;
+  o[5] = (float)avg * cf;
+  pr1 = p8s_apm1(d->col_apm1[0], &d->col_idx[0], st, y, pr, a->c[4], 7);
+  pr2 = p8s_apm1(d->col_apm1[1], &d->col_idx[1], st, y, pr, a->c[5], 7);
+  o[6] = (float)pr1 * cf; o[7] = (float)pr2 * cf;
+  pr = (pr * 2 + pr1 * 3 + pr2 * 3 + 4) >> 3;
+  o[8] = (float)pr * cf;
+  pr = (pr + avg + 1) >> 1;
+  o[9] = (float)pr * cf;
   return pr;
 }
 #endif

@@ -55,6 +55,54 @@ def header_lookalikes():
     return b"".join(parts)
 
 
+def photo(w, h, planes, seed):
+    """a synthetic photograph: smooth gradients, a few edges, sensor-like noise; [h, w, planes] u8"""
+    r = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    img = np.empty((h, w, planes))
+    for c in range(planes):
+        a, b, ph = r.uniform(0.5, 2.5), r.uniform(0.5, 2.5), r.uniform(0, 6)
+        img[:, :, c] = 128 + 70 * np.sin(xx / w * 3 * a + ph) * np.cos(yy / h * 2 * b) + 40 * ((xx * 0.7 + yy) % 37 > 18) + r.normal(0, 2.5, (h, w))
+    if planes == 4:
+        img[:, :, 3] = 255
+    return img.clip(0, 255).astype(np.uint8)
+
+
+def bmp_file(img):
+    """bottom-up BITMAPINFOHEADER file of an [h, w, 3 or 4] image (rows padded to 4 bytes)"""
+    h, w, planes = img.shape
+    row = (w * planes + 3) & ~3
+    pix = b"".join(img[y].tobytes() + bytes(row - w * planes) for y in range(h - 1, -1, -1))
+    return (b"BM" + (54 + len(pix)).to_bytes(4, "little") + bytes(4) + (54).to_bytes(4, "little") + (40).to_bytes(4, "little") + w.to_bytes(4, "little") +
+            h.to_bytes(4, "little") + (1).to_bytes(2, "little") + (8 * planes).to_bytes(2, "little") + bytes(4) + len(pix).to_bytes(4, "little") + bytes(16) + pix)
+
+
+def preprocessed(payload):
+    """the stream the reference's preprocessor (preprocessor.cpp:568 Encode) hands the predictor for a file: block headers, detected
+    types (HDR + IMAGE24 / IMAGE32 for a BMP), its transforms -- through oracle/_ref/libcmixref.so (oracle/ref_harness.cpp)"""
+    import tempfile
+    L = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libcmixref.so"))
+    L.ref_preprocess_encode.argtypes = [C.c_char_p] * 3
+    d = tempfile.mkdtemp()
+    open(os.path.join(d, "in"), "wb").write(payload)
+    assert L.ref_preprocess_encode(os.path.join(d, "in").encode(), os.path.join(d, "out").encode(), os.path.join(d, "tmp").encode()) == 0
+    return open(os.path.join(d, "out"), "rb").read()
+
+
+def image_streams():
+    """24 / 32-bit images (im24bitModel, paq8.cpp:5001-5353): as IMAGE24 / IMAGE32 blocks the preprocessor makes of BMP files between
+    other data (block path, contextModel2 :8165-8166), and as a BMP file inside a DEFAULT block (`cmix -n`: no preprocessing; paq8's own
+    header detector imgModel :5386-5504 switches the model on and off). Row widths are multiples of the pixel size (see p8f_image.c)."""
+    from cmix_amd import synth
+    from make_golden import default_block
+    text = synth.enwik_like(700, 11)
+    return {
+        "bmp24_14k": preprocessed(text[:300] + bmp_file(photo(96, 48, 3, 1)) + text[300:]),
+        "bmp32_8k": preprocessed(text[:200] + bmp_file(photo(48, 40, 4, 2)) + bytes(range(256))),
+        "bmp24_raw_9k": default_block(text[:150] + bmp_file(photo(64, 44, 3, 3)) + text[150:400]),
+    }
+
+
 def streams():
     from cmix_amd import synth
     from make_golden import default_block, text_block
@@ -72,6 +120,7 @@ def streams():
         # the head of the bench shard (round 3: rich alphabet, V = 205): multi-byte UTF-8 from 46 script blocks, all of ASCII
         "rich_16k": text_block(synth.enwik_like(16384 - 6, 1000, rich=True)),
         "hdrs_4k": default_block(header_lookalikes()),
+        **image_streams(),
     }
 
 

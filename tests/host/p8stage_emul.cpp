@@ -36,6 +36,11 @@ struct Emul {
   P8DmcShared dsh;
   uint64_t steps = 0;
   int last_bit = 0;
+  // the image models: their one ContextMap each runs the first design's per-context body (p8cm_dev.h) in the reference's order; the
+  // process-wide rnd() stream changes hands whenever a byte's model differs from the previous byte's (as between two kernels)
+  P8CmShared xsh[P8_NMODEL - 1];
+  int fam_owner = 0;      // whose copy of the generator state is current: 0 the generic family, m an image model
+  int last_byte = 0;      // the last whole byte of the stream (ContextMap's c1)
   uint64_t fam_serial = 0, cm2_serial = 0;
   int late = 0;           // 1: the DECODER's order of operations (cmx_late.h): the front end emits a step's records only after the bit before it has been
                           // handed in, and the maps' uniform registers take that bit at the top of the step (p8d_bit_y, p8f_uni_tail + p8f_uni_head)
@@ -74,6 +79,7 @@ void* p8s_create(int level) {
     p8f_front_free(e->front); delete e; return nullptr;
   }
   e->fsh.r = e->S.fam.regs; e->fsh.rnd = e->S.fam.rnd;
+  for (int m = 0; m < P8_NMODEL - 1; m++) { e->xsh[m].r = e->S.xfam[m].regs; e->xsh[m].rnd = e->S.xfam[m].rnd; }
   e->use_v1 = getenv("CMX_P8FAM_V1") != nullptr;
   for (int k = 0; k < P8_NCM2; k++) e->c2[k] = new P8Cm2V2Shared();
   e->f2mem.resize(sizeof(P8FamShared) + (size_t)e->S.fam.nslots * 512 + 64);
@@ -122,10 +128,18 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
   std::vector<uint16_t> fchk(n * L.fam_slots), c2chk[P8_NCM2];
   std::vector<int32_t> sel(T * P8_NSEL);
   std::vector<P8ApmRec> apm(T);
-  P8Chunk c;
+  P8Chunk c = P8Chunk();
   c.fam_ctx = fctx.data(); c.fam_chk = fchk.data();
   for (int k = 0; k < P8_NCM2; k++) { c2ctx[k].resize(n * L.cm2_count[k]); c2chk[k].resize(n * L.cm2_count[k]); c.cm2_ctx[k] = c2ctx[k].data(); c.cm2_chk[k] = c2chk[k].data(); }
   c.ops = ops.data(); c.sel = sel.data(); c.apm = apm.data();
+  std::vector<uint8_t> model(n, 0);
+  std::vector<uint32_t> xops, xfctx;
+  std::vector<uint16_t> xfchk;
+  c.model = model.data();
+  if (!e->late) {   // (the decoder's form of the image models is not built: the front end refuses such a byte when it has nowhere to put its records)
+    xops.assign(T * P8_XL_NLANE, 0); xfctx.assign(n * P8_XL_MAXS, 0); xfchk.assign(n * P8_XL_MAXS, 0);
+    c.xops = xops.data(); c.xfam_ctx = xfctx.data(); c.xfam_chk = xfchk.data();
+  }
   std::vector<uint8_t> bits(T), order(T, 0);
   for (size_t i = 0; i < T; i++) bits[i] = (bytes[i >> 3] >> (7 - (i & 7))) & 1;
   if (!e->late) {
@@ -159,9 +173,29 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
     }
     int16_t* xr = x.data() + t * P8_NX;
     float* orow = out + t * P8_NOUT;
+    const int md = c.model[t >> 3];                      // the byte's model (its record exists from the byte's first step on)
+    const int lim_off = md ? L.xl[md - 1].prefix_nx : P8_NX;
+    if (md != e->fam_owner && !e->use_v1) {               // the generator changes hands: what a kernel boundary does on the device
+      if (e->fam_owner == 0) { for (int tid = 0; tid < 256; tid++) p8f_store(&S.fam, S.fam_home, S.fam.sm, e->f2, e->f2_i, tid, 256); e->xsh[md - 1].rnd = S.fam.rnd; }
+      else if (md == 0) {
+        S.fam.rnd = e->xsh[e->fam_owner - 1].rnd;
+        for (int tid = 0; tid < 256; tid++) p8f_load(&S.fam, S.fam_home, S.fam.sm, e->f2, tid, 256);
+        e->f2_lk = 0; e->f2_i = e->f2_prev_i = (uint32_t)S.fam.rnd.i; f_run.lk = 0;
+      } else e->xsh[md - 1].rnd = e->xsh[e->fam_owner - 1].rnd;
+      e->fam_owner = md;
+    } else if (md != e->fam_owner) {
+      if (e->fam_owner == 0) e->xsh[md - 1].rnd = e->fsh.rnd;
+      else if (md == 0) e->fsh.rnd = e->xsh[e->fam_owner - 1].rnd;
+      else e->xsh[md - 1].rnd = e->xsh[e->fam_owner - 1].rnd;
+      e->fam_owner = md;
+    }
     // the uniform registers advance on every step, the lanes run once a byte boundary has been passed
     P8Cm2Bit cu[P8_NCM2];
+    const int md_pre = c.model[t >> 3];
     for (int k = 0; k < P8_NCM2; k++) {
+      // TextModel's and exeModel's ContextMap2 keep their OWN partial byte (ContextMap2::mix :1305-1309): a step that does not call them
+      // leaves it where it was -- only the bit that precedes their next call is the stream's
+      if (k > 0 && md_pre) { cu[k] = P8Cm2Bit(); c_last_y[k] = bits[t]; continue; }
       if (e->late) { cu[k] = p8d_bit_y(&S.cm2[k], c.cm2_ctx[k], c.cm2_chk[k], t ? y : c_last_y[k], x.data(), (int)t, &run_bits[k]); if (t + 1 == T) c_last_y[k] = bits[t]; }
       else cu[k] = p8d_bit(&S.cm2[k], c.cm2_ctx[k], c.cm2_chk[k], bits.data(), x.data(), (int)t, &run_bits[k], &c_last_y[k]);
     }
@@ -169,6 +203,7 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
     (void)fu_pre;
     if (g >= 8 && e->use_v1) {
       for (int k = 0; k < P8_NCM2; k++) {   // instance 0 first: the family needs its return value
+        if (k > 0 && md) continue;          // TextModel's and exeModel's maps are not called in an image model's step (:8161-8166)
         P8Cm2Dev* d = &S.cm2[k];
         for (int i = d->C - 1; i >= 0; i--) p8d_touch(d, &e->csh[k], cu[k], i);
         for (int i = d->C - 1; i >= 0; i--) p8d_conflict(d, &e->csh[k], i);
@@ -178,6 +213,7 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
       }
     } else if (g >= 8) {   // second design: the control flow of cmx_p8s_cm2v2_kernel
       for (int k = 0; k < P8_NCM2; k++) {
+        if (k > 0 && md) continue;
         P8Cm2Dev* d = &S.cm2[k];
         P8Cm2V2Shared* sh = e->c2[k];
         const bool look = cu[k].bpos == 0 || cu[k].bpos == 2 || cu[k].bpos == 5;
@@ -195,7 +231,7 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
     }
     if (e->use_v1) {
     const P8CmBit fu = p8d_cm_bit(&S.fam, c.fam_ctx, c.fam_chk, bits.data(), x.data(), order.data(), (int)t, &f_last_y, &f_c1);
-    if (g >= 8) {
+    if (g >= 8 && !md) {
       P8CmDev* d = &S.fam;
       for (int s = d->nslots - 1; s >= 0; s--) p8d_cm_touch(d, &e->fsh, fu, s);
       for (int s = d->nslots - 1; s >= 0; s--) p8d_cm_check(d, &e->fsh, s);
@@ -208,9 +244,13 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
       P8FamShared* sh = e->f2;
       const int SS = d->nslots;
       if (e->late && t > 0) p8f_uni_tail(&f_run, (int)((t - 1) & 7), y);   // (t == 0: f_run.last_y is the carried bit, as the kernel takes it from the box)
-      const P8FamUni fu = e->late ? p8f_uni_head(c.fam_ctx, c.fam_chk, x.data(), order.data(), (int)t, &f_run, e->f2_i)
-                                  : p8f_uni_inc(d, c.fam_ctx, c.fam_chk, bits.data(), x.data(), order.data(), (int)t, &f_run, e->f2_i);
-      if (g >= 8) {
+      P8FamUni fu = P8FamUni();
+      if (md) {   // an image model's step: the generic family only follows the bits (last bit, partial byte, last whole byte)
+        if ((t & 7) == 0) f_run.c0 = 1;
+        p8f_uni_tail(&f_run, (int)(t & 7), bits[t]);
+      } else fu = e->late ? p8f_uni_head(c.fam_ctx, c.fam_chk, x.data(), order.data(), (int)t, &f_run, e->f2_i)
+                          : p8f_uni_inc(d, c.fam_ctx, c.fam_chk, bits.data(), x.data(), order.data(), (int)t, &f_run, e->f2_i);
+      if (g >= 8 && !md) {
         static P8FamTmp tmp[P8CM_MAXS];
         for (int s = SS - 1; s >= 0; s--) { p8f_lane(d, s, &tmp[s]); tmp[s].cx = p8f_ctx(d, fu, s); tmp[s].ck = p8f_chk(d, fu, s); p8f_phase1(d, sh, fu, s, &tmp[s]); }
         for (uint32_t base = e->f2_prev_i + P8F_LOOK + 1; base <= e->f2_i + P8F_LOOK; base += 24)
@@ -290,10 +330,24 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
       }
     }
     if (g == 0) { memcpy(orow, S.tail.out, sizeof S.tail.out); continue; }   // no step 0: the constructor's 0.5
-    for (int l = S.lanes.nlanes - 1; l >= 0; l--) p8s_lane_step(&S.lanes, &S.lanes.regs[l], l, c.ops[t * P8_NLANE + l], y, order[t], xr);
-    for (int tid = P8DMC_THREADS - 1; tid >= 0; tid--) p8d_dmc_step1(&S.dmc, &e->dsh, tid, y);
-    for (int tid = P8DMC_THREADS - 1; tid >= 0; tid--) p8d_dmc_step2(&S.dmc, &e->dsh, tid, (int)(g & 7), xr + L.dmc_off);
-    for (int tid = P8DMC_THREADS - 1; tid >= 0; tid--) p8d_dmc_step3(&S.dmc, &e->dsh, tid);
+    for (int l = S.lanes.nlanes - 1; l >= 0; l--) p8s_lane_step(&S.lanes, &S.lanes.regs[l], l, c.ops[t * P8_NLANE + l], y, order[t], xr, lim_off);
+    if (!md) {
+      for (int tid = P8DMC_THREADS - 1; tid >= 0; tid--) p8d_dmc_step1(&S.dmc, &e->dsh, tid, y);
+      for (int tid = P8DMC_THREADS - 1; tid >= 0; tid--) p8d_dmc_step2(&S.dmc, &e->dsh, tid, (int)(g & 7), xr + L.dmc_off);
+      for (int tid = P8DMC_THREADS - 1; tid >= 0; tid--) p8d_dmc_step3(&S.dmc, &e->dsh, tid);
+    } else {   // the image model's own maps: its ContextMap in the reference's context order, then its lane table
+      P8CmDev* xd = &S.xfam[md - 1];
+      P8CmBit u;
+      const int bp = (int)(t & 7);
+      int c0 = 1;
+      for (int j = 0; j < bp; j++) c0 = c0 * 2 + bits[t - bp + j];
+      u.y = y; u.bp = bp; u.c0 = c0; u.c1 = (t >> 3) ? bytes[(t >> 3) - 1] : e->last_byte; u.order = 0;
+      u.ctx = c.xfam_ctx + (t >> 3) * P8_XL_MAXS; u.chk = c.xfam_chk + (t >> 3) * P8_XL_MAXS; u.out = xr;
+      for (int sl = 0; sl < xd->nslots; sl++) p8d_cm_ctx(xd, &e->xsh[md - 1], u, sl, nullptr);
+      P8XLanesDev* XD = &S.xlanes[md - 1];
+      const P8LaneTabs tb = {XD->nex, XD->stretch};
+      for (int l = XD->nlanes - 1; l >= 0; l--) p8s_lane_step_t(&XD->lane[l], &tb, &XD->regs[l], c.xops[t * P8_XL_NLANE + l], y, order[t], xr, P8_NX);
+    }
     // ---- mixer + tail (Mixer::p :553-581, Predictor::update :8281-8358) ----
     P8TailDev& Tl = S.tail;
     Tl.misses += Tl.misses + (uint64_t)((Tl.pr >> 11) != y);
@@ -301,15 +355,17 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
     memset(xs, 0, sizeof xs);
     int nx = P8_NX;
     if (g < 8) { nx = S.mix.nx_first; for (int i = 0; i < nx; i++) xs[i] = xr[S.mix.first_map[i]]; }
+    else if (md) { nx = c.apm[t].c[8]; memcpy(xs, xr, (size_t)nx * 2); }   // an image model's step: fewer inputs, fewer weight sets (p8_rec.h)
     else memcpy(xs, xr, P8_NX * 2);
+    const int nsel = md ? (int)c.apm[t].c[9] : P8_NSEL;
     const float cf = (float)(1.0 / 4095);
     for (int i = 0; i < nx; i++) Tl.out[i] = (float)p8s_squash(Tl.squash, xs[i]) * cf;
     const int npad = (nx + 7) & ~7;
     int row[P8_NSEL], pr[P8_NSEL];
     int16_t st[32];
     memset(st, 0, sizeof st);
-    for (int i = 0; i < P8_NSEL; i++) {
-      row[i] = p8s_sel(i, c.sel[t * P8_NSEL + i], order[t], Tl.pr);
+    for (int i = 0; i < nsel; i++) {
+      row[i] = md ? c.sel[t * P8_NSEL + i] : p8s_sel(i, c.sel[t * P8_NSEL + i], order[t], Tl.pr);
       const int dsum = dot(xs, S.mix.wx + (size_t)row[i] * P8_NX, npad);
       pr[i] = p8s_squash(Tl.squash, (int32_t)((uint32_t)dsum * 9u) >> 9);
       st[i] = Tl.stretch[pr[i]];
@@ -317,14 +373,18 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
     }
     const int p2 = p8s_squash(Tl.squash, dot(st, S.mix.wx2, 32) >> 9);
     int res[8];
-    for (int j = 3; j >= 0; j--) p8s_tail_a(&Tl, &c.apm[t], y, p2, j, res);
-    for (int j = 2; j >= 0; j--) p8s_tail_b(&Tl, &c.apm[t], y, p2, j, res);
-    const int fin = p8s_tail_c(&c.apm[t], p2, res, Tl.out + nx + P8_NSEL);
+    int fin;
+    if (c.apm[t].text == P8_APM_COLOR) fin = p8s_tail_color(&Tl, &c.apm[t], y, p2, Tl.out + nx + nsel);
+    else {
+      for (int j = 3; j >= 0; j--) p8s_tail_a(&Tl, &c.apm[t], y, p2, j, res);
+      for (int j = 2; j >= 0; j--) p8s_tail_b(&Tl, &c.apm[t], y, p2, j, res);
+      fin = p8s_tail_c(&c.apm[t], p2, res, Tl.out + nx + nsel);
+    }
     Tl.pr = fin;
     memcpy(orow, Tl.out, sizeof Tl.out);
     // training with this step's bit (the reference does it at the start of the next step: nothing reads the rows in between)
     const int yb = bits[t];
-    for (int i = 0; i < P8_NSEL; i++) train(xs, S.mix.wx + (size_t)row[i] * P8_NX, npad, ((yb << 12) - pr[i]) * 7);
+    for (int i = 0; i < nsel; i++) train(xs, S.mix.wx + (size_t)row[i] * P8_NX, npad, ((yb << 12) - pr[i]) * 7);
     train(st, S.mix.wx2, 32, ((yb << 12) - p2) * 7);
   }
   if (e->late && T) {   // the chunk's last bit: into the run registers a later chunk starts from, and to the front end
@@ -333,7 +393,11 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
   }
   if (!e->use_v1) { f_last_y = f_run.last_y; f_c1 = f_run.c1; }
   S.fam.last_y = f_last_y; S.fam.c1 = f_c1;
-  if (!e->use_v1) for (int tid = 0; tid < 256; tid++) p8f_store(&S.fam, S.fam_home, S.fam.sm, e->f2, e->f2_i, tid, 256);
+  if (!e->use_v1) {
+    if (e->fam_owner == 0) for (int tid = 0; tid < 256; tid++) p8f_store(&S.fam, S.fam_home, S.fam.sm, e->f2, e->f2_i, tid, 256);
+    else { S.fam.rnd = e->xsh[e->fam_owner - 1].rnd; e->fam_owner = 0; }   // (the generic family's own state was stored when the generator left it)
+  } else if (e->fam_owner) { e->fsh.rnd = e->xsh[e->fam_owner - 1].rnd; e->fam_owner = 0; }
+  if (n) e->last_byte = bytes[n - 1];
   for (int k = 0; k < P8_NCM2; k++) { S.cm2[k].bits = run_bits[k]; S.cm2[k].last_y = c_last_y[k]; if (!e->use_v1) S.cm2[k].regs = e->c2[k]->base.r; }
   e->steps += T; e->last_bit = T ? bits[T - 1] : e->last_bit;
   return 0;
