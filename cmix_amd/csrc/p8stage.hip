@@ -37,8 +37,11 @@ extern "C" int cmx_device_count(void);
 
 // ---------------------------------------------------------------- role kernels
 // skip: chunk-local steps before the stream's first byte boundary (the maps have no contexts yet, reference :1072 loop over cn == 0)
+// model (TextModel's and exeModel's maps in a chunk that holds image-model bytes, else nullptr): a step of an image model does not call these
+// maps -- their state, their own partial byte included (ContextMap2::mix :1305-1309), stays where it was; only the bit before their
+// next call is the stream's.
 __global__ __launch_bounds__(P8CM2_MAXC) void cmx_p8s_cm2v2_kernel(P8Cm2Dev* d, const uint32_t* ctx, const uint16_t* chk, const uint8_t* bits, int16_t* x,
-                                                                  uint8_t* order_out, int nbits, int skip) {
+                                                                  uint8_t* order_out, int nbits, int skip, const uint8_t* model) {
   __shared__ __attribute__((aligned(16))) P8Cm2V2Shared sh;
   const int i = threadIdx.x, C = d->C;
   p8c2_load(d, &sh, i, P8CM2_MAXC);
@@ -48,6 +51,7 @@ __global__ __launch_bounds__(P8CM2_MAXC) void cmx_p8s_cm2v2_kernel(P8Cm2Dev* d, 
   if (i < C) p8c2_reload(d, &sh, i);
   __syncthreads();
   for (int t = 0; t < nbits; t++) {
+    if (model && model[t >> 3]) { last_y = bits[t]; continue; }
     const P8Cm2Bit u = p8d_bit(d, ctx, chk, bits, x, t, &run_bits, &last_y);
     if (t < skip) { if (order_out && i == 0) order_out[t] = 0; continue; }
     const bool look = u.bpos == 0 || u.bpos == 2 || u.bpos == 5;
@@ -274,26 +278,31 @@ __global__ __launch_bounds__(P8FAM_THREADS) void cmx_p8s_fam2_late_kernel(P8CmDe
 // The (up to 64) learners are independent of each other and of six different kinds (p8s_lane_step switches on the lane's kind): on one
 // wavefront the kinds run one after the other every step. 8 wavefronts of 8 learners each keep most kinds in wavefronts of their own.
 constexpr int P8LANES_THREADS = 512;
+// model / lim (a chunk that holds image-model bytes; else nullptr): in such a byte's steps only the lanes of the common prefix -- input
+// positions below lim[model - 1] -- belong to the generic layout; the others neither run nor write (their positions are the image model's).
+struct P8LaneLim { int lim[P8_NMODEL - 1]; };
 __global__ __launch_bounds__(P8LANES_THREADS) void cmx_p8s_lanes_kernel(P8LanesDev* d, const uint32_t* ops, const uint8_t* bits, const uint8_t* order, int16_t* x,
-                                                                       int nbits, int t0) {
+                                                                       int nbits, int t0, const uint8_t* model, P8LaneLim lim) {
   const int ln = threadIdx.x & 63, l = ln < 8 ? 8 * (int)(threadIdx.x >> 6) + ln : P8_NLANE;
   if (l >= P8_NLANE) return;
   P8LaneRegs r = d->regs[l];
   const int last_y = d->last_y;
   for (int t = t0; t < nbits; t++) {
     const int y = t ? bits[t - 1] : last_y;
-    if (l < d->nlanes) p8s_lane_step(d, &r, l, ops[(size_t)t * P8_NLANE + l], y, order[t], x + (size_t)t * P8_NX);
+    const int md = model ? model[t >> 3] : 0;
+    if (l < d->nlanes) p8s_lane_step(d, &r, l, ops[(size_t)t * P8_NLANE + l], y, order[t], x + (size_t)t * P8_NX, md ? lim.lim[md - 1] : (int)P8_NX);
   }
   d->regs[l] = r;
   if (l == 0) d->last_y = bits[nbits - 1];
 }
 
-__global__ __launch_bounds__(P8DMC_THREADS) void cmx_p8s_dmc_kernel(P8DmcDev* d, const uint8_t* bits, int16_t* x, int off, int nbits, int t0) {
+__global__ __launch_bounds__(P8DMC_THREADS) void cmx_p8s_dmc_kernel(P8DmcDev* d, const uint8_t* bits, int16_t* x, int off, int nbits, int t0, const uint8_t* model) {
   __shared__ P8DmcShared sh;
   const int tid = threadIdx.x;
   const uint32_t done = d->bits_done;
   const int last_y = d->last_y;
   for (int t = t0; t < nbits; t++) {
+    if (model && model[t >> 3]) continue;   // a step of an image model does not call the forest (uniform: no barrier is skipped by part of the workgroup)
     const int y = t ? bits[t - 1] : last_y;
     p8d_dmc_step1(d, &sh, tid, y);
     __syncthreads();
@@ -1006,6 +1015,169 @@ __global__ __launch_bounds__(MX_THREADS) void cmx_p8s_mix4_kernel(const P8MixDev
   }
 }
 
+// ---------------------------------------------------------------- the image models' role kernels (p8_rec.h P8XLayout)
+// A chunk that holds bytes of an image model is rare and runs its roles one after the other on one stream (cmx_p8stage_run): these
+// kernels are plain -- correctness first; an image byte still costs far less than on the reference's CPU path.
+//
+// The model's one ContextMap: the first design's four phases (p8cm_dev.h: buckets touched / overlap check + draw ranks / the generator's
+// values / every context with "its" draw, or the reference's serial walk on lane 0 when two contexts meet in a bucket), one lane per context.
+// last_y / c1: the bit and the whole byte before the segment (the host knows them); the generator arrives in d->rnd (cmx_p8s_rnd_copy_kernel).
+__global__ __launch_bounds__(64) void cmx_p8s_xfam_kernel(P8CmDev* d, const uint32_t* xctx, const uint16_t* xchk, const uint8_t* bits, int16_t* x, int nbits, int last_y, int c1_in) {
+  __shared__ P8CmShared sh;
+  const int s = threadIdx.x, S = d->nslots;
+  if (s < S) { sh.r.cp[s] = d->regs.cp[s]; sh.r.cp0[s] = d->regs.cp0[s]; sh.r.runp[s] = d->regs.runp[s]; sh.r.sm_cxt[s] = d->regs.sm_cxt[s]; }
+  sh.rnd.table[s] = d->rnd.table[s];
+  if (s == 0) sh.rnd.i = d->rnd.i;
+  __syncthreads();
+  int y = last_y, c1 = c1_in, c0 = 1;
+  for (int t = 0; t < nbits; t++) {
+    const int bp = t & 7;
+    if (bp == 0) c0 = 1;
+    P8CmBit u;
+    u.y = y; u.bp = bp; u.c0 = c0; u.c1 = c1; u.order = 0;
+    u.ctx = xctx + (size_t)(t >> 3) * P8_XL_MAXS; u.chk = xchk + (size_t)(t >> 3) * P8_XL_MAXS; u.out = x + (size_t)t * P8_NX;
+    if (s < S) p8d_cm_touch(d, &sh, u, s);
+    __syncthreads();
+    if (s < S) p8d_cm_check(d, &sh, s);
+    __syncthreads();
+    p8d_cm_draw(d, &sh, s);
+    __syncthreads();
+    if (s < S) p8d_cm_run(d, &sh, u, s);
+    __syncthreads();
+    const int bit = bits[t];
+    y = bit; c0 = c0 * 2 + bit;
+    if (bp == 7) c1 = c0 & 0xff;
+  }
+  if (s < S) { d->regs.cp[s] = sh.r.cp[s]; d->regs.cp0[s] = sh.r.cp0[s]; d->regs.runp[s] = sh.r.runp[s]; d->regs.sm_cxt[s] = sh.r.sm_cxt[s]; }
+  d->rnd.table[s] = sh.rnd.table[s];
+  if (s == 0) d->rnd.i = sh.rnd.i;
+}
+// the process-wide rnd() stream (:152-165) changes hands between the generic family and an image model's ContextMap
+__global__ __launch_bounds__(64) void cmx_p8s_rnd_copy_kernel(P8CmDev* dst, const P8CmDev* src) {
+  dst->rnd.table[threadIdx.x] = src->rnd.table[threadIdx.x];
+  if (threadIdx.x == 0) dst->rnd.i = src->rnd.i;
+}
+// the generic family after bytes it was not called for: the bit and the whole byte before its next step are the stream's (ContextMap::mix
+// reads the globals y and buf(1), :1072-1145)
+__global__ void cmx_p8s_fam_resume_kernel(P8CmDev* d, int last_y, int c1) { d->last_y = last_y; d->c1 = c1; }
+
+// the model's small maps: one lane each, in the steps of its bytes
+__global__ __launch_bounds__(P8_XL_NLANE) void cmx_p8s_xlanes_kernel(P8XLanesDev* d, const uint32_t* xops, const uint8_t* bits, const uint8_t* order, int16_t* x,
+                                                                     const uint8_t* model, int nbits, int t0, int last_y) {
+  const int l = threadIdx.x;
+  if (l >= d->nlanes) return;
+  P8LaneRegs r = d->regs[l];
+  const P8LaneTabs tb = {d->nex, d->stretch};
+  const int mine = d->model;
+  for (int t = t0; t < nbits; t++) {
+    if (model[t >> 3] != mine) continue;
+    const int y = t ? bits[t - 1] : last_y;
+    p8s_lane_step_t(&d->lane[l], &tb, &r, xops[(size_t)t * P8_XL_NLANE + l], y, order[t], x + (size_t)t * P8_NX, P8_NX);
+  }
+  d->regs[l] = r;
+}
+
+// The mixer of an image model's steps (one segment of consecutive such bytes): the step's nx inputs (P8ApmRec.c[8]; zeros behind them, which
+// neither the dot products nor the training see), its nsel weight sets (c[9]; absolute rows, no device terms) one per wavefront, the second layer,
+// the model's APM chain on one lane (p8s_tail_color), the export: nx + nsel + 10 values back to back, the rest of the 1591 as they were
+// (AddPrediction() counts on, :504-510). Same packed arithmetic as cmx_p8s_mix4_kernel. T: the state the generic mixer leaves and takes over.
+constexpr int XMX_THREADS = 1024;
+__global__ __launch_bounds__(XMX_THREADS) void cmx_p8s_xmix_kernel(const P8MixDev* M, P8TailDev* T, const int16_t* x, const int32_t* sel, const P8ApmRec* apm, const uint8_t* bits,
+                                                                 float* out, size_t ld, int nbits, int last_y) {
+  __shared__ __attribute__((aligned(16))) uint32_t xs[P8_NX / 2];
+  __shared__ float outs[P8_NOUT];
+  __shared__ int pr_s[16], p_s, fin_s;
+  __shared__ uint32_t st_s[16];
+  __shared__ int16_t squash[4096], stretch[4096];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < 4096; i += XMX_THREADS) { squash[i] = M->squash[i]; stretch[i] = M->stretch[i]; }
+  for (int i = tid; i < P8_NOUT; i += XMX_THREADS) outs[i] = T->out[i];
+  const float cf = (float)(1.0 / 4095);
+  unsigned long long misses = T->misses;
+  int lastpr = T->pr;
+  MX_GLOBAL int16_t* const wx = (MX_GLOBAL int16_t*)M->wx; MX_GLOBAL int16_t* const wx2 = (MX_GLOBAL int16_t*)M->wx2;
+  __syncthreads();
+  for (int t = 0; t < nbits; t++) {
+    const P8ApmRec* a = apm + t;
+    const int nx = a->c[8], nsel = a->c[9];
+    const int y = t ? (int)bits[t - 1] : last_y;
+    misses += misses + (unsigned long long)((lastpr >> 11) != y);   // Predictor::update's first line (:8250)
+    const int16_t* xr = x + (size_t)t * P8_NX;
+    for (int i = tid; i < P8_NX / 2; i += XMX_THREADS) {
+      const uint32_t lo = 2 * i < nx ? (uint32_t)(uint16_t)xr[2 * i] : 0u, hi = 2 * i + 1 < nx ? (uint32_t)(uint16_t)xr[2 * i + 1] : 0u;
+      xs[i] = lo | (hi << 16);
+    }
+    __syncthreads();
+    for (int i = tid; i < nx; i += XMX_THREADS) outs[i] = (float)p8s_squash(squash, reinterpret_cast<const int16_t*>(xs)[i]) * cf;
+    uint4 w[4];
+    int my_pr = 2048, row = 0;
+    if (wave < nsel) {
+      row = sel[(size_t)t * P8_NSEL + wave];
+      const MX_GLOBAL int16_t* wr = wx + (size_t)row * P8_NX;
+      uint32_t acc = 0;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int grp = lane + 64 * g;
+        w[g] = grp < MX_GROUPS ? mx_gload4(wr, grp) : make_uint4(0, 0, 0, 0);
+        const uint4 xv = grp < MX_GROUPS ? reinterpret_cast<const uint4*>(xs)[grp] : make_uint4(0, 0, 0, 0);
+        acc += pair_dot(xv.x, w[g].x) + pair_dot(xv.y, w[g].y) + pair_dot(xv.z, w[g].z) + pair_dot(xv.w, w[g].w);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+      my_pr = p8s_squash(squash, (int32_t)(acc * 9u) >> 9);
+      if (lane == 0) pr_s[wave] = my_pr;
+    }
+    __syncthreads();
+    if (wave == 0) {   // second layer (its row is 32 wide; inputs behind nsel are zero)
+      const int av = lane < nsel ? stretch[pr_s[lane]] : 0;
+      if (lane < nsel) outs[nx + lane] = (float)p8s_squash(squash, av) * cf;
+      const int bv = __shfl_down(av, 1);
+      if ((lane & 1) == 0 && lane < 32) st_s[lane >> 1] = ((uint32_t)av & 0xffffu) | ((uint32_t)bv << 16);
+      __builtin_amdgcn_s_waitcnt(0);
+      __builtin_amdgcn_wave_barrier();
+      uint32_t acc = 0;
+      if (lane < 16) acc = pair_dot(st_s[lane], reinterpret_cast<const MX_GLOBAL uint32_t*>(wx2)[lane]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+      if (lane == 0) p_s = p8s_squash(squash, (int32_t)acc >> 9);
+    }
+    __syncthreads();
+    if (tid == 0) {   // the model's chain, serial on the tables in HBM
+      T->misses = misses;
+      fin_s = p8s_tail_color(T, a, y, p_s, outs + nx + nsel);
+    }
+    __syncthreads();
+    float* orow = out + (size_t)t * ld;
+    for (int i = tid; i < P8_NOUT; i += XMX_THREADS) orow[i] = outs[i];
+    lastpr = fin_s;
+    const int yb = bits[t];
+    if (wave < nsel) {
+      const int err = (int)(int16_t)(((yb << 12) - my_pr) * 7);
+      MX_GLOBAL int16_t* wr = wx + (size_t)row * P8_NX;
+      if (err) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int grp = lane + 64 * g;
+          if (grp < MX_GROUPS) {
+            const uint4 xv = reinterpret_cast<const uint4*>(xs)[grp];
+            uint4 v = w[g];
+            v.x = pair_train(xv.x, v.x, err); v.y = pair_train(xv.y, v.y, err); v.z = pair_train(xv.z, v.z, err); v.w = pair_train(xv.w, v.w, err);
+            mx_gstore4(wr, grp, v);
+          }
+        }
+      }
+    }
+    if (wave == 0 && lane < 16) {
+      const int err2 = (int)(int16_t)(((yb << 12) - p_s) * 7);
+      MX_GLOBAL uint32_t* w2 = reinterpret_cast<MX_GLOBAL uint32_t*>(wx2);
+      if (err2) w2[lane] = pair_train(st_s[lane], w2[lane], err2);
+    }
+    __syncthreads();   // (drains the rows' stores before the next step's loads; xs / st_s / p_s are free again)
+  }
+  for (int i = tid; i < P8_NOUT; i += XMX_THREADS) T->out[i] = outs[i];
+  if (tid == 0) { T->pr = lastpr; T->misses = misses; }
+}
+
 // ---------------------------------------------------------------- host side
 namespace {
 struct DevPolicy {
@@ -1024,7 +1196,9 @@ enum { P8S_BUFS = CMX_PIPELINE_SLOTS, P8S_XBUFS = 3 };   // staging buffers; inp
 struct Staging {   // one chunk's records: page-locked host arrays and their device twins
   size_t cap = 0;  // bytes of input
   char* h = nullptr; char* d = nullptr;
-  size_t o_fctx, o_fchk, o_cctx[P8_NCM2], o_cchk[P8_NCM2], o_ops, o_sel, o_apm, o_bits, total;
+  size_t o_fctx, o_fchk, o_cctx[P8_NCM2], o_cchk[P8_NCM2], o_ops, o_sel, o_apm, o_bits, o_model, total;
+  char* hx = nullptr; char* dx = nullptr;   // the image models' records (xops, xfam_ctx, xfam_chk): uploaded only for a chunk that holds such bytes
+  size_t ox_ops, ox_fctx, ox_fchk, xtotal;
   hipEvent_t done = nullptr;
   hipEvent_t t0[7] = {}, t1[7] = {};   // HIP-event brackets of the role kernels of the chunk: family, mixer, cm2[0..2], lanes, DMC
   bool used = false, timed = false;
@@ -1043,6 +1217,9 @@ struct cmx_p8stage {
   DevPolicy pol;
   P8CmDev* d_fam = nullptr; P8FamHome* d_fam_home = nullptr; size_t fam_lds = 0; P8Cm2Dev* d_cm2[P8_NCM2] = {}; P8LanesDev* d_lanes = nullptr; P8DmcDev* d_dmc = nullptr;
   P8TailDev* d_tail = nullptr; P8MixDev* d_mix = nullptr;
+  P8CmDev* d_xfam[P8_NMODEL - 1] = {}; P8XLanesDev* d_xlanes[P8_NMODEL - 1] = {};   // the image models (p8_rec.h P8XLayout)
+  int last_byte = 0;                    // the last whole byte of the stream
+  uint64_t image_chunks = 0;
   Staging st[P8S_BUFS];
   int next = 0;
   int16_t* d_x[P8S_XBUFS] = {}; uint8_t* d_order[P8S_XBUFS] = {}; size_t x_cap = 0;   // two chunks' input rows / order values: the mixer of chunk c runs under the tables of chunk c + 1
@@ -1079,6 +1256,8 @@ void cmx_p8stage_destroy(cmx_p8stage_t* h) {
   for (auto& s : h->st) {
     if (s.h) (void)hipHostFree(s.h);
     if (s.d) (void)hipFree(s.d);
+    if (s.hx) (void)hipHostFree(s.hx);
+    if (s.dx) (void)hipFree(s.dx);
     if (s.done) (void)hipEventDestroy(s.done);
     for (hipEvent_t e : s.t0) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : s.t1) if (e) (void)hipEventDestroy(e);
@@ -1124,6 +1303,8 @@ cmx_p8stage_t* cmx_p8stage_create(int device) {
     h->d_dmc = dev_copy(S->dmc, h->pol);
     h->d_tail = dev_copy(S->tail, h->pol);
     h->d_mix = dev_copy(S->mix, h->pol);
+    for (int m = 0; m < P8_NMODEL - 1; m++)
+      if (h->L.xl[m].nx) { h->d_xfam[m] = dev_copy(S->xfam[m], h->pol); h->d_xlanes[m] = dev_copy(S->xlanes[m], h->pol); }
     ok = h->pol.ok;
   }
   delete S;
@@ -1174,22 +1355,34 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
   if (b.cap < n) {
     if (b.h) (void)hipHostFree(b.h);
     if (b.d) (void)hipFree(b.d);
-    b.h = b.d = nullptr; b.cap = 0;
+    if (b.hx) (void)hipHostFree(b.hx);
+    if (b.dx) (void)hipFree(b.dx);
+    b.h = b.d = b.hx = b.dx = nullptr; b.cap = 0;
     size_t o = 0;
     auto take = [&](size_t bytes_) { const size_t at = o; o += (bytes_ + 255) & ~(size_t)255; return at; };
     b.o_fctx = take(n * L.fam_slots * 4); b.o_fchk = take(n * L.fam_slots * 2);
     for (int k = 0; k < P8_NCM2; k++) { b.o_cctx[k] = take(n * L.cm2_count[k] * 4); b.o_cchk[k] = take(n * L.cm2_count[k] * 2); }
-    b.o_ops = take(T * P8_NLANE * 4); b.o_sel = take(T * P8_NSEL * 4); b.o_apm = take(T * sizeof(P8ApmRec)); b.o_bits = take(T);
+    b.o_ops = take(T * P8_NLANE * 4); b.o_sel = take(T * P8_NSEL * 4); b.o_apm = take(T * sizeof(P8ApmRec)); b.o_bits = take(T); b.o_model = take(n);
     b.total = o;
-    if (hipHostMalloc((void**)&b.h, o, hipHostMallocDefault) != hipSuccess || hipMalloc((void**)&b.d, o) != hipSuccess) { cmx_set_err("cmx_p8stage_run: staging allocation failed"); h->failed = true; return 1; }
+    o = 0;
+    b.ox_ops = take(T * P8_XL_NLANE * 4); b.ox_fctx = take(n * P8_XL_MAXS * 4); b.ox_fchk = take(n * P8_XL_MAXS * 2);
+    b.xtotal = o;
+    if (hipHostMalloc((void**)&b.h, b.total, hipHostMallocDefault) != hipSuccess || hipMalloc((void**)&b.d, b.total) != hipSuccess ||
+        hipHostMalloc((void**)&b.hx, b.xtotal, hipHostMallocDefault) != hipSuccess || hipMalloc((void**)&b.dx, b.xtotal) != hipSuccess) {
+      cmx_set_err("cmx_p8stage_run: staging allocation failed"); h->failed = true; return 1;
+    }
     b.cap = n;
   }
   P8Chunk c = P8Chunk();
   c.fam_ctx = (uint32_t*)(b.h + b.o_fctx); c.fam_chk = (uint16_t*)(b.h + b.o_fchk);
   for (int k = 0; k < P8_NCM2; k++) { c.cm2_ctx[k] = (uint32_t*)(b.h + b.o_cctx[k]); c.cm2_chk[k] = (uint16_t*)(b.h + b.o_cchk[k]); }
   c.ops = (uint32_t*)(b.h + b.o_ops); c.sel = (int32_t*)(b.h + b.o_sel); c.apm = (P8ApmRec*)(b.h + b.o_apm);
+  c.model = (uint8_t*)(b.h + b.o_model); c.xops = (uint32_t*)(b.hx + b.ox_ops); c.xfam_ctx = (uint32_t*)(b.hx + b.ox_fctx); c.xfam_chk = (uint16_t*)(b.hx + b.ox_fchk);
+  memset(c.model, 0, n);
   const int rc = p8f_front_run(h->front, bytes, n, &c);
   if (rc) { cmx_set_err(std::string("cmx_p8stage_run: ") + p8f_strerror(rc)); h->failed = true; return 1; }
+  bool any_image = false;
+  for (size_t i = 0; i < n && !any_image; i++) any_image = c.model[i] != 0;
   uint8_t* hb = (uint8_t*)(b.h + b.o_bits);
   for (size_t i = 0; i < T; i++) hb[i] = (bytes[i >> 3] >> (7 - (i & 7))) & 1;
   hipStream_t s = (hipStream_t)stream;
@@ -1226,14 +1419,95 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
   const int nbits = (int)T;
   const int skip = h->steps >= 8 ? 0 : (int)(8 - h->steps), t0 = h->steps == 0 ? 1 : 0;
   const uint8_t* d_bits = (const uint8_t*)(b.d + b.o_bits);
-  auto cm2 = [&](int k, hipStream_t q, uint8_t* ord) {
+  const uint8_t* d_model = (const uint8_t*)(b.d + b.o_model);
+  P8LaneLim lim;
+  for (int m = 0; m < P8_NMODEL - 1; m++) lim.lim[m] = L.xl[m].prefix_nx;
+  auto cm2 = [&](int k, hipStream_t q, uint8_t* ord, const uint8_t* mdl) {
     (void)hipEventRecord(b.t0[2 + k], q);
     hipLaunchKernelGGL(cmx_p8s_cm2v2_kernel, dim3(1), dim3(P8CM2_MAXC), 0, q, h->d_cm2[k], (const uint32_t*)(b.d + b.o_cctx[k]),
-                       (const uint16_t*)(b.d + b.o_cchk[k]), d_bits, dx, ord, nbits, skip);
+                       (const uint16_t*)(b.d + b.o_cchk[k]), d_bits, dx, ord, nbits, skip, mdl);
     (void)hipEventRecord(b.t1[2 + k], q);
   };
-  if (ok) {
-    cm2(0, h->s_d, dord);
+  if (ok && any_image) {
+    // ---- a chunk that holds bytes of an image model (p8_rec.h P8XLayout): every role of the chunk on ONE stream (s_m), behind everything the
+    // stage has in flight, in dependency order; the ContextMap family and the mixer by segments of consecutive bytes of one kind -- the
+    // generic kernels on the generic bytes, the image model's on its own, the rnd() stream handed over at every switch. Correctness first:
+    // such chunks are rare, and an image byte still costs far less here than on the reference's CPU path.
+    hipStream_t q = h->s_m;
+    { hipStream_t rs[6] = {h->s_a, h->s_b, h->s_c, h->s_d, h->s_e, h->s_f}; hipEvent_t re[6] = {h->ev_a, h->ev_b, h->ev_c, h->ev_ord, h->ev_e, h->ev_f};
+      for (int i = 0; i < 6; i++) ok = ok && hipEventRecord(re[i], rs[i]) == hipSuccess && hipStreamWaitEvent(q, re[i], 0) == hipSuccess; }
+    ok = ok && hipMemcpyAsync(b.dx, b.hx, b.xtotal, hipMemcpyHostToDevice, h->s_up) == hipSuccess;
+    ok = ok && hipEventRecord(h->ev_up, h->s_up) == hipSuccess;
+    ok = ok && hipStreamWaitEvent(q, h->ev_up, 0) == hipSuccess;
+    for (int i = 0; i < 7; i++) (void)hipEventRecord(b.t0[i], q);
+    cm2(0, q, dord, nullptr);
+    cm2(1, q, nullptr, d_model);
+    cm2(2, q, nullptr, d_model);
+    hipLaunchKernelGGL(cmx_p8s_lanes_kernel, dim3(1), dim3(P8LANES_THREADS), 0, q, h->d_lanes, (const uint32_t*)(b.d + b.o_ops), d_bits, (const uint8_t*)dord, dx, nbits, t0, d_model, lim);
+    hipLaunchKernelGGL(cmx_p8s_dmc_kernel, dim3(1), dim3(P8DMC_THREADS), 0, q, h->d_dmc, d_bits, dx, (int)L.dmc_off, nbits, t0, d_model);
+    for (int m = 0; m < P8_NMODEL - 1; m++)
+      if (h->d_xlanes[m])
+        hipLaunchKernelGGL(cmx_p8s_xlanes_kernel, dim3(1), dim3(P8_XL_NLANE), 0, q, h->d_xlanes[m], (const uint32_t*)(b.dx + b.ox_ops), d_bits, (const uint8_t*)dord, dx, d_model, nbits, t0,
+                           h->last_bit);
+    // segments: [b0, b1) bytes of one model
+    int owner = 0;   // whose copy of the generator is current (0: the generic family's -- the state between chunks)
+    for (int pass = 0; pass < 2 && ok; pass++) {   // pass 0: the ContextMaps, pass 1: the mixers (they need every input row of their steps)
+      size_t b0 = 0;
+      while (b0 < n) {
+        const int md = c.model[b0];
+        size_t b1 = b0 + 1;
+        while (b1 < n && c.model[b1] == md) ++b1;
+        const size_t s0 = 8 * b0;
+        const int sbits = (int)(8 * (b1 - b0));
+        const int ly = s0 ? (int)hb[s0 - 1] : h->last_bit, lc1 = b0 ? (int)bytes[b0 - 1] : h->last_byte;
+        if (pass == 0) {
+          if (md == 0) {
+            if (owner) {
+              hipLaunchKernelGGL(cmx_p8s_rnd_copy_kernel, dim3(1), dim3(64), 0, q, h->d_fam, (const P8CmDev*)h->d_xfam[owner - 1]);
+              owner = 0;
+            }
+            if (b0) hipLaunchKernelGGL(cmx_p8s_fam_resume_kernel, dim3(1), dim3(1), 0, q, h->d_fam, ly, lc1);   // (a chunk's first segment: the family's own registers are current)
+            hipLaunchKernelGGL(cmx_p8s_fam2_kernel, dim3(1), dim3(P8FAM_THREADS), h->fam_lds, q, h->d_fam, h->d_fam_home, (const uint32_t*)(b.d + b.o_fctx) + b0 * L.fam_slots,
+                               (const uint16_t*)(b.d + b.o_fchk) + b0 * L.fam_slots, d_bits + s0, dx + s0 * P8_NX, (const uint8_t*)dord + s0, sbits, b0 == 0 ? skip : 0, h->d_prof);
+          } else {
+            if (owner != md) {
+              hipLaunchKernelGGL(cmx_p8s_rnd_copy_kernel, dim3(1), dim3(64), 0, q, h->d_xfam[md - 1], (const P8CmDev*)(owner ? h->d_xfam[owner - 1] : h->d_fam));
+              owner = md;
+            }
+            hipLaunchKernelGGL(cmx_p8s_xfam_kernel, dim3(1), dim3(64), 0, q, h->d_xfam[md - 1], (const uint32_t*)(b.dx + b.ox_fctx) + b0 * P8_XL_MAXS,
+                               (const uint16_t*)(b.dx + b.ox_fchk) + b0 * P8_XL_MAXS, d_bits + s0, dx + s0 * P8_NX, sbits, ly, lc1);
+          }
+        } else {
+          if (md == 0) {
+            ++h->mix_epoch;
+            hipLaunchKernelGGL(cmx_p8s_mix4_kernel, dim3(4), dim3(MX_THREADS), 0, q, (const P8MixDev*)h->d_mix, h->d_tail, (const int16_t*)dx + s0 * P8_NX, (const int32_t*)(b.d + b.o_sel) + s0 * P8_NSEL,
+                               (const P8ApmRec*)(b.d + b.o_apm) + s0, (const uint8_t*)dord + s0, d_bits + s0, d_out + s0 * ld, ld, sbits, b0 == 0 ? t0 : 0, b0 == 0 ? skip : 0, ly, h->d_prx,
+                               h->mix_epoch, h->h_mixfail);
+          } else {
+            hipLaunchKernelGGL(cmx_p8s_xmix_kernel, dim3(1), dim3(XMX_THREADS), 0, q, (const P8MixDev*)h->d_mix, h->d_tail, (const int16_t*)dx + s0 * P8_NX, (const int32_t*)(b.d + b.o_sel) + s0 * P8_NSEL,
+                               (const P8ApmRec*)(b.d + b.o_apm) + s0, d_bits + s0, d_out + s0 * ld, ld, sbits, ly);
+          }
+        }
+        b0 = b1;
+      }
+      if (pass == 0 && owner) {   // between chunks the generator is the generic family's, and its registers follow the stream
+        hipLaunchKernelGGL(cmx_p8s_rnd_copy_kernel, dim3(1), dim3(64), 0, q, h->d_fam, (const P8CmDev*)h->d_xfam[owner - 1]);
+        owner = 0;
+      }
+      if (pass == 0 && c.model[n - 1] != 0) hipLaunchKernelGGL(cmx_p8s_fam_resume_kernel, dim3(1), dim3(1), 0, q, h->d_fam, (int)hb[T - 1], (int)bytes[n - 1]);
+    }
+    ok = ok && hipGetLastError() == hipSuccess;
+    for (int i = 0; i < 7; i++) (void)hipEventRecord(b.t1[i], q);
+    b.timed = true;
+    ok = ok && hipEventRecord(h->ev_mix[par], q) == hipSuccess;
+    ok = ok && hipEventRecord(b.done, q) == hipSuccess;
+    for (hipStream_t r : {h->s_a, h->s_b, h->s_c, h->s_d, h->s_e, h->s_f}) ok = ok && hipStreamWaitEvent(r, h->ev_mix[par], 0) == hipSuccess;   // the next chunk's roles start behind this one
+    ok = ok && hipStreamWaitEvent(s, h->ev_mix[par], 0) == hipSuccess;
+    h->mix_used[par] = true;
+    h->chunks++;
+    h->image_chunks++;
+  } else if (ok) {
+    cm2(0, h->s_d, dord, nullptr);
     ok = hipEventRecord(h->ev_ord, h->s_d) == hipSuccess;
     ok = ok && hipStreamWaitEvent(h->s_a, h->ev_ord, 0) == hipSuccess;   // (implies the upload)
     (void)hipEventRecord(b.t0[0], h->s_a);
@@ -1242,20 +1516,21 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
     (void)hipEventRecord(b.t1[0], h->s_a);
     ok = ok && hipEventRecord(h->ev_a, h->s_a) == hipSuccess;
     ok = ok && hipStreamWaitEvent(h->s_b, h->ev_up, 0) == hipSuccess;
-    cm2(1, h->s_b, nullptr);
+    cm2(1, h->s_b, nullptr, nullptr);
     ok = ok && hipEventRecord(h->ev_b, h->s_b) == hipSuccess;
     ok = ok && hipStreamWaitEvent(h->s_e, h->ev_up, 0) == hipSuccess;
-    cm2(2, h->s_e, nullptr);
+    cm2(2, h->s_e, nullptr, nullptr);
     ok = ok && hipEventRecord(h->ev_e, h->s_e) == hipSuccess;
     ok = ok && hipStreamWaitEvent(h->s_c, h->ev_ord, 0) == hipSuccess;
     (void)hipEventRecord(b.t0[5], h->s_c);
-    hipLaunchKernelGGL(cmx_p8s_lanes_kernel, dim3(1), dim3(P8LANES_THREADS), 0, h->s_c, h->d_lanes, (const uint32_t*)(b.d + b.o_ops), d_bits, (const uint8_t*)dord, dx, nbits, t0);
+    hipLaunchKernelGGL(cmx_p8s_lanes_kernel, dim3(1), dim3(P8LANES_THREADS), 0, h->s_c, h->d_lanes, (const uint32_t*)(b.d + b.o_ops), d_bits, (const uint8_t*)dord, dx, nbits, t0,
+                       (const uint8_t*)nullptr, lim);
     (void)hipEventRecord(b.t1[5], h->s_c);
     ok = ok && hipEventRecord(h->ev_c, h->s_c) == hipSuccess;
     // the DMC forest reads the coded bits only: on a stream of its own it runs beside the small learners (4.0 + 2.8 us/bit in a row before)
     if (h->s_f != h->s_c) ok = ok && hipStreamWaitEvent(h->s_f, h->ev_up, 0) == hipSuccess;
     (void)hipEventRecord(b.t0[6], h->s_f);
-    hipLaunchKernelGGL(cmx_p8s_dmc_kernel, dim3(1), dim3(P8DMC_THREADS), 0, h->s_f, h->d_dmc, d_bits, dx, (int)L.dmc_off, nbits, t0);
+    hipLaunchKernelGGL(cmx_p8s_dmc_kernel, dim3(1), dim3(P8DMC_THREADS), 0, h->s_f, h->d_dmc, d_bits, dx, (int)L.dmc_off, nbits, t0, (const uint8_t*)nullptr);
     (void)hipEventRecord(b.t1[6], h->s_f);
     ok = ok && hipEventRecord(h->ev_f, h->s_f) == hipSuccess;
     for (hipEvent_t e : {h->ev_a, h->ev_b, h->ev_c, h->ev_e, h->ev_f}) ok = ok && hipStreamWaitEvent(h->s_m, e, 0) == hipSuccess;
@@ -1278,6 +1553,7 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
   b.used = true;
   h->steps += T;
   h->last_bit = hb[T - 1];
+  h->last_byte = bytes[n - 1];
   return 0;
 }
 
