@@ -48,6 +48,7 @@ struct P8CmShared {
   uint32_t draw_val[P8CM_MAXS];
   int conflict, ndraws;
   P8Rnd rnd;
+  int nact;   // contexts that are set this byte when that is fewer than the family has (an image model's ContextMap, ContextMap::mix loops over cn :1072); 0: all
 };
 struct P8CmBit { int y, bp, c0, c1, order; const uint32_t* ctx; const uint16_t* chk; int16_t* out; };
 
@@ -158,7 +159,8 @@ P8_HD void p8d_cm_check(P8CmDev* d, P8CmShared* sh, int s) {   // step b
   const P8CmInst* x = &d->inst[d->slot_inst[s]];
   const int32_t* L = sh->touched[s];
   int hit = 0;
-  for (int o = x->first; o < x->first + x->count && !hit; o++) {
+  const int nall = sh->nact > 0 ? sh->nact : d->nslots;
+  for (int o = x->first; o < x->first + x->count && o < nall && !hit; o++) {
     if (o == s) continue;
     const int32_t* O = sh->touched[o];
     for (int a = 0; a < 5 && !hit; a++)
@@ -169,7 +171,7 @@ P8_HD void p8d_cm_check(P8CmDev* d, P8CmShared* sh, int s) {   // step b
   int rank = 0;
   for (int o = 0; o < s; o++) rank += sh->draws[o];
   sh->rank[s] = (uint16_t)rank;
-  if (s == d->nslots - 1) sh->ndraws = rank + sh->draws[s];
+  if (s == nall - 1) sh->ndraws = rank + sh->draws[s];
 }
 P8_HD void p8d_cm_draw(P8CmDev* d, P8CmShared* sh, int s) {   // step b2
   if (s != 0 || sh->conflict || !d->slot_parallel) return;
@@ -177,7 +179,7 @@ P8_HD void p8d_cm_draw(P8CmDev* d, P8CmShared* sh, int s) {   // step b2
 }
 P8_HD void p8d_cm_run(P8CmDev* d, P8CmShared* sh, const P8CmBit& u, int s) {   // step c
   if (!sh->conflict && d->slot_parallel) p8d_cm_ctx(d, sh, u, s, &sh->draw_val[sh->rank[s]]);
-  else if (s == 0) for (int j = 0; j < d->nslots; j++) p8d_cm_ctx(d, sh, u, j, nullptr);
+  else if (s == 0) { const int nall = sh->nact > 0 ? sh->nact : d->nslots; for (int j = 0; j < nall; j++) p8d_cm_ctx(d, sh, u, j, nullptr); }
 }
 // uniform values of step t of a chunk. order: the order-N map's return values per step (NULL: no order context)
 P8_HD P8CmBit p8d_cm_bit(const P8CmDev* d, const uint32_t* ctx, const uint16_t* chk, const uint8_t* bits_in, int16_t* out, const uint8_t* order, int t, int* last_y, int* c1) {

@@ -108,7 +108,7 @@ static int xcm_step(CM1* c, int bp, const uint64_t* ctx, int nset, int16_t* out,
     else if (X->fam_size != c->size) { fail("an image model's ContextMap changed"); return 0; }
   }
   if (bp == 0) {
-    if (c->cn + nset > c->count || c->cn + nset > P8_XL_MAXS) { fail("too many contexts set (image model)"); return 0; }
+    if (c->cn + nset > c->count || c->cn + nset >= P8_XL_MAXS) { fail("too many contexts set (image model)"); return 0; }
     if (e->xdiscovering) { if (c->cn + nset > X->fam_count) X->fam_count = c->cn + nset; }
     else if (c->cn + nset > X->fam_count) { fail("an image model's ContextMap got more contexts than in the layout pass"); return 0; }
     for (int i = 0; i < nset; ++i, ++c->cn) {
@@ -118,6 +118,8 @@ static int xcm_step(CM1* c, int bp, const uint64_t* ctx, int nset, int16_t* out,
         e->chunk->xfam_chk[e->byte_row * (size_t)P8_XL_MAXS + (size_t)c->cn] = (uint16_t)(p8f_checksum64(h, c->hashbits, 16) & 0xffff);
       }
     }
+    /* how many contexts the byte has set (im8bitModel: 25 for a grayscale image, 52 for a palette one): the row's last cell */
+    if (e->chunk && e->chunk->xfam_ctx) e->chunk->xfam_ctx[e->byte_row * (size_t)P8_XL_MAXS + (size_t)(P8_XL_MAXS - 1)] = (uint32_t)c->cn;
   }
   const int n = 5 * c->cn;
   if (n) {

@@ -67,6 +67,9 @@ int p8f_exe_step(Exe* e, int y, int bpos, int c0, uint32_t c4, int blpos, const 
 Lpm* p8f_lpm_new(void);
 int p8f_lpm_step(Lpm* m, int y, int bpos, int c0, const uint8_t* last, int16_t* out);
 typedef struct Im24 Im24;
+typedef struct Im8 Im8;
+Im8* p8f_im8_new(int level);
+int p8f_im8_step(Im8* m, int y, int bpos, int c0, const uint8_t* hist, uint32_t bmask, int pos, int w, int gray, int16_t* out, int* sets, int* ranges, uint32_t* stats);
 Im24* p8f_im24_new(int level);
 int p8f_im24_step(Im24* m, int y, int bpos, int c0, const uint8_t* hist, uint32_t bmask, int pos, int w, int alpha, int16_t* out, int* sets, int* ranges, uint32_t* stats);
 P8fStateMap32* p8f_statemap32_new(int n);
@@ -110,6 +113,7 @@ typedef struct {
   int img_gray, img_pltorder;                      /* imgModel's statics `gray`, `pltorder` while a palette is being skipped */
   int img_w, img_bpp, img_eoi, img_alpha;          /* imgModel's statics w, bpp, eoi, alpha: an image payload is being modelled while w != 0 */
   Im24* im24;
+  Im8* im8;
   uint32_t img_stats[8];                           /* ModelStats.Image of the byte: W, N, NN, WW, Wp1, Np1, plane, ctx */
   int model;                                       /* P8_MODEL_* of the current step */
   int nsel;                                        /* weight sets of the current step */
@@ -152,6 +156,8 @@ static P8Predictor* predictor_new(int level) {
   p->lpm = p8f_lpm_new();
   p8f_emit_model(p8f_cur, P8_MODEL_IM24);   /* its maps and ContextMap go to the model's own tables (p8_rec.h P8XLayout) */
   p->im24 = p8f_im24_new(level);
+  p8f_emit_model(p8f_cur, P8_MODEL_IM8);
+  p->im8 = p8f_im8_new(level);
   p8f_emit_model(p8f_cur, 0);
   return p;
 }
@@ -270,7 +276,7 @@ static int img_detect(P8Predictor* p, uint32_t* record) {
     const int n = (int)((uint32_t)p->img_w * p->bmp.Height);
     if (n > 64) {
       p->img_eoi = n + pos;
-      if (bpp < 24) return P8F_ERR_BMP;   /* the 1 / 4 / 8-bit image models are not built */
+      if (bpp < 8) return P8F_ERR_BMP;   /* the 1 / 4-bit image models are not built */
     } else { p->img_eoi = 0; p->bmp.Header = 0; p->img_w = 0; }   /* too small to be an image: dropped, as the reference drops it */
   }
   if (pos >= p->img_eoi + 8 && !p->tga.Header) {
@@ -297,7 +303,7 @@ static int img_detect(P8Predictor* p, uint32_t* record) {
       const int n = p->img_w * (int)p->tga.Height;
       if (n > 64) {
         p->img_eoi = n + pos;
-        if (p->img_bpp < 24) return P8F_ERR_TGA;
+        if (p->img_bpp < 8) return P8F_ERR_TGA;
       } else { p->img_eoi = 0; p->tga.Header = 0; p->img_w = 0; }
     }
   }
@@ -383,35 +389,38 @@ static int context_model2(P8Predictor* p, int y, int32_t* sel) {
   /* :8161-8167: an image block, or an image / audio / JPEG payload found inside another block, is modelled by its own sub-model
    * INSTEAD of everything below */
   p->model = P8_MODEL_GENERIC; p->nsel = P8_NSEL;
-  int img_w = 0, img_alpha = 0, by_block = 0;
+  int img_w = 0, img_alpha = 0, img_bpp = 24, img_gray = 0, by_block = 0;
   if (p->filetype == FT_IMAGE24 || p->filetype == FT_IMAGE32) { img_w = p->info; img_alpha = p->filetype == FT_IMAGE32; by_block = 1; }
-  else if (p->filetype >= FT_IMAGE1 && p->filetype <= FT_IMAGE8GRAY) return P8F_ERR_IMAGE_BLOCK;
+  else if (p->filetype == FT_IMAGE8 || p->filetype == FT_IMAGE8GRAY) { img_w = p->info; img_bpp = 8; img_gray = p->filetype == FT_IMAGE8GRAY; by_block = 1; }
+  else if (p->filetype == FT_IMAGE1 || p->filetype == FT_IMAGE4) return P8F_ERR_IMAGE_BLOCK;
   else {
     int e;
     if (bpos == 0 && p->filetype != FT_EXE && (e = jpeg_detect(p)) != 0) return e;
     if (p->size > 0) {   /* imgModel :5386-5504 */
       if (bpos == 0 && (e = img_detect(p, &p->stat_record)) != 0) return e;
       if (p->pos > p->img_eoi) p->img_w = 0;
-      img_w = p->img_w; img_alpha = p->img_alpha;
+      img_w = p->img_w; img_alpha = p->img_alpha; img_bpp = p->img_bpp; img_gray = p->img_gray;
     }
     if (!img_w && bpos == 0 && (e = wav_detect(p)) != 0) return e;
   }
-  if (img_w) {   /* im24bitModel :5001-5353 through the model's own tables; 13 weight sets */
+  if (img_w) {   /* im24bitModel :5001-5353 / im8bitModel :4743-4999 through the model's own tables and weight sets */
     P8Emit* const em = p8f_cur;
     if (em->chunk && !em->chunk->xops) return P8F_ERR_IMAGE_LATE;
     int sets[16], ranges[16];
-    const int prefix = nx;
-    p8f_emit_model(em, P8_MODEL_IM24);
-    const int n = p8f_im24_step(p->im24, y, bpos, c0, p->buf, p->bmask, p->pos, img_w, img_alpha, in + nx, sets, ranges, bpos == 0 ? p->img_stats : NULL);
+    const int prefix = nx, model = img_bpp == 8 ? P8_MODEL_IM8 : P8_MODEL_IM24, nsel = img_bpp == 8 ? 8 : 13;
+    p8f_emit_model(em, model);
+    const int n = img_bpp == 8 ? p8f_im8_step(p->im8, y, bpos, c0, p->buf, p->bmask, p->pos, img_w, img_gray, in + nx, sets, ranges, bpos == 0 ? p->img_stats : NULL)
+                               : p8f_im24_step(p->im24, y, bpos, c0, p->buf, p->bmask, p->pos, img_w, img_alpha, in + nx, sets, ranges, bpos == 0 ? p->img_stats : NULL);
     p8f_emit_model(em, 0);
     if (n < 0) return P8F_ERR_IMAGE_PADDING;
     nx += n;
-    if (em->xdiscovering) { em->L.xl[P8_MODEL_IM24 - 1].prefix_nx = prefix; em->L.xl[P8_MODEL_IM24 - 1].nx = nx; }
-    else if (em->L.xl[P8_MODEL_IM24 - 1].prefix_nx != prefix || em->L.xl[P8_MODEL_IM24 - 1].nx != nx) { fprintf(stderr, "paq8 front end: image step with %d + %d inputs\n", prefix, n); return P8F_ERR_INTERNAL; }
-    p->nx = nx; p->model = P8_MODEL_IM24; p->nsel = 13;
-    if (!by_block) p->type = img_alpha ? FT_IMAGE32 : FT_IMAGE24;   /* Stats->Type :5495 */
+    P8XLayout* X = &em->L.xl[model - 1];
+    if (em->xdiscovering) { X->prefix_nx = prefix; if (nx > X->nx) X->nx = nx; }
+    else if (X->prefix_nx != prefix || nx > X->nx) { fprintf(stderr, "paq8 front end: image step with %d + %d inputs\n", prefix, n); return P8F_ERR_INTERNAL; }
+    p->nx = nx; p->model = model; p->nsel = nsel;
+    if (!by_block) p->type = img_bpp == 8 ? (img_gray ? FT_IMAGE8GRAY : FT_IMAGE8) : (img_alpha ? FT_IMAGE32 : FT_IMAGE24);   /* Stats->Type :5493-5495 */
     int base = 0;
-    for (int i = 0; i < 13; i++) { sel[ns++] = base + sets[i]; base += ranges[i]; }
+    for (int i = 0; i < nsel; i++) { sel[ns++] = base + sets[i]; base += ranges[i]; }
     for (; ns < P8_NSEL; ns++) sel[ns] = -1;
     if (!by_block && bpos == 7 && p->pos + 1 == p->img_eoi) { memset(&p->tga, 0, sizeof p->tga); p->bmp.Header = 0; p->img_gray = p->img_alpha = 0; }   /* :5498-5501 */
     return 0;
@@ -530,7 +539,24 @@ static int front_step(P8Front* f, int y, int32_t* sel, P8ApmRec* apm) {
     apm->c[3] = (uint16_t)((c0 << 8) | (int)(st[7] & 0xff));
     apm->c[4] = (uint16_t)p8f_finalize64(p8f_hash4((uint64_t)c0, st[0], (uint64_t)(uint32_t)((c4 & 0xff) - st[4]), st[6]), 16);   /* (c4 & 0xff) - Wp1 in 32-bit unsigned arithmetic */
     apm->c[5] = (uint16_t)p8f_finalize64(p8f_hash4((uint64_t)c0, st[1], (uint64_t)(uint32_t)((c4 & 0xff) - st[5]), st[6]), 16);
-  } else {   /* the other image types never get here (refused above) */
+  } else if (p->type == FT_IMAGE8GRAY) {   /* Image.Gray :8315-8324 */
+    const uint32_t* st = p->img_stats;
+    apm->text = P8_APM_GRAY;
+    apm->limit = (uint16_t)(0x3FF >> ((p->blpos < 0xFFF) * 4));
+    apm->c[0] = (uint16_t)(c0 << 4);
+    apm->c[1] = (uint16_t)((c0 << 8) | (int)(st[7] & 0xff));
+    apm->c[2] = (uint16_t)((uint32_t)bpos | (st[7] & 0xF8) | (eb << 8));
+  } else if (p->type == FT_IMAGE8) {   /* Image.Palette :8325-8340 */
+    const uint32_t* st = p->img_stats;   /* W, N, NN, WW */
+    apm->text = P8_APM_PALETTE;
+    apm->limit = (uint16_t)(0x3FF >> ((p->blpos < 0xFFF) * 4));
+    apm->c[0] = (uint16_t)(c0 << 4);
+    apm->c[1] = (uint16_t)p8f_finalize64(p8f_hash3((uint64_t)c0, st[0], st[1]), 16);
+    apm->c[2] = (uint16_t)p8f_finalize64(p8f_hash3((uint64_t)c0, st[1], st[2]), 16);
+    apm->c[3] = (uint16_t)p8f_finalize64(p8f_hash3((uint64_t)c0, st[0], st[3]), 16);
+    apm->c[4] = (uint16_t)p8f_finalize64(p8f_hash3((uint64_t)c0, eb, st[1]), 16);
+    apm->c[5] = (uint16_t)p8f_finalize64(p8f_hash3((uint64_t)c0, st[0], st[1]), 16);
+  } else {   /* the 1 / 4-bit image types never get here (refused above) */
     apm->c[0] = (uint16_t)((mlen << 11) | ((uint32_t)c0 << 3));
     apm->c[1] = (uint16_t)((uint32_t)c0 | RB(1) << 8);
     apm->c[2] = (uint16_t)((uint32_t)c0 ^ p8f_finalize64(hash1(c4 & 0xffff), 16));
@@ -572,7 +598,9 @@ P8Front* p8f_front_new(int level) {
   /* layout pass of the image models: a second throw-away set of models through an IMAGE24 block of two rows (header: type, size,
    * width -- preprocessor.cpp:303-304) -- where their inputs start (the common prefix), how many there are, which maps exist */
   {
-    static const uint8_t img[] = {FT_IMAGE24, 0, 0, 0, 24, 0, 0, 0, 12,   1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12,   1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12};
+    static const uint8_t img[] = {FT_IMAGE24, 0, 0, 0, 24, 0, 0, 0, 12,   1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12,   1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12,
+                                  FT_IMAGE8, 0, 0, 0, 8, 0, 0, 0, 4,   1, 2, 3, 4, 5, 6, 7, 8,
+                                  FT_IMAGE8GRAY, 0, 0, 0, 8, 0, 0, 0, 4,   1, 2, 3, 4, 5, 6, 7, 8, 0};
     f->emit.xdiscovering = 1; f->emit.lane_objs = 0; memset(f->emit.xlane_objs, 0, sizeof f->emit.xlane_objs);
     f->p = predictor_new(level);
     int bit = 0;
@@ -581,7 +609,7 @@ P8Front* p8f_front_new(int level) {
       rc = front_step(f, bit, sel, &apm);
       bit = (img[t >> 3] >> (7 - (t & 7))) & 1;
     }
-    if (rc == 0 && f->emit.L.xl[P8_MODEL_IM24 - 1].nx == 0) rc = 1;
+    if (rc == 0 && (f->emit.L.xl[P8_MODEL_IM24 - 1].nx == 0 || f->emit.L.xl[P8_MODEL_IM8 - 1].nx == 0)) rc = 1;
     release_models(f);
     f->emit.xdiscovering = 0;
     if (rc != 0 || f->emit.err) { fprintf(stderr, "paq8 front end: layout pass of the image models failed (%d)\n", rc); free(f); return NULL; }
@@ -633,10 +661,10 @@ int p8f_front_run(P8Front* f, const uint8_t* bytes, size_t nbytes, P8Chunk* out)
 const char* p8f_strerror(int code) {
   switch (code) {
     case 0: return "ok";
-    case P8F_ERR_IMAGE_BLOCK: return "paq8 stage: 1 / 4 / 8-bit image block (only the 24 / 32-bit image model is built)";
+    case P8F_ERR_IMAGE_BLOCK: return "paq8 stage: 1 / 4-bit image block (the 8-bit and 24 / 32-bit image models are built)";
     case P8F_ERR_JPEG: return "paq8 stage: JPEG stream detected (jpegModel is outside the stage's scope)";
-    case P8F_ERR_BMP: return "paq8 stage: 1 / 4 / 8-bit BMP payload detected (only the 24 / 32-bit image model is built)";
-    case P8F_ERR_TGA: return "paq8 stage: 8-bit TGA payload detected (only the 24 / 32-bit image model is built)";
+    case P8F_ERR_BMP: return "paq8 stage: 1 / 4-bit BMP payload detected (the 8-bit and 24 / 32-bit image models are built)";
+    case P8F_ERR_TGA: return "paq8 stage: TGA payload of an unsupported pixel size";
     case P8F_ERR_WAV: return "paq8 stage: WAV header detected (audioModel is outside the stage's scope)";
     case P8F_ERR_IMAGE_PADDING: return "paq8 stage: image rows whose byte width is not a multiple of the pixel size (the reference indexes past its OLS array there, paq8.cpp:5043,5226: undefined)";
     case P8F_ERR_IMAGE_LATE: return "paq8 stage: an image model in a decoder's chunk (the late-bit form of the image models is not built)";

@@ -1,6 +1,9 @@
 /* p8front/p8f_image.c -- HOST FRONT END of the paq8 stage (product code; tables are recorded through p8f_emit.h, the device learns).
  *
- * Host front end for paq8's 24/32-bit image model (reference src/models/paq8.cpp:5001-5353, im24bitModel), switched on by
+ * Host front end for paq8's image models: im24bitModel (24/32-bit pixels, below) and im8bitModel (8-bit palette / grayscale, at the end
+ * of the file; reference src/models/paq8.cpp:4743-4999).
+ *
+ * The 24/32-bit image model (reference src/models/paq8.cpp:5001-5353, im24bitModel), switched on by
  * contextModel2 for IMAGE24 / IMAGE32 blocks (:8165-8166) and by imgModel for 24/32-bit BMP / TGA payloads inside other blocks
  * (:5386-5504). Per byte: the pixel neighbourhood out of the byte history, 76 + 58 neighbourhood predictors (contexts of 100
  * StationaryMaps and 59 SmallStationaryContextMaps), six recursive-least-squares predictors per colour plane (OLS<double, U8>
@@ -448,5 +451,265 @@ int p8f_im24_step(Im24* m, int y, int bpos, int c0, const uint8_t* hist, uint32_
   SET(imin(255, (x + line) / 32), 256);
 #undef SET
 #undef BUF
+  return nx;
+}
+
+/* ---------------------------------------------------------------- im8bitModel :4743-4999
+ * One model, two faces: grayscale images (25 of the ContextMap's 52 contexts, 62 StationaryMaps on neighbourhood predictors and five
+ * least-squares predictors) and palette images (all 52 contexts, four of them through IndirectContext<U8> byte histories, and four
+ * SmallStationaryContextMaps). The tables are shared (the reference's function statics), the inputs a step produces differ. */
+enum { G_MAPS0 = 2, G_MAPS1 = 55, G_OLS = 5, G_MAPS = G_MAPS0 + G_MAPS1 + G_OLS, G_PLT = 4, G_CM = 48 + G_PLT };
+typedef struct Im8 {
+  CM1* cm;
+  DMap* map[G_MAPS];
+  DMap* plt[G_PLT];
+  Ols ols[G_OLS];
+  uint8_t ictx_data[G_PLT][65536];   /* IndirectContext<U8>(16, 8) :1468-1492: the byte that followed a 16-bit context last time */
+  uint32_t ictx_at[G_PLT];
+  int ctx, last_pos, col, x, line;
+  int columns[2], column[2];
+  uint8_t mctx[G_MAPS1], pols[G_OLS];
+  uint8_t W, WW, N, NN, NW, NE, NNE, NNW, NNWW, NNEE;
+} Im8;
+
+Im8* p8f_im8_new(int level) {
+  static const double lambda[G_OLS] = {0.996, 0.87, 0.93, 0.8, 0.9};
+  static const int num[G_OLS] = {32, 12, 15, 10, 14};
+  Im8* m = (Im8*)calloc(1, sizeof *m);
+  m->cm = p8f_cm_new((0x10000ull << level) * 4, G_CM);
+  for (int i = 0; i < G_MAPS; i++) m->map[i] = i == 0 ? p8f_dmap_new(1, 0, 8, 0) : i == 1 ? p8f_dmap_new(1, 15, 1, 0) : p8f_dmap_new(1, 11, 1, 0);
+  for (int i = 0; i < G_PLT; i++) m->plt[i] = p8f_dmap_new(0, 11, 1, 0);
+  for (int j = 0; j < G_OLS; j++) ols_init(&m->ols[j], num[j], lambda[j]);
+  m->columns[0] = m->columns[1] = 1;
+  return m;
+}
+
+/* One step; gray: 0 = palette image, else grayscale (the value the caller holds -- imgModel's may be 0x100 | byte, which only matters
+ * for the shift in stats[7], :4973). sets[8] / ranges[8]; stats[8] (at bpos == 0): W, N, NN, WW, -, -, -, ctx >> gray. */
+int p8f_im8_step(Im8* m, int y, int bpos, int c0, const uint8_t* hist, uint32_t bmask, int pos, int w, int gray, int16_t* out, int* sets, int* ranges, uint32_t* stats) {
+#define BUF(i) ((int)hist[((uint32_t)pos - (uint32_t)(i)) & bmask])
+  if (bpos == 0) {
+    if (pos != m->last_pos + 1) {
+      m->x = m->line = 0;
+      m->columns[0] = imax(1, w / imax(1, (int)ilog2u((unsigned)w) * 2));
+      m->columns[1] = imax(1, m->columns[0] / imax(1, (int)ilog2u((unsigned)m->columns[0])));
+    } else {
+      ++m->x;
+      m->x *= m->x < w;
+      m->line += (m->x == 0);
+    }
+    m->last_pos = pos;
+    m->column[0] = m->x / m->columns[0];
+    m->column[1] = m->x / m->columns[1];
+    const int WWWWW = BUF(5), WWWW = BUF(4), WWW = BUF(3), WW = BUF(2), W = BUF(1);
+    const int NWWWW = BUF(w + 4), NWWW = BUF(w + 3), NWW = BUF(w + 2), NW = BUF(w + 1), N = BUF(w), NE = BUF(w - 1), NEE = BUF(w - 2), NEEE = BUF(w - 3), NEEEE = BUF(w - 4);
+    const int NNWWW = BUF(w * 2 + 3), NNWW = BUF(w * 2 + 2), NNW = BUF(w * 2 + 1), NN = BUF(w * 2), NNE = BUF(w * 2 - 1), NNEE = BUF(w * 2 - 2), NNEEE = BUF(w * 2 - 3);
+    const int NNNWW = BUF(w * 3 + 2), NNNW = BUF(w * 3 + 1), NNN = BUF(w * 3), NNNE = BUF(w * 3 - 1), NNNEE = BUF(w * 3 - 2);
+    const int NNNNW = BUF(w * 4 + 1), NNNN = BUF(w * 4), NNNNE = BUF(w * 4 - 1), NNNNN = BUF(w * 5), NNNNNN = BUF(w * 6);
+    const int WWWWWW = BUF(6);
+    uint8_t* q = m->mctx;
+    int j = 0;
+    q[j++] = clamp4(W + N - NW, W, NW, N, NE);
+    q[j++] = clip(W + N - NW);
+    q[j++] = clamp4(W + NE - N, W, NW, N, NE);
+    q[j++] = clip(W + NE - N);
+    q[j++] = clamp4(N + NW - NNW, W, NW, N, NE);
+    q[j++] = clip(N + NW - NNW);
+    q[j++] = clamp4(N + NE - NNE, W, N, NE, NEE);
+    q[j++] = clip(N + NE - NNE);
+    q[j++] = (uint8_t)((W + NEE) / 2);
+    q[j++] = clip(N * 3 - NN * 3 + NNN);
+    q[j++] = clip(W * 3 - WW * 3 + WWW);
+    q[j++] = (uint8_t)((W + clip(NE * 3 - NNE * 3 + NNNE)) / 2);
+    q[j++] = (uint8_t)((W + clip(NEE * 3 - NNEEE * 3 + BUF(w * 3 - 4))) / 2);
+    q[j++] = clip(NN + NNNN - NNNNNN);
+    q[j++] = clip(WW + WWWW - WWWWWW);
+    q[j++] = clip((NNNNN - 6 * NNNN + 15 * NNN - 20 * NN + 15 * N + clamp4(W * 2 - NWW, W, NW, N, NN)) / 6);
+    q[j++] = clip((-3 * WW + 8 * W + clamp4(NEE * 3 - NNEE * 3 + NNNEE, NE, NEE, NEEE, NEEEE)) / 6);
+    q[j++] = clip(NN + NW - NNNW);
+    q[j++] = clip(NN + NE - NNNE);
+    q[j++] = clip((W * 2 + NW) - (WW + 2 * NWW) + NWWW);
+    q[j++] = clip(((NW + NWW) / 2) * 3 - NNWWW * 3 + (BUF(w * 3 + 4) + BUF(w * 3 + 5)) / 2);
+    q[j++] = clip(NEE + NE - NNEEE);
+    q[j++] = clip(NWW + WW - NWWWW);
+    q[j++] = clip(((W + NW) * 3 - NWW * 6 + NWWW + NNWWW) / 2);
+    q[j++] = clip((NE * 2 + NNE) - (NNEE + NNNEE * 2) + BUF(w * 4 - 3));
+    q[j++] = (uint8_t)NNNNNN;
+    q[j++] = (uint8_t)((NEEEE + BUF(w - 6)) / 2);
+    q[j++] = (uint8_t)((WWWW + WWWWWW) / 2);
+    q[j++] = (uint8_t)((W + N + BUF(w - 5) + BUF(w - 7)) / 4);
+    q[j++] = clip(NEEE + W - NEE);
+    q[j++] = clip(4 * NNN - 3 * NNNN);
+    q[j++] = clip(N + NN - NNN);
+    q[j++] = clip(W + WW - WWW);
+    q[j++] = clip(W + NEE - NE);
+    q[j++] = clip(WW + NEE - N);
+    q[j++] = (uint8_t)((clip(W * 2 - NW) + clip(W * 2 - NWW) + N + NE) / 4);
+    q[j++] = clamp4(N * 2 - NN, W, N, NE, NEE);
+    q[j++] = (uint8_t)((N + NNN) / 2);
+    q[j++] = clip(NN + W - NNW);
+    q[j++] = clip(NWW + N - NNWW);
+    q[j++] = clip((4 * WWW - 15 * WW + 20 * W + clip(NEE * 2 - NNEE)) / 10);
+    q[j++] = clip((BUF(w * 3 - 3) - 4 * NNEE + 6 * NE + clip(W * 3 - NW * 3 + NNW)) / 4);
+    q[j++] = clip((N * 2 + NE) - (NN + 2 * NNE) + NNNE);
+    q[j++] = clip((NW * 2 + NNW) - (NNWW + NNNWW * 2) + BUF(w * 4 + 3));
+    q[j++] = clip(NNWW + W - NNWWW);
+    q[j++] = clip((-NNNN + 5 * NNN - 10 * NN + 10 * N + clip(W * 4 - NWW * 6 + NNWWW * 4 - BUF(w * 3 + 4))) / 5);
+    q[j++] = clip(NEE + clip(NEEE * 2 - BUF(w * 2 - 4)) - NEEEE);
+    q[j++] = clip(NW + W - NWW);
+    q[j++] = clip((N * 2 + NW) - (NN + 2 * NNW) + NNNW);
+    q[j++] = clip(NN + clip(NEE * 2 - NNEEE) - NNE);
+    q[j++] = clip((-WWWW + 5 * WWW - 10 * WW + 10 * W + clip(NE * 2 - NNE)) / 5);
+    q[j++] = clip((-WWWWW + 4 * WWWW - 5 * WWW + 5 * W + clip(NE * 2 - NNE)) / 4);
+    q[j++] = clip((WWW - 4 * WW + 6 * W + clip(NE * 3 - NNE * 3 + NNNE)) / 4);
+    q[j++] = clip((-NNEE + 3 * NE + clip(W * 4 - NW * 6 + NNW * 4 - NNNW)) / 3);
+    q[j++] = (uint8_t)(((W + N) * 3 - NW * 2) / 4);
+    {
+      /* (the first tap is the function's static WWWWWW, which im8bitModel never assigns -- :4784 starts at WWWWW: always 0) */
+      const uint8_t t1[32] = {0, (uint8_t)WWWWW, (uint8_t)WWWW, (uint8_t)WWW, (uint8_t)WW, (uint8_t)W, (uint8_t)NWWWW, (uint8_t)NWWW, (uint8_t)NWW, (uint8_t)NW, (uint8_t)N,
+                              (uint8_t)NE, (uint8_t)NEE, (uint8_t)NEEE, (uint8_t)NEEEE, (uint8_t)NNWWW, (uint8_t)NNWW, (uint8_t)NNW, (uint8_t)NN, (uint8_t)NNE, (uint8_t)NNEE, (uint8_t)NNEEE,
+                              (uint8_t)NNNWW, (uint8_t)NNNW, (uint8_t)NNN, (uint8_t)NNNE, (uint8_t)NNNEE, (uint8_t)NNNNW, (uint8_t)NNNN, (uint8_t)NNNNE, (uint8_t)NNNNN, (uint8_t)NNNNNN};
+      const uint8_t t2[12] = {(uint8_t)WWW, (uint8_t)WW, (uint8_t)W, (uint8_t)NWW, (uint8_t)NW, (uint8_t)N, (uint8_t)NE, (uint8_t)NEE, (uint8_t)NNW, (uint8_t)NN, (uint8_t)NNE, (uint8_t)NNN};
+      const uint8_t t3[15] = {(uint8_t)N, (uint8_t)NE, (uint8_t)NEE, (uint8_t)NEEE, (uint8_t)NEEEE, (uint8_t)NN, (uint8_t)NNE, (uint8_t)NNEE, (uint8_t)NNEEE, (uint8_t)NNN, (uint8_t)NNNE,
+                              (uint8_t)NNNEE, (uint8_t)NNNN, (uint8_t)NNNNE, (uint8_t)NNNNN};
+      const uint8_t t4[10] = {(uint8_t)N, (uint8_t)NE, (uint8_t)NEE, (uint8_t)NEEE, (uint8_t)NN, (uint8_t)NNE, (uint8_t)NNEE, (uint8_t)NNN, (uint8_t)NNNE, (uint8_t)NNNN};
+      const uint8_t t5[14] = {(uint8_t)WWWW, (uint8_t)WWW, (uint8_t)WW, (uint8_t)W, (uint8_t)NWWW, (uint8_t)NWW, (uint8_t)NW, (uint8_t)N, (uint8_t)NNWW, (uint8_t)NNW, (uint8_t)NN, (uint8_t)NNNW,
+                              (uint8_t)NNN, (uint8_t)NNNN};
+      const uint8_t* taps[G_OLS] = {t1, t2, t3, t4, t5};
+      for (j = 0; j < G_OLS; j++) {   /* every predictor learns the byte just coded, then predicts (:4868-4871) */
+        ols_update(&m->ols[j], (uint8_t)W);
+        m->pols[j] = clip((int)floor(ols_predict(&m->ols[j], taps[j])));
+      }
+    }
+    for (j = 0; j < G_PLT; j++) m->ictx_data[j][m->ictx_at[j]] = (uint8_t)W;   /* iCtx[j] += W: an 8-bit cell shifted by 8 keeps only the new byte */
+    m->ictx_at[0] = (uint32_t)(W | (NE << 8)) & 0xffff;
+    m->ictx_at[1] = (uint32_t)(W | (N << 8)) & 0xffff;
+    m->ictx_at[2] = (uint32_t)(W | (WW << 8)) & 0xffff;
+    m->ictx_at[3] = (uint32_t)(N | (NN << 8)) & 0xffff;
+    uint64_t cx[G_CM];
+    int n = 0;
+    int64_t i = 0;
+    if (!gray) {
+      cx[n++] = H2(++i, W);
+      cx[n++] = H3(++i, W, m->column[0]);
+      cx[n++] = H2(++i, N);
+      cx[n++] = H3(++i, N, m->column[0]);
+      cx[n++] = H2(++i, NW);
+      cx[n++] = H3(++i, NW, m->column[0]);
+      cx[n++] = H2(++i, NE);
+      cx[n++] = H3(++i, NE, m->column[0]);
+      cx[n++] = H2(++i, NWW);
+      cx[n++] = H2(++i, NEE);
+      cx[n++] = H2(++i, WW);
+      cx[n++] = H2(++i, NN);
+      cx[n++] = H3(++i, W, N);
+      cx[n++] = H3(++i, W, NW);
+      cx[n++] = H3(++i, W, NE);
+      cx[n++] = H3(++i, W, NEE);
+      cx[n++] = H3(++i, W, NWW);
+      cx[n++] = H3(++i, N, NW);
+      cx[n++] = H3(++i, N, NE);
+      cx[n++] = H3(++i, NW, NE);
+      cx[n++] = H3(++i, W, WW);
+      cx[n++] = H3(++i, N, NN);
+      cx[n++] = H3(++i, NW, NNWW);
+      cx[n++] = H3(++i, NE, NNEE);
+      cx[n++] = H3(++i, NW, NWW);
+      cx[n++] = H3(++i, NW, NNW);
+      cx[n++] = H3(++i, NE, NEE);
+      cx[n++] = H3(++i, NE, NNE);
+      cx[n++] = H3(++i, N, NNW);
+      cx[n++] = H3(++i, N, NNE);
+      cx[n++] = H3(++i, N, NNN);
+      cx[n++] = H3(++i, W, WWW);
+      cx[n++] = H3(++i, WW, NEE);
+      cx[n++] = H3(++i, WW, NN);
+      cx[n++] = H3(++i, W, NEEE);
+      cx[n++] = H3(++i, W, NEEEE);
+      cx[n++] = H4(++i, W, N, NW);
+      cx[n++] = H4(++i, N, NN, NNN);
+      cx[n++] = H4(++i, W, NE, NEE);
+      cx[n++] = H5(++i, W, NW, N, NE);
+      cx[n++] = H5(++i, N, NE, NN, NNE);
+      cx[n++] = H5(++i, N, NW, NNW, NN);
+      cx[n++] = H5(++i, W, WW, NWW, NW);
+      cx[n++] = hashn(6, (const int64_t[]){++i, W, NW, N, WW, NWW});
+      cx[n++] = H2(++i, m->column[0]);
+      cx[n++] = H3(++i, N, m->column[1]);
+      cx[n++] = H3(++i, W, m->column[1]);
+      cx[n++] = (uint64_t)(++i);   /* cm.set(++i): the bare counter */
+      for (j = 0; j < G_PLT; j++) cx[n++] = H2(++i, m->ictx_data[j][m->ictx_at[j]]);
+      m->ctx = imin(0x1F, m->x / imin(0x20, m->columns[0]));
+    } else {
+      cx[n++] = H2(++i, N);
+      cx[n++] = H2(++i, W);
+      cx[n++] = H2(++i, NW);
+      cx[n++] = H2(++i, NE);
+      cx[n++] = H3(++i, N, NN);
+      cx[n++] = H3(++i, W, WW);
+      cx[n++] = H3(++i, NE, NNEE);
+      cx[n++] = H3(++i, NW, NNWW);
+      cx[n++] = H3(++i, W, NEE);
+      cx[n++] = H3(++i, clamp4(W + N - NW, W, NW, N, NE) / 2, LMD(clip(N + NE - NNE), clip(N + NW - NNW)));
+      cx[n++] = H4(++i, W / 4, NE / 4, m->column[0]);
+      cx[n++] = H3(++i, clip(W * 2 - WW) / 4, clip(N * 2 - NN) / 4);
+      cx[n++] = H3(++i, clamp4(N + NE - NNE, W, N, NE, NEE) / 4, m->column[0]);
+      cx[n++] = H3(++i, clamp4(N + NW - NNW, W, NW, N, NE) / 4, m->column[0]);
+      cx[n++] = H3(++i, (W + NEE) / 4, m->column[0]);
+      cx[n++] = H3(++i, clip(W + N - NW), m->column[0]);
+      cx[n++] = H3(++i, clamp4(N * 3 - NN * 3 + NNN, W, N, NN, NE), LMD(W, clip(NW * 2 - NNW)));
+      cx[n++] = H3(++i, clamp4(W * 3 - WW * 3 + WWW, W, N, NE, NEE), LMD(N, clip(NW * 2 - NWW)));
+      cx[n++] = H3(++i, (W + clamp4(NE * 3 - NNE * 3 + NNNE, W, N, NE, NEE)) / 2, LMD(N, (NW + NE) / 2));
+      cx[n++] = H3(++i, (N + NNN) / 8, clip(N * 3 - NN * 3 + NNN) / 4);
+      cx[n++] = H3(++i, (W + WWW) / 8, clip(W * 3 - WW * 3 + WWW) / 4);
+      cx[n++] = H2(++i, clip((-WWWW + 5 * WWW - 10 * WW + 10 * W + clamp4(NE * 4 - NNE * 6 + NNNE * 4 - NNNNE, N, NE, NEE, NEEE)) / 5));
+      cx[n++] = H3(++i, clip(N * 2 - NN), LMD(N, clip(NN * 2 - NNN)));
+      cx[n++] = H3(++i, clip(W * 2 - WW), LMD(NE, clip(N * 2 - NW)));
+      cx[n++] = (uint64_t)(uint32_t)~0xde7ec7edu;   /* cm.set(~0xde7ec7ed): the literal is an unsigned int, its complement widens with zeros */
+      m->ctx = imin(0x1F, m->x / imax(1, w / imin(32, m->columns[0]))) | ((((abs(W - N) * 16 > W + N) << 1) | (abs(N - NW) > 8)) << 5) | ((W + N) & 0x180);
+    }
+    int k = 0;
+    p8f_cm_step(m->cm, y, 0, c0, W, cx, n, out, &k);
+    m->W = (uint8_t)W; m->WW = (uint8_t)WW; m->N = (uint8_t)N; m->NN = (uint8_t)NN; m->NW = (uint8_t)NW; m->NE = (uint8_t)NE; m->NNE = (uint8_t)NNE; m->NNW = (uint8_t)NNW;
+    m->NNWW = (uint8_t)NNWW; m->NNEE = (uint8_t)NNEE;
+    if (stats) {
+      stats[0] = (uint32_t)W; stats[1] = (uint32_t)N; stats[2] = (uint32_t)NN; stats[3] = (uint32_t)WW; stats[4] = stats[5] = stats[6] = 0;
+      stats[7] = (uint32_t)(uint8_t)(m->ctx >> (gray & 31));   /* Stats->Image.ctx = ctx >> gray into a U8; the shift count as x86 takes it */
+    }
+  }
+  const int W = m->W, WW = m->WW, N = m->N, NN = m->NN, NW = m->NW, NE = m->NE, NNE = m->NNE, NNW = m->NNW;
+  const int B = (uint8_t)(c0 << (8 - bpos));
+  int i = 1;
+  p8f_dmap_set_direct(m->map[i++], (uint32_t)((((uint8_t)(clip(W + N - NW) - B)) * 8 + bpos) | (LMD(clip(N + NE - NNE), clip(N + NW - NNW)) << 11)));
+  for (int j = 0; j < G_MAPS1; i++, j++) p8f_dmap_set_direct(m->map[i], (uint32_t)((m->mctx[j] - B) * 8 + bpos));
+  for (int j = 0; i < G_MAPS; i++, j++) p8f_dmap_set_direct(m->map[i], (uint32_t)((m->pols[j] - B) * 8 + bpos));
+  int nx = 0, k = 0;
+  const int ncm = gray ? 25 : G_CM;
+  if (bpos) p8f_cm_step(m->cm, y, bpos, c0, W, NULL, 0, out, &k);
+  else k = 5 * ncm;
+  nx += k;
+  if (gray) {
+    for (int j = 0; j < G_MAPS; j++) nx += p8f_dmap_mix(m->map[j], y, 1023, 1, 4, out + nx);   /* Map[i].mix(m): multiplier 1, divisor 4, limit 1023 */
+  } else {
+    for (int j = 0; j < G_PLT; j++) {
+      p8f_dmap_set_direct(m->plt[j], (uint32_t)((bpos << 8) | m->ictx_data[j][m->ictx_at[j]]));
+      nx += p8f_dmap_mix(m->plt[j], y, 7, 1, 4, out + nx);                                        /* pltMap[i].mix(m): rate 7, 1 / 4 */
+    }
+  }
+  m->col = (m->col + 1) & 7;
+  int ns = 0;
+#define SET(v, r) do { sets[ns] = (int)(v); ranges[ns] = (int)(r); ++ns; } while (0)
+  SET(m->ctx, 2048);
+  SET(m->col, 8);
+  SET((N + W) >> 4, 32);
+  SET(c0, 256);
+  SET(((abs(W - N) > 4) << 9) | ((abs(N - NE) > 4) << 8) | ((abs(W - NW) > 4) << 7) | ((W > N) << 6) | ((N > NE) << 5) | ((W > NW) << 4) | ((W > WW) << 3) | ((N > NN) << 2) |
+          ((NW > m->NNWW) << 1) | (NE > m->NNEE), 1024);
+  SET(imin(63, m->column[0]), 64);
+  SET(imin(127, m->column[1]), 128);
+  SET(imin(255, (m->x + m->line) / 32), 256);
+#undef SET
+#undef BUF
+  (void)NNE; (void)NNW;
   return nx;
 }

@@ -1036,13 +1036,16 @@ __global__ __launch_bounds__(64) void cmx_p8s_xfam_kernel(P8CmDev* d, const uint
     P8CmBit u;
     u.y = y; u.bp = bp; u.c0 = c0; u.c1 = c1; u.order = 0;
     u.ctx = xctx + (size_t)(t >> 3) * P8_XL_MAXS; u.chk = xchk + (size_t)(t >> 3) * P8_XL_MAXS; u.out = x + (size_t)t * P8_NX;
-    if (s < S) p8d_cm_touch(d, &sh, u, s);
+    const int A = (int)u.ctx[P8_XL_MAXS - 1];   // the contexts this byte has set (the row's last cell): the others are not touched
+    if (s == 0) sh.nact = A;
     __syncthreads();
-    if (s < S) p8d_cm_check(d, &sh, s);
+    if (s < A) p8d_cm_touch(d, &sh, u, s);
+    __syncthreads();
+    if (s < A) p8d_cm_check(d, &sh, s);
     __syncthreads();
     p8d_cm_draw(d, &sh, s);
     __syncthreads();
-    if (s < S) p8d_cm_run(d, &sh, u, s);
+    if (s < A) p8d_cm_run(d, &sh, u, s);
     __syncthreads();
     const int bit = bits[t];
     y = bit; c0 = c0 * 2 + bit;
@@ -1072,14 +1075,15 @@ __global__ __launch_bounds__(P8_XL_NLANE) void cmx_p8s_xlanes_kernel(P8XLanesDev
   for (int t = t0; t < nbits; t++) {
     if (model[t >> 3] != mine) continue;
     const int y = t ? bits[t - 1] : last_y;
-    p8s_lane_step_t(&d->lane[l], &tb, &r, xops[(size_t)t * P8_XL_NLANE + l], y, order[t], x + (size_t)t * P8_NX, P8_NX);
+    const uint32_t op = xops[(size_t)t * P8_XL_NLANE + l];
+    if (op & P8OP_MIX) p8s_lane_step_t(&d->lane[l], &tb, &r, op, y, order[t], x + (size_t)t * P8_NX, P8_NX);   // (a map the step does not call writes nothing: its positions may be the model's other face's)
   }
   d->regs[l] = r;
 }
 
 // The mixer of an image model's steps (one segment of consecutive such bytes): the step's nx inputs (P8ApmRec.c[8]; zeros behind them, which
 // neither the dot products nor the training see), its nsel weight sets (c[9]; absolute rows, no device terms) one per wavefront, the second layer,
-// the model's APM chain on one lane (p8s_tail_color), the export: nx + nsel + 10 values back to back, the rest of the 1591 as they were
+// the model's APM chain on one lane (p8s_tail_image), the export: nx + nsel + 10 values back to back, the rest of the 1591 as they were
 // (AddPrediction() counts on, :504-510). Same packed arithmetic as cmx_p8s_mix4_kernel. T: the state the generic mixer leaves and takes over.
 constexpr int XMX_THREADS = 1024;
 __global__ __launch_bounds__(XMX_THREADS) void cmx_p8s_xmix_kernel(const P8MixDev* M, P8TailDev* T, const int16_t* x, const int32_t* sel, const P8ApmRec* apm, const uint8_t* bits,
@@ -1144,7 +1148,7 @@ __global__ __launch_bounds__(XMX_THREADS) void cmx_p8s_xmix_kernel(const P8MixDe
     __syncthreads();
     if (tid == 0) {   // the model's chain, serial on the tables in HBM
       T->misses = misses;
-      fin_s = p8s_tail_color(T, a, y, p_s, outs + nx + nsel);
+      fin_s = p8s_tail_image(T, a, y, p_s, outs + nx + nsel);
     }
     __syncthreads();
     float* orow = out + (size_t)t * ld;

@@ -178,12 +178,17 @@ bool build_stage(P8StageState& S, Policy& P, const P8Layout& L, int level, const
     T.gen[0] = (uint16_t*)up(v.data(), (size_t)0x2000 * 33 * 2);
     for (int k = 1; k < 7; k++) T.gen[k] = (uint16_t*)up(v.data(), v.size() * 2);
     for (int k = 0; k < 2; k++) T.col_apm1[k] = (uint16_t*)up(v.data(), v.size() * 2);   // Image.Color's APM1s :8224
+    for (int k = 0; k < 2; k++) T.pal_apm1[k] = (uint16_t*)up(v.data(), v.size() * 2);   // Image.Palette's
   }
   {
     std::vector<uint32_t> v((size_t)0x10000 * 24);
     for (size_t i = 0; i < v.size(); i++) { const int p = (((int)(i % 24) * 2 + 1) * 4096) / 48 - 2048; v[i] = ((uint32_t)sq(p) << 20) + 6; }
     T.col_apm[0] = (uint32_t*)up(v.data(), (size_t)0x1000 * 24 * 4);                      // Image.Color's APMs {0x1000}, 3 x {0x10000} :8223
     for (int k = 1; k < 4; k++) T.col_apm[k] = (uint32_t*)up(v.data(), v.size() * 4);
+    T.pal_apm[0] = (uint32_t*)up(v.data(), (size_t)0x1000 * 24 * 4);
+    for (int k = 1; k < 4; k++) T.pal_apm[k] = (uint32_t*)up(v.data(), v.size() * 4);
+    T.gray_apm[0] = (uint32_t*)up(v.data(), (size_t)0x1000 * 24 * 4);
+    for (int k = 1; k < 3; k++) T.gray_apm[k] = (uint32_t*)up(v.data(), v.size() * 4);
   }
   return true;
 }

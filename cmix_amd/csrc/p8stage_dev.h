@@ -125,6 +125,9 @@ struct P8TailDev {
   uint16_t* gen[7]; int gen_idx[7];      // other blocks: seven APM1 (0x2000 and 6 x 0x10000 contexts)
   uint32_t* col_apm[4]; int col_cxt[4];  // IMAGE24 / IMAGE32 (Image.Color :8222-8225): four APM (0x1000, 3 x 0x10000 contexts) ...
   uint16_t* col_apm1[2]; int col_idx[2]; // ... and two APM1 (0x10000)
+  uint32_t* pal_apm[4]; int pal_cxt[4];  // IMAGE8 (Image.Palette :8226-8229): the same shapes
+  uint16_t* pal_apm1[2]; int pal_idx[2];
+  uint32_t* gray_apm[3]; int gray_cxt[3];   // IMAGE8GRAY (Image.Gray :8230-8232): three APM (0x1000, 2 x 0x10000)
   uint64_t misses;
   int pr;                                 // the last final prediction (12 bits)
   const int16_t* stretch; const int16_t* squash;   // squash: index d + 2048
@@ -218,5 +221,45 @@ P8_HD int p8s_tail_color(P8TailDev* d, const P8ApmRec* a, int y, int pr0, float*
   pr = (pr + avg + 1) >> 1;
   o[9] = (float)pr * cf;
   return pr;
+}
+// Image.Palette (:8325-8340): 10 exported values
+P8_HD int p8s_tail_palette(P8TailDev* d, const P8ApmRec* a, int y, int pr0, float* o) {
+  const int16_t* st = d->stretch;
+  const float cf = (float)(1.0 / 4095);
+  const int lim = a->limit;
+  int pr = p8s_apm(d->pal_apm[0], &d->pal_cxt[0], st, y, pr0, a->c[0] | (int)(d->misses & 0xF), lim);
+  int pr1 = p8s_apm(d->pal_apm[1], &d->pal_cxt[1], st, y, pr0, a->c[1], lim);
+  int pr2 = p8s_apm(d->pal_apm[2], &d->pal_cxt[2], st, y, pr0, a->c[2], lim);
+  const int pr3 = p8s_apm(d->pal_apm[3], &d->pal_cxt[3], st, y, pr0, a->c[3], lim);
+  o[0] = (float)pr0 * cf; o[1] = (float)pr * cf; o[2] = (float)pr1 * cf; o[3] = (float)pr2 * cf; o[4] = (float)pr3 * cf;
+  const int avg = (pr0 + pr1 + pr2 + pr3 + 2) >> 2;
+  o[5] = (float)avg * cf;
+  pr1 = p8s_apm1(d->pal_apm1[0], &d->pal_idx[0], st, y, avg, a->c[4], 5);
+  pr2 = p8s_apm1(d->pal_apm1[1], &d->pal_idx[1], st, y, pr, a->c[5], 6);
+  o[6] = (float)pr1 * cf; o[7] = (float)pr2 * cf;
+  pr = (pr * 2 + pr1 + pr2 + 2) >> 2;
+  o[8] = (float)pr * cf;
+  pr = (pr + avg + 1) >> 1;
+  o[9] = (float)pr * cf;
+  return pr;
+}
+// Image.Gray (:8315-8324): 6 exported values; the second APM refines the first one's output
+P8_HD int p8s_tail_gray(P8TailDev* d, const P8ApmRec* a, int y, int pr0, float* o) {
+  const int16_t* st = d->stretch;
+  const float cf = (float)(1.0 / 4095);
+  const int lim = a->limit;
+  int pr = p8s_apm(d->gray_apm[0], &d->gray_cxt[0], st, y, pr0, a->c[0] | (int)(d->misses & 0xF), lim);
+  const int pr1 = p8s_apm(d->gray_apm[1], &d->gray_cxt[1], st, y, pr, a->c[1], lim);
+  const int pr2 = p8s_apm(d->gray_apm[2], &d->gray_cxt[2], st, y, pr0, a->c[2], lim);
+  o[0] = (float)pr0 * cf; o[1] = (float)pr * cf; o[2] = (float)pr1 * cf; o[3] = (float)pr2 * cf;
+  const int avg = (2 * pr0 + pr1 + pr2 + 2) >> 2;
+  o[4] = (float)avg * cf;
+  pr = (pr + avg + 1) >> 1;
+  o[5] = (float)pr * cf;
+  return pr;
+}
+// the chain of an image model's step by its kind (P8ApmRec.text)
+P8_HD int p8s_tail_image(P8TailDev* d, const P8ApmRec* a, int y, int pr0, float* o) {
+  return a->text == P8_APM_COLOR ? p8s_tail_color(d, a, y, pr0, o) : a->text == P8_APM_GRAY ? p8s_tail_gray(d, a, y, pr0, o) : p8s_tail_palette(d, a, y, pr0, o);
 }
 #endif

@@ -77,6 +77,17 @@ def bmp_file(img):
             h.to_bytes(4, "little") + (1).to_bytes(2, "little") + (8 * planes).to_bytes(2, "little") + bytes(4) + len(pix).to_bytes(4, "little") + bytes(16) + pix)
 
 
+def bmp8_file(img, palette):
+    """bottom-up 8-bit BMP of an [h, w] index image with a 256-entry palette ([256, 3] BGR)"""
+    h, w = img.shape
+    row = (w + 3) & ~3
+    pix = b"".join(img[y].tobytes() + bytes(row - w) for y in range(h - 1, -1, -1))
+    pal = b"".join(bytes([int(b), int(g), int(r), 0]) for b, g, r in palette)
+    off = 54 + 1024
+    return (b"BM" + (off + len(pix)).to_bytes(4, "little") + bytes(4) + off.to_bytes(4, "little") + (40).to_bytes(4, "little") + w.to_bytes(4, "little") +
+            h.to_bytes(4, "little") + (1).to_bytes(2, "little") + (8).to_bytes(2, "little") + bytes(4) + len(pix).to_bytes(4, "little") + bytes(16) + pal + pix)
+
+
 def preprocessed(payload):
     """the stream the reference's preprocessor (preprocessor.cpp:568 Encode) hands the predictor for a file: block headers, detected
     types (HDR + IMAGE24 / IMAGE32 for a BMP), its transforms -- through oracle/_ref/libcmixref.so (oracle/ref_harness.cpp)"""
@@ -100,6 +111,12 @@ def image_streams():
         "bmp24_14k": preprocessed(text[:300] + bmp_file(photo(96, 48, 3, 1)) + text[300:]),
         "bmp32_8k": preprocessed(text[:200] + bmp_file(photo(48, 40, 4, 2)) + bytes(range(256))),
         "bmp24_raw_9k": default_block(text[:150] + bmp_file(photo(64, 44, 3, 3)) + text[150:400]),
+        # 8-bit images (im8bitModel :4743-4999): a binary PGM, which the preprocessor turns into an IMAGE8GRAY block; BMP files with a gray ramp
+        # palette (paq8's detector walks the palette, finds it gray: the grayscale face of the model) and with a colour palette (the palette face)
+        "pgm8_4k": preprocessed(text[:250] + b"P5\n64 56\n255\n" + photo(64, 56, 1, 4)[:, :, 0].tobytes() + text[250:500]),
+        "bmp8_gray_raw_5k": default_block(text[:100] + bmp8_file(photo(64, 52, 1, 5)[:, :, 0], [(i, i, i) for i in range(256)]) + text[100:300]),
+        "bmp8_pal_raw_5k": default_block(text[:120] + bmp8_file(((photo(64, 52, 1, 6)[:, :, 0] >> 3).astype(np.uint8) * np.uint8(5)),
+                                                                np.random.default_rng(8).integers(0, 256, (256, 3))) + text[120:300]),
     }
 
 

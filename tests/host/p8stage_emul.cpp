@@ -115,6 +115,15 @@ void p8s_dump_fam(void* h, uint32_t* out /* [nslots][5] */) {
   }
 }
 void p8s_dump_table(void* h, int inst, uint8_t* out) { Emul* e = (Emul*)h; memcpy(out, e->S.fam.inst[inst].table, ((size_t)e->S.fam.inst[inst].mask + 1) * 64); }
+// diagnostics: where the tables' inputs sit
+void p8s_layout_dump(void* h) {
+  const P8Layout& L = *p8f_front_layout(((Emul*)h)->front);
+  int s = 0;
+  for (int k = 0; k < L.fam_ninst; k++) { printf("family inst %d: %d contexts, inputs %d..%d\n", k, L.fam_count[k], L.fam_off[s], L.fam_off[s + L.fam_count[k] - 1] + 4); s += L.fam_count[k]; }
+  for (int k = 0; k < P8_NCM2; k++) printf("cm2 %d: %d contexts at %d\n", k, L.cm2_count[k], L.cm2_off[k]);
+  for (int l = 0; l < L.nlanes; l++) printf("lane %d kind %d off %d nout %d\n", l, L.lane[l].kind, L.lane[l].off, L.lane[l].nout);
+  for (int m = 0; m < P8_NMODEL - 1; m++) printf("image model %d: prefix %d nx %d lanes %d contexts %d (first at %d)\n", m + 1, L.xl[m].prefix_nx, L.xl[m].nx, L.xl[m].nlanes, L.xl[m].fam_count, L.xl[m].fam_off[0]);
+}
 void p8s_set_miniwalk(void* h, int mode) { ((Emul*)h)->fam_miniwalk = mode; }
 void p8s_set_late(void* h, int on) { ((Emul*)h)->late = on; }
 void p8s_miniwalk_stats(void* h, uint64_t* out2) { out2[0] = ((Emul*)h)->fam_mini; out2[1] = ((Emul*)h)->fam_mini_full; }
@@ -343,10 +352,19 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
       for (int j = 0; j < bp; j++) c0 = c0 * 2 + bits[t - bp + j];
       u.y = y; u.bp = bp; u.c0 = c0; u.c1 = (t >> 3) ? bytes[(t >> 3) - 1] : e->last_byte; u.order = 0;
       u.ctx = c.xfam_ctx + (t >> 3) * P8_XL_MAXS; u.chk = c.xfam_chk + (t >> 3) * P8_XL_MAXS; u.out = xr;
-      for (int sl = 0; sl < xd->nslots; sl++) p8d_cm_ctx(xd, &e->xsh[md - 1], u, sl, nullptr);
+      const int nact = (int)u.ctx[P8_XL_MAXS - 1];   // the contexts this byte has set
+      P8CmShared* xs = &e->xsh[md - 1];   // the four phases of cmx_p8s_xfam_kernel, lanes looped per phase
+      xs->nact = nact;
+      for (int sl = nact - 1; sl >= 0; sl--) p8d_cm_touch(xd, xs, u, sl);
+      for (int sl = nact - 1; sl >= 0; sl--) p8d_cm_check(xd, xs, sl);
+      for (int sl = nact - 1; sl >= 0; sl--) p8d_cm_draw(xd, xs, sl);
+      for (int sl = nact - 1; sl >= 0; sl--) p8d_cm_run(xd, xs, u, sl);
       P8XLanesDev* XD = &S.xlanes[md - 1];
       const P8LaneTabs tb = {XD->nex, XD->stretch};
-      for (int l = XD->nlanes - 1; l >= 0; l--) p8s_lane_step_t(&XD->lane[l], &tb, &XD->regs[l], c.xops[t * P8_XL_NLANE + l], y, order[t], xr, P8_NX);
+      for (int l = XD->nlanes - 1; l >= 0; l--) {   // a map the step does not call is not touched and writes nothing: its positions may be another face's (im8bitModel: gray / palette)
+        const uint32_t op = c.xops[t * P8_XL_NLANE + l];
+        if (op & P8OP_MIX) p8s_lane_step_t(&XD->lane[l], &tb, &XD->regs[l], op, y, order[t], xr, P8_NX);
+      }
     }
     // ---- mixer + tail (Mixer::p :553-581, Predictor::update :8281-8358) ----
     P8TailDev& Tl = S.tail;
@@ -374,7 +392,7 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
     const int p2 = p8s_squash(Tl.squash, dot(st, S.mix.wx2, 32) >> 9);
     int res[8];
     int fin;
-    if (c.apm[t].text == P8_APM_COLOR) fin = p8s_tail_color(&Tl, &c.apm[t], y, p2, Tl.out + nx + nsel);
+    if (c.apm[t].text >= P8_APM_COLOR) fin = p8s_tail_image(&Tl, &c.apm[t], y, p2, Tl.out + nx + nsel);
     else {
       for (int j = 3; j >= 0; j--) p8s_tail_a(&Tl, &c.apm[t], y, p2, j, res);
       for (int j = 2; j >= 0; j--) p8s_tail_b(&Tl, &c.apm[t], y, p2, j, res);

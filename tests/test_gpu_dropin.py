@@ -294,6 +294,17 @@ def test_dropin_engine_empty_and_tiny_files():
         assert _run(mode, [("in", v[name + "_payload"])], exe=DROPIN, timeout=300) == v[name + "_file"], name
 
 
+def test_dropin_engine_file_with_a_24bit_bmp_is_byte_identical():
+    """text + a 96 x 48 BMP + text (tests/golden/make_dropin_bmp.py): the reference's detector makes HDR + IMAGE24 blocks of the picture, its
+    preprocessor the colour transform; paq8's im24bitModel runs in the paq8 stage's image kernels (p8stage.hip), every other stage on the
+    image's bytes as on any others. The file the unmodified reference binary wrote."""
+    if not os.path.exists(DROPIN):
+        _missing("oracle/_ref/cmix_dropin not built")
+    with np.load(os.path.join(GOLDEN, "dropin_bmp.npz")) as z:
+        payload, blob = z["payload"].tobytes(), z["cmix_file"].tobytes()
+    assert _run("-c", [("in", payload)], exe=DROPIN, timeout=600) == blob
+
+
 # ---- DECOMPRESSION with the whole engine: `cmix_dropin -d` = the reference's runner.cpp + decoder.cpp + preprocessor, no model ----
 # Decoder::Decode (decoder.cpp:20-39) calls Predict() and only then knows the bit it hands to Perceive(): the library's late-bit
 # protocol (cmix_amd/csrc/cmx_late.h) -- every stage kernel of the chunk pipeline, fxcm and paq8 included, waiting for the bits

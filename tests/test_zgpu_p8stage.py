@@ -52,10 +52,10 @@ def test_stage_vs_reference_hashes(name):
     assert bad.size == 0, (name, "first differing step:", bad[0], "of", len(want))
 
 
-@pytest.mark.parametrize("name", ["bmp24_14k", "bmp32_8k", "bmp24_raw_9k"])
+@pytest.mark.parametrize("name", ["bmp24_14k", "bmp32_8k", "bmp24_raw_9k", "pgm8_4k", "bmp8_gray_raw_5k", "bmp8_pal_raw_5k"])
 def test_image_model_streams_vs_reference_hashes(name):
     """24 / 32-bit images (im24bitModel): an IMAGE24 block between other blocks, and BMP files inside DEFAULT blocks where paq8's own detector
-    switches the model on and off. Chunks that hold image bytes run their roles on one stream, the ContextMap family and the mixer by
+    switches the model on and off; 8-bit images (im8bitModel): an IMAGE8GRAY block (a PGM), BMP files with a gray and with a colour palette. Chunks that hold image bytes run their roles on one stream, the ContextMap family and the mixer by
     segments (generic kernels / the image model's: cmx_p8s_xfam_kernel, cmx_p8s_xlanes_kernel, cmx_p8s_xmix_kernel), the rnd() stream handed
     over at every switch; the ragged chunk sizes put the switches at chunk starts, ends and in the middle."""
     from make_paq8_hashes import row_hash
