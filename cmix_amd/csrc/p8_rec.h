@@ -22,11 +22,12 @@ enum {
   P8_NLANE = 64,           /* small learners + host-computed inputs, one lane each */
   P8_ORDER_MAX = 10,       /* ContextMap2::mix's return value for the 10-context order-N map */
   /* the image models (im24bitModel :5001-5353, im8bitModel :4743-4999): a model id per byte, 0 = everything above */
-  P8_NMODEL = 3,           /* 0 generic (text / default / exe ...), 1 im24 (IMAGE24 / IMAGE32 blocks, 24 / 32-bit BMP / TGA payloads), 2 im8 */
+  P8_NMODEL = 5,           /* 0 generic (text / default / exe ...), 1 im24 (IMAGE24 / IMAGE32 blocks, 24 / 32-bit BMP / TGA payloads), 2 im8, 3 audio8, 4 wav16 */
   P8_XL_NLANE = 192,       /* small maps of one image model (im24: 100 StationaryMap + 59 SmallStationaryContextMap) */
-  P8_XL_MAXS = 64          /* contexts of an image model's ContextMap (im24: 47, im8: 52) */
+  P8_XL_MAXS = 64,         /* slots of a model's ContextMap family (im24: 47, im8: 52, wav16: 11 + recordModel's 25); the row's last two cells: active range */
+  P8_XL_MAXG = 8           /* generic ContextMap instances a model also calls (the audio models: recordModel's four) */
 };
-enum { P8_MODEL_GENERIC = 0, P8_MODEL_IM24 = 1, P8_MODEL_IM8 = 2 };
+enum { P8_MODEL_GENERIC = 0, P8_MODEL_IM24 = 1, P8_MODEL_IM8 = 2, P8_MODEL_AUDIO8 = 3, P8_MODEL_WAV16 = 4 };
 
 /* small lanes (one wavefront): kinds */
 enum {
@@ -53,6 +54,8 @@ typedef struct {
   int16_t nout;                /* inputs produced (2 for the maps, 1 for SM32 / PIC / DIRECT) */
   uint32_t cells;              /* table size in cells */
   uint32_t init;               /* cell initial value (SM32 with 256 cells: the state-table prior instead) */
+  uint32_t modes;              /* a lane of the generic table: bit m set = it is also called in the steps of model m (the common prefix: every model; recordModel's
+                                * maps: the audio models) */
 } P8Lane;
 
 /* An image model's part of the layout. Its steps run contextModel2's common prefix (:8133-8160: the constant, two StateMap32, the
@@ -64,9 +67,17 @@ typedef struct {
   int prefix_nx, nx;
   int nlanes;
   P8Lane lane[P8_XL_NLANE];
-  uint64_t fam_size;                   /* the model's one ContextMap */
+  uint64_t fam_size;                   /* the model's own ContextMap (fam_count == 0: none) */
   int fam_count;
-  int16_t fam_off[P8_XL_MAXS];
+  int16_t fam_off[P8_XL_MAXS];         /* input position of a family slot's five inputs (own contexts first, then the generic instances') */
+  /* generic ContextMap instances the model calls after its own maps (the audio models end with recordModel :5861): they join the model's
+   * family at slots gen_first[k] .., sharing tables and per-context state with the generic family (handed over at every switch) */
+  int ngen, gen_inst[P8_XL_MAXG], gen_first[P8_XL_MAXG];
+  int nslots;                          /* fam_count + the generic instances' contexts */
+  /* the step's inputs in add() order -> positions in the 1552-vector: the model's own first (position = order), then the generic maps' at their
+   * generic positions. own_opt: inputs [opt_lo, opt_lo + opt_n) are the own ContextMap's, absent in a byte it is silent (P8ApmRec.c[7]) */
+  int16_t map[P8_NX];
+  int opt_lo, opt_n;
 } P8XLayout;
 
 typedef struct {
@@ -98,7 +109,8 @@ enum { P8_SEL_ORDER3 = 19, P8_SEL_ORDER5_A = 20, P8_SEL_ORDER5_B = 21, P8_SEL_OR
  *              misses & 3 = 0..3, c[5], c[6] = third, fourth; c[7..9] = the three APM1 contexts
  * other:       c[0] = mlen << 11 | c0 << 3 (device ORs misses & 7), c[1..3] = ctx1..3, c[4] = expected byte << 8 | c1 */
 /* IMAGE24/32 (kind 2, Image.Color :8299-8314): c[0] = c0 << 4 (device ORs misses & 15), c[1..3] = the other three APMs' contexts,
- *              c[4], c[5] = the two APM1 contexts; c[8] = the step's input count nx, c[9] = its weight-set count
+ *              c[4], c[5] = the two APM1 contexts; c[8] = the step's input count nx, c[9] = its weight-set count, c[7] = 1: the model's own ContextMap is silent this byte
+ *              (every image / audio kind)
  * IMAGE8GRAY (kind 3, Image.Gray :8315-8324): c[0] as above, c[1], c[2]; IMAGE8 (kind 4, Image.Palette :8325-8340): c[0..3], c[4], c[5] */
 enum { P8_APM_GENERIC = 0, P8_APM_TEXT = 1, P8_APM_COLOR = 2, P8_APM_GRAY = 3, P8_APM_PALETTE = 4 };
 typedef struct { uint16_t c[10]; uint16_t limit; uint8_t text /* = kind: P8_APM_* */, model /* P8_MODEL_* of the step */; } P8ApmRec;

@@ -48,8 +48,13 @@ struct P8CmShared {
   uint32_t draw_val[P8CM_MAXS];
   int conflict, ndraws;
   P8Rnd rnd;
-  int nact;   // contexts that are set this byte when that is fewer than the family has (an image model's ContextMap, ContextMap::mix loops over cn :1072); 0: all
+  // the slots [act_lo, act_hi) are the ones whose ContextMap is called this byte with a context set (an image / audio model's family:
+  // im8bitModel sets 25 or 52 contexts, wavModel's map is silent during a block's first sample; ContextMap::mix loops over cn :1072);
+  // act_hi == 0: all
+  int act_lo, act_hi;
 };
+P8_HD int p8d_cm_lo(const P8CmShared* sh) { return sh->act_hi > 0 ? sh->act_lo : 0; }
+P8_HD int p8d_cm_hi(const P8CmDev* d, const P8CmShared* sh) { return sh->act_hi > 0 ? sh->act_hi : d->nslots; }
 struct P8CmBit { int y, bp, c0, c1, order; const uint32_t* ctx; const uint16_t* chk; int16_t* out; };
 
 
@@ -129,7 +134,7 @@ P8_HD void p8d_cm_touch(P8CmDev* d, P8CmShared* sh, const P8CmBit& u, int s) {  
   const P8CmRegs* r = &sh->r;
   int32_t* L = sh->touched[s];
   for (int j = 0; j < 5; j++) L[j] = -1;
-  if (s == 0) sh->conflict = 0;
+  if (s == p8d_cm_lo(sh)) sh->conflict = 0;
   sh->draws[s] = 0;
   if (r->cp[s] != P8_NIL) {
     L[0] = (int32_t)(r->cp[s] >> 6);
@@ -159,8 +164,8 @@ P8_HD void p8d_cm_check(P8CmDev* d, P8CmShared* sh, int s) {   // step b
   const P8CmInst* x = &d->inst[d->slot_inst[s]];
   const int32_t* L = sh->touched[s];
   int hit = 0;
-  const int nall = sh->nact > 0 ? sh->nact : d->nslots;
-  for (int o = x->first; o < x->first + x->count && o < nall && !hit; o++) {
+  const int lo = p8d_cm_lo(sh), nall = p8d_cm_hi(d, sh);
+  for (int o = x->first > lo ? x->first : lo; o < x->first + x->count && o < nall && !hit; o++) {
     if (o == s) continue;
     const int32_t* O = sh->touched[o];
     for (int a = 0; a < 5 && !hit; a++)
@@ -169,17 +174,17 @@ P8_HD void p8d_cm_check(P8CmDev* d, P8CmShared* sh, int s) {   // step b
   }
   if (hit) sh->conflict = 1;
   int rank = 0;
-  for (int o = 0; o < s; o++) rank += sh->draws[o];
+  for (int o = lo; o < s; o++) rank += sh->draws[o];
   sh->rank[s] = (uint16_t)rank;
   if (s == nall - 1) sh->ndraws = rank + sh->draws[s];
 }
 P8_HD void p8d_cm_draw(P8CmDev* d, P8CmShared* sh, int s) {   // step b2
-  if (s != 0 || sh->conflict || !d->slot_parallel) return;
+  if (s != p8d_cm_lo(sh) || sh->conflict || !d->slot_parallel) return;
   for (int k = 0; k < sh->ndraws; k++) sh->draw_val[k] = p8d_rnd_next(&sh->rnd);
 }
 P8_HD void p8d_cm_run(P8CmDev* d, P8CmShared* sh, const P8CmBit& u, int s) {   // step c
   if (!sh->conflict && d->slot_parallel) p8d_cm_ctx(d, sh, u, s, &sh->draw_val[sh->rank[s]]);
-  else if (s == 0) { const int nall = sh->nact > 0 ? sh->nact : d->nslots; for (int j = 0; j < nall; j++) p8d_cm_ctx(d, sh, u, j, nullptr); }
+  else if (s == p8d_cm_lo(sh)) { const int nall = p8d_cm_hi(d, sh); for (int j = s; j < nall; j++) p8d_cm_ctx(d, sh, u, j, nullptr); }
 }
 // uniform values of step t of a chunk. order: the order-N map's return values per step (NULL: no order context)
 P8_HD P8CmBit p8d_cm_bit(const P8CmDev* d, const uint32_t* ctx, const uint16_t* chk, const uint8_t* bits_in, int16_t* out, const uint8_t* order, int t, int* last_y, int* c1) {

@@ -61,18 +61,25 @@ static void fail(const char* what) {
 void p8f_emit_begin_step(P8Emit* e, int16_t* in_base, P8Chunk* chunk, size_t byte_row, size_t step_row, int full) {
   e->in_base = in_base; e->chunk = chunk; e->byte_row = byte_row; e->step_row = step_row; e->full = full;
   e->fam_calls = e->cm2_calls = 0;
-  e->model = 0;
+  e->model = 0; e->step_model = 0;
   if (chunk) memset(chunk->ops + step_row * P8_NLANE, 0, P8_NLANE * sizeof(uint32_t));
 }
-void p8f_emit_model(P8Emit* e, int m) {
-  e->model = m;
+void p8f_emit_model(P8Emit* e, int m) { e->model = m; }
+void p8f_emit_step_model(P8Emit* e, int m) {
+  e->step_model = m;
   if (m && e->chunk && e->chunk->xops) memset(e->chunk->xops + e->step_row * P8_XL_NLANE, 0, P8_XL_NLANE * sizeof(uint32_t));
+}
+/* discovery: input `compact` (add() order) of the current step's model sits at `pos` of the 1552-vector */
+static void xmap(P8Emit* e, int compact, int pos, int n) {
+  if (!e->xdiscovering || !e->step_model) return;
+  P8XLayout* X = &e->L.xl[e->step_model - 1];
+  for (int j = 0; j < n; j++) if (compact + j >= 0 && compact + j < P8_NX) X->map[compact + j] = (int16_t)(pos + j);
 }
 
 static int claim(P8Emit* e, const int16_t* out, int n) {  /* discovery: remember who produces which input positions */
   const int off = (int)(out - e->in_base);
   if (off < 0 || off + n > P8_NX) { fail("input position out of range"); return 0; }
-  if (e->discovering && !e->model) memset((e->full ? e->claimed : e->claimed0) + off, 1, (size_t)n);
+  if (e->discovering && !e->model && !e->step_model) memset((e->full ? e->claimed : e->claimed0) + off, 1, (size_t)n);
   return off;
 }
 
@@ -82,6 +89,10 @@ CM1* p8f_cm_new(uint64_t size_bytes, int count) {
   CM1* c = (CM1*)calloc(1, sizeof *c);
   c->inst = -1; c->count = count; c->size = size_bytes; c->order_idx = -1;
   c->model = p8f_cur ? p8f_cur->model : 0;
+  if (c->model && p8f_cur->xdiscovering) {   /* a model's own ContextMap: its slots come first in the model's family, whenever it is first called */
+    P8XLayout* X = &p8f_cur->L.xl[c->model - 1];
+    X->fam_size = size_bytes; X->fam_count = count; if (X->nslots < count) X->nslots = count;
+  }
   c->hashbits = (int)ilog2u((unsigned)(size_bytes >> 6));
   return c;
 }
@@ -104,13 +115,11 @@ static int xcm_step(CM1* c, int bp, const uint64_t* ctx, int nset, int16_t* out,
   if (e->model != c->model) { fail("an image model's ContextMap called outside its model"); return 0; }
   if (c->inst < 0) {
     c->inst = 0;
-    if (e->xdiscovering) { X->fam_size = c->size; X->fam_count = 0; }
-    else if (X->fam_size != c->size) { fail("an image model's ContextMap changed"); return 0; }
+    if (X->fam_size != c->size) { fail("an image model's ContextMap changed"); return 0; }
   }
   if (bp == 0) {
-    if (c->cn + nset > c->count || c->cn + nset >= P8_XL_MAXS) { fail("too many contexts set (image model)"); return 0; }
-    if (e->xdiscovering) { if (c->cn + nset > X->fam_count) X->fam_count = c->cn + nset; }
-    else if (c->cn + nset > X->fam_count) { fail("an image model's ContextMap got more contexts than in the layout pass"); return 0; }
+    if (c->cn + nset > c->count || c->cn + nset > P8_XL_MAXS - 2) { fail("too many contexts set (image model)"); return 0; }
+    if (c->cn + nset > X->fam_count) { fail("an image model's ContextMap got more contexts than in the layout pass"); return 0; }
     for (int i = 0; i < nset; ++i, ++c->cn) {
       const uint64_t h = p8f_hash2(ctx[i], (uint64_t)c->cn);
       if (e->chunk && e->chunk->xfam_ctx) {
@@ -119,12 +128,58 @@ static int xcm_step(CM1* c, int bp, const uint64_t* ctx, int nset, int16_t* out,
       }
     }
     /* how many contexts the byte has set (im8bitModel: 25 for a grayscale image, 52 for a palette one): the row's last cell */
-    if (e->chunk && e->chunk->xfam_ctx) e->chunk->xfam_ctx[e->byte_row * (size_t)P8_XL_MAXS + (size_t)(P8_XL_MAXS - 1)] = (uint32_t)c->cn;
+    if (e->chunk && e->chunk->xfam_ctx) {
+      e->chunk->xfam_ctx[e->byte_row * (size_t)P8_XL_MAXS + (size_t)(P8_XL_MAXS - 2)] = 0;
+      e->chunk->xfam_ctx[e->byte_row * (size_t)P8_XL_MAXS + (size_t)(P8_XL_MAXS - 1)] = (uint32_t)c->cn;
+    }
   }
   const int n = 5 * c->cn;
   if (n) {
     const int off = claim(e, out, n);
-    if (e->xdiscovering) for (int i = 0; i < c->cn; ++i) X->fam_off[i] = (int16_t)(off + 5 * i);
+    if (e->xdiscovering) {
+      for (int i = 0; i < c->cn; ++i) X->fam_off[i] = (int16_t)(off + 5 * i);
+      xmap(e, off, off, n);
+      X->opt_lo = off; if (n > X->opt_n) X->opt_n = n;
+    }
+  }
+  if (bp == 7) c->cn = 0;
+  *nout = n;
+  return 0;
+}
+/* a generic ContextMap called in a model's step (recordModel under the audio models): it joins the model's family -- its contexts also go
+ * to the model's family row, at the slots the layout pass gave the instance -- and its inputs stay at their generic positions */
+static int gcm_in_model(CM1* c, int bp, const uint64_t* ctx, int nset, int16_t* out, int* nout) {
+  P8Emit* e = p8f_cur;
+  P8Layout* L = &e->L;
+  P8XLayout* X = &L->xl[e->step_model - 1];
+  if (c->inst < 0) { fail("a generic ContextMap first called inside a model's step"); return 0; }
+  int g = -1;
+  for (int k = 0; k < X->ngen; k++) if (X->gen_inst[k] == c->inst) g = k;
+  if (g < 0) {
+    if (!e->xdiscovering || X->ngen >= P8_XL_MAXG) { fail("a generic ContextMap the model's layout does not know"); return 0; }
+    g = X->ngen++;
+    X->gen_inst[g] = c->inst;
+    X->gen_first[g] = g ? X->gen_first[g - 1] + L->fam_count[X->gen_inst[g - 1]] : X->fam_count;
+    X->nslots = X->gen_first[g] + L->fam_count[c->inst];
+    if (X->nslots > P8_XL_MAXS - 2) { fail("a model's ContextMap family is too large"); return 0; }
+  }
+  int first = 0;
+  for (int i = 0; i < c->inst; ++i) first += L->fam_count[i];
+  if (bp == 0) {
+    if (c->cn + nset > L->fam_count[c->inst]) { fail("too many contexts set"); return 0; }
+    for (int i = 0; i < nset; ++i, ++c->cn) {
+      const uint64_t h = p8f_hash2(ctx[i], (uint64_t)c->cn);
+      if (e->chunk && e->chunk->xfam_ctx) {
+        const size_t at = e->byte_row * (size_t)P8_XL_MAXS + (size_t)(X->gen_first[g] + c->cn);
+        e->chunk->xfam_ctx[at] = p8f_finalize64(h, c->hashbits);
+        e->chunk->xfam_chk[at] = (uint16_t)(p8f_checksum64(h, c->hashbits, 16) & 0xffff);
+      }
+    }
+  }
+  const int n = 5 * c->cn;
+  if (n) {
+    const int compact = (int)(out - e->in_base);
+    if (e->xdiscovering) for (int i = 0; i < c->cn; ++i) { xmap(e, compact + 5 * i, L->fam_off[first + i], 5); X->fam_off[X->gen_first[g] + i] = L->fam_off[first + i]; }
   }
   if (bp == 7) c->cn = 0;
   *nout = n;
@@ -134,6 +189,7 @@ int p8f_cm_step(CM1* c, int y1, int bp, int c0, int c1, const uint64_t* ctx, int
   P8Emit* e = p8f_cur;
   (void)y1; (void)c0; (void)c1;
   if (c->model) return xcm_step(c, bp, ctx, nset, out, nout);
+  if (e->step_model) return gcm_in_model(c, bp, ctx, nset, out, nout);
   P8Layout* L = &e->L;
   const int k = e->fam_calls++;
   if (c->inst < 0) {  /* first call: the instance takes the next place in the walk */
@@ -252,6 +308,11 @@ static void lane_out(int model, int l, const int16_t* out, int nout, int a, int 
     if (!e->xdiscovering) return;
     P8Lane* q = &e->L.xl[model - 1].lane[l];
     q->off = (int16_t)off; q->nout = (int16_t)nout; q->a = (uint8_t)a; q->mul = (uint8_t)mul; q->div = (uint8_t)div; q->limit = (uint16_t)limit; q->bits_per_ctx = (uint16_t)bpc;
+    xmap(e, off, off, nout);
+    return;
+  }
+  if (e->step_model) {   /* a generic map called in a model's step: it runs at its generic place */
+    if (e->xdiscovering) { e->L.lane[l].modes |= 1u << e->step_model; xmap(e, off, e->L.lane[l].off, nout); }
     return;
   }
   if (!e->discovering) return;

@@ -24,6 +24,8 @@ typedef struct {
   /* image models (p8_rec.h P8XLayout): while `model` is non-zero, maps and the ContextMap that are created / called belong to
    * that model's own tables (xops / xfam_* of the chunk) */
   int model;
+  int step_model;                        /* the model of the step being emitted (set when the front end enters it, kept to the end of the step): generic
+                                          * maps called under it (recordModel in an audio step) run at their generic places, read through the model's map */
   int xdiscovering;                      /* layout pass of the image models (the generic objects are already fixed) */
   int xlane_objs[P8_NMODEL - 1];
   int16_t lane_off0[P8_NLANE];           /* discovery: input positions during the first byte */
@@ -40,5 +42,7 @@ int p8f_emit_finish_discovery(P8Emit* e, int nx_first, int nx_full);
 void p8f_emit_directs(P8Emit* e, int lim_off);
 /* the models of image model m (1 ..) are being constructed / stepped from here on (0: back to the generic tables) */
 void p8f_emit_model(P8Emit* e, int m);
+/* the step belongs to model m from here on (its records: xops row cleared, family row's active range reset) */
+void p8f_emit_step_model(P8Emit* e, int m);
 
 #endif

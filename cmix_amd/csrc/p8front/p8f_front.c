@@ -66,6 +66,12 @@ int p8f_exe_step(Exe* e, int y, int bpos, int c0, uint32_t c4, int blpos, const 
                  uint32_t* x86_out);
 Lpm* p8f_lpm_new(void);
 int p8f_lpm_step(Lpm* m, int y, int bpos, int c0, const uint8_t* last, int16_t* out);
+typedef struct Audio8 Audio8;
+typedef struct Wav16 Wav16;
+Audio8* p8f_audio8_new(void);
+int p8f_audio8_step(Audio8* m, int y, int bpos, int c0, const uint8_t* hist, uint32_t bmask, int pos, int info, int blpos, uint32_t* record, int16_t* out, int* sets, int* ranges);
+Wav16* p8f_wav16_new(int level);
+int p8f_wav16_step(Wav16* m, int y, int bpos, int c0, const uint8_t* hist, uint32_t bmask, int pos, int info, uint32_t* record, int16_t* out, int* sets, int* ranges, int* cm_active);
 typedef struct Im24 Im24;
 typedef struct Im8 Im8;
 Im8* p8f_im8_new(int level);
@@ -114,6 +120,10 @@ typedef struct {
   int img_w, img_bpp, img_eoi, img_alpha;          /* imgModel's statics w, bpp, eoi, alpha: an image payload is being modelled while w != 0 */
   Im24* im24;
   Im8* im8;
+  Audio8* audio8;
+  Wav16* wav16;
+  uint32_t wav_eoi, wav_info;                      /* audioModel's statics eoi, info: PCM samples are being modelled while info != 0 */
+  int own_silent;                                  /* the step's model has a ContextMap of its own and it has no contexts this byte */
   uint32_t img_stats[8];                           /* ModelStats.Image of the byte: W, N, NN, WW, Wp1, Np1, plane, ctx */
   int model;                                       /* P8_MODEL_* of the current step */
   int nsel;                                        /* weight sets of the current step */
@@ -158,6 +168,10 @@ static P8Predictor* predictor_new(int level) {
   p->im24 = p8f_im24_new(level);
   p8f_emit_model(p8f_cur, P8_MODEL_IM8);
   p->im8 = p8f_im8_new(level);
+  p8f_emit_model(p8f_cur, P8_MODEL_AUDIO8);
+  p->audio8 = p8f_audio8_new();
+  p8f_emit_model(p8f_cur, P8_MODEL_WAV16);
+  p->wav16 = p8f_wav16_new(level);
   p8f_emit_model(p8f_cur, 0);
   return p;
 }
@@ -309,9 +323,9 @@ static int img_detect(P8Predictor* p, uint32_t* record) {
   }
   return 0;
 }
-static int wav_detect(P8Predictor* p) {  /* audioModel :5814-5851 with eoi == 0 */
+static int wav_detect(P8Predictor* p) {  /* audioModel's byte-boundary part :5814-5851 */
   const int pos = p->pos;
-  if (pos >= 4 && !p->wav.Header && m4(p, 4) == 0x52494646) { p->wav.Header = (uint32_t)pos; p->wav.Chunk = 0; p->wav_length = 0; }
+  if (pos >= (int)(p->wav_eoi + 4) && !p->wav.Header && m4(p, 4) == 0x52494646) { p->wav.Header = (uint32_t)pos; p->wav.Chunk = 0; p->wav_length = 0; }
   else if (p->wav.Header) {
     const int q = pos - (int)p->wav.Header;
     const uint32_t length = p->wav_length;
@@ -331,7 +345,10 @@ static int wav_detect(P8Predictor* p) {  /* audioModel :5814-5851 with eoi == 0 
       p->wav.Header *= (p->wav.Chunk <= 0xFFFFF);
     } else if (q == (int)(40 + length + p->wav.Chunk)) {
       p->wav.Data = (i4(p, 4) + 1) & (uint32_t)(-2);
-      if (p->wav.Data && (p->wav.Data % (p->wav.Channels * (p->wav.BitsPerSample / 8))) == 0) return P8F_ERR_WAV;
+      if (p->wav.Data && (p->wav.Data % (p->wav.Channels * (p->wav.BitsPerSample / 8))) == 0) {   /* PCM samples follow: the audio model runs to eoi */
+        p->wav_info = (p->wav.Channels + p->wav.BitsPerSample / 4 - 3) + 1;
+        p->wav_eoi = (uint32_t)pos + p->wav.Data;
+      }
     }
   }
   return 0;
@@ -403,28 +420,58 @@ static int context_model2(P8Predictor* p, int y, int32_t* sel) {
     }
     if (!img_w && bpos == 0 && (e = wav_detect(p)) != 0) return e;
   }
-  if (img_w) {   /* im24bitModel :5001-5353 / im8bitModel :4743-4999 through the model's own tables and weight sets */
+  /* audioModel :5810-5865 (reached only when no image model took the step) */
+  int aud_info = 0;
+  if (!img_w) {
+    if (p->pos > (int)p->wav_eoi) p->wav_info = 0;
+    aud_info = (int)p->wav_info;
+  }
+  if (img_w || aud_info) {   /* im24bitModel :5001-5353 / im8bitModel :4743-4999 / audio8bModel :5552-5657 / wavModel :5659-5804 through the model's own tables and weight sets */
     P8Emit* const em = p8f_cur;
     if (em->chunk && !em->chunk->xops) return P8F_ERR_IMAGE_LATE;
     int sets[16], ranges[16];
-    const int prefix = nx, model = img_bpp == 8 ? P8_MODEL_IM8 : P8_MODEL_IM24, nsel = img_bpp == 8 ? 8 : 13;
+    const int prefix = nx;
+    const int model = img_w ? (img_bpp == 8 ? P8_MODEL_IM8 : P8_MODEL_IM24) : (((aud_info - 1) & 2) == 0 ? P8_MODEL_AUDIO8 : P8_MODEL_WAV16);
+    int nsel = model == P8_MODEL_IM24 ? 13 : model == P8_MODEL_IM8 ? 8 : 5;
+    P8XLayout* X = &em->L.xl[model - 1];
+    p8f_emit_step_model(em, model);
+    if (em->xdiscovering) for (int i = 0; i < prefix; i++) X->map[i] = (int16_t)i;
     p8f_emit_model(em, model);
-    const int n = img_bpp == 8 ? p8f_im8_step(p->im8, y, bpos, c0, p->buf, p->bmask, p->pos, img_w, img_gray, in + nx, sets, ranges, bpos == 0 ? p->img_stats : NULL)
-                               : p8f_im24_step(p->im24, y, bpos, c0, p->buf, p->bmask, p->pos, img_w, img_alpha, in + nx, sets, ranges, bpos == 0 ? p->img_stats : NULL);
+    int n, own_active = 1;
+    if (model == P8_MODEL_IM8) n = p8f_im8_step(p->im8, y, bpos, c0, p->buf, p->bmask, p->pos, img_w, img_gray, in + nx, sets, ranges, bpos == 0 ? p->img_stats : NULL);
+    else if (model == P8_MODEL_IM24) n = p8f_im24_step(p->im24, y, bpos, c0, p->buf, p->bmask, p->pos, img_w, img_alpha, in + nx, sets, ranges, bpos == 0 ? p->img_stats : NULL);
+    else if (model == P8_MODEL_AUDIO8) { n = p8f_audio8_step(p->audio8, y, bpos, c0, p->buf, p->bmask, p->pos, aud_info - 1, p->blpos, &p->stat_record, in + nx, sets, ranges); own_active = 0; }
+    else n = p8f_wav16_step(p->wav16, y, bpos, c0, p->buf, p->bmask, p->pos, aud_info - 1, &p->stat_record, in + nx, sets, ranges, &own_active);
     p8f_emit_model(em, 0);
     if (n < 0) return P8F_ERR_IMAGE_PADDING;
     nx += n;
-    P8XLayout* X = &em->L.xl[model - 1];
-    if (em->xdiscovering) { X->prefix_nx = prefix; if (nx > X->nx) X->nx = nx; }
-    else if (X->prefix_nx != prefix || nx > X->nx) { fprintf(stderr, "paq8 front end: image step with %d + %d inputs\n", prefix, n); return P8F_ERR_INTERNAL; }
-    p->nx = nx; p->model = model; p->nsel = nsel;
-    if (!by_block) p->type = img_bpp == 8 ? (img_gray ? FT_IMAGE8GRAY : FT_IMAGE8) : (img_alpha ? FT_IMAGE32 : FT_IMAGE24);   /* Stats->Type :5493-5495 */
     int base = 0;
     for (int i = 0; i < nsel; i++) { sel[ns++] = base + sets[i]; base += ranges[i]; }
+    if (aud_info) {   /* recordModel(m, AUDIO, Stats) :5861: the generic maps, at their generic places, read through the model's input map */
+      int rec_sets[3];
+      uint32_t io[6] = {(uint32_t)p->blpos, 0, FT_AUDIO, p->stat_record, p->match_length, p->match_expected};
+      io[1] = (bpos > 0) ? P8_ASCII_GROUP_C0[(1 << bpos) - 2 + (c0 & ((1 << bpos) - 1))] : 0;
+      nx += p8f_record_step(p->rec, y, bpos, c0, p->c4, io, p->buf, p->bmask, p->pos, in + nx, rec_sets);
+      p->stat_record = io[3];
+      for (int i = 0; i < 3; i++) sel[ns++] = base + rec_sets[i];   /* (its three sets come with their cumulative offsets: 1024, 512, 11 * 32 rows) */
+      base += 1024 + 512 + 11 * 32;
+      nsel += 3;
+    }
+    p->own_silent = X->fam_count > 0 && !own_active;
+    if (bpos == 0 && em->chunk && em->chunk->xfam_ctx) {   /* the family slots that are called with a context this byte */
+      uint32_t* row = em->chunk->xfam_ctx + em->byte_row * (size_t)P8_XL_MAXS;
+      if (X->ngen) { row[P8_XL_MAXS - 2] = own_active ? 0 : (uint32_t)X->fam_count; row[P8_XL_MAXS - 1] = (uint32_t)X->nslots; }
+    }
+    if (em->xdiscovering) { X->prefix_nx = prefix; if (nx > X->nx) X->nx = nx; }
+    else if (X->prefix_nx != prefix || nx > X->nx) { fprintf(stderr, "paq8 front end: model step with %d + %d inputs\n", prefix, nx - prefix); return P8F_ERR_INTERNAL; }
+    p->nx = nx; p->model = model; p->nsel = nsel;
+    if (img_w && !by_block) p->type = img_bpp == 8 ? (img_gray ? FT_IMAGE8GRAY : FT_IMAGE8) : (img_alpha ? FT_IMAGE32 : FT_IMAGE24);   /* Stats->Type :5493-5495 */
     for (; ns < P8_NSEL; ns++) sel[ns] = -1;
-    if (!by_block && bpos == 7 && p->pos + 1 == p->img_eoi) { memset(&p->tga, 0, sizeof p->tga); p->bmp.Header = 0; p->img_gray = p->img_alpha = 0; }   /* :5498-5501 */
+    if (img_w && !by_block && bpos == 7 && p->pos + 1 == p->img_eoi) { memset(&p->tga, 0, sizeof p->tga); p->bmp.Header = 0; p->img_gray = p->img_alpha = 0; }   /* :5498-5501 */
+    if (aud_info && bpos == 7 && p->pos + 1 == (int)p->wav_eoi) memset(&p->wav, 0, sizeof p->wav);   /* :5864 */
     return 0;
   }
+  if (!img_w && bpos == 7 && p->pos + 1 == (int)p->wav_eoi) memset(&p->wav, 0, sizeof p->wav);
   uint8_t last[64];
   for (int i = 0; i < 64; i++) last[i] = (uint8_t)RB(i + 1);
   int sm_sets[2], rec_sets[3], text_sets[8], exe_sets[6];
@@ -518,7 +565,7 @@ static int front_step(P8Front* f, int y, int32_t* sel, P8ApmRec* apm) {
   const uint32_t c4 = p->c4, mlen = lg < 3 ? lg : 3, eb = p->match_expected;
   memset(apm, 0, sizeof *apm);
   apm->model = (uint8_t)p->model;
-  if (p->model) { apm->c[8] = (uint16_t)p->nx; apm->c[9] = (uint16_t)p->nsel; }
+  if (p->model) { apm->c[7] = (uint16_t)p->own_silent; apm->c[8] = (uint16_t)p->nx; apm->c[9] = (uint16_t)p->nsel; }
   if (p->type == FT_TEXT) {
     apm->text = P8_APM_TEXT;
     apm->limit = (uint16_t)(0x3FF >> ((p->blpos < 0xFFF) * 2));
@@ -600,7 +647,13 @@ P8Front* p8f_front_new(int level) {
   {
     static const uint8_t img[] = {FT_IMAGE24, 0, 0, 0, 24, 0, 0, 0, 12,   1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12,   1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12,
                                   FT_IMAGE8, 0, 0, 0, 8, 0, 0, 0, 4,   1, 2, 3, 4, 5, 6, 7, 8,
-                                  FT_IMAGE8GRAY, 0, 0, 0, 8, 0, 0, 0, 4,   1, 2, 3, 4, 5, 6, 7, 8, 0};
+                                  FT_IMAGE8GRAY, 0, 0, 0, 8, 0, 0, 0, 4,   1, 2, 3, 4, 5, 6, 7, 8,
+                                  /* a DEFAULT block with two RIFF / WAVE files: 8-bit stereo (6 samples), 16-bit stereo (4 samples) */
+                                  FT_DEFAULT, 0, 0, 0, 44 + 12 + 44 + 16,
+                                  'R', 'I', 'F', 'F', 48, 0, 0, 0, 'W', 'A', 'V', 'E', 'f', 'm', 't', ' ', 16, 0, 0, 0, 1, 0, 2, 0, 0x44, 0xAC, 0, 0, 0x88, 0x58, 1, 0, 2, 0, 8, 0,
+                                  'd', 'a', 't', 'a', 12, 0, 0, 0,   128, 127, 129, 126, 130, 125, 131, 124, 132, 123, 133, 122,
+                                  'R', 'I', 'F', 'F', 52, 0, 0, 0, 'W', 'A', 'V', 'E', 'f', 'm', 't', ' ', 16, 0, 0, 0, 1, 0, 2, 0, 0x44, 0xAC, 0, 0, 0x10, 0xB1, 2, 0, 4, 0, 16, 0,
+                                  'd', 'a', 't', 'a', 16, 0, 0, 0,   1, 0, 2, 0, 3, 0, 4, 0, 5, 0, 6, 0, 7, 0, 8, 0, 0};
     f->emit.xdiscovering = 1; f->emit.lane_objs = 0; memset(f->emit.xlane_objs, 0, sizeof f->emit.xlane_objs);
     f->p = predictor_new(level);
     int bit = 0;
@@ -609,7 +662,10 @@ P8Front* p8f_front_new(int level) {
       rc = front_step(f, bit, sel, &apm);
       bit = (img[t >> 3] >> (7 - (t & 7))) & 1;
     }
-    if (rc == 0 && (f->emit.L.xl[P8_MODEL_IM24 - 1].nx == 0 || f->emit.L.xl[P8_MODEL_IM8 - 1].nx == 0)) rc = 1;
+    for (int m = 0; m < P8_NMODEL - 1 && rc == 0; m++) if (f->emit.L.xl[m].nx == 0) rc = 2 + m;   /* every model must have been met */
+    /* the common prefix's maps run in every model's steps */
+    for (int l = 0; l < f->emit.L.nlanes; l++) if (f->emit.L.lane[l].off < f->emit.L.xl[0].prefix_nx) f->emit.L.lane[l].modes = ~0u;
+    for (int m = 0; m < P8_NMODEL - 1; m++) if (f->emit.L.xl[m].nslots < f->emit.L.xl[m].fam_count) f->emit.L.xl[m].nslots = f->emit.L.xl[m].fam_count;
     release_models(f);
     f->emit.xdiscovering = 0;
     if (rc != 0 || f->emit.err) { fprintf(stderr, "paq8 front end: layout pass of the image models failed (%d)\n", rc); free(f); return NULL; }

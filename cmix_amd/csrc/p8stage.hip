@@ -278,11 +278,10 @@ __global__ __launch_bounds__(P8FAM_THREADS) void cmx_p8s_fam2_late_kernel(P8CmDe
 // The (up to 64) learners are independent of each other and of six different kinds (p8s_lane_step switches on the lane's kind): on one
 // wavefront the kinds run one after the other every step. 8 wavefronts of 8 learners each keep most kinds in wavefronts of their own.
 constexpr int P8LANES_THREADS = 512;
-// model / lim (a chunk that holds image-model bytes; else nullptr): in such a byte's steps only the lanes of the common prefix -- input
-// positions below lim[model - 1] -- belong to the generic layout; the others neither run nor write (their positions are the image model's).
-struct P8LaneLim { int lim[P8_NMODEL - 1]; };
+// model (a chunk that holds bytes of an image / audio model; else nullptr): in such a byte's steps only the lanes the model calls (P8Lane.modes:
+// the common prefix; recordModel's maps under the audio models) run; the others neither run nor write (their positions may be the model's).
 __global__ __launch_bounds__(P8LANES_THREADS) void cmx_p8s_lanes_kernel(P8LanesDev* d, const uint32_t* ops, const uint8_t* bits, const uint8_t* order, int16_t* x,
-                                                                       int nbits, int t0, const uint8_t* model, P8LaneLim lim) {
+                                                                       int nbits, int t0, const uint8_t* model) {
   const int ln = threadIdx.x & 63, l = ln < 8 ? 8 * (int)(threadIdx.x >> 6) + ln : P8_NLANE;
   if (l >= P8_NLANE) return;
   P8LaneRegs r = d->regs[l];
@@ -290,7 +289,7 @@ __global__ __launch_bounds__(P8LANES_THREADS) void cmx_p8s_lanes_kernel(P8LanesD
   for (int t = t0; t < nbits; t++) {
     const int y = t ? bits[t - 1] : last_y;
     const int md = model ? model[t >> 3] : 0;
-    if (l < d->nlanes) p8s_lane_step(d, &r, l, ops[(size_t)t * P8_NLANE + l], y, order[t], x + (size_t)t * P8_NX, md ? lim.lim[md - 1] : (int)P8_NX);
+    if (l < d->nlanes) p8s_lane_step(d, &r, l, ops[(size_t)t * P8_NLANE + l], y, order[t], x + (size_t)t * P8_NX, md);
   }
   d->regs[l] = r;
   if (l == 0) d->last_y = bits[nbits - 1];
@@ -1036,16 +1035,17 @@ __global__ __launch_bounds__(64) void cmx_p8s_xfam_kernel(P8CmDev* d, const uint
     P8CmBit u;
     u.y = y; u.bp = bp; u.c0 = c0; u.c1 = c1; u.order = 0;
     u.ctx = xctx + (size_t)(t >> 3) * P8_XL_MAXS; u.chk = xchk + (size_t)(t >> 3) * P8_XL_MAXS; u.out = x + (size_t)t * P8_NX;
-    const int A = (int)u.ctx[P8_XL_MAXS - 1];   // the contexts this byte has set (the row's last cell): the others are not touched
-    if (s == 0) sh.nact = A;
+    const int A0 = (int)u.ctx[P8_XL_MAXS - 2], A = (int)u.ctx[P8_XL_MAXS - 1];   // the slots whose map is called with a context this byte (the row's last two cells): the others are not touched
+    if (s == 0) { sh.act_lo = A0; sh.act_hi = A; }
     __syncthreads();
-    if (s < A) p8d_cm_touch(d, &sh, u, s);
+    const bool act = s >= A0 && s < A;
+    if (act) p8d_cm_touch(d, &sh, u, s);
     __syncthreads();
-    if (s < A) p8d_cm_check(d, &sh, s);
+    if (act) p8d_cm_check(d, &sh, s);
     __syncthreads();
-    p8d_cm_draw(d, &sh, s);
+    if (act) p8d_cm_draw(d, &sh, s);
     __syncthreads();
-    if (s < A) p8d_cm_run(d, &sh, u, s);
+    if (act) p8d_cm_run(d, &sh, u, s);
     __syncthreads();
     const int bit = bits[t];
     y = bit; c0 = c0 * 2 + bit;
@@ -1424,8 +1424,6 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
   const int skip = h->steps >= 8 ? 0 : (int)(8 - h->steps), t0 = h->steps == 0 ? 1 : 0;
   const uint8_t* d_bits = (const uint8_t*)(b.d + b.o_bits);
   const uint8_t* d_model = (const uint8_t*)(b.d + b.o_model);
-  P8LaneLim lim;
-  for (int m = 0; m < P8_NMODEL - 1; m++) lim.lim[m] = L.xl[m].prefix_nx;
   auto cm2 = [&](int k, hipStream_t q, uint8_t* ord, const uint8_t* mdl) {
     (void)hipEventRecord(b.t0[2 + k], q);
     hipLaunchKernelGGL(cmx_p8s_cm2v2_kernel, dim3(1), dim3(P8CM2_MAXC), 0, q, h->d_cm2[k], (const uint32_t*)(b.d + b.o_cctx[k]),
@@ -1447,7 +1445,7 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
     cm2(0, q, dord, nullptr);
     cm2(1, q, nullptr, d_model);
     cm2(2, q, nullptr, d_model);
-    hipLaunchKernelGGL(cmx_p8s_lanes_kernel, dim3(1), dim3(P8LANES_THREADS), 0, q, h->d_lanes, (const uint32_t*)(b.d + b.o_ops), d_bits, (const uint8_t*)dord, dx, nbits, t0, d_model, lim);
+    hipLaunchKernelGGL(cmx_p8s_lanes_kernel, dim3(1), dim3(P8LANES_THREADS), 0, q, h->d_lanes, (const uint32_t*)(b.d + b.o_ops), d_bits, (const uint8_t*)dord, dx, nbits, t0, d_model);
     hipLaunchKernelGGL(cmx_p8s_dmc_kernel, dim3(1), dim3(P8DMC_THREADS), 0, q, h->d_dmc, d_bits, dx, (int)L.dmc_off, nbits, t0, d_model);
     for (int m = 0; m < P8_NMODEL - 1; m++)
       if (h->d_xlanes[m])
@@ -1528,7 +1526,7 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
     ok = ok && hipStreamWaitEvent(h->s_c, h->ev_ord, 0) == hipSuccess;
     (void)hipEventRecord(b.t0[5], h->s_c);
     hipLaunchKernelGGL(cmx_p8s_lanes_kernel, dim3(1), dim3(P8LANES_THREADS), 0, h->s_c, h->d_lanes, (const uint32_t*)(b.d + b.o_ops), d_bits, (const uint8_t*)dord, dx, nbits, t0,
-                       (const uint8_t*)nullptr, lim);
+                       (const uint8_t*)nullptr);
     (void)hipEventRecord(b.t1[5], h->s_c);
     ok = ok && hipEventRecord(h->ev_c, h->s_c) == hipSuccess;
     // the DMC forest reads the coded bits only: on a stream of its own it runs beside the small learners (4.0 + 2.8 us/bit in a row before)

@@ -13,6 +13,26 @@
 #include "p8fam_dev.h"
 #include "p8stage_dev.h"
 
+// ---- a model's ContextMap family that contains generic instances (the audio models call recordModel, :5861) ----------------------------------
+// The model's family runs the first design's per-context body (p8cm_dev.h) on a P8CmDev whose later instances ARE the generic family's: the
+// same tables; the per-context registers and StateMaps are handed over at every switch between the generic family (second design: P8FamHome
+// + the cached slot / run bytes, which equal the table between kernels) and the model's.
+struct P8ViewMap { int n, gen_first[P8_XL_MAXG], view_first[P8_XL_MAXG], count[P8_XL_MAXG]; };
+P8_HD void p8v_slot_in(const P8FamHome* gh, const uint16_t* gsm, P8CmRegs* vr, uint16_t* vsm, int g, int v) {
+  vr->cp0[v] = gh->cp0[g]; vr->runp[v] = gh->runp[g];
+  vr->cp[v] = gh->cpo[g] == P8F_NIL ? P8_NIL : gh->cp0[g] + gh->cpo[g];
+  vr->sm_cxt[v] = gh->smc[g];
+  for (int i = 0; i < 256; i++) vsm[(size_t)v * 256 + i] = gsm[(size_t)g * 256 + i];
+}
+P8_HD void p8v_slot_out(P8FamHome* gh, uint16_t* gsm, const P8CmRegs* vr, const uint16_t* vsm, const uint8_t* T, int g, int v) {
+  gh->cp0[g] = vr->cp0[v]; gh->runp[g] = vr->runp[v];
+  gh->cpo[g] = vr->cp[v] == P8_NIL ? (uint8_t)P8F_NIL : (uint8_t)(vr->cp[v] - vr->cp0[v]);
+  gh->smc[g] = (uint8_t)vr->sm_cxt[v];
+  gh->rc[g] = T[vr->runp[v]]; gh->rb[g] = T[vr->runp[v] + 1];
+  for (int k = 0; k < 7; k++) gh->slot[g][k] = T[vr->cp0[v] + k];
+  for (int i = 0; i < 256; i++) gsm[(size_t)g * 256 + i] = vsm[(size_t)v * 256 + i];
+}
+
 struct P8MixDev {
   int16_t* wx;             // [P8_NROWS][P8_NX]
   int16_t* wx2;            // [32]: the second layer's one row
@@ -34,6 +54,7 @@ struct P8StageState {
   // their own lane tables
   P8CmDev xfam[P8_NMODEL - 1];
   P8XLanesDev xlanes[P8_NMODEL - 1];
+  P8ViewMap xview[P8_NMODEL - 1];   // the generic instances inside a model's family
 };
 
 namespace p8b {
@@ -122,9 +143,42 @@ bool build_stage(P8StageState& S, Policy& P, const P8Layout& L, int level, const
     memset(&S.xfam[m], 0, sizeof S.xfam[m]);
     memset(&S.xlanes[m], 0, sizeof S.xlanes[m]);
     if (X.nx == 0) continue;   // (a model the front end has not got)
-    if (!build_family(S.xfam[m], P, 1, &X.fam_size, &X.fam_count, nex1024, stretch4096, ilog65536)) return false;
-    S.xfam[m].row_stride = P8_NX;
-    for (int s = 0; s < X.fam_count; s++) S.xfam[m].slot_off[s] = X.fam_off[s];
+    {   // the model's family: its own ContextMap (if it has one), then the generic instances it calls -- the generic family's own tables
+      P8CmDev& h = S.xfam[m];
+      P8ViewMap& V = S.xview[m];
+      memset(&V, 0, sizeof V);
+      h.slot_parallel = 1;
+      int s = 0, k = 0;
+      auto add = [&](uint8_t* table, uint32_t mask, int count) {
+        h.inst[k].table = table; h.inst[k].mask = mask; h.inst[k].first = s; h.inst[k].count = count;
+        for (int i = 0; i < count; i++, s++) { h.slot_inst[s] = (uint8_t)k; h.regs.cp0[s] = h.regs.cp[s] = P8_B_STATE; h.regs.runp[s] = P8_B_STATE + 3; }
+        k++;
+      };
+      if (X.fam_count > 0) {
+        const uint64_t sz = X.fam_size;
+        if (sz < 4096 || (sz & (sz - 1)) || (sz >> 6) > 0x4000000ull) return false;
+        add((uint8_t*)P.zalloc((size_t)sz), (uint32_t)((sz >> 6) - 1), X.fam_count);
+      }
+      for (int g = 0; g < X.ngen; g++) {
+        const P8CmInst& gi = S.fam.inst[X.gen_inst[g]];
+        V.gen_first[g] = gi.first; V.view_first[g] = s; V.count[g] = gi.count; V.n = g + 1;
+        add(gi.table, gi.mask, gi.count);
+      }
+      if (s == 0 || s > P8_XL_MAXS - 2 || k > P8CM_MAXI) return false;
+      h.ninst = k; h.nslots = s;
+      h.row_stride = P8_NX; h.order_slot = -1;
+      for (int i = 0; i < s; i++) h.slot_off[i] = X.fam_off[i];
+      h.nex = S.fam.nex; h.stretch = S.fam.stretch; h.ilog = S.fam.ilog;
+      std::vector<uint16_t> sm((size_t)s * 256);
+      for (size_t i = 0; i < sm.size(); ++i) {   // StateMap :626-635
+        int n0 = nex1024[4 * (i & 255) + 2], n1 = nex1024[4 * (i & 255) + 3];
+        if (n0 == 0) n1 *= 64;
+        if (n1 == 0) n0 *= 64;
+        sm[i] = (uint16_t)(65536 * (n1 + 1) / (n0 + n1 + 2));
+      }
+      h.sm = (uint16_t*)up(sm.data(), sm.size() * 2);
+      h.rnd = S.fam.rnd;
+    }
     P8XLanesDev& XD = S.xlanes[m];
     XD.nlanes = X.nlanes; XD.model = m + 1;
     XD.nex = D.nex; XD.stretch = D.stretch;

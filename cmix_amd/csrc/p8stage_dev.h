@@ -113,9 +113,11 @@ P8_HD void p8s_lane_step_t(const P8LaneDev* L, const P8LaneTabs* d, P8LaneRegs* 
   r->bcount++; r->B += r->B + 1;
   if (r->bcount == L->q.bits_per_ctx) r->bcount = r->B = 0;
 }
-P8_HD void p8s_lane_step(const P8LanesDev* d, P8LaneRegs* r, int l, uint32_t op, int y, int order, int16_t* x, int lim_off = P8_NX) {
+// md: the step's model (0: generic); a lane of the generic table runs in a model's step only if the model calls it (P8Lane.modes)
+P8_HD void p8s_lane_step(const P8LanesDev* d, P8LaneRegs* r, int l, uint32_t op, int y, int order, int16_t* x, int md = 0) {
   const P8LaneTabs tb = {d->nex, d->stretch};
-  p8s_lane_step_t(&d->lane[l], &tb, r, op, y, order, x, lim_off);
+  if (md && !((d->lane[l].q.modes >> md) & 1u)) return;
+  p8s_lane_step_t(&d->lane[l], &tb, r, op, y, order, x, P8_NX);
 }
 
 // ---------------------------------------------------------------- tail of Predictor::update
@@ -260,6 +262,12 @@ P8_HD int p8s_tail_gray(P8TailDev* d, const P8ApmRec* a, int y, int pr0, float* 
 }
 // the chain of an image model's step by its kind (P8ApmRec.text)
 P8_HD int p8s_tail_image(P8TailDev* d, const P8ApmRec* a, int y, int pr0, float* o) {
+  if (a->text == P8_APM_GENERIC) {   // an audio model's step inside an ordinary block: the general chain, one table after the other
+    int res[8];
+    for (int j = 0; j < 4; j++) p8s_tail_a(d, a, y, pr0, j, res);
+    for (int j = 0; j < 3; j++) p8s_tail_b(d, a, y, pr0, j, res);
+    return p8s_tail_c(a, pr0, res, o);
+  }
   return a->text == P8_APM_COLOR ? p8s_tail_color(d, a, y, pr0, o) : a->text == P8_APM_GRAY ? p8s_tail_gray(d, a, y, pr0, o) : p8s_tail_palette(d, a, y, pr0, o);
 }
 #endif

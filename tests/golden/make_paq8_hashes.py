@@ -88,6 +88,24 @@ def bmp8_file(img, palette):
             h.to_bytes(4, "little") + (1).to_bytes(2, "little") + (8).to_bytes(2, "little") + bytes(4) + len(pix).to_bytes(4, "little") + bytes(16) + pal + pix)
 
 
+def wav_file(nsamples, channels, bits, seed):
+    """RIFF / WAVE, PCM: a few sine partials + noise per channel (the second channel mostly follows the first)"""
+    r = np.random.default_rng(seed)
+    t = np.arange(nsamples)
+    base = sum(a * np.sin(t * f + ph) for a, f, ph in zip((0.5, 0.25, 0.12), r.uniform(0.01, 0.2, 3), r.uniform(0, 6, 3)))
+    chans = [base + r.normal(0, 0.01, nsamples)] + [0.8 * base + 0.1 * np.sin(t * 0.05) + r.normal(0, 0.01, nsamples) for _ in range(channels - 1)]
+    x = np.stack(chans, -1)
+    if bits == 8:
+        data = (128 + 100 * x).clip(0, 255).astype(np.uint8).tobytes()
+    else:
+        data = (12000 * x).clip(-32768, 32767).astype("<i2").tobytes()
+    ba = channels * bits // 8
+    fmt = (16).to_bytes(4, "little") + (1).to_bytes(2, "little") + channels.to_bytes(2, "little") + (22050).to_bytes(4, "little") + (22050 * ba).to_bytes(4, "little") + \
+        ba.to_bytes(2, "little") + bits.to_bytes(2, "little")
+    body = b"WAVE" + b"fmt " + fmt + b"data" + len(data).to_bytes(4, "little") + data
+    return b"RIFF" + len(body).to_bytes(4, "little") + body
+
+
 def preprocessed(payload):
     """the stream the reference's preprocessor (preprocessor.cpp:568 Encode) hands the predictor for a file: block headers, detected
     types (HDR + IMAGE24 / IMAGE32 for a BMP), its transforms -- through oracle/_ref/libcmixref.so (oracle/ref_harness.cpp)"""
@@ -115,6 +133,11 @@ def image_streams():
         # palette (paq8's detector walks the palette, finds it gray: the grayscale face of the model) and with a colour palette (the palette face)
         "pgm8_4k": preprocessed(text[:250] + b"P5\n64 56\n255\n" + photo(64, 56, 1, 4)[:, :, 0].tobytes() + text[250:500]),
         "bmp8_gray_raw_5k": default_block(text[:100] + bmp8_file(photo(64, 52, 1, 5)[:, :, 0], [(i, i, i) for i in range(256)]) + text[100:300]),
+        # PCM audio (audio8bModel :5552-5657, wavModel :5659-5804, each followed by recordModel): WAV files as the preprocessor frames them
+        "wav16s_6k": preprocessed(text[:200] + wav_file(1400, 2, 16, 9) + text[200:450]),
+        "wav8s_4k": preprocessed(text[:150] + wav_file(1800, 2, 8, 10) + text[150:300]),
+        "wav16m_3k": preprocessed(text[:100] + wav_file(1300, 1, 16, 11) + text[100:200]),
+        "wav8m_2k": preprocessed(text[:100] + wav_file(1700, 1, 8, 12) + text[100:200]),
         "bmp8_pal_raw_5k": default_block(text[:120] + bmp8_file(((photo(64, 52, 1, 6)[:, :, 0] >> 3).astype(np.uint8) * np.uint8(5)),
                                                                 np.random.default_rng(8).integers(0, 256, (256, 3))) + text[120:300]),
     }

@@ -183,22 +183,33 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
     int16_t* xr = x.data() + t * P8_NX;
     float* orow = out + t * P8_NOUT;
     const int md = c.model[t >> 3];                      // the byte's model (its record exists from the byte's first step on)
-    const int lim_off = md ? L.xl[md - 1].prefix_nx : P8_NX;
-    if (md != e->fam_owner && !e->use_v1) {               // the generator changes hands: what a kernel boundary does on the device
-      if (e->fam_owner == 0) { for (int tid = 0; tid < 256; tid++) p8f_store(&S.fam, S.fam_home, S.fam.sm, e->f2, e->f2_i, tid, 256); e->xsh[md - 1].rnd = S.fam.rnd; }
-      else if (md == 0) {
-        S.fam.rnd = e->xsh[e->fam_owner - 1].rnd;
-        for (int tid = 0; tid < 256; tid++) p8f_load(&S.fam, S.fam_home, S.fam.sm, e->f2, tid, 256);
-        e->f2_lk = 0; e->f2_i = e->f2_prev_i = (uint32_t)S.fam.rnd.i; f_run.lk = 0;
-      } else e->xsh[md - 1].rnd = e->xsh[e->fam_owner - 1].rnd;
-      e->fam_owner = md;
-    } else if (md != e->fam_owner) {
-      if (e->fam_owner == 0) e->xsh[md - 1].rnd = e->fsh.rnd;
-      else if (md == 0) e->fsh.rnd = e->xsh[e->fam_owner - 1].rnd;
-      else e->xsh[md - 1].rnd = e->xsh[e->fam_owner - 1].rnd;
+    if (md != e->fam_owner) {   // the generator -- and the per-context state of the generic instances a model's family contains -- changes hands: what the kernels between two segments do on the device
+      auto view_out = [&](int m) {   // model m's family -> the generic family's home
+        const P8ViewMap& V = S.xview[m - 1];
+        P8CmShared* xs = &e->xsh[m - 1];
+        for (int g = 0; g < V.n; g++) for (int i = 0; i < V.count[g]; i++)
+          p8v_slot_out(S.fam_home, S.fam.sm, &xs->r, S.xfam[m - 1].sm, S.fam.inst[S.fam.slot_inst[V.gen_first[g]]].table, V.gen_first[g] + i, V.view_first[g] + i);
+      };
+      auto view_in = [&](int m) {
+        const P8ViewMap& V = S.xview[m - 1];
+        P8CmShared* xs = &e->xsh[m - 1];
+        for (int g = 0; g < V.n; g++) for (int i = 0; i < V.count[g]; i++) p8v_slot_in(S.fam_home, S.fam.sm, &xs->r, S.xfam[m - 1].sm, V.gen_first[g] + i, V.view_first[g] + i);
+      };
+      if (e->use_v1) { fprintf(stderr, "p8stage_emul: models with their own tables need the second-design family (unset CMX_P8FAM_V1)\n"); return -99; }
+      if (e->fam_owner == 0) {
+        for (int tid = 0; tid < 256; tid++) p8f_store(&S.fam, S.fam_home, S.fam.sm, e->f2, e->f2_i, tid, 256);
+        e->xsh[md - 1].rnd = S.fam.rnd;
+        view_in(md);
+      } else {
+        view_out(e->fam_owner);
+        if (md == 0) {
+          S.fam.rnd = e->xsh[e->fam_owner - 1].rnd;
+          for (int tid = 0; tid < 256; tid++) p8f_load(&S.fam, S.fam_home, S.fam.sm, e->f2, tid, 256);
+          e->f2_lk = 0; e->f2_i = e->f2_prev_i = (uint32_t)S.fam.rnd.i; f_run.lk = 0;
+        } else { e->xsh[md - 1].rnd = e->xsh[e->fam_owner - 1].rnd; view_in(md); }
+      }
       e->fam_owner = md;
     }
-    // the uniform registers advance on every step, the lanes run once a byte boundary has been passed
     P8Cm2Bit cu[P8_NCM2];
     const int md_pre = c.model[t >> 3];
     for (int k = 0; k < P8_NCM2; k++) {
@@ -339,7 +350,7 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
       }
     }
     if (g == 0) { memcpy(orow, S.tail.out, sizeof S.tail.out); continue; }   // no step 0: the constructor's 0.5
-    for (int l = S.lanes.nlanes - 1; l >= 0; l--) p8s_lane_step(&S.lanes, &S.lanes.regs[l], l, c.ops[t * P8_NLANE + l], y, order[t], xr, lim_off);
+    for (int l = S.lanes.nlanes - 1; l >= 0; l--) p8s_lane_step(&S.lanes, &S.lanes.regs[l], l, c.ops[t * P8_NLANE + l], y, order[t], xr, md);
     if (!md) {
       for (int tid = P8DMC_THREADS - 1; tid >= 0; tid--) p8d_dmc_step1(&S.dmc, &e->dsh, tid, y);
       for (int tid = P8DMC_THREADS - 1; tid >= 0; tid--) p8d_dmc_step2(&S.dmc, &e->dsh, tid, (int)(g & 7), xr + L.dmc_off);
@@ -352,13 +363,13 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
       for (int j = 0; j < bp; j++) c0 = c0 * 2 + bits[t - bp + j];
       u.y = y; u.bp = bp; u.c0 = c0; u.c1 = (t >> 3) ? bytes[(t >> 3) - 1] : e->last_byte; u.order = 0;
       u.ctx = c.xfam_ctx + (t >> 3) * P8_XL_MAXS; u.chk = c.xfam_chk + (t >> 3) * P8_XL_MAXS; u.out = xr;
-      const int nact = (int)u.ctx[P8_XL_MAXS - 1];   // the contexts this byte has set
+      const int a0 = (int)u.ctx[P8_XL_MAXS - 2], a1 = (int)u.ctx[P8_XL_MAXS - 1];   // the slots whose map is called with a context this byte
       P8CmShared* xs = &e->xsh[md - 1];   // the four phases of cmx_p8s_xfam_kernel, lanes looped per phase
-      xs->nact = nact;
-      for (int sl = nact - 1; sl >= 0; sl--) p8d_cm_touch(xd, xs, u, sl);
-      for (int sl = nact - 1; sl >= 0; sl--) p8d_cm_check(xd, xs, sl);
-      for (int sl = nact - 1; sl >= 0; sl--) p8d_cm_draw(xd, xs, sl);
-      for (int sl = nact - 1; sl >= 0; sl--) p8d_cm_run(xd, xs, u, sl);
+      xs->act_lo = a0; xs->act_hi = a1;
+      for (int sl = a1 - 1; sl >= a0; sl--) p8d_cm_touch(xd, xs, u, sl);
+      for (int sl = a1 - 1; sl >= a0; sl--) p8d_cm_check(xd, xs, sl);
+      for (int sl = a1 - 1; sl >= a0; sl--) p8d_cm_draw(xd, xs, sl);
+      for (int sl = a1 - 1; sl >= a0; sl--) p8d_cm_run(xd, xs, u, sl);
       P8XLanesDev* XD = &S.xlanes[md - 1];
       const P8LaneTabs tb = {XD->nex, XD->stretch};
       for (int l = XD->nlanes - 1; l >= 0; l--) {   // a map the step does not call is not touched and writes nothing: its positions may be another face's (im8bitModel: gray / palette)
@@ -373,7 +384,12 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
     memset(xs, 0, sizeof xs);
     int nx = P8_NX;
     if (g < 8) { nx = S.mix.nx_first; for (int i = 0; i < nx; i++) xs[i] = xr[S.mix.first_map[i]]; }
-    else if (md) { nx = c.apm[t].c[8]; memcpy(xs, xr, (size_t)nx * 2); }   // an image model's step: fewer inputs, fewer weight sets (p8_rec.h)
+    else if (md) {   // a model's step: its inputs in add() order through the model's map (p8_rec.h), fewer weight sets
+      const P8XLayout& X = L.xl[md - 1];
+      nx = c.apm[t].c[8];
+      const int skip = c.apm[t].c[7] ? X.opt_n : 0;   // the model's own ContextMap is silent this byte: its inputs are not there
+      for (int i = 0; i < nx; i++) xs[i] = xr[X.map[(skip && i >= X.opt_lo) ? i + skip : i]];
+    }
     else memcpy(xs, xr, P8_NX * 2);
     const int nsel = md ? (int)c.apm[t].c[9] : P8_NSEL;
     const float cf = (float)(1.0 / 4095);
@@ -413,8 +429,14 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
   S.fam.last_y = f_last_y; S.fam.c1 = f_c1;
   if (!e->use_v1) {
     if (e->fam_owner == 0) for (int tid = 0; tid < 256; tid++) p8f_store(&S.fam, S.fam_home, S.fam.sm, e->f2, e->f2_i, tid, 256);
-    else { S.fam.rnd = e->xsh[e->fam_owner - 1].rnd; e->fam_owner = 0; }   // (the generic family's own state was stored when the generator left it)
-  } else if (e->fam_owner) { e->fsh.rnd = e->xsh[e->fam_owner - 1].rnd; e->fam_owner = 0; }
+    else {   // (the generic family's own state was stored when the generator left it; what the model's family shares with it goes back now)
+      const int m = e->fam_owner;
+      const P8ViewMap& V = S.xview[m - 1];
+      for (int g = 0; g < V.n; g++) for (int i = 0; i < V.count[g]; i++)
+        p8v_slot_out(S.fam_home, S.fam.sm, &e->xsh[m - 1].r, S.xfam[m - 1].sm, S.fam.inst[S.fam.slot_inst[V.gen_first[g]]].table, V.gen_first[g] + i, V.view_first[g] + i);
+      S.fam.rnd = e->xsh[m - 1].rnd; e->fam_owner = 0;
+    }
+  }
   if (n) e->last_byte = bytes[n - 1];
   for (int k = 0; k < P8_NCM2; k++) { S.cm2[k].bits = run_bits[k]; S.cm2[k].last_y = c_last_y[k]; if (!e->use_v1) S.cm2[k].regs = e->c2[k]->base.r; }
   e->steps += T; e->last_bit = T ? bits[T - 1] : e->last_bit;

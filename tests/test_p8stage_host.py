@@ -127,13 +127,16 @@ def load_hashes(name):
         return z["stream"].copy(), z["hash"].copy()
 
 
+# PCM audio in RIFF / WAVE files inside DEFAULT blocks (paq8's detector switches audio8bModel / wavModel + recordModel on: the model's family
+# holds recordModel's generic ContextMaps, whose state changes hands at every switch; wavModel's long-double Cholesky on the host);
 # 8-bit images (im8bitModel: the grayscale face on a PGM the preprocessor makes an IMAGE8GRAY block of and on a BMP whose gray palette paq8's
 # detector walks, the palette face on a BMP with a colour palette), and 24 / 32-bit images (im24bitModel through the model's own ContextMap and lane table, 13 weight sets, Image.Color's APM
 # chain): an IMAGE24 block between other blocks; 32-bit and 24-bit BMP files inside DEFAULT blocks, where paq8's own detector switches the
 # model on -- and, in the short 32-bit one, off again before the stream ends
 @pytest.mark.parametrize("name,nbytes", [("text_32k", 6144), ("wiki_12k", 4096), ("records_8k", 4096), ("mixed_24k", 6400), ("rich_16k", 16384), ("hdrs_4k", 3560),
                                          ("bmp24_14k", 14602), ("bmp32_8k", 8195), ("bmp24_raw_9k", 8907),
-                                         ("pgm8_4k", 4116), ("bmp8_gray_raw_5k", 4711), ("bmp8_pal_raw_5k", 4711)])
+                                         ("pgm8_4k", 4116), ("bmp8_gray_raw_5k", 4711), ("bmp8_pal_raw_5k", 4711),
+                                         ("wav16s_6k", 6099), ("wav8s_4k", 3949), ("wav16m_3k", 2849), ("wav8m_2k", 1949)])
 def test_stage_vs_reference_hashes(name, nbytes):
     """Prefixes of the reference-derived fixtures of tests/golden/make_paq8_hashes.py (the device test runs them whole)."""
     from make_paq8_hashes import row_hash
