@@ -1060,6 +1060,18 @@ __global__ __launch_bounds__(64) void cmx_p8s_rnd_copy_kernel(P8CmDev* dst, cons
   dst->rnd.table[threadIdx.x] = src->rnd.table[threadIdx.x];
   if (threadIdx.x == 0) dst->rnd.i = src->rnd.i;
 }
+// a model's family takes over / gives back the per-context state of the generic instances it contains (p8stage_build.h P8ViewMap): one thread per context
+__global__ __launch_bounds__(64) void cmx_p8s_view_in_kernel(P8CmDev* view, const P8CmDev* gen, const P8FamHome* gh, P8ViewMap V) {
+  for (int g = 0; g < V.n; g++)
+    if ((int)threadIdx.x < V.count[g]) p8v_slot_in(gh, gen->sm, &view->regs, view->sm, V.gen_first[g] + (int)threadIdx.x, V.view_first[g] + (int)threadIdx.x);
+}
+__global__ __launch_bounds__(64) void cmx_p8s_view_out_kernel(const P8CmDev* view, P8CmDev* gen, P8FamHome* gh, P8ViewMap V) {
+  for (int g = 0; g < V.n; g++)
+    if ((int)threadIdx.x < V.count[g]) {
+      const int vs = V.view_first[g] + (int)threadIdx.x;
+      p8v_slot_out(gh, gen->sm, &view->regs, view->sm, view->inst[view->slot_inst[vs]].table, V.gen_first[g] + (int)threadIdx.x, vs);
+    }
+}
 // the generic family after bytes it was not called for: the bit and the whole byte before its next step are the stream's (ContextMap::mix
 // reads the globals y and buf(1), :1072-1145)
 __global__ void cmx_p8s_fam_resume_kernel(P8CmDev* d, int last_y, int c1) { d->last_y = last_y; d->c1 = c1; }
@@ -1086,8 +1098,9 @@ __global__ __launch_bounds__(P8_XL_NLANE) void cmx_p8s_xlanes_kernel(P8XLanesDev
 // the model's APM chain on one lane (p8s_tail_image), the export: nx + nsel + 10 values back to back, the rest of the 1591 as they were
 // (AddPrediction() counts on, :504-510). Same packed arithmetic as cmx_p8s_mix4_kernel. T: the state the generic mixer leaves and takes over.
 constexpr int XMX_THREADS = 1024;
-__global__ __launch_bounds__(XMX_THREADS) void cmx_p8s_xmix_kernel(const P8MixDev* M, P8TailDev* T, const int16_t* x, const int32_t* sel, const P8ApmRec* apm, const uint8_t* bits,
-                                                                 float* out, size_t ld, int nbits, int last_y) {
+struct P8XMixMap { int16_t map[P8_NX]; int opt_lo, opt_n; };   // a model's inputs in add() order -> positions in the 1552-vector (P8XLayout.map)
+__global__ __launch_bounds__(XMX_THREADS) void cmx_p8s_xmix_kernel(const P8MixDev* M, P8TailDev* T, const P8XMixMap* maps, const int16_t* x, const int32_t* sel, const P8ApmRec* apm,
+                                                                 const uint8_t* bits, float* out, size_t ld, int nbits, int last_y) {
   __shared__ __attribute__((aligned(16))) uint32_t xs[P8_NX / 2];
   __shared__ float outs[P8_NOUT];
   __shared__ int pr_s[16], p_s, fin_s;
@@ -1107,8 +1120,12 @@ __global__ __launch_bounds__(XMX_THREADS) void cmx_p8s_xmix_kernel(const P8MixDe
     const int y = t ? (int)bits[t - 1] : last_y;
     misses += misses + (unsigned long long)((lastpr >> 11) != y);   // Predictor::update's first line (:8250)
     const int16_t* xr = x + (size_t)t * P8_NX;
+    const P8XMixMap* mp = maps + (a->model - 1);
+    const int skp = a->c[7] ? mp->opt_n : 0, olo = mp->opt_lo;   // the model's own ContextMap is silent this byte: its inputs are not there
     for (int i = tid; i < P8_NX / 2; i += XMX_THREADS) {
-      const uint32_t lo = 2 * i < nx ? (uint32_t)(uint16_t)xr[2 * i] : 0u, hi = 2 * i + 1 < nx ? (uint32_t)(uint16_t)xr[2 * i + 1] : 0u;
+      const int i0 = 2 * i, i1 = 2 * i + 1;
+      const uint32_t lo = i0 < nx ? (uint32_t)(uint16_t)xr[mp->map[(skp && i0 >= olo) ? i0 + skp : i0]] : 0u;
+      const uint32_t hi = i1 < nx ? (uint32_t)(uint16_t)xr[mp->map[(skp && i1 >= olo) ? i1 + skp : i1]] : 0u;
       xs[i] = lo | (hi << 16);
     }
     __syncthreads();
@@ -1222,6 +1239,7 @@ struct cmx_p8stage {
   P8CmDev* d_fam = nullptr; P8FamHome* d_fam_home = nullptr; size_t fam_lds = 0; P8Cm2Dev* d_cm2[P8_NCM2] = {}; P8LanesDev* d_lanes = nullptr; P8DmcDev* d_dmc = nullptr;
   P8TailDev* d_tail = nullptr; P8MixDev* d_mix = nullptr;
   P8CmDev* d_xfam[P8_NMODEL - 1] = {}; P8XLanesDev* d_xlanes[P8_NMODEL - 1] = {};   // the image models (p8_rec.h P8XLayout)
+  P8ViewMap xview[P8_NMODEL - 1]; P8XMixMap* d_xmaps = nullptr;
   int last_byte = 0;                    // the last whole byte of the stream
   uint64_t image_chunks = 0;
   Staging st[P8S_BUFS];
@@ -1308,7 +1326,13 @@ cmx_p8stage_t* cmx_p8stage_create(int device) {
     h->d_tail = dev_copy(S->tail, h->pol);
     h->d_mix = dev_copy(S->mix, h->pol);
     for (int m = 0; m < P8_NMODEL - 1; m++)
-      if (h->L.xl[m].nx) { h->d_xfam[m] = dev_copy(S->xfam[m], h->pol); h->d_xlanes[m] = dev_copy(S->xlanes[m], h->pol); }
+      if (h->L.xl[m].nx) { h->d_xfam[m] = dev_copy(S->xfam[m], h->pol); h->d_xlanes[m] = dev_copy(S->xlanes[m], h->pol); h->xview[m] = S->xview[m]; }
+    {
+      std::vector<P8XMixMap> mm(P8_NMODEL - 1);
+      for (int m = 0; m < P8_NMODEL - 1; m++) { memcpy(mm[m].map, h->L.xl[m].map, sizeof mm[m].map); mm[m].opt_lo = h->L.xl[m].opt_lo; mm[m].opt_n = h->L.xl[m].opt_n; }
+      h->d_xmaps = (P8XMixMap*)h->pol.zalloc(mm.size() * sizeof(P8XMixMap));
+      h->pol.upload(h->d_xmaps, mm.data(), mm.size() * sizeof(P8XMixMap));
+    }
     ok = h->pol.ok;
   }
   delete S;
@@ -1465,6 +1489,7 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
         if (pass == 0) {
           if (md == 0) {
             if (owner) {
+              if (h->xview[owner - 1].n) hipLaunchKernelGGL(cmx_p8s_view_out_kernel, dim3(1), dim3(64), 0, q, (const P8CmDev*)h->d_xfam[owner - 1], h->d_fam, h->d_fam_home, h->xview[owner - 1]);
               hipLaunchKernelGGL(cmx_p8s_rnd_copy_kernel, dim3(1), dim3(64), 0, q, h->d_fam, (const P8CmDev*)h->d_xfam[owner - 1]);
               owner = 0;
             }
@@ -1473,7 +1498,9 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
                                (const uint16_t*)(b.d + b.o_fchk) + b0 * L.fam_slots, d_bits + s0, dx + s0 * P8_NX, (const uint8_t*)dord + s0, sbits, b0 == 0 ? skip : 0, h->d_prof);
           } else {
             if (owner != md) {
+              if (owner && h->xview[owner - 1].n) hipLaunchKernelGGL(cmx_p8s_view_out_kernel, dim3(1), dim3(64), 0, q, (const P8CmDev*)h->d_xfam[owner - 1], h->d_fam, h->d_fam_home, h->xview[owner - 1]);
               hipLaunchKernelGGL(cmx_p8s_rnd_copy_kernel, dim3(1), dim3(64), 0, q, h->d_xfam[md - 1], (const P8CmDev*)(owner ? h->d_xfam[owner - 1] : h->d_fam));
+              if (h->xview[md - 1].n) hipLaunchKernelGGL(cmx_p8s_view_in_kernel, dim3(1), dim3(64), 0, q, h->d_xfam[md - 1], (const P8CmDev*)h->d_fam, (const P8FamHome*)h->d_fam_home, h->xview[md - 1]);
               owner = md;
             }
             hipLaunchKernelGGL(cmx_p8s_xfam_kernel, dim3(1), dim3(64), 0, q, h->d_xfam[md - 1], (const uint32_t*)(b.dx + b.ox_fctx) + b0 * P8_XL_MAXS,
@@ -1486,13 +1513,14 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
                                (const P8ApmRec*)(b.d + b.o_apm) + s0, (const uint8_t*)dord + s0, d_bits + s0, d_out + s0 * ld, ld, sbits, b0 == 0 ? t0 : 0, b0 == 0 ? skip : 0, ly, h->d_prx,
                                h->mix_epoch, h->h_mixfail);
           } else {
-            hipLaunchKernelGGL(cmx_p8s_xmix_kernel, dim3(1), dim3(XMX_THREADS), 0, q, (const P8MixDev*)h->d_mix, h->d_tail, (const int16_t*)dx + s0 * P8_NX, (const int32_t*)(b.d + b.o_sel) + s0 * P8_NSEL,
+            hipLaunchKernelGGL(cmx_p8s_xmix_kernel, dim3(1), dim3(XMX_THREADS), 0, q, (const P8MixDev*)h->d_mix, h->d_tail, (const P8XMixMap*)h->d_xmaps, (const int16_t*)dx + s0 * P8_NX, (const int32_t*)(b.d + b.o_sel) + s0 * P8_NSEL,
                                (const P8ApmRec*)(b.d + b.o_apm) + s0, d_bits + s0, d_out + s0 * ld, ld, sbits, ly);
           }
         }
         b0 = b1;
       }
-      if (pass == 0 && owner) {   // between chunks the generator is the generic family's, and its registers follow the stream
+      if (pass == 0 && owner) {   // between chunks the generator -- and everything a model's family shares with it -- is the generic family's, and its registers follow the stream
+        if (h->xview[owner - 1].n) hipLaunchKernelGGL(cmx_p8s_view_out_kernel, dim3(1), dim3(64), 0, q, (const P8CmDev*)h->d_xfam[owner - 1], h->d_fam, h->d_fam_home, h->xview[owner - 1]);
         hipLaunchKernelGGL(cmx_p8s_rnd_copy_kernel, dim3(1), dim3(64), 0, q, h->d_fam, (const P8CmDev*)h->d_xfam[owner - 1]);
         owner = 0;
       }
