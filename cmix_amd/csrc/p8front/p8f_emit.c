@@ -382,6 +382,24 @@ void p8f_pic_emit(P8fPic* p, int i, int cxt, int first, int16_t* out) {
   put_op(0, p->lane[i], P8OP_MIX | P8OP_SET | (first ? P8OP_ZERO : 0) | ((uint32_t)cxt & P8OP_CTX));
 }
 
+/* im1bitModel's eleven maps (:4634-4673): a bit-history byte per context in one shared array -- disjoint context ranges, so one array per map --
+ * and a u16 StateMap each; at the model's first call all of them sit on cell 0, which belongs to map 0's range: it takes their updates too */
+typedef struct P8fBitMaps { int n, pair, lane[16]; } P8fBitMaps;
+/* pair: maps pair, pair + 1 have overlapping context ranges (im1bitModel's cxt[6] = 0xC00 + up to 0xC3F and cxt[7] = 0x1000 + ...): one lane runs
+ * both on one array, in the reference's order (P8L_PIC2); -1: none */
+P8fBitMaps* p8f_bitmaps_new(int n, uint32_t cells, int pair) {
+  P8fBitMaps* p = (P8fBitMaps*)calloc(1, sizeof *p);
+  p->n = n; p->pair = pair;
+  for (int i = 0; i < n; ++i) p->lane[i] = new_lane(i == pair ? P8L_PIC2 : i == pair + 1 && pair >= 0 ? P8L_NONE : P8L_PIC, cells, 0);
+  return p;
+}
+void p8f_bitmaps_emit(P8fBitMaps* p, int i, int cxt, int first, int16_t* out) {
+  P8Emit* e = p8f_cur;
+  if (p->pair >= 0 && i == p->pair + 1) { (void)claim(e, out, 1); put_op(e->model, p->lane[i], (uint32_t)cxt & P8OP_CTX); return; }   /* the pair's second context: only its op word */
+  lane_out(e->model, p->lane[i], out, i == p->pair ? 2 : 1, i, 1, 1, p->n - 1, 0);   /* a = which map; limit = the extra updates of cell 0 at the first call */
+  put_op(e->model, p->lane[i], P8OP_MIX | P8OP_SET | (first ? P8OP_ZERO : 0) | ((uint32_t)cxt & P8OP_CTX));
+}
+
 /* dmcForest (:7777-7822): bits only, lives on the device */
 typedef struct Forest { int level; } Forest;
 Forest* p8f_dmc_new(int level) { Forest* f = (Forest*)calloc(1, sizeof *f); f->level = level; return f; }

@@ -72,6 +72,9 @@ Audio8* p8f_audio8_new(void);
 int p8f_audio8_step(Audio8* m, int y, int bpos, int c0, const uint8_t* hist, uint32_t bmask, int pos, int info, int blpos, uint32_t* record, int16_t* out, int* sets, int* ranges);
 Wav16* p8f_wav16_new(int level);
 int p8f_wav16_step(Wav16* m, int y, int bpos, int c0, const uint8_t* hist, uint32_t bmask, int pos, int info, uint32_t* record, int16_t* out, int* sets, int* ranges, int* cm_active);
+typedef struct Im1 Im1;
+Im1* p8f_im1_new(void);
+int p8f_im1_step(Im1* m, int y, int bpos, const uint8_t* hist, uint32_t bmask, int pos, int w, int16_t* out, int* sets, int* ranges);
 typedef struct Im24 Im24;
 typedef struct Im8 Im8;
 Im8* p8f_im8_new(int level);
@@ -122,6 +125,7 @@ typedef struct {
   Im8* im8;
   Audio8* audio8;
   Wav16* wav16;
+  Im1* im1;
   uint32_t wav_eoi, wav_info;                      /* audioModel's statics eoi, info: PCM samples are being modelled while info != 0 */
   int own_silent;                                  /* the step's model has a ContextMap of its own and it has no contexts this byte */
   uint32_t img_stats[8];                           /* ModelStats.Image of the byte: W, N, NN, WW, Wp1, Np1, plane, ctx */
@@ -172,6 +176,8 @@ static P8Predictor* predictor_new(int level) {
   p->audio8 = p8f_audio8_new();
   p8f_emit_model(p8f_cur, P8_MODEL_WAV16);
   p->wav16 = p8f_wav16_new(level);
+  p8f_emit_model(p8f_cur, P8_MODEL_IM1);
+  p->im1 = p8f_im1_new();
   p8f_emit_model(p8f_cur, 0);
   return p;
 }
@@ -290,7 +296,7 @@ static int img_detect(P8Predictor* p, uint32_t* record) {
     const int n = (int)((uint32_t)p->img_w * p->bmp.Height);
     if (n > 64) {
       p->img_eoi = n + pos;
-      if (bpp < 8) return P8F_ERR_BMP;   /* the 1 / 4-bit image models are not built */
+      if (bpp == 4) return P8F_ERR_BMP;   /* the 4-bit image model is not built */
     } else { p->img_eoi = 0; p->bmp.Header = 0; p->img_w = 0; }   /* too small to be an image: dropped, as the reference drops it */
   }
   if (pos >= p->img_eoi + 8 && !p->tga.Header) {
@@ -409,7 +415,8 @@ static int context_model2(P8Predictor* p, int y, int32_t* sel) {
   int img_w = 0, img_alpha = 0, img_bpp = 24, img_gray = 0, by_block = 0;
   if (p->filetype == FT_IMAGE24 || p->filetype == FT_IMAGE32) { img_w = p->info; img_alpha = p->filetype == FT_IMAGE32; by_block = 1; }
   else if (p->filetype == FT_IMAGE8 || p->filetype == FT_IMAGE8GRAY) { img_w = p->info; img_bpp = 8; img_gray = p->filetype == FT_IMAGE8GRAY; by_block = 1; }
-  else if (p->filetype == FT_IMAGE1 || p->filetype == FT_IMAGE4) return P8F_ERR_IMAGE_BLOCK;
+  else if (p->filetype == FT_IMAGE1) { img_w = p->info; img_bpp = 1; by_block = 1; }
+  else if (p->filetype == FT_IMAGE4) return P8F_ERR_IMAGE_BLOCK;
   else {
     int e;
     if (bpos == 0 && p->filetype != FT_EXE && (e = jpeg_detect(p)) != 0) return e;
@@ -431,14 +438,15 @@ static int context_model2(P8Predictor* p, int y, int32_t* sel) {
     if (em->chunk && !em->chunk->xops) return P8F_ERR_IMAGE_LATE;
     int sets[16], ranges[16];
     const int prefix = nx;
-    const int model = img_w ? (img_bpp == 8 ? P8_MODEL_IM8 : P8_MODEL_IM24) : (((aud_info - 1) & 2) == 0 ? P8_MODEL_AUDIO8 : P8_MODEL_WAV16);
-    int nsel = model == P8_MODEL_IM24 ? 13 : model == P8_MODEL_IM8 ? 8 : 5;
+    const int model = img_w ? (img_bpp == 1 ? P8_MODEL_IM1 : img_bpp == 8 ? P8_MODEL_IM8 : P8_MODEL_IM24) : (((aud_info - 1) & 2) == 0 ? P8_MODEL_AUDIO8 : P8_MODEL_WAV16);
+    int nsel = model == P8_MODEL_IM24 ? 13 : model == P8_MODEL_IM8 ? 8 : model == P8_MODEL_IM1 ? 4 : 5;
     P8XLayout* X = &em->L.xl[model - 1];
     p8f_emit_step_model(em, model);
     if (em->xdiscovering) for (int i = 0; i < prefix; i++) X->map[i] = (int16_t)i;
     p8f_emit_model(em, model);
     int n, own_active = 1;
-    if (model == P8_MODEL_IM8) n = p8f_im8_step(p->im8, y, bpos, c0, p->buf, p->bmask, p->pos, img_w, img_gray, in + nx, sets, ranges, bpos == 0 ? p->img_stats : NULL);
+    if (model == P8_MODEL_IM1) n = p8f_im1_step(p->im1, y, bpos, p->buf, p->bmask, p->pos, img_w, in + nx, sets, ranges);
+    else if (model == P8_MODEL_IM8) n = p8f_im8_step(p->im8, y, bpos, c0, p->buf, p->bmask, p->pos, img_w, img_gray, in + nx, sets, ranges, bpos == 0 ? p->img_stats : NULL);
     else if (model == P8_MODEL_IM24) n = p8f_im24_step(p->im24, y, bpos, c0, p->buf, p->bmask, p->pos, img_w, img_alpha, in + nx, sets, ranges, bpos == 0 ? p->img_stats : NULL);
     else if (model == P8_MODEL_AUDIO8) { n = p8f_audio8_step(p->audio8, y, bpos, c0, p->buf, p->bmask, p->pos, aud_info - 1, p->blpos, &p->stat_record, in + nx, sets, ranges); own_active = 0; }
     else n = p8f_wav16_step(p->wav16, y, bpos, c0, p->buf, p->bmask, p->pos, aud_info - 1, &p->stat_record, in + nx, sets, ranges, &own_active);
@@ -465,7 +473,7 @@ static int context_model2(P8Predictor* p, int y, int32_t* sel) {
     if (em->xdiscovering) { X->prefix_nx = prefix; if (nx > X->nx) X->nx = nx; }
     else if (X->prefix_nx != prefix || nx > X->nx) { fprintf(stderr, "paq8 front end: model step with %d + %d inputs\n", prefix, nx - prefix); return P8F_ERR_INTERNAL; }
     p->nx = nx; p->model = model; p->nsel = nsel;
-    if (img_w && !by_block) p->type = img_bpp == 8 ? (img_gray ? FT_IMAGE8GRAY : FT_IMAGE8) : (img_alpha ? FT_IMAGE32 : FT_IMAGE24);   /* Stats->Type :5493-5495 */
+    if (img_w && !by_block && img_bpp >= 8) p->type = img_bpp == 8 ? (img_gray ? FT_IMAGE8GRAY : FT_IMAGE8) : (img_alpha ? FT_IMAGE32 : FT_IMAGE24);   /* Stats->Type :5493-5495 */
     for (; ns < P8_NSEL; ns++) sel[ns] = -1;
     if (img_w && !by_block && bpos == 7 && p->pos + 1 == p->img_eoi) { memset(&p->tga, 0, sizeof p->tga); p->bmp.Header = 0; p->img_gray = p->img_alpha = 0; }   /* :5498-5501 */
     if (aud_info && bpos == 7 && p->pos + 1 == (int)p->wav_eoi) memset(&p->wav, 0, sizeof p->wav);   /* :5864 */
@@ -648,6 +656,7 @@ P8Front* p8f_front_new(int level) {
     static const uint8_t img[] = {FT_IMAGE24, 0, 0, 0, 24, 0, 0, 0, 12,   1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12,   1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12,
                                   FT_IMAGE8, 0, 0, 0, 8, 0, 0, 0, 4,   1, 2, 3, 4, 5, 6, 7, 8,
                                   FT_IMAGE8GRAY, 0, 0, 0, 8, 0, 0, 0, 4,   1, 2, 3, 4, 5, 6, 7, 8,
+                                  FT_IMAGE1, 0, 0, 0, 4, 0, 0, 0, 2,   0x55, 0x0F, 0x33, 0xF0,
                                   /* a DEFAULT block with two RIFF / WAVE files: 8-bit stereo (6 samples), 16-bit stereo (4 samples) */
                                   FT_DEFAULT, 0, 0, 0, 44 + 12 + 44 + 16,
                                   'R', 'I', 'F', 'F', 48, 0, 0, 0, 'W', 'A', 'V', 'E', 'f', 'm', 't', ' ', 16, 0, 0, 0, 1, 0, 2, 0, 0x44, 0xAC, 0, 0, 0x88, 0x58, 1, 0, 2, 0, 8, 0,
@@ -717,9 +726,9 @@ int p8f_front_run(P8Front* f, const uint8_t* bytes, size_t nbytes, P8Chunk* out)
 const char* p8f_strerror(int code) {
   switch (code) {
     case 0: return "ok";
-    case P8F_ERR_IMAGE_BLOCK: return "paq8 stage: 1 / 4-bit image block (the 8-bit and 24 / 32-bit image models are built)";
+    case P8F_ERR_IMAGE_BLOCK: return "paq8 stage: 4-bit image block (im4bitModel is not built; the 1-, 8- and 24 / 32-bit image models are)";
     case P8F_ERR_JPEG: return "paq8 stage: JPEG stream detected (jpegModel is outside the stage's scope)";
-    case P8F_ERR_BMP: return "paq8 stage: 1 / 4-bit BMP payload detected (the 8-bit and 24 / 32-bit image models are built)";
+    case P8F_ERR_BMP: return "paq8 stage: 4-bit BMP payload detected (im4bitModel is not built; the 1-, 8- and 24 / 32-bit image models are)";
     case P8F_ERR_TGA: return "paq8 stage: TGA payload of an unsupported pixel size";
     case P8F_ERR_WAV: return "paq8 stage: WAV header detected (audioModel is outside the stage's scope)";
     case P8F_ERR_IMAGE_PADDING: return "paq8 stage: image rows whose byte width is not a multiple of the pixel size (the reference indexes past its OLS array there, paq8.cpp:5043,5226: undefined)";

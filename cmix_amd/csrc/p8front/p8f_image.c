@@ -713,3 +713,48 @@ int p8f_im8_step(Im8* m, int y, int bpos, int c0, const uint8_t* hist, uint32_t 
   (void)NNE; (void)NNW;
   return nx;
 }
+
+/* ---------------------------------------------------------------- im1bitModel :4634-4673
+ * 1-bit images: the last four pixel rows as shift registers, eleven contexts of neighbouring pixels, a bit history and a StateMap each. */
+typedef struct P8fBitMaps P8fBitMaps;
+P8fBitMaps* p8f_bitmaps_new(int n, uint32_t cells, int pair);
+void p8f_bitmaps_emit(P8fBitMaps* p, int i, int cxt, int first, int16_t* out);
+enum { B1_N = 11 };
+typedef struct Im1 { P8fBitMaps* maps; uint32_t r0, r1, r2, r3; int cxt[B1_N]; int started; } Im1;
+Im1* p8f_im1_new(void) {
+  Im1* m = (Im1*)calloc(1, sizeof *m);
+  m->maps = p8f_bitmaps_new(B1_N, 0x23000, 6);   /* cxt[6]'s range reaches into cxt[7]'s: one lane for the two */
+  return m;
+}
+/* One step (the model works per bit); w: bytes per row; sets[4] / ranges[4]. Returns the 11 inputs. */
+int p8f_im1_step(Im1* m, int y, int bpos, const uint8_t* hist, uint32_t bmask, int pos, int w, int16_t* out, int* sets, int* ranges) {
+#define BUF(i) ((uint32_t)hist[((uint32_t)pos - (uint32_t)(i)) & bmask])
+  m->r0 += m->r0 + (uint32_t)y;
+  m->r1 += m->r1 + ((BUF(w - 1) >> (7 - bpos)) & 1);
+  m->r2 += m->r2 + ((BUF(w + w - 1) >> (7 - bpos)) & 1);
+  m->r3 += m->r3 + ((BUF(w + w + w - 1) >> (7 - bpos)) & 1);
+  const uint32_t r0 = m->r0, r1 = m->r1, r2 = m->r2, r3 = m->r3;
+  int* c = m->cxt;
+  c[0] = (int)((r0 & 0x7) | (r1 >> 4 & 0x38) | (r2 >> 3 & 0xc0));
+  c[1] = (int)(0x100 + ((r0 & 1) | (r1 >> 4 & 0x3e) | (r2 >> 2 & 0x40) | (r3 >> 1 & 0x80)));
+  c[2] = (int)(0x200 + ((r0 & 1) | (r1 >> 4 & 0x1d) | (r2 >> 1 & 0x60) | (r3 & 0xC0)));
+  c[3] = (int)(0x300 + ((uint32_t)y | ((r0 << 1) & 4) | ((r1 >> 1) & 0xF0) | ((r2 >> 3) & 0xA)));
+  c[4] = (int)(0x400 + ((r0 >> 4 & 0x2AC) | (r1 & 0xA4) | (r2 & 0x349) | (uint32_t)(!(r3 & 0x14D))));
+  c[5] = (int)(0x800 + ((uint32_t)y | ((r1 >> 4) & 0xE) | ((r2 >> 1) & 0x70) | ((r3 << 2) & 0x380)));
+  c[6] = (int)(0xC00 + (((r1 & 0x30) ^ (r3 & 0x0c0c)) | (r0 & 3)));
+  c[7] = (int)(0x1000 + ((uint32_t)(!(r0 & 0x444)) | (r1 & 0xC0C) | (r2 & 0xAE3) | (r3 & 0x51C)));
+  c[8] = (int)(0x2000 + ((r0 & 7) | ((r1 >> 1) & 0x3F8) | ((r2 << 5) & 0xC00)));
+  c[9] = (int)(0x3000 + ((r0 & 0x3f) ^ (r1 & 0x3ffe) ^ (r2 << 2 & 0x7f00) ^ (r3 << 5 & 0xf800)));
+  c[10] = (int)(0x13000 + ((r0 & 0x3e) ^ (r1 & 0x0c0c) ^ (r2 & 0xc800)));
+  for (int i = 0; i < B1_N; i++) p8f_bitmaps_emit(m->maps, i, c[i], !m->started, out + i);
+  m->started = 1;
+  int ns = 0;
+#define SET(v, r) do { sets[ns] = (int)(v); ranges[ns] = (int)(r); ++ns; } while (0)
+  SET((r0 & 7) | ((r1 & 0x3E) >> 2) | ((r2 & 0x1C0) << 2), 2048);
+  SET((uint32_t)y | ((r1 & 0x1C0) >> 5) | ((r2 & 0x1C0) >> 2) | ((r3 & 0x1C0) << 1), 1024);
+  SET(((r1 >> 5) & 0xFE) | (uint32_t)y, 256);
+  SET((r0 & 0x3) | ((r1 & 0xF80) >> 5), 128);
+#undef SET
+#undef BUF
+  return B1_N;
+}

@@ -1088,7 +1088,8 @@ __global__ __launch_bounds__(P8_XL_NLANE) void cmx_p8s_xlanes_kernel(P8XLanesDev
     if (model[t >> 3] != mine) continue;
     const int y = t ? bits[t - 1] : last_y;
     const uint32_t op = xops[(size_t)t * P8_XL_NLANE + l];
-    if (op & P8OP_MIX) p8s_lane_step_t(&d->lane[l], &tb, &r, op, y, order[t], x + (size_t)t * P8_NX, P8_NX);   // (a map the step does not call writes nothing: its positions may be the model's other face's)
+    if (d->lane[l].q.kind == P8L_PIC2) p8s_lane_pic2(&d->lane[l], &tb, &r, op, xops[(size_t)t * P8_XL_NLANE + l + 1], y, x + (size_t)t * P8_NX);
+    else if (op & P8OP_MIX) p8s_lane_step_t(&d->lane[l], &tb, &r, op, y, order[t], x + (size_t)t * P8_NX, P8_NX);   // (a map the step does not call writes nothing: its positions may be the model's other face's)
   }
   d->regs[l] = r;
 }
@@ -1503,6 +1504,7 @@ int cmx_p8stage_run(cmx_p8stage_t* h, const uint8_t* bytes, size_t nbytes, float
               if (h->xview[md - 1].n) hipLaunchKernelGGL(cmx_p8s_view_in_kernel, dim3(1), dim3(64), 0, q, h->d_xfam[md - 1], (const P8CmDev*)h->d_fam, (const P8FamHome*)h->d_fam_home, h->xview[md - 1]);
               owner = md;
             }
+            if (h->L.xl[md - 1].nslots)   // (a model without ContextMaps -- im1bitModel -- only holds the generator for the moment)
             hipLaunchKernelGGL(cmx_p8s_xfam_kernel, dim3(1), dim3(64), 0, q, h->d_xfam[md - 1], (const uint32_t*)(b.dx + b.ox_fctx) + b0 * P8_XL_MAXS,
                                (const uint16_t*)(b.dx + b.ox_fchk) + b0 * P8_XL_MAXS, d_bits + s0, dx + s0 * P8_NX, sbits, ly, lc1);
           }

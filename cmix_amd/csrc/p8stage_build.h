@@ -164,7 +164,7 @@ bool build_stage(P8StageState& S, Policy& P, const P8Layout& L, int level, const
         V.gen_first[g] = gi.first; V.view_first[g] = s; V.count[g] = gi.count; V.n = g + 1;
         add(gi.table, gi.mask, gi.count);
       }
-      if (s == 0 || s > P8_XL_MAXS - 2 || k > P8CM_MAXI) return false;
+      if (s > P8_XL_MAXS - 2 || k > P8CM_MAXI) return false;   // (s == 0: a model without ContextMaps, im1bitModel)
       h.ninst = k; h.nslots = s;
       h.row_stride = P8_NX; h.order_slot = -1;
       for (int i = 0; i < s; i++) h.slot_off[i] = X.fam_off[i];
@@ -188,7 +188,20 @@ bool build_stage(P8StageState& S, Policy& P, const P8Layout& L, int level, const
       const size_t n = q.q.cells;
       if (q.q.kind == P8L_SSCM) { std::vector<uint16_t> v(n, (uint16_t)q.q.init); q.c16 = (uint16_t*)up(v.data(), n * 2); }
       else if (q.q.kind == P8L_STAT) { std::vector<uint32_t> v(n, q.q.init); q.c32 = (uint32_t*)up(v.data(), n * 4); }
-      else return false;   // the image models hold no other kind
+      else if (q.q.kind == P8L_PIC || q.q.kind == P8L_PIC2) {
+        q.c8 = (uint8_t*)P.zalloc(n);
+        uint16_t sm[512];
+        for (int i = 0; i < 512; i++) {   // StateMap :626-635 (two of them for a pair)
+          int n0 = nex1024[4 * (i & 255) + 2], n1 = nex1024[4 * (i & 255) + 3];
+          if (n0 == 0) n1 *= 64;
+          if (n1 == 0) n0 *= 64;
+          sm[i] = (uint16_t)(65536 * (n1 + 1) / (n0 + n1 + 2));
+        }
+        q.sm16 = (uint16_t*)up(sm, sizeof sm);
+        continue;
+      }
+      else if (q.q.kind == P8L_NONE) continue;
+      else return false;   // the models hold no other kind
       q.stride = (1u << q.q.bits_per_ctx) - 1;
       q.mask = q.stride ? (uint32_t)(n / q.stride) - 1 : 0;
     }

@@ -65,7 +65,7 @@ P8_HD void p8s_lane_step_t(const P8LaneDev* L, const P8LaneTabs* d, P8LaneRegs* 
   if (kind == P8L_PIC) {   // t[old] = nex(t[old], y); stretch(sm.p(t[new]))
     uint8_t* t = L->c8;
     int s = d->nex[4 * t[r->cp] + y];
-    if ((op & P8OP_ZERO) && L->q.a == 0) { s = d->nex[4 * s + y]; s = d->nex[4 * s + y]; }   // stream start: all three maps sit on cell 0
+    if ((op & P8OP_ZERO) && L->q.a == 0) { const int extra = L->q.limit ? L->q.limit : 2; for (int k = 0; k < extra; k++) s = d->nex[4 * s + y]; }   // the model's first call: all its maps sit on cell 0 of their shared array
     t[r->cp] = (uint8_t)s;
     r->cp = op & P8OP_CTX;
     const int st = t[r->cp];
@@ -114,6 +114,23 @@ P8_HD void p8s_lane_step_t(const P8LaneDev* L, const P8LaneTabs* d, P8LaneRegs* 
   if (r->bcount == L->q.bits_per_ctx) r->bcount = r->B = 0;
 }
 // md: the step's model (0: generic); a lane of the generic table runs in a model's step only if the model calls it (P8Lane.modes)
+// P8L_PIC2: the second context's registers live in the fields a bit-history lane does not use (context = its cell, B = its StateMap context)
+P8_HD void p8s_lane_pic2(const P8LaneDev* L, const P8LaneTabs* d, P8LaneRegs* r, uint32_t op, uint32_t op2, int y, int16_t* x) {
+  if (!(op & P8OP_MIX)) return;
+  uint8_t* t = L->c8;
+  uint16_t* m1 = L->sm16; uint16_t* m2 = L->sm16 + 256;
+  t[r->cp] = d->nex[4 * t[r->cp] + y];
+  t[r->context] = d->nex[4 * t[r->context] + y];
+  r->cp = op & P8OP_CTX; r->context = op2 & P8OP_CTX;
+  const int s1 = t[r->cp], s2 = t[r->context];
+  m1[r->sm_cxt] = (uint16_t)(m1[r->sm_cxt] + (((y << 16) - m1[r->sm_cxt] + 128) >> 8));
+  r->sm_cxt = s1;
+  m2[r->B] = (uint16_t)(m2[r->B] + (((y << 16) - m2[r->B] + 128) >> 8));
+  r->B = (uint32_t)s2;
+  int16_t* o = x + L->q.off;
+  o[0] = d->stretch[m1[s1] >> 4];
+  o[1] = d->stretch[m2[s2] >> 4];
+}
 P8_HD void p8s_lane_step(const P8LanesDev* d, P8LaneRegs* r, int l, uint32_t op, int y, int order, int16_t* x, int md = 0) {
   const P8LaneTabs tb = {d->nex, d->stretch};
   if (md && !((d->lane[l].q.modes >> md) & 1u)) return;

@@ -106,6 +106,17 @@ def wav_file(nsamples, channels, bits, seed):
     return b"RIFF" + len(body).to_bytes(4, "little") + body
 
 
+def bmp1_file(bits):
+    """bottom-up 1-bit BMP of an [h, w] 0/1 image (two palette entries, rows padded to 4 bytes)"""
+    h, w = bits.shape
+    row = ((w + 31) >> 5) * 4
+    pix = b"".join(np.packbits(bits[y]).tobytes().ljust(row, b"\0") for y in range(h - 1, -1, -1))
+    off = 54 + 8
+    return (b"BM" + (off + len(pix)).to_bytes(4, "little") + bytes(4) + off.to_bytes(4, "little") + (40).to_bytes(4, "little") + w.to_bytes(4, "little") +
+            h.to_bytes(4, "little") + (1).to_bytes(2, "little") + (1).to_bytes(2, "little") + bytes(4) + len(pix).to_bytes(4, "little") + bytes(16) +
+            bytes([0, 0, 0, 0, 255, 255, 255, 0]) + pix)
+
+
 def preprocessed(payload):
     """the stream the reference's preprocessor (preprocessor.cpp:568 Encode) hands the predictor for a file: block headers, detected
     types (HDR + IMAGE24 / IMAGE32 for a BMP), its transforms -- through oracle/_ref/libcmixref.so (oracle/ref_harness.cpp)"""
@@ -133,6 +144,9 @@ def image_streams():
         # palette (paq8's detector walks the palette, finds it gray: the grayscale face of the model) and with a colour palette (the palette face)
         "pgm8_4k": preprocessed(text[:250] + b"P5\n64 56\n255\n" + photo(64, 56, 1, 4)[:, :, 0].tobytes() + text[250:500]),
         "bmp8_gray_raw_5k": default_block(text[:100] + bmp8_file(photo(64, 52, 1, 5)[:, :, 0], [(i, i, i) for i in range(256)]) + text[100:300]),
+        # 1-bit images (im1bitModel :4634-4673): a binary PBM, which the preprocessor turns into an IMAGE1 block, and a 1-bit BMP inside a DEFAULT block
+        "pbm1_2k": preprocessed(text[:200] + b"P4\n128 96\n" + np.packbits(photo(128, 96, 1, 13)[:, :, 0] > 128, axis=1).tobytes() + text[200:400]),
+        "bmp1_raw_2k": default_block(text[:100] + bmp1_file((photo(160, 80, 1, 14)[:, :, 0] > 120).astype(np.uint8)) + text[100:250]),
         # PCM audio (audio8bModel :5552-5657, wavModel :5659-5804, each followed by recordModel): WAV files as the preprocessor frames them
         "wav16s_6k": preprocessed(text[:200] + wav_file(1400, 2, 16, 9) + text[200:450]),
         "wav8s_4k": preprocessed(text[:150] + wav_file(1800, 2, 8, 10) + text[150:300]),

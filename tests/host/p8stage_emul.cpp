@@ -363,8 +363,9 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
       for (int j = 0; j < bp; j++) c0 = c0 * 2 + bits[t - bp + j];
       u.y = y; u.bp = bp; u.c0 = c0; u.c1 = (t >> 3) ? bytes[(t >> 3) - 1] : e->last_byte; u.order = 0;
       u.ctx = c.xfam_ctx + (t >> 3) * P8_XL_MAXS; u.chk = c.xfam_chk + (t >> 3) * P8_XL_MAXS; u.out = xr;
-      const int a0 = (int)u.ctx[P8_XL_MAXS - 2], a1 = (int)u.ctx[P8_XL_MAXS - 1];   // the slots whose map is called with a context this byte
+      int a0 = (int)u.ctx[P8_XL_MAXS - 2], a1 = (int)u.ctx[P8_XL_MAXS - 1];   // the slots whose map is called with a context this byte
       P8CmShared* xs = &e->xsh[md - 1];   // the four phases of cmx_p8s_xfam_kernel, lanes looped per phase
+      if (xd->nslots == 0) a0 = a1 = 0;    // (a model without ContextMaps: im1bitModel)
       xs->act_lo = a0; xs->act_hi = a1;
       for (int sl = a1 - 1; sl >= a0; sl--) p8d_cm_touch(xd, xs, u, sl);
       for (int sl = a1 - 1; sl >= a0; sl--) p8d_cm_check(xd, xs, sl);
@@ -374,7 +375,8 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
       const P8LaneTabs tb = {XD->nex, XD->stretch};
       for (int l = XD->nlanes - 1; l >= 0; l--) {   // a map the step does not call is not touched and writes nothing: its positions may be another face's (im8bitModel: gray / palette)
         const uint32_t op = c.xops[t * P8_XL_NLANE + l];
-        if (op & P8OP_MIX) p8s_lane_step_t(&XD->lane[l], &tb, &XD->regs[l], op, y, order[t], xr, P8_NX);
+        if (XD->lane[l].q.kind == P8L_PIC2) p8s_lane_pic2(&XD->lane[l], &tb, &XD->regs[l], op, c.xops[t * P8_XL_NLANE + l + 1], y, xr);
+        else if (op & P8OP_MIX) p8s_lane_step_t(&XD->lane[l], &tb, &XD->regs[l], op, y, order[t], xr, P8_NX);
       }
     }
     // ---- mixer + tail (Mixer::p :553-581, Predictor::update :8281-8358) ----

@@ -305,6 +305,20 @@ def test_dropin_engine_file_with_a_24bit_bmp_is_byte_identical():
     assert _run("-c", [("in", payload)], exe=DROPIN, timeout=600) == blob
 
 
+def test_dropin_engine_file_with_a_16bit_stereo_wav_is_byte_identical():
+    """text + a RIFF / WAVE file (1500 16-bit stereo samples) + text (tests/golden/make_dropin_wav.py): paq8's own detector switches wavModel
+    (a least-squares predictor per channel on the host, its ContextMap and maps on the device) and recordModel on for the samples. The file
+    the unmodified reference binary wrote."""
+    if not os.path.exists(DROPIN):
+        _missing("oracle/_ref/cmix_dropin not built")
+    fx = os.path.join(GOLDEN, "dropin_wav.npz")
+    if not os.path.exists(fx):
+        _missing("tests/golden/dropin_wav.npz missing (make_dropin_wav.py)")
+    with np.load(fx) as z:
+        payload, blob = z["payload"].tobytes(), z["cmix_file"].tobytes()
+    assert _run("-c", [("in", payload)], exe=DROPIN, timeout=600) == blob
+
+
 # ---- DECOMPRESSION with the whole engine: `cmix_dropin -d` = the reference's runner.cpp + decoder.cpp + preprocessor, no model ----
 # Decoder::Decode (decoder.cpp:20-39) calls Predict() and only then knows the bit it hands to Perceive(): the library's late-bit
 # protocol (cmix_amd/csrc/cmx_late.h) -- every stage kernel of the chunk pipeline, fxcm and paq8 included, waiting for the bits

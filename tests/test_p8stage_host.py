@@ -127,6 +127,7 @@ def load_hashes(name):
         return z["stream"].copy(), z["hash"].copy()
 
 
+# 1-bit images (im1bitModel: a PBM the preprocessor makes an IMAGE1 block of, a 1-bit BMP inside a DEFAULT block);
 # PCM audio in RIFF / WAVE files inside DEFAULT blocks (paq8's detector switches audio8bModel / wavModel + recordModel on: the model's family
 # holds recordModel's generic ContextMaps, whose state changes hands at every switch; wavModel's long-double Cholesky on the host);
 # 8-bit images (im8bitModel: the grayscale face on a PGM the preprocessor makes an IMAGE8GRAY block of and on a BMP whose gray palette paq8's
@@ -136,7 +137,8 @@ def load_hashes(name):
 @pytest.mark.parametrize("name,nbytes", [("text_32k", 6144), ("wiki_12k", 4096), ("records_8k", 4096), ("mixed_24k", 6400), ("rich_16k", 16384), ("hdrs_4k", 3560),
                                          ("bmp24_14k", 14602), ("bmp32_8k", 8195), ("bmp24_raw_9k", 8907),
                                          ("pgm8_4k", 4116), ("bmp8_gray_raw_5k", 4711), ("bmp8_pal_raw_5k", 4711),
-                                         ("wav16s_6k", 6099), ("wav8s_4k", 3949), ("wav16m_3k", 2849), ("wav8m_2k", 1949)])
+                                         ("wav16s_6k", 6099), ("wav8s_4k", 3949), ("wav16m_3k", 2849), ("wav8m_2k", 1949),
+                                         ("pbm1_2k", 1965), ("bmp1_raw_2k", 1917)])
 def test_stage_vs_reference_hashes(name, nbytes):
     """Prefixes of the reference-derived fixtures of tests/golden/make_paq8_hashes.py (the device test runs them whole)."""
     from make_paq8_hashes import row_hash
