@@ -400,6 +400,41 @@ void p8f_bitmaps_emit(P8fBitMaps* p, int i, int cxt, int first, int16_t* out) {
   put_op(e->model, p->lane[i], P8OP_MIX | P8OP_SET | (first ? P8OP_ZERO : 0) | ((uint32_t)cxt & P8OP_CTX));
 }
 
+/* im4bitModel's HashTable<16> with its 14 contexts (:4675-4742): one worker lane + 14 lanes that only carry the nibble's hashed contexts */
+typedef struct P8fHt16 { int lane[15]; int hashbits; } P8fHt16;
+P8fHt16* p8f_ht16_new(uint32_t table_bytes) {
+  P8fHt16* p = (P8fHt16*)calloc(1, sizeof *p);
+  p->hashbits = (int)ilog2u(table_bytes);
+  p->lane[0] = new_lane(P8L_HT16, table_bytes, 0);
+  for (int i = 1; i < 15; ++i) p->lane[i] = new_lane(P8L_NONE, 0, 0);
+  return p;
+}
+/* keys: the 14 contexts of the nibble (NULL between nibble boundaries) */
+int p8f_ht16_step(P8fHt16* p, const uint64_t* keys, int16_t* out) {
+  P8Emit* e = p8f_cur;
+  lane_out(e->model, p->lane[0], out, 42, 0, 1, 1, 0, 0);
+  put_op(e->model, p->lane[0], P8OP_MIX);
+  if (keys)
+    for (int i = 0; i < 14; ++i) {   /* HashTable<B>::operator[] :841-843: 8-bit checksum, item index (the table has 2^hashbits bytes, 16 per item) */
+      const uint32_t chk = (uint32_t)(p8f_checksum64(keys[i], p->hashbits, 8) & 0xff);
+      const uint32_t item = (uint32_t)((((uint64_t)p8f_finalize64(keys[i], p->hashbits) * 16) & (((uint64_t)1 << p->hashbits) - 1)) >> 4);
+      put_op(e->model, p->lane[1 + i], (chk << 22) | item);
+    }
+  return 42;
+}
+/* a StateMap32 read out as stretch(p) >> 1 (im4bitModel :4735) */
+typedef struct P8fSm32b { int lane; } P8fSm32b;
+P8fSm32b* p8f_sm32b_new(int n) {
+  P8fSm32b* s = (P8fSm32b*)calloc(1, sizeof *s);
+  s->lane = new_lane(P8L_SM32, (uint32_t)n, 1u << 31);
+  return s;
+}
+void p8f_sm32b_emit(P8fSm32b* s, int cx, int16_t* out) {
+  P8Emit* e = p8f_cur;
+  lane_out(e->model, s->lane, out, 1, 1, 1, 1, 1023, 0);   /* a = 1: no rounding bit */
+  put_op(e->model, s->lane, P8OP_MIX | P8OP_SET | ((uint32_t)cx & P8OP_CTX));
+}
+
 /* dmcForest (:7777-7822): bits only, lives on the device */
 typedef struct Forest { int level; } Forest;
 Forest* p8f_dmc_new(int level) { Forest* f = (Forest*)calloc(1, sizeof *f); f->level = level; return f; }

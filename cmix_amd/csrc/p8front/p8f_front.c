@@ -72,6 +72,9 @@ Audio8* p8f_audio8_new(void);
 int p8f_audio8_step(Audio8* m, int y, int bpos, int c0, const uint8_t* hist, uint32_t bmask, int pos, int info, int blpos, uint32_t* record, int16_t* out, int* sets, int* ranges);
 Wav16* p8f_wav16_new(int level);
 int p8f_wav16_step(Wav16* m, int y, int bpos, int c0, const uint8_t* hist, uint32_t bmask, int pos, int info, uint32_t* record, int16_t* out, int* sets, int* ranges, int* cm_active);
+typedef struct Im4 Im4;
+Im4* p8f_im4_new(int level);
+int p8f_im4_step(Im4* m, int y, int bpos, int c0, uint32_t c4, const uint8_t* hist, uint32_t bmask, int pos, int w, int16_t* out, int* sets, int* ranges);
 typedef struct Im1 Im1;
 Im1* p8f_im1_new(void);
 int p8f_im1_step(Im1* m, int y, int bpos, const uint8_t* hist, uint32_t bmask, int pos, int w, int16_t* out, int* sets, int* ranges);
@@ -126,6 +129,7 @@ typedef struct {
   Audio8* audio8;
   Wav16* wav16;
   Im1* im1;
+  Im4* im4;
   uint32_t wav_eoi, wav_info;                      /* audioModel's statics eoi, info: PCM samples are being modelled while info != 0 */
   int own_silent;                                  /* the step's model has a ContextMap of its own and it has no contexts this byte */
   uint32_t img_stats[8];                           /* ModelStats.Image of the byte: W, N, NN, WW, Wp1, Np1, plane, ctx */
@@ -178,6 +182,8 @@ static P8Predictor* predictor_new(int level) {
   p->wav16 = p8f_wav16_new(level);
   p8f_emit_model(p8f_cur, P8_MODEL_IM1);
   p->im1 = p8f_im1_new();
+  p8f_emit_model(p8f_cur, P8_MODEL_IM4);
+  p->im4 = p8f_im4_new(level);
   p8f_emit_model(p8f_cur, 0);
   return p;
 }
@@ -296,7 +302,7 @@ static int img_detect(P8Predictor* p, uint32_t* record) {
     const int n = (int)((uint32_t)p->img_w * p->bmp.Height);
     if (n > 64) {
       p->img_eoi = n + pos;
-      if (bpp == 4) return P8F_ERR_BMP;   /* the 4-bit image model is not built */
+      /* (every pixel size the header test admits has its model) */
     } else { p->img_eoi = 0; p->bmp.Header = 0; p->img_w = 0; }   /* too small to be an image: dropped, as the reference drops it */
   }
   if (pos >= p->img_eoi + 8 && !p->tga.Header) {
@@ -416,7 +422,7 @@ static int context_model2(P8Predictor* p, int y, int32_t* sel) {
   if (p->filetype == FT_IMAGE24 || p->filetype == FT_IMAGE32) { img_w = p->info; img_alpha = p->filetype == FT_IMAGE32; by_block = 1; }
   else if (p->filetype == FT_IMAGE8 || p->filetype == FT_IMAGE8GRAY) { img_w = p->info; img_bpp = 8; img_gray = p->filetype == FT_IMAGE8GRAY; by_block = 1; }
   else if (p->filetype == FT_IMAGE1) { img_w = p->info; img_bpp = 1; by_block = 1; }
-  else if (p->filetype == FT_IMAGE4) return P8F_ERR_IMAGE_BLOCK;
+  else if (p->filetype == FT_IMAGE4) { img_w = p->info; img_bpp = 4; by_block = 1; }
   else {
     int e;
     if (bpos == 0 && p->filetype != FT_EXE && (e = jpeg_detect(p)) != 0) return e;
@@ -438,14 +444,15 @@ static int context_model2(P8Predictor* p, int y, int32_t* sel) {
     if (em->chunk && !em->chunk->xops) return P8F_ERR_IMAGE_LATE;
     int sets[16], ranges[16];
     const int prefix = nx;
-    const int model = img_w ? (img_bpp == 1 ? P8_MODEL_IM1 : img_bpp == 8 ? P8_MODEL_IM8 : P8_MODEL_IM24) : (((aud_info - 1) & 2) == 0 ? P8_MODEL_AUDIO8 : P8_MODEL_WAV16);
-    int nsel = model == P8_MODEL_IM24 ? 13 : model == P8_MODEL_IM8 ? 8 : model == P8_MODEL_IM1 ? 4 : 5;
+    const int model = img_w ? (img_bpp == 1 ? P8_MODEL_IM1 : img_bpp == 4 ? P8_MODEL_IM4 : img_bpp == 8 ? P8_MODEL_IM8 : P8_MODEL_IM24) : (((aud_info - 1) & 2) == 0 ? P8_MODEL_AUDIO8 : P8_MODEL_WAV16);
+    int nsel = model == P8_MODEL_IM24 ? 13 : model == P8_MODEL_IM8 ? 8 : model == P8_MODEL_IM1 ? 4 : model == P8_MODEL_IM4 ? 6 : 5;
     P8XLayout* X = &em->L.xl[model - 1];
     p8f_emit_step_model(em, model);
     if (em->xdiscovering) for (int i = 0; i < prefix; i++) X->map[i] = (int16_t)i;
     p8f_emit_model(em, model);
     int n, own_active = 1;
-    if (model == P8_MODEL_IM1) n = p8f_im1_step(p->im1, y, bpos, p->buf, p->bmask, p->pos, img_w, in + nx, sets, ranges);
+    if (model == P8_MODEL_IM4) n = p8f_im4_step(p->im4, y, bpos, c0, p->c4, p->buf, p->bmask, p->pos, img_w, in + nx, sets, ranges);
+    else if (model == P8_MODEL_IM1) n = p8f_im1_step(p->im1, y, bpos, p->buf, p->bmask, p->pos, img_w, in + nx, sets, ranges);
     else if (model == P8_MODEL_IM8) n = p8f_im8_step(p->im8, y, bpos, c0, p->buf, p->bmask, p->pos, img_w, img_gray, in + nx, sets, ranges, bpos == 0 ? p->img_stats : NULL);
     else if (model == P8_MODEL_IM24) n = p8f_im24_step(p->im24, y, bpos, c0, p->buf, p->bmask, p->pos, img_w, img_alpha, in + nx, sets, ranges, bpos == 0 ? p->img_stats : NULL);
     else if (model == P8_MODEL_AUDIO8) { n = p8f_audio8_step(p->audio8, y, bpos, c0, p->buf, p->bmask, p->pos, aud_info - 1, p->blpos, &p->stat_record, in + nx, sets, ranges); own_active = 0; }
@@ -657,6 +664,7 @@ P8Front* p8f_front_new(int level) {
                                   FT_IMAGE8, 0, 0, 0, 8, 0, 0, 0, 4,   1, 2, 3, 4, 5, 6, 7, 8,
                                   FT_IMAGE8GRAY, 0, 0, 0, 8, 0, 0, 0, 4,   1, 2, 3, 4, 5, 6, 7, 8,
                                   FT_IMAGE1, 0, 0, 0, 4, 0, 0, 0, 2,   0x55, 0x0F, 0x33, 0xF0,
+                                  FT_IMAGE4, 0, 0, 0, 4, 0, 0, 0, 2,   0x12, 0x34, 0x56, 0x78,
                                   /* a DEFAULT block with two RIFF / WAVE files: 8-bit stereo (6 samples), 16-bit stereo (4 samples) */
                                   FT_DEFAULT, 0, 0, 0, 44 + 12 + 44 + 16,
                                   'R', 'I', 'F', 'F', 48, 0, 0, 0, 'W', 'A', 'V', 'E', 'f', 'm', 't', ' ', 16, 0, 0, 0, 1, 0, 2, 0, 0x44, 0xAC, 0, 0, 0x88, 0x58, 1, 0, 2, 0, 8, 0,

@@ -758,3 +758,71 @@ int p8f_im1_step(Im1* m, int y, int bpos, const uint8_t* hist, uint32_t bmask, i
 #undef BUF
   return B1_N;
 }
+
+/* ---------------------------------------------------------------- im4bitModel :4675-4742
+ * 4-bit images: two pixels per byte; 14 hashed contexts of the neighbouring nibbles per pixel on a HashTable<16> (the device's, p8stage_dev.h
+ * P8L_HT16), a run model, a StateMap32 on the partial nibble. */
+typedef struct P8fHt16 P8fHt16;
+P8fHt16* p8f_ht16_new(uint32_t table_bytes);
+int p8f_ht16_step(P8fHt16* p, const uint64_t* keys, int16_t* out);
+typedef struct P8fSm32b P8fSm32b;
+P8fSm32b* p8f_sm32b_new(int n);
+void p8f_sm32b_emit(P8fSm32b* s, int cx, int16_t* out);
+typedef struct Im4 {
+  P8fHt16* ht; P8fSm32b* map;
+  int WW, W, NWW, NW, N, NE, NEE, NNWW, NNW, NN, NNE, NNEE;
+  int col, line, run, prev_color, px;
+} Im4;
+Im4* p8f_im4_new(int level) {
+  Im4* m = (Im4*)calloc(1, sizeof *m);
+  m->ht = p8f_ht16_new((uint32_t)((0x10000ull << level) / 2));
+  m->map = p8f_sm32b_new(16);
+  return m;
+}
+/* One step; c4: the last four whole bytes; sets[6] / ranges[6]. Returns the 43 inputs. */
+int p8f_im4_step(Im4* m, int y, int bpos, int c0, uint32_t c4, const uint8_t* hist, uint32_t bmask, int pos, int w, int16_t* out, int* sets, int* ranges) {
+#define BUF(i) ((int)hist[((uint32_t)pos - (uint32_t)(i)) & bmask])
+  uint64_t keys[14];
+  int have = 0;
+  if (!bpos || bpos == 4) {
+    m->WW = m->W; m->NWW = m->NW; m->NW = m->N; m->N = m->NE; m->NE = m->NEE; m->NNWW = m->NWW; m->NNW = m->NN; m->NN = m->NNE; m->NNE = m->NNEE;
+    if (!bpos) { m->W = (int)(c4 & 0xF); m->NEE = BUF(w - 1) >> 4; m->NNEE = BUF(w * 2 - 1) >> 4; }
+    else { m->W = c0 & 0xF; m->NEE = BUF(w - 1) & 0xF; m->NNEE = BUF(w * 2 - 1) & 0xF; }
+    if (m->W != m->WW || !m->col) { m->prev_color = m->WW; m->run = 0; } else m->run = imin(0xFFF, m->run + 1);
+    m->px = 1;
+    const int W = m->W, WW = m->WW, N = m->N, NN = m->NN, NW = m->NW, NE = m->NE, NEE = m->NEE, NWW = m->NWW, NNW = m->NNW, NNE = m->NNE, NNEE = m->NNEE, NNWW = m->NNWW;
+    const int col = m->col, line = m->line;
+    int64_t i = 0;
+    keys[0] = H4(i, W, NW, N);
+    i++; keys[1] = H3(i, N, imin(0xFFF, col / 8));
+    i++; keys[2] = hashn(6, (const int64_t[]){i, W, NW, N, NN, NE});
+    i++; keys[3] = H5(i, W, N, NE + NNE * 16, NEE + NNEE * 16);
+    i++; keys[4] = H5(i, W, N, NW + NNW * 16, NWW + NNWW * 16);
+    i++; keys[5] = H5(i, W, ilog2u((unsigned)(m->run + 1)), m->prev_color, col / imax(1, w / 2));
+    i++; keys[6] = H3(i, NE, imin(0x3FF, (col + line) / imax(1, w * 8)));
+    i++; keys[7] = H3(i, NW, (col - line) / imax(1, w * 8));
+    i++; keys[8] = H4(i, WW * 16 + W, NN * 16 + N, NNWW * 16 + NW);
+    i++; keys[9] = H3(i, N, NN);
+    i++; keys[10] = H3(i, W, WW);
+    i++; keys[11] = H3(i, W, NE);
+    i++; keys[12] = H4(i, WW, NN, NEE);
+    keys[13] = (uint64_t)(int64_t)-1;   /* cp[13] = t[-1] */
+    have = 1;
+    ++m->col;
+    m->col *= m->col < w * 2;
+    m->line += (!m->col);
+  } else m->px += m->px + y;
+  int nx = p8f_ht16_step(m->ht, have ? keys : NULL, out);
+  p8f_sm32b_emit(m->map, m->px, out + nx); nx++;
+  int ns = 0;
+#define SET(v, r) do { sets[ns] = (int)(v); ranges[ns] = (int)(r); ++ns; } while (0)
+  SET(m->W * 16 + m->px, 256);
+  SET(imin(31, m->col / imax(1, w / 16)) + m->N * 32, 512);
+  SET((bpos & 3) + 4 * m->W + 64 * imin(7, (int)ilog2u((unsigned)(m->run + 1))), 512);
+  SET(m->W + m->NE * 16 + (bpos & 3) * 256, 1024);
+  SET(m->px, 16);
+  SET(0, 1);
+#undef SET
+#undef BUF
+  return nx;
+}

@@ -1088,7 +1088,8 @@ __global__ __launch_bounds__(P8_XL_NLANE) void cmx_p8s_xlanes_kernel(P8XLanesDev
     if (model[t >> 3] != mine) continue;
     const int y = t ? bits[t - 1] : last_y;
     const uint32_t op = xops[(size_t)t * P8_XL_NLANE + l];
-    if (d->lane[l].q.kind == P8L_PIC2) p8s_lane_pic2(&d->lane[l], &tb, &r, op, xops[(size_t)t * P8_XL_NLANE + l + 1], y, x + (size_t)t * P8_NX);
+    if (d->lane[l].q.kind == P8L_HT16) p8s_lane_ht16(&d->lane[l], &tb, xops + (size_t)t * P8_XL_NLANE + l, y, t & 7, x + (size_t)t * P8_NX);
+    else if (d->lane[l].q.kind == P8L_PIC2) p8s_lane_pic2(&d->lane[l], &tb, &r, op, xops[(size_t)t * P8_XL_NLANE + l + 1], y, x + (size_t)t * P8_NX);
     else if (op & P8OP_MIX) p8s_lane_step_t(&d->lane[l], &tb, &r, op, y, order[t], x + (size_t)t * P8_NX, P8_NX);   // (a map the step does not call writes nothing: its positions may be the model's other face's)
   }
   d->regs[l] = r;

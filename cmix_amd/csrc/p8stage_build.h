@@ -201,6 +201,20 @@ bool build_stage(P8StageState& S, Policy& P, const P8Layout& L, int level, const
         continue;
       }
       else if (q.q.kind == P8L_NONE) continue;
+      else if (q.q.kind == P8L_SM32) { std::vector<uint32_t> v(n, q.q.init); q.c32 = (uint32_t*)up(v.data(), n * 4); continue; }
+      else if (q.q.kind == P8L_HT16) {
+        q.c8 = (uint8_t*)P.zalloc(n);          // the HashTable<16>
+        q.c32 = (uint32_t*)P.zalloc(64 * 4);   // the 14 contexts' pointers and StateMap contexts
+        std::vector<uint16_t> sm(14 * 256);
+        for (size_t i = 0; i < sm.size(); i++) {   // StateMap :626-635
+          int n0 = nex1024[4 * (i & 255) + 2], n1 = nex1024[4 * (i & 255) + 3];
+          if (n0 == 0) n1 *= 64;
+          if (n1 == 0) n0 *= 64;
+          sm[i] = (uint16_t)(65536 * (n1 + 1) / (n0 + n1 + 2));
+        }
+        q.sm16 = (uint16_t*)up(sm.data(), sm.size() * 2);
+        continue;
+      }
       else return false;   // the models hold no other kind
       q.stride = (1u << q.q.bits_per_ctx) - 1;
       q.mask = q.stride ? (uint32_t)(n / q.stride) - 1 : 0;

@@ -59,7 +59,7 @@ P8_HD void p8s_lane_step_t(const P8LaneDev* L, const P8LaneTabs* d, P8LaneRegs* 
   if (!(op & P8OP_MIX)) { for (int j = 0; j < L->q.nout; j++) o[j] = 0; return; }
   if (kind == P8L_SM32) {
     const int p = p8s_sm32(L->c32, &r->sm_cxt, y, (int)(op & P8OP_CTX), L->q.limit);
-    o[0] = (op & P8OP_ZERO) ? (int16_t)0 : (int16_t)((d->stretch[p] + 1) >> 1);
+    o[0] = (op & P8OP_ZERO) ? (int16_t)0 : (int16_t)((d->stretch[p] + (L->q.a ? 0 : 1)) >> 1);   // (a: im4bitModel's stretch(p) >> 1, :4735)
     return;
   }
   if (kind == P8L_PIC) {   // t[old] = nex(t[old], y); stretch(sm.p(t[new]))
@@ -114,6 +114,48 @@ P8_HD void p8s_lane_step_t(const P8LaneDev* L, const P8LaneTabs* d, P8LaneRegs* 
   if (r->bcount == L->q.bits_per_ctx) r->bcount = r->B = 0;
 }
 // md: the step's model (0: generic); a lane of the generic table runs in a model's step only if the model calls it (P8Lane.modes)
+// P8L_HT16 (im4bitModel :4675-4742): HashTable<16>::operator[] :841-856 on the lane's table; c32: [0..13] the contexts' byte offsets, [16..29] their
+// StateMap contexts, [31] started; sm16: 14 StateMaps. ops: the lane's op word and the 14 hash words behind it. bpos: the step's bit position.
+P8_HD uint32_t p8s_ht16_find(uint8_t* p, uint32_t i, uint8_t chk) {
+  enum { B = 16 };
+  if (p[i] == chk) return i + 1;
+  if (p[i ^ B] == chk) return (i ^ B) + 1;
+  if (p[i ^ (B * 2)] == chk) return (i ^ (B * 2)) + 1;
+  if (p[i + 1] > p[(i + 1) ^ B] || p[i + 1] > p[(i + 1) ^ (B * 2)]) i ^= B;
+  if (p[i + 1] > p[(i + 1) ^ B ^ (B * 2)]) i ^= B ^ (B * 2);
+  for (int k = 0; k < B; k++) p[i + k] = 0;
+  p[i] = chk;
+  return i + 1;
+}
+P8_HD void p8s_lane_ht16(const P8LaneDev* L, const P8LaneTabs* d, const uint32_t* ops, int y, int bpos, int16_t* x) {
+  enum { S = 14 };
+  if (!(ops[0] & P8OP_MIX)) return;
+  uint32_t* st = L->c32;
+  uint8_t* T = L->c8;
+  if (!st[31]) { for (int i = 0; i < S; i++) st[i] = 1; st[31] = 1; }   // cp[i] = t[263 * i] + 1: every such key is item 0 with checksum 0
+  for (int i = 0; i < S; i++) T[st[i]] = d->nex[4 * T[st[i]] + y];
+  if (bpos == 0 || bpos == 4) {
+    for (int i = 0; i < S; i++) { const uint32_t wd = ops[1 + i]; st[i] = p8s_ht16_find(T, (wd & 0x3FFFFFu) << 4, (uint8_t)(wd >> 22)); }
+  } else {
+    const uint32_t j = (uint32_t)(y + 1) << (bpos & 3);
+    for (int i = 0; i < S; i++) st[i] += j;
+  }
+  int16_t* o = x + L->q.off;
+  for (int i = 0; i < S; i++) {
+    const int s = T[st[i]];
+    const int n0 = -!d->nex[4 * s + 2], n1 = -!d->nex[4 * s + 3];
+    uint16_t* m = L->sm16 + 256 * i;
+    uint32_t* cx = &st[16 + i];
+    m[*cx] = (uint16_t)(m[*cx] + (((y << 16) - m[*cx] + 128) >> 8));
+    *cx = (uint32_t)s;
+    const int p1 = m[s] >> 4;
+    const int sv = d->stretch[p1] >> 1;
+    const int dn = n1 - n0;
+    o[3 * i] = (int16_t)sv;
+    o[3 * i + 1] = (int16_t)((p1 - 2047) >> 2);
+    o[3 * i + 2] = (int16_t)(sv * (dn < 0 ? -dn : dn));
+  }
+}
 // P8L_PIC2: the second context's registers live in the fields a bit-history lane does not use (context = its cell, B = its StateMap context)
 P8_HD void p8s_lane_pic2(const P8LaneDev* L, const P8LaneTabs* d, P8LaneRegs* r, uint32_t op, uint32_t op2, int y, int16_t* x) {
   if (!(op & P8OP_MIX)) return;

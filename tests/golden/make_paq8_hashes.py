@@ -106,6 +106,20 @@ def wav_file(nsamples, channels, bits, seed):
     return b"RIFF" + len(body).to_bytes(4, "little") + body
 
 
+def bmp4_file(img, palette):
+    """bottom-up 4-bit BMP of an [h, w] image of values 0..15 with a 16-entry palette"""
+    h, w = img.shape
+    row = ((w * 4 + 31) >> 5) * 4
+    def pack(r):
+        r = np.concatenate([r, np.zeros(w & 1, np.uint8)])
+        return ((r[0::2] << 4) | r[1::2]).astype(np.uint8).tobytes().ljust(row, b"\0")
+    pix = b"".join(pack(img[y]) for y in range(h - 1, -1, -1))
+    pal = b"".join(bytes([int(b), int(g), int(r), 0]) for b, g, r in palette)
+    off = 54 + 64
+    return (b"BM" + (off + len(pix)).to_bytes(4, "little") + bytes(4) + off.to_bytes(4, "little") + (40).to_bytes(4, "little") + w.to_bytes(4, "little") +
+            h.to_bytes(4, "little") + (1).to_bytes(2, "little") + (4).to_bytes(2, "little") + bytes(4) + len(pix).to_bytes(4, "little") + bytes(16) + pal + pix)
+
+
 def bmp1_file(bits):
     """bottom-up 1-bit BMP of an [h, w] 0/1 image (two palette entries, rows padded to 4 bytes)"""
     h, w = bits.shape
@@ -147,6 +161,8 @@ def image_streams():
         # 1-bit images (im1bitModel :4634-4673): a binary PBM, which the preprocessor turns into an IMAGE1 block, and a 1-bit BMP inside a DEFAULT block
         "pbm1_2k": preprocessed(text[:200] + b"P4\n128 96\n" + np.packbits(photo(128, 96, 1, 13)[:, :, 0] > 128, axis=1).tobytes() + text[200:400]),
         "bmp1_raw_2k": default_block(text[:100] + bmp1_file((photo(160, 80, 1, 14)[:, :, 0] > 120).astype(np.uint8)) + text[100:250]),
+        # 4-bit images (im4bitModel :4675-4742, its 14 contexts on a HashTable<16>): a 16-colour BMP inside a DEFAULT block
+        "bmp4_raw_3k": default_block(text[:100] + bmp4_file((photo(96, 56, 1, 15)[:, :, 0] >> 4).astype(np.uint8), np.random.default_rng(16).integers(0, 256, (16, 3))) + text[100:250]),
         # PCM audio (audio8bModel :5552-5657, wavModel :5659-5804, each followed by recordModel): WAV files as the preprocessor frames them
         "wav16s_6k": preprocessed(text[:200] + wav_file(1400, 2, 16, 9) + text[200:450]),
         "wav8s_4k": preprocessed(text[:150] + wav_file(1800, 2, 8, 10) + text[150:300]),

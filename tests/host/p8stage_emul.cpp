@@ -375,7 +375,8 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
       const P8LaneTabs tb = {XD->nex, XD->stretch};
       for (int l = XD->nlanes - 1; l >= 0; l--) {   // a map the step does not call is not touched and writes nothing: its positions may be another face's (im8bitModel: gray / palette)
         const uint32_t op = c.xops[t * P8_XL_NLANE + l];
-        if (XD->lane[l].q.kind == P8L_PIC2) p8s_lane_pic2(&XD->lane[l], &tb, &XD->regs[l], op, c.xops[t * P8_XL_NLANE + l + 1], y, xr);
+        if (XD->lane[l].q.kind == P8L_HT16) p8s_lane_ht16(&XD->lane[l], &tb, &c.xops[t * P8_XL_NLANE + l], y, (int)(t & 7), xr);
+        else if (XD->lane[l].q.kind == P8L_PIC2) p8s_lane_pic2(&XD->lane[l], &tb, &XD->regs[l], op, c.xops[t * P8_XL_NLANE + l + 1], y, xr);
         else if (op & P8OP_MIX) p8s_lane_step_t(&XD->lane[l], &tb, &XD->regs[l], op, y, order[t], xr, P8_NX);
       }
     }
