@@ -22,12 +22,12 @@ enum {
   P8_NLANE = 64,           /* small learners + host-computed inputs, one lane each */
   P8_ORDER_MAX = 10,       /* ContextMap2::mix's return value for the 10-context order-N map */
   /* the image models (im24bitModel :5001-5353, im8bitModel :4743-4999): a model id per byte, 0 = everything above */
-  P8_NMODEL = 7,           /* 0 generic (text / default / exe ...), 1 im24 (IMAGE24 / IMAGE32 blocks, 24 / 32-bit BMP / TGA payloads), 2 im8, 3 audio8, 4 wav16, 5 im1, 6 im4 */
+  P8_NMODEL = 8,           /* 0 generic (text / default / exe ...), 1 im24 (IMAGE24 / IMAGE32 blocks, 24 / 32-bit BMP / TGA payloads), 2 im8, 3 audio8, 4 wav16, 5 im1, 6 im4, 7 jpeg */
   P8_XL_NLANE = 192,       /* small maps of one image model (im24: 100 StationaryMap + 59 SmallStationaryContextMap) */
   P8_XL_MAXS = 64,         /* slots of a model's ContextMap family (im24: 47, im8: 52, wav16: 11 + recordModel's 25); the row's last two cells: active range */
   P8_XL_MAXG = 8           /* generic ContextMap instances a model also calls (the audio models: recordModel's four) */
 };
-enum { P8_MODEL_GENERIC = 0, P8_MODEL_IM24 = 1, P8_MODEL_IM8 = 2, P8_MODEL_AUDIO8 = 3, P8_MODEL_WAV16 = 4, P8_MODEL_IM1 = 5, P8_MODEL_IM4 = 6 };
+enum { P8_MODEL_GENERIC = 0, P8_MODEL_IM24 = 1, P8_MODEL_IM8 = 2, P8_MODEL_AUDIO8 = 3, P8_MODEL_WAV16 = 4, P8_MODEL_IM1 = 5, P8_MODEL_IM4 = 6, P8_MODEL_JPEG = 7 };
 
 /* small lanes (one wavefront): kinds */
 enum {
@@ -42,6 +42,10 @@ enum {
   P8L_HT16,      /* im4bitModel's 14 contexts on its HashTable<16> (:828-856, :4675-4742): ONE lane walks them in the reference's order -- items are found and
                   * replaced by priority, two contexts may come to share one --; a bit history per context and nibble position, a u16 StateMap each; the 14
                   * hashed contexts of a nibble (checksum << 22 | item index) are the raw op words of the 14 P8L_NONE lanes behind it; 42 inputs */
+  P8L_JPG,       /* jpegModel's learning half (:6482-6596): ONE lane -- 32 contexts on a BH<9> table (found / moved to the front in the reference's order), a
+                  * StateMap each, the model's own 33-input mixer with three weight sets and its second layer, two APM stages; op word: P8OP_MIX | hbcount |
+                  * (huffcode & 1) << 2; behind it 64 raw words (the 32 contexts' checksum / item index, every third bit of a code) and 5 more (the three
+                  * weight rows, the two APM contexts); 70 inputs + 4 values that are only exported (the mixer's constant input and its three set outputs) */
   P8L_PIC2       /* two P8L_PIC maps whose context ranges overlap in the reference's shared array (im1bitModel's cxt[6] / cxt[7]): one lane, one array,
                   * the two contexts in the reference's order; the second context's op word is the next lane's (a P8L_NONE placeholder); two inputs */
 };
@@ -84,6 +88,10 @@ typedef struct {
    * generic positions. own_opt: inputs [opt_lo, opt_lo + opt_n) are the own ContextMap's, absent in a byte it is silent (P8ApmRec.c[7]) */
   int16_t map[P8_NX];
   int opt_lo, opt_n;
+  /* jpegModel's coded steps export more than their inputs, interleaved (the model's own mixer exports too, :504-507): positions of the 1552-vector in
+   * export order (P8ApmRec.c[7] == 2 selects it; otherwise a step exports its inputs in order) */
+  int exp_n;
+  int16_t exp[P8_NX];
 } P8XLayout;
 
 typedef struct {

@@ -435,6 +435,33 @@ void p8f_sm32b_emit(P8fSm32b* s, int cx, int16_t* out) {
   put_op(e->model, s->lane, P8OP_MIX | P8OP_SET | ((uint32_t)cx & P8OP_CTX));
 }
 
+/* jpegModel's learning half (p8_rec.h P8L_JPG): the worker lane, 64 + 5 lanes that carry its raw words */
+typedef struct P8fJpg { int lane[70]; int hashbits; } P8fJpg;
+P8fJpg* p8f_jpg_new(uint64_t table_items) {
+  P8fJpg* j = (P8fJpg*)calloc(1, sizeof *j);
+  j->hashbits = (int)ilog2u((unsigned)table_items);
+  j->lane[0] = new_lane(P8L_JPG, (uint32_t)table_items, 0);
+  for (int i = 1; i < 70; ++i) j->lane[i] = new_lane(P8L_NONE, 0, 0);
+  return j;
+}
+/* a coded step: cxt = the 32 context hashes (NULL unless hbcount == 0); 70 inputs at out[0..70), the export-only values at out[70..74) */
+int p8f_jpg_step(P8fJpg* j, int hbcount, int hc_low, const uint64_t* cxt, const int* m1sel, int a1ctx, int a2ctx, int16_t* out) {
+  P8Emit* e = p8f_cur;
+  lane_out(e->model, j->lane[0], out, 74, 0, 1, 1, 0, 0);
+  put_op(e->model, j->lane[0], P8OP_MIX | (uint32_t)(hbcount & 3) | ((uint32_t)(hc_low & 1) << 2));
+  if (cxt)
+    for (int i = 0; i < 32; ++i) {   /* BH<9>::operator[] :790-793: 16-bit checksum, first item of the 8-item neighbourhood */
+      const uint32_t chk = (uint32_t)(p8f_checksum64(cxt[i], j->hashbits, 16) & 0xffff);
+      const uint32_t item = (uint32_t)(((uint64_t)p8f_finalize64(cxt[i], j->hashbits) * 8) & (((uint64_t)1 << j->hashbits) - 1));
+      put_op(e->model, j->lane[1 + 2 * i], chk);
+      put_op(e->model, j->lane[2 + 2 * i], item);
+    }
+  for (int i = 0; i < 3; ++i) put_op(e->model, j->lane[65 + i], (uint32_t)m1sel[i]);
+  put_op(e->model, j->lane[68], (uint32_t)a1ctx);
+  put_op(e->model, j->lane[69], (uint32_t)a2ctx);
+  return 70;
+}
+
 /* dmcForest (:7777-7822): bits only, lives on the device */
 typedef struct Forest { int level; } Forest;
 Forest* p8f_dmc_new(int level) { Forest* f = (Forest*)calloc(1, sizeof *f); f->level = level; return f; }

@@ -72,6 +72,8 @@ Audio8* p8f_audio8_new(void);
 int p8f_audio8_step(Audio8* m, int y, int bpos, int c0, const uint8_t* hist, uint32_t bmask, int pos, int info, int blpos, uint32_t* record, int16_t* out, int* sets, int* ranges);
 Wav16* p8f_wav16_new(int level);
 int p8f_wav16_step(Wav16* m, int y, int bpos, int c0, const uint8_t* hist, uint32_t bmask, int pos, int info, uint32_t* record, int16_t* out, int* sets, int* ranges, int* cm_active);
+struct Jpeg* p8f_jpeg_new(int level);
+int p8f_jpeg_step(struct Jpeg* j, int y, int bpos, const uint8_t* hist, uint32_t bmask, int pos, int16_t* out, int* sets, int* ranges, int* kind);
 typedef struct Im4 Im4;
 Im4* p8f_im4_new(int level);
 int p8f_im4_step(Im4* m, int y, int bpos, int c0, uint32_t c4, const uint8_t* hist, uint32_t bmask, int pos, int w, int16_t* out, int* sets, int* ranges);
@@ -131,12 +133,12 @@ typedef struct {
   Im1* im1;
   Im4* im4;
   uint32_t wav_eoi, wav_info;                      /* audioModel's statics eoi, info: PCM samples are being modelled while info != 0 */
-  int own_silent;                                  /* the step's model has a ContextMap of its own and it has no contexts this byte */
+  int own_silent;                                  /* the step's model has a ContextMap of its own and it has no contexts this byte (2: a coded JPEG step, exported through the model's export map) */
+  int jpeg_const;                                  /* a stuffed / restart step of the JPEG model: its one constant input */
   uint32_t img_stats[8];                           /* ModelStats.Image of the byte: W, N, NN, WW, Wp1, Np1, plane, ctx */
   int model;                                       /* P8_MODEL_* of the current step */
   int nsel;                                        /* weight sets of the current step */
-  struct { int offset, jpeg, app; } jimg[4];       /* jpegModel's images[0..3] as far as the header phase goes (:5898-5908) */
-  int jidx, jlast_pos, jdqt_state, jdqt_end, jqnum;
+  struct Jpeg* jpeg;                                /* jpegModel :5911-6597 (p8f_jpeg.c) */
   struct { uint32_t Header, IdLength, Bpp, ImgType, MapSize, Width, Height; } tga;
   struct { uint32_t Header, Size, Channels, BitsPerSample, Chunk, Data; } wav;
   uint32_t wav_length;
@@ -159,7 +161,6 @@ static P8Predictor* predictor_new(int level) {
   p->level = level;
   p->buf = (uint8_t*)p8f_tracked_calloc(mem * 8, 1); p->bmask = (uint32_t)(mem * 8 - 1);
   p->c0 = 1;
-  p->jdqt_state = -1;
   p->cm = p8f_cm2_new(mem * 16, 10);
   p->text = p8f_text_new((uint32_t)(mem * 16));
   p->match = p8f_match_new((uint32_t)(mem * 2));
@@ -184,6 +185,8 @@ static P8Predictor* predictor_new(int level) {
   p->im1 = p8f_im1_new();
   p8f_emit_model(p8f_cur, P8_MODEL_IM4);
   p->im4 = p8f_im4_new(level);
+  p8f_emit_model(p8f_cur, P8_MODEL_JPEG);
+  p->jpeg = p8f_jpeg_new(level);
   p8f_emit_model(p8f_cur, 0);
   return p;
 }
@@ -200,48 +203,6 @@ static uint64_t hash1(uint64_t a) { return (a + 1) * 0x9E3779B97F4A7C15ull; }
  * reference up to the byte at which the sub-model would switch on (its return value turns non-zero and contextModel2 :8161-8167
  * takes the short path): only there is the stream refused. A header-like pattern that the reference itself drops (a DIB header
  * with no plausible pixel area, an SOI that is not followed by a valid scan header) is ordinary data here too. */
-
-/* jpegModel :5911-6133, header phase. images[idx].jpeg: 1 after SOI + marker, 2 once a valid SOS has been seen -- from that byte on
- * the model codes Huffman data and returns 1. Before that, everything it does (APPx skipping with embedded thumbnails, DQT tables,
- * pointers to SOF / DHT) is private state; what matters is which bytes reset it. bpos == 0 here, so `jassert` failures reset. */
-#define JFINISH() do { const int length_ = p->pos - p->jimg[p->jidx].offset; memset(&p->jimg[p->jidx], 0, sizeof p->jimg[0]); \
-    p->jdqt_state = -1; p->jidx -= (p->jidx > 0); p->jimg[p->jidx].app -= length_; if (p->jimg[p->jidx].app < 0) p->jimg[p->jidx].app = 0; } while (0)
-#define JASSERT(x) do { if (!(x)) { if (p->jidx > 0) JFINISH(); else p->jimg[p->jidx].jpeg = 0; return 0; } } while (0)
-static int jpeg_detect(P8Predictor* p) {
-  const uint32_t b1 = RB(1), b2 = RB(2), b3 = RB(3), b4 = RB(4);
-  const int soi_marker = b4 == 0xFF && b3 == 0xD8 && b2 == 0xFF && ((b1 & 0xFE) == 0xC0 || b1 == 0xC4 || (b1 >= 0xDB && b1 <= 0xFE));
-  if (p->jimg[p->jidx].app > 0) {   /* inside an APPx / COM segment: only an embedded image is looked for (:6058-6063) */
-    --p->jimg[p->jidx].app;
-    if (p->jidx < 3 && soi_marker) { ++p->jidx; memset(&p->jimg[p->jidx], 0, sizeof p->jimg[0]); }
-  }
-  if (p->jimg[p->jidx].app > 0) return 0;
-  if (!p->jimg[p->jidx].jpeg && soi_marker) {   /* :6098-6107 */
-    p->jimg[p->jidx].jpeg = 1;
-    p->jimg[p->jidx].offset = p->pos - 4;
-    p->jimg[p->jidx].app = ((b1 >> 4) == 0xE) * 2;
-  }
-  /* the end-of-image test (:6111-6114) needs images[idx].data, which only a valid SOS sets: never true before the refusal below */
-  p->jlast_pos = p->pos;
-  if (!p->jimg[p->jidx].jpeg) return 0;
-  if (!p->jimg[p->jidx].app && b4 == 0xFF && ((b3 > 0xC1 && b3 <= 0xCF && b3 != 0xC4) || (b3 >= 0xDC && b3 <= 0xFE))) {   /* :6119-6123 */
-    p->jimg[p->jidx].app = (int)(b2 * 256 + b1 + 2);
-    if (p->jidx > 0) JASSERT(p->pos + p->jimg[p->jidx].app < p->jimg[p->jidx].offset + p->jimg[p->jidx - 1].app);
-  }
-  if (RB(5) == 0xFF && b4 == 0xDA) {   /* SOS with a consistent length: Huffman-coded data follows, the model switches on (:6126-6130) */
-    const int len = (int)(b3 * 256 + b2);
-    if (len == 6 + 2 * (int)b1 && b1 && b1 <= 4) return P8F_ERR_JPEG;
-  }
-  if (b4 == 0xFF && b3 == 0xDB) { p->jdqt_end = p->pos + (int)(b2 * 256 + b1) - 1; p->jdqt_state = 0; }   /* DQT :6136-6151 */
-  else if (p->jdqt_state >= 0) {
-    if (p->pos >= p->jdqt_end) p->jdqt_state = -1;
-    else {
-      if (p->jdqt_state % 65 == 0) p->jqnum = (int)b1;
-      else { JASSERT(b1 > 0); JASSERT(p->jqnum >= 0 && p->jqnum < 4); }
-      p->jdqt_state++;
-    }
-  }
-  return 0;
-}
 
 /* imgModel :5386-5483 with w == 0, eoi == 0. *record = Stats.Record, which the palette walk of an 8-bit header rewrites (:5363) and
  * recordModel reads (:4225). */
@@ -425,7 +386,42 @@ static int context_model2(P8Predictor* p, int y, int32_t* sel) {
   else if (p->filetype == FT_IMAGE4) { img_w = p->info; img_bpp = 4; by_block = 1; }
   else {
     int e;
-    if (bpos == 0 && p->filetype != FT_EXE && (e = jpeg_detect(p)) != 0) return e;
+    if (p->filetype != FT_EXE) {   /* jpegModel :5911-6597: it follows every byte of the stream; a non-zero return makes the step its own */
+      P8Emit* const em = p8f_cur;
+      int sets[3], ranges[3], kind = 0;
+      const int prefix = nx;
+      P8XLayout* X = &em->L.xl[P8_MODEL_JPEG - 1];
+      p8f_emit_step_model(em, P8_MODEL_JPEG);
+      p8f_emit_model(em, P8_MODEL_JPEG);
+      const int jp = p8f_jpeg_step(p->jpeg, y, bpos, p->buf, p->bmask, p->pos, in + nx, sets, ranges, &kind);
+      p8f_emit_model(em, 0);
+      if (jp) {
+        if (em->chunk && !em->chunk->xops) return P8F_ERR_IMAGE_LATE;
+        nx += kind == 3 ? 70 : kind ? 1 : 0;
+        if (em->xdiscovering) {
+          for (int i = 0; i < prefix; i++) X->map[i] = (int16_t)i;
+          X->prefix_nx = prefix; if (nx > X->nx) X->nx = nx;
+          if (kind == 1 || kind == 2) X->map[prefix] = (int16_t)prefix;
+          if (kind == 3) {   /* the coded step's exports in call order (:6572-6591): m1.add(128); per context m.add, m1.add, m.add; m1.p()'s three; six more */
+            int k = 0;
+            for (int i = 0; i < prefix; i++) X->exp[k++] = (int16_t)i;
+            X->exp[k++] = (int16_t)(prefix + 70);
+            for (int i = 0; i < 32; i++) { X->exp[k++] = (int16_t)(prefix + 2 * i); X->exp[k++] = (int16_t)(prefix + 2 * i + 1); X->exp[k++] = (int16_t)(prefix + 2 * i + 1); }
+            for (int i = 0; i < 3; i++) X->exp[k++] = (int16_t)(prefix + 71 + i);
+            for (int i = 0; i < 6; i++) X->exp[k++] = (int16_t)(prefix + 64 + i);
+            X->exp_n = k;
+          }
+        } else if (X->prefix_nx != prefix) return P8F_ERR_INTERNAL;
+        p->nx = nx; p->model = P8_MODEL_JPEG; p->nsel = kind ? 3 : 0;
+        p->own_silent = kind == 3 ? 2 : 0;
+        p->jpeg_const = kind == 1 ? 128 : kind == 2 ? 4095 : 0;
+        int base = 0;
+        for (int i = 0; i < p->nsel; i++) { sel[ns++] = base + sets[i]; base += ranges[i]; }
+        for (; ns < P8_NSEL; ns++) sel[ns] = -1;
+        return 0;
+      }
+      p8f_emit_step_model(em, 0);
+    }
     if (p->size > 0) {   /* imgModel :5386-5504 */
       if (bpos == 0 && (e = img_detect(p, &p->stat_record)) != 0) return e;
       if (p->pos > p->img_eoi) p->img_w = 0;
@@ -580,7 +576,7 @@ static int front_step(P8Front* f, int y, int32_t* sel, P8ApmRec* apm) {
   const uint32_t c4 = p->c4, mlen = lg < 3 ? lg : 3, eb = p->match_expected;
   memset(apm, 0, sizeof *apm);
   apm->model = (uint8_t)p->model;
-  if (p->model) { apm->c[7] = (uint16_t)p->own_silent; apm->c[8] = (uint16_t)p->nx; apm->c[9] = (uint16_t)p->nsel; }
+  if (p->model) { apm->c[7] = (uint16_t)p->own_silent; apm->c[8] = (uint16_t)p->nx; apm->c[9] = (uint16_t)p->nsel; apm->c[6] = (uint16_t)(p->model == P8_MODEL_JPEG ? p->jpeg_const : 0); }
   if (p->type == FT_TEXT) {
     apm->text = P8_APM_TEXT;
     apm->limit = (uint16_t)(0x3FF >> ((p->blpos < 0xFFF) * 2));
@@ -670,7 +666,10 @@ P8Front* p8f_front_new(int level) {
                                   'R', 'I', 'F', 'F', 48, 0, 0, 0, 'W', 'A', 'V', 'E', 'f', 'm', 't', ' ', 16, 0, 0, 0, 1, 0, 2, 0, 0x44, 0xAC, 0, 0, 0x88, 0x58, 1, 0, 2, 0, 8, 0,
                                   'd', 'a', 't', 'a', 12, 0, 0, 0,   128, 127, 129, 126, 130, 125, 131, 124, 132, 123, 133, 122,
                                   'R', 'I', 'F', 'F', 52, 0, 0, 0, 'W', 'A', 'V', 'E', 'f', 'm', 't', ' ', 16, 0, 0, 0, 1, 0, 2, 0, 0x44, 0xAC, 0, 0, 0x10, 0xB1, 2, 0, 4, 0, 16, 0,
-                                  'd', 'a', 't', 'a', 16, 0, 0, 0,   1, 0, 2, 0, 3, 0, 4, 0, 5, 0, 6, 0, 7, 0, 8, 0, 0};
+                                  'd', 'a', 't', 'a', 16, 0, 0, 0,   1, 0, 2, 0, 3, 0, 4, 0, 5, 0, 6, 0, 7, 0, 8, 0,
+                                  /* a DEFAULT block with a baseline JPEG: SOI, DQT, SOF0 (8 x 8, one component), SOS, six bytes of coded data (no DHT: the standard tables), EOI */
+                                  FT_DEFAULT, 0, 0, 0, 102,
+                                  255, 216, 255, 219, 0, 67, 0, 16, 11, 12, 14, 12, 10, 16, 14, 13, 14, 18, 17, 16, 19, 24, 40, 26, 24, 22, 22, 24, 49, 35, 37, 29, 40, 58, 51, 61, 60, 57, 51, 56, 55, 64, 72, 92, 78, 64, 68, 87, 69, 55, 56, 80, 109, 81, 87, 95, 98, 103, 104, 103, 62, 77, 113, 121, 112, 100, 120, 92, 101, 103, 99, 255, 192, 0, 11, 8, 0, 8, 0, 8, 1, 1, 17, 0, 255, 218, 0, 8, 1, 1, 0, 0, 63, 0, 165, 97, 160, 244, 249, 43, 255, 217, 0};
     f->emit.xdiscovering = 1; f->emit.lane_objs = 0; memset(f->emit.xlane_objs, 0, sizeof f->emit.xlane_objs);
     f->p = predictor_new(level);
     int bit = 0;

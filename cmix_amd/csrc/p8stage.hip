@@ -1088,7 +1088,8 @@ __global__ __launch_bounds__(P8_XL_NLANE) void cmx_p8s_xlanes_kernel(P8XLanesDev
     if (model[t >> 3] != mine) continue;
     const int y = t ? bits[t - 1] : last_y;
     const uint32_t op = xops[(size_t)t * P8_XL_NLANE + l];
-    if (d->lane[l].q.kind == P8L_HT16) p8s_lane_ht16(&d->lane[l], &tb, xops + (size_t)t * P8_XL_NLANE + l, y, t & 7, x + (size_t)t * P8_NX);
+    if (d->lane[l].q.kind == P8L_JPG) p8s_lane_jpg(&d->lane[l], &tb, d->squash, xops + (size_t)t * P8_XL_NLANE + l, y, x + (size_t)t * P8_NX);
+    else if (d->lane[l].q.kind == P8L_HT16) p8s_lane_ht16(&d->lane[l], &tb, xops + (size_t)t * P8_XL_NLANE + l, y, t & 7, x + (size_t)t * P8_NX);
     else if (d->lane[l].q.kind == P8L_PIC2) p8s_lane_pic2(&d->lane[l], &tb, &r, op, xops[(size_t)t * P8_XL_NLANE + l + 1], y, x + (size_t)t * P8_NX);
     else if (op & P8OP_MIX) p8s_lane_step_t(&d->lane[l], &tb, &r, op, y, order[t], x + (size_t)t * P8_NX, P8_NX);   // (a map the step does not call writes nothing: its positions may be the model's other face's)
   }
@@ -1100,7 +1101,7 @@ __global__ __launch_bounds__(P8_XL_NLANE) void cmx_p8s_xlanes_kernel(P8XLanesDev
 // the model's APM chain on one lane (p8s_tail_image), the export: nx + nsel + 10 values back to back, the rest of the 1591 as they were
 // (AddPrediction() counts on, :504-510). Same packed arithmetic as cmx_p8s_mix4_kernel. T: the state the generic mixer leaves and takes over.
 constexpr int XMX_THREADS = 1024;
-struct P8XMixMap { int16_t map[P8_NX]; int opt_lo, opt_n; };   // a model's inputs in add() order -> positions in the 1552-vector (P8XLayout.map)
+struct P8XMixMap { int16_t map[P8_NX]; int opt_lo, opt_n; int exp_n; int16_t exp[P8_NX]; };   // a model's inputs in add() order -> positions in the 1552-vector; its export order (P8XLayout)
 __global__ __launch_bounds__(XMX_THREADS) void cmx_p8s_xmix_kernel(const P8MixDev* M, P8TailDev* T, const P8XMixMap* maps, const int16_t* x, const int32_t* sel, const P8ApmRec* apm,
                                                                  const uint8_t* bits, float* out, size_t ld, int nbits, int last_y) {
   __shared__ __attribute__((aligned(16))) uint32_t xs[P8_NX / 2];
@@ -1123,15 +1124,21 @@ __global__ __launch_bounds__(XMX_THREADS) void cmx_p8s_xmix_kernel(const P8MixDe
     misses += misses + (unsigned long long)((lastpr >> 11) != y);   // Predictor::update's first line (:8250)
     const int16_t* xr = x + (size_t)t * P8_NX;
     const P8XMixMap* mp = maps + (a->model - 1);
-    const int skp = a->c[7] ? mp->opt_n : 0, olo = mp->opt_lo;   // the model's own ContextMap is silent this byte: its inputs are not there
+    const int skp = a->c[7] == 1 ? mp->opt_n : 0, olo = mp->opt_lo;   // the model's own ContextMap is silent this byte: its inputs are not there
+    const int jc = a->model == P8_MODEL_JPEG ? (int)a->c[6] : 0;        // a stuffed / restart step of the JPEG model: its one constant input
+    const int ne = a->c[7] == 2 ? mp->exp_n : nx;                       // exported values in front of the second layer's
     for (int i = tid; i < P8_NX / 2; i += XMX_THREADS) {
       const int i0 = 2 * i, i1 = 2 * i + 1;
       const uint32_t lo = i0 < nx ? (uint32_t)(uint16_t)xr[mp->map[(skp && i0 >= olo) ? i0 + skp : i0]] : 0u;
-      const uint32_t hi = i1 < nx ? (uint32_t)(uint16_t)xr[mp->map[(skp && i1 >= olo) ? i1 + skp : i1]] : 0u;
-      xs[i] = lo | (hi << 16);
+      uint32_t hi = i1 < nx ? (uint32_t)(uint16_t)xr[mp->map[(skp && i1 >= olo) ? i1 + skp : i1]] : 0u;
+      uint32_t lo2 = lo;
+      if (jc && i0 == nx - 1) lo2 = (uint32_t)(uint16_t)jc;
+      if (jc && i1 == nx - 1) hi = (uint32_t)(uint16_t)jc;
+      xs[i] = lo2 | (hi << 16);
     }
     __syncthreads();
-    for (int i = tid; i < nx; i += XMX_THREADS) outs[i] = (float)p8s_squash(squash, reinterpret_cast<const int16_t*>(xs)[i]) * cf;
+    if (a->c[7] == 2) { for (int i = tid; i < ne; i += XMX_THREADS) outs[i] = (float)p8s_squash(squash, xr[mp->exp[i]]) * cf; }
+    else for (int i = tid; i < nx; i += XMX_THREADS) outs[i] = (float)p8s_squash(squash, reinterpret_cast<const int16_t*>(xs)[i]) * cf;
     uint4 w[4];
     int my_pr = 2048, row = 0;
     if (wave < nsel) {
@@ -1153,7 +1160,7 @@ __global__ __launch_bounds__(XMX_THREADS) void cmx_p8s_xmix_kernel(const P8MixDe
     __syncthreads();
     if (wave == 0) {   // second layer (its row is 32 wide; inputs behind nsel are zero)
       const int av = lane < nsel ? stretch[pr_s[lane]] : 0;
-      if (lane < nsel) outs[nx + lane] = (float)p8s_squash(squash, av) * cf;
+      if (lane < nsel) outs[ne + lane] = (float)p8s_squash(squash, av) * cf;
       const int bv = __shfl_down(av, 1);
       if ((lane & 1) == 0 && lane < 32) st_s[lane >> 1] = ((uint32_t)av & 0xffffu) | ((uint32_t)bv << 16);
       __builtin_amdgcn_s_waitcnt(0);
@@ -1167,7 +1174,7 @@ __global__ __launch_bounds__(XMX_THREADS) void cmx_p8s_xmix_kernel(const P8MixDe
     __syncthreads();
     if (tid == 0) {   // the model's chain, serial on the tables in HBM
       T->misses = misses;
-      fin_s = p8s_tail_image(T, a, y, p_s, outs + nx + nsel);
+      fin_s = p8s_tail_image(T, a, y, p_s, outs + ne + nsel);
     }
     __syncthreads();
     float* orow = out + (size_t)t * ld;
@@ -1331,7 +1338,10 @@ cmx_p8stage_t* cmx_p8stage_create(int device) {
       if (h->L.xl[m].nx) { h->d_xfam[m] = dev_copy(S->xfam[m], h->pol); h->d_xlanes[m] = dev_copy(S->xlanes[m], h->pol); h->xview[m] = S->xview[m]; }
     {
       std::vector<P8XMixMap> mm(P8_NMODEL - 1);
-      for (int m = 0; m < P8_NMODEL - 1; m++) { memcpy(mm[m].map, h->L.xl[m].map, sizeof mm[m].map); mm[m].opt_lo = h->L.xl[m].opt_lo; mm[m].opt_n = h->L.xl[m].opt_n; }
+      for (int m = 0; m < P8_NMODEL - 1; m++) {
+        memcpy(mm[m].map, h->L.xl[m].map, sizeof mm[m].map); mm[m].opt_lo = h->L.xl[m].opt_lo; mm[m].opt_n = h->L.xl[m].opt_n;
+        memcpy(mm[m].exp, h->L.xl[m].exp, sizeof mm[m].exp); mm[m].exp_n = h->L.xl[m].exp_n;
+      }
       h->d_xmaps = (P8XMixMap*)h->pol.zalloc(mm.size() * sizeof(P8XMixMap));
       h->pol.upload(h->d_xmaps, mm.data(), mm.size() * sizeof(P8XMixMap));
     }

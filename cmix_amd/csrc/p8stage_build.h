@@ -182,6 +182,7 @@ bool build_stage(P8StageState& S, Policy& P, const P8Layout& L, int level, const
     P8XLanesDev& XD = S.xlanes[m];
     XD.nlanes = X.nlanes; XD.model = m + 1;
     XD.nex = D.nex; XD.stretch = D.stretch;
+    XD.squash = (const int16_t*)up(squash4096, 4096 * 2);
     for (int l = 0; l < X.nlanes; l++) {
       P8LaneDev& q = XD.lane[l];
       q.q = X.lane[l];
@@ -202,6 +203,27 @@ bool build_stage(P8StageState& S, Policy& P, const P8Layout& L, int level, const
       }
       else if (q.q.kind == P8L_NONE) continue;
       else if (q.q.kind == P8L_SM32) { std::vector<uint32_t> v(n, q.q.init); q.c32 = (uint32_t*)up(v.data(), n * 4); continue; }
+      else if (q.q.kind == P8L_JPG) {   // jpegModel's tables :6484-6490 (BH<9> t(MEM()), StateMap sm[32], Mixer m1(33, 2050, 3), APM a1(0x8000), a2(0x20000))
+        P8JpgDev J;
+        memset(&J, 0, sizeof J);
+        J.t = (uint8_t*)P.zalloc((size_t)n * 9 + 64); J.mask = (uint32_t)(n - 1);
+        std::vector<uint16_t> sm(32 * 256);
+        for (size_t i = 0; i < sm.size(); i++) {   // StateMap :626-635
+          int n0 = nex1024[4 * (i & 255) + 2], n1 = nex1024[4 * (i & 255) + 3];
+          if (n0 == 0) n1 *= 64;
+          if (n1 == 0) n0 *= 64;
+          sm[i] = (uint16_t)(65536 * (n1 + 1) / (n0 + n1 + 2));
+        }
+        J.sm = (uint16_t*)up(sm.data(), sm.size() * 2);
+        J.w1 = (int16_t*)P.zalloc((size_t)2050 * 40 * 2);
+        for (int i = 0; i < 8; i++) J.w2[i] = 0x7fff;
+        std::vector<uint32_t> av((size_t)0x20000 * 24);
+        for (size_t i = 0; i < av.size(); i++) { const int pp = (((int)(i % 24) * 2 + 1) * 4096) / 48 - 2048; av[i] = ((uint32_t)(pp > 2047 ? 4095 : pp < -2047 ? 0 : (int)squash4096[pp + 2048]) << 20) + 6; }   // APM :693-698
+        J.a1 = (uint32_t*)up(av.data(), (size_t)0x8000 * 24 * 4);
+        J.a2 = (uint32_t*)up(av.data(), av.size() * 4);
+        q.jpg = (P8JpgDev*)up(&J, sizeof J);
+        continue;
+      }
       else if (q.q.kind == P8L_HT16) {
         q.c8 = (uint8_t*)P.zalloc(n);          // the HashTable<16>
         q.c32 = (uint32_t*)P.zalloc(64 * 4);   // the 14 contexts' pointers and StateMap contexts

@@ -12,8 +12,10 @@
 #include "p8cm2_dev.h"   // P8_HD
 
 // ---------------------------------------------------------------- small lanes
+struct P8JpgDev;
 struct P8LaneDev {
   P8Lane q;
+  P8JpgDev* jpg;             // P8L_JPG: the worker's state (below)
   uint32_t mask, stride;     // context mask and cells per context (dmaps)
   uint8_t* c8; uint16_t* c16; uint32_t* c32;   // the lane's cells, by kind
   uint32_t* sm;              // IND: StateMap32(256); PIC: unused
@@ -43,7 +45,7 @@ struct P8XLanesDev {
   int nlanes, model;
   P8LaneDev lane[P8_XL_NLANE];
   P8LaneRegs regs[P8_XL_NLANE];   // home between chunks
-  const uint8_t* nex; const int16_t* stretch;
+  const uint8_t* nex; const int16_t* stretch; const int16_t* squash;
 };
 
 // one lane, one step. x: the step's 1552-vector; order: the order-N map's return value of this step; lim_off: the first input
@@ -154,6 +156,129 @@ P8_HD void p8s_lane_ht16(const P8LaneDev* L, const P8LaneTabs* d, const uint32_t
     o[3 * i] = (int16_t)sv;
     o[3 * i + 1] = (int16_t)((p1 - 2047) >> 2);
     o[3 * i + 2] = (int16_t)(sv * (dn < 0 ? -dn : dn));
+  }
+}
+// ---- P8L_JPG: jpegModel's learning half (:6482-6596) on one lane --------------------------------------------------------------------------
+// paq8's Mixer arithmetic in scalar form (dot_product :407-413 / :478-484, train :419-430 / :486-494; the wave-parallel form is p8stage.hip's)
+P8_HD int p8s_sat16(int v) { return v > 32767 ? 32767 : v < -32768 ? -32768 : v; }
+P8_HD int p8s_dot16(const int16_t* t, const int16_t* w, int n) {
+  uint32_t sum = 0;
+  for (int i = 0; i + 1 < n; i += 2) {
+    const uint32_t pair = (uint32_t)((int32_t)t[i] * w[i]) + (uint32_t)((int32_t)t[i + 1] * w[i + 1]);
+    sum += (uint32_t)((int32_t)pair >> 8);
+  }
+  return (int32_t)sum;
+}
+P8_HD void p8s_train16(const int16_t* t, int16_t* w, int n, int e) {
+  if (!e) return;
+  const int16_t err = (int16_t)e;
+  for (int i = 0; i < n; ++i) {
+    int v = p8s_sat16(2 * (int)t[i]);
+    v = (v * (int)err) >> 16;
+    v = p8s_sat16(v + 1) >> 1;
+    w[i] = (int16_t)p8s_sat16(v + (int)w[i]);
+  }
+}
+struct P8JpgDev {
+  uint8_t* t; uint32_t mask;            // BH<9> t(MEM()): items of 9 bytes (u16 checksum, 7 bit histories), 8-item neighbourhoods
+  uint32_t cp[32]; int smc[32]; int started;
+  uint16_t* sm;                         // [32][256] StateMaps
+  int16_t* w1;                          // m1's weights [2050][40] (Mixer m1(N + 1, 2050, 3): rows start at 0), created lazily in the reference = all zero here
+  int16_t w2[8];                        // its second layer's one row (0x7fff)
+  int16_t tx[40], tx2[8];               // the inputs of its last p()
+  int nx, row[3], pr[3], pr2, live;     // live: a p() has happened (update() has something to learn from)
+  uint32_t* a1; uint32_t* a2; int a1c, a2c;   // APM a1(0x8000), a2(0x20000)
+};
+// BH<9>::operator[] :788-813: the item of checksum chk in the neighbourhood starting at item i, moved to the front; returns its byte offset + 1
+P8_HD uint32_t p8s_bh9_get(uint8_t* t, uint32_t i, uint16_t chk) {
+  enum { B = 9, M = 8 };
+  uint32_t p = 0;
+  int j;
+  for (j = 0; j < M; ++j) {
+    p = (i + (uint32_t)j) * B;
+    const uint16_t cur = (uint16_t)(t[p] | (t[p + 1] << 8));
+    if (t[p + 2] == 0) { t[p] = (uint8_t)chk; t[p + 1] = (uint8_t)(chk >> 8); break; }
+    if (cur == chk) break;
+  }
+  if (j == 0) return p + 1;
+  uint8_t tmp[B];
+  if (j == M) {
+    --j;
+    for (int k = 0; k < B; k++) tmp[k] = 0;
+    tmp[0] = (uint8_t)chk; tmp[1] = (uint8_t)(chk >> 8);
+    if (t[(i + (uint32_t)j) * B + 2] > t[(i + (uint32_t)j - 1) * B + 2]) --j;
+  } else for (int k = 0; k < B; k++) tmp[k] = t[p + k];
+  for (int k = j * B - 1; k >= 0; k--) t[(i + 1) * B + (uint32_t)k] = t[i * B + (uint32_t)k];   // memmove(&t[(i + 1) * B], &t[i * B], j * B)
+  for (int k = 0; k < B; k++) t[i * B + (uint32_t)k] = tmp[k];
+  return i * B + 1;
+}
+// one coded step. ops: the worker's op word, then the 64 + 5 raw words; x: the step's vector (inputs at off .. off + 69, exported-only values behind)
+P8_HD void p8s_lane_jpg(const P8LaneDev* L, const P8LaneTabs* d, const int16_t* squash, const uint32_t* ops, int y, int16_t* x) {
+  enum { N = 32 };
+  if (!(ops[0] & P8OP_MIX)) return;
+  P8JpgDev* J = L->jpg;
+  const int hbcount = (int)(ops[0] & 3u), hcl = (int)((ops[0] >> 2) & 1u);
+  uint8_t* T = J->t;
+  if (J->started) for (int i = 0; i < N; ++i) T[J->cp[i]] = d->nex[4 * T[J->cp[i]] + y];   // if (cp[N-1]) *cp[i] = nex(*cp[i], y)
+  if (J->live) {   // m1.update() :529-541: every selected set learns the bit from its own output
+    for (int i = 0; i < 3; ++i) p8s_train16(J->tx, J->w1 + (size_t)J->row[i] * 40, J->nx, ((y << 12) - J->pr[i]) * 7);
+  }
+  int16_t* o = x + L->q.off;
+  int nx = 0;
+  J->tx[nx++] = 128;                    // m1.add(128)
+  o[70] = 128;
+  for (int i = 0; i < N; ++i) {
+    if (hbcount == 0) J->cp[i] = p8s_bh9_get(T, ops[2 + 2 * i] & J->mask, (uint16_t)ops[1 + 2 * i]) + 1;
+    else J->cp[i] += hbcount == 1 ? (uint32_t)(1 + hcl * 3) : (uint32_t)(1 + hcl);
+    uint16_t* m = J->sm + 256 * i;
+    m[J->smc[i]] = (uint16_t)(m[J->smc[i]] + (((y << 16) - m[J->smc[i]] + 128) >> 8));   // sm[i].p(*cp[i])
+    J->smc[i] = T[J->cp[i]];
+    const int p = m[J->smc[i]] >> 4;
+    const int sp = d->stretch[p];
+    o[2 * i] = (int16_t)((p - 2048) >> 2);
+    J->tx[nx++] = (int16_t)sp;
+    o[2 * i + 1] = (int16_t)sp;
+  }
+  J->started = 1;
+  // m1.p() :553-572: pad, the second layer learns, the three sets, the second layer
+  while (nx & 7) J->tx[nx++] = 0;
+  J->nx = nx;
+  if (J->live) p8s_train16(J->tx2, J->w2, 8, ((y << 12) - J->pr2) * 7);   // mp->update()
+  for (int i = 0; i < 8; ++i) J->tx2[i] = 0;
+  for (int i = 0; i < 3; ++i) {
+    J->row[i] = (int)ops[65 + i];
+    const int dp = p8s_dot16(J->tx, J->w1 + (size_t)J->row[i] * 40, nx);
+    const int dv = (int32_t)((uint32_t)dp * 9u) >> 9;
+    J->pr[i] = dv > 2047 ? 4095 : dv < -2047 ? 0 : squash[dv + 2048];
+    J->tx2[i] = d->stretch[J->pr[i]];
+    o[71 + i] = J->tx2[i];
+  }
+  {
+    const int z = p8s_dot16(J->tx2, J->w2, 8);
+    const int zz = z >> 9;
+    J->pr2 = zz > 2047 ? 4095 : zz < -2047 ? 0 : squash[zz + 2048];
+  }
+  J->live = 1;
+  int pr = J->pr2;
+  o[64] = d->stretch[pr]; o[65] = (int16_t)(pr - 2048);
+  {   // a1.p(pr, ctx, 1023), a2.p(pr, ctx, 1023): APM::p :699-711
+    uint32_t* tb[2] = {J->a1, J->a2};
+    int* cxs[2] = {&J->a1c, &J->a2c};
+    for (int k = 0; k < 2; ++k) {
+      uint32_t* t = tb[k];
+      int* cxt = cxs[k];
+      uint32_t p0 = t[*cxt];
+      const int n = p0 & 1023, q = p0 >> 10;
+      if (n < 1023) ++p0; else p0 = (p0 & 0xfffffc00u) | 1023u;
+      p0 += ((uint32_t)(((y << 22) - q) >> 3) * (uint32_t)(16384 / (n + n + 3))) & 0xfffffc00u;
+      t[*cxt] = p0;
+      int s = (d->stretch[pr] + 2048) * 23;
+      const int wt = s & 0xfff;
+      const int cx = (int)ops[68 + k] * 24 + (s >> 12);
+      *cxt = cx + (wt >> 11);
+      pr = (int)(((t[cx] >> 13) * (uint32_t)(4096 - wt) + (t[cx + 1] >> 13) * (uint32_t)wt) >> 19);
+      o[66 + 2 * k] = d->stretch[pr]; o[67 + 2 * k] = (int16_t)(pr - 2048);
+    }
   }
 }
 // P8L_PIC2: the second context's registers live in the fields a bit-history lane does not use (context = its cell, B = its StateMap context)

@@ -131,6 +131,15 @@ def bmp1_file(bits):
             bytes([0, 0, 0, 0, 255, 255, 255, 0]) + pix)
 
 
+def jpeg_file(img, **kw):
+    """a baseline JPEG of an [h, w, 3] (or [h, w]) image (Pillow's encoder: JFIF APP0, DQT, SOF0, DHT, SOS, entropy-coded data, EOI)"""
+    import io
+    from PIL import Image
+    b = io.BytesIO()
+    Image.fromarray(img).save(b, "JPEG", **kw)
+    return b.getvalue()
+
+
 def preprocessed(payload):
     """the stream the reference's preprocessor (preprocessor.cpp:568 Encode) hands the predictor for a file: block headers, detected
     types (HDR + IMAGE24 / IMAGE32 for a BMP), its transforms -- through oracle/_ref/libcmixref.so (oracle/ref_harness.cpp)"""
@@ -163,6 +172,10 @@ def image_streams():
         "bmp1_raw_2k": default_block(text[:100] + bmp1_file((photo(160, 80, 1, 14)[:, :, 0] > 120).astype(np.uint8)) + text[100:250]),
         # 4-bit images (im4bitModel :4675-4742, its 14 contexts on a HashTable<16>): a 16-colour BMP inside a DEFAULT block
         "bmp4_raw_3k": default_block(text[:100] + bmp4_file((photo(96, 56, 1, 15)[:, :, 0] >> 4).astype(np.uint8), np.random.default_rng(16).integers(0, 256, (16, 3))) + text[100:250]),
+        # baseline JPEG (jpegModel :5911-6597): a colour picture with 4:2:0 chroma as the preprocessor frames it (a JPEG block), and a grayscale one with
+        # restart markers every 2 MCU rows inside a DEFAULT block
+        "jpeg_5k": preprocessed(text[:200] + jpeg_file(photo(96, 80, 3, 17), quality=70) + text[200:400]),
+        "jpeg_rst_raw_3k": default_block(text[:100] + jpeg_file(photo(112, 64, 1, 18)[:, :, 0], quality=60, restart_marker_rows=2) + text[100:200]),
         # PCM audio (audio8bModel :5552-5657, wavModel :5659-5804, each followed by recordModel): WAV files as the preprocessor frames them
         "wav16s_6k": preprocessed(text[:200] + wav_file(1400, 2, 16, 9) + text[200:450]),
         "wav8s_4k": preprocessed(text[:150] + wav_file(1800, 2, 8, 10) + text[150:300]),

@@ -375,7 +375,8 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
       const P8LaneTabs tb = {XD->nex, XD->stretch};
       for (int l = XD->nlanes - 1; l >= 0; l--) {   // a map the step does not call is not touched and writes nothing: its positions may be another face's (im8bitModel: gray / palette)
         const uint32_t op = c.xops[t * P8_XL_NLANE + l];
-        if (XD->lane[l].q.kind == P8L_HT16) p8s_lane_ht16(&XD->lane[l], &tb, &c.xops[t * P8_XL_NLANE + l], y, (int)(t & 7), xr);
+        if (XD->lane[l].q.kind == P8L_JPG) p8s_lane_jpg(&XD->lane[l], &tb, XD->squash, &c.xops[t * P8_XL_NLANE + l], y, xr);
+        else if (XD->lane[l].q.kind == P8L_HT16) p8s_lane_ht16(&XD->lane[l], &tb, &c.xops[t * P8_XL_NLANE + l], y, (int)(t & 7), xr);
         else if (XD->lane[l].q.kind == P8L_PIC2) p8s_lane_pic2(&XD->lane[l], &tb, &XD->regs[l], op, c.xops[t * P8_XL_NLANE + l + 1], y, xr);
         else if (op & P8OP_MIX) p8s_lane_step_t(&XD->lane[l], &tb, &XD->regs[l], op, y, order[t], xr, P8_NX);
       }
@@ -391,11 +392,19 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
       const P8XLayout& X = L.xl[md - 1];
       nx = c.apm[t].c[8];
       const int skip = c.apm[t].c[7] ? X.opt_n : 0;   // the model's own ContextMap is silent this byte: its inputs are not there
-      for (int i = 0; i < nx; i++) xs[i] = xr[X.map[(skip && i >= X.opt_lo) ? i + skip : i]];
+      const int skp = c.apm[t].c[7] == 1 ? skip : 0;
+      for (int i = 0; i < nx; i++) xs[i] = xr[X.map[(skp && i >= X.opt_lo) ? i + skp : i]];
+      if (md == P8_MODEL_JPEG && c.apm[t].c[6]) xs[nx - 1] = (int16_t)c.apm[t].c[6];   // a stuffed / restart step's one constant input (jpegModel :6466, :6473)
     }
     else memcpy(xs, xr, P8_NX * 2);
     const int nsel = md ? (int)c.apm[t].c[9] : P8_NSEL;
     const float cf = (float)(1.0 / 4095);
+    int ne = nx;   // exported values in front of the second layer's: the inputs in order -- or, a coded JPEG step, through the model's export map
+    if (md && c.apm[t].c[7] == 2) {
+      const P8XLayout& X = L.xl[md - 1];
+      ne = X.exp_n;
+      for (int i = 0; i < ne; i++) Tl.out[i] = (float)p8s_squash(Tl.squash, xr[X.exp[i]]) * cf;
+    } else
     for (int i = 0; i < nx; i++) Tl.out[i] = (float)p8s_squash(Tl.squash, xs[i]) * cf;
     const int npad = (nx + 7) & ~7;
     int row[P8_NSEL], pr[P8_NSEL];
@@ -406,16 +415,16 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
       const int dsum = dot(xs, S.mix.wx + (size_t)row[i] * P8_NX, npad);
       pr[i] = p8s_squash(Tl.squash, (int32_t)((uint32_t)dsum * 9u) >> 9);
       st[i] = Tl.stretch[pr[i]];
-      Tl.out[nx + i] = (float)p8s_squash(Tl.squash, st[i]) * cf;
+      Tl.out[ne + i] = (float)p8s_squash(Tl.squash, st[i]) * cf;
     }
     const int p2 = p8s_squash(Tl.squash, dot(st, S.mix.wx2, 32) >> 9);
     int res[8];
     int fin;
-    if (c.apm[t].text >= P8_APM_COLOR) fin = p8s_tail_image(&Tl, &c.apm[t], y, p2, Tl.out + nx + nsel);
+    if (c.apm[t].text >= P8_APM_COLOR) fin = p8s_tail_image(&Tl, &c.apm[t], y, p2, Tl.out + ne + nsel);
     else {
       for (int j = 3; j >= 0; j--) p8s_tail_a(&Tl, &c.apm[t], y, p2, j, res);
       for (int j = 2; j >= 0; j--) p8s_tail_b(&Tl, &c.apm[t], y, p2, j, res);
-      fin = p8s_tail_c(&c.apm[t], p2, res, Tl.out + nx + nsel);
+      fin = p8s_tail_c(&c.apm[t], p2, res, Tl.out + ne + nsel);
     }
     Tl.pr = fin;
     memcpy(orow, Tl.out, sizeof Tl.out);
