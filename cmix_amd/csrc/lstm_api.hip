@@ -24,6 +24,7 @@
 extern "C" __global__ void cmx_lstm_prep(const LstmState, const float*, const uint8_t*, size_t, int, int);
 extern "C" __global__ void cmx_lstm_bptt_acc(const LstmState, int, int);
 extern "C" __global__ void cmx_lstm_bptt_gb(const LstmState, int, int);
+extern "C" __global__ void cmx_lstm_bptt_acc_mfma(const LstmState, int, int);
 extern "C" __global__ void cmx_lstm_fwdblk(const LstmState, const uint8_t*, const float*, float*, size_t, int, int, int);
 extern "C" __global__ void cmx_lstm_bpttblk(const LstmState);
 extern "C" __global__ void cmx_bytemodel_bits(const float*, const float*, const uint8_t*, size_t, float*, int*, size_t, int,
@@ -44,6 +45,7 @@ struct cmx_lstm {
   int hc = 0;                // which hid[] / stateb[] buffer holds the current hidden_ / state_
   size_t fb_lds = 0, bp_lds = 0;   // dynamic LDS of the block kernels (lstm_block.hip)
   uint64_t bptt_rounds = 0;  // LstmLayer::update_steps_ = min(rounds, 3000) (lstm-layer.cpp:131-133)
+  bool tolerance = false;    // cmx_lstm_set_tolerance: the weight-update contraction on the matrix cores (NOT bit-exact)
 };
 
 
@@ -237,7 +239,8 @@ int cmx_lstm_run(cmx_lstm_t* h, const float* d_in_probs, const uint8_t* d_bytes,
       hipLaunchKernelGGL(cmx_lstm_prep, dim3(1), dim3(256), 0, st, S, d_in_probs + n * 256, d_bytes, n, e, -1);
       if (!sync_reset()) { cmx_set_err("cmx_lstm_run: hipMemsetAsync failed"); return 1; }
       hipLaunchKernelGGL(cmx_lstm_bpttblk, dim3(LSTM_BP_G), dim3(LSTM_BP_THREADS), h->bp_lds, st, S);
-      hipLaunchKernelGGL(cmx_lstm_bptt_acc, dim3((S.rowlen[1] + 63) / 64, LSTM_C / 4, 6), dim3(64, 4), 0, st, S, us, -1);
+      if (h->tolerance) hipLaunchKernelGGL(cmx_lstm_bptt_acc_mfma, dim3((S.rowlen[1] + 15) / 16, (LSTM_C + 15) / 16, 6), dim3(64), 0, st, S, us, -1);
+      else hipLaunchKernelGGL(cmx_lstm_bptt_acc, dim3((S.rowlen[1] + 63) / 64, LSTM_C / 4, 6), dim3(64, 4), 0, st, S, us, -1);
       hipLaunchKernelGGL(cmx_lstm_bptt_gb, dim3(6), dim3(256), 0, st, S, us, -1);
     }
     const size_t left = nbytes - n;
@@ -260,6 +263,13 @@ int cmx_lstm_run(cmx_lstm_t* h, const float* d_in_probs, const uint8_t* d_bytes,
 }
 
 // 1 = a bounded in-launch wait of a block kernel ran out (the stream's LSTM results are void); synchronises the device
+/* TOLERANCE mode of the stage (NOT bit-exact; measurement only -- no file-writing tool turns it on): the BPTT round's weight-update
+ * contraction runs as v_mfma_f32_16x16x4_f32 tiles (cmx_lstm_bptt_acc_mfma) instead of the reference's ordered, separately rounded chain */
+int cmx_lstm_set_tolerance(cmx_lstm_t* h, int on) {
+  if (!h) { cmx_set_err("cmx_lstm_set_tolerance: null handle"); return 1; }
+  h->tolerance = on != 0;
+  return 0;
+}
 int cmx_lstm_failed(cmx_lstm_t* h) {
   if (!h) return 1;
   (void)hipSetDevice(h->device);

@@ -103,6 +103,58 @@ extern "C" __global__ void cmx_lstm_bptt_acc(const LstmState P, int update_steps
   S->WT[layer][g][lstm_wt_index(V, insz, c, i)] = w;
 }
 
+// ---- the same sweep in TOLERANCE mode (cmx_lstm_set_tolerance; NOT bit-exact): the dense part of update_[i][c] = sum over the 100 epochs of
+//      error_[e][i] * layer_input[e][c] is a 200 x rowlen x 100 matrix product per gate -- here on the matrix cores, v_mfma_f32_16x16x4_f32
+//      (f32 in, f32 accumulate: the products are fused into the running sum and the epochs are summed upwards, four at a time, instead of the
+//      reference's separately rounded fmul + fadd from epoch 99 down; lstm-layer.cpp:182-186). One wavefront per 16 x 16 tile of the weight matrix:
+//      lane l feeds A[i0 + (l & 15)][e0 + (l >> 4)] = error_ and B[e0 + (l >> 4)][c0 + (l & 15)] = the input; its four accumulators are rows
+//      i0 + 4 (l >> 4) + r of column c0 + (l & 15). The one-hot part (c < V) keeps the reference's order; Adam is the strict kernel's.
+//      grid (ceil(rowlen / 16), ceil(200 / 16), 6), block 64.
+extern "C" __global__ __launch_bounds__(64) void cmx_lstm_bptt_acc_mfma(const LstmState P, int update_steps, int k) {
+  const LstmState* S = &P;
+  if (k >= 0) update_steps = P.blk->us;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int layer = blockIdx.z / 3, g = blockIdx.z % 3;
+  const int V = S->V, rl = S->rowlen[layer], insz = S->insz[layer];
+  const int lane = threadIdx.x, c0 = blockIdx.x * 16, i0 = blockIdx.y * 16;
+  const int am = i0 + (lane & 15), bn = c0 + (lane & 15), kk = lane >> 4;
+  const float* E = S->E[layer][g];
+  const float* LI = S->layer_input[layer];
+  const bool aval = am < C, bval = bn >= V && bn < rl;
+  f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+  for (int e0 = 0; e0 < H; e0 += 4) {
+    const int e = e0 + kk;
+    const float a = (aval && e < H) ? E[(size_t)e * C + am] : 0.0f;
+    const float b = (bval && e < H) ? LI[(size_t)e * insz + (bn - V)] : 0.0f;
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+  }
+  const int c = bn;
+  if (c >= rl) return;
+  const float* tab = S->adam_tab + 4 * update_steps;
+  const float alpha = tab[0], b1 = tab[1], b2 = tab[2];
+  const float beta1 = 0.025f, beta2 = 0.9999f, eps = 1e-6f;
+  for (int r = 0; r < 4; ++r) {
+    const int i = i0 + 4 * kk + r;
+    if (i >= C) continue;
+    float a_ = acc[r];
+    if (c < V) {
+      a_ = 0.0f;
+      for (int e = H - 1; e >= 0; --e) if (S->bp_symbol[e] == (unsigned)c) a_ = fadd(a_, E[(size_t)e * C + i]);
+    }
+    const size_t ix = (size_t)i * rl + c;
+    float m = S->M[layer][g][ix], v = S->Vv[layer][g][ix], w = S->W[layer][g][ix];
+    m = fmul(m, beta1);
+    m = fadd(m, fmul(fsub(1.0f, beta1), a_));
+    v = fmul(v, beta2);
+    v = fadd(v, fmul(fmul(fsub(1.0f, beta2), a_), a_));
+    w = fsub(w, fmul(alpha, fdiv(fdiv(m, b1), fsqrt(fadd(fdiv(v, b2), eps)))));
+    S->M[layer][g][ix] = m;
+    S->Vv[layer][g][ix] = v;
+    S->W[layer][g][ix] = w;
+    S->WT[layer][g][lstm_wt_index(V, insz, c, i)] = w;
+  }
+}
+
 // ---- Adam for gamma / beta (lstm-layer.cpp:191-195); grid 6 blocks of 256
 extern "C" __global__ void cmx_lstm_bptt_gb(const LstmState P, int update_steps, int k) {
   const LstmState* S = &P;

@@ -435,6 +435,7 @@ int cmx_pipeline_enable_paq8(cmx_pipeline_t* h) {
 int cmx_pipeline_set_tolerance(cmx_pipeline_t* h, int on) {
   if (!h) { cmx_set_err("cmx_pipeline_set_tolerance: null handle"); return 1; }
   if (h->chunks || h->late) { cmx_set_err("cmx_pipeline_set_tolerance: only before the first chunk"); return 1; }
+  if (cmx_lstm_set_tolerance(h->lstm, on)) return 1;   // the LSTM's weight-update contraction on the matrix cores
   return cmx_mixnet_set_tolerance(h->mix, on);
 }
 int cmx_pipeline_mixnet_mode(cmx_pipeline_t* h) { return h ? cmx_mixnet_mode(h->mix) : -1; }

@@ -71,6 +71,7 @@ def lib():
         L.cmx_lstm_create.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.cmx_lstm_destroy.argtypes = [C.c_void_p]
         L.cmx_lstm_vocab_size.argtypes = [C.c_void_p]
+        L.cmx_lstm_set_tolerance.argtypes = [C.c_void_p, C.c_int]
         L.cmx_lstm_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                    C.c_size_t, C.c_void_p, C.c_void_p]
         L.cmx_bytemodel_bits_run.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
@@ -281,6 +282,11 @@ class Lstm:
         if not self.h:
             raise CmxError(last_error())
         self.V = lib().cmx_lstm_vocab_size(self.h)
+
+    def set_tolerance(self, on=True):
+        """TOLERANCE mode (NOT bit-exact): the BPTT round's weight-update contraction as v_mfma_f32_16x16x4_f32 tiles"""
+        if lib().cmx_lstm_set_tolerance(self.h, 1 if on else 0):
+            raise CmxError(last_error())
 
     def close(self):
         if getattr(self, "h", None):

@@ -200,6 +200,9 @@ int cmx_lstm_gate_rowlen(const cmx_lstm_t*, int layer);
 /* 1 if a bounded in-launch wait of the multi-workgroup kernels (lstm_block.hip) ran out -- the stream's LSTM output
  * is void from that point --, 0 otherwise. Synchronises the device. */
 int cmx_lstm_failed(cmx_lstm_t*);
+/* TOLERANCE mode (NOT bit-exact, measurement only): the BPTT round's weight-update contraction (200 x rowlen x 100 per gate,
+ * reference src/mixer/lstm-layer.cpp:182-186) as v_mfma_f32_16x16x4_f32 tiles instead of the ordered, separately rounded chain */
+int cmx_lstm_set_tolerance(cmx_lstm_t*, int on);
 /* DEVICE address of the sticky flag cmx_lstm_failed reads (4 bytes): copy it back in stream order behind the stage's
  * kernels to learn of a timed-out hand-off without synchronising the device. */
 const unsigned* cmx_lstm_fail_flag(cmx_lstm_t*);

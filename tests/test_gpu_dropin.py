@@ -319,6 +319,33 @@ def test_dropin_engine_file_with_a_16bit_stereo_wav_is_byte_identical():
     assert _run("-c", [("in", payload)], exe=DROPIN, timeout=600) == blob
 
 
+def test_dropin_engine_file_with_a_jpeg_is_byte_identical():
+    """text + a 128 x 96 4:2:0 baseline JPEG + text (tests/golden/make_dropin_jpeg.py): the reference's detector makes a JPEG block of the picture; paq8's
+    jpegModel (marker parser + Huffman decoder on the host, its tables / own mixer / APM stages on the device) codes it. The reference binary's file."""
+    if not os.path.exists(DROPIN):
+        _missing("oracle/_ref/cmix_dropin not built")
+    fx = os.path.join(GOLDEN, "dropin_jpeg.npz")
+    if not os.path.exists(fx):
+        _missing("tests/golden/dropin_jpeg.npz missing (make_dropin_jpeg.py)")
+    with np.load(fx) as z:
+        payload, blob = z["payload"].tobytes(), z["cmix_file"].tobytes()
+    assert _run("-c", [("in", payload)], exe=DROPIN, timeout=600) == blob
+
+
+def test_dropin_decoding_a_file_with_an_image_fails_loudly():
+    """The decoder's form of the image / audio / JPEG models is not built: `cmix_dropin -d` on the BMP fixture must stop with the stage's message and a
+    non-zero exit code -- never write different bytes. (The unmodified reference binary decodes these files: they are its own, byte for byte.)"""
+    if not os.path.exists(DROPIN):
+        _missing("oracle/_ref/cmix_dropin not built")
+    with np.load(os.path.join(GOLDEN, "dropin_bmp.npz")) as z:
+        blob = z["cmix_file"].tobytes()
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "in"), "wb").write(blob)
+        r = subprocess.run([DROPIN, "-d", os.path.join(d, "in"), os.path.join(d, "out")], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "decoder" in (r.stderr + r.stdout)
+
+
 # ---- DECOMPRESSION with the whole engine: `cmix_dropin -d` = the reference's runner.cpp + decoder.cpp + preprocessor, no model ----
 # Decoder::Decode (decoder.cpp:20-39) calls Predict() and only then knows the bit it hands to Perceive(): the library's late-bit
 # protocol (cmix_amd/csrc/cmx_late.h) -- every stage kernel of the chunk pipeline, fxcm and paq8 included, waiting for the bits

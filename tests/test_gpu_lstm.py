@@ -67,6 +67,37 @@ def test_golden_ragged_chunks_across_bptt_boundary():
     _check_golden("text_2k_nofull", nbytes=230, chunks=[1, 2, 99, 100, 101, 199, 205])
 
 
+def test_tolerance_mode_mfma_weight_update_deviation():
+    """TOLERANCE mode (cmx_lstm_set_tolerance; NOT bit-exact): the BPTT round's weight-update contraction -- per gate a 200 x rowlen x 100 product of
+    the round's error signals and layer inputs (lstm-layer.cpp:182-186) -- as v_mfma_f32_16x16x4_f32 tiles (fused products, the epochs summed
+    upwards) instead of the reference's ordered chain of separately rounded operations. Measured on the MI355X after five rounds (profiles/r04_lstm_mfma_tolerance.txt):
+    max |dp| = 2.1e-6 over the 256-way output distributions, 5.8e-6 relative on the gate weights (Adam divides the deviating sums by the square root of
+    their own second moment: a last-place difference of an f32 sum becomes a few 1e-6 of a weight) -- north_star's 1e-6 is NOT met on the weights, and the
+    test says so with the bounds that do hold: 1e-5 on the distributions, 2e-5 on the weights. Strict mode is untouched."""
+    import torch
+    from cmix_amd import engine as E
+    g = load_golden("text_2k_nofull")
+    N = 450   # BPTT + Adam at bytes 0, 100, 200, 300, 400
+    res, wts = [], []
+    for tol in (False, True):
+        l = E.Lstm(g["vocab"], 0)
+        if tol:
+            l.set_tolerance(True)
+        d_in = torch.from_numpy(np.ascontiguousarray(g["ppmd_probs"][1:N + 1], np.float32)).cuda()
+        d_b = torch.from_numpy(np.ascontiguousarray(g["stream"][:N], np.uint8)).cuda()
+        o, _, _ = l.run(d_in, d_b)
+        torch.cuda.synchronize()
+        res.append(o.cpu().numpy())
+        wts.append([l.gate_weights(layer, gate).copy() for layer in range(2) for gate in range(3)])
+        l.close()
+    dp = float(np.abs(res[0].astype(np.float64) - res[1]).max())
+    dw = max(float(np.abs(a.astype(np.float64) - b).max() / np.abs(a).max()) for a, b in zip(*wts))
+    same = float((res[0].view(np.uint32) == res[1].view(np.uint32)).mean())
+    print("LSTM tolerance mode after 5 BPTT rounds: max |dp| = %.3g over the 256-way distributions (%.1f %% of the values bit-identical), max relative gate-weight deviation %.3g" % (dp, 100 * same, dw))
+    assert bits_equal(res[0][:100], res[1][:100]).all()   # the first update lands after byte 100's round: before it nothing differs
+    assert 0 < dw < 2e-5 and dp < 1e-5
+
+
 def test_small_vocabulary_vs_oracle():
     """V = 3 (ragged rows, tiny softmax) and a vocabulary-complete random distribution stream."""
     from oracle import oracle as O
