@@ -39,6 +39,8 @@ enum {
   P8L_PIC,       /* picModel :3844-3864, im1bitModel :4634-4673: a bit-history byte per context + a u16 StateMap (limit: with P8OP_ZERO on the map whose
                   * range holds cell 0 (a == 0), the extra updates of that cell at the model's first call -- every context still sits on it; 0 = picModel's 2) */
   P8L_DIRECT,    /* an input the host front end computes itself (run maps, match lengths, constants): op = the value */
+  P8L_RCM,       /* RunContextMap :857-889 over BH<4> :778-813: the byte that followed a hashed context last time and how often in a row; the op word of a
+                  * byte's first step carries P8OP_SET | checksum << 8 | the byte just coded, the next lane's (a P8L_NONE placeholder) the item index; one input */
   P8L_HT16,      /* im4bitModel's 14 contexts on its HashTable<16> (:828-856, :4675-4742): ONE lane walks them in the reference's order -- items are found and
                   * replaced by priority, two contexts may come to share one --; a bit history per context and nibble position, a u16 StateMap each; the 14
                   * hashed contexts of a nibble (checksum << 22 | item index) are the raw op words of the 14 P8L_NONE lanes behind it; 42 inputs */

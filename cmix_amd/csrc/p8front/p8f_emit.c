@@ -1,7 +1,6 @@
 /* p8f_emit.c -- recording implementation of the table interface (p8f_emit.h) + the helpers the sub-models share:
- * hash functions (reference src/models/paq8.cpp:714-776), ilog (:253-266), squash / stretch tables, and the
- * RunContextMap over BH<4> (:778-889), which is kept whole on the host: its prediction is a pure function of the bytes
- * that followed a context (run byte + run length), it never sees a coded probability. */
+ * hash functions (reference src/models/paq8.cpp:714-776), ilog (:253-266), squash / stretch tables, and the recorders of
+ * the tables that are walked by one lane on the device (RunContextMap over BH<4> :778-889, im4bitModel's HashTable<16>, jpegModel's BH<9>). */
 #include "p8f_emit.h"
 
 #include <stdio.h>
@@ -494,7 +493,7 @@ int p8f_emit_finish_discovery(P8Emit* e, int nx_first, int nx_full) {
   if (nd != nd0) { fail("host-computed inputs differ between the first byte and later ones"); return 1; }
   for (int l = 0; l < L->nlanes; ++l) {
     const P8Lane* q = &L->lane[l];
-    if (q->kind == P8L_DIRECT) continue;
+    if (q->kind == P8L_DIRECT || q->kind == P8L_NONE) continue;   /* (NONE: a lane that only carries another lane's second op word) */
     if (q->off < 0) { fail("a small map was never called"); return 1; }
     for (int j = 0; j < q->nout; ++j) L->first_map[e->lane_off0[l] + j] = (int16_t)(q->off + j);
   }
@@ -520,53 +519,28 @@ void p8f_emit_directs(P8Emit* e, int lim_off) {
   }
 }
 
-/* ---- BH<4> (:778-813) and RunContextMap (:857-889): whole, on the host ---- */
-typedef struct RCM { uint8_t* t; uint32_t mask; int hashbits; uint32_t cp; } RCM;
-static uint32_t bh4_get(RCM* r, uint64_t ctx) {
-  enum { Bsz = 4, Mlim = 8 };
-  const uint16_t chk = (uint16_t)(p8f_checksum64(ctx, r->hashbits, 16) & 0xffff);
-  const uint32_t i = (p8f_finalize64(ctx, r->hashbits) * Mlim) & r->mask;
-  uint8_t* t = r->t;
-  int j;
-  uint32_t p = 0;
-  for (j = 0; j < Mlim; ++j) {
-    p = (i + j) * Bsz;
-    uint16_t cur;
-    memcpy(&cur, t + p, 2);
-    if (t[p + 2] == 0) { memcpy(t + p, &chk, 2); break; }
-    if (cur == chk) break;
-  }
-  if (j == 0) return p + 1;
-  uint8_t tmp[Bsz];
-  if (j == Mlim) {
-    --j;
-    memset(tmp, 0, Bsz);
-    memcpy(tmp, &chk, 2);
-    if (Mlim > 2 && t[(i + j) * Bsz + 2] > t[(i + j - 1) * Bsz + 2]) --j;
-  } else memcpy(tmp, t + p, Bsz);
-  memmove(t + (i + 1) * Bsz, t + i * Bsz, (size_t)j * Bsz);
-  memcpy(t + i * Bsz, tmp, Bsz);
-  return i * Bsz + 1;
-}
+/* ---- RunContextMap (:857-889) over BH<4> (:778-813): the table is the device's (P8L_RCM); the front end hands it the hashed context per byte ---- */
+typedef struct RCM { int lane, lane2, hashbits, pending; uint32_t chk, item, c1; } RCM;
 RCM* p8f_rcm_new(int m) {
   ilog_init();
   RCM* r = (RCM*)calloc(1, sizeof *r);
-  const int n = m / 4;
-  r->t = (uint8_t*)calloc((size_t)n * 4 + 64, 1);
-  r->mask = (uint32_t)(n - 1);
-  r->hashbits = (int)ilog2u(r->mask + 1);
-  r->cp = bh4_get(r, 0) + 1;
+  r->hashbits = (int)ilog2u((unsigned)(m / 4));
+  r->lane = new_lane(P8L_RCM, (uint32_t)m, 0);
+  r->lane2 = new_lane(P8L_NONE, 0, 0);
   return r;
 }
-void p8f_rcm_free(RCM* r) { if (r) { free(r->t); free(r); } }
-void p8f_rcm_set(RCM* r, uint64_t cx, int c1) {
-  uint8_t* cp = r->t + r->cp;
-  if (cp[0] == 0 || cp[1] != c1) { cp[0] = 1; cp[1] = (uint8_t)c1; }
-  else if (cp[0] < 255) ++cp[0];
-  r->cp = bh4_get(r, cx) + 1;
+void p8f_rcm_free(RCM* r) { free(r); }
+void p8f_rcm_set(RCM* r, uint64_t cx, int c1) {   /* set(cx) :866-872 happens on the device at the byte's first step, with the byte just coded */
+  r->chk = (uint32_t)(p8f_checksum64(cx, r->hashbits, 16) & 0xffff);
+  r->item = (uint32_t)(((uint64_t)p8f_finalize64(cx, r->hashbits) * 8) & (((uint64_t)1 << r->hashbits) - 1));
+  r->c1 = (uint32_t)c1 & 0xff;
+  r->pending = 1;
 }
 int p8f_rcm_mix(RCM* r, int bpos, int c0, int16_t* out) {
-  const uint8_t* cp = r->t + r->cp;
-  out[0] = (int16_t)(((cp[1] + 256) >> (8 - bpos)) == c0 ? (((cp[1] >> (7 - bpos)) & 1) * 2 - 1) * p8f_ilog(cp[0] + 1) * 8 : 0);
-  return cp[0] != 0;
+  (void)bpos; (void)c0;
+  lane_out(0, r->lane, out, 1, 0, 1, 1, 0, 0);
+  put_op(0, r->lane, P8OP_MIX | (r->pending ? P8OP_SET | (r->chk << 8) | r->c1 : 0));
+  put_op(0, r->lane2, r->item);
+  r->pending = 0;
+  return 0;
 }

@@ -3,8 +3,9 @@
  * src/models/paq8.cpp:891-1358); here they only RECORD what the tables are asked -- hashed contexts per byte, one op
  * word per small map and step -- into the chunk records of ../p8_rec.h, which the device kernels (../p8stage.hip)
  * consume. The sub-models themselves (p8f_word.c, p8f_text.c, ...) compute everything that depends on the byte stream
- * alone; nothing in this directory holds a learned table except the three RunContextMaps (byte-run bookkeeping, no
- * dependence on coded predictions). */
+ * alone; nothing in this directory holds a learned table (the three RunContextMaps moved to the device in round 4: P8L_RCM). What it does
+ * hold is arithmetic on the bytes themselves: the least-squares predictors of the image / audio models (f64, wavModel's in long double),
+ * the JPEG parser and Huffman decoder. */
 #ifndef CMX_P8F_EMIT_H
 #define CMX_P8F_EMIT_H
 #include <stddef.h>

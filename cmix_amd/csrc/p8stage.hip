@@ -286,10 +286,12 @@ __global__ __launch_bounds__(P8LANES_THREADS) void cmx_p8s_lanes_kernel(P8LanesD
   if (l >= P8_NLANE) return;
   P8LaneRegs r = d->regs[l];
   const int last_y = d->last_y;
+  int c0 = 1;   // the partial byte (chunks are whole bytes; a stream's first step is bit 1 of byte 0: c0 = 1 as well)
   for (int t = t0; t < nbits; t++) {
     const int y = t ? bits[t - 1] : last_y;
     const int md = model ? model[t >> 3] : 0;
-    if (l < d->nlanes) p8s_lane_step(d, &r, l, ops[(size_t)t * P8_NLANE + l], y, order[t], x + (size_t)t * P8_NX, md);
+    c0 = (t & 7) ? c0 * 2 + y : 1;
+    if (l < d->nlanes) p8s_glane_step(d, &r, l, ops + (size_t)t * P8_NLANE + l, y, order[t], t & 7, c0, x + (size_t)t * P8_NX, md);
   }
   d->regs[l] = r;
   if (l == 0) d->last_y = bits[nbits - 1];
@@ -318,12 +320,14 @@ __global__ __launch_bounds__(P8LANES_THREADS) void cmx_p8s_lanes_late_kernel(P8L
   const int ln = threadIdx.x & 63, l = ln < 8 ? 8 * (int)(threadIdx.x >> 6) + ln : P8_NLANE;
   const bool act = l < P8_NLANE;
   P8LaneRegs r = d->regs[act ? l : 0];
+  int c0 = 1;
   for (int t = 0; t < nbits; t++) {
     if (threadIdx.x == 0) late_y_s = late_y(B, t);
     __syncthreads();
     const int y = late_y_s;
     if (y < 0) return;
     __syncthreads();
+    c0 = (t & 7) ? c0 * 2 + y : 1;
     if (t >= t0 && act && l < d->nlanes) {
       const uint32_t op = *(volatile const uint32_t*)(ops + (size_t)t * P8_NLANE + l);
       int ord = 0;
@@ -331,7 +335,8 @@ __global__ __launch_bounds__(P8LANES_THREADS) void cmx_p8s_lanes_late_kernel(P8L
         if (!late_wait_cnt(B, LC_CM2_0, (uint32_t)(t + 1))) ord = 0;
         else ord = (int)*(volatile const uint8_t*)(order + t);
       }
-      p8s_lane_step(d, &r, l, op, y, ord, x + (size_t)t * P8_NX);
+      const uint32_t op2[2] = {op, l + 1 < P8_NLANE ? *(volatile const uint32_t*)(ops + (size_t)t * P8_NLANE + l + 1) : 0u};
+      p8s_glane_step(d, &r, l, op2, y, ord, t & 7, c0, x + (size_t)t * P8_NX, 0);
     }
     __syncthreads();
     if (threadIdx.x == 0) late_publish(B, LC_LANES, (uint32_t)(t + 1));
@@ -1082,7 +1087,7 @@ __global__ __launch_bounds__(P8_XL_NLANE) void cmx_p8s_xlanes_kernel(P8XLanesDev
   const int l = threadIdx.x;
   if (l >= d->nlanes) return;
   P8LaneRegs r = d->regs[l];
-  const P8LaneTabs tb = {d->nex, d->stretch};
+  const P8LaneTabs tb = {d->nex, d->stretch, nullptr};
   const int mine = d->model;
   for (int t = t0; t < nbits; t++) {
     if (model[t >> 3] != mine) continue;

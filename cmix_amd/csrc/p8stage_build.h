@@ -91,6 +91,7 @@ bool build_stage(P8StageState& S, Policy& P, const P8Layout& L, int level, const
   D.nlanes = L.nlanes;
   D.nex = (const uint8_t*)up(nex1024, 1024);
   D.stretch = (const int16_t*)up(stretch4096, 4096 * 2);
+  D.ilog = S.fam.ilog;
   uint32_t prior[256];
   for (int i = 0; i < 256; i++) prior[i] = sm32_prior(nex1024, i);
   for (int l = 0; l < L.nlanes; l++) {
@@ -118,6 +119,11 @@ bool build_stage(P8StageState& S, Policy& P, const P8Layout& L, int level, const
         q.c32 = (uint32_t*)up(v.data(), n * 4);
         break;
       }
+      case P8L_RCM:   // RunContextMap(m): BH<4> t(m / 4); cp = t[0] + 1 :862
+        q.c8 = (uint8_t*)P.zalloc(n + 64);
+        q.mask = (uint32_t)(n / 4 - 1);
+        D.regs[l].cp = 2;
+        break;
       case P8L_PIC: {
         q.c8 = (uint8_t*)P.zalloc(n);
         uint16_t sm[256];

@@ -26,7 +26,7 @@ struct P8LanesDev {
   int nlanes;
   P8LaneDev lane[P8_NLANE];
   P8LaneRegs regs[P8_NLANE];   // home between chunks
-  const uint8_t* nex; const int16_t* stretch;
+  const uint8_t* nex; const int16_t* stretch; const uint8_t* ilog;
   int last_y;
 };
 
@@ -51,13 +51,13 @@ struct P8XLanesDev {
 // one lane, one step. x: the step's 1552-vector; order: the order-N map's return value of this step; lim_off: the first input
 // position that is NOT this table's at this step (a step of an image model ends the generic layout at the common prefix: a generic
 // lane behind it neither runs nor writes; P8_NX otherwise).
-struct P8LaneTabs { const uint8_t* nex; const int16_t* stretch; };
+struct P8LaneTabs { const uint8_t* nex; const int16_t* stretch; const uint8_t* ilog; };
 P8_HD void p8s_lane_step_t(const P8LaneDev* L, const P8LaneTabs* d, P8LaneRegs* r, uint32_t op, int y, int order, int16_t* x, int lim_off) {
   const int kind = L->q.kind;
   if (L->q.off >= lim_off) return;
   int16_t* o = x + L->q.off;
   if (kind == P8L_DIRECT) { if (op & P8OP_MIX) o[0] = (int16_t)(op & 0xffffu); return; }
-  if (kind == P8L_NONE) return;
+  if (kind == P8L_NONE || kind == P8L_RCM) return;   // (RCM: p8s_lane_rcm, which needs the step's partial byte)
   if (!(op & P8OP_MIX)) { for (int j = 0; j < L->q.nout; j++) o[j] = 0; return; }
   if (kind == P8L_SM32) {
     const int p = p8s_sm32(L->c32, &r->sm_cxt, y, (int)(op & P8OP_CTX), L->q.limit);
@@ -189,9 +189,10 @@ struct P8JpgDev {
   int nx, row[3], pr[3], pr2, live;     // live: a p() has happened (update() has something to learn from)
   uint32_t* a1; uint32_t* a2; int a1c, a2c;   // APM a1(0x8000), a2(0x20000)
 };
-// BH<9>::operator[] :788-813: the item of checksum chk in the neighbourhood starting at item i, moved to the front; returns its byte offset + 1
-P8_HD uint32_t p8s_bh9_get(uint8_t* t, uint32_t i, uint16_t chk) {
-  enum { B = 9, M = 8 };
+// BH<B>::operator[] :788-813: the item of checksum chk in the neighbourhood starting at item i, moved to the front; returns its byte offset + 1
+template <int B>
+P8_HD uint32_t p8s_bh_get(uint8_t* t, uint32_t i, uint16_t chk) {
+  enum { M = 8 };
   uint32_t p = 0;
   int j;
   for (j = 0; j < M; ++j) {
@@ -212,6 +213,20 @@ P8_HD uint32_t p8s_bh9_get(uint8_t* t, uint32_t i, uint16_t chk) {
   for (int k = 0; k < B; k++) t[i * B + (uint32_t)k] = tmp[k];
   return i * B + 1;
 }
+// P8L_RCM: RunContextMap::set (at a byte's first step) + mix :866-888. c0 / bpos: the partial byte and bit position of the step; op2: the next lane's word
+P8_HD void p8s_lane_rcm(const P8LaneDev* L, const P8LaneTabs* d, P8LaneRegs* r, uint32_t op, uint32_t op2, int bpos, int c0, int16_t* x) {
+  if (!(op & P8OP_MIX)) { x[L->q.off] = 0; return; }
+  uint8_t* T = L->c8;
+  if (op & P8OP_SET) {
+    const int c1 = (int)(op & 0xffu);
+    uint8_t* cp = T + r->cp;
+    if (cp[0] == 0 || cp[1] != c1) { cp[0] = 1; cp[1] = (uint8_t)c1; }
+    else if (cp[0] < 255) ++cp[0];
+    r->cp = p8s_bh_get<4>(T, op2 & L->mask, (uint16_t)((op >> 8) & 0xffffu)) + 1;
+  }
+  const uint8_t* cp = T + r->cp;
+  x[L->q.off] = (int16_t)(((cp[1] + 256) >> (8 - bpos)) == c0 ? (((cp[1] >> (7 - bpos)) & 1) * 2 - 1) * d->ilog[cp[0] + 1] * 8 : 0);
+}
 // one coded step. ops: the worker's op word, then the 64 + 5 raw words; x: the step's vector (inputs at off .. off + 69, exported-only values behind)
 P8_HD void p8s_lane_jpg(const P8LaneDev* L, const P8LaneTabs* d, const int16_t* squash, const uint32_t* ops, int y, int16_t* x) {
   enum { N = 32 };
@@ -228,7 +243,7 @@ P8_HD void p8s_lane_jpg(const P8LaneDev* L, const P8LaneTabs* d, const int16_t* 
   J->tx[nx++] = 128;                    // m1.add(128)
   o[70] = 128;
   for (int i = 0; i < N; ++i) {
-    if (hbcount == 0) J->cp[i] = p8s_bh9_get(T, ops[2 + 2 * i] & J->mask, (uint16_t)ops[1 + 2 * i]) + 1;
+    if (hbcount == 0) J->cp[i] = p8s_bh_get<9>(T, ops[2 + 2 * i] & J->mask, (uint16_t)ops[1 + 2 * i]) + 1;
     else J->cp[i] += hbcount == 1 ? (uint32_t)(1 + hcl * 3) : (uint32_t)(1 + hcl);
     uint16_t* m = J->sm + 256 * i;
     m[J->smc[i]] = (uint16_t)(m[J->smc[i]] + (((y << 16) - m[J->smc[i]] + 128) >> 8));   // sm[i].p(*cp[i])
@@ -299,9 +314,17 @@ P8_HD void p8s_lane_pic2(const P8LaneDev* L, const P8LaneTabs* d, P8LaneRegs* r,
   o[1] = d->stretch[m2[s2] >> 4];
 }
 P8_HD void p8s_lane_step(const P8LanesDev* d, P8LaneRegs* r, int l, uint32_t op, int y, int order, int16_t* x, int md = 0) {
-  const P8LaneTabs tb = {d->nex, d->stretch};
+  const P8LaneTabs tb = {d->nex, d->stretch, d->ilog};
   if (md && !((d->lane[l].q.modes >> md) & 1u)) return;
   p8s_lane_step_t(&d->lane[l], &tb, r, op, y, order, x, P8_NX);
+}
+// a lane of the GENERIC table at one step: ops = its op word (the next lane's follows), c0 / bpos = the step's partial byte / bit position
+P8_HD void p8s_glane_step(const P8LanesDev* d, P8LaneRegs* r, int l, const uint32_t* ops, int y, int order, int bpos, int c0, int16_t* x, int md) {
+  if (d->lane[l].q.kind == P8L_RCM) {
+    if (md && !((d->lane[l].q.modes >> md) & 1u)) return;
+    const P8LaneTabs tb = {d->nex, d->stretch, d->ilog};
+    p8s_lane_rcm(&d->lane[l], &tb, r, ops[0], ops[1], bpos, c0, x);
+  } else p8s_lane_step(d, r, l, ops[0], y, order, x, md);
 }
 
 // ---------------------------------------------------------------- tail of Predictor::update

@@ -350,7 +350,11 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
       }
     }
     if (g == 0) { memcpy(orow, S.tail.out, sizeof S.tail.out); continue; }   // no step 0: the constructor's 0.5
-    for (int l = S.lanes.nlanes - 1; l >= 0; l--) p8s_lane_step(&S.lanes, &S.lanes.regs[l], l, c.ops[t * P8_NLANE + l], y, order[t], xr, md);
+    {
+      int c0g = 1;
+      for (int j = 0; j < (int)(t & 7); j++) c0g = c0g * 2 + bits[t - (t & 7) + j];
+      for (int l = S.lanes.nlanes - 1; l >= 0; l--) p8s_glane_step(&S.lanes, &S.lanes.regs[l], l, &c.ops[t * P8_NLANE + l], y, order[t], (int)(t & 7), c0g, xr, md);
+    }
     if (!md) {
       for (int tid = P8DMC_THREADS - 1; tid >= 0; tid--) p8d_dmc_step1(&S.dmc, &e->dsh, tid, y);
       for (int tid = P8DMC_THREADS - 1; tid >= 0; tid--) p8d_dmc_step2(&S.dmc, &e->dsh, tid, (int)(g & 7), xr + L.dmc_off);
@@ -372,7 +376,7 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
       for (int sl = a1 - 1; sl >= a0; sl--) p8d_cm_draw(xd, xs, sl);
       for (int sl = a1 - 1; sl >= a0; sl--) p8d_cm_run(xd, xs, u, sl);
       P8XLanesDev* XD = &S.xlanes[md - 1];
-      const P8LaneTabs tb = {XD->nex, XD->stretch};
+      const P8LaneTabs tb = {XD->nex, XD->stretch, nullptr};
       for (int l = XD->nlanes - 1; l >= 0; l--) {   // a map the step does not call is not touched and writes nothing: its positions may be another face's (im8bitModel: gray / palette)
         const uint32_t op = c.xops[t * P8_XL_NLANE + l];
         if (XD->lane[l].q.kind == P8L_JPG) p8s_lane_jpg(&XD->lane[l], &tb, XD->squash, &c.xops[t * P8_XL_NLANE + l], y, xr);
