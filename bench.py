@@ -325,7 +325,9 @@ def main():
             "end_to_end": {"value": a.payload_bytes * world / (dt + t_construct), "unit": "input bytes/s", "construct_s": t_construct,
                            "note": "payload bytes / (framing + engine construction: ~20 GB of tables allocated and initialised + the timed run incl. the coder); "
                                    "`value` above is the predictor-only figure of SURVEY.md 8d (stream bytes / the Compress() loop)"},
-            "mfma": {"instructions": 0, "note": "strict mode: every dot product on the path is an ordered chain of separately rounded f32 (or wrapping int16-pair) operations; an MFMA "
+            "mfma": {"instructions": None, "note": "tolerance mode: the LSTM's weight-update contraction runs as v_mfma_f32_16x16x4_f32 tiles (113 100 SQ_INSTS_VALU_MFMA_F32 per BPTT round, "
+                                                   "profiles/r04_lstm_mfma_tolerance.txt); nothing else on the path issues one"} if mode_name == "tolerance" else
+                    {"instructions": 0, "note": "strict mode: every dot product on the path is an ordered chain of separately rounded f32 (or wrapping int16-pair) operations; an MFMA "
                                                 "step fuses the multiply-add and fixes a blocked K order, so no kernel of the product issues one (SQ_INSTS_VALU_MFMA_* = 0)"},
             "stage_us_per_bit": dict(us, note="mean HIP-event time per bit of each stage's kernel(s) over the timed run; the stages overlap on their own streams, "
                                               "so the stream's period is the slowest one (paq8 = its slowest role kernel)"),

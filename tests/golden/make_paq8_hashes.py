@@ -176,6 +176,10 @@ def image_streams():
         # restart markers every 2 MCU rows inside a DEFAULT block
         "jpeg_5k": preprocessed(text[:200] + jpeg_file(photo(96, 80, 3, 17), quality=70) + text[200:400]),
         "jpeg_rst_raw_3k": default_block(text[:100] + jpeg_file(photo(112, 64, 1, 18)[:, :, 0], quality=60, restart_marker_rows=2) + text[100:200]),
+        # everything in one file, as the preprocessor frames it: text, a 24-bit BMP (IMAGE24 block), a WAV (paq8's own detector), a JPEG (JPEG block), a PGM
+        # (IMAGE8GRAY block), text -- every switch between the generic models and a model with tables of its own, in chunks that cut anywhere
+        "mixed_media_12k": preprocessed(text[:150] + bmp_file(photo(48, 32, 3, 41)) + text[150:220] + wav_file(500, 2, 16, 42) + text[220:300] +
+                                        jpeg_file(photo(64, 48, 3, 43), quality=60) + text[300:360] + b"P5\n48 40\n255\n" + photo(48, 40, 1, 44)[:, :, 0].tobytes() + text[360:500]),
         # PCM audio (audio8bModel :5552-5657, wavModel :5659-5804, each followed by recordModel): WAV files as the preprocessor frames them
         "wav16s_6k": preprocessed(text[:200] + wav_file(1400, 2, 16, 9) + text[200:450]),
         "wav8s_4k": preprocessed(text[:150] + wav_file(1800, 2, 8, 10) + text[150:300]),
