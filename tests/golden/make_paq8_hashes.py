@@ -140,6 +140,25 @@ def jpeg_file(img, **kw):
     return b.getvalue()
 
 
+def tga_file(img, kind):
+    """uncompressed TGA: kind 2 = true colour ([h, w, 3] or [h, w, 4]), 3 = grayscale ([h, w]), 1 = colour-mapped ([h, w] indices + a 256-entry 24-bit map)"""
+    h, w = img.shape[:2]
+    if kind == 1:
+        cmap = np.random.default_rng(5).integers(0, 256, (256, 3), dtype=np.uint8).tobytes()
+        hdr = bytes([0, 1, 1, 0, 0, 0, 1, 24]) + bytes(4) + w.to_bytes(2, "little") + h.to_bytes(2, "little") + bytes([8, 0])
+        return hdr + cmap + img.tobytes()
+    bpp = 8 if kind == 3 else 8 * img.shape[2]
+    hdr = bytes([0, 0, kind, 0, 0, 0, 0, 0]) + bytes(4) + w.to_bytes(2, "little") + h.to_bytes(2, "little") + bytes([bpp, 8 if bpp == 32 else 0])
+    return hdr + img.tobytes()
+
+
+def jpeg_with_thumbnail(img, thumb):
+    """a JPEG whose first segment after SOI is an APP1 that contains a complete small JPEG"""
+    main, small = jpeg_file(img, quality=70), jpeg_file(thumb, quality=50)
+    body = b"Exif\0\0" + small
+    return main[:2] + b"\xff\xe1" + (len(body) + 2).to_bytes(2, "big") + body + main[2:]
+
+
 def preprocessed(payload):
     """the stream the reference's preprocessor (preprocessor.cpp:568 Encode) hands the predictor for a file: block headers, detected
     types (HDR + IMAGE24 / IMAGE32 for a BMP), its transforms -- through oracle/_ref/libcmixref.so (oracle/ref_harness.cpp)"""
@@ -180,6 +199,17 @@ def image_streams():
         # (IMAGE8GRAY block), text -- every switch between the generic models and a model with tables of its own, in chunks that cut anywhere
         "mixed_media_12k": preprocessed(text[:150] + bmp_file(photo(48, 32, 3, 41)) + text[150:220] + wav_file(500, 2, 16, 42) + text[220:300] +
                                         jpeg_file(photo(64, 48, 3, 43), quality=60) + text[300:360] + b"P5\n48 40\n255\n" + photo(48, 40, 1, 44)[:, :, 0].tobytes() + text[360:500]),
+        # TGA payloads (imgModel's second detector :5441-5481): true colour as the preprocessor frames it, grayscale / colour-mapped / 32-bit inside DEFAULT blocks
+        "tga24_5k": preprocessed(text[:120] + tga_file(photo(48, 32, 3, 51), 2) + text[120:300]),
+        "tga_gray_map_32_raw_9k": default_block(text[:80] + tga_file(photo(56, 40, 1, 52)[:, :, 0], 3) + text[80:160] + tga_file((photo(48, 36, 1, 53)[:, :, 0] >> 2), 1) + text[160:220] +
+                                                tga_file(photo(32, 28, 4, 54), 2) + text[220:300]),
+        # more JPEG shapes: 4:4:4 chroma, a progressive file (SOF2: the model must stay off), a file cut off in the middle of its scan followed by text
+        "jpeg_444_prog_cut_6k": preprocessed(text[:100] + jpeg_file(photo(64, 48, 3, 55), quality=80, subsampling=0) + text[100:160] +
+                                             jpeg_file(photo(64, 48, 3, 56), quality=70, progressive=True) + text[160:220] + jpeg_file(photo(80, 64, 3, 57), quality=75)[:1100] + text[220:500]),
+        # a 32-bit PAM (the preprocessor makes an IMAGE32 block: the block path with alpha) and a JPEG whose APP1 segment holds a thumbnail JPEG (the parser's
+        # embedded-image stack :6058-6063) inside a DEFAULT block
+        "pam32_thumb_8k": preprocessed(text[:90] + b"P7\nWIDTH 40\nHEIGHT 30\nDEPTH 4\nMAXVAL 255\nTUPLTYPE RGB_ALPHA\nENDHDR\n" + photo(40, 30, 4, 61).tobytes() + text[90:200]) +
+                          default_block(text[200:260] + jpeg_with_thumbnail(photo(64, 48, 3, 62), photo(24, 16, 3, 63)) + text[260:400]),
         # PCM audio (audio8bModel :5552-5657, wavModel :5659-5804, each followed by recordModel): WAV files as the preprocessor frames them
         "wav16s_6k": preprocessed(text[:200] + wav_file(1400, 2, 16, 9) + text[200:450]),
         "wav8s_4k": preprocessed(text[:150] + wav_file(1800, 2, 8, 10) + text[150:300]),

@@ -127,6 +127,9 @@ def load_hashes(name):
         return z["stream"].copy(), z["hash"].copy()
 
 
+# a 32-bit PAM (IMAGE32 block: the alpha path) and a JPEG with a thumbnail JPEG inside its APP1 segment;
+# TGA payloads (true colour as an IMAGE24 block; grayscale, colour-mapped and 32-bit ones found by paq8's own detector); JPEG with 4:4:4 chroma, a progressive
+# JPEG (the model stays off) and a JPEG cut off in the middle of its scan;
 # one file with a BMP, a WAV, a JPEG and a PGM between pieces of text (every switch between the generic models and a model with its own tables);
 # baseline JPEG (jpegModel: the marker parser, the Huffman decoder and the coefficient predictors on the host; 32 contexts on a BH<9> table, the model's
 # own mixer and two APM stages on one lane; exports interleaved in call order): a 4:2:0 colour picture in a JPEG block, a grayscale one with restart
@@ -144,7 +147,8 @@ def load_hashes(name):
                                          ("pgm8_4k", 4116), ("bmp8_gray_raw_5k", 4711), ("bmp8_pal_raw_5k", 4711),
                                          ("wav16s_6k", 6099), ("wav8s_4k", 3949), ("wav16m_3k", 2849), ("wav8m_2k", 1949),
                                          ("pbm1_2k", 1965), ("bmp1_raw_2k", 1917), ("bmp4_raw_3k", 3061),
-                                         ("jpeg_5k", 2124), ("jpeg_rst_raw_3k", 1287), ("mixed_media_12k", 10168)])
+                                         ("jpeg_5k", 2124), ("jpeg_rst_raw_3k", 1287), ("mixed_media_12k", 10168),
+                                         ("tga24_5k", 4950), ("tga_gray_map_32_raw_9k", 8679), ("jpeg_444_prog_cut_6k", 4051), ("pam32_thumb_8k", 7085)])
 def test_stage_vs_reference_hashes(name, nbytes):
     """Prefixes of the reference-derived fixtures of tests/golden/make_paq8_hashes.py (the device test runs them whole)."""
     from make_paq8_hashes import row_hash
