@@ -24,7 +24,8 @@ extern "C" __global__ void cmx_mixnet_kernel(MixState*, const float*, const uint
 extern "C" __global__ void cmx_mixnet_chunk_kernel(MixState*, const float*, const uint32_t*,
                                                    const uint8_t*, const float*, int, float*, float*, int);
 extern "C" __global__ void cmx_mixnet_spec_kernel(MixState*, SpecXfer*, const float*, const uint32_t*, const uint8_t*, const float*, int, float*,
-                                                  float*, int, CmxLate);
+                                                  float*, int);
+extern "C" __global__ void cmx_mixnet_spec_late_kernel(MixState*, SpecXfer*, const float*, const uint32_t*, const float*, int, float*, float*, int, CmxLate);
 extern "C" __global__ void cmx_sse_init_kernel(MixState*);
 extern "C" __global__ void cmx_probe_libm_kernel(int, const float*, float*, size_t);
 
@@ -305,7 +306,8 @@ cmx_mixnet_t* cmx_mixnet_create(int device) {
   { const char* v = getenv("CMX_MIXNET_V1"); h->use_v1 = v && v[0] == '1'; }
   { const char* v = getenv("CMX_MIXNET_SPEC"); h->use_spec = !(v && v[0] == '0'); }
   h->d_xfer = (SpecXfer*)dalloc(sizeof(SpecXfer), true);   // incl. the zero padding of the input ring
-  if (!h->d_xfer || hipFuncSetAttribute((const void*)cmx_mixnet_spec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CMX_SPEC_LDS_BYTES) != hipSuccess) {
+  if (!h->d_xfer || hipFuncSetAttribute((const void*)cmx_mixnet_spec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CMX_SPEC_LDS_BYTES) != hipSuccess ||
+      hipFuncSetAttribute((const void*)cmx_mixnet_spec_late_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CMX_SPEC_LDS_BYTES) != hipSuccess) {
     set_err("cmx_mixnet_create: hand-off area / kernel attribute (spec kernel) failed");
     cmx_mixnet_destroy(h);
     return nullptr;
@@ -470,9 +472,13 @@ static int mixnet_run_impl(cmx_mixnet_t* h, const float* d_probs, const uint32_t
   else if (h->use_spec) {
     // epochs and value|tag words restart at 0 with every launch; 1 main + 26 helper workgroups, co-resident (27 of 256 CUs)
     HIP_OK(hipMemsetAsync(h->d_xfer, 0, CMX_SPEC_HEADER_BYTES, st));
-    hipLaunchKernelGGL(cmx_mixnet_spec_kernel, dim3(1 + CMX_SPEC_HELPERS), dim3(CMX_SPEC_THREADS), CMX_SPEC_LDS_BYTES, st,
-                       h->d_state, h->d_xfer, d_probs, d_sel, d_bits, dd, (int)nbits, d_p_out, d_mix_out,
-                       3 | (h->profile ? 4 : 0) | ((h->dbg & 15) << 4) | (h->tolerance ? 0x1000 : 0), box ? *box : CmxLate());
+    const int kmode = 3 | (h->profile ? 4 : 0) | ((h->dbg & 15) << 4) | (h->tolerance ? 0x1000 : 0);
+    if (box && box->box)   // a decoder's chunk: the patient instantiation of the same roles
+      hipLaunchKernelGGL(cmx_mixnet_spec_late_kernel, dim3(1 + CMX_SPEC_HELPERS), dim3(CMX_SPEC_THREADS), CMX_SPEC_LDS_BYTES, st,
+                         h->d_state, h->d_xfer, d_probs, d_sel, dd, (int)nbits, d_p_out, d_mix_out, kmode, *box);
+    else
+      hipLaunchKernelGGL(cmx_mixnet_spec_kernel, dim3(1 + CMX_SPEC_HELPERS), dim3(CMX_SPEC_THREADS), CMX_SPEC_LDS_BYTES, st,
+                         h->d_state, h->d_xfer, d_probs, d_sel, d_bits, dd, (int)nbits, d_p_out, d_mix_out, kmode);
   } else
     // XCD placement (observed: block b runs on XCD b % 8): 8 blocks, all but block `xcd` leave at once
     hipLaunchKernelGGL(cmx_mixnet_chunk_kernel, dim3(h->xcd >= 0 ? 8 : 1), dim3(CMX_CHUNK_THREADS), CMX_CHUNK_LDS_BYTES, st,

@@ -131,14 +131,16 @@ __device__ __forceinline__ bool late_expired(CmxLateBox* B, unsigned long long& 
   if (now - t0 > CMX_LATE_TIMEOUT_TICKS) { late_st(&B->fail, 1u); return true; }
   return false;
 }
-__device__ __forceinline__ bool wait_ge(Ctl* ctl, const int* p, int target, bool sleepy) {
+template <bool LATE = false> __device__ __forceinline__ bool wait_ge(Ctl* ctl, const int* p, int target, bool sleepy) {
   unsigned spins = 0;
   unsigned long long t0 = 0;
   while (lds_poll(p) < target) {
     if (sleepy) __builtin_amdgcn_s_sleep(2);
     if ((++spins & 1023u) == 0) {
-      CmxLateBox* const B = ctl_box(ctl);
-      if (lds_poll(&ctl->abort) || (B ? late_expired(B, t0) : spins > SPIN_LIMIT)) {
+      bool out;
+      if (LATE) { CmxLateBox* const B = ctl_box(ctl); out = B ? late_expired(B, t0) : spins > SPIN_LIMIT; }
+      else out = spins > SPIN_LIMIT;
+      if (lds_poll(&ctl->abort) || out) {
         lds_publish_store(&ctl->abort, 1);
         return false;
       }
@@ -983,7 +985,7 @@ __device__ void tail_role(MixState* S, const Lds& L, const float* decay1, int nb
 // layer 2 (every mixer learns from its own output, mixer.cpp:56-72), so the two halves are a pipeline: tail_a_role (wave 1) does layer 1 of
 // bit t and hands the 49 layer-2 inputs over through LDS (Lds::h2, two slots); tail_b_role (wave 3) does layer 2, the SSE and the output of
 // bit t while wave 1 is on bit t + 1. Same arithmetic, same order, per half as in tail_role.
-__device__ void tail_a_role(MixState* S, const Lds& L, const float* decay1, int nbits, float* mix_out, int lane, bool prof_on) {
+template <bool LATE> __device__ void tail_a_role(MixState* S, const Lds& L, const float* decay1, int nbits, float* mix_out, int lane, bool prof_on) {
   uint64_t tprev = __builtin_readcyclecounter();
   uint64_t pacc[6] = {0, 0, 0, 0, 0, 0};
 #define TPROF(k) do { if (prof_on) { uint64_t now_ = __builtin_readcyclecounter(); pacc[k - 6] += now_ - tprev; tprev = now_; } } while (0)
@@ -1008,7 +1010,7 @@ __device__ void tail_a_role(MixState* S, const Lds& L, const float* decay1, int 
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   for (int t = 0; t < nbits; ++t) {
     TPROF(11);
-    if (!wait_ge(L.ctl, &L.ctl->scout_epoch, t + 1, true)) return;
+    if (!wait_ge<LATE>(L.ctl, &L.ctl->scout_epoch, t + 1, true)) return;
     const BitRec* rec = L.rec + (t % L.rr);
     const uint32_t newrow = rec->rowidx[CMX_MIX0 + kk];
     const uint32_t row2 = rec->rowidx[CMX_MIXERS - 1];
@@ -1034,8 +1036,8 @@ __device__ void tail_a_role(MixState* S, const Lds& L, const float* decay1, int 
       }
     }
     TPROF(6);
-    if (t >= 2 && !wait_ge(L.ctl, &L.ctl->b_done, t - 1, false)) return;   // the hand-over slot t & 1 is free
-    if (!wait_ge(L.ctl, &L.ctl->tail_in, t + 1, false)) return;
+    if (t >= 2 && !wait_ge<LATE>(L.ctl, &L.ctl->b_done, t - 1, false)) return;   // the hand-over slot t & 1 is free
+    if (!wait_ge<LATE>(L.ctl, &L.ctl->tail_in, t + 1, false)) return;
     TPROF(7);
     const TailRec* tr = L.trec + (t & 1);
     int bit = tr->bit;   // (late mode: not known yet -- awaited below, where layer 1 learns)
@@ -1067,8 +1069,8 @@ __device__ void tail_a_role(MixState* S, const Lds& L, const float* decay1, int 
     __builtin_amdgcn_wave_barrier();
     st_rel(&L.ctl->b_in, t + 1);
     TPROF(8);
-    if (L.late.box) {   // the decoder's bit: the output wave (tail_b_role) receives it after p has gone out
-      if (!wait_ge(L.ctl, &L.ctl->bit_epoch, t + 1, false)) return;
+    if (LATE) {   // the decoder's bit: the output wave (tail_b_role) receives it after p has gone out
+      if (!wait_ge<LATE>(L.ctl, &L.ctl->bit_epoch, t + 1, false)) return;
       bit = L.bitring[t & 7];
     }
     // ---- Mixer::Perceive, layer 1 ----
@@ -1118,7 +1120,7 @@ __device__ void tail_a_role(MixState* S, const Lds& L, const float* decay1, int 
   }
 }
 
-__device__ void tail_b_role(MixState* S, const Lds& L, const float* decay1, int nbits, float* p_out, float* mix_out, int lane, bool prof_on) {
+template <bool LATE> __device__ void tail_b_role(MixState* S, const Lds& L, const float* decay1, int nbits, float* p_out, float* mix_out, int lane, bool prof_on) {
   uint64_t tprev = __builtin_readcyclecounter();
   uint64_t pacc[3] = {0, 0, 0};
 #define TPROF(k) do { if (prof_on) { uint64_t now_ = __builtin_readcyclecounter(); pacc[k] += now_ - tprev; tprev = now_; } } while (0)
@@ -1152,9 +1154,9 @@ __device__ void tail_b_role(MixState* S, const Lds& L, const float* decay1, int 
       else addr = (const float*)(x1 + (((((b << 8) + (int)(ffl_ & 255)) << 3) + (int)((pc_ >> 5) & 7)) * 79 + sse_mx1mask((int)j_)));
       touch_line(as_global(addr), L.pfdump + 256 + 256);
     }
-    if (!wait_ge(L.ctl, &L.ctl->b_in, t + 1, false)) return;
+    if (!wait_ge<LATE>(L.ctl, &L.ctl->b_in, t + 1, false)) return;
     TPROF(0);
-    if (L.late.box && lane == 0) late_stamp(L.late, 4);   // layer 1 done
+    if (LATE && lane == 0) late_stamp(L.late, 4);   // layer 1 done
     const float* const in2 = L.h2 + 64 * (t & 1);
     int bit = __float_as_int(in2[49]);
     {  // layer 2 has one weight set in cmix (selector = zero_context_); a changing key is still honoured
@@ -1216,7 +1218,7 @@ __device__ void tail_b_role(MixState* S, const Lds& L, const float* decay1, int 
       const float lp = in2[50];
       if (lp == 0.0f || lp == 1.0f) pf = lp;               // predictor.cpp:383,415-417
       as_global(p_out)[t] = pf;
-      if (L.late.box) {
+      if (LATE) {
         // Decoder::Decode (decoder.cpp:20-39): p goes to the host (value | tag, one 8-byte store into its mapped memory); the arithmetic
         // decoder turns it into the bit, which comes back through the box and is handed to the waves that learn from it
         __hip_atomic_store(&L.late.box->p_word[t % CMX_LATE_P_RING], ((unsigned long long)(unsigned)(t + 1) << 32) | (unsigned)__float_as_int(pf), __ATOMIC_RELAXED,
@@ -1249,7 +1251,7 @@ __device__ void tail_b_role(MixState* S, const Lds& L, const float* decay1, int 
       if (mix_out) as_global(mix_out)[(size_t)t * CMX_MIXERS + CMX_MIXERS - 1] = p2_;
       ++steps_done;
     }
-    if (L.late.box && lds_poll(&L.ctl->abort)) return;   // (uniform: the decoder has left)
+    if (LATE && lds_poll(&L.ctl->abort)) return;   // (uniform: the decoder has left)
     TPROF(1);
     u2 = bcast_lane(u2, 0);
     df2 = __builtin_amdgcn_readlane(df2, 0);
@@ -1340,7 +1342,7 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
-__device__ void helper_role(MixState* S, SpecXfer* X, HelperLds* H, int nbits, int m, int w, int lane, bool tol, CmxLateBox* LB) {
+template <bool LATE> __device__ void helper_role(MixState* S, SpecXfer* X, HelperLds* H, int nbits, int m, int w, int lane, bool tol, CmxLateBox* LB) {
   const gptr<float> rows0 = as_global(S->rows0);
   const int base = 512 * w;                 // first element of this wave's segment
   const int nseg = w == 3 ? CMX_IN0 - 1536 : 512;
@@ -1355,7 +1357,7 @@ __device__ void helper_role(MixState* S, SpecXfer* X, HelperLds* H, int nbits, i
   auto failed = [&]() { return lds_poll(&H->abort) != 0; };
   unsigned long long late_t0 = 0;
   // has a wait for the main workgroup run out? a compressor's: by spin count; a decoder's (the wait then includes the host): by its box
-  auto spun_out = [&](unsigned spins) { return LB ? late_expired(LB, late_t0) : spins > SPEC_SPIN; };
+  auto spun_out = [&](unsigned spins) { return LATE ? late_expired(LB, late_t0) : spins > SPEC_SPIN; };
   auto give_up = [&]() { lds_publish_store(&H->abort, 1); __hip_atomic_store(&X->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   // fetch the inputs of bit t (this wave's slice) and, if its selector changes, the incoming row
   auto fetch = [&](int t) -> bool {
@@ -1502,23 +1504,23 @@ __device__ void helper_role(MixState* S, SpecXfer* X, HelperLds* H, int nbits, i
 // two more for the row selection), more than a whole bit of the helpers. Only Mixer::GetContextData is stateful; the stretch of a
 // bit's inputs depends on nothing, so four stretch waves take the bits round robin (each bit still costs its ~12 k clocks, four
 // are in flight) and one select wave follows them in order.
-__device__ void stretch_role(MixState* S, const Lds& L, SpecXfer* X, const float* probs, const uint8_t* bits, int nbits, int sw, int lane) {
+template <bool LATE> __device__ void stretch_role(MixState* S, const Lds& L, SpecXfer* X, const float* probs, const uint8_t* bits, int nbits, int sw, int lane) {
   const gptr<const float> lut = as_global(S->logit_lut);
   const gptr<const float> gprobs = as_global(probs);
   const float smin = S->stretch_min, smax = S->stretch_max;
   for (int t = sw; t < nbits; t += 4) {
-    if (t >= L.lead && !wait_ge(L.ctl, &L.ctl->consumed, 4 * (t - L.lead) + 1, true)) return;   // the gather wave has begun bit t - lead
-    if (t >= L.rr && !wait_ge(L.ctl, &L.ctl->tail_done, t - L.rr + 1, true)) return;             // rec slot t % rr is free (see scout_role)
+    if (t >= L.lead && !wait_ge<LATE>(L.ctl, &L.ctl->consumed, 4 * (t - L.lead) + 1, true)) return;   // the gather wave has begun bit t - lead
+    if (t >= L.rr && !wait_ge<LATE>(L.ctl, &L.ctl->tail_done, t - L.rr + 1, true)) return;             // rec slot t % rr is free (see scout_role)
     BitRec* rec = L.rec + (t % L.rr);
     const gptr<const float> pr = gprobs + (size_t)t * CMX_IN0;
-    if (L.late.box) {   // a decoder: row t exists once every producing stage has counted it (cmx_late.h), one lane per counter
+    if (LATE) {   // a decoder: row t exists once every producing stage has counted it (cmx_late.h), one lane per counter
       bool ok = true;
       if (lane <= LC_P8) ok = late_wait_cnt(L.late, lane, (uint32_t)(t + 1));
       if (__ballot(!ok)) { lds_publish_store(&L.ctl->abort, 1); return; }
       if (lane == 0) late_stamp(L.late, 2);   // row t complete
     }
     float pv[33];
-    if (L.late.box) {
+    if (LATE) {
       // `probs` is a const __restrict__ kernel argument: the compiler may treat its contents as invariant for the whole launch (merge a
       // load with an earlier one, move it above the wait). A decoder's rows are written WHILE this kernel runs: atomic loads, which
       // it has to perform where they stand.
@@ -1534,7 +1536,7 @@ __device__ void stretch_role(MixState* S, const Lds& L, SpecXfer* X, const float
         pv[r] = i < CMX_IN0 ? pr[i] : 0.5f;
       }
     }
-    const int bitv = L.late.box ? 0 : (int)bits[t];   // (late: not known yet; the waves that learn wait for it)
+    const int bitv = LATE ? 0 : (int)bits[t];   // (late: not known yet; the waves that learn wait for it)
     const float lstm_raw = bcast_lane(pv[32], 29);   // probs[t][2077]
 #pragma unroll
     for (int r = 0; r < 33; ++r) {   // MixerInput::SetInput (mixer-input.cpp:11-15) + Sigmoid::Logit (sigmoid.cpp:12-17)
@@ -1574,17 +1576,17 @@ __device__ void stretch_role(MixState* S, const Lds& L, SpecXfer* X, const float
   }
 }
 
-__device__ void select_role(MixState* S, const Lds& L, SpecXfer* X, const uint32_t* sel, int nbits, int lane) {
+template <bool LATE> __device__ void select_role(MixState* S, const Lds& L, SpecXfer* X, const uint32_t* sel, int nbits, int lane) {
   const gptr<const uint32_t> gsel = as_global(sel);
   for (int t = 0; t < nbits; ++t) {
-    uint32_t key = (!L.late.box && lane < CMX_MIXERS) ? gsel[(size_t)t * CMX_MIXERS + lane] : 0;
+    uint32_t key = (!LATE && lane < CMX_MIXERS) ? gsel[(size_t)t * CMX_MIXERS + lane] : 0;
     BitRec* rec = L.rec + (t % L.rr);
     const BitRec* prev = L.rec + ((t + L.rr - 1) % L.rr);
-    if (L.late.box) {
+    if (LATE) {
       // A decoder: the context stage counts row t (LC_CTX) ~13 us before the slowest producer does, and 46 of the 47 selections need
       // nothing else -- they are done while the stretch wave still waits for the row; only the auxiliary-context mixer (its key comes out
       // of three of the inputs) follows the stretch wave. `sel` is a const __restrict__ kernel argument (see stretch_role): atomic loads.
-      if (t >= L.rr && !wait_ge(L.ctl, &L.ctl->tail_done, t - L.rr + 1, true)) return;   // rec slot t % rr is free (as the stretch wave checks)
+      if (t >= L.rr && !wait_ge<LATE>(L.ctl, &L.ctl->tail_done, t - L.rr + 1, true)) return;   // rec slot t % rr is free (as the stretch wave checks)
       bool ok = true;
       if (lane == 0) ok = late_wait_cnt(L.late, LC_CTX, (uint32_t)(t + 1));
       if (__ballot(!ok)) { lds_publish_store(&L.ctl->abort, 1); return; }
@@ -1600,9 +1602,9 @@ __device__ void select_role(MixState* S, const Lds& L, SpecXfer* X, const uint32
         }
       }
     }
-    if (!wait_ge(L.ctl, &L.sdone[t % L.rr], t + 1, true)) return;
+    if (!wait_ge<LATE>(L.ctl, &L.sdone[t % L.rr], t + 1, true)) return;
     if (lane == CMX_AUX) key = rec->auxkey;
-    if (lane < CMX_MIXERS && (!L.late.box || lane == CMX_AUX)) {
+    if (lane < CMX_MIXERS && (!LATE || lane == CMX_AUX)) {
       uint32_t r = select_row(S, lane, key);
       rec->rowidx[lane] = r;
       const uint32_t chg = (t == 0) || (r != prev->rowidx[lane]);
@@ -1616,13 +1618,13 @@ __device__ void select_role(MixState* S, const Lds& L, SpecXfer* X, const uint32
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) __hip_atomic_store(&X->scout_epoch, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     st_rel(&L.ctl->scout_epoch, t + 1);
-    if (L.late.box && lane == 0) late_stamp(L.late, 5);   // inputs and rows published to the helpers
+    if (LATE && lane == 0) late_stamp(L.late, 5);   // inputs and rows published to the helpers
   }
 }
 
 // ------------------------------------------------------------------ gather (main workgroup, wave 0)
 // chain_role with the 26 ordered sums arriving from the helpers instead of being added up here.
-__device__ void gather_role(MixState* S, const Lds& L, SpecXfer* X, const float* decay1, int nbits,
+template <bool LATE> __device__ void gather_role(MixState* S, const Lds& L, SpecXfer* X, const float* decay1, int nbits,
                             float* mix_out, bool prof_on, int lane) {
   const int m = lane;
   const bool is0 = m < CMX_MIX0;
@@ -1665,7 +1667,7 @@ __device__ void gather_role(MixState* S, const Lds& L, SpecXfer* X, const float*
 #pragma unroll
   for (int i = 0; i < 7; ++i) ewn[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   for (int t = 0; t < nbits; ++t) {
-    if (!wait_ge(L.ctl, &L.ctl->scout_epoch, t + 1, false)) return;
+    if (!wait_ge<LATE>(L.ctl, &L.ctl->scout_epoch, t + 1, false)) return;
     st_rel(&L.ctl->consumed, 4 * t + 1);      // the scout may go on to bit t + 1 (it waits for consumed >= 4 t)
     GPROF(0);
     const BitRec* rec = L.rec + (t % L.rr);
@@ -1706,7 +1708,7 @@ __device__ void gather_role(MixState* S, const Lds& L, SpecXfer* X, const float*
           if ((unsigned)(v >> 32) == (unsigned)(t + 1)) { pm = __int_as_float((int)(unsigned)v); have = true; }
         }
         if (__ballot(!have) == 0) break;
-        if ((++spins & 1023u) == 0 && ((L.late.box ? late_expired(L.late.box, gt0) : spins > SPEC_SPIN) || lds_poll(&L.ctl->abort) || ld_u32(&X->fail))) {
+        if ((++spins & 1023u) == 0 && ((LATE ? late_expired(L.late.box, gt0) : spins > SPEC_SPIN) || lds_poll(&L.ctl->abort) || ld_u32(&X->fail))) {
           lds_publish_store(&L.ctl->abort, 1);
           __hip_atomic_store(&X->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           return;
@@ -1714,7 +1716,7 @@ __device__ void gather_role(MixState* S, const Lds& L, SpecXfer* X, const float*
       }
     }
     GPROF(2);
-    if (L.late.box && lane == 0) late_stamp(L.late, 3);   // the 26 sums are there
+    if (LATE && lane == 0) late_stamp(L.late, 3);   // the 26 sums are there
     float e = 0.0f;
 #pragma unroll
     for (int j = 0; j < CMX_MIX0; ++j) {      // intra-layer chain (predictor.cpp:395-400), see chain_role
@@ -1727,7 +1729,7 @@ __device__ void gather_role(MixState* S, const Lds& L, SpecXfer* X, const float*
     GPROF(3);
     int bitv = bit;
     auto hand_to_tail = [&]() -> bool {
-      if (t >= 2 && !wait_ge(L.ctl, &L.ctl->tail_done, t - 1, false)) return false;
+      if (t >= 2 && !wait_ge<LATE>(L.ctl, &L.ctl->tail_done, t - 1, false)) return false;
       TailRec* tr = L.trec + (t & 1);
       if (is0) tr->out0[m] = myout;
       if (m >= CMX_MIX0 && m < CMX_MIXERS) tr->rowidx[m - CMX_MIX0] = rec->rowidx[m];
@@ -1736,9 +1738,9 @@ __device__ void gather_role(MixState* S, const Lds& L, SpecXfer* X, const float*
       st_rel(&L.ctl->tail_in, t + 1);
       return true;
     };
-    if (L.late.box) {   // a decoder: the bit is an output of the arithmetic decoder, which needs p -- the tail waves first, then the wait
+    if (LATE) {   // a decoder: the bit is an output of the arithmetic decoder, which needs p -- the tail waves first, then the wait
       if (!hand_to_tail()) return;
-      if (!wait_ge(L.ctl, &L.ctl->bit_epoch, t + 1, false)) return;
+      if (!wait_ge<LATE>(L.ctl, &L.ctl->bit_epoch, t + 1, false)) return;
       bitv = L.bitring[t & 7];
     }
     float uu = fmul(dlr, fsub(cmx_logistic_t(p_, L.exptab), (float)bitv));   // Mixer::Perceive scalar (mixer.cpp:56-64)
@@ -1747,7 +1749,7 @@ __device__ void gather_role(MixState* S, const Lds& L, SpecXfer* X, const float*
     const bool dfl = (rsteps & 1023) == 0;
     if (is0) st_u64(&X->u[m], ((unsigned long long)(2u * (unsigned)(t + 1) + (dfl ? 1u : 0u)) << 32) | (unsigned)__float_as_int(uu));
     GPROF(4);
-    if (!L.late.box && !hand_to_tail()) return;
+    if (!LATE && !hand_to_tail()) return;
     GPROF(12);
     if (is0 && mix_out) as_global(mix_out)[(size_t)t * CMX_MIXERS + m] = p_;
 #pragma unroll
@@ -1829,13 +1831,13 @@ extern "C" __global__ __launch_bounds__(NTHREADS) void cmx_mixnet_chunk_kernel(
   if (tid == 0 && L.ctl->abort) S->error = 1;
 }
 
-// Grid: 1 + 26 workgroups of 256 threads; all of them must be resident at once (they hand values to each other inside the launch;
-// every wait is bounded and a time-out sets SpecXfer::fail / MixState::error instead of hanging).
-extern "C" __global__ __launch_bounds__(CMX_SPEC_THREADS) void cmx_mixnet_spec_kernel(
+// LATE: a decoder's chunk (cmx_late.h) -- `bits` is unused, rows / selectors arrive as their stages count them, p goes to the box. A compile-time
+// switch: the compressor's kernel carries none of the decoder's state (125 VGPRs / 71 spilled SGPRs as before the decoder existed, against
+// 167 / 135 when the two forms shared one kernel body at run time; the measured time per bit is the same either way, 6.8 us in the pipeline).
+template <bool LATE> __device__ __forceinline__ void spec_kernel_body(
     MixState* __restrict__ S, SpecXfer* __restrict__ X, const float* __restrict__ probs, const uint32_t* __restrict__ sel,
     const uint8_t* __restrict__ bits, const float* __restrict__ decay1, int nbits,
-    float* __restrict__ p_out, float* __restrict__ mix_out, int mode, CmxLate box) {
-  // box != nullptr: a decoder's chunk (cmx_late.h) -- `bits` is unused, rows / selectors arrive as their stages count them, p goes to the box
+    float* __restrict__ p_out, float* __restrict__ mix_out, int mode, const CmxLate& box) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -1843,7 +1845,7 @@ extern "C" __global__ __launch_bounds__(CMX_SPEC_THREADS) void cmx_mixnet_spec_k
     HelperLds* H = reinterpret_cast<HelperLds*>(smem);
     for (int i = tid; i < (int)(sizeof(HelperLds) / 4); i += CMX_SPEC_THREADS) reinterpret_cast<int*>(H)[i] = 0;
     __syncthreads();
-    if (wave < 4) helper_role(S, X, H, nbits, (int)blockIdx.x - 1, wave, lane, (mode & 0x1000) != 0, box.box);
+    if (wave < 4) helper_role<LATE>(S, X, H, nbits, (int)blockIdx.x - 1, wave, lane, (mode & 0x1000) != 0, LATE ? box.box : nullptr);
     return;
   }
   Lds L;
@@ -1865,20 +1867,35 @@ extern "C" __global__ __launch_bounds__(CMX_SPEC_THREADS) void cmx_mixnet_spec_k
   L.lst = lst; L.lsq = lst + 32768;
   L.h2 = reinterpret_cast<float*>(lst + 65536);                   // 2 x 64
   L.bitring = reinterpret_cast<int*>(L.h2 + 128);                 // 8
-  L.late = box;
+  L.late = LATE ? box : CmxLate();
   for (int i = tid; i < 32768; i += CMX_SPEC_THREADS) reinterpret_cast<uint32_t*>(lst)[i] = i < 16384 ? reinterpret_cast<const uint32_t*>(S->t_st)[i] : reinterpret_cast<const uint32_t*>(S->t_sq)[i - 16384];
   if (tid < 32) { L.upd[tid] = 0.0f; L.dflag[tid] = 0; L.exptab[tid] = cmx_exp2f_tab[tid]; }
   if (tid < 8) L.sdone[tid] = 0;
   if (tid < (int)(sizeof(Ctl) / 4)) reinterpret_cast<int*>(L.ctl)[tid] = 0;
   __syncthreads();
-  if (tid == 0) { L.ctl->late_lo = (unsigned)(unsigned long long)box.box; L.ctl->late_hi = (unsigned)((unsigned long long)box.box >> 32); }
+  if (LATE && tid == 0) { L.ctl->late_lo = (unsigned)(unsigned long long)box.box; L.ctl->late_hi = (unsigned)((unsigned long long)box.box >> 32); }   // (0 otherwise: cleared above)
   __syncthreads();
   const bool prof = (mode & 4) != 0;
-  if (wave == 0) gather_role(S, L, X, decay1, nbits, mix_out, prof, lane);
-  else if (wave == 1) tail_a_role(S, L, decay1, nbits, mix_out, lane, prof && ((mode >> 4) & 4) != 0);
-  else if (wave == 3) tail_b_role(S, L, decay1, nbits, p_out, mix_out, lane, prof && ((mode >> 4) & 4) != 0);
-  else if (wave == 2) select_role(S, L, X, sel, nbits, lane);
-  else if (wave >= 4) stretch_role(S, L, X, probs, bits, nbits, wave - 4, lane);
+  if (wave == 0) gather_role<LATE>(S, L, X, decay1, nbits, mix_out, prof, lane);
+  else if (wave == 1) tail_a_role<LATE>(S, L, decay1, nbits, mix_out, lane, prof && ((mode >> 4) & 4) != 0);
+  else if (wave == 3) tail_b_role<LATE>(S, L, decay1, nbits, p_out, mix_out, lane, prof && ((mode >> 4) & 4) != 0);
+  else if (wave == 2) select_role<LATE>(S, L, X, sel, nbits, lane);
+  else if (wave >= 4) stretch_role<LATE>(S, L, X, probs, bits, nbits, wave - 4, lane);
   __syncthreads();
   if (tid == 0 && (L.ctl->abort || ld_u32(&X->fail))) S->error = 1;
+}
+
+// Grid: 1 + 26 workgroups of 256 threads; all of them must be resident at once (they hand values to each other inside the launch;
+// every wait is bounded and a time-out sets SpecXfer::fail / MixState::error instead of hanging).
+extern "C" __global__ __launch_bounds__(CMX_SPEC_THREADS) void cmx_mixnet_spec_kernel(
+    MixState* __restrict__ S, SpecXfer* __restrict__ X, const float* __restrict__ probs, const uint32_t* __restrict__ sel,
+    const uint8_t* __restrict__ bits, const float* __restrict__ decay1, int nbits,
+    float* __restrict__ p_out, float* __restrict__ mix_out, int mode) {
+  spec_kernel_body<false>(S, X, probs, sel, bits, decay1, nbits, p_out, mix_out, mode, CmxLate());
+}
+// the decoder's form (engine mode 3, cmx_late.h): same grid, same roles, patient
+extern "C" __global__ __launch_bounds__(CMX_SPEC_THREADS) void cmx_mixnet_spec_late_kernel(
+    MixState* __restrict__ S, SpecXfer* __restrict__ X, const float* __restrict__ probs, const uint32_t* __restrict__ sel,
+    const float* __restrict__ decay1, int nbits, float* __restrict__ p_out, float* __restrict__ mix_out, int mode, CmxLate box) {
+  spec_kernel_body<true>(S, X, probs, sel, nullptr, decay1, nbits, p_out, mix_out, mode, box);
 }
