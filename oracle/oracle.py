@@ -4,6 +4,7 @@ ctypes binding for oracle/_build/libcmixoracle.so (the plain-C restatement in
 oracle/*.c).  Importers allowed: tests/, __graft_entry__.smoke(), bench.py's
 cpu_baseline leg.  The product package cmix_amd/ must never import this.
 """
+import contextlib
 import ctypes as C
 import os
 import subprocess
@@ -163,6 +164,38 @@ def lib():
         L.orc_ctx_model_column.argtypes = [C.c_void_p, C.c_int]
         _lib = L
     return _lib
+
+
+# ---- lifetime of the oracle's models (orc_alloc.h): they are C structs without destructors ----------------------------------------
+@contextlib.contextmanager
+def scope():
+    """Everything the oracle allocates inside the block and has not freed itself is freed at its end. Do not create MixNet / SSE /
+    Lstm / CtxModels objects inside (their __del__ frees through the oracle's own destroy functions)."""
+    L = lib()
+    L.orc_scope_begin.restype = C.c_uint32
+    L.orc_scope_begin()
+    try:
+        yield
+    finally:
+        L.orc_scope_end()
+
+
+def new_owned(ctor, *args):
+    """(handle, tag) of a model built by `ctor(*args)`: release(tag) frees every table the constructor allocated."""
+    L = lib()
+    L.orc_scope_begin.restype = C.c_uint32
+    tag = L.orc_scope_begin()
+    try:
+        h = ctor(*args)
+    finally:
+        L.orc_scope_pause()
+    return h, tag
+
+
+def release(tag):
+    L = lib()
+    L.orc_scope_free.argtypes = [C.c_uint32]
+    L.orc_scope_free(tag)
 
 
 def logistic(x):

@@ -39,7 +39,7 @@ def oracle_rows(data, lstmpr, lstmex, dictionary=None, blpos=0):
     lib.orc_fx_model_new_dict.restype = C.c_void_p
     lib.orc_fx_model_new_dict.argtypes = [C.c_char_p]
     lib.orc_fx_model_update.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
-    h = lib.orc_fx_model_new_dict(dictionary) if dictionary else lib.orc_fx_model_new()
+    h, tag = O.new_owned(lib.orc_fx_model_new_dict, dictionary) if dictionary else O.new_owned(lib.orc_fx_model_new)
     if blpos:
         lib.orc_fx_model_set_blpos.argtypes = [C.c_void_p, C.c_int]
         lib.orc_fx_model_set_blpos(h, blpos)
@@ -52,6 +52,7 @@ def oracle_rows(data, lstmpr, lstmex, dictionary=None, blpos=0):
             if q + 1 < len(rows):
                 rows[q + 1] = out
             q += 1
+    O.release(tag)   # (the model's tables: 4.4 GB of address space, freed here rather than at pytest's exit)
     return rows
 
 

@@ -9,6 +9,19 @@ import pytest
 from oracle import oracle as O
 from oracle import refharness as R
 
+
+@pytest.fixture(autouse=True)
+def _oracle_scope():
+    """The restatement's objects have no destructors (orc_alloc.h): what a test builds and does not free is freed when it ends."""
+    with O.scope():
+        yield
+    import _ctypes
+    while _PRIVATE_COPIES:   # the reference's state of a whole-model run lives in that copy's globals: unloading it runs their destructors
+        _ctypes.dlclose(_PRIVATE_COPIES.pop()._handle)
+
+
+_PRIVATE_COPIES = []
+
 needs_ref = pytest.mark.skipif(not R.fxcmcore_available(), reason="oracle/_ref/libcmixreffxcm.so not built")
 P = C.c_void_p
 
@@ -294,6 +307,7 @@ def _private_fx_copy(tmp_path):
     dst = tmp_path / "libcmixreffxcm_private.so"
     shutil.copy(R.FXCM_LIB_PATH, dst)
     L = C.CDLL(str(dst))
+    _PRIVATE_COPIES.append(L)
     L.reffx_model_new.restype = P
     L.reffx_model_update.argtypes = [P, C.c_int, C.c_int, C.c_int, P]
     L.reffx_model_debug.argtypes = [P]

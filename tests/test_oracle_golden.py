@@ -43,7 +43,7 @@ def test_paq8_oracle_reproduces_golden_columns(name):
     g = load_golden(name)
     probs, bits = mg.unpack_probs(g), g["bits"]
     lib.orc_p8_rnd_reset()
-    h = lib.orc_p8_predictor_new(11)
+    h, tag = O.new_owned(lib.orc_p8_predictor_new, 11)
     out = np.zeros(1591, np.float32)
     assert (probs[0, 434:2025] == 0.5).all()          # PAQ8::Predict() before the first Perceive
     for t in range(len(bits) - 1):
@@ -51,6 +51,7 @@ def test_paq8_oracle_reproduces_golden_columns(name):
         want = np.ascontiguousarray(probs[t + 1, 434:2025])
         bad = np.nonzero(want.view(np.uint32) != out.view(np.uint32))[0]
         assert bad.size == 0, (name, t, bad[:8], want[bad[:4]] * 4095, out[bad[:4]] * 4095)
+    O.release(tag)
 
 
 @pytest.mark.parametrize("name", ["text_96", "binary_64"])
@@ -68,7 +69,7 @@ def test_fxcm_oracle_reproduces_golden_columns(name):
     probs, bits, stream = mg.unpack_probs(g), g["bits"], g["stream"]
     assert (probs[0, 3:434] == 0.5).all()              # FXCM::Predict() before the first Perceive
     l = O.Lstm(g["vocab"])
-    h = lib.orc_fx_model_new()
+    h, tag = O.new_owned(lib.orc_fx_model_new)
     out = np.zeros(431, np.float32)
     t = 0
     for n in range(len(stream)):
@@ -88,6 +89,7 @@ def test_fxcm_oracle_reproduces_golden_columns(name):
             bad = np.nonzero(want.view(np.uint32) != out.view(np.uint32))[0]
             assert bad.size == 0, (name, t, bad[:8], want[bad[:4]] * 4095, out[bad[:4]] * 4095)
             t += 1
+    O.release(tag)
 
 
 def test_stretch_matches_reference_layer0():

@@ -12,6 +12,19 @@ from conftest import GOLDEN
 from oracle import oracle as O
 from oracle import refharness as R
 
+
+@pytest.fixture(autouse=True)
+def _oracle_scope():
+    """The restatement's objects have no destructors (orc_alloc.h): what a test builds and does not free is freed when it ends."""
+    with O.scope():
+        yield
+    import _ctypes
+    while _PRIVATE_COPIES:   # the reference's state of a whole-model run lives in that copy's globals: unloading it runs their destructors
+        _ctypes.dlclose(_PRIVATE_COPIES.pop()._handle)
+
+
+_PRIVATE_COPIES = []
+
 needs_ref = pytest.mark.skipif(not R.paq8core_available(), reason="oracle/_ref/libcmixrefpaq8.so not built")
 
 
@@ -835,6 +848,7 @@ def _private_ref_copy(tmp_path):
     dst = tmp_path / "libcmixrefpaq8_private.so"
     shutil.copy(R.PAQ8_LIB_PATH, dst)
     L = C.CDLL(str(dst))
+    _PRIVATE_COPIES.append(L)
     L.refp8_predictor_new.restype = C.c_void_p
     L.refp8_predictor_new.argtypes = [C.c_int]
     L.refp8_predictor_update.argtypes = [C.c_void_p, C.c_int, C.c_void_p]

@@ -94,11 +94,12 @@ def oracle_columns(data):
     lib.orc_p8_predictor_new.argtypes = [C.c_int]
     lib.orc_p8_predictor_update.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.orc_p8_rnd_reset()
-    h = lib.orc_p8_predictor_new(11)
+    h, tag = O.new_owned(lib.orc_p8_predictor_new, 11)
     bits = np.unpackbits(np.frombuffer(bytes(data), np.uint8))
     out = np.full((len(bits), 1591), 0.5, np.float32)
     for t in range(len(bits) - 1):
         assert lib.orc_p8_predictor_update(h, int(bits[t]), out[t + 1].ctypes.data) >= 0
+    O.release(tag)
     return out
 
 
