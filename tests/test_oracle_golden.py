@@ -212,3 +212,26 @@ def test_ctxmodels_random_160k_local():
 
 def test_ctxmodels_pretrained_golden():
     _check_ctxmodels("pretrained_128")  # 300 dictionary bytes through Predictor::Pretrain first
+
+
+def test_oracle_models_are_freed_by_their_scope():
+    """orc_alloc.h: what a constructor allocates between new_owned() and release() is gone afterwards, blocks the oracle frees itself
+    are not freed twice, and nothing outside a scope is touched."""
+    import ctypes as C
+    lib = O.lib()
+    lib.orc_live_bytes.restype = C.c_size_t
+    lib.orc_p8_mixer_new.restype = C.c_void_p
+    keep = lib.orc_p8_mixer_new(8, 4, 1, 0)                   # outside any scope
+    base = lib.orc_live_bytes()
+    lib.orc_p8_predictor_new.restype = C.c_void_p
+    lib.orc_p8_predictor_new.argtypes = [C.c_int]
+    h, tag = O.new_owned(lib.orc_p8_predictor_new, 11)
+    assert h and lib.orc_live_bytes() - base > 1 << 30        # the level-11 tables
+    with O.scope():
+        m = lib.orc_p8_mixer_new(8, 4, 1, 0)
+        lib.orc_p8_mixer_free(m)                              # freed by the oracle itself inside the scope
+        lib.orc_p8_mixer_new(8, 4, 1, 0)                      # left to the scope
+    O.release(tag)
+    assert lib.orc_live_bytes() == base
+    lib.orc_p8_mixer_free(keep)
+    assert lib.orc_live_bytes() < base
