@@ -43,6 +43,7 @@ struct Emul {
   int last_byte = 0;      // the last whole byte of the stream (ContextMap's c1)
   uint64_t fam_serial = 0, cm2_serial = 0;
   int late = 0;           // 1: the DECODER's order of operations (cmx_late.h): the front end emits a step's records only after the bit before it has been
+  int late_models = 0;    // with late: model steps (images, audio, JPEG) in the decoder's order too
                           // handed in, and the maps' uniform registers take that bit at the top of the step (p8d_bit_y, p8f_uni_tail + p8f_uni_head)
   int fam_miniwalk = 1;   // 0: whole-instance walks only; 1: the kernel's narrowed walk; 2: with every second visit treated as unlisted (the fall-back path)
   uint64_t fam_mini = 0, fam_mini_full = 0;
@@ -125,7 +126,7 @@ void p8s_layout_dump(void* h) {
   for (int m = 0; m < P8_NMODEL - 1; m++) printf("image model %d: prefix %d nx %d lanes %d contexts %d (first at %d)\n", m + 1, L.xl[m].prefix_nx, L.xl[m].nx, L.xl[m].nlanes, L.xl[m].fam_count, L.xl[m].fam_off[0]);
 }
 void p8s_set_miniwalk(void* h, int mode) { ((Emul*)h)->fam_miniwalk = mode; }
-void p8s_set_late(void* h, int on) { ((Emul*)h)->late = on; }
+void p8s_set_late(void* h, int on) { ((Emul*)h)->late = on & 1; ((Emul*)h)->late_models = (on >> 1) & 1; }
 void p8s_miniwalk_stats(void* h, uint64_t* out2) { out2[0] = ((Emul*)h)->fam_mini; out2[1] = ((Emul*)h)->fam_mini_full; }
 void p8s_stats(void* h, uint64_t* out3) { Emul* e = (Emul*)h; out3[0] = e->steps; out3[1] = e->fam_serial; out3[2] = e->cm2_serial; }
 // nbytes more bytes of the stream; out [8 nbytes][1591] f32 = PAQ8::Predict() before each of their bits. 0 or a negative front-end code.
@@ -145,7 +146,8 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
   std::vector<uint32_t> xops, xfctx;
   std::vector<uint16_t> xfchk;
   c.model = model.data();
-  if (!e->late) {   // (the decoder's form of the image models is not built: the front end refuses such a byte when it has nowhere to put its records)
+  if (!e->late || e->late_models) {   // (the DEVICE's decoder form of the image models is not built: there the front end refuses such a byte -- it has nowhere to put its
+    // records; late_models: the emulation of what that form has to do, step by step)
     xops.assign(T * P8_XL_NLANE, 0); xfctx.assign(n * P8_XL_MAXS, 0); xfchk.assign(n * P8_XL_MAXS, 0);
     c.xops = xops.data(); c.xfam_ctx = xfctx.data(); c.xfam_chk = xfchk.data();
   }
@@ -267,7 +269,7 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
       P8FamUni fu = P8FamUni();
       if (md) {   // an image model's step: the generic family only follows the bits (last bit, partial byte, last whole byte)
         if ((t & 7) == 0) f_run.c0 = 1;
-        p8f_uni_tail(&f_run, (int)(t & 7), bits[t]);
+        if (!e->late) p8f_uni_tail(&f_run, (int)(t & 7), bits[t]);   // (a decoder does not know bits[t] yet: the tail of this step is taken at the top of the next one, above)
       } else fu = e->late ? p8f_uni_head(c.fam_ctx, c.fam_chk, x.data(), order.data(), (int)t, &f_run, e->f2_i)
                           : p8f_uni_inc(d, c.fam_ctx, c.fam_chk, bits.data(), x.data(), order.data(), (int)t, &f_run, e->f2_i);
       if (g >= 8 && !md) {

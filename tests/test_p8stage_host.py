@@ -58,7 +58,7 @@ def run_stage(data, chunks=None, miniwalk=None, mini_stats=None, late=False):
         L.p8s_set_miniwalk(h, miniwalk)
     if late:
         L.p8s_set_late.argtypes = [C.c_void_p, C.c_int]
-        L.p8s_set_late(h, 1)
+        L.p8s_set_late(h, int(late))   # 1: the decoder's order; 3: for the steps of the models with their own tables too
     out = np.zeros((8 * len(data), 1591), np.float32)
     pos, k = 0, 0
     chunks = chunks or [len(data)]
@@ -204,3 +204,18 @@ def test_decoders_order_of_operations_gives_the_same_columns():
     x, _ = run_stage(data, chunks=[512])
     y, _ = run_stage(data, chunks=[512, 1, 300], late=True)
     assert (x.view(np.uint32) == y.view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("name,nbytes", [("mixed_media_12k", 10168), ("bmp4_raw_3k", 3061), ("jpeg_5k", 2124), ("wav8m_2k", 1949), ("pgm8_4k", 4116),
+                                         ("pam32_thumb_8k", 7085)])
+def test_decoders_order_of_operations_on_media_streams(name, nbytes):
+    """What the decoder's form of the image / audio / JPEG steps has to compute (the device form is not built yet: `cmix_dropin -d` refuses
+    such a file): the front end emits a model step's records only after the bit before it is known (its detectors, the JPEG parser and
+    the OLS predictors advance bit by bit), the generic maps follow the bits of a model's bytes through the tail of the step before
+    (never reading a bit ahead), and the generator / the shared instances change hands at the same byte boundaries. Same values as the
+    reference's, across every switch between the generic models and a model with tables of its own."""
+    from make_paq8_hashes import row_hash
+    stream, want = load_hashes(name)
+    got, _ = run_stage(stream[:nbytes], chunks=[512, 77, 300], late=3)
+    bad = np.nonzero(row_hash(got) != want[:8 * nbytes])[0]
+    assert bad.size == 0, (name, "first differing step:", bad[0], "of", 8 * nbytes)
