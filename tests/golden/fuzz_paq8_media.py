@@ -150,8 +150,8 @@ def run_case(seed):
     stream = bytes(stream)[:9000]
     r = np.random.default_rng(seed)
     chunks = [int(r.integers(60, 1500)) for _ in range(3)]
-    want = M.reference_hashes(stream)
-    # the emulator (as tests/test_p8stage_host.run_stage, but a refusal of the front end is a result, not an assertion)
+    # the emulator first (as tests/test_p8stage_host.run_stage, but a refusal of the front end is a result, not an assertion): on a stream the
+    # product refuses because the reference reads past an array there (image rows with padding, p8f_image.c), the reference may crash
     L = T.emul()
     data = np.ascontiguousarray(np.frombuffer(stream, np.uint8))
     h = L.p8s_create(11)
@@ -165,6 +165,10 @@ def run_case(seed):
             break
         pos += n
     L.p8s_destroy(h)
+    head = "seed %d  %d bytes  chunks %s  [%s]  " % (seed, len(stream), chunks, desc)
+    if rc:   # (said before the reference runs: should it crash, the driver loop logs this line with the crash)
+        print(head + "REFUSED rc=%d in the chunk at byte %d%s; the reference on the same stream ..." % (rc, pos, " (padded rows: expected)" if padded else " (UNEXPECTED)"), flush=True)
+    want = M.reference_hashes(stream)
     if rc:
         got = M.row_hash(out[:8 * pos])
         bad = np.nonzero(got != want[:8 * pos])[0]
@@ -193,6 +197,8 @@ if __name__ == "__main__":
                 o, e = p.communicate()
                 mine = [l for l in o.splitlines() if l.startswith("seed ")]   # (the reference's preprocessor prints its block statistics too)
                 line = mine[-1] if mine else "seed %d  CRASH rc=%s %s" % (s, p.returncode, e.strip().splitlines()[-1:])
+                if p.returncode and mine:
+                    line += " CRASHED (rc %d)" % p.returncode
                 with open(LOG, "a") as f:
                     f.write(line + "\n")
                 print(line, flush=True)
