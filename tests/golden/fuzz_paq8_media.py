@@ -7,7 +7,8 @@ thumbnail) between pieces of text and binary data -- framed either by the refere
 (32-bit row hashes, make_paq8_hashes.row_hash) with the stage's host emulation (tests/host/p8stage_emul.cpp: the device kernels' own step
 functions + the product's front end) run in random chunk sizes.
 
-    python tests/golden/fuzz_paq8_media.py FIRST_SEED COUNT [WORKERS]     # appends to tests/golden/fuzz_media_log.txt
+    python tests/golden/fuzz_paq8_media.py FIRST_SEED COUNT [WORKERS] [--late]   # appends to tests/golden/fuzz_media_log.txt
+                                                                  # --late: the emulation in the decoder's order of operations
     python tests/golden/fuzz_paq8_media.py --case SEED                    # one case, in this process (one reference predictor per process)
 """
 import os
@@ -155,6 +156,9 @@ def run_case(seed):
     L = T.emul()
     data = np.ascontiguousarray(np.frombuffer(stream, np.uint8))
     h = L.p8s_create(11)
+    if LATE:   # the decoder's order of operations, model steps included (p8stage_emul.cpp: p8s_set_late)
+        L.p8s_set_late.argtypes = [C.c_void_p, C.c_int]
+        L.p8s_set_late(h, 3)
     out = np.zeros((8 * len(data), 1591), np.float32)
     pos, k, rc = 0, 0, 0
     while pos < len(data):
@@ -165,7 +169,7 @@ def run_case(seed):
             break
         pos += n
     L.p8s_destroy(h)
-    head = "seed %d  %d bytes  chunks %s  [%s]  " % (seed, len(stream), chunks, desc)
+    head = "seed %d%s  %d bytes  chunks %s  [%s]  " % (seed, " (decoder's order)" if LATE else "", len(stream), chunks, desc)
     if rc:   # (said before the reference runs: should it crash, the driver loop logs this line with the crash)
         print(head + "REFUSED rc=%d in the chunk at byte %d%s; the reference on the same stream ..." % (rc, pos, " (padded rows: expected)" if padded else " (UNEXPECTED)"), flush=True)
     want = M.reference_hashes(stream)
@@ -177,8 +181,12 @@ def run_case(seed):
     else:
         bad = np.nonzero(M.row_hash(out) != want)[0]
         res = "ok" if bad.size == 0 else "MISMATCH at step %d (byte %d)" % (bad[0], bad[0] >> 3)
-    return "seed %d  %d bytes  chunks %s  [%s]  %s" % (seed, len(stream), chunks, desc, res)
+    return head + res
 
+
+LATE = "--late" in sys.argv
+if LATE:
+    sys.argv.remove("--late")
 
 if __name__ == "__main__":
     if sys.argv[1] == "--case":
@@ -191,7 +199,7 @@ if __name__ == "__main__":
     while seeds or running:
         while seeds and len(running) < workers:
             s = seeds.pop(0)
-            running[s] = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--case", str(s)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            running[s] = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--case", str(s)] + (["--late"] if LATE else []), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         for s, p in list(running.items()):
             if p.poll() is not None:
                 o, e = p.communicate()
