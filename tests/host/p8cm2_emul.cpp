@@ -1,4 +1,4 @@
-// tests/host/p8cm2_emul.cpp -- TEST INFRASTRUCTURE ONLY. The body of cmx_p8cm2_kernel (cmix_amd/csrc/p8cm2_dev.h) on the
+// tests/host/p8cm2_emul.cpp -- TEST INFRASTRUCTURE ONLY. The step functions of cmx_p8s_cm2v2_kernel (cmix_amd/csrc/p8cm2_dev.h; the stand-alone cmx_p8cm2 kernel is gone since round 3) on the
 // host: same step functions, same construction (p8cm2_build.h), the workgroup replaced by a loop over lanes per barrier
 // step in a seeded shuffled order. Checked against the oracle in tests/test_p8cm2_host.py. Nothing in cmix_amd/ loads it.
 #include <cstdint>

@@ -1,4 +1,4 @@
-// tests/host/p8cm_emul.cpp -- TEST INFRASTRUCTURE ONLY. The body of cmx_p8cm_kernel (cmix_amd/csrc/p8cm_dev.h) on the host:
+// tests/host/p8cm_emul.cpp -- TEST INFRASTRUCTURE ONLY. The step functions of the ContextMap family (cmix_amd/csrc/p8cm_dev.h: first design, used by cmx_p8s_xfam_kernel; p8fam_dev.h: cmx_p8s_fam2_kernel) on the host:
 // same step functions and construction, the workgroup replaced by a loop over lanes per barrier step in a seeded shuffled
 // order. Checked against the oracle in tests/test_p8cm_host.py. Nothing in cmix_amd/ loads it.
 #include <cstdint>

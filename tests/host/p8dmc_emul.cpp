@@ -1,4 +1,4 @@
-// tests/host/p8dmc_emul.cpp -- TEST INFRASTRUCTURE ONLY. The body of cmx_p8dmc_kernel (cmix_amd/csrc/p8dmc_dev.h) on the
+// tests/host/p8dmc_emul.cpp -- TEST INFRASTRUCTURE ONLY. The step functions of cmx_p8s_dmc_kernel (cmix_amd/csrc/p8dmc_dev.h) on the
 // host: same step functions and construction, lanes looped per barrier step in reverse order. Checked against the oracle in
 // tests/test_p8dmc_host.py. Nothing in cmix_amd/ loads it.
 #include <cstdint>

@@ -1,4 +1,4 @@
-"""paq8's ContextMap2 as a device building block, without a GPU: the BODY of cmx_p8cm2_kernel (cmix_amd/csrc/p8cm2_dev.h:
+"""paq8's ContextMap2 as a device building block, without a GPU: the step functions of cmx_p8s_cm2v2_kernel (cmix_amd/csrc/p8cm2_dev.h:
 bucket lists, overlap check, update + mix per context lane) run on the host by tests/host/p8cm2_emul.cpp -- a loop over
 lanes per barrier step in shuffled order -- against the oracle's restatement (oracle/paq8_maps.c, itself pinned against
 the reference's own ContextMap2 class). All 7 inputs of every context for every bit. The same comparison runs on the

@@ -1,4 +1,4 @@
-"""The family of paq8's older ContextMap instances as a device building block, without a GPU: the BODY of cmx_p8cm_kernel
+"""The family of paq8's older ContextMap instances as a device building block, without a GPU: the step functions of the family kernels (cmx_p8s_fam2_kernel, cmx_p8s_xfam_kernel)
 (cmix_amd/csrc/p8cm_dev.h: bucket lists, overlap check, ranked draws of the process-global rnd(), one lane per context)
 run on the host by tests/host/p8cm_emul.cpp -- loops over lanes per barrier step in shuffled order -- against the
 oracle's restatement (oracle/paq8_maps.c, pinned against the reference's own class and generator), stepped instance by

@@ -1,4 +1,4 @@
-"""paq8's DMC forest as a device building block, without a GPU: the BODY of cmx_p8dmc_kernel (cmix_amd/csrc/p8dmc_dev.h:
+"""paq8's DMC forest as a device building block, without a GPU: the step functions of cmx_p8s_dmc_kernel (cmix_amd/csrc/p8dmc_dev.h:
 one lane per state graph, cooperative reset) run on the host by tests/host/p8dmc_emul.cpp against the oracle's restatement
 (oracle/paq8_dmc.c, pinned against the reference's own classes): the 6 mixer inputs of every bit, at level 0 (the graphs
 fill within a few KB and the eight fast models are reset again and again) and at level 5. The same comparison runs on the
