@@ -134,6 +134,7 @@ struct cmx_mixnet {
   int xcd = -1;         // CMX_MIXNET_XCD=k: place the persistent kernel on XCD k (speed only; -1 = wherever block 0 lands)
   bool use_v1 = false;  // CMX_MIXNET_V1=1: run chunks through the bit-synchronous kernel
   bool tolerance = false;   // cmx_mixnet_set_tolerance (opt-in through the API, NOT bit-exact): layer-0 dot products as f64 tree sums rounded once (cmx_mixnet_spec_kernel only)
+  bool seg8 = false;    // the helpers cut the 2078-term chain into eight segments (all eight waves of a helper workgroup) instead of four; CMX_MIXNET_SEG8
   bool use_spec = true; // cmx_mixnet_spec_kernel (26 helper workgroups, speculative segment-parallel chains); CMX_MIXNET_SPEC=0: the one-workgroup kernel
   SpecXfer* d_xfer = nullptr;
   float* d_late_p = nullptr; size_t late_p_cap = 0;   // the decoder's form: the kernel's p[] array (the host reads p from the box)
@@ -305,6 +306,7 @@ cmx_mixnet_t* cmx_mixnet_create(int device) {
   }
   { const char* v = getenv("CMX_MIXNET_V1"); h->use_v1 = v && v[0] == '1'; }
   { const char* v = getenv("CMX_MIXNET_SPEC"); h->use_spec = !(v && v[0] == '0'); }
+  { const char* v = getenv("CMX_MIXNET_SEG8"); h->seg8 = v ? v[0] == '1' : CMX_MIXNET_SEG8_DEFAULT; }
   h->d_xfer = (SpecXfer*)dalloc(sizeof(SpecXfer), true);   // incl. the zero padding of the input ring
   if (!h->d_xfer || hipFuncSetAttribute((const void*)cmx_mixnet_spec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CMX_SPEC_LDS_BYTES) != hipSuccess ||
       hipFuncSetAttribute((const void*)cmx_mixnet_spec_late_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CMX_SPEC_LDS_BYTES) != hipSuccess) {
@@ -472,7 +474,7 @@ static int mixnet_run_impl(cmx_mixnet_t* h, const float* d_probs, const uint32_t
   else if (h->use_spec) {
     // epochs and value|tag words restart at 0 with every launch; 1 main + 26 helper workgroups, co-resident (27 of 256 CUs)
     HIP_OK(hipMemsetAsync(h->d_xfer, 0, CMX_SPEC_HEADER_BYTES, st));
-    const int kmode = 3 | (h->profile ? 4 : 0) | ((h->dbg & 15) << 4) | (h->tolerance ? 0x1000 : 0);
+    const int kmode = 3 | (h->profile ? 4 : 0) | ((h->dbg & 15) << 4) | (h->tolerance ? 0x1000 : 0) | (h->seg8 ? 0x2000 : 0);
     if (box && box->box)   // a decoder's chunk: the patient instantiation of the same roles
       hipLaunchKernelGGL(cmx_mixnet_spec_late_kernel, dim3(1 + CMX_SPEC_HELPERS), dim3(CMX_SPEC_THREADS), CMX_SPEC_LDS_BYTES, st,
                          h->d_state, h->d_xfer, d_probs, d_sel, dd, (int)nbits, d_p_out, d_mix_out, kmode, *box);

@@ -188,13 +188,14 @@ __device__ __forceinline__ float add4(float p, float4 v) {
 // Ordered add chain over one staged segment (n = 512, or 542 for the last one): software-
 // pipelined so the LDS reads of the next 32 terms are in flight while the current 32 are added.
 // A (mixer, segment) row is SEG = 548 floats, so reading float4 128..135 is always in bounds.
-__device__ __forceinline__ float chain_seg(const float* rowp, int n, float p) {
+// NB: whole batches of 32 floats in the segment (16: 512 / 542 terms; 8: 256 / 286 terms, the helpers' eight-wave split)
+template <int NB> __device__ __forceinline__ float chain_seg_n(const float* rowp, int n, float p) {
   const float4* row = reinterpret_cast<const float4*>(__builtin_assume_aligned(rowp, 16));
   float4 a[8], b[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) a[i] = row[i];
 #pragma unroll 1
-  for (int bi = 0; bi < 16; bi += 2) {
+  for (int bi = 0; bi < NB; bi += 2) {
     // sched_barrier(0): nothing may be scheduled across, so the next batch's LDS reads are
     // issued BEFORE the current batch's 32 dependent adds and retire underneath them.
     __builtin_amdgcn_sched_barrier(0);
@@ -205,22 +206,23 @@ __device__ __forceinline__ float chain_seg(const float* rowp, int n, float p) {
     for (int i = 0; i < 8; ++i) p = add4(p, a[i]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) a[i] = row[(bi + 2) * 8 + i];   // bi == 14: the remainder batch
+    for (int i = 0; i < 8; ++i) a[i] = row[(bi + 2) * 8 + i];   // bi == NB - 2: the remainder batch
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 8; ++i) p = add4(p, b[i]);
   }
   __builtin_amdgcn_sched_barrier(0);
-  const int rem4 = (n >> 2) - 128;  // 0 or 7
+  const int rem4 = (n >> 2) - NB * 8;  // 0 or 7
 #pragma unroll
   for (int i = 0; i < 7; ++i)
     if (i < rem4) p = add4(p, a[i]);
-  if (n & 2) {                      // 542 = 135 * 4 + 2
+  if (n & 2) {                      // 542 = 135 * 4 + 2, 286 = 71 * 4 + 2
     p = fadd(p, a[7].x);
     p = fadd(p, a[7].y);
   }
   return p;
 }
+__device__ __forceinline__ float chain_seg(const float* rowp, int n, float p) { return chain_seg_n<16>(rowp, n, p); }
 
 // ------------------------------------------------------------------ scout (wave 2)
 // X != nullptr (cmx_mixnet_spec_kernel): the stretched inputs and the layer-0 rows of the bit are also published to the helper
@@ -1306,11 +1308,11 @@ template <bool LATE> __device__ void tail_b_role(MixState* S, const Lds& L, cons
 //                         -> the sum of bit t goes back to the gather wave.
 // Two global hand-offs per bit (sum, u), 8-byte value|tag words, agent scope.
 struct HelperLds {
-  float prod[4][SEG];          // rounded products of the four segments (each read back as broadcast float4s by its own wave)
-  double segsum[4];            // f64 sum of a segment's products
-  float res[4];                // exact running sum after segment w
-  int sum_epoch[4];            // bit + 1 for which segsum[w] is valid
-  int res_epoch[4];            // bit + 1 for which res[w] is valid
+  float prod[8][SEG];          // rounded products of the (four or eight) segments (each read back as broadcast float4s by its own wave)
+  double segsum[8];            // f64 sum of a segment's products
+  float res[8];                // exact running sum after segment w
+  int sum_epoch[8];            // bit + 1 for which segsum[w] is valid
+  int res_epoch[8];            // bit + 1 for which res[w] is valid
   int abort;
 };
 
@@ -1342,15 +1344,18 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
-template <bool LATE> __device__ void helper_role(MixState* S, SpecXfer* X, HelperLds* H, int nbits, int m, int w, int lane, bool tol, CmxLateBox* LB) {
+template <bool LATE, int NW> __device__ void helper_role(MixState* S, SpecXfer* X, HelperLds* H, int nbits, int m, int w, int lane, bool tol, CmxLateBox* LB) {
   const gptr<float> rows0 = as_global(S->rows0);
-  const int base = 512 * w;                 // first element of this wave's segment
-  const int nseg = w == 3 ? CMX_IN0 - 1536 : 512;
-  const bool tailk = w == 3 && lane < 30;   // k == 8: elements 2048 + lane (lane < 30)
+  // NW waves cut the 2078-term chain: 4 x 512 (+ 30) or 8 x 256 (+ 30) terms. Shorter segments: a shorter chain and a cheaper re-run on a
+  // miss (two thirds of the bits re-run a segment in at least one helper, profiles/r04_spec_chain_per_bit_study.txt), more hops to resolve.
+  constexpr int SEGN = 2048 / NW, KS = SEGN / 64, LASTW = NW - 1;
+  const int base = SEGN * w;                // first element of this wave's segment
+  const int nseg = w == LASTW ? CMX_IN0 - SEGN * LASTW : SEGN;
+  const bool tailk = w == LASTW && lane < 30;   // slot KS: elements 2048 + lane (lane < 30)
   const float cdec = 1.0f - 3.0e-6f;
-  float W[9], Wn[9], xc[9], xp[9];
+  float W[KS + 1], Wn[KS + 1], xc[KS + 1], xp[KS + 1];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) { W[k] = 0.0f; Wn[k] = 0.0f; xc[k] = 0.0f; xp[k] = 0.0f; }
+  for (int k = 0; k < KS + 1; ++k) { W[k] = 0.0f; Wn[k] = 0.0f; xc[k] = 0.0f; xp[k] = 0.0f; }
   unsigned long long n_spec = 0, n_hit = 0, n_miss = 0;
   uint32_t cur_base = 0;
   bool f_chg = false; uint32_t f_base = 0;   // of the bit fetched last: its selector changes, and to which row (read off the serial path)
@@ -1370,15 +1375,15 @@ template <bool LATE> __device__ void helper_role(MixState* S, SpecXfer* X, Helpe
     const int slot = t % CMX_SPEC_RING;
     const float* gx = X->xs[slot] + base;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) xc[k] = ld_f32(gx + 64 * k + lane);
-    xc[8] = tailk ? ld_f32(gx + 512 + lane) : 0.0f;
+    for (int k = 0; k < KS; ++k) xc[k] = ld_f32(gx + 64 * k + lane);
+    xc[KS] = tailk ? ld_f32(gx + SEGN + lane) : 0.0f;
     f_chg = ld_u32(&X->changed[slot][m]) != 0;
     if (f_chg) {
       const uint32_t nb = ((uint32_t)m * CMX_ROWS_PER_MIXER + ld_u32(&X->rowidx[slot][m])) * CMX_ROW0_STRIDE + (uint32_t)base;
       f_base = nb;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) Wn[k] = rows0[nb + 64 * k + lane];
-      Wn[8] = tailk ? rows0[nb + 512 + lane] : 0.0f;
+      for (int k = 0; k < KS; ++k) Wn[k] = rows0[nb + 64 * k + lane];
+      Wn[KS] = tailk ? rows0[nb + SEGN + lane] : 0.0f;
     }
     return true;
   };
@@ -1396,7 +1401,7 @@ template <bool LATE> __device__ void helper_role(MixState* S, SpecXfer* X, Helpe
       const float u = __int_as_float((int)(unsigned)v);
       const bool df = ((v >> 32) & 1ull) != 0;
 #pragma unroll
-      for (int k = 0; k < 9; ++k) {          // mixer.cpp:66-71; xp = the inputs of bit t-1
+      for (int k = 0; k < KS + 1; ++k) {          // mixer.cpp:66-71; xp = the inputs of bit t-1
         W[k] = fsub(W[k], fmul(u, xp[k]));
         if (df) W[k] = fmul(W[k], cdec);
       }
@@ -1405,13 +1410,13 @@ template <bool LATE> __device__ void helper_role(MixState* S, SpecXfer* X, Helpe
     if (chg) {                               // outgoing row to HBM (16 B per 4 lanes: 64 consecutive floats per k), incoming row is in Wn
       if (t > 0) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) rows0[cur_base + 64 * k + lane] = W[k];
-        if (tailk) rows0[cur_base + 512 + lane] = W[8];
+        for (int k = 0; k < KS; ++k) rows0[cur_base + 64 * k + lane] = W[k];
+        if (tailk) rows0[cur_base + SEGN + lane] = W[KS];
       }
       if (live) {
         cur_base = f_base;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) W[k] = Wn[k];
+        for (int k = 0; k < KS + 1; ++k) W[k] = Wn[k];
       }
     }
     if (!live) break;
@@ -1419,22 +1424,22 @@ template <bool LATE> __device__ void helper_role(MixState* S, SpecXfer* X, Helpe
     float* pr = H->prod[w];
     double ds = 0.0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { const float p = fmul(xc[k], W[k]); pr[64 * k + lane] = p; ds += (double)p; }
-    if (w == 3) { const float p = tailk ? fmul(xc[8], W[8]) : 0.0f; if (lane < 36) pr[512 + lane] = p; ds += (double)p; }   // 542..547: zero pad read by chain_seg
+    for (int k = 0; k < KS; ++k) { const float p = fmul(xc[k], W[k]); pr[64 * k + lane] = p; ds += (double)p; }
+    if (w == LASTW) { const float p = tailk ? fmul(xc[KS], W[KS]) : 0.0f; if (lane < 36) pr[SEGN + lane] = p; ds += (double)p; }   // nseg .. nseg + 5: zero pad read by chain_seg_n
 #pragma unroll
-    for (int k = 0; k < 9; ++k) xp[k] = xc[k];
+    for (int k = 0; k < KS + 1; ++k) xp[k] = xc[k];
     if (tol) {
       // TOLERANCE MODE (opt-in, cmx_mixnet_set_tolerance; NOT bit-exact): the dot product as a tree sum -- every wave reduces its segment's products in
       // f64 across its lanes, the last wave adds the four segment sums and rounds once. No ordered chain, no speculation. The value differs from the
       // reference's sequentially rounded f32 sum in the last bits (it is the more accurate one); streams coded with it are not the reference's.
       ds = wave_sum_f64(ds);
-      if (w < 3) {
+      if (w < LASTW) {
         if (lane == 0) H->segsum[w] = ds;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane == 0) lds_publish_store(&H->sum_epoch[w], t + 1);
       } else {
         double tot = 0.0;
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < LASTW; ++q) {
           unsigned spins = 0;
           while (lds_poll(&H->sum_epoch[q]) < t + 1)
             if ((++spins & 1023u) == 0 && (spins > SPEC_SPIN || failed())) { give_up(); return; }
@@ -1446,7 +1451,7 @@ template <bool LATE> __device__ void helper_role(MixState* S, SpecXfer* X, Helpe
       if (t + 1 < nbits && !fetch(t + 1)) return;
       continue;
     }
-    if (w < 3) {                             // the later waves centre their candidates on the sum of what precedes them
+    if (w < LASTW) {                         // the later waves centre their candidates on the sum of what precedes them
       ds = wave_sum_f64(ds);
       if (lane == 0) H->segsum[w] = ds;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1466,7 +1471,7 @@ template <bool LATE> __device__ void helper_role(MixState* S, SpecXfer* X, Helpe
       }
       start = ord2f(f2ord((float)est) + lane - 32);
     }
-    float r = chain_seg(pr, nseg, start);
+    float r = chain_seg_n<NW == 4 ? 16 : 8>(pr, nseg, start);
     // ---- resolve against the true start ----
     if (w > 0) {
       unsigned spins = 0;
@@ -1479,11 +1484,11 @@ template <bool LATE> __device__ void helper_role(MixState* S, SpecXfer* X, Helpe
         r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), (int)__builtin_amdgcn_readfirstlane(__ffsll((long long)hit) - 1)));
         ++n_hit;
       } else {
-        r = chain_seg(pr, nseg, s);          // outside the candidates: the serial path
+        r = chain_seg_n<NW == 4 ? 16 : 8>(pr, nseg, s);          // outside the candidates: the serial path
         ++n_miss;
       }
     }
-    if (w < 3) {
+    if (w < LASTW) {
       if (lane == 0) H->res[w] = r;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (lane == 0) lds_publish_store(&H->res_epoch[w], t + 1);
@@ -1495,7 +1500,7 @@ template <bool LATE> __device__ void helper_role(MixState* S, SpecXfer* X, Helpe
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (lane == 0 && w > 0) {
-    atomicAdd(&X->stat[0], n_spec); atomicAdd(&X->stat[1], n_hit); atomicAdd(&X->stat[1 + w], n_miss);
+    atomicAdd(&X->stat[0], n_spec); atomicAdd(&X->stat[1], n_hit); atomicAdd(&X->stat[NW == 4 ? 1 + w : 2 + (w - 1) / 3], n_miss);   // ([2..4]: re-runs of segment 1, 2, 3 -- with eight waves of segments 1-3, 4-6, 7)
   }
 }
 
@@ -1845,7 +1850,8 @@ template <bool LATE> __device__ __forceinline__ void spec_kernel_body(
     HelperLds* H = reinterpret_cast<HelperLds*>(smem);
     for (int i = tid; i < (int)(sizeof(HelperLds) / 4); i += CMX_SPEC_THREADS) reinterpret_cast<int*>(H)[i] = 0;
     __syncthreads();
-    if (wave < 4) helper_role<LATE>(S, X, H, nbits, (int)blockIdx.x - 1, wave, lane, (mode & 0x1000) != 0, LATE ? box.box : nullptr);
+    if (mode & 0x2000) helper_role<LATE, 8>(S, X, H, nbits, (int)blockIdx.x - 1, wave, lane, (mode & 0x1000) != 0, LATE ? box.box : nullptr);   // all eight waves
+    else if (wave < 4) helper_role<LATE, 4>(S, X, H, nbits, (int)blockIdx.x - 1, wave, lane, (mode & 0x1000) != 0, LATE ? box.box : nullptr);
     return;
   }
   Lds L;

@@ -76,7 +76,8 @@ struct MixState {
 #define CMX_SPEC_RING 8        /* bits the scout may publish ahead (it is held to 2 ahead of the gather wave) */
 #define CMX_SPEC_XS 2112       /* stretched inputs of a bit, zero padded (2078 used) */
 #define CMX_SPEC_HELPERS CMX_MIX0
-#define CMX_SPEC_THREADS 512      /* main: gather, tail, select, -, 4 stretch waves; helpers use the first four */
+#define CMX_SPEC_THREADS 512      /* main: gather, tail, select, -, 4 stretch waves; helpers use the first four, or all eight (CMX_MIXNET_SEG8) */
+#define CMX_MIXNET_SEG8_DEFAULT false   /* the helpers' eight-segment split: opt-in (CMX_MIXNET_SEG8=1) until it has been measured in the pipeline */
 struct SpecXfer {
   unsigned scout_epoch;        // bits whose inputs / rows the scout has published
   unsigned fail;               // sticky: a bounded in-launch wait ran out

@@ -59,7 +59,8 @@ void spec_probe(const void* mixer, const float* in, const float* w, int n_in) {
   const int S = g_nseg;
   int edge[MAXSEG + 1];
   for (int k = 0; k <= S; ++k) edge[k] = (int)((long)n_in * k / S);
-  if (S == 4) { edge[1] = 512; edge[2] = 1024; edge[3] = 1536; }   /* as the helper workgroups cut the chain (mixnet_chunk.hip helper_role) */
+  if (S == 4) { edge[1] = 512; edge[2] = 1024; edge[3] = 1536; }
+  if (S == 8) for (int k = 1; k < 8; ++k) edge[k] = 256 * k;   /* as the helper workgroups cut the chain (mixnet_chunk.hip helper_role) */
   /* true starts and f64 prefix data */
   float s = 0; double d = 0, dmax = 0;
   int all[NSCHEME]; for (int c = 0; c < NSCHEME; ++c) all[c] = 1;
