@@ -334,7 +334,7 @@ int cmx_ppmd_run(cmx_ppmd_t*, const uint8_t* bytes, size_t nbytes, float* out_pr
  *   CMX_MIXNET_SPEC=0      the one-workgroup mixing-network kernel (1 compute unit per stream instead of 27: many streams per GPU)
  *   CMX_MIXNET_SEG8=1      the mixing network's helper workgroups cut the ordered chain into eight segments instead of four (bit-exact either way;
  *                          measured slower on synthetic inputs, kept for measurements in the pipeline)
- *   (tolerance mode is NOT an environment switch: cmx_mixnet_set_tolerance / cmx_lstm_set_tolerance / cmx_pipeline_set_tolerance, above --
+ *   (tolerance mode is NOT an environment switch: cmx_mixnet_set_tolerance / cmx_lstm_set_tolerance / cmx_pipeline_set_tolerance --
  *    no program that writes files turns it on)
  *   CMX_P8CM_SERIAL        1: paq8's table families walk every instance serially (A/B timing); 2: the ContextMap family's narrowed walk takes
  *                          its whole-instance fall-back at every second visit (test switch)
