@@ -3,7 +3,7 @@
 # bench line (1 MiB rich shard, verified against the reference binary's file, CPU reference beside it), rocprofv3 kernel stats and the
 # HBM-traffic counters of the bench command (one counter per pass, PMC + kernel-trace only), the decoder's time per bit.
 # Outputs under gpurun_out/<tag>/; the summaries that are judged are copied to profiles/<rNN>_* by hand.
-# CMX_SKIP_TESTS=1 skips the suite; CMX_SKIP_PMC=1 the counter passes.
+# CMX_SKIP_TESTS=1 skips the suite; CMX_SKIP_PMC=1 the counter passes; CMX_AB="VAR=1 ..." adds one 256 KB bench run per opt-in variant.
 cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
 R="${GRAFT_REPO_ROOT:-/root/repo}"
 TAG="${1:-measure}"
@@ -18,6 +18,11 @@ timeout 600 python bench.py > $O/bench_1m.json 2> $O/bench_1m.err; cut -c1-400 $
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -o pipe -- python $R/bench.py --payload-bytes 262144 --steps 8 --warmup 1 --no-cpu-baseline > $R/$O/prof_bench_256k.json 2> $R/$O/prof.err )
 for f in $(find $O/prof -name '*kernel_stats*.csv'); do grep -v "at::native\|rocclr" $f | head -30 > $O/bench_256k_kernel_stats.csv; done
 cut -c1-160 $O/bench_256k_kernel_stats.csv | head -12
+# A/B of opt-in kernel variants in the pipeline (256 KB, no CPU baseline): CMX_AB="CMX_MIXNET_SEG8=1 ..." (one variable assignment per variant)
+for v in $CMX_AB; do
+  ( export "$v"; timeout 200 python bench.py --payload-bytes 262144 --steps 5 --warmup 1 --no-cpu-baseline > "$O/bench_256k_$v.json" 2> "$O/bench_256k_$v.err" )
+  python -c "import json,sys; d=json.load(open(sys.argv[1])); print(sys.argv[2], d['value'], d['stage_us_per_bit'])" "$O/bench_256k_$v.json" "$v" 2>&1 | cut -c1-300
+done
 if [ "$CMX_SKIP_PMC" != "1" ]; then
 for c in FETCH_SIZE WRITE_SIZE; do
 ( cd /tmp && timeout -k 5 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$O/pmc -o pmc_$c -- python $R/bench.py --payload-bytes 131072 --steps 4 --warmup 1 --no-cpu-baseline > $R/$O/pmc_$c.out 2> $R/$O/pmc_$c.err ; echo "rocprofv3 $c rc=$?" )
