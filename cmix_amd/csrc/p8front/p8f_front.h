@@ -10,7 +10,7 @@
 extern "C" {
 #endif
 typedef struct P8Front P8Front;
-enum { P8F_ERR_IMAGE_BLOCK = -1, P8F_ERR_JPEG = -2, P8F_ERR_BMP = -3, P8F_ERR_TGA = -4, P8F_ERR_WAV = -5, P8F_ERR_IMAGE_PADDING = -6, P8F_ERR_IMAGE_LATE = -7, P8F_ERR_INTERNAL = -9 };
+enum { P8F_ERR_IMAGE_BLOCK = -1, P8F_ERR_JPEG = -2, P8F_ERR_BMP = -3, P8F_ERR_TGA = -4, P8F_ERR_WAV = -5, P8F_ERR_IMAGE_PADDING = -6, P8F_ERR_IMAGE_LATE = -7, P8F_ERR_MODEL_IN_TEXT = -8, P8F_ERR_INTERNAL = -9 };
 
 P8Front* p8f_front_new(int level);                 /* cmix runs paq8 at level 11 (reference src/models/paq8.cpp:8368, paq8.h) */
 void p8f_front_free(P8Front* f);

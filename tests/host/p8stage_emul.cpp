@@ -397,6 +397,7 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
     else if (md) {   // a model's step: its inputs in add() order through the model's map (p8_rec.h), fewer weight sets
       const P8XLayout& X = L.xl[md - 1];
       nx = c.apm[t].c[8];
+      if (nx < 0 || nx > P8_NX || c.apm[t].model != md) { fprintf(stderr, "p8stage_emul: step %zu (byte %zu of the chunk, stream step %llu): model %d, record says model %d with %d inputs\n", t, t >> 3, (unsigned long long)g, md, (int)c.apm[t].model, nx); return -98; }
       const int skip = c.apm[t].c[7] ? X.opt_n : 0;   // the model's own ContextMap is silent this byte: its inputs are not there
       const int skp = c.apm[t].c[7] == 1 ? skip : 0;
       for (int i = 0; i < nx; i++) xs[i] = xr[X.map[(skp && i >= X.opt_lo) ? i + skp : i]];

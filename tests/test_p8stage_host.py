@@ -219,3 +219,20 @@ def test_decoders_order_of_operations_on_media_streams(name, nbytes):
     got, _ = run_stage(stream[:nbytes], chunks=[512, 77, 300], late=3)
     bad = np.nonzero(row_hash(got) != want[:8 * nbytes])[0]
     assert bad.size == 0, (name, "first differing step:", bad[0], "of", 8 * nbytes)
+
+
+def test_model_step_inside_a_text_block_is_refused():
+    """Audio (or a 1- / 4-bit image, or JPEG) data that paq8's own detectors find INSIDE A TEXT BLOCK ends in the text chain of final APM stages
+    (paq8.cpp:8281-8296), which a step of a model with tables of its own does not run here: the front end refuses the stream (P8F_ERR_MODEL_IN_TEXT,
+    -8) instead of coding it differently. The same data in a DEFAULT block is the fixtures' case and is bit-exact."""
+    from make_paq8_hashes import wav_file
+    from cmix_amd import synth
+    text = synth.enwik_like(900, 21)
+    L = emul()
+    for framing, want in ((mg.text_block, -8), (mg.default_block, 0)):
+        data = np.ascontiguousarray(np.frombuffer(bytes(framing(text[:400] + wav_file(300, 1, 8, 3) + text[400:700])), np.uint8))
+        h = L.p8s_create(11)
+        out = np.zeros((8 * len(data), 1591), np.float32)
+        rc = L.p8s_run(h, data.ctypes.data, len(data), out.ctypes.data)
+        L.p8s_destroy(h)
+        assert rc == want, (framing.__name__, rc)
