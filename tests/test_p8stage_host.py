@@ -236,3 +236,26 @@ def test_model_step_inside_a_text_block_is_refused():
         rc = L.p8s_run(h, data.ctypes.data, len(data), out.ctypes.data)
         L.p8s_destroy(h)
         assert rc == want, (framing.__name__, rc)
+
+
+@pytest.mark.skipif(os.environ.get("CMX_LONG") != "1", reason="168 KB through the host emulation: about two minutes (CMX_LONG=1); the device test runs it always")
+def test_big_media_stream_digests():
+    """tests/golden/make_paq8_big_media.py: 168 KB of images, audio and a JPEG at sizes where a model's segment runs through many chunks -- every
+    256 steps' digest of the 1591 values against the unmodified reference's."""
+    from make_paq8_hashes import row_hash
+    from make_paq8_big_media import digest
+    with np.load(os.path.join(ROOT, "tests", "golden", "paq8_big_media_168k.npz")) as z:
+        stream, want = z["stream"].copy(), z["digest"].copy()
+    L = emul()
+    h = L.p8s_create(11)
+    hashes = np.zeros(8 * len(stream), np.uint32)
+    pos = 0
+    while pos < len(stream):
+        n = min(4096, len(stream) - pos)
+        out = np.zeros((8 * n, 1591), np.float32)
+        assert L.p8s_run(h, stream[pos:].ctypes.data, n, out.ctypes.data) == 0
+        hashes[8 * pos:8 * (pos + n)] = row_hash(out)
+        pos += n
+    L.p8s_destroy(h)
+    bad = np.nonzero(digest(hashes) != want)[0]
+    assert bad.size == 0, ("first differing block of 256 steps:", bad[0], "of", len(want))
