@@ -26,7 +26,8 @@ def digest(h):
         return (v.reshape(n, STEPS) * w).sum(axis=1, dtype=np.uint64)
 
 
-def stream():
+def payload():
+    """the file itself (what `cmix -c` is given: tests/golden/make_dropin_media.py)"""
     import make_paq8_hashes as M
     from cmix_amd import synth
     t = synth.enwik_like(3000, 77)
@@ -34,7 +35,13 @@ def stream():
              M.jpeg_file(M.photo(320, 240, 3, 103), quality=75), t[1300:1500], b"P5\n200 150\n255\n" + M.photo(200, 150, 1, 104)[:, :, 0].tobytes(), t[1700:1900],
              M.bmp4_file((M.photo(256, 128, 1, 105)[:, :, 0] >> 4).astype(np.uint8), np.random.default_rng(106).integers(0, 256, (16, 3))), t[2100:2300],
              M.bmp8_file(M.photo(120, 90, 1, 107)[:, :, 0], np.random.default_rng(108).integers(0, 256, (256, 3))), t[2500:2700]]
-    return bytes(M.preprocessed(b"".join(parts)))
+    return b"".join(parts)
+
+
+def stream():
+    """what the reference's preprocessor hands the predictor for it"""
+    import make_paq8_hashes as M
+    return bytes(M.preprocessed(payload()))
 
 
 if __name__ == "__main__":
