@@ -319,22 +319,6 @@ def test_dropin_engine_file_with_a_16bit_stereo_wav_is_byte_identical():
     assert _run("-c", [("in", payload)], exe=DROPIN, timeout=600) == blob
 
 
-def test_dropin_engine_file_with_168k_of_media_is_byte_identical():
-    """tests/golden/make_dropin_media.py: a 160 x 120 24-bit BMP (the preprocessor's IMAGE24 block: 57 KB, the image model's kernels launched for fourteen
-    consecutive chunks), a 40 KB 16-bit stereo WAV, a 320 x 240 JPEG, a 200 x 150 PGM, 4- and 8-bit BMPs between short pieces of text -- every stage of the
-    engine on media at scale. The file the unmodified reference binary wrote (10 minutes of its time). Written after round 4's GPU time was spent:
-    the paq8 stage's values on this stream are pinned on the host emulation (tests/test_p8stage_host.py::test_big_media_stream_digests)."""
-    if not os.path.exists(DROPIN):
-        _missing("oracle/_ref/cmix_dropin not built")
-    fx = os.path.join(GOLDEN, "dropin_media_168k.npz")
-    if not os.path.exists(fx):
-        _missing("tests/golden/dropin_media_168k.npz missing (make_dropin_media.py)")
-    with np.load(fx) as z:
-        payload, blob = z["payload"].tobytes(), z["cmix_file"].tobytes()
-    got = _run("-c", [("in", payload)], exe=DROPIN, timeout=900)
-    assert len(got) == len(blob) and got == blob, ("sizes", len(got), len(blob))
-
-
 def test_dropin_engine_file_with_a_jpeg_is_byte_identical():
     """text + a 128 x 96 4:2:0 baseline JPEG + text (tests/golden/make_dropin_jpeg.py): the reference's detector makes a JPEG block of the picture; paq8's
     jpegModel (marker parser + Huffman decoder on the host, its tables / own mixer / APM stages on the device) codes it. The reference binary's file."""

@@ -94,27 +94,3 @@ def test_serial_walk_paths_on_device(monkeypatch):
     got = run_device(g["stream"], [9, 50])
     want = np.ascontiguousarray(probs[:, 434:2025])
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
-
-
-def test_big_media_stream_digests():
-    """tests/golden/make_paq8_big_media.py: 168 KB of media as the reference's preprocessor frames them -- a 57 KB IMAGE24 block (the image model's
-    segment runs through fourteen 4 KB chunks: the model's family, lanes and mixer kernels launched chunk after chunk with their state in memory in
-    between), a 40 KB WAV, a JPEG, a PGM block, 4- and 8-bit BMPs. One digest per 256 steps of the 1591 values against the unmodified reference's."""
-    import torch
-    from cmix_amd import engine as E
-    from make_paq8_hashes import row_hash
-    from make_paq8_big_media import digest
-    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "paq8_big_media_168k.npz")) as z:
-        stream, want = bytes(z["stream"]), z["digest"].copy()
-    st = E.P8Stage(0)
-    hashes = np.zeros(8 * len(stream), np.uint32)
-    pos = 0
-    while pos < len(stream):
-        n = min(4096, len(stream) - pos)
-        o = st.run(stream[pos:pos + n])
-        st.sync()
-        hashes[8 * pos:8 * (pos + n)] = row_hash(o.cpu().numpy())
-        pos += n
-    st.close()
-    bad = np.nonzero(digest(hashes) != want)[0]
-    assert bad.size == 0, ("first differing block of 256 steps:", bad[0], "of", len(want))
