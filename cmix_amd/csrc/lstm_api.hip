@@ -16,13 +16,14 @@
 #include <vector>
 
 #include "../../include/cmix_amd.h"
+#include "mixnet_state.h"   // CMX_MIXNET_XCD_DEFAULT: the XCD the block kernels leave to the mixing network
 #include "lstm_state.h"
 #include "cmx_late.h"
 #include "cmx_late.h"
 #include "cmx_glibc_rand.h"
 
 extern "C" __global__ void cmx_lstm_prep(const LstmState, const float*, const uint8_t*, size_t, int, int);
-extern "C" __global__ void cmx_lstm_bptt_acc(const LstmState, int, int);
+extern "C" __global__ void cmx_lstm_bptt_acc(const LstmState, int, int, int, int);
 extern "C" __global__ void cmx_lstm_bptt_gb(const LstmState, int, int);
 extern "C" __global__ void cmx_lstm_bptt_acc_mfma(const LstmState, int, int);
 extern "C" __global__ void cmx_lstm_fwdblk(const LstmState, const uint8_t*, const float*, float*, size_t, int, int, int);
@@ -88,6 +89,8 @@ cmx_lstm_t* cmx_lstm_create(const uint8_t vocab[256], int skip_rand, int device)
   S.rowlen[1] = S.insz[1] + V;
   S.lr = 0.03f;
   { const char* v = getenv("CMX_LSTM_XCD"); S.xcd = v ? atoi(v) : -1; }
+  { const char* v = getenv("CMX_LSTM_SLEEP"); S.poll_sleep = v && v[0] == '1'; }
+  { const char* v = getenv("CMX_LSTM_AVOID_XCD"); if (!v) v = getenv("CMX_MIXNET_XCD"); S.avoid_xcd = v ? atoi(v) : CMX_MIXNET_XCD_DEFAULT; if (S.avoid_xcd > 7) S.avoid_xcd = -1; }   // the mixing network's XCD (mixnet_state.h)
   bool fail = false;
   auto dallocf = [&](size_t count, const float* init) -> float* {
     void* p = nullptr;
@@ -238,15 +241,15 @@ int cmx_lstm_run(cmx_lstm_t* h, const float* d_in_probs, const uint8_t* d_bytes,
     if (e == 0) {                                // lstm.cpp:93
       hipLaunchKernelGGL(cmx_lstm_prep, dim3(1), dim3(256), 0, st, S, d_in_probs + n * 256, d_bytes, n, e, -1);
       if (!sync_reset()) { cmx_set_err("cmx_lstm_run: hipMemsetAsync failed"); return 1; }
-      hipLaunchKernelGGL(cmx_lstm_bpttblk, dim3(LSTM_BP_G), dim3(LSTM_BP_THREADS), h->bp_lds, st, S);
+      hipLaunchKernelGGL(cmx_lstm_bpttblk, dim3(lstm_grid_for_roles(LSTM_BP_G, S.avoid_xcd)), dim3(LSTM_BP_THREADS), h->bp_lds, st, S);
       if (h->tolerance) hipLaunchKernelGGL(cmx_lstm_bptt_acc_mfma, dim3((S.rowlen[1] + 15) / 16, (LSTM_C + 15) / 16, 6), dim3(64), 0, st, S, us, -1);
-      else hipLaunchKernelGGL(cmx_lstm_bptt_acc, dim3((S.rowlen[1] + 63) / 64, LSTM_C / 4, 6), dim3(64, 4), 0, st, S, us, -1);
+      else { const int gx = (S.rowlen[1] + 63) / 64, gy = LSTM_C / 4; hipLaunchKernelGGL(cmx_lstm_bptt_acc, dim3(lstm_grid_for_roles(gx * gy * 6, S.avoid_xcd)), dim3(64, 4), 0, st, S, us, -1, gx, gy); }
       hipLaunchKernelGGL(cmx_lstm_bptt_gb, dim3(6), dim3(256), 0, st, S, us, -1);
     }
     const size_t left = nbytes - n;
     const int cnt = (int)(left < (size_t)(LSTM_H - e) ? left : (size_t)(LSTM_H - e));
     if (!sync_reset()) { cmx_set_err("cmx_lstm_run: hipMemsetAsync failed"); return 1; }
-    hipLaunchKernelGGL(cmx_lstm_fwdblk, dim3(2 * LSTM_FB_GL + LSTM_FB_GO), dim3(LSTM_FB_THREADS), h->fb_lds, st, S, d_bytes,
+    hipLaunchKernelGGL(cmx_lstm_fwdblk, dim3(lstm_grid_for_roles(2 * LSTM_FB_GL + LSTM_FB_GO, S.avoid_xcd)), dim3(LSTM_FB_THREADS), h->fb_lds, st, S, d_bytes,
                        d_in_probs, d_out_probs, n, cnt, e, hc);
     h->hc ^= 1;
     h->bytes_done += cnt;

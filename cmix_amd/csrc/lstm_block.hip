@@ -51,10 +51,11 @@ __device__ __forceinline__ void st_f(float* p, float v) { __hip_atomic_store(p, 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // lane 0 polls the counter, the workgroup waits at the barrier
-__device__ __forceinline__ void wg_wait(const unsigned* p, unsigned want, unsigned* fail) {
+__device__ __forceinline__ void wg_wait(const unsigned* p, unsigned want, unsigned* fail, int sleepy) {
   if (threadIdx.x == 0) {
     unsigned it = 0;
     while (ld_u(p) < want) {
+      if (sleepy) __builtin_amdgcn_s_sleep(1);   // A/B (CMX_LSTM_SLEEP): a poll every ~64 clocks instead of back to back
       if ((++it & 1023u) == 0 && (it > SPIN_LIMIT || ld_u(fail))) {
         __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
@@ -128,7 +129,7 @@ __device__ __forceinline__ void fb_finish_layer(const LstmState* S, int layer, i
                                                 float* xh, float& st) {
   const int tid = threadIdx.x;
   LstmSync* Y = S->sync;
-  wg_wait(&Y->raw_cnt[layer][e], GL, &Y->fail);
+  wg_wait(&Y->raw_cnt[layer][e], GL, &Y->fail, S->poll_sleep);
   const float* rr = S->raw_ring + ((size_t)layer * H + e) * (3 * C);
   for (int idx = tid; idx < 3 * C; idx += FT) rawl[idx] = ld_f(rr + idx);
   lds_barrier();
@@ -230,7 +231,7 @@ __device__ void fb_gate_wg(const LstmState* S, const FbArgs& A, int layer, int w
     if (lead && tid < C) li[V + tid] = xv[V + tid];   // keep the assembled vector for BPTT
     if (tid < 64) f = lds_chain(f, Wl, R, r, xv, V, V + C);
     if (layer == 1) {  // layer 0's new hidden (lstm.cpp:127-131)
-      wg_wait(&Y->h_flag[0][e], 1, &Y->fail);
+      wg_wait(&Y->h_flag[0][e], 1, &Y->fail, S->poll_sleep);
       if (tid < C) {
         const float h = ld_f(&S->h_ring[(size_t)e * NH + tid]);
         xv[V + C + tid] = h;
@@ -314,12 +315,12 @@ __device__ void fb_out_wg(const LstmState* S, const FbArgs& A, int w, float* lds
       }
       OLs[(size_t)q * RP + rr] = v;
     }
-    wg_wait(&Y->h_flag[0][e], 1, &Y->fail);
+    wg_wait(&Y->h_flag[0][e], 1, &Y->fail, S->poll_sleep);
     if (tid < C) hcur[tid] = ld_f(&S->h_ring[(size_t)e * NH + tid]);
     lds_barrier();
     float sum = 0.0f;
     if (tid < 64) sum = lds_chain(sum, OLs, RP, r, hcur, 0, C);
-    wg_wait(&Y->h_flag[1][e], 1, &Y->fail);
+    wg_wait(&Y->h_flag[1][e], 1, &Y->fail, S->poll_sleep);
     if (tid < C) hcur[C + tid] = ld_f(&S->h_ring[(size_t)e * NH + C + tid]);
     if (tid == 0) hcur[2 * C] = 1.0f;   // bias element of hidden_ (lstm.cpp:18)
     lds_barrier();
@@ -328,7 +329,7 @@ __device__ void fb_out_wg(const LstmState* S, const FbArgs& A, int w, float* lds
       if (tid < nr) st_f(&S->logit_ring[(size_t)e * VP + i0 + tid], sum);
       wave_signal(&Y->logit_cnt[e]);
     }
-    wg_wait(&Y->logit_cnt[e], GO, &Y->fail);
+    wg_wait(&Y->logit_cnt[e], GO, &Y->fail, S->poll_sleep);
     float lg = 0.0f;
     if (tid < V) lg = ld_f(&S->logit_ring[(size_t)e * VP + tid]);
     red[tid] = tid < V ? lg : 0.0f;   // max_out starts at 0 (lstm.cpp:132)
@@ -373,7 +374,8 @@ extern "C" __global__ __launch_bounds__(LSTM_FB_THREADS) void cmx_lstm_fwdblk(co
   extern __shared__ float4 fb_lds[];
   FbArgs A;
   A.bytes = bytes; A.in_probs = in_probs; A.out_probs = out_probs; A.n0 = n0; A.cnt = cnt; A.e0 = e0; A.hc = hc;
-  const int b = blockIdx.x;
+  const int b = lstm_role_of_block((int)blockIdx.x, P.avoid_xcd);
+  if (b < 0 || b >= 2 * GL + GO) return;
   if (b < GL) fb_gate_wg(&P, A, 0, b, reinterpret_cast<float*>(fb_lds));
   else if (b < 2 * GL) fb_gate_wg(&P, A, 1, b - GL, reinterpret_cast<float*>(fb_lds));
   else fb_out_wg(&P, A, b - 2 * GL, reinterpret_cast<float*>(fb_lds));
@@ -400,7 +402,8 @@ extern "C" __global__ __launch_bounds__(LSTM_BP_THREADS) void cmx_lstm_bpttblk(c
   extern __shared__ float4 bp_lds[];
   const LstmState* S = &P;
   LstmSync* Y = S->sync;
-  const int tid = threadIdx.x, V = S->V, b = blockIdx.x, j0 = b * J;
+  const int tid = threadIdx.x, V = S->V, b = lstm_role_of_block((int)blockIdx.x, P.avoid_xcd), j0 = b * J;
+  if (b < 0 || b >= GB) return;
   const bool lead = b == 0;
   // LDS
   float4* Wb = bp_lds;                                   // [9 slots][50 quads of j][J] : W[l][g][j][2V + kind*C + j0 + cl]
@@ -504,7 +507,7 @@ extern "C" __global__ __launch_bounds__(LSTM_BP_THREADS) void cmx_lstm_bpttblk(c
     lds_barrier();   // slice s+2 is in LDS
     // the next step's chain does not depend on this step when it starts from zero (layer 0 leaves hidden_error_ = 0)
     if (layer == 0 && s + 1 < 2 * H && tid < 64) hpre = p1_chain(s + 1, 0.0f);
-    wg_wait(&Y->bp_cnt[s], GB, &Y->fail);
+    wg_wait(&Y->bp_cnt[s], GB, &Y->fail, S->poll_sleep);
     if (tid < C) {
       const float h = ld_f(pub + (size_t)s * 2 * C + tid);
       if (s > 0) stored_o = ld_f(pub + (size_t)s * 2 * C + C + tid);   // the previous step's layer

@@ -61,20 +61,25 @@ extern "C" __global__ void cmx_lstm_prep(const LstmState P, const float* in256, 
 
 // ---- BPTT sweep: update_[i][c] accumulated over epochs 99..0 (lstm-layer.cpp:182-186) held in a
 //      register, then Adam (lstm-layer.cpp:11-32) and both weight layouts rewritten.
-//      grid (ceil(rowlen/64), 50, 6): blockIdx.z = layer*3 + gate; block (64, 4) = 64 columns x 4 rows.
-extern "C" __global__ void cmx_lstm_bptt_acc(const LstmState P, int update_steps, int k) {
+//      roles (ceil(rowlen/64), 50, 6): z = layer*3 + gate; block (64, 4) = 64 columns x 4 rows.
+extern "C" __global__ void cmx_lstm_bptt_acc(const LstmState P, int update_steps, int k, int gx, int gy) {
   const LstmState* S = &P;
   if (k >= 0) update_steps = P.blk->us;
   __shared__ float es[H][4];
   __shared__ float ins[H][64];
   __shared__ unsigned sym[H];
-  const int layer = blockIdx.z / 3, g = blockIdx.z % 3;
+  // launched as a 1-D grid of gx * gy * 6 roles (+ padding when one XCD is left to the mixing network, LstmState::avoid_xcd: a tile on that XCD would
+  // share its compute units with 27 spinning workgroups and hold the whole sweep up -- 0.10 -> 0.89 ms, profiles/r05_kernel_stats_xcd7.csv)
+  const int role = lstm_role_of_block((int)blockIdx.x, P.avoid_xcd);
+  if (role < 0 || role >= gx * gy * 6) return;
+  const int bx = role % gx, by = (role / gx) % gy, bz = role / (gx * gy);
+  const int layer = bz / 3, g = bz % 3;
   const int V = S->V, rl = S->rowlen[layer], insz = S->insz[layer];
-  const int c = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
+  const int c = bx * 64 + threadIdx.x, i = by * 4 + threadIdx.y;
   const int t = threadIdx.y * 64 + threadIdx.x;
-  for (int k = t; k < H * 4; k += 256) es[k >> 2][k & 3] = S->E[layer][g][(size_t)(k >> 2) * C + blockIdx.y * 4 + (k & 3)];
+  for (int k = t; k < H * 4; k += 256) es[k >> 2][k & 3] = S->E[layer][g][(size_t)(k >> 2) * C + by * 4 + (k & 3)];
   for (int k = t; k < H * 64; k += 256) {
-    int ee = k >> 6, cc = blockIdx.x * 64 + (k & 63);
+    int ee = k >> 6, cc = bx * 64 + (k & 63);
     ins[ee][k & 63] = (cc >= V && cc < rl) ? S->layer_input[layer][(size_t)ee * insz + (cc - V)] : 0.0f;
   }
   if (t < H) sym[t] = S->bp_symbol[t];

@@ -54,6 +54,9 @@ struct LstmState {
   unsigned char vocab[256];
   float lr;                      // 0.03
   int xcd;                       // >= 0: the single-workgroup kernels run as block `xcd` of 8 (XCD placement, speed only)
+  int poll_sleep;                // A/B switch (CMX_LSTM_SLEEP=1): s_sleep 1 between two polls of an in-launch counter
+  int avoid_xcd;                 // >= 0: the block kernels leave this XCD to the mixing network (CMX_MIXNET_XCD: its 27 workgroups share that XCD's L2) --
+                                 //   the grids are padded and the blocks with blockIdx % 8 == avoid_xcd exit (observed: block b runs on XCD b % 8; speed only)
 
   // gate parameters, g = 0 forget, 1 input node, 2 output gate
   float* W[LSTM_L][3];           // [C][rowlen]   reference layout (coalesced for the BPTT matvecs)
@@ -95,6 +98,22 @@ struct LstmState {
 // lane's four consecutive terms are one 16-byte load: [d/4][i][4]; the insz%4 trailing columns are
 // stored [d][i] again. (dword loads left the CU's L2->L1 path at ~1/3 of its rate.)
 #if defined(__HIPCC__) || defined(__cplusplus)
+// grid size and role of a block when one XCD is left out: roles 0 .. n-1 go to the blocks whose index is not congruent to `avoid` modulo 8
+static inline
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+int lstm_role_of_block(int b, int avoid) {   // -1: the block has no role
+  if (avoid < 0) return b;
+  if ((b & 7) == avoid) return -1;
+  return b - (b >= avoid ? (b - avoid) / 8 + 1 : 0);
+}
+static inline int lstm_grid_for_roles(int n, int avoid) {
+  if (avoid < 0) return n;
+  int g = n;
+  while (lstm_role_of_block(g - 1, avoid) < n - 1) ++g;
+  return g;
+}
 static inline
 #if defined(__HIPCC__)
 __host__ __device__

@@ -262,6 +262,15 @@ class MixNet:
             raise CmxError(last_error())
         return v.value
 
+    def helper_phases(self):
+        """Profiling launches: shader clocks per phase of the four waves of helper 12 (16-segment form), [wave][phase]."""
+        out = (C.c_uint64 * 32)()
+        lib().cmx_mixnet_helper_phases.argtypes = [C.c_void_p, C.c_void_p]
+        if lib().cmx_mixnet_helper_phases(self.h, out):
+            raise CmxError(last_error())
+        v = list(out)
+        return [v[8 * w:8 * w + 8] for w in range(4)]
+
     def spec_stats(self):
         """Speculative segment-parallel chain (cmx_mixnet_spec_kernel): segments run, resolved from a candidate, re-runs of segment 1..3."""
         out = (C.c_uint64 * 5)()

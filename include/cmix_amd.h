@@ -159,6 +159,10 @@ int cmx_mixnet_last_kernel_ms(cmx_mixnet_t*, float* ms);
  * start holds the reference's result, otherwise the segment is re-run). Statistics since creation: out[0] speculative segments,
  * [1] resolved from a candidate, [2..4] re-runs of segment 1 / 2 / 3. Synchronises the device. */
 int cmx_mixnet_spec_stats(cmx_mixnet_t*, uint64_t out[5]);
+/* Diagnostics of the helpers' 16-segment form (CMX_MIXNET_SEG16, mixnet_chunk.hip helper_dpp_role) in profiling launches: shader clocks per phase of
+ * the four waves of helper 12 since creation, out[8 w + k]: k = 0 wait u, 1 update + products + segment sums, 2 wait the earlier waves' sums,
+ * 3 candidates + chain, 4 wait the true start, 5 resolve (+ re-runs) + publish, 6 fetch of the next bit. Synchronises the device. */
+int cmx_mixnet_helper_phases(cmx_mixnet_t*, uint64_t out[32]);
 
 /* ------------------------------------------------------------------------
  * 2b. Stage: byte-level LSTM byte mixer = ByteMixer + Lstm + LstmLayer + its ByteModel bit
