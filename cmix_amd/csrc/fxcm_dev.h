@@ -42,13 +42,45 @@ enum { FX_THREADS = 256, FX_BMASK = 0xffffff,
        FX_M_WGS = 2, FX_M_WAVES = 16,   // role M of the device stage: workgroups x 8 wavefronts, each wavefront owns whole maps
        FX_TAB_RC1 = 0, FX_TAB_ST1 = 512, FX_TAB_ST2 = 512 + 4096, FX_TAB_ST32 = 512 + 8192, FX_TAB_ST8 = 512 + 8192 + 256, FX_TAB_LEN = 512 + 8192 + 512 };
 
+// Pointer members of the stream's device structures. The kernels work on an LDS COPY of FxDev, so every table pointer is itself loaded from memory and
+// the compiler cannot know where it points: each access through it became a FLAT instruction, which waits for the LDS counter AND for every outstanding
+// global load and store of the wavefront (444 of them in cmx_fxcm_roles_kernel in round 4). These wrappers keep the 8-byte layout the host fills in
+// and, on the device, hand the pointer out through an address-space cast: FxGP = device-global memory, FxLP = the workgroup's LDS (the tables the
+// kernel copies there at its start). Host code (fxcm_build.h, tests/host) sees plain pointers; `.p` is the raw value.
+template <class T> struct FxGP {
+  T* p;
+  FX_HD FxGP& operator=(T* q) { p = q; return *this; }
+  FX_HD operator T*() const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __attribute__((address_space(1))) T* q = (__attribute__((address_space(1))) T*)p;
+    asm("" : "+v"(q));   // (opaque: a bare cast there and back is folded away and the access stays flat)
+    return (T*)q;
+#else
+    return p;
+#endif
+  }
+};
+template <class T> struct FxLP {
+  T* p;
+  FX_HD FxLP& operator=(T* q) { p = q; return *this; }
+  FX_HD operator T*() const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __attribute__((address_space(3))) T* q = (__attribute__((address_space(3))) T*)p;
+    asm("" : "+v"(q));
+    return (T*)q;
+#else
+    return p;
+#endif
+  }
+};
+
 struct FxMapDev {
-  uint8_t* t; uint32_t tmask;          // buckets
+  FxGP<uint8_t> t; uint32_t tmask;     // buckets
   int A, B, C, kep, u;                 // slots per bucket, bytes per bucket, contexts, keep flag, st2 input on/off
   int slot_base, tx_off, exp_off;      // first slot in FxByteRec::cx; first input / first exported value (normal layout)
-  const uint8_t* nn;                   // state table: next state on 0 / on 1, n0, n1
-  const int16_t* tab;                  // rc1[512] st1[4096] st2[4096] st32[256] st8[256]
-  uint32_t* sm;                        // C StateMaps of 256 cells
+  FxLP<const uint8_t> nn;              // state table: next state on 0 / on 1, n0, n1 (on the device: the kernel's LDS copy, FxDev::sta)
+  FxGP<const int16_t> tab;             // rc1[512] st1[4096] st2[4096] st32[256] st8[256]
+  FxGP<uint32_t> sm;                   // C StateMaps of 256 cells
   uint32_t cp[8], cp0[8], runp[8], cxt[8];
   int sm_cxt[8];
 };
@@ -60,17 +92,17 @@ struct FxDev {                         // everything a stream owns on the device
   uint8_t slot_map[FX_NSLOTS], slot_idx[FX_NSLOTS];   // slot -> map (mixing order), context index within the map
   int slot_parallel;                   // 1: one lane per context slot with a per-map serial fallback; 0: one lane per map
   uint8_t mw_slot[FX_M_WAVES + 1], mw_map[FX_M_WAVES + 1];   // role M's wavefront w owns slots [mw_slot[w], mw_slot[w + 1]) = maps [mw_map[w], mw_map[w + 1])
-  const int16_t *squash, *stretch;     // squash[d + 2047], stretch[p]
-  const uint8_t* wrt;                  // byte -> 2-bit class [256], 3-bit class [256] of cmix's WRT-swapped alphabet
+  FxLP<const int16_t> squash, stretch; // squash[d + 2047], stretch[p]   (on the device: LDS copies)
+  FxLP<const uint8_t> wrt;             // byte -> 2-bit class [256], 3-bit class [256] of cmix's WRT-swapped alphabet
   const uint8_t* sta[6];               // the six state tables the maps' nn pointers refer to (the kernel keeps copies in LDS)
-  uint16_t* sscm_data[FX_NSSCM]; int sscm_mask[FX_NSSCM], sscm_ctx[FX_NSSCM], sscm_B[FX_NSSCM], sscm_bcount[FX_NSSCM], sscm_cp[FX_NSSCM];
-  uint32_t* sm1_t[3]; int sm1_mask[3], sm1_cxt[3];
-  uint8_t* rcm_t; uint32_t rcm_n, rcm_cp; int16_t rcm_rc[512];
-  FxMatchInfo cand[4]; uint32_t nActive; uint32_t* mhash; uint32_t mhashmask;
-  uint32_t* sp_table; FxMtf sp_list; uint32_t sp_hashes[4], sp_hashIndex, sp_length, sp_index; uint8_t sp_expectedByte, sp_valid;
-  uint8_t* buffer; int pos;
-  int16_t* wx[12]; int mx_M[12], mx_shift[12], mx_uperr[12];
-  uint16_t* apm_t[6];
+  FxGP<uint16_t> sscm_data[FX_NSSCM]; int sscm_mask[FX_NSSCM], sscm_ctx[FX_NSSCM], sscm_B[FX_NSSCM], sscm_bcount[FX_NSSCM], sscm_cp[FX_NSSCM];
+  FxGP<uint32_t> sm1_t[3]; int sm1_mask[3], sm1_cxt[3];
+  FxGP<uint8_t> rcm_t; uint32_t rcm_n, rcm_cp; int16_t rcm_rc[512];
+  FxMatchInfo cand[4]; uint32_t nActive; FxGP<uint32_t> mhash; uint32_t mhashmask;
+  FxGP<uint32_t> sp_table; FxMtf sp_list; uint32_t sp_hashes[4], sp_hashIndex, sp_length, sp_index; uint8_t sp_expectedByte, sp_valid;
+  FxGP<uint8_t> buffer; int pos;
+  FxGP<int16_t> wx[12]; int mx_M[12], mx_shift[12], mx_uperr[12];
+  FxGP<uint16_t> apm_t[6];
   // scalars carried between chunks (copied to / from FxShared by thread 0)
   int mx_elim[12], mx_cxt[12], mx_pr[12], apm_index[6];
   int blpos, lastbyte, pr, parity, have_rec;
@@ -527,7 +559,7 @@ FX_HD void fxd_sscm_unit(FxDev* d, FxShared* sh, const FxBit& u, int j) {
 
 // ---------------------------------------------------------------- RunContextMap :756-829
 FX_HD uint32_t fxd_rcm_find(FxDev* d, uint32_t i) {  // offset of byte 1 of the element; 4-byte elements, 4-way probe, move to front
-  uint32_t* t = (uint32_t*)d->rcm_t;
+  uint32_t* t = (uint32_t*)(uint8_t*)d->rcm_t;
   const uint32_t chk = ((i >> 16) ^ i) & 0xffff;
   i = (i * 4) & d->rcm_n;
   int j;

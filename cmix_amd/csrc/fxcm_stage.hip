@@ -89,7 +89,7 @@ __device__ __forceinline__ void fx_fail_next(const FxShared* sh, const FxBit& u,
   if (pr >= 848) ++z;
   *fails = f; *failz = z; *failcount = c;
 }
-__device__ __forceinline__ void fx_phase2a_dev(FxDev* d, FxShared* sh, const FxBit& u) {
+__device__ __forceinline__ void fx_phase2a_dev(FxDev* d, FxShared* sh, const FxBit& u, int is_match = -1) {   // is_match >= 0: the value (the caller fetched it from role U's row itself)
   if (u.boundary)
     for (int i = 0; i < FX_NMIX1; i++)
       sh->mx_elim[i] = (sh->fails & 255) == 0 ? fxd_max(256, sh->mx_elim[i] + 1) : fxd_max(0, fxd_min(16, sh->mx_elim[i] - 1));
@@ -99,7 +99,7 @@ __device__ __forceinline__ void fx_phase2a_dev(FxDev* d, FxShared* sh, const FxB
   const FxByteRec* r = u.rec;
   const int bpos = u.bpos, c0b = u.c0 << (8 - bpos);
   const uint32_t s2 = r->s2, s3 = r->s3, s3R = r->s3R, BrFc = r->BrFc, words = r->words, FcIdx = r->FcIdx, isPar = r->isPar;
-  const uint32_t isMatch = (uint32_t)sh->isMatch;
+  const uint32_t isMatch = (uint32_t)(is_match >= 0 ? is_match : sh->isMatch);
   const uint8_t* w2b = d->wrt;
   const uint8_t* w3b = w2b + 256;
   int* cx = sh->mx_cxt;
@@ -187,9 +187,28 @@ __device__ __forceinline__ void fx_phase3_dots(FxDev* d, FxShared* sh, const FxB
 // two, the six APMs as a three-level tree (0, 1, 2 | 3, 4 | 5) reading the context rows a lane of wave 7 fetched into LDS
 // during phase 1a -- every APM context is known when the bit starts (c0, the parser's hashes, the failure history).
 struct FxApmRows { uint32_t cx[6]; uint16_t row[6][34]; };
-__device__ __forceinline__ void fx_apm_ctx(const FxShared* sh, const FxBit& u, uint32_t cx[6]) {   // update1 :4792-4826
+// combo >= 0: the APM contexts of an update whose final probability is not known yet -- it enters only through two comparisons (fx_fail_next: pr >= e_l[bpos],
+// pr >= 848; every e_l is above 848), so there are three cases: combo 0 = neither, 1 = only the second, 2 = both. A compressor's role X computes all three for the
+// NEXT update on idle lanes while phase 5 of this one runs, and picks one when the probability is there.
+__device__ __forceinline__ int fx_fail_combo(const FxShared* sh, const FxBit& u) {
+  const int bp_ = u.bpos;
+  const int e_lo = bp_ & 2 ? (bp_ & 1 ? 1851 : 1973) : (bp_ & 1 ? 1997 : 1830), e_hi = bp_ & 2 ? (bp_ & 1 ? 1842 : 1998) : (bp_ & 1 ? 1690 : 1897);
+  const int e_l_bpos = bp_ & 4 ? e_hi : e_lo;
+  int pr = sh->pr;
+  if (u.y) pr = 4095 - pr;
+  return pr >= e_l_bpos ? 2 : pr >= 848 ? 1 : 0;
+}
+__device__ __forceinline__ void fx_apm_ctx(const FxShared* sh, const FxBit& u, uint32_t cx[6], int combo = -1) {   // update1 :4792-4826
   uint32_t fails, failz, failcount;
-  fx_fail_next(sh, u, &fails, &failz, &failcount);
+  if (combo < 0) fx_fail_next(sh, u, &fails, &failz, &failcount);
+  else {
+    uint32_t f = sh->fails, z = sh->failz, c = sh->failcount;
+    if (f & 0x00000080) --c;
+    f *= 2; z *= 2;
+    if (combo == 2) { ++f; ++c; }
+    if (combo >= 1) ++z;
+    fails = f; failz = z; failcount = c;
+  }
   // tri[4] = {0, 4, 3, 7}, trj[4] = {0, 6, 6, 12} as arithmetic (no table in constant memory)
   const FxByteRec* r = u.rec;
   const uint32_t c0 = (uint32_t)u.c0;
@@ -218,13 +237,33 @@ __device__ __forceinline__ void fx_apm_prefetch(FxDev* d, const FxShared* sh, co
   for (int q = 0; q < 33; q++) A->row[j][q] = v[q];
   A->cx[j] = cxj;
 }
+// the same in two halves, spread over a whole wavefront: the six row numbers by six lanes (into LDS), then lane l fetches elements l, l + 64, .. of the 6 x 33
+// (four loads per lane instead of 33 on six lanes) into registers early in the bit; the commit (registers -> LDS) comes just before phase 5 needs the rows,
+// so the wave that fetches does not hold the workgroup's barriers up
+struct FxApmRegs { uint16_t v[4]; };
+__device__ __forceinline__ void fx_apm_issue(FxDev* d, const uint32_t* apmcx, FxApmRegs* R, int lane) {
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int idx = lane + 64 * r;
+    if (idx < 6 * 33) { const int j = idx / 33, q = idx - 33 * j; R->v[r] = (d->apm_t[j] + (size_t)apmcx[j] * 33)[q]; }
+  }
+}
+__device__ __forceinline__ void fx_apm_commit(FxApmRows* A, const uint32_t* apmcx, const FxApmRegs* R, int lane) {
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int idx = lane + 64 * r;
+    if (idx < 6 * 33) { const int j = idx / 33, q = idx - 33 * j; A->row[j][q] = R->v[r]; }
+  }
+  if (lane < 6) A->cx[lane] = apmcx[lane];
+}
 __device__ __forceinline__ int fx_apm_row_p(const FxDev* d, FxShared* sh, const FxApmRows* A, int j, int pr) {   // fxd_apm_p on the fetched row
   pr = d->stretch[pr];
   const int w = pr & 127, i = (pr + 2048) >> 7;
   sh->apm_index[j] = i + (int)A->cx[j] * 33;
   return (A->row[j][i] * (128 - w) + A->row[j][i + 1] * w) >> 11;
 }
-__device__ __forceinline__ void fx_phase5_dev(FxDev* d, FxShared* sh, const FxBit& u, const FxApmRows* A, int lane, int* scr) {   // wave 0; scr: 16 ints of LDS
+// msw / mscx != nullptr (round 5): the selected rows of the final mixers 10 / 11 in LDS (16 weights each) -- trained there at the top of the next bit
+__device__ __forceinline__ void fx_phase5_dev(FxDev* d, FxShared* sh, const FxBit& u, const FxApmRows* A, int lane, int* scr, int16_t* msw = nullptr, int* mscx = nullptr) {   // wave 0; scr: 16 ints of LDS
   const FxLayout l = fxd_layout(d, u.normal);
   float* ex = u.orow + l.exp_mix;
   if (lane < FX_NMIX1) {   // p1 :641-651, mxInputs2.add
@@ -240,15 +279,18 @@ __device__ __forceinline__ void fx_phase5_dev(FxDev* d, FxShared* sh, const FxBi
   if (lane == 10) sh->in2[10] = (int16_t)(d->stretch[u.lstmpr] / 2);
   __builtin_amdgcn_s_waitcnt(0xC07F);
   __builtin_amdgcn_wave_barrier();
+  if (msw && lane == 0) *(volatile int*)&scr[12] = u.q + 1;   // mx_pr[0..9] of this bit are in place (the next update's mixer errors are computed from them, fx_roles_body)
   if (lane < 2) {
     const int k = 10 + lane;
-    int dp = (int32_t)((uint32_t)fxd_dot16(sh->in2, d->wx[k] + (size_t)sh->mx_cxt[k] * 16) * (uint32_t)d->mx_shift[k]) >> 11;
+    const int16_t* wrow = msw ? msw + 16 * lane : d->wx[k] + (size_t)sh->mx_cxt[k] * 16;
+    int dp = (int32_t)((uint32_t)fxd_dot16(sh->in2, wrow) * (uint32_t)d->mx_shift[k]) >> 11;
     dp = fxd_clp(dp);
     sh->mx_pr[k] = fxd_squash(d, dp);
     scr[lane] = dp;
   }
   __builtin_amdgcn_s_waitcnt(0xC07F);
   __builtin_amdgcn_wave_barrier();
+  if (msw && lane == 0) *(volatile int*)&scr[13] = u.q + 1;   // mx_pr[10..11] as well
   const int pr = fxd_squash(d, (scr[0] * 7 + scr[1] + 4) >> 3);
   // level 1: APM 0, 1, 2 on pr
   if (lane < 3) scr[4 + lane] = fx_apm_row_p(d, sh, A, lane, pr);
@@ -271,7 +313,7 @@ __device__ __forceinline__ void fx_phase5_dev(FxDev* d, FxShared* sh, const FxBi
   else fin = (pt * 4 + pu * 5 + pv * 12 + pz * 11 + 31) >> 5;
   EXPV(fin);
 #undef EXPV
-  while (ex < u.orow + FX_OUTPUTS) *ex++ = 0.5f;   // slots no AddPrediction reaches keep the constructor's 0.5 (:94)
+  if (!u.normal || !msw) while (ex < u.orow + FX_OUTPUTS) *ex++ = 0.5f;   // slots no AddPrediction reaches keep the constructor's 0.5 (:94); (msw: a compressor's role X fills them once per chunk)
   sh->pr = fin;
   sh->parity ^= 1;
 }
@@ -380,13 +422,13 @@ __device__ __forceinline__ void fx_roles_body(FxDev* gd, FxXfer* X, unsigned* ro
   const int role = (int)blockIdx.x < FX_M_WGS ? 0 : (int)blockIdx.x - FX_M_WGS + 1, mwg = blockIdx.x;   // 0 = M (FX_M_WGS workgroups), 1 = U, 2 = X
   // ---- every role starts from the stream's state (it uses its own part of it) ----
   for (int i = tid; i < (int)(sizeof(FxDev) / 4); i += FX_DEV_THREADS) ((uint32_t*)d)[i] = ((const uint32_t*)gd)[i];
-  for (int i = tid; i < 4095; i += FX_DEV_THREADS) loc.squash[i] = gd->squash[i];
-  for (int i = tid; i < 4096; i += FX_DEV_THREADS) loc.stretch[i] = gd->stretch[i];
-  for (int i = tid; i < 512; i += FX_DEV_THREADS) loc.wrt[i] = gd->wrt[i];
+  for (int i = tid; i < 4095; i += FX_DEV_THREADS) loc.squash[i] = gd->squash.p[i];
+  for (int i = tid; i < 4096; i += FX_DEV_THREADS) loc.stretch[i] = gd->stretch.p[i];
+  for (int i = tid; i < 512; i += FX_DEV_THREADS) loc.wrt[i] = gd->wrt.p[i];
   for (int i = tid; i < 6 * 1024; i += FX_DEV_THREADS) loc.sta[i >> 10][i & 1023] = gd->sta[i >> 10][i & 1023];
   __syncthreads();
   if (tid == 0) { d->squash = loc.squash; d->stretch = loc.stretch; d->wrt = loc.wrt; }
-  if (tid < FX_NMAPS) for (int q = 0; q < 6; q++) if (gd->maps[tid].nn == gd->sta[q]) d->maps[tid].nn = loc.sta[q];
+  if (tid < FX_NMAPS) for (int q = 0; q < 6; q++) if (gd->maps[tid].nn.p == gd->sta[q]) d->maps[tid].nn = loc.sta[q];
   const int nbits = 8 * n, blpos0 = d->blpos, lastbyte0 = d->lastbyte, have0 = d->have_rec;
   if (tid < FX_THREADS) fxd_load_shared(d, &sh, tid);
   if (role == 2) for (int i = tid; i < FX_OUTPUTS; i += FX_DEV_THREADS) out[i] = gd->pending[i];   // row 0: what the previous chunk's last update left
@@ -403,6 +445,30 @@ __device__ __forceinline__ void fx_roles_body(FxDev* gd, FxXfer* X, unsigned* ro
   unsigned have_row = 0;
   if (LATE && role == 2 && tid == 0) late_publish(LB, LC_FX, 1u);   // row 0 (above) is in place
   unsigned late_part = 0;   // LATE: the bits of the byte in force decoded so far (kept by the wavefront that stages them)
+  // a compressor's role X (round 5): the first-layer rows are trained by the threads that own their words (registers, below); the final mixers' two 16-weight
+  // rows in LDS (msw, row numbers mscx); merr = fxd_mixer_err of the update, computed once per bit
+  __shared__ int mscx[2], merr[12];
+  __shared__ uint32_t apmcx[6], apmspec[3][6];
+  __shared__ __attribute__((aligned(16))) int16_t msw[32];
+  unsigned long long wtop = 0, wp3 = 0, w7[3] = {0, 0, 0};   // profiling: per-wave clocks of role X's top block / phase 3
+  FxApmRegs xapm;
+  bool xapm_ok = false;   // loc.apm holds the rows phase 5 of the previous bit read
+  uint32_t xw[FX_NMIX1], xt = 0;           // the thread's words of the ten selected rows as the last dot products used them, its pair of the inputs they met
+  int xcn[FX_NMIX1];                       // the numbers of those rows in their tables
+#pragma unroll
+  for (int k = 0; k < FX_NMIX1; k++) { xw[k] = 0; xcn[k] = 0; }
+  if (!LATE && role == 2) {
+    if (tid < FX_THREADS) {
+      xt = reinterpret_cast<const uint32_t*>(sh.tx[sh.parity])[tid];
+#pragma unroll
+      for (int k = 0; k < FX_NMIX1; k++) { xcn[k] = sh.mx_cxt[k]; xw[k] = reinterpret_cast<const uint32_t*>(d->wx[k] + (size_t)xcn[k] * FX_TX)[tid]; }
+    }
+    if (tid < 32) msw[tid] = (d->wx[10 + (tid >> 4)] + (size_t)sh.mx_cxt[10 + (tid >> 4)] * 16)[tid & 15];
+    if (tid < 2) mscx[tid] = sh.mx_cxt[10 + tid];
+    if (tid >= 64 && tid < 76) { const FxBit u0 = fx_bit_dev(d, &ah, &loc, 0, blpos0, lastbyte0, have0); merr[tid - 64] = fxd_mixer_err(&sh, d, u0, tid - 64); }   // the first update's errors
+    for (int i = ln.exp_mix + FX_NMIX1 + 7 + tid; i < FX_OUTPUTS; i += FX_DEV_THREADS) { loc.ex[0][i] = 0.5f; loc.ex[1][i] = 0.5f; }   // the slots behind the last export keep 0.5 (fx_phase5_dev)
+    __syncthreads();
+  }
   if (role == 0) {
     // ================= role M: the context maps, one free-running wavefront per group of maps =================
     // Nothing a map learns depends on another map or on role X, and the coded bits are the chunk's bytes: every wavefront owns whole maps
@@ -509,7 +575,7 @@ __device__ __forceinline__ void fx_roles_body(FxDev* gd, FxXfer* X, unsigned* ro
     FxBit u = fx_bit_dev(d, &ah, &loc, q, blpos0, lastbyte0, have0);
     float* const real_row = q + 1 < nbits ? out + (long)(q + 1) * ostride : gd->pending;
     unsigned* const row = rows + (size_t)q * FX_ROW_WORDS;
-    const FxLayout l = fxd_layout(d, u.normal);
+    const FxLayout l = u.normal ? ln : fxd_layout(d, 0);
     if (role == 1) {
       // ================= role U: match models, SSCMs, run map, LSTM input =================
       u.orow = loc.ex[0];
@@ -544,6 +610,67 @@ __device__ __forceinline__ void fx_roles_body(FxDev* gd, FxXfer* X, unsigned* ro
     } else {
       // ================= role X: trainers, selectors, mixers, APM chain =================
       u.orow = loc.ex[q & 1];
+      const unsigned long long wt0 = (prof && lane == 0) ? __builtin_readcyclecounter() : 0ull;
+      if (!LATE) {   // what learns from the coded bit needs nothing of this bit's rows: it runs under the wait for them
+        if (tid < FX_THREADS) {   // thread t OWNS word t (two weights) of every first-layer row: it trains the words it used in the last dot products (registers), stores them
+          // without a wait and reloads them in phase 3 -- a word is only ever loaded and stored by its owner, in order, so nothing has to be drained (see below)
+          int e[FX_NMIX1];
+#pragma unroll
+          for (int k = 0; k < FX_NMIX1; k++) e[k] = merr[k];
+#pragma unroll
+          for (int k = 0; k < FX_NMIX1; k++)
+            if (e[k]) { xw[k] = fx_pair_train(xt, xw[k], (int)(int16_t)e[k]); reinterpret_cast<uint32_t*>(d->wx[k] + (size_t)xcn[k] * FX_TX)[tid] = xw[k]; }
+        } else if (wave == 6) {
+          if (lane < 32) {   // fxd_train_small on the LDS copy of the selected rows: lane 16 j + i OWNS weight i of final mixer 10 + j (in the table as well)
+            const int j = lane >> 4, i = lane & 15;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int err = merr[10 + j];
+            if (err) {
+              const int16_t w = fxd_train1(sh.in2[i], msw[lane], (int16_t)err);
+              msw[lane] = w;
+              (d->wx[10 + j] + (size_t)mscx[j] * 16)[i] = w;
+            }
+          }
+        } else if (wave == 7) {
+          unsigned long long w7a = 0, w7b = 0;
+          if (lane < 6) {   // fxd_apm_update with the two cells taken from the row in LDS: this wave fetched it after its own last store, nobody else writes the table
+            const int j = lane, rate = j == 0 ? 3 : j == 1 ? u.rate + 1 : u.rate;
+            const int idx = sh.apm_index[j];
+            if (xapm_ok) {
+              const int i = idx - (int)loc.apm.cx[j] * 33;
+              const int g = (u.y << 16) + (u.y << rate) - u.y * 2;
+              const int t0 = loc.apm.row[j][i], t1 = loc.apm.row[j][i + 1];
+              uint16_t* t = d->apm_t[j] + idx;
+              t[0] = (uint16_t)(t0 + ((g - t0) >> rate));
+              t[1] = (uint16_t)(t1 + ((g - t1) >> rate));
+            } else fxd_apm_update(d, &sh, u, lane);   // the chunk's first update: the row of the previous chunk's last bit is not in LDS
+            if (prof && lane == 0) w7a = __builtin_readcyclecounter();
+            if (xapm_ok) apmcx[j] = apmspec[fx_fail_combo(&sh, u)][j];   // computed for the three possible outcomes under the previous bit's phase 5
+            else {
+              uint32_t cx[6];
+              fx_apm_ctx(&sh, u, cx);
+              apmcx[j] = j == 0 ? cx[0] : j == 1 ? cx[1] : j == 2 ? cx[2] : j == 3 ? cx[3] : j == 4 ? cx[4] : cx[5];
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the row numbers are in LDS; the cell stores above and the fetches below are the same wave's: performed in order)
+          __builtin_amdgcn_wave_barrier();
+          if (prof && lane == 0) w7b = __builtin_readcyclecounter();
+          fx_apm_issue(d, apmcx, &xapm, lane);
+          if (prof && lane == 0) { const unsigned long long w7c = __builtin_readcyclecounter(); w7[0] += w7a - wt0; w7[1] += w7b - w7a; w7[2] += w7c - w7b; }
+        }
+        else if (wave == 5) fx_stage_ahead(&ah, &loc, bytes, recs, lstmpr, lstmex, n, q, lane);
+        xapm_ok = true;
+      }
+      if (prof && lane == 0 && role == 2) wtop += __builtin_readcyclecounter() - wt0;   // this wave's share of the top block (before the wait for the rows)
+      if (!LATE) {   // one lane per row counter (role M's wavefronts, role U) on wave 4, which has nothing else to do up here; the value the poll returned is kept
+        if (wave == 4 && lane <= FX_M_WAVES && have_row < (unsigned)(q + 1)) {
+          unsigned* const c = lane < FX_M_WAVES ? &X->mw_done[lane] : &X->u_done;
+          unsigned it = 0, v;
+          while ((v = fx_ld_u(c)) < (unsigned)(q + 1))
+            if ((++it & 4095u) == 0 && (it > (unsigned)FX_ROLE_SPIN || fx_ld_u(&X->fail))) { fx_st_u(&X->fail, 1u); break; }
+          have_row = v;
+        }
+      } else
       if (tid <= FX_M_WAVES && have_row < (unsigned)(q + 1)) {   // one lane per row counter: role M's wavefronts, role U
         unsigned* const c = tid < FX_M_WAVES ? &X->mw_done[tid] : &X->u_done;
         fx_wait_ge(c, (unsigned)(q + 1), &X->fail);
@@ -572,24 +699,81 @@ __device__ __forceinline__ void fx_roles_body(FxDev* gd, FxXfer* X, unsigned* ro
         } else if (tid == FX_THREADS + 13) sh.isMatch = (int)fx_ld_u(row + FX_ROW_MATCH);
         else if (tid >= FX_THREADS + 16 && tid < FX_THREADS + 24) res8_s[tid - FX_THREADS - 16] = (int)fx_ld_u(row + FX_ROW_RES + (tid - FX_THREADS - 16));
       }
+      if (!LATE) {
+        // phase 2 (the selectors) in the same interval as the gather: its two lanes fetch the nine words of the row they need themselves
+        if (tid == 64) {
+          int r8[8];
+#pragma unroll
+          for (int i = 0; i < 8; i++) r8[i] = (int)fx_ld_u(row + FX_ROW_RES + i);
+          sh.isMatch = (int)fx_ld_u(row + FX_ROW_MATCH);
+#pragma unroll
+          for (int i = 0; i < 8; i++) res8_s[i] = r8[i];
+          fx_phase2b_tail(d, &sh, u, res8_s);
+        } else if (tid == 320) {
+          const int im = (int)fx_ld_u(row + FX_ROW_MATCH);
+          fx_phase2a_dev(d, &sh, u, im);
+        }
+        FX_TICK(2);
+        fx_lds_barrier();   // (an LDS barrier: nothing stored to the tables in this bit is read from them in this bit)
+      } else {
       if (wave == 2 || wave == 3) fx_train_rows_fast(d, &sh, u, tid - 128);
       else if (wave == 6) { if (lane == 2 || lane == 3) fxd_train_small(d, &sh, u, 10 + lane - 2); }
       else if (wave == 7) { if (lane < 6) { fxd_apm_update(d, &sh, u, lane); fx_apm_prefetch(d, &sh, u, &loc.apm, lane); } }
-      else if (!LATE && wave == 5) fx_stage_ahead(&ah, &loc, bytes, recs, lstmpr, lstmex, n, q, lane);
       FX_TICK(2);
       // the full barrier of the bit: the trained rows and APM cells are stored before phase 3 / 5 read them
       __syncthreads();
+      }
       FX_TICK(3);
-      if (tid == 0) fx_phase2b_tail(d, &sh, u, res8_s);
-      else if (tid == 256) fx_phase2a_dev(d, &sh, u);
-      fx_lds_barrier();
+      if (LATE) {
+        if (tid == 0) fx_phase2b_tail(d, &sh, u, res8_s);
+        else if (tid == 256) fx_phase2a_dev(d, &sh, u);
+        fx_lds_barrier();
+      }
       FX_TICK(4);
-      if (tid < FX_THREADS) fx_phase3_dots(d, &sh, u, tid);
+      const unsigned long long wt3 = (prof && lane == 0) ? __builtin_readcyclecounter() : 0ull;
+      if (!LATE) {
+        if (tid < FX_THREADS) {   // phase 3: the ten selected rows' words from the table (each by its owner: what it stored above comes back, in order), the pair products
+          const uint32_t t = reinterpret_cast<const uint32_t*>(sh.tx[sh.parity ^ 1])[tid];
+#pragma unroll
+          for (int k = 0; k < FX_NMIX1; k++) xcn[k] = sh.mx_cxt[k];
+#pragma unroll
+          for (int k = 0; k < FX_NMIX1; k++) xw[k] = reinterpret_cast<const uint32_t*>(d->wx[k] + (size_t)xcn[k] * FX_TX)[tid];
+#pragma unroll
+          for (int k = 0; k < FX_NMIX1; k++) sh.part[k][tid] = fx_pair_dot(t, xw[k]);
+          xt = t;
+        } else if (wave == 6) {
+          if (lane < 32) {   // the final mixers' rows for phase 5, fetched here if their selector moved (each lane its own weight: it stored the old one itself)
+            const int j = lane >> 4, i = lane & 15, c = sh.mx_cxt[10 + j];
+            if (c != mscx[j]) msw[lane] = (d->wx[10 + j] + (size_t)c * 16)[i];
+          }
+        }
+      } else if (tid < FX_THREADS) fx_phase3_dots(d, &sh, u, tid);
+      if (prof && lane == 0 && role == 2) wp3 += __builtin_readcyclecounter() - wt3;
       fx_lds_barrier();
       if (tid < FX_THREADS) fxd_phase4(d, &sh, u, tid);
+      else if (!LATE && wave == 7) { fx_apm_commit(&loc.apm, apmcx, &xapm, lane); }
+      else if (!LATE && wave == 6) { if (lane >= 32 && lane < 34) mscx[lane - 32] = sh.mx_cxt[10 + lane - 32]; }
       fx_lds_barrier();
       FX_TICK(5);
-      if (tid < 64) fx_phase5_dev(d, &sh, u, &loc.apm, tid, scr_s);
+      if (tid < 64) { if (!LATE) fx_phase5_dev(d, &sh, u, &loc.apm, tid, scr_s, msw, mscx); else fx_phase5_dev(d, &sh, u, &loc.apm, tid, scr_s); }
+      else if (!LATE && wave == 7 && q + 1 < nbits) {   // the NEXT update's APM contexts for the three possible outcomes of this bit's probability (fx_apm_ctx)
+        if (lane < 18) {
+          const FxBit un = fx_bit_dev(d, &ah, &loc, q + 1, blpos0, lastbyte0, have0);
+          const int combo = lane / 6, j = lane - 6 * combo;
+          uint32_t cx[6];
+          fx_apm_ctx(&sh, un, cx, combo);
+          apmspec[combo][j] = j == 0 ? cx[0] : j == 1 ? cx[1] : j == 2 ? cx[2] : j == 3 ? cx[3] : j == 4 ? cx[4] : cx[5];
+        }
+      }
+      else if (!LATE && wave == 4 && q + 1 < nbits) {   // the NEXT update's mixer errors (fxd_mixer_err: the coded bit is known, the outputs are this bit's) -- once for all trainers.
+        // mx_pr[0..9] / [10..11] are written by wave 0 during phase 5: this wave waits for its two flags (scr_s[12], scr_s[13] = bit + 1)
+        if (lane < 12) {
+          const int* const flag = &scr_s[lane < FX_NMIX1 ? 12 : 13];
+          while (*(volatile const int*)flag != q + 1) __builtin_amdgcn_s_sleep(1);
+          const FxBit un = fx_bit_dev(d, &ah, &loc, q + 1, blpos0, lastbyte0, have0);
+          merr[lane] = fxd_mixer_err(&sh, d, un, lane);
+        }
+      }
       fx_lds_barrier();
       FX_TICK(6);
       for (int i = l.exp_mix + tid; i < FX_OUTPUTS; i += FX_DEV_THREADS) real_row[i] = loc.ex[q & 1][i];
@@ -602,6 +786,7 @@ __device__ __forceinline__ void fx_roles_body(FxDev* gd, FxXfer* X, unsigned* ro
   }
   __syncthreads();
   if (prof && tid == 0 && blockIdx.x != 1) for (int k = 0; k < 8; k++) prof[16 * role + k] += pacc[k];
+  if (prof && role == 2 && lane == 0) { prof[48 + wave] += wtop; prof[56 + wave] += wp3; if (wave == 7) { prof[40] += w7[0]; prof[41] += w7[1]; prof[42] += w7[2]; } }
   if (prof && blockIdx.x == 0 && tid < 64) prof[64 + tid] += pbp[tid >> 3][tid & 7];
 #undef FX_TICK
   // ---- every role writes its own part of the stream's state back ----

@@ -50,6 +50,8 @@ if os.environ.get("CMX_FXCM_PROFILE") == "1":
             nm, ph = names[r]
             vals = [acc[16 * r + k] / nb for k in range(len(ph))]
             print("role %s: %6.0f clk/bit |" % (nm, sum(vals)), "  ".join("%s %.0f" % (a_, b_) for a_, b_ in zip(ph, vals)))
+        print("role X per wave, clk/bit: top block", " ".join("%5.0f" % (acc[48 + w] / nb) for w in range(8)), "| phase 3", " ".join("%5.0f" % (acc[56 + w] / nb) for w in range(8)))
+        print("role X wave 7 (APM), clk/bit: cell update %.0f, contexts %.0f, row fetch issue %.0f" % (acc[40] / nb, acc[41] / nb, acc[42] / nb))
         print("role M by bit position (bpos of the update = position of the NEXT bit; lookups at 0, 2, 5), clk per bit of that position:")
         for bp in range(8):
             vals = [acc[64 + 8 * bp + k] / (nb / 8) for k in range(6)]
