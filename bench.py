@@ -120,8 +120,8 @@ class CpuReference:
     mode) and `-n` (predictor only: no preprocessing), each as (run on 256 + nbytes bytes) - (run on 256 bytes:
     construction, ~4 s), each on its own pinned core. start() before the GPU work, result() after it."""
 
-    def __init__(self, payload, nbytes, cores):
-        self.payload, self.nbytes, self.cores = payload, nbytes, cores
+    def __init__(self, payload, nbytes, cores, modes=("-c", "-n")):
+        self.payload, self.nbytes, self.cores, self.modes = payload, nbytes, cores, modes
         self.exe = os.path.join(ROOT, "oracle", "_ref", "cmix_O3")
         self.pin = subprocess.call(["which", "taskset"], stdout=subprocess.DEVNULL) == 0
         self.res, self.threads = {}, []
@@ -148,7 +148,7 @@ class CpuReference:
         if not os.path.exists(self.exe):
             return False
         import threading
-        for mode, core in zip(("-c", "-n"), self.cores):
+        for mode, core in zip(self.modes, self.cores):
             t = threading.Thread(target=self._one, args=(mode, core), daemon=True)
             t.start()
             self.threads.append(t)
@@ -198,11 +198,31 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    if os.environ.get("CMX_BENCH_SAME_DEVICE") == "1":   # dry runs of the N > 1 path on a one-GPU box: every rank on device 0
+        local = 0
     torch.cuda.set_device(local)
 
     payload = synth.enwik_like(a.payload_bytes, shard.shard_seed(rank), rich=True)
     ncpu = os.cpu_count() or 2
     cpu = None
+    # N > 1 (north_star: the reference CPU cmix on the node's own host cores in the same run, at 1 / 2 / 4 / 8 GPUs): one pinned reference process per rank,
+    # each on the prefix of ITS rank's shard (`-c`: the GPU run's mode), as many as the host's memory holds at ~32 GB each; rank 0 reports their sum
+    # (cores = the number of processes). They run beside the timed GPU run on the highest-numbered cores; the bench threads are kept off those.
+    cpu_n = None
+    if world > 1 and not a.no_cpu_baseline and ncpu >= 2 * world + 2:
+        try:
+            mem_gb = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") / 2 ** 30
+        except (ValueError, OSError):
+            mem_gb = 64.0
+        nref = max(1, min(world, int(mem_gb // 32)))
+        if rank < nref:
+            cpu_n = CpuReference(payload, min(a.cpu_baseline_bytes, a.payload_bytes), (ncpu - 1 - rank,), modes=("-c",))
+            if not cpu_n.start():
+                cpu_n = None
+        try:
+            os.sched_setaffinity(0, set(range(ncpu - world)))
+        except (AttributeError, OSError):
+            pass
     if rank == 0 and world == 1 and not a.no_cpu_baseline and ncpu >= 4:
         cpu = CpuReference(payload, min(a.cpu_baseline_bytes, a.payload_bytes), (ncpu - 1, ncpu - 2))
         cpu.serial = a.cpu_baseline_serial
@@ -285,6 +305,14 @@ def main():
             mine.update(fixture=os.path.relpath(fxr, ROOT), identical_to_reference_file=bool(hashlib.sha256(b2).hexdigest() == w_sha and len(b2) == w_size))
         rank_checks = [None] * world
         dist.all_gather_object(rank_checks, mine)
+    cpu_all = None
+    if world > 1:
+        mine_cpu = None
+        if cpu_n is not None:
+            r = cpu_n.result()
+            mine_cpu = {"rank": rank, "value": r.get("value"), "core": ncpu - 1 - rank, "error": r.get("error"), "sample": r.get("sample"), "cpu_model": r.get("cpu_model")}
+        cpu_all = [None] * world
+        dist.all_gather_object(cpu_all, mine_cpu)
     if rank == 0:
         sha = hashlib.sha256(blob).hexdigest()
         verified = {"output_bytes": len(blob), "sha256": sha, "fixture": None, "identical_to_reference_file": None}
@@ -351,6 +379,16 @@ def main():
         if rank_checks is not None:
             rank_checks[0].update(fixture=verified["fixture"], identical_to_reference_file=verified["identical_to_reference_file"], whole_file=True)
             out["verified"]["ranks"] = rank_checks
+        if cpu_all is not None:
+            good = [c for c in cpu_all if c and c.get("value")]
+            if good:
+                out["cpu_baseline"] = {"value": sum(c["value"] for c in good), "unit": "input bytes/s", "cores": len(good), "kind": "reference", "cpu_model": good[0]["cpu_model"],
+                                       "host_cores": ncpu, "concurrent_with_gpu_run": True, "per_rank": [{k: c[k] for k in ("rank", "value", "core")} for c in good],
+                                       "sample": "%d concurrent pinned processes of oracle/_ref/cmix_O3 -c, one per rank on the first %d bytes of that rank's shard (minus a 256-byte run: "
+                                                 "construction), beside the timed GPU run; value = the sum of their bytes/s; rank 0's: %s" % (len(good), min(a.cpu_baseline_bytes, a.payload_bytes), good[0]["sample"])}
+                out["speedup_vs_cpu_reference"] = out["value"] / out["cpu_baseline"]["value"]
+            else:
+                out["cpu_baseline"] = {"error": "no rank's reference run finished: %s" % [c.get("error") if c else None for c in cpu_all]}
         if cpu is not None:
             if a.cpu_baseline_serial:
                 cpu.start()

@@ -389,6 +389,27 @@ int cmx_mixnet_helper_phases(cmx_mixnet_t* h, uint64_t out[32]) {
   return 0;
 }
 
+// A HIP stream for a stage's kernels. With the mixing network placed on one XCD through a compute-unit mask (CMX_MIXNET_XCD=k CMX_CUMASK=1) the network's
+// stream may use ONLY that XCD's compute units and every other stage's stream everything BUT them: a stage whose workgroups land on the crowded XCD is held
+// up there (profiles/r05_xcd_placement.txt: the LSTM's block kernels 4.7 -> 6.5 us/bit next to 27 spinning workgroups, whichever XCD). Bit i of the mask is
+// compute unit i / 8 of XCC i % 8 (the KFD spreads a queue's mask over the XCCs bit by bit). which: 0 = any other stage, 1 = the mixing network.
+int cmx_make_stream(hipStream_t* st, int which) {
+  static const char* const xe = getenv("CMX_MIXNET_XCD");
+  static const bool masked = getenv("CMX_CUMASK") != nullptr && xe && atoi(xe) >= 0 && atoi(xe) < 8;
+  if (masked) {
+    const int x = atoi(xe);
+    uint32_t m[8];
+    for (int w = 0; w < 8; ++w) {
+      m[w] = 0;
+      for (int b = 0; b < 32; ++b) { const int cu = 32 * w + b; if (((cu & 7) == x) == (which == 1)) m[w] |= 1u << b; }
+    }
+    if (hipExtStreamCreateWithCUMask(st, 8, m) == hipSuccess) return 0;
+    (void)hipGetLastError();
+  }
+  return hipStreamCreateWithFlags(st, hipStreamNonBlocking) == hipSuccess ? 0 : 1;
+}
+int cmx_cumask_on(void) { static const char* const xe = getenv("CMX_MIXNET_XCD"); return getenv("CMX_CUMASK") != nullptr && xe && atoi(xe) >= 0 && atoi(xe) < 8; }
+
 // The stream the handle's host-to-device copies go on (the pipeline gives all its stages ONE upload stream that never has
 // a kernel in front of a copy); without it the handle creates its own on first use.
 // Tolerance mode (NOT bit-exact; north_star's "per-bit probabilities within a tolerance"): the layer-0 dot products as f64 tree sums
@@ -501,8 +522,10 @@ static int mixnet_run_impl(cmx_mixnet_t* h, const float* d_probs, const uint32_t
   else if (h->use_spec) {
     // epochs and value|tag words restart at 0 with every launch; 1 main + 26 helper workgroups, co-resident (27 of 256 CUs)
     HIP_OK(hipMemsetAsync(h->d_xfer, 0, CMX_SPEC_HEADER_BYTES, st));
-    const int kmode = 3 | (h->profile ? 4 : 0) | ((h->dbg & 15) << 4) | (h->tolerance ? 0x1000 : 0) | (h->seg8 ? 0x2000 : 0) | (h->pad ? 0x4000 : 0) | (h->sleepy ? 0x8000 : 0) | (h->seg16 ? 0x10000 : 0) | (h->seg16 == 2 ? 0x40000 : 0) | (h->xcd >= 0 ? 0x20000 | ((h->xcd & 7) << 20) : 0) | (h->rerun4 ? 0x80000 : 0);
-    const unsigned grid = (1 + CMX_SPEC_HELPERS) * (h->xcd >= 0 ? 8 : 1);   // placement: 8 x 27 workgroups, those with blockIdx % 8 == xcd work
+    const bool cumask = cmx_cumask_on() != 0;   // the stream's compute-unit mask does the placement: 27 workgroups, all of them work, the XCC census still decides the hand-off's form
+    const int kmode = 3 | (h->profile ? 4 : 0) | ((h->dbg & 15) << 4) | (h->tolerance ? 0x1000 : 0) | (h->seg8 ? 0x2000 : 0) | (h->pad ? 0x4000 : 0) | (h->sleepy ? 0x8000 : 0) | (h->seg16 ? 0x10000 : 0) | (h->seg16 == 2 ? 0x40000 : 0) | (h->xcd >= 0 ? 0x20000 | ((h->xcd & 7) << 20) : 0) | (h->rerun4 ? 0x80000 : 0) | (getenv("CMX_MIXNET_XCD_NOLOCAL") ? 0x800000 : 0) | (cumask ? 0x400000 : 0);
+    static const bool padgrid = getenv("CMX_MIXNET_PADGRID") != nullptr;   // diagnostic: the 8 x 27 grid of the one-XCD placement without the placement (blocks 27.. leave at once)
+    const unsigned grid = (1 + CMX_SPEC_HELPERS) * ((h->xcd >= 0 && !cumask) || padgrid ? 8 : 1);   // placement: 8 x 27 workgroups, those with blockIdx % 8 == xcd work
     if (box && box->box)   // a decoder's chunk: the patient instantiation of the same roles
       hipLaunchKernelGGL(cmx_mixnet_spec_late_kernel, dim3(grid), dim3(CMX_SPEC_THREADS), CMX_SPEC_LDS_BYTES, st,
                          h->d_state, h->d_xfer, d_probs, d_sel, dd, (int)nbits, d_p_out, d_mix_out, kmode, *box);

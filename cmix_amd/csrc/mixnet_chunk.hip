@@ -2180,9 +2180,12 @@ template <bool LATE, int HV> __device__ __forceinline__ void spec_kernel_body(
   // only ever time out, never deliver a stale value.
   int role = (int)blockIdx.x;
   bool local = false;
+  if (!(mode & 0x20000) && role > CMX_SPEC_HELPERS) return;   // diagnostic launches with a padded grid (CMX_MIXNET_PADGRID): the surplus workgroups leave at once
   if (mode & 0x20000) {
-    if (((int)blockIdx.x & 7) != ((mode >> 20) & 7)) return;
-    role = (int)blockIdx.x >> 3;
+    if (!(mode & 0x400000)) {   // (0x400000: the stream carries a compute-unit mask that does the placement -- grid 27, every block has a role)
+      if (((int)blockIdx.x & 7) != ((mode >> 20) & 7)) return;
+      role = (int)blockIdx.x >> 3;
+    }
     __shared__ int s_local;
     if (tid == 0) {
       unsigned id;
@@ -2203,7 +2206,7 @@ template <bool LATE, int HV> __device__ __forceinline__ void spec_kernel_body(
       if (lane == 0) { s_local = ok && same; if (!ok) __hip_atomic_store(&X->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     }
     __syncthreads();
-    local = s_local != 0;
+    local = s_local != 0 && !(mode & 0x800000);   // (0x800000: diagnostic, CMX_MIXNET_XCD_NOLOCAL -- the placement without the L2 form of the hand-off)
   }
   if (role > 0) {
     HelperLds* H = reinterpret_cast<HelperLds*>(smem);

@@ -34,6 +34,7 @@
 
 void cmx_set_err(const std::string& s);  // cmx_api.hip
 extern "C" int cmx_device_count(void);
+extern "C" int cmx_make_stream(hipStream_t* st, int which);   // cmx_api.hip: a stage's kernel stream (compute-unit mask when the mixing network owns an XCD)
 
 // ---------------------------------------------------------------- role kernels
 // skip: chunk-local steps before the stream's first byte boundary (the maps have no contexts yet, reference :1072 loop over cn == 0)
@@ -1361,12 +1362,12 @@ cmx_p8stage_t* cmx_p8stage_create(int device) {
     // stream: the stage's period grows to their sum, the stream count is what many engines per GPU need.
     const char* ns = getenv("CMX_PIPELINE_STREAMS");
     const int mode = ns && ns[0] == '2' ? 2 : ns && ns[0] == '1' ? 1 : 0;
-    for (hipStream_t* q : {&h->s_a, &h->s_d, &h->s_m}) ok = ok && hipStreamCreateWithFlags(q, hipStreamNonBlocking) == hipSuccess;
-    if (mode == 0) for (hipStream_t* q : {&h->s_b, &h->s_e}) ok = ok && hipStreamCreateWithFlags(q, hipStreamNonBlocking) == hipSuccess;
+    for (hipStream_t* q : {&h->s_a, &h->s_d, &h->s_m}) ok = ok && cmx_make_stream(q, 0) == 0;
+    if (mode == 0) for (hipStream_t* q : {&h->s_b, &h->s_e}) ok = ok && cmx_make_stream(q, 0) == 0;
     else { h->s_b = h->s_d; h->s_e = h->s_d; }
     if (mode == 1) h->s_c = h->s_d;
-    else ok = ok && hipStreamCreateWithFlags(&h->s_c, hipStreamNonBlocking) == hipSuccess;
-    if (mode == 0) ok = ok && hipStreamCreateWithFlags(&h->s_f, hipStreamNonBlocking) == hipSuccess;   // the DMC forest beside the small learners
+    else ok = ok && cmx_make_stream(&h->s_c, 0) == 0;
+    if (mode == 0) ok = ok && cmx_make_stream(&h->s_f, 0) == 0;   // the DMC forest beside the small learners
     else h->s_f = h->s_c;
   }
   for (hipEvent_t* e : {&h->ev_up, &h->ev_ord, &h->ev_a, &h->ev_b, &h->ev_c, &h->ev_e, &h->ev_f}) ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;

@@ -28,6 +28,7 @@
 #include "cmx_late.h"
 
 void cmx_set_err(const std::string& s);  // cmx_api.hip
+extern "C" int cmx_make_stream(hipStream_t* st, int which);   // cmx_api.hip: a stage's kernel stream (compute-unit mask when the mixing network owns an XCD)
 static double late_now();   // ms on the steady clock (defined with the late-bit pipeline below)
 
 // ---- construction ahead of time ------------------------------------------------------------------------------
@@ -328,10 +329,10 @@ cmx_pipeline_t* cmx_pipeline_create(const uint8_t vocab[256], int device, size_t
   const char* ns = getenv("CMX_PIPELINE_STREAMS");
   const bool two = ns && (ns[0] == '2' || ns[0] == '1');   // 2: contexts on the LSTM's stream, paq8 on 4 streams; 1: fxcm there too, paq8 on 3
   h->compact = ns && ns[0] == '1' ? 1 : two ? 2 : 0;
-  ok = ok && hipStreamCreateWithFlags(&h->s_lstm, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && cmx_make_stream(&h->s_lstm, 0) == 0;
   if (two) h->s_ctx = h->s_lstm;
-  else ok = ok && hipStreamCreateWithFlags(&h->s_ctx, hipStreamNonBlocking) == hipSuccess;
-  ok = ok && hipStreamCreateWithFlags(&h->s_mix, hipStreamNonBlocking) == hipSuccess;
+  else ok = ok && cmx_make_stream(&h->s_ctx, 0) == 0;
+  ok = ok && cmx_make_stream(&h->s_mix, 1) == 0;
   ok = ok && hipStreamCreateWithFlags(&h->s_up, hipStreamNonBlocking) == hipSuccess;
   ok = ok && cmx_mixnet_set_upload_stream(h->mix, h->s_up) == 0;
   const size_t n = max_chunk_bytes;
@@ -374,7 +375,7 @@ int cmx_pipeline_enable_fxcm(cmx_pipeline_t* h, const char* dictionary_path) {
   const size_t n = h->max_chunk;
   bool ok = true;
   if (h->compact == 1) h->s_fx = h->s_lstm;   // throughput mode: LSTM, contexts and fxcm take turns on one stream
-  else ok = hipStreamCreateWithFlags(&h->s_fx, hipStreamNonBlocking) == hipSuccess;
+  else ok = cmx_make_stream(&h->s_fx, 0) == 0;
   ok = ok && hipMalloc((void**)&h->d_fx_scratch, 8 * n * 434 * sizeof(float)) == hipSuccess;
   for (Slot& s : h->slot) {
     ok = ok && hipMalloc((void**)&s.d_fx_pr, 8 * n * 2) == hipSuccess;
@@ -413,7 +414,7 @@ int cmx_pipeline_enable_paq8(cmx_pipeline_t* h) {
   if (!p8) return 1;
   bool ok = true;
   if (h->compact) h->s_p8 = h->s_mix;   // throughput mode: the mixing network's stream itself waits for the stage's mixer
-  else ok = hipStreamCreateWithFlags(&h->s_p8, hipStreamNonBlocking) == hipSuccess;
+  else ok = cmx_make_stream(&h->s_p8, 0) == 0;
   ok = ok && hipMalloc((void**)&h->d_p8_scratch, 8 * h->max_chunk * 1591 * sizeof(float)) == hipSuccess;
   for (Slot& s : h->slot)
     for (hipEvent_t* e : {&s.ev_p80, &s.ev_p81}) ok = ok && hipEventCreate(e) == hipSuccess;

@@ -140,5 +140,34 @@ def main():
         print("%-7s next to %s: %s   (alone %.2f)" % (a, want, " ".join(row), alone[a]))
 
 
+def crowd():
+    """CMX_CROWD=a,b,..: the first stage timed while ALL the others loop, and again with each of them left out in turn."""
+    want = os.environ["CMX_CROWD"].split(",")
+    mk = {"lstm": LstmJob, "mixnet": MixnetJob, "fxcm": FxcmJob, "paq8": P8Job}
+    jobs = {n: mk[n]() for n in want}
+    reps = {"lstm": 8, "mixnet": 6, "fxcm": 4, "paq8": 4}
+    a = want[0]
+    print("env:", {k: v for k, v in os.environ.items() if k.startswith("CMX_")})
+    print("%s alone: %.2f us/bit" % (a, timed(jobs[a], reps[a])))
+    for leave in [None] + want[1:]:
+        others = [n for n in want[1:] if n != leave]
+        stop = threading.Event()
+        ths = []
+        for b in others:
+            def spin(j=jobs[b]):
+                while not stop.is_set():
+                    j.once()
+            t = threading.Thread(target=spin); t.start(); ths.append(t)
+        time.sleep(0.1)
+        v = timed(jobs[a], reps[a])
+        stop.set()
+        for t in ths:
+            t.join()
+        print("%s next to %s: %.2f us/bit" % (a, "+".join(others) or "-", v))
+
+
 if __name__ == "__main__":
-    main()
+    if os.environ.get("CMX_CROWD"):
+        crowd()
+    else:
+        main()
