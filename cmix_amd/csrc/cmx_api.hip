@@ -29,6 +29,7 @@ typedef void (*cmx_spec_kernel_t)(MixState*, SpecXfer*, const float*, const uint
 extern "C" __global__ void cmx_mixnet_spec_seg8_kernel(MixState*, SpecXfer*, const float*, const uint32_t*, const uint8_t*, const float*, int, float*, float*, int);
 extern "C" __global__ void cmx_mixnet_spec_rerun4_kernel(MixState*, SpecXfer*, const float*, const uint32_t*, const uint8_t*, const float*, int, float*, float*, int);
 extern "C" __global__ void cmx_mixnet_spec_dpp64_kernel(MixState*, SpecXfer*, const float*, const uint32_t*, const uint8_t*, const float*, int, float*, float*, int);
+extern "C" __global__ void cmx_mixnet_spec_cand2_kernel(MixState*, SpecXfer*, const float*, const uint32_t*, const uint8_t*, const float*, int, float*, float*, int);
 extern "C" __global__ void cmx_mixnet_spec_dpp128_kernel(MixState*, SpecXfer*, const float*, const uint32_t*, const uint8_t*, const float*, int, float*, float*, int);
 extern "C" __global__ void cmx_mixnet_spec_late_kernel(MixState*, SpecXfer*, const float*, const uint32_t*, const float*, int, float*, float*, int, CmxLate);
 extern "C" __global__ void cmx_sse_init_kernel(MixState*);
@@ -142,6 +143,7 @@ struct cmx_mixnet {
   bool seg8 = false;    // the helpers cut the 2078-term chain into eight segments (all eight waves of a helper workgroup) instead of four; CMX_MIXNET_SEG8
   int seg16 = 0;        // CMX_MIXNET_SEG16: helper_dpp_role (1: 64 candidates per segment, 2: 128)
   bool rerun4 = false;  // CMX_MIXNET_RERUN4
+  bool cand2 = CMX_MIXNET_CAND2_DEFAULT;   // CMX_MIXNET_CAND: 2 = 128 candidate start values per speculative segment (two running sums per lane)
   bool pad = false, sleepy = false;   // A/B switches of the hand-off words (CMX_MIXNET_PAD, CMX_MIXNET_SLEEP), see mixnet_state.h
   bool use_spec = true; // cmx_mixnet_spec_kernel (26 helper workgroups, speculative segment-parallel chains); CMX_MIXNET_SPEC=0: the one-workgroup kernel
   SpecXfer* d_xfer = nullptr;
@@ -317,12 +319,13 @@ cmx_mixnet_t* cmx_mixnet_create(int device) {
   { const char* v = getenv("CMX_MIXNET_SEG8"); h->seg8 = v ? v[0] == '1' : CMX_MIXNET_SEG8_DEFAULT; }
   { const char* v = getenv("CMX_MIXNET_SEG16"); h->seg16 = v ? atoi(v) : 0; }    // helper_dpp_role: 16 segments per mixer fed by DPP row broadcasts; 1 = 64, 2 = 128 candidates per segment
   { const char* v = getenv("CMX_MIXNET_RERUN4"); h->rerun4 = v ? v[0] == '1' : CMX_MIXNET_RERUN4_DEFAULT; }   // a missed segment re-run in four pieces on the helpers' idle waves
+  { const char* v = getenv("CMX_MIXNET_CAND"); if (v) h->cand2 = v[0] == '2'; }
   { const char* v = getenv("CMX_MIXNET_PAD"); h->pad = v && v[0] == '1'; }       // A/B: one 128-byte line per u / sum word
   { const char* v = getenv("CMX_MIXNET_SLEEP"); h->sleepy = v && v[0] == '1'; }  // A/B: s_sleep 1 in the polls of the global hand-off words
   h->d_xfer = (SpecXfer*)dalloc(sizeof(SpecXfer), true);   // incl. the zero padding of the input ring
   bool attr_ok = true;
   for (const void* k : {(const void*)cmx_mixnet_spec_kernel, (const void*)cmx_mixnet_spec_seg8_kernel, (const void*)cmx_mixnet_spec_rerun4_kernel,
-                        (const void*)cmx_mixnet_spec_dpp64_kernel, (const void*)cmx_mixnet_spec_dpp128_kernel, (const void*)cmx_mixnet_spec_late_kernel})
+                        (const void*)cmx_mixnet_spec_dpp64_kernel, (const void*)cmx_mixnet_spec_dpp128_kernel, (const void*)cmx_mixnet_spec_cand2_kernel, (const void*)cmx_mixnet_spec_late_kernel})
     attr_ok = attr_ok && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, CMX_SPEC_LDS_BYTES) == hipSuccess;
   if (!h->d_xfer || !attr_ok) {
     set_err("cmx_mixnet_create: hand-off area / kernel attribute (spec kernel) failed");
@@ -537,6 +540,7 @@ static int mixnet_run_impl(cmx_mixnet_t* h, const float* d_probs, const uint32_t
         else if (h->seg16) k = cmx_mixnet_spec_dpp64_kernel;
         else if (h->seg8) k = cmx_mixnet_spec_seg8_kernel;
         else if (h->rerun4) k = cmx_mixnet_spec_rerun4_kernel;
+        else if (h->cand2) k = cmx_mixnet_spec_cand2_kernel;
       }
       hipLaunchKernelGGL(k, dim3(grid), dim3(CMX_SPEC_THREADS), CMX_SPEC_LDS_BYTES, st,
                          h->d_state, h->d_xfer, d_probs, d_sel, d_bits, dd, (int)nbits, d_p_out, d_mix_out, kmode);

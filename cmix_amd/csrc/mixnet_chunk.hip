@@ -223,6 +223,42 @@ template <int NB> __device__ __forceinline__ float chain_seg_n(const float* rowp
   return p;
 }
 __device__ __forceinline__ float chain_seg(const float* rowp, int n, float p) { return chain_seg_n<16>(rowp, n, p); }
+// The same chain on TWO running sums per lane (CMX_MIXNET_CAND=2: 128 candidate start values per speculative segment instead of 64). The chain is bound by
+// the LDS return path (one broadcast ds_read_b128 per four terms, ~8 clocks per term with four chain waves on the compute unit), not by the adder: the second
+// sum's add consumes the same broadcast operand and issues in the slack.
+__device__ __forceinline__ void add4x2(float& p, float& q, float4 v) {
+  p = fadd(p, v.x); q = fadd(q, v.x); p = fadd(p, v.y); q = fadd(q, v.y); p = fadd(p, v.z); q = fadd(q, v.z); p = fadd(p, v.w); q = fadd(q, v.w);
+}
+template <int NB> __device__ __forceinline__ void chain_seg2_n(const float* rowp, int n, float& p, float& q) {
+  const float4* row = reinterpret_cast<const float4*>(__builtin_assume_aligned(rowp, 16));
+  float4 a[8], b[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = row[i];
+#pragma unroll 1
+  for (int bi = 0; bi < NB; bi += 2) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b[i] = row[(bi + 1) * 8 + i];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) add4x2(p, q, a[i]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = row[(bi + 2) * 8 + i];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) add4x2(p, q, b[i]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const int rem4 = (n >> 2) - NB * 8;  // 0 or 7
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+    if (i < rem4) add4x2(p, q, a[i]);
+  if (n & 2) {
+    p = fadd(p, a[7].x); q = fadd(q, a[7].x);
+    p = fadd(p, a[7].y); q = fadd(q, a[7].y);
+  }
+}
 
 // ------------------------------------------------------------------ scout (wave 2)
 // X != nullptr (cmx_mixnet_spec_kernel): the stretched inputs and the layer-0 rows of the bit are also published to the helper
@@ -1411,7 +1447,7 @@ __device__ void rerun_role(SpecXfer* X, HelperLds* H, int nbits, int j, int lane
   }
 }
 
-template <bool LATE, int NW, bool SPLIT = false> __device__ void helper_role(MixState* S, SpecXfer* X, HelperLds* H, int nbits, int m, int w, int lane, bool tol, CmxLateBox* LB, int pitch, bool sleepy, bool local) {
+template <bool LATE, int NW, bool SPLIT = false, int NCAND = 1> __device__ void helper_role(MixState* S, SpecXfer* X, HelperLds* H, int nbits, int m, int w, int lane, bool tol, CmxLateBox* LB, int pitch, bool sleepy, bool local) {
   const gptr<float> rows0 = as_global(S->rows0);
   // NW waves cut the 2078-term chain: 4 x 512 (+ 30) or 8 x 256 (+ 30) terms. Shorter segments: a shorter chain and a cheaper re-run on a
   // miss (two thirds of the bits re-run a segment in at least one helper, profiles/r04_spec_chain_per_bit_study.txt), more hops to resolve.
@@ -1537,9 +1573,15 @@ template <bool LATE, int NW, bool SPLIT = false> __device__ void helper_role(Mix
           if ((++spins & 1023u) == 0 && (spins > SPEC_SPIN || failed())) { give_up(); return; }
         est += H->segsum[q];
       }
-      start = ord2f(f2ord((float)est) + lane - 32);
+      start = ord2f(f2ord((float)est) + lane - (NCAND == 2 ? 64 : 32));
     }
-    float r = chain_seg_n<NW == 4 ? 16 : 8>(pr, nseg, start);
+    float start2 = 0.0f, r2 = 0.0f;
+    float r;
+    if (NCAND == 2 && w > 0) {   // candidates estimate - 64 .. - 1 (r) and estimate .. + 63 (r2)
+      start2 = ord2f(f2ord(start) + 64);
+      r = start; r2 = start2;
+      chain_seg2_n<NW == 4 ? 16 : 8>(pr, nseg, r, r2);
+    } else r = chain_seg_n<NW == 4 ? 16 : 8>(pr, nseg, start);
     // ---- resolve against the true start ----
     if (w > 0) {
       unsigned spins = 0;
@@ -1547,9 +1589,13 @@ template <bool LATE, int NW, bool SPLIT = false> __device__ void helper_role(Mix
         if ((++spins & 1023u) == 0 && (spins > SPEC_SPIN || failed())) { give_up(); return; }
       const float s = H->res[w - 1];
       const unsigned long long hit = __ballot(__float_as_int(start) == __float_as_int(s));
+      const unsigned long long hit2 = NCAND == 2 ? __ballot(__float_as_int(start2) == __float_as_int(s)) : 0ull;
       ++n_spec;
       if (hit) {
         r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), (int)__builtin_amdgcn_readfirstlane(__ffsll((long long)hit) - 1)));
+        ++n_hit;
+      } else if (NCAND == 2 && hit2) {
+        r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r2), (int)__builtin_amdgcn_readfirstlane(__ffsll((long long)hit2) - 1)));
         ++n_hit;
       } else {
         if (SPLIT) {                                              // in four pieces, three of them on the idle waves (rerun_role)
@@ -2223,6 +2269,7 @@ template <bool LATE, int HV> __device__ __forceinline__ void spec_kernel_body(
       if (wave < 4) helper_role<LATE, 4, true>(S, X, H, nbits, role - 1, wave, lane, false, lb, pitch, sleepy, local);
       else if (wave < 7) rerun_role(X, H, nbits, wave - 3, lane);
     }
+    else if constexpr (HV == 5) { if (wave < 4) helper_role<LATE, 4, false, 2>(S, X, H, nbits, role - 1, wave, lane, false, lb, pitch, sleepy, local); }   // 128 candidates per segment
     else if (wave < 4) helper_role<LATE, 4>(S, X, H, nbits, role - 1, wave, lane, tol, lb, pitch, sleepy, local);
     return;
   }
@@ -2277,6 +2324,7 @@ CMX_SPEC_KERNEL(cmx_mixnet_spec_seg8_kernel, 1)
 CMX_SPEC_KERNEL(cmx_mixnet_spec_rerun4_kernel, 2)
 CMX_SPEC_KERNEL(cmx_mixnet_spec_dpp64_kernel, 3)
 CMX_SPEC_KERNEL(cmx_mixnet_spec_dpp128_kernel, 4)
+CMX_SPEC_KERNEL(cmx_mixnet_spec_cand2_kernel, 5)
 // the decoder's form (engine mode 3, cmx_late.h): same grid, same roles, patient
 extern "C" __global__ __launch_bounds__(CMX_SPEC_THREADS) void cmx_mixnet_spec_late_kernel(
     MixState* __restrict__ S, SpecXfer* __restrict__ X, const float* __restrict__ probs, const uint32_t* __restrict__ sel,

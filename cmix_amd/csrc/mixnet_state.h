@@ -79,6 +79,7 @@ struct MixState {
 #define CMX_SPEC_THREADS 512      /* main: gather, tail, select, -, 4 stretch waves; helpers use the first four, or all eight (CMX_MIXNET_SEG8) */
 #define CMX_MIXNET_XCD_DEFAULT (-1)   /* the XCD the mixing network's 27 workgroups are placed on (-1: as dispatched); CMX_MIXNET_XCD overrides; the LSTM's block kernels leave it free */
 #define CMX_MIXNET_RERUN4_DEFAULT false   /* a missed segment re-run in four 128-term pieces on the helpers' idle waves (rerun_role) */
+#define CMX_MIXNET_CAND2_DEFAULT false    /* 128 candidates per speculative segment (two running sums per lane; CMX_MIXNET_CAND=2) */
 #define CMX_MIXNET_SEG8_DEFAULT false   /* the helpers' eight-segment split: opt-in (CMX_MIXNET_SEG8=1) until it has been measured in the pipeline */
 struct SpecXfer {
   unsigned scout_epoch;        // bits whose inputs / rows the scout has published

@@ -87,11 +87,11 @@ typedef struct {
   int ngen, gen_inst[P8_XL_MAXG], gen_first[P8_XL_MAXG];
   int nslots;                          /* fam_count + the generic instances' contexts */
   /* the step's inputs in add() order -> positions in the 1552-vector: the model's own first (position = order), then the generic maps' at their
-   * generic positions. own_opt: inputs [opt_lo, opt_lo + opt_n) are the own ContextMap's, absent in a byte it is silent (P8ApmRec.c[7]) */
+   * generic positions. own_opt: inputs [opt_lo, opt_lo + opt_n) are the own ContextMap's, absent in a byte it is silent (P8ApmRec.m[0]) */
   int16_t map[P8_NX];
   int opt_lo, opt_n;
   /* jpegModel's coded steps export more than their inputs, interleaved (the model's own mixer exports too, :504-507): positions of the 1552-vector in
-   * export order (P8ApmRec.c[7] == 2 selects it; otherwise a step exports its inputs in order) */
+   * export order (P8ApmRec.m[0] == 2 selects it; otherwise a step exports its inputs in order) */
   int exp_n;
   int16_t exp[P8_NX];
 } P8XLayout;
@@ -129,7 +129,11 @@ enum { P8_SEL_ORDER3 = 19, P8_SEL_ORDER5_A = 20, P8_SEL_ORDER5_B = 21, P8_SEL_OR
  *              (every image / audio kind)
  * IMAGE8GRAY (kind 3, Image.Gray :8315-8324): c[0] as above, c[1], c[2]; IMAGE8 (kind 4, Image.Palette :8325-8340): c[0..3], c[4], c[5] */
 enum { P8_APM_GENERIC = 0, P8_APM_TEXT = 1, P8_APM_COLOR = 2, P8_APM_GRAY = 3, P8_APM_PALETTE = 4 };
-typedef struct { uint16_t c[10]; uint16_t limit; uint8_t text /* = kind: P8_APM_* */, model /* P8_MODEL_* of the step */; } P8ApmRec;
+/* m[0..3] (round 5): a step of a model with tables of its own -- m[0] own_silent (1: the model's own ContextMap is silent this byte, 2: the export order of
+ * P8XLayout), m[1] nx (its inputs), m[2] nsel (its weight sets), m[3] the JPEG model's one constant input. Fields of their own since such a step can end in
+ * the TEXT chain, whose ten contexts fill c[0..9] (paq8.cpp:8281-8296: a WAV / JPEG / 1- or 4-bit image the detectors find inside a TEXT block). The generic
+ * mixer kernels stage only the first 24 bytes of a record (they never see a model's step). */
+typedef struct { uint16_t c[10]; uint16_t limit; uint8_t text /* = kind: P8_APM_* */, model /* P8_MODEL_* of the step */; uint16_t m[4]; } P8ApmRec;
 
 /* one chunk of nbytes input bytes = 8 nbytes steps */
 typedef struct {

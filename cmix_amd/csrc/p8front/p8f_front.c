@@ -570,18 +570,15 @@ static int front_step(P8Front* f, int y, int32_t* sel, P8ApmRec* apm) {
   p->bpos = (p->bpos + 1) & 7;
   const int rc = context_model2(p, y, sel);
   if (rc < 0) return rc;
-  /* A step of a model with tables of its own (audio, a 1- / 4-bit image, JPEG: the ones that leave Stats.Type alone) INSIDE A TEXT BLOCK ends in the
-   * text chain (:8281-8296), whose ten contexts need every cell of the record -- the step's own fields (c[6..9] below) have no room beside them, and
-   * the model kernels do not run that chain. Refused, never coded differently. (Found by a 170 KB media file whose WAV the preprocessor left in a
-   * TEXT block; in DEFAULT / HDR / EXE / image blocks the general chain and the image chains leave c[6..9] free.) */
-  if (p->model && p->type == FT_TEXT) return P8F_ERR_MODEL_IN_TEXT;
+  /* (A step of a model with tables of its own -- audio, a 1- / 4-bit image, JPEG: the ones that leave Stats.Type alone -- INSIDE A TEXT BLOCK ends in the
+   * text chain, :8281-8296: the record carries the step's own fields in m[], the chain's ten contexts in c[] as for any text step.) */
   /* the final APM stages (:8281-8358): contexts as far as the host knows them (misses and the probabilities are device state) */
   const int c0 = p->c0, bpos = p->bpos;
   const uint32_t lg = ilog2u(p->match_length + 1);
   const uint32_t c4 = p->c4, mlen = lg < 3 ? lg : 3, eb = p->match_expected;
   memset(apm, 0, sizeof *apm);
   apm->model = (uint8_t)p->model;
-  if (p->model) { apm->c[7] = (uint16_t)p->own_silent; apm->c[8] = (uint16_t)p->nx; apm->c[9] = (uint16_t)p->nsel; apm->c[6] = (uint16_t)(p->model == P8_MODEL_JPEG ? p->jpeg_const : 0); }
+  if (p->model) { apm->m[0] = (uint16_t)p->own_silent; apm->m[1] = (uint16_t)p->nx; apm->m[2] = (uint16_t)p->nsel; apm->m[3] = (uint16_t)(p->model == P8_MODEL_JPEG ? p->jpeg_const : 0); }
   if (p->type == FT_TEXT) {
     apm->text = P8_APM_TEXT;
     apm->limit = (uint16_t)(0x3FF >> ((p->blpos < 0xFFF) * 2));
@@ -744,7 +741,7 @@ const char* p8f_strerror(int code) {
     case P8F_ERR_TGA: return "paq8 stage: TGA payload of an unsupported pixel size";
     case P8F_ERR_WAV: return "paq8 stage: WAV header detected (audioModel is outside the stage's scope)";
     case P8F_ERR_IMAGE_PADDING: return "paq8 stage: image rows whose byte width is not a multiple of the pixel size (the reference indexes past its OLS array there, paq8.cpp:5043,5226: undefined)";
-    case P8F_ERR_MODEL_IN_TEXT: return "paq8 stage: audio / 1- or 4-bit image / JPEG data inside a TEXT block (a model step that ends in the text chain is not built)";
+    case P8F_ERR_MODEL_IN_TEXT: return "paq8 stage: (unused since round 5: a model step inside a TEXT block runs the text chain)";
     case P8F_ERR_IMAGE_LATE: return "paq8 stage: an image model in a decoder's chunk (the late-bit form of the image models is not built)";
     default: return "paq8 stage: internal inconsistency in the front end";
   }

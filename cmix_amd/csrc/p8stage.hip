@@ -1102,8 +1102,8 @@ __global__ __launch_bounds__(P8_XL_NLANE) void cmx_p8s_xlanes_kernel(P8XLanesDev
   d->regs[l] = r;
 }
 
-// The mixer of an image model's steps (one segment of consecutive such bytes): the step's nx inputs (P8ApmRec.c[8]; zeros behind them, which
-// neither the dot products nor the training see), its nsel weight sets (c[9]; absolute rows, no device terms) one per wavefront, the second layer,
+// The mixer of an image model's steps (one segment of consecutive such bytes): the step's nx inputs (P8ApmRec.m[1]; zeros behind them, which
+// neither the dot products nor the training see), its nsel weight sets (m[2]; absolute rows, no device terms) one per wavefront, the second layer,
 // the model's APM chain on one lane (p8s_tail_image), the export: nx + nsel + 10 values back to back, the rest of the 1591 as they were
 // (AddPrediction() counts on, :504-510). Same packed arithmetic as cmx_p8s_mix4_kernel. T: the state the generic mixer leaves and takes over.
 constexpr int XMX_THREADS = 1024;
@@ -1125,14 +1125,14 @@ __global__ __launch_bounds__(XMX_THREADS) void cmx_p8s_xmix_kernel(const P8MixDe
   __syncthreads();
   for (int t = 0; t < nbits; t++) {
     const P8ApmRec* a = apm + t;
-    const int nx = a->c[8], nsel = a->c[9];
+    const int nx = a->m[1], nsel = a->m[2];
     const int y = t ? (int)bits[t - 1] : last_y;
     misses += misses + (unsigned long long)((lastpr >> 11) != y);   // Predictor::update's first line (:8250)
     const int16_t* xr = x + (size_t)t * P8_NX;
     const P8XMixMap* mp = maps + (a->model - 1);
-    const int skp = a->c[7] == 1 ? mp->opt_n : 0, olo = mp->opt_lo;   // the model's own ContextMap is silent this byte: its inputs are not there
-    const int jc = a->model == P8_MODEL_JPEG ? (int)a->c[6] : 0;        // a stuffed / restart step of the JPEG model: its one constant input
-    const int ne = a->c[7] == 2 ? mp->exp_n : nx;                       // exported values in front of the second layer's
+    const int skp = a->m[0] == 1 ? mp->opt_n : 0, olo = mp->opt_lo;   // the model's own ContextMap is silent this byte: its inputs are not there
+    const int jc = a->model == P8_MODEL_JPEG ? (int)a->m[3] : 0;        // a stuffed / restart step of the JPEG model: its one constant input
+    const int ne = a->m[0] == 2 ? mp->exp_n : nx;                       // exported values in front of the second layer's
     for (int i = tid; i < P8_NX / 2; i += XMX_THREADS) {
       const int i0 = 2 * i, i1 = 2 * i + 1;
       const uint32_t lo = i0 < nx ? (uint32_t)(uint16_t)xr[mp->map[(skp && i0 >= olo) ? i0 + skp : i0]] : 0u;
@@ -1143,7 +1143,7 @@ __global__ __launch_bounds__(XMX_THREADS) void cmx_p8s_xmix_kernel(const P8MixDe
       xs[i] = lo2 | (hi << 16);
     }
     __syncthreads();
-    if (a->c[7] == 2) { for (int i = tid; i < ne; i += XMX_THREADS) outs[i] = (float)p8s_squash(squash, xr[mp->exp[i]]) * cf; }
+    if (a->m[0] == 2) { for (int i = tid; i < ne; i += XMX_THREADS) outs[i] = (float)p8s_squash(squash, xr[mp->exp[i]]) * cf; }
     else for (int i = tid; i < nx; i += XMX_THREADS) outs[i] = (float)p8s_squash(squash, reinterpret_cast<const int16_t*>(xs)[i]) * cf;
     uint4 w[4];
     int my_pr = 2048, row = 0;

@@ -469,7 +469,7 @@ P8_HD int p8s_tail_gray(P8TailDev* d, const P8ApmRec* a, int y, int pr0, float* 
 }
 // the chain of an image model's step by its kind (P8ApmRec.text)
 P8_HD int p8s_tail_image(P8TailDev* d, const P8ApmRec* a, int y, int pr0, float* o) {
-  if (a->text == P8_APM_GENERIC) {   // an audio model's step inside an ordinary block: the general chain, one table after the other
+  if (a->text == P8_APM_GENERIC || a->text == P8_APM_TEXT) {   // a model's step inside an ordinary block, or inside a TEXT block (the text chain, :8281-8296): the chain of the block's type, one table after the other
     int res[8];
     for (int j = 0; j < 4; j++) p8s_tail_a(d, a, y, pr0, j, res);
     for (int j = 0; j < 3; j++) p8s_tail_b(d, a, y, pr0, j, res);

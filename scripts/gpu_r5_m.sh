@@ -1,0 +1,13 @@
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
+O=gpurun_out/r5m; mkdir -p $O
+for v in "CMX_MIXNET_CAND=2"; do
+  echo "== $v" | tee -a $O/mixnet_variants.txt
+  ( export $v; timeout 300 python -m pytest tests/test_gpu_mixnet.py -q -x -p no:cacheprovider 2>&1 | tail -3 ) | tee -a $O/mixnet_variants.txt
+  ( export $v; timeout 120 python scripts/gpu_prof.py 4096 2>&1 | grep -v amdgpu.ids | head -9 ) | tee -a $O/mixnet_variants.txt
+done
+for v in "CMX_MIXNET_CAND=2" "X=0"; do
+  n=$(echo $v | tr ' ' '_')
+  ( export $v; timeout 200 python bench.py --payload-bytes 262144 --steps 5 --warmup 1 --no-cpu-baseline > "$O/bench_256k_$n.json" 2> "$O/bench_256k_$n.err" )
+  python -c "import json,sys; d=json.load(open(sys.argv[1])); print(sys.argv[2], round(d['value']), {k: (round(v, 2) if isinstance(v, float) else v) for k, v in d['stage_us_per_bit'].items() if k != 'note'}, d['verified']['sha256'][:16])" "$O/bench_256k_$n.json" "$n" 2>&1 | cut -c1-400 | tee -a $O/bench_ab.txt
+done

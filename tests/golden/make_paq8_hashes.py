@@ -176,7 +176,7 @@ def image_streams():
     other data (block path, contextModel2 :8165-8166), and as a BMP file inside a DEFAULT block (`cmix -n`: no preprocessing; paq8's own
     header detector imgModel :5386-5504 switches the model on and off). Row widths are multiples of the pixel size (see p8f_image.c)."""
     from cmix_amd import synth
-    from make_golden import default_block
+    from make_golden import default_block, text_block
     text = synth.enwik_like(700, 11)
     return {
         "bmp24_14k": preprocessed(text[:300] + bmp_file(photo(96, 48, 3, 1)) + text[300:]),
@@ -215,6 +215,11 @@ def image_streams():
         "wav8s_4k": preprocessed(text[:150] + wav_file(1800, 2, 8, 10) + text[150:300]),
         "wav16m_3k": preprocessed(text[:100] + wav_file(1300, 1, 16, 11) + text[100:200]),
         "wav8m_2k": preprocessed(text[:100] + wav_file(1700, 1, 8, 12) + text[100:200]),
+        # models with tables of their own INSIDE A TEXT BLOCK (the preprocessor lets a TEXT block run past the end of the text; paq8's own detectors switch the
+        # models on, Stats.Type stays TEXT, so every such step ends in the text chain of final APM stages, :8281-8296): a WAV, a JPEG, a 4-bit and a 1-bit BMP
+        "media_in_text_9k": text_block(text[:300] + wav_file(700, 1, 8, 71) + text[300:420] + jpeg_file(photo(64, 48, 3, 72), quality=60) + text[420:520] +
+                                       bmp4_file((photo(64, 40, 1, 73)[:, :, 0] >> 4).astype(np.uint8), np.random.default_rng(74).integers(0, 256, (16, 3))) + text[520:600] +
+                                       bmp1_file((photo(96, 48, 1, 75)[:, :, 0] > 120).astype(np.uint8)) + wav_file(400, 2, 16, 76) + text[600:700]),
         "bmp8_pal_raw_5k": default_block(text[:120] + bmp8_file(((photo(64, 52, 1, 6)[:, :, 0] >> 3).astype(np.uint8) * np.uint8(5)),
                                                                 np.random.default_rng(8).integers(0, 256, (256, 3))) + text[120:300]),
     }

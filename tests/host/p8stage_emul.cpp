@@ -396,18 +396,18 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
     if (g < 8) { nx = S.mix.nx_first; for (int i = 0; i < nx; i++) xs[i] = xr[S.mix.first_map[i]]; }
     else if (md) {   // a model's step: its inputs in add() order through the model's map (p8_rec.h), fewer weight sets
       const P8XLayout& X = L.xl[md - 1];
-      nx = c.apm[t].c[8];
+      nx = c.apm[t].m[1];
       if (nx < 0 || nx > P8_NX || c.apm[t].model != md) { fprintf(stderr, "p8stage_emul: step %zu (byte %zu of the chunk, stream step %llu): model %d, record says model %d with %d inputs\n", t, t >> 3, (unsigned long long)g, md, (int)c.apm[t].model, nx); return -98; }
-      const int skip = c.apm[t].c[7] ? X.opt_n : 0;   // the model's own ContextMap is silent this byte: its inputs are not there
-      const int skp = c.apm[t].c[7] == 1 ? skip : 0;
+      const int skip = c.apm[t].m[0] ? X.opt_n : 0;   // the model's own ContextMap is silent this byte: its inputs are not there
+      const int skp = c.apm[t].m[0] == 1 ? skip : 0;
       for (int i = 0; i < nx; i++) xs[i] = xr[X.map[(skp && i >= X.opt_lo) ? i + skp : i]];
-      if (md == P8_MODEL_JPEG && c.apm[t].c[6]) xs[nx - 1] = (int16_t)c.apm[t].c[6];   // a stuffed / restart step's one constant input (jpegModel :6466, :6473)
+      if (md == P8_MODEL_JPEG && c.apm[t].m[3]) xs[nx - 1] = (int16_t)c.apm[t].m[3];   // a stuffed / restart step's one constant input (jpegModel :6466, :6473)
     }
     else memcpy(xs, xr, P8_NX * 2);
-    const int nsel = md ? (int)c.apm[t].c[9] : P8_NSEL;
+    const int nsel = md ? (int)c.apm[t].m[2] : P8_NSEL;
     const float cf = (float)(1.0 / 4095);
     int ne = nx;   // exported values in front of the second layer's: the inputs in order -- or, a coded JPEG step, through the model's export map
-    if (md && c.apm[t].c[7] == 2) {
+    if (md && c.apm[t].m[0] == 2) {
       const P8XLayout& X = L.xl[md - 1];
       ne = X.exp_n;
       for (int i = 0; i < ne; i++) Tl.out[i] = (float)p8s_squash(Tl.squash, xr[X.exp[i]]) * cf;

@@ -54,7 +54,7 @@ def test_stage_vs_reference_hashes(name):
 
 @pytest.mark.parametrize("name", ["bmp24_14k", "bmp32_8k", "bmp24_raw_9k", "pgm8_4k", "bmp8_gray_raw_5k", "bmp8_pal_raw_5k",
                                   "wav16s_6k", "wav8s_4k", "wav16m_3k", "wav8m_2k", "pbm1_2k", "bmp1_raw_2k", "bmp4_raw_3k", "jpeg_5k", "jpeg_rst_raw_3k", "mixed_media_12k",
-                                  "tga24_5k", "tga_gray_map_32_raw_9k", "jpeg_444_prog_cut_6k", "pam32_thumb_8k"])
+                                  "tga24_5k", "tga_gray_map_32_raw_9k", "jpeg_444_prog_cut_6k", "pam32_thumb_8k", "media_in_text_9k"])
 def test_image_model_streams_vs_reference_hashes(name):
     """24 / 32-bit images (im24bitModel): an IMAGE24 block between other blocks, and BMP files inside DEFAULT blocks where paq8's own detector
     switches the model on and off; 8-bit images (im8bitModel): an IMAGE8GRAY block (a PGM), BMP files with a gray and with a colour palette. Chunks that hold image bytes run their roles on one stream, the ContextMap family and the mixer by
