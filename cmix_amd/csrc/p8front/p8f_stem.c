@@ -4,8 +4,8 @@
  * derivative with prefix / superlative handling and word-class flags, used by wordModel and TextModel. The suffix and
  * exception lists are data extracted from the reference (p8f_stem_tables.h, scripts/gen_paq8_stem_tables.py);
  * the control flow below follows the reference step by step because the stem, the flags and the hashes of every word
- * have to come out identical. Pinned in tests/test_oracle_paq8core.py against the reference's own class on its 44 k-word
- * dictionary and on inflected forms generated from it. */
+ * have to come out identical. Pinned in tests/test_p8front_twins.py (THIS file's objects against the reference's own class on a 6 000-word vocabulary
+ * and its inflected forms; tests/test_oracle_paq8core.py pins the oracle's twin, oracle/paq8_stem.c, the same way). */
 #include <ctype.h>
 #include <stdint.h>
 #include <string.h>
