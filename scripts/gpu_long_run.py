@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--bytes", type=int, default=8 << 20)
     ap.add_argument("--seed", type=int, default=1000)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "long_run.json"))
+    ap.add_argument("--golden", default=os.path.join(ROOT, "tests", "golden"), help="where the reference binary's file fixtures are (a second build under test keeps its own tree)")
     a = ap.parse_args()
     import torch
     from cmix_amd import engine as E, synth
@@ -59,6 +60,9 @@ def main():
         print("  %6.1f MiB  %8.0f B/s" % (pos / 2**20, per_mib[-1]["bytes_per_s"]), flush=True)
     blob = eng.finish()
     dt = time.perf_counter() - t_start
+    # SHA-256 of the probabilities of every MiB of input (float32, as the arithmetic coder sees them): two builds that differ can be compared MiB by MiB
+    p_all = eng.p_dev[:8 * n].cpu().numpy()
+    p_sha = [hashlib.sha256(p_all[8 * i:8 * min(n, i + step)].tobytes()).hexdigest()[:16] for i in range(0, n, step)]
     rows = np.zeros(47, np.uint32)
     spec = np.zeros(5, np.uint64)
     prof = np.zeros(128, np.uint64)
@@ -74,7 +78,7 @@ def main():
     out = {
         "what": "first %d bytes of the bench shard (seed %d, rich alphabet) through the whole engine, strict mode, one stream on one MI355X" % (a.bytes, a.seed),
         "payload_bytes": a.bytes, "stream_bytes": n, "output_bytes": len(blob), "sha256": hashlib.sha256(blob).hexdigest(),
-        "seconds": dt, "bytes_per_s": n / dt, "per_mib": per_mib, "payload_generation_s": t_gen,
+        "seconds": dt, "bytes_per_s": n / dt, "per_mib": per_mib, "p_sha256_16_per_mib": p_sha, "payload_generation_s": t_gen,
         "stage_us_per_bit": {"mixnet": st["mixnet"] * 1e3 / bits_per_sub, "ctxmodels": st["ctxmodels"] * 1e3 / bits_per_sub, "lstm": st["lstm"] * 1e3 / bits_per_sub,
                              "fxcm": eng.pipe.fxcm_total_ms() / nsub * 1e3 / bits_per_sub, "paq8_roles": {k: v / max(rch, 1) * 1e3 / bits_per_sub for k, v in roles.items()}},
         "mixer_rows": {"allocated": [int(x) for x in rows], "cap": 10000, "mixers_at_cap": int((rows >= 10000).sum()),
@@ -92,7 +96,7 @@ def main():
         out["paq8_family"] = {"steps_by_bit_position": [int(x) for x in steps], "steps_that_left_the_one_pass_path": [int(x) for x in rounds],
                               "share_by_bit_position": [float(r / s) if s else 0.0 for r, s in zip(rounds, steps)], "share_overall": float(rounds.sum() / max(steps.sum(), 1))}
     name = "dropin_1m.npz" if (a.bytes, a.seed) == (1 << 20, 1000) else "dropin_rich_%dk%s.npz" % (a.bytes >> 10, "" if a.seed == 1000 else "_s%d" % a.seed)
-    fx = os.path.join(ROOT, "tests", "golden", name)
+    fx = os.path.join(a.golden, name)
     if os.path.exists(fx):
         with np.load(fx) as z:
             want_sha, want_size = z["sha256"].tobytes().hex(), int(z["size"][0])

@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""Per-64-KB digests of the layer-0 columns (130 groups of 16 consecutive columns) and of the final probability over a long stream, on the
+device -- the engine's side of oracle/ref_long_trace.cpp (same digest: sum over bits t and columns c of (bits(p[t][c]) + 1) * A[c] * B[t mod 2^19]
+mod 2^64). Compared block by block with the unmodified reference Predictor's digests this tells WHICH columns leave the reference's values first,
+and where.
+
+    python scripts/gpu_stage_hashes.py --bytes 8388608 --out gpurun_out/stage_hashes_8m.txt [--ref ref_hashes.txt]
+    python scripts/gpu_stage_hashes.py --compare mine.txt ref.txt         (no GPU: compare two digest files)
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+NG = 130
+
+
+def group_name(g):
+    if g == NG:
+        return "final p"
+    lo, hi = 16 * g, min(2078, 16 * g + 16) - 1
+    def owner(c):
+        return ("contexts" if c < 3 or 2025 <= c < 2076 else "PPMd" if c == 2076 else "LSTM" if c == 2077 else "fxcm" if c < 434 else "paq8[%d]" % (c - 434))
+    a, b = owner(lo), owner(hi)
+    return "cols %d..%d (%s)" % (lo, hi, a if a == b else a + " .. " + b)
+
+
+def compare(mine_path, ref_path):
+    mine = [l.split() for l in open(mine_path) if l.strip()]
+    ref = [l.split() for l in open(ref_path) if l.strip()]
+    n = min(len(mine), len(ref))
+    for b in range(n):
+        bad = [g for g in range(NG + 1) if mine[b][1 + g] != ref[b][1 + g]]
+        if bad:
+            print("compared %d blocks: FIRST DIFFERENCE in block %d (bytes %d..%s): %d groups differ" % (n, b, b * 65536, mine[b][0], len(bad)))
+            for g in bad[:40]:
+                print("   ", group_name(g))
+            later = {}
+            for bb in range(b, n):
+                for g in range(NG + 1):
+                    if mine[bb][1 + g] != ref[bb][1 + g]:
+                        later.setdefault(g, bb)
+            print("    first block each group differs in:", {group_name(g): v for g, v in sorted(later.items(), key=lambda kv: kv[1])[:60]})
+            return b
+    print("compared %d blocks: all digests equal" % n)
+    return None
+
+
+def splitmix64(x):
+    x = (x + np.uint64(0x9E3779B97F4A7C15))
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return x ^ (x >> np.uint64(31))
+
+
+def main():
+    if len(sys.argv) == 4 and sys.argv[1] == "--compare":
+        compare(sys.argv[2], sys.argv[3])
+        return
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--bytes", type=int, default=8 << 20)
+    ap.add_argument("--seed", type=int, default=1000)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "stage_hashes.txt"))
+    ap.add_argument("--ref", default=None, help="oracle/_ref/ref_long_trace's output: compare and report the first block / group that differs")
+    a = ap.parse_args()
+    import torch
+    from cmix_amd import engine as E, synth
+    from cmix_amd.pipeline import EngineStream, text_file_stream
+    with np.errstate(over="ignore"):
+        A = splitmix64(np.arange(2078, dtype=np.uint64)) | np.uint64(1)
+        B = splitmix64(np.uint64(0x1000000) + np.arange(1 << 19, dtype=np.uint64)) | np.uint64(1)
+    dev = torch.device("cuda", 0)
+    At = torch.from_numpy(A.view(np.int64)).to(dev)
+    Bt = torch.from_numpy(B.view(np.int64)).to(dev)
+    At = torch.cat([At, torch.zeros(16 * NG - 2078, dtype=torch.int64, device=dev)])
+    payload = synth.enwik_like(a.bytes, a.seed, rich=True)
+    stream = text_file_stream(payload)
+    n = len(stream)
+    eng = EngineStream(0, stream, 4096)
+    sub = eng.sub
+    nsub = -(-n // sub)
+    blocks = -(-n // 65536)
+    H = torch.zeros((blocks, NG + 1), dtype=torch.int64, device=dev)
+
+    def digest(k):   # sub-chunk k is complete: fold its rows into its 64 KB block's digests
+        eng.pipe.wait(k)
+        lo, hi = k * sub, min(n, (k + 1) * sub)
+        l0 = eng.layer0[k % E.PIPELINE_SLOTS][:8 * (hi - lo)]
+        t = torch.arange(8 * lo, 8 * hi, device=dev) & ((1 << 19) - 1)
+        v = (l0.view(torch.int32).to(torch.int64) & 0xffffffff) + 1
+        v = torch.nn.functional.pad(v, (0, 16 * NG - 2078))
+        w = (v * At[None, :]).view(-1, NG, 16).sum(2)          # (int64 arithmetic wraps: the digest is mod 2^64; no int64 matrix product on the device)
+        bt = Bt[t]
+        H[lo // 65536, :NG] += (w * bt[:, None]).sum(0)
+        pv = (eng.p_dev[8 * lo:8 * hi].view(torch.int32).to(torch.int64) & 0xffffffff) + 1
+        H[lo // 65536, NG] += (pv * bt).sum()
+
+    t0 = time.perf_counter()
+    for k in range(nsub):
+        if k >= E.PIPELINE_SLOTS:
+            digest(k - E.PIPELINE_SLOTS)          # its layer-0 slot is about to be reused
+        m = min(sub, n - eng.pos)
+        eng.pipe.submit(eng.stream[eng.pos:eng.pos + m], eng.layer0[k % E.PIPELINE_SLOTS][:8 * m], eng.p_dev[8 * eng.pos:8 * (eng.pos + m)])
+        eng.pos += m
+        eng.nsub += 1
+    for k in range(max(0, nsub - E.PIPELINE_SLOTS), nsub):
+        digest(k)
+    eng.pipe.sync()
+    dt = time.perf_counter() - t0
+    Hh = H.cpu().numpy().view(np.uint64)
+    os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+    with open(a.out, "w") as f:
+        for b in range(blocks):
+            f.write("%d %s\n" % (min(n, (b + 1) * 65536), " ".join("%016x" % int(x) for x in Hh[b])))
+    print("%d bytes in %.1f s (%.0f B/s), %d blocks of 64 KB -> %s" % (n, dt, n / dt, blocks, a.out))
+    if a.ref and os.path.exists(a.ref):
+        compare(a.out, a.ref)
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
