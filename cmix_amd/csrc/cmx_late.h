@@ -19,7 +19,8 @@
 // writes and another reads WHILE BOTH RUN (rows, selectors, distributions, hints) and the producers' row counters live in UNCACHED
 // DEVICE memory (no stale line in an XCD's L2), written with plain stores followed by `s_waitcnt vmcnt(0)` and the producer's counter,
 // read after the consumer has seen the counter.
-// Every wait is bounded by wall-clock time (CMX_LATE_TIMEOUT_S without progress) and by the box's abort word: a decoder that
+// Every wait is bounded by wall-clock time (CMX_LATE_TIMEOUT_TICKS below: a COMPILE-TIME 30 s without progress -- a caller that stalls longer
+// between predict() and perceive(), e.g. under a debugger, voids the stream; there is no run-time knob) and by the box's abort word: a decoder that
 // stops mid-chunk (cmx_destroy) unwinds the kernels instead of leaving them spinning.
 #ifndef CMX_LATE_H
 #define CMX_LATE_H

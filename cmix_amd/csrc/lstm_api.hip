@@ -19,7 +19,6 @@
 #include "mixnet_state.h"   // CMX_MIXNET_XCD_DEFAULT: the XCD the block kernels leave to the mixing network
 #include "lstm_state.h"
 #include "cmx_late.h"
-#include "cmx_late.h"
 #include "cmx_glibc_rand.h"
 
 extern "C" __global__ void cmx_lstm_prep(const LstmState, const float*, const uint8_t*, size_t, int, int);

@@ -99,6 +99,19 @@ enum { FT_DEFAULT, FT_HDR, FT_JPEG, FT_EXE, FT_TEXT, FT_IMAGE1, FT_IMAGE4, FT_IM
 
 /* ---- allocation tracking (p8f_alloc.h) ---- */
 typedef struct Blk { struct Blk* next; } Blk;
+/* A compressor coding a step of an image / audio / JPEG model: the archive is the reference's, but THIS library's decoder cannot restore it (the late-bit
+   form of those steps is not built: P8F_ERR_IMAGE_LATE); say so once per process, on the compress side, before the user finds out while decoding.
+   CMX_P8_MEDIA_WARNING=0 silences it. */
+static void p8f_media_step_notice(const P8Emit* em) {
+  static int said = 0;
+  if (said || !em->chunk || !em->chunk->xops) return;
+  said = 1;
+  const char* e = getenv("CMX_P8_MEDIA_WARNING");
+  if (e && e[0] == '0') return;
+  fprintf(stderr, "cmix_amd: this stream codes steps of paq8's image / audio / JPEG models; the file decodes with the reference binary, NOT with this library's "
+                  "decoder (cmix_dropin -d stops at the first such step: the decoder's form of those models is not built)\n");
+}
+
 static __thread Blk** g_blocks;
 #undef calloc
 #undef malloc
@@ -397,6 +410,7 @@ static int context_model2(P8Predictor* p, int y, int32_t* sel) {
       p8f_emit_model(em, 0);
       if (jp) {
         if (em->chunk && !em->chunk->xops) return P8F_ERR_IMAGE_LATE;
+        p8f_media_step_notice(em);
         nx += kind == 3 ? 70 : kind ? 1 : 0;
         if (em->xdiscovering) {
           for (int i = 0; i < prefix; i++) X->map[i] = (int16_t)i;
@@ -438,6 +452,7 @@ static int context_model2(P8Predictor* p, int y, int32_t* sel) {
   if (img_w || aud_info) {   /* im24bitModel :5001-5353 / im8bitModel :4743-4999 / audio8bModel :5552-5657 / wavModel :5659-5804 through the model's own tables and weight sets */
     P8Emit* const em = p8f_cur;
     if (em->chunk && !em->chunk->xops) return P8F_ERR_IMAGE_LATE;
+    p8f_media_step_notice(em);
     int sets[16], ranges[16];
     const int prefix = nx;
     const int model = img_w ? (img_bpp == 1 ? P8_MODEL_IM1 : img_bpp == 4 ? P8_MODEL_IM4 : img_bpp == 8 ? P8_MODEL_IM8 : P8_MODEL_IM24) : (((aud_info - 1) & 2) == 0 ? P8_MODEL_AUDIO8 : P8_MODEL_WAV16);

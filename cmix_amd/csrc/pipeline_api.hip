@@ -152,6 +152,7 @@ struct Late {
   LateSet set[3];
   bool active = false, failed = false, predicted = false;
   uint64_t launched = 0;   // chunks whose kernels are enqueued
+  bool touched = false;    // a launch was attempted (some of a chunk's kernels may be running even if the attempt failed half-way)
   uint64_t cur = 0;        // chunk being decoded
   size_t t = 0;            // its next bit
   unsigned partial = 0;
@@ -167,6 +168,7 @@ struct Late {
 struct cmx_pipeline {
   int device = 0;
   Late* late = nullptr;
+  bool lstm_tolerance = false;   // cmx_pipeline_set_tolerance switched the LSTM's weight update to its MFMA form
   size_t max_chunk = 0;
   cmx_ppmd_t* ppmd = nullptr;
   cmx_ctxmodels_t* ctx = nullptr;
@@ -436,10 +438,16 @@ int cmx_pipeline_enable_paq8(cmx_pipeline_t* h) {
 int cmx_pipeline_set_tolerance(cmx_pipeline_t* h, int on) {
   if (!h) { cmx_set_err("cmx_pipeline_set_tolerance: null handle"); return 1; }
   if (h->chunks || h->late) { cmx_set_err("cmx_pipeline_set_tolerance: only before the first chunk"); return 1; }
-  if (cmx_lstm_set_tolerance(h->lstm, on)) return 1;   // the LSTM's weight-update contraction on the matrix cores
-  return cmx_mixnet_set_tolerance(h->mix, on);
+  // the mixing network first (it can refuse: CMX_MIXNET_SPEC=0 / CMX_MIXNET_V1 have no tolerance form); the LSTM's switch (its weight-update contraction
+  // on the matrix cores) follows and is rolled back with the network's if it fails, so that the two never disagree about the mode
+  const int was = cmx_mixnet_mode(h->mix);
+  if (cmx_mixnet_set_tolerance(h->mix, on)) return 1;
+  if (cmx_lstm_set_tolerance(h->lstm, on)) { (void)cmx_mixnet_set_tolerance(h->mix, was == 1); return 1; }
+  h->lstm_tolerance = on != 0;
+  return 0;
 }
-int cmx_pipeline_mixnet_mode(cmx_pipeline_t* h) { return h ? cmx_mixnet_mode(h->mix) : -1; }
+// 0 strict, 1 tolerance: not strict as soon as EITHER the mixing network or the LSTM computes in its tolerance form
+int cmx_pipeline_mixnet_mode(cmx_pipeline_t* h) { return !h ? -1 : (h->lstm_tolerance ? 1 : cmx_mixnet_mode(h->mix)); }
 // ---- diagnostics of a long run (scripts/gpu_long_run.py): all of them synchronise the device ----
 int cmx_pipeline_mixnet_rows(cmx_pipeline_t* h, uint32_t rows[47]) { return h ? cmx_mixnet_rows(h->mix, rows) : 1; }
 int cmx_pipeline_spec_stats(cmx_pipeline_t* h, uint64_t out[5]) { return h ? cmx_mixnet_spec_stats(h->mix, out) : 1; }
@@ -752,6 +760,7 @@ static uint32_t pq_want(uint64_t c, size_t n) { return c ? ((uint32_t)((c - 1) &
 // enqueue every stage kernel of chunk number c (its bits arrive later)
 static int late_launch(cmx_pipeline* h, uint64_t c) {
   Late* L = h->late;
+  L->touched = true;
   const int s = (int)(c % 3);
   LateSet& q = L->set[s];
   const size_t n = kLateChunk;
@@ -845,14 +854,14 @@ int cmx_pipeline_late_start(cmx_pipeline_t* h, int last_bit) {
 int cmx_pipeline_late_stop(cmx_pipeline_t* h) {
   if (!h || !h->late) return 0;
   Late* L = h->late;
-  if (!L->active) return 0;
+  if (!L->active && !L->touched) return 0;   // (a start that failed AFTER its first launch leaves kernels waiting: they are unwound here too)
   for (LateSet& q : L->set) if (q.box) { q.box->abort = 1; }
   __sync_synchronize();
   (void)hipSetDevice(h->device);
   const double t0 = late_now();
   const bool ok = hipDeviceSynchronize() == hipSuccess;
   if (getenv("CMX_TIMING")) fprintf(stderr, "[cmx timing] %-28s %.3f s\n", "late_stop: kernels unwound", (late_now() - t0) / 1e3);
-  L->active = false;
+  L->active = false; L->touched = false;
   if (!ok) { cmx_set_err("cmx_pipeline_late_stop: device error"); return 1; }
   return 0;
 }
@@ -923,7 +932,7 @@ int cmx_pipeline_late_perceive(cmx_pipeline_t* h, int bit) {
   double t0 = late_now();
   auto lap = [&](int k) { const double now = late_now(); L->ms[k] += now - t0; t0 = now; };
   // ---- host stages for the step after this bit: their records are in place before the bit is published ----
-  (void)cmx_p8stage_late_bit(h->p8, bit);
+  if (cmx_p8stage_late_bit(h->p8, bit)) return 1;
   const bool byte_done = (t & 7) == 7, chunk_done = t + 1 == T;
   const size_t b = t >> 3;
   uint8_t byte = 0;

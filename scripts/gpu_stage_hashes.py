@@ -5,7 +5,7 @@ mod 2^64). Compared block by block with the unmodified reference Predictor's dig
 and where.
 
     python scripts/gpu_stage_hashes.py --bytes 8388608 --out gpurun_out/stage_hashes_8m.txt [--ref ref_hashes.txt]
-    python scripts/gpu_stage_hashes.py --compare mine.txt ref.txt         (no GPU: compare two digest files)
+    python scripts/gpu_stage_hashes.py --compare mine.txt ref.txt [g0 g1] (no GPU: compare two digest files, optionally groups g0..g1 only)
 """
 import argparse
 import os
@@ -30,24 +30,24 @@ def group_name(g):
     return "cols %d..%d (%s)" % (lo, hi, a if a == b else a + " .. " + b)
 
 
-def compare(mine_path, ref_path):
+def compare(mine_path, ref_path, glo=0, ghi=NG):
     mine = [l.split() for l in open(mine_path) if l.strip()]
     ref = [l.split() for l in open(ref_path) if l.strip()]
     n = min(len(mine), len(ref))
     for b in range(n):
-        bad = [g for g in range(NG + 1) if mine[b][1 + g] != ref[b][1 + g]]
+        bad = [g for g in range(glo, ghi + 1) if mine[b][1 + g] != ref[b][1 + g]]
         if bad:
             print("compared %d blocks: FIRST DIFFERENCE in block %d (bytes %d..%s): %d groups differ" % (n, b, b * 65536, mine[b][0], len(bad)))
             for g in bad[:40]:
                 print("   ", group_name(g))
             later = {}
             for bb in range(b, n):
-                for g in range(NG + 1):
+                for g in range(glo, ghi + 1):
                     if mine[bb][1 + g] != ref[bb][1 + g]:
                         later.setdefault(g, bb)
             print("    first block each group differs in:", {group_name(g): v for g, v in sorted(later.items(), key=lambda kv: kv[1])[:60]})
             return b
-    print("compared %d blocks: all digests equal" % n)
+    print("compared %d blocks, groups %d..%d: all digests equal" % (n, glo, ghi))
     return None
 
 
@@ -59,8 +59,8 @@ def splitmix64(x):
 
 
 def main():
-    if len(sys.argv) == 4 and sys.argv[1] == "--compare":
-        compare(sys.argv[2], sys.argv[3])
+    if len(sys.argv) >= 4 and sys.argv[1] == "--compare":   # [first group, last group]: oracle/ref_paq8_trace.cpp fills groups 28..125 only
+        compare(sys.argv[2], sys.argv[3], *[int(x) for x in sys.argv[4:6]])
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--bytes", type=int, default=8 << 20)
