@@ -67,7 +67,12 @@ def main():
     ap.add_argument("--seed", type=int, default=1000)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "stage_hashes.txt"))
     ap.add_argument("--ref", default=None, help="oracle/_ref/ref_long_trace's output: compare and report the first block / group that differs")
+    ap.add_argument("--detail-block", type=int, default=-1, help="stop after this 64 KB block and compare its rows with the reference's detail files (ref_long_trace's "
+                    "<out>.block<k>.g<g>.f32 / .p.f32 under --detail-dir): first differing bit and column of every dumped group, both values")
+    ap.add_argument("--detail-dir", default=os.path.join(ROOT, "tmp_longref"))
     a = ap.parse_args()
+    import glob
+    import re
     import torch
     from cmix_amd import engine as E, synth
     from cmix_amd.pipeline import EngineStream, text_file_stream
@@ -80,7 +85,19 @@ def main():
     At = torch.cat([At, torch.zeros(16 * NG - 2078, dtype=torch.int64, device=dev)])
     payload = synth.enwik_like(a.bytes, a.seed, rich=True)
     stream = text_file_stream(payload)
+    detail = {}
+    if a.detail_block >= 0:   # the reference's rows of the block, by group (and "p")
+        for f in glob.glob(os.path.join(a.detail_dir, "*.block%d.*.f32" % a.detail_block)):
+            m = re.search(r"\.block%d\.(g(\d+)|p)\.f32$" % a.detail_block, f)
+            if m:
+                key = "p" if m.group(1) == "p" else int(m.group(2))
+                arr = np.fromfile(f, np.float32)
+                detail[key] = torch.from_numpy(arr if key == "p" else arr.reshape(-1, 16)).to(dev)
+        print("detail files of block %d: %s" % (a.detail_block, sorted(map(str, detail))))
     n = len(stream)
+    if a.detail_block >= 0:   # the engine is built for the WHOLE stream (its vocabulary is the file's), only the head of it is run
+        n = min(n, (a.detail_block + 1) * 65536)
+    report = {}
     eng = EngineStream(0, stream, 4096)
     sub = eng.sub
     nsub = -(-n // sub)
@@ -99,6 +116,29 @@ def main():
         H[lo // 65536, :NG] += (w * bt[:, None]).sum(0)
         pv = (eng.p_dev[8 * lo:8 * hi].view(torch.int32).to(torch.int64) & 0xffffffff) + 1
         H[lo // 65536, NG] += (pv * bt).sum()
+        if detail and lo // 65536 == a.detail_block:
+            r0 = 8 * (lo - a.detail_block * 65536)
+            for key, ref in detail.items():
+                mine = eng.p_dev[8 * lo:8 * hi].view(-1, 1) if key == "p" else l0[:, 16 * key:16 * key + 16]
+                if ref.shape[0] < r0 + mine.shape[0]:
+                    continue   # (the reference's file ends inside this piece)
+                want = ref[r0:r0 + mine.shape[0]].view(mine.shape[0], -1)[:, :mine.shape[1]]
+                bad = (mine.view(torch.int32) != want.view(torch.int32))
+                rep = report.setdefault(key, {"bits_differing": 0, "per_column": [0] * mine.shape[1], "first": None})
+                rep["bits_differing"] += int(bad.any(1).sum())
+                pc = bad.sum(0).tolist()
+                rep["per_column"] = [x + y for x, y in zip(rep["per_column"], pc)]
+                if rep["first"] is None and bool(bad.any()):
+                    t = int(torch.nonzero(bad.any(1))[0])
+                    cols = torch.nonzero(bad[t]).flatten().tolist()
+                    w0, w1 = max(0, t - 24), min(mine.shape[0], t + 40)
+                    c = cols[0]
+                    rep["first"] = {"bit_in_stream": 8 * lo + t, "byte": lo + t // 8, "bit_of_byte": t % 8, "columns": [(0 if key == "p" else 16 * key) + x for x in cols],
+                                    "engine": [float(mine[t, x]) for x in cols], "reference": [float(want[t, x]) for x in cols],
+                                    "engine_hex": ["%08x" % (int(mine[t, x].view(torch.int32)) & 0xffffffff) for x in cols],
+                                    "reference_hex": ["%08x" % (int(want[t, x].view(torch.int32)) & 0xffffffff) for x in cols],
+                                    "window_from_bit": 8 * lo + w0, "window_engine": [float(v) for v in mine[w0:w1, c]], "window_reference": [float(v) for v in want[w0:w1, c]],
+                                    "bytes_before": bytes(stream[max(0, lo + t // 8 - 48):lo + t // 8 + 1]).decode("latin1")}
 
     t0 = time.perf_counter()
     for k in range(nsub):
@@ -118,6 +158,12 @@ def main():
         for b in range(blocks):
             f.write("%d %s\n" % (min(n, (b + 1) * 65536), " ".join("%016x" % int(x) for x in Hh[b])))
     print("%d bytes in %.1f s (%.0f B/s), %d blocks of 64 KB -> %s" % (n, dt, n / dt, blocks, a.out))
+    if detail:
+        import json
+        with open(a.out + ".detail.json", "w") as f:
+            json.dump({str(k): v for k, v in report.items()}, f, indent=1)
+        for k, v in sorted(report.items(), key=lambda kv: str(kv[0])):
+            print("group %s: %d bits differ in block %d; first: %s" % (k, v["bits_differing"], a.detail_block, json.dumps(v["first"])[:1500]))
     if a.ref and os.path.exists(a.ref):
         compare(a.out, a.ref)
     eng.close()
