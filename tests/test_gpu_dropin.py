@@ -30,6 +30,9 @@ def _missing(what):
     pytest.skip(what)
 
 
+LAST_STDERR = [""]   # of the most recent _run (the compress-side notices are checked through it)
+
+
 def _run(mode, files, timeout=600, exe=None):
     with tempfile.TemporaryDirectory() as d:
         paths = []
@@ -42,6 +45,7 @@ def _run(mode, files, timeout=600, exe=None):
         exe = exe or EXE
         r = subprocess.run([exe, mode] + paths + [out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
         assert r.returncode == 0, f"{os.path.basename(exe)} {mode} failed: {r.stderr.decode(errors='replace')[-400:]}"
+        LAST_STDERR[0] = r.stderr.decode(errors="replace")
         with open(out, "rb") as f:
             return f.read()
 
@@ -330,6 +334,8 @@ def test_dropin_engine_file_with_a_jpeg_is_byte_identical():
     with np.load(fx) as z:
         payload, blob = z["payload"].tobytes(), z["cmix_file"].tobytes()
     assert _run("-c", [("in", payload)], exe=DROPIN, timeout=600) == blob
+    # the compress side says that this library's decoder cannot restore the file (p8f_media_step_notice), a plain text file does not trigger it
+    assert "NOT with this library's decoder" in LAST_STDERR[0]
 
 
 def test_dropin_decoding_a_file_with_an_image_fails_loudly():
