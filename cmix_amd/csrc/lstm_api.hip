@@ -269,6 +269,7 @@ int cmx_lstm_run(cmx_lstm_t* h, const float* d_in_probs, const uint8_t* d_bytes,
  * contraction runs as v_mfma_f32_16x16x4_f32 tiles (cmx_lstm_bptt_acc_mfma) instead of the reference's ordered, separately rounded chain */
 int cmx_lstm_set_tolerance(cmx_lstm_t* h, int on) {
   if (!h) { cmx_set_err("cmx_lstm_set_tolerance: null handle"); return 1; }
+  if (h->bytes_done && h->tolerance != (on != 0)) { cmx_set_err("cmx_lstm_set_tolerance: only before the first byte (a stream is strict or tolerant from its start)"); return 1; }
   h->tolerance = on != 0;
   return 0;
 }

@@ -197,3 +197,38 @@ def test_eight_segment_split_is_bit_exact(monkeypatch):
     assert np.array_equal(out["0"][0][:1536].view(np.uint32), ref.view(np.uint32)), "four segments != oracle"
     assert np.array_equal(out["1"][0].view(np.uint32), out["0"][0].view(np.uint32)), "eight segments: final p differs"
     assert np.array_equal(out["1"][1].view(np.uint32), out["0"][1].view(np.uint32)), "eight segments: a mixer output differs"
+
+
+@pytest.mark.parametrize("switch", ["CMX_MIXNET_PAD=1", "CMX_MIXNET_SLEEP=1", "CMX_MIXNET_RERUN4=1", "CMX_MIXNET_SEG16=1", "CMX_MIXNET_SEG16=2",
+                                    "CMX_MIXNET_CAND=2", "CMX_MIXNET_XCD=7"])
+def test_round5_kernel_variants_are_bit_exact(monkeypatch, switch):
+    """The opt-in forms of the speculative kernel measured in round 5 (DESIGN.md 4.1's table: padded hand-off words, sleepy polls, a missed segment
+    re-run in four pieces, 16 DPP-fed segments with 64 / 128 candidates, 128 candidates on four segments, all workgroups on one XCD with the hand-off
+    words in its L2): every one is the same ordered f32 sum by construction -- the same bits as the default kernel and as the oracle, over two launches."""
+    import torch
+    from cmix_amd import engine as E
+    from oracle import oracle as O
+    T = 3072
+    probs, sel, bits = synth_mixnet_inputs(T, seed=2)
+    ref = O.MixNet().run(probs[:1024], sel[:1024], bits[:1024])
+    d_probs = torch.from_numpy(probs).cuda()
+    d_sel = torch.from_numpy((sel & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.int32)).cuda()
+    d_bits = torch.from_numpy(bits).cuda()
+    out = {}
+    for on in (False, True):
+        name, val = switch.split("=")
+        if on:
+            monkeypatch.setenv(name, val)
+        else:
+            monkeypatch.delenv(name, raising=False)
+        net = E.MixNet(0)
+        p = torch.empty(T, dtype=torch.float32, device="cuda")
+        mix = torch.empty((T, 47), dtype=torch.float32, device="cuda")
+        for a, b in ((0, 700), (700, T)):
+            net.run(d_probs[a:b], d_sel[a:b], d_bits[a:b], p[a:b], mix[a:b])
+            torch.cuda.synchronize()
+        out[on] = (p.cpu().numpy(), mix.cpu().numpy())
+        net.close()
+    assert np.array_equal(out[False][0][:1024].view(np.uint32), ref.view(np.uint32)), "default kernel != oracle"
+    assert np.array_equal(out[True][0].view(np.uint32), out[False][0].view(np.uint32)), switch + ": final p differs"
+    assert np.array_equal(out[True][1].view(np.uint32), out[False][1].view(np.uint32)), switch + ": a mixer output differs"
