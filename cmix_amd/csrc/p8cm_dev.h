@@ -61,8 +61,9 @@ struct P8CmBit { int y, bp, c0, c1, order; const uint32_t* ctx; const uint16_t* 
 P8_HD uint32_t p8d_cm_ctxof(const P8CmDev* d, const P8CmBit& u, int s) { return s == d->order_slot ? d->order_ctx[u.order] : u.ctx[s]; }
 P8_HD uint16_t p8d_cm_chkof(const P8CmDev* d, const P8CmBit& u, int s) { return s == d->order_slot ? d->order_chk[u.order] : u.chk[s]; }
 P8_HD uint32_t p8d_rnd_next(P8Rnd* g) {   // Random::operator() :158-161
-  ++g->i;
-  return g->table[g->i & 63] = g->table[(g->i - 24) & 63] ^ g->table[(g->i - 55) & 63];
+  const uint32_t i = (uint32_t)g->i + 1u;   // (the reference's `int i` wraps after 2^31 draws; only i mod 64 matters: unsigned here, no overflow to reason about)
+  g->i = (int)i;
+  return g->table[i & 63] = g->table[(i - 24) & 63] ^ g->table[(i - 55) & 63];
 }
 // one context, one bit: ContextMap::mix1's loop body (:1072-1145). rv: the generator value this context consumes if its
 // update draws (parallel path), or NULL to draw from the generator itself (serial walk).

@@ -95,7 +95,13 @@ P8_HD void p8f_load(const P8CmDev* d, const P8FamHome* home, const uint16_t* sm_
     for (int k = 0; k < P8CM_MAXI + 8; k++) sh->shared[k] = 0;
     const int i0 = d->rnd.i;   // V(idx) for idx in (i0 - 64, i0] is the generator's table; then the next 256
     for (int k = 0; k < 64; k++) { const int idx = i0 - k; sh->rv[(uint32_t)idx & (P8F_RV - 1)] = d->rnd.table[idx & 63]; }
-    for (int idx = i0 + 1; idx <= i0 + P8F_LOOK; idx++) sh->rv[(uint32_t)idx & (P8F_RV - 1)] = sh->rv[(uint32_t)(idx - 24) & (P8F_RV - 1)] ^ sh->rv[(uint32_t)(idx - 55) & (P8F_RV - 1)];
+    // (the counter is the reference's `int i` (paq8.cpp:154,163), which wraps; only its value mod 64 matters to the generator. Every index below is taken
+    // modulo 2^32 and every range is walked by COUNT: a `<=` between two such indices fails in the step in which the counter passes 2^32 -- after
+    // 4.29 G draws, 8.0 MB into enwik-like text -- and leaves the ring with stale values for good: round 5's 8 MiB finding)
+    for (uint32_t k = 1; k <= (uint32_t)P8F_LOOK; k++) {
+      const uint32_t idx = (uint32_t)i0 + k;
+      sh->rv[idx & (P8F_RV - 1)] = sh->rv[(idx - 24) & (P8F_RV - 1)] ^ sh->rv[(idx - 55) & (P8F_RV - 1)];
+    }
   }
 }
 P8_HD void p8f_store(P8CmDev* d, P8FamHome* home, uint16_t* sm_home, const P8FamShared* sh, uint32_t rnd_i, int tid, int nthreads) {
@@ -113,11 +119,16 @@ P8_HD void p8f_store(P8CmDev* d, P8FamHome* home, uint16_t* sm_home, const P8Fam
 }
 // keep the ring 256 values ahead of i: values (old_i + 256, new_i + 256], 24 at a time (a value depends on those 24 and 55
 // back, so 24 consecutive new ones are independent of each other). One call = one group of 24; callers loop over the
-// groups with all 24 lanes per group (one wavefront in lockstep on the device).
-P8_HD void p8f_refill_group(P8FamShared* sh, uint32_t base, uint32_t hi, int lane24) {
+// groups with all 24 lanes per group (one wavefront in lockstep on the device): P8F_REFILL below. Indices are modulo 2^32 (the
+// generator's counter wraps, p8f_load); `left` = how many values from `base` on are still due.
+P8_HD void p8f_refill_group(P8FamShared* sh, uint32_t base, uint32_t left, int lane24) {
   const uint32_t idx = base + (uint32_t)lane24;
-  if (idx <= hi) sh->rv[idx & (P8F_RV - 1)] = sh->rv[(idx - 24) & (P8F_RV - 1)] ^ sh->rv[(idx - 55) & (P8F_RV - 1)];
+  if ((uint32_t)lane24 < left) sh->rv[idx & (P8F_RV - 1)] = sh->rv[(idx - 24) & (P8F_RV - 1)] ^ sh->rv[(idx - 55) & (P8F_RV - 1)];
 }
+// the groups of one step: the counter went from prev_i to rnd_i
+#define P8F_REFILL(sh, prev_i, rnd_i, lane24) \
+  for (uint32_t p8f_k = 0, p8f_n = (uint32_t)(rnd_i) - (uint32_t)(prev_i); p8f_k < p8f_n; p8f_k += 24) \
+    p8f_refill_group((sh), (uint32_t)(prev_i) + (uint32_t)P8F_LOOK + 1u + p8f_k, p8f_n - p8f_k, (lane24))
 
 P8_HD void p8f_lane(const P8CmDev* d, int s, P8FamTmp* t) {
   t->inst = d->slot_inst[s];

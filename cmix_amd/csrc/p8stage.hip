@@ -203,7 +203,7 @@ __device__ __forceinline__ void p8s_fam2_body(P8CmDev* d, P8FamHome* home, const
     }
     if (sl < S) p8f_phase1(d, &sh, u, sl, &tmp);
     if (rl >= 0)   // 24 lanes of one wavefront in lockstep, a group of 24 values per iteration
-      for (uint32_t base = prev_i + P8F_LOOK + 1; base <= rnd_i + P8F_LOOK; base += 24) p8f_refill_group(&sh, base, rnd_i + P8F_LOOK, rl);
+      P8F_REFILL(&sh, prev_i, rnd_i, rl);
     P8F_TICK(1);
     __syncthreads();
     P8F_TICK(2);
@@ -1709,6 +1709,17 @@ int cmx_p8stage_late_bit(cmx_p8stage_t* h, int bit) {
   if (!h) { cmx_set_err("cmx_p8stage_late_bit: null handle"); return 1; }
   p8f_front_set_bit(h->front, bit);
   h->last_bit = bit ? 1 : 0;
+  return 0;
+}
+// test hook: place the counter of the ContextMap family's shared generator (Random::i, paq8.cpp:154) before the first byte. The generator's VALUES do not
+// depend on the counter, only on counter mod 64 (the 64 table words keep their places for a multiple of 64): tests put it shortly before 2^31 / 2^32 to
+// check in seconds what a stream reaches after 4 / 8 MB (tests/test_zgpu_p8stage.py, round 5's 8 MiB finding).
+int cmx_p8stage_set_generator_counter(cmx_p8stage_t* h, uint32_t counter) {
+  if (!h || !h->d_fam) { cmx_set_err("cmx_p8stage_set_generator_counter: null handle"); return 1; }
+  if (counter & 63u) { cmx_set_err("cmx_p8stage_set_generator_counter: a multiple of 64 (the table words stay where they are)"); return 1; }
+  if (hipSetDevice(h->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { cmx_set_err("cmx_p8stage_set_generator_counter: device error"); return 1; }
+  const int v = (int)counter;
+  if (hipMemcpy((char*)h->d_fam + offsetof(P8CmDev, rnd) + offsetof(P8Rnd, i), &v, sizeof v, hipMemcpyHostToDevice) != hipSuccess) { cmx_set_err("cmx_p8stage_set_generator_counter: copy failed"); return 1; }
   return 0;
 }
 int cmx_p8stage_mixfail(cmx_p8stage_t* h) { return h && h->h_mixfail && *h->h_mixfail ? 1 : 0; }

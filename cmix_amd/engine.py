@@ -48,6 +48,7 @@ def lib():
         L.cmx_p8stage_destroy.argtypes = [C.c_void_p]
         L.cmx_p8stage_run.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
         L.cmx_p8stage_sync.argtypes = [C.c_void_p]
+        L.cmx_p8stage_set_generator_counter.argtypes = [C.c_void_p, C.c_uint32]
         L.cmx_fxcm_create.restype = C.c_void_p
         L.cmx_fxcm_create.argtypes = [C.c_char_p, C.c_int]
         L.cmx_fxcm_destroy.argtypes = [C.c_void_p]
@@ -877,6 +878,11 @@ class P8Stage:
 
     def sync(self):
         if lib().cmx_p8stage_sync(self.h):
+            raise CmxError(last_error())
+
+    def set_generator_counter(self, counter):
+        """Test hook (before the first byte): the counter of the ContextMap family's shared generator, a multiple of 64."""
+        if lib().cmx_p8stage_set_generator_counter(self.h, int(counter) & 0xFFFFFFFF):
             raise CmxError(last_error())
 
     def close(self):

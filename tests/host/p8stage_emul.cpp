@@ -128,6 +128,8 @@ void p8s_layout_dump(void* h) {
 void p8s_set_miniwalk(void* h, int mode) { ((Emul*)h)->fam_miniwalk = mode; }
 void p8s_set_late(void* h, int on) { ((Emul*)h)->late = on & 1; ((Emul*)h)->late_models = (on >> 1) & 1; }
 void p8s_miniwalk_stats(void* h, uint64_t* out2) { out2[0] = ((Emul*)h)->fam_mini; out2[1] = ((Emul*)h)->fam_mini_full; }
+uint32_t p8s_rnd_i(void* h) { return ((Emul*)h)->f2_i; }   // how many values of the shared generator the family has drawn (mod 2^32)
+void p8s_set_rnd_i(void* h, uint32_t i) { Emul* e = (Emul*)h; e->S.fam.rnd.i = (int)i; e->f2_i = e->f2_prev_i = i; }   // test hook: place the generator's counter (its 64 values stay) -- to reach the counter's sign change without 8 MB of input
 void p8s_stats(void* h, uint64_t* out3) { Emul* e = (Emul*)h; out3[0] = e->steps; out3[1] = e->fam_serial; out3[2] = e->cm2_serial; }
 // nbytes more bytes of the stream; out [8 nbytes][1591] f32 = PAQ8::Predict() before each of their bits. 0 or a negative front-end code.
 int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
@@ -275,8 +277,8 @@ int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {
       if (g >= 8 && !md) {
         static P8FamTmp tmp[P8CM_MAXS];
         for (int s = SS - 1; s >= 0; s--) { p8f_lane(d, s, &tmp[s]); tmp[s].cx = p8f_ctx(d, fu, s); tmp[s].ck = p8f_chk(d, fu, s); p8f_phase1(d, sh, fu, s, &tmp[s]); }
-        for (uint32_t base = e->f2_prev_i + P8F_LOOK + 1; base <= e->f2_i + P8F_LOOK; base += 24)
-          for (int l = 23; l >= 0; l--) p8f_refill_group(sh, base, e->f2_i + P8F_LOOK, l);
+        for (uint32_t k = 0, nn = e->f2_i - e->f2_prev_i; k < nn; k += 24)   // (P8F_REFILL with the lanes of a group looped)
+          for (int l = 23; l >= 0; l--) p8f_refill_group(sh, e->f2_prev_i + P8F_LOOK + 1u + k, nn - k, l);
         const bool look = fu.bp == 0 || fu.bp == 2 || fu.bp == 5;
         int total = 0;
         if (getenv("CMX_P8_TRACE_G") && g == (uint64_t)atoi(getenv("CMX_P8_TRACE_G"))) {

@@ -261,3 +261,32 @@ def test_big_media_stream_digests():
     L.p8s_destroy(h)
     bad = np.nonzero(digest(hashes) != want)[0]
     assert bad.size == 0, ("first differing block of 256 steps:", bad[0], "of", len(want))
+
+
+@pytest.mark.parametrize("start", [(1 << 31) - 64 * 15000, (1 << 32) - 64 * 15000])
+def test_shared_generator_counter_wraps_like_the_references(start):
+    """The ContextMap family's shared rnd() (paq8.cpp:152-165) keeps an `int` counter that only matters modulo 64; it passes 2^31 after ~4 MB and 2^32
+    after 8.0 MB of enwik-like text (34..67 draws per bit). Round 5's 8 MiB run left the reference exactly there: the look-ahead ring of generator values
+    was refilled up to an index compared with `<=`, which fails in the step the counter wraps. Here the counter is placed shortly before 2^31 / 2^32
+    (a multiple of 64: the 64 table words keep their places, so the VALUES are those of a fresh generator) and the outputs must stay the reference's."""
+    from make_paq8_hashes import row_hash
+    L = emul()
+    L.p8s_rnd_i.restype = C.c_uint32
+    L.p8s_rnd_i.argtypes = [C.c_void_p]
+    L.p8s_set_rnd_i.argtypes = [C.c_void_p, C.c_uint32]
+    stream, want = load_hashes("rich_16k")
+    n = 7000
+    h = L.p8s_create(11)
+    L.p8s_set_rnd_i(h, start & 0xFFFFFFFF)
+    d = np.ascontiguousarray(stream[:n])
+    out = np.zeros((8 * n, 1591), np.float32)
+    pos = 0
+    while pos < n:
+        m = min(1000, n - pos)
+        assert L.p8s_run(h, d[pos:].ctypes.data, m, out[8 * pos:].ctypes.data) == 0
+        pos += m
+    end = L.p8s_rnd_i(h)
+    L.p8s_destroy(h)
+    assert end < (start & 0xFFFFFFFF) or (start < (1 << 31) <= end), "the counter did not pass the boundary: lengthen the stream"
+    bad = np.nonzero(row_hash(out) != want[:8 * n])[0]
+    assert bad.size == 0, ("first differing step:", int(bad[0]), "byte", int(bad[0]) // 8)

@@ -13,10 +13,12 @@ import make_golden as mg
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
 
 
-def run_device(data, chunks):
+def run_device(data, chunks, generator_counter=None):
     import torch
     from cmix_amd import engine as E
     st = E.P8Stage(0)
+    if generator_counter is not None:
+        st.set_generator_counter(generator_counter)
     outs, pos, k = [], 0, 0
     data = bytes(data)
     while pos < len(data):
@@ -50,6 +52,20 @@ def test_stage_vs_reference_hashes(name):
     h = row_hash(got)
     bad = np.nonzero(h != want)[0]
     assert bad.size == 0, (name, "first differing step:", bad[0], "of", len(want))
+
+
+@pytest.mark.parametrize("start", [(1 << 31) - 64 * 15000, (1 << 32) - 64 * 15000])
+def test_shared_generator_counter_wraps_like_the_references(start):
+    """Round 5's 8 MiB finding on the device: the ContextMap family's shared generator has drawn 2^32 values 8.0 MB into enwik-like text, and the kernel's
+    look-ahead ring of its values was refilled up to an index compared with `<=` -- wrong in the step the counter wraps, and for good afterwards. The
+    counter is placed shortly before 2^31 / 2^32 (a multiple of 64: the same VALUES as a fresh generator, tests/test_p8stage_host.py has the host twin)
+    and the stage's 1591 columns must stay the reference's over the wrap."""
+    from make_paq8_hashes import row_hash
+    from test_p8stage_host import load_hashes
+    stream, want = load_hashes("rich_16k")
+    got = run_device(stream, [1024, 1, 4096, 333], generator_counter=start)
+    bad = np.nonzero(row_hash(got) != want)[0]
+    assert bad.size == 0, ("first differing step:", bad[0], "of", len(want))
 
 
 @pytest.mark.parametrize("name", ["bmp24_14k", "bmp32_8k", "bmp24_raw_9k", "pgm8_4k", "bmp8_gray_raw_5k", "bmp8_pal_raw_5k",
