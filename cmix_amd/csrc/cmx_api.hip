@@ -526,7 +526,7 @@ static int mixnet_run_impl(cmx_mixnet_t* h, const float* d_probs, const uint32_t
     // epochs and value|tag words restart at 0 with every launch; 1 main + 26 helper workgroups, co-resident (27 of 256 CUs)
     HIP_OK(hipMemsetAsync(h->d_xfer, 0, CMX_SPEC_HEADER_BYTES, st));
     const bool cumask = cmx_cumask_on() != 0;   // the stream's compute-unit mask does the placement: 27 workgroups, all of them work, the XCC census still decides the hand-off's form
-    const int kmode = 3 | (h->profile ? 4 : 0) | ((h->dbg & 15) << 4) | (h->tolerance ? 0x1000 : 0) | (h->seg8 ? 0x2000 : 0) | (h->pad ? 0x4000 : 0) | (h->sleepy ? 0x8000 : 0) | (h->seg16 ? 0x10000 : 0) | (h->seg16 == 2 ? 0x40000 : 0) | (h->xcd >= 0 ? 0x20000 | ((h->xcd & 7) << 20) : 0) | (h->rerun4 ? 0x80000 : 0) | (getenv("CMX_MIXNET_XCD_NOLOCAL") ? 0x800000 : 0) | (cumask ? 0x400000 : 0);
+    const int kmode = 3 | (h->profile ? 4 : 0) | ((h->dbg & 15) << 4) | (h->tolerance ? 0x1000 : 0) | (h->seg8 ? 0x2000 : 0) | (h->pad ? 0x4000 : 0) | (h->sleepy ? 0x8000 : 0) | (h->seg16 ? 0x10000 : 0) | (h->seg16 == 2 ? 0x40000 : 0) | (h->xcd >= 0 ? 0x20000 | ((h->xcd & 7) << 20) : 0) | (h->rerun4 ? 0x80000 : 0) | (getenv("CMX_MIXNET_XCD_NOLOCAL") ? 0x800000 : 0) | (cumask ? 0x1000000 : 0);
     static const bool padgrid = getenv("CMX_MIXNET_PADGRID") != nullptr;   // diagnostic: the 8 x 27 grid of the one-XCD placement without the placement (blocks 27.. leave at once)
     const unsigned grid = (1 + CMX_SPEC_HELPERS) * ((h->xcd >= 0 && !cumask) || padgrid ? 8 : 1);   // placement: 8 x 27 workgroups, those with blockIdx % 8 == xcd work
     if (box && box->box)   // a decoder's chunk: the patient instantiation of the same roles

@@ -2228,7 +2228,9 @@ template <bool LATE, int HV> __device__ __forceinline__ void spec_kernel_body(
   bool local = false;
   if (!(mode & 0x20000) && role > CMX_SPEC_HELPERS) return;   // diagnostic launches with a padded grid (CMX_MIXNET_PADGRID): the surplus workgroups leave at once
   if (mode & 0x20000) {
-    if (!(mode & 0x400000)) {   // (0x400000: the stream carries a compute-unit mask that does the placement -- grid 27, every block has a role)
+    if (!(mode & 0x1000000)) {   // (0x1000000: the stream carries a compute-unit mask that does the placement -- grid 27, every block has a role. NOT a bit of
+                                 // 20..22, the XCD number's field: as 0x400000 it made XCD 4..7 take this branch -- 216 workgroups with roles up to 215,
+                                 // out-of-bounds rows, the memory fault of profiles/r05_xcd_fault.txt)
       if (((int)blockIdx.x & 7) != ((mode >> 20) & 7)) return;
       role = (int)blockIdx.x >> 3;
     }

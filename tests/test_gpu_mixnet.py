@@ -200,14 +200,13 @@ def test_eight_segment_split_is_bit_exact(monkeypatch):
 
 
 @pytest.mark.parametrize("switch", ["CMX_MIXNET_PAD=1", "CMX_MIXNET_SLEEP=1", "CMX_MIXNET_RERUN4=1", "CMX_MIXNET_SEG16=1", "CMX_MIXNET_SEG16=2",
-                                    "CMX_MIXNET_CAND=2"])
+                                    "CMX_MIXNET_CAND=2", "CMX_MIXNET_XCD=7", "CMX_MIXNET_XCD=2"])
 def test_round5_kernel_variants_are_bit_exact(monkeypatch, switch):
     """The opt-in forms of the speculative kernel measured in round 5 (DESIGN.md 4.1's table: padded hand-off words, sleepy polls, a missed segment
     re-run in four pieces, 16 DPP-fed segments with 64 / 128 candidates, 128 candidates on four segments): every one is the same ordered f32 sum by
-    construction -- the same bits as the default kernel and as the oracle, over two launches. NOT in the list: the one-XCD placement (CMX_MIXNET_XCD).
-    It is bit-exact when every handle of the process uses it (this whole file passes with the variable set, profiles/r05_mixnet_rerun4_xcd.txt), but a
-    handle created with it AFTER a default handle of the same process aborted with a GPU memory fault (profiles/r05_xcd_fault.txt; cause not found): the
-    switch is experimental and documented as such."""
+    construction -- the same bits as the default kernel and as the oracle, over two launches. The one-XCD placement (all workgroups on one XCD, the hand-off
+    words in its L2) is in the list with an XCD number below and above 4: the flag of the CU-mask diagnostic once shared a bit with that number's field,
+    which sent XCD 4..7 down the wrong branch (216 workgroups with roles, out-of-bounds rows: profiles/r05_xcd_fault.txt)."""
     import torch
     from cmix_amd import engine as E
     from oracle import oracle as O
