@@ -59,7 +59,7 @@ class EngineStream:
     is for a compressor (reference src/predictor.cpp:361-469), a sub-chunk of known bytes at a time. feed() enqueues;
     finish() returns the container bytes (header + arithmetic code), identical to the reference binary's file."""
 
-    def __init__(self, device_index, stream, sub_chunk=4096, dictionary_used=False):
+    def __init__(self, device_index, stream, sub_chunk=4096, dictionary_used=False, vocab=None):
         import torch
         self.torch = torch
         self.dev = torch.device("cuda", device_index)
@@ -67,7 +67,9 @@ class EngineStream:
         n = len(self.stream)
         self.sub = max(1, min(sub_chunk, n))
         self.vocab = np.ones(256, np.uint8)
-        if n >= 10000:  # kMinVocabFileSize (runner.cpp:14,196-199)
+        if vocab is not None:   # the HEAD of a longer stream is run (diagnosis scripts): the vocabulary is the whole file's
+            self.vocab = np.ascontiguousarray(vocab, np.uint8).copy()
+        elif n >= 10000:  # kMinVocabFileSize (runner.cpp:14,196-199)
             self.vocab = np.zeros(256, np.uint8)
             self.vocab[np.unique(self.stream)] = 1
         self.header = E.header_write(n, self.vocab, dictionary_used)

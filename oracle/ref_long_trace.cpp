@@ -27,9 +27,19 @@ float ref_predict(void);
 void ref_perceive(int bit);
 int ref_get_model_probs(float* out);
 }
+#ifdef WITH_ORACLE_MIXNET   // -DWITH_ORACLE_MIXNET -L_build -lcmixoracle: every row is also fed to the oracle's restatement of the final mixing network + SSE, whose
+extern "C" {                // result must be the float Predictor::Predict() returned; the selectors come from ref_get_mixers (ref_harness.cpp)
+#include "cmix_oracle.h"
+int ref_get_mixers(int layer, uint64_t* ctx, float* out);
+int ref_num_mixers(int layer);
+}
+static orc_mixnet* g_om = nullptr;
+static unsigned long long g_mix_bad = 0; static long long g_mix_first = -1;
+#endif
 static uint64_t splitmix64(uint64_t x) { x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; return x ^ (x >> 31); }
 enum { NG = 130, BLOCK_BITS = 1 << 19 };
 static uint64_t A[2078], B[BLOCK_BITS];
+static FILE* g_pfile = nullptr;   // REF_TRACE_P_FILE=path: every final probability, 4 bytes per bit (to run the coder over them: is this harness the binary?)
 static std::vector<uint8_t> s;
 
 struct Detail {   // what the woken child writes while it repeats a block
@@ -51,6 +61,19 @@ static void run_block(size_t t0, size_t t1, uint64_t* h, Detail* d) {
       uint32_t u; memcpy(&u, &probs[c], 4);
       g[c >> 4] += ((uint64_t)u + 1ull) * A[c];
     }
+#ifdef WITH_ORACLE_MIXNET
+    {
+      uint64_t sel[64]; float mo[64]; int q = 0;
+      for (int layer = 0; layer < 3; ++layer) { ref_get_mixers(layer, sel + q, mo + q); q += ref_num_mixers(layer); }
+      const float p_orc = orc_mixnet_step(g_om, probs, sel, (s[t >> 3] >> (7 - (t & 7))) & 1, nullptr);
+      if (memcmp(&p_orc, &p, 4) != 0) {
+        if (g_mix_first < 0) g_mix_first = (long long)t;
+        if (g_mix_bad < 20) fprintf(stderr, "oracle mixing network != reference at bit %zu (byte %zu bit %zu): oracle %.9g (%08x) reference %.9g (%08x)\n", t, t >> 3, t & 7, p_orc, *(uint32_t*)&p_orc, p, *(const uint32_t*)&p);
+        ++g_mix_bad;
+      }
+    }
+#endif
+    if (g_pfile) fwrite(&p, 4, 1, g_pfile);
     uint32_t u; memcpy(&u, &p, 4);
     const uint64_t hp = ((uint64_t)u + 1ull) * b;
     for (int k = 0; k < NG; ++k) h[k] += g[k] * b;
@@ -94,6 +117,10 @@ int main(int argc, char** argv) {
   const size_t first_snapshot = argc > 5 ? (size_t)atol(argv[5]) : 0;
   FILE* out = fopen(outp.c_str(), "w"); if (!out) return 5;
   if (ref_create(vocab, "")) return 6;
+  if (getenv("REF_TRACE_P_FILE")) g_pfile = fopen(getenv("REF_TRACE_P_FILE"), "wb");
+#ifdef WITH_ORACLE_MIXNET
+  g_om = orc_mixnet_create();
+#endif
   for (int c = 0; c < 2078; ++c) A[c] = splitmix64((uint64_t)c) | 1ull;
   for (int i = 0; i < BLOCK_BITS; ++i) B[i] = splitmix64(0x1000000ull + (uint64_t)i) | 1ull;
   const size_t nbits = s.size() * 8, nblocks = (nbits + BLOCK_BITS - 1) / BLOCK_BITS;
@@ -149,8 +176,12 @@ int main(int argc, char** argv) {
     }
     fprintf(out, "%zu", t1 >> 3);
     for (int g = 0; g <= NG; ++g) fprintf(out, " %016llx", (unsigned long long)h[g]);
+#ifdef WITH_ORACLE_MIXNET
+    fprintf(out, " mixnet_bits_differing_so_far %llu first %lld", g_mix_bad, g_mix_first);
+#endif
     fprintf(out, "\n"); fflush(out);
   }
   fclose(out);
+  if (g_pfile) fclose(g_pfile);
   return 0;
 }

@@ -70,6 +70,10 @@ def main():
     ap.add_argument("--detail-block", type=int, default=-1, help="stop after this 64 KB block and compare its rows with the reference's detail files (ref_long_trace's "
                     "<out>.block<k>.g<g>.f32 / .p.f32 under --detail-dir): first differing bit and column of every dumped group, both values")
     ap.add_argument("--detail-dir", default=os.path.join(ROOT, "tmp_longref"))
+    ap.add_argument("--lean", action="store_true", help="with --detail-block: no digests, only the detail block's comparison; the report is written (and the process ends) at the "
+                    "first difference -- for a run that has seconds of GPU time; --head-file / --vocab-file: the stream's head and the whole file's vocabulary from files")
+    ap.add_argument("--head-file", default=None)
+    ap.add_argument("--vocab-file", default=None)
     a = ap.parse_args()
     import glob
     import re
@@ -83,8 +87,11 @@ def main():
     At = torch.from_numpy(A.view(np.int64)).to(dev)
     Bt = torch.from_numpy(B.view(np.int64)).to(dev)
     At = torch.cat([At, torch.zeros(16 * NG - 2078, dtype=torch.int64, device=dev)])
-    payload = synth.enwik_like(a.bytes, a.seed, rich=True)
-    stream = text_file_stream(payload)
+    if a.head_file:
+        stream = np.fromfile(a.head_file, np.uint8).tobytes()
+    else:
+        payload = synth.enwik_like(a.bytes, a.seed, rich=True)
+        stream = text_file_stream(payload)
     detail = {}
     if a.detail_block >= 0:   # the reference's rows of the block, by group (and "p")
         for f in glob.glob(os.path.join(a.detail_dir, "*.block%d.*.f32" % a.detail_block)):
@@ -98,15 +105,17 @@ def main():
     if a.detail_block >= 0:   # the engine is built for the WHOLE stream (its vocabulary is the file's), only the head of it is run
         n = min(n, (a.detail_block + 1) * 65536)
     report = {}
-    eng = EngineStream(0, stream, 4096)
+    eng = EngineStream(0, stream, 4096, vocab=np.fromfile(a.vocab_file, np.uint8) if a.vocab_file else None)
     sub = eng.sub
     nsub = -(-n // sub)
     blocks = -(-n // 65536)
     H = torch.zeros((blocks, NG + 1), dtype=torch.int64, device=dev)
 
     def digest(k):   # sub-chunk k is complete: fold its rows into its 64 KB block's digests
-        eng.pipe.wait(k)
         lo, hi = k * sub, min(n, (k + 1) * sub)
+        if a.lean and lo // 65536 != a.detail_block:
+            return   # (submit() itself waits for a free slot)
+        eng.pipe.wait(k)
         l0 = eng.layer0[k % E.PIPELINE_SLOTS][:8 * (hi - lo)]
         t = torch.arange(8 * lo, 8 * hi, device=dev) & ((1 << 19) - 1)
         v = (l0.view(torch.int32).to(torch.int64) & 0xffffffff) + 1
@@ -139,6 +148,15 @@ def main():
                                     "reference_hex": ["%08x" % (int(want[t, x].view(torch.int32)) & 0xffffffff) for x in cols],
                                     "window_from_bit": 8 * lo + w0, "window_engine": [float(v) for v in mine[w0:w1, c]], "window_reference": [float(v) for v in want[w0:w1, c]],
                                     "bytes_before": bytes(stream[max(0, lo + t // 8 - 48):lo + t // 8 + 1]).decode("latin1")}
+                    if a.lean:   # seconds of GPU time left: the report NOW, then out
+                        import json
+                        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+                        with open(a.out + ".detail.json", "w") as f:
+                            json.dump({str(kk): vv for kk, vv in report.items()}, f, indent=1)
+                            f.flush()
+                            os.fsync(f.fileno())
+                        print("first difference: %s" % json.dumps(rep["first"])[:1200], flush=True)
+                        os._exit(0)
 
     t0 = time.perf_counter()
     for k in range(nsub):
