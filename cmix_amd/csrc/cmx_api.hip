@@ -25,12 +25,7 @@ extern "C" __global__ void cmx_mixnet_chunk_kernel(MixState*, const float*, cons
                                                    const uint8_t*, const float*, int, float*, float*, int);
 extern "C" __global__ void cmx_mixnet_spec_kernel(MixState*, SpecXfer*, const float*, const uint32_t*, const uint8_t*, const float*, int, float*,
                                                   float*, int);
-typedef void (*cmx_spec_kernel_t)(MixState*, SpecXfer*, const float*, const uint32_t*, const uint8_t*, const float*, int, float*, float*, int);
-extern "C" __global__ void cmx_mixnet_spec_seg8_kernel(MixState*, SpecXfer*, const float*, const uint32_t*, const uint8_t*, const float*, int, float*, float*, int);
-extern "C" __global__ void cmx_mixnet_spec_rerun4_kernel(MixState*, SpecXfer*, const float*, const uint32_t*, const uint8_t*, const float*, int, float*, float*, int);
-extern "C" __global__ void cmx_mixnet_spec_dpp64_kernel(MixState*, SpecXfer*, const float*, const uint32_t*, const uint8_t*, const float*, int, float*, float*, int);
-extern "C" __global__ void cmx_mixnet_spec_cand2_kernel(MixState*, SpecXfer*, const float*, const uint32_t*, const uint8_t*, const float*, int, float*, float*, int);
-extern "C" __global__ void cmx_mixnet_spec_dpp128_kernel(MixState*, SpecXfer*, const float*, const uint32_t*, const uint8_t*, const float*, int, float*, float*, int);
+extern "C" __global__ void cmx_mixnet_spec_jitter_kernel(MixState*, SpecXfer*, const float*, const uint32_t*, const uint8_t*, const float*, int, float*, float*, int);
 extern "C" __global__ void cmx_mixnet_spec_late_kernel(MixState*, SpecXfer*, const float*, const uint32_t*, const float*, int, float*, float*, int, CmxLate);
 extern "C" __global__ void cmx_sse_init_kernel(MixState*);
 extern "C" __global__ void cmx_probe_libm_kernel(int, const float*, float*, size_t);
@@ -137,14 +132,10 @@ struct cmx_mixnet {
   unsigned sync_slot = 0;
   int profile = 0;
   int dbg = 0;          // CMX_MIXNET_DBG: timing experiments (results invalid when nonzero)
+  int jitter = 0;       // CMX_MIXNET_JITTER=1..15 (test hook, tests/test_gpu_mixnet.py): pseudo-random stalls in every role but the gather wave -- same results, every lead / lag between the roles
   int xcd = -1;         // CMX_MIXNET_XCD=k: place the persistent kernel on XCD k (speed only; -1 = wherever block 0 lands)
   bool use_v1 = false;  // CMX_MIXNET_V1=1: run chunks through the bit-synchronous kernel
   bool tolerance = false;   // cmx_mixnet_set_tolerance (opt-in through the API, NOT bit-exact): layer-0 dot products as f64 tree sums rounded once (cmx_mixnet_spec_kernel only)
-  bool seg8 = false;    // the helpers cut the 2078-term chain into eight segments (all eight waves of a helper workgroup) instead of four; CMX_MIXNET_SEG8
-  int seg16 = 0;        // CMX_MIXNET_SEG16: helper_dpp_role (1: 64 candidates per segment, 2: 128)
-  bool rerun4 = false;  // CMX_MIXNET_RERUN4
-  bool cand2 = CMX_MIXNET_CAND2_DEFAULT;   // CMX_MIXNET_CAND: 2 = 128 candidate start values per speculative segment (two running sums per lane)
-  bool pad = false, sleepy = false;   // A/B switches of the hand-off words (CMX_MIXNET_PAD, CMX_MIXNET_SLEEP), see mixnet_state.h
   bool use_spec = true; // cmx_mixnet_spec_kernel (26 helper workgroups, speculative segment-parallel chains); CMX_MIXNET_SPEC=0: the one-workgroup kernel
   SpecXfer* d_xfer = nullptr;
   float* d_late_p = nullptr; size_t late_p_cap = 0;   // the decoder's form: the kernel's p[] array (the host reads p from the box)
@@ -316,16 +307,9 @@ cmx_mixnet_t* cmx_mixnet_create(int device) {
   }
   { const char* v = getenv("CMX_MIXNET_V1"); h->use_v1 = v && v[0] == '1'; }
   { const char* v = getenv("CMX_MIXNET_SPEC"); h->use_spec = !(v && v[0] == '0'); }
-  { const char* v = getenv("CMX_MIXNET_SEG8"); h->seg8 = v ? v[0] == '1' : CMX_MIXNET_SEG8_DEFAULT; }
-  { const char* v = getenv("CMX_MIXNET_SEG16"); h->seg16 = v ? atoi(v) : 0; }    // helper_dpp_role: 16 segments per mixer fed by DPP row broadcasts; 1 = 64, 2 = 128 candidates per segment
-  { const char* v = getenv("CMX_MIXNET_RERUN4"); h->rerun4 = v ? v[0] == '1' : CMX_MIXNET_RERUN4_DEFAULT; }   // a missed segment re-run in four pieces on the helpers' idle waves
-  { const char* v = getenv("CMX_MIXNET_CAND"); if (v) h->cand2 = v[0] == '2'; }
-  { const char* v = getenv("CMX_MIXNET_PAD"); h->pad = v && v[0] == '1'; }       // A/B: one 128-byte line per u / sum word
-  { const char* v = getenv("CMX_MIXNET_SLEEP"); h->sleepy = v && v[0] == '1'; }  // A/B: s_sleep 1 in the polls of the global hand-off words
   h->d_xfer = (SpecXfer*)dalloc(sizeof(SpecXfer), true);   // incl. the zero padding of the input ring
   bool attr_ok = true;
-  for (const void* k : {(const void*)cmx_mixnet_spec_kernel, (const void*)cmx_mixnet_spec_seg8_kernel, (const void*)cmx_mixnet_spec_rerun4_kernel,
-                        (const void*)cmx_mixnet_spec_dpp64_kernel, (const void*)cmx_mixnet_spec_dpp128_kernel, (const void*)cmx_mixnet_spec_cand2_kernel, (const void*)cmx_mixnet_spec_late_kernel})
+  for (const void* k : {(const void*)cmx_mixnet_spec_kernel, (const void*)cmx_mixnet_spec_jitter_kernel, (const void*)cmx_mixnet_spec_late_kernel})
     attr_ok = attr_ok && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, CMX_SPEC_LDS_BYTES) == hipSuccess;
   if (!h->d_xfer || !attr_ok) {
     set_err("cmx_mixnet_create: hand-off area / kernel attribute (spec kernel) failed");
@@ -333,6 +317,7 @@ cmx_mixnet_t* cmx_mixnet_create(int device) {
     return nullptr;
   }
   { const char* v = getenv("CMX_MIXNET_DBG"); h->dbg = v ? atoi(v) : 0; }
+  { const char* v = getenv("CMX_MIXNET_JITTER"); h->jitter = v ? atoi(v) & 15 : 0; }
   { const char* v = getenv("CMX_MIXNET_XCD"); h->xcd = v ? atoi(v) : CMX_MIXNET_XCD_DEFAULT; if (h->xcd > 7) h->xcd = -1; }
   hipEventCreate(&h->ev0);
   hipEventCreate(&h->ev1);
@@ -377,18 +362,6 @@ int cmx_mixnet_spec_stats(cmx_mixnet_t* h, uint64_t out[5]) {
   unsigned long long st[8];
   HIP_OK(hipMemcpy(st, (char*)h->d_xfer + offsetof(SpecXfer, stat), sizeof st, hipMemcpyDeviceToHost));
   for (int i = 0; i < 5; ++i) out[i] = st[i];
-  return 0;
-}
-
-// Profiling launches (cmx_mixnet_profile): shader clocks per phase of the four waves of helper 12 (helper_dpp_role), accumulated since creation:
-// out[8 w + k], k = 0 wait u, 1 update + products + segment sums, 2 wait the earlier waves' sums, 3 candidates + chain, 4 wait the true start,
-// 5 resolve (+ re-runs) + publish, 6 fetch of the next bit. Synchronises the device.
-int cmx_mixnet_helper_phases(cmx_mixnet_t* h, uint64_t out[32]) {
-  const int fail_value = 1;
-  if (!h || !out) { set_err("cmx_mixnet_helper_phases: bad argument"); return 1; }
-  HIP_OK(hipSetDevice(h->device));
-  HIP_OK(hipDeviceSynchronize());
-  HIP_OK(hipMemcpy(out, (char*)h->d_xfer + offsetof(SpecXfer, hprof), 32 * 8, hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -526,23 +499,15 @@ static int mixnet_run_impl(cmx_mixnet_t* h, const float* d_probs, const uint32_t
     // epochs and value|tag words restart at 0 with every launch; 1 main + 26 helper workgroups, co-resident (27 of 256 CUs)
     HIP_OK(hipMemsetAsync(h->d_xfer, 0, CMX_SPEC_HEADER_BYTES, st));
     const bool cumask = cmx_cumask_on() != 0;   // the stream's compute-unit mask does the placement: 27 workgroups, all of them work, the XCC census still decides the hand-off's form
-    const int kmode = 3 | (h->profile ? 4 : 0) | ((h->dbg & 15) << 4) | (h->tolerance ? 0x1000 : 0) | (h->seg8 ? 0x2000 : 0) | (h->pad ? 0x4000 : 0) | (h->sleepy ? 0x8000 : 0) | (h->seg16 ? 0x10000 : 0) | (h->seg16 == 2 ? 0x40000 : 0) | (h->xcd >= 0 ? 0x20000 | ((h->xcd & 7) << 20) : 0) | (h->rerun4 ? 0x80000 : 0) | (getenv("CMX_MIXNET_XCD_NOLOCAL") ? 0x800000 : 0) | (cumask ? 0x1000000 : 0);
+    const int kmode = 3 | (h->profile ? 4 : 0) | ((h->dbg & 15) << 4) | (h->tolerance ? 0x1000 : 0) | (h->xcd >= 0 ? 0x20000 | ((h->xcd & 7) << 20) : 0) |
+                      (getenv("CMX_MIXNET_XCD_NOLOCAL") ? 0x800000 : 0) | (cumask ? 0x1000000 : 0) | (h->jitter ? 0x2000000 | ((h->jitter & 15) << 26) : 0);
     static const bool padgrid = getenv("CMX_MIXNET_PADGRID") != nullptr;   // diagnostic: the 8 x 27 grid of the one-XCD placement without the placement (blocks 27.. leave at once)
     const unsigned grid = (1 + CMX_SPEC_HELPERS) * ((h->xcd >= 0 && !cumask) || padgrid ? 8 : 1);   // placement: 8 x 27 workgroups, those with blockIdx % 8 == xcd work
     if (box && box->box)   // a decoder's chunk: the patient instantiation of the same roles
       hipLaunchKernelGGL(cmx_mixnet_spec_late_kernel, dim3(grid), dim3(CMX_SPEC_THREADS), CMX_SPEC_LDS_BYTES, st,
                          h->d_state, h->d_xfer, d_probs, d_sel, dd, (int)nbits, d_p_out, d_mix_out, kmode, *box);
     else {
-      // the helpers' form selects the kernel (tolerance mode exists in the four-segment form only)
-      cmx_spec_kernel_t k = cmx_mixnet_spec_kernel;
-      if (!h->tolerance) {
-        if (h->seg16 == 2) k = cmx_mixnet_spec_dpp128_kernel;
-        else if (h->seg16) k = cmx_mixnet_spec_dpp64_kernel;
-        else if (h->seg8) k = cmx_mixnet_spec_seg8_kernel;
-        else if (h->rerun4) k = cmx_mixnet_spec_rerun4_kernel;
-        else if (h->cand2) k = cmx_mixnet_spec_cand2_kernel;
-      }
-      hipLaunchKernelGGL(k, dim3(grid), dim3(CMX_SPEC_THREADS), CMX_SPEC_LDS_BYTES, st,
+      hipLaunchKernelGGL(h->jitter ? cmx_mixnet_spec_jitter_kernel : cmx_mixnet_spec_kernel, dim3(grid), dim3(CMX_SPEC_THREADS), CMX_SPEC_LDS_BYTES, st,
                          h->d_state, h->d_xfer, d_probs, d_sel, d_bits, dd, (int)nbits, d_p_out, d_mix_out, kmode);
     }
   } else

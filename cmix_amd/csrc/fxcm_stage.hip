@@ -467,6 +467,7 @@ __device__ __forceinline__ void fx_roles_body(FxDev* gd, FxXfer* X, unsigned* ro
     if (tid < 2) mscx[tid] = sh.mx_cxt[10 + tid];
     if (tid >= 64 && tid < 76) { const FxBit u0 = fx_bit_dev(d, &ah, &loc, 0, blpos0, lastbyte0, have0); merr[tid - 64] = fxd_mixer_err(&sh, d, u0, tid - 64); }   // the first update's errors
     for (int i = ln.exp_mix + FX_NMIX1 + 7 + tid; i < FX_OUTPUTS; i += FX_DEV_THREADS) { loc.ex[0][i] = 0.5f; loc.ex[1][i] = 0.5f; }   // the slots behind the last export keep 0.5 (fx_phase5_dev)
+    if (tid < 16) scr_s[tid] = 0;   // incl. wave 4's two ready flags ([12], [13] = bit + 1): LDS keeps whatever the compute unit's previous kernel left there
     __syncthreads();
   }
   if (role == 0) {
@@ -769,7 +770,13 @@ __device__ __forceinline__ void fx_roles_body(FxDev* gd, FxXfer* X, unsigned* ro
         // mx_pr[0..9] / [10..11] are written by wave 0 during phase 5: this wave waits for its two flags (scr_s[12], scr_s[13] = bit + 1)
         if (lane < 12) {
           const int* const flag = &scr_s[lane < FX_NMIX1 ? 12 : 13];
-          while (*(volatile const int*)flag != q + 1) __builtin_amdgcn_s_sleep(1);
+          unsigned spins = 0;
+          bool gone = false;
+          while (*(volatile const int*)flag != q + 1) {   // bounded like every other in-launch wait: a flag that never comes fails the stage (fx_wait_ge's rule)
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 0xFFFFu) == 0 && (spins > (1u << 26) || __hip_atomic_load(&X->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { gone = true; break; }
+          }
+          if (gone) __hip_atomic_store(&X->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const FxBit un = fx_bit_dev(d, &ah, &loc, q + 1, blpos0, lastbyte0, have0);
           merr[lane] = fxd_mixer_err(&sh, d, un, lane);
         }

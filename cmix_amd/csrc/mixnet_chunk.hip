@@ -88,7 +88,22 @@ struct Lds {
   float* h2;        // [2][64] cmx_mixnet_spec_kernel: the layer-2 inputs of a bit (49) + bit, lstm_p, layer-2 row, from tail_a_role to tail_b_role
   int* bitring;     // [8] late mode: the decoded bits, slot bit % 8 (Ctl::bit_epoch)
   CmxLate late;     // late mode: the decoder's box + row counters; late.box == nullptr: every bit of the chunk is known (compression)
+  int jit;          // CMX_MIXNET_JITTER (test hook): 0 = off, else the seed of the roles' pseudo-random stalls (jitter_stall)
 };
+
+// Test hook (CMX_MIXNET_JITTER=seed, tests/test_gpu_mixnet.py): a role stalls at pseudo-random bits for 0 .. ~100 us. The roles of this kernel are
+// coupled only through counters and value|tag words, so every result must be independent of how far any role runs ahead of or behind any other --
+// in a clean run the gather wave is the bottleneck and the leads sit at their maxima, the short-lead paths are the least exercised code of the
+// kernel. Wave-uniform (t and who are).
+template <bool JIT> __device__ __forceinline__ void jitter_stall(int jit, int t, int who) {
+  if constexpr (!JIT) return;
+  unsigned h = (unsigned)t * 2654435761u + (unsigned)who * 0x9E3779B9u + (unsigned)jit * 0x85EBCA6Bu;
+  h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+  if ((h & 7u) == 0) {
+    const int n = (int)((h >> 3) & 31u);
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+}
 
 // All inter-wave traffic of this kernel goes through LDS, so its synchronisation only has to
 // order LDS operations (lgkmcnt). The C++ workgroup-scope acquire/release atomics also drain
@@ -223,42 +238,6 @@ template <int NB> __device__ __forceinline__ float chain_seg_n(const float* rowp
   return p;
 }
 __device__ __forceinline__ float chain_seg(const float* rowp, int n, float p) { return chain_seg_n<16>(rowp, n, p); }
-// The same chain on TWO running sums per lane (CMX_MIXNET_CAND=2: 128 candidate start values per speculative segment instead of 64). The chain is bound by
-// the LDS return path (one broadcast ds_read_b128 per four terms, ~8 clocks per term with four chain waves on the compute unit), not by the adder: the second
-// sum's add consumes the same broadcast operand and issues in the slack.
-__device__ __forceinline__ void add4x2(float& p, float& q, float4 v) {
-  p = fadd(p, v.x); q = fadd(q, v.x); p = fadd(p, v.y); q = fadd(q, v.y); p = fadd(p, v.z); q = fadd(q, v.z); p = fadd(p, v.w); q = fadd(q, v.w);
-}
-template <int NB> __device__ __forceinline__ void chain_seg2_n(const float* rowp, int n, float& p, float& q) {
-  const float4* row = reinterpret_cast<const float4*>(__builtin_assume_aligned(rowp, 16));
-  float4 a[8], b[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) a[i] = row[i];
-#pragma unroll 1
-  for (int bi = 0; bi < NB; bi += 2) {
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) b[i] = row[(bi + 1) * 8 + i];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) add4x2(p, q, a[i]);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) a[i] = row[(bi + 2) * 8 + i];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) add4x2(p, q, b[i]);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  const int rem4 = (n >> 2) - NB * 8;  // 0 or 7
-#pragma unroll
-  for (int i = 0; i < 7; ++i)
-    if (i < rem4) add4x2(p, q, a[i]);
-  if (n & 2) {
-    p = fadd(p, a[7].x); q = fadd(q, a[7].x);
-    p = fadd(p, a[7].y); q = fadd(q, a[7].y);
-  }
-}
 
 // ------------------------------------------------------------------ scout (wave 2)
 // X != nullptr (cmx_mixnet_spec_kernel): the stretched inputs and the layer-0 rows of the bit are also published to the helper
@@ -1023,7 +1002,7 @@ __device__ void tail_role(MixState* S, const Lds& L, const float* decay1, int nb
 // layer 2 (every mixer learns from its own output, mixer.cpp:56-72), so the two halves are a pipeline: tail_a_role (wave 1) does layer 1 of
 // bit t and hands the 49 layer-2 inputs over through LDS (Lds::h2, two slots); tail_b_role (wave 3) does layer 2, the SSE and the output of
 // bit t while wave 1 is on bit t + 1. Same arithmetic, same order, per half as in tail_role.
-template <bool LATE> __device__ void tail_a_role(MixState* S, const Lds& L, const float* decay1, int nbits, float* mix_out, int lane, bool prof_on) {
+template <bool LATE, bool JIT = false> __device__ void tail_a_role(MixState* S, const Lds& L, const float* decay1, int nbits, float* mix_out, int lane, bool prof_on) {
   uint64_t tprev = __builtin_readcyclecounter();
   uint64_t pacc[6] = {0, 0, 0, 0, 0, 0};
 #define TPROF(k) do { if (prof_on) { uint64_t now_ = __builtin_readcyclecounter(); pacc[k - 6] += now_ - tprev; tprev = now_; } } while (0)
@@ -1048,6 +1027,7 @@ template <bool LATE> __device__ void tail_a_role(MixState* S, const Lds& L, cons
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   for (int t = 0; t < nbits; ++t) {
     TPROF(11);
+    jitter_stall<JIT>(L.jit, t, 1);
     if (!wait_ge<LATE>(L.ctl, &L.ctl->scout_epoch, t + 1, true)) return;
     const BitRec* rec = L.rec + (t % L.rr);
     const uint32_t newrow = rec->rowidx[CMX_MIX0 + kk];
@@ -1077,6 +1057,7 @@ template <bool LATE> __device__ void tail_a_role(MixState* S, const Lds& L, cons
     if (t >= 2 && !wait_ge<LATE>(L.ctl, &L.ctl->b_done, t - 1, false)) return;   // the hand-over slot t & 1 is free
     if (!wait_ge<LATE>(L.ctl, &L.ctl->tail_in, t + 1, false)) return;
     TPROF(7);
+    jitter_stall<JIT>(L.jit, t, 12);
     const TailRec* tr = L.trec + (t & 1);
     int bit = tr->bit;   // (late mode: not known yet -- awaited below, where layer 1 learns)
     float* const in2 = L.h2 + 64 * (t & 1);   // this bit's layer-2 inputs: built here, read by tail_b_role
@@ -1158,7 +1139,7 @@ template <bool LATE> __device__ void tail_a_role(MixState* S, const Lds& L, cons
   }
 }
 
-template <bool LATE> __device__ void tail_b_role(MixState* S, const Lds& L, const float* decay1, int nbits, float* p_out, float* mix_out, int lane, bool prof_on) {
+template <bool LATE, bool JIT = false> __device__ void tail_b_role(MixState* S, const Lds& L, const float* decay1, int nbits, float* p_out, float* mix_out, int lane, bool prof_on) {
   uint64_t tprev = __builtin_readcyclecounter();
   uint64_t pacc[3] = {0, 0, 0};
 #define TPROF(k) do { if (prof_on) { uint64_t now_ = __builtin_readcyclecounter(); pacc[k] += now_ - tprev; tprev = now_; } } while (0)
@@ -1180,6 +1161,7 @@ template <bool LATE> __device__ void tail_b_role(MixState* S, const Lds& L, cons
   unsigned sj = S->sse_j, spc = S->sse_pc, sffl = S->sse_ffl;
   uint64_t steps_done = 0;
   for (int t = 0; t < nbits; ++t) {
+    jitter_stall<JIT>(L.jit, t, 13);
     const double d1 = (double)as_global(decay1)[t];
     // SSE contexts for a = 0..2 / b = 0..3 (sse.cpp:248-262): lane i pulls candidate cell i towards the caches (see tail_role)
     if (k < 13) {
@@ -1344,22 +1326,13 @@ template <bool LATE> __device__ void tail_b_role(MixState* S, const Lds& L, cons
 //                         -> the sum of bit t goes back to the gather wave.
 // Two global hand-offs per bit (sum, u), 8-byte value|tag words, agent scope.
 struct HelperLds {
-  float prod[8][SEG];          // rounded products of the (four or eight) segments (each read back as broadcast float4s by its own wave)
-  double segsum[8];            // f64 sum of a segment's products
-  float res[8];                // exact running sum after segment w
-  int sum_epoch[8];            // bit + 1 for which segsum[w] is valid
-  int res_epoch[8];            // bit + 1 for which res[w] is valid
+  float prod[4][SEG];          // rounded products of the four segments (each read back as broadcast float4s by its own wave)
+  double segsum[4];            // f64 sum of a segment's products
+  float res[4];                // exact running sum after segment w
+  int sum_epoch[4];            // bit + 1 for which segsum[w] is valid
+  int res_epoch[4];            // bit + 1 for which res[w] is valid
   int abort;
   int pad_;
-  unsigned long long resw[4];  // helper_dpp_role: ((bit + 1) << 32) | bits of the exact running sum after wave w's four segments
-  // CMX_MIXNET_RERUN4: a missed segment is re-run in four pieces, three of them speculatively on the workgroup's idle waves 4..6 (rerun_role).
-  // One request at a time: a wave can only miss once the wave before it has delivered, so the waves post in turn.
-  int rr_epoch;                // requests posted so far in this launch
-  int rr_seg;                  // the segment of the current request (1..3)
-  float rr_start;              // its true start
-  float rr_res[4];             // exact running sum after piece j of the current request
-  int rr_res_epoch[4];         // request number for which rr_res[j] is valid
-  int bit_done;                // bit + 1 whose sum has gone out (the idle waves leave when it reaches the launch's length)
 };
 
 __device__ __forceinline__ unsigned long long ld_u64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1390,68 +1363,11 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
-// Ordered add chain over terms [i0, i0 + n) of a staged segment (i0 a multiple of 4, n even): the pieces of a re-run (not software-pipelined by
-// hand like chain_seg_n: a piece is 128 or 158 terms).
-__device__ __forceinline__ float chain_range(const float* rowp, int i0, int n, float p) {
-  const float4* row = reinterpret_cast<const float4*>(__builtin_assume_aligned(rowp, 16)) + (i0 >> 2);
-  const int n4 = n >> 2;
-#pragma unroll 8
-  for (int i = 0; i < n4; ++i) p = add4(p, row[i]);
-  if (n & 2) {
-    const float4 v = row[n4];
-    p = fadd(p, v.x);
-    p = fadd(p, v.y);
-  }
-  return p;
-}
-
-// CMX_MIXNET_RERUN4 (opt-in): waves 4..6 of a helper workgroup. A speculative segment that misses is 512 (542) dependent adds on one wave while the
-// other 25 helpers wait (two thirds of the bits have such a miss somewhere, profiles/r04_spec_chain_per_bit_study.txt). Here the wave that missed
-// runs only the first 128 terms from the true start; wave 3 + j runs terms [128 j, 128 (j + 1)) (the last piece: to the segment's end) from 64
-// candidates around start + the f64 sum of the products before its piece -- over so few terms the rounding drift is a couple of ulp, so these
-// practically always hit -- and the pieces resolve in a cascade exactly like the segments do: a candidate with the true start's bit pattern holds
-// the exact result, otherwise the piece is re-run from it. Same value as the serial path either way.
-__device__ void rerun_role(SpecXfer* X, HelperLds* H, int nbits, int j, int lane) {
-  int served = 0;
-  unsigned idle = 0;
-  for (;;) {
-    if (lds_poll(&H->rr_epoch) > served) {
-      const int rq = served + 1;
-      const int seg = lds_poll(&H->rr_seg);
-      const float s = __int_as_float(lds_poll(reinterpret_cast<const int*>(&H->rr_start)));
-      const float* pr = H->prod[seg];
-      const int nseg = seg == 3 ? CMX_IN0 - 1536 : 512;
-      const int i0 = 128 * j, n = j == 3 ? nseg - 384 : 128;
-      double ds = 0.0;                                  // the products before the piece: element 64 k + lane, k < 2 j
-      for (int k = 0; k < 2 * j; ++k) ds += (double)pr[64 * k + lane];
-      ds = wave_sum_f64(ds);
-      const float start = ord2f(f2ord((float)((double)s + ds)) + lane - 32);
-      float r = chain_range(pr, i0, n, start);
-      unsigned spins = 0;
-      while (lds_poll(&H->rr_res_epoch[j - 1]) < rq)
-        if ((++spins & 1023u) == 0 && (spins > SPEC_SPIN || lds_poll(&H->abort) || ld_u32(&X->fail))) { lds_publish_store(&H->abort, 1); return; }
-      const float ts = H->rr_res[j - 1];
-      const unsigned long long hit = __ballot(__float_as_int(start) == __float_as_int(ts));
-      if (hit) r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), (int)__builtin_amdgcn_readfirstlane(__ffsll((long long)hit) - 1)));
-      else r = chain_range(pr, i0, n, ts);
-      if (lane == 0) H->rr_res[j] = r;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (lane == 0) lds_publish_store(&H->rr_res_epoch[j], rq);
-      served = rq;
-      idle = 0;
-      continue;
-    }
-    if (lds_poll(&H->bit_done) >= nbits) return;
-    __builtin_amdgcn_s_sleep(2);                        // (shares a SIMD with a chain wave: an idle poll must not take its issue slots)
-    if ((++idle & 0xFFFFu) == 0 && (lds_poll(&H->abort) || ld_u32(&X->fail))) return;
-  }
-}
-
-template <bool LATE, int NW, bool SPLIT = false, int NCAND = 1> __device__ void helper_role(MixState* S, SpecXfer* X, HelperLds* H, int nbits, int m, int w, int lane, bool tol, CmxLateBox* LB, int pitch, bool sleepy, bool local) {
+template <bool LATE, bool JIT = false> __device__ void helper_role(MixState* S, SpecXfer* X, HelperLds* H, int nbits, int m, int w, int lane, bool tol, CmxLateBox* LB, bool local, int jit) {
   const gptr<float> rows0 = as_global(S->rows0);
-  // NW waves cut the 2078-term chain: 4 x 512 (+ 30) or 8 x 256 (+ 30) terms. Shorter segments: a shorter chain and a cheaper re-run on a
-  // miss (two thirds of the bits re-run a segment in at least one helper, profiles/r04_spec_chain_per_bit_study.txt), more hops to resolve.
-  constexpr int SEGN = 2048 / NW, KS = SEGN / 64, LASTW = NW - 1;
+  // four waves cut the 2078-term chain: 4 x 512 (+ 30) terms (other cuts, candidate counts and re-run forms were measured and are slower:
+  // scripts/study/mixnet_variants.patch)
+  constexpr int NW = 4, SEGN = 2048 / NW, KS = SEGN / 64, LASTW = NW - 1;
   const int base = SEGN * w;                // first element of this wave's segment
   const int nseg = w == LASTW ? CMX_IN0 - SEGN * LASTW : SEGN;
   const bool tailk = w == LASTW && lane < 30;   // slot KS: elements 2048 + lane (lane < 30)
@@ -1493,12 +1409,12 @@ template <bool LATE, int NW, bool SPLIT = false, int NCAND = 1> __device__ void 
   if (nbits > 0 && !fetch(0)) return;
   for (int t = 0; t <= nbits; ++t) {
     const bool live = t < nbits;             // t == nbits: apply the last update and store the row
+    jitter_stall<JIT>(jit, t, 16 + 4 * m + w);
     // ---- u of bit t-1 (the serial hand-off of the bit) ----
     if (t > 0) {
       unsigned long long v;
       unsigned spins = 0;
-      while ((unsigned)((v = ld_u64(&X->u[m * pitch])) >> 33) != (unsigned)t) {
-        if (sleepy) __builtin_amdgcn_s_sleep(1);
+      while ((unsigned)((v = ld_u64(&X->u[m])) >> 33) != (unsigned)t) {
         if ((++spins & 1023u) == 0 && (spun_out(spins) || failed() || ld_u32(&X->fail))) { give_up(); return; }
       }
       late_t0 = 0;
@@ -1550,7 +1466,7 @@ template <bool LATE, int NW, bool SPLIT = false, int NCAND = 1> __device__ void 
           tot += H->segsum[q];
         }
         tot += ds;
-        if (lane == 0) st_u64(&X->sum[m * pitch], ((unsigned long long)(unsigned)(t + 1) << 32) | (unsigned)__float_as_int((float)tot));
+        if (lane == 0) st_u64(&X->sum[m], ((unsigned long long)(unsigned)(t + 1) << 32) | (unsigned)__float_as_int((float)tot));
       }
       if (t + 1 < nbits && !fetch(t + 1)) return;
       continue;
@@ -1573,15 +1489,9 @@ template <bool LATE, int NW, bool SPLIT = false, int NCAND = 1> __device__ void 
           if ((++spins & 1023u) == 0 && (spins > SPEC_SPIN || failed())) { give_up(); return; }
         est += H->segsum[q];
       }
-      start = ord2f(f2ord((float)est) + lane - (NCAND == 2 ? 64 : 32));
+      start = ord2f(f2ord((float)est) + lane - 32);
     }
-    float start2 = 0.0f, r2 = 0.0f;
-    float r;
-    if (NCAND == 2 && w > 0) {   // candidates estimate - 64 .. - 1 (r) and estimate .. + 63 (r2)
-      start2 = ord2f(f2ord(start) + 64);
-      r = start; r2 = start2;
-      chain_seg2_n<NW == 4 ? 16 : 8>(pr, nseg, r, r2);
-    } else r = chain_seg_n<NW == 4 ? 16 : 8>(pr, nseg, start);
+    float r = chain_seg_n<16>(pr, nseg, start);
     // ---- resolve against the true start ----
     if (w > 0) {
       unsigned spins = 0;
@@ -1589,30 +1499,12 @@ template <bool LATE, int NW, bool SPLIT = false, int NCAND = 1> __device__ void 
         if ((++spins & 1023u) == 0 && (spins > SPEC_SPIN || failed())) { give_up(); return; }
       const float s = H->res[w - 1];
       const unsigned long long hit = __ballot(__float_as_int(start) == __float_as_int(s));
-      const unsigned long long hit2 = NCAND == 2 ? __ballot(__float_as_int(start2) == __float_as_int(s)) : 0ull;
       ++n_spec;
       if (hit) {
         r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), (int)__builtin_amdgcn_readfirstlane(__ffsll((long long)hit) - 1)));
         ++n_hit;
-      } else if (NCAND == 2 && hit2) {
-        r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r2), (int)__builtin_amdgcn_readfirstlane(__ffsll((long long)hit2) - 1)));
-        ++n_hit;
       } else {
-        if (SPLIT) {                                              // in four pieces, three of them on the idle waves (rerun_role)
-          const int rq = lds_poll(&H->rr_epoch) + 1;
-          if (lane == 0) { H->rr_seg = w; H->rr_start = s; }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          if (lane == 0) lds_publish_store(&H->rr_epoch, rq);
-          const float r0 = chain_range(pr, 0, 128, s);
-          if (lane == 0) H->rr_res[0] = r0;
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          if (lane == 0) lds_publish_store(&H->rr_res_epoch[0], rq);
-          unsigned sp2 = 0;
-          while (lds_poll(&H->rr_res_epoch[3]) < rq)
-            if ((++sp2 & 1023u) == 0 && (sp2 > SPEC_SPIN || failed())) { give_up(); return; }
-          r = H->rr_res[3];
-        } else
-        r = chain_seg_n<NW == 4 ? 16 : 8>(pr, nseg, s);          // outside the candidates: the serial path
+        r = chain_seg_n<16>(pr, nseg, s);          // outside the candidates: the serial path
         ++n_miss;
       }
     }
@@ -1622,251 +1514,17 @@ template <bool LATE, int NW, bool SPLIT = false, int NCAND = 1> __device__ void 
       if (lane == 0) lds_publish_store(&H->res_epoch[w], t + 1);
     } else if (lane == 0) {
       const unsigned long long word = ((unsigned long long)(unsigned)(t + 1) << 32) | (unsigned)__float_as_int(r);
-      if (local) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(&X->sum[m * pitch]), "v"(word) : "memory");   // stays in this XCD's L2 (every reader is on this XCD, checked at launch)
-      else st_u64(&X->sum[m * pitch], word);
-      if (SPLIT) lds_publish_store(&H->bit_done, t + 1);
+      if (local) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(&X->sum[m]), "v"(word) : "memory");   // stays in this XCD's L2 (every reader is on this XCD, checked at launch)
+      else st_u64(&X->sum[m], word);
     }
     // ---- while the gather wave works: the inputs / incoming row of bit t+1 ----
+    jitter_stall<JIT>(jit, t, 144 + 4 * m + w);
     if (t + 1 < nbits && !fetch(t + 1)) return;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (lane == 0 && w > 0) {
-    atomicAdd(&X->stat[0], n_spec); atomicAdd(&X->stat[1], n_hit); atomicAdd(&X->stat[NW == 4 ? 1 + w : 2 + (w - 1) / 3], n_miss);   // ([2..4]: re-runs of segment 1, 2, 3 -- with eight waves of segments 1-3, 4-6, 7)
+    atomicAdd(&X->stat[0], n_spec); atomicAdd(&X->stat[1], n_hit); atomicAdd(&X->stat[1 + w], n_miss);   // ([2..4]: re-runs of segment 1, 2, 3)
   }
-}
-
-// ------------------------------------------------------------------ helper, round 5: sixteen segments fed by DPP row broadcasts
-// What bounds helper_role is not the 512 dependent adds of a segment (2.3 k clocks) but their operand path: every term has to reach all
-// 64 candidate lanes, and a broadcast read from LDS occupies the compute unit's one LDS return path for 8 clocks per 16 bytes per wave
-// (4.4 k clocks per bit for the four chain waves). Here no operand goes through LDS at all:
-//   * a wave holds FOUR segments, one per row of 16 lanes; term t of a row's segment lives in lane t % 16 of the row, register t / 16
-//     (the lane that owns the weight made the product), and ONE VALU instruction -- v_mov_b32_dpp row_newbcast:r -- copies it to the 16
-//     lanes of its row; the four rows of the wave (four different segments) do this in the same instruction;
-//   * every lane carries 2 NACC candidate running sums in NACC register pairs, advanced by v_pk_add_f32 (two IEEE f32 adds per issue, the
-//     broadcast value selected for both halves by op_sel): 16 lanes x 2 NACC = 64 (128) consecutive candidate start values per segment;
-//   * so one term costs 1 + NACC VALU issues for four segments at once, and a mixer's 2078-term chain becomes 16 segments of 130 terms
-//     that run at the same time on four waves: ~1.0 k clocks instead of 4.1 k.
-// (The matrix cores can do the broadcast as well -- v_mfma_f32_4x4x1_16b_f32 with B = 1.0 is an exact f32 adder, A from one lane lands in
-// 16 accumulators; scripts/ubench/mfma_adder.hip: 8.4e9 adds, none differs from v_add_f32 -- but a dependent 4x4x1 MFMA is 24 clocks,
-// three times the packed VALU step: profiles/r05_mfma_adder.txt.)
-// Resolve: in order, segment by segment -- the candidate with the bit pattern of the true start holds exactly the reference's running sum
-// (same operations on the same operands, mixer.cpp:40-43); outside the candidates the segment's 130 terms are re-run from the true start.
-// A row whose segment is shorter (the last: 128 terms) adds -0.0 (x + -0.0 == x for every x, signed zeros included).
-template <int R> __device__ __forceinline__ float row_bcast(float v) {   // lane R of each row of 16 lanes to the whole row (DPP row_newbcast, gfx90a+)
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + R, 0xf, 0xf, true));
-}
-typedef float pf2 __attribute__((ext_vector_type(2)));
-constexpr int MSEG = 130;          // terms per segment (16 segments: 15 x 130 + 128 = 2078)
-template <int NACC> struct DppAcc { pf2 a[NACC]; };
-#define CMX_DP_STEP(PK, R_) { const float x_ = row_bcast<R_>(PK); const pf2 xx_ = {x_, x_}; _Pragma("unroll") for (int q_ = 0; q_ < NACC; ++q_) A.a[q_] = A.a[q_] + xx_; }
-// Eight terms. The empty asm ties the batch's broadcasts to the running sums as they stand in front of it: a broadcast depends on nothing the chain
-// computes, and left alone the compiler hoists all 130 of them in front of the first add (and spills the lot). Nothing is lost by the tie: a term is
-// 1 + NACC VALU issues whatever the order, and a sum's own adds are NACC + 1 issues apart -- more than the adder's latency.
-#define CMX_DP_TIE(X_) { if constexpr (NACC == 2) asm volatile("" : "+v"(X_) : "v"(A.a[0]), "v"(A.a[1])); else asm volatile("" : "+v"(X_) : "v"(A.a[0]), "v"(A.a[1]), "v"(A.a[2]), "v"(A.a[3])); }
-#define CMX_DP_ADD(X_) { const pf2 xx_ = {X_, X_}; _Pragma("unroll") for (int q_ = 0; q_ < NACC; ++q_) A.a[q_] = A.a[q_] + xx_; }
-#define CMX_DP_B8(PK, R0) { float pk_ = PK; CMX_DP_TIE(pk_) \
-  const float x0_ = row_bcast<R0>(pk_), x1_ = row_bcast<R0 + 1>(pk_), x2_ = row_bcast<R0 + 2>(pk_), x3_ = row_bcast<R0 + 3>(pk_); \
-  const float x4_ = row_bcast<R0 + 4>(pk_), x5_ = row_bcast<R0 + 5>(pk_), x6_ = row_bcast<R0 + 6>(pk_), x7_ = row_bcast<R0 + 7>(pk_); \
-  CMX_DP_ADD(x0_) CMX_DP_ADD(x1_) CMX_DP_ADD(x2_) CMX_DP_ADD(x3_) CMX_DP_ADD(x4_) CMX_DP_ADD(x5_) CMX_DP_ADD(x6_) CMX_DP_ADD(x7_) }
-#define CMX_DP_ROW16(PK) CMX_DP_B8(PK, 0) CMX_DP_B8(PK, 8)
-// the 130 ordered terms of the wave's four segments on every candidate: A <- A + P[t / 16] of lane t % 16 of the row, t = 0 .. 129
-template <int NACC> __device__ __forceinline__ void dpp_chain130(DppAcc<NACC>& A, const float (&P)[9]) {
-  CMX_DP_ROW16(P[0]) CMX_DP_ROW16(P[1]) CMX_DP_ROW16(P[2]) CMX_DP_ROW16(P[3])
-  CMX_DP_ROW16(P[4]) CMX_DP_ROW16(P[5]) CMX_DP_ROW16(P[6]) CMX_DP_ROW16(P[7])
-  { float pk_ = P[8]; CMX_DP_TIE(pk_) CMX_DP_STEP(pk_, 0) CMX_DP_STEP(pk_, 1) }
-}
-// the same chain on ONE running sum per lane (the re-run of a segment whose true start no candidate had)
-#define CMX_D1_STEP(PK, R_) s = fadd(s, row_bcast<R_>(PK));
-#define CMX_D1_B8(PK, R0) { float pk_ = PK; asm volatile("" : "+v"(pk_) : "v"(s)); \
-  CMX_D1_STEP(pk_, R0) CMX_D1_STEP(pk_, R0 + 1) CMX_D1_STEP(pk_, R0 + 2) CMX_D1_STEP(pk_, R0 + 3) CMX_D1_STEP(pk_, R0 + 4) CMX_D1_STEP(pk_, R0 + 5) CMX_D1_STEP(pk_, R0 + 6) CMX_D1_STEP(pk_, R0 + 7) }
-#define CMX_D1_ROW16(PK) CMX_D1_B8(PK, 0) CMX_D1_B8(PK, 8)
-__device__ __forceinline__ float dpp_chain130_one(float s, float p0, float p1, float p2, float p3, float p4, float p5, float p6, float p7, float p8) {
-  CMX_D1_ROW16(p0) CMX_D1_ROW16(p1) CMX_D1_ROW16(p2) CMX_D1_ROW16(p3) CMX_D1_ROW16(p4) CMX_D1_ROW16(p5) CMX_D1_ROW16(p6) CMX_D1_ROW16(p7)
-  { float pk_ = p8; asm volatile("" : "+v"(pk_) : "v"(s)); CMX_D1_STEP(pk_, 0) CMX_D1_STEP(pk_, 1) }
-  return s;
-}
-// sum of a double over each row of 16 lanes, in every lane of the row (any order: it only centres the candidates)
-__device__ __forceinline__ double row_sum_f64(double v) {
-  v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
-  v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
-  v += dpp_f64<0x124>(v);   // row_ror:4
-  v += dpp_f64<0x128>(v);   // row_ror:8
-  return v;
-}
-// LDS hand-off of one float between the waves of a helper as ONE 8-byte value|tag word (a write and a poll, no separate flag)
-typedef __attribute__((address_space(3))) unsigned long long lds_u64;
-__device__ __forceinline__ unsigned long long lds_poll64(const unsigned long long* p) {
-  unsigned long long v;
-  asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((const lds_u64*)p) : "memory");
-  return v;
-}
-__device__ __forceinline__ void lds_store64(unsigned long long* p, unsigned long long v) {
-  asm volatile("ds_write_b64 %0, %1" :: "v"((lds_u64*)p), "v"(v) : "memory");
-}
-
-template <bool LATE, int NACC> __device__ void helper_dpp_role(MixState* S, SpecXfer* X, HelperLds* H, int nbits, int m, int w, int lane, CmxLateBox* LB, int pitch, bool sleepy, bool local, bool prof_on) {
-  constexpr int NC = 32 * NACC;                              // candidates per segment
-  const bool hp = prof_on && m == 12;
-  uint64_t hacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  uint64_t hprev = __builtin_readcyclecounter();
-#define HPROF(k) do { if (hp) { const uint64_t now_ = __builtin_readcyclecounter(); hacc[k] += now_ - hprev; hprev = now_; } } while (0)
-  const gptr<float> rows0 = as_global(S->rows0);
-  const int g = lane >> 4, r = lane & 15;
-  const int seg = 4 * w + g;
-  const int base = MSEG * seg;                               // first element of this row's segment
-  const int seglen = seg == 15 ? CMX_IN0 - 15 * MSEG : MSEG; // 128 for the last one
-  const bool v8 = 128 + r < seglen;                          // register 8 holds terms 128, 129 (lanes 0, 1 of a row; none in the last segment)
-  const float cdec = 1.0f - 3.0e-6f;
-  float W[9], Wn[9], xc[9], xp[9], P[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) { W[k] = 0.0f; Wn[k] = 0.0f; xc[k] = 0.0f; xp[k] = 0.0f; P[k] = 0.0f; }
-  unsigned long long n_spec = 0, n_hit = 0, n_miss = 0;
-  uint32_t cur_base = 0;
-  bool f_chg = false; uint32_t f_base = 0;
-  auto failed = [&]() { return lds_poll(&H->abort) != 0; };
-  unsigned long long late_t0 = 0;
-  auto spun_out = [&](unsigned spins) { return LATE ? late_expired(LB, late_t0) : spins > SPEC_SPIN; };
-  auto give_up = [&]() { lds_publish_store(&H->abort, 1); __hip_atomic_store(&X->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-  auto fetch = [&](int t) -> bool {
-    unsigned spins = 0;
-    while (ld_u32(&X->scout_epoch) < (unsigned)(t + 1)) {
-      __builtin_amdgcn_s_sleep(1);
-      if ((++spins & 1023u) == 0 && (spun_out(spins) || failed() || ld_u32(&X->fail))) { give_up(); return false; }
-    }
-    late_t0 = 0;
-    const int slot = t % CMX_SPEC_RING;
-    const float* gx = X->xs[slot] + base;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) xc[k] = ld_f32(gx + 16 * k + r);
-    xc[8] = v8 ? ld_f32(gx + 128 + r) : 0.0f;
-    f_chg = ld_u32(&X->changed[slot][m]) != 0;
-    if (f_chg) {
-      const uint32_t nb = ((uint32_t)m * CMX_ROWS_PER_MIXER + ld_u32(&X->rowidx[slot][m])) * CMX_ROW0_STRIDE + (uint32_t)base;
-      f_base = nb;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) Wn[k] = rows0[nb + 16 * k + r];
-      Wn[8] = v8 ? rows0[nb + 128 + r] : 0.0f;
-    }
-    return true;
-  };
-  if (nbits > 0 && !fetch(0)) return;
-  for (int t = 0; t <= nbits; ++t) {
-    const bool live = t < nbits;
-    // ---- u of bit t-1 (the serial hand-off of the bit) ----
-    if (t > 0) {
-      unsigned long long v;
-      unsigned spins = 0;
-      while ((unsigned)((v = ld_u64(&X->u[m * pitch])) >> 33) != (unsigned)t) {
-        if (sleepy) __builtin_amdgcn_s_sleep(1);
-        if ((++spins & 1023u) == 0 && (spun_out(spins) || failed() || ld_u32(&X->fail))) { give_up(); return; }
-      }
-      late_t0 = 0;
-      HPROF(0);
-      const float u = __int_as_float((int)(unsigned)v);
-      const bool df = ((v >> 32) & 1ull) != 0;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) {          // mixer.cpp:66-71; xp = the inputs of bit t-1
-        W[k] = fsub(W[k], fmul(u, xp[k]));
-        if (df) W[k] = fmul(W[k], cdec);
-      }
-    }
-    const bool chg = !live || f_chg;
-    if (chg) {
-      if (t > 0) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) rows0[cur_base + 16 * k + r] = W[k];
-        if (v8) rows0[cur_base + 128 + r] = W[8];
-      }
-      if (live) {
-        cur_base = f_base;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) W[k] = Wn[k];
-      }
-    }
-    if (!live) break;
-    // ---- products of bit t (mixer.cpp:41: in[i] * w[i], rounded), f64 sum of each row's segment ----
-    double ds = 0.0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { P[k] = fmul(xc[k], W[k]); ds += (double)P[k]; }
-    P[8] = v8 ? fmul(xc[8], W[8]) : -0.0f;                 // past the segment's end: x + -0.0 == x
-    ds += (double)P[8];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) xp[k] = xc[k];
-    ds = row_sum_f64(ds);
-    const double s0 = readlane_f64(ds, 0), s1 = readlane_f64(ds, 16), s2 = readlane_f64(ds, 32), s3 = readlane_f64(ds, 48);
-    if (w < 3) {                                           // the later waves centre their candidates on what precedes them
-      if (lane == 0) H->segsum[w] = (s0 + s1) + (s2 + s3);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (lane == 0) lds_publish_store(&H->sum_epoch[w], t + 1);
-    }
-    HPROF(1);
-    double pre = 0.0;
-    for (int q = 0; q < w; ++q) {
-      unsigned spins = 0;
-      while (lds_poll(&H->sum_epoch[q]) < t + 1)
-        if ((++spins & 1023u) == 0 && (spins > SPEC_SPIN || failed())) { give_up(); return; }
-      pre += H->segsum[q];
-    }
-    // estimates of the four rows' start values (wave-uniform), the candidates around them: candidate c = 16 q + r of a row is element q of the
-    // lane's 2 NACC running sums, start = estimate + (c - NC / 2) ulp
-    const int o0 = __builtin_amdgcn_readfirstlane(f2ord((float)pre)), o1 = __builtin_amdgcn_readfirstlane(f2ord((float)(pre + s0)));
-    const int o2 = __builtin_amdgcn_readfirstlane(f2ord((float)(pre + (s0 + s1)))), o3 = __builtin_amdgcn_readfirstlane(f2ord((float)(pre + ((s0 + s1) + s2))));
-    const int og = g == 0 ? o0 : g == 1 ? o1 : g == 2 ? o2 : o3;
-    const bool exact0 = w == 0 && g == 0;                  // the chain's first segment starts at +0.0f, no speculation
-    HPROF(2);
-    DppAcc<NACC> A;
-#pragma unroll
-    for (int q = 0; q < NACC; ++q) {
-      A.a[q][0] = exact0 ? 0.0f : ord2f(og + 32 * q + r - NC / 2);
-      A.a[q][1] = exact0 ? 0.0f : ord2f(og + 32 * q + 16 + r - NC / 2);
-    }
-    dpp_chain130<NACC>(A, P);
-    HPROF(3);
-    // ---- resolve, in order ----
-    float st;                                              // the true running sum where the next segment starts (wave-uniform)
-    if (w == 0) st = 0.0f;
-    else {
-      unsigned spins = 0;
-      unsigned long long rv;
-      while ((unsigned)((rv = lds_poll64(&H->resw[w - 1])) >> 32) != (unsigned)(t + 1))
-        if ((++spins & 1023u) == 0 && (spins > SPEC_SPIN || failed())) { give_up(); return; }
-      st = __int_as_float((int)(unsigned)rv);
-    }
-    HPROF(4);
-    int gg0 = 0;
-    if (w == 0) { st = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(A.a[0][0]), 0)); gg0 = 1; }   // (all candidates of the first segment are the exact start)
-#pragma unroll 1
-    for (int gg = gg0; gg < 4; ++gg) {                       // (not unrolled: ONE copy of the re-run chain in the code)
-      const int oe = gg == 0 ? o0 : gg == 1 ? o1 : gg == 2 ? o2 : o3;
-      const int idx = __builtin_amdgcn_readfirstlane(f2ord(st)) - oe + NC / 2;
-      ++n_spec;
-      if ((unsigned)idx < (unsigned)NC) {
-        const int q = idx >> 4;                            // which of the lane's 2 NACC sums (wave-uniform)
-        float pick = A.a[0][0];
-#pragma unroll
-        for (int j = 1; j < 2 * NACC; ++j) pick = q == j ? A.a[j >> 1][j & 1] : pick;
-        st = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pick), 16 * gg + (idx & 15)));
-        ++n_hit;
-      } else {                                             // outside the candidates: the segment again, from the true start
-        const float rr = dpp_chain130_one(st, P[0], P[1], P[2], P[3], P[4], P[5], P[6], P[7], P[8]);
-        st = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rr), 16 * gg));
-        ++n_miss;
-      }
-    }
-    const unsigned long long word = ((unsigned long long)(unsigned)(t + 1) << 32) | (unsigned)__float_as_int(st);
-    if (w < 3) { if (lane == 0) lds_store64(&H->resw[w], word); }
-    else if (lane == 0) {
-      if (local) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(&X->sum[m * pitch]), "v"(word) : "memory");   // stays in this XCD's L2 (every reader is on this XCD, checked at launch)
-      else st_u64(&X->sum[m * pitch], word);
-    }
-    HPROF(5);
-    if (t + 1 < nbits && !fetch(t + 1)) return;
-    HPROF(6);
-  }
-  if (hp && lane == 0) { for (int k = 0; k < 8; ++k) atomicAdd(&X->hprof[w][k], hacc[k]); }
-#undef HPROF
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (lane == 0) { atomicAdd(&X->stat[0], n_spec); atomicAdd(&X->stat[1], n_hit); atomicAdd(&X->stat[2 + (w > 2 ? 2 : w)], n_miss); }
 }
 
 // ------------------------------------------------------------------ scout, split (main workgroup of cmx_mixnet_spec_kernel)
@@ -1874,11 +1532,12 @@ template <bool LATE, int NACC> __device__ void helper_dpp_role(MixState* S, Spec
 // two more for the row selection), more than a whole bit of the helpers. Only Mixer::GetContextData is stateful; the stretch of a
 // bit's inputs depends on nothing, so four stretch waves take the bits round robin (each bit still costs its ~12 k clocks, four
 // are in flight) and one select wave follows them in order.
-template <bool LATE> __device__ void stretch_role(MixState* S, const Lds& L, SpecXfer* X, const float* probs, const uint8_t* bits, int nbits, int sw, int lane) {
+template <bool LATE, bool JIT = false> __device__ void stretch_role(MixState* S, const Lds& L, SpecXfer* X, const float* probs, const uint8_t* bits, int nbits, int sw, int lane) {
   const gptr<const float> lut = as_global(S->logit_lut);
   const gptr<const float> gprobs = as_global(probs);
   const float smin = S->stretch_min, smax = S->stretch_max;
   for (int t = sw; t < nbits; t += 4) {
+    jitter_stall<JIT>(L.jit, t, 4 + sw);
     if (t >= L.lead && !wait_ge<LATE>(L.ctl, &L.ctl->consumed, 4 * (t - L.lead) + 1, true)) return;   // the gather wave has begun bit t - lead
     if (t >= L.rr && !wait_ge<LATE>(L.ctl, &L.ctl->tail_done, t - L.rr + 1, true)) return;             // rec slot t % rr is free (see scout_role)
     BitRec* rec = L.rec + (t % L.rr);
@@ -1942,13 +1601,15 @@ template <bool LATE> __device__ void stretch_role(MixState* S, const Lds& L, Spe
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the ring slot and the record are complete
     __builtin_amdgcn_wave_barrier();
+    jitter_stall<JIT>(L.jit, t, 8 + sw);
     if (lane == 0) st_rel(&L.sdone[t % L.rr], t + 1);
   }
 }
 
-template <bool LATE> __device__ void select_role(MixState* S, const Lds& L, SpecXfer* X, const uint32_t* sel, int nbits, int lane) {
+template <bool LATE, bool JIT = false> __device__ void select_role(MixState* S, const Lds& L, SpecXfer* X, const uint32_t* sel, int nbits, int lane) {
   const gptr<const uint32_t> gsel = as_global(sel);
   for (int t = 0; t < nbits; ++t) {
+    jitter_stall<JIT>(L.jit, t, 2);
     uint32_t key = (!LATE && lane < CMX_MIXERS) ? gsel[(size_t)t * CMX_MIXERS + lane] : 0;
     BitRec* rec = L.rec + (t % L.rr);
     const BitRec* prev = L.rec + ((t + L.rr - 1) % L.rr);
@@ -1986,6 +1647,7 @@ template <bool LATE> __device__ void select_role(MixState* S, const Lds& L, Spec
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    jitter_stall<JIT>(L.jit, t, 3);
     if (lane == 0) __hip_atomic_store(&X->scout_epoch, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     st_rel(&L.ctl->scout_epoch, t + 1);
     if (LATE && lane == 0) late_stamp(L.late, 5);   // inputs and rows published to the helpers
@@ -1994,8 +1656,8 @@ template <bool LATE> __device__ void select_role(MixState* S, const Lds& L, Spec
 
 // ------------------------------------------------------------------ gather (main workgroup, wave 0)
 // chain_role with the 26 ordered sums arriving from the helpers instead of being added up here.
-template <bool LATE> __device__ void gather_role(MixState* S, const Lds& L, SpecXfer* X, const float* decay1, int nbits,
-                            float* mix_out, bool prof_on, int lane, int pitch, bool sleepy, bool local) {
+template <bool LATE, bool JIT = false> __device__ void gather_role(MixState* S, const Lds& L, SpecXfer* X, const float* decay1, int nbits,
+                            float* mix_out, bool prof_on, int lane, bool local) {
   const int m = lane;
   const bool is0 = m < CMX_MIX0;
   const float smin = S->stretch_min, smax = S->stretch_max;
@@ -2037,6 +1699,7 @@ template <bool LATE> __device__ void gather_role(MixState* S, const Lds& L, Spec
 #pragma unroll
   for (int i = 0; i < 7; ++i) ewn[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   for (int t = 0; t < nbits; ++t) {
+    jitter_stall<JIT>(L.jit, t, 0);
     if (!wait_ge<LATE>(L.ctl, &L.ctl->scout_epoch, t + 1, false)) return;
     st_rel(&L.ctl->consumed, 4 * t + 1);      // the scout may go on to bit t + 1 (it waits for consumed >= 4 t)
     GPROF(0);
@@ -2074,11 +1737,10 @@ template <bool LATE> __device__ void gather_role(MixState* S, const Lds& L, Spec
       unsigned long long gt0 = 0;
       while (true) {
         if (!have) {
-          const unsigned long long v = ld_u64(&X->sum[mm * pitch]);
+          const unsigned long long v = ld_u64(&X->sum[mm]);
           if ((unsigned)(v >> 32) == (unsigned)(t + 1)) { pm = __int_as_float((int)(unsigned)v); have = true; }
         }
         if (__ballot(!have) == 0) break;
-        if (sleepy) __builtin_amdgcn_s_sleep(1);
         if ((++spins & 1023u) == 0 && ((LATE ? late_expired(L.late.box, gt0) : spins > SPEC_SPIN) || lds_poll(&L.ctl->abort) || ld_u32(&X->fail))) {
           lds_publish_store(&L.ctl->abort, 1);
           __hip_atomic_store(&X->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2120,8 +1782,8 @@ template <bool LATE> __device__ void gather_role(MixState* S, const Lds& L, Spec
     const bool dfl = (rsteps & 1023) == 0;
     if (is0) {
       const unsigned long long uw = ((unsigned long long)(2u * (unsigned)(t + 1) + (dfl ? 1u : 0u)) << 32) | (unsigned)__float_as_int(uu);
-      if (local) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(&X->u[m * pitch]), "v"(uw) : "memory");   // stays in this XCD's L2: every helper is on this XCD (checked at launch)
-      else st_u64(&X->u[m * pitch], uw);
+      if (local) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(&X->u[m]), "v"(uw) : "memory");   // stays in this XCD's L2: every helper is on this XCD (checked at launch)
+      else st_u64(&X->u[m], uw);
     }
     GPROF(4);
     if (!LATE && !hand_to_tail()) return;
@@ -2177,7 +1839,7 @@ extern "C" __global__ __launch_bounds__(NTHREADS) void cmx_mixnet_chunk_kernel(
   L.prod = smem;                                                  // 2 * PBUF
   L.xs = L.prod + 2 * PBUF;                                       // 3 * XS
   L.rec = reinterpret_cast<BitRec*>(L.xs + 3 * XS);               // 3
-  L.rr = 3; L.lead = 2; L.lst = nullptr; L.lsq = nullptr; L.sdone = nullptr; L.h2 = nullptr; L.bitring = nullptr; L.late = CmxLate();
+  L.rr = 3; L.lead = 2; L.lst = nullptr; L.lsq = nullptr; L.sdone = nullptr; L.h2 = nullptr; L.bitring = nullptr; L.late = CmxLate(); L.jit = 0;
   L.trec = reinterpret_cast<TailRec*>(L.rec + 3);                 // 2
   L.upd = reinterpret_cast<float*>(L.trec + 2);                   // 32
   L.dflag = reinterpret_cast<uint32_t*>(L.upd + 32);              // 32
@@ -2209,10 +1871,7 @@ extern "C" __global__ __launch_bounds__(NTHREADS) void cmx_mixnet_chunk_kernel(
 // LATE: a decoder's chunk (cmx_late.h) -- `bits` is unused, rows / selectors arrive as their stages count them, p goes to the box. A compile-time
 // switch: the compressor's kernel carries none of the decoder's state (125 VGPRs / 71 spilled SGPRs as before the decoder existed, against
 // 167 / 135 when the two forms shared one kernel body at run time; the measured time per bit is the same either way, 6.8 us in the pipeline).
-// HV: the helpers' form, one kernel each (a kernel's registers are those of its hungriest path): 0 four segments (+ the tolerance mode's tree sums),
-// 1 eight segments (CMX_MIXNET_SEG8), 2 four segments with re-runs in pieces (CMX_MIXNET_RERUN4), 3 / 4 sixteen segments by DPP row broadcasts with 64 / 128
-// candidates (CMX_MIXNET_SEG16 = 1 / 2).
-template <bool LATE, int HV> __device__ __forceinline__ void spec_kernel_body(
+template <bool LATE, bool JIT = false> __device__ __forceinline__ void spec_kernel_body(
     MixState* __restrict__ S, SpecXfer* __restrict__ X, const float* __restrict__ probs, const uint32_t* __restrict__ sel,
     const uint8_t* __restrict__ bits, const float* __restrict__ decay1, int nbits,
     float* __restrict__ p_out, float* __restrict__ mix_out, int mode, const CmxLate& box) {
@@ -2260,19 +1919,9 @@ template <bool LATE, int HV> __device__ __forceinline__ void spec_kernel_body(
     HelperLds* H = reinterpret_cast<HelperLds*>(smem);
     for (int i = tid; i < (int)(sizeof(HelperLds) / 4); i += CMX_SPEC_THREADS) reinterpret_cast<int*>(H)[i] = 0;
     __syncthreads();
-    const int pitch = (mode & 0x4000) ? 16 : 1;   // CMX_MIXNET_PAD: one 128-byte line per value|tag word
-    const bool sleepy = (mode & 0x8000) != 0;     // CMX_MIXNET_SLEEP: s_sleep 1 in the polls of the global words
     CmxLateBox* const lb = LATE ? box.box : nullptr;
     const bool tol = (mode & 0x1000) != 0;
-    if constexpr (HV == 3) { if (wave < 4) helper_dpp_role<LATE, 2>(S, X, H, nbits, role - 1, wave, lane, lb, pitch, sleepy, local, (mode & 4) != 0); }
-    else if constexpr (HV == 4) { if (wave < 4) helper_dpp_role<LATE, 4>(S, X, H, nbits, role - 1, wave, lane, lb, pitch, sleepy, local, (mode & 4) != 0); }
-    else if constexpr (HV == 1) helper_role<LATE, 8>(S, X, H, nbits, role - 1, wave, lane, tol, lb, pitch, sleepy, local);   // all eight waves
-    else if constexpr (HV == 2) {   // four segments, a miss re-run in pieces on waves 4..6
-      if (wave < 4) helper_role<LATE, 4, true>(S, X, H, nbits, role - 1, wave, lane, false, lb, pitch, sleepy, local);
-      else if (wave < 7) rerun_role(X, H, nbits, wave - 3, lane);
-    }
-    else if constexpr (HV == 5) { if (wave < 4) helper_role<LATE, 4, false, 2>(S, X, H, nbits, role - 1, wave, lane, false, lb, pitch, sleepy, local); }   // 128 candidates per segment
-    else if (wave < 4) helper_role<LATE, 4>(S, X, H, nbits, role - 1, wave, lane, tol, lb, pitch, sleepy, local);
+    if (wave < 4) helper_role<LATE, JIT>(S, X, H, nbits, role - 1, wave, lane, tol, lb, local, JIT ? ((mode >> 26) & 15) | 16 : 0);
     return;
   }
   Lds L;
@@ -2295,6 +1944,7 @@ template <bool LATE, int HV> __device__ __forceinline__ void spec_kernel_body(
   L.h2 = reinterpret_cast<float*>(lst + 65536);                   // 2 x 64
   L.bitring = reinterpret_cast<int*>(L.h2 + 128);                 // 8
   L.late = LATE ? box : CmxLate();
+  L.jit = JIT ? ((mode >> 26) & 15) | 16 : 0;
   for (int i = tid; i < 32768; i += CMX_SPEC_THREADS) reinterpret_cast<uint32_t*>(lst)[i] = i < 16384 ? reinterpret_cast<const uint32_t*>(S->t_st)[i] : reinterpret_cast<const uint32_t*>(S->t_sq)[i - 16384];
   if (tid < 32) { L.upd[tid] = 0.0f; L.dflag[tid] = 0; L.exptab[tid] = cmx_exp2f_tab[tid]; }
   if (tid < 8) L.sdone[tid] = 0;
@@ -2303,34 +1953,33 @@ template <bool LATE, int HV> __device__ __forceinline__ void spec_kernel_body(
   if (LATE && tid == 0) { L.ctl->late_lo = (unsigned)(unsigned long long)box.box; L.ctl->late_hi = (unsigned)((unsigned long long)box.box >> 32); }   // (0 otherwise: cleared above)
   __syncthreads();
   const bool prof = (mode & 4) != 0;
-  if (wave == 0) gather_role<LATE>(S, L, X, decay1, nbits, mix_out, prof, lane, (mode & 0x4000) ? 16 : 1, (mode & 0x8000) != 0, local);
-  else if (wave == 1) tail_a_role<LATE>(S, L, decay1, nbits, mix_out, lane, prof && ((mode >> 4) & 4) != 0);
-  else if (wave == 3) tail_b_role<LATE>(S, L, decay1, nbits, p_out, mix_out, lane, prof && ((mode >> 4) & 4) != 0);
-  else if (wave == 2) select_role<LATE>(S, L, X, sel, nbits, lane);
-  else if (wave >= 4) stretch_role<LATE>(S, L, X, probs, bits, nbits, wave - 4, lane);
+  if (wave == 0) gather_role<LATE, JIT>(S, L, X, decay1, nbits, mix_out, prof, lane, local);
+  else if (wave == 1) tail_a_role<LATE, JIT>(S, L, decay1, nbits, mix_out, lane, prof && ((mode >> 4) & 4) != 0);
+  else if (wave == 3) tail_b_role<LATE, JIT>(S, L, decay1, nbits, p_out, mix_out, lane, prof && ((mode >> 4) & 4) != 0);
+  else if (wave == 2) select_role<LATE, JIT>(S, L, X, sel, nbits, lane);
+  else if (wave >= 4) stretch_role<LATE, JIT>(S, L, X, probs, bits, nbits, wave - 4, lane);
   __syncthreads();
   if (tid == 0 && (L.ctl->abort || ld_u32(&X->fail))) S->error = 1;
 }
 
 // Grid: 1 + 26 workgroups of 512 threads (x 8 with the one-XCD placement); all of them must be resident at once (they hand values to each other inside
 // the launch; every wait is bounded and a time-out sets SpecXfer::fail / MixState::error instead of hanging).
-#define CMX_SPEC_KERNEL(NAME, HV)                                                                                                  \
-  extern "C" __global__ __launch_bounds__(CMX_SPEC_THREADS) void NAME(                                                             \
-      MixState* __restrict__ S, SpecXfer* __restrict__ X, const float* __restrict__ probs, const uint32_t* __restrict__ sel,       \
-      const uint8_t* __restrict__ bits, const float* __restrict__ decay1, int nbits,                                               \
-      float* __restrict__ p_out, float* __restrict__ mix_out, int mode) {                                                          \
-    spec_kernel_body<false, HV>(S, X, probs, sel, bits, decay1, nbits, p_out, mix_out, mode, CmxLate());                           \
-  }
-CMX_SPEC_KERNEL(cmx_mixnet_spec_kernel, 0)
-CMX_SPEC_KERNEL(cmx_mixnet_spec_seg8_kernel, 1)
-CMX_SPEC_KERNEL(cmx_mixnet_spec_rerun4_kernel, 2)
-CMX_SPEC_KERNEL(cmx_mixnet_spec_dpp64_kernel, 3)
-CMX_SPEC_KERNEL(cmx_mixnet_spec_dpp128_kernel, 4)
-CMX_SPEC_KERNEL(cmx_mixnet_spec_cand2_kernel, 5)
+extern "C" __global__ __launch_bounds__(CMX_SPEC_THREADS) void cmx_mixnet_spec_kernel(
+    MixState* __restrict__ S, SpecXfer* __restrict__ X, const float* __restrict__ probs, const uint32_t* __restrict__ sel,
+    const uint8_t* __restrict__ bits, const float* __restrict__ decay1, int nbits,
+    float* __restrict__ p_out, float* __restrict__ mix_out, int mode) {
+  spec_kernel_body<false>(S, X, probs, sel, bits, decay1, nbits, p_out, mix_out, mode, CmxLate());
+}
+// test hook (CMX_MIXNET_JITTER, jitter_stall): the same roles with pseudo-random stalls -- an instantiation of its own, so the product kernel carries none of it
+extern "C" __global__ __launch_bounds__(CMX_SPEC_THREADS) void cmx_mixnet_spec_jitter_kernel(
+    MixState* __restrict__ S, SpecXfer* __restrict__ X, const float* __restrict__ probs, const uint32_t* __restrict__ sel,
+    const uint8_t* __restrict__ bits, const float* __restrict__ decay1, int nbits,
+    float* __restrict__ p_out, float* __restrict__ mix_out, int mode) {
+  spec_kernel_body<false, true>(S, X, probs, sel, bits, decay1, nbits, p_out, mix_out, mode, CmxLate());
+}
 // the decoder's form (engine mode 3, cmx_late.h): same grid, same roles, patient
 extern "C" __global__ __launch_bounds__(CMX_SPEC_THREADS) void cmx_mixnet_spec_late_kernel(
     MixState* __restrict__ S, SpecXfer* __restrict__ X, const float* __restrict__ probs, const uint32_t* __restrict__ sel,
     const float* __restrict__ decay1, int nbits, float* __restrict__ p_out, float* __restrict__ mix_out, int mode, CmxLate box) {
-  if (mode & 0x2000) spec_kernel_body<true, 1>(S, X, probs, sel, nullptr, decay1, nbits, p_out, mix_out, mode, box);
-  else spec_kernel_body<true, 0>(S, X, probs, sel, nullptr, decay1, nbits, p_out, mix_out, mode, box);
+  spec_kernel_body<true>(S, X, probs, sel, nullptr, decay1, nbits, p_out, mix_out, mode, box);
 }

@@ -76,28 +76,22 @@ struct MixState {
 #define CMX_SPEC_RING 8        /* bits the scout may publish ahead (it is held to 2 ahead of the gather wave) */
 #define CMX_SPEC_XS 2112       /* stretched inputs of a bit, zero padded (2078 used) */
 #define CMX_SPEC_HELPERS CMX_MIX0
-#define CMX_SPEC_THREADS 512      /* main: gather, tail, select, -, 4 stretch waves; helpers use the first four, or all eight (CMX_MIXNET_SEG8) */
-#define CMX_MIXNET_XCD_DEFAULT (-1)   /* the XCD the mixing network's 27 workgroups are placed on (-1: as dispatched); CMX_MIXNET_XCD overrides; the LSTM's block kernels leave it free */
-#define CMX_MIXNET_RERUN4_DEFAULT false   /* a missed segment re-run in four 128-term pieces on the helpers' idle waves (rerun_role) */
-#define CMX_MIXNET_CAND2_DEFAULT false    /* 128 candidates per speculative segment (two running sums per lane; CMX_MIXNET_CAND=2) */
-#define CMX_MIXNET_SEG8_DEFAULT false   /* the helpers' eight-segment split: opt-in (CMX_MIXNET_SEG8=1) until it has been measured in the pipeline */
+#define CMX_SPEC_THREADS 512      /* main: gather, tail a, select, tail b, 4 stretch waves; helpers use the first four */
+#define CMX_MIXNET_XCD_DEFAULT (-1)   /* the XCD the mixing network's 27 workgroups are placed on (-1: as dispatched); CMX_MIXNET_XCD overrides */
 struct SpecXfer {
   unsigned scout_epoch;        // bits whose inputs / rows the scout has published
   unsigned fail;               // sticky: a bounded in-launch wait ran out
   unsigned pad0[14];
   unsigned xcc[32];            // XCD placement (CMX_MIXNET_XCD): 1 + HW_REG_XCC_ID of the workgroup with role r, written at launch; all equal => the u / sum words
                                //   are exchanged through that XCD's L2 (plain stores, L1-bypassing loads), otherwise through the fabric (agent-scope stores)
-  // word m of u / sum sits at index m * pitch: pitch 1 = contiguous (round 3/4), pitch 16 = one 128-byte line per word (CMX_MIXNET_PAD: 104 helper waves
-  // poll u while the gather wave stores to it -- with contiguous words they all hit the same two to four lines)
-  unsigned long long u[32 * 16];    // by the gather wave after bit t: ((2 (t + 1) + decay flag) << 32) | bits of u = decay * lr * err   (mixer.cpp:56-64)
-  unsigned long long sum[32 * 16];  // by helper m after bit t: ((t + 1) << 32) | bits of the 2078-term ordered sum                     (mixer.cpp:40-43)
+  unsigned long long u[32];    // by the gather wave after bit t: ((2 (t + 1) + decay flag) << 32) | bits of u = decay * lr * err   (mixer.cpp:56-64)
+  unsigned long long sum[32];  // by helper m after bit t: ((t + 1) << 32) | bits of the 2078-term ordered sum                     (mixer.cpp:40-43)
   unsigned rowidx[CMX_SPEC_RING][32];
   unsigned changed[CMX_SPEC_RING][32];
   float xs[CMX_SPEC_RING][CMX_SPEC_XS];
   unsigned long long stat[8];  // [0] speculative segments run, [1] of them resolved from a candidate lane, [2..4] misses of segment 1..3
-  unsigned long long hprof[4][8];  // profiling launches: shader clocks per phase of the four waves of helper 12 (helper_dpp_role)
 };
-#define CMX_SPEC_HEADER_BYTES (64 + 128 + 2 * 32 * 16 * 8)   /* what the host clears ahead of every launch (epochs and tags restart at 0) */
+#define CMX_SPEC_HEADER_BYTES (64 + 128 + 2 * 32 * 8)   /* what the host clears ahead of every launch (epochs and tags restart at 0) */
 #define CMX_SPEC_LDS_BYTES 147456  /* main workgroup: 128 KB of SSE tables + records; a helper uses 9 KB of it */
 
 // dynamic LDS of cmx_mixnet_chunk_kernel (see the carve-up in mixnet_chunk.hip)

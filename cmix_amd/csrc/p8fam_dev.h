@@ -94,7 +94,7 @@ P8_HD void p8f_load(const P8CmDev* d, const P8FamHome* home, const uint16_t* sm_
     sh->anyconf[0] = sh->anyconf[1] = 0; sh->walk_cnt = 0; sh->kcount = 0; sh->anyshared = 0;
     for (int k = 0; k < P8CM_MAXI + 8; k++) sh->shared[k] = 0;
     const int i0 = d->rnd.i;   // V(idx) for idx in (i0 - 64, i0] is the generator's table; then the next 256
-    for (int k = 0; k < 64; k++) { const int idx = i0 - k; sh->rv[(uint32_t)idx & (P8F_RV - 1)] = d->rnd.table[idx & 63]; }
+    for (int k = 0; k < 64; k++) { const uint32_t idx = (uint32_t)i0 - (uint32_t)k; sh->rv[idx & (P8F_RV - 1)] = d->rnd.table[idx & 63]; }
     // (the counter is the reference's `int i` (paq8.cpp:154,163), which wraps; only its value mod 64 matters to the generator. Every index below is taken
     // modulo 2^32 and every range is walked by COUNT: a `<=` between two such indices fails in the step in which the counter passes 2^32 -- after
     // 4.29 G draws, 8.0 MB into enwik-like text -- and leaves the ring with stale values for good: round 5's 8 MiB finding)

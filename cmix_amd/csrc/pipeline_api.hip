@@ -197,6 +197,8 @@ struct cmx_pipeline {
   int last_slot = -1;
   double tot_ms[3] = {0, 0, 0};  // HIP-event time of every finished chunk's stages since the last reset
   uint64_t tot_chunks = 0;
+  float* dbg_mix = nullptr;      // diagnosis (cmx_pipeline_debug_mix_out): the 47 mixer outputs of every bit, [bit][47], as far as dbg_mix_cap bits
+  uint64_t dbg_mix_cap = 0, dbg_mix_bits = 0;
 };
 
 namespace {
@@ -611,7 +613,10 @@ static int finish_impl(cmx_pipeline_t* h, const float* cols, int first_col, int 
   if (h->fxcm) (void)hipStreamWaitEvent(h->s_mix, s.ev_fx1, 0);
   if (h->p8) (void)hipStreamWaitEvent(h->s_mix, s.ev_p81, 0);
   (void)hipEventRecord(s.ev_mix0, h->s_mix);
-  if (cmx_mixnet_run(h->mix, s.d_layer0, s.d_sel, s.d_bits, 8 * n, d_p_out, nullptr, h->s_mix)) return 1;
+  float* dmix = nullptr;
+  if (h->dbg_mix && h->dbg_mix_bits + 8 * n <= h->dbg_mix_cap) dmix = h->dbg_mix + h->dbg_mix_bits * 47;   // (CMX_MIXERS, mixnet_state.h)
+  h->dbg_mix_bits += 8 * n;
+  if (cmx_mixnet_run(h->mix, s.d_layer0, s.d_sel, s.d_bits, 8 * n, d_p_out, dmix, h->s_mix)) return 1;
   // the kernel's sticky time-out word, in stream order behind it: cmx_pipeline_wait looks at it per chunk (a look-ahead coder never
   // calls cmx_pipeline_sync, the only other place where it is read)
   (void)hipMemcpyAsync(&s.h_fail[2], cmx_mixnet_error_flag(h->mix), 4, hipMemcpyDeviceToHost, h->s_mix);
@@ -623,6 +628,14 @@ static int finish_impl(cmx_pipeline_t* h, const float* cols, int first_col, int 
   h->finished++;
   if (h->hinted < h->finished) h->hinted = h->finished;  // hints nobody asked for are skipped
   txn.ok = true;
+  return 0;
+}
+
+// diagnosis (scripts/gpu_foreign_load.py): a DEVICE area of cap_bits x 47 floats that receives every mixer's output (Mixer::Mix, before the clamp) of
+// every bit of the stream from now on, in stream order; NULL switches it off. Look-ahead chunks only.
+int cmx_pipeline_debug_mix_out(cmx_pipeline_t* h, float* d_mix, uint64_t cap_bits) {
+  if (!h) { cmx_set_err("cmx_pipeline_debug_mix_out: null handle"); return 1; }
+  h->dbg_mix = d_mix; h->dbg_mix_cap = d_mix ? cap_bits : 0; h->dbg_mix_bits = 0;
   return 0;
 }
 

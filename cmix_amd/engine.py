@@ -144,6 +144,7 @@ def lib():
         L.cmx_pipeline_fxcm_total_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.cmx_pipeline_enable_paq8.argtypes = [C.c_void_p]
         L.cmx_pipeline_wait.argtypes = [C.c_void_p, C.c_uint64]
+        L.cmx_pipeline_debug_mix_out.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         L.cmx_pipeline_paq8_total_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.cmx_pipeline_host_ms.argtypes = [C.c_void_p, C.c_void_p]
         L.cmx_pipeline_paq8_role_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -262,15 +263,6 @@ class MixNet:
         if lib().cmx_mixnet_last_kernel_ms(self.h, C.byref(v)):
             raise CmxError(last_error())
         return v.value
-
-    def helper_phases(self):
-        """Profiling launches: shader clocks per phase of the four waves of helper 12 (16-segment form), [wave][phase]."""
-        out = (C.c_uint64 * 32)()
-        lib().cmx_mixnet_helper_phases.argtypes = [C.c_void_p, C.c_void_p]
-        if lib().cmx_mixnet_helper_phases(self.h, out):
-            raise CmxError(last_error())
-        v = list(out)
-        return [v[8 * w:8 * w + 8] for w in range(4)]
 
     def spec_stats(self):
         """Speculative segment-parallel chain (cmx_mixnet_spec_kernel): segments run, resolved from a candidate, re-runs of segment 1..3."""
@@ -468,6 +460,11 @@ class Pipeline:
 
     def wait(self, index):
         if lib().cmx_pipeline_wait(self.h, index):
+            raise CmxError(last_error())
+
+    def debug_mix_out(self, d_mix):
+        """Diagnosis: d_mix = a CUDA float32 tensor [bits][47] that receives all 47 mixer outputs of every bit from now on (None: off)."""
+        if lib().cmx_pipeline_debug_mix_out(self.h, d_mix.data_ptr() if d_mix is not None else None, d_mix.shape[0] if d_mix is not None else 0):
             raise CmxError(last_error())
 
     def enable_paq8(self):

@@ -159,10 +159,6 @@ int cmx_mixnet_last_kernel_ms(cmx_mixnet_t*, float* ms);
  * start holds the reference's result, otherwise the segment is re-run). Statistics since creation: out[0] speculative segments,
  * [1] resolved from a candidate, [2..4] re-runs of segment 1 / 2 / 3. Synchronises the device. */
 int cmx_mixnet_spec_stats(cmx_mixnet_t*, uint64_t out[5]);
-/* Diagnostics of the helpers' 16-segment form (CMX_MIXNET_SEG16, mixnet_chunk.hip helper_dpp_role) in profiling launches: shader clocks per phase of
- * the four waves of helper 12 since creation, out[8 w + k]: k = 0 wait u, 1 update + products + segment sums, 2 wait the earlier waves' sums,
- * 3 candidates + chain, 4 wait the true start, 5 resolve (+ re-runs) + publish, 6 fetch of the next bit. Synchronises the device. */
-int cmx_mixnet_helper_phases(cmx_mixnet_t*, uint64_t out[32]);
 
 /* ------------------------------------------------------------------------
  * 2b. Stage: byte-level LSTM byte mixer = ByteMixer + Lstm + LstmLayer + its ByteModel bit
@@ -336,8 +332,8 @@ int cmx_ppmd_run(cmx_ppmd_t*, const uint8_t* bytes, size_t nbytes, float* out_pr
  *   CMX_PIPELINE_STREAMS   2 or 1: throughput mode for several streams per GPU -- fewer hardware queues per engine (8 or 6;
  *                          roles take turns on shared streams, the per-stream period grows)
  *   CMX_MIXNET_SPEC=0      the one-workgroup mixing-network kernel (1 compute unit per stream instead of 27: many streams per GPU)
- *   CMX_MIXNET_SEG8=1      the mixing network's helper workgroups cut the ordered chain into eight segments instead of four (bit-exact either way;
- *                          measured slower on synthetic inputs, kept for measurements in the pipeline)
+ *   CMX_MIXNET_XCD=k       the mixing network's 27 workgroups on XCD k, hand-off words through that XCD's L2 (bit-exact either way)
+ *   CMX_MIXNET_JITTER=1..15  test hook: pseudo-random stalls in the mixing network's roles (bit-exact by construction; tests/test_gpu_mixnet.py)
  *   (tolerance mode is NOT an environment switch: cmx_mixnet_set_tolerance / cmx_lstm_set_tolerance / cmx_pipeline_set_tolerance --
  *    no program that writes files turns it on)
  *   CMX_P8CM_SERIAL        1: paq8's table families walk every instance serially (A/B timing); 2: the ContextMap family's narrowed walk takes
@@ -416,6 +412,9 @@ int cmx_pipeline_fxcm_total_ms(cmx_pipeline_t*, double* ms);
 int cmx_mixnet_rows(cmx_mixnet_t*, uint32_t rows[47]);
 int cmx_ppmd_arena(cmx_ppmd_t*, uint64_t out3[3]);
 int cmx_pipeline_mixnet_rows(cmx_pipeline_t*, uint32_t rows[47]);
+/* diagnosis: from now on every mixer's output (Mixer::Mix, mixer.cpp:38-55, all 47) of every bit of the stream's look-ahead chunks goes to
+ * the DEVICE area d_mix[cap_bits][47] in stream order (bits past cap_bits are not recorded); NULL switches it off */
+int cmx_pipeline_debug_mix_out(cmx_pipeline_t*, float* d_mix, uint64_t cap_bits);
 int cmx_pipeline_spec_stats(cmx_pipeline_t*, uint64_t out[5]);
 int cmx_pipeline_paq8_profile(cmx_pipeline_t*, unsigned long long out128[128]);
 int cmx_pipeline_ppmd_arena(cmx_pipeline_t*, uint64_t out3[3]);

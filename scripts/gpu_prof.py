@@ -42,13 +42,3 @@ for n, v in zip(names, pr):
     if n == 'simd ids':
         continue
     print('  %-34s %9.0f ticks/bit  %5.1f%%' % (n, v / T, 100.0 * v / tot))
-
-
-
-if os.environ.get('CMX_MIXNET_SEG16'):
-    hp = net.helper_phases()
-    hn = ['wait u', 'update + products + segment sums', 'wait earlier waves sums', 'candidates + chain', 'wait true start', 'resolve (+ re-runs) + publish', 'fetch next bit']
-    print('helper 12, ticks per bit by wave (profiled launch):')
-    for k, n in enumerate(hn):
-        print('  %-36s' % n, ' '.join('%7.0f' % (hp[w][k] / T) for w in range(4)))
-    print('  %-36s' % 'total', ' '.join('%7.0f' % (sum(hp[w][:7]) / T) for w in range(4)))

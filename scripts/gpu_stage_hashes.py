@@ -72,6 +72,9 @@ def main():
     ap.add_argument("--detail-dir", default=os.path.join(ROOT, "tmp_longref"))
     ap.add_argument("--lean", action="store_true", help="with --detail-block: no digests, only the detail block's comparison; the report is written (and the process ends) at the "
                     "first difference -- for a run that has seconds of GPU time; --head-file / --vocab-file: the stream's head and the whole file's vocabulary from files")
+    ap.add_argument("--stop-block", type=int, default=-1, help="run only the stream's first N + 1 blocks of 64 KB (the engine is still built for the whole stream)")
+    ap.add_argument("--selfcheck", action="store_true", help="round 6 (DESIGN.md 5): is a difference of the final probability's digest the ENGINE's or the READ-BACK's? Keeps a copy of p as "
+                    "each digest read it, recomputes the digests from the finished run's p, then runs the same bytes through a second engine WITHOUT any digest work and compares the two runs' p")
     ap.add_argument("--head-file", default=None)
     ap.add_argument("--vocab-file", default=None)
     a = ap.parse_args()
@@ -104,8 +107,13 @@ def main():
     n = len(stream)
     if a.detail_block >= 0:   # the engine is built for the WHOLE stream (its vocabulary is the file's), only the head of it is run
         n = min(n, (a.detail_block + 1) * 65536)
+    if a.stop_block >= 0:
+        n = min(n, (a.stop_block + 1) * 65536)
+    whole_vocab = np.zeros(256, np.uint8)
+    whole_vocab[np.unique(np.frombuffer(stream, np.uint8))] = 1
     report = {}
-    eng = EngineStream(0, stream, 4096, vocab=np.fromfile(a.vocab_file, np.uint8) if a.vocab_file else None)
+    eng = EngineStream(0, stream, 4096, vocab=np.fromfile(a.vocab_file, np.uint8) if a.vocab_file else whole_vocab if a.stop_block >= 0 else None)
+    psnap = torch.zeros(8 * n, dtype=torch.float32, device=dev) if a.selfcheck else None
     sub = eng.sub
     nsub = -(-n // sub)
     blocks = -(-n // 65536)
@@ -125,6 +133,8 @@ def main():
         H[lo // 65536, :NG] += (w * bt[:, None]).sum(0)
         pv = (eng.p_dev[8 * lo:8 * hi].view(torch.int32).to(torch.int64) & 0xffffffff) + 1
         H[lo // 65536, NG] += (pv * bt).sum()
+        if psnap is not None:
+            psnap[8 * lo:8 * hi] = eng.p_dev[8 * lo:8 * hi]
         if detail and lo // 65536 == a.detail_block:
             r0 = 8 * (lo - a.detail_block * 65536)
             for key, ref in detail.items():
@@ -184,6 +194,41 @@ def main():
             print("group %s: %d bits differ in block %d; first: %s" % (k, v["bits_differing"], a.detail_block, json.dumps(v["first"])[:1500]))
     if a.ref and os.path.exists(a.ref):
         compare(a.out, a.ref)
+    if a.selfcheck:
+        torch.cuda.synchronize()
+        p_loaded = eng.p_dev[:8 * n].clone()
+        # (1) what each digest read against what the finished run holds: a difference = the digest read p before it was written
+        late = torch.nonzero(psnap.view(torch.int32) != p_loaded.view(torch.int32)).flatten()
+        print("selfcheck 1: p as the digests read it vs p after the run: %d bits differ%s" % (len(late), "" if not len(late) else "; first bit %d (block %d)" % (int(late[0]), int(late[0]) >> 19)))
+        # (2) the digests recomputed from the finished run's p
+        H2 = torch.zeros(blocks, dtype=torch.int64, device=dev)
+        for b in range(blocks):
+            lo, hi = b << 19, min(8 * n, (b + 1) << 19)
+            pv = (p_loaded[lo:hi].view(torch.int32).to(torch.int64) & 0xffffffff) + 1
+            H2[b] = (pv * Bt[:hi - lo]).sum()
+        badb = torch.nonzero(H2 != H[:, NG]).flatten().tolist()
+        print("selfcheck 2: final-p digests taken during the run vs recomputed afterwards: blocks that differ: %s" % badb)
+        eng.close()
+        del eng
+        torch.cuda.empty_cache()
+        # (3) the same bytes through a second engine with nothing else on the device
+        eng2 = EngineStream(0, stream, 4096, vocab=whole_vocab if a.stop_block >= 0 else None)
+        eng2.feed(n)
+        eng2.pipe.sync()
+        torch.cuda.synchronize()
+        p_clean = eng2.p_dev[:8 * n]
+        d = torch.nonzero(p_clean.view(torch.int32) != p_loaded.view(torch.int32)).flatten()
+        print("selfcheck 3: p of the digest run vs p of a clean run of the same %d bytes: %d bits differ%s" % (n, len(d), "" if not len(d) else "; first bit %d (byte %d, block %d)" % (int(d[0]), int(d[0]) >> 3, int(d[0]) >> 19)))
+        H3 = []
+        for b in range(blocks):
+            lo, hi = b << 19, min(8 * n, (b + 1) << 19)
+            pv = (p_clean[lo:hi].view(torch.int32).to(torch.int64) & 0xffffffff) + 1
+            H3.append(int((pv * Bt[:hi - lo]).sum()) & 0xFFFFFFFFFFFFFFFF)
+        with open(a.out + ".clean_p_digests.txt", "w") as f:
+            for b in range(blocks):
+                f.write("%d %016x\n" % (min(n, (b + 1) * 65536), H3[b]))
+        eng2.close()
+        return
     eng.close()
 
 

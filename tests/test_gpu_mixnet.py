@@ -162,51 +162,13 @@ def test_tolerance_mode_stays_within_its_tolerance(monkeypatch):
         assert d.max() < 1e-3 and bits_equal(a, b).mean() > 0.99, (name, d.max(), bits_equal(a, b).mean())
 
 
-def test_eight_segment_split_is_bit_exact(monkeypatch):
-    """CMX_MIXNET_SEG8: the helper workgroups cut the 2078-term ordered chain into eight segments of 256 (+ 30) terms on all eight of their
-    waves instead of four of 512 (+ 30) -- a shorter chain, a cheaper re-run on a speculation miss, more hops to resolve. The ordered f32 sum is
-    the same by construction (every segment ends on the exact running sum or is re-run from it): same bits as the four-segment kernel and as the
-    oracle, across two launches (the rows go to memory and come back). The two kernels' times go to gpurun_out/seg8_time.txt."""
-    import os
-    import torch
-    from cmix_amd import engine as E
-    from oracle import oracle as O
-    T = 4096
-    probs, sel, bits = synth_mixnet_inputs(T, seed=1)
-    ref = O.MixNet().run(probs[:1536], sel[:1536], bits[:1536])
-    d_probs = torch.from_numpy(probs).cuda()
-    d_sel = torch.from_numpy((sel & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.int32)).cuda()
-    d_bits = torch.from_numpy(bits).cuda()
-    out, lines = {}, []
-    for seg8 in ("0", "1"):
-        monkeypatch.setenv("CMX_MIXNET_SEG8", seg8)
-        net = E.MixNet(0)
-        p = torch.empty(T, dtype=torch.float32, device="cuda")
-        mix = torch.empty((T, 47), dtype=torch.float32, device="cuda")
-        ms = 0.0
-        for a, b in ((0, 1000), (1000, T)):
-            net.run(d_probs[a:b], d_sel[a:b], d_bits[a:b], p[a:b], mix[a:b])
-            torch.cuda.synchronize()
-            ms += net.last_kernel_ms()
-        out[seg8] = (p.cpu().numpy(), mix.cpu().numpy())
-        lines.append("CMX_MIXNET_SEG8=%s: %d bits in two launches, %.2f ms = %.2f us/bit; speculation %s" % (seg8, T, ms, ms * 1e3 / T, net.spec_stats()))
-        net.close()
-    os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
-    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "seg8_time.txt"), "w") as f:
-        f.write("\n".join(lines) + "\n")
-    assert np.array_equal(out["0"][0][:1536].view(np.uint32), ref.view(np.uint32)), "four segments != oracle"
-    assert np.array_equal(out["1"][0].view(np.uint32), out["0"][0].view(np.uint32)), "eight segments: final p differs"
-    assert np.array_equal(out["1"][1].view(np.uint32), out["0"][1].view(np.uint32)), "eight segments: a mixer output differs"
-
-
-@pytest.mark.parametrize("switch", ["CMX_MIXNET_PAD=1", "CMX_MIXNET_SLEEP=1", "CMX_MIXNET_RERUN4=1", "CMX_MIXNET_SEG16=1", "CMX_MIXNET_SEG16=2",
-                                    "CMX_MIXNET_CAND=2", "CMX_MIXNET_XCD=7", "CMX_MIXNET_XCD=2"])
-def test_round5_kernel_variants_are_bit_exact(monkeypatch, switch):
-    """The opt-in forms of the speculative kernel measured in round 5 (DESIGN.md 4.1's table: padded hand-off words, sleepy polls, a missed segment
-    re-run in four pieces, 16 DPP-fed segments with 64 / 128 candidates, 128 candidates on four segments): every one is the same ordered f32 sum by
-    construction -- the same bits as the default kernel and as the oracle, over two launches. The one-XCD placement (all workgroups on one XCD, the hand-off
-    words in its L2) is in the list with an XCD number below and above 4: the flag of the CU-mask diagnostic once shared a bit with that number's field,
-    which sent XCD 4..7 down the wrong branch (216 workgroups with roles, out-of-bounds rows: profiles/r05_xcd_fault.txt)."""
+@pytest.mark.parametrize("switch", ["CMX_MIXNET_XCD=7", "CMX_MIXNET_XCD=2", "CMX_MIXNET_JITTER=3", "CMX_MIXNET_JITTER=9"])
+def test_kernel_switches_are_bit_exact(monkeypatch, switch):
+    """Run-time forms of the speculative kernel: the one-XCD placement (all workgroups on one XCD, the hand-off words in its L2; an XCD number below and
+    above 4 -- the flag of a diagnostic once shared a bit with that number's field, which sent XCD 4..7 down the wrong branch: profiles/r05_xcd_fault.txt)
+    and the jitter hook (pseudo-random stalls in every role but the gather wave: every lead / lag the roles can have towards each other). Same ordered
+    f32 sums by construction: the same bits as the default kernel and as the oracle, over two launches. (The slower forms of the helper chain that round 5
+    measured -- eight / sixteen segments, 128 candidates, re-runs in pieces, padded or sleepy hand-off words -- left the product: scripts/study/.)"""
     import torch
     from cmix_amd import engine as E
     from oracle import oracle as O
