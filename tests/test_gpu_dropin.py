@@ -144,7 +144,8 @@ def test_lookahead_1mib_shard_prefix_is_byte_identical():
         _missing("fixture or oracle/_ref/cmix_lookahead missing")
     with np.load(path) as z:
         want_sha, want_size, (n, seed) = z["sha256"].tobytes(), int(z["size"][0]), z["seed"]
-    got = _run("-c", [("in", synth.enwik_like(int(n), int(seed)))], exe=LOOKAHEAD, timeout=1500)
+        rich = "rich" in z.files and bool(z["rich"][0])
+    got = _run("-c", [("in", synth.enwik_like(int(n), int(seed), rich=rich))], exe=LOOKAHEAD, timeout=1500)
     assert len(got) == want_size and hashlib.sha256(got).digest() == want_sha
 
 
@@ -189,15 +190,16 @@ def test_engine_12k_and_50k_files_are_byte_identical():
     assert len(got) == want_size and hashlib.sha256(got).digest() == want_sha
 
 
-def _shard_prefix(fixture, timeout):
+def _shard_prefix(fixture, timeout, exe=None):
     import hashlib
     from cmix_amd import synth
+    exe = exe or ENGINE
     path = os.path.join(GOLDEN, fixture)
-    if not os.path.exists(path) or not os.path.exists(ENGINE):
-        _missing("fixture or oracle/_ref/cmix_engine missing")
-    with np.load(path) as z:
-        want_sha, want_size, (n, seed) = z["sha256"].tobytes(), int(z["size"][0]), z["seed"]
-    got = _run("-c", [("in", synth.enwik_like(int(n), int(seed)))], exe=ENGINE, timeout=timeout)
+    if not os.path.exists(path) or not os.path.exists(exe):
+        _missing("fixture or %s missing" % exe)
+    with np.load(path) as z:   # (fixtures written since round 3 carry `rich`: the V = 205 alphabet of the bench shard)
+        want_sha, want_size, (n, seed), rich = z["sha256"].tobytes(), int(z["size"][0]), z["seed"], ("rich" in z.files and bool(z["rich"][0]))
+    got = _run("-c", [("in", synth.enwik_like(int(n), int(seed), rich=rich))], exe=exe, timeout=timeout)
     assert len(got) == want_size and hashlib.sha256(got).digest() == want_sha
 
 
@@ -286,6 +288,15 @@ def test_dropin_engine_12k_and_50k_files_are_byte_identical():
         want_sha, want_size, (n, seed) = z["text50k_c_sha256"].tobytes(), int(z["text50k_c_size"][0]), z["text50k_c_seed"]
     got = _run("-c", [("in", synth.enwik_like(int(n), int(seed)))], exe=DROPIN, timeout=900)
     assert len(got) == want_size and hashlib.sha256(got).digest() == want_sha
+
+
+@pytest.mark.skipif(os.environ.get("CMX_LONG") != "1", reason="~4 GPU-minutes; set CMX_LONG=1")
+def test_dropin_engine_4mib_rich_shard_prefix_is_byte_identical():
+    """The PRODUCT's drop-in path past 1 MiB: the reference's own runner + encoder over Predict() / Perceive() (look-ahead mode of the C ABI,
+    no reference model object) on the first 4 MiB of the bench shard -- size and SHA-256 of the file the unmodified reference binary wrote
+    (tests/golden/dropin_rich_4096k.npz: 1 204 197 bytes, 3.7 CPU-hours there). Rounds 4 / 5 checked 4 and 8 MiB through the Python
+    EngineStream only (scripts/gpu_long_run.py)."""
+    _shard_prefix("dropin_rich_4096k.npz", 1500, exe=DROPIN)
 
 
 def test_dropin_engine_empty_and_tiny_files():
