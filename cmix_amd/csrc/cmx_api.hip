@@ -612,6 +612,19 @@ int cmx_mixnet_profile(cmx_mixnet_t* h, int enable, uint64_t* out16) {
   return 0;
 }
 
+// Test hook (state injection; tests/golden/make_wrap_traces.py, the twin of oracle/ref_harness.cpp ref_debug_set_mixer_steps): the network as after `steps`
+// bits -- Mixer::steps_ of all 47 mixers (mixer.cpp:58,61: the argument of the decay schedule). Between chunks only.
+int cmx_mixnet_debug_set_steps(cmx_mixnet_t* h, uint64_t steps) {
+  const int fail_value = 1;
+  if (!h) { set_err("cmx_mixnet_debug_set_steps: null handle"); return 1; }
+  if (h->predicted) { set_err("cmx_mixnet_debug_set_steps: a bit-synchronous predict() is pending"); return 1; }
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipDeviceSynchronize());
+  HIP_OK(hipMemcpy((char*)h->d_state + offsetof(MixState, steps), &steps, 8, hipMemcpyHostToDevice));
+  h->bits_done = steps;
+  return 0;
+}
+
 int cmx_mixnet_bits_done(const cmx_mixnet_t* h, uint64_t* out) {
   if (!h || !out) { set_err("cmx_mixnet_bits_done: null argument"); return 1; }
   *out = h->bits_done;

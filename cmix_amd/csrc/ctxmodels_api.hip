@@ -390,6 +390,26 @@ int cmx_ctxmodels_debug_slow_bytes(cmx_ctxmodels_t* h, uint64_t out2[2]) {
                  hipSuccess ? 0 : 1;
 }
 
+// Test hook (state injection; tests/golden/make_wrap_traces.py, the twin of oracle/ref_harness.cpp ref_debug_set_history): the stage as after `pos`
+// bytes of a stream whose last n bytes were `tail` -- the history ring's write position (context-manager.cpp:24-27: modulo 100 000 000), every
+// Match model's own byte counter (match.cpp:43-46: not reduced), the ring's bytes in front of the position. Between chunks only.
+int cmx_ctxmodels_debug_set_history(cmx_ctxmodels_t* h, uint64_t pos, const uint8_t* tail, uint64_t n) {
+  if (!h || (n && !tail) || n > CTX_HISTORY) { cmx_set_err("cmx_ctxmodels_debug_set_history: bad argument"); return 1; }
+  if (cmx_ctxmodels_sync(h)) return 1;
+  CtxPersist* P = new CtxPersist();
+  bool ok = hipMemcpy(P, h->dev.persist, sizeof *P, hipMemcpyDeviceToHost) == hipSuccess;
+  P->history_pos = pos % CTX_HISTORY;
+  for (int l = 0; l < 64; ++l) P->m_history_pos[l] = pos;
+  ok = ok && hipMemcpy(h->dev.persist, P, sizeof *P, hipMemcpyHostToDevice) == hipSuccess;
+  delete P;
+  const uint64_t first = (pos + CTX_HISTORY - n % CTX_HISTORY) % CTX_HISTORY;   // ring index of tail[0]
+  const uint64_t n1 = n < CTX_HISTORY - first ? n : CTX_HISTORY - first;
+  if (n1) ok = ok && hipMemcpy(h->dev.history + first, tail, n1, hipMemcpyHostToDevice) == hipSuccess;
+  if (n > n1) ok = ok && hipMemcpy(h->dev.history, tail + n1, n - n1, hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) { cmx_set_err("cmx_ctxmodels_debug_set_history: device error"); return 1; }
+  return 0;
+}
+
 // Test readout in the layout the parity tests use for ContextManager state: regs25, ctx54, bitctx8
 int cmx_ctxmodels_get_manager(cmx_ctxmodels_t* h, uint64_t* regs25, uint64_t* ctx54, uint64_t* bitctx8) {
   if (!h) return 1;

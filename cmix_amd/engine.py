@@ -264,6 +264,12 @@ class MixNet:
             raise CmxError(last_error())
         return v.value
 
+    def debug_set_steps(self, steps):
+        """Test hook (state injection): the network as after `steps` bits -- Mixer::steps_ of all 47 mixers."""
+        lib().cmx_mixnet_debug_set_steps.argtypes = [C.c_void_p, C.c_uint64]
+        if lib().cmx_mixnet_debug_set_steps(self.h, int(steps)):
+            raise CmxError(last_error())
+
     def spec_stats(self):
         """Speculative segment-parallel chain (cmx_mixnet_spec_kernel): segments run, resolved from a candidate, re-runs of segment 1..3."""
         out = (C.c_uint64 * 5)()
@@ -396,6 +402,13 @@ class CtxModels:
             stream = torch.cuda.current_stream(byte.device).cuda_stream
         if lib().cmx_ctxmodels_peek(self.h, byte.data_ptr(), -1, probs8.data_ptr(), N_INPUTS, sel8.data_ptr(),
                                     C.c_void_p(stream)):
+            raise CmxError(last_error())
+
+    def debug_set_history(self, pos, tail):
+        """Test hook (state injection): the stage as after `pos` bytes of a stream that ended in `tail` -- history ring position, Match counters."""
+        tail = np.ascontiguousarray(np.frombuffer(bytes(tail), np.uint8))
+        lib().cmx_ctxmodels_debug_set_history.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+        if lib().cmx_ctxmodels_debug_set_history(self.h, int(pos), tail.ctypes.data, len(tail)):
             raise CmxError(last_error())
 
     def slow_bytes(self):

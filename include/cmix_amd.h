@@ -159,6 +159,9 @@ int cmx_mixnet_last_kernel_ms(cmx_mixnet_t*, float* ms);
  * start holds the reference's result, otherwise the segment is re-run). Statistics since creation: out[0] speculative segments,
  * [1] resolved from a candidate, [2..4] re-runs of segment 1 / 2 / 3. Synchronises the device. */
 int cmx_mixnet_spec_stats(cmx_mixnet_t*, uint64_t out[5]);
+/* Test hook (state injection): the network as after `steps` bits of a stream -- Mixer::steps_ (mixer.cpp:58,61) of all 47 mixers. The wrap / threshold
+ * fixtures of tests/golden/make_wrap_traces.py place the reference's counters the same way (oracle/ref_harness.cpp). Between chunks only. */
+int cmx_mixnet_debug_set_steps(cmx_mixnet_t*, uint64_t steps);
 
 /* ------------------------------------------------------------------------
  * 2b. Stage: byte-level LSTM byte mixer = ByteMixer + Lstm + LstmLayer + its ByteModel bit
@@ -239,6 +242,9 @@ int cmx_ctxmodels_pretrain(cmx_ctxmodels_t*, const uint8_t* d_bytes, size_t nbyt
 /* Test introspection: bytes that went through the serial path taken when two Indirect models' 256-byte windows of
  * the shared map overlap (indirect.cpp:16-31) -- [0] committed, [1] in dry (peek) passes. Synchronises. */
 int cmx_ctxmodels_debug_slow_bytes(cmx_ctxmodels_t*, uint64_t out2[2]);
+/* Test hook (state injection): the stage as after `pos` bytes of a stream whose last n bytes were `tail` (HOST) -- ContextManager::history_pos_ (modulo the
+ * 100 000 000-byte ring, context-manager.cpp:24-27), every Match model's own byte counter (match.cpp:43-46), the ring's bytes in front of the position. */
+int cmx_ctxmodels_debug_set_history(cmx_ctxmodels_t*, uint64_t pos, const uint8_t* tail, uint64_t n);
 /* Waits for the handle's work; reports device-side failures. */
 int cmx_ctxmodels_sync(cmx_ctxmodels_t*);
 /* Test hook: ContextManager registers (25), byte contexts (54), bit contexts (8) between bytes. */

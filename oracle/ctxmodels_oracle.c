@@ -599,3 +599,11 @@ void orc_ctx_run(orc_ctx* o, const uint8_t* bytes, size_t n, float* probs, uint6
       orc_ctx_perceive(o, (bytes[i] >> j) & 1);
     }
 }
+
+/* state injection: the twin of ref_debug_set_history (oracle/ref_harness.cpp) */
+void orc_ctx_set_history(orc_ctx* o, uint64_t pos, const uint8_t* tail, uint64_t n) {
+  for (uint64_t i = 0; i < n; ++i) o->history[(pos - n + i) % HISTORY_SIZE] = tail[i];
+  o->history_pos = pos % HISTORY_SIZE;
+  for (int k = 0; k < N_MODELS; ++k)
+    if (o->m[k].type == M_MATCH) o->m[k].m_history_pos = pos;
+}

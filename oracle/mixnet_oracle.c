@@ -258,3 +258,8 @@ float orc_mixnet_step(orc_mixnet* n, const float* probs, const uint64_t* sel_in,
   orc_sse_perceive(n->sse, bit);
   return p;
 }
+
+/* state injection: the twin of ref_debug_set_mixer_steps (oracle/ref_harness.cpp) */
+void orc_mixnet_set_steps(orc_mixnet* n, uint64_t steps) {
+  for (int k = 0; k < ORC_N_MIX; ++k) n->mx[k]->steps = steps;
+}

@@ -246,6 +246,11 @@ class MixNet:
     def aux_context(self):
         return int(lib().orc_mixnet_aux_context(self.h))
 
+    def set_steps(self, steps):
+        """State injection: Mixer::steps_ of all 47 mixers (tests/golden/make_wrap_traces.py)."""
+        lib().orc_mixnet_set_steps.argtypes = [C.c_void_p, C.c_uint64]
+        lib().orc_mixnet_set_steps(self.h, int(steps))
+
     def close(self):
         if self.h:
             lib().orc_mixnet_destroy(self.h)
@@ -336,6 +341,12 @@ class CtxModels:
 
     def bracket_probs(self):
         return np.ctypeslib.as_array(lib().orc_ctx_bracket_probs(self.h), shape=(256,)).copy()
+
+    def set_history(self, pos, tail):
+        """State injection: the history ring's write position, the Match models' byte counters, the bytes in front of it."""
+        tail = np.ascontiguousarray(np.frombuffer(bytes(tail), np.uint8))
+        lib().orc_ctx_set_history.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+        lib().orc_ctx_set_history(self.h, int(pos), tail.ctypes.data, len(tail))
 
     def run(self, data):
         """data: bytes -> (probs [T,54] f32, sel [T,47] u64)"""

@@ -37,6 +37,7 @@
 #include "mixer/byte-mixer.h"
 #include "models/byte-model.h"
 #include "models/ppmd.h"
+#include "models/match.h"
 #include "contexts/interval.h"
 #include "contexts/interval-hash.h"
 #include "states/nonstationary.h"
@@ -245,6 +246,31 @@ int ref_ppmd_update(int byte, float* out256) {
   for (int i = 0; i < 256; ++i) out256[i] = g_ppmd->probs_[i];
   return 0;
 }
+
+// ---- state injection (round 6: wrap / threshold regression traces, tests/golden/make_wrap_traces.py) ----------------------------------
+// Counters that only reach their interesting values hundreds of megabytes into a stream are PLACED there; everything that then happens
+// is the unmodified reference's own code. Only member access is widened, as everywhere in this file.
+// Mixer::steps_ of all 47 mixers (they tick together, mixer.cpp:61): the argument of the decay schedule's pow() (mixer.cpp:58).
+int ref_debug_set_mixer_steps(uint64_t steps) {
+  int n = 0;
+  for (auto& layer : g_p->mixers_)
+    for (auto& m : layer) { m->steps_ = steps; ++n; }
+  return n;
+}
+// ContextManager::history_pos_ (the write position in the 100 MB ring, context-manager.cpp:24-27) and every Match model's own history_pos_
+// (bytes seen so far, match.cpp:43-46: NOT reduced modulo the ring -- the two agree until the ring wraps): as after `pos` bytes of a stream
+// whose last n bytes were `tail` (written to the ring in front of pos). Returns the number of Match models.
+int ref_debug_set_history(uint64_t pos, const uint8_t* tail, uint64_t n) {
+  ContextManager& m = g_p->manager_;
+  const uint64_t size = m.history_.size();
+  for (uint64_t i = 0; i < n; ++i) m.history_[(pos - n + i) % size] = tail[i];
+  m.history_pos_ = pos % size;
+  int k = 0;
+  for (auto& md : g_p->models_)
+    if (Match* mm = dynamic_cast<Match*>(md.get())) { mm->history_pos_ = pos; ++k; }
+  return k;
+}
+uint64_t ref_history_size(void) { return g_p->manager_.history_.size(); }
 
 // libm probes: the exact host functions the reference's float path resolves to,
 // exported so tests can compare the device re-implementations against the very

@@ -94,6 +94,16 @@ class Ref:
                                  bctx.ctypes.data_as(C.c_void_p))
         return regs, ctx, bctx
 
+    # ---- state injection (round 6; oracle/ref_harness.cpp): counters placed where a stream would take them after hundreds of megabytes ----
+    def set_mixer_steps(self, steps):
+        self.lib.ref_debug_set_mixer_steps.argtypes = [C.c_uint64]
+        return self.lib.ref_debug_set_mixer_steps(int(steps))
+
+    def set_history(self, pos, tail):
+        tail = np.ascontiguousarray(np.frombuffer(bytes(tail), np.uint8))
+        self.lib.ref_debug_set_history.argtypes = [C.c_uint64, C.c_void_p, C.c_uint64]
+        return self.lib.ref_debug_set_history(int(pos), tail.ctypes.data_as(C.c_void_p), len(tail))
+
     def context_sizes(self):
         return np.array([self.lib.ref_context_size(i) for i in range(self.n_ctx)], np.uint64)
 

@@ -52,9 +52,12 @@ def default_block(payload: bytes) -> bytes:
     return bytes([0]) + len(payload).to_bytes(4, "big") + payload
 
 
-def trace(stream: bytes, full=True, pretrain: bytes = b""):
+def trace(stream: bytes, full=True, pretrain: bytes = b"", inject=None):
+    """inject (tests/golden/make_wrap_traces.py): called with the fresh reference before the first bit -- places counters (state injection)."""
     from oracle import refharness as R
     r = R.Ref(R.vocab_of(stream))
+    if inject:
+        inject(r)
     for byte in pretrain:  # preprocessor::Pretrain (preprocessor.cpp:37-69): Predictor::Pretrain per bit, MSB first
         for j in range(7, -1, -1):
             r.pretrain((byte >> j) & 1)
