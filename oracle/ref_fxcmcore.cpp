@@ -270,6 +270,14 @@ int reffx_model_update(void* h, int bit, int hint_pr, int hint_ex, float* out431
   for (int i = 0; i < 431; ++i) out431[i] = fx::model_predictions[i];
   return fx::pr;
 }
+// state injection (round 6): the model's position in its block -- what fxcm's thresholds read (update1 :4772-4774: 3.67 MB and 14.7 MB; modelPrediction
+// :3200, :3918, :3965: 448 MB .. 463 MB). The twin of orc_fx_model_set_blpos / fxe_set_blpos.
+// The two rates the model keeps (recomputed at every byte boundary from the position alone) are set to what that recomputation gives for the position.
+void reffx_model_set_blpos(void* h, int blpos) {
+  fx::x.blpos = blpos;
+  fx::sscmrate = (blpos > 14 * 256 * 1024);
+  (void)h; fx::rate = 6 + (blpos > 14 * 256 * 1024) + (blpos > 28 * 512 * 1024);
+}
 int reffx_model_debug(uint32_t* out) {
   int n = 0;
   for (int i = 0; i < 12; i++) out[n++] = (uint32_t)fx::mxA[i].cxt;

@@ -355,6 +355,35 @@ def test_whole_fxcm_model_vs_reference(name, tmp_path):
                 assert (ca == cb).all(), (name, n, np.nonzero(ca != cb)[0])
 
 
+@needs_ref
+@pytest.mark.parametrize("blpos", [14 * 256 * 1024 - 700, 28 * 512 * 1024 - 700, 448131719 - 500, 451531986 - 500, 463139793 - 500])
+def test_whole_fxcm_model_vs_reference_across_block_position_thresholds(blpos, tmp_path):
+    """fxcm reads its position in the block at five places: the SSCM / APM rates step at 3.67 MB and 14.7 MB (update1, fxcmv1.cpp:4772-4774) and
+    modelPrediction changes three decisions between 448 MB and 463 MB (:3200, :3918 / :3929, :3965). The 4 and 8 MiB files cross the first for real;
+    the others lie beyond every stream that was ever run here. State injection (round 6's wrap / threshold audit): the reference's own
+    fxcmv1::Predictor and the oracle are both placed shortly before each threshold and run across it -- all 431 values after every bit. The stage's
+    host bodies and device kernels are pinned on the oracle at the same places (tests/test_fxcm_stage_host.py, test_zgpu_stage_fxcm.py)."""
+    from cmix_amd import synth
+    L, lib = _private_fx_copy(tmp_path), O.lib()
+    lib.orc_fx_model_new.restype = P
+    lib.orc_fx_model_update.argtypes = [P, C.c_int, C.c_int, C.c_int, P]
+    lib.orc_fx_model_set_blpos.argtypes = [P, C.c_int]
+    L.reffx_model_set_blpos.argtypes = [P, C.c_int]
+    rng = np.random.default_rng(blpos & 0xffff)
+    data = synth.enwik_like(1400, 61, rich=True)
+    ref, got = L.reffx_model_new(), lib.orc_fx_model_new()
+    L.reffx_model_set_blpos(ref, blpos)
+    lib.orc_fx_model_set_blpos(got, blpos)
+    a, b = np.zeros(431, np.float32), np.zeros(431, np.float32)
+    for n, byte in enumerate(data):
+        for bpos in range(8):
+            y = (byte >> (7 - bpos)) & 1
+            hp, hx = int(rng.integers(1, 4095)), int(rng.integers(0, 256))
+            pr, pg = L.reffx_model_update(ref, y, hp, hx, a.ctypes.data), lib.orc_fx_model_update(got, y, hp, hx, b.ctypes.data)
+            bad = np.nonzero(a.view(np.uint32) != b.view(np.uint32))[0]
+            assert bad.size == 0 and pr == pg, (blpos, n, bpos, bad[:8], pr, pg)
+
+
 DICTIONARY = "/root/reference/dictionary/english.dic"
 
 
