@@ -157,6 +157,7 @@ typedef struct {
   uint32_t wav_length;
   uint32_t match_length, match_expected, stat_record, text_first_letter, text_mask;
   int type, nx;
+  uint64_t nbytes;                                 /* bytes seen (the sanity check of front_step: the first byte has fewer inputs; NOT `pos`, which a test may place) */
   int16_t in[P8_NX + 64];
 } P8Predictor;
 
@@ -524,7 +525,7 @@ static int context_model2(P8Predictor* p, int y, int32_t* sel) {
   nx += p8f_exe_step(p->exe, y, bpos, c0, p->c4, p->blpos, p->buf, p->bmask, p->pos, in + nx, exe_sets, &scratch);
   nx += p8f_lpm_step(p->lpm, y, bpos, c0, last, in + nx);
   /* 1552 once a byte boundary has been passed; fewer during the very first byte, when the context maps have no contexts yet */
-  if (nx > P8_NX || (p->pos > 0 && nx != P8_NX)) { fprintf(stderr, "paq8 front end: %d mixer inputs, expected %d\n", nx, P8_NX); return P8F_ERR_INTERNAL; }
+  if (nx > P8_NX || (p->nbytes > 0 && nx != P8_NX)) { fprintf(stderr, "paq8 front end: %d mixer inputs, expected %d\n", nx, P8_NX); return P8F_ERR_INTERNAL; }
   p->nx = nx;
 
   /* the 28 weight-set selectors, absolute positions in the 77472-row table, in the order the models call set(); the
@@ -562,6 +563,7 @@ static int front_step(P8Front* f, int y, int32_t* sel, P8ApmRec* apm) {
   p->c0 += p->c0 + y;
   if (p->c0 >= 256) {
     p->buf[(uint32_t)p->pos++ & p->bmask] = (uint8_t)p->c0;
+    p->nbytes++;
     p->c0 -= 256;
     const uint32_t b = (uint32_t)p->c0;
     p->c4 = (p->c4 << 8) + b;
@@ -736,6 +738,9 @@ int p8f_front_emit_step(P8Front* f, P8Chunk* out, size_t step_row) {
   return 0;
 }
 void p8f_front_set_bit(P8Front* f, int bit) { f->last_bit = bit ? 1 : 0; }
+/* test hook (state injection; the twin of oracle/ref_paq8core.cpp refp8_set_pos): the model's byte position -- the index into its 2^30-byte history ring
+ * (paq8.cpp:167-186). Before the first step only. */
+void p8f_front_set_pos(P8Front* f, int pos) { f->p->pos = pos; }
 
 int p8f_front_run(P8Front* f, const uint8_t* bytes, size_t nbytes, P8Chunk* out) {
   if (f->err) return f->err;

@@ -22,6 +22,7 @@ int p8f_front_run(P8Front* f, const uint8_t* bytes, size_t nbytes, P8Chunk* out)
  * the bit that was coded with them. p8f_front_run() is a loop of the two. */
 int p8f_front_emit_step(P8Front* f, P8Chunk* out, size_t step_row);
 void p8f_front_set_bit(P8Front* f, int bit);
+void p8f_front_set_pos(P8Front* f, int pos);   /* test hook: the model's byte position (before the first step) */
 const char* p8f_strerror(int code);
 /* data tables the device side is built from (the reference's nex() state table, stretch, squash, ilog) */
 const uint8_t* p8f_state_table(void);     /* [1024]  nex(s, k) = t[4 s + k] */

@@ -1722,6 +1722,13 @@ int cmx_p8stage_set_generator_counter(cmx_p8stage_t* h, uint32_t counter) {
   if (hipMemcpy((char*)h->d_fam + offsetof(P8CmDev, rnd) + offsetof(P8Rnd, i), &v, sizeof v, hipMemcpyHostToDevice) != hipSuccess) { cmx_set_err("cmx_p8stage_set_generator_counter: copy failed"); return 1; }
   return 0;
 }
+// Test hook (state injection, round 6): the front end's byte position -- the index into paq8's 2^30-byte history ring (paq8.cpp:167-186), which a stream reaches
+// after 1 GB; tests/golden/paq8_cols_pos_1g_6k.npz holds the unmodified paq8::Predictor's values across it. Before the first chunk only.
+int cmx_p8stage_debug_set_pos(cmx_p8stage_t* h, int pos) {
+  if (!h || !h->front) { cmx_set_err("cmx_p8stage_debug_set_pos: null handle"); return 1; }
+  p8f_front_set_pos(h->front, pos);
+  return 0;
+}
 int cmx_p8stage_mixfail(cmx_p8stage_t* h) { return h && h->h_mixfail && *h->h_mixfail ? 1 : 0; }
 
 int cmx_p8stage_set_upload_stream(cmx_p8stage_t* h, void* stream) {

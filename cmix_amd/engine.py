@@ -890,6 +890,12 @@ class P8Stage:
         if lib().cmx_p8stage_sync(self.h):
             raise CmxError(last_error())
 
+    def debug_set_pos(self, pos):
+        """Test hook (before the first byte): the front end's byte position (the index into paq8's 2^30-byte history ring)."""
+        lib().cmx_p8stage_debug_set_pos.argtypes = [C.c_void_p, C.c_int]
+        if lib().cmx_p8stage_debug_set_pos(self.h, int(pos)):
+            raise CmxError(last_error())
+
     def set_generator_counter(self, counter):
         """Test hook (before the first byte): the counter of the ContextMap family's shared generator, a multiple of 64."""
         if lib().cmx_p8stage_set_generator_counter(self.h, int(counter) & 0xFFFFFFFF):

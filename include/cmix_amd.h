@@ -507,6 +507,9 @@ int cmx_p8stage_mixfail(cmx_p8stage_t*);
 /* test hook: the counter of the ContextMap family's shared generator (paq8.cpp:152-165: `int i`, only i mod 64 matters), a multiple of 64, before the
  * first byte -- so that a test passes 2^31 / 2^32 draws (4 / 8 MB into a stream) within a few KB */
 int cmx_p8stage_set_generator_counter(cmx_p8stage_t*, uint32_t counter);
+/* test hook (state injection): the front end's byte position `pos` (paq8.cpp:167: the index into the 2^30-byte history ring at level 11), before the first
+ * byte -- a test passes the ring's end, which a stream reaches after 1 GB, within a few KB */
+int cmx_p8stage_debug_set_pos(cmx_p8stage_t*, int pos);
 int cmx_mixnet_run_late(cmx_mixnet_t*, void* box, const float* probs, const uint32_t* sel, size_t nbits, void* stream);
 /* One stream, bit by bit. The handle is a pipeline of section 3 with the fxcm and paq8 stages enabled (and, if there is a
  * dictionary, pretrained): cmx_pipeline_late_start() launches the first chunks' kernels (last_bit: the bit coded before the first

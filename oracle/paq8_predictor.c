@@ -94,6 +94,7 @@ typedef struct {
   int level;
   uint8_t* buf; uint32_t bmask;     /* Buf of MEM()*8 bytes (:8368) */
   /* globals :167-200, :3866-3870, :4538 */
+  unsigned long long nbytes;   /* bytes seen (the sanity check below: the first byte has fewer inputs; not `pos`, which a test may place) */
   int pos, c0, bpos, blpos;
   uint32_t c4, b2, b3, w4, w5, f4, tt, x4, x5, last_prediction;
   /* contextModel2 statics */
@@ -308,7 +309,7 @@ static int context_model2(P8Predictor* p, int y) {
   nx += orc_p8_exe_step(p->exe, y, bpos, c0, p->c4, p->blpos, p->buf, p->bmask, p->pos, in + nx, exe_sets, &scratch);
   nx += orc_p8_lpm_step(p->lpm, y, bpos, c0, last, in + nx);
   /* 1552 once a byte boundary has been passed; fewer during the very first byte, when the context maps have no contexts yet */
-  if (nx > P8_NUM_INPUTS || (p->pos > 0 && nx != P8_NUM_INPUTS)) { fprintf(stderr, "paq8 oracle: %d mixer inputs, expected %d\n", nx, P8_NUM_INPUTS); return ORC_P8_ERR_INTERNAL; }
+  if (nx > P8_NUM_INPUTS || (p->nbytes > 0 && nx != P8_NUM_INPUTS)) { fprintf(stderr, "paq8 oracle: %d mixer inputs, expected %d\n", nx, P8_NUM_INPUTS); return ORC_P8_ERR_INTERNAL; }
 
   /* the 28 weight-set selectors, absolute positions in the 77472-row table, in the order the models call set() */
   int base = 0;
@@ -341,6 +342,9 @@ static int context_model2(P8Predictor* p, int y) {
   return nexp == nx + P8_NUM_SETS ? pr : ORC_P8_ERR_INTERNAL;
 }
 
+/* state injection (the twin of oracle/ref_paq8core.cpp refp8_set_pos): the byte position, before the first update */
+void orc_p8_predictor_set_pos(P8Predictor* p, int pos) { p->pos = pos; }
+
 /* Predictor::update :8248-8362 = PAQ8::Perceive(bit). Returns the new prediction (12 bits) or a negative ORC_P8_ERR_*;
  * out1591 (may be NULL) receives PAQ8::Predict()'s vector for the next bit. */
 int orc_p8_predictor_update(P8Predictor* p, int y, float* out1591) {
@@ -349,6 +353,7 @@ int orc_p8_predictor_update(P8Predictor* p, int y, float* out1591) {
   p->misses += p->misses + (uint64_t)((p->pr >> 11) != y);
   if (p->c0 >= 256) {
     p->buf[(uint32_t)p->pos++ & p->bmask] = (uint8_t)p->c0;
+    p->nbytes++;
     p->c0 -= 256;
     const uint32_t b = (uint32_t)p->c0;
     p->c4 = (p->c4 << 8) + b;

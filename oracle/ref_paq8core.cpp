@@ -468,6 +468,9 @@ void* refp8_predictor_new(int level) {
   paq8::buf.setsize(paq8::MEM() * 8);
   return new paq8::Predictor();
 }
+// state injection (round 6's wrap / threshold audit): paq8's byte position `pos` (:167) -- the index into the 2^30-byte history ring at level 11 (Buf :169-186,
+// every read is (pos - i) & (size - 1)) and the value the match models and the detectors store and compare. A stream reaches 2^30 after 1 GB.
+void refp8_set_pos(int pos) { paq8::pos = pos; }
 int refp8_predictor_update(void* h, int bit, float* out1591) {
   paq8::y = bit;
   ((paq8::Predictor*)h)->update();

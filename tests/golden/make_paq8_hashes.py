@@ -242,16 +242,25 @@ def streams():
         # the head of the bench shard (round 3: rich alphabet, V = 205): multi-byte UTF-8 from 46 script blocks, all of ASCII
         "rich_16k": text_block(synth.enwik_like(16384 - 6, 1000, rich=True)),
         "hdrs_4k": default_block(header_lookalikes()),
+        # state injection: the history ring's index passes 2^30 in the middle of this stream (INJECT_POS); text with repeats, so that the match models hold
+        # positions from in front of the wrap
+        "pos_1g_6k": text_block((synth.enwik_like(2600, 88, rich=True) * 3)[:6144 - 6]),
         **image_streams(),
     }
 
 
-def reference_hashes(stream):
+INJECT_POS = {"pos_1g_6k": (1 << 30) - 3000}   # state injection (round 6): the stream starts with paq8's byte position 3000 below the end of its 2^30-byte ring
+
+
+def reference_hashes(stream, pos=None):
     L = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libcmixrefpaq8.so"))
     L.refp8_predictor_new.restype = C.c_void_p
     L.refp8_predictor_new.argtypes = [C.c_int]
     L.refp8_predictor_update.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     h = L.refp8_predictor_new(11)
+    if pos is not None:
+        L.refp8_set_pos.argtypes = [C.c_int]
+        L.refp8_set_pos(pos)
     bits = np.unpackbits(np.frombuffer(stream, np.uint8))
     out = np.full((len(bits), 1591), 0.5, np.float32)   # PAQ8::Predict() before the first Perceive: 0.5 everywhere
     for t in range(len(bits) - 1):
@@ -263,7 +272,8 @@ if __name__ == "__main__":
     for name, s in streams().items():
         # one reference predictor per process (it keeps state in globals)
         if len(sys.argv) > 1 and sys.argv[1] == name:
-            np.savez_compressed(os.path.join(HERE, "paq8_cols_%s.npz" % name), stream=np.frombuffer(s, np.uint8), hash=reference_hashes(s))
+            extra = {"inject_pos": np.array([INJECT_POS[name]], np.int64)} if name in INJECT_POS else {}
+            np.savez_compressed(os.path.join(HERE, "paq8_cols_%s.npz" % name), stream=np.frombuffer(s, np.uint8), hash=reference_hashes(s, INJECT_POS.get(name)), **extra)
             print(name, len(s), "bytes")
         elif len(sys.argv) == 1:
             import subprocess

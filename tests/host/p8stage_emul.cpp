@@ -130,6 +130,7 @@ void p8s_set_late(void* h, int on) { ((Emul*)h)->late = on & 1; ((Emul*)h)->late
 void p8s_miniwalk_stats(void* h, uint64_t* out2) { out2[0] = ((Emul*)h)->fam_mini; out2[1] = ((Emul*)h)->fam_mini_full; }
 uint32_t p8s_rnd_i(void* h) { return ((Emul*)h)->f2_i; }   // how many values of the shared generator the family has drawn (mod 2^32)
 void p8s_set_rnd_i(void* h, uint32_t i) { Emul* e = (Emul*)h; e->S.fam.rnd.i = (int)i; e->f2_i = e->f2_prev_i = i; }   // test hook: place the generator's counter (its 64 values stay) -- to reach the counter's sign change without 8 MB of input
+void p8s_set_pos(void* h, int pos) { p8f_front_set_pos(((Emul*)h)->front, pos); }   // test hook: the front end's byte position (before the first byte)
 void p8s_stats(void* h, uint64_t* out3) { Emul* e = (Emul*)h; out3[0] = e->steps; out3[1] = e->fam_serial; out3[2] = e->cm2_serial; }
 // nbytes more bytes of the stream; out [8 nbytes][1591] f32 = PAQ8::Predict() before each of their bits. 0 or a negative front-end code.
 int p8s_run(void* h, const uint8_t* bytes, int nbytes, float* out) {

@@ -904,6 +904,37 @@ def test_whole_paq8_predictor_vs_reference(name, tmp_path):
             assert pr == pg, (n, bpos, pr, pg)
 
 
+@needs_ref
+@pytest.mark.parametrize("level, log2size", [(2, 21), (4, 23)])
+def test_whole_paq8_predictor_vs_reference_across_the_history_rings_end(level, log2size, tmp_path):
+    """paq8's byte position `pos` (paq8.cpp:167) indexes a ring of MEM() * 8 bytes (:169-186, :8368: 2^30 at cmix's level 11, 2^21 / 2^23 at the levels
+    run here) and is stored / compared unmasked by the match models and the detectors. State injection (round 6's wrap / threshold audit): the reference's
+    own paq8::Predictor and the oracle both start 2500 bytes below the ring's size and run across it -- all 1591 values after every bit. (At level 11 the
+    same is pinned by the per-step hashes of tests/golden/paq8_cols_pos_1g_6k.npz on the stage's front end and on the device.)"""
+    from cmix_amd import synth
+    L, lib = _private_ref_copy(tmp_path), O.lib()
+    lib.orc_p8_predictor_new.restype = C.c_void_p
+    lib.orc_p8_predictor_new.argtypes = [C.c_int]
+    lib.orc_p8_predictor_update.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.orc_p8_predictor_set_pos.argtypes = [C.c_void_p, C.c_int]
+    L.refp8_set_pos.argtypes = [C.c_int]
+    data = (synth.enwik_like(2200, 88, rich=True) * 2)[:4000]
+    lib.orc_p8_rnd_reset()
+    ref, got = L.refp8_predictor_new(level), lib.orc_p8_predictor_new(level)
+    pos0 = (1 << log2size) - 2500
+    L.refp8_set_pos(pos0)
+    lib.orc_p8_predictor_set_pos(got, pos0)
+    o_ref, o_got = np.zeros(1591, np.float32), np.zeros(1591, np.float32)
+    for n, byte in enumerate(data):
+        for bpos in range(8):
+            y = (byte >> (7 - bpos)) & 1
+            pr = L.refp8_predictor_update(ref, y, o_ref.ctypes.data)
+            pg = lib.orc_p8_predictor_update(got, y, o_got.ctypes.data)
+            assert pg >= 0, (n, bpos, pg)
+            bad = np.nonzero(o_ref.view(np.uint32) != o_got.view(np.uint32))[0]
+            assert bad.size == 0 and pr == pg, (level, n, bpos, bad[:8], pr, pg)
+
+
 def test_paq8_predictor_refuses_streams_it_does_not_model():
     """JPEG / BMP / WAV payloads and image-typed blocks switch on sub-models the oracle does not restate: it must
     return an error code, never a number."""

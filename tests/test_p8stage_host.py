@@ -290,3 +290,35 @@ def test_shared_generator_counter_wraps_like_the_references(start):
     assert end < (start & 0xFFFFFFFF) or (start < (1 << 31) <= end), "the counter did not pass the boundary: lengthen the stream"
     bad = np.nonzero(row_hash(out) != want[:8 * n])[0]
     assert bad.size == 0, ("first differing step:", int(bad[0]), "byte", int(bad[0]) // 8)
+
+
+def test_byte_position_passes_the_end_of_the_history_ring_like_the_references():
+    """paq8's `pos` (paq8.cpp:167) indexes a 2^30-byte ring at cmix's level 11 (Buf :169-186: every read is (pos - i) & (size - 1)); the match models and the
+    detectors store and compare the unmasked value. A stream gets there after 1 GB. State injection (round 6's wrap / threshold audit): the unmodified
+    paq8::Predictor started 3000 bytes below 2^30 (oracle/ref_paq8core.cpp refp8_set_pos) gave the fixture; the front end is placed the same way."""
+    from make_paq8_hashes import row_hash
+    L = emul()
+    L.p8s_set_pos.argtypes = [C.c_void_p, C.c_int]
+    with np.load(os.path.join(ROOT, "tests", "golden", "paq8_cols_pos_1g_6k.npz")) as z:
+        stream, want, pos0 = z["stream"].copy(), z["hash"].copy(), int(z["inject_pos"][0])
+    n = len(stream)
+    assert pos0 < (1 << 30) < pos0 + n
+    h = L.p8s_create(11)
+    L.p8s_set_pos(h, pos0)
+    d = np.ascontiguousarray(stream)
+    out = np.zeros((8 * n, 1591), np.float32)
+    pos = 0
+    for m in (2990, 10, 1, 1000, n):   # a chunk that ends 2990 + 10 = 3000 bytes in: exactly at the ring's end; the byte behind it alone
+        m = min(m, n - pos)
+        if m:
+            assert L.p8s_run(h, d[pos:].ctypes.data, m, out[8 * pos:].ctypes.data) == 0
+        pos += m
+    L.p8s_destroy(h)
+    bad = np.nonzero(row_hash(out) != want)[0]
+    assert bad.size == 0, ("first differing step:", int(bad[0]), "byte", int(bad[0]) // 8, "(the ring ends in front of byte 3000)")
+    # and the fixture does depend on the injection: from position 0 the same stream gives other values
+    h = L.p8s_create(11)
+    out2 = np.zeros((8 * 400, 1591), np.float32)
+    assert L.p8s_run(h, d.ctypes.data, 400, out2.ctypes.data) == 0
+    L.p8s_destroy(h)
+    assert (row_hash(out2) != want[:8 * 400]).any()

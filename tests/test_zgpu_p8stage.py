@@ -13,12 +13,14 @@ import make_golden as mg
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
 
 
-def run_device(data, chunks, generator_counter=None):
+def run_device(data, chunks, generator_counter=None, pos=None):
     import torch
     from cmix_amd import engine as E
     st = E.P8Stage(0)
     if generator_counter is not None:
         st.set_generator_counter(generator_counter)
+    if pos is not None:
+        st.debug_set_pos(pos)
     outs, pos, k = [], 0, 0
     data = bytes(data)
     while pos < len(data):
@@ -64,6 +66,17 @@ def test_shared_generator_counter_wraps_like_the_references(start):
     from test_p8stage_host import load_hashes
     stream, want = load_hashes("rich_16k")
     got = run_device(stream, [1024, 1, 4096, 333], generator_counter=start)
+    bad = np.nonzero(row_hash(got) != want)[0]
+    assert bad.size == 0, ("first differing step:", bad[0], "of", len(want))
+
+
+def test_byte_position_passes_the_end_of_the_history_ring_like_the_references():
+    """paq8's byte position passes 2^30, the size of its history ring at level 11, 3000 bytes into this stream (state injection: the fixture is the unmodified
+    paq8::Predictor started there, tests/golden/make_paq8_hashes.py pos_1g_6k; tests/test_p8stage_host.py has the host twin): a stream reaches it after 1 GB."""
+    from make_paq8_hashes import row_hash
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "paq8_cols_pos_1g_6k.npz")) as z:
+        stream, want, pos0 = z["stream"].copy(), z["hash"].copy(), int(z["inject_pos"][0])
+    got = run_device(stream, [2990, 10, 1, 1000, 4096], pos=pos0)
     bad = np.nonzero(row_hash(got) != want)[0]
     assert bad.size == 0, ("first differing step:", bad[0], "of", len(want))
 
