@@ -612,7 +612,7 @@ int cmx_mixnet_profile(cmx_mixnet_t* h, int enable, uint64_t* out16) {
   return 0;
 }
 
-// Test hook (state injection; tests/golden/make_wrap_traces.py, the twin of oracle/ref_harness.cpp ref_debug_set_mixer_steps): the network as after `steps`
+// Test hook (state injection; tests/golden/make_wrap_traces.py, the twin of the reference harness's ref_debug_set_mixer_steps): the network as after `steps`
 // bits -- Mixer::steps_ of all 47 mixers (mixer.cpp:58,61: the argument of the decay schedule). Between chunks only.
 int cmx_mixnet_debug_set_steps(cmx_mixnet_t* h, uint64_t steps) {
   const int fail_value = 1;

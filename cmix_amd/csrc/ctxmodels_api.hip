@@ -390,7 +390,7 @@ int cmx_ctxmodels_debug_slow_bytes(cmx_ctxmodels_t* h, uint64_t out2[2]) {
                  hipSuccess ? 0 : 1;
 }
 
-// Test hook (state injection; tests/golden/make_wrap_traces.py, the twin of oracle/ref_harness.cpp ref_debug_set_history): the stage as after `pos`
+// Test hook (state injection; tests/golden/make_wrap_traces.py, the twin of the reference harness's ref_debug_set_history): the stage as after `pos`
 // bytes of a stream whose last n bytes were `tail` -- the history ring's write position (context-manager.cpp:24-27: modulo 100 000 000), every
 // Match model's own byte counter (match.cpp:43-46: not reduced), the ring's bytes in front of the position. Between chunks only.
 int cmx_ctxmodels_debug_set_history(cmx_ctxmodels_t* h, uint64_t pos, const uint8_t* tail, uint64_t n) {

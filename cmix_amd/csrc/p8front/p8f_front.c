@@ -738,7 +738,7 @@ int p8f_front_emit_step(P8Front* f, P8Chunk* out, size_t step_row) {
   return 0;
 }
 void p8f_front_set_bit(P8Front* f, int bit) { f->last_bit = bit ? 1 : 0; }
-/* test hook (state injection; the twin of oracle/ref_paq8core.cpp refp8_set_pos): the model's byte position -- the index into its 2^30-byte history ring
+/* test hook (state injection; the twin of the reference harness's refp8_set_pos): the model's byte position -- the index into its 2^30-byte history ring
  * (paq8.cpp:167-186). Before the first step only. */
 void p8f_front_set_pos(P8Front* f, int pos) { f->p->pos = pos; }
 
