@@ -26,6 +26,7 @@ extern "C" __global__ void cmx_lstm_bptt_acc(const LstmState, int, int, int, int
 extern "C" __global__ void cmx_lstm_bptt_gb(const LstmState, int, int);
 extern "C" __global__ void cmx_lstm_bptt_acc_mfma(const LstmState, int, int);
 extern "C" __global__ void cmx_lstm_fwdblk(const LstmState, const uint8_t*, const float*, float*, size_t, int, int, int);
+extern "C" __global__ void cmx_lstm_fwdblk_late(const LstmState, CmxLate, const float*, const float*, float*, int, int, int, int, int);
 extern "C" __global__ void cmx_lstm_bpttblk(const LstmState);
 extern "C" __global__ void cmx_bytemodel_bits(const float*, const float*, const uint8_t*, size_t, float*, int*, size_t, int,
                                               float*);
@@ -199,6 +200,7 @@ cmx_lstm_t* cmx_lstm_create(const uint8_t vocab[256], int skip_rand, int device)
     h->bp_lds = (size_t)9 * 50 * LSTM_BP_J * 16 +
                 ((size_t)3 * 256 * LSTM_BP_J + 3 * 256 + 3 * LSTM_C + 3 * LSTM_C + 4 + 6 * LSTM_BP_J) * 4;
     if (hipFuncSetAttribute((const void*)cmx_lstm_fwdblk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->fb_lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cmx_lstm_fwdblk_late, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->fb_lds) != hipSuccess ||
         hipFuncSetAttribute((const void*)cmx_lstm_bpttblk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bp_lds) != hipSuccess)
       fail = true;
   }
@@ -262,6 +264,42 @@ int cmx_lstm_run(cmx_lstm_t* h, const float* d_in_probs, const uint8_t* d_bytes,
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { cmx_set_err(std::string("cmx_lstm_run: ") + hipGetErrorString(e)); return 1; }
   return 0;
+}
+
+// The decoder's form of a run (cmx_late.h; round 6): bytes b0 .. of a decoder's chunk, of which only byte b0 is known (its value and the byte models' distribution
+// after it: HOST pointers h_in256 / byte0, for the bookkeeping and the BPTT round an epoch-0 byte begins with, lstm.cpp:93). ONE forward launch covers the bytes up to
+// the end of the truncated-BPTT block or of the chunk (nchunk bytes), whichever comes first: its steps wait for their bytes inside the launch
+// (cmx_lstm_fwdblk_late), read PPMd's distributions from the relay's device mirror d_ppmd ([nchunk + 1][256], row b + 1 = after byte b; the chunk's last byte:
+// from the host's own array h_ppmd, same layout, device-mapped) and count every distribution that goes out into d_out ([nchunk][256]) on LC_LSTM.
+// Returns the number of bytes the launch covers (>= 1), or -1. The caller calls again when those bytes have been decoded.
+int cmx_lstm_run_late(cmx_lstm_t* h, const void* late_box, const float* d_ppmd, const float* h_ppmd, const uint8_t* h_bytes, float* d_out, size_t b0, size_t nchunk, void* stream) {
+  if (!h || !late_box || !d_ppmd || !h_ppmd || !h_bytes || !d_out || b0 >= nchunk) { cmx_set_err("cmx_lstm_run_late: bad argument"); return -1; }
+  if (hipSetDevice(h->device) != hipSuccess) { cmx_set_err("hipSetDevice failed"); return -1; }
+  if (h->tolerance) { cmx_set_err("cmx_lstm_run_late: a decoder is strict"); return -1; }
+  hipStream_t st = (hipStream_t)stream;
+  const LstmState& S = h->h_state;
+  const int e = (int)(h->bytes_done % LSTM_H);
+  const int hc = h->hc;
+  auto sync_reset = [&]() { return hipMemsetAsync((char*)S.sync + 16, 0, sizeof(LstmSync) - 16, st) == hipSuccess; };
+  if (e == 0) {   // lstm.cpp:93: the BPTT round over the block that has just ended, with the bookkeeping of this byte in front of it (device-mapped host rows)
+    h->bptt_rounds += 1;
+    const int us = (int)(h->bptt_rounds < LSTM_UPDATE_LIMIT ? h->bptt_rounds : LSTM_UPDATE_LIMIT);
+    hipLaunchKernelGGL(cmx_lstm_prep, dim3(1), dim3(256), 0, st, S, h_ppmd + (b0 + 1) * 256, h_bytes, b0, e, -1);
+    if (!sync_reset()) { cmx_set_err("cmx_lstm_run_late: hipMemsetAsync failed"); return -1; }
+    hipLaunchKernelGGL(cmx_lstm_bpttblk, dim3(lstm_grid_for_roles(LSTM_BP_G, S.avoid_xcd)), dim3(LSTM_BP_THREADS), h->bp_lds, st, S);
+    { const int gx = (S.rowlen[1] + 63) / 64, gy = LSTM_C / 4; hipLaunchKernelGGL(cmx_lstm_bptt_acc, dim3(lstm_grid_for_roles(gx * gy * 6, S.avoid_xcd)), dim3(64, 4), 0, st, S, us, -1, gx, gy); }
+    hipLaunchKernelGGL(cmx_lstm_bptt_gb, dim3(6), dim3(256), 0, st, S, us, -1);
+  }
+  const size_t left = nchunk - b0;
+  const int cnt = (int)(left < (size_t)(LSTM_H - e) ? left : (size_t)(LSTM_H - e));
+  if (!sync_reset()) { cmx_set_err("cmx_lstm_run_late: hipMemsetAsync failed"); return -1; }
+  hipLaunchKernelGGL(cmx_lstm_fwdblk_late, dim3(lstm_grid_for_roles(2 * LSTM_FB_GL + LSTM_FB_GO, S.avoid_xcd)), dim3(LSTM_FB_THREADS), h->fb_lds, st, S, *(const CmxLate*)late_box,
+                     d_ppmd, h_ppmd, d_out, (int)b0, cnt, e, hc, (int)nchunk);
+  h->hc ^= 1;
+  h->bytes_done += cnt;
+  const hipError_t er = hipGetLastError();
+  if (er != hipSuccess) { cmx_set_err(std::string("cmx_lstm_run_late: ") + hipGetErrorString(er)); return -1; }
+  return cnt;
 }
 
 // 1 = a bounded in-launch wait of a block kernel ran out (the stream's LSTM results are void); synchronises the device

@@ -28,6 +28,7 @@
 #include <stdint.h>
 #include "cmx_libm.h"
 #include "lstm_state.h"
+#include "cmx_late.h"
 
 namespace {
 
@@ -64,6 +65,44 @@ __device__ __forceinline__ void wg_wait(const unsigned* p, unsigned want, unsign
   }
   lds_barrier();
 }
+// The decoder's form of a forward block (cmx_lstm_fwdblk_late): the launch covers bytes that do not exist yet, so every in-launch wait may last as long as the
+// decoder (host) takes -- bounded by the box's abort / fail words and 30 s of wall-clock time (cmx_late.h), not by a spin count. A wait that ends that way sets
+// LstmSync::fail: every later wait of the launch then falls through and the kernel drains.
+template <bool LATE> __device__ __forceinline__ void wg_wait_t(const unsigned* p, unsigned want, unsigned* fail, int sleepy, CmxLateBox* B) {
+  if (!LATE) { wg_wait(p, want, fail, sleepy); return; }
+  if (threadIdx.x == 0 && ld_u(p) < want) {
+    unsigned it = 0;
+    unsigned long long t0 = 0;
+    for (;;) {
+      __builtin_amdgcn_s_sleep(1);
+      if (ld_u(p) >= want) break;
+      if ((++it & 255u) == 0) {
+        bool out = ld_u(fail) || late_ld(&B->abort) || late_ld(&B->fail);
+        const unsigned long long now = wall_clock64();
+        if (!t0) t0 = now;
+        else if (now - t0 > CMX_LATE_TIMEOUT_TICKS) { late_st(&B->fail, 1u); out = true; }
+        if (out) { __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+    }
+  }
+  lds_barrier();
+}
+// the decoder's byte b of the chunk (bit 8 b + 7 decoded, the host stages' records of the step behind it in place): thread 0 waits for the relay's count,
+// the workgroup at the barrier; then every thread assembles the byte from the device mirror of the bits. -1: aborted / timed out (LstmSync::fail is set).
+__device__ __forceinline__ int late_byte(const CmxLate& LT, int b, unsigned* fail, int* flag_s) {
+  if (threadIdx.x == 0) {
+    const bool ok = !ld_u(fail) && late_wait_cnt(LT, LC_KNOWN, (uint32_t)(8 * (b + 1) + 1));
+    if (!ok) __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag_s = ok ? 1 : 0;
+  }
+  lds_barrier();
+  if (!*flag_s) return -1;
+  int v = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v = (v << 1) | (int)(*(volatile const uint8_t*)(LT.dbit0 + 8 * b + j) & 1);
+  return v;
+}
+
 // the calling wave's agent-scope stores are complete, then the counter moves (callers: lanes of wave 0 only)
 __device__ __forceinline__ void wave_signal(unsigned* p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -120,16 +159,19 @@ __device__ __forceinline__ float lds_chain(float f, const float4* Wq, int stride
 struct FbArgs {
   const uint8_t* bytes; const float* in_probs; float* out_probs;
   size_t n0; int cnt; int e0; int hc;
+  // the decoder's form: n0 = the first byte's index IN ITS CHUNK; bytes come from the device mirror of the decoded bits, PPMd's distribution after byte b from
+  // row b + 1 of its device mirror (the relay brings a row with the first step of the byte behind it) -- the chunk's last byte: from the host's own row
+  CmxLate late; const float* d_ppmd; const float* h_ppmd; int nchunk;
 };
 
 // RMS norm + activations + cell update of layer `layer` at epoch e from the gathered raw sums (lstm-layer.cpp:62-83,
 // :93-98), redundantly in every workgroup of the layer's group; the lead workgroup keeps the per-epoch caches BPTT
 // reads and publishes the new hidden vector. xh <- the 200 new hidden values.
-__device__ __forceinline__ void fb_finish_layer(const LstmState* S, int layer, int e, bool lead, float* rawl, float* ivar_s,
-                                                float* xh, float& st) {
+template <bool LATE> __device__ __forceinline__ void fb_finish_layer(const LstmState* S, int layer, int e, bool lead, float* rawl, float* ivar_s,
+                                                float* xh, float& st, CmxLateBox* LB) {
   const int tid = threadIdx.x;
   LstmSync* Y = S->sync;
-  wg_wait(&Y->raw_cnt[layer][e], GL, &Y->fail, S->poll_sleep);
+  wg_wait_t<LATE>(&Y->raw_cnt[layer][e], GL, &Y->fail, S->poll_sleep, LB);
   const float* rr = S->raw_ring + ((size_t)layer * H + e) * (3 * C);
   for (int idx = tid; idx < 3 * C; idx += FT) rawl[idx] = ld_f(rr + idx);
   lds_barrier();
@@ -176,7 +218,7 @@ __device__ __forceinline__ void fb_finish_layer(const LstmState* S, int layer, i
   else lds_barrier();
 }
 
-__device__ void fb_gate_wg(const LstmState* S, const FbArgs& A, int layer, int w, float* lds) {
+template <bool LATE> __device__ void fb_gate_wg(const LstmState* S, const FbArgs& A, int layer, int w, float* lds) {
   const int tid = threadIdx.x, V = S->V, insz = S->insz[layer];
   const bool lead = w == 0;
   LstmSync* Y = S->sync;
@@ -186,6 +228,8 @@ __device__ void fb_gate_wg(const LstmState* S, const FbArgs& A, int layer, int w
   float* rawl = xv + 836;                               // [600]
   float* ivar_s = rawl + 3 * C;                         // [4]
   int* sym2byte = reinterpret_cast<int*>(ivar_s + 4);   // [256]
+  __shared__ int late_flag;
+  CmxLateBox* const LB = LATE ? A.late.box : nullptr;
   const int row0 = w * R, g = row0 / C, i0 = row0 - g * C;   // 50 divides 200: one gate per workgroup
   const float* wt = S->WT[layer][g];
   for (int idx = tid; idx < nq * R; idx += FT) {
@@ -209,11 +253,23 @@ __device__ void fb_gate_wg(const LstmState* S, const FbArgs& A, int layer, int w
   for (int k = 0; k < A.cnt; ++k) {
     const int e = A.e0 + k;
     const size_t n = A.n0 + k;
-    const int cur_sym = S->byte_map[A.bytes[n]];
+    // A decoder: byte k only exists once the distribution of byte k - 1 has gone out, which needs this layer's hidden vector of that step -- the previous
+    // step is finished BEFORE the wait (a compressor finishes it under the first part of this step's chains, below: the same operations on the same operands
+    // in another order of independent parts)
+    if (LATE && k > 0) fb_finish_layer<LATE>(S, layer, e - 1, lead, rawl, ivar_s, xv + V, st, LB);
+    int byte_k;
+    if (LATE) { byte_k = late_byte(A.late, (int)n, &Y->fail, &late_flag); if (byte_k < 0) byte_k = 0; }
+    else byte_k = A.bytes[n];
+    const int cur_sym = S->byte_map[byte_k];
     float* li = S->layer_input[layer] + (size_t)e * insz;
     lds_barrier();
     if (tid < V) {  // ByteMixer::SetInput / Lstm::SetInput (byte-mixer.cpp:15-20): inputs_ *= 2 / num_models_
-      const float v = fmul(A.in_probs[n * 256 + sym2byte[tid]], 2.0f);
+      float pin;
+      if (LATE) {
+        const float* src = (int)n + 1 < A.nchunk ? A.d_ppmd + (n + 1) * 256 : A.h_ppmd + (n + 1) * 256;
+        pin = __hip_atomic_load(src + sym2byte[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      } else pin = A.in_probs[n * 256 + sym2byte[tid]];
+      const float v = fmul(pin, 2.0f);
       xv[tid] = v;
       if (lead && e != 0) li[tid] = v;   // epoch 0: written by cmx_lstm_prep ahead of the BPTT round
     }
@@ -227,11 +283,11 @@ __device__ void fb_gate_wg(const LstmState* S, const FbArgs& A, int layer, int w
       f = wt[(size_t)cur_sym * C + i0 + r];
       f = lds_chain(f, Wl, R, r, xv, 0, V);
     }
-    if (k > 0) fb_finish_layer(S, layer, e - 1, lead, rawl, ivar_s, xv + V, st);
+    if (!LATE && k > 0) fb_finish_layer<LATE>(S, layer, e - 1, lead, rawl, ivar_s, xv + V, st, LB);
     if (lead && tid < C) li[V + tid] = xv[V + tid];   // keep the assembled vector for BPTT
     if (tid < 64) f = lds_chain(f, Wl, R, r, xv, V, V + C);
     if (layer == 1) {  // layer 0's new hidden (lstm.cpp:127-131)
-      wg_wait(&Y->h_flag[0][e], 1, &Y->fail, S->poll_sleep);
+      wg_wait_t<LATE>(&Y->h_flag[0][e], 1, &Y->fail, S->poll_sleep, LB);
       if (tid < C) {
         const float h = ld_f(&S->h_ring[(size_t)e * NH + tid]);
         xv[V + C + tid] = h;
@@ -247,7 +303,7 @@ __device__ void fb_gate_wg(const LstmState* S, const FbArgs& A, int layer, int w
   }
   lds_barrier();
   const int el = A.e0 + A.cnt - 1;
-  fb_finish_layer(S, layer, el, lead, rawl, ivar_s, xv + V, st);
+  fb_finish_layer<LATE>(S, layer, el, lead, rawl, ivar_s, xv + V, st, LB);
   if (lead && tid < C) {
     S->stateb[A.hc ^ 1][layer][tid] = st;
     S->hid[A.hc ^ 1][layer * C + tid] = xv[V + tid];
@@ -259,7 +315,7 @@ __device__ void fb_gate_wg(const LstmState* S, const FbArgs& A, int layer, int w
 // of lstm.cpp:112-116 on them (and the copy BPTT reads, output_layer_[epoch]), the 401-term chains (lstm.cpp:132-140),
 // all-gather of the logits, softmax (lstm.cpp:141-149) redundantly, ByteMixer::ByteUpdate tail (byte-mixer.cpp:27-37).
 // ---------------------------------------------------------------------------------------------------------------
-__device__ void fb_out_wg(const LstmState* S, const FbArgs& A, int w, float* lds) {
+template <bool LATE> __device__ void fb_out_wg(const LstmState* S, const FbArgs& A, int w, float* lds) {
   const int tid = threadIdx.x, V = S->V;
   const bool lead = w == 0;
   LstmSync* Y = S->sync;
@@ -274,6 +330,8 @@ __device__ void fb_out_wg(const LstmState* S, const FbArgs& A, int w, float* lds
   float* le_s = red + 256;                   // [36]
   float* outp = le_s + 36;                   // [36]  output_[last] of the own rows
   float* tot_s = outp + 36;                  // [4]
+  __shared__ int late_flag;
+  CmxLateBox* const LB = LATE ? A.late.box : nullptr;
   const int last0 = A.e0 == 0 ? H - 1 : A.e0 - 1;
   for (int idx = tid; idx < nr * NQ; idx += FT) {
     const int rr = idx / NQ, q = idx - rr * NQ, j = q * 4;
@@ -290,7 +348,10 @@ __device__ void fb_out_wg(const LstmState* S, const FbArgs& A, int w, float* lds
   for (int k = 0; k < A.cnt; ++k) {
     const int e = A.e0 + k;
     const size_t n = A.n0 + k;
-    const int cur_sym = S->byte_map[A.bytes[n]];
+    int byte_k;
+    if (LATE) { byte_k = late_byte(A.late, (int)n, &Y->fail, &late_flag); if (byte_k < 0) byte_k = 0; }
+    else byte_k = A.bytes[n];
+    const int cur_sym = S->byte_map[byte_k];
     float* hprev = hbuf + pb * 404;
     float* hcur = hbuf + (pb ^ 1) * 404;
     lds_barrier();
@@ -315,12 +376,12 @@ __device__ void fb_out_wg(const LstmState* S, const FbArgs& A, int w, float* lds
       }
       OLs[(size_t)q * RP + rr] = v;
     }
-    wg_wait(&Y->h_flag[0][e], 1, &Y->fail, S->poll_sleep);
+    wg_wait_t<LATE>(&Y->h_flag[0][e], 1, &Y->fail, S->poll_sleep, LB);
     if (tid < C) hcur[tid] = ld_f(&S->h_ring[(size_t)e * NH + tid]);
     lds_barrier();
     float sum = 0.0f;
     if (tid < 64) sum = lds_chain(sum, OLs, RP, r, hcur, 0, C);
-    wg_wait(&Y->h_flag[1][e], 1, &Y->fail, S->poll_sleep);
+    wg_wait_t<LATE>(&Y->h_flag[1][e], 1, &Y->fail, S->poll_sleep, LB);
     if (tid < C) hcur[C + tid] = ld_f(&S->h_ring[(size_t)e * NH + C + tid]);
     if (tid == 0) hcur[2 * C] = 1.0f;   // bias element of hidden_ (lstm.cpp:18)
     lds_barrier();
@@ -329,7 +390,7 @@ __device__ void fb_out_wg(const LstmState* S, const FbArgs& A, int w, float* lds
       if (tid < nr) st_f(&S->logit_ring[(size_t)e * VP + i0 + tid], sum);
       wave_signal(&Y->logit_cnt[e]);
     }
-    wg_wait(&Y->logit_cnt[e], GO, &Y->fail, S->poll_sleep);
+    wg_wait_t<LATE>(&Y->logit_cnt[e], GO, &Y->fail, S->poll_sleep, LB);
     float lg = 0.0f;
     if (tid < V) lg = ld_f(&S->logit_ring[(size_t)e * VP + tid]);
     red[tid] = tid < V ? lg : 0.0f;   // max_out starts at 0 (lstm.cpp:132)
@@ -362,6 +423,11 @@ __device__ void fb_out_wg(const LstmState* S, const FbArgs& A, int w, float* lds
       S->byte_probs[tid] = pbv;
       if (A.out_probs) A.out_probs[n * 256 + tid] = pbv;
     }
+    if (LATE && lead) {   // the distribution after byte n of the chunk is in place (uncached device memory): count it, as the one-thread kernel behind a per-byte launch did
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0 && !ld_u(&Y->fail)) late_publish(A.late, LC_LSTM, (uint32_t)(n + 1));
+    }
     pb ^= 1;
   }
 }
@@ -376,9 +442,27 @@ extern "C" __global__ __launch_bounds__(LSTM_FB_THREADS) void cmx_lstm_fwdblk(co
   A.bytes = bytes; A.in_probs = in_probs; A.out_probs = out_probs; A.n0 = n0; A.cnt = cnt; A.e0 = e0; A.hc = hc;
   const int b = lstm_role_of_block((int)blockIdx.x, P.avoid_xcd);
   if (b < 0 || b >= 2 * GL + GO) return;
-  if (b < GL) fb_gate_wg(&P, A, 0, b, reinterpret_cast<float*>(fb_lds));
-  else if (b < 2 * GL) fb_gate_wg(&P, A, 1, b - GL, reinterpret_cast<float*>(fb_lds));
-  else fb_out_wg(&P, A, b - 2 * GL, reinterpret_cast<float*>(fb_lds));
+  A.late = CmxLate(); A.d_ppmd = nullptr; A.h_ppmd = nullptr; A.nchunk = 0;
+  if (b < GL) fb_gate_wg<false>(&P, A, 0, b, reinterpret_cast<float*>(fb_lds));
+  else if (b < 2 * GL) fb_gate_wg<false>(&P, A, 1, b - GL, reinterpret_cast<float*>(fb_lds));
+  else fb_out_wg<false>(&P, A, b - 2 * GL, reinterpret_cast<float*>(fb_lds));
+}
+
+// The decoder's form (round 6): ONE launch for the bytes b0 .. b0 + cnt - 1 of a decoder's chunk (to the end of the truncated-BPTT block or of the chunk),
+// none of which but the first exists when it starts -- every step waits for its byte (the relay's step count, cmx_late.h), the output group counts the
+// distributions as they go out (LC_LSTM). Round 4 / 5 launched cmx_lstm_fwdblk once per byte: 32 workgroups reloading 4 MB of weights into LDS, ~120 us of
+// every byte's first bit.
+extern "C" __global__ __launch_bounds__(LSTM_FB_THREADS) void cmx_lstm_fwdblk_late(const LstmState P, CmxLate late, const float* d_ppmd, const float* h_ppmd,
+                                                                                  float* out_probs, int b0, int cnt, int e0, int hc, int nchunk) {
+  extern __shared__ float4 fb_lds[];
+  FbArgs A;
+  A.bytes = nullptr; A.in_probs = nullptr; A.out_probs = out_probs; A.n0 = (size_t)b0; A.cnt = cnt; A.e0 = e0; A.hc = hc;
+  A.late = late; A.d_ppmd = d_ppmd; A.h_ppmd = h_ppmd; A.nchunk = nchunk;
+  const int b = lstm_role_of_block((int)blockIdx.x, P.avoid_xcd);
+  if (b < 0 || b >= 2 * GL + GO) return;
+  if (b < GL) fb_gate_wg<true>(&P, A, 0, b, reinterpret_cast<float*>(fb_lds));
+  else if (b < 2 * GL) fb_gate_wg<true>(&P, A, 1, b - GL, reinterpret_cast<float*>(fb_lds));
+  else fb_out_wg<true>(&P, A, b - 2 * GL, reinterpret_cast<float*>(fb_lds));
 }
 
 // ---------------------------------------------------------------------------------------------------------------

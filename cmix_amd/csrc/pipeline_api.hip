@@ -160,6 +160,8 @@ struct Late {
   const float* lstm0 = nullptr;
   double ms[6] = {0, 0, 0, 0, 0, 0};
   uint64_t bits = 0;
+  int lstm_covered = 0;    // bytes of the chunk in progress that the LSTM's last forward launch still covers (cmx_lstm_run_late)
+  bool lstm_per_byte = false;   // CMX_LATE_LSTM_PER_BYTE=1: rounds 4 / 5's one launch per byte (A/B)
   float* dbg_row = nullptr; uint32_t* dbg_sel = nullptr;   // pinned: cmx_pipeline_late_debug_row
   uint64_t mix_chunk0 = 0;                                  // the mixing-network handle's launch count when the stream started (debug hook)
 };
@@ -850,6 +852,7 @@ int cmx_pipeline_late_start(cmx_pipeline_t* h, int last_bit) {
   }
   if (hipDeviceSynchronize() != hipSuccess) { cmx_set_err("cmx_pipeline_late_start: device error"); L->failed = true; return 1; }
   L->lstm0 = cmx_lstm_byte_probs(h->lstm);
+  { const char* v = getenv("CMX_LATE_LSTM_PER_BYTE"); L->lstm_per_byte = v && v[0] == '1'; }
   L->mix_chunk0 = cmx_mixnet_runs(h->mix);
   // chunk 0 and, queued behind it, chunk 1
   if (late_launch(h, 0)) { L->failed = true; return 1; }
@@ -974,8 +977,14 @@ int cmx_pipeline_late_perceive(cmx_pipeline_t* h, int bit) {
   if (nq) *(volatile uint32_t*)&nq->box->start = 1;
   // ---- the LSTM byte mixer's step for the completed byte (predictor.cpp:450-461), then "its distribution is there" ----
   if (byte_done) {
-    if (cmx_lstm_run(h->lstm, q.ppmd + (b + 1) * 256, q.bytes + b, 1, q.lstm + b * 256, nullptr, 0, nullptr, h->s_lstm)) return 1;
-    if (cmx_late_bump(h->device, q.cnt + LC_LSTM * CMX_LATE_CNT_STRIDE, q.lt.base | (uint32_t)(b + 1), nullptr, 0, h->s_lstm)) { cmx_set_err("cmx_pipeline_late_perceive: launch failed"); return 1; }
+    if (L->lstm_per_byte) {
+      if (cmx_lstm_run(h->lstm, q.ppmd + (b + 1) * 256, q.bytes + b, 1, q.lstm + b * 256, nullptr, 0, nullptr, h->s_lstm)) return 1;
+      if (cmx_late_bump(h->device, q.cnt + LC_LSTM * CMX_LATE_CNT_STRIDE, q.lt.base | (uint32_t)(b + 1), nullptr, 0, h->s_lstm)) { cmx_set_err("cmx_pipeline_late_perceive: launch failed"); return 1; }
+    } else if (L->lstm_covered == 0) {   // a new truncated-BPTT block or a new chunk begins with this byte: one launch for all of its bytes, which wait for theirs inside it
+      const int c = cmx_lstm_run_late(h->lstm, &q.lt, q.d_ppmd, q.ppmd, q.bytes, q.lstm, b, n, h->s_lstm);
+      if (c < 1) return 1;
+      L->lstm_covered = c - 1;
+    } else --L->lstm_covered;
     lap(4);
   }
   L->predicted = false;

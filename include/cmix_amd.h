@@ -511,6 +511,9 @@ int cmx_p8stage_set_generator_counter(cmx_p8stage_t*, uint32_t counter);
  * byte -- a test passes the ring's end, which a stream reaches after 1 GB, within a few KB */
 int cmx_p8stage_debug_set_pos(cmx_p8stage_t*, int pos);
 int cmx_mixnet_run_late(cmx_mixnet_t*, void* box, const float* probs, const uint32_t* sel, size_t nbits, void* stream);
+/* the LSTM byte mixer in a decoder's chunk (round 6): one forward launch for the bytes b0 .. up to the end of the truncated-BPTT block or of the chunk -- its steps
+ * wait for their bytes inside the launch and count the distributions they write (LC_LSTM); returns the number of bytes covered, -1 on error */
+int cmx_lstm_run_late(cmx_lstm_t*, const void* late_box, const float* d_ppmd, const float* h_ppmd, const uint8_t* h_bytes, float* d_out, size_t b0, size_t nchunk, void* stream);
 /* One stream, bit by bit. The handle is a pipeline of section 3 with the fxcm and paq8 stages enabled (and, if there is a
  * dictionary, pretrained): cmx_pipeline_late_start() launches the first chunks' kernels (last_bit: the bit coded before the first
  * one -- the last Pretrain bit, else 0); then strictly alternating cmx_pipeline_late_predict() -> p, cmx_pipeline_late_perceive(bit).
