@@ -604,6 +604,32 @@ int cmx_stage_input(cmx_t* h, const uint8_t* bytes, size_t n) {
   return rc;
 }
 
+// Decoder::Decode (decoder.cpp:20-39) over a whole stream inside the library: `code` = the arithmetic code (what follows the container header, runner.cpp:34-84),
+// nbytes = the stream's length from that header; out receives the bytes the predictor saw (the preprocessed stream). The handle decodes from its first bit
+// (late-bit mode): every model family is a device stage, the host stages (paq8's front end per step, PPMd / fxcm's parser per byte) run on this
+// thread between two bits -- which is also why the arithmetic decoder's dozen integer operations stay here: the front end needs every bit on the host before it
+// can emit the next step's records, so a decoder on the device would not take the host off the per-bit path (DESIGN.md 4.10 has the measured split).
+// The same loop as the reference's Decompress + decoder.cpp over cmx_predict / cmx_perceive, without an ABI crossing per bit.
+int cmx_decode_stream(cmx_t* h, const uint8_t* code, size_t code_len, uint8_t* out, size_t nbytes) {
+  if (!h || (!code && code_len) || (!out && nbytes)) { cmx_set_err("cmx_decode_stream: bad argument"); return 1; }
+  cmx_decoder_t* d = cmx_decoder_create(code, code_len);
+  if (!d) { cmx_set_err("cmx_decode_stream: decoder construction failed"); return 1; }
+  int rc = 0;
+  for (size_t i = 0; i < nbytes && !rc; ++i) {
+    unsigned byte = 0;
+    for (int j = 0; j < 8; ++j) {
+      const float p = cmx_predict(h);
+      if (p < 0.0f) { rc = 1; break; }
+      const int bit = cmx_decoder_decode(d, p);
+      if (bit < 0 || cmx_perceive(h, bit)) { rc = 1; break; }
+      byte = (byte << 1) | (unsigned)bit;
+    }
+    out[i] = (uint8_t)byte;
+  }
+  cmx_decoder_destroy(d);
+  return rc;
+}
+
 // 0 undecided, 1 per-bit stages, 2 look-ahead pipeline; in mode 2 *chunks_in_flight (may be NULL) = submitted - used up
 int cmx_mode(cmx_t* h, int* chunks_in_flight) {
   if (!h) return -1;

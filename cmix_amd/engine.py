@@ -800,6 +800,16 @@ class Predictor:
         n = C.c_int(0)
         return lib().cmx_mode(self.h, C.byref(n)), n.value
 
+    def decode_stream(self, code, nbytes):
+        """Decoder::Decode over a whole stream inside the library (cmx_decode_stream): the arithmetic code behind the container header -> the nbytes
+        bytes the predictor saw. On a fresh handle."""
+        code = np.ascontiguousarray(np.frombuffer(bytes(code), np.uint8))
+        out = np.zeros(nbytes, np.uint8)
+        lib().cmx_decode_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        if lib().cmx_decode_stream(self.h, code.ctypes.data if len(code) else None, len(code), out.ctypes.data if nbytes else None, nbytes):
+            raise CmxError(last_error())
+        return out.tobytes()
+
     def lstm_hint(self):
         a, b = C.c_int(0), C.c_int(0)
         if lib().cmx_get_lstm_hint(self.h, C.byref(a), C.byref(b)):

@@ -67,6 +67,11 @@ cmx_t* cmx_create(const uint8_t vocab[256], const char* dict_path, int device); 
 float cmx_predict(cmx_t*);             /* Predictor::Predict,  predictor.cpp:361; < 0 on error */
 int cmx_perceive(cmx_t*, int bit);     /* Predictor::Perceive, predictor.cpp:421 */
 int cmx_pretrain(cmx_t*, int bit);     /* Predictor::Pretrain, predictor.cpp:471 */
+/* Decoder::Decode (coder/decoder.cpp:20-39) + the Decompress loop (runner.cpp:214-246) over a whole stream inside the library: `code` = the arithmetic code behind
+ * the container header, nbytes = the stream's length from that header, out[nbytes] = the bytes the predictor saw (the preprocessed stream; the caller runs the
+ * reference's preprocessor::Decode over them). Call on a fresh handle (after cmx_pretrain, if there is a dictionary). Equivalent to nbytes x 8 rounds of
+ * cmx_predict / cmx_decoder_decode / cmx_perceive; the reference's own decoder.cpp over the ABI remains the parity path (integration/predictor_dropin.h). */
+int cmx_decode_stream(cmx_t*, const uint8_t* code, size_t code_len, uint8_t* out, size_t nbytes);
 /* The two vendored model families without a device stage yet (fxcm, paq8) stay with the caller, which owns the
  * reference's objects: before every cmx_predict() it hands in their outputs for that bit -- layer-0 columns
  * 3..2024 in the reference's order (431 fxcm values, then 1591 paq8 values; predictor.cpp:363-369). cmx_predict()

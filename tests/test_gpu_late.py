@@ -160,3 +160,42 @@ def test_late_round_trip_text():
 
 def test_late_round_trip_binary():
     _run_child(_ROUNDTRIP.format(root=ROOT, payload="bytes(np.random.default_rng(5).integers(0, 256, 700, dtype=np.uint8))"))
+
+
+_DECODE_STREAM = r'''
+import sys, os, time
+import numpy as np
+sys.path.insert(0, {root!r})
+from cmix_amd import engine as E, synth
+payload = bytes(synth.enwik_like(1400, 4321, rich=True))
+vocab = np.zeros(256, np.uint8); vocab[list(set(payload))] = 1
+enc_p = E.Predictor(vocab, 0)
+enc_p.stage_input(payload)
+enc = E.Encoder()
+for B in payload:
+    for j in range(8):
+        bit = (B >> (7 - j)) & 1
+        enc.encode_bits(np.array([enc_p.Predict()], np.float32), np.array([bit], np.uint8))
+        enc_p.Perceive(bit)
+enc.flush()
+code = enc.data()
+enc_p.close()
+dec_p = E.Predictor(vocab, 0)
+t0 = time.time()
+out = dec_p.decode_stream(code, len(payload))
+dt = time.time() - t0
+assert dec_p.mode()[0] == 3
+dec_p.close()
+assert out == payload, "cmx_decode_stream returned other bytes"
+print("cmx_decode_stream: %d bytes in %.2f s (incl. the decoder's start-up) = %.0f us/byte" % (len(payload), dt, 1e6 * dt / len(payload)))
+'''
+
+
+def test_decode_stream_round_trip_inside_the_library():
+    """cmx_decode_stream (round 6): a stream the look-ahead engine coded, decoded from its arithmetic code alone by a fresh handle -- Decoder::Decode
+    (decoder.cpp:20-39) and the Decompress loop inside the library over the decoder's form of the engine (every model family a device stage; the LSTM's
+    forward block as ONE launch per truncated-BPTT block, fourteen of which this stream crosses, and three decoder's chunks of 512 bytes)."""
+    out = _run_child(_DECODE_STREAM.format(root=ROOT))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "decode_stream_time.txt"), "a") as f:
+        f.write(out)
