@@ -66,7 +66,9 @@ struct CmxLate {
   CmxLateBox* box;
   uint32_t* cnt;     // [LC_N][CMX_LATE_CNT_STRIDE]
   uint32_t base;     // (chunk number & 0xFFFF) << 16
-  uint32_t pad;
+  uint32_t pad;      // 1 = HOST PUSH (round 6): the decoder thread stores every step's bit and records into the device mirrors itself and counts the step (LC_KNOWN) --
+                     //   posted writes through the PCIe BAR (hipDeviceAttributeIsLargeBar) instead of the relay wave's polls and copies, two non-posted read round
+                     //   trips per bit (scripts/ubench/host_push.hip: 2.95 us against 7.89 us per host -> kernel -> host round trip with 1 KB of records); the relay stays idle
   const uint8_t* dbit0;   // DEVICE mirror of the bits: dbit0[t] = bit t of the chunk, dbit0[-1] = the bit before it (the relay wave fills it)
 };
 // ONE wavefront per stream talks to the host (the relay, wave 3 of cmx_bytemodel_late_kernel): it polls the box, copies every newly

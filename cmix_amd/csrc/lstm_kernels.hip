@@ -246,7 +246,10 @@ cmx_bytemodel_late_kernel(CmxLate B, size_t nbytes, const float* brk0, const flo
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (threadIdx.x == 0) { relay_done = 0; relay_seen = 0; }
   __syncthreads();
-  if (w >= 3) { late_relay(B, dbit0, relay, nrelay, (int)(8 * nbytes), lane, w - 3, CMX_RELAY_WAVES, &relay_done, &relay_seen); return; }
+  if (w >= 3) {   // the relay -- unless the HOST pushes the steps into device memory itself (CmxLate::pad = 1: round 6, cmx_late.h)
+    if (!B.pad) late_relay(B, dbit0, relay, nrelay, (int)(8 * nbytes), lane, w - 3, CMX_RELAY_WAVES, &relay_done, &relay_seen);
+    return;
+  }
   float* const pr = prs[w];
   const int col = w == 0 ? 0 : w == 1 ? 2076 : 2077;
   const int which = w == 0 ? LC_BM0 : w == 1 ? LC_BM1 : LC_BM2;

@@ -139,6 +139,7 @@ struct LateSet {
   float* d_ppmd = nullptr;       // device mirror of ppmd (the relay wave copies row b over with byte b's first step)
   uint8_t* d_bits = nullptr;     // device mirror of the bits: [8] prefix (byte 7 = the bit before the chunk), then [8 n]
   cmx_late_relay_t* d_relay = nullptr; int nrelay = 0;   // what the relay wave copies, per step / per byte (device copy of the table)
+  cmx_late_relay_t relay[CMX_LATE_RELAY_MAX];            // the same table on the host: in push mode this thread does the copies
   // uncached device memory: what one stage kernel writes and another reads while both run
   uint32_t* cnt = nullptr;       // [LC_N][CMX_LATE_CNT_STRIDE] row counters (base | rows, never cleared)
   float* layer0 = nullptr;       // [8 n][2078]
@@ -160,6 +161,7 @@ struct Late {
   const float* lstm0 = nullptr;
   double ms[6] = {0, 0, 0, 0, 0, 0};
   uint64_t bits = 0;
+  bool push = false;       // the decoder thread stores steps into device memory itself (large BAR; CMX_LATE_PULL=1: rounds 4 / 5's relay wave instead)
   int lstm_covered = 0;    // bytes of the chunk in progress that the LSTM's last forward launch still covers (cmx_lstm_run_late)
   bool lstm_per_byte = false;   // CMX_LATE_LSTM_PER_BYTE=1: rounds 4 / 5's one launch per byte (A/B)
   float* dbg_row = nullptr; uint32_t* dbg_sel = nullptr;   // pinned: cmx_pipeline_late_debug_row
@@ -768,6 +770,24 @@ int cmx_pipeline_last_stage_ms(cmx_pipeline_t* h, float ms[3]) {
 // ================================================================================================================================
 size_t cmx_late_box_bytes(size_t nbits) { return sizeof(CmxLateBox) + nbits + 64; }
 
+// HOST PUSH (cmx_late.h, CmxLate::pad): what late_relay() does on the device, done by the decoder thread with stores into device memory -- bit s - 1 of the chunk
+// (s == 0: the bit before it), the host stages' records of step s into their device mirrors, then the step count. The stores go through the PCIe BAR in program
+// order (the mirrors and counters are uncached device memory); the fence drains the write-combining buffers before the counter, and again behind it.
+static void late_push_step(LateSet& q, size_t s, size_t nbits, int ybit) {
+  q.d_bits[8 + (ptrdiff_t)s - 1] = (uint8_t)(ybit & 1);
+  for (int e = 0; e < q.nrelay; ++e) {
+    const cmx_late_relay_t& r = q.relay[e];
+    size_t row;
+    if (r.kind == 0) { if (s >= nbits) continue; row = s; }
+    else if (r.kind == 1) { if ((s & 7) || s >= nbits) continue; row = s >> 3; }
+    else { if ((s & 7) || s < 8) continue; row = (s >> 3) - 1; }
+    memcpy((char*)r.dst + row * r.stride, (const char*)r.src + row * r.stride, r.stride);
+  }
+  __builtin_ia32_sfence();
+  *(volatile uint32_t*)(q.cnt + LC_KNOWN * CMX_LATE_CNT_STRIDE) = q.lt.base | (uint32_t)(s + 1);
+  __builtin_ia32_sfence();
+}
+
 static double late_now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // the previous chunk's counter value that says "all n of its bytes' distributions are in place"
@@ -784,7 +804,7 @@ static int late_launch(cmx_pipeline* h, uint64_t c) {
   memset(B, 0, sizeof(CmxLateBox));
   B->nbits = (uint32_t)(8 * n);
   __sync_synchronize();
-  q.lt.box = B; q.lt.cnt = q.cnt; q.lt.base = (uint32_t)(c & 0xFFFFu) << 16; q.lt.pad = 0; q.lt.dbit0 = q.d_bits + 8;   // the counters are never cleared: a value of the chunk three back is below this base
+  q.lt.box = B; q.lt.cnt = q.cnt; q.lt.base = (uint32_t)(c & 0xFFFFu) << 16; q.lt.pad = L->push ? 1u : 0u; q.lt.dbit0 = q.d_bits + 8;   // the counters are never cleared: a value of the chunk three back is below this base
   void* const LT = &q.lt;
   const float* brk0 = nullptr;
   if (cmx_ctxmodels_run_late(h->ctx, LT, n, q.layer0, CMX_N_INPUTS, q.sel, q.brk, &brk0, h->s_ctx)) return 1;
@@ -848,11 +868,17 @@ int cmx_pipeline_late_start(cmx_pipeline_t* h, int last_bit) {
     k += kf;
     tab[k].src = q.ppmd; tab[k].dst = q.d_ppmd; tab[k].stride = 1024; tab[k].kind = 1; ++k;
     q.nrelay = k;
+    memcpy(q.relay, tab, (size_t)k * sizeof(cmx_late_relay_t));
     if (hipMemcpy(q.d_relay, tab, (size_t)k * sizeof(cmx_late_relay_t), hipMemcpyHostToDevice) != hipSuccess) { cmx_set_err("cmx_pipeline_late_start: table upload failed"); L->failed = true; return 1; }
   }
   if (hipDeviceSynchronize() != hipSuccess) { cmx_set_err("cmx_pipeline_late_start: device error"); L->failed = true; return 1; }
   L->lstm0 = cmx_lstm_byte_probs(h->lstm);
   { const char* v = getenv("CMX_LATE_LSTM_PER_BYTE"); L->lstm_per_byte = v && v[0] == '1'; }
+  {   // host push needs the device's memory in this process's address space (large BAR); CMX_LATE_PULL=1 keeps the relay wave (A/B, and the fall-back)
+    int bar = 0;
+    const char* v = getenv("CMX_LATE_PULL");
+    L->push = !(v && v[0] == '1') && hipDeviceGetAttribute(&bar, hipDeviceAttributeIsLargeBar, h->device) == hipSuccess && bar == 1;
+  }
   L->mix_chunk0 = cmx_mixnet_runs(h->mix);
   // chunk 0 and, queued behind it, chunk 1
   if (late_launch(h, 0)) { L->failed = true; return 1; }
@@ -862,6 +888,7 @@ int cmx_pipeline_late_start(cmx_pipeline_t* h, int last_bit) {
   q0.box->last_y = last_bit ? 1u : 0u;
   __sync_synchronize();
   q0.box->start = 1;
+  if (L->push) late_push_step(q0, 0, T, last_bit ? 1 : 0);
   if (late_launch(h, 1)) { L->failed = true; return 1; }
   L->active = true;
   return 0;
@@ -975,6 +1002,10 @@ int cmx_pipeline_late_perceive(cmx_pipeline_t* h, int bit) {
   *(volatile uint32_t*)&q.box->nknown = (uint32_t)(t + 1);
   *(volatile unsigned long long*)&q.box->kb = ((unsigned long long)(unsigned)bit << 32) | (unsigned long long)(t + 1);
   if (nq) *(volatile uint32_t*)&nq->box->start = 1;
+  if (L->push) {   // this thread is the relay: the step's bit and records into the device mirrors, then the count (the next chunk's step 0 with this chunk's last)
+    late_push_step(q, t + 1, T, bit);
+    if (nq) late_push_step(*nq, 0, T, bit);
+  }
   // ---- the LSTM byte mixer's step for the completed byte (predictor.cpp:450-461), then "its distribution is there" ----
   if (byte_done) {
     if (L->lstm_per_byte) {

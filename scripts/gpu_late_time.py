@@ -7,6 +7,8 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if os.environ.get("CMX_LATE_NATIVE_LOOP") != "1":
+    os.environ["CMX_LATE_PULL"] = "1"   # the per-stage time stamps are taken relative to the RELAY's "step is on the device" stamp: the relay wave runs (round 6's default is the host push)
 sys.path.insert(0, ROOT)
 from cmix_amd import engine as E  # noqa: E402
 
