@@ -72,10 +72,11 @@ int cmx_pretrain(cmx_t*, int bit);     /* Predictor::Pretrain, predictor.cpp:471
  * reference's preprocessor::Decode over them). Call on a fresh handle (after cmx_pretrain, if there is a dictionary). Equivalent to nbytes x 8 rounds of
  * cmx_predict / cmx_decoder_decode / cmx_perceive; the reference's own decoder.cpp over the ABI remains the parity path (integration/predictor_dropin.h). */
 int cmx_decode_stream(cmx_t*, const uint8_t* code, size_t code_len, uint8_t* out, size_t nbytes);
-/* The two vendored model families without a device stage yet (fxcm, paq8) stay with the caller, which owns the
- * reference's objects: before every cmx_predict() it hands in their outputs for that bit -- layer-0 columns
- * 3..2024 in the reference's order (431 fxcm values, then 1591 paq8 values; predictor.cpp:363-369). cmx_predict()
- * fails loudly when they are missing: nothing is computed on the CPU in their place. */
+/* TEST HOOK (the third mode of a handle; rounds 1-3 decoded this way): fxcm and paq8 have been device stages since round 2 -- a compressor (cmx_stage_input)
+ * and a decoder (cmx_predict without staged input) take no column from the caller. A handle that is given columns BEFORE its first cmx_predict() runs the
+ * per-bit stages instead and takes the two families' outputs of every bit from the caller -- layer-0 columns 3..2024 in the reference's order (431 fxcm values,
+ * then 1591 paq8 values; predictor.cpp:363-369) -- which is how tests/test_gpu_predictor.py isolates the other stages. cmx_predict() fails loudly when the
+ * columns of a bit are missing: nothing is computed on the CPU in their place. */
 int cmx_set_model_outputs(cmx_t*, const float cols_3_to_2024[2022]);
 /* The hidden globals `lstmpr`, `lstmex` (predictor.cpp:359,462-465) as they stand after the last cmx_perceive():
  * what the caller's fxcm reads in its own Perceive. cmx_perceive() only enqueues the device work; this call (or the

@@ -15,7 +15,7 @@ cp gpurun_out/decode_time.txt gpurun_out/config3_dict_time.txt gpurun_out/config
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $O/smoke.txt
 fi
 timeout 600 python bench.py > $O/bench_1m.json 2> $O/bench_1m.err; cut -c1-400 $O/bench_1m.json; tail -2 $O/bench_1m.err
-( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -o pipe -- python $R/bench.py --payload-bytes 262144 --steps 8 --warmup 1 --no-cpu-baseline > $R/$O/prof_bench_256k.json 2> $R/$O/prof.err )
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -o pipe -- python $R/bench.py --payload-bytes 262144 --steps 8 --warmup 1 --no-cpu-baseline --decode-bytes 0 > $R/$O/prof_bench_256k.json 2> $R/$O/prof.err )
 for f in $(find $O/prof -name '*kernel_stats*.csv'); do grep -v "at::native\|rocclr" $f | head -30 > $O/bench_256k_kernel_stats.csv; done
 cut -c1-160 $O/bench_256k_kernel_stats.csv | head -12
 # A/B of opt-in kernel variants in the pipeline (256 KB, no CPU baseline): CMX_AB="CMX_MIXNET_SEG8=1 ..." (one variable assignment per variant)
@@ -25,8 +25,10 @@ for v in $CMX_AB; do
 done
 if [ "$CMX_SKIP_PMC" != "1" ]; then
 for c in FETCH_SIZE WRITE_SIZE; do
-( cd /tmp && timeout -k 5 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$O/pmc -o pmc_$c -- python $R/bench.py --payload-bytes 131072 --steps 4 --warmup 1 --no-cpu-baseline > $R/$O/pmc_$c.out 2> $R/$O/pmc_$c.err ; echo "rocprofv3 $c rc=$?" )
+( cd /tmp && timeout -k 5 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/$O/pmc -o pmc_$c -- python $R/bench.py --payload-bytes 131072 --steps 4 --warmup 1 --no-cpu-baseline --decode-bytes 0 > $R/$O/pmc_$c.out 2> $R/$O/pmc_$c.err ; echo "rocprofv3 $c rc=$?" )
 done
+# one occupancy pass (round-5 review 4 iv): waves launched, cycles the SQ was busy, cycles waves waited for any instruction, per kernel
+( cd /tmp && timeout -k 5 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $R/$O/pmc -o pmc_SQ -- python $R/bench.py --payload-bytes 131072 --steps 4 --warmup 1 --no-cpu-baseline --decode-bytes 0 > $R/$O/pmc_SQ.out 2> $R/$O/pmc_SQ.err ; echo "rocprofv3 SQ rc=$?" )
 python - "$O" <<'PY'
 import csv, glob, collections, json, sys
 O = sys.argv[1]

@@ -1,4 +1,1 @@
-O=gpurun_out/s8; mkdir -p $O
-( time timeout 900 python -m pytest tests/test_gpu_late.py -x -q -m gpu -p no:cacheprovider 2>&1 | tail -8 ) > $O/late_tests.txt 2>&1; tail -6 $O/late_tests.txt
-CMX_LATE_NATIVE_LOOP=1 timeout 200 python scripts/gpu_late_time.py text_2k_nofull 2>&1 | grep -v amdgpu.ids | tee $O/late_time_native_push.txt
-CMX_LATE_PULL=1 CMX_LATE_NATIVE_LOOP=1 timeout 200 python scripts/gpu_late_time.py text_2k_nofull 2>&1 | grep -v amdgpu.ids | tee $O/late_time_native_pull.txt
+CMX_SKIP_TESTS=1 bash scripts/gpu_measure.sh r06
