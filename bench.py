@@ -322,7 +322,7 @@ def main():
     t_warm = time.perf_counter() - t_c1
     if t_cold is None:
         t_cold = t_warm
-    t_construct = t_framing + t_cold   # framing + a COLD engine construction (the process's first; the timed engine's own, after the warm-up engine primed the allocator, is `construct_warm_s`)
+    t_construct = t_framing + max(t_cold, t_warm)   # framing + the SLOWER of the process's two engine constructions (the first -- HIP context, tables mapped for the first time -- and the timed engine's own: `construct_first_s` / `construct_warm_s`)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -410,9 +410,9 @@ def main():
                 "mode": ("tolerance (--tolerance -> cmx_pipeline_set_tolerance: tree-sum dot products in the final mixing network; NOT bit-exact, the output is not the "
                          "reference's file and `verified` says so)") if mode_name == "tolerance" else "strict (bit-exact; the default and the only mode that claims stream parity)"},
             "us_per_bit": dt / (8.0 * n) * 1e6,
-            "end_to_end": {"value": a.payload_bytes * world / (dt + t_construct), "unit": "input bytes/s", "construct_s": t_construct, "construct_warm_s": t_framing + t_warm,
-                           "note": "payload bytes / (framing + COLD engine construction -- the first engine this process built: HIP context, ~20 GB of tables allocated and initialised -- "
-                                   "+ the timed run incl. the coder); construct_warm_s = the timed engine's own construction after the warm-up engine had primed the allocator; "
+            "end_to_end": {"value": a.payload_bytes * world / (dt + t_construct), "unit": "input bytes/s", "construct_s": t_construct, "construct_first_s": t_framing + t_cold, "construct_warm_s": t_framing + t_warm,
+                           "note": "payload bytes / (framing + engine construction: ~20 GB of tables allocated and initialised; the SLOWER of the process's first construction -- the warm-up engine's, "
+                                   "HIP context included: construct_first_s -- and the timed engine's own, construct_warm_s -- + the timed run incl. the coder); "
                                    "`value` above is the predictor-only figure of SURVEY.md 8d (stream bytes / the Compress() loop)"},
             "mfma": {"instructions": None, "note": "tolerance mode: the LSTM's weight-update contraction runs as v_mfma_f32_16x16x4_f32 tiles (113 100 SQ_INSTS_VALU_MFMA_F32 per BPTT round, "
                                                    "profiles/r04_lstm_mfma_tolerance.txt); nothing else on the path issues one"} if mode_name == "tolerance" else

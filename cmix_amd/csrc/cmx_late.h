@@ -19,8 +19,8 @@
 // writes and another reads WHILE BOTH RUN (rows, selectors, distributions, hints) and the producers' row counters live in UNCACHED
 // DEVICE memory (no stale line in an XCD's L2), written with plain stores followed by `s_waitcnt vmcnt(0)` and the producer's counter,
 // read after the consumer has seen the counter.
-// Every wait is bounded by wall-clock time (CMX_LATE_TIMEOUT_TICKS below: a COMPILE-TIME 30 s without progress -- a caller that stalls longer
-// between predict() and perceive(), e.g. under a debugger, voids the stream; there is no run-time knob) and by the box's abort word: a decoder that
+// Every wait is bounded by wall-clock time (30 s without progress by default; CMX_LATE_TIMEOUT_S=seconds when the stream starts puts another bound into every
+// chunk's box -- a caller that stalls between predict() and perceive(), e.g. under a debugger, needs a longer one) and by the box's abort word: a decoder that
 // stops mid-chunk (cmx_destroy) unwinds the kernels instead of leaving them spinning.
 #ifndef CMX_LATE_H
 #define CMX_LATE_H
@@ -50,7 +50,8 @@ struct CmxLateBox {   // HOST-coherent pinned memory: what the decoder thread an
   uint32_t abort;    // host -> device: leave
   uint32_t fail;     // device -> host, sticky: a wait ran out of time
   uint32_t nbits;    // bits of this chunk (information only)
-  uint32_t pad0[2];
+  uint32_t timeout_s;   // host -> device: seconds a wait may last without progress (0: the default, CMX_LATE_TIMEOUT_TICKS); read on the slow path of a wait only
+  uint32_t pad0[1];
   unsigned long long kb;   // host -> device, ONE 8-byte store: (bit t << 32) | (t + 1) -- what nknown and bit[t] say, in one PCIe read for the relay
   uint32_t pad1[6];
   unsigned long long p_word[CMX_LATE_P_RING];           // device -> host: ((t + 1) << 32) | bits of p(t), slot t % ring -- ONE self-validating word
@@ -87,6 +88,11 @@ typedef struct { const void* src; void* dst; uint32_t stride; int32_t kind; } cm
 #endif
 __device__ __forceinline__ uint32_t late_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void late_st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// the bound of a wait, in ticks of the 100 MHz clock: the box's (CMX_LATE_TIMEOUT_S at cmx_pipeline_late_start) or the default
+__device__ __forceinline__ unsigned long long late_timeout_ticks(CmxLateBox* B) {
+  const uint32_t s = late_ld(&B->timeout_s);
+  return s ? (unsigned long long)s * 100000000ull : CMX_LATE_TIMEOUT_TICKS;
+}
 // Bounded wait until *p has reached `want` (wrap-safe: a counter is base | rows). Callable by one lane or by a whole wavefront on a
 // uniform address. false: aborted / timed out.
 __device__ __forceinline__ bool late_wait_ge(CmxLateBox* B, const uint32_t* p, uint32_t want) {
@@ -100,7 +106,7 @@ __device__ __forceinline__ bool late_wait_ge(CmxLateBox* B, const uint32_t* p, u
       if (late_ld(&B->abort) || late_ld(&B->fail)) return false;
       const unsigned long long now = wall_clock64();
       if (!t0) t0 = now;
-      else if (now - t0 > CMX_LATE_TIMEOUT_TICKS) { late_st(&B->fail, 1u); return false; }
+      else if (now - t0 > late_timeout_ticks(B)) { late_st(&B->fail, 1u); return false; }
     }
   }
 }
@@ -153,7 +159,7 @@ __device__ __forceinline__ void late_relay(const CmxLate& L, uint8_t* dbit0, con
             if (late_ld(&B->abort) || late_ld(&B->fail)) { ok = false; break; }
             const unsigned long long now = wall_clock64();
             if (!t0) t0 = now;
-            else if (now - t0 > CMX_LATE_TIMEOUT_TICKS) { late_st(&B->fail, 1u); ok = false; break; }
+            else if (now - t0 > late_timeout_ticks(B)) { late_st(&B->fail, 1u); ok = false; break; }
           }
         }
         if (ok && (uint32_t)v == (uint32_t)s) ybit = (int)(v >> 32) & 1;

@@ -80,7 +80,7 @@ template <bool LATE> __device__ __forceinline__ void wg_wait_t(const unsigned* p
         bool out = ld_u(fail) || late_ld(&B->abort) || late_ld(&B->fail);
         const unsigned long long now = wall_clock64();
         if (!t0) t0 = now;
-        else if (now - t0 > CMX_LATE_TIMEOUT_TICKS) { late_st(&B->fail, 1u); out = true; }
+        else if (now - t0 > late_timeout_ticks(B)) { late_st(&B->fail, 1u); out = true; }
         if (out) { __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
       }
     }

@@ -143,7 +143,7 @@ __device__ __forceinline__ bool late_expired(CmxLateBox* B, unsigned long long& 
   if (late_ld(&B->abort) || late_ld(&B->fail)) return true;
   const unsigned long long now = wall_clock64();
   if (!t0) { t0 = now; return false; }
-  if (now - t0 > CMX_LATE_TIMEOUT_TICKS) { late_st(&B->fail, 1u); return true; }
+  if (now - t0 > late_timeout_ticks(B)) { late_st(&B->fail, 1u); return true; }
   return false;
 }
 template <bool LATE = false> __device__ __forceinline__ bool wait_ge(Ctl* ctl, const int* p, int target, bool sleepy) {

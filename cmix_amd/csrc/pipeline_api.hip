@@ -161,6 +161,7 @@ struct Late {
   const float* lstm0 = nullptr;
   double ms[6] = {0, 0, 0, 0, 0, 0};
   uint64_t bits = 0;
+  uint32_t timeout_s = 0;  // CMX_LATE_TIMEOUT_S: seconds an in-launch wait of a decoder's kernels may last without progress (0: the 30 s default)
   bool push = false;       // the decoder thread stores steps into device memory itself (large BAR; CMX_LATE_PULL=1: rounds 4 / 5's relay wave instead)
   int lstm_covered = 0;    // bytes of the chunk in progress that the LSTM's last forward launch still covers (cmx_lstm_run_late)
   bool lstm_per_byte = false;   // CMX_LATE_LSTM_PER_BYTE=1: rounds 4 / 5's one launch per byte (A/B)
@@ -803,6 +804,7 @@ static int late_launch(cmx_pipeline* h, uint64_t c) {
   // the box of the chunk three back: nothing reads it any more (its kernels ended before those of chunk c - 2 began)
   memset(B, 0, sizeof(CmxLateBox));
   B->nbits = (uint32_t)(8 * n);
+  B->timeout_s = L->timeout_s;
   __sync_synchronize();
   q.lt.box = B; q.lt.cnt = q.cnt; q.lt.base = (uint32_t)(c & 0xFFFFu) << 16; q.lt.pad = L->push ? 1u : 0u; q.lt.dbit0 = q.d_bits + 8;   // the counters are never cleared: a value of the chunk three back is below this base
   void* const LT = &q.lt;
@@ -874,6 +876,7 @@ int cmx_pipeline_late_start(cmx_pipeline_t* h, int last_bit) {
   if (hipDeviceSynchronize() != hipSuccess) { cmx_set_err("cmx_pipeline_late_start: device error"); L->failed = true; return 1; }
   L->lstm0 = cmx_lstm_byte_probs(h->lstm);
   { const char* v = getenv("CMX_LATE_LSTM_PER_BYTE"); L->lstm_per_byte = v && v[0] == '1'; }
+  { const char* v = getenv("CMX_LATE_TIMEOUT_S"); const long t = v ? atol(v) : 0; L->timeout_s = t > 0 ? (uint32_t)(t < 86400 ? t : 86400) : 0u; }   // (the host's own bound in late_predict follows: twice this, at least 60 s)
   {   // host push needs the device's memory in this process's address space (large BAR); CMX_LATE_PULL=1 keeps the relay wave (A/B, and the fall-back)
     int bar = 0;
     const char* v = getenv("CMX_LATE_PULL");
@@ -936,7 +939,7 @@ float cmx_pipeline_late_predict(cmx_pipeline_t* h) {
       }
       if (*(volatile uint32_t*)&q.box->fail) why = "a stage kernel's wait ran out of time (are all stage kernels co-resident?)";
       else if (cmx_p8stage_mixfail(h->p8)) why = "the paq8 mixer's workgroup 0 timed out waiting for another workgroup";
-      else if (el > 60000.0) why = "no prediction from the device for 60 s";
+      else if (el > (L->timeout_s > 30 ? 2000.0 * L->timeout_s : 60000.0)) why = "no prediction from the device for 60 s (or twice CMX_LATE_TIMEOUT_S)";
       if (why) {
         std::string st = " [box: nknown " + std::to_string(q.box->nknown) + " start " + std::to_string(q.box->start) + " rows";
         static const char* const nm[] = {"ctx", "bm0", "bm1", "bm2", "fx", "p8", "cm2a", "cm2b", "cm2c", "fam", "lanes", "dmc", "brk", "lstm", "known"};
