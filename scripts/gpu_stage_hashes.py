@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--stop-block", type=int, default=-1, help="run only the stream's first N + 1 blocks of 64 KB (the engine is still built for the whole stream)")
     ap.add_argument("--selfcheck", action="store_true", help="round 6 (DESIGN.md 5): is a difference of the final probability's digest the ENGINE's or the READ-BACK's? Keeps a copy of p as "
                     "each digest read it, recomputes the digests from the finished run's p, then runs the same bytes through a second engine WITHOUT any digest work and compares the two runs' p")
+    ap.add_argument("--finish", action="store_true", help="after the run: the arithmetic coder over every p (size and SHA-256 of the file `cmix -c` would write), the mixers' row counts, "
+                    "the speculation statistics, PPMd's arena -- what scripts/gpu_long_run.py reports; with it the digests so far are also written every 16 MiB (<out>.partial)")
     ap.add_argument("--head-file", default=None)
     ap.add_argument("--vocab-file", default=None)
     a = ap.parse_args()
@@ -169,9 +171,20 @@ def main():
                         os._exit(0)
 
     t0 = time.perf_counter()
+    t_mark, pos_mark = t0, 0
     for k in range(nsub):
         if k >= E.PIPELINE_SLOTS:
             digest(k - E.PIPELINE_SLOTS)          # its layer-0 slot is about to be reused
+        if a.finish and k and k % 4096 == 0:       # every 16 MiB: the rate of the piece, and the digests of the complete blocks so far to <out>.partial
+            now = time.perf_counter()
+            print("  %7.1f MiB  %8.0f B/s" % (eng.pos / 2**20, (eng.pos - pos_mark) / (now - t_mark)), flush=True)
+            t_mark, pos_mark = now, eng.pos
+            done_blocks = max(0, (eng.pos - (E.PIPELINE_SLOTS + 1) * sub) // 65536)
+            Hp = H[:done_blocks].cpu().numpy().view(np.uint64)
+            os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+            with open(a.out + ".partial", "w") as f:
+                for b in range(done_blocks):
+                    f.write("%d %s\n" % ((b + 1) * 65536, " ".join("%016x" % int(x) for x in Hp[b])))
         m = min(sub, n - eng.pos)
         eng.pipe.submit(eng.stream[eng.pos:eng.pos + m], eng.layer0[k % E.PIPELINE_SLOTS][:8 * m], eng.p_dev[8 * eng.pos:8 * (eng.pos + m)])
         eng.pos += m
@@ -194,6 +207,27 @@ def main():
             print("group %s: %d bits differ in block %d; first: %s" % (k, v["bits_differing"], a.detail_block, json.dumps(v["first"])[:1500]))
     if a.ref and os.path.exists(a.ref):
         compare(a.out, a.ref)
+    if a.finish:
+        import ctypes as C
+        import hashlib
+        import json
+        L = E.lib()
+        for fn in ("cmx_pipeline_mixnet_rows", "cmx_pipeline_spec_stats", "cmx_pipeline_ppmd_arena"):
+            getattr(L, fn).argtypes = [C.c_void_p, C.c_void_p]
+        rows = np.zeros(47, np.uint32); spec = np.zeros(5, np.uint64); arena = np.zeros(3, np.uint64)
+        L.cmx_pipeline_mixnet_rows(eng.pipe.h, rows.ctypes.data)
+        L.cmx_pipeline_spec_stats(eng.pipe.h, spec.ctypes.data)
+        L.cmx_pipeline_ppmd_arena(eng.pipe.h, arena.ctypes.data)
+        tc = time.perf_counter()
+        eng.pos = n
+        blob = eng.finish()          # p[] back, the arithmetic coder (host)
+        rep = {"stream_bytes": n, "seconds": dt, "bytes_per_s": n / dt, "coder_seconds": time.perf_counter() - tc, "output_bytes": len(blob), "sha256": hashlib.sha256(blob).hexdigest(),
+               "bits_per_byte": 8.0 * len(blob) / n, "mixer_rows": rows.tolist(), "mixers_at_row_cap": int((rows >= 10000).sum()),
+               "speculation": {"segments": int(spec[0]), "hits": int(spec[1]), "hit_rate": float(spec[1]) / max(1, int(spec[0])), "reruns": [int(x) for x in spec[2:5]]},
+               "ppmd_arena_bytes": {"reserved": int(arena[0]), "untouched": int(arena[1]), "in_use": int(arena[2])}}
+        with open(a.out + ".run.json", "w") as f:
+            json.dump(rep, f, indent=1)
+        print(json.dumps({k: v for k, v in rep.items() if k != "mixer_rows"}), flush=True)
     if a.selfcheck:
         torch.cuda.synchronize()
         p_loaded = eng.p_dev[:8 * n].clone()
