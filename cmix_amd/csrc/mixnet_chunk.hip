@@ -1363,8 +1363,10 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
-template <bool LATE, bool JIT = false> __device__ void helper_role(MixState* S, SpecXfer* X, HelperLds* H, int nbits, int m, int w, int lane, bool tol, CmxLateBox* LB, bool local, int jit) {
+template <bool LATE, bool JIT = false> __device__ void helper_role(MixState* S, SpecXfer* X, HelperLds* H, int nbits, int m, int w, int lane, bool tol, CmxLateBox* LB, bool local, int jit,
+                                                                  const CmxLate& late, const float* probs) {
   const gptr<float> rows0 = as_global(S->rows0);
+  const gptr<const float> lut = as_global(S->logit_lut);
   // four waves cut the 2078-term chain: 4 x 512 (+ 30) terms (other cuts, candidate counts and re-run forms were measured and are slower:
   // scripts/study/mixnet_variants.patch)
   constexpr int NW = 4, SEGN = 2048 / NW, KS = SEGN / 64, LASTW = NW - 1;
@@ -1386,16 +1388,14 @@ template <bool LATE, bool JIT = false> __device__ void helper_role(MixState* S, 
   // fetch the inputs of bit t (this wave's slice) and, if its selector changes, the incoming row
   auto fetch = [&](int t) -> bool {
     unsigned spins = 0;
-    while (ld_u32(&X->scout_epoch) < (unsigned)(t + 1)) {
+    // a decoder's chunk: the row selection of this mixer is published ahead of the stretched inputs (sel_epoch; the auxiliary-context mixer's with scout_epoch)
+    const unsigned* const ep = LATE && m != CMX_AUX ? &X->sel_epoch : &X->scout_epoch;
+    while (ld_u32(ep) < (unsigned)(t + 1)) {
       __builtin_amdgcn_s_sleep(1);
       if ((++spins & 1023u) == 0 && (spun_out(spins) || failed() || ld_u32(&X->fail))) { give_up(); return false; }
     }
     late_t0 = 0;
     const int slot = t % CMX_SPEC_RING;
-    const float* gx = X->xs[slot] + base;
-#pragma unroll
-    for (int k = 0; k < KS; ++k) xc[k] = ld_f32(gx + 64 * k + lane);
-    xc[KS] = tailk ? ld_f32(gx + SEGN + lane) : 0.0f;
     f_chg = ld_u32(&X->changed[slot][m]) != 0;
     if (f_chg) {
       const uint32_t nb = ((uint32_t)m * CMX_ROWS_PER_MIXER + ld_u32(&X->rowidx[slot][m])) * CMX_ROW0_STRIDE + (uint32_t)base;
@@ -1404,6 +1404,53 @@ template <bool LATE, bool JIT = false> __device__ void helper_role(MixState* S, 
       for (int k = 0; k < KS; ++k) Wn[k] = rows0[nb + 64 * k + lane];
       Wn[KS] = tailk ? rows0[nb + SEGN + lane] : 0.0f;
     }
+    if (LATE) {
+      // round 6: this wave's slice of the bit's inputs straight from the producers' row (uncached device memory), as soon as the stages that write its columns have
+      // counted the row -- MixerInput::SetInput + Sigmoid::Logit (mixer-input.cpp:11-15, sigmoid.cpp:12-17) with the stretch wave's arithmetic; no ring, no second hop.
+      // columns: 0 Bracket, 1..2 + 2025..2075 contexts, 3..433 fxcm, 434..2024 paq8, 2076 PPMd, 2077 LSTM
+      const unsigned need = w == 0 ? (1u << LC_CTX) | (1u << LC_BM0) | (1u << LC_FX) | (1u << LC_P8) : w == LASTW ? (1u << LC_P8) | (1u << LC_CTX) | (1u << LC_BM1) | (1u << LC_BM2) : (1u << LC_P8);
+      bool ok = true;
+      if (lane <= LC_P8 && ((need >> lane) & 1u)) ok = late_wait_cnt(late, lane, (uint32_t)(t + 1));
+      if (__ballot(!ok)) { give_up(); return false; }
+      const float* row = probs + (size_t)t * CMX_IN0 + base;
+      float pv[KS + 1];
+#pragma unroll
+      for (int k = 0; k < KS; ++k) pv[k] = __hip_atomic_load(row + 64 * k + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pv[KS] = tailk ? __hip_atomic_load(row + SEGN + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.5f;
+#pragma unroll
+      for (int k = 0; k < KS + 1; ++k) {
+        float p = pv[k];
+        if (p < 1.0e-4f) p = 1.0e-4f;
+        else if (p > 1 - 1.0e-4f) p = 1 - 1.0e-4f;
+        int idx = (int)(p * 100001.0f);
+        if (idx >= 100001) idx = 100000;
+        else if (idx < 0) idx = 0;
+        xc[k] = lut[idx];
+      }
+      if (!tailk) xc[KS] = 0.0f;
+    } else {
+      const float* gx = X->xs[slot] + base;
+#pragma unroll
+      for (int k = 0; k < KS; ++k) xc[k] = ld_f32(gx + 64 * k + lane);
+      xc[KS] = tailk ? ld_f32(gx + SEGN + lane) : 0.0f;
+    }
+    return true;
+  };
+  // u of bit tu - 1 -> W -= u x (mixer.cpp:66-71; xp = the inputs of that bit), the 1024-step decay
+  auto apply_u = [&](int tu) -> bool {
+    unsigned long long v;
+    unsigned spins = 0;
+    while ((unsigned)((v = ld_u64(&X->u[m])) >> 33) != (unsigned)tu) {
+      if ((++spins & 1023u) == 0 && (spun_out(spins) || failed() || ld_u32(&X->fail))) { give_up(); return false; }
+    }
+    late_t0 = 0;
+    const float u = __int_as_float((int)(unsigned)v);
+    const bool df = ((v >> 32) & 1ull) != 0;
+#pragma unroll
+    for (int k = 0; k < KS + 1; ++k) {
+      W[k] = fsub(W[k], fmul(u, xp[k]));
+      if (df) W[k] = fmul(W[k], cdec);
+    }
     return true;
   };
   if (nbits > 0 && !fetch(0)) return;
@@ -1411,21 +1458,9 @@ template <bool LATE, bool JIT = false> __device__ void helper_role(MixState* S, 
     const bool live = t < nbits;             // t == nbits: apply the last update and store the row
     jitter_stall<JIT>(jit, t, 16 + 4 * m + w);
     // ---- u of bit t-1 (the serial hand-off of the bit) ----
-    if (t > 0) {
-      unsigned long long v;
-      unsigned spins = 0;
-      while ((unsigned)((v = ld_u64(&X->u[m])) >> 33) != (unsigned)t) {
-        if ((++spins & 1023u) == 0 && (spun_out(spins) || failed() || ld_u32(&X->fail))) { give_up(); return; }
-      }
-      late_t0 = 0;
-      const float u = __int_as_float((int)(unsigned)v);
-      const bool df = ((v >> 32) & 1ull) != 0;
-#pragma unroll
-      for (int k = 0; k < KS + 1; ++k) {          // mixer.cpp:66-71; xp = the inputs of bit t-1
-        W[k] = fsub(W[k], fmul(u, xp[k]));
-        if (df) W[k] = fmul(W[k], cdec);
-      }
-    }
+    // (a decoder's chunk: taken at the END of iteration t - 1, below -- the bit is known long before the next row is complete, so the poll's round trip and the
+    // update run under the wait for the row instead of behind it)
+    if (t > 0 && !LATE) { if (!apply_u(t)) return; }
     const bool chg = !live || f_chg;
     if (chg) {                               // outgoing row to HBM (16 B per 4 lanes: 64 consecutive floats per k), incoming row is in Wn
       if (t > 0) {
@@ -1519,6 +1554,7 @@ template <bool LATE, bool JIT = false> __device__ void helper_role(MixState* S, 
     }
     // ---- while the gather wave works: the inputs / incoming row of bit t+1 ----
     jitter_stall<JIT>(jit, t, 144 + 4 * m + w);
+    if (LATE && !apply_u(t + 1)) return;     // (a decoder: u of THIS bit first -- it arrives with the bit, the next row much later)
     if (t + 1 < nbits && !fetch(t + 1)) return;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1577,11 +1613,13 @@ template <bool LATE, bool JIT = false> __device__ void stretch_role(MixState* S,
       else if (idx < 0) idx = 0;
       pv[r] = lut[idx];
     }
-    float* gx = X->xs[t % CMX_SPEC_RING];
+    if (!LATE) {   // (a decoder's helpers stretch their own slice of the row straight from the producers' memory, helper_role's fetch: one hop less on every bit's path)
+      float* gx = X->xs[t % CMX_SPEC_RING];
 #pragma unroll
-    for (int r = 0; r < 33; ++r) {
-      int i = r * 64 + lane;
-      if (i < CMX_IN0) __hip_atomic_store(gx + i, pv[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int r = 0; r < 33; ++r) {
+        int i = r * 64 + lane;
+        if (i < CMX_IN0) __hip_atomic_store(gx + i, pv[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     const float ax0 = bcast_lane(pv[6], 49), ax1 = bcast_lane(pv[31], 40), ax2 = bcast_lane(pv[32], 29);   // columns 433, 2024, 2077
     if (lane < 3) {
@@ -1606,8 +1644,9 @@ template <bool LATE, bool JIT = false> __device__ void stretch_role(MixState* S,
   }
 }
 
-template <bool LATE, bool JIT = false> __device__ void select_role(MixState* S, const Lds& L, SpecXfer* X, const uint32_t* sel, int nbits, int lane) {
+template <bool LATE, bool JIT = false> __device__ void select_role(MixState* S, const Lds& L, SpecXfer* X, const uint32_t* sel, const float* probs, int nbits, int lane) {
   const gptr<const uint32_t> gsel = as_global(sel);
+  const gptr<const float> lut = as_global(S->logit_lut);
   for (int t = 0; t < nbits; ++t) {
     jitter_stall<JIT>(L.jit, t, 2);
     uint32_t key = (!LATE && lane < CMX_MIXERS) ? gsel[(size_t)t * CMX_MIXERS + lane] : 0;
@@ -1632,10 +1671,47 @@ template <bool LATE, bool JIT = false> __device__ void select_role(MixState* S, 
           __hip_atomic_store(&X->changed[t % CMX_SPEC_RING][lane], chg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
+      // round 6: the 46 selections are out -- their helpers fetch the incoming rows and, as the producers count the row, their slices of it, without waiting
+      // for the stretch wave; the auxiliary-context mixer's key (predictor.cpp:388-393: the mean of three of the bit's squashed stretched inputs) is formed
+      // HERE from those three columns as soon as their producers have counted the row, with the stretch wave's own arithmetic
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) __hip_atomic_store(&X->sel_epoch, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bool ok3 = true;
+      if (lane < 3) ok3 = late_wait_cnt(L.late, lane == 0 ? LC_FX : lane == 1 ? LC_P8 : LC_BM2, (uint32_t)(t + 1));
+      if (__ballot(!ok3)) { lds_publish_store(&L.ctl->abort, 1); return; }
+      float ax = 0.0f;
+      if (lane < 3) {
+        float pa = __hip_atomic_load(probs + (size_t)t * CMX_IN0 + (lane == 0 ? 433 : lane == 1 ? 2024 : 2077), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (pa < 1.0e-4f) pa = 1.0e-4f;
+        else if (pa > 1 - 1.0e-4f) pa = 1 - 1.0e-4f;
+        int idx = (int)(pa * 100001.0f);
+        if (idx >= 100001) idx = 100000;
+        else if (idx < 0) idx = 0;
+        ax = cmx_logistic(lut[idx]);
+      }
+      const float a0 = bcast_lane(ax, 0), a1 = bcast_lane(ax, 1), a2 = bcast_lane(ax, 2);
+      if (lane == CMX_AUX) {
+        float avg = 0;
+        avg = fadd(avg, a0);
+        avg = fadd(avg, a1);
+        avg = fadd(avg, a2);
+        avg = avg / 3.0f;
+        key = (uint32_t)(unsigned long long)(avg * 15);
+        const uint32_t r = select_row(S, lane, key);
+        rec->rowidx[lane] = r;
+        const uint32_t chg = (t == 0) || (r != prev->rowidx[lane]);
+        rec->changed[lane] = chg;
+        __hip_atomic_store(&X->rowidx[t % CMX_SPEC_RING][lane], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&X->changed[t % CMX_SPEC_RING][lane], chg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) __hip_atomic_store(&X->scout_epoch, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (!wait_ge<LATE>(L.ctl, &L.sdone[t % L.rr], t + 1, true)) return;
+    if (!wait_ge<LATE>(L.ctl, &L.sdone[t % L.rr], t + 1, true)) return;   // (the stretch wave's record of the bit: what the gather and tail waves read)
     if (lane == CMX_AUX) key = rec->auxkey;
-    if (lane < CMX_MIXERS && (!LATE || lane == CMX_AUX)) {
+    if (lane < CMX_MIXERS && !LATE) {
       uint32_t r = select_row(S, lane, key);
       rec->rowidx[lane] = r;
       const uint32_t chg = (t == 0) || (r != prev->rowidx[lane]);
@@ -1648,7 +1724,7 @@ template <bool LATE, bool JIT = false> __device__ void select_role(MixState* S, 
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     jitter_stall<JIT>(L.jit, t, 3);
-    if (lane == 0) __hip_atomic_store(&X->scout_epoch, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!LATE && lane == 0) __hip_atomic_store(&X->scout_epoch, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (a decoder: published above, ahead of the stretch wave)
     st_rel(&L.ctl->scout_epoch, t + 1);
     if (LATE && lane == 0) late_stamp(L.late, 5);   // inputs and rows published to the helpers
   }
@@ -1921,7 +1997,7 @@ template <bool LATE, bool JIT = false> __device__ __forceinline__ void spec_kern
     __syncthreads();
     CmxLateBox* const lb = LATE ? box.box : nullptr;
     const bool tol = (mode & 0x1000) != 0;
-    if (wave < 4) helper_role<LATE, JIT>(S, X, H, nbits, role - 1, wave, lane, tol, lb, local, JIT ? ((mode >> 26) & 15) | 16 : 0);
+    if (wave < 4) helper_role<LATE, JIT>(S, X, H, nbits, role - 1, wave, lane, tol, lb, local, JIT ? ((mode >> 26) & 15) | 16 : 0, box, probs);
     return;
   }
   Lds L;
@@ -1956,7 +2032,7 @@ template <bool LATE, bool JIT = false> __device__ __forceinline__ void spec_kern
   if (wave == 0) gather_role<LATE, JIT>(S, L, X, decay1, nbits, mix_out, prof, lane, local);
   else if (wave == 1) tail_a_role<LATE, JIT>(S, L, decay1, nbits, mix_out, lane, prof && ((mode >> 4) & 4) != 0);
   else if (wave == 3) tail_b_role<LATE, JIT>(S, L, decay1, nbits, p_out, mix_out, lane, prof && ((mode >> 4) & 4) != 0);
-  else if (wave == 2) select_role<LATE, JIT>(S, L, X, sel, nbits, lane);
+  else if (wave == 2) select_role<LATE, JIT>(S, L, X, sel, probs, nbits, lane);
   else if (wave >= 4) stretch_role<LATE, JIT>(S, L, X, probs, bits, nbits, wave - 4, lane);
   __syncthreads();
   if (tid == 0 && (L.ctl->abort || ld_u32(&X->fail))) S->error = 1;

@@ -81,7 +81,9 @@ struct MixState {
 struct SpecXfer {
   unsigned scout_epoch;        // bits whose inputs / rows the scout has published
   unsigned fail;               // sticky: a bounded in-launch wait ran out
-  unsigned pad0[14];
+  unsigned sel_epoch;          // a decoder's chunk (round 6): bits whose 46 context-keyed row selections are published -- ahead of scout_epoch, which also covers the
+                               //   auxiliary-context mixer's (its key comes out of three of the bit's inputs)
+  unsigned pad0[13];
   unsigned xcc[32];            // XCD placement (CMX_MIXNET_XCD): 1 + HW_REG_XCC_ID of the workgroup with role r, written at launch; all equal => the u / sum words
                                //   are exchanged through that XCD's L2 (plain stores, L1-bypassing loads), otherwise through the fabric (agent-scope stores)
   unsigned long long u[32];    // by the gather wave after bit t: ((2 (t + 1) + decay flag) << 32) | bits of u = decay * lr * err   (mixer.cpp:56-64)
