@@ -369,9 +369,17 @@ int cmx_mixnet_spec_stats(cmx_mixnet_t* h, uint64_t out[5]) {
 // stream may use ONLY that XCD's compute units and every other stage's stream everything BUT them: a stage whose workgroups land on the crowded XCD is held
 // up there (profiles/r05_xcd_placement.txt: the LSTM's block kernels 4.7 -> 6.5 us/bit next to 27 spinning workgroups, whichever XCD). Bit i of the mask is
 // compute unit i / 8 of XCC i % 8 (the KFD spreads a queue's mask over the XCCs bit by bit). which: 0 = any other stage, 1 = the mixing network.
+static bool g_cumask_applied = false;   // at least one masked stream was really created (the kernels' placement flag follows THIS, not the environment: advisor, round 5)
+static bool cumask_wanted() {
+  static const char* const xe = getenv("CMX_MIXNET_XCD");
+  // (ignored in the compact stream modes, CMX_PIPELINE_STREAMS: there roles share the mixing network's stream, and a one-XCD mask would confine them to the
+  // compute units its 27 spinning workgroups already occupy)
+  static const bool w = getenv("CMX_CUMASK") != nullptr && xe && atoi(xe) >= 0 && atoi(xe) < 8 && getenv("CMX_PIPELINE_STREAMS") == nullptr;
+  return w;
+}
 int cmx_make_stream(hipStream_t* st, int which) {
   static const char* const xe = getenv("CMX_MIXNET_XCD");
-  static const bool masked = getenv("CMX_CUMASK") != nullptr && xe && atoi(xe) >= 0 && atoi(xe) < 8;
+  const bool masked = cumask_wanted();
   if (masked) {
     const int x = atoi(xe);
     uint32_t m[8];
@@ -379,12 +387,12 @@ int cmx_make_stream(hipStream_t* st, int which) {
       m[w] = 0;
       for (int b = 0; b < 32; ++b) { const int cu = 32 * w + b; if (((cu & 7) == x) == (which == 1)) m[w] |= 1u << b; }
     }
-    if (hipExtStreamCreateWithCUMask(st, 8, m) == hipSuccess) return 0;
+    if (hipExtStreamCreateWithCUMask(st, 8, m) == hipSuccess) { if (which == 1) g_cumask_applied = true; return 0; }
     (void)hipGetLastError();
   }
   return hipStreamCreateWithFlags(st, hipStreamNonBlocking) == hipSuccess ? 0 : 1;
 }
-int cmx_cumask_on(void) { static const char* const xe = getenv("CMX_MIXNET_XCD"); return getenv("CMX_CUMASK") != nullptr && xe && atoi(xe) >= 0 && atoi(xe) < 8; }
+int cmx_cumask_on(void) { return cumask_wanted() && g_cumask_applied; }   // the mixing network's stream really carries its one-XCD mask
 
 // The stream the handle's host-to-device copies go on (the pipeline gives all its stages ONE upload stream that never has
 // a kernel in front of a copy); without it the handle creates its own on first use.
