@@ -132,6 +132,7 @@ struct cmx_mixnet {
   unsigned sync_slot = 0;
   int profile = 0;
   int dbg = 0;          // CMX_MIXNET_DBG: timing experiments (results invalid when nonzero)
+  int rotate = 0;       // CMX_MIXNET_ROTATE=1 (test hook): the roles' workgroups move to another XCD with every launch (see spec_kernel_body)
   int jitter = 0;       // CMX_MIXNET_JITTER=1..15 (test hook, tests/test_gpu_mixnet.py): pseudo-random stalls in every role but the gather wave -- same results, every lead / lag between the roles
   int xcd = -1;         // CMX_MIXNET_XCD=k: place the persistent kernel on XCD k (speed only; -1 = wherever block 0 lands)
   bool use_v1 = false;  // CMX_MIXNET_V1=1: run chunks through the bit-synchronous kernel
@@ -318,6 +319,7 @@ cmx_mixnet_t* cmx_mixnet_create(int device) {
   }
   { const char* v = getenv("CMX_MIXNET_DBG"); h->dbg = v ? atoi(v) : 0; }
   { const char* v = getenv("CMX_MIXNET_JITTER"); h->jitter = v ? atoi(v) & 15 : 0; }
+  { const char* v = getenv("CMX_MIXNET_ROTATE"); h->rotate = v && v[0] == '1'; }
   { const char* v = getenv("CMX_MIXNET_XCD"); h->xcd = v ? atoi(v) : CMX_MIXNET_XCD_DEFAULT; if (h->xcd > 7) h->xcd = -1; }
   hipEventCreate(&h->ev0);
   hipEventCreate(&h->ev1);
@@ -507,10 +509,11 @@ static int mixnet_run_impl(cmx_mixnet_t* h, const float* d_probs, const uint32_t
     // epochs and value|tag words restart at 0 with every launch; 1 main + 26 helper workgroups, co-resident (27 of 256 CUs)
     HIP_OK(hipMemsetAsync(h->d_xfer, 0, CMX_SPEC_HEADER_BYTES, st));
     const bool cumask = cmx_cumask_on() != 0;   // the stream's compute-unit mask does the placement: 27 workgroups, all of them work, the XCC census still decides the hand-off's form
-    const int kmode = 3 | (h->profile ? 4 : 0) | ((h->dbg & 15) << 4) | (h->tolerance ? 0x1000 : 0) | (h->xcd >= 0 ? 0x20000 | ((h->xcd & 7) << 20) : 0) |
+    const int rot = h->rotate && h->xcd < 0 ? (int)((h->runs * 3) & 7) : 0;   // (h->runs was advanced above: the launch's number + 1; x 3: not the neighbouring XCD every time)
+    const int kmode = 3 | (rot << 8) | (h->profile ? 4 : 0) | ((h->dbg & 15) << 4) | (h->tolerance ? 0x1000 : 0) | (h->xcd >= 0 ? 0x20000 | ((h->xcd & 7) << 20) : 0) |
                       (getenv("CMX_MIXNET_XCD_NOLOCAL") ? 0x800000 : 0) | (cumask ? 0x1000000 : 0) | (h->jitter ? 0x2000000 | ((h->jitter & 15) << 26) : 0);
     static const bool padgrid = getenv("CMX_MIXNET_PADGRID") != nullptr;   // diagnostic: the 8 x 27 grid of the one-XCD placement without the placement (blocks 27.. leave at once)
-    const unsigned grid = (1 + CMX_SPEC_HELPERS) * ((h->xcd >= 0 && !cumask) || padgrid ? 8 : 1);   // placement: 8 x 27 workgroups, those with blockIdx % 8 == xcd work
+    const unsigned grid = (1 + CMX_SPEC_HELPERS) * ((h->xcd >= 0 && !cumask) || padgrid ? 8 : 1) + (unsigned)rot;   // placement: 8 x 27 workgroups, those with blockIdx % 8 == xcd work
     if (box && box->box)   // a decoder's chunk: the patient instantiation of the same roles
       hipLaunchKernelGGL(cmx_mixnet_spec_late_kernel, dim3(grid), dim3(CMX_SPEC_THREADS), CMX_SPEC_LDS_BYTES, st,
                          h->d_state, h->d_xfer, d_probs, d_sel, dd, (int)nbits, d_p_out, d_mix_out, kmode, *box);

@@ -168,7 +168,7 @@ struct FbArgs {
 // :93-98), redundantly in every workgroup of the layer's group; the lead workgroup keeps the per-epoch caches BPTT
 // reads and publishes the new hidden vector. xh <- the 200 new hidden values.
 template <bool LATE> __device__ __forceinline__ void fb_finish_layer(const LstmState* S, int layer, int e, bool lead, float* rawl, float* ivar_s,
-                                                float* xh, float& st, CmxLateBox* LB) {
+                                                float* xh, float& st, CmxLateBox* LB, const void* late_ptr = nullptr) {
   const int tid = threadIdx.x;
   LstmSync* Y = S->sync;
   wg_wait_t<LATE>(&Y->raw_cnt[layer][e], GL, &Y->fail, S->poll_sleep, LB);
@@ -216,6 +216,7 @@ template <bool LATE> __device__ __forceinline__ void fb_finish_layer(const LstmS
   }
   if (lead) wg_signal(&Y->h_flag[layer][e]);
   else lds_barrier();
+  if (LATE && lead && tid == 0) late_stamp(*reinterpret_cast<const CmxLate*>(late_ptr), 7 + layer);   // diagnostics: this layer's hidden vector of the step is out
 }
 
 template <bool LATE> __device__ void fb_gate_wg(const LstmState* S, const FbArgs& A, int layer, int w, float* lds) {
@@ -256,10 +257,11 @@ template <bool LATE> __device__ void fb_gate_wg(const LstmState* S, const FbArgs
     // A decoder: byte k only exists once the distribution of byte k - 1 has gone out, which needs this layer's hidden vector of that step -- the previous
     // step is finished BEFORE the wait (a compressor finishes it under the first part of this step's chains, below: the same operations on the same operands
     // in another order of independent parts)
-    if (LATE && k > 0) fb_finish_layer<LATE>(S, layer, e - 1, lead, rawl, ivar_s, xv + V, st, LB);
+    if (LATE && k > 0) fb_finish_layer<LATE>(S, layer, e - 1, lead, rawl, ivar_s, xv + V, st, LB, &A.late);
     int byte_k;
     if (LATE) { byte_k = late_byte(A.late, (int)n, &Y->fail, &late_flag); if (byte_k < 0) byte_k = 0; }
     else byte_k = A.bytes[n];
+    if (LATE && lead && layer == 0 && tid == 0) late_stamp(A.late, 6);   // diagnostics (scripts/gpu_late_time.py): the byte has arrived
     const int cur_sym = S->byte_map[byte_k];
     float* li = S->layer_input[layer] + (size_t)e * insz;
     lds_barrier();
@@ -283,7 +285,7 @@ template <bool LATE> __device__ void fb_gate_wg(const LstmState* S, const FbArgs
       f = wt[(size_t)cur_sym * C + i0 + r];
       f = lds_chain(f, Wl, R, r, xv, 0, V);
     }
-    if (!LATE && k > 0) fb_finish_layer<LATE>(S, layer, e - 1, lead, rawl, ivar_s, xv + V, st, LB);
+    if (!LATE && k > 0) fb_finish_layer<LATE>(S, layer, e - 1, lead, rawl, ivar_s, xv + V, st, LB, &A.late);
     if (lead && tid < C) li[V + tid] = xv[V + tid];   // keep the assembled vector for BPTT
     if (tid < 64) f = lds_chain(f, Wl, R, r, xv, V, V + C);
     if (layer == 1) {  // layer 0's new hidden (lstm.cpp:127-131)
@@ -303,7 +305,7 @@ template <bool LATE> __device__ void fb_gate_wg(const LstmState* S, const FbArgs
   }
   lds_barrier();
   const int el = A.e0 + A.cnt - 1;
-  fb_finish_layer<LATE>(S, layer, el, lead, rawl, ivar_s, xv + V, st, LB);
+  fb_finish_layer<LATE>(S, layer, el, lead, rawl, ivar_s, xv + V, st, LB, &A.late);
   if (lead && tid < C) {
     S->stateb[A.hc ^ 1][layer][tid] = st;
     S->hid[A.hc ^ 1][layer * C + tid] = xv[V + tid];
@@ -426,7 +428,7 @@ template <bool LATE> __device__ void fb_out_wg(const LstmState* S, const FbArgs&
     if (LATE && lead) {   // the distribution after byte n of the chunk is in place (uncached device memory): count it, as the one-thread kernel behind a per-byte launch did
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0 && !ld_u(&Y->fail)) late_publish(A.late, LC_LSTM, (uint32_t)(n + 1));
+      if (tid == 0 && !ld_u(&Y->fail)) { late_publish(A.late, LC_LSTM, (uint32_t)(n + 1)); late_stamp(A.late, 9); }
     }
     pb ^= 1;
   }

@@ -277,23 +277,44 @@ cmx_bytemodel_late_kernel(CmxLate B, size_t nbytes, const float* brk0, const flo
     for (int k = 0; k < 8; ++k) {
       const size_t t = 8 * n + k;
       const int mid = bot + ((top - bot) / 2);
-      if (lane == 0) {   // byte-model.cpp:8-24
-        float num = 0.0f;
-        for (int i = mid + 1; i <= top; ++i) num = fadd(num, pr[i]);
-        float denom = num;
-        for (int i = bot; i <= mid; ++i) denom = fadd(denom, pr[i]);
+      {   // byte-model.cpp:8-24. Round 6: the two ordered sums (up to 128 + 128 dependent adds at a byte's first bit) run on every lane from broadcast LDS reads,
+          // eight in flight ahead of the adds -- one lane reading and adding a term at a time put ~25 us between the LSTM's distribution and its column of the
+          // byte's first bit (profiles/r06_decode_time.txt); the likeliest byte (`ex`: the first index of the range's maximum, byte-model.cpp:19-23) is a wave reduction
+          // with that tie rule instead of a 256-step scan.
+        auto ordered = [&](float acc, int a, int b) {   // acc + pr[a] + pr[a + 1] + ... + pr[b], in that order
+          int i = a;
+          for (; i + 7 <= b; i += 8) {
+            const float v0 = pr[i], v1 = pr[i + 1], v2 = pr[i + 2], v3 = pr[i + 3], v4 = pr[i + 4], v5 = pr[i + 5], v6 = pr[i + 6], v7 = pr[i + 7];
+            acc = fadd(acc, v0); acc = fadd(acc, v1); acc = fadd(acc, v2); acc = fadd(acc, v3);
+            acc = fadd(acc, v4); acc = fadd(acc, v5); acc = fadd(acc, v6); acc = fadd(acc, v7);
+          }
+          for (; i <= b; ++i) acc = fadd(acc, pr[i]);
+          return acc;
+        };
+        const float num = ordered(0.0f, mid + 1, top);
+        const float denom = ordered(num, bot, mid);
         const float p = denom == 0.0f ? 0.5f : fdiv(num, denom);
-        if (n < nbytes) layer0[t * pstride + col] = p;
+        int ex = 0;
         if (w == 2 && t > 0) {
-          int ex = bot;
-          float mx = pr[bot];
-          for (int i = bot + 1; i <= top; ++i)
-            if (pr[i] > mx) { mx = pr[i]; ex = i; }
-          const float prod = fmul(4094.0f, p);     // Discretize (predictor.cpp:180-182): the product is rounded to float, then 1 is added
-          hint_pr[t - 1] = (int16_t)(unsigned)fadd(1.0f, prod);
-          hint_ex[t - 1] = (uint8_t)ex;
+          float bv = -1.0f;   // (probabilities: every value of the range is >= 0)
+          int bi = 0x7fffffff;
+          for (int i = bot + lane; i <= top; i += 64) { const float v = pr[i]; if (v > bv) { bv = v; bi = i; } }   // ascending i: the lane's first maximum
+          for (int sft = 32; sft > 0; sft >>= 1) {
+            const float ov = __shfl_xor(bv, sft);
+            const int oi = __shfl_xor(bi, sft);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+          }
+          ex = bi;
         }
-        late_publish(B, which, (uint32_t)(t + 1));
+        if (lane == 0) {
+          if (n < nbytes) layer0[t * pstride + col] = p;
+          if (w == 2 && t > 0) {
+            const float prod = fmul(4094.0f, p);     // Discretize (predictor.cpp:180-182): the product is rounded to float, then 1 is added
+            hint_pr[t - 1] = (int16_t)(unsigned)fadd(1.0f, prod);
+            hint_ex[t - 1] = (uint8_t)ex;
+          }
+          late_publish(B, which, (uint32_t)(t + 1));
+        }
       }
       if (n == nbytes) break;
       const int bit = late_y(B, (int)t + 1);

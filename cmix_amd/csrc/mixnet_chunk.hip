@@ -1959,8 +1959,12 @@ template <bool LATE, bool JIT = false> __device__ __forceinline__ void spec_kern
   // 0.37 us per all-gather instead of ~1.1 through the fabric, profiles/r05_allgather.txt). The mapping is an observation, not a contract: every
   // workgroup publishes the XCC it really runs on and the fast form is used only if all 27 agree; the words are value|tag, so a wrong guess could
   // only ever time out, never deliver a stale value.
-  int role = (int)blockIdx.x;
+  // Test hook (CMX_MIXNET_ROTATE, mode bits 8..10): the first `rot` workgroups of the grid leave at once and the roles move up by that many -- block b runs on
+  // XCD b mod 8, so with rot = launch number mod 8 every role changes its XCD (its L2) from one launch of a stream to the next. A stream's state crosses launches
+  // through memory only (weight rows, row state, SSE cells); results must not depend on WHERE a role ran last time.
+  int role = (int)blockIdx.x - ((mode >> 8) & 7);
   bool local = false;
+  if (role < 0) return;
   if (!(mode & 0x20000) && role > CMX_SPEC_HELPERS) return;   // diagnostic launches with a padded grid (CMX_MIXNET_PADGRID): the surplus workgroups leave at once
   if (mode & 0x20000) {
     if (!(mode & 0x1000000)) {   // (0x1000000: the stream carries a compute-unit mask that does the placement -- grid 27, every block has a role. NOT a bit of

@@ -644,6 +644,17 @@ int cmx_pipeline_debug_mix_out(cmx_pipeline_t* h, float* d_mix, uint64_t cap_bit
   return 0;
 }
 
+// diagnosis (scripts/gpu_mixnet_vote.py): the DEVICE buffers of chunk number `index` (0 = the first submitted; one of the last CMX_PIPELINE_SLOTS) that the mixing
+// network reads beside the layer-0 rows -- its 47 selectors per bit and the coded bits -- valid until the slot is reused CMX_PIPELINE_SLOTS submits later
+int cmx_pipeline_debug_slot(cmx_pipeline_t* h, uint64_t index, const uint32_t** d_sel, const uint8_t** d_bits, size_t* nbytes) {
+  if (!h || index >= h->finished || index + kSlots < h->finished) { cmx_set_err("cmx_pipeline_debug_slot: that chunk is not in flight"); return 1; }
+  const Slot& s = h->slot[index % kSlots];
+  if (d_sel) *d_sel = s.d_sel;
+  if (d_bits) *d_bits = s.d_bits;
+  if (nbytes) *nbytes = s.n;
+  return 0;
+}
+
 int cmx_pipeline_submit(cmx_pipeline_t* h, const uint8_t* bytes, size_t n, float* d_layer0, float* d_p_out) {
   if (!h) { cmx_set_err("cmx_pipeline_submit: null handle"); return 1; }
   if (n == 0) return 0;

@@ -427,6 +427,8 @@ int cmx_pipeline_mixnet_rows(cmx_pipeline_t*, uint32_t rows[47]);
 /* diagnosis: from now on every mixer's output (Mixer::Mix, mixer.cpp:38-55, all 47) of every bit of the stream's look-ahead chunks goes to
  * the DEVICE area d_mix[cap_bits][47] in stream order (bits past cap_bits are not recorded); NULL switches it off */
 int cmx_pipeline_debug_mix_out(cmx_pipeline_t*, float* d_mix, uint64_t cap_bits);
+/* diagnosis: the DEVICE selectors [8 n][47] and coded bits [8 n] of chunk number `index` (one of the last CMX_PIPELINE_SLOTS submitted), valid until its slot is reused */
+int cmx_pipeline_debug_slot(cmx_pipeline_t*, uint64_t index, const uint32_t** d_sel, const uint8_t** d_bits, size_t* nbytes);
 int cmx_pipeline_spec_stats(cmx_pipeline_t*, uint64_t out[5]);
 int cmx_pipeline_paq8_profile(cmx_pipeline_t*, unsigned long long out128[128]);
 int cmx_pipeline_ppmd_arena(cmx_pipeline_t*, uint64_t out3[3]);

@@ -97,8 +97,14 @@ def part_a(a):
     out = {}
     report = []
     for kind in ["none"] + a.loads.split(","):
-        F = Foreign(kind, dev) if kind != "none" else None
+        envset = None
+        if kind.startswith("env:"):   # a library switch instead of foreign work: "env:CMX_MIXNET_ROTATE=1" (the roles' workgroups change XCD with every launch)
+            envset = kind[4:].split("=")
+            os.environ[envset[0]] = envset[1]
+        F = Foreign(kind, dev) if kind != "none" and not envset else None
         net = E.MixNet(0)
+        if envset:
+            os.environ.pop(envset[0], None)
         p = torch.zeros(T, dtype=torch.float32, device=dev)
         mix = torch.zeros((T, 47), dtype=torch.float32, device=dev)
         torch.cuda.synchronize()

@@ -48,8 +48,11 @@ for t in range(len(bits)):
         if L.cmx_pipeline_late_debug_times(pipe.h, tv.ctypes.data) == 0:
             t_known = int(tv[2 * 14 + 1])
             d = {NAMES[i]: ((int(tv[2 * i + 1]) - t_known) & 0xFFFFFFFF) / 100.0 for i in range(12)}
-            for k, nm in ((1, "p_out"), (2, "row_complete"), (3, "sums_there"), (4, "layer1_done"), (5, "helpers_fed")):
+            for k, nm in ((1, "p_out"), (2, "row_complete"), (3, "sums_there"), (4, "layer1_done"), (5, "helpers_fed"), (6, "lstm_byte_seen"), (7, "lstm_h0"), (8, "lstm_h1"), (9, "lstm_dist")):
                 d[nm] = ((int(tv[30 + k]) - t_known) & 0xFFFFFFFF) / 100.0
+            if t & 7:   # the LSTM's stamps belong to the byte's first bit (the step that followed the completed byte)
+                for nm in ("lstm_byte_seen", "lstm_h0", "lstm_h1", "lstm_dist"):
+                    d[nm] = 0.0
             if all(v < 1e5 for v in d.values()):
                 samples.setdefault(t & 7, []).append(d)
     pipe.late_perceive(int(bits[t]))

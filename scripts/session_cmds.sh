@@ -1,3 +1,3 @@
-O=gpurun_out/enwik8b; mkdir -p $O
-timeout 3500 python -u scripts/gpu_stage_hashes.py --bytes 100000000 --stop-block 767 --finish --out $O/hashes_100m_head768_engine.txt > $O/run.log 2>&1
-tail -5 $O/run.log
+O=gpurun_out/vote; mkdir -p $O
+timeout 3550 python -u scripts/gpu_mixnet_vote.py --bytes 70000000 --extra 4 --seconds 3350 --out $O/vote.json > $O/vote.log 2>&1
+tail -5 $O/vote.log | cut -c1-600

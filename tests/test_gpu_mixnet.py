@@ -162,7 +162,7 @@ def test_tolerance_mode_stays_within_its_tolerance(monkeypatch):
         assert d.max() < 1e-3 and bits_equal(a, b).mean() > 0.99, (name, d.max(), bits_equal(a, b).mean())
 
 
-@pytest.mark.parametrize("switch", ["CMX_MIXNET_XCD=7", "CMX_MIXNET_XCD=2", "CMX_MIXNET_JITTER=3", "CMX_MIXNET_JITTER=9"])
+@pytest.mark.parametrize("switch", ["CMX_MIXNET_XCD=7", "CMX_MIXNET_XCD=2", "CMX_MIXNET_JITTER=3", "CMX_MIXNET_JITTER=9", "CMX_MIXNET_ROTATE=1"])
 def test_kernel_switches_are_bit_exact(monkeypatch, switch):
     """Run-time forms of the speculative kernel: the one-XCD placement (all workgroups on one XCD, the hand-off words in its L2; an XCD number below and
     above 4 -- the flag of a diagnostic once shared a bit with that number's field, which sent XCD 4..7 down the wrong branch: profiles/r05_xcd_fault.txt)
