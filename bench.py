@@ -56,7 +56,9 @@ HBM_PEAK_GBS = 8000.0
 # the line is a PREFIX of a 100 MB-shaped shard; how far file identity with the reference has been checked on this shard (records under profiles/)
 FULL_SHARD_PARITY = ("unverified beyond 16 MiB: the file equals the unmodified reference binary's through 8 MiB (tests/golden/dropin_rich_8192k.npz, profiles/r05_long_run_8m_fixed.json; "
                      "4 MiB also through the drop-in, profiles/r06_dropin_4mib.txt); 16 MiB: the reference's model families run piecewise against the engine's per-64-KB column digests "
-                     "(profiles/r06_long_run_16m.txt); counters / thresholds a longer stream reaches are pinned by state injection (tests/test_wraps_and_thresholds.py)")
+                     "(profiles/r06_long_run_16m.txt); counters / thresholds a longer stream reaches are pinned by state injection (tests/test_wraps_and_thresholds.py). "
+                     "OPEN: two digest-harness runs of one 50 MB stream had equal column digests and different final probabilities from 33.9 MB on "
+                     "(profiles/r06_two_runs_50m.txt, DESIGN.md 8 item 0): a rare nondeterminism no file comparison has shown")
 # algorithmic HBM bytes per input byte: weights touched per bit x 8 B (read + write) x 8 bits
 ALGO = {
     "mixnet": 55172 * 8 * 8 + 4 * 64 * 8,                 # final mixers (f32) + 4 SSE lines per bit

@@ -200,8 +200,9 @@ def test_kernel_switches_are_bit_exact(monkeypatch, switch):
 
 def test_bit_exact_under_foreign_load_and_random_lead(monkeypatch):
     """Round 5 saw, ONCE, the final probabilities of a stream leave the reference's while torch kernels shared the device (DESIGN.md 5 "Long streams");
-    round 6 repeated that run three times and could not reproduce it (profiles/r06_foreign_load.txt). What a disturbance could change is pinned here for
-    good: the mixing network's 27 workgroups hand values to each other through counters and value|tag words only, so neither foreign kernels on the device
+    round 6 repeated that run three times without reproducing it (profiles/r06_foreign_load.txt) and then saw it once more, 33.9 MB into a stream
+    (profiles/r06_two_runs_50m.txt; the network given identical inputs is excluded by scripts/gpu_mixnet_vote.py). What a disturbance could change in the
+    network's kernel is pinned here for good: the mixing network's 27 workgroups hand values to each other through counters and value|tag words only, so neither foreign kernels on the device
     (memory-bound copies, LDS-heavy sorts and scans, hundreds of tiny launches, allocation churn: scripts/gpu_foreign_load.py) nor any lead / lag between
     its roles (CMX_MIXNET_JITTER: pseudo-random stalls of up to 100 us in every role) may change a single bit. 16 launches of 1024 bits under each
     disturbance against a clean run of the same inputs, and the first 2048 bits against the oracle."""
