@@ -575,9 +575,9 @@ __device__ __forceinline__ void ctxmodels_body(const CtxDev& D, const uint8_t* _
       }
       *(float4*)(bracket_dist + n * 256 + 4 * lane) = make_float4(v[0], v[1], v[2], v[3]);
     }
+    if (late) wave_mem_sync();   // (this wave's stores of the distribution have landed before the barrier: a barrier alone does not wait for them)
     __syncthreads();
     if (late) {   // the Bracket model's distribution after byte n is in place (the ByteModel kernel of the late pipeline reads it)
-      wave_mem_sync();
       if (lane == 0) late_publish(LB, LC_BRK, (uint32_t)(n + 1));
     }
   }

@@ -440,6 +440,7 @@ __device__ __forceinline__ void fx_roles_body(FxDev* gd, FxXfer* X, unsigned* ro
   if (role != 2 && tid == 0) sh.parity = 0;   // M and U build the bit's inputs in tx[1]
   // all workgroups hold the state before any of them may write a part of it back (or the pending row)
   if (tid == 0) { __hip_atomic_fetch_add(&X->started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); fx_wait_ge(&X->started, (unsigned)(FX_M_WGS + 2), &X->fail); }
+  if (LATE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (row 0's stores, every wave's, before the barrier in front of its count)
   __syncthreads();
   const FxLayout ln = fxd_layout(d, 1);   // the normal layout's offsets
   unsigned have_row = 0;
@@ -786,6 +787,7 @@ __device__ __forceinline__ void fx_roles_body(FxDev* gd, FxXfer* X, unsigned* ro
       for (int i = l.exp_mix + tid; i < FX_OUTPUTS; i += FX_DEV_THREADS) real_row[i] = loc.ex[q & 1][i];
       FX_TICK(7);
       if (LATE && q + 1 < nbits) {   // row q + 1 is complete (roles M and U finished theirs before this update began)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave's stores of the row have landed before the barrier (s_barrier alone does not wait for them)
         __syncthreads();
         if (tid == 0) late_publish(LB, LC_FX, (unsigned)(q + 2));
       }

@@ -118,7 +118,8 @@ __global__ __launch_bounds__(P8CM2_MAXC) void cmx_p8s_cm2v2_late_kernel(P8Cm2Dev
       __syncthreads();
       if (i < C) p8c2_reload(d, &sh, i);
     } else if (i < C) p8c2_run(d, &sh, u, i, &tmp);
-    __syncthreads();   // (drains every thread's stores: the step's inputs are in the row)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY wave's stores have landed before the barrier (s_barrier alone does not wait for them) -- then one thread counts the row
+    __syncthreads();
     if (i == 0) {
       if (order_out) { int o = 0; for (int k = 0; k < C; k++) o += sh.base.nz[k]; order_out[t] = (uint8_t)o; }
       late_publish(B, counter, (uint32_t)(t + 1));
@@ -250,6 +251,7 @@ __device__ __forceinline__ void p8s_fam2_body(P8CmDev* d, P8FamHome* home, const
     P8F_COUNT(80 + u.bp, 1);
     P8F_TICK(4);
     if (LATE) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY wave's stores have landed before the barrier (s_barrier alone does not wait for them) -- then one thread counts the row
       __syncthreads();   // every context's inputs of the step are in the row
       if (tid == 0) late_publish(B, LC_FAM, (uint32_t)(t + 1));
     }
@@ -339,6 +341,7 @@ __global__ __launch_bounds__(P8LANES_THREADS) void cmx_p8s_lanes_late_kernel(P8L
       const uint32_t op2[2] = {op, l + 1 < P8_NLANE ? *(volatile const uint32_t*)(ops + (size_t)t * P8_NLANE + l + 1) : 0u};
       p8s_glane_step(d, &r, l, op2, y, ord, t & 7, c0, x + (size_t)t * P8_NX, 0);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY wave's stores have landed before the barrier (s_barrier alone does not wait for them) -- then one thread counts the row
     __syncthreads();
     if (threadIdx.x == 0) late_publish(B, LC_LANES, (uint32_t)(t + 1));
   }
@@ -362,6 +365,7 @@ __global__ __launch_bounds__(P8DMC_THREADS) void cmx_p8s_dmc_late_kernel(P8DmcDe
       p8d_dmc_step2(d, &sh, tid, (int)((done + (uint32_t)t) & 7), x + (size_t)t * P8_NX + off);
       __syncthreads();
       p8d_dmc_step3(d, &sh, tid);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY wave's stores have landed before the barrier (s_barrier alone does not wait for them) -- then one thread counts the row
       __syncthreads();
     }
     if (tid == 0) late_publish(B, LC_DMC, (uint32_t)(t + 1));
@@ -789,6 +793,7 @@ __device__ __forceinline__ void mx4_late_body(const P8MixDev* M, P8TailDev* T, C
   __syncthreads();
   if (MAIN && t0) {   // no step 0: the constructor's values are row 0
     for (int i = tid; i < P8_NOUT; i += MX_THREADS) out[i] = outs[i];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY wave's stores have landed before the barrier (s_barrier alone does not wait for them) -- then one thread counts the row
     __syncthreads();
     if (tid == 0) late_publish(B, LC_P8, 1u);
   }
@@ -953,7 +958,8 @@ __device__ __forceinline__ void mx4_late_body(const P8MixDev* M, P8TailDev* T, C
       mx_lds_barrier();   // outs complete, fin_s
       float* orow = out + (size_t)t * ld;
       for (int i = tid; i < P8_NOUT; i += MX_THREADS) orow[i] = outs[i];
-      __syncthreads();   // (drains every thread's stores)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // EVERY wave's stores have landed before the barrier (s_barrier alone does not wait for them) -- then one thread counts the row
+      __syncthreads();
       if (tid == 0) late_publish(B, LC_P8, (uint32_t)(t + 1));
     }
     // ---- the step's own bit, then training ----

@@ -1,3 +1,6 @@
-O=gpurun_out/vote; mkdir -p $O
-timeout 3550 python -u scripts/gpu_mixnet_vote.py --bytes 70000000 --extra 4 --seconds 3350 --out $O/vote.json > $O/vote.log 2>&1
-tail -5 $O/vote.log | cut -c1-600
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+O=gpurun_out/final7; mkdir -p $O
+( time timeout 85 python -m pytest tests/test_gpu_dropin.py -q -k "decodes_the_reference or decodes_empty or decodes_mixed or decodes_12k" 2>&1 | grep -v amdgpu | tail -4 ) > $O/pytest_dec.txt 2>&1
+cat $O/pytest_dec.txt

@@ -434,7 +434,13 @@ def test_dropin_round_trips_50k_and_256k():
         payload = synth.enwik_like(n, seed)
         blob = _run("-c", [("in", payload)], exe=DROPIN, timeout=900)
         t0 = time.time()
-        assert _run("-d", [("in", blob)], exe=DROPIN, timeout=1500) == payload
+        back = _run("-d", [("in", blob)], exe=DROPIN, timeout=1500)
+        if back != payload:   # keep both sides of a wrong round trip: the file tells (against the reference binary's, dev container) whether the compressor or the decoder left the path
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            for tag, data in (("file", blob), ("decoded", back)):
+                with open(os.path.join(ROOT, "gpurun_out", "roundtrip_fail_%d_%s.bin" % (n, tag)), "wb") as f:
+                    f.write(data)
+        assert back == payload
         times.append((n, time.time() - t0))
     (n0, t0_), (n1, t1_) = times
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
