@@ -77,6 +77,9 @@ def main():
                     "each digest read it, recomputes the digests from the finished run's p, then runs the same bytes through a second engine WITHOUT any digest work and compares the two runs' p")
     ap.add_argument("--finish", action="store_true", help="after the run: the arithmetic coder over every p (size and SHA-256 of the file `cmix -c` would write), the mixers' row counts, "
                     "the speculation statistics, PPMd's arena -- what scripts/gpu_long_run.py reports; with it the digests so far are also written every 16 MiB (<out>.partial)")
+    ap.add_argument("--inputs-digest", action="store_true", help="round 6 (DESIGN.md 8 item 0): also digest what the mixing network reads BESIDE the 2078 columns -- the 47 selectors of "
+                    "every bit and the coded bits, from the chunk's slot buffers (cmx_pipeline_debug_slot) -- per 64 KB block into <out>.inputs (47 + 1 digests per block; two "
+                    "runs are compared with --compare a.inputs b.inputs 0 47). Not yet run on a device (written after the round's last GPU minute).")
     ap.add_argument("--head-file", default=None)
     ap.add_argument("--vocab-file", default=None)
     a = ap.parse_args()
@@ -120,6 +123,15 @@ def main():
     nsub = -(-n // sub)
     blocks = -(-n // 65536)
     H = torch.zeros((blocks, NG + 1), dtype=torch.int64, device=dev)
+    HX = selbuf = bitbuf = hip = None
+    if a.inputs_digest:
+        import ctypes as C
+        HX = torch.zeros((blocks, 48), dtype=torch.int64, device=dev)
+        selbuf = torch.zeros(8 * sub * 47, dtype=torch.int32, device=dev)
+        bitbuf = torch.zeros(8 * sub, dtype=torch.uint8, device=dev)
+        hip = C.cdll.LoadLibrary("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        E.lib().cmx_pipeline_debug_slot.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
 
     def digest(k):   # sub-chunk k is complete: fold its rows into its 64 KB block's digests
         lo, hi = k * sub, min(n, (k + 1) * sub)
@@ -135,6 +147,16 @@ def main():
         H[lo // 65536, :NG] += (w * bt[:, None]).sum(0)
         pv = (eng.p_dev[8 * lo:8 * hi].view(torch.int32).to(torch.int64) & 0xffffffff) + 1
         H[lo // 65536, NG] += (pv * bt).sum()
+        if HX is not None:   # the chunk's selectors and bits as they lie in its slot (what the mixing network's kernel read)
+            sel_p, bits_p, nb = C.c_void_p(), C.c_void_p(), C.c_size_t()
+            if E.lib().cmx_pipeline_debug_slot(eng.pipe.h, k, C.byref(sel_p), C.byref(bits_p), C.byref(nb)):
+                raise RuntimeError(E.last_error())
+            tb = 8 * nb.value
+            if tb != 8 * (hi - lo) or hip.hipMemcpy(selbuf.data_ptr(), sel_p, tb * 47 * 4, 3) or hip.hipMemcpy(bitbuf.data_ptr(), bits_p, tb, 3):
+                raise RuntimeError("slot %d: size %d / copy failed" % (k, tb))
+            sv = (selbuf[:tb * 47].view(tb, 47).to(torch.int64) & 0xffffffff) + 1
+            HX[lo // 65536, :47] += (sv * bt[:, None]).sum(0)
+            HX[lo // 65536, 47] += ((bitbuf[:tb].to(torch.int64) + 1) * bt).sum()
         if psnap is not None:
             psnap[8 * lo:8 * hi] = eng.p_dev[8 * lo:8 * hi]
         if detail and lo // 65536 == a.detail_block:
@@ -198,6 +220,11 @@ def main():
     with open(a.out, "w") as f:
         for b in range(blocks):
             f.write("%d %s\n" % (min(n, (b + 1) * 65536), " ".join("%016x" % int(x) for x in Hh[b])))
+    if HX is not None:
+        Hx = HX.cpu().numpy().view(np.uint64)
+        with open(a.out + ".inputs", "w") as f:
+            for b in range(blocks):
+                f.write("%d %s\n" % (min(n, (b + 1) * 65536), " ".join("%016x" % int(x) for x in Hx[b])))
     print("%d bytes in %.1f s (%.0f B/s), %d blocks of 64 KB -> %s" % (n, dt, n / dt, blocks, a.out))
     if detail:
         import json
